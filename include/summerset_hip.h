@@ -1,0 +1,258 @@
+/*
+ * summerset_hip.h -- C-ABI of libsummerset_hip.so, the MI355X (gfx950) batched
+ * multi-group consensus engine.
+ *
+ * The reference (josehu07/summerset) has NO FFI/C-ABI/plugin interface for this
+ * path; its nearest boundary is the Rust trait `GenericReplica`
+ * (src/server/replica.rs:16-42) plus the per-protocol event-handler
+ * convention `handle_req_batch / handle_msg_recv / handle_log_result /
+ * handle_cmd_result` (dispatch sites src/protocols/multipaxos/mod.rs:837-905).
+ * Every entry point below names the reference handler(s) it stands in for;
+ * INTEGRATION.md shows the Rust `extern "C"` binding a maintainer would add.
+ *
+ * Conventions:
+ *   - plain pointers + sizes, no C++/torch types;
+ *   - `int` return: 0 = ok, < 0 = error class, text via smr_last_error()
+ *     (mirrors SummersetError(String), src/utils/error.rs:7);
+ *   - outdated / out-of-range inputs are IGNORED and counted, never errors
+ *     (multipaxos/messages.rs:377-379,394-406);
+ *   - a handle has ONE owner thread (the reference's protocol struct is
+ *     `&mut self` single-owner, README.md:59); it is not thread-safe;
+ *   - pointers named *_dev are DEVICE (HBM) pointers, *_host are host
+ *     pointers; `stream` is a hipStream_t passed as void* (NULL = default).
+ *
+ * All per-group arrays are structure-of-arrays with the GROUP index fastest
+ * ("one group = one lane"): X[g], Y[k][g] == Y[k * n_groups + g].
+ */
+#ifndef SUMMERSET_HIP_H
+#define SUMMERSET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMR_OK 0
+#define SMR_ERR_ARG (-1)     /* bad argument / configuration */
+#define SMR_ERR_DEVICE (-2)  /* HIP runtime error (no device, OOM, launch failure) */
+#define SMR_ERR_STATE (-3)   /* call not valid in the current state */
+
+#define SMR_NO_REPLICA 0xFFu /* Option<ReplicaId>::None */
+#define SMR_MAX_REPLICAS 8
+
+/* Status enum of multipaxos/mod.rs:168-174 (also RSPaxos). */
+enum { SMR_ST_NULL = 0, SMR_ST_PREPARING = 1, SMR_ST_ACCEPTING = 2, SMR_ST_COMMITTED = 3, SMR_ST_EXECUTED = 4 };
+
+/* ackctl word (per outbox entry, per group): delivery order of the peers'
+ * replies + which of them are lost.  bits 0..23: replica ids, 3 bits each, in
+ * delivery order (the receiver skips its own id and ids >= population);
+ * bits 24..31: drop mask by replica id. */
+#define SMR_CTL_IDENTITY 0x00FAC688u
+
+const char *smr_last_error(void);
+/* number of visible HIP devices, or < 0 */
+int smr_device_count(void);
+/* library/ABI version, bumped on incompatible change */
+uint32_t smr_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Reed-Solomon over GF(2^8)  (RSPaxos / CRaft / Crossword value sharding)
+ * replaces: RSCodeword::compute_parity  src/utils/rscoding.rs:447-486
+ *           (-> reed_solomon_erasure::galois_8::ReedSolomon::encode :484)
+ *           with the from_data shard geometry of :165-220 fused in
+ *           (shard_len = ceil(data_len / d), zero padding, contiguous split);
+ *           RSCodeword::reconstruct{,_data}  :490-537;  verify_parity :541-577.
+ * ---------------------------------------------------------------------- */
+
+/* (d+p) x d coding matrix, row major, into a host buffer. */
+int smr_rs_matrix(int d, int p, uint8_t *out_host);
+
+/* ceil(data_len / d), rscoding.rs:177-181 */
+uint64_t smr_rs_shard_len(uint64_t data_len, int d);
+
+/* Encode n_cw codewords.  Codeword i occupies data_dev[i*cw_stride ..
+ * i*cw_stride + data_len) (the serialized bytes; need NOT be padded -- bytes
+ * at and beyond data_len are treated as zero and never read).  Data shard k
+ * is bytes [k*shard_len, (k+1)*shard_len) of that range.  Parity shard k of
+ * codeword i is written to parity_dev[i*par_stride + k*par_shard_stride ..
+ * + shard_len).  Returns SMR_ERR_ARG for the reference's error cases
+ * (d == 0, data_len == 0 "codeword is null"); p == 0 is a no-op. */
+int smr_rs_encode(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw,
+                  int d, int p, uint8_t *parity_dev, uint64_t par_stride,
+                  uint64_t par_shard_stride, void *stream);
+
+/* Same, with the GF(2^8) multiplies done through LDS-resident product tables
+ * instead of bit-sliced xtime arithmetic (kept selectable for A/B runs). */
+int smr_rs_encode_lut(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw,
+                      int d, int p, uint8_t *parity_dev, uint64_t par_stride,
+                      uint64_t par_shard_stride, void *stream);
+
+/* Rebuild missing shards of n_cw codewords that all share one erasure
+ * pattern.  shards_dev: shard k of codeword i at i*cw_stride + k*shard_stride,
+ * shard_len bytes each, k in [0, d+p).  present_mask bit k = shard k valid.
+ * data_only != 0 rebuilds data shards only (reconstruct_data).  Returns
+ * SMR_ERR_ARG when fewer than d shards are present. */
+int smr_rs_reconstruct(uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_stride,
+                       uint64_t cw_stride, uint64_t n_cw, int d, int p, uint32_t present_mask,
+                       int data_only, void *stream);
+
+/* verify_parity for n_cw codewords; ok_dev[i] = 1 if parity matches. */
+int smr_rs_verify(const uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_stride,
+                  uint64_t cw_stride, uint64_t n_cw, int d, int p, uint8_t *ok_dev, void *stream);
+
+/* ------------------------------------------------------------------------
+ * MultiPaxos / RSPaxos cluster of G groups x R replicas in lock-step (LS-1)
+ * ---------------------------------------------------------------------- */
+typedef struct smr_mp_cluster smr_mp_cluster;
+
+typedef struct {
+    uint32_t n_groups;      /* G */
+    uint8_t population;     /* R, 3..8 */
+    uint8_t commit_extra;   /* RSPaxos fault_tolerance f (rspaxos/messages.rs:438-439); 0 = MultiPaxos */
+    uint8_t reserved0, reserved1;
+    uint32_t window;        /* W: ring slots per replica per group, power of two */
+    uint32_t win_reserve;   /* leader refuses new batches once W - win_reserve slots are live */
+    uint32_t outbox_cap;    /* max messages a replica may emit per tick (>= W + 4 recommended) */
+    uint32_t commit_list_cap; /* entries of the per-replica committed-slot list (0 = no list) */
+} smr_mp_cfg;
+
+/* Per-replica, per-group state as the reference keeps it
+ * (multipaxos/mod.rs:387-514). */
+typedef struct {
+    uint8_t leader;                  /* SMR_NO_REPLICA = None */
+    uint8_t overflow;                /* group frozen: ring window / outbox exhausted */
+    uint64_t bal_prep_sent, bal_prepared, bal_max_seen;
+    uint32_t start_slot, log_len;    /* log covers [start_slot, log_len) */
+    uint32_t accept_bar, commit_bar, exec_bar, snap_bar;
+    uint32_t peer_exec_bar[SMR_MAX_REPLICAS];
+} smr_mp_group_state;
+
+int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out);
+void smr_mp_cluster_destroy(smr_mp_cluster *c);
+
+/* Synthetic start state of SURVEY.md §8d config 2: replica `rep` already
+ * prepared with ballot make_unique_ballot(1) on an empty log. */
+int smr_mp_preset_leader(smr_mp_cluster *c, uint8_t rep);
+
+/*
+ * One lock-step tick = rounds R1..R4 below for every group.  Device inputs
+ * (NULL = none):
+ *   timeout_rep_dev[G], timeout_src_dev[G]   HeartbeatEvent::HearTimeout on
+ *       replica timeout_rep (SMR_NO_REPLICA = none) about peer timeout_src
+ *   req_target_dev[G], req_cnt_dev[G], req_val_dev[S][G]   client batches:
+ *       req_cnt[g] <= S opaque non-zero batch tokens delivered to replica
+ *       req_target[g]
+ *   ackctl_dev[outbox_cap][G]   reply order / loss per outbox entry
+ *   do_heartbeat   run the heartbeat round + ring trim this tick
+ */
+int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t *timeout_src_dev,
+                const uint8_t *req_target_dev, const uint32_t *req_cnt_dev,
+                const uint32_t *req_val_dev, uint32_t S, const uint32_t *ackctl_dev,
+                int do_heartbeat, void *stream);
+
+/* The four rounds of a tick as separate calls (a host that owns real I/O, or
+ * the multi-GPU driver, interleaves its exchange between them):
+ *  R1  become_a_leader (leadership.rs:73-214) on HearTimeout, handle_req_batch
+ *      (request.rs:112-224) + leader self-ack (durability.rs:85-107)
+ *  R2  handle_msg_prepare / handle_msg_accept (messages.rs:12-83,295-367) on
+ *      every peer + their WAL completions (durability.rs:10-145): fills the
+ *      senders' ack matrices and PrepareReply lists
+ *  R3  handle_msg_prepare_reply / handle_msg_accept_reply (messages.rs:87-292,
+ *      370-443) + handle_logged_commit_slot (durability.rs:148-218) +
+ *      handle_cmd_result exec-bar scan (execution.rs:56-79): THE quorum kernel
+ *  R4  all-to-all Heartbeat -> heard_heartbeat / advance_commit_bar
+ *      (leadership.rs:217-427), then ring trim (snapshot.rs:121-186 log part)
+ */
+int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev,
+                       const uint8_t *timeout_src_dev, const uint8_t *req_target_dev,
+                       const uint32_t *req_cnt_dev, const uint32_t *req_val_dev, uint32_t S,
+                       void *stream);
+int smr_mp_round_deliver(smr_mp_cluster *c, void *stream);
+int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publish_heartbeat,
+                         void *stream);
+int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream);
+/* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
+int smr_mp_end_tick(smr_mp_cluster *c);
+
+/* Device pointer + geometry of replica `rep`'s ack matrix: uint64
+ * reply_bal[outbox_cap][R][G], 0 = no reply.  A host that receives real
+ * AcceptReply messages (or the multi-GPU exchange) fills it before R3. */
+int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes);
+
+/* --- read-back (host buffers; each call synchronizes the device) -------- */
+int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_mp_group_state *out);
+
+/* Whole-replica canonical dump, SoA over groups; slot arrays are [W][G]
+ * indexed by slot % W, zero outside [start_slot, log_len).  flags: bit0
+ * leader_bk present, bit1 replica_bk present, bit2 external. */
+typedef struct {
+    uint8_t *leader; uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
+    uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
+    uint32_t *peer_exec_bar;            /* [R][G] */
+    uint64_t *s_bal; uint8_t *s_status; uint32_t *s_reqs; uint64_t *s_vbal; uint32_t *s_vreqs;
+    uint8_t *s_flags, *s_acks, *s_packs; uint64_t *s_pmax; uint32_t *s_ltrig, *s_lendp;
+    uint8_t *s_src; uint32_t *s_rtrig, *s_rendp;
+    uint8_t *overflow;                  /* [G] */
+} smr_mp_dump_bufs;
+int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *host_bufs);
+
+/* counters of replica `rep`: [0] leader-side commits (Accepting->Committed,
+ * messages.rs:412-433), [1] redirected batches (request.rs:128-154),
+ * [2] batches refused by ring back-pressure */
+int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]);
+
+/* Drain replica `rep`'s committed-slot list (leader-side commits since the
+ * last poll) into host arrays.  Order: ascending commit order within a group;
+ * unspecified across groups.  *n_out may exceed cap (entries were dropped). */
+int smr_mp_poll_commits(smr_mp_cluster *c, uint8_t rep, uint32_t *groups_host, uint32_t *slots_host,
+                        uint64_t cap, uint64_t *n_out);
+
+/* Per-kernel device time accounting (HIP events on `stream` around each
+ * round kernel).  which: 0 = R1, 1 = R2, 2 = R3 (quorum kernel), 3 = R4. */
+int smr_mp_profile_enable(smr_mp_cluster *c, int on);
+int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t *launches);
+
+/* ------------------------------------------------------------------------
+ * Raft leader-side match-index quorum over G groups
+ * replaces: RaftReplica::handle_req_batch (raft/request.rs:70-90) log append,
+ *           handle_msg_append_entries_reply (raft/messages.rs:222-388)
+ * ---------------------------------------------------------------------- */
+typedef struct smr_raft_leader smr_raft_leader;
+
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population;     /* R */
+    uint8_t leader_id;      /* my replica id in every group */
+    uint8_t commit_extra;   /* CRaft fault_tolerance (craft/messages.rs:301-313); 0 = Raft */
+    uint8_t reserved0;
+    uint32_t window;        /* W: ring of entry terms, power of two */
+    uint64_t term;          /* curr_term at creation (role = Leader) */
+} smr_raft_cfg;
+
+int smr_raft_leader_create(const smr_raft_cfg *cfg, smr_raft_leader **out);
+void smr_raft_leader_destroy(smr_raft_leader *l);
+/* append n_new[g] entries of the current term per group (handle_req_batch) */
+int smr_raft_leader_append(smr_raft_leader *l, const uint32_t *n_new_dev, void *stream);
+/* One AppendEntriesReply per (peer, group): reply_term[R][G], end_slot[R][G],
+ * conflict_term[R][G], conflict_slot[R][G], flags[R][G] (bit0 valid, bit1
+ * conflict present).  Peers are processed in `order_dev[g]` order (ackctl
+ * encoding; NULL = identity). */
+int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_term_dev,
+                                   const uint32_t *end_slot_dev, const uint64_t *conflict_term_dev,
+                                   const uint32_t *conflict_slot_dev, const uint8_t *flags_dev,
+                                   const uint32_t *order_dev, void *stream);
+typedef struct {
+    uint8_t *role; uint64_t *curr_term; uint32_t *log_len, *last_commit, *last_snap;
+    uint32_t *next_slot, *try_next_slot, *match_slot;   /* [R][G] */
+    uint64_t *entry_term;                               /* [W][G] by slot % W */
+    uint8_t *leader; uint32_t *start_slot;
+} smr_raft_dump_bufs;
+int smr_raft_leader_dump(smr_raft_leader *l, const smr_raft_dump_bufs *host_bufs);
+int smr_raft_leader_total_commits(smr_raft_leader *l, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMMERSET_HIP_H */

@@ -1,0 +1,260 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the summerset_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c"]
+
+CTL_IDENTITY = 0x00FAC688
+NO_LEADER = 0xFF
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (seconds)."""
+    srcs = [os.path.join(_HERE, s) for s in _SRCS if os.path.exists(os.path.join(_HERE, s))]
+    if not force and os.path.exists(_LIB_PATH):
+        if all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+            return _LIB_PATH
+    cmd = ["gcc", "-O2", "-fPIC", "-std=c11", "-shared", "-o", _LIB_PATH] + srcs
+    subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _declare(L):
+    u8, u32, u64, i32, vp = C.c_uint8, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p
+    L.orc_gf_mul.restype = u8; L.orc_gf_mul.argtypes = [u8, u8]
+    L.orc_gf_div.restype = u8; L.orc_gf_div.argtypes = [u8, u8]
+    L.orc_gf_exp.restype = u8; L.orc_gf_exp.argtypes = [u8, i32]
+    L.orc_gf_tables.argtypes = [vp, vp]
+    L.orc_rs_matrix.restype = i32; L.orc_rs_matrix.argtypes = [i32, i32, vp]
+    L.orc_rs_shard_len.restype = u64; L.orc_rs_shard_len.argtypes = [u64, i32]
+    L.orc_rs_encode.restype = i32; L.orc_rs_encode.argtypes = [i32, i32, vp, u64, vp]
+    L.orc_rs_encode_batch.restype = i32
+    L.orc_rs_encode_batch.argtypes = [i32, i32, vp, u64, u64, u64, vp, u64]
+    L.orc_rs_reconstruct.restype = i32; L.orc_rs_reconstruct.argtypes = [i32, i32, vp, u64, vp, i32]
+    L.orc_rs_verify.restype = i32; L.orc_rs_verify.argtypes = [i32, i32, vp, u64]
+    L.orc_bincode_string.restype = u64; L.orc_bincode_string.argtypes = [vp, u64, vp]
+    L.orc_bincode_reqbatch_put.restype = u64
+    L.orc_bincode_reqbatch_put.argtypes = [u64, u64, vp, u64, vp, u64, vp]
+    L.orc_mp_new.restype = vp; L.orc_mp_new.argtypes = [u32, u8, u32, u32, u32, u8, i32]
+    L.orc_mp_free.argtypes = [vp]
+    L.orc_mp_preset_leader.argtypes = [vp, u8]
+    L.orc_mp_tick.argtypes = [vp, vp, vp, vp, vp, vp, u32, vp, i32]
+    L.orc_mp_dump.argtypes = [vp, u8] + [vp] * 26
+    L.orc_mp_total_commits.restype = u64; L.orc_mp_total_commits.argtypes = [vp, u8]
+    L.orc_mp_take_commits.restype = u64; L.orc_mp_take_commits.argtypes = [vp, u8, vp, vp, u64]
+    L.orc_raft_new.restype = vp; L.orc_raft_new.argtypes = [u32, u8, u32, u8, u64, u8]
+    L.orc_raft_free.argtypes = [vp]
+    L.orc_raft_leader_append.argtypes = [vp, vp]
+    L.orc_raft_handle_replies.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.orc_raft_dump.argtypes = [vp] + [vp] * 11
+    L.orc_raft_total_commits.restype = u64; L.orc_raft_total_commits.argtypes = [vp]
+    L.orc_raft_counters.argtypes = [vp, vp]
+
+
+# ---------------------------------------------------------------- GF / RS ---
+def gf_mul(a, b):
+    return lib().orc_gf_mul(a, b)
+
+
+def gf_exp(a, n):
+    return lib().orc_gf_exp(a, n)
+
+
+def rs_matrix(d, p):
+    m = np.zeros((d + p, d), np.uint8)
+    rc = lib().orc_rs_matrix(d, p, _p(m))
+    if rc != 0:
+        raise ValueError("bad RS scheme")
+    return m
+
+
+def rs_shard_len(data_len, d):
+    return int(lib().orc_rs_shard_len(data_len, d))
+
+
+def rs_encode(d, p, data):
+    """from_data geometry + compute_parity for one codeword -> [p, shard_len]."""
+    data = np.ascontiguousarray(data, np.uint8)
+    if d <= 0:
+        raise ValueError("num_data_shards is zero")
+    sl = rs_shard_len(data.size, d)
+    par = np.zeros((p, sl), np.uint8)
+    rc = lib().orc_rs_encode(d, p, _p(data), data.size, _p(par))
+    if rc != 0:
+        raise ValueError("codeword is null / bad scheme")
+    return par
+
+
+def rs_encode_batch(d, p, data, data_len, cw_stride, n_cw, par_stride=None):
+    sl = rs_shard_len(data_len, d)
+    if par_stride is None:
+        par_stride = p * sl
+    par = np.zeros(n_cw * par_stride, np.uint8)
+    rc = lib().orc_rs_encode_batch(d, p, _p(data), data_len, cw_stride, n_cw, _p(par), par_stride)
+    if rc != 0:
+        raise ValueError("codeword is null / bad scheme")
+    return par
+
+
+def rs_reconstruct(d, p, shards, present, data_only=False):
+    """shards [d+p, shard_len] (modified in place), present [d+p] bool."""
+    shards = np.ascontiguousarray(shards, np.uint8)
+    pres = np.ascontiguousarray(present, np.uint8).copy()
+    rc = lib().orc_rs_reconstruct(d, p, _p(shards), shards.shape[1], _p(pres), int(data_only))
+    if rc != 0:
+        raise ValueError("too few shards present")
+    return shards, pres.astype(bool)
+
+
+def rs_verify(d, p, shards):
+    shards = np.ascontiguousarray(shards, np.uint8)
+    return bool(lib().orc_rs_verify(d, p, _p(shards), shards.shape[1]))
+
+
+def bincode_string(s):
+    s = np.frombuffer(bytes(s), np.uint8)
+    out = np.zeros(s.size + 9, np.uint8)
+    n = lib().orc_bincode_string(_p(s), s.size, _p(out))
+    return out[:n].copy()
+
+
+def bincode_reqbatch_put(client, req_id, key, value):
+    k = np.frombuffer(bytes(key), np.uint8)
+    v = np.frombuffer(bytes(value), np.uint8)
+    out = np.zeros(k.size + v.size + 64, np.uint8)
+    n = lib().orc_bincode_reqbatch_put(client, req_id, _p(k), k.size, _p(v), v.size, _p(out))
+    return out[:n].copy()
+
+
+# --------------------------------------------------------------- MultiPaxos -
+MP_SCALARS = ["leader", "bal_prep_sent", "bal_prepared", "bal_max_seen", "start_slot", "log_len",
+              "accept_bar", "commit_bar", "exec_bar", "snap_bar"]
+MP_SLOTS = [("s_bal", np.uint64), ("s_status", np.uint8), ("s_reqs", np.uint32), ("s_vbal", np.uint64),
+            ("s_vreqs", np.uint32), ("s_flags", np.uint8), ("s_acks", np.uint8), ("s_packs", np.uint8),
+            ("s_pmax", np.uint64), ("s_ltrig", np.uint32), ("s_lendp", np.uint32), ("s_src", np.uint8),
+            ("s_rtrig", np.uint32), ("s_rendp", np.uint32)]
+_MP_SCALAR_T = {"leader": np.uint8, "bal_prep_sent": np.uint64, "bal_prepared": np.uint64,
+                "bal_max_seen": np.uint64}
+
+
+class MpOracle:
+    """G groups x R replicas of the literal MultiPaxos restatement (LS-1)."""
+
+    def __init__(self, G, R=5, W=64, win_reserve=None, cap=None, commit_extra=0, record_commits=True):
+        self.G, self.R, self.W = G, R, W
+        self.win_reserve = W // 4 if win_reserve is None else win_reserve
+        self.cap = W + 4 if cap is None else cap
+        self.h = lib().orc_mp_new(G, R, W, self.win_reserve, self.cap, commit_extra, int(record_commits))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_mp_free(self.h)
+            self.h = None
+
+    def preset_leader(self, rep=0):
+        lib().orc_mp_preset_leader(self.h, rep)
+
+    def tick(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None,
+             ackctl=None, heartbeat=False):
+        S = 0 if req_val is None else req_val.shape[0]
+        for a, t in ((timeout_rep, np.uint8), (timeout_src, np.uint8), (req_target, np.uint8),
+                     (req_cnt, np.uint32), (req_val, np.uint32), (ackctl, np.uint32)):
+            assert a is None or (a.dtype == t and a.flags.c_contiguous)
+        if ackctl is not None:
+            assert ackctl.shape == (self.cap, self.G)
+        lib().orc_mp_tick(self.h, _p(timeout_rep), _p(timeout_src), _p(req_target), _p(req_cnt),
+                          _p(req_val), S, _p(ackctl), int(heartbeat))
+
+    def dump(self, rep):
+        G, W, R = self.G, self.W, self.R
+        out = {}
+        for n in MP_SCALARS:
+            out[n] = np.zeros(G, _MP_SCALAR_T.get(n, np.uint32))
+        out["peer_exec_bar"] = np.zeros((R, G), np.uint32)
+        for n, t in MP_SLOTS:
+            out[n] = np.zeros((W, G), t)
+        out["overflow"] = np.zeros(G, np.uint8)
+        args = [out[n] for n in MP_SCALARS] + [out["peer_exec_bar"]] + [out[n] for n, _ in MP_SLOTS] \
+            + [out["overflow"]]
+        lib().orc_mp_dump(self.h, rep, *[_p(a) for a in args])
+        return out
+
+    def total_commits(self, rep):
+        return int(lib().orc_mp_total_commits(self.h, rep))
+
+    def take_commits(self, rep, max_n=1 << 24):
+        g = np.zeros(max_n, np.uint32)
+        s = np.zeros(max_n, np.uint32)
+        n = int(lib().orc_mp_take_commits(self.h, rep, _p(g), _p(s), max_n))
+        assert n <= max_n
+        return g[:n].copy(), s[:n].copy()
+
+
+# --------------------------------------------------------------------- Raft -
+RAFT_FIELDS = ["role", "curr_term", "log_len", "last_commit", "last_snap", "next_slot", "try_next_slot",
+               "match_slot", "entry_term", "leader", "start_slot"]
+_RAFT_T = {"role": np.uint8, "leader": np.uint8, "curr_term": np.uint64, "entry_term": np.uint64}
+
+
+class RaftOracle:
+    """G groups of the literal Raft leader restatement."""
+
+    def __init__(self, G, R=5, W=64, leader_id=0, term=1, commit_extra=0):
+        self.G, self.R, self.W = G, R, W
+        self.h = lib().orc_raft_new(G, R, W, leader_id, term, commit_extra)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_raft_free(self.h)
+            self.h = None
+
+    def append(self, n_new):
+        assert n_new.dtype == np.uint32
+        lib().orc_raft_leader_append(self.h, _p(n_new))
+
+    def handle_replies(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None, order=None):
+        assert reply_term.dtype == np.uint64 and end_slot.dtype == np.uint32 and flags.dtype == np.uint8
+        lib().orc_raft_handle_replies(self.h, _p(reply_term), _p(end_slot), _p(conflict_term), _p(conflict_slot),
+                                      _p(flags), _p(order))
+
+    def dump(self):
+        G, W, R = self.G, self.W, self.R
+        out = {}
+        for n in RAFT_FIELDS:
+            shape = (R, G) if n in ("next_slot", "try_next_slot", "match_slot") else ((W, G) if n == "entry_term" else (G,))
+            out[n] = np.zeros(shape, _RAFT_T.get(n, np.uint32))
+        lib().orc_raft_dump(self.h, *[_p(out[n]) for n in RAFT_FIELDS])
+        return out
+
+    def total_commits(self):
+        return int(lib().orc_raft_total_commits(self.h))
+
+    def counters(self):
+        c = np.zeros(4, np.uint64)
+        lib().orc_raft_counters(self.h, _p(c))
+        return c

@@ -1,0 +1,125 @@
+"""ctypes binding of libsummerset_hip.so -- the only way Python reaches the engine.
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, the
+caller gets an exception.  (The CPU oracle lives under oracle/ and is test
+infrastructure only; this package never imports it.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsummerset_hip.so")
+
+SMR_OK, SMR_ERR_ARG, SMR_ERR_DEVICE, SMR_ERR_STATE = 0, -1, -2, -3
+SMR_NO_REPLICA = 0xFF
+SMR_MAX_REPLICAS = 8
+SMR_CTL_IDENTITY = 0x00FAC688
+
+
+class SummersetError(RuntimeError):
+    """Mirror of the reference's `SummersetError(String)` (src/utils/error.rs:7)."""
+
+    def __init__(self, code, msg):
+        super().__init__("[%d] %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class MpCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("commit_extra", C.c_uint8),
+                ("reserved0", C.c_uint8), ("reserved1", C.c_uint8), ("window", C.c_uint32),
+                ("win_reserve", C.c_uint32), ("outbox_cap", C.c_uint32), ("commit_list_cap", C.c_uint32)]
+
+
+class MpGroupState(C.Structure):
+    _fields_ = [("leader", C.c_uint8), ("overflow", C.c_uint8), ("bal_prep_sent", C.c_uint64),
+                ("bal_prepared", C.c_uint64), ("bal_max_seen", C.c_uint64), ("start_slot", C.c_uint32),
+                ("log_len", C.c_uint32), ("accept_bar", C.c_uint32), ("commit_bar", C.c_uint32),
+                ("exec_bar", C.c_uint32), ("snap_bar", C.c_uint32),
+                ("peer_exec_bar", C.c_uint32 * SMR_MAX_REPLICAS)]
+
+
+MP_DUMP_FIELDS = ["leader", "bal_prep_sent", "bal_prepared", "bal_max_seen", "start_slot", "log_len",
+                  "accept_bar", "commit_bar", "exec_bar", "snap_bar", "peer_exec_bar", "s_bal", "s_status",
+                  "s_reqs", "s_vbal", "s_vreqs", "s_flags", "s_acks", "s_packs", "s_pmax", "s_ltrig",
+                  "s_lendp", "s_src", "s_rtrig", "s_rendp", "overflow"]
+
+
+class MpDumpBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in MP_DUMP_FIELDS]
+
+
+class RaftCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("leader_id", C.c_uint8),
+                ("commit_extra", C.c_uint8), ("reserved0", C.c_uint8), ("window", C.c_uint32),
+                ("term", C.c_uint64)]
+
+
+RAFT_DUMP_FIELDS = ["role", "curr_term", "log_len", "last_commit", "last_snap", "next_slot", "try_next_slot",
+                    "match_slot", "entry_term", "leader", "start_slot"]
+
+
+class RaftDumpBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RAFT_DUMP_FIELDS]
+
+
+# every symbol include/summerset_hip.h declares: (name, restype, argtypes)
+_vp, _u8, _u32, _u64, _i = C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.c_int
+SYMBOLS = [
+    ("smr_last_error", C.c_char_p, []),
+    ("smr_device_count", _i, []),
+    ("smr_abi_version", _u32, []),
+    ("smr_rs_matrix", _i, [_i, _i, _vp]),
+    ("smr_rs_shard_len", _u64, [_u64, _i]),
+    ("smr_rs_encode", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _u64, _vp]),
+    ("smr_rs_encode_lut", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _u64, _vp]),
+    ("smr_rs_reconstruct", _i, [_vp, _u64, _u64, _u64, _u64, _i, _i, _u32, _i, _vp]),
+    ("smr_rs_verify", _i, [_vp, _u64, _u64, _u64, _u64, _i, _i, _vp, _vp]),
+    ("smr_mp_cluster_create", _i, [C.POINTER(MpCfg), C.POINTER(_vp)]),
+    ("smr_mp_cluster_destroy", None, [_vp]),
+    ("smr_mp_preset_leader", _i, [_vp, _u8]),
+    ("smr_mp_tick", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i, _vp]),
+    ("smr_mp_round_local", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    ("smr_mp_round_deliver", _i, [_vp, _vp]),
+    ("smr_mp_round_replies", _i, [_vp, _vp, _i, _vp]),
+    ("smr_mp_round_heartbeat", _i, [_vp, _vp]),
+    ("smr_mp_end_tick", _i, [_vp]),
+    ("smr_mp_ack_matrix", _i, [_vp, _u8, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("smr_mp_read_group_state", _i, [_vp, _u32, _u8, C.POINTER(MpGroupState)]),
+    ("smr_mp_dump", _i, [_vp, _u8, C.POINTER(MpDumpBufs)]),
+    ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),
+    ("smr_mp_poll_commits", _i, [_vp, _u8, _vp, _vp, _u64, C.POINTER(_u64)]),
+    ("smr_mp_profile_enable", _i, [_vp, _i]),
+    ("smr_mp_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    ("smr_raft_leader_create", _i, [C.POINTER(RaftCfg), C.POINTER(_vp)]),
+    ("smr_raft_leader_destroy", None, [_vp]),
+    ("smr_raft_leader_append", _i, [_vp, _vp, _vp]),
+    ("smr_raft_leader_handle_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_leader_dump", _i, [_vp, C.POINTER(RaftDumpBufs)]),
+    ("smr_raft_leader_total_commits", _i, [_vp, C.POINTER(_u64)]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen the engine; raises if it has not been built (see summerset_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SummersetError(SMR_ERR_STATE, "libsummerset_hip.so is not built: run "
+                                 "`python -c 'import __graft_entry__ as g; g.build()'` "
+                                 "(there is no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)        # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SummersetError(rc, load().smr_last_error().decode("utf-8", "replace"))
+    return rc

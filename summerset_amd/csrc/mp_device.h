@@ -1,0 +1,463 @@
+// Per-lane MultiPaxos replica handlers for gfx950 (lane = one replica group).
+//
+// Each function restates one reference handler of
+// src/protocols/multipaxos/{request,messages,durability,leadership,execution}.rs
+// on the SoA ring layout of mp_types.h, together with the WAL / executor
+// completions that handler triggers under schedule LS-1 ("every WAL append and
+// every state-machine command completes right after the handler that submitted
+// it returns, in submission order").  Written independently of
+// oracle/mp_oracle.c, which replays the same handlers over explicit queues.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mp_types.h"
+
+namespace smr {
+
+__device__ __forceinline__ uint32_t m_st(uint32_t m) { return m & M_STATUS; }
+__device__ __forceinline__ uint32_t m_set_st(uint32_t m, uint32_t st) { return (m & ~M_STATUS) | st; }
+__device__ __forceinline__ uint32_t m_acks(uint32_t m) { return (m >> M_ACKS_SH) & 0xFFu; }
+__device__ __forceinline__ uint32_t m_packs(uint32_t m) { return (m >> M_PACKS_SH) & 0xFFu; }
+__device__ __forceinline__ uint32_t m_src(uint32_t m) { return (m >> M_SRC_SH) & 0x7u; }
+__device__ __forceinline__ uint32_t m_vmode(uint32_t m) { return (m >> M_VMODE_SH) & 0x3u; }
+__device__ __forceinline__ uint32_t m_set_vmode(uint32_t m, uint32_t vm) {
+    return (m & ~(0x3u << M_VMODE_SH)) | (vm << M_VMODE_SH);
+}
+__device__ __forceinline__ uint32_t m_set_src(uint32_t m, uint32_t s) {
+    return (m & ~(0x7u << M_SRC_SH)) | (s << M_SRC_SH);
+}
+__device__ __forceinline__ uint32_t ctl_order(uint32_t ctl, int i) { return (ctl >> (3 * i)) & 7u; }
+__device__ __forceinline__ uint32_t ctl_drop(uint32_t ctl) { return ctl >> 24; }
+
+// Lane context: the group's scalar state of one replica cached in registers.
+struct Lane {
+    const MpParams &P;
+    const MpRep &v;
+    const uint32_t g;
+    const uint32_t me;
+    int par;                       // outbox parity of the current tick
+    uint32_t leader;
+    uint64_t bps, bpd, bms;        // bal_prep_sent, bal_prepared, bal_max_seen
+    uint32_t start, len, abar, cbar, ebar, snap, nlb;
+    // values as loaded, for write-back of only what changed
+    uint32_t o_leader; uint64_t o_bps, o_bpd, o_bms;
+    uint32_t o_start, o_len, o_abar, o_cbar, o_ebar, o_snap, o_nlb;
+    uint32_t obn[2];               // outbox counts (both parities)
+    bool obn_loaded[2];
+    uint32_t n_commit, n_redirect, n_reject;
+    bool ovf;
+
+    __device__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
+        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), ovf(false) {
+        obn_loaded[0] = obn_loaded[1] = false;
+        obn[0] = obn[1] = 0;
+    }
+
+    __device__ void load() {
+        o_leader = leader = v.leader[g];
+        o_bps = bps = v.bal_prep_sent[g];
+        o_bpd = bpd = v.bal_prepared[g];
+        o_bms = bms = v.bal_max_seen[g];
+        o_start = start = v.start_slot[g];
+        o_len = len = v.log_len[g];
+        o_abar = abar = v.accept_bar[g];
+        o_cbar = cbar = v.commit_bar[g];
+        o_ebar = ebar = v.exec_bar[g];
+        o_snap = snap = v.snap_bar[g];
+        o_nlb = nlb = v.null_lb[g];
+    }
+    __device__ void store() {
+        if (leader != o_leader) v.leader[g] = (uint8_t)leader;
+        if (bps != o_bps) v.bal_prep_sent[g] = bps;
+        if (bpd != o_bpd) v.bal_prepared[g] = bpd;
+        if (bms != o_bms) v.bal_max_seen[g] = bms;
+        if (start != o_start) v.start_slot[g] = start;
+        if (len != o_len) v.log_len[g] = len;
+        if (abar != o_abar) v.accept_bar[g] = abar;
+        if (cbar != o_cbar) v.commit_bar[g] = cbar;
+        if (ebar != o_ebar) v.exec_bar[g] = ebar;
+        if (snap != o_snap) v.snap_bar[g] = snap;
+        if (nlb != o_nlb) v.null_lb[g] = nlb;
+        for (int p = 0; p < 2; p++)
+            if (obn_loaded[p]) v.ob_cnt[p][g] = obn[p];
+        if (ovf) P.overflow[g] = 1;
+    }
+
+    __device__ __forceinline__ size_t ix(uint32_t slot) const { return (size_t)(slot & P.Wmask) * P.G + g; }
+    __device__ __forceinline__ bool is_leader() const { return leader == me; }
+
+    // mod.rs:553-561
+    __device__ __forceinline__ uint64_t make_greater_ballot(uint64_t bal) const {
+        return (((bal >> 8) + 1) << 8) | (uint64_t)(me + 1);
+    }
+
+    // Vec::push(null_instance()) (mod.rs:527-538) on the ring; false = window exhausted
+    __device__ bool push_null() {
+        if (len - start >= P.W) { ovf = true; return false; }
+        size_t i = ix(len);
+        v.s_meta[i] = 0; v.s_bal[i] = 0; v.s_val[i] = 0;
+        len++;
+        return true;
+    }
+    // pad with nulls until `slot` exists; records that Nulls may now sit at [old_len, slot)
+    __device__ bool pad_to(uint32_t slot) {
+        if (len <= slot && len < nlb) nlb = len;
+        while (len <= slot)
+            if (!push_null()) return false;
+        return true;
+    }
+
+    // Instance::voted accessors
+    __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val) {
+        if (m_vmode(m) == VM_SAME) {
+            v.s_vbal[i] = bal; v.s_vval[i] = val;
+            m = m_set_vmode(m, VM_SIDE);
+        }
+        return m;
+    }
+    __device__ __forceinline__ void get_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val, uint64_t &vb,
+                                              uint32_t &vv) const {
+        uint32_t vm = m_vmode(m);
+        if (vm == VM_SAME) { vb = bal; vv = val; }
+        else if (vm == VM_SIDE) { vb = v.s_vbal[i]; vv = v.s_vval[i]; }
+        else { vb = 0; vv = 0; }
+    }
+
+    __device__ void ob_load(int p) {
+        if (!obn_loaded[p]) { obn[p] = v.ob_cnt[p][g]; obn_loaded[p] = true; }
+    }
+    // transport_hub.bcast_msg(): append to my outbox of parity p
+    __device__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
+        ob_load(p);
+        uint32_t c = obn[p];
+        if (c >= P.cap) { ovf = true; return; }
+        size_t o = (size_t)c * P.G + g;
+        v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
+        v.ob_bal[p][o] = bal;
+        v.ob_val[p][o] = val;
+        if (kind == OB_HEARTBEAT) v.ob_aux[p][o] = aux;
+        obn[p] = c + 1;
+    }
+
+    // committed-slot list: wave-aggregated append ((group<<32)|slot)
+    __device__ void record_commit(uint32_t slot) {
+        n_commit++;
+        if (P.clist_cap == 0) return;
+        unsigned long long mask = __ballot(1);
+        int lane = __lane_id();
+        int first = __ffsll((long long)mask) - 1;
+        unsigned int base = 0;
+        if (lane == first) base = atomicAdd(v.clist_n, (unsigned int)__popcll(mask));
+        base = __shfl(base, first);
+        unsigned int idx = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+        if (idx < P.clist_cap) v.clist[idx] = ((unsigned long long)g << 32) | slot;
+    }
+
+    // leadership.rs:11-67 check_leader (lease branches are config-off)
+    __device__ __forceinline__ void check_leader(uint32_t peer, uint64_t ballot) {
+        if (ballot > bms) { leader = peer; bms = ballot; }
+    }
+
+    // durability.rs:134-142: accept_bar forward scan after logging slot
+    __device__ __forceinline__ void accept_bar_scan(uint32_t slot) {
+        if (slot == abar)
+            while (abar < len) {
+                if (m_st(v.s_meta[ix(abar)]) < SMR_ST_ACCEPTING) break;
+                abar++;
+            }
+    }
+
+    // durability.rs:148-218 handle_logged_commit_slot(slot), then the executor
+    // results of what it submitted: execution.rs:56-79 handle_cmd_result.
+    __device__ void commit_complete(uint32_t slot) {
+        if (slot < start || slot != cbar) return;
+        const uint32_t c0 = cbar;
+        while (cbar < abar) {                                   // durability.rs:162
+            size_t i = ix(cbar);
+            uint32_t m = v.s_meta[i];
+            if (m_st(m) < SMR_ST_COMMITTED) break;              // :164-166
+            if (v.s_val[i] == 0) v.s_meta[i] = m_set_st(m, SMR_ST_EXECUTED);   // :171-172 empty batch
+            // else if Committed: commands go to the state machine (:173-181)
+            cbar++;                                             // :189
+        }
+        for (uint32_t s = c0; s < cbar; s++) {                  // executor acks, in submission order
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            if (m_st(m) != SMR_ST_COMMITTED) continue;          // not submitted
+            v.s_meta[i] = m_set_st(m, SMR_ST_EXECUTED);         // execution.rs:57
+            if (s == ebar)                                      // execution.rs:70-78
+                while (ebar < len) {
+                    if (m_st(v.s_meta[ix(ebar)]) < SMR_ST_EXECUTED) break;
+                    ebar++;
+                }
+        }
+    }
+
+    // messages.rs:370-443 handle_msg_accept_reply + its CommitSlot completion
+    __device__ void accept_reply(uint32_t peer, uint32_t slot, uint64_t ballot) {
+        if (slot < start) return;                               // :377-379
+        if (ballot != bpd) return;                              // :388
+        if (slot >= len) return;                                // debug_assert :389
+        size_t i = ix(slot);
+        uint32_t m = v.s_meta[i];
+        if (!is_leader() || m_st(m) != SMR_ST_ACCEPTING) return;   // :394-399
+        if (ballot < v.s_bal[i]) return;
+        if (!(m & M_LBK)) return;                               // debug_assert :402
+        uint32_t bit = 1u << (peer + M_ACKS_SH);
+        if (m & bit) return;                                    // :404-406
+        m |= bit;                                               // :409
+        bool committed = (uint32_t)__popc(m_acks(m)) >= P.thresh;   // :412 (rspaxos/messages.rs:438-439)
+        if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
+        v.s_meta[i] = m;
+        if (committed) {
+            record_commit(slot);
+            commit_complete(slot);                              // WAL CommitSlot :427-433 -> durability.rs:148
+        }
+    }
+
+    // durability.rs:85-145 handle_logged_accept_data, leader branch
+    __device__ void self_accept_logged(uint32_t slot) {
+        size_t i = ix(slot);
+        accept_reply(me, slot, v.s_bal[i]);                     // :99-103
+        accept_bar_scan(slot);
+    }
+
+    // request.rs:112-224 handle_req_batch + durability.rs:85-107 (self ack)
+    __device__ void req_batch(uint32_t reqs) {
+        if (!is_leader() || bpd == 0) { n_redirect++; return; }    // :128-154
+        // mod.rs:541-549 first_null_slot, scanning only where a Null can be
+        uint32_t slot = 0xFFFFFFFFu;
+        uint32_t s0 = ebar > nlb ? ebar : nlb;
+        for (uint32_t s = s0; s < len; s++)
+            if (m_st(v.s_meta[ix(s)]) == SMR_ST_NULL) { slot = s; break; }
+        if (slot == 0xFFFFFFFFu) {
+            if ((len - start) + P.win_reserve >= P.W) { n_reject++; return; }   // ring back-pressure
+            slot = len;
+            len++;                                              // push; filled right below
+        }
+        nlb = slot + 1;
+        size_t i = ix(slot);
+        // :158-182 fresh LeaderBookkeeping (all-zero side fields), Accepting at bal_prepared,
+        // voted = (bal, reqs) :190
+        uint32_t m = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH);
+        v.s_bal[i] = bpd;
+        v.s_val[i] = reqs;
+        v.s_meta[i] = m;
+        ob_push(par, OB_ACCEPT, slot, bpd, reqs, 0);            // :209-216
+        self_accept_logged(slot);                               // WAL AcceptData :191-201 completes
+    }
+
+    // messages.rs:87-292 handle_msg_prepare_reply (+ the AcceptData completions
+    // of a reached quorum).  peer_accept_bar bookkeeping is lease-only.
+    __device__ void prepare_reply(uint32_t peer, uint32_t slot, uint32_t trig, uint32_t endp, uint64_t ballot,
+                                  bool has_voted, uint64_t vbal, uint32_t vval) {
+        if (slot < start) return;                               // :97-99
+        if (ballot != bps) return;                              // :110
+        if (!is_leader()) return;                               // :112-114
+        if (trig < start || trig >= len) return;                // debug_assert :116-119
+        const size_t ti = ix(trig);
+        uint32_t tm = v.s_meta[ti];
+        if (!(tm & M_LBK)) return;                              // :120-125
+        const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp[ti] : 0;   // :149-153
+        while (len <= slot) {                                   // :154-190 slot unknown at become_a_leader
+            uint32_t this_slot = len;
+            if (!push_null()) return;
+            size_t i = ix(this_slot);
+            v.s_bal[i] = bps;
+            v.s_ltrig[i] = trig; v.s_lendp[i] = my_endp; v.s_pmax[i] = 0;
+            v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
+            // its PrepareBal completion is a no-op on the leader (this_slot > endprep)
+        }
+        {
+            size_t i = ix(slot);
+            uint32_t m = v.s_meta[i];
+            uint64_t b = v.s_bal[i];
+            if (m_st(m) != SMR_ST_PREPARING || ballot < b) return;   // :196-198
+            if (has_voted && (m & M_LBK)) {                     // :203-216
+                uint64_t pm = (m & M_LBKX) ? v.s_pmax[i] : 0;
+                if (vbal > pm) {
+                    if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
+                    v.s_pmax[i] = vbal;
+                    m = materialize_voted(i, m, b, v.s_val[i]);
+                    v.s_val[i] = vval;                          // inst.reqs = val
+                    v.s_meta[i] = m;
+                }
+            }
+        }
+        if (slot != endp) return;                               // :222
+        tm = v.s_meta[ti];
+        tm |= 1u << (peer + M_PACKS_SH);                        // :228
+        v.s_meta[ti] = tm;
+        if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
+        bpd = ballot;                                           // :236
+        for (uint32_t s = trig; s < len; s++) {                 // :238-286
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            if (m_st(m) != SMR_ST_PREPARING) continue;
+            v.s_meta[i] = m_set_st(m, SMR_ST_ACCEPTING);
+            ob_push(par ^ 1, OB_ACCEPT, s, ballot, v.s_val[i], 0);   // travels in the next tick
+        }
+        // AcceptData completions, in order: exactly the slots moved above are
+        // Accepting at this (fresh, unique) ballot with no self ack yet
+        for (uint32_t s = trig; s < len; s++) {
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            if (m_st(m) == SMR_ST_ACCEPTING && v.s_bal[i] == ballot && !(m_acks(m) & (1u << me)))
+                self_accept_logged(s);
+        }
+    }
+
+    // leadership.rs:73-214 become_a_leader + its PrepareBal completions
+    // (durability.rs:10-49: the leader's own PrepareReply)
+    __device__ void become_a_leader(uint32_t src) {
+        if (leader != NO_REP && leader != src) return;          // :77-81
+        leader = me;                                            // :98
+        // :104 bcast_heartbeats() now, still carrying the old bal_max_seen (:240-247)
+        ob_push(par, OB_HEARTBEAT, cbar, bms, ebar, snap);
+        for (uint32_t p = 0; p < P.R; p++) v.peer_exec_bar[(size_t)p * P.G + g] = 0;   // :107-109
+        bpd = 0;                                                // :112-114
+        bps = make_greater_ballot(bms);
+        bms = bps;
+        uint32_t trig = len, endp = len;                        // :117-130
+        for (uint32_t s = start; s < len; s++)
+            if (m_st(v.s_meta[ix(s)]) < SMR_ST_COMMITTED) { trig = s; break; }
+        for (uint32_t s = len; s > start; s--)
+            if (m_st(v.s_meta[ix(s - 1)]) < SMR_ST_COMMITTED) { endp = s - 1; break; }
+        if (trig == len)                                        // :131-134
+            if (!push_null()) return;
+        const uint32_t e0 = ebar;
+        for (uint32_t s = e0; s < len; s++) {                   // :142-183
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            uint32_t st = m_st(m);
+            if (st == SMR_ST_EXECUTED) continue;
+            m |= M_EXT;
+            if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
+            m = materialize_voted(i, m, v.s_bal[i], v.s_val[i]);
+            v.s_bal[i] = bps;
+            m = m_set_st(m, SMR_ST_PREPARING) | M_LBK | M_LBKX;
+            m &= ~((0xFFu << M_ACKS_SH) | (0xFFu << M_PACKS_SH));
+            v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = 0;
+            v.s_meta[i] = m;
+        }
+        ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
+        // PrepareBal completions: the slots just moved are exactly those
+        // Preparing at the fresh ballot
+        for (uint32_t s = e0; s < len; s++) {
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            uint64_t b = v.s_bal[i];
+            if (m_st(m) != SMR_ST_PREPARING || b != bps) continue;
+            if (!is_leader()) break;
+            if (s <= endp) {                                    // durability.rs:33-48
+                uint64_t vb; uint32_t vv;
+                get_voted(i, m, b, v.s_val[i], vb, vv);
+                prepare_reply(me, s, trig, endp, b, vb > 0, vb, vv);
+            }
+        }
+    }
+
+    // messages.rs:12-83 handle_msg_prepare + durability.rs:50-78 (PrepareReply
+    // per slot, written as one batch: header + (voted_bal, voted_reqs) entries)
+    __device__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
+        if (trig < start) return;                               // :18-20
+        if (ballot < bms) return;                               // :29
+        check_leader(peer, ballot);
+        if (!pad_to(trig)) return;                              // :37-39
+        uint32_t last = start;                                  // :43-52
+        for (uint32_t s = len; s > start; s--)
+            if (m_st(v.s_meta[ix(s - 1)]) > SMR_ST_NULL) { last = s - 1; break; }
+        const uint32_t endp = last > trig ? last : trig;
+        const uint32_t n = endp - trig + 1;
+        const bool follower = !is_leader();
+        if (follower && (v.pr_cnt[g] != 0 || n > P.pcap)) { ovf = true; return; }
+        for (uint32_t s = trig; s <= endp; s++) {               // :55-79
+            size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            uint64_t b = v.s_bal[i];
+            uint32_t val = v.s_val[i];
+            uint64_t vb; uint32_t vv;
+            get_voted(i, m, b, val, vb, vv);
+            m = materialize_voted(i, m, b, val);
+            v.s_bal[i] = ballot;
+            m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
+            v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
+            v.s_meta[i] = m;
+            if (follower) {                                     // durability.rs:50-78
+                size_t o = (size_t)(s - trig) * P.G + g;
+                v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
+            }
+        }
+        if (follower) {
+            v.pr_dest[g] = (uint8_t)peer; v.pr_trig[g] = trig; v.pr_endp[g] = endp;
+            v.pr_bal[g] = ballot; v.pr_abar[g] = abar;
+            v.pr_cnt[g] = n;
+        }
+    }
+
+    // messages.rs:295-367 handle_msg_accept + durability.rs:85-145; returns the
+    // AcceptReply ballot for the sender (0 = no reply)
+    __device__ uint64_t msg_accept(uint32_t peer, uint32_t slot, uint64_t ballot, uint32_t reqs) {
+        if (slot < start) return 0;                             // :302-304
+        if (ballot < bms) return 0;                             // :313
+        check_leader(peer, ballot);
+        uint32_t m = 0;
+        size_t i = ix(slot);
+        if (slot < len) m = v.s_meta[i];
+        else if (slot == len) {                                 // common case: push + fill fused
+            if (len - start >= P.W) { ovf = true; return 0; }
+            len++;
+        } else {
+            if (!pad_to(slot)) return 0;                        // :321-323
+        }
+        m = m_set_st(m, SMR_ST_ACCEPTING);                      // :327-329
+        if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;            // :331-339
+        m = m_set_src(m, peer);
+        m = m_set_vmode(m, VM_SAME);                            // :351 voted = (ballot, reqs)
+        v.s_bal[i] = ballot;
+        v.s_val[i] = reqs;
+        v.s_meta[i] = m;
+        uint64_t reply = 0;
+        if (is_leader()) accept_reply(me, slot, ballot);        // durability.rs:99-103 (not reachable: a
+                                                                // peer's ballot >= mine deposes me)
+        else reply = ballot;                                    // durability.rs:108-131 -> source == peer
+        accept_bar_scan(slot);                                  // durability.rs:134-142
+        return reply;
+    }
+
+    // leadership.rs:270-346 heard_heartbeat + :372-427 advance_commit_bar
+    __device__ void heard_heartbeat(uint32_t peer, uint64_t ballot, uint32_t hb_commit, uint32_t hb_exec,
+                                    uint32_t hb_snap) {
+        if (peer != me) check_leader(peer, ballot);             // :278-285
+        if (ballot < bms) return;                               // :303-305
+        if (hb_exec < ebar) return;                             // :312-314
+        if (hb_commit > cbar) {                                 // :379
+            if (len < hb_commit && !pad_to(hb_commit - 1)) return;   // :380-382
+            uint32_t first = 0xFFFFFFFFu;
+            for (uint32_t s = cbar; s < hb_commit; s++) {       // :385-416
+                size_t i = ix(s);
+                uint32_t m = v.s_meta[i];
+                uint32_t st = m_st(m);
+                if (v.s_bal[i] < ballot || st < SMR_ST_ACCEPTING) break;
+                if (st >= SMR_ST_COMMITTED) continue;
+                v.s_meta[i] = m_set_st(m, SMR_ST_COMMITTED);
+                if (first == 0xFFFFFFFFu) first = s;
+            }
+            // CommitSlot completions: only the first can sit at commit_bar
+            if (first != 0xFFFFFFFFu) commit_complete(first);
+        }
+        if (peer != me) {                                       // :320-342
+            size_t po = (size_t)peer * P.G + g;
+            if (hb_exec > v.peer_exec_bar[po]) {
+                v.peer_exec_bar[po] = hb_exec;
+                uint32_t passed = 1;
+                for (uint32_t p = 0; p < P.R; p++)
+                    if (p != me && v.peer_exec_bar[(size_t)p * P.G + g] >= hb_exec) passed++;
+                if (passed == P.R) snap = hb_exec;
+            }
+            if (hb_snap > snap) snap = hb_snap;
+        }
+    }
+};
+
+}  // namespace smr

@@ -1,0 +1,537 @@
+// MultiPaxos / RSPaxos lock-step cluster: round kernels + C-ABI.
+//
+// Grid shape of every round kernel: blockIdx.y = replica id, 256 lanes per
+// block = 256 consecutive groups, so every per-group array access of a
+// wavefront is one contiguous request.  Rounds are separate launches because
+// each consumes what the previous one wrote for OTHER replicas (and, in the
+// multi-GPU layout, the exchange sits between them).
+#include <string.h>
+
+#include <vector>
+
+#include "mp_device.h"
+#include "smr_common.h"
+
+namespace smr {
+
+__device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
+    // wave-reduce the three counters, one atomic per wave
+    unsigned int c0 = active ? L.n_commit : 0, c1 = active ? L.n_redirect : 0, c2 = active ? L.n_reject : 0;
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+        c2 += __shfl_xor(c2, off);
+    }
+    if (__lane_id() == 0) {
+        if (c0) atomicAdd(&L.v.counters[0], (unsigned long long)c0);
+        if (c1) atomicAdd(&L.v.counters[1], (unsigned long long)c1);
+        if (c2) atomicAdd(&L.v.counters[2], (unsigned long long)c2);
+    }
+}
+
+// R1: HearTimeout -> become_a_leader; client batches -> handle_req_batch
+__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
+                                                      const uint8_t *__restrict__ timeout_rep,
+                                                      const uint8_t *__restrict__ timeout_src,
+                                                      const uint8_t *__restrict__ req_target,
+                                                      const uint32_t *__restrict__ req_cnt,
+                                                      const uint32_t *__restrict__ req_val, uint32_t S) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    Lane L(P, r, g < P.G ? g : 0, par);
+    bool active = g < P.G && !P.overflow[g];
+    bool has_to = active && timeout_rep && timeout_rep[g] == r;
+    uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
+    if (n_req > S) n_req = S;
+    active = has_to || n_req > 0;
+    if (active) {
+        L.load();
+        if (has_to) L.become_a_leader(timeout_src[g]);
+        for (uint32_t k = 0; k < n_req && !L.ovf; k++) L.req_batch(req_val[(size_t)k * P.G + g]);
+        L.store();
+    }
+    flush_counters(L, active);
+}
+
+// R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    Lane L(P, r, g < P.G ? g : 0, par);
+    bool active = g < P.G && !P.overflow[g];
+    if (active) {
+        bool loaded = false;
+        if (L.v.pr_cnt[g]) L.v.pr_cnt[g] = 0;
+        for (uint32_t s = 0; s < P.R; s++) {
+            if (s == r) continue;
+            const MpRep &snd = P.rep[s];
+            const uint32_t cnt = snd.ob_cnt[par][g];
+            for (uint32_t j = 0; j < cnt; j++) {
+                if (!loaded) { L.load(); loaded = true; }
+                size_t o = (size_t)j * P.G + g;
+                uint32_t e = snd.ob_slot[par][o];
+                uint64_t bal = snd.ob_bal[par][o];
+                uint32_t kind = e >> OB_KIND_SH, slot = e & OB_SLOT_MASK;
+                if (kind == OB_ACCEPT) {
+                    uint64_t rep = L.msg_accept(s, slot, bal, snd.ob_val[par][o]);
+                    snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
+                } else if (kind == OB_PREPARE) {
+                    L.msg_prepare(s, slot, bal);
+                } else if (kind == OB_HEARTBEAT) {
+                    L.heard_heartbeat(s, bal, slot, snd.ob_val[par][o], snd.ob_aux[par][o]);
+                }
+                if (L.ovf) break;
+            }
+            if (L.ovf) break;
+        }
+        if (loaded) L.store();
+        active = loaded;
+    }
+    flush_counters(L, active);
+}
+
+// R3: replies reach their destination: PrepareReplies (sender order of the
+// tick's ackctl word, FIFO per sender), then the AcceptReply matrix of my own
+// outbox, entry-major with per-entry peer order / loss.  THE quorum kernel.
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+                                                        const uint32_t *__restrict__ ackctl,
+                                                        int publish_hb) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t d = blockIdx.y;
+    Lane L(P, d, g < P.G ? g : 0, par);
+    bool active = g < P.G && !P.overflow[g];
+    bool loaded = false;
+    if (active) {
+        const MpRep &v = P.rep[d];
+        const uint32_t tickctl = ackctl ? ackctl[g] : SMR_CTL_IDENTITY;
+        // (a) PrepareReplies addressed to me
+        for (uint32_t oi = 0; oi < P.R; oi++) {
+            uint32_t s = ctl_order(tickctl, oi);
+            if (s == d || s >= P.R) continue;
+            const MpRep &snd = P.rep[s];
+            uint32_t n = snd.pr_cnt[g];
+            if (n == 0 || snd.pr_dest[g] != d) continue;
+            if (!loaded) { L.load(); loaded = true; }
+            uint32_t trig = snd.pr_trig[g], endp = snd.pr_endp[g];
+            uint64_t bal = snd.pr_bal[g];
+            for (uint32_t k = 0; k < n && !L.ovf; k++) {
+                size_t o = (size_t)k * P.G + g;
+                uint64_t vb = snd.pr_vbal[o];
+                L.prepare_reply(s, trig + k, trig, endp, bal, vb > 0, vb, snd.pr_vval[o]);
+            }
+        }
+        // (b) AcceptReplies to my Accepts of this tick
+        const uint32_t cnt = v.ob_cnt[par][g];
+        if (cnt) {
+            if (!loaded) { L.load(); loaded = true; }
+            for (uint32_t j = 0; j < cnt; j++) {
+                size_t o = (size_t)j * P.G + g;
+                uint32_t e = v.ob_slot[par][o];
+                if ((e >> OB_KIND_SH) != OB_ACCEPT) continue;
+                uint32_t slot = e & OB_SLOT_MASK;
+                uint32_t ctl = ackctl ? ackctl[o] : SMR_CTL_IDENTITY;
+                uint32_t drop = ctl_drop(ctl);
+                for (uint32_t oi = 0; oi < P.R; oi++) {
+                    uint32_t s = ctl_order(ctl, oi);
+                    if (s == d || s >= P.R) continue;
+                    if (drop & (1u << s)) continue;
+                    uint64_t a = v.ack[((size_t)j * P.R + s) * P.G + g];
+                    if (!a) continue;
+                    L.accept_reply(s, slot, a);
+                }
+            }
+            L.ob_load(par);
+            L.obn[par] = 0;                                      // outbox consumed
+        }
+        if (publish_hb) {                                        // leadership.rs:240-247 record
+            if (!loaded) { L.load(); loaded = true; }
+            v.hb_bal[g] = L.bms; v.hb_commit[g] = L.cbar; v.hb_exec[g] = L.ebar; v.hb_snap[g] = L.snap;
+        }
+        if (loaded) L.store();
+    }
+    flush_counters(L, active && loaded);
+}
+
+// R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
+// trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
+// as carried by this round's heartbeats).
+__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    Lane L(P, r, g < P.G ? g : 0, par);
+    bool active = g < P.G && !P.overflow[g];
+    if (active) {
+        L.load();
+        const MpRep &v = P.rep[r];
+        L.heard_heartbeat(r, v.hb_bal[g], v.hb_commit[g], v.hb_exec[g], v.hb_snap[g]);   // :254-261
+        uint32_t bound = 0xFFFFFFFFu;
+        for (uint32_t s = 0; s < P.R; s++) {
+            if (s == r) continue;
+            const MpRep &snd = P.rep[s];
+            uint32_t he = snd.hb_exec[g];
+            if (he < bound) bound = he;
+            if (!L.ovf) L.heard_heartbeat(s, snd.hb_bal[g], snd.hb_commit[g], he, snd.hb_snap[g]);
+        }
+        if (L.ebar < bound) bound = L.ebar;
+        if (bound > L.start) L.start = bound;
+        L.store();
+    }
+    flush_counters(L, active);
+}
+
+// ------------------------------------------------------------------ host ---
+struct ProfEv { hipEvent_t a, b; int which; };
+
+}  // namespace smr
+
+using namespace smr;
+
+struct smr_mp_cluster {
+    smr_mp_cfg cfg;
+    MpParams hp;            // host copy (device pointers inside)
+    MpParams *dp = nullptr; // device copy
+    Arena arena;
+    uint32_t pcap = 0;
+    int par = 0;
+    bool profile = false;
+    std::vector<ProfEv> evs;
+    double prof_ms[4] = {0, 0, 0, 0};
+    uint64_t prof_n[4] = {0, 0, 0, 0};
+};
+
+namespace smr {
+
+static bool is_pow2(uint32_t x) { return x && !(x & (x - 1)); }
+
+template <typename T> static void carve(Arena &a, T *&p, size_t n, bool dry) {
+    size_t off = a.reserve(n * sizeof(T));
+    if (!dry) p = a.at<T>(off);
+}
+
+static void layout(smr_mp_cluster *c, bool dry) {
+    Arena &a = c->arena;
+    a.used = 0;
+    const size_t G = c->cfg.n_groups, W = c->cfg.window, R = c->cfg.population, cap = c->cfg.outbox_cap,
+                 pcap = c->pcap;
+    MpParams &P = c->hp;
+    carve(a, P.overflow, G, dry);
+    for (size_t r = 0; r < R; r++) {
+        MpRep &v = P.rep[r];
+        carve(a, v.leader, G, dry);
+        carve(a, v.bal_prep_sent, G, dry); carve(a, v.bal_prepared, G, dry); carve(a, v.bal_max_seen, G, dry);
+        carve(a, v.start_slot, G, dry); carve(a, v.log_len, G, dry); carve(a, v.accept_bar, G, dry);
+        carve(a, v.commit_bar, G, dry); carve(a, v.exec_bar, G, dry); carve(a, v.snap_bar, G, dry);
+        carve(a, v.null_lb, G, dry);
+        carve(a, v.peer_exec_bar, R * G, dry);
+        carve(a, v.s_bal, W * G, dry); carve(a, v.s_val, W * G, dry); carve(a, v.s_meta, W * G, dry);
+        carve(a, v.s_vbal, W * G, dry); carve(a, v.s_vval, W * G, dry); carve(a, v.s_pmax, W * G, dry);
+        carve(a, v.s_ltrig, W * G, dry); carve(a, v.s_lendp, W * G, dry);
+        carve(a, v.s_rtrig, W * G, dry); carve(a, v.s_rendp, W * G, dry);
+        for (int p = 0; p < 2; p++) {
+            carve(a, v.ob_cnt[p], G, dry);
+            carve(a, v.ob_slot[p], cap * G, dry); carve(a, v.ob_bal[p], cap * G, dry);
+            carve(a, v.ob_val[p], cap * G, dry); carve(a, v.ob_aux[p], cap * G, dry);
+        }
+        carve(a, v.ack, cap * R * G, dry);
+        carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);
+        carve(a, v.pr_trig, G, dry); carve(a, v.pr_endp, G, dry); carve(a, v.pr_abar, G, dry);
+        carve(a, v.pr_bal, G, dry);
+        carve(a, v.pr_vbal, pcap * G, dry); carve(a, v.pr_vval, pcap * G, dry);
+        carve(a, v.hb_bal, G, dry); carve(a, v.hb_commit, G, dry); carve(a, v.hb_exec, G, dry);
+        carve(a, v.hb_snap, G, dry);
+        carve(a, v.counters, 4, dry);
+        carve(a, v.clist, (size_t)c->cfg.commit_list_cap, dry);
+        carve(a, v.clist_n, 1, dry);
+    }
+}
+
+static int prof_begin(smr_mp_cluster *c, int which, hipStream_t st) {
+    if (!c->profile) return SMR_OK;
+    ProfEv e; e.which = which;
+    SMR_HIP_TRY(hipEventCreate(&e.a));
+    SMR_HIP_TRY(hipEventCreate(&e.b));
+    SMR_HIP_TRY(hipEventRecord(e.a, st));
+    c->evs.push_back(e);
+    return SMR_OK;
+}
+static int prof_end(smr_mp_cluster *c, hipStream_t st) {
+    if (!c->profile) return SMR_OK;
+    SMR_HIP_TRY(hipEventRecord(c->evs.back().b, st));
+    return SMR_OK;
+}
+
+static dim3 mp_grid(const smr_mp_cluster *c) { return dim3((c->cfg.n_groups + 255) / 256, c->cfg.population); }
+
+}  // namespace smr
+
+extern "C" {
+
+int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
+    if (!cfg || !out) return fail(SMR_ERR_ARG, "mp: null argument");
+    if (cfg->n_groups == 0) return fail(SMR_ERR_ARG, "mp: n_groups is zero");
+    if (cfg->population < 3 || cfg->population > SMR_MAX_REPLICAS)
+        return fail(SMR_ERR_ARG, "mp: population must be in 3..8");
+    if (!is_pow2(cfg->window) || cfg->window < 8 || cfg->window > (1u << 20))
+        return fail(SMR_ERR_ARG, "mp: window must be a power of two in 8..2^20");
+    if (cfg->win_reserve >= cfg->window) return fail(SMR_ERR_ARG, "mp: win_reserve >= window");
+    if (cfg->outbox_cap < 4) return fail(SMR_ERR_ARG, "mp: outbox_cap < 4");
+    uint32_t quorum = cfg->population / 2 + 1;                    // multipaxos/mod.rs:774
+    if (cfg->commit_extra > cfg->population - quorum)             // rspaxos/mod.rs:600-605
+        return fail(SMR_ERR_ARG, "mp: commit_extra (fault_tolerance) exceeds population - majority");
+    smr_mp_cluster *c = new smr_mp_cluster();
+    c->cfg = *cfg;
+    c->pcap = cfg->window;
+    memset(&c->hp, 0, sizeof(c->hp));
+    layout(c, true);
+    c->arena.size = c->arena.used + 256;
+    hipError_t e = hipMalloc((void **)&c->arena.base, c->arena.size);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(SMR_ERR_DEVICE, std::string("mp: hipMalloc of engine state: ") + hipGetErrorString(e));
+    }
+    layout(c, false);
+    MpParams &P = c->hp;
+    P.G = cfg->n_groups; P.W = cfg->window; P.Wmask = cfg->window - 1; P.cap = cfg->outbox_cap;
+    P.pcap = c->pcap; P.win_reserve = cfg->win_reserve; P.clist_cap = cfg->commit_list_cap;
+    P.R = cfg->population; P.quorum = quorum; P.thresh = quorum + cfg->commit_extra; P.rspaxos = 0;
+    e = hipMemset(c->arena.base, 0, c->arena.size);
+    for (uint32_t r = 0; e == hipSuccess && r < P.R; r++) e = hipMemset(P.rep[r].leader, 0xFF, P.G);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->dp, sizeof(MpParams));
+    if (e == hipSuccess) e = hipMemcpy(c->dp, &c->hp, sizeof(MpParams), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(c->arena.base);
+        if (c->dp) (void)hipFree(c->dp);
+        delete c;
+        return fail(SMR_ERR_DEVICE, std::string("mp: init: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return SMR_OK;
+}
+
+void smr_mp_cluster_destroy(smr_mp_cluster *c) {
+    if (!c) return;
+    for (auto &e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (c->dp) (void)hipFree(c->dp);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    delete c;
+}
+
+int smr_mp_preset_leader(smr_mp_cluster *c, uint8_t rep) {
+    if (!c || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad replica id");
+    const uint32_t G = c->cfg.n_groups;
+    std::vector<uint64_t> b(G, (1ull << 8) | (uint64_t)(rep + 1));
+    for (uint32_t r = 0; r < c->cfg.population; r++) {
+        MpRep &v = c->hp.rep[r];
+        SMR_HIP_TRY(hipMemset(v.leader, rep, G));
+        SMR_HIP_TRY(hipMemcpy(v.bal_max_seen, b.data(), G * 8, hipMemcpyHostToDevice));
+        if (r == rep) {
+            SMR_HIP_TRY(hipMemcpy(v.bal_prep_sent, b.data(), G * 8, hipMemcpyHostToDevice));
+            SMR_HIP_TRY(hipMemcpy(v.bal_prepared, b.data(), G * 8, hipMemcpyHostToDevice));
+        }
+    }
+    return SMR_OK;
+}
+
+int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t *timeout_src_dev,
+                       const uint8_t *req_target_dev, const uint32_t *req_cnt_dev, const uint32_t *req_val_dev,
+                       uint32_t S, void *stream) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    if (timeout_rep_dev && !timeout_src_dev) return fail(SMR_ERR_ARG, "mp: timeout_rep without timeout_src");
+    if (req_target_dev && (!req_cnt_dev || !req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
+    if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prof_begin(c, 0, st); if (rc) return rc;
+    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
+                       timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S);
+    SMR_HIP_TRY(hipGetLastError());
+    return prof_end(c, st);
+}
+
+int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prof_begin(c, 1, st); if (rc) return rc;
+    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    SMR_HIP_TRY(hipGetLastError());
+    return prof_end(c, st);
+}
+
+int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publish_heartbeat, void *stream) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prof_begin(c, 2, st); if (rc) return rc;
+    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
+                       publish_heartbeat);
+    SMR_HIP_TRY(hipGetLastError());
+    return prof_end(c, st);
+}
+
+int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = prof_begin(c, 3, st); if (rc) return rc;
+    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    SMR_HIP_TRY(hipGetLastError());
+    return prof_end(c, st);
+}
+
+int smr_mp_end_tick(smr_mp_cluster *c) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    c->par ^= 1;
+    return SMR_OK;
+}
+
+int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t *timeout_src_dev,
+                const uint8_t *req_target_dev, const uint32_t *req_cnt_dev, const uint32_t *req_val_dev,
+                uint32_t S, const uint32_t *ackctl_dev, int do_heartbeat, void *stream) {
+    int rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S,
+                                stream);
+    if (rc) return rc;
+    if ((rc = smr_mp_round_deliver(c, stream))) return rc;
+    if ((rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream))) return rc;
+    if (do_heartbeat && (rc = smr_mp_round_heartbeat(c, stream))) return rc;
+    return smr_mp_end_tick(c);
+}
+
+int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes) {
+    if (!c || rep >= c->cfg.population || !ack_dev) return fail(SMR_ERR_ARG, "mp: bad argument");
+    *ack_dev = c->hp.rep[rep].ack;
+    if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * c->cfg.population * c->cfg.n_groups * 8;
+    return SMR_OK;
+}
+
+int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_mp_group_state *out) {
+    if (!c || !out || rep >= c->cfg.population || group >= c->cfg.n_groups)
+        return fail(SMR_ERR_ARG, "mp: bad group / replica");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const MpRep &v = c->hp.rep[rep];
+    memset(out, 0, sizeof(*out));
+#define RD(dst, src) SMR_HIP_TRY(hipMemcpy(&(dst), (src) + group, sizeof(dst), hipMemcpyDeviceToHost))
+    RD(out->leader, v.leader); RD(out->overflow, c->hp.overflow);
+    RD(out->bal_prep_sent, v.bal_prep_sent); RD(out->bal_prepared, v.bal_prepared);
+    RD(out->bal_max_seen, v.bal_max_seen);
+    RD(out->start_slot, v.start_slot); RD(out->log_len, v.log_len); RD(out->accept_bar, v.accept_bar);
+    RD(out->commit_bar, v.commit_bar); RD(out->exec_bar, v.exec_bar); RD(out->snap_bar, v.snap_bar);
+#undef RD
+    for (uint32_t p = 0; p < c->cfg.population; p++)
+        if (p != rep)
+            SMR_HIP_TRY(hipMemcpy(&out->peer_exec_bar[p], v.peer_exec_bar + (size_t)p * c->cfg.n_groups + group, 4,
+                                  hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
+    if (!c || !hb || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const MpRep &v = c->hp.rep[rep];
+    const size_t G = c->cfg.n_groups, W = c->cfg.window, R = c->cfg.population;
+#define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+    D2H(hb->leader, v.leader, G);
+    D2H(hb->bal_prep_sent, v.bal_prep_sent, G * 8); D2H(hb->bal_prepared, v.bal_prepared, G * 8);
+    D2H(hb->bal_max_seen, v.bal_max_seen, G * 8);
+    D2H(hb->start_slot, v.start_slot, G * 4); D2H(hb->log_len, v.log_len, G * 4);
+    D2H(hb->accept_bar, v.accept_bar, G * 4); D2H(hb->commit_bar, v.commit_bar, G * 4);
+    D2H(hb->exec_bar, v.exec_bar, G * 4); D2H(hb->snap_bar, v.snap_bar, G * 4);
+    D2H(hb->peer_exec_bar, v.peer_exec_bar, R * G * 4);
+    D2H(hb->overflow, c->hp.overflow, G);
+    for (size_t g = 0; g < G; g++) hb->peer_exec_bar[(size_t)rep * G + g] = 0;
+    std::vector<uint64_t> bal(W * G), vbal(W * G), pmax(W * G);
+    std::vector<uint32_t> val(W * G), meta(W * G), vval(W * G), ltrig(W * G), lendp(W * G), rtrig(W * G), rendp(W * G);
+    D2H(bal.data(), v.s_bal, W * G * 8); D2H(vbal.data(), v.s_vbal, W * G * 8); D2H(pmax.data(), v.s_pmax, W * G * 8);
+    D2H(val.data(), v.s_val, W * G * 4); D2H(meta.data(), v.s_meta, W * G * 4); D2H(vval.data(), v.s_vval, W * G * 4);
+    D2H(ltrig.data(), v.s_ltrig, W * G * 4); D2H(lendp.data(), v.s_lendp, W * G * 4);
+    D2H(rtrig.data(), v.s_rtrig, W * G * 4); D2H(rendp.data(), v.s_rendp, W * G * 4);
+#undef D2H
+    // canonicalise: explicit Instance fields, zero outside [start_slot, log_len)
+    for (size_t w = 0; w < W; w++)
+        for (size_t g = 0; g < G; g++) {
+            size_t o = w * G + g;
+            hb->s_bal[o] = 0; hb->s_status[o] = 0; hb->s_reqs[o] = 0; hb->s_vbal[o] = 0; hb->s_vreqs[o] = 0;
+            hb->s_flags[o] = 0; hb->s_acks[o] = 0; hb->s_packs[o] = 0; hb->s_pmax[o] = 0; hb->s_ltrig[o] = 0;
+            hb->s_lendp[o] = 0; hb->s_src[o] = 0; hb->s_rtrig[o] = 0; hb->s_rendp[o] = 0;
+        }
+    for (size_t g = 0; g < G; g++) {
+        uint32_t lo = hb->start_slot[g], hi = hb->log_len[g];
+        if (hi - lo > W) hi = lo + (uint32_t)W;
+        for (uint32_t s = lo; s < hi; s++) {
+            size_t o = (size_t)(s & (W - 1)) * G + g;
+            uint32_t m = meta[o];
+            hb->s_bal[o] = bal[o]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[o];
+            uint32_t vm = (m >> M_VMODE_SH) & 3u;
+            hb->s_vbal[o] = vm == VM_SAME ? bal[o] : (vm == VM_SIDE ? vbal[o] : 0);
+            hb->s_vreqs[o] = vm == VM_SAME ? val[o] : (vm == VM_SIDE ? vval[o] : 0);
+            bool lbk = m & M_LBK, rbk = m & M_RBK;
+            hb->s_flags[o] = (uint8_t)((lbk ? 1 : 0) | (rbk ? 2 : 0) | ((m & M_EXT) ? 4 : 0));
+            hb->s_acks[o] = lbk ? (uint8_t)((m >> M_ACKS_SH) & 0xFF) : 0;
+            hb->s_packs[o] = lbk ? (uint8_t)((m >> M_PACKS_SH) & 0xFF) : 0;
+            bool lx = lbk && (m & M_LBKX), rx = rbk && (m & M_RBKX);
+            hb->s_pmax[o] = lx ? pmax[o] : 0; hb->s_ltrig[o] = lx ? ltrig[o] : 0; hb->s_lendp[o] = lx ? lendp[o] : 0;
+            hb->s_src[o] = rbk ? (uint8_t)((m >> M_SRC_SH) & 7) : 0;
+            hb->s_rtrig[o] = rx ? rtrig[o] : 0; hb->s_rendp[o] = rx ? rendp[o] : 0;
+        }
+    }
+    return SMR_OK;
+}
+
+int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]) {
+    if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[4];
+    SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return SMR_OK;
+}
+
+int smr_mp_poll_commits(smr_mp_cluster *c, uint8_t rep, uint32_t *groups_host, uint32_t *slots_host, uint64_t cap,
+                        uint64_t *n_out) {
+    if (!c || rep >= c->cfg.population || !n_out) return fail(SMR_ERR_ARG, "mp: bad argument");
+    if (c->cfg.commit_list_cap == 0) return fail(SMR_ERR_STATE, "mp: cluster was created without a commit list");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const MpRep &v = c->hp.rep[rep];
+    unsigned int n = 0;
+    SMR_HIP_TRY(hipMemcpy(&n, v.clist_n, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    uint64_t take = n;
+    if (take > c->cfg.commit_list_cap) take = c->cfg.commit_list_cap;
+    if (take > cap) take = cap;
+    if (take && groups_host && slots_host) {
+        std::vector<unsigned long long> tmp(take);
+        SMR_HIP_TRY(hipMemcpy(tmp.data(), v.clist, take * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < take; i++) {
+            groups_host[i] = (uint32_t)(tmp[i] >> 32);
+            slots_host[i] = (uint32_t)tmp[i];
+        }
+    }
+    SMR_HIP_TRY(hipMemset(v.clist_n, 0, 4));
+    return SMR_OK;
+}
+
+int smr_mp_profile_enable(smr_mp_cluster *c, int on) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    c->profile = on != 0;
+    return SMR_OK;
+}
+
+int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t *launches) {
+    if (!c || which < 0 || which > 3) return fail(SMR_ERR_ARG, "mp: bad argument");
+    if (!c->evs.empty()) {
+        SMR_HIP_TRY(hipDeviceSynchronize());
+        for (auto &e : c->evs) {
+            float ms = 0;
+            SMR_HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+            c->prof_ms[e.which] += ms;
+            c->prof_n[e.which]++;
+            (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        }
+        c->evs.clear();
+    }
+    if (total_ms) *total_ms = c->prof_ms[which];
+    if (launches) *launches = c->prof_n[which];
+    return SMR_OK;
+}
+
+}  // extern "C"

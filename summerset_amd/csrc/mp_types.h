@@ -1,0 +1,91 @@
+// Device-side data layout of the MultiPaxos / RSPaxos engine.
+//
+// One `MpRep` = the batched counterpart of the reference's
+// `MultiPaxosReplica` struct (src/protocols/multipaxos/mod.rs:387-514) for ONE
+// replica id over G groups.  Everything is structure-of-arrays with the group
+// index fastest, so a wavefront touching lane-consecutive groups issues one
+// contiguous 256/512-byte request per field.
+//
+//   per-group scalars   X[g]
+//   slot ring           X[(slot & (W-1)) * G + g]      (Vec<Instance>, mod.rs:426)
+//   outbox (x2 parity)  X[j * G + g], j < cap          (bcast_msg of Prepare /
+//                                                       Accept / Heartbeat)
+//   ack matrix          ack[(j * R + r) * G + g]       AcceptReply ballot of
+//                                                       replica r to my j-th
+//                                                       outbox entry (0 = none)
+//
+// Instance fields are packed so the steady-state path touches 16 bytes per
+// (replica, slot): s_bal (8) + s_val (4) + s_meta (4).  Rarely-used fields live
+// in side arrays that are only valid when the matching meta flag says so.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/summerset_hip.h"
+
+namespace smr {
+
+// s_meta bit layout
+constexpr uint32_t M_STATUS = 0x7u;        // Status, mod.rs:168-174
+constexpr uint32_t M_EXT = 1u << 3;        // Instance::external
+constexpr uint32_t M_LBK = 1u << 4;        // leader_bk is Some
+constexpr uint32_t M_LBKX = 1u << 5;       // leader_bk.{trigger,endprep}_slot / prepare_max_bal in side arrays (else 0)
+constexpr uint32_t M_RBK = 1u << 6;        // replica_bk is Some
+constexpr uint32_t M_RBKX = 1u << 7;       // replica_bk.{trigger,endprep}_slot in side arrays (else 0)
+constexpr int M_ACKS_SH = 8;               // leader_bk.accept_acks  (8 bits)
+constexpr int M_PACKS_SH = 16;             // leader_bk.prepare_acks (8 bits)
+constexpr int M_SRC_SH = 24;               // replica_bk.source      (3 bits)
+constexpr int M_VMODE_SH = 28;             // Instance::voted encoding (2 bits)
+constexpr uint32_t VM_NONE = 0;            // voted == (0, empty)
+constexpr uint32_t VM_SAME = 1;            // voted == (bal, reqs) as stored
+constexpr uint32_t VM_SIDE = 2;            // voted in s_vbal / s_vval
+
+// outbox entry kinds, stored in the top 2 bits of ob_slot
+constexpr uint32_t OB_PREPARE = 1, OB_ACCEPT = 2, OB_HEARTBEAT = 3;
+constexpr int OB_KIND_SH = 30;
+constexpr uint32_t OB_SLOT_MASK = (1u << 30) - 1;
+
+constexpr uint32_t NO_REP = 0xFFu;
+constexpr int MAXR = 8;
+
+struct MpRep {
+    // scalars [G]
+    uint8_t *leader;
+    uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
+    uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
+    uint32_t *null_lb;        // aux: no Null instance in [exec_bar, null_lb)
+    uint32_t *peer_exec_bar;  // [R][G]
+    // slot ring [W][G]
+    uint64_t *s_bal;
+    uint32_t *s_val;          // reqs token (0 = empty batch)
+    uint32_t *s_meta;
+    uint64_t *s_vbal; uint32_t *s_vval;
+    uint64_t *s_pmax;
+    uint32_t *s_ltrig, *s_lendp, *s_rtrig, *s_rendp;
+    // outbox [2][cap][G]
+    uint32_t *ob_cnt[2];
+    uint32_t *ob_slot[2];     // kind<<30 | slot   (HB: commit_bar)
+    uint64_t *ob_bal[2];
+    uint32_t *ob_val[2];      // Accept: reqs token; HB: exec_bar
+    uint32_t *ob_aux[2];      // HB: snap_bar
+    // replies to my Accepts [cap][R][G]
+    uint64_t *ack;
+    // my PrepareReply batch of this tick: header [G] + entries [pcap][G]
+    uint32_t *pr_cnt; uint8_t *pr_dest;
+    uint32_t *pr_trig, *pr_endp, *pr_abar; uint64_t *pr_bal;
+    uint64_t *pr_vbal; uint32_t *pr_vval;
+    // heartbeat record [G]
+    uint64_t *hb_bal; uint32_t *hb_commit, *hb_exec, *hb_snap;
+    // outputs
+    unsigned long long *counters;   // [0] commits [1] redirects [2] rejects
+    unsigned long long *clist;      // (group << 32) | slot
+    unsigned int *clist_n;
+};
+
+struct MpParams {
+    uint32_t G, W, Wmask, cap, pcap, win_reserve, clist_cap;
+    uint32_t R, quorum, thresh, rspaxos;
+    uint8_t *overflow;              // [G] sticky, shared by all replicas of a group
+    MpRep rep[MAXR];
+};
+
+}  // namespace smr

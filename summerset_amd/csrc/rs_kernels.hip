@@ -1,0 +1,422 @@
+// Reed-Solomon over GF(2^8) for gfx950: shard-matrix products
+//   out_shard[r][i] = XOR_c  M[r][c] * in_shard[c][i]      (GF(2^8), poly 0x11D)
+// used for encode (M = parity rows), reconstruct (M = rows of the inverted
+// sub-matrix, composed with parity rows) and verify.
+//
+// Stands in for reed_solomon_erasure::galois_8::ReedSolomon::{encode,
+// reconstruct, reconstruct_data, verify} as called by
+// src/utils/rscoding.rs:484,515-517,575, with RSCodeword::from_data's shard
+// geometry (rscoding.rs:165-220) fused into the address arithmetic: the data
+// shards are consecutive shard_len-byte slices of the serialized bytes and the
+// zero padding is synthesised, never materialised.
+//
+// HBM-bound byte work (no MFMA).  One lane owns 16 consecutive byte columns of
+// one codeword: d 16-byte loads, p 16-byte stores, so a wave moves 1 KiB per
+// memory instruction.  Two arithmetic back ends:
+//   * xtime : bit-sliced multiply-by-2 on 4 packed bytes per VGPR; the matrix
+//             coefficients are wave-uniform kernel arguments, so the per-bit
+//             "accumulate?" branches are scalar branches;
+//   * lut   : 256-entry product tables per coefficient, resident in LDS.
+#include "smr_common.h"
+
+namespace smr {
+
+constexpr int RS_MAX_IN = 16;   // d  (data / present shards)
+constexpr int RS_MAX_OUT = 8;   // p  (or number of shards to rebuild)
+
+struct RsArgs {
+    const uint8_t *in_base;
+    uint8_t *out_base;
+    uint64_t in_cw_stride, out_cw_stride;
+    uint64_t in_off[RS_MAX_IN];    // byte offset of input shard c inside a codeword
+    uint64_t out_off[RS_MAX_OUT];  // byte offset of output shard r inside a codeword
+    uint64_t in_valid;             // bytes of a codeword's input that exist (beyond: zero)
+    uint64_t shard_len;
+    uint64_t n_cw;
+    uint32_t nblk;                 // ceil(shard_len / 16)
+    int n_in, n_out;
+    uint8_t coef[RS_MAX_OUT][RS_MAX_IN];
+    uint8_t colmask[RS_MAX_IN];    // OR over r of coef[r][c]
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// multiply 4 packed GF(2^8) bytes by 2 (poly 0x11D), no cross-byte carries
+__device__ __forceinline__ uint32_t gf_xtime4(uint32_t x) {
+    uint32_t hi = x & 0x80808080u;
+    uint32_t lo = (x << 1) & 0xFEFEFEFEu;
+    // per byte: 0x80 -> 0x7F -> & 0x1D ; 0 -> 0
+    return lo ^ ((hi - (hi >> 7)) & 0x1D1D1D1Du);
+}
+
+__device__ __forceinline__ u32x4 load16(const uint8_t *p) {
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);   // align-1 global load: one dwordx4 on gfx950
+    return v;
+}
+__device__ __forceinline__ void store16(uint8_t *p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
+
+// Load 16 byte-columns of input shard c; bytes at codeword offset >= in_valid
+// are zero (fused from_data padding, rscoding.rs:188-189) and never read.
+__device__ __forceinline__ u32x4 load_cols(const RsArgs &a, const uint8_t *cw, int c, uint64_t c0) {
+    uint64_t o = a.in_off[c] + c0;
+    if (o + 16 <= a.in_valid) return load16(cw + o);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    uint8_t tmp[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) tmp[i] = (o + i < a.in_valid) ? cw[o + i] : (uint8_t)0;
+    __builtin_memcpy(&v, tmp, 16);
+    return v;
+}
+
+__device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, uint64_t c0, u32x4 v) {
+    uint8_t *p = cw + a.out_off[r] + c0;
+    if (c0 + 16 <= a.shard_len) { store16(p, v); return; }
+    uint8_t tmp[16];
+    __builtin_memcpy(tmp, &v, 16);
+    for (uint64_t i = 0; c0 + i < a.shard_len; i++) p[i] = tmp[i];
+}
+
+template <int NOUT>
+__global__ __launch_bounds__(256) void rs_matmul_xtime(const RsArgs a) {
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t cw_i = t / a.nblk;
+    if (cw_i >= a.n_cw) return;
+    uint64_t c0 = (t - cw_i * a.nblk) * 16;
+    const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
+    u32x4 acc[NOUT];
+#pragma unroll
+    for (int r = 0; r < NOUT; r++) acc[r] = (u32x4){0u, 0u, 0u, 0u};
+    for (int c = 0; c < a.n_in; c++) {
+        u32x4 x = load_cols(a, cw, c, c0);
+        uint32_t m = a.colmask[c];          // wave-uniform
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if ((m >> b) == 0) break;       // no higher coefficient bits left
+#pragma unroll
+            for (int r = 0; r < NOUT; r++)
+                if ((a.coef[r][c] >> b) & 1) acc[r] ^= x;   // scalar branch
+            x.x = gf_xtime4(x.x); x.y = gf_xtime4(x.y);
+            x.z = gf_xtime4(x.z); x.w = gf_xtime4(x.w);
+        }
+    }
+    uint8_t *ocw = a.out_base + cw_i * a.out_cw_stride;
+#pragma unroll
+    for (int r = 0; r < NOUT; r++)
+        if (r < a.n_out) store_cols(a, ocw, r, c0, acc[r]);
+}
+
+// LDS product-table variant: tab[(r * n_in + c) * 256 + v] = coef[r][c] * v
+template <int NOUT>
+__global__ __launch_bounds__(256) void rs_matmul_lut(const RsArgs a, const uint8_t *__restrict__ tabs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tab[];
+    const int ntab = a.n_out * a.n_in * 256;
+    for (int i = threadIdx.x * 16; i < ntab; i += 256 * 16)
+        *reinterpret_cast<u32x4 *>(lds_tab + i) = *reinterpret_cast<const u32x4 *>(tabs + i);
+    __syncthreads();
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t cw_i = t / a.nblk;
+    if (cw_i >= a.n_cw) return;
+    uint64_t c0 = (t - cw_i * a.nblk) * 16;
+    const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
+    u32x4 acc[NOUT];
+#pragma unroll
+    for (int r = 0; r < NOUT; r++) acc[r] = (u32x4){0u, 0u, 0u, 0u};
+    for (int c = 0; c < a.n_in; c++) {
+        u32x4 x = load_cols(a, cw, c, c0);
+#pragma unroll
+        for (int r = 0; r < NOUT; r++) {
+            if (r >= a.n_out) break;
+            const uint8_t *tb = lds_tab + (r * a.n_in + c) * 256;
+            uint32_t w[4] = {x.x, x.y, x.z, x.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                o[k] = (uint32_t)tb[w[k] & 0xFF] | ((uint32_t)tb[(w[k] >> 8) & 0xFF] << 8) |
+                       ((uint32_t)tb[(w[k] >> 16) & 0xFF] << 16) | ((uint32_t)tb[w[k] >> 24] << 24);
+            acc[r].x ^= o[0]; acc[r].y ^= o[1]; acc[r].z ^= o[2]; acc[r].w ^= o[3];
+        }
+    }
+    uint8_t *ocw = a.out_base + cw_i * a.out_cw_stride;
+#pragma unroll
+    for (int r = 0; r < NOUT; r++)
+        if (r < a.n_out) store_cols(a, ocw, r, c0, acc[r]);
+}
+
+// verify: recompute the n_out shards and compare with what is stored at out_off
+template <int NOUT>
+__global__ __launch_bounds__(256) void rs_verify_xtime(const RsArgs a, uint8_t *ok) {
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint64_t cw_i = t / a.nblk;
+    if (cw_i >= a.n_cw) return;
+    uint64_t c0 = (t - cw_i * a.nblk) * 16;
+    const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
+    u32x4 acc[NOUT];
+#pragma unroll
+    for (int r = 0; r < NOUT; r++) acc[r] = (u32x4){0u, 0u, 0u, 0u};
+    for (int c = 0; c < a.n_in; c++) {
+        u32x4 x = load_cols(a, cw, c, c0);
+        uint32_t m = a.colmask[c];
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if ((m >> b) == 0) break;
+#pragma unroll
+            for (int r = 0; r < NOUT; r++)
+                if ((a.coef[r][c] >> b) & 1) acc[r] ^= x;
+            x.x = gf_xtime4(x.x); x.y = gf_xtime4(x.y);
+            x.z = gf_xtime4(x.z); x.w = gf_xtime4(x.w);
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < NOUT; r++) {
+        if (r >= a.n_out) break;
+        const uint8_t *p = a.out_base + cw_i * a.out_cw_stride + a.out_off[r] + c0;
+        uint8_t tmp[16];
+        __builtin_memcpy(tmp, &acc[r], 16);
+        for (uint64_t i = 0; i < 16 && c0 + i < a.shard_len; i++) bad |= (p[i] != tmp[i]);
+    }
+    if (bad) ok[cw_i] = 0;
+}
+
+// ------------------------------------------------------------------ host ---
+// GF(2^8) helpers for building coding / inversion matrices (tiny, host side).
+struct Gf {
+    uint8_t exp[512], log[256];
+    Gf() {
+        int x = 1;
+        for (int i = 0; i < 255; i++) {
+            exp[i] = (uint8_t)x; log[x] = (uint8_t)i;
+            x <<= 1; if (x & 0x100) x ^= 0x11D;
+        }
+        for (int i = 255; i < 512; i++) exp[i] = exp[i - 255];
+        log[0] = 0;
+    }
+    uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+    uint8_t div(uint8_t a, uint8_t b) const { return a ? exp[(log[a] + 255 - log[b]) % 255] : 0; }
+    uint8_t pow(uint8_t a, int n) const {
+        if (n == 0) return 1;
+        if (a == 0) return 0;
+        return exp[(log[a] * n) % 255];
+    }
+};
+static const Gf &gf() { static Gf g; return g; }
+
+// in-place Gauss-Jordan inverse of an n x n matrix (row major); false if singular
+static bool gf_invert(uint8_t *m, int n) {
+    const Gf &g = gf();
+    uint8_t aug[RS_MAX_IN][2 * RS_MAX_IN] = {};
+    for (int r = 0; r < n; r++) {
+        for (int c = 0; c < n; c++) aug[r][c] = m[r * n + c];
+        aug[r][n + r] = 1;
+    }
+    for (int c = 0; c < n; c++) {
+        int piv = -1;
+        for (int r = c; r < n; r++) if (aug[r][c]) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != c) for (int k = 0; k < 2 * n; k++) { uint8_t t = aug[c][k]; aug[c][k] = aug[piv][k]; aug[piv][k] = t; }
+        uint8_t d = aug[c][c];
+        for (int k = 0; k < 2 * n; k++) aug[c][k] = g.div(aug[c][k], d);
+        for (int r = 0; r < n; r++) {
+            if (r == c || !aug[r][c]) continue;
+            uint8_t f = aug[r][c];
+            for (int k = 0; k < 2 * n; k++) aug[r][k] ^= g.mul(f, aug[c][k]);
+        }
+    }
+    for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) m[r * n + c] = aug[r][n + c];
+    return true;
+}
+
+// (d+p) x d systematic coding matrix: Vandermonde(r^c) * inverse(top d x d)
+static bool rs_build_matrix(int d, int p, uint8_t *out) {
+    if (d <= 0 || d > RS_MAX_IN || p < 0 || d + p > 256) return false;
+    const Gf &g = gf();
+    int t = d + p;
+    std::string vbuf((size_t)t * d, '\0');
+    uint8_t *v = reinterpret_cast<uint8_t *>(&vbuf[0]);
+    for (int r = 0; r < t; r++) for (int c = 0; c < d; c++) v[r * d + c] = g.pow((uint8_t)r, c);
+    uint8_t top[RS_MAX_IN * RS_MAX_IN];
+    for (int i = 0; i < d * d; i++) top[i] = v[i];
+    if (!gf_invert(top, d)) return false;
+    for (int r = 0; r < t; r++)
+        for (int c = 0; c < d; c++) {
+            uint8_t acc = 0;
+            for (int k = 0; k < d; k++) acc ^= g.mul(v[r * d + k], top[k * d + c]);
+            out[r * d + c] = acc;
+        }
+    return true;
+}
+
+static void rs_finish_args(RsArgs &a) {
+    a.nblk = (uint32_t)((a.shard_len + 15) / 16);
+    for (int c = 0; c < RS_MAX_IN; c++) {
+        uint8_t m = 0;
+        for (int r = 0; r < a.n_out; r++) m |= a.coef[r][c];
+        a.colmask[c] = (c < a.n_in) ? m : 0;
+    }
+}
+
+static uint8_t *g_lut_dev = nullptr;     // scratch for LUT variant tables
+static size_t g_lut_cap = 0;
+
+template <bool LUT>
+static int rs_launch(RsArgs &a, hipStream_t st) {
+    rs_finish_args(a);
+    uint64_t threads = a.n_cw * a.nblk;
+    if (threads == 0) return SMR_OK;
+    uint64_t blocks = (threads + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return fail(SMR_ERR_ARG, "rs: too many codewords for one launch");
+    dim3 grid((unsigned)blocks), block(256);
+    if (LUT) {
+        const Gf &g = gf();
+        size_t ntab = (size_t)a.n_out * a.n_in * 256;
+        std::string tb(ntab, '\0');
+        for (int r = 0; r < a.n_out; r++)
+            for (int c = 0; c < a.n_in; c++)
+                for (int v = 0; v < 256; v++)
+                    tb[((size_t)r * a.n_in + c) * 256 + v] = (char)g.mul(a.coef[r][c], (uint8_t)v);
+        if (ntab > g_lut_cap) {
+            if (g_lut_dev) (void)hipFree(g_lut_dev);
+            SMR_HIP_TRY(hipMalloc((void **)&g_lut_dev, ntab));
+            g_lut_cap = ntab;
+        }
+        SMR_HIP_TRY(hipMemcpyAsync(g_lut_dev, tb.data(), ntab, hipMemcpyHostToDevice, st));
+        SMR_HIP_TRY(hipStreamSynchronize(st));   // tb is a host temporary
+        if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_lut<2>, grid, block, ntab, st, a, g_lut_dev);
+        else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_lut<4>, grid, block, ntab, st, a, g_lut_dev);
+        else hipLaunchKernelGGL(rs_matmul_lut<8>, grid, block, ntab, st, a, g_lut_dev);
+    } else {
+        if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_xtime<2>, grid, block, 0, st, a);
+        else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_xtime<4>, grid, block, 0, st, a);
+        else hipLaunchKernelGGL(rs_matmul_xtime<8>, grid, block, 0, st, a);
+    }
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+template <bool LUT>
+static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,
+                          int p, uint8_t *parity, uint64_t par_stride, uint64_t par_shard_stride, void *stream) {
+    if (d <= 0) return fail(SMR_ERR_ARG, "num_data_shards is zero");          // rscoding.rs:172-174
+    if (data_len == 0) return fail(SMR_ERR_ARG, "codeword is null");          // rscoding.rs:451-453
+    if (p == 0) return SMR_OK;                                                 // rscoding.rs:454-456
+    if (d > RS_MAX_IN || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: scheme exceeds d<=16, p<=8");
+    if (!data || !parity) return fail(SMR_ERR_ARG, "rs: null buffer");
+    uint8_t m[(RS_MAX_IN + RS_MAX_OUT) * RS_MAX_IN];
+    if (!rs_build_matrix(d, p, m)) return fail(SMR_ERR_ARG, "rs: cannot build coding matrix");
+    RsArgs a = {};
+    a.in_base = data; a.out_base = parity;
+    a.in_cw_stride = cw_stride; a.out_cw_stride = par_stride;
+    a.shard_len = smr_rs_shard_len(data_len, d);
+    a.in_valid = data_len;
+    a.n_cw = n_cw; a.n_in = d; a.n_out = p;
+    if (par_shard_stride < a.shard_len) return fail(SMR_ERR_ARG, "rs: par_shard_stride < shard_len");
+    for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)c * a.shard_len;
+    for (int r = 0; r < p; r++) {
+        a.out_off[r] = (uint64_t)r * par_shard_stride;
+        for (int c = 0; c < d; c++) a.coef[r][c] = m[(d + r) * d + c];
+    }
+    return rs_launch<LUT>(a, (hipStream_t)stream);
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+extern "C" {
+
+int smr_rs_matrix(int d, int p, uint8_t *out_host) {
+    if (!out_host || !rs_build_matrix(d, p, out_host)) return fail(SMR_ERR_ARG, "rs: bad scheme");
+    return SMR_OK;
+}
+
+uint64_t smr_rs_shard_len(uint64_t data_len, int d) {
+    if (d <= 0) return 0;
+    return (data_len % (uint64_t)d == 0) ? data_len / d : data_len / d + 1;
+}
+
+int smr_rs_encode(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d, int p,
+                  uint8_t *parity_dev, uint64_t par_stride, uint64_t par_shard_stride, void *stream) {
+    return rs_encode_impl<false>(data_dev, data_len, cw_stride, n_cw, d, p, parity_dev, par_stride,
+                                 par_shard_stride, stream);
+}
+
+int smr_rs_encode_lut(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,
+                      int p, uint8_t *parity_dev, uint64_t par_stride, uint64_t par_shard_stride,
+                      void *stream) {
+    return rs_encode_impl<true>(data_dev, data_len, cw_stride, n_cw, d, p, parity_dev, par_stride,
+                                par_shard_stride, stream);
+}
+
+int smr_rs_reconstruct(uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_stride, uint64_t cw_stride,
+                       uint64_t n_cw, int d, int p, uint32_t present_mask, int data_only, void *stream) {
+    if (d <= 0 || d > RS_MAX_IN || p < 0 || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: bad scheme");
+    if (shard_len == 0) return fail(SMR_ERR_ARG, "codeword is null");
+    int t = d + p, have = 0;
+    for (int k = 0; k < t; k++) have += (present_mask >> k) & 1;
+    if (have < d) return fail(SMR_ERR_ARG, "too few shards present");
+    if (have == t) return SMR_OK;
+    uint8_t m[(RS_MAX_IN + RS_MAX_OUT) * RS_MAX_IN];
+    if (!rs_build_matrix(d, p, m)) return fail(SMR_ERR_ARG, "rs: cannot build coding matrix");
+    // first d present shards -> sub-matrix -> inverse (upstream reconstruct)
+    int src[RS_MAX_IN]; uint8_t inv[RS_MAX_IN * RS_MAX_IN];
+    int n = 0;
+    for (int k = 0; k < t && n < d; k++)
+        if ((present_mask >> k) & 1) { for (int c = 0; c < d; c++) inv[n * d + c] = m[k * d + c]; src[n++] = k; }
+    if (!gf_invert(inv, d)) return fail(SMR_ERR_ARG, "rs: singular sub-matrix");
+    const Gf &g = gf();
+    RsArgs a = {};
+    a.in_base = shards_dev; a.out_base = shards_dev;
+    a.in_cw_stride = cw_stride; a.out_cw_stride = cw_stride;
+    a.shard_len = shard_len; a.in_valid = ~0ull >> 1; a.n_cw = n_cw; a.n_in = d;
+    for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)src[c] * shard_stride;
+    int n_out = 0;
+    for (int k = 0; k < t; k++) {
+        if ((present_mask >> k) & 1) continue;
+        if (k >= d && data_only) continue;
+        if (n_out == RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: too many missing shards");
+        a.out_off[n_out] = (uint64_t)k * shard_stride;
+        for (int c = 0; c < d; c++) {
+            if (k < d) a.coef[n_out][c] = inv[k * d + c];
+            else {  // parity row composed with the data-recovery matrix
+                uint8_t acc = 0;
+                for (int j = 0; j < d; j++) acc ^= g.mul(m[k * d + j], inv[j * d + c]);
+                a.coef[n_out][c] = acc;
+            }
+        }
+        n_out++;
+    }
+    a.n_out = n_out;
+    if (n_out == 0) return SMR_OK;
+    return rs_launch<false>(a, (hipStream_t)stream);
+}
+
+int smr_rs_verify(const uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_stride, uint64_t cw_stride,
+                  uint64_t n_cw, int d, int p, uint8_t *ok_dev, void *stream) {
+    if (d <= 0 || d > RS_MAX_IN || p < 0 || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: bad scheme");
+    if (shard_len == 0) return fail(SMR_ERR_ARG, "codeword is null");
+    hipStream_t st = (hipStream_t)stream;
+    SMR_HIP_TRY(hipMemsetAsync(ok_dev, 1, n_cw, st));
+    if (p == 0 || n_cw == 0) return SMR_OK;
+    uint8_t m[(RS_MAX_IN + RS_MAX_OUT) * RS_MAX_IN];
+    if (!rs_build_matrix(d, p, m)) return fail(SMR_ERR_ARG, "rs: cannot build coding matrix");
+    RsArgs a = {};
+    a.in_base = shards_dev; a.out_base = const_cast<uint8_t *>(shards_dev);
+    a.in_cw_stride = cw_stride; a.out_cw_stride = cw_stride;
+    a.shard_len = shard_len; a.in_valid = ~0ull >> 1; a.n_cw = n_cw; a.n_in = d; a.n_out = p;
+    for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)c * shard_stride;
+    for (int r = 0; r < p; r++) {
+        a.out_off[r] = (uint64_t)(d + r) * shard_stride;
+        for (int c = 0; c < d; c++) a.coef[r][c] = m[(d + r) * d + c];
+    }
+    rs_finish_args(a);
+    uint64_t blocks = (a.n_cw * a.nblk + 255) / 256;
+    dim3 grid((unsigned)blocks), block(256);
+    if (p <= 2) hipLaunchKernelGGL(rs_verify_xtime<2>, grid, block, 0, st, a, ok_dev);
+    else if (p <= 4) hipLaunchKernelGGL(rs_verify_xtime<4>, grid, block, 0, st, a, ok_dev);
+    else hipLaunchKernelGGL(rs_verify_xtime<8>, grid, block, 0, st, a, ok_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+}  // extern "C"

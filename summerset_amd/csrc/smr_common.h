@@ -1,0 +1,40 @@
+// Internal helpers shared by the translation units of libsummerset_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/summerset_hip.h"
+
+namespace smr {
+
+void set_error(const std::string &msg);
+
+inline int fail(int code, const std::string &msg) {
+    set_error(msg);
+    return code;
+}
+
+#define SMR_HIP_TRY(expr)                                                                 \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            return ::smr::fail(SMR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        }                                                                                 \
+    } while (0)
+
+// bump allocator over one hipMalloc'd arena: one allocation per engine object,
+// every array 256-byte aligned so wave-wide accesses start on a cache line.
+struct Arena {
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+    size_t reserve(size_t bytes) {
+        size_t off = (used + 255) & ~size_t(255);
+        used = off + bytes;
+        return off;
+    }
+    template <typename T> T *at(size_t off) const { return reinterpret_cast<T *>(base + off); }
+};
+
+}  // namespace smr

@@ -1,0 +1,126 @@
+"""Host-side handle of the batched MultiPaxos / RSPaxos cluster.
+
+Mirrors what `MultiPaxosReplica` (src/protocols/multipaxos/mod.rs:387-514) keeps
+and does, for G independent groups x R replicas stepped in lock-step (schedule
+LS-1).  Thin: every method is one C-ABI call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MpCfg, MpDumpBufs, MpGroupState, SummersetError, check
+
+_DUMP_T = {"leader": np.uint8, "bal_prep_sent": np.uint64, "bal_prepared": np.uint64, "bal_max_seen": np.uint64,
+           "s_bal": np.uint64, "s_status": np.uint8, "s_reqs": np.uint32, "s_vbal": np.uint64,
+           "s_vreqs": np.uint32, "s_flags": np.uint8, "s_acks": np.uint8, "s_packs": np.uint8,
+           "s_pmax": np.uint64, "s_ltrig": np.uint32, "s_lendp": np.uint32, "s_src": np.uint8,
+           "s_rtrig": np.uint32, "s_rendp": np.uint32, "overflow": np.uint8}
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class MultiPaxosCluster:
+    def __init__(self, n_groups, population=5, window=64, win_reserve=None, outbox_cap=None, commit_extra=0,
+                 commit_list_cap=0):
+        self.G, self.R, self.W = int(n_groups), int(population), int(window)
+        self.win_reserve = self.W // 4 if win_reserve is None else int(win_reserve)
+        self.cap = self.W + 4 if outbox_cap is None else int(outbox_cap)
+        cfg = MpCfg(self.G, self.R, commit_extra, 0, 0, self.W, self.win_reserve, self.cap, commit_list_cap)
+        h = C.c_void_p()
+        self._L = _lib.load()
+        check(self._L.smr_mp_cluster_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.commit_list_cap = commit_list_cap
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_mp_cluster_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            import torch
+            return torch.cuda.current_stream().cuda_stream
+        return int(stream)
+
+    def preset_leader(self, rep=0):
+        check(self._L.smr_mp_preset_leader(self._h, rep))
+
+    def tick(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None, ackctl=None,
+             heartbeat=False, stream=None):
+        """One lock-step tick; arguments are device tensors (uint8 / uint32), see smr_mp_tick."""
+        S = 0 if req_val is None else int(req_val.shape[0])
+        check(self._L.smr_mp_tick(self._h, _ptr(timeout_rep), _ptr(timeout_src), _ptr(req_target), _ptr(req_cnt),
+                                  _ptr(req_val), S, _ptr(ackctl), int(heartbeat), self._stream(stream)))
+
+    # the four rounds individually (multi-GPU driver / hosts with real I/O)
+    def round_local(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None,
+                    stream=None):
+        S = 0 if req_val is None else int(req_val.shape[0])
+        check(self._L.smr_mp_round_local(self._h, _ptr(timeout_rep), _ptr(timeout_src), _ptr(req_target),
+                                         _ptr(req_cnt), _ptr(req_val), S, self._stream(stream)))
+
+    def round_deliver(self, stream=None):
+        check(self._L.smr_mp_round_deliver(self._h, self._stream(stream)))
+
+    def round_replies(self, ackctl=None, publish_heartbeat=False, stream=None):
+        check(self._L.smr_mp_round_replies(self._h, _ptr(ackctl), int(publish_heartbeat), self._stream(stream)))
+
+    def round_heartbeat(self, stream=None):
+        check(self._L.smr_mp_round_heartbeat(self._h, self._stream(stream)))
+
+    def end_tick(self):
+        check(self._L.smr_mp_end_tick(self._h))
+
+    def ack_matrix_ptr(self, rep):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(self._L.smr_mp_ack_matrix(self._h, rep, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_group_state(self, group, rep):
+        st = MpGroupState()
+        check(self._L.smr_mp_read_group_state(self._h, group, rep, C.byref(st)))
+        return st
+
+    def dump(self, rep):
+        """Canonical per-replica state as host numpy arrays (same shape as the oracle's dump)."""
+        G, W, R = self.G, self.W, self.R
+        out, bufs = {}, MpDumpBufs()
+        for name in _lib.MP_DUMP_FIELDS:
+            t = _DUMP_T.get(name, np.uint32)
+            shape = (R, G) if name == "peer_exec_bar" else ((W, G) if name.startswith("s_") else (G,))
+            out[name] = np.zeros(shape, t)
+            setattr(bufs, name, out[name].ctypes.data_as(C.c_void_p))
+        check(self._L.smr_mp_dump(self._h, rep, C.byref(bufs)))
+        return out
+
+    def counters(self, rep):
+        arr = (C.c_uint64 * 3)()
+        check(self._L.smr_mp_counters(self._h, rep, C.byref(arr)))
+        return {"commits": int(arr[0]), "redirects": int(arr[1]), "rejects": int(arr[2])}
+
+    def poll_commits(self, rep, cap=None):
+        cap = self.commit_list_cap if cap is None else cap
+        g = np.zeros(cap, np.uint32)
+        s = np.zeros(cap, np.uint32)
+        n = C.c_uint64()
+        check(self._L.smr_mp_poll_commits(self._h, rep, g.ctypes.data_as(C.c_void_p),
+                                          s.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        if n.value > cap:
+            raise SummersetError(_lib.SMR_ERR_STATE, "commit list overflowed: %d > %d" % (n.value, cap))
+        return g[:n.value].copy(), s[:n.value].copy()
+
+    def profile_enable(self, on=True):
+        check(self._L.smr_mp_profile_enable(self._h, int(on)))
+
+    def profile_read(self, which):
+        ms, n = C.c_double(), C.c_uint64()
+        check(self._L.smr_mp_profile_read(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,171 @@
+"""Batched mirror of the reference's `RSCodeword<T>` (src/utils/rscoding.rs).
+
+One `RSCodewordBatch` holds n codewords of identical geometry in ONE device
+buffer `buf[n, cw_stride]`: bytes [0, data_len) of a row are the serialized
+value (what `bincode::encode_into_std_write` produced in `from_data`,
+rscoding.rs:223-243), shard k is bytes [k*shard_len, (k+1)*shard_len), the d
+data shards are followed by the p parity shards.  The zero padding of
+`internal_new` (rscoding.rs:188-189) is fused into the encode kernel.  Method
+names, argument meaning and error behaviour follow the reference; every
+compute call goes to the HIP kernels behind include/summerset_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SummersetError, check
+
+
+def rs_matrix(d, p):
+    """(d+p) x d coding matrix (host numpy) -- ReedSolomon::new(d, p)."""
+    m = np.zeros((d + p, d), np.uint8)
+    check(_lib.load().smr_rs_matrix(d, p, m.ctypes.data_as(C.c_void_p)))
+    return m
+
+
+def rs_shard_len(data_len, d):
+    """shard_len rule of internal_new (rscoding.rs:177-181)."""
+    if d == 0:
+        raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards is zero")
+    return int(_lib.load().smr_rs_shard_len(data_len, d))
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return int(stream)
+
+
+class RSCodewordBatch:
+    """n RSCodewords sharing (d, p, data_len); see module docstring."""
+
+    def __init__(self, n, data_len, num_data_shards, num_parity_shards, device="cuda"):
+        import torch
+        if num_data_shards == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards is zero")
+        self.n = int(n)
+        self.d = int(num_data_shards)
+        self.p = int(num_parity_shards)
+        self.data_len = int(data_len)
+        self.shard_len = rs_shard_len(self.data_len, self.d) if self.data_len else 0
+        total = (self.d + self.p) * self.shard_len
+        self.cw_stride = (total + 15) // 16 * 16
+        self.buf = torch.zeros((self.n, max(self.cw_stride, 16)), dtype=torch.uint8, device=device)
+        self.avail = 0  # bitmap of available shard indexes (avail_shards_map)
+
+    # -- constructors ------------------------------------------------------
+    @classmethod
+    def from_data(cls, data, num_data_shards, num_parity_shards):
+        """`data`: uint8 tensor [n, data_len] of serialized bytes (device)."""
+        cw = cls(data.shape[0], data.shape[1], num_data_shards, num_parity_shards, device=data.device)
+        cw.buf[:, :cw.data_len].copy_(data)
+        cw.avail = (1 << cw.d) - 1
+        return cw
+
+    @classmethod
+    def from_null(cls, n, num_data_shards, num_parity_shards, device="cuda"):
+        return cls(n, 0, num_data_shards, num_parity_shards, device=device)
+
+    # -- accessors (rscoding.rs:343-434) -------------------------------------
+    def num_data_shards(self):
+        return self.d
+
+    def num_parity_shards(self):
+        return self.p
+
+    def num_shards(self):
+        return self.d + self.p
+
+    def avail_shards_map(self):
+        return [bool((self.avail >> k) & 1) for k in range(self.d + self.p)]
+
+    def avail_data_shards(self):
+        return bin(self.avail & ((1 << self.d) - 1)).count("1")
+
+    def avail_parity_shards(self):
+        return bin(self.avail >> self.d).count("1")
+
+    def avail_shards(self):
+        return bin(self.avail).count("1")
+
+    def shard(self, k):
+        """view [n, shard_len] of shard k"""
+        return self.buf[:, k * self.shard_len:(k + 1) * self.shard_len]
+
+    def erase(self, idxs):
+        """drop shards (test helper: `cw.shards[i] = None`)"""
+        for k in idxs:
+            self.avail &= ~(1 << k)
+            self.shard(k).fill_(0xEE)
+
+    # -- compute -------------------------------------------------------------
+    def compute_parity(self, rs=True, stream=None, lut=False):
+        """rscoding.rs:447-486.  `rs` stands for the `Option<&ReedSolomon>` coder."""
+        if self.data_len == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if self.p == 0:
+            return
+        if not rs:
+            raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon coder is None")
+        if self.avail_data_shards() < self.d:
+            raise SummersetError(_lib.SMR_ERR_ARG, "not all data shards present: %d / %d"
+                                 % (self.avail_data_shards(), self.d))
+        L = _lib.load()
+        fn = L.smr_rs_encode_lut if lut else L.smr_rs_encode
+        base = self.buf.data_ptr()
+        check(fn(base, self.data_len, self.cw_stride, self.n, self.d, self.p,
+                 base + self.d * self.shard_len, self.cw_stride, self.shard_len, _stream_ptr(stream)))
+        self.avail |= ((1 << self.p) - 1) << self.d
+
+    def _reconstruct(self, rs, data_only, stream):
+        if self.data_len == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if self.p == 0:
+            if self.avail_data_shards() == self.d:
+                return
+            raise SummersetError(_lib.SMR_ERR_ARG, "insufficient data shards: %d / %d"
+                                 % (self.avail_data_shards(), self.d))
+        if not rs:
+            raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon coder is None")
+        check(_lib.load().smr_rs_reconstruct(self.buf.data_ptr(), self.shard_len, self.shard_len,
+                                             self.cw_stride, self.n, self.d, self.p, self.avail,
+                                             int(data_only), _stream_ptr(stream)))
+        self.avail |= (1 << self.d) - 1
+        if not data_only:
+            self.avail |= ((1 << self.p) - 1) << self.d
+
+    def reconstruct_all(self, rs=True, stream=None):
+        self._reconstruct(rs, False, stream)
+
+    def reconstruct_data(self, rs=True, stream=None):
+        self._reconstruct(rs, True, stream)
+
+    def verify_parity(self, rs=True, stream=None):
+        """rscoding.rs:541-577 -> bool tensor [n]"""
+        import torch
+        if self.data_len == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if self.p == 0:
+            if self.avail_data_shards() == self.d:
+                return torch.ones(self.n, dtype=torch.bool, device=self.buf.device)
+            raise SummersetError(_lib.SMR_ERR_ARG, "not all shards present")
+        if not rs:
+            raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon is None")
+        if self.avail_shards() < self.d + self.p:
+            raise SummersetError(_lib.SMR_ERR_ARG, "not all shards present: %d / %d"
+                                 % (self.avail_shards(), self.d + self.p))
+        ok = torch.empty(self.n, dtype=torch.uint8, device=self.buf.device)
+        check(_lib.load().smr_rs_verify(self.buf.data_ptr(), self.shard_len, self.shard_len, self.cw_stride,
+                                        self.n, self.d, self.p, ok.data_ptr(), _stream_ptr(stream)))
+        return ok.bool()
+
+    def get_data(self):
+        """rscoding.rs:583-609: the serialized bytes, all data shards required."""
+        if self.data_len == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if self.avail_data_shards() < self.d:
+            raise SummersetError(_lib.SMR_ERR_ARG, "not all data shards present: %d / %d"
+                                 % (self.avail_data_shards(), self.d))
+        return self.buf[:, :self.data_len]

@@ -1,0 +1,138 @@
+"""Pins the CPU RS oracle (oracle/rs_oracle.c): upstream-family known answers,
+the reference's own structural tests (src/utils/rscoding.rs:697-876), and the
+committed golden vectors.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "rs_golden.npz")
+
+
+def test_galois_known_answers(oracle):
+    # Backblaze JavaReedSolomon GaloisTest / klauspost galois_test / reed-solomon-erasure galois_8 tests
+    assert oracle.gf_mul(3, 4) == 12
+    assert oracle.gf_mul(7, 7) == 21
+    assert oracle.gf_mul(23, 45) == 41
+    assert oracle.gf_exp(2, 2) == 4
+    assert oracle.gf_exp(5, 20) == 235
+    assert oracle.gf_exp(13, 7) == 43
+    exp = np.zeros(256, np.uint8)
+    log = np.zeros(256, np.uint8)
+    oracle.lib().orc_gf_tables(exp.ctypes.data, log.ctypes.data)
+    assert list(exp[:10]) == [1, 2, 4, 8, 16, 32, 64, 128, 29, 58]        # poly 0x11D, generator 2
+    assert (log[2], log[3], log[4], log[5]) == (1, 25, 2, 50)
+
+
+def test_field_axioms(oracle):
+    rng = np.random.default_rng(1)
+    for a, b, c in rng.integers(0, 256, (200, 3)):
+        a, b, c = int(a), int(b), int(c)
+        assert oracle.gf_mul(a, b) == oracle.gf_mul(b, a)
+        assert oracle.gf_mul(a, oracle.gf_mul(b, c)) == oracle.gf_mul(oracle.gf_mul(a, b), c)
+        assert oracle.gf_mul(a, b ^ c) == oracle.gf_mul(a, b) ^ oracle.gf_mul(a, c)
+    for a in range(1, 256):
+        assert oracle.gf_mul(a, 1) == a and oracle.gf_mul(a, 0) == 0
+        inv = oracle.lib().orc_gf_div(1, a)
+        assert oracle.gf_mul(a, inv) == 1
+
+
+def test_one_encode_known_answer(oracle):
+    # upstream "one encode" vector: 5+5 code, 2-byte shards
+    data = np.array([[0, 1], [4, 5], [2, 3], [6, 7], [8, 9]], np.uint8)
+    m = oracle.rs_matrix(5, 5)
+    assert np.array_equal(m[:5], np.eye(5, dtype=np.uint8))               # systematic
+    par = np.zeros((5, 2), np.uint8)
+    for k in range(5):
+        for i in range(2):
+            acc = 0
+            for c in range(5):
+                acc ^= oracle.gf_mul(int(m[5 + k, c]), int(data[c, i]))
+            par[k, i] = acc
+    assert par.tolist() == [[12, 13], [10, 11], [14, 15], [90, 91], [94, 95]]
+    # same through the encode entry point (shards are consecutive slices of the buffer)
+    assert np.array_equal(oracle.rs_encode(5, 5, data.reshape(-1)), par)
+
+
+def test_rs32_rows(oracle):
+    assert oracle.rs_matrix(3, 2).tolist() == [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [15, 8, 6]]
+
+
+def test_shard_len_rule_and_errors(oracle):
+    # rscoding.rs:177-181 and the from_data / compute_parity error cases (:697-812)
+    assert oracle.rs_shard_len(18, 3) == 6 and oracle.rs_shard_len(19, 3) == 7 and oracle.rs_shard_len(1, 3) == 1
+    with pytest.raises(ValueError):
+        oracle.rs_encode(0, 0, np.ones(4, np.uint8))         # num_data_shards is zero
+    with pytest.raises(ValueError):
+        oracle.rs_encode(3, 2, np.zeros(0, np.uint8))         # codeword is null
+    assert oracle.rs_encode(3, 0, np.ones(4, np.uint8)).shape == (0, 2)   # p == 0 is fine
+
+
+def test_bincode_layouts(oracle):
+    s = oracle.bincode_string(b"interesting_value")
+    assert s[0] == 17 and bytes(s[1:]) == b"interesting_value"
+    big = oracle.bincode_string(b"x" * 4096)
+    assert len(big) == 4099 and list(big[:3]) == [0xFB, 0x00, 0x10]
+    rb = oracle.bincode_reqbatch_put(7, 300, b"k0000003", b"v" * 4096)
+    assert list(rb[:2]) == [1, 7] and rb[2] == 0 and list(rb[3:6]) == [0xFB, 0x2C, 0x01] and rb[6] == 1
+    # 1 (vec len) + 1 (client) + 1 (Req) + 3 (id 300) + 1 (Put) + 1 + 8 (key) + 3 + 4096 (value)
+    assert len(rb) == 4111 + 1 + 3
+
+
+def _split(ser, d, p, par):
+    sl = par.shape[1]
+    buf = np.zeros((d + p, sl), np.uint8)
+    flat = np.zeros(d * sl, np.uint8)
+    flat[:ser.size] = ser
+    buf[:d] = flat.reshape(d, sl)
+    buf[d:] = par
+    return buf
+
+
+def test_reference_round_trips(oracle):
+    # rscoding.rs:788-876: compute -> verify; erase <= 2 -> reconstruct -> data back; 3 erased -> error
+    ser = oracle.bincode_string(b"interesting_value")
+    par = oracle.rs_encode(3, 2, ser)
+    full = _split(ser, 3, 2, par)
+    assert oracle.rs_verify(3, 2, full)
+    bad = full.copy(); bad[4, 0] ^= 1
+    assert not oracle.rs_verify(3, 2, bad)
+    import itertools
+    for k in (1, 2):
+        for lost in itertools.combinations(range(5), k):
+            sh = full.copy()
+            pres = np.ones(5, bool)
+            for i in lost:
+                sh[i] = 0xEE; pres[i] = False
+            out, pres2 = oracle.rs_reconstruct(3, 2, sh, pres)
+            assert pres2.all() and np.array_equal(out, full), lost
+            sh2 = full.copy()
+            for i in lost:
+                sh2[i] = 0xEE
+            out2, pres3 = oracle.rs_reconstruct(3, 2, sh2, pres, data_only=True)
+            assert np.array_equal(out2[:3], full[:3]) and pres3[:3].all()
+    with pytest.raises(ValueError):
+        oracle.rs_reconstruct(3, 2, full.copy(), np.array([0, 0, 1, 1, 0], bool))
+
+
+def test_golden_vectors(oracle):
+    g = np.load(GOLD)
+    assert np.array_equal(g["matrix_3_2"], oracle.rs_matrix(3, 2))
+    assert np.array_equal(g["matrix_5_5"], oracle.rs_matrix(5, 5))
+    names = [k[:-5] for k in g.files if k.endswith("_data")]
+    assert len(names) >= 15
+    for n in names:
+        d, p = (3, 2)
+        if n.startswith("s"):
+            d, p = int(n[1:].split("_")[0]), int(n[1:].split("_")[1])
+        assert np.array_equal(oracle.rs_encode(d, p, g[n + "_data"]), g[n + "_parity"]), n
+    assert g["bench4k_data"].size == 4099 and g["bench4k_parity"].shape == (2, 1367)
+
+
+def test_batch_matches_single(oracle):
+    rng = np.random.default_rng(3)
+    L, n, stride = 100, 7, 128
+    data = rng.integers(0, 256, n * stride, dtype=np.uint8)
+    par = oracle.rs_encode_batch(3, 2, data, L, stride, n).reshape(n, 2, -1)
+    for i in range(n):
+        assert np.array_equal(par[i], oracle.rs_encode(3, 2, data[i * stride:i * stride + L]))
