@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- committed slots/sec of the batched MultiPaxos hot path on MI355X.
+
+One "step" = one lock-step tick (rounds R1..R4) over G replica
+groups x 5 replicas with S new client batches per group: leader append ->
+follower accept -> quorum tally + commit/exec bars -> (every H ticks) heartbeat.
+Inputs (batch tokens, reply order / loss words, timeout events) are resident in
+HBM before the timed region.  One process per GPU; groups shard across ranks
+with no data-path collective (weak scaling: G groups PER GPU).
+
+Prints ONE JSON line (rank 0).  `value` counts leader-side Accepting->Committed
+transitions (multipaxos/messages.rs:412-433) per second, whole job.
+Also reports, in the same line: the HBM roofline of the quorum kernel (R3), the
+CPU oracle timed on this host on a bounded sample (`cpu_baseline`), and the
+RS(3,2) encode rate of BASELINE config 4 (`rs_encode`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--groups", type=int, default=65536, help="replica groups per GPU")
+    ap.add_argument("--slots", type=int, default=32, help="S: new batches per group per tick")
+    ap.add_argument("--hb-every", type=int, default=4)
+    ap.add_argument("--window", type=int, default=512)
+    ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated tick inputs cycled in HBM")
+    ap.add_argument("--drop", type=float, default=0.1)
+    ap.add_argument("--timeouts", type=float, default=0.01)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
+    ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def rs_leg(torch, dev, run_cpu, cpu_seconds):
+    """BASELINE config 4: 16384 codewords, 4 KiB values -> bincode(String) L = 4099, RS(3,2)."""
+    from summerset_amd import RSCodewordBatch
+    n, L = 16384, 4099
+    data = torch.randint(0, 256, (n, L), dtype=torch.uint8, device=dev)
+    out = {}
+    for name, lut in (("xtime", False), ("lut", True)):
+        cw = RSCodewordBatch.from_data(data, 3, 2)
+        for _ in range(3):
+            cw.compute_parity(lut=lut)
+        torch.cuda.synchronize()
+        iters = 50
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            cw.compute_parity(lut=lut)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        alg = n * 5 * cw.shard_len                       # 5 * ceil(L/3) bytes per codeword
+        out[name] = {"ms_per_launch": ms, "payload_GiBps": n * L / 2**30 / (ms * 1e-3),
+                     "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String)",
+           "value": out["xtime"]["payload_GiBps"], "unit": "GiB/s payload",
+           "roofline": {"bound": "hbm", "achieved": out["xtime"]["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": out["xtime"]["frac"], "traffic": None},
+           "lut_variant_GiBps": out["lut"]["payload_GiBps"]}
+    if run_cpu:
+        from oracle import oracle as O
+        host = data[:2048].cpu().numpy().reshape(-1)
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < cpu_seconds / 3:
+            O.rs_encode_batch(3, 2, host, L, L, 2048)
+            done += 2048
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": done * L / 2**30 / dt, "unit": "GiB/s payload", "cores": 1, "kind": "port",
+                               "sample": "%d codewords of L=4099 through oracle/rs_oracle.c table encoder "
+                                         "(padding copy included)" % done}
+    return res
+
+
+def cpu_leg(args, seconds):
+    """The CPU oracle (literal restatement of the reference handlers) on a bounded sample of the
+    same workload: 1024 groups, same S / H / loss / timeout rates, single thread."""
+    from oracle import oracle as O
+    from summerset_amd import stream
+    G, R, S, W = 1024, 5, args.slots, args.window
+    cap = W + 4
+    m = O.MpOracle(G, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
+    m.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=64, drop_p=args.drop, timeout_frac=args.timeouts,
+                                 hb_every=args.hb_every, rand_rows=S + 4, max_drop=2)
+    pool = [st.tick(t) for t in range(8)]
+    spent, ticks, t = 0.0, 0, 0
+    while spent < seconds:
+        inp = dict(pool[t % 8])
+        live = st.tick_events(t)
+        inp.update(live)
+        t0 = time.perf_counter()
+        m.tick(**inp)
+        spent += time.perf_counter() - t0
+        ticks += 1
+        t += 1
+    commits = sum(m.total_commits(r) for r in range(R))
+    return {"value": commits / spent, "unit": "slots/s", "cores": 1, "kind": "port",
+            "sample": "%d ticks of %d groups x 5 replicas x S=%d (oracle/mp_oracle.c, one thread, %.1f s); the "
+                      "reference's Rust/tokio path cannot be built here (no cargo, no vendored crates)"
+                      % (ticks, G, S, spent)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from summerset_amd import MultiPaxosCluster, stream
+
+    G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
+    cap = W + 4
+    n_ticks = args.warmup + args.steps
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+    eng.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts,
+                                 hb_every=H, rand_rows=S + 4, seed=stream.DEFAULT_SEED + rank, max_drop=2)
+    # inputs resident in HBM before the clock starts
+    pool = []
+    for t in range(args.pool):
+        x = st.tick(t)
+        pool.append({k: torch.from_numpy(x[k]).to(dev) for k in ("req_cnt", "req_val", "ackctl")})
+    events = []
+    for t in range(n_ticks):
+        e = st.tick_events(t)
+        events.append({k: torch.from_numpy(v).to(dev) for k, v in e.items() if isinstance(v, np.ndarray)})
+
+    def step(t):
+        p, e = pool[t % args.pool], events[t]
+        eng.tick(timeout_rep=e["timeout_rep"], timeout_src=e["timeout_src"], req_target=e["req_target"],
+                 req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"], heartbeat=st.heartbeat(t))
+
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    c0 = sum(eng.counters(r)["commits"] for r in range(R))
+    eng.profile_enable(True)                      # HIP events around each round kernel, on the launch stream
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_ticks):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile_enable(False)
+    c1 = sum(eng.counters(r)["commits"] for r in range(R))
+    commits = c1 - c0
+    rej = sum(eng.counters(r)["rejects"] for r in range(R))
+    overflow = int(eng.dump(0)["overflow"].sum()) if G <= 4096 else None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        cc = torch.tensor([commits], dtype=torch.int64, device=dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        elapsed, commits = float(tt.item()), int(cc.item())
+    prof = {}
+    for i, name in enumerate(("R1_local", "R2_deliver", "R3_replies", "R4_heartbeat")):
+        ms, n = eng.profile_read(i)
+        prof[name] = {"avg_us": (ms / n * 1e3) if n else None, "launches": int(n)}
+    r3_ms = prof["R3_replies"]["avg_us"] / 1e3
+    alg_bytes = G * (52 * S + 33)                 # bytes per quorum-kernel launch
+    achieved = alg_bytes / (r3_ms * 1e-3) / 1e9
+    line = {
+        "metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, "
+                               "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout"
+                               % (G, S, H, args.drop * 100, args.timeouts * 100),
+                   "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "mp_round_replies",
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["R3_replies"]["avg_us"]},
+        "kernels": prof, "rejected_batches": rej, "overflow_groups": overflow,
+        "decisions_per_sec_quorum_kernel": G * S / (r3_ms * 1e-3),
+    }
+    if rank == 0:
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_leg(args, args.cpu_seconds)
+        if not args.no_rs:
+            line["rs_encode"] = rs_leg(torch, dev, not args.no_cpu, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,18 +42,18 @@ struct Lane {
     // values as loaded, for write-back of only what changed
     uint32_t o_leader; uint64_t o_bps, o_bpd, o_bms;
     uint32_t o_start, o_len, o_abar, o_cbar, o_ebar, o_snap, o_nlb;
-    uint32_t obn[2];               // outbox counts (both parities)
-    bool obn_loaded[2];
+    uint32_t obn0, obn1;           // outbox counts of parity 0 / 1 (scalars: a runtime-indexed
+    bool obl0, obl1;               // array would live in scratch memory)
     uint32_t n_commit, n_redirect, n_reject;
     bool ovf;
 
-    __device__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
+    __device__ __forceinline__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
         : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), ovf(false) {
-        obn_loaded[0] = obn_loaded[1] = false;
-        obn[0] = obn[1] = 0;
+        obl0 = obl1 = false;
+        obn0 = obn1 = 0;
     }
 
-    __device__ void load() {
+    __device__ __forceinline__ void load() {
         o_leader = leader = v.leader[g];
         o_bps = bps = v.bal_prep_sent[g];
         o_bpd = bpd = v.bal_prepared[g];
@@ -66,7 +66,7 @@ struct Lane {
         o_snap = snap = v.snap_bar[g];
         o_nlb = nlb = v.null_lb[g];
     }
-    __device__ void store() {
+    __device__ __forceinline__ void store() {
         if (leader != o_leader) v.leader[g] = (uint8_t)leader;
         if (bps != o_bps) v.bal_prep_sent[g] = bps;
         if (bpd != o_bpd) v.bal_prepared[g] = bpd;
@@ -78,8 +78,8 @@ struct Lane {
         if (ebar != o_ebar) v.exec_bar[g] = ebar;
         if (snap != o_snap) v.snap_bar[g] = snap;
         if (nlb != o_nlb) v.null_lb[g] = nlb;
-        for (int p = 0; p < 2; p++)
-            if (obn_loaded[p]) v.ob_cnt[p][g] = obn[p];
+        if (obl0) v.ob_cnt[0][g] = obn0;
+        if (obl1) v.ob_cnt[1][g] = obn1;
         if (ovf) P.overflow[g] = 1;
     }
 
@@ -92,7 +92,7 @@ struct Lane {
     }
 
     // Vec::push(null_instance()) (mod.rs:527-538) on the ring; false = window exhausted
-    __device__ bool push_null() {
+    __device__ __forceinline__ bool push_null() {
         if (len - start >= P.W) { ovf = true; return false; }
         size_t i = ix(len);
         v.s_meta[i] = 0; v.s_bal[i] = 0; v.s_val[i] = 0;
@@ -100,7 +100,7 @@ struct Lane {
         return true;
     }
     // pad with nulls until `slot` exists; records that Nulls may now sit at [old_len, slot)
-    __device__ bool pad_to(uint32_t slot) {
+    __device__ __forceinline__ bool pad_to(uint32_t slot) {
         if (len <= slot && len < nlb) nlb = len;
         while (len <= slot)
             if (!push_null()) return false;
@@ -123,24 +123,29 @@ struct Lane {
         else { vb = 0; vv = 0; }
     }
 
-    __device__ void ob_load(int p) {
-        if (!obn_loaded[p]) { obn[p] = v.ob_cnt[p][g]; obn_loaded[p] = true; }
+    __device__ __forceinline__ void ob_load(int p) {
+        if (p == 0) { if (!obl0) { obn0 = v.ob_cnt[0][g]; obl0 = true; } }
+        else { if (!obl1) { obn1 = v.ob_cnt[1][g]; obl1 = true; } }
+    }
+    __device__ __forceinline__ void ob_set(int p, uint32_t n) {
+        ob_load(p);
+        if (p == 0) obn0 = n; else obn1 = n;
     }
     // transport_hub.bcast_msg(): append to my outbox of parity p
-    __device__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
+    __device__ __forceinline__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
         ob_load(p);
-        uint32_t c = obn[p];
+        uint32_t c = p == 0 ? obn0 : obn1;
         if (c >= P.cap) { ovf = true; return; }
         size_t o = (size_t)c * P.G + g;
         v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
         v.ob_bal[p][o] = bal;
         v.ob_val[p][o] = val;
         if (kind == OB_HEARTBEAT) v.ob_aux[p][o] = aux;
-        obn[p] = c + 1;
+        if (p == 0) obn0 = c + 1; else obn1 = c + 1;
     }
 
     // committed-slot list: wave-aggregated append ((group<<32)|slot)
-    __device__ void record_commit(uint32_t slot) {
+    __device__ __forceinline__ void record_commit(uint32_t slot) {
         n_commit++;
         if (P.clist_cap == 0) return;
         unsigned long long mask = __ballot(1);
@@ -169,7 +174,7 @@ struct Lane {
 
     // durability.rs:148-218 handle_logged_commit_slot(slot), then the executor
     // results of what it submitted: execution.rs:56-79 handle_cmd_result.
-    __device__ void commit_complete(uint32_t slot) {
+    __device__ __forceinline__ void commit_complete(uint32_t slot) {
         if (slot < start || slot != cbar) return;
         const uint32_t c0 = cbar;
         while (cbar < abar) {                                   // durability.rs:162
@@ -194,7 +199,7 @@ struct Lane {
     }
 
     // messages.rs:370-443 handle_msg_accept_reply + its CommitSlot completion
-    __device__ void accept_reply(uint32_t peer, uint32_t slot, uint64_t ballot) {
+    __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t slot, uint64_t ballot) {
         if (slot < start) return;                               // :377-379
         if (ballot != bpd) return;                              // :388
         if (slot >= len) return;                                // debug_assert :389
@@ -216,14 +221,14 @@ struct Lane {
     }
 
     // durability.rs:85-145 handle_logged_accept_data, leader branch
-    __device__ void self_accept_logged(uint32_t slot) {
+    __device__ __forceinline__ void self_accept_logged(uint32_t slot) {
         size_t i = ix(slot);
         accept_reply(me, slot, v.s_bal[i]);                     // :99-103
         accept_bar_scan(slot);
     }
 
     // request.rs:112-224 handle_req_batch + durability.rs:85-107 (self ack)
-    __device__ void req_batch(uint32_t reqs) {
+    __device__ __forceinline__ void req_batch(uint32_t reqs) {
         if (!is_leader() || bpd == 0) { n_redirect++; return; }    // :128-154
         // mod.rs:541-549 first_null_slot, scanning only where a Null can be
         uint32_t slot = 0xFFFFFFFFu;
@@ -249,7 +254,7 @@ struct Lane {
 
     // messages.rs:87-292 handle_msg_prepare_reply (+ the AcceptData completions
     // of a reached quorum).  peer_accept_bar bookkeeping is lease-only.
-    __device__ void prepare_reply(uint32_t peer, uint32_t slot, uint32_t trig, uint32_t endp, uint64_t ballot,
+    __device__ __forceinline__ void prepare_reply(uint32_t peer, uint32_t slot, uint32_t trig, uint32_t endp, uint64_t ballot,
                                   bool has_voted, uint64_t vbal, uint32_t vval) {
         if (slot < start) return;                               // :97-99
         if (ballot != bps) return;                              // :110
@@ -309,7 +314,7 @@ struct Lane {
 
     // leadership.rs:73-214 become_a_leader + its PrepareBal completions
     // (durability.rs:10-49: the leader's own PrepareReply)
-    __device__ void become_a_leader(uint32_t src) {
+    __device__ __forceinline__ void become_a_leader(uint32_t src) {
         if (leader != NO_REP && leader != src) return;          // :77-81
         leader = me;                                            // :98
         // :104 bcast_heartbeats() now, still carrying the old bal_max_seen (:240-247)
@@ -359,7 +364,7 @@ struct Lane {
 
     // messages.rs:12-83 handle_msg_prepare + durability.rs:50-78 (PrepareReply
     // per slot, written as one batch: header + (voted_bal, voted_reqs) entries)
-    __device__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
+    __device__ __forceinline__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
         if (trig < start) return;                               // :18-20
         if (ballot < bms) return;                               // :29
         check_leader(peer, ballot);
@@ -397,7 +402,7 @@ struct Lane {
 
     // messages.rs:295-367 handle_msg_accept + durability.rs:85-145; returns the
     // AcceptReply ballot for the sender (0 = no reply)
-    __device__ uint64_t msg_accept(uint32_t peer, uint32_t slot, uint64_t ballot, uint32_t reqs) {
+    __device__ __forceinline__ uint64_t msg_accept(uint32_t peer, uint32_t slot, uint64_t ballot, uint32_t reqs) {
         if (slot < start) return 0;                             // :302-304
         if (ballot < bms) return 0;                             // :313
         check_leader(peer, ballot);
@@ -426,7 +431,7 @@ struct Lane {
     }
 
     // leadership.rs:270-346 heard_heartbeat + :372-427 advance_commit_bar
-    __device__ void heard_heartbeat(uint32_t peer, uint64_t ballot, uint32_t hb_commit, uint32_t hb_exec,
+    __device__ __forceinline__ void heard_heartbeat(uint32_t peer, uint64_t ballot, uint32_t hb_commit, uint32_t hb_exec,
                                     uint32_t hb_snap) {
         if (peer != me) check_leader(peer, ballot);             // :278-285
         if (ballot < bms) return;                               // :303-305

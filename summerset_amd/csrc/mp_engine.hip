@@ -143,8 +143,7 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
                     L.accept_reply(s, slot, a);
                 }
             }
-            L.ob_load(par);
-            L.obn[par] = 0;                                      // outbox consumed
+            L.ob_set(par, 0);                                    // outbox consumed
         }
         if (publish_hb) {                                        // leadership.rs:240-247 record
             if (!loaded) { L.load(); loaded = true; }

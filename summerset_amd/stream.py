@@ -32,11 +32,15 @@ def _key(seed, *parts):
     return h
 
 
-def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None):
+def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None, max_drop=None):
     """ackctl[cap][G]: per outbox entry a random peer order + loss mask.
 
     Rows >= n_entries (never reached by a tick that emits <= n_entries
-    messages) hold the identity order with no loss.
+    messages) hold the identity order with no loss.  `max_drop` caps how many
+    replica ids may be marked lost per entry: the reference never retransmits
+    an Accept (TCP is reliable), so an entry that loses its quorum stalls its
+    group's commit_bar until the next leader change; with max_drop = R - thresh
+    every entry stays committable whoever leads.
     """
     cap = n_entries if cap is None else cap
     out = np.full((cap, G), CTL_IDENTITY, np.uint32)
@@ -55,6 +59,8 @@ def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None):
     if drop_p > 0:
         u = (_key(seed, 0xD209, tick, j, g, r) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
         bits = (u < drop_p).astype(np.uint32)
+        if max_drop is not None:
+            bits = np.where(np.cumsum(bits, axis=2) > max_drop, 0, bits).astype(np.uint32)
         mask = np.zeros((n_entries, G), np.uint32)
         for i in range(R):
             mask |= bits[:, :, i] << np.uint32(i)
@@ -71,10 +77,10 @@ class MultiPaxosStream:
     follow the new leader."""
 
     def __init__(self, G, R=5, S=1, cap=None, n_ticks=1024, seed=DEFAULT_SEED, drop_p=0.1, timeout_frac=0.01,
-                 timeout_rep=1, hb_every=4, rand_rows=None):
+                 timeout_rep=1, hb_every=4, rand_rows=None, max_drop=None):
         self.G, self.R, self.S, self.n_ticks, self.seed = G, R, S, n_ticks, seed
         self.cap = cap if cap is not None else S + 8
-        self.drop_p, self.hb_every, self.timeout_rep = drop_p, hb_every, timeout_rep
+        self.drop_p, self.hb_every, self.timeout_rep, self.max_drop = drop_p, hb_every, timeout_rep, max_drop
         self.rand_rows = min(self.cap, rand_rows if rand_rows is not None else self.cap)
         g = np.arange(G, dtype=np.uint64)
         h = _key(seed, 0x7130, g)
@@ -85,18 +91,24 @@ class MultiPaxosStream:
     def heartbeat(self, t):
         return (t % self.hb_every) == self.hb_every - 1
 
-    def tick(self, t):
-        G, S = self.G, self.S
+    def tick_events(self, t):
+        """the tick's small per-group arrays: HearTimeout events and where the clients send"""
         hit = self.timeout_tick == t
         timeout_rep = np.where(hit, self.timeout_rep, NO_REPLICA).astype(np.uint8)
         timeout_src = np.where(hit, 0, NO_REPLICA).astype(np.uint8)
         moved = (self.timeout_tick >= 0) & (t > self.timeout_tick)
         req_target = np.where(moved, self.timeout_rep, 0).astype(np.uint8)
-        req_cnt = np.full(G, S, np.uint32)
+        return dict(timeout_rep=timeout_rep, timeout_src=timeout_src, req_target=req_target)
+
+    def tick(self, t):
+        G, S = self.G, self.S
+        out = self.tick_events(t)
         k = np.arange(S, dtype=np.uint64)[:, None]
         g = np.arange(G, dtype=np.uint64)[None, :]
         # opaque non-zero batch tokens (consensus kernels never read payload bytes)
         req_val = ((_key(self.seed, 0x70CE, t, k, g) & np.uint64(0x7FFFFFFF)) | np.uint64(1)).astype(np.uint32)
-        ackctl = random_ackctl(self.seed, t, self.rand_rows, G, self.R, self.drop_p, cap=self.cap)
-        return dict(timeout_rep=timeout_rep, timeout_src=timeout_src, req_target=req_target, req_cnt=req_cnt,
-                    req_val=np.ascontiguousarray(req_val), ackctl=ackctl, heartbeat=self.heartbeat(t))
+        out.update(req_cnt=np.full(G, S, np.uint32), req_val=np.ascontiguousarray(req_val),
+                   ackctl=random_ackctl(self.seed, t, self.rand_rows, G, self.R, self.drop_p, cap=self.cap,
+                                        max_drop=self.max_drop),
+                   heartbeat=self.heartbeat(t))
+        return out

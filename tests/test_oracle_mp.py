@@ -44,7 +44,7 @@ def test_hand_trace_single_slot(oracle):
     # heartbeat: followers learn the commit (advance_commit_bar), execute, everything trims
     m.tick(ackctl=ctl, heartbeat=True)
     F = m.dump(2)
-    assert F["commit_bar"][0] == 1 and F["exec_bar"][0] == 1 and F["s_status"][0, 0] == 0 and F["start_slot"][0] == 0
+    assert F["commit_bar"][0] == 1 and F["exec_bar"][0] == 1 and F["s_status"][0, 0] == 4 and F["start_slot"][0] == 0
     m.tick(ackctl=ctl, heartbeat=True)
     assert m.dump(2)["start_slot"][0] == 1 and m.dump(0)["start_slot"][0] == 1
 

@@ -1,0 +1,70 @@
+"""Raft leader-side parity (SURVEY §8d config 3 stream): HIP kernel vs the literal
+CPU restatement on identical synthetic AppendEntriesReply matrices, bit-exact."""
+import numpy as np
+import pytest
+
+from summerset_amd import stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _replies(seed, t, G, R, log_len, curr_term, lag_max=3, drop_p=0.05, stale_p=0.005, conflict_p=0.005,
+             higher_p=0.0):
+    """per (peer, group): end_slot = leader_last - lag, some dropped / stale-term / conflict replies"""
+    p = np.arange(R, dtype=np.uint64)[:, None]
+    g = np.arange(G, dtype=np.uint64)[None, :]
+    u = lambda tag: (stream._key(seed, tag, t, p, g) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    lag = (stream._key(seed, 1, t, p, g) % np.uint64(lag_max + 1)).astype(np.int64)
+    last = log_len.astype(np.int64)[None, :] - 1
+    end_slot = np.maximum(last - lag, 0).astype(np.uint32)
+    flags = (u(2) >= drop_p).astype(np.uint8)
+    term = np.broadcast_to(curr_term[None, :], (R, G)).astype(np.uint64).copy()
+    stale = u(3) < stale_p
+    term[stale] = 0                                                    # stale (smaller) term: still processed
+    higher = u(6) < higher_p
+    term[higher] += 1                                                  # a peer moved on: leader steps down
+    conflict = u(4) < conflict_p
+    flags = (flags | (conflict.astype(np.uint8) << 1)).astype(np.uint8)
+    cterm = np.where(conflict, curr_term[None, :], 0).astype(np.uint64)
+    cslot = np.where(conflict, np.maximum(end_slot.astype(np.int64) - 2, 1), 0).astype(np.uint32)
+    order = stream.random_ackctl(seed, t, 1, G, R, 0.0)[0]
+    return term, end_slot, flags, cterm, cslot, np.ascontiguousarray(order)
+
+
+def _run(cuda, oracle, G, R, W, T, commit_extra=0, higher_p=0.0, n_new_max=3, seed=77):
+    import torch
+    from summerset_amd import RaftLeaderGroup
+    eng = RaftLeaderGroup(G, R, 0, W, term=1, commit_extra=commit_extra)
+    orc = oracle.RaftOracle(G, R, W, 0, 1, commit_extra)
+    dev = lambda a: torch.from_numpy(a).to(cuda)
+    for t in range(T):
+        n_new = (stream._key(seed, 9, t, np.arange(G, dtype=np.uint64)) % np.uint64(n_new_max + 1)).astype(np.uint32)
+        orc.append(n_new)
+        eng.handle_req_batch(dev(n_new))
+        d = orc.dump()
+        term, es, fl, ct, cs, order = _replies(seed, t, G, R, d["log_len"], d["curr_term"], higher_p=higher_p)
+        orc.handle_replies(term, es, fl, ct, cs, order)
+        eng.handle_msg_append_entries_reply(dev(term), dev(es), dev(fl), dev(ct), dev(cs), dev(order))
+        a, b = eng.dump(), orc.dump()
+        for k in b:
+            assert np.array_equal(a[k], b[k]), "tick %d field %s" % (t, k)
+        assert eng.total_commits() == orc.total_commits()
+    assert orc.total_commits() > 0
+    return eng, orc
+
+
+def test_raft_steady(cuda, oracle):
+    _run(cuda, oracle, G=1000, R=5, W=64, T=60)
+
+
+def test_raft_three_replicas_and_stepdown(cuda, oracle):
+    eng, orc = _run(cuda, oracle, G=500, R=3, W=32, T=40, higher_p=0.002)
+    assert (orc.dump()["role"] == 0).any()                             # some leaders stepped down (check_term)
+
+
+def test_craft_threshold(cuda, oracle):
+    _run(cuda, oracle, G=300, R=5, W=64, T=40, commit_extra=1)
+
+
+def test_raft_config3_65536_groups(cuda, oracle):
+    _run(cuda, oracle, G=65536, R=5, W=64, T=12)
