@@ -152,7 +152,7 @@ struct Lane {
         int lane = __lane_id();
         int first = __ffsll((long long)mask) - 1;
         unsigned int base = 0;
-        if (lane == first) base = atomicAdd(v.clist_n, (unsigned int)__popcll(mask));
+        if (lane == first) base = atomicAdd((unsigned int *)v.clist_n, (unsigned int)__popcll(mask));
         base = __shfl(base, first);
         unsigned int idx = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
         if (idx < P.clist_cap) v.clist[idx] = ((unsigned long long)g << 32) | slot;
@@ -163,38 +163,89 @@ struct Lane {
         if (ballot > bms) { leader = peer; bms = ballot; }
     }
 
-    // durability.rs:134-142: accept_bar forward scan after logging slot
-    __device__ __forceinline__ void accept_bar_scan(uint32_t slot) {
-        if (slot == abar)
-            while (abar < len) {
-                if (m_st(v.s_meta[ix(abar)]) < SMR_ST_ACCEPTING) break;
-                abar++;
-            }
+    // meta of N consecutive slots [s0, s0+N) below lim, as independent loads
+    template <int N>
+    __device__ __forceinline__ void fetch_meta(uint32_t s0, uint32_t lim, uint32_t (&mm)[N]) const {
+#pragma unroll
+        for (int k = 0; k < N; k++) mm[k] = (s0 + k < lim) ? v.s_meta[ix(s0 + k)] : 0u;
     }
 
-    // durability.rs:148-218 handle_logged_commit_slot(slot), then the executor
-    // results of what it submitted: execution.rs:56-79 handle_cmd_result.
-    __device__ __forceinline__ void commit_complete(uint32_t slot) {
-        if (slot < start || slot != cbar) return;
-        const uint32_t c0 = cbar;
-        while (cbar < abar) {                                   // durability.rs:162
-            size_t i = ix(cbar);
-            uint32_t m = v.s_meta[i];
-            if (m_st(m) < SMR_ST_COMMITTED) break;              // :164-166
-            if (v.s_val[i] == 0) v.s_meta[i] = m_set_st(m, SMR_ST_EXECUTED);   // :171-172 empty batch
-            // else if Committed: commands go to the state machine (:173-181)
-            cbar++;                                             // :189
+    // durability.rs:134-142: accept_bar forward scan after logging `slot`, whose
+    // own status the caller knows to be >= Accepting
+    __device__ __forceinline__ void accept_bar_scan(uint32_t slot) {
+        if (slot != abar) return;
+        abar++;
+        while (abar < len) {
+            uint32_t mm[4];
+            fetch_meta<4>(abar, len, mm);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (abar >= len) return;
+                if (m_st(mm[k]) < SMR_ST_ACCEPTING) return;
+                abar++;
+            }
         }
-        for (uint32_t s = c0; s < cbar; s++) {                  // executor acks, in submission order
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            if (m_st(m) != SMR_ST_COMMITTED) continue;          // not submitted
-            v.s_meta[i] = m_set_st(m, SMR_ST_EXECUTED);         // execution.rs:57
-            if (s == ebar)                                      // execution.rs:70-78
-                while (ebar < len) {
-                    if (m_st(v.s_meta[ix(ebar)]) < SMR_ST_EXECUTED) break;
+    }
+
+    // durability.rs:148-218 handle_logged_commit_slot(slot) followed by the
+    // executor results of what it submitted (execution.rs:56-79 handle_cmd_result,
+    // one per non-empty batch, in submission order), fused into ONE forward pass:
+    //   * every slot of the run [commit_bar, first slot < Committed or accept_bar)
+    //     ends Executed: empty batches at commit time (durability.rs:171-172),
+    //     the others when their command result arrives (execution.rs:57);
+    //   * exec_bar only ever moves when a command result arrives for the slot AT
+    //     exec_bar (execution.rs:70); once that happens inside the run it walks
+    //     over the whole rest of the run (each later slot is either already
+    //     Executed or is itself the next result) and on through Executed slots
+    //     beyond it.  A run whose exec_bar slot is an EMPTY batch never moves
+    //     exec_bar -- the reference's no-op pin, kept as is.
+    // `m_slot` is the (already stored) meta of `slot`; `next_hint` optionally the
+    // meta of slot + 1 if the caller holds it (0xFFFFFFFF = unknown); NB = slots
+    // fetched per batch of independent loads when the run goes on.
+    template <int NB>
+    __device__ __forceinline__ void commit_complete(uint32_t slot, uint32_t m_slot, uint32_t next_hint = 0xFFFFFFFFu) {
+        if (slot < start || slot != cbar) return;
+        const uint32_t e0 = ebar;
+        bool chase = false;
+        uint32_t unexec_at = 0xFFFFFFFFu;          // where the run stopped on a slot < Committed
+        uint32_t s = cbar;
+        auto visit = [&](uint32_t m) -> bool {      // false = run ends here
+            if (m_st(m) < SMR_ST_COMMITTED) { unexec_at = s; return false; }   // durability.rs:164-166
+            if (m_st(m) == SMR_ST_COMMITTED) {
+                if ((m & M_NONEMPTY) && s == e0) chase = true;
+                v.s_meta[ix(s)] = m_set_st(m, SMR_ST_EXECUTED);
+            }
+            s++;                                    // durability.rs:189
+            return true;
+        };
+        bool go = s < abar && visit(m_slot);
+        if (go && s < abar && next_hint != 0xFFFFFFFFu && m_st(next_hint) < SMR_ST_COMMITTED) {
+            unexec_at = s;                          // caller's copy of slot + 1: still in flight
+            go = false;
+        }
+        while (go && s < abar) {                    // durability.rs:162
+            uint32_t mm[NB];
+            fetch_meta<NB>(s, abar, mm);
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if (s >= abar) { go = false; break; }
+                if (!visit(mm[k])) { go = false; break; }
+            }
+        }
+        cbar = s;
+        if (chase) {                                // execution.rs:70-78
+            ebar = cbar;
+            bool scan = ebar != unexec_at;
+            while (scan && ebar < len) {
+                uint32_t ee[NB];
+                fetch_meta<NB>(ebar, len, ee);
+#pragma unroll
+                for (int q = 0; q < NB; q++) {
+                    if (ebar >= len) { scan = false; break; }
+                    if (m_st(ee[q]) < SMR_ST_EXECUTED) { scan = false; break; }
                     ebar++;
                 }
+            }
         }
     }
 
@@ -216,7 +267,43 @@ struct Lane {
         v.s_meta[i] = m;
         if (committed) {
             record_commit(slot);
-            commit_complete(slot);                              // WAL CommitSlot :427-433 -> durability.rs:148
+            commit_complete<2>(slot, m);                        // WAL CommitSlot :427-433 -> durability.rs:148
+        }
+    }
+
+    // All AcceptReplies to ONE of my Accepts (an ack-matrix row), applied in
+    // registers: `m`, `b` are the slot's meta / ballot as prefetched, `acks[s]`
+    // the reply ballot of replica s (0 = none), `ctl` the delivery order / loss
+    // word.  Same per-reply filter chain as accept_reply (messages.rs:377-412).
+    __device__ __forceinline__ void accept_entry(uint32_t slot, uint32_t m, uint64_t b, uint32_t ctl,
+                                                 const uint64_t (&acks)[MAXR], uint32_t next_hint = 0xFFFFFFFFu) {
+        if (slot < start || slot >= len) return;                // :377-379, :389
+        if (!is_leader() || !(m & M_LBK)) return;               // :394, :402
+        const uint32_t drop = ctl_drop(ctl);
+        bool changed = false, committed = false;
+#pragma unroll
+        for (int oi = 0; oi < MAXR; oi++) {
+            const uint32_t s = ctl_order(ctl, oi);
+            if ((uint32_t)oi >= P.R || s == me || s >= P.R || ((drop >> s) & 1u)) continue;
+            uint64_t a = 0;
+#pragma unroll
+            for (int q = 0; q < MAXR; q++) a = (s == (uint32_t)q) ? acks[q] : a;
+            if (a == 0 || a != bpd) continue;                   // no reply / :388
+            if (m_st(m) != SMR_ST_ACCEPTING || a < b) continue; // :394-399 (a Committed slot ignores the rest)
+            const uint32_t bit = 1u << (s + M_ACKS_SH);
+            if (m & bit) continue;                              // :404-406
+            m |= bit;                                           // :409
+            changed = true;
+            if ((uint32_t)__popc(m_acks(m)) >= P.thresh) {      // :412
+                m = m_set_st(m, SMR_ST_COMMITTED);
+                committed = true;
+            }
+        }
+        if (!changed) return;
+        v.s_meta[ix(slot)] = m;
+        if (committed) {
+            record_commit(slot);
+            commit_complete<2>(slot, m, next_hint);
         }
     }
 
@@ -243,13 +330,20 @@ struct Lane {
         nlb = slot + 1;
         size_t i = ix(slot);
         // :158-182 fresh LeaderBookkeeping (all-zero side fields), Accepting at bal_prepared,
-        // voted = (bal, reqs) :190
-        uint32_t m = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH);
+        // voted = (bal, reqs) :190.  The WAL AcceptData append (:191-201) completes at once:
+        // durability.rs:99-103 self AcceptReply -- every filter of messages.rs:377-406 passes by
+        // construction (slot in range, ballot == bal_prepared == inst.bal, leader, Accepting,
+        // fresh accept_acks), so the self bit is set right here.
+        uint32_t m = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (reqs ? M_NONEMPTY : 0u) |
+                     (1u << (me + M_ACKS_SH));
+        const bool committed = P.thresh <= 1;                   // messages.rs:412 (only for a 1-ack threshold)
+        if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
         v.s_bal[i] = bpd;
         v.s_val[i] = reqs;
         v.s_meta[i] = m;
         ob_push(par, OB_ACCEPT, slot, bpd, reqs, 0);            // :209-216
-        self_accept_logged(slot);                               // WAL AcceptData :191-201 completes
+        if (committed) { record_commit(slot); commit_complete<2>(slot, m); }
+        accept_bar_scan(slot);                                  // durability.rs:134-142
     }
 
     // messages.rs:87-292 handle_msg_prepare_reply (+ the AcceptData completions
@@ -285,6 +379,7 @@ struct Lane {
                     v.s_pmax[i] = vbal;
                     m = materialize_voted(i, m, b, v.s_val[i]);
                     v.s_val[i] = vval;                          // inst.reqs = val
+                    m = vval ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                     v.s_meta[i] = m;
                 }
             }
@@ -419,6 +514,7 @@ struct Lane {
         if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;            // :331-339
         m = m_set_src(m, peer);
         m = m_set_vmode(m, VM_SAME);                            // :351 voted = (ballot, reqs)
+        m = reqs ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
         v.s_bal[i] = ballot;
         v.s_val[i] = reqs;
         v.s_meta[i] = m;
@@ -438,18 +534,35 @@ struct Lane {
         if (hb_exec < ebar) return;                             // :312-314
         if (hb_commit > cbar) {                                 // :379
             if (len < hb_commit && !pad_to(hb_commit - 1)) return;   // :380-382
-            uint32_t first = 0xFFFFFFFFu;
-            for (uint32_t s = cbar; s < hb_commit; s++) {       // :385-416
-                size_t i = ix(s);
-                uint32_t m = v.s_meta[i];
-                uint32_t st = m_st(m);
-                if (v.s_bal[i] < ballot || st < SMR_ST_ACCEPTING) break;
-                if (st >= SMR_ST_COMMITTED) continue;
-                v.s_meta[i] = m_set_st(m, SMR_ST_COMMITTED);
-                if (first == 0xFFFFFFFFu) first = s;
+            uint32_t first = 0xFFFFFFFFu, first_m = 0;
+            {                                                   // :385-416, 8 slots per batch of loads
+                uint32_t s = cbar;
+                bool go = true;
+                while (go && s < hb_commit) {
+                    uint32_t mm[8]; uint64_t bb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        bool in = s + k < hb_commit;
+                        size_t i = ix(s + k);
+                        mm[k] = in ? v.s_meta[i] : 0u;
+                        bb[k] = in ? v.s_bal[i] : 0ull;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (s >= hb_commit) { go = false; break; }
+                        uint32_t st = m_st(mm[k]);
+                        if (bb[k] < ballot || st < SMR_ST_ACCEPTING) { go = false; break; }
+                        if (st < SMR_ST_COMMITTED) {
+                            uint32_t m = m_set_st(mm[k], SMR_ST_COMMITTED);
+                            v.s_meta[ix(s)] = m;
+                            if (first == 0xFFFFFFFFu) { first = s; first_m = m; }
+                        }
+                        s++;
+                    }
+                }
             }
             // CommitSlot completions: only the first can sit at commit_bar
-            if (first != 0xFFFFFFFFu) commit_complete(first);
+            if (first != 0xFFFFFFFFu) commit_complete<8>(first, first_m);
         }
         if (peer != me) {                                       // :320-342
             size_t po = (size_t)peer * P.G + g;

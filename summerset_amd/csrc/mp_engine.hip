@@ -23,20 +23,19 @@ __device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
         c2 += __shfl_xor(c2, off);
     }
     if (__lane_id() == 0) {
-        if (c0) atomicAdd(&L.v.counters[0], (unsigned long long)c0);
-        if (c1) atomicAdd(&L.v.counters[1], (unsigned long long)c1);
-        if (c2) atomicAdd(&L.v.counters[2], (unsigned long long)c2);
+        if (c0) atomicAdd((unsigned long long *)&L.v.counters[0], (unsigned long long)c0);
+        if (c1) atomicAdd((unsigned long long *)&L.v.counters[1], (unsigned long long)c1);
+        if (c2) atomicAdd((unsigned long long *)&L.v.counters[2], (unsigned long long)c2);
     }
 }
 
 // R1: HearTimeout -> become_a_leader; client batches -> handle_req_batch
-__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
+__global__ __launch_bounds__(256) void mp_round_local(const MpParams P, int par,
                                                       const uint8_t *__restrict__ timeout_rep,
                                                       const uint8_t *__restrict__ timeout_src,
                                                       const uint8_t *__restrict__ req_target,
                                                       const uint32_t *__restrict__ req_cnt,
                                                       const uint32_t *__restrict__ req_val, uint32_t S) {
-    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -48,15 +47,58 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
     if (active) {
         L.load();
         if (has_to) L.become_a_leader(timeout_src[g]);
-        for (uint32_t k = 0; k < n_req && !L.ovf; k++) L.req_batch(req_val[(size_t)k * P.G + g]);
+        uint32_t k0 = 0;
+        // Steady-state fast path: a prepared leader whose log has no holes and
+        // whose accept_bar sits at the log end appends all n_req batches as a
+        // tight store-only loop.  Exactly what req_batch() does per batch in that
+        // state (first_null_slot -> push, fresh LeaderBookkeeping + self ack,
+        // Accept bcast, accept_bar + 1), with the array pointers hoisted.
+        if (!L.ovf && n_req && L.is_leader() && L.bpd != 0 && P.thresh > 1 && L.nlb >= L.len &&
+            L.abar == L.len && (L.len - L.start) + n_req - 1 + P.win_reserve < P.W) {
+            L.ob_load(par);
+            const uint32_t c0 = par == 0 ? L.obn0 : L.obn1;
+            if (c0 + n_req <= P.cap) {
+                const MpRep &v = P.rep[r];
+                SMR_G uint64_t *const sb = v.s_bal; SMR_G uint32_t *const sv = v.s_val; SMR_G uint32_t *const sm = v.s_meta;
+                SMR_G uint32_t *const os = v.ob_slot[par]; SMR_G uint64_t *const obl = v.ob_bal[par];
+                SMR_G uint32_t *const ov = v.ob_val[par];
+                const uint64_t bal = L.bpd;
+                const uint32_t base = L.len, G = P.G, Wm = P.Wmask;
+                const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (r + M_ACKS_SH));
+                for (uint32_t k = 0; k < n_req; k += 8) {
+                    uint32_t tok[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) tok[q] = (k + q < n_req) ? req_val[(size_t)(k + q) * G + g] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (k + q >= n_req) break;
+                        const uint32_t slot = base + k + q;
+                        const size_t i = (size_t)(slot & Wm) * G + g;
+                        const size_t o = (size_t)(c0 + k + q) * G + g;
+                        sb[i] = bal; sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
+                        os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; ov[o] = tok[q];
+                    }
+                }
+                L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
+                if (par == 0) L.obn0 = c0 + n_req; else L.obn1 = c0 + n_req;
+                k0 = n_req;
+            }
+        }
+        for (; k0 < n_req && !L.ovf; k0 += 8) {                  // generic path, 8 token loads per batch
+            uint32_t tok[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) tok[k] = (k0 + k < n_req) ? req_val[(size_t)(k0 + k) * P.G + g] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k0 + k < n_req && !L.ovf) L.req_batch(tok[k]);
+        }
         L.store();
     }
     flush_counters(L, active);
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
-__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par) {
-    const MpParams &P = *Pp;
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int par) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -64,25 +106,89 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
     if (active) {
         bool loaded = false;
         if (L.v.pr_cnt[g]) L.v.pr_cnt[g] = 0;
+        uint32_t cnts[MAXR];
+        uint32_t n_senders = 0, the_sender = 0;
+#pragma unroll
+        for (int s = 0; s < MAXR; s++) {
+            cnts[s] = ((uint32_t)s < P.R && (uint32_t)s != r) ? P.rep[s].ob_cnt[par][g] : 0u;
+            if (cnts[s]) { n_senders++; the_sender = (uint32_t)s; }
+        }
+        uint32_t fast_done = 0;
+        // Steady-state fast path: the only sender is the leader I already follow and
+        // each message is an Accept at my bal_max_seen for the slot right at my log
+        // end, with accept_bar at the log end too.  Per message this is exactly
+        // msg_accept(): check_leader is a no-op (ballot == bal_max_seen), push + fill
+        // fused (fresh ReplicaBookkeeping, voted = (ballot, reqs)), the WAL completion
+        // answers with the ballot, accept_bar + 1.  The first message that does not
+        // fit hands the rest of the outbox to the generic handlers below.
+        if (n_senders == 1) {
+            L.load(); loaded = true;
+            const uint32_t s = the_sender;
+            if (L.leader == s && L.abar == L.len) {
+                const MpRep &snd = P.rep[s];
+                const MpRep &v = P.rep[r];
+                SMR_G const uint32_t *const os = snd.ob_slot[par]; SMR_G const uint64_t *const obl = snd.ob_bal[par];
+                SMR_G const uint32_t *const ov = snd.ob_val[par]; SMR_G uint64_t *const ack = snd.ack;
+                SMR_G uint64_t *const sb = v.s_bal; SMR_G uint32_t *const sv = v.s_val; SMR_G uint32_t *const sm = v.s_meta;
+                const uint32_t cnt = cnts[s], G = P.G, Wm = P.Wmask, W = P.W, R = P.R, start = L.start;
+                const uint64_t bms = L.bms;
+                const uint32_t m0 = SMR_ST_ACCEPTING | M_RBK | (s << M_SRC_SH) | (VM_SAME << M_VMODE_SH);
+                uint32_t len = L.len;
+                bool ok = true;
+                for (uint32_t j0 = 0; j0 < cnt && ok; j0 += 8) {
+                    uint32_t e[8], val[8]; uint64_t bal[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const bool in = j0 + k < cnt;
+                        const size_t o = (size_t)(j0 + k) * G + g;
+                        e[k] = in ? os[o] : 0u; bal[k] = in ? obl[o] : 0ull; val[k] = in ? ov[o] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (j0 + k >= cnt || !ok) break;
+                        if (e[k] != ((OB_ACCEPT << OB_KIND_SH) | (len & OB_SLOT_MASK)) || bal[k] != bms || len - start >= W) {
+                            ok = false;
+                            break;
+                        }
+                        const size_t i = (size_t)(len & Wm) * G + g;
+                        sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+                        ack[((size_t)(j0 + k) * R + r) * G + g] = bms;
+                        len++;
+                        fast_done++;
+                    }
+                }
+                L.len = len; L.abar = len;
+            }
+        }
         for (uint32_t s = 0; s < P.R; s++) {
             if (s == r) continue;
             const MpRep &snd = P.rep[s];
             const uint32_t cnt = snd.ob_cnt[par][g];
-            for (uint32_t j = 0; j < cnt; j++) {
+            for (uint32_t j0 = (s == the_sender ? fast_done : 0u); j0 < cnt && !L.ovf; j0 += 8) {   // 8 messages per batch
                 if (!loaded) { L.load(); loaded = true; }
-                size_t o = (size_t)j * P.G + g;
-                uint32_t e = snd.ob_slot[par][o];
-                uint64_t bal = snd.ob_bal[par][o];
-                uint32_t kind = e >> OB_KIND_SH, slot = e & OB_SLOT_MASK;
-                if (kind == OB_ACCEPT) {
-                    uint64_t rep = L.msg_accept(s, slot, bal, snd.ob_val[par][o]);
-                    snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
-                } else if (kind == OB_PREPARE) {
-                    L.msg_prepare(s, slot, bal);
-                } else if (kind == OB_HEARTBEAT) {
-                    L.heard_heartbeat(s, bal, slot, snd.ob_val[par][o], snd.ob_aux[par][o]);
+                uint32_t e[8], val[8]; uint64_t bal[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    bool in = j0 + k < cnt;
+                    size_t o = (size_t)(j0 + k) * P.G + g;
+                    e[k] = in ? snd.ob_slot[par][o] : 0u;
+                    bal[k] = in ? snd.ob_bal[par][o] : 0ull;
+                    val[k] = in ? snd.ob_val[par][o] : 0u;
                 }
-                if (L.ovf) break;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (j0 + k >= cnt || L.ovf) break;
+                    const uint32_t j = j0 + k;
+                    const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
+                    if (kind == OB_ACCEPT) {
+                        uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
+                        snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
+                    } else if (kind == OB_PREPARE) {
+                        L.msg_prepare(s, slot, bal[k]);
+                    } else if (kind == OB_HEARTBEAT) {
+                        L.heard_heartbeat(s, bal[k], slot, val[k], snd.ob_aux[par][(size_t)j * P.G + g]);
+                    }
+                }
             }
             if (L.ovf) break;
         }
@@ -95,10 +201,9 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
 // R3: replies reach their destination: PrepareReplies (sender order of the
 // tick's ackctl word, FIFO per sender), then the AcceptReply matrix of my own
 // outbox, entry-major with per-entry peer order / loss.  THE quorum kernel.
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams P, int par,
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb) {
-    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t d = blockIdx.y;
     Lane L(P, d, g < P.G ? g : 0, par);
@@ -127,20 +232,78 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         const uint32_t cnt = v.ob_cnt[par][g];
         if (cnt) {
             if (!loaded) { L.load(); loaded = true; }
-            for (uint32_t j = 0; j < cnt; j++) {
-                size_t o = (size_t)j * P.G + g;
-                uint32_t e = v.ob_slot[par][o];
-                if ((e >> OB_KIND_SH) != OB_ACCEPT) continue;
-                uint32_t slot = e & OB_SLOT_MASK;
-                uint32_t ctl = ackctl ? ackctl[o] : SMR_CTL_IDENTITY;
-                uint32_t drop = ctl_drop(ctl);
-                for (uint32_t oi = 0; oi < P.R; oi++) {
-                    uint32_t s = ctl_order(ctl, oi);
-                    if (s == d || s >= P.R) continue;
-                    if (drop & (1u << s)) continue;
-                    uint64_t a = v.ack[((size_t)j * P.R + s) * P.G + g];
-                    if (!a) continue;
-                    L.accept_reply(s, slot, a);
+            constexpr int C = 4;                                 // ack-matrix rows per batch of loads
+            SMR_G const uint32_t *const os = v.ob_slot[par]; SMR_G const uint64_t *const ack = v.ack;
+            SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
+            const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
+            const bool lead = L.is_leader();
+            const uint64_t bpd = L.bpd;
+            for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
+                uint32_t e[C], ctl[C], m[C];
+                uint64_t a[C][MAXR], b[C];
+                bool have[C];
+#pragma unroll
+                for (int k = 0; k < C; k++) {                    // wave 1: everything addressed by (j, g) alone
+                    const bool in = j0 + k < cnt;
+                    const size_t o = (size_t)(j0 + k) * G + g;
+                    e[k] = in ? os[o] : 0u;
+                    ctl[k] = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
+#pragma unroll
+                    for (int q = 0; q < MAXR; q++)
+                        a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)(j0 + k) * R + q) * G + g] : 0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < C; k++) {                    // wave 2: the slots those Accepts name
+                    const uint32_t slot = e[k] & OB_SLOT_MASK;
+                    have[k] = (e[k] >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
+                    const size_t i = (size_t)(slot & Wm) * G + g;
+                    m[k] = have[k] ? sm[i] : 0u;
+                    b[k] = have[k] ? sb[i] : 0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    if (!have[k]) continue;
+                    const uint32_t slot = e[k] & OB_SLOT_MASK;
+                    const int kn = k + 1 < C ? k + 1 : k;
+                    const bool next_known = k + 1 < C && have[kn] && (e[kn] & OB_SLOT_MASK) == slot + 1;
+                    // The row's replies applied in registers: same filter chain as
+                    // accept_reply() / accept_entry() (messages.rs:377-412).
+                    uint32_t mk = m[k];
+                    if (!lead || !(mk & M_LBK)) continue;
+                    const uint32_t drop = ctl_drop(ctl[k]);
+                    bool changed = false, committed = false;
+#pragma unroll
+                    for (int oi = 0; oi < MAXR; oi++) {
+                        const uint32_t s = ctl_order(ctl[k], oi);
+                        if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
+                        uint64_t av = 0;
+#pragma unroll
+                        for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
+                        if (av == 0 || av != bpd) continue;
+                        if (m_st(mk) != SMR_ST_ACCEPTING || av < b[k]) continue;
+                        const uint32_t bit = 1u << (s + M_ACKS_SH);
+                        if (mk & bit) continue;
+                        mk |= bit;
+                        changed = true;
+                        if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
+                    }
+                    if (!changed) continue;
+                    const size_t i = (size_t)(slot & Wm) * G + g;
+                    if (!committed) { sm[i] = mk; continue; }
+                    L.record_commit(slot);
+                    // commit_complete() in its common shape, in registers: the slot sits at
+                    // commit_bar == exec_bar below accept_bar with a non-empty batch, and the
+                    // run ends right behind it (next slot still Accepting, or the log ends).
+                    const bool stops = (next_known && m_st(m[kn]) < SMR_ST_COMMITTED) ||
+                                       (slot + 1 >= L.abar && slot + 1 >= L.len);
+                    if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
+                        sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
+                        L.cbar = slot + 1;
+                        L.ebar = slot + 1;
+                    } else {
+                        sm[i] = mk;
+                        L.commit_complete<2>(slot, mk, next_known ? m[kn] : 0xFFFFFFFFu);
+                    }
                 }
             }
             L.ob_set(par, 0);                                    // outbox consumed
@@ -157,8 +320,7 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
 // trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
 // as carried by this round's heartbeats).
-__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par) {
-    const MpParams &P = *Pp;
+__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams P, int par) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -344,7 +506,7 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 0, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
+    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->hp, c->par, timeout_rep_dev,
                        timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
@@ -354,7 +516,7 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 1, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->hp, c->par);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }
@@ -363,7 +525,7 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
+    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->hp, c->par, ackctl_dev,
                        publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
@@ -373,7 +535,7 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 3, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->hp, c->par);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }

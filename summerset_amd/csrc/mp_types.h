@@ -22,6 +22,17 @@
 
 #include "../../include/summerset_hip.h"
 
+// Pointers that live inside a struct in memory would be "flat" to the compiler
+// (flat_load / flat_store count against BOTH vmcnt and lgkmcnt, so every scalar
+// pointer reload then waits for all outstanding stores).  On the device pass
+// they are typed as global address space; the host sees plain pointers of the
+// same size.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMR_G __attribute__((address_space(1)))
+#else
+#define SMR_G
+#endif
+
 namespace smr {
 
 // s_meta bit layout
@@ -34,6 +45,7 @@ constexpr uint32_t M_RBKX = 1u << 7;       // replica_bk.{trigger,endprep}_slot 
 constexpr int M_ACKS_SH = 8;               // leader_bk.accept_acks  (8 bits)
 constexpr int M_PACKS_SH = 16;             // leader_bk.prepare_acks (8 bits)
 constexpr int M_SRC_SH = 24;               // replica_bk.source      (3 bits)
+constexpr uint32_t M_NONEMPTY = 1u << 27;  // !Instance::reqs.is_empty()  (mirrors s_val != 0)
 constexpr int M_VMODE_SH = 28;             // Instance::voted encoding (2 bits)
 constexpr uint32_t VM_NONE = 0;            // voted == (0, empty)
 constexpr uint32_t VM_SAME = 1;            // voted == (bal, reqs) as stored
@@ -49,42 +61,42 @@ constexpr int MAXR = 8;
 
 struct MpRep {
     // scalars [G]
-    uint8_t *leader;
-    uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
-    uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
-    uint32_t *null_lb;        // aux: no Null instance in [exec_bar, null_lb)
-    uint32_t *peer_exec_bar;  // [R][G]
+    SMR_G uint8_t *leader;
+    SMR_G uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
+    SMR_G uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
+    SMR_G uint32_t *null_lb;        // aux: no Null instance in [exec_bar, null_lb)
+    SMR_G uint32_t *peer_exec_bar;  // [R][G]
     // slot ring [W][G]
-    uint64_t *s_bal;
-    uint32_t *s_val;          // reqs token (0 = empty batch)
-    uint32_t *s_meta;
-    uint64_t *s_vbal; uint32_t *s_vval;
-    uint64_t *s_pmax;
-    uint32_t *s_ltrig, *s_lendp, *s_rtrig, *s_rendp;
+    SMR_G uint64_t *s_bal;
+    SMR_G uint32_t *s_val;          // reqs token (0 = empty batch)
+    SMR_G uint32_t *s_meta;
+    SMR_G uint64_t *s_vbal; SMR_G uint32_t *s_vval;
+    SMR_G uint64_t *s_pmax;
+    SMR_G uint32_t *s_ltrig, *s_lendp, *s_rtrig, *s_rendp;
     // outbox [2][cap][G]
-    uint32_t *ob_cnt[2];
-    uint32_t *ob_slot[2];     // kind<<30 | slot   (HB: commit_bar)
-    uint64_t *ob_bal[2];
-    uint32_t *ob_val[2];      // Accept: reqs token; HB: exec_bar
-    uint32_t *ob_aux[2];      // HB: snap_bar
+    SMR_G uint32_t *ob_cnt[2];
+    SMR_G uint32_t *ob_slot[2];     // kind<<30 | slot   (HB: commit_bar)
+    SMR_G uint64_t *ob_bal[2];
+    SMR_G uint32_t *ob_val[2];      // Accept: reqs token; HB: exec_bar
+    SMR_G uint32_t *ob_aux[2];      // HB: snap_bar
     // replies to my Accepts [cap][R][G]
-    uint64_t *ack;
+    SMR_G uint64_t *ack;
     // my PrepareReply batch of this tick: header [G] + entries [pcap][G]
-    uint32_t *pr_cnt; uint8_t *pr_dest;
-    uint32_t *pr_trig, *pr_endp, *pr_abar; uint64_t *pr_bal;
-    uint64_t *pr_vbal; uint32_t *pr_vval;
+    SMR_G uint32_t *pr_cnt; SMR_G uint8_t *pr_dest;
+    SMR_G uint32_t *pr_trig, *pr_endp, *pr_abar; SMR_G uint64_t *pr_bal;
+    SMR_G uint64_t *pr_vbal; SMR_G uint32_t *pr_vval;
     // heartbeat record [G]
-    uint64_t *hb_bal; uint32_t *hb_commit, *hb_exec, *hb_snap;
+    SMR_G uint64_t *hb_bal; SMR_G uint32_t *hb_commit, *hb_exec, *hb_snap;
     // outputs
-    unsigned long long *counters;   // [0] commits [1] redirects [2] rejects
-    unsigned long long *clist;      // (group << 32) | slot
-    unsigned int *clist_n;
+    SMR_G unsigned long long *counters;   // [0] commits [1] redirects [2] rejects
+    SMR_G unsigned long long *clist;      // (group << 32) | slot
+    SMR_G unsigned int *clist_n;
 };
 
 struct MpParams {
     uint32_t G, W, Wmask, cap, pcap, win_reserve, clist_cap;
     uint32_t R, quorum, thresh, rspaxos;
-    uint8_t *overflow;              // [G] sticky, shared by all replicas of a group
+    SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
     MpRep rep[MAXR];
 };
 

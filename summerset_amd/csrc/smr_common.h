@@ -34,7 +34,7 @@ struct Arena {
         used = off + bytes;
         return off;
     }
-    template <typename T> T *at(size_t off) const { return reinterpret_cast<T *>(base + off); }
+    template <typename T> T *at(size_t off) const { return (T *)(base + off); }  // C cast: T may carry an address space on the device pass
 };
 
 }  // namespace smr
