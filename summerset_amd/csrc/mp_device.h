@@ -346,8 +346,90 @@ struct Lane {
         accept_bar_scan(slot);                                  // durability.rs:134-142
     }
 
-    // messages.rs:87-292 handle_msg_prepare_reply (+ the AcceptData completions
-    // of a reached quorum).  peer_accept_bar bookkeeping is lease-only.
+    // first slot of [lo, hi) whose status is below `bound`, else hi (16 metas per batch of loads)
+    __device__ __forceinline__ uint32_t first_status_below(uint32_t lo, uint32_t hi, uint32_t bound) const {
+        for (uint32_t s = lo; s < hi; s += 16) {
+            uint32_t mm[16];
+            fetch_meta<16>(s, hi, mm);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (s + k < hi && m_st(mm[k]) < bound) return s + k;
+        }
+        return hi;
+    }
+    // last slot of [lo, hi) whose status is below `bound` (below = true) or above it, else `none`
+    __device__ __forceinline__ uint32_t last_status(uint32_t lo, uint32_t hi, uint32_t bound, bool below,
+                                                    uint32_t none) const {
+        uint32_t top = hi;
+        while (top > lo) {
+            const uint32_t base = top - lo >= 8 ? top - 8 : lo;
+            uint32_t mm[8];
+            fetch_meta<8>(base, top, mm);
+#pragma unroll
+            for (int k = 7; k >= 0; k--) {
+                if (base + k >= top) continue;
+                const uint32_t st = m_st(mm[k]);
+                if (below ? st < bound : st > bound) return base + k;
+            }
+            top = base;
+        }
+        return none;
+    }
+
+    // messages.rs:219-287: the sender's PrepareReplies are complete up to its
+    // endprep_slot -> count it on the trigger slot; on a quorum, bal_prepared = ballot
+    // and every Preparing slot from the trigger on enters the Accept phase.
+    // The AcceptData completions (durability.rs:85-145: self ack + accept_bar scan)
+    // are folded into the same ascending pass: each touches only its own slot, and
+    // the accept_bar scan that the completion of the slot AT accept_bar starts runs
+    // over the slots' final statuses, which an ascending pass knows as it goes.
+    __device__ __forceinline__ void prepare_quorum_step(uint32_t peer, uint32_t trig, uint64_t ballot) {
+        const size_t ti = ix(trig);
+        uint32_t tm = v.s_meta[ti];
+        tm |= 1u << (peer + M_PACKS_SH);                        // :228
+        v.s_meta[ti] = tm;
+        if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
+        bpd = ballot;                                           // :236
+        int chase = 0;                                          // 0 not started, 1 running, 2 over
+        for (uint32_t s0 = trig; s0 < len; s0 += 8) {           // :238-286
+            uint32_t mm[8], vv[8]; uint64_t bb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool in = s0 + k < len;
+                const size_t i = ix(s0 + k);
+                mm[k] = in ? v.s_meta[i] : 0u; vv[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t s = s0 + k;
+                if (s >= len) break;
+                uint32_t m = mm[k];
+                const bool moved = m_st(m) == SMR_ST_PREPARING;
+                if (moved) {
+                    m = m_set_st(m, SMR_ST_ACCEPTING);
+                    ob_push(par ^ 1, OB_ACCEPT, s, ballot, vv[k], 0);   // travels in the next tick
+                    // its AcceptData completion: messages.rs:377-412 with peer = me, ballot = inst.bal
+                    if (bb[k] == ballot && (m & M_LBK) && !(m_acks(m) & (1u << me))) {
+                        m |= 1u << (me + M_ACKS_SH);
+                        if ((uint32_t)__popc(m_acks(m)) >= P.thresh) {   // only with a 1-ack threshold
+                            m = m_set_st(m, SMR_ST_COMMITTED);
+                            v.s_meta[ix(s)] = m;
+                            record_commit(s);
+                            commit_complete<2>(s, m);
+                            m = v.s_meta[ix(s)];
+                        }
+                    }
+                    v.s_meta[ix(s)] = m;
+                }
+                if (chase == 0 && moved && s == abar) chase = 1;            // durability.rs:134
+                if (chase == 1 && s == abar) {
+                    if (m_st(m) >= SMR_ST_ACCEPTING) abar = s + 1; else chase = 2;
+                }
+            }
+        }
+    }
+
+    // messages.rs:87-292 handle_msg_prepare_reply.  peer_accept_bar bookkeeping is lease-only.
     __device__ __forceinline__ void prepare_reply(uint32_t peer, uint32_t slot, uint32_t trig, uint32_t endp, uint64_t ballot,
                                   bool has_voted, uint64_t vbal, uint32_t vval) {
         if (slot < start) return;                               // :97-99
@@ -385,30 +467,62 @@ struct Lane {
             }
         }
         if (slot != endp) return;                               // :222
-        tm = v.s_meta[ti];
-        tm |= 1u << (peer + M_PACKS_SH);                        // :228
-        v.s_meta[ti] = tm;
-        if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
-        bpd = ballot;                                           // :236
-        for (uint32_t s = trig; s < len; s++) {                 // :238-286
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            if (m_st(m) != SMR_ST_PREPARING) continue;
-            v.s_meta[i] = m_set_st(m, SMR_ST_ACCEPTING);
-            ob_push(par ^ 1, OB_ACCEPT, s, ballot, v.s_val[i], 0);   // travels in the next tick
-        }
-        // AcceptData completions, in order: exactly the slots moved above are
-        // Accepting at this (fresh, unique) ballot with no self ack yet
-        for (uint32_t s = trig; s < len; s++) {
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            if (m_st(m) == SMR_ST_ACCEPTING && v.s_bal[i] == ballot && !(m_acks(m) & (1u << me)))
-                self_accept_logged(s);
+        prepare_quorum_step(peer, trig, ballot);
+    }
+
+    // One sender's whole PrepareReply batch (slots trig .. trig+n-1, FIFO): the checks of
+    // messages.rs:97-125 do not depend on the slot, so they are made once; the per-slot
+    // part (:196-216) runs on 8 slots per batch of loads.  A slot beyond my log end
+    // (:154-190) goes through prepare_reply() one by one.
+    __device__ __forceinline__ void prepare_reply_batch(uint32_t peer, uint32_t trig, uint32_t endp, uint64_t ballot,
+                                                        uint32_t n, SMR_G const uint64_t *pr_vbal,
+                                                        SMR_G const uint32_t *pr_vval) {
+        if (ballot != bps || !is_leader()) return;              // :110-114
+        if (trig < start || trig >= len) return;                // :97-99 (slot >= trig), :116-119
+        if (!(v.s_meta[ix(trig)] & M_LBK)) return;              // :120-125
+        for (uint32_t k0 = 0; k0 < n && !ovf; k0 += 8) {
+            uint32_t mm[8], vv[8]; uint64_t bb[8], pm[8], vb[8];
+            const uint32_t len0 = len;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t slot = trig + k0 + k;
+                const bool in = k0 + k < n, mine = in && slot < len0;
+                const size_t o = (size_t)(k0 + k) * P.G + g, i = ix(slot);
+                vb[k] = in ? pr_vbal[o] : 0ull; vv[k] = in ? pr_vval[o] : 0u;
+                mm[k] = mine ? v.s_meta[i] : 0u; bb[k] = mine ? v.s_bal[i] : 0ull; pm[k] = mine ? v.s_pmax[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k0 + k >= n || ovf) break;
+                const uint32_t slot = trig + k0 + k;
+                if (slot >= len0) {                             // unknown slot: pad + reply, the long way
+                    prepare_reply(peer, slot, trig, endp, ballot, vb[k] > 0, vb[k], vv[k]);
+                    continue;
+                }
+                uint32_t m = mm[k];
+                if (m_st(m) == SMR_ST_PREPARING && ballot >= bb[k] && vb[k] > 0 && (m & M_LBK)) {   // :196-216
+                    const uint64_t cur = (m & M_LBKX) ? pm[k] : 0ull;
+                    if (vb[k] > cur) {
+                        const size_t i = ix(slot);
+                        if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
+                        v.s_pmax[i] = vb[k];
+                        m = materialize_voted(i, m, bb[k], v.s_val[i]);
+                        v.s_val[i] = vv[k];
+                        m = vv[k] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                        v.s_meta[i] = m;
+                    }
+                }
+                if (slot == endp && m_st(m) == SMR_ST_PREPARING && ballot >= bb[k])   // :196-198, :222
+                    prepare_quorum_step(peer, trig, ballot);
+            }
         }
     }
 
     // leadership.rs:73-214 become_a_leader + its PrepareBal completions
-    // (durability.rs:10-49: the leader's own PrepareReply)
+    // (durability.rs:10-49: the leader's own PrepareReply, messages.rs:196-228).
+    // Those completions touch only their own slot (and, for the last one, the trigger
+    // slot's prepare_acks), so they are folded into the one ascending pass that rewrites
+    // the in-progress instances; 8 slots per batch of loads.
     __device__ __forceinline__ void become_a_leader(uint32_t src) {
         if (leader != NO_REP && leader != src) return;          // :77-81
         leader = me;                                            // :98
@@ -418,74 +532,93 @@ struct Lane {
         bpd = 0;                                                // :112-114
         bps = make_greater_ballot(bms);
         bms = bps;
-        uint32_t trig = len, endp = len;                        // :117-130
-        for (uint32_t s = start; s < len; s++)
-            if (m_st(v.s_meta[ix(s)]) < SMR_ST_COMMITTED) { trig = s; break; }
-        for (uint32_t s = len; s > start; s--)
-            if (m_st(v.s_meta[ix(s - 1)]) < SMR_ST_COMMITTED) { endp = s - 1; break; }
+        uint32_t trig = first_status_below(start, len, SMR_ST_COMMITTED);          // :117-123 (else log end)
+        const uint32_t endp = last_status(start, len, SMR_ST_COMMITTED, true, len); // :124-130 (else log end)
         if (trig == len)                                        // :131-134
             if (!push_null()) return;
         const uint32_t e0 = ebar;
-        for (uint32_t s = e0; s < len; s++) {                   // :142-183
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            uint32_t st = m_st(m);
-            if (st == SMR_ST_EXECUTED) continue;
-            m |= M_EXT;
-            if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
-            m = materialize_voted(i, m, v.s_bal[i], v.s_val[i]);
-            v.s_bal[i] = bps;
-            m = m_set_st(m, SMR_ST_PREPARING) | M_LBK | M_LBKX;
-            m &= ~((0xFFu << M_ACKS_SH) | (0xFFu << M_PACKS_SH));
-            v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = 0;
-            v.s_meta[i] = m;
-        }
-        ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
-        // PrepareBal completions: the slots just moved are exactly those
-        // Preparing at the fresh ballot
-        for (uint32_t s = e0; s < len; s++) {
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            uint64_t b = v.s_bal[i];
-            if (m_st(m) != SMR_ST_PREPARING || b != bps) continue;
-            if (!is_leader()) break;
-            if (s <= endp) {                                    // durability.rs:33-48
+        // Will my own PrepareReplies be counted?  messages.rs:116-125 looks at the trigger
+        // slot's leader_bk, which the pass below creates when the trigger lies in it.
+        const bool self_ok = trig >= e0 ? true : (v.s_meta[ix(trig)] & M_LBK) != 0;
+        for (uint32_t s0 = e0; s0 < len; s0 += 8) {             // :142-183
+            uint32_t mm[8], vl[8]; uint64_t bb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool in = s0 + k < len;
+                const size_t i = ix(s0 + k);
+                mm[k] = in ? v.s_meta[i] : (uint32_t)SMR_ST_EXECUTED; vl[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t s = s0 + k;
+                if (s >= len) break;
+                const size_t i = ix(s);
+                uint32_t m = mm[k];
+                const uint32_t st = m_st(m);
+                if (st == SMR_ST_EXECUTED) continue;
+                m |= M_EXT;
+                if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
                 uint64_t vb; uint32_t vv;
-                get_voted(i, m, b, v.s_val[i], vb, vv);
-                prepare_reply(me, s, trig, endp, b, vb > 0, vb, vv);
+                get_voted(i, m, bb[k], vl[k], vb, vv);
+                m = materialize_voted(i, m, bb[k], vl[k]);
+                m = m_set_st(m, SMR_ST_PREPARING) | M_LBK | M_LBKX;
+                m &= ~((0xFFu << M_ACKS_SH) | (0xFFu << M_PACKS_SH));
+                uint64_t pmax = 0;
+                // PrepareBal completion -> my own PrepareReply for this slot (durability.rs:33-48):
+                // keep the value I voted for, if any (messages.rs:203-216 with prepare_max_bal == 0)
+                if (self_ok && s <= endp && vb > 0) {
+                    pmax = vb;
+                    if (vv != vl[k]) v.s_val[i] = vv;
+                    m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                }
+                v.s_bal[i] = bps;
+                v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = pmax;
+                v.s_meta[i] = m;
             }
         }
+        ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
+        // the completion of slot endprep counts me in (messages.rs:222-233)
+        if (self_ok && endp >= e0 && endp < len) prepare_quorum_step(me, trig, bps);
     }
 
     // messages.rs:12-83 handle_msg_prepare + durability.rs:50-78 (PrepareReply
-    // per slot, written as one batch: header + (voted_bal, voted_reqs) entries)
+    // per slot, written as one batch: header + (voted_bal, voted_reqs) entries);
+    // 8 slots per batch of loads
     __device__ __forceinline__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
         if (trig < start) return;                               // :18-20
         if (ballot < bms) return;                               // :29
         check_leader(peer, ballot);
         if (!pad_to(trig)) return;                              // :37-39
-        uint32_t last = start;                                  // :43-52
-        for (uint32_t s = len; s > start; s--)
-            if (m_st(v.s_meta[ix(s - 1)]) > SMR_ST_NULL) { last = s - 1; break; }
+        const uint32_t last = last_status(start, len, SMR_ST_NULL, false, start);   // :43-52 (unwrap_or(0))
         const uint32_t endp = last > trig ? last : trig;
         const uint32_t n = endp - trig + 1;
         const bool follower = !is_leader();
         if (follower && (v.pr_cnt[g] != 0 || n > P.pcap)) { ovf = true; return; }
-        for (uint32_t s = trig; s <= endp; s++) {               // :55-79
-            size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            uint64_t b = v.s_bal[i];
-            uint32_t val = v.s_val[i];
-            uint64_t vb; uint32_t vv;
-            get_voted(i, m, b, val, vb, vv);
-            m = materialize_voted(i, m, b, val);
-            v.s_bal[i] = ballot;
-            m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
-            v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
-            v.s_meta[i] = m;
-            if (follower) {                                     // durability.rs:50-78
-                size_t o = (size_t)(s - trig) * P.G + g;
-                v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
+        for (uint32_t s0 = trig; s0 <= endp; s0 += 8) {         // :55-79
+            uint32_t mm[8], vl[8]; uint64_t bb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool in = s0 + k <= endp;
+                const size_t i = ix(s0 + k);
+                mm[k] = in ? v.s_meta[i] : 0u; vl[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t s = s0 + k;
+                if (s > endp) break;
+                const size_t i = ix(s);
+                uint32_t m = mm[k];
+                uint64_t vb; uint32_t vv;
+                get_voted(i, m, bb[k], vl[k], vb, vv);
+                m = materialize_voted(i, m, bb[k], vl[k]);
+                v.s_bal[i] = ballot;
+                m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
+                v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
+                v.s_meta[i] = m;
+                if (follower) {                                 // durability.rs:50-78
+                    size_t o = (size_t)(s - trig) * P.G + g;
+                    v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
+                }
             }
         }
         if (follower) {

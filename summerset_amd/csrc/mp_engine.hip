@@ -220,13 +220,7 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams P, int pa
             uint32_t n = snd.pr_cnt[g];
             if (n == 0 || snd.pr_dest[g] != d) continue;
             if (!loaded) { L.load(); loaded = true; }
-            uint32_t trig = snd.pr_trig[g], endp = snd.pr_endp[g];
-            uint64_t bal = snd.pr_bal[g];
-            for (uint32_t k = 0; k < n && !L.ovf; k++) {
-                size_t o = (size_t)k * P.G + g;
-                uint64_t vb = snd.pr_vbal[o];
-                L.prepare_reply(s, trig + k, trig, endp, bal, vb > 0, vb, snd.pr_vval[o]);
-            }
+            L.prepare_reply_batch(s, snd.pr_trig[g], snd.pr_endp[g], snd.pr_bal[g], n, snd.pr_vbal, snd.pr_vval);
         }
         // (b) AcceptReplies to my Accepts of this tick
         const uint32_t cnt = v.ob_cnt[par][g];
