@@ -46,12 +46,22 @@ struct Lane {
     bool obl0, obl1;               // array would live in scratch memory)
     uint32_t n_commit, n_redirect, n_reject;
     bool ovf;
+    // Wave-cooperative ("uniform") mode: all 64 lanes of a wavefront run the SAME
+    // (group, replica) handler with identical scalar state; only lane 0 commits
+    // stores (`wr`), and converted slot loops are strided by lane (`cl`, `cn`).
+    // In the normal per-lane mode wr = true, cl = 0, cn = 1.
+    bool wr;
+    uint32_t cl, cn;
 
     __device__ __forceinline__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
-        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), ovf(false) {
+        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), ovf(false),
+          wr(true), cl(0), cn(1) {
         obl0 = obl1 = false;
         obn0 = obn1 = 0;
     }
+
+    __device__ __forceinline__ void set_uniform() { wr = __lane_id() == 0; cl = (uint32_t)__lane_id(); cn = 64; }
+    __device__ __forceinline__ bool coop() const { return cn != 1; }
 
     __device__ __forceinline__ void load() {
         o_leader = leader = v.leader[g];
@@ -67,20 +77,20 @@ struct Lane {
         o_nlb = nlb = v.null_lb[g];
     }
     __device__ __forceinline__ void store() {
-        if (leader != o_leader) v.leader[g] = (uint8_t)leader;
-        if (bps != o_bps) v.bal_prep_sent[g] = bps;
-        if (bpd != o_bpd) v.bal_prepared[g] = bpd;
-        if (bms != o_bms) v.bal_max_seen[g] = bms;
-        if (start != o_start) v.start_slot[g] = start;
-        if (len != o_len) v.log_len[g] = len;
-        if (abar != o_abar) v.accept_bar[g] = abar;
-        if (cbar != o_cbar) v.commit_bar[g] = cbar;
-        if (ebar != o_ebar) v.exec_bar[g] = ebar;
-        if (snap != o_snap) v.snap_bar[g] = snap;
-        if (nlb != o_nlb) v.null_lb[g] = nlb;
-        if (obl0) v.ob_cnt[0][g] = obn0;
-        if (obl1) v.ob_cnt[1][g] = obn1;
-        if (ovf) P.overflow[g] = 1;
+        if (leader != o_leader) if (wr) v.leader[g] = (uint8_t)leader;
+        if (bps != o_bps) if (wr) v.bal_prep_sent[g] = bps;
+        if (bpd != o_bpd) if (wr) v.bal_prepared[g] = bpd;
+        if (bms != o_bms) if (wr) v.bal_max_seen[g] = bms;
+        if (start != o_start) if (wr) v.start_slot[g] = start;
+        if (len != o_len) if (wr) v.log_len[g] = len;
+        if (abar != o_abar) if (wr) v.accept_bar[g] = abar;
+        if (cbar != o_cbar) if (wr) v.commit_bar[g] = cbar;
+        if (ebar != o_ebar) if (wr) v.exec_bar[g] = ebar;
+        if (snap != o_snap) if (wr) v.snap_bar[g] = snap;
+        if (nlb != o_nlb) if (wr) v.null_lb[g] = nlb;
+        if (obl0) if (wr) v.ob_cnt[0][g] = obn0;
+        if (obl1) if (wr) v.ob_cnt[1][g] = obn1;
+        if (ovf && wr) P.overflow[g] = 1;
     }
 
     __device__ __forceinline__ size_t ix(uint32_t slot) const { return (size_t)(slot & P.Wmask) * P.G + g; }
@@ -95,7 +105,7 @@ struct Lane {
     __device__ __forceinline__ bool push_null() {
         if (len - start >= P.W) { ovf = true; return false; }
         size_t i = ix(len);
-        v.s_meta[i] = 0; v.s_bal[i] = 0; v.s_val[i] = 0;
+        if (wr) v.s_meta[i] = 0; if (wr) v.s_bal[i] = 0; if (wr) v.s_val[i] = 0;
         len++;
         return true;
     }
@@ -110,7 +120,7 @@ struct Lane {
     // Instance::voted accessors
     __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val) {
         if (m_vmode(m) == VM_SAME) {
-            v.s_vbal[i] = bal; v.s_vval[i] = val;
+            if (wr) v.s_vbal[i] = bal; if (wr) v.s_vval[i] = val;
             m = m_set_vmode(m, VM_SIDE);
         }
         return m;
@@ -137,10 +147,10 @@ struct Lane {
         uint32_t c = p == 0 ? obn0 : obn1;
         if (c >= P.cap) { ovf = true; return; }
         size_t o = (size_t)c * P.G + g;
-        v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
-        v.ob_bal[p][o] = bal;
-        v.ob_val[p][o] = val;
-        if (kind == OB_HEARTBEAT) v.ob_aux[p][o] = aux;
+        if (wr) v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
+        if (wr) v.ob_bal[p][o] = bal;
+        if (wr) v.ob_val[p][o] = val;
+        if (kind == OB_HEARTBEAT) if (wr) v.ob_aux[p][o] = aux;
         if (p == 0) obn0 = c + 1; else obn1 = c + 1;
     }
 
@@ -148,6 +158,13 @@ struct Lane {
     __device__ __forceinline__ void record_commit(uint32_t slot) {
         n_commit++;
         if (P.clist_cap == 0) return;
+        if (coop()) {                              // uniform mode: one entry, appended by lane 0
+            if (wr) {
+                unsigned int idx = atomicAdd((unsigned int *)v.clist_n, 1u);
+                if (idx < P.clist_cap) v.clist[idx] = ((unsigned long long)g << 32) | slot;
+            }
+            return;
+        }
         unsigned long long mask = __ballot(1);
         int lane = __lane_id();
         int first = __ffsll((long long)mask) - 1;
@@ -213,7 +230,7 @@ struct Lane {
             if (m_st(m) < SMR_ST_COMMITTED) { unexec_at = s; return false; }   // durability.rs:164-166
             if (m_st(m) == SMR_ST_COMMITTED) {
                 if ((m & M_NONEMPTY) && s == e0) chase = true;
-                v.s_meta[ix(s)] = m_set_st(m, SMR_ST_EXECUTED);
+                if (wr) v.s_meta[ix(s)] = m_set_st(m, SMR_ST_EXECUTED);
             }
             s++;                                    // durability.rs:189
             return true;
@@ -264,7 +281,7 @@ struct Lane {
         m |= bit;                                               // :409
         bool committed = (uint32_t)__popc(m_acks(m)) >= P.thresh;   // :412 (rspaxos/messages.rs:438-439)
         if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
-        v.s_meta[i] = m;
+        if (wr) v.s_meta[i] = m;
         if (committed) {
             record_commit(slot);
             commit_complete<2>(slot, m);                        // WAL CommitSlot :427-433 -> durability.rs:148
@@ -300,7 +317,7 @@ struct Lane {
             }
         }
         if (!changed) return;
-        v.s_meta[ix(slot)] = m;
+        if (wr) v.s_meta[ix(slot)] = m;
         if (committed) {
             record_commit(slot);
             commit_complete<2>(slot, m, next_hint);
@@ -338,9 +355,9 @@ struct Lane {
                      (1u << (me + M_ACKS_SH));
         const bool committed = P.thresh <= 1;                   // messages.rs:412 (only for a 1-ack threshold)
         if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
-        v.s_bal[i] = bpd;
-        v.s_val[i] = reqs;
-        v.s_meta[i] = m;
+        if (wr) v.s_bal[i] = bpd;
+        if (wr) v.s_val[i] = reqs;
+        if (wr) v.s_meta[i] = m;
         ob_push(par, OB_ACCEPT, slot, bpd, reqs, 0);            // :209-216
         if (committed) { record_commit(slot); commit_complete<2>(slot, m); }
         accept_bar_scan(slot);                                  // durability.rs:134-142
@@ -387,7 +404,7 @@ struct Lane {
         const size_t ti = ix(trig);
         uint32_t tm = v.s_meta[ti];
         tm |= 1u << (peer + M_PACKS_SH);                        // :228
-        v.s_meta[ti] = tm;
+        if (wr) v.s_meta[ti] = tm;
         if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
         bpd = ballot;                                           // :236
         int chase = 0;                                          // 0 not started, 1 running, 2 over
@@ -413,13 +430,13 @@ struct Lane {
                         m |= 1u << (me + M_ACKS_SH);
                         if ((uint32_t)__popc(m_acks(m)) >= P.thresh) {   // only with a 1-ack threshold
                             m = m_set_st(m, SMR_ST_COMMITTED);
-                            v.s_meta[ix(s)] = m;
+                            if (wr) v.s_meta[ix(s)] = m;
                             record_commit(s);
                             commit_complete<2>(s, m);
                             m = v.s_meta[ix(s)];
                         }
                     }
-                    v.s_meta[ix(s)] = m;
+                    if (wr) v.s_meta[ix(s)] = m;
                 }
                 if (chase == 0 && moved && s == abar) chase = 1;            // durability.rs:134
                 if (chase == 1 && s == abar) {
@@ -444,9 +461,9 @@ struct Lane {
             uint32_t this_slot = len;
             if (!push_null()) return;
             size_t i = ix(this_slot);
-            v.s_bal[i] = bps;
-            v.s_ltrig[i] = trig; v.s_lendp[i] = my_endp; v.s_pmax[i] = 0;
-            v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
+            if (wr) v.s_bal[i] = bps;
+            if (wr) v.s_ltrig[i] = trig; if (wr) v.s_lendp[i] = my_endp; if (wr) v.s_pmax[i] = 0;
+            if (wr) v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
             // its PrepareBal completion is a no-op on the leader (this_slot > endprep)
         }
         {
@@ -457,12 +474,12 @@ struct Lane {
             if (has_voted && (m & M_LBK)) {                     // :203-216
                 uint64_t pm = (m & M_LBKX) ? v.s_pmax[i] : 0;
                 if (vbal > pm) {
-                    if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
-                    v.s_pmax[i] = vbal;
+                    if (!(m & M_LBKX)) { if (wr) v.s_ltrig[i] = 0; if (wr) v.s_lendp[i] = 0; m |= M_LBKX; }
+                    if (wr) v.s_pmax[i] = vbal;
                     m = materialize_voted(i, m, b, v.s_val[i]);
-                    v.s_val[i] = vval;                          // inst.reqs = val
+                    if (wr) v.s_val[i] = vval;                          // inst.reqs = val
                     m = vval ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                    v.s_meta[i] = m;
+                    if (wr) v.s_meta[i] = m;
                 }
             }
         }
@@ -504,12 +521,12 @@ struct Lane {
                     const uint64_t cur = (m & M_LBKX) ? pm[k] : 0ull;
                     if (vb[k] > cur) {
                         const size_t i = ix(slot);
-                        if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
-                        v.s_pmax[i] = vb[k];
+                        if (!(m & M_LBKX)) { if (wr) v.s_ltrig[i] = 0; if (wr) v.s_lendp[i] = 0; m |= M_LBKX; }
+                        if (wr) v.s_pmax[i] = vb[k];
                         m = materialize_voted(i, m, bb[k], v.s_val[i]);
-                        v.s_val[i] = vv[k];
+                        if (wr) v.s_val[i] = vv[k];
                         m = vv[k] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                        v.s_meta[i] = m;
+                        if (wr) v.s_meta[i] = m;
                     }
                 }
                 if (slot == endp && m_st(m) == SMR_ST_PREPARING && ballot >= bb[k])   // :196-198, :222
@@ -528,7 +545,7 @@ struct Lane {
         leader = me;                                            // :98
         // :104 bcast_heartbeats() now, still carrying the old bal_max_seen (:240-247)
         ob_push(par, OB_HEARTBEAT, cbar, bms, ebar, snap);
-        for (uint32_t p = 0; p < P.R; p++) v.peer_exec_bar[(size_t)p * P.G + g] = 0;   // :107-109
+        for (uint32_t p = 0; p < P.R; p++) if (wr) v.peer_exec_bar[(size_t)p * P.G + g] = 0;   // :107-109
         bpd = 0;                                                // :112-114
         bps = make_greater_ballot(bms);
         bms = bps;
@@ -557,7 +574,7 @@ struct Lane {
                 const uint32_t st = m_st(m);
                 if (st == SMR_ST_EXECUTED) continue;
                 m |= M_EXT;
-                if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
+                if (st == SMR_ST_COMMITTED) { if (wr) v.s_meta[i] = m; continue; }
                 uint64_t vb; uint32_t vv;
                 get_voted(i, m, bb[k], vl[k], vb, vv);
                 m = materialize_voted(i, m, bb[k], vl[k]);
@@ -568,12 +585,12 @@ struct Lane {
                 // keep the value I voted for, if any (messages.rs:203-216 with prepare_max_bal == 0)
                 if (self_ok && s <= endp && vb > 0) {
                     pmax = vb;
-                    if (vv != vl[k]) v.s_val[i] = vv;
+                    if (vv != vl[k]) if (wr) v.s_val[i] = vv;
                     m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                 }
-                v.s_bal[i] = bps;
-                v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = pmax;
-                v.s_meta[i] = m;
+                if (wr) v.s_bal[i] = bps;
+                if (wr) v.s_ltrig[i] = trig; if (wr) v.s_lendp[i] = endp; if (wr) v.s_pmax[i] = pmax;
+                if (wr) v.s_meta[i] = m;
             }
         }
         ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
@@ -611,20 +628,20 @@ struct Lane {
                 uint64_t vb; uint32_t vv;
                 get_voted(i, m, bb[k], vl[k], vb, vv);
                 m = materialize_voted(i, m, bb[k], vl[k]);
-                v.s_bal[i] = ballot;
+                if (wr) v.s_bal[i] = ballot;
                 m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
-                v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
-                v.s_meta[i] = m;
+                if (wr) v.s_rtrig[i] = trig; if (wr) v.s_rendp[i] = endp;
+                if (wr) v.s_meta[i] = m;
                 if (follower) {                                 // durability.rs:50-78
                     size_t o = (size_t)(s - trig) * P.G + g;
-                    v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
+                    if (wr) v.pr_vbal[o] = vb; if (wr) v.pr_vval[o] = vv;
                 }
             }
         }
         if (follower) {
-            v.pr_dest[g] = (uint8_t)peer; v.pr_trig[g] = trig; v.pr_endp[g] = endp;
-            v.pr_bal[g] = ballot; v.pr_abar[g] = abar;
-            v.pr_cnt[g] = n;
+            if (wr) v.pr_dest[g] = (uint8_t)peer; if (wr) v.pr_trig[g] = trig; if (wr) v.pr_endp[g] = endp;
+            if (wr) v.pr_bal[g] = ballot; if (wr) v.pr_abar[g] = abar;
+            if (wr) v.pr_cnt[g] = n;
         }
     }
 
@@ -648,9 +665,9 @@ struct Lane {
         m = m_set_src(m, peer);
         m = m_set_vmode(m, VM_SAME);                            // :351 voted = (ballot, reqs)
         m = reqs ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-        v.s_bal[i] = ballot;
-        v.s_val[i] = reqs;
-        v.s_meta[i] = m;
+        if (wr) v.s_bal[i] = ballot;
+        if (wr) v.s_val[i] = reqs;
+        if (wr) v.s_meta[i] = m;
         uint64_t reply = 0;
         if (is_leader()) accept_reply(me, slot, ballot);        // durability.rs:99-103 (not reachable: a
                                                                 // peer's ballot >= mine deposes me)
@@ -687,7 +704,7 @@ struct Lane {
                         if (bb[k] < ballot || st < SMR_ST_ACCEPTING) { go = false; break; }
                         if (st < SMR_ST_COMMITTED) {
                             uint32_t m = m_set_st(mm[k], SMR_ST_COMMITTED);
-                            v.s_meta[ix(s)] = m;
+                            if (wr) v.s_meta[ix(s)] = m;
                             if (first == 0xFFFFFFFFu) { first = s; first_m = m; }
                         }
                         s++;
@@ -700,7 +717,7 @@ struct Lane {
         if (peer != me) {                                       // :320-342
             size_t po = (size_t)peer * P.G + g;
             if (hb_exec > v.peer_exec_bar[po]) {
-                v.peer_exec_bar[po] = hb_exec;
+                if (wr) v.peer_exec_bar[po] = hb_exec;
                 uint32_t passed = 1;
                 for (uint32_t p = 0; p < P.R; p++)
                     if (p != me && v.peer_exec_bar[(size_t)p * P.G + g] >= hb_exec) passed++;

@@ -14,18 +14,41 @@
 
 namespace smr {
 
-__device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
-    // wave-reduce the three counters, one atomic per wave
+// wave-reduce the three counters, one atomic per wave; `job` = what the wave's
+// cooperative jobs counted (wave-uniform, added once)
+__device__ __forceinline__ void flush_counters(const Lane &L, bool active, const unsigned int (&job)[3]) {
     unsigned int c0 = active ? L.n_commit : 0, c1 = active ? L.n_redirect : 0, c2 = active ? L.n_reject : 0;
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_xor(c0, off);
         c1 += __shfl_xor(c1, off);
         c2 += __shfl_xor(c2, off);
     }
+    c0 += job[0]; c1 += job[1]; c2 += job[2];
     if (__lane_id() == 0) {
         if (c0) atomicAdd((unsigned long long *)&L.v.counters[0], (unsigned long long)c0);
         if (c1) atomicAdd((unsigned long long *)&L.v.counters[1], (unsigned long long)c1);
         if (c2) atomicAdd((unsigned long long *)&L.v.counters[2], (unsigned long long)c2);
+    }
+}
+
+// Rare, long-running work (leader changes) is not run by one lane while 63 idle: the
+// wavefront takes the lanes that need it one at a time and ALL 64 lanes execute that
+// lane's (group, replica) handler in uniform mode (Lane::set_uniform), slot loops
+// strided by lane.  `pending` = this lane has such a job.
+#define SMR_FOR_EACH_JOB(pending, src)                                            \
+    for (unsigned long long _jm = __ballot(pending); _jm; _jm &= _jm - 1)        \
+        if (const int src = __ffsll((long long)_jm) - 1; true)
+
+// ---- R1 ---------------------------------------------------------------------
+__device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__restrict__ req_val, uint32_t k0,
+                                                   uint32_t n_req) {
+    for (; k0 < n_req && !L.ovf; k0 += 8) {                      // 8 token loads per batch
+        uint32_t tok[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tok[k] = (k0 + k < n_req) ? req_val[(size_t)(k0 + k) * L.P.G + L.g] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k0 + k < n_req && !L.ovf) L.req_batch(tok[k]);
     }
 }
 
@@ -40,21 +63,20 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams P, int par,
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
     bool active = g < P.G && !P.overflow[g];
-    bool has_to = active && timeout_rep && timeout_rep[g] == r;
+    const bool has_to = active && timeout_rep && timeout_rep[g] == r;
     uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
     if (n_req > S) n_req = S;
-    active = has_to || n_req > 0;
+    active = !has_to && n_req > 0;
     if (active) {
         L.load();
-        if (has_to) L.become_a_leader(timeout_src[g]);
         uint32_t k0 = 0;
         // Steady-state fast path: a prepared leader whose log has no holes and
         // whose accept_bar sits at the log end appends all n_req batches as a
         // tight store-only loop.  Exactly what req_batch() does per batch in that
         // state (first_null_slot -> push, fresh LeaderBookkeeping + self ack,
         // Accept bcast, accept_bar + 1), with the array pointers hoisted.
-        if (!L.ovf && n_req && L.is_leader() && L.bpd != 0 && P.thresh > 1 && L.nlb >= L.len &&
-            L.abar == L.len && (L.len - L.start) + n_req - 1 + P.win_reserve < P.W) {
+        if (L.is_leader() && L.bpd != 0 && P.thresh > 1 && L.nlb >= L.len && L.abar == L.len &&
+            (L.len - L.start) + n_req - 1 + P.win_reserve < P.W) {
             L.ob_load(par);
             const uint32_t c0 = par == 0 ? L.obn0 : L.obn1;
             if (c0 + n_req <= P.cap) {
@@ -84,17 +106,60 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams P, int par,
                 k0 = n_req;
             }
         }
-        for (; k0 < n_req && !L.ovf; k0 += 8) {                  // generic path, 8 token loads per batch
-            uint32_t tok[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) tok[k] = (k0 + k < n_req) ? req_val[(size_t)(k0 + k) * P.G + g] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (k0 + k < n_req && !L.ovf) L.req_batch(tok[k]);
-        }
+        r1_generic_batches(L, req_val, k0, n_req);
         L.store();
     }
-    flush_counters(L, active);
+    unsigned int jc[3] = {0, 0, 0};
+    SMR_FOR_EACH_JOB(has_to, src) {                             // leader change: the whole wave on one lane's group
+        const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src);
+        Lane J(P, r, gj, par);
+        J.set_uniform();
+        J.load();
+        J.become_a_leader(timeout_src[gj]);
+        r1_generic_batches(J, req_val, 0, nj);
+        J.store();
+        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+    }
+    flush_counters(L, active, jc);
+}
+
+// ---- R2 ---------------------------------------------------------------------
+// every outbox but mine, sender-major, FIFO; `first_sender` / `first_j`: resume point
+// left by the fast path
+__device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint32_t first_j) {
+    const MpParams &P = L.P;
+    const uint32_t g = L.g, r = L.me;
+    const int par = L.par;
+    for (uint32_t s = first_sender; s < P.R && !L.ovf; s++) {
+        if (s == r) continue;
+        const MpRep &snd = P.rep[s];
+        const uint32_t cnt = snd.ob_cnt[par][g];
+        for (uint32_t j0 = (s == first_sender ? first_j : 0u); j0 < cnt && !L.ovf; j0 += 8) {   // 8 messages per batch
+            uint32_t e[8], val[8]; uint64_t bal[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bool in = j0 + k < cnt;
+                size_t o = (size_t)(j0 + k) * P.G + g;
+                e[k] = in ? snd.ob_slot[par][o] : 0u;
+                bal[k] = in ? snd.ob_bal[par][o] : 0ull;
+                val[k] = in ? snd.ob_val[par][o] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (j0 + k >= cnt || L.ovf) break;
+                const uint32_t j = j0 + k;
+                const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
+                if (kind == OB_ACCEPT) {
+                    uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
+                    if (L.wr) snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
+                } else if (kind == OB_PREPARE) {
+                    L.msg_prepare(s, slot, bal[k]);
+                } else if (kind == OB_HEARTBEAT) {
+                    L.heard_heartbeat(s, bal[k], slot, val[k], snd.ob_aux[par][(size_t)j * P.G + g]);
+                }
+            }
+        }
+    }
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
@@ -103,27 +168,30 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int pa
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
     bool active = g < P.G && !P.overflow[g];
+    bool job = false;
+    uint32_t job_sender = 0, job_j = 0;
+    bool loaded = false;
     if (active) {
-        bool loaded = false;
         if (L.v.pr_cnt[g]) L.v.pr_cnt[g] = 0;
         uint32_t cnts[MAXR];
-        uint32_t n_senders = 0, the_sender = 0;
+        uint32_t n_senders = 0, the_sender = 0, first = MAXR;
 #pragma unroll
         for (int s = 0; s < MAXR; s++) {
             cnts[s] = ((uint32_t)s < P.R && (uint32_t)s != r) ? P.rep[s].ob_cnt[par][g] : 0u;
-            if (cnts[s]) { n_senders++; the_sender = (uint32_t)s; }
+            if (cnts[s]) { n_senders++; the_sender = (uint32_t)s; if (first == MAXR) first = (uint32_t)s; }
         }
-        uint32_t fast_done = 0;
+        uint32_t fast_done = 0, the_cnt = 0;
         // Steady-state fast path: the only sender is the leader I already follow and
         // each message is an Accept at my bal_max_seen for the slot right at my log
         // end, with accept_bar at the log end too.  Per message this is exactly
         // msg_accept(): check_leader is a no-op (ballot == bal_max_seen), push + fill
         // fused (fresh ReplicaBookkeeping, voted = (ballot, reqs)), the WAL completion
         // answers with the ballot, accept_bar + 1.  The first message that does not
-        // fit hands the rest of the outbox to the generic handlers below.
+        // fit hands the rest of the outbox to the generic handlers.
         if (n_senders == 1) {
             L.load(); loaded = true;
             const uint32_t s = the_sender;
+            the_cnt = cnts[s];
             if (L.leader == s && L.abar == L.len) {
                 const MpRep &snd = P.rep[s];
                 const MpRep &v = P.rep[r];
@@ -160,42 +228,125 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int pa
                 L.len = len; L.abar = len;
             }
         }
-        for (uint32_t s = 0; s < P.R; s++) {
-            if (s == r) continue;
-            const MpRep &snd = P.rep[s];
-            const uint32_t cnt = snd.ob_cnt[par][g];
-            for (uint32_t j0 = (s == the_sender ? fast_done : 0u); j0 < cnt && !L.ovf; j0 += 8) {   // 8 messages per batch
-                if (!loaded) { L.load(); loaded = true; }
-                uint32_t e[8], val[8]; uint64_t bal[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    bool in = j0 + k < cnt;
-                    size_t o = (size_t)(j0 + k) * P.G + g;
-                    e[k] = in ? snd.ob_slot[par][o] : 0u;
-                    bal[k] = in ? snd.ob_bal[par][o] : 0ull;
-                    val[k] = in ? snd.ob_val[par][o] : 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (j0 + k >= cnt || L.ovf) break;
-                    const uint32_t j = j0 + k;
-                    const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
-                    if (kind == OB_ACCEPT) {
-                        uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
-                        snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
-                    } else if (kind == OB_PREPARE) {
-                        L.msg_prepare(s, slot, bal[k]);
-                    } else if (kind == OB_HEARTBEAT) {
-                        L.heard_heartbeat(s, bal[k], slot, val[k], snd.ob_aux[par][(size_t)j * P.G + g]);
-                    }
-                }
-            }
-            if (L.ovf) break;
-        }
+        // whatever is left goes to the wave as a cooperative job
+        if (n_senders > 1) { job = true; job_sender = first; job_j = 0; }
+        else if (n_senders == 1 && fast_done < the_cnt) { job = true; job_sender = the_sender; job_j = fast_done; }
         if (loaded) L.store();
-        active = loaded;
     }
-    flush_counters(L, active);
+    unsigned int jc[3] = {0, 0, 0};
+    SMR_FOR_EACH_JOB(job, src) {
+        const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src);
+        Lane J(P, r, gj, par);
+        J.set_uniform();
+        J.load();
+        r2_generic(J, sj, jj);
+        J.store();
+        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+    }
+    flush_counters(L, active && loaded, jc);
+}
+
+// ---- R3 ---------------------------------------------------------------------
+// (a) PrepareReplies addressed to me: sender order of the tick's ackctl word, FIFO per sender
+__device__ __forceinline__ void r3_prepare_replies(Lane &L, uint32_t tickctl) {
+    const MpParams &P = L.P;
+    const uint32_t g = L.g, d = L.me;
+    for (uint32_t oi = 0; oi < P.R; oi++) {
+        uint32_t s = ctl_order(tickctl, oi);
+        if (s == d || s >= P.R) continue;
+        const MpRep &snd = P.rep[s];
+        uint32_t n = snd.pr_cnt[g];
+        if (n == 0 || snd.pr_dest[g] != d) continue;
+        L.prepare_reply_batch(s, snd.pr_trig[g], snd.pr_endp[g], snd.pr_bal[g], n, snd.pr_vbal, snd.pr_vval);
+    }
+}
+
+// (b) AcceptReplies to my Accepts of this tick: the ack matrix of my outbox, entry-major,
+// per-entry peer order / loss from ackctl; C rows per batch of loads, tally in registers
+__device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__restrict__ ackctl, uint32_t cnt) {
+    const MpParams &P = L.P;
+    const uint32_t g = L.g, d = L.me;
+    const int par = L.par;
+    const MpRep &v = P.rep[d];
+    constexpr int C = 4;                                         // ack-matrix rows per batch of loads
+    SMR_G const uint32_t *const os = v.ob_slot[par]; SMR_G const uint64_t *const ack = v.ack;
+    SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
+    const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
+    const bool lead = L.is_leader();
+    const uint64_t bpd = L.bpd;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
+        uint32_t e[C], ctl[C], m[C];
+        uint64_t a[C][MAXR], b[C];
+        bool have[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) {                            // wave 1: everything addressed by (j, g) alone
+            const bool in = j0 + k < cnt;
+            const size_t o = (size_t)(j0 + k) * G + g;
+            e[k] = in ? os[o] : 0u;
+            ctl[k] = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
+#pragma unroll
+            for (int q = 0; q < MAXR; q++)
+                a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)(j0 + k) * R + q) * G + g] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < C; k++) {                            // wave 2: the slots those Accepts name
+            const uint32_t slot = e[k] & OB_SLOT_MASK;
+            have[k] = (e[k] >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
+            const size_t i = (size_t)(slot & Wm) * G + g;
+            m[k] = have[k] ? sm[i] : 0u;
+            b[k] = have[k] ? sb[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            if (!have[k]) continue;
+            const uint32_t slot = e[k] & OB_SLOT_MASK;
+            const int kn = k + 1 < C ? k + 1 : k;
+            const bool next_known = k + 1 < C && have[kn] && (e[kn] & OB_SLOT_MASK) == slot + 1;
+            // The row's replies applied in registers: same filter chain as
+            // accept_reply() / accept_entry() (messages.rs:377-412).
+            uint32_t mk = m[k];
+            if (!lead || !(mk & M_LBK)) continue;
+            const uint32_t drop = ctl_drop(ctl[k]);
+            bool changed = false, committed = false;
+#pragma unroll
+            for (int oi = 0; oi < MAXR; oi++) {
+                const uint32_t s = ctl_order(ctl[k], oi);
+                if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
+                uint64_t av = 0;
+#pragma unroll
+                for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
+                if (av == 0 || av != bpd) continue;
+                if (m_st(mk) != SMR_ST_ACCEPTING || av < b[k]) continue;
+                const uint32_t bit = 1u << (s + M_ACKS_SH);
+                if (mk & bit) continue;
+                mk |= bit;
+                changed = true;
+                if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
+            }
+            if (!changed) continue;
+            const size_t i = (size_t)(slot & Wm) * G + g;
+            if (!committed) { if (L.wr) sm[i] = mk; continue; }
+            L.record_commit(slot);
+            // commit_complete() in its common shape, in registers: the slot sits at
+            // commit_bar == exec_bar below accept_bar with a non-empty batch, and the
+            // run ends right behind it (next slot still Accepting, or the log ends).
+            const bool stops = (next_known && m_st(m[kn]) < SMR_ST_COMMITTED) || (slot + 1 >= L.abar && slot + 1 >= L.len);
+            if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
+                if (L.wr) sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
+                L.cbar = slot + 1;
+                L.ebar = slot + 1;
+            } else {
+                if (L.wr) sm[i] = mk;
+                L.commit_complete<2>(slot, mk, next_known ? m[kn] : 0xFFFFFFFFu);
+            }
+        }
+    }
+    L.ob_set(par, 0);                                            // outbox consumed
+}
+
+__device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.rs:240-247 record
+    const MpRep &v = L.v;
+    if (L.wr) { v.hb_bal[L.g] = L.bms; v.hb_commit[L.g] = L.cbar; v.hb_exec[L.g] = L.ebar; v.hb_snap[L.g] = L.snap; }
 }
 
 // R3: replies reach their destination: PrepareReplies (sender order of the
@@ -208,107 +359,39 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams P, int pa
     const uint32_t d = blockIdx.y;
     Lane L(P, d, g < P.G ? g : 0, par);
     bool active = g < P.G && !P.overflow[g];
-    bool loaded = false;
+    bool loaded = false, job = false;
     if (active) {
         const MpRep &v = P.rep[d];
         const uint32_t tickctl = ackctl ? ackctl[g] : SMR_CTL_IDENTITY;
-        // (a) PrepareReplies addressed to me
-        for (uint32_t oi = 0; oi < P.R; oi++) {
-            uint32_t s = ctl_order(tickctl, oi);
-            if (s == d || s >= P.R) continue;
-            const MpRep &snd = P.rep[s];
-            uint32_t n = snd.pr_cnt[g];
-            if (n == 0 || snd.pr_dest[g] != d) continue;
-            if (!loaded) { L.load(); loaded = true; }
-            L.prepare_reply_batch(s, snd.pr_trig[g], snd.pr_endp[g], snd.pr_bal[g], n, snd.pr_vbal, snd.pr_vval);
-        }
-        // (b) AcceptReplies to my Accepts of this tick
+        bool has_pr = false;
+#pragma unroll
+        for (int s = 0; s < MAXR; s++)
+            if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[g] != 0 && P.rep[s].pr_dest[g] == d) has_pr = true;
         const uint32_t cnt = v.ob_cnt[par][g];
-        if (cnt) {
-            if (!loaded) { L.load(); loaded = true; }
-            constexpr int C = 4;                                 // ack-matrix rows per batch of loads
-            SMR_G const uint32_t *const os = v.ob_slot[par]; SMR_G const uint64_t *const ack = v.ack;
-            SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
-            const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
-            const bool lead = L.is_leader();
-            const uint64_t bpd = L.bpd;
-            for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
-                uint32_t e[C], ctl[C], m[C];
-                uint64_t a[C][MAXR], b[C];
-                bool have[C];
-#pragma unroll
-                for (int k = 0; k < C; k++) {                    // wave 1: everything addressed by (j, g) alone
-                    const bool in = j0 + k < cnt;
-                    const size_t o = (size_t)(j0 + k) * G + g;
-                    e[k] = in ? os[o] : 0u;
-                    ctl[k] = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
-#pragma unroll
-                    for (int q = 0; q < MAXR; q++)
-                        a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)(j0 + k) * R + q) * G + g] : 0ull;
-                }
-#pragma unroll
-                for (int k = 0; k < C; k++) {                    // wave 2: the slots those Accepts name
-                    const uint32_t slot = e[k] & OB_SLOT_MASK;
-                    have[k] = (e[k] >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
-                    const size_t i = (size_t)(slot & Wm) * G + g;
-                    m[k] = have[k] ? sm[i] : 0u;
-                    b[k] = have[k] ? sb[i] : 0ull;
-                }
-#pragma unroll
-                for (int k = 0; k < C; k++) {
-                    if (!have[k]) continue;
-                    const uint32_t slot = e[k] & OB_SLOT_MASK;
-                    const int kn = k + 1 < C ? k + 1 : k;
-                    const bool next_known = k + 1 < C && have[kn] && (e[kn] & OB_SLOT_MASK) == slot + 1;
-                    // The row's replies applied in registers: same filter chain as
-                    // accept_reply() / accept_entry() (messages.rs:377-412).
-                    uint32_t mk = m[k];
-                    if (!lead || !(mk & M_LBK)) continue;
-                    const uint32_t drop = ctl_drop(ctl[k]);
-                    bool changed = false, committed = false;
-#pragma unroll
-                    for (int oi = 0; oi < MAXR; oi++) {
-                        const uint32_t s = ctl_order(ctl[k], oi);
-                        if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
-                        uint64_t av = 0;
-#pragma unroll
-                        for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
-                        if (av == 0 || av != bpd) continue;
-                        if (m_st(mk) != SMR_ST_ACCEPTING || av < b[k]) continue;
-                        const uint32_t bit = 1u << (s + M_ACKS_SH);
-                        if (mk & bit) continue;
-                        mk |= bit;
-                        changed = true;
-                        if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
-                    }
-                    if (!changed) continue;
-                    const size_t i = (size_t)(slot & Wm) * G + g;
-                    if (!committed) { sm[i] = mk; continue; }
-                    L.record_commit(slot);
-                    // commit_complete() in its common shape, in registers: the slot sits at
-                    // commit_bar == exec_bar below accept_bar with a non-empty batch, and the
-                    // run ends right behind it (next slot still Accepting, or the log ends).
-                    const bool stops = (next_known && m_st(m[kn]) < SMR_ST_COMMITTED) ||
-                                       (slot + 1 >= L.abar && slot + 1 >= L.len);
-                    if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
-                        sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
-                        L.cbar = slot + 1;
-                        L.ebar = slot + 1;
-                    } else {
-                        sm[i] = mk;
-                        L.commit_complete<2>(slot, mk, next_known ? m[kn] : 0xFFFFFFFFu);
-                    }
-                }
-            }
-            L.ob_set(par, 0);                                    // outbox consumed
+        // a leader change in flight (PrepareReplies for me, or the long outbox of the
+        // re-Accept round) is a cooperative job for the whole wave
+        job = has_pr || cnt > 64;
+        if (!job) {
+            if (cnt) { L.load(); loaded = true; r3_accept_replies(L, ackctl, cnt); }
+            if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
+            if (loaded) L.store();
         }
-        if (publish_hb) {                                        // leadership.rs:240-247 record
-            if (!loaded) { L.load(); loaded = true; }
-            v.hb_bal[g] = L.bms; v.hb_commit[g] = L.cbar; v.hb_exec[g] = L.ebar; v.hb_snap[g] = L.snap;
-        }
-        if (loaded) L.store();
+        (void)tickctl;
     }
-    flush_counters(L, active && loaded);
+    unsigned int jc[3] = {0, 0, 0};
+    SMR_FOR_EACH_JOB(job, src) {
+        const uint32_t gj = __shfl(g, src);
+        Lane J(P, d, gj, par);
+        J.set_uniform();
+        J.load();
+        r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
+        const uint32_t cnt = P.rep[d].ob_cnt[par][gj];
+        if (cnt) r3_accept_replies(J, ackctl, cnt);
+        if (publish_hb) r3_publish_hb(J);
+        J.store();
+        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+    }
+    flush_counters(L, active && loaded, jc);
 }
 
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
@@ -335,7 +418,8 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams P, int 
         if (bound > L.start) L.start = bound;
         L.store();
     }
-    flush_counters(L, active);
+    const unsigned int nojob[3] = {0, 0, 0};
+    flush_counters(L, active, nojob);
 }
 
 // ------------------------------------------------------------------ host ---
