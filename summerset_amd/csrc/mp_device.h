@@ -29,6 +29,16 @@ __device__ __forceinline__ uint32_t m_set_src(uint32_t m, uint32_t s) {
 __device__ __forceinline__ uint32_t ctl_order(uint32_t ctl, int i) { return (ctl >> (3 * i)) & 7u; }
 __device__ __forceinline__ uint32_t ctl_drop(uint32_t ctl) { return ctl >> 24; }
 
+// wave-wide reductions (all 64 lanes must be active: uniform mode only)
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
+    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off); x = y < x ? y : x; }
+    return x;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+    for (int off = 32; off > 0; off >>= 1) { uint32_t y = __shfl_xor(x, off); x = y > x ? y : x; }
+    return x;
+}
+
 // Lane context: the group's scalar state of one replica cached in registers.
 struct Lane {
     const MpParams &P;
@@ -118,12 +128,17 @@ struct Lane {
     }
 
     // Instance::voted accessors
-    __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val) {
+    // `w`: does this lane commit the stores (uniform mode: lane 0, unless the caller is a
+    // lane-strided loop in which every lane owns its slots)
+    __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val, bool w) {
         if (m_vmode(m) == VM_SAME) {
-            if (wr) v.s_vbal[i] = bal; if (wr) v.s_vval[i] = val;
+            if (w) { v.s_vbal[i] = bal; v.s_vval[i] = val; }
             m = m_set_vmode(m, VM_SIDE);
         }
         return m;
+    }
+    __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val) {
+        return materialize_voted(i, m, bal, val, wr);
     }
     __device__ __forceinline__ void get_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val, uint64_t &vb,
                                               uint32_t &vv) const {
@@ -363,34 +378,26 @@ struct Lane {
         accept_bar_scan(slot);                                  // durability.rs:134-142
     }
 
-    // first slot of [lo, hi) whose status is below `bound`, else hi (16 metas per batch of loads)
+    // first slot of [lo, hi) whose status is below `bound`, else hi.  Lane-strided in
+    // uniform mode (each lane checks every 64th slot, then a wave-wide min).
     __device__ __forceinline__ uint32_t first_status_below(uint32_t lo, uint32_t hi, uint32_t bound) const {
-        for (uint32_t s = lo; s < hi; s += 16) {
-            uint32_t mm[16];
-            fetch_meta<16>(s, hi, mm);
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (s + k < hi && m_st(mm[k]) < bound) return s + k;
-        }
-        return hi;
+        uint32_t found = hi;
+        for (uint32_t s = lo + cl; s < hi; s += cn)
+            if (m_st(v.s_meta[ix(s)]) < bound) { found = s; break; }
+        return coop() ? wave_min(found) : found;
     }
     // last slot of [lo, hi) whose status is below `bound` (below = true) or above it, else `none`
     __device__ __forceinline__ uint32_t last_status(uint32_t lo, uint32_t hi, uint32_t bound, bool below,
                                                     uint32_t none) const {
-        uint32_t top = hi;
-        while (top > lo) {
-            const uint32_t base = top - lo >= 8 ? top - 8 : lo;
-            uint32_t mm[8];
-            fetch_meta<8>(base, top, mm);
-#pragma unroll
-            for (int k = 7; k >= 0; k--) {
-                if (base + k >= top) continue;
-                const uint32_t st = m_st(mm[k]);
-                if (below ? st < bound : st > bound) return base + k;
+        uint32_t found = 0;                                       // slot + 1, 0 = none
+        if (hi > lo)
+            for (uint32_t t = cl; t < hi - lo; t += cn) {          // t-th slot from the top
+                const uint32_t s = hi - 1 - t;
+                const uint32_t st = m_st(v.s_meta[ix(s)]);
+                if (below ? st < bound : st > bound) { found = s + 1; break; }
             }
-            top = base;
-        }
-        return none;
+        if (coop()) found = wave_max(found);
+        return found ? found - 1 : none;
     }
 
     // messages.rs:219-287: the sender's PrepareReplies are complete up to its
@@ -407,6 +414,54 @@ struct Lane {
         if (wr) v.s_meta[ti] = tm;
         if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
         bpd = ballot;                                           // :236
+        if (coop() && P.thresh > 1) {
+            // 64 consecutive slots per step, one per lane: the Accepts go to the outbox in slot
+            // order (ballot + prefix count), the accept_bar scan runs on the bitmaps.
+            ob_load(par ^ 1);
+            uint32_t c = (par ^ 1) == 0 ? obn0 : obn1;
+            int chase = 0;
+            for (uint32_t base = trig; base < len; base += 64) {
+                const uint32_t sl = base + cl;
+                const bool in = sl < len;
+                const size_t i = ix(sl);
+                uint32_t m = in ? v.s_meta[i] : 0u;
+                const bool moved = in && m_st(m) == SMR_ST_PREPARING;
+                if (moved) {
+                    m = m_set_st(m, SMR_ST_ACCEPTING);
+                    if (v.s_bal[i] == ballot && (m & M_LBK) && !(m_acks(m) & (1u << me))) m |= 1u << (me + M_ACKS_SH);
+                    v.s_meta[i] = m;
+                }
+                const unsigned long long mv = __ballot(moved);
+                const unsigned long long acc = __ballot(in && m_st(m) >= SMR_ST_ACCEPTING);
+                if (moved) {
+                    const uint32_t pos = c + (uint32_t)__popcll(mv & ((1ull << cl) - 1ull));
+                    if (pos < P.cap) {
+                        const size_t o = (size_t)pos * P.G + g;
+                        v.ob_slot[par ^ 1][o] = (OB_ACCEPT << OB_KIND_SH) | (sl & OB_SLOT_MASK);
+                        v.ob_bal[par ^ 1][o] = ballot;
+                        v.ob_val[par ^ 1][o] = v.s_val[i];
+                    }
+                }
+                c += (uint32_t)__popcll(mv);
+                // durability.rs:134-142 on the bitmaps: the scan starts at the completion of the
+                // moved slot sitting AT accept_bar and runs while slots are >= Accepting
+                if (chase != 2 && abar >= base && abar < base + 64 && abar < len) {
+                    const uint32_t pbit = abar - base;
+                    if (chase == 0 && ((mv >> pbit) & 1ull)) chase = 1;
+                    if (chase == 1) {
+                        const unsigned long long run = ~(acc >> pbit);           // first 0 = first slot < Accepting
+                        uint32_t n = run ? (uint32_t)(__ffsll((long long)run) - 1) : 64u - pbit;
+                        if (n > 64u - pbit) n = 64u - pbit;
+                        abar += n;
+                        if (abar < base + 64 && abar < len) chase = 2;           // stopped inside the chunk
+                        if (abar > len) abar = len;
+                    }
+                }
+            }
+            if (c > P.cap) { ovf = true; c = P.cap; }
+            if ((par ^ 1) == 0) obn0 = c; else obn1 = c;
+            return;
+        }
         int chase = 0;                                          // 0 not started, 1 running, 2 over
         for (uint32_t s0 = trig; s0 < len; s0 += 8) {           // :238-286
             uint32_t mm[8], vv[8]; uint64_t bb[8];
@@ -497,41 +552,38 @@ struct Lane {
         if (ballot != bps || !is_leader()) return;              // :110-114
         if (trig < start || trig >= len) return;                // :97-99 (slot >= trig), :116-119
         if (!(v.s_meta[ix(trig)] & M_LBK)) return;              // :120-125
-        for (uint32_t k0 = 0; k0 < n && !ovf; k0 += 8) {
-            uint32_t mm[8], vv[8]; uint64_t bb[8], pm[8], vb[8];
-            const uint32_t len0 = len;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t slot = trig + k0 + k;
-                const bool in = k0 + k < n, mine = in && slot < len0;
-                const size_t o = (size_t)(k0 + k) * P.G + g, i = ix(slot);
-                vb[k] = in ? pr_vbal[o] : 0ull; vv[k] = in ? pr_vval[o] : 0u;
-                mm[k] = mine ? v.s_meta[i] : 0u; bb[k] = mine ? v.s_bal[i] : 0ull; pm[k] = mine ? v.s_pmax[i] : 0ull;
+        const uint32_t len0 = len;
+        const uint32_t n_mine = trig + n <= len0 ? n : len0 - trig;      // replies for slots I already hold
+        for (uint32_t k = cl; k < n_mine; k += cn) {             // :196-216, every lane owns its slots
+            const uint32_t slot = trig + k;
+            const size_t o = (size_t)k * P.G + g, i = ix(slot);
+            const uint64_t vb = pr_vbal[o];
+            if (vb == 0) continue;                               // voted: None
+            uint32_t m = v.s_meta[i];
+            const uint64_t b = v.s_bal[i];
+            if (m_st(m) != SMR_ST_PREPARING || ballot < b || !(m & M_LBK)) continue;
+            const uint64_t cur = (m & M_LBKX) ? v.s_pmax[i] : 0ull;
+            if (vb > cur) {
+                const uint32_t vv = pr_vval[o];
+                if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
+                v.s_pmax[i] = vb;
+                m = materialize_voted(i, m, b, v.s_val[i], true);
+                v.s_val[i] = vv;
+                m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                v.s_meta[i] = m;
             }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (k0 + k >= n || ovf) break;
-                const uint32_t slot = trig + k0 + k;
-                if (slot >= len0) {                             // unknown slot: pad + reply, the long way
-                    prepare_reply(peer, slot, trig, endp, ballot, vb[k] > 0, vb[k], vv[k]);
-                    continue;
-                }
-                uint32_t m = mm[k];
-                if (m_st(m) == SMR_ST_PREPARING && ballot >= bb[k] && vb[k] > 0 && (m & M_LBK)) {   // :196-216
-                    const uint64_t cur = (m & M_LBKX) ? pm[k] : 0ull;
-                    if (vb[k] > cur) {
-                        const size_t i = ix(slot);
-                        if (!(m & M_LBKX)) { if (wr) v.s_ltrig[i] = 0; if (wr) v.s_lendp[i] = 0; m |= M_LBKX; }
-                        if (wr) v.s_pmax[i] = vb[k];
-                        m = materialize_voted(i, m, bb[k], v.s_val[i]);
-                        if (wr) v.s_val[i] = vv[k];
-                        m = vv[k] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                        if (wr) v.s_meta[i] = m;
-                    }
-                }
-                if (slot == endp && m_st(m) == SMR_ST_PREPARING && ballot >= bb[k])   // :196-198, :222
-                    prepare_quorum_step(peer, trig, ballot);
+        }
+        if (n_mine == n) {                                       // the batch ends inside my log: :222
+            if (endp >= trig && endp < trig + n) {
+                const size_t i = ix(endp);
+                if (m_st(v.s_meta[i]) == SMR_ST_PREPARING && ballot >= v.s_bal[i]) prepare_quorum_step(peer, trig, ballot);
             }
+            return;
+        }
+        for (uint32_t k = n_mine; k < n && !ovf; k++) {          // unknown slots: pad + reply, one by one
+            const size_t o = (size_t)k * P.G + g;
+            const uint64_t vb = pr_vbal[o];
+            prepare_reply(peer, trig + k, trig, endp, ballot, vb > 0, vb, pr_vval[o]);
         }
     }
 
@@ -557,41 +609,31 @@ struct Lane {
         // Will my own PrepareReplies be counted?  messages.rs:116-125 looks at the trigger
         // slot's leader_bk, which the pass below creates when the trigger lies in it.
         const bool self_ok = trig >= e0 ? true : (v.s_meta[ix(trig)] & M_LBK) != 0;
-        for (uint32_t s0 = e0; s0 < len; s0 += 8) {             // :142-183
-            uint32_t mm[8], vl[8]; uint64_t bb[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool in = s0 + k < len;
-                const size_t i = ix(s0 + k);
-                mm[k] = in ? v.s_meta[i] : (uint32_t)SMR_ST_EXECUTED; vl[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
+        for (uint32_t s = e0 + cl; s < len; s += cn) {          // :142-183, every lane owns its slots
+            const size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            const uint32_t st = m_st(m);
+            if (st == SMR_ST_EXECUTED) continue;
+            m |= M_EXT;
+            if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
+            const uint64_t b = v.s_bal[i];
+            const uint32_t val = v.s_val[i];
+            uint64_t vb; uint32_t vv;
+            get_voted(i, m, b, val, vb, vv);
+            m = materialize_voted(i, m, b, val, true);
+            m = m_set_st(m, SMR_ST_PREPARING) | M_LBK | M_LBKX;
+            m &= ~((0xFFu << M_ACKS_SH) | (0xFFu << M_PACKS_SH));
+            uint64_t pmax = 0;
+            // PrepareBal completion -> my own PrepareReply for this slot (durability.rs:33-48):
+            // keep the value I voted for, if any (messages.rs:203-216 with prepare_max_bal == 0)
+            if (self_ok && s <= endp && vb > 0) {
+                pmax = vb;
+                if (vv != val) v.s_val[i] = vv;
+                m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
             }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t s = s0 + k;
-                if (s >= len) break;
-                const size_t i = ix(s);
-                uint32_t m = mm[k];
-                const uint32_t st = m_st(m);
-                if (st == SMR_ST_EXECUTED) continue;
-                m |= M_EXT;
-                if (st == SMR_ST_COMMITTED) { if (wr) v.s_meta[i] = m; continue; }
-                uint64_t vb; uint32_t vv;
-                get_voted(i, m, bb[k], vl[k], vb, vv);
-                m = materialize_voted(i, m, bb[k], vl[k]);
-                m = m_set_st(m, SMR_ST_PREPARING) | M_LBK | M_LBKX;
-                m &= ~((0xFFu << M_ACKS_SH) | (0xFFu << M_PACKS_SH));
-                uint64_t pmax = 0;
-                // PrepareBal completion -> my own PrepareReply for this slot (durability.rs:33-48):
-                // keep the value I voted for, if any (messages.rs:203-216 with prepare_max_bal == 0)
-                if (self_ok && s <= endp && vb > 0) {
-                    pmax = vb;
-                    if (vv != vl[k]) if (wr) v.s_val[i] = vv;
-                    m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                }
-                if (wr) v.s_bal[i] = bps;
-                if (wr) v.s_ltrig[i] = trig; if (wr) v.s_lendp[i] = endp; if (wr) v.s_pmax[i] = pmax;
-                if (wr) v.s_meta[i] = m;
-            }
+            v.s_bal[i] = bps;
+            v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = pmax;
+            v.s_meta[i] = m;
         }
         ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
         // the completion of slot endprep counts me in (messages.rs:222-233)
@@ -611,31 +653,21 @@ struct Lane {
         const uint32_t n = endp - trig + 1;
         const bool follower = !is_leader();
         if (follower && (v.pr_cnt[g] != 0 || n > P.pcap)) { ovf = true; return; }
-        for (uint32_t s0 = trig; s0 <= endp; s0 += 8) {         // :55-79
-            uint32_t mm[8], vl[8]; uint64_t bb[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool in = s0 + k <= endp;
-                const size_t i = ix(s0 + k);
-                mm[k] = in ? v.s_meta[i] : 0u; vl[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t s = s0 + k;
-                if (s > endp) break;
-                const size_t i = ix(s);
-                uint32_t m = mm[k];
-                uint64_t vb; uint32_t vv;
-                get_voted(i, m, bb[k], vl[k], vb, vv);
-                m = materialize_voted(i, m, bb[k], vl[k]);
-                if (wr) v.s_bal[i] = ballot;
-                m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
-                if (wr) v.s_rtrig[i] = trig; if (wr) v.s_rendp[i] = endp;
-                if (wr) v.s_meta[i] = m;
-                if (follower) {                                 // durability.rs:50-78
-                    size_t o = (size_t)(s - trig) * P.G + g;
-                    if (wr) v.pr_vbal[o] = vb; if (wr) v.pr_vval[o] = vv;
-                }
+        for (uint32_t s = trig + cl; s <= endp; s += cn) {      // :55-79, every lane owns its slots
+            const size_t i = ix(s);
+            uint32_t m = v.s_meta[i];
+            const uint64_t b = v.s_bal[i];
+            const uint32_t val = v.s_val[i];
+            uint64_t vb; uint32_t vv;
+            get_voted(i, m, b, val, vb, vv);
+            m = materialize_voted(i, m, b, val, true);
+            v.s_bal[i] = ballot;
+            m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
+            v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
+            v.s_meta[i] = m;
+            if (follower) {                                     // durability.rs:50-78
+                size_t o = (size_t)(s - trig) * P.G + g;
+                v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
             }
         }
         if (follower) {
