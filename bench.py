@@ -200,6 +200,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "mp_round_replies",
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["R3_replies"]["avg_us"]},
         "kernels": prof, "rejected_batches": rej, "overflow_groups": overflow,
+        "generic_path_batches": [eng.debug_generic_units(r) for r in range(R)],
         "decisions_per_sec_quorum_kernel": G * S / (r3_ms * 1e-3),
     }
     if rank == 0:

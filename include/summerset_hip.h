@@ -203,6 +203,10 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *host_buf
  * [2] batches refused by ring back-pressure */
 int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]);
 
+/* debug: client batches of replica `rep` that were handled by the generic per-lane path
+ * instead of the steady-state fast path (a performance, not a correctness, figure) */
+int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out);
+
 /* Drain replica `rep`'s committed-slot list (leader-side commits since the
  * last poll) into host arrays.  Order: ascending commit order within a group;
  * unspecified across groups.  *n_out may exceed cap (entries were dropped). */

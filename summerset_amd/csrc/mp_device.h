@@ -55,6 +55,7 @@ struct Lane {
     uint32_t obn0, obn1;           // outbox counts of parity 0 / 1 (scalars: a runtime-indexed
     bool obl0, obl1;               // array would live in scratch memory)
     uint32_t n_commit, n_redirect, n_reject;
+    uint32_t n_generic;            // debug: units of work that left the fast paths
     bool ovf;
     // Wave-cooperative ("uniform") mode: all 64 lanes of a wavefront run the SAME
     // (group, replica) handler with identical scalar state; only lane 0 commits
@@ -64,7 +65,7 @@ struct Lane {
     uint32_t cl, cn;
 
     __device__ __forceinline__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
-        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), ovf(false),
+        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), n_generic(0), ovf(false),
           wr(true), cl(0), cn(1) {
         obl0 = obl1 = false;
         obn0 = obn1 = 0;
@@ -348,6 +349,7 @@ struct Lane {
 
     // request.rs:112-224 handle_req_batch + durability.rs:85-107 (self ack)
     __device__ __forceinline__ void req_batch(uint32_t reqs) {
+        n_generic++;
         if (!is_leader() || bpd == 0) { n_redirect++; return; }    // :128-154
         // mod.rs:541-549 first_null_slot, scanning only where a Null can be
         uint32_t slot = 0xFFFFFFFFu;
@@ -519,6 +521,7 @@ struct Lane {
             if (wr) v.s_bal[i] = bps;
             if (wr) v.s_ltrig[i] = trig; if (wr) v.s_lendp[i] = my_endp; if (wr) v.s_pmax[i] = 0;
             if (wr) v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
+            if (nlb == this_slot) nlb = this_slot + 1;          // filled at once: still no Null below the log end
             // its PrepareBal completion is a no-op on the leader (this_slot > endprep)
         }
         {
@@ -603,8 +606,10 @@ struct Lane {
         bms = bps;
         uint32_t trig = first_status_below(start, len, SMR_ST_COMMITTED);          // :117-123 (else log end)
         const uint32_t endp = last_status(start, len, SMR_ST_COMMITTED, true, len); // :124-130 (else log end)
-        if (trig == len)                                        // :131-134
+        if (trig == len) {                                      // :131-134
             if (!push_null()) return;
+            if (nlb == len - 1) nlb = len;                      // it turns Preparing below: not a Null hole
+        }
         const uint32_t e0 = ebar;
         // Will my own PrepareReplies be counted?  messages.rs:116-125 looks at the trigger
         // slot's leader_bk, which the pass below creates when the trigger lies in it.
@@ -688,6 +693,7 @@ struct Lane {
         if (slot < len) m = v.s_meta[i];
         else if (slot == len) {                                 // common case: push + fill fused
             if (len - start >= P.W) { ovf = true; return 0; }
+            if (nlb == len) nlb = len + 1;                      // still no Null below the log end
             len++;
         } else {
             if (!pad_to(slot)) return 0;                        // :321-323

@@ -18,13 +18,16 @@ namespace smr {
 // cooperative jobs counted (wave-uniform, added once)
 __device__ __forceinline__ void flush_counters(const Lane &L, bool active, const unsigned int (&job)[3]) {
     unsigned int c0 = active ? L.n_commit : 0, c1 = active ? L.n_redirect : 0, c2 = active ? L.n_reject : 0;
+    unsigned int c3 = active ? L.n_generic : 0;
     for (int off = 32; off > 0; off >>= 1) {
         c0 += __shfl_xor(c0, off);
         c1 += __shfl_xor(c1, off);
         c2 += __shfl_xor(c2, off);
+        c3 += __shfl_xor(c3, off);
     }
     c0 += job[0]; c1 += job[1]; c2 += job[2];
     if (__lane_id() == 0) {
+        if (c3) atomicAdd((unsigned long long *)&L.v.counters[3], (unsigned long long)c3);
         if (c0) atomicAdd((unsigned long long *)&L.v.counters[0], (unsigned long long)c0);
         if (c1) atomicAdd((unsigned long long *)&L.v.counters[1], (unsigned long long)c1);
         if (c2) atomicAdd((unsigned long long *)&L.v.counters[2], (unsigned long long)c2);
@@ -134,7 +137,50 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         if (s == r) continue;
         const MpRep &snd = P.rep[s];
         const uint32_t cnt = snd.ob_cnt[par][g];
-        for (uint32_t j0 = (s == first_sender ? first_j : 0u); j0 < cnt && !L.ovf; j0 += 8) {   // 8 messages per batch
+        uint32_t jstart = (s == first_sender ? first_j : 0u);
+        // Uniform mode: 64 messages per step, one per lane, when they are the re-Accept round of a
+        // new leader -- all Accepts at one ballot >= bal_max_seen for consecutive slots I already
+        // hold.  Per message this is msg_accept(); the accept_bar scan runs on the bitmap.
+        while (L.coop() && jstart < cnt && !L.ovf) {
+            const uint32_t j = jstart + L.cl;
+            const bool in = j < cnt;
+            const size_t o = (size_t)j * P.G + g;
+            const uint32_t e = in ? snd.ob_slot[par][o] : 0u;
+            const uint64_t bl = in ? snd.ob_bal[par][o] : 0ull;
+            const uint32_t slot = e & OB_SLOT_MASK;
+            const uint32_t slot0 = __shfl(slot, 0);
+            const uint64_t bal0 = __shfl(bl, 0);
+            const uint32_t nin = cnt - jstart < 64 ? cnt - jstart : 64u;
+            const bool fits = !in || ((e >> OB_KIND_SH) == OB_ACCEPT && bl == bal0 && slot == slot0 + L.cl);
+            if (!__all(fits) || bal0 < L.bms || slot0 < L.start || slot0 + nin > L.len) break;
+            L.check_leader(s, bal0);                             // messages.rs:313-316
+            if (L.is_leader()) break;
+            const MpRep &v = P.rep[r];
+            uint32_t m = 0;
+            if (in) {
+                const size_t i = L.ix(slot);
+                const uint32_t val = snd.ob_val[par][o];
+                m = v.s_meta[i];
+                m = m_set_st(m, SMR_ST_ACCEPTING);              // :327-329
+                if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;    // :331-339
+                m = m_set_src(m, s);
+                m = m_set_vmode(m, VM_SAME);                     // :351
+                m = val ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                v.s_bal[i] = bal0; v.s_val[i] = val; v.s_meta[i] = m;
+                snd.ack[((size_t)j * P.R + r) * P.G + g] = bal0; // durability.rs:108-131
+            }
+            // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
+            // slot of the run is Accepting now, beyond it the scan reads memory
+            if (L.abar >= slot0 && L.abar < slot0 + nin) {
+                L.abar = slot0 + nin;
+                while (L.abar < L.len) {
+                    if (m_st(v.s_meta[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
+                    L.abar++;
+                }
+            }
+            jstart += nin;
+        }
+        for (uint32_t j0 = jstart; j0 < cnt && !L.ovf; j0 += 8) {   // 8 messages per batch
             uint32_t e[8], val[8]; uint64_t bal[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -225,6 +271,7 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int pa
                         fast_done++;
                     }
                 }
+                if (L.nlb == L.len) L.nlb = len;                 // still no Null below the log end
                 L.len = len; L.abar = len;
             }
         }
@@ -274,6 +321,69 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
     const bool lead = L.is_leader();
     const uint64_t bpd = L.bpd;
+    if (L.coop()) {
+        // Uniform mode (long outbox of a re-Accept round): 64 ack-matrix rows per step, one per
+        // lane, tallied in parallel; rows that reach the quorum are then committed one by one in
+        // entry order -- their Committed status is only written then, so every commit-bar run sees
+        // exactly the slots an entry-by-entry replay would have committed so far.
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
+            const uint32_t j = j0 + L.cl;
+            const bool in = j < cnt;
+            const size_t o = (size_t)j * G + g;
+            const uint32_t e = in ? os[o] : 0u;
+            const uint32_t ctl = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
+            uint64_t a[MAXR];
+#pragma unroll
+            for (int q = 0; q < MAXR; q++)
+                a[q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)j * R + q) * G + g] : 0ull;
+            const uint32_t slot = e & OB_SLOT_MASK;
+            const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
+            const size_t i = (size_t)(slot & Wm) * G + g;
+            const uint32_t m0 = have ? sm[i] : 0u;
+            const uint64_t b = have ? sb[i] : 0ull;
+            uint32_t mk = m0;
+            bool changed = false, committed = false;
+            if (have && lead && (mk & M_LBK)) {
+                const uint32_t drop = ctl_drop(ctl);
+#pragma unroll
+                for (int oi = 0; oi < MAXR; oi++) {
+                    const uint32_t s = ctl_order(ctl, oi);
+                    if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
+                    uint64_t av = 0;
+#pragma unroll
+                    for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[q] : av;
+                    if (av == 0 || av != bpd) continue;
+                    if (m_st(mk) != SMR_ST_ACCEPTING || av < b) continue;
+                    const uint32_t bit = 1u << (s + M_ACKS_SH);
+                    if (mk & bit) continue;
+                    mk |= bit;
+                    changed = true;
+                    if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
+                }
+            }
+            if (changed && !committed) sm[i] = mk;               // every lane owns its row's slot
+            for (unsigned long long cm = __ballot(changed && committed); cm; cm &= cm - 1) {
+                const int src = __ffsll((long long)cm) - 1;
+                const int nx = src < 63 ? src + 1 : src;
+                const uint32_t cs = __shfl(slot, src), cmk = __shfl(mk, src);
+                const uint32_t ns = __shfl(slot, nx), nm = __shfl(m0, nx);
+                const bool next_known = src < 63 && __shfl((int)have, nx) && ns == cs + 1;
+                const size_t ci = (size_t)(cs & Wm) * G + g;
+                L.record_commit(cs);
+                const bool stops = (next_known && m_st(nm) < SMR_ST_COMMITTED) || (cs + 1 >= L.abar && cs + 1 >= L.len);
+                if (cs == L.cbar && cs == L.ebar && cs < L.abar && (cmk & M_NONEMPTY) && stops) {
+                    if (L.wr) sm[ci] = m_set_st(cmk, SMR_ST_EXECUTED);
+                    L.cbar = cs + 1;
+                    L.ebar = cs + 1;
+                } else {
+                    if (L.wr) sm[ci] = cmk;
+                    L.commit_complete<2>(cs, cmk, next_known ? nm : 0xFFFFFFFFu);
+                }
+            }
+        }
+        L.ob_set(par, 0);
+        return;
+    }
     for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
         uint32_t e[C], ctl[C], m[C];
         uint64_t a[C][MAXR], b[C];
@@ -722,6 +832,15 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]) {
     unsigned long long h[4];
     SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return SMR_OK;
+}
+
+int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
+    if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[4];
+    SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
+    *out = h[3];
     return SMR_OK;
 }
 

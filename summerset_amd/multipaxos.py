@@ -106,6 +106,11 @@ class MultiPaxosCluster:
         check(self._L.smr_mp_counters(self._h, rep, C.byref(arr)))
         return {"commits": int(arr[0]), "redirects": int(arr[1]), "rejects": int(arr[2])}
 
+    def debug_generic_units(self, rep):
+        n = C.c_uint64()
+        check(self._L.smr_mp_debug_generic_units(self._h, rep, C.byref(n)))
+        return int(n.value)
+
     def poll_commits(self, rep, cap=None):
         cap = self.commit_list_cap if cap is None else cap
         g = np.zeros(cap, np.uint32)
