@@ -176,9 +176,11 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
 
-/* Device pointer + geometry of replica `rep`'s ack matrix: uint64
- * reply_bal[outbox_cap][R][G], 0 = no reply.  A host that receives real
- * AcceptReply messages (or the multi-GPU exchange) fills it before R3. */
+/* Device pointer + geometry of replica `rep`'s ack matrix: uint64 reply ballots,
+ * 0 = no reply, wave-tiled: the reply of replica r to my j-th outbox entry for
+ * group g lives at index (((g/64)*outbox_cap + j)*R + r)*64 + g%64 (n_groups
+ * rounded up to a multiple of 64).  A host that receives real AcceptReply
+ * messages (or the multi-GPU exchange) fills it before R3. */
 int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes);
 
 /* --- read-back (host buffers; each call synchronizes the device) -------- */

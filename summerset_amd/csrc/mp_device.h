@@ -104,7 +104,7 @@ struct Lane {
         if (ovf && wr) P.overflow[g] = 1;
     }
 
-    __device__ __forceinline__ size_t ix(uint32_t slot) const { return (size_t)(slot & P.Wmask) * P.G + g; }
+    __device__ __forceinline__ size_t ix(uint32_t slot) const { return tix(P.W, slot & P.Wmask, g); }
     __device__ __forceinline__ bool is_leader() const { return leader == me; }
 
     // mod.rs:553-561
@@ -162,7 +162,7 @@ struct Lane {
         ob_load(p);
         uint32_t c = p == 0 ? obn0 : obn1;
         if (c >= P.cap) { ovf = true; return; }
-        size_t o = (size_t)c * P.G + g;
+        size_t o = tix(P.cap, c, g);
         if (wr) v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
         if (wr) v.ob_bal[p][o] = bal;
         if (wr) v.ob_val[p][o] = val;
@@ -438,7 +438,7 @@ struct Lane {
                 if (moved) {
                     const uint32_t pos = c + (uint32_t)__popcll(mv & ((1ull << cl) - 1ull));
                     if (pos < P.cap) {
-                        const size_t o = (size_t)pos * P.G + g;
+                        const size_t o = tix(P.cap, pos, g);
                         v.ob_slot[par ^ 1][o] = (OB_ACCEPT << OB_KIND_SH) | (sl & OB_SLOT_MASK);
                         v.ob_bal[par ^ 1][o] = ballot;
                         v.ob_val[par ^ 1][o] = v.s_val[i];
@@ -559,7 +559,7 @@ struct Lane {
         const uint32_t n_mine = trig + n <= len0 ? n : len0 - trig;      // replies for slots I already hold
         for (uint32_t k = cl; k < n_mine; k += cn) {             // :196-216, every lane owns its slots
             const uint32_t slot = trig + k;
-            const size_t o = (size_t)k * P.G + g, i = ix(slot);
+            const size_t o = tix(P.pcap, k, g), i = ix(slot);
             const uint64_t vb = pr_vbal[o];
             if (vb == 0) continue;                               // voted: None
             uint32_t m = v.s_meta[i];
@@ -584,7 +584,7 @@ struct Lane {
             return;
         }
         for (uint32_t k = n_mine; k < n && !ovf; k++) {          // unknown slots: pad + reply, one by one
-            const size_t o = (size_t)k * P.G + g;
+            const size_t o = tix(P.pcap, k, g);
             const uint64_t vb = pr_vbal[o];
             prepare_reply(peer, trig + k, trig, endp, ballot, vb > 0, vb, pr_vval[o]);
         }
@@ -671,7 +671,7 @@ struct Lane {
             v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
             v.s_meta[i] = m;
             if (follower) {                                     // durability.rs:50-78
-                size_t o = (size_t)(s - trig) * P.G + g;
+                size_t o = tix(P.pcap, s - trig, g);
                 v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
             }
         }

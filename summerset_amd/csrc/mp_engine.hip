@@ -56,12 +56,13 @@ __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__re
 }
 
 // R1: HearTimeout -> become_a_leader; client batches -> handle_req_batch
-__global__ __launch_bounds__(256) void mp_round_local(const MpParams P, int par,
+__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
                                                       const uint8_t *__restrict__ timeout_rep,
                                                       const uint8_t *__restrict__ timeout_src,
                                                       const uint8_t *__restrict__ req_target,
                                                       const uint32_t *__restrict__ req_cnt,
                                                       const uint32_t *__restrict__ req_val, uint32_t S) {
+    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -98,8 +99,8 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams P, int par,
                     for (int q = 0; q < 8; q++) {
                         if (k + q >= n_req) break;
                         const uint32_t slot = base + k + q;
-                        const size_t i = (size_t)(slot & Wm) * G + g;
-                        const size_t o = (size_t)(c0 + k + q) * G + g;
+                        const size_t i = tix(P.W, slot & Wm, g);
+                        const size_t o = tix(P.cap, c0 + k + q, g);
                         sb[i] = bal; sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
                         os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; ov[o] = tok[q];
                     }
@@ -144,7 +145,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         while (L.coop() && jstart < cnt && !L.ovf) {
             const uint32_t j = jstart + L.cl;
             const bool in = j < cnt;
-            const size_t o = (size_t)j * P.G + g;
+            const size_t o = tix(P.cap, j, g);
             const uint32_t e = in ? snd.ob_slot[par][o] : 0u;
             const uint64_t bl = in ? snd.ob_bal[par][o] : 0ull;
             const uint32_t slot = e & OB_SLOT_MASK;
@@ -167,7 +168,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 m = m_set_vmode(m, VM_SAME);                     // :351
                 m = val ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                 v.s_bal[i] = bal0; v.s_val[i] = val; v.s_meta[i] = m;
-                snd.ack[((size_t)j * P.R + r) * P.G + g] = bal0; // durability.rs:108-131
+                snd.ack[tix(P.cap * P.R, j * P.R + r, g)] = bal0; // durability.rs:108-131
             }
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
             // slot of the run is Accepting now, beyond it the scan reads memory
@@ -185,7 +186,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 bool in = j0 + k < cnt;
-                size_t o = (size_t)(j0 + k) * P.G + g;
+                size_t o = tix(P.cap, j0 + k, g);
                 e[k] = in ? snd.ob_slot[par][o] : 0u;
                 bal[k] = in ? snd.ob_bal[par][o] : 0ull;
                 val[k] = in ? snd.ob_val[par][o] : 0u;
@@ -197,11 +198,11 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
                 if (kind == OB_ACCEPT) {
                     uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
-                    if (L.wr) snd.ack[((size_t)j * P.R + r) * P.G + g] = rep;
+                    if (L.wr) snd.ack[tix(P.cap * P.R, j * P.R + r, g)] = rep;
                 } else if (kind == OB_PREPARE) {
                     L.msg_prepare(s, slot, bal[k]);
                 } else if (kind == OB_HEARTBEAT) {
-                    L.heard_heartbeat(s, bal[k], slot, val[k], snd.ob_aux[par][(size_t)j * P.G + g]);
+                    L.heard_heartbeat(s, bal[k], slot, val[k], snd.ob_aux[par][tix(P.cap, j, g)]);
                 }
             }
         }
@@ -209,7 +210,8 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
-__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int par) {
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int pa
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const bool in = j0 + k < cnt;
-                        const size_t o = (size_t)(j0 + k) * G + g;
+                        const size_t o = tix(P.cap, j0 + k, g);
                         e[k] = in ? os[o] : 0u; bal[k] = in ? obl[o] : 0ull; val[k] = in ? ov[o] : 0u;
                     }
 #pragma unroll
@@ -264,9 +266,9 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams P, int pa
                             ok = false;
                             break;
                         }
-                        const size_t i = (size_t)(len & Wm) * G + g;
+                        const size_t i = tix(W, len & Wm, g);
                         sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
-                        ack[((size_t)(j0 + k) * R + r) * G + g] = bms;
+                        ack[tix(P.cap * R, (j0 + k) * R + r, g)] = bms;
                         len++;
                         fast_done++;
                     }
@@ -329,16 +331,16 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
         for (uint32_t j0 = 0; j0 < cnt; j0 += 64) {
             const uint32_t j = j0 + L.cl;
             const bool in = j < cnt;
-            const size_t o = (size_t)j * G + g;
+            const size_t o = tix(P.cap, j, g);
             const uint32_t e = in ? os[o] : 0u;
-            const uint32_t ctl = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
+            const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
             uint64_t a[MAXR];
 #pragma unroll
             for (int q = 0; q < MAXR; q++)
-                a[q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)j * R + q) * G + g] : 0ull;
+                a[q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, j * R + q, g)] : 0ull;
             const uint32_t slot = e & OB_SLOT_MASK;
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
-            const size_t i = (size_t)(slot & Wm) * G + g;
+            const size_t i = tix(P.W, slot & Wm, g);
             const uint32_t m0 = have ? sm[i] : 0u;
             const uint64_t b = have ? sb[i] : 0ull;
             uint32_t mk = m0;
@@ -368,7 +370,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
                 const uint32_t cs = __shfl(slot, src), cmk = __shfl(mk, src);
                 const uint32_t ns = __shfl(slot, nx), nm = __shfl(m0, nx);
                 const bool next_known = src < 63 && __shfl((int)have, nx) && ns == cs + 1;
-                const size_t ci = (size_t)(cs & Wm) * G + g;
+                const size_t ci = tix(P.W, cs & Wm, g);
                 L.record_commit(cs);
                 const bool stops = (next_known && m_st(nm) < SMR_ST_COMMITTED) || (cs + 1 >= L.abar && cs + 1 >= L.len);
                 if (cs == L.cbar && cs == L.ebar && cs < L.abar && (cmk & M_NONEMPTY) && stops) {
@@ -391,18 +393,18 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 1: everything addressed by (j, g) alone
             const bool in = j0 + k < cnt;
-            const size_t o = (size_t)(j0 + k) * G + g;
+            const size_t o = tix(P.cap, j0 + k, g);
             e[k] = in ? os[o] : 0u;
-            ctl[k] = (in && ackctl) ? ackctl[o] : SMR_CTL_IDENTITY;
+            ctl[k] = (in && ackctl) ? ackctl[(size_t)(j0 + k) * G + g] : SMR_CTL_IDENTITY;
 #pragma unroll
             for (int q = 0; q < MAXR; q++)
-                a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[((size_t)(j0 + k) * R + q) * G + g] : 0ull;
+                a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, (j0 + k) * R + q, g)] : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 2: the slots those Accepts name
             const uint32_t slot = e[k] & OB_SLOT_MASK;
             have[k] = (e[k] >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
-            const size_t i = (size_t)(slot & Wm) * G + g;
+            const size_t i = tix(P.W, slot & Wm, g);
             m[k] = have[k] ? sm[i] : 0u;
             b[k] = have[k] ? sb[i] : 0ull;
         }
@@ -434,7 +436,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
                 if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
             }
             if (!changed) continue;
-            const size_t i = (size_t)(slot & Wm) * G + g;
+            const size_t i = tix(P.W, slot & Wm, g);
             if (!committed) { if (L.wr) sm[i] = mk; continue; }
             L.record_commit(slot);
             // commit_complete() in its common shape, in registers: the slot sits at
@@ -462,9 +464,10 @@ __device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.r
 // R3: replies reach their destination: PrepareReplies (sender order of the
 // tick's ackctl word, FIFO per sender), then the AcceptReply matrix of my own
 // outbox, entry-major with per-entry peer order / loss.  THE quorum kernel.
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams P, int par,
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb) {
+    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t d = blockIdx.y;
     Lane L(P, d, g < P.G ? g : 0, par);
@@ -507,7 +510,8 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams P, int pa
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
 // trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
 // as carried by this round's heartbeats).
-__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams P, int par) {
+__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
@@ -566,6 +570,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     a.used = 0;
     const size_t G = c->cfg.n_groups, W = c->cfg.window, R = c->cfg.population, cap = c->cfg.outbox_cap,
                  pcap = c->pcap;
+    const size_t Gp = (G + 63) / 64 * 64;               // wave-tiled arrays hold whole 64-group tiles
     MpParams &P = c->hp;
     carve(a, P.overflow, G, dry);
     for (size_t r = 0; r < R; r++) {
@@ -576,20 +581,20 @@ static void layout(smr_mp_cluster *c, bool dry) {
         carve(a, v.commit_bar, G, dry); carve(a, v.exec_bar, G, dry); carve(a, v.snap_bar, G, dry);
         carve(a, v.null_lb, G, dry);
         carve(a, v.peer_exec_bar, R * G, dry);
-        carve(a, v.s_bal, W * G, dry); carve(a, v.s_val, W * G, dry); carve(a, v.s_meta, W * G, dry);
-        carve(a, v.s_vbal, W * G, dry); carve(a, v.s_vval, W * G, dry); carve(a, v.s_pmax, W * G, dry);
-        carve(a, v.s_ltrig, W * G, dry); carve(a, v.s_lendp, W * G, dry);
-        carve(a, v.s_rtrig, W * G, dry); carve(a, v.s_rendp, W * G, dry);
+        carve(a, v.s_bal, W * Gp, dry); carve(a, v.s_val, W * Gp, dry); carve(a, v.s_meta, W * Gp, dry);
+        carve(a, v.s_vbal, W * Gp, dry); carve(a, v.s_vval, W * Gp, dry); carve(a, v.s_pmax, W * Gp, dry);
+        carve(a, v.s_ltrig, W * Gp, dry); carve(a, v.s_lendp, W * Gp, dry);
+        carve(a, v.s_rtrig, W * Gp, dry); carve(a, v.s_rendp, W * Gp, dry);
         for (int p = 0; p < 2; p++) {
             carve(a, v.ob_cnt[p], G, dry);
-            carve(a, v.ob_slot[p], cap * G, dry); carve(a, v.ob_bal[p], cap * G, dry);
-            carve(a, v.ob_val[p], cap * G, dry); carve(a, v.ob_aux[p], cap * G, dry);
+            carve(a, v.ob_slot[p], cap * Gp, dry); carve(a, v.ob_bal[p], cap * Gp, dry);
+            carve(a, v.ob_val[p], cap * Gp, dry); carve(a, v.ob_aux[p], cap * Gp, dry);
         }
-        carve(a, v.ack, cap * R * G, dry);
+        carve(a, v.ack, cap * R * Gp, dry);
         carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);
         carve(a, v.pr_trig, G, dry); carve(a, v.pr_endp, G, dry); carve(a, v.pr_abar, G, dry);
         carve(a, v.pr_bal, G, dry);
-        carve(a, v.pr_vbal, pcap * G, dry); carve(a, v.pr_vval, pcap * G, dry);
+        carve(a, v.pr_vbal, pcap * Gp, dry); carve(a, v.pr_vval, pcap * Gp, dry);
         carve(a, v.hb_bal, G, dry); carve(a, v.hb_commit, G, dry); carve(a, v.hb_exec, G, dry);
         carve(a, v.hb_snap, G, dry);
         carve(a, v.counters, 4, dry);
@@ -694,7 +699,7 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 0, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->hp, c->par, timeout_rep_dev,
+    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
                        timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
@@ -704,7 +709,7 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 1, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->hp, c->par);
+    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }
@@ -713,7 +718,7 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->hp, c->par, ackctl_dev,
+    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
                        publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
@@ -723,7 +728,7 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 3, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->hp, c->par);
+    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }
@@ -749,7 +754,7 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
 int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes) {
     if (!c || rep >= c->cfg.population || !ack_dev) return fail(SMR_ERR_ARG, "mp: bad argument");
     *ack_dev = c->hp.rep[rep].ack;
-    if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * c->cfg.population * c->cfg.n_groups * 8;
+    if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * c->cfg.population * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
     return SMR_OK;
 }
 
@@ -788,14 +793,16 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
     D2H(hb->peer_exec_bar, v.peer_exec_bar, R * G * 4);
     D2H(hb->overflow, c->hp.overflow, G);
     for (size_t g = 0; g < G; g++) hb->peer_exec_bar[(size_t)rep * G + g] = 0;
-    std::vector<uint64_t> bal(W * G), vbal(W * G), pmax(W * G);
-    std::vector<uint32_t> val(W * G), meta(W * G), vval(W * G), ltrig(W * G), lendp(W * G), rtrig(W * G), rendp(W * G);
-    D2H(bal.data(), v.s_bal, W * G * 8); D2H(vbal.data(), v.s_vbal, W * G * 8); D2H(pmax.data(), v.s_pmax, W * G * 8);
-    D2H(val.data(), v.s_val, W * G * 4); D2H(meta.data(), v.s_meta, W * G * 4); D2H(vval.data(), v.s_vval, W * G * 4);
-    D2H(ltrig.data(), v.s_ltrig, W * G * 4); D2H(lendp.data(), v.s_lendp, W * G * 4);
-    D2H(rtrig.data(), v.s_rtrig, W * G * 4); D2H(rendp.data(), v.s_rendp, W * G * 4);
+    const size_t Gp = (G + 63) / 64 * 64;
+    std::vector<uint64_t> bal(W * Gp), vbal(W * Gp), pmax(W * Gp);
+    std::vector<uint32_t> val(W * Gp), meta(W * Gp), vval(W * Gp), ltrig(W * Gp), lendp(W * Gp), rtrig(W * Gp), rendp(W * Gp);
+    D2H(bal.data(), v.s_bal, W * Gp * 8); D2H(vbal.data(), v.s_vbal, W * Gp * 8); D2H(pmax.data(), v.s_pmax, W * Gp * 8);
+    D2H(val.data(), v.s_val, W * Gp * 4); D2H(meta.data(), v.s_meta, W * Gp * 4); D2H(vval.data(), v.s_vval, W * Gp * 4);
+    D2H(ltrig.data(), v.s_ltrig, W * Gp * 4); D2H(lendp.data(), v.s_lendp, W * Gp * 4);
+    D2H(rtrig.data(), v.s_rtrig, W * Gp * 4); D2H(rendp.data(), v.s_rendp, W * Gp * 4);
 #undef D2H
-    // canonicalise: explicit Instance fields, zero outside [start_slot, log_len)
+    // canonicalise: explicit Instance fields, zero outside [start_slot, log_len); the host
+    // buffers are plain [W][G], the device arrays wave-tiled (tix)
     for (size_t w = 0; w < W; w++)
         for (size_t g = 0; g < G; g++) {
             size_t o = w * G + g;
@@ -807,20 +814,21 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
         uint32_t lo = hb->start_slot[g], hi = hb->log_len[g];
         if (hi - lo > W) hi = lo + (uint32_t)W;
         for (uint32_t s = lo; s < hi; s++) {
-            size_t o = (size_t)(s & (W - 1)) * G + g;
-            uint32_t m = meta[o];
-            hb->s_bal[o] = bal[o]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[o];
+            const size_t o = (size_t)(s & (W - 1)) * G + g;                     // host index
+            const size_t t = tix((uint32_t)W, s & (uint32_t)(W - 1), (uint32_t)g);   // device index
+            uint32_t m = meta[t];
+            hb->s_bal[o] = bal[t]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[t];
             uint32_t vm = (m >> M_VMODE_SH) & 3u;
-            hb->s_vbal[o] = vm == VM_SAME ? bal[o] : (vm == VM_SIDE ? vbal[o] : 0);
-            hb->s_vreqs[o] = vm == VM_SAME ? val[o] : (vm == VM_SIDE ? vval[o] : 0);
+            hb->s_vbal[o] = vm == VM_SAME ? bal[t] : (vm == VM_SIDE ? vbal[t] : 0);
+            hb->s_vreqs[o] = vm == VM_SAME ? val[t] : (vm == VM_SIDE ? vval[t] : 0);
             bool lbk = m & M_LBK, rbk = m & M_RBK;
             hb->s_flags[o] = (uint8_t)((lbk ? 1 : 0) | (rbk ? 2 : 0) | ((m & M_EXT) ? 4 : 0));
             hb->s_acks[o] = lbk ? (uint8_t)((m >> M_ACKS_SH) & 0xFF) : 0;
             hb->s_packs[o] = lbk ? (uint8_t)((m >> M_PACKS_SH) & 0xFF) : 0;
             bool lx = lbk && (m & M_LBKX), rx = rbk && (m & M_RBKX);
-            hb->s_pmax[o] = lx ? pmax[o] : 0; hb->s_ltrig[o] = lx ? ltrig[o] : 0; hb->s_lendp[o] = lx ? lendp[o] : 0;
+            hb->s_pmax[o] = lx ? pmax[t] : 0; hb->s_ltrig[o] = lx ? ltrig[t] : 0; hb->s_lendp[o] = lx ? lendp[t] : 0;
             hb->s_src[o] = rbk ? (uint8_t)((m >> M_SRC_SH) & 7) : 0;
-            hb->s_rtrig[o] = rx ? rtrig[o] : 0; hb->s_rendp[o] = rx ? rendp[o] : 0;
+            hb->s_rtrig[o] = rx ? rtrig[t] : 0; hb->s_rendp[o] = rx ? rendp[t] : 0;
         }
     }
     return SMR_OK;

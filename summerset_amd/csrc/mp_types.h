@@ -7,12 +7,13 @@
 // contiguous 256/512-byte request per field.
 //
 //   per-group scalars   X[g]
-//   slot ring           X[(slot & (W-1)) * G + g]      (Vec<Instance>, mod.rs:426)
-//   outbox (x2 parity)  X[j * G + g], j < cap          (bcast_msg of Prepare /
+//   slot ring           X[tix(W, slot & (W-1), g)]     (Vec<Instance>, mod.rs:426)
+//   outbox (x2 parity)  X[tix(cap, j, g)], j < cap     (bcast_msg of Prepare /
 //                                                       Accept / Heartbeat)
-//   ack matrix          ack[(j * R + r) * G + g]       AcceptReply ballot of
+//   ack matrix          ack[tix(cap*R, j*R + r, g)]    AcceptReply ballot of
 //                                                       replica r to my j-th
 //                                                       outbox entry (0 = none)
+//   with tix(rows, row, g) = ((g/64)*rows + row)*64 + g%64   (wave-tiled, see below)
 //
 // Instance fields are packed so the steady-state path touches 16 bytes per
 // (replica, slot): s_bal (8) + s_val (4) + s_meta (4).  Rarely-used fields live
@@ -58,6 +59,23 @@ constexpr uint32_t OB_SLOT_MASK = (1u << 30) - 1;
 
 constexpr uint32_t NO_REP = 0xFFu;
 constexpr int MAXR = 8;
+
+// Wave-tiled indexing of every array with a row dimension (ring slots, outbox entries,
+// ack-matrix rows, PrepareReply entries):  X[g / 64][row][g % 64].  A wavefront's 64
+// consecutive groups still form one contiguous 256/512-byte request per row, and the
+// rows of ONE group tile are adjacent in memory (64 slots of a group span 16-32 KB, not
+// 64 pages 256 KB apart), which is what the lane-per-slot cooperative paths need.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t tix(uint32_t rows, uint32_t row, uint32_t g) {
+#ifdef SMR_ROWMAJOR_G   /* experiment only: plain [row][g] with a compile-time group count */
+    (void)rows;
+    return (size_t)row * SMR_ROWMAJOR_G + g;
+#else
+    return ((((size_t)(g >> 6)) * rows + row) << 6) | (size_t)(g & 63u);
+#endif
+}
 
 struct MpRep {
     // scalars [G]
