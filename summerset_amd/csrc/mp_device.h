@@ -161,6 +161,7 @@ struct Lane {
     __device__ __forceinline__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
         ob_load(p);
         uint32_t c = p == 0 ? obn0 : obn1;
+        if (wr) v.ob_reg[p][g] = 0;                             // no longer (only) a steady-state append run
         if (c >= P.cap) { ovf = true; return; }
         size_t o = tix(P.cap, c, g);
         if (wr) v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
@@ -421,6 +422,7 @@ struct Lane {
             // order (ballot + prefix count), the accept_bar scan runs on the bitmaps.
             ob_load(par ^ 1);
             uint32_t c = (par ^ 1) == 0 ? obn0 : obn1;
+            if (wr) v.ob_reg[par ^ 1][g] = 0;
             int chase = 0;
             for (uint32_t base = trig; base < len; base += 64) {
                 const uint32_t sl = base + cl;

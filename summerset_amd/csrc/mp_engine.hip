@@ -107,6 +107,8 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
                 }
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
                 if (par == 0) L.obn0 = c0 + n_req; else L.obn1 = c0 + n_req;
+                v.ob_reg[par][g] = c0 == 0 ? base + 1 : 0u;
+                if (c0 == 0) v.ob_rbal[par][g] = bal;
                 k0 = n_req;
             }
         }
@@ -251,6 +253,26 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_RBK | (s << M_SRC_SH) | (VM_SAME << M_VMODE_SH);
                 uint32_t len = L.len;
                 bool ok = true;
+                const uint32_t reg = snd.ob_reg[par][g];
+                if (reg != 0 && reg - 1 == len && snd.ob_rbal[par][g] == bms && (len - start) + cnt <= W) {
+                    // regular outbox: Accepts for slots len, len+1, ... at my bal_max_seen, all of
+                    // which fit the window -- only the batch tokens are read
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
+                        uint32_t val[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) val[k] = (j0 + k < cnt) ? ov[tix(P.cap, j0 + k, g)] : 0u;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            if (j0 + k >= cnt) break;
+                            const size_t i = tix(W, (len + j0 + k) & Wm, g);
+                            sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+                            ack[tix(P.cap * R, (j0 + k) * R + r, g)] = bms;
+                        }
+                    }
+                    len += cnt;
+                    fast_done = cnt;
+                    ok = false;                                  // nothing left for the per-message loop
+                }
                 for (uint32_t j0 = 0; j0 < cnt && ok; j0 += 8) {
                     uint32_t e[8], val[8]; uint64_t bal[8];
 #pragma unroll
@@ -312,12 +334,13 @@ __device__ __forceinline__ void r3_prepare_replies(Lane &L, uint32_t tickctl) {
 
 // (b) AcceptReplies to my Accepts of this tick: the ack matrix of my outbox, entry-major,
 // per-entry peer order / loss from ackctl; C rows per batch of loads, tally in registers
+template <int NR>   // NR >= population: replica columns held in registers
 __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__restrict__ ackctl, uint32_t cnt) {
     const MpParams &P = L.P;
     const uint32_t g = L.g, d = L.me;
     const int par = L.par;
     const MpRep &v = P.rep[d];
-    constexpr int C = 4;                                         // ack-matrix rows per batch of loads
+    constexpr int C = 8;                                         // ack-matrix rows per batch of loads
     SMR_G const uint32_t *const os = v.ob_slot[par]; SMR_G const uint64_t *const ack = v.ack;
     SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
@@ -334,9 +357,9 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const size_t o = tix(P.cap, j, g);
             const uint32_t e = in ? os[o] : 0u;
             const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-            uint64_t a[MAXR];
+            uint64_t a[NR];
 #pragma unroll
-            for (int q = 0; q < MAXR; q++)
+            for (int q = 0; q < NR; q++)
                 a[q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, j * R + q, g)] : 0ull;
             const uint32_t slot = e & OB_SLOT_MASK;
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
@@ -348,12 +371,12 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             if (have && lead && (mk & M_LBK)) {
                 const uint32_t drop = ctl_drop(ctl);
 #pragma unroll
-                for (int oi = 0; oi < MAXR; oi++) {
+                for (int oi = 0; oi < NR; oi++) {
                     const uint32_t s = ctl_order(ctl, oi);
                     if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
                     uint64_t av = 0;
 #pragma unroll
-                    for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[q] : av;
+                    for (int q = 0; q < NR; q++) av = (s == (uint32_t)q) ? a[q] : av;
                     if (av == 0 || av != bpd) continue;
                     if (m_st(mk) != SMR_ST_ACCEPTING || av < b) continue;
                     const uint32_t bit = 1u << (s + M_ACKS_SH);
@@ -386,18 +409,21 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
         L.ob_set(par, 0);
         return;
     }
+    // regular outbox (steady-state appends): entry j is the Accept for slot (reg - 1) + j, so
+    // nothing depends on ob_slot and all loads of a batch go out together
+    const uint32_t reg = v.ob_reg[par][g];
     for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
         uint32_t e[C], ctl[C], m[C];
-        uint64_t a[C][MAXR], b[C];
+        uint64_t a[C][NR], b[C];
         bool have[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 1: everything addressed by (j, g) alone
             const bool in = j0 + k < cnt;
             const size_t o = tix(P.cap, j0 + k, g);
-            e[k] = in ? os[o] : 0u;
+            e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
             ctl[k] = (in && ackctl) ? ackctl[(size_t)(j0 + k) * G + g] : SMR_CTL_IDENTITY;
 #pragma unroll
-            for (int q = 0; q < MAXR; q++)
+            for (int q = 0; q < NR; q++)
                 a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, (j0 + k) * R + q, g)] : 0ull;
         }
 #pragma unroll
@@ -421,12 +447,12 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint32_t drop = ctl_drop(ctl[k]);
             bool changed = false, committed = false;
 #pragma unroll
-            for (int oi = 0; oi < MAXR; oi++) {
+            for (int oi = 0; oi < NR; oi++) {
                 const uint32_t s = ctl_order(ctl[k], oi);
                 if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
                 uint64_t av = 0;
 #pragma unroll
-                for (int q = 0; q < MAXR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
+                for (int q = 0; q < NR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
                 if (av == 0 || av != bpd) continue;
                 if (m_st(mk) != SMR_ST_ACCEPTING || av < b[k]) continue;
                 const uint32_t bit = 1u << (s + M_ACKS_SH);
@@ -485,7 +511,10 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         // re-Accept round) is a cooperative job for the whole wave
         job = has_pr || cnt > 64;
         if (!job) {
-            if (cnt) { L.load(); loaded = true; r3_accept_replies(L, ackctl, cnt); }
+            if (cnt) {
+                L.load(); loaded = true;
+                if (P.R <= 5) r3_accept_replies<5>(L, ackctl, cnt); else r3_accept_replies<MAXR>(L, ackctl, cnt);
+            }
             if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
             if (loaded) L.store();
         }
@@ -499,7 +528,7 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         J.load();
         r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
         const uint32_t cnt = P.rep[d].ob_cnt[par][gj];
-        if (cnt) r3_accept_replies(J, ackctl, cnt);
+        if (cnt) { if (P.R <= 5) r3_accept_replies<5>(J, ackctl, cnt); else r3_accept_replies<MAXR>(J, ackctl, cnt); }
         if (publish_hb) r3_publish_hb(J);
         J.store();
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
@@ -589,6 +618,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
             carve(a, v.ob_cnt[p], G, dry);
             carve(a, v.ob_slot[p], cap * Gp, dry); carve(a, v.ob_bal[p], cap * Gp, dry);
             carve(a, v.ob_val[p], cap * Gp, dry); carve(a, v.ob_aux[p], cap * Gp, dry);
+            carve(a, v.ob_reg[p], G, dry); carve(a, v.ob_rbal[p], G, dry);
         }
         carve(a, v.ack, cap * R * Gp, dry);
         carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);

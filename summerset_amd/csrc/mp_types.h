@@ -97,6 +97,11 @@ struct MpRep {
     SMR_G uint64_t *ob_bal[2];
     SMR_G uint32_t *ob_val[2];      // Accept: reqs token; HB: exec_bar
     SMR_G uint32_t *ob_aux[2];      // HB: snap_bar
+    // "regular outbox" descriptor [G]: ob_reg != 0 means the outbox holds ONLY Accepts for the
+    // consecutive slots (ob_reg - 1) + j, j < ob_cnt, all at ballot ob_rbal (what the steady-state
+    // append produces), so consumers need not read ob_slot / ob_bal.  Any other push clears it.
+    SMR_G uint32_t *ob_reg[2];
+    SMR_G uint64_t *ob_rbal[2];
     // replies to my Accepts [cap][R][G]
     SMR_G uint64_t *ack;
     // my PrepareReply batch of this tick: header [G] + entries [pcap][G]
