@@ -332,6 +332,39 @@ __device__ __forceinline__ void r3_prepare_replies(Lane &L, uint32_t tickctl) {
     }
 }
 
+// One ack-matrix row applied to its slot, branch-free, in 32-bit integer ops.
+// Filter chain of handle_msg_accept_reply (messages.rs:377-412) for every reply of the
+// row: reply present and == bal_prepared (:388), instance Accepting (:394), reply ballot
+// >= inst.bal (:396; all valid replies equal bal_prepared, so this is one test per row),
+// not a duplicate (:404-406); replies taken in the ackctl order, lost ones skipped; the
+// mask freezes once popcount reaches the threshold (:412).
+template <int NR>
+__device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t ctl, const uint64_t (&a)[NR],
+                                              uint64_t bpd, uint32_t thresh, uint32_t R, bool &changed,
+                                              bool &committed) {
+    uint32_t valid = 0;                                          // bit s: replica s answered with bal_prepared
+#pragma unroll
+    for (int q = 0; q < NR; q++) valid |= (uint32_t)(a[q] != 0 && a[q] == bpd) << q;
+    valid &= ~ctl_drop(ctl);
+    uint32_t accepting = (m_st(m) == SMR_ST_ACCEPTING && bpd >= b) ? 1u : 0u;
+    uint32_t acks = m_acks(m), chg = 0, done = 0;
+#pragma unroll
+    for (int oi = 0; oi < NR; oi++) {
+        const uint32_t s = ctl_order(ctl, oi);                   // ids >= R never have a valid bit
+        const uint32_t nb = ((valid >> s) & ~(acks >> s) & accepting & ((uint32_t)oi < R ? 1u : 0u)) & 1u;
+        acks |= nb << s;
+        chg |= nb;
+        const uint32_t hit = nb & ((uint32_t)__popc(acks) >= thresh ? 1u : 0u);
+        done |= hit;
+        accepting &= ~hit;
+    }
+    changed = chg != 0;
+    committed = done != 0;
+    m = (m & ~(0xFFu << M_ACKS_SH)) | (acks << M_ACKS_SH);
+    if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
+    return m;
+}
+
 // (b) AcceptReplies to my Accepts of this tick: the ack matrix of my outbox, entry-major,
 // per-entry peer order / loss from ackctl; C rows per batch of loads, tally in registers
 template <int NR>   // NR >= population: replica columns held in registers
@@ -368,24 +401,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint64_t b = have ? sb[i] : 0ull;
             uint32_t mk = m0;
             bool changed = false, committed = false;
-            if (have && lead && (mk & M_LBK)) {
-                const uint32_t drop = ctl_drop(ctl);
-#pragma unroll
-                for (int oi = 0; oi < NR; oi++) {
-                    const uint32_t s = ctl_order(ctl, oi);
-                    if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
-                    uint64_t av = 0;
-#pragma unroll
-                    for (int q = 0; q < NR; q++) av = (s == (uint32_t)q) ? a[q] : av;
-                    if (av == 0 || av != bpd) continue;
-                    if (m_st(mk) != SMR_ST_ACCEPTING || av < b) continue;
-                    const uint32_t bit = 1u << (s + M_ACKS_SH);
-                    if (mk & bit) continue;
-                    mk |= bit;
-                    changed = true;
-                    if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
-                }
-            }
+            if (have && lead && (mk & M_LBK)) mk = tally_row<NR>(m0, b, ctl, a, bpd, thresh, R, changed, committed);
             if (changed && !committed) sm[i] = mk;               // every lane owns its row's slot
             for (unsigned long long cm = __ballot(changed && committed); cm; cm &= cm - 1) {
                 const int src = __ffsll((long long)cm) - 1;
@@ -444,23 +460,8 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             // accept_reply() / accept_entry() (messages.rs:377-412).
             uint32_t mk = m[k];
             if (!lead || !(mk & M_LBK)) continue;
-            const uint32_t drop = ctl_drop(ctl[k]);
             bool changed = false, committed = false;
-#pragma unroll
-            for (int oi = 0; oi < NR; oi++) {
-                const uint32_t s = ctl_order(ctl[k], oi);
-                if ((uint32_t)oi >= R || s == d || s >= R || ((drop >> s) & 1u)) continue;
-                uint64_t av = 0;
-#pragma unroll
-                for (int q = 0; q < NR; q++) av = (s == (uint32_t)q) ? a[k][q] : av;
-                if (av == 0 || av != bpd) continue;
-                if (m_st(mk) != SMR_ST_ACCEPTING || av < b[k]) continue;
-                const uint32_t bit = 1u << (s + M_ACKS_SH);
-                if (mk & bit) continue;
-                mk |= bit;
-                changed = true;
-                if ((uint32_t)__popc(m_acks(mk)) >= thresh) { mk = m_set_st(mk, SMR_ST_COMMITTED); committed = true; }
-            }
+            mk = tally_row<NR>(mk, b[k], ctl[k], a[k], bpd, thresh, R, changed, committed);
             if (!changed) continue;
             const size_t i = tix(P.W, slot & Wm, g);
             if (!committed) { if (L.wr) sm[i] = mk; continue; }
