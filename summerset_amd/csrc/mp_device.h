@@ -236,11 +236,13 @@ struct Lane {
     // `m_slot` is the (already stored) meta of `slot`; `next_hint` optionally the
     // meta of slot + 1 if the caller holds it (0xFFFFFFFF = unknown); NB = slots
     // fetched per batch of independent loads when the run goes on.
+    // `chase_in`: the caller already walked a prefix of this run and exec_bar is riding along.
     template <int NB>
-    __device__ __forceinline__ void commit_complete(uint32_t slot, uint32_t m_slot, uint32_t next_hint = 0xFFFFFFFFu) {
+    __device__ __forceinline__ void commit_complete(uint32_t slot, uint32_t m_slot, uint32_t next_hint = 0xFFFFFFFFu,
+                                                    bool chase_in = false) {
         if (slot < start || slot != cbar) return;
         const uint32_t e0 = ebar;
-        bool chase = false;
+        bool chase = chase_in;
         uint32_t unexec_at = 0xFFFFFFFFu;          // where the run stopped on a slot < Committed
         uint32_t s = cbar;
         auto visit = [&](uint32_t m) -> bool {      // false = run ends here
@@ -724,9 +726,41 @@ struct Lane {
         if (hb_exec < ebar) return;                             // :312-314
         if (hb_commit > cbar) {                                 // :379
             if (len < hb_commit && !pad_to(hb_commit - 1)) return;   // :380-382
+            // Fused prefix (the steady state of a follower): while slots are Accepting at a ballot
+            // >= the heartbeat's and below accept_bar, advance_commit_bar marks them Committed
+            // (:385-416), the CommitSlot completion of the first one starts the commit-bar run
+            // (durability.rs:162-189) which passes each of them, and their command results bring
+            // them to Executed (execution.rs:57) -- one read and one write per slot instead of three
+            // passes.  Exact: the run was started by slot commit_bar itself (it is Accepting here),
+            // and exec_bar rides along iff that slot is a non-empty batch sitting at exec_bar.
+            const uint32_t c0 = cbar, e0 = ebar;
+            uint32_t sfx = cbar;
+            bool chase = false;
+            if (!coop()) {
+                bool simple = true;
+                while (simple && sfx < hb_commit) {
+                    uint32_t mm[8]; uint64_t bb[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        bool in = sfx + k < hb_commit;
+                        size_t i = ix(sfx + k);
+                        mm[k] = in ? v.s_meta[i] : 0u;
+                        bb[k] = in ? v.s_bal[i] : 0ull;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (sfx >= hb_commit) break;
+                        if (!(m_st(mm[k]) == SMR_ST_ACCEPTING && bb[k] >= ballot && sfx < abar)) { simple = false; break; }
+                        if ((mm[k] & M_NONEMPTY) && sfx == e0) chase = true;
+                        v.s_meta[ix(sfx)] = m_set_st(mm[k], SMR_ST_EXECUTED);
+                        sfx++;
+                    }
+                }
+                if (sfx > c0) { cbar = sfx; if (chase) ebar = sfx; }
+            }
             uint32_t first = 0xFFFFFFFFu, first_m = 0;
             {                                                   // :385-416, 8 slots per batch of loads
-                uint32_t s = cbar;
+                uint32_t s = sfx;
                 bool go = true;
                 while (go && s < hb_commit) {
                     uint32_t mm[8]; uint64_t bb[8];
@@ -751,8 +785,14 @@ struct Lane {
                     }
                 }
             }
-            // CommitSlot completions: only the first can sit at commit_bar
-            if (first != 0xFFFFFFFFu) commit_complete<8>(first, first_m);
+            if (sfx > c0) {
+                // the run started in the fused prefix goes on from commit_bar, whatever marked it
+                if (cbar < len) commit_complete<8>(cbar, v.s_meta[ix(cbar)], 0xFFFFFFFFu, chase);
+                else if (chase) ebar = cbar;
+            } else if (first != 0xFFFFFFFFu) {
+                // CommitSlot completions: only the first can sit at commit_bar
+                commit_complete<8>(first, first_m);
+            }
         }
         if (peer != me) {                                       // :320-342
             size_t po = (size_t)peer * P.G + g;

@@ -155,7 +155,10 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             const uint64_t bal0 = __shfl(bl, 0);
             const uint32_t nin = cnt - jstart < 64 ? cnt - jstart : 64u;
             const bool fits = !in || ((e >> OB_KIND_SH) == OB_ACCEPT && bl == bal0 && slot == slot0 + L.cl);
-            if (!__all(fits) || bal0 < L.bms || slot0 < L.start || slot0 + nin > L.len) break;
+            if (!__all(fits) || bal0 < L.bms || slot0 < L.start) break;
+            const bool appending = slot0 == L.len;               // brand-new slots (push + fill fused)
+            if (!appending && slot0 + nin > L.len) break;        // a mix of old and new slots: one by one
+            if (appending && (L.len - L.start) + nin > P.W) break;   // ring window: let the serial path flag it
             L.check_leader(s, bal0);                             // messages.rs:313-316
             if (L.is_leader()) break;
             const MpRep &v = P.rep[r];
@@ -163,7 +166,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             if (in) {
                 const size_t i = L.ix(slot);
                 const uint32_t val = snd.ob_val[par][o];
-                m = v.s_meta[i];
+                m = appending ? 0u : v.s_meta[i];
                 m = m_set_st(m, SMR_ST_ACCEPTING);              // :327-329
                 if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;    // :331-339
                 m = m_set_src(m, s);
@@ -174,6 +177,10 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             }
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
             // slot of the run is Accepting now, beyond it the scan reads memory
+            if (appending) {
+                if (L.nlb == L.len) L.nlb = L.len + nin;         // still no Null below the log end
+                L.len += nin;
+            }
             if (L.abar >= slot0 && L.abar < slot0 + nin) {
                 L.abar = slot0 + nin;
                 while (L.abar < L.len) {
@@ -403,7 +410,31 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             bool changed = false, committed = false;
             if (have && lead && (mk & M_LBK)) mk = tally_row<NR>(m0, b, ctl, a, bpd, thresh, R, changed, committed);
             if (changed && !committed) sm[i] = mk;               // every lane owns its row's slot
-            for (unsigned long long cm = __ballot(changed && committed); cm; cm &= cm - 1) {
+            unsigned long long cm = __ballot(changed && committed);
+            {
+                // Common shape of a re-Accept round: the step's rows are consecutive slots starting at
+                // commit_bar == exec_bar, all below accept_bar, all non-empty, and ALL reach the
+                // quorum.  Replayed one by one each would take the register fast path above (commit,
+                // execute, both bars + 1), so the whole step is: every slot Executed, bars + n.
+                const uint32_t nin = cnt - j0 < 64 ? cnt - j0 : 64u;
+                const unsigned long long full = nin == 64 ? ~0ull : ((1ull << nin) - 1ull);
+                const uint32_t slot0 = __shfl(slot, 0);
+                const bool shape = !in || (have && slot == slot0 + L.cl && (mk & M_NONEMPTY));
+                if (cm == full && __all(shape) && slot0 == L.cbar && slot0 == L.ebar && slot0 + nin <= L.abar &&
+                    P.clist_cap == 0) {
+                    bool tail_ok = slot0 + nin >= L.abar && slot0 + nin >= L.len;   // run ends with the log ...
+                    if (!tail_ok && slot0 + nin < L.len)
+                        tail_ok = m_st(sm[tix(P.W, (slot0 + nin) & Wm, g)]) < SMR_ST_COMMITTED;   // next slot not committed yet
+                    if (tail_ok) {
+                        if (in) sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
+                        L.n_commit += nin;
+                        L.cbar = slot0 + nin;
+                        L.ebar = slot0 + nin;
+                        cm = 0;
+                    }
+                }
+            }
+            for (; cm; cm &= cm - 1) {
                 const int src = __ffsll((long long)cm) - 1;
                 const int nx = src < 63 ? src + 1 : src;
                 const uint32_t cs = __shfl(slot, src), cmk = __shfl(mk, src);
@@ -491,35 +522,112 @@ __device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.r
 // R3: replies reach their destination: PrepareReplies (sender order of the
 // tick's ackctl word, FIFO per sender), then the AcceptReply matrix of my own
 // outbox, entry-major with per-entry peer order / loss.  THE quorum kernel.
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
-                                                        const uint32_t *__restrict__ ackctl,
-                                                        int publish_hb) {
-    const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+//
+// Block = 4 wavefronts over the SAME 64 groups.  Steady state (regular outbox of <= 64
+// Accepts on a prepared leader): the wavefronts tally a quarter of the ack-matrix rows each
+// -- all loads of a row batch are independent -- and leave the per-row outcome in LDS; after
+// the barrier wavefront 0 replays the commits in entry order on registers (commit bar, exec
+// bar), which is the only sequential part.  Every other lane (irregular outbox, leader change
+// in flight) is handled by wavefront 0 alone: per lane, or as a cooperative job.
+template <int NR>
+__device__ __forceinline__ void r3_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
+                                         int publish_hb, uint32_t *sh_mk, uint8_t *sh_fl) {
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 64 + lane;
     const uint32_t d = blockIdx.y;
-    Lane L(P, d, g < P.G ? g : 0, par);
-    bool active = g < P.G && !P.overflow[g];
-    bool loaded = false, job = false;
+    const MpRep &v = P.rep[d];
+    const bool active = g < P.G && !P.overflow[g];
+    const uint32_t gg = g < P.G ? g : 0;
+    // what every wavefront needs to agree on the lane's mode
+    uint32_t cnt = 0, reg = 0;
+    bool has_pr = false, lead = false;
+    uint64_t bpd = 0;
+    uint32_t start = 0, len = 0;
     if (active) {
-        const MpRep &v = P.rep[d];
-        const uint32_t tickctl = ackctl ? ackctl[g] : SMR_CTL_IDENTITY;
-        bool has_pr = false;
+        cnt = v.ob_cnt[par][gg];
 #pragma unroll
         for (int s = 0; s < MAXR; s++)
-            if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[g] != 0 && P.rep[s].pr_dest[g] == d) has_pr = true;
-        const uint32_t cnt = v.ob_cnt[par][g];
-        // a leader change in flight (PrepareReplies for me, or the long outbox of the
-        // re-Accept round) is a cooperative job for the whole wave
-        job = has_pr || cnt > 64;
-        if (!job) {
-            if (cnt) {
-                L.load(); loaded = true;
-                if (P.R <= 5) r3_accept_replies<5>(L, ackctl, cnt); else r3_accept_replies<MAXR>(L, ackctl, cnt);
-            }
-            if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
-            if (loaded) L.store();
+            if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[gg] != 0 && P.rep[s].pr_dest[gg] == d) has_pr = true;
+        if (cnt) {
+            reg = v.ob_reg[par][gg];
+            lead = v.leader[gg] == d;
+            bpd = v.bal_prepared[gg];
+            start = v.start_slot[gg]; len = v.log_len[gg];
         }
-        (void)tickctl;
+    }
+    const bool job = active && (has_pr || cnt > 64);
+    const bool fast4 = active && !job && cnt > 0 && reg != 0 && lead && bpd != 0;
+    // ---- phase 1: parallel tally of my quarter of the rows ------------------------------------
+    if (fast4) {
+        const uint32_t q = (cnt + 3) / 4;
+        const uint32_t jlo = w * q, jhi = (jlo + q < cnt) ? jlo + q : cnt;
+        SMR_G const uint64_t *const ack = v.ack;
+        SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
+        const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
+        for (uint32_t j0 = jlo; j0 < jhi; j0 += 8) {
+            uint32_t ctl[8], m[8]; uint64_t a[8][NR], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool in = j0 + k < jhi;
+                const uint32_t j = j0 + k, slot = reg - 1 + j;
+                ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
+#pragma unroll
+                for (int qq = 0; qq < NR; qq++)
+                    a[k][qq] = (in && (uint32_t)qq < R && (uint32_t)qq != d) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
+                const bool have = in && slot >= start && slot < len;
+                const size_t i = tix(P.W, slot & Wm, g);
+                m[k] = have ? sm[i] : 0xFFFFFFFFu;
+                b[k] = have ? sb[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (j0 + k >= jhi) break;
+                const uint32_t j = j0 + k, slot = reg - 1 + j;
+                const bool have = m[k] != 0xFFFFFFFFu;
+                uint32_t mk = have ? m[k] : 0u;
+                bool changed = false, committed = false;
+                if (have && (mk & M_LBK)) mk = tally_row<NR>(mk, b[k], ctl[k], a[k], bpd, thresh, R, changed, committed);
+                if (changed && !committed) sm[tix(P.W, slot & Wm, g)] = mk;
+                sh_mk[j * 64 + lane] = mk;
+                sh_fl[j * 64 + lane] = (uint8_t)((have ? 1 : 0) | (changed ? 2 : 0) | (committed ? 4 : 0) |
+                                                 ((have && m_st(m[k]) < SMR_ST_COMMITTED) ? 8 : 0));
+            }
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    // ---- phase 2 (wavefront 0): commits in entry order; everything that is not fast4 ------------
+    Lane L(P, d, gg, par);
+    bool loaded = false;
+    if (fast4) {
+        L.load(); loaded = true;
+        SMR_G uint32_t *const sm = v.s_meta;
+        const uint32_t Wm = P.Wmask;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t fl = sh_fl[j * 64 + lane];
+            if ((fl & 6) != 6) continue;                        // not (changed and committed)
+            const uint32_t slot = reg - 1 + j, mk = sh_mk[j * 64 + lane];
+            const uint32_t fn = j + 1 < cnt ? sh_fl[(j + 1) * 64 + lane] : 0u;
+            const bool next_known = (fn & 1) != 0;              // regular outbox: entry j+1 names slot + 1
+            const size_t i = tix(P.W, slot & Wm, g);
+            L.record_commit(slot);
+            const bool stops = (next_known && (fn & 8)) || (slot + 1 >= L.abar && slot + 1 >= L.len);
+            if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
+                sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
+                L.cbar = slot + 1;
+                L.ebar = slot + 1;
+            } else {
+                sm[i] = mk;
+                L.commit_complete<2>(slot, mk);
+            }
+        }
+        L.ob_set(par, 0);
+        if (publish_hb) r3_publish_hb(L);
+        L.store();
+    } else if (active && !job) {
+        if (cnt) { L.load(); loaded = true; r3_accept_replies<NR>(L, ackctl, cnt); }
+        if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
+        if (loaded) L.store();
     }
     unsigned int jc[3] = {0, 0, 0};
     SMR_FOR_EACH_JOB(job, src) {
@@ -528,13 +636,23 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         J.set_uniform();
         J.load();
         r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
-        const uint32_t cnt = P.rep[d].ob_cnt[par][gj];
-        if (cnt) { if (P.R <= 5) r3_accept_replies<5>(J, ackctl, cnt); else r3_accept_replies<MAXR>(J, ackctl, cnt); }
+        const uint32_t cj = P.rep[d].ob_cnt[par][gj];
+        if (cj) r3_accept_replies<NR>(J, ackctl, cj);
         if (publish_hb) r3_publish_hb(J);
         J.store();
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
     }
     flush_counters(L, active && loaded, jc);
+}
+
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+                                                        const uint32_t *__restrict__ ackctl,
+                                                        int publish_hb) {
+    const MpParams &P = *Pp;
+    __shared__ uint32_t sh_mk[64 * 64];
+    __shared__ uint8_t sh_fl[64 * 64];
+    if (P.R <= 5) r3_block<5>(P, par, ackctl, publish_hb, sh_mk, sh_fl);
+    else r3_block<MAXR>(P, par, ackctl, publish_hb, sh_mk, sh_fl);
 }
 
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
@@ -749,8 +867,8 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
-                       publish_heartbeat);
+    hipLaunchKernelGGL(mp_round_replies, dim3((c->cfg.n_groups + 63) / 64, c->cfg.population), dim3(256), 0, st,
+                       c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }
