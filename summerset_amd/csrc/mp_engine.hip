@@ -521,53 +521,63 @@ __device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.r
 
 // R3: replies reach their destination: PrepareReplies (sender order of the
 // tick's ackctl word, FIFO per sender), then the AcceptReply matrix of my own
-// outbox, entry-major with per-entry peer order / loss.  THE quorum kernel.
+// outbox, entry-major with per-entry peer order / loss.  THE quorum kernel, in two launches:
 //
-// Block = 4 wavefronts over the SAME 64 groups.  Steady state (regular outbox of <= 64
-// Accepts on a prepared leader): the wavefronts tally a quarter of the ack-matrix rows each
-// -- all loads of a row batch are independent -- and leave the per-row outcome in LDS; after
-// the barrier wavefront 0 replays the commits in entry order on registers (commit bar, exec
-// bar), which is the only sequential part.  Every other lane (irregular outbox, leader change
-// in flight) is handled by wavefront 0 alone: per lane, or as a cooperative job.
+//  * mp_quorum_tally -- the steady state: a prepared leader whose outbox is "regular"
+//    (<= 64 Accepts for consecutive slots at bal_prepared).  Block = 4 wavefronts over the
+//    SAME 64 groups; each tallies a quarter of the ack-matrix rows (every load of a row batch
+//    is independent of the others) and leaves the per-row outcome in LDS.  After the barrier:
+//    if every row reached the quorum, the rows are the consecutive slots at commit_bar ==
+//    exec_bar and all batches are non-empty, then an entry-by-entry replay would commit and
+//    execute each in turn (both bars + 1 per row), so each wavefront writes its rows Executed
+//    and wavefront 0 moves the bars; otherwise wavefront 0 replays the commits in entry order.
+//  * mp_round_replies -- every other lane (irregular outbox, non-leader, PrepareReplies, the
+//    long outbox of a re-Accept round): per lane, or as a cooperative job for the wavefront.
+__device__ __forceinline__ bool r3_is_fast4(const MpRep &v, int par, uint32_t g, uint32_t d, bool has_pr,
+                                            uint32_t cnt, uint32_t &reg, uint64_t &bpd) {
+    if (has_pr || cnt == 0 || cnt > 64) return false;
+    reg = v.ob_reg[par][g];
+    bpd = v.bal_prepared[g];
+    return reg != 0 && bpd != 0 && v.leader[g] == d;
+}
+
 template <int NR>
-__device__ __forceinline__ void r3_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
-                                         int publish_hb, uint32_t *sh_mk, uint8_t *sh_fl) {
+__device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
+                                                   int publish_hb, uint8_t *sh_fl) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const uint32_t d = blockIdx.y;
     const MpRep &v = P.rep[d];
     const bool active = g < P.G && !P.overflow[g];
     const uint32_t gg = g < P.G ? g : 0;
-    // what every wavefront needs to agree on the lane's mode
     uint32_t cnt = 0, reg = 0;
-    bool has_pr = false, lead = false;
     uint64_t bpd = 0;
-    uint32_t start = 0, len = 0;
+    bool has_pr = false;
     if (active) {
         cnt = v.ob_cnt[par][gg];
 #pragma unroll
         for (int s = 0; s < MAXR; s++)
             if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[gg] != 0 && P.rep[s].pr_dest[gg] == d) has_pr = true;
-        if (cnt) {
-            reg = v.ob_reg[par][gg];
-            lead = v.leader[gg] == d;
-            bpd = v.bal_prepared[gg];
-            start = v.start_slot[gg]; len = v.log_len[gg];
-        }
     }
-    const bool job = active && (has_pr || cnt > 64);
-    const bool fast4 = active && !job && cnt > 0 && reg != 0 && lead && bpd != 0;
-    // ---- phase 1: parallel tally of my quarter of the rows ------------------------------------
+    const bool fast4 = active && r3_is_fast4(v, par, gg, d, has_pr, cnt, reg, bpd);
+    if (!__syncthreads_or(fast4)) return;                       // nothing for this block: leave at once
+    SMR_G uint32_t *const sm = v.s_meta;
+    const uint32_t Wm = P.Wmask;
+    const uint32_t q = (cnt + 3) / 4;
+    const uint32_t jlo = w * q, jhi = (jlo + q < cnt) ? jlo + q : cnt;
+    uint32_t mine[16];                                          // post-tally meta of my rows (q <= 16)
+    // ---- phase 1: parallel tally of my quarter of the rows, 4 rows per batch of loads ----------
     if (fast4) {
-        const uint32_t q = (cnt + 3) / 4;
-        const uint32_t jlo = w * q, jhi = (jlo + q < cnt) ? jlo + q : cnt;
+        const uint32_t start = v.start_slot[gg], len = v.log_len[gg];
         SMR_G const uint64_t *const ack = v.ack;
-        SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
-        const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
-        for (uint32_t j0 = jlo; j0 < jhi; j0 += 8) {
-            uint32_t ctl[8], m[8]; uint64_t a[8][NR], b[8];
+        SMR_G const uint64_t *const sb = v.s_bal;
+        const uint32_t G = P.G, R = P.R, thresh = P.thresh;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+        for (int c = 0; c < 4; c++) {
+            const uint32_t j0 = jlo + 4 * c;
+            uint32_t ctl[4], m[4]; uint64_t a[4][NR], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
                 const bool in = j0 + k < jhi;
                 const uint32_t j = j0 + k, slot = reg - 1 + j;
                 ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
@@ -580,54 +590,94 @@ __device__ __forceinline__ void r3_block(const MpParams &P, int par, const uint3
                 b[k] = have ? sb[i] : 0ull;
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (j0 + k >= jhi) break;
+            for (int k = 0; k < 4; k++) {
+                mine[4 * c + k] = 0;
+                if (j0 + k >= jhi) continue;
                 const uint32_t j = j0 + k, slot = reg - 1 + j;
                 const bool have = m[k] != 0xFFFFFFFFu;
                 uint32_t mk = have ? m[k] : 0u;
                 bool changed = false, committed = false;
                 if (have && (mk & M_LBK)) mk = tally_row<NR>(mk, b[k], ctl[k], a[k], bpd, thresh, R, changed, committed);
+                // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
                 if (changed && !committed) sm[tix(P.W, slot & Wm, g)] = mk;
-                sh_mk[j * 64 + lane] = mk;
+                mine[4 * c + k] = mk;
                 sh_fl[j * 64 + lane] = (uint8_t)((have ? 1 : 0) | (changed ? 2 : 0) | (committed ? 4 : 0) |
-                                                 ((have && m_st(m[k]) < SMR_ST_COMMITTED) ? 8 : 0));
+                                                 ((mk & M_NONEMPTY) ? 16 : 0));
             }
         }
     }
     __syncthreads();
-    if (w != 0) return;
-    // ---- phase 2 (wavefront 0): commits in entry order; everything that is not fast4 ------------
-    Lane L(P, d, gg, par);
-    bool loaded = false;
+    // ---- phase 2: the all-commit closed form, or leave the lane to mp_round_replies ------------------
+    bool closed = false;
+    uint32_t first = reg - 1;
     if (fast4) {
-        L.load(); loaded = true;
-        SMR_G uint32_t *const sm = v.s_meta;
-        const uint32_t Wm = P.Wmask;
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t fl = sh_fl[j * 64 + lane];
-            if ((fl & 6) != 6) continue;                        // not (changed and committed)
-            const uint32_t slot = reg - 1 + j, mk = sh_mk[j * 64 + lane];
-            const uint32_t fn = j + 1 < cnt ? sh_fl[(j + 1) * 64 + lane] : 0u;
-            const bool next_known = (fn & 1) != 0;              // regular outbox: entry j+1 names slot + 1
-            const size_t i = tix(P.W, slot & Wm, g);
-            L.record_commit(slot);
-            const bool stops = (next_known && (fn & 8)) || (slot + 1 >= L.abar && slot + 1 >= L.len);
-            if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
-                sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
-                L.cbar = slot + 1;
-                L.ebar = slot + 1;
-            } else {
-                sm[i] = mk;
-                L.commit_complete<2>(slot, mk);
+        const uint32_t cbar = v.commit_bar[gg], ebar = v.exec_bar[gg], abar = v.accept_bar[gg], len = v.log_len[gg];
+        uint32_t all = 0xFF;
+        for (uint32_t j = 0; j < cnt; j++) all &= sh_fl[j * 64 + lane];
+        // every row: present, changed, committed, non-empty; rows = slots commit_bar.. == exec_bar..,
+        // all below accept_bar, and the run ends behind the last one (accept_bar and log end)
+        closed = (all & 23) == 23 && first == cbar && first == ebar && first + cnt == abar && first + cnt >= len &&
+                 P.clist_cap == 0;
+        if (closed) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t j = jlo + k;
+                if (j < jhi) sm[tix(P.W, (first + j) & Wm, g)] = m_set_st(mine[k], SMR_ST_EXECUTED);
             }
         }
-        L.ob_set(par, 0);
-        if (publish_hb) r3_publish_hb(L);
-        L.store();
-    } else if (active && !job) {
-        if (cnt) { L.load(); loaded = true; r3_accept_replies<NR>(L, ackctl, cnt); }
-        if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
-        if (loaded) L.store();
+    }
+    if (w != 0) return;
+    unsigned int nc = 0;
+    if (closed) {
+        v.commit_bar[gg] = first + cnt;
+        v.exec_bar[gg] = first + cnt;
+        v.ob_cnt[par][gg] = 0;                                  // outbox consumed: nothing left for mp_round_replies
+        if (publish_hb) {                                       // leadership.rs:240-247 record
+            v.hb_bal[gg] = v.bal_max_seen[gg]; v.hb_commit[gg] = first + cnt; v.hb_exec[gg] = first + cnt;
+            v.hb_snap[gg] = v.snap_bar[gg];
+        }
+        nc = cnt;
+    }
+    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
+    if (lane == 0 && nc) atomicAdd((unsigned long long *)&v.counters[0], (unsigned long long)nc);
+}
+
+__global__ __launch_bounds__(256) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
+                                                       const uint32_t *__restrict__ ackctl, int publish_hb) {
+    const MpParams &P = *Pp;
+    __shared__ uint8_t sh_fl[64 * 64];
+    if (P.R <= 5) quorum_tally_block<5>(P, par, ackctl, publish_hb, sh_fl);
+    else quorum_tally_block<MAXR>(P, par, ackctl, publish_hb, sh_fl);
+}
+
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+                                                        const uint32_t *__restrict__ ackctl,
+                                                        int publish_hb) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t d = blockIdx.y;
+    Lane L(P, d, g < P.G ? g : 0, par);
+    bool active = g < P.G && !P.overflow[g];
+    bool loaded = false, job = false;
+    if (active) {
+        const MpRep &v = P.rep[d];
+        bool has_pr = false;
+#pragma unroll
+        for (int s = 0; s < MAXR; s++)
+            if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[g] != 0 && P.rep[s].pr_dest[g] == d) has_pr = true;
+        const uint32_t cnt = v.ob_cnt[par][g];
+        // (a lane mp_quorum_tally closed shows up here with an empty outbox)
+        // a leader change in flight (PrepareReplies for me, or the long outbox of the
+        // re-Accept round) is a cooperative job for the whole wave
+        job = has_pr || cnt > 64;
+        if (!job) {
+            if (cnt) {
+                L.load(); loaded = true;
+                if (P.R <= 5) r3_accept_replies<5>(L, ackctl, cnt); else r3_accept_replies<MAXR>(L, ackctl, cnt);
+            }
+            if (publish_hb) { if (!loaded) { L.load(); loaded = true; } r3_publish_hb(L); }
+            if (loaded) L.store();
+        }
     }
     unsigned int jc[3] = {0, 0, 0};
     SMR_FOR_EACH_JOB(job, src) {
@@ -637,22 +687,12 @@ __device__ __forceinline__ void r3_block(const MpParams &P, int par, const uint3
         J.load();
         r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
         const uint32_t cj = P.rep[d].ob_cnt[par][gj];
-        if (cj) r3_accept_replies<NR>(J, ackctl, cj);
+        if (cj) { if (P.R <= 5) r3_accept_replies<5>(J, ackctl, cj); else r3_accept_replies<MAXR>(J, ackctl, cj); }
         if (publish_hb) r3_publish_hb(J);
         J.store();
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
     }
     flush_counters(L, active && loaded, jc);
-}
-
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
-                                                        const uint32_t *__restrict__ ackctl,
-                                                        int publish_hb) {
-    const MpParams &P = *Pp;
-    __shared__ uint32_t sh_mk[64 * 64];
-    __shared__ uint8_t sh_fl[64 * 64];
-    if (P.R <= 5) r3_block<5>(P, par, ackctl, publish_hb, sh_mk, sh_fl);
-    else r3_block<MAXR>(P, par, ackctl, publish_hb, sh_mk, sh_fl);
 }
 
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
@@ -721,6 +761,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     const size_t Gp = (G + 63) / 64 * 64;               // wave-tiled arrays hold whole 64-group tiles
     MpParams &P = c->hp;
     carve(a, P.overflow, G, dry);
+    carve(a, P.dbg, 64, dry);
     for (size_t r = 0; r < R; r++) {
         MpRep &v = P.rep[r];
         carve(a, v.leader, G, dry);
@@ -867,8 +908,11 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_replies, dim3((c->cfg.n_groups + 63) / 64, c->cfg.population), dim3(256), 0, st,
+    hipLaunchKernelGGL(mp_quorum_tally, dim3((c->cfg.n_groups + 63) / 64, c->cfg.population), dim3(256), 0, st,
                        c->dp, c->par, ackctl_dev, publish_heartbeat);
+    SMR_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
+                       publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     return prof_end(c, st);
 }
@@ -998,6 +1042,13 @@ int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
     unsigned long long h[4];
     SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
     *out = h[3];
+    return SMR_OK;
+}
+
+int smr_mp_debug_stamps(smr_mp_cluster *c, uint64_t *out64) {
+    if (!c || !out64) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    SMR_HIP_TRY(hipMemcpy(out64, c->hp.dbg, 64 * 8, hipMemcpyDeviceToHost));
     return SMR_OK;
 }
 

@@ -120,6 +120,7 @@ struct MpParams {
     uint32_t G, W, Wmask, cap, pcap, win_reserve, clist_cap;
     uint32_t R, quorum, thresh, rspaxos;
     SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
+    SMR_G unsigned long long *dbg;  // [64] debug clock stamps (block 100 of the leader row)
     MpRep rep[MAXR];
 };
 
