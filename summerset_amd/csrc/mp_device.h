@@ -387,8 +387,14 @@ struct Lane {
     // uniform mode (each lane checks every 64th slot, then a wave-wide min).
     __device__ __forceinline__ uint32_t first_status_below(uint32_t lo, uint32_t hi, uint32_t bound) const {
         uint32_t found = hi;
-        for (uint32_t s = lo + cl; s < hi; s += cn)
-            if (m_st(v.s_meta[ix(s)]) < bound) { found = s; break; }
+        for (uint32_t s0 = lo + cl; s0 < hi && found == hi; s0 += 4 * cn) {
+            uint32_t mm[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) mm[u] = (s0 + u * cn < hi) ? v.s_meta[ix(s0 + u * cn)] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (found == hi && mm[u] != 0xFFFFFFFFu && m_st(mm[u]) < bound) found = s0 + u * cn;
+        }
         return coop() ? wave_min(found) : found;
     }
     // last slot of [lo, hi) whose status is below `bound` (below = true) or above it, else `none`
@@ -561,23 +567,37 @@ struct Lane {
         if (!(v.s_meta[ix(trig)] & M_LBK)) return;              // :120-125
         const uint32_t len0 = len;
         const uint32_t n_mine = trig + n <= len0 ? n : len0 - trig;      // replies for slots I already hold
-        for (uint32_t k = cl; k < n_mine; k += cn) {             // :196-216, every lane owns its slots
-            const uint32_t slot = trig + k;
-            const size_t o = tix(P.pcap, k, g), i = ix(slot);
-            const uint64_t vb = pr_vbal[o];
-            if (vb == 0) continue;                               // voted: None
-            uint32_t m = v.s_meta[i];
-            const uint64_t b = v.s_bal[i];
-            if (m_st(m) != SMR_ST_PREPARING || ballot < b || !(m & M_LBK)) continue;
-            const uint64_t cur = (m & M_LBKX) ? v.s_pmax[i] : 0ull;
-            if (vb > cur) {
-                const uint32_t vv = pr_vval[o];
-                if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
-                v.s_pmax[i] = vb;
-                m = materialize_voted(i, m, b, v.s_val[i], true);
-                v.s_val[i] = vv;
-                m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                v.s_meta[i] = m;
+        // This ballot already has its quorum and every slot of the batch is one I hold: the quorum
+        // step moved all Preparing slots from the trigger on to Accepting, so each reply fails the
+        // status test of :196-198 and nothing (not even prepare_acks, :222 comes after) changes.
+        if (bpd == ballot && n_mine == n) return;
+        for (uint32_t k0 = cl; k0 < n_mine; k0 += 4 * cn) {      // :196-216, every lane owns its slots;
+            uint64_t vb[4], bb[4], pm[4]; uint32_t mm[4], vv[4], vl[4];   // 4 strided slots per lane, loads first
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + u * cn;
+                const bool in = k < n_mine;
+                const size_t o = tix(P.pcap, in ? k : 0, g), i = ix(trig + (in ? k : 0));
+                vb[u] = in ? pr_vbal[o] : 0ull; vv[u] = in ? pr_vval[o] : 0u;
+                mm[u] = in ? v.s_meta[i] : 0u; bb[u] = in ? v.s_bal[i] : 0ull;
+                pm[u] = in ? v.s_pmax[i] : 0ull; vl[u] = in ? v.s_val[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = k0 + u * cn;
+                if (k >= n_mine || vb[u] == 0) continue;         // voted: None
+                uint32_t m = mm[u];
+                if (m_st(m) != SMR_ST_PREPARING || ballot < bb[u] || !(m & M_LBK)) continue;
+                const uint64_t cur = (m & M_LBKX) ? pm[u] : 0ull;
+                if (vb[u] > cur) {
+                    const size_t i = ix(trig + k);
+                    if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
+                    v.s_pmax[i] = vb[u];
+                    m = materialize_voted(i, m, bb[u], vl[u], true);
+                    v.s_val[i] = vv[u];
+                    m = vv[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                    v.s_meta[i] = m;
+                }
             }
         }
         if (n_mine == n) {                                       // the batch ends inside my log: :222
@@ -585,6 +605,27 @@ struct Lane {
                 const size_t i = ix(endp);
                 if (m_st(v.s_meta[i]) == SMR_ST_PREPARING && ballot >= v.s_bal[i]) prepare_quorum_step(peer, trig, ballot);
             }
+            return;
+        }
+        if (coop() && (len0 - start) + (n - n_mine) <= P.W) {
+            // Unknown slots (:154-190), all at once: slot len0 + t is pushed, becomes a Preparing
+            // instance of this Prepare phase with a fresh LeaderBookkeeping, and then takes the reply
+            // (:196-216 with prepare_max_bal == 0): the voted value, if any.  One lane per slot.
+            const size_t ti = ix(trig);
+            const uint32_t tm = v.s_meta[ti];
+            const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp[ti] : 0;   // :149-153
+            for (uint32_t k = n_mine + cl; k < n; k += cn) {
+                const size_t o = tix(P.pcap, k, g), i = ix(trig + k);
+                const uint64_t vb = pr_vbal[o];
+                const uint32_t vv = vb > 0 ? pr_vval[o] : 0u;
+                v.s_bal[i] = bps;
+                v.s_val[i] = vv;
+                v.s_ltrig[i] = trig; v.s_lendp[i] = my_endp; v.s_pmax[i] = vb;
+                v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX | (vv ? M_NONEMPTY : 0u);
+            }
+            if (nlb == len0) nlb = trig + n;                     // filled at once: no Null below the log end
+            len = trig + n;
+            if (endp >= trig + n_mine && endp < trig + n) prepare_quorum_step(peer, trig, ballot);   // :222
             return;
         }
         for (uint32_t k = n_mine; k < n && !ovf; k++) {          // unknown slots: pad + reply, one by one

@@ -38,6 +38,7 @@ __device__ __forceinline__ void flush_counters(const Lane &L, bool active, const
 // wavefront takes the lanes that need it one at a time and ALL 64 lanes execute that
 // lane's (group, replica) handler in uniform mode (Lane::set_uniform), slot loops
 // strided by lane.  `pending` = this lane has such a job.
+#define JSTAMP(k) do { if (__lane_id() == 0) P.dbg[(k)] = wall_clock64(); } while (0)
 #define SMR_FOR_EACH_JOB(pending, src)                                            \
     for (unsigned long long _jm = __ballot(pending); _jm; _jm &= _jm - 1)        \
         if (const int src = __ffsll((long long)_jm) - 1; true)
@@ -120,10 +121,14 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
         const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src);
         Lane J(P, r, gj, par);
         J.set_uniform();
+        JSTAMP(8);
         J.load();
+        JSTAMP(9);
         J.become_a_leader(timeout_src[gj]);
+        JSTAMP(10);
         r1_generic_batches(J, req_val, 0, nj);
         J.store();
+        JSTAMP(11);
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
     }
     flush_counters(L, active, jc);
@@ -141,15 +146,84 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         const MpRep &snd = P.rep[s];
         const uint32_t cnt = snd.ob_cnt[par][g];
         uint32_t jstart = (s == first_sender ? first_j : 0u);
-        // Uniform mode: 64 messages per step, one per lane, when they are the re-Accept round of a
-        // new leader -- all Accepts at one ballot >= bal_max_seen for consecutive slots I already
-        // hold.  Per message this is msg_accept(); the accept_bar scan runs on the bitmap.
+        // Uniform mode, first choice: the whole rest of this outbox (<= 512 messages) is ONE run of
+        // Accepts at one ballot >= bal_max_seen for consecutive slots that start inside or right at
+        // the end of my log (the re-Accept round of a new leader followed by its new batches).  Each
+        // lane takes every 64th message; all loads of the run go out in two rounds.  Per message this
+        // is msg_accept(); the accept_bar scan that the message AT accept_bar starts ends behind the
+        // run (every slot of it is Accepting by then) and goes on in memory.
+        if (L.coop() && jstart < cnt && cnt - jstart <= 512 && !L.ovf) {
+            const uint32_t n = cnt - jstart;
+            uint32_t e[8], tok[8]; uint64_t bl[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t t = L.cl + 64u * u;
+                const bool in = t < n;
+                const size_t o = tix(P.cap, jstart + (in ? t : 0), g);
+                e[u] = in ? snd.ob_slot[par][o] : 0u; bl[u] = in ? snd.ob_bal[par][o] : 0ull;
+                tok[u] = in ? snd.ob_val[par][o] : 0u;
+            }
+            const uint32_t slot0 = __shfl(e[0], 0) & OB_SLOT_MASK;
+            const uint64_t bal0 = __shfl(bl[0], 0);
+            bool fits = true;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t t = L.cl + 64u * u;
+                if (t < n) fits = fits && e[u] == ((OB_ACCEPT << OB_KIND_SH) | ((slot0 + t) & OB_SLOT_MASK)) && bl[u] == bal0;
+            }
+            const uint32_t len0 = L.len;
+            if (__all(fits) && bal0 >= L.bms && slot0 >= L.start && slot0 <= len0) {
+                const uint32_t n_old = (len0 - slot0 < n) ? len0 - slot0 : n, n_new = n - n_old;
+                const bool mine_before = L.is_leader();
+                uint32_t ldr = L.leader; uint64_t bm = L.bms;
+                if (bal0 > bm) { ldr = s; bm = bal0; }            // check_leader, messages.rs:313-316
+                if ((len0 - L.start) + n_new <= P.W && ldr != r) {
+                    (void)mine_before;
+                    L.leader = ldr; L.bms = bm;
+                    const MpRep &v = P.rep[r];
+                    uint32_t mo[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t t = L.cl + 64u * u;
+                        mo[u] = (t < n_old) ? v.s_meta[L.ix(slot0 + t)] : 0u;   // fresh instance beyond my log end
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const uint32_t t = L.cl + 64u * u;
+                        if (t >= n) continue;
+                        const size_t i = L.ix(slot0 + t);
+                        uint32_t m = m_set_st(mo[u], SMR_ST_ACCEPTING);     // :327-329
+                        if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;        // :331-339
+                        m = m_set_src(m, s);
+                        m = m_set_vmode(m, VM_SAME);                         // :351
+                        m = tok[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
+                        v.s_bal[i] = bal0; v.s_val[i] = tok[u]; v.s_meta[i] = m;
+                        snd.ack[tix(P.cap * P.R, (jstart + t) * P.R + r, g)] = bal0;   // durability.rs:108-131
+                    }
+                    if (n_new) {
+                        if (L.nlb == len0) L.nlb = len0 + n_new;  // still no Null below the log end
+                        L.len = len0 + n_new;
+                    }
+                    if (L.abar >= slot0 && L.abar < slot0 + n) {  // durability.rs:134-142
+                        L.abar = slot0 + n;
+                        while (L.abar < L.len) {
+                            if (m_st(v.s_meta[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
+                            L.abar++;
+                        }
+                    }
+                    jstart = cnt;
+                }
+            }
+        }
+        // Uniform mode, second choice: 64 messages per step, one per lane, when they are a run as
+        // above.  Per message this is msg_accept(); the accept_bar scan runs on the bitmap.
         while (L.coop() && jstart < cnt && !L.ovf) {
             const uint32_t j = jstart + L.cl;
             const bool in = j < cnt;
             const size_t o = tix(P.cap, j, g);
             const uint32_t e = in ? snd.ob_slot[par][o] : 0u;
             const uint64_t bl = in ? snd.ob_bal[par][o] : 0ull;
+            const uint32_t tok = in ? snd.ob_val[par][o] : 0u;   // fetched with the header: one round of loads
             const uint32_t slot = e & OB_SLOT_MASK;
             const uint32_t slot0 = __shfl(slot, 0);
             const uint64_t bal0 = __shfl(bl, 0);
@@ -165,7 +239,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             uint32_t m = 0;
             if (in) {
                 const size_t i = L.ix(slot);
-                const uint32_t val = snd.ob_val[par][o];
+                const uint32_t val = tok;
                 m = appending ? 0u : v.s_meta[i];
                 m = m_set_st(m, SMR_ST_ACCEPTING);              // :327-329
                 if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;    // :331-339
@@ -316,9 +390,13 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
         const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src);
         Lane J(P, r, gj, par);
         J.set_uniform();
+        JSTAMP(16);
         J.load();
+        JSTAMP(17);
         r2_generic(J, sj, jj);
+        JSTAMP(18);
         J.store();
+        JSTAMP(19);
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
     }
     flush_counters(L, active && loaded, jc);
@@ -684,12 +762,17 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         const uint32_t gj = __shfl(g, src);
         Lane J(P, d, gj, par);
         J.set_uniform();
+        JSTAMP(24);
         J.load();
+        JSTAMP(25);
         r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
+        JSTAMP(26);
         const uint32_t cj = P.rep[d].ob_cnt[par][gj];
         if (cj) { if (P.R <= 5) r3_accept_replies<5>(J, ackctl, cj); else r3_accept_replies<MAXR>(J, ackctl, cj); }
+        JSTAMP(27);
         if (publish_hb) r3_publish_hb(J);
         J.store();
+        JSTAMP(28);
         jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
     }
     flush_counters(L, active && loaded, jc);
