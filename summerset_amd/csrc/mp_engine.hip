@@ -498,8 +498,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
                 const unsigned long long full = nin == 64 ? ~0ull : ((1ull << nin) - 1ull);
                 const uint32_t slot0 = __shfl(slot, 0);
                 const bool shape = !in || (have && slot == slot0 + L.cl && (mk & M_NONEMPTY));
-                if (cm == full && __all(shape) && slot0 == L.cbar && slot0 == L.ebar && slot0 + nin <= L.abar &&
-                    P.clist_cap == 0) {
+                if (cm == full && __all(shape) && slot0 == L.cbar && slot0 + nin <= L.abar && P.clist_cap == 0) {
                     bool tail_ok = slot0 + nin >= L.abar && slot0 + nin >= L.len;   // run ends with the log ...
                     if (!tail_ok && slot0 + nin < L.len)
                         tail_ok = m_st(sm[tix(P.W, (slot0 + nin) & Wm, g)]) < SMR_ST_COMMITTED;   // next slot not committed yet
@@ -507,7 +506,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
                         if (in) sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
                         L.n_commit += nin;
                         L.cbar = slot0 + nin;
-                        L.ebar = slot0 + nin;
+                        if (L.ebar >= slot0 && L.ebar < slot0 + nin) L.ebar = slot0 + nin;   // rides from the row at it
                         cm = 0;
                     }
                 }
@@ -521,10 +520,10 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
                 const size_t ci = tix(P.W, cs & Wm, g);
                 L.record_commit(cs);
                 const bool stops = (next_known && m_st(nm) < SMR_ST_COMMITTED) || (cs + 1 >= L.abar && cs + 1 >= L.len);
-                if (cs == L.cbar && cs == L.ebar && cs < L.abar && (cmk & M_NONEMPTY) && stops) {
+                if (cs == L.cbar && cs < L.abar && stops) {
                     if (L.wr) sm[ci] = m_set_st(cmk, SMR_ST_EXECUTED);
                     L.cbar = cs + 1;
-                    L.ebar = cs + 1;
+                    if ((cmk & M_NONEMPTY) && cs == L.ebar) L.ebar = cs + 1;   // execution.rs:70
                 } else {
                     if (L.wr) sm[ci] = cmk;
                     L.commit_complete<2>(cs, cmk, next_known ? nm : 0xFFFFFFFFu);
@@ -579,10 +578,10 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             // commit_bar == exec_bar below accept_bar with a non-empty batch, and the
             // run ends right behind it (next slot still Accepting, or the log ends).
             const bool stops = (next_known && m_st(m[kn]) < SMR_ST_COMMITTED) || (slot + 1 >= L.abar && slot + 1 >= L.len);
-            if (slot == L.cbar && slot == L.ebar && slot < L.abar && (mk & M_NONEMPTY) && stops) {
+            if (slot == L.cbar && slot < L.abar && stops) {
                 if (L.wr) sm[i] = m_set_st(mk, SMR_ST_EXECUTED);
                 L.cbar = slot + 1;
-                L.ebar = slot + 1;
+                if ((mk & M_NONEMPTY) && slot == L.ebar) L.ebar = slot + 1;   // execution.rs:70
             } else {
                 if (L.wr) sm[i] = mk;
                 L.commit_complete<2>(slot, mk, next_known ? m[kn] : 0xFFFFFFFFu);
@@ -687,15 +686,16 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     __syncthreads();
     // ---- phase 2: the all-commit closed form, or leave the lane to mp_round_replies ------------------
     bool closed = false;
-    uint32_t first = reg - 1;
+    uint32_t first = reg - 1, ebar_new = 0;
     if (fast4) {
         const uint32_t cbar = v.commit_bar[gg], ebar = v.exec_bar[gg], abar = v.accept_bar[gg], len = v.log_len[gg];
         uint32_t all = 0xFF;
         for (uint32_t j = 0; j < cnt; j++) all &= sh_fl[j * 64 + lane];
-        // every row: present, changed, committed, non-empty; rows = slots commit_bar.. == exec_bar..,
-        // all below accept_bar, and the run ends behind the last one (accept_bar and log end)
-        closed = (all & 23) == 23 && first == cbar && first == ebar && first + cnt == abar && first + cnt >= len &&
-                 P.clist_cap == 0;
+        // every row: present, changed, committed, non-empty; rows = slots commit_bar.., all below
+        // accept_bar, and the run ends behind the last one (accept_bar and log end).  exec_bar rides
+        // along from the row that sits AT it (execution.rs:70), if any -- a pinned exec_bar stays.
+        closed = (all & 23) == 23 && first == cbar && first + cnt == abar && first + cnt >= len && P.clist_cap == 0;
+        ebar_new = (ebar >= first && ebar < first + cnt) ? first + cnt : ebar;
         if (closed) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -708,10 +708,10 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     unsigned int nc = 0;
     if (closed) {
         v.commit_bar[gg] = first + cnt;
-        v.exec_bar[gg] = first + cnt;
+        v.exec_bar[gg] = ebar_new;
         v.ob_cnt[par][gg] = 0;                                  // outbox consumed: nothing left for mp_round_replies
         if (publish_hb) {                                       // leadership.rs:240-247 record
-            v.hb_bal[gg] = v.bal_max_seen[gg]; v.hb_commit[gg] = first + cnt; v.hb_exec[gg] = first + cnt;
+            v.hb_bal[gg] = v.bal_max_seen[gg]; v.hb_commit[gg] = first + cnt; v.hb_exec[gg] = ebar_new;
             v.hb_snap[gg] = v.snap_bar[gg];
         }
         nc = cnt;
