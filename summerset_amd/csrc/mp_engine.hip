@@ -618,31 +618,45 @@ __device__ __forceinline__ bool r3_is_fast4(const MpRep &v, int par, uint32_t g,
     return reg != 0 && bpd != 0 && v.leader[g] == d;
 }
 
+// which replicas have PrepareReplies addressed to them (bit d), for group g
+__device__ __forceinline__ uint32_t r3_pr_dest_mask(const MpParams &P, uint32_t g) {
+    uint32_t mask = 0;
+#pragma unroll
+    for (int s = 0; s < MAXR; s++)
+        if ((uint32_t)s < P.R && P.rep[s].pr_cnt[g] != 0) mask |= 1u << P.rep[s].pr_dest[g];
+    return mask;
+}
+
+// Block = 4 wavefronts over the same 64 groups, ALL replicas: every lane works for the one
+// replica of its group that has a steady-state tally to do (its prepared leader), so there is
+// no block without work.  The kernel also publishes the heartbeat record of every replica whose
+// round is already complete, and tells mp_round_replies which (replica, tile) pairs still need it.
 template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
                                                    int publish_hb, uint8_t *sh_fl) {
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
-    const uint32_t d = blockIdx.y;
-    const MpRep &v = P.rep[d];
     const bool active = g < P.G && !P.overflow[g];
     const uint32_t gg = g < P.G ? g : 0;
-    uint32_t cnt = 0, reg = 0;
-    uint64_t bpd = 0;
-    bool has_pr = false;
-    if (active) {
-        cnt = v.ob_cnt[par][gg];
+    // one round of loads: every replica's outbox count and who is owed PrepareReplies
+    uint32_t cnts[MAXR];
 #pragma unroll
-        for (int s = 0; s < MAXR; s++)
-            if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[gg] != 0 && P.rep[s].pr_dest[gg] == d) has_pr = true;
-    }
-    const bool fast4 = active && r3_is_fast4(v, par, gg, d, has_pr, cnt, reg, bpd);
-    if (!__syncthreads_or(fast4)) return;                       // nothing for this block: leave at once
+    for (int d = 0; d < MAXR; d++) cnts[d] = (active && (uint32_t)d < P.R) ? P.rep[d].ob_cnt[par][gg] : 0u;
+    const uint32_t prmask = active ? r3_pr_dest_mask(P, gg) : 0u;
+    // my replica: the lowest one with a non-empty outbox (a second one, if any, is left to mp_round_replies)
+    uint32_t dl = P.R, cnt = 0;
+#pragma unroll
+    for (int d = MAXR - 1; d >= 0; d--) if (cnts[d] != 0) { dl = (uint32_t)d; cnt = cnts[d]; }
+    const MpRep &v = P.rep[dl < P.R ? dl : 0];                  // per-lane replica: pointers become vector values
+    uint32_t reg = 0;
+    uint64_t bpd = 0;
+    const bool fast4 = active && dl < P.R && r3_is_fast4(v, par, gg, dl, (prmask >> dl) & 1u, cnt, reg, bpd);
+    __syncthreads();
     SMR_G uint32_t *const sm = v.s_meta;
     const uint32_t Wm = P.Wmask;
-    const uint32_t q = (cnt + 3) / 4;
-    const uint32_t jlo = w * q, jhi = (jlo + q < cnt) ? jlo + q : cnt;
-    uint32_t mine[16];                                          // post-tally meta of my rows (q <= 16)
+    const uint32_t q4 = (cnt + 3) / 4;
+    const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
+    uint32_t mine[16];                                          // post-tally meta of my rows (q4 <= 16)
     // ---- phase 1: parallel tally of my quarter of the rows, 4 rows per batch of loads ----------
     if (fast4) {
         const uint32_t start = v.start_slot[gg], len = v.log_len[gg];
@@ -660,7 +674,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
                 ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
 #pragma unroll
                 for (int qq = 0; qq < NR; qq++)
-                    a[k][qq] = (in && (uint32_t)qq < R && (uint32_t)qq != d) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
+                    a[k][qq] = (in && (uint32_t)qq < R && (uint32_t)qq != dl) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
                 const bool have = in && slot >= start && slot < len;
                 const size_t i = tix(P.W, slot & Wm, g);
                 m[k] = have ? sm[i] : 0xFFFFFFFFu;
@@ -686,7 +700,8 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     __syncthreads();
     // ---- phase 2: the all-commit closed form, or leave the lane to mp_round_replies ------------------
     bool closed = false;
-    uint32_t first = reg - 1, ebar_new = 0;
+    const uint32_t first = reg - 1;
+    uint32_t ebar_new = 0;
     if (fast4) {
         const uint32_t cbar = v.commit_bar[gg], ebar = v.exec_bar[gg], abar = v.accept_bar[gg], len = v.log_len[gg];
         uint32_t all = 0xFF;
@@ -710,14 +725,35 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         v.commit_bar[gg] = first + cnt;
         v.exec_bar[gg] = ebar_new;
         v.ob_cnt[par][gg] = 0;                                  // outbox consumed: nothing left for mp_round_replies
-        if (publish_hb) {                                       // leadership.rs:240-247 record
-            v.hb_bal[gg] = v.bal_max_seen[gg]; v.hb_commit[gg] = first + cnt; v.hb_exec[gg] = ebar_new;
-            v.hb_snap[gg] = v.snap_bar[gg];
-        }
         nc = cnt;
     }
-    for (int off = 32; off > 0; off >>= 1) nc += __shfl_xor(nc, off);
-    if (lane == 0 && nc) atomicAdd((unsigned long long *)&v.counters[0], (unsigned long long)nc);
+    // which replicas of my group still need mp_round_replies: a non-empty outbox I did not close,
+    // or PrepareReplies waiting; everybody else's round is complete
+    uint32_t need = prmask;
+#pragma unroll
+    for (int d = 0; d < MAXR; d++)
+        if (cnts[d] != 0 && !(closed && (uint32_t)d == dl)) need |= 1u << d;
+    if (!active) need = 0;
+    if (publish_hb && active) {                                 // leadership.rs:240-247 record, complete rounds only
+        for (uint32_t d = 0; d < P.R; d++) {
+            if ((need >> d) & 1u) continue;                     // mp_round_replies publishes after its work
+            const MpRep &u = P.rep[d];
+            u.hb_bal[gg] = u.bal_max_seen[gg]; u.hb_commit[gg] = u.commit_bar[gg]; u.hb_exec[gg] = u.exec_bar[gg];
+            u.hb_snap[gg] = u.snap_bar[gg];
+        }
+    }
+    // commit counter of each lane's replica: sum per replica over the wavefront
+    for (uint32_t d = 0; d < P.R; d++) {
+        unsigned int x = (closed && dl == d) ? nc : 0u;
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d].counters[0], (unsigned long long)x);
+    }
+    uint32_t nd = need;
+    for (int off = 32; off > 0; off >>= 1) nd |= __shfl_xor(nd, off);
+    if (lane == 0) {
+        const uint32_t ntile = (P.G + 63) / 64;
+        for (uint32_t d = 0; d < P.R; d++) P.r3_need[(size_t)d * ntile + blockIdx.x] = (uint8_t)((nd >> d) & 1u);
+    }
 }
 
 __global__ __launch_bounds__(256) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
@@ -734,6 +770,13 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
     const MpParams &P = *Pp;
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t d = blockIdx.y;
+    {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
+        const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)d * ntile + t0 + k] : 0u;
+        if (!any) return;
+    }
     Lane L(P, d, g < P.G ? g : 0, par);
     bool active = g < P.G && !P.overflow[g];
     bool loaded = false, job = false;
@@ -845,6 +888,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     MpParams &P = c->hp;
     carve(a, P.overflow, G, dry);
     carve(a, P.dbg, 64, dry);
+    carve(a, P.r3_need, R * ((G + 63) / 64), dry);
     for (size_t r = 0; r < R; r++) {
         MpRep &v = P.rep[r];
         carve(a, v.leader, G, dry);
@@ -991,7 +1035,7 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_quorum_tally, dim3((c->cfg.n_groups + 63) / 64, c->cfg.population), dim3(256), 0, st,
+    hipLaunchKernelGGL(mp_quorum_tally, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
                        c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,

@@ -120,7 +120,8 @@ struct MpParams {
     uint32_t G, W, Wmask, cap, pcap, win_reserve, clist_cap;
     uint32_t R, quorum, thresh, rspaxos;
     SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
-    SMR_G unsigned long long *dbg;  // [64] debug clock stamps (block 100 of the leader row)
+    SMR_G unsigned long long *dbg;  // [64] debug clock stamps
+    SMR_G uint8_t *r3_need;         // [R][ceil(G/64)]: this 64-group tile has work left for mp_round_replies
     MpRep rep[MAXR];
 };
 
