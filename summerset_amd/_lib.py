@@ -112,7 +112,7 @@ def load():
             raise SummersetError(SMR_ERR_STATE, "libsummerset_hip.so is not built: run "
                                  "`python -c 'import __graft_entry__ as g; g.build()'` "
                                  "(there is no CPU fallback)")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("SUMMERSET_HIP_LIB", LIB_PATH))   # override: kernel-variant experiments only
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)        # AttributeError if the ABI lost a symbol
             fn.restype = res

@@ -424,13 +424,9 @@ __device__ __forceinline__ void r3_prepare_replies(Lane &L, uint32_t tickctl) {
 // not a duplicate (:404-406); replies taken in the ackctl order, lost ones skipped; the
 // mask freezes once popcount reaches the threshold (:412).
 template <int NR>
-__device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t ctl, const uint64_t (&a)[NR],
-                                              uint64_t bpd, uint32_t thresh, uint32_t R, bool &changed,
-                                              bool &committed) {
-    uint32_t valid = 0;                                          // bit s: replica s answered with bal_prepared
-#pragma unroll
-    for (int q = 0; q < NR; q++) valid |= (uint32_t)(a[q] != 0 && a[q] == bpd) << q;
-    valid &= ~ctl_drop(ctl);
+__device__ __forceinline__ uint32_t tally_valid(uint32_t m, uint64_t b, uint32_t ctl, uint32_t valid, uint64_t bpd,
+                                                uint32_t thresh, uint32_t R, bool &changed, bool &committed) {
+    valid &= ~ctl_drop(ctl);                                     // bit s: replica s answered with bal_prepared
     uint32_t accepting = (m_st(m) == SMR_ST_ACCEPTING && bpd >= b) ? 1u : 0u;
     uint32_t acks = m_acks(m), chg = 0, done = 0;
 #pragma unroll
@@ -448,6 +444,16 @@ __device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t c
     m = (m & ~(0xFFu << M_ACKS_SH)) | (acks << M_ACKS_SH);
     if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
     return m;
+}
+
+template <int NR>
+__device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t ctl, const uint64_t (&a)[NR],
+                                              uint64_t bpd, uint32_t thresh, uint32_t R, bool &changed,
+                                              bool &committed) {
+    uint32_t valid = 0;
+#pragma unroll
+    for (int q = 0; q < NR; q++) valid |= (uint32_t)(a[q] != 0 && a[q] == bpd) << q;
+    return tally_valid<NR>(m, b, ctl, valid, bpd, thresh, R, changed, committed);
 }
 
 // (b) AcceptReplies to my Accepts of this tick: the ack matrix of my outbox, entry-major,
@@ -627,105 +633,131 @@ __device__ __forceinline__ uint32_t r3_pr_dest_mask(const MpParams &P, uint32_t 
     return mask;
 }
 
+// the same array of another replica: the arena lays every replica out identically
+template <typename T>
+__device__ __forceinline__ T *rep_shift(T *p0, size_t byte_off) { return (T *)((SMR_G char *)p0 + byte_off); }
+
 // Block = 4 wavefronts over the same 64 groups, ALL replicas: every lane works for the one
 // replica of its group that has a steady-state tally to do (its prepared leader), so there is
 // no block without work.  The kernel also publishes the heartbeat record of every replica whose
 // round is already complete, and tells mp_round_replies which (replica, tile) pairs still need it.
+// Loads are arranged in three dependent rounds: (1) who has an outbox, (2) that replica's
+// scalars + its ack-matrix rows, (3) the ring rows.
 template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
-                                                   int publish_hb, uint8_t *sh_fl) {
+                                                   int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk) {
+#ifndef TALLY_C
+#define TALLY_C 4
+#endif
+    constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
+    constexpr int NC = NR - 1;                                  // ack columns: every replica but mine
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
-    const bool active = g < P.G && !P.overflow[g];
     const uint32_t gg = g < P.G ? g : 0;
-    // one round of loads: every replica's outbox count and who is owed PrepareReplies
-    uint32_t cnts[MAXR];
+    const uint32_t R = P.R, G = P.G, Wm = P.Wmask, thresh = P.thresh;
+    // ---- round 1: every replica's outbox count and who is owed PrepareReplies --------------------
+    const uint32_t ovf = P.overflow[gg];
+    uint32_t cnts[MAXR], prc[MAXR], prd[MAXR];
 #pragma unroll
-    for (int d = 0; d < MAXR; d++) cnts[d] = (active && (uint32_t)d < P.R) ? P.rep[d].ob_cnt[par][gg] : 0u;
-    const uint32_t prmask = active ? r3_pr_dest_mask(P, gg) : 0u;
+    for (int d = 0; d < MAXR; d++) {
+        const bool in = (uint32_t)d < R;
+        cnts[d] = in ? P.rep[d].ob_cnt[par][gg] : 0u;
+        prc[d] = in ? P.rep[d].pr_cnt[gg] : 0u;
+        prd[d] = in ? P.rep[d].pr_dest[gg] : 0u;
+    }
+    const bool active = g < G && !ovf;
+    uint32_t prmask = 0;
+#pragma unroll
+    for (int d = 0; d < MAXR; d++) {
+        if (!active) cnts[d] = 0;
+        if (active && prc[d] != 0) prmask |= 1u << prd[d];
+    }
     // my replica: the lowest one with a non-empty outbox (a second one, if any, is left to mp_round_replies)
-    uint32_t dl = P.R, cnt = 0;
+    uint32_t dl = R, cnt = 0;
 #pragma unroll
     for (int d = MAXR - 1; d >= 0; d--) if (cnts[d] != 0) { dl = (uint32_t)d; cnt = cnts[d]; }
-    const MpRep &v = P.rep[dl < P.R ? dl : 0];                  // per-lane replica: pointers become vector values
-    uint32_t reg = 0;
-    uint64_t bpd = 0;
-    const bool fast4 = active && dl < P.R && r3_is_fast4(v, par, gg, dl, (prmask >> dl) & 1u, cnt, reg, bpd);
-    __syncthreads();
-    SMR_G uint32_t *const sm = v.s_meta;
-    const uint32_t Wm = P.Wmask;
+    const bool cand = dl < R && !((prmask >> dl) & 1u) && cnt <= 64;
+    const size_t ro = (size_t)(dl < R ? dl : 0) * P.rep_stride;  // per-lane replica: addresses are vector values
+    const MpRep &v0 = P.rep[0];
+    SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
+    SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
+    SMR_G const uint64_t *const ack = rep_shift(v0.ack, ro);
+    SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
     const uint32_t q4 = (cnt + 3) / 4;
     const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
-    uint32_t mine[16];                                          // post-tally meta of my rows (q4 <= 16)
-    // ---- phase 1: parallel tally of my quarter of the rows, 4 rows per batch of loads ----------
-    if (fast4) {
-        const uint32_t start = v.start_slot[gg], len = v.log_len[gg];
-        SMR_G const uint64_t *const ack = v.ack;
-        SMR_G const uint64_t *const sb = v.s_bal;
-        const uint32_t G = P.G, R = P.R, thresh = P.thresh;
+    // ---- round 2: my replica's scalars, and the ack-matrix rows of pass 0 ------------------------
+    uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0;
+    uint64_t bpd = 0;
+    uint32_t ctl[C]; uint64_t a[C][NC];
+    if (cand) {
+        reg = rep_shift(v0.ob_reg[par], ro)[gg]; bpd = rep_shift(v0.bal_prepared, ro)[gg];
+        leader = rep_shift(v0.leader, ro)[gg];
+        start = rep_shift(v0.start_slot, ro)[gg]; len = rep_shift(v0.log_len, ro)[gg];
+        cbar = p_cbar[gg]; ebar = p_ebar[gg]; abar = rep_shift(v0.accept_bar, ro)[gg];
+    }
+    auto load_acks = [&](uint32_t j0) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const uint32_t j0 = jlo + 4 * c;
-            uint32_t ctl[4], m[4]; uint64_t a[4][NR], b[4];
+        for (int k = 0; k < C; k++) {
+            const uint32_t j = j0 + k;
+            const bool in = cand && j < jhi;
+            ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const bool in = j0 + k < jhi;
-                const uint32_t j = j0 + k, slot = reg - 1 + j;
-                ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-#pragma unroll
-                for (int qq = 0; qq < NR; qq++)
-                    a[k][qq] = (in && (uint32_t)qq < R && (uint32_t)qq != dl) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
-                const bool have = in && slot >= start && slot < len;
-                const size_t i = tix(P.W, slot & Wm, g);
-                m[k] = have ? sm[i] : 0xFFFFFFFFu;
-                b[k] = have ? sb[i] : 0ull;
+            for (int c = 0; c < NC; c++) {
+                const uint32_t qq = (uint32_t)c + ((uint32_t)c >= dl ? 1u : 0u);
+                a[k][c] = (in && qq < R) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
             }
+        }
+    };
+    load_acks(jlo);
+    const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
+    // ---- round 3 + tally: C rows per pass (one pass unless the outbox is longer than 4 * C) -------
+#pragma unroll 1
+    for (uint32_t j0 = jlo; j0 < jhi; j0 += C) {
+        if (j0 != jlo) load_acks(j0);
+        uint32_t m[C]; uint64_t b[C];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                mine[4 * c + k] = 0;
-                if (j0 + k >= jhi) continue;
-                const uint32_t j = j0 + k, slot = reg - 1 + j;
-                const bool have = m[k] != 0xFFFFFFFFu;
-                uint32_t mk = have ? m[k] : 0u;
-                bool changed = false, committed = false;
-                if (have && (mk & M_LBK)) mk = tally_row<NR>(mk, b[k], ctl[k], a[k], bpd, thresh, R, changed, committed);
-                // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
-                if (changed && !committed) sm[tix(P.W, slot & Wm, g)] = mk;
-                mine[4 * c + k] = mk;
-                sh_fl[j * 64 + lane] = (uint8_t)((have ? 1 : 0) | (changed ? 2 : 0) | (committed ? 4 : 0) |
-                                                 ((mk & M_NONEMPTY) ? 16 : 0));
+        for (int k = 0; k < C; k++) {
+            const uint32_t slot = reg - 1 + j0 + k;
+            const bool have = fast4 && j0 + k < jhi && slot >= start && slot < len;
+            const size_t i = tix(P.W, slot & Wm, g);
+            m[k] = have ? sm[i] : 0xFFFFFFFFu;
+            b[k] = have ? sb[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const uint32_t j = j0 + k;
+            if (!fast4 || j >= jhi) continue;
+            const bool have = m[k] != 0xFFFFFFFFu;
+            uint32_t mk = have ? m[k] : 0u;
+            bool changed = false, committed = false;
+            if (have && (mk & M_LBK)) {
+                uint32_t valid = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    valid |= (uint32_t)(a[k][c] != 0 && a[k][c] == bpd) << ((uint32_t)c + ((uint32_t)c >= dl ? 1u : 0u));
+                mk = tally_valid<NR>(mk, b[k], ctl[k], valid, bpd, thresh, R, changed, committed);
             }
+            // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
+            if (changed && !committed) sm[tix(P.W, (reg - 1 + j) & Wm, g)] = mk;
+            sh_mk[j * 64 + lane] = mk;
+            sh_fl[j * 64 + lane] = (uint8_t)((have ? 1 : 0) | (changed ? 2 : 0) | (committed ? 4 : 0) |
+                                             ((mk & M_NONEMPTY) ? 16 : 0));
         }
     }
     __syncthreads();
-    // ---- phase 2: the all-commit closed form, or leave the lane to mp_round_replies ------------------
+    // ---- the all-commit closed form, or leave the lane to mp_round_replies ------------------------
     bool closed = false;
     const uint32_t first = reg - 1;
-    uint32_t ebar_new = 0;
     if (fast4) {
-        const uint32_t cbar = v.commit_bar[gg], ebar = v.exec_bar[gg], abar = v.accept_bar[gg], len = v.log_len[gg];
         uint32_t all = 0xFF;
         for (uint32_t j = 0; j < cnt; j++) all &= sh_fl[j * 64 + lane];
         // every row: present, changed, committed, non-empty; rows = slots commit_bar.., all below
         // accept_bar, and the run ends behind the last one (accept_bar and log end).  exec_bar rides
         // along from the row that sits AT it (execution.rs:70), if any -- a pinned exec_bar stays.
         closed = (all & 23) == 23 && first == cbar && first + cnt == abar && first + cnt >= len && P.clist_cap == 0;
-        ebar_new = (ebar >= first && ebar < first + cnt) ? first + cnt : ebar;
-        if (closed) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t j = jlo + k;
-                if (j < jhi) sm[tix(P.W, (first + j) & Wm, g)] = m_set_st(mine[k], SMR_ST_EXECUTED);
-            }
-        }
-    }
-    if (w != 0) return;
-    unsigned int nc = 0;
-    if (closed) {
-        v.commit_bar[gg] = first + cnt;
-        v.exec_bar[gg] = ebar_new;
-        v.ob_cnt[par][gg] = 0;                                  // outbox consumed: nothing left for mp_round_replies
-        nc = cnt;
+        if (closed)
+            for (uint32_t j = jlo; j < jhi; j++)
+                sm[tix(P.W, (first + j) & Wm, g)] = m_set_st(sh_mk[j * 64 + lane], SMR_ST_EXECUTED);
     }
     // which replicas of my group still need mp_round_replies: a non-empty outbox I did not close,
     // or PrepareReplies waiting; everybody else's round is complete
@@ -733,35 +765,58 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #pragma unroll
     for (int d = 0; d < MAXR; d++)
         if (cnts[d] != 0 && !(closed && (uint32_t)d == dl)) need |= 1u << d;
-    if (!active) need = 0;
+    if (w == 0 && closed) {
+        p_cbar[gg] = first + cnt;
+        if (ebar >= first && ebar < first + cnt) p_ebar[gg] = first + cnt;
+        rep_shift(v0.ob_cnt[par], ro)[gg] = 0;                 // outbox consumed: nothing left for mp_round_replies
+    }
     if (publish_hb && active) {                                 // leadership.rs:240-247 record, complete rounds only
-        for (uint32_t d = 0; d < P.R; d++) {
+        for (uint32_t d = w; d < R; d += 4) {                   // replicas dealt over the four wavefronts
             if ((need >> d) & 1u) continue;                     // mp_round_replies publishes after its work
             const MpRep &u = P.rep[d];
-            u.hb_bal[gg] = u.bal_max_seen[gg]; u.hb_commit[gg] = u.commit_bar[gg]; u.hb_exec[gg] = u.exec_bar[gg];
+            uint32_t cb = u.commit_bar[gg], eb = u.exec_bar[gg];
+            if (closed && d == dl) {                            // wavefront 0's stores above may not have landed
+                cb = first + cnt;
+                eb = (ebar >= first && ebar < first + cnt) ? first + cnt : ebar;
+            }
+            u.hb_bal[gg] = u.bal_max_seen[gg]; u.hb_commit[gg] = cb; u.hb_exec[gg] = eb;
             u.hb_snap[gg] = u.snap_bar[gg];
         }
     }
-    // commit counter of each lane's replica: sum per replica over the wavefront
-    for (uint32_t d = 0; d < P.R; d++) {
-        unsigned int x = (closed && dl == d) ? nc : 0u;
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d].counters[0], (unsigned long long)x);
+    if (w != 0) return;
+    // commit counter of each lane's replica: one sum when the whole wavefront serves one replica
+    {
+        const unsigned int nc = closed ? cnt : 0u;
+        const uint32_t d0 = __shfl(dl, __ffsll((long long)(__ballot(closed) | (1ull << 63))) - 1);
+        if (__all(!closed || dl == d0)) {
+            unsigned int x = nc;
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d0].counters[0], (unsigned long long)x);
+        } else {
+            for (uint32_t d = 0; d < R; d++) {
+                unsigned int x = (closed && dl == d) ? nc : 0u;
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+                if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d].counters[0], (unsigned long long)x);
+            }
+        }
     }
     uint32_t nd = need;
     for (int off = 32; off > 0; off >>= 1) nd |= __shfl_xor(nd, off);
     if (lane == 0) {
-        const uint32_t ntile = (P.G + 63) / 64;
-        for (uint32_t d = 0; d < P.R; d++) P.r3_need[(size_t)d * ntile + blockIdx.x] = (uint8_t)((nd >> d) & 1u);
+        const uint32_t ntile = (G + 63) / 64;
+        for (uint32_t d = 0; d < R; d++) P.r3_need[(size_t)d * ntile + blockIdx.x] = (uint8_t)((nd >> d) & 1u);
     }
 }
 
-__global__ __launch_bounds__(256) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
+#ifndef TALLY_MINW
+#define TALLY_MINW 1
+#endif
+template <int NR>
+__global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
                                                        const uint32_t *__restrict__ ackctl, int publish_hb) {
-    const MpParams &P = *Pp;
     __shared__ uint8_t sh_fl[64 * 64];
-    if (P.R <= 5) quorum_tally_block<5>(P, par, ackctl, publish_hb, sh_fl);
-    else quorum_tally_block<MAXR>(P, par, ackctl, publish_hb, sh_fl);
+    __shared__ uint32_t sh_mk[64 * 64];
+    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk);
 }
 
 __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
@@ -918,6 +973,19 @@ static void layout(smr_mp_cluster *c, bool dry) {
         carve(a, v.clist, (size_t)c->cfg.commit_list_cap, dry);
         carve(a, v.clist_n, 1, dry);
     }
+    // identical carve sequence per replica => constant distance between the replicas' arrays
+    if (!dry) P.rep_stride = R > 1 ? (size_t)((char *)P.rep[1].leader - (char *)P.rep[0].leader) : 0;
+}
+
+static bool stride_ok(const MpParams &P) {
+    for (uint32_t r = 1; r < P.R; r++) {
+        const size_t o = r * P.rep_stride;
+        if ((char *)P.rep[r].s_meta != (char *)P.rep[0].s_meta + o || (char *)P.rep[r].ack != (char *)P.rep[0].ack + o ||
+            (char *)P.rep[r].ob_cnt[1] != (char *)P.rep[0].ob_cnt[1] + o ||
+            (char *)P.rep[r].clist_n != (char *)P.rep[0].clist_n + o)
+            return false;
+    }
+    return true;
 }
 
 static int prof_begin(smr_mp_cluster *c, int which, hipStream_t st) {
@@ -969,6 +1037,11 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     P.G = cfg->n_groups; P.W = cfg->window; P.Wmask = cfg->window - 1; P.cap = cfg->outbox_cap;
     P.pcap = c->pcap; P.win_reserve = cfg->win_reserve; P.clist_cap = cfg->commit_list_cap;
     P.R = cfg->population; P.quorum = quorum; P.thresh = quorum + cfg->commit_extra; P.rspaxos = 0;
+    if (!stride_ok(P)) {
+        (void)hipFree(c->arena.base);
+        delete c;
+        return fail(SMR_ERR_DEVICE, "mp: replica arrays are not equally spaced in the arena");
+    }
     e = hipMemset(c->arena.base, 0, c->arena.size);
     for (uint32_t r = 0; e == hipSuccess && r < P.R; r++) e = hipMemset(P.rep[r].leader, 0xFF, P.G);
     if (e == hipSuccess) e = hipMalloc((void **)&c->dp, sizeof(MpParams));
@@ -1035,8 +1108,12 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = prof_begin(c, 2, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_quorum_tally, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
-                       c->dp, c->par, ackctl_dev, publish_heartbeat);
+    if (c->cfg.population <= 5)
+        hipLaunchKernelGGL(mp_quorum_tally<5>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
+                           c->dp, c->par, ackctl_dev, publish_heartbeat);
+    else
+        hipLaunchKernelGGL(mp_quorum_tally<MAXR>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
+                           c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
                        publish_heartbeat);

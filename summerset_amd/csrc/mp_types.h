@@ -122,6 +122,7 @@ struct MpParams {
     SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
     SMR_G unsigned long long *dbg;  // [64] debug clock stamps
     SMR_G uint8_t *r3_need;         // [R][ceil(G/64)]: this 64-group tile has work left for mp_round_replies
+    size_t rep_stride;              // bytes from an array of replica d to the same array of replica d + 1
     MpRep rep[MAXR];
 };
 
