@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated tick inputs cycled in HBM")
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
+    ap.add_argument("--timeout-span", type=int, default=None, help="draw the timeout ticks from [0, N) instead of the whole run")
+    ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change runs on the side stream (0 = off)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -135,10 +137,11 @@ def main():
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4
     n_ticks = args.warmup + args.steps
-    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
     eng.preset_leader(0)
     st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts,
-                                 hb_every=H, rand_rows=S + 4, seed=stream.DEFAULT_SEED + rank, max_drop=2)
+                                 hb_every=H, rand_rows=S + 4, seed=stream.DEFAULT_SEED + rank, max_drop=2,
+                                 timeout_span=args.timeout_span)
     # inputs resident in HBM before the clock starts
     pool = []
     for t in range(args.pool):
@@ -149,9 +152,12 @@ def main():
         e = st.tick_events(t)
         events.append({k: torch.from_numpy(v).to(dev) for k, v in e.items() if isinstance(v, np.ndarray)})
 
+    fired = [bool((st.timeout_tick == t).any()) for t in range(n_ticks)]   # host-side fact: did any timer fire
+
     def step(t):
         p, e = pool[t % args.pool], events[t]
-        eng.tick(timeout_rep=e["timeout_rep"], timeout_src=e["timeout_src"], req_target=e["req_target"],
+        eng.tick(timeout_rep=e["timeout_rep"] if fired[t] else None,
+                 timeout_src=e["timeout_src"] if fired[t] else None, req_target=e["req_target"],
                  req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"], heartbeat=st.heartbeat(t))
 
     for t in range(args.warmup):

@@ -106,12 +106,16 @@ int smr_rs_verify(const uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_
  * MultiPaxos / RSPaxos cluster of G groups x R replicas in lock-step (LS-1)
  * ---------------------------------------------------------------------- */
 typedef struct smr_mp_cluster smr_mp_cluster;
+#define SMR_STRAGGLER_OFF 0xFF
 
 typedef struct {
     uint32_t n_groups;      /* G */
     uint8_t population;     /* R, 3..8 */
     uint8_t commit_extra;   /* RSPaxos fault_tolerance f (rspaxos/messages.rs:438-439); 0 = MultiPaxos */
-    uint8_t reserved0, reserved1;
+    uint8_t straggler_ticks; /* ticks a group spends on the engine's side stream after a HearTimeout, so its leader
+                              * change runs beside the steady-state kernels (results do not depend on it):
+                              * 0 / SMR_STRAGGLER_OFF = never (default) */
+    uint8_t reserved1;
     uint32_t window;        /* W: ring slots per replica per group, power of two */
     uint32_t win_reserve;   /* leader refuses new batches once W - win_reserve slots are live */
     uint32_t outbox_cap;    /* max messages a replica may emit per tick (>= W + 4 recommended) */

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t x) {
 // Lane context: the group's scalar state of one replica cached in registers.
 struct Lane {
     const MpParams &P;
-    const MpRep &v;
+    const RepView v;               // my replica's arrays (the replica index may differ from lane to lane)
     const uint32_t g;
     const uint32_t me;
     int par;                       // outbox parity of the current tick
@@ -65,7 +65,7 @@ struct Lane {
     uint32_t cl, cn;
 
     __device__ __forceinline__ Lane(const MpParams &P_, uint32_t rep, uint32_t g_, int par_)
-        : P(P_), v(P_.rep[rep]), g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), n_generic(0), ovf(false),
+        : P(P_), v{P_.rep[0], (size_t)rep * P_.rep_stride}, g(g_), me(rep), par(par_), n_commit(0), n_redirect(0), n_reject(0), n_generic(0), ovf(false),
           wr(true), cl(0), cn(1) {
         obl0 = obl1 = false;
         obn0 = obn1 = 0;
@@ -75,32 +75,32 @@ struct Lane {
     __device__ __forceinline__ bool coop() const { return cn != 1; }
 
     __device__ __forceinline__ void load() {
-        o_leader = leader = v.leader[g];
-        o_bps = bps = v.bal_prep_sent[g];
-        o_bpd = bpd = v.bal_prepared[g];
-        o_bms = bms = v.bal_max_seen[g];
-        o_start = start = v.start_slot[g];
-        o_len = len = v.log_len[g];
-        o_abar = abar = v.accept_bar[g];
-        o_cbar = cbar = v.commit_bar[g];
-        o_ebar = ebar = v.exec_bar[g];
-        o_snap = snap = v.snap_bar[g];
-        o_nlb = nlb = v.null_lb[g];
+        o_leader = leader = v.leader()[g];
+        o_bps = bps = v.bal_prep_sent()[g];
+        o_bpd = bpd = v.bal_prepared()[g];
+        o_bms = bms = v.bal_max_seen()[g];
+        o_start = start = v.start_slot()[g];
+        o_len = len = v.log_len()[g];
+        o_abar = abar = v.accept_bar()[g];
+        o_cbar = cbar = v.commit_bar()[g];
+        o_ebar = ebar = v.exec_bar()[g];
+        o_snap = snap = v.snap_bar()[g];
+        o_nlb = nlb = v.null_lb()[g];
     }
     __device__ __forceinline__ void store() {
-        if (leader != o_leader) if (wr) v.leader[g] = (uint8_t)leader;
-        if (bps != o_bps) if (wr) v.bal_prep_sent[g] = bps;
-        if (bpd != o_bpd) if (wr) v.bal_prepared[g] = bpd;
-        if (bms != o_bms) if (wr) v.bal_max_seen[g] = bms;
-        if (start != o_start) if (wr) v.start_slot[g] = start;
-        if (len != o_len) if (wr) v.log_len[g] = len;
-        if (abar != o_abar) if (wr) v.accept_bar[g] = abar;
-        if (cbar != o_cbar) if (wr) v.commit_bar[g] = cbar;
-        if (ebar != o_ebar) if (wr) v.exec_bar[g] = ebar;
-        if (snap != o_snap) if (wr) v.snap_bar[g] = snap;
-        if (nlb != o_nlb) if (wr) v.null_lb[g] = nlb;
-        if (obl0) if (wr) v.ob_cnt[0][g] = obn0;
-        if (obl1) if (wr) v.ob_cnt[1][g] = obn1;
+        if (leader != o_leader) if (wr) v.leader()[g] = (uint8_t)leader;
+        if (bps != o_bps) if (wr) v.bal_prep_sent()[g] = bps;
+        if (bpd != o_bpd) if (wr) v.bal_prepared()[g] = bpd;
+        if (bms != o_bms) if (wr) v.bal_max_seen()[g] = bms;
+        if (start != o_start) if (wr) v.start_slot()[g] = start;
+        if (len != o_len) if (wr) v.log_len()[g] = len;
+        if (abar != o_abar) if (wr) v.accept_bar()[g] = abar;
+        if (cbar != o_cbar) if (wr) v.commit_bar()[g] = cbar;
+        if (ebar != o_ebar) if (wr) v.exec_bar()[g] = ebar;
+        if (snap != o_snap) if (wr) v.snap_bar()[g] = snap;
+        if (nlb != o_nlb) if (wr) v.null_lb()[g] = nlb;
+        if (obl0) if (wr) v.ob_cnt(0)[g] = obn0;
+        if (obl1) if (wr) v.ob_cnt(1)[g] = obn1;
         if (ovf && wr) P.overflow[g] = 1;
     }
 
@@ -116,7 +116,7 @@ struct Lane {
     __device__ __forceinline__ bool push_null() {
         if (len - start >= P.W) { ovf = true; return false; }
         size_t i = ix(len);
-        if (wr) v.s_meta[i] = 0; if (wr) v.s_bal[i] = 0; if (wr) v.s_val[i] = 0;
+        if (wr) v.s_meta()[i] = 0; if (wr) v.s_bal()[i] = 0; if (wr) v.s_val()[i] = 0;
         len++;
         return true;
     }
@@ -133,7 +133,7 @@ struct Lane {
     // lane-strided loop in which every lane owns its slots)
     __device__ __forceinline__ uint32_t materialize_voted(size_t i, uint32_t m, uint64_t bal, uint32_t val, bool w) {
         if (m_vmode(m) == VM_SAME) {
-            if (w) { v.s_vbal[i] = bal; v.s_vval[i] = val; }
+            if (w) { v.s_vbal()[i] = bal; v.s_vval()[i] = val; }
             m = m_set_vmode(m, VM_SIDE);
         }
         return m;
@@ -145,13 +145,13 @@ struct Lane {
                                               uint32_t &vv) const {
         uint32_t vm = m_vmode(m);
         if (vm == VM_SAME) { vb = bal; vv = val; }
-        else if (vm == VM_SIDE) { vb = v.s_vbal[i]; vv = v.s_vval[i]; }
+        else if (vm == VM_SIDE) { vb = v.s_vbal()[i]; vv = v.s_vval()[i]; }
         else { vb = 0; vv = 0; }
     }
 
     __device__ __forceinline__ void ob_load(int p) {
-        if (p == 0) { if (!obl0) { obn0 = v.ob_cnt[0][g]; obl0 = true; } }
-        else { if (!obl1) { obn1 = v.ob_cnt[1][g]; obl1 = true; } }
+        if (p == 0) { if (!obl0) { obn0 = v.ob_cnt(0)[g]; obl0 = true; } }
+        else { if (!obl1) { obn1 = v.ob_cnt(1)[g]; obl1 = true; } }
     }
     __device__ __forceinline__ void ob_set(int p, uint32_t n) {
         ob_load(p);
@@ -161,13 +161,13 @@ struct Lane {
     __device__ __forceinline__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
         ob_load(p);
         uint32_t c = p == 0 ? obn0 : obn1;
-        if (wr) v.ob_reg[p][g] = 0;                             // no longer (only) a steady-state append run
+        if (wr) v.ob_reg(p)[g] = 0;                             // no longer (only) a steady-state append run
         if (c >= P.cap) { ovf = true; return; }
         size_t o = tix(P.cap, c, g);
-        if (wr) v.ob_slot[p][o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
-        if (wr) v.ob_bal[p][o] = bal;
-        if (wr) v.ob_val[p][o] = val;
-        if (kind == OB_HEARTBEAT) if (wr) v.ob_aux[p][o] = aux;
+        if (wr) v.ob_slot(p)[o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
+        if (wr) v.ob_bal(p)[o] = bal;
+        if (wr) v.ob_val(p)[o] = val;
+        if (kind == OB_HEARTBEAT) if (wr) v.ob_aux(p)[o] = aux;
         if (p == 0) obn0 = c + 1; else obn1 = c + 1;
     }
 
@@ -177,19 +177,25 @@ struct Lane {
         if (P.clist_cap == 0) return;
         if (coop()) {                              // uniform mode: one entry, appended by lane 0
             if (wr) {
-                unsigned int idx = atomicAdd((unsigned int *)v.clist_n, 1u);
-                if (idx < P.clist_cap) v.clist[idx] = ((unsigned long long)g << 32) | slot;
+                unsigned int idx = atomicAdd((unsigned int *)v.clist_n(), 1u);
+                if (idx < P.clist_cap) v.clist()[idx] = ((unsigned long long)g << 32) | slot;
             }
             return;
         }
-        unsigned long long mask = __ballot(1);
-        int lane = __lane_id();
-        int first = __ffsll((long long)mask) - 1;
-        unsigned int base = 0;
-        if (lane == first) base = atomicAdd((unsigned int *)v.clist_n, (unsigned int)__popcll(mask));
-        base = __shfl(base, first);
-        unsigned int idx = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
-        if (idx < P.clist_cap) v.clist[idx] = ((unsigned long long)g << 32) | slot;
+        // lanes of a wavefront may stand for different replicas, each with its own list
+        const int lane = __lane_id();
+        for (unsigned long long todo = __ballot(1); todo;) {
+            const int first = __ffsll((long long)todo) - 1;
+            const unsigned long long mask = __ballot(me == __shfl(me, first)) & todo;
+            todo &= ~mask;
+            if (!((mask >> lane) & 1ull)) continue;
+            unsigned int base = 0;
+            if (lane == first) base = atomicAdd((unsigned int *)v.clist_n(), (unsigned int)__popcll(mask));
+            base = __shfl(base, first);
+            const unsigned int idx = base + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (idx < P.clist_cap) v.clist()[idx] = ((unsigned long long)g << 32) | slot;
+            break;
+        }
     }
 
     // leadership.rs:11-67 check_leader (lease branches are config-off)
@@ -201,7 +207,7 @@ struct Lane {
     template <int N>
     __device__ __forceinline__ void fetch_meta(uint32_t s0, uint32_t lim, uint32_t (&mm)[N]) const {
 #pragma unroll
-        for (int k = 0; k < N; k++) mm[k] = (s0 + k < lim) ? v.s_meta[ix(s0 + k)] : 0u;
+        for (int k = 0; k < N; k++) mm[k] = (s0 + k < lim) ? v.s_meta()[ix(s0 + k)] : 0u;
     }
 
     // durability.rs:134-142: accept_bar forward scan after logging `slot`, whose
@@ -249,7 +255,7 @@ struct Lane {
             if (m_st(m) < SMR_ST_COMMITTED) { unexec_at = s; return false; }   // durability.rs:164-166
             if (m_st(m) == SMR_ST_COMMITTED) {
                 if ((m & M_NONEMPTY) && s == e0) chase = true;
-                if (wr) v.s_meta[ix(s)] = m_set_st(m, SMR_ST_EXECUTED);
+                if (wr) v.s_meta()[ix(s)] = m_set_st(m, SMR_ST_EXECUTED);
             }
             s++;                                    // durability.rs:189
             return true;
@@ -291,16 +297,16 @@ struct Lane {
         if (ballot != bpd) return;                              // :388
         if (slot >= len) return;                                // debug_assert :389
         size_t i = ix(slot);
-        uint32_t m = v.s_meta[i];
+        uint32_t m = v.s_meta()[i];
         if (!is_leader() || m_st(m) != SMR_ST_ACCEPTING) return;   // :394-399
-        if (ballot < v.s_bal[i]) return;
+        if (ballot < v.s_bal()[i]) return;
         if (!(m & M_LBK)) return;                               // debug_assert :402
         uint32_t bit = 1u << (peer + M_ACKS_SH);
         if (m & bit) return;                                    // :404-406
         m |= bit;                                               // :409
         bool committed = (uint32_t)__popc(m_acks(m)) >= P.thresh;   // :412 (rspaxos/messages.rs:438-439)
         if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
-        if (wr) v.s_meta[i] = m;
+        if (wr) v.s_meta()[i] = m;
         if (committed) {
             record_commit(slot);
             commit_complete<2>(slot, m);                        // WAL CommitSlot :427-433 -> durability.rs:148
@@ -336,7 +342,7 @@ struct Lane {
             }
         }
         if (!changed) return;
-        if (wr) v.s_meta[ix(slot)] = m;
+        if (wr) v.s_meta()[ix(slot)] = m;
         if (committed) {
             record_commit(slot);
             commit_complete<2>(slot, m, next_hint);
@@ -346,7 +352,7 @@ struct Lane {
     // durability.rs:85-145 handle_logged_accept_data, leader branch
     __device__ __forceinline__ void self_accept_logged(uint32_t slot) {
         size_t i = ix(slot);
-        accept_reply(me, slot, v.s_bal[i]);                     // :99-103
+        accept_reply(me, slot, v.s_bal()[i]);                     // :99-103
         accept_bar_scan(slot);
     }
 
@@ -358,7 +364,7 @@ struct Lane {
         uint32_t slot = 0xFFFFFFFFu;
         uint32_t s0 = ebar > nlb ? ebar : nlb;
         for (uint32_t s = s0; s < len; s++)
-            if (m_st(v.s_meta[ix(s)]) == SMR_ST_NULL) { slot = s; break; }
+            if (m_st(v.s_meta()[ix(s)]) == SMR_ST_NULL) { slot = s; break; }
         if (slot == 0xFFFFFFFFu) {
             if ((len - start) + P.win_reserve >= P.W) { n_reject++; return; }   // ring back-pressure
             slot = len;
@@ -375,9 +381,9 @@ struct Lane {
                      (1u << (me + M_ACKS_SH));
         const bool committed = P.thresh <= 1;                   // messages.rs:412 (only for a 1-ack threshold)
         if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
-        if (wr) v.s_bal[i] = bpd;
-        if (wr) v.s_val[i] = reqs;
-        if (wr) v.s_meta[i] = m;
+        if (wr) v.s_bal()[i] = bpd;
+        if (wr) v.s_val()[i] = reqs;
+        if (wr) v.s_meta()[i] = m;
         ob_push(par, OB_ACCEPT, slot, bpd, reqs, 0);            // :209-216
         if (committed) { record_commit(slot); commit_complete<2>(slot, m); }
         accept_bar_scan(slot);                                  // durability.rs:134-142
@@ -390,7 +396,7 @@ struct Lane {
         for (uint32_t s0 = lo + cl; s0 < hi && found == hi; s0 += 4 * cn) {
             uint32_t mm[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) mm[u] = (s0 + u * cn < hi) ? v.s_meta[ix(s0 + u * cn)] : 0xFFFFFFFFu;
+            for (int u = 0; u < 4; u++) mm[u] = (s0 + u * cn < hi) ? v.s_meta()[ix(s0 + u * cn)] : 0xFFFFFFFFu;
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (found == hi && mm[u] != 0xFFFFFFFFu && m_st(mm[u]) < bound) found = s0 + u * cn;
@@ -404,7 +410,7 @@ struct Lane {
         if (hi > lo)
             for (uint32_t t = cl; t < hi - lo; t += cn) {          // t-th slot from the top
                 const uint32_t s = hi - 1 - t;
-                const uint32_t st = m_st(v.s_meta[ix(s)]);
+                const uint32_t st = m_st(v.s_meta()[ix(s)]);
                 if (below ? st < bound : st > bound) { found = s + 1; break; }
             }
         if (coop()) found = wave_max(found);
@@ -420,9 +426,9 @@ struct Lane {
     // over the slots' final statuses, which an ascending pass knows as it goes.
     __device__ __forceinline__ void prepare_quorum_step(uint32_t peer, uint32_t trig, uint64_t ballot) {
         const size_t ti = ix(trig);
-        uint32_t tm = v.s_meta[ti];
+        uint32_t tm = v.s_meta()[ti];
         tm |= 1u << (peer + M_PACKS_SH);                        // :228
-        if (wr) v.s_meta[ti] = tm;
+        if (wr) v.s_meta()[ti] = tm;
         if ((uint32_t)__popc(m_packs(tm)) < P.quorum) return;   // :233
         bpd = ballot;                                           // :236
         if (coop() && P.thresh > 1) {
@@ -430,18 +436,18 @@ struct Lane {
             // order (ballot + prefix count), the accept_bar scan runs on the bitmaps.
             ob_load(par ^ 1);
             uint32_t c = (par ^ 1) == 0 ? obn0 : obn1;
-            if (wr) v.ob_reg[par ^ 1][g] = 0;
+            if (wr) v.ob_reg(par ^ 1)[g] = 0;
             int chase = 0;
             for (uint32_t base = trig; base < len; base += 64) {
                 const uint32_t sl = base + cl;
                 const bool in = sl < len;
                 const size_t i = ix(sl);
-                uint32_t m = in ? v.s_meta[i] : 0u;
+                uint32_t m = in ? v.s_meta()[i] : 0u;
                 const bool moved = in && m_st(m) == SMR_ST_PREPARING;
                 if (moved) {
                     m = m_set_st(m, SMR_ST_ACCEPTING);
-                    if (v.s_bal[i] == ballot && (m & M_LBK) && !(m_acks(m) & (1u << me))) m |= 1u << (me + M_ACKS_SH);
-                    v.s_meta[i] = m;
+                    if (v.s_bal()[i] == ballot && (m & M_LBK) && !(m_acks(m) & (1u << me))) m |= 1u << (me + M_ACKS_SH);
+                    v.s_meta()[i] = m;
                 }
                 const unsigned long long mv = __ballot(moved);
                 const unsigned long long acc = __ballot(in && m_st(m) >= SMR_ST_ACCEPTING);
@@ -449,9 +455,9 @@ struct Lane {
                     const uint32_t pos = c + (uint32_t)__popcll(mv & ((1ull << cl) - 1ull));
                     if (pos < P.cap) {
                         const size_t o = tix(P.cap, pos, g);
-                        v.ob_slot[par ^ 1][o] = (OB_ACCEPT << OB_KIND_SH) | (sl & OB_SLOT_MASK);
-                        v.ob_bal[par ^ 1][o] = ballot;
-                        v.ob_val[par ^ 1][o] = v.s_val[i];
+                        v.ob_slot(par ^ 1)[o] = (OB_ACCEPT << OB_KIND_SH) | (sl & OB_SLOT_MASK);
+                        v.ob_bal(par ^ 1)[o] = ballot;
+                        v.ob_val(par ^ 1)[o] = v.s_val()[i];
                     }
                 }
                 c += (uint32_t)__popcll(mv);
@@ -481,7 +487,7 @@ struct Lane {
             for (int k = 0; k < 8; k++) {
                 const bool in = s0 + k < len;
                 const size_t i = ix(s0 + k);
-                mm[k] = in ? v.s_meta[i] : 0u; vv[k] = in ? v.s_val[i] : 0u; bb[k] = in ? v.s_bal[i] : 0ull;
+                mm[k] = in ? v.s_meta()[i] : 0u; vv[k] = in ? v.s_val()[i] : 0u; bb[k] = in ? v.s_bal()[i] : 0ull;
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -497,13 +503,13 @@ struct Lane {
                         m |= 1u << (me + M_ACKS_SH);
                         if ((uint32_t)__popc(m_acks(m)) >= P.thresh) {   // only with a 1-ack threshold
                             m = m_set_st(m, SMR_ST_COMMITTED);
-                            if (wr) v.s_meta[ix(s)] = m;
+                            if (wr) v.s_meta()[ix(s)] = m;
                             record_commit(s);
                             commit_complete<2>(s, m);
-                            m = v.s_meta[ix(s)];
+                            m = v.s_meta()[ix(s)];
                         }
                     }
-                    if (wr) v.s_meta[ix(s)] = m;
+                    if (wr) v.s_meta()[ix(s)] = m;
                 }
                 if (chase == 0 && moved && s == abar) chase = 1;            // durability.rs:134
                 if (chase == 1 && s == abar) {
@@ -521,33 +527,33 @@ struct Lane {
         if (!is_leader()) return;                               // :112-114
         if (trig < start || trig >= len) return;                // debug_assert :116-119
         const size_t ti = ix(trig);
-        uint32_t tm = v.s_meta[ti];
+        uint32_t tm = v.s_meta()[ti];
         if (!(tm & M_LBK)) return;                              // :120-125
-        const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp[ti] : 0;   // :149-153
+        const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp()[ti] : 0;   // :149-153
         while (len <= slot) {                                   // :154-190 slot unknown at become_a_leader
             uint32_t this_slot = len;
             if (!push_null()) return;
             size_t i = ix(this_slot);
-            if (wr) v.s_bal[i] = bps;
-            if (wr) v.s_ltrig[i] = trig; if (wr) v.s_lendp[i] = my_endp; if (wr) v.s_pmax[i] = 0;
-            if (wr) v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
+            if (wr) v.s_bal()[i] = bps;
+            if (wr) v.s_ltrig()[i] = trig; if (wr) v.s_lendp()[i] = my_endp; if (wr) v.s_pmax()[i] = 0;
+            if (wr) v.s_meta()[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX;
             if (nlb == this_slot) nlb = this_slot + 1;          // filled at once: still no Null below the log end
             // its PrepareBal completion is a no-op on the leader (this_slot > endprep)
         }
         {
             size_t i = ix(slot);
-            uint32_t m = v.s_meta[i];
-            uint64_t b = v.s_bal[i];
+            uint32_t m = v.s_meta()[i];
+            uint64_t b = v.s_bal()[i];
             if (m_st(m) != SMR_ST_PREPARING || ballot < b) return;   // :196-198
             if (has_voted && (m & M_LBK)) {                     // :203-216
-                uint64_t pm = (m & M_LBKX) ? v.s_pmax[i] : 0;
+                uint64_t pm = (m & M_LBKX) ? v.s_pmax()[i] : 0;
                 if (vbal > pm) {
-                    if (!(m & M_LBKX)) { if (wr) v.s_ltrig[i] = 0; if (wr) v.s_lendp[i] = 0; m |= M_LBKX; }
-                    if (wr) v.s_pmax[i] = vbal;
-                    m = materialize_voted(i, m, b, v.s_val[i]);
-                    if (wr) v.s_val[i] = vval;                          // inst.reqs = val
+                    if (!(m & M_LBKX)) { if (wr) v.s_ltrig()[i] = 0; if (wr) v.s_lendp()[i] = 0; m |= M_LBKX; }
+                    if (wr) v.s_pmax()[i] = vbal;
+                    m = materialize_voted(i, m, b, v.s_val()[i]);
+                    if (wr) v.s_val()[i] = vval;                          // inst.reqs = val
                     m = vval ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                    if (wr) v.s_meta[i] = m;
+                    if (wr) v.s_meta()[i] = m;
                 }
             }
         }
@@ -564,7 +570,7 @@ struct Lane {
                                                         SMR_G const uint32_t *pr_vval) {
         if (ballot != bps || !is_leader()) return;              // :110-114
         if (trig < start || trig >= len) return;                // :97-99 (slot >= trig), :116-119
-        if (!(v.s_meta[ix(trig)] & M_LBK)) return;              // :120-125
+        if (!(v.s_meta()[ix(trig)] & M_LBK)) return;              // :120-125
         const uint32_t len0 = len;
         const uint32_t n_mine = trig + n <= len0 ? n : len0 - trig;      // replies for slots I already hold
         // This ballot already has its quorum and every slot of the batch is one I hold: the quorum
@@ -579,8 +585,8 @@ struct Lane {
                 const bool in = k < n_mine;
                 const size_t o = tix(P.pcap, in ? k : 0, g), i = ix(trig + (in ? k : 0));
                 vb[u] = in ? pr_vbal[o] : 0ull; vv[u] = in ? pr_vval[o] : 0u;
-                mm[u] = in ? v.s_meta[i] : 0u; bb[u] = in ? v.s_bal[i] : 0ull;
-                pm[u] = in ? v.s_pmax[i] : 0ull; vl[u] = in ? v.s_val[i] : 0u;
+                mm[u] = in ? v.s_meta()[i] : 0u; bb[u] = in ? v.s_bal()[i] : 0ull;
+                pm[u] = in ? v.s_pmax()[i] : 0ull; vl[u] = in ? v.s_val()[i] : 0u;
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -591,19 +597,19 @@ struct Lane {
                 const uint64_t cur = (m & M_LBKX) ? pm[u] : 0ull;
                 if (vb[u] > cur) {
                     const size_t i = ix(trig + k);
-                    if (!(m & M_LBKX)) { v.s_ltrig[i] = 0; v.s_lendp[i] = 0; m |= M_LBKX; }
-                    v.s_pmax[i] = vb[u];
+                    if (!(m & M_LBKX)) { v.s_ltrig()[i] = 0; v.s_lendp()[i] = 0; m |= M_LBKX; }
+                    v.s_pmax()[i] = vb[u];
                     m = materialize_voted(i, m, bb[u], vl[u], true);
-                    v.s_val[i] = vv[u];
+                    v.s_val()[i] = vv[u];
                     m = vv[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                    v.s_meta[i] = m;
+                    v.s_meta()[i] = m;
                 }
             }
         }
         if (n_mine == n) {                                       // the batch ends inside my log: :222
             if (endp >= trig && endp < trig + n) {
                 const size_t i = ix(endp);
-                if (m_st(v.s_meta[i]) == SMR_ST_PREPARING && ballot >= v.s_bal[i]) prepare_quorum_step(peer, trig, ballot);
+                if (m_st(v.s_meta()[i]) == SMR_ST_PREPARING && ballot >= v.s_bal()[i]) prepare_quorum_step(peer, trig, ballot);
             }
             return;
         }
@@ -612,16 +618,16 @@ struct Lane {
             // instance of this Prepare phase with a fresh LeaderBookkeeping, and then takes the reply
             // (:196-216 with prepare_max_bal == 0): the voted value, if any.  One lane per slot.
             const size_t ti = ix(trig);
-            const uint32_t tm = v.s_meta[ti];
-            const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp[ti] : 0;   // :149-153
+            const uint32_t tm = v.s_meta()[ti];
+            const uint32_t my_endp = (tm & M_LBKX) ? v.s_lendp()[ti] : 0;   // :149-153
             for (uint32_t k = n_mine + cl; k < n; k += cn) {
                 const size_t o = tix(P.pcap, k, g), i = ix(trig + k);
                 const uint64_t vb = pr_vbal[o];
                 const uint32_t vv = vb > 0 ? pr_vval[o] : 0u;
-                v.s_bal[i] = bps;
-                v.s_val[i] = vv;
-                v.s_ltrig[i] = trig; v.s_lendp[i] = my_endp; v.s_pmax[i] = vb;
-                v.s_meta[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX | (vv ? M_NONEMPTY : 0u);
+                v.s_bal()[i] = bps;
+                v.s_val()[i] = vv;
+                v.s_ltrig()[i] = trig; v.s_lendp()[i] = my_endp; v.s_pmax()[i] = vb;
+                v.s_meta()[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX | (vv ? M_NONEMPTY : 0u);
             }
             if (nlb == len0) nlb = trig + n;                     // filled at once: no Null below the log end
             len = trig + n;
@@ -645,7 +651,7 @@ struct Lane {
         leader = me;                                            // :98
         // :104 bcast_heartbeats() now, still carrying the old bal_max_seen (:240-247)
         ob_push(par, OB_HEARTBEAT, cbar, bms, ebar, snap);
-        for (uint32_t p = 0; p < P.R; p++) if (wr) v.peer_exec_bar[(size_t)p * P.G + g] = 0;   // :107-109
+        for (uint32_t p = 0; p < P.R; p++) if (wr) v.peer_exec_bar()[(size_t)p * P.G + g] = 0;   // :107-109
         bpd = 0;                                                // :112-114
         bps = make_greater_ballot(bms);
         bms = bps;
@@ -658,16 +664,16 @@ struct Lane {
         const uint32_t e0 = ebar;
         // Will my own PrepareReplies be counted?  messages.rs:116-125 looks at the trigger
         // slot's leader_bk, which the pass below creates when the trigger lies in it.
-        const bool self_ok = trig >= e0 ? true : (v.s_meta[ix(trig)] & M_LBK) != 0;
+        const bool self_ok = trig >= e0 ? true : (v.s_meta()[ix(trig)] & M_LBK) != 0;
         for (uint32_t s = e0 + cl; s < len; s += cn) {          // :142-183, every lane owns its slots
             const size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
+            uint32_t m = v.s_meta()[i];
             const uint32_t st = m_st(m);
             if (st == SMR_ST_EXECUTED) continue;
             m |= M_EXT;
-            if (st == SMR_ST_COMMITTED) { v.s_meta[i] = m; continue; }
-            const uint64_t b = v.s_bal[i];
-            const uint32_t val = v.s_val[i];
+            if (st == SMR_ST_COMMITTED) { v.s_meta()[i] = m; continue; }
+            const uint64_t b = v.s_bal()[i];
+            const uint32_t val = v.s_val()[i];
             uint64_t vb; uint32_t vv;
             get_voted(i, m, b, val, vb, vv);
             m = materialize_voted(i, m, b, val, true);
@@ -678,12 +684,12 @@ struct Lane {
             // keep the value I voted for, if any (messages.rs:203-216 with prepare_max_bal == 0)
             if (self_ok && s <= endp && vb > 0) {
                 pmax = vb;
-                if (vv != val) v.s_val[i] = vv;
+                if (vv != val) v.s_val()[i] = vv;
                 m = vv ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
             }
-            v.s_bal[i] = bps;
-            v.s_ltrig[i] = trig; v.s_lendp[i] = endp; v.s_pmax[i] = pmax;
-            v.s_meta[i] = m;
+            v.s_bal()[i] = bps;
+            v.s_ltrig()[i] = trig; v.s_lendp()[i] = endp; v.s_pmax()[i] = pmax;
+            v.s_meta()[i] = m;
         }
         ob_push(par, OB_PREPARE, trig, bps, 0, 0);              // :192-198
         // the completion of slot endprep counts me in (messages.rs:222-233)
@@ -702,28 +708,28 @@ struct Lane {
         const uint32_t endp = last > trig ? last : trig;
         const uint32_t n = endp - trig + 1;
         const bool follower = !is_leader();
-        if (follower && (v.pr_cnt[g] != 0 || n > P.pcap)) { ovf = true; return; }
+        if (follower && (v.pr_cnt()[g] != 0 || n > P.pcap)) { ovf = true; return; }
         for (uint32_t s = trig + cl; s <= endp; s += cn) {      // :55-79, every lane owns its slots
             const size_t i = ix(s);
-            uint32_t m = v.s_meta[i];
-            const uint64_t b = v.s_bal[i];
-            const uint32_t val = v.s_val[i];
+            uint32_t m = v.s_meta()[i];
+            const uint64_t b = v.s_bal()[i];
+            const uint32_t val = v.s_val()[i];
             uint64_t vb; uint32_t vv;
             get_voted(i, m, b, val, vb, vv);
             m = materialize_voted(i, m, b, val, true);
-            v.s_bal[i] = ballot;
+            v.s_bal()[i] = ballot;
             m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
-            v.s_rtrig[i] = trig; v.s_rendp[i] = endp;
-            v.s_meta[i] = m;
+            v.s_rtrig()[i] = trig; v.s_rendp()[i] = endp;
+            v.s_meta()[i] = m;
             if (follower) {                                     // durability.rs:50-78
                 size_t o = tix(P.pcap, s - trig, g);
-                v.pr_vbal[o] = vb; v.pr_vval[o] = vv;
+                v.pr_vbal()[o] = vb; v.pr_vval()[o] = vv;
             }
         }
         if (follower) {
-            if (wr) v.pr_dest[g] = (uint8_t)peer; if (wr) v.pr_trig[g] = trig; if (wr) v.pr_endp[g] = endp;
-            if (wr) v.pr_bal[g] = ballot; if (wr) v.pr_abar[g] = abar;
-            if (wr) v.pr_cnt[g] = n;
+            if (wr) v.pr_dest()[g] = (uint8_t)peer; if (wr) v.pr_trig()[g] = trig; if (wr) v.pr_endp()[g] = endp;
+            if (wr) v.pr_bal()[g] = ballot; if (wr) v.pr_abar()[g] = abar;
+            if (wr) v.pr_cnt()[g] = n;
         }
     }
 
@@ -735,7 +741,7 @@ struct Lane {
         check_leader(peer, ballot);
         uint32_t m = 0;
         size_t i = ix(slot);
-        if (slot < len) m = v.s_meta[i];
+        if (slot < len) m = v.s_meta()[i];
         else if (slot == len) {                                 // common case: push + fill fused
             if (len - start >= P.W) { ovf = true; return 0; }
             if (nlb == len) nlb = len + 1;                      // still no Null below the log end
@@ -748,9 +754,9 @@ struct Lane {
         m = m_set_src(m, peer);
         m = m_set_vmode(m, VM_SAME);                            // :351 voted = (ballot, reqs)
         m = reqs ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-        if (wr) v.s_bal[i] = ballot;
-        if (wr) v.s_val[i] = reqs;
-        if (wr) v.s_meta[i] = m;
+        if (wr) v.s_bal()[i] = ballot;
+        if (wr) v.s_val()[i] = reqs;
+        if (wr) v.s_meta()[i] = m;
         uint64_t reply = 0;
         if (is_leader()) accept_reply(me, slot, ballot);        // durability.rs:99-103 (not reachable: a
                                                                 // peer's ballot >= mine deposes me)
@@ -760,13 +766,23 @@ struct Lane {
     }
 
     // leadership.rs:270-346 heard_heartbeat + :372-427 advance_commit_bar
+    // in three parts, so that a kernel can run the commit-bar pass of lanes whose senders differ together
     __device__ __forceinline__ void heard_heartbeat(uint32_t peer, uint64_t ballot, uint32_t hb_commit, uint32_t hb_exec,
                                     uint32_t hb_snap) {
+        if (!hb_gate(peer, ballot, hb_exec)) return;
+        if (hb_commit > cbar && !hb_advance(ballot, hb_commit)) return;   // :379
+        hb_peer(peer, hb_exec, hb_snap);
+    }
+    __device__ __forceinline__ bool hb_gate(uint32_t peer, uint64_t ballot, uint32_t hb_exec) {
         if (peer != me) check_leader(peer, ballot);             // :278-285
-        if (ballot < bms) return;                               // :303-305
-        if (hb_exec < ebar) return;                             // :312-314
-        if (hb_commit > cbar) {                                 // :379
-            if (len < hb_commit && !pad_to(hb_commit - 1)) return;   // :380-382
+        if (ballot < bms) return false;                         // :303-305
+        if (hb_exec < ebar) return false;                       // :312-314
+        return true;
+    }
+    // advance_commit_bar (:372-427) for hb_commit > commit_bar; false = the heartbeat is dropped here
+    __device__ __forceinline__ bool hb_advance(uint64_t ballot, uint32_t hb_commit) {
+        {
+            if (len < hb_commit && !pad_to(hb_commit - 1)) return false;   // :380-382
             // Fused prefix (the steady state of a follower): while slots are Accepting at a ballot
             // >= the heartbeat's and below accept_bar, advance_commit_bar marks them Committed
             // (:385-416), the CommitSlot completion of the first one starts the commit-bar run
@@ -785,15 +801,15 @@ struct Lane {
                     for (int k = 0; k < 8; k++) {
                         bool in = sfx + k < hb_commit;
                         size_t i = ix(sfx + k);
-                        mm[k] = in ? v.s_meta[i] : 0u;
-                        bb[k] = in ? v.s_bal[i] : 0ull;
+                        mm[k] = in ? v.s_meta()[i] : 0u;
+                        bb[k] = in ? v.s_bal()[i] : 0ull;
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         if (sfx >= hb_commit) break;
                         if (!(m_st(mm[k]) == SMR_ST_ACCEPTING && bb[k] >= ballot && sfx < abar)) { simple = false; break; }
                         if ((mm[k] & M_NONEMPTY) && sfx == e0) chase = true;
-                        v.s_meta[ix(sfx)] = m_set_st(mm[k], SMR_ST_EXECUTED);
+                        v.s_meta()[ix(sfx)] = m_set_st(mm[k], SMR_ST_EXECUTED);
                         sfx++;
                     }
                 }
@@ -809,8 +825,8 @@ struct Lane {
                     for (int k = 0; k < 8; k++) {
                         bool in = s + k < hb_commit;
                         size_t i = ix(s + k);
-                        mm[k] = in ? v.s_meta[i] : 0u;
-                        bb[k] = in ? v.s_bal[i] : 0ull;
+                        mm[k] = in ? v.s_meta()[i] : 0u;
+                        bb[k] = in ? v.s_bal()[i] : 0ull;
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -819,7 +835,7 @@ struct Lane {
                         if (bb[k] < ballot || st < SMR_ST_ACCEPTING) { go = false; break; }
                         if (st < SMR_ST_COMMITTED) {
                             uint32_t m = m_set_st(mm[k], SMR_ST_COMMITTED);
-                            if (wr) v.s_meta[ix(s)] = m;
+                            if (wr) v.s_meta()[ix(s)] = m;
                             if (first == 0xFFFFFFFFu) { first = s; first_m = m; }
                         }
                         s++;
@@ -828,20 +844,23 @@ struct Lane {
             }
             if (sfx > c0) {
                 // the run started in the fused prefix goes on from commit_bar, whatever marked it
-                if (cbar < len) commit_complete<8>(cbar, v.s_meta[ix(cbar)], 0xFFFFFFFFu, chase);
+                if (cbar < len) commit_complete<8>(cbar, v.s_meta()[ix(cbar)], 0xFFFFFFFFu, chase);
                 else if (chase) ebar = cbar;
             } else if (first != 0xFFFFFFFFu) {
                 // CommitSlot completions: only the first can sit at commit_bar
                 commit_complete<8>(first, first_m);
             }
         }
+        return true;
+    }
+    __device__ __forceinline__ void hb_peer(uint32_t peer, uint32_t hb_exec, uint32_t hb_snap) {
         if (peer != me) {                                       // :320-342
             size_t po = (size_t)peer * P.G + g;
-            if (hb_exec > v.peer_exec_bar[po]) {
-                if (wr) v.peer_exec_bar[po] = hb_exec;
+            if (hb_exec > v.peer_exec_bar()[po]) {
+                if (wr) v.peer_exec_bar()[po] = hb_exec;
                 uint32_t passed = 1;
                 for (uint32_t p = 0; p < P.R; p++)
-                    if (p != me && v.peer_exec_bar[(size_t)p * P.G + g] >= hb_exec) passed++;
+                    if (p != me && v.peer_exec_bar()[(size_t)p * P.G + g] >= hb_exec) passed++;
                 if (passed == P.R) snap = hb_exec;
             }
             if (hb_snap > snap) snap = hb_snap;

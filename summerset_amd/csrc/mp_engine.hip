@@ -2,7 +2,8 @@
 //
 // Grid shape of every round kernel: blockIdx.y = replica id, 256 lanes per
 // block = 256 consecutive groups, so every per-group array access of a
-// wavefront is one contiguous request.  Rounds are separate launches because
+// wavefront is one contiguous request.  (mp_quorum_tally is the exception: its
+// lanes pick their group's leader, whichever replica that is.)  Rounds are separate launches because
 // each consumes what the previous one wrote for OTHER replicas (and, in the
 // multi-GPU layout, the exchange sits between them).
 #include <string.h>
@@ -14,24 +15,38 @@
 
 namespace smr {
 
-// wave-reduce the three counters, one atomic per wave; `job` = what the wave's
-// cooperative jobs counted (wave-uniform, added once)
-__device__ __forceinline__ void flush_counters(const Lane &L, bool active, const unsigned int (&job)[3]) {
-    unsigned int c0 = active ? L.n_commit : 0, c1 = active ? L.n_redirect : 0, c2 = active ? L.n_reject : 0;
-    unsigned int c3 = active ? L.n_generic : 0;
-    for (int off = 32; off > 0; off >>= 1) {
-        c0 += __shfl_xor(c0, off);
-        c1 += __shfl_xor(c1, off);
-        c2 += __shfl_xor(c2, off);
-        c3 += __shfl_xor(c3, off);
+// wave-reduce the counters, one atomic per wave and replica
+__device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
+    unsigned int c[4] = {active ? L.n_commit : 0u, active ? L.n_redirect : 0u, active ? L.n_reject : 0u,
+                         active ? L.n_generic : 0u};
+    const bool any = (c[0] | c[1] | c[2] | c[3]) != 0;
+    // lanes of a wavefront may stand for different replicas: one reduction per replica that counted
+    for (unsigned long long todo = __ballot(any); todo;) {
+        const uint32_t rep = __shfl(L.me, __ffsll((long long)todo) - 1);
+        const bool mine = any && L.me == rep;
+        todo &= ~__ballot(mine);
+        unsigned int x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x[k] = mine ? c[k] : 0u;
+            for (int off = 32; off > 0; off >>= 1) x[k] += __shfl_xor(x[k], off);
+        }
+        if (__lane_id() == 0) {
+            SMR_G unsigned long long *const ctr = RepView{L.P.rep[0], (size_t)rep * L.P.rep_stride}.counters();
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (x[k]) atomicAdd((unsigned long long *)&ctr[k], (unsigned long long)x[k]);
+        }
     }
-    c0 += job[0]; c1 += job[1]; c2 += job[2];
-    if (__lane_id() == 0) {
-        if (c3) atomicAdd((unsigned long long *)&L.v.counters[3], (unsigned long long)c3);
-        if (c0) atomicAdd((unsigned long long *)&L.v.counters[0], (unsigned long long)c0);
-        if (c1) atomicAdd((unsigned long long *)&L.v.counters[1], (unsigned long long)c1);
-        if (c2) atomicAdd((unsigned long long *)&L.v.counters[2], (unsigned long long)c2);
-    }
+}
+
+// a cooperative job's counters: identical in all lanes, added once
+__device__ __forceinline__ void flush_job(const Lane &J) {
+    if (__lane_id() != 0) return;
+    SMR_G unsigned long long *const ctr = J.v.counters();
+    if (J.n_commit) atomicAdd((unsigned long long *)&ctr[0], (unsigned long long)J.n_commit);
+    if (J.n_redirect) atomicAdd((unsigned long long *)&ctr[1], (unsigned long long)J.n_redirect);
+    if (J.n_reject) atomicAdd((unsigned long long *)&ctr[2], (unsigned long long)J.n_reject);
 }
 
 // Rare, long-running work (leader changes) is not run by one lane while 63 idle: the
@@ -42,6 +57,43 @@ __device__ __forceinline__ void flush_counters(const Lane &L, bool active, const
 #define SMR_FOR_EACH_JOB(pending, src)                                            \
     for (unsigned long long _jm = __ballot(pending); _jm; _jm &= _jm - 1)        \
         if (const int src = __ffsll((long long)_jm) - 1; true)
+
+// Which group a lane works on.  Bulk launch (side == 0): lane = group, minus the groups the
+// tick's mark pass moved to the straggler list.  Straggler launch (side = 1 + list parity): one
+// listed group per wavefront, on lane 0, so that its handlers run as wave-cooperative jobs
+// beside the bulk kernels instead of at their tail.
+__device__ __forceinline__ bool pick_group(const MpParams &P, int side, uint32_t &g) {
+    if (side == 0) {
+        g = blockIdx.x * blockDim.x + threadIdx.x;
+        return g < P.G && !P.overflow[g] && !P.slow[g];
+    }
+    const uint32_t idx = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t n = P.slow_n[side - 1];
+    if (n > P.slow_cap) n = P.slow_cap;
+    g = P.G;
+    if ((threadIdx.x & 63) != 0 || idx >= n) return false;
+    g = P.slow_list[idx];
+    return !P.overflow[g];
+}
+
+// start of a tick: a HearTimeout puts its group on the straggler list for `ttl` ticks
+__global__ __launch_bounds__(256) void mp_mark_stragglers(const MpParams *__restrict__ Pp, int lpar,
+                                                          const uint8_t *__restrict__ timeout_rep, uint32_t ttl) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) P.slow_n[lpar ^ 1] = 0;                          // next tick's counter
+    if (g >= P.G) return;
+    uint32_t t = P.slow_ttl[g];
+    if (timeout_rep && timeout_rep[g] != NO_REP) t = ttl;
+    uint8_t s = 0;
+    if (t > 0) {
+        const uint32_t idx = atomicAdd(&P.slow_n[lpar], 1u);
+        if (idx < P.slow_cap) { P.slow_list[idx] = g; s = 1; }   // list full: the group stays with the bulk
+        t--;
+        P.slow_ttl[g] = (uint8_t)t;
+    }
+    if (P.slow[g] != s) P.slow[g] = s;
+}
 
 // ---- R1 ---------------------------------------------------------------------
 __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__restrict__ req_val, uint32_t k0,
@@ -62,12 +114,12 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
                                                       const uint8_t *__restrict__ timeout_src,
                                                       const uint8_t *__restrict__ req_target,
                                                       const uint32_t *__restrict__ req_cnt,
-                                                      const uint32_t *__restrict__ req_val, uint32_t S) {
+                                                      const uint32_t *__restrict__ req_val, uint32_t S, int side) {
     const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t g;
+    bool active = pick_group(P, side, g);
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
-    bool active = g < P.G && !P.overflow[g];
     const bool has_to = active && timeout_rep && timeout_rep[g] == r;
     uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
     if (n_req > S) n_req = S;
@@ -85,10 +137,10 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
             L.ob_load(par);
             const uint32_t c0 = par == 0 ? L.obn0 : L.obn1;
             if (c0 + n_req <= P.cap) {
-                const MpRep &v = P.rep[r];
-                SMR_G uint64_t *const sb = v.s_bal; SMR_G uint32_t *const sv = v.s_val; SMR_G uint32_t *const sm = v.s_meta;
-                SMR_G uint32_t *const os = v.ob_slot[par]; SMR_G uint64_t *const obl = v.ob_bal[par];
-                SMR_G uint32_t *const ov = v.ob_val[par];
+                const RepView &v = L.v;
+                SMR_G uint64_t *const sb = v.s_bal(); SMR_G uint32_t *const sv = v.s_val(); SMR_G uint32_t *const sm = v.s_meta();
+                SMR_G uint32_t *const os = v.ob_slot(par); SMR_G uint64_t *const obl = v.ob_bal(par);
+                SMR_G uint32_t *const ov = v.ob_val(par);
                 const uint64_t bal = L.bpd;
                 const uint32_t base = L.len, G = P.G, Wm = P.Wmask;
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (r + M_ACKS_SH));
@@ -108,15 +160,14 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
                 }
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
                 if (par == 0) L.obn0 = c0 + n_req; else L.obn1 = c0 + n_req;
-                v.ob_reg[par][g] = c0 == 0 ? base + 1 : 0u;
-                if (c0 == 0) v.ob_rbal[par][g] = bal;
+                v.ob_reg(par)[g] = c0 == 0 ? base + 1 : 0u;
+                if (c0 == 0) v.ob_rbal(par)[g] = bal;
                 k0 = n_req;
             }
         }
         r1_generic_batches(L, req_val, k0, n_req);
         L.store();
     }
-    unsigned int jc[3] = {0, 0, 0};
     SMR_FOR_EACH_JOB(has_to, src) {                             // leader change: the whole wave on one lane's group
         const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src);
         Lane J(P, r, gj, par);
@@ -129,9 +180,9 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
         r1_generic_batches(J, req_val, 0, nj);
         J.store();
         JSTAMP(11);
-        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+        flush_job(J);
     }
-    flush_counters(L, active, jc);
+    flush_counters(L, active);
 }
 
 // ---- R2 ---------------------------------------------------------------------
@@ -180,12 +231,12 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 if ((len0 - L.start) + n_new <= P.W && ldr != r) {
                     (void)mine_before;
                     L.leader = ldr; L.bms = bm;
-                    const MpRep &v = P.rep[r];
+                    const RepView &v = L.v;
                     uint32_t mo[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const uint32_t t = L.cl + 64u * u;
-                        mo[u] = (t < n_old) ? v.s_meta[L.ix(slot0 + t)] : 0u;   // fresh instance beyond my log end
+                        mo[u] = (t < n_old) ? v.s_meta()[L.ix(slot0 + t)] : 0u;   // fresh instance beyond my log end
                     }
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
@@ -197,7 +248,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                         m = m_set_src(m, s);
                         m = m_set_vmode(m, VM_SAME);                         // :351
                         m = tok[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                        v.s_bal[i] = bal0; v.s_val[i] = tok[u]; v.s_meta[i] = m;
+                        v.s_bal()[i] = bal0; v.s_val()[i] = tok[u]; v.s_meta()[i] = m;
                         snd.ack[tix(P.cap * P.R, (jstart + t) * P.R + r, g)] = bal0;   // durability.rs:108-131
                     }
                     if (n_new) {
@@ -207,7 +258,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                     if (L.abar >= slot0 && L.abar < slot0 + n) {  // durability.rs:134-142
                         L.abar = slot0 + n;
                         while (L.abar < L.len) {
-                            if (m_st(v.s_meta[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
+                            if (m_st(v.s_meta()[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
                             L.abar++;
                         }
                     }
@@ -235,18 +286,18 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             if (appending && (L.len - L.start) + nin > P.W) break;   // ring window: let the serial path flag it
             L.check_leader(s, bal0);                             // messages.rs:313-316
             if (L.is_leader()) break;
-            const MpRep &v = P.rep[r];
+            const RepView &v = L.v;
             uint32_t m = 0;
             if (in) {
                 const size_t i = L.ix(slot);
                 const uint32_t val = tok;
-                m = appending ? 0u : v.s_meta[i];
+                m = appending ? 0u : v.s_meta()[i];
                 m = m_set_st(m, SMR_ST_ACCEPTING);              // :327-329
                 if (!(m & M_RBK)) m = (m | M_RBK) & ~M_RBKX;    // :331-339
                 m = m_set_src(m, s);
                 m = m_set_vmode(m, VM_SAME);                     // :351
                 m = val ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
-                v.s_bal[i] = bal0; v.s_val[i] = val; v.s_meta[i] = m;
+                v.s_bal()[i] = bal0; v.s_val()[i] = val; v.s_meta()[i] = m;
                 snd.ack[tix(P.cap * P.R, j * P.R + r, g)] = bal0; // durability.rs:108-131
             }
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
@@ -258,7 +309,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             if (L.abar >= slot0 && L.abar < slot0 + nin) {
                 L.abar = slot0 + nin;
                 while (L.abar < L.len) {
-                    if (m_st(v.s_meta[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
+                    if (m_st(v.s_meta()[L.ix(L.abar)]) < SMR_ST_ACCEPTING) break;
                     L.abar++;
                 }
             }
@@ -293,25 +344,25 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
-__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par) {
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t g;
+    bool active = pick_group(P, side, g);
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
-    bool active = g < P.G && !P.overflow[g];
     bool job = false;
     uint32_t job_sender = 0, job_j = 0;
     bool loaded = false;
     if (active) {
-        if (L.v.pr_cnt[g]) L.v.pr_cnt[g] = 0;
+        if (L.v.pr_cnt()[g]) L.v.pr_cnt()[g] = 0;
         uint32_t cnts[MAXR];
-        uint32_t n_senders = 0, the_sender = 0, first = MAXR;
+        uint32_t n_senders = 0, the_sender = 0, the_cnt = 0, first = MAXR;
 #pragma unroll
         for (int s = 0; s < MAXR; s++) {
             cnts[s] = ((uint32_t)s < P.R && (uint32_t)s != r) ? P.rep[s].ob_cnt[par][g] : 0u;
-            if (cnts[s]) { n_senders++; the_sender = (uint32_t)s; if (first == MAXR) first = (uint32_t)s; }
+            if (cnts[s]) { n_senders++; the_sender = (uint32_t)s; the_cnt = cnts[s]; if (first == MAXR) first = (uint32_t)s; }
         }
-        uint32_t fast_done = 0, the_cnt = 0;
+        uint32_t fast_done = 0;
         // Steady-state fast path: the only sender is the leader I already follow and
         // each message is an Accept at my bal_max_seen for the slot right at my log
         // end, with accept_bar at the log end too.  Per message this is exactly
@@ -321,21 +372,20 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
         // fit hands the rest of the outbox to the generic handlers.
         if (n_senders == 1) {
             L.load(); loaded = true;
-            const uint32_t s = the_sender;
-            the_cnt = cnts[s];
+            const uint32_t s = the_sender;                       // differs from lane to lane: addressed like my own arrays
             if (L.leader == s && L.abar == L.len) {
-                const MpRep &snd = P.rep[s];
-                const MpRep &v = P.rep[r];
-                SMR_G const uint32_t *const os = snd.ob_slot[par]; SMR_G const uint64_t *const obl = snd.ob_bal[par];
-                SMR_G const uint32_t *const ov = snd.ob_val[par]; SMR_G uint64_t *const ack = snd.ack;
-                SMR_G uint64_t *const sb = v.s_bal; SMR_G uint32_t *const sv = v.s_val; SMR_G uint32_t *const sm = v.s_meta;
-                const uint32_t cnt = cnts[s], G = P.G, Wm = P.Wmask, W = P.W, R = P.R, start = L.start;
+                const RepView snd{P.rep[0], (size_t)s * P.rep_stride};
+                const RepView &v = L.v;
+                SMR_G const uint32_t *const os = snd.ob_slot(par); SMR_G const uint64_t *const obl = snd.ob_bal(par);
+                SMR_G const uint32_t *const ov = snd.ob_val(par); SMR_G uint64_t *const ack = snd.ack();
+                SMR_G uint64_t *const sb = v.s_bal(); SMR_G uint32_t *const sv = v.s_val(); SMR_G uint32_t *const sm = v.s_meta();
+                const uint32_t cnt = the_cnt, Wm = P.Wmask, W = P.W, R = P.R, start = L.start;
                 const uint64_t bms = L.bms;
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_RBK | (s << M_SRC_SH) | (VM_SAME << M_VMODE_SH);
                 uint32_t len = L.len;
                 bool ok = true;
-                const uint32_t reg = snd.ob_reg[par][g];
-                if (reg != 0 && reg - 1 == len && snd.ob_rbal[par][g] == bms && (len - start) + cnt <= W) {
+                const uint32_t reg = snd.ob_reg(par)[g];
+                if (reg != 0 && reg - 1 == len && snd.ob_rbal(par)[g] == bms && (len - start) + cnt <= W) {
                     // regular outbox: Accepts for slots len, len+1, ... at my bal_max_seen, all of
                     // which fit the window -- only the batch tokens are read
                     for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {
@@ -385,7 +435,6 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
         else if (n_senders == 1 && fast_done < the_cnt) { job = true; job_sender = the_sender; job_j = fast_done; }
         if (loaded) L.store();
     }
-    unsigned int jc[3] = {0, 0, 0};
     SMR_FOR_EACH_JOB(job, src) {
         const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src);
         Lane J(P, r, gj, par);
@@ -397,9 +446,9 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
         JSTAMP(18);
         J.store();
         JSTAMP(19);
-        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+        flush_job(J);
     }
-    flush_counters(L, active && loaded, jc);
+    flush_counters(L, active && loaded);
 }
 
 // ---- R3 ---------------------------------------------------------------------
@@ -463,10 +512,10 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     const MpParams &P = L.P;
     const uint32_t g = L.g, d = L.me;
     const int par = L.par;
-    const MpRep &v = P.rep[d];
+    const RepView &v = L.v;
     constexpr int C = 8;                                         // ack-matrix rows per batch of loads
-    SMR_G const uint32_t *const os = v.ob_slot[par]; SMR_G const uint64_t *const ack = v.ack;
-    SMR_G uint32_t *const sm = v.s_meta; SMR_G const uint64_t *const sb = v.s_bal;
+    SMR_G const uint32_t *const os = v.ob_slot(par); SMR_G const uint64_t *const ack = v.ack();
+    SMR_G uint32_t *const sm = v.s_meta(); SMR_G const uint64_t *const sb = v.s_bal();
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
     const bool lead = L.is_leader();
     const uint64_t bpd = L.bpd;
@@ -541,7 +590,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     }
     // regular outbox (steady-state appends): entry j is the Accept for slot (reg - 1) + j, so
     // nothing depends on ob_slot and all loads of a batch go out together
-    const uint32_t reg = v.ob_reg[par][g];
+    const uint32_t reg = v.ob_reg(par)[g];
     for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
         uint32_t e[C], ctl[C], m[C];
         uint64_t a[C][NR], b[C];
@@ -598,8 +647,8 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
 }
 
 __device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.rs:240-247 record
-    const MpRep &v = L.v;
-    if (L.wr) { v.hb_bal[L.g] = L.bms; v.hb_commit[L.g] = L.cbar; v.hb_exec[L.g] = L.ebar; v.hb_snap[L.g] = L.snap; }
+    const RepView &v = L.v;
+    if (L.wr) { v.hb_bal()[L.g] = L.bms; v.hb_commit()[L.g] = L.cbar; v.hb_exec()[L.g] = L.ebar; v.hb_snap()[L.g] = L.snap; }
 }
 
 // R3: replies reach their destination: PrepareReplies (sender order of the
@@ -616,14 +665,6 @@ __device__ __forceinline__ void r3_publish_hb(Lane &L) {         // leadership.r
 //    and wavefront 0 moves the bars; otherwise wavefront 0 replays the commits in entry order.
 //  * mp_round_replies -- every other lane (irregular outbox, non-leader, PrepareReplies, the
 //    long outbox of a re-Accept round): per lane, or as a cooperative job for the wavefront.
-__device__ __forceinline__ bool r3_is_fast4(const MpRep &v, int par, uint32_t g, uint32_t d, bool has_pr,
-                                            uint32_t cnt, uint32_t &reg, uint64_t &bpd) {
-    if (has_pr || cnt == 0 || cnt > 64) return false;
-    reg = v.ob_reg[par][g];
-    bpd = v.bal_prepared[g];
-    return reg != 0 && bpd != 0 && v.leader[g] == d;
-}
-
 // which replicas have PrepareReplies addressed to them (bit d), for group g
 __device__ __forceinline__ uint32_t r3_pr_dest_mask(const MpParams &P, uint32_t g) {
     uint32_t mask = 0;
@@ -656,7 +697,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     const uint32_t gg = g < P.G ? g : 0;
     const uint32_t R = P.R, G = P.G, Wm = P.Wmask, thresh = P.thresh;
     // ---- round 1: every replica's outbox count and who is owed PrepareReplies --------------------
-    const uint32_t ovf = P.overflow[gg];
+    const uint32_t ovf = (uint32_t)P.overflow[gg] | (uint32_t)P.slow[gg];
     uint32_t cnts[MAXR], prc[MAXR], prd[MAXR];
 #pragma unroll
     for (int d = 0; d < MAXR; d++) {
@@ -665,7 +706,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         prc[d] = in ? P.rep[d].pr_cnt[gg] : 0u;
         prd[d] = in ? P.rep[d].pr_dest[gg] : 0u;
     }
-    const bool active = g < G && !ovf;
+    const bool active = g < G && !ovf;                          // ovf: frozen, or on the straggler list
     uint32_t prmask = 0;
 #pragma unroll
     for (int d = 0; d < MAXR; d++) {
@@ -804,7 +845,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     for (int off = 32; off > 0; off >>= 1) nd |= __shfl_xor(nd, off);
     if (lane == 0) {
         const uint32_t ntile = (G + 63) / 64;
-        for (uint32_t d = 0; d < R; d++) P.r3_need[(size_t)d * ntile + blockIdx.x] = (uint8_t)((nd >> d) & 1u);
+        for (uint32_t k = 0; k < R; k++) P.r3_need[(size_t)k * ntile + blockIdx.x] = (uint8_t)((nd >> k) & 1u);
     }
 }
 
@@ -821,27 +862,27 @@ __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParam
 
 __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
                                                         const uint32_t *__restrict__ ackctl,
-                                                        int publish_hb) {
+                                                        int publish_hb, int side) {
     const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t d = blockIdx.y;
-    {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
+    if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
         const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
         uint32_t any = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)d * ntile + t0 + k] : 0u;
+        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
         if (!any) return;
     }
+    uint32_t g;
+    bool active = pick_group(P, side, g);
+    const uint32_t d = blockIdx.y;
     Lane L(P, d, g < P.G ? g : 0, par);
-    bool active = g < P.G && !P.overflow[g];
     bool loaded = false, job = false;
     if (active) {
-        const MpRep &v = P.rep[d];
+        const RepView &v = L.v;
         bool has_pr = false;
 #pragma unroll
         for (int s = 0; s < MAXR; s++)
             if ((uint32_t)s < P.R && (uint32_t)s != d && P.rep[s].pr_cnt[g] != 0 && P.rep[s].pr_dest[g] == d) has_pr = true;
-        const uint32_t cnt = v.ob_cnt[par][g];
+        const uint32_t cnt = v.ob_cnt(par)[g];
         // (a lane mp_quorum_tally closed shows up here with an empty outbox)
         // a leader change in flight (PrepareReplies for me, or the long outbox of the
         // re-Accept round) is a cooperative job for the whole wave
@@ -855,7 +896,6 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
             if (loaded) L.store();
         }
     }
-    unsigned int jc[3] = {0, 0, 0};
     SMR_FOR_EACH_JOB(job, src) {
         const uint32_t gj = __shfl(g, src);
         Lane J(P, d, gj, par);
@@ -865,30 +905,30 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
         JSTAMP(25);
         r3_prepare_replies(J, ackctl ? ackctl[gj] : SMR_CTL_IDENTITY);
         JSTAMP(26);
-        const uint32_t cj = P.rep[d].ob_cnt[par][gj];
+        const uint32_t cj = J.v.ob_cnt(par)[gj];
         if (cj) { if (P.R <= 5) r3_accept_replies<5>(J, ackctl, cj); else r3_accept_replies<MAXR>(J, ackctl, cj); }
         JSTAMP(27);
         if (publish_hb) r3_publish_hb(J);
         J.store();
         JSTAMP(28);
-        jc[0] += J.n_commit; jc[1] += J.n_redirect; jc[2] += J.n_reject;
+        flush_job(J);
     }
-    flush_counters(L, active && loaded, jc);
+    flush_counters(L, active && loaded);
 }
 
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
 // trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
 // as carried by this round's heartbeats).
-__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par) {
+__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t g;
+    bool active = pick_group(P, side, g);
     const uint32_t r = blockIdx.y;
     Lane L(P, r, g < P.G ? g : 0, par);
-    bool active = g < P.G && !P.overflow[g];
     if (active) {
         L.load();
-        const MpRep &v = P.rep[r];
-        L.heard_heartbeat(r, v.hb_bal[g], v.hb_commit[g], v.hb_exec[g], v.hb_snap[g]);   // :254-261
+        const RepView &v = L.v;
+        L.heard_heartbeat(r, v.hb_bal()[g], v.hb_commit()[g], v.hb_exec()[g], v.hb_snap()[g]);   // :254-261
         uint32_t bound = 0xFFFFFFFFu;
         for (uint32_t s = 0; s < P.R; s++) {
             if (s == r) continue;
@@ -901,8 +941,7 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__rest
         if (bound > L.start) L.start = bound;
         L.store();
     }
-    const unsigned int nojob[3] = {0, 0, 0};
-    flush_counters(L, active, nojob);
+    flush_counters(L, active);
 }
 
 // ------------------------------------------------------------------ host ---
@@ -919,6 +958,12 @@ struct smr_mp_cluster {
     Arena arena;
     uint32_t pcap = 0;
     int par = 0;
+    int lpar = 0;                    // straggler-list counter parity
+    uint32_t ttl = 0;                // ticks on the side stream after a HearTimeout (0 = never)
+    hipStream_t side = nullptr;      // straggler launches
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool forked = false, marked = false, side_on = false;
+    uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     bool profile = false;
     std::vector<ProfEv> evs;
     double prof_ms[4] = {0, 0, 0, 0};
@@ -926,6 +971,8 @@ struct smr_mp_cluster {
 };
 
 namespace smr {
+
+constexpr uint32_t SLOW_CAP = 1024;   // groups per tick the side stream takes (4 per block)
 
 static bool is_pow2(uint32_t x) { return x && !(x & (x - 1)); }
 
@@ -944,6 +991,8 @@ static void layout(smr_mp_cluster *c, bool dry) {
     carve(a, P.overflow, G, dry);
     carve(a, P.dbg, 64, dry);
     carve(a, P.r3_need, R * ((G + 63) / 64), dry);
+    carve(a, P.slow, G, dry); carve(a, P.slow_ttl, G, dry);
+    carve(a, P.slow_list, (size_t)SLOW_CAP, dry); carve(a, P.slow_n, 2, dry);
     for (size_t r = 0; r < R; r++) {
         MpRep &v = P.rep[r];
         carve(a, v.leader, G, dry);
@@ -1004,6 +1053,41 @@ static int prof_end(smr_mp_cluster *c, hipStream_t st) {
 }
 
 static dim3 mp_grid(const smr_mp_cluster *c) { return dim3((c->cfg.n_groups + 255) / 256, c->cfg.population); }
+static dim3 side_grid(const smr_mp_cluster *c) { return dim3(SLOW_CAP / 4, c->cfg.population); }
+
+// Straggler side stream.  The first round call of a tick builds the tick's list; a round then
+// launches its kernel twice -- bulk groups on the caller's stream, listed groups on the side
+// stream -- between a fork (side waits for the caller's stream) and a join (the caller's stream
+// waits for the side).  smr_mp_tick forks once around all rounds, a lone round call around itself.
+static int ensure_marked(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, hipStream_t st) {
+    if (!c->ttl || c->marked) return SMR_OK;
+    c->marked = true;
+    // no HearTimeout array for ttl + 1 ticks: every list entry has expired and the last mark pass
+    // cleared the flags, so the tick runs without the side stream at all
+    if (timeout_rep_dev) c->side_live = c->ttl + 1;
+    c->side_on = c->side_live != 0;
+    if (!c->side_on) return SMR_OK;
+    c->side_live--;
+    hipLaunchKernelGGL(mp_mark_stragglers, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, st, c->dp, c->lpar,
+                       timeout_rep_dev, c->ttl);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+static int fork_side(smr_mp_cluster *c, hipStream_t st, bool &own) {
+    own = false;
+    if (!c->side_on || c->forked) return SMR_OK;
+    SMR_HIP_TRY(hipEventRecord(c->ev_fork, st));
+    SMR_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    c->forked = own = true;
+    return SMR_OK;
+}
+static int join_side(smr_mp_cluster *c, hipStream_t st, bool own) {
+    if (!own) return SMR_OK;
+    SMR_HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    SMR_HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    c->forked = false;
+    return SMR_OK;
+}
 
 }  // namespace smr
 
@@ -1037,6 +1121,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     P.G = cfg->n_groups; P.W = cfg->window; P.Wmask = cfg->window - 1; P.cap = cfg->outbox_cap;
     P.pcap = c->pcap; P.win_reserve = cfg->win_reserve; P.clist_cap = cfg->commit_list_cap;
     P.R = cfg->population; P.quorum = quorum; P.thresh = quorum + cfg->commit_extra; P.rspaxos = 0;
+    P.slow_cap = SLOW_CAP;
     if (!stride_ok(P)) {
         (void)hipFree(c->arena.base);
         delete c;
@@ -1052,12 +1137,26 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
         delete c;
         return fail(SMR_ERR_DEVICE, std::string("mp: init: ") + hipGetErrorString(e));
     }
+    c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
+    if (c->ttl) {
+        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            smr_mp_cluster_destroy(c);
+            return fail(SMR_ERR_DEVICE, std::string("mp: side stream: ") + hipGetErrorString(e));
+        }
+    }
     *out = c;
     return SMR_OK;
 }
 
 void smr_mp_cluster_destroy(smr_mp_cluster *c) {
     if (!c) return;
+    (void)hipDeviceSynchronize();
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     for (auto &e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->dp) (void)hipFree(c->dp);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -1086,28 +1185,53 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     if (timeout_rep_dev && !timeout_src_dev) return fail(SMR_ERR_ARG, "mp: timeout_rep without timeout_src");
     if (req_target_dev && (!req_cnt_dev || !req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
-    if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
     hipStream_t st = (hipStream_t)stream;
-    int rc = prof_begin(c, 0, st); if (rc) return rc;
+    int rc = ensure_marked(c, timeout_rep_dev, st); if (rc) return rc;
+    if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
+    bool own;
+    if ((rc = fork_side(c, st, own))) return rc;
+    if (c->side_on) {
+        hipLaunchKernelGGL(mp_round_local, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, timeout_rep_dev,
+                           timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 1 + c->lpar);
+        SMR_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = prof_begin(c, 0, st))) return rc;
     hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
-                       timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S);
+                       timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 0);
     SMR_HIP_TRY(hipGetLastError());
-    return prof_end(c, st);
+    if ((rc = prof_end(c, st))) return rc;
+    return join_side(c, st, own);
 }
 
 int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
-    int rc = prof_begin(c, 1, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
+    bool own;
+    if ((rc = fork_side(c, st, own))) return rc;
+    if (c->side_on) {
+        hipLaunchKernelGGL(mp_round_deliver, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
+        SMR_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = prof_begin(c, 1, st))) return rc;
+    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
-    return prof_end(c, st);
+    if ((rc = prof_end(c, st))) return rc;
+    return join_side(c, st, own);
 }
 
 int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publish_heartbeat, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
-    int rc = prof_begin(c, 2, st); if (rc) return rc;
+    int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
+    bool own;
+    if ((rc = fork_side(c, st, own))) return rc;
+    if (c->side_on) {
+        hipLaunchKernelGGL(mp_round_replies, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, ackctl_dev,
+                           publish_heartbeat, 1 + c->lpar);
+        SMR_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = prof_begin(c, 2, st))) return rc;
     if (c->cfg.population <= 5)
         hipLaunchKernelGGL(mp_quorum_tally<5>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
                            c->dp, c->par, ackctl_dev, publish_heartbeat);
@@ -1116,35 +1240,54 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
                            c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
-                       publish_heartbeat);
+                       publish_heartbeat, 0);
     SMR_HIP_TRY(hipGetLastError());
-    return prof_end(c, st);
+    if ((rc = prof_end(c, st))) return rc;
+    return join_side(c, st, own);
 }
 
 int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
-    int rc = prof_begin(c, 3, st); if (rc) return rc;
-    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par);
+    int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
+    bool own;
+    if ((rc = fork_side(c, st, own))) return rc;
+    if (c->side_on) {
+        hipLaunchKernelGGL(mp_round_heartbeat, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
+        SMR_HIP_TRY(hipGetLastError());
+    }
+    if ((rc = prof_begin(c, 3, st))) return rc;
+    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
-    return prof_end(c, st);
+    if ((rc = prof_end(c, st))) return rc;
+    return join_side(c, st, own);
 }
 
 int smr_mp_end_tick(smr_mp_cluster *c) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    if (c->forked) return fail(SMR_ERR_STATE, "mp: end_tick inside an open side-stream fork");
     c->par ^= 1;
+    if (c->marked && c->side_on) c->lpar ^= 1;
+    c->marked = false;
+    c->side_on = false;
     return SMR_OK;
 }
 
 int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t *timeout_src_dev,
                 const uint8_t *req_target_dev, const uint32_t *req_cnt_dev, const uint32_t *req_val_dev,
                 uint32_t S, const uint32_t *ackctl_dev, int do_heartbeat, void *stream) {
-    int rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S,
-                                stream);
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensure_marked(c, timeout_rep_dev, st); if (rc) return rc;
+    bool own;
+    if ((rc = fork_side(c, st, own))) return rc;                // one fork around the whole tick
+    rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, stream);
+    if (!rc) rc = smr_mp_round_deliver(c, stream);
+    if (!rc) rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream);
+    if (!rc && do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
+    const int rj = join_side(c, st, own);
     if (rc) return rc;
-    if ((rc = smr_mp_round_deliver(c, stream))) return rc;
-    if ((rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream))) return rc;
-    if (do_heartbeat && (rc = smr_mp_round_heartbeat(c, stream))) return rc;
+    if (rj) return rj;
     return smr_mp_end_tick(c);
 }
 

@@ -116,12 +116,79 @@ struct MpRep {
     SMR_G unsigned int *clist_n;
 };
 
+// The arena lays every replica's arrays out identically, `rep_stride` bytes apart, so the arrays
+// of replica r are replica 0's shifted by r * rep_stride.  RepView is that addressing: the round
+// kernels use it for their own replica (uniform per block) and for a sender or leader that
+// differs from group to group, i.e. from lane to lane.
+#if defined(__HIPCC__)
+#define SMR_HD __host__ __device__ __forceinline__
+#else
+#define SMR_HD inline
+#endif
+struct RepView {
+    const MpRep &b;
+    size_t ro;                      // byte offset of my replica's arrays from replica 0's
+    template <typename T> SMR_HD T *sh(T *p0) const { return (T *)((SMR_G char *)p0 + ro); }
+    SMR_HD SMR_G uint8_t *leader() const { return sh(b.leader); }
+    SMR_HD SMR_G uint64_t *bal_prep_sent() const { return sh(b.bal_prep_sent); }
+    SMR_HD SMR_G uint64_t *bal_prepared() const { return sh(b.bal_prepared); }
+    SMR_HD SMR_G uint64_t *bal_max_seen() const { return sh(b.bal_max_seen); }
+    SMR_HD SMR_G uint32_t *start_slot() const { return sh(b.start_slot); }
+    SMR_HD SMR_G uint32_t *log_len() const { return sh(b.log_len); }
+    SMR_HD SMR_G uint32_t *accept_bar() const { return sh(b.accept_bar); }
+    SMR_HD SMR_G uint32_t *commit_bar() const { return sh(b.commit_bar); }
+    SMR_HD SMR_G uint32_t *exec_bar() const { return sh(b.exec_bar); }
+    SMR_HD SMR_G uint32_t *snap_bar() const { return sh(b.snap_bar); }
+    SMR_HD SMR_G uint32_t *null_lb() const { return sh(b.null_lb); }
+    SMR_HD SMR_G uint32_t *peer_exec_bar() const { return sh(b.peer_exec_bar); }
+    SMR_HD SMR_G uint64_t *s_bal() const { return sh(b.s_bal); }
+    SMR_HD SMR_G uint32_t *s_val() const { return sh(b.s_val); }
+    SMR_HD SMR_G uint32_t *s_meta() const { return sh(b.s_meta); }
+    SMR_HD SMR_G uint64_t *s_vbal() const { return sh(b.s_vbal); }
+    SMR_HD SMR_G uint32_t *s_vval() const { return sh(b.s_vval); }
+    SMR_HD SMR_G uint64_t *s_pmax() const { return sh(b.s_pmax); }
+    SMR_HD SMR_G uint32_t *s_ltrig() const { return sh(b.s_ltrig); }
+    SMR_HD SMR_G uint32_t *s_lendp() const { return sh(b.s_lendp); }
+    SMR_HD SMR_G uint32_t *s_rtrig() const { return sh(b.s_rtrig); }
+    SMR_HD SMR_G uint32_t *s_rendp() const { return sh(b.s_rendp); }
+    SMR_HD SMR_G uint64_t *ack() const { return sh(b.ack); }
+    SMR_HD SMR_G uint32_t *pr_cnt() const { return sh(b.pr_cnt); }
+    SMR_HD SMR_G uint8_t *pr_dest() const { return sh(b.pr_dest); }
+    SMR_HD SMR_G uint32_t *pr_trig() const { return sh(b.pr_trig); }
+    SMR_HD SMR_G uint32_t *pr_endp() const { return sh(b.pr_endp); }
+    SMR_HD SMR_G uint32_t *pr_abar() const { return sh(b.pr_abar); }
+    SMR_HD SMR_G uint64_t *pr_bal() const { return sh(b.pr_bal); }
+    SMR_HD SMR_G uint64_t *pr_vbal() const { return sh(b.pr_vbal); }
+    SMR_HD SMR_G uint32_t *pr_vval() const { return sh(b.pr_vval); }
+    SMR_HD SMR_G uint64_t *hb_bal() const { return sh(b.hb_bal); }
+    SMR_HD SMR_G uint32_t *hb_commit() const { return sh(b.hb_commit); }
+    SMR_HD SMR_G uint32_t *hb_exec() const { return sh(b.hb_exec); }
+    SMR_HD SMR_G uint32_t *hb_snap() const { return sh(b.hb_snap); }
+    SMR_HD SMR_G unsigned long long *counters() const { return sh(b.counters); }
+    SMR_HD SMR_G unsigned long long *clist() const { return sh(b.clist); }
+    SMR_HD SMR_G unsigned int *clist_n() const { return sh(b.clist_n); }
+    SMR_HD SMR_G uint32_t *ob_cnt(int p) const { return sh(b.ob_cnt[p]); }
+    SMR_HD SMR_G uint32_t *ob_slot(int p) const { return sh(b.ob_slot[p]); }
+    SMR_HD SMR_G uint64_t *ob_bal(int p) const { return sh(b.ob_bal[p]); }
+    SMR_HD SMR_G uint32_t *ob_val(int p) const { return sh(b.ob_val[p]); }
+    SMR_HD SMR_G uint32_t *ob_aux(int p) const { return sh(b.ob_aux[p]); }
+    SMR_HD SMR_G uint32_t *ob_reg(int p) const { return sh(b.ob_reg[p]); }
+    SMR_HD SMR_G uint64_t *ob_rbal(int p) const { return sh(b.ob_rbal[p]); }
+};
+
 struct MpParams {
     uint32_t G, W, Wmask, cap, pcap, win_reserve, clist_cap;
     uint32_t R, quorum, thresh, rspaxos;
     SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
     SMR_G unsigned long long *dbg;  // [64] debug clock stamps
     SMR_G uint8_t *r3_need;         // [R][ceil(G/64)]: this 64-group tile has work left for mp_round_replies
+    // straggler list of the tick (mp_mark_stragglers): groups in a leader change are taken out of the
+    // bulk launches and run one per wavefront on a side stream
+    SMR_G uint8_t *slow;            // [G] 1 = on the list this tick
+    SMR_G uint8_t *slow_ttl;        // [G] ticks left on the list
+    SMR_G uint32_t *slow_list;      // [slow_cap]
+    SMR_G uint32_t *slow_n;         // [2] list length, by tick parity
+    uint32_t slow_cap;
     size_t rep_stride;              // bytes from an array of replica d to the same array of replica d + 1
     MpRep rep[MAXR];
 };

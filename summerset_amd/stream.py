@@ -77,7 +77,7 @@ class MultiPaxosStream:
     follow the new leader."""
 
     def __init__(self, G, R=5, S=1, cap=None, n_ticks=1024, seed=DEFAULT_SEED, drop_p=0.1, timeout_frac=0.01,
-                 timeout_rep=1, hb_every=4, rand_rows=None, max_drop=None):
+                 timeout_rep=1, hb_every=4, rand_rows=None, max_drop=None, timeout_span=None):
         self.G, self.R, self.S, self.n_ticks, self.seed = G, R, S, n_ticks, seed
         self.cap = cap if cap is not None else S + 8
         self.drop_p, self.hb_every, self.timeout_rep, self.max_drop = drop_p, hb_every, timeout_rep, max_drop
@@ -85,7 +85,9 @@ class MultiPaxosStream:
         g = np.arange(G, dtype=np.uint64)
         h = _key(seed, 0x7130, g)
         u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
-        t_at = (_key(seed, 0x7131, g) % np.uint64(max(n_ticks, 1))).astype(np.int64)
+        # the seeded tick of a group's timeout, drawn from [0, timeout_span) (default: the whole run)
+        span = n_ticks if timeout_span is None else timeout_span
+        t_at = (_key(seed, 0x7131, g) % np.uint64(max(span, 1))).astype(np.int64)
         self.timeout_tick = np.where(u < timeout_frac, t_at, -1)
 
     def heartbeat(self, t):

@@ -33,10 +33,11 @@ def _compare(eng, orc, R, tick, check_slots=True):
 
 
 def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, preset, commit_extra=0, seed=None,
-         every=1, timeout_rep=1):
+         every=1, timeout_rep=1, straggler_ticks=0, per_round=False):
     from summerset_amd import MultiPaxosCluster, stream
     cap = W + 4
-    eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * S * 4 + 64)
+    eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * S * 4 + 64,
+                            straggler_ticks=straggler_ticks)
     orc = oracle.MpOracle(G, R, W, cap=cap, commit_extra=commit_extra)
     if preset:
         eng.preset_leader(0)
@@ -54,7 +55,16 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
     for t in range(n_ticks):
         inp = st.tick(t)
         orc.tick(**inp)
-        eng.tick(**_to_dev(inp, cuda))
+        if per_round:                       # the four rounds as separate C-ABI calls
+            d = _to_dev(inp, cuda)
+            eng.round_local(d["timeout_rep"], d["timeout_src"], d["req_target"], d["req_cnt"], d["req_val"])
+            eng.round_deliver()
+            eng.round_replies(d["ackctl"], publish_heartbeat=inp["heartbeat"])
+            if inp["heartbeat"]:
+                eng.round_heartbeat()
+            eng.end_tick()
+        else:
+            eng.tick(**_to_dev(inp, cuda))
         if t % every == 0 or t == n_ticks - 1:
             _compare(eng, orc, R, t)
         # ordered committed-slot list of the (possibly several) leaders
@@ -80,9 +90,24 @@ def test_steady_state_drops_s4(cuda, oracle):
     _run(cuda, oracle, G=1000, R=5, S=4, W=64, n_ticks=60, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
 
 
-def test_leader_change(cuda, oracle):
-    # every group sees a HearTimeout on replica 1 at some tick
-    _run(cuda, oracle, G=512, R=5, S=2, W=64, n_ticks=48, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
+@pytest.mark.parametrize("straggler_ticks", [0, 1, 0xFF])
+def test_leader_change(cuda, oracle, straggler_ticks):
+    # every group sees a HearTimeout on replica 1 at some tick; groups in a leader change run on the
+    # engine's side stream for the default 4 ticks / 1 tick / never -- same results
+    _run(cuda, oracle, G=512, R=5, S=2, W=64, n_ticks=48, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+         straggler_ticks=straggler_ticks)
+
+
+def test_leader_change_round_by_round(cuda, oracle):
+    _run(cuda, oracle, G=300, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+         per_round=True)
+
+
+def test_leader_change_straggler_list_overflow(cuda, oracle):
+    # 4096 groups time out within 6 ticks: more than the side stream's list takes per tick, the rest
+    # must be handled by the bulk launches
+    _run(cuda, oracle, G=4096, R=5, S=2, W=64, n_ticks=12, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+         every=3)
 
 
 def test_natural_bootstrap_noop_slot(cuda, oracle):
@@ -115,3 +140,39 @@ def test_config2_4096_groups(cuda, oracle):
     # BASELINE.json configs[1]: 4096 groups x 5 replicas, 10 % ack loss, 1 % leader timeouts
     _run(cuda, oracle, G=4096, R=5, S=1, W=64, n_ticks=128, drop_p=0.1, timeout_frac=0.01, hb_every=4,
          preset=True, every=8)
+
+
+def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, every=6, log=None):
+    """bench.py's shape (S=32, W=512, pooled tick inputs, <= 2 acks lost per slot) with leader
+    changes: logs of 100+ slots go through the long-outbox / cooperative paths the small shapes
+    above never reach."""
+    from summerset_amd import MultiPaxosCluster, stream
+    R, S, W, H = 5, 32, 512, 4
+    cap = W + 4
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=straggler_ticks)
+    orc = oracle.MpOracle(G, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
+    eng.preset_leader(0)
+    orc.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=0.1, timeout_frac=frac, hb_every=H,
+                                 rand_rows=S + 4, max_drop=2, timeout_span=span)
+    pool = [st.tick(t) for t in range(4)]
+    for t in range(n_ticks):
+        inp = dict(pool[t % 4])
+        inp.update(st.tick_events(t))
+        inp["heartbeat"] = st.heartbeat(t)
+        orc.tick(**inp)
+        if not (inp["timeout_rep"] != 0xFF).any():     # a host knows when no timer fired: no array at all
+            inp["timeout_rep"] = inp["timeout_src"] = None
+        eng.tick(**_to_dev(inp, cuda))
+        if t % every == every - 1 or t == n_ticks - 1:
+            _compare(eng, orc, R, t)
+            if log:
+                log("tick %d ok; rejects %s" % (t, [eng.counters(r)["rejects"] for r in range(R)]))
+    for r in range(R):
+        assert eng.counters(r)["commits"] == orc.total_commits(r)
+    return eng, orc
+
+
+@pytest.mark.parametrize("straggler_ticks", [0, 4])
+def test_bench_shape_leader_changes(cuda, oracle, straggler_ticks):
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, straggler_ticks=straggler_ticks)
