@@ -31,6 +31,7 @@ struct RsArgs {
     uint64_t in_off[RS_MAX_IN];    // byte offset of input shard c inside a codeword
     uint64_t out_off[RS_MAX_OUT];  // byte offset of output shard r inside a codeword
     uint64_t in_valid;             // bytes of a codeword's input that exist (beyond: zero)
+    uint64_t in_bytes;             // bytes readable from in_base (end of the last codeword's input)
     uint64_t shard_len;
     uint64_t n_cw;
     uint32_t nblk;                 // ceil(shard_len / 16)
@@ -57,24 +58,52 @@ __device__ __forceinline__ u32x4 load16(const uint8_t *p) {
 __device__ __forceinline__ void store16(uint8_t *p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
 
 // Load 16 byte-columns of input shard c; bytes at codeword offset >= in_valid
-// are zero (fused from_data padding, rscoding.rs:188-189) and never read.
+// are zero (fused from_data padding, rscoding.rs:188-189).  The block that straddles the end of
+// the valid bytes is still ONE 16-byte load with the excess masked off, as long as the load stays
+// inside the buffer: with shard_len = ceil(L / d) nearly every wavefront holds such a lane, and a
+// byte-wise path there is run (divergently) by the whole wavefront.  Only the last few bytes of
+// the whole buffer take the byte loop.
 __device__ __forceinline__ u32x4 load_cols(const RsArgs &a, const uint8_t *cw, int c, uint64_t c0) {
-    uint64_t o = a.in_off[c] + c0;
+    const uint64_t o = a.in_off[c] + c0;
     if (o + 16 <= a.in_valid) return load16(cw + o);
+    const uint64_t room = (uint64_t)((a.in_base + a.in_bytes) - cw);   // readable bytes from this codeword's start
+    const uint32_t nv = o >= a.in_valid ? 0u : (uint32_t)(a.in_valid - o);   // < 16 bytes of the window exist
     u32x4 v = {0u, 0u, 0u, 0u};
-    uint8_t tmp[16];
+    if (nv == 0) return v;
+    if (o + 16 <= room) {
+        v = load16(cw + o);
+        const uint32_t m0 = nv >= 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u;
+        const uint32_t m1 = nv >= 8 ? 0xFFFFFFFFu : (nv > 4 ? (1u << (8 * (nv - 4))) - 1u : 0u);
+        const uint32_t m2 = nv >= 12 ? 0xFFFFFFFFu : (nv > 8 ? (1u << (8 * (nv - 8))) - 1u : 0u);
+        const uint32_t m3 = nv > 12 ? (1u << (8 * (nv - 12))) - 1u : 0u;
+        v.x &= m0; v.y &= m1; v.z &= m2; v.w &= m3;
+        return v;
+    }
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) tmp[i] = (o + i < a.in_valid) ? cw[o + i] : (uint8_t)0;
-    __builtin_memcpy(&v, tmp, 16);
-    return v;
+    for (int i = 0; i < 16; i++) {
+        const uint32_t byte = ((uint32_t)i < nv) ? cw[o + i] : 0u;
+        if (i < 4) w0 |= byte << (8 * i); else if (i < 8) w1 |= byte << (8 * (i - 4));
+        else if (i < 12) w2 |= byte << (8 * (i - 8)); else w3 |= byte << (8 * (i - 12));
+    }
+    return (u32x4){w0, w1, w2, w3};
 }
 
+// the shard's last block stores its n < 16 bytes as whole dwords plus at most three single bytes
 __device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, uint64_t c0, u32x4 v) {
     uint8_t *p = cw + a.out_off[r] + c0;
     if (c0 + 16 <= a.shard_len) { store16(p, v); return; }
-    uint8_t tmp[16];
-    __builtin_memcpy(tmp, &v, 16);
-    for (uint64_t i = 0; c0 + i < a.shard_len; i++) p[i] = tmp[i];
+    const uint32_t n = (uint32_t)(a.shard_len - c0);
+    const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
+#define SMR_ST_PART(k, w)                                                                  \
+    if (n >= 4 * (k) + 4) __builtin_memcpy(p + 4 * (k), &w, 4);                          \
+    else if (n > 4 * (k)) {                                                                \
+        p[4 * (k)] = (uint8_t)(w);                                                         \
+        if (n > 4 * (k) + 1) p[4 * (k) + 1] = (uint8_t)((w) >> 8);                         \
+        if (n > 4 * (k) + 2) p[4 * (k) + 2] = (uint8_t)((w) >> 16);                        \
+    }
+    SMR_ST_PART(0, w0) SMR_ST_PART(1, w1) SMR_ST_PART(2, w2) SMR_ST_PART(3, w3)
+#undef SMR_ST_PART
 }
 
 template <int NOUT>
@@ -309,6 +338,7 @@ static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_st
     a.in_cw_stride = cw_stride; a.out_cw_stride = par_stride;
     a.shard_len = smr_rs_shard_len(data_len, d);
     a.in_valid = data_len;
+    a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + data_len : 0;   // rows may be packed tightly (cw_stride == data_len)
     a.n_cw = n_cw; a.n_in = d; a.n_out = p;
     if (par_shard_stride < a.shard_len) return fail(SMR_ERR_ARG, "rs: par_shard_stride < shard_len");
     for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)c * a.shard_len;
@@ -369,6 +399,7 @@ int smr_rs_reconstruct(uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_s
     a.in_base = shards_dev; a.out_base = shards_dev;
     a.in_cw_stride = cw_stride; a.out_cw_stride = cw_stride;
     a.shard_len = shard_len; a.in_valid = ~0ull >> 1; a.n_cw = n_cw; a.n_in = d;
+    a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + (uint64_t)(t - 1) * shard_stride + shard_len : 0;
     for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)src[c] * shard_stride;
     int n_out = 0;
     for (int k = 0; k < t; k++) {
@@ -404,6 +435,7 @@ int smr_rs_verify(const uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_
     a.in_base = shards_dev; a.out_base = const_cast<uint8_t *>(shards_dev);
     a.in_cw_stride = cw_stride; a.out_cw_stride = cw_stride;
     a.shard_len = shard_len; a.in_valid = ~0ull >> 1; a.n_cw = n_cw; a.n_in = d; a.n_out = p;
+    a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + (uint64_t)(d + p - 1) * shard_stride + shard_len : 0;
     for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)c * shard_stride;
     for (int r = 0; r < p; r++) {
         a.out_off[r] = (uint64_t)(d + r) * shard_stride;
