@@ -123,9 +123,8 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from summerset_amd import shard
+    rank, local, world = shard.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local)
@@ -140,8 +139,8 @@ def main():
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
     eng.preset_leader(0)
     st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts,
-                                 hb_every=H, rand_rows=S + 4, seed=stream.DEFAULT_SEED + rank, max_drop=2,
-                                 timeout_span=args.timeout_span)
+                                 hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=args.timeout_span,
+                                 group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
     # inputs resident in HBM before the clock starts
     pool = []
     for t in range(args.pool):
@@ -180,12 +179,7 @@ def main():
     commits = c1 - c0
     rej = sum(eng.counters(r)["rejects"] for r in range(R))
     overflow = int(eng.dump(0)["overflow"].sum()) if G <= 4096 else None
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        cc = torch.tensor([commits], dtype=torch.int64, device=dev)
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
-        elapsed, commits = float(tt.item()), int(cc.item())
+    elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)   # MAX over ranks, SUM over ranks
     prof = {}
     for i, name in enumerate(("R1_local", "R2_deliver", "R3_replies", "R4_heartbeat")):
         ms, n = eng.profile_read(i)

@@ -11,4 +11,4 @@ from ._lib import SummersetError, SMR_CTL_IDENTITY, SMR_NO_REPLICA  # noqa: F401
 from .rscoding import RSCodewordBatch, rs_matrix, rs_shard_len  # noqa: F401
 from .multipaxos import MultiPaxosCluster  # noqa: F401
 from .raft import RaftLeaderGroup  # noqa: F401
-from . import stream  # noqa: F401
+from . import shard, stream  # noqa: F401

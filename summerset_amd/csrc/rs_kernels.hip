@@ -13,9 +13,14 @@
 // HBM-bound byte work (no MFMA).  One lane owns 16 consecutive byte columns of
 // one codeword: d 16-byte loads, p 16-byte stores, so a wave moves 1 KiB per
 // memory instruction.  Two arithmetic back ends:
-//   * xtime : bit-sliced multiply-by-2 on 4 packed bytes per VGPR; the matrix
-//             coefficients are wave-uniform kernel arguments, so the per-bit
-//             "accumulate?" branches are scalar branches;
+//   * xtime : bit-sliced multiply-by-2 on 4 packed bytes per VGPR, evaluated per output row as
+//             a Horner scheme over the coefficient BIT PLANES:
+//                 out_r = XOR_b 2^b * (XOR_{c : bit b of M[r][c]} in_c)
+//                       = (..((P_7) * 2 ^ P_6) * 2 ^ ..) * 2 ^ P_0
+//             so a row costs (highest coefficient bit) doublings whatever the number of input
+//             shards (RS(3,2): 3 doublings per 4 bytes of a codeword column instead of 9).  The
+//             coefficients are wave-uniform kernel arguments: "is column c in plane b" is a
+//             scalar branch;
 //   * lut   : 256-entry product tables per coefficient, resident in LDS.
 #include "smr_common.h"
 
@@ -38,6 +43,8 @@ struct RsArgs {
     int n_in, n_out;
     uint8_t coef[RS_MAX_OUT][RS_MAX_IN];
     uint8_t colmask[RS_MAX_IN];    // OR over r of coef[r][c]
+    uint16_t plane[RS_MAX_OUT][8]; // plane[r][b]: bit c set iff bit b of coef[r][c] is set
+    int8_t hib[RS_MAX_OUT];        // highest non-empty plane of row r (-1: all-zero row)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -106,29 +113,45 @@ __device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, 
 #undef SMR_ST_PART
 }
 
-template <int NOUT>
-__global__ __launch_bounds__(256) void rs_matmul_xtime(const RsArgs a) {
-    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t cw_i = t / a.nblk;
-    if (cw_i >= a.n_cw) return;
-    uint64_t c0 = (t - cw_i * a.nblk) * 16;
-    const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
-    u32x4 acc[NOUT];
+// acc[r] = XOR_c coef[r][c] * in_c for 16 byte columns, all input loads issued up front
+template <int NOUT, int NIN>
+__device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t *cw, uint64_t c0, u32x4 (&acc)[NOUT]) {
+    u32x4 x[NIN];
 #pragma unroll
-    for (int r = 0; r < NOUT; r++) acc[r] = (u32x4){0u, 0u, 0u, 0u};
-    for (int c = 0; c < a.n_in; c++) {
-        u32x4 x = load_cols(a, cw, c, c0);
-        uint32_t m = a.colmask[c];          // wave-uniform
+    for (int c = 0; c < NIN; c++) x[c] = (c < a.n_in) ? load_cols(a, cw, c, c0) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if ((m >> b) == 0) break;       // no higher coefficient bits left
+    for (int r = 0; r < NOUT; r++) {
+        u32x4 s = {0u, 0u, 0u, 0u};
+        const int hi = (r < a.n_out) ? a.hib[r] : -1;            // wave-uniform
 #pragma unroll
-            for (int r = 0; r < NOUT; r++)
-                if ((a.coef[r][c] >> b) & 1) acc[r] ^= x;   // scalar branch
-            x.x = gf_xtime4(x.x); x.y = gf_xtime4(x.y);
-            x.z = gf_xtime4(x.z); x.w = gf_xtime4(x.w);
+        for (int b = 7; b >= 0; b--) {
+            if (b > hi) continue;
+            if (b < hi) { s.x = gf_xtime4(s.x); s.y = gf_xtime4(s.y); s.z = gf_xtime4(s.z); s.w = gf_xtime4(s.w); }
+            const uint32_t pl = a.plane[r][b];
+            if (pl == 0) continue;
+#pragma unroll
+            for (int c = 0; c < NIN; c++)
+                if ((pl >> c) & 1u) s ^= x[c];                   // scalar branch
         }
+        acc[r] = s;
     }
+}
+
+// this lane's (codeword, first byte column), from the flat thread index
+__device__ __forceinline__ bool rs_locate(const RsArgs &a, uint64_t &cw_i, uint64_t &c0) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;          // host keeps n_cw * nblk below 2^32
+    const uint32_t q = t / a.nblk;
+    cw_i = q;
+    c0 = (uint64_t)(t - q * a.nblk) * 16;
+    return q < a.n_cw;
+}
+
+template <int NOUT, int NIN>
+__global__ __launch_bounds__(256) void rs_matmul_xtime(const RsArgs a) {
+    uint64_t cw_i, c0;
+    if (!rs_locate(a, cw_i, c0)) return;
+    u32x4 acc[NOUT];
+    rs_product_xtime<NOUT, NIN>(a, a.in_base + cw_i * a.in_cw_stride, c0, acc);
     uint8_t *ocw = a.out_base + cw_i * a.out_cw_stride;
 #pragma unroll
     for (int r = 0; r < NOUT; r++)
@@ -143,10 +166,8 @@ __global__ __launch_bounds__(256) void rs_matmul_lut(const RsArgs a, const uint8
     for (int i = threadIdx.x * 16; i < ntab; i += 256 * 16)
         *reinterpret_cast<u32x4 *>(lds_tab + i) = *reinterpret_cast<const u32x4 *>(tabs + i);
     __syncthreads();
-    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t cw_i = t / a.nblk;
-    if (cw_i >= a.n_cw) return;
-    uint64_t c0 = (t - cw_i * a.nblk) * 16;
+    uint64_t cw_i, c0;
+    if (!rs_locate(a, cw_i, c0)) return;
     const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
     u32x4 acc[NOUT];
 #pragma unroll
@@ -173,29 +194,12 @@ __global__ __launch_bounds__(256) void rs_matmul_lut(const RsArgs a, const uint8
 }
 
 // verify: recompute the n_out shards and compare with what is stored at out_off
-template <int NOUT>
+template <int NOUT, int NIN>
 __global__ __launch_bounds__(256) void rs_verify_xtime(const RsArgs a, uint8_t *ok) {
-    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint64_t cw_i = t / a.nblk;
-    if (cw_i >= a.n_cw) return;
-    uint64_t c0 = (t - cw_i * a.nblk) * 16;
-    const uint8_t *cw = a.in_base + cw_i * a.in_cw_stride;
+    uint64_t cw_i, c0;
+    if (!rs_locate(a, cw_i, c0)) return;
     u32x4 acc[NOUT];
-#pragma unroll
-    for (int r = 0; r < NOUT; r++) acc[r] = (u32x4){0u, 0u, 0u, 0u};
-    for (int c = 0; c < a.n_in; c++) {
-        u32x4 x = load_cols(a, cw, c, c0);
-        uint32_t m = a.colmask[c];
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if ((m >> b) == 0) break;
-#pragma unroll
-            for (int r = 0; r < NOUT; r++)
-                if ((a.coef[r][c] >> b) & 1) acc[r] ^= x;
-            x.x = gf_xtime4(x.x); x.y = gf_xtime4(x.y);
-            x.z = gf_xtime4(x.z); x.w = gf_xtime4(x.w);
-        }
-    }
+    rs_product_xtime<NOUT, NIN>(a, a.in_base + cw_i * a.in_cw_stride, c0, acc);
     bool bad = false;
 #pragma unroll
     for (int r = 0; r < NOUT; r++) {
@@ -283,7 +287,33 @@ static void rs_finish_args(RsArgs &a) {
         for (int r = 0; r < a.n_out; r++) m |= a.coef[r][c];
         a.colmask[c] = (c < a.n_in) ? m : 0;
     }
+    for (int r = 0; r < RS_MAX_OUT; r++) {
+        a.hib[r] = -1;
+        for (int b = 0; b < 8; b++) {
+            uint16_t pl = 0;
+            if (r < a.n_out)
+                for (int c = 0; c < a.n_in; c++) pl |= (uint16_t)(((a.coef[r][c] >> b) & 1) << c);
+            a.plane[r][b] = pl;
+            if (pl) a.hib[r] = (int8_t)b;
+        }
+    }
 }
+
+// kernel instance by (outputs, inputs) bucket: the input columns live in registers
+#define RS_DISPATCH(K, a, ...)                                                                     \
+    do {                                                                                           \
+        const int no_ = (a).n_out <= 2 ? 2 : (a).n_out <= 4 ? 4 : 8;                               \
+        const int ni_ = (a).n_in <= 4 ? 4 : (a).n_in <= 8 ? 8 : 16;                                \
+        if (no_ == 2 && ni_ == 4) hipLaunchKernelGGL((K<2, 4>), __VA_ARGS__);                      \
+        else if (no_ == 2 && ni_ == 8) hipLaunchKernelGGL((K<2, 8>), __VA_ARGS__);                 \
+        else if (no_ == 2) hipLaunchKernelGGL((K<2, 16>), __VA_ARGS__);                            \
+        else if (no_ == 4 && ni_ == 4) hipLaunchKernelGGL((K<4, 4>), __VA_ARGS__);                 \
+        else if (no_ == 4 && ni_ == 8) hipLaunchKernelGGL((K<4, 8>), __VA_ARGS__);                 \
+        else if (no_ == 4) hipLaunchKernelGGL((K<4, 16>), __VA_ARGS__);                            \
+        else if (ni_ == 4) hipLaunchKernelGGL((K<8, 4>), __VA_ARGS__);                             \
+        else if (ni_ == 8) hipLaunchKernelGGL((K<8, 8>), __VA_ARGS__);                             \
+        else hipLaunchKernelGGL((K<8, 16>), __VA_ARGS__);                                          \
+    } while (0)
 
 static uint8_t *g_lut_dev = nullptr;     // scratch for LUT variant tables
 static size_t g_lut_cap = 0;
@@ -294,7 +324,7 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
     uint64_t threads = a.n_cw * a.nblk;
     if (threads == 0) return SMR_OK;
     uint64_t blocks = (threads + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return fail(SMR_ERR_ARG, "rs: too many codewords for one launch");
+    if (blocks > 0xFFFFFFull) return fail(SMR_ERR_ARG, "rs: too many codewords for one launch");
     dim3 grid((unsigned)blocks), block(256);
     if (LUT) {
         const Gf &g = gf();
@@ -315,9 +345,7 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
         else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_lut<4>, grid, block, ntab, st, a, g_lut_dev);
         else hipLaunchKernelGGL(rs_matmul_lut<8>, grid, block, ntab, st, a, g_lut_dev);
     } else {
-        if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_xtime<2>, grid, block, 0, st, a);
-        else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_xtime<4>, grid, block, 0, st, a);
-        else hipLaunchKernelGGL(rs_matmul_xtime<8>, grid, block, 0, st, a);
+        RS_DISPATCH(rs_matmul_xtime, a, grid, block, 0, st, a);
     }
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
@@ -444,9 +472,8 @@ int smr_rs_verify(const uint8_t *shards_dev, uint64_t shard_len, uint64_t shard_
     rs_finish_args(a);
     uint64_t blocks = (a.n_cw * a.nblk + 255) / 256;
     dim3 grid((unsigned)blocks), block(256);
-    if (p <= 2) hipLaunchKernelGGL(rs_verify_xtime<2>, grid, block, 0, st, a, ok_dev);
-    else if (p <= 4) hipLaunchKernelGGL(rs_verify_xtime<4>, grid, block, 0, st, a, ok_dev);
-    else hipLaunchKernelGGL(rs_verify_xtime<8>, grid, block, 0, st, a, ok_dev);
+    if (blocks > 0xFFFFFFull) return fail(SMR_ERR_ARG, "rs: too many codewords for one launch");
+    RS_DISPATCH(rs_verify_xtime, a, grid, block, 0, st, a, ok_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -32,7 +32,7 @@ def _key(seed, *parts):
     return h
 
 
-def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None, max_drop=None):
+def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None, max_drop=None, group_base=0):
     """ackctl[cap][G]: per outbox entry a random peer order + loss mask.
 
     Rows >= n_entries (never reached by a tick that emits <= n_entries
@@ -47,7 +47,7 @@ def random_ackctl(seed, tick, n_entries, G, R, drop_p, cap=None, max_drop=None):
     if n_entries == 0:
         return out
     j = np.arange(n_entries, dtype=np.uint64)[:, None, None]
-    g = np.arange(G, dtype=np.uint64)[None, :, None]
+    g = (np.arange(G, dtype=np.uint64) + np.uint64(group_base))[None, :, None]   # keyed by the GLOBAL group id
     r = np.arange(R, dtype=np.uint64)[None, None, :]
     keys = _key(seed, 0xA11C, tick, j, g, r)
     order = np.argsort(keys, axis=2, kind="stable").astype(np.uint32)        # [n, G, R] replica ids
@@ -77,12 +77,15 @@ class MultiPaxosStream:
     follow the new leader."""
 
     def __init__(self, G, R=5, S=1, cap=None, n_ticks=1024, seed=DEFAULT_SEED, drop_p=0.1, timeout_frac=0.01,
-                 timeout_rep=1, hb_every=4, rand_rows=None, max_drop=None, timeout_span=None):
+                 timeout_rep=1, hb_every=4, rand_rows=None, max_drop=None, timeout_span=None, group_base=0):
         self.G, self.R, self.S, self.n_ticks, self.seed = G, R, S, n_ticks, seed
         self.cap = cap if cap is not None else S + 8
         self.drop_p, self.hb_every, self.timeout_rep, self.max_drop = drop_p, hb_every, timeout_rep, max_drop
         self.rand_rows = min(self.cap, rand_rows if rand_rows is not None else self.cap)
-        g = np.arange(G, dtype=np.uint64)
+        # group_base: this stream covers groups [group_base, group_base + G) of a larger job -- every
+        # value is keyed by the global group id, so a sharded job sees exactly the unsharded stream
+        self.group_base = int(group_base)
+        g = np.arange(G, dtype=np.uint64) + np.uint64(group_base)
         h = _key(seed, 0x7130, g)
         u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
         # the seeded tick of a group's timeout, drawn from [0, timeout_span) (default: the whole run)
@@ -106,11 +109,11 @@ class MultiPaxosStream:
         G, S = self.G, self.S
         out = self.tick_events(t)
         k = np.arange(S, dtype=np.uint64)[:, None]
-        g = np.arange(G, dtype=np.uint64)[None, :]
+        g = (np.arange(G, dtype=np.uint64) + np.uint64(self.group_base))[None, :]
         # opaque non-zero batch tokens (consensus kernels never read payload bytes)
         req_val = ((_key(self.seed, 0x70CE, t, k, g) & np.uint64(0x7FFFFFFF)) | np.uint64(1)).astype(np.uint32)
         out.update(req_cnt=np.full(G, S, np.uint32), req_val=np.ascontiguousarray(req_val),
                    ackctl=random_ackctl(self.seed, t, self.rand_rows, G, self.R, self.drop_p, cap=self.cap,
-                                        max_drop=self.max_drop),
+                                        max_drop=self.max_drop, group_base=self.group_base),
                    heartbeat=self.heartbeat(t))
         return out

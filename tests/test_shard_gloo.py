@@ -1,0 +1,100 @@
+"""The N > 1 path of bench.py on CPU: world_size 2 over gloo.
+
+Layout L1: the job's groups are block-partitioned over the
+ranks, every rank steps its own shard (here: the CPU oracle stands in for the
+HIP engine, which needs a GPU), and the metric is reduced at the end -- MAX of
+the elapsed time, SUM of the committed slots.  The sharded job must be the
+unsharded one: same streams (keyed by global group id), same commits."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G_TOTAL, R, S, W, TICKS = 96, 5, 3, 64, 20
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stream(n_groups, base):
+    from summerset_amd import stream
+    return stream.MultiPaxosStream(n_groups, R, S, cap=W + 4, n_ticks=TICKS, drop_p=0.1, timeout_frac=0.3,
+                                   hb_every=4, max_drop=2, group_base=base)
+
+
+def _run_shard(lo, hi):
+    from oracle import oracle as O
+    m = O.MpOracle(hi - lo, R, W, cap=W + 4, record_commits=False)
+    m.preset_leader(0)
+    st = _stream(hi - lo, lo)
+    for t in range(TICKS):
+        m.tick(**st.tick(t))
+    commits = sum(m.total_commits(r) for r in range(R))
+    return commits, m.dump(0)["commit_bar"].copy(), m.dump(1)["leader"].copy()
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from summerset_amd import shard
+    r, _, w = shard.env_world()
+    dist.init_process_group("gloo", rank=r, world_size=w)
+    lo, hi = shard.group_range(G_TOTAL, w, r)
+    commits, cbar, leader = _run_shard(lo, hi)
+    elapsed, total = shard.reduce_metric(1.0 + r, commits)          # rank 1 is "slower": MAX must pick 2.0
+    np.savez(os.path.join(out_dir, "rank%d.npz" % r), lo=lo, hi=hi, commits=commits, cbar=cbar, leader=leader,
+             elapsed=elapsed, total=total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_group_range_partitions():
+    from summerset_amd import shard
+    for total, world in ((96, 2), (65536, 8), (10, 3), (3, 8), (0, 4)):
+        edges = [shard.group_range(total, world, k) for k in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        sizes = [hi - lo for lo, hi in edges]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.group_range(8, 2, 2)
+    assert shard.reduce_metric(0.5, 7) == (0.5, 7)                   # no process group: identity
+
+
+def test_sharded_stream_is_the_global_stream():
+    full = _stream(G_TOTAL, 0)
+    a, b = _stream(40, 0), _stream(G_TOTAL - 40, 40)
+    assert np.array_equal(full.timeout_tick, np.concatenate([a.timeout_tick, b.timeout_tick]))
+    for t in (0, 7):
+        f, x, y = full.tick(t), a.tick(t), b.tick(t)
+        for k in ("req_val", "ackctl"):
+            assert np.array_equal(f[k], np.concatenate([x[k], y[k]], axis=1)), k
+        for k in ("timeout_rep", "req_target", "req_cnt"):
+            assert np.array_equal(f[k], np.concatenate([x[k], y[k]])), k
+
+
+def test_world_size_2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2))
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 48, 48, 96)
+    # both ranks hold the reduced metric
+    assert float(r0["elapsed"]) == float(r1["elapsed"]) == 2.0
+    assert int(r0["total"]) == int(r1["total"]) == int(r0["commits"]) + int(r1["commits"])
+    # ... and the sharded job is the unsharded one
+    sys.path.insert(0, ROOT)
+    commits, cbar, leader = _run_shard(0, G_TOTAL)
+    assert commits == int(r0["total"]) and commits > 0
+    assert np.array_equal(cbar, np.concatenate([r0["cbar"], r1["cbar"]]))
+    assert np.array_equal(leader, np.concatenate([r0["leader"], r1["leader"]]))
