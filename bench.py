@@ -26,6 +26,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r1d_pmc_traffic.json")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs, gfx950 corrections applied: see the file's "corrections"); None if
+    the file is absent.  bench.py cannot collect PMC counters itself -- they need rocprofv3."""
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)["kernels"][kernel]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -70,10 +82,14 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
         alg = n * 5 * cw.shard_len                       # 5 * ceil(L/3) bytes per codeword
         out[name] = {"ms_per_launch": ms, "payload_GiBps": n * L / 2**30 / (ms * 1e-3),
                      "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    t_rs = pmc_traffic("smr::rs_matmul_xtime<2, 4>")
     res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String)",
            "value": out["xtime"]["payload_GiBps"], "unit": "GiB/s payload",
            "roofline": {"bound": "hbm", "achieved": out["xtime"]["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": out["xtime"]["frac"], "traffic": None},
+                        "unit": "GB/s", "frac": out["xtime"]["frac"], "kernel": "rs_matmul_xtime<2, 4>",
+                        "alg_bytes_per_launch": n * 5 * cw.shard_len, "avg_launch_us": out["xtime"]["ms_per_launch"] * 1e3,
+                        "traffic": (t_rs["hbm_bytes_per_launch"] / 65536 * n) if t_rs else None,
+                        "traffic_note": "PMC bytes of a 65536-codeword launch scaled to this launch's %d codewords" % n},
            "lut_variant_GiBps": out["lut"]["payload_GiBps"]}
     if run_cpu:
         from oracle import oracle as O
@@ -181,12 +197,17 @@ def main():
     overflow = int(eng.dump(0)["overflow"].sum()) if G <= 4096 else None
     elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)   # MAX over ranks, SUM over ranks
     prof = {}
-    for i, name in enumerate(("R1_local", "R2_deliver", "R3_replies", "R4_heartbeat")):
+    for i, name in enumerate(("R1_local", "R2_deliver", "R3_replies", "R4_heartbeat", "mp_quorum_tally")):
         ms, n = eng.profile_read(i)
         prof[name] = {"avg_us": (ms / n * 1e3) if n else None, "launches": int(n)}
+    # the dominant kernel of the path: mp_quorum_tally (accept-ack tally + commit/exec bars of the bulk
+    # groups), timed alone by its own HIP event pair on the launch stream; "R3_replies" is the whole
+    # round (tally + the mp_round_replies launch for everything the closed form left)
+    qt_ms = prof["mp_quorum_tally"]["avg_us"] / 1e3
     r3_ms = prof["R3_replies"]["avg_us"] / 1e3
     alg_bytes = G * (52 * S + 33)                 # bytes per quorum-kernel launch
-    achieved = alg_bytes / (r3_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (qt_ms * 1e-3) / 1e9
+    t_qt = pmc_traffic("smr::mp_quorum_tally<5>") if S == 32 else None
     line = {
         "metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -197,11 +218,16 @@ def main():
                                % (G, S, H, args.drop * 100, args.timeouts * 100),
                    "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "mp_round_replies",
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["R3_replies"]["avg_us"]},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None,
+                     "traffic_source": "profiles/r1d_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "tools/pmc_probe.py, bytes per launch at 65536 groups, S=32)",
+                     "kernel": "mp_quorum_tally",
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["mp_quorum_tally"]["avg_us"],
+                     "whole_round_frac": alg_bytes / (r3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "kernels": prof, "rejected_batches": rej, "overflow_groups": overflow,
         "generic_path_batches": [eng.debug_generic_units(r) for r in range(R)],
-        "decisions_per_sec_quorum_kernel": G * S / (r3_ms * 1e-3),
+        "decisions_per_sec_quorum_kernel": G * S / (qt_ms * 1e-3),
     }
     if rank == 0:
         if not args.no_cpu:

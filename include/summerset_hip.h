@@ -223,7 +223,8 @@ int smr_mp_poll_commits(smr_mp_cluster *c, uint8_t rep, uint32_t *groups_host, u
                         uint64_t cap, uint64_t *n_out);
 
 /* Per-kernel device time accounting (HIP events on `stream` around each
- * round kernel).  which: 0 = R1, 1 = R2, 2 = R3 (quorum kernel), 3 = R4. */
+ * round).  which: 0 = R1, 1 = R2, 2 = R3 (both kernels), 3 = R4,
+ * 4 = mp_quorum_tally alone (the kernel the roofline is quoted on). */
 int smr_mp_profile_enable(smr_mp_cluster *c, int on);
 int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t *launches);
 

@@ -966,8 +966,8 @@ struct smr_mp_cluster {
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     bool profile = false;
     std::vector<ProfEv> evs;
-    double prof_ms[4] = {0, 0, 0, 0};
-    uint64_t prof_n[4] = {0, 0, 0, 0};
+    double prof_ms[5] = {0, 0, 0, 0, 0};
+    uint64_t prof_n[5] = {0, 0, 0, 0, 0};
 };
 
 namespace smr {
@@ -1037,18 +1037,21 @@ static bool stride_ok(const MpParams &P) {
     return true;
 }
 
-static int prof_begin(smr_mp_cluster *c, int which, hipStream_t st) {
+// bracket [begin, end) of launches on `st` with a HIP event pair; idx = which pair to close
+static int prof_begin(smr_mp_cluster *c, int which, hipStream_t st, int &idx) {
+    idx = -1;
     if (!c->profile) return SMR_OK;
     ProfEv e; e.which = which;
     SMR_HIP_TRY(hipEventCreate(&e.a));
     SMR_HIP_TRY(hipEventCreate(&e.b));
     SMR_HIP_TRY(hipEventRecord(e.a, st));
     c->evs.push_back(e);
+    idx = (int)c->evs.size() - 1;
     return SMR_OK;
 }
-static int prof_end(smr_mp_cluster *c, hipStream_t st) {
-    if (!c->profile) return SMR_OK;
-    SMR_HIP_TRY(hipEventRecord(c->evs.back().b, st));
+static int prof_end(smr_mp_cluster *c, int idx, hipStream_t st) {
+    if (idx < 0) return SMR_OK;
+    SMR_HIP_TRY(hipEventRecord(c->evs[(size_t)idx].b, st));
     return SMR_OK;
 }
 
@@ -1195,11 +1198,12 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
                            timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
-    if ((rc = prof_begin(c, 0, st))) return rc;
+    int pi;
+    if ((rc = prof_begin(c, 0, st, pi))) return rc;
     hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
                        timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 0);
     SMR_HIP_TRY(hipGetLastError());
-    if ((rc = prof_end(c, st))) return rc;
+    if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
 }
 
@@ -1213,10 +1217,11 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
         hipLaunchKernelGGL(mp_round_deliver, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
-    if ((rc = prof_begin(c, 1, st))) return rc;
+    int pi;
+    if ((rc = prof_begin(c, 1, st, pi))) return rc;
     hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
-    if ((rc = prof_end(c, st))) return rc;
+    if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
 }
 
@@ -1231,7 +1236,10 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
                            publish_heartbeat, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
-    if ((rc = prof_begin(c, 2, st))) return rc;
+    int pi;
+    if ((rc = prof_begin(c, 2, st, pi))) return rc;
+    int pt;
+    if ((rc = prof_begin(c, 4, st, pt))) return rc;             // the quorum-tally kernel alone
     if (c->cfg.population <= 5)
         hipLaunchKernelGGL(mp_quorum_tally<5>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
                            c->dp, c->par, ackctl_dev, publish_heartbeat);
@@ -1239,10 +1247,11 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
         hipLaunchKernelGGL(mp_quorum_tally<MAXR>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
                            c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
+    if ((rc = prof_end(c, pt, st))) return rc;
     hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
                        publish_heartbeat, 0);
     SMR_HIP_TRY(hipGetLastError());
-    if ((rc = prof_end(c, st))) return rc;
+    if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
 }
 
@@ -1256,10 +1265,11 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
         hipLaunchKernelGGL(mp_round_heartbeat, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
-    if ((rc = prof_begin(c, 3, st))) return rc;
+    int pi;
+    if ((rc = prof_begin(c, 3, st, pi))) return rc;
     hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
-    if ((rc = prof_end(c, st))) return rc;
+    if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
 }
 
@@ -1430,7 +1440,7 @@ int smr_mp_profile_enable(smr_mp_cluster *c, int on) {
 }
 
 int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t *launches) {
-    if (!c || which < 0 || which > 3) return fail(SMR_ERR_ARG, "mp: bad argument");
+    if (!c || which < 0 || which > 4) return fail(SMR_ERR_ARG, "mp: bad argument");
     if (!c->evs.empty()) {
         SMR_HIP_TRY(hipDeviceSynchronize());
         for (auto &e : c->evs) {
