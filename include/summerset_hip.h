@@ -266,6 +266,35 @@ typedef struct {
 int smr_raft_leader_dump(smr_raft_leader *l, const smr_raft_dump_bufs *host_bufs);
 int smr_raft_leader_total_commits(smr_raft_leader *l, uint64_t *out);
 
+/* ------------------------------------------------------------------------
+ * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing
+ * ---------------------------------------------------------------------- */
+typedef struct smr_repnothing smr_repnothing;
+#define SMR_CMD_GET 0   /* Command::Get { key }        (src/server/statemach.rs:21-27) */
+#define SMR_CMD_PUT 1   /* Command::Put { key, value } */
+
+int smr_repnothing_create(smr_repnothing **out);
+void smr_repnothing_destroy(smr_repnothing *h);
+
+/* handle_req_batch (src/protocols/rep_nothing/request.rs:11-37) for one batch
+ * of n >= 1 requests, followed -- LS-1 rule 0 -- by its WAL completion
+ * (durability.rs:10-51) and the execution of its commands in order
+ * (statemach.rs:193-202, execution.rs:10-67); one reply per request is queued.
+ * value / value_len are read for Put entries only. */
+int smr_repnothing_submit_batch(smr_repnothing *h, uint32_t n, const uint64_t *client, const uint64_t *req_id,
+                                const uint8_t *kind, const char *const *key, const uint32_t *key_len,
+                                const char *const *value, const uint32_t *value_len, uint64_t *inst_idx);
+
+/* Next queued ApiReply::normal (execution.rs:46-52): returns 1 and fills the
+ * outputs, 0 when the queue is empty, < 0 on error.  has_value: Get -> value
+ * found; Put -> old_value existed. */
+int smr_repnothing_poll_reply(smr_repnothing *h, uint64_t *client, uint64_t *req_id, uint8_t *kind, int *has_value,
+                              char *value_buf, uint32_t value_cap, uint32_t *value_len);
+
+/* instances logged, WAL offset (framed bincode sizes), commands executed, keys in the state */
+int smr_repnothing_stats(smr_repnothing *h, uint64_t *n_insts, uint64_t *wal_offset, uint64_t *n_execed,
+                         uint64_t *n_keys);
+
 #ifdef __cplusplus
 }
 #endif

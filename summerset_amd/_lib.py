@@ -99,6 +99,12 @@ SYMBOLS = [
     ("smr_raft_leader_handle_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_leader_dump", _i, [_vp, C.POINTER(RaftDumpBufs)]),
     ("smr_raft_leader_total_commits", _i, [_vp, C.POINTER(_u64)]),
+    ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
+    ("smr_repnothing_destroy", None, [_vp]),
+    ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    ("smr_repnothing_poll_reply", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_uint8),
+                                       C.POINTER(C.c_int), _vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("smr_repnothing_stats", _i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
 ]
 
 _lib = None
