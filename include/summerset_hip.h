@@ -229,8 +229,8 @@ int smr_mp_profile_enable(smr_mp_cluster *c, int on);
 int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t *launches);
 
 /* ------------------------------------------------------------------------
- * Raft leader-side match-index quorum over G groups
- * replaces: RaftReplica::handle_req_batch (raft/request.rs:70-90) log append,
+ * Raft replica over G groups (one replica per group)
+ * leader side replaces: RaftReplica::handle_req_batch (raft/request.rs:70-90) log append,
  *           handle_msg_append_entries_reply (raft/messages.rs:222-388)
  * ---------------------------------------------------------------------- */
 typedef struct smr_raft_leader smr_raft_leader;
@@ -265,6 +265,60 @@ typedef struct {
 } smr_raft_dump_bufs;
 int smr_raft_leader_dump(smr_raft_leader *l, const smr_raft_dump_bufs *host_bufs);
 int smr_raft_leader_total_commits(smr_raft_leader *l, uint64_t *out);
+
+/* ---- Raft follower side and elections, same replica object ---------------------------
+ * One replica per group; `l` is the object created above (role Leader at creation;
+ * smr_raft_replica_preset puts every group's replica into another role for a scenario). */
+int smr_raft_replica_preset(smr_raft_leader *l, uint8_t role /* 0 Follower 1 Candidate 2 Leader */, uint8_t leader,
+                            uint64_t term, uint8_t voted_for /* SMR_NO_REPLICA = None */);
+
+/* One AppendEntries message per group (device arrays [G]; entry_term[k][G], k < max_entries).
+ * flags bit0 = a message is present. */
+typedef struct {
+    const uint8_t *flags, *leader;
+    const uint64_t *term;
+    const uint32_t *prev_slot;
+    const uint64_t *prev_term;
+    const uint32_t *n_entries;
+    const uint64_t *entry_term;
+    uint32_t max_entries;
+    const uint32_t *leader_commit, *last_snap;
+} smr_raft_append_entries;
+/* The AppendEntriesReply each group's replica sends (device arrays [G]): flags bit0 = a
+ * reply is sent, bit1 = it carries `conflict`. */
+typedef struct {
+    uint8_t *flags;
+    uint64_t *term;
+    uint32_t *end_slot;
+    uint64_t *conflict_term;
+    uint32_t *conflict_slot;
+} smr_raft_append_reply;
+/* RaftReplica::handle_msg_append_entries (raft/messages.rs:13-218) followed by the WAL
+ * completions of the appended entries (handle_logged_follower_append, durability.rs:97-132). */
+int smr_raft_replica_handle_append_entries(smr_raft_leader *l, const smr_raft_append_entries *msg_dev,
+                                           const smr_raft_append_reply *reply_dev, void *stream);
+
+/* become_a_candidate (raft/leadership.rs:76-142) on HearTimeout events: timeout_src[g] =
+ * replica the timer was about, SMR_NO_REPLICA = no event.  rv_flags bit0 = RequestVote
+ * {rv_term, rv_last_slot, rv_last_term} is broadcast. */
+int smr_raft_replica_become_candidate(smr_raft_leader *l, const uint8_t *timeout_src_dev, uint8_t *rv_flags_dev,
+                                      uint64_t *rv_term_dev, uint32_t *rv_last_slot_dev, uint64_t *rv_last_term_dev,
+                                      void *stream);
+/* handle_msg_request_vote (raft/messages.rs:391-482).  r_flags bit0 = a RequestVoteReply is
+ * sent (the reference sends none when it neither refuses by term nor grants), bit1 = granted. */
+int smr_raft_replica_handle_request_vote(smr_raft_leader *l, const uint8_t *flags_dev, const uint8_t *candidate_dev,
+                                         const uint64_t *term_dev, const uint32_t *last_slot_dev,
+                                         const uint64_t *last_term_dev, uint8_t *r_flags_dev, uint64_t *r_term_dev,
+                                         void *stream);
+/* handle_msg_request_vote_reply (raft/messages.rs:485-510) for one reply per (peer, group):
+ * term[R][G], flags[R][G] bit0 = present, peers taken in order_dev[g] order (ackctl encoding).
+ * At a quorum: become_the_leader (leadership.rs:145-179); hb_prev_slot[p][g] = prev_slot of the
+ * heartbeat it computes for peer p (bcast_heartbeats, :182-218), 0xFFFFFFFF if not elected here. */
+int smr_raft_replica_handle_vote_replies(smr_raft_leader *l, const uint64_t *term_dev, const uint8_t *flags_dev,
+                                         const uint32_t *order_dev, uint32_t *hb_prev_slot_dev, uint8_t *elected_dev,
+                                         void *stream);
+int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
+                                uint32_t *n_trunc_host);
 
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing

@@ -74,6 +74,12 @@ def _declare(L):
     L.orc_raft_dump.argtypes = [vp] + [vp] * 11
     L.orc_raft_total_commits.restype = u64; L.orc_raft_total_commits.argtypes = [vp]
     L.orc_raft_counters.argtypes = [vp, vp]
+    L.orc_raft_preset.argtypes = [vp, u8, u8, u64, u8]
+    L.orc_raft_handle_append_entries.argtypes = [vp] + [vp] * 7 + [u32] + [vp] * 7
+    L.orc_raft_become_candidate.argtypes = [vp] + [vp] * 5
+    L.orc_raft_handle_request_vote.argtypes = [vp] + [vp] * 7
+    L.orc_raft_handle_vote_replies.argtypes = [vp] + [vp] * 6
+    L.orc_raft_dump_votes.argtypes = [vp] + [vp] * 4
 
 
 # ---------------------------------------------------------------- GF / RS ---
@@ -258,3 +264,50 @@ class RaftOracle:
         c = np.zeros(4, np.uint64)
         lib().orc_raft_counters(self.h, _p(c))
         return c
+
+    # ---- follower side and elections ----
+    def preset(self, role, leader, term, voted_for=0xFF):
+        lib().orc_raft_preset(self.h, role, leader, term, voted_for)
+
+    def handle_append_entries(self, flags, leader, term, prev_slot, prev_term, n_entries, entry_term, leader_commit,
+                              last_snap):
+        G = self.G
+        K = entry_term.shape[0]
+        assert entry_term.dtype == np.uint64 and entry_term.shape == (K, G) and entry_term.flags.c_contiguous
+        r = dict(flags=np.zeros(G, np.uint8), term=np.zeros(G, np.uint64), end_slot=np.zeros(G, np.uint32),
+                 conflict_term=np.zeros(G, np.uint64), conflict_slot=np.zeros(G, np.uint32))
+        lib().orc_raft_handle_append_entries(self.h, _p(flags), _p(leader), _p(term), _p(prev_slot), _p(prev_term),
+                                             _p(n_entries), _p(entry_term), K, _p(leader_commit), _p(last_snap),
+                                             _p(r["flags"]), _p(r["term"]), _p(r["end_slot"]), _p(r["conflict_term"]),
+                                             _p(r["conflict_slot"]))
+        return r
+
+    def become_candidate(self, timeout_src):
+        G = self.G
+        r = dict(flags=np.zeros(G, np.uint8), term=np.zeros(G, np.uint64), last_slot=np.zeros(G, np.uint32),
+                 last_term=np.zeros(G, np.uint64))
+        lib().orc_raft_become_candidate(self.h, _p(timeout_src), _p(r["flags"]), _p(r["term"]), _p(r["last_slot"]),
+                                        _p(r["last_term"]))
+        return r
+
+    def handle_request_vote(self, flags, candidate, term, last_slot, last_term):
+        G = self.G
+        r = dict(flags=np.zeros(G, np.uint8), term=np.zeros(G, np.uint64))
+        lib().orc_raft_handle_request_vote(self.h, _p(flags), _p(candidate), _p(term), _p(last_slot), _p(last_term),
+                                           _p(r["flags"]), _p(r["term"]))
+        return r
+
+    def handle_vote_replies(self, term, flags, order=None, granted=None):
+        G, R = self.G, self.R
+        r = dict(hb_prev_slot=np.zeros((R, G), np.uint32), elected=np.zeros(G, np.uint8))
+        granted = np.ones((R, G), np.uint8) if granted is None else granted
+        lib().orc_raft_handle_vote_replies(self.h, _p(term), _p(granted), _p(flags), _p(order), _p(r["hb_prev_slot"]),
+                                           _p(r["elected"]))
+        return r
+
+    def dump_votes(self):
+        G = self.G
+        r = dict(voted_for=np.zeros(G, np.uint8), votes=np.zeros(G, np.uint8), n_exec=np.zeros(G, np.uint64),
+                 n_trunc=np.zeros(G, np.uint64))
+        lib().orc_raft_dump_votes(self.h, _p(r["voted_for"]), _p(r["votes"]), _p(r["n_exec"]), _p(r["n_trunc"]))
+        return r

@@ -1,7 +1,10 @@
 /*
- * oracle/raft_oracle.c -- CPU restatement of the Raft LEADER side hot path of
- * Summerset over G independent groups: log append + AppendEntriesReply
- * handling (match-index quorum -> last_commit, last_snap, next_slot back-off).
+ * oracle/raft_oracle.c -- CPU restatement of the Raft hot path of Summerset over
+ * G independent groups, one replica per group: leader side (log append +
+ * AppendEntriesReply handling: match-index quorum -> last_commit, last_snap,
+ * next_slot back-off), follower side (AppendEntries: consistency check, conflict
+ * hint, truncate, append, commit learning) and the term / vote state machine
+ * (become_a_candidate, RequestVote, RequestVoteReply, become_the_leader).
  *
  * TEST INFRASTRUCTURE ONLY (see oracle/mp_oracle.c header for the rules).
  *
@@ -12,6 +15,14 @@
  *   handle_msg_append_entries_reply     messages.rs:222-388
  *   dummy 0-th entry                    recovery.rs:96-102
  *   become_the_leader init              leadership.rs:145-179, mod.rs:553-562
+ *   handle_msg_append_entries           messages.rs:13-218
+ *   handle_logged_follower_append       durability.rs:97-132
+ *   become_a_candidate                  leadership.rs:76-142
+ *   handle_msg_request_vote             messages.rs:391-482
+ *   handle_msg_request_vote_reply       messages.rs:485-510
+ *   bcast_heartbeats                    leadership.rs:182-218
+ * WAL completions are inline (LS-1 rule 0); timers, the WAL file
+ * offsets and the `external` reply flag of entries are not modelled.
  * Deliberately literal (forward loops over the log tail exactly as written).
  *
  * PARITY STATUS: "parity unpinned" -- the reference has no unit tests or
@@ -28,12 +39,17 @@ enum { ROLE_FOLLOWER = 0, ROLE_CANDIDATE = 1, ROLE_LEADER = 2 };
 typedef struct {
     uint8_t id, population, quorum_cnt, commit_thresh;
     uint8_t role, leader;
+    uint8_t voted_for;        /* NO_LEADER = None */
+    uint8_t votes;            /* votes_granted as a bitmask */
     uint64_t curr_term;
     uint64_t *log_term;       /* term of every entry; index = slot - start_slot */
     uint32_t n_log, cap_log, start_slot;
+    uint32_t ring_W, ring_lo; /* harness guard shared with the engine, whose log is a ring of W entry terms: once the
+                               * log has reached length n, slots below n - W are gone for good (also after a truncation) */
     uint32_t last_commit, last_snap;
     uint32_t next_slot[MAXR], try_next_slot[MAXR], match_slot[MAXR];
     uint64_t n_committed, n_redirect, n_reject, n_sent;
+    uint64_t n_exec, n_trunc; /* follower: entries submitted for execution, log truncations */
 } RaftRep;
 
 typedef struct {
@@ -49,6 +65,7 @@ static void log_push(RaftRep *r, uint64_t term) {
         r->log_term = (uint64_t *)realloc(r->log_term, sizeof(uint64_t) * r->cap_log);
     }
     r->log_term[r->n_log++] = term;
+    if (r->ring_W && log_end(r) > r->ring_W && log_end(r) - r->ring_W > r->ring_lo) r->ring_lo = log_end(r) - r->ring_W;
 }
 
 void *orc_raft_new(uint32_t G, uint8_t R, uint32_t W, uint8_t leader_id, uint64_t term, uint8_t commit_extra) {
@@ -57,11 +74,11 @@ void *orc_raft_new(uint32_t G, uint8_t R, uint32_t W, uint8_t leader_id, uint64_
     cl->reps = (RaftRep *)calloc(G, sizeof(RaftRep));
     for (uint32_t g = 0; g < G; g++) {
         RaftRep *r = &cl->reps[g];
-        r->id = leader_id; r->population = R;
+        r->id = leader_id; r->population = R; r->ring_W = W;
         r->quorum_cnt = (uint8_t)(R / 2 + 1);
         r->commit_thresh = (uint8_t)(r->quorum_cnt + commit_extra);
         log_push(r, 0);                                   /* recovery.rs:96-102 dummy entry */
-        r->role = ROLE_LEADER; r->leader = leader_id; r->curr_term = term;
+        r->role = ROLE_LEADER; r->leader = leader_id; r->curr_term = term; r->voted_for = NO_LEADER;
         for (int p = 0; p < R; p++) {                     /* leadership.rs:159-168 */
             r->next_slot[p] = log_end(r); r->try_next_slot[p] = log_end(r); r->match_slot[p] = 0;
         }
@@ -109,6 +126,8 @@ void orc_raft_leader_append(void *h, const uint32_t *n_new) {
 static int check_term(RaftRep *r, uint8_t peer, uint64_t term) {
     if (term > r->curr_term) {
         r->curr_term = term;
+        r->voted_for = NO_LEADER;                         /* :21-22 */
+        r->votes = 0;
         r->leader = peer;
         if (r->role == ROLE_FOLLOWER) return 0;
         r->role = ROLE_FOLLOWER;
@@ -119,7 +138,8 @@ static int check_term(RaftRep *r, uint8_t peer, uint64_t term) {
 
 static uint64_t term_at(const RaftRep *r, uint32_t slot, uint32_t W, int *ok) {
     /* ring guard shared with the engine: only the last W entries are readable */
-    if (slot < r->start_slot || slot >= log_end(r) || slot + W < log_end(r)) { *ok = 0; return 0; }
+    (void)W;
+    if (slot < r->start_slot || slot >= log_end(r) || slot < r->ring_lo) { *ok = 0; return 0; }
     *ok = 1;
     return r->log_term[slot - r->start_slot];
 }
@@ -192,6 +212,180 @@ void orc_raft_handle_replies(void *h, const uint64_t *reply_term, const uint32_t
     }
 }
 
+/* ---- follower side and elections ---------------------------------------- */
+
+/* test set-up: put every group's replica into a given role / term / leader / vote */
+void orc_raft_preset(void *h, uint8_t role, uint8_t leader, uint64_t term, uint8_t voted_for) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        RaftRep *r = &cl->reps[g];
+        r->role = role; r->leader = leader; r->curr_term = term; r->voted_for = voted_for; r->votes = 0;
+    }
+}
+
+/* messages.rs:13-218, durability.rs:97-132.  Reply: flags bit0 = a reply is sent, bit1 = conflict */
+static void handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t leader, uint64_t term, uint32_t prev_slot,
+                                      uint64_t prev_term, uint32_t n, const uint64_t *ent, size_t ent_stride,
+                                      uint32_t leader_commit, uint32_t last_snap, uint8_t *r_flags, uint64_t *r_term,
+                                      uint32_t *r_end, uint64_t *r_cterm, uint32_t *r_cslot) {
+    *r_flags = 0; *r_term = 0; *r_end = 0; *r_cterm = 0; *r_cslot = 0;
+    if (check_term(r, leader, term) || r->role != ROLE_FOLLOWER) {            /* :32 */
+        if (term == r->curr_term && r->role == ROLE_CANDIDATE) {              /* :33-39 */
+            r->curr_term -= 1;
+            check_term(r, leader, term);
+        } else return;
+    }
+    int ok; uint64_t t_prev = term_at(r, prev_slot, W, &ok);
+    if (n != 0 && (term < r->curr_term || prev_slot < r->start_slot || prev_slot >= log_end(r) || !ok ||
+                   t_prev != prev_term)) {                                    /* :46-51 (!ok: ring guard) */
+        uint64_t conflict_term = (prev_slot >= r->start_slot && prev_slot < log_end(r) && ok) ? t_prev : 0;
+        uint32_t conflict_slot = prev_slot;
+        while (conflict_term > 0 && conflict_slot > r->start_slot) {          /* :60-68 */
+            int ok2; uint64_t t = term_at(r, conflict_slot - 1, W, &ok2);
+            if (ok2 && t == conflict_term) conflict_slot--; else break;
+        }
+        *r_flags = 3; *r_term = r->curr_term; *r_end = prev_slot + n;         /* :70-77 */
+        *r_cterm = conflict_term; *r_cslot = conflict_slot;
+        return;
+    }
+    r->leader = leader;                                                       /* :94 */
+    uint32_t first_new = prev_slot + 1;                                       /* :99-139 */
+    for (uint32_t s = 0; s < n; s++) {
+        uint32_t slot = prev_slot + 1 + s;
+        if (slot >= log_end(r)) { first_new = slot; break; }
+        int ok3; uint64_t t = term_at(r, slot, W, &ok3);
+        if (!ok3 || t != ent[s * ent_stride]) {
+            r->n_log = slot - r->start_slot;                                  /* :136 truncate */
+            r->n_trunc++;
+            first_new = slot;
+            break;
+        }
+    }
+    /* :143-167 entries.drain(first_new - prev_slot - 1 ..): every drained entry is PUSHED -- also
+     * when the loop above never broke (all entries already present): they are appended again */
+    uint32_t skipped = first_new - prev_slot - 1, num_appended = 0;
+    uint32_t slot_e = prev_slot + n;
+    for (uint32_t s = skipped; s < n; s++) {
+        uint32_t slot = (s - skipped) + first_new;
+        log_push(r, ent[s * ent_stride]);
+        num_appended++;
+        /* WAL completion, durability.rs:97-132 */
+        if (!(slot < r->start_slot || r->role != ROLE_FOLLOWER) && slot == slot_e && r->leader != NO_LEADER) {
+            *r_flags = 1; *r_term = r->curr_term; *r_end = slot_e;
+        }
+    }
+    if (num_appended == 0) { *r_flags = 1; *r_term = r->curr_term; *r_end = first_new - 1; }   /* :172-181 */
+    if (leader_commit > r->last_commit) {                                     /* :184-208; entries.len() is now `skipped` */
+        uint32_t new_commit = leader_commit < prev_slot + skipped ? leader_commit : prev_slot + skipped;
+        if (new_commit > log_end(r) - 1) new_commit = log_end(r) - 1;
+        if (new_commit > r->last_commit) r->n_exec += new_commit - r->last_commit;
+        r->last_commit = new_commit;
+    }
+    if (last_snap > r->last_snap) r->last_snap = last_snap;                   /* :211-213 */
+}
+
+void orc_raft_handle_append_entries(void *h, const uint8_t *flags, const uint8_t *leader, const uint64_t *term,
+                                    const uint32_t *prev_slot, const uint64_t *prev_term, const uint32_t *n_entries,
+                                    const uint64_t *entry_term, uint32_t K, const uint32_t *leader_commit,
+                                    const uint32_t *last_snap, uint8_t *r_flags, uint64_t *r_term, uint32_t *r_end,
+                                    uint64_t *r_cterm, uint32_t *r_cslot) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        r_flags[g] = 0; r_term[g] = 0; r_end[g] = 0; r_cterm[g] = 0; r_cslot[g] = 0;
+        if (!(flags[g] & 1)) continue;
+        uint32_t n = n_entries[g] < K ? n_entries[g] : K;
+        handle_msg_append_entries(&cl->reps[g], cl->W, leader[g], term[g], prev_slot[g], prev_term[g], n,
+                                  entry_term + g, G, leader_commit[g], last_snap[g], &r_flags[g], &r_term[g],
+                                  &r_end[g], &r_cterm[g], &r_cslot[g]);
+    }
+}
+
+/* leadership.rs:76-142; rv_flags bit0 = RequestVote broadcast */
+void orc_raft_become_candidate(void *h, const uint8_t *timeout_src, uint8_t *rv_flags, uint64_t *rv_term,
+                               uint32_t *rv_last_slot, uint64_t *rv_last_term) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        RaftRep *r = &cl->reps[g];
+        rv_flags[g] = 0; rv_term[g] = 0; rv_last_slot[g] = 0; rv_last_term[g] = 0;
+        if (timeout_src[g] == NO_LEADER) continue;
+        if (r->role != ROLE_FOLLOWER || (r->leader != NO_LEADER && r->leader != timeout_src[g])) continue;   /* :80-85 */
+        r->role = ROLE_CANDIDATE;
+        r->curr_term += 1;                                                    /* :90-92 */
+        r->voted_for = r->id;
+        r->votes = (uint8_t)(1u << r->id);
+        uint32_t last_slot = log_end(r) - 1;                                  /* :99-101 */
+        int ok; uint64_t lt = term_at(r, last_slot, cl->W, &ok);
+        rv_flags[g] = 1; rv_term[g] = r->curr_term; rv_last_slot[g] = last_slot; rv_last_term[g] = ok ? lt : 0;
+    }
+}
+
+/* messages.rs:391-482; r_flags bit0 = a reply is sent, bit1 = granted */
+void orc_raft_handle_request_vote(void *h, const uint8_t *flags, const uint8_t *cand, const uint64_t *term,
+                                  const uint32_t *last_slot, const uint64_t *last_term, uint8_t *r_flags,
+                                  uint64_t *r_term) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        RaftRep *r = &cl->reps[g];
+        r_flags[g] = 0; r_term[g] = 0;
+        if (!(flags[g] & 1)) continue;
+        check_term(r, cand[g], term[g]);                                      /* :405 */
+        if (term[g] < r->curr_term) { r_flags[g] = 1; r_term[g] = r->curr_term; continue; }   /* :408-422 */
+        if (r->voted_for == NO_LEADER || r->voted_for == cand[g]) {           /* :427 */
+            int ok; uint64_t my_last = term_at(r, log_end(r) - 1, cl->W, &ok);
+            if (last_term[g] >= my_last || (last_term[g] == r->curr_term && last_slot[g] + 1 >= log_end(r))) {   /* :428-430 */
+                r_flags[g] = 3; r_term[g] = r->curr_term;
+                r->voted_for = cand[g];                                       /* :450 */
+            }
+        }
+    }
+}
+
+/* messages.rs:485-510 + leadership.rs:145-218.  hb_prev[p][g] = prev_slot of the heartbeat
+ * computed for peer p when the replica gets elected in this call (0xFFFFFFFF otherwise); the
+ * reference broadcasts EACH of them to ALL peers (bcast_msg inside the per-peer loop). */
+void orc_raft_handle_vote_replies(void *h, const uint64_t *term, const uint8_t *granted, const uint8_t *flags,
+                                  const uint32_t *order, uint32_t *hb_prev, uint8_t *elected) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    (void)granted;                                                            /* :503 inserts the peer whatever it answered */
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        elected[g] = 0;
+        for (int p = 0; p < cl->R; p++) hb_prev[(size_t)p * G + g] = 0xFFFFFFFFu;
+        uint32_t ctl = order ? order[g] : CTL_IDENTITY;
+        for (int oi = 0; oi < cl->R; oi++) {
+            int p = (int)ctl_order(ctl, oi);
+            if (p == r->id || p >= cl->R) continue;
+            size_t o = (size_t)p * G + g;
+            if (!(flags[o] & 1)) continue;
+            if (check_term(r, (uint8_t)p, term[o]) || r->role != ROLE_CANDIDATE) continue;   /* :498-500 */
+            r->votes |= (uint8_t)(1u << p);                                   /* :503 */
+            if (__builtin_popcount(r->votes) >= r->quorum_cnt) {              /* :506-508 */
+                r->role = ROLE_LEADER;                                        /* leadership.rs:149 */
+                for (int q = 0; q < cl->R; q++) {                             /* :156 bcast_heartbeats, :186-196 */
+                    if (q == r->id) continue;
+                    uint32_t a = r->try_next_slot[q] - 1, b = log_end(r) - 1;
+                    hb_prev[(size_t)q * G + g] = a < b ? a : b;
+                }
+                for (int q = 0; q < cl->R; q++) {                             /* :159-168 */
+                    r->next_slot[q] = log_end(r); r->try_next_slot[q] = log_end(r); r->match_slot[q] = 0;
+                }
+                elected[g] = 1;
+            }
+        }
+    }
+}
+
+void orc_raft_dump_votes(void *h, uint8_t *voted_for, uint8_t *votes, uint64_t *n_exec, uint64_t *n_trunc) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        voted_for[g] = cl->reps[g].voted_for; votes[g] = cl->reps[g].votes;
+        if (n_exec) n_exec[g] = cl->reps[g].n_exec;
+        if (n_trunc) n_trunc[g] = cl->reps[g].n_trunc;
+    }
+}
+
 void orc_raft_dump(void *h, uint8_t *role, uint64_t *curr_term, uint32_t *log_len, uint32_t *last_commit,
                    uint32_t *last_snap, uint32_t *next_slot, uint32_t *try_next_slot, uint32_t *match_slot,
                    uint64_t *entry_term, uint8_t *leader, uint32_t *start_slot) {
@@ -209,7 +403,7 @@ void orc_raft_dump(void *h, uint8_t *role, uint64_t *curr_term, uint32_t *log_le
             match_slot[o] = p == r->id ? 0 : r->match_slot[p];
         }
         for (uint32_t w = 0; w < W; w++) entry_term[(size_t)w * G + g] = 0;
-        uint32_t lo = log_end(r) > W ? log_end(r) - W : r->start_slot;
+        uint32_t lo = r->ring_lo > r->start_slot ? r->ring_lo : r->start_slot;
         for (uint32_t s = lo; s < log_end(r); s++) entry_term[(size_t)(s % W) * G + g] = r->log_term[s - r->start_slot];
     }
 }

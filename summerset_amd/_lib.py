@@ -65,6 +65,17 @@ class RaftDumpBufs(C.Structure):
 
 # every symbol include/summerset_hip.h declares: (name, restype, argtypes)
 _vp, _u8, _u32, _u64, _i = C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.c_int
+class RaftAppendEntries(C.Structure):
+    _fields_ = [("flags", C.c_void_p), ("leader", C.c_void_p), ("term", C.c_void_p), ("prev_slot", C.c_void_p),
+                ("prev_term", C.c_void_p), ("n_entries", C.c_void_p), ("entry_term", C.c_void_p),
+                ("max_entries", C.c_uint32), ("leader_commit", C.c_void_p), ("last_snap", C.c_void_p)]
+
+
+class RaftAppendReply(C.Structure):
+    _fields_ = [("flags", C.c_void_p), ("term", C.c_void_p), ("end_slot", C.c_void_p), ("conflict_term", C.c_void_p),
+                ("conflict_slot", C.c_void_p)]
+
+
 SYMBOLS = [
     ("smr_last_error", C.c_char_p, []),
     ("smr_device_count", _i, []),
@@ -99,6 +110,12 @@ SYMBOLS = [
     ("smr_raft_leader_handle_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_leader_dump", _i, [_vp, C.POINTER(RaftDumpBufs)]),
     ("smr_raft_leader_total_commits", _i, [_vp, C.POINTER(_u64)]),
+    ("smr_raft_replica_preset", _i, [_vp, _u8, _u8, _u64, _u8]),
+    ("smr_raft_replica_handle_append_entries", _i, [_vp, C.POINTER(RaftAppendEntries), C.POINTER(RaftAppendReply), _vp]),
+    ("smr_raft_replica_become_candidate", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_replica_handle_request_vote", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_replica_handle_vote_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_replica_dump_votes", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

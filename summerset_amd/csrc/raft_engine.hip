@@ -1,5 +1,9 @@
-// Raft leader-side hot path over G groups (lane = group): log append and the
-// AppendEntriesReply match-index quorum kernel.
+// Raft hot path over G groups (lane = group, one replica per group): leader side (log
+// append and the AppendEntriesReply match-index quorum kernel), follower side
+// (handle_msg_append_entries, raft/messages.rs:13-218 + durability.rs:97-132) and the
+// term / vote state machine (become_a_candidate leadership.rs:76-142, RequestVote
+// messages.rs:391-482, RequestVoteReply messages.rs:485-510, become_the_leader
+// leadership.rs:145-218).  WAL completions are inline (LS-1 rule 0).
 //
 // Stands in for RaftReplica::{handle_req_batch (raft/request.rs:10-91),
 // handle_logged_leader_append (raft/durability.rs:12-94, try_next_slot),
@@ -17,13 +21,17 @@
 namespace smr {
 
 constexpr int RMAX = SMR_MAX_REPLICAS;
+constexpr uint8_t NO_REP = 0xFF;
 enum { ROLE_FOLLOWER = 0, ROLE_CANDIDATE = 1, ROLE_LEADER = 2 };
 
 struct RaftView {
     uint32_t G, W, Wmask, R, me, thresh;
     uint8_t *role, *leader;
+    uint8_t *voted_for, *votes;                          // Option<ReplicaId> (0xFF = None); votes_granted bitmask
+    uint32_t *n_exec, *n_trunc;                          // follower: entries submitted for execution, truncations
     uint64_t *curr_term;
     uint32_t *log_len, *start_slot, *last_commit, *last_snap;
+    uint32_t *ring_lo;                                  // lowest slot whose term is still in the W-entry ring
     uint32_t *next_slot, *try_next_slot, *match_slot;   // [R][G]
     uint64_t *entry_term;                               // [W][G]
     unsigned long long *counters;                       // commits, redirects, rejects, entries sent
@@ -67,6 +75,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                     }
                 }
                 v.log_len[g] = len;
+                if (len > v.W && len - v.W > v.ring_lo[g]) v.ring_lo[g] = len - v.W;
 #pragma unroll
                 for (int p = 0; p < RMAX; p++)
                     if ((uint32_t)p < v.R && (uint32_t)p != v.me) v.try_next_slot[(size_t)p * v.G + g] = tn[p];
@@ -87,7 +96,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
     if (g < v.G) {
         uint32_t role = v.role[g], leader = v.leader[g];
         uint64_t term = v.curr_term[g];
-        const uint32_t len = v.log_len[g], start = v.start_slot[g];
+        const uint32_t len = v.log_len[g], start = v.start_slot[g], rlo = v.ring_lo[g];
         uint32_t commit = v.last_commit[g], snap = v.last_snap[g];
         const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
         const uint64_t o_term = term;
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
             bool stepped = false;
             if (rt > term) {
                 term = rt; leader = p;
+                v.voted_for[g] = NO_REP; v.votes[g] = 0;        // :21-22
                 if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
             }
             if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 }
                 uint32_t hi = m < len - 1 ? m : len - 1;
                 for (uint32_t s = hi; s > commit; s--) {
-                    if (s + v.W < len) break;                   // beyond the term ring
+                    if (s < rlo) break;                         // beyond the term ring
                     if (v.entry_term[(size_t)(s & v.Wmask) * v.G + g] == term) {
                         c[0] += s - commit;                     // :278-293 exec submissions
                         commit = s;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                     const uint64_t ct = conflict_term ? conflict_term[o] : 0;
                     const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
                     for (;;) {                                  // :320-330
-                        bool readable = nxp >= start && nxp < len && nxp + v.W >= len;
+                        bool readable = nxp >= start && nxp < len && nxp >= rlo;
                         if (!(nxp > start && readable && nxp >= cs && nxp > 1)) break;
                         if (v.entry_term[(size_t)(nxp & v.Wmask) * v.G + g] != ct) break;
                         nxp -= 1;
@@ -198,6 +208,214 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
     raft_flush(v, c);
 }
 
+// ---- follower side and elections ------------------------------------------------------------
+// scalar replica state of one group in registers
+struct RaftLane {
+    const RaftView &v;
+    const uint32_t g;
+    uint32_t role, leader, voted_for, votes, len, start, commit, snap, rlo;
+    uint64_t term;
+    uint32_t o_role, o_leader, o_voted, o_votes, o_len, o_commit, o_snap, o_rlo;
+    uint64_t o_term;
+    __device__ __forceinline__ RaftLane(const RaftView &v_, uint32_t g_) : v(v_), g(g_) {
+        o_role = role = v.role[g]; o_leader = leader = v.leader[g]; o_voted = voted_for = v.voted_for[g];
+        o_votes = votes = v.votes[g]; o_len = len = v.log_len[g]; start = v.start_slot[g];
+        o_commit = commit = v.last_commit[g]; o_snap = snap = v.last_snap[g]; o_term = term = v.curr_term[g];
+        o_rlo = rlo = v.ring_lo[g];
+    }
+    __device__ __forceinline__ void store() {
+        if (role != o_role) v.role[g] = (uint8_t)role;
+        if (leader != o_leader) v.leader[g] = (uint8_t)leader;
+        if (voted_for != o_voted) v.voted_for[g] = (uint8_t)voted_for;
+        if (votes != o_votes) v.votes[g] = (uint8_t)votes;
+        if (len != o_len) v.log_len[g] = len;
+        if (commit != o_commit) v.last_commit[g] = commit;
+        if (snap != o_snap) v.last_snap[g] = snap;
+        if (term != o_term) v.curr_term[g] = term;
+        if (rlo != o_rlo) v.ring_lo[g] = rlo;
+    }
+    // leadership.rs:16-72; true iff the role was not Follower and now is
+    __device__ __forceinline__ bool check_term(uint32_t peer, uint64_t t) {
+        if (t <= term) return false;
+        term = t; voted_for = NO_REP; votes = 0; leader = peer;
+        if (role == ROLE_FOLLOWER) return false;
+        role = ROLE_FOLLOWER;
+        return true;
+    }
+    // entry term if the slot is in the log and still in the W-entry ring (the harness guard)
+    __device__ __forceinline__ bool term_at(uint32_t slot, uint64_t &t) const {
+        if (slot < start || slot >= len || slot < rlo) return false;
+        t = v.entry_term[(size_t)(slot & v.Wmask) * v.G + g];
+        return true;
+    }
+};
+
+// messages.rs:13-218 + durability.rs:97-132
+__global__ __launch_bounds__(256) void raft_append_entries_kernel(
+    const RaftView v, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ leader_id,
+    const uint64_t *__restrict__ term, const uint32_t *__restrict__ prev_slot, const uint64_t *__restrict__ prev_term,
+    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, uint32_t K,
+    const uint32_t *__restrict__ leader_commit, const uint32_t *__restrict__ last_snap, uint8_t *__restrict__ r_flags,
+    uint64_t *__restrict__ r_term, uint32_t *__restrict__ r_end, uint64_t *__restrict__ r_cterm,
+    uint32_t *__restrict__ r_cslot) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    uint8_t of = 0; uint64_t ot = 0, oct = 0; uint32_t oe = 0, ocs = 0;
+    if (flags[g] & 1) {
+        RaftLane L(v, g);
+        const uint32_t ld = leader_id[g], ps = prev_slot[g];
+        const uint64_t tm = term[g], pt = prev_term[g];
+        const uint32_t n = n_entries[g] < K ? n_entries[g] : K;
+        bool go = true;
+        if (L.check_term(ld, tm) || L.role != ROLE_FOLLOWER) {                  // :32
+            if (tm == L.term && L.role == ROLE_CANDIDATE) { L.term -= 1; L.check_term(ld, tm); }   // :33-39
+            else go = false;
+        }
+        if (go) {
+            uint64_t t_prev = 0;
+            const bool ok = L.term_at(ps, t_prev);
+            if (n != 0 && (tm < L.term || ps < L.start || ps >= L.len || !ok || t_prev != pt)) {   // :46-51
+                const uint64_t ct = (ps >= L.start && ps < L.len && ok) ? t_prev : 0;
+                uint32_t cs = ps;
+                while (ct > 0 && cs > L.start) {                                // :60-68
+                    uint64_t t;
+                    if (L.term_at(cs - 1, t) && t == ct) cs--; else break;
+                }
+                of = 3; ot = L.term; oe = ps + n; oct = ct; ocs = cs;            // :70-77
+            } else {
+                L.leader = ld;                                                  // :94
+                uint32_t first_new = ps + 1;                                    // :99-139
+                for (uint32_t s = 0; s < n; s++) {
+                    const uint32_t slot = ps + 1 + s;
+                    if (slot >= L.len) { first_new = slot; break; }
+                    uint64_t t;
+                    if (!L.term_at(slot, t) || t != entry_term[(size_t)s * v.G + g]) {
+                        L.len = slot;                                           // :136 truncate
+                        v.n_trunc[g] += 1;
+                        first_new = slot;
+                        break;
+                    }
+                }
+                // :143-167: everything from first_new on is PUSHED (also when nothing differed)
+                const uint32_t skipped = first_new - ps - 1, slot_e = ps + n;
+                uint32_t appended = 0;
+                for (uint32_t s = skipped; s < n; s++) {
+                    const uint32_t slot = (s - skipped) + first_new;
+                    v.entry_term[(size_t)(L.len & v.Wmask) * v.G + g] = entry_term[(size_t)s * v.G + g];
+                    L.len++;
+                    if (L.len > v.W && L.len - v.W > L.rlo) L.rlo = L.len - v.W;
+                    appended++;
+                    if (slot >= L.start && L.role == ROLE_FOLLOWER && slot == slot_e && L.leader != NO_REP) {   // durability.rs:104-128
+                        of = 1; ot = L.term; oe = slot_e;
+                    }
+                }
+                if (appended == 0) { of = 1; ot = L.term; oe = first_new - 1; }  // :172-181
+                const uint32_t lc = leader_commit[g];
+                if (lc > L.commit) {                                            // :184-208 (entries.len() == skipped by now)
+                    uint32_t nc = lc < ps + skipped ? lc : ps + skipped;
+                    if (nc > L.len - 1) nc = L.len - 1;
+                    if (nc > L.commit) v.n_exec[g] += nc - L.commit;
+                    L.commit = nc;
+                }
+                const uint32_t ls = last_snap[g];
+                if (ls > L.snap) L.snap = ls;                                   // :211-213
+            }
+        }
+        L.store();
+    }
+    r_flags[g] = of; r_term[g] = ot; r_end[g] = oe; r_cterm[g] = oct; r_cslot[g] = ocs;
+}
+
+// leadership.rs:76-142
+__global__ __launch_bounds__(256) void raft_become_candidate_kernel(const RaftView v, const uint8_t *__restrict__ timeout_src,
+                                                                    uint8_t *__restrict__ rv_flags, uint64_t *__restrict__ rv_term,
+                                                                    uint32_t *__restrict__ rv_last_slot,
+                                                                    uint64_t *__restrict__ rv_last_term) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    uint8_t of = 0; uint64_t ot = 0, olt = 0; uint32_t ols = 0;
+    const uint32_t src = timeout_src[g];
+    if (src != NO_REP) {
+        RaftLane L(v, g);
+        if (L.role == ROLE_FOLLOWER && !(L.leader != NO_REP && L.leader != src)) {   // :80-85
+            L.role = ROLE_CANDIDATE;
+            L.term += 1; L.voted_for = v.me; L.votes = 1u << v.me;              // :90-92
+            ols = L.len - 1;                                                    // :99-101
+            uint64_t t = 0;
+            olt = L.term_at(ols, t) ? t : 0;
+            of = 1; ot = L.term;
+            L.store();
+        }
+    }
+    rv_flags[g] = of; rv_term[g] = ot; rv_last_slot[g] = ols; rv_last_term[g] = olt;
+}
+
+// messages.rs:391-482
+__global__ __launch_bounds__(256) void raft_request_vote_kernel(const RaftView v, const uint8_t *__restrict__ flags,
+                                                                const uint8_t *__restrict__ cand, const uint64_t *__restrict__ term,
+                                                                const uint32_t *__restrict__ last_slot,
+                                                                const uint64_t *__restrict__ last_term,
+                                                                uint8_t *__restrict__ r_flags, uint64_t *__restrict__ r_term) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    uint8_t of = 0; uint64_t ot = 0;
+    if (flags[g] & 1) {
+        RaftLane L(v, g);
+        const uint32_t c = cand[g];
+        const uint64_t tm = term[g];
+        L.check_term(c, tm);                                                    // :405
+        if (tm < L.term) { of = 1; ot = L.term; }                               // :408-422
+        else if (L.voted_for == NO_REP || L.voted_for == c) {                   // :427
+            uint64_t my_last = 0;
+            L.term_at(L.len - 1, my_last);
+            const uint64_t lt = last_term[g];
+            if (lt >= my_last || (lt == L.term && last_slot[g] + 1 >= L.len)) { // :428-430
+                of = 3; ot = L.term;
+                L.voted_for = c;                                                // :450
+            }
+        }
+        L.store();
+    }
+    r_flags[g] = of; r_term[g] = ot;
+}
+
+// messages.rs:485-510 + leadership.rs:145-218
+__global__ __launch_bounds__(256) void raft_vote_replies_kernel(const RaftView v, const uint64_t *__restrict__ term,
+                                                                const uint8_t *__restrict__ flags,
+                                                                const uint32_t *__restrict__ order,
+                                                                uint32_t *__restrict__ hb_prev, uint8_t *__restrict__ elected) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    RaftLane L(v, g);
+    uint8_t el = 0;
+    for (uint32_t p = 0; p < v.R; p++) hb_prev[(size_t)p * v.G + g] = 0xFFFFFFFFu;
+    const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+    const uint32_t quorum = v.R / 2 + 1;
+    for (uint32_t oi = 0; oi < v.R; oi++) {
+        const uint32_t p = (ctl >> (3 * oi)) & 7u;
+        if (p == v.me || p >= v.R) continue;
+        const size_t o = (size_t)p * v.G + g;
+        if (!(flags[o] & 1)) continue;
+        if (L.check_term(p, term[o]) || L.role != ROLE_CANDIDATE) continue;     // :498-500
+        L.votes |= 1u << p;                                                     // :503 (whatever `granted` says)
+        if ((uint32_t)__popc(L.votes) >= quorum) {                              // :506-508
+            L.role = ROLE_LEADER;                                               // leadership.rs:149
+            for (uint32_t q = 0; q < v.R; q++) {                                // :156 -> :186-196, before the re-init below
+                if (q == v.me) continue;
+                const uint32_t a = v.try_next_slot[(size_t)q * v.G + g] - 1, b = L.len - 1;
+                hb_prev[(size_t)q * v.G + g] = a < b ? a : b;
+            }
+            for (uint32_t q = 0; q < v.R; q++) {                                // :159-168
+                const size_t oq = (size_t)q * v.G + g;
+                v.next_slot[oq] = L.len; v.try_next_slot[oq] = L.len; v.match_slot[oq] = 0;
+            }
+            el = 1;
+        }
+    }
+    L.store();
+    elected[g] = el;
+}
+
 }  // namespace smr
 
 using namespace smr;
@@ -219,8 +437,9 @@ static void raft_layout(smr_raft_leader *l, bool dry) {
     RaftView &v = l->v;
     const size_t G = l->cfg.n_groups, W = l->cfg.window, R = l->cfg.population;
     rcarve(a, v.role, G, dry); rcarve(a, v.leader, G, dry); rcarve(a, v.curr_term, G, dry);
+    rcarve(a, v.voted_for, G, dry); rcarve(a, v.votes, G, dry); rcarve(a, v.n_exec, G, dry); rcarve(a, v.n_trunc, G, dry);
     rcarve(a, v.log_len, G, dry); rcarve(a, v.start_slot, G, dry); rcarve(a, v.last_commit, G, dry);
-    rcarve(a, v.last_snap, G, dry);
+    rcarve(a, v.last_snap, G, dry); rcarve(a, v.ring_lo, G, dry);
     rcarve(a, v.next_slot, R * G, dry); rcarve(a, v.try_next_slot, R * G, dry); rcarve(a, v.match_slot, R * G, dry);
     rcarve(a, v.entry_term, W * G, dry);
     rcarve(a, v.counters, 4, dry);
@@ -256,6 +475,7 @@ int smr_raft_leader_create(const smr_raft_cfg *cfg, smr_raft_leader **out) {
     std::vector<uint32_t> one(G * v.R, 1u);
     if (e == hipSuccess) e = hipMemset(v.role, ROLE_LEADER, G);
     if (e == hipSuccess) e = hipMemset(v.leader, cfg->leader_id, G);
+    if (e == hipSuccess) e = hipMemset(v.voted_for, 0xFF, G);
     if (e == hipSuccess) e = hipMemcpy(v.curr_term, t.data(), G * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v.log_len, one.data(), G * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v.next_slot, one.data(), G * v.R * 4, hipMemcpyHostToDevice);
@@ -303,13 +523,15 @@ int smr_raft_leader_dump(smr_raft_leader *l, const smr_raft_dump_bufs *hb) {
     D2H(hb->next_slot, v.next_slot, R * G * 4); D2H(hb->try_next_slot, v.try_next_slot, R * G * 4);
     D2H(hb->match_slot, v.match_slot, R * G * 4);
     std::vector<uint64_t> et(W * G);
+    std::vector<uint32_t> rlo(G);
     D2H(et.data(), v.entry_term, W * G * 8);
+    D2H(rlo.data(), v.ring_lo, G * 4);
 #undef D2H
     for (size_t g = 0; g < G; g++) {
         hb->next_slot[(size_t)v.me * G + g] = 0; hb->try_next_slot[(size_t)v.me * G + g] = 0;
         hb->match_slot[(size_t)v.me * G + g] = 0;
         for (size_t w = 0; w < W; w++) hb->entry_term[w * G + g] = 0;
-        uint32_t len = hb->log_len[g], lo = len > W ? len - (uint32_t)W : hb->start_slot[g];
+        uint32_t len = hb->log_len[g], lo = rlo[g] > hb->start_slot[g] ? rlo[g] : hb->start_slot[g];
         for (uint32_t s = lo; s < len; s++) hb->entry_term[(size_t)(s & (W - 1)) * G + g] = et[(size_t)(s & (W - 1)) * G + g];
     }
     return SMR_OK;
@@ -321,6 +543,78 @@ int smr_raft_leader_total_commits(smr_raft_leader *l, uint64_t *out) {
     unsigned long long h[4];
     SMR_HIP_TRY(hipMemcpy(h, l->v.counters, sizeof(h), hipMemcpyDeviceToHost));
     *out = h[0];
+    return SMR_OK;
+}
+
+int smr_raft_replica_preset(smr_raft_leader *l, uint8_t role, uint8_t leader, uint64_t term, uint8_t voted_for) {
+    if (!l || role > ROLE_LEADER) return fail(SMR_ERR_ARG, "raft: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const size_t G = l->v.G;
+    std::vector<uint64_t> t(G, term);
+    SMR_HIP_TRY(hipMemset(l->v.role, role, G));
+    SMR_HIP_TRY(hipMemset(l->v.leader, leader, G));
+    SMR_HIP_TRY(hipMemset(l->v.voted_for, voted_for, G));
+    SMR_HIP_TRY(hipMemset(l->v.votes, 0, G));
+    SMR_HIP_TRY(hipMemcpy(l->v.curr_term, t.data(), G * 8, hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
+int smr_raft_replica_handle_append_entries(smr_raft_leader *l, const smr_raft_append_entries *m,
+                                           const smr_raft_append_reply *r, void *stream) {
+    if (!l || !m || !r || !m->flags || !m->leader || !m->term || !m->prev_slot || !m->prev_term || !m->n_entries ||
+        !m->leader_commit || !m->last_snap || (m->max_entries && !m->entry_term) || !r->flags || !r->term ||
+        !r->end_slot || !r->conflict_term || !r->conflict_slot)
+        return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_append_entries_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                       m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term,
+                       m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
+                       r->conflict_slot);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_replica_become_candidate(smr_raft_leader *l, const uint8_t *timeout_src_dev, uint8_t *rv_flags_dev,
+                                      uint64_t *rv_term_dev, uint32_t *rv_last_slot_dev, uint64_t *rv_last_term_dev,
+                                      void *stream) {
+    if (!l || !timeout_src_dev || !rv_flags_dev || !rv_term_dev || !rv_last_slot_dev || !rv_last_term_dev)
+        return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_become_candidate_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                       timeout_src_dev, rv_flags_dev, rv_term_dev, rv_last_slot_dev, rv_last_term_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_replica_handle_request_vote(smr_raft_leader *l, const uint8_t *flags_dev, const uint8_t *candidate_dev,
+                                         const uint64_t *term_dev, const uint32_t *last_slot_dev,
+                                         const uint64_t *last_term_dev, uint8_t *r_flags_dev, uint64_t *r_term_dev,
+                                         void *stream) {
+    if (!l || !flags_dev || !candidate_dev || !term_dev || !last_slot_dev || !last_term_dev || !r_flags_dev || !r_term_dev)
+        return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_request_vote_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                       flags_dev, candidate_dev, term_dev, last_slot_dev, last_term_dev, r_flags_dev, r_term_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_replica_handle_vote_replies(smr_raft_leader *l, const uint64_t *term_dev, const uint8_t *flags_dev,
+                                         const uint32_t *order_dev, uint32_t *hb_prev_slot_dev, uint8_t *elected_dev,
+                                         void *stream) {
+    if (!l || !term_dev || !flags_dev || !hb_prev_slot_dev || !elected_dev) return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_vote_replies_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                       term_dev, flags_dev, order_dev, hb_prev_slot_dev, elected_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
+                                uint32_t *n_trunc_host) {
+    if (!l || !voted_for_host || !votes_host) return fail(SMR_ERR_ARG, "raft: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const size_t G = l->v.G;
+    SMR_HIP_TRY(hipMemcpy(voted_for_host, l->v.voted_for, G, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(votes_host, l->v.votes, G, hipMemcpyDeviceToHost));
+    if (n_exec_host) SMR_HIP_TRY(hipMemcpy(n_exec_host, l->v.n_exec, G * 4, hipMemcpyDeviceToHost));
+    if (n_trunc_host) SMR_HIP_TRY(hipMemcpy(n_trunc_host, l->v.n_trunc, G * 4, hipMemcpyDeviceToHost));
     return SMR_OK;
 }
 

@@ -1,15 +1,18 @@
-"""Host-side handle of the batched Raft leader (G groups, one replica id).
+"""Host-side handle of the batched Raft replica (G groups, one replica id).
 
-Mirrors the leader half of `RaftReplica` (src/protocols/raft/mod.rs:237-330):
-`handle_req_batch` log append and `handle_msg_append_entries_reply`
-(raft/messages.rs:222-388).  Thin: every method is one C-ABI call.
+Mirrors `RaftReplica` (src/protocols/raft/mod.rs:237-330): the leader half --
+`handle_req_batch` log append, `handle_msg_append_entries_reply`
+(raft/messages.rs:222-388) -- the follower's `handle_msg_append_entries`
+(messages.rs:13-218) and the election handlers (`become_a_candidate`,
+`handle_msg_request_vote`, `handle_msg_request_vote_reply`).  Thin: every
+method is one C-ABI call; messages are device tensors with one entry per group.
 """
 import ctypes as C
 
 import numpy as np
 
 from . import _lib
-from ._lib import RaftCfg, RaftDumpBufs, check
+from ._lib import RaftAppendEntries, RaftAppendReply, RaftCfg, RaftDumpBufs, check
 
 _T = {"role": np.uint8, "leader": np.uint8, "curr_term": np.uint64, "entry_term": np.uint64}
 
@@ -68,3 +71,61 @@ class RaftLeaderGroup:
         n = C.c_uint64()
         check(self._L.smr_raft_leader_total_commits(self._h, C.byref(n)))
         return int(n.value)
+
+    # ---- follower side and elections (device tensors, one entry per group) ----
+    def preset(self, role, leader, term, voted_for=0xFF):
+        check(self._L.smr_raft_replica_preset(self._h, role, leader, term, voted_for))
+
+    def handle_msg_append_entries(self, flags, leader, term, prev_slot, prev_term, n_entries, entry_term,
+                                  leader_commit, last_snap, stream=None):
+        """returns the AppendEntriesReply tensors dict(flags, term, end_slot, conflict_term, conflict_slot)"""
+        import torch
+        dev, G = flags.device, self.G
+        r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev),
+                 end_slot=torch.zeros(G, dtype=torch.int32, device=dev),
+                 conflict_term=torch.zeros(G, dtype=torch.int64, device=dev),
+                 conflict_slot=torch.zeros(G, dtype=torch.int32, device=dev))
+        m = RaftAppendEntries(_ptr(flags), _ptr(leader), _ptr(term), _ptr(prev_slot), _ptr(prev_term), _ptr(n_entries),
+                              _ptr(entry_term), int(entry_term.shape[0]), _ptr(leader_commit), _ptr(last_snap))
+        rr = RaftAppendReply(*[_ptr(r[k]) for k in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])
+        check(self._L.smr_raft_replica_handle_append_entries(self._h, C.byref(m), C.byref(rr), self._stream(stream)))
+        return r
+
+    def become_a_candidate(self, timeout_src, stream=None):
+        import torch
+        dev, G = timeout_src.device, self.G
+        r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev),
+                 last_slot=torch.zeros(G, dtype=torch.int32, device=dev),
+                 last_term=torch.zeros(G, dtype=torch.int64, device=dev))
+        check(self._L.smr_raft_replica_become_candidate(self._h, _ptr(timeout_src), _ptr(r["flags"]), _ptr(r["term"]),
+                                                        _ptr(r["last_slot"]), _ptr(r["last_term"]),
+                                                        self._stream(stream)))
+        return r
+
+    def handle_msg_request_vote(self, flags, candidate, term, last_slot, last_term, stream=None):
+        import torch
+        dev, G = flags.device, self.G
+        r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev))
+        check(self._L.smr_raft_replica_handle_request_vote(self._h, _ptr(flags), _ptr(candidate), _ptr(term),
+                                                           _ptr(last_slot), _ptr(last_term), _ptr(r["flags"]),
+                                                           _ptr(r["term"]), self._stream(stream)))
+        return r
+
+    def handle_msg_request_vote_reply(self, term, flags, order=None, stream=None):
+        """one RequestVoteReply per (peer, group), tensors [R, G]"""
+        import torch
+        dev, G, R = flags.device, self.G, self.R
+        r = dict(hb_prev_slot=torch.zeros((R, G), dtype=torch.int32, device=dev),
+                 elected=torch.zeros(G, dtype=torch.uint8, device=dev))
+        check(self._L.smr_raft_replica_handle_vote_replies(self._h, _ptr(term), _ptr(flags), _ptr(order),
+                                                           _ptr(r["hb_prev_slot"]), _ptr(r["elected"]),
+                                                           self._stream(stream)))
+        return r
+
+    def dump_votes(self):
+        G = self.G
+        r = dict(voted_for=np.zeros(G, np.uint8), votes=np.zeros(G, np.uint8), n_exec=np.zeros(G, np.uint32),
+                 n_trunc=np.zeros(G, np.uint32))
+        check(self._L.smr_raft_replica_dump_votes(self._h, *[r[k].ctypes.data_as(C.c_void_p)
+                                                              for k in ("voted_for", "votes", "n_exec", "n_trunc")]))
+        return r

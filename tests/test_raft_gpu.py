@@ -68,3 +68,76 @@ def test_craft_threshold(cuda, oracle):
 
 def test_raft_config3_65536_groups(cuda, oracle):
     _run(cuda, oracle, G=65536, R=5, W=64, T=12)
+
+
+# ---- follower side and elections (raft/messages.rs:13-218, 391-510; leadership.rs:76-218) ----
+def _t(a, cuda):
+    import torch
+    return torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else (a.view(np.int32) if a.dtype == np.uint32 else a)).to(cuda)
+
+
+def _same_state(eng, orc, step):
+    a, b = eng.dump(), orc.dump()
+    for n in a:
+        assert np.array_equal(a[n], b[n]), (step, n, np.nonzero(a[n] != b[n]))
+    va, vb = eng.dump_votes(), orc.dump_votes()
+    for n in va:
+        assert np.array_equal(va[n].astype(np.uint64), vb[n].astype(np.uint64)), (step, n)
+
+
+def _same_reply(r_eng, r_orc, step):
+    for k, v in r_orc.items():
+        e = r_eng[k].cpu().numpy()
+        assert e.dtype.itemsize == v.dtype.itemsize, k
+        assert np.array_equal(e.view(v.dtype), v), (step, k, np.nonzero(e.view(v.dtype) != v))
+
+
+@pytest.mark.parametrize("G,W", [(777, 64), (4096, 32)])
+def test_follower_and_elections_match_oracle(cuda, oracle, G, W):
+    from summerset_amd import RaftLeaderGroup
+    import raft_scenarios as sc                       # tests/ is on sys.path under pytest
+    R, me, K = 5, 2, 6
+    rng = np.random.default_rng(G + W)
+    eng = RaftLeaderGroup(G, R, leader_id=me, window=W, term=1)
+    orc = oracle.RaftOracle(G, R, W, leader_id=me, term=1)
+    # a few leader appends give every group a log, then everybody is a follower of replica 0
+    for _ in range(3):
+        n_new = rng.integers(0, 4, G).astype(np.uint32)
+        eng.handle_req_batch(_t(n_new, cuda))
+        orc.append(n_new)
+    eng.preset(0, 0, 1)
+    orc.preset(0, 0, 1)
+    _same_state(eng, orc, "preset")
+    from summerset_amd import stream
+    for step in range(40):
+        d = orc.dump()
+        kind = step % 5
+        if kind in (0, 1, 2):
+            m = sc.append_entries_round(rng, d, G, K, me, W)
+            ro = orc.handle_append_entries(**m)
+            re_ = eng.handle_msg_append_entries(**{k: _t(v, cuda) for k, v in m.items()})
+            _same_reply(re_, ro, step)
+        elif kind == 3:
+            src = sc.timeout_round(rng, d, G, me)
+            ro = orc.become_candidate(src)
+            re_ = eng.become_a_candidate(_t(src, cuda))
+            _same_reply(re_, ro, step)
+            m = sc.request_vote_round(rng, orc.dump(), G, me, W)
+            ro = orc.handle_request_vote(**m)
+            re_ = eng.handle_msg_request_vote(**{k: _t(v, cuda) for k, v in m.items()})
+            _same_reply(re_, ro, step)
+        else:
+            ctl = stream.random_ackctl(7, step, 1, G, R, 0.0)[0]
+            m = sc.vote_reply_round(rng, d, G, R, me, np.ascontiguousarray(ctl))
+            ro = orc.handle_vote_replies(m["term"], m["flags"], m["order"])
+            re_ = eng.handle_msg_request_vote_reply(_t(m["term"], cuda), _t(m["flags"], cuda), _t(m["order"], cuda))
+            _same_reply(re_, ro, step)
+            # the elected ones lead for a moment: appends and replies go through the leader kernels
+            n_new = rng.integers(0, 3, G).astype(np.uint32)
+            eng.handle_req_batch(_t(n_new, cuda))
+            orc.append(n_new)
+        _same_state(eng, orc, step)
+    roles = orc.dump()["role"]
+    assert (roles == 0).any() and (roles == 1).any() and (roles == 2).any()      # every role was reached
+    v = orc.dump_votes()
+    assert v["n_trunc"].sum() > 0 and v["n_exec"].sum() > 0
