@@ -1,0 +1,438 @@
+/*
+ * oracle/ep_oracle.c -- CPU restatement of the EPaxos command-leader / acceptor
+ * hot path of Summerset over G independent groups, one replica (id `me`) per
+ * group: dependency and sequence computation, PreAccept handling, the
+ * fast-quorum decision on PreAcceptReplies, the slow-path Accept tally and the
+ * commit bars.
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/mp_oracle.c header for the rules).
+ *
+ * Follows src/protocols/epaxos/:
+ *   handle_req_batch                 request.rs:10-108
+ *   first_null_slot / null_instance  mod.rs:467-496
+ *   identify_deps, refresh_highest_cols, max_seq_num, DepSet::union
+ *                                    dependency.rs:85-167
+ *   fast_quorum_eligibility          dependency.rs:175-240
+ *   get_enough_identical             dependency.rs:333-367
+ *   handle_msg_pre_accept            messages.rs:10-93
+ *   handle_msg_pre_accept_reply      messages.rs:96-270
+ *   handle_msg_accept                messages.rs:273-345
+ *   handle_msg_accept_reply          messages.rs:348-436
+ *   handle_logged_{pre_accept,accept,commit}_slot   durability.rs:10-163
+ *   quorum sizes, default ballot     mod.rs:500-514,693-698
+ * WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one
+ * key of a small key space (key id < n_keys), which is
+ * all identify_deps / refresh_highest_cols look at.  NOT modelled: dependency-
+ * graph execution (execution.rs; its order depends on petgraph internals,
+ * SURVEY.md §8c), explicit prepare, timers (the set of peers whose hear timer
+ * "exploded" is an input of the reply handler).
+ *
+ * PARITY STATUS: "parity unpinned" -- the reference has no unit tests or
+ * fixtures for these handlers and cannot be built here; pinned by hand-derived
+ * traces (tests/test_oracle_ep.py).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ST_NULL = 0, ST_PREACCEPTING = 1, ST_ACCEPTING = 2, ST_COMMITTED = 3, ST_EXECUTING = 4, ST_EXECUTED = 5 };
+#define MAXR 8
+#define NONE 0xFFFFFFFFu            /* Option<usize>::None in a DepSet */
+#define NO_KEY 0xFF                 /* empty ReqBatch */
+#define NO_REP 0xFF
+
+typedef struct { uint32_t c[MAXR]; } DepSet;
+
+typedef struct {
+    uint64_t bal, seq;
+    uint8_t status, key;
+    DepSet deps;
+    uint8_t has_lbk, has_rbk, source, avoid_fast_path;
+    /* LeaderBookkeeping */
+    uint8_t pa_acks, acc_acks;
+    uint8_t pa_has[MAXR]; uint64_t pa_seq[MAXR]; DepSet pa_deps[MAXR];   /* pre_accept_replies: HashMap<peer, (seq, deps)> */
+} Inst;
+
+typedef struct {
+    uint8_t id, population, simple_q, super_q;
+    uint32_t n_keys, W;
+    Inst *rows[MAXR]; uint32_t len[MAXR], cap[MAXR];
+    uint32_t start_col;
+    uint32_t commit_bars[MAXR], exec_bars[MAXR];
+    DepSet *highest_cols; uint8_t *hc_present;      /* HashMap<key, DepSet> */
+    uint64_t n_fast, n_slow, n_accept_commits;
+} EpRep;
+
+typedef struct { uint32_t G; uint8_t R; EpRep *reps; } EpCl;
+
+static DepSet dep_empty(void) { DepSet d; for (int i = 0; i < MAXR; i++) d.c[i] = NONE; return d; }
+static void dep_union(DepSet *s, const DepSet *o, int R) {          /* dependency.rs:85-97 */
+    for (int i = 0; i < R; i++) {
+        if (s->c[i] != NONE) { if (o->c[i] != NONE && o->c[i] > s->c[i]) s->c[i] = o->c[i]; }
+        else s->c[i] = o->c[i];
+    }
+}
+static int dep_eq(const DepSet *a, const DepSet *b, int R) {
+    for (int i = 0; i < R; i++) if (a->c[i] != b->c[i]) return 0;
+    return 1;
+}
+
+static Inst null_instance(void) {                                   /* mod.rs:467-480 */
+    Inst in; memset(&in, 0, sizeof(in));
+    in.status = ST_NULL; in.key = NO_KEY; in.deps = dep_empty(); in.source = NO_REP;
+    for (int p = 0; p < MAXR; p++) in.pa_deps[p] = dep_empty();
+    return in;
+}
+static void row_push(EpRep *r, int row, Inst in) {
+    if (r->len[row] == r->cap[row]) {
+        r->cap[row] = r->cap[row] ? r->cap[row] * 2 : 16;
+        r->rows[row] = (Inst *)realloc(r->rows[row], sizeof(Inst) * r->cap[row]);
+    }
+    r->rows[row][r->len[row]++] = in;
+}
+static Inst *at(EpRep *r, int row, uint32_t col) { return &r->rows[row][col - r->start_col]; }
+
+void *orc_ep_new(uint32_t G, uint8_t R, uint8_t me, uint32_t W, uint32_t n_keys, uint8_t optimized_quorum) {
+    EpCl *cl = (EpCl *)calloc(1, sizeof(EpCl));
+    cl->G = G; cl->R = R;
+    cl->reps = (EpRep *)calloc(G, sizeof(EpRep));
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        r->id = me; r->population = R; r->W = W; r->n_keys = n_keys;
+        r->simple_q = (uint8_t)(R / 2 + 1);                          /* mod.rs:693 */
+        r->super_q = optimized_quorum ? (uint8_t)(R / 2 + (R / 2 + 1) / 2) : (uint8_t)((R / 2) * 2);   /* :694-698 */
+        r->highest_cols = (DepSet *)calloc(n_keys, sizeof(DepSet));
+        r->hc_present = (uint8_t *)calloc(n_keys, 1);
+    }
+    return cl;
+}
+void orc_ep_free(void *h) {
+    EpCl *cl = (EpCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        for (int i = 0; i < MAXR; i++) free(cl->reps[g].rows[i]);
+        free(cl->reps[g].highest_cols); free(cl->reps[g].hc_present);
+    }
+    free(cl->reps); free(cl);
+}
+
+/* dependency.rs:101-109; harness guard shared with the engine: an instance older than the
+ * row's last W columns is no longer held (the engine keeps rings of W instances per row) */
+static uint64_t max_seq_num(EpRep *r, const DepSet *deps) {
+    uint64_t m = 0;
+    for (int row = 0; row < r->population; row++) {
+        uint32_t c = deps->c[row];
+        if (c == NONE) continue;
+        if (c < r->start_col || c >= r->start_col + r->len[row] || c + r->W < r->start_col + r->len[row]) continue;
+        uint64_t s = at(r, row, c)->seq;
+        if (s > m) m = s;
+    }
+    return m;
+}
+static DepSet identify_deps(EpRep *r, uint8_t key) {                /* dependency.rs:113-137 */
+    DepSet d = dep_empty();
+    if (key != NO_KEY && r->hc_present[key]) dep_union(&d, &r->highest_cols[key], r->population);
+    return d;
+}
+static void refresh_highest_cols(EpRep *r, int row, uint32_t col, uint8_t key) {   /* dependency.rs:141-167 */
+    if (key == NO_KEY) return;
+    if (r->hc_present[key]) {
+        uint32_t *hc = &r->highest_cols[key].c[row];
+        if (*hc != NONE) { if (col > *hc) *hc = col; } else *hc = col;
+    } else {
+        r->highest_cols[key] = dep_empty();
+        r->highest_cols[key].c[row] = col;
+        r->hc_present[key] = 1;
+    }
+}
+
+/* durability.rs:104-163 without the execution attempt */
+static void handle_logged_commit_slot(EpRep *r, int row, uint32_t col) {
+    if (col < r->start_col) return;
+    if (col == r->commit_bars[row]) {
+        while (r->commit_bars[row] < r->start_col + r->len[row]) {
+            Inst *in = at(r, row, r->commit_bars[row]);
+            if (in->status < ST_COMMITTED) break;
+            else if (in->key == NO_KEY) in->status = ST_EXECUTED;
+            r->commit_bars[row]++;
+        }
+    }
+}
+
+/* dependency.rs:333-367 over the replies held so far, in peer-id order (the reference iterates a
+ * HashMap; the outcome does not depend on the order: classes of equal (seq, deps)) */
+static int get_enough_identical(EpRep *r, Inst *in, uint8_t thresh, uint64_t *seq, DepSet *deps, uint8_t *max_cnt) {
+    int idx[MAXR], n = 0;
+    for (int p = 0; p < r->population; p++) if (in->pa_has[p]) idx[n++] = p;
+    uint8_t visited[MAXR] = {0};
+    int first = 0; uint8_t mc = 1;
+    visited[0] = 1;
+    while (first < n) {
+        int next_first = n; uint8_t same = 1;
+        for (int i = first + 1; i < n; i++) {
+            if (!visited[i]) {
+                if (in->pa_seq[idx[i]] == in->pa_seq[idx[first]] &&
+                    dep_eq(&in->pa_deps[idx[i]], &in->pa_deps[idx[first]], r->population)) { visited[i] = 1; same++; }
+                else if (next_first == n) next_first = i;
+            }
+        }
+        if (same >= thresh) { *seq = in->pa_seq[idx[first]]; *deps = in->pa_deps[idx[first]]; *max_cnt = same; return 1; }
+        first = next_first;
+        if (same > mc) mc = same;
+    }
+    *max_cnt = mc;
+    return 0;
+}
+
+/* dependency.rs:175-240: 0 = undecided, else the Status to enter with (seq, deps) */
+static int fast_quorum_eligibility(EpRep *r, Inst *in, uint8_t exploded, uint64_t *seq, DepSet *deps) {
+    uint8_t all_cnt = (uint8_t)__builtin_popcount(in->pa_acks);
+    if (all_cnt < r->simple_q) return 0;
+    if (!in->avoid_fast_path) {
+        uint8_t bad = 0;
+        for (int p = 0; p < r->population; p++)
+            if (!((in->pa_acks >> p) & 1) && p != r->id && ((exploded >> p) & 1)) bad++;
+        uint8_t max_cnt;
+        if (get_enough_identical(r, in, r->super_q, seq, deps, &max_cnt)) return ST_COMMITTED;
+        if (max_cnt + (r->population - bad - all_cnt) >= r->super_q) return 0;      /* :221-236 */
+    }
+    *seq = 0; *deps = dep_empty();                                    /* union of deps, max of seqs */
+    for (int p = 0; p < r->population; p++)
+        if (in->pa_has[p]) { dep_union(deps, &in->pa_deps[p], r->population); if (in->pa_seq[p] > *seq) *seq = in->pa_seq[p]; }
+    return ST_ACCEPTING;
+}
+
+static void handle_msg_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t ballot);
+
+/* messages.rs:96-270; ballot == 0: "failure suspected" re-evaluation */
+static void handle_msg_pre_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t ballot, uint64_t seq,
+                                        const DepSet *deps, uint8_t exploded) {
+    if (col < r->start_col) return;
+    if (col >= r->start_col + r->len[row]) return;                  /* :125-127 */
+    Inst *in = at(r, row, col);
+    if (in->status != ST_PREACCEPTING || (ballot > 0 && in->bal != ballot) || !in->has_lbk) return;   /* :129-134 */
+    if ((in->pa_acks >> peer) & 1) return;                          /* :136-138 */
+    if (ballot > 0) {                                                /* :141-144 */
+        in->pa_has[peer] = 1; in->pa_seq[peer] = seq; in->pa_deps[peer] = *deps;
+        in->pa_acks |= (uint8_t)(1u << peer);
+    }
+    uint64_t dseq; DepSet ddeps;
+    int next = fast_quorum_eligibility(r, in, exploded, &dseq, &ddeps);
+    if (next == ST_COMMITTED) {                                      /* :158-206 */
+        in->status = ST_COMMITTED; in->seq = dseq; in->deps = ddeps;
+        r->n_fast++;
+        handle_logged_commit_slot(r, row, col);
+    } else if (next == ST_ACCEPTING) {                               /* :209-262 */
+        in->status = ST_ACCEPTING; in->seq = dseq; in->deps = ddeps;
+        r->n_slow++;
+        handle_msg_accept_reply(r, r->id, row, col, in->bal);         /* durability.rs:78-83: my own AcceptSlot completion */
+    }
+}
+
+/* messages.rs:348-436 */
+static void handle_msg_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t ballot) {
+    if (col < r->start_col) return;
+    if (col >= r->start_col + r->len[row]) return;
+    Inst *in = at(r, row, col);
+    if (in->status != ST_ACCEPTING || in->bal != ballot || !in->has_lbk) return;     /* :371-376 */
+    if ((in->acc_acks >> peer) & 1) return;
+    in->acc_acks |= (uint8_t)(1u << peer);
+    if (__builtin_popcount(in->acc_acks) >= r->simple_q) {           /* :386 */
+        in->status = ST_COMMITTED;
+        r->n_accept_commits++;
+        handle_logged_commit_slot(r, row, col);
+    }
+}
+
+/* request.rs:10-108 + the command leader's own PreAcceptSlot completion (durability.rs:25-35).
+ * Output: the PreAccept message it broadcasts. */
+void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_t *m_flags, uint32_t *m_col,
+                    uint64_t *m_seq, uint32_t *m_deps) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        m_flags[g] = 0; m_col[g] = 0; m_seq[g] = 0;
+        for (int i = 0; i < cl->R; i++) m_deps[(size_t)i * G + g] = NONE;
+        if (key[g] == NO_KEY) continue;
+        int row = r->id;
+        uint32_t col = NONE;                                         /* mod.rs:485-496 first_null_slot */
+        for (uint32_t c = r->exec_bars[row]; c < r->start_col + r->len[row]; c++)
+            if (at(r, row, c)->status == ST_NULL) { col = c; break; }
+        if (col == NONE) { row_push(r, row, null_instance()); col = r->start_col + r->len[row] - 1; }
+        DepSet deps = identify_deps(r, key[g]);
+        uint64_t seq = 1 + max_seq_num(r, &deps);
+        Inst *in = at(r, row, col);
+        in->bal = (uint64_t)(r->id + 1);                              /* make_default_ballot: (0 << 8) | (id + 1) */
+        in->seq = seq; in->deps = deps; in->key = key[g];
+        refresh_highest_cols(r, row, col, key[g]);
+        in->has_lbk = 1; in->pa_acks = 0; in->acc_acks = 0;
+        for (int p = 0; p < MAXR; p++) in->pa_has[p] = 0;
+        in->status = ST_PREACCEPTING;
+        m_flags[g] = 1; m_col[g] = col; m_seq[g] = seq;
+        for (int i = 0; i < cl->R; i++) m_deps[(size_t)i * G + g] = deps.c[i];
+        handle_msg_pre_accept_reply(r, r->id, row, col, in->bal, seq, &deps, exploded ? exploded[g] : 0);
+    }
+}
+
+/* messages.rs:10-93 + the acceptor's PreAcceptSlot completion (durability.rs:36-54): the reply */
+void orc_ep_handle_pre_accept(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col,
+                              const uint64_t *ballot, const uint64_t *seq, const uint32_t *deps, const uint8_t *key,
+                              uint8_t *r_flags, uint64_t *r_ballot, uint64_t *r_seq, uint32_t *r_deps) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        r_flags[g] = 0; r_ballot[g] = 0; r_seq[g] = 0;
+        for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = NONE;
+        if (!(flags[g] & 1)) continue;
+        int row = peer[g];                                           /* the command leader's own row */
+        uint32_t c = col[g];
+        if (c < r->start_col) continue;
+        while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :33-36 */
+        Inst *in = at(r, row, c);
+        if (ballot[g] >= in->bal) {                                  /* :40 */
+            DepSet d; for (int i = 0; i < MAXR; i++) d.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
+            DepSet my = identify_deps(r, key[g]);
+            dep_union(&d, &my, r->population);
+            uint64_t s = seq[g], ms = 1 + max_seq_num(r, &my);
+            if (ms > s) s = ms;
+            in->bal = ballot[g]; in->status = ST_PREACCEPTING; in->seq = s; in->deps = d; in->key = key[g];
+            refresh_highest_cols(r, row, c, key[g]);
+            in->has_rbk = 1; in->source = peer[g];
+            /* WAL completion: leader_bk takes precedence (durability.rs:25), else reply to source */
+            if (in->has_lbk) handle_msg_pre_accept_reply(r, r->id, row, c, in->bal, in->seq, &in->deps, 0);
+            else {
+                r_flags[g] = 1; r_ballot[g] = in->bal; r_seq[g] = in->seq;
+                for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = in->deps.c[i];
+            }
+        }
+    }
+}
+
+static uint32_t ctl_order(uint32_t ctl, int i) { return (ctl >> (3 * i)) & 7u; }
+#define CTL_IDENTITY 0x00FAC688u
+
+/* PreAcceptReplies to my instance (me, col[g]): per peer [R][G] ballot, seq, deps[R][R][G];
+ * flags[R][G] bit0 = present; peers in `order` order (ackctl encoding).  decision: 0 / ST_* */
+void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64_t *ballot, const uint64_t *seq,
+                                      const uint32_t *deps, const uint8_t *flags, const uint32_t *order,
+                                      const uint8_t *exploded, uint8_t *decision, uint64_t *d_seq, uint32_t *d_deps) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G; const int R = cl->R;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        int row = r->id;
+        uint32_t ctl = order ? order[g] : CTL_IDENTITY;
+        uint8_t before = 0;
+        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) before = at(r, row, col[g])->status;
+        for (int oi = 0; oi < R; oi++) {
+            int p = (int)ctl_order(ctl, oi);
+            if (p == r->id || p >= R) continue;
+            size_t o = (size_t)p * G + g;
+            if (!(flags[o] & 1)) continue;
+            DepSet d = dep_empty();
+            for (int i = 0; i < R; i++) d.c[i] = deps[((size_t)p * R + i) * G + g];
+            handle_msg_pre_accept_reply(r, (uint8_t)p, row, col[g], ballot[o], seq[o], &d, exploded ? exploded[g] : 0);
+        }
+        decision[g] = 0; d_seq[g] = 0;
+        for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = NONE;
+        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) {
+            Inst *in = at(r, row, col[g]);
+            if (before == ST_PREACCEPTING && in->status != ST_PREACCEPTING) {
+                decision[g] = in->status >= ST_COMMITTED ? ST_COMMITTED : ST_ACCEPTING;
+                if (in->status == ST_ACCEPTING || in->status >= ST_COMMITTED) {
+                    d_seq[g] = in->seq;
+                    for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = in->deps.c[i];
+                }
+                /* an instance that went Accepting and on to Committed by my own ack alone (simple_q == 1) would
+                 * read Committed here; with R >= 3 the slow path needs peers */
+                if (in->status == ST_ACCEPTING) decision[g] = ST_ACCEPTING;
+            }
+        }
+    }
+}
+
+/* messages.rs:273-345 + the acceptor's AcceptSlot completion (durability.rs:84-100) */
+void orc_ep_handle_accept(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col, const uint64_t *ballot,
+                          const uint64_t *seq, const uint32_t *deps, const uint8_t *key, uint8_t *r_flags,
+                          uint64_t *r_ballot) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        r_flags[g] = 0; r_ballot[g] = 0;
+        if (!(flags[g] & 1)) continue;
+        int row = peer[g];
+        uint32_t c = col[g];
+        if (c < r->start_col) continue;
+        while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());
+        Inst *in = at(r, row, c);
+        if (ballot[g] >= in->bal) {
+            in->bal = ballot[g]; in->status = ST_ACCEPTING; in->seq = seq[g]; in->key = key[g];
+            for (int i = 0; i < MAXR; i++) in->deps.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
+            refresh_highest_cols(r, row, c, key[g]);
+            in->has_rbk = 1; in->source = peer[g];
+            if (in->has_lbk) handle_msg_accept_reply(r, r->id, row, c, in->bal);
+            else { r_flags[g] = 1; r_ballot[g] = in->bal; }
+        }
+    }
+}
+
+/* AcceptReplies to my instance (me, col[g]): ballot[R][G], flags[R][G]; committed[g] = 1 if it commits here */
+void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *ballot, const uint8_t *flags,
+                                  const uint32_t *order, uint8_t *committed) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G; const int R = cl->R;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        int row = r->id;
+        uint32_t ctl = order ? order[g] : CTL_IDENTITY;
+        uint8_t before = 0;
+        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) before = at(r, row, col[g])->status;
+        for (int oi = 0; oi < R; oi++) {
+            int p = (int)ctl_order(ctl, oi);
+            if (p == r->id || p >= R) continue;
+            size_t o = (size_t)p * G + g;
+            if (!(flags[o] & 1)) continue;
+            handle_msg_accept_reply(r, (uint8_t)p, row, col[g], ballot[o]);
+        }
+        committed[g] = 0;
+        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row])
+            committed[g] = (before == ST_ACCEPTING && at(r, row, col[g])->status >= ST_COMMITTED) ? 1 : 0;
+    }
+}
+
+/* canonical dump: rows x the last W columns (by col % W), bars, highest_cols, counters */
+void orc_ep_dump(void *h, uint32_t *len, uint32_t *commit_bars, uint64_t *bal, uint64_t *seq, uint8_t *status,
+                 uint8_t *key, uint32_t *deps, uint8_t *pa_acks, uint8_t *acc_acks, uint8_t *bk, uint32_t *highest_cols,
+                 uint64_t *counters) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G; const int R = cl->R;
+    counters[0] = counters[1] = counters[2] = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        const uint32_t W = r->W;
+        counters[0] += r->n_fast; counters[1] += r->n_slow; counters[2] += r->n_accept_commits;
+        for (int row = 0; row < R; row++) {
+            len[(size_t)row * G + g] = r->start_col + r->len[row];
+            commit_bars[(size_t)row * G + g] = r->commit_bars[row];
+            for (uint32_t w = 0; w < W; w++) {
+                size_t o = ((size_t)row * W + w) * G + g;
+                bal[o] = 0; seq[o] = 0; status[o] = 0; key[o] = NO_KEY; pa_acks[o] = 0; acc_acks[o] = 0; bk[o] = 0;
+                for (int i = 0; i < R; i++) deps[(o * R) + i] = NONE;
+            }
+            uint32_t end = r->start_col + r->len[row], lo = end > W ? end - W : r->start_col;
+            for (uint32_t c = lo; c < end; c++) {
+                Inst *in = at(r, row, c);
+                size_t o = ((size_t)row * W + (c % W)) * G + g;
+                bal[o] = in->bal; seq[o] = in->seq; status[o] = in->status; key[o] = in->key;
+                pa_acks[o] = in->pa_acks; acc_acks[o] = in->acc_acks;
+                bk[o] = (uint8_t)(in->has_lbk | (in->has_rbk << 1) | ((in->has_rbk ? in->source : 0) << 2));
+                for (int i = 0; i < R; i++) deps[(o * R) + i] = in->deps.c[i];
+            }
+        }
+        for (uint32_t k = 0; k < r->n_keys; k++)
+            for (int i = 0; i < R; i++)
+                highest_cols[((size_t)k * R + i) * G + g] = r->hc_present[k] ? r->highest_cols[k].c[i] : NONE;
+    }
+}

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c"]
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c"]
 
 CTL_IDENTITY = 0x00FAC688
 NO_LEADER = 0xFF
@@ -80,6 +80,14 @@ def _declare(L):
     L.orc_raft_handle_request_vote.argtypes = [vp] + [vp] * 7
     L.orc_raft_handle_vote_replies.argtypes = [vp] + [vp] * 6
     L.orc_raft_dump_votes.argtypes = [vp] + [vp] * 4
+    L.orc_ep_new.restype = vp; L.orc_ep_new.argtypes = [u32, u8, u8, u32, u32, u8]
+    L.orc_ep_free.argtypes = [vp]
+    L.orc_ep_propose.argtypes = [vp] + [vp] * 6
+    L.orc_ep_handle_pre_accept.argtypes = [vp] + [vp] * 11
+    L.orc_ep_handle_pre_accept_replies.argtypes = [vp] + [vp] * 10
+    L.orc_ep_handle_accept.argtypes = [vp] + [vp] * 9
+    L.orc_ep_handle_accept_replies.argtypes = [vp] + [vp] * 5
+    L.orc_ep_dump.argtypes = [vp] + [vp] * 12
 
 
 # ---------------------------------------------------------------- GF / RS ---
@@ -311,3 +319,67 @@ class RaftOracle:
                  n_trunc=np.zeros(G, np.uint64))
         lib().orc_raft_dump_votes(self.h, _p(r["voted_for"]), _p(r["votes"]), _p(r["n_exec"]), _p(r["n_trunc"]))
         return r
+
+
+EP_NONE = 0xFFFFFFFF
+EP_NO_KEY = 0xFF
+
+
+class EpOracle:
+    """G groups of the literal EPaxos command-leader / acceptor restatement (replica `me`)."""
+
+    def __init__(self, G, R=5, me=0, W=32, n_keys=64, optimized_quorum=True):
+        self.G, self.R, self.me, self.W, self.n_keys = G, R, me, W, n_keys
+        self.h = lib().orc_ep_new(G, R, me, W, n_keys, int(optimized_quorum))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ep_free(self.h)
+            self.h = None
+
+    def propose(self, key, exploded=None):
+        G, R = self.G, self.R
+        m = dict(flags=np.zeros(G, np.uint8), col=np.zeros(G, np.uint32), seq=np.zeros(G, np.uint64),
+                 deps=np.zeros((R, G), np.uint32))
+        lib().orc_ep_propose(self.h, _p(key), _p(exploded), _p(m["flags"]), _p(m["col"]), _p(m["seq"]), _p(m["deps"]))
+        return m
+
+    def handle_pre_accept(self, flags, peer, col, ballot, seq, deps, key):
+        G, R = self.G, self.R
+        r = dict(flags=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64), seq=np.zeros(G, np.uint64),
+                 deps=np.zeros((R, G), np.uint32))
+        lib().orc_ep_handle_pre_accept(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key),
+                                       _p(r["flags"]), _p(r["ballot"]), _p(r["seq"]), _p(r["deps"]))
+        return r
+
+    def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None):
+        G, R = self.G, self.R
+        assert deps.shape == (R, R, G) and ballot.shape == (R, G)
+        r = dict(decision=np.zeros(G, np.uint8), seq=np.zeros(G, np.uint64), deps=np.zeros((R, G), np.uint32))
+        lib().orc_ep_handle_pre_accept_replies(self.h, _p(col), _p(ballot), _p(seq), _p(deps), _p(flags), _p(order),
+                                               _p(exploded), _p(r["decision"]), _p(r["seq"]), _p(r["deps"]))
+        return r
+
+    def handle_accept(self, flags, peer, col, ballot, seq, deps, key):
+        G = self.G
+        r = dict(flags=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64))
+        lib().orc_ep_handle_accept(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key),
+                                   _p(r["flags"]), _p(r["ballot"]))
+        return r
+
+    def handle_accept_replies(self, col, ballot, flags, order=None):
+        r = dict(committed=np.zeros(self.G, np.uint8))
+        lib().orc_ep_handle_accept_replies(self.h, _p(col), _p(ballot), _p(flags), _p(order), _p(r["committed"]))
+        return r
+
+    def dump(self):
+        G, R, W, K = self.G, self.R, self.W, self.n_keys
+        d = dict(len=np.zeros((R, G), np.uint32), commit_bars=np.zeros((R, G), np.uint32),
+                 bal=np.zeros((R, W, G), np.uint64), seq=np.zeros((R, W, G), np.uint64),
+                 status=np.zeros((R, W, G), np.uint8), key=np.zeros((R, W, G), np.uint8),
+                 deps=np.zeros((R, W, G, R), np.uint32), pa_acks=np.zeros((R, W, G), np.uint8),
+                 acc_acks=np.zeros((R, W, G), np.uint8), bk=np.zeros((R, W, G), np.uint8),
+                 highest_cols=np.zeros((K, R, G), np.uint32), counters=np.zeros(3, np.uint64))
+        lib().orc_ep_dump(self.h, *[_p(d[k]) for k in ("len", "commit_bars", "bal", "seq", "status", "key", "deps", "pa_acks",
+                                                       "acc_acks", "bk", "highest_cols", "counters")])
+        return d
