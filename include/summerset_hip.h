@@ -321,6 +321,80 @@ int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uin
                                 uint32_t *n_trunc_host);
 
 /* ------------------------------------------------------------------------
+ * EPaxos command leader / acceptor over G groups (one replica id per group)
+ * replaces: EPaxosReplica::handle_req_batch (epaxos/request.rs:10-108) with
+ *           identify_deps / refresh_highest_cols / max_seq_num (dependency.rs:85-167),
+ *           handle_msg_pre_accept (messages.rs:10-93), handle_msg_pre_accept_reply
+ *           (:96-270) with fast_quorum_eligibility (dependency.rs:175-240),
+ *           handle_msg_accept (:273-345), handle_msg_accept_reply (:348-436), the
+ *           WAL completions and commit bars (durability.rs:10-135).
+ * A request batch is one Put on key id < n_keys (SMR_EP_NO_KEY = nothing proposed / empty batch).
+ * DepSets are R uint32 per group ([R][G]), SMR_EP_NONE = Option::None.
+ * ---------------------------------------------------------------------- */
+typedef struct smr_ep_replica smr_ep_replica;
+#define SMR_EP_NONE 0xFFFFFFFFu
+#define SMR_EP_NO_KEY 0xFFu
+
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population;        /* R, 3..8 */
+    uint8_t me;                /* my replica id (= my row of the instance space) in every group */
+    uint8_t optimized_quorum;  /* ReplicaConfigEPaxos::optimized_quorum (mod.rs:59,91): super quorum F + ceil(F/2) */
+    uint8_t reserved0;
+    uint32_t window;           /* W: columns kept per row, power of two */
+    uint32_t n_keys;           /* key space per group, 1..255 */
+} smr_ep_cfg;
+
+int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out);
+void smr_ep_replica_destroy(smr_ep_replica *e);
+
+/* One PreAccept / Accept message (or a reply to one) per group: device arrays [G], deps [R][G].
+ * flags bit0 = present.  `peer` = sender = the row of `col`.  Replies leave peer / col / key unused. */
+typedef struct {
+    uint8_t *flags;
+    uint8_t *peer;
+    uint32_t *col;
+    uint64_t *ballot;
+    uint64_t *seq;
+    uint32_t *deps;
+    uint8_t *key;
+} smr_ep_msg;
+
+/* handle_req_batch for key_dev[g] (+ my own PreAcceptSlot completion = my own reply); `out` receives the
+ * PreAccept that is broadcast (flags, col, seq, deps; ballot is make_default_ballot(me) = me + 1).
+ * exploded_dev (may be NULL): bit p = peer p's hear timer has exploded (dependency.rs:205-211). */
+int smr_ep_propose(smr_ep_replica *e, const uint8_t *key_dev, const uint8_t *exploded_dev, const smr_ep_msg *out,
+                   void *stream);
+/* handle_msg_pre_accept + WAL completion: reply = PreAcceptReply {ballot, seq, deps} (flags bit0 = sent) */
+int smr_ep_handle_pre_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream);
+/* handle_msg_accept + WAL completion: reply = AcceptReply {ballot} */
+int smr_ep_handle_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream);
+/* The PreAcceptReplies to my instance (me, col[g]): ballot / seq / flags [R][G], deps [R][R][G]
+ * (peer, dep row, group); ballot 0 = the "failure suspected" re-evaluation call; peers in
+ * order_dev[g] order (ackctl encoding, NULL = identity).  decision[g]: 0 = undecided,
+ * 3 = Committed on the fast path, 2 = Accepting (slow path) with (d_seq, d_deps [R][G]). */
+int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                     const uint64_t *seq_dev, const uint32_t *deps_dev, const uint8_t *flags_dev,
+                                     const uint32_t *order_dev, const uint8_t *exploded_dev, uint8_t *decision_dev,
+                                     uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream);
+/* The AcceptReplies to my instance (me, col[g]): ballot / flags [R][G]; committed[g] = 1 if it commits here */
+int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                 const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream);
+/* host buffers: len / commit_bars [R][G]; per instance [R][W][G] by col % W (cells outside the last W
+ * columns of a row read as null); deps [R][W][G][R]; highest_cols [n_keys][R][G]; counters[3] =
+ * fast-path commits, slow-path entries, slow-path commits */
+typedef struct {
+    uint32_t *len, *commit_bars;
+    uint64_t *bal, *seq;
+    uint8_t *status, *key;
+    uint32_t *deps;
+    uint8_t *pa_acks, *acc_acks, *bk;
+    uint32_t *highest_cols;
+    uint64_t *counters;
+} smr_ep_dump_bufs;
+int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *host_bufs);
+
+/* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing
  * ---------------------------------------------------------------------- */
 typedef struct smr_repnothing smr_repnothing;

@@ -91,6 +91,11 @@ static void row_push(EpRep *r, int row, Inst in) {
     r->rows[row][r->len[row]++] = in;
 }
 static Inst *at(EpRep *r, int row, uint32_t col) { return &r->rows[row][col - r->start_col]; }
+/* harness guard shared with the engine (rings of W instances per row): is the column still held? */
+static int held(const EpRep *r, int row, uint32_t col) {
+    uint32_t end = r->start_col + r->len[row];
+    return col >= r->start_col && col < end && col + r->W >= end;
+}
 
 void *orc_ep_new(uint32_t G, uint8_t R, uint8_t me, uint32_t W, uint32_t n_keys, uint8_t optimized_quorum) {
     EpCl *cl = (EpCl *)calloc(1, sizeof(EpCl));
@@ -122,7 +127,7 @@ static uint64_t max_seq_num(EpRep *r, const DepSet *deps) {
     for (int row = 0; row < r->population; row++) {
         uint32_t c = deps->c[row];
         if (c == NONE) continue;
-        if (c < r->start_col || c >= r->start_col + r->len[row] || c + r->W < r->start_col + r->len[row]) continue;
+        if (!held(r, row, c)) continue;
         uint64_t s = at(r, row, c)->seq;
         if (s > m) m = s;
     }
@@ -149,7 +154,7 @@ static void refresh_highest_cols(EpRep *r, int row, uint32_t col, uint8_t key) {
 static void handle_logged_commit_slot(EpRep *r, int row, uint32_t col) {
     if (col < r->start_col) return;
     if (col == r->commit_bars[row]) {
-        while (r->commit_bars[row] < r->start_col + r->len[row]) {
+        while (r->commit_bars[row] < r->start_col + r->len[row] && held(r, row, r->commit_bars[row])) {
             Inst *in = at(r, row, r->commit_bars[row]);
             if (in->status < ST_COMMITTED) break;
             else if (in->key == NO_KEY) in->status = ST_EXECUTED;
@@ -207,7 +212,7 @@ static void handle_msg_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t co
 static void handle_msg_pre_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t ballot, uint64_t seq,
                                         const DepSet *deps, uint8_t exploded) {
     if (col < r->start_col) return;
-    if (col >= r->start_col + r->len[row]) return;                  /* :125-127 */
+    if (col >= r->start_col + r->len[row] || !held(r, row, col)) return;   /* :125-127 */
     Inst *in = at(r, row, col);
     if (in->status != ST_PREACCEPTING || (ballot > 0 && in->bal != ballot) || !in->has_lbk) return;   /* :129-134 */
     if ((in->pa_acks >> peer) & 1) return;                          /* :136-138 */
@@ -231,7 +236,7 @@ static void handle_msg_pre_accept_reply(EpRep *r, uint8_t peer, int row, uint32_
 /* messages.rs:348-436 */
 static void handle_msg_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t ballot) {
     if (col < r->start_col) return;
-    if (col >= r->start_col + r->len[row]) return;
+    if (col >= r->start_col + r->len[row] || !held(r, row, col)) return;
     Inst *in = at(r, row, col);
     if (in->status != ST_ACCEPTING || in->bal != ballot || !in->has_lbk) return;     /* :371-376 */
     if ((in->acc_acks >> peer) & 1) return;
@@ -257,7 +262,7 @@ void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_
         int row = r->id;
         uint32_t col = NONE;                                         /* mod.rs:485-496 first_null_slot */
         for (uint32_t c = r->exec_bars[row]; c < r->start_col + r->len[row]; c++)
-            if (at(r, row, c)->status == ST_NULL) { col = c; break; }
+            if (held(r, row, c) && at(r, row, c)->status == ST_NULL) { col = c; break; }
         if (col == NONE) { row_push(r, row, null_instance()); col = r->start_col + r->len[row] - 1; }
         DepSet deps = identify_deps(r, key[g]);
         uint64_t seq = 1 + max_seq_num(r, &deps);
@@ -287,7 +292,7 @@ void orc_ep_handle_pre_accept(void *h, const uint8_t *flags, const uint8_t *peer
         if (!(flags[g] & 1)) continue;
         int row = peer[g];                                           /* the command leader's own row */
         uint32_t c = col[g];
-        if (c < r->start_col) continue;
+        if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
         while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :33-36 */
         Inst *in = at(r, row, c);
         if (ballot[g] >= in->bal) {                                  /* :40 */
@@ -324,7 +329,7 @@ void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64
         int row = r->id;
         uint32_t ctl = order ? order[g] : CTL_IDENTITY;
         uint8_t before = 0;
-        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) before = at(r, row, col[g])->status;
+        if (held(r, row, col[g])) before = at(r, row, col[g])->status;
         for (int oi = 0; oi < R; oi++) {
             int p = (int)ctl_order(ctl, oi);
             if (p == r->id || p >= R) continue;
@@ -336,7 +341,7 @@ void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64
         }
         decision[g] = 0; d_seq[g] = 0;
         for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = NONE;
-        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) {
+        if (held(r, row, col[g])) {
             Inst *in = at(r, row, col[g]);
             if (before == ST_PREACCEPTING && in->status != ST_PREACCEPTING) {
                 decision[g] = in->status >= ST_COMMITTED ? ST_COMMITTED : ST_ACCEPTING;
@@ -364,7 +369,7 @@ void orc_ep_handle_accept(void *h, const uint8_t *flags, const uint8_t *peer, co
         if (!(flags[g] & 1)) continue;
         int row = peer[g];
         uint32_t c = col[g];
-        if (c < r->start_col) continue;
+        if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
         while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());
         Inst *in = at(r, row, c);
         if (ballot[g] >= in->bal) {
@@ -388,7 +393,7 @@ void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *
         int row = r->id;
         uint32_t ctl = order ? order[g] : CTL_IDENTITY;
         uint8_t before = 0;
-        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row]) before = at(r, row, col[g])->status;
+        if (held(r, row, col[g])) before = at(r, row, col[g])->status;
         for (int oi = 0; oi < R; oi++) {
             int p = (int)ctl_order(ctl, oi);
             if (p == r->id || p >= R) continue;
@@ -397,7 +402,7 @@ void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *
             handle_msg_accept_reply(r, (uint8_t)p, row, col[g], ballot[o]);
         }
         committed[g] = 0;
-        if (col[g] >= r->start_col && col[g] < r->start_col + r->len[row])
+        if (held(r, row, col[g]))
             committed[g] = (before == ST_ACCEPTING && at(r, row, col[g])->status >= ST_COMMITTED) ? 1 : 0;
     }
 }

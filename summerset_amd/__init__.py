@@ -1,7 +1,7 @@
 """summerset_amd -- MI355X-native batched multi-group consensus engine.
 
 Host-side mirror of the one hot path of josehu07/summerset this project
-accelerates: the MultiPaxos / Raft / RSPaxos quorum-check +
+accelerates: the MultiPaxos / Raft / RSPaxos / EPaxos quorum-check +
 log-advance + commit loop over thousands of independent replica groups, and the
 RS(3,2) GF(2^8) erasure encode.  All compute happens in hand-written HIP
 kernels inside libsummerset_hip.so, reached through the C-ABI of
@@ -11,4 +11,6 @@ from ._lib import SummersetError, SMR_CTL_IDENTITY, SMR_NO_REPLICA  # noqa: F401
 from .rscoding import RSCodewordBatch, rs_matrix, rs_shard_len  # noqa: F401
 from .multipaxos import MultiPaxosCluster  # noqa: F401
 from .raft import RaftLeaderGroup  # noqa: F401
+from .epaxos import EPaxosReplicaGroup  # noqa: F401
+from .repnothing import RepNothingReplica  # noqa: F401
 from . import shard, stream  # noqa: F401

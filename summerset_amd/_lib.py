@@ -76,6 +76,23 @@ class RaftAppendReply(C.Structure):
                 ("conflict_slot", C.c_void_p)]
 
 
+class EpCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("me", C.c_uint8), ("optimized_quorum", C.c_uint8),
+                ("reserved0", C.c_uint8), ("window", C.c_uint32), ("n_keys", C.c_uint32)]
+
+
+class EpMsg(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("flags", "peer", "col", "ballot", "seq", "deps", "key")]
+
+
+EP_DUMP_FIELDS = ("len", "commit_bars", "bal", "seq", "status", "key", "deps", "pa_acks", "acc_acks", "bk", "highest_cols",
+                  "counters")
+
+
+class EpDumpBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in EP_DUMP_FIELDS]
+
+
 SYMBOLS = [
     ("smr_last_error", C.c_char_p, []),
     ("smr_device_count", _i, []),
@@ -116,6 +133,14 @@ SYMBOLS = [
     ("smr_raft_replica_handle_request_vote", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_replica_handle_vote_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_replica_dump_votes", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),
+    ("smr_ep_replica_destroy", None, [_vp]),
+    ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),
+    ("smr_ep_handle_pre_accept", _i, [_vp, C.POINTER(EpMsg), C.POINTER(EpMsg), _vp]),
+    ("smr_ep_handle_accept", _i, [_vp, C.POINTER(EpMsg), C.POINTER(EpMsg), _vp]),
+    ("smr_ep_handle_pre_accept_replies", _i, [_vp] + [_vp] * 11),
+    ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
+    ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

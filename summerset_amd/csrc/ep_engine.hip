@@ -1,0 +1,560 @@
+// EPaxos command-leader / acceptor hot path over G groups (lane = group), one replica id per
+// group: dependency and sequence computation, PreAccept handling, the fast-quorum decision on
+// PreAcceptReplies, the slow-path Accept tally and the commit bars.
+//
+// Stands in for EPaxosReplica::{handle_req_batch (epaxos/request.rs:10-108), first_null_slot
+// (mod.rs:485-496), identify_deps / refresh_highest_cols / max_seq_num / DepSet::union
+// (dependency.rs:85-167), fast_quorum_eligibility (:175-240), get_enough_identical (:333-367),
+// handle_msg_pre_accept (messages.rs:10-93), handle_msg_pre_accept_reply (:96-270),
+// handle_msg_accept (:273-345), handle_msg_accept_reply (:348-436),
+// handle_logged_{pre_accept,accept,commit}_slot (durability.rs:10-163)}.
+// WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one key of a small key
+// space, which is all the dependency tracking looks at; dependency-graph execution
+// (execution.rs) is not built.
+//
+// Layout (group fastest): instance fields X[(row * W + (col & (W-1))) * G + g]; DepSets as R
+// consecutive such planes; the per-key highest columns hc[(key * R + row) * G + g].
+#include <string.h>
+
+#include <vector>
+
+#include "smr_common.h"
+
+namespace smr {
+
+constexpr int EMAXR = SMR_MAX_REPLICAS;
+constexpr uint32_t EP_NONE = 0xFFFFFFFFu;
+constexpr uint8_t EP_NO_KEY = 0xFF;
+enum { EST_NULL = 0, EST_PREACCEPTING = 1, EST_ACCEPTING = 2, EST_COMMITTED = 3, EST_EXECUTING = 4, EST_EXECUTED = 5 };
+
+struct EpView {
+    uint32_t G, W, Wmask, R, me, n_keys, simple_q, super_q;
+    uint64_t *bal, *seq;                 // [R][W][G]
+    uint8_t *status, *key, *bk;          // bk: has_lbk | has_rbk << 1 | source << 2
+    uint8_t *pa_acks, *acc_acks;
+    uint32_t *deps;                      // [R][W][R][G]
+    uint64_t *pa_seq;                    // my row only: [W][R][G]
+    uint32_t *pa_deps;                   // my row only: [W][R][R][G]
+    uint32_t *len, *commit_bars;         // [R][G]
+    uint32_t *hc;                        // [n_keys][R][G]
+    unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits
+};
+
+struct EpLane {
+    const EpView &v;
+    const uint32_t g;
+    unsigned int n_fast = 0, n_slow = 0, n_acc = 0;
+    __device__ __forceinline__ EpLane(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
+    __device__ __forceinline__ size_t ix(uint32_t row, uint32_t col) const { return ((size_t)row * v.W + (col & v.Wmask)) * v.G + g; }
+    __device__ __forceinline__ size_t dx(uint32_t row, uint32_t col, uint32_t i) const {
+        return (((size_t)row * v.W + (col & v.Wmask)) * v.R + i) * v.G + g;
+    }
+    __device__ __forceinline__ uint32_t &len(uint32_t row) const { return v.len[(size_t)row * v.G + g]; }
+    // is the column still in the row's ring of W instances (the harness guard)
+    __device__ __forceinline__ bool held(uint32_t row, uint32_t col) const {
+        const uint32_t end = len(row);
+        return col < end && col + v.W >= end;
+    }
+    __device__ __forceinline__ void push_null(uint32_t row) {            // mod.rs:467-480
+        const uint32_t col = len(row);
+        const size_t i = ix(row, col);
+        v.bal[i] = 0; v.seq[i] = 0; v.status[i] = EST_NULL; v.key[i] = EP_NO_KEY; v.bk[i] = 0;
+        v.pa_acks[i] = 0; v.acc_acks[i] = 0;
+        for (uint32_t k = 0; k < v.R; k++) v.deps[dx(row, col, k)] = EP_NONE;
+        len(row) = col + 1;
+    }
+    __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[EMAXR]) const {   // dependency.rs:113-137
+#pragma unroll
+        for (int i = 0; i < EMAXR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)key * v.R + i) * v.G + g] : EP_NONE;
+    }
+    __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[EMAXR]) const {         // dependency.rs:101-109
+        uint64_t m = 0;
+#pragma unroll
+        for (int row = 0; row < EMAXR; row++) {
+            if ((uint32_t)row >= v.R || d[row] == EP_NONE || !held(row, d[row])) continue;
+            const uint64_t s = v.seq[ix(row, d[row])];
+            if (s > m) m = s;
+        }
+        return m;
+    }
+    __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
+        if (key == EP_NO_KEY) return;
+        const size_t o = ((size_t)key * v.R + row) * v.G + g;
+        const uint32_t hc = v.hc[o];
+        if (hc == EP_NONE || col > hc) v.hc[o] = col;
+    }
+    __device__ __forceinline__ void logged_commit_slot(uint32_t row, uint32_t col) {             // durability.rs:104-135
+        uint32_t cb = v.commit_bars[(size_t)row * v.G + g];
+        if (col != cb) return;
+        while (cb < len(row) && held(row, cb)) {
+            const size_t i = ix(row, cb);
+            const uint32_t st = v.status[i];
+            if (st < EST_COMMITTED) break;
+            if (v.key[i] == EP_NO_KEY) v.status[i] = EST_EXECUTED;
+            cb++;
+        }
+        v.commit_bars[(size_t)row * v.G + g] = cb;
+    }
+    // messages.rs:348-436 on my instance (me, col)
+    __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t col, uint64_t ballot) {
+        const uint32_t row = v.me;
+        if (!held(row, col)) return;
+        const size_t i = ix(row, col);
+        if (v.status[i] != EST_ACCEPTING || v.bal[i] != ballot || !(v.bk[i] & 1)) return;   // :371-376
+        uint32_t acks = v.acc_acks[i];
+        if ((acks >> peer) & 1u) return;
+        acks |= 1u << peer;
+        v.acc_acks[i] = (uint8_t)acks;
+        if ((uint32_t)__popc(acks) >= v.simple_q) {                              // :386
+            v.status[i] = EST_COMMITTED;
+            n_acc++;
+            logged_commit_slot(row, col);
+        }
+    }
+    // messages.rs:96-270 on my instance (me, col); rd = the reply's DepSet
+    __device__ __forceinline__ void pre_accept_reply(uint32_t peer, uint32_t col, uint64_t ballot, uint64_t rseq,
+                                                     const uint32_t (&rd)[EMAXR], uint32_t exploded) {
+        const uint32_t row = v.me, R = v.R;
+        if (!held(row, col)) return;                                             // :125-127
+        const size_t i = ix(row, col);
+        if (v.status[i] != EST_PREACCEPTING || (ballot > 0 && v.bal[i] != ballot) || !(v.bk[i] & 1)) return;   // :129-134
+        uint32_t acks = v.pa_acks[i];
+        if ((acks >> peer) & 1u) return;                                         // :136-138
+        const uint32_t w = col & v.Wmask;
+        if (ballot > 0) {                                                        // :141-144
+            v.pa_seq[((size_t)w * R + peer) * v.G + g] = rseq;
+            for (uint32_t k = 0; k < R; k++) v.pa_deps[(((size_t)w * R + peer) * R + k) * v.G + g] = rd[k];
+            acks |= 1u << peer;
+            v.pa_acks[i] = (uint8_t)acks;
+        }
+        // dependency.rs:175-240 fast_quorum_eligibility
+        const uint32_t all_cnt = __popc(acks);
+        if (all_cnt < v.simple_q) return;
+        // the replies held, in registers: seq + DepSet of every acked peer
+        uint64_t ps[EMAXR]; uint32_t pd[EMAXR][EMAXR];
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++) {
+            const bool on = (uint32_t)p < R && ((acks >> p) & 1u);
+            ps[p] = on ? v.pa_seq[((size_t)w * R + p) * v.G + g] : 0;
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++)
+                pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] : EP_NONE;
+        }
+        // dependency.rs:333-367 get_enough_identical: size of the largest class of equal (seq, deps)
+        uint32_t max_cnt = 0; int best = -1;
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++) {
+            if (!((acks >> p) & 1u) || (uint32_t)p >= R) continue;
+            uint32_t same = 0;
+#pragma unroll
+            for (int q = 0; q < EMAXR; q++) {
+                if (!((acks >> q) & 1u) || (uint32_t)q >= R) continue;
+                bool eq = ps[q] == ps[p];
+#pragma unroll
+                for (int k = 0; k < EMAXR; k++) eq = eq && pd[q][k] == pd[p][k];
+                same += eq ? 1u : 0u;
+            }
+            if (same > max_cnt) { max_cnt = same; best = p; }
+        }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++)
+            if ((uint32_t)p < R && !((acks >> p) & 1u) && (uint32_t)p != v.me && ((exploded >> p) & 1u)) bad++;
+        uint64_t dseq = 0; uint32_t dd[EMAXR];
+        int next = 0;
+        if (max_cnt >= v.super_q) {                                              // fast path
+            next = EST_COMMITTED;
+            dseq = 0;
+#pragma unroll
+            for (int p = 0; p < EMAXR; p++) if (p == best) dseq = ps[p];
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++) {
+                dd[k] = EP_NONE;
+#pragma unroll
+                for (int p = 0; p < EMAXR; p++) if (p == best) dd[k] = pd[p][k];
+            }
+        } else if (max_cnt + (R - bad - all_cnt) < v.super_q) {                  // :221-236 slow path: union / max
+            next = EST_ACCEPTING;
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++) dd[k] = EP_NONE;
+#pragma unroll
+            for (int p = 0; p < EMAXR; p++) {
+                if (!((acks >> p) & 1u) || (uint32_t)p >= R) continue;
+                if (ps[p] > dseq) dseq = ps[p];
+#pragma unroll
+                for (int k = 0; k < EMAXR; k++) {                                // dependency.rs:85-97 union
+                    if (dd[k] != EP_NONE) { if (pd[p][k] != EP_NONE && pd[p][k] > dd[k]) dd[k] = pd[p][k]; }
+                    else dd[k] = pd[p][k];
+                }
+            }
+        }
+        if (next == 0) return;
+        v.seq[i] = dseq;
+        for (uint32_t k = 0; k < R; k++) {
+            uint32_t x = EP_NONE;
+#pragma unroll
+            for (int kk = 0; kk < EMAXR; kk++) if ((uint32_t)kk == k) x = dd[kk];
+            v.deps[dx(row, col, k)] = x;
+        }
+        if (next == EST_COMMITTED) {                                             // :158-206
+            v.status[i] = EST_COMMITTED;
+            n_fast++;
+            logged_commit_slot(row, col);
+        } else {                                                                 // :209-262
+            v.status[i] = EST_ACCEPTING;
+            n_slow++;
+            accept_reply(v.me, col, v.bal[i]);                                   // durability.rs:78-83
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        unsigned int c[3] = {n_fast, n_slow, n_acc};
+        for (int k = 0; k < 3; k++) {
+            unsigned int x = c[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (__lane_id() == 0 && x) atomicAdd(&v.counters[k], (unsigned long long)x);
+        }
+    }
+};
+
+// request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35)
+__global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const uint8_t *__restrict__ key,
+                                                         const uint8_t *__restrict__ exploded, uint8_t *__restrict__ m_flags,
+                                                         uint32_t *__restrict__ m_col, uint64_t *__restrict__ m_seq,
+                                                         uint32_t *__restrict__ m_deps) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        uint8_t of = 0; uint32_t oc = 0; uint64_t os = 0;
+        uint32_t d[EMAXR];
+#pragma unroll
+        for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
+        const uint32_t k = key[g];
+        if (k != EP_NO_KEY) {
+            const uint32_t row = v.me;
+            uint32_t col = EP_NONE;                                              // mod.rs:485-496 (exec_bars stay 0 here)
+            const uint32_t end = L.len(row);
+            for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
+                if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
+            if (col == EP_NONE) { L.push_null(row); col = L.len(row) - 1; }
+            L.identify_deps(k, d);
+            const uint64_t seq = 1 + L.max_seq_num(d);
+            const size_t i = L.ix(row, col);
+            const uint64_t bal = (uint64_t)(v.me + 1);                           // make_default_ballot
+            v.bal[i] = bal; v.seq[i] = seq; v.key[i] = (uint8_t)k;
+            for (uint32_t q = 0; q < v.R; q++) {
+                uint32_t x = EP_NONE;
+#pragma unroll
+                for (int qq = 0; qq < EMAXR; qq++) if ((uint32_t)qq == q) x = d[qq];
+                v.deps[L.dx(row, col, q)] = x;
+            }
+            L.refresh_highest_cols(row, col, k);
+            v.bk[i] = (uint8_t)(v.bk[i] | 1u);                                   // fresh LeaderBookkeeping
+            v.pa_acks[i] = 0; v.acc_acks[i] = 0;
+            v.status[i] = EST_PREACCEPTING;
+            of = 1; oc = col; os = seq;
+            L.pre_accept_reply(v.me, col, bal, seq, d, exploded ? exploded[g] : 0u);
+        }
+        m_flags[g] = of; m_col[g] = oc; m_seq[g] = os;
+#pragma unroll
+        for (int i = 0; i < EMAXR; i++) if ((uint32_t)i < v.R) m_deps[(size_t)i * v.G + g] = d[i];
+    }
+    L.flush();
+}
+
+// messages.rs:10-93 (ACCEPT = false) / :273-345 (ACCEPT = true) + the acceptor's WAL completion
+template <bool ACCEPT>
+__global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const uint8_t *__restrict__ flags,
+                                                          const uint8_t *__restrict__ peer, const uint32_t *__restrict__ col,
+                                                          const uint64_t *__restrict__ ballot, const uint64_t *__restrict__ seq,
+                                                          const uint32_t *__restrict__ deps, const uint8_t *__restrict__ key,
+                                                          uint8_t *__restrict__ r_flags, uint64_t *__restrict__ r_ballot,
+                                                          uint64_t *__restrict__ r_seq, uint32_t *__restrict__ r_deps) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        uint8_t of = 0; uint64_t ob = 0, os = 0;
+        uint32_t d[EMAXR];
+#pragma unroll
+        for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
+        if (flags[g] & 1) {
+            const uint32_t row = peer[g], c = col[g], k = key[g];
+            const uint64_t b = ballot[g];
+            if (!(c < L.len(row) && !L.held(row, c))) {                          // col < start_col analogue
+                while (L.len(row) <= c) L.push_null(row);                        // :33-36
+                const size_t i = L.ix(row, c);
+                if (b >= v.bal[i]) {                                             // :40
+                    uint32_t in[EMAXR];
+#pragma unroll
+                    for (int q = 0; q < EMAXR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
+                    uint64_t s = seq[g];
+                    if (!ACCEPT) {
+                        uint32_t my[EMAXR];
+                        L.identify_deps(k, my);
+#pragma unroll
+                        for (int q = 0; q < EMAXR; q++) {                        // deps.union(&my_deps)
+                            if (in[q] != EP_NONE) { if (my[q] != EP_NONE && my[q] > in[q]) in[q] = my[q]; }
+                            else in[q] = my[q];
+                        }
+                        const uint64_t ms = 1 + L.max_seq_num(my);
+                        if (ms > s) s = ms;
+                    }
+                    v.bal[i] = b; v.status[i] = ACCEPT ? EST_ACCEPTING : EST_PREACCEPTING; v.seq[i] = s; v.key[i] = (uint8_t)k;
+                    for (uint32_t q = 0; q < v.R; q++) {
+                        uint32_t x = EP_NONE;
+#pragma unroll
+                        for (int qq = 0; qq < EMAXR; qq++) if ((uint32_t)qq == q) x = in[qq];
+                        v.deps[L.dx(row, c, q)] = x;
+                    }
+                    L.refresh_highest_cols(row, c, k);
+                    const uint32_t bk = v.bk[i];
+                    v.bk[i] = (uint8_t)((bk & 1u) | 2u | (row << 2));            // replica_bk.source = peer
+                    if (bk & 1u) {                                               // durability.rs:25 / :78: leader_bk first
+                        if (ACCEPT) L.accept_reply(v.me, c, b); else L.pre_accept_reply(v.me, c, b, s, in, 0u);
+                    } else {
+                        of = 1; ob = b; os = s;
+#pragma unroll
+                        for (int q = 0; q < EMAXR; q++) d[q] = in[q];
+                    }
+                }
+            }
+        }
+        r_flags[g] = of; r_ballot[g] = ob;
+        if (!ACCEPT) {
+            r_seq[g] = os;
+#pragma unroll
+            for (int i = 0; i < EMAXR; i++) if ((uint32_t)i < v.R) r_deps[(size_t)i * v.G + g] = d[i];
+        }
+    }
+    L.flush();
+}
+
+// the PreAcceptReplies to my instance (me, col[g])
+__global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
+                                                                    const uint64_t *__restrict__ ballot,
+                                                                    const uint64_t *__restrict__ seq,
+                                                                    const uint32_t *__restrict__ deps,
+                                                                    const uint8_t *__restrict__ flags,
+                                                                    const uint32_t *__restrict__ order,
+                                                                    const uint8_t *__restrict__ exploded,
+                                                                    uint8_t *__restrict__ decision, uint64_t *__restrict__ d_seq,
+                                                                    uint32_t *__restrict__ d_deps) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        const uint32_t c = col[g], row = v.me, R = v.R;
+        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+        const uint32_t ex = exploded ? exploded[g] : 0u;
+        const bool h = L.held(row, c);
+        const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
+        for (uint32_t oi = 0; oi < R; oi++) {
+            const uint32_t p = (ctl >> (3 * oi)) & 7u;
+            if (p == v.me || p >= R) continue;
+            const size_t o = (size_t)p * v.G + g;
+            if (!(flags[o] & 1)) continue;
+            uint32_t rd[EMAXR];
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++) rd[k] = (uint32_t)k < R ? deps[((size_t)p * R + k) * v.G + g] : EP_NONE;
+            L.pre_accept_reply(p, c, ballot[o], seq[o], rd, ex);
+        }
+        uint8_t dec = 0; uint64_t ds = 0;
+        uint32_t after = h ? v.status[L.ix(row, c)] : 0u;
+        if (h && before == EST_PREACCEPTING && after != EST_PREACCEPTING) {
+            dec = after >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING;
+            ds = v.seq[L.ix(row, c)];
+        }
+        decision[g] = dec; d_seq[g] = ds;
+        for (uint32_t k = 0; k < R; k++) d_deps[(size_t)k * v.G + g] = dec ? v.deps[L.dx(row, c, k)] : EP_NONE;
+    }
+    L.flush();
+}
+
+__global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
+                                                                const uint64_t *__restrict__ ballot,
+                                                                const uint8_t *__restrict__ flags,
+                                                                const uint32_t *__restrict__ order,
+                                                                uint8_t *__restrict__ committed) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        const uint32_t c = col[g], row = v.me, R = v.R;
+        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+        const bool h = L.held(row, c);
+        const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
+        for (uint32_t oi = 0; oi < R; oi++) {
+            const uint32_t p = (ctl >> (3 * oi)) & 7u;
+            if (p == v.me || p >= R) continue;
+            const size_t o = (size_t)p * v.G + g;
+            if (!(flags[o] & 1)) continue;
+            L.accept_reply(p, c, ballot[o]);
+        }
+        committed[g] = (h && before == EST_ACCEPTING && v.status[L.ix(row, c)] >= EST_COMMITTED) ? 1 : 0;
+    }
+    L.flush();
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+struct smr_ep_replica {
+    smr_ep_cfg cfg;
+    EpView v;
+    Arena arena;
+};
+
+namespace smr {
+template <typename T> static void ecarve(Arena &a, T *&p, size_t n, bool dry) {
+    size_t off = a.reserve(n * sizeof(T));
+    if (!dry) p = a.at<T>(off);
+}
+static void ep_layout(smr_ep_replica *e, bool dry) {
+    Arena &a = e->arena;
+    a.used = 0;
+    EpView &v = e->v;
+    const size_t G = e->cfg.n_groups, W = e->cfg.window, R = e->cfg.population, K = e->cfg.n_keys;
+    ecarve(a, v.bal, R * W * G, dry); ecarve(a, v.seq, R * W * G, dry);
+    ecarve(a, v.status, R * W * G, dry); ecarve(a, v.key, R * W * G, dry); ecarve(a, v.bk, R * W * G, dry);
+    ecarve(a, v.pa_acks, R * W * G, dry); ecarve(a, v.acc_acks, R * W * G, dry);
+    ecarve(a, v.deps, R * W * R * G, dry);
+    ecarve(a, v.pa_seq, W * R * G, dry); ecarve(a, v.pa_deps, W * R * R * G, dry);
+    ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry);
+    ecarve(a, v.hc, K * R * G, dry);
+    ecarve(a, v.counters, 4, dry);
+}
+}  // namespace smr
+
+extern "C" {
+
+int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
+    if (!cfg || !out) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (cfg->n_groups == 0) return fail(SMR_ERR_ARG, "epaxos: n_groups is zero");
+    if (cfg->population < 3 || cfg->population > SMR_MAX_REPLICAS) return fail(SMR_ERR_ARG, "epaxos: population must be in 3..8");
+    if (cfg->me >= cfg->population) return fail(SMR_ERR_ARG, "epaxos: replica id out of range");
+    if (!cfg->window || (cfg->window & (cfg->window - 1)) || cfg->window < 8)
+        return fail(SMR_ERR_ARG, "epaxos: window must be a power of two >= 8");
+    if (cfg->n_keys == 0 || cfg->n_keys > 255) return fail(SMR_ERR_ARG, "epaxos: n_keys must be in 1..255");
+    smr_ep_replica *e = new smr_ep_replica();
+    e->cfg = *cfg;
+    memset(&e->v, 0, sizeof(e->v));
+    ep_layout(e, true);
+    e->arena.size = e->arena.used + 256;
+    hipError_t err = hipMalloc((void **)&e->arena.base, e->arena.size);
+    if (err != hipSuccess) { delete e; return fail(SMR_ERR_DEVICE, std::string("epaxos: hipMalloc: ") + hipGetErrorString(err)); }
+    ep_layout(e, false);
+    EpView &v = e->v;
+    const uint32_t R = cfg->population;
+    v.G = cfg->n_groups; v.W = cfg->window; v.Wmask = cfg->window - 1; v.R = R; v.me = cfg->me; v.n_keys = cfg->n_keys;
+    v.simple_q = R / 2 + 1;                                                      // mod.rs:693
+    v.super_q = cfg->optimized_quorum ? R / 2 + (R / 2 + 1) / 2 : (R / 2) * 2;   // mod.rs:694-698
+    err = hipMemset(e->arena.base, 0, e->arena.size);
+    if (err == hipSuccess) err = hipMemset(v.hc, 0xFF, (size_t)cfg->n_keys * R * v.G * 4);
+    if (err == hipSuccess) err = hipMemset(v.deps, 0xFF, (size_t)R * v.W * R * v.G * 4);
+    if (err == hipSuccess) err = hipMemset(v.key, 0xFF, (size_t)R * v.W * v.G);
+    if (err != hipSuccess) {
+        (void)hipFree(e->arena.base); delete e;
+        return fail(SMR_ERR_DEVICE, std::string("epaxos: init: ") + hipGetErrorString(err));
+    }
+    *out = e;
+    return SMR_OK;
+}
+
+void smr_ep_replica_destroy(smr_ep_replica *e) {
+    if (!e) return;
+    if (e->arena.base) (void)hipFree(e->arena.base);
+    delete e;
+}
+
+#define EP_GRID(e) dim3(((e)->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream
+
+int smr_ep_propose(smr_ep_replica *e, const uint8_t *key_dev, const uint8_t *exploded_dev, const smr_ep_msg *out,
+                   void *stream) {
+    if (!e || !key_dev || !out || !out->flags || !out->col || !out->seq || !out->deps)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    hipLaunchKernelGGL(ep_propose_kernel, EP_GRID(e), e->v, key_dev, exploded_dev, out->flags, out->col, out->seq, out->deps);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+static int ep_acceptor(smr_ep_replica *e, bool accept, const smr_ep_msg *m, const smr_ep_msg *r, void *stream) {
+    if (!e || !m || !r || !m->flags || !m->peer || !m->col || !m->ballot || !m->seq || !m->deps || !m->key || !r->flags ||
+        !r->ballot || (!accept && (!r->seq || !r->deps)))
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (accept)
+        hipLaunchKernelGGL(ep_acceptor_kernel<true>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
+                           m->key, r->flags, r->ballot, r->seq, r->deps);
+    else
+        hipLaunchKernelGGL(ep_acceptor_kernel<false>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
+                           m->key, r->flags, r->ballot, r->seq, r->deps);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_ep_handle_pre_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream) {
+    return ep_acceptor(e, false, msg, reply, stream);
+}
+
+int smr_ep_handle_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream) {
+    return ep_acceptor(e, true, msg, reply, stream);
+}
+
+int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                     const uint64_t *seq_dev, const uint32_t *deps_dev, const uint8_t *flags_dev,
+                                     const uint32_t *order_dev, const uint8_t *exploded_dev, uint8_t *decision_dev,
+                                     uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream) {
+    if (!e || !col_dev || !ballot_dev || !seq_dev || !deps_dev || !flags_dev || !decision_dev || !d_seq_dev || !d_deps_dev)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    hipLaunchKernelGGL(ep_pre_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev,
+                       order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                 const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream) {
+    if (!e || !col_dev || !ballot_dev || !flags_dev || !committed_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    hipLaunchKernelGGL(ep_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, flags_dev, order_dev, committed_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
+    if (!e || !hb) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const EpView &v = e->v;
+    const size_t G = v.G, W = v.W, R = v.R, K = v.n_keys;
+#define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+    D2H(hb->len, v.len, R * G * 4); D2H(hb->commit_bars, v.commit_bars, R * G * 4);
+    D2H(hb->highest_cols, v.hc, K * R * G * 4);
+    std::vector<uint64_t> bal(R * W * G), seq(R * W * G);
+    std::vector<uint8_t> st(R * W * G), key(R * W * G), bk(R * W * G), pa(R * W * G), ac(R * W * G);
+    std::vector<uint32_t> deps(R * W * R * G);
+    D2H(bal.data(), v.bal, R * W * G * 8); D2H(seq.data(), v.seq, R * W * G * 8);
+    D2H(st.data(), v.status, R * W * G); D2H(key.data(), v.key, R * W * G); D2H(bk.data(), v.bk, R * W * G);
+    D2H(pa.data(), v.pa_acks, R * W * G); D2H(ac.data(), v.acc_acks, R * W * G);
+    D2H(deps.data(), v.deps, R * W * R * G * 4);
+    unsigned long long c[4];
+    D2H(c, v.counters, sizeof(c));
+#undef D2H
+    hb->counters[0] = c[0]; hb->counters[1] = c[1]; hb->counters[2] = c[2];
+    // canonical form: only the last W columns of each row are state; deps as [row][w][g][i]
+    for (size_t row = 0; row < R; row++)
+        for (size_t w = 0; w < W; w++)
+            for (size_t g = 0; g < G; g++) {
+                const size_t o = (row * W + w) * G + g;
+                const uint32_t end = hb->len[row * G + g], lo = end > W ? end - (uint32_t)W : 0;
+                // the column this cell holds, if any
+                bool live = false;
+                if (end > lo) {
+                    uint32_t cc = (lo & ~(uint32_t)(W - 1)) | (uint32_t)w;
+                    if (cc < lo) cc += (uint32_t)W;
+                    live = cc < end;
+                }
+                hb->bal[o] = live ? bal[o] : 0; hb->seq[o] = live ? seq[o] : 0; hb->status[o] = live ? st[o] : 0;
+                hb->key[o] = live ? key[o] : 0xFF; hb->pa_acks[o] = live ? pa[o] : 0; hb->acc_acks[o] = live ? ac[o] : 0;
+                hb->bk[o] = live ? bk[o] : 0;
+                for (size_t i = 0; i < R; i++) hb->deps[o * R + i] = live ? deps[((row * W + w) * R + i) * G + g] : 0xFFFFFFFFu;
+            }
+    return SMR_OK;
+}
+
+}  // extern "C"
