@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change runs on the side stream (0 = off)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -104,6 +105,114 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
                                "sample": "%d codewords of L=4099 through oracle/rs_oracle.c table encoder "
                                          "(padding copy included)" % done}
     return res
+
+
+def _time_us(torch, fn, iters):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def raft_leg(torch, dev, S=32, ticks=24):
+    """BASELINE config 3: Raft, 65 536 groups x 5 replicas, leader-side AppendEntriesReply match-index quorum
+    (raft/messages.rs:222-388): per tick S appends, then one reply per follower with end_slot = leader_last -
+    lag (lag 0..3 seeded), 5 % dropped, 0.5 % stale-term, 0.5 % conflict replies."""
+    from summerset_amd import RaftLeaderGroup
+    G, R, W = 65536, 5, 512
+    eng = RaftLeaderGroup(G, R, leader_id=0, window=W, term=2)
+    rng = np.random.default_rng(0x5EED5EED)
+    n_new = torch.full((G,), S, dtype=torch.int32, device=dev)
+    pool = []
+    for t in range(ticks):
+        last = 1 + S * (t + 1) - 1
+        lag = rng.integers(0, 4, (R, G))
+        u = rng.random((R, G))
+        flags = (u >= 0.05).astype(np.uint8)
+        term = np.full((R, G), 2, np.uint64)
+        term[(u >= 0.05) & (u < 0.055)] = 1                                   # stale term: ignored
+        conflict = (u >= 0.055) & (u < 0.06)
+        flags[conflict] |= 2
+        end_slot = np.maximum(last - lag, 0).astype(np.uint32)
+        pool.append(tuple(torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else
+                                           (x.view(np.int32) if x.dtype == np.uint32 else x)).to(dev)
+                          for x in (term, end_slot, flags, np.full((R, G), 2, np.uint64),
+                                    np.maximum(end_slot.astype(np.int64) - 1, 1).astype(np.uint32))))
+    times = []
+
+    def tick(i):
+        eng.handle_req_batch(n_new)
+        rt, es, fl, ct, cs = pool[i]
+        eng.handle_msg_append_entries_reply(rt, es, fl, ct, cs)
+
+    t0 = time.perf_counter()
+    us = _time_us(torch, tick, ticks)
+    commits = eng.total_commits()
+    # the replies kernel alone, re-running the last tick's replies (idempotent once applied)
+    rt, es, fl, ct, cs = pool[-1]
+    us_k = _time_us(torch, lambda i: eng.handle_msg_append_entries_reply(rt, es, fl, ct, cs), 20)
+    alg = G * (280 + 8 * S)                                                   # SURVEY §8d
+    return {"workload": "Raft leader, %d groups x 5 replicas, S=%d appends + 4 AppendEntriesReply per group per tick "
+                        "(lag 0-3, 5%% dropped, 0.5%% stale term, 0.5%% conflict)" % (G, S),
+            "value": commits / (us * 1e-6 * ticks), "unit": "slots/s", "us_per_tick": us,
+            "roofline": {"bound": "hbm", "kernel": "raft_replies_kernel", "achieved": alg / (us_k * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us_k * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us_k, "traffic": None}}
+
+
+def epaxos_leg(torch, dev, ticks=16):
+    """BASELINE config 5 (one replica's share): EPaxos, 65 536 groups x 5 replicas, optimized quorums (3/3): per tick
+    every group's replica 0 proposes one instance on a Zipf(0.99) key out of 64 and receives the 4
+    PreAcceptReplies, 10 % of which carry an extra dependency (dependency.rs:175-240, messages.rs:96-270)."""
+    from summerset_amd import EPaxosReplicaGroup
+    G, R, W, K = 65536, 5, 32, 64
+    eng = EPaxosReplicaGroup(G, R, me=0, window=W, n_keys=K)
+    rng = np.random.default_rng(0x5EED5EED)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x.view(np.int64) if x.dtype == np.uint64 else
+                                                          (x.view(np.int32) if x.dtype == np.uint32 else x))).to(dev)
+    keys = [i32(rng.choice(K, G, p=zipf).astype(np.uint8)) for _ in range(ticks)]
+    extra = [rng.random((R, G)) < 0.1 for _ in range(ticks)]
+    flags = np.ones((R, G), np.uint8)
+    flags[0] = 0
+    flags_d = i32(flags)
+    ballot_d = i32(np.full((R, G), 1, np.uint64))
+    t_prop = t_rep = 0.0
+    committed = 0
+    for t in range(ticks):
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        e0.record()
+        m = eng.handle_req_batch(keys[t])
+        e1.record()
+        # the peers' answers: my (seq, deps), 10 % with seq + 1 and one more dependency (stand-in for the
+        # four acceptors, built on the device from the PreAccept just produced; not timed)
+        ex = torch.from_numpy(extra[t]).to(dev)
+        seq = (m["seq"].unsqueeze(0).repeat(R, 1) + ex.to(torch.int64)).contiguous()
+        deps = m["deps"].unsqueeze(0).repeat(R, 1, 1)
+        deps[:, 1, :] = torch.where(ex, torch.clamp(deps[:, 1, :], min=0) + 1, deps[:, 1, :])
+        deps = deps.contiguous()
+        e2.record()
+        r = eng.handle_msg_pre_accept_reply(m["col"], ballot_d, seq, deps, flags_d)
+        e3.record()
+        torch.cuda.synchronize()
+        t_prop += e0.elapsed_time(e1)
+        t_rep += e2.elapsed_time(e3)
+        committed += int((r["decision"] == 3).sum())
+    us_rep = t_rep / ticks * 1e3
+    alg = G * 370                                                             # SURVEY §8d: <= 370 B per instance
+    return {"workload": "EPaxos command leader, %d groups x 5 replicas, 1 proposal per group per tick on Zipf(0.99) keys "
+                        "of 64, 4 PreAcceptReplies each, 10%% with an extra dependency" % G,
+            "value": committed / (t_rep * 1e-3), "unit": "fast-path commits/s of the reply kernel",
+            "fast_path_fraction": committed / (G * ticks), "propose_kernel_us": t_prop / ticks * 1e3,
+            "roofline": {"bound": "hbm", "kernel": "ep_pre_accept_replies_kernel", "achieved": alg / (us_rep * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us_rep * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us_rep, "traffic": None}}
+
 
 
 def cpu_leg(args, seconds):
@@ -234,6 +343,9 @@ def main():
             line["cpu_baseline"] = cpu_leg(args, args.cpu_seconds)
         if not args.no_rs:
             line["rs_encode"] = rs_leg(torch, dev, not args.no_cpu, args.cpu_seconds)
+        if not args.no_extra:
+            line["raft_quorum"] = raft_leg(torch, dev)
+            line["epaxos_fast_quorum"] = epaxos_leg(torch, dev)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

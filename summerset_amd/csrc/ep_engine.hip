@@ -36,6 +36,7 @@ struct EpView {
     uint64_t *pa_seq;                    // my row only: [W][R][G]
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
     uint32_t *len, *commit_bars;         // [R][G]
+    uint32_t *my_nulls;                  // [G] null instances currently in my own row (first_null_slot need not scan at 0)
     uint32_t *hc;                        // [n_keys][R][G]
     unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits
 };
@@ -62,6 +63,7 @@ struct EpLane {
         v.pa_acks[i] = 0; v.acc_acks[i] = 0;
         for (uint32_t k = 0; k < v.R; k++) v.deps[dx(row, col, k)] = EP_NONE;
         len(row) = col + 1;
+        if (row == v.me) v.my_nulls[g] += 1;
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[EMAXR]) const {   // dependency.rs:113-137
 #pragma unroll
@@ -233,9 +235,11 @@ __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const u
             const uint32_t row = v.me;
             uint32_t col = EP_NONE;                                              // mod.rs:485-496 (exec_bars stay 0 here)
             const uint32_t end = L.len(row);
-            for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
-                if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
+            if (v.my_nulls[g] != 0)                                              // only a PreAccept / Accept for my own row pads it
+                for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
+                    if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
             if (col == EP_NONE) { L.push_null(row); col = L.len(row) - 1; }
+            v.my_nulls[g] -= 1;                                                  // the slot stops being null
             L.identify_deps(k, d);
             const uint64_t seq = 1 + L.max_seq_num(d);
             const size_t i = L.ix(row, col);
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
                 while (L.len(row) <= c) L.push_null(row);                        // :33-36
                 const size_t i = L.ix(row, c);
                 if (b >= v.bal[i]) {                                             // :40
+                    if (row == v.me && v.status[i] == EST_NULL) v.my_nulls[g] -= 1;
                     uint32_t in[EMAXR];
 #pragma unroll
                     for (int q = 0; q < EMAXR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
@@ -328,7 +333,65 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
     L.flush();
 }
 
-// the PreAcceptReplies to my instance (me, col[g])
+// dependency.rs:175-240 fast_quorum_eligibility over a reply table held in registers (row p valid iff
+// bit p of acks): 0 = undecided, else the Status to enter with (dseq, dd)
+template <int NR>
+__device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uint64_t (&ps)[NR], const uint32_t (&pd)[NR][NR],
+                                       uint32_t exploded, uint64_t &dseq, uint32_t (&dd)[NR]) {
+    const uint32_t R = v.R, all_cnt = __popc(acks);
+    if (all_cnt < v.simple_q) return 0;
+    // dependency.rs:333-367 get_enough_identical: the largest class of equal (seq, deps)
+    uint32_t max_cnt = 0; int best = -1;
+#pragma unroll
+    for (int p = 0; p < NR; p++) {
+        if (!((acks >> p) & 1u)) continue;
+        uint32_t same = 0;
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            bool eq = ((acks >> q) & 1u) && ps[q] == ps[p];
+#pragma unroll
+            for (int k = 0; k < NR; k++) eq = eq && pd[q][k] == pd[p][k];
+            same += eq ? 1u : 0u;
+        }
+        if (same > max_cnt) { max_cnt = same; best = p; }
+    }
+    if (max_cnt >= v.super_q) {                                              // fast path
+        dseq = 0;
+#pragma unroll
+        for (int p = 0; p < NR; p++) if (p == best) dseq = ps[p];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            dd[k] = EP_NONE;
+#pragma unroll
+            for (int p = 0; p < NR; p++) if (p == best) dd[k] = pd[p][k];
+        }
+        return EST_COMMITTED;
+    }
+    uint32_t bad = 0;
+#pragma unroll
+    for (int p = 0; p < NR; p++)
+        if ((uint32_t)p < R && !((acks >> p) & 1u) && (uint32_t)p != v.me && ((exploded >> p) & 1u)) bad++;
+    if (max_cnt + (R - bad - all_cnt) >= v.super_q) return 0;                // :221-236 may still be reached
+    dseq = 0;                                                                // slow path: max of seqs, union of deps
+#pragma unroll
+    for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
+#pragma unroll
+    for (int p = 0; p < NR; p++) {
+        if (!((acks >> p) & 1u)) continue;
+        if (ps[p] > dseq) dseq = ps[p];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {                                       // dependency.rs:85-97 union
+            if (dd[k] != EP_NONE) { if (pd[p][k] != EP_NONE && pd[p][k] > dd[k]) dd[k] = pd[p][k]; }
+            else dd[k] = pd[p][k];
+        }
+    }
+    return EST_ACCEPTING;
+}
+
+// The PreAcceptReplies to my instance (me, col[g]), applied in peer order exactly as one
+// handle_msg_pre_accept_reply call each (messages.rs:96-270) -- but on a register copy of the
+// instance and of its reply table: every input is loaded up front, the result is stored once.
+template <int NR>
 __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
                                                                     const uint64_t *__restrict__ ballot,
                                                                     const uint64_t *__restrict__ seq,
@@ -341,29 +404,82 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     if (g < v.G) {
-        const uint32_t c = col[g], row = v.me, R = v.R;
+        const uint32_t c = col[g], row = v.me, R = v.R, w = c & v.Wmask;
         const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
         const uint32_t ex = exploded ? exploded[g] : 0u;
         const bool h = L.held(row, c);
-        const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
+        const size_t i = L.ix(row, c);
+        // the incoming replies
+        uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const bool on = (uint32_t)p < R && (uint32_t)p != v.me;
+            const size_t o = (size_t)p * v.G + g;
+            in_f[p] = on ? flags[o] : 0u; in_b[p] = on ? ballot[o] : 0ull; in_s[p] = on ? seq[o] : 0ull;
+#pragma unroll
+            for (int k = 0; k < NR; k++) in_d[p][k] = (on && (uint32_t)k < R) ? deps[((size_t)p * R + k) * v.G + g] : EP_NONE;
+        }
+        // the instance and the replies it already holds
+        uint32_t st = h ? v.status[i] : 0u, acks = h ? v.pa_acks[i] : 0u;
+        const uint64_t b = h ? v.bal[i] : 0ull;
+        const uint32_t bk = h ? v.bk[i] : 0u;
+        const uint32_t before = st, acks0 = acks;
+        uint64_t ps[NR]; uint32_t pd[NR][NR];
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const bool on = (acks >> p) & 1u;
+            ps[p] = on ? v.pa_seq[((size_t)w * R + p) * v.G + g] : 0ull;
+#pragma unroll
+            for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] : EP_NONE;
+        }
+        uint64_t dseq = 0; uint32_t dd[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
         for (uint32_t oi = 0; oi < R; oi++) {
             const uint32_t p = (ctl >> (3 * oi)) & 7u;
             if (p == v.me || p >= R) continue;
-            const size_t o = (size_t)p * v.G + g;
-            if (!(flags[o] & 1)) continue;
-            uint32_t rd[EMAXR];
+            uint32_t f = 0; uint64_t rb = 0, rs = 0;
 #pragma unroll
-            for (int k = 0; k < EMAXR; k++) rd[k] = (uint32_t)k < R ? deps[((size_t)p * R + k) * v.G + g] : EP_NONE;
-            L.pre_accept_reply(p, c, ballot[o], seq[o], rd, ex);
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = in_f[q]; rb = in_b[q]; rs = in_s[q]; }
+            if (!(f & 1u) || !h) continue;
+            if (st != EST_PREACCEPTING || (rb > 0 && b != rb) || !(bk & 1u)) continue;   // :129-134
+            if ((acks >> p) & 1u) continue;                                      // :136-138
+            if (rb > 0) {                                                        // :141-144
+#pragma unroll
+                for (int q = 0; q < NR; q++)
+                    if ((uint32_t)q == p) {
+                        ps[q] = rs;
+#pragma unroll
+                        for (int k = 0; k < NR; k++) pd[q][k] = in_d[q][k];
+                    }
+                acks |= 1u << p;
+            }
+            const int next = ep_eval<NR>(v, acks, ps, pd, ex, dseq, dd);
+            if (next) st = (uint32_t)next;
         }
-        uint8_t dec = 0; uint64_t ds = 0;
-        uint32_t after = h ? v.status[L.ix(row, c)] : 0u;
-        if (h && before == EST_PREACCEPTING && after != EST_PREACCEPTING) {
-            dec = after >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING;
-            ds = v.seq[L.ix(row, c)];
+        // write back: new replies, the ack mask, the decision
+        const uint32_t fresh = acks & ~acks0;
+#pragma unroll
+        for (int p = 0; p < NR; p++)
+            if ((fresh >> p) & 1u) {
+                v.pa_seq[((size_t)w * R + p) * v.G + g] = ps[p];
+#pragma unroll
+                for (int k = 0; k < NR; k++)
+                    if ((uint32_t)k < R) v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] = pd[p][k];
+            }
+        if (fresh) v.pa_acks[i] = (uint8_t)acks;
+        uint8_t dec = 0;
+        if (h && before == EST_PREACCEPTING && st != EST_PREACCEPTING) {
+            v.seq[i] = dseq;
+#pragma unroll
+            for (int k = 0; k < NR; k++) if ((uint32_t)k < R) v.deps[L.dx(row, c, k)] = dd[k];
+            v.status[i] = (uint8_t)st;
+            if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c); dec = EST_COMMITTED; }   // :158-206
+            else { L.n_slow++; L.accept_reply(v.me, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
         }
-        decision[g] = dec; d_seq[g] = ds;
-        for (uint32_t k = 0; k < R; k++) d_deps[(size_t)k * v.G + g] = dec ? v.deps[L.dx(row, c, k)] : EP_NONE;
+        decision[g] = dec; d_seq[g] = dec ? dseq : 0ull;
+#pragma unroll
+        for (int k = 0; k < NR; k++) if ((uint32_t)k < R) d_deps[(size_t)k * v.G + g] = dec ? dd[k] : EP_NONE;
     }
     L.flush();
 }
@@ -417,7 +533,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     ecarve(a, v.pa_acks, R * W * G, dry); ecarve(a, v.acc_acks, R * W * G, dry);
     ecarve(a, v.deps, R * W * R * G, dry);
     ecarve(a, v.pa_seq, W * R * G, dry); ecarve(a, v.pa_deps, W * R * R * G, dry);
-    ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry);
+    ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry);
     ecarve(a, v.hc, K * R * G, dry);
     ecarve(a, v.counters, 4, dry);
 }
@@ -503,8 +619,12 @@ int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev,
                                      uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream) {
     if (!e || !col_dev || !ballot_dev || !seq_dev || !deps_dev || !flags_dev || !decision_dev || !d_seq_dev || !d_deps_dev)
         return fail(SMR_ERR_ARG, "epaxos: null argument");
-    hipLaunchKernelGGL(ep_pre_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev,
-                       order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
+    if (e->v.R <= 5)
+        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<5>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev,
+                           order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
+    else
+        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<EMAXR>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev,
+                           flags_dev, order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
