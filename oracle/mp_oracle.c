@@ -628,10 +628,14 @@ void orc_mp_tick(void *h, const uint8_t *timeout_rep, const uint8_t *timeout_src
                 heard_heartbeat(r, r->id, r->hb_bal, r->hb_commit, r->hb_exec, r->hb_snap);
                 drain(r, NULL, NO_LEADER);
             }
+            /* LS-1 order of the peers' heartbeats at a replica: the replica it currently follows first
+             * (the one heartbeat that moves its commit bar), then the others by ascending id */
             for (int i = 0; i < R; i++) {
                 Replica *r = &reps[i];
-                for (int s = 0; s < R; s++) {
-                    if (s == i) continue;
+                const int first = (r->leader != NO_LEADER && r->leader != i && r->leader < R) ? r->leader : -1;
+                for (int k = -1; k < R; k++) {
+                    const int s = k < 0 ? first : k;
+                    if (s < 0 || s == i || (k >= 0 && s == first)) continue;
                     Replica *snd = &reps[s];
                     heard_heartbeat(r, (uint8_t)s, snd->hb_bal, snd->hb_commit, snd->hb_exec, snd->hb_snap);
                     drain(r, NULL, NO_LEADER);

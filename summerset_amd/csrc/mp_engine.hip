@@ -930,12 +930,22 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__rest
         const RepView &v = L.v;
         L.heard_heartbeat(r, v.hb_bal()[g], v.hb_commit()[g], v.hb_exec()[g], v.hb_snap()[g]);   // :254-261
         uint32_t bound = 0xFFFFFFFFu;
-        for (uint32_t s = 0; s < P.R; s++) {
-            if (s == r) continue;
-            const MpRep &snd = P.rep[s];
-            uint32_t he = snd.hb_exec[g];
+        // LS-1 order: the replica I follow first -- its heartbeat is the one that moves my commit bar, and
+        // with it in the same position for every lane the long pass runs once per wavefront whichever
+        // replicas lead the lanes' groups -- then the other peers by ascending id
+        const uint32_t first = (L.leader != NO_REP && L.leader != r && L.leader < P.R) ? L.leader : NO_REP;
+        uint32_t nxt = 0;                                       // ascending cursor over the other peers
+        for (uint32_t k = 0; k + 1 < P.R; k++) {                // one call site: the sender is a per-lane value
+            uint32_t s;
+            if (k == 0 && first != NO_REP) s = first;
+            else {
+                while (nxt == r || nxt == first) nxt++;
+                s = nxt++;
+            }
+            const RepView snd{P.rep[0], (size_t)s * P.rep_stride};
+            const uint32_t he = snd.hb_exec()[g];
             if (he < bound) bound = he;
-            if (!L.ovf) L.heard_heartbeat(s, snd.hb_bal[g], snd.hb_commit[g], he, snd.hb_snap[g]);
+            if (!L.ovf) L.heard_heartbeat(s, snd.hb_bal()[g], snd.hb_commit()[g], he, snd.hb_snap()[g]);
         }
         if (L.ebar < bound) bound = L.ebar;
         if (bound > L.start) L.start = bound;
