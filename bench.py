@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
     ap.add_argument("--timeout-span", type=int, default=None, help="draw the timeout ticks from [0, N) instead of the whole run")
-    ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change runs on the side stream (0 = off)")
+    ap.add_argument("--straggler-ticks", type=int, default=0, help="ticks a group in a leader change runs on the side stream (0 = off: measured a wash, DESIGN.md §4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")

@@ -109,16 +109,10 @@ __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__re
 }
 
 // R1: HearTimeout -> become_a_leader; client batches -> handle_req_batch
-__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
-                                                      const uint8_t *__restrict__ timeout_rep,
-                                                      const uint8_t *__restrict__ timeout_src,
-                                                      const uint8_t *__restrict__ req_target,
-                                                      const uint32_t *__restrict__ req_cnt,
-                                                      const uint32_t *__restrict__ req_val, uint32_t S, int side) {
-    const MpParams &P = *Pp;
-    uint32_t g;
-    bool active = pick_group(P, side, g);
-    const uint32_t r = blockIdx.y;
+__device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_t *__restrict__ timeout_rep,
+                                        const uint8_t *__restrict__ timeout_src, const uint8_t *__restrict__ req_target,
+                                        const uint32_t *__restrict__ req_cnt, const uint32_t *__restrict__ req_val,
+                                        uint32_t S, const uint32_t g, bool active, const uint32_t r) {
     Lane L(P, r, g < P.G ? g : 0, par);
     const bool has_to = active && timeout_rep && timeout_rep[g] == r;
     uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
@@ -183,6 +177,18 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
         flush_job(J);
     }
     flush_counters(L, active);
+}
+
+__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
+                                                      const uint8_t *__restrict__ timeout_rep,
+                                                      const uint8_t *__restrict__ timeout_src,
+                                                      const uint8_t *__restrict__ req_target,
+                                                      const uint32_t *__restrict__ req_cnt,
+                                                      const uint32_t *__restrict__ req_val, uint32_t S, int side) {
+    const MpParams &P = *Pp;
+    uint32_t g;
+    const bool active = pick_group(P, side, g);
+    r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, active, blockIdx.y);
 }
 
 // ---- R2 ---------------------------------------------------------------------
@@ -344,11 +350,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
-__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
-    const MpParams &P = *Pp;
-    uint32_t g;
-    bool active = pick_group(P, side, g);
-    const uint32_t r = blockIdx.y;
+__device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32_t g, bool active, const uint32_t r) {
     Lane L(P, r, g < P.G ? g : 0, par);
     bool job = false;
     uint32_t job_sender = 0, job_j = 0;
@@ -449,6 +451,13 @@ __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restri
         flush_job(J);
     }
     flush_counters(L, active && loaded);
+}
+
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
+    const MpParams &P = *Pp;
+    uint32_t g;
+    const bool active = pick_group(P, side, g);
+    r2_body(P, par, g, active, blockIdx.y);
 }
 
 // ---- R3 ---------------------------------------------------------------------
@@ -860,20 +869,8 @@ __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParam
     quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk);
 }
 
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
-                                                        const uint32_t *__restrict__ ackctl,
-                                                        int publish_hb, int side) {
-    const MpParams &P = *Pp;
-    if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
-        const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
-        if (!any) return;
-    }
-    uint32_t g;
-    bool active = pick_group(P, side, g);
-    const uint32_t d = blockIdx.y;
+__device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32_t *__restrict__ ackctl, int publish_hb,
+                                        const uint32_t g, bool active, const uint32_t d) {
     Lane L(P, d, g < P.G ? g : 0, par);
     bool loaded = false, job = false;
     if (active) {
@@ -916,14 +913,26 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
     flush_counters(L, active && loaded);
 }
 
+__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+                                                        const uint32_t *__restrict__ ackctl,
+                                                        int publish_hb, int side) {
+    const MpParams &P = *Pp;
+    if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
+        const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+        if (!any) return;
+    }
+    uint32_t g;
+    const bool active = pick_group(P, side, g);
+    r3_body(P, par, ackctl, publish_hb, g, active, blockIdx.y);
+}
+
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
 // trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
 // as carried by this round's heartbeats).
-__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
-    const MpParams &P = *Pp;
-    uint32_t g;
-    bool active = pick_group(P, side, g);
-    const uint32_t r = blockIdx.y;
+__device__ __forceinline__ void r4_body(const MpParams &P, int par, const uint32_t g, bool active, const uint32_t r) {
     Lane L(P, r, g < P.G ? g : 0, par);
     if (active) {
         L.load();
@@ -954,6 +963,46 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__rest
     flush_counters(L, active);
 }
 
+__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
+    const MpParams &P = *Pp;
+    uint32_t g;
+    const bool active = pick_group(P, side, g);
+    r4_body(P, par, g, active, blockIdx.y);
+}
+
+// One launch for the whole tick of the straggler list: a block per listed group (round robin), one
+// wavefront per replica with the group on lane 0, the four rounds back to back with a block barrier in
+// between -- what the bulk launches get from stream order.  Removes three launch boundaries from the
+// stragglers' critical path (a leader change's handlers are serial latency, not bandwidth).
+__global__ __launch_bounds__(512) void mp_straggler_tick(const MpParams *__restrict__ Pp, int par, int lpar,
+                                                          const uint8_t *__restrict__ timeout_rep,
+                                                          const uint8_t *__restrict__ timeout_src,
+                                                          const uint8_t *__restrict__ req_target,
+                                                          const uint32_t *__restrict__ req_cnt,
+                                                          const uint32_t *__restrict__ req_val, uint32_t S,
+                                                          const uint32_t *__restrict__ ackctl, int do_heartbeat) {
+    const MpParams &P = *Pp;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t n = P.slow_n[lpar];
+    if (n > P.slow_cap) n = P.slow_cap;
+    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {               // uniform per block
+        const bool mine = w < P.R && lane == 0;
+        const uint32_t g = mine ? P.slow_list[idx] : P.G;
+        const uint32_t r = w < P.R ? w : 0;
+        if (timeout_rep || req_target)
+            r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, mine && !P.overflow[g], r);
+        __threadfence(); __syncthreads();
+        r2_body(P, par, g, mine && !P.overflow[g], r);                         // (a round may freeze the group)
+        __threadfence(); __syncthreads();
+        r3_body(P, par, ackctl, do_heartbeat, g, mine && !P.overflow[g], r);
+        __threadfence(); __syncthreads();
+        if (do_heartbeat) {
+            r4_body(P, par, g, mine && !P.overflow[g], r);
+            __threadfence(); __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host ---
 struct ProfEv { hipEvent_t a, b; int which; };
 
@@ -972,7 +1021,7 @@ struct smr_mp_cluster {
     uint32_t ttl = 0;                // ticks on the side stream after a HearTimeout (0 = never)
     hipStream_t side = nullptr;      // straggler launches
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool forked = false, marked = false, side_on = false;
+    bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     bool profile = false;
     std::vector<ProfEv> evs;
@@ -1203,7 +1252,7 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
-    if (c->side_on) {
+    if (c->side_on && !c->side_fused) {
         hipLaunchKernelGGL(mp_round_local, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, timeout_rep_dev,
                            timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
@@ -1223,7 +1272,7 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
-    if (c->side_on) {
+    if (c->side_on && !c->side_fused) {
         hipLaunchKernelGGL(mp_round_deliver, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
@@ -1241,7 +1290,7 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
-    if (c->side_on) {
+    if (c->side_on && !c->side_fused) {
         hipLaunchKernelGGL(mp_round_replies, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, ackctl_dev,
                            publish_heartbeat, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
@@ -1271,7 +1320,7 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
     int rc = ensure_marked(c, nullptr, st); if (rc) return rc;
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
-    if (c->side_on) {
+    if (c->side_on && !c->side_fused) {
         hipLaunchKernelGGL(mp_round_heartbeat, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
@@ -1299,12 +1348,22 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_marked(c, timeout_rep_dev, st); if (rc) return rc;
+    if (timeout_rep_dev && !timeout_src_dev) return fail(SMR_ERR_ARG, "mp: timeout_rep without timeout_src");
+    if (req_target_dev && (!req_cnt_dev || !req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;                // one fork around the whole tick
+    if (own) {                                                  // the list's whole tick: ONE launch on the side stream
+        hipLaunchKernelGGL(mp_straggler_tick, dim3(SLOW_CAP / 4), dim3(512), 0, c->side, c->dp, c->par, c->lpar,
+                           timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, ackctl_dev,
+                           do_heartbeat);
+        SMR_HIP_TRY(hipGetLastError());
+        c->side_fused = true;                                   // the round calls below launch the bulk only
+    }
     rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, stream);
     if (!rc) rc = smr_mp_round_deliver(c, stream);
     if (!rc) rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream);
     if (!rc && do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
+    c->side_fused = false;
     const int rj = join_side(c, st, own);
     if (rc) return rc;
     if (rj) return rj;
