@@ -182,12 +182,22 @@ def epaxos_leg(torch, dev, ticks=16):
     flags[0] = 0
     flags_d = i32(flags)
     ballot_d = i32(np.full((R, G), 1, np.uint64))
+    # outputs allocated once and the C-ABI called directly, so that the event pairs bracket the kernels alone
+    import ctypes as C
+    from summerset_amd._lib import EpMsg, check
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    m = dict(flags=z(G, torch.uint8), col=z(G, torch.int32), ballot=z(G, torch.int64), seq=z(G, torch.int64),
+             deps=z((R, G), torch.int32))
+    r = dict(decision=z(G, torch.uint8), seq=z(G, torch.int64), deps=z((R, G), torch.int32))
+    msg = EpMsg(m["flags"].data_ptr(), None, m["col"].data_ptr(), m["ballot"].data_ptr(), m["seq"].data_ptr(),
+                m["deps"].data_ptr(), None)
+    st_ = torch.cuda.current_stream().cuda_stream
     t_prop = t_rep = 0.0
     committed = 0
     for t in range(ticks):
         e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         e0.record()
-        m = eng.handle_req_batch(keys[t])
+        check(eng._L.smr_ep_propose(eng._h, keys[t].data_ptr(), None, C.byref(msg), st_))
         e1.record()
         # the peers' answers: my (seq, deps), 10 % with seq + 1 and one more dependency (stand-in for the
         # four acceptors, built on the device from the PreAccept just produced; not timed)
@@ -197,7 +207,10 @@ def epaxos_leg(torch, dev, ticks=16):
         deps[:, 1, :] = torch.where(ex, torch.clamp(deps[:, 1, :], min=0) + 1, deps[:, 1, :])
         deps = deps.contiguous()
         e2.record()
-        r = eng.handle_msg_pre_accept_reply(m["col"], ballot_d, seq, deps, flags_d)
+        check(eng._L.smr_ep_handle_pre_accept_replies(eng._h, m["col"].data_ptr(), ballot_d.data_ptr(), seq.data_ptr(),
+                                                      deps.data_ptr(), flags_d.data_ptr(), None, None,
+                                                      r["decision"].data_ptr(), r["seq"].data_ptr(),
+                                                      r["deps"].data_ptr(), st_))
         e3.record()
         torch.cuda.synchronize()
         t_prop += e0.elapsed_time(e1)
