@@ -353,13 +353,18 @@ def main():
         "decisions_per_sec_quorum_kernel": G * S / (qt_ms * 1e-3),
     }
     if rank == 0:
+        def leg(name, fn, *a):                     # a secondary leg must never cost the headline line
+            try:
+                line[name] = fn(*a)
+            except Exception as e:                 # noqa: BLE001
+                line[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_cpu:
-            line["cpu_baseline"] = cpu_leg(args, args.cpu_seconds)
+            leg("cpu_baseline", cpu_leg, args, args.cpu_seconds)
         if not args.no_rs:
-            line["rs_encode"] = rs_leg(torch, dev, not args.no_cpu, args.cpu_seconds)
+            leg("rs_encode", rs_leg, torch, dev, not args.no_cpu, args.cpu_seconds)
         if not args.no_extra:
-            line["raft_quorum"] = raft_leg(torch, dev)
-            line["epaxos_fast_quorum"] = epaxos_leg(torch, dev)
+            leg("raft_quorum", raft_leg, torch, dev)
+            leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
