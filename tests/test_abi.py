@@ -58,6 +58,32 @@ def test_argument_errors_do_not_need_a_device(engine_lib):
     assert "num_data_shards is zero" in e.value.msg
 
 
+def test_argument_errors_of_the_other_protocol_objects(engine_lib):
+    import ctypes as C
+    from summerset_amd import _lib
+    from summerset_amd._lib import EpCfg, RaftCfg, SummersetError, check
+    h = C.c_void_p()
+    for cfg, frag in ((RaftCfg(0, 5, 0, 0, 0, 64, 1), "n_groups"), (RaftCfg(8, 9, 0, 0, 0, 64, 1), "population"),
+                      (RaftCfg(8, 5, 5, 0, 0, 64, 1), "leader_id"), (RaftCfg(8, 5, 0, 0, 0, 40, 1), "power of two"),
+                      (RaftCfg(8, 5, 0, 3, 0, 64, 1), "commit_extra")):
+        with pytest.raises(SummersetError) as e:
+            check(engine_lib.smr_raft_leader_create(C.byref(cfg), C.byref(h)))
+        assert e.value.code == _lib.SMR_ERR_ARG and frag in e.value.msg
+    for cfg, frag in ((EpCfg(0, 5, 0, 1, 0, 32, 64), "n_groups"), (EpCfg(8, 2, 0, 1, 0, 32, 64), "population"),
+                      (EpCfg(8, 5, 5, 1, 0, 32, 64), "replica id"), (EpCfg(8, 5, 0, 1, 0, 24, 64), "power of two"),
+                      (EpCfg(8, 5, 0, 1, 0, 32, 0), "n_keys"), (EpCfg(8, 5, 0, 1, 0, 32, 256), "n_keys")):
+        with pytest.raises(SummersetError) as e:
+            check(engine_lib.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
+        assert e.value.code == _lib.SMR_ERR_ARG and frag in e.value.msg
+    # null handles are refused, not dereferenced
+    for fn, args in ((engine_lib.smr_raft_replica_preset, (None, 0, 0, 1, 0xFF)),
+                     (engine_lib.smr_ep_propose, (None, None, None, None, None)),
+                     (engine_lib.smr_mp_end_tick, (None,)),
+                     (engine_lib.smr_repnothing_stats, (None, None, None, None, None))):
+        with pytest.raises(SummersetError):
+            check(fn(*args))
+
+
 def test_no_silent_cpu_fallback(engine_lib):
     """Without a GPU every compute entry point must raise, never compute on the host."""
     import torch
