@@ -423,6 +423,49 @@ int smr_repnothing_poll_reply(smr_repnothing *h, uint64_t *client, uint64_t *req
 int smr_repnothing_stats(smr_repnothing *h, uint64_t *n_insts, uint64_t *wal_offset, uint64_t *n_execed,
                          uint64_t *n_keys);
 
+/* ------------------------------------------------------------------------
+ * Wire + WAL formats of the MultiPaxos hot-path messages (host only)
+ * frame = 8-byte big-endian length + bincode-standard payload (src/utils/safetcp.rs:46,127-132;
+ * src/server/storage.rs:326-346); payload = PeerMessage::Msg { msg: PeerMsg } (src/server/
+ * transport.rs:37-52, src/protocols/multipaxos/mod.rs:298-368) resp. WalEntry (mod.rs:261-274).
+ * Encoders return the frame's byte count (< 0: error, e.g. buffer too small).
+ * ---------------------------------------------------------------------- */
+#define SMR_WIRE_PREPARE 0
+#define SMR_WIRE_PREPARE_REPLY 1
+#define SMR_WIRE_ACCEPT 2
+#define SMR_WIRE_ACCEPT_REPLY 3
+#define SMR_WIRE_LEAVE 0xFE      /* PeerMessage::Leave */
+#define SMR_WIRE_OTHER 0xFF      /* a frame of another kind (lease, quorum read): skipped */
+
+/* bincode(ReqBatch) of n Get / Put requests -- the bytes an Accept carries and RSCodeword shards;
+ * no frame header.  Arguments as smr_repnothing_submit_batch. */
+int64_t smr_wire_reqbatch(uint32_t n, const uint64_t *client, const uint64_t *req_id, const uint8_t *kind,
+                          const char *const *key, const uint32_t *key_len, const char *const *value,
+                          const uint32_t *value_len, uint8_t *out, uint64_t cap);
+int64_t smr_wire_prepare(uint64_t trigger_slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+int64_t smr_wire_prepare_reply(uint64_t slot, uint64_t trigger_slot, uint64_t endprep_slot, uint64_t ballot,
+                               int has_voted, uint64_t voted_ballot, const uint8_t *voted_reqs, uint64_t voted_reqs_len,
+                               uint64_t accept_bar, uint8_t *out, uint64_t cap);
+/* reqs = bincode(ReqBatch) bytes (smr_wire_reqbatch) */
+int64_t smr_wire_accept(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
+                        uint64_t cap);
+int64_t smr_wire_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+/* WalEntry::{PrepareBal, AcceptData, CommitSlot} log records */
+int64_t smr_wal_prepare_bal(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+int64_t smr_wal_accept_data(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
+                            uint64_t cap);
+int64_t smr_wal_commit_slot(uint64_t slot, uint8_t *out, uint64_t cap);
+
+typedef struct {
+    uint8_t kind;                  /* SMR_WIRE_* */
+    uint8_t has_voted;             /* PrepareReply: voted is Some */
+    uint64_t slot, ballot, trigger_slot, endprep_slot, accept_bar, voted_ballot;
+    uint64_t reqs_off, reqs_len;   /* Accept / voted: where in the buffer the bincode(ReqBatch) bytes lie */
+} smr_wire_msg;
+/* Parses the first TCP frame of buf[0, len): returns the bytes it occupies, 0 if it is not complete
+ * yet (safetcp.rs:30-70 reads until it is), < 0 if malformed. */
+int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *out);
+
 #ifdef __cplusplus
 }
 #endif

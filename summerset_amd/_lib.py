@@ -93,6 +93,12 @@ class EpDumpBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in EP_DUMP_FIELDS]
 
 
+class WireMsg(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("has_voted", C.c_uint8), ("slot", C.c_uint64), ("ballot", C.c_uint64),
+                ("trigger_slot", C.c_uint64), ("endprep_slot", C.c_uint64), ("accept_bar", C.c_uint64),
+                ("voted_ballot", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64)]
+
+
 SYMBOLS = [
     ("smr_last_error", C.c_char_p, []),
     ("smr_device_count", _i, []),
@@ -141,6 +147,15 @@ SYMBOLS = [
     ("smr_ep_handle_pre_accept_replies", _i, [_vp] + [_vp] * 11),
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
+    ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
+    ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),
+    ("smr_wire_accept", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
+    ("smr_wire_accept_reply", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wal_prepare_bal", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wal_accept_data", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
+    ("smr_wal_commit_slot", C.c_int64, [_u64, _vp, _u64]),
+    ("smr_wire_decode", C.c_int64, [_vp, _u64, C.POINTER(WireMsg)]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

@@ -1,0 +1,218 @@
+// Wire + WAL formats of the MultiPaxos hot-path messages: what a host needs
+// to feed the engine from, and answer to, real Summerset peers.  Host-only.
+//
+// Frame, both on TCP and in the log file: 8-byte BIG-endian length, then the bincode 2.0
+// "standard"-config bytes of the object (src/utils/safetcp.rs:46,127-132; src/server/storage.rs:
+// 326-346).  On TCP the object is `PeerMessage::Msg { msg: PeerMsg }` (src/server/transport.rs:
+// 37-52, variant 0) around the protocol's `PeerMsg` (src/protocols/multipaxos/mod.rs:298-368:
+// Prepare 0, PrepareReply 1, Accept 2, AcceptReply 3); in the log it is `WalEntry`
+// (mod.rs:261-274: PrepareBal 0, AcceptData 1, CommitSlot 2).  `ReqBatch` =
+// Vec<(ClientId, ApiRequest)> (src/server/external.rs:33-54: Req 0; src/server/statemach.rs:21-27:
+// Get 0, Put 1).
+//
+// bincode "standard": little-endian varint integers (< 251: one byte; 0xFB + u16; 0xFC + u32;
+// 0xFD + u64), enum variant index as varint u32, Option as a 0/1 byte, String / Vec as varint
+// length + elements, struct / tuple fields in declaration order.  bincode is not vendored with the
+// reference: this layout is restated and unpinned against the crate.
+#include <string.h>
+
+#include <string>
+
+#include "smr_common.h"
+
+namespace smr {
+
+struct Wr {
+    uint8_t *p; uint64_t cap, n = 0; bool ok = true;
+    void byte(uint8_t b) { if (n < cap) p[n] = b; else ok = false; n++; }
+    void raw(const void *src, uint64_t len) {
+        if (n + len <= cap && len) memcpy(p + n, src, len); else if (len) ok = false;
+        n += len;
+    }
+    void le(uint64_t v, int bytes) { for (int i = 0; i < bytes; i++) byte((uint8_t)(v >> (8 * i))); }
+    void varint(uint64_t v) {
+        if (v < 251) byte((uint8_t)v);
+        else if (v < (1ull << 16)) { byte(0xFB); le(v, 2); }
+        else if (v < (1ull << 32)) { byte(0xFC); le(v, 4); }
+        else { byte(0xFD); le(v, 8); }
+    }
+    void bytes(const void *src, uint64_t len) { varint(len); raw(src, len); }      // String / Vec<u8>
+};
+
+struct Rd {
+    const uint8_t *p; uint64_t len, n = 0; bool ok = true;
+    uint8_t byte() { if (n < len) return p[n++]; ok = false; return 0; }
+    uint64_t le(int bytes) { uint64_t v = 0; for (int i = 0; i < bytes; i++) v |= (uint64_t)byte() << (8 * i); return v; }
+    uint64_t varint() {
+        const uint8_t b = byte();
+        if (b < 251) return b;
+        if (b == 0xFB) return le(2);
+        if (b == 0xFC) return le(4);
+        if (b == 0xFD) return le(8);
+        ok = false;                                                              // 0xFE (u128) / 0xFF never occur here
+        return 0;
+    }
+    bool skip(uint64_t k) { if (n + k <= len) { n += k; return true; } ok = false; return false; }
+};
+
+// finishes a frame whose payload was written at out + 8
+static int64_t frame_done(Wr &w, uint8_t *out) {
+    if (!w.ok) return fail(SMR_ERR_ARG, "wire: output buffer too small");
+    const uint64_t len = w.n - 8;
+    for (int i = 0; i < 8; i++) out[i] = (uint8_t)(len >> (8 * (7 - i)));          // big-endian length
+    return (int64_t)w.n;
+}
+static Wr frame_begin(uint8_t *out, uint64_t cap) {
+    Wr w{out, cap};
+    for (int i = 0; i < 8; i++) w.byte(0);
+    return w;
+}
+
+// walks one bincode ReqBatch starting at r.n; false if malformed
+static bool skip_reqbatch(Rd &r) {
+    const uint64_t n = r.varint();
+    for (uint64_t i = 0; i < n && r.ok; i++) {
+        r.varint();                                                              // ClientId
+        const uint64_t req = r.varint();                                         // ApiRequest variant
+        if (req == 0) {                                                          // Req { id, cmd }
+            r.varint();
+            const uint64_t cmd = r.varint();
+            if (cmd > 1) { r.ok = false; break; }
+            r.skip(r.varint());                                                  // key
+            if (cmd == 1) r.skip(r.varint());                                    // value
+        } else if (req == 2) {                                                   // Leave
+        } else { r.ok = false; }                                                 // Conf: not on this path
+    }
+    return r.ok;
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+extern "C" {
+
+int64_t smr_wire_reqbatch(uint32_t n, const uint64_t *client, const uint64_t *req_id, const uint8_t *kind,
+                          const char *const *key, const uint32_t *key_len, const char *const *value,
+                          const uint32_t *value_len, uint8_t *out, uint64_t cap) {
+    if (!client || !req_id || !kind || !key || !key_len || (!out && cap)) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w{out, cap};
+    w.varint(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (kind[i] > SMR_CMD_PUT) return fail(SMR_ERR_ARG, "wire: unknown command kind");
+        w.varint(client[i]);
+        w.varint(0);                                                             // ApiRequest::Req
+        w.varint(req_id[i]);
+        w.varint(kind[i]);                                                       // Command::{Get, Put}
+        w.bytes(key[i], key_len[i]);
+        if (kind[i] == SMR_CMD_PUT) {
+            if (!value || !value_len) return fail(SMR_ERR_ARG, "wire: Put without value arrays");
+            w.bytes(value[i], value_len[i]);
+        }
+    }
+    if (!w.ok) return fail(SMR_ERR_ARG, "wire: output buffer too small");
+    return (int64_t)w.n;
+}
+
+int64_t smr_wire_prepare(uint64_t trigger_slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_PREPARE); w.varint(trigger_slot); w.varint(ballot);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_prepare_reply(uint64_t slot, uint64_t trigger_slot, uint64_t endprep_slot, uint64_t ballot,
+                               int has_voted, uint64_t voted_ballot, const uint8_t *voted_reqs, uint64_t voted_reqs_len,
+                               uint64_t accept_bar, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_PREPARE_REPLY);
+    w.varint(slot); w.varint(trigger_slot); w.varint(endprep_slot); w.varint(ballot);
+    w.byte(has_voted ? 1 : 0);                                                   // Option<(Ballot, ReqBatch)>
+    if (has_voted) { w.varint(voted_ballot); w.raw(voted_reqs, voted_reqs_len); }
+    w.varint(accept_bar);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_accept(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
+                        uint64_t cap) {
+    if (!reqs && reqs_len) return fail(SMR_ERR_ARG, "wire: null request batch");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_ACCEPT); w.varint(slot); w.varint(ballot);
+    w.raw(reqs, reqs_len);                                                       // already bincode(ReqBatch)
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_ACCEPT_REPLY); w.varint(slot); w.varint(ballot);
+    w.byte(0);                                                                   // reply_ts: None
+    return frame_done(w, out);
+}
+
+int64_t smr_wal_prepare_bal(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(slot); w.varint(ballot);
+    return frame_done(w, out);
+}
+
+int64_t smr_wal_accept_data(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
+                            uint64_t cap) {
+    if (!reqs && reqs_len) return fail(SMR_ERR_ARG, "wire: null request batch");
+    Wr w = frame_begin(out, cap);
+    w.varint(1); w.varint(slot); w.varint(ballot); w.raw(reqs, reqs_len);
+    return frame_done(w, out);
+}
+
+int64_t smr_wal_commit_slot(uint64_t slot, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(2); w.varint(slot);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *m) {
+    if (!buf || !m) return fail(SMR_ERR_ARG, "wire: null argument");
+    memset(m, 0, sizeof(*m));
+    if (len < 8) return 0;                                                       // length not complete yet
+    uint64_t plen = 0;
+    for (int i = 0; i < 8; i++) plen = (plen << 8) | buf[i];
+    if (plen > 1000000000000ull) return fail(SMR_ERR_ARG, "wire: invalidly large frame");   // safetcp.rs:56-66
+    if (len - 8 < plen) return 0;                                                // frame not complete yet
+    Rd r{buf + 8, plen};
+    const uint64_t outer = r.varint();
+    if (outer == 2) { m->kind = SMR_WIRE_LEAVE; return (int64_t)(8 + plen); }    // PeerMessage::Leave
+    if (outer != 0) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }    // lease traffic: not this path
+    const uint64_t v = r.varint();
+    m->kind = (uint8_t)(v <= SMR_WIRE_ACCEPT_REPLY ? v : SMR_WIRE_OTHER);
+    switch (v) {
+        case SMR_WIRE_PREPARE: m->trigger_slot = r.varint(); m->ballot = r.varint(); break;
+        case SMR_WIRE_PREPARE_REPLY: {
+            m->slot = r.varint(); m->trigger_slot = r.varint(); m->endprep_slot = r.varint(); m->ballot = r.varint();
+            m->has_voted = r.byte();
+            if (m->has_voted > 1) r.ok = false;
+            if (m->has_voted == 1) {
+                m->voted_ballot = r.varint();
+                m->reqs_off = 8 + r.n;
+                if (skip_reqbatch(r)) m->reqs_len = 8 + r.n - m->reqs_off;
+            }
+            m->accept_bar = r.varint();
+            break;
+        }
+        case SMR_WIRE_ACCEPT: {
+            m->slot = r.varint(); m->ballot = r.varint();
+            m->reqs_off = 8 + r.n;
+            if (skip_reqbatch(r)) m->reqs_len = 8 + r.n - m->reqs_off;
+            break;
+        }
+        case SMR_WIRE_ACCEPT_REPLY: {
+            m->slot = r.varint(); m->ballot = r.varint();
+            const uint8_t ts = r.byte();                                          // Option<SystemTime>
+            if (ts == 1) { r.varint(); r.varint(); }                              // Duration { secs u64, nanos u32 } since the epoch
+            else if (ts != 0) r.ok = false;
+            break;
+        }
+        default: return (int64_t)(8 + plen);                                      // ReadQuery & co: not this path
+    }
+    if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
+    return (int64_t)(8 + plen);
+}
+
+}  // extern "C"

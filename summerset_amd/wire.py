@@ -1,0 +1,78 @@
+"""Wire + WAL formats of the MultiPaxos hot-path messages (host only): thin ctypes mirror of
+smr_wire_* / smr_wal_* (include/summerset_hip.h).  Frames are bytes objects:
+8-byte big-endian length + bincode-standard payload (src/utils/safetcp.rs:46,127-132)."""
+import ctypes as C
+
+from . import _lib
+from ._lib import WireMsg, check
+
+PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, LEAVE, OTHER = 0, 1, 2, 3, 0xFE, 0xFF
+GET, PUT = 0, 1
+
+
+def _call(fn, *args, cap=64):
+    L = _lib.load()
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = getattr(L, fn)(*args, buf, cap)
+        if n >= 0:
+            return buf.raw[:n]
+        if cap > (1 << 30):
+            check(int(n))
+        cap *= 8                      # "output buffer too small": grow and retry
+
+
+def reqbatch(reqs):
+    """bincode(ReqBatch) of [(client, req_id, ("get", key) | ("put", key, value)), ...]"""
+    n = len(reqs)
+    b = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+    kinds = [PUT if r[2][0] == "put" else GET for r in reqs]
+    keys = [b(r[2][1]) for r in reqs]
+    vals = [b(r[2][2]) if k == PUT else b"" for r, k in zip(reqs, kinds)]
+    args = ((C.c_uint64 * n)(*[r[0] for r in reqs]), (C.c_uint64 * n)(*[r[1] for r in reqs]), (C.c_uint8 * n)(*kinds),
+            (C.c_char_p * n)(*keys), (C.c_uint32 * n)(*[len(k) for k in keys]), (C.c_char_p * n)(*vals),
+            (C.c_uint32 * n)(*[len(v) for v in vals]))
+    return _call("smr_wire_reqbatch", n, *args, cap=64 + sum(len(k) + len(v) + 32 for k, v in zip(keys, vals)))
+
+
+def prepare(trigger_slot, ballot):
+    return _call("smr_wire_prepare", trigger_slot, ballot)
+
+
+def prepare_reply(slot, trigger_slot, endprep_slot, ballot, voted=None, accept_bar=0):
+    vb, vr = voted if voted is not None else (0, b"")
+    return _call("smr_wire_prepare_reply", slot, trigger_slot, endprep_slot, ballot, int(voted is not None), vb, vr, len(vr),
+                 accept_bar, cap=96 + len(vr))
+
+
+def accept(slot, ballot, reqs):
+    return _call("smr_wire_accept", slot, ballot, reqs, len(reqs), cap=64 + len(reqs))
+
+
+def accept_reply(slot, ballot):
+    return _call("smr_wire_accept_reply", slot, ballot)
+
+
+def wal_prepare_bal(slot, ballot):
+    return _call("smr_wal_prepare_bal", slot, ballot)
+
+
+def wal_accept_data(slot, ballot, reqs):
+    return _call("smr_wal_accept_data", slot, ballot, reqs, len(reqs), cap=64 + len(reqs))
+
+
+def wal_commit_slot(slot):
+    return _call("smr_wal_commit_slot", slot)
+
+
+def decode(buf):
+    """first frame of buf -> (bytes consumed, dict) ; (0, None) if the frame is not complete yet"""
+    m = WireMsg()
+    n = _lib.load().smr_wire_decode(bytes(buf), len(buf), C.byref(m))
+    if n < 0:
+        check(int(n))
+    if n == 0:
+        return 0, None
+    d = {k: getattr(m, k) for k, _ in WireMsg._fields_}
+    d["reqs"] = bytes(buf[m.reqs_off:m.reqs_off + m.reqs_len]) if m.reqs_len else b""
+    return int(n), d

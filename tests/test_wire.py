@@ -1,0 +1,71 @@
+"""Wire / WAL frames of the MultiPaxos hot-path messages (host only): byte layouts worked out from
+the reference's type definitions (multipaxos/mod.rs:261-368, transport.rs:37-52, external.rs:33-54,
+statemach.rs:21-27) under the bincode-standard rules of SURVEY.md Appendix C, round trips, and the
+incomplete / malformed cases of safetcp.rs:30-70."""
+import numpy as np
+import pytest
+
+from summerset_amd import wire
+from summerset_amd._lib import SummersetError
+
+
+def test_reqbatch_bytes_match_appendix_c_and_the_oracle(oracle):
+    val = b"v" * 4096
+    rb = wire.reqbatch([(7, 42, ("put", b"k0000003", val))])
+    # 01 | client | 00 (Req) | id | 01 (Put) | 08 key | FB 00 10 value
+    assert rb[:5] == bytes([1, 7, 0, 42, 1]) and rb[5] == 8 and rb[6:14] == b"k0000003"
+    assert rb[14:17] == bytes([0xFB, 0x00, 0x10]) and rb[17:] == val and len(rb) == 4110 + 1 + 1 + 1
+    assert rb == bytes(oracle.bincode_reqbatch_put(7, 42, b"k0000003", val))        # independent restatement
+    g = wire.reqbatch([(300, 70000, ("get", "a"))])
+    assert g == bytes([1, 0xFB, 0x2C, 0x01, 0, 0xFC, 0x70, 0x11, 0x01, 0x00, 0, 1]) + b"a"
+
+
+def test_frames_byte_for_byte():
+    assert wire.prepare(5, 0x202) == bytes([0, 0, 0, 0, 0, 0, 0, 6, 0, 0, 5, 0xFB, 0x02, 0x02])
+    assert wire.accept_reply(9, 0x101) == bytes([0, 0, 0, 0, 0, 0, 0, 7, 0, 3, 9, 0xFB, 0x01, 0x01, 0])
+    rb = wire.reqbatch([(1, 2, ("put", "k", "v"))])
+    a = wire.accept(300, 0x101, rb)
+    assert a[:8] == (len(a) - 8).to_bytes(8, "big") and a[8:10] == bytes([0, 2]) and a[10:13] == bytes([0xFB, 0x2C, 0x01])
+    assert a.endswith(rb)
+    assert wire.wal_commit_slot(1 << 40) == bytes([0, 0, 0, 0, 0, 0, 0, 10, 2, 0xFD]) + (1 << 40).to_bytes(8, "little")
+    assert wire.wal_prepare_bal(3, 4) == bytes([0, 0, 0, 0, 0, 0, 0, 3, 0, 3, 4])
+    w = wire.wal_accept_data(3, 0x101, rb)
+    assert w[8:13] == bytes([1, 3, 0xFB, 0x01, 0x01]) and w[13:] == rb
+
+
+def test_round_trips_and_stream_reassembly():
+    rb = wire.reqbatch([(1, 2, ("put", "key", "value")), (1, 3, ("get", "key"))])
+    frames = [wire.prepare(17, 0x303), wire.prepare_reply(18, 17, 40, 0x303, voted=(0x101, rb), accept_bar=16),
+              wire.prepare_reply(19, 17, 40, 0x303), wire.accept(1000, 0x303, rb), wire.accept_reply(1000, 0x303)]
+    stream = b"".join(frames)
+    out = []
+    while stream:
+        n, m = wire.decode(stream)
+        assert n > 0
+        out.append(m)
+        stream = stream[n:]
+    assert [m["kind"] for m in out] == [wire.PREPARE, wire.PREPARE_REPLY, wire.PREPARE_REPLY, wire.ACCEPT, wire.ACCEPT_REPLY]
+    assert (out[0]["trigger_slot"], out[0]["ballot"]) == (17, 0x303)
+    assert (out[1]["slot"], out[1]["endprep_slot"], out[1]["has_voted"], out[1]["voted_ballot"]) == (18, 40, 1, 0x101)
+    assert out[1]["accept_bar"] == 16 and out[1]["reqs"] == rb
+    assert out[2]["has_voted"] == 0 and out[2]["reqs"] == b""
+    assert (out[3]["slot"], out[3]["ballot"]) == (1000, 0x303) and out[3]["reqs"] == rb
+    assert (out[4]["slot"], out[4]["ballot"]) == (1000, 0x303)
+    # a frame cut anywhere is "not complete yet" (safetcp.rs reads on), never an error
+    f = frames[3]
+    for cut in (0, 3, 8, 9, len(f) - 1):
+        assert wire.decode(f[:cut]) == (0, None)
+
+
+def test_malformed_frames_are_errors():
+    f = bytearray(wire.accept_reply(9, 0x101))
+    f[-1] = 7                                               # Option tag neither 0 nor 1
+    with pytest.raises(SummersetError):
+        wire.decode(bytes(f))
+    g = wire.accept(1, 2, bytes([1, 1, 0, 5, 9]))     # ReqBatch with an unknown Command variant
+    with pytest.raises(SummersetError):
+        wire.decode(g)
+    with pytest.raises(SummersetError):
+        wire.decode(bytes([0x7F]) * 8 + b"x")               # absurd length (safetcp.rs:56-66)
+    n, m = wire.decode(bytes([0, 0, 0, 0, 0, 0, 0, 1, 2]))  # PeerMessage::Leave
+    assert n == 9 and m["kind"] == wire.LEAVE
