@@ -369,6 +369,8 @@ int smr_ep_propose(smr_ep_replica *e, const uint8_t *key_dev, const uint8_t *exp
 int smr_ep_handle_pre_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream);
 /* handle_msg_accept + WAL completion: reply = AcceptReply {ballot} */
 int smr_ep_handle_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream);
+/* handle_msg_commit_notice (epaxos/messages.rs:438-508) + its CommitSlot completion (commit bar) */
+int smr_ep_handle_commit_notice(smr_ep_replica *e, const smr_ep_msg *msg, void *stream);
 /* The PreAcceptReplies to my instance (me, col[g]): ballot / seq / flags [R][G], deps [R][R][G]
  * (peer, dep row, group); ballot 0 = the "failure suspected" re-evaluation call; peers in
  * order_dev[g] order (ackctl encoding, NULL = identity).  decision[g]: 0 = undecided,

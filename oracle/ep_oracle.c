@@ -18,6 +18,7 @@
  *   handle_msg_pre_accept_reply      messages.rs:96-270
  *   handle_msg_accept                messages.rs:273-345
  *   handle_msg_accept_reply          messages.rs:348-436
+ *   handle_msg_commit_notice         messages.rs:438-508
  *   handle_logged_{pre_accept,accept,commit}_slot   durability.rs:10-163
  *   quorum sizes, default ballot     mod.rs:500-514,693-698
  * WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one
@@ -404,6 +405,28 @@ void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *
         committed[g] = 0;
         if (held(r, row, col[g]))
             committed[g] = (before == ST_ACCEPTING && at(r, row, col[g])->status >= ST_COMMITTED) ? 1 : 0;
+    }
+}
+
+/* messages.rs:438-508 + handle_logged_commit_slot */
+void orc_ep_handle_commit_notice(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col,
+                                 const uint64_t *ballot, const uint64_t *seq, const uint32_t *deps, const uint8_t *key) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        if (!(flags[g] & 1)) continue;
+        int row = peer[g];
+        uint32_t c = col[g];
+        if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
+        while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :462-465 */
+        Inst *in = at(r, row, c);
+        if (ballot[g] >= in->bal) {                                  /* :469 */
+            in->bal = ballot[g]; in->status = ST_COMMITTED; in->seq = seq[g]; in->key = key[g];
+            for (int i = 0; i < MAXR; i++) in->deps.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
+            refresh_highest_cols(r, row, c, key[g]);
+            handle_logged_commit_slot(r, row, c);
+        }
     }
 }
 

@@ -87,6 +87,7 @@ def _declare(L):
     L.orc_ep_handle_pre_accept_replies.argtypes = [vp] + [vp] * 10
     L.orc_ep_handle_accept.argtypes = [vp] + [vp] * 9
     L.orc_ep_handle_accept_replies.argtypes = [vp] + [vp] * 5
+    L.orc_ep_handle_commit_notice.argtypes = [vp] + [vp] * 7
     L.orc_ep_dump.argtypes = [vp] + [vp] * 12
 
 
@@ -366,6 +367,9 @@ class EpOracle:
         lib().orc_ep_handle_accept(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key),
                                    _p(r["flags"]), _p(r["ballot"]))
         return r
+
+    def handle_commit_notice(self, flags, peer, col, ballot, seq, deps, key):
+        lib().orc_ep_handle_commit_notice(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key))
 
     def handle_accept_replies(self, col, ballot, flags, order=None):
         r = dict(committed=np.zeros(self.G, np.uint8))

@@ -144,6 +144,7 @@ SYMBOLS = [
     ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),
     ("smr_ep_handle_pre_accept", _i, [_vp, C.POINTER(EpMsg), C.POINTER(EpMsg), _vp]),
     ("smr_ep_handle_accept", _i, [_vp, C.POINTER(EpMsg), C.POINTER(EpMsg), _vp]),
+    ("smr_ep_handle_commit_notice", _i, [_vp, C.POINTER(EpMsg), _vp]),
     ("smr_ep_handle_pre_accept_replies", _i, [_vp] + [_vp] * 11),
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),

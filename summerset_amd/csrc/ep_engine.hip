@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const u
     L.flush();
 }
 
-// messages.rs:10-93 (ACCEPT = false) / :273-345 (ACCEPT = true) + the acceptor's WAL completion
-template <bool ACCEPT>
+// messages.rs:10-93 (MODE 0: PreAccept) / :273-345 (MODE 1: Accept) / :438-508 (MODE 2: CommitNotice) + the
+// acceptor's WAL completion
+template <int MODE>
 __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const uint8_t *__restrict__ flags,
                                                           const uint8_t *__restrict__ peer, const uint32_t *__restrict__ col,
                                                           const uint64_t *__restrict__ ballot, const uint64_t *__restrict__ seq,
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
 #pragma unroll
                     for (int q = 0; q < EMAXR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
                     uint64_t s = seq[g];
-                    if (!ACCEPT) {
+                    if (MODE == 0) {
                         uint32_t my[EMAXR];
                         L.identify_deps(k, my);
 #pragma unroll
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
                         const uint64_t ms = 1 + L.max_seq_num(my);
                         if (ms > s) s = ms;
                     }
-                    v.bal[i] = b; v.status[i] = ACCEPT ? EST_ACCEPTING : EST_PREACCEPTING; v.seq[i] = s; v.key[i] = (uint8_t)k;
+                    v.bal[i] = b; v.status[i] = MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING);
+                    v.seq[i] = s; v.key[i] = (uint8_t)k;
                     for (uint32_t q = 0; q < v.R; q++) {
                         uint32_t x = EP_NONE;
 #pragma unroll
@@ -311,20 +313,24 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
                         v.deps[L.dx(row, c, q)] = x;
                     }
                     L.refresh_highest_cols(row, c, k);
-                    const uint32_t bk = v.bk[i];
-                    v.bk[i] = (uint8_t)((bk & 1u) | 2u | (row << 2));            // replica_bk.source = peer
-                    if (bk & 1u) {                                               // durability.rs:25 / :78: leader_bk first
-                        if (ACCEPT) L.accept_reply(v.me, c, b); else L.pre_accept_reply(v.me, c, b, s, in, 0u);
+                    if (MODE == 2) {
+                        L.logged_commit_slot(row, c);                            // durability.rs:104-135
                     } else {
-                        of = 1; ob = b; os = s;
+                        const uint32_t bk = v.bk[i];
+                        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (row << 2));        // replica_bk.source = peer
+                        if (bk & 1u) {                                           // durability.rs:25 / :78: leader_bk first
+                            if (MODE == 1) L.accept_reply(v.me, c, b); else L.pre_accept_reply(v.me, c, b, s, in, 0u);
+                        } else {
+                            of = 1; ob = b; os = s;
 #pragma unroll
-                        for (int q = 0; q < EMAXR; q++) d[q] = in[q];
+                            for (int q = 0; q < EMAXR; q++) d[q] = in[q];
+                        }
                     }
                 }
             }
         }
-        r_flags[g] = of; r_ballot[g] = ob;
-        if (!ACCEPT) {
+        if (MODE != 2) { r_flags[g] = of; r_ballot[g] = ob; }
+        if (MODE == 0) {
             r_seq[g] = os;
 #pragma unroll
             for (int i = 0; i < EMAXR; i++) if ((uint32_t)i < v.R) r_deps[(size_t)i * v.G + g] = d[i];
@@ -591,26 +597,34 @@ int smr_ep_propose(smr_ep_replica *e, const uint8_t *key_dev, const uint8_t *exp
     return SMR_OK;
 }
 
-static int ep_acceptor(smr_ep_replica *e, bool accept, const smr_ep_msg *m, const smr_ep_msg *r, void *stream) {
-    if (!e || !m || !r || !m->flags || !m->peer || !m->col || !m->ballot || !m->seq || !m->deps || !m->key || !r->flags ||
-        !r->ballot || (!accept && (!r->seq || !r->deps)))
+static int ep_acceptor(smr_ep_replica *e, int mode, const smr_ep_msg *m, const smr_ep_msg *r, void *stream) {
+    if (!e || !m || !m->flags || !m->peer || !m->col || !m->ballot || !m->seq || !m->deps || !m->key)
         return fail(SMR_ERR_ARG, "epaxos: null argument");
-    if (accept)
-        hipLaunchKernelGGL(ep_acceptor_kernel<true>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
+    if (mode != 2 && (!r || !r->flags || !r->ballot || (mode == 0 && (!r->seq || !r->deps))))
+        return fail(SMR_ERR_ARG, "epaxos: null reply buffers");
+    if (mode == 2)
+        hipLaunchKernelGGL(ep_acceptor_kernel<2>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
+                           m->key, (uint8_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+    else if (mode == 1)
+        hipLaunchKernelGGL(ep_acceptor_kernel<1>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
                            m->key, r->flags, r->ballot, r->seq, r->deps);
     else
-        hipLaunchKernelGGL(ep_acceptor_kernel<false>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
+        hipLaunchKernelGGL(ep_acceptor_kernel<0>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
                            m->key, r->flags, r->ballot, r->seq, r->deps);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
 
 int smr_ep_handle_pre_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream) {
-    return ep_acceptor(e, false, msg, reply, stream);
+    return ep_acceptor(e, 0, msg, reply, stream);
 }
 
 int smr_ep_handle_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream) {
-    return ep_acceptor(e, true, msg, reply, stream);
+    return ep_acceptor(e, 1, msg, reply, stream);
+}
+
+int smr_ep_handle_commit_notice(smr_ep_replica *e, const smr_ep_msg *msg, void *stream) {
+    return ep_acceptor(e, 2, msg, nullptr, stream);
 }
 
 int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,

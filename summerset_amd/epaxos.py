@@ -73,6 +73,9 @@ class EPaxosReplicaGroup:
         check(self._L.smr_ep_handle_accept(self._h, C.byref(self._msg(msg)), C.byref(self._msg(out)), self._stream(stream)))
         return out
 
+    def handle_msg_commit_notice(self, msg, stream=None):
+        check(self._L.smr_ep_handle_commit_notice(self._h, C.byref(self._msg(msg)), self._stream(stream)))
+
     def handle_msg_pre_accept_reply(self, col, ballot, seq, deps, flags, order=None, exploded=None, stream=None):
         """replies [R, G] (deps [R, R, G]) to my instance (me, col[g]); returns decision / seq / deps"""
         import torch

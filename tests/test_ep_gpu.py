@@ -63,3 +63,29 @@ def test_epaxos_handlers_match_oracle(cuda, oracle, G, W, me):
     c = orc.dump()["counters"]
     assert c[0] > 0 and c[1] > 0 and c[2] > 0, c             # fast commits, slow-path entries, slow-path commits
     assert (orc.dump()["commit_bars"][me] > 0).any()
+
+
+def test_closed_loop_cluster_matches_oracle(cuda, oracle):
+    """five per-replica engine objects wired into a cluster (tests/ep_cluster.py: PreAccept fan-out, replies,
+    slow-path Accepts, CommitNotices) against five oracles wired the same way"""
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup
+    G, R, W, K, T = 700, 5, 32, 6, 10
+    engs = [ec.NumpyEngine(EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K), cuda) for r in range(R)]
+    orcs = [oracle.EpOracle(G, R, me=r, W=W, n_keys=K) for r in range(R)]
+    rng = np.random.default_rng(5)
+    slow = fast = 0
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < 0.15 for s in range(R) for q in range(R) if s != q}
+        oe, oo = ec.tick(engs, keys, drop), ec.tick(orcs, keys, drop)
+        for s in range(R):
+            for k in oo[s]:
+                assert np.array_equal(oe[s][k], oo[s][k]), (t, s, k)
+            fast += int((oo[s]["decision"] == 3).sum())
+            slow += int((oo[s]["decision"] == 2).sum())
+    for r in range(R):
+        a, b = engs[r].dump(), orcs[r].dump()
+        for n in b:
+            assert np.array_equal(a[n], b[n]), (r, n)
+    assert fast > 0 and slow > 0
