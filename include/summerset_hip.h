@@ -317,6 +317,14 @@ int smr_raft_replica_handle_request_vote(smr_raft_leader *l, const uint8_t *flag
 int smr_raft_replica_handle_vote_replies(smr_raft_leader *l, const uint64_t *term_dev, const uint8_t *flags_dev,
                                          const uint32_t *order_dev, uint32_t *hb_prev_slot_dev, uint8_t *elected_dev,
                                          void *stream);
+/* smr_raft_leader_append that also reports, per peer p, the first slot of the entries its appends sent to p
+ * (first_sent[p][g]; 0xFFFFFFFF = nothing: handle_logged_leader_append, raft/durability.rs:28-88) */
+int smr_raft_leader_append_emit(smr_raft_leader *l, const uint32_t *n_new_dev, uint32_t *first_sent_dev, void *stream);
+/* Fills `msg` (the arrays are written) with the AppendEntries for one peer: the entries
+ * [first[g], min(first[g] + max_entries, log end)) as ONE message per group (the reference sends one per
+ * appended batch; a follower that handles them in order ends in the same state). */
+int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev, const smr_raft_append_entries *msg,
+                                   void *stream);
 int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
                                 uint32_t *n_trunc_host);
 

@@ -70,6 +70,8 @@ def _declare(L):
     L.orc_raft_new.restype = vp; L.orc_raft_new.argtypes = [u32, u8, u32, u8, u64, u8]
     L.orc_raft_free.argtypes = [vp]
     L.orc_raft_leader_append.argtypes = [vp, vp]
+    L.orc_raft_leader_append_emit.argtypes = [vp, vp, vp]
+    L.orc_raft_gather_entries.argtypes = [vp, vp, u32] + [vp] * 9
     L.orc_raft_handle_replies.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.orc_raft_dump.argtypes = [vp] + [vp] * 11
     L.orc_raft_total_commits.restype = u64; L.orc_raft_total_commits.argtypes = [vp]
@@ -251,6 +253,21 @@ class RaftOracle:
     def append(self, n_new):
         assert n_new.dtype == np.uint32
         lib().orc_raft_leader_append(self.h, _p(n_new))
+
+    def append_emit(self, n_new):
+        """append + [R, G] first slot sent to each peer (0xFFFFFFFF = nothing)"""
+        first = np.zeros((self.R, self.G), np.uint32)
+        lib().orc_raft_leader_append_emit(self.h, _p(n_new), _p(first))
+        return first
+
+    def gather_entries(self, first, K):
+        G = self.G
+        m = dict(flags=np.zeros(G, np.uint8), leader=np.zeros(G, np.uint8), term=np.zeros(G, np.uint64),
+                 prev_slot=np.zeros(G, np.uint32), prev_term=np.zeros(G, np.uint64), n_entries=np.zeros(G, np.uint32),
+                 entry_term=np.zeros((K, G), np.uint64), leader_commit=np.zeros(G, np.uint32), last_snap=np.zeros(G, np.uint32))
+        lib().orc_raft_gather_entries(self.h, _p(np.ascontiguousarray(first)), K, *[_p(m[k]) for k in (
+            "flags", "leader", "term", "prev_slot", "prev_term", "n_entries", "entry_term", "leader_commit", "last_snap")])
+        return m
 
     def handle_replies(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None, order=None):
         assert reply_term.dtype == np.uint64 and end_slot.dtype == np.uint32 and flags.dtype == np.uint8

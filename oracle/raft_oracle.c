@@ -35,6 +35,7 @@
 enum { ROLE_FOLLOWER = 0, ROLE_CANDIDATE = 1, ROLE_LEADER = 2 };
 #define MAXR 8
 #define NO_LEADER 0xFF
+#define NONE32 0xFFFFFFFFu
 
 typedef struct {
     uint8_t id, population, quorum_cnt, commit_thresh;
@@ -50,6 +51,7 @@ typedef struct {
     uint32_t next_slot[MAXR], try_next_slot[MAXR], match_slot[MAXR];
     uint64_t n_committed, n_redirect, n_reject, n_sent;
     uint64_t n_exec, n_trunc; /* follower: entries submitted for execution, log truncations */
+    uint32_t ae_first[MAXR];  /* first slot sent to each peer during the current append call (NONE32 = nothing) */
 } RaftRep;
 
 typedef struct {
@@ -101,6 +103,7 @@ static void handle_logged_leader_append(RaftRep *r, uint32_t slot) {
         if (prev_slot < r->start_slot) return;            /* logged_err */
         if (prev_slot >= log_end(r)) continue;
         if (slot >= r->try_next_slot[peer]) {
+            if (r->ae_first[peer] == NONE32) r->ae_first[peer] = r->try_next_slot[peer];   /* :44-52 entries from here */
             r->n_sent += slot + 1 - r->try_next_slot[peer];
             r->try_next_slot[peer] = slot + 1;            /* :85 */
         }
@@ -116,10 +119,46 @@ static void handle_req_batch(RaftRep *r, uint32_t W) {
     handle_logged_leader_append(r, slot);                  /* WAL completes at once */
 }
 
-void orc_raft_leader_append(void *h, const uint32_t *n_new) {
+static uint64_t term_at(const RaftRep *r, uint32_t slot, uint32_t W, int *ok);
+
+/* ae_first (may be NULL) [R][G]: the first slot of the entries sent to each peer by this call's appends
+ * (durability.rs:44-88), NONE32 if nothing was sent: all AppendEntries of the call to one peer, taken
+ * together, carry the slots [ae_first, log end) */
+void orc_raft_leader_append_emit(void *h, const uint32_t *n_new, uint32_t *ae_first) {
     RaftCl *cl = (RaftCl *)h;
-    for (uint32_t g = 0; g < cl->G; g++)
-        for (uint32_t k = 0; k < n_new[g]; k++) handle_req_batch(&cl->reps[g], cl->W);
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        for (int p = 0; p < MAXR; p++) r->ae_first[p] = NONE32;
+        for (uint32_t k = 0; k < n_new[g]; k++) handle_req_batch(r, cl->W);
+        if (ae_first) for (int p = 0; p < cl->R; p++) ae_first[(size_t)p * G + g] = r->ae_first[p];
+    }
+}
+void orc_raft_leader_append(void *h, const uint32_t *n_new) { orc_raft_leader_append_emit(h, n_new, NULL); }
+
+/* The AppendEntries a leader's appends produced for one peer, as ONE message per group (the reference sends
+ * one per appended batch, durability.rs:57-80; a follower that handles them in order ends in the same
+ * state): entries [first, min(first + K, log end)), prev = first - 1. */
+void orc_raft_gather_entries(void *h, const uint32_t *first, uint32_t K, uint8_t *flags, uint8_t *leader, uint64_t *term,
+                             uint32_t *prev_slot, uint64_t *prev_term, uint32_t *n_entries, uint64_t *entry_term,
+                             uint32_t *leader_commit, uint32_t *last_snap) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        flags[g] = 0; leader[g] = r->id; term[g] = r->curr_term; prev_slot[g] = 0; prev_term[g] = 0; n_entries[g] = 0;
+        leader_commit[g] = r->last_commit; last_snap[g] = r->last_snap;
+        for (uint32_t k = 0; k < K; k++) entry_term[(size_t)k * G + g] = 0;
+        if (first[g] == NONE32 || r->role != ROLE_LEADER || first[g] < 1 || first[g] > log_end(r)) continue;
+        int ok; uint64_t pt = term_at(r, first[g] - 1, cl->W, &ok);
+        if (!ok) continue;                                  /* prev fell out of the ring: nothing to send (harness) */
+        uint32_t n = log_end(r) - first[g];
+        if (n > K) n = K;
+        flags[g] = 1; prev_slot[g] = first[g] - 1; prev_term[g] = pt; n_entries[g] = n;
+        for (uint32_t k = 0; k < n; k++) {
+            int ok2; entry_term[(size_t)k * G + g] = term_at(r, first[g] + k, cl->W, &ok2);
+        }
+    }
 }
 
 /* leadership.rs:16-72; returns 1 iff the role was not Follower and now is */

@@ -139,6 +139,8 @@ SYMBOLS = [
     ("smr_raft_replica_handle_request_vote", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_replica_handle_vote_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_replica_dump_votes", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_leader_append_emit", _i, [_vp, _vp, _vp, _vp]),
+    ("smr_raft_leader_gather_entries", _i, [_vp, _vp, C.POINTER(RaftAppendEntries), _vp]),
     ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),
     ("smr_ep_replica_destroy", None, [_vp]),
     ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),

@@ -45,10 +45,14 @@ __device__ __forceinline__ void raft_flush(const RaftView &v, unsigned int c[4])
     }
 }
 
-__global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, const uint32_t *__restrict__ n_new) {
+__global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, const uint32_t *__restrict__ n_new,
+                                                          uint32_t *__restrict__ ae_first) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
     if (g < v.G) {
+        uint32_t fs[RMAX];                                     // first slot sent to each peer by this call's appends
+#pragma unroll
+        for (int p = 0; p < RMAX; p++) fs[p] = 0xFFFFFFFFu;
         const uint32_t n = n_new[g];
         if (n) {
             if (v.role[g] != ROLE_LEADER) c[1] = n;            // request.rs:19-42 redirect
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                         uint32_t prev = tn[p] - 1;
                         if (prev < start) break;                 // logged_err
                         if (prev >= len) continue;
-                        if (slot >= tn[p]) { c[3] += slot + 1 - tn[p]; tn[p] = slot + 1; }
+                        if (slot >= tn[p]) { if (fs[p] == 0xFFFFFFFFu) fs[p] = tn[p]; c[3] += slot + 1 - tn[p]; tn[p] = slot + 1; }
                     }
                 }
                 v.log_len[g] = len;
@@ -80,6 +84,10 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                 for (int p = 0; p < RMAX; p++)
                     if ((uint32_t)p < v.R && (uint32_t)p != v.me) v.try_next_slot[(size_t)p * v.G + g] = tn[p];
             }
+        }
+        if (ae_first) {
+#pragma unroll
+            for (int p = 0; p < RMAX; p++) if ((uint32_t)p < v.R) ae_first[(size_t)p * v.G + g] = fs[p];
         }
     }
     raft_flush(v, c);
@@ -416,6 +424,34 @@ __global__ __launch_bounds__(256) void raft_vote_replies_kernel(const RaftView v
     elected[g] = el;
 }
 
+// The AppendEntries a leader's appends produced for one peer, as ONE message per group (the reference
+// sends one per appended batch, durability.rs:57-80; a follower handling them in order ends in the same
+// state): entries [first, min(first + K, log end)), prev = first - 1.
+__global__ __launch_bounds__(256) void raft_gather_kernel(const RaftView v, const uint32_t *__restrict__ first, uint32_t K,
+                                                          uint8_t *__restrict__ flags, uint8_t *__restrict__ leader,
+                                                          uint64_t *__restrict__ term, uint32_t *__restrict__ prev_slot,
+                                                          uint64_t *__restrict__ prev_term, uint32_t *__restrict__ n_entries,
+                                                          uint64_t *__restrict__ entry_term, uint32_t *__restrict__ leader_commit,
+                                                          uint32_t *__restrict__ last_snap) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    RaftLane L(v, g);
+    const uint32_t f = first[g];
+    uint8_t fl = 0; uint32_t ps = 0, n = 0; uint64_t pt = 0;
+    if (f != 0xFFFFFFFFu && L.role == ROLE_LEADER && f >= 1 && f <= L.len && L.term_at(f - 1, pt)) {
+        n = L.len - f;
+        if (n > K) n = K;
+        fl = 1; ps = f - 1;
+    } else pt = 0;
+    for (uint32_t k = 0; k < K; k++) {
+        uint64_t t = 0;
+        if (k < n) L.term_at(f + k, t);
+        entry_term[(size_t)k * v.G + g] = t;
+    }
+    flags[g] = fl; leader[g] = (uint8_t)v.me; term[g] = L.term; prev_slot[g] = ps; prev_term[g] = pt; n_entries[g] = n;
+    leader_commit[g] = L.commit; last_snap[g] = L.snap;
+}
+
 }  // namespace smr
 
 using namespace smr;
@@ -496,7 +532,8 @@ void smr_raft_leader_destroy(smr_raft_leader *l) {
 
 int smr_raft_leader_append(smr_raft_leader *l, const uint32_t *n_new_dev, void *stream) {
     if (!l || !n_new_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    hipLaunchKernelGGL(raft_append_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev);
+    hipLaunchKernelGGL(raft_append_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
+                       (uint32_t *)nullptr);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -615,6 +652,27 @@ int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uin
     SMR_HIP_TRY(hipMemcpy(votes_host, l->v.votes, G, hipMemcpyDeviceToHost));
     if (n_exec_host) SMR_HIP_TRY(hipMemcpy(n_exec_host, l->v.n_exec, G * 4, hipMemcpyDeviceToHost));
     if (n_trunc_host) SMR_HIP_TRY(hipMemcpy(n_trunc_host, l->v.n_trunc, G * 4, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_raft_leader_append_emit(smr_raft_leader *l, const uint32_t *n_new_dev, uint32_t *first_sent_dev, void *stream) {
+    if (!l || !n_new_dev || !first_sent_dev) return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_append_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
+                       first_sent_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev, const smr_raft_append_entries *m,
+                                   void *stream) {
+    if (!l || !first_dev || !m || !m->flags || !m->leader || !m->term || !m->prev_slot || !m->prev_term || !m->n_entries ||
+        !m->leader_commit || !m->last_snap || (m->max_entries && !m->entry_term))
+        return fail(SMR_ERR_ARG, "raft: null argument");
+    hipLaunchKernelGGL(raft_gather_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, first_dev,
+                       m->max_entries, (uint8_t *)m->flags, (uint8_t *)m->leader, (uint64_t *)m->term, (uint32_t *)m->prev_slot,
+                       (uint64_t *)m->prev_term, (uint32_t *)m->n_entries, (uint64_t *)m->entry_term,
+                       (uint32_t *)m->leader_commit, (uint32_t *)m->last_snap);
+    SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
 

@@ -49,6 +49,27 @@ class RaftLeaderGroup:
         """append n_new[g] entries of the current term to every group's log"""
         check(self._L.smr_raft_leader_append(self._h, _ptr(n_new), self._stream(stream)))
 
+    def handle_req_batch_emit(self, n_new, stream=None):
+        """handle_req_batch + [R, G] first slot of the entries sent to each peer (-1 = nothing)"""
+        import torch
+        first = torch.zeros((self.R, self.G), dtype=torch.int32, device=n_new.device)
+        check(self._L.smr_raft_leader_append_emit(self._h, _ptr(n_new), _ptr(first), self._stream(stream)))
+        return first
+
+    def gather_entries(self, first, max_entries, stream=None):
+        """the AppendEntries for one peer out of my log: first[g] = first slot to send (row of handle_req_batch_emit)"""
+        import torch
+        dev, G, K = first.device, self.G, int(max_entries)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        m = dict(flags=z(G, torch.uint8), leader=z(G, torch.uint8), term=z(G, torch.int64), prev_slot=z(G, torch.int32),
+                 prev_term=z(G, torch.int64), n_entries=z(G, torch.int32), entry_term=z((K, G), torch.int64),
+                 leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
+        msg = RaftAppendEntries(_ptr(m["flags"]), _ptr(m["leader"]), _ptr(m["term"]), _ptr(m["prev_slot"]),
+                                _ptr(m["prev_term"]), _ptr(m["n_entries"]), _ptr(m["entry_term"]), K,
+                                _ptr(m["leader_commit"]), _ptr(m["last_snap"]))
+        check(self._L.smr_raft_leader_gather_entries(self._h, _ptr(first), C.byref(msg), self._stream(stream)))
+        return m
+
     def handle_msg_append_entries_reply(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None,
                                         order=None, stream=None):
         """one AppendEntriesReply per (peer, group); device tensors shaped [R, G]"""

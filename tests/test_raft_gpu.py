@@ -141,3 +141,44 @@ def test_follower_and_elections_match_oracle(cuda, oracle, G, W):
     assert (roles == 0).any() and (roles == 1).any() and (roles == 2).any()      # every role was reached
     v = orc.dump_votes()
     assert v["n_trunc"].sum() > 0 and v["n_exec"].sum() > 0
+
+
+def test_closed_loop_cluster_matches_oracle(cuda, oracle):
+    """five per-replica engine objects wired into a Raft cluster (tests/raft_cluster.py: elections, the
+    AppendEntries the leaders' appends produce, replies, match-index quorum) against five oracles wired the same way"""
+    import raft_cluster as rc
+    from summerset_amd import RaftLeaderGroup
+    G, W, K, R = 600, 64, 8, 5
+    engs = [rc.NumpyRaft(RaftLeaderGroup(G, R, leader_id=r, window=W, term=1), cuda) for r in range(R)]
+    orcs = [oracle.RaftOracle(G, R, W, leader_id=r, term=1) for r in range(R)]
+    for x in engs + orcs:
+        x.preset(rc.FOLLOWER, 0xFF, 0)
+    rng = np.random.default_rng(9)
+    none = np.full((R, G), 0xFF, np.uint8)
+
+    def same(step):
+        for r in range(R):
+            a, b = engs[r].dump(), orcs[r].dump()
+            for n in b:
+                assert np.array_equal(a[n], b[n]), (step, r, n)
+            va, vb = engs[r].dump_votes(), orcs[r].dump_votes()
+            for n in vb:
+                assert np.array_equal(va[n].astype(np.uint64), vb[n].astype(np.uint64)), (step, r, n)
+
+    to = none.copy()
+    to[np.arange(G) % R, np.arange(G)] = 0xFE               # first election: replica g % 5 of each group
+    for reps in (engs, orcs):
+        rc.tick(reps, to, np.zeros((R, G), np.uint32), K)
+    same("election")
+    for t in range(16):
+        n_new = rng.integers(0, 4, (R, G)).astype(np.uint32)
+        to = none.copy()
+        if t == 7:                                          # a second election in a third of the groups
+            gs = np.arange(0, G, 3)
+            to[(gs + 2) % R, gs] = (gs % R).astype(np.uint8)
+        for reps in (engs, orcs):
+            rc.tick(reps, to, n_new, K)
+        same(t)
+    d = [o.dump() for o in orcs]
+    assert min(int(np.stack([x["last_commit"] for x in d]).max(axis=0).min()), 99) > 5
+    assert (np.stack([x["curr_term"] for x in d]).max(axis=0) == 2).any()
