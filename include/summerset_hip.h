@@ -213,7 +213,8 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]);
  * instead of the steady-state fast path (a performance, not a correctness, figure) */
 int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out);
 
-/* debug: 64 wall-clock stamps (100 MHz) written by one block of the quorum kernel */
+/* debug: 64 wall-clock stamps (100 MHz) of the cooperative jobs' phases; all zero unless the library was
+ * built with -DSMR_JOB_STAMPS (tools/dbg_stamps.py) */
 int smr_mp_debug_stamps(smr_mp_cluster *c, uint64_t *out64);
 
 /* Drain replica `rep`'s committed-slot list (leader-side commits since the

@@ -14,6 +14,7 @@ SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep
 HEADERS = ["smr_common.h", "mp_types.h", "mp_device.h", os.path.join("..", "..", "include", "summerset_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("SMR_EXTRA_HIPCC_FLAGS", "").split()       # e.g. -DSMR_JOB_STAMPS for tools/dbg_stamps.py
 
 
 def _stale(target, deps):

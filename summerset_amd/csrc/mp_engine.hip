@@ -53,7 +53,13 @@ __device__ __forceinline__ void flush_job(const Lane &J) {
 // wavefront takes the lanes that need it one at a time and ALL 64 lanes execute that
 // lane's (group, replica) handler in uniform mode (Lane::set_uniform), slot loops
 // strided by lane.  `pending` = this lane has such a job.
+// phase stamps of the cooperative jobs (read back by smr_mp_debug_stamps): only in a -DSMR_JOB_STAMPS
+// build (tools/dbg_stamps.py), nothing in the shipped kernels
+#ifdef SMR_JOB_STAMPS
 #define JSTAMP(k) do { if (__lane_id() == 0) P.dbg[(k)] = wall_clock64(); } while (0)
+#else
+#define JSTAMP(k) do { } while (0)
+#endif
 #define SMR_FOR_EACH_JOB(pending, src)                                            \
     for (unsigned long long _jm = __ballot(pending); _jm; _jm &= _jm - 1)        \
         if (const int src = __ffsll((long long)_jm) - 1; true)

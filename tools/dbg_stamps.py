@@ -1,3 +1,4 @@
+# needs a stamps build:  SMR_EXTRA_HIPCC_FLAGS=-DSMR_JOB_STAMPS python summerset_amd/build.py --force
 import sys; sys.path.insert(0,'.')
 import numpy as np, torch, ctypes as C
 from summerset_amd import MultiPaxosCluster, stream
