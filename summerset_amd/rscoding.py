@@ -68,6 +68,43 @@ class RSCodewordBatch:
     def from_null(cls, n, num_data_shards, num_parity_shards, device="cuda"):
         return cls(n, 0, num_data_shards, num_parity_shards, device=device)
 
+    # -- shard sets (rscoding.rs:253-346): what an RSPaxos leader fans out and a follower collects ----
+    def subset_copy(self, subset, copy_data=False):
+        """a batch that owns a copy of the shards whose bit is set in `subset` (a bitmap over shard ids);
+        shards the source does not hold stay missing.  (`copy_data`: the reference also clones its
+        `data_copy`; this mirror keeps no separate data copy, the data shards are the data.)"""
+        if self.data_len == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if subset >> (self.d + self.p):
+            raise SummersetError(_lib.SMR_ERR_ARG, "shard index %d out-of-bound" % (subset.bit_length() - 1))
+        out = RSCodewordBatch(self.n, self.data_len, self.d, self.p, device=self.buf.device)
+        for k in range(self.d + self.p):
+            if (subset >> k) & 1 and (self.avail >> k) & 1:
+                out.shard(k).copy_(self.shard(k))
+                out.avail |= 1 << k
+        return out
+
+    def absorb_other(self, other):
+        """take the shards `other` holds and I do not (rscoding.rs:296-346); a null batch adopts the geometry"""
+        if self.d != other.d:
+            raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards mismatch: expected %d, other %d" % (self.d, other.d))
+        if self.p != other.p:
+            raise SummersetError(_lib.SMR_ERR_ARG, "num_parity_shards mismatch: expected %d, other %d" % (self.p, other.p))
+        if self.data_len != 0 and self.data_len != other.data_len:
+            raise SummersetError(_lib.SMR_ERR_ARG, "data_len mismatch: expected %d, other %d" % (self.data_len, other.data_len))
+        if self.shard_len != 0 and self.shard_len != other.shard_len:
+            raise SummersetError(_lib.SMR_ERR_ARG, "shard_len mismatch: expected %d, other %d" % (self.shard_len, other.shard_len))
+        if self.n != other.n:
+            raise SummersetError(_lib.SMR_ERR_ARG, "batch size mismatch: expected %d, other %d" % (self.n, other.n))
+        if self.data_len == 0:                      # null so far: same data_len / shard_len as the input
+            fresh = RSCodewordBatch(self.n, other.data_len, self.d, self.p, device=other.buf.device)
+            self.data_len, self.shard_len, self.cw_stride, self.buf = fresh.data_len, fresh.shard_len, fresh.cw_stride, fresh.buf
+        for k in range(self.d + self.p):
+            if (other.avail >> k) & 1 and not (self.avail >> k) & 1:
+                self.shard(k).copy_(other.shard(k))
+                self.avail |= 1 << k
+        other.avail = 0                             # the reference moves the shards out of `other`
+
     # -- accessors (rscoding.rs:343-434) -------------------------------------
     def num_data_shards(self):
         return self.d

@@ -174,3 +174,41 @@ def test_padding_bytes_are_never_read(cuda, oracle):
     for i in range(n):
         assert np.array_equal(got[i, :, :sl], oracle.rs_encode(3, 2, raw[i, :L]))
     assert (got[:, :, sl:] == 0).all()                              # nothing written past shard_len
+
+
+def test_subset_copy_and_absorb_other_rspaxos_flow(cuda, oracle):
+    """what RSPaxos does with a request batch (rspaxos/request.rs:127-142, messages.rs:227-259): the leader
+    encodes, hands every follower a one-shard subset, and a replica that collected any d shards rebuilds
+    the data (rscoding.rs:253-346, 697-876 for the error cases)"""
+    import torch
+    from summerset_amd import RSCodewordBatch
+    from summerset_amd._lib import SummersetError
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, (33, 1000), dtype=np.uint8)
+    cw = RSCodewordBatch.from_data(torch.from_numpy(data).to(cuda), 3, 2)
+    cw.compute_parity()
+    parts = [cw.subset_copy(1 << k) for k in range(5)]
+    assert [p.avail_shards() for p in parts] == [1] * 5 and parts[3].avail_parity_shards() == 1
+    for got in ([4, 1, 3], [0, 1, 2], [2, 3, 4]):
+        mine = RSCodewordBatch.from_null(33, 3, 2, device=cuda)
+        for k in got:
+            mine.absorb_other(cw.subset_copy(1 << k))
+        assert mine.avail_shards() == 3 and mine.data_len == 1000 and mine.shard_len == cw.shard_len
+        mine.reconstruct_data()
+        assert np.array_equal(mine.get_data().cpu().numpy(), data), got
+    two = RSCodewordBatch.from_null(33, 3, 2, device=cuda)
+    two.absorb_other(parts[0]); two.absorb_other(parts[4])
+    assert parts[0].avail_shards() == 0                       # moved out
+    with pytest.raises(SummersetError):
+        two.reconstruct_data()                                # too few shards
+    with pytest.raises(SummersetError):
+        RSCodewordBatch.from_null(33, 3, 2, device=cuda).subset_copy(1)    # "codeword is null"
+    with pytest.raises(SummersetError):
+        cw.subset_copy(1 << 5)                                # shard index out-of-bound
+    with pytest.raises(SummersetError):
+        two.absorb_other(RSCodewordBatch.from_data(torch.from_numpy(data[:, :999].copy()).to(cuda), 3, 2))   # data_len mismatch
+    with pytest.raises(SummersetError):
+        two.absorb_other(RSCodewordBatch.from_data(torch.from_numpy(data).to(cuda), 4, 1))   # scheme mismatch
+    again = cw.subset_copy(0b00111)
+    again.absorb_other(cw.subset_copy(0b11100))               # overlapping shard 2: kept, not overwritten
+    assert again.avail_shards() == 5 and again.verify_parity().all()
