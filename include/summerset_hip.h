@@ -180,12 +180,14 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
 
-/* Device pointer + geometry of replica `rep`'s ack matrix: uint64 reply ballots,
- * 0 = no reply, wave-tiled: the reply of replica r to my j-th outbox entry for
- * group g lives at index (((g/64)*outbox_cap + j)*R + r)*64 + g%64 (n_groups
- * rounded up to a multiple of 64).  A host that receives real AcceptReply
- * messages (or the multi-GPU exchange) fills it before R3. */
-int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes);
+/* Device pointer + geometry of replica `rep`'s ack matrix: one 8-byte word per (outbox entry,
+ * group); byte r of the word = 1 iff replica r sent an AcceptReply to that entry.  An AcceptReply
+ * always carries the ballot of the Accept it answers (multipaxos/durability.rs:108-131), so the cell
+ * does not repeat it.  Wave-tiled: the word of my j-th outbox entry for group g lives at 64-bit index
+ * ((g/64)*outbox_cap + j)*64 + g%64 (n_groups rounded up to a multiple of 64).  A host that receives
+ * real AcceptReply messages (or the multi-GPU exchange) sets the bytes before R3, dropping replies
+ * whose ballot is not the entry's. */
+int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_t *n_bytes);
 
 /* --- read-back (host buffers; each call synchronizes the device) -------- */
 int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_mp_group_state *out);

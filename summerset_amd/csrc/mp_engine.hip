@@ -261,7 +261,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                         m = m_set_vmode(m, VM_SAME);                         // :351
                         m = tok[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                         v.s_bal()[i] = bal0; v.s_val()[i] = tok[u]; v.s_meta()[i] = m;
-                        snd.ack[tix(P.cap * P.R, (jstart + t) * P.R + r, g)] = bal0;   // durability.rs:108-131
+                        snd.ack[ack_ix(P.cap, jstart + t, r, g)] = 1;   // durability.rs:108-131
                     }
                     if (n_new) {
                         if (L.nlb == len0) L.nlb = len0 + n_new;  // still no Null below the log end
@@ -310,7 +310,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 m = m_set_vmode(m, VM_SAME);                     // :351
                 m = val ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                 v.s_bal()[i] = bal0; v.s_val()[i] = val; v.s_meta()[i] = m;
-                snd.ack[tix(P.cap * P.R, j * P.R + r, g)] = bal0; // durability.rs:108-131
+                snd.ack[ack_ix(P.cap, j, r, g)] = 1; // durability.rs:108-131
             }
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
             // slot of the run is Accepting now, beyond it the scan reads memory
@@ -344,7 +344,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
                 if (kind == OB_ACCEPT) {
                     uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
-                    if (L.wr) snd.ack[tix(P.cap * P.R, j * P.R + r, g)] = rep;
+                    if (L.wr) snd.ack[ack_ix(P.cap, j, r, g)] = rep ? 1 : 0;   // rep == bal[k] or none
                 } else if (kind == OB_PREPARE) {
                     L.msg_prepare(s, slot, bal[k]);
                 } else if (kind == OB_HEARTBEAT) {
@@ -385,9 +385,9 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                 const RepView snd{P.rep[0], (size_t)s * P.rep_stride};
                 const RepView &v = L.v;
                 SMR_G const uint32_t *const os = snd.ob_slot(par); SMR_G const uint64_t *const obl = snd.ob_bal(par);
-                SMR_G const uint32_t *const ov = snd.ob_val(par); SMR_G uint64_t *const ack = snd.ack();
+                SMR_G const uint32_t *const ov = snd.ob_val(par); SMR_G uint8_t *const ack = snd.ack();
                 SMR_G uint64_t *const sb = v.s_bal(); SMR_G uint32_t *const sv = v.s_val(); SMR_G uint32_t *const sm = v.s_meta();
-                const uint32_t cnt = the_cnt, Wm = P.Wmask, W = P.W, R = P.R, start = L.start;
+                const uint32_t cnt = the_cnt, Wm = P.Wmask, W = P.W, start = L.start;
                 const uint64_t bms = L.bms;
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_RBK | (s << M_SRC_SH) | (VM_SAME << M_VMODE_SH);
                 uint32_t len = L.len;
@@ -405,7 +405,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                             if (j0 + k >= cnt) break;
                             const size_t i = tix(W, (len + j0 + k) & Wm, g);
                             sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
-                            ack[tix(P.cap * R, (j0 + k) * R + r, g)] = bms;
+                            ack[ack_ix(P.cap, j0 + k, r, g)] = 1;
                         }
                     }
                     len += cnt;
@@ -429,7 +429,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         }
                         const size_t i = tix(W, len & Wm, g);
                         sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
-                        ack[tix(P.cap * R, (j0 + k) * R + r, g)] = bms;
+                        ack[ack_ix(P.cap, j0 + k, r, g)] = 1;
                         len++;
                         fast_done++;
                     }
@@ -510,13 +510,18 @@ __device__ __forceinline__ uint32_t tally_valid(uint32_t m, uint64_t b, uint32_t
     return m;
 }
 
+// `aw` = the row's ack word (byte q = 1 iff replica q answered), `eb` = the ballot of the Accept the row
+// is about, which is also the ballot every answer carries; `me` never answers itself
 template <int NR>
-__device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t ctl, const uint64_t (&a)[NR],
+__device__ __forceinline__ uint32_t tally_row(uint32_t m, uint64_t b, uint32_t ctl, uint64_t aw, uint32_t me, uint64_t eb,
                                               uint64_t bpd, uint32_t thresh, uint32_t R, bool &changed,
                                               bool &committed) {
     uint32_t valid = 0;
+    if (eb != 0 && eb == bpd) {                                    // messages.rs:388: reply ballot == bal_prepared
 #pragma unroll
-    for (int q = 0; q < NR; q++) valid |= (uint32_t)(a[q] != 0 && a[q] == bpd) << q;
+        for (int q = 0; q < NR; q++) valid |= ((uint32_t)(aw >> (8 * q)) & 1u) << q;
+        valid &= ~(1u << me);
+    }
     return tally_valid<NR>(m, b, ctl, valid, bpd, thresh, R, changed, committed);
 }
 
@@ -529,7 +534,9 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     const int par = L.par;
     const RepView &v = L.v;
     constexpr int C = 8;                                         // ack-matrix rows per batch of loads
-    SMR_G const uint32_t *const os = v.ob_slot(par); SMR_G const uint64_t *const ack = v.ack();
+    SMR_G const uint32_t *const os = v.ob_slot(par);
+    SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)v.ack();   // one word per (entry, group), byte q = replica q
+    SMR_G const uint64_t *const obl = v.ob_bal(par);
     SMR_G uint32_t *const sm = v.s_meta(); SMR_G const uint64_t *const sb = v.s_bal();
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
     const bool lead = L.is_leader();
@@ -544,11 +551,9 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const bool in = j < cnt;
             const size_t o = tix(P.cap, j, g);
             const uint32_t e = in ? os[o] : 0u;
+            const uint64_t eb = in ? obl[o] : 0ull;
             const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-            uint64_t a[NR];
-#pragma unroll
-            for (int q = 0; q < NR; q++)
-                a[q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, j * R + q, g)] : 0ull;
+            const uint64_t a = in ? ackw[o] : 0ull;
             const uint32_t slot = e & OB_SLOT_MASK;
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
             const size_t i = tix(P.W, slot & Wm, g);
@@ -556,7 +561,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint64_t b = have ? sb[i] : 0ull;
             uint32_t mk = m0;
             bool changed = false, committed = false;
-            if (have && lead && (mk & M_LBK)) mk = tally_row<NR>(m0, b, ctl, a, bpd, thresh, R, changed, committed);
+            if (have && lead && (mk & M_LBK)) mk = tally_row<NR>(m0, b, ctl, a, d, eb, bpd, thresh, R, changed, committed);
             if (changed && !committed) sm[i] = mk;               // every lane owns its row's slot
             unsigned long long cm = __ballot(changed && committed);
             {
@@ -606,19 +611,19 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     // regular outbox (steady-state appends): entry j is the Accept for slot (reg - 1) + j, so
     // nothing depends on ob_slot and all loads of a batch go out together
     const uint32_t reg = v.ob_reg(par)[g];
+    const uint64_t rbal = reg ? v.ob_rbal(par)[g] : 0ull;
     for (uint32_t j0 = 0; j0 < cnt; j0 += C) {
         uint32_t e[C], ctl[C], m[C];
-        uint64_t a[C][NR], b[C];
+        uint64_t b[C], eb[C], a[C];
         bool have[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 1: everything addressed by (j, g) alone
             const bool in = j0 + k < cnt;
             const size_t o = tix(P.cap, j0 + k, g);
             e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
+            eb[k] = !in ? 0ull : (reg ? rbal : obl[o]);
             ctl[k] = (in && ackctl) ? ackctl[(size_t)(j0 + k) * G + g] : SMR_CTL_IDENTITY;
-#pragma unroll
-            for (int q = 0; q < NR; q++)
-                a[k][q] = (in && (uint32_t)q < R && (uint32_t)q != d) ? ack[tix(P.cap * R, (j0 + k) * R + q, g)] : 0ull;
+            a[k] = in ? ackw[o] : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 2: the slots those Accepts name
@@ -639,7 +644,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             uint32_t mk = m[k];
             if (!lead || !(mk & M_LBK)) continue;
             bool changed = false, committed = false;
-            mk = tally_row<NR>(mk, b[k], ctl[k], a[k], bpd, thresh, R, changed, committed);
+            mk = tally_row<NR>(mk, b[k], ctl[k], a[k], d, eb[k], bpd, thresh, R, changed, committed);
             if (!changed) continue;
             const size_t i = tix(P.W, slot & Wm, g);
             if (!committed) { if (L.wr) sm[i] = mk; continue; }
@@ -706,7 +711,6 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #define TALLY_C 4
 #endif
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
-    constexpr int NC = NR - 1;                                  // ack columns: every replica but mine
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 64 + lane;
     const uint32_t gg = g < P.G ? g : 0;
@@ -737,16 +741,18 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     const MpRep &v0 = P.rep[0];
     SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
     SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
-    SMR_G const uint64_t *const ack = rep_shift(v0.ack, ro);
+    SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)rep_shift(v0.ack, ro);
     SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
     const uint32_t q4 = (cnt + 3) / 4;
     const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
     // ---- round 2: my replica's scalars, and the ack-matrix rows of pass 0 ------------------------
     uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0;
     uint64_t bpd = 0;
-    uint32_t ctl[C]; uint64_t a[C][NC];
+    uint32_t ctl[C];
+    uint64_t a[C], rbal = 0;
     if (cand) {
         reg = rep_shift(v0.ob_reg[par], ro)[gg]; bpd = rep_shift(v0.bal_prepared, ro)[gg];
+        rbal = rep_shift(v0.ob_rbal[par], ro)[gg];
         leader = rep_shift(v0.leader, ro)[gg];
         start = rep_shift(v0.start_slot, ro)[gg]; len = rep_shift(v0.log_len, ro)[gg];
         cbar = p_cbar[gg]; ebar = p_ebar[gg]; abar = rep_shift(v0.accept_bar, ro)[gg];
@@ -757,11 +763,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             const uint32_t j = j0 + k;
             const bool in = cand && j < jhi;
             ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const uint32_t qq = (uint32_t)c + ((uint32_t)c >= dl ? 1u : 0u);
-                a[k][c] = (in && qq < R) ? ack[tix(P.cap * R, j * R + qq, g)] : 0ull;
-            }
+            a[k] = in ? ackw[tix(P.cap, j, g)] : 0ull;
         }
     };
     load_acks(jlo);
@@ -787,10 +789,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             uint32_t mk = have ? m[k] : 0u;
             bool changed = false, committed = false;
             if (have && (mk & M_LBK)) {
-                uint32_t valid = 0;
+                uint32_t valid = 0;                              // an answer carries the Accept's ballot: ob_rbal
+                if (rbal != 0 && rbal == bpd) {
 #pragma unroll
-                for (int c = 0; c < NC; c++)
-                    valid |= (uint32_t)(a[k][c] != 0 && a[k][c] == bpd) << ((uint32_t)c + ((uint32_t)c >= dl ? 1u : 0u));
+                    for (int q = 0; q < NR; q++) valid |= ((uint32_t)(a[k] >> (8 * q)) & 1u) << q;
+                    valid &= ~(1u << dl);
+                }
                 mk = tally_valid<NR>(mk, b[k], ctl[k], valid, bpd, thresh, R, changed, committed);
             }
             // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
@@ -1076,7 +1080,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
             carve(a, v.ob_val[p], cap * Gp, dry); carve(a, v.ob_aux[p], cap * Gp, dry);
             carve(a, v.ob_reg[p], G, dry); carve(a, v.ob_rbal[p], G, dry);
         }
-        carve(a, v.ack, cap * R * Gp, dry);
+        carve(a, v.ack, cap * Gp * 8, dry);          // one 8-byte word per (entry, group)
         carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);
         carve(a, v.pr_trig, G, dry); carve(a, v.pr_endp, G, dry); carve(a, v.pr_abar, G, dry);
         carve(a, v.pr_bal, G, dry);
@@ -1376,10 +1380,10 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
     return smr_mp_end_tick(c);
 }
 
-int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint64_t **ack_dev, uint64_t *n_bytes) {
+int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_t *n_bytes) {
     if (!c || rep >= c->cfg.population || !ack_dev) return fail(SMR_ERR_ARG, "mp: bad argument");
     *ack_dev = c->hp.rep[rep].ack;
-    if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * c->cfg.population * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
+    if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
     return SMR_OK;
 }
 

@@ -10,7 +10,7 @@
 //   slot ring           X[tix(W, slot & (W-1), g)]     (Vec<Instance>, mod.rs:426)
 //   outbox (x2 parity)  X[tix(cap, j, g)], j < cap     (bcast_msg of Prepare /
 //                                                       Accept / Heartbeat)
-//   ack matrix          ack[tix(cap*R, j*R + r, g)]    AcceptReply ballot of
+//   ack matrix          ack[tix(cap*R, j*R + r, g)]    u8: AcceptReply (its ballot = the Accept's) of
 //                                                       replica r to my j-th
 //                                                       outbox entry (0 = none)
 //   with tix(rows, row, g) = ((g/64)*rows + row)*64 + g%64   (wave-tiled, see below)
@@ -68,6 +68,15 @@ constexpr int MAXR = 8;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
+inline size_t tix(uint32_t rows, uint32_t row, uint32_t g);
+// byte of replica r in the ack word of (entry j, group g)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t ack_ix(uint32_t cap, uint32_t j, uint32_t r, uint32_t g) { return tix(cap, j, g) * 8 + r; }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
 inline size_t tix(uint32_t rows, uint32_t row, uint32_t g) {
 #ifdef SMR_ROWMAJOR_G   /* experiment only: plain [row][g] with a compile-time group count */
     (void)rows;
@@ -102,8 +111,10 @@ struct MpRep {
     // append produces), so consumers need not read ob_slot / ob_bal.  Any other push clears it.
     SMR_G uint32_t *ob_reg[2];
     SMR_G uint64_t *ob_rbal[2];
-    // replies to my Accepts [cap][R][G]
-    SMR_G uint64_t *ack;
+    // replies to my Accepts: one 8-byte word per (entry j, group), byte r = 1 iff replica r answered my j-th
+    // message.  An AcceptReply always carries the ballot of the Accept it answers (durability.rs:108-131),
+    // so the cell need not repeat it; followers store their byte, the leader loads the word
+    SMR_G uint8_t *ack;
     // my PrepareReply batch of this tick: header [G] + entries [pcap][G]
     SMR_G uint32_t *pr_cnt; SMR_G uint8_t *pr_dest;
     SMR_G uint32_t *pr_trig, *pr_endp, *pr_abar; SMR_G uint64_t *pr_bal;
@@ -151,7 +162,7 @@ struct RepView {
     SMR_HD SMR_G uint32_t *s_lendp() const { return sh(b.s_lendp); }
     SMR_HD SMR_G uint32_t *s_rtrig() const { return sh(b.s_rtrig); }
     SMR_HD SMR_G uint32_t *s_rendp() const { return sh(b.s_rendp); }
-    SMR_HD SMR_G uint64_t *ack() const { return sh(b.ack); }
+    SMR_HD SMR_G uint8_t *ack() const { return sh(b.ack); }
     SMR_HD SMR_G uint32_t *pr_cnt() const { return sh(b.pr_cnt); }
     SMR_HD SMR_G uint8_t *pr_dest() const { return sh(b.pr_dest); }
     SMR_HD SMR_G uint32_t *pr_trig() const { return sh(b.pr_trig); }
