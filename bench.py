@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r1d_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")
 
 
 def pmc_traffic(kernel):
@@ -360,7 +360,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None,
-                     "traffic_source": "profiles/r1d_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                     "traffic_source": "profiles/r1g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                        "tools/pmc_probe.py, bytes per launch at 65536 groups, S=32)",
                      "kernel": "mp_quorum_tally",
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["mp_quorum_tally"]["avg_us"],
