@@ -324,7 +324,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(args.warmup, n_ticks):
-        eng.profile_enable(t % 3 == 0)            # event pairs on every third tick (all tick phases come by): the
+        eng.profile_enable((t - args.warmup) % 3 == 0)   # event pairs on every third tick (all tick phases come by): the
         step(t)                                   # events themselves cost launch-gap time
     torch.cuda.synchronize()
     if world > 1:
