@@ -109,3 +109,23 @@ def test_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 on its own"""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "summerset_hip.h"\nint main(void) { smr_mp_cfg c; c.n_groups = 1; return (int)sizeof(smr_wire_msg) * 0 + (int)c.n_groups - 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                           "-o", str(tmp_path / "abi.o")])
+
+
+def test_cxx_host_loop_example_builds_and_links(engine_lib, tmp_path):
+    """examples/mp_host_loop.cpp (the reference's run() loop over the C-ABI) compiles and links against the
+    built library; running it needs a GPU"""
+    import subprocess
+    out = tmp_path / "mp_host_loop"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "mp_host_loop.cpp"), "-L", os.path.join(ROOT, "summerset_amd"),
+                           "-lsummerset_hip", "-Wl,-rpath," + os.path.join(ROOT, "summerset_amd"), "-o", str(out)])
+    assert out.exists()
