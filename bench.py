@@ -107,6 +107,65 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
     return res
 
 
+def raft_cpu_baseline(S=32, G=4096, seconds=3.0):
+    """oracle/raft_oracle.c on the Raft leg's stream (one core): appends + four replies per group per tick"""
+    from oracle import oracle as O
+    R, W = 5, 512
+    o = O.RaftOracle(G, R, W, leader_id=0, term=2)
+    rng = np.random.default_rng(0x5EED5EED)
+    n_new = np.full(G, S, np.uint32)
+    spent, t = 0.0, 0
+    while spent < seconds:
+        last = 1 + S * (t + 1) - 1
+        lag = rng.integers(0, 4, (R, G))
+        u = rng.random((R, G))
+        flags = (u >= 0.05).astype(np.uint8)
+        term = np.full((R, G), 2, np.uint64)
+        term[(u >= 0.05) & (u < 0.055)] = 1
+        flags[(u >= 0.055) & (u < 0.06)] |= 2
+        end_slot = np.maximum(last - lag, 0).astype(np.uint32)
+        ct = np.full((R, G), 2, np.uint64)
+        cs = np.maximum(end_slot.astype(np.int64) - 1, 1).astype(np.uint32)
+        t0 = time.perf_counter()
+        o.append(n_new)
+        o.handle_replies(term, end_slot, flags, ct, cs)
+        spent += time.perf_counter() - t0
+        t += 1
+    return {"value": o.total_commits() / spent, "unit": "slots/s", "cores": 1, "kind": "port",
+            "sample": "oracle/raft_oracle.c, %d ticks of %d groups, one thread, %.1f s" % (t, G, spent)}
+
+
+def epaxos_cpu_baseline(G=4096, seconds=3.0):
+    """oracle/ep_oracle.c on the EPaxos leg's stream (one core): propose + the four PreAcceptReplies"""
+    from oracle import oracle as O
+    R, W, K = 5, 32, 64
+    o = O.EpOracle(G, R, me=0, W=W, n_keys=K)
+    rng = np.random.default_rng(0x5EED5EED)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    flags = np.ones((R, G), np.uint8)
+    flags[0] = 0
+    ballot = np.full((R, G), 1, np.uint64)
+    spent, t, committed = 0.0, 0, 0
+    while spent < seconds:
+        key = rng.choice(K, G, p=zipf).astype(np.uint8)
+        ex = rng.random((R, G)) < 0.1
+        t0 = time.perf_counter()
+        m = o.propose(key)
+        spent += time.perf_counter() - t0
+        seq = np.ascontiguousarray(np.broadcast_to(m["seq"], (R, G)) + ex.astype(np.uint64))
+        deps = np.broadcast_to(m["deps"], (R, R, G)).copy()
+        d1 = deps[:, 1, :]
+        deps[:, 1, :] = np.where(ex, np.where(d1 == 0xFFFFFFFF, 1, d1 + 1), d1)
+        t0 = time.perf_counter()
+        r = o.handle_pre_accept_replies(m["col"], ballot, seq, np.ascontiguousarray(deps.astype(np.uint32)), flags)
+        spent += time.perf_counter() - t0
+        committed += int((r["decision"] == 3).sum())
+        t += 1
+    return {"value": committed / spent, "unit": "fast-path commits/s (propose + reply handling)", "cores": 1, "kind": "port",
+            "sample": "oracle/ep_oracle.c, %d ticks of %d groups, one thread, %.1f s" % (t, G, spent)}
+
+
 def _time_us(torch, fn, iters):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -382,6 +441,13 @@ def main():
         if not args.no_extra:
             leg("raft_quorum", raft_leg, torch, dev)
             leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
+            if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
+                for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
+                    if isinstance(line.get(name), dict) and "error" not in line[name]:
+                        try:
+                            line[name]["cpu_baseline"] = fn()
+                        except Exception as e:     # noqa: BLE001
+                            line[name]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
