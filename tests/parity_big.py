@@ -1,9 +1,9 @@
 """Large-shape parity run (bench.py's shape): HIP engine vs CPU oracle, compared every few ticks.
-usage: parity_big.py [groups] [timeout_frac] [timeout_span] [ticks] [straggler_ticks]"""
+usage: python tests/parity_big.py [groups] [timeout_frac] [timeout_span] [ticks] [straggler_ticks]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root
 import torch
 
 from oracle import oracle as O
