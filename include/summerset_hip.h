@@ -479,6 +479,28 @@ typedef struct {
  * yet (safetcp.rs:30-70 reads until it is), < 0 if malformed. */
 int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *out);
 
+/* ---- Raft frames (src/protocols/raft/mod.rs:117-234): PeerMsg::{AppendEntries 0, AppendEntriesReply 1,
+ * RequestVote 2, RequestVoteReply 3}; DurEntry::Metadata log record */
+int64_t smr_wire_raft_append_entries(uint64_t term, uint64_t prev_slot, uint64_t prev_term, uint32_t n,
+                                     const uint64_t *entry_term, const uint8_t *reqs, const uint64_t *reqs_off,
+                                     const uint8_t *external, uint64_t leader_commit, uint64_t last_snap, uint8_t *out,
+                                     uint64_t cap);
+int64_t smr_wire_raft_append_entries_reply(uint64_t term, uint64_t end_slot, int has_conflict, uint64_t conflict_term,
+                                           uint64_t conflict_slot, uint8_t *out, uint64_t cap);
+int64_t smr_wire_raft_request_vote(uint64_t term, uint64_t last_slot, uint64_t last_term, uint8_t *out, uint64_t cap);
+int64_t smr_wire_raft_request_vote_reply(uint64_t term, int granted, uint8_t *out, uint64_t cap);
+int64_t smr_wal_raft_metadata(uint64_t curr_term, uint8_t voted_for, uint8_t *out, uint64_t cap);
+typedef struct {
+    uint8_t kind;                  /* 0..3 as above, SMR_WIRE_LEAVE, SMR_WIRE_OTHER */
+    uint8_t has_conflict, granted;
+    uint32_t n_entries;
+    uint64_t term, prev_slot, prev_term, leader_commit, last_snap, end_slot, conflict_term, conflict_slot, last_slot,
+        last_term;
+} smr_wire_raft_msg;
+/* as smr_wire_decode; the terms of an AppendEntries' entries go to entry_term_out[0 .. max_entries) */
+int64_t smr_wire_raft_decode(const uint8_t *buf, uint64_t len, smr_wire_raft_msg *out, uint64_t *entry_term_out,
+                             uint32_t max_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,12 @@ class EpDumpBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in EP_DUMP_FIELDS]
 
 
+class WireRaftMsg(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("has_conflict", C.c_uint8), ("granted", C.c_uint8), ("n_entries", C.c_uint32)] + \
+               [(n, C.c_uint64) for n in ("term", "prev_slot", "prev_term", "leader_commit", "last_snap", "end_slot",
+                                           "conflict_term", "conflict_slot", "last_slot", "last_term")]
+
+
 class WireMsg(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("has_voted", C.c_uint8), ("slot", C.c_uint64), ("ballot", C.c_uint64),
                 ("trigger_slot", C.c_uint64), ("endprep_slot", C.c_uint64), ("accept_bar", C.c_uint64),
@@ -159,6 +165,12 @@ SYMBOLS = [
     ("smr_wal_accept_data", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
     ("smr_wal_commit_slot", C.c_int64, [_u64, _vp, _u64]),
     ("smr_wire_decode", C.c_int64, [_vp, _u64, C.POINTER(WireMsg)]),
+    ("smr_wire_raft_append_entries", C.c_int64, [_u64, _u64, _u64, C.c_uint32, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _u64]),
+    ("smr_wire_raft_append_entries_reply", C.c_int64, [_u64, _u64, _i, _u64, _u64, _vp, _u64]),
+    ("smr_wire_raft_request_vote", C.c_int64, [_u64, _u64, _u64, _vp, _u64]),
+    ("smr_wire_raft_request_vote_reply", C.c_int64, [_u64, _i, _vp, _u64]),
+    ("smr_wal_raft_metadata", C.c_int64, [_u64, _u8, _vp, _u64]),
+    ("smr_wire_raft_decode", C.c_int64, [_vp, _u64, C.POINTER(WireRaftMsg), _vp, C.c_uint32]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

@@ -10,6 +10,10 @@
 // Vec<(ClientId, ApiRequest)> (src/server/external.rs:33-54: Req 0; src/server/statemach.rs:21-27:
 // Get 0, Put 1).
 //
+// Raft (src/protocols/raft/mod.rs:117-234): PeerMsg { AppendEntries 0, AppendEntriesReply 1, RequestVote 2,
+// RequestVoteReply 3 }, LogEntry { term, reqs, external: bool, log_offset }, DurEntry { Metadata 0 { curr_term,
+// voted_for: u8 (None = 255) }, LogEntry 1 }.
+//
 // bincode "standard": little-endian varint integers (< 251: one byte; 0xFB + u16; 0xFC + u32;
 // 0xFD + u64), enum variant index as varint u32, Option as a 0/1 byte, String / Vec as varint
 // length + elements, struct / tuple fields in declaration order.  bincode is not vendored with the
@@ -210,6 +214,105 @@ int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *m) {
             break;
         }
         default: return (int64_t)(8 + plen);                                      // ReadQuery & co: not this path
+    }
+    if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
+    return (int64_t)(8 + plen);
+}
+
+/* ---- Raft ------------------------------------------------------------------------------------ */
+// entries: n LogEntry records; entry i = (entry_term[i], reqs bytes reqs[reqs_off[i] .. reqs_off[i + 1]),
+// external[i]); log_offset is written as 0, as the leader does before sending (durability.rs:49-53
+// clones the in-memory entry; followers reset it, messages.rs:150)
+int64_t smr_wire_raft_append_entries(uint64_t term, uint64_t prev_slot, uint64_t prev_term, uint32_t n,
+                                     const uint64_t *entry_term, const uint8_t *reqs, const uint64_t *reqs_off,
+                                     const uint8_t *external, uint64_t leader_commit, uint64_t last_snap, uint8_t *out,
+                                     uint64_t cap) {
+    if (n && (!entry_term || !reqs || !reqs_off)) return fail(SMR_ERR_ARG, "wire: null entry arrays");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(0);                                                    // PeerMessage::Msg, AppendEntries
+    w.varint(term); w.varint(prev_slot); w.varint(prev_term);
+    w.varint(n);
+    for (uint32_t i = 0; i < n; i++) {
+        w.varint(entry_term[i]);
+        w.raw(reqs + reqs_off[i], reqs_off[i + 1] - reqs_off[i]);                // bincode(ReqBatch)
+        w.byte(external && external[i] ? 1 : 0);
+        w.varint(0);                                                             // log_offset
+    }
+    w.varint(leader_commit); w.varint(last_snap);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_raft_append_entries_reply(uint64_t term, uint64_t end_slot, int has_conflict, uint64_t conflict_term,
+                                           uint64_t conflict_slot, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(1); w.varint(term); w.varint(end_slot);
+    w.byte(has_conflict ? 1 : 0);
+    if (has_conflict) { w.varint(conflict_term); w.varint(conflict_slot); }
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_raft_request_vote(uint64_t term, uint64_t last_slot, uint64_t last_term, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(2); w.varint(term); w.varint(last_slot); w.varint(last_term);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_raft_request_vote_reply(uint64_t term, int granted, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(3); w.varint(term); w.byte(granted ? 1 : 0);
+    return frame_done(w, out);
+}
+
+/* DurEntry::Metadata { curr_term, voted_for } log record (voted_for 255 = None, mod.rs:146-151,158-163) */
+int64_t smr_wal_raft_metadata(uint64_t curr_term, uint8_t voted_for, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(curr_term); w.byte(voted_for);                         // u8 is a raw byte
+    return frame_done(w, out);
+}
+
+/* Parses the first Raft TCP frame.  For AppendEntries the entries are walked: entry_term_out[i] (up to
+ * max_entries of them) and n_entries are filled, reqs are skipped. */
+int64_t smr_wire_raft_decode(const uint8_t *buf, uint64_t len, smr_wire_raft_msg *m, uint64_t *entry_term_out,
+                             uint32_t max_entries) {
+    if (!buf || !m) return fail(SMR_ERR_ARG, "wire: null argument");
+    memset(m, 0, sizeof(*m));
+    if (len < 8) return 0;
+    uint64_t plen = 0;
+    for (int i = 0; i < 8; i++) plen = (plen << 8) | buf[i];
+    if (plen > 1000000000000ull) return fail(SMR_ERR_ARG, "wire: invalidly large frame");
+    if (len - 8 < plen) return 0;
+    Rd r{buf + 8, plen};
+    const uint64_t outer = r.varint();
+    if (outer == 2) { m->kind = SMR_WIRE_LEAVE; return (int64_t)(8 + plen); }
+    if (outer != 0) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }
+    const uint64_t v = r.varint();
+    if (v > 3) return fail(SMR_ERR_ARG, "wire: unknown Raft message");
+    m->kind = (uint8_t)v;
+    switch (v) {
+        case 0: {
+            m->term = r.varint(); m->prev_slot = r.varint(); m->prev_term = r.varint();
+            const uint64_t n = r.varint();
+            if (n > plen) { r.ok = false; break; }                               // every entry takes bytes
+            m->n_entries = (uint32_t)n;
+            for (uint64_t i = 0; i < n && r.ok; i++) {
+                const uint64_t t = r.varint();
+                if (entry_term_out && i < max_entries) entry_term_out[i] = t;
+                skip_reqbatch(r);
+                if (r.byte() > 1) r.ok = false;                                  // external
+                r.varint();                                                      // log_offset
+            }
+            m->leader_commit = r.varint(); m->last_snap = r.varint();
+            break;
+        }
+        case 1: {
+            m->term = r.varint(); m->end_slot = r.varint();
+            m->has_conflict = r.byte();
+            if (m->has_conflict > 1) r.ok = false;
+            if (m->has_conflict == 1) { m->conflict_term = r.varint(); m->conflict_slot = r.varint(); }
+            break;
+        }
+        case 2: m->term = r.varint(); m->last_slot = r.varint(); m->last_term = r.varint(); break;
+        case 3: m->term = r.varint(); m->granted = r.byte(); if (m->granted > 1) r.ok = false; break;
     }
     if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
     return (int64_t)(8 + plen);

@@ -4,7 +4,7 @@ smr_wire_* / smr_wal_* (include/summerset_hip.h).  Frames are bytes objects:
 import ctypes as C
 
 from . import _lib
-from ._lib import WireMsg, check
+from ._lib import WireMsg, WireRaftMsg, check
 
 PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, LEAVE, OTHER = 0, 1, 2, 3, 0xFE, 0xFF
 GET, PUT = 0, 1
@@ -75,4 +75,53 @@ def decode(buf):
         return 0, None
     d = {k: getattr(m, k) for k, _ in WireMsg._fields_}
     d["reqs"] = bytes(buf[m.reqs_off:m.reqs_off + m.reqs_len]) if m.reqs_len else b""
+    return int(n), d
+
+
+# ---- Raft (src/protocols/raft/mod.rs:117-234) ----
+RAFT_APPEND_ENTRIES, RAFT_APPEND_ENTRIES_REPLY, RAFT_REQUEST_VOTE, RAFT_REQUEST_VOTE_REPLY = 0, 1, 2, 3
+
+
+def raft_append_entries(term, prev_slot, prev_term, entries, leader_commit, last_snap=0):
+    """entries: [(term, reqs_bytes, external), ...]"""
+    n = len(entries)
+    terms = (C.c_uint64 * max(n, 1))(*[e[0] for e in entries])
+    blob = b"".join(e[1] for e in entries)
+    off, acc = [0], 0
+    for e in entries:
+        acc += len(e[1])
+        off.append(acc)
+    offs = (C.c_uint64 * (n + 1))(*off)
+    ext = (C.c_uint8 * max(n, 1))(*[int(e[2]) for e in entries])
+    return _call("smr_wire_raft_append_entries", term, prev_slot, prev_term, n, terms, blob, offs, ext, leader_commit,
+                 last_snap, cap=128 + len(blob) + 24 * n)
+
+
+def raft_append_entries_reply(term, end_slot, conflict=None):
+    ct, cs = conflict if conflict is not None else (0, 0)
+    return _call("smr_wire_raft_append_entries_reply", term, end_slot, int(conflict is not None), ct, cs)
+
+
+def raft_request_vote(term, last_slot, last_term):
+    return _call("smr_wire_raft_request_vote", term, last_slot, last_term)
+
+
+def raft_request_vote_reply(term, granted):
+    return _call("smr_wire_raft_request_vote_reply", term, int(granted))
+
+
+def wal_raft_metadata(curr_term, voted_for=None):
+    return _call("smr_wal_raft_metadata", curr_term, 255 if voted_for is None else voted_for)
+
+
+def raft_decode(buf, max_entries=64):
+    m = WireRaftMsg()
+    terms = (C.c_uint64 * max_entries)()
+    n = _lib.load().smr_wire_raft_decode(bytes(buf), len(buf), C.byref(m), terms, max_entries)
+    if n < 0:
+        check(int(n))
+    if n == 0:
+        return 0, None
+    d = {k: getattr(m, k) for k, _ in WireRaftMsg._fields_}
+    d["entry_terms"] = list(terms[:min(m.n_entries, max_entries)])
     return int(n), d

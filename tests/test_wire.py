@@ -69,3 +69,35 @@ def test_malformed_frames_are_errors():
         wire.decode(bytes([0x7F]) * 8 + b"x")               # absurd length (safetcp.rs:56-66)
     n, m = wire.decode(bytes([0, 0, 0, 0, 0, 0, 0, 1, 2]))  # PeerMessage::Leave
     assert n == 9 and m["kind"] == wire.LEAVE
+
+
+def test_raft_frames(oracle):
+    rb = wire.reqbatch([(1, 2, ("put", "k", "v"))])
+    f = wire.raft_request_vote(7, 300, 6)
+    assert f == bytes([0, 0, 0, 0, 0, 0, 0, 7, 0, 2, 7, 0xFB, 0x2C, 0x01, 6])
+    assert wire.raft_request_vote_reply(7, True) == bytes([0, 0, 0, 0, 0, 0, 0, 4, 0, 3, 7, 1])
+    assert wire.raft_append_entries_reply(3, 9) == bytes([0, 0, 0, 0, 0, 0, 0, 5, 0, 1, 3, 9, 0])
+    assert wire.raft_append_entries_reply(3, 9, conflict=(2, 4)) == bytes([0, 0, 0, 0, 0, 0, 0, 7, 0, 1, 3, 9, 1, 2, 4])
+    assert wire.wal_raft_metadata(5) == bytes([0, 0, 0, 0, 0, 0, 0, 3, 0, 5, 255])   # voted_for None = ReplicaId::MAX
+    assert wire.wal_raft_metadata(5, 2)[-1] == 2
+    ae = wire.raft_append_entries(4, 10, 3, [(4, rb, True), (4, b"\x00", False)], leader_commit=9, last_snap=1)
+    # 0 0 | term prev_slot prev_term | n=2 | (term reqs external log_offset) x 2 | leader_commit last_snap
+    assert ae[8:14] == bytes([0, 0, 4, 10, 3, 2]) and ae[14] == 4 and ae[15:15 + len(rb)] == rb
+    assert ae[15 + len(rb):] == bytes([1, 0, 4, 0, 0, 0, 9, 1])
+    hb = wire.raft_append_entries(4, 10, 3, [], leader_commit=9)
+    stream = ae + hb + f + wire.raft_append_entries_reply(3, 9, conflict=(2, 4))
+    got = []
+    while stream:
+        n, m = wire.raft_decode(stream)
+        assert n > 0
+        got.append(m)
+        stream = stream[n:]
+    assert [m["kind"] for m in got] == [0, 0, 2, 1]
+    assert (got[0]["term"], got[0]["prev_slot"], got[0]["prev_term"], got[0]["n_entries"], got[0]["entry_terms"],
+            got[0]["leader_commit"], got[0]["last_snap"]) == (4, 10, 3, 2, [4, 4], 9, 1)
+    assert got[1]["n_entries"] == 0 and got[1]["leader_commit"] == 9
+    assert (got[2]["term"], got[2]["last_slot"], got[2]["last_term"]) == (7, 300, 6)
+    assert (got[3]["has_conflict"], got[3]["conflict_term"], got[3]["conflict_slot"], got[3]["end_slot"]) == (1, 2, 4, 9)
+    assert wire.raft_decode(ae[:-1]) == (0, None)
+    with pytest.raises(SummersetError):
+        wire.raft_decode(bytes([0, 0, 0, 0, 0, 0, 0, 2, 0, 9]))     # unknown PeerMsg variant
