@@ -166,6 +166,68 @@ def epaxos_cpu_baseline(G=4096, seconds=3.0):
             "sample": "oracle/ep_oracle.c, %d ticks of %d groups, one thread, %.1f s" % (t, G, spent)}
 
 
+def repnothing_leg(n_ops=200000):
+    """BASELINE config 1 (CPU only, plumbing): RepNothing, 1 group x 1 replica, Put{key = "k%07d" (i mod 5), value =
+    1024 B alnum}, batches of 1, through the C-ABI host path (csrc/rep_nothing.hip); a bounded sample of the
+    1 000 000-op configuration."""
+    from summerset_amd import RepNothingReplica
+    r = RepNothingReplica()
+    rng = np.random.default_rng(0x5EED5EED)
+    alnum = np.frombuffer(b"0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", np.uint8)
+    vals = [alnum[rng.integers(0, 62, 1024)].tobytes() for _ in range(64)]
+    keys = [("k%07d" % i).encode() for i in range(5)]
+    t0 = time.perf_counter()
+    for i in range(n_ops):
+        r.handle_req_batch([(1, i, ("put", keys[i % 5], vals[i & 63]))])
+    dt = time.perf_counter() - t0
+    s = r.stats()
+    assert s["executed"] == n_ops and s["keys"] == 5
+    return {"workload": "RepNothing, 1 group x 1 replica, %d Puts of 1024 B on 5 keys, batches of 1 (host only)" % n_ops,
+            "value": n_ops / dt, "unit": "ops/s", "cores": 1,
+            "note": "Python ctypes call per batch included; WAL accounted (%d bytes), not written" % s["wal_offset"]}
+
+
+def rspaxos_leg(torch, dev, ticks=40, warmup=8):
+    """BASELINE config 4: RSPaxos, 16 384 groups x 5 replicas, one Put of a 4 KiB value per batch: per tick the leader
+    RS(3,2)-encodes the tick's 16 384 request batches (rspaxos/request.rs:71-77) and the batch runs through the
+    MultiPaxos engine with the RSPaxos commit rule majority + fault_tolerance, f = 1 (rspaxos/messages.rs:438-439).
+    The followers' shard-availability gate of RSPaxos is not modelled."""
+    from summerset_amd import MultiPaxosCluster, RSCodewordBatch, stream
+    G, R, S, W, L = 16384, 5, 1, 64, 4113                                     # bincode ReqBatch of one 4 KiB Put
+    cap = W + 4
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, commit_extra=1)
+    eng.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=warmup + ticks, drop_p=0.1, timeout_frac=0.0, hb_every=4,
+                                 rand_rows=S + 4, max_drop=1)                 # 4 of 5 must answer: at most 1 lost
+    pool = []
+    for t in range(4):
+        x = st.tick(t)
+        pool.append({k: torch.from_numpy(x[k]).to(dev) for k in ("req_cnt", "req_val", "ackctl", "req_target")})
+    data = torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev)
+    cw = RSCodewordBatch.from_data(data, 3, 2)
+
+    def step(t):
+        cw.compute_parity()                                                   # the tick's batches -> 5 shards each
+        p = pool[t % 4]
+        eng.tick(req_target=p["req_target"], req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"],
+                 heartbeat=st.heartbeat(t))
+
+    for t in range(warmup):
+        step(t)
+    torch.cuda.synchronize()
+    c0 = eng.counters(0)["commits"]
+    t0 = time.perf_counter()
+    for t in range(warmup, warmup + ticks):
+        step(t)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    commits = eng.counters(0)["commits"] - c0
+    return {"workload": "RSPaxos (f = 1), %d groups x 5 replicas, one 4 KiB Put per group per tick: RS(3,2) encode of the "
+                        "tick's batches (L = %d) + the commit path with threshold majority + 1" % (G, L),
+            "value": commits / dt, "unit": "slots/s", "ms_per_tick": dt / ticks * 1e3,
+            "rs_payload_GiBps": G * L * ticks / 2**30 / dt, "committed_per_tick": commits / ticks}
+
+
 def _time_us(torch, fn, iters):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -441,6 +503,8 @@ def main():
         if not args.no_extra:
             leg("raft_quorum", raft_leg, torch, dev)
             leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
+            leg("rspaxos", rspaxos_leg, torch, dev)
+            leg("repnothing", repnothing_leg)
             if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
                 for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
                     if isinstance(line.get(name), dict) and "error" not in line[name]:
