@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
+    ap.add_argument("--leg", default=None, help="internal: run one secondary leg in this process and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -226,6 +227,15 @@ def rspaxos_leg(torch, dev, ticks=40, warmup=8):
                         "tick's batches (L = %d) + the commit path with threshold majority + 1" % (G, L),
             "value": commits / dt, "unit": "slots/s", "ms_per_tick": dt / ticks * 1e3,
             "rs_payload_GiBps": G * L * ticks / 2**30 / dt, "committed_per_tick": commits / ticks}
+
+
+def leg_isolated(name, timeout=180):
+    """a secondary leg in a child process: a device fault there cannot take the headline line with it"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name], capture_output=True, timeout=timeout)
+    if out.returncode != 0:
+        raise RuntimeError("child exited %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
+    return json.loads(out.stdout.decode().strip().splitlines()[-1])
 
 
 def _time_us(torch, fn, iters):
@@ -401,6 +411,10 @@ def main():
     import torch.distributed as dist
     from summerset_amd import shard
     rank, local, world = shard.env_world()
+    if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
+        torch.cuda.set_device(local)
+        print(json.dumps({"rspaxos": rspaxos_leg}[args.leg](torch, torch.device("cuda", local))))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local)
@@ -503,7 +517,7 @@ def main():
         if not args.no_extra:
             leg("raft_quorum", raft_leg, torch, dev)
             leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
-            leg("rspaxos", rspaxos_leg, torch, dev)
+            leg("rspaxos", leg_isolated, "rspaxos")
             leg("repnothing", repnothing_leg)
             if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
                 for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
