@@ -23,10 +23,36 @@
  *   quorum sizes, default ballot     mod.rs:500-514,693-698
  * WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one
  * key of a small key space (key id < n_keys), which is
- * all identify_deps / refresh_highest_cols look at.  NOT modelled: dependency-
- * graph execution (execution.rs; its order depends on petgraph internals,
- * SURVEY.md §8c), explicit prepare, timers (the set of peers whose hear timer
- * "exploded" is an input of the reply handler).
+ * all identify_deps / refresh_highest_cols look at.  NOT modelled: explicit
+ * prepare, timers (the set of peers whose hear timer "exploded" is an input of
+ * the reply handler).
+ *
+ * Dependency-graph execution (execution.rs:25-149 attempt_execution, :152-211
+ * handle_cmd_result, durability.rs:136-160 the attempts after a commit-bar
+ * advance) is restated literally and switched on with orc_ep_set_execute():
+ * the breadth-first walk over deps, the graph it builds, Tarjan's algorithm on
+ * it, the per-component sort by seq.  Two facts about the reference that the
+ * restatement keeps (tests/test_oracle_ep_exec.py derives them by hand):
+ *   (1) the walk adds an edge from the slot popped just BEFORE a new node to
+ *       that node (execution.rs:57-59), not from a node to its dependencies.
+ *       Every node therefore has at most one incoming edge, made when it joins:
+ *       the graph is a forest, every strongly connected component is a single
+ *       node (n_multi_scc counts the exceptions: none), and the submission
+ *       order is the depth-first post-order of that forest.
+ *   (2) GraphMap::add_edge inserts a missing endpoint, so a slot that was
+ *       pruned as already executing and is popped right before a new node
+ *       re-enters the graph and is submitted AGAIN (n_reexec).
+ * The order then depends on three published behaviours of petgraph 0.8 (not
+ * vendored, "parity unpinned"): GraphMap keeps nodes and edges in insertion
+ * order and into_graph() keeps both orders; Graph::neighbors() walks a node's
+ * outgoing edges newest first; tarjan_scc() starts from nodes in index order,
+ * recurses over neighbors() and emits components in post-order.
+ * The state machine is one Put per instance: kv[key] = token(row, col), result
+ * = the old token; the digest chains (token, old token) in submission order.
+ * Rule 0: command results arrive right after the handler that
+ * submitted them returns, in submission order.
+ * Harness guard: an instance that left its row's ring of W columns counts as
+ * executed (pruned) and cannot re-enter the graph (n_unheld counts the pops).
  *
  * PARITY STATUS: "parity unpinned" -- the reference has no unit tests or
  * fixtures for these handlers and cannot be built here; pinned by hand-derived
@@ -54,6 +80,8 @@ typedef struct {
     uint8_t pa_has[MAXR]; uint64_t pa_seq[MAXR]; DepSet pa_deps[MAXR];   /* pre_accept_replies: HashMap<peer, (seq, deps)> */
 } Inst;
 
+typedef struct { uint8_t row; uint32_t col; } Slot;
+
 typedef struct {
     uint8_t id, population, simple_q, super_q;
     uint32_t n_keys, W;
@@ -62,6 +90,12 @@ typedef struct {
     uint32_t commit_bars[MAXR], exec_bars[MAXR];
     DepSet *highest_cols; uint8_t *hc_present;      /* HashMap<key, DepSet> */
     uint64_t n_fast, n_slow, n_accept_commits;
+    /* execution */
+    uint8_t execute;
+    Slot *execq; uint32_t n_execq, cap_execq;       /* commands submitted to the state machine, results pending */
+    uint64_t *kv;                                   /* [n_keys] token of the last Put, 0 = none */
+    uint64_t digest;
+    uint64_t n_exec, n_reexec, n_unheld, n_multi_scc, n_attempts, n_aborts;
 } EpRep;
 
 typedef struct { uint32_t G; uint8_t R; EpRep *reps; } EpCl;
@@ -109,14 +143,20 @@ void *orc_ep_new(uint32_t G, uint8_t R, uint8_t me, uint32_t W, uint32_t n_keys,
         r->super_q = optimized_quorum ? (uint8_t)(R / 2 + (R / 2 + 1) / 2) : (uint8_t)((R / 2) * 2);   /* :694-698 */
         r->highest_cols = (DepSet *)calloc(n_keys, sizeof(DepSet));
         r->hc_present = (uint8_t *)calloc(n_keys, 1);
+        r->kv = (uint64_t *)calloc(n_keys, sizeof(uint64_t));
     }
     return cl;
+}
+void orc_ep_set_execute(void *h, uint8_t on) {
+    EpCl *cl = (EpCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) cl->reps[g].execute = on;
 }
 void orc_ep_free(void *h) {
     EpCl *cl = (EpCl *)h;
     for (uint32_t g = 0; g < cl->G; g++) {
         for (int i = 0; i < MAXR; i++) free(cl->reps[g].rows[i]);
         free(cl->reps[g].highest_cols); free(cl->reps[g].hc_present);
+        free(cl->reps[g].kv); free(cl->reps[g].execq);
     }
     free(cl->reps); free(cl);
 }
@@ -151,15 +191,181 @@ static void refresh_highest_cols(EpRep *r, int row, uint32_t col, uint8_t key) {
     }
 }
 
-/* durability.rs:104-163 without the execution attempt */
+/* ---- execution.rs:25-149 ---- */
+#define TOKEN(row, col) ((((uint64_t)(row) + 1) << 32) | (uint64_t)(col))
+#define DG_MUL 0x100000001B3ull
+
+typedef struct { Slot *v; uint32_t n, cap; } SlotVec;
+static void sv_push(SlotVec *s, Slot x) {
+    if (s->n == s->cap) { s->cap = s->cap ? s->cap * 2 : 32; s->v = (Slot *)realloc(s->v, sizeof(Slot) * s->cap); }
+    s->v[s->n++] = x;
+}
+static int sv_find(const SlotVec *s, Slot x) {
+    for (uint32_t i = 0; i < s->n; i++) if (s->v[i].row == x.row && s->v[i].col == x.col) return (int)i;
+    return -1;
+}
+
+/* petgraph::algo::tarjan_scc as of 0.6-0.8 (one index per node that doubles as the component mark;
+ * components come out in post-order = reverse topological order) over a Graph given as per-node
+ * lists of outgoing edges, newest edge first */
+typedef struct {
+    uint32_t n; const uint32_t *head, *next, *dst;    /* adjacency: head[v] -> edge, next[edge], dst[edge]; ~0 = end */
+    uint64_t *rootindex;                              /* 0 = None */
+    uint64_t index, componentcount;
+    uint32_t *stack; uint32_t n_stack;
+    uint32_t *out; uint32_t n_out;                    /* component members, concatenated */
+    uint32_t *out_end; uint32_t n_comp;               /* end offset of each component in out */
+} Tarjan;
+static void tarjan_visit(Tarjan *t, uint32_t v) {
+    int v_is_local_root = 1;
+    t->rootindex[v] = t->index++;
+    for (uint32_t e = t->head[v]; e != ~0u; e = t->next[e]) {
+        uint32_t w = t->dst[e];
+        if (t->rootindex[w] == 0) tarjan_visit(t, w);
+        if (t->rootindex[w] < t->rootindex[v]) { t->rootindex[v] = t->rootindex[w]; v_is_local_root = 0; }
+    }
+    if (v_is_local_root) {
+        uint64_t indexadjustment = 1, c = t->componentcount;
+        uint32_t start = t->n_stack;
+        while (start > 0 && !(t->rootindex[v] > t->rootindex[t->stack[start - 1]])) {
+            t->rootindex[t->stack[start - 1]] = c; indexadjustment++; start--;
+        }
+        t->rootindex[v] = c;
+        t->stack[t->n_stack++] = v;
+        for (uint32_t i = start; i < t->n_stack; i++) t->out[t->n_out++] = t->stack[i];
+        t->out_end[t->n_comp++] = t->n_out;
+        t->n_stack = start;
+        t->index -= indexadjustment;
+        t->componentcount--;
+    } else t->stack[t->n_stack++] = v;
+}
+
+static void handle_cmd_result(EpRep *r, int row, uint32_t col);
+
+/* execution.rs:25-149, sync_exec = false */
+static int attempt_execution(EpRep *r, int trow, uint32_t tcol) {
+    const int R = r->population;
+    SlotVec nodes = {0}, ea = {0}, eb = {0}, queue = {0};          /* GraphMap nodes; edges (a -> b); dep_queue */
+    uint32_t qh = 0;
+    Slot last = {0, 0}; int has_last = 0;
+    r->n_attempts++;
+    sv_push(&queue, (Slot){(uint8_t)trow, tcol});
+    while (qh < queue.n) {
+        Slot s = queue.v[qh++];
+        if (s.col >= r->commit_bars[s.row]) {                      /* :41-45 dependency not committed */
+            r->n_aborts++;
+            free(nodes.v); free(ea.v); free(eb.v); free(queue.v);
+            return 0;
+        }
+        int is_held = held(r, s.row, s.col);
+        if (!is_held) r->n_unheld++;
+        if (s.col < r->start_col || !is_held || at(r, s.row, s.col)->status >= ST_EXECUTING) {
+            /* :46-51 already submitted: prune it and what it depends on */
+        } else if (sv_find(&nodes, s) >= 0) {
+            /* :52-54 already in the graph */
+        } else {
+            sv_push(&nodes, s);                                    /* :56-59 */
+            if (has_last && held(r, last.row, last.col)) {
+                sv_push(&ea, last); sv_push(&eb, s);
+                if (sv_find(&nodes, last) < 0) { sv_push(&nodes, last); r->n_reexec++; }   /* GraphMap::add_edge inserts it */
+            }
+            Inst *in = at(r, s.row, s.col);                        /* :62-77 */
+            for (int i = 0; i < R; i++)
+                if (in->deps.c[i] != NONE) sv_push(&queue, (Slot){(uint8_t)i, in->deps.c[i]});
+            if (s.col > r->start_col) sv_push(&queue, (Slot){s.row, s.col - 1});
+        }
+        last = s; has_last = 1;
+    }
+    /* into_graph(): node i = i-th inserted node; edges re-added in insertion order, so each node's
+     * list of outgoing edges ends up newest first */
+    const uint32_t n = nodes.n, m = ea.n;
+    uint32_t *head = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1)), *next = (uint32_t *)malloc(sizeof(uint32_t) * (m + 1));
+    uint32_t *dst = (uint32_t *)malloc(sizeof(uint32_t) * (m + 1));
+    for (uint32_t i = 0; i < n; i++) head[i] = ~0u;
+    for (uint32_t e = 0; e < m; e++) {
+        uint32_t a = (uint32_t)sv_find(&nodes, ea.v[e]), b = (uint32_t)sv_find(&nodes, eb.v[e]);
+        dst[e] = b; next[e] = head[a]; head[a] = e;
+    }
+    Tarjan t; memset(&t, 0, sizeof(t));
+    t.n = n; t.head = head; t.next = next; t.dst = dst;
+    t.rootindex = (uint64_t *)calloc(n + 1, sizeof(uint64_t));
+    t.index = 1; t.componentcount = UINT64_MAX;
+    t.stack = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    t.out = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    t.out_end = (uint32_t *)malloc(sizeof(uint32_t) * (n + 1));
+    for (uint32_t v = 0; v < n; v++) if (t.rootindex[v] == 0) tarjan_visit(&t, v);
+    uint32_t lo = 0;
+    for (uint32_t ci = 0; ci < t.n_comp; ci++) {
+        uint32_t hi = t.out_end[ci];
+        if (hi - lo > 1) r->n_multi_scc++;
+        for (uint32_t i = lo + 1; i < hi; i++) {                   /* :99-102 sort_by_key(seq), stable */
+            uint32_t x = t.out[i]; uint64_t sx = at(r, nodes.v[x].row, nodes.v[x].col)->seq;
+            uint32_t j = i;
+            while (j > lo && at(r, nodes.v[t.out[j - 1]].row, nodes.v[t.out[j - 1]].col)->seq > sx) { t.out[j] = t.out[j - 1]; j--; }
+            t.out[j] = x;
+        }
+        for (uint32_t i = lo; i < hi; i++) {                       /* :105-142 */
+            Slot s = nodes.v[t.out[i]];
+            Inst *in = at(r, s.row, s.col);
+            if (in->key != NO_KEY) {                               /* submit_cmd: the state machine runs them in order */
+                uint64_t tok = TOKEN(s.row, s.col), old = r->kv[in->key];
+                r->kv[in->key] = tok;
+                r->digest = (r->digest ^ tok) * DG_MUL; r->digest = (r->digest ^ old) * DG_MUL;
+                r->n_exec++;
+                if (r->n_execq == r->cap_execq) {
+                    r->cap_execq = r->cap_execq ? r->cap_execq * 2 : 32;
+                    r->execq = (Slot *)realloc(r->execq, sizeof(Slot) * r->cap_execq);
+                }
+                r->execq[r->n_execq++] = s;
+            }
+            in->status = ST_EXECUTING;
+        }
+        lo = hi;
+    }
+    free(head); free(next); free(dst); free(t.rootindex); free(t.stack); free(t.out); free(t.out_end);
+    free(nodes.v); free(ea.v); free(eb.v); free(queue.v);
+    return 1;
+}
+
+/* execution.rs:152-211 (one command per instance) */
+static void handle_cmd_result(EpRep *r, int row, uint32_t col) {
+    if (col < r->start_col || !held(r, row, col)) return;
+    at(r, row, col)->status = ST_EXECUTED;
+    if (col == r->exec_bars[row]) {
+        while (r->exec_bars[row] < r->start_col + r->len[row] && held(r, row, r->exec_bars[row])) {
+            if (at(r, row, r->exec_bars[row])->status < ST_EXECUTED) break;
+            r->exec_bars[row]++;
+        }
+    }
+}
+/* Rule 0: the results of the commands a handler submitted, in submission order, once it has returned */
+static void drain_exec(EpRep *r) {
+    for (uint32_t i = 0; i < r->n_execq; i++) handle_cmd_result(r, r->execq[i].row, r->execq[i].col);
+    r->n_execq = 0;
+}
+
+/* durability.rs:104-163 */
 static void handle_logged_commit_slot(EpRep *r, int row, uint32_t col) {
     if (col < r->start_col) return;
     if (col == r->commit_bars[row]) {
+        int advanced = 0;
         while (r->commit_bars[row] < r->start_col + r->len[row] && held(r, row, r->commit_bars[row])) {
             Inst *in = at(r, row, r->commit_bars[row]);
             if (in->status < ST_COMMITTED) break;
             else if (in->key == NO_KEY) in->status = ST_EXECUTED;
             r->commit_bars[row]++;
+            advanced = 1;
+        }
+        if (advanced && r->execute) {                              /* :136-160 */
+            if (attempt_execution(r, row, r->commit_bars[row] - 1)) {
+                Slot re[MAXR]; int n_re = 0;
+                for (int q = 0; q < r->population; q++) {
+                    uint32_t c = r->commit_bars[q];
+                    if (c > r->exec_bars[q] && held(r, q, c - 1) && at(r, q, c - 1)->status == ST_COMMITTED)
+                        re[n_re++] = (Slot){(uint8_t)q, c - 1};
+                }
+                for (int i = 0; i < n_re; i++) attempt_execution(r, re[i].row, re[i].col);
+            }
         }
     }
 }
@@ -276,7 +482,7 @@ void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_
         in->status = ST_PREACCEPTING;
         m_flags[g] = 1; m_col[g] = col; m_seq[g] = seq;
         for (int i = 0; i < cl->R; i++) m_deps[(size_t)i * G + g] = deps.c[i];
-        handle_msg_pre_accept_reply(r, r->id, row, col, in->bal, seq, &deps, exploded ? exploded[g] : 0);
+        handle_msg_pre_accept_reply(r, r->id, row, col, in->bal, seq, &deps, exploded ? exploded[g] : 0); drain_exec(r);
     }
 }
 
@@ -306,7 +512,7 @@ void orc_ep_handle_pre_accept(void *h, const uint8_t *flags, const uint8_t *peer
             refresh_highest_cols(r, row, c, key[g]);
             in->has_rbk = 1; in->source = peer[g];
             /* WAL completion: leader_bk takes precedence (durability.rs:25), else reply to source */
-            if (in->has_lbk) handle_msg_pre_accept_reply(r, r->id, row, c, in->bal, in->seq, &in->deps, 0);
+            if (in->has_lbk) { handle_msg_pre_accept_reply(r, r->id, row, c, in->bal, in->seq, &in->deps, 0); drain_exec(r); }
             else {
                 r_flags[g] = 1; r_ballot[g] = in->bal; r_seq[g] = in->seq;
                 for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = in->deps.c[i];
@@ -338,7 +544,7 @@ void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64
             if (!(flags[o] & 1)) continue;
             DepSet d = dep_empty();
             for (int i = 0; i < R; i++) d.c[i] = deps[((size_t)p * R + i) * G + g];
-            handle_msg_pre_accept_reply(r, (uint8_t)p, row, col[g], ballot[o], seq[o], &d, exploded ? exploded[g] : 0);
+            handle_msg_pre_accept_reply(r, (uint8_t)p, row, col[g], ballot[o], seq[o], &d, exploded ? exploded[g] : 0); drain_exec(r);
         }
         decision[g] = 0; d_seq[g] = 0;
         for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = NONE;
@@ -378,7 +584,7 @@ void orc_ep_handle_accept(void *h, const uint8_t *flags, const uint8_t *peer, co
             for (int i = 0; i < MAXR; i++) in->deps.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
             refresh_highest_cols(r, row, c, key[g]);
             in->has_rbk = 1; in->source = peer[g];
-            if (in->has_lbk) handle_msg_accept_reply(r, r->id, row, c, in->bal);
+            if (in->has_lbk) { handle_msg_accept_reply(r, r->id, row, c, in->bal); drain_exec(r); }
             else { r_flags[g] = 1; r_ballot[g] = in->bal; }
         }
     }
@@ -400,7 +606,7 @@ void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *
             if (p == r->id || p >= R) continue;
             size_t o = (size_t)p * G + g;
             if (!(flags[o] & 1)) continue;
-            handle_msg_accept_reply(r, (uint8_t)p, row, col[g], ballot[o]);
+            handle_msg_accept_reply(r, (uint8_t)p, row, col[g], ballot[o]); drain_exec(r);
         }
         committed[g] = 0;
         if (held(r, row, col[g]))
@@ -425,7 +631,7 @@ void orc_ep_handle_commit_notice(void *h, const uint8_t *flags, const uint8_t *p
             in->bal = ballot[g]; in->status = ST_COMMITTED; in->seq = seq[g]; in->key = key[g];
             for (int i = 0; i < MAXR; i++) in->deps.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
             refresh_highest_cols(r, row, c, key[g]);
-            handle_logged_commit_slot(r, row, c);
+            handle_logged_commit_slot(r, row, c); drain_exec(r);
         }
     }
 }
@@ -462,5 +668,22 @@ void orc_ep_dump(void *h, uint32_t *len, uint32_t *commit_bars, uint64_t *bal, u
         for (uint32_t k = 0; k < r->n_keys; k++)
             for (int i = 0; i < R; i++)
                 highest_cols[((size_t)k * R + i) * G + g] = r->hc_present[k] ? r->highest_cols[k].c[i] : NONE;
+    }
+}
+
+/* execution state: exec_bars[R][G], kv[n_keys][G], digest[G], counters[6] = commands submitted, of them
+ * re-submissions of an already executing instance, pops of an instance no longer held, components with
+ * more than one node, attempts, aborted attempts */
+void orc_ep_exec_dump(void *h, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (int k = 0; k < 6; k++) counters[k] = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        for (int row = 0; row < cl->R; row++) exec_bars[(size_t)row * G + g] = r->exec_bars[row];
+        for (uint32_t k = 0; k < r->n_keys; k++) kv[(size_t)k * G + g] = r->kv[k];
+        digest[g] = r->digest;
+        counters[0] += r->n_exec; counters[1] += r->n_reexec; counters[2] += r->n_unheld;
+        counters[3] += r->n_multi_scc; counters[4] += r->n_attempts; counters[5] += r->n_aborts;
     }
 }

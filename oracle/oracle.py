@@ -91,6 +91,8 @@ def _declare(L):
     L.orc_ep_handle_accept_replies.argtypes = [vp] + [vp] * 5
     L.orc_ep_handle_commit_notice.argtypes = [vp] + [vp] * 7
     L.orc_ep_dump.argtypes = [vp] + [vp] * 12
+    L.orc_ep_set_execute.argtypes = [vp, u8]
+    L.orc_ep_exec_dump.argtypes = [vp] + [vp] * 4
 
 
 # ---------------------------------------------------------------- GF / RS ---
@@ -346,9 +348,11 @@ EP_NO_KEY = 0xFF
 class EpOracle:
     """G groups of the literal EPaxos command-leader / acceptor restatement (replica `me`)."""
 
-    def __init__(self, G, R=5, me=0, W=32, n_keys=64, optimized_quorum=True):
+    def __init__(self, G, R=5, me=0, W=32, n_keys=64, optimized_quorum=True, execute=False):
         self.G, self.R, self.me, self.W, self.n_keys = G, R, me, W, n_keys
         self.h = lib().orc_ep_new(G, R, me, W, n_keys, int(optimized_quorum))
+        if execute:
+            lib().orc_ep_set_execute(self.h, 1)
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -403,4 +407,12 @@ class EpOracle:
                  highest_cols=np.zeros((K, R, G), np.uint32), counters=np.zeros(3, np.uint64))
         lib().orc_ep_dump(self.h, *[_p(d[k]) for k in ("len", "commit_bars", "bal", "seq", "status", "key", "deps", "pa_acks",
                                                        "acc_acks", "bk", "highest_cols", "counters")])
+        return d
+
+    def exec_dump(self):
+        """execution state: exec_bars [R, G], kv [n_keys, G] (token of the last Put), digest [G], counters [6]"""
+        G, R, K = self.G, self.R, self.n_keys
+        d = dict(exec_bars=np.zeros((R, G), np.uint32), kv=np.zeros((K, G), np.uint64), digest=np.zeros(G, np.uint64),
+                 counters=np.zeros(6, np.uint64))
+        lib().orc_ep_exec_dump(self.h, _p(d["exec_bars"]), _p(d["kv"]), _p(d["digest"]), _p(d["counters"]))
         return d

@@ -9,9 +9,9 @@ import ep_cluster as ec
 N = 0xFFFFFFFF
 
 
-def _run(oracle, G, ticks, n_keys, seed, drop_p=0.0):
+def _run(oracle, G, ticks, n_keys, seed, drop_p=0.0, execute=False):
     R, W = 5, 64
-    reps = [oracle.EpOracle(G, R, me=r, W=W, n_keys=n_keys) for r in range(R)]
+    reps = [oracle.EpOracle(G, R, me=r, W=W, n_keys=n_keys, execute=execute) for r in range(R)]
     rng = np.random.default_rng(seed)
     log = []
     for t in range(ticks):
@@ -81,3 +81,43 @@ def test_cluster_with_lost_pre_accepts(oracle):
     # lost PreAccepts: fewer replies, more slow paths and undecided instances, the same safety properties
     reps, log = _run(oracle, G=40, ticks=12, n_keys=6, seed=2, drop_p=0.25)
     _check(reps, log, 40)
+
+
+def _exec_props(oracle, drop_p, seed):
+    G, T, K = 60, 14, 6
+    reps, log = _run(oracle, G, T, K, seed, drop_p, execute=True)
+    plain, _ = _run(oracle, G, T, K, seed, drop_p)
+    xs, ds, ps = [r.exec_dump() for r in reps], [r.dump() for r in reps], [r.dump() for r in plain]
+    for q in range(5):
+        x, d, p = xs[q], ds[q], ps[q]
+        c = dict(zip(("n_exec", "n_reexec", "n_unheld", "n_multi_scc", "n_attempts", "n_aborts"), (int(v) for v in x["counters"])))
+        # the graph is a forest (every component a single node), and no dependency left the ring (W = 64 > ticks):
+        # nothing the harness adds to the reference was reached
+        assert c["n_multi_scc"] == 0 and c["n_unheld"] == 0 and c["n_exec"] > 0, c
+        assert (x["exec_bars"] <= d["commit_bars"]).all()
+        # execution only moves instances from Committed on; the protocol state is what it is without it
+        for n in ("len", "commit_bars", "bal", "seq", "key", "deps", "pa_acks", "acc_acks", "bk", "highest_cols", "counters"):
+            assert np.array_equal(d[n], p[n]), n
+        assert np.array_equal(np.minimum(d["status"], 3), np.minimum(p["status"], 3))
+        # below its exec bar a row is Executed
+        W = reps[q].W
+        for row in range(5):
+            for g in range(G):
+                for col in range(int(x["exec_bars"][row, g])):
+                    assert d["status"][row, col % W, g] == 5, (q, row, col, g)
+        # lock-step delivers the commits in the same order everywhere: same submissions, same store
+        assert np.array_equal(x["digest"], xs[0]["digest"]) and np.array_equal(x["kv"], xs[0]["kv"])
+    return xs, ds
+
+
+def test_cluster_execution(oracle):
+    xs, ds = _exec_props(oracle, 0.0, 4)
+    for q in range(5):                                         # nothing lost: everything committed has run
+        assert np.array_equal(xs[q]["exec_bars"], ds[q]["commit_bars"])
+    assert int(xs[0]["counters"][1]) > 0                       # and some instances ran twice (add_edge re-inserting a pruned slot)
+
+
+def test_cluster_execution_with_lost_pre_accepts(oracle):
+    xs, ds = _exec_props(oracle, 0.2, 6)
+    assert int(xs[0]["counters"][5]) > 0                       # attempts abandoned on an uncommitted dependency
+    assert (xs[0]["exec_bars"] < ds[0]["commit_bars"]).any()
