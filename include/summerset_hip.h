@@ -351,7 +351,7 @@ typedef struct {
     uint8_t population;        /* R, 3..8 */
     uint8_t me;                /* my replica id (= my row of the instance space) in every group */
     uint8_t optimized_quorum;  /* ReplicaConfigEPaxos::optimized_quorum (mod.rs:59,91): super quorum F + ceil(F/2) */
-    uint8_t reserved0;
+    uint8_t execute;           /* 1: run attempt_execution (execution.rs:25-149) behind every handler call, see below */
     uint32_t window;           /* W: columns kept per row, power of two */
     uint32_t n_keys;           /* key space per group, 1..255 */
 } smr_ep_cfg;
@@ -406,6 +406,20 @@ typedef struct {
     uint64_t *counters;
 } smr_ep_dump_bufs;
 int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *host_bufs);
+
+/* Dependency-graph execution (smr_ep_cfg.execute = 1; needs population * window <= 32768).  Every entry
+ * point above then launches a second kernel behind its own that does what handle_logged_commit_slot
+ * does once a row's commit bar has moved (durability.rs:136-160): attempt_execution on the row's new
+ * tail (execution.rs:25-149: the walk over deps, the graph whose edges join consecutively popped
+ * slots, its components in tarjan_scc's order), the re-attempts on the rows whose tail is still
+ * Committed, and then handle_cmd_result (:152-211) for every submitted command in submission order:
+ * Executing -> Executed, exec bars.  The state machine is one Put per instance: kv[key] = token,
+ * token(row, col) = (row + 1) << 32 | col, result = the old token; digest chains
+ * d = (d ^ token) * 0x100000001B3, d = (d ^ old) * 0x100000001B3 over the submissions of a group.
+ * Host buffers: exec_bars [R][G], kv [n_keys][G], digest [G], counters[6] = commands submitted, of them
+ * re-submissions of an already executing instance, pops of an instance that left the ring (counted
+ * as executed), 0, attempts, abandoned attempts. */
+int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters);
 
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing

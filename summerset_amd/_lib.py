@@ -51,7 +51,7 @@ class MpDumpBufs(C.Structure):
 
 class RaftCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("leader_id", C.c_uint8),
-                ("commit_extra", C.c_uint8), ("reserved0", C.c_uint8), ("window", C.c_uint32),
+                ("commit_extra", C.c_uint8), ("execute", C.c_uint8), ("window", C.c_uint32),
                 ("term", C.c_uint64)]
 
 
@@ -78,7 +78,7 @@ class RaftAppendReply(C.Structure):
 
 class EpCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("me", C.c_uint8), ("optimized_quorum", C.c_uint8),
-                ("reserved0", C.c_uint8), ("window", C.c_uint32), ("n_keys", C.c_uint32)]
+                ("execute", C.c_uint8), ("window", C.c_uint32), ("n_keys", C.c_uint32)]
 
 
 class EpMsg(C.Structure):
@@ -156,6 +156,7 @@ SYMBOLS = [
     ("smr_ep_handle_pre_accept_replies", _i, [_vp] + [_vp] * 11),
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
+    ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
     ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),

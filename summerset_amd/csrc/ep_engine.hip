@@ -9,8 +9,11 @@
 // handle_msg_accept (:273-345), handle_msg_accept_reply (:348-436),
 // handle_logged_{pre_accept,accept,commit}_slot (durability.rs:10-163)}.
 // WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one key of a small key
-// space, which is all the dependency tracking looks at; dependency-graph execution
-// (execution.rs) is not built.
+// space, which is all the dependency tracking looks at.
+//
+// Dependency-graph execution (execution.rs:25-149 attempt_execution, :152-211 handle_cmd_result,
+// durability.rs:136-160) is a separate kernel, ep_execute_kernel, that the entry points launch
+// behind their own kernel when smr_ep_cfg.execute is set (see the comment on EpExec).
 //
 // Layout (group fastest): instance fields X[(row * W + (col & (W-1))) * G + g]; DepSets as R
 // consecutive such planes; the per-key highest columns hc[(key * R + row) * G + g].
@@ -217,6 +220,185 @@ struct EpLane {
         }
     }
 };
+
+// ---- dependency-graph execution ------------------------------------------------------------------
+// One call of a handler kernel moves at most one row's commit bar per group (one message or one
+// instance per group per call), so the attempts the reference makes inside handle_logged_commit_slot
+// (durability.rs:136-160) can run right behind the handler: ep_execute_kernel finds the row whose
+// commit bar differs from the copy it kept (prev_cb) and does, for tail = (row, commit_bar - 1):
+//   attempt_execution(tail); if it ran: the re-attempts on every row whose tail is still Committed;
+//   then the results of the submitted commands in submission order (LS-1 rule 0).
+// What attempt_execution builds (execution.rs:33-83): a breadth-first walk over deps + the implicit
+// row predecessor; a NEW node gets one edge, from the slot popped just before it (:57-59), and
+// GraphMap::add_edge inserts that slot as a node if it is not one (a pruned, already executing slot
+// then runs again).  Every node has at most one incoming edge, made when it joins, so the graph is
+// a forest, every strongly connected component is a single node (the oracle runs the full Tarjan
+// and counts the exceptions: none) and tarjan_scc's output (:87-93) is the depth-first post-order:
+// trees started from nodes in insertion order, children newest edge first.  The per-component sort
+// by seq (:99-102) has nothing to sort.
+// The walk needs no queue: pops are the tail followed by the pushes of each new node in the order
+// the nodes joined.  Per group: nodes in insertion order (nslot, bit 15 = new), the forest as
+// head / sib / parent links over node ids, node_of[ring cell] = node id + 1, and the submissions of
+// the whole call in `order`; all uint16 [index][G].
+constexpr uint16_t XNIL = 0xFFFF;
+constexpr uint16_t XNEW = 0x8000;
+constexpr uint64_t EP_DG_MUL = 0x100000001B3ull;
+
+struct EpExec {
+    uint32_t *exec_bars, *prev_cb;       // [R][G]
+    uint64_t *kv;                        // [n_keys][G] token of the last Put, 0 = none
+    uint64_t *digest;                    // [G] chain over (token, old token) in submission order
+    uint16_t *node_of, *nslot, *head, *sib, *parent;   // [R*W][G]
+    uint16_t *order;                     // [2*R*W][G]
+    unsigned long long *counters;        // commands submitted, re-submissions, pops of an instance no longer held,
+                                         // (unused: components > 1 node), attempts, abandoned attempts
+};
+
+struct EpExecLane {
+    const EpView &v;
+    const EpExec &x;
+    const EpLane &L;
+    const uint32_t g, wshift;
+    uint32_t n_nodes = 0, n_order = 0, last = XNIL;          // last: ring cell of the slot popped before, XNIL = none / not held
+    unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
+    __device__ __forceinline__ EpExecLane(const EpView &v_, const EpExec &x_, const EpLane &L_, uint32_t g_)
+        : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
+    __device__ __forceinline__ size_t at(uint32_t i) const { return (size_t)i * v.G + g; }
+    // the column a ring cell of this row holds (the one of its residue among the last W)
+    __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
+        const uint32_t end = L.len(row), lo = end > v.W ? end - v.W : 0u;
+        uint32_t c = (lo & ~v.Wmask) | w;
+        if (c < lo) c += v.W;
+        return c;
+    }
+    __device__ __forceinline__ uint32_t new_node(uint32_t ring, uint16_t flag) {
+        const uint32_t id = n_nodes++;
+        x.nslot[at(id)] = (uint16_t)(ring | flag);
+        x.head[at(id)] = XNIL; x.sib[at(id)] = XNIL; x.parent[at(id)] = XNIL;
+        x.node_of[at(ring)] = (uint16_t)(id + 1);
+        return id;
+    }
+    // one pop of the walk (execution.rs:37-82); true = the attempt is abandoned
+    __device__ __forceinline__ bool pop(uint32_t row, uint32_t col) {
+        if (col >= v.commit_bars[(size_t)row * v.G + g]) return true;            // :41-45
+        if (!L.held(row, col)) { c_unheld++; last = XNIL; return false; }        // harness: left the ring = executed
+        const uint32_t ring = (row << wshift) | (col & v.Wmask);
+        if (v.status[L.ix(row, col)] >= EST_EXECUTING || x.node_of[at(ring)] != 0) { last = ring; return false; }   // :46-54
+        const uint32_t id = new_node(ring, XNEW);                                // :56-59
+        if (last != XNIL) {
+            uint32_t a = x.node_of[at(last)];
+            if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; }               // add_edge inserts the missing endpoint
+            a -= 1;
+            x.sib[at(id)] = x.head[at(a)]; x.head[at(a)] = (uint16_t)id; x.parent[at(id)] = (uint16_t)a;
+        }
+        last = ring;
+        return false;
+    }
+    // execution.rs:105-142 for one node, sync_exec = false
+    __device__ __forceinline__ void submit(uint32_t id) {
+        const uint32_t ring = x.nslot[at(id)] & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
+        const size_t i = L.ix(row, col);
+        const uint32_t key = v.key[i];
+        if (key != EP_NO_KEY) {
+            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = x.kv[(size_t)key * v.G + g];
+            x.kv[(size_t)key * v.G + g] = tok;
+            uint64_t d = x.digest[g];
+            d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
+            x.digest[g] = d;
+            x.order[at(n_order++)] = (uint16_t)ring;
+            c_exec++;
+        }
+        v.status[i] = EST_EXECUTING;
+    }
+    __device__ __forceinline__ bool attempt(uint32_t trow, uint32_t tcol) {
+        c_attempts++;
+        n_nodes = 0; last = XNIL;
+        bool abandoned = pop(trow, tcol);
+        for (uint32_t i = 0; !abandoned && i < n_nodes; i++) {
+            const uint32_t s = x.nslot[at(i)];
+            if (!(s & XNEW)) continue;
+            const uint32_t ring = s & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
+            for (uint32_t k = 0; k < v.R && !abandoned; k++) {                   // :62-73 its dependencies, row order
+                const uint32_t d = v.deps[L.dx(row, col, k)];
+                if (d != EP_NONE) abandoned = pop(k, d);
+            }
+            if (!abandoned && col > 0) abandoned = pop(row, col - 1);            // :74-77 the row predecessor
+        }
+        if (abandoned) {
+            c_aborts++;
+            for (uint32_t i = 0; i < n_nodes; i++) x.node_of[at(x.nslot[at(i)] & 0x7FFFu)] = 0;
+            return false;
+        }
+        // post-order over the forest; entering a node clears its node_of cell (= visited, and the cleanup)
+        for (uint32_t root = 0; root < n_nodes; root++) {
+            const uint32_t rr = x.nslot[at(root)] & 0x7FFFu;
+            if (x.node_of[at(rr)] == 0) continue;
+            x.node_of[at(rr)] = 0;
+            uint32_t u = root;
+            for (;;) {
+                const uint32_t c = x.head[at(u)];
+                if (c != XNIL) {
+                    x.head[at(u)] = x.sib[at(c)];
+                    const uint32_t cr = x.nslot[at(c)] & 0x7FFFu;
+                    if (x.node_of[at(cr)] != 0) { x.node_of[at(cr)] = 0; u = c; }
+                } else {
+                    submit(u);
+                    if (u == root) break;
+                    u = x.parent[at(u)];
+                }
+            }
+        }
+        return true;
+    }
+    // execution.rs:152-211, one command per instance
+    __device__ __forceinline__ void cmd_result(uint32_t ring) {
+        const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
+        v.status[L.ix(row, col)] = EST_EXECUTED;
+        uint32_t eb = x.exec_bars[(size_t)row * v.G + g];
+        if (col != eb) return;
+        while (eb < L.len(row) && L.held(row, eb) && v.status[L.ix(row, eb)] >= EST_EXECUTED) eb++;
+        x.exec_bars[(size_t)row * v.G + g] = eb;
+    }
+    // durability.rs:136-160 for the row whose commit bar moved
+    __device__ __forceinline__ void advanced(uint32_t row, uint32_t cb) {
+        n_order = 0;
+        if (attempt(row, cb - 1)) {
+            uint32_t re = 0;                                                     // rows to re-attempt, found before any of them runs
+            for (uint32_t q = 0; q < v.R; q++) {
+                const uint32_t c = v.commit_bars[(size_t)q * v.G + g];
+                if (c > x.exec_bars[(size_t)q * v.G + g] && L.held(q, c - 1) && v.status[L.ix(q, c - 1)] == EST_COMMITTED) re |= 1u << q;
+            }
+            for (uint32_t q = 0; q < v.R; q++)
+                if ((re >> q) & 1u) (void)attempt(q, v.commit_bars[(size_t)q * v.G + g] - 1);
+        }
+        for (uint32_t i = 0; i < n_order; i++) cmd_result(x.order[at(i)]);
+    }
+    __device__ __forceinline__ void flush() {
+        unsigned int c[5] = {c_exec, c_reexec, c_unheld, c_attempts, c_aborts};
+        const int slot[5] = {0, 1, 2, 4, 5};
+        for (int k = 0; k < 5; k++) {
+            unsigned int y = c[k];
+            for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
+            if (__lane_id() == 0 && y) atomicAdd(&x.counters[slot[k]], (unsigned long long)y);
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void ep_execute_kernel(const EpView v, const EpExec x) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    EpExecLane E(v, x, L, L.g);
+    if (g < v.G) {
+        for (uint32_t row = 0; row < v.R; row++) {
+            const size_t o = (size_t)row * v.G + g;
+            const uint32_t cb = v.commit_bars[o];
+            if (cb == x.prev_cb[o]) continue;
+            x.prev_cb[o] = cb;
+            E.advanced(row, cb);
+        }
+    }
+    E.flush();
+}
 
 // request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35)
 __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const uint8_t *__restrict__ key,
@@ -521,6 +703,7 @@ using namespace smr;
 struct smr_ep_replica {
     smr_ep_cfg cfg;
     EpView v;
+    EpExec x;
     Arena arena;
 };
 
@@ -542,6 +725,15 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry);
     ecarve(a, v.hc, K * R * G, dry);
     ecarve(a, v.counters, 4, dry);
+    if (e->cfg.execute) {
+        EpExec &x = e->x;
+        ecarve(a, x.exec_bars, R * G, dry); ecarve(a, x.prev_cb, R * G, dry);
+        ecarve(a, x.kv, K * G, dry); ecarve(a, x.digest, G, dry);
+        ecarve(a, x.node_of, R * W * G, dry); ecarve(a, x.nslot, R * W * G, dry); ecarve(a, x.head, R * W * G, dry);
+        ecarve(a, x.sib, R * W * G, dry); ecarve(a, x.parent, R * W * G, dry);
+        ecarve(a, x.order, 2 * R * W * G, dry);
+        ecarve(a, x.counters, 8, dry);
+    }
 }
 }  // namespace smr
 
@@ -555,9 +747,13 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     if (!cfg->window || (cfg->window & (cfg->window - 1)) || cfg->window < 8)
         return fail(SMR_ERR_ARG, "epaxos: window must be a power of two >= 8");
     if (cfg->n_keys == 0 || cfg->n_keys > 255) return fail(SMR_ERR_ARG, "epaxos: n_keys must be in 1..255");
+    if (cfg->execute > 1) return fail(SMR_ERR_ARG, "epaxos: execute must be 0 or 1");
+    if (cfg->execute && (uint64_t)cfg->population * cfg->window > 32768)
+        return fail(SMR_ERR_ARG, "epaxos: execution keeps 15-bit ring cell ids: population * window must be <= 32768");
     smr_ep_replica *e = new smr_ep_replica();
     e->cfg = *cfg;
     memset(&e->v, 0, sizeof(e->v));
+    memset(&e->x, 0, sizeof(e->x));
     ep_layout(e, true);
     e->arena.size = e->arena.used + 256;
     hipError_t err = hipMalloc((void **)&e->arena.base, e->arena.size);
@@ -588,13 +784,21 @@ void smr_ep_replica_destroy(smr_ep_replica *e) {
 
 #define EP_GRID(e) dim3(((e)->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream
 
+// the attempts of handle_logged_commit_slot for whatever the kernel just launched committed
+static int ep_execute(smr_ep_replica *e, void *stream) {
+    if (!e->cfg.execute) return SMR_OK;
+    hipLaunchKernelGGL(ep_execute_kernel, EP_GRID(e), e->v, e->x);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
 int smr_ep_propose(smr_ep_replica *e, const uint8_t *key_dev, const uint8_t *exploded_dev, const smr_ep_msg *out,
                    void *stream) {
     if (!e || !key_dev || !out || !out->flags || !out->col || !out->seq || !out->deps)
         return fail(SMR_ERR_ARG, "epaxos: null argument");
     hipLaunchKernelGGL(ep_propose_kernel, EP_GRID(e), e->v, key_dev, exploded_dev, out->flags, out->col, out->seq, out->deps);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ep_execute(e, stream);
 }
 
 static int ep_acceptor(smr_ep_replica *e, int mode, const smr_ep_msg *m, const smr_ep_msg *r, void *stream) {
@@ -612,7 +816,7 @@ static int ep_acceptor(smr_ep_replica *e, int mode, const smr_ep_msg *m, const s
         hipLaunchKernelGGL(ep_acceptor_kernel<0>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
                            m->key, r->flags, r->ballot, r->seq, r->deps);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ep_execute(e, stream);
 }
 
 int smr_ep_handle_pre_accept(smr_ep_replica *e, const smr_ep_msg *msg, const smr_ep_msg *reply, void *stream) {
@@ -640,7 +844,7 @@ int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev,
         hipLaunchKernelGGL(ep_pre_accept_replies_kernel<EMAXR>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev,
                            flags_dev, order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ep_execute(e, stream);
 }
 
 int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
@@ -648,7 +852,7 @@ int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, con
     if (!e || !col_dev || !ballot_dev || !flags_dev || !committed_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
     hipLaunchKernelGGL(ep_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, flags_dev, order_dev, committed_dev);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ep_execute(e, stream);
 }
 
 int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
@@ -688,6 +892,21 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
                 hb->bk[o] = live ? bk[o] : 0;
                 for (size_t i = 0; i < R; i++) hb->deps[o * R + i] = live ? deps[((row * W + w) * R + i) * G + g] : 0xFFFFFFFFu;
             }
+    return SMR_OK;
+}
+
+int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters) {
+    if (!e || !exec_bars || !kv || !digest || !counters) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.execute) return fail(SMR_ERR_ARG, "epaxos: created without execution");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const EpView &v = e->v;
+    const size_t G = v.G, R = v.R, K = v.n_keys;
+    SMR_HIP_TRY(hipMemcpy(exec_bars, e->x.exec_bars, R * G * 4, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(kv, e->x.kv, K * G * 8, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(digest, e->x.digest, G * 8, hipMemcpyDeviceToHost));
+    unsigned long long c[8];
+    SMR_HIP_TRY(hipMemcpy(c, e->x.counters, sizeof(c), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; k++) counters[k] = c[k];
     return SMR_OK;
 }
 

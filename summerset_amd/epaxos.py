@@ -2,7 +2,10 @@
 
 Mirrors `EPaxosReplica` (src/protocols/epaxos/mod.rs) on the pre-execution path:
 `handle_req_batch`, `handle_msg_pre_accept`, `handle_msg_pre_accept_reply` (the
-fast-quorum decision), `handle_msg_accept`, `handle_msg_accept_reply`.  Thin: every
+fast-quorum decision), `handle_msg_accept`, `handle_msg_accept_reply`,
+`handle_msg_commit_notice`; with `execute=True` every call is followed by the
+dependency-graph execution the reference runs from `handle_logged_commit_slot`
+(`attempt_execution`, `handle_cmd_result`; state read back by `exec_dump`).  Thin: every
 method is one C-ABI call; messages are device tensors with one entry per group,
 DepSets are int32 tensors [R, G] with -1 (0xFFFFFFFF) = None.
 """
@@ -21,9 +24,9 @@ def _ptr(t):
 
 
 class EPaxosReplicaGroup:
-    def __init__(self, n_groups, population=5, me=0, window=32, n_keys=64, optimized_quorum=True):
+    def __init__(self, n_groups, population=5, me=0, window=32, n_keys=64, optimized_quorum=True, execute=False):
         self.G, self.R, self.me, self.W, self.K = int(n_groups), int(population), int(me), int(window), int(n_keys)
-        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), 0, self.W, self.K)
+        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), int(bool(execute)), self.W, self.K)
         h = C.c_void_p()
         self._L = _lib.load()
         check(self._L.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
@@ -106,3 +109,12 @@ class EPaxosReplicaGroup:
             setattr(bufs, n, out[n].ctypes.data_as(C.c_void_p))
         check(self._L.smr_ep_dump(self._h, C.byref(bufs)))
         return out
+
+    def exec_dump(self):
+        """execution state: exec_bars [R, G], kv [n_keys, G] (token of the last Put), digest [G], counters [6]"""
+        G, R, K = self.G, self.R, self.K
+        d = dict(exec_bars=np.zeros((R, G), np.uint32), kv=np.zeros((K, G), np.uint64), digest=np.zeros(G, np.uint64),
+                 counters=np.zeros(6, np.uint64))
+        check(self._L.smr_ep_exec_dump(self._h, *[d[k].ctypes.data_as(C.c_void_p)
+                                                  for k in ("exec_bars", "kv", "digest", "counters")]))
+        return d

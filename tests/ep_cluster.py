@@ -14,6 +14,7 @@ class NumpyEngine:
     def __init__(self, eng, cuda):
         import torch
         self.e, self.cuda, self.torch = eng, cuda, torch
+        self.W, self.n_keys = eng.W, eng.K
 
     def _t(self, a):
         if a is None:
@@ -51,6 +52,9 @@ class NumpyEngine:
 
     def dump(self):
         return self.e.dump()
+
+    def exec_dump(self):
+        return self.e.exec_dump()
 
 
 def tick(reps, keys, drop=None):

@@ -76,3 +76,31 @@ def accept_replies_round(rng, col, G, R, me, ctl):
     ballot = np.full((R, G), me + 1, np.uint64)
     ballot[rng.random((R, G)) < 0.05] = 9
     return dict(col=col, ballot=np.ascontiguousarray(ballot), flags=np.ascontiguousarray(flags), order=ctl)
+
+
+def commit_round(rng, dump, G, R, me, n_keys, W):
+    """one CommitNotice per group from a random peer: mostly for the column at its row's commit bar (the bar
+    moves and execution is attempted), sometimes one beyond (a hole), sometimes an older column again;
+    dependencies mostly below the other rows' commit bars (the attempt can run), sometimes beyond"""
+    lens, bars = dump["len"], dump["commit_bars"]
+    flags = (rng.random(G) < 0.9).astype(np.uint8)
+    peer = rng.integers(0, R, G).astype(np.uint8)
+    peer[peer == me] = (me + 1) % R
+    g = np.arange(G)
+    bar = bars[peer, g]
+    kind = rng.integers(0, 10, G)
+    col = bar.copy()
+    col = np.where(kind == 0, bar + 1, col)
+    col = np.where((kind == 1) & (bar > 0), bar - 1, col).astype(np.uint32)
+    ballot = (peer.astype(np.uint64) + 1)
+    seq = rng.integers(1, 6, G).astype(np.uint64)
+    deps = np.full((R, G), N, np.uint32)
+    for r in range(R):
+        below = (rng.random(G) * np.maximum(bars[r], 1)).astype(np.uint32)
+        beyond = bars[r] + rng.integers(0, 2, G).astype(np.uint32)
+        pick = rng.random(G)
+        d = np.where(pick < 0.45, N, np.where((pick < 0.92) & (bars[r] > 0), below, beyond))
+        deps[r] = d.astype(np.uint32)
+    key = rng.integers(0, n_keys, G).astype(np.uint8)
+    key[rng.random(G) < 0.05] = NO_KEY
+    return dict(flags=flags, peer=peer, col=col, ballot=ballot, seq=seq, deps=np.ascontiguousarray(deps), key=key)

@@ -57,8 +57,30 @@ def _st(o, row, col):
     return int(o.dump()["status"][row, col % o.W, 0])
 
 
+def _new(oracle):
+    return oracle.EpOracle(1, 5, me=4, W=8, n_keys=4, execute=True)
+
+
 def test_execution_traces(oracle):
-    o = oracle.EpOracle(1, 5, me=4, W=8, n_keys=4, execute=True)
+    trace_execution(_new(oracle))
+
+
+def test_path_order_and_sibling_order(oracle):
+    trace_path_order(_new(oracle))
+
+
+def test_two_children_newest_edge_first(oracle):
+    trace_two_children(_new(oracle))
+
+
+def test_instance_outside_the_ring_is_pruned(oracle):
+    trace_outside_the_ring(_new(oracle))
+
+
+TRACES = ("trace_execution", "trace_path_order", "trace_two_children", "trace_outside_the_ring")
+
+
+def trace_execution(o):
     m = _Model()
     # A. (0,0) alone: commit bar of row 0 -> 1, attempt on tail (0,0): one node, submitted; its result
     #    arrives once the handler is back (rule 0): Executed, exec bar of row 0 -> 1
@@ -111,11 +133,10 @@ def test_execution_traces(oracle):
     _check(o, m, [3, 2, 1, 1, 0], n_attempts=8, n_aborts=3, n_reexec=1)
 
 
-def test_path_order_and_sibling_order(oracle):
+def trace_path_order(o):
     """T = (0,1) with three unexecuted dependencies: each new node hangs under the slot popped before it, so
     the forest is the path T -> d1 -> d2 -> d3 and the post-order is d3, d2, d1, T -- unless a pruned
     pop sits in between, which starts a new tree."""
-    o = oracle.EpOracle(1, 5, me=4, W=8, n_keys=4, execute=True)
     m = _Model()
     # three committed instances that cannot run: each waits for (0,1)
     for row in (1, 2, 3):
@@ -131,10 +152,9 @@ def test_path_order_and_sibling_order(oracle):
     _check(o, m, [2, 1, 1, 1, 0], n_reexec=0)
 
 
-def test_two_children_newest_edge_first(oracle):
+def trace_two_children(o):
     """A node that is popped twice can get two children; Graph::neighbors walks the newer edge first.
     (0,2) depends on (1,0) and (1,1)... built so that (0,2) is `last` for two different new nodes."""
-    o = oracle.EpOracle(1, 5, me=4, W=8, n_keys=4, execute=True)
     m = _Model()
     _commit(o, 0, 0, 0, 1)
     m.run([(0, 0, 0)])
@@ -172,9 +192,8 @@ def test_two_children_newest_edge_first(oracle):
     _check(o, m, [3, 2, 1, 2, 0], n_reexec=0)
 
 
-def test_instance_outside_the_ring_is_pruned(oracle):
+def trace_outside_the_ring(o):
     """harness guard: a dependency that left its row's ring of W columns counts as executed"""
-    o = oracle.EpOracle(1, 5, me=4, W=8, n_keys=4, execute=True)
     m = _Model()
     for c in range(10):                                        # row 0 runs to column 9: columns 0, 1 leave the ring
         _commit(o, 0, c, 0, c + 1)
