@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void rs_matmul_xtime(const RsArgs a) {
 // LDS product-table variant: tab[(r * n_in + c) * 256 + v] = coef[r][c] * v
 template <int NOUT>
 __global__ __launch_bounds__(256) void rs_matmul_lut(const RsArgs a, const uint8_t *__restrict__ tabs) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tab[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lds_tab)
     const int ntab = a.n_out * a.n_in * 256;
     for (int i = threadIdx.x * 16; i < ntab; i += 256 * 16)
         *reinterpret_cast<u32x4 *>(lds_tab + i) = *reinterpret_cast<const u32x4 *>(tabs + i);

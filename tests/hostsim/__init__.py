@@ -1,57 +1,117 @@
 """Kernel-source simulation for the CPU test suite (TEST INFRASTRUCTURE ONLY).
 
-`build()` compiles the lane-independent engines (Raft, EPaxos) from the very .hip sources that ship,
-for the host, against tests/hostsim/hip/hip_runtime.h, into tests/hostsim/_build/; `patched()` points
+`build()` compiles the engine from the very .hip sources that ship, for the host, against
+tests/hostsim/hip/hip_runtime.h (lanes as fibers, hipsim_rt.cpp), into tests/hostsim/_build/; `patched()` points
 the package's ctypes handle at that library for the duration of a test, so the Python mirror and the
 C-ABI entry points under test are the shipped ones and only the "device" is simulated.  See the header
 of the shim for what this does and does not show."""
 import contextlib
 import ctypes as C
 import os
+import re
+import struct
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "summerset_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build")
-SOURCES = ["core.hip", "raft_engine.hip", "ep_engine.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rep_nothing.hip", "wire.hip"]
 LIB = os.path.join(_OUT, "libsummerset_sim.so")
+# clang: the RS kernels use ext_vector_type, which g++ does not have (this is the host compiler hipcc itself drives)
+CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
 def build():
     os.makedirs(_OUT, exist_ok=True)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_CSRC, "smr_common.h"),
-                   os.path.join(_ROOT, "include", "summerset_hip.h")]
+    rt = os.path.join(_HERE, "hipsim_rt.cpp")
+    deps = srcs + [rt, os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
+    deps += [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
-    cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-w", "-I", _HERE, "-o", LIB]
+    # kernels: -fsanitize=thread only for the call it puts in front of every load / store (hipsim_rt.cpp provides the
+    # hooks; no sanitizer runtime is linked); no block placement: code order = source order (see hipsim_rt.cpp)
+    base = [CXX, "-O1", "-gline-tables-only", "-fno-optimize-sibling-calls", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC",
+            "-w", "-I", _HERE]
+    kern = ["-mllvm", "-disable-block-placement", "-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0",
+            "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-instrument-memintrinsics=0"]
+    objs = []
     for s in srcs:
-        cmd += ["-x", "c++", s]
-    subprocess.run(cmd, check=True)
+        o = os.path.join(_OUT, os.path.basename(s) + ".o")
+        subprocess.run(base + kern + ["-c", "-x", "c++", s, "-o", o], check=True)
+        objs.append(o)
+    o = os.path.join(_OUT, "hipsim_rt.o")
+    subprocess.run(base + ["-c", rt, "-o", o], check=True)
+    subprocess.run([CXX, "-shared", "-o", LIB + ".tmp"] + objs + [o], check=True)
+    _rank_sites(LIB + ".tmp", LIB + ".sites")
+    os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+_XLANE = re.compile(r"call\w*\s+\S+\s+<(__tsan_(?:unaligned_)?(?:read|write)\d+|_Z\d+__(?:shfl|shfl_xor|ballot|all|any)\w*)@plt>")
+
+
+def _rank_sites(lib, out):
+    """Source position of every parking site (the return address of a memory hook or of a cross-lane
+    operation): the (line, column) of each inlined frame, outermost first.  Sorted, that is program order
+    inside a function whatever the code layout; the scheduler lets the lane at the lowest rank go first.
+    File: u64 count, then (u64 offset in the library, u64 rank) pairs sorted by offset."""
+    tools = os.path.dirname(CXX)
+    dis = subprocess.run([os.path.join(tools, "llvm-objdump"), "-d", "--no-show-raw-insn", lib], check=True,
+                         capture_output=True, text=True).stdout.splitlines()
+    sites, pending = [], False
+    for ln in dis:
+        head = ln.split(":", 1)
+        is_insn = len(head) == 2 and head[0].strip() and all(c in "0123456789abcdef" for c in head[0].strip())
+        if pending and is_insn:
+            sites.append(int(head[0].strip(), 16))              # the instruction after the call = the return address
+            pending = False
+        if is_insn and _XLANE.search(ln):
+            pending = True
+    sym = subprocess.run([os.path.join(tools, "llvm-symbolizer"), "-e", lib, "--inlines", "--functions=none"],
+                         input="\n".join(hex(a - 1) for a in sites) + "\n", check=True, capture_output=True, text=True).stdout
+    keys, cur = [], []
+    for ln in sym.splitlines():
+        if not ln.strip():                                       # blank line = end of one address's frames (innermost first)
+            keys.append(tuple(reversed(cur)))
+            cur = []
+            continue
+        parts = ln.rsplit(":", 2)
+        try:
+            cur.append((int(parts[1]), int(parts[2])))
+        except (IndexError, ValueError):
+            cur.append((0, 0))
+    assert len(keys) == len(sites), (len(keys), len(sites))
+    rank = {k: i for i, k in enumerate(sorted(set(keys)))}
+    with open(out, "wb") as f:
+        f.write(struct.pack("<Q", len(sites)))
+        for a, k in sorted(zip(sites, keys)):
+            f.write(struct.pack("<QQ", a, rank[k]))
 
 
 def load():
     from summerset_amd import _lib
     lib = C.CDLL(build())
     for name, res, args in _lib.SYMBOLS:
-        fn = getattr(lib, name, None)       # the simulated library holds only the lane-independent engines
-        if fn is not None:
-            fn.restype, fn.argtypes = res, args
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
     return lib
 
 
 @contextlib.contextmanager
 def patched():
     """the package talks to the simulated library; streams are the null stream"""
-    from summerset_amd import _lib, epaxos, raft
+    from summerset_amd import _lib, epaxos, multipaxos, raft, rscoding
     sim = load()
-    saved = (_lib._lib, epaxos.EPaxosReplicaGroup._stream, raft.RaftLeaderGroup._stream)
-    _lib._lib = sim
-    epaxos.EPaxosReplicaGroup._stream = staticmethod(lambda stream: 0)
-    raft.RaftLeaderGroup._stream = staticmethod(lambda stream: 0)
+    null = staticmethod(lambda stream: 0)
+    spots = [(_lib, "_lib", sim), (epaxos.EPaxosReplicaGroup, "_stream", null), (raft.RaftLeaderGroup, "_stream", null),
+             (multipaxos.MultiPaxosCluster, "_stream", null), (rscoding, "_stream_ptr", lambda stream: 0)]
+    saved = [(o, n, o.__dict__[n]) for o, n, _ in spots]
+    for o, n, v in spots:
+        setattr(o, n, v)
     try:
         yield sim
     finally:
-        _lib._lib, epaxos.EPaxosReplicaGroup._stream, raft.RaftLeaderGroup._stream = saved
+        for o, n, v in saved:
+            setattr(o, n, v)

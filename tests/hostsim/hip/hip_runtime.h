@@ -1,63 +1,139 @@
 /* tests/hostsim/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
  *
- * A stand-in for <hip/hip_runtime.h> that lets g++ compile the engine's .hip sources for the host
- * and run a launch as a plain loop over the grid, one "lane" at a time.  It exists so that the CPU
- * test suite can drive the very kernel source that ships (through the same C-ABI) against the
- * oracle when there is no GPU at hand.  It is only valid for kernels whose lanes do not talk to
- * each other: no LDS, no barriers, and shuffles only in the "sum a per-lane counter over the
- * wavefront" idiom (a lone lane sees 0 from every other lane).  That is the Raft and EPaxos
- * engines; the MultiPaxos engine and the RS kernels are wave-cooperative and are NOT covered.
- * It says nothing about how a kernel behaves on the GPU (memory model, occupancy, speed) --
- * tests/test_*_gpu.py do that -- and the package itself never loads a library built with it.
+ * A stand-in for <hip/hip_runtime.h> that lets g++ compile the engine's .hip sources for the host, so
+ * that the CPU test suite can drive the very kernel source that ships -- through the same C-ABI and
+ * Python mirror -- against the oracle when there is no GPU at hand.  A launch runs block after block;
+ * inside a block every lane is a fiber (tests/hostsim/hipsim_rt.cpp) that runs until it reaches a
+ * cross-lane operation (__shfl*, __ballot, __all, __any, __syncthreads), where the lanes of its
+ * wavefront (64) resp. of its block meet and exchange values the way the hardware does for the lanes
+ * that execute the operation together.  "Device memory" is host memory, streams and events are no-ops.
+ *
+ * What it shows: the logic of a kernel -- indexing, protocol rules, cross-lane choreography -- is what
+ * the oracle says.  What it cannot show: anything about the device (memory model between wavefronts,
+ * occupancy, speed, compiler behaviour for gfx950); tests/test_*_gpu.py do that.  The package itself
+ * never loads a library built with it.
  */
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
+
 #define __global__
 #define __device__
 #define __host__
-#define __forceinline__ inline
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)::hipsim::dyn_shared();
 
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct hipsim_idx { unsigned x, y, z; };
-inline thread_local hipsim_idx blockIdx, threadIdx, blockDim, gridDim;
+extern thread_local hipsim_idx blockIdx, threadIdx, blockDim, gridDim;
+static const int warpSize = 64;
+
+namespace hipsim {
+enum { K_SHFL = 1, K_BALLOT, K_ALL, K_ANY, K_BARRIER };
+/* called by a lane: park at a cross-lane operation, come back with its result */
+uint64_t collective(int kind, const void *site, const void *frame, uint64_t val, int arg);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
+void *dyn_shared();
+}  // namespace hipsim
+extern "C" unsigned long hipsim_partial_wave_ops(void);   /* wave operations that met with live lanes elsewhere */
 
 typedef void *hipStream_t;
+typedef void *hipEvent_t;
 typedef enum { hipSuccess = 0, hipErrorOutOfMemory = 2 } hipError_t;
 typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 } hipMemcpyKind;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "out of memory"; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipGetLastError(void) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)1; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 inline int __ffs(int x) { return __builtin_ffs(x); }
-inline unsigned __lane_id(void) { return 0; }
-template <typename T> inline T __shfl_xor(T, int) { return T(0); }      /* the other lanes are idle: they hold 0 */
-template <typename T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+inline unsigned __lane_id(void) { return threadIdx.x & 63u; }
+inline void __threadfence(void) {}
+inline void __threadfence_block(void) {}
+/* not instrumented: no parking point inside, so the read-modify-write is atomic among the fibers */
+#define HIPSIM_ATOMIC inline __attribute__((no_sanitize("thread")))
+template <typename T, typename U> HIPSIM_ATOMIC T atomicAdd(T *p, U v) { T o = *p; *p = (T)(o + v); return o; }
+template <typename T, typename U> HIPSIM_ATOMIC T atomicOr(T *p, U v) { T o = *p; *p = (T)(o | v); return o; }
+template <typename T, typename U> HIPSIM_ATOMIC T atomicMax(T *p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <typename T, typename U> HIPSIM_ATOMIC T atomicMin(T *p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <typename T, typename U> HIPSIM_ATOMIC T atomicExch(T *p, U v) { T o = *p; *p = (T)v; return o; }
+
+/* noinline: the return address identifies the call site, which is how lanes that execute the same
+ * operation find each other.  convergent: what the device compiler knows about these operations -- the
+ * host compiler must not make a call depend on a condition it did not depend on (unswitching, jump
+ * threading), or lanes on different copies would never meet.  (noduplicate would say the same for
+ * clones, but clang then ignores noinline.) */
+#define HIPSIM_XLANE __attribute__((noinline, convergent))
+template <typename T> HIPSIM_XLANE T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shuffles of up to 8 bytes");
+    (void)width;
+    uint64_t x = 0;
+    memcpy(&x, &v, sizeof(T));
+    const uint64_t r = hipsim::collective(hipsim::K_SHFL, __builtin_return_address(0), __builtin_frame_address(1), x, src & 63);
+    T o;
+    memcpy(&o, &r, sizeof(T));
+    return o;
+}
+template <typename T> HIPSIM_XLANE T __shfl_xor(T v, int mask, int width = 64) {
+    static_assert(sizeof(T) <= 8, "shuffles of up to 8 bytes");
+    (void)width;
+    uint64_t x = 0;
+    memcpy(&x, &v, sizeof(T));
+    const uint64_t r = hipsim::collective(hipsim::K_SHFL, __builtin_return_address(0), __builtin_frame_address(1), x, (int)((threadIdx.x ^ (unsigned)mask) & 63u));
+    T o;
+    memcpy(&o, &r, sizeof(T));
+    return o;
+}
+HIPSIM_XLANE inline unsigned long long __ballot(int pred) {
+    return hipsim::collective(hipsim::K_BALLOT, __builtin_return_address(0), __builtin_frame_address(1), pred ? 1 : 0, 0);
+}
+HIPSIM_XLANE inline int __all(int pred) {
+    return (int)hipsim::collective(hipsim::K_ALL, __builtin_return_address(0), __builtin_frame_address(1), pred ? 1 : 0, 0);
+}
+HIPSIM_XLANE inline int __any(int pred) {
+    return (int)hipsim::collective(hipsim::K_ANY, __builtin_return_address(0), __builtin_frame_address(1), pred ? 1 : 0, 0);
+}
+HIPSIM_XLANE inline void __syncthreads(void) {
+    (void)hipsim::collective(hipsim::K_BARRIER, nullptr, nullptr, 0, 0);
+}
 
 #define hipLaunchKernelGGLInternal(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)        \
     do {                                                                                                 \
-        const dim3 hs_g = (numBlocks), hs_b = (numThreads);                                              \
-        (void)(memPerBlock); (void)(streamId);                                                           \
-        gridDim = {hs_g.x, hs_g.y, hs_g.z}; blockDim = {hs_b.x, hs_b.y, hs_b.z};                         \
-        for (unsigned hs_i = 0; hs_i < hs_g.x; hs_i++)                                                   \
-            for (unsigned hs_t = 0; hs_t < hs_b.x; hs_t++) {                                             \
-                blockIdx = {hs_i, 0, 0}; threadIdx = {hs_t, 0, 0};                                       \
-                kernelName(__VA_ARGS__);                                                                 \
-            }                                                                                            \
+        (void)(streamId);                                                                                \
+        ::hipsim::launch((numBlocks), (numThreads), (size_t)(memPerBlock), [&]() { kernelName(__VA_ARGS__); }); \
     } while (0)
 #define hipLaunchKernelGGL(kernelName, ...) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__)

@@ -1,7 +1,8 @@
-"""The Raft and EPaxos kernels -- the shipped .hip sources, compiled for the host by tests/hostsim and run
-one lane at a time -- against the CPU oracle, through the shipped C-ABI and Python mirror.  This reruns
-the scenarios of tests/test_{raft,ep}_gpu.py where no GPU is at hand: it checks the kernels' logic,
-not their behaviour on the device (the gpu-marked tests do that)."""
+"""The engine's kernels -- the shipped .hip sources, compiled for the host by tests/hostsim, every lane a
+fiber, cross-lane operations meeting per wavefront / block -- against the CPU oracle, through the shipped
+C-ABI and Python mirror.  This reruns scenarios of tests/test_*_gpu.py (at smaller shapes) where no GPU
+is at hand: it checks the kernels' logic, not their behaviour on the device (the gpu-marked tests do
+that)."""
 import pytest
 
 
@@ -47,3 +48,39 @@ def test_epaxos_execution_kernel_on_the_host(sim, oracle):
         t.test_handler_streams_with_execution("cpu", oracle, 257, 16, 3)
         t.test_closed_loop_cluster_with_execution("cpu", oracle, 0.0)
         t.test_closed_loop_cluster_with_execution("cpu", oracle, 0.15)
+
+
+def test_multipaxos_kernels_on_the_host(sim, oracle):
+    """steady state, ack loss, leader changes on every group (Prepare phase, wave-cooperative jobs, the
+    quorum tally with its LDS hand-off), three replicas, RSPaxos threshold, window back-pressure"""
+    import test_mp_gpu as t
+    with sim.patched() as lib:
+        t._run("cpu", oracle, G=70, R=5, S=1, W=32, n_ticks=24, drop_p=0.0, timeout_frac=0.0, hb_every=4, preset=True)
+        t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
+        for sticks in (0, 1):
+            t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+                   straggler_ticks=sticks)
+        t._run("cpu", oracle, G=96, R=5, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+               per_round=True)
+        t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False)
+        t._run("cpu", oracle, G=65, R=3, S=2, W=32, n_ticks=30, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True)
+        t._run("cpu", oracle, G=100, R=5, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True,
+               commit_extra=1)
+        eng, _ = t._run("cpu", oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True)
+        assert eng.counters(0)["rejects"] > 0
+
+
+def test_rs_kernels_on_the_host(sim, oracle):
+    import test_rs_gpu as t
+    with sim.patched():
+        for lut in (False, True):
+            t.test_golden_vectors("cpu", oracle, lut)
+        for L in (1, 2, 3, 5, 16, 31, 48, 97, 1000, 4099, 4113):
+            t.test_encode_matches_oracle_ragged("cpu", oracle, L)
+        for scheme in ((3, 2), (6, 4), (12, 8), (5, 5), (4, 1), (1, 1)):
+            t.test_other_schemes("cpu", oracle, scheme)
+        t.test_all_erasure_patterns_rs32("cpu", oracle)
+        t.test_error_cases_mirror_reference("cpu")
+        t.test_verify_detects_corruption("cpu")
+        t.test_padding_bytes_are_never_read("cpu", oracle)
+        t.test_subset_copy_and_absorb_other_rspaxos_flow("cpu", oracle)

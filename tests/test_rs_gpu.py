@@ -160,7 +160,7 @@ def test_full_size_properties_config4(cuda):
 def test_padding_bytes_are_never_read(cuda, oracle):
     """The serialized bytes are NOT padded by the caller: poison everything past data_len."""
     import torch
-    from summerset_amd import _lib
+    from summerset_amd import _lib, rscoding
     from summerset_amd._lib import check
     L, n, stride = 4099, 8, 4112
     rng = np.random.default_rng(2)
@@ -169,7 +169,7 @@ def test_padding_bytes_are_never_read(cuda, oracle):
     sl = 1367
     par = torch.zeros((n, 2, 1376), dtype=torch.uint8, device=cuda)
     check(_lib.load().smr_rs_encode(dev.data_ptr(), L, stride, n, 3, 2, par.data_ptr(), 2 * 1376, 1376,
-                                    torch.cuda.current_stream().cuda_stream))
+                                    rscoding._stream_ptr(None)))
     got = par.cpu().numpy()
     for i in range(n):
         assert np.array_equal(got[i, :, :sl], oracle.rs_encode(3, 2, raw[i, :L]))
