@@ -1,10 +1,11 @@
 """Kernel-source simulation for the CPU test suite (TEST INFRASTRUCTURE ONLY).
 
 `build()` compiles the engine from the very .hip sources that ship, for the host, against
-tests/hostsim/hip/hip_runtime.h (lanes as fibers, hipsim_rt.cpp), into tests/hostsim/_build/; `patched()` points
-the package's ctypes handle at that library for the duration of a test, so the Python mirror and the
-C-ABI entry points under test are the shipped ones and only the "device" is simulated.  See the header
-of the shim for what this does and does not show."""
+tests/hostsim/hip/hip_runtime.h (a SIMT emulation: lanes as fibers, wavefront meetings, lock-step memory
+order; hipsim_rt.cpp), into tests/hostsim/_build/; `patched()` points the package's ctypes handle at that
+library for the duration of a test, so the Python mirror and the C-ABI entry points under test are the
+shipped ones and only the "device" is simulated.  See the header of the shim for what this does and does
+not show."""
 import contextlib
 import ctypes as C
 import os

@@ -1,17 +1,22 @@
 /* tests/hostsim/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
  *
- * A stand-in for <hip/hip_runtime.h> that lets g++ compile the engine's .hip sources for the host, so
- * that the CPU test suite can drive the very kernel source that ships -- through the same C-ABI and
- * Python mirror -- against the oracle when there is no GPU at hand.  A launch runs block after block;
- * inside a block every lane is a fiber (tests/hostsim/hipsim_rt.cpp) that runs until it reaches a
- * cross-lane operation (__shfl*, __ballot, __all, __any, __syncthreads), where the lanes of its
- * wavefront (64) resp. of its block meet and exchange values the way the hardware does for the lanes
- * that execute the operation together.  "Device memory" is host memory, streams and events are no-ops.
+ * A stand-in for <hip/hip_runtime.h> that lets the host compiler (clang++) compile the engine's .hip
+ * sources for the host, so that the CPU test suite can drive the very kernel source that ships --
+ * through the same C-ABI and Python mirror -- against the oracle when there is no GPU at hand.
+ * A launch runs block after block; inside a block every lane is a fiber (tests/hostsim/hipsim_rt.cpp):
+ *   - cross-lane operations (__shfl*, __ballot, __all, __any) park the lane until the lanes of its
+ *     wavefront (64) that execute the operation with it have arrived; __syncthreads likewise per block;
+ *   - every load / store outside the lane's own stack parks it too (the sources are compiled with
+ *     -fsanitize=thread purely for the call that puts in front of each access; no sanitizer runtime is
+ *     linked), and parked lanes are let go in program order (source position of the access, from the
+ *     debug info), which gives a wavefront the lock-step memory order the kernels are written for
+ *     ("every lane reads X, then lane 0 overwrites X");
+ *   - atomics are uninterrupted; "device memory" is host memory; streams and events are no-ops.
  *
- * What it shows: the logic of a kernel -- indexing, protocol rules, cross-lane choreography -- is what
- * the oracle says.  What it cannot show: anything about the device (memory model between wavefronts,
- * occupancy, speed, compiler behaviour for gfx950); tests/test_*_gpu.py do that.  The package itself
- * never loads a library built with it.
+ * What it shows: the logic of a kernel -- indexing, protocol rules, cross-lane choreography, LDS hand-offs
+ * -- is what the oracle says.  What it cannot show: anything about the device (memory model between
+ * wavefronts, occupancy, speed, what the gfx950 compiler does); tests/test_*_gpu.py do that.  The package
+ * itself never loads a library built with it.
  */
 #pragma once
 #include <stddef.h>
