@@ -32,6 +32,12 @@ struct Arena {
     size_t reserve(size_t bytes) {
         size_t off = (used + 255) & ~size_t(255);
         used = off + bytes;
+#ifdef SMR_ARENA_GUARD
+        // kernel-source simulation only (tests/hostsim): an unowned gap behind every array, reported when a
+        // kernel touches it, so an index that runs off the end of its array cannot quietly land in the neighbour
+        if (base) hipsim::poison(base + used, SMR_ARENA_GUARD);
+        used += SMR_ARENA_GUARD;
+#endif
         return off;
     }
     template <typename T> T *at(size_t off) const { return (T *)(base + off); }  // C cast: T may carry an address space on the device pass

@@ -23,6 +23,14 @@ LIB = os.path.join(_OUT, "libsummerset_sim.so")
 CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
 
+# kernels: -fsanitize=thread only for the call it puts in front of every load / store (hipsim_rt.cpp provides the
+# hooks; no sanitizer runtime is linked); no block placement; SMR_ARENA_GUARD: unowned gaps between an arena's arrays
+_BASE = [CXX, "-O1", "-gline-tables-only", "-fno-optimize-sibling-calls", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC",
+         "-w", "-I", _HERE]
+_KERN = ["-DSMR_ARENA_GUARD=4096", "-mllvm", "-disable-block-placement", "-fsanitize=thread", "-mllvm",
+         "-tsan-instrument-func-entry-exit=0", "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-instrument-memintrinsics=0"]
+
+
 def build():
     os.makedirs(_OUT, exist_ok=True)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
@@ -31,12 +39,7 @@ def build():
     deps += [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
-    # kernels: -fsanitize=thread only for the call it puts in front of every load / store (hipsim_rt.cpp provides the
-    # hooks; no sanitizer runtime is linked); no block placement: code order = source order (see hipsim_rt.cpp)
-    base = [CXX, "-O1", "-gline-tables-only", "-fno-optimize-sibling-calls", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC",
-            "-w", "-I", _HERE]
-    kern = ["-mllvm", "-disable-block-placement", "-fsanitize=thread", "-mllvm", "-tsan-instrument-func-entry-exit=0",
-            "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-instrument-memintrinsics=0"]
+    base, kern = _BASE, _KERN
     objs = []
     for s in srcs:
         o = os.path.join(_OUT, os.path.basename(s) + ".o")
@@ -50,7 +53,23 @@ def build():
     return LIB
 
 
-_XLANE = re.compile(r"call\w*\s+\S+\s+<(__tsan_(?:unaligned_)?(?:read|write)\d+|_Z\d+__(?:shfl|shfl_xor|ballot|all|any)\w*)@plt>")
+def build_selftest():
+    """tests/hostsim/selftest.cpp with the library's flags (its own copy of the runtime, its own sites file)"""
+    os.makedirs(_OUT, exist_ok=True)
+    exe = os.path.join(_OUT, "selftest")
+    rt, src = os.path.join(_HERE, "hipsim_rt.cpp"), os.path.join(_HERE, "selftest.cpp")
+    deps = [rt, src, os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+        return exe
+    subprocess.run(_BASE + _KERN + ["-c", "-x", "c++", src, "-o", exe + ".k.o"], check=True)
+    subprocess.run(_BASE + ["-c", rt, "-o", exe + ".rt.o"], check=True)
+    subprocess.run([CXX, "-pie", "-rdynamic", "-o", exe + ".tmp", exe + ".k.o", exe + ".rt.o", "-ldl"], check=True)
+    _rank_sites(exe + ".tmp", exe + ".sites")
+    os.replace(exe + ".tmp", exe)
+    return exe
+
+
+_XLANE = re.compile(r"call\w*\s+\S+\s+<(__tsan_(?:unaligned_)?(?:read|write)\d+|_Z\d+__(?:shfl|shfl_xor|ballot|all|any)\w*)(?:@plt)?>")
 
 
 def _rank_sites(lib, out):

@@ -49,6 +49,11 @@ enum { K_SHFL = 1, K_BALLOT, K_ALL, K_ANY, K_BARRIER };
 uint64_t collective(int kind, const void *site, const void *frame, uint64_t val, int arg);
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 void *dyn_shared();
+/* memory no kernel may touch (the gaps -DSMR_ARENA_GUARD leaves between the arrays of an arena); a kernel
+ * access into one aborts with the access site.  dev_free lifts the marks inside the freed block. */
+void poison(const void *p, size_t n);
+void *dev_malloc(size_t n);
+void dev_free(void *p);
 }  // namespace hipsim
 extern "C" unsigned long hipsim_partial_wave_ops(void);   /* wave operations that met with live lanes elsewhere */
 
@@ -59,9 +64,9 @@ typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDevi
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "out of memory"; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = hipsim::dev_malloc(n); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
-inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void *p) { hipsim::dev_free(p); return hipSuccess; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

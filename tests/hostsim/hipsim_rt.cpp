@@ -18,6 +18,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #if !defined(__x86_64__)
 #include <ucontext.h>
@@ -223,15 +224,34 @@ uint64_t collective(int kind, const void *site, const void *frame, uint64_t val,
     return F[cur].res;
 }
 
+std::map<uintptr_t, uintptr_t> poisoned;          // start -> end
+std::vector<std::pair<uintptr_t, uintptr_t>> poison_flat;
+bool poison_dirty;
+std::map<uintptr_t, size_t> blocks;               // hipMalloc'd blocks
+
 // A lane is about to touch memory that is not its own stack (the library is compiled with
 // -fsanitize=thread only to get this call in front of every such load and store): it parks, and goes on
 // when it is its instruction's turn -- the lanes of a wavefront advance through their memory accesses in
 // program order like the lock-step hardware, so "every lane reads X, then lane 0 overwrites X" keeps its
 // meaning even though the lanes are run one after the other.
-void before_access(const void *addr, const void *site, const void *frame) {
+void before_access(const void *addr, size_t size, const void *site, const void *frame) {
     if (!in_fiber) return;
     const char *lo = stacks + (size_t)cur * STACK;
     if ((const char *)addr >= lo && (const char *)addr < lo + STACK) return;
+    if (!poisoned.empty()) {                                      // [start, end) ranges, disjoint, by start
+        const uintptr_t a = (uintptr_t)addr;
+        if (poison_dirty) {
+            poison_flat.assign(poisoned.begin(), poisoned.end());
+            poison_dirty = false;
+        }
+        auto it = std::upper_bound(poison_flat.begin(), poison_flat.end(), std::make_pair(a + size - 1, ~(uintptr_t)0));
+        if (it != poison_flat.begin() && (--it)->second > a) {
+            fprintf(stderr, "hipsim: kernel access of %zu bytes at %p runs into an arena guard gap [%p, %p): site +0x%lx, block (%u,%u) "
+                    "thread %u\n", size, addr, (void *)it->first, (void *)it->second, (unsigned long)((uintptr_t)site - lib_base),
+                    blockIdx.x, blockIdx.y, threadIdx.x);
+            abort();
+        }
+    }
     Fiber &f = F[cur];
     f.site = site; f.rank = rank_of(site);
     f.frame = (const void *)((uintptr_t)frame - (uintptr_t)lo);
@@ -240,6 +260,22 @@ void before_access(const void *addr, const void *site, const void *frame) {
 }
 
 void *dyn_shared() { return dyn.data(); }
+
+void poison(const void *p, size_t n) { if (n) { poisoned[(uintptr_t)p] = (uintptr_t)p + n; poison_dirty = true; } }
+void *dev_malloc(size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (p) blocks[(uintptr_t)p] = n;
+    return p;
+}
+void dev_free(void *p) {
+    auto b = blocks.find((uintptr_t)p);
+    if (b != blocks.end()) {
+        poisoned.erase(poisoned.lower_bound(b->first), poisoned.lower_bound(b->first + b->second));
+        poison_dirty = true;
+        blocks.erase(b);
+    }
+    free(p);
+}
 
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn) {
     const unsigned n = block.x * block.y * block.z;
@@ -267,14 +303,14 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
 extern "C" unsigned long hipsim_partial_wave_ops(void) { return hipsim::partial_ops; }
 
 // the -fsanitize=thread hooks (no ThreadSanitizer runtime is linked; these are all there is)
-#define HIPSIM_HOOK(name)                                                                                    \
+#define HIPSIM_HOOK(name, size)                                                                              \
     extern "C" __attribute__((noinline)) void name(void *a) {                                                \
-        hipsim::before_access(a, __builtin_return_address(0), __builtin_frame_address(1));                   \
+        hipsim::before_access(a, size, __builtin_return_address(0), __builtin_frame_address(1));             \
     }
-HIPSIM_HOOK(__tsan_read1) HIPSIM_HOOK(__tsan_read2) HIPSIM_HOOK(__tsan_read4) HIPSIM_HOOK(__tsan_read8) HIPSIM_HOOK(__tsan_read16)
-HIPSIM_HOOK(__tsan_write1) HIPSIM_HOOK(__tsan_write2) HIPSIM_HOOK(__tsan_write4) HIPSIM_HOOK(__tsan_write8) HIPSIM_HOOK(__tsan_write16)
-HIPSIM_HOOK(__tsan_unaligned_read2) HIPSIM_HOOK(__tsan_unaligned_read4) HIPSIM_HOOK(__tsan_unaligned_read8) HIPSIM_HOOK(__tsan_unaligned_read16)
-HIPSIM_HOOK(__tsan_unaligned_write2) HIPSIM_HOOK(__tsan_unaligned_write4) HIPSIM_HOOK(__tsan_unaligned_write8) HIPSIM_HOOK(__tsan_unaligned_write16)
+HIPSIM_HOOK(__tsan_read1, 1) HIPSIM_HOOK(__tsan_read2, 2) HIPSIM_HOOK(__tsan_read4, 4) HIPSIM_HOOK(__tsan_read8, 8) HIPSIM_HOOK(__tsan_read16, 16)
+HIPSIM_HOOK(__tsan_write1, 1) HIPSIM_HOOK(__tsan_write2, 2) HIPSIM_HOOK(__tsan_write4, 4) HIPSIM_HOOK(__tsan_write8, 8) HIPSIM_HOOK(__tsan_write16, 16)
+HIPSIM_HOOK(__tsan_unaligned_read2, 2) HIPSIM_HOOK(__tsan_unaligned_read4, 4) HIPSIM_HOOK(__tsan_unaligned_read8, 8) HIPSIM_HOOK(__tsan_unaligned_read16, 16)
+HIPSIM_HOOK(__tsan_unaligned_write2, 2) HIPSIM_HOOK(__tsan_unaligned_write4, 4) HIPSIM_HOOK(__tsan_unaligned_write8, 8) HIPSIM_HOOK(__tsan_unaligned_write16, 16)
 extern "C" void __tsan_init(void) {}
 extern "C" void __tsan_func_entry(void *) {}
 extern "C" void __tsan_func_exit(void) {}

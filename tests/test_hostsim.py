@@ -13,6 +13,18 @@ def sim():
     return hostsim
 
 
+def test_emulation_selftest(sim):
+    """tests/hostsim/selftest.cpp: wave-aggregated appends from divergent callers, counter flushes, lock-step
+    memory order inside a wavefront, the LDS hand-off across a block, a loop that lanes leave early -- and
+    an access into an arena guard gap must abort"""
+    import subprocess
+    exe = sim.build_selftest()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout, r.stderr)
+    r = subprocess.run([exe, "guard"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "arena guard gap" in r.stderr and "guard not hit" not in r.stdout, (r.stdout, r.stderr)
+
+
 def test_sim_library_is_not_the_product(sim, engine_lib):
     """the package's own handle is the HIP library; the simulated one is only ever swapped in by a test"""
     from summerset_amd import _lib
