@@ -422,6 +422,83 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *host_bufs);
 int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters);
 
 /* ------------------------------------------------------------------------
+ * RSPaxos replica: G groups, one replica id per object, one call = one handler
+ * of RSPaxosReplica per group (+ the WAL / command completions it triggers, LS-1 rule 0).
+ *   smr_rsp_req_batch              handle_req_batch (rspaxos/request.rs:10-151): from_data + compute_parity,
+ *                                  one shard per peer (subset_copy, rscoding.rs:255-293)
+ *   smr_rsp_handle_accept          handle_msg_accept (messages.rs:343-403) + handle_logged_accept_data
+ *   smr_rsp_handle_accept_replies  handle_msg_accept_reply (:406-464): threshold majority + fault_tolerance;
+ *                                  handle_logged_commit_slot (durability.rs:125-186): the commit-bar run stops
+ *                                  at an instance holding fewer than `majority` shards; handle_cmd_result
+ *   smr_rsp_become_leader          become_a_leader on HearTimeout (leadership.rs:47-185): step-up Heartbeat,
+ *                                  Prepare, the Reconstruct list (committed instances short of shards)
+ *   smr_rsp_handle_prepare         handle_msg_prepare (:12-84) + the PrepareReply batch (voted ballot, shards)
+ *   smr_rsp_handle_prepare_replies handle_msg_prepare_reply (:87-340): shards of the highest voted ballot
+ *                                  merged (absorb_other, rscoding.rs:296-346); at the quorum, instances with
+ *                                  >= majority shards are reconstructed and re-Accepted, at >= population -
+ *                                  fault_tolerance replies the others become empty batches
+ *   smr_rsp_handle_reconstruct / _reply   handle_msg_reconstruct (:467-515), handle_msg_reconstruct_reply (:518-594)
+ *   smr_rsp_handle_heartbeat / smr_rsp_bcast_heartbeat   heard_heartbeat, bcast_heartbeats (leadership.rs:187-340)
+ * A request batch is an opaque 32-bit token (0 = the empty batch, SMR_RSP_NULL = none / a null codeword); a
+ * codeword is (token, mask of shards present): the shard BYTES are smr_rs_encode / smr_rs_reconstruct's.
+ * Device arrays: one entry per group [G]; lists are [W][G] with a count [G]; per-peer matrices [R][G].
+ * ---------------------------------------------------------------------- */
+typedef struct smr_rsp_replica smr_rsp_replica;
+#define SMR_RSP_NULL 0xFFFFFFFFu
+
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population;        /* R, 3..8; RS(majority, R - majority) */
+    uint8_t me;                /* my replica id in every group */
+    uint8_t fault_tolerance;   /* ReplicaConfigRSPaxos::fault_tolerance (mod.rs:75,600-604) */
+    uint8_t reserved0;
+    uint32_t window;           /* W: slots kept per group, power of two >= 8 */
+} smr_rsp_cfg;
+
+typedef struct { uint32_t *n, *slot, *val; uint64_t *ballot; } smr_rsp_accepts;            /* Accepts to every peer (shard {peer} each) */
+typedef struct { uint8_t *flags; uint64_t *ballot; uint32_t *commit_bar, *exec_bar, *snap_bar; } smr_rsp_heartbeat;
+typedef struct { uint32_t *n, *trig, *endp; uint64_t *ballot, *vbal; uint32_t *vval; uint8_t *vmask; } smr_rsp_prepare_reply;
+typedef struct { uint32_t *n, *slot; uint64_t *bal; uint32_t *val; uint8_t *mask; } smr_rsp_shards;   /* ReconstructReply rows */
+
+int smr_rsp_replica_create(const smr_rsp_cfg *cfg, smr_rsp_replica **out);
+void smr_rsp_replica_destroy(smr_rsp_replica *e);
+/* every replica believes in `leader`, which is prepared at make_unique_ballot(1) (host call) */
+int smr_rsp_preset_leader(smr_rsp_replica *e, uint8_t leader);
+int smr_rsp_req_batch(smr_rsp_replica *e, const uint32_t *val_dev, const smr_rsp_accepts *out, void *stream);
+int smr_rsp_handle_accept(smr_rsp_replica *e, const uint8_t *flags_dev, const uint8_t *peer_dev, const uint32_t *slot_dev,
+                          const uint64_t *ballot_dev, const uint32_t *val_dev, const uint8_t *mask_dev, uint64_t *r_ballot_dev,
+                          uint32_t *r_slot_dev, void *stream);
+int smr_rsp_handle_accept_replies(smr_rsp_replica *e, const uint32_t *slot_dev, const uint64_t *ballot_dev, const uint8_t *flags_dev,
+                                  const uint32_t *order_dev, uint8_t *committed_dev, void *stream);
+int smr_rsp_become_leader(smr_rsp_replica *e, const uint8_t *src_dev, const smr_rsp_heartbeat *hb, uint8_t *p_flags_dev,
+                          uint32_t *p_trig_dev, uint64_t *p_ballot_dev, uint32_t *rc_n_dev, uint32_t *rc_slot_dev, void *stream);
+int smr_rsp_handle_prepare(smr_rsp_replica *e, const uint8_t *flags_dev, const uint8_t *peer_dev, const uint32_t *trig_dev,
+                           const uint64_t *ballot_dev, const smr_rsp_prepare_reply *out, void *stream);
+int smr_rsp_handle_prepare_replies(smr_rsp_replica *e, const uint8_t *peer_dev, const smr_rsp_prepare_reply *in,
+                                   const smr_rsp_accepts *out, void *stream);
+int smr_rsp_handle_reconstruct(smr_rsp_replica *e, const uint8_t *flags_dev, const uint32_t *rc_n_dev, const uint32_t *rc_slot_dev,
+                               const smr_rsp_shards *out, void *stream);
+int smr_rsp_handle_reconstruct_reply(smr_rsp_replica *e, const uint8_t *flags_dev, const smr_rsp_shards *in, void *stream);
+/* in->flags: a Heartbeat from peer_dev[g] arrives; reply_dev[g] = 1: mine goes back (fields in `out`) */
+int smr_rsp_handle_heartbeat(smr_rsp_replica *e, const uint8_t *peer_dev, const smr_rsp_heartbeat *in, uint8_t *reply_dev,
+                             const smr_rsp_heartbeat *out, void *stream);
+int smr_rsp_bcast_heartbeat(smr_rsp_replica *e, const uint8_t *flags_dev, const smr_rsp_heartbeat *out, void *stream);
+/* host buffers: scalars [G], peer_exec_bar [R][G], per slot [W][G] by slot % W (cells outside the ring read as
+ * null instances); s_flags: bit0 leader_bk, bit1 replica_bk, bit2 external; counters[4] = commits, commands
+ * executed, absorbs of a different token (none in a correct run), redirected batches */
+typedef struct {
+    uint8_t *leader;
+    uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
+    uint32_t *len, *commit_bar, *exec_bar, *snap_bar, *peer_exec_bar;
+    uint64_t *digest;
+    uint64_t *s_bal; uint8_t *s_status; uint32_t *s_val; uint8_t *s_mask; uint64_t *s_vbal; uint32_t *s_vval; uint8_t *s_vmask;
+    uint8_t *s_flags; uint32_t *s_ltrig, *s_lendp; uint8_t *s_packs, *s_aacks; uint64_t *s_pmax; uint8_t *s_rsrc;
+    uint32_t *s_rtrig, *s_rendp;
+    uint64_t *counters;
+} smr_rsp_dump_bufs;
+int smr_rsp_dump(smr_rsp_replica *e, const smr_rsp_dump_bufs *host_bufs);
+
+/* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing
  * ---------------------------------------------------------------------- */
 typedef struct smr_repnothing smr_repnothing;

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c"]
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c"]
 
 CTL_IDENTITY = 0x00FAC688
 NO_LEADER = 0xFF
@@ -93,6 +93,20 @@ def _declare(L):
     L.orc_ep_dump.argtypes = [vp] + [vp] * 12
     L.orc_ep_set_execute.argtypes = [vp, u8]
     L.orc_ep_exec_dump.argtypes = [vp] + [vp] * 4
+    L.orc_rsp_new.restype = vp; L.orc_rsp_new.argtypes = [u32, u8, u8, u32, u8]
+    L.orc_rsp_free.argtypes = [vp]
+    L.orc_rsp_preset_leader.argtypes = [vp, u8]
+    L.orc_rsp_req_batch.argtypes = [vp] + [vp] * 5
+    L.orc_rsp_accept.argtypes = [vp] + [vp] * 8
+    L.orc_rsp_accept_replies.argtypes = [vp] + [vp] * 5
+    L.orc_rsp_become_leader.argtypes = [vp] + [vp] * 11
+    L.orc_rsp_prepare.argtypes = [vp] + [vp] * 11
+    L.orc_rsp_prepare_replies.argtypes = [vp] + [vp] * 12
+    L.orc_rsp_reconstruct.argtypes = [vp] + [vp] * 8
+    L.orc_rsp_reconstruct_reply.argtypes = [vp] + [vp] * 6
+    L.orc_rsp_heartbeat.argtypes = [vp] + [vp] * 11
+    L.orc_rsp_bcast_heartbeat.argtypes = [vp] + [vp] * 5
+    L.orc_rsp_dump.argtypes = [vp] + [vp] * 27
 
 
 # ---------------------------------------------------------------- GF / RS ---
@@ -415,4 +429,113 @@ class EpOracle:
         d = dict(exec_bars=np.zeros((R, G), np.uint32), kv=np.zeros((K, G), np.uint64), digest=np.zeros(G, np.uint64),
                  counters=np.zeros(6, np.uint64))
         lib().orc_ep_exec_dump(self.h, _p(d["exec_bars"]), _p(d["kv"]), _p(d["digest"]), _p(d["counters"]))
+        return d
+
+
+# ------------------------------------------------------------- RSPaxos ---
+RSP_SCALARS = (("leader", np.uint8), ("bal_prep_sent", np.uint64), ("bal_prepared", np.uint64), ("bal_max_seen", np.uint64),
+               ("len", np.uint32), ("commit_bar", np.uint32), ("exec_bar", np.uint32), ("snap_bar", np.uint32))
+RSP_SLOTS = (("s_bal", np.uint64), ("s_status", np.uint8), ("s_val", np.uint32), ("s_mask", np.uint8), ("s_vbal", np.uint64),
+             ("s_vval", np.uint32), ("s_vmask", np.uint8), ("s_flags", np.uint8), ("s_ltrig", np.uint32), ("s_lendp", np.uint32),
+             ("s_packs", np.uint8), ("s_aacks", np.uint8), ("s_pmax", np.uint64), ("s_rsrc", np.uint8), ("s_rtrig", np.uint32),
+             ("s_rendp", np.uint32))
+RSP_NULL = 0xFFFFFFFF
+
+
+class RspOracle:
+    """G groups of the literal RSPaxos replica restatement (replica `me`); messages are dicts of numpy arrays with one
+    entry per group, lists as [W, G] with a count."""
+
+    def __init__(self, G, R=5, me=0, W=32, fault_tolerance=0):
+        self.G, self.R, self.me, self.W = G, R, me, W
+        self.h = lib().orc_rsp_new(G, R, me, W, fault_tolerance)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rsp_free(self.h)
+            self.h = None
+
+    def preset_leader(self, leader):
+        lib().orc_rsp_preset_leader(self.h, leader)
+
+    def _accepts(self):
+        G, W = self.G, self.W
+        return dict(a_n=np.zeros(G, np.uint32), a_slot=np.zeros((W, G), np.uint32), a_val=np.zeros((W, G), np.uint32),
+                    a_ballot=np.zeros(G, np.uint64))
+
+    def req_batch(self, val):
+        o = self._accepts()
+        lib().orc_rsp_req_batch(self.h, _p(val), *[_p(o[k]) for k in ("a_n", "a_slot", "a_val", "a_ballot")])
+        return o
+
+    def accept(self, flags, peer, slot, ballot, val, mask):
+        o = dict(r_ballot=np.zeros(self.G, np.uint64), r_slot=np.zeros(self.G, np.uint32))
+        lib().orc_rsp_accept(self.h, _p(flags), _p(peer), _p(slot), _p(ballot), _p(val), _p(mask), _p(o["r_ballot"]), _p(o["r_slot"]))
+        return o
+
+    def accept_replies(self, slot, ballot, flags, order=None):
+        o = dict(committed=np.zeros(self.G, np.uint8))
+        lib().orc_rsp_accept_replies(self.h, _p(slot), _p(ballot), _p(flags), _p(order), _p(o["committed"]))
+        return o
+
+    def become_leader(self, src):
+        G, W = self.G, self.W
+        o = dict(hb_flags=np.zeros(G, np.uint8), hb_ballot=np.zeros(G, np.uint64), hb_commit=np.zeros(G, np.uint32),
+                 hb_exec=np.zeros(G, np.uint32), hb_snap=np.zeros(G, np.uint32), p_flags=np.zeros(G, np.uint8),
+                 p_trig=np.zeros(G, np.uint32), p_ballot=np.zeros(G, np.uint64), rc_n=np.zeros(G, np.uint32),
+                 rc_slot=np.zeros((W, G), np.uint32))
+        lib().orc_rsp_become_leader(self.h, _p(src), *[_p(o[k]) for k in ("hb_flags", "hb_ballot", "hb_commit", "hb_exec", "hb_snap",
+                                                                           "p_flags", "p_trig", "p_ballot", "rc_n", "rc_slot")])
+        return o
+
+    def prepare(self, flags, peer, trig, ballot):
+        G, W = self.G, self.W
+        o = dict(pr_n=np.zeros(G, np.uint32), pr_trig=np.zeros(G, np.uint32), pr_endp=np.zeros(G, np.uint32),
+                 pr_ballot=np.zeros(G, np.uint64), pr_vbal=np.zeros((W, G), np.uint64), pr_vval=np.zeros((W, G), np.uint32),
+                 pr_vmask=np.zeros((W, G), np.uint8))
+        lib().orc_rsp_prepare(self.h, _p(flags), _p(peer), _p(trig), _p(ballot),
+                              *[_p(o[k]) for k in ("pr_n", "pr_trig", "pr_endp", "pr_ballot", "pr_vbal", "pr_vval", "pr_vmask")])
+        return o
+
+    def prepare_replies(self, peer, pr_n, pr_trig, pr_endp, pr_ballot, pr_vbal, pr_vval, pr_vmask):
+        o = self._accepts()
+        lib().orc_rsp_prepare_replies(self.h, _p(peer), _p(pr_n), _p(pr_trig), _p(pr_endp), _p(pr_ballot), _p(pr_vbal), _p(pr_vval),
+                                      _p(pr_vmask), *[_p(o[k]) for k in ("a_n", "a_slot", "a_val", "a_ballot")])
+        return o
+
+    def reconstruct(self, flags, rc_n, rc_slot):
+        G, W = self.G, self.W
+        o = dict(rr_n=np.zeros(G, np.uint32), rr_slot=np.zeros((W, G), np.uint32), rr_bal=np.zeros((W, G), np.uint64),
+                 rr_val=np.zeros((W, G), np.uint32), rr_mask=np.zeros((W, G), np.uint8))
+        lib().orc_rsp_reconstruct(self.h, _p(flags), _p(rc_n), _p(rc_slot), *[_p(o[k]) for k in ("rr_n", "rr_slot", "rr_bal", "rr_val", "rr_mask")])
+        return o
+
+    def reconstruct_reply(self, flags, rr_n, rr_slot, rr_bal, rr_val, rr_mask):
+        lib().orc_rsp_reconstruct_reply(self.h, _p(flags), _p(rr_n), _p(rr_slot), _p(rr_bal), _p(rr_val), _p(rr_mask))
+
+    def heartbeat(self, flags, peer, ballot, commit_bar, exec_bar, snap_bar):
+        G = self.G
+        o = dict(reply=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64), commit_bar=np.zeros(G, np.uint32),
+                 exec_bar=np.zeros(G, np.uint32), snap_bar=np.zeros(G, np.uint32))
+        lib().orc_rsp_heartbeat(self.h, _p(flags), _p(peer), _p(ballot), _p(commit_bar), _p(exec_bar), _p(snap_bar),
+                                *[_p(o[k]) for k in ("reply", "ballot", "commit_bar", "exec_bar", "snap_bar")])
+        return o
+
+    def bcast_heartbeat(self, flags):
+        G = self.G
+        o = dict(ballot=np.zeros(G, np.uint64), commit_bar=np.zeros(G, np.uint32), exec_bar=np.zeros(G, np.uint32),
+                 snap_bar=np.zeros(G, np.uint32))
+        lib().orc_rsp_bcast_heartbeat(self.h, _p(flags), *[_p(o[k]) for k in ("ballot", "commit_bar", "exec_bar", "snap_bar")])
+        return o
+
+    def dump(self):
+        G, R, W = self.G, self.R, self.W
+        d = {n: np.zeros(G, t) for n, t in RSP_SCALARS}
+        d["peer_exec_bar"] = np.zeros((R, G), np.uint32)
+        d["digest"] = np.zeros(G, np.uint64)
+        for n, t in RSP_SLOTS:
+            d[n] = np.zeros((W, G), t)
+        d["counters"] = np.zeros(4, np.uint64)
+        order = [n for n, _ in RSP_SCALARS] + ["peer_exec_bar", "digest"] + [n for n, _ in RSP_SLOTS] + ["counters"]
+        lib().orc_rsp_dump(self.h, *[_p(d[k]) for k in order])
         return d

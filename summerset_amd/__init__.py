@@ -12,5 +12,6 @@ from .rscoding import RSCodewordBatch, rs_matrix, rs_shard_len  # noqa: F401
 from .multipaxos import MultiPaxosCluster  # noqa: F401
 from .raft import RaftLeaderGroup  # noqa: F401
 from .epaxos import EPaxosReplicaGroup  # noqa: F401
+from .rspaxos import RSPaxosReplicaGroup  # noqa: F401
 from .repnothing import RepNothingReplica  # noqa: F401
 from . import shard, stream  # noqa: F401

@@ -85,6 +85,25 @@ class EpMsg(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("flags", "peer", "col", "ballot", "seq", "deps", "key")]
 
 
+class RspCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("me", C.c_uint8), ("fault_tolerance", C.c_uint8),
+                ("reserved0", C.c_uint8), ("window", C.c_uint32)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(n, C.c_void_p) for n in fields]})
+
+
+RspAccepts = _ptr_struct("RspAccepts", ("n", "slot", "val", "ballot"))
+RspHeartbeat = _ptr_struct("RspHeartbeat", ("flags", "ballot", "commit_bar", "exec_bar", "snap_bar"))
+RspPrepareReply = _ptr_struct("RspPrepareReply", ("n", "trig", "endp", "ballot", "vbal", "vval", "vmask"))
+RspShards = _ptr_struct("RspShards", ("n", "slot", "bal", "val", "mask"))
+RSP_DUMP_FIELDS = ("leader", "bal_prep_sent", "bal_prepared", "bal_max_seen", "len", "commit_bar", "exec_bar", "snap_bar",
+                   "peer_exec_bar", "digest", "s_bal", "s_status", "s_val", "s_mask", "s_vbal", "s_vval", "s_vmask", "s_flags",
+                   "s_ltrig", "s_lendp", "s_packs", "s_aacks", "s_pmax", "s_rsrc", "s_rtrig", "s_rendp", "counters")
+RspDumpBufs = _ptr_struct("RspDumpBufs", RSP_DUMP_FIELDS)
+
+
 EP_DUMP_FIELDS = ("len", "commit_bars", "bal", "seq", "status", "key", "deps", "pa_acks", "acc_acks", "bk", "highest_cols",
                   "counters")
 
@@ -157,6 +176,20 @@ SYMBOLS = [
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("smr_rsp_replica_create", _i, [C.POINTER(RspCfg), C.POINTER(_vp)]),
+    ("smr_rsp_replica_destroy", None, [_vp]),
+    ("smr_rsp_preset_leader", _i, [_vp, _u8]),
+    ("smr_rsp_req_batch", _i, [_vp, _vp, C.POINTER(RspAccepts), _vp]),
+    ("smr_rsp_handle_accept", _i, [_vp] + [_vp] * 9),
+    ("smr_rsp_handle_accept_replies", _i, [_vp] + [_vp] * 6),
+    ("smr_rsp_become_leader", _i, [_vp, _vp, C.POINTER(RspHeartbeat), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_rsp_handle_prepare", _i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(RspPrepareReply), _vp]),
+    ("smr_rsp_handle_prepare_replies", _i, [_vp, _vp, C.POINTER(RspPrepareReply), C.POINTER(RspAccepts), _vp]),
+    ("smr_rsp_handle_reconstruct", _i, [_vp, _vp, _vp, _vp, C.POINTER(RspShards), _vp]),
+    ("smr_rsp_handle_reconstruct_reply", _i, [_vp, _vp, C.POINTER(RspShards), _vp]),
+    ("smr_rsp_handle_heartbeat", _i, [_vp, _vp, C.POINTER(RspHeartbeat), _vp, C.POINTER(RspHeartbeat), _vp]),
+    ("smr_rsp_bcast_heartbeat", _i, [_vp, _vp, C.POINTER(RspHeartbeat), _vp]),
+    ("smr_rsp_dump", _i, [_vp, C.POINTER(RspDumpBufs)]),
     ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
     ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),

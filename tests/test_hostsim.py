@@ -96,3 +96,12 @@ def test_rs_kernels_on_the_host(sim, oracle):
         t.test_verify_detects_corruption("cpu")
         t.test_padding_bytes_are_never_read("cpu", oracle)
         t.test_subset_copy_and_absorb_other_rspaxos_flow("cpu", oracle)
+
+
+def test_rspaxos_kernels_on_the_host(sim, oracle):
+    import test_zz_rsp_gpu as t
+    with sim.patched():
+        t.test_traces_on_the_engine("cpu", oracle)
+        t.test_closed_loop_cluster_matches_oracle("cpu", oracle, 130, 32, 0, 0.0)
+        t.test_closed_loop_cluster_matches_oracle("cpu", oracle, 130, 32, 1, 0.1)
+        t.test_closed_loop_cluster_matches_oracle("cpu", oracle, 70, 16, 1, 0.05)
