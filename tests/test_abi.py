@@ -61,7 +61,7 @@ def test_argument_errors_do_not_need_a_device(engine_lib):
 def test_argument_errors_of_the_other_protocol_objects(engine_lib):
     import ctypes as C
     from summerset_amd import _lib
-    from summerset_amd._lib import EpCfg, RaftCfg, SummersetError, check
+    from summerset_amd._lib import EpCfg, RaftCfg, RspCfg, SummersetError, check
     h = C.c_void_p()
     for cfg, frag in ((RaftCfg(0, 5, 0, 0, 0, 64, 1), "n_groups"), (RaftCfg(8, 9, 0, 0, 0, 64, 1), "population"),
                       (RaftCfg(8, 5, 5, 0, 0, 64, 1), "leader_id"), (RaftCfg(8, 5, 0, 0, 0, 40, 1), "power of two"),
@@ -75,8 +75,21 @@ def test_argument_errors_of_the_other_protocol_objects(engine_lib):
         with pytest.raises(SummersetError) as e:
             check(engine_lib.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
         assert e.value.code == _lib.SMR_ERR_ARG and frag in e.value.msg
+    for cfg, frag in ((EpCfg(8, 5, 0, 1, 2, 32, 64), "execute must be"), (EpCfg(8, 8, 0, 1, 1, 8192, 64), "15-bit")):
+        with pytest.raises(SummersetError) as e:
+            check(engine_lib.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
+        assert e.value.code == _lib.SMR_ERR_ARG and frag in e.value.msg
+    for cfg, frag in ((RspCfg(0, 5, 0, 0, 0, 32), "n_groups"), (RspCfg(8, 2, 0, 0, 0, 32), "population"),
+                      (RspCfg(8, 5, 5, 0, 0, 32), "replica id"), (RspCfg(8, 5, 0, 0, 0, 24), "power of two"),
+                      (RspCfg(8, 5, 0, 3, 0, 32), "fault_tolerance")):       # mod.rs:600-604: at most population - majority
+        with pytest.raises(SummersetError) as e:
+            check(engine_lib.smr_rsp_replica_create(C.byref(cfg), C.byref(h)))
+        assert e.value.code == _lib.SMR_ERR_ARG and frag in e.value.msg
     # null handles are refused, not dereferenced
     for fn, args in ((engine_lib.smr_raft_replica_preset, (None, 0, 0, 1, 0xFF)),
+                     (engine_lib.smr_rsp_req_batch, (None, None, None, None)),
+                     (engine_lib.smr_rsp_preset_leader, (None, 0)),
+                     (engine_lib.smr_ep_exec_dump, (None, None, None, None, None)),
                      (engine_lib.smr_ep_propose, (None, None, None, None, None)),
                      (engine_lib.smr_mp_end_tick, (None,)),
                      (engine_lib.smr_repnothing_stats, (None, None, None, None, None))):
