@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
+    ap.add_argument("--late-legs", action="store_true", help="also run the legs of kernels that have not had a device run yet "
+                    "(EPaxos execution, the RSPaxos replica engine), each in a child process")
     ap.add_argument("--leg", default=None, help="internal: run one secondary leg in this process and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -371,6 +373,74 @@ def epaxos_leg(torch, dev, ticks=16):
 
 
 
+def epaxos_exec_leg(torch, dev, ticks=16):
+    """the EPaxos leg with dependency-graph execution on (smr_ep_cfg.execute): every handler call is followed by
+    ep_execute_kernel (execution.rs:25-211).  Opt-in (--late-legs): the kernel has not had a device run yet."""
+    from summerset_amd import EPaxosReplicaGroup
+    G, R, W, K = 65536, 5, 32, 64
+    eng = EPaxosReplicaGroup(G, R, me=0, window=W, n_keys=K, execute=True)
+    rng = np.random.default_rng(0x5EED5EED)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    keys = [torch.from_numpy(rng.choice(K, G, p=zipf).astype(np.uint8)).to(dev) for _ in range(ticks)]
+    flags = np.ones((R, G), np.uint8)
+    flags[0] = 0
+    flags_d = torch.from_numpy(flags).to(dev)
+    ballot_d = torch.ones((R, G), dtype=torch.int64, device=dev)
+    t_prop = t_rep = 0.0
+    for t in range(ticks):
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        e0.record()
+        m = eng.handle_req_batch(keys[t])
+        e1.record()
+        seq = m["seq"].unsqueeze(0).repeat(R, 1).contiguous()
+        deps = m["deps"].unsqueeze(0).repeat(R, 1, 1).contiguous()
+        e2.record()
+        eng.handle_msg_pre_accept_reply(m["col"], ballot_d, seq, deps, flags_d)
+        e3.record()
+        torch.cuda.synchronize()
+        t_prop += e0.elapsed_time(e1)
+        t_rep += e2.elapsed_time(e3)
+    x = eng.exec_dump()
+    c = [int(v) for v in x["counters"]]
+    return {"workload": "EPaxos command leader with execution, %d groups, 1 proposal + 4 agreeing PreAcceptReplies per group per tick" % G,
+            "value": c[0] / ((t_prop + t_rep) * 1e-3), "unit": "commands executed/s (handler + execution kernels, incl. host call overhead)",
+            "propose_call_us": t_prop / ticks * 1e3, "replies_call_us": t_rep / ticks * 1e3,
+            "executed": c[0], "re_executed": c[1], "attempts": c[4], "abandoned": c[5]}
+
+
+def rspaxos_replica_leg(torch, dev, ticks=32):
+    """the RSPaxos replica engine (csrc/rsp_engine.hip), leader side of BASELINE config 4: 16 384 groups, per tick one
+    batch per group (handle_req_batch) and the 4 followers' AcceptReplies (10 % lost), threshold majority + 1.
+    Opt-in (--late-legs): the kernels have not had a device run yet."""
+    from summerset_amd import RSPaxosReplicaGroup
+    G, R, W = 16384, 5, 64
+    eng = RSPaxosReplicaGroup(G, R, me=0, window=W, fault_tolerance=1)
+    eng.preset_leader(0)
+    rng = np.random.default_rng(0x5EED5EED)
+    b0 = (1 << 8) | 1
+    ballot = torch.full((R, G), b0, dtype=torch.int64, device=dev)
+    t_req = t_rep = 0.0
+    for t in range(ticks):
+        val = torch.arange(1 + t * G, 1 + (t + 1) * G, dtype=torch.int32, device=dev)
+        fl = (rng.random((R, G)) >= 0.1).astype(np.uint8)
+        fl[0] = 0
+        fl = torch.from_numpy(fl).to(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        a = eng.req_batch(val)
+        e1.record()
+        eng.accept_replies(a["a_slot"][0].contiguous(), ballot, fl)
+        e2.record()
+        torch.cuda.synchronize()
+        t_req += e0.elapsed_time(e1)
+        t_rep += e1.elapsed_time(e2)
+    c = [int(v) for v in eng.dump()["counters"]]
+    return {"workload": "RSPaxos replica engine, leader of %d groups x 5 replicas, f = 1: one batch + 4 AcceptReplies (10%% lost) per tick" % G,
+            "value": c[0] / ((t_req + t_rep) * 1e-3), "unit": "committed slots/s (incl. host call overhead)",
+            "req_batch_call_us": t_req / ticks * 1e3, "accept_replies_call_us": t_rep / ticks * 1e3, "commits": c[0], "executed": c[1]}
+
+
 def _cpu_run(a):
     """one process, one thread: the CPU oracle on G groups of the bench workload for about `seconds`"""
     slots, window, drop, timeouts, hb_every, G, seconds = a
@@ -425,7 +495,8 @@ def main():
     rank, local, world = shard.env_world()
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
-        print(json.dumps({"rspaxos": rspaxos_leg}[args.leg](torch, torch.device("cuda", local))))
+        legs = {"rspaxos": rspaxos_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg}
+        print(json.dumps(legs[args.leg](torch, torch.device("cuda", local))))
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
@@ -531,6 +602,9 @@ def main():
             leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
             leg("rspaxos", leg_isolated, "rspaxos")
             leg("repnothing", repnothing_leg)
+            if args.late_legs:
+                leg("epaxos_execution", leg_isolated, "epaxos_execution")
+                leg("rspaxos_replica", leg_isolated, "rspaxos_replica")
             if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
                 for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
                     if isinstance(line.get(name), dict) and "error" not in line[name]:
