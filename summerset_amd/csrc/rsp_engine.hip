@@ -70,6 +70,7 @@ struct RspLane {
         const size_t i = ix(len);
         v.s_bal[i] = 0; v.s_st[i] = RST_NULL; v.s_val[i] = RSP_NULL; v.s_mask[i] = 0;
         v.s_vbal[i] = 0; v.s_vval[i] = RSP_NULL; v.s_vmask[i] = 0; v.s_fl[i] = 0;
+        v.s_pmax[i] = 0;       // read by handle_msg_prepare_reply even without leader bookkeeping (the reference would panic there)
         len++;
     }
     // while (len <= slot) push(null); only the last W pushes leave anything behind
@@ -391,19 +392,26 @@ __global__ __launch_bounds__(256) void rsp_prepare_kernel(const RspView v, const
             const size_t i = L.ix(s);
             v.s_bal[i] = b; v.s_st[i] = RST_PREPARING;
             v.s_fl[i] = (uint8_t)(v.s_fl[i] | RFL_RBK); v.s_rsrc[i] = peer[g]; v.s_rtrig[i] = t; v.s_rendp[i] = endp;
-            if (follower) {                                              // its PrepareBal completion: one row of the reply
+        }
+        // the PrepareBal completions come once every slot above is Preparing (rule 0), in slot order: on a follower
+        // one row of the reply each; on a replica that still leads (a Prepare carrying its own ballot) a Prepare
+        // reply from itself, whose quorum step may turn LATER slots of this very range back to Accepting
+        for (uint32_t s = t; s <= endp; s++) {
+            if (!L.held(s)) continue;
+            const size_t i = L.ix(s);
+            if (follower) {
                 const uint32_t k = s - t;
-                if (n == 0) { o_trig = t; o_endp = endp; o_bal = b; }
+                if (n == 0) { o_trig = t; o_endp = endp; o_bal = v.s_bal[i]; }
                 if (k < v.W) {
                     const uint64_t vb = v.s_vbal[i];
                     const size_t o = (size_t)k * v.G + g;
                     pr_vbal[o] = vb; pr_vval[o] = vb > 0 ? v.s_vval[i] : RSP_NULL; pr_vmask[o] = vb > 0 ? v.s_vmask[i] : (uint8_t)0;
                     if (k + 1 > n) n = k + 1;
                 }
-            } else if ((v.s_fl[i] & RFL_LBK) && s <= v.s_lendp[i]) {     // (a replica that still leads: reply to itself)
+            } else if ((v.s_fl[i] & RFL_LBK) && s <= v.s_lendp[i]) {
                 uint32_t na = 0;
                 const uint64_t vb = v.s_vbal[i];
-                L.prepare_reply(v.me, s, v.s_ltrig[i], v.s_lendp[i], b, vb > 0, vb, v.s_vval[i], v.s_vmask[i], nullptr, nullptr, na);
+                L.prepare_reply(v.me, s, v.s_ltrig[i], v.s_lendp[i], v.s_bal[i], vb > 0, vb, v.s_vval[i], v.s_vmask[i], nullptr, nullptr, na);
             }
         }
     }

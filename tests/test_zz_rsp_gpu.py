@@ -64,3 +64,28 @@ def test_closed_loop_cluster_matches_oracle(cuda, oracle, G, W, ft, loss):
     assert c[0] > 0 and c[1] > 0 and c[2] == 0
     assert sum(e["voted"] for e in ev if e["kind"] == "prepare_reply") > 0 and sum(e["n"] for e in ev if e["kind"] == "re_accept") > 0
     assert sum(e["rows"] for e in ev if e["kind"] == "recon_reply") > 0
+
+
+@pytest.mark.parametrize("G,W,me,ft", [(500, 8, 0, 0), (500, 16, 2, 1), (500, 32, 4, 2)])
+def test_random_handler_calls_match_oracle(cuda, oracle, G, W, me, ft):
+    """differential: seeded random (not protocol-legal) calls, small rings so that slots leave them all the time"""
+    import rsp_cluster as rc
+    import rsp_random as rr
+    from summerset_amd import RSPaxosReplicaGroup
+    R = 5
+    eng = rc.NumpyEngine(RSPaxosReplicaGroup(G, R, me=me, window=W, fault_tolerance=ft), cuda)
+    orc = oracle.RspOracle(G, R, me=me, W=W, fault_tolerance=ft)
+    eng.preset_leader(0); orc.preset_leader(0)
+    rng = np.random.default_rng(G + W + me)
+    seen = set()
+    for step in range(160):
+        for name, kw in rr.calls(rng, orc.dump(), G, R, me, W):
+            seen.add(name)
+            a, b = getattr(eng, name)(**kw), getattr(orc, name)(**kw)
+            if b is not None:
+                for k in b:
+                    assert np.array_equal(a[k], b[k]), (step, name, k, [x[:4] for x in np.nonzero(a[k] != b[k])])
+            _same([eng], [orc], (step, name))
+    assert len(seen) == 10
+    c = orc.dump()["counters"]
+    assert c[0] > 0 and c[1] > 0
