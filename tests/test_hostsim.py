@@ -80,6 +80,11 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
                commit_extra=1)
         eng, _ = t._run("cpu", oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True)
         assert eng.counters(0)["rejects"] > 0
+        # populations the device tests do not run (the 8-replica template instances of the tally and the reply kernels)
+        t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
+        t._run("cpu", oracle, G=100, R=4, S=3, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=3, preset=True)
+        t._run("cpu", oracle, G=70, R=8, S=1, W=32, n_ticks=30, drop_p=0.2, timeout_frac=1.0, hb_every=2, preset=True)
+        t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True, commit_extra=2)
 
 
 def test_rs_kernels_on_the_host(sim, oracle):
