@@ -528,6 +528,9 @@ class RspOracle:
         lib().orc_rsp_bcast_heartbeat(self.h, _p(flags), *[_p(o[k]) for k in ("ballot", "commit_bar", "exec_bar", "snap_bar")])
         return o
 
+    def is_leader(self):
+        return (self.dump()["leader"] == self.me).astype(np.uint8)
+
     def dump(self):
         G, R, W = self.G, self.R, self.W
         d = {n: np.zeros(G, t) for n, t in RSP_SCALARS}

@@ -1,0 +1,159 @@
+"""Lock-step schedule of an RSPaxos cluster out of R per-replica handler objects (RSPaxosReplicaGroup behind the
+numpy adapter below, or -- in tests -- the CPU oracle's objects with the same interface; with `spread.SpreadReplica`
+around them the replicas of a group live on different ranks and every handler's output is exchanged).  One tick:
+  1. HearTimeouts -> become_a_leader (step-up Heartbeat, Prepare, Reconstruct list)
+  2. the client batch of the tick at its target replica -> Accepts (one shard per peer)
+  3. step-up Heartbeats and the replies to them
+  4. Prepares -> PrepareReply batches -> the Accepts the quorum lets the new leader send
+  5. Reconstruct reads and their replies
+  6. Accepts -> AcceptReplies -> commits (commit bar run gated on shard availability, execution)
+  7. every `hb_every` ticks: the leaders' periodic Heartbeats (commit learning) and the replies
+Message order: senders ascending, receivers ascending.  `drop[(kind, s, q)]` (optional): bool [G], the message
+of that kind from s to q is lost in these groups."""
+import numpy as np
+
+NULL, NO_REP = 0xFFFFFFFF, 0xFF
+
+
+class NumpyEngine:
+    """RSPaxosReplicaGroup (device tensors) behind the RspOracle-style numpy interface"""
+
+    def __init__(self, eng, dev):
+        import torch
+        self.e, self.dev, self.torch = eng, dev, torch
+        self.G, self.R, self.W, self.me = eng.G, eng.R, eng.W, eng.me
+
+    def _t(self, a):
+        if a is None:
+            return None
+        v = a.view(np.int64) if a.dtype == np.uint64 else (a.view(np.int32) if a.dtype == np.uint32 else a)
+        return self.torch.from_numpy(np.ascontiguousarray(v)).to(self.dev)
+
+    @staticmethod
+    def _n(d):
+        conv = {"int64": np.uint64, "int32": np.uint32, "uint8": np.uint8}
+        return {k: v.cpu().numpy().view(conv[str(v.dtype).split(".")[-1]]) for k, v in d.items()}
+
+    def preset_leader(self, leader):
+        self.e.preset_leader(leader)
+
+    def __getattr__(self, name):
+        if name in ("req_batch", "accept", "accept_replies", "become_leader", "prepare", "prepare_replies", "reconstruct",
+                    "reconstruct_reply", "heartbeat", "bcast_heartbeat"):
+            fn = getattr(self.e, name)
+
+            def call(*a, **kw):
+                out = fn(*[self._t(x) for x in a], **{k: self._t(v) for k, v in kw.items()})
+                return None if out is None else self._n(out)
+            return call
+        raise AttributeError(name)
+
+    def dump(self):
+        return self.e.dump()
+
+    def is_leader(self):
+        return (self.e.dump()["leader"] == self.me).astype(np.uint8)
+
+
+def _lost(drop, kind, s, q, G):
+    if drop is None or (kind, s, q) not in drop:
+        return np.zeros(G, bool)
+    return drop[(kind, s, q)]
+
+
+def _deliver_heartbeat(reps, s, hb_flags, ballot, commit, exec_, snap, drop):
+    R, G = len(reps), len(hb_flags)
+    for q in range(R):
+        if q == s:
+            continue
+        fl = (hb_flags & ~_lost(drop, "hb", s, q, G)).astype(np.uint8)
+        if not fl.any():
+            continue
+        rp = reps[q].heartbeat(flags=fl, peer=np.full(G, s, np.uint8), ballot=ballot, commit_bar=commit, exec_bar=exec_,
+                               snap_bar=snap)
+        back = (rp["reply"].astype(bool) & ~_lost(drop, "hb", q, s, G)).astype(np.uint8)
+        if back.any():                                           # the follower's Heartbeat back to its leader: no reply to it
+            reps[s].heartbeat(flags=back, peer=np.full(G, q, np.uint8), ballot=rp["ballot"], commit_bar=rp["commit_bar"],
+                              exec_bar=rp["exec_bar"], snap_bar=rp["snap_bar"])
+
+
+def _deliver_accepts(reps, s, acc, drop, log):
+    """the Accepts replica s has to send (a list of up to W slots per group), one list entry at a time"""
+    R, G = len(reps), len(acc["a_n"])
+    for k in range(int(acc["a_n"].max()) if len(acc["a_n"]) else 0):
+        live = (acc["a_n"] > k)
+        slot, val = np.ascontiguousarray(acc["a_slot"][k]), np.ascontiguousarray(acc["a_val"][k])
+        ballot = np.zeros((R, G), np.uint64); flags = np.zeros((R, G), np.uint8)
+        for q in range(R):
+            if q == s:
+                continue
+            fl = (live & ~_lost(drop, "accept", s, q, G)).astype(np.uint8)
+            ar = reps[q].accept(flags=fl, peer=np.full(G, s, np.uint8), slot=slot, ballot=acc["a_ballot"], val=val,
+                                mask=np.full(G, 1 << q, np.uint8))
+            got = (ar["r_ballot"] != 0) & ~_lost(drop, "accept_reply", q, s, G)
+            flags[q] = got.astype(np.uint8); ballot[q] = ar["r_ballot"]
+        res = reps[s].accept_replies(slot=slot, ballot=ballot, flags=flags)
+        log.append(dict(kind="commit", s=s, slot=slot, val=val, committed=res["committed"] & live.astype(np.uint8)))
+
+
+def tick(reps, val, target, timeouts=None, drop=None, heartbeat=False):
+    """val[G]: the tick's client batch (NULL = none), target[G]: the replica it is sent to; timeouts[r][G]:
+    HearTimeout source seen by replica r (NO_REP = none).  Returns the tick's commit log."""
+    R, G = len(reps), len(val)
+    log = []
+    u8 = lambda v: np.full(G, v, np.uint8)
+    # 1. HearTimeouts
+    bl = [reps[r].become_leader(timeouts[r] if timeouts is not None else u8(NO_REP)) for r in range(R)]
+    # 2. client batches
+    acc = [reps[r].req_batch(np.where(target == r, val, NULL).astype(np.uint32)) for r in range(R)]
+    # 3. step-up heartbeats
+    for s in range(R):
+        if bl[s]["hb_flags"].any():
+            _deliver_heartbeat(reps, s, bl[s]["hb_flags"], bl[s]["hb_ballot"], bl[s]["hb_commit"], bl[s]["hb_exec"], bl[s]["hb_snap"], drop)
+    # 4. Prepare phase
+    late = []
+    for s in range(R):
+        if not bl[s]["p_flags"].any():
+            continue
+        for q in range(R):
+            if q == s:
+                continue
+            fl = (bl[s]["p_flags"] & ~_lost(drop, "prepare", s, q, G)).astype(np.uint8)
+            pr = reps[q].prepare(flags=fl, peer=u8(s), trig=bl[s]["p_trig"], ballot=bl[s]["p_ballot"])
+            n = np.where(_lost(drop, "prepare_reply", q, s, G), 0, pr["pr_n"]).astype(np.uint32)
+            if n.any():
+                log.append(dict(kind="prepare_reply", s=s, q=q, rows=int(n.sum()), voted=int((pr["pr_vbal"] > 0).sum())))
+                late.append((s, reps[s].prepare_replies(peer=u8(q), pr_n=n, pr_trig=pr["pr_trig"], pr_endp=pr["pr_endp"],
+                                                        pr_ballot=pr["pr_ballot"], pr_vbal=pr["pr_vbal"], pr_vval=pr["pr_vval"],
+                                                        pr_vmask=pr["pr_vmask"])))
+    # 5. reconstruction reads
+    for s in range(R):
+        if not bl[s]["rc_n"].any():
+            continue
+        for q in range(R):
+            if q == s:
+                continue
+            fl = ((bl[s]["rc_n"] > 0) & ~_lost(drop, "recon", s, q, G)).astype(np.uint8)
+            rr = reps[q].reconstruct(flags=fl, rc_n=bl[s]["rc_n"], rc_slot=bl[s]["rc_slot"])
+            fl2 = ((rr["rr_n"] > 0) & ~_lost(drop, "recon_reply", q, s, G)).astype(np.uint8)
+            if fl2.any():
+                log.append(dict(kind="recon_reply", s=s, q=q, rows=int(rr["rr_n"][fl2.astype(bool)].sum())))
+                reps[s].reconstruct_reply(flags=fl2, **rr)
+    # 6. Accept phase: the client batches, then what the Prepare quorum released
+    for s in range(R):
+        _deliver_accepts(reps, s, acc[s], drop, log)
+    for s, a in late:
+        if a["a_n"].any():
+            log.append(dict(kind="re_accept", s=s, n=int(a["a_n"].sum()), empty=int(((a["a_val"] == 0) & (np.arange(len(a["a_val"]))[:, None] < a["a_n"][None, :])).sum())))
+        _deliver_accepts(reps, s, a, drop, log)
+    # 7. periodic heartbeats of the replicas that lead
+    if heartbeat:
+        leaders = [reps[r].is_leader() if hasattr(reps[r], "is_leader") else (reps[r].dump()["leader"] == r).astype(np.uint8)
+                   for r in range(R)]
+        for s in range(R):
+            fl = leaders[s]
+            if not fl.any():
+                continue
+            hb = reps[s].bcast_heartbeat(fl)
+            _deliver_heartbeat(reps, s, fl, hb["ballot"], hb["commit_bar"], hb["exec_bar"], hb["snap_bar"], drop)
+    return log

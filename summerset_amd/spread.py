@@ -1,0 +1,99 @@
+"""Layout L2 for the per-replica engines: the replicas of a group live on DIFFERENT ranks (replica r
+on rank r mod world), so every message crosses ranks -- the exchange step the co-located layout L1 (shard.py) does
+not have.
+
+SPMD: every rank runs the same lock-step schedule (rsp_cluster.tick) over the same list of R replica objects and
+calls the same handlers in the same order.  `SpreadReplica` wraps one replica: on the rank that owns it the call
+runs the handler (the HIP engine, or in tests the oracle) and its outputs -- the messages some other replica
+consumes next -- are packed into ONE buffer and broadcast (RCCL over xGMI with the nccl backend, gloo on CPU); on
+the other ranks the call just receives that buffer.  After a call every rank holds the same message arrays, which
+is the property the quorum kernels need ("the same ack matrix visible at every rank").  One collective per handler
+call, sized by the message (a [W][G] list is one buffer, not W x G sends).  First version: a broadcast delivers to
+every rank what only the destination replica's rank needs; grouping a step's messages into one all-to-all is the
+next refinement.  Not measured yet (needs more than one GPU)."""
+import numpy as np
+
+_G, _WG = "G", "WG"
+_ACC = dict(a_n=("u4", _G), a_slot=("u4", _WG), a_val=("u4", _WG), a_ballot=("u8", _G))
+RSP_OUT = {
+    "req_batch": _ACC, "prepare_replies": _ACC,
+    "accept": dict(r_ballot=("u8", _G), r_slot=("u4", _G)),
+    "accept_replies": dict(committed=("u1", _G)),
+    "become_leader": dict(hb_flags=("u1", _G), hb_ballot=("u8", _G), hb_commit=("u4", _G), hb_exec=("u4", _G), hb_snap=("u4", _G),
+                          p_flags=("u1", _G), p_trig=("u4", _G), p_ballot=("u8", _G), rc_n=("u4", _G), rc_slot=("u4", _WG)),
+    "prepare": dict(pr_n=("u4", _G), pr_trig=("u4", _G), pr_endp=("u4", _G), pr_ballot=("u8", _G), pr_vbal=("u8", _WG),
+                    pr_vval=("u4", _WG), pr_vmask=("u1", _WG)),
+    "reconstruct": dict(rr_n=("u4", _G), rr_slot=("u4", _WG), rr_bal=("u8", _WG), rr_val=("u4", _WG), rr_mask=("u1", _WG)),
+    "reconstruct_reply": None,
+    "heartbeat": dict(reply=("u1", _G), ballot=("u8", _G), commit_bar=("u4", _G), exec_bar=("u4", _G), snap_bar=("u4", _G)),
+    "bcast_heartbeat": dict(ballot=("u8", _G), commit_bar=("u4", _G), exec_bar=("u4", _G), snap_bar=("u4", _G)),
+    "is_leader": dict(leader=("u1", _G)),
+}
+
+
+def owner_of(replica, world):
+    return replica % world
+
+
+class SpreadReplica:
+    """replica `rid` of every group, owned by rank owner_of(rid, world); `local` is the real object on that rank
+    (numpy interface of rsp_cluster), None elsewhere"""
+
+    def __init__(self, rid, local, G, W, rank, world, device="cpu"):
+        self.me, self.local, self.G, self.W, self.rank, self.world, self.device = rid, local, G, W, rank, world, device
+        self.owner = owner_of(rid, world)
+        assert (local is not None) == (self.owner == rank)
+        self.bytes_exchanged = 0
+
+    def _shape(self, kind):
+        return (self.G,) if kind == _G else (self.W, self.G)
+
+    def _exchange(self, spec, out):
+        """owner: pack `out` (dict of numpy arrays) and broadcast; others: receive and unpack"""
+        import torch
+        import torch.distributed as dist
+        sizes = [int(np.prod(self._shape(k))) * np.dtype(dt).itemsize for dt, k in spec.values()]
+        buf = np.zeros(sum(sizes), np.uint8)
+        if out is not None:
+            o = 0
+            for (name, (dt, kind)), n in zip(spec.items(), sizes):
+                a = np.ascontiguousarray(out[name], np.dtype(dt))
+                assert a.shape == self._shape(kind), (name, a.shape)
+                buf[o:o + n] = a.view(np.uint8).reshape(-1)
+                o += n
+        if self.world > 1:
+            t = torch.from_numpy(buf).to(self.device)
+            dist.broadcast(t, src=self.owner)
+            buf = t.cpu().numpy()
+            self.bytes_exchanged += buf.size
+        res, o = {}, 0
+        for (name, (dt, kind)), n in zip(spec.items(), sizes):
+            res[name] = buf[o:o + n].view(np.dtype(dt)).reshape(self._shape(kind)).copy()
+            o += n
+        return res
+
+    def __getattr__(self, name):
+        if name not in RSP_OUT:
+            raise AttributeError(name)
+        spec = RSP_OUT[name]
+
+        def call(*a, **kw):
+            out = None
+            if self.local is not None:
+                out = getattr(self.local, name)(*a, **kw)
+                if name == "is_leader":
+                    out = dict(leader=out)
+            if spec is None:
+                return None
+            res = self._exchange(spec, out)
+            return res["leader"] if name == "is_leader" else res
+        return call
+
+    def preset_leader(self, leader):
+        if self.local is not None:
+            self.local.preset_leader(leader)
+
+    def dump(self):
+        if self.local is None:
+            raise RuntimeError("replica %d lives on rank %d" % (self.me, self.owner))
+        return self.local.dump()
