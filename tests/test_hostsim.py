@@ -80,6 +80,10 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
                commit_extra=1)
         eng, _ = t._run("cpu", oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True)
         assert eng.counters(0)["rejects"] > 0
+        # bench.py's shape (S = 32, W = 512, no commit list: the tally's closed form; long outboxes after a leader change),
+        # with and without the straggler side launch
+        for sticks in (0, 4):
+            t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=sticks, every=4)
         # populations the device tests do not run (the 8-replica template instances of the tally and the reply kernels)
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
         t._run("cpu", oracle, G=100, R=4, S=3, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=3, preset=True)
