@@ -190,7 +190,8 @@ struct RspLane {
             v.s_vbal[i] = ballot; v.s_vval[i] = val; v.s_vmask[i] = (uint8_t)(mask & (1u << v.me));
             if (a_slot) { a_slot[(size_t)(n_acc & v.Wmask) * v.G + g] = s; a_val[(size_t)(n_acc & v.Wmask) * v.G + g] = val; }
             n_acc++;
-            accept_reply(v.me, s, ballot);                               // my own AcceptData completion (durability.rs:100-104)
+            accept_reply(v.me, s, v.s_bal[i]);                           // my own AcceptData completion carries inst.bal (durability.rs:100-104),
+                                                                         // which the quorum step does not raise to `ballot`
         }
     }
     // leadership.rs:236-340; true = my Heartbeat goes back to `peer`

@@ -116,4 +116,4 @@ def test_rspaxos_kernels_on_the_host(sim, oracle):
         t.test_closed_loop_cluster_matches_oracle("cpu", oracle, 70, 16, 1, 0.05)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 8, 0, 0)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 16, 2, 1)
-        t.test_random_handler_calls_match_oracle("cpu", oracle, 120, 32, 4, 2)
+        t.test_random_handler_calls_match_oracle("cpu", oracle, 500, 32, 4, 2)
