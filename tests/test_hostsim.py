@@ -117,3 +117,9 @@ def test_rspaxos_kernels_on_the_host(sim, oracle):
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 8, 0, 0)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 16, 2, 1)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 500, 32, 4, 2)
+
+
+def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
+    import test_zz_rsp_bytes_gpu as t
+    with sim.patched():
+        t.test_tokens_are_real_shard_bytes("cpu", oracle)
