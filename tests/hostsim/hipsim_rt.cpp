@@ -14,6 +14,7 @@
 // A meeting that leaves live lanes of the wavefront elsewhere (divergent use of a wave operation) is
 // counted in hipsim_partial_wave_ops().
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <sys/mman.h>
 
@@ -98,6 +99,8 @@ thread_local char *stacks;
 thread_local std::vector<char> dyn;
 thread_local bool in_fiber;
 unsigned long partial_ops;
+thread_local const char *host_lo, *host_hi;        // the launching thread's stack (kernel arguments are read from it)
+unsigned long long mem_bytes[2], mem_ops[2];     // [load, store]: kernel accesses outside the lanes' stacks
 
 // program-order ranks of the parking sites, made at build time from the debug info (tests/hostsim/__init__.py)
 std::vector<std::pair<uint64_t, uint64_t>> site_rank;
@@ -234,10 +237,13 @@ std::map<uintptr_t, size_t> blocks;               // hipMalloc'd blocks
 // when it is its instruction's turn -- the lanes of a wavefront advance through their memory accesses in
 // program order like the lock-step hardware, so "every lane reads X, then lane 0 overwrites X" keeps its
 // meaning even though the lanes are run one after the other.
-void before_access(const void *addr, size_t size, const void *site, const void *frame) {
+void before_access(const void *addr, size_t size, int is_store, const void *site, const void *frame) {
     if (!in_fiber) return;
     const char *lo = stacks + (size_t)cur * STACK;
     if ((const char *)addr >= lo && (const char *)addr < lo + STACK) return;
+    if ((const char *)addr < host_lo || (const char *)addr >= host_hi) {   // not the launcher's stack: kernel arguments live there
+        mem_bytes[is_store] += size; mem_ops[is_store]++;
+    }
     if (!poisoned.empty()) {                                      // [start, end) ranges, disjoint, by start
         const uintptr_t a = (uintptr_t)addr;
         if (poison_dirty) {
@@ -283,6 +289,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
         fprintf(stderr, "hipsim: unsupported launch shape\n");
         abort();
     }
+    if (!host_lo) {
+        pthread_attr_t at;
+        void *sa = nullptr; size_t sz = 0;
+        if (!pthread_getattr_np(pthread_self(), &at)) { pthread_attr_getstack(&at, &sa, &sz); pthread_attr_destroy(&at); }
+        host_lo = (const char *)sa; host_hi = host_lo + sz;
+    }
     if (!stacks) {
         if (site_rank.empty()) load_sites();
         stacks = (char *)mmap(nullptr, STACK * MAX_THREADS, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -301,16 +313,22 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &fn
 }  // namespace hipsim
 
 extern "C" unsigned long hipsim_partial_wave_ops(void) { return hipsim::partial_ops; }
+// bytes / accesses the kernels made to memory outside the lanes' stacks since the last reset: out[0..3] =
+// bytes loaded, bytes stored, loads, stores (an upper bound of a kernel's algorithmic traffic: no caches, no merging)
+extern "C" void hipsim_traffic(unsigned long long *out, int reset) {
+    out[0] = hipsim::mem_bytes[0]; out[1] = hipsim::mem_bytes[1]; out[2] = hipsim::mem_ops[0]; out[3] = hipsim::mem_ops[1];
+    if (reset) hipsim::mem_bytes[0] = hipsim::mem_bytes[1] = hipsim::mem_ops[0] = hipsim::mem_ops[1] = 0;
+}
 
 // the -fsanitize=thread hooks (no ThreadSanitizer runtime is linked; these are all there is)
-#define HIPSIM_HOOK(name, size)                                                                              \
+#define HIPSIM_HOOK(name, size, st)                                                                             \
     extern "C" __attribute__((noinline)) void name(void *a) {                                                \
-        hipsim::before_access(a, size, __builtin_return_address(0), __builtin_frame_address(1));             \
+        hipsim::before_access(a, size, st, __builtin_return_address(0), __builtin_frame_address(1));      \
     }
-HIPSIM_HOOK(__tsan_read1, 1) HIPSIM_HOOK(__tsan_read2, 2) HIPSIM_HOOK(__tsan_read4, 4) HIPSIM_HOOK(__tsan_read8, 8) HIPSIM_HOOK(__tsan_read16, 16)
-HIPSIM_HOOK(__tsan_write1, 1) HIPSIM_HOOK(__tsan_write2, 2) HIPSIM_HOOK(__tsan_write4, 4) HIPSIM_HOOK(__tsan_write8, 8) HIPSIM_HOOK(__tsan_write16, 16)
-HIPSIM_HOOK(__tsan_unaligned_read2, 2) HIPSIM_HOOK(__tsan_unaligned_read4, 4) HIPSIM_HOOK(__tsan_unaligned_read8, 8) HIPSIM_HOOK(__tsan_unaligned_read16, 16)
-HIPSIM_HOOK(__tsan_unaligned_write2, 2) HIPSIM_HOOK(__tsan_unaligned_write4, 4) HIPSIM_HOOK(__tsan_unaligned_write8, 8) HIPSIM_HOOK(__tsan_unaligned_write16, 16)
+HIPSIM_HOOK(__tsan_read1, 1, 0) HIPSIM_HOOK(__tsan_read2, 2, 0) HIPSIM_HOOK(__tsan_read4, 4, 0) HIPSIM_HOOK(__tsan_read8, 8, 0) HIPSIM_HOOK(__tsan_read16, 16, 0)
+HIPSIM_HOOK(__tsan_write1, 1, 1) HIPSIM_HOOK(__tsan_write2, 2, 1) HIPSIM_HOOK(__tsan_write4, 4, 1) HIPSIM_HOOK(__tsan_write8, 8, 1) HIPSIM_HOOK(__tsan_write16, 16, 1)
+HIPSIM_HOOK(__tsan_unaligned_read2, 2, 0) HIPSIM_HOOK(__tsan_unaligned_read4, 4, 0) HIPSIM_HOOK(__tsan_unaligned_read8, 8, 0) HIPSIM_HOOK(__tsan_unaligned_read16, 16, 0)
+HIPSIM_HOOK(__tsan_unaligned_write2, 2, 1) HIPSIM_HOOK(__tsan_unaligned_write4, 4, 1) HIPSIM_HOOK(__tsan_unaligned_write8, 8, 1) HIPSIM_HOOK(__tsan_unaligned_write16, 16, 1)
 extern "C" void __tsan_init(void) {}
 extern "C" void __tsan_func_entry(void *) {}
 extern "C" void __tsan_func_exit(void) {}
