@@ -592,6 +592,46 @@ typedef struct {
 int64_t smr_wire_raft_decode(const uint8_t *buf, uint64_t len, smr_wire_raft_msg *out, uint64_t *entry_term_out,
                              uint32_t max_entries);
 
+/* ---- RSPaxos wire + WAL (src/protocols/rspaxos/mod.rs:207-311) and RSCodeword's own Encode / Decode
+ * (src/utils/rscoding.rs:43-109): num_data_shards u8, num_parity_shards u8, data_len, shard_len,
+ * Vec<Option<Vec<u8>>> shards, Option<T> data_copy (None on the wire).  PeerMsg variants: Prepare 0, PrepareReply 1,
+ * Accept 2, AcceptReply 3 (SMR_WIRE_* above), Reconstruct 4, ReconstructReply 5, Heartbeat 6. */
+#define SMR_WIRE_RSP_RECONSTRUCT 4
+#define SMR_WIRE_RSP_RECONSTRUCT_REPLY 5
+#define SMR_WIRE_RSP_HEARTBEAT 6
+/* bincode(RSCodeword) of one codeword (no frame): shard k is read from shards + k * shard_stride if bit k of avail_mask */
+int64_t smr_wire_rscodeword(uint8_t d, uint8_t p, uint64_t data_len, uint64_t shard_len, uint32_t avail_mask, const uint8_t *shards,
+                            uint64_t shard_stride, uint8_t *out, uint64_t cap);
+int64_t smr_wire_rsp_prepare(uint64_t trigger_slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+/* cw = bytes from smr_wire_rscodeword */
+int64_t smr_wire_rsp_prepare_reply(uint64_t slot, uint64_t trigger_slot, uint64_t endprep_slot, uint64_t ballot, int has_voted,
+                                   uint64_t voted_ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap);
+int64_t smr_wire_rsp_accept(uint64_t slot, uint64_t ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap);
+int64_t smr_wire_rsp_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+int64_t smr_wire_rsp_reconstruct(uint32_t n, const uint64_t *slots, uint8_t *out, uint64_t cap);
+/* n entries of the slots_data map in the order given; codeword i = cws[cw_off[i] .. cw_off[i + 1]) */
+int64_t smr_wire_rsp_reconstruct_reply(uint32_t n, const uint64_t *slots, const uint64_t *ballots, const uint8_t *cws,
+                                       const uint64_t *cw_off, uint8_t *out, uint64_t cap);
+int64_t smr_wire_rsp_heartbeat(uint64_t ballot, uint64_t commit_bar, uint64_t exec_bar, uint64_t snap_bar, uint8_t *out, uint64_t cap);
+/* WalEntry::AcceptData { slot, ballot, reqs_cw }; PrepareBal / CommitSlot are smr_wal_prepare_bal / smr_wal_commit_slot */
+int64_t smr_wal_rsp_accept_data(uint64_t slot, uint64_t ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap);
+
+typedef struct {
+    uint8_t num_data_shards, num_parity_shards;
+    uint32_t avail_mask;            /* shards present */
+    uint64_t data_len, shard_len;
+    uint64_t shard_off[16];         /* where in the buffer shard k's bytes lie (present shards only) */
+} smr_wire_codeword;
+typedef struct {
+    uint8_t kind;                   /* SMR_WIRE_* / SMR_WIRE_RSP_* */
+    uint8_t has_voted;
+    uint32_t n_items;               /* codewords (Accept / voted: 1), Reconstruct slots, ReconstructReply entries */
+    uint64_t slot, ballot, trigger_slot, endprep_slot, voted_ballot, commit_bar, exec_bar, snap_bar;
+} smr_wire_rsp_msg;
+/* as smr_wire_decode; codewords go to cws[0 .. max_items), Reconstruct(Reply) slots / ballots to slots / ballots */
+int64_t smr_wire_rsp_decode(const uint8_t *buf, uint64_t len, smr_wire_rsp_msg *out, smr_wire_codeword *cws, uint64_t *slots,
+                            uint64_t *ballots, uint32_t max_items);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,17 @@ class WireMsg(C.Structure):
                 ("voted_ballot", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64)]
 
 
+class WireCodeword(C.Structure):
+    _fields_ = [("num_data_shards", C.c_uint8), ("num_parity_shards", C.c_uint8), ("avail_mask", C.c_uint32),
+                ("data_len", C.c_uint64), ("shard_len", C.c_uint64), ("shard_off", C.c_uint64 * 16)]
+
+
+class WireRspMsg(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("has_voted", C.c_uint8), ("n_items", C.c_uint32), ("slot", C.c_uint64),
+                ("ballot", C.c_uint64), ("trigger_slot", C.c_uint64), ("endprep_slot", C.c_uint64), ("voted_ballot", C.c_uint64),
+                ("commit_bar", C.c_uint64), ("exec_bar", C.c_uint64), ("snap_bar", C.c_uint64)]
+
+
 SYMBOLS = [
     ("smr_last_error", C.c_char_p, []),
     ("smr_device_count", _i, []),
@@ -205,6 +216,16 @@ SYMBOLS = [
     ("smr_wire_raft_request_vote_reply", C.c_int64, [_u64, _i, _vp, _u64]),
     ("smr_wal_raft_metadata", C.c_int64, [_u64, _u8, _vp, _u64]),
     ("smr_wire_raft_decode", C.c_int64, [_vp, _u64, C.POINTER(WireRaftMsg), _vp, C.c_uint32]),
+    ("smr_wire_rscodeword", C.c_int64, [_u8, _u8, _u64, _u64, _u32, _vp, _u64, _vp, _u64]),
+    ("smr_wire_rsp_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wire_rsp_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _vp, _u64]),
+    ("smr_wire_rsp_accept", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
+    ("smr_wire_rsp_accept_reply", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wire_rsp_reconstruct", C.c_int64, [_u32, _vp, _vp, _u64]),
+    ("smr_wire_rsp_reconstruct_reply", C.c_int64, [_u32, _vp, _vp, _vp, _vp, _vp, _u64]),
+    ("smr_wire_rsp_heartbeat", C.c_int64, [_u64, _u64, _u64, _u64, _vp, _u64]),
+    ("smr_wal_rsp_accept_data", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
+    ("smr_wire_rsp_decode", C.c_int64, [_vp, _u64, C.POINTER(WireRspMsg), _vp, _vp, _vp, _u32]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

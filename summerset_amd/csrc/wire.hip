@@ -318,4 +318,162 @@ int64_t smr_wire_raft_decode(const uint8_t *buf, uint64_t len, smr_wire_raft_msg
     return (int64_t)(8 + plen);
 }
 
+/* ---- RSPaxos -------------------------------------------------------------------------------- */
+// RSCodeword<ReqBatch> (src/utils/rscoding.rs:43-66): num_data_shards u8, num_parity_shards u8, data_len, shard_len,
+// shards as Vec<Option<Vec<u8>>>, data_copy: Option<T> (never sent along: subset_copy(.., false) drops it).
+// `shards` = the (d + p) x shard_len bytes of a codeword, shard k at k * shard_stride; only those in avail_mask are read.
+static void put_codeword(Wr &w, uint8_t d, uint8_t p, uint64_t data_len, uint64_t shard_len, uint32_t avail_mask,
+                         const uint8_t *shards, uint64_t shard_stride) {
+    w.byte(d); w.byte(p);                                                          // u8: a plain byte, not a varint
+    w.varint(data_len); w.varint(shard_len);
+    w.varint((uint64_t)d + p);
+    for (uint32_t k = 0; k < (uint32_t)d + p; k++) {
+        if ((avail_mask >> k) & 1u) { w.byte(1); w.bytes(shards + (uint64_t)k * shard_stride, shard_len); }
+        else w.byte(0);
+    }
+    w.byte(0);                                                                     // data_copy: None
+}
+static bool get_codeword(Rd &r, uint64_t base, smr_wire_codeword *c) {
+    memset(c, 0, sizeof(*c));
+    c->num_data_shards = r.byte(); c->num_parity_shards = r.byte();
+    c->data_len = r.varint(); c->shard_len = r.varint();
+    const uint64_t n = r.varint();
+    if (!r.ok || n != (uint64_t)c->num_data_shards + c->num_parity_shards || n > 16) { r.ok = false; return false; }
+    for (uint64_t k = 0; k < n && r.ok; k++) {
+        const uint8_t some = r.byte();
+        if (some > 1) { r.ok = false; break; }
+        if (!some) continue;
+        const uint64_t len = r.varint();
+        if (len != c->shard_len) { r.ok = false; break; }
+        c->avail_mask |= 1u << k;
+        c->shard_off[k] = base + r.n;
+        r.skip(len);
+    }
+    const uint8_t dc = r.byte();                                                   // data_copy
+    if (dc == 1) skip_reqbatch(r); else if (dc != 0) r.ok = false;
+    return r.ok;
+}
+
+int64_t smr_wire_rscodeword(uint8_t d, uint8_t p, uint64_t data_len, uint64_t shard_len, uint32_t avail_mask, const uint8_t *shards,
+                            uint64_t shard_stride, uint8_t *out, uint64_t cap) {
+    if (!out || (avail_mask && !shards) || (uint32_t)d + p > 16) return fail(SMR_ERR_ARG, "wire: bad argument");
+    Wr w{out, cap};
+    put_codeword(w, d, p, data_len, shard_len, avail_mask, shards, shard_stride);
+    if (!w.ok) return fail(SMR_ERR_ARG, "wire: output buffer too small");
+    return (int64_t)w.n;
+}
+
+// PeerMessage::Msg (variant 0) around rspaxos PeerMsg (mod.rs:247-311): Prepare 0, PrepareReply 1, Accept 2, AcceptReply 3,
+// Reconstruct 4, ReconstructReply 5, Heartbeat 6.  `cw` = bincode(RSCodeword) bytes from smr_wire_rscodeword.
+int64_t smr_wire_rsp_prepare(uint64_t trigger_slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
+    if (!out) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(0); w.varint(trigger_slot); w.varint(ballot);
+    return frame_done(w, out);
+}
+int64_t smr_wire_rsp_prepare_reply(uint64_t slot, uint64_t trigger_slot, uint64_t endprep_slot, uint64_t ballot, int has_voted,
+                                   uint64_t voted_ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap) {
+    if (!out || (has_voted && !cw)) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(1); w.varint(slot); w.varint(trigger_slot); w.varint(endprep_slot); w.varint(ballot);
+    w.byte(has_voted ? 1 : 0);
+    if (has_voted) { w.varint(voted_ballot); w.raw(cw, cw_len); }
+    return frame_done(w, out);
+}
+int64_t smr_wire_rsp_accept(uint64_t slot, uint64_t ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap) {
+    if (!out || !cw) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(2); w.varint(slot); w.varint(ballot); w.raw(cw, cw_len);
+    return frame_done(w, out);
+}
+int64_t smr_wire_rsp_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
+    if (!out) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(3); w.varint(slot); w.varint(ballot);
+    return frame_done(w, out);
+}
+int64_t smr_wire_rsp_reconstruct(uint32_t n, const uint64_t *slots, uint8_t *out, uint64_t cap) {
+    if (!out || (n && !slots)) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(4); w.varint(n);
+    for (uint32_t i = 0; i < n; i++) w.varint(slots[i]);
+    return frame_done(w, out);
+}
+// slots_data: HashMap<usize, (Ballot, RSCodeword)> = varint count, then (key, (ballot, codeword)) in the map's iteration
+// order -- here: the order given; codeword i = cws[cw_off[i] .. cw_off[i + 1])
+int64_t smr_wire_rsp_reconstruct_reply(uint32_t n, const uint64_t *slots, const uint64_t *ballots, const uint8_t *cws,
+                                       const uint64_t *cw_off, uint8_t *out, uint64_t cap) {
+    if (!out || (n && (!slots || !ballots || !cws || !cw_off))) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(5); w.varint(n);
+    for (uint32_t i = 0; i < n; i++) { w.varint(slots[i]); w.varint(ballots[i]); w.raw(cws + cw_off[i], cw_off[i + 1] - cw_off[i]); }
+    return frame_done(w, out);
+}
+int64_t smr_wire_rsp_heartbeat(uint64_t ballot, uint64_t commit_bar, uint64_t exec_bar, uint64_t snap_bar, uint8_t *out, uint64_t cap) {
+    if (!out) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(6); w.varint(ballot); w.varint(commit_bar); w.varint(exec_bar); w.varint(snap_bar);
+    return frame_done(w, out);
+}
+// rspaxos WalEntry (mod.rs:207-222): PrepareBal 0, AcceptData 1 { slot, ballot, reqs_cw }, CommitSlot 2
+int64_t smr_wal_rsp_accept_data(uint64_t slot, uint64_t ballot, const uint8_t *cw, uint64_t cw_len, uint8_t *out, uint64_t cap) {
+    if (!out || !cw) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(1); w.varint(slot); w.varint(ballot); w.raw(cw, cw_len);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_rsp_decode(const uint8_t *buf, uint64_t len, smr_wire_rsp_msg *m, smr_wire_codeword *cws, uint64_t *slots,
+                            uint64_t *ballots, uint32_t max_items) {
+    if (!buf || !m) return fail(SMR_ERR_ARG, "wire: null argument");
+    memset(m, 0, sizeof(*m));
+    if (len < 8) return 0;
+    uint64_t plen = 0;
+    for (int i = 0; i < 8; i++) plen = (plen << 8) | buf[i];
+    if (plen > 1000000000000ull) return fail(SMR_ERR_ARG, "wire: invalidly large frame");
+    if (len - 8 < plen) return 0;
+    Rd r{buf + 8, plen};
+    const uint64_t outer = r.varint();
+    if (outer == 2) { m->kind = SMR_WIRE_LEAVE; return (int64_t)(8 + plen); }
+    if (outer != 0) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }
+    const uint64_t v = r.varint();
+    m->kind = (uint8_t)(v <= SMR_WIRE_RSP_HEARTBEAT ? v : SMR_WIRE_OTHER);
+    smr_wire_codeword scratch;
+    switch (v) {
+        case SMR_WIRE_PREPARE: m->trigger_slot = r.varint(); m->ballot = r.varint(); break;
+        case SMR_WIRE_PREPARE_REPLY:
+            m->slot = r.varint(); m->trigger_slot = r.varint(); m->endprep_slot = r.varint(); m->ballot = r.varint();
+            m->has_voted = r.byte();
+            if (m->has_voted > 1) r.ok = false;
+            if (m->has_voted == 1) { m->voted_ballot = r.varint(); get_codeword(r, 8, (cws && max_items) ? &cws[0] : &scratch); m->n_items = 1; }
+            break;
+        case SMR_WIRE_ACCEPT:
+            m->slot = r.varint(); m->ballot = r.varint();
+            get_codeword(r, 8, (cws && max_items) ? &cws[0] : &scratch); m->n_items = 1;
+            break;
+        case SMR_WIRE_ACCEPT_REPLY: m->slot = r.varint(); m->ballot = r.varint(); break;
+        case SMR_WIRE_RSP_RECONSTRUCT: {
+            const uint64_t n = r.varint();
+            m->n_items = (uint32_t)n;
+            for (uint64_t i = 0; i < n && r.ok; i++) { const uint64_t s = r.varint(); if (slots && i < max_items) slots[i] = s; }
+            break;
+        }
+        case SMR_WIRE_RSP_RECONSTRUCT_REPLY: {
+            const uint64_t n = r.varint();
+            m->n_items = (uint32_t)n;
+            for (uint64_t i = 0; i < n && r.ok; i++) {
+                const uint64_t s = r.varint(), b = r.varint();
+                if (slots && i < max_items) slots[i] = s;
+                if (ballots && i < max_items) ballots[i] = b;
+                get_codeword(r, 8, (cws && i < max_items) ? &cws[i] : &scratch);
+            }
+            break;
+        }
+        case SMR_WIRE_RSP_HEARTBEAT: m->ballot = r.varint(); m->commit_bar = r.varint(); m->exec_bar = r.varint(); m->snap_bar = r.varint(); break;
+        default: return (int64_t)(8 + plen);
+    }
+    if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
+    return (int64_t)(8 + plen);
+}
+
 }  // extern "C"

@@ -4,7 +4,7 @@ smr_wire_* / smr_wal_* (include/summerset_hip.h).  Frames are bytes objects:
 import ctypes as C
 
 from . import _lib
-from ._lib import WireMsg, WireRaftMsg, check
+from ._lib import WireCodeword, WireMsg, WireRaftMsg, WireRspMsg, check
 
 PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, LEAVE, OTHER = 0, 1, 2, 3, 0xFE, 0xFF
 GET, PUT = 0, 1
@@ -125,3 +125,87 @@ def raft_decode(buf, max_entries=64):
     d = {k: getattr(m, k) for k, _ in WireRaftMsg._fields_}
     d["entry_terms"] = list(terms[:min(m.n_entries, max_entries)])
     return int(n), d
+
+
+# ---- RSPaxos (src/protocols/rspaxos/mod.rs:207-311) and RSCodeword (src/utils/rscoding.rs:43-109) ------------------
+RSP_RECONSTRUCT, RSP_RECONSTRUCT_REPLY, RSP_HEARTBEAT = 4, 5, 6
+
+
+def rscodeword(d, p, data_len, shards):
+    """bincode(RSCodeword): `shards` = list of d + p entries, bytes of equal length or None (shard absent)"""
+    assert len(shards) == d + p
+    have = [x for x in shards if x is not None]
+    sl = len(have[0]) if have else 0
+    assert all(len(x) == sl for x in have)
+    mask = sum(1 << k for k, x in enumerate(shards) if x is not None)
+    flat = b"".join(x if x is not None else bytes(sl) for x in shards)
+    return _call("smr_wire_rscodeword", d, p, data_len, sl, mask, flat, sl, cap=64 + len(flat) + 8 * (d + p))
+
+
+def rsp_prepare(trigger_slot, ballot):
+    return _call("smr_wire_rsp_prepare", trigger_slot, ballot)
+
+
+def rsp_prepare_reply(slot, trigger_slot, endprep_slot, ballot, voted=None):
+    vb, cw = voted if voted is not None else (0, b"")
+    return _call("smr_wire_rsp_prepare_reply", slot, trigger_slot, endprep_slot, ballot, int(voted is not None), vb, cw, len(cw),
+                 cap=96 + len(cw))
+
+
+def rsp_accept(slot, ballot, cw):
+    return _call("smr_wire_rsp_accept", slot, ballot, cw, len(cw), cap=64 + len(cw))
+
+
+def rsp_accept_reply(slot, ballot):
+    return _call("smr_wire_rsp_accept_reply", slot, ballot)
+
+
+def rsp_reconstruct(slots):
+    n = len(slots)
+    return _call("smr_wire_rsp_reconstruct", n, (C.c_uint64 * max(n, 1))(*slots), cap=64 + 9 * n)
+
+
+def rsp_reconstruct_reply(entries):
+    """entries: [(slot, ballot, codeword bytes), ...] in the order the map iterates"""
+    n = len(entries)
+    off = [0]
+    for e in entries:
+        off.append(off[-1] + len(e[2]))
+    return _call("smr_wire_rsp_reconstruct_reply", n, (C.c_uint64 * max(n, 1))(*[e[0] for e in entries]),
+                 (C.c_uint64 * max(n, 1))(*[e[1] for e in entries]), b"".join(e[2] for e in entries), (C.c_uint64 * (n + 1))(*off),
+                 cap=64 + off[-1] + 18 * n)
+
+
+def rsp_heartbeat(ballot, commit_bar, exec_bar, snap_bar):
+    return _call("smr_wire_rsp_heartbeat", ballot, commit_bar, exec_bar, snap_bar)
+
+
+def wal_rsp_accept_data(slot, ballot, cw):
+    return _call("smr_wal_rsp_accept_data", slot, ballot, cw, len(cw), cap=64 + len(cw))
+
+
+def rsp_decode(buf, max_items=16):
+    """first RSPaxos frame of `buf`: (bytes consumed, dict) -- (0, None) while incomplete; codewords come back as dicts
+    with the shard bytes sliced out of `buf`"""
+    m = WireRspMsg()
+    cws = (WireCodeword * max_items)()
+    slots, ballots = (C.c_uint64 * max_items)(), (C.c_uint64 * max_items)()
+    n = _lib.load().smr_wire_rsp_decode(bytes(buf), len(buf), C.byref(m), cws, slots, ballots, max_items)
+    if n < 0:
+        check(int(n))
+    if n == 0:
+        return 0, None
+    out = {f: getattr(m, f) for f, _ in WireRspMsg._fields_}
+
+    def cw(c):
+        k = c.num_data_shards + c.num_parity_shards
+        return dict(d=c.num_data_shards, p=c.num_parity_shards, data_len=c.data_len, shard_len=c.shard_len, avail=c.avail_mask,
+                    shards=[bytes(buf[c.shard_off[i]:c.shard_off[i] + c.shard_len]) if (c.avail_mask >> i) & 1 else None for i in range(k)])
+    k = min(m.n_items, max_items)
+    if m.kind in (ACCEPT, PREPARE_REPLY) and m.n_items:
+        out["codeword"] = cw(cws[0])
+    if m.kind == RSP_RECONSTRUCT:
+        out["slots"] = list(slots[:k])
+    if m.kind == RSP_RECONSTRUCT_REPLY:
+        out["entries"] = [(slots[i], ballots[i], cw(cws[i])) for i in range(k)]
+    return int(n), out

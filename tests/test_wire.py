@@ -101,3 +101,67 @@ def test_raft_frames(oracle):
     assert wire.raft_decode(ae[:-1]) == (0, None)
     with pytest.raises(SummersetError):
         wire.raft_decode(bytes([0, 0, 0, 0, 0, 0, 0, 2, 0, 9]))     # unknown PeerMsg variant
+
+
+# ---- RSPaxos frames and RSCodeword's own encoding ----------------------------------------------------------------------
+def test_rscodeword_bytes_by_hand(engine_lib):
+    from summerset_amd import wire
+    # rscoding.rs:43-66: d u8, p u8, data_len, shard_len, Vec<Option<Vec<u8>>> (len; 0 | 1 + len + bytes), data_copy None
+    cw = wire.rscodeword(3, 2, 4, [b"ab", None, b"cd", None, b"\xfe\xff"])
+    assert cw == bytes([3, 2, 4, 2, 5, 1, 2]) + b"ab" + bytes([0, 1, 2]) + b"cd" + bytes([0, 1, 2, 0xFE, 0xFF, 0])
+    # a null codeword (from_null): lengths 0, five absent shards
+    assert wire.rscodeword(3, 2, 0, [None] * 5) == bytes([3, 2, 0, 0, 5, 0, 0, 0, 0, 0, 0])
+    # lengths are varints: 251..65535 -> 0xFB + u16 LE (the two u8 fields stay single raw bytes)
+    big = wire.rscodeword(1, 1, 300, [bytes(300), None])
+    assert big[:9] == bytes([1, 1, 0xFB, 0x2C, 0x01, 0xFB, 0x2C, 0x01, 2]) and big[9:13] == bytes([1, 0xFB, 0x2C, 0x01]) and len(big) == 13 + 300 + 2
+
+
+def test_rspaxos_frames_by_hand_and_round_trip(engine_lib):
+    from summerset_amd import wire
+    cw = wire.rscodeword(3, 2, 4, [None, b"xy", None, None, None])
+    f = wire.rsp_accept(7, 0x102, cw)                            # PeerMessage::Msg (0) { PeerMsg::Accept (2) { slot, ballot, reqs_cw } }
+    assert f == (len(f) - 8).to_bytes(8, "big") + bytes([0, 2, 7, 0xFB, 0x02, 0x01]) + cw
+    n, m = wire.rsp_decode(f)
+    assert n == len(f) and (m["kind"], m["slot"], m["ballot"]) == (wire.ACCEPT, 7, 0x102)
+    assert m["codeword"] == dict(d=3, p=2, data_len=4, shard_len=2, avail=0b00010, shards=[None, b"xy", None, None, None])
+    # PrepareReply with and without a vote
+    f = wire.rsp_prepare_reply(5, 3, 9, 0x202, voted=(0x101, cw))
+    assert f[8:] == bytes([0, 1, 5, 3, 9, 0xFB, 0x02, 0x02, 1, 0xFB, 0x01, 0x01]) + cw
+    n, m = wire.rsp_decode(f)
+    assert (m["has_voted"], m["voted_ballot"], m["trigger_slot"], m["endprep_slot"], m["codeword"]["avail"]) == (1, 0x101, 3, 9, 2)
+    f = wire.rsp_prepare_reply(5, 3, 9, 0x202)
+    assert f[8:] == bytes([0, 1, 5, 3, 9, 0xFB, 0x02, 0x02, 0]) and wire.rsp_decode(f)[1]["has_voted"] == 0
+    # Reconstruct { slots: Vec<usize> } and its reply (HashMap<usize, (Ballot, RSCodeword)>)
+    f = wire.rsp_reconstruct([4, 300])
+    assert f[8:] == bytes([0, 4, 2, 4, 0xFB, 0x2C, 0x01]) and wire.rsp_decode(f)[1]["slots"] == [4, 300]
+    f = wire.rsp_reconstruct_reply([(4, 0x101, cw), (6, 0x101, wire.rscodeword(3, 2, 4, [b"pq", None, None, None, None]))])
+    n, m = wire.rsp_decode(f)
+    assert n == len(f) and [(s, b, c["avail"]) for s, b, c in m["entries"]] == [(4, 0x101, 2), (6, 0x101, 1)]
+    assert m["entries"][1][2]["shards"][0] == b"pq"
+    # Heartbeat (6), AcceptReply (3), Prepare (0)
+    f = wire.rsp_heartbeat(0x101, 12, 10, 0)
+    assert f[8:] == bytes([0, 6, 0xFB, 0x01, 0x01, 12, 10, 0])
+    assert {k: wire.rsp_decode(f)[1][k] for k in ("kind", "ballot", "commit_bar", "exec_bar", "snap_bar")} == \
+        dict(kind=6, ballot=0x101, commit_bar=12, exec_bar=10, snap_bar=0)
+    assert wire.rsp_accept_reply(7, 1)[8:] == bytes([0, 3, 7, 1]) and wire.rsp_prepare(2, 1)[8:] == bytes([0, 0, 2, 1])
+    # WalEntry::AcceptData (1) { slot, ballot, reqs_cw }: no PeerMessage wrapper in the log
+    assert wire.wal_rsp_accept_data(7, 1, cw)[8:] == bytes([1, 7, 1]) + cw
+    # incomplete / malformed
+    f = wire.rsp_accept(7, 1, cw)
+    assert wire.rsp_decode(f[:-1]) == (0, None)
+    bad = bytearray(f); bad[8 + 4 + 4] = 9                       # the shard count no longer matches d + p
+    with pytest.raises(Exception):
+        wire.rsp_decode(bytes(bad))
+
+
+def test_rspaxos_frames_carry_the_rs_kernels_shards(engine_lib, oracle):
+    """the bytes an Accept carries are a shard of the codeword the RS path produces (here: the oracle's encoder)"""
+    from summerset_amd import wire
+    data = bytes(range(1, 11))                                   # L = 10 -> shard_len 4, zero padded
+    par = oracle.rs_encode(3, 2, np.frombuffer(data, np.uint8))
+    padded = data + bytes(2)
+    shards = [padded[0:4], padded[4:8], padded[8:12], par[0].tobytes(), par[1].tobytes()]
+    for peer in range(5):
+        only = [s if k == peer else None for k, s in enumerate(shards)]
+        n, m = wire.rsp_decode(wire.rsp_accept(1, 0x101, wire.rscodeword(3, 2, len(data), only)))
+        assert m["codeword"]["avail"] == 1 << peer and m["codeword"]["shards"][peer] == shards[peer] and m["codeword"]["data_len"] == 10
