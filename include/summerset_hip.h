@@ -632,6 +632,27 @@ typedef struct {
 int64_t smr_wire_rsp_decode(const uint8_t *buf, uint64_t len, smr_wire_rsp_msg *out, smr_wire_codeword *cws, uint64_t *slots,
                             uint64_t *ballots, uint32_t max_items);
 
+/* ---- EPaxos wire + WAL (src/protocols/epaxos/mod.rs:124,199,254-377): SlotIdx(row u8, col), DepSet = Vec<Option<usize>>
+ * (deps[i] == SMR_EP_NONE: None).  kind = PeerMsg variant: */
+#define SMR_WIRE_EP_PRE_ACCEPT 0
+#define SMR_WIRE_EP_PRE_ACCEPT_REPLY 1
+#define SMR_WIRE_EP_ACCEPT 2
+#define SMR_WIRE_EP_ACCEPT_REPLY 3
+#define SMR_WIRE_EP_COMMIT_NOTICE 4
+/* seq / deps are ignored for AcceptReply; reqs = bincode(ReqBatch), read for PreAccept / Accept / CommitNotice only */
+int64_t smr_wire_ep_msg(uint8_t kind, uint8_t row, uint64_t col, uint64_t ballot, uint64_t seq, const uint32_t *deps, uint32_t n_deps,
+                        const uint8_t *reqs, uint64_t reqs_len, uint8_t *out, uint64_t cap);
+/* WalEntry::{PreAcceptSlot 0, AcceptSlot 1, CommitSlot 2} { slot, ballot, seq, deps, reqs } */
+int64_t smr_wal_ep_slot(uint8_t kind, uint8_t row, uint64_t col, uint64_t ballot, uint64_t seq, const uint32_t *deps, uint32_t n_deps,
+                        const uint8_t *reqs, uint64_t reqs_len, uint8_t *out, uint64_t cap);
+typedef struct {
+    uint8_t kind, row;              /* SMR_WIRE_EP_* (or SMR_WIRE_LEAVE / SMR_WIRE_OTHER); SlotIdx.0 */
+    uint32_t n_deps;
+    uint64_t col, ballot, seq;
+    uint64_t reqs_off, reqs_len;    /* where in the buffer the bincode(ReqBatch) bytes lie */
+} smr_wire_ep_msg_t;
+int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *out, uint32_t *deps_out, uint32_t max_deps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,11 @@ class WireCodeword(C.Structure):
                 ("data_len", C.c_uint64), ("shard_len", C.c_uint64), ("shard_off", C.c_uint64 * 16)]
 
 
+class WireEpMsg(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("row", C.c_uint8), ("n_deps", C.c_uint32), ("col", C.c_uint64), ("ballot", C.c_uint64),
+                ("seq", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64)]
+
+
 class WireRspMsg(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("has_voted", C.c_uint8), ("n_items", C.c_uint32), ("slot", C.c_uint64),
                 ("ballot", C.c_uint64), ("trigger_slot", C.c_uint64), ("endprep_slot", C.c_uint64), ("voted_ballot", C.c_uint64),
@@ -226,6 +231,9 @@ SYMBOLS = [
     ("smr_wire_rsp_heartbeat", C.c_int64, [_u64, _u64, _u64, _u64, _vp, _u64]),
     ("smr_wal_rsp_accept_data", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
     ("smr_wire_rsp_decode", C.c_int64, [_vp, _u64, C.POINTER(WireRspMsg), _vp, _vp, _vp, _u32]),
+    ("smr_wire_ep_msg", C.c_int64, [_u8, _u8, _u64, _u64, _u64, _vp, _u32, _vp, _u64, _vp, _u64]),
+    ("smr_wal_ep_slot", C.c_int64, [_u8, _u8, _u64, _u64, _u64, _vp, _u32, _vp, _u64, _vp, _u64]),
+    ("smr_wire_ep_decode", C.c_int64, [_vp, _u64, C.POINTER(WireEpMsg), _vp, _u32]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

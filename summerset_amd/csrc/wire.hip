@@ -476,4 +476,76 @@ int64_t smr_wire_rsp_decode(const uint8_t *buf, uint64_t len, smr_wire_rsp_msg *
     return (int64_t)(8 + plen);
 }
 
+/* ---- EPaxos --------------------------------------------------------------------------------- */
+// epaxos/mod.rs: SlotIdx(ReplicaId u8, usize) (:199), DepSet(Vec<Option<usize>>) (:124), SeqNum u64; PeerMsg (:306-377):
+// PreAccept 0 { slot, ballot, seq, deps, reqs }, PreAcceptReply 1 { slot, ballot, seq, deps }, Accept 2 (as PreAccept),
+// AcceptReply 3 { slot, ballot }, CommitNotice 4 (as PreAccept); WalEntry (:254-281): PreAcceptSlot 0, AcceptSlot 1,
+// CommitSlot 2, all { slot, ballot, seq, deps, reqs }.  deps[i] == SMR_EP_NONE: None.
+static void put_ep_body(Wr &w, uint8_t row, uint64_t col, uint64_t ballot, bool with_seq_deps, uint64_t seq, const uint32_t *deps,
+                        uint32_t n_deps, const uint8_t *reqs, uint64_t reqs_len) {
+    w.byte(row); w.varint(col); w.varint(ballot);
+    if (!with_seq_deps) return;
+    w.varint(seq);
+    w.varint(n_deps);
+    for (uint32_t i = 0; i < n_deps; i++) {
+        if (deps[i] == SMR_EP_NONE) w.byte(0);
+        else { w.byte(1); w.varint(deps[i]); }
+    }
+    if (reqs) w.raw(reqs, reqs_len);
+}
+
+int64_t smr_wire_ep_msg(uint8_t kind, uint8_t row, uint64_t col, uint64_t ballot, uint64_t seq, const uint32_t *deps, uint32_t n_deps,
+                        const uint8_t *reqs, uint64_t reqs_len, uint8_t *out, uint64_t cap) {
+    if (!out || kind > SMR_WIRE_EP_COMMIT_NOTICE) return fail(SMR_ERR_ARG, "wire: bad argument");
+    const bool body = kind != SMR_WIRE_EP_ACCEPT_REPLY, has_reqs = body && kind != SMR_WIRE_EP_PRE_ACCEPT_REPLY;
+    if ((body && n_deps && !deps) || (has_reqs && !reqs)) return fail(SMR_ERR_ARG, "wire: null argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(kind);
+    put_ep_body(w, row, col, ballot, body, seq, deps, n_deps, has_reqs ? reqs : nullptr, reqs_len);
+    return frame_done(w, out);
+}
+int64_t smr_wal_ep_slot(uint8_t kind, uint8_t row, uint64_t col, uint64_t ballot, uint64_t seq, const uint32_t *deps, uint32_t n_deps,
+                        const uint8_t *reqs, uint64_t reqs_len, uint8_t *out, uint64_t cap) {
+    if (!out || kind > 2 || !reqs || (n_deps && !deps)) return fail(SMR_ERR_ARG, "wire: bad argument");
+    Wr w = frame_begin(out, cap);
+    w.varint(kind);
+    put_ep_body(w, row, col, ballot, true, seq, deps, n_deps, reqs, reqs_len);
+    return frame_done(w, out);
+}
+int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *m, uint32_t *deps_out, uint32_t max_deps) {
+    if (!buf || !m) return fail(SMR_ERR_ARG, "wire: null argument");
+    memset(m, 0, sizeof(*m));
+    if (len < 8) return 0;
+    uint64_t plen = 0;
+    for (int i = 0; i < 8; i++) plen = (plen << 8) | buf[i];
+    if (plen > 1000000000000ull) return fail(SMR_ERR_ARG, "wire: invalidly large frame");
+    if (len - 8 < plen) return 0;
+    Rd r{buf + 8, plen};
+    const uint64_t outer = r.varint();
+    if (outer == 2) { m->kind = SMR_WIRE_LEAVE; return (int64_t)(8 + plen); }
+    if (outer != 0) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }
+    const uint64_t v = r.varint();
+    if (v > SMR_WIRE_EP_COMMIT_NOTICE) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }   // ExpPrepare & co, Heartbeat
+    m->kind = (uint8_t)v;
+    m->row = r.byte(); m->col = r.varint(); m->ballot = r.varint();
+    if (v != SMR_WIRE_EP_ACCEPT_REPLY) {
+        m->seq = r.varint();
+        const uint64_t n = r.varint();
+        if (n > 64) r.ok = false;
+        m->n_deps = (uint32_t)n;
+        for (uint64_t i = 0; i < n && r.ok; i++) {
+            const uint8_t some = r.byte();
+            uint32_t d = SMR_EP_NONE;
+            if (some == 1) d = (uint32_t)r.varint(); else if (some != 0) r.ok = false;
+            if (deps_out && i < max_deps) deps_out[i] = d;
+        }
+        if (v != SMR_WIRE_EP_PRE_ACCEPT_REPLY) {
+            m->reqs_off = 8 + r.n;
+            if (skip_reqbatch(r)) m->reqs_len = 8 + r.n - m->reqs_off;
+        }
+    }
+    if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
+    return (int64_t)(8 + plen);
+}
+
 }  // extern "C"

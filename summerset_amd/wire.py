@@ -4,7 +4,7 @@ smr_wire_* / smr_wal_* (include/summerset_hip.h).  Frames are bytes objects:
 import ctypes as C
 
 from . import _lib
-from ._lib import WireCodeword, WireMsg, WireRaftMsg, WireRspMsg, check
+from ._lib import WireCodeword, WireEpMsg, WireMsg, WireRaftMsg, WireRspMsg, check
 
 PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, LEAVE, OTHER = 0, 1, 2, 3, 0xFE, 0xFF
 GET, PUT = 0, 1
@@ -208,4 +208,40 @@ def rsp_decode(buf, max_items=16):
         out["slots"] = list(slots[:k])
     if m.kind == RSP_RECONSTRUCT_REPLY:
         out["entries"] = [(slots[i], ballots[i], cw(cws[i])) for i in range(k)]
+    return int(n), out
+
+
+# ---- EPaxos (src/protocols/epaxos/mod.rs:124,199,254-377) ------------------------------------------------------------
+EP_PRE_ACCEPT, EP_PRE_ACCEPT_REPLY, EP_ACCEPT, EP_ACCEPT_REPLY, EP_COMMIT_NOTICE = 0, 1, 2, 3, 4
+EP_NONE = 0xFFFFFFFF
+
+
+def _deps(deps):
+    d = [EP_NONE if x is None else x for x in (deps or [])]
+    return (C.c_uint32 * max(len(d), 1))(*d), len(d)
+
+
+def ep_msg(kind, row, col, ballot, seq=0, deps=None, reqs=None):
+    """one EPaxos PeerMsg frame; deps: list with None for Option::None; reqs: bincode(ReqBatch) bytes"""
+    d, n = _deps(deps)
+    r = reqs if reqs is not None else b""
+    return _call("smr_wire_ep_msg", kind, row, col, ballot, seq, d, n, r if reqs is not None else None, len(r), cap=96 + 10 * n + len(r))
+
+
+def wal_ep_slot(kind, row, col, ballot, seq, deps, reqs):
+    d, n = _deps(deps)
+    return _call("smr_wal_ep_slot", kind, row, col, ballot, seq, d, n, reqs, len(reqs), cap=96 + 10 * n + len(reqs))
+
+
+def ep_decode(buf, max_deps=8):
+    m = WireEpMsg()
+    deps = (C.c_uint32 * max_deps)()
+    n = _lib.load().smr_wire_ep_decode(bytes(buf), len(buf), C.byref(m), deps, max_deps)
+    if n < 0:
+        check(int(n))
+    if n == 0:
+        return 0, None
+    out = {f: getattr(m, f) for f, _ in WireEpMsg._fields_}
+    out["deps"] = [None if deps[i] == EP_NONE else deps[i] for i in range(min(m.n_deps, max_deps))]
+    out["reqs"] = bytes(buf[m.reqs_off:m.reqs_off + m.reqs_len])
     return int(n), out

@@ -165,3 +165,33 @@ def test_rspaxos_frames_carry_the_rs_kernels_shards(engine_lib, oracle):
         only = [s if k == peer else None for k, s in enumerate(shards)]
         n, m = wire.rsp_decode(wire.rsp_accept(1, 0x101, wire.rscodeword(3, 2, len(data), only)))
         assert m["codeword"]["avail"] == 1 << peer and m["codeword"]["shards"][peer] == shards[peer] and m["codeword"]["data_len"] == 10
+
+
+# ---- EPaxos frames -------------------------------------------------------------------------------------------------------
+def test_epaxos_frames_by_hand_and_round_trip(engine_lib):
+    from summerset_amd import wire
+    reqs = wire.reqbatch([(7, 3, ("put", "k1", "v"))])
+    # PeerMessage::Msg (0) { PeerMsg::PreAccept (0) { slot: SlotIdx(2, 300), ballot 3, seq 5, deps [None, Some(4), Some(299), None, None], reqs } }
+    f = wire.ep_msg(wire.EP_PRE_ACCEPT, 2, 300, 3, seq=5, deps=[None, 4, 299, None, None], reqs=reqs)
+    body = bytes([0, 0, 2, 0xFB, 0x2C, 0x01, 3, 5, 5, 0, 1, 4, 1, 0xFB, 0x2B, 0x01, 0, 0]) + reqs
+    assert f == len(body).to_bytes(8, "big") + body
+    n, m = wire.ep_decode(f)
+    assert n == len(f) and (m["kind"], m["row"], m["col"], m["ballot"], m["seq"]) == (0, 2, 300, 3, 5)
+    assert m["deps"] == [None, 4, 299, None, None] and m["reqs"] == reqs
+    # PreAcceptReply (1): no reqs; AcceptReply (3): slot and ballot only
+    f = wire.ep_msg(wire.EP_PRE_ACCEPT_REPLY, 1, 9, 2, seq=6, deps=[0, None, None])
+    assert f[8:] == bytes([0, 1, 1, 9, 2, 6, 3, 1, 0, 0, 0]) and wire.ep_decode(f)[1]["deps"] == [0, None, None]
+    f = wire.ep_msg(wire.EP_ACCEPT_REPLY, 4, 1, 5)
+    assert f[8:] == bytes([0, 3, 4, 1, 5]) and wire.ep_decode(f)[1]["kind"] == 3
+    for kind in (wire.EP_ACCEPT, wire.EP_COMMIT_NOTICE):
+        f = wire.ep_msg(kind, 0, 1, 1, seq=2, deps=[None] * 5, reqs=reqs)
+        assert f[8:10] == bytes([0, kind]) and wire.ep_decode(f)[1]["reqs"] == reqs
+    # WalEntry::CommitSlot (2): no PeerMessage wrapper
+    f = wire.wal_ep_slot(2, 3, 7, 4, 9, [None, None, 1], reqs)
+    assert f[8:] == bytes([2, 3, 7, 4, 9, 3, 0, 0, 1, 1]) + reqs
+    # other variants (ExpPrepare 5 ...) are skipped, incomplete frames wait, malformed ones raise
+    assert wire.ep_decode((2).to_bytes(8, "big") + bytes([0, 5]))[1]["kind"] == wire.OTHER
+    f = wire.ep_msg(wire.EP_ACCEPT_REPLY, 4, 1, 5)
+    assert wire.ep_decode(f[:-2]) == (0, None)
+    with pytest.raises(Exception):
+        wire.ep_decode((6).to_bytes(8, "big") + bytes([0, 3, 4, 1, 5, 9]))      # a trailing byte
