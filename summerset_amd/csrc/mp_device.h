@@ -157,11 +157,31 @@ struct Lane {
         ob_load(p);
         if (p == 0) obn0 = n; else obn1 = n;
     }
+    // The outbox of parity p stops being a pure steady-state append run (ob_reg != 0: entry j is the Accept for slot
+    // ob_reg - 1 + j at ballot ob_rbal).  Experiment -DSMR_SKIP_REG_OUTBOX (tools/experiments/README.md): such a run does
+    // not store ob_slot / ob_bal at all -- 12 of the 32 bytes mp_round_local writes per new slot -- and readers derive
+    // them; whoever ends the run writes the `c` entries out first.
+    __device__ __forceinline__ void ob_end_run(int p, uint32_t c) {
+#ifdef SMR_SKIP_REG_OUTBOX
+        const uint32_t reg = v.ob_reg(p)[g];
+        if (reg != 0) {
+            const uint64_t rb = v.ob_rbal(p)[g];
+            for (uint32_t j = cl; j < c && j < P.cap; j += cn) {  // uniform mode: every lane its share
+                const size_t oj = tix(P.cap, j, g);
+                v.ob_slot(p)[oj] = (OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j) & OB_SLOT_MASK);
+                v.ob_bal(p)[oj] = rb;
+            }
+        }
+#else
+        (void)c;
+#endif
+        if (wr) v.ob_reg(p)[g] = 0;
+    }
     // transport_hub.bcast_msg(): append to my outbox of parity p
     __device__ __forceinline__ void ob_push(int p, uint32_t kind, uint32_t slot, uint64_t bal, uint32_t val, uint32_t aux) {
         ob_load(p);
         uint32_t c = p == 0 ? obn0 : obn1;
-        if (wr) v.ob_reg(p)[g] = 0;                             // no longer (only) a steady-state append run
+        ob_end_run(p, c);                                       // no longer (only) a steady-state append run
         if (c >= P.cap) { ovf = true; return; }
         size_t o = tix(P.cap, c, g);
         if (wr) v.ob_slot(p)[o] = (kind << OB_KIND_SH) | (slot & OB_SLOT_MASK);
@@ -436,7 +456,7 @@ struct Lane {
             // order (ballot + prefix count), the accept_bar scan runs on the bitmaps.
             ob_load(par ^ 1);
             uint32_t c = (par ^ 1) == 0 ? obn0 : obn1;
-            if (wr) v.ob_reg(par ^ 1)[g] = 0;
+            ob_end_run(par ^ 1, c);
             int chase = 0;
             for (uint32_t base = trig; base < len; base += 64) {
                 const uint32_t sl = base + cl;

@@ -155,7 +155,12 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                         const size_t i = tix(P.W, slot & Wm, g);
                         const size_t o = tix(P.cap, c0 + k + q, g);
                         sb[i] = bal; sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
+#ifdef SMR_SKIP_REG_OUTBOX
+                        if (c0 != 0) { os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; }   // else: follow from ob_reg / ob_rbal
+                        ov[o] = tok[q];
+#else
                         os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; ov[o] = tok[q];
+#endif
                     }
                 }
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
@@ -209,6 +214,16 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         const MpRep &snd = P.rep[s];
         const uint32_t cnt = snd.ob_cnt[par][g];
         uint32_t jstart = (s == first_sender ? first_j : 0u);
+#ifdef SMR_SKIP_REG_OUTBOX
+        // a pure append run stores no ob_slot / ob_bal: entry j = Accept for slot ob_reg - 1 + j at ob_rbal
+        const uint32_t sreg = snd.ob_reg[par][g];
+        const uint64_t srbal = sreg ? snd.ob_rbal[par][g] : 0ull;
+#define SND_SLOT(j, o) (sreg ? ((OB_ACCEPT << OB_KIND_SH) | ((sreg - 1 + (j)) & OB_SLOT_MASK)) : snd.ob_slot[par][o])
+#define SND_BAL(o) (sreg ? srbal : snd.ob_bal[par][o])
+#else
+#define SND_SLOT(j, o) snd.ob_slot[par][o]
+#define SND_BAL(o) snd.ob_bal[par][o]
+#endif
         // Uniform mode, first choice: the whole rest of this outbox (<= 512 messages) is ONE run of
         // Accepts at one ballot >= bal_max_seen for consecutive slots that start inside or right at
         // the end of my log (the re-Accept round of a new leader followed by its new batches).  Each
@@ -223,7 +238,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 const uint32_t t = L.cl + 64u * u;
                 const bool in = t < n;
                 const size_t o = tix(P.cap, jstart + (in ? t : 0), g);
-                e[u] = in ? snd.ob_slot[par][o] : 0u; bl[u] = in ? snd.ob_bal[par][o] : 0ull;
+                e[u] = in ? SND_SLOT(jstart + t, o) : 0u; bl[u] = in ? SND_BAL(o) : 0ull;
                 tok[u] = in ? snd.ob_val[par][o] : 0u;
             }
             const uint32_t slot0 = __shfl(e[0], 0) & OB_SLOT_MASK;
@@ -284,8 +299,8 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             const uint32_t j = jstart + L.cl;
             const bool in = j < cnt;
             const size_t o = tix(P.cap, j, g);
-            const uint32_t e = in ? snd.ob_slot[par][o] : 0u;
-            const uint64_t bl = in ? snd.ob_bal[par][o] : 0ull;
+            const uint32_t e = in ? SND_SLOT(j, o) : 0u;
+            const uint64_t bl = in ? SND_BAL(o) : 0ull;
             const uint32_t tok = in ? snd.ob_val[par][o] : 0u;   // fetched with the header: one round of loads
             const uint32_t slot = e & OB_SLOT_MASK;
             const uint32_t slot0 = __shfl(slot, 0);
@@ -333,8 +348,8 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             for (int k = 0; k < 8; k++) {
                 bool in = j0 + k < cnt;
                 size_t o = tix(P.cap, j0 + k, g);
-                e[k] = in ? snd.ob_slot[par][o] : 0u;
-                bal[k] = in ? snd.ob_bal[par][o] : 0ull;
+                e[k] = in ? SND_SLOT(j0 + k, o) : 0u;
+                bal[k] = in ? SND_BAL(o) : 0ull;
                 val[k] = in ? snd.ob_val[par][o] : 0u;
             }
 #pragma unroll
@@ -418,7 +433,13 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                     for (int k = 0; k < 8; k++) {
                         const bool in = j0 + k < cnt;
                         const size_t o = tix(P.cap, j0 + k, g);
+#ifdef SMR_SKIP_REG_OUTBOX
+                        e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
+                        bal[k] = !in ? 0ull : (reg ? snd.ob_rbal(par)[g] : obl[o]);
+                        val[k] = in ? ov[o] : 0u;
+#else
                         e[k] = in ? os[o] : 0u; bal[k] = in ? obl[o] : 0ull; val[k] = in ? ov[o] : 0u;
+#endif
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -550,8 +571,14 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint32_t j = j0 + L.cl;
             const bool in = j < cnt;
             const size_t o = tix(P.cap, j, g);
+#ifdef SMR_SKIP_REG_OUTBOX
+            const uint32_t creg = v.ob_reg(par)[g];
+            const uint32_t e = !in ? 0u : (creg ? ((OB_ACCEPT << OB_KIND_SH) | ((creg - 1 + j) & OB_SLOT_MASK)) : os[o]);
+            const uint64_t eb = !in ? 0ull : (creg ? v.ob_rbal(par)[g] : obl[o]);
+#else
             const uint32_t e = in ? os[o] : 0u;
             const uint64_t eb = in ? obl[o] : 0ull;
+#endif
             const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
             const uint64_t a = in ? ackw[o] : 0ull;
             const uint32_t slot = e & OB_SLOT_MASK;

@@ -31,7 +31,20 @@ _KERN = ["-DSMR_ARENA_GUARD=4096", "-mllvm", "-disable-block-placement", "-fsani
          "-tsan-instrument-func-entry-exit=0", "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-instrument-memintrinsics=0"]
 
 
-def build():
+def build(defines=()):
+    """`defines`: extra -D flags for the kernel sources (a kernel experiment, tools/experiments/README.md): own library"""
+    global LIB
+    if defines:
+        saved = LIB
+        LIB = os.path.join(_OUT, "libsummerset_sim_%s.so" % "_".join(d.replace("=", "-") for d in defines))
+        try:
+            return _build(tuple("-D" + d for d in defines))
+        finally:
+            LIB = saved
+    return _build(())
+
+
+def _build(extra):
     os.makedirs(_OUT, exist_ok=True)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     rt = os.path.join(_HERE, "hipsim_rt.cpp")
@@ -42,8 +55,8 @@ def build():
     base, kern = _BASE, _KERN
     objs = []
     for s in srcs:
-        o = os.path.join(_OUT, os.path.basename(s) + ".o")
-        subprocess.run(base + kern + ["-c", "-x", "c++", s, "-o", o], check=True)
+        o = os.path.join(_OUT, os.path.basename(LIB) + "." + os.path.basename(s) + ".o")
+        subprocess.run(base + kern + list(extra) + ["-c", "-x", "c++", s, "-o", o], check=True)
         objs.append(o)
     o = os.path.join(_OUT, "hipsim_rt.o")
     subprocess.run(base + ["-c", rt, "-o", o], check=True)
@@ -110,9 +123,9 @@ def _rank_sites(lib, out):
             f.write(struct.pack("<QQ", a, rank[k]))
 
 
-def load():
+def load(defines=()):
     from summerset_amd import _lib
-    lib = C.CDLL(build())
+    lib = C.CDLL(build(defines))
     for name, res, args in _lib.SYMBOLS:
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -120,10 +133,10 @@ def load():
 
 
 @contextlib.contextmanager
-def patched():
+def patched(defines=()):
     """the package talks to the simulated library; streams are the null stream"""
     from summerset_amd import _lib, epaxos, multipaxos, raft, rscoding, rspaxos
-    sim = load()
+    sim = load(defines)
     null = staticmethod(lambda stream: 0)
     spots = [(_lib, "_lib", sim), (epaxos.EPaxosReplicaGroup, "_stream", null), (raft.RaftLeaderGroup, "_stream", null), (rspaxos.RSPaxosReplicaGroup, "_stream", null),
              (multipaxos.MultiPaxosCluster, "_stream", null), (rscoding, "_stream_ptr", lambda stream: 0)]
