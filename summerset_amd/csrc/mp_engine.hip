@@ -203,6 +203,18 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
 }
 
 // ---- R2 ---------------------------------------------------------------------
+#ifdef SMR_ACK_BITS
+#define ACK_STORE(arr, j, val) do { if ((j) >= 64u) (arr)[ack_ix(P.cap, (j), r, g)] = (val); } while (0)
+template <int NR>
+__device__ __forceinline__ uint64_t ack_word_from_bits(const uint64_t (&ab)[NR], uint32_t j) {   // j < 64
+    uint64_t a = 0;
+#pragma unroll
+    for (int q = 0; q < NR; q++) a |= ((ab[q] >> j) & 1ull) << (8 * q);
+    return a;
+}
+#else
+#define ACK_STORE(arr, j, val) (arr)[ack_ix(P.cap, (j), r, g)] = (val)
+#endif
 // every outbox but mine, sender-major, FIFO; `first_sender` / `first_j`: resume point
 // left by the fast path
 __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint32_t first_j) {
@@ -223,6 +235,10 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 #else
 #define SND_SLOT(j, o) snd.ob_slot[par][o]
 #define SND_BAL(o) snd.ob_bal[par][o]
+#endif
+#ifdef SMR_ACK_BITS
+        uint64_t abits = 0;                                      // my answers to this sender's entries < 64 (uniform in a job)
+        const uint32_t ab_first = jstart;
 #endif
         // Uniform mode, first choice: the whole rest of this outbox (<= 512 messages) is ONE run of
         // Accepts at one ballot >= bal_max_seen for consecutive slots that start inside or right at
@@ -276,8 +292,11 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                         m = m_set_vmode(m, VM_SAME);                         // :351
                         m = tok[u] ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                         v.s_bal()[i] = bal0; v.s_val()[i] = tok[u]; v.s_meta()[i] = m;
-                        snd.ack[ack_ix(P.cap, jstart + t, r, g)] = 1;   // durability.rs:108-131
+                        ACK_STORE(snd.ack, jstart + t, 1);   // durability.rs:108-131
                     }
+#ifdef SMR_ACK_BITS
+                    abits |= ack_range_bits(jstart, jstart + n);
+#endif
                     if (n_new) {
                         if (L.nlb == len0) L.nlb = len0 + n_new;  // still no Null below the log end
                         L.len = len0 + n_new;
@@ -325,8 +344,11 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 m = m_set_vmode(m, VM_SAME);                     // :351
                 m = val ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
                 v.s_bal()[i] = bal0; v.s_val()[i] = val; v.s_meta()[i] = m;
-                snd.ack[ack_ix(P.cap, j, r, g)] = 1; // durability.rs:108-131
+                ACK_STORE(snd.ack, j, 1); // durability.rs:108-131
             }
+#ifdef SMR_ACK_BITS
+            abits |= ack_range_bits(jstart, jstart + nin);
+#endif
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
             // slot of the run is Accepting now, beyond it the scan reads memory
             if (appending) {
@@ -359,7 +381,10 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 const uint32_t kind = e[k] >> OB_KIND_SH, slot = e[k] & OB_SLOT_MASK;
                 if (kind == OB_ACCEPT) {
                     uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
-                    if (L.wr) snd.ack[ack_ix(P.cap, j, r, g)] = rep ? 1 : 0;   // rep == bal[k] or none
+                    if (L.wr) ACK_STORE(snd.ack, j, rep ? 1 : 0);   // rep == bal[k] or none
+#ifdef SMR_ACK_BITS
+                    if (rep && j < 64u) abits |= 1ull << j;
+#endif
                 } else if (kind == OB_PREPARE) {
                     L.msg_prepare(s, slot, bal[k]);
                 } else if (kind == OB_HEARTBEAT) {
@@ -367,6 +392,12 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 }
             }
         }
+#ifdef SMR_ACK_BITS
+        if (cnt != 0 && L.wr) {                                  // one word for this sender: the tick's first writer stores, a resumed one adds
+            SMR_G uint64_t *const w = &ack_bits_base(snd.ack, P.cap, P.G)[tix(MAXR, r, g)];
+            *w = ab_first == 0 ? abits : (*w | abits);
+        }
+#endif
     }
 }
 
@@ -420,7 +451,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                             if (j0 + k >= cnt) break;
                             const size_t i = tix(W, (len + j0 + k) & Wm, g);
                             sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
-                            ack[ack_ix(P.cap, j0 + k, r, g)] = 1;
+                            ACK_STORE(ack, j0 + k, 1);
                         }
                     }
                     len += cnt;
@@ -450,13 +481,16 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         }
                         const size_t i = tix(W, len & Wm, g);
                         sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
-                        ack[ack_ix(P.cap, j0 + k, r, g)] = 1;
+                        ACK_STORE(ack, j0 + k, 1);
                         len++;
                         fast_done++;
                     }
                 }
                 if (L.nlb == L.len) L.nlb = len;                 // still no Null below the log end
                 L.len = len; L.abar = len;
+#ifdef SMR_ACK_BITS
+                if (fast_done) ack_bits_base(ack, P.cap, P.G)[tix(MAXR, r, g)] = ack_range_bits(0, fast_done);   // all of them accepted
+#endif
             }
         }
         // whatever is left goes to the wave as a cooperative job
@@ -557,6 +591,11 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     constexpr int C = 8;                                         // ack-matrix rows per batch of loads
     SMR_G const uint32_t *const os = v.ob_slot(par);
     SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)v.ack();   // one word per (entry, group), byte q = replica q
+#ifdef SMR_ACK_BITS
+    uint64_t ab[NR];                                             // entries < 64: one word per follower instead
+#pragma unroll
+    for (int q = 0; q < NR; q++) ab[q] = (uint32_t)q < P.R ? ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, q, g)] : 0ull;
+#endif
     SMR_G const uint64_t *const obl = v.ob_bal(par);
     SMR_G uint32_t *const sm = v.s_meta(); SMR_G const uint64_t *const sb = v.s_bal();
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
@@ -580,7 +619,11 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint64_t eb = in ? obl[o] : 0ull;
 #endif
             const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
+#ifdef SMR_ACK_BITS
+            const uint64_t a = !in ? 0ull : (j < 64u ? ack_word_from_bits<NR>(ab, j) : ackw[o]);
+#else
             const uint64_t a = in ? ackw[o] : 0ull;
+#endif
             const uint32_t slot = e & OB_SLOT_MASK;
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
             const size_t i = tix(P.W, slot & Wm, g);
@@ -650,7 +693,11 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
             eb[k] = !in ? 0ull : (reg ? rbal : obl[o]);
             ctl[k] = (in && ackctl) ? ackctl[(size_t)(j0 + k) * G + g] : SMR_CTL_IDENTITY;
+#ifdef SMR_ACK_BITS
+            a[k] = !in ? 0ull : (j0 + k < 64u ? ack_word_from_bits<NR>(ab, j0 + k) : ackw[o]);
+#else
             a[k] = in ? ackw[o] : 0ull;
+#endif
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 2: the slots those Accepts name
@@ -769,6 +816,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
     SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
     SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)rep_shift(v0.ack, ro);
+#ifdef SMR_ACK_BITS
+    uint64_t ab[NR];                                             // my replica's followers, entries < 64 (cand: cnt <= 64)
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+        ab[q] = (cand && (uint32_t)q < R) ? ack_bits_base(rep_shift(v0.ack, ro), P.cap, P.G)[tix(MAXR, q, gg)] : 0ull;
+#endif
     SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
     const uint32_t q4 = (cnt + 3) / 4;
     const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
@@ -790,7 +843,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             const uint32_t j = j0 + k;
             const bool in = cand && j < jhi;
             ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
+#ifdef SMR_ACK_BITS
+            a[k] = in ? ack_word_from_bits<NR>(ab, j) : 0ull;
+            (void)ackw;
+#else
             a[k] = in ? ackw[tix(P.cap, j, g)] : 0ull;
+#endif
         }
     };
     load_acks(jlo);
@@ -1107,7 +1165,11 @@ static void layout(smr_mp_cluster *c, bool dry) {
             carve(a, v.ob_val[p], cap * Gp, dry); carve(a, v.ob_aux[p], cap * Gp, dry);
             carve(a, v.ob_reg[p], G, dry); carve(a, v.ob_rbal[p], G, dry);
         }
+#ifdef SMR_ACK_BITS
+        carve(a, v.ack, cap * Gp * 8 + (size_t)MAXR * Gp * 8, dry);   // + one word per (follower, group): ack_bits_base()
+#else
         carve(a, v.ack, cap * Gp * 8, dry);          // one 8-byte word per (entry, group)
+#endif
         carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);
         carve(a, v.pr_trig, G, dry); carve(a, v.pr_endp, G, dry); carve(a, v.pr_abar, G, dry);
         carve(a, v.pr_bal, G, dry);

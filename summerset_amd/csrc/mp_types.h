@@ -74,6 +74,28 @@ inline size_t tix(uint32_t rows, uint32_t row, uint32_t g);
 __host__ __device__
 #endif
 inline size_t ack_ix(uint32_t cap, uint32_t j, uint32_t r, uint32_t g) { return tix(cap, j, g) * 8 + r; }
+#ifdef SMR_ACK_BITS
+// Experiment (tools/experiments/README.md): the answers to the first 64 entries of an outbox as ONE word per
+// (follower q, group) -- bit j = follower q accepted entry j -- behind the ack words of the same replica:
+// word index tix(SMR_MAX_REPLICAS, q, g).  A follower stores one word per group instead of a byte per entry; the
+// leader loads R words per group instead of one word per row.  Entries >= 64 (the long outbox of a re-Accept
+// round) keep their byte cells.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline SMR_G uint64_t *ack_bits_base(SMR_G uint8_t *ack, uint32_t cap, uint32_t G) {
+    return (SMR_G uint64_t *)(ack + (size_t)cap * (((size_t)G + 63) / 64 * 64) * 8);
+}
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t ack_range_bits(uint32_t lo, uint32_t hi) {       // bits [lo, hi) clipped to [0, 64)
+    if (hi > 64u) hi = 64u;
+    if (lo >= hi) return 0ull;
+    const uint64_t upto_hi = hi == 64u ? ~0ull : ((1ull << hi) - 1ull);
+    return upto_hi & ~((1ull << lo) - 1ull);
+}
+#endif
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

@@ -128,8 +128,10 @@ def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
 def test_multipaxos_experiment_variants_on_the_host(sim, oracle):
     """compile-time kernel experiments waiting for their device A/B (tools/experiments/README.md) must at least be right"""
     import test_mp_gpu as t
-    with sim.patched(defines=("SMR_SKIP_REG_OUTBOX",)):
-        t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
-        t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
-        t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False)
-        t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=0, every=4)
+    for defs in (("SMR_SKIP_REG_OUTBOX",), ("SMR_ACK_BITS", "SMR_SKIP_REG_OUTBOX")):
+        with sim.patched(defines=defs):
+            t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
+            t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
+            t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False)
+            t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
+            t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=0, every=4)
