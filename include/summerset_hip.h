@@ -653,6 +653,20 @@ typedef struct {
 } smr_wire_ep_msg_t;
 int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *out, uint32_t *deps_out, uint32_t max_deps);
 
+/* ---- request batching front-end (host only; src/server/external.rs:323-344 get_req_batch, :697-730 the batch
+ * ticker): requests queue per group; one tick turns, for every group with queued requests, up to max_batch_size
+ * of them (0 = all) into one ReqBatch, FIFO; groups with an empty queue get no batch. */
+typedef struct smr_batcher smr_batcher;
+int smr_batcher_create(uint32_t n_groups, uint32_t max_batch_size, smr_batcher **out);
+void smr_batcher_destroy(smr_batcher *b);
+int smr_batcher_submit(smr_batcher *b, uint32_t group, uint64_t client, uint64_t req_id, uint8_t kind, const char *key, uint32_t key_len,
+                       const char *value, uint32_t value_len);
+int smr_batcher_pending(smr_batcher *b, uint64_t *n);
+/* returns the number n of groups that got a batch (< 0: error, nothing consumed): groups[k], counts[k] requests,
+ * bincode(ReqBatch) bytes at bytes[off[k] .. off[k + 1]) */
+int64_t smr_batcher_tick(smr_batcher *b, uint32_t *groups, uint32_t *counts, uint64_t *off, uint32_t max_groups, uint8_t *bytes,
+                         uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,9 @@
 // reference: this layout is restated and unpinned against the crate.
 #include <string.h>
 
+#include <deque>
 #include <string>
+#include <vector>
 
 #include "smr_common.h"
 
@@ -546,6 +548,78 @@ int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *
     }
     if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
     return (int64_t)(8 + plen);
+}
+
+}  // extern "C"
+
+/* ---- request batching front-end ------------------------------------------------
+ * ExternalApi (src/server/external.rs): client requests queue up in rx_req; every batch_interval the ticker
+ * (:697-730) wakes get_req_batch (:323-344), which drains up to max_batch_size requests (0 = no limit) into one
+ * ReqBatch, FIFO, and ignores ticks that find the queue empty.  Here: one queue per group, one call per tick. */
+namespace smr { struct BtReq { uint64_t client, req_id; uint8_t kind; std::string key, value; }; }
+struct smr_batcher {
+    uint32_t max_batch_size;
+    std::vector<std::deque<smr::BtReq>> q;
+    uint64_t pending = 0;
+};
+
+extern "C" {
+
+int smr_batcher_create(uint32_t n_groups, uint32_t max_batch_size, smr_batcher **out) {
+    if (!out || n_groups == 0) return fail(SMR_ERR_ARG, "batcher: bad argument");
+    smr_batcher *b = new smr_batcher();
+    b->max_batch_size = max_batch_size;
+    b->q.resize(n_groups);
+    *out = b;
+    return SMR_OK;
+}
+void smr_batcher_destroy(smr_batcher *b) { delete b; }
+
+int smr_batcher_submit(smr_batcher *b, uint32_t group, uint64_t client, uint64_t req_id, uint8_t kind, const char *key, uint32_t key_len,
+                       const char *value, uint32_t value_len) {
+    if (!b || group >= b->q.size() || kind > SMR_CMD_PUT || (key_len && !key) || (kind == SMR_CMD_PUT && value_len && !value))
+        return fail(SMR_ERR_ARG, "batcher: bad argument");
+    b->q[group].push_back(smr::BtReq{client, req_id, kind, std::string(key ? key : "", key_len),
+                                     std::string(kind == SMR_CMD_PUT && value ? value : "", kind == SMR_CMD_PUT ? value_len : 0)});
+    b->pending++;
+    return SMR_OK;
+}
+
+int smr_batcher_pending(smr_batcher *b, uint64_t *n) {
+    if (!b || !n) return fail(SMR_ERR_ARG, "batcher: null argument");
+    *n = b->pending;
+    return SMR_OK;
+}
+
+int64_t smr_batcher_tick(smr_batcher *b, uint32_t *groups, uint32_t *counts, uint64_t *off, uint32_t max_groups, uint8_t *bytes, uint64_t cap) {
+    if (!b || !groups || !counts || !off || !bytes) return fail(SMR_ERR_ARG, "batcher: null argument");
+    // first pass: sizes (nothing is consumed unless everything fits)
+    Wr w{bytes, cap};
+    uint32_t n = 0;
+    for (uint32_t g = 0; g < b->q.size(); g++) {
+        const std::deque<smr::BtReq> &q = b->q[g];
+        if (q.empty()) continue;                                                  // "ignore ticks with an empty batch"
+        if (n == max_groups) return fail(SMR_ERR_ARG, "batcher: more groups with requests than max_groups");
+        const uint32_t take = (b->max_batch_size == 0 || q.size() < b->max_batch_size) ? (uint32_t)q.size() : b->max_batch_size;
+        groups[n] = g; counts[n] = take; off[n] = w.n;
+        w.varint(take);
+        for (uint32_t i = 0; i < take; i++) {
+            const smr::BtReq &r = q[i];
+            w.varint(r.client); w.varint(0);                                       // ApiRequest::Req { id, cmd }
+            w.varint(r.req_id); w.varint(r.kind);
+            w.bytes(r.key.data(), r.key.size());
+            if (r.kind == SMR_CMD_PUT) w.bytes(r.value.data(), r.value.size());
+        }
+        n++;
+    }
+    off[n] = w.n;
+    if (!w.ok) return fail(SMR_ERR_ARG, "batcher: output buffer too small");
+    for (uint32_t k = 0; k < n; k++) {
+        std::deque<smr::BtReq> &q = b->q[groups[k]];
+        q.erase(q.begin(), q.begin() + counts[k]);
+        b->pending -= counts[k];
+    }
+    return (int64_t)n;
 }
 
 }  // extern "C"

@@ -245,3 +245,43 @@ def ep_decode(buf, max_deps=8):
     out["deps"] = [None if deps[i] == EP_NONE else deps[i] for i in range(min(m.n_deps, max_deps))]
     out["reqs"] = bytes(buf[m.reqs_off:m.reqs_off + m.reqs_len])
     return int(n), out
+
+
+# ---- request batching front-end (src/server/external.rs:323-344, 697-730) ---------------------------------------------------
+class Batcher:
+    """per-group request queues; `tick()` = one batch interval: {group: (n requests, bincode(ReqBatch) bytes)}"""
+
+    def __init__(self, n_groups, max_batch_size=0):
+        self.G = int(n_groups)
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.smr_batcher_create(self.G, int(max_batch_size), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.smr_batcher_destroy(self._h)
+            self._h = None
+
+    def submit(self, group, client, req_id, cmd):
+        """cmd: ("get", key) | ("put", key, value)"""
+        b = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+        key = b(cmd[1])
+        val = b(cmd[2]) if cmd[0] == "put" else b""
+        check(self._L.smr_batcher_submit(self._h, group, client, req_id, PUT if cmd[0] == "put" else GET, key, len(key), val, len(val)))
+
+    def pending(self):
+        n = C.c_uint64()
+        check(self._L.smr_batcher_pending(self._h, C.byref(n)))
+        return n.value
+
+    def tick(self, cap=1 << 16):
+        groups, counts, off = (C.c_uint32 * self.G)(), (C.c_uint32 * self.G)(), (C.c_uint64 * (self.G + 1))()
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = self._L.smr_batcher_tick(self._h, groups, counts, off, self.G, buf, cap)
+            if n >= 0:
+                return {groups[k]: (counts[k], buf.raw[off[k]:off[k + 1]]) for k in range(n)}
+            if cap > (1 << 30):
+                check(int(n))
+            cap *= 8

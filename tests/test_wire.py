@@ -195,3 +195,27 @@ def test_epaxos_frames_by_hand_and_round_trip(engine_lib):
     assert wire.ep_decode(f[:-2]) == (0, None)
     with pytest.raises(Exception):
         wire.ep_decode((6).to_bytes(8, "big") + bytes([0, 3, 4, 1, 5, 9]))      # a trailing byte
+
+
+# ---- request batching front-end ---------------------------------------------------------------------------------------------
+def test_batcher_follows_get_req_batch(engine_lib):
+    """external.rs:323-344: a tick drains up to max_batch_size queued requests (0 = all) into one ReqBatch, FIFO;
+    a tick that finds a queue empty produces nothing for it"""
+    from summerset_amd import wire
+    b = wire.Batcher(4, max_batch_size=2)
+    assert b.tick() == {} and b.pending() == 0
+    reqs = [(7, 1, ("put", "k", "v1")), (8, 1, ("get", "k")), (7, 2, ("put", "k", "v2"))]
+    for r in reqs:
+        b.submit(2, *r)
+    b.submit(0, 9, 5, ("get", "x"))
+    out = b.tick()
+    assert set(out) == {0, 2} and out[2] == (2, wire.reqbatch(reqs[:2])) and out[0] == (1, wire.reqbatch([(9, 5, ("get", "x"))]))
+    assert b.pending() == 1
+    assert b.tick() == {2: (1, wire.reqbatch(reqs[2:]))} and b.tick() == {}
+    every = wire.Batcher(1)                                     # max_batch_size 0: no limit
+    many = [(c, c * 3, ("put", "key%d" % c, "x" * c)) for c in range(300)]
+    for r in many:
+        every.submit(0, *r)
+    assert every.tick(cap=64) == {0: (300, wire.reqbatch(many))}   # the first buffer is too small: nothing consumed, retried
+    with pytest.raises(SummersetError):
+        b.submit(4, 1, 1, ("get", "k"))                          # no such group
