@@ -32,7 +32,10 @@
  * Rule 0: WAL appends and state-machine commands complete right after the handler
  * that submitted them returns, in submission order.  The state machine: digest = (digest ^ (slot << 32
  * | token)) * 0x100000001B3 per executed command.  NOT modelled: snapshots (start_slot = 0), leases,
- * timers (a HearTimeout is an input), msg_chunk_size (one Reconstruct message per step-up).
+ * timers (a HearTimeout is an input), msg_chunk_size (one Reconstruct message per step-up; the Heartbeat the
+ * reference injects behind each chunk, leadership.rs:173-183, is a plain broadcast of fields this call returns and
+ * is delivered by the schedule, summerset_amd/rsp_cluster.py).  ReconstructReply rows are taken in the order
+ * given (the reference iterates a HashMap; the outcome does not depend on the order).
  * Harness guard shared with the engine: an instance that left the ring of the last W slots is ignored
  * like a slot below start_slot.
  *

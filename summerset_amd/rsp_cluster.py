@@ -5,7 +5,7 @@ around them the replicas of a group live on different ranks and every handler's 
   2. the client batch of the tick at its target replica -> Accepts (one shard per peer)
   3. step-up Heartbeats and the replies to them
   4. Prepares -> PrepareReply batches -> the Accepts the quorum lets the new leader send
-  5. Reconstruct reads and their replies
+  5. Reconstruct reads and their replies, then the Heartbeat the new leader injects behind them
   6. Accepts -> AcceptReplies -> commits (commit bar run gated on shard availability, execution)
   7. every `hb_every` ticks: the leaders' periodic Heartbeats (commit learning) and the replies
 Message order: senders ascending, receivers ascending.  `drop[(kind, s, q)]` (optional): bool [G], the message
@@ -139,6 +139,10 @@ def tick(reps, val, target, timeouts=None, drop=None, heartbeat=False):
             if fl2.any():
                 log.append(dict(kind="recon_reply", s=s, q=q, rows=int(rr["rr_n"][fl2.astype(bool)].sum())))
                 reps[s].reconstruct_reply(flags=fl2, **rr)
+        # "inject a heartbeat after every chunk to keep peers happy" (leadership.rs:173-183): a plain broadcast with the
+        # NEW ballot (bal_max_seen = bal_prep_sent by now) and the bars of the step-up moment; the sender does not hear it
+        _deliver_heartbeat(reps, s, (bl[s]["rc_n"] > 0).astype(np.uint8), bl[s]["p_ballot"], bl[s]["hb_commit"], bl[s]["hb_exec"],
+                           bl[s]["hb_snap"], drop)
     # 6. Accept phase: the client batches, then what the Prepare quorum released
     for s in range(R):
         _deliver_accepts(reps, s, acc[s], drop, log)
