@@ -420,6 +420,11 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *host_bufs);
  * re-submissions of an already executing instance, pops of an instance that left the ring (counted
  * as executed), 0, attempts, abandoned attempts. */
 int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters);
+/* the commands the LAST handler call submitted to the state machine (state_machine.submit_cmd, execution.rs:113-131),
+ * group-major, in submission order within a group: instance (row, col) of group -- the host applies them in this
+ * order.  *n_out = how many there were; the first `cap` are written and the list is consumed; with NULL host arrays
+ * the call only counts and leaves the list in place. */
+int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host, uint32_t *col_host, uint64_t cap, uint64_t *n_out);
 
 /* ------------------------------------------------------------------------
  * RSPaxos replica: G groups, one replica id per object, one call = one handler

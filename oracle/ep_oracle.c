@@ -93,6 +93,7 @@ typedef struct {
     /* execution */
     uint8_t execute;
     Slot *execq; uint32_t n_execq, cap_execq;       /* commands submitted to the state machine, results pending */
+    Slot *sublog; uint32_t n_sublog, cap_sublog;    /* every submission since the last orc_ep_take_submissions */
     uint64_t *kv;                                   /* [n_keys] token of the last Put, 0 = none */
     uint64_t digest;
     uint64_t n_exec, n_reexec, n_unheld, n_multi_scc, n_attempts, n_aborts;
@@ -156,7 +157,7 @@ void orc_ep_free(void *h) {
     for (uint32_t g = 0; g < cl->G; g++) {
         for (int i = 0; i < MAXR; i++) free(cl->reps[g].rows[i]);
         free(cl->reps[g].highest_cols); free(cl->reps[g].hc_present);
-        free(cl->reps[g].kv); free(cl->reps[g].execq);
+        free(cl->reps[g].kv); free(cl->reps[g].execq); free(cl->reps[g].sublog);
     }
     free(cl->reps); free(cl);
 }
@@ -317,6 +318,11 @@ static int attempt_execution(EpRep *r, int trow, uint32_t tcol) {
                     r->execq = (Slot *)realloc(r->execq, sizeof(Slot) * r->cap_execq);
                 }
                 r->execq[r->n_execq++] = s;
+                if (r->n_sublog == r->cap_sublog) {
+                    r->cap_sublog = r->cap_sublog ? r->cap_sublog * 2 : 32;
+                    r->sublog = (Slot *)realloc(r->sublog, sizeof(Slot) * r->cap_sublog);
+                }
+                r->sublog[r->n_sublog++] = s;
             }
             in->status = ST_EXECUTING;
         }
@@ -686,4 +692,18 @@ void orc_ep_exec_dump(void *h, uint32_t *exec_bars, uint64_t *kv, uint64_t *dige
         counters[0] += r->n_exec; counters[1] += r->n_reexec; counters[2] += r->n_unheld;
         counters[3] += r->n_multi_scc; counters[4] += r->n_attempts; counters[5] += r->n_aborts;
     }
+}
+
+/* the commands submitted since the last call, group-major, in submission order within a group: (group, row, col);
+ * returns how many there were (only the first cap are written) */
+uint64_t orc_ep_take_submissions(void *h, uint32_t *group, uint8_t *row, uint32_t *col, uint64_t cap) {
+    EpCl *cl = (EpCl *)h;
+    uint64_t n = 0;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        EpRep *r = &cl->reps[g];
+        for (uint32_t i = 0; i < r->n_sublog; i++, n++)
+            if (n < cap) { group[n] = g; row[n] = r->sublog[i].row; col[n] = r->sublog[i].col; }
+        r->n_sublog = 0;
+    }
+    return n;
 }

@@ -93,6 +93,7 @@ def _declare(L):
     L.orc_ep_dump.argtypes = [vp] + [vp] * 12
     L.orc_ep_set_execute.argtypes = [vp, u8]
     L.orc_ep_exec_dump.argtypes = [vp] + [vp] * 4
+    L.orc_ep_take_submissions.restype = u64; L.orc_ep_take_submissions.argtypes = [vp, vp, vp, vp, u64]
     L.orc_rsp_new.restype = vp; L.orc_rsp_new.argtypes = [u32, u8, u8, u32, u8]
     L.orc_rsp_free.argtypes = [vp]
     L.orc_rsp_preset_leader.argtypes = [vp, u8]
@@ -422,6 +423,16 @@ class EpOracle:
         lib().orc_ep_dump(self.h, *[_p(d[k]) for k in ("len", "commit_bars", "bal", "seq", "status", "key", "deps", "pa_acks",
                                                        "acc_acks", "bk", "highest_cols", "counters")])
         return d
+
+    def take_submissions(self):
+        """(group, row, col) of the commands submitted since the last call: group-major, submission order per group"""
+        cap = 1 << 16
+        while True:
+            g, r, c = np.zeros(cap, np.uint32), np.zeros(cap, np.uint8), np.zeros(cap, np.uint32)
+            n = lib().orc_ep_take_submissions(self.h, _p(g), _p(r), _p(c), cap)
+            if n <= cap:
+                return g[:n], r[:n], c[:n]
+            raise RuntimeError("more than %d submissions between two polls" % cap)
 
     def exec_dump(self):
         """execution state: exec_bars [R, G], kv [n_keys, G] (token of the last Put), digest [G], counters [6]"""

@@ -192,6 +192,7 @@ SYMBOLS = [
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("smr_rsp_replica_create", _i, [C.POINTER(RspCfg), C.POINTER(_vp)]),
     ("smr_rsp_replica_destroy", None, [_vp]),
     ("smr_rsp_preset_leader", _i, [_vp, _u8]),

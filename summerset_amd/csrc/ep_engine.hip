@@ -249,7 +249,8 @@ struct EpExec {
     uint64_t *kv;                        // [n_keys][G] token of the last Put, 0 = none
     uint64_t *digest;                    // [G] chain over (token, old token) in submission order
     uint16_t *node_of, *nslot, *head, *sib, *parent;   // [R*W][G]
-    uint16_t *order;                     // [2*R*W][G]
+    uint16_t *order;                     // [2*R*W][G] this call's submissions (ring cells), ...
+    uint32_t *n_sub;                     // ... [G] how many: what smr_ep_exec_poll reads
     unsigned long long *counters;        // commands submitted, re-submissions, pops of an instance no longer held,
                                          // (unused: components > 1 node), attempts, abandoned attempts
 };
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(256) void ep_execute_kernel(const EpView v, const E
             x.prev_cb[o] = cb;
             E.advanced(row, cb);
         }
+        x.n_sub[g] = E.n_order;                                              // 0 when no commit bar moved
     }
     E.flush();
 }
@@ -731,7 +733,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
         ecarve(a, x.kv, K * G, dry); ecarve(a, x.digest, G, dry);
         ecarve(a, x.node_of, R * W * G, dry); ecarve(a, x.nslot, R * W * G, dry); ecarve(a, x.head, R * W * G, dry);
         ecarve(a, x.sib, R * W * G, dry); ecarve(a, x.parent, R * W * G, dry);
-        ecarve(a, x.order, 2 * R * W * G, dry);
+        ecarve(a, x.order, 2 * R * W * G, dry); ecarve(a, x.n_sub, G, dry);
         ecarve(a, x.counters, 8, dry);
     }
 }
@@ -907,6 +909,36 @@ int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint6
     unsigned long long c[8];
     SMR_HIP_TRY(hipMemcpy(c, e->x.counters, sizeof(c), hipMemcpyDeviceToHost));
     for (int k = 0; k < 6; k++) counters[k] = c[k];
+    return SMR_OK;
+}
+
+int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host, uint32_t *col_host, uint64_t cap, uint64_t *n_out) {
+    if (!e || !n_out) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.execute) return fail(SMR_ERR_ARG, "epaxos: created without execution");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const EpView &v = e->v;
+    const size_t G = v.G, R = v.R;
+    std::vector<uint32_t> n_sub(G), len(R * G);
+    SMR_HIP_TRY(hipMemcpy(n_sub.data(), e->x.n_sub, G * 4, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(len.data(), v.len, R * G * 4, hipMemcpyDeviceToHost));
+    uint32_t most = 0;
+    for (size_t g = 0; g < G; g++) most = n_sub[g] > most ? n_sub[g] : most;
+    std::vector<uint16_t> order((size_t)most * G);
+    if (most) SMR_HIP_TRY(hipMemcpy(order.data(), e->x.order, (size_t)most * G * 2, hipMemcpyDeviceToHost));
+    uint32_t wshift = 0;
+    while ((1u << wshift) < v.W) wshift++;
+    uint64_t n = 0;
+    for (size_t g = 0; g < G; g++)
+        for (uint32_t k = 0; k < n_sub[g]; k++, n++) {
+            if (n >= cap || !group_host || !row_host || !col_host) continue;
+            const uint32_t ring = order[(size_t)k * G + g], row = ring >> wshift, w = ring & v.Wmask;
+            const uint32_t end = len[row * G + g], lo = end > v.W ? end - v.W : 0u;
+            uint32_t col = (lo & ~v.Wmask) | w;                              // the column of that residue among the last W
+            if (col < lo) col += v.W;
+            group_host[n] = (uint32_t)g; row_host[n] = (uint8_t)row; col_host[n] = col;
+        }
+    *n_out = n;
+    if (group_host && row_host && col_host) SMR_HIP_TRY(hipMemset(e->x.n_sub, 0, G * 4));   // a count-only call leaves them
     return SMR_OK;
 }
 

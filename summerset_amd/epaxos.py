@@ -26,7 +26,8 @@ def _ptr(t):
 class EPaxosReplicaGroup:
     def __init__(self, n_groups, population=5, me=0, window=32, n_keys=64, optimized_quorum=True, execute=False):
         self.G, self.R, self.me, self.W, self.K = int(n_groups), int(population), int(me), int(window), int(n_keys)
-        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), int(bool(execute)), self.W, self.K)
+        self.execute = bool(execute)
+        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), int(self.execute), self.W, self.K)
         h = C.c_void_p()
         self._L = _lib.load()
         check(self._L.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
@@ -118,3 +119,13 @@ class EPaxosReplicaGroup:
         check(self._L.smr_ep_exec_dump(self._h, *[d[k].ctypes.data_as(C.c_void_p)
                                                   for k in ("exec_bars", "kv", "digest", "counters")]))
         return d
+
+    def exec_poll(self):
+        """(group, row, col) of the commands the last handler call submitted: group-major, submission order per group"""
+        n = C.c_uint64()
+        check(self._L.smr_ep_exec_poll(self._h, None, None, None, 0, C.byref(n)))     # count only
+        k = max(int(n.value), 1)
+        g, r, c = np.zeros(k, np.uint32), np.zeros(k, np.uint8), np.zeros(k, np.uint32)
+        check(self._L.smr_ep_exec_poll(self._h, g.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p),
+                                       c.ctypes.data_as(C.c_void_p), k, C.byref(n)))
+        return g[:n.value], r[:n.value], c[:n.value]

@@ -15,6 +15,11 @@ class NumpyEngine:
         import torch
         self.e, self.cuda, self.torch = eng, cuda, torch
         self.W, self.n_keys = eng.W, eng.K
+        self._polls = []                                         # with execution on: the submissions of every call so far
+
+    def _after_call(self):
+        if getattr(self.e, "execute", False):
+            self._polls.append(self.e.exec_poll())               # the engine keeps only the last call's list
 
     def _t(self, a):
         if a is None:
@@ -28,26 +33,32 @@ class NumpyEngine:
 
     def propose(self, key, exploded=None):
         o = self.e.handle_req_batch(self._t(key), self._t(exploded))
+        self._after_call()
         return self._n(o, dict(flags=np.uint8, col=np.uint32, seq=np.uint64, deps=np.uint32))
 
     def handle_pre_accept(self, **m):
         o = self.e.handle_msg_pre_accept({k: self._t(v) for k, v in m.items()})
+        self._after_call()
         return self._n(o, dict(flags=np.uint8, ballot=np.uint64, seq=np.uint64, deps=np.uint32))
 
     def handle_accept(self, **m):
         o = self.e.handle_msg_accept({k: self._t(v) for k, v in m.items()})
+        self._after_call()
         return self._n(o, dict(flags=np.uint8, ballot=np.uint64))
 
     def handle_commit_notice(self, **m):
         self.e.handle_msg_commit_notice({k: self._t(v) for k, v in m.items()})
+        self._after_call()
 
     def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None):
         o = self.e.handle_msg_pre_accept_reply(self._t(col), self._t(ballot), self._t(seq), self._t(deps), self._t(flags),
                                                self._t(order), self._t(exploded))
+        self._after_call()
         return self._n(o, dict(decision=np.uint8, seq=np.uint64, deps=np.uint32))
 
     def handle_accept_replies(self, col, ballot, flags, order=None):
         o = self.e.handle_msg_accept_reply(self._t(col), self._t(ballot), self._t(flags), self._t(order))
+        self._after_call()
         return self._n(o, dict(committed=np.uint8))
 
     def dump(self):
@@ -55,6 +66,15 @@ class NumpyEngine:
 
     def exec_dump(self):
         return self.e.exec_dump()
+
+    def take_submissions(self):
+        """like EpOracle.take_submissions: everything since the last call, group-major, submission order per group"""
+        g = np.concatenate([p[0] for p in self._polls]) if self._polls else np.zeros(0, np.uint32)
+        r = np.concatenate([p[1] for p in self._polls]) if self._polls else np.zeros(0, np.uint8)
+        c = np.concatenate([p[2] for p in self._polls]) if self._polls else np.zeros(0, np.uint32)
+        self._polls = []
+        k = np.argsort(g, kind="stable")
+        return g[k], r[k], c[k]
 
 
 def tick(reps, keys, drop=None):

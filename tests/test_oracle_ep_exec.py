@@ -20,9 +20,10 @@ def tok(row, col):
 
 class _Model:
     def __init__(self):
-        self.kv, self.digest, self.n = {}, 0, 0
+        self.kv, self.digest, self.n, self.pending = {}, 0, 0, []
 
     def run(self, order):
+        self.pending += [(row, col) for row, col, _ in order]
         for row, col, key in order:
             t, old = tok(row, col), self.kv.get(key, 0)
             self.kv[key] = t
@@ -41,6 +42,9 @@ def _commit(o, row, col, key, seq, *deps, R=5):
 
 
 def _check(o, m, exec_bars, **counters):
+    _, r, c = o.take_submissions()                             # the hand-derived submission order itself
+    assert [(int(a), int(b)) for a, b in zip(r, c)] == m.pending, (list(zip(r, c)), m.pending)
+    m.pending = []
     x = o.exec_dump()
     assert [int(v) for v in x["exec_bars"][:, 0]] == exec_bars, x["exec_bars"][:, 0]
     assert int(x["digest"][0]) == m.digest

@@ -16,6 +16,9 @@ def _same_all(eng, orc, step):
     a, b = eng.dump(), orc.dump()
     for n in b:
         assert np.array_equal(a[n], b[n]), (step, n, [x[:5] for x in np.nonzero(a[n] != b[n])])
+    # the submissions of the call just made, in order: what a host applies to its state machine
+    for x, y in zip(eng.take_submissions(), orc.take_submissions()):
+        assert np.array_equal(x, y), (step, "submissions", len(x), len(y))
     a, b = eng.exec_dump(), orc.exec_dump()
     for n in ("exec_bars", "kv", "digest"):
         assert np.array_equal(a[n], b[n]), (step, n, [x[:5] for x in np.nonzero(a[n] != b[n])])
