@@ -502,6 +502,10 @@ typedef struct {
     uint64_t *counters;
 } smr_rsp_dump_bufs;
 int smr_rsp_dump(smr_rsp_replica *e, const smr_rsp_dump_bufs *host_bufs);
+/* the commands the LAST handler call executed (state_machine.submit_cmd + its result, durability.rs:166-176,
+ * execution.rs:10-65), group-major, in execution order within a group: (group, slot, batch token).  *n_out = how
+ * many; the first `cap` are written (NULL host arrays: count only).  The next handler call starts a new list. */
+int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_host, uint32_t *val_host, uint64_t cap, uint64_t *n_out);
 
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing

@@ -108,6 +108,7 @@ def _declare(L):
     L.orc_rsp_heartbeat.argtypes = [vp] + [vp] * 11
     L.orc_rsp_bcast_heartbeat.argtypes = [vp] + [vp] * 5
     L.orc_rsp_dump.argtypes = [vp] + [vp] * 27
+    L.orc_rsp_take_executed.restype = u64; L.orc_rsp_take_executed.argtypes = [vp, vp, vp, vp, u64]
 
 
 # ---------------------------------------------------------------- GF / RS ---
@@ -541,6 +542,14 @@ class RspOracle:
 
     def is_leader(self):
         return (self.dump()["leader"] == self.me).astype(np.uint8)
+
+    def take_executed(self):
+        """(group, slot, token) of the commands executed since the last call: group-major, execution order per group"""
+        cap = 1 << 18
+        g, s, v = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        n = lib().orc_rsp_take_executed(self.h, _p(g), _p(s), _p(v), cap)
+        assert n <= cap
+        return g[:n], s[:n], v[:n]
 
     def dump(self):
         G, R, W = self.G, self.R, self.W

@@ -79,6 +79,7 @@ typedef struct {
     Act *wal; uint32_t n_wal, cap_wal;
     uint32_t *execq; uint32_t n_exec, cap_exec;
     uint64_t digest;
+    uint32_t *xlog, *xlog_val; uint32_t n_xlog, cap_xlog;               /* executed since the last orc_rsp_take_executed */
     uint64_t n_commit, n_exec_total, n_mixed, n_redirect;
     /* messages produced by the handler in flight */
     uint64_t out_acc_reply;                                             /* AcceptReply ballot (0 = none) */
@@ -251,6 +252,11 @@ static void handle_cmd_result(Rep *r, uint32_t slot) {
     Inst *in = &r->insts[slot];
     r->digest = (r->digest ^ (((uint64_t)slot << 32) | in->cw.val)) * DG_MUL;
     r->n_exec_total++;
+    if (r->n_xlog == r->cap_xlog) {
+        r->cap_xlog = r->cap_xlog ? r->cap_xlog * 2 : 32;
+        r->xlog = (uint32_t *)realloc(r->xlog, 4 * r->cap_xlog); r->xlog_val = (uint32_t *)realloc(r->xlog_val, 4 * r->cap_xlog);
+    }
+    r->xlog[r->n_xlog] = slot; r->xlog_val[r->n_xlog] = in->cw.val; r->n_xlog++;
     in->status = ST_EXECUTED;
     if (slot == r->exec_bar)
         while (r->exec_bar < r->len && held(r, r->exec_bar)) {
@@ -332,7 +338,7 @@ void orc_rsp_free(void *h) {
     for (uint32_t g = 0; g < cl->G; g++) {
         Rep *r = &cl->reps[g];
         free(r->insts); free(r->wal); free(r->execq); free(r->out_acc_slot); free(r->out_acc_val);
-        free(r->pr_vbal); free(r->pr_vval); free(r->pr_vmask);
+        free(r->pr_vbal); free(r->pr_vval); free(r->pr_vmask); free(r->xlog); free(r->xlog_val);
     }
     free(cl->reps); free(cl);
 }
@@ -639,4 +645,17 @@ void orc_rsp_dump(void *h, uint8_t *leader, uint64_t *bal_prep_sent, uint64_t *b
             s_rsrc[o] = in->has_rbk ? in->r_src : NO_REP; s_rtrig[o] = in->has_rbk ? in->r_trig : 0; s_rendp[o] = in->has_rbk ? in->r_endp : 0;
         }
     }
+}
+
+/* the commands executed since the last call: (group, slot, token), group-major, execution order within a group */
+uint64_t orc_rsp_take_executed(void *h, uint32_t *group, uint32_t *slot, uint32_t *val, uint64_t cap) {
+    Cl *cl = (Cl *)h;
+    uint64_t n = 0;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        Rep *r = &cl->reps[g];
+        for (uint32_t i = 0; i < r->n_xlog; i++, n++)
+            if (n < cap) { group[n] = g; slot[n] = r->xlog[i]; val[n] = r->xlog_val[i]; }
+        r->n_xlog = 0;
+    }
+    return n;
 }

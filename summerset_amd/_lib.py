@@ -207,6 +207,7 @@ SYMBOLS = [
     ("smr_rsp_handle_heartbeat", _i, [_vp, _vp, C.POINTER(RspHeartbeat), _vp, C.POINTER(RspHeartbeat), _vp]),
     ("smr_rsp_bcast_heartbeat", _i, [_vp, _vp, C.POINTER(RspHeartbeat), _vp]),
     ("smr_rsp_dump", _i, [_vp, C.POINTER(RspDumpBufs)]),
+    ("smr_rsp_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
     ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),

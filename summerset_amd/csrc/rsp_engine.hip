@@ -41,7 +41,8 @@ struct RspView {
     uint64_t *s_bal, *s_vbal, *s_pmax;   // [W][G]
     uint8_t *s_st, *s_mask, *s_vmask, *s_fl, *s_packs, *s_aacks, *s_rsrc;
     uint32_t *s_val, *s_vval, *s_ltrig, *s_lendp, *s_rtrig, *s_rendp;
-    uint32_t *xq;                        // [W][G] commands submitted by the handler in flight
+    uint32_t *xq;                        // [W][G] slots whose command the call in flight submitted, in order ...
+    uint32_t *xn;                        // ... [G] how many: what smr_rsp_exec_poll reads
     unsigned long long *counters;        // commits, commands executed, mixed absorbs, redirects
 };
 
@@ -50,7 +51,7 @@ struct RspLane {
     const uint32_t g;
     uint32_t leader, len, cbar, ebar, snap;
     uint64_t bps, bpd, bms;
-    uint32_t n_xq = 0;
+    uint32_t n_xq = 0, x_lo = 0;          // submitted so far in this call / of them already executed
     unsigned int c_commit = 0, c_exec = 0, c_mixed = 0, c_redirect = 0;
     __device__ __forceinline__ RspLane(const RspView &v_, uint32_t g_) : v(v_), g(g_) {
         leader = v.leader[g]; len = v.len[g]; cbar = v.cbar[g]; ebar = v.ebar[g]; snap = v.snap[g];
@@ -59,6 +60,7 @@ struct RspLane {
     __device__ __forceinline__ void store() {
         v.leader[g] = (uint8_t)leader; v.len[g] = len; v.cbar[g] = cbar; v.ebar[g] = ebar; v.snap[g] = snap;
         v.bps[g] = bps; v.bpd[g] = bpd; v.bms[g] = bms;
+        v.xn[g] = n_xq;
     }
     __device__ __forceinline__ size_t ix(uint32_t slot) const { return (size_t)(slot & v.Wmask) * v.G + g; }
     __device__ __forceinline__ bool held(uint32_t slot) const { return slot < len && slot + v.W >= len; }
@@ -105,8 +107,9 @@ struct RspLane {
     }
     // execution.rs:10-65 for the commands the handler submitted, in order (rule 0)
     __device__ __forceinline__ void drain_exec() {
+        if (x_lo == n_xq) return;
         uint64_t dg = v.digest[g];
-        for (uint32_t k = 0; k < n_xq; k++) {
+        for (uint32_t k = x_lo; k < n_xq; k++) {
             const uint32_t slot = v.xq[(size_t)(k & v.Wmask) * v.G + g];
             if (!held(slot)) continue;
             const size_t i = ix(slot);
@@ -116,8 +119,8 @@ struct RspLane {
             if (slot == ebar)
                 while (ebar < len && held(ebar) && v.s_st[ix(ebar)] >= RST_EXECUTED) ebar++;
         }
-        if (n_xq) v.digest[g] = dg;
-        n_xq = 0;
+        v.digest[g] = dg;
+        x_lo = n_xq;                                                       // the list stays: the host polls it after the call
     }
     // messages.rs:406-464 + the CommitSlot completion (durability.rs:125-186) + the command results
     __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t slot, uint64_t ballot) {
@@ -542,7 +545,7 @@ static void rsp_layout(smr_rsp_replica *e, bool dry) {
     qcarve(a, v.s_packs, W * G, dry); qcarve(a, v.s_aacks, W * G, dry); qcarve(a, v.s_rsrc, W * G, dry);
     qcarve(a, v.s_val, W * G, dry); qcarve(a, v.s_vval, W * G, dry); qcarve(a, v.s_ltrig, W * G, dry); qcarve(a, v.s_lendp, W * G, dry);
     qcarve(a, v.s_rtrig, W * G, dry); qcarve(a, v.s_rendp, W * G, dry);
-    qcarve(a, v.xq, W * G, dry);
+    qcarve(a, v.xq, W * G, dry); qcarve(a, v.xn, G, dry);
     qcarve(a, v.counters, 4, dry);
 }
 }  // namespace smr
@@ -733,6 +736,32 @@ int smr_rsp_dump(smr_rsp_replica *e, const smr_rsp_dump_bufs *hb) {
             if (!(fl & 1)) { hb->s_ltrig[o] = 0; hb->s_lendp[o] = 0; hb->s_packs[o] = 0; hb->s_aacks[o] = 0; hb->s_pmax[o] = 0; }
             if (!(fl & 2)) { hb->s_rsrc[o] = 0xFF; hb->s_rtrig[o] = 0; hb->s_rendp[o] = 0; }
         }
+    return SMR_OK;
+}
+
+int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_host, uint32_t *val_host, uint64_t cap, uint64_t *n_out) {
+    if (!e || !n_out) return fail(SMR_ERR_ARG, "rspaxos: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const RspView &v = e->v;
+    const size_t G = v.G, W = v.W;
+    std::vector<uint32_t> xn(G);
+    SMR_HIP_TRY(hipMemcpy(xn.data(), v.xn, G * 4, hipMemcpyDeviceToHost));
+    uint32_t most = 0;
+    for (size_t g = 0; g < G; g++) most = xn[g] > most ? xn[g] : most;
+    if (most > W) most = (uint32_t)W;
+    std::vector<uint32_t> xq((size_t)most * G), val(W * G);
+    if (most) {
+        SMR_HIP_TRY(hipMemcpy(xq.data(), v.xq, (size_t)most * G * 4, hipMemcpyDeviceToHost));
+        SMR_HIP_TRY(hipMemcpy(val.data(), v.s_val, W * G * 4, hipMemcpyDeviceToHost));
+    }
+    uint64_t n = 0;
+    for (size_t g = 0; g < G; g++)
+        for (uint32_t k = 0; k < xn[g] && k < most; k++, n++) {
+            if (n >= cap || !group_host || !slot_host || !val_host) continue;
+            const uint32_t slot = xq[(size_t)k * G + g];
+            group_host[n] = (uint32_t)g; slot_host[n] = slot; val_host[n] = val[(size_t)(slot & v.Wmask) * G + g];
+        }
+    *n_out = n;
     return SMR_OK;
 }
 

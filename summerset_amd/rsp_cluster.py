@@ -22,6 +22,7 @@ class NumpyEngine:
         import torch
         self.e, self.dev, self.torch = eng, dev, torch
         self.G, self.R, self.W, self.me = eng.G, eng.R, eng.W, eng.me
+        self._polls = []                                         # what every call so far executed (the engine keeps the last call's list)
 
     def _t(self, a):
         if a is None:
@@ -44,6 +45,7 @@ class NumpyEngine:
 
             def call(*a, **kw):
                 out = fn(*[self._t(x) for x in a], **{k: self._t(v) for k, v in kw.items()})
+                self._polls.append(self.e.exec_poll())
                 return None if out is None else self._n(out)
             return call
         raise AttributeError(name)
@@ -53,6 +55,13 @@ class NumpyEngine:
 
     def is_leader(self):
         return (self.e.dump()["leader"] == self.me).astype(np.uint8)
+
+    def take_executed(self):
+        """like RspOracle.take_executed: everything since the last call, group-major, execution order per group"""
+        cols = [np.concatenate([p[i] for p in self._polls]) if self._polls else np.zeros(0, np.uint32) for i in range(3)]
+        self._polls = []
+        k = np.argsort(cols[0], kind="stable")
+        return tuple(c[k] for c in cols)
 
 
 def _lost(drop, kind, s, q, G):

@@ -163,3 +163,13 @@ class RSPaxosReplicaGroup:
             setattr(bufs, n, out[n].ctypes.data_as(C.c_void_p))
         check(self._L.smr_rsp_dump(self._h, C.byref(bufs)))
         return out
+
+    def exec_poll(self):
+        """(group, slot, token) of the commands the last handler call executed: group-major, execution order per group"""
+        n = C.c_uint64()
+        check(self._L.smr_rsp_exec_poll(self._h, None, None, None, 0, C.byref(n)))
+        k = max(int(n.value), 1)
+        g, s, v = np.zeros(k, np.uint32), np.zeros(k, np.uint32), np.zeros(k, np.uint32)
+        check(self._L.smr_rsp_exec_poll(self._h, g.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+                                        v.ctypes.data_as(C.c_void_p), k, C.byref(n)))
+        return g[:n.value], s[:n.value], v[:n.value]

@@ -27,6 +27,8 @@ def test_traces_on_the_engine(cuda, oracle):
 
 def _same(engs, orcs, where):
     for r in range(len(engs)):
+        for x, y in zip(engs[r].take_executed(), orcs[r].take_executed()):    # what a host would have applied, in order
+            assert np.array_equal(x, y), (where, r, "executed", len(x), len(y))
         a, b = engs[r].dump(), orcs[r].dump()
         for n in b:
             assert np.array_equal(a[n], b[n]), (where, r, n, [x[:4] for x in np.nonzero(a[n] != b[n])])
@@ -42,12 +44,15 @@ def test_closed_loop_cluster_matches_oracle(cuda, oracle, G, W, ft, loss):
     orcs = [oracle.RspOracle(G, R, me=r, W=W, fault_tolerance=ft) for r in range(R)]
     # the two clusters run the same seeded scenario one after the other, compared tick by tick through their logs,
     # and state by state at the end (the oracles' per-tick dumps are kept for the comparison)
-    snaps = []
-    lo = sc.run(orcs, G, T, seed=G + ft, loss=loss, on_tick=lambda t: snaps.append([o.dump() for o in orcs]))
+    snaps, execd = [], []
+    lo = sc.run(orcs, G, T, seed=G + ft, loss=loss,
+                on_tick=lambda t: (snaps.append([o.dump() for o in orcs]), execd.append([o.take_executed() for o in orcs])))
     step = [0]
 
     def check(t):
         for r in range(R):
+            for x, y in zip(engs[r].take_executed(), execd[t][r]):           # what a host would have applied this tick, in order
+                assert np.array_equal(x, y), (t, r, "executed", len(x), len(y))
             a, b = engs[r].dump(), snaps[t][r]
             for n in b:
                 assert np.array_equal(a[n], b[n]), (t, r, n, [x[:4] for x in np.nonzero(a[n] != b[n])])
