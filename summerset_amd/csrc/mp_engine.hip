@@ -399,6 +399,8 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         }
 #endif
     }
+#undef SND_SLOT
+#undef SND_BAL
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
