@@ -52,6 +52,19 @@ struct Lane {
     // values as loaded, for write-back of only what changed
     uint32_t o_leader; uint64_t o_bps, o_bpd, o_bms;
     uint32_t o_start, o_len, o_abar, o_cbar, o_ebar, o_snap, o_nlb;
+#ifdef SMR_BAL_RUN
+    // Experiment (tools/experiments/README.md): [brun, len) is a run of slots all holding bal == bal_max_seen, kept by the
+    // follower's steady-state append path and dropped (BAL_TOUCH) by everything else that writes a ballot or moves
+    // bal_max_seen; the heartbeat's commit learning then need not load s_bal for slots inside it (8 of its 16 B per slot).
+    uint32_t brun, o_brun;
+#define BAL_TOUCH() do { brun = 0xFFFFFFFFu; } while (0)
+#define BAL_EXTEND(from) do { if (brun == 0xFFFFFFFFu || brun > (from)) brun = (from); } while (0)
+#define HB_BAL(slot, i) ((slot) >= brun ? ballot : v.s_bal()[i])
+#else
+#define BAL_TOUCH() do { } while (0)
+#define BAL_EXTEND(from) do { } while (0)
+#define HB_BAL(slot, i) v.s_bal()[i]
+#endif
     uint32_t obn0, obn1;           // outbox counts of parity 0 / 1 (scalars: a runtime-indexed
     bool obl0, obl1;               // array would live in scratch memory)
     uint32_t n_commit, n_redirect, n_reject;
@@ -86,6 +99,9 @@ struct Lane {
         o_ebar = ebar = v.exec_bar()[g];
         o_snap = snap = v.snap_bar()[g];
         o_nlb = nlb = v.null_lb()[g];
+#ifdef SMR_BAL_RUN
+        o_brun = brun = v.bal_lo()[g];
+#endif
     }
     __device__ __forceinline__ void store() {
         if (leader != o_leader) if (wr) v.leader()[g] = (uint8_t)leader;
@@ -99,6 +115,9 @@ struct Lane {
         if (ebar != o_ebar) if (wr) v.exec_bar()[g] = ebar;
         if (snap != o_snap) if (wr) v.snap_bar()[g] = snap;
         if (nlb != o_nlb) if (wr) v.null_lb()[g] = nlb;
+#ifdef SMR_BAL_RUN
+        if (brun != o_brun) if (wr) v.bal_lo()[g] = brun;
+#endif
         if (obl0) if (wr) v.ob_cnt(0)[g] = obn0;
         if (obl1) if (wr) v.ob_cnt(1)[g] = obn1;
         if (ovf && wr) P.overflow[g] = 1;
@@ -117,6 +136,7 @@ struct Lane {
         if (len - start >= P.W) { ovf = true; return false; }
         size_t i = ix(len);
         if (wr) v.s_meta()[i] = 0; if (wr) v.s_bal()[i] = 0; if (wr) v.s_val()[i] = 0;
+        BAL_TOUCH();
         len++;
         return true;
     }
@@ -220,7 +240,7 @@ struct Lane {
 
     // leadership.rs:11-67 check_leader (lease branches are config-off)
     __device__ __forceinline__ void check_leader(uint32_t peer, uint64_t ballot) {
-        if (ballot > bms) { leader = peer; bms = ballot; }
+        if (ballot > bms) { leader = peer; bms = ballot; BAL_TOUCH(); }
     }
 
     // meta of N consecutive slots [s0, s0+N) below lim, as independent loads
@@ -402,6 +422,7 @@ struct Lane {
         const bool committed = P.thresh <= 1;                   // messages.rs:412 (only for a 1-ack threshold)
         if (committed) m = m_set_st(m, SMR_ST_COMMITTED);
         if (wr) v.s_bal()[i] = bpd;
+        BAL_TOUCH();
         if (wr) v.s_val()[i] = reqs;
         if (wr) v.s_meta()[i] = m;
         ob_push(par, OB_ACCEPT, slot, bpd, reqs, 0);            // :209-216
@@ -645,6 +666,7 @@ struct Lane {
                 const uint64_t vb = pr_vbal[o];
                 const uint32_t vv = vb > 0 ? pr_vval[o] : 0u;
                 v.s_bal()[i] = bps;
+                BAL_TOUCH();
                 v.s_val()[i] = vv;
                 v.s_ltrig()[i] = trig; v.s_lendp()[i] = my_endp; v.s_pmax()[i] = vb;
                 v.s_meta()[i] = SMR_ST_PREPARING | M_EXT | M_LBK | M_LBKX | (vv ? M_NONEMPTY : 0u);
@@ -675,6 +697,7 @@ struct Lane {
         bpd = 0;                                                // :112-114
         bps = make_greater_ballot(bms);
         bms = bps;
+        BAL_TOUCH();
         uint32_t trig = first_status_below(start, len, SMR_ST_COMMITTED);          // :117-123 (else log end)
         const uint32_t endp = last_status(start, len, SMR_ST_COMMITTED, true, len); // :124-130 (else log end)
         if (trig == len) {                                      // :131-134
@@ -738,6 +761,7 @@ struct Lane {
             get_voted(i, m, b, val, vb, vv);
             m = materialize_voted(i, m, b, val, true);
             v.s_bal()[i] = ballot;
+            BAL_TOUCH();
             m = m_set_src(m_set_st(m, SMR_ST_PREPARING) | M_RBK | M_RBKX, peer);
             v.s_rtrig()[i] = trig; v.s_rendp()[i] = endp;
             v.s_meta()[i] = m;
@@ -775,6 +799,7 @@ struct Lane {
         m = m_set_vmode(m, VM_SAME);                            // :351 voted = (ballot, reqs)
         m = reqs ? (m | M_NONEMPTY) : (m & ~M_NONEMPTY);
         if (wr) v.s_bal()[i] = ballot;
+        BAL_TOUCH();
         if (wr) v.s_val()[i] = reqs;
         if (wr) v.s_meta()[i] = m;
         uint64_t reply = 0;
@@ -822,7 +847,7 @@ struct Lane {
                         bool in = sfx + k < hb_commit;
                         size_t i = ix(sfx + k);
                         mm[k] = in ? v.s_meta()[i] : 0u;
-                        bb[k] = in ? v.s_bal()[i] : 0ull;
+                        bb[k] = in ? HB_BAL(sfx + k, i) : 0ull;
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -846,7 +871,7 @@ struct Lane {
                         bool in = s + k < hb_commit;
                         size_t i = ix(s + k);
                         mm[k] = in ? v.s_meta()[i] : 0u;
-                        bb[k] = in ? v.s_bal()[i] : 0ull;
+                        bb[k] = in ? HB_BAL(s + k, i) : 0ull;
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {

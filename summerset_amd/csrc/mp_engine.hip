@@ -274,6 +274,9 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 if ((len0 - L.start) + n_new <= P.W && ldr != r) {
                     (void)mine_before;
                     L.leader = ldr; L.bms = bm;
+#ifdef SMR_BAL_RUN
+                    L.brun = 0xFFFFFFFFu;                            // ballots of a re-Accept run: not tracked
+#endif
                     const RepView &v = L.v;
                     uint32_t mo[8];
 #pragma unroll
@@ -332,6 +335,9 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             if (appending && (L.len - L.start) + nin > P.W) break;   // ring window: let the serial path flag it
             L.check_leader(s, bal0);                             // messages.rs:313-316
             if (L.is_leader()) break;
+#ifdef SMR_BAL_RUN
+            L.brun = 0xFFFFFFFFu;
+#endif
             const RepView &v = L.v;
             uint32_t m = 0;
             if (in) {
@@ -489,6 +495,9 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                     }
                 }
                 if (L.nlb == L.len) L.nlb = len;                 // still no Null below the log end
+#ifdef SMR_BAL_RUN
+                if (fast_done) { if (L.brun == 0xFFFFFFFFu || L.brun > L.len) L.brun = L.len; }   // appended at bal_max_seen
+#endif
                 L.len = len; L.abar = len;
 #ifdef SMR_ACK_BITS
                 if (fast_done) ack_bits_base(ack, P.cap, P.G)[tix(MAXR, r, g)] = ack_range_bits(0, fast_done);   // all of them accepted
@@ -1156,6 +1165,9 @@ static void layout(smr_mp_cluster *c, bool dry) {
         carve(a, v.start_slot, G, dry); carve(a, v.log_len, G, dry); carve(a, v.accept_bar, G, dry);
         carve(a, v.commit_bar, G, dry); carve(a, v.exec_bar, G, dry); carve(a, v.snap_bar, G, dry);
         carve(a, v.null_lb, G, dry);
+#ifdef SMR_BAL_RUN
+        carve(a, v.bal_lo, G, dry);
+#endif
         carve(a, v.peer_exec_bar, R * G, dry);
         carve(a, v.s_bal, W * Gp, dry); carve(a, v.s_val, W * Gp, dry); carve(a, v.s_meta, W * Gp, dry);
         carve(a, v.s_vbal, W * Gp, dry); carve(a, v.s_vval, W * Gp, dry); carve(a, v.s_pmax, W * Gp, dry);

@@ -114,6 +114,9 @@ struct MpRep {
     SMR_G uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
     SMR_G uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
     SMR_G uint32_t *null_lb;        // aux: no Null instance in [exec_bar, null_lb)
+#ifdef SMR_BAL_RUN
+    SMR_G uint32_t *bal_lo;         // experiment: every slot in [bal_lo, log_len) holds bal == bal_max_seen (0xFFFFFFFF: none)
+#endif
     SMR_G uint32_t *peer_exec_bar;  // [R][G]
     // slot ring [W][G]
     SMR_G uint64_t *s_bal;
@@ -173,6 +176,9 @@ struct RepView {
     SMR_HD SMR_G uint32_t *exec_bar() const { return sh(b.exec_bar); }
     SMR_HD SMR_G uint32_t *snap_bar() const { return sh(b.snap_bar); }
     SMR_HD SMR_G uint32_t *null_lb() const { return sh(b.null_lb); }
+#ifdef SMR_BAL_RUN
+    SMR_HD SMR_G uint32_t *bal_lo() const { return sh(b.bal_lo); }
+#endif
     SMR_HD SMR_G uint32_t *peer_exec_bar() const { return sh(b.peer_exec_bar); }
     SMR_HD SMR_G uint64_t *s_bal() const { return sh(b.s_bal); }
     SMR_HD SMR_G uint32_t *s_val() const { return sh(b.s_val); }

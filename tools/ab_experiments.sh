@@ -2,7 +2,8 @@
 # Device A/B of the prepared kernel experiments (tools/experiments/README.md), one gpurun call:
 #   python tools/build_variant.py regout -DSMR_SKIP_REG_OUTBOX          (here, before the call: the .so travels)
 #   python tools/build_variant.py ackbits -DSMR_ACK_BITS
-#   python tools/build_variant.py both -DSMR_ACK_BITS -DSMR_SKIP_REG_OUTBOX
+#   python tools/build_variant.py balrun -DSMR_BAL_RUN
+#   python tools/build_variant.py all3 -DSMR_ACK_BITS -DSMR_SKIP_REG_OUTBOX -DSMR_BAL_RUN
 #   gpurun --timeout 1500 -- 'bash tools/ab_experiments.sh'
 # Per variant: the MultiPaxos device tests (parity first), then the headline bench line twice; results in gpurun_out/ab_*.
 mkdir -p gpurun_out
@@ -26,7 +27,7 @@ PY
     done
 }
 run shipped ""
-for tag in regout ackbits both; do
+for tag in regout ackbits balrun all3; do
     lib=$PWD/summerset_amd/variants/libsummerset_hip_$tag.so
     [ -f "$lib" ] && run $tag "$lib" || echo "$tag: build it first (tools/build_variant.py)"
 done
