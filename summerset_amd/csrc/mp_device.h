@@ -57,7 +57,14 @@ struct Lane {
     // follower's steady-state append path and dropped (BAL_TOUCH) by everything else that writes a ballot or moves
     // bal_max_seen; the heartbeat's commit learning then need not load s_bal for slots inside it (8 of its 16 B per slot).
     uint32_t brun, o_brun;
+#ifdef SMR_BAL_LAZY
+    // ... and, one step further (-DSMR_BAL_LAZY): the follower's steady-state append does not STORE the ballot of a slot
+    // inside the run (8 of the 16 B it writes per slot) -- the true value is bal_max_seen; whoever ends the run writes
+    // the ballots out first (uniform mode: every lane its share), with the bal_max_seen the run was built under.
+#define BAL_TOUCH() do { if (brun != 0xFFFFFFFFu) { for (uint32_t _s = (brun > start ? brun : start) + cl; _s < len; _s += cn) v.s_bal()[ix(_s)] = bms; brun = 0xFFFFFFFFu; } } while (0)
+#else
 #define BAL_TOUCH() do { brun = 0xFFFFFFFFu; } while (0)
+#endif
 #define BAL_EXTEND(from) do { if (brun == 0xFFFFFFFFu || brun > (from)) brun = (from); } while (0)
 #define HB_BAL(slot, i) ((slot) >= brun ? ballot : v.s_bal()[i])
 #else
@@ -84,6 +91,7 @@ struct Lane {
         obn0 = obn1 = 0;
     }
 
+    __device__ __forceinline__ void bal_touch() { BAL_TOUCH(); }   // for callers outside the struct (experiments, see above)
     __device__ __forceinline__ void set_uniform() { wr = __lane_id() == 0; cl = (uint32_t)__lane_id(); cn = 64; }
     __device__ __forceinline__ bool coop() const { return cn != 1; }
 
@@ -240,7 +248,7 @@ struct Lane {
 
     // leadership.rs:11-67 check_leader (lease branches are config-off)
     __device__ __forceinline__ void check_leader(uint32_t peer, uint64_t ballot) {
-        if (ballot > bms) { leader = peer; bms = ballot; BAL_TOUCH(); }
+        if (ballot > bms) { BAL_TOUCH(); leader = peer; bms = ballot; }
     }
 
     // meta of N consecutive slots [s0, s0+N) below lim, as independent loads
@@ -696,8 +704,8 @@ struct Lane {
         for (uint32_t p = 0; p < P.R; p++) if (wr) v.peer_exec_bar()[(size_t)p * P.G + g] = 0;   // :107-109
         bpd = 0;                                                // :112-114
         bps = make_greater_ballot(bms);
-        bms = bps;
         BAL_TOUCH();
+        bms = bps;
         uint32_t trig = first_status_below(start, len, SMR_ST_COMMITTED);          // :117-123 (else log end)
         const uint32_t endp = last_status(start, len, SMR_ST_COMMITTED, true, len); // :124-130 (else log end)
         if (trig == len) {                                      // :131-134
@@ -745,6 +753,7 @@ struct Lane {
     __device__ __forceinline__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
         if (trig < start) return;                               // :18-20
         if (ballot < bms) return;                               // :29
+        BAL_TOUCH();                                            // (reads slot ballots below)
         check_leader(peer, ballot);
         if (!pad_to(trig)) return;                              // :37-39
         const uint32_t last = last_status(start, len, SMR_ST_NULL, false, start);   // :43-52 (unwrap_or(0))
@@ -782,6 +791,7 @@ struct Lane {
     __device__ __forceinline__ uint64_t msg_accept(uint32_t peer, uint32_t slot, uint64_t ballot, uint32_t reqs) {
         if (slot < start) return 0;                             // :302-304
         if (ballot < bms) return 0;                             // :313
+        BAL_TOUCH();                                            // (reads the slot's ballot below)
         check_leader(peer, ballot);
         uint32_t m = 0;
         size_t i = ix(slot);

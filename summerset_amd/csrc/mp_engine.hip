@@ -273,10 +273,8 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 if (bal0 > bm) { ldr = s; bm = bal0; }            // check_leader, messages.rs:313-316
                 if ((len0 - L.start) + n_new <= P.W && ldr != r) {
                     (void)mine_before;
+                    L.bal_touch();                                   // ballots of a re-Accept run: not tracked
                     L.leader = ldr; L.bms = bm;
-#ifdef SMR_BAL_RUN
-                    L.brun = 0xFFFFFFFFu;                            // ballots of a re-Accept run: not tracked
-#endif
                     const RepView &v = L.v;
                     uint32_t mo[8];
 #pragma unroll
@@ -333,11 +331,9 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
             const bool appending = slot0 == L.len;               // brand-new slots (push + fill fused)
             if (!appending && slot0 + nin > L.len) break;        // a mix of old and new slots: one by one
             if (appending && (L.len - L.start) + nin > P.W) break;   // ring window: let the serial path flag it
+            L.bal_touch();
             L.check_leader(s, bal0);                             // messages.rs:313-316
             if (L.is_leader()) break;
-#ifdef SMR_BAL_RUN
-            L.brun = 0xFFFFFFFFu;
-#endif
             const RepView &v = L.v;
             uint32_t m = 0;
             if (in) {
@@ -458,7 +454,12 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         for (int k = 0; k < 8; k++) {
                             if (j0 + k >= cnt) break;
                             const size_t i = tix(W, (len + j0 + k) & Wm, g);
-                            sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+#ifdef SMR_BAL_LAZY
+                            (void)sb;
+#else
+                            sb[i] = bms;
+#endif
+                            sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
                             ACK_STORE(ack, j0 + k, 1);
                         }
                     }
@@ -488,7 +489,12 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                             break;
                         }
                         const size_t i = tix(W, len & Wm, g);
-                        sb[i] = bms; sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+#ifdef SMR_BAL_LAZY
+                        (void)sb;
+#else
+                        sb[i] = bms;
+#endif
+                        sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
                         ACK_STORE(ack, j0 + k, 1);
                         len++;
                         fast_done++;
@@ -1532,6 +1538,10 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
     D2H(val.data(), v.s_val, W * Gp * 4); D2H(meta.data(), v.s_meta, W * Gp * 4); D2H(vval.data(), v.s_vval, W * Gp * 4);
     D2H(ltrig.data(), v.s_ltrig, W * Gp * 4); D2H(lendp.data(), v.s_lendp, W * Gp * 4);
     D2H(rtrig.data(), v.s_rtrig, W * Gp * 4); D2H(rendp.data(), v.s_rendp, W * Gp * 4);
+#ifdef SMR_BAL_LAZY
+    std::vector<uint32_t> bal_lo(G);
+    D2H(bal_lo.data(), v.bal_lo, G * 4);
+#endif
 #undef D2H
     // canonicalise: explicit Instance fields, zero outside [start_slot, log_len); the host
     // buffers are plain [W][G], the device arrays wave-tiled (tix)
@@ -1549,6 +1559,9 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
             const size_t o = (size_t)(s & (W - 1)) * G + g;                     // host index
             const size_t t = tix((uint32_t)W, s & (uint32_t)(W - 1), (uint32_t)g);   // device index
             uint32_t m = meta[t];
+#ifdef SMR_BAL_LAZY
+            if (s >= bal_lo[g]) bal[t] = hb->bal_max_seen[g];                    // inside the run the ballot is not stored
+#endif
             hb->s_bal[o] = bal[t]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[t];
             uint32_t vm = (m >> M_VMODE_SH) & 3u;
             hb->s_vbal[o] = vm == VM_SAME ? bal[t] : (vm == VM_SIDE ? vbal[t] : 0);
