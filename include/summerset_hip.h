@@ -269,6 +269,29 @@ typedef struct {
 int smr_raft_leader_dump(smr_raft_leader *l, const smr_raft_dump_bufs *host_bufs);
 int smr_raft_leader_total_commits(smr_raft_leader *l, uint64_t *out);
 
+/* ---- CRaft leader variant (src/protocols/craft/, a fork of raft/) ----------------------
+ * smr_raft_craft_enable turns every group's leader of `l` into a CRaft leader (call it right after create):
+ * handle_replies then follows craft/messages.rs:256-404 -- every reply taken counts as a heard heartbeat
+ * (Heartbeater::update_heard_cnt, server/heartbeat.rs:280-296), success replies are not tested for staleness, and an
+ * entry commits at `majority + fault_tolerance` matches, `majority` while the group is in full-copy mode (:307-313).
+ * The leader created every entry of its log, so it holds all shards and every committed entry is executable.
+ * repeat_threshold = hear_timeout_min / send_interval of the Heartbeater (heartbeat.rs:257-259). */
+int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t repeat_threshold);
+/* CRaftReplica::bcast_heartbeats on the send tick (craft/leadership.rs:249-291): the empty AppendEntries per peer
+ * (hb_flags[R][G] 1 = sent; prev_slot, prev_term [R][G]; leader_commit, last_snap [G]), update_bcast_cnts
+ * (heartbeat.rs:240-276), then fall back to full-copy mode if `population - alive >= fault_tolerance` (:283-288). */
+int smr_raft_craft_bcast_heartbeats(smr_raft_leader *l, uint8_t *hb_flags_dev, uint32_t *prev_slot_dev, uint64_t *prev_term_dev,
+                                    uint32_t *leader_commit_dev, uint32_t *last_snap_dev, void *stream);
+/* switch_assignment_mode (craft/leadership.rs:80-141): to_full[G] 0 / 1, anything else = no call for the group */
+int smr_raft_craft_switch_assignment_mode(smr_raft_leader *l, const uint8_t *to_full_dev, void *stream);
+/* Shard masks of a new entry's RS codeword (smr_rs_encode makes the shards): persist[G] = what the leader's WAL entry holds
+ * (craft/request.rs:86-100), send[R][G] = what an AppendEntries to each peer carries (craft/durability.rs:41-80,
+ * messages.rs:416-460): the data shards 0..majority in full-copy mode, else the receiver's own shard. */
+int smr_raft_craft_assignment(smr_raft_leader *l, uint32_t *persist_dev, uint32_t *send_dev, void *stream);
+/* host arrays: full_copy_mode[G], peer_alive[G] (bitmap), reply_cnts .0 / .1 / .2 as [R][G] */
+int smr_raft_craft_dump(smr_raft_leader *l, uint8_t *full_copy_host, uint8_t *alive_host, uint64_t *hb_replied_host,
+                        uint64_t *hb_seen_host, uint8_t *hb_repeat_host);
+
 /* ---- Raft follower side and elections, same replica object ---------------------------
  * One replica per group; `l` is the object created above (role Leader at creation;
  * smr_raft_replica_preset puts every group's replica into another role for a scenario). */

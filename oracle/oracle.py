@@ -82,6 +82,11 @@ def _declare(L):
     L.orc_raft_handle_request_vote.argtypes = [vp] + [vp] * 7
     L.orc_raft_handle_vote_replies.argtypes = [vp] + [vp] * 6
     L.orc_raft_dump_votes.argtypes = [vp] + [vp] * 4
+    L.orc_craft_enable.argtypes = [vp, u8, u8]
+    L.orc_craft_switch_assignment_mode.argtypes = [vp, vp]
+    L.orc_craft_bcast_heartbeats.argtypes = [vp] + [vp] * 5
+    L.orc_craft_assignment.argtypes = [vp, vp, vp]
+    L.orc_craft_dump.argtypes = [vp] + [vp] * 5
     L.orc_ep_new.restype = vp; L.orc_ep_new.argtypes = [u32, u8, u8, u32, u32, u8]
     L.orc_ep_free.argtypes = [vp]
     L.orc_ep_propose.argtypes = [vp] + [vp] * 6
@@ -359,6 +364,38 @@ class RaftOracle:
 
 EP_NONE = 0xFFFFFFFF
 EP_NO_KEY = 0xFF
+
+
+class CRaftOracle(RaftOracle):
+    """the CRaft leader variant of the restatement (oracle/raft_oracle.c, orc_craft_*)"""
+
+    def __init__(self, G, R=5, W=64, leader_id=0, term=1, fault_tolerance=1, repeat_threshold=3):
+        super().__init__(G, R, W, leader_id, term, 0)
+        lib().orc_craft_enable(self.h, fault_tolerance, repeat_threshold)
+
+    def bcast_heartbeats(self):
+        R, G = self.R, self.G
+        m = dict(hb_flags=np.zeros((R, G), np.uint8), prev_slot=np.zeros((R, G), np.uint32), prev_term=np.zeros((R, G), np.uint64),
+                 leader_commit=np.zeros(G, np.uint32), last_snap=np.zeros(G, np.uint32))
+        lib().orc_craft_bcast_heartbeats(self.h, *[_p(m[k]) for k in ("hb_flags", "prev_slot", "prev_term", "leader_commit", "last_snap")])
+        return m
+
+    def switch_assignment_mode(self, to_full_copy):
+        assert to_full_copy.dtype == np.uint8
+        lib().orc_craft_switch_assignment_mode(self.h, _p(to_full_copy))
+
+    def assignment(self):
+        persist, send = np.zeros(self.G, np.uint32), np.zeros((self.R, self.G), np.uint32)
+        lib().orc_craft_assignment(self.h, _p(persist), _p(send))
+        return persist, send
+
+    def dump_craft(self):
+        R, G = self.R, self.G
+        out = dict(full_copy_mode=np.zeros(G, np.uint8), peer_alive=np.zeros(G, np.uint8), hb_replied=np.zeros((R, G), np.uint64),
+                   hb_seen=np.zeros((R, G), np.uint64), hb_repeat=np.zeros((R, G), np.uint8))
+        lib().orc_craft_dump(self.h, *[_p(out[k]) for k in ("full_copy_mode", "peer_alive", "hb_replied", "hb_seen", "hb_repeat")])
+        return out
+
 
 
 class EpOracle:

@@ -21,6 +21,14 @@
  *   handle_msg_request_vote             messages.rs:391-482
  *   handle_msg_request_vote_reply       messages.rs:485-510
  *   bcast_heartbeats                    leadership.rs:182-218
+ * and, for the CRaft leader variant (orc_craft_*; src/protocols/craft/ is a fork of raft/ -- only the leader's
+ * reply / heartbeat path of the fork is restated, on a leader that created every entry of its log itself):
+ *   handle_msg_append_entries_reply     craft/messages.rs:256-404  (no stale-success test, the
+ *                                       `majority + fault_tolerance` / full-copy commit rule :301-313)
+ *   bcast_heartbeats + fallback check   craft/leadership.rs:249-291
+ *   switch_assignment_mode              craft/leadership.rs:80-141
+ *   shard assignment of an entry        craft/request.rs:71-100, craft/messages.rs:416-460
+ *   Heartbeater reply counters          server/heartbeat.rs:117-119,240-296 (update_bcast_cnts, update_heard_cnt)
  * WAL completions are inline (LS-1 rule 0); timers, the WAL file
  * offsets and the `external` reply flag of entries are not modelled.
  * Deliberately literal (forward loops over the log tail exactly as written).
@@ -52,6 +60,11 @@ typedef struct {
     uint64_t n_committed, n_redirect, n_reject, n_sent;
     uint64_t n_exec, n_trunc; /* follower: entries submitted for execution, log truncations */
     uint32_t ae_first[MAXR];  /* first slot sent to each peer during the current append call (NONE32 = nothing) */
+    /* CRaft leader variant */
+    uint8_t craft, fault_tolerance, full_copy_mode, repeat_threshold;
+    uint8_t peer_alive;       /* heartbeat.rs:57 Bitmap, bit p; starts all true (:131) */
+    uint64_t hb_replied[MAXR], hb_seen[MAXR];   /* heartbeat.rs:52 reply_cnts .0 / .1, start (1, 0, 0) (:117-119) */
+    uint8_t hb_repeat[MAXR];                    /* .2 */
 } RaftRep;
 
 typedef struct {
@@ -183,12 +196,20 @@ static uint64_t term_at(const RaftRep *r, uint32_t slot, uint32_t W, int *ok) {
     return r->log_term[slot - r->start_slot];
 }
 
-/* messages.rs:222-388 */
+/* heartbeat.rs:280-296 */
+static void update_heard_cnt(RaftRep *r, uint8_t peer) {
+    r->hb_replied[peer] += 1;
+    if (!((r->peer_alive >> peer) & 1)) r->peer_alive |= (uint8_t)(1u << peer);
+}
+
+/* messages.rs:222-388; CRaft: craft/messages.rs:256-404 */
 static void handle_msg_append_entries_reply(RaftRep *r, uint32_t W, uint8_t peer, uint64_t term, uint32_t end_slot,
                                             int has_conflict, uint64_t conflict_term, uint32_t conflict_slot) {
     if (check_term(r, peer, term) || r->role != ROLE_LEADER) return;   /* :239-241 */
+    if (r->craft) update_heard_cnt(r, peer);               /* craft/messages.rs:275 heard_heartbeat -> leadership.rs:300-303 */
     if (!has_conflict) {
-        if (r->next_slot[peer] > end_slot + 1) return;     /* :245-247 */
+        /* raft :245-247; the fork only debug_asserts it (craft/messages.rs:279): a release build goes on */
+        if (!r->craft && r->next_slot[peer] > end_slot + 1) return;
         r->next_slot[peer] = end_slot + 1;
         if (r->try_next_slot[peer] < end_slot + 1) r->try_next_slot[peer] = end_slot + 1;
         r->match_slot[peer] = end_slot;
@@ -199,8 +220,15 @@ static void handle_msg_append_entries_reply(RaftRep *r, uint32_t W, uint8_t peer
             int match_cnt = 1;
             for (int q = 0; q < r->population; q++)
                 if (q != r->id && r->match_slot[q] >= slot) match_cnt++;
-            if (match_cnt >= r->commit_thresh) new_commit = slot;
+            if (!r->craft) {
+                if (match_cnt >= r->commit_thresh) new_commit = slot;
+            } else if ((!r->full_copy_mode && match_cnt >= r->quorum_cnt + r->fault_tolerance) ||
+                       (r->full_copy_mode && match_cnt >= r->quorum_cnt)) {   /* craft/messages.rs:307-313 */
+                new_commit = slot;
+            }
         }
+        /* craft/messages.rs:315-358: the leader holds every shard of an entry it created itself (request.rs:71-76,
+         * 113-119), so avail_shards() >= majority and every slot up to new_commit is submitted (can_execute stays) */
         r->n_committed += new_commit - r->last_commit;     /* :278-293 exec submission */
         r->last_commit = new_commit;                       /* :295 */
         for (uint32_t slot = r->last_snap + 1; slot <= end_slot; slot++) {   /* :298-309 */
@@ -460,5 +488,116 @@ void orc_raft_counters(void *h, uint64_t out[4]) {
     for (uint32_t g = 0; g < cl->G; g++) {
         out[0] += cl->reps[g].n_committed; out[1] += cl->reps[g].n_redirect;
         out[2] += cl->reps[g].n_reject; out[3] += cl->reps[g].n_sent;
+    }
+}
+
+/* ---- CRaft leader variant ------------------------------------------------ */
+
+/* turn every group's leader into a CRaft leader: craft/mod.rs:573 (full_copy_mode false), heartbeat.rs:117-131 */
+void orc_craft_enable(void *h, uint8_t fault_tolerance, uint8_t repeat_threshold) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++) {
+        RaftRep *r = &cl->reps[g];
+        r->craft = 1; r->fault_tolerance = fault_tolerance; r->repeat_threshold = repeat_threshold;
+        r->full_copy_mode = 0;
+        r->peer_alive = (uint8_t)((1u << cl->R) - 1u);
+        for (int p = 0; p < cl->R; p++) {
+            r->hb_replied[p] = p == r->id ? 0 : 1; r->hb_seen[p] = 0; r->hb_repeat[p] = 0;
+        }
+    }
+}
+
+/* craft/leadership.rs:80-141 (state effect; the re-send it once did is commented out there) */
+static void switch_assignment_mode(RaftRep *r, int to_full_copy) {
+    if (r->full_copy_mode == (uint8_t)to_full_copy) return;
+    r->full_copy_mode = (uint8_t)to_full_copy;
+}
+
+/* to_full[g]: 0 / 1, anything else = no call for the group */
+void orc_craft_switch_assignment_mode(void *h, const uint8_t *to_full) {
+    RaftCl *cl = (RaftCl *)h;
+    for (uint32_t g = 0; g < cl->G; g++)
+        if (to_full[g] <= 1) switch_assignment_mode(&cl->reps[g], to_full[g]);
+}
+
+/* heartbeat.rs:240-276 */
+static int update_bcast_cnts(RaftRep *r) {
+    int peer_death = 0;
+    for (int peer = 0; peer < r->population; peer++) {
+        if (peer == r->id) continue;
+        if (r->hb_replied[peer] > r->hb_seen[peer]) {
+            r->hb_seen[peer] = r->hb_replied[peer];
+            r->hb_repeat[peer] = 0;
+        } else {
+            r->hb_repeat[peer] += 1;
+            if (r->hb_repeat[peer] > r->repeat_threshold) {
+                if ((r->peer_alive >> peer) & 1) {
+                    r->peer_alive &= (uint8_t)~(1u << peer);
+                    peer_death = 1;
+                }
+                r->hb_repeat[peer] = 0;
+            }
+        }
+    }
+    return peer_death;
+}
+
+/* craft/leadership.rs:249-291, on the send tick (only a leader's Heartbeater ticks: leadership.rs:65,217).
+ * hb_flags[R][G]: 1 = a heartbeat goes to that peer (prev_slot, prev_term [R][G]; leader_commit, last_snap [G]) */
+void orc_craft_bcast_heartbeats(void *h, uint8_t *hb_flags, uint32_t *prev_slot, uint64_t *prev_term,
+                                uint32_t *leader_commit, uint32_t *last_snap) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        leader_commit[g] = r->last_commit; last_snap[g] = r->last_snap;
+        for (int p = 0; p < cl->R; p++) {
+            size_t o = (size_t)p * G + g;
+            hb_flags[o] = 0; prev_slot[o] = 0; prev_term[o] = 0;
+        }
+        if (r->role != ROLE_LEADER) continue;
+        for (int peer = 0; peer < r->population; peer++) {       /* :252-273 */
+            if (peer == r->id) continue;
+            uint32_t ps = r->try_next_slot[peer] - 1;
+            if (ps > log_end(r) - 1) ps = log_end(r) - 1;
+            int ok; uint64_t pt = term_at(r, ps, cl->W, &ok);
+            if (!ok) continue;                                   /* out of the term ring (harness) */
+            size_t o = (size_t)peer * G + g;
+            hb_flags[o] = 1; prev_slot[o] = ps; prev_term[o] = pt;
+        }
+        (void)update_bcast_cnts(r);                              /* :277 */
+        /* :280 heard_heartbeat(self.id): nothing for peer == id (:300) */
+        int alive = 0;
+        for (int p = 0; p < r->population; p++) alive += (r->peer_alive >> p) & 1;
+        if (!r->full_copy_mode && r->population - alive >= r->fault_tolerance) switch_assignment_mode(r, 1);   /* :283-288 */
+    }
+}
+
+/* Which shards of a new entry's codeword go where (bitmask over shard indices):
+ * persist[g]: what the leader's WAL entry holds (craft/request.rs:86-100): full copy = the data shards 0..majority,
+ * else its own shard; send[R][G]: what an AppendEntries to peer p carries (craft/messages.rs:420-460,
+ * durability.rs:44-70): full copy = the data shards, else shard p */
+void orc_craft_assignment(void *h, uint32_t *persist, uint32_t *send) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        uint32_t data = (1u << r->quorum_cnt) - 1u;
+        persist[g] = r->full_copy_mode ? data : (1u << r->id);
+        for (int p = 0; p < cl->R; p++) send[(size_t)p * G + g] = p == r->id ? 0 : (r->full_copy_mode ? data : (1u << p));
+    }
+}
+
+void orc_craft_dump(void *h, uint8_t *full_copy_mode, uint8_t *peer_alive, uint64_t *hb_replied, uint64_t *hb_seen,
+                    uint8_t *hb_repeat) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        full_copy_mode[g] = r->full_copy_mode; peer_alive[g] = r->peer_alive;
+        for (int p = 0; p < cl->R; p++) {
+            size_t o = (size_t)p * G + g;
+            hb_replied[o] = r->hb_replied[p]; hb_seen[o] = r->hb_seen[p]; hb_repeat[o] = r->hb_repeat[p];
+        }
     }
 }

@@ -182,6 +182,11 @@ SYMBOLS = [
     ("smr_raft_replica_dump_votes", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_leader_append_emit", _i, [_vp, _vp, _vp, _vp]),
     ("smr_raft_leader_gather_entries", _i, [_vp, _vp, C.POINTER(RaftAppendEntries), _vp]),
+    ("smr_raft_craft_enable", _i, [_vp, _u8, _u8]),
+    ("smr_raft_craft_bcast_heartbeats", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_craft_switch_assignment_mode", _i, [_vp, _vp, _vp]),
+    ("smr_raft_craft_assignment", _i, [_vp, _vp, _vp, _vp]),
+    ("smr_raft_craft_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),
     ("smr_ep_replica_destroy", None, [_vp]),
     ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),

@@ -37,6 +37,15 @@ struct RaftView {
     unsigned long long *counters;                       // commits, redirects, rejects, entries sent
 };
 
+// CRaft leader variant (src/protocols/craft/, a fork of raft/): the fall-back flag of craft/mod.rs:283 and the
+// Heartbeater's reply counters (server/heartbeat.rs:52-57) per group; only kernels of the variant see it
+struct CraftView {
+    uint32_t ft, rep_thr, quorum;
+    uint8_t *full_copy, *alive;                          // [G]; alive = peer_alive bitmap
+    uint8_t *hb_repeat;                                  // [R][G] reply_cnts.2
+    uint64_t *hb_replied, *hb_seen;                      // [R][G] reply_cnts.0 / .1
+};
+
 __device__ __forceinline__ void raft_flush(const RaftView &v, unsigned int c[4]) {
     for (int k = 0; k < 4; k++) {
         unsigned int x = c[k];
@@ -93,15 +102,21 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
     raft_flush(v, c);
 }
 
+// CRAFT: craft/messages.rs:256-404 -- every reply a leader takes also counts as a heard heartbeat (:275 ->
+// heartbeat.rs:280-296), a success reply is not tested for staleness (:279 is a debug_assert; a release build goes
+// on), and the commit rule is `majority + fault_tolerance` matches, `majority` in full-copy mode (:307-313)
+template <bool CRAFT>
 __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, const uint64_t *__restrict__ reply_term,
                                                            const uint32_t *__restrict__ end_slot,
                                                            const uint64_t *__restrict__ conflict_term,
                                                            const uint32_t *__restrict__ conflict_slot,
                                                            const uint8_t *__restrict__ flags,
-                                                           const uint32_t *__restrict__ order) {
+                                                           const uint32_t *__restrict__ order, const CraftView cv) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
     if (g < v.G) {
+        uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
+        if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
         uint32_t role = v.role[g], leader = v.leader[g];
         uint64_t term = v.curr_term[g];
         const uint32_t len = v.log_len[g], start = v.start_slot[g], rlo = v.ring_lo[g];
@@ -134,20 +149,21 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
             }
             if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
+            if (CRAFT) heard |= 1u << p;
             // registers indexed by a runtime peer id: unrolled select
             uint32_t nxp = 0, tnp = 0;
 #pragma unroll
             for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nxp = nx[q]; tnp = tn[q]; }
             uint32_t mtp;
             if (!(f & 2)) {
-                if (nxp > es + 1) continue;                     // :245-247
+                if (!CRAFT && nxp > es + 1) continue;           // :245-247
                 nxp = es + 1;
                 if (tnp < es + 1) tnp = es + 1;
                 mtp = es;
 #pragma unroll
                 for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
                 // commit index, closed form of :256-275
-                const uint32_t need = v.thresh - 1;             // peers needed besides me
+                const uint32_t need = CRAFT ? commit_need : v.thresh - 1;   // peers needed besides me
                 uint32_t m = 0xFFFFFFFFu;
                 if (need > 0) {
                     m = 0;
@@ -212,8 +228,71 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 size_t o = (size_t)p * v.G + g;
                 v.next_slot[o] = nx[p]; v.try_next_slot[o] = tn[p]; v.match_slot[o] = mt[p];
             }
+        if (CRAFT && heard) {                                   // heartbeat.rs:284-290 update_heard_cnt
+            for (uint32_t p = 0; p < v.R; p++)
+                if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
+            const uint32_t al = cv.alive[g];
+            if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
+        }
     }
     raft_flush(v, c);
+}
+
+// craft/leadership.rs:249-291 bcast_heartbeats on a leader's send tick: the empty AppendEntries per peer (:252-273),
+// Heartbeater::update_bcast_cnts (heartbeat.rs:240-276), then the fall-back test (:283-288)
+__global__ __launch_bounds__(256) void craft_heartbeat_kernel(const RaftView v, const CraftView cv, uint8_t *__restrict__ hb_flags,
+                                                              uint32_t *__restrict__ prev_slot, uint64_t *__restrict__ prev_term,
+                                                              uint32_t *__restrict__ leader_commit,
+                                                              uint32_t *__restrict__ last_snap) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    leader_commit[g] = v.last_commit[g]; last_snap[g] = v.last_snap[g];
+    const bool sending = v.role[g] == ROLE_LEADER;            // only a leader's Heartbeater ticks (leadership.rs:65,217)
+    const uint32_t len = v.log_len[g], start = v.start_slot[g], rlo = v.ring_lo[g];
+    uint32_t alive = cv.alive[g];
+    const uint32_t o_alive = alive;
+    for (uint32_t p = 0; p < v.R; p++) {
+        const size_t o = (size_t)p * v.G + g;
+        uint8_t f = 0; uint32_t ps = 0; uint64_t pt = 0;
+        if (sending && p != v.me) {
+            ps = v.try_next_slot[o] - 1;
+            if (ps > len - 1) ps = len - 1;
+            if (ps >= start && ps >= rlo) { f = 1; pt = v.entry_term[(size_t)(ps & v.Wmask) * v.G + g]; } else { ps = 0; }
+            const uint64_t c0 = cv.hb_replied[o], c1 = cv.hb_seen[o];
+            uint32_t rep = cv.hb_repeat[o];
+            if (c0 > c1) {
+                cv.hb_seen[o] = c0;
+                if (rep) cv.hb_repeat[o] = 0;
+            } else {
+                rep += 1;
+                if (rep > cv.rep_thr) { alive &= ~(1u << p); rep = 0; }
+                cv.hb_repeat[o] = (uint8_t)rep;
+            }
+        }
+        hb_flags[o] = f; prev_slot[o] = ps; prev_term[o] = pt;
+    }
+    if (!sending) return;
+    if (alive != o_alive) cv.alive[g] = (uint8_t)alive;
+    if (!cv.full_copy[g] && v.R - (uint32_t)__popc(alive) >= cv.ft) cv.full_copy[g] = 1;   // switch_assignment_mode(true)
+}
+
+// switch_assignment_mode (craft/leadership.rs:80-141; to_full NULL = no call) and the shard assignment of a new entry:
+// persist = what the leader's WAL entry holds (craft/request.rs:86-100), send[p] = what an AppendEntries to p carries
+// (craft/durability.rs:41-80, messages.rs:416-460): the data shards 0..majority in full-copy mode, else one's own shard
+__global__ __launch_bounds__(256) void craft_mode_kernel(const RaftView v, const CraftView cv, const uint8_t *__restrict__ to_full,
+                                                         uint32_t *__restrict__ persist, uint32_t *__restrict__ send) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    uint32_t full = cv.full_copy[g];
+    if (to_full) {
+        const uint32_t t = to_full[g];
+        if (t <= 1 && t != full) { full = t; cv.full_copy[g] = (uint8_t)t; }
+    }
+    if (persist) {
+        const uint32_t data = (1u << cv.quorum) - 1u;
+        persist[g] = full ? data : (1u << v.me);
+        for (uint32_t p = 0; p < v.R; p++) send[(size_t)p * v.G + g] = p == v.me ? 0u : (full ? data : (1u << p));
+    }
 }
 
 // ---- follower side and elections ------------------------------------------------------------
@@ -460,6 +539,9 @@ struct smr_raft_leader {
     smr_raft_cfg cfg;
     RaftView v;
     Arena arena;
+    bool craft = false;
+    CraftView cv;
+    uint8_t *craft_base = nullptr;
 };
 
 namespace smr {
@@ -527,6 +609,7 @@ int smr_raft_leader_create(const smr_raft_cfg *cfg, smr_raft_leader **out) {
 void smr_raft_leader_destroy(smr_raft_leader *l) {
     if (!l) return;
     if (l->arena.base) (void)hipFree(l->arena.base);
+    if (l->craft_base) (void)hipFree(l->craft_base);
     delete l;
 }
 
@@ -542,9 +625,81 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
                                    const uint64_t *conflict_term_dev, const uint32_t *conflict_slot_dev,
                                    const uint8_t *flags_dev, const uint32_t *order_dev, void *stream) {
     if (!l || !reply_term_dev || !end_slot_dev || !flags_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    hipLaunchKernelGGL(raft_replies_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
-                       reply_term_dev, end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev);
+    if (l->craft)
+        hipLaunchKernelGGL(raft_replies_kernel<true>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                           reply_term_dev, end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, l->cv);
+    else
+        hipLaunchKernelGGL(raft_replies_kernel<false>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                           reply_term_dev, end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, CraftView{});
     SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t repeat_threshold) {
+    if (!l) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (l->craft) return fail(SMR_ERR_ARG, "craft: already enabled");
+    const uint32_t R = l->v.R, quorum = R / 2 + 1;
+    if (fault_tolerance > R - quorum) return fail(SMR_ERR_ARG, "craft: fault_tolerance too large");   // craft/mod.rs:528-533
+    const size_t G = l->v.G;
+    const size_t n8 = (R * G * 8 + 255) & ~(size_t)255, n1 = (R * G + 255) & ~(size_t)255, ng = (G + 255) & ~(size_t)255;
+    const size_t total = 2 * n8 + n1 + 2 * ng;
+    SMR_HIP_TRY(hipMalloc((void **)&l->craft_base, total));
+    SMR_HIP_TRY(hipMemset(l->craft_base, 0, total));
+    CraftView &cv = l->cv;
+    uint8_t *b = l->craft_base;
+    cv.hb_replied = (uint64_t *)b; b += n8; cv.hb_seen = (uint64_t *)b; b += n8;
+    cv.hb_repeat = b; b += n1; cv.full_copy = b; b += ng; cv.alive = b;
+    cv.ft = fault_tolerance; cv.rep_thr = repeat_threshold; cv.quorum = quorum;
+    std::vector<uint64_t> one(R * G, 1);                      // heartbeat.rs:117-119 reply_cnts start at (1, 0, 0)
+    for (size_t g = 0; g < G; g++) one[(size_t)l->v.me * G + g] = 0;
+    SMR_HIP_TRY(hipMemcpy(cv.hb_replied, one.data(), R * G * 8, hipMemcpyHostToDevice));
+    SMR_HIP_TRY(hipMemset(cv.alive, (int)((1u << R) - 1u), G));   // heartbeat.rs:131
+    l->v.thresh = quorum + fault_tolerance;
+    l->craft = true;
+    return SMR_OK;
+}
+
+int smr_raft_craft_switch_assignment_mode(smr_raft_leader *l, const uint8_t *to_full_dev, void *stream) {
+    if (!l || !to_full_dev) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this leader");
+    hipLaunchKernelGGL(craft_mode_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv, to_full_dev,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_assignment(smr_raft_leader *l, uint32_t *persist_dev, uint32_t *send_dev, void *stream) {
+    if (!l || !persist_dev || !send_dev) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this leader");
+    hipLaunchKernelGGL(craft_mode_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv,
+                       (const uint8_t *)nullptr, persist_dev, send_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_bcast_heartbeats(smr_raft_leader *l, uint8_t *hb_flags_dev, uint32_t *prev_slot_dev, uint64_t *prev_term_dev,
+                                    uint32_t *leader_commit_dev, uint32_t *last_snap_dev, void *stream) {
+    if (!l || !hb_flags_dev || !prev_slot_dev || !prev_term_dev || !leader_commit_dev || !last_snap_dev)
+        return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this leader");
+    hipLaunchKernelGGL(craft_heartbeat_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv,
+                       hb_flags_dev, prev_slot_dev, prev_term_dev, leader_commit_dev, last_snap_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_dump(smr_raft_leader *l, uint8_t *full_copy_host, uint8_t *alive_host, uint64_t *hb_replied_host,
+                        uint64_t *hb_seen_host, uint8_t *hb_repeat_host) {
+    if (!l || !full_copy_host || !alive_host || !hb_replied_host || !hb_seen_host || !hb_repeat_host)
+        return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this leader");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const size_t G = l->v.G, R = l->v.R;
+    SMR_HIP_TRY(hipMemcpy(full_copy_host, l->cv.full_copy, G, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(alive_host, l->cv.alive, G, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(hb_replied_host, l->cv.hb_replied, R * G * 8, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(hb_seen_host, l->cv.hb_seen, R * G * 8, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(hb_repeat_host, l->cv.hb_repeat, R * G, hipMemcpyDeviceToHost));
     return SMR_OK;
 }
 

@@ -150,3 +150,48 @@ class RaftLeaderGroup:
         check(self._L.smr_raft_replica_dump_votes(self._h, *[r[k].ctypes.data_as(C.c_void_p)
                                                               for k in ("voted_for", "votes", "n_exec", "n_trunc")]))
         return r
+
+
+class CRaftLeaderGroup(RaftLeaderGroup):
+    """The leader of `CRaftReplica` (src/protocols/craft/, a fork of raft/): Raft's match-index quorum with the
+    `majority + fault_tolerance` commit rule (craft/messages.rs:301-313), the full-copy fall-back mode
+    (`switch_assignment_mode`, craft/leadership.rs:80-141) that `bcast_heartbeats` enters when the Heartbeater's reply
+    counters (server/heartbeat.rs:240-296) say `fault_tolerance` or more peers are gone (craft/leadership.rs:283-288),
+    and the shard assignment of a new entry's RS codeword (craft/request.rs:71-100; the shards themselves:
+    `rscoding.RSCodeword`).  Leader side only: every entry of the log was created by this leader."""
+
+    def __init__(self, n_groups, population=5, leader_id=0, window=64, term=1, fault_tolerance=1, repeat_threshold=3):
+        super().__init__(n_groups, population, leader_id, window, term, commit_extra=0)
+        self.fault_tolerance = int(fault_tolerance)
+        check(self._L.smr_raft_craft_enable(self._h, self.fault_tolerance, int(repeat_threshold)))
+
+    def bcast_heartbeats(self, device, stream=None):
+        """the send tick: {hb_flags, prev_slot, prev_term} [R, G], {leader_commit, last_snap} [G]"""
+        import torch
+        R, G = self.R, self.G
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        m = dict(hb_flags=z((R, G), torch.uint8), prev_slot=z((R, G), torch.int32), prev_term=z((R, G), torch.int64),
+                 leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
+        check(self._L.smr_raft_craft_bcast_heartbeats(self._h, _ptr(m["hb_flags"]), _ptr(m["prev_slot"]), _ptr(m["prev_term"]),
+                                                      _ptr(m["leader_commit"]), _ptr(m["last_snap"]), self._stream(stream)))
+        return m
+
+    def switch_assignment_mode(self, to_full_copy, stream=None):
+        """to_full_copy[g] (uint8): 0 / 1, anything else = no call for that group"""
+        check(self._L.smr_raft_craft_switch_assignment_mode(self._h, _ptr(to_full_copy), self._stream(stream)))
+
+    def assignment(self, device, stream=None):
+        """shard masks of a new entry: persist [G] (the leader's WAL entry), send [R, G] (AppendEntries per peer)"""
+        import torch
+        persist = torch.zeros(self.G, dtype=torch.int32, device=device)
+        send = torch.zeros((self.R, self.G), dtype=torch.int32, device=device)
+        check(self._L.smr_raft_craft_assignment(self._h, _ptr(persist), _ptr(send), self._stream(stream)))
+        return persist, send
+
+    def dump_craft(self):
+        R, G = self.R, self.G
+        out = dict(full_copy_mode=np.zeros(G, np.uint8), peer_alive=np.zeros(G, np.uint8), hb_replied=np.zeros((R, G), np.uint64),
+                   hb_seen=np.zeros((R, G), np.uint64), hb_repeat=np.zeros((R, G), np.uint8))
+        check(self._L.smr_raft_craft_dump(self._h, *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                                     ("full_copy_mode", "peer_alive", "hb_replied", "hb_seen", "hb_repeat")]))
+        return out

@@ -52,6 +52,16 @@ def test_raft_kernels_on_the_host(sim, oracle):
         t.test_closed_loop_cluster_matches_oracle("cpu", oracle)
 
 
+def test_craft_leader_kernels_on_the_host(sim, oracle):
+    """the CRaft leader variant (a15): reply kernel with the fork's rules, heartbeat tick with the reply counters and the
+    full-copy fall-back, mode switches, shard assignment + the RS kernels"""
+    import test_zz_craft_gpu as t
+    with sim.patched():
+        t.test_craft_leader_fallback_and_commit_rule("cpu", oracle)
+        t.test_craft_leader_step_down_and_other_populations("cpu", oracle)
+        t.test_craft_entry_shards_follow_the_assignment("cpu", oracle)
+
+
 def test_epaxos_execution_kernel_on_the_host(sim, oracle):
     import test_zz_ep_exec_gpu as t
     with sim.patched():
