@@ -699,6 +699,47 @@ int smr_batcher_pending(smr_batcher *b, uint64_t *n);
 int64_t smr_batcher_tick(smr_batcher *b, uint32_t *groups, uint32_t *counts, uint64_t *off, uint32_t max_groups, uint8_t *bytes,
                          uint64_t cap);
 
+/* ---- MultiPaxos near quorum reads -------------------------------------
+ * One replica per group, G groups.  Replaces MultiPaxosReplica::{refresh_highest_slot, inspect_highest_slot,
+ * handle_msg_read_query, handle_msg_read_query_reply} (multipaxos/quorumread.rs:8-26, 30-73, 75-188, 190-346) and the
+ * ReadQueryBookkeeping set-up of treat_read_only_reqs (request.rs:55-101).  Model: keys are integers < n_keys, a value
+ * is a 32-bit token (0 = none), a request batch = its Put keys + the token they write; an outstanding query
+ * (client, request id) is an index q < n_queries.  Option<(slot, Option<value>)> = (state, slot, val) with state
+ * 0 None, 1 Some((slot, None)), 2 Some((slot, Some(val))).  All device arrays are [..][G], group fastest. */
+typedef struct smr_qread smr_qread;
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population, replica_id, n_keys, max_reads;   /* max_reads = longest Get list of one ReadQuery */
+    uint32_t n_queries;
+} smr_qread_cfg;
+typedef struct { uint8_t *state; uint32_t *slot, *val; } smr_qread_replies;   /* [max_reads][G], or [R][max_reads][G] */
+/* the replica's log as inspect_highest_slot sees it: start_slot, insts.len() [G]; status (Status as u8: Committed = 3)
+ * and batch token per slot, rings [window][G] indexed by slot % window */
+typedef struct { const uint32_t *start_slot, *log_len; const uint8_t *status; const uint32_t *token; uint32_t window; } smr_qread_log;
+int smr_qread_create(const smr_qread_cfg *cfg, smr_qread **out);
+void smr_qread_destroy(smr_qread *h);
+/* refresh_highest_slot for the batch saved into slot[g] (0xFFFFFFFF = no batch): put_keys[max_reads][G], 0xFF = not a Put */
+int smr_qread_refresh_highest_slot(smr_qread *h, const uint32_t *slot_dev, const uint8_t *put_keys_dev, void *stream);
+/* handle_msg_read_query: n[g] Gets on keys[max_reads][G] (n = 0: no message).  stable_leader[G] (may be NULL) != 0: the
+ * replica is a stable leased leader and answers from the state machine kv[n_keys][G] (from_leader = 1); else every key
+ * is answered by inspect_highest_slot. */
+int smr_qread_handle_read_query(smr_qread *h, const uint8_t *keys_dev, const uint8_t *n_dev, const uint8_t *stable_leader_dev,
+                                const uint32_t *kv_dev, const smr_qread_log *log, const smr_qread_replies *out,
+                                uint8_t *from_leader_dev, void *stream);
+/* the issuer's bookkeeping of query q (request.rs:62-101): n[g] reads (0 = none issued), own = its own
+ * inspect_highest_slot answers (what smr_qread_handle_read_query returns without stable_leader) */
+int smr_qread_issue(smr_qread *h, uint32_t q, const uint8_t *n_dev, const smr_qread_replies *own, void *stream);
+/* handle_msg_read_query_reply, one reply per (peer, group) to query q: replies [R][max_reads][G], flags[R][G] bit0 a
+ * reply is there, bit1 from_leader; peers in order[g] order (ackctl encoding, NULL = identity).  When the query is
+ * decided: done[g] = 1 and per read outcome[max_reads][G] 1 = not found, 2 = retry on the slow path (ApiReply::rq_retry),
+ * 3 = out_val; 0 elsewhere. */
+int smr_qread_handle_replies(smr_qread *h, uint32_t q, const smr_qread_replies *replies, const uint8_t *flags_dev,
+                             const uint32_t *order_dev, uint8_t *outcome_dev, uint32_t *out_val_dev, uint8_t *done_dev, void *stream);
+/* host arrays: highest_slot[n_keys][G] (0xFFFFFFFF = never seen); live, n, rq_acks [n_queries][G]; max_replies as
+ * state / slot / val [n_queries][max_reads][G]; counters[4] = values returned, retries, not found, conflicting values */
+int smr_qread_dump(smr_qread *h, uint32_t *highest_slot_host, uint8_t *live_host, uint8_t *n_host, uint8_t *rq_acks_host,
+                   uint8_t *mx_state_host, uint32_t *mx_slot_host, uint32_t *mx_val_host, uint64_t *counters_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c"]
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c", "qr_oracle.c"]
 
 CTL_IDENTITY = 0x00FAC688
 NO_LEADER = 0xFF
@@ -82,6 +82,13 @@ def _declare(L):
     L.orc_raft_handle_request_vote.argtypes = [vp] + [vp] * 7
     L.orc_raft_handle_vote_replies.argtypes = [vp] + [vp] * 6
     L.orc_raft_dump_votes.argtypes = [vp] + [vp] * 4
+    L.orc_qr_new.restype = vp; L.orc_qr_new.argtypes = [u32, u8, u8, u32, u32, u32]
+    L.orc_qr_free.argtypes = [vp]
+    L.orc_qr_refresh_highest_slot.argtypes = [vp, vp, vp]
+    L.orc_qr_handle_read_query.argtypes = [vp] + [vp] * 8 + [u32] + [vp] * 4
+    L.orc_qr_issue.argtypes = [vp, u32] + [vp] * 4
+    L.orc_qr_handle_replies.argtypes = [vp, u32] + [vp] * 8
+    L.orc_qr_dump.argtypes = [vp] + [vp] * 8
     L.orc_craft_enable.argtypes = [vp, u8, u8]
     L.orc_craft_switch_assignment_mode.argtypes = [vp, vp]
     L.orc_craft_bcast_heartbeats.argtypes = [vp] + [vp] * 5
@@ -599,3 +606,47 @@ class RspOracle:
         order = [n for n, _ in RSP_SCALARS] + ["peer_exec_bar", "digest"] + [n for n, _ in RSP_SLOTS] + ["counters"]
         lib().orc_rsp_dump(self.h, *[_p(d[k]) for k in order])
         return d
+
+
+class QrOracle:
+    """G groups of the literal quorum-read restatement (oracle/qr_oracle.c)"""
+
+    def __init__(self, G, R=5, me=0, K=16, B=4, Q=2):
+        self.G, self.R, self.me, self.K, self.B, self.Q = G, R, me, K, B, Q
+        self.h = lib().orc_qr_new(G, R, me, K, B, Q)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_qr_free(self.h)
+            self.h = None
+
+    def refresh_highest_slot(self, slot, put_keys):
+        assert slot.dtype == np.uint32 and put_keys.dtype == np.uint8 and put_keys.shape == (self.B, self.G)
+        lib().orc_qr_refresh_highest_slot(self.h, _p(slot), _p(put_keys))
+
+    def handle_read_query(self, keys, n, log, stable_leader=None, kv=None):
+        B, G = self.B, self.G
+        out = dict(state=np.zeros((B, G), np.uint8), slot=np.zeros((B, G), np.uint32), val=np.zeros((B, G), np.uint32))
+        fl = np.zeros(G, np.uint8)
+        lib().orc_qr_handle_read_query(self.h, _p(keys), _p(n), _p(stable_leader), _p(kv), _p(log["start_slot"]), _p(log["log_len"]),
+                                       _p(log["status"]), _p(log["token"]), log["status"].shape[0], _p(out["state"]), _p(out["slot"]),
+                                       _p(out["val"]), _p(fl))
+        return out, fl
+
+    def issue(self, q, n, own):
+        lib().orc_qr_issue(self.h, q, _p(n), _p(own["state"]), _p(own["slot"]), _p(own["val"]))
+
+    def handle_replies(self, q, replies, flags, order=None):
+        B, G = self.B, self.G
+        outcome, out_val, done = np.zeros((B, G), np.uint8), np.zeros((B, G), np.uint32), np.zeros(G, np.uint8)
+        lib().orc_qr_handle_replies(self.h, q, _p(replies["state"]), _p(replies["slot"]), _p(replies["val"]), _p(flags), _p(order),
+                                    _p(outcome), _p(out_val), _p(done))
+        return outcome, out_val, done
+
+    def dump(self):
+        G, K, B, Q = self.G, self.K, self.B, self.Q
+        out = dict(highest_slot=np.zeros((K, G), np.uint32), live=np.zeros((Q, G), np.uint8), n=np.zeros((Q, G), np.uint8),
+                   rq_acks=np.zeros((Q, G), np.uint8), mx_state=np.zeros((Q, B, G), np.uint8), mx_slot=np.zeros((Q, B, G), np.uint32),
+                   mx_val=np.zeros((Q, B, G), np.uint32), counters=np.zeros(4, np.uint64))
+        lib().orc_qr_dump(self.h, *[_p(out[k]) for k in ("highest_slot", "live", "n", "rq_acks", "mx_state", "mx_slot", "mx_val", "counters")])
+        return out

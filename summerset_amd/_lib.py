@@ -49,6 +49,20 @@ class MpDumpBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in MP_DUMP_FIELDS]
 
 
+class QreadCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("replica_id", C.c_uint8), ("n_keys", C.c_uint8),
+                ("max_reads", C.c_uint8), ("n_queries", C.c_uint32)]
+
+
+class QreadReplies(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("slot", C.c_void_p), ("val", C.c_void_p)]
+
+
+class QreadLog(C.Structure):
+    _fields_ = [("start_slot", C.c_void_p), ("log_len", C.c_void_p), ("status", C.c_void_p), ("token", C.c_void_p),
+                ("window", C.c_uint32)]
+
+
 class RaftCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("leader_id", C.c_uint8),
                 ("commit_extra", C.c_uint8), ("execute", C.c_uint8), ("window", C.c_uint32),
@@ -246,6 +260,13 @@ SYMBOLS = [
     ("smr_batcher_submit", _i, [_vp, _u32, _u64, _u64, _u8, C.c_char_p, _u32, C.c_char_p, _u32]),
     ("smr_batcher_pending", _i, [_vp, C.POINTER(_u64)]),
     ("smr_batcher_tick", C.c_int64, [_vp, _vp, _vp, _vp, _u32, _vp, _u64]),
+    ("smr_qread_create", _i, [C.POINTER(QreadCfg), C.POINTER(_vp)]),
+    ("smr_qread_destroy", None, [_vp]),
+    ("smr_qread_refresh_highest_slot", _i, [_vp, _vp, _vp, _vp]),
+    ("smr_qread_handle_read_query", _i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(QreadLog), C.POINTER(QreadReplies), _vp, _vp]),
+    ("smr_qread_issue", _i, [_vp, _u32, _vp, C.POINTER(QreadReplies), _vp]),
+    ("smr_qread_handle_replies", _i, [_vp, _u32, C.POINTER(QreadReplies), _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_qread_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

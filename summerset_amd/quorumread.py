@@ -1,0 +1,98 @@
+"""Host-side handle of the batched near-quorum-read path of MultiPaxos (G groups, one replica id).
+
+Mirrors `MultiPaxosReplica`'s quorum-read methods (src/protocols/multipaxos/quorumread.rs): `refresh_highest_slot`
+(:8-26), `inspect_highest_slot` (:30-73), `handle_msg_read_query` (:75-188), `handle_msg_read_query_reply` (:190-346)
+and the `ReadQueryBookkeeping` set-up of `treat_read_only_reqs` (request.rs:55-101).  Thin: every method is one C-ABI
+call on device tensors with one entry per group (include/summerset_hip.h, `smr_qread_*`, for the data model)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import QreadCfg, QreadLog, QreadReplies, check
+
+NONE, SLOT, VALUE = 0, 1, 2                       # Option<(slot, Option<value>)>
+PENDING, NOT_FOUND, RETRY, GOT_VALUE = 0, 1, 2, 3
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class QuorumReadGroup:
+    def __init__(self, n_groups, population=5, replica_id=0, n_keys=16, max_reads=4, n_queries=2):
+        self.G, self.R, self.me = int(n_groups), int(population), int(replica_id)
+        self.K, self.B, self.Q = int(n_keys), int(max_reads), int(n_queries)
+        cfg = QreadCfg(self.G, self.R, self.me, self.K, self.B, self.Q)
+        h = C.c_void_p()
+        self._L = _lib.load()
+        check(self._L.smr_qread_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_qread_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            import torch
+            return torch.cuda.current_stream().cuda_stream
+        return int(stream)
+
+    def _replies(self, lead, device):
+        import torch
+        shape = tuple(lead) + (self.B, self.G)
+        return dict(state=torch.zeros(shape, dtype=torch.uint8, device=device), slot=torch.zeros(shape, dtype=torch.int32, device=device),
+                    val=torch.zeros(shape, dtype=torch.int32, device=device))
+
+    @staticmethod
+    def _rs(d):
+        return QreadReplies(_ptr(d["state"]), _ptr(d["slot"]), _ptr(d["val"]))
+
+    def refresh_highest_slot(self, slot, put_keys, stream=None):
+        """slot[g] (int32, -1 = no batch) gets a batch whose Puts write put_keys[B, g] (uint8, 0xFF = not a Put)"""
+        check(self._L.smr_qread_refresh_highest_slot(self._h, _ptr(slot), _ptr(put_keys), self._stream(stream)))
+
+    def handle_msg_read_query(self, keys, n, log, stable_leader=None, kv=None, stream=None):
+        """log = dict(start_slot, log_len [G] int32; status uint8, token int32 [W, G]).  Returns (replies, from_leader)"""
+        import torch
+        out = self._replies((), keys.device)
+        fl = torch.zeros(self.G, dtype=torch.uint8, device=keys.device)
+        lg = QreadLog(_ptr(log["start_slot"]), _ptr(log["log_len"]), _ptr(log["status"]), _ptr(log["token"]), int(log["status"].shape[0]))
+        rs = self._rs(out)
+        check(self._L.smr_qread_handle_read_query(self._h, _ptr(keys), _ptr(n), _ptr(stable_leader), _ptr(kv), C.byref(lg),
+                                                  C.byref(rs), _ptr(fl), self._stream(stream)))
+        return out, fl
+
+    def inspect_highest_slot(self, keys, n, log, stream=None):
+        return self.handle_msg_read_query(keys, n, log, stream=stream)[0]
+
+    def issue(self, q, n, own, stream=None):
+        rs = self._rs(own)
+        check(self._L.smr_qread_issue(self._h, int(q), _ptr(n), C.byref(rs), self._stream(stream)))
+
+    def handle_msg_read_query_reply(self, q, replies, flags, order=None, stream=None):
+        """replies: dict of [R, B, G] tensors; flags [R, G] (bit0 present, bit1 from_leader).  Returns outcome, out_val [B, G], done [G]"""
+        import torch
+        dev = flags.device
+        outcome = torch.zeros((self.B, self.G), dtype=torch.uint8, device=dev)
+        out_val = torch.zeros((self.B, self.G), dtype=torch.int32, device=dev)
+        done = torch.zeros(self.G, dtype=torch.uint8, device=dev)
+        rs = self._rs(replies)
+        check(self._L.smr_qread_handle_replies(self._h, int(q), C.byref(rs), _ptr(flags), _ptr(order), _ptr(outcome), _ptr(out_val),
+                                               _ptr(done), self._stream(stream)))
+        return outcome, out_val, done
+
+    def dump(self):
+        G, K, B, Q = self.G, self.K, self.B, self.Q
+        out = dict(highest_slot=np.zeros((K, G), np.uint32), live=np.zeros((Q, G), np.uint8), n=np.zeros((Q, G), np.uint8),
+                   rq_acks=np.zeros((Q, G), np.uint8), mx_state=np.zeros((Q, B, G), np.uint8), mx_slot=np.zeros((Q, B, G), np.uint32),
+                   mx_val=np.zeros((Q, B, G), np.uint32), counters=np.zeros(4, np.uint64))
+        check(self._L.smr_qread_dump(self._h, *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                                ("highest_slot", "live", "n", "rq_acks", "mx_state", "mx_slot", "mx_val", "counters")]))
+        return out

@@ -62,6 +62,14 @@ def test_craft_leader_kernels_on_the_host(sim, oracle):
         t.test_craft_entry_shards_follow_the_assignment("cpu", oracle)
 
 
+def test_quorum_read_kernels_on_the_host(sim, oracle):
+    """MultiPaxos near quorum reads (f.4): highest-slot table, responder, the issuer's read-quorum tally"""
+    import test_zz_qread_gpu as t
+    with sim.patched():
+        t.test_quorum_reads_match_oracle("cpu", oracle)
+        t.test_quorum_reads_other_shapes("cpu", oracle)
+
+
 def test_epaxos_execution_kernel_on_the_host(sim, oracle):
     import test_zz_ep_exec_gpu as t
     with sim.patched():
