@@ -570,8 +570,12 @@ int smr_repnothing_stats(smr_repnothing *h, uint64_t *n_insts, uint64_t *wal_off
 #define SMR_WIRE_PREPARE_REPLY 1
 #define SMR_WIRE_ACCEPT 2
 #define SMR_WIRE_ACCEPT_REPLY 3
+#define SMR_WIRE_READ_QUERY 4
+#define SMR_WIRE_READ_QUERY_REPLY 5
+#define SMR_WIRE_HEARTBEAT 6
+#define SMR_WIRE_COMMIT_NOTICE 7
 #define SMR_WIRE_LEAVE 0xFE      /* PeerMessage::Leave */
-#define SMR_WIRE_OTHER 0xFF      /* a frame of another kind (lease, quorum read): skipped */
+#define SMR_WIRE_OTHER 0xFF      /* a frame of another kind (lease traffic): skipped */
 
 /* bincode(ReqBatch) of n Get / Put requests -- the bytes an Accept carries and RSCodeword shards;
  * no frame header.  Arguments as smr_repnothing_submit_batch. */
@@ -586,6 +590,14 @@ int64_t smr_wire_prepare_reply(uint64_t slot, uint64_t trigger_slot, uint64_t en
 int64_t smr_wire_accept(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
                         uint64_t cap);
 int64_t smr_wire_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap);
+/* PeerMsg::ReadQuery { reads }: reads = bincode(ReqBatch) of Gets; ReadQueryReply { rq_id, replies, from_leader } with
+ * replies[i] = state[i] 0 None / 1 Some((slot, None)) / 2 Some((slot, Some(value))) (multipaxos/mod.rs:344-362) */
+int64_t smr_wire_read_query(const uint8_t *reads, uint64_t reads_len, uint8_t *out, uint64_t cap);
+int64_t smr_wire_read_query_reply(uint64_t rq_client, uint64_t rq_req_id, uint32_t n, const uint8_t *state, const uint64_t *slot,
+                                  const char *const *value, const uint32_t *value_len, int from_leader, uint8_t *out, uint64_t cap);
+/* PeerMsg::Heartbeat / CommitNotice (multipaxos/mod.rs:364-378) */
+int64_t smr_wire_heartbeat(uint64_t ballot, uint64_t commit_bar, uint64_t exec_bar, uint64_t snap_bar, uint8_t *out, uint64_t cap);
+int64_t smr_wire_commit_notice(uint64_t ballot, uint64_t commit_bar, uint8_t *out, uint64_t cap);
 /* WalEntry::{PrepareBal, AcceptData, CommitSlot} log records */
 int64_t smr_wal_prepare_bal(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap);
 int64_t smr_wal_accept_data(uint64_t slot, uint64_t ballot, const uint8_t *reqs, uint64_t reqs_len, uint8_t *out,
@@ -596,11 +608,19 @@ typedef struct {
     uint8_t kind;                  /* SMR_WIRE_* */
     uint8_t has_voted;             /* PrepareReply: voted is Some */
     uint64_t slot, ballot, trigger_slot, endprep_slot, accept_bar, voted_ballot;
-    uint64_t reqs_off, reqs_len;   /* Accept / voted: where in the buffer the bincode(ReqBatch) bytes lie */
+    uint64_t reqs_off, reqs_len;   /* Accept / voted / ReadQuery: where in the buffer the bincode(ReqBatch) bytes lie */
+    uint64_t commit_bar, exec_bar, snap_bar;          /* Heartbeat, CommitNotice */
+    uint64_t rq_client, rq_req_id, n_replies;         /* ReadQueryReply */
+    uint64_t replies_off, replies_len;                /* its Vec of replies, for smr_wire_read_query_replies */
+    uint8_t from_leader;
 } smr_wire_msg;
 /* Parses the first TCP frame of buf[0, len): returns the bytes it occupies, 0 if it is not complete
  * yet (safetcp.rs:30-70 reads until it is), < 0 if malformed. */
 int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *out);
+/* unpacks the replies of a decoded ReadQueryReply (p = buf + replies_off, len = replies_len): state / slot per reply and
+ * where its value bytes lie relative to p; returns their number (< 0: malformed, or more than max) */
+int64_t smr_wire_read_query_replies(const uint8_t *p, uint64_t len, uint32_t max, uint8_t *state, uint64_t *slot, uint64_t *value_off,
+                                    uint64_t *value_len);
 
 /* ---- Raft frames (src/protocols/raft/mod.rs:117-234): PeerMsg::{AppendEntries 0, AppendEntriesReply 1,
  * RequestVote 2, RequestVoteReply 3}; DurEntry::Metadata log record */

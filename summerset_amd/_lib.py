@@ -135,7 +135,10 @@ class WireRaftMsg(C.Structure):
 class WireMsg(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("has_voted", C.c_uint8), ("slot", C.c_uint64), ("ballot", C.c_uint64),
                 ("trigger_slot", C.c_uint64), ("endprep_slot", C.c_uint64), ("accept_bar", C.c_uint64),
-                ("voted_ballot", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64)]
+                ("voted_ballot", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64),
+                ("commit_bar", C.c_uint64), ("exec_bar", C.c_uint64), ("snap_bar", C.c_uint64),
+                ("rq_client", C.c_uint64), ("rq_req_id", C.c_uint64), ("n_replies", C.c_uint64),
+                ("replies_off", C.c_uint64), ("replies_len", C.c_uint64), ("from_leader", C.c_uint8)]
 
 
 class WireCodeword(C.Structure):
@@ -236,6 +239,11 @@ SYMBOLS = [
     ("smr_wal_accept_data", C.c_int64, [_u64, _u64, _vp, _u64, _vp, _u64]),
     ("smr_wal_commit_slot", C.c_int64, [_u64, _vp, _u64]),
     ("smr_wire_decode", C.c_int64, [_vp, _u64, C.POINTER(WireMsg)]),
+    ("smr_wire_read_query", C.c_int64, [_vp, _u64, _vp, _u64]),
+    ("smr_wire_read_query_reply", C.c_int64, [_u64, _u64, _u32, _vp, _vp, _vp, _vp, _i, _vp, _u64]),
+    ("smr_wire_heartbeat", C.c_int64, [_u64, _u64, _u64, _u64, _vp, _u64]),
+    ("smr_wire_commit_notice", C.c_int64, [_u64, _u64, _vp, _u64]),
+    ("smr_wire_read_query_replies", C.c_int64, [_vp, _u64, _u32, _vp, _vp, _vp, _vp]),
     ("smr_wire_raft_append_entries", C.c_int64, [_u64, _u64, _u64, C.c_uint32, _vp, _vp, _vp, _vp, _u64, _u64, _vp, _u64]),
     ("smr_wire_raft_append_entries_reply", C.c_int64, [_u64, _u64, _i, _u64, _u64, _vp, _u64]),
     ("smr_wire_raft_request_vote", C.c_int64, [_u64, _u64, _u64, _vp, _u64]),

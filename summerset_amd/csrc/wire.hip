@@ -154,6 +154,66 @@ int64_t smr_wire_accept_reply(uint64_t slot, uint64_t ballot, uint8_t *out, uint
     return frame_done(w, out);
 }
 
+int64_t smr_wire_read_query(const uint8_t *reads, uint64_t reads_len, uint8_t *out, uint64_t cap) {
+    if (!reads || !reads_len) return fail(SMR_ERR_ARG, "wire: null read batch");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_READ_QUERY); w.raw(reads, reads_len);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_read_query_reply(uint64_t rq_client, uint64_t rq_req_id, uint32_t n, const uint8_t *state, const uint64_t *slot,
+                                  const char *const *value, const uint32_t *value_len, int from_leader, uint8_t *out, uint64_t cap) {
+    if (n && (!state || !slot || !value || !value_len)) return fail(SMR_ERR_ARG, "wire: null reply arrays");
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_READ_QUERY_REPLY);
+    w.varint(rq_client); w.varint(rq_req_id);                                     // rq_id: (ClientId, RequestId)
+    w.varint(n);                                                                  // Vec<Option<(usize, Option<String>)>>
+    for (uint32_t i = 0; i < n; i++) {
+        if (state[i] > 2) return fail(SMR_ERR_ARG, "wire: unknown reply state");
+        if (state[i] == 0) { w.byte(0); continue; }
+        w.byte(1); w.varint(slot[i]);
+        if (state[i] == 1) { w.byte(0); continue; }
+        w.byte(1); w.bytes(value[i], value_len[i]);
+    }
+    w.byte(from_leader ? 1 : 0);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_heartbeat(uint64_t ballot, uint64_t commit_bar, uint64_t exec_bar, uint64_t snap_bar, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_HEARTBEAT); w.varint(ballot); w.varint(commit_bar); w.varint(exec_bar); w.varint(snap_bar);
+    return frame_done(w, out);
+}
+
+int64_t smr_wire_commit_notice(uint64_t ballot, uint64_t commit_bar, uint8_t *out, uint64_t cap) {
+    Wr w = frame_begin(out, cap);
+    w.varint(0); w.varint(SMR_WIRE_COMMIT_NOTICE); w.varint(ballot); w.varint(commit_bar);
+    return frame_done(w, out);
+}
+
+// the replies of a decoded ReadQueryReply: p = buf + replies_off, len = replies_len (smr_wire_msg)
+int64_t smr_wire_read_query_replies(const uint8_t *p, uint64_t len, uint32_t max, uint8_t *state, uint64_t *slot, uint64_t *value_off,
+                                    uint64_t *value_len) {
+    if (!p || !state || !slot || !value_off || !value_len) return fail(SMR_ERR_ARG, "wire: null argument");
+    Rd r{p, len};
+    const uint64_t n = r.varint();
+    if (!r.ok || n > max) return fail(SMR_ERR_ARG, "wire: more replies than the caller has room for");
+    for (uint64_t i = 0; i < n && r.ok; i++) {
+        state[i] = 0; slot[i] = 0; value_off[i] = 0; value_len[i] = 0;
+        const uint8_t t = r.byte();
+        if (t == 0) continue;
+        if (t != 1) { r.ok = false; break; }
+        state[i] = 1; slot[i] = r.varint();
+        const uint8_t tv = r.byte();
+        if (tv == 0) continue;
+        if (tv != 1) { r.ok = false; break; }
+        state[i] = 2; value_len[i] = r.varint(); value_off[i] = r.n;
+        r.skip(value_len[i]);
+    }
+    if (!r.ok || r.n != len) return fail(SMR_ERR_ARG, "wire: malformed replies");
+    return (int64_t)n;
+}
+
 int64_t smr_wal_prepare_bal(uint64_t slot, uint64_t ballot, uint8_t *out, uint64_t cap) {
     Wr w = frame_begin(out, cap);
     w.varint(0); w.varint(slot); w.varint(ballot);
@@ -187,7 +247,7 @@ int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *m) {
     if (outer == 2) { m->kind = SMR_WIRE_LEAVE; return (int64_t)(8 + plen); }    // PeerMessage::Leave
     if (outer != 0) { m->kind = SMR_WIRE_OTHER; return (int64_t)(8 + plen); }    // lease traffic: not this path
     const uint64_t v = r.varint();
-    m->kind = (uint8_t)(v <= SMR_WIRE_ACCEPT_REPLY ? v : SMR_WIRE_OTHER);
+    m->kind = (uint8_t)(v <= SMR_WIRE_COMMIT_NOTICE ? v : SMR_WIRE_OTHER);
     switch (v) {
         case SMR_WIRE_PREPARE: m->trigger_slot = r.varint(); m->ballot = r.varint(); break;
         case SMR_WIRE_PREPARE_REPLY: {
@@ -215,7 +275,36 @@ int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *m) {
             else if (ts != 0) r.ok = false;
             break;
         }
-        default: return (int64_t)(8 + plen);                                      // ReadQuery & co: not this path
+        case SMR_WIRE_READ_QUERY: {
+            m->reqs_off = 8 + r.n;
+            if (skip_reqbatch(r)) m->reqs_len = 8 + r.n - m->reqs_off;
+            break;
+        }
+        case SMR_WIRE_READ_QUERY_REPLY: {
+            m->rq_client = r.varint(); m->rq_req_id = r.varint();
+            m->replies_off = 8 + r.n;
+            const uint64_t n = r.varint();
+            m->n_replies = n;
+            for (uint64_t i = 0; i < n && r.ok; i++) {
+                const uint8_t t = r.byte();
+                if (t == 0) continue;
+                if (t != 1) { r.ok = false; break; }
+                r.varint();
+                const uint8_t tv = r.byte();
+                if (tv == 1) r.skip(r.varint());
+                else if (tv != 0) r.ok = false;
+            }
+            m->replies_len = 8 + r.n - m->replies_off;
+            const uint8_t fl = r.byte();
+            if (fl > 1) r.ok = false;
+            m->from_leader = fl;
+            break;
+        }
+        case SMR_WIRE_HEARTBEAT:
+            m->ballot = r.varint(); m->commit_bar = r.varint(); m->exec_bar = r.varint(); m->snap_bar = r.varint();
+            break;
+        case SMR_WIRE_COMMIT_NOTICE: m->ballot = r.varint(); m->commit_bar = r.varint(); break;
+        default: return (int64_t)(8 + plen);                                      // a variant this build does not know
     }
     if (!r.ok || r.n != plen) return fail(SMR_ERR_ARG, "wire: malformed frame");
     return (int64_t)(8 + plen);

@@ -6,7 +6,8 @@ import ctypes as C
 from . import _lib
 from ._lib import WireCodeword, WireEpMsg, WireMsg, WireRaftMsg, WireRspMsg, check
 
-PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, LEAVE, OTHER = 0, 1, 2, 3, 0xFE, 0xFF
+PREPARE, PREPARE_REPLY, ACCEPT, ACCEPT_REPLY, READ_QUERY, READ_QUERY_REPLY, HEARTBEAT, COMMIT_NOTICE = range(8)
+LEAVE, OTHER = 0xFE, 0xFF
 GET, PUT = 0, 1
 
 
@@ -53,6 +54,30 @@ def accept_reply(slot, ballot):
     return _call("smr_wire_accept_reply", slot, ballot)
 
 
+def read_query(reads):
+    """PeerMsg::ReadQuery; reads = reqbatch([... Gets ...])"""
+    return _call("smr_wire_read_query", reads, len(reads), cap=64 + len(reads))
+
+
+def read_query_reply(rq_id, replies, from_leader=False):
+    """replies: [None | (slot, None) | (slot, value)] as `Vec<Option<(usize, Option<String>)>>`"""
+    n = len(replies)
+    b = lambda x: x.encode() if isinstance(x, str) else bytes(x)
+    state = [0 if r is None else (1 if r[1] is None else 2) for r in replies]
+    vals = [b(r[1]) if st == 2 else b"" for r, st in zip(replies, state)]
+    return _call("smr_wire_read_query_reply", rq_id[0], rq_id[1], n, (C.c_uint8 * n)(*state),
+                 (C.c_uint64 * n)(*[0 if r is None else r[0] for r in replies]), (C.c_char_p * n)(*vals),
+                 (C.c_uint32 * n)(*[len(v) for v in vals]), int(from_leader), cap=64 + sum(len(v) + 24 for v in vals))
+
+
+def heartbeat(ballot, commit_bar, exec_bar, snap_bar):
+    return _call("smr_wire_heartbeat", ballot, commit_bar, exec_bar, snap_bar)
+
+
+def commit_notice(ballot, commit_bar):
+    return _call("smr_wire_commit_notice", ballot, commit_bar)
+
+
 def wal_prepare_bal(slot, ballot):
     return _call("smr_wal_prepare_bal", slot, ballot)
 
@@ -75,6 +100,14 @@ def decode(buf):
         return 0, None
     d = {k: getattr(m, k) for k, _ in WireMsg._fields_}
     d["reqs"] = bytes(buf[m.reqs_off:m.reqs_off + m.reqs_len]) if m.reqs_len else b""
+    if m.kind == READ_QUERY_REPLY:
+        k = int(m.n_replies)
+        part = bytes(buf[m.replies_off:m.replies_off + m.replies_len])
+        st, sl, vo, vl = (C.c_uint8 * k)(), (C.c_uint64 * k)(), (C.c_uint64 * k)(), (C.c_uint64 * k)()
+        got = _lib.load().smr_wire_read_query_replies(part, len(part), k, st, sl, vo, vl)
+        if got < 0:
+            check(int(got))
+        d["replies"] = [None if st[i] == 0 else ((sl[i], None) if st[i] == 1 else (sl[i], part[vo[i]:vo[i] + vl[i]])) for i in range(k)]
     return int(n), d
 
 

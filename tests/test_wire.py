@@ -57,6 +57,40 @@ def test_round_trips_and_stream_reassembly():
         assert wire.decode(f[:cut]) == (0, None)
 
 
+def test_quorum_read_heartbeat_and_commit_notice_frames():
+    """PeerMsg variants 4..7 (multipaxos/mod.rs:344-378), bytes worked out by hand from the bincode standard config"""
+    assert wire.heartbeat(0x101, 7, 5, 300) == bytes([0, 0, 0, 0, 0, 0, 0, 10, 0, 6, 0xFB, 0x01, 0x01, 7, 5, 0xFB, 0x2C, 0x01])
+    assert wire.commit_notice(0x101, 9) == bytes([0, 0, 0, 0, 0, 0, 0, 6, 0, 7, 0xFB, 0x01, 0x01, 9])
+    reads = wire.reqbatch([(4, 11, ("get", "a")), (5, 12, ("get", "bc"))])
+    f = wire.read_query(reads)
+    assert f[:8] == (2 + len(reads)).to_bytes(8, "big") and f[8:10] == bytes([0, 4]) and f[10:] == reads
+    # rq_id (4, 11); replies [None, Some((3, None)), Some((260, Some("xy")))]; from_leader false
+    g = wire.read_query_reply((4, 11), [None, (3, None), (260, "xy")])
+    assert g == bytes([0, 0, 0, 0, 0, 0, 0, 18, 0, 5, 4, 11, 3, 0, 1, 3, 0, 1, 0xFB, 0x04, 0x01, 1, 2]) + b"xy" + bytes([0])
+    stream = f + g + wire.read_query_reply((9, 1), [(0, "v")], from_leader=True) + wire.heartbeat(0x202, 1, 2, 3) + wire.commit_notice(0x202, 8)
+    out = []
+    while stream:
+        n, m = wire.decode(stream)
+        assert n > 0
+        out.append(m)
+        stream = stream[n:]
+    assert [m["kind"] for m in out] == [wire.READ_QUERY, wire.READ_QUERY_REPLY, wire.READ_QUERY_REPLY, wire.HEARTBEAT, wire.COMMIT_NOTICE]
+    assert out[0]["reqs"] == reads
+    assert (out[1]["rq_client"], out[1]["rq_req_id"], out[1]["from_leader"]) == (4, 11, 0)
+    assert out[1]["replies"] == [None, (3, None), (260, b"xy")]
+    assert out[2]["from_leader"] == 1 and out[2]["replies"] == [(0, b"v")]
+    assert (out[3]["ballot"], out[3]["commit_bar"], out[3]["exec_bar"], out[3]["snap_bar"]) == (0x202, 1, 2, 3)
+    assert (out[4]["ballot"], out[4]["commit_bar"]) == (0x202, 8)
+    for cut in (0, 5, 8, len(g) - 1):
+        assert wire.decode(g[:cut]) == (0, None)
+    bad = bytearray(g); bad[-1] = 2                         # from_leader is a bool
+    with pytest.raises(SummersetError):
+        wire.decode(bytes(bad))
+    bad = bytearray(g); bad[13] = 3                         # Option tag of the first reply
+    with pytest.raises(SummersetError):
+        wire.decode(bytes(bad))
+
+
 def test_malformed_frames_are_errors():
     f = bytearray(wire.accept_reply(9, 0x101))
     f[-1] = 7                                               # Option tag neither 0 nor 1
