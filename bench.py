@@ -441,6 +441,80 @@ def rspaxos_replica_leg(torch, dev, ticks=32):
             "req_batch_call_us": t_req / ticks * 1e3, "accept_replies_call_us": t_rep / ticks * 1e3, "commits": c[0], "executed": c[1]}
 
 
+def craft_leader_leg(torch, dev, ticks=32):
+    """the CRaft leader variant (raft_replies_kernel<true>, craft_heartbeat_kernel): 65 536 groups, per tick up to 2 new
+    entries per group, the 4 followers' AppendEntriesReplies (5 % lost, one follower of every third group silent), a
+    heartbeat tick every 4th tick.  Opt-in (--late-legs): the kernels have not had a device run yet."""
+    from summerset_amd import CRaftLeaderGroup
+    G, R, W = 65536, 5, 64
+    eng = CRaftLeaderGroup(G, R, 0, W, term=1, fault_tolerance=1, repeat_threshold=2)
+    rng = np.random.default_rng(0xC4AF7)
+    term = torch.ones((R, G), dtype=torch.int64, device=dev)
+    log_len = np.ones(G, np.int64)
+    t_app = t_rep = t_hb = 0.0
+    n_hb = 0
+    for t in range(ticks):
+        n_new = rng.integers(0, 3, G).astype(np.int32)
+        log_len += n_new
+        es = np.maximum(log_len[None, :] - 1 - rng.integers(0, 3, (R, G)), 0).astype(np.int32)
+        fl = (rng.random((R, G)) >= 0.05).astype(np.uint8)
+        fl[0] = 0
+        fl[1, ::3] = 0
+        d_new, d_es, d_fl = torch.from_numpy(n_new).to(dev), torch.from_numpy(es).to(dev), torch.from_numpy(fl).to(dev)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        eng.handle_req_batch(d_new)
+        e[1].record()
+        eng.handle_msg_append_entries_reply(term, d_es, d_fl)
+        e[2].record()
+        if t % 4 == 3:
+            eng.bcast_heartbeats(dev)
+            n_hb += 1
+        e[3].record()
+        torch.cuda.synchronize()
+        t_app += e[0].elapsed_time(e[1]); t_rep += e[1].elapsed_time(e[2]); t_hb += e[2].elapsed_time(e[3]) if t % 4 == 3 else 0.0
+    c = eng.dump_craft()
+    commits = eng.total_commits()
+    return {"workload": "CRaft leader of %d groups x 5 replicas, f = 1: appends + 4 AppendEntriesReplies per tick, heartbeat tick every 4th" % G,
+            "value": commits / ((t_app + t_rep + t_hb) * 1e-3), "unit": "committed entries/s (incl. host call overhead)",
+            "append_call_us": t_app / ticks * 1e3, "replies_call_us": t_rep / ticks * 1e3, "heartbeat_call_us": t_hb / max(n_hb, 1) * 1e3,
+            "commits": commits, "groups_in_full_copy_mode": int(c["full_copy_mode"].sum())}
+
+
+def quorum_read_leg(torch, dev, ticks=32):
+    """MultiPaxos near quorum reads (csrc/qread.hip), the issuer's side: 65 536 groups, per tick one ReadQuery of 4 Gets per
+    group issued and the 4 peers' ReadQueryReplies tallied (10 % lost).  Opt-in (--late-legs): no device run yet."""
+    from summerset_amd import QuorumReadGroup
+    G, R, K, B = 65536, 5, 64, 4
+    eng = QuorumReadGroup(G, R, 0, K, B, 1)
+    rng = np.random.default_rng(0x9EAD)
+    n = torch.full((G,), B, dtype=torch.uint8, device=dev)
+    t_iss = t_rep = 0.0
+    answered = 0
+    for t in range(ticks):
+        st = rng.integers(0, 3, (R, B, G)).astype(np.uint8)
+        sl = rng.integers(1, 50, (R, B, G)).astype(np.int32)
+        rep = dict(state=torch.from_numpy(st).to(dev), slot=torch.from_numpy(sl).to(dev), val=torch.from_numpy(sl * 7).to(dev))
+        own = {k: v[0].contiguous() for k, v in rep.items()}
+        fl = (rng.random((R, G)) >= 0.1).astype(np.uint8)
+        fl[0] = 0
+        d_fl = torch.from_numpy(fl).to(dev)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        eng.issue(0, n, own)
+        e1.record()
+        outcome, val, done = eng.handle_msg_read_query_reply(0, rep, d_fl)
+        e2.record()
+        torch.cuda.synchronize()
+        t_iss += e0.elapsed_time(e1); t_rep += e1.elapsed_time(e2)
+        answered += int(done.sum())
+    c = [int(x) for x in eng.dump()["counters"]]
+    return {"workload": "quorum reads, issuer of %d groups x 5 replicas: one ReadQuery of %d Gets + 4 ReadQueryReplies (10%% lost) per tick" % (G, B),
+            "value": answered * B / ((t_iss + t_rep) * 1e-3), "unit": "reads answered/s (incl. host call overhead)",
+            "issue_call_us": t_iss / ticks * 1e3, "replies_call_us": t_rep / ticks * 1e3, "values": c[0], "retries": c[1], "not_found": c[2],
+            "conflicts": c[3]}
+
+
 def _cpu_run(a):
     """one process, one thread: the CPU oracle on G groups of the bench workload for about `seconds`"""
     slots, window, drop, timeouts, hb_every, G, seconds = a
@@ -495,7 +569,8 @@ def main():
     rank, local, world = shard.env_world()
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
-        legs = {"rspaxos": rspaxos_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg}
+        legs = {"rspaxos": rspaxos_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
+                "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg}
         print(json.dumps(legs[args.leg](torch, torch.device("cuda", local))))
         return
     if not torch.cuda.is_available():
@@ -605,6 +680,8 @@ def main():
             if args.late_legs:
                 leg("epaxos_execution", leg_isolated, "epaxos_execution")
                 leg("rspaxos_replica", leg_isolated, "rspaxos_replica")
+                leg("craft_leader", leg_isolated, "craft_leader")
+                leg("quorum_read", leg_isolated, "quorum_read")
             if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
                 for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
                     if isinstance(line.get(name), dict) and "error" not in line[name]:
