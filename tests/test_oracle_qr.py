@@ -144,3 +144,58 @@ def test_delivery_order_decides_which_replies_count(orc):
     order = np.full(G, 3 | (2 << 3) | (1 << 6) | (0 << 9) | (4 << 12), np.uint32)   # peers 3, 2 first
     outcome, val, done = orc.handle_replies(0, rep, fl, order)
     assert outcome[0].tolist() == [GOT, GOT] and val[0].tolist() == [22, 22]
+
+
+def test_reads_never_miss_an_acknowledged_write(oracle):
+    """the restatement against the optimisation's own safety argument (Charapko et al., HotStorage '19, cited at
+    request.rs:59-61) on logs that are consistent the way MultiPaxos keeps them: one value per slot, a slot is chosen once
+    a majority holds it, a replica marks a slot committed only if it is chosen and it holds it, the leader (replica 0)
+    holds everything.  Whatever a read quorum answers -- any issuer, any 2 other repliers, any delivery order -- a read
+    that returns a value returns the value of the highest slot any member of the quorum has seen for the key, and that
+    slot is not below the highest write the leader has acknowledged (committed); a read that says "not found" implies no
+    acknowledged write to the key.  Reads that cannot tell are sent to the slow path, never answered wrong."""
+    rng = np.random.default_rng(11)
+    G, R, K, B, W, S = 400, 5, 6, 3, 32, 20
+    orcs = [oracle.QrOracle(G, R, r, K, B, 1) for r in range(R)]
+    key_of = rng.integers(0, K + 2, (S, G)); key_of[key_of >= K] = 0xFF        # slot s of group g puts key_of (0xFF: no Put)
+    token = (1000 + np.arange(S)[:, None] * G + np.arange(G)[None, :]).astype(np.uint32)
+    holds = rng.random((R, S, G)) < 0.7; holds[0] = True                        # who accepted which slot
+    chosen = holds.sum(0) >= 3
+    committed = holds & chosen[None] & (rng.random((R, S, G)) < 0.6)
+    for s in range(S):
+        pk = np.full((B, G), 0xFF, np.uint8); pk[0] = key_of[s]
+        for r in range(R):
+            orcs[r].refresh_highest_slot(np.where(holds[r, s], s, NO).astype(np.uint32), pk)
+    tok_ring = np.zeros((W, G), np.uint32); tok_ring[:S] = token
+    checked = {GOT: 0, RETRY: 0, NOT_FOUND: 0}
+    for trial in range(12):
+        keys = rng.integers(0, K, (B, G)).astype(np.uint8)
+        n = np.full(G, B, np.uint8)
+        views = []
+        for r in range(R):
+            status = np.full((W, G), 2, np.uint8); status[:S][committed[r]] = 3
+            log = dict(start_slot=np.zeros(G, np.uint32), log_len=np.full(G, S, np.uint32), status=status, token=tok_ring)
+            views.append(orcs[r].handle_read_query(keys, n, log)[0])
+        iss = trial % R
+        orcs[iss].issue(0, n, views[iss])
+        rep = {k: np.stack([views[r][k] for r in range(R)]) for k in ("state", "slot", "val")}
+        order = np.array([sum(int(p) << (3 * i) for i, p in enumerate(rng.permutation(R))) for _ in range(G)], np.uint32)
+        fl = np.ones((R, G), np.uint8); fl[iss] = 0
+        outcome, val, done = orcs[iss].handle_replies(0, rep, fl, order)
+        assert done.all()
+        for g in range(G):
+            quorum = [iss] + [p for p in [(int(order[g]) >> (3 * i)) & 7 for i in range(R)] if p != iss][:2]
+            for i in range(B):
+                k = keys[i, g]
+                writes = np.nonzero(key_of[:, g] == k)[0]
+                acked = [s for s in writes if committed[0, s, g]]
+                seen = [s for s in writes if any(holds[r, s, g] for r in quorum)]
+                o = outcome[i, g]
+                checked[int(o)] += 1
+                if o == GOT:
+                    assert val[i, g] == token[max(seen), g] and (not acked or max(seen) >= max(acked))
+                elif o == NOT_FOUND:
+                    assert not seen and not acked
+                else:
+                    assert o == RETRY and seen
+    assert all(v > 100 for v in checked.values()), checked
