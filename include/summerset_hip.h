@@ -733,9 +733,14 @@ typedef struct {
     uint32_t n_queries;
 } smr_qread_cfg;
 typedef struct { uint8_t *state; uint32_t *slot, *val; } smr_qread_replies;   /* [max_reads][G], or [R][max_reads][G] */
-/* the replica's log as inspect_highest_slot sees it: start_slot, insts.len() [G]; status (Status as u8: Committed = 3)
- * and batch token per slot, rings [window][G] indexed by slot % window */
-typedef struct { const uint32_t *start_slot, *log_len; const uint8_t *status; const uint32_t *token; uint32_t window; } smr_qread_log;
+/* the replica's log as inspect_highest_slot sees it: start_slot and log_end = start_slot + insts.len() [G]; Status
+ * (Committed = 3) and batch token per slot, rings of `window` slots indexed by slot % window.  mp_layout 0: status is
+ * uint8 [window][G], token uint32 [window][G].  mp_layout 1: the arrays of a replica of the MultiPaxos cluster engine as
+ * they lie in HBM (smr_mp_replica_log_view): wave-tiled rings, status = the low 3 bits of the 32-bit meta words. */
+typedef struct { const uint32_t *start_slot, *log_end; const void *status; const uint32_t *token; uint32_t window, mp_layout; } smr_qread_log;
+/* the log of replica `rep` of a MultiPaxos cluster as smr_qread_handle_read_query reads it, in place (device pointers
+ * into the cluster's arena; valid while the cluster lives; read them between ticks) */
+int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out);
 int smr_qread_create(const smr_qread_cfg *cfg, smr_qread **out);
 void smr_qread_destroy(smr_qread *h);
 /* refresh_highest_slot for the batch saved into slot[g] (0xFFFFFFFF = no batch): put_keys[max_reads][G], 0xFF = not a Put */

@@ -628,7 +628,7 @@ class QrOracle:
         B, G = self.B, self.G
         out = dict(state=np.zeros((B, G), np.uint8), slot=np.zeros((B, G), np.uint32), val=np.zeros((B, G), np.uint32))
         fl = np.zeros(G, np.uint8)
-        lib().orc_qr_handle_read_query(self.h, _p(keys), _p(n), _p(stable_leader), _p(kv), _p(log["start_slot"]), _p(log["log_len"]),
+        lib().orc_qr_handle_read_query(self.h, _p(keys), _p(n), _p(stable_leader), _p(kv), _p(log["start_slot"]), _p(log["log_end"]),
                                        _p(log["status"]), _p(log["token"]), log["status"].shape[0], _p(out["state"]), _p(out["slot"]),
                                        _p(out["val"]), _p(fl))
         return out, fl

@@ -13,7 +13,7 @@
  * Model: keys are small integers (< K), a value is a 32-bit token (0 = no value), a request batch is its list of
  * Put keys and one token -- the value every Put of the batch writes --, so "the latest value for the key in the
  * batch" (quorumread.rs:50-60) is the token of the slot; the error of a highest_slot entry whose batch does not
- * write the key (:62-66) cannot arise.  The log is what the caller shows (start_slot, length, status and token
+ * write the key (:62-66) cannot arise.  The log is what the caller shows (start_slot, end, status and token
  * per slot, a ring of W); a query id (client, request id) is a slot index q < Q of the outstanding-query table.
  * Leases (is_stable_leader) are an input flag; the stable leader answers from the KV table (kv[key], 0 = None).
  * Deliberately literal (the match arms of :218-252 as written, incl. the arm that drops a committed value when
@@ -93,12 +93,12 @@ void orc_qr_refresh_highest_slot(void *h, const uint32_t *slot, const uint8_t *p
 
 /* quorumread.rs:30-73 */
 static Reply inspect_highest_slot(const QrCl *cl, const QrRep *r, uint32_t g, uint8_t key, const uint32_t *start_slot,
-                                  const uint32_t *log_len, const uint8_t *status, const uint32_t *token, uint32_t W) {
+                                  const uint32_t *log_end, const uint8_t *status, const uint32_t *token, uint32_t W) {
     Reply out = {RP_NONE, 0, 0};
     uint32_t slot = r->highest_slot[key];
     if (slot == NONE32) return out;                              /* never seen this key */
     out.state = RP_SLOT; out.slot = slot;
-    if (slot < start_slot[g] || slot >= start_slot[g] + log_len[g]) return out;   /* GCed / not locatable */
+    if (slot < start_slot[g] || slot >= log_end[g]) return out;   /* GCed / not locatable; log_end = start_slot + insts.len() */
     size_t o = (size_t)(slot % W) * cl->G + g;
     if (status[o] < ST_COMMITTED) return out;                    /* not committed on me yet */
     out.state = RP_VALUE; out.val = token[o];
@@ -108,7 +108,7 @@ static Reply inspect_highest_slot(const QrCl *cl, const QrRep *r, uint32_t g, ui
 /* quorumread.rs:75-188: the reply to a ReadQuery of n[g] Gets (keys[B][G]).  stable_leader (may be NULL) [G]: answer
  * from the KV table kv[K][G] instead (:99-147).  Out: state / slot / val [B][G], from_leader[G]. */
 void orc_qr_handle_read_query(void *h, const uint8_t *keys, const uint8_t *n, const uint8_t *stable_leader, const uint32_t *kv,
-                              const uint32_t *start_slot, const uint32_t *log_len, const uint8_t *status, const uint32_t *token,
+                              const uint32_t *start_slot, const uint32_t *log_end, const uint8_t *status, const uint32_t *token,
                               uint32_t W, uint8_t *o_state, uint32_t *o_slot, uint32_t *o_val, uint8_t *from_leader) {
     QrCl *cl = (QrCl *)h;
     const uint32_t G = cl->G;
@@ -130,7 +130,7 @@ void orc_qr_handle_read_query(void *h, const uint8_t *keys, const uint8_t *n, co
                 uint32_t v = kv[(size_t)key * G + g];           /* do_sync_cmd(Get) -> value.map(|v| (0, Some(v))) :124-131 */
                 if (v) { rp.state = RP_VALUE; rp.slot = 0; rp.val = v; }
             } else {
-                rp = inspect_highest_slot(cl, r, g, key, start_slot, log_len, status, token, W);   /* :158 */
+                rp = inspect_highest_slot(cl, r, g, key, start_slot, log_end, status, token, W);   /* :158 */
             }
             o_state[o] = rp.state; o_slot[o] = rp.slot; o_val[o] = rp.val;
         }

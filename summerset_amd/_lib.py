@@ -59,8 +59,8 @@ class QreadReplies(C.Structure):
 
 
 class QreadLog(C.Structure):
-    _fields_ = [("start_slot", C.c_void_p), ("log_len", C.c_void_p), ("status", C.c_void_p), ("token", C.c_void_p),
-                ("window", C.c_uint32)]
+    _fields_ = [("start_slot", C.c_void_p), ("log_end", C.c_void_p), ("status", C.c_void_p), ("token", C.c_void_p),
+                ("window", C.c_uint32), ("mp_layout", C.c_uint32)]
 
 
 class RaftCfg(C.Structure):
@@ -268,6 +268,7 @@ SYMBOLS = [
     ("smr_batcher_submit", _i, [_vp, _u32, _u64, _u64, _u8, C.c_char_p, _u32, C.c_char_p, _u32]),
     ("smr_batcher_pending", _i, [_vp, C.POINTER(_u64)]),
     ("smr_batcher_tick", C.c_int64, [_vp, _vp, _vp, _vp, _u32, _vp, _u64]),
+    ("smr_mp_replica_log_view", _i, [_vp, _u8, C.POINTER(QreadLog)]),
     ("smr_qread_create", _i, [C.POINTER(QreadCfg), C.POINTER(_vp)]),
     ("smr_qread_destroy", None, [_vp]),
     ("smr_qread_refresh_highest_slot", _i, [_vp, _vp, _vp, _vp]),

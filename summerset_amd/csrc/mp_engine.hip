@@ -1496,6 +1496,14 @@ int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_
     return SMR_OK;
 }
 
+int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out) {
+    if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    const MpRep &v = c->hp.rep[rep];
+    out->start_slot = v.start_slot; out->log_end = v.log_len;       // log_len is kept as start_slot + insts.len()
+    out->status = v.s_meta; out->token = v.s_val; out->window = c->cfg.window; out->mp_layout = 1;
+    return SMR_OK;
+}
+
 int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_mp_group_state *out) {
     if (!c || !out || rep >= c->cfg.population || group >= c->cfg.n_groups)
         return fail(SMR_ERR_ARG, "mp: bad group / replica");

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void qr_refresh_kernel(const QrView v, const u
 __global__ __launch_bounds__(256) void qr_read_query_kernel(const QrView v, const uint8_t *__restrict__ keys,
                                                             const uint8_t *__restrict__ n, const uint8_t *__restrict__ stable_leader,
                                                             const uint32_t *__restrict__ kv, const uint32_t *__restrict__ start_slot,
-                                                            const uint32_t *__restrict__ log_len, const uint8_t *__restrict__ status,
-                                                            const uint32_t *__restrict__ token, uint32_t Wmask,
+                                                            const uint32_t *__restrict__ log_end, const void *__restrict__ status,
+                                                            const uint32_t *__restrict__ token, uint32_t Wmask, uint32_t mp_layout,
                                                             uint8_t *__restrict__ o_state, uint32_t *__restrict__ o_slot,
                                                             uint32_t *__restrict__ o_val, uint8_t *__restrict__ from_leader) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void qr_read_query_kernel(const QrView v, cons
     const uint32_t cnt = n[g] < v.B ? n[g] : v.B;
     const bool stable = cnt && stable_leader && stable_leader[g];
     from_leader[g] = stable ? 1 : 0;
-    const uint32_t start = start_slot[g], end = start + log_len[g];
+    const uint32_t start = start_slot[g], end = log_end[g];
     for (uint32_t i = 0; i < v.B; i++) {
         const size_t o = (size_t)i * v.G + g;
         uint32_t st = RP_NONE, sl = 0, vl = 0;
@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256) void qr_read_query_kernel(const QrView v, cons
                 if (h != QR_NONE) {
                     st = RP_SLOT; sl = h;
                     if (h >= start && h < end) {
-                        const size_t w = (size_t)(h & Wmask) * v.G + g;
-                        if (status[w] >= QR_COMMITTED) { st = RP_VALUE; vl = token[w]; }
+                        // mp_layout: the MultiPaxos engine's own rings -- wave-tiled (mp_types.h tix) meta words, Status in the low 3 bits
+                        const size_t w = mp_layout ? ((size_t)(g >> 6) * (Wmask + 1) + (h & Wmask)) * 64 + (g & 63) : (size_t)(h & Wmask) * v.G + g;
+                        const uint32_t sv = mp_layout ? (((const uint32_t *)status)[w] & 7u) : ((const uint8_t *)status)[w];
+                        if (sv >= QR_COMMITTED) { st = RP_VALUE; vl = token[w]; }
                     }
                 }
             }
@@ -246,12 +248,12 @@ int smr_qread_handle_read_query(smr_qread *h, const uint8_t *keys_dev, const uin
                                 const uint32_t *kv_dev, const smr_qread_log *log, const smr_qread_replies *out,
                                 uint8_t *from_leader_dev, void *stream) {
     if (!h || !keys_dev || !n_dev || !log || !out || !from_leader_dev) return fail(SMR_ERR_ARG, "qread: null argument");
-    if (!log->start_slot || !log->log_len || !log->status || !log->token || !out->state || !out->slot || !out->val)
+    if (!log->start_slot || !log->log_end || !log->status || !log->token || !out->state || !out->slot || !out->val)
         return fail(SMR_ERR_ARG, "qread: null argument");
     if (stable_leader_dev && !kv_dev) return fail(SMR_ERR_ARG, "qread: stable_leader without a kv table");
     if (!log->window || (log->window & (log->window - 1))) return fail(SMR_ERR_ARG, "qread: log window must be a power of two");
     hipLaunchKernelGGL(qr_read_query_kernel, QR_GRID(h), h->v, keys_dev, n_dev, stable_leader_dev, kv_dev, log->start_slot,
-                       log->log_len, log->status, log->token, log->window - 1, out->state, out->slot, out->val, from_leader_dev);
+                       log->log_end, log->status, log->token, log->window - 1, log->mp_layout, out->state, out->slot, out->val, from_leader_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -91,6 +91,14 @@ class MultiPaxosCluster:
         check(self._L.smr_mp_read_group_state(self._h, group, rep, C.byref(st)))
         return st
 
+    def replica_log_view(self, rep):
+        """replica `rep`'s log as the quorum-read responder reads it, in place on the device (`QuorumReadGroup.
+        handle_msg_read_query(..., log=view)`): start_slot, log end, Status and batch token per slot"""
+        from ._lib import QreadLog
+        view = QreadLog()
+        check(self._L.smr_mp_replica_log_view(self._h, rep, C.byref(view)))
+        return view
+
     def dump(self, rep):
         """Canonical per-replica state as host numpy arrays (same shape as the oracle's dump)."""
         G, W, R = self.G, self.W, self.R

@@ -59,11 +59,13 @@ class QuorumReadGroup:
         check(self._L.smr_qread_refresh_highest_slot(self._h, _ptr(slot), _ptr(put_keys), self._stream(stream)))
 
     def handle_msg_read_query(self, keys, n, log, stable_leader=None, kv=None, stream=None):
-        """log = dict(start_slot, log_len [G] int32; status uint8, token int32 [W, G]).  Returns (replies, from_leader)"""
+        """log = dict(start_slot, log_end [G] int32; status uint8, token int32 [W, G]), or the `QreadLog` view of a replica
+        of the MultiPaxos cluster engine (`MultiPaxosCluster.replica_log_view`).  Returns (replies, from_leader)"""
         import torch
         out = self._replies((), keys.device)
         fl = torch.zeros(self.G, dtype=torch.uint8, device=keys.device)
-        lg = QreadLog(_ptr(log["start_slot"]), _ptr(log["log_len"]), _ptr(log["status"]), _ptr(log["token"]), int(log["status"].shape[0]))
+        lg = log if isinstance(log, QreadLog) else QreadLog(_ptr(log["start_slot"]), _ptr(log["log_end"]), _ptr(log["status"]),
+                                                            _ptr(log["token"]), int(log["status"].shape[0]), 0)
         rs = self._rs(out)
         check(self._L.smr_qread_handle_read_query(self._h, _ptr(keys), _ptr(n), _ptr(stable_leader), _ptr(kv), C.byref(lg),
                                                   C.byref(rs), _ptr(fl), self._stream(stream)))

@@ -68,6 +68,7 @@ def test_quorum_read_kernels_on_the_host(sim, oracle):
     with sim.patched():
         t.test_quorum_reads_match_oracle("cpu", oracle)
         t.test_quorum_reads_other_shapes("cpu", oracle)
+        t.test_responder_reads_the_multipaxos_engines_log_in_place("cpu", oracle)
 
 
 def test_epaxos_execution_kernel_on_the_host(sim, oracle):

@@ -22,7 +22,7 @@ def _log(start=0, length=6, committed=(), tokens=None):
     token = np.zeros((W, G), np.uint32)
     for s in range(W):
         token[s] = 100 + s if tokens is None else tokens.get(s, 0)
-    return dict(start_slot=np.full(G, start, np.uint32), log_len=np.full(G, length, np.uint32), status=status, token=token)
+    return dict(start_slot=np.full(G, start, np.uint32), log_end=np.full(G, start + length, np.uint32), status=status, token=token)
 
 
 def _keys(*ks):
@@ -174,7 +174,7 @@ def test_reads_never_miss_an_acknowledged_write(oracle):
         views = []
         for r in range(R):
             status = np.full((W, G), 2, np.uint8); status[:S][committed[r]] = 3
-            log = dict(start_slot=np.zeros(G, np.uint32), log_len=np.full(G, S, np.uint32), status=status, token=tok_ring)
+            log = dict(start_slot=np.zeros(G, np.uint32), log_end=np.full(G, S, np.uint32), status=status, token=tok_ring)
             views.append(orcs[r].handle_read_query(keys, n, log)[0])
         iss = trial % R
         orcs[iss].issue(0, n, views[iss])

@@ -81,7 +81,7 @@ def _run(cuda, oracle, G, R, K, B, Q, W, T, seed):
             # slot of ring row w for group g: the newest slot congruent to w below log_len
             abs_slot = (log_len[None, :].astype(np.int64) - 1 - ((log_len[None, :].astype(np.int64) - 1 - sl_idx) % W))
             status[(abs_slot >= 0) & (abs_slot < commit[r][None, :])] = 3
-            log = dict(start_slot=start, log_len=(log_len - start).astype(np.uint32), status=status, token=token)
+            log = dict(start_slot=start, log_end=log_len.copy(), status=status, token=token)
             st_in = stable if r == 0 and iss != 0 else None
             o_out, o_fl = orcs[r].handle_read_query(keys, n, log, st_in, kv if st_in is not None else None)
             dlog = {k: _t(v, cuda) for k, v in log.items()}
@@ -129,3 +129,42 @@ def test_quorum_reads_match_oracle(cuda, oracle):
 def test_quorum_reads_other_shapes(cuda, oracle):
     _run(cuda, oracle, G=130, R=3, K=5, B=1, Q=1, W=8, T=40, seed=22)
     _run(cuda, oracle, G=257, R=7, K=30, B=5, Q=3, W=32, T=30, seed=23)
+
+
+def test_responder_reads_the_multipaxos_engines_log_in_place(cuda, oracle):
+    """quorum reads on top of the MultiPaxos cluster engine: after some ticks of the bench-like stream (loss, a leader
+    change) every replica answers ReadQueries straight from its device-resident log (`smr_mp_replica_log_view`: wave-tiled
+    rings, Status inside the meta words); the oracle answers from the dumped state"""
+    import test_mp_gpu as t
+    from summerset_amd import MultiPaxosCluster, QuorumReadGroup
+    G, R, S, W, K, B = 200, 5, 4, 32, 10, 3
+    cap = W + 4
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+    eng.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=12, drop_p=0.15, timeout_frac=0.02, hb_every=3, rand_rows=S + 4, max_drop=2)
+    rng = np.random.default_rng(8)
+    qe = [QuorumReadGroup(G, R, r, K, B, 1) for r in range(R)]
+    qo = [oracle.QrOracle(G, R, r, K, B, 1) for r in range(R)]
+    n_val = 0
+    for tick in range(12):
+        eng.tick(**t._to_dev(st.tick(tick), cuda))
+        if tick % 3 != 2:
+            continue
+        for r in range(R):
+            d = eng.dump(r)
+            # highest-slot entries anywhere around the replica's log: below start_slot, inside, at and past the end
+            for _ in range(4):
+                slot = rng.integers(0, int(d["log_len"].max()) + 3, G).astype(np.uint32)
+                pk = rng.integers(0, K + 3, (B, G)).astype(np.uint8); pk[pk >= K] = 0xFF
+                qo[r].refresh_highest_slot(slot, pk)
+                qe[r].refresh_highest_slot(_t(slot, cuda), _t(pk, cuda))
+            keys = rng.integers(0, K, (B, G)).astype(np.uint8)
+            n = rng.integers(0, B + 1, G).astype(np.uint8)
+            log = dict(start_slot=d["start_slot"], log_end=d["log_len"], status=d["s_status"], token=d["s_reqs"])
+            o_out, _ = qo[r].handle_read_query(keys, n, log)
+            e_out, _ = qe[r].handle_msg_read_query(_t(keys, cuda), _t(n, cuda), eng.replica_log_view(r))
+            e_np = _np(e_out)
+            for k in o_out:
+                assert np.array_equal(e_np[k], o_out[k]), (tick, r, k, np.nonzero(e_np[k] != o_out[k]))
+            n_val += int((o_out["state"] == 2).sum())
+    assert n_val > 100
