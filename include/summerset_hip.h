@@ -765,6 +765,20 @@ int smr_qread_handle_replies(smr_qread *h, uint32_t q, const smr_qread_replies *
 int smr_qread_dump(smr_qread *h, uint32_t *highest_slot_host, uint8_t *live_host, uint8_t *n_host, uint8_t *rq_acks_host,
                    uint8_t *mx_state_host, uint32_t *mx_slot_host, uint32_t *mx_val_host, uint64_t *counters_host);
 
+/* ---- device-resident KV state machine ------------------------------------
+ * StateMachineExecutorTask::execute (src/server/statemach.rs:193-202) per group, commands in submission order.
+ * Keys < n_keys, values 32-bit tokens, 0 = None (the model of smr_qread_* and the EPaxos execution kernel). */
+typedef struct smr_kv smr_kv;
+int smr_kv_create(uint32_t n_groups, uint32_t n_keys, smr_kv **out);
+void smr_kv_destroy(smr_kv *h);
+/* n_rows commands per group, row after row: kind[n_rows][G] 0 Get / 1 Put / else none, key, val; res[n_rows][G] =
+ * CommandResult: Get { value }, Put { old_value } */
+int smr_kv_execute(smr_kv *h, uint32_t n_rows, const uint8_t *kind_dev, const uint8_t *key_dev, const uint32_t *val_dev,
+                   uint32_t *res_dev, void *stream);
+/* the table kv[n_keys][G] on the device, e.g. for smr_qread_handle_read_query's stable-leader arm */
+int smr_kv_table(smr_kv *h, uint32_t **kv_dev);
+int smr_kv_dump(smr_kv *h, uint32_t *kv_host);
+
 #ifdef __cplusplus
 }
 #endif

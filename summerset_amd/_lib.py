@@ -269,6 +269,11 @@ SYMBOLS = [
     ("smr_batcher_pending", _i, [_vp, C.POINTER(_u64)]),
     ("smr_batcher_tick", C.c_int64, [_vp, _vp, _vp, _vp, _u32, _vp, _u64]),
     ("smr_mp_replica_log_view", _i, [_vp, _u8, C.POINTER(QreadLog)]),
+    ("smr_kv_create", _i, [_u32, _u32, C.POINTER(_vp)]),
+    ("smr_kv_destroy", None, [_vp]),
+    ("smr_kv_execute", _i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_kv_table", _i, [_vp, C.POINTER(_vp)]),
+    ("smr_kv_dump", _i, [_vp, _vp]),
     ("smr_qread_create", _i, [C.POINTER(QreadCfg), C.POINTER(_vp)]),
     ("smr_qread_destroy", None, [_vp]),
     ("smr_qread_refresh_highest_slot", _i, [_vp, _vp, _vp, _vp]),

@@ -16,7 +16,7 @@ PENDING, NOT_FOUND, RETRY, GOT_VALUE = 0, 1, 2, 3
 
 
 def _ptr(t):
-    return None if t is None else t.data_ptr()
+    return None if t is None else (t if isinstance(t, int) else t.data_ptr())
 
 
 class QuorumReadGroup:
@@ -97,4 +97,45 @@ class QuorumReadGroup:
                    mx_val=np.zeros((Q, B, G), np.uint32), counters=np.zeros(4, np.uint64))
         check(self._L.smr_qread_dump(self._h, *[out[k].ctypes.data_as(C.c_void_p) for k in
                                                 ("highest_slot", "live", "n", "rq_acks", "mx_state", "mx_slot", "mx_val", "counters")]))
+        return out
+
+
+GET, PUT = 0, 1
+
+
+class KvStateMachine:
+    """`StateMachineExecutorTask::execute` (src/server/statemach.rs:193-202) for G groups, state resident on the device:
+    commands [rows, G] are applied row after row; a Get returns the value, a Put the old value (0 = None)."""
+
+    def __init__(self, n_groups, n_keys=16):
+        self.G, self.K = int(n_groups), int(n_keys)
+        h = C.c_void_p()
+        self._L = _lib.load()
+        check(self._L.smr_kv_create(self.G, self.K, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_kv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    _stream = QuorumReadGroup._stream
+
+    def execute(self, kind, key, val, stream=None):
+        import torch
+        res = torch.zeros(kind.shape, dtype=torch.int32, device=kind.device)
+        check(self._L.smr_kv_execute(self._h, int(kind.shape[0]), _ptr(kind), _ptr(key), _ptr(val), _ptr(res), self._stream(stream)))
+        return res
+
+    def table_ptr(self):
+        p = C.c_void_p()
+        check(self._L.smr_kv_table(self._h, C.byref(p)))
+        return p.value
+
+    def dump(self):
+        out = np.zeros((self.K, self.G), np.uint32)
+        check(self._L.smr_kv_dump(self._h, out.ctypes.data_as(C.c_void_p)))
         return out

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "summerset_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build")
-SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rep_nothing.hip", "wire.hip", "qread.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rep_nothing.hip", "wire.hip", "qread.hip", "kv_exec.hip"]
 LIB = os.path.join(_OUT, "libsummerset_sim.so")
 # clang: the RS kernels use ext_vector_type, which g++ does not have (this is the host compiler hipcc itself drives)
 CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
@@ -139,7 +139,7 @@ def patched(defines=()):
     sim = load(defines)
     null = staticmethod(lambda stream: 0)
     spots = [(_lib, "_lib", sim), (epaxos.EPaxosReplicaGroup, "_stream", null), (raft.RaftLeaderGroup, "_stream", null), (rspaxos.RSPaxosReplicaGroup, "_stream", null),
-             (multipaxos.MultiPaxosCluster, "_stream", null), (quorumread.QuorumReadGroup, "_stream", null), (rscoding, "_stream_ptr", lambda stream: 0)]
+             (multipaxos.MultiPaxosCluster, "_stream", null), (quorumread.QuorumReadGroup, "_stream", null), (quorumread.KvStateMachine, "_stream", null), (rscoding, "_stream_ptr", lambda stream: 0)]
     saved = [(o, n, o.__dict__[n]) for o, n, _ in spots]
     for o, n, v in spots:
         setattr(o, n, v)

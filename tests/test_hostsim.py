@@ -71,6 +71,15 @@ def test_quorum_read_kernels_on_the_host(sim, oracle):
         t.test_responder_reads_the_multipaxos_engines_log_in_place("cpu", oracle)
 
 
+def test_kv_state_machine_kernel_on_the_host(sim, oracle):
+    """the device KV executor (f.3) against the reference's state-machine tests and a dict, and under a stable leader's reads"""
+    import test_zz_kv_gpu as t
+    with sim.patched():
+        t.test_reference_state_machine_tests("cpu")
+        t.test_put_rand_get_rand_per_group("cpu")
+        t.test_stable_leader_reads_the_executed_state("cpu", oracle)
+
+
 def test_epaxos_execution_kernel_on_the_host(sim, oracle):
     import test_zz_ep_exec_gpu as t
     with sim.patched():
