@@ -2,7 +2,8 @@
 
 The reference (Rust) cannot be built or imported here, and its own tests hold no
 byte-level vectors for this path, so these fixtures are produced
-by the KAT-pinned CPU oracle (oracle/rs_oracle.c, oracle/mp_oracle.c) and frozen:
+by the KAT-pinned CPU oracle (oracle/rs_oracle.c, oracle/mp_oracle.c; late_golden.npz: raft_oracle.c's CRaft
+variant, qr_oracle.c) and frozen:
 they pin BOTH the oracle and the HIP path against silent drift.  Re-run only on a
 deliberate semantic change:   python tests/golden/make_golden.py
 """
@@ -71,7 +72,25 @@ def mp_fixture():
     np.savez_compressed(os.path.join(HERE, "mp_golden.npz"), **out)
 
 
+def late_fixture():
+    """Final states of the frozen runs of the engines that came after the MultiPaxos cluster: the CRaft leader
+    (oracle/raft_oracle.c, orc_craft_*) and the quorum reads of five replicas (oracle/qr_oracle.c), on the seeded streams
+    of tests/test_zz_{craft,qread}_gpu.py -- the device tests hold the engines equal to the oracles after every call, the
+    CPU tests hold the oracles' final states equal to this file."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_zz_craft_gpu as craft
+    import test_zz_qread_gpu as qread
+    out = {}
+    for k, v in craft._run(None, O, **craft.GOLDEN_RUN).items():
+        out["craft_" + k] = v
+    for k, v in qread._run(None, O, **qread.GOLDEN_RUN).items():
+        out["qr_" + k] = v
+    np.savez_compressed(os.path.join(HERE, "late_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    rs_fixture()
-    mp_fixture()
+    if "--late-only" not in sys.argv:
+        rs_fixture()
+        mp_fixture()
+    late_fixture()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

@@ -60,6 +60,7 @@ def test_craft_leader_kernels_on_the_host(sim, oracle):
         t.test_craft_leader_fallback_and_commit_rule("cpu", oracle)
         t.test_craft_leader_step_down_and_other_populations("cpu", oracle)
         t.test_craft_entry_shards_follow_the_assignment("cpu", oracle)
+        t.test_final_state_is_the_golden_one("cpu", oracle)
 
 
 def test_quorum_read_kernels_on_the_host(sim, oracle):
@@ -69,6 +70,7 @@ def test_quorum_read_kernels_on_the_host(sim, oracle):
         t.test_quorum_reads_match_oracle("cpu", oracle)
         t.test_quorum_reads_other_shapes("cpu", oracle)
         t.test_responder_reads_the_multipaxos_engines_log_in_place("cpu", oracle)
+        t.test_final_state_is_the_golden_one("cpu", oracle)
 
 
 def test_kv_state_machine_kernel_on_the_host(sim, oracle):

@@ -112,3 +112,12 @@ def test_heartbeat_prev_slot_follows_try_next(orc):
     hb = orc.bcast_heartbeats()
     assert (hb["hb_flags"] == 0).all()
     assert np.array_equal(orc.dump_craft()["hb_repeat"], np.zeros((5, G), np.uint8))
+
+
+def test_golden_final_state(oracle):
+    """the frozen run of tests/test_zz_craft_gpu.py, oracle alone, ends in the committed state (tests/golden/late_golden.npz)"""
+    import os
+    import test_zz_craft_gpu as t
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "late_golden.npz"))
+    out = t._run(None, oracle, **t.GOLDEN_RUN)
+    assert out and all(np.array_equal(v, gold["craft_" + k]) for k, v in out.items())

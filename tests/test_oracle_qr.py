@@ -199,3 +199,12 @@ def test_reads_never_miss_an_acknowledged_write(oracle):
                 else:
                     assert o == RETRY and seen
     assert all(v > 100 for v in checked.values()), checked
+
+
+def test_golden_final_state(oracle):
+    """the frozen run of tests/test_zz_qread_gpu.py, oracle alone, ends in the committed state (tests/golden/late_golden.npz)"""
+    import os
+    import test_zz_qread_gpu as t
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "late_golden.npz"))
+    out = t._run(None, oracle, **t.GOLDEN_RUN)
+    assert out and all(np.array_equal(v, gold["qr_" + k]) for k, v in out.items())

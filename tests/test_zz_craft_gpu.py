@@ -34,39 +34,51 @@ def _same(eng, orc, where):
 
 
 def _run(cuda, oracle, G, R, W, T, ft, thr, higher_p=0.0, seed=5):
-    import torch
-    from summerset_amd import CRaftLeaderGroup
-    eng = CRaftLeaderGroup(G, R, 0, W, term=1, fault_tolerance=ft, repeat_threshold=thr)
+    """cuda None: the oracle alone (tests/golden/make_golden.py and the CPU test that pins its final state)"""
     orc = oracle.CRaftOracle(G, R, W, 0, 1, ft, thr)
-    dev = lambda a: torch.from_numpy(a).to(cuda)
-    _same(eng, orc, "start")
+    eng = None
+    if cuda is not None:
+        import torch
+        from summerset_amd import CRaftLeaderGroup
+        eng = CRaftLeaderGroup(G, R, 0, W, term=1, fault_tolerance=ft, repeat_threshold=thr)
+        dev = lambda a: torch.from_numpy(a).to(cuda)
+        _same(eng, orc, "start")
     for t in range(T):
         n_new = (stream._key(seed, 9, t, np.arange(G, dtype=np.uint64)) % np.uint64(3)).astype(np.uint32)
         orc.append(n_new)
-        eng.handle_req_batch(dev(n_new))
-        pe, se = eng.assignment(cuda)
         po, so = orc.assignment()
-        assert np.array_equal(pe.cpu().numpy().view(np.uint32), po) and np.array_equal(se.cpu().numpy().view(np.uint32), so), t
+        if eng:
+            eng.handle_req_batch(dev(n_new))
+            pe, se = eng.assignment(cuda)
+            assert np.array_equal(pe.cpu().numpy().view(np.uint32), po) and np.array_equal(se.cpu().numpy().view(np.uint32), so), t
         d = orc.dump()
         term, es, fl, ct, cs, order = _replies(seed, t, G, R, d["log_len"], d["curr_term"], higher_p=higher_p)
         fl[_silent(G, R, t)] = 0
         orc.handle_replies(term, es, fl, ct, cs, order)
-        eng.handle_msg_append_entries_reply(dev(term), dev(es), dev(fl), dev(ct), dev(cs), dev(order))
-        _same(eng, orc, ("replies", t))
+        if eng:
+            eng.handle_msg_append_entries_reply(dev(term), dev(es), dev(fl), dev(ct), dev(cs), dev(order))
+            _same(eng, orc, ("replies", t))
         if t % 2 == 1:                                        # the send tick
-            he, ho = eng.bcast_heartbeats(cuda), orc.bcast_heartbeats()
-            for k, v in ho.items():
-                e = he[k].cpu().numpy()
-                assert np.array_equal(e.view(v.dtype), v), ("heartbeat", t, k)
-            _same(eng, orc, ("heartbeat", t))
+            ho = orc.bcast_heartbeats()
+            if eng:
+                he = eng.bcast_heartbeats(cuda)
+                for k, v in ho.items():
+                    e = he[k].cpu().numpy()
+                    assert np.array_equal(e.view(v.dtype), v), ("heartbeat", t, k)
+                _same(eng, orc, ("heartbeat", t))
         if t == T // 2:                                       # someone switches a few groups by hand, both ways
             to = np.full(G, 0xFF, np.uint8); to[::5] = 1; to[2::5] = 0
             orc.switch_assignment_mode(to)
-            eng.switch_assignment_mode(dev(to))
-            _same(eng, orc, ("switch", t))
+            if eng:
+                eng.switch_assignment_mode(dev(to))
+                _same(eng, orc, ("switch", t))
     c = orc.dump_craft()
     assert orc.total_commits() > 0
+    c.update(orc.dump())
     return c
+
+
+GOLDEN_RUN = dict(G=96, R=5, W=32, T=36, ft=1, thr=2, higher_p=0.002, seed=31)   # tests/golden/late_golden.npz, "craft_*"
 
 
 def test_craft_leader_fallback_and_commit_rule(cuda, oracle):
@@ -118,3 +130,12 @@ def test_craft_entry_shards_follow_the_assignment(cuda, oracle):
     # full-copy groups: one peer's share is already the batch
     one = cw.subset_copy(int(send[2, 1]))
     assert one.avail == 7 and np.array_equal(one.get_data().cpu().numpy(), data) and sl * 3 >= L
+
+
+def test_final_state_is_the_golden_one(cuda, oracle):
+    """the oracle (and the engine, equal to it after every call) ends the frozen run in the committed state"""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "late_golden.npz"))
+    c = _run(cuda, oracle, **GOLDEN_RUN)
+    for k, v in c.items():
+        assert np.array_equal(v, gold["craft_" + k]), k

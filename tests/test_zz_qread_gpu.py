@@ -35,8 +35,11 @@ def _np(d):
 
 
 def _run(cuda, oracle, G, R, K, B, Q, W, T, seed):
-    from summerset_amd import QuorumReadGroup
-    engs = [QuorumReadGroup(G, R, r, K, B, Q) for r in range(R)]
+    """cuda None: the oracles alone (tests/golden/make_golden.py and the CPU test that pins their final state)"""
+    engs = None
+    if cuda is not None:
+        from summerset_amd import QuorumReadGroup
+        engs = [QuorumReadGroup(G, R, r, K, B, Q) for r in range(R)]
     orcs = [oracle.QrOracle(G, R, r, K, B, Q) for r in range(R)]
     g = np.arange(G, dtype=np.uint64)
     i_ = np.arange(B, dtype=np.uint64)[:, None]
@@ -63,7 +66,8 @@ def _run(cuda, oracle, G, R, K, B, Q, W, T, seed):
         for r in range(R):
             sl = np.where(hears[r], slot, NO).astype(np.uint32)
             orcs[r].refresh_highest_slot(sl, put_keys)
-            engs[r].refresh_highest_slot(_t(sl, cuda), _t(put_keys, cuda))
+            if engs:
+                engs[r].refresh_highest_slot(_t(sl, cuda), _t(put_keys, cuda))
         log_len = (log_len + has).astype(np.uint32)
         adv = (_u(seed, 4, t, r_, g[None, :]) % np.uint64(3)).astype(np.uint32)
         commit = np.minimum(commit + adv, log_len[None, :]).astype(np.uint32)
@@ -84,17 +88,19 @@ def _run(cuda, oracle, G, R, K, B, Q, W, T, seed):
             log = dict(start_slot=start, log_end=log_len.copy(), status=status, token=token)
             st_in = stable if r == 0 and iss != 0 else None
             o_out, o_fl = orcs[r].handle_read_query(keys, n, log, st_in, kv if st_in is not None else None)
-            dlog = {k: _t(v, cuda) for k, v in log.items()}
-            e_out, e_fl = engs[r].handle_msg_read_query(_t(keys, cuda), _t(n, cuda), dlog, None if st_in is None else _t(st_in, cuda),
-                                                        None if st_in is None else _t(kv, cuda))
-            e_np = _np(e_out)
-            for k in o_out:
-                assert np.array_equal(e_np[k], o_out[k]), ("read_query", t, r, k)
-            assert np.array_equal(e_fl.cpu().numpy(), o_fl), ("from_leader", t, r)
+            if engs:
+                dlog = {k: _t(v, cuda) for k, v in log.items()}
+                e_out, e_fl = engs[r].handle_msg_read_query(_t(keys, cuda), _t(n, cuda), dlog, None if st_in is None else _t(st_in, cuda),
+                                                            None if st_in is None else _t(kv, cuda))
+                e_np = _np(e_out)
+                for k in o_out:
+                    assert np.array_equal(e_np[k], o_out[k]), ("read_query", t, r, k)
+                assert np.array_equal(e_fl.cpu().numpy(), o_fl), ("from_leader", t, r)
             if r == iss:
                 orcs[r].issue(q, n, o_out)
-                engs[r].issue(q, _t(n, cuda), e_out)
-                _same_dump(engs[r], orcs[r], ("issue", t))
+                if engs:
+                    engs[r].issue(q, _t(n, cuda), e_out)
+                    _same_dump(engs[r], orcs[r], ("issue", t))
             else:
                 for k in rep:
                     rep[k][r] = o_out[k]
@@ -111,15 +117,24 @@ def _run(cuda, oracle, G, R, K, B, Q, W, T, seed):
         halves[1][~split & ~twice] = 0
         for hi, fl in enumerate(halves):
             oo = orcs[iss].handle_replies(q, rep, fl, np.ascontiguousarray(order))
-            ee = engs[iss].handle_msg_read_query_reply(q, {k: _t(v, cuda) for k, v in rep.items()}, _t(fl, cuda), _t(np.ascontiguousarray(order), cuda))
-            for name, a, b in zip(("outcome", "out_val", "done"), ee, oo):
-                a = a.cpu().numpy()
-                assert np.array_equal(a.view(b.dtype) if a.dtype.itemsize == 4 else a, b), (name, t, hi)
             n_done += int(oo[2].sum())
-            _same_dump(engs[iss], orcs[iss], ("replies", t, hi))
+            if engs:
+                ee = engs[iss].handle_msg_read_query_reply(q, {k: _t(v, cuda) for k, v in rep.items()}, _t(fl, cuda), _t(np.ascontiguousarray(order), cuda))
+                for name, a, b in zip(("outcome", "out_val", "done"), ee, oo):
+                    a = a.cpu().numpy()
+                    assert np.array_equal(a.view(b.dtype) if a.dtype.itemsize == 4 else a, b), (name, t, hi)
+                _same_dump(engs[iss], orcs[iss], ("replies", t, hi))
     c = sum(o.dump()["counters"] for o in orcs)
     assert n_done > 0 and all(int(x) > 0 for x in c), c           # values, retries, not-founds and conflicts all occurred
-    return c
+    final = {"counters": c}
+    for r in range(R):
+        for k, v in orcs[r].dump().items():
+            if k != "counters":
+                final["r%d_%s" % (r, k)] = v
+    return final
+
+
+GOLDEN_RUN = dict(G=64, R=5, K=9, B=3, Q=2, W=16, T=30, seed=77)   # tests/golden/late_golden.npz, "qr_*"
 
 
 def test_quorum_reads_match_oracle(cuda, oracle):
@@ -168,3 +183,11 @@ def test_responder_reads_the_multipaxos_engines_log_in_place(cuda, oracle):
                 assert np.array_equal(e_np[k], o_out[k]), (tick, r, k, np.nonzero(e_np[k] != o_out[k]))
             n_val += int((o_out["state"] == 2).sum())
     assert n_val > 100
+
+
+def test_final_state_is_the_golden_one(cuda, oracle):
+    """the oracles (and the engines, equal to them after every call) end the frozen run in the committed state"""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "late_golden.npz"))
+    for k, v in _run(cuda, oracle, **GOLDEN_RUN).items():
+        assert np.array_equal(v, gold["qr_" + k]), k
