@@ -72,6 +72,31 @@ def mp_fixture():
     np.savez_compressed(os.path.join(HERE, "mp_golden.npz"), **out)
 
 
+def cluster_states(oracle):
+    """final states of the five oracles of the closed-loop EPaxos (with execution, 10 % lost PreAccepts) and RSPaxos
+    (f = 1, 10 % loss) clusters of tests/test_oracle_{ep,rsp}_cluster.py ("ep_*", "rsp_*")"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import rsp_scenarios as sc
+    import test_oracle_ep_cluster as epc
+    import test_oracle_rsp_cluster as rspc
+    out = {}
+    reps, _ = epc._run(oracle, 48, 20, 6, seed=41, drop_p=0.1, execute=True)
+    for r, rep in enumerate(reps):
+        for k, v in rep.dump().items():
+            if isinstance(v, np.ndarray):
+                out["ep_r%d_%s" % (r, k)] = v
+        for k, v in rep.exec_dump().items():
+            if isinstance(v, np.ndarray):
+                out["ep_r%d_x_%s" % (r, k)] = v
+    reps = rspc._cluster(oracle, 40, 1)
+    sc.run(reps, 40, 24, seed=8, loss=0.1)
+    for r, rep in enumerate(reps):
+        for k, v in rep.dump().items():
+            if isinstance(v, np.ndarray):
+                out["rsp_r%d_%s" % (r, k)] = v
+    return out
+
+
 def late_fixture():
     """Final states of the frozen runs of the engines that came after the MultiPaxos cluster: the CRaft leader
     (oracle/raft_oracle.c, orc_craft_*) and the quorum reads of five replicas (oracle/qr_oracle.c), on the seeded streams
@@ -85,6 +110,7 @@ def late_fixture():
         out["craft_" + k] = v
     for k, v in qread._run(None, O, **qread.GOLDEN_RUN).items():
         out["qr_" + k] = v
+    out.update(cluster_states(O))
     np.savez_compressed(os.path.join(HERE, "late_golden.npz"), **out)
 
 

@@ -121,3 +121,19 @@ def test_cluster_execution_with_lost_pre_accepts(oracle):
     xs, ds = _exec_props(oracle, 0.2, 6)
     assert int(xs[0]["counters"][5]) > 0                       # attempts abandoned on an uncommitted dependency
     assert (xs[0]["exec_bars"] < ds[0]["commit_bars"]).any()
+
+
+def test_golden_final_states(oracle):
+    """the frozen EPaxos and RSPaxos cluster runs end in the committed states (tests/golden/late_golden.npz, generator
+    tests/golden/make_golden.py: cluster_states) -- pins both oracles against drift"""
+    import importlib.util
+    import os
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(here, "golden", "late_golden.npz"))
+    out = mg.cluster_states(oracle)
+    assert len(out) > 50
+    for k, v in out.items():
+        assert np.array_equal(v, gold[k]), k
