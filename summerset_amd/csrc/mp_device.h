@@ -57,11 +57,26 @@ struct Lane {
     // follower's steady-state append path and dropped (BAL_TOUCH) by everything else that writes a ballot or moves
     // bal_max_seen; the heartbeat's commit learning then need not load s_bal for slots inside it (8 of its 16 B per slot).
     uint32_t brun, o_brun;
-#ifdef SMR_BAL_LAZY
+#if defined(SMR_BAL_LAZY) || defined(SMR_STATUS_LAZY)
     // ... and, one step further (-DSMR_BAL_LAZY): the follower's steady-state append does not STORE the ballot of a slot
     // inside the run (8 of the 16 B it writes per slot) -- the true value is bal_max_seen; whoever ends the run writes
     // the ballots out first (uniform mode: every lane its share), with the bal_max_seen the run was built under.
-#define BAL_TOUCH() do { if (brun != 0xFFFFFFFFu) { for (uint32_t _s = (brun > start ? brun : start) + cl; _s < len; _s += cn) v.s_bal()[ix(_s)] = bms; brun = 0xFFFFFFFFu; } } while (0)
+    // -DSMR_STATUS_LAZY: inside the run the heartbeat's commit learning (hb_advance, fused prefix) moves the bars over the
+    // slots without touching them -- every slot of the run is as appended (Accepting at bal_max_seen), so the prefix
+    // passes them all; a run slot below commit_bar is Executed by definition (stored: Accepting), and whoever ends the
+    // run writes those statuses out first.  Nothing reads a slot below commit_bar before that: the bar scans start at
+    // commit_bar / accept_bar, every generic handler ends the run on entry.
+#ifdef SMR_BAL_LAZY
+#define BAL_MAT_BAL(_s) v.s_bal()[ix(_s)] = bms
+#else
+#define BAL_MAT_BAL(_s) ((void)0)
+#endif
+#ifdef SMR_STATUS_LAZY
+#define BAL_MAT_ST(_s) do { if ((_s) < cbar) { const size_t _i = ix(_s); v.s_meta()[_i] = m_set_st(v.s_meta()[_i], SMR_ST_EXECUTED); } } while (0)
+#else
+#define BAL_MAT_ST(_s) ((void)0)
+#endif
+#define BAL_TOUCH() do { if (brun != 0xFFFFFFFFu) { for (uint32_t _s = (brun > start ? brun : start) + cl; _s < len; _s += cn) { BAL_MAT_BAL(_s); BAL_MAT_ST(_s); } brun = 0xFFFFFFFFu; } } while (0)
 #else
 #define BAL_TOUCH() do { brun = 0xFFFFFFFFu; } while (0)
 #endif
@@ -850,24 +865,40 @@ struct Lane {
             bool chase = false;
             if (!coop()) {
                 bool simple = true;
-                while (simple && sfx < hb_commit) {
+#ifdef SMR_STATUS_LAZY
+                // slots below the run the usual way, then the run in one step
+                const bool lz = brun != 0xFFFFFFFFu && bms >= ballot;
+                const uint32_t eager_end = lz && brun < hb_commit ? (brun > sfx ? brun : sfx) : hb_commit;
+#else
+                const uint32_t eager_end = hb_commit;
+#endif
+                while (simple && sfx < eager_end) {
                     uint32_t mm[8]; uint64_t bb[8];
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        bool in = sfx + k < hb_commit;
+                        bool in = sfx + k < eager_end;
                         size_t i = ix(sfx + k);
                         mm[k] = in ? v.s_meta()[i] : 0u;
                         bb[k] = in ? HB_BAL(sfx + k, i) : 0ull;
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        if (sfx >= hb_commit) break;
+                        if (sfx >= eager_end) break;
                         if (!(m_st(mm[k]) == SMR_ST_ACCEPTING && bb[k] >= ballot && sfx < abar)) { simple = false; break; }
                         if ((mm[k] & M_NONEMPTY) && sfx == e0) chase = true;
                         v.s_meta()[ix(sfx)] = m_set_st(mm[k], SMR_ST_EXECUTED);
                         sfx++;
                     }
                 }
+#ifdef SMR_STATUS_LAZY
+                if (simple && lz && sfx >= brun && sfx < hb_commit) {
+                    const uint32_t tgt = hb_commit < abar ? hb_commit : abar;
+                    if (tgt > sfx) {
+                        if (sfx == e0 && (v.s_meta()[ix(sfx)] & M_NONEMPTY)) chase = true;
+                        sfx = tgt;
+                    }
+                }
+#endif
                 if (sfx > c0) { cbar = sfx; if (chase) ebar = sfx; }
             }
             uint32_t first = 0xFFFFFFFFu, first_m = 0;
@@ -890,6 +921,9 @@ struct Lane {
                         if (bb[k] < ballot || st < SMR_ST_ACCEPTING) { go = false; break; }
                         if (st < SMR_ST_COMMITTED) {
                             uint32_t m = m_set_st(mm[k], SMR_ST_COMMITTED);
+#ifdef SMR_STATUS_LAZY
+                            BAL_TOUCH();                        // a slot of the run marked one by one: the run ends here
+#endif
                             if (wr) v.s_meta()[ix(s)] = m;
                             if (first == 0xFFFFFFFFu) { first = s; first_m = m; }
                         }

@@ -1498,6 +1498,9 @@ int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_
 
 int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out) {
     if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+#ifdef SMR_STATUS_LAZY
+    return fail(SMR_ERR_ARG, "mp: this experimental build keeps follower statuses implicit; no in-place log view");
+#endif
     const MpRep &v = c->hp.rep[rep];
     out->start_slot = v.start_slot; out->log_end = v.log_len;       // log_len is kept as start_slot + insts.len()
     out->status = v.s_meta; out->token = v.s_val; out->window = c->cfg.window; out->mp_layout = 1;
@@ -1546,7 +1549,7 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
     D2H(val.data(), v.s_val, W * Gp * 4); D2H(meta.data(), v.s_meta, W * Gp * 4); D2H(vval.data(), v.s_vval, W * Gp * 4);
     D2H(ltrig.data(), v.s_ltrig, W * Gp * 4); D2H(lendp.data(), v.s_lendp, W * Gp * 4);
     D2H(rtrig.data(), v.s_rtrig, W * Gp * 4); D2H(rendp.data(), v.s_rendp, W * Gp * 4);
-#ifdef SMR_BAL_LAZY
+#if defined(SMR_BAL_LAZY) || defined(SMR_STATUS_LAZY)
     std::vector<uint32_t> bal_lo(G);
     D2H(bal_lo.data(), v.bal_lo, G * 4);
 #endif
@@ -1569,6 +1572,9 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
             uint32_t m = meta[t];
 #ifdef SMR_BAL_LAZY
             if (s >= bal_lo[g]) bal[t] = hb->bal_max_seen[g];                    // inside the run the ballot is not stored
+#endif
+#ifdef SMR_STATUS_LAZY
+            if (s >= bal_lo[g] && s < hb->commit_bar[g]) m = (m & ~M_STATUS) | SMR_ST_EXECUTED;   // nor the statuses the bars imply
 #endif
             hb->s_bal[o] = bal[t]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[t];
             uint32_t vm = (m >> M_VMODE_SH) & 3u;

@@ -158,7 +158,7 @@ def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
 def test_multipaxos_experiment_variants_on_the_host(sim, oracle):
     """compile-time kernel experiments waiting for their device A/B (tools/experiments/README.md) must at least be right"""
     import test_mp_gpu as t
-    for defs in (("SMR_ACK_BITS", "SMR_SKIP_REG_OUTBOX", "SMR_BAL_RUN", "SMR_BAL_LAZY"),):   # each also alone by hand (tools/experiments/README.md); together here
+    for defs in (("SMR_ACK_BITS", "SMR_SKIP_REG_OUTBOX", "SMR_BAL_RUN", "SMR_BAL_LAZY", "SMR_STATUS_LAZY"),):   # each also alone by hand (tools/experiments/README.md); together here
         with sim.patched(defines=defs):
             t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
             t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)

@@ -4,7 +4,8 @@
 #   python tools/build_variant.py ackbits -DSMR_ACK_BITS
 #   python tools/build_variant.py balrun -DSMR_BAL_RUN
 #   python tools/build_variant.py ballazy -DSMR_BAL_RUN -DSMR_BAL_LAZY
-#   python tools/build_variant.py all4 -DSMR_ACK_BITS -DSMR_SKIP_REG_OUTBOX -DSMR_BAL_RUN -DSMR_BAL_LAZY
+#   python tools/build_variant.py statuslazy -DSMR_BAL_RUN -DSMR_STATUS_LAZY
+#   python tools/build_variant.py all5 -DSMR_ACK_BITS -DSMR_SKIP_REG_OUTBOX -DSMR_BAL_RUN -DSMR_BAL_LAZY -DSMR_STATUS_LAZY
 #   gpurun --timeout 1500 -- 'bash tools/ab_experiments.sh'
 # Per variant: the MultiPaxos device tests (parity first), then the headline bench line twice; results in gpurun_out/ab_*.
 mkdir -p gpurun_out
@@ -28,7 +29,7 @@ PY
     done
 }
 run shipped ""
-for tag in regout ackbits balrun ballazy all4; do
+for tag in regout ackbits balrun ballazy statuslazy all5; do
     lib=$PWD/summerset_amd/variants/libsummerset_hip_$tag.so
     [ -f "$lib" ] && run $tag "$lib" || echo "$tag: build it first (tools/build_variant.py)"
 done
