@@ -97,3 +97,58 @@ class SpreadReplica:
         if self.local is None:
             raise RuntimeError("replica %d lives on rank %d" % (self.me, self.owner))
         return self.local.dump()
+
+
+# ---- near quorum reads over L2 (multipaxos/quorumread.rs; summerset_amd/quorumread.py) ---------------------------
+def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, order=None, stable=None, kv=None):
+    """One ReadQuery round of replica `issuer` with the replicas of every group spread over the ranks (replica r on rank
+    r mod world).  `replicas[r]` is the local object of replica r (numpy interface: handle_read_query / issue /
+    handle_replies, i.e. the oracle in tests or an adapter over QuorumReadGroup) on its owner's rank, None elsewhere;
+    `logs[r]` likewise the log view of replica r.  The exchange: every rank answers for its replicas, ONE all-gather of
+    the packed replies (state u8 + slot u32 + val u32 + from_leader per (replica, read, group)) gives every rank the
+    [R][B][G] reply arrays, the issuer's rank tallies, ONE broadcast returns the clients' answers.  `flags[R][G]` says
+    which replies arrive (loss); returns (outcome, out_val, done) on every rank."""
+    import torch
+    import torch.distributed as dist
+    R = len(replicas)
+    mine = [r for r in range(R) if owner_of(r, world) == rank]
+    B, G = keys.shape
+    per = B * G * 9 + G                                            # bytes of one replica's packed reply
+    slots = (R + world - 1) // world                               # replicas per rank, padded
+    buf = np.zeros(slots * per, np.uint8)
+    own = None
+    for i, r in enumerate(mine):
+        st = stable if (stable is not None and r != issuer) else None
+        out, fl = replicas[r].handle_read_query(keys, n, logs[r], st, kv if st is not None else None)
+        if r == issuer:
+            own = out
+        o = i * per
+        buf[o:o + B * G] = out["state"].ravel(); o += B * G
+        buf[o:o + 4 * B * G] = out["slot"].astype(np.uint32).ravel().view(np.uint8); o += 4 * B * G
+        buf[o:o + 4 * B * G] = out["val"].astype(np.uint32).ravel().view(np.uint8); o += 4 * B * G
+        buf[o:o + G] = fl
+    gathered = [torch.zeros(slots * per, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(buf))
+    rep = dict(state=np.zeros((R, B, G), np.uint8), slot=np.zeros((R, B, G), np.uint32), val=np.zeros((R, B, G), np.uint32))
+    from_leader = np.zeros((R, G), np.uint8)
+    for rk in range(world):
+        a = gathered[rk].numpy()
+        for i, r in enumerate([x for x in range(R) if owner_of(x, world) == rk]):
+            o = i * per
+            rep["state"][r] = a[o:o + B * G].reshape(B, G); o += B * G
+            rep["slot"][r] = a[o:o + 4 * B * G].view(np.uint32).reshape(B, G); o += 4 * B * G
+            rep["val"][r] = a[o:o + 4 * B * G].view(np.uint32).reshape(B, G); o += 4 * B * G
+            from_leader[r] = a[o:o + G]
+    res = np.zeros(B * G * 5 + G, np.uint8)
+    if owner_of(issuer, world) == rank:
+        replicas[issuer].issue(q, n, own)
+        fl = (flags & 1) | (from_leader << 1) * (flags & 1)
+        fl[issuer] = 0
+        outcome, out_val, done = replicas[issuer].handle_replies(q, rep, fl.astype(np.uint8), order)
+        res[:B * G] = outcome.ravel()
+        res[B * G:5 * B * G] = out_val.astype(np.uint32).ravel().view(np.uint8)
+        res[5 * B * G:] = done
+    t = torch.from_numpy(res)
+    dist.broadcast(t, src=owner_of(issuer, world))
+    res = t.numpy()
+    return (res[:B * G].reshape(B, G).copy(), res[B * G:5 * B * G].view(np.uint32).reshape(B, G).copy(), res[5 * B * G:].copy())
