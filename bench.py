@@ -668,6 +668,8 @@ def main():
                 line[name] = fn(*a)
             except Exception as e:                 # noqa: BLE001
                 line[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:                              # secondary legs and the CPU baseline belong to the N=1 line only: the
+            args.no_cpu = args.no_rs = args.no_extra = True   # other ranks sit in the closing barrier meanwhile
         if not args.no_cpu:
             leg("cpu_baseline", cpu_leg, args, args.cpu_seconds)
         if not args.no_rs:
