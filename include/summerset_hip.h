@@ -189,6 +189,30 @@ int smr_mp_end_tick(smr_mp_cluster *c);
  * whose ballot is not the entry's. */
 int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_t *n_bytes);
 
+/* The same acknowledgements as RECORDS: one per PeerMsg::AcceptReply { slot, ballot } that replica `peer` sent to
+ * replica `rep` of `group` (multipaxos/messages.rs:370-443; emitted at durability.rs:108-131).  This is the form a host
+ * with real sockets holds them in (what `smr_wire_*` decodes a frame to) and the form the multi-GPU exchange ships.
+ *   smr_mp_deliver_acks  between R2 and R3: puts n device records into `rep`'s ack matrix, i.e. the batched
+ *       "handle_msg_accept_reply was called with these" -- the handler's own filters (ballot == bal_prepared, status,
+ *       duplicates; messages.rs:377-406) run in R3 as for locally produced acknowledgements.  A record that answers no
+ *       Accept `rep` sent this tick (other ballot, slot not in the outbox, bad group / peer, peer == rep) is ignored and
+ *       counted in *dropped_dev (device u64, may be NULL; the caller zeroes it) -- never an error.
+ *   smr_mp_collect_acks  the inverse, after R2: every set cell of `rep`'s ack matrix as a record, in no particular
+ *       order (arrival order is ackctl's business); *n_dev (device u64) = their number, of which at most `cap` are stored.
+ *   smr_mp_clear_acks    zeroes `rep`'s ack matrix (a host that delivers records instead of running R2 for remote
+ *       followers starts the tick's matrix from nothing).
+ * All three only enqueue work on `stream`. */
+typedef struct {
+    uint32_t group, slot;
+    uint64_t ballot;
+    uint32_t peer;          /* the replica that accepted (ReplicaId) */
+    uint32_t reserved;      /* 0 */
+} smr_mp_ack;               /* 24 bytes */
+int smr_mp_deliver_acks(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_dev, uint64_t n, uint64_t *dropped_dev,
+                        void *stream);
+int smr_mp_collect_acks(smr_mp_cluster *c, uint8_t rep, smr_mp_ack *out_dev, uint64_t cap, uint64_t *n_dev, void *stream);
+int smr_mp_clear_acks(smr_mp_cluster *c, uint8_t rep, void *stream);
+
 /* --- read-back (host buffers; each call synchronizes the device) -------- */
 int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_mp_group_state *out);
 

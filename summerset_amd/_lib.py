@@ -177,6 +177,9 @@ SYMBOLS = [
     ("smr_mp_round_heartbeat", _i, [_vp, _vp]),
     ("smr_mp_end_tick", _i, [_vp]),
     ("smr_mp_ack_matrix", _i, [_vp, _u8, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("smr_mp_deliver_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),
+    ("smr_mp_collect_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),
+    ("smr_mp_clear_acks", _i, [_vp, _u8, _vp]),
     ("smr_mp_read_group_state", _i, [_vp, _u32, _u8, C.POINTER(MpGroupState)]),
     ("smr_mp_dump", _i, [_vp, _u8, C.POINTER(MpDumpBufs)]),
     ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),

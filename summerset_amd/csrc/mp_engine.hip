@@ -1118,6 +1118,95 @@ __global__ __launch_bounds__(512) void mp_straggler_tick(const MpParams *__restr
 // ------------------------------------------------------------------ host ---
 struct ProfEv { hipEvent_t a, b; int which; };
 
+
+// ---- AcceptReply records <-> ack matrix (smr_mp_deliver_acks / smr_mp_collect_acks) ---------------
+// The ack matrix is the batched form of "the AcceptReply messages that reached replica `rep` this tick"
+// (PeerMsg::AcceptReply { slot, ballot } from `peer`, multipaxos/messages.rs:370-443).  A host that owns real
+// I/O, or the multi-GPU exchange, holds them as records; these two kernels convert, one way and back.
+// my outbox entry that is the Accept (slot, ballot) of group g, or NO_ENTRY
+constexpr uint32_t NO_ENTRY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t find_accept_entry(const MpParams &P, const RepView &v, int par, uint32_t g,
+                                                      uint32_t slot, uint64_t ballot) {
+    uint32_t cnt = v.ob_cnt(par)[g];
+    if (cnt > P.cap) cnt = P.cap;
+    const uint32_t reg = v.ob_reg(par)[g];
+    if (reg) {                                                   // Accepts of the consecutive slots (reg - 1) + j at ob_rbal
+        const uint32_t j = slot - (reg - 1);
+        return (slot >= reg - 1 && j < cnt && ballot == v.ob_rbal(par)[g]) ? j : NO_ENTRY;
+    }
+    for (uint32_t j = 0; j < cnt; j++) {
+        const size_t o = tix(P.cap, j, g);
+        const uint32_t e = v.ob_slot(par)[o];
+        if ((e >> OB_KIND_SH) == OB_ACCEPT && (e & OB_SLOT_MASK) == slot && v.ob_bal(par)[o] == ballot) return j;
+    }
+    return NO_ENTRY;
+}
+
+// one lane per record; a record that answers no Accept of this tick's outbox (other ballot, unknown slot, bad group /
+// peer, my own id) is counted in *dropped and ignored, as the reference ignores an outdated AcceptReply
+__global__ __launch_bounds__(256) void mp_deliver_acks_kernel(const MpParams *__restrict__ Pp, int par, uint32_t rep,
+                                                              const smr_mp_ack *__restrict__ recs, uint64_t n,
+                                                              unsigned long long *__restrict__ dropped) {
+    const MpParams &P = *Pp;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t drop = 0;
+    if (i < n) {
+        const smr_mp_ack a = recs[i];
+        drop = 1;
+        if (a.group < P.G && a.peer < P.R && a.peer != rep) {
+            const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+            const uint32_t j = find_accept_entry(P, v, par, a.group, a.slot, a.ballot);
+            if (j != NO_ENTRY) {
+                drop = 0;
+#ifdef SMR_ACK_BITS
+                if (j < 64u) atomicOr((unsigned long long *)&ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, a.peer, a.group)], 1ull << j);
+                else
+#endif
+                v.ack()[ack_ix(P.cap, j, a.peer, a.group)] = 1;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) drop += __shfl_xor(drop, off);
+    if (__lane_id() == 0 && drop && dropped) atomicAdd(dropped, (unsigned long long)drop);
+}
+
+// one lane per group: every set cell of my ack matrix as a record (any order); *n_out counts them all, records past
+// `cap` are not stored
+__global__ __launch_bounds__(256) void mp_collect_acks_kernel(const MpParams *__restrict__ Pp, int par, uint32_t rep,
+                                                              smr_mp_ack *__restrict__ out, uint64_t cap,
+                                                              unsigned long long *__restrict__ n_out) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P.G) return;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    uint32_t cnt = v.ob_cnt(par)[g];
+    if (cnt > P.cap) cnt = P.cap;
+    const uint32_t reg = v.ob_reg(par)[g];
+    const uint64_t rbal = reg ? v.ob_rbal(par)[g] : 0ull;
+    SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)v.ack();
+    for (uint32_t j = 0; j < cnt; j++) {
+        const size_t o = tix(P.cap, j, g);
+        uint32_t slot; uint64_t bal;
+        if (reg) { slot = reg - 1 + j; bal = rbal; }
+        else {
+            const uint32_t e = v.ob_slot(par)[o];
+            if ((e >> OB_KIND_SH) != OB_ACCEPT) continue;
+            slot = e & OB_SLOT_MASK; bal = v.ob_bal(par)[o];
+        }
+        uint64_t w = ackw[o];
+#ifdef SMR_ACK_BITS
+        if (j < 64u) {
+            w = 0;
+            for (uint32_t q = 0; q < P.R; q++) w |= ((ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, q, g)] >> j) & 1ull) << (8 * q);
+        }
+#endif
+        for (uint32_t q = 0; q < P.R; q++) {
+            if (q == rep || !((w >> (8 * q)) & 0xFFull)) continue;
+            const unsigned long long idx = atomicAdd(n_out, 1ull);
+            if (idx < cap) { smr_mp_ack a; a.group = g; a.slot = slot; a.ballot = bal; a.peer = q; a.reserved = 0; out[idx] = a; }
+        }
+    }
+}
 }  // namespace smr
 
 using namespace smr;
@@ -1493,6 +1582,36 @@ int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_
     if (!c || rep >= c->cfg.population || !ack_dev) return fail(SMR_ERR_ARG, "mp: bad argument");
     *ack_dev = c->hp.rep[rep].ack;
     if (n_bytes) *n_bytes = (uint64_t)c->cfg.outbox_cap * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
+    return SMR_OK;
+}
+
+int smr_mp_deliver_acks(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_dev, uint64_t n, uint64_t *dropped_dev,
+                        void *stream) {
+    if (!c || rep >= c->cfg.population || (n && !acks_dev)) return fail(SMR_ERR_ARG, "mp: bad argument");
+    if (!n) return SMR_OK;
+    if (n > 0x7FFFFFFFull * 256) return fail(SMR_ERR_ARG, "mp: too many ack records for one call");
+    hipLaunchKernelGGL(mp_deliver_acks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c->dp, c->par,
+                       (uint32_t)rep, acks_dev, n, (unsigned long long *)dropped_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_mp_collect_acks(smr_mp_cluster *c, uint8_t rep, smr_mp_ack *out_dev, uint64_t cap, uint64_t *n_dev, void *stream) {
+    if (!c || rep >= c->cfg.population || !n_dev || (cap && !out_dev)) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipMemsetAsync(n_dev, 0, 8, (hipStream_t)stream));
+    hipLaunchKernelGGL(mp_collect_acks_kernel, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->dp,
+                       c->par, (uint32_t)rep, out_dev, cap, (unsigned long long *)n_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_mp_clear_acks(smr_mp_cluster *c, uint8_t rep, void *stream) {
+    if (!c || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    size_t nb = (size_t)c->cfg.outbox_cap * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
+#ifdef SMR_ACK_BITS
+    nb += (size_t)MAXR * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
+#endif
+    SMR_HIP_TRY(hipMemsetAsync(c->hp.rep[rep].ack, 0, nb, (hipStream_t)stream));
     return SMR_OK;
 }
 

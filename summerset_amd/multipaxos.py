@@ -18,6 +18,10 @@ _DUMP_T = {"leader": np.uint8, "bal_prep_sent": np.uint64, "bal_prepared": np.ui
            "s_rtrig": np.uint32, "s_rendp": np.uint32, "overflow": np.uint8}
 
 
+# smr_mp_ack (include/summerset_hip.h): one PeerMsg::AcceptReply { slot, ballot } from `peer`
+ACK_DTYPE = np.dtype([("group", "<u4"), ("slot", "<u4"), ("ballot", "<u8"), ("peer", "<u4"), ("reserved", "<u4")])
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -85,6 +89,21 @@ class MultiPaxosCluster:
         p, n = C.c_void_p(), C.c_uint64()
         check(self._L.smr_mp_ack_matrix(self._h, rep, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    # AcceptReply records <-> ack matrix (a host with real sockets; the multi-GPU exchange, spread.mp_exchange_acks)
+    def collect_acks(self, rep, out, n_out, stream=None):
+        """every AcceptReply that reached replica `rep` this tick (after R2) as ACK_DTYPE records into the device
+        uint8 tensor `out` (capacity len(out) // 24 records); their number into the device int64 tensor `n_out`"""
+        check(self._L.smr_mp_collect_acks(self._h, rep, _ptr(out), out.numel() // ACK_DTYPE.itemsize, _ptr(n_out),
+                                          self._stream(stream)))
+
+    def deliver_acks(self, rep, recs, n, dropped=None, stream=None):
+        """the first n ACK_DTYPE records of the device uint8 tensor `recs` into replica `rep`'s ack matrix (between R2
+        and R3); records answering no Accept of this tick are ignored and counted in the device int64 `dropped`"""
+        check(self._L.smr_mp_deliver_acks(self._h, rep, _ptr(recs), int(n), _ptr(dropped), self._stream(stream)))
+
+    def clear_acks(self, rep, stream=None):
+        check(self._L.smr_mp_clear_acks(self._h, rep, self._stream(stream)))
 
     def read_group_state(self, group, rep):
         st = MpGroupState()

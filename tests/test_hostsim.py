@@ -165,3 +165,10 @@ def test_multipaxos_experiment_variants_on_the_host(sim, oracle):
             t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False)
             t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
             t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=0, every=4)
+
+
+def test_accept_reply_records_on_the_host(sim, oracle):
+    """the AcceptReply record <-> ack matrix kernels (smr_mp_collect_acks / smr_mp_deliver_acks) under the emulator"""
+    import test_mp_gpu as t
+    with sim.patched():
+        t.test_accept_replies_as_records("cpu", oracle)

@@ -32,6 +32,47 @@ def _compare(eng, orc, R, tick, check_slots=True):
                                          % (tick, r, n, list(zip(w[:5], g[:5])), a[n][w[:5], g[:5]], b[n][w[:5], g[:5]]))
 
 
+def _acks_as_records(eng, cuda, G, R, cap, t):
+    """between R2 and R3: every replica's ack matrix taken out as AcceptReply records (smr_mp_collect_acks), the matrix
+    zeroed, the records -- shuffled, with records that answer nothing mixed in -- put back (smr_mp_deliver_acks); a
+    second collect must give the same set, and the tick must still end in the oracle's state"""
+    import torch
+    from summerset_amd.multipaxos import ACK_DTYPE
+    rng = np.random.default_rng(1000 + t)
+    room = cap * G * R
+    for r in range(R):
+        out = torch.zeros(room * ACK_DTYPE.itemsize, dtype=torch.uint8, device=cuda)
+        n = torch.zeros(1, dtype=torch.int64, device=cuda)
+        eng.collect_acks(r, out, n)
+        n0 = int(n.item())
+        assert n0 <= room
+        rec = out.cpu().numpy().view(ACK_DTYPE)[:n0].copy()
+        assert (rec["peer"] != r).all() and (rec["peer"] < R).all() and (rec["group"] < G).all()
+        junk = np.zeros(7, ACK_DTYPE)                          # must all be ignored and counted
+        if n0:
+            junk[:] = rec[rng.integers(0, n0, 7)]
+        junk["ballot"][0] += 1 << 8                            # an AcceptReply of another ballot
+        junk["slot"][1] += 100000                              # of a slot I sent no Accept for
+        junk["group"][2] = G                                   # out of range
+        junk["peer"][3] = R
+        junk["peer"][4] = r                                    # my own id
+        junk["ballot"][5] = 0
+        junk["slot"][6] = (1 << 30) - 1
+        mixed = np.concatenate([rec, junk])
+        mixed = mixed[rng.permutation(len(mixed))]
+        dev = torch.from_numpy(mixed.view(np.uint8).reshape(-1).copy()).to(cuda)
+        dropped = torch.zeros(1, dtype=torch.int64, device=cuda)
+        eng.clear_acks(r)
+        eng.collect_acks(r, out, n)
+        assert int(n.item()) == 0, "cleared matrix still holds acknowledgements"
+        eng.deliver_acks(r, dev, len(mixed), dropped)
+        eng.collect_acks(r, out, n)
+        assert int(dropped.item()) == len(junk), (t, r, int(dropped.item()))
+        assert int(n.item()) == n0, (t, r, int(n.item()), n0)
+        back = out.cpu().numpy().view(ACK_DTYPE)[:n0]
+        assert np.array_equal(np.sort(back, order=list(ACK_DTYPE.names)), np.sort(rec, order=list(ACK_DTYPE.names))), (t, r)
+
+
 def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, preset, commit_extra=0, seed=None,
          every=1, timeout_rep=1, straggler_ticks=0, per_round=False):
     from summerset_amd import MultiPaxosCluster, stream
@@ -59,6 +100,8 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
             d = _to_dev(inp, cuda)
             eng.round_local(d["timeout_rep"], d["timeout_src"], d["req_target"], d["req_cnt"], d["req_val"])
             eng.round_deliver()
+            if per_round == "records":
+                _acks_as_records(eng, cuda, G, R, cap, t)
             eng.round_replies(d["ackctl"], publish_heartbeat=inp["heartbeat"])
             if inp["heartbeat"]:
                 eng.round_heartbeat()
@@ -101,6 +144,16 @@ def test_leader_change(cuda, oracle, straggler_ticks):
 def test_leader_change_round_by_round(cuda, oracle):
     _run(cuda, oracle, G=300, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
          per_round=True)
+
+
+def test_accept_replies_as_records(cuda, oracle):
+    """smr_mp_collect_acks / smr_mp_clear_acks / smr_mp_deliver_acks: the acknowledgements of every tick -- steady
+    appends (regular outbox), losses, leader changes with their long re-Accept outboxes -- go through the record form
+    and the cluster still matches the oracle after every tick"""
+    _run(cuda, oracle, G=200, R=5, S=2, W=64, n_ticks=36, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True,
+         per_round="records")
+    _run(cuda, oracle, G=70, R=3, S=4, W=32, n_ticks=12, drop_p=0.0, timeout_frac=0.0, hb_every=3, preset=True,
+         per_round="records")
 
 
 def test_leader_change_straggler_list_overflow(cuda, oracle):
