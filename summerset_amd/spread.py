@@ -152,3 +152,56 @@ def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, ord
     dist.broadcast(t, src=owner_of(issuer, world))
     res = t.numpy()
     return (res[:B * G].reshape(B, G).copy(), res[B * G:5 * B * G].view(np.uint32).reshape(B, G).copy(), res[5 * B * G:].copy())
+
+
+# ---- MultiPaxos cluster engine: the AcceptReply exchange of L2 (multipaxos.MultiPaxosCluster.collect_acks / deliver_acks) ----
+def split_acks_by_owner(rec, total_groups, world):
+    """ACK_DTYPE records with GLOBAL group ids -> one array per rank, by the rank that owns the group's leader-side state
+    (shard.group_range blocks); group ids are rebased to the owner's block"""
+    from . import shard
+    out = []
+    for k in range(world):
+        lo, hi = shard.group_range(total_groups, world, k)
+        part = rec[(rec["group"] >= lo) & (rec["group"] < hi)].copy()
+        part["group"] -= lo
+        out.append(part)
+    return out
+
+
+def mp_exchange_acks(outgoing, rank, world, device="cpu"):
+    """The follower->leader half of a tick's all-to-all: `outgoing[k]` = the AcceptReply records
+    (multipaxos.ACK_DTYPE, 24 B each) the replicas hosted on this rank produced for leaders whose state lives on rank k
+    (smr_mp_collect_acks + split_acks_by_owner).  One all-gather of the world x world count matrix, then ONE collective
+    for the records -- all_to_all_single with the exact split sizes over RCCL (nccl backend); an all-gather of padded
+    buffers where the backend has no all-to-all (gloo on CPU).  Returns the records addressed to this rank, sender-major,
+    ready for smr_mp_deliver_acks before the quorum kernel (R3)."""
+    import torch
+    import torch.distributed as dist
+    from .multipaxos import ACK_DTYPE
+    B = ACK_DTYPE.itemsize
+    assert len(outgoing) == world
+    if world == 1:
+        return outgoing[0].copy()
+    cnt = torch.tensor([len(o) for o in outgoing], dtype=torch.int64, device=device)
+    allcnt = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(allcnt, cnt)
+    counts = torch.stack(allcnt).cpu().numpy()                       # counts[src][dst]
+    send = np.concatenate([o.view(np.uint8).reshape(-1) for o in outgoing]) if counts[rank].sum() else np.zeros(0, np.uint8)
+    if dist.get_backend() == "nccl":
+        t_in = torch.from_numpy(send.copy()).to(device)
+        t_out = torch.empty(int(counts[:, rank].sum()) * B, dtype=torch.uint8, device=device)
+        dist.all_to_all_single(t_out, t_in, output_split_sizes=[int(c) * B for c in counts[:, rank]],
+                               input_split_sizes=[int(c) * B for c in counts[rank]])
+        got = t_out.cpu().numpy()
+    else:
+        width = int(counts.sum(axis=1).max()) * B                     # every rank's whole send buffer, padded
+        buf = np.zeros(max(width, 1), np.uint8)
+        buf[:send.size] = send
+        gathered = [torch.zeros(max(width, 1), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(gathered, torch.from_numpy(buf))
+        parts = []
+        for src in range(world):
+            off = int(counts[src][:rank].sum()) * B
+            parts.append(gathered[src].numpy()[off:off + int(counts[src][rank]) * B])
+        got = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    return got.view(ACK_DTYPE).copy()

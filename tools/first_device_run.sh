@@ -6,7 +6,7 @@
 # 1. their device tests  2. their bench legs  3. a kernel trace of the legs (summary -> gpurun_out/)
 set -x
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_zz_ep_exec_gpu.py tests/test_zz_mp_wide_gpu.py tests/test_zz_rsp_gpu.py tests/test_zz_rsp_bytes_gpu.py tests/test_zz_craft_gpu.py tests/test_zz_qread_gpu.py tests/test_zz_kv_gpu.py -q -m gpu 2>&1 | tail -15 | tee gpurun_out/late_tests.log
+timeout 600 python -m pytest tests/test_zz_ep_exec_gpu.py tests/test_zz_mp_wide_gpu.py tests/test_zz_rsp_gpu.py tests/test_zz_rsp_bytes_gpu.py tests/test_zz_craft_gpu.py tests/test_zz_qread_gpu.py tests/test_zz_kv_gpu.py tests/test_mp_gpu.py::test_accept_replies_as_records -q -m gpu 2>&1 | tail -15 | tee gpurun_out/late_tests.log
 for leg in epaxos_execution rspaxos_replica craft_leader quorum_read; do
     timeout 200 python bench.py --leg $leg > gpurun_out/leg_$leg.json 2> gpurun_out/leg_$leg.err || echo "leg $leg failed"
     tail -c 600 gpurun_out/leg_$leg.json
