@@ -61,6 +61,8 @@ def parse():
                     "(EPaxos execution, the RSPaxos replica engine), each in a child process")
     ap.add_argument("--leg", default=None, help="internal: run one secondary leg in this process and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--launch-check", action="store_true", help="only prove the launch: start the ranks --gpus asks for, count them "
+                    "with one all-reduce (RCCL with GPUs, gloo without) and print {n_gpus, ranks}; runs no kernel")
     return ap.parse_args()
 
 
@@ -561,12 +563,50 @@ def cpu_leg(args, seconds):
                       "path cannot be built here (no cargo, no vendored crates)" % (args.slots, cores, sn, s1, n1)}
 
 
-def main():
-    args = parse()
+def self_spawn(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks exactly as the driver's own
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would and hand
+    rank 0's JSON line (the only thing the ranks print on stdout) through."""
+    import subprocess
+    from summerset_amd import shard
+    cmd = shard.launch_command(n, os.path.abspath(__file__), sys.argv[1:])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS="1")
+    sys.stderr.write("bench.py: --gpus %d without a launcher: %s\n" % (n, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(rank, local, world):
     import torch
     import torch.distributed as dist
+    gpu = torch.cuda.is_available()
+    if gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d devices are visible" % (world, torch.cuda.device_count()))
+    dev = torch.device("cuda", local) if gpu else torch.device("cpu")
+    if gpu:
+        torch.cuda.set_device(local)
+    ranks = 1
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev) if gpu else dist.init_process_group("gloo")
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        ranks = int(one.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": ranks, "backend": ("nccl" if gpu else "gloo") if world > 1 else None}))
+
+
+def main():
+    args = parse()
     from summerset_amd import shard
-    rank, local, world = shard.env_world()
+    plan = shard.resolve_world(args.gpus)          # raises when the launcher's world is not --gpus
+    if plan[0] == "spawn":
+        self_spawn(plan[1])
+    _, rank, local, world = plan
+    if args.launch_check:
+        return launch_check(rank, local, world)
+    import torch
+    import torch.distributed as dist
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
         legs = {"rspaxos": rspaxos_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
@@ -575,6 +615,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d but only %d devices are visible" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -643,7 +685,8 @@ def main():
     t_qt = pmc_traffic("smr::mp_quorum_tally<5>") if S == 32 else None
     line = {
         "metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, "

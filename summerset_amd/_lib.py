@@ -312,6 +312,15 @@ def load():
     return _lib
 
 
+def stream_ptr(stream):
+    """The hipStream_t a call is launched on: an explicit handle (int), or torch's current stream.
+    One helper for every mirror class, so the binding layer has a single path (and one test)."""
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return int(stream)
+
+
 def check(rc):
     if rc != 0:
         raise SummersetError(rc, load().smr_last_error().decode("utf-8", "replace"))

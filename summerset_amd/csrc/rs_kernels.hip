@@ -22,6 +22,9 @@
 //             coefficients are wave-uniform kernel arguments: "is column c in plane b" is a
 //             scalar branch;
 //   * lut   : 256-entry product tables per coefficient, resident in LDS.
+#include <map>
+#include <mutex>
+
 #include "smr_common.h"
 
 namespace smr {
@@ -315,8 +318,33 @@ static void rs_finish_args(RsArgs &a) {
         else hipLaunchKernelGGL((K<8, 16>), __VA_ARGS__);                                          \
     } while (0)
 
-static uint8_t *g_lut_dev = nullptr;     // scratch for LUT variant tables
-static size_t g_lut_cap = 0;
+// Product tables of the LUT variant: one IMMUTABLE device buffer per coefficient matrix, built once under a
+// mutex and never overwritten or freed, so calls with different schemes / erasure patterns on different
+// streams or threads cannot disturb each other's tables (and no call waits for a stream to drain).
+static std::mutex g_lut_mu;
+static std::map<std::string, uint8_t *> g_lut_cache;
+
+static int rs_lut_table(const RsArgs &a, uint8_t **out) {
+    std::string key;
+    key.push_back((char)a.n_out); key.push_back((char)a.n_in);
+    for (int r = 0; r < a.n_out; r++) for (int c = 0; c < a.n_in; c++) key.push_back((char)a.coef[r][c]);
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    auto it = g_lut_cache.find(key);
+    if (it != g_lut_cache.end()) { *out = it->second; return SMR_OK; }
+    const Gf &g = gf();
+    const size_t ntab = (size_t)a.n_out * a.n_in * 256;
+    std::string tb(ntab, '\0');
+    for (int r = 0; r < a.n_out; r++)
+        for (int c = 0; c < a.n_in; c++)
+            for (int v = 0; v < 256; v++)
+                tb[((size_t)r * a.n_in + c) * 256 + v] = (char)g.mul(a.coef[r][c], (uint8_t)v);
+    uint8_t *dev = nullptr;
+    SMR_HIP_TRY(hipMalloc((void **)&dev, ntab));
+    SMR_HIP_TRY(hipMemcpy(dev, tb.data(), ntab, hipMemcpyHostToDevice));       // blocking, once per matrix
+    g_lut_cache.emplace(std::move(key), dev);
+    *out = dev;
+    return SMR_OK;
+}
 
 template <bool LUT>
 static int rs_launch(RsArgs &a, hipStream_t st) {
@@ -327,23 +355,12 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
     if (blocks > 0xFFFFFFull) return fail(SMR_ERR_ARG, "rs: too many codewords for one launch");
     dim3 grid((unsigned)blocks), block(256);
     if (LUT) {
-        const Gf &g = gf();
-        size_t ntab = (size_t)a.n_out * a.n_in * 256;
-        std::string tb(ntab, '\0');
-        for (int r = 0; r < a.n_out; r++)
-            for (int c = 0; c < a.n_in; c++)
-                for (int v = 0; v < 256; v++)
-                    tb[((size_t)r * a.n_in + c) * 256 + v] = (char)g.mul(a.coef[r][c], (uint8_t)v);
-        if (ntab > g_lut_cap) {
-            if (g_lut_dev) (void)hipFree(g_lut_dev);
-            SMR_HIP_TRY(hipMalloc((void **)&g_lut_dev, ntab));
-            g_lut_cap = ntab;
-        }
-        SMR_HIP_TRY(hipMemcpyAsync(g_lut_dev, tb.data(), ntab, hipMemcpyHostToDevice, st));
-        SMR_HIP_TRY(hipStreamSynchronize(st));   // tb is a host temporary
-        if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_lut<2>, grid, block, ntab, st, a, g_lut_dev);
-        else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_lut<4>, grid, block, ntab, st, a, g_lut_dev);
-        else hipLaunchKernelGGL(rs_matmul_lut<8>, grid, block, ntab, st, a, g_lut_dev);
+        const size_t ntab = (size_t)a.n_out * a.n_in * 256;
+        uint8_t *lut = nullptr;
+        if (int rc = rs_lut_table(a, &lut)) return rc;
+        if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_lut<2>, grid, block, ntab, st, a, lut);
+        else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_lut<4>, grid, block, ntab, st, a, lut);
+        else hipLaunchKernelGGL(rs_matmul_lut<8>, grid, block, ntab, st, a, lut);
     } else {
         RS_DISPATCH(rs_matmul_xtime, a, grid, block, 0, st, a);
     }

@@ -32,7 +32,7 @@ struct Wr {
     uint8_t *p; uint64_t cap, n = 0; bool ok = true;
     void byte(uint8_t b) { if (n < cap) p[n] = b; else ok = false; n++; }
     void raw(const void *src, uint64_t len) {
-        if (n + len <= cap && len) memcpy(p + n, src, len); else if (len) ok = false;
+        if (n <= cap && len <= cap - n) { if (len) memcpy(p + n, src, len); } else ok = false;
         n += len;
     }
     void le(uint64_t v, int bytes) { for (int i = 0; i < bytes; i++) byte((uint8_t)(v >> (8 * i))); }
@@ -58,7 +58,10 @@ struct Rd {
         ok = false;                                                              // 0xFE (u128) / 0xFF never occur here
         return 0;
     }
-    bool skip(uint64_t k) { if (n + k <= len) { n += k; return true; } ok = false; return false; }
+    // k comes off the wire (a peer's varint, up to 2^64 - 1): compare against the bytes LEFT, never n + k
+    bool skip(uint64_t k) { if (ok && k <= len - n) { n += k; return true; } ok = false; return false; }
+    // an element count: every element of every Vec on this path is >= 1 byte, so a count above the bytes left is malformed
+    uint64_t count() { const uint64_t c = varint(); if (!ok || c > len - n) { ok = false; return 0; } return c; }
 };
 
 // finishes a frame whose payload was written at out + 8
@@ -76,7 +79,7 @@ static Wr frame_begin(uint8_t *out, uint64_t cap) {
 
 // walks one bincode ReqBatch starting at r.n; false if malformed
 static bool skip_reqbatch(Rd &r) {
-    const uint64_t n = r.varint();
+    const uint64_t n = r.count();
     for (uint64_t i = 0; i < n && r.ok; i++) {
         r.varint();                                                              // ClientId
         const uint64_t req = r.varint();                                         // ApiRequest variant
@@ -196,7 +199,7 @@ int64_t smr_wire_read_query_replies(const uint8_t *p, uint64_t len, uint32_t max
                                     uint64_t *value_len) {
     if (!p || !state || !slot || !value_off || !value_len) return fail(SMR_ERR_ARG, "wire: null argument");
     Rd r{p, len};
-    const uint64_t n = r.varint();
+    const uint64_t n = r.count();
     if (!r.ok || n > max) return fail(SMR_ERR_ARG, "wire: more replies than the caller has room for");
     for (uint64_t i = 0; i < n && r.ok; i++) {
         state[i] = 0; slot[i] = 0; value_off[i] = 0; value_len[i] = 0;
@@ -283,7 +286,7 @@ int64_t smr_wire_decode(const uint8_t *buf, uint64_t len, smr_wire_msg *m) {
         case SMR_WIRE_READ_QUERY_REPLY: {
             m->rq_client = r.varint(); m->rq_req_id = r.varint();
             m->replies_off = 8 + r.n;
-            const uint64_t n = r.varint();
+            const uint64_t n = r.count();
             m->n_replies = n;
             for (uint64_t i = 0; i < n && r.ok; i++) {
                 const uint8_t t = r.byte();
@@ -382,7 +385,7 @@ int64_t smr_wire_raft_decode(const uint8_t *buf, uint64_t len, smr_wire_raft_msg
     switch (v) {
         case 0: {
             m->term = r.varint(); m->prev_slot = r.varint(); m->prev_term = r.varint();
-            const uint64_t n = r.varint();
+            const uint64_t n = r.count();
             if (n > plen) { r.ok = false; break; }                               // every entry takes bytes
             m->n_entries = (uint32_t)n;
             for (uint64_t i = 0; i < n && r.ok; i++) {
@@ -428,7 +431,7 @@ static bool get_codeword(Rd &r, uint64_t base, smr_wire_codeword *c) {
     memset(c, 0, sizeof(*c));
     c->num_data_shards = r.byte(); c->num_parity_shards = r.byte();
     c->data_len = r.varint(); c->shard_len = r.varint();
-    const uint64_t n = r.varint();
+    const uint64_t n = r.count();
     if (!r.ok || n != (uint64_t)c->num_data_shards + c->num_parity_shards || n > 16) { r.ok = false; return false; }
     for (uint64_t k = 0; k < n && r.ok; k++) {
         const uint8_t some = r.byte();
@@ -544,13 +547,13 @@ int64_t smr_wire_rsp_decode(const uint8_t *buf, uint64_t len, smr_wire_rsp_msg *
             break;
         case SMR_WIRE_ACCEPT_REPLY: m->slot = r.varint(); m->ballot = r.varint(); break;
         case SMR_WIRE_RSP_RECONSTRUCT: {
-            const uint64_t n = r.varint();
+            const uint64_t n = r.count();
             m->n_items = (uint32_t)n;
             for (uint64_t i = 0; i < n && r.ok; i++) { const uint64_t s = r.varint(); if (slots && i < max_items) slots[i] = s; }
             break;
         }
         case SMR_WIRE_RSP_RECONSTRUCT_REPLY: {
-            const uint64_t n = r.varint();
+            const uint64_t n = r.count();
             m->n_items = (uint32_t)n;
             for (uint64_t i = 0; i < n && r.ok; i++) {
                 const uint64_t s = r.varint(), b = r.varint();
@@ -621,7 +624,7 @@ int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *
     m->row = r.byte(); m->col = r.varint(); m->ballot = r.varint();
     if (v != SMR_WIRE_EP_ACCEPT_REPLY) {
         m->seq = r.varint();
-        const uint64_t n = r.varint();
+        const uint64_t n = r.count();
         if (n > 64) r.ok = false;
         m->n_deps = (uint32_t)n;
         for (uint64_t i = 0; i < n && r.ok; i++) {

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EpCfg, EpDumpBufs, EpMsg, check
+from ._lib import EpCfg, EpDumpBufs, EpMsg, check, stream_ptr
 
 NONE, NO_KEY = 0xFFFFFFFF, 0xFF
 
@@ -41,13 +41,6 @@ class EPaxosReplicaGroup:
     def __del__(self):
         self.close()
 
-    @staticmethod
-    def _stream(stream):
-        if stream is None:
-            import torch
-            return torch.cuda.current_stream().cuda_stream
-        return int(stream)
-
     def _out(self, dev, with_deps=True):
         import torch
         G, R = self.G, self.R
@@ -63,22 +56,22 @@ class EPaxosReplicaGroup:
         """propose key[g] (0xFF = nothing) per group; returns the PreAccept tensors (flags, col, seq, deps)"""
         out = self._out(key.device)
         m = self._msg(out)
-        check(self._L.smr_ep_propose(self._h, _ptr(key), _ptr(exploded), C.byref(m), self._stream(stream)))
+        check(self._L.smr_ep_propose(self._h, _ptr(key), _ptr(exploded), C.byref(m), stream_ptr(stream)))
         return out
 
     def handle_msg_pre_accept(self, msg, stream=None):
         out = self._out(msg["flags"].device)
         check(self._L.smr_ep_handle_pre_accept(self._h, C.byref(self._msg(msg)), C.byref(self._msg(out)),
-                                               self._stream(stream)))
+                                               stream_ptr(stream)))
         return out
 
     def handle_msg_accept(self, msg, stream=None):
         out = self._out(msg["flags"].device)
-        check(self._L.smr_ep_handle_accept(self._h, C.byref(self._msg(msg)), C.byref(self._msg(out)), self._stream(stream)))
+        check(self._L.smr_ep_handle_accept(self._h, C.byref(self._msg(msg)), C.byref(self._msg(out)), stream_ptr(stream)))
         return out
 
     def handle_msg_commit_notice(self, msg, stream=None):
-        check(self._L.smr_ep_handle_commit_notice(self._h, C.byref(self._msg(msg)), self._stream(stream)))
+        check(self._L.smr_ep_handle_commit_notice(self._h, C.byref(self._msg(msg)), stream_ptr(stream)))
 
     def handle_msg_pre_accept_reply(self, col, ballot, seq, deps, flags, order=None, exploded=None, stream=None):
         """replies [R, G] (deps [R, R, G]) to my instance (me, col[g]); returns decision / seq / deps"""
@@ -88,14 +81,14 @@ class EPaxosReplicaGroup:
                  deps=torch.zeros((R, G), dtype=torch.int32, device=dev))
         check(self._L.smr_ep_handle_pre_accept_replies(self._h, _ptr(col), _ptr(ballot), _ptr(seq), _ptr(deps), _ptr(flags),
                                                        _ptr(order), _ptr(exploded), _ptr(r["decision"]), _ptr(r["seq"]),
-                                                       _ptr(r["deps"]), self._stream(stream)))
+                                                       _ptr(r["deps"]), stream_ptr(stream)))
         return r
 
     def handle_msg_accept_reply(self, col, ballot, flags, order=None, stream=None):
         import torch
         r = dict(committed=torch.zeros(self.G, dtype=torch.uint8, device=flags.device))
         check(self._L.smr_ep_handle_accept_replies(self._h, _ptr(col), _ptr(ballot), _ptr(flags), _ptr(order),
-                                                   _ptr(r["committed"]), self._stream(stream)))
+                                                   _ptr(r["committed"]), stream_ptr(stream)))
         return r
 
     def dump(self):

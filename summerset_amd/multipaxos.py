@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MpCfg, MpDumpBufs, MpGroupState, SummersetError, check
+from ._lib import MpCfg, MpDumpBufs, MpGroupState, SummersetError, check, stream_ptr
 
 _DUMP_T = {"leader": np.uint8, "bal_prep_sent": np.uint64, "bal_prepared": np.uint64, "bal_max_seen": np.uint64,
            "s_bal": np.uint64, "s_status": np.uint8, "s_reqs": np.uint32, "s_vbal": np.uint64,
@@ -49,13 +49,6 @@ class MultiPaxosCluster:
     def __del__(self):
         self.close()
 
-    @staticmethod
-    def _stream(stream):
-        if stream is None:
-            import torch
-            return torch.cuda.current_stream().cuda_stream
-        return int(stream)
-
     def preset_leader(self, rep=0):
         check(self._L.smr_mp_preset_leader(self._h, rep))
 
@@ -64,23 +57,23 @@ class MultiPaxosCluster:
         """One lock-step tick; arguments are device tensors (uint8 / uint32), see smr_mp_tick."""
         S = 0 if req_val is None else int(req_val.shape[0])
         check(self._L.smr_mp_tick(self._h, _ptr(timeout_rep), _ptr(timeout_src), _ptr(req_target), _ptr(req_cnt),
-                                  _ptr(req_val), S, _ptr(ackctl), int(heartbeat), self._stream(stream)))
+                                  _ptr(req_val), S, _ptr(ackctl), int(heartbeat), stream_ptr(stream)))
 
     # the four rounds individually (multi-GPU driver / hosts with real I/O)
     def round_local(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None,
                     stream=None):
         S = 0 if req_val is None else int(req_val.shape[0])
         check(self._L.smr_mp_round_local(self._h, _ptr(timeout_rep), _ptr(timeout_src), _ptr(req_target),
-                                         _ptr(req_cnt), _ptr(req_val), S, self._stream(stream)))
+                                         _ptr(req_cnt), _ptr(req_val), S, stream_ptr(stream)))
 
     def round_deliver(self, stream=None):
-        check(self._L.smr_mp_round_deliver(self._h, self._stream(stream)))
+        check(self._L.smr_mp_round_deliver(self._h, stream_ptr(stream)))
 
     def round_replies(self, ackctl=None, publish_heartbeat=False, stream=None):
-        check(self._L.smr_mp_round_replies(self._h, _ptr(ackctl), int(publish_heartbeat), self._stream(stream)))
+        check(self._L.smr_mp_round_replies(self._h, _ptr(ackctl), int(publish_heartbeat), stream_ptr(stream)))
 
     def round_heartbeat(self, stream=None):
-        check(self._L.smr_mp_round_heartbeat(self._h, self._stream(stream)))
+        check(self._L.smr_mp_round_heartbeat(self._h, stream_ptr(stream)))
 
     def end_tick(self):
         check(self._L.smr_mp_end_tick(self._h))
@@ -95,15 +88,15 @@ class MultiPaxosCluster:
         """every AcceptReply that reached replica `rep` this tick (after R2) as ACK_DTYPE records into the device
         uint8 tensor `out` (capacity len(out) // 24 records); their number into the device int64 tensor `n_out`"""
         check(self._L.smr_mp_collect_acks(self._h, rep, _ptr(out), out.numel() // ACK_DTYPE.itemsize, _ptr(n_out),
-                                          self._stream(stream)))
+                                          stream_ptr(stream)))
 
     def deliver_acks(self, rep, recs, n, dropped=None, stream=None):
         """the first n ACK_DTYPE records of the device uint8 tensor `recs` into replica `rep`'s ack matrix (between R2
         and R3); records answering no Accept of this tick are ignored and counted in the device int64 `dropped`"""
-        check(self._L.smr_mp_deliver_acks(self._h, rep, _ptr(recs), int(n), _ptr(dropped), self._stream(stream)))
+        check(self._L.smr_mp_deliver_acks(self._h, rep, _ptr(recs), int(n), _ptr(dropped), stream_ptr(stream)))
 
     def clear_acks(self, rep, stream=None):
-        check(self._L.smr_mp_clear_acks(self._h, rep, self._stream(stream)))
+        check(self._L.smr_mp_clear_acks(self._h, rep, stream_ptr(stream)))
 
     def read_group_state(self, group, rep):
         st = MpGroupState()

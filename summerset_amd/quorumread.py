@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import QreadCfg, QreadLog, QreadReplies, check
+from ._lib import QreadCfg, QreadLog, QreadReplies, check, stream_ptr
 
 NONE, SLOT, VALUE = 0, 1, 2                       # Option<(slot, Option<value>)>
 PENDING, NOT_FOUND, RETRY, GOT_VALUE = 0, 1, 2, 3
@@ -37,13 +37,6 @@ class QuorumReadGroup:
     def __del__(self):
         self.close()
 
-    @staticmethod
-    def _stream(stream):
-        if stream is None:
-            import torch
-            return torch.cuda.current_stream().cuda_stream
-        return int(stream)
-
     def _replies(self, lead, device):
         import torch
         shape = tuple(lead) + (self.B, self.G)
@@ -56,7 +49,7 @@ class QuorumReadGroup:
 
     def refresh_highest_slot(self, slot, put_keys, stream=None):
         """slot[g] (int32, -1 = no batch) gets a batch whose Puts write put_keys[B, g] (uint8, 0xFF = not a Put)"""
-        check(self._L.smr_qread_refresh_highest_slot(self._h, _ptr(slot), _ptr(put_keys), self._stream(stream)))
+        check(self._L.smr_qread_refresh_highest_slot(self._h, _ptr(slot), _ptr(put_keys), stream_ptr(stream)))
 
     def handle_msg_read_query(self, keys, n, log, stable_leader=None, kv=None, stream=None):
         """log = dict(start_slot, log_end [G] int32; status uint8, token int32 [W, G]), or the `QreadLog` view of a replica
@@ -68,7 +61,7 @@ class QuorumReadGroup:
                                                             _ptr(log["token"]), int(log["status"].shape[0]), 0)
         rs = self._rs(out)
         check(self._L.smr_qread_handle_read_query(self._h, _ptr(keys), _ptr(n), _ptr(stable_leader), _ptr(kv), C.byref(lg),
-                                                  C.byref(rs), _ptr(fl), self._stream(stream)))
+                                                  C.byref(rs), _ptr(fl), stream_ptr(stream)))
         return out, fl
 
     def inspect_highest_slot(self, keys, n, log, stream=None):
@@ -76,7 +69,7 @@ class QuorumReadGroup:
 
     def issue(self, q, n, own, stream=None):
         rs = self._rs(own)
-        check(self._L.smr_qread_issue(self._h, int(q), _ptr(n), C.byref(rs), self._stream(stream)))
+        check(self._L.smr_qread_issue(self._h, int(q), _ptr(n), C.byref(rs), stream_ptr(stream)))
 
     def handle_msg_read_query_reply(self, q, replies, flags, order=None, stream=None):
         """replies: dict of [R, B, G] tensors; flags [R, G] (bit0 present, bit1 from_leader).  Returns outcome, out_val [B, G], done [G]"""
@@ -87,7 +80,7 @@ class QuorumReadGroup:
         done = torch.zeros(self.G, dtype=torch.uint8, device=dev)
         rs = self._rs(replies)
         check(self._L.smr_qread_handle_replies(self._h, int(q), C.byref(rs), _ptr(flags), _ptr(order), _ptr(outcome), _ptr(out_val),
-                                               _ptr(done), self._stream(stream)))
+                                               _ptr(done), stream_ptr(stream)))
         return outcome, out_val, done
 
     def dump(self):
@@ -122,12 +115,10 @@ class KvStateMachine:
     def __del__(self):
         self.close()
 
-    _stream = QuorumReadGroup._stream
-
     def execute(self, kind, key, val, stream=None):
         import torch
         res = torch.zeros(kind.shape, dtype=torch.int32, device=kind.device)
-        check(self._L.smr_kv_execute(self._h, int(kind.shape[0]), _ptr(kind), _ptr(key), _ptr(val), _ptr(res), self._stream(stream)))
+        check(self._L.smr_kv_execute(self._h, int(kind.shape[0]), _ptr(kind), _ptr(key), _ptr(val), _ptr(res), stream_ptr(stream)))
         return res
 
     def table_ptr(self):

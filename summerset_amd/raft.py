@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RaftAppendEntries, RaftAppendReply, RaftCfg, RaftDumpBufs, check
+from ._lib import RaftAppendEntries, RaftAppendReply, RaftCfg, RaftDumpBufs, check, stream_ptr
 
 _T = {"role": np.uint8, "leader": np.uint8, "curr_term": np.uint64, "entry_term": np.uint64}
 
@@ -38,22 +38,15 @@ class RaftLeaderGroup:
     def __del__(self):
         self.close()
 
-    @staticmethod
-    def _stream(stream):
-        if stream is None:
-            import torch
-            return torch.cuda.current_stream().cuda_stream
-        return int(stream)
-
     def handle_req_batch(self, n_new, stream=None):
         """append n_new[g] entries of the current term to every group's log"""
-        check(self._L.smr_raft_leader_append(self._h, _ptr(n_new), self._stream(stream)))
+        check(self._L.smr_raft_leader_append(self._h, _ptr(n_new), stream_ptr(stream)))
 
     def handle_req_batch_emit(self, n_new, stream=None):
         """handle_req_batch + [R, G] first slot of the entries sent to each peer (-1 = nothing)"""
         import torch
         first = torch.zeros((self.R, self.G), dtype=torch.int32, device=n_new.device)
-        check(self._L.smr_raft_leader_append_emit(self._h, _ptr(n_new), _ptr(first), self._stream(stream)))
+        check(self._L.smr_raft_leader_append_emit(self._h, _ptr(n_new), _ptr(first), stream_ptr(stream)))
         return first
 
     def gather_entries(self, first, max_entries, stream=None):
@@ -67,7 +60,7 @@ class RaftLeaderGroup:
         msg = RaftAppendEntries(_ptr(m["flags"]), _ptr(m["leader"]), _ptr(m["term"]), _ptr(m["prev_slot"]),
                                 _ptr(m["prev_term"]), _ptr(m["n_entries"]), _ptr(m["entry_term"]), K,
                                 _ptr(m["leader_commit"]), _ptr(m["last_snap"]))
-        check(self._L.smr_raft_leader_gather_entries(self._h, _ptr(first), C.byref(msg), self._stream(stream)))
+        check(self._L.smr_raft_leader_gather_entries(self._h, _ptr(first), C.byref(msg), stream_ptr(stream)))
         return m
 
     def handle_msg_append_entries_reply(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None,
@@ -75,7 +68,7 @@ class RaftLeaderGroup:
         """one AppendEntriesReply per (peer, group); device tensors shaped [R, G]"""
         check(self._L.smr_raft_leader_handle_replies(self._h, _ptr(reply_term), _ptr(end_slot), _ptr(conflict_term),
                                                      _ptr(conflict_slot), _ptr(flags), _ptr(order),
-                                                     self._stream(stream)))
+                                                     stream_ptr(stream)))
 
     def dump(self):
         G, W, R = self.G, self.W, self.R
@@ -109,7 +102,7 @@ class RaftLeaderGroup:
         m = RaftAppendEntries(_ptr(flags), _ptr(leader), _ptr(term), _ptr(prev_slot), _ptr(prev_term), _ptr(n_entries),
                               _ptr(entry_term), int(entry_term.shape[0]), _ptr(leader_commit), _ptr(last_snap))
         rr = RaftAppendReply(*[_ptr(r[k]) for k in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])
-        check(self._L.smr_raft_replica_handle_append_entries(self._h, C.byref(m), C.byref(rr), self._stream(stream)))
+        check(self._L.smr_raft_replica_handle_append_entries(self._h, C.byref(m), C.byref(rr), stream_ptr(stream)))
         return r
 
     def become_a_candidate(self, timeout_src, stream=None):
@@ -120,7 +113,7 @@ class RaftLeaderGroup:
                  last_term=torch.zeros(G, dtype=torch.int64, device=dev))
         check(self._L.smr_raft_replica_become_candidate(self._h, _ptr(timeout_src), _ptr(r["flags"]), _ptr(r["term"]),
                                                         _ptr(r["last_slot"]), _ptr(r["last_term"]),
-                                                        self._stream(stream)))
+                                                        stream_ptr(stream)))
         return r
 
     def handle_msg_request_vote(self, flags, candidate, term, last_slot, last_term, stream=None):
@@ -129,7 +122,7 @@ class RaftLeaderGroup:
         r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev))
         check(self._L.smr_raft_replica_handle_request_vote(self._h, _ptr(flags), _ptr(candidate), _ptr(term),
                                                            _ptr(last_slot), _ptr(last_term), _ptr(r["flags"]),
-                                                           _ptr(r["term"]), self._stream(stream)))
+                                                           _ptr(r["term"]), stream_ptr(stream)))
         return r
 
     def handle_msg_request_vote_reply(self, term, flags, order=None, stream=None):
@@ -140,7 +133,7 @@ class RaftLeaderGroup:
                  elected=torch.zeros(G, dtype=torch.uint8, device=dev))
         check(self._L.smr_raft_replica_handle_vote_replies(self._h, _ptr(term), _ptr(flags), _ptr(order),
                                                            _ptr(r["hb_prev_slot"]), _ptr(r["elected"]),
-                                                           self._stream(stream)))
+                                                           stream_ptr(stream)))
         return r
 
     def dump_votes(self):
@@ -173,19 +166,19 @@ class CRaftLeaderGroup(RaftLeaderGroup):
         m = dict(hb_flags=z((R, G), torch.uint8), prev_slot=z((R, G), torch.int32), prev_term=z((R, G), torch.int64),
                  leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
         check(self._L.smr_raft_craft_bcast_heartbeats(self._h, _ptr(m["hb_flags"]), _ptr(m["prev_slot"]), _ptr(m["prev_term"]),
-                                                      _ptr(m["leader_commit"]), _ptr(m["last_snap"]), self._stream(stream)))
+                                                      _ptr(m["leader_commit"]), _ptr(m["last_snap"]), stream_ptr(stream)))
         return m
 
     def switch_assignment_mode(self, to_full_copy, stream=None):
         """to_full_copy[g] (uint8): 0 / 1, anything else = no call for that group"""
-        check(self._L.smr_raft_craft_switch_assignment_mode(self._h, _ptr(to_full_copy), self._stream(stream)))
+        check(self._L.smr_raft_craft_switch_assignment_mode(self._h, _ptr(to_full_copy), stream_ptr(stream)))
 
     def assignment(self, device, stream=None):
         """shard masks of a new entry: persist [G] (the leader's WAL entry), send [R, G] (AppendEntries per peer)"""
         import torch
         persist = torch.zeros(self.G, dtype=torch.int32, device=device)
         send = torch.zeros((self.R, self.G), dtype=torch.int32, device=device)
-        check(self._L.smr_raft_craft_assignment(self._h, _ptr(persist), _ptr(send), self._stream(stream)))
+        check(self._L.smr_raft_craft_assignment(self._h, _ptr(persist), _ptr(send), stream_ptr(stream)))
         return persist, send
 
     def dump_craft(self):

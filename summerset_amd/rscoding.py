@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import SummersetError, check
+from ._lib import SummersetError, check, stream_ptr
 
 
 def rs_matrix(d, p):
@@ -29,13 +29,6 @@ def rs_shard_len(data_len, d):
     if d == 0:
         raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards is zero")
     return int(_lib.load().smr_rs_shard_len(data_len, d))
-
-
-def _stream_ptr(stream):
-    if stream is None:
-        import torch
-        return torch.cuda.current_stream().cuda_stream
-    return int(stream)
 
 
 class RSCodewordBatch:
@@ -153,7 +146,7 @@ class RSCodewordBatch:
         fn = L.smr_rs_encode_lut if lut else L.smr_rs_encode
         base = self.buf.data_ptr()
         check(fn(base, self.data_len, self.cw_stride, self.n, self.d, self.p,
-                 base + self.d * self.shard_len, self.cw_stride, self.shard_len, _stream_ptr(stream)))
+                 base + self.d * self.shard_len, self.cw_stride, self.shard_len, stream_ptr(stream)))
         self.avail |= ((1 << self.p) - 1) << self.d
 
     def _reconstruct(self, rs, data_only, stream):
@@ -168,7 +161,7 @@ class RSCodewordBatch:
             raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon coder is None")
         check(_lib.load().smr_rs_reconstruct(self.buf.data_ptr(), self.shard_len, self.shard_len,
                                              self.cw_stride, self.n, self.d, self.p, self.avail,
-                                             int(data_only), _stream_ptr(stream)))
+                                             int(data_only), stream_ptr(stream)))
         self.avail |= (1 << self.d) - 1
         if not data_only:
             self.avail |= ((1 << self.p) - 1) << self.d
@@ -195,7 +188,7 @@ class RSCodewordBatch:
                                  % (self.avail_shards(), self.d + self.p))
         ok = torch.empty(self.n, dtype=torch.uint8, device=self.buf.device)
         check(_lib.load().smr_rs_verify(self.buf.data_ptr(), self.shard_len, self.shard_len, self.cw_stride,
-                                        self.n, self.d, self.p, ok.data_ptr(), _stream_ptr(stream)))
+                                        self.n, self.d, self.p, ok.data_ptr(), stream_ptr(stream)))
         return ok.bool()
 
     def get_data(self):

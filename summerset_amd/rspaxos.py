@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import RspAccepts, RspCfg, RspDumpBufs, RspHeartbeat, RspPrepareReply, RspShards, check
+from ._lib import RspAccepts, RspCfg, RspDumpBufs, RspHeartbeat, RspPrepareReply, RspShards, check, stream_ptr
 
 NULL, NO_REP = 0xFFFFFFFF, 0xFF
 
@@ -39,13 +39,6 @@ class RSPaxosReplicaGroup:
 
     def __del__(self):
         self.close()
-
-    @staticmethod
-    def _stream(stream):
-        if stream is None:
-            import torch
-            return torch.cuda.current_stream().cuda_stream
-        return int(stream)
 
     def preset_leader(self, leader):
         check(self._L.smr_rsp_preset_leader(self._h, int(leader)))
@@ -73,21 +66,21 @@ class RSPaxosReplicaGroup:
     # ---- handlers -------------------------------------------------------------------------------
     def req_batch(self, val, stream=None):
         d, s = self._accepts(val.device)
-        check(self._L.smr_rsp_req_batch(self._h, _ptr(val), C.byref(s), self._stream(stream)))
+        check(self._L.smr_rsp_req_batch(self._h, _ptr(val), C.byref(s), stream_ptr(stream)))
         return d
 
     def accept(self, flags, peer, slot, ballot, val, mask, stream=None):
         import torch
         d = dict(r_ballot=self._z(flags.device, torch.int64), r_slot=self._z(flags.device, torch.int32))
         check(self._L.smr_rsp_handle_accept(self._h, _ptr(flags), _ptr(peer), _ptr(slot), _ptr(ballot), _ptr(val), _ptr(mask),
-                                            _ptr(d["r_ballot"]), _ptr(d["r_slot"]), self._stream(stream)))
+                                            _ptr(d["r_ballot"]), _ptr(d["r_slot"]), stream_ptr(stream)))
         return d
 
     def accept_replies(self, slot, ballot, flags, order=None, stream=None):
         import torch
         d = dict(committed=self._z(flags.device, torch.uint8))
         check(self._L.smr_rsp_handle_accept_replies(self._h, _ptr(slot), _ptr(ballot), _ptr(flags), _ptr(order),
-                                                    _ptr(d["committed"]), self._stream(stream)))
+                                                    _ptr(d["committed"]), stream_ptr(stream)))
         return d
 
     def become_leader(self, src, stream=None):
@@ -97,7 +90,7 @@ class RSPaxosReplicaGroup:
         d.update(p_flags=self._z(dev, torch.uint8), p_trig=self._z(dev, torch.int32), p_ballot=self._z(dev, torch.int64),
                  rc_n=self._z(dev, torch.int32), rc_slot=self._z(dev, torch.int32, self.W, self.G))
         check(self._L.smr_rsp_become_leader(self._h, _ptr(src), C.byref(hb), _ptr(d["p_flags"]), _ptr(d["p_trig"]),
-                                            _ptr(d["p_ballot"]), _ptr(d["rc_n"]), _ptr(d["rc_slot"]), self._stream(stream)))
+                                            _ptr(d["p_ballot"]), _ptr(d["rc_n"]), _ptr(d["rc_slot"]), stream_ptr(stream)))
         return d
 
     def _pr(self, d):
@@ -110,13 +103,13 @@ class RSPaxosReplicaGroup:
                  pr_ballot=self._z(dev, torch.int64), pr_vbal=self._z(dev, torch.int64, W, G),
                  pr_vval=self._z(dev, torch.int32, W, G, fill=-1), pr_vmask=self._z(dev, torch.uint8, W, G))
         check(self._L.smr_rsp_handle_prepare(self._h, _ptr(flags), _ptr(peer), _ptr(trig), _ptr(ballot), C.byref(self._pr(d)),
-                                             self._stream(stream)))
+                                             stream_ptr(stream)))
         return d
 
     def prepare_replies(self, peer, pr_n, pr_trig, pr_endp, pr_ballot, pr_vbal, pr_vval, pr_vmask, stream=None):
         d, s = self._accepts(peer.device)
         src = dict(pr_n=pr_n, pr_trig=pr_trig, pr_endp=pr_endp, pr_ballot=pr_ballot, pr_vbal=pr_vbal, pr_vval=pr_vval, pr_vmask=pr_vmask)
-        check(self._L.smr_rsp_handle_prepare_replies(self._h, _ptr(peer), C.byref(self._pr(src)), C.byref(s), self._stream(stream)))
+        check(self._L.smr_rsp_handle_prepare_replies(self._h, _ptr(peer), C.byref(self._pr(src)), C.byref(s), stream_ptr(stream)))
         return d
 
     def reconstruct(self, flags, rc_n, rc_slot, stream=None):
@@ -125,12 +118,12 @@ class RSPaxosReplicaGroup:
         d = dict(rr_n=self._z(dev, torch.int32), rr_slot=self._z(dev, torch.int32, W, G), rr_bal=self._z(dev, torch.int64, W, G),
                  rr_val=self._z(dev, torch.int32, W, G, fill=-1), rr_mask=self._z(dev, torch.uint8, W, G))
         s = RspShards(*[_ptr(d[k]) for k in ("rr_n", "rr_slot", "rr_bal", "rr_val", "rr_mask")])
-        check(self._L.smr_rsp_handle_reconstruct(self._h, _ptr(flags), _ptr(rc_n), _ptr(rc_slot), C.byref(s), self._stream(stream)))
+        check(self._L.smr_rsp_handle_reconstruct(self._h, _ptr(flags), _ptr(rc_n), _ptr(rc_slot), C.byref(s), stream_ptr(stream)))
         return d
 
     def reconstruct_reply(self, flags, rr_n, rr_slot, rr_bal, rr_val, rr_mask, stream=None):
         s = RspShards(_ptr(rr_n), _ptr(rr_slot), _ptr(rr_bal), _ptr(rr_val), _ptr(rr_mask))
-        check(self._L.smr_rsp_handle_reconstruct_reply(self._h, _ptr(flags), C.byref(s), self._stream(stream)))
+        check(self._L.smr_rsp_handle_reconstruct_reply(self._h, _ptr(flags), C.byref(s), stream_ptr(stream)))
 
     def heartbeat(self, flags, peer, ballot, commit_bar, exec_bar, snap_bar, stream=None):
         import torch
@@ -138,12 +131,12 @@ class RSPaxosReplicaGroup:
         o, out = self._hb(dev, "", False)
         reply = self._z(dev, torch.uint8)
         inp = RspHeartbeat(_ptr(flags), _ptr(ballot), _ptr(commit_bar), _ptr(exec_bar), _ptr(snap_bar))
-        check(self._L.smr_rsp_handle_heartbeat(self._h, _ptr(peer), C.byref(inp), _ptr(reply), C.byref(out), self._stream(stream)))
+        check(self._L.smr_rsp_handle_heartbeat(self._h, _ptr(peer), C.byref(inp), _ptr(reply), C.byref(out), stream_ptr(stream)))
         return dict(reply=reply, ballot=o["ballot"], commit_bar=o["commit"], exec_bar=o["exec"], snap_bar=o["snap"])
 
     def bcast_heartbeat(self, flags, stream=None):
         o, out = self._hb(flags.device, "", False)
-        check(self._L.smr_rsp_bcast_heartbeat(self._h, _ptr(flags), C.byref(out), self._stream(stream)))
+        check(self._L.smr_rsp_bcast_heartbeat(self._h, _ptr(flags), C.byref(out), stream_ptr(stream)))
         return dict(ballot=o["ballot"], commit_bar=o["commit"], exec_bar=o["exec"], snap_bar=o["snap"])
 
     def dump(self):

@@ -11,6 +11,13 @@ LEAVE, OTHER = 0xFE, 0xFF
 GET, PUT = 0, 1
 
 
+def _grow_or_raise(rc, cap):
+    """a negative return is retried with a larger buffer ONLY when the library says the buffer was the problem"""
+    msg = _lib.load().smr_last_error().decode("utf-8", "replace")
+    if "output buffer too small" not in msg or cap > (1 << 30):
+        raise _lib.SummersetError(int(rc), msg)
+
+
 def _call(fn, *args, cap=64):
     L = _lib.load()
     while True:
@@ -18,9 +25,8 @@ def _call(fn, *args, cap=64):
         n = getattr(L, fn)(*args, buf, cap)
         if n >= 0:
             return buf.raw[:n]
-        if cap > (1 << 30):
-            check(int(n))
-        cap *= 8                      # "output buffer too small": grow and retry
+        _grow_or_raise(n, cap)        # anything but "output buffer too small" is the caller's error: raise now
+        cap *= 8
 
 
 def reqbatch(reqs):
@@ -315,6 +321,5 @@ class Batcher:
             n = self._L.smr_batcher_tick(self._h, groups, counts, off, self.G, buf, cap)
             if n >= 0:
                 return {groups[k]: (counts[k], buf.raw[off[k]:off[k + 1]]) for k in range(n)}
-            if cap > (1 << 30):
-                check(int(n))
+            _grow_or_raise(n, cap)
             cap *= 8

@@ -132,14 +132,20 @@ def load(defines=()):
     return lib
 
 
+class _NullStream:
+    """what `torch.cuda.current_stream()` hands back under the emulator: the null stream"""
+    cuda_stream = 0
+
+
 @contextlib.contextmanager
 def patched(defines=()):
-    """the package talks to the simulated library; streams are the null stream"""
-    from summerset_amd import _lib, epaxos, multipaxos, quorumread, raft, rscoding, rspaxos
+    """the package talks to the simulated library.  Nothing of the Python mirror is replaced: the
+    mirror's own `_lib.stream_ptr(None)` runs and asks torch for the current stream, and only
+    torch's answer (there is no device here) is the null stream."""
+    import torch
+    from summerset_amd import _lib
     sim = load(defines)
-    null = staticmethod(lambda stream: 0)
-    spots = [(_lib, "_lib", sim), (epaxos.EPaxosReplicaGroup, "_stream", null), (raft.RaftLeaderGroup, "_stream", null), (rspaxos.RSPaxosReplicaGroup, "_stream", null),
-             (multipaxos.MultiPaxosCluster, "_stream", null), (quorumread.QuorumReadGroup, "_stream", null), (quorumread.KvStateMachine, "_stream", null), (rscoding, "_stream_ptr", lambda stream: 0)]
+    spots = [(_lib, "_lib", sim), (torch.cuda, "current_stream", lambda device=None: _NullStream())]
     saved = [(o, n, o.__dict__[n]) for o, n, _ in spots]
     for o, n, v in spots:
         setattr(o, n, v)

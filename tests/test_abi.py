@@ -142,3 +142,26 @@ def test_cxx_host_loop_example_builds_and_links(engine_lib, tmp_path):
                            os.path.join(ROOT, "examples", "mp_host_loop.cpp"), "-L", os.path.join(ROOT, "summerset_amd"),
                            "-lsummerset_hip", "-Wl,-rpath," + os.path.join(ROOT, "summerset_amd"), "-o", str(out)])
     assert out.exists()
+
+
+def test_stream_handle_goes_through_one_helper(monkeypatch):
+    """Round 1's device failure: `KvStateMachine._stream = QuorumReadGroup._stream` unwrapped a staticmethod into
+    a bound method, and the emulator replaced `_stream` on every class, so no CPU test ran the real line.  Now
+    every mirror calls `_lib.stream_ptr`, the emulator patches torch only, and this test runs the helper itself."""
+    import inspect
+    import torch
+    from summerset_amd import _lib, epaxos, multipaxos, quorumread, raft, rscoding, rspaxos
+    assert _lib.stream_ptr(7) == 7 and _lib.stream_ptr(0) == 0
+
+    class S:
+        cuda_stream = 0x1234
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: S())
+    assert _lib.stream_ptr(None) == 0x1234
+    n_calls = 0
+    for mod in (epaxos, multipaxos, quorumread, raft, rscoding, rspaxos):
+        src = inspect.getsource(mod)
+        assert "current_stream" not in src, mod.__name__          # no private copy of the helper
+        n_calls += src.count("stream_ptr(stream)")
+        for _, cls in inspect.getmembers(mod, inspect.isclass):
+            assert not hasattr(cls, "_stream"), cls
+    assert n_calls > 40

@@ -169,7 +169,7 @@ def test_padding_bytes_are_never_read(cuda, oracle):
     sl = 1367
     par = torch.zeros((n, 2, 1376), dtype=torch.uint8, device=cuda)
     check(_lib.load().smr_rs_encode(dev.data_ptr(), L, stride, n, 3, 2, par.data_ptr(), 2 * 1376, 1376,
-                                    rscoding._stream_ptr(None)))
+                                    _lib.stream_ptr(None)))
     got = par.cpu().numpy()
     for i in range(n):
         assert np.array_equal(got[i, :, :sl], oracle.rs_encode(3, 2, raw[i, :L]))

@@ -98,3 +98,41 @@ def test_world_size_2_gloo(tmp_path):
     assert commits == int(r0["total"]) and commits > 0
     assert np.array_equal(cbar, np.concatenate([r0["cbar"], r1["cbar"]]))
     assert np.array_equal(leader, np.concatenate([r0["leader"], r1["leader"]]))
+
+
+def test_bench_launch_plan():
+    """`python bench.py --gpus N` is how the driver asks for N ranks at round end (through torchrun) and how a user does
+    without one: the flag and the launcher's environment must agree, and without a launcher the script spawns the ranks"""
+    from summerset_amd import shard
+    assert shard.resolve_world(1, {}) == ("run", 0, 0, 1)
+    assert shard.resolve_world(8, {}) == ("spawn", 8)
+    assert shard.resolve_world(4, {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}) == ("run", 3, 3, 4)
+    assert shard.resolve_world(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}) == ("run", 0, 0, 1)
+    with pytest.raises(ValueError):
+        shard.resolve_world(8, {"WORLD_SIZE": "1"})           # round 1's bug shape: --gpus parsed, never honoured
+    with pytest.raises(ValueError):
+        shard.resolve_world(1, {"WORLD_SIZE": "2"})
+    with pytest.raises(ValueError):
+        shard.resolve_world(0, {})
+    cmd = shard.launch_command(8, "bench.py", ["--gpus", "8", "--steps", "20"], port=29511, python="python")
+    assert cmd == ["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                   "--master-port", "29511", "bench.py", "--gpus", "8", "--steps", "20"]
+
+
+def test_bench_self_spawns_the_ranks():
+    """the real thing on CPU: `python bench.py --gpus 2 --launch-check` starts two ranks (gloo: there is no GPU here),
+    they count themselves with one all-reduce and rank 0 prints one line"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo"
+    # a launcher whose world is not --gpus is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "launcher started 1 ranks" in bad.stderr

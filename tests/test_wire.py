@@ -253,3 +253,96 @@ def test_batcher_follows_get_req_batch(engine_lib):
     assert every.tick(cap=64) == {0: (300, wire.reqbatch(many))}   # the first buffer is too small: nothing consumed, retried
     with pytest.raises(SummersetError):
         b.submit(4, 1, 1, ("get", "k"))                          # no such group
+
+
+# ---- hostile frames: lengths and counts off the wire are a peer's to choose (Rd::skip overflow) ----
+
+def _frame(payload):
+    return len(payload).to_bytes(8, "big") + bytes(payload)
+
+
+_U64 = lambda v: bytes([0xFD]) + int(v).to_bytes(8, "little")
+
+
+def _decoders():
+    return [wire.decode, wire.raft_decode, wire.rsp_decode, wire.ep_decode]
+
+
+def test_huge_varint_lengths_are_malformed_not_a_hang():
+    """the 35-byte Accept of the advisor's report: ReqBatch count 2^64-1, key_len 2^64-13 -- `n + k` wrapped, the
+    cursor moved backwards and the element was re-parsed for ever"""
+    reqs = _U64(2 ** 64 - 1) + bytes([1, 0, 2, 1]) + _U64(2 ** 64 - 13)
+    acc = _frame(bytes([0, wire.ACCEPT, 5]) + bytes([0xFB, 0x01, 0x01]) + reqs)
+    with pytest.raises(SummersetError):
+        wire.decode(acc)
+    # the same batch with an honest count but a key length just past the end of the frame
+    for klen in (2 ** 64 - 1, 2 ** 63, 2 ** 32, 40):
+        reqs = bytes([1, 1, 0, 2, 1]) + _U64(klen) + b"k" * 8
+        with pytest.raises(SummersetError):
+            wire.decode(_frame(bytes([0, wire.ACCEPT, 5, 7]) + reqs))
+
+
+def test_element_counts_are_bounded_by_the_bytes_left():
+    # a ReqBatch that claims 2^40 requests inside a 20-byte frame
+    with pytest.raises(SummersetError):
+        wire.decode(_frame(bytes([0, wire.ACCEPT, 5, 7]) + _U64(2 ** 40) + bytes(6)))
+    # ReadQueryReply: a reply count far beyond the payload
+    good = wire.read_query_reply((3, 4), [(5, b"abc"), None])
+    n, m = wire.decode(good)
+    assert n == len(good) and m["kind"] == wire.READ_QUERY_REPLY
+
+
+def test_random_garbage_never_hangs_or_reads_outside_the_frame():
+    """every decoder on mutated valid frames and on random payloads: returns, raises SummersetError, or says
+    "incomplete" -- and every (offset, length) it hands back lies inside the buffer"""
+    rng = np.random.default_rng(0xF022)
+    rb = wire.reqbatch([(1, 2, ("put", "key", "value")), (1, 3, ("get", "key"))])
+    seeds = [wire.accept(9, 0x101, rb), wire.prepare_reply(18, 17, 40, 0x303, voted=(0x101, rb), accept_bar=16),
+             wire.read_query_reply((3, 4), [(5, b"abc"), None]), wire.raft_append_entries(2, 4, 1, [(2, rb, 1), (2, rb, 0)], 3),
+             wire.rsp_accept(4, 0x101, wire.rscodeword(3, 2, 10, [b"abcd", None, b"efgh", None, None])),
+             wire.rsp_reconstruct([1, 2, 3]), wire.ep_msg(0, 1, 2, 3, seq=4, deps=[1, None, 3, None, 5], reqs=rb)]
+    hostile = [0xFD, 0xFC, 0xFB, 0xFF, 0xFE, 0xFA, 0x00, 0x01]
+    tried = 0
+    for seed in seeds:
+        for _ in range(300):
+            b = bytearray(seed)
+            for _k in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(8, len(b)))
+                b[pos] = hostile[int(rng.integers(len(hostile)))] if rng.random() < 0.6 else int(rng.integers(256))
+                if rng.random() < 0.3:                          # a maximal u64 behind a 0xFD tag
+                    b[pos:pos + 9] = _U64(2 ** 64 - int(rng.integers(1, 20)))[: max(0, len(b) - pos)]
+            b = bytes(b[:len(seed)])
+            for dec in _decoders():
+                tried += 1
+                try:
+                    n, m = dec(b)
+                except SummersetError:
+                    continue
+                assert 0 <= n <= len(b)
+                if m:
+                    for k, v in m.items():
+                        if isinstance(v, (bytes, bytearray)):
+                            assert len(v) <= len(b)
+    for _ in range(500):
+        payload = rng.integers(0, 256, int(rng.integers(1, 48)), dtype=np.uint8).tobytes()
+        for dec in _decoders():
+            tried += 1
+            try:
+                n, m = dec(_frame(payload))
+                assert 0 <= n <= len(payload) + 8
+            except SummersetError:
+                pass
+    assert tried > 10000
+
+
+def test_argument_errors_do_not_grow_buffers():
+    """a negative return that is not "output buffer too small" raises at once (_call retried ten times
+    and ended on an 8 GiB allocation)"""
+    import time
+    t0 = time.time()
+    with pytest.raises(SummersetError):
+        wire.read_query(b"")
+    assert time.time() - t0 < 1.0
+    # and a small buffer still grows as before
+    big = wire.reqbatch([(1, 2, ("put", "k" * 300, "v" * 5000))])
+    assert len(big) > 5300
