@@ -115,7 +115,10 @@ typedef struct {
     uint8_t straggler_ticks; /* ticks a group spends on the engine's side stream after a HearTimeout, so its leader
                               * change runs beside the steady-state kernels (results do not depend on it):
                               * 0 / SMR_STRAGGLER_OFF = never (default) */
-    uint8_t reserved1;
+    uint8_t side_cus;        /* compute units set aside for that side stream (0 = none): while a tick has listed groups, the
+                              * side launch runs on these CUs only and the bulk launches on the others (two CU-masked HIP
+                              * streams forked from / joined to the caller's), so the serial latency of a leader change
+                              * overlaps the bulk kernels without taking wavefront slots from them */
     uint32_t window;        /* W: ring slots per replica per group, power of two */
     uint32_t win_reserve;   /* leader refuses new batches once W - win_reserve slots are live */
     uint32_t outbox_cap;    /* max messages a replica may emit per tick (>= W + 4 recommended) */
@@ -229,6 +232,10 @@ typedef struct {
     uint8_t *overflow;                  /* [G] */
 } smr_mp_dump_bufs;
 int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *host_bufs);
+/* the same for groups [g0, g0 + n) only (g0 a multiple of 64): host arrays are [n] / [R][n] / [W][n].  What a
+ * parity check at BASELINE sizes uses: 65 536 groups run on the device, slices of them are compared against an
+ * oracle started at that group offset (1.8 GB per replica would cross PCIe for a full dump at W = 512). */
+int smr_mp_dump_range(smr_mp_cluster *c, uint8_t rep, uint32_t g0, uint32_t n, const smr_mp_dump_bufs *host_bufs);
 
 /* counters of replica `rep`: [0] leader-side commits (Accepting->Committed,
  * messages.rs:412-433), [1] redirected batches (request.rs:128-154),
@@ -760,8 +767,11 @@ typedef struct { uint8_t *state; uint32_t *slot, *val; } smr_qread_replies;   /*
 /* the replica's log as inspect_highest_slot sees it: start_slot and log_end = start_slot + insts.len() [G]; Status
  * (Committed = 3) and batch token per slot, rings of `window` slots indexed by slot % window.  mp_layout 0: status is
  * uint8 [window][G], token uint32 [window][G].  mp_layout 1: the arrays of a replica of the MultiPaxos cluster engine as
- * they lie in HBM (smr_mp_replica_log_view): wave-tiled rings, status = the low 3 bits of the 32-bit meta words. */
-typedef struct { const uint32_t *start_slot, *log_end; const void *status; const uint32_t *token; uint32_t window, mp_layout; } smr_qread_log;
+ * they lie in HBM (smr_mp_replica_log_view): wave-tiled rings, status = the low 3 bits of the 32-bit meta words.
+ * run_lo / run_hi [G] (both NULL, or both set): slots in [run_lo[g], run_hi[g]) are Executed whatever the stored status
+ * says -- the engine keeps the statuses its followers learn by heartbeat implicit in (run start, commit_bar). */
+typedef struct { const uint32_t *start_slot, *log_end; const void *status; const uint32_t *token; uint32_t window, mp_layout;
+                 const uint32_t *run_lo, *run_hi; } smr_qread_log;
 /* the log of replica `rep` of a MultiPaxos cluster as smr_qread_handle_read_query reads it, in place (device pointers
  * into the cluster's arena; valid while the cluster lives; read them between ticks) */
 int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out);

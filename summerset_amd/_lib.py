@@ -27,7 +27,7 @@ class SummersetError(RuntimeError):
 
 class MpCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("commit_extra", C.c_uint8),
-                ("straggler_ticks", C.c_uint8), ("reserved1", C.c_uint8), ("window", C.c_uint32),
+                ("straggler_ticks", C.c_uint8), ("side_cus", C.c_uint8), ("window", C.c_uint32),
                 ("win_reserve", C.c_uint32), ("outbox_cap", C.c_uint32), ("commit_list_cap", C.c_uint32)]
 
 
@@ -60,7 +60,7 @@ class QreadReplies(C.Structure):
 
 class QreadLog(C.Structure):
     _fields_ = [("start_slot", C.c_void_p), ("log_end", C.c_void_p), ("status", C.c_void_p), ("token", C.c_void_p),
-                ("window", C.c_uint32), ("mp_layout", C.c_uint32)]
+                ("window", C.c_uint32), ("mp_layout", C.c_uint32), ("run_lo", C.c_void_p), ("run_hi", C.c_void_p)]
 
 
 class RaftCfg(C.Structure):
@@ -182,6 +182,7 @@ SYMBOLS = [
     ("smr_mp_clear_acks", _i, [_vp, _u8, _vp]),
     ("smr_mp_read_group_state", _i, [_vp, _u32, _u8, C.POINTER(MpGroupState)]),
     ("smr_mp_dump", _i, [_vp, _u8, C.POINTER(MpDumpBufs)]),
+    ("smr_mp_dump_range", _i, [_vp, C.c_uint8, _u32, _u32, C.POINTER(MpDumpBufs)]),
     ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),
     ("smr_mp_debug_generic_units", _i, [_vp, _u8, C.POINTER(_u64)]),
     ("smr_mp_debug_stamps", _i, [_vp, _vp]),

@@ -52,12 +52,10 @@ struct Lane {
     // values as loaded, for write-back of only what changed
     uint32_t o_leader; uint64_t o_bps, o_bpd, o_bms;
     uint32_t o_start, o_len, o_abar, o_cbar, o_ebar, o_snap, o_nlb;
-#ifdef SMR_BAL_RUN
     // Experiment (tools/experiments/README.md): [brun, len) is a run of slots all holding bal == bal_max_seen, kept by the
     // follower's steady-state append path and dropped (BAL_TOUCH) by everything else that writes a ballot or moves
     // bal_max_seen; the heartbeat's commit learning then need not load s_bal for slots inside it (8 of its 16 B per slot).
     uint32_t brun, o_brun;
-#if defined(SMR_BAL_LAZY) || defined(SMR_STATUS_LAZY)
     // ... and, one step further (-DSMR_BAL_LAZY): the follower's steady-state append does not STORE the ballot of a slot
     // inside the run (8 of the 16 B it writes per slot) -- the true value is bal_max_seen; whoever ends the run writes
     // the ballots out first (uniform mode: every lane its share), with the bal_max_seen the run was built under.
@@ -66,27 +64,11 @@ struct Lane {
     // passes them all; a run slot below commit_bar is Executed by definition (stored: Accepting), and whoever ends the
     // run writes those statuses out first.  Nothing reads a slot below commit_bar before that: the bar scans start at
     // commit_bar / accept_bar, every generic handler ends the run on entry.
-#ifdef SMR_BAL_LAZY
 #define BAL_MAT_BAL(_s) v.s_bal()[ix(_s)] = bms
-#else
-#define BAL_MAT_BAL(_s) ((void)0)
-#endif
-#ifdef SMR_STATUS_LAZY
 #define BAL_MAT_ST(_s) do { if ((_s) < cbar) { const size_t _i = ix(_s); v.s_meta()[_i] = m_set_st(v.s_meta()[_i], SMR_ST_EXECUTED); } } while (0)
-#else
-#define BAL_MAT_ST(_s) ((void)0)
-#endif
 #define BAL_TOUCH() do { if (brun != 0xFFFFFFFFu) { for (uint32_t _s = (brun > start ? brun : start) + cl; _s < len; _s += cn) { BAL_MAT_BAL(_s); BAL_MAT_ST(_s); } brun = 0xFFFFFFFFu; } } while (0)
-#else
-#define BAL_TOUCH() do { brun = 0xFFFFFFFFu; } while (0)
-#endif
 #define BAL_EXTEND(from) do { if (brun == 0xFFFFFFFFu || brun > (from)) brun = (from); } while (0)
 #define HB_BAL(slot, i) ((slot) >= brun ? ballot : v.s_bal()[i])
-#else
-#define BAL_TOUCH() do { } while (0)
-#define BAL_EXTEND(from) do { } while (0)
-#define HB_BAL(slot, i) v.s_bal()[i]
-#endif
     uint32_t obn0, obn1;           // outbox counts of parity 0 / 1 (scalars: a runtime-indexed
     bool obl0, obl1;               // array would live in scratch memory)
     uint32_t n_commit, n_redirect, n_reject;
@@ -122,9 +104,7 @@ struct Lane {
         o_ebar = ebar = v.exec_bar()[g];
         o_snap = snap = v.snap_bar()[g];
         o_nlb = nlb = v.null_lb()[g];
-#ifdef SMR_BAL_RUN
         o_brun = brun = v.bal_lo()[g];
-#endif
     }
     __device__ __forceinline__ void store() {
         if (leader != o_leader) if (wr) v.leader()[g] = (uint8_t)leader;
@@ -138,9 +118,7 @@ struct Lane {
         if (ebar != o_ebar) if (wr) v.exec_bar()[g] = ebar;
         if (snap != o_snap) if (wr) v.snap_bar()[g] = snap;
         if (nlb != o_nlb) if (wr) v.null_lb()[g] = nlb;
-#ifdef SMR_BAL_RUN
         if (brun != o_brun) if (wr) v.bal_lo()[g] = brun;
-#endif
         if (obl0) if (wr) v.ob_cnt(0)[g] = obn0;
         if (obl1) if (wr) v.ob_cnt(1)[g] = obn1;
         if (ovf && wr) P.overflow[g] = 1;
@@ -205,7 +183,6 @@ struct Lane {
     // not store ob_slot / ob_bal at all -- 12 of the 32 bytes mp_round_local writes per new slot -- and readers derive
     // them; whoever ends the run writes the `c` entries out first.
     __device__ __forceinline__ void ob_end_run(int p, uint32_t c) {
-#ifdef SMR_SKIP_REG_OUTBOX
         const uint32_t reg = v.ob_reg(p)[g];
         if (reg != 0) {
             const uint64_t rb = v.ob_rbal(p)[g];
@@ -215,9 +192,6 @@ struct Lane {
                 v.ob_bal(p)[oj] = rb;
             }
         }
-#else
-        (void)c;
-#endif
         if (wr) v.ob_reg(p)[g] = 0;
     }
     // transport_hub.bcast_msg(): append to my outbox of parity p
@@ -865,13 +839,9 @@ struct Lane {
             bool chase = false;
             if (!coop()) {
                 bool simple = true;
-#ifdef SMR_STATUS_LAZY
                 // slots below the run the usual way, then the run in one step
                 const bool lz = brun != 0xFFFFFFFFu && bms >= ballot;
                 const uint32_t eager_end = lz && brun < hb_commit ? (brun > sfx ? brun : sfx) : hb_commit;
-#else
-                const uint32_t eager_end = hb_commit;
-#endif
                 while (simple && sfx < eager_end) {
                     uint32_t mm[8]; uint64_t bb[8];
 #pragma unroll
@@ -890,7 +860,6 @@ struct Lane {
                         sfx++;
                     }
                 }
-#ifdef SMR_STATUS_LAZY
                 if (simple && lz && sfx >= brun && sfx < hb_commit) {
                     const uint32_t tgt = hb_commit < abar ? hb_commit : abar;
                     if (tgt > sfx) {
@@ -898,7 +867,6 @@ struct Lane {
                         sfx = tgt;
                     }
                 }
-#endif
                 if (sfx > c0) { cbar = sfx; if (chase) ebar = sfx; }
             }
             uint32_t first = 0xFFFFFFFFu, first_m = 0;
@@ -921,9 +889,7 @@ struct Lane {
                         if (bb[k] < ballot || st < SMR_ST_ACCEPTING) { go = false; break; }
                         if (st < SMR_ST_COMMITTED) {
                             uint32_t m = m_set_st(mm[k], SMR_ST_COMMITTED);
-#ifdef SMR_STATUS_LAZY
                             BAL_TOUCH();                        // a slot of the run marked one by one: the run ends here
-#endif
                             if (wr) v.s_meta()[ix(s)] = m;
                             if (first == 0xFFFFFFFFu) { first = s; first_m = m; }
                         }

@@ -155,12 +155,8 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                         const size_t i = tix(P.W, slot & Wm, g);
                         const size_t o = tix(P.cap, c0 + k + q, g);
                         sb[i] = bal; sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
-#ifdef SMR_SKIP_REG_OUTBOX
                         if (c0 != 0) { os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; }   // else: follow from ob_reg / ob_rbal
                         ov[o] = tok[q];
-#else
-                        os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; ov[o] = tok[q];
-#endif
                     }
                 }
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
@@ -203,7 +199,6 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
 }
 
 // ---- R2 ---------------------------------------------------------------------
-#ifdef SMR_ACK_BITS
 #define ACK_STORE(arr, j, val) do { if ((j) >= 64u) (arr)[ack_ix(P.cap, (j), r, g)] = (val); } while (0)
 template <int NR>
 __device__ __forceinline__ uint64_t ack_word_from_bits(const uint64_t (&ab)[NR], uint32_t j) {   // j < 64
@@ -212,9 +207,6 @@ __device__ __forceinline__ uint64_t ack_word_from_bits(const uint64_t (&ab)[NR],
     for (int q = 0; q < NR; q++) a |= ((ab[q] >> j) & 1ull) << (8 * q);
     return a;
 }
-#else
-#define ACK_STORE(arr, j, val) (arr)[ack_ix(P.cap, (j), r, g)] = (val)
-#endif
 // every outbox but mine, sender-major, FIFO; `first_sender` / `first_j`: resume point
 // left by the fast path
 __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint32_t first_j) {
@@ -226,20 +218,13 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
         const MpRep &snd = P.rep[s];
         const uint32_t cnt = snd.ob_cnt[par][g];
         uint32_t jstart = (s == first_sender ? first_j : 0u);
-#ifdef SMR_SKIP_REG_OUTBOX
         // a pure append run stores no ob_slot / ob_bal: entry j = Accept for slot ob_reg - 1 + j at ob_rbal
         const uint32_t sreg = snd.ob_reg[par][g];
         const uint64_t srbal = sreg ? snd.ob_rbal[par][g] : 0ull;
 #define SND_SLOT(j, o) (sreg ? ((OB_ACCEPT << OB_KIND_SH) | ((sreg - 1 + (j)) & OB_SLOT_MASK)) : snd.ob_slot[par][o])
 #define SND_BAL(o) (sreg ? srbal : snd.ob_bal[par][o])
-#else
-#define SND_SLOT(j, o) snd.ob_slot[par][o]
-#define SND_BAL(o) snd.ob_bal[par][o]
-#endif
-#ifdef SMR_ACK_BITS
         uint64_t abits = 0;                                      // my answers to this sender's entries < 64 (uniform in a job)
         const uint32_t ab_first = jstart;
-#endif
         // Uniform mode, first choice: the whole rest of this outbox (<= 512 messages) is ONE run of
         // Accepts at one ballot >= bal_max_seen for consecutive slots that start inside or right at
         // the end of my log (the re-Accept round of a new leader followed by its new batches).  Each
@@ -295,9 +280,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                         v.s_bal()[i] = bal0; v.s_val()[i] = tok[u]; v.s_meta()[i] = m;
                         ACK_STORE(snd.ack, jstart + t, 1);   // durability.rs:108-131
                     }
-#ifdef SMR_ACK_BITS
                     abits |= ack_range_bits(jstart, jstart + n);
-#endif
                     if (n_new) {
                         if (L.nlb == len0) L.nlb = len0 + n_new;  // still no Null below the log end
                         L.len = len0 + n_new;
@@ -348,9 +331,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 v.s_bal()[i] = bal0; v.s_val()[i] = val; v.s_meta()[i] = m;
                 ACK_STORE(snd.ack, j, 1); // durability.rs:108-131
             }
-#ifdef SMR_ACK_BITS
             abits |= ack_range_bits(jstart, jstart + nin);
-#endif
             // durability.rs:134-142: the completion of the slot AT accept_bar starts the scan; every
             // slot of the run is Accepting now, beyond it the scan reads memory
             if (appending) {
@@ -384,9 +365,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 if (kind == OB_ACCEPT) {
                     uint64_t rep = L.msg_accept(s, slot, bal[k], val[k]);
                     if (L.wr) ACK_STORE(snd.ack, j, rep ? 1 : 0);   // rep == bal[k] or none
-#ifdef SMR_ACK_BITS
                     if (rep && j < 64u) abits |= 1ull << j;
-#endif
                 } else if (kind == OB_PREPARE) {
                     L.msg_prepare(s, slot, bal[k]);
                 } else if (kind == OB_HEARTBEAT) {
@@ -394,12 +373,10 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
                 }
             }
         }
-#ifdef SMR_ACK_BITS
         if (cnt != 0 && L.wr) {                                  // one word for this sender: the tick's first writer stores, a resumed one adds
             SMR_G uint64_t *const w = &ack_bits_base(snd.ack, P.cap, P.G)[tix(MAXR, r, g)];
             *w = ab_first == 0 ? abits : (*w | abits);
         }
-#endif
     }
 #undef SND_SLOT
 #undef SND_BAL
@@ -454,11 +431,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         for (int k = 0; k < 8; k++) {
                             if (j0 + k >= cnt) break;
                             const size_t i = tix(W, (len + j0 + k) & Wm, g);
-#ifdef SMR_BAL_LAZY
                             (void)sb;
-#else
-                            sb[i] = bms;
-#endif
                             sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
                             ACK_STORE(ack, j0 + k, 1);
                         }
@@ -473,13 +446,9 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                     for (int k = 0; k < 8; k++) {
                         const bool in = j0 + k < cnt;
                         const size_t o = tix(P.cap, j0 + k, g);
-#ifdef SMR_SKIP_REG_OUTBOX
                         e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
                         bal[k] = !in ? 0ull : (reg ? snd.ob_rbal(par)[g] : obl[o]);
                         val[k] = in ? ov[o] : 0u;
-#else
-                        e[k] = in ? os[o] : 0u; bal[k] = in ? obl[o] : 0ull; val[k] = in ? ov[o] : 0u;
-#endif
                     }
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
@@ -489,11 +458,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                             break;
                         }
                         const size_t i = tix(W, len & Wm, g);
-#ifdef SMR_BAL_LAZY
                         (void)sb;
-#else
-                        sb[i] = bms;
-#endif
                         sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
                         ACK_STORE(ack, j0 + k, 1);
                         len++;
@@ -501,13 +466,9 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                     }
                 }
                 if (L.nlb == L.len) L.nlb = len;                 // still no Null below the log end
-#ifdef SMR_BAL_RUN
                 if (fast_done) { if (L.brun == 0xFFFFFFFFu || L.brun > L.len) L.brun = L.len; }   // appended at bal_max_seen
-#endif
                 L.len = len; L.abar = len;
-#ifdef SMR_ACK_BITS
                 if (fast_done) ack_bits_base(ack, P.cap, P.G)[tix(MAXR, r, g)] = ack_range_bits(0, fast_done);   // all of them accepted
-#endif
             }
         }
         // whatever is left goes to the wave as a cooperative job
@@ -608,11 +569,9 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
     constexpr int C = 8;                                         // ack-matrix rows per batch of loads
     SMR_G const uint32_t *const os = v.ob_slot(par);
     SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)v.ack();   // one word per (entry, group), byte q = replica q
-#ifdef SMR_ACK_BITS
     uint64_t ab[NR];                                             // entries < 64: one word per follower instead
 #pragma unroll
     for (int q = 0; q < NR; q++) ab[q] = (uint32_t)q < P.R ? ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, q, g)] : 0ull;
-#endif
     SMR_G const uint64_t *const obl = v.ob_bal(par);
     SMR_G uint32_t *const sm = v.s_meta(); SMR_G const uint64_t *const sb = v.s_bal();
     const uint32_t G = P.G, Wm = P.Wmask, R = P.R, thresh = P.thresh;
@@ -627,20 +586,11 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const uint32_t j = j0 + L.cl;
             const bool in = j < cnt;
             const size_t o = tix(P.cap, j, g);
-#ifdef SMR_SKIP_REG_OUTBOX
             const uint32_t creg = v.ob_reg(par)[g];
             const uint32_t e = !in ? 0u : (creg ? ((OB_ACCEPT << OB_KIND_SH) | ((creg - 1 + j) & OB_SLOT_MASK)) : os[o]);
             const uint64_t eb = !in ? 0ull : (creg ? v.ob_rbal(par)[g] : obl[o]);
-#else
-            const uint32_t e = in ? os[o] : 0u;
-            const uint64_t eb = in ? obl[o] : 0ull;
-#endif
             const uint32_t ctl = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-#ifdef SMR_ACK_BITS
             const uint64_t a = !in ? 0ull : (j < 64u ? ack_word_from_bits<NR>(ab, j) : ackw[o]);
-#else
-            const uint64_t a = in ? ackw[o] : 0ull;
-#endif
             const uint32_t slot = e & OB_SLOT_MASK;
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
             const size_t i = tix(P.W, slot & Wm, g);
@@ -710,11 +660,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             e[k] = !in ? 0u : (reg ? ((OB_ACCEPT << OB_KIND_SH) | ((reg - 1 + j0 + k) & OB_SLOT_MASK)) : os[o]);
             eb[k] = !in ? 0ull : (reg ? rbal : obl[o]);
             ctl[k] = (in && ackctl) ? ackctl[(size_t)(j0 + k) * G + g] : SMR_CTL_IDENTITY;
-#ifdef SMR_ACK_BITS
             a[k] = !in ? 0ull : (j0 + k < 64u ? ack_word_from_bits<NR>(ab, j0 + k) : ackw[o]);
-#else
-            a[k] = in ? ackw[o] : 0ull;
-#endif
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {                            // wave 2: the slots those Accepts name
@@ -833,12 +779,10 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
     SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
     SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)rep_shift(v0.ack, ro);
-#ifdef SMR_ACK_BITS
     uint64_t ab[NR];                                             // my replica's followers, entries < 64 (cand: cnt <= 64)
 #pragma unroll
     for (int q = 0; q < NR; q++)
         ab[q] = (cand && (uint32_t)q < R) ? ack_bits_base(rep_shift(v0.ack, ro), P.cap, P.G)[tix(MAXR, q, gg)] : 0ull;
-#endif
     SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
     const uint32_t q4 = (cnt + 3) / 4;
     const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
@@ -860,12 +804,8 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             const uint32_t j = j0 + k;
             const bool in = cand && j < jhi;
             ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-#ifdef SMR_ACK_BITS
             a[k] = in ? ack_word_from_bits<NR>(ab, j) : 0ull;
             (void)ackw;
-#else
-            a[k] = in ? ackw[tix(P.cap, j, g)] : 0ull;
-#endif
         }
     };
     load_acks(jlo);
@@ -1158,10 +1098,8 @@ __global__ __launch_bounds__(256) void mp_deliver_acks_kernel(const MpParams *__
             const uint32_t j = find_accept_entry(P, v, par, a.group, a.slot, a.ballot);
             if (j != NO_ENTRY) {
                 drop = 0;
-#ifdef SMR_ACK_BITS
                 if (j < 64u) atomicOr((unsigned long long *)&ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, a.peer, a.group)], 1ull << j);
                 else
-#endif
                 v.ack()[ack_ix(P.cap, j, a.peer, a.group)] = 1;
             }
         }
@@ -1194,12 +1132,10 @@ __global__ __launch_bounds__(256) void mp_collect_acks_kernel(const MpParams *__
             slot = e & OB_SLOT_MASK; bal = v.ob_bal(par)[o];
         }
         uint64_t w = ackw[o];
-#ifdef SMR_ACK_BITS
         if (j < 64u) {
             w = 0;
             for (uint32_t q = 0; q < P.R; q++) w |= ((ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, q, g)] >> j) & 1ull) << (8 * q);
         }
-#endif
         for (uint32_t q = 0; q < P.R; q++) {
             if (q == rep || !((w >> (8 * q)) & 0xFFull)) continue;
             const unsigned long long idx = atomicAdd(n_out, 1ull);
@@ -1221,7 +1157,8 @@ struct smr_mp_cluster {
     int lpar = 0;                    // straggler-list counter parity
     uint32_t ttl = 0;                // ticks on the side stream after a HearTimeout (0 = never)
     hipStream_t side = nullptr;      // straggler launches
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t bulk = nullptr;      // side_cus > 0: the bulk launches of a tick that has stragglers (the CUs the side stream leaves)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bjoin = nullptr;
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     bool profile = false;
@@ -1260,9 +1197,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
         carve(a, v.start_slot, G, dry); carve(a, v.log_len, G, dry); carve(a, v.accept_bar, G, dry);
         carve(a, v.commit_bar, G, dry); carve(a, v.exec_bar, G, dry); carve(a, v.snap_bar, G, dry);
         carve(a, v.null_lb, G, dry);
-#ifdef SMR_BAL_RUN
         carve(a, v.bal_lo, G, dry);
-#endif
         carve(a, v.peer_exec_bar, R * G, dry);
         carve(a, v.s_bal, W * Gp, dry); carve(a, v.s_val, W * Gp, dry); carve(a, v.s_meta, W * Gp, dry);
         carve(a, v.s_vbal, W * Gp, dry); carve(a, v.s_vval, W * Gp, dry); carve(a, v.s_pmax, W * Gp, dry);
@@ -1274,11 +1209,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
             carve(a, v.ob_val[p], cap * Gp, dry); carve(a, v.ob_aux[p], cap * Gp, dry);
             carve(a, v.ob_reg[p], G, dry); carve(a, v.ob_rbal[p], G, dry);
         }
-#ifdef SMR_ACK_BITS
         carve(a, v.ack, cap * Gp * 8 + (size_t)MAXR * Gp * 8, dry);   // + one word per (follower, group): ack_bits_base()
-#else
-        carve(a, v.ack, cap * Gp * 8, dry);          // one 8-byte word per (entry, group)
-#endif
         carve(a, v.pr_cnt, G, dry); carve(a, v.pr_dest, G, dry);
         carve(a, v.pr_trig, G, dry); carve(a, v.pr_endp, G, dry); carve(a, v.pr_abar, G, dry);
         carve(a, v.pr_bal, G, dry);
@@ -1409,7 +1340,26 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     }
     c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
     if (c->ttl) {
-        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        if (cfg->side_cus) {
+            // CU partition: mask bit i = compute unit i (interleaved over the XCDs, so the low bits are spread over
+            // all eight); the side stream gets the first side_cus, the bulk stream the rest
+            int dev = 0;
+            hipDeviceProp_t prop;
+            e = hipGetDevice(&dev);
+            if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+            const uint32_t ncu = e == hipSuccess ? (uint32_t)prop.multiProcessorCount : 0u;
+            if (e == hipSuccess && (cfg->side_cus >= ncu || ncu > 1024)) {
+                smr_mp_cluster_destroy(c);
+                return fail(SMR_ERR_ARG, "mp: side_cus must be smaller than the device's compute-unit count");
+            }
+            std::vector<uint32_t> ms((ncu + 31) / 32, 0u), mb((ncu + 31) / 32, 0u);
+            for (uint32_t i = 0; i < ncu; i++) (i < cfg->side_cus ? ms : mb)[i / 32] |= 1u << (i % 32);
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->side, (uint32_t)ms.size(), ms.data());
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->bulk, (uint32_t)mb.size(), mb.data());
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bjoin, hipEventDisableTiming);
+        } else {
+            e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -1426,7 +1376,9 @@ void smr_mp_cluster_destroy(smr_mp_cluster *c) {
     (void)hipDeviceSynchronize();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_bjoin) (void)hipEventDestroy(c->ev_bjoin);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->bulk) (void)hipStreamDestroy(c->bulk);
     for (auto &e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->dp) (void)hipFree(c->dp);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -1567,11 +1519,21 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
         SMR_HIP_TRY(hipGetLastError());
         c->side_fused = true;                                   // the round calls below launch the bulk only
     }
+    const bool split = own && c->bulk;                          // CU partition: the bulk launches of THIS tick go to the
+    if (split) {                                                // masked bulk stream (ticks without stragglers keep every CU)
+        SMR_HIP_TRY(hipStreamWaitEvent(c->bulk, c->ev_fork, 0));
+        stream = (void *)c->bulk;
+    }
     rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, stream);
     if (!rc) rc = smr_mp_round_deliver(c, stream);
     if (!rc) rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream);
     if (!rc && do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
     c->side_fused = false;
+    if (split) {
+        hipError_t e = hipEventRecord(c->ev_bjoin, c->bulk);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_bjoin, 0);
+        if (e != hipSuccess && !rc) rc = fail(SMR_ERR_DEVICE, std::string("mp: bulk join: ") + hipGetErrorString(e));
+    }
     const int rj = join_side(c, st, own);
     if (rc) return rc;
     if (rj) return rj;
@@ -1608,21 +1570,17 @@ int smr_mp_collect_acks(smr_mp_cluster *c, uint8_t rep, smr_mp_ack *out_dev, uin
 int smr_mp_clear_acks(smr_mp_cluster *c, uint8_t rep, void *stream) {
     if (!c || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
     size_t nb = (size_t)c->cfg.outbox_cap * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
-#ifdef SMR_ACK_BITS
     nb += (size_t)MAXR * ((c->cfg.n_groups + 63) / 64 * 64) * 8;
-#endif
     SMR_HIP_TRY(hipMemsetAsync(c->hp.rep[rep].ack, 0, nb, (hipStream_t)stream));
     return SMR_OK;
 }
 
 int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out) {
     if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
-#ifdef SMR_STATUS_LAZY
-    return fail(SMR_ERR_ARG, "mp: this experimental build keeps follower statuses implicit; no in-place log view");
-#endif
     const MpRep &v = c->hp.rep[rep];
     out->start_slot = v.start_slot; out->log_end = v.log_len;       // log_len is kept as start_slot + insts.len()
     out->status = v.s_meta; out->token = v.s_val; out->window = c->cfg.window; out->mp_layout = 1;
+    out->run_lo = v.bal_lo; out->run_hi = v.commit_bar;             // inside the run a slot below commit_bar is Executed, unwritten
     return SMR_OK;
 }
 
@@ -1646,55 +1604,52 @@ int smr_mp_read_group_state(smr_mp_cluster *c, uint32_t group, uint8_t rep, smr_
     return SMR_OK;
 }
 
-int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
+int smr_mp_dump_range(smr_mp_cluster *c, uint8_t rep, uint32_t g0, uint32_t n, const smr_mp_dump_bufs *hb) {
     if (!c || !hb || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    const size_t GT = c->cfg.n_groups, W = c->cfg.window, R = c->cfg.population;
+    if ((g0 & 63u) || (size_t)g0 + n > GT || (size_t)g0 + n < g0)
+        return fail(SMR_ERR_ARG, "mp: dump range must start on a multiple of 64 and lie inside the cluster");
+    if (n == 0) return SMR_OK;
     SMR_HIP_TRY(hipDeviceSynchronize());
     const MpRep &v = c->hp.rep[rep];
-    const size_t G = c->cfg.n_groups, W = c->cfg.window, R = c->cfg.population;
-#define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
-    D2H(hb->leader, v.leader, G);
-    D2H(hb->bal_prep_sent, v.bal_prep_sent, G * 8); D2H(hb->bal_prepared, v.bal_prepared, G * 8);
-    D2H(hb->bal_max_seen, v.bal_max_seen, G * 8);
-    D2H(hb->start_slot, v.start_slot, G * 4); D2H(hb->log_len, v.log_len, G * 4);
-    D2H(hb->accept_bar, v.accept_bar, G * 4); D2H(hb->commit_bar, v.commit_bar, G * 4);
-    D2H(hb->exec_bar, v.exec_bar, G * 4); D2H(hb->snap_bar, v.snap_bar, G * 4);
-    D2H(hb->peer_exec_bar, v.peer_exec_bar, R * G * 4);
-    D2H(hb->overflow, c->hp.overflow, G);
+    const size_t G = n;                                                          // host buffers are [..][n]
+#define D2H(dst, src, bytes) SMR_HIP_TRY(hipMemcpy((dst), (src), (bytes), hipMemcpyDeviceToHost))
+    D2H(hb->leader, v.leader + g0, G);
+    D2H(hb->bal_prep_sent, v.bal_prep_sent + g0, G * 8); D2H(hb->bal_prepared, v.bal_prepared + g0, G * 8);
+    D2H(hb->bal_max_seen, v.bal_max_seen + g0, G * 8);
+    D2H(hb->start_slot, v.start_slot + g0, G * 4); D2H(hb->log_len, v.log_len + g0, G * 4);
+    D2H(hb->accept_bar, v.accept_bar + g0, G * 4); D2H(hb->commit_bar, v.commit_bar + g0, G * 4);
+    D2H(hb->exec_bar, v.exec_bar + g0, G * 4); D2H(hb->snap_bar, v.snap_bar + g0, G * 4);
+    for (size_t r = 0; r < R; r++) D2H(hb->peer_exec_bar + r * G, v.peer_exec_bar + r * GT + g0, G * 4);
+    D2H(hb->overflow, c->hp.overflow + g0, G);
     for (size_t g = 0; g < G; g++) hb->peer_exec_bar[(size_t)rep * G + g] = 0;
-    const size_t Gp = (G + 63) / 64 * 64;
+    // the rows of groups [g0, g0 + n) are the wave tiles g0/64 .. : one contiguous piece of every tiled array
+    const size_t Gp = (G + 63) / 64 * 64, t0 = (size_t)(g0 >> 6) * W * 64;
     std::vector<uint64_t> bal(W * Gp), vbal(W * Gp), pmax(W * Gp);
     std::vector<uint32_t> val(W * Gp), meta(W * Gp), vval(W * Gp), ltrig(W * Gp), lendp(W * Gp), rtrig(W * Gp), rendp(W * Gp);
-    D2H(bal.data(), v.s_bal, W * Gp * 8); D2H(vbal.data(), v.s_vbal, W * Gp * 8); D2H(pmax.data(), v.s_pmax, W * Gp * 8);
-    D2H(val.data(), v.s_val, W * Gp * 4); D2H(meta.data(), v.s_meta, W * Gp * 4); D2H(vval.data(), v.s_vval, W * Gp * 4);
-    D2H(ltrig.data(), v.s_ltrig, W * Gp * 4); D2H(lendp.data(), v.s_lendp, W * Gp * 4);
-    D2H(rtrig.data(), v.s_rtrig, W * Gp * 4); D2H(rendp.data(), v.s_rendp, W * Gp * 4);
-#if defined(SMR_BAL_LAZY) || defined(SMR_STATUS_LAZY)
+    D2H(bal.data(), v.s_bal + t0, W * Gp * 8); D2H(vbal.data(), v.s_vbal + t0, W * Gp * 8); D2H(pmax.data(), v.s_pmax + t0, W * Gp * 8);
+    D2H(val.data(), v.s_val + t0, W * Gp * 4); D2H(meta.data(), v.s_meta + t0, W * Gp * 4); D2H(vval.data(), v.s_vval + t0, W * Gp * 4);
+    D2H(ltrig.data(), v.s_ltrig + t0, W * Gp * 4); D2H(lendp.data(), v.s_lendp + t0, W * Gp * 4);
+    D2H(rtrig.data(), v.s_rtrig + t0, W * Gp * 4); D2H(rendp.data(), v.s_rendp + t0, W * Gp * 4);
     std::vector<uint32_t> bal_lo(G);
-    D2H(bal_lo.data(), v.bal_lo, G * 4);
-#endif
+    D2H(bal_lo.data(), v.bal_lo + g0, G * 4);
 #undef D2H
     // canonicalise: explicit Instance fields, zero outside [start_slot, log_len); the host
-    // buffers are plain [W][G], the device arrays wave-tiled (tix)
-    for (size_t w = 0; w < W; w++)
-        for (size_t g = 0; g < G; g++) {
-            size_t o = w * G + g;
-            hb->s_bal[o] = 0; hb->s_status[o] = 0; hb->s_reqs[o] = 0; hb->s_vbal[o] = 0; hb->s_vreqs[o] = 0;
-            hb->s_flags[o] = 0; hb->s_acks[o] = 0; hb->s_packs[o] = 0; hb->s_pmax[o] = 0; hb->s_ltrig[o] = 0;
-            hb->s_lendp[o] = 0; hb->s_src[o] = 0; hb->s_rtrig[o] = 0; hb->s_rendp[o] = 0;
-        }
+    // buffers are plain [W][n], the device arrays wave-tiled (tix)
+    memset(hb->s_bal, 0, W * G * 8); memset(hb->s_status, 0, W * G); memset(hb->s_reqs, 0, W * G * 4);
+    memset(hb->s_vbal, 0, W * G * 8); memset(hb->s_vreqs, 0, W * G * 4); memset(hb->s_flags, 0, W * G);
+    memset(hb->s_acks, 0, W * G); memset(hb->s_packs, 0, W * G); memset(hb->s_pmax, 0, W * G * 8);
+    memset(hb->s_ltrig, 0, W * G * 4); memset(hb->s_lendp, 0, W * G * 4); memset(hb->s_src, 0, W * G);
+    memset(hb->s_rtrig, 0, W * G * 4); memset(hb->s_rendp, 0, W * G * 4);
     for (size_t g = 0; g < G; g++) {
         uint32_t lo = hb->start_slot[g], hi = hb->log_len[g];
         if (hi - lo > W) hi = lo + (uint32_t)W;
         for (uint32_t s = lo; s < hi; s++) {
             const size_t o = (size_t)(s & (W - 1)) * G + g;                     // host index
-            const size_t t = tix((uint32_t)W, s & (uint32_t)(W - 1), (uint32_t)g);   // device index
+            const size_t t = tix((uint32_t)W, s & (uint32_t)(W - 1), (uint32_t)g);   // index inside the copied tiles
             uint32_t m = meta[t];
-#ifdef SMR_BAL_LAZY
             if (s >= bal_lo[g]) bal[t] = hb->bal_max_seen[g];                    // inside the run the ballot is not stored
-#endif
-#ifdef SMR_STATUS_LAZY
             if (s >= bal_lo[g] && s < hb->commit_bar[g]) m = (m & ~M_STATUS) | SMR_ST_EXECUTED;   // nor the statuses the bars imply
-#endif
             hb->s_bal[o] = bal[t]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[t];
             uint32_t vm = (m >> M_VMODE_SH) & 3u;
             hb->s_vbal[o] = vm == VM_SAME ? bal[t] : (vm == VM_SIDE ? vbal[t] : 0);
@@ -1710,6 +1665,11 @@ int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
         }
     }
     return SMR_OK;
+}
+
+int smr_mp_dump(smr_mp_cluster *c, uint8_t rep, const smr_mp_dump_bufs *hb) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: bad argument");
+    return smr_mp_dump_range(c, rep, 0, c->cfg.n_groups, hb);
 }
 
 int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]) {

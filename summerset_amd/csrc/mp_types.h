@@ -74,7 +74,6 @@ inline size_t tix(uint32_t rows, uint32_t row, uint32_t g);
 __host__ __device__
 #endif
 inline size_t ack_ix(uint32_t cap, uint32_t j, uint32_t r, uint32_t g) { return tix(cap, j, g) * 8 + r; }
-#ifdef SMR_ACK_BITS
 // Experiment (tools/experiments/README.md): the answers to the first 64 entries of an outbox as ONE word per
 // (follower q, group) -- bit j = follower q accepted entry j -- behind the ack words of the same replica:
 // word index tix(SMR_MAX_REPLICAS, q, g).  A follower stores one word per group instead of a byte per entry; the
@@ -95,7 +94,6 @@ inline uint64_t ack_range_bits(uint32_t lo, uint32_t hi) {       // bits [lo, hi
     const uint64_t upto_hi = hi == 64u ? ~0ull : ((1ull << hi) - 1ull);
     return upto_hi & ~((1ull << lo) - 1ull);
 }
-#endif
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -114,9 +112,7 @@ struct MpRep {
     SMR_G uint64_t *bal_prep_sent, *bal_prepared, *bal_max_seen;
     SMR_G uint32_t *start_slot, *log_len, *accept_bar, *commit_bar, *exec_bar, *snap_bar;
     SMR_G uint32_t *null_lb;        // aux: no Null instance in [exec_bar, null_lb)
-#ifdef SMR_BAL_RUN
     SMR_G uint32_t *bal_lo;         // experiment: every slot in [bal_lo, log_len) holds bal == bal_max_seen (0xFFFFFFFF: none)
-#endif
     SMR_G uint32_t *peer_exec_bar;  // [R][G]
     // slot ring [W][G]
     SMR_G uint64_t *s_bal;
@@ -176,9 +172,7 @@ struct RepView {
     SMR_HD SMR_G uint32_t *exec_bar() const { return sh(b.exec_bar); }
     SMR_HD SMR_G uint32_t *snap_bar() const { return sh(b.snap_bar); }
     SMR_HD SMR_G uint32_t *null_lb() const { return sh(b.null_lb); }
-#ifdef SMR_BAL_RUN
     SMR_HD SMR_G uint32_t *bal_lo() const { return sh(b.bal_lo); }
-#endif
     SMR_HD SMR_G uint32_t *peer_exec_bar() const { return sh(b.peer_exec_bar); }
     SMR_HD SMR_G uint64_t *s_bal() const { return sh(b.s_bal); }
     SMR_HD SMR_G uint32_t *s_val() const { return sh(b.s_val); }

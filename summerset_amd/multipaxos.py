@@ -28,13 +28,13 @@ def _ptr(t):
 
 class MultiPaxosCluster:
     def __init__(self, n_groups, population=5, window=64, win_reserve=None, outbox_cap=None, commit_extra=0,
-                 commit_list_cap=0, straggler_ticks=0):
+                 commit_list_cap=0, straggler_ticks=0, side_cus=0):
         """straggler_ticks: ticks a group stays on the engine's side stream after a HearTimeout
         (0 = engine default, 0xFF = off); a scheduling knob only, results do not depend on it."""
         self.G, self.R, self.W = int(n_groups), int(population), int(window)
         self.win_reserve = self.W // 4 if win_reserve is None else int(win_reserve)
         self.cap = self.W + 4 if outbox_cap is None else int(outbox_cap)
-        cfg = MpCfg(self.G, self.R, commit_extra, int(straggler_ticks), 0, self.W, self.win_reserve, self.cap, commit_list_cap)
+        cfg = MpCfg(self.G, self.R, commit_extra, int(straggler_ticks), int(side_cus), self.W, self.win_reserve, self.cap, commit_list_cap)
         h = C.c_void_p()
         self._L = _lib.load()
         check(self._L.smr_mp_cluster_create(C.byref(cfg), C.byref(h)))
@@ -111,16 +111,18 @@ class MultiPaxosCluster:
         check(self._L.smr_mp_replica_log_view(self._h, rep, C.byref(view)))
         return view
 
-    def dump(self, rep):
-        """Canonical per-replica state as host numpy arrays (same shape as the oracle's dump)."""
-        G, W, R = self.G, self.W, self.R
+    def dump(self, rep, g0=0, n=None):
+        """Canonical per-replica state as host numpy arrays (same shape as the oracle's dump); with g0 / n only the
+        groups [g0, g0 + n) (g0 a multiple of 64): the arrays of an oracle that runs just those groups."""
+        W, R = self.W, self.R
+        G = self.G - g0 if n is None else int(n)
         out, bufs = {}, MpDumpBufs()
         for name in _lib.MP_DUMP_FIELDS:
             t = _DUMP_T.get(name, np.uint32)
             shape = (R, G) if name == "peer_exec_bar" else ((W, G) if name.startswith("s_") else (G,))
             out[name] = np.zeros(shape, t)
             setattr(bufs, name, out[name].ctypes.data_as(C.c_void_p))
-        check(self._L.smr_mp_dump(self._h, rep, C.byref(bufs)))
+        check(self._L.smr_mp_dump_range(self._h, rep, int(g0), G, C.byref(bufs)))
         return out
 
     def counters(self, rep):

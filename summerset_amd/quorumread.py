@@ -58,7 +58,7 @@ class QuorumReadGroup:
         out = self._replies((), keys.device)
         fl = torch.zeros(self.G, dtype=torch.uint8, device=keys.device)
         lg = log if isinstance(log, QreadLog) else QreadLog(_ptr(log["start_slot"]), _ptr(log["log_end"]), _ptr(log["status"]),
-                                                            _ptr(log["token"]), int(log["status"].shape[0]), 0)
+                                                            _ptr(log["token"]), int(log["status"].shape[0]), 0, None, None)
         rs = self._rs(out)
         check(self._L.smr_qread_handle_read_query(self._h, _ptr(keys), _ptr(n), _ptr(stable_leader), _ptr(kv), C.byref(lg),
                                                   C.byref(rs), _ptr(fl), stream_ptr(stream)))

@@ -6,8 +6,11 @@ import numpy as np
 import rsp_cluster as rc
 
 
-def run(reps, G, ticks, seed, loss=0.0, changes=True, on_tick=None):
+def run(reps, G, ticks, seed, loss=0.0, changes=True, on_tick=None, view=None):
+    """view = (g0, n): the scenario is the one of G groups, but `reps` hold only its groups [g0, g0 + n) and get that
+    slice of every input (groups are independent: the slice must behave as it does inside the whole population)"""
     R = len(reps)
+    cut = (lambda a: a) if view is None else (lambda a: np.ascontiguousarray(a[view[0]:view[0] + view[1]]))
     for r in reps:
         r.preset_leader(0)
     rng = np.random.default_rng(seed)
@@ -32,7 +35,8 @@ def run(reps, G, ticks, seed, loss=0.0, changes=True, on_tick=None):
         if loss:
             kinds = ("accept", "accept_reply", "prepare", "prepare_reply", "recon", "recon_reply", "hb")
             drop = {(k, s, q): rng.random(G) < loss for k in kinds for s in range(R) for q in range(R) if s != q}
-        out = rc.tick(reps, val, target, timeouts=to, drop=drop, heartbeat=(t % 3 == 2))
+        out = rc.tick(reps, cut(val), cut(target), timeouts=None if to is None else [cut(x) for x in to],
+                      drop=None if drop is None else {k: cut(v) for k, v in drop.items()}, heartbeat=(t % 3 == 2))
         log.append((t, out))
         if on_tick:
             on_tick(t)

