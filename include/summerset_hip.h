@@ -115,10 +115,7 @@ typedef struct {
     uint8_t straggler_ticks; /* ticks a group spends on the engine's side stream after a HearTimeout, so its leader
                               * change runs beside the steady-state kernels (results do not depend on it):
                               * 0 / SMR_STRAGGLER_OFF = never (default) */
-    uint8_t side_cus;        /* compute units set aside for that side stream (0 = none): while a tick has listed groups, the
-                              * side launch runs on these CUs only and the bulk launches on the others (two CU-masked HIP
-                              * streams forked from / joined to the caller's), so the serial latency of a leader change
-                              * overlaps the bulk kernels without taking wavefront slots from them */
+    uint8_t reserved1;
     uint32_t window;        /* W: ring slots per replica per group, power of two */
     uint32_t win_reserve;   /* leader refuses new batches once W - win_reserve slots are live */
     uint32_t outbox_cap;    /* max messages a replica may emit per tick (>= W + 4 recommended) */

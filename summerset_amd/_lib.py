@@ -27,7 +27,7 @@ class SummersetError(RuntimeError):
 
 class MpCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("commit_extra", C.c_uint8),
-                ("straggler_ticks", C.c_uint8), ("side_cus", C.c_uint8), ("window", C.c_uint32),
+                ("straggler_ticks", C.c_uint8), ("reserved1", C.c_uint8), ("window", C.c_uint32),
                 ("win_reserve", C.c_uint32), ("outbox_cap", C.c_uint32), ("commit_list_cap", C.c_uint32)]
 
 

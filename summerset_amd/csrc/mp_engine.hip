@@ -1157,8 +1157,7 @@ struct smr_mp_cluster {
     int lpar = 0;                    // straggler-list counter parity
     uint32_t ttl = 0;                // ticks on the side stream after a HearTimeout (0 = never)
     hipStream_t side = nullptr;      // straggler launches
-    hipStream_t bulk = nullptr;      // side_cus > 0: the bulk launches of a tick that has stragglers (the CUs the side stream leaves)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_bjoin = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     bool profile = false;
@@ -1340,26 +1339,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     }
     c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
     if (c->ttl) {
-        if (cfg->side_cus) {
-            // CU partition: mask bit i = compute unit i (interleaved over the XCDs, so the low bits are spread over
-            // all eight); the side stream gets the first side_cus, the bulk stream the rest
-            int dev = 0;
-            hipDeviceProp_t prop;
-            e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-            const uint32_t ncu = e == hipSuccess ? (uint32_t)prop.multiProcessorCount : 0u;
-            if (e == hipSuccess && (cfg->side_cus >= ncu || ncu > 1024)) {
-                smr_mp_cluster_destroy(c);
-                return fail(SMR_ERR_ARG, "mp: side_cus must be smaller than the device's compute-unit count");
-            }
-            std::vector<uint32_t> ms((ncu + 31) / 32, 0u), mb((ncu + 31) / 32, 0u);
-            for (uint32_t i = 0; i < ncu; i++) (i < cfg->side_cus ? ms : mb)[i / 32] |= 1u << (i % 32);
-            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->side, (uint32_t)ms.size(), ms.data());
-            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->bulk, (uint32_t)mb.size(), mb.data());
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_bjoin, hipEventDisableTiming);
-        } else {
-            e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-        }
+        e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -1376,9 +1356,7 @@ void smr_mp_cluster_destroy(smr_mp_cluster *c) {
     (void)hipDeviceSynchronize();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_bjoin) (void)hipEventDestroy(c->ev_bjoin);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->bulk) (void)hipStreamDestroy(c->bulk);
     for (auto &e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->dp) (void)hipFree(c->dp);
     if (c->arena.base) (void)hipFree(c->arena.base);
@@ -1519,21 +1497,11 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
         SMR_HIP_TRY(hipGetLastError());
         c->side_fused = true;                                   // the round calls below launch the bulk only
     }
-    const bool split = own && c->bulk;                          // CU partition: the bulk launches of THIS tick go to the
-    if (split) {                                                // masked bulk stream (ticks without stragglers keep every CU)
-        SMR_HIP_TRY(hipStreamWaitEvent(c->bulk, c->ev_fork, 0));
-        stream = (void *)c->bulk;
-    }
     rc = smr_mp_round_local(c, timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, stream);
     if (!rc) rc = smr_mp_round_deliver(c, stream);
     if (!rc) rc = smr_mp_round_replies(c, ackctl_dev, do_heartbeat, stream);
     if (!rc && do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
     c->side_fused = false;
-    if (split) {
-        hipError_t e = hipEventRecord(c->ev_bjoin, c->bulk);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_bjoin, 0);
-        if (e != hipSuccess && !rc) rc = fail(SMR_ERR_DEVICE, std::string("mp: bulk join: ") + hipGetErrorString(e));
-    }
     const int rj = join_side(c, st, own);
     if (rc) return rc;
     if (rj) return rj;

@@ -28,13 +28,13 @@ def _ptr(t):
 
 class MultiPaxosCluster:
     def __init__(self, n_groups, population=5, window=64, win_reserve=None, outbox_cap=None, commit_extra=0,
-                 commit_list_cap=0, straggler_ticks=0, side_cus=0):
+                 commit_list_cap=0, straggler_ticks=0):
         """straggler_ticks: ticks a group stays on the engine's side stream after a HearTimeout
         (0 = engine default, 0xFF = off); a scheduling knob only, results do not depend on it."""
         self.G, self.R, self.W = int(n_groups), int(population), int(window)
         self.win_reserve = self.W // 4 if win_reserve is None else int(win_reserve)
         self.cap = self.W + 4 if outbox_cap is None else int(outbox_cap)
-        cfg = MpCfg(self.G, self.R, commit_extra, int(straggler_ticks), int(side_cus), self.W, self.win_reserve, self.cap, commit_list_cap)
+        cfg = MpCfg(self.G, self.R, commit_extra, int(straggler_ticks), 0, self.W, self.win_reserve, self.cap, commit_list_cap)
         h = C.c_void_p()
         self._L = _lib.load()
         check(self._L.smr_mp_cluster_create(C.byref(cfg), C.byref(h)))

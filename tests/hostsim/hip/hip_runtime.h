@@ -77,10 +77,6 @@ inline hipError_t hipGetLastError(void) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 0; return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-struct hipDeviceProp_t { int multiProcessorCount; };
-inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 256; return hipSuccess; }
-inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { *s = (hipStream_t)1; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)1; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }

@@ -42,13 +42,13 @@ def test_config1_multipaxos_4096_groups_bit_exact(cuda, oracle):
 # the headline metric's configuration: "65 536 groups, 5 replicas" at bench.py's shape (S = 32, W = 512, heartbeat
 # every 4th tick, 10 % ack loss capped at 2 per slot, 1 % of the groups change leader)
 # ---------------------------------------------------------------------------------------------------------------
-def run_multipaxos_slices(cuda, oracle, G, S, W, n_ticks, frac, span, width, n_slices, every=4):
+def run_multipaxos_slices(cuda, oracle, G, S, W, n_ticks, frac, span, width, n_slices, every=4, straggler_ticks=0):
     from oracle.oracle import MP_SCALARS, MP_SLOTS
     from summerset_amd import MultiPaxosCluster, stream
     R, H = 5, 4
     cap = W + 4
     kw = dict(cap=cap, n_ticks=n_ticks, drop_p=0.1, timeout_frac=frac, hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=span)
-    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=straggler_ticks)
     eng.preset_leader(0)
     st = stream.MultiPaxosStream(G, R, S, **kw)
     sl = _slices(G, width, n_slices, seed=G + S)
