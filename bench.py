@@ -26,18 +26,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r1g_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+PMC_NOTE = ("profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
+            "gfx950 corrections of MI355X_MICROARCH.md applied; bytes per launch at 65536 groups, S=32, default workload)")
+
+
+def pmc_file():
+    """the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs, gfx950 corrections applied: see the
+    file's "corrections"); None if absent.  bench.py cannot collect PMC counters itself -- they need rocprofv3."""
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE, separate runs, gfx950 corrections applied: see the file's "corrections"); None if
-    the file is absent.  bench.py cannot collect PMC counters itself -- they need rocprofv3."""
-    try:
-        with open(PMC_FILE) as f:
-            return json.load(f)["kernels"][kernel]
-    except (OSError, KeyError, ValueError):
-        return None
+    d = pmc_file()
+    return d["kernels"].get(kernel) if d else None
 
 
 def parse():
@@ -53,7 +59,13 @@ def parse():
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
     ap.add_argument("--timeout-span", type=int, default=None, help="draw the timeout ticks from [0, N) instead of the whole run")
-    ap.add_argument("--straggler-ticks", type=int, default=0, help="ticks a group in a leader change runs on the side stream (0 = off: measured a wash, DESIGN.md §4)")
+    ap.add_argument("--straggler-ticks", type=int, default=8, help="ticks a group in a leader change runs on the side stream (0 = off); 8 measured best "
+                    "on the default workload once the side kernel lost its agent-scope fences (profiles/r2g_straggler_sweep.log)")
+    ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
+                    "excludes the side stream).  0 = one smr_mp_tick call per tick: five per-round launches + the straggler side launch "
+                    "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
+    ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
+                    "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
@@ -625,10 +637,13 @@ def main():
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4
-    n_ticks = args.warmup + args.steps
+    n_timed = args.warmup + args.steps
+    n_ticks = n_timed + args.round_ticks          # the per-round pass goes on where the timed region stopped
+    if args.fused:
+        args.straggler_ticks = 0                  # the fused tick kernel and the side stream exclude each other
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
     eng.preset_leader(0)
-    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts,
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=args.timeouts,
                                  hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=args.timeout_span,
                                  group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
     # inputs resident in HBM before the clock starts
@@ -643,24 +658,41 @@ def main():
 
     fired = [bool((st.timeout_tick == t).any()) for t in range(n_ticks)]   # host-side fact: did any timer fire
 
-    def step(t):
+    def tick_args(t):
         p, e = pool[t % args.pool], events[t]
-        eng.tick(timeout_rep=e["timeout_rep"] if fired[t] else None,
-                 timeout_src=e["timeout_src"] if fired[t] else None, req_target=e["req_target"],
-                 req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"], heartbeat=st.heartbeat(t))
+        return dict(timeout_rep=e["timeout_rep"] if fired[t] else None, timeout_src=e["timeout_src"] if fired[t] else None,
+                    req_target=e["req_target"], req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"],
+                    heartbeat=st.heartbeat(t))
 
-    for t in range(args.warmup):
-        step(t)
+    launches = []                                 # fused: (event pair, ticks) of every launch of the timed region
+
+    def run(t0_, t1_, timed=False):
+        if not args.fused:
+            for t in range(t0_, t1_):
+                if timed:
+                    eng.profile_enable((t - t0_) % 3 == 0)   # event pairs on every third tick (all tick phases come by):
+                eng.tick(**tick_args(t))          # the events themselves cost launch-gap time
+            return
+        for b0 in range(t0_, t1_, args.fused):
+            batch = [tick_args(t) for t in range(b0, min(b0 + args.fused, t1_))]
+            chunks = [batch[i:i + 16] for i in range(0, len(batch), 16)]       # one launch per 16 ticks
+            for ch in chunks:
+                if timed:                         # HIP events on the launch stream (torch's current stream IS the
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # stream the
+                    ea.record()                   # kernel is launched on: the mirror passes it to the C-ABI)
+                eng.run_ticks(ch)
+                if timed:
+                    eb.record()
+                    launches.append((ea, eb, len(ch)))
+
+    run(0, args.warmup)
     torch.cuda.synchronize()
     c0 = sum(eng.counters(r)["commits"] for r in range(R))
-    eng.profile_enable(True)                      # HIP events around each round kernel, on the launch stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(args.warmup, n_ticks):
-        eng.profile_enable((t - args.warmup) % 3 == 0)   # event pairs on every third tick (all tick phases come by): the
-        step(t)                                   # events themselves cost launch-gap time
+    run(args.warmup, n_timed, timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -671,18 +703,62 @@ def main():
     rej = sum(eng.counters(r)["rejects"] for r in range(R))
     overflow = int(eng.dump(0)["overflow"].sum()) if G <= 4096 else None
     elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)   # MAX over ranks, SUM over ranks
+    # untimed: the same workload a few ticks further through the per-round kernels, an event pair around each
+    if args.fused and args.round_ticks:
+        eng.profile_enable(True)
+        for t in range(n_timed, n_ticks):
+            eng.tick(**tick_args(t))
+        torch.cuda.synchronize()
+        eng.profile_enable(False)
     prof = {}
     for i, name in enumerate(("R1_local", "R2_deliver", "R3_replies", "R4_heartbeat", "mp_quorum_tally")):
         ms, n = eng.profile_read(i)
         prof[name] = {"avg_us": (ms / n * 1e3) if n else None, "launches": int(n)}
-    # the dominant kernel of the path: mp_quorum_tally (accept-ack tally + commit/exec bars of the bulk
-    # groups), timed alone by its own HIP event pair on the launch stream; "R3_replies" is the whole
-    # round (tally + the mp_round_replies launch for everything the closed form left)
-    qt_ms = prof["mp_quorum_tally"]["avg_us"] / 1e3
-    r3_ms = prof["R3_replies"]["avg_us"] / 1e3
-    alg_bytes = G * (52 * S + 33)                 # bytes per quorum-kernel launch
-    achieved = alg_bytes / (qt_ms * 1e-3) / 1e9
-    t_qt = pmc_traffic("smr::mp_quorum_tally<5>") if S == 32 else None
+    alg_tick = G * (52 * S + 33)                  # algorithmic bytes of one tick's quorum decisions
+    tick_us = elapsed / args.steps * 1e6
+    pmc = pmc_file()
+    # HBM bytes per tick from the committed PMC passes (per launch; the heartbeat round runs every H-th tick)
+    pmc_tick = None
+    if pmc and S == 32 and G == 65536:
+        k = pmc["kernels"]
+        if args.fused and "smr::mp_ticks_fused<5, 5>" in k:
+            pmc_tick = k["smr::mp_ticks_fused<5, 5>"]["hbm_bytes_per_launch"] / pmc.get("ticks_per_fused_launch", 16)
+        elif not args.fused:
+            pmc_tick = sum(k[n]["hbm_bytes_per_launch"] / (H if n == "smr::mp_round_heartbeat" else 1)
+                           for n in ("smr::mp_round_local", "smr::mp_round_deliver", "smr::mp_quorum_tally<5>",
+                                     "smr::mp_round_replies", "smr::mp_round_heartbeat") if n in k)
+    if args.fused:
+        # the dominant kernel of the path is the fused tick kernel itself: every launch of the timed region between
+        # its own HIP event pair; algorithmic bytes = the §8(d) figure x the decisions of the launch's ticks
+        us = [ea.elapsed_time(eb) * 1e3 for ea, eb, _ in launches]
+        nt = sum(n for _, _, n in launches)
+        avg_launch_us = sum(us) / max(len(us), 1)
+        alg_launch = alg_tick * nt / max(len(us), 1)
+        achieved = alg_launch / (avg_launch_us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_tick * nt / max(len(us), 1) if pmc_tick else None,
+                "traffic_source": PMC_NOTE, "kernel": "mp_ticks_fused<5, 5>", "launches": len(us), "ticks_per_launch": nt / max(len(us), 1),
+                "alg_bytes_per_launch": alg_launch, "avg_launch_us": avg_launch_us}
+    else:
+        qt_us = prof["mp_quorum_tally"]["avg_us"]
+        achieved = alg_tick / (qt_us * 1e-6) / 1e9
+        t_qt = pmc["kernels"].get("smr::mp_quorum_tally<5>") if pmc and S == 32 else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None, "traffic_source": PMC_NOTE,
+                "kernel": "mp_quorum_tally", "alg_bytes_per_launch": alg_tick, "avg_launch_us": qt_us}
+    # the whole tick against the roofline, both ways: on the §8(d) algorithmic bytes of its decisions and on the HBM
+    # bytes the tick really moves (PMC); and the quorum kernel alone, from the per-round pass
+    roof["whole_tick"] = {"us": tick_us, "frac_alg": alg_tick / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                          "hbm_bytes_pmc": pmc_tick,
+                          "frac_pmc": (pmc_tick / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if pmc_tick else None}
+    if prof["mp_quorum_tally"]["avg_us"]:
+        qt_us = prof["mp_quorum_tally"]["avg_us"]
+        t_qt = pmc["kernels"].get("smr::mp_quorum_tally<5>") if pmc and S == 32 else None
+        roof["quorum_kernel_alone"] = {"kernel": "mp_quorum_tally", "avg_launch_us": qt_us, "alg_bytes_per_launch": alg_tick,
+                                       "frac": alg_tick / (qt_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None,
+                                       "pass": "untimed per-round pass of %d ticks behind the timed region" % args.round_ticks
+                                               if args.fused else "timed region, every third tick"}
     line = {
         "metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s",
         "n_gpus": world, "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None,
@@ -692,18 +768,13 @@ def main():
         "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, "
                                "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout"
                                % (G, S, H, args.drop * 100, args.timeouts * 100),
-                   "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None,
-                     "traffic_source": "profiles/r1g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                       "tools/pmc_probe.py, bytes per launch at 65536 groups, S=32)",
-                     "kernel": "mp_quorum_tally",
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_us": prof["mp_quorum_tally"]["avg_us"],
-                     "whole_round_frac": alg_bytes / (r3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-        "kernels": prof, "rejected_batches": rej, "overflow_groups": overflow,
+                   "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated",
+                   "launch": ("fused tick kernel, <= %d ticks per launch" % min(args.fused, 16)) if args.fused else "five per-round launches per tick"},
+        "roofline": roof,
+        "kernels": prof, "kernels_pass": "untimed per-round pass" if args.fused else "timed region",
+        "rejected_batches": rej, "overflow_groups": overflow,
         "generic_path_batches": [eng.debug_generic_units(r) for r in range(R)],
-        "decisions_per_sec_quorum_kernel": G * S / (qt_ms * 1e-3),
+        "decisions_per_sec": G * S * args.steps / elapsed,
     }
     if rank == 0:
         def leg(name, fn, *a):                     # a secondary leg must never cost the headline line

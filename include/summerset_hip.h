@@ -177,6 +177,19 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream);
 int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publish_heartbeat,
                          void *stream);
 int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream);
+/* A batch of consecutive ticks in as few launches as possible (co-located layout only: every replica of a group is
+ * on this device).  ticks[i] holds the arguments smr_mp_tick takes for tick i (device pointers, NULL = none); the
+ * result is bit for bit what n smr_mp_tick calls give.  One fused kernel runs the four rounds of up to 16 ticks back
+ * to back with block barriers where the per-round launches have kernel boundaries: a block owns 64 groups with all
+ * their replicas, so a leader change's serial latency delays its own block only.  Needs straggler_ticks = off. */
+typedef struct {
+    const uint8_t *timeout_rep_dev, *timeout_src_dev, *req_target_dev;
+    const uint32_t *req_cnt_dev, *req_val_dev;
+    uint32_t S;
+    const uint32_t *ackctl_dev;
+    int do_heartbeat;
+} smr_mp_tick_in;
+int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
 

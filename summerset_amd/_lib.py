@@ -31,6 +31,12 @@ class MpCfg(C.Structure):
                 ("win_reserve", C.c_uint32), ("outbox_cap", C.c_uint32), ("commit_list_cap", C.c_uint32)]
 
 
+class MpTickIn(C.Structure):
+    _fields_ = [("timeout_rep_dev", C.c_void_p), ("timeout_src_dev", C.c_void_p), ("req_target_dev", C.c_void_p),
+                ("req_cnt_dev", C.c_void_p), ("req_val_dev", C.c_void_p), ("S", C.c_uint32), ("ackctl_dev", C.c_void_p),
+                ("do_heartbeat", C.c_int)]
+
+
 class MpGroupState(C.Structure):
     _fields_ = [("leader", C.c_uint8), ("overflow", C.c_uint8), ("bal_prep_sent", C.c_uint64),
                 ("bal_prepared", C.c_uint64), ("bal_max_seen", C.c_uint64), ("start_slot", C.c_uint32),
@@ -171,6 +177,7 @@ SYMBOLS = [
     ("smr_mp_cluster_destroy", None, [_vp]),
     ("smr_mp_preset_leader", _i, [_vp, _u8]),
     ("smr_mp_tick", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i, _vp]),
+    ("smr_mp_run_ticks", _i, [_vp, C.POINTER(MpTickIn), _u32, _vp]),
     ("smr_mp_round_local", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("smr_mp_round_deliver", _i, [_vp, _vp]),
     ("smr_mp_round_replies", _i, [_vp, _vp, _i, _vp]),

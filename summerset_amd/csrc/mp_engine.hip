@@ -749,6 +749,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #endif
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w >= 4) { __syncthreads(); return; }                    // (the fused tick kernel's block has a wavefront per replica)
     const uint32_t g = blockIdx.x * 64 + lane;
     const uint32_t gg = g < P.G ? g : 0;
     const uint32_t R = P.R, G = P.G, Wm = P.Wmask, thresh = P.thresh;
@@ -1043,14 +1044,79 @@ __global__ __launch_bounds__(512) void mp_straggler_tick(const MpParams *__restr
         const uint32_t r = w < P.R ? w : 0;
         if (timeout_rep || req_target)
             r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, mine && !P.overflow[g], r);
-        __threadfence(); __syncthreads();
+        __syncthreads();
         r2_body(P, par, g, mine && !P.overflow[g], r);                         // (a round may freeze the group)
-        __threadfence(); __syncthreads();
+        __syncthreads();
         r3_body(P, par, ackctl, do_heartbeat, g, mine && !P.overflow[g], r);
-        __threadfence(); __syncthreads();
+        __syncthreads();
         if (do_heartbeat) {
             r4_body(P, par, g, mine && !P.overflow[g], r);
-            __threadfence(); __syncthreads();
+            __syncthreads();
+        }
+    }
+}
+
+// The whole tick -- and a batch of consecutive ticks -- in ONE launch.  Groups never talk to each other, so the round
+// boundaries only have to order the replicas of the SAME group: a block owns 64 groups with all their replicas (a
+// wavefront per replica for R1 / R2 / R3-rest / R4, four wavefronts for the quorum tally's row split) and a block
+// barrier stands where the per-round launches have a kernel boundary.  What that buys on the co-located layout:
+// no launch gaps (5 launches per tick -> 1 per batch); blocks drift apart, so one block's load latency is another's
+// bandwidth; and a leader change -- serial latency of one wavefront, 100 us and more over its rounds -- delays only its
+// own 64 groups while every other block keeps going, through the following ticks of the batch as well.  The per-round
+// kernels above remain what the spread layout (an exchange between the rounds) and hosts with real I/O call.
+// (the phases are separate functions on purpose: inlined into one body the register allocator keeps the union of
+// their working sets -- 229 VGPRs, two wavefronts per SIMD -- instead of the largest one)
+__device__ __forceinline__ void fused_r1(const MpParams *Pp, int par, const uint8_t *timeout_rep, const uint8_t *timeout_src,
+                                      const uint8_t *req_target, const uint32_t *req_cnt, const uint32_t *req_val, uint32_t S,
+                                      uint32_t g, uint32_t r) {
+    r1_body(*Pp, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, g < Pp->G && !Pp->overflow[g], r);
+}
+__device__ __forceinline__ void fused_r2(const MpParams *Pp, int par, uint32_t g, uint32_t r) {
+    r2_body(*Pp, par, g, g < Pp->G && !Pp->overflow[g], r);     // (a round may freeze the group)
+}
+template <int NR>
+__device__ __forceinline__ void fused_tally(const MpParams *Pp, int par, const uint32_t *ackctl, int publish_hb, uint8_t *sh_fl,
+                                         uint32_t *sh_mk) {
+    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk);
+}
+__device__ __forceinline__ void fused_r3(const MpParams *Pp, int par, const uint32_t *ackctl, int publish_hb, uint32_t g, uint32_t r) {
+    r3_body(*Pp, par, ackctl, publish_hb, g, g < Pp->G && !Pp->overflow[g], r);
+}
+__device__ __forceinline__ void fused_r4(const MpParams *Pp, int par, uint32_t g, uint32_t r) {
+    r4_body(*Pp, par, g, g < Pp->G && !Pp->overflow[g], r);
+}
+
+#ifndef FUSED_MINW
+#define FUSED_MINW 2
+#endif
+template <int NR, int NW>
+__global__ __launch_bounds__(NW * 64, FUSED_MINW) void mp_ticks_fused(const MpParams *__restrict__ Pp, const MpTickBatch B) {
+    __shared__ uint8_t sh_fl[64 * 64];
+    __shared__ uint32_t sh_mk[64 * 64];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 64 + lane;
+    const uint32_t R = Pp->R;
+    const bool rw = w < R;                                       // this wavefront stands for replica w
+    const uint32_t r = rw ? w : 0;
+    const uint32_t ntile = (Pp->G + 63) / 64;
+    // Round boundaries are `__syncthreads()` alone: HIP's barrier carries a workgroup-scope release / acquire, and the
+    // wavefronts of a block share their CU's L1, so what one replica's wavefront stored is what the others load.  (A
+    // `__threadfence()` here is an AGENT-scope fence -- on gfx950 an L2 write-back per barrier: measured 0.67 ms per tick.)
+    for (uint32_t t = 0; t < B.n; t++) {
+        const MpTickIn &in = B.t[t];
+        const int par = B.par0 ^ (int)(t & 1u);
+        if (rw && (in.timeout_rep || in.req_target))
+            fused_r1(Pp, par, in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, r);
+        __syncthreads();
+        if (rw) fused_r2(Pp, par, g, r);
+        __syncthreads();
+        fused_tally<NR>(Pp, par, in.ackctl, in.heartbeat, sh_fl, sh_mk);
+        __syncthreads();
+        if (rw && Pp->r3_need[(size_t)r * ntile + blockIdx.x]) fused_r3(Pp, par, in.ackctl, in.heartbeat, g, r);
+        __syncthreads();
+        if (in.heartbeat) {
+            if (rw) fused_r4(Pp, par, g, r);
+            __syncthreads();
         }
     }
 }
@@ -1506,6 +1572,36 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
     if (rc) return rc;
     if (rj) return rj;
     return smr_mp_end_tick(c);
+}
+
+int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n, void *stream) {
+    if (!c || (n && !ticks)) return fail(SMR_ERR_ARG, "mp: null argument");
+    if (c->ttl) return fail(SMR_ERR_STATE, "mp: run_ticks and the straggler side stream exclude each other (straggler_ticks must be off)");
+    if (c->forked || c->marked) return fail(SMR_ERR_STATE, "mp: run_ticks inside an open tick");
+    hipStream_t st = (hipStream_t)stream;
+    for (uint32_t i = 0; i < n; i++) {
+        const smr_mp_tick_in &x = ticks[i];
+        if (x.timeout_rep_dev && !x.timeout_src_dev) return fail(SMR_ERR_ARG, "mp: timeout_rep without timeout_src");
+        if (x.req_target_dev && (!x.req_cnt_dev || !x.req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
+    }
+    const uint32_t R = c->cfg.population;
+    const dim3 grid((c->cfg.n_groups + 63) / 64);
+    for (uint32_t i0 = 0; i0 < n; i0 += MP_FUSED_MAXT) {
+        MpTickBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n - i0 < MP_FUSED_MAXT ? n - i0 : MP_FUSED_MAXT;
+        b.par0 = c->par;
+        for (uint32_t k = 0; k < b.n; k++) {
+            const smr_mp_tick_in &x = ticks[i0 + k];
+            b.t[k] = MpTickIn{x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.ackctl_dev,
+                              x.S, x.do_heartbeat ? 1 : 0};
+        }
+        if (R <= 5) hipLaunchKernelGGL((mp_ticks_fused<5, 5>), grid, dim3(5 * 64), 0, st, c->dp, b);
+        else hipLaunchKernelGGL((mp_ticks_fused<MAXR, MAXR>), grid, dim3(MAXR * 64), 0, st, c->dp, b);
+        SMR_HIP_TRY(hipGetLastError());
+        c->par ^= (int)(b.n & 1u);
+    }
+    return SMR_OK;
 }
 
 int smr_mp_ack_matrix(smr_mp_cluster *c, uint8_t rep, uint8_t **ack_dev, uint64_t *n_bytes) {

@@ -226,4 +226,20 @@ struct MpParams {
     MpRep rep[MAXR];
 };
 
+// One tick's device inputs (the arguments of smr_mp_tick), and a batch of consecutive ticks handed to ONE launch of
+// the fused tick kernel (mp_ticks_fused) as a by-value kernel argument: the tick index is block-uniform, so the
+// descriptors are read with scalar loads from the kernarg segment.
+struct MpTickIn {
+    const uint8_t *timeout_rep, *timeout_src, *req_target;
+    const uint32_t *req_cnt, *req_val, *ackctl;
+    uint32_t S;
+    int32_t heartbeat;
+};
+constexpr uint32_t MP_FUSED_MAXT = 16;
+struct MpTickBatch {
+    uint32_t n;
+    int32_t par0;                   // outbox parity of the first tick
+    MpTickIn t[MP_FUSED_MAXT];
+};
+
 }  // namespace smr

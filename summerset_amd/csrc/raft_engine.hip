@@ -115,6 +115,13 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
     if (g < v.G) {
+        // One lane per group and 65 536 groups are one wavefront per SIMD: the kernel is a chain of dependent memory
+        // round trips, so the chain is kept at TWO rounds of loads.  Round 1: the group's scalars, every peer's state
+        // and every peer's reply (addressed by peer id, not by the delivery order, so nothing waits for the order
+        // word).  Pass A then replays the replies in delivery order in registers -- everything of the handler except
+        // the commit scan, whose upper end `hi` depends only on the match indices -- and round 2 loads the entry terms
+        // at those (<= R - 1) slots together.  Pass B finishes the commit scans in the same order; it goes back to
+        // memory only when the entry at `hi` is of an older term (never in a steady term).
         uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
         if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
         uint32_t role = v.role[g], leader = v.leader[g];
@@ -123,24 +130,33 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
         uint32_t commit = v.last_commit[g], snap = v.last_snap[g];
         const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
         const uint64_t o_term = term;
-        uint32_t nx[RMAX], tn[RMAX], mt[RMAX];
+        uint32_t nx[RMAX], tn[RMAX], mt[RMAX], rf[RMAX], res[RMAX];
+        uint64_t rtm[RMAX];
         bool dirty[RMAX];
 #pragma unroll
         for (int p = 0; p < RMAX; p++) {
             bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
             size_t o = (size_t)p * v.G + g;
             nx[p] = on ? v.next_slot[o] : 0; tn[p] = on ? v.try_next_slot[o] : 0; mt[p] = on ? v.match_slot[o] : 0;
+            rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
             dirty[p] = false;
         }
         const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+        uint32_t hi_at[RMAX];                                   // by delivery position: upper end of that reply's commit scan
+#pragma unroll
+        for (int q = 0; q < RMAX; q++) hi_at[q] = 0xFFFFFFFFu;
+        const uint64_t lead_term = term;                        // commit scans only happen while I lead: in this term
+        // ---- pass A -------------------------------------------------------------------------------------------
         for (uint32_t oi = 0; oi < v.R; oi++) {
             const uint32_t p = (ctl >> (3 * oi)) & 7u;
             if (p == v.me || p >= v.R) continue;
             const size_t o = (size_t)p * v.G + g;
-            const uint32_t f = flags[o];
+            // registers indexed by a runtime peer id: unrolled select
+            uint32_t f = 0, es = 0, nxp = 0, tnp = 0;
+            uint64_t rt = 0;
+#pragma unroll
+            for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
             if (!(f & 1)) continue;
-            const uint64_t rt = reply_term[o];
-            const uint32_t es = end_slot[o];
             // leadership.rs:16-72 check_term
             bool stepped = false;
             if (rt > term) {
@@ -150,10 +166,6 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
             }
             if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
             if (CRAFT) heard |= 1u << p;
-            // registers indexed by a runtime peer id: unrolled select
-            uint32_t nxp = 0, tnp = 0;
-#pragma unroll
-            for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nxp = nx[q]; tnp = tn[q]; }
             uint32_t mtp;
             if (!(f & 2)) {
                 if (!CRAFT && nxp > es + 1) continue;           // :245-247
@@ -177,15 +189,9 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                         if (ge >= need && mt[q] > m) m = mt[q];
                     }
                 }
-                uint32_t hi = m < len - 1 ? m : len - 1;
-                for (uint32_t s = hi; s > commit; s--) {
-                    if (s < rlo) break;                         // beyond the term ring
-                    if (v.entry_term[(size_t)(s & v.Wmask) * v.G + g] == term) {
-                        c[0] += s - commit;                     // :278-293 exec submissions
-                        commit = s;
-                        break;
-                    }
-                }
+                const uint32_t hi = m < len - 1 ? m : len - 1;
+#pragma unroll
+                for (int q = 0; q < RMAX; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
                 // snapshot-safe index, closed form of :298-309
                 uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
@@ -215,6 +221,28 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 }
 #pragma unroll
                 for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
+            }
+        }
+        // ---- round 2: the entry terms at the scans' upper ends, together -------------------------------------------
+        uint64_t et[RMAX];
+#pragma unroll
+        for (int q = 0; q < RMAX; q++) {
+            const uint32_t h = hi_at[q];
+            et[q] = (h != 0xFFFFFFFFu && h > commit && h >= rlo) ? v.entry_term[(size_t)(h & v.Wmask) * v.G + g] : 0ull;
+        }
+        // ---- pass B: the scans of :256-275 / :278-293 in delivery order ----------------------------------------------
+#pragma unroll
+        for (int q = 0; q < RMAX; q++) {
+            const uint32_t hi = hi_at[q];
+            if (hi == 0xFFFFFFFFu) continue;
+            for (uint32_t s2 = hi; s2 > commit; s2--) {
+                if (s2 < rlo) break;                            // beyond the term ring
+                const uint64_t e = s2 == hi ? et[q] : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + g];
+                if (e == lead_term) {
+                    c[0] += s2 - commit;                        // :278-293 exec submissions
+                    commit = s2;
+                    break;
+                }
             }
         }
         if (role != o_role) v.role[g] = (uint8_t)role;

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import MpCfg, MpDumpBufs, MpGroupState, SummersetError, check, stream_ptr
+from ._lib import MpCfg, MpDumpBufs, MpGroupState, MpTickIn, SummersetError, check, stream_ptr
 
 _DUMP_T = {"leader": np.uint8, "bal_prep_sent": np.uint64, "bal_prepared": np.uint64, "bal_max_seen": np.uint64,
            "s_bal": np.uint64, "s_status": np.uint8, "s_reqs": np.uint32, "s_vbal": np.uint64,
@@ -58,6 +58,19 @@ class MultiPaxosCluster:
         S = 0 if req_val is None else int(req_val.shape[0])
         check(self._L.smr_mp_tick(self._h, _ptr(timeout_rep), _ptr(timeout_src), _ptr(req_target), _ptr(req_cnt),
                                   _ptr(req_val), S, _ptr(ackctl), int(heartbeat), stream_ptr(stream)))
+
+    def run_ticks(self, ticks, stream=None):
+        """a batch of consecutive ticks (each a dict of `tick`'s arguments) through the fused tick kernel: one launch per
+        16 ticks instead of five per tick, same results (`smr_mp_run_ticks`; straggler_ticks must be off)"""
+        n = len(ticks)
+        arr = (MpTickIn * max(n, 1))()
+        for a, t in zip(arr, ticks):
+            rv = t.get("req_val")
+            a.timeout_rep_dev, a.timeout_src_dev = _ptr(t.get("timeout_rep")), _ptr(t.get("timeout_src"))
+            a.req_target_dev, a.req_cnt_dev, a.req_val_dev = _ptr(t.get("req_target")), _ptr(t.get("req_cnt")), _ptr(rv)
+            a.S = 0 if rv is None else int(rv.shape[0])
+            a.ackctl_dev, a.do_heartbeat = _ptr(t.get("ackctl")), int(bool(t.get("heartbeat", False)))
+        check(self._L.smr_mp_run_ticks(self._h, arr, n, stream_ptr(stream)))
 
     # the four rounds individually (multi-GPU driver / hosts with real I/O)
     def round_local(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None,

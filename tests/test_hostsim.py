@@ -172,3 +172,17 @@ def test_baseline_config_slice_tests_on_the_host(sim, oracle):
         assert changed > 0 and total > 0
         t.run_rspaxos_slices("cpu", oracle, G=256, W=16, T=12, ft=1, loss=0.05, width=64, n_slices=3)
         t.run_epaxos_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=3)
+
+
+def test_fused_tick_kernel_on_the_host(sim, oracle):
+    """smr_mp_run_ticks: batches of ticks in one launch of mp_ticks_fused (a block = 64 groups x all replicas, block
+    barriers for round boundaries) give what tick-by-tick launches give"""
+    import test_mp_gpu as t
+    with sim.patched():
+        for fused in (1, 3, 16):
+            t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=36, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=fused)
+        t._run("cpu", oracle, G=130, R=5, S=4, W=64, n_ticks=30, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True, fused=7)
+        t._run("cpu", oracle, G=64, R=5, S=1, W=64, n_ticks=24, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False, fused=4)
+        t._run("cpu", oracle, G=65, R=3, S=2, W=32, n_ticks=30, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5)
+        t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6)
+        t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, every=4, fused=16)

@@ -74,10 +74,10 @@ def _acks_as_records(eng, cuda, G, R, cap, t):
 
 
 def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, preset, commit_extra=0, seed=None,
-         every=1, timeout_rep=1, straggler_ticks=0, per_round=False):
+         every=1, timeout_rep=1, straggler_ticks=0, per_round=False, fused=0):
     from summerset_amd import MultiPaxosCluster, stream
     cap = W + 4
-    eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * S * 4 + 64,
+    eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * (S * 4 * max(fused, 1) + W) + 64,
                             straggler_ticks=straggler_ticks)
     orc = oracle.MpOracle(G, R, W, cap=cap, commit_extra=commit_extra)
     if preset:
@@ -93,10 +93,21 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
         eng.tick(**_to_dev(t0, cuda))
         _compare(eng, orc, R, -1)
     total = 0
+    pending = []                            # fused: ticks collected for one smr_mp_run_ticks call
+    og_acc = [[np.zeros(0, np.uint32)] * 2 for _ in range(R)]
     for t in range(n_ticks):
         inp = st.tick(t)
         orc.tick(**inp)
-        if per_round:                       # the four rounds as separate C-ABI calls
+        if fused:                           # batches of `fused` ticks through the fused tick kernel (one launch each)
+            pending.append(_to_dev(inp, cuda))
+            for r in range(R):
+                g_, s_ = orc.take_commits(r)
+                og_acc[r] = [np.concatenate([og_acc[r][0], g_]), np.concatenate([og_acc[r][1], s_])]
+            if len(pending) < fused and t != n_ticks - 1:
+                continue
+            eng.run_ticks(pending)
+            pending = []
+        elif per_round:                     # the four rounds as separate C-ABI calls
             d = _to_dev(inp, cuda)
             eng.round_local(d["timeout_rep"], d["timeout_src"], d["req_target"], d["req_cnt"], d["req_val"])
             eng.round_deliver()
@@ -108,11 +119,12 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
             eng.end_tick()
         else:
             eng.tick(**_to_dev(inp, cuda))
-        if t % every == 0 or t == n_ticks - 1:
+        if fused or t % every == 0 or t == n_ticks - 1:
             _compare(eng, orc, R, t)
         # ordered committed-slot list of the (possibly several) leaders
         for r in range(R):
-            og, os_ = orc.take_commits(r)
+            og, os_ = og_acc[r] if fused else orc.take_commits(r)
+            og_acc[r] = [np.zeros(0, np.uint32)] * 2
             eg, es = eng.poll_commits(r)
             assert len(og) == len(eg), "tick %d rep %d commit count %d vs %d" % (t, r, len(eg), len(og))
             ko = np.lexsort((np.arange(len(og)), og))
@@ -195,7 +207,7 @@ def test_config2_4096_groups(cuda, oracle):
          preset=True, every=8)
 
 
-def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, every=6, log=None):
+def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, every=6, log=None, fused=0):
     """bench.py's shape (S=32, W=512, pooled tick inputs, <= 2 acks lost per slot) with leader
     changes: logs of 100+ slots go through the long-outbox / cooperative paths the small shapes
     above never reach."""
@@ -209,6 +221,7 @@ def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, ev
     st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=0.1, timeout_frac=frac, hb_every=H,
                                  rand_rows=S + 4, max_drop=2, timeout_span=span)
     pool = [st.tick(t) for t in range(4)]
+    batch = []
     for t in range(n_ticks):
         inp = dict(pool[t % 4])
         inp.update(st.tick_events(t))
@@ -216,7 +229,13 @@ def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, ev
         orc.tick(**inp)
         if not (inp["timeout_rep"] != 0xFF).any():     # a host knows when no timer fired: no array at all
             inp["timeout_rep"] = inp["timeout_src"] = None
-        eng.tick(**_to_dev(inp, cuda))
+        if fused:                                      # `fused` ticks per smr_mp_run_ticks call
+            batch.append(_to_dev(inp, cuda))
+            if len(batch) == fused or t == n_ticks - 1 or t % every == every - 1:
+                eng.run_ticks(batch)
+                batch = []
+        else:
+            eng.tick(**_to_dev(inp, cuda))
         if t % every == every - 1 or t == n_ticks - 1:
             _compare(eng, orc, R, t)
             if log:
@@ -229,3 +248,31 @@ def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, ev
 @pytest.mark.parametrize("straggler_ticks", [0, 4])
 def test_bench_shape_leader_changes(cuda, oracle, straggler_ticks):
     _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, straggler_ticks=straggler_ticks)
+
+
+# ---- the fused tick kernel (smr_mp_run_ticks): batches of ticks in one launch, same results as tick by tick ----
+@pytest.mark.parametrize("fused", [1, 3, 16, 20])
+def test_fused_ticks_leader_change(cuda, oracle, fused):
+    _run(cuda, oracle, G=512, R=5, S=2, W=64, n_ticks=48, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=fused)
+
+
+def test_fused_ticks_other_shapes(cuda, oracle):
+    _run(cuda, oracle, G=1000, R=5, S=4, W=64, n_ticks=60, drop_p=0.1, timeout_frac=0.0, hb_every=3, preset=True, fused=7)
+    _run(cuda, oracle, G=128, R=5, S=1, W=64, n_ticks=30, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False, fused=4)
+    _run(cuda, oracle, G=257, R=3, S=2, W=32, n_ticks=40, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5)
+    _run(cuda, oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6)
+    _run(cuda, oracle, G=400, R=5, S=2, W=64, n_ticks=40, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True, commit_extra=1, fused=16)
+    eng, _ = _run(cuda, oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True, fused=9)
+    assert eng.counters(0)["rejects"] > 0
+
+
+def test_fused_ticks_bench_shape(cuda, oracle):
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=16)
+
+
+def test_fused_ticks_need_the_straggler_list_off(cuda):
+    from summerset_amd import MultiPaxosCluster
+    from summerset_amd._lib import SummersetError
+    eng = MultiPaxosCluster(64, 5, 32, straggler_ticks=2)
+    with pytest.raises(SummersetError):
+        eng.run_ticks([dict(heartbeat=True)])

@@ -31,6 +31,18 @@ for t in range(a.ticks):
     eng.tick(timeout_rep=e["timeout_rep"] if fired else None, timeout_src=e["timeout_src"] if fired else None, req_target=e["req_target"],
              heartbeat=st.heartbeat(t), **pool[t % 4])
 torch.cuda.synchronize()
+# the same workload through the fused tick kernel: two launches of 16 ticks each (smr_mp_run_ticks)
+eng2 = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+eng2.preset_leader(0)
+batch = []
+for t in range(32):
+    e = {k: torch.from_numpy(v).to(dev) for k, v in st.tick_events(t % a.ticks).items()}
+    fired = bool((st.timeout_tick == t % a.ticks).any()) and t < a.ticks
+    batch.append(dict(timeout_rep=e["timeout_rep"] if fired else None, timeout_src=e["timeout_src"] if fired else None,
+                      req_target=e["req_target"], heartbeat=st.heartbeat(t), **pool[t % 4]))
+eng2.run_ticks(batch)
+torch.cuda.synchronize()
+del eng2
 data = torch.randint(0, 256, (65536, 4099), dtype=torch.uint8, device=dev)     # 268 MB: past the 256 MB L3
 cw = RSCodewordBatch.from_data(data, 3, 2)
 for _ in range(3):
