@@ -66,6 +66,10 @@ def parse():
                     "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
+    ap.add_argument("--layout", choices=("colocated", "spread"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
+                    "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
+    ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
+                    "kernels, plans and buffers; the collective is a device copy)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
@@ -89,37 +93,80 @@ def _rs_cpu_run(a):
     return done * L / 2**30 / (time.perf_counter() - t0), done
 
 
+def rse_sweep(torch, dev):
+    """benches/rse_bench.rs:19-26: RS(3,2) over String values of 4 KiB ... 4 MiB.  Per size: batches of codewords sized to
+    ~256 MB per launch, 3 batches in rotation.  `encode` = compute_parity alone on bytes already laid out as a codeword;
+    `from_data_and_encode` adds the from_data-equivalent work of the reference's loop body (rse_bench.rs:161-169): copying
+    the serialized bytes into the codeword buffer (a device copy stands in for bincode + allocation)."""
+    from summerset_amd import RSCodewordBatch
+    out = []
+    for size in (4096, 16 * 1024, 64 * 1024, 256 * 1024, 1024 * 1024, 4096 * 1024):
+        L = size + (3 if size < 65536 else 5)                 # bincode String: varint length (0xFB u16 / 0xFC u32) + bytes
+        n = max(8, (256 << 20) // (L * 5 // 3))
+        srcs = [torch.randint(0, 256, (n, L), dtype=torch.uint8, device=dev) for _ in range(3)]
+        cws = [RSCodewordBatch.from_data(x, 3, 2) for x in srcs]
+        for c in cws:
+            c.compute_parity()
+        us_enc = _time_us(torch, lambda i: cws[i % 3].compute_parity(), 9)
+
+        def both(i):
+            c = cws[i % 3]
+            c.buf[:, :L].copy_(srcs[i % 3])                   # from_data: the serialized bytes into the shard buffer
+            c.compute_parity()
+        us_both = _time_us(torch, both, 9)
+        sl = cws[0].shard_len
+        out.append({"value_bytes": size, "codewords_per_launch": n, "encode_GiBps": n * L / 2**30 / (us_enc * 1e-6),
+                    "encode_frac": n * 5 * sl / (us_enc * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "from_data_and_encode_GiBps": n * L / 2**30 / (us_both * 1e-6)})
+        del srcs, cws
+    return out
+
+
 def rs_leg(torch, dev, run_cpu, cpu_seconds):
     """BASELINE config 4: 16384 codewords, 4 KiB values -> bincode(String) L = 4099, RS(3,2)."""
     from summerset_amd import RSCodewordBatch
     n, L = 16384, 4099
-    data = torch.randint(0, 256, (n, L), dtype=torch.uint8, device=dev)
+    # Config 4's tick is 16384 codewords (67 MB in, 45 MB out): re-encoding ONE such batch would sit in the 256 MiB
+    # Infinity Cache (MI355X_MICROARCH.md: FETCH_SIZE counts L3 hits), so the timed loop rotates NB distinct batches whose
+    # inputs + outputs total NB x 112 MB > 3 x the L3 -- every launch streams from HBM and writes to HBM.
+    NB = 8
+    batches = [RSCodewordBatch.from_data(torch.randint(0, 256, (n, L), dtype=torch.uint8, device=dev), 3, 2) for _ in range(NB)]
+    data = batches[0].get_data()
     out = {}
     for name, lut in (("xtime", False), ("lut", True)):
-        cw = RSCodewordBatch.from_data(data, 3, 2)
-        for _ in range(3):
+        for cw in batches:
             cw.compute_parity(lut=lut)
         torch.cuda.synchronize()
-        iters = 50
+        iters = 48
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            cw.compute_parity(lut=lut)
+        for i in range(iters):
+            batches[i % NB].compute_parity(lut=lut)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
+        cw = batches[0]
         alg = n * 5 * cw.shard_len                       # SURVEY §8d: 5 * ceil(L/3) bytes per codeword
         out[name] = {"ms_per_launch": ms, "payload_GiBps": n * L / 2**30 / (ms * 1e-3),
                      "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # one launch over 65536 codewords (448 MB of traffic by itself), and the single hot batch for comparison
+    big = RSCodewordBatch.from_data(torch.randint(0, 256, (65536, L), dtype=torch.uint8, device=dev), 3, 2)
+    us_big = _time_us(torch, lambda i: big.compute_parity(), 12)
+    us_hot = _time_us(torch, lambda i: batches[0].compute_parity(), 48)
+    del big
     t_rs = pmc_traffic("smr::rs_matmul_xtime<2, 4>")
-    res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String)",
+    res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String) per launch, "
+                       "%d distinct batches in rotation (%.0f MB in + out: beyond the 256 MiB L3)" % (NB, NB * n * 5 * cw.shard_len / 1e6),
            "value": out["xtime"]["payload_GiBps"], "unit": "GiB/s payload",
            "roofline": {"bound": "hbm", "achieved": out["xtime"]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": out["xtime"]["frac"], "kernel": "rs_matmul_xtime<2, 4>",
                         "alg_bytes_per_launch": n * 5 * cw.shard_len, "avg_launch_us": out["xtime"]["ms_per_launch"] * 1e3,
                         "traffic": (t_rs["hbm_bytes_per_launch"] / 65536 * n) if t_rs else None,
                         "traffic_note": "PMC bytes of a 65536-codeword launch scaled to this launch's %d codewords" % n},
-           "lut_variant_GiBps": out["lut"]["payload_GiBps"]}
+           "lut_variant_GiBps": out["lut"]["payload_GiBps"],
+           "one_launch_65536_codewords": {"avg_launch_us": us_big, "frac": 65536 * 5 * cw.shard_len / (us_big * 1e-6) / 1e9 / HBM_PEAK_GBS},
+           "single_hot_batch_L3_assisted": {"avg_launch_us": us_hot, "frac": n * 5 * cw.shard_len / (us_hot * 1e-6) / 1e9 / HBM_PEAK_GBS},
+           "rse_bench_sweep": rse_sweep(torch, dev)}
     if run_cpu:
         import multiprocessing as mp
         host = data[:2048].cpu().numpy().reshape(-1).copy()
@@ -575,6 +622,69 @@ def cpu_leg(args, seconds):
                       "path cannot be built here (no cargo, no vendored crates)" % (args.slots, cores, sn, s1, n1)}
 
 
+def spread_main(args, torch, dist, rank, local, world, dev):
+    """--layout spread: the headline workload with the replicas of every group on different ranks.  Weak scaling like the
+    co-located line: args.groups groups per GPU.  At world 1 the job's ranks are virtual (spread_mp.in_process)."""
+    from summerset_amd import shard, spread_mp, stream
+    R, S, W, H = 5, args.slots, args.window, args.hb_every
+    cap = W + 4
+    virtual = world == 1
+    nr = args.spread_ranks if virtual else world
+    total = args.groups * (1 if virtual else world)
+    kw = dict(win_reserve=W // 8, outbox_cap=cap)
+    job = spread_mp.in_process(total, R, W, nr, dev, S, **kw) if virtual else spread_mp.SpreadMultiPaxos(total, R, W, rank, world, dev, S, **kw)
+    job.preset_leader(0)
+    mine = sorted({b for rk in job.ranks for b in rk.blocks} if virtual else job.blocks)
+    n_ticks = args.warmup + args.steps
+    skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2,
+               timeout_span=args.timeout_span)
+    sts = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **skw) for b, (lo, hi) in ((b, shard.group_range(total, nr, b)) for b in mine)}
+    pools = {b: [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(args.pool)]
+             for b, st in sts.items()}
+    evs = {b: [{k: torch.from_numpy(v).to(dev) for k, v in st.tick_events(t).items()} for t in range(n_ticks)] for b, st in sts.items()}
+    hb = next(iter(sts.values())).heartbeat
+
+    def step(t):
+        job.tick({b: dict(pools[b][t % args.pool], **evs[b][t]) for b in mine}, heartbeat=hb(t))
+    commits_of = (lambda: sum(rk.commits() for rk in job.ranks)) if virtual else job.commits
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    c0 = commits_of()
+    sent0 = sum(rk.bytes_sent for rk in job.ranks) if virtual else job.bytes_sent
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_ticks):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    commits = commits_of() - c0
+    sent = (sum(rk.bytes_sent for rk in job.ranks) if virtual else job.bytes_sent) - sent0
+    dropped = sum(rk.dropped_overflow_entries() for rk in job.ranks) if virtual else job.dropped_overflow_entries()
+    elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)
+    line = {"metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s", "n_gpus": world,
+            "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, heartbeat every %d ticks, "
+                                   "%.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout" % (args.groups, S, H, args.drop * 100, args.timeouts * 100),
+                       "groups_per_gpu": args.groups, "replicas": R, "slots_per_tick": S, "window": W, "layout": "spread",
+                       "spread_ranks": nr, "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
+            "exchange": {"collectives_per_tick": "3 with a heartbeat round, else 2 (one all_to_all_single each)",
+                         "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1), "overflow_entries_dropped": dropped},
+            "roofline": None, "cpu_baseline": None,
+            "note": "correctness layout of the north star's inter-replica fan-out; the roofline / cpu_baseline objects belong to the co-located line"}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks exactly as the driver's own
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would and hand
@@ -634,6 +744,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     from summerset_amd import MultiPaxosCluster, stream
+    if args.layout == "spread":
+        return spread_main(args, torch, dist, rank, local, world, dev)
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4

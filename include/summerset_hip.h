@@ -190,6 +190,26 @@ typedef struct {
     int do_heartbeat;
 } smr_mp_tick_in;
 int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n, void *stream);
+/* ---- spread layout: the replicas of a group on different ranks --------------------------------
+ * smr_mp_set_live: bit r of live_mask = replica r of this cluster object runs on this device; the round calls then
+ * skip the others, which are IMAGES: only what the rounds hand from one replica to another exists of them here.
+ * Between rounds the host moves those pieces (server/transport.rs:208-275 send_msg / bcast_msg stand-in):
+ *   after R1  SMR_IMG_OUTBOX           of every live replica -> the ranks holding the group's other replicas
+ *   after R2  SMR_IMG_ACKS             (rep = an image's id, other = my live follower): the AcceptReplies it is owed -> its rank
+ *             SMR_IMG_PREPARE_REPLIES  of every live replica -> the ranks holding the group's other replicas
+ *   after R3  SMR_IMG_HEARTBEAT        of every live replica -> ... (ticks with a heartbeat round)
+ * as fixed-size device buffers: smr_mp_image_bytes(kind, rows, ovf_cap) bytes, `rows` = outbox entries per group shipped
+ * in the per-group part (the tick's S), ovf_cap = entries of the overflow list that carries what a leader change adds.
+ * pack reads a LIVE replica (ACKS: the image `rep` my live follower `other` wrote into), unpack writes an image
+ * (ACKS: into my live sender `rep`, the column of follower `other`).  An overflow list that ran full is counted in the
+ * image header (uint32 [2]) and the entries are lost: size ovf_cap for the leader changes a tick can hold. */
+enum { SMR_IMG_OUTBOX = 0, SMR_IMG_ACKS = 1, SMR_IMG_PREPARE_REPLIES = 2, SMR_IMG_HEARTBEAT = 3 };
+int smr_mp_set_live(smr_mp_cluster *c, uint32_t live_mask);
+int64_t smr_mp_image_bytes(smr_mp_cluster *c, int kind, uint32_t rows, uint32_t ovf_cap);
+int smr_mp_image_pack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, uint8_t *img_dev, uint64_t img_bytes,
+                      uint32_t rows, uint32_t ovf_cap, void *stream);
+int smr_mp_image_unpack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, const uint8_t *img_dev, uint64_t img_bytes,
+                        uint32_t rows, uint32_t ovf_cap, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
 

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict
                                                       const uint32_t *__restrict__ req_cnt,
                                                       const uint32_t *__restrict__ req_val, uint32_t S, int side) {
     const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;                 // spread layout: that replica lives on another rank
     uint32_t g;
     const bool active = pick_group(P, side, g);
     r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, active, blockIdx.y);
@@ -494,6 +495,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
 
 __global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
     r2_body(P, par, g, active, blockIdx.y);
@@ -767,9 +769,10 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     uint32_t prmask = 0;
 #pragma unroll
     for (int d = 0; d < MAXR; d++) {
-        if (!active) cnts[d] = 0;
+        if (!active || !((P.live >> d) & 1u)) cnts[d] = 0;      // (an image's outbox is its own rank's to tally)
         if (active && prc[d] != 0) prmask |= 1u << prd[d];
     }
+    prmask &= P.live;
     // my replica: the lowest one with a non-empty outbox (a second one, if any, is left to mp_round_replies)
     uint32_t dl = R, cnt = 0;
 #pragma unroll
@@ -875,7 +878,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     }
     if (publish_hb && active) {                                 // leadership.rs:240-247 record, complete rounds only
         for (uint32_t d = w; d < R; d += 4) {                   // replicas dealt over the four wavefronts
-            if ((need >> d) & 1u) continue;                     // mp_round_replies publishes after its work
+            if (((need >> d) & 1u) || !((P.live >> d) & 1u)) continue;   // mp_round_replies publishes after its work
             const MpRep &u = P.rep[d];
             uint32_t cb = u.commit_bar[gg], eb = u.exec_bar[gg];
             if (closed && d == dl) {                            // wavefront 0's stores above may not have landed
@@ -970,6 +973,7 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb, int side) {
     const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
     if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
         const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
         uint32_t any = 0;
@@ -1018,6 +1022,7 @@ __device__ __forceinline__ void r4_body(const MpParams &P, int par, const uint32
 
 __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
     r4_body(P, par, g, active, blockIdx.y);
@@ -1119,6 +1124,161 @@ __global__ __launch_bounds__(NW * 64, FUSED_MINW) void mp_ticks_fused(const MpPa
             __syncthreads();
         }
     }
+}
+
+// ---- spread layout: what the rounds hand from one replica to another, as fixed-size images ------
+// Replica r of a group may live on another rank.  This rank then holds r as an IMAGE: of everything r owns only the
+// arrays the other replicas read or write between rounds exist here -- its outbox (R1 -> R2), the ack words / cells
+// its followers fill (R2 -> R3), its PrepareReply batch (R2 -> R3) and its heartbeat record (R3 -> R4).  After a
+// round, each rank packs those pieces of its LIVE replicas into contiguous buffers, one collective moves them
+// (summerset_amd/spread.py: all_to_all_single over RCCL, static split sizes), and the receivers unpack them into
+// the images.  Sizes are fixed per (kind, G, rows): a per-group part for the steady state and an overflow list of
+// MP_IMG_OVF entries for what a leader change adds (irregular outboxes, ack cells of entries >= 64, PrepareReply rows).
+struct ImgHdr { uint32_t ovf_n, ovf_cap, dropped, pad; };
+struct ImgOvf { uint32_t g, j, a, b, c, pad; uint64_t d; };      // 32 B; meaning of a..d per kind, below
+__device__ __forceinline__ void img_push(ImgHdr *h, ImgOvf *ov, uint32_t cap, const ImgOvf &e) {
+    const uint32_t i = atomicAdd(&h->ovf_n, 1u);                 // (the header is zeroed by a memset in front of the pack kernel)
+    if (i < cap) ov[i] = e; else atomicAdd(&h->dropped, 1u);
+}
+__host__ __device__ inline size_t img_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// byte offsets of the parts of an image
+struct ImgLayout { size_t hdr, a, b, c, d, e, ovf, total; };
+__host__ __device__ inline ImgLayout img_layout(uint32_t kind, uint32_t G, uint32_t rows, uint32_t ovf_cap) {
+    ImgLayout L{};
+    size_t o = img_align(sizeof(ImgHdr));
+    L.hdr = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = img_align(o + bytes); return at; };
+    if (kind == SMR_IMG_OUTBOX) { L.a = take((size_t)G * 4); L.b = take((size_t)G * 4); L.c = take((size_t)G * 8); L.d = take((size_t)rows * G * 4); }
+    else if (kind == SMR_IMG_ACKS) { L.a = take((size_t)G * 8); }
+    else if (kind == SMR_IMG_PREPARE_REPLIES) { L.a = take((size_t)G * 4); L.b = take((size_t)G * 4); L.c = take((size_t)G * 4); L.d = take((size_t)G * 4); L.e = take((size_t)G * 8); }
+    else { L.a = take((size_t)G * 8); L.b = take((size_t)G * 4); L.c = take((size_t)G * 4); L.d = take((size_t)G * 4); }
+    L.ovf = take((size_t)ovf_cap * sizeof(ImgOvf));
+    L.total = o;
+    return L;
+}
+
+// OUTBOX of replica `rep` (parity par): cnt, reg, rbal per group; the tokens of a regular outbox's first `rows`
+// entries; everything else as overflow entries (a = ob_slot, b = ob_val, c = ob_aux, d = ob_bal; regular: b only)
+__global__ __launch_bounds__(256) void mp_img_pack_outbox(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t rows,
+                                                          uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
+    if (g >= P.G) return;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    ImgHdr *h = (ImgHdr *)img; ImgOvf *ov = (ImgOvf *)(img + L.ovf);
+    uint32_t cnt = v.ob_cnt(par)[g];
+    if (cnt > P.cap) cnt = P.cap;
+    const uint32_t reg = v.ob_reg(par)[g];
+    ((uint32_t *)(img + L.a))[g] = cnt; ((uint32_t *)(img + L.b))[g] = reg;
+    ((uint64_t *)(img + L.c))[g] = reg ? v.ob_rbal(par)[g] : 0ull;
+    uint32_t *tok = (uint32_t *)(img + L.d);
+    for (uint32_t j = 0; j < cnt; j++) {
+        const size_t o = tix(P.cap, j, g);
+        if (reg && j < rows) tok[(size_t)j * P.G + g] = v.ob_val(par)[o];
+        else if (reg) img_push(h, ov, ocap, ImgOvf{g, j, 0u, v.ob_val(par)[o], 0u, 0u, 0ull});
+        else img_push(h, ov, ocap, ImgOvf{g, j, v.ob_slot(par)[o], v.ob_val(par)[o], v.ob_aux(par)[o], 0u, v.ob_bal(par)[o]});
+    }
+}
+__global__ __launch_bounds__(256) void mp_img_unpack_outbox(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t rows,
+                                                            const uint8_t *__restrict__ img, ImgLayout L) {
+    const MpParams &P = *Pp;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
+    const uint32_t *cnts = (const uint32_t *)(img + L.a), *regs = (const uint32_t *)(img + L.b);
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < P.G) {
+        const uint32_t cnt = cnts[g], reg = regs[g];
+        v.ob_cnt(par)[g] = cnt; v.ob_reg(par)[g] = reg;
+        if (reg) v.ob_rbal(par)[g] = ((const uint64_t *)(img + L.c))[g];
+        const uint32_t *tok = (const uint32_t *)(img + L.d);
+        if (reg) for (uint32_t j = 0; j < cnt && j < rows; j++) v.ob_val(par)[tix(P.cap, j, g)] = tok[(size_t)j * P.G + g];
+    }
+    const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const ImgOvf e = ov[i];
+        if (e.g >= P.G || e.j >= P.cap) continue;
+        const size_t o = tix(P.cap, e.j, e.g);
+        v.ob_val(par)[o] = e.b;
+        if (!regs[e.g]) { v.ob_slot(par)[o] = e.a; v.ob_aux(par)[o] = e.c; v.ob_bal(par)[o] = e.d; }
+    }
+}
+// ACKS follower `fol` gave sender `rep` this tick: the word for entries < 64; the byte cells of entries >= 64 (both
+// values: the sender's cells are overwritten) as overflow entries (a = value)
+__global__ __launch_bounds__(256) void mp_img_pack_acks(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t fol,
+                                                        uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
+    if (g >= P.G) return;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    ImgHdr *h = (ImgHdr *)img; ImgOvf *ov = (ImgOvf *)(img + L.ovf);
+    uint32_t cnt = v.ob_cnt(par)[g];
+    if (cnt > P.cap) cnt = P.cap;
+    ((uint64_t *)(img + L.a))[g] = cnt ? ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, fol, g)] : 0ull;
+    for (uint32_t j = 64; j < cnt; j++) img_push(h, ov, ocap, ImgOvf{g, j, (uint32_t)v.ack()[ack_ix(P.cap, j, fol, g)], 0u, 0u, 0u, 0ull});
+}
+__global__ __launch_bounds__(256) void mp_img_unpack_acks(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t fol,
+                                                          const uint8_t *__restrict__ img, ImgLayout L) {
+    const MpParams &P = *Pp;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < P.G && v.ob_cnt(par)[g]) ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, fol, g)] = ((const uint64_t *)(img + L.a))[g];
+    const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const ImgOvf e = ov[i];
+        if (e.g < P.G && e.j < P.cap) v.ack()[ack_ix(P.cap, e.j, fol, e.g)] = (uint8_t)e.a;
+    }
+}
+// PREPARE_REPLIES of replica `rep`: header per group; the (voted_bal, voted_reqs) rows as overflow entries (a = vval, d = vbal)
+__global__ __launch_bounds__(256) void mp_img_pack_pr(const MpParams *__restrict__ Pp, uint32_t rep, uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
+    if (g >= P.G) return;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    ImgHdr *h = (ImgHdr *)img; ImgOvf *ov = (ImgOvf *)(img + L.ovf);
+    uint32_t n = v.pr_cnt()[g];
+    ((uint32_t *)(img + L.a))[g] = n; ((uint32_t *)(img + L.b))[g] = n ? v.pr_dest()[g] : 0u;
+    ((uint32_t *)(img + L.c))[g] = n ? v.pr_trig()[g] : 0u; ((uint32_t *)(img + L.d))[g] = n ? v.pr_endp()[g] : 0u;
+    ((uint64_t *)(img + L.e))[g] = n ? v.pr_bal()[g] : 0ull;
+    if (n > P.pcap) n = P.pcap;
+    for (uint32_t k = 0; k < n; k++) {
+        const size_t o = tix(P.pcap, k, g);
+        img_push(h, ov, ocap, ImgOvf{g, k, v.pr_vval()[o], 0u, 0u, 0u, v.pr_vbal()[o]});
+    }
+}
+__global__ __launch_bounds__(256) void mp_img_unpack_pr(const MpParams *__restrict__ Pp, uint32_t rep, const uint8_t *__restrict__ img, ImgLayout L) {
+    const MpParams &P = *Pp;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < P.G) {
+        const uint32_t n = ((const uint32_t *)(img + L.a))[g];
+        v.pr_cnt()[g] = n;
+        if (n) {
+            v.pr_dest()[g] = (uint8_t)((const uint32_t *)(img + L.b))[g]; v.pr_trig()[g] = ((const uint32_t *)(img + L.c))[g];
+            v.pr_endp()[g] = ((const uint32_t *)(img + L.d))[g]; v.pr_bal()[g] = ((const uint64_t *)(img + L.e))[g];
+        }
+    }
+    const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const ImgOvf e = ov[i];
+        if (e.g >= P.G || e.j >= P.pcap) continue;
+        const size_t o = tix(P.pcap, e.j, e.g);
+        v.pr_vval()[o] = e.a; v.pr_vbal()[o] = e.d;
+    }
+}
+// HEARTBEAT record of replica `rep` (leadership.rs:240-247): (bal_max_seen, commit_bar, exec_bar, snap_bar)
+__global__ __launch_bounds__(256) void mp_img_heartbeat(const MpParams *__restrict__ Pp, uint32_t rep, uint8_t *__restrict__ img, ImgLayout L, int unpack) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= P.G) return;
+    const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+    uint64_t *b = (uint64_t *)(img + L.a); uint32_t *c = (uint32_t *)(img + L.b), *x = (uint32_t *)(img + L.c), *sn = (uint32_t *)(img + L.d);
+    if (unpack) { v.hb_bal()[g] = b[g]; v.hb_commit()[g] = c[g]; v.hb_exec()[g] = x[g]; v.hb_snap()[g] = sn[g]; }
+    else { b[g] = v.hb_bal()[g]; c[g] = v.hb_commit()[g]; x[g] = v.hb_exec()[g]; sn[g] = v.hb_snap()[g]; }
 }
 
 // ------------------------------------------------------------------ host ---
@@ -1388,6 +1548,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     P.pcap = c->pcap; P.win_reserve = cfg->win_reserve; P.clist_cap = cfg->commit_list_cap;
     P.R = cfg->population; P.quorum = quorum; P.thresh = quorum + cfg->commit_extra; P.rspaxos = 0;
     P.slow_cap = SLOW_CAP;
+    P.live = (1u << cfg->population) - 1u;                    // co-located: every replica runs here
     if (!stride_ok(P)) {
         (void)hipFree(c->arena.base);
         delete c;
@@ -1557,7 +1718,9 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;                // one fork around the whole tick
     if (own) {                                                  // the list's whole tick: ONE launch on the side stream
-        hipLaunchKernelGGL(mp_straggler_tick, dim3(SLOW_CAP / 4), dim3(512), 0, c->side, c->dp, c->par, c->lpar,
+        // a wavefront per replica: 5 x 64 lanes for the common populations (the idle wavefronts of a 512-lane block would
+        // hold 227 VGPRs each on the CU the bulk kernels share with it)
+        hipLaunchKernelGGL(mp_straggler_tick, dim3(SLOW_CAP / 4), dim3(c->cfg.population <= 5 ? 320 : 512), 0, c->side, c->dp, c->par, c->lpar,
                            timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, ackctl_dev,
                            do_heartbeat);
         SMR_HIP_TRY(hipGetLastError());
@@ -1577,6 +1740,7 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
 int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n, void *stream) {
     if (!c || (n && !ticks)) return fail(SMR_ERR_ARG, "mp: null argument");
     if (c->ttl) return fail(SMR_ERR_STATE, "mp: run_ticks and the straggler side stream exclude each other (straggler_ticks must be off)");
+    if (c->hp.live != (1u << c->cfg.population) - 1u) return fail(SMR_ERR_STATE, "mp: run_ticks needs every replica live (co-located layout)");
     if (c->forked || c->marked) return fail(SMR_ERR_STATE, "mp: run_ticks inside an open tick");
     hipStream_t st = (hipStream_t)stream;
     for (uint32_t i = 0; i < n; i++) {
@@ -1601,6 +1765,62 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
         SMR_HIP_TRY(hipGetLastError());
         c->par ^= (int)(b.n & 1u);
     }
+    return SMR_OK;
+}
+
+int smr_mp_set_live(smr_mp_cluster *c, uint32_t live_mask) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    const uint32_t all = (1u << c->cfg.population) - 1u;
+    if ((live_mask & ~all) != 0) return fail(SMR_ERR_ARG, "mp: live mask names a replica beyond the population");
+    if (c->ttl && live_mask != all) return fail(SMR_ERR_STATE, "mp: the spread layout and the straggler side stream exclude each other");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    c->hp.live = live_mask;
+    SMR_HIP_TRY(hipMemcpy(c->dp, &c->hp, sizeof(MpParams), hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
+int64_t smr_mp_image_bytes(smr_mp_cluster *c, int kind, uint32_t rows, uint32_t ovf_cap) {
+    if (!c || kind < SMR_IMG_OUTBOX || kind > SMR_IMG_HEARTBEAT) return fail(SMR_ERR_ARG, "mp: bad image kind");
+    return (int64_t)img_layout((uint32_t)kind, c->cfg.n_groups, rows, ovf_cap).total;
+}
+
+static int img_check(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, const void *img, uint64_t img_bytes, uint32_t rows,
+                     uint32_t ovf_cap, ImgLayout &L) {
+    if (!c || !img || kind < SMR_IMG_OUTBOX || kind > SMR_IMG_HEARTBEAT) return fail(SMR_ERR_ARG, "mp: bad image argument");
+    if (rep >= c->cfg.population || (kind == SMR_IMG_ACKS && (other >= c->cfg.population || other == rep)))
+        return fail(SMR_ERR_ARG, "mp: bad replica for an image");
+    if (((uintptr_t)img & 7u) != 0) return fail(SMR_ERR_ARG, "mp: image buffers must be 8-byte aligned");
+    L = img_layout((uint32_t)kind, c->cfg.n_groups, rows, ovf_cap);
+    if (img_bytes < L.total) return fail(SMR_ERR_ARG, "mp: image buffer smaller than smr_mp_image_bytes()");
+    return SMR_OK;
+}
+
+int smr_mp_image_pack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, uint8_t *img_dev, uint64_t img_bytes, uint32_t rows,
+                      uint32_t ovf_cap, void *stream) {
+    ImgLayout L;
+    if (int rc = img_check(c, kind, rep, other, img_dev, img_bytes, rows, ovf_cap, L)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SMR_HIP_TRY(hipMemsetAsync(img_dev, 0, sizeof(ImgHdr), st));
+    const dim3 grid((c->cfg.n_groups + 255) / 256), block(256);
+    if (kind == SMR_IMG_OUTBOX) hipLaunchKernelGGL(mp_img_pack_outbox, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, rows, img_dev, L, ovf_cap);
+    else if (kind == SMR_IMG_ACKS) hipLaunchKernelGGL(mp_img_pack_acks, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, (uint32_t)other, img_dev, L, ovf_cap);
+    else if (kind == SMR_IMG_PREPARE_REPLIES) hipLaunchKernelGGL(mp_img_pack_pr, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L, ovf_cap);
+    else hipLaunchKernelGGL(mp_img_heartbeat, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L, 0);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_mp_image_unpack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, const uint8_t *img_dev, uint64_t img_bytes,
+                        uint32_t rows, uint32_t ovf_cap, void *stream) {
+    ImgLayout L;
+    if (int rc = img_check(c, kind, rep, other, img_dev, img_bytes, rows, ovf_cap, L)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((c->cfg.n_groups + 255) / 256), block(256);
+    if (kind == SMR_IMG_OUTBOX) hipLaunchKernelGGL(mp_img_unpack_outbox, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, rows, img_dev, L);
+    else if (kind == SMR_IMG_ACKS) hipLaunchKernelGGL(mp_img_unpack_acks, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, (uint32_t)other, img_dev, L);
+    else if (kind == SMR_IMG_PREPARE_REPLIES) hipLaunchKernelGGL(mp_img_unpack_pr, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L);
+    else hipLaunchKernelGGL(mp_img_heartbeat, grid, block, 0, st, c->dp, (uint32_t)rep, (uint8_t *)img_dev, L, 1);
+    SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
 

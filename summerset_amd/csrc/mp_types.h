@@ -222,6 +222,7 @@ struct MpParams {
     SMR_G uint32_t *slow_list;      // [slow_cap]
     SMR_G uint32_t *slow_n;         // [2] list length, by tick parity
     uint32_t slow_cap;
+    uint32_t live;                  // bit r: replica r runs on this device (spread layout: the others are images, see mp_img_*)
     size_t rep_stride;              // bytes from an array of replica d to the same array of replica d + 1
     MpRep rep[MAXR];
 };

@@ -186,3 +186,13 @@ def test_fused_tick_kernel_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=65, R=3, S=2, W=32, n_ticks=30, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5)
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6)
         t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, every=4, fused=16)
+
+
+def test_spread_layout_images_on_the_host(sim):
+    """layout L2 of the MultiPaxos cluster engine with every rank in this process (tests/test_spread_mp.py): live masks,
+    image pack / unpack kernels, exchange plan -- against the co-located engine, every tick"""
+    import test_spread_mp as t
+    with sim.patched():
+        t.run_spread_vs_colocated("cpu", G=256, R=5, S=2, W=64, world=2, n_ticks=24, drop_p=0.1, timeout_frac=1.0)
+        t.run_spread_vs_colocated("cpu", G=192, R=5, S=2, W=64, world=3, n_ticks=18, drop_p=0.1, timeout_frac=1.0)
+        t.run_spread_vs_colocated("cpu", G=128, R=3, S=2, W=32, world=2, n_ticks=16, drop_p=0.2, timeout_frac=0.5, hb_every=2)

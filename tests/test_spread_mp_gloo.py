@@ -1,0 +1,140 @@
+"""Layout L2 of the MultiPaxos cluster engine as a real two-process job: world_size 2 over gloo, the EMULATOR BUILD of the
+engine on every rank (tests/hostsim: the shipped kernels compiled for the host -- not the oracle), one
+`all_to_all_single` per exchange on the engine's own send / receive buffers.  Every rank's live replicas must hold, after
+every tick, exactly what the single-process co-located engine holds for those (group, replica) pairs.  Also through the
+L1 path: `shard.py` block partition driving the emulator engine (that test used to run the oracle)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, R, S, W, TICKS = 256, 5, 2, 64, 20
+FIELDS = None
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _kw():
+    return dict(cap=W + 4, n_ticks=TICKS, drop_p=0.1, timeout_frac=1.0, hb_every=3)
+
+
+def _fields():
+    from oracle.oracle import MP_SCALARS, MP_SLOTS
+    return list(MP_SCALARS) + ["peer_exec_bar"] + [n for n, _ in MP_SLOTS]
+
+
+def _spread_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    import hostsim
+    from summerset_amd import shard, spread_mp, stream
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with hostsim.patched():
+        job = spread_mp.SpreadMultiPaxos(G, R, W, rank, world, "cpu", S, outbox_cap=W + 4)
+        job.preset_leader(0)
+        bst = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **_kw()) for b, (_, _, lo, hi) in job.blocks.items()}
+        out = {}
+        for t in range(TICKS):
+            inputs, hb = {}, False
+            for b, s_ in bst.items():
+                x = s_.tick(t)
+                hb = x.pop("heartbeat")
+                inputs[b] = {k: torch.from_numpy(v) for k, v in x.items()}
+            job.tick(inputs, heartbeat=hb)
+            for b, (cl, live, lo, hi) in job.blocks.items():
+                for r in live:
+                    d = cl.dump(r)
+                    for name in _fields():
+                        out["t%d_b%d_r%d_%s" % (t, b, r, name)] = d[name]
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), commits=job.commits(), sent=job.bytes_sent,
+                 dropped=job.dropped_overflow_entries(), live=np.array([(b, r) for b, (_, lv, _, _) in job.blocks.items() for r in lv]), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_spread_job_is_the_colocated_one(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    import hostsim
+    from summerset_amd import MultiPaxosCluster, shard, stream
+    hostsim.build()                                                   # once, before the workers race to build it
+    port = _free_port()
+    mp.spawn(_spread_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
+    assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
+    assert sorted(rk["live"].tolist()[0][0] for rk in ranks) and all(int(rk["sent"]) > 0 and int(rk["dropped"]) == 0 for rk in ranks)
+    with hostsim.patched():
+        ref = MultiPaxosCluster(G, R, W, outbox_cap=W + 4)
+        ref.preset_leader(0)
+        st = stream.MultiPaxosStream(G, R, S, **_kw())
+        for t in range(TICKS):
+            inp = st.tick(t)
+            ref.tick(**{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in inp.items()})
+            for k, rk in enumerate(ranks):
+                for b, r in rk["live"].tolist():
+                    lo, hi = shard.group_range(G, 2, b)
+                    x = ref.dump(r, lo, hi - lo)
+                    for name in _fields():
+                        assert np.array_equal(rk["t%d_b%d_r%d_%s" % (t, b, r, name)], x[name]), (t, k, b, r, name)
+        assert sum(int(rk["commits"]) for rk in ranks) == sum(ref.counters(r)["commits"] for r in range(R)) > 0
+
+
+def _shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    import hostsim
+    from summerset_amd import MultiPaxosCluster, shard, stream
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard.group_range(G, world, rank)
+    with hostsim.patched():
+        eng = MultiPaxosCluster(hi - lo, R, W, outbox_cap=W + 4)
+        eng.preset_leader(0)
+        st = stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **_kw())
+        for t in range(TICKS):
+            eng.tick(**{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in st.tick(t).items()})
+        commits = sum(eng.counters(r)["commits"] for r in range(R))
+        elapsed, total = shard.reduce_metric(1.0 + rank, commits)
+        np.savez(os.path.join(out_dir, "shard%d.npz" % rank), commits=commits, total=total, elapsed=elapsed, ranks=shard.count_ranks(),
+                 cbar=eng.dump(0)["commit_bar"], leader=eng.dump(1)["leader"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_sharded_engine_job_l1(tmp_path):
+    """layout L1 (what `bench.py --gpus N` runs): the block partition of shard.py with the emulator build of the ENGINE
+    on every rank; the sharded job is the unsharded one and the metric reduction is MAX / SUM over the ranks"""
+    import torch
+    import torch.multiprocessing as mp
+    import hostsim
+    from summerset_amd import MultiPaxosCluster, stream
+    hostsim.build()
+    port = _free_port()
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(str(tmp_path / ("shard%d.npz" % k))) for k in range(2))
+    assert float(a["elapsed"]) == float(b["elapsed"]) == 2.0 and int(a["ranks"]) == int(b["ranks"]) == 2
+    assert int(a["total"]) == int(b["total"]) == int(a["commits"]) + int(b["commits"])
+    with hostsim.patched():
+        ref = MultiPaxosCluster(G, R, W, outbox_cap=W + 4)
+        ref.preset_leader(0)
+        st = stream.MultiPaxosStream(G, R, S, **_kw())
+        for t in range(TICKS):
+            ref.tick(**{k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in st.tick(t).items()})
+        assert sum(ref.counters(r)["commits"] for r in range(R)) == int(a["total"])
+        assert np.array_equal(ref.dump(0)["commit_bar"], np.concatenate([a["cbar"], b["cbar"]]))
+        assert np.array_equal(ref.dump(1)["leader"], np.concatenate([a["leader"], b["leader"]]))
