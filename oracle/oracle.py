@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c", "qr_oracle.c"]
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c", "qr_oracle.c", "bitmap_oracle.c", "hb_oracle.c"]
 
 CTL_IDENTITY = 0x00FAC688
 NO_LEADER = 0xFF
@@ -650,3 +650,129 @@ class QrOracle:
                    mx_val=np.zeros((Q, B, G), np.uint32), counters=np.zeros(4, np.uint64))
         lib().orc_qr_dump(self.h, *[_p(out[k]) for k in ("highest_slot", "live", "n", "rq_acks", "mx_state", "mx_slot", "mx_val", "counters")])
         return out
+
+
+# ------------------------------------------------------------- Bitmap ---
+class _BitmapS(C.Structure):
+    _fields_ = [("size", C.c_uint8), ("bits", C.c_uint64)]
+
+
+class Bitmap:
+    """`Bitmap` of src/utils/bitmap.rs restated (oracle/bitmap_oracle.c); errors as ValueError, the panics as AssertionError"""
+
+    def __init__(self, size, ones=False, _from=None):
+        self.m = _BitmapS()
+        L = lib()
+        rc = L.orc_bitmap_new(C.byref(self.m), size, int(ones)) if _from is None else \
+            L.orc_bitmap_from(C.byref(self.m), size, (C.c_uint8 * max(len(_from), 1))(*_from), len(_from))
+        if rc:
+            raise AssertionError("invalid bitmap size %d" % size if _from is None or size == 0 else "index out of bound")
+
+    @classmethod
+    def from_ones(cls, size, ones):
+        return cls(size, _from=sorted(set(int(x) for x in ones)))
+
+    def set(self, idx, flag):
+        if lib().orc_bitmap_set(C.byref(self.m), idx, int(flag)):
+            raise ValueError("index %d out of bound" % idx)
+
+    def get(self, idx):
+        out = C.c_int()
+        if lib().orc_bitmap_get(C.byref(self.m), idx, C.byref(out)):
+            raise ValueError("index %d out of bound" % idx)
+        return bool(out.value)
+
+    def size(self):
+        return int(lib().orc_bitmap_size(C.byref(self.m)))
+
+    def count(self):
+        return int(lib().orc_bitmap_count(C.byref(self.m)))
+
+    def flip(self):
+        lib().orc_bitmap_flip(C.byref(self.m))
+
+    def union(self, other):
+        if lib().orc_bitmap_union(C.byref(self.m), C.byref(other.m)):
+            raise ValueError("unioning sizes mismatch: %d != %d" % (self.size(), other.size()))
+
+    def clear(self):
+        lib().orc_bitmap_clear(C.byref(self.m))
+
+    def to_vec(self):
+        out = (C.c_uint8 * 64)()
+        n = lib().orc_bitmap_to_vec(C.byref(self.m), out)
+        return [int(out[i]) for i in range(n)]
+
+    def iter(self):
+        return [(i, self.get(i)) for i in range(self.size())]
+
+    def mask(self):
+        lib().orc_bitmap_mask.restype = C.c_uint64
+        return int(lib().orc_bitmap_mask(C.byref(self.m)))
+
+    def bincode(self):
+        out = (C.c_uint8 * 32)()
+        n = lib().orc_bitmap_bincode(C.byref(self.m), out)
+        return bytes(out[:n])
+
+    def __eq__(self, other):
+        return self.size() == other.size() and self.mask() == other.mask()
+
+
+# ------------------------------------------------------------- Heartbeater ---
+HB_ALL, HB_NONE = 0xFE, 0xFF
+
+
+class HbOracle:
+    """`Heartbeater` of src/server/heartbeat.rs for G groups (oracle/hb_oracle.c): explicit clock and random draws"""
+
+    def __init__(self, G, R=5, me=0, hear_min_ms=1200, hear_max_ms=2000, send_ms=20, now_ms=0):
+        L = lib()
+        L.orc_hb_new.restype = C.c_void_p
+        L.orc_hb_new.argtypes = [C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        for n in ("orc_hb_free", "orc_hb_set_sending", "orc_hb_clear_reply_cnts", "orc_hb_update_heard_cnt"):
+            getattr(L, n).argtypes = [C.c_void_p] + ([C.c_void_p] if n != "orc_hb_free" else [])
+            getattr(L, n).restype = None
+        L.orc_hb_kickoff_hear_timer.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_hb_poll.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_hb_update_bcast_cnts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hb_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        self.G, self.R, self.me = G, R, me
+        self.h = L.orc_hb_new(G, R, me, hear_min_ms, hear_max_ms, send_ms, now_ms)
+        if not self.h:
+            raise ValueError("invalid heartbeat configuration")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_hb_free(self.h)
+            self.h = None
+
+    def set_sending(self, sending):
+        lib().orc_hb_set_sending(self.h, _p(np.ascontiguousarray(sending, np.uint8)))
+
+    def kickoff_hear_timer(self, peer, now_ms, draw):
+        lib().orc_hb_kickoff_hear_timer(self.h, _p(np.ascontiguousarray(peer, np.uint8)), int(now_ms), _p(np.ascontiguousarray(draw, np.uint32)))
+
+    def poll(self, now_ms):
+        t, s = np.zeros((self.R, self.G), np.uint8), np.zeros(self.G, np.uint8)
+        lib().orc_hb_poll(self.h, int(now_ms), _p(t), _p(s))
+        return t, s
+
+    def clear_reply_cnts(self, peer):
+        lib().orc_hb_clear_reply_cnts(self.h, _p(np.ascontiguousarray(peer, np.uint8)))
+
+    def update_bcast_cnts(self, flags):
+        d = np.zeros(self.G, np.uint8)
+        lib().orc_hb_update_bcast_cnts(self.h, _p(np.ascontiguousarray(flags, np.uint8)), _p(d))
+        return d
+
+    def update_heard_cnt(self, peer):
+        lib().orc_hb_update_heard_cnt(self.h, _p(np.ascontiguousarray(peer, np.uint8)))
+
+    def dump(self):
+        R, G = self.R, self.G
+        d = dict(deadline=np.zeros((R, G), np.uint64), exploded=np.zeros((R, G), np.uint8), is_sending=np.zeros(G, np.uint8),
+                 next_tick=np.zeros(G, np.uint64), cnt0=np.zeros((R, G), np.uint64), cnt1=np.zeros((R, G), np.uint64),
+                 rep=np.zeros((R, G), np.uint8), alive=np.zeros(G, np.uint8))
+        lib().orc_hb_dump(self.h, *[_p(d[k]) for k in ("deadline", "exploded", "is_sending", "next_tick", "cnt0", "cnt1", "rep", "alive")])
+        return d

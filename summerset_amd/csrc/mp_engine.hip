@@ -747,7 +747,7 @@ template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
                                                    int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk) {
 #ifndef TALLY_C
-#define TALLY_C 4
+#define TALLY_C 8
 #endif
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -764,6 +764,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         cnts[d] = in ? P.rep[d].ob_cnt[par][gg] : 0u;
         prc[d] = in ? P.rep[d].pr_cnt[gg] : 0u;
         prd[d] = in ? P.rep[d].pr_dest[gg] : 0u;
+    }
+    uint32_t ctl[C];                                             // the reply order / loss words of my first C rows
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const uint32_t j = w + 4u * (uint32_t)k;
+        ctl[k] = (ackctl && j < P.cap) ? ackctl[(size_t)j * G + gg] : SMR_CTL_IDENTITY;
     }
     const bool active = g < G && !ovf;                          // ovf: frozen, or on the straggler list
     uint32_t prmask = 0;
@@ -782,18 +788,16 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     const MpRep &v0 = P.rep[0];
     SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
     SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
-    SMR_G const uint64_t *const ackw = (SMR_G const uint64_t *)rep_shift(v0.ack, ro);
     uint64_t ab[NR];                                             // my replica's followers, entries < 64 (cand: cnt <= 64)
 #pragma unroll
     for (int q = 0; q < NR; q++)
         ab[q] = (cand && (uint32_t)q < R) ? ack_bits_base(rep_shift(v0.ack, ro), P.cap, P.G)[tix(MAXR, q, gg)] : 0ull;
     SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
-    const uint32_t q4 = (cnt + 3) / 4;
-    const uint32_t jlo = w * q4, jhi = (jlo + q4 < cnt) ? jlo + q4 : cnt;
-    // ---- round 2: my replica's scalars, and the ack-matrix rows of pass 0 ------------------------
+    // Rows are dealt to the four wavefronts round robin -- wavefront w takes rows w, w + 4, w + 8, ... -- so WHICH rows a
+    // wavefront tallies depends on nothing it has to load first: their ackctl words went out with round 1 above.
+    // ---- round 2: my replica's scalars -------------------------------------------------------------
     uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0;
     uint64_t bpd = 0;
-    uint32_t ctl[C];
     uint64_t a[C], rbal = 0;
     if (cand) {
         reg = rep_shift(v0.ob_reg[par], ro)[gg]; bpd = rep_shift(v0.bal_prepared, ro)[gg];
@@ -802,35 +806,32 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         start = rep_shift(v0.start_slot, ro)[gg]; len = rep_shift(v0.log_len, ro)[gg];
         cbar = p_cbar[gg]; ebar = p_ebar[gg]; abar = rep_shift(v0.accept_bar, ro)[gg];
     }
-    auto load_acks = [&](uint32_t j0) {
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-            const uint32_t j = j0 + k;
-            const bool in = cand && j < jhi;
-            ctl[k] = (in && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
-            a[k] = in ? ack_word_from_bits<NR>(ab, j) : 0ull;
-            (void)ackw;
-        }
-    };
-    load_acks(jlo);
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
     // ---- round 3 + tally: C rows per pass (one pass unless the outbox is longer than 4 * C) -------
 #pragma unroll 1
-    for (uint32_t j0 = jlo; j0 < jhi; j0 += C) {
-        if (j0 != jlo) load_acks(j0);
+    for (uint32_t k0 = 0; w + 4u * k0 < cnt; k0 += C) {
+        if (k0 != 0) {
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                const uint32_t j = w + 4u * (k0 + k);
+                ctl[k] = (cand && j < cnt && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
+            }
+        }
         uint32_t m[C]; uint64_t b[C];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const uint32_t slot = reg - 1 + j0 + k;
-            const bool have = fast4 && j0 + k < jhi && slot >= start && slot < len;
+            const uint32_t j = w + 4u * (k0 + k);
+            const uint32_t slot = reg - 1 + j;
+            const bool have = fast4 && j < cnt && slot >= start && slot < len;
             const size_t i = tix(P.W, slot & Wm, g);
             m[k] = have ? sm[i] : 0xFFFFFFFFu;
             b[k] = have ? sb[i] : 0ull;
+            a[k] = (cand && j < cnt) ? ack_word_from_bits<NR>(ab, j) : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const uint32_t j = j0 + k;
-            if (!fast4 || j >= jhi) continue;
+            const uint32_t j = w + 4u * (k0 + k);
+            if (!fast4 || j >= cnt) continue;
             const bool have = m[k] != 0xFFFFFFFFu;
             uint32_t mk = have ? m[k] : 0u;
             bool changed = false, committed = false;
@@ -862,7 +863,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         // along from the row that sits AT it (execution.rs:70), if any -- a pinned exec_bar stays.
         closed = (all & 23) == 23 && first == cbar && first + cnt == abar && first + cnt >= len && P.clist_cap == 0;
         if (closed)
-            for (uint32_t j = jlo; j < jhi; j++)
+            for (uint32_t j = w; j < cnt; j += 4)
                 sm[tix(P.W, (first + j) & Wm, g)] = m_set_st(sh_mk[j * 64 + lane], SMR_ST_EXECUTED);
     }
     // which replicas of my group still need mp_round_replies: a non-empty outbox I did not close,
@@ -1032,7 +1033,10 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__rest
 // wavefront per replica with the group on lane 0, the four rounds back to back with a block barrier in
 // between -- what the bulk launches get from stream order.  Removes three launch boundaries from the
 // stragglers' critical path (a leader change's handlers are serial latency, not bandwidth).
-__global__ __launch_bounds__(512) void mp_straggler_tick(const MpParams *__restrict__ Pp, int par, int lpar,
+#ifndef STRAG_MINW
+#define STRAG_MINW 1
+#endif
+__global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpParams *__restrict__ Pp, int par, int lpar,
                                                           const uint8_t *__restrict__ timeout_rep,
                                                           const uint8_t *__restrict__ timeout_src,
                                                           const uint8_t *__restrict__ req_target,
