@@ -843,6 +843,33 @@ int smr_kv_execute(smr_kv *h, uint32_t n_rows, const uint8_t *kind_dev, const ui
 int smr_kv_table(smr_kv *h, uint32_t **kv_dev);
 int smr_kv_dump(smr_kv *h, uint32_t *kv_host);
 
+/* ---- batched Heartbeater (src/server/heartbeat.rs:26-296) --------------------------------
+ * One object = replica `replica_id` of n_groups groups: hear timers, send ticker, reply counters / peer_alive.  Clocks and
+ * randomness are explicit: calls take now_ms; a kickoff takes draw[R][G], the u32 each timer's random_range would have
+ * drawn (timeout = min + draw mod (max - min + 1)).  Per-group selectors: a peer id, SMR_HB_ALL (the reference's None =
+ * every peer) or SMR_NO_REPLICA (no call for that group).  smr_hb_create fails on the configurations new_and_setup
+ * rejects (:69-89). */
+#define SMR_HB_ALL 0xFE
+typedef struct smr_hb smr_hb;
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population, replica_id;
+    uint64_t hear_timeout_min_ms, hear_timeout_max_ms, send_interval_ms;
+} smr_hb_cfg;
+int smr_hb_create(const smr_hb_cfg *cfg, uint64_t now_ms, smr_hb **out);
+void smr_hb_destroy(smr_hb *h);
+int smr_hb_set_sending(smr_hb *h, const uint8_t *sending_dev, void *stream);                 /* :130-132; 0xFF = leave as is */
+int smr_hb_kickoff_hear_timer(smr_hb *h, const uint8_t *peer_dev, uint64_t now_ms, const uint32_t *draw_dev, void *stream);   /* :189-210 */
+/* get_event (:134-160) drained: timeouts[R][G] = 1 where HeartbeatEvent::HearTimeout { peer } is delivered now (a timer
+ * that exploded and was not re-armed since), send_ticked[G] = 1 where SendTicked is (ticker on, due; late ticks skipped) */
+int smr_hb_poll(smr_hb *h, uint64_t now_ms, uint8_t *timeouts_dev, uint8_t *send_ticked_dev, void *stream);
+int smr_hb_clear_reply_cnts(smr_hb *h, const uint8_t *peer_dev, void *stream);               /* :223-241 */
+int smr_hb_update_bcast_cnts(smr_hb *h, const uint8_t *flags_dev, uint8_t *peer_death_dev, void *stream);   /* :247-281 */
+int smr_hb_update_heard_cnt(smr_hb *h, const uint8_t *peer_dev, void *stream);               /* :285-300 */
+/* host arrays: deadline / exploded / cnt0 / cnt1 / rep as [R][G], is_sending / next_tick / alive as [G] */
+int smr_hb_dump(smr_hb *h, uint64_t *deadline, uint8_t *exploded, uint8_t *is_sending, uint64_t *next_tick, uint64_t *cnt0,
+                uint64_t *cnt1, uint8_t *rep, uint8_t *alive);
+
 #ifdef __cplusplus
 }
 #endif

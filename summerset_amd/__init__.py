@@ -15,4 +15,5 @@ from .raft import CRaftLeaderGroup, RaftLeaderGroup  # noqa: F401
 from .epaxos import EPaxosReplicaGroup  # noqa: F401
 from .rspaxos import RSPaxosReplicaGroup  # noqa: F401
 from .repnothing import RepNothingReplica  # noqa: F401
+from .heartbeater import Heartbeater  # noqa: F401
 from . import shard, stream  # noqa: F401

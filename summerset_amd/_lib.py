@@ -31,6 +31,11 @@ class MpCfg(C.Structure):
                 ("win_reserve", C.c_uint32), ("outbox_cap", C.c_uint32), ("commit_list_cap", C.c_uint32)]
 
 
+class HbCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("replica_id", C.c_uint8), ("hear_timeout_min_ms", C.c_uint64),
+                ("hear_timeout_max_ms", C.c_uint64), ("send_interval_ms", C.c_uint64)]
+
+
 class MpTickIn(C.Structure):
     _fields_ = [("timeout_rep_dev", C.c_void_p), ("timeout_src_dev", C.c_void_p), ("req_target_dev", C.c_void_p),
                 ("req_cnt_dev", C.c_void_p), ("req_val_dev", C.c_void_p), ("S", C.c_uint32), ("ackctl_dev", C.c_void_p),
@@ -296,6 +301,15 @@ SYMBOLS = [
     ("smr_qread_issue", _i, [_vp, _u32, _vp, C.POINTER(QreadReplies), _vp]),
     ("smr_qread_handle_replies", _i, [_vp, _u32, C.POINTER(QreadReplies), _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_qread_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_hb_create", _i, [C.POINTER(HbCfg), _u64, C.POINTER(_vp)]),
+    ("smr_hb_destroy", None, [_vp]),
+    ("smr_hb_set_sending", _i, [_vp, _vp, _vp]),
+    ("smr_hb_kickoff_hear_timer", _i, [_vp, _vp, _u64, _vp, _vp]),
+    ("smr_hb_poll", _i, [_vp, _u64, _vp, _vp, _vp]),
+    ("smr_hb_clear_reply_cnts", _i, [_vp, _vp, _vp]),
+    ("smr_hb_update_bcast_cnts", _i, [_vp, _vp, _vp, _vp]),
+    ("smr_hb_update_heard_cnt", _i, [_vp, _vp, _vp]),
+    ("smr_hb_dump", _i, [_vp] + [_vp] * 8),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

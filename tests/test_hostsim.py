@@ -196,3 +196,18 @@ def test_spread_layout_images_on_the_host(sim):
         t.run_spread_vs_colocated("cpu", G=256, R=5, S=2, W=64, world=2, n_ticks=24, drop_p=0.1, timeout_frac=1.0)
         t.run_spread_vs_colocated("cpu", G=192, R=5, S=2, W=64, world=3, n_ticks=18, drop_p=0.1, timeout_frac=1.0)
         t.run_spread_vs_colocated("cpu", G=128, R=3, S=2, W=32, world=2, n_ticks=16, drop_p=0.2, timeout_frac=0.5, hb_every=2)
+
+
+def test_heartbeater_kernels_on_the_host(sim, oracle):
+    """the batched Heartbeater (f.4): hear timers, send ticker, reply counters -- the traces and a random call stream"""
+    import test_zz_hb_gpu as t
+    with sim.patched():
+        t.test_traces_on_the_engine("cpu", oracle)
+        t.test_random_calls_match_oracle("cpu", oracle, 300, 5, 0)
+        t.test_random_calls_match_oracle("cpu", oracle, 130, 3, 2)
+
+
+def test_heartbeater_drives_the_multipaxos_engine_on_the_host(sim, oracle):
+    import test_zz_hb_gpu as t
+    with sim.patched():
+        t.test_timeouts_feed_the_multipaxos_engine("cpu", oracle)
