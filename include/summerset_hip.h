@@ -843,6 +843,24 @@ int smr_kv_execute(smr_kv *h, uint32_t n_rows, const uint8_t *kind_dev, const ui
 int smr_kv_table(smr_kv *h, uint32_t **kv_dev);
 int smr_kv_dump(smr_kv *h, uint32_t *kv_host);
 
+/* ---- device-resident KV state machine over real keys and values -----------------------
+ * `State = HashMap<String, String>` of src/server/statemach.rs:21-63,193-202 per group: an open-addressing table of
+ * `slots` entries (power of two) + an append-only heap of heap_bytes per group on the device.  Commands name their key /
+ * value bytes by (off, len) into payload_dev (e.g. the decoded ReqBatch bytes); rows are applied in order.  Results:
+ * res_state 0 = None, 1 = Some -- the value (Get) / old value (Put) is bytes [res_off, res_off + res_len) of the GROUP's
+ * heap strip (smr_skv_heap: strip g starts at g * heap_bytes_per_group; old bytes are never moved or reused) --, 2 = the
+ * group's table or heap is full (sticky; smr_skv_stats) or the command's bytes lie outside the payload buffer. */
+typedef struct smr_skv smr_skv;
+int smr_skv_create(uint32_t n_groups, uint32_t slots, uint64_t heap_bytes, smr_skv **out);
+void smr_skv_destroy(smr_skv *h);
+int smr_skv_execute(smr_skv *h, uint32_t n_rows, const uint8_t *kind_dev, const uint8_t *payload_dev, uint64_t payload_bytes,
+                    const uint32_t *key_off_dev, const uint32_t *key_len_dev, const uint32_t *val_off_dev, const uint32_t *val_len_dev,
+                    uint8_t *res_state_dev, uint32_t *res_off_dev, uint32_t *res_len_dev, void *stream);
+int smr_skv_heap(smr_skv *h, uint8_t **heap_dev, uint64_t *heap_bytes_per_group);
+/* host copy of bytes [off, off + len) of group's heap strip (a device consumer reads them in place) */
+int smr_skv_read(smr_skv *h, uint32_t group, uint32_t off, uint32_t len, uint8_t *host_buf);
+int smr_skv_stats(smr_skv *h, uint32_t *n_keys_host, uint32_t *heap_used_host, uint8_t *full_host);
+
 /* ---- batched Heartbeater (src/server/heartbeat.rs:26-296) --------------------------------
  * One object = replica `replica_id` of n_groups groups: hear timers, send ticker, reply counters / peer_alive.  Clocks and
  * randomness are explicit: calls take now_ms; a kickoff takes draw[R][G], the u32 each timer's random_range would have

@@ -10,7 +10,7 @@ include/summerset_hip.h; PyTorch only provides device buffers and streams.
 from ._lib import SummersetError, SMR_CTL_IDENTITY, SMR_NO_REPLICA  # noqa: F401
 from .rscoding import RSCodewordBatch, rs_matrix, rs_shard_len  # noqa: F401
 from .multipaxos import MultiPaxosCluster  # noqa: F401
-from .quorumread import KvStateMachine, QuorumReadGroup  # noqa: F401
+from .quorumread import KvStateMachine, QuorumReadGroup, StringKvStateMachine  # noqa: F401
 from .raft import CRaftLeaderGroup, RaftLeaderGroup  # noqa: F401
 from .epaxos import EPaxosReplicaGroup  # noqa: F401
 from .rspaxos import RSPaxosReplicaGroup  # noqa: F401

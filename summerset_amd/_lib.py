@@ -301,6 +301,12 @@ SYMBOLS = [
     ("smr_qread_issue", _i, [_vp, _u32, _vp, C.POINTER(QreadReplies), _vp]),
     ("smr_qread_handle_replies", _i, [_vp, _u32, C.POINTER(QreadReplies), _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_qread_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_skv_create", _i, [_u32, _u32, _u64, C.POINTER(_vp)]),
+    ("smr_skv_destroy", None, [_vp]),
+    ("smr_skv_execute", _i, [_vp, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_skv_heap", _i, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
+    ("smr_skv_read", _i, [_vp, _u32, _u32, _u32, _vp]),
+    ("smr_skv_stats", _i, [_vp, _vp, _vp, _vp]),
     ("smr_hb_create", _i, [C.POINTER(HbCfg), _u64, C.POINTER(_vp)]),
     ("smr_hb_destroy", None, [_vp]),
     ("smr_hb_set_sending", _i, [_vp, _vp, _vp]),

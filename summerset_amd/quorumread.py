@@ -130,3 +130,51 @@ class KvStateMachine:
         out = np.zeros((self.K, self.G), np.uint32)
         check(self._L.smr_kv_dump(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+class StringKvStateMachine:
+    """`StateMachineExecutorTask::execute` on `HashMap<String, String>` (src/server/statemach.rs:21-63,193-202) for G groups, keys
+    and values as bytes, state resident on the device (`smr_skv_*`): a hash table + an append-only heap per group"""
+
+    def __init__(self, n_groups, slots=256, heap_bytes=1 << 16):
+        self.G, self.slots, self.heap_bytes = int(n_groups), int(slots), int(heap_bytes)
+        h = C.c_void_p()
+        self._L = _lib.load()
+        check(self._L.smr_skv_create(self.G, self.slots, self.heap_bytes, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_skv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def execute(self, kind, payload, key_off, key_len, val_off, val_len, stream=None):
+        """kind uint8 [rows, G] (GET / PUT / else none); payload uint8 [n]; offsets / lengths int32 [rows, G].
+        -> (state uint8, off int32, len int32) [rows, G]: None / Some(bytes of the group's heap strip) / refused"""
+        import torch
+        dev = kind.device
+        st = torch.zeros(kind.shape, dtype=torch.uint8, device=dev)
+        off = torch.zeros(kind.shape, dtype=torch.int32, device=dev)
+        ln = torch.zeros(kind.shape, dtype=torch.int32, device=dev)
+        check(self._L.smr_skv_execute(self._h, int(kind.shape[0]), _ptr(kind), _ptr(payload), int(payload.numel()), _ptr(key_off), _ptr(key_len),
+                                      _ptr(val_off), _ptr(val_len), _ptr(st), _ptr(off), _ptr(ln), stream_ptr(stream)))
+        return st, off, ln
+
+    def heap_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(self._L.smr_skv_heap(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def heap_bytes_of(self, group, off, length):
+        """host copy of bytes [off, off + length) of `group`'s heap strip (tests; a device consumer reads them in place)"""
+        buf = (C.c_uint8 * max(int(length), 1))()
+        check(self._L.smr_skv_read(self._h, int(group), int(off), int(length), buf))
+        return bytes(buf[:int(length)])
+
+    def stats(self):
+        nk, hu, fl = np.zeros(self.G, np.uint32), np.zeros(self.G, np.uint32), np.zeros(self.G, np.uint8)
+        check(self._L.smr_skv_stats(self._h, nk.ctypes.data_as(C.c_void_p), hu.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p)))
+        return dict(n_keys=nk, heap_used=hu, full=fl)

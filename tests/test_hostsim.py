@@ -211,3 +211,12 @@ def test_heartbeater_drives_the_multipaxos_engine_on_the_host(sim, oracle):
     import test_zz_hb_gpu as t
     with sim.patched():
         t.test_timeouts_feed_the_multipaxos_engine("cpu", oracle)
+
+
+def test_string_kv_state_machine_kernel_on_the_host(sim):
+    """the device KV over real keys and values (f.3): reference state-machine tests, dict + host executor, full / refused"""
+    import test_zz_skv_gpu as t
+    with sim.patched():
+        t.test_reference_state_machine_tests("cpu")
+        t.test_put_rand_get_rand_per_group_and_the_host_state_machine("cpu")
+        t.test_full_table_and_heap_are_sticky_not_silent("cpu")
