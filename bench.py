@@ -263,6 +263,38 @@ def repnothing_leg(n_ops=200000):
             "note": "Python ctypes call per batch included; WAL accounted (%d bytes), not written" % s["wal_offset"]}
 
 
+def epaxos_cluster_leg(torch, dev, ticks=10):
+    """BASELINE config 5 as written: EPaxos, 65 536 groups x 5 replicas, optimized quorums, EVERY replica proposes one
+    instance per group per tick on Zipf(0.99) keys of 64 -- five replica objects in the closed loop of
+    summerset_amd/ep_cluster.py (PreAccept fan-out, replies, fast / slow decision, Accept rounds, CommitNotices), every
+    message a device tensor between the handlers, dependency-graph execution on."""
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster
+    G, R, W, K = 65536, 5, 32, 64
+    reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    rng = np.random.default_rng(0x5EED5EED)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    keys = [[torch.from_numpy(rng.choice(K, G, p=zipf).astype(np.uint8)).to(dev) for _ in range(R)] for _ in range(ticks + 2)]
+    for t in range(2):
+        ep_cluster.tick(reps, keys[t])
+    torch.cuda.synchronize()
+    committed = torch.zeros((), dtype=torch.int64, device=dev)
+    slow = torch.zeros((), dtype=torch.int64, device=dev)
+    t0 = time.perf_counter()
+    for t in range(2, ticks + 2):
+        for o in ep_cluster.tick(reps, keys[t]):
+            committed += o["committed"].sum()
+            slow += (o["decision"] == 2).sum()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ex = sum(int(r.exec_dump()["counters"][0]) for r in reps)
+    return {"workload": "EPaxos closed loop, %d groups x 5 replicas, every replica proposes 1 instance per group per tick (Zipf(0.99) keys "
+                        "of 64), execution on; five replica objects on one GPU, messages stay on the device" % G,
+            "value": int(committed.item()) / dt, "unit": "instances committed/s (handler calls of the Python driver included)",
+            "ms_per_tick": dt / ticks * 1e3, "slow_path_fraction": int(slow.item()) / max(int(committed.item()), 1),
+            "handler_calls_per_tick": R + 2 * R * (R - 1) + 2 * R, "commands_executed": ex}
+
+
 def rspaxos_leg(torch, dev, ticks=40, warmup=8):
     """BASELINE config 4: RSPaxos, 16 384 groups x 5 replicas, one Put of a 4 KiB value per batch: per tick the leader
     RS(3,2)-encodes the tick's 16 384 request batches (rspaxos/request.rs:71-77) and the batch runs through the
@@ -313,9 +345,14 @@ def leg_isolated(name, timeout=180):
     return json.loads(out.stdout.decode().strip().splitlines()[-1])
 
 
-def _time_us(torch, fn, iters):
+def _time_us(torch, fn, iters, sleep_cycles=6_000_000):
+    """average device time per call of fn between two HIP events.  A ~3 ms device-side sleep goes first so that the host
+    has every launch queued before the first one starts: a Python + ctypes call costs 10-20 us of host time, more than
+    some of these kernels run, and an empty queue would make the event pair measure the host instead."""
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if sleep_cycles:
+        torch.cuda._sleep(int(sleep_cycles))
     e0.record()
     for i in range(iters):
         fn(i)
@@ -348,19 +385,21 @@ def raft_leg(torch, dev, S=32, ticks=24):
                                            (x.view(np.int32) if x.dtype == np.uint32 else x)).to(dev)
                           for x in (term, end_slot, flags, np.full((R, G), 2, np.uint64),
                                     np.maximum(end_slot.astype(np.int64) - 1, 1).astype(np.uint32))))
-    times = []
+    pairs = []
 
     def tick(i):
         eng.handle_req_batch(n_new)
         rt, es, fl, ct, cs = pool[i]
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
         eng.handle_msg_append_entries_reply(rt, es, fl, ct, cs)
+        eb.record()
+        pairs.append((ea, eb))
 
-    t0 = time.perf_counter()
-    us = _time_us(torch, tick, ticks)
+    us = _time_us(torch, tick, ticks)            # (queue prefilled: device time, not host call time)
     commits = eng.total_commits()
-    # the replies kernel alone, re-running the last tick's replies (idempotent once applied)
-    rt, es, fl, ct, cs = pool[-1]
-    us_k = _time_us(torch, lambda i: eng.handle_msg_append_entries_reply(rt, es, fl, ct, cs), 20)
+    # the replies kernel alone: its own event pair in every tick of the run above (real replies, not a re-run)
+    us_k = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs) * 1e3
     alg = G * (280 + 8 * S)
     return {"workload": "Raft leader, %d groups x 5 replicas, S=%d appends + 4 AppendEntriesReply per group per tick "
                         "(lag 0-3, 5%% dropped, 0.5%% stale term, 0.5%% conflict)" % (G, S),
@@ -398,8 +437,11 @@ def epaxos_leg(torch, dev, ticks=16):
     msg = EpMsg(m["flags"].data_ptr(), None, m["col"].data_ptr(), m["ballot"].data_ptr(), m["seq"].data_ptr(),
                 m["deps"].data_ptr(), None)
     st_ = torch.cuda.current_stream().cuda_stream
-    t_prop = t_rep = 0.0
-    committed = 0
+    extra_d = [torch.from_numpy(x).to(dev) for x in extra]
+    commits_d = torch.zeros((), dtype=torch.int64, device=dev)
+    ev = []
+    torch.cuda.synchronize()
+    torch.cuda._sleep(6_000_000)                  # the host queues the ticks while the device waits: event pairs = device time
     for t in range(ticks):
         e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         e0.record()
@@ -407,7 +449,7 @@ def epaxos_leg(torch, dev, ticks=16):
         e1.record()
         # the peers' answers: my (seq, deps), 10 % with seq + 1 and one more dependency (stand-in for the
         # four acceptors, built on the device from the PreAccept just produced; not timed)
-        ex = torch.from_numpy(extra[t]).to(dev)
+        ex = extra_d[t]
         seq = (m["seq"].unsqueeze(0).repeat(R, 1) + ex.to(torch.int64)).contiguous()
         deps = m["deps"].unsqueeze(0).repeat(R, 1, 1)
         deps[:, 1, :] = torch.where(ex, torch.clamp(deps[:, 1, :], min=0) + 1, deps[:, 1, :])
@@ -418,10 +460,12 @@ def epaxos_leg(torch, dev, ticks=16):
                                                       r["decision"].data_ptr(), r["seq"].data_ptr(),
                                                       r["deps"].data_ptr(), st_))
         e3.record()
-        torch.cuda.synchronize()
-        t_prop += e0.elapsed_time(e1)
-        t_rep += e2.elapsed_time(e3)
-        committed += int((r["decision"] == 3).sum())
+        commits_d += (r["decision"] == 3).sum()
+        ev.append((e0, e1, e2, e3, seq, deps))
+    torch.cuda.synchronize()
+    t_prop = sum(e[0].elapsed_time(e[1]) for e in ev)
+    t_rep = sum(e[2].elapsed_time(e[3]) for e in ev)
+    committed = int(commits_d.item())
     us_rep = t_rep / ticks * 1e3
     alg = G * 370                                                             # <= 370 B per instance
     return {"workload": "EPaxos command leader, %d groups x 5 replicas, 1 proposal per group per tick on Zipf(0.99) keys "
@@ -731,7 +775,7 @@ def main():
     import torch.distributed as dist
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
-        legs = {"rspaxos": rspaxos_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
+        legs = {"rspaxos": rspaxos_leg, "epaxos_cluster": epaxos_cluster_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
                 "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg}
         print(json.dumps(legs[args.leg](torch, torch.device("cuda", local))))
         return
@@ -903,6 +947,7 @@ def main():
         if not args.no_extra:
             leg("raft_quorum", raft_leg, torch, dev)
             leg("epaxos_fast_quorum", epaxos_leg, torch, dev)
+            leg("epaxos_cluster", leg_isolated, "epaxos_cluster")
             leg("rspaxos", leg_isolated, "rspaxos")
             leg("repnothing", repnothing_leg)
             if args.late_legs:

@@ -210,6 +210,23 @@ int smr_mp_image_pack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, u
                       uint32_t rows, uint32_t ovf_cap, void *stream);
 int smr_mp_image_unpack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, const uint8_t *img_dev, uint64_t img_bytes,
                         uint32_t rows, uint32_t ovf_cap, void *stream);
+/* A whole exchange at once.  Which replica's piece goes into which slice of the send / receive buffer never changes, so
+ * the operations are handed over once (smr_mp_image_plan_create) and an exchange is then three launches to pack -- clear the
+ * headers, pack every image, duplicate the pieces that go to several ranks (copy_of_dev != NULL: this image is a copy of
+ * the one packed at that address) -- and one to unpack, whatever the number of images.  All clusters of a plan must be in
+ * the same tick. */
+typedef struct {
+    smr_mp_cluster *cluster;
+    int kind;
+    uint8_t rep, other;
+    uint8_t *img_dev;
+    uint64_t img_bytes;
+    const uint8_t *copy_of_dev;
+} smr_mp_image_op;
+typedef struct smr_mp_image_plan smr_mp_image_plan;
+int smr_mp_image_plan_create(const smr_mp_image_op *ops, uint32_t n, uint32_t rows, uint32_t ovf_cap, smr_mp_image_plan **out);
+void smr_mp_image_plan_destroy(smr_mp_image_plan *p);
+int smr_mp_image_plan_run(smr_mp_image_plan *p, int unpack, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
 

@@ -42,6 +42,11 @@ class MpTickIn(C.Structure):
                 ("do_heartbeat", C.c_int)]
 
 
+class MpImageOp(C.Structure):
+    _fields_ = [("cluster", C.c_void_p), ("kind", C.c_int), ("rep", C.c_uint8), ("other", C.c_uint8), ("img_dev", C.c_void_p),
+                ("img_bytes", C.c_uint64), ("copy_of_dev", C.c_void_p)]
+
+
 class MpGroupState(C.Structure):
     _fields_ = [("leader", C.c_uint8), ("overflow", C.c_uint8), ("bal_prep_sent", C.c_uint64),
                 ("bal_prepared", C.c_uint64), ("bal_max_seen", C.c_uint64), ("start_slot", C.c_uint32),
@@ -187,6 +192,9 @@ SYMBOLS = [
     ("smr_mp_image_bytes", C.c_int64, [_vp, _i, _u32, _u32]),
     ("smr_mp_image_pack", _i, [_vp, _i, _u8, _u8, _vp, _u64, _u32, _u32, _vp]),
     ("smr_mp_image_unpack", _i, [_vp, _i, _u8, _u8, _vp, _u64, _u32, _u32, _vp]),
+    ("smr_mp_image_plan_create", _i, [C.POINTER(MpImageOp), _u32, _u32, _u32, C.POINTER(_vp)]),
+    ("smr_mp_image_plan_destroy", None, [_vp]),
+    ("smr_mp_image_plan_run", _i, [_vp, _i, _vp]),
     ("smr_mp_round_local", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("smr_mp_round_deliver", _i, [_vp, _vp]),
     ("smr_mp_round_replies", _i, [_vp, _vp, _i, _vp]),

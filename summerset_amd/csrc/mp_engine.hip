@@ -1163,10 +1163,9 @@ __host__ __device__ inline ImgLayout img_layout(uint32_t kind, uint32_t G, uint3
 
 // OUTBOX of replica `rep` (parity par): cnt, reg, rbal per group; the tokens of a regular outbox's first `rows`
 // entries; everything else as overflow entries (a = ob_slot, b = ob_val, c = ob_aux, d = ob_bal; regular: b only)
-__global__ __launch_bounds__(256) void mp_img_pack_outbox(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t rows,
-                                                          uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
-    const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void img_pack_outbox(const MpParams &P, int par, uint32_t rep, uint32_t rows, uint8_t *img, const ImgLayout &L,
+                                                uint32_t ocap, const uint32_t g, const uint32_t stride) {
+    (void)stride;
     if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
     if (g >= P.G) return;
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
@@ -1184,13 +1183,11 @@ __global__ __launch_bounds__(256) void mp_img_pack_outbox(const MpParams *__rest
         else img_push(h, ov, ocap, ImgOvf{g, j, v.ob_slot(par)[o], v.ob_val(par)[o], v.ob_aux(par)[o], 0u, v.ob_bal(par)[o]});
     }
 }
-__global__ __launch_bounds__(256) void mp_img_unpack_outbox(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t rows,
-                                                            const uint8_t *__restrict__ img, ImgLayout L) {
-    const MpParams &P = *Pp;
+__device__ __forceinline__ void img_unpack_outbox(const MpParams &P, int par, uint32_t rep, uint32_t rows, const uint8_t *img,
+                                                  const ImgLayout &L, const uint32_t g, const uint32_t stride) {
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
     const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
     const uint32_t *cnts = (const uint32_t *)(img + L.a), *regs = (const uint32_t *)(img + L.b);
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g < P.G) {
         const uint32_t cnt = cnts[g], reg = regs[g];
         v.ob_cnt(par)[g] = cnt; v.ob_reg(par)[g] = reg;
@@ -1199,7 +1196,7 @@ __global__ __launch_bounds__(256) void mp_img_unpack_outbox(const MpParams *__re
         if (reg) for (uint32_t j = 0; j < cnt && j < rows; j++) v.ob_val(par)[tix(P.cap, j, g)] = tok[(size_t)j * P.G + g];
     }
     const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (uint32_t i = g; i < n; i += stride) {
         const ImgOvf e = ov[i];
         if (e.g >= P.G || e.j >= P.cap) continue;
         const size_t o = tix(P.cap, e.j, e.g);
@@ -1209,10 +1206,9 @@ __global__ __launch_bounds__(256) void mp_img_unpack_outbox(const MpParams *__re
 }
 // ACKS follower `fol` gave sender `rep` this tick: the word for entries < 64; the byte cells of entries >= 64 (both
 // values: the sender's cells are overwritten) as overflow entries (a = value)
-__global__ __launch_bounds__(256) void mp_img_pack_acks(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t fol,
-                                                        uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
-    const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void img_pack_acks(const MpParams &P, int par, uint32_t rep, uint32_t fol, uint8_t *img, const ImgLayout &L,
+                                              uint32_t ocap, const uint32_t g, const uint32_t stride) {
+    (void)stride;
     if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
     if (g >= P.G) return;
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
@@ -1222,23 +1218,21 @@ __global__ __launch_bounds__(256) void mp_img_pack_acks(const MpParams *__restri
     ((uint64_t *)(img + L.a))[g] = cnt ? ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, fol, g)] : 0ull;
     for (uint32_t j = 64; j < cnt; j++) img_push(h, ov, ocap, ImgOvf{g, j, (uint32_t)v.ack()[ack_ix(P.cap, j, fol, g)], 0u, 0u, 0u, 0ull});
 }
-__global__ __launch_bounds__(256) void mp_img_unpack_acks(const MpParams *__restrict__ Pp, int par, uint32_t rep, uint32_t fol,
-                                                          const uint8_t *__restrict__ img, ImgLayout L) {
-    const MpParams &P = *Pp;
+__device__ __forceinline__ void img_unpack_acks(const MpParams &P, int par, uint32_t rep, uint32_t fol, const uint8_t *img,
+                                                const ImgLayout &L, const uint32_t g, const uint32_t stride) {
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
     const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g < P.G && v.ob_cnt(par)[g]) ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, fol, g)] = ((const uint64_t *)(img + L.a))[g];
     const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (uint32_t i = g; i < n; i += stride) {
         const ImgOvf e = ov[i];
         if (e.g < P.G && e.j < P.cap) v.ack()[ack_ix(P.cap, e.j, fol, e.g)] = (uint8_t)e.a;
     }
 }
 // PREPARE_REPLIES of replica `rep`: header per group; the (voted_bal, voted_reqs) rows as overflow entries (a = vval, d = vbal)
-__global__ __launch_bounds__(256) void mp_img_pack_pr(const MpParams *__restrict__ Pp, uint32_t rep, uint8_t *__restrict__ img, ImgLayout L, uint32_t ocap) {
-    const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void img_pack_pr(const MpParams &P, uint32_t rep, uint8_t *img, const ImgLayout &L, uint32_t ocap, const uint32_t g,
+                                            const uint32_t stride) {
+    (void)stride;
     if (g == 0) ((ImgHdr *)img)->ovf_cap = ocap;
     if (g >= P.G) return;
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
@@ -1253,11 +1247,10 @@ __global__ __launch_bounds__(256) void mp_img_pack_pr(const MpParams *__restrict
         img_push(h, ov, ocap, ImgOvf{g, k, v.pr_vval()[o], 0u, 0u, 0u, v.pr_vbal()[o]});
     }
 }
-__global__ __launch_bounds__(256) void mp_img_unpack_pr(const MpParams *__restrict__ Pp, uint32_t rep, const uint8_t *__restrict__ img, ImgLayout L) {
-    const MpParams &P = *Pp;
+__device__ __forceinline__ void img_unpack_pr(const MpParams &P, uint32_t rep, const uint8_t *img, const ImgLayout &L, const uint32_t g,
+                                              const uint32_t stride) {
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
     const ImgHdr *h = (const ImgHdr *)img; const ImgOvf *ov = (const ImgOvf *)(img + L.ovf);
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g < P.G) {
         const uint32_t n = ((const uint32_t *)(img + L.a))[g];
         v.pr_cnt()[g] = n;
@@ -1267,7 +1260,7 @@ __global__ __launch_bounds__(256) void mp_img_unpack_pr(const MpParams *__restri
         }
     }
     const uint32_t n = h->ovf_n < h->ovf_cap ? h->ovf_n : h->ovf_cap;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    for (uint32_t i = g; i < n; i += stride) {
         const ImgOvf e = ov[i];
         if (e.g >= P.G || e.j >= P.pcap) continue;
         const size_t o = tix(P.pcap, e.j, e.g);
@@ -1275,14 +1268,60 @@ __global__ __launch_bounds__(256) void mp_img_unpack_pr(const MpParams *__restri
     }
 }
 // HEARTBEAT record of replica `rep` (leadership.rs:240-247): (bal_max_seen, commit_bar, exec_bar, snap_bar)
-__global__ __launch_bounds__(256) void mp_img_heartbeat(const MpParams *__restrict__ Pp, uint32_t rep, uint8_t *__restrict__ img, ImgLayout L, int unpack) {
-    const MpParams &P = *Pp;
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void img_heartbeat(const MpParams &P, uint32_t rep, uint8_t *img, const ImgLayout &L, int unpack, const uint32_t g) {
     if (g >= P.G) return;
     const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
     uint64_t *b = (uint64_t *)(img + L.a); uint32_t *c = (uint32_t *)(img + L.b), *x = (uint32_t *)(img + L.c), *sn = (uint32_t *)(img + L.d);
     if (unpack) { v.hb_bal()[g] = b[g]; v.hb_commit()[g] = c[g]; v.hb_exec()[g] = x[g]; v.hb_snap()[g] = sn[g]; }
     else { b[g] = v.hb_bal()[g]; c[g] = v.hb_commit()[g]; x[g] = v.hb_exec()[g]; sn[g] = v.hb_snap()[g]; }
+}
+
+// one image operation, as the plan kernels see it (smr_mp_image_plan_*): the cluster's device parameters, what to move
+struct ImgOp {
+    const MpParams *dp; uint8_t *img; const uint8_t *src;       // src: SMR_IMG_COPY only (the image this one duplicates)
+    uint32_t kind, rep, other, G;
+    uint64_t bytes;
+    ImgLayout L;
+};
+constexpr uint32_t SMR_IMG_COPY = 4;
+
+__device__ __forceinline__ void img_run(const ImgOp &op, int par, uint32_t rows, uint32_t ocap, bool unpack, uint32_t g, uint32_t stride) {
+    const MpParams &P = *op.dp;
+    if (!unpack) {
+        if (g >= P.G) return;
+        if (op.kind == SMR_IMG_OUTBOX) img_pack_outbox(P, par, op.rep, rows, op.img, op.L, ocap, g, stride);
+        else if (op.kind == SMR_IMG_ACKS) img_pack_acks(P, par, op.rep, op.other, op.img, op.L, ocap, g, stride);
+        else if (op.kind == SMR_IMG_PREPARE_REPLIES) img_pack_pr(P, op.rep, op.img, op.L, ocap, g, stride);
+        else if (op.kind == SMR_IMG_HEARTBEAT) img_heartbeat(P, op.rep, op.img, op.L, 0, g);
+    } else {
+        if (op.kind == SMR_IMG_OUTBOX) img_unpack_outbox(P, par, op.rep, rows, op.img, op.L, g, stride);
+        else if (op.kind == SMR_IMG_ACKS) img_unpack_acks(P, par, op.rep, op.other, op.img, op.L, g, stride);
+        else if (op.kind == SMR_IMG_PREPARE_REPLIES) img_unpack_pr(P, op.rep, op.img, op.L, g, stride);
+        else if (op.kind == SMR_IMG_HEARTBEAT && g < P.G) img_heartbeat(P, op.rep, op.img, op.L, 1, g);
+    }
+}
+// one image per launch (smr_mp_image_pack / _unpack)
+__global__ __launch_bounds__(256) void mp_img_one(const ImgOp op, int par, uint32_t rows, uint32_t ocap, int unpack) {
+    img_run(op, par, rows, ocap, unpack != 0, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+// a whole exchange's images in one launch: blockIdx.y = the operation
+__global__ __launch_bounds__(256) void mp_img_many(const ImgOp *__restrict__ ops, int par, uint32_t rows, uint32_t ocap, int unpack) {
+    const ImgOp op = ops[blockIdx.y];
+    if (blockIdx.x * 256 >= ((op.G + 255) / 256) * 256) return;
+    img_run(op, par, rows, ocap, unpack != 0, blockIdx.x * 256 + threadIdx.x, ((op.G + 255) / 256) * 256);
+}
+// pack side, in front of mp_img_many: the images' headers cleared (their overflow counters are bumped with atomics)
+__global__ __launch_bounds__(256) void mp_img_zero_headers(const ImgOp *__restrict__ ops, uint32_t n, uint32_t ocap) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) *(ImgHdr *)ops[i].img = ImgHdr{0u, ocap, 0u, 0u};
+}
+// pack side, behind mp_img_many: the same piece for another rank is a copy of the packed one (16 bytes per lane and step)
+__global__ __launch_bounds__(256) void mp_img_copy_many(const ImgOp *__restrict__ ops) {
+    const ImgOp op = ops[blockIdx.y];
+    struct alignas(16) B16 { uint64_t a, b; };
+    const uint64_t n16 = op.bytes / 16;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256)
+        ((B16 *)op.img)[i] = ((const B16 *)op.src)[i];
 }
 
 // ------------------------------------------------------------------ host ---
@@ -1799,17 +1838,21 @@ static int img_check(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, co
     return SMR_OK;
 }
 
+static ImgOp img_op(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, uint8_t *img, const ImgLayout &L) {
+    ImgOp op{};
+    op.dp = c->dp; op.img = img; op.src = nullptr; op.kind = (uint32_t)kind; op.rep = rep; op.other = other; op.G = c->cfg.n_groups;
+    op.bytes = L.total; op.L = L;
+    return op;
+}
+
 int smr_mp_image_pack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, uint8_t *img_dev, uint64_t img_bytes, uint32_t rows,
                       uint32_t ovf_cap, void *stream) {
     ImgLayout L;
     if (int rc = img_check(c, kind, rep, other, img_dev, img_bytes, rows, ovf_cap, L)) return rc;
     hipStream_t st = (hipStream_t)stream;
     SMR_HIP_TRY(hipMemsetAsync(img_dev, 0, sizeof(ImgHdr), st));
-    const dim3 grid((c->cfg.n_groups + 255) / 256), block(256);
-    if (kind == SMR_IMG_OUTBOX) hipLaunchKernelGGL(mp_img_pack_outbox, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, rows, img_dev, L, ovf_cap);
-    else if (kind == SMR_IMG_ACKS) hipLaunchKernelGGL(mp_img_pack_acks, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, (uint32_t)other, img_dev, L, ovf_cap);
-    else if (kind == SMR_IMG_PREPARE_REPLIES) hipLaunchKernelGGL(mp_img_pack_pr, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L, ovf_cap);
-    else hipLaunchKernelGGL(mp_img_heartbeat, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L, 0);
+    hipLaunchKernelGGL(mp_img_one, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, st, img_op(c, kind, rep, other, img_dev, L), c->par, rows,
+                       ovf_cap, 0);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -1818,12 +1861,81 @@ int smr_mp_image_unpack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other,
                         uint32_t rows, uint32_t ovf_cap, void *stream) {
     ImgLayout L;
     if (int rc = img_check(c, kind, rep, other, img_dev, img_bytes, rows, ovf_cap, L)) return rc;
+    hipLaunchKernelGGL(mp_img_one, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       img_op(c, kind, rep, other, (uint8_t *)img_dev, L), c->par, rows, ovf_cap, 1);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+// ---- a whole exchange as a plan: the operations are static (which replica's piece goes into which buffer slice), so
+// their descriptors are uploaded once and an exchange is three launches to pack (clear headers, pack, duplicate) and one
+// to unpack, whatever the number of images
+struct smr_mp_image_plan {
+    std::vector<smr_mp_cluster *> cl;
+    ImgOp *ops_dev = nullptr, *dup_dev = nullptr;
+    uint32_t n_ops = 0, n_dup = 0, rows = 0, ovf_cap = 0, max_g = 0;
+    uint64_t max_bytes = 0;
+};
+
+int smr_mp_image_plan_create(const smr_mp_image_op *ops, uint32_t n, uint32_t rows, uint32_t ovf_cap, smr_mp_image_plan **out) {
+    if (!out || (n && !ops)) return fail(SMR_ERR_ARG, "mp: null argument");
+    std::vector<ImgOp> main_ops, dup_ops;
+    smr_mp_image_plan *p = new smr_mp_image_plan();
+    p->rows = rows; p->ovf_cap = ovf_cap;
+    for (uint32_t i = 0; i < n; i++) {
+        const smr_mp_image_op &o = ops[i];
+        ImgLayout L;
+        if (int rc = img_check(o.cluster, o.kind, o.rep, o.other, o.img_dev, o.img_bytes, rows, ovf_cap, L)) { delete p; return rc; }
+        ImgOp d = img_op(o.cluster, o.kind, o.rep, o.other, o.img_dev, L);
+        if (o.copy_of_dev) {
+            if (((uintptr_t)o.copy_of_dev & 15u) || ((uintptr_t)o.img_dev & 15u)) { delete p; return fail(SMR_ERR_ARG, "mp: duplicated images must be 16-byte aligned"); }
+            d.kind = SMR_IMG_COPY; d.src = o.copy_of_dev;
+            dup_ops.push_back(d);
+            if (L.total > p->max_bytes) p->max_bytes = L.total;
+        } else {
+            main_ops.push_back(d);
+            if (d.G > p->max_g) p->max_g = d.G;
+        }
+        p->cl.push_back(o.cluster);
+    }
+    p->n_ops = (uint32_t)main_ops.size(); p->n_dup = (uint32_t)dup_ops.size();
+    hipError_t e = hipSuccess;
+    if (p->n_ops) {
+        e = hipMalloc((void **)&p->ops_dev, sizeof(ImgOp) * p->n_ops);
+        if (e == hipSuccess) e = hipMemcpy(p->ops_dev, main_ops.data(), sizeof(ImgOp) * p->n_ops, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && p->n_dup) {
+        e = hipMalloc((void **)&p->dup_dev, sizeof(ImgOp) * p->n_dup);
+        if (e == hipSuccess) e = hipMemcpy(p->dup_dev, dup_ops.data(), sizeof(ImgOp) * p->n_dup, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { smr_mp_image_plan_destroy(p); return fail(SMR_ERR_DEVICE, std::string("mp: image plan: ") + hipGetErrorString(e)); }
+    *out = p;
+    return SMR_OK;
+}
+
+void smr_mp_image_plan_destroy(smr_mp_image_plan *p) {
+    if (!p) return;
+    if (p->ops_dev) (void)hipFree(p->ops_dev);
+    if (p->dup_dev) (void)hipFree(p->dup_dev);
+    delete p;
+}
+
+int smr_mp_image_plan_run(smr_mp_image_plan *p, int unpack, void *stream) {
+    if (!p) return fail(SMR_ERR_ARG, "mp: null plan");
+    if (p->cl.empty()) return SMR_OK;
+    const int par = p->cl[0]->par;
+    for (smr_mp_cluster *c : p->cl)
+        if (c->par != par) return fail(SMR_ERR_STATE, "mp: the clusters of an exchange must be in the same tick (outbox parity differs)");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((c->cfg.n_groups + 255) / 256), block(256);
-    if (kind == SMR_IMG_OUTBOX) hipLaunchKernelGGL(mp_img_unpack_outbox, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, rows, img_dev, L);
-    else if (kind == SMR_IMG_ACKS) hipLaunchKernelGGL(mp_img_unpack_acks, grid, block, 0, st, c->dp, c->par, (uint32_t)rep, (uint32_t)other, img_dev, L);
-    else if (kind == SMR_IMG_PREPARE_REPLIES) hipLaunchKernelGGL(mp_img_unpack_pr, grid, block, 0, st, c->dp, (uint32_t)rep, img_dev, L);
-    else hipLaunchKernelGGL(mp_img_heartbeat, grid, block, 0, st, c->dp, (uint32_t)rep, (uint8_t *)img_dev, L, 1);
+    if (unpack && p->n_dup) return fail(SMR_ERR_ARG, "mp: a receive plan has no duplicated images");
+    if (p->n_ops) {
+        if (!unpack) hipLaunchKernelGGL(mp_img_zero_headers, dim3((p->n_ops + 255) / 256), dim3(256), 0, st, p->ops_dev, p->n_ops, p->ovf_cap);
+        hipLaunchKernelGGL(mp_img_many, dim3((p->max_g + 255) / 256, p->n_ops), dim3(256), 0, st, p->ops_dev, par, p->rows, p->ovf_cap, unpack);
+    }
+    if (!unpack && p->n_dup) {
+        const uint64_t blocks = (p->max_bytes / 16 + 255) / 256;
+        hipLaunchKernelGGL(mp_img_copy_many, dim3((unsigned)(blocks < 1024 ? (blocks ? blocks : 1) : 1024), p->n_dup), dim3(256), 0, st, p->dup_dev);
+    }
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -54,14 +54,15 @@ __device__ __forceinline__ void raft_flush(const RaftView &v, unsigned int c[4])
     }
 }
 
+template <int NR>
 __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, const uint32_t *__restrict__ n_new,
                                                           uint32_t *__restrict__ ae_first) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
     if (g < v.G) {
-        uint32_t fs[RMAX];                                     // first slot sent to each peer by this call's appends
+        uint32_t fs[NR];                                     // first slot sent to each peer by this call's appends
 #pragma unroll
-        for (int p = 0; p < RMAX; p++) fs[p] = 0xFFFFFFFFu;
+        for (int p = 0; p < NR; p++) fs[p] = 0xFFFFFFFFu;
         const uint32_t n = n_new[g];
         if (n) {
             if (v.role[g] != ROLE_LEADER) c[1] = n;            // request.rs:19-42 redirect
@@ -69,9 +70,9 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                 uint32_t len = v.log_len[g];
                 const uint32_t start = v.start_slot[g], snap = v.last_snap[g];
                 const uint64_t term = v.curr_term[g];
-                uint32_t tn[RMAX];
+                uint32_t tn[NR];
 #pragma unroll
-                for (int p = 0; p < RMAX; p++) tn[p] = (uint32_t)p < v.R ? v.try_next_slot[(size_t)p * v.G + g] : 0;
+                for (int p = 0; p < NR; p++) tn[p] = (uint32_t)p < v.R ? v.try_next_slot[(size_t)p * v.G + g] : 0;
                 for (uint32_t k = 0; k < n; k++) {
                     if (len - snap >= v.W) { c[2]++; continue; }   // ring back-pressure
                     const uint32_t slot = len;                   // request.rs:77
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                     len++;
                     // durability.rs:28-88: who is sent entries, try_next_slot
 #pragma unroll
-                    for (int p = 0; p < RMAX; p++) {
+                    for (int p = 0; p < NR; p++) {
                         if ((uint32_t)p >= v.R || (uint32_t)p == v.me || tn[p] < 1) continue;
                         uint32_t prev = tn[p] - 1;
                         if (prev < start) break;                 // logged_err
@@ -90,13 +91,13 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                 v.log_len[g] = len;
                 if (len > v.W && len - v.W > v.ring_lo[g]) v.ring_lo[g] = len - v.W;
 #pragma unroll
-                for (int p = 0; p < RMAX; p++)
+                for (int p = 0; p < NR; p++)
                     if ((uint32_t)p < v.R && (uint32_t)p != v.me) v.try_next_slot[(size_t)p * v.G + g] = tn[p];
             }
         }
         if (ae_first) {
 #pragma unroll
-            for (int p = 0; p < RMAX; p++) if ((uint32_t)p < v.R) ae_first[(size_t)p * v.G + g] = fs[p];
+            for (int p = 0; p < NR; p++) if ((uint32_t)p < v.R) ae_first[(size_t)p * v.G + g] = fs[p];
         }
     }
     raft_flush(v, c);
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
 // CRAFT: craft/messages.rs:256-404 -- every reply a leader takes also counts as a heard heartbeat (:275 ->
 // heartbeat.rs:280-296), a success reply is not tested for staleness (:279 is a debug_assert; a release build goes
 // on), and the commit rule is `majority + fault_tolerance` matches, `majority` in full-copy mode (:307-313)
-template <bool CRAFT>
+// NR >= population: every per-peer array and every loop over peers is NR wide (5 for the common populations -- the
+// R x R match-index comparison is 25 selects instead of 64; one lane per group is one wavefront per SIMD, so the kernel's
+// time is its straight-line ALU between the two load rounds)
+template <bool CRAFT, int NR>
 __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, const uint64_t *__restrict__ reply_term,
                                                            const uint32_t *__restrict__ end_slot,
                                                            const uint64_t *__restrict__ conflict_term,
@@ -130,11 +134,11 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
         uint32_t commit = v.last_commit[g], snap = v.last_snap[g];
         const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
         const uint64_t o_term = term;
-        uint32_t nx[RMAX], tn[RMAX], mt[RMAX], rf[RMAX], res[RMAX];
-        uint64_t rtm[RMAX];
-        bool dirty[RMAX];
+        uint32_t nx[NR], tn[NR], mt[NR], rf[NR], res[NR];
+        uint64_t rtm[NR];
+        bool dirty[NR];
 #pragma unroll
-        for (int p = 0; p < RMAX; p++) {
+        for (int p = 0; p < NR; p++) {
             bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
             size_t o = (size_t)p * v.G + g;
             nx[p] = on ? v.next_slot[o] : 0; tn[p] = on ? v.try_next_slot[o] : 0; mt[p] = on ? v.match_slot[o] : 0;
@@ -142,9 +146,9 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
             dirty[p] = false;
         }
         const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
-        uint32_t hi_at[RMAX];                                   // by delivery position: upper end of that reply's commit scan
+        uint32_t hi_at[NR];                                   // by delivery position: upper end of that reply's commit scan
 #pragma unroll
-        for (int q = 0; q < RMAX; q++) hi_at[q] = 0xFFFFFFFFu;
+        for (int q = 0; q < NR; q++) hi_at[q] = 0xFFFFFFFFu;
         const uint64_t lead_term = term;                        // commit scans only happen while I lead: in this term
         // ---- pass A -------------------------------------------------------------------------------------------
         for (uint32_t oi = 0; oi < v.R; oi++) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
             uint32_t f = 0, es = 0, nxp = 0, tnp = 0;
             uint64_t rt = 0;
 #pragma unroll
-            for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
             if (!(f & 1)) continue;
             // leadership.rs:16-72 check_term
             bool stepped = false;
@@ -173,29 +177,29 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 if (tnp < es + 1) tnp = es + 1;
                 mtp = es;
 #pragma unroll
-                for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
                 // commit index, closed form of :256-275
                 const uint32_t need = CRAFT ? commit_need : v.thresh - 1;   // peers needed besides me
                 uint32_t m = 0xFFFFFFFFu;
                 if (need > 0) {
                     m = 0;
 #pragma unroll
-                    for (int q = 0; q < RMAX; q++) {
+                    for (int q = 0; q < NR; q++) {
                         if ((uint32_t)q >= v.R || (uint32_t)q == v.me) continue;
                         uint32_t ge = 0;
 #pragma unroll
-                        for (int q2 = 0; q2 < RMAX; q2++)
+                        for (int q2 = 0; q2 < NR; q2++)
                             if ((uint32_t)q2 < v.R && (uint32_t)q2 != v.me && mt[q2] >= mt[q]) ge++;
                         if (ge >= need && mt[q] > m) m = mt[q];
                     }
                 }
                 const uint32_t hi = m < len - 1 ? m : len - 1;
 #pragma unroll
-                for (int q = 0; q < RMAX; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
                 // snapshot-safe index, closed form of :298-309
                 uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-                for (int q = 0; q < RMAX; q++)
+                for (int q = 0; q < NR; q++)
                     if ((uint32_t)q < v.R && (uint32_t)q != v.me && mt[q] < mn) mn = mt[q];
                 uint32_t cand = mn < es ? mn : es;
                 if (cand > snap) snap = cand;
@@ -206,11 +210,21 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                     nxp -= 1;                                   // :318
                     const uint64_t ct = conflict_term ? conflict_term[o] : 0;
                     const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
-                    for (;;) {                                  // :320-330
-                        bool readable = nxp >= start && nxp < len && nxp >= rlo;
-                        if (!(nxp > start && readable && nxp >= cs && nxp > 1)) break;
-                        if (v.entry_term[(size_t)(nxp & v.Wmask) * v.G + g] != ct) break;
-                        nxp -= 1;
+                    for (bool more = true; more;) {              // :320-330, eight candidates per round of loads: the
+                        uint64_t e8[8]; bool ok8[8];            // loop's tests depend on next_slot alone
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t cnd = nxp - (uint32_t)k;
+                            ok8[k] = (uint32_t)k < nxp && cnd > start && cnd < len && cnd >= rlo && cnd >= cs && cnd > 1;
+                            e8[k] = ok8[k] ? v.entry_term[(size_t)(cnd & v.Wmask) * v.G + g] : 0ull;
+                        }
+                        more = false;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            if (!ok8[k] || e8[k] != ct) break;
+                            nxp -= 1;
+                            if (k == 7) more = true;
+                        }
                     }
                     tnp = nxp;                                  // :331
                     uint32_t prev = nxp - 1;
@@ -220,19 +234,19 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
             }
         }
         // ---- round 2: the entry terms at the scans' upper ends, together -------------------------------------------
-        uint64_t et[RMAX];
+        uint64_t et[NR];
 #pragma unroll
-        for (int q = 0; q < RMAX; q++) {
+        for (int q = 0; q < NR; q++) {
             const uint32_t h = hi_at[q];
             et[q] = (h != 0xFFFFFFFFu && h > commit && h >= rlo) ? v.entry_term[(size_t)(h & v.Wmask) * v.G + g] : 0ull;
         }
         // ---- pass B: the scans of :256-275 / :278-293 in delivery order ----------------------------------------------
 #pragma unroll
-        for (int q = 0; q < RMAX; q++) {
+        for (int q = 0; q < NR; q++) {
             const uint32_t hi = hi_at[q];
             if (hi == 0xFFFFFFFFu) continue;
             for (uint32_t s2 = hi; s2 > commit; s2--) {
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
         if (commit != o_commit) v.last_commit[g] = commit;
         if (snap != o_snap) v.last_snap[g] = snap;
 #pragma unroll
-        for (int p = 0; p < RMAX; p++)
+        for (int p = 0; p < NR; p++)
             if (dirty[p]) {
                 size_t o = (size_t)p * v.G + g;
                 v.next_slot[o] = nx[p]; v.try_next_slot[o] = tn[p]; v.match_slot[o] = mt[p];
@@ -643,7 +657,7 @@ void smr_raft_leader_destroy(smr_raft_leader *l) {
 
 int smr_raft_leader_append(smr_raft_leader *l, const uint32_t *n_new_dev, void *stream) {
     if (!l || !n_new_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    hipLaunchKernelGGL(raft_append_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
+    hipLaunchKernelGGL((l->v.R <= 5 ? raft_append_kernel<5> : raft_append_kernel<RMAX>), dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
                        (uint32_t *)nullptr);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
@@ -653,12 +667,14 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
                                    const uint64_t *conflict_term_dev, const uint32_t *conflict_slot_dev,
                                    const uint8_t *flags_dev, const uint32_t *order_dev, void *stream) {
     if (!l || !reply_term_dev || !end_slot_dev || !flags_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    if (l->craft)
-        hipLaunchKernelGGL(raft_replies_kernel<true>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
-                           reply_term_dev, end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, l->cv);
-    else
-        hipLaunchKernelGGL(raft_replies_kernel<false>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
-                           reply_term_dev, end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, CraftView{});
+    const dim3 grid((l->v.G + 255) / 256), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const CraftView cv = l->craft ? l->cv : CraftView{};
+#define RAFT_REPLIES(C, N) hipLaunchKernelGGL((raft_replies_kernel<C, N>), grid, block, 0, st, l->v, reply_term_dev, end_slot_dev, \
+                                              conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, cv)
+    if (l->v.R <= 5) { if (l->craft) RAFT_REPLIES(true, 5); else RAFT_REPLIES(false, 5); }
+    else { if (l->craft) RAFT_REPLIES(true, RMAX); else RAFT_REPLIES(false, RMAX); }
+#undef RAFT_REPLIES
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -840,7 +856,7 @@ int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uin
 
 int smr_raft_leader_append_emit(smr_raft_leader *l, const uint32_t *n_new_dev, uint32_t *first_sent_dev, void *stream) {
     if (!l || !n_new_dev || !first_sent_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    hipLaunchKernelGGL(raft_append_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
+    hipLaunchKernelGGL((l->v.R <= 5 ? raft_append_kernel<5> : raft_append_kernel<RMAX>), dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_new_dev,
                        first_sent_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;

@@ -1,0 +1,64 @@
+"""Closed-loop EPaxos cluster on the device: R `EPaxosReplicaGroup` objects (one per replica id, every one holding all G
+groups) wired into BASELINE config 5's tick -- EVERY replica proposes one instance per group per tick; the PreAccepts fan
+out to all peers; their replies come back; each command leader decides fast / slow path; slow-path Accepts and their
+replies; CommitNotices to all peers.  Message order: senders ascending, each receiver handles one sender's message at a
+time (the order tests/ep_cluster.py fixes for the numpy backends; `tests/test_zz_ep_cluster_gpu.py` checks this driver
+against that one).  Every message stays a device tensor between the handlers: the only host work per tick is the
+handler calls themselves (R proposals + R (R - 1) PreAccepts + R reply tallies + R accept-reply tallies + R (R - 1)
+CommitNotices, plus Accept rounds when a slow path was taken)."""
+
+NO_KEY = 0xFF
+NONE = -1                                       # Option::None in a DepSet (0xFFFFFFFF as int32)
+
+
+def tick(reps, keys, drop=None, always_accept_round=False):
+    """reps[r]: EPaxosReplicaGroup of replica r; keys[r]: uint8 [G] device tensor, replica r's proposal per group
+    (0xFF = none); drop[(s, q)] (optional): bool [G], the PreAccept from s to q is lost (with its reply).
+    Returns per command leader dict(col, proposed, decision, committed, seq, deps) of device tensors."""
+    import torch
+    R = len(reps)
+    G = keys[0].shape[0]
+    dev = keys[0].device
+    u8 = lambda v: torch.full((G,), v, dtype=torch.uint8, device=dev)
+    i64 = lambda v: torch.full((G,), v, dtype=torch.int64, device=dev)
+    pa = [reps[r].handle_req_batch(keys[r], None) for r in range(R)]
+    rep = {}
+    for q in range(R):
+        for s in range(R):
+            if s == q:
+                continue
+            fl = pa[s]["flags"]
+            if drop is not None and (s, q) in drop:
+                fl = torch.where(drop[(s, q)], torch.zeros_like(fl), fl)
+            rep[(q, s)] = reps[q].handle_msg_pre_accept(dict(flags=fl, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=pa[s]["seq"],
+                                                             deps=pa[s]["deps"], key=keys[s]))
+    out = []
+    zero_f, zero_b = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int64, device=dev)
+    none_d = torch.full((R, G), NONE, dtype=torch.int32, device=dev)
+    for s in range(R):
+        flags = torch.stack([zero_f if q == s else rep[(q, s)]["flags"] for q in range(R)])
+        ballot = torch.stack([zero_b if q == s else rep[(q, s)]["ballot"] for q in range(R)])
+        seq = torch.stack([zero_b if q == s else rep[(q, s)]["seq"] for q in range(R)])
+        deps = torch.stack([none_d if q == s else rep[(q, s)]["deps"] for q in range(R)])
+        dec = reps[s].handle_msg_pre_accept_reply(pa[s]["col"], ballot, seq, deps, flags)
+        slow = (dec["decision"] == 2).to(torch.uint8)
+        aflags = torch.zeros((R, G), dtype=torch.uint8, device=dev)
+        aballot = torch.zeros((R, G), dtype=torch.int64, device=dev)
+        if always_accept_round or bool(slow.any()):              # (.any() is the one device -> host read of the tick)
+            for q in range(R):
+                if q == s:
+                    continue
+                ar = reps[q].handle_msg_accept(dict(flags=slow, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec["seq"],
+                                                    deps=dec["deps"], key=keys[s]))
+                aflags[q] = ar["flags"]
+                aballot[q] = ar["ballot"]
+        acc = reps[s].handle_msg_accept_reply(pa[s]["col"], aballot, aflags)
+        committed = ((dec["decision"] == 3) | (acc["committed"] == 1)).to(torch.uint8)
+        for q in range(R):
+            if q == s:
+                continue
+            reps[q].handle_msg_commit_notice(dict(flags=committed, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec["seq"],
+                                                  deps=dec["deps"], key=keys[s]))
+        out.append(dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec["decision"], committed=committed, seq=dec["seq"],
+                        deps=dec["deps"]))
+    return out

@@ -100,16 +100,20 @@ class SpreadReplica:
 
 
 # ---- near quorum reads over L2 (multipaxos/quorumread.rs; summerset_amd/quorumread.py) ---------------------------
-def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, order=None, stable=None, kv=None):
+def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, order=None, stable=None, kv=None, device="cpu"):
     """One ReadQuery round of replica `issuer` with the replicas of every group spread over the ranks (replica r on rank
     r mod world).  `replicas[r]` is the local object of replica r (numpy interface: handle_read_query / issue /
     handle_replies, i.e. the oracle in tests or an adapter over QuorumReadGroup) on its owner's rank, None elsewhere;
     `logs[r]` likewise the log view of replica r.  The exchange: every rank answers for its replicas, ONE all-gather of
     the packed replies (state u8 + slot u32 + val u32 + from_leader per (replica, read, group)) gives every rank the
     [R][B][G] reply arrays, the issuer's rank tallies, ONE broadcast returns the clients' answers.  `flags[R][G]` says
-    which replies arrive (loss); returns (outcome, out_val, done) on every rank."""
+    which replies arrive (loss); returns (outcome, out_val, done) on every rank.  `device`: where the two collectives'
+    buffers live -- "cpu" under gloo; with the nccl (RCCL) backend pass the rank's cuda device (the packed buffers are
+    staged through it; this host-staged prototype is not the device-resident path, see spread_mp.py)."""
     import torch
     import torch.distributed as dist
+    if dist.get_backend() == "nccl" and str(device) == "cpu":
+        raise ValueError("read_quorum_step: the nccl backend needs device= the rank's cuda device")
     R = len(replicas)
     mine = [r for r in range(R) if owner_of(r, world) == rank]
     B, G = keys.shape
@@ -127,12 +131,12 @@ def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, ord
         buf[o:o + 4 * B * G] = out["slot"].astype(np.uint32).ravel().view(np.uint8); o += 4 * B * G
         buf[o:o + 4 * B * G] = out["val"].astype(np.uint32).ravel().view(np.uint8); o += 4 * B * G
         buf[o:o + G] = fl
-    gathered = [torch.zeros(slots * per, dtype=torch.uint8) for _ in range(world)]
-    dist.all_gather(gathered, torch.from_numpy(buf))
+    gathered = [torch.zeros(slots * per, dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(buf).to(device))
     rep = dict(state=np.zeros((R, B, G), np.uint8), slot=np.zeros((R, B, G), np.uint32), val=np.zeros((R, B, G), np.uint32))
     from_leader = np.zeros((R, G), np.uint8)
     for rk in range(world):
-        a = gathered[rk].numpy()
+        a = gathered[rk].cpu().numpy()
         for i, r in enumerate([x for x in range(R) if owner_of(x, world) == rk]):
             o = i * per
             rep["state"][r] = a[o:o + B * G].reshape(B, G); o += B * G
@@ -148,9 +152,9 @@ def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, ord
         res[:B * G] = outcome.ravel()
         res[B * G:5 * B * G] = out_val.astype(np.uint32).ravel().view(np.uint8)
         res[5 * B * G:] = done
-    t = torch.from_numpy(res)
+    t = torch.from_numpy(res).to(device)
     dist.broadcast(t, src=owner_of(issuer, world))
-    res = t.numpy()
+    res = t.cpu().numpy()
     return (res[:B * G].reshape(B, G).copy(), res[B * G:5 * B * G].view(np.uint32).reshape(B, G).copy(), res[5 * B * G:].copy())
 
 

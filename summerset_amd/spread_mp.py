@@ -20,7 +20,7 @@ a harness guard) are per rank here: a run that overflows a ring is outside what 
 import numpy as np
 
 from . import _lib, shard
-from ._lib import check, stream_ptr
+from ._lib import MpImageOp, check, stream_ptr
 from .multipaxos import MultiPaxosCluster
 
 OUTBOX, ACKS, PREPARE_REPLIES, HEARTBEAT = 0, 1, 2, 3
@@ -111,30 +111,44 @@ class SpreadMultiPaxos:
             m.size, m.roff = self._img_bytes(m.block, m.kind), off
             off += m.size
             out_split[m.src] += m.size
-        return dict(send=send, recv=recv, in_split=in_split, out_split=out_split,
-                    sbuf=torch.zeros(max(n_send, 8), dtype=torch.uint8, device=self.device),
-                    rbuf=torch.zeros(max(off, 8), dtype=torch.uint8, device=self.device))
+        plan = dict(send=send, recv=recv, in_split=in_split, out_split=out_split,
+                    sbuf=torch.zeros(max(n_send, 16), dtype=torch.uint8, device=self.device),
+                    rbuf=torch.zeros(max(off, 16), dtype=torch.uint8, device=self.device))
+        # the exchange's operations never change: handed to the library once (smr_mp_image_plan_create), an exchange is
+        # then 3 launches to pack (clear headers, pack, duplicate) + 1 to unpack instead of one or two per image
+        plan["pack"] = self._make_plan(send, plan["sbuf"].data_ptr(), True)
+        plan["unpack"] = self._make_plan(recv, plan["rbuf"].data_ptr(), False)
+        return plan
+
+    def _make_plan(self, msgs, base, sending):
+        import ctypes as C
+        ops = (MpImageOp * max(len(msgs), 1))()
+        for o, m in zip(ops, msgs):
+            o.cluster, o.kind, o.rep, o.other = self.blocks[m.block][0]._h, m.kind, m.rep, m.other
+            o.img_dev, o.img_bytes = base + (m.soff if sending else m.roff), m.size
+            o.copy_of_dev = (base + m.dup_of.soff) if (sending and m.dup_of is not None) else None
+        h = C.c_void_p()
+        check(self._L.smr_mp_image_plan_create(ops, len(msgs), self.S, self.ovf_cap, C.byref(h)))
+        return h
+
+    def close(self):
+        for p in getattr(self, "_plans", {}).values():
+            for k in ("pack", "unpack"):
+                if p.get(k):
+                    self._L.smr_mp_image_plan_destroy(p[k])
+                    p[k] = None
+
+    def __del__(self):
+        self.close()
 
     # ---- one exchange: pack -> ONE all_to_all_single -> unpack ---------------------------------------------------------
     def _pack(self, phase, stream=None):
         p = self._plans[phase]
-        st = stream_ptr(stream)
-        base = p["sbuf"].data_ptr()
-        for m in p["send"]:
-            if m.dup_of is not None:
-                p["sbuf"][m.soff:m.soff + m.size].copy_(p["sbuf"][m.dup_of.soff:m.dup_of.soff + m.size])
-                continue
-            cl = self.blocks[m.block][0]
-            check(self._L.smr_mp_image_pack(cl._h, m.kind, m.rep, m.other, base + m.soff, m.size, self.S, self.ovf_cap, st))
+        check(self._L.smr_mp_image_plan_run(p["pack"], 0, stream_ptr(stream)))
         self.bytes_sent += sum(p["in_split"])
 
     def _unpack(self, phase, stream=None):
-        p = self._plans[phase]
-        st = stream_ptr(stream)
-        base = p["rbuf"].data_ptr()
-        for m in p["recv"]:
-            cl = self.blocks[m.block][0]
-            check(self._L.smr_mp_image_unpack(cl._h, m.kind, m.rep, m.other, base + m.roff, m.size, self.S, self.ovf_cap, st))
+        check(self._L.smr_mp_image_plan_run(self._plans[phase]["unpack"], 1, stream_ptr(stream)))
 
     def _exchange(self, phase, stream=None):
         import torch.distributed as dist

@@ -220,3 +220,9 @@ def test_string_kv_state_machine_kernel_on_the_host(sim):
         t.test_reference_state_machine_tests("cpu")
         t.test_put_rand_get_rand_per_group_and_the_host_state_machine("cpu")
         t.test_full_table_and_heap_are_sticky_not_silent("cpu")
+
+
+def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
+    import test_zz_ep_cluster_gpu as t
+    with sim.patched():
+        t.test_device_cluster_tick_matches_the_oracle_cluster("cpu", oracle, 300, 6, 0.15)

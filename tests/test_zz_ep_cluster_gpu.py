@@ -1,0 +1,39 @@
+"""The device-resident EPaxos cluster tick (summerset_amd/ep_cluster.py: every message a device tensor between the
+handlers) against the numpy-staged driver of tests/ep_cluster.py on five ORACLES wired the same way -- per-leader
+decisions of every tick and every replica's final state, with lost PreAccepts and execution on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("G,K,loss", [(700, 6, 0.15), (2048, 64, 0.0)])
+def test_device_cluster_tick_matches_the_oracle_cluster(cuda, oracle, G, K, loss):
+    import torch
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster
+    R, W, T = 5, 32, 9
+    engs = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    orcs = [oracle.EpOracle(G, R, me=r, W=W, n_keys=K, execute=True) for r in range(R)]
+    rng = np.random.default_rng(G + K)
+    fast = slow = 0
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q} if loss else None
+        oo = ec.tick(orcs, keys, drop)
+        oe = ep_cluster.tick(engs, [torch.from_numpy(np.ascontiguousarray(keys[r])).to(cuda) for r in range(R)],
+                             None if drop is None else {k: torch.from_numpy(v).to(cuda) for k, v in drop.items()})
+        for s in range(R):
+            for k in oo[s]:
+                e = oe[s][k].cpu().numpy()
+                assert np.array_equal(e.view(oo[s][k].dtype), oo[s][k]), (t, s, k)
+            fast += int((oo[s]["decision"] == 3).sum())
+            slow += int((oo[s]["decision"] == 2).sum())
+    for r in range(R):
+        a, b = engs[r].dump(), orcs[r].dump()
+        for n in b:
+            assert np.array_equal(a[n], b[n]), (r, n)
+        xa, xb = engs[r].exec_dump(), orcs[r].exec_dump()
+        for n in xb:
+            assert np.array_equal(xa[n], xb[n]), (r, "exec", n)
+    assert fast > 0 and (slow > 0 or loss == 0.0)

@@ -1,0 +1,11 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_raft_gpu.py tests/test_zz_craft_gpu.py tests/test_baseline_configs_gpu.py -q -m gpu -p no:cacheprovider -k "raft or craft" 2>&1 | tail -2
+timeout 300 python bench.py --no-cpu --no-rs > gpurun_out/r2m_bench.json 2> gpurun_out/r2m_bench.err
+python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r2m_bench.json").read().strip().splitlines()[-1])
+print("headline %.3e %.4f" % (d["value"], d["ms_per_step"]))
+print("raft", d["raft_quorum"]["roofline"]["frac"], d["raft_quorum"]["roofline"]["avg_launch_us"], d["raft_quorum"]["us_per_tick"], "%.3e" % d["raft_quorum"]["value"])
+print("ep", d["epaxos_fast_quorum"]["roofline"]["frac"], d["epaxos_fast_quorum"]["roofline"]["avg_launch_us"])
+PY
