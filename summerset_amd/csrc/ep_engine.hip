@@ -216,7 +216,7 @@ struct EpLane {
         for (int k = 0; k < 3; k++) {
             unsigned int x = c[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (__lane_id() == 0 && x) atomicAdd(&v.counters[k], (unsigned long long)x);
+            if (__lane_id() == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
         }
     }
 };
@@ -380,7 +380,7 @@ struct EpExecLane {
         for (int k = 0; k < 5; k++) {
             unsigned int y = c[k];
             for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
-            if (__lane_id() == 0 && y) atomicAdd(&x.counters[slot[k]], (unsigned long long)y);
+            if (__lane_id() == 0 && y) ctr_add(x.counters, (int)slot[k], (unsigned long long)y);
         }
     }
 };
@@ -726,7 +726,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     ecarve(a, v.pa_seq, W * R * G, dry); ecarve(a, v.pa_deps, W * R * R * G, dry);
     ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry);
     ecarve(a, v.hc, K * R * G, dry);
-    ecarve(a, v.counters, 4, dry);
+    ecarve(a, v.counters, SMR_CTR_WORDS, dry);
     if (e->cfg.execute) {
         EpExec &x = e->x;
         ecarve(a, x.exec_bars, R * G, dry); ecarve(a, x.prev_cb, R * G, dry);
@@ -734,7 +734,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
         ecarve(a, x.node_of, R * W * G, dry); ecarve(a, x.nslot, R * W * G, dry); ecarve(a, x.head, R * W * G, dry);
         ecarve(a, x.sib, R * W * G, dry); ecarve(a, x.parent, R * W * G, dry);
         ecarve(a, x.order, 2 * R * W * G, dry); ecarve(a, x.n_sub, G, dry);
-        ecarve(a, x.counters, 8, dry);
+        ecarve(a, x.counters, SMR_CTR_WORDS, dry);
     }
 }
 }  // namespace smr
@@ -873,7 +873,7 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
     D2H(pa.data(), v.pa_acks, R * W * G); D2H(ac.data(), v.acc_acks, R * W * G);
     D2H(deps.data(), v.deps, R * W * R * G * 4);
     unsigned long long c[4];
-    D2H(c, v.counters, sizeof(c));
+    SMR_HIP_TRY(ctr_read(v.counters, 4, c));
 #undef D2H
     hb->counters[0] = c[0]; hb->counters[1] = c[1]; hb->counters[2] = c[2];
     // canonical form: only the last W columns of each row are state; deps as [row][w][g][i]
@@ -907,7 +907,7 @@ int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint6
     SMR_HIP_TRY(hipMemcpy(kv, e->x.kv, K * G * 8, hipMemcpyDeviceToHost));
     SMR_HIP_TRY(hipMemcpy(digest, e->x.digest, G * 8, hipMemcpyDeviceToHost));
     unsigned long long c[8];
-    SMR_HIP_TRY(hipMemcpy(c, e->x.counters, sizeof(c), hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(ctr_read(e->x.counters, 8, c));
     for (int k = 0; k < 6; k++) counters[k] = c[k];
     return SMR_OK;
 }

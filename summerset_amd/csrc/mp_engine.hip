@@ -35,7 +35,7 @@ __device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
             SMR_G unsigned long long *const ctr = RepView{L.P.rep[0], (size_t)rep * L.P.rep_stride}.counters();
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (x[k]) atomicAdd((unsigned long long *)&ctr[k], (unsigned long long)x[k]);
+                if (x[k]) ctr_add((unsigned long long *)ctr, k, (unsigned long long)x[k]);
         }
     }
 }
@@ -44,9 +44,9 @@ __device__ __forceinline__ void flush_counters(const Lane &L, bool active) {
 __device__ __forceinline__ void flush_job(const Lane &J) {
     if (__lane_id() != 0) return;
     SMR_G unsigned long long *const ctr = J.v.counters();
-    if (J.n_commit) atomicAdd((unsigned long long *)&ctr[0], (unsigned long long)J.n_commit);
-    if (J.n_redirect) atomicAdd((unsigned long long *)&ctr[1], (unsigned long long)J.n_redirect);
-    if (J.n_reject) atomicAdd((unsigned long long *)&ctr[2], (unsigned long long)J.n_reject);
+    if (J.n_commit) ctr_add((unsigned long long *)ctr, 0, (unsigned long long)J.n_commit);
+    if (J.n_redirect) ctr_add((unsigned long long *)ctr, 1, (unsigned long long)J.n_redirect);
+    if (J.n_reject) ctr_add((unsigned long long *)ctr, 2, (unsigned long long)J.n_reject);
 }
 
 // Rare, long-running work (leader changes) is not run by one lane while 63 idle: the
@@ -898,12 +898,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         if (__all(!closed || dl == d0)) {
             unsigned int x = nc;
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d0].counters[0], (unsigned long long)x);
+            if (lane == 0 && x) ctr_add((unsigned long long *)P.rep[d0].counters, 0, (unsigned long long)x);
         } else {
             for (uint32_t d = 0; d < R; d++) {
                 unsigned int x = (closed && dl == d) ? nc : 0u;
                 for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-                if (lane == 0 && x) atomicAdd((unsigned long long *)&P.rep[d].counters[0], (unsigned long long)x);
+                if (lane == 0 && x) ctr_add((unsigned long long *)P.rep[d].counters, 0, (unsigned long long)x);
             }
         }
     }
@@ -1484,7 +1484,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
         carve(a, v.pr_vbal, pcap * Gp, dry); carve(a, v.pr_vval, pcap * Gp, dry);
         carve(a, v.hb_bal, G, dry); carve(a, v.hb_commit, G, dry); carve(a, v.hb_exec, G, dry);
         carve(a, v.hb_snap, G, dry);
-        carve(a, v.counters, 4, dry);
+        carve(a, v.counters, SMR_CTR_WORDS, dry);
         carve(a, v.clist, (size_t)c->cfg.commit_list_cap, dry);
         carve(a, v.clist_n, 1, dry);
     }
@@ -2076,7 +2076,7 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]) {
     if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[4];
-    SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(ctr_read((const unsigned long long *)c->hp.rep[rep].counters, 4, h));
     out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return SMR_OK;
 }
@@ -2085,7 +2085,7 @@ int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
     if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());
     unsigned long long h[4];
-    SMR_HIP_TRY(hipMemcpy(h, c->hp.rep[rep].counters, sizeof(h), hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(ctr_read((const unsigned long long *)c->hp.rep[rep].counters, 4, h));
     *out = h[3];
     return SMR_OK;
 }

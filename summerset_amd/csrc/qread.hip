@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void qr_replies_kernel(const QrView v, uint32_
     for (int k = 0; k < 4; k++) {
         unsigned int x = c[k];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-        if (__lane_id() == 0 && x) atomicAdd(&v.counters[k], (unsigned long long)x);
+        if (__lane_id() == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
     }
 }
 
@@ -196,7 +196,7 @@ static void qr_layout(smr_qread *h, bool dry) {
     qcarve(a, v.highest_slot, K * G, dry);
     qcarve(a, v.live, Q * G, dry); qcarve(a, v.n, Q * G, dry); qcarve(a, v.acks, Q * G, dry);
     qcarve(a, v.mx_state, Q * B * G, dry); qcarve(a, v.mx_slot, Q * B * G, dry); qcarve(a, v.mx_val, Q * B * G, dry);
-    qcarve(a, v.counters, 4, dry);
+    qcarve(a, v.counters, SMR_CTR_WORDS, dry);
 }
 }  // namespace smr
 
@@ -297,7 +297,7 @@ int smr_qread_dump(smr_qread *h, uint32_t *highest_slot_host, uint8_t *live_host
     SMR_HIP_TRY(hipMemcpy(mx_slot_host, v.mx_slot, Q * B * G * 4, hipMemcpyDeviceToHost));
     SMR_HIP_TRY(hipMemcpy(mx_val_host, v.mx_val, Q * B * G * 4, hipMemcpyDeviceToHost));
     unsigned long long c[4];
-    SMR_HIP_TRY(hipMemcpy(c, v.counters, sizeof(c), hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(ctr_read(v.counters, 4, c));
     for (int k = 0; k < 4; k++) counters_host[k] = c[k];
     // canonical form: rows of queries that are gone, rows past a query's reads and fields its state does not use read 0
     for (size_t q = 0; q < Q; q++)

@@ -239,7 +239,7 @@ struct RspLane {
         for (int k = 0; k < 4; k++) {
             unsigned int x = c[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-            if (__lane_id() == 0 && x) atomicAdd(&v.counters[k], (unsigned long long)x);
+            if (__lane_id() == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
         }
     }
 };
@@ -546,7 +546,7 @@ static void rsp_layout(smr_rsp_replica *e, bool dry) {
     qcarve(a, v.s_val, W * G, dry); qcarve(a, v.s_vval, W * G, dry); qcarve(a, v.s_ltrig, W * G, dry); qcarve(a, v.s_lendp, W * G, dry);
     qcarve(a, v.s_rtrig, W * G, dry); qcarve(a, v.s_rendp, W * G, dry);
     qcarve(a, v.xq, W * G, dry); qcarve(a, v.xn, G, dry);
-    qcarve(a, v.counters, 4, dry);
+    qcarve(a, v.counters, SMR_CTR_WORDS, dry);
 }
 }  // namespace smr
 
@@ -716,7 +716,7 @@ int smr_rsp_dump(smr_rsp_replica *e, const smr_rsp_dump_bufs *hb) {
     D2H(hb->s_pmax, v.s_pmax, W * G * 8); D2H(hb->s_rsrc, v.s_rsrc, W * G); D2H(hb->s_rtrig, v.s_rtrig, W * G * 4);
     D2H(hb->s_rendp, v.s_rendp, W * G * 4);
     unsigned long long c[4];
-    D2H(c, v.counters, sizeof(c));
+    SMR_HIP_TRY(ctr_read(v.counters, 4, c));
 #undef D2H
     for (int k = 0; k < 4; k++) hb->counters[k] = c[k];
     // canonical form: cells outside the ring of the last W slots read as null instances; bookkeeping fields only

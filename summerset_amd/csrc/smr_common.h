@@ -24,6 +24,27 @@ inline int fail(int code, const std::string &msg) {
         }                                                                                 \
     } while (0)
 
+// Event counters (commits, redirects, ...) are kept as SMR_CTR_SHARDS partial sums, one 64-byte line each: a kernel's
+// wavefronts add to different lines, the host sums them when it reads.  One shared word per counter looked harmless and
+// WAS the kernels' run time: ~15 ns per same-address atomic, 1024 wavefronts -> 15-30 us (profiles/r2q: the Raft reply
+// kernel went from 33 to 126 us when eight lanes per group made it 8192 wavefronts -- its atomics, not its loads).
+constexpr uint32_t SMR_CTR_SHARDS = 256, SMR_CTR_STRIDE = 8;     // u64 words per shard
+constexpr size_t SMR_CTR_WORDS = (size_t)SMR_CTR_SHARDS * SMR_CTR_STRIDE;
+__device__ __forceinline__ void ctr_add(unsigned long long *base, int k, unsigned long long x) {
+    const uint32_t shard = ((blockIdx.x + blockIdx.y * 37u) * 4u + (threadIdx.x >> 6)) & (SMR_CTR_SHARDS - 1u);
+    atomicAdd(&base[(size_t)shard * SMR_CTR_STRIDE + (uint32_t)k], x);
+}
+// host: the n <= SMR_CTR_STRIDE counters behind `dev_base`, shards summed
+inline hipError_t ctr_read(const unsigned long long *dev_base, int n, unsigned long long *out) {
+    static thread_local unsigned long long buf[SMR_CTR_WORDS];
+    hipError_t e = hipMemcpy(buf, dev_base, sizeof(buf), hipMemcpyDeviceToHost);
+    for (int k = 0; k < n; k++) {
+        out[k] = 0;
+        for (uint32_t s2 = 0; s2 < SMR_CTR_SHARDS; s2++) out[k] += buf[(size_t)s2 * SMR_CTR_STRIDE + k];
+    }
+    return e;
+}
+
 // bump allocator over one hipMalloc'd arena: one allocation per engine object,
 // every array 256-byte aligned so wave-wide accesses start on a cache line.
 struct Arena {

@@ -110,10 +110,11 @@ template <typename T, typename U> HIPSIM_ATOMIC T atomicExch(T *p, U v) { T o = 
 #define HIPSIM_XLANE __attribute__((noinline, convergent))
 template <typename T> HIPSIM_XLANE T __shfl(T v, int src, int width = 64) {
     static_assert(sizeof(T) <= 8, "shuffles of up to 8 bytes");
-    (void)width;
     uint64_t x = 0;
     memcpy(&x, &v, sizeof(T));
-    const uint64_t r = hipsim::collective(hipsim::K_SHFL, __builtin_return_address(0), __builtin_frame_address(1), x, src & 63);
+    // width < 64: the source lane is taken inside the caller's own width-aligned segment (HIP / CUDA semantics)
+    const int lane = (int)(threadIdx.x & 63u), tgt = (lane & ~(width - 1)) | (src & (width - 1));
+    const uint64_t r = hipsim::collective(hipsim::K_SHFL, __builtin_return_address(0), __builtin_frame_address(1), x, tgt & 63);
     T o;
     memcpy(&o, &r, sizeof(T));
     return o;
