@@ -106,164 +106,180 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
 // CRAFT: craft/messages.rs:256-404 -- every reply a leader takes also counts as a heard heartbeat (:275 ->
 // heartbeat.rs:280-296), a success reply is not tested for staleness (:279 is a debug_assert; a release build goes
 // on), and the commit rule is `majority + fault_tolerance` matches, `majority` in full-copy mode (:307-313)
-// EIGHT LANES PER GROUP, lane = peer id.  One lane per group is 1024 wavefronts for 65 536 groups -- one per SIMD, 77 % of
-// its cycles spent waiting on two rounds of loads with nothing else to run (profiles/r2p_sq_counters.txt) -- so the group's
-// per-peer state is spread over lanes instead: lane p holds (next, try_next, match) of peer p and its reply, the scalars
-// are replicated, and what the handler needs across peers comes from width-8 shuffles: the reply of the peer whose turn
-// it is (delivery order), the k-th largest match index (every lane counts how many peers match at least as far as its
-// own), the minimum match index.  8192 wavefronts, eight per SIMD.  The replies are still applied one after the other
-// in delivery order, exactly as one handle_msg_append_entries_reply call each; everything is predicated rather than
-// branched so that the eight lanes of a group always shuffle together.  Pass A replays the replies without the commit
-// scans (their upper ends depend on the match indices alone), the entry terms at those ends are loaded together
-// (lane q: the scan of delivery position q), pass B finishes the scans in order.
-template <bool CRAFT>
+// (Measured and dropped, profiles/r2s_raft_lanes_ab.log: eight lanes per group with width-8 shuffles -- 8192 wavefronts --
+// ran 29.5 us against this kernel's 17.3: each load then touches eight 32-byte pieces of eight rows instead of one
+// contiguous run.  What HAD made one lane per group slow were the shared counter words, see ctr_add.)
+// NR >= population: every per-peer array and every loop over peers is NR wide (5 for the common populations -- the
+// R x R match-index comparison is 25 selects instead of 64; one lane per group is one wavefront per SIMD, so the kernel's
+// time is its straight-line ALU between the two load rounds)
+template <bool CRAFT, int NR>
 __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, const uint64_t *__restrict__ reply_term,
                                                            const uint32_t *__restrict__ end_slot,
                                                            const uint64_t *__restrict__ conflict_term,
                                                            const uint32_t *__restrict__ conflict_slot,
                                                            const uint8_t *__restrict__ flags,
                                                            const uint32_t *__restrict__ order, const CraftView cv) {
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = tid >> 3, p = tid & 7u;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
-    const bool live = g < v.G;
-    const uint32_t gg = live ? g : 0;
-    const bool on = live && p < v.R && p != v.me;              // this lane stands for a peer
-    const size_t o = (size_t)(p < v.R ? p : 0) * v.G + gg;
-    // ---- round 1: the group's scalars (same address in the eight lanes), my peer's state and its reply ----------
-    uint32_t commit_need = v.thresh - 1;                        // peers needed besides me
-    if (CRAFT && cv.full_copy[gg]) commit_need = cv.quorum - 1;
-    uint32_t role = v.role[gg], leader = v.leader[gg];
-    uint64_t term = v.curr_term[gg];
-    const uint32_t len = v.log_len[gg], start = v.start_slot[gg], rlo = v.ring_lo[gg];
-    uint32_t commit = v.last_commit[gg], snap = v.last_snap[gg];
-    const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
-    const uint64_t o_term = term;
-    uint32_t nx = on ? v.next_slot[o] : 0, tn = on ? v.try_next_slot[o] : 0, mt = on ? v.match_slot[o] : 0;
-    const uint32_t rf = on ? flags[o] : 0u, res = on ? end_slot[o] : 0u;
-    const uint64_t rtm = on ? reply_term[o] : 0ull;
-    const uint32_t ctl = order ? order[gg] : SMR_CTL_IDENTITY;
-    bool dirty = false, vote_reset = false;
-    uint32_t heard = 0;
-    uint32_t hi_at[RMAX];                                       // by delivery position: upper end of that reply's commit scan
+    if (g < v.G) {
+        // One lane per group and 65 536 groups are one wavefront per SIMD: the kernel is a chain of dependent memory
+        // round trips, so the chain is kept at TWO rounds of loads.  Round 1: the group's scalars, every peer's state
+        // and every peer's reply (addressed by peer id, not by the delivery order, so nothing waits for the order
+        // word).  Pass A then replays the replies in delivery order in registers -- everything of the handler except
+        // the commit scan, whose upper end `hi` depends only on the match indices -- and round 2 loads the entry terms
+        // at those (<= R - 1) slots together.  Pass B finishes the commit scans in the same order; it goes back to
+        // memory only when the entry at `hi` is of an older term (never in a steady term).
+        uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
+        if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
+        uint32_t role = v.role[g], leader = v.leader[g];
+        uint64_t term = v.curr_term[g];
+        const uint32_t len = v.log_len[g], start = v.start_slot[g], rlo = v.ring_lo[g];
+        uint32_t commit = v.last_commit[g], snap = v.last_snap[g];
+        const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
+        const uint64_t o_term = term;
+        uint32_t nx[NR], tn[NR], mt[NR], rf[NR], res[NR];
+        uint64_t rtm[NR];
+        bool dirty[NR];
 #pragma unroll
-    for (int q = 0; q < RMAX; q++) hi_at[q] = 0xFFFFFFFFu;
-    const uint64_t lead_term = term;                            // commit scans only happen while I lead: in this term
-    const uint32_t need = CRAFT ? commit_need : v.thresh - 1;
-    // ---- pass A ---------------------------------------------------------------------------------------------------
+        for (int p = 0; p < NR; p++) {
+            bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+            size_t o = (size_t)p * v.G + g;
+            nx[p] = on ? v.next_slot[o] : 0; tn[p] = on ? v.try_next_slot[o] : 0; mt[p] = on ? v.match_slot[o] : 0;
+            rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
+            dirty[p] = false;
+        }
+        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+        uint32_t hi_at[NR];                                   // by delivery position: upper end of that reply's commit scan
 #pragma unroll
-    for (int oi = 0; oi < RMAX; oi++) {
-        const uint32_t pc = (ctl >> (3 * oi)) & 7u;             // the peer whose reply is delivered now
-        const uint32_t f = __shfl(rf, (int)pc, 8), es = __shfl(res, (int)pc, 8);
-        const uint64_t rt = __shfl(rtm, (int)pc, 8);
-        bool act = live && (uint32_t)oi < v.R && pc != v.me && pc < v.R && (f & 1u);
-        // leadership.rs:16-72 check_term
-        bool stepped = false;
-        if (act && rt > term) {
-            term = rt; leader = pc; vote_reset = true;          // :21-22 voted_for = None, votes cleared
-            if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
-        }
-        act = act && !stepped && role == ROLE_LEADER;           // messages.rs:239-241
-        if (CRAFT && act) heard |= 1u << pc;
-        const uint32_t nxp = __shfl(nx, (int)pc, 8);
-        const bool mine = p == pc;
-        bool succ = act && !(f & 2u);
-        if (!CRAFT && succ && nxp > es + 1) succ = false;       // :245-247 stale success reply
-        if (succ && mine) {
-            nx = es + 1;
-            if (tn < es + 1) tn = es + 1;
-            mt = es;
-            dirty = true;
-        }
-        // commit index, closed form of :256-275: the largest match index that `need` peers reach
-        uint32_t ge = 0;
+        for (int q = 0; q < NR; q++) hi_at[q] = 0xFFFFFFFFu;
+        const uint64_t lead_term = term;                        // commit scans only happen while I lead: in this term
+        // ---- pass A -------------------------------------------------------------------------------------------
+        for (uint32_t oi = 0; oi < v.R; oi++) {
+            const uint32_t p = (ctl >> (3 * oi)) & 7u;
+            if (p == v.me || p >= v.R) continue;
+            const size_t o = (size_t)p * v.G + g;
+            // registers indexed by a runtime peer id: unrolled select
+            uint32_t f = 0, es = 0, nxp = 0, tnp = 0;
+            uint64_t rt = 0;
 #pragma unroll
-        for (int q2 = 0; q2 < RMAX; q2++) {
-            const uint32_t mq = __shfl(mt, q2, 8);
-            if ((uint32_t)q2 < v.R && (uint32_t)q2 != v.me && mq >= mt) ge++;
-        }
-        uint32_t m = (on && ge >= need) ? mt : 0u;
-        uint32_t mn = on ? mt : 0xFFFFFFFFu;                    // snapshot-safe index, closed form of :298-309
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
+            if (!(f & 1)) continue;
+            // leadership.rs:16-72 check_term
+            bool stepped = false;
+            if (rt > term) {
+                term = rt; leader = p;
+                v.voted_for[g] = NO_REP; v.votes[g] = 0;        // :21-22
+                if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
+            }
+            if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
+            if (CRAFT) heard |= 1u << p;
+            uint32_t mtp;
+            if (!(f & 2)) {
+                if (!CRAFT && nxp > es + 1) continue;           // :245-247
+                nxp = es + 1;
+                if (tnp < es + 1) tnp = es + 1;
+                mtp = es;
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            const uint32_t a = __shfl_xor(m, off, 8), b2 = __shfl_xor(mn, off, 8);
-            m = a > m ? a : m; mn = b2 < mn ? b2 : mn;
-        }
-        if (need == 0) m = 0xFFFFFFFFu;
-        if (succ) {
-            hi_at[oi] = m < len - 1 ? m : len - 1;
-            const uint32_t cand = mn < es ? mn : es;
-            if (cand > snap) snap = cand;
-        }
-        if (act && (f & 2u) && mine) {                          // :311-340 conflict: only the lane of that peer walks back
-            uint32_t n2 = nx, t2 = tn;
-            if (n2 == 1) {                                      // :313-316
-                t2 = 1;
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
+                // commit index, closed form of :256-275
+                const uint32_t need = CRAFT ? commit_need : v.thresh - 1;   // peers needed besides me
+                uint32_t m = 0xFFFFFFFFu;
+                if (need > 0) {
+                    m = 0;
+#pragma unroll
+                    for (int q = 0; q < NR; q++) {
+                        if ((uint32_t)q >= v.R || (uint32_t)q == v.me) continue;
+                        uint32_t ge = 0;
+#pragma unroll
+                        for (int q2 = 0; q2 < NR; q2++)
+                            if ((uint32_t)q2 < v.R && (uint32_t)q2 != v.me && mt[q2] >= mt[q]) ge++;
+                        if (ge >= need && mt[q] > m) m = mt[q];
+                    }
+                }
+                const uint32_t hi = m < len - 1 ? m : len - 1;
+#pragma unroll
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
+                // snapshot-safe index, closed form of :298-309
+                uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < NR; q++)
+                    if ((uint32_t)q < v.R && (uint32_t)q != v.me && mt[q] < mn) mn = mt[q];
+                uint32_t cand = mn < es ? mn : es;
+                if (cand > snap) snap = cand;
             } else {
-                n2 -= 1;                                        // :318
-                const uint64_t ct = conflict_term ? conflict_term[o] : 0;
-                const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
-                for (bool more = true; more;) {                  // :320-330, eight candidates per round of loads: the
-                    uint64_t e8[8]; bool ok8[8];                // loop's tests depend on next_slot alone
+                if (nxp == 1) {                                 // :313-316
+                    tnp = 1;
+                } else {
+                    nxp -= 1;                                   // :318
+                    const uint64_t ct = conflict_term ? conflict_term[o] : 0;
+                    const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
+                    for (bool more = true; more;) {              // :320-330, eight candidates per round of loads: the
+                        uint64_t e8[8]; bool ok8[8];            // loop's tests depend on next_slot alone
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t cnd = n2 - (uint32_t)k;
-                        ok8[k] = (uint32_t)k < n2 && cnd > start && cnd < len && cnd >= rlo && cnd >= cs && cnd > 1;
-                        e8[k] = ok8[k] ? v.entry_term[(size_t)(cnd & v.Wmask) * v.G + gg] : 0ull;
+                        for (int k = 0; k < 8; k++) {
+                            const uint32_t cnd = nxp - (uint32_t)k;
+                            ok8[k] = (uint32_t)k < nxp && cnd > start && cnd < len && cnd >= rlo && cnd >= cs && cnd > 1;
+                            e8[k] = ok8[k] ? v.entry_term[(size_t)(cnd & v.Wmask) * v.G + g] : 0ull;
+                        }
+                        more = false;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            if (!ok8[k] || e8[k] != ct) break;
+                            nxp -= 1;
+                            if (k == 7) more = true;
+                        }
                     }
-                    more = false;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (!ok8[k] || e8[k] != ct) break;
-                        n2 -= 1;
-                        if (k == 7) more = true;
+                    tnp = nxp;                                  // :331
+                    uint32_t prev = nxp - 1;
+                    if (prev >= start && prev < len) {          // :335-340
+                        if (es + 1 > nxp) c[3] += es + 1 - nxp;
+                        tnp = es + 1;                           // :384
                     }
                 }
-                t2 = n2;                                        // :331
-                const uint32_t prev = n2 - 1;
-                if (prev >= start && prev < len) {              // :335-340
-                    if (es + 1 > n2) c[3] += es + 1 - n2;
-                    t2 = es + 1;                                // :384
+#pragma unroll
+                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
+            }
+        }
+        // ---- round 2: the entry terms at the scans' upper ends, together -------------------------------------------
+        uint64_t et[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            const uint32_t h = hi_at[q];
+            et[q] = (h != 0xFFFFFFFFu && h > commit && h >= rlo) ? v.entry_term[(size_t)(h & v.Wmask) * v.G + g] : 0ull;
+        }
+        // ---- pass B: the scans of :256-275 / :278-293 in delivery order ----------------------------------------------
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            const uint32_t hi = hi_at[q];
+            if (hi == 0xFFFFFFFFu) continue;
+            for (uint32_t s2 = hi; s2 > commit; s2--) {
+                if (s2 < rlo) break;                            // beyond the term ring
+                const uint64_t e = s2 == hi ? et[q] : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + g];
+                if (e == lead_term) {
+                    c[0] += s2 - commit;                        // :278-293 exec submissions
+                    commit = s2;
+                    break;
                 }
             }
-            nx = n2; tn = t2; dirty = true;
         }
-    }
-    // ---- round 2: the entry terms at the scans' upper ends, lane q the one of delivery position q --------------
-    uint32_t my_hi = 0xFFFFFFFFu;
-#pragma unroll
-    for (int q = 0; q < RMAX; q++) if ((uint32_t)q == p) my_hi = hi_at[q];
-    const uint64_t et = (my_hi != 0xFFFFFFFFu && my_hi > commit && my_hi >= rlo) ? v.entry_term[(size_t)(my_hi & v.Wmask) * v.G + gg] : 0ull;
-    // ---- pass B: the scans of :256-275 / :278-293 in delivery order (identical in the eight lanes) ---------------
-#pragma unroll
-    for (int q = 0; q < RMAX; q++) {
-        const uint32_t hi = hi_at[q];
-        const uint64_t eq = __shfl(et, q, 8);
-        if (hi == 0xFFFFFFFFu) continue;
-        for (uint32_t s2 = hi; s2 > commit; s2--) {
-            if (s2 < rlo) break;                                // beyond the term ring
-            const uint64_t e = s2 == hi ? eq : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + gg];
-            if (e == lead_term) {
-                if (p == 0) c[0] += s2 - commit;                // :278-293 exec submissions (counted once per group)
-                commit = s2;
-                break;
-            }
-        }
-    }
-    if (live && p == 0) {
-        if (vote_reset) { v.voted_for[g] = NO_REP; v.votes[g] = 0; }
         if (role != o_role) v.role[g] = (uint8_t)role;
         if (leader != o_leader) v.leader[g] = (uint8_t)leader;
         if (term != o_term) v.curr_term[g] = term;
         if (commit != o_commit) v.last_commit[g] = commit;
         if (snap != o_snap) v.last_snap[g] = snap;
-        if (CRAFT && heard) {
+#pragma unroll
+        for (int p = 0; p < NR; p++)
+            if (dirty[p]) {
+                size_t o = (size_t)p * v.G + g;
+                v.next_slot[o] = nx[p]; v.try_next_slot[o] = tn[p]; v.match_slot[o] = mt[p];
+            }
+        if (CRAFT && heard) {                                   // heartbeat.rs:284-290 update_heard_cnt
+            for (uint32_t p = 0; p < v.R; p++)
+                if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
             const uint32_t al = cv.alive[g];
             if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
         }
     }
-    if (on && dirty) { v.next_slot[o] = nx; v.try_next_slot[o] = tn; v.match_slot[o] = mt; }
-    if (CRAFT && on && ((heard >> p) & 1u)) cv.hb_replied[o] += 1;   // heartbeat.rs:284-290 update_heard_cnt
     raft_flush(v, c);
 }
 
@@ -654,13 +670,14 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
                                    const uint64_t *conflict_term_dev, const uint32_t *conflict_slot_dev,
                                    const uint8_t *flags_dev, const uint32_t *order_dev, void *stream) {
     if (!l || !reply_term_dev || !end_slot_dev || !flags_dev) return fail(SMR_ERR_ARG, "raft: null argument");
-    const dim3 grid((unsigned)(((uint64_t)l->v.G * 8 + 255) / 256)), block(256);   // eight lanes per group
+    const dim3 grid((l->v.G + 255) / 256), block(256);
     hipStream_t st = (hipStream_t)stream;
     const CraftView cv = l->craft ? l->cv : CraftView{};
-    if (l->craft) hipLaunchKernelGGL(raft_replies_kernel<true>, grid, block, 0, st, l->v, reply_term_dev, end_slot_dev, conflict_term_dev,
-                                     conflict_slot_dev, flags_dev, order_dev, cv);
-    else hipLaunchKernelGGL(raft_replies_kernel<false>, grid, block, 0, st, l->v, reply_term_dev, end_slot_dev, conflict_term_dev,
-                            conflict_slot_dev, flags_dev, order_dev, cv);
+#define RAFT_REPLIES(C, N) hipLaunchKernelGGL((raft_replies_kernel<C, N>), grid, block, 0, st, l->v, reply_term_dev, end_slot_dev, \
+                                              conflict_term_dev, conflict_slot_dev, flags_dev, order_dev, cv)
+    if (l->v.R <= 5) { if (l->craft) RAFT_REPLIES(true, 5); else RAFT_REPLIES(false, 5); }
+    else { if (l->craft) RAFT_REPLIES(true, RMAX); else RAFT_REPLIES(false, RMAX); }
+#undef RAFT_REPLIES
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
