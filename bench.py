@@ -882,7 +882,8 @@ def main():
         elif not args.fused:
             pmc_tick = sum(k[n]["hbm_bytes_per_launch"] / (H if n == "smr::mp_round_heartbeat" else 1)
                            for n in ("smr::mp_round_local", "smr::mp_round_deliver", "smr::mp_quorum_tally<5>",
-                                     "smr::mp_round_replies", "smr::mp_round_heartbeat") if n in k)
+                                     "smr::mp_round_replies", "smr::mp_round_heartbeat", "smr::mp_straggler_tick",
+                                     "smr::mp_mark_stragglers") if n in k)
     if args.fused:
         # the dominant kernel of the path is the fused tick kernel itself: every launch of the timed region between
         # its own HIP event pair; algorithmic bytes = the §8(d) figure x the decisions of the launch's ticks

@@ -17,11 +17,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--timeouts", type=float, default=0.01)
 ap.add_argument("--ticks", type=int, default=16)
 ap.add_argument("--extra", action="store_true")
+ap.add_argument("--straggler-ticks", type=int, default=8, help="as bench.py: ticks a group in a leader change spends on the side stream")
 a = ap.parse_args()
 dev = torch.device("cuda")
 G, R, S, W, H = 65536, 5, 32, 512, 4
 cap = W + 4
-eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)
+eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=a.straggler_ticks)
 eng.preset_leader(0)
 st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=a.ticks, drop_p=0.1, timeout_frac=a.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2)
 pool = [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(4)]
