@@ -934,11 +934,15 @@ def main():
         "decisions_per_sec": G * S * args.steps / elapsed,
     }
     if rank == 0:
-        def leg(name, fn, *a):                     # a secondary leg must never cost the headline line
-            try:
+        failed = []
+
+        def leg(name, fn, *a):                     # a secondary leg must never cost the headline line -- but it must not
+            try:                                   # fail silently either: `legs_failed` names it at the top level, stderr says why
                 line[name] = fn(*a)
             except Exception as e:                 # noqa: BLE001
                 line[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                failed.append(name)
+                sys.stderr.write("bench.py: leg %s FAILED: %s: %s\n" % (name, type(e).__name__, e))
         if world > 1:                              # secondary legs and the CPU baseline belong to the N=1 line only: the
             args.no_cpu = args.no_rs = args.no_extra = True   # other ranks sit in the closing barrier meanwhile
         if not args.no_cpu:
@@ -963,6 +967,8 @@ def main():
                             line[name]["cpu_baseline"] = fn()
                         except Exception as e:     # noqa: BLE001
                             line[name]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                            failed.append(name + ".cpu_baseline")
+        line["legs_failed"] = failed               # [] = every leg that was asked for ran (a missing cpu_baseline / roofline is an error here)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -747,8 +747,8 @@ template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
                                                    int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk) {
 #ifndef TALLY_C
-#define TALLY_C 8
-#endif
+#define TALLY_C 4          // 95 VGPRs, five wavefronts per SIMD: measured better than 8 rows per pass (128 VGPRs) with and without
+#endif                     // the side stream's blocks on the same CUs (profiles/r2u_tally_rows_per_pass.log)
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (w >= 4) { __syncthreads(); return; }                    // (the fused tick kernel's block has a wavefront per replica)
@@ -976,10 +976,9 @@ __global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restri
     const MpParams &P = *Pp;
     if (!((P.live >> blockIdx.y) & 1u)) return;
     if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
-        const uint32_t ntile = (P.G + 63) / 64, t0 = blockIdx.x * 4;
+        const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;   // 64-group tiles of this block
         uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+        for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
         if (!any) return;
     }
     uint32_t g;
@@ -1521,7 +1520,13 @@ static int prof_end(smr_mp_cluster *c, int idx, hipStream_t st) {
     return SMR_OK;
 }
 
-static dim3 mp_grid(const smr_mp_cluster *c) { return dim3((c->cfg.n_groups + 255) / 256, c->cfg.population); }
+// Bulk round kernels: lane = group, blockIdx.y = replica.  MP_BLOCK lanes per block: nothing in them crosses a wavefront
+// (no LDS, no block barrier), so a block is ONE wavefront -- it fits any free wavefront slot, also on the CUs the side
+// stream's long-lived blocks share with it, where a 4-wavefront block often does not.
+#ifndef MP_BLOCK
+#define MP_BLOCK 64
+#endif
+static dim3 mp_grid(const smr_mp_cluster *c) { return dim3((c->cfg.n_groups + MP_BLOCK - 1) / MP_BLOCK, c->cfg.population); }
 static dim3 side_grid(const smr_mp_cluster *c) { return dim3(SLOW_CAP / 4, c->cfg.population); }
 
 // Straggler side stream.  The first round call of a tick builds the tick's list; a round then
@@ -1667,7 +1672,7 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     }
     int pi;
     if ((rc = prof_begin(c, 0, st, pi))) return rc;
-    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(256), 0, st, c->dp, c->par, timeout_rep_dev,
+    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, timeout_rep_dev,
                        timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 0);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
@@ -1686,7 +1691,7 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     }
     int pi;
     if ((rc = prof_begin(c, 1, st, pi))) return rc;
-    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
+    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
@@ -1715,7 +1720,7 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
                            c->dp, c->par, ackctl_dev, publish_heartbeat);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pt, st))) return rc;
-    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(256), 0, st, c->dp, c->par, ackctl_dev,
+    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, ackctl_dev,
                        publish_heartbeat, 0);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
@@ -1734,7 +1739,7 @@ int smr_mp_round_heartbeat(smr_mp_cluster *c, void *stream) {
     }
     int pi;
     if ((rc = prof_begin(c, 3, st, pi))) return rc;
-    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(256), 0, st, c->dp, c->par, 0);
+    hipLaunchKernelGGL(mp_round_heartbeat, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, 0);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
