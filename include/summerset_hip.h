@@ -905,6 +905,41 @@ int smr_hb_update_heard_cnt(smr_hb *h, const uint8_t *peer_dev, void *stream);  
 int smr_hb_dump(smr_hb *h, uint64_t *deadline, uint8_t *exploded, uint8_t *is_sending, uint64_t *next_tick, uint64_t *cnt0,
                 uint64_t *cnt1, uint8_t *rep, uint8_t *alive);
 
+/* ---- LeaseManager (src/server/leaseman.rs:132-935), batched: G groups, one replica id per object -------------------------
+ * Time is explicit: one smr_lease_step = the timers that exploded up to now_ms (their GrantTimeout / LeaseTimeout notices,
+ * earliest first), then one notice per group, through run()'s lease-number filter (:840-926) and handle_notice (:791-835);
+ * out come the actions get_action() (:275-290) would drain.  A notice is three u64 per group -- num (its LeaseNum), meta,
+ * bar (accept_bar) -- with meta = kind | peer << 8 | peers << 16 | msg << 24 | held << 32 | has_bar << 40 (peers: a
+ * bitmap of replica ids, or SMR_LEASE_ALL for the reference's `None`).  Actions come back in the same shape, slot i of
+ * group g at [i * G + g]: num, meta = kind | peer << 8 | peers << 16 | msg << 24 | flag << 32 (flag: `held` of a
+ * PromiseReply / RevokeReply / GrantRemoved, or "has accept_bar" of a Guard), bar; only the first act_n[g] slots of a
+ * group are written.  smr_lease_create fails on the configurations new_and_setup rejects (:175-193). */
+#define SMR_LEASE_ALL 0xFF
+#define SMR_LEASE_ACT_CAP 20
+enum { SMR_LEASE_N_NONE = 0, SMR_LEASE_N_NEW_GRANTS = 1, SMR_LEASE_N_DO_REVOKE = 2, SMR_LEASE_N_CLEAR_HELD = 3, SMR_LEASE_N_RECV_MSG = 4 };
+enum { SMR_LEASE_M_GUARD = 0, SMR_LEASE_M_GUARD_REPLY = 1, SMR_LEASE_M_PROMISE = 2, SMR_LEASE_M_PROMISE_REPLY = 3, SMR_LEASE_M_REVOKE = 4,
+       SMR_LEASE_M_REVOKE_REPLY = 5 };
+enum { SMR_LEASE_A_SEND = 1, SMR_LEASE_A_BCAST = 2, SMR_LEASE_A_NEXT_REFRESH = 3, SMR_LEASE_A_GRANT_REMOVED = 4, SMR_LEASE_A_LEASE_CLEARED = 5,
+       SMR_LEASE_A_GRANT_TIMEOUT = 6, SMR_LEASE_A_LEASE_TIMEOUT = 7, SMR_LEASE_A_HIGHER_NUMBER = 8, SMR_LEASE_A_GUARD_ACCEPT_BAR = 9 };
+typedef struct smr_lease smr_lease;
+typedef struct {
+    uint32_t n_groups;
+    uint8_t population, replica_id;
+    uint64_t expire_timeout_ms, hb_send_interval_ms;
+} smr_lease_cfg;
+int smr_lease_create(const smr_lease_cfg *cfg, smr_lease **out);
+void smr_lease_destroy(smr_lease *h);
+/* meta_dev == NULL: timers only */
+int smr_lease_step(smr_lease *h, uint64_t now_ms, const uint64_t *num_dev, const uint64_t *meta_dev, const uint64_t *bar_dev,
+                   uint8_t *act_n_dev, uint64_t *act_num_dev, uint64_t *act_meta_dev, uint64_t *act_bar_dev, void *stream);
+/* attempt_refresh (:296-317): call[g] != 0 where it is called, peers[g] a bitmap or SMR_LEASE_ALL; to_refresh[g] out */
+int smr_lease_attempt_refresh(smr_lease *h, uint64_t now_ms, const uint8_t *call_dev, const uint8_t *peers_dev, uint8_t *to_refresh_dev,
+                              void *stream);
+/* grant_set (:236-243) / lease_set (:246-253) / lease_cnt (:257-259) per group, as of the last step; any pointer may be NULL */
+int smr_lease_sets(smr_lease *h, uint8_t *grant_set_dev, uint8_t *lease_set_dev, uint8_t *lease_cnt_dev, void *stream);
+/* host arrays: phase / deadlines as [R][G] (phase bits: 1 guards_sent, 2 guards_held, 4 promises_sent, 8 promises_held) */
+int smr_lease_dump(smr_lease *h, uint64_t *active_num, uint8_t *phase, uint64_t *grant_deadline, uint64_t *hold_deadline, uint8_t *refresh_mark);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c", "qr_oracle.c", "bitmap_oracle.c", "hb_oracle.c"]
+_SRCS = ["rs_oracle.c", "mp_oracle.c", "raft_oracle.c", "ep_oracle.c", "rsp_oracle.c", "qr_oracle.c", "bitmap_oracle.c", "hb_oracle.c", "lease_oracle.c"]
 
 CTL_IDENTITY = 0x00FAC688
 NO_LEADER = 0xFF
@@ -775,4 +775,67 @@ class HbOracle:
                  next_tick=np.zeros(G, np.uint64), cnt0=np.zeros((R, G), np.uint64), cnt1=np.zeros((R, G), np.uint64),
                  rep=np.zeros((R, G), np.uint8), alive=np.zeros(G, np.uint8))
         lib().orc_hb_dump(self.h, *[_p(d[k]) for k in ("deadline", "exploded", "is_sending", "next_tick", "cnt0", "cnt1", "rep", "alive")])
+        return d
+
+
+class LeaseOracle:
+    """`LeaseManager` of src/server/leaseman.rs for G groups (oracle/lease_oracle.c): explicit clock, one notice per group
+    and call.  Notices / messages / actions are small tuples so the restated reference tests read like the originals."""
+    N_NONE, N_NEW_GRANTS, N_DO_REVOKE, N_CLEAR_HELD, N_RECV_MSG = range(5)
+    GUARD, GUARD_REPLY, PROMISE, PROMISE_REPLY, REVOKE, REVOKE_REPLY = range(6)
+    A_SEND, A_BCAST, A_NEXT_REFRESH, A_GRANT_REMOVED, A_LEASE_CLEARED, A_GRANT_TIMEOUT, A_LEASE_TIMEOUT, A_HIGHER_NUMBER, \
+        A_GUARD_ACCEPT_BAR = range(1, 10)
+    ALL = 0xFF
+    ACT_CAP = 20
+
+    def __init__(self, G, R=5, me=0, expire_ms=2000, hb_send_ms=20):
+        L = lib()
+        L.orc_lease_new.restype = C.c_void_p
+        L.orc_lease_new.argtypes = [C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint64, C.c_uint64]
+        L.orc_lease_free.argtypes = [C.c_void_p]
+        L.orc_lease_step.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 16
+        L.orc_lease_attempt_refresh.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 3
+        L.orc_lease_dump.argtypes = [C.c_void_p] + [C.c_void_p] * 10
+        self._L, self.G, self.R, self.me = L, G, R, me
+        self._h = L.orc_lease_new(G, R, me, expire_ms, hb_send_ms)
+        if not self._h:
+            raise ValueError("invalid lease manager configuration")     # new_and_setup's logged_err! paths
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_lease_free(self._h)
+            self._h = None
+
+    def step_arrays(self, now, kind, num, peer, peers, msg, held, has_bar, bar):
+        """raw form: arrays of G entries in, (act_n[G], dict of [ACT_CAP, G] arrays) out"""
+        G, A = self.G, self.ACT_CAP
+        ins = [np.ascontiguousarray(kind, np.uint8), np.ascontiguousarray(num, np.uint64), np.ascontiguousarray(peer, np.uint8),
+               np.ascontiguousarray(peers, np.uint8), np.ascontiguousarray(msg, np.uint8), np.ascontiguousarray(held, np.uint8),
+               np.ascontiguousarray(has_bar, np.uint8), np.ascontiguousarray(bar, np.uint64)]
+        n = np.zeros(G, np.uint8)
+        out = dict(num=np.zeros((A, G), np.uint64), kind=np.zeros((A, G), np.uint8), peer=np.zeros((A, G), np.uint8),
+                   mask=np.zeros((A, G), np.uint8), msg=np.zeros((A, G), np.uint8), flag=np.zeros((A, G), np.uint8),
+                   bar=np.zeros((A, G), np.uint64))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._L.orc_lease_step(self._h, int(now), *[p(a) for a in ins], p(n),
+                               *[p(out[k]) for k in ("num", "kind", "peer", "mask", "msg", "flag", "bar")])
+        return n, out
+
+    def attempt_refresh_arrays(self, now, call, peers):
+        call = np.ascontiguousarray(call, np.uint8)
+        peers = np.ascontiguousarray(peers, np.uint8)
+        out = np.zeros(self.G, np.uint8)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._L.orc_lease_attempt_refresh(self._h, int(now), p(call), p(peers), p(out))
+        return out
+
+    def dump(self):
+        R, G = self.R, self.G
+        d = dict(active_num=np.zeros(G, np.uint64), grant_set=np.zeros(G, np.uint8), lease_set=np.zeros(G, np.uint8),
+                 lease_cnt=np.zeros(G, np.uint8), guards_sent=np.zeros(G, np.uint8), guards_held=np.zeros(G, np.uint8),
+                 refresh_mark=np.zeros(G, np.uint8), ps_deadline=np.zeros((R, G), np.uint64),
+                 gh_deadline=np.zeros((R, G), np.uint64), ph_deadline=np.zeros((R, G), np.uint64))
+        self._L.orc_lease_dump(self._h, *[d[k].ctypes.data_as(C.c_void_p) for k in
+                                          ("active_num", "grant_set", "lease_set", "lease_cnt", "guards_sent", "guards_held",
+                                           "refresh_mark", "ps_deadline", "gh_deadline", "ph_deadline")])
         return d

@@ -16,4 +16,5 @@ from .epaxos import EPaxosReplicaGroup  # noqa: F401
 from .rspaxos import RSPaxosReplicaGroup  # noqa: F401
 from .repnothing import RepNothingReplica  # noqa: F401
 from .heartbeater import Heartbeater  # noqa: F401
+from .leaseman import LeaseManager  # noqa: F401
 from . import shard, stream  # noqa: F401

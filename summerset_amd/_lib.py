@@ -36,6 +36,11 @@ class HbCfg(C.Structure):
                 ("hear_timeout_max_ms", C.c_uint64), ("send_interval_ms", C.c_uint64)]
 
 
+class LeaseCfg(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("replica_id", C.c_uint8), ("expire_timeout_ms", C.c_uint64),
+                ("hb_send_interval_ms", C.c_uint64)]
+
+
 class MpTickIn(C.Structure):
     _fields_ = [("timeout_rep_dev", C.c_void_p), ("timeout_src_dev", C.c_void_p), ("req_target_dev", C.c_void_p),
                 ("req_cnt_dev", C.c_void_p), ("req_val_dev", C.c_void_p), ("S", C.c_uint32), ("ackctl_dev", C.c_void_p),
@@ -324,6 +329,12 @@ SYMBOLS = [
     ("smr_hb_update_bcast_cnts", _i, [_vp, _vp, _vp, _vp]),
     ("smr_hb_update_heard_cnt", _i, [_vp, _vp, _vp]),
     ("smr_hb_dump", _i, [_vp] + [_vp] * 8),
+    ("smr_lease_create", _i, [C.POINTER(LeaseCfg), C.POINTER(_vp)]),
+    ("smr_lease_destroy", None, [_vp]),
+    ("smr_lease_step", _i, [_vp, _u64] + [_vp] * 8),
+    ("smr_lease_attempt_refresh", _i, [_vp, _u64, _vp, _vp, _vp, _vp]),
+    ("smr_lease_sets", _i, [_vp, _vp, _vp, _vp, _vp]),
+    ("smr_lease_dump", _i, [_vp] * 6),
     ("smr_repnothing_create", _i, [C.POINTER(_vp)]),
     ("smr_repnothing_destroy", None, [_vp]),
     ("smr_repnothing_submit_batch", _i, [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),

@@ -207,6 +207,20 @@ def test_heartbeater_kernels_on_the_host(sim, oracle):
         t.test_random_calls_match_oracle("cpu", oracle, 130, 3, 2)
 
 
+def test_lease_manager_kernels_on_the_host(sim, oracle):
+    """the batched LeaseManager (f.4): the reference's unit tests on the kernels, and random notices against the oracle"""
+    import test_zz_lease_gpu as t
+    import lease_scenarios as LS
+    with sim.patched():
+        for tr in LS.ALL_TRACES:
+            t.test_reference_trace_on_the_engine("cpu", tr)
+        t.test_mutual_leases_on_the_engine("cpu")
+        t.test_random_notices_match_oracle("cpu", oracle, 300, 5, 2, 0)
+        t.test_random_notices_match_oracle("cpu", oracle, 130, 8, 7, 2)
+        t.test_create_rejects_what_new_and_setup_rejects("cpu")
+        t.test_sets_kernel("cpu")
+
+
 def test_heartbeater_drives_the_multipaxos_engine_on_the_host(sim, oracle):
     import test_zz_hb_gpu as t
     with sim.patched():
