@@ -23,9 +23,28 @@
  *   quorum sizes, default ballot     mod.rs:500-514,693-698
  * WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one
  * key of a small key space (key id < n_keys), which is
- * all identify_deps / refresh_highest_cols look at.  NOT modelled: explicit
- * prepare, timers (the set of peers whose hear timer "exploded" is an input of
- * the reply handler).
+ * all identify_deps / refresh_highest_cols look at.  Timers are inputs (the set
+ * of peers whose hear timer "exploded" is an argument of the reply handler, a
+ * HearTimeout an argument of orc_ep_heartbeat_timeout).
+ *
+ * Explicit prepare (recovery of a suspected peer's row):
+ *   heartbeat_timeout                heartbeat.rs:17-125 (the protocol part: the
+ *                                    fast-quorum re-evaluation of my PreAccepting
+ *                                    instances, ExpPrepare for the peer's row, my
+ *                                    own ExpPrepareReply)
+ *   make_greater_ballot              mod.rs:500-508
+ *   handle_msg_exp_prepare           messages.rs:511-574
+ *   handle_msg_exp_prepare_reply     messages.rs:577-821
+ *   exp_prepare_next_step            dependency.rs:249-327
+ * exp_prepare_voteds is a HashMap in the reference and exp_prepare_next_step
+ * takes "the last Committed / Accepting / PreAccepting reply in iteration
+ * order" as its representative (dependency.rs:266-273): arbitrary when two
+ * PreAccepting replies at the same ballot differ.  Canonical choice here (and in
+ * the engine): iteration in peer-id order, i.e. the HIGHEST peer id of a status.
+ * With recovery, a replica leads instances outside its own row and messages
+ * name their slot's row apart from their sender: the handlers below take an
+ * optional `row` array (NULL: the sender's row for requests, my own row for
+ * replies -- the only cases there are without recovery).
  *
  * Dependency-graph execution (execution.rs:25-149 attempt_execution, :152-211
  * handle_cmd_result, durability.rs:136-160 the attempts after a commit-bar
@@ -78,12 +97,15 @@ typedef struct {
     /* LeaderBookkeeping */
     uint8_t pa_acks, acc_acks;
     uint8_t pa_has[MAXR]; uint64_t pa_seq[MAXR]; DepSet pa_deps[MAXR];   /* pre_accept_replies: HashMap<peer, (seq, deps)> */
+    uint8_t xp_acks; uint64_t xp_max_bal;                                 /* exp_prepare_acks, exp_prepare_max_bal */
+    uint8_t xp_has[MAXR], xp_status[MAXR], xp_key[MAXR]; uint64_t xp_seq[MAXR]; DepSet xp_deps[MAXR];   /* exp_prepare_voteds */
 } Inst;
 
 typedef struct { uint8_t row; uint32_t col; } Slot;
 
 typedef struct {
     uint8_t id, population, simple_q, super_q;
+    uint64_t n_xp_commit, n_xp_accept, n_xp_pre_accept, n_xp_noop;   /* explicit-prepare outcomes */
     uint32_t n_keys, W;
     Inst *rows[MAXR]; uint32_t len[MAXR], cap[MAXR];
     uint32_t start_col;
@@ -116,7 +138,7 @@ static int dep_eq(const DepSet *a, const DepSet *b, int R) {
 static Inst null_instance(void) {                                   /* mod.rs:467-480 */
     Inst in; memset(&in, 0, sizeof(in));
     in.status = ST_NULL; in.key = NO_KEY; in.deps = dep_empty(); in.source = NO_REP;
-    for (int p = 0; p < MAXR; p++) in.pa_deps[p] = dep_empty();
+    for (int p = 0; p < MAXR; p++) { in.pa_deps[p] = dep_empty(); in.xp_deps[p] = dep_empty(); in.xp_key[p] = NO_KEY; }
     return in;
 }
 static void row_push(EpRep *r, int row, Inst in) {
@@ -461,6 +483,12 @@ static void handle_msg_accept_reply(EpRep *r, uint8_t peer, int row, uint32_t co
     }
 }
 
+/* LeaderBookkeeping { .. } as request.rs:48-57 and heartbeat.rs:88-97 make it */
+static void fresh_leader_bk(Inst *in) {
+    in->has_lbk = 1; in->pa_acks = 0; in->acc_acks = 0; in->xp_acks = 0; in->xp_max_bal = 0;
+    for (int p = 0; p < MAXR; p++) { in->pa_has[p] = 0; in->xp_has[p] = 0; }
+}
+
 /* request.rs:10-108 + the command leader's own PreAcceptSlot completion (durability.rs:25-35).
  * Output: the PreAccept message it broadcasts. */
 void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_t *m_flags, uint32_t *m_col,
@@ -483,8 +511,7 @@ void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_
         in->bal = (uint64_t)(r->id + 1);                              /* make_default_ballot: (0 << 8) | (id + 1) */
         in->seq = seq; in->deps = deps; in->key = key[g];
         refresh_highest_cols(r, row, col, key[g]);
-        in->has_lbk = 1; in->pa_acks = 0; in->acc_acks = 0;
-        for (int p = 0; p < MAXR; p++) in->pa_has[p] = 0;
+        fresh_leader_bk(in);
         in->status = ST_PREACCEPTING;
         m_flags[g] = 1; m_col[g] = col; m_seq[g] = seq;
         for (int i = 0; i < cl->R; i++) m_deps[(size_t)i * G + g] = deps.c[i];
@@ -495,7 +522,7 @@ void orc_ep_propose(void *h, const uint8_t *key, const uint8_t *exploded, uint8_
 /* messages.rs:10-93 + the acceptor's PreAcceptSlot completion (durability.rs:36-54): the reply */
 void orc_ep_handle_pre_accept(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col,
                               const uint64_t *ballot, const uint64_t *seq, const uint32_t *deps, const uint8_t *key,
-                              uint8_t *r_flags, uint64_t *r_ballot, uint64_t *r_seq, uint32_t *r_deps) {
+                              uint8_t *r_flags, uint64_t *r_ballot, uint64_t *r_seq, uint32_t *r_deps, const uint8_t *rows) {
     EpCl *cl = (EpCl *)h;
     const uint32_t G = cl->G;
     for (uint32_t g = 0; g < G; g++) {
@@ -503,7 +530,7 @@ void orc_ep_handle_pre_accept(void *h, const uint8_t *flags, const uint8_t *peer
         r_flags[g] = 0; r_ballot[g] = 0; r_seq[g] = 0;
         for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = NONE;
         if (!(flags[g] & 1)) continue;
-        int row = peer[g];                                           /* the command leader's own row */
+        int row = rows ? rows[g] : peer[g];                          /* (without recovery: the command leader's own row) */
         uint32_t c = col[g];
         if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
         while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :33-36 */
@@ -534,12 +561,13 @@ static uint32_t ctl_order(uint32_t ctl, int i) { return (ctl >> (3 * i)) & 7u; }
  * flags[R][G] bit0 = present; peers in `order` order (ackctl encoding).  decision: 0 / ST_* */
 void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64_t *ballot, const uint64_t *seq,
                                       const uint32_t *deps, const uint8_t *flags, const uint32_t *order,
-                                      const uint8_t *exploded, uint8_t *decision, uint64_t *d_seq, uint32_t *d_deps) {
+                                      const uint8_t *exploded, uint8_t *decision, uint64_t *d_seq, uint32_t *d_deps,
+                                      const uint8_t *rows) {
     EpCl *cl = (EpCl *)h;
     const uint32_t G = cl->G; const int R = cl->R;
     for (uint32_t g = 0; g < G; g++) {
         EpRep *r = &cl->reps[g];
-        int row = r->id;
+        int row = rows ? rows[g] : r->id;
         uint32_t ctl = order ? order[g] : CTL_IDENTITY;
         uint8_t before = 0;
         if (held(r, row, col[g])) before = at(r, row, col[g])->status;
@@ -573,14 +601,14 @@ void orc_ep_handle_pre_accept_replies(void *h, const uint32_t *col, const uint64
 /* messages.rs:273-345 + the acceptor's AcceptSlot completion (durability.rs:84-100) */
 void orc_ep_handle_accept(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col, const uint64_t *ballot,
                           const uint64_t *seq, const uint32_t *deps, const uint8_t *key, uint8_t *r_flags,
-                          uint64_t *r_ballot) {
+                          uint64_t *r_ballot, const uint8_t *rows) {
     EpCl *cl = (EpCl *)h;
     const uint32_t G = cl->G;
     for (uint32_t g = 0; g < G; g++) {
         EpRep *r = &cl->reps[g];
         r_flags[g] = 0; r_ballot[g] = 0;
         if (!(flags[g] & 1)) continue;
-        int row = peer[g];
+        int row = rows ? rows[g] : peer[g];
         uint32_t c = col[g];
         if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
         while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());
@@ -598,12 +626,12 @@ void orc_ep_handle_accept(void *h, const uint8_t *flags, const uint8_t *peer, co
 
 /* AcceptReplies to my instance (me, col[g]): ballot[R][G], flags[R][G]; committed[g] = 1 if it commits here */
 void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *ballot, const uint8_t *flags,
-                                  const uint32_t *order, uint8_t *committed) {
+                                  const uint32_t *order, uint8_t *committed, const uint8_t *rows) {
     EpCl *cl = (EpCl *)h;
     const uint32_t G = cl->G; const int R = cl->R;
     for (uint32_t g = 0; g < G; g++) {
         EpRep *r = &cl->reps[g];
-        int row = r->id;
+        int row = rows ? rows[g] : r->id;
         uint32_t ctl = order ? order[g] : CTL_IDENTITY;
         uint8_t before = 0;
         if (held(r, row, col[g])) before = at(r, row, col[g])->status;
@@ -622,13 +650,14 @@ void orc_ep_handle_accept_replies(void *h, const uint32_t *col, const uint64_t *
 
 /* messages.rs:438-508 + handle_logged_commit_slot */
 void orc_ep_handle_commit_notice(void *h, const uint8_t *flags, const uint8_t *peer, const uint32_t *col,
-                                 const uint64_t *ballot, const uint64_t *seq, const uint32_t *deps, const uint8_t *key) {
+                                 const uint64_t *ballot, const uint64_t *seq, const uint32_t *deps, const uint8_t *key,
+                                 const uint8_t *rows) {
     EpCl *cl = (EpCl *)h;
     const uint32_t G = cl->G;
     for (uint32_t g = 0; g < G; g++) {
         EpRep *r = &cl->reps[g];
         if (!(flags[g] & 1)) continue;
-        int row = peer[g];
+        int row = rows ? rows[g] : peer[g];
         uint32_t c = col[g];
         if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
         while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :462-465 */
@@ -638,6 +667,241 @@ void orc_ep_handle_commit_notice(void *h, const uint8_t *flags, const uint8_t *p
             for (int i = 0; i < MAXR; i++) in->deps.c[i] = i < cl->R ? deps[(size_t)i * G + g] : NONE;
             refresh_highest_cols(r, row, c, key[g]);
             handle_logged_commit_slot(r, row, c); drain_exec(r);
+        }
+    }
+}
+
+/* ---- explicit prepare ---------------------------------------------------------------------------------------------- */
+static uint64_t make_greater_ballot(uint8_t id, uint64_t bal) { return (((bal >> 8) + 1) << 8) | (uint64_t)(id + 1); }   /* mod.rs:500-508 */
+
+/* dependency.rs:249-327: 0 = cannot decide yet, else the Status of the next phase with the instance state to feed it */
+static int exp_prepare_next_step(EpRep *r, int slot_row, Inst *in, uint64_t *seq, DepSet *deps, uint8_t *key) {
+    if (__builtin_popcount(in->xp_acks) < r->simple_q) return 0;     /* :257-260 */
+    int has_commit = -1, has_accept = -1, has_pre_accept = -1;       /* :264-273, peers in id order (see the header) */
+    for (int p = 0; p < r->population; p++) {
+        if (!in->xp_has[p]) continue;
+        if (in->xp_status[p] == ST_COMMITTED) has_commit = p;
+        else if (in->xp_status[p] == ST_ACCEPTING) has_accept = p;
+        else if (in->xp_status[p] == ST_PREACCEPTING) has_pre_accept = p;
+    }
+    if (has_commit >= 0) { *seq = in->xp_seq[has_commit]; *deps = in->xp_deps[has_commit]; *key = in->xp_key[has_commit]; return ST_COMMITTED; }
+    if (has_accept >= 0) { *seq = in->xp_seq[has_accept]; *deps = in->xp_deps[has_accept]; *key = in->xp_key[has_accept]; return ST_ACCEPTING; }
+    /* :286-311 at least N/2 identical PreAccepting replies under the row's default ballot, none from the row's owner */
+    if (in->xp_max_bal == (uint64_t)(slot_row + 1)) {
+        int idx[MAXR], n = 0;
+        for (int p = 0; p < r->population; p++)
+            if (in->xp_has[p] && p != slot_row && in->xp_status[p] == ST_PREACCEPTING) idx[n++] = p;
+        if (n >= r->simple_q - 1 && n > 0) {                         /* :302-306 (get_enough_identical's thresh is simple_quorum_cnt itself) */
+            uint8_t visited[MAXR] = {0};
+            int first = 0;
+            visited[0] = 1;
+            while (first < n) {                                      /* :333-367 */
+                int next_first = n, same = 1;
+                for (int i = first + 1; i < n; i++) {
+                    if (visited[i]) continue;
+                    if (in->xp_seq[idx[i]] == in->xp_seq[idx[first]] && in->xp_key[idx[i]] == in->xp_key[idx[first]] &&
+                        dep_eq(&in->xp_deps[idx[i]], &in->xp_deps[idx[first]], r->population)) { visited[i] = 1; same++; }
+                    else if (next_first == n) next_first = i;
+                }
+                if (same >= r->simple_q) {
+                    *seq = in->xp_seq[idx[first]]; *deps = in->xp_deps[idx[first]]; *key = in->xp_key[idx[first]];
+                    return ST_ACCEPTING;                             /* :313-315 */
+                }
+                first = next_first;
+            }
+        }
+    }
+    if (has_pre_accept >= 0) {                                       /* :316-319 */
+        *seq = in->xp_seq[has_pre_accept]; *deps = in->xp_deps[has_pre_accept]; *key = in->xp_key[has_pre_accept];
+        return ST_PREACCEPTING;
+    }
+    *seq = 1; *deps = dep_empty(); *key = NO_KEY;                    /* :320-327 no-op */
+    return ST_PREACCEPTING;
+}
+
+/* messages.rs:577-821 with the WAL completions of what it logs (durability.rs:25-35, 78-83, 104-); returns the Status of
+ * the message it broadcasts (CommitNotice / Accept / PreAccept for (row, col) under new_ballot with inst's seq / deps /
+ * reqs) or 0 */
+static int handle_msg_exp_prepare_reply(EpRep *r, uint8_t peer, int row, uint32_t col, uint64_t new_ballot, uint64_t voted_bal,
+                                        uint8_t voted_status, uint64_t voted_seq, const DepSet *voted_deps, uint8_t voted_key) {
+    if (col < r->start_col) return 0;
+    if (col >= r->start_col + r->len[row] || !held(r, row, col)) return 0;   /* :599-601 */
+    Inst *in = at(r, row, col);
+    if (new_ballot <= in->bal || !in->has_lbk) return 0;             /* :603-605 */
+    if ((in->xp_acks >> peer) & 1) return 0;                         /* :607-609 */
+    if (voted_bal > in->xp_max_bal) {                                /* :612-615 */
+        for (int p = 0; p < MAXR; p++) in->xp_has[p] = 0;
+        in->xp_max_bal = voted_bal;
+    }
+    if (voted_bal >= in->xp_max_bal) {                               /* :616-621 */
+        in->xp_has[peer] = 1; in->xp_status[peer] = voted_status; in->xp_seq[peer] = voted_seq; in->xp_deps[peer] = *voted_deps;
+        in->xp_key[peer] = voted_key;
+    }
+    in->xp_acks |= (uint8_t)(1u << peer);
+    uint64_t seq; DepSet deps; uint8_t key;
+    int next = exp_prepare_next_step(r, row, in, &seq, &deps, &key);
+    if (!next) return 0;
+    in->bal = new_ballot; in->status = (uint8_t)next; in->seq = seq; in->deps = deps; in->key = key;
+    refresh_highest_cols(r, row, col, key);
+    if (next == ST_COMMITTED) {                                      /* :637-690 */
+        r->n_xp_commit++;
+        handle_logged_commit_slot(r, row, col);
+    } else if (next == ST_ACCEPTING) {                               /* :692-745 */
+        r->n_xp_accept++;
+        handle_msg_accept_reply(r, r->id, row, col, in->bal);
+    } else {                                                         /* :747-815 */
+        in->avoid_fast_path = 1;
+        if (key == NO_KEY) r->n_xp_noop++; else r->n_xp_pre_accept++;
+        handle_msg_pre_accept_reply(r, r->id, row, col, in->bal, in->seq, &in->deps, 0);
+    }
+    return next;
+}
+
+/* heartbeat.rs:17-125 for HearTimeout { peer = src[g] } (NO_REP: none in this group).  Out: the ExpPrepare { slot, new_ballot }
+ * broadcasts of the call, in column order: n[g], col / bal [W][G]. */
+void orc_ep_heartbeat_timeout(void *h, const uint8_t *src, const uint8_t *exploded, uint32_t *out_n, uint32_t *out_col,
+                              uint64_t *out_bal) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        out_n[g] = 0;
+        if (src[g] == NO_REP || src[g] >= r->population || src[g] == r->id) continue;
+        const uint8_t ts = src[g];
+        /* :35-60 the instances I lead that sit in PreAccept phase: "reply" with ballot 0 */
+        SlotVec mk = {0, 0, 0};
+        for (int row = 0; row < r->population; row++)
+            for (uint32_t c = r->commit_bars[row]; c < r->start_col + r->len[row]; c++) {
+                if (!held(r, row, c)) continue;
+                Inst *in = at(r, row, c);
+                if (in->status == ST_PREACCEPTING && in->has_lbk) sv_push(&mk, (Slot){(uint8_t)row, c});
+            }
+        DepSet none = dep_empty();
+        for (uint32_t i = 0; i < mk.n; i++) {
+            handle_msg_pre_accept_reply(r, ts, mk.v[i].row, mk.v[i].col, 0, 0, &none, exploded ? exploded[g] : 0); drain_exec(r);
+        }
+        free(mk.v);
+        /* :62-107 ExpPrepare for every in-progress instance of that peer's row */
+        const int row = ts;
+        uint32_t n = 0;
+        for (uint32_t c = r->exec_bars[row]; c < r->start_col + r->len[row]; c++) {
+            if (!held(r, row, c)) continue;
+            Inst *in = at(r, row, c);
+            if (in->status >= ST_EXECUTING || (in->has_rbk && in->source != ts)) continue;   /* :73-80 */
+            if (in->status == ST_COMMITTED) continue;                /* :82-84 (`external` is not modelled) */
+            const uint64_t nb = make_greater_ballot(r->id, in->bal);
+            fresh_leader_bk(in);
+            if (n < r->W) { out_col[(size_t)n * G + g] = c; out_bal[(size_t)n * G + g] = nb; }
+            n++;
+        }
+        out_n[g] = n;
+        /* :110-123 my own ExpPrepareReplies */
+        for (uint32_t i = 0; i < n && i < r->W; i++) {
+            const uint32_t c = out_col[(size_t)i * G + g];
+            Inst *in = at(r, row, c);
+            DepSet d = in->deps;
+            handle_msg_exp_prepare_reply(r, r->id, row, c, out_bal[(size_t)i * G + g], in->bal, in->status, in->seq, &d, in->key);
+            drain_exec(r);
+        }
+    }
+}
+
+/* messages.rs:511-574: one ExpPrepare { slot = (row, col), new_ballot } from `peer` per group; the ExpPrepareReply back */
+void orc_ep_handle_exp_prepare(void *h, const uint8_t *flags, const uint8_t *peer, const uint8_t *rows, const uint32_t *col,
+                               const uint64_t *new_ballot, uint8_t *r_flags, uint64_t *r_voted_bal, uint8_t *r_status,
+                               uint64_t *r_seq, uint32_t *r_deps, uint8_t *r_key) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        r_flags[g] = 0; r_voted_bal[g] = 0; r_status[g] = 0; r_seq[g] = 0; r_key[g] = NO_KEY;
+        for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = NONE;
+        if (!(flags[g] & 1)) continue;
+        int row = rows[g];
+        uint32_t c = col[g];
+        if (c < r->start_col || (c < r->start_col + r->len[row] && !held(r, row, c))) continue;
+        while (r->start_col + r->len[row] <= c) row_push(r, row, null_instance());   /* :530-533 */
+        Inst *in = at(r, row, c);
+        if (new_ballot[g] > in->bal) {                               /* :537 */
+            in->has_rbk = 1; in->source = peer[g];
+            r_flags[g] = 1; r_voted_bal[g] = in->bal; r_status[g] = in->status; r_seq[g] = in->seq; r_key[g] = in->key;
+            for (int i = 0; i < cl->R; i++) r_deps[(size_t)i * G + g] = in->deps.c[i];
+        }
+    }
+}
+
+/* The ExpPrepareReplies to the instance (rows[g], col[g]) I am preparing: per peer [R][G] new_ballot, voted_bal, voted_status,
+ * voted_seq, voted_key, voted_deps [R][R][G]; flags[R][G] bit0 = present; peers in `order` order.  Out: decision[g] = the
+ * Status of the message broadcast here (0: none) with its ballot / seq / deps / key. */
+void orc_ep_handle_exp_prepare_replies(void *h, const uint8_t *rows, const uint32_t *col, const uint64_t *new_ballot,
+                                       const uint64_t *voted_bal, const uint8_t *voted_status, const uint64_t *voted_seq,
+                                       const uint32_t *voted_deps, const uint8_t *voted_key, const uint8_t *flags,
+                                       const uint32_t *order, uint8_t *decision, uint64_t *d_ballot, uint64_t *d_seq,
+                                       uint32_t *d_deps, uint8_t *d_key) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G; const int R = cl->R;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        const int row = rows[g];
+        uint32_t ctl = order ? order[g] : CTL_IDENTITY;
+        decision[g] = 0; d_ballot[g] = 0; d_seq[g] = 0; d_key[g] = NO_KEY;
+        for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = NONE;
+        for (int oi = 0; oi < R; oi++) {
+            int p = (int)ctl_order(ctl, oi);
+            if (p == r->id || p >= R) continue;
+            size_t o = (size_t)p * G + g;
+            if (!(flags[o] & 1)) continue;
+            DepSet d = dep_empty();
+            for (int i = 0; i < R; i++) d.c[i] = voted_deps[((size_t)p * R + i) * G + g];
+            int next = handle_msg_exp_prepare_reply(r, (uint8_t)p, row, col[g], new_ballot[o], voted_bal[o], voted_status[o],
+                                                    voted_seq[o], &d, voted_key[o]);
+            drain_exec(r);
+            if (next) {
+                Inst *in = at(r, row, col[g]);
+                decision[g] = (uint8_t)next; d_ballot[g] = new_ballot[o]; d_seq[g] = in->seq; d_key[g] = in->key;
+                for (int i = 0; i < R; i++) d_deps[(size_t)i * G + g] = in->deps.c[i];
+            }
+        }
+    }
+}
+
+/* explicit-prepare bookkeeping, [R][W][G] by col % W like orc_ep_dump: acks, max_bal, avoid_fast_path, the peers with a
+ * voted entry (bitmap) and those entries [R][W][R][G] (+ deps [R][W][R][R][G]); counters[4] = decisions Committed, Accepting,
+ * PreAccepting with a command, PreAccepting as a no-op */
+void orc_ep_xp_dump(void *h, uint8_t *acks, uint64_t *max_bal, uint8_t *avoid, uint8_t *has, uint8_t *vstatus, uint64_t *vseq,
+                    uint8_t *vkey, uint32_t *vdeps, uint64_t *counters) {
+    EpCl *cl = (EpCl *)h;
+    const uint32_t G = cl->G; const int R = cl->R;
+    for (int k = 0; k < 4; k++) counters[k] = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        EpRep *r = &cl->reps[g];
+        const uint32_t W = r->W;
+        counters[0] += r->n_xp_commit; counters[1] += r->n_xp_accept; counters[2] += r->n_xp_pre_accept; counters[3] += r->n_xp_noop;
+        for (int row = 0; row < R; row++) {
+            for (uint32_t w = 0; w < W; w++) {
+                size_t o = ((size_t)row * W + w) * G + g;
+                acks[o] = 0; max_bal[o] = 0; avoid[o] = 0; has[o] = 0;
+                for (int p = 0; p < R; p++) {
+                    size_t q = (((size_t)row * W + w) * R + p) * G + g;
+                    vstatus[q] = 0; vseq[q] = 0; vkey[q] = NO_KEY;
+                    for (int i = 0; i < R; i++) vdeps[((((size_t)row * W + w) * R + p) * R + i) * G + g] = NONE;
+                }
+            }
+            uint32_t end = r->start_col + r->len[row], lo = end > W ? end - W : r->start_col;
+            for (uint32_t c = lo; c < end; c++) {
+                Inst *in = at(r, row, c);
+                size_t o = ((size_t)row * W + (c % W)) * G + g;
+                avoid[o] = in->avoid_fast_path;
+                if (!in->has_lbk) continue;
+                acks[o] = in->xp_acks; max_bal[o] = in->xp_max_bal;
+                for (int p = 0; p < R; p++) {
+                    if (!in->xp_has[p]) continue;
+                    has[o] |= (uint8_t)(1u << p);
+                    size_t q = (((size_t)row * W + (c % W)) * R + p) * G + g;
+                    vstatus[q] = in->xp_status[p]; vseq[q] = in->xp_seq[p]; vkey[q] = in->xp_key[p];
+                    for (int i = 0; i < R; i++) vdeps[((((size_t)row * W + (c % W)) * R + p) * R + i) * G + g] = in->xp_deps[p].c[i];
+                }
+            }
         }
     }
 }

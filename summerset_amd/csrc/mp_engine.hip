@@ -170,8 +170,8 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
         L.store();
     }
     SMR_FOR_EACH_JOB(has_to, src) {                             // leader change: the whole wave on one lane's group
-        const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src);
-        Lane J(P, r, gj, par);
+        const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src), rj = __shfl(r, src);   // (lanes may stand for different replicas)
+        Lane J(P, rj, gj, par);
         J.set_uniform();
         JSTAMP(8);
         J.load();
@@ -478,8 +478,8 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
         if (loaded) L.store();
     }
     SMR_FOR_EACH_JOB(job, src) {
-        const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src);
-        Lane J(P, r, gj, par);
+        const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src), rj = __shfl(r, src);
+        Lane J(P, rj, gj, par);
         J.set_uniform();
         JSTAMP(16);
         J.load();
@@ -951,8 +951,8 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
         }
     }
     SMR_FOR_EACH_JOB(job, src) {
-        const uint32_t gj = __shfl(g, src);
-        Lane J(P, d, gj, par);
+        const uint32_t gj = __shfl(g, src), dj = __shfl(d, src);
+        Lane J(P, dj, gj, par);
         J.set_uniform();
         JSTAMP(24);
         J.load();
@@ -1032,8 +1032,18 @@ __global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__rest
 // wavefront per replica with the group on lane 0, the four rounds back to back with a block barrier in
 // between -- what the bulk launches get from stream order.  Removes three launch boundaries from the
 // stragglers' critical path (a leader change's handlers are serial latency, not bandwidth).
+// (Round 2 tried packing the list tighter, twice.  A listed group's replicas on neighbouring lanes of ONE wavefront:
+// 0.208 ms per tick against 0.157 (profiles/r2w_strag_lanes.log) -- the replicas' handlers are divergent serial chains; on
+// one wavefront they run one after the other, on five they overlap.  STRAG_K listed groups per block, on lanes 0..K-1 of
+// every replica's wavefront: 0.19 ms at K = 2, 0.24 at K = 4 (profiles/r2x_strag_k.log) -- cooperative jobs of the same
+// wavefront queue behind each other.  What both runs showed: bench.py's list is a few dozen groups per tick, nowhere
+// near the 256 blocks; this launch lasts as long as ONE group's leader change takes through its four rounds (~128 us
+// of dependent memory round trips), and neither residency nor packing touches that.)
 #ifndef STRAG_MINW
 #define STRAG_MINW 1
+#endif
+#ifndef STRAG_K
+#define STRAG_K 1      // listed groups per block: lanes 0 .. STRAG_K - 1 of every replica's wavefront
 #endif
 __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpParams *__restrict__ Pp, int par, int lpar,
                                                           const uint8_t *__restrict__ timeout_rep,
@@ -1046,8 +1056,11 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t n = P.slow_n[lpar];
     if (n > P.slow_cap) n = P.slow_cap;
-    for (uint32_t idx = blockIdx.x; idx < n; idx += gridDim.x) {               // uniform per block
-        const bool mine = w < P.R && lane == 0;
+    // entry (pass, lane, block) of the list = (pass * STRAG_K + lane) * gridDim.x + block: every block gets a group before
+    // any block gets a second one
+    for (uint32_t idx0 = blockIdx.x; idx0 < n; idx0 += gridDim.x * STRAG_K) {  // uniform per block
+        const uint32_t idx = idx0 + lane * gridDim.x;
+        const bool mine = w < P.R && lane < STRAG_K && idx < n;
         const uint32_t g = mine ? P.slow_list[idx] : P.G;
         const uint32_t r = w < P.R ? w : 0;
         if (timeout_rep || req_target)
@@ -1436,7 +1449,10 @@ struct smr_mp_cluster {
 
 namespace smr {
 
-constexpr uint32_t SLOW_CAP = 1024;   // groups per tick the side stream takes (4 per block)
+#ifndef SMR_SLOW_CAP
+#define SMR_SLOW_CAP 1024
+#endif
+constexpr uint32_t SLOW_CAP = SMR_SLOW_CAP;   // groups per tick the side stream takes
 
 static bool is_pow2(uint32_t x) { return x && !(x & (x - 1)); }
 
@@ -1768,7 +1784,7 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
     if (own) {                                                  // the list's whole tick: ONE launch on the side stream
         // a wavefront per replica: 5 x 64 lanes for the common populations (the idle wavefronts of a 512-lane block would
         // hold 227 VGPRs each on the CU the bulk kernels share with it)
-        hipLaunchKernelGGL(mp_straggler_tick, dim3(SLOW_CAP / 4), dim3(c->cfg.population <= 5 ? 320 : 512), 0, c->side, c->dp, c->par, c->lpar,
+        hipLaunchKernelGGL(mp_straggler_tick, dim3(256), dim3(c->cfg.population <= 5 ? 320 : 512), 0, c->side, c->dp, c->par, c->lpar,
                            timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, ackctl_dev,
                            do_heartbeat);
         SMR_HIP_TRY(hipGetLastError());

@@ -118,6 +118,8 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
         t._run("cpu", oracle, G=100, R=4, S=3, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=3, preset=True)
         t._run("cpu", oracle, G=70, R=8, S=1, W=32, n_ticks=30, drop_p=0.2, timeout_frac=1.0, hb_every=2, preset=True)
+        # the straggler launch keeps a group's replicas on the lanes of one wavefront: eight of them
+        t._run("cpu", oracle, G=70, R=8, S=1, W=32, n_ticks=30, drop_p=0.2, timeout_frac=1.0, hb_every=2, preset=True, straggler_ticks=3)
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True, commit_extra=2)
 
 
