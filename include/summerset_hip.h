@@ -455,13 +455,15 @@ typedef struct {
     uint8_t execute;           /* 1: run attempt_execution (execution.rs:25-149) behind every handler call, see below */
     uint32_t window;           /* W: columns kept per row, power of two */
     uint32_t n_keys;           /* key space per group, 1..255 */
+    uint32_t recovery;         /* 1: explicit prepare (below); leader bookkeeping for every row.  Not together with execute */
 } smr_ep_cfg;
 
 int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out);
 void smr_ep_replica_destroy(smr_ep_replica *e);
 
 /* One PreAccept / Accept message (or a reply to one) per group: device arrays [G], deps [R][G].
- * flags bit0 = present.  `peer` = sender = the row of `col`.  Replies leave peer / col / key unused. */
+ * flags bit0 = present.  `peer` = sender; `row` = the row of `col` where that is not the sender's (an instance under
+ * explicit prepare, needs recovery = 1), NULL = the sender's row.  Replies leave peer / col / key / row unused. */
 typedef struct {
     uint8_t *flags;
     uint8_t *peer;
@@ -470,6 +472,7 @@ typedef struct {
     uint64_t *seq;
     uint32_t *deps;
     uint8_t *key;
+    uint8_t *row;
 } smr_ep_msg;
 
 /* handle_req_batch for key_dev[g] (+ my own PreAcceptSlot completion = my own reply); `out` receives the
@@ -494,6 +497,52 @@ int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev,
 /* The AcceptReplies to my instance (me, col[g]): ballot / flags [R][G]; committed[g] = 1 if it commits here */
 int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
                                  const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream);
+/* ---- explicit prepare (smr_ep_cfg.recovery = 1): recovery of a suspected peer's row --------------------------------------
+ * replaces: EPaxosReplica::heartbeat_timeout (epaxos/heartbeat.rs:17-125, the protocol part), handle_msg_exp_prepare
+ *           (messages.rs:511-574), handle_msg_exp_prepare_reply (:577-821) with exp_prepare_next_step (dependency.rs:249-327).
+ * exp_prepare_voteds is a HashMap in the reference and next_step takes the last reply of a Status in iteration order as its
+ * representative (dependency.rs:266-273); here: peer-id order, i.e. the highest peer id.
+ * smr_ep_heartbeat_timeout: HearTimeout { peer: src[g] } (SMR_NO_REPLICA: none).  Re-evaluates the fast quorum of every
+ *   PreAccepting instance I lead (a PreAcceptReply with ballot 0 from src, exploded_dev as in smr_ep_propose), then starts
+ *   ExpPrepare for every in-progress instance of src's row and handles my own ExpPrepareReply to each.  Out: the
+ *   ExpPrepare { slot: (src, col), new_ballot } broadcasts in column order, n[g] of them, col / ballot as [W][G].
+ * smr_ep_handle_exp_prepare: one ExpPrepare per group -> the ExpPrepareReply (flags bit0 = sent).
+ * smr_ep_handle_exp_prepare_replies: the replies [R][G] (voted_deps [R][R][G]) to my ExpPrepare of (row[g], col[g]) under
+ *   new_ballot[R][G], peers in order_dev[g] order; decision[g] = the Status of what is broadcast here -- 3: CommitNotice,
+ *   2: Accept, 1: PreAccept (the instance then avoids the fast path) -- with its ballot / seq / deps / key; 0: nothing yet.
+ * The Accept / PreAccept rounds that follow go through the handlers above with `row` set (smr_ep_msg.row, *_replies_at). */
+typedef struct {
+    uint8_t *flags, *peer, *row;
+    uint32_t *col;
+    uint64_t *new_ballot;
+} smr_ep_exp_prepare;
+typedef struct {
+    uint8_t *flags;            /* as a message: [G]; as the replies handed to smr_ep_handle_exp_prepare_replies: [R][G] */
+    uint64_t *voted_bal;
+    uint8_t *voted_status;
+    uint64_t *voted_seq;
+    uint32_t *voted_deps;      /* [R][G] resp. [R][R][G] */
+    uint8_t *voted_key;
+} smr_ep_exp_prepare_reply;
+int smr_ep_heartbeat_timeout(smr_ep_replica *e, const uint8_t *src_dev, const uint8_t *exploded_dev, uint32_t *n_dev, uint32_t *col_dev,
+                             uint64_t *ballot_dev, void *stream);
+int smr_ep_handle_exp_prepare(smr_ep_replica *e, const smr_ep_exp_prepare *msg, const smr_ep_exp_prepare_reply *reply, void *stream);
+int smr_ep_handle_exp_prepare_replies(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *new_ballot_dev,
+                                      const smr_ep_exp_prepare_reply *replies, const uint32_t *order_dev, uint8_t *decision_dev,
+                                      uint64_t *d_ballot_dev, uint64_t *d_seq_dev, uint32_t *d_deps_dev, uint8_t *d_key_dev, void *stream);
+/* the reply handlers for an instance I lead outside my own row (row_dev NULL = my row: the calls above) */
+int smr_ep_handle_pre_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev,
+                                        const uint64_t *ballot_dev, const uint64_t *seq_dev, const uint32_t *deps_dev,
+                                        const uint8_t *flags_dev, const uint32_t *order_dev, const uint8_t *exploded_dev,
+                                        uint8_t *decision_dev, uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream);
+int smr_ep_handle_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                    const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream);
+/* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with
+ * an entry in exp_prepare_voteds (bitmap); those entries [R][W][R][G], deps [R][W][R][R][G]; counters[4] = decisions
+ * Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op */
+int smr_ep_xp_dump(smr_ep_replica *e, uint8_t *acks, uint64_t *max_bal, uint8_t *avoid, uint8_t *has, uint8_t *vstatus, uint64_t *vseq,
+                   uint8_t *vkey, uint32_t *vdeps, uint64_t *counters);
+
 /* host buffers: len / commit_bars [R][G]; per instance [R][W][G] by col % W (cells outside the last W
  * columns of a row read as null); deps [R][W][G][R]; highest_cols [n_keys][R][G]; counters[3] =
  * fast-path commits, slow-path entries, slow-path commits */

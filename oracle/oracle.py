@@ -97,11 +97,15 @@ def _declare(L):
     L.orc_ep_new.restype = vp; L.orc_ep_new.argtypes = [u32, u8, u8, u32, u32, u8]
     L.orc_ep_free.argtypes = [vp]
     L.orc_ep_propose.argtypes = [vp] + [vp] * 6
-    L.orc_ep_handle_pre_accept.argtypes = [vp] + [vp] * 11
-    L.orc_ep_handle_pre_accept_replies.argtypes = [vp] + [vp] * 10
-    L.orc_ep_handle_accept.argtypes = [vp] + [vp] * 9
-    L.orc_ep_handle_accept_replies.argtypes = [vp] + [vp] * 5
-    L.orc_ep_handle_commit_notice.argtypes = [vp] + [vp] * 7
+    L.orc_ep_handle_pre_accept.argtypes = [vp] + [vp] * 12
+    L.orc_ep_handle_pre_accept_replies.argtypes = [vp] + [vp] * 11
+    L.orc_ep_handle_accept.argtypes = [vp] + [vp] * 10
+    L.orc_ep_handle_accept_replies.argtypes = [vp] + [vp] * 6
+    L.orc_ep_handle_commit_notice.argtypes = [vp] + [vp] * 8
+    L.orc_ep_heartbeat_timeout.argtypes = [vp] + [vp] * 5
+    L.orc_ep_handle_exp_prepare.argtypes = [vp] + [vp] * 11
+    L.orc_ep_handle_exp_prepare_replies.argtypes = [vp] + [vp] * 15
+    L.orc_ep_xp_dump.argtypes = [vp] + [vp] * 9
     L.orc_ep_dump.argtypes = [vp] + [vp] * 12
     L.orc_ep_set_execute.argtypes = [vp, u8]
     L.orc_ep_exec_dump.argtypes = [vp] + [vp] * 4
@@ -426,36 +430,72 @@ class EpOracle:
         lib().orc_ep_propose(self.h, _p(key), _p(exploded), _p(m["flags"]), _p(m["col"]), _p(m["seq"]), _p(m["deps"]))
         return m
 
-    def handle_pre_accept(self, flags, peer, col, ballot, seq, deps, key):
+    def handle_pre_accept(self, flags, peer, col, ballot, seq, deps, key, row=None):
+        """row: the slot's row where it is not the sender's (an instance under explicit prepare); None = peer"""
         G, R = self.G, self.R
         r = dict(flags=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64), seq=np.zeros(G, np.uint64),
                  deps=np.zeros((R, G), np.uint32))
         lib().orc_ep_handle_pre_accept(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key),
-                                       _p(r["flags"]), _p(r["ballot"]), _p(r["seq"]), _p(r["deps"]))
+                                       _p(r["flags"]), _p(r["ballot"]), _p(r["seq"]), _p(r["deps"]), _p(row))
         return r
 
-    def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None):
+    def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None, row=None):
         G, R = self.G, self.R
         assert deps.shape == (R, R, G) and ballot.shape == (R, G)
         r = dict(decision=np.zeros(G, np.uint8), seq=np.zeros(G, np.uint64), deps=np.zeros((R, G), np.uint32))
         lib().orc_ep_handle_pre_accept_replies(self.h, _p(col), _p(ballot), _p(seq), _p(deps), _p(flags), _p(order),
-                                               _p(exploded), _p(r["decision"]), _p(r["seq"]), _p(r["deps"]))
+                                               _p(exploded), _p(r["decision"]), _p(r["seq"]), _p(r["deps"]), _p(row))
         return r
 
-    def handle_accept(self, flags, peer, col, ballot, seq, deps, key):
+    def handle_accept(self, flags, peer, col, ballot, seq, deps, key, row=None):
         G = self.G
         r = dict(flags=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64))
         lib().orc_ep_handle_accept(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key),
-                                   _p(r["flags"]), _p(r["ballot"]))
+                                   _p(r["flags"]), _p(r["ballot"]), _p(row))
         return r
 
-    def handle_commit_notice(self, flags, peer, col, ballot, seq, deps, key):
-        lib().orc_ep_handle_commit_notice(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key))
+    def handle_commit_notice(self, flags, peer, col, ballot, seq, deps, key, row=None):
+        lib().orc_ep_handle_commit_notice(self.h, _p(flags), _p(peer), _p(col), _p(ballot), _p(seq), _p(deps), _p(key), _p(row))
 
-    def handle_accept_replies(self, col, ballot, flags, order=None):
+    def handle_accept_replies(self, col, ballot, flags, order=None, row=None):
         r = dict(committed=np.zeros(self.G, np.uint8))
-        lib().orc_ep_handle_accept_replies(self.h, _p(col), _p(ballot), _p(flags), _p(order), _p(r["committed"]))
+        lib().orc_ep_handle_accept_replies(self.h, _p(col), _p(ballot), _p(flags), _p(order), _p(r["committed"]), _p(row))
         return r
+
+    # ---- explicit prepare (heartbeat.rs:17-125, messages.rs:511-821) ----
+    def heartbeat_timeout(self, src, exploded=None):
+        """HearTimeout { peer: src[g] } (0xFF: none) -> the ExpPrepare broadcasts: n [G], col / ballot [W, G]"""
+        G, W = self.G, self.W
+        o = dict(n=np.zeros(G, np.uint32), col=np.zeros((W, G), np.uint32), ballot=np.zeros((W, G), np.uint64))
+        lib().orc_ep_heartbeat_timeout(self.h, _p(src), _p(exploded), _p(o["n"]), _p(o["col"]), _p(o["ballot"]))
+        return o
+
+    def handle_exp_prepare(self, flags, peer, row, col, new_ballot):
+        G, R = self.G, self.R
+        r = dict(flags=np.zeros(G, np.uint8), voted_bal=np.zeros(G, np.uint64), status=np.zeros(G, np.uint8),
+                 seq=np.zeros(G, np.uint64), deps=np.zeros((R, G), np.uint32), key=np.zeros(G, np.uint8))
+        lib().orc_ep_handle_exp_prepare(self.h, _p(flags), _p(peer), _p(row), _p(col), _p(new_ballot), _p(r["flags"]),
+                                        _p(r["voted_bal"]), _p(r["status"]), _p(r["seq"]), _p(r["deps"]), _p(r["key"]))
+        return r
+
+    def handle_exp_prepare_replies(self, row, col, new_ballot, voted_bal, voted_status, voted_seq, voted_deps, voted_key, flags,
+                                   order=None):
+        G, R = self.G, self.R
+        assert voted_deps.shape == (R, R, G) and new_ballot.shape == (R, G)
+        r = dict(decision=np.zeros(G, np.uint8), ballot=np.zeros(G, np.uint64), seq=np.zeros(G, np.uint64),
+                 deps=np.zeros((R, G), np.uint32), key=np.zeros(G, np.uint8))
+        lib().orc_ep_handle_exp_prepare_replies(self.h, _p(row), _p(col), _p(new_ballot), _p(voted_bal), _p(voted_status),
+                                                _p(voted_seq), _p(voted_deps), _p(voted_key), _p(flags), _p(order),
+                                                _p(r["decision"]), _p(r["ballot"]), _p(r["seq"]), _p(r["deps"]), _p(r["key"]))
+        return r
+
+    def xp_dump(self):
+        G, R, W = self.G, self.R, self.W
+        d = dict(acks=np.zeros((R, W, G), np.uint8), max_bal=np.zeros((R, W, G), np.uint64), avoid=np.zeros((R, W, G), np.uint8),
+                 has=np.zeros((R, W, G), np.uint8), vstatus=np.zeros((R, W, R, G), np.uint8), vseq=np.zeros((R, W, R, G), np.uint64),
+                 vkey=np.zeros((R, W, R, G), np.uint8), vdeps=np.zeros((R, W, R, R, G), np.uint32), counters=np.zeros(4, np.uint64))
+        lib().orc_ep_xp_dump(self.h, *[_p(d[k]) for k in ("acks", "max_bal", "avoid", "has", "vstatus", "vseq", "vkey", "vdeps", "counters")])
+        return d
 
     def dump(self):
         G, R, W, K = self.G, self.R, self.W, self.n_keys

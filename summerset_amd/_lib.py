@@ -113,11 +113,19 @@ class RaftAppendReply(C.Structure):
 
 class EpCfg(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("population", C.c_uint8), ("me", C.c_uint8), ("optimized_quorum", C.c_uint8),
-                ("execute", C.c_uint8), ("window", C.c_uint32), ("n_keys", C.c_uint32)]
+                ("execute", C.c_uint8), ("window", C.c_uint32), ("n_keys", C.c_uint32), ("recovery", C.c_uint32)]
 
 
 class EpMsg(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("flags", "peer", "col", "ballot", "seq", "deps", "key")]
+    _fields_ = [(n, C.c_void_p) for n in ("flags", "peer", "col", "ballot", "seq", "deps", "key", "row")]
+
+
+class EpExpPrepare(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("flags", "peer", "row", "col", "new_ballot")]
+
+
+class EpExpPrepareReply(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("flags", "voted_bal", "voted_status", "voted_seq", "voted_deps", "voted_key")]
 
 
 class RspCfg(C.Structure):
@@ -245,6 +253,12 @@ SYMBOLS = [
     ("smr_ep_handle_commit_notice", _i, [_vp, C.POINTER(EpMsg), _vp]),
     ("smr_ep_handle_pre_accept_replies", _i, [_vp] + [_vp] * 11),
     ("smr_ep_handle_accept_replies", _i, [_vp] + [_vp] * 6),
+    ("smr_ep_handle_pre_accept_replies_at", _i, [_vp] + [_vp] * 12),
+    ("smr_ep_handle_accept_replies_at", _i, [_vp] + [_vp] * 7),
+    ("smr_ep_heartbeat_timeout", _i, [_vp] + [_vp] * 6),
+    ("smr_ep_handle_exp_prepare", _i, [_vp, C.POINTER(EpExpPrepare), C.POINTER(EpExpPrepareReply), _vp]),
+    ("smr_ep_handle_exp_prepare_replies", _i, [_vp, _vp, _vp, _vp, C.POINTER(EpExpPrepareReply)] + [_vp] * 7),
+    ("smr_ep_xp_dump", _i, [_vp] + [_vp] * 9),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),

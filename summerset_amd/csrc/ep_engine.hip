@@ -11,6 +11,13 @@
 // WAL completions are inline (LS-1 rule 0).  A request batch is one Put on one key of a small key
 // space, which is all the dependency tracking looks at.
 //
+// Explicit prepare (smr_ep_cfg.recovery = 1): heartbeat_timeout (heartbeat.rs:17-125: the fast-quorum re-evaluation of
+// the PreAccepting instances I lead, ExpPrepare for every in-progress instance of the suspected peer's row, my own
+// ExpPrepareReply), handle_msg_exp_prepare (messages.rs:511-574), handle_msg_exp_prepare_reply (:577-821) with
+// exp_prepare_next_step (dependency.rs:249-327).  A replica then leads instances outside its own row: the leader
+// bookkeeping (PreAcceptReplies held, exp_prepare_voteds) exists for every row, and the handlers take the slot's row apart
+// from the message's sender.  Rare, latency-bound work: these kernels are plain lane = group loops over a row's ring.
+//
 // Dependency-graph execution (execution.rs:25-149 attempt_execution, :152-211 handle_cmd_result,
 // durability.rs:136-160) is a separate kernel, ep_execute_kernel, that the entry points launch
 // behind their own kernel when smr_ep_cfg.execute is set (see the comment on EpExec).
@@ -41,14 +48,37 @@ struct EpView {
     uint32_t *len, *commit_bars;         // [R][G]
     uint32_t *my_nulls;                  // [G] null instances currently in my own row (first_null_slot need not scan at 0)
     uint32_t *hc;                        // [n_keys][R][G]
-    unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits
+    unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits; explicit prepare outcomes:
+                                         // Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op
+    // explicit prepare (recovery != 0; pa_seq / pa_deps then hold every row: [R][W][R][G] / [R][W][R][R][G])
+    uint32_t recovery;
+    uint8_t *avoid;                      // [R][W][G] avoid_fast_path
+    uint8_t *xp_acks, *xp_has;           // [R][W][G] exp_prepare_acks, the peers with an entry in exp_prepare_voteds
+    uint64_t *xp_max;                    // [R][W][G] exp_prepare_max_bal
+    uint8_t *xv_status, *xv_key;         // [R][W][R][G] exp_prepare_voteds
+    uint64_t *xv_seq;
+    uint32_t *xv_deps;                   // [R][W][R][R][G]
 };
 
 struct EpLane {
     const EpView &v;
     const uint32_t g;
-    unsigned int n_fast = 0, n_slow = 0, n_acc = 0;
+    unsigned int n_fast = 0, n_slow = 0, n_acc = 0, n_xc = 0, n_xa = 0, n_xp = 0, n_xn = 0;
     __device__ __forceinline__ EpLane(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
+    // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
+    __device__ __forceinline__ size_t pw(uint32_t row, uint32_t col) const { return (size_t)(v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
+    __device__ __forceinline__ size_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
+    __device__ __forceinline__ size_t pd_ix(uint32_t row, uint32_t col, uint32_t peer, uint32_t k) const {
+        return ((pw(row, col) * v.R + peer) * v.R + k) * v.G + g;
+    }
+    __device__ __forceinline__ size_t xv_ix(uint32_t row, uint32_t col, uint32_t peer) const {
+        return (((size_t)row * v.W + (col & v.Wmask)) * v.R + peer) * v.G + g;
+    }
+    __device__ __forceinline__ void fresh_leader_bk(size_t i) const {        // request.rs:48-57, heartbeat.rs:88-97
+        v.bk[i] = (uint8_t)(v.bk[i] | 1u);
+        v.pa_acks[i] = 0; v.acc_acks[i] = 0;
+        if (v.recovery) { v.xp_acks[i] = 0; v.xp_has[i] = 0; v.xp_max[i] = 0; }
+    }
     __device__ __forceinline__ size_t ix(uint32_t row, uint32_t col) const { return ((size_t)row * v.W + (col & v.Wmask)) * v.G + g; }
     __device__ __forceinline__ size_t dx(uint32_t row, uint32_t col, uint32_t i) const {
         return (((size_t)row * v.W + (col & v.Wmask)) * v.R + i) * v.G + g;
@@ -100,9 +130,8 @@ struct EpLane {
         }
         v.commit_bars[(size_t)row * v.G + g] = cb;
     }
-    // messages.rs:348-436 on my instance (me, col)
-    __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t col, uint64_t ballot) {
-        const uint32_t row = v.me;
+    // messages.rs:348-436 on an instance I lead
+    __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot) {
         if (!held(row, col)) return;
         const size_t i = ix(row, col);
         if (v.status[i] != EST_ACCEPTING || v.bal[i] != ballot || !(v.bk[i] & 1)) return;   // :371-376
@@ -116,22 +145,22 @@ struct EpLane {
             logged_commit_slot(row, col);
         }
     }
-    // messages.rs:96-270 on my instance (me, col); rd = the reply's DepSet
-    __device__ __forceinline__ void pre_accept_reply(uint32_t peer, uint32_t col, uint64_t ballot, uint64_t rseq,
+    // messages.rs:96-270 on an instance I lead; rd = the reply's DepSet
+    __device__ __forceinline__ void pre_accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot, uint64_t rseq,
                                                      const uint32_t (&rd)[EMAXR], uint32_t exploded) {
-        const uint32_t row = v.me, R = v.R;
+        const uint32_t R = v.R;
         if (!held(row, col)) return;                                             // :125-127
         const size_t i = ix(row, col);
         if (v.status[i] != EST_PREACCEPTING || (ballot > 0 && v.bal[i] != ballot) || !(v.bk[i] & 1)) return;   // :129-134
         uint32_t acks = v.pa_acks[i];
         if ((acks >> peer) & 1u) return;                                         // :136-138
-        const uint32_t w = col & v.Wmask;
         if (ballot > 0) {                                                        // :141-144
-            v.pa_seq[((size_t)w * R + peer) * v.G + g] = rseq;
-            for (uint32_t k = 0; k < R; k++) v.pa_deps[(((size_t)w * R + peer) * R + k) * v.G + g] = rd[k];
+            v.pa_seq[ps_ix(row, col, peer)] = rseq;
+            for (uint32_t k = 0; k < R; k++) v.pa_deps[pd_ix(row, col, peer, k)] = rd[k];
             acks |= 1u << peer;
             v.pa_acks[i] = (uint8_t)acks;
         }
+        const bool avoid = v.recovery && v.avoid[i];                             // dependency.rs:196
         // dependency.rs:175-240 fast_quorum_eligibility
         const uint32_t all_cnt = __popc(acks);
         if (all_cnt < v.simple_q) return;
@@ -140,10 +169,10 @@ struct EpLane {
 #pragma unroll
         for (int p = 0; p < EMAXR; p++) {
             const bool on = (uint32_t)p < R && ((acks >> p) & 1u);
-            ps[p] = on ? v.pa_seq[((size_t)w * R + p) * v.G + g] : 0;
+            ps[p] = on ? v.pa_seq[ps_ix(row, col, p)] : 0;
 #pragma unroll
             for (int k = 0; k < EMAXR; k++)
-                pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] : EP_NONE;
+                pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[pd_ix(row, col, p, k)] : EP_NONE;
         }
         // dependency.rs:333-367 get_enough_identical: size of the largest class of equal (seq, deps)
         uint32_t max_cnt = 0; int best = -1;
@@ -167,7 +196,7 @@ struct EpLane {
             if ((uint32_t)p < R && !((acks >> p) & 1u) && (uint32_t)p != v.me && ((exploded >> p) & 1u)) bad++;
         uint64_t dseq = 0; uint32_t dd[EMAXR];
         int next = 0;
-        if (max_cnt >= v.super_q) {                                              // fast path
+        if (!avoid && max_cnt >= v.super_q) {                                    // fast path
             next = EST_COMMITTED;
             dseq = 0;
 #pragma unroll
@@ -178,7 +207,7 @@ struct EpLane {
 #pragma unroll
                 for (int p = 0; p < EMAXR; p++) if (p == best) dd[k] = pd[p][k];
             }
-        } else if (max_cnt + (R - bad - all_cnt) < v.super_q) {                  // :221-236 slow path: union / max
+        } else if (avoid || max_cnt + (R - bad - all_cnt) < v.super_q) {         // :221-236 slow path: union / max
             next = EST_ACCEPTING;
 #pragma unroll
             for (int k = 0; k < EMAXR; k++) dd[k] = EP_NONE;
@@ -208,12 +237,104 @@ struct EpLane {
         } else {                                                                 // :209-262
             v.status[i] = EST_ACCEPTING;
             n_slow++;
-            accept_reply(v.me, col, v.bal[i]);                                   // durability.rs:78-83
+            accept_reply(v.me, row, col, v.bal[i]);                              // durability.rs:78-83
         }
     }
+    // messages.rs:577-821 with exp_prepare_next_step (dependency.rs:249-327) and the WAL completions of what it logs;
+    // returns the Status of the message it broadcasts for (row, col) under new_ballot (the instance holds its seq / deps /
+    // reqs), 0 = none
+    __device__ __forceinline__ int exp_prepare_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t nb, uint64_t vbal,
+                                                     uint32_t vstatus, uint64_t vseq, const uint32_t (&vd)[EMAXR], uint32_t vkey) {
+        const uint32_t R = v.R;
+        if (!held(row, col)) return 0;                                           // :599-601
+        const size_t i = ix(row, col);
+        if (nb <= v.bal[i] || !(v.bk[i] & 1)) return 0;                          // :603-605
+        uint32_t acks = v.xp_acks[i], has = v.xp_has[i];
+        if ((acks >> peer) & 1u) return 0;                                       // :607-609
+        uint64_t mx = v.xp_max[i];
+        if (vbal > mx) { has = 0; mx = vbal; v.xp_max[i] = mx; }                 // :612-615
+        if (vbal >= mx) {                                                        // :616-621
+            has |= 1u << peer;
+            const size_t q = xv_ix(row, col, peer);
+            v.xv_status[q] = (uint8_t)vstatus; v.xv_seq[q] = vseq; v.xv_key[q] = (uint8_t)vkey;
+            for (uint32_t k = 0; k < R; k++) v.xv_deps[(q / v.G * R + k) * v.G + g] = vd[k];
+        }
+        acks |= 1u << peer;
+        v.xp_acks[i] = (uint8_t)acks; v.xp_has[i] = (uint8_t)has;
+        if ((uint32_t)__popc(acks) < v.simple_q) return 0;                       // dependency.rs:257-260
+        // the voted entries, in registers
+        uint32_t xs[EMAXR], xk[EMAXR]; uint64_t xq[EMAXR]; uint32_t xd[EMAXR][EMAXR];
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++) {
+            const bool on = (uint32_t)p < R && ((has >> p) & 1u);
+            const size_t q = xv_ix(row, col, on ? p : 0);
+            xs[p] = on ? v.xv_status[q] : 0xFFu; xq[p] = on ? v.xv_seq[q] : 0; xk[p] = on ? v.xv_key[q] : EP_NO_KEY;
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++) xd[p][k] = (on && (uint32_t)k < R) ? v.xv_deps[(q / v.G * R + k) * v.G + g] : EP_NONE;
+        }
+        int has_commit = -1, has_accept = -1, has_pre = -1;                      // :264-273: the highest peer id of a status
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++) {
+            if (xs[p] == EST_COMMITTED) has_commit = p;
+            else if (xs[p] == EST_ACCEPTING) has_accept = p;
+            else if (xs[p] == EST_PREACCEPTING) has_pre = p;
+        }
+        int next = 0, pick = -1;
+        if (has_commit >= 0) { next = EST_COMMITTED; pick = has_commit; }
+        else if (has_accept >= 0) { next = EST_ACCEPTING; pick = has_accept; }
+        else {
+            if (mx == (uint64_t)(row + 1)) {                                     // :286-311 make_default_ballot(slot_row)
+                uint32_t n = 0;
+#pragma unroll
+                for (int p = 0; p < EMAXR; p++) n += ((uint32_t)p != row && xs[p] == EST_PREACCEPTING) ? 1u : 0u;
+                if (n + 1 >= v.simple_q && n > 0) {
+#pragma unroll
+                    for (int p = 0; p < EMAXR; p++) {                            // a class of >= simple_q equal entries: at most one
+                        if ((uint32_t)p == row || xs[p] != EST_PREACCEPTING || pick >= 0) continue;
+                        uint32_t same = 0;
+#pragma unroll
+                        for (int q = 0; q < EMAXR; q++) {
+                            bool eq = (uint32_t)q != row && xs[q] == EST_PREACCEPTING && xq[q] == xq[p] && xk[q] == xk[p];
+#pragma unroll
+                            for (int k = 0; k < EMAXR; k++) eq = eq && xd[q][k] == xd[p][k];
+                            same += eq ? 1u : 0u;
+                        }
+                        if (same >= v.simple_q) { next = EST_ACCEPTING; pick = p; }
+                    }
+                }
+            }
+            if (!next) { next = EST_PREACCEPTING; pick = has_pre; }              // :316-327 (pick < 0: the no-op)
+        }
+        uint64_t dseq = 1; uint32_t dkey = EP_NO_KEY; uint32_t dd[EMAXR];
+#pragma unroll
+        for (int k = 0; k < EMAXR; k++) dd[k] = EP_NONE;
+#pragma unroll
+        for (int p = 0; p < EMAXR; p++)
+            if (p == pick) {
+                dseq = xq[p]; dkey = xk[p];
+#pragma unroll
+                for (int k = 0; k < EMAXR; k++) dd[k] = xd[p][k];
+            }
+        v.bal[i] = nb; v.status[i] = (uint8_t)next; v.seq[i] = dseq; v.key[i] = (uint8_t)dkey;
+        for (uint32_t k = 0; k < R; k++) {
+            uint32_t x = EP_NONE;
+#pragma unroll
+            for (int kk = 0; kk < EMAXR; kk++) if ((uint32_t)kk == k) x = dd[kk];
+            v.deps[dx(row, col, k)] = x;
+        }
+        refresh_highest_cols(row, col, dkey);
+        if (next == EST_COMMITTED) { n_xc++; logged_commit_slot(row, col); }     // :637-690
+        else if (next == EST_ACCEPTING) { n_xa++; accept_reply(v.me, row, col, nb); }   // :692-745
+        else {                                                                   // :747-815
+            v.avoid[i] = 1;
+            if (dkey == EP_NO_KEY) n_xn++; else n_xp++;
+            pre_accept_reply(v.me, row, col, nb, dseq, dd, 0u);
+        }
+        return next;
+    }
     __device__ __forceinline__ void flush() {
-        unsigned int c[3] = {n_fast, n_slow, n_acc};
-        for (int k = 0; k < 3; k++) {
+        unsigned int c[7] = {n_fast, n_slow, n_acc, n_xc, n_xa, n_xp, n_xn};
+        for (int k = 0; k < (v.recovery ? 7 : 3); k++) {
             unsigned int x = c[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
             if (__lane_id() == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
@@ -436,11 +557,10 @@ __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const u
                 v.deps[L.dx(row, col, q)] = x;
             }
             L.refresh_highest_cols(row, col, k);
-            v.bk[i] = (uint8_t)(v.bk[i] | 1u);                                   // fresh LeaderBookkeeping
-            v.pa_acks[i] = 0; v.acc_acks[i] = 0;
+            L.fresh_leader_bk(i);
             v.status[i] = EST_PREACCEPTING;
             of = 1; oc = col; os = seq;
-            L.pre_accept_reply(v.me, col, bal, seq, d, exploded ? exploded[g] : 0u);
+            L.pre_accept_reply(v.me, row, col, bal, seq, d, exploded ? exploded[g] : 0u);
         }
         m_flags[g] = of; m_col[g] = oc; m_seq[g] = os;
 #pragma unroll
@@ -457,7 +577,8 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
                                                           const uint64_t *__restrict__ ballot, const uint64_t *__restrict__ seq,
                                                           const uint32_t *__restrict__ deps, const uint8_t *__restrict__ key,
                                                           uint8_t *__restrict__ r_flags, uint64_t *__restrict__ r_ballot,
-                                                          uint64_t *__restrict__ r_seq, uint32_t *__restrict__ r_deps) {
+                                                          uint64_t *__restrict__ r_seq, uint32_t *__restrict__ r_deps,
+                                                          const uint8_t *__restrict__ rows) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     if (g < v.G) {
@@ -466,9 +587,9 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
 #pragma unroll
         for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
         if (flags[g] & 1) {
-            const uint32_t row = peer[g], c = col[g], k = key[g];
+            const uint32_t src = peer[g], row = rows ? rows[g] : src, c = col[g], k = key[g];   // (rows: an instance under explicit prepare)
             const uint64_t b = ballot[g];
-            if (!(c < L.len(row) && !L.held(row, c))) {                          // col < start_col analogue
+            if (row < v.R && !(c < L.len(row) && !L.held(row, c))) {             // col < start_col analogue
                 while (L.len(row) <= c) L.push_null(row);                        // :33-36
                 const size_t i = L.ix(row, c);
                 if (b >= v.bal[i]) {                                             // :40
@@ -501,9 +622,9 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
                         L.logged_commit_slot(row, c);                            // durability.rs:104-135
                     } else {
                         const uint32_t bk = v.bk[i];
-                        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (row << 2));        // replica_bk.source = peer
+                        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (src << 2));        // replica_bk.source = peer
                         if (bk & 1u) {                                           // durability.rs:25 / :78: leader_bk first
-                            if (MODE == 1) L.accept_reply(v.me, c, b); else L.pre_accept_reply(v.me, c, b, s, in, 0u);
+                            if (MODE == 1) L.accept_reply(v.me, row, c, b); else L.pre_accept_reply(v.me, row, c, b, s, in, 0u);
                         } else {
                             of = 1; ob = b; os = s;
 #pragma unroll
@@ -527,7 +648,7 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
 // bit p of acks): 0 = undecided, else the Status to enter with (dseq, dd)
 template <int NR>
 __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uint64_t (&ps)[NR], const uint32_t (&pd)[NR][NR],
-                                       uint32_t exploded, uint64_t &dseq, uint32_t (&dd)[NR]) {
+                                       uint32_t exploded, bool avoid, uint64_t &dseq, uint32_t (&dd)[NR]) {
     const uint32_t R = v.R, all_cnt = __popc(acks);
     if (all_cnt < v.simple_q) return 0;
     // dependency.rs:333-367 get_enough_identical: the largest class of equal (seq, deps)
@@ -545,7 +666,7 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
         }
         if (same > max_cnt) { max_cnt = same; best = p; }
     }
-    if (max_cnt >= v.super_q) {                                              // fast path
+    if (!avoid && max_cnt >= v.super_q) {                                    // fast path
         dseq = 0;
 #pragma unroll
         for (int p = 0; p < NR; p++) if (p == best) dseq = ps[p];
@@ -561,7 +682,7 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 #pragma unroll
     for (int p = 0; p < NR; p++)
         if ((uint32_t)p < R && !((acks >> p) & 1u) && (uint32_t)p != v.me && ((exploded >> p) & 1u)) bad++;
-    if (max_cnt + (R - bad - all_cnt) >= v.super_q) return 0;                // :221-236 may still be reached
+    if (!avoid && max_cnt + (R - bad - all_cnt) >= v.super_q) return 0;      // :221-236 may still be reached
     dseq = 0;                                                                // slow path: max of seqs, union of deps
 #pragma unroll
     for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
@@ -590,11 +711,11 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
                                                                     const uint32_t *__restrict__ order,
                                                                     const uint8_t *__restrict__ exploded,
                                                                     uint8_t *__restrict__ decision, uint64_t *__restrict__ d_seq,
-                                                                    uint32_t *__restrict__ d_deps) {
+                                                                    uint32_t *__restrict__ d_deps, const uint8_t *__restrict__ rows) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     if (g < v.G) {
-        const uint32_t c = col[g], row = v.me, R = v.R, w = c & v.Wmask;
+        const uint32_t c = col[g], row = (rows && rows[g] < v.R) ? rows[g] : v.me, R = v.R;
         const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
         const uint32_t ex = exploded ? exploded[g] : 0u;
         const bool h = L.held(row, c);
@@ -613,14 +734,15 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
         uint32_t st = h ? v.status[i] : 0u, acks = h ? v.pa_acks[i] : 0u;
         const uint64_t b = h ? v.bal[i] : 0ull;
         const uint32_t bk = h ? v.bk[i] : 0u;
+        const bool avoid = h && v.recovery && v.avoid[i];
         const uint32_t before = st, acks0 = acks;
         uint64_t ps[NR]; uint32_t pd[NR][NR];
 #pragma unroll
         for (int p = 0; p < NR; p++) {
             const bool on = (acks >> p) & 1u;
-            ps[p] = on ? v.pa_seq[((size_t)w * R + p) * v.G + g] : 0ull;
+            ps[p] = on ? v.pa_seq[L.ps_ix(row, c, p)] : 0ull;
 #pragma unroll
-            for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] : EP_NONE;
+            for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[L.pd_ix(row, c, p, k)] : EP_NONE;
         }
         uint64_t dseq = 0; uint32_t dd[NR];
 #pragma unroll
@@ -644,7 +766,7 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
                     }
                 acks |= 1u << p;
             }
-            const int next = ep_eval<NR>(v, acks, ps, pd, ex, dseq, dd);
+            const int next = ep_eval<NR>(v, acks, ps, pd, ex, avoid, dseq, dd);
             if (next) st = (uint32_t)next;
         }
         // write back: new replies, the ack mask, the decision
@@ -652,10 +774,10 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
 #pragma unroll
         for (int p = 0; p < NR; p++)
             if ((fresh >> p) & 1u) {
-                v.pa_seq[((size_t)w * R + p) * v.G + g] = ps[p];
+                v.pa_seq[L.ps_ix(row, c, p)] = ps[p];
 #pragma unroll
                 for (int k = 0; k < NR; k++)
-                    if ((uint32_t)k < R) v.pa_deps[(((size_t)w * R + p) * R + k) * v.G + g] = pd[p][k];
+                    if ((uint32_t)k < R) v.pa_deps[L.pd_ix(row, c, p, k)] = pd[p][k];
             }
         if (fresh) v.pa_acks[i] = (uint8_t)acks;
         uint8_t dec = 0;
@@ -665,7 +787,7 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
             for (int k = 0; k < NR; k++) if ((uint32_t)k < R) v.deps[L.dx(row, c, k)] = dd[k];
             v.status[i] = (uint8_t)st;
             if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c); dec = EST_COMMITTED; }   // :158-206
-            else { L.n_slow++; L.accept_reply(v.me, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
+            else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
         }
         decision[g] = dec; d_seq[g] = dec ? dseq : 0ull;
 #pragma unroll
@@ -678,11 +800,11 @@ __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, 
                                                                 const uint64_t *__restrict__ ballot,
                                                                 const uint8_t *__restrict__ flags,
                                                                 const uint32_t *__restrict__ order,
-                                                                uint8_t *__restrict__ committed) {
+                                                                uint8_t *__restrict__ committed, const uint8_t *__restrict__ rows) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     if (g < v.G) {
-        const uint32_t c = col[g], row = v.me, R = v.R;
+        const uint32_t c = col[g], row = (rows && rows[g] < v.R) ? rows[g] : v.me, R = v.R;
         const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
         const bool h = L.held(row, c);
         const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
@@ -691,9 +813,134 @@ __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, 
             if (p == v.me || p >= R) continue;
             const size_t o = (size_t)p * v.G + g;
             if (!(flags[o] & 1)) continue;
-            L.accept_reply(p, c, ballot[o]);
+            L.accept_reply(p, row, c, ballot[o]);
         }
         committed[g] = (h && before == EST_ACCEPTING && v.status[L.ix(row, c)] >= EST_COMMITTED) ? 1 : 0;
+    }
+    L.flush();
+}
+
+// ---- explicit prepare --------------------------------------------------------------------------------------------------
+// heartbeat.rs:17-125 for HearTimeout { peer = src[g] } (SMR_NO_REPLICA: none in this group)
+__global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView v, const uint8_t *__restrict__ src,
+                                                                   const uint8_t *__restrict__ exploded, uint32_t *__restrict__ out_n,
+                                                                   uint32_t *__restrict__ out_col, uint64_t *__restrict__ out_bal) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        const uint32_t ts = src[g], R = v.R;
+        uint32_t n = 0;
+        if (ts < R && ts != v.me) {
+            const uint32_t ex = exploded ? exploded[g] : 0u;
+            uint32_t none[EMAXR];
+#pragma unroll
+            for (int k = 0; k < EMAXR; k++) none[k] = EP_NONE;
+            // :35-60 every PreAccepting instance I lead, from its row's commit bar: "reply" with ballot 0
+            for (uint32_t row = 0; row < R; row++) {
+                const uint32_t end = L.len(row);
+                for (uint32_t c = v.commit_bars[(size_t)row * v.G + g]; c < end; c++) {
+                    if (!L.held(row, c)) continue;
+                    const size_t i = L.ix(row, c);
+                    if (v.status[i] == EST_PREACCEPTING && (v.bk[i] & 1)) L.pre_accept_reply(ts, row, c, 0, 0, none, ex);
+                }
+            }
+            // :62-107 ExpPrepare for every in-progress instance of that peer's row (exec bars: 0 without execution)
+            const uint32_t row = ts, end = L.len(row);
+            for (uint32_t c = end > v.W ? end - v.W : 0u; c < end; c++) {
+                const size_t i = L.ix(row, c);
+                const uint32_t st = v.status[i], bk = v.bk[i];
+                if (st >= EST_EXECUTING || ((bk & 2u) && ((bk >> 2) & 7u) != ts)) continue;   // :73-80
+                if (st == EST_COMMITTED) continue;                               // :82-84
+                const uint64_t nb = (((v.bal[i] >> 8) + 1) << 8) | (uint64_t)(v.me + 1);   // make_greater_ballot, mod.rs:500-508
+                L.fresh_leader_bk(i);
+                out_col[(size_t)n * v.G + g] = c; out_bal[(size_t)n * v.G + g] = nb;
+                n++;
+            }
+            // :110-123 my own ExpPrepareReplies
+            for (uint32_t k = 0; k < n; k++) {
+                const uint32_t c = out_col[(size_t)k * v.G + g];
+                const size_t i = L.ix(row, c);
+                uint32_t d[EMAXR];
+#pragma unroll
+                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? v.deps[L.dx(row, c, q)] : EP_NONE;
+                L.exp_prepare_reply(v.me, row, c, out_bal[(size_t)k * v.G + g], v.bal[i], v.status[i], v.seq[i], d, v.key[i]);
+            }
+        }
+        out_n[g] = n;
+    }
+    L.flush();
+}
+
+// messages.rs:511-574: one ExpPrepare { slot = (row, col), new_ballot } from `peer` per group; the ExpPrepareReply back
+__global__ __launch_bounds__(256) void ep_exp_prepare_kernel(const EpView v, const uint8_t *__restrict__ flags,
+                                                             const uint8_t *__restrict__ peer, const uint8_t *__restrict__ rows,
+                                                             const uint32_t *__restrict__ col, const uint64_t *__restrict__ nbal,
+                                                             uint8_t *__restrict__ r_flags, uint64_t *__restrict__ r_vbal,
+                                                             uint8_t *__restrict__ r_status, uint64_t *__restrict__ r_seq,
+                                                             uint32_t *__restrict__ r_deps, uint8_t *__restrict__ r_key) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    EpLane L(v, g);
+    uint8_t of = 0, ost = 0, ok = EP_NO_KEY; uint64_t ob = 0, os = 0;
+    uint32_t d[EMAXR];
+#pragma unroll
+    for (int q = 0; q < EMAXR; q++) d[q] = EP_NONE;
+    if (flags[g] & 1) {
+        const uint32_t row = rows[g], c = col[g];
+        if (row < v.R && !(c < L.len(row) && !L.held(row, c))) {
+            while (L.len(row) <= c) L.push_null(row);                            // :530-533
+            const size_t i = L.ix(row, c);
+            if (nbal[g] > v.bal[i]) {                                            // :537
+                v.bk[i] = (uint8_t)((v.bk[i] & 1u) | 2u | ((uint32_t)peer[g] << 2));   // replica_bk.source = peer
+                of = 1; ob = v.bal[i]; ost = v.status[i]; os = v.seq[i]; ok = v.key[i];
+#pragma unroll
+                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < v.R ? v.deps[L.dx(row, c, q)] : EP_NONE;
+            }
+        }
+    }
+    r_flags[g] = of; r_vbal[g] = ob; r_status[g] = ost; r_seq[g] = os; r_key[g] = ok;
+#pragma unroll
+    for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < v.R) r_deps[(size_t)q * v.G + g] = d[q];
+}
+
+// The ExpPrepareReplies to the instance (rows[g], col[g]) I am preparing, one handle_msg_exp_prepare_reply each, peers in
+// order[g] order; decision[g] = the Status of the message broadcast here (0: none) with its ballot / seq / deps / key
+__global__ __launch_bounds__(256) void ep_exp_prepare_replies_kernel(const EpView v, const uint8_t *__restrict__ rows,
+                                                                     const uint32_t *__restrict__ col, const uint64_t *__restrict__ nbal,
+                                                                     const uint64_t *__restrict__ vbal, const uint8_t *__restrict__ vstatus,
+                                                                     const uint64_t *__restrict__ vseq, const uint32_t *__restrict__ vdeps,
+                                                                     const uint8_t *__restrict__ vkey, const uint8_t *__restrict__ flags,
+                                                                     const uint32_t *__restrict__ order, uint8_t *__restrict__ decision,
+                                                                     uint64_t *__restrict__ d_bal, uint64_t *__restrict__ d_seq,
+                                                                     uint32_t *__restrict__ d_deps, uint8_t *__restrict__ d_key) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    EpLane L(v, g < v.G ? g : 0);
+    if (g < v.G) {
+        const uint32_t row = rows[g], c = col[g], R = v.R;
+        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
+        uint8_t dec = 0, dk = EP_NO_KEY; uint64_t db = 0, ds = 0;
+        uint32_t dd[EMAXR];
+#pragma unroll
+        for (int q = 0; q < EMAXR; q++) dd[q] = EP_NONE;
+        for (uint32_t oi = 0; oi < R && row < R; oi++) {
+            const uint32_t p = (ctl >> (3 * oi)) & 7u;
+            if (p == v.me || p >= R) continue;
+            const size_t o = (size_t)p * v.G + g;
+            if (!(flags[o] & 1)) continue;
+            uint32_t d[EMAXR];
+#pragma unroll
+            for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? vdeps[((size_t)p * R + q) * v.G + g] : EP_NONE;
+            const int next = L.exp_prepare_reply(p, row, c, nbal[o], vbal[o], vstatus[o], vseq[o], d, vkey[o]);
+            if (next) {
+                const size_t i = L.ix(row, c);
+                dec = (uint8_t)next; db = nbal[o]; ds = v.seq[i]; dk = v.key[i];
+#pragma unroll
+                for (int q = 0; q < EMAXR; q++) dd[q] = (uint32_t)q < R ? v.deps[L.dx(row, c, q)] : EP_NONE;
+            }
+        }
+        decision[g] = dec; d_bal[g] = db; d_seq[g] = ds; d_key[g] = dk;
+#pragma unroll
+        for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < R) d_deps[(size_t)q * v.G + g] = dd[q];
     }
     L.flush();
 }
@@ -723,7 +970,14 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     ecarve(a, v.status, R * W * G, dry); ecarve(a, v.key, R * W * G, dry); ecarve(a, v.bk, R * W * G, dry);
     ecarve(a, v.pa_acks, R * W * G, dry); ecarve(a, v.acc_acks, R * W * G, dry);
     ecarve(a, v.deps, R * W * R * G, dry);
-    ecarve(a, v.pa_seq, W * R * G, dry); ecarve(a, v.pa_deps, W * R * R * G, dry);
+    const size_t PR = e->cfg.recovery ? R : 1;                                   // reply tables: every row / my row only
+    ecarve(a, v.pa_seq, PR * W * R * G, dry); ecarve(a, v.pa_deps, PR * W * R * R * G, dry);
+    if (e->cfg.recovery) {
+        ecarve(a, v.avoid, R * W * G, dry); ecarve(a, v.xp_acks, R * W * G, dry); ecarve(a, v.xp_has, R * W * G, dry);
+        ecarve(a, v.xp_max, R * W * G, dry);
+        ecarve(a, v.xv_status, R * W * R * G, dry); ecarve(a, v.xv_key, R * W * R * G, dry); ecarve(a, v.xv_seq, R * W * R * G, dry);
+        ecarve(a, v.xv_deps, R * W * R * R * G, dry);
+    }
     ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry);
     ecarve(a, v.hc, K * R * G, dry);
     ecarve(a, v.counters, SMR_CTR_WORDS, dry);
@@ -750,6 +1004,10 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
         return fail(SMR_ERR_ARG, "epaxos: window must be a power of two >= 8");
     if (cfg->n_keys == 0 || cfg->n_keys > 255) return fail(SMR_ERR_ARG, "epaxos: n_keys must be in 1..255");
     if (cfg->execute > 1) return fail(SMR_ERR_ARG, "epaxos: execute must be 0 or 1");
+    if (cfg->recovery > 1) return fail(SMR_ERR_ARG, "epaxos: recovery must be 0 or 1");
+    if (cfg->recovery && cfg->execute)
+        return fail(SMR_ERR_ARG, "epaxos: explicit prepare and dependency-graph execution are not built to run together (a HearTimeout "
+                                 "can move several commit bars in one call; the execution kernel follows one)");
     if (cfg->execute && (uint64_t)cfg->population * cfg->window > 32768)
         return fail(SMR_ERR_ARG, "epaxos: execution keeps 15-bit ring cell ids: population * window must be <= 32768");
     smr_ep_replica *e = new smr_ep_replica();
@@ -764,6 +1022,7 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     EpView &v = e->v;
     const uint32_t R = cfg->population;
     v.G = cfg->n_groups; v.W = cfg->window; v.Wmask = cfg->window - 1; v.R = R; v.me = cfg->me; v.n_keys = cfg->n_keys;
+    v.recovery = cfg->recovery;
     v.simple_q = R / 2 + 1;                                                      // mod.rs:693
     v.super_q = cfg->optimized_quorum ? R / 2 + (R / 2 + 1) / 2 : (R / 2) * 2;   // mod.rs:694-698
     err = hipMemset(e->arena.base, 0, e->arena.size);
@@ -808,15 +1067,16 @@ static int ep_acceptor(smr_ep_replica *e, int mode, const smr_ep_msg *m, const s
         return fail(SMR_ERR_ARG, "epaxos: null argument");
     if (mode != 2 && (!r || !r->flags || !r->ballot || (mode == 0 && (!r->seq || !r->deps))))
         return fail(SMR_ERR_ARG, "epaxos: null reply buffers");
+    if (m->row && !e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: a message with a row of its own needs smr_ep_cfg.recovery");
     if (mode == 2)
         hipLaunchKernelGGL(ep_acceptor_kernel<2>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
-                           m->key, (uint8_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr);
+                           m->key, (uint8_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, m->row);
     else if (mode == 1)
         hipLaunchKernelGGL(ep_acceptor_kernel<1>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
-                           m->key, r->flags, r->ballot, r->seq, r->deps);
+                           m->key, r->flags, r->ballot, r->seq, r->deps, m->row);
     else
         hipLaunchKernelGGL(ep_acceptor_kernel<0>, EP_GRID(e), e->v, m->flags, m->peer, m->col, m->ballot, m->seq, m->deps,
-                           m->key, r->flags, r->ballot, r->seq, r->deps);
+                           m->key, r->flags, r->ballot, r->seq, r->deps, m->row);
     SMR_HIP_TRY(hipGetLastError());
     return ep_execute(e, stream);
 }
@@ -833,28 +1093,127 @@ int smr_ep_handle_commit_notice(smr_ep_replica *e, const smr_ep_msg *msg, void *
     return ep_acceptor(e, 2, msg, nullptr, stream);
 }
 
+int smr_ep_handle_pre_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev,
+                                        const uint64_t *ballot_dev, const uint64_t *seq_dev, const uint32_t *deps_dev,
+                                        const uint8_t *flags_dev, const uint32_t *order_dev, const uint8_t *exploded_dev,
+                                        uint8_t *decision_dev, uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream) {
+    if (!e || !col_dev || !ballot_dev || !seq_dev || !deps_dev || !flags_dev || !decision_dev || !d_seq_dev || !d_deps_dev)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (row_dev && !e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: replies to an instance outside my row need smr_ep_cfg.recovery");
+    if (e->v.R <= 5)
+        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<5>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev,
+                           order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev, row_dev);
+    else
+        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<EMAXR>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev,
+                           flags_dev, order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev, row_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return ep_execute(e, stream);
+}
+
 int smr_ep_handle_pre_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
                                      const uint64_t *seq_dev, const uint32_t *deps_dev, const uint8_t *flags_dev,
                                      const uint32_t *order_dev, const uint8_t *exploded_dev, uint8_t *decision_dev,
                                      uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream) {
-    if (!e || !col_dev || !ballot_dev || !seq_dev || !deps_dev || !flags_dev || !decision_dev || !d_seq_dev || !d_deps_dev)
-        return fail(SMR_ERR_ARG, "epaxos: null argument");
-    if (e->v.R <= 5)
-        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<5>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev,
-                           order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
-    else
-        hipLaunchKernelGGL(ep_pre_accept_replies_kernel<EMAXR>, EP_GRID(e), e->v, col_dev, ballot_dev, seq_dev, deps_dev,
-                           flags_dev, order_dev, exploded_dev, decision_dev, d_seq_dev, d_deps_dev);
+    return smr_ep_handle_pre_accept_replies_at(e, nullptr, col_dev, ballot_dev, seq_dev, deps_dev, flags_dev, order_dev, exploded_dev,
+                                               decision_dev, d_seq_dev, d_deps_dev, stream);
+}
+
+int smr_ep_handle_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                    const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream) {
+    if (!e || !col_dev || !ballot_dev || !flags_dev || !committed_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (row_dev && !e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: replies to an instance outside my row need smr_ep_cfg.recovery");
+    hipLaunchKernelGGL(ep_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, flags_dev, order_dev, committed_dev, row_dev);
     SMR_HIP_TRY(hipGetLastError());
     return ep_execute(e, stream);
 }
 
 int smr_ep_handle_accept_replies(smr_ep_replica *e, const uint32_t *col_dev, const uint64_t *ballot_dev,
                                  const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream) {
-    if (!e || !col_dev || !ballot_dev || !flags_dev || !committed_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
-    hipLaunchKernelGGL(ep_accept_replies_kernel, EP_GRID(e), e->v, col_dev, ballot_dev, flags_dev, order_dev, committed_dev);
+    return smr_ep_handle_accept_replies_at(e, nullptr, col_dev, ballot_dev, flags_dev, order_dev, committed_dev, stream);
+}
+
+int smr_ep_heartbeat_timeout(smr_ep_replica *e, const uint8_t *src_dev, const uint8_t *exploded_dev, uint32_t *n_dev, uint32_t *col_dev,
+                             uint64_t *ballot_dev, void *stream) {
+    if (!e || !src_dev || !n_dev || !col_dev || !ballot_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: created without recovery");
+    hipLaunchKernelGGL(ep_heartbeat_timeout_kernel, EP_GRID(e), e->v, src_dev, exploded_dev, n_dev, col_dev, ballot_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_ep_handle_exp_prepare(smr_ep_replica *e, const smr_ep_exp_prepare *m, const smr_ep_exp_prepare_reply *r, void *stream) {
+    if (!e || !m || !r || !m->flags || !m->peer || !m->row || !m->col || !m->new_ballot || !r->flags || !r->voted_bal ||
+        !r->voted_status || !r->voted_seq || !r->voted_deps || !r->voted_key)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: created without recovery");
+    hipLaunchKernelGGL(ep_exp_prepare_kernel, EP_GRID(e), e->v, m->flags, m->peer, m->row, m->col, m->new_ballot, r->flags,
+                       r->voted_bal, r->voted_status, r->voted_seq, r->voted_deps, r->voted_key);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_ep_handle_exp_prepare_replies(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *new_ballot_dev,
+                                      const smr_ep_exp_prepare_reply *replies, const uint32_t *order_dev, uint8_t *decision_dev,
+                                      uint64_t *d_ballot_dev, uint64_t *d_seq_dev, uint32_t *d_deps_dev, uint8_t *d_key_dev, void *stream) {
+    if (!e || !row_dev || !col_dev || !new_ballot_dev || !replies || !replies->flags || !replies->voted_bal || !replies->voted_status ||
+        !replies->voted_seq || !replies->voted_deps || !replies->voted_key || !decision_dev || !d_ballot_dev || !d_seq_dev ||
+        !d_deps_dev || !d_key_dev)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: created without recovery");
+    hipLaunchKernelGGL(ep_exp_prepare_replies_kernel, EP_GRID(e), e->v, row_dev, col_dev, new_ballot_dev, replies->voted_bal,
+                       replies->voted_status, replies->voted_seq, replies->voted_deps, replies->voted_key, replies->flags, order_dev,
+                       decision_dev, d_ballot_dev, d_seq_dev, d_deps_dev, d_key_dev);
     SMR_HIP_TRY(hipGetLastError());
     return ep_execute(e, stream);
+}
+
+int smr_ep_xp_dump(smr_ep_replica *e, uint8_t *acks, uint64_t *max_bal, uint8_t *avoid, uint8_t *has, uint8_t *vstatus, uint64_t *vseq,
+                   uint8_t *vkey, uint32_t *vdeps, uint64_t *counters) {
+    if (!e || !acks || !max_bal || !avoid || !has || !vstatus || !vseq || !vkey || !vdeps || !counters)
+        return fail(SMR_ERR_ARG, "epaxos: null argument");
+    if (!e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: created without recovery");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const EpView &v = e->v;
+    const size_t G = v.G, W = v.W, R = v.R, N = R * W * G;
+    std::vector<uint32_t> len(R * G);
+    std::vector<uint8_t> a(N), h(N), av(N), bk(N), xs(N * R), xk(N * R);
+    std::vector<uint64_t> mx(N), xq(N * R);
+    std::vector<uint32_t> xd(N * R * R);
+#define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
+    D2H(len.data(), v.len, R * G * 4); D2H(a.data(), v.xp_acks, N); D2H(h.data(), v.xp_has, N); D2H(av.data(), v.avoid, N);
+    D2H(bk.data(), v.bk, N); D2H(mx.data(), v.xp_max, N * 8);
+    D2H(xs.data(), v.xv_status, N * R); D2H(xk.data(), v.xv_key, N * R); D2H(xq.data(), v.xv_seq, N * R * 8);
+    D2H(xd.data(), v.xv_deps, N * R * R * 4);
+#undef D2H
+    unsigned long long c[8];
+    SMR_HIP_TRY(ctr_read(v.counters, 7, c));
+    for (int k = 0; k < 4; k++) counters[k] = c[3 + k];
+    // canonical form, like smr_ep_dump: cells outside the last W columns of a row, instances without leader bookkeeping and
+    // peers without a voted entry read as empty
+    for (size_t row = 0; row < R; row++)
+        for (size_t w = 0; w < W; w++)
+            for (size_t g = 0; g < G; g++) {
+                const size_t o = (row * W + w) * G + g;
+                const uint32_t end = len[row * G + g], lo = end > W ? end - (uint32_t)W : 0;
+                bool live = false;
+                if (end > lo) {
+                    uint32_t cc = (lo & ~(uint32_t)(W - 1)) | (uint32_t)w;
+                    if (cc < lo) cc += (uint32_t)W;
+                    live = cc < end;
+                }
+                const bool lb = live && (bk[o] & 1);
+                avoid[o] = live ? av[o] : 0; acks[o] = lb ? a[o] : 0; max_bal[o] = lb ? mx[o] : 0; has[o] = lb ? h[o] : 0;
+                for (size_t p = 0; p < R; p++) {
+                    const size_t q = ((row * W + w) * R + p) * G + g;
+                    const bool on = lb && ((h[o] >> p) & 1);
+                    vstatus[q] = on ? xs[q] : 0; vseq[q] = on ? xq[q] : 0; vkey[q] = on ? xk[q] : 0xFF;
+                    for (size_t i = 0; i < R; i++) {
+                        const size_t z = (((row * W + w) * R + p) * R + i) * G + g;
+                        vdeps[z] = on ? xd[z] : 0xFFFFFFFFu;
+                    }
+                }
+            }
+    return SMR_OK;
 }
 
 int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
@@ -873,7 +1232,7 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
     D2H(pa.data(), v.pa_acks, R * W * G); D2H(ac.data(), v.acc_acks, R * W * G);
     D2H(deps.data(), v.deps, R * W * R * G * 4);
     unsigned long long c[4];
-    SMR_HIP_TRY(ctr_read(v.counters, 4, c));
+    SMR_HIP_TRY(ctr_read(v.counters, 4, c));   // (explicit-prepare outcomes: smr_ep_xp_dump)
 #undef D2H
     hb->counters[0] = c[0]; hb->counters[1] = c[1]; hb->counters[2] = c[2];
     // canonical form: only the last W columns of each row are state; deps as [row][w][g][i]

@@ -5,7 +5,11 @@ Mirrors `EPaxosReplica` (src/protocols/epaxos/mod.rs) on the pre-execution path:
 fast-quorum decision), `handle_msg_accept`, `handle_msg_accept_reply`,
 `handle_msg_commit_notice`; with `execute=True` every call is followed by the
 dependency-graph execution the reference runs from `handle_logged_commit_slot`
-(`attempt_execution`, `handle_cmd_result`; state read back by `exec_dump`).  Thin: every
+(`attempt_execution`, `handle_cmd_result`; state read back by `exec_dump`); with
+`recovery=True` the explicit prepare of a suspected peer's row: `heartbeat_timeout`,
+`handle_msg_exp_prepare`, `handle_msg_exp_prepare_reply` (heartbeat.rs:17-125,
+messages.rs:511-821), and `row=` on the other handlers for the instances a replica then
+leads outside its own row.  Thin: every
 method is one C-ABI call; messages are device tensors with one entry per group,
 DepSets are int32 tensors [R, G] with -1 (0xFFFFFFFF) = None.
 """
@@ -14,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import EpCfg, EpDumpBufs, EpMsg, check, stream_ptr
+from ._lib import EpCfg, EpDumpBufs, EpExpPrepare, EpExpPrepareReply, EpMsg, check, stream_ptr
 
 NONE, NO_KEY = 0xFFFFFFFF, 0xFF
 
@@ -24,10 +28,10 @@ def _ptr(t):
 
 
 class EPaxosReplicaGroup:
-    def __init__(self, n_groups, population=5, me=0, window=32, n_keys=64, optimized_quorum=True, execute=False):
+    def __init__(self, n_groups, population=5, me=0, window=32, n_keys=64, optimized_quorum=True, execute=False, recovery=False):
         self.G, self.R, self.me, self.W, self.K = int(n_groups), int(population), int(me), int(window), int(n_keys)
-        self.execute = bool(execute)
-        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), int(self.execute), self.W, self.K)
+        self.execute, self.recovery = bool(execute), bool(recovery)
+        cfg = EpCfg(self.G, self.R, self.me, int(optimized_quorum), int(self.execute), self.W, self.K, int(self.recovery))
         h = C.c_void_p()
         self._L = _lib.load()
         check(self._L.smr_ep_replica_create(C.byref(cfg), C.byref(h)))
@@ -50,7 +54,7 @@ class EPaxosReplicaGroup:
 
     @staticmethod
     def _msg(d):
-        return EpMsg(*[_ptr(d.get(k)) for k in ("flags", "peer", "col", "ballot", "seq", "deps", "key")])
+        return EpMsg(*[_ptr(d.get(k)) for k in ("flags", "peer", "col", "ballot", "seq", "deps", "key", "row")])
 
     def handle_req_batch(self, key, exploded=None, stream=None):
         """propose key[g] (0xFF = nothing) per group; returns the PreAccept tensors (flags, col, seq, deps)"""
@@ -73,23 +77,78 @@ class EPaxosReplicaGroup:
     def handle_msg_commit_notice(self, msg, stream=None):
         check(self._L.smr_ep_handle_commit_notice(self._h, C.byref(self._msg(msg)), stream_ptr(stream)))
 
-    def handle_msg_pre_accept_reply(self, col, ballot, seq, deps, flags, order=None, exploded=None, stream=None):
-        """replies [R, G] (deps [R, R, G]) to my instance (me, col[g]); returns decision / seq / deps"""
+    def handle_msg_pre_accept_reply(self, col, ballot, seq, deps, flags, order=None, exploded=None, row=None, stream=None):
+        """replies [R, G] (deps [R, R, G]) to the instance (row[g], col[g]) I lead (row None: my own row); returns
+        decision / seq / deps"""
         import torch
         dev, G, R = flags.device, self.G, self.R
         r = dict(decision=torch.zeros(G, dtype=torch.uint8, device=dev), seq=torch.zeros(G, dtype=torch.int64, device=dev),
                  deps=torch.zeros((R, G), dtype=torch.int32, device=dev))
-        check(self._L.smr_ep_handle_pre_accept_replies(self._h, _ptr(col), _ptr(ballot), _ptr(seq), _ptr(deps), _ptr(flags),
-                                                       _ptr(order), _ptr(exploded), _ptr(r["decision"]), _ptr(r["seq"]),
-                                                       _ptr(r["deps"]), stream_ptr(stream)))
+        check(self._L.smr_ep_handle_pre_accept_replies_at(self._h, _ptr(row), _ptr(col), _ptr(ballot), _ptr(seq), _ptr(deps),
+                                                          _ptr(flags), _ptr(order), _ptr(exploded), _ptr(r["decision"]),
+                                                          _ptr(r["seq"]), _ptr(r["deps"]), stream_ptr(stream)))
         return r
 
-    def handle_msg_accept_reply(self, col, ballot, flags, order=None, stream=None):
+    def handle_msg_accept_reply(self, col, ballot, flags, order=None, row=None, stream=None):
         import torch
         r = dict(committed=torch.zeros(self.G, dtype=torch.uint8, device=flags.device))
-        check(self._L.smr_ep_handle_accept_replies(self._h, _ptr(col), _ptr(ballot), _ptr(flags), _ptr(order),
-                                                   _ptr(r["committed"]), stream_ptr(stream)))
+        check(self._L.smr_ep_handle_accept_replies_at(self._h, _ptr(row), _ptr(col), _ptr(ballot), _ptr(flags), _ptr(order),
+                                                      _ptr(r["committed"]), stream_ptr(stream)))
         return r
+
+    # ---- explicit prepare (recovery=True) ----
+    def heartbeat_timeout(self, src, exploded=None, stream=None):
+        """HearTimeout { peer: src[g] } (0xFF: none) -> the ExpPrepare broadcasts: n [G], col / ballot [W, G]"""
+        import torch
+        dev, G, W = src.device, self.G, self.W
+        o = dict(n=torch.zeros(G, dtype=torch.int32, device=dev), col=torch.zeros((W, G), dtype=torch.int32, device=dev),
+                 ballot=torch.zeros((W, G), dtype=torch.int64, device=dev))
+        check(self._L.smr_ep_heartbeat_timeout(self._h, _ptr(src), _ptr(exploded), _ptr(o["n"]), _ptr(o["col"]), _ptr(o["ballot"]),
+                                               stream_ptr(stream)))
+        return o
+
+    def _xp_reply_bufs(self, dev, per_peer):
+        import torch
+        G, R = self.G, self.R
+        lead = (R,) if per_peer else ()
+        return dict(flags=torch.zeros(lead + (G,), dtype=torch.uint8, device=dev), voted_bal=torch.zeros(lead + (G,), dtype=torch.int64, device=dev),
+                    voted_status=torch.zeros(lead + (G,), dtype=torch.uint8, device=dev),
+                    voted_seq=torch.zeros(lead + (G,), dtype=torch.int64, device=dev),
+                    voted_deps=torch.zeros(lead + (R, G), dtype=torch.int32, device=dev),
+                    voted_key=torch.zeros(lead + (G,), dtype=torch.uint8, device=dev))
+
+    @staticmethod
+    def _xp_reply(d):
+        return EpExpPrepareReply(*[_ptr(d[k]) for k in ("flags", "voted_bal", "voted_status", "voted_seq", "voted_deps", "voted_key")])
+
+    def handle_msg_exp_prepare(self, msg, stream=None):
+        """msg: flags / peer / row / col / new_ballot [G] -> the ExpPrepareReply tensors"""
+        out = self._xp_reply_bufs(msg["flags"].device, False)
+        m = EpExpPrepare(*[_ptr(msg[k]) for k in ("flags", "peer", "row", "col", "new_ballot")])
+        check(self._L.smr_ep_handle_exp_prepare(self._h, C.byref(m), C.byref(self._xp_reply(out)), stream_ptr(stream)))
+        return out
+
+    def handle_msg_exp_prepare_reply(self, row, col, new_ballot, replies, order=None, stream=None):
+        """replies: dict of [R, G] tensors (voted_deps [R, R, G]) to my ExpPrepare of (row[g], col[g]) -> decision / ballot /
+        seq / deps / key of what is broadcast"""
+        import torch
+        dev, G, R = row.device, self.G, self.R
+        r = dict(decision=torch.zeros(G, dtype=torch.uint8, device=dev), ballot=torch.zeros(G, dtype=torch.int64, device=dev),
+                 seq=torch.zeros(G, dtype=torch.int64, device=dev), deps=torch.zeros((R, G), dtype=torch.int32, device=dev),
+                 key=torch.zeros(G, dtype=torch.uint8, device=dev))
+        check(self._L.smr_ep_handle_exp_prepare_replies(self._h, _ptr(row), _ptr(col), _ptr(new_ballot), C.byref(self._xp_reply(replies)),
+                                                        _ptr(order), _ptr(r["decision"]), _ptr(r["ballot"]), _ptr(r["seq"]),
+                                                        _ptr(r["deps"]), _ptr(r["key"]), stream_ptr(stream)))
+        return r
+
+    def xp_dump(self):
+        G, R, W = self.G, self.R, self.W
+        d = dict(acks=np.zeros((R, W, G), np.uint8), max_bal=np.zeros((R, W, G), np.uint64), avoid=np.zeros((R, W, G), np.uint8),
+                 has=np.zeros((R, W, G), np.uint8), vstatus=np.zeros((R, W, R, G), np.uint8), vseq=np.zeros((R, W, R, G), np.uint64),
+                 vkey=np.zeros((R, W, R, G), np.uint8), vdeps=np.zeros((R, W, R, R, G), np.uint32), counters=np.zeros(4, np.uint64))
+        check(self._L.smr_ep_xp_dump(self._h, *[d[k].ctypes.data_as(C.c_void_p) for k in
+                                                ("acks", "max_bal", "avoid", "has", "vstatus", "vseq", "vkey", "vdeps", "counters")]))
+        return d
 
     def dump(self):
         G, R, W, K = self.G, self.R, self.W, self.K

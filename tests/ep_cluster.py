@@ -36,30 +36,56 @@ class NumpyEngine:
         self._after_call()
         return self._n(o, dict(flags=np.uint8, col=np.uint32, seq=np.uint64, deps=np.uint32))
 
-    def handle_pre_accept(self, **m):
-        o = self.e.handle_msg_pre_accept({k: self._t(v) for k, v in m.items()})
+    def _m(self, flags, peer, col, ballot, seq, deps, key, row):
+        m = dict(flags=flags, peer=peer, col=col, ballot=ballot, seq=seq, deps=deps, key=key, row=row)
+        return {k: self._t(v) for k, v in m.items() if v is not None}
+
+    def handle_pre_accept(self, flags, peer, col, ballot, seq, deps, key, row=None):
+        o = self.e.handle_msg_pre_accept(self._m(flags, peer, col, ballot, seq, deps, key, row))
         self._after_call()
         return self._n(o, dict(flags=np.uint8, ballot=np.uint64, seq=np.uint64, deps=np.uint32))
 
-    def handle_accept(self, **m):
-        o = self.e.handle_msg_accept({k: self._t(v) for k, v in m.items()})
+    def handle_accept(self, flags, peer, col, ballot, seq, deps, key, row=None):
+        o = self.e.handle_msg_accept(self._m(flags, peer, col, ballot, seq, deps, key, row))
         self._after_call()
         return self._n(o, dict(flags=np.uint8, ballot=np.uint64))
 
-    def handle_commit_notice(self, **m):
-        self.e.handle_msg_commit_notice({k: self._t(v) for k, v in m.items()})
+    def handle_commit_notice(self, flags, peer, col, ballot, seq, deps, key, row=None):
+        self.e.handle_msg_commit_notice(self._m(flags, peer, col, ballot, seq, deps, key, row))
         self._after_call()
 
-    def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None):
+    def handle_pre_accept_replies(self, col, ballot, seq, deps, flags, order=None, exploded=None, row=None):
         o = self.e.handle_msg_pre_accept_reply(self._t(col), self._t(ballot), self._t(seq), self._t(deps), self._t(flags),
-                                               self._t(order), self._t(exploded))
+                                               self._t(order), self._t(exploded), self._t(row))
         self._after_call()
         return self._n(o, dict(decision=np.uint8, seq=np.uint64, deps=np.uint32))
 
-    def handle_accept_replies(self, col, ballot, flags, order=None):
-        o = self.e.handle_msg_accept_reply(self._t(col), self._t(ballot), self._t(flags), self._t(order))
+    def handle_accept_replies(self, col, ballot, flags, order=None, row=None):
+        o = self.e.handle_msg_accept_reply(self._t(col), self._t(ballot), self._t(flags), self._t(order), self._t(row))
         self._after_call()
         return self._n(o, dict(committed=np.uint8))
+
+    def heartbeat_timeout(self, src, exploded=None):
+        o = self.e.heartbeat_timeout(self._t(src), self._t(exploded))
+        return self._n(o, dict(n=np.uint32, col=np.uint32, ballot=np.uint64))
+
+    def handle_exp_prepare(self, flags, peer, row, col, new_ballot):
+        o = self.e.handle_msg_exp_prepare(dict(flags=self._t(flags), peer=self._t(peer), row=self._t(row), col=self._t(col),
+                                               new_ballot=self._t(new_ballot)))
+        r = self._n(o, dict(flags=np.uint8, voted_bal=np.uint64, voted_status=np.uint8, voted_seq=np.uint64, voted_deps=np.uint32,
+                            voted_key=np.uint8))
+        return dict(flags=r["flags"], voted_bal=r["voted_bal"], status=r["voted_status"], seq=r["voted_seq"], deps=r["voted_deps"],
+                    key=r["voted_key"])
+
+    def handle_exp_prepare_replies(self, row, col, new_ballot, voted_bal, voted_status, voted_seq, voted_deps, voted_key, flags,
+                                   order=None):
+        rep = dict(flags=self._t(flags), voted_bal=self._t(voted_bal), voted_status=self._t(voted_status), voted_seq=self._t(voted_seq),
+                   voted_deps=self._t(voted_deps), voted_key=self._t(voted_key))
+        o = self.e.handle_msg_exp_prepare_reply(self._t(row), self._t(col), self._t(new_ballot), rep, self._t(order))
+        return self._n(o, dict(decision=np.uint8, ballot=np.uint64, seq=np.uint64, deps=np.uint32, key=np.uint8))
+
+    def xp_dump(self):
+        return self.e.xp_dump()
 
     def dump(self):
         return self.e.dump()
@@ -138,3 +164,135 @@ def zipf_keys(rng, R, G, n_keys, p_propose=0.9):
     k = rng.choice(n_keys, (R, G), p=z).astype(np.uint8)
     k[rng.random((R, G)) >= p_propose] = NO_KEY
     return k
+
+
+# ---- explicit prepare: a command leader dies mid-instance, the others recover its row ------------------------------------
+def crash_tick(reps, dead, keys, rng, G):
+    """replica `dead` proposes keys[g]; per group the run is cut at a seeded point: (0) PreAccepts reach a random subset of
+    the peers and nothing comes back; (1) all replies come back and the leader decides, a slow-path Accept reaches a random
+    subset; (2) the instance commits at the leader and the CommitNotice reaches a random subset.  After this call `dead`
+    is never driven again.  Returns the cut per group."""
+    R = len(reps)
+    u8 = lambda v: np.full(G, v, np.uint8)
+    cut = rng.integers(0, 3, G)
+    pa = reps[dead].propose(np.ascontiguousarray(keys))
+    reach = {q: rng.random(G) < 0.6 for q in range(R) if q != dead}
+    rep = {}
+    for q in range(R):
+        if q == dead:
+            continue
+        fl = pa["flags"].copy()
+        fl[(cut == 0) & ~reach[q]] = 0
+        rep[q] = reps[q].handle_pre_accept(flags=fl, peer=u8(dead), col=pa["col"], ballot=np.full(G, dead + 1, np.uint64),
+                                           seq=pa["seq"], deps=np.ascontiguousarray(pa["deps"]), key=np.ascontiguousarray(keys))
+    ballot = np.zeros((R, G), np.uint64); seq = np.zeros((R, G), np.uint64)
+    deps = np.full((R, R, G), N, np.uint32); flags = np.zeros((R, G), np.uint8)
+    for q in rep:
+        flags[q] = rep[q]["flags"] * (cut > 0); ballot[q] = rep[q]["ballot"]; seq[q] = rep[q]["seq"]; deps[q] = rep[q]["deps"]
+    dec = reps[dead].handle_pre_accept_replies(pa["col"], ballot, seq, deps, flags)
+    slow = (dec["decision"] == 2)
+    aflags = np.zeros((R, G), np.uint8); aballot = np.zeros((R, G), np.uint64)
+    for q in range(R):
+        if q == dead:
+            continue
+        fl = (slow & ((cut == 2) | reach[q])).astype(np.uint8)
+        ar = reps[q].handle_accept(flags=fl, peer=u8(dead), col=pa["col"], ballot=np.full(G, dead + 1, np.uint64), seq=dec["seq"],
+                                   deps=np.ascontiguousarray(dec["deps"]), key=np.ascontiguousarray(keys))
+        aflags[q] = ar["flags"] * (cut == 2); aballot[q] = ar["ballot"]
+    acc = reps[dead].handle_accept_replies(pa["col"], aballot, aflags)
+    committed = ((dec["decision"] == 3) | (acc["committed"] == 1)) & (cut == 2)
+    for q in range(R):
+        if q == dead:
+            continue
+        reps[q].handle_commit_notice(flags=(committed & reach[q]).astype(np.uint8), peer=u8(dead), col=pa["col"],
+                                     ballot=np.full(G, dead + 1, np.uint64), seq=dec["seq"], deps=np.ascontiguousarray(dec["deps"]),
+                                     key=np.ascontiguousarray(keys))
+    return cut
+
+
+def recover_row(reps, who, dead, live, G, rng=None, loss=0.0, trace=None):
+    """replica `who` times out on `dead` and recovers its row with the help of the replicas in `live` (messages to and from
+    each of them lost with probability `loss`).  Every output of every call goes to `trace` (a list) for comparison
+    between backends.  Returns how many instances reached which decision."""
+    R = len(reps)
+    u8 = lambda v: np.full(G, v, np.uint8)
+    rec = (lambda *x: trace.append(x)) if trace is not None else (lambda *x: None)
+    lost = (lambda: (rng.random(G) < loss)) if (rng is not None and loss > 0) else (lambda: np.zeros(G, bool))
+    exploded = u8(1 << dead)
+    hb = reps[who].heartbeat_timeout(u8(dead), exploded)
+    rec("hb", hb["n"].copy(), hb["col"].copy(), hb["ballot"].copy())
+    tally = {1: 0, 2: 0, 3: 0}
+    row = u8(dead)
+    for k in range(int(hb["n"].max()) if G else 0):
+        on = (hb["n"] > k)
+        col, nb = np.ascontiguousarray(hb["col"][k]), np.ascontiguousarray(hb["ballot"][k])
+        nbal = np.zeros((R, G), np.uint64); vb = np.zeros((R, G), np.uint64); vs = np.zeros((R, G), np.uint8)
+        vq = np.zeros((R, G), np.uint64); vd = np.full((R, R, G), N, np.uint32); vk = np.full((R, G), NO_KEY, np.uint8)
+        fl = np.zeros((R, G), np.uint8)
+        for q in live:
+            if q == who:
+                continue
+            r_ = reps[q].handle_exp_prepare((on & ~lost()).astype(np.uint8), u8(who), row, col, nb)
+            rec("xp", q, k, *[r_[x].copy() for x in ("flags", "voted_bal", "status", "seq", "deps", "key")])
+            fl[q] = r_["flags"] * ~lost(); nbal[q] = nb; vb[q] = r_["voted_bal"]; vs[q] = r_["status"]; vq[q] = r_["seq"]
+            vd[q] = r_["deps"]; vk[q] = r_["key"]
+        dec = reps[who].handle_exp_prepare_replies(row, col, nbal, vb, vs, vq, vd, vk, fl)
+        rec("dec", k, *[dec[x].copy() for x in ("decision", "ballot", "seq", "deps", "key")])
+        for st in (1, 2, 3):
+            tally[st] += int((dec["decision"] == st).sum())
+        seq, deps, key, bal = dec["seq"], np.ascontiguousarray(dec["deps"]), dec["key"], dec["ballot"]
+        # PreAccepting: a PreAccept round under the new ballot; the instance avoids the fast path
+        pre = dec["decision"] == 1
+        if pre.any():
+            ballot = np.zeros((R, G), np.uint64); rs = np.zeros((R, G), np.uint64)
+            rd = np.full((R, R, G), N, np.uint32); rf = np.zeros((R, G), np.uint8)
+            for q in live:
+                if q == who:
+                    continue
+                r_ = reps[q].handle_pre_accept(flags=(pre & ~lost()).astype(np.uint8), peer=u8(who), col=col, ballot=bal, seq=seq,
+                                               deps=deps, key=key, row=row)
+                rf[q] = r_["flags"] * ~lost(); ballot[q] = r_["ballot"]; rs[q] = r_["seq"]; rd[q] = r_["deps"]
+            d2 = reps[who].handle_pre_accept_replies(col, ballot, rs, rd, rf, exploded=exploded, row=row)
+            rec("pre", k, *[d2[x].copy() for x in ("decision", "seq", "deps")])
+            assert not ((d2["decision"] == 3) & pre).any()         # no fast path after an explicit prepare
+            took = pre & (d2["decision"] == 2)
+            seq = np.where(took, d2["seq"], seq); deps = np.where(took[None, :], d2["deps"], deps)
+            acc_now = (dec["decision"] == 2) | took
+        else:
+            acc_now = dec["decision"] == 2
+        committed = dec["decision"] == 3
+        if acc_now.any():
+            aflags = np.zeros((R, G), np.uint8); aballot = np.zeros((R, G), np.uint64)
+            for q in live:
+                if q == who:
+                    continue
+                ar = reps[q].handle_accept(flags=(acc_now & ~lost()).astype(np.uint8), peer=u8(who), col=col, ballot=bal, seq=seq,
+                                           deps=np.ascontiguousarray(deps), key=key, row=row)
+                aflags[q] = ar["flags"] * ~lost(); aballot[q] = ar["ballot"]
+            acc = reps[who].handle_accept_replies(col, aballot, aflags, row=row)
+            rec("acc", k, acc["committed"].copy())
+            committed = committed | (acc["committed"] == 1)
+        for q in live:
+            if q == who:
+                continue
+            reps[q].handle_commit_notice(flags=(committed & ~lost()).astype(np.uint8), peer=u8(who), col=col, ballot=bal, seq=seq,
+                                         deps=np.ascontiguousarray(deps), key=key, row=row)
+    return tally
+
+
+def check_agreement(reps, live, dead, G):
+    """safety: wherever two live replicas hold a column of the dead row as committed, they hold the same (seq, deps, key)"""
+    dumps = {q: reps[q].dump() for q in live}
+    W = reps[live[0]].W
+    n_committed = 0
+    for a in live:
+        for b in live:
+            if b <= a:
+                continue
+            da, db = dumps[a], dumps[b]
+            both = (da["status"][dead] >= 3) & (db["status"][dead] >= 3) & (da["len"][dead][None, :] == db["len"][dead][None, :])
+            assert (da["seq"][dead][both] == db["seq"][dead][both]).all()
+            assert (da["key"][dead][both] == db["key"][dead][both]).all()
+            assert (da["deps"][dead][both] == db["deps"][dead][both]).all()
+            n_committed += int(both.sum())
+    return n_committed

@@ -238,6 +238,18 @@ def test_string_kv_state_machine_kernel_on_the_host(sim):
         t.test_full_table_and_heap_are_sticky_not_silent("cpu")
 
 
+def test_epaxos_explicit_prepare_kernels_on_the_host(sim, oracle):
+    """EPaxos recovery of a dead command leader's row: the hand-derived traces on the kernels, and a crash-and-recovery cluster
+    run against the oracle cluster, call by call"""
+    import test_zz_ep_recovery_gpu as t
+    with sim.patched():
+        for trace in t.TRACES:
+            t.test_trace_on_the_engine("cpu", trace)
+        t.test_crash_and_recovery_matches_the_oracle_cluster("cpu", oracle, 200, 0, 0.0)
+        t.test_crash_and_recovery_matches_the_oracle_cluster("cpu", oracle, 130, 3, 0.2)
+        t.test_recovery_needs_the_flag_and_excludes_execution("cpu")
+
+
 def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
     import test_zz_ep_cluster_gpu as t
     with sim.patched():
