@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
                     "excludes the side stream).  0 = one smr_mp_tick call per tick: five per-round launches + the straggler side launch "
                     "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
+    ap.add_argument("--batch", type=int, default=8, help="> 0: ticks per smr_mp_run_ticks call WITH the straggler list on: the bulk kernels still "
+                    "run tick by tick, the list's groups go through the whole batch in one side-stream launch and the streams meet "
+                    "once per batch (<= 16 ticks) instead of once per tick; 8 measured best (profiles/r2z_batch.log).  0 = one "
+                    "smr_mp_tick call per tick")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
     ap.add_argument("--layout", choices=("colocated", "spread"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
@@ -823,6 +827,14 @@ def main():
     launches = []                                 # fused: (event pair, ticks) of every launch of the timed region
 
     def run(t0_, t1_, timed=False):
+        if args.batch and not args.fused:
+            chunks = [list(range(b0, min(b0 + min(args.batch, 16), t1_))) for b0 in range(t0_, t1_, min(args.batch, 16))]
+            for i, ch in enumerate(chunks):
+                # event pairs around the round kernels of ONE batch of the timed region (the last: the shortest when the
+                # steps do not divide): they cost launch-gap time on every tick they cover
+                eng.profile_enable(timed and i == len(chunks) - 1)
+                eng.run_ticks([tick_args(t) for t in ch])
+            return
         if not args.fused:
             for t in range(t0_, t1_):
                 if timed:
@@ -915,7 +927,7 @@ def main():
                                        "frac": alg_tick / (qt_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                        "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None,
                                        "pass": "untimed per-round pass of %d ticks behind the timed region" % args.round_ticks
-                                               if args.fused else "timed region, every third tick"}
+                                               if args.fused else ("timed region, last batch" if args.batch else "timed region, every third tick")}
     line = {
         "metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s",
         "n_gpus": world, "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None,
@@ -926,7 +938,10 @@ def main():
                                "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout"
                                % (G, S, H, args.drop * 100, args.timeouts * 100),
                    "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated",
-                   "launch": ("fused tick kernel, <= %d ticks per launch" % min(args.fused, 16)) if args.fused else "five per-round launches per tick"},
+                   "launch": ("fused tick kernel, <= %d ticks per launch" % min(args.fused, 16)) if args.fused else
+                             ("batches of <= %d ticks per smr_mp_run_ticks call: five per-round launches per tick for the bulk, one "
+                              "side-stream launch per batch for the straggler list" % min(args.batch, 16)) if args.batch else
+                             "five per-round launches per tick + one side-stream launch per tick for the straggler list"},
         "roofline": roof,
         "kernels": prof, "kernels_pass": "untimed per-round pass" if args.fused else "timed region",
         "rejected_batches": rej, "overflow_groups": overflow,

@@ -1077,6 +1077,75 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
     }
 }
 
+// The list's work for a BATCH of ticks in one launch (smr_mp_run_ticks with the straggler list on): a listed group never
+// meets the bulk kernels, and groups never talk to each other, so its block simply runs the batch's ticks back to back
+// while the bulk kernels go through them one launch at a time on the caller's stream.  What this buys over the per-tick
+// launch above: a leader change costs its group ~130 us in the tick it happens and ~40 us in the next, far more than a
+// bulk tick -- per tick, that chain IS the tick; per batch it only has to fit into the time the bulk takes for the whole
+// batch, and the two meet once, at the batch's end.
+// (STRAG_BATCH_K listed groups per block, on lanes 0 .. K-1 of every replica's wavefront: per tick that packing lost --
+// the cooperative jobs of a wavefront queue behind each other and the tick waits for the longest queue -- but a batch has
+// slack, and what counts here is how many listed groups the 256 blocks get through in the time the bulk needs.)
+#ifndef STRAG_BATCH_K
+#define STRAG_BATCH_K 4
+#endif
+#ifndef STRAG_BATCH_BLOCKS
+#define STRAG_BATCH_BLOCKS 256
+#endif
+#ifndef STRAG_BATCH_MINW
+#define STRAG_BATCH_MINW STRAG_MINW
+#endif
+__global__ __launch_bounds__(512, STRAG_BATCH_MINW) void mp_straggler_batch(const MpParams *__restrict__ Pp, int lpar, const MpTickBatch B) {
+    const MpParams &P = *Pp;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t n = P.slow_n[lpar];
+    if (n > P.slow_cap) n = P.slow_cap;
+    for (uint32_t idx0 = blockIdx.x; idx0 < n; idx0 += gridDim.x * STRAG_BATCH_K) {  // uniform per block
+        const uint32_t idx = idx0 + lane * gridDim.x;
+        const bool mine = w < P.R && lane < STRAG_BATCH_K && idx < n;
+        const uint32_t g = mine ? P.slow_list[idx] : P.G;
+        const uint32_t r = w < P.R ? w : 0;
+        for (uint32_t t = 0; t < B.n; t++) {
+            const MpTickIn &in = B.t[t];
+            const int par = B.par0 ^ (int)(t & 1u);
+            if (in.timeout_rep || in.req_target)
+                r1_body(P, par, in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, mine && !P.overflow[g], r);
+            __syncthreads();
+            r2_body(P, par, g, mine && !P.overflow[g], r);
+            __syncthreads();
+            r3_body(P, par, in.ackctl, in.heartbeat, g, mine && !P.overflow[g], r);
+            __syncthreads();
+            if (in.heartbeat) {
+                r4_body(P, par, g, mine && !P.overflow[g], r);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// mp_mark_stragglers for a batch: a group that would be on the list in ANY tick of the batch is on it for the whole batch
+// (its ttl evolves tick by tick exactly as the per-tick mark pass would have it, and carries over to the next batch)
+__global__ __launch_bounds__(256) void mp_mark_batch(const MpParams *__restrict__ Pp, int lpar, const MpTickBatch B, uint32_t ttl) {
+    const MpParams &P = *Pp;
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) P.slow_n[lpar ^ 1] = 0;
+    if (g >= P.G) return;
+    uint32_t t = P.slow_ttl[g];
+    bool any = false;
+    for (uint32_t k = 0; k < B.n; k++) {
+        const uint8_t *tr = B.t[k].timeout_rep;
+        if (tr && tr[g] != NO_REP) t = ttl;
+        if (t > 0) { any = true; t--; }
+    }
+    uint8_t s = 0;
+    if (any) {
+        const uint32_t idx = atomicAdd(&P.slow_n[lpar], 1u);
+        if (idx < P.slow_cap) { P.slow_list[idx] = g; s = 1; }   // list full: the group stays with the bulk
+    }
+    P.slow_ttl[g] = (uint8_t)t;
+    if (P.slow[g] != s) P.slow[g] = s;
+}
+
 // The whole tick -- and a batch of consecutive ticks -- in ONE launch.  Groups never talk to each other, so the round
 // boundaries only have to order the replicas of the SAME group: a block owns 64 groups with all their replicas (a
 // wavefront per replica for R1 / R2 / R3-rest / R4, four wavefronts for the quorum tally's row split) and a block
@@ -1803,7 +1872,6 @@ int smr_mp_tick(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const uint8_t
 
 int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n, void *stream) {
     if (!c || (n && !ticks)) return fail(SMR_ERR_ARG, "mp: null argument");
-    if (c->ttl) return fail(SMR_ERR_STATE, "mp: run_ticks and the straggler side stream exclude each other (straggler_ticks must be off)");
     if (c->hp.live != (1u << c->cfg.population) - 1u) return fail(SMR_ERR_STATE, "mp: run_ticks needs every replica live (co-located layout)");
     if (c->forked || c->marked) return fail(SMR_ERR_STATE, "mp: run_ticks inside an open tick");
     hipStream_t st = (hipStream_t)stream;
@@ -1824,10 +1892,38 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             b.t[k] = MpTickIn{x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.ackctl_dev,
                               x.S, x.do_heartbeat ? 1 : 0};
         }
-        if (R <= 5) hipLaunchKernelGGL((mp_ticks_fused<5, 5>), grid, dim3(5 * 64), 0, st, c->dp, b);
-        else hipLaunchKernelGGL((mp_ticks_fused<MAXR, MAXR>), grid, dim3(MAXR * 64), 0, st, c->dp, b);
+        if (!c->ttl) {                                          // no straggler list: the whole batch in one fused launch
+            if (R <= 5) hipLaunchKernelGGL((mp_ticks_fused<5, 5>), grid, dim3(5 * 64), 0, st, c->dp, b);
+            else hipLaunchKernelGGL((mp_ticks_fused<MAXR, MAXR>), grid, dim3(MAXR * 64), 0, st, c->dp, b);
+            SMR_HIP_TRY(hipGetLastError());
+            c->par ^= (int)(b.n & 1u);
+            continue;
+        }
+        // Straggler list on: the list of the whole batch, its groups' ticks back to back in ONE launch on the side stream,
+        // the bulk kernels tick by tick on the caller's stream; the streams meet at the end of the batch.
+        hipLaunchKernelGGL(mp_mark_batch, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, st, c->dp, c->lpar, b, c->ttl);
         SMR_HIP_TRY(hipGetLastError());
-        c->par ^= (int)(b.n & 1u);
+        SMR_HIP_TRY(hipEventRecord(c->ev_fork, st));
+        SMR_HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        hipLaunchKernelGGL(mp_straggler_batch, dim3(STRAG_BATCH_BLOCKS), dim3(R <= 5 ? 320 : 512), 0, c->side, c->dp, c->lpar, b);
+        SMR_HIP_TRY(hipGetLastError());
+        c->marked = c->side_on = c->forked = c->side_fused = true;   // the round calls below: bulk only, no fork of their own
+        int rc = SMR_OK;
+        for (uint32_t k = 0; k < b.n && !rc; k++) {
+            const smr_mp_tick_in &x = ticks[i0 + k];
+            rc = smr_mp_round_local(c, x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.S, stream);
+            if (!rc) rc = smr_mp_round_deliver(c, stream);
+            if (!rc) rc = smr_mp_round_replies(c, x.ackctl_dev, x.do_heartbeat ? 1 : 0, stream);
+            if (!rc && x.do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
+            c->par ^= 1;
+        }
+        c->marked = c->side_on = c->forked = c->side_fused = false;
+        hipError_t e1 = hipEventRecord(c->ev_join, c->side);
+        hipError_t e2 = hipStreamWaitEvent(st, c->ev_join, 0);
+        c->lpar ^= 1;
+        if (rc) return rc;
+        SMR_HIP_TRY(e1);
+        SMR_HIP_TRY(e2);
     }
     return SMR_OK;
 }

@@ -61,7 +61,8 @@ class MultiPaxosCluster:
 
     def run_ticks(self, ticks, stream=None):
         """a batch of consecutive ticks (each a dict of `tick`'s arguments) through the fused tick kernel: one launch per
-        16 ticks instead of five per tick, same results (`smr_mp_run_ticks`; straggler_ticks must be off)"""
+        16 ticks instead of five per tick, same results (`smr_mp_run_ticks`).  With straggler_ticks on, the bulk kernels still run
+        tick by tick and the straggler list's groups go through the whole batch in one side-stream launch"""
         n = len(ticks)
         arr = (MpTickIn * max(n, 1))()
         for a, t in zip(arr, ticks):

@@ -270,9 +270,48 @@ def test_fused_ticks_bench_shape(cuda, oracle):
     _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=16)
 
 
-def test_fused_ticks_need_the_straggler_list_off(cuda):
-    from summerset_amd import MultiPaxosCluster
-    from summerset_amd._lib import SummersetError
-    eng = MultiPaxosCluster(64, 5, 32, straggler_ticks=2)
-    with pytest.raises(SummersetError):
-        eng.run_ticks([dict(heartbeat=True)])
+# ---- smr_mp_run_ticks with the straggler list on: the list's groups run the batch's ticks in one side-stream launch ----
+@pytest.mark.parametrize("fused,sticks", [(16, 8), (5, 2), (20, 3), (1, 4)])
+def test_batched_ticks_with_the_straggler_list(cuda, oracle, fused, sticks):
+    _run(cuda, oracle, G=512, R=5, S=2, W=64, n_ticks=48, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=fused,
+         straggler_ticks=sticks)
+    _run(cuda, oracle, G=300, R=5, S=1, W=64, n_ticks=40, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=True, fused=fused,
+         straggler_ticks=sticks)
+
+
+def test_batched_ticks_with_the_straggler_list_other_shapes(cuda, oracle):
+    _run(cuda, oracle, G=257, R=3, S=2, W=32, n_ticks=40, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5, straggler_ticks=4)
+    _run(cuda, oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6, straggler_ticks=8)
+    _run(cuda, oracle, G=128, R=5, S=1, W=64, n_ticks=30, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False, fused=4, straggler_ticks=2)
+    # more groups with a timeout in one batch than the list holds (1024): the rest stay with the bulk kernels
+    _run(cuda, oracle, G=3000, R=5, S=2, W=64, n_ticks=20, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=16, straggler_ticks=8)
+
+
+def test_batched_ticks_with_the_straggler_list_bench_shape(cuda, oracle):
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=16, straggler_ticks=8)
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=7, straggler_ticks=4, every=3)
+
+
+def test_batches_and_single_ticks_share_the_list(cuda, oracle):
+    """a batch leaves ttl behind that the per-tick mark pass picks up, and the other way round"""
+    from summerset_amd import MultiPaxosCluster, stream
+    G, R, S, W = 256, 5, 2, 64
+    cap = W + 4
+    eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_list_cap=G * (S * 64 + W) + 64, straggler_ticks=6)
+    orc = oracle.MpOracle(G, R, W, cap=cap)
+    eng.preset_leader(0); orc.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=36, drop_p=0.1, timeout_frac=1.0, hb_every=4)
+    t = 0
+    for chunk in (3, 1, 1, 5, 1, 16, 1, 1, 7):
+        ins = []
+        for _ in range(chunk):
+            inp = st.tick(t); t += 1
+            orc.tick(**inp)
+            ins.append(_to_dev(inp, cuda))
+        if chunk == 1:
+            eng.tick(**ins[0])
+        else:
+            eng.run_ticks(ins)
+        _compare(eng, orc, R, t)
+    for r in range(R):
+        assert eng.counters(r)["commits"] == orc.total_commits(r)
