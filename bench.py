@@ -59,8 +59,8 @@ def parse():
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
     ap.add_argument("--timeout-span", type=int, default=None, help="draw the timeout ticks from [0, N) instead of the whole run")
-    ap.add_argument("--straggler-ticks", type=int, default=8, help="ticks a group in a leader change runs on the side stream (0 = off); 8 measured best "
-                    "on the default workload once the side kernel lost its agent-scope fences (profiles/r2g_straggler_sweep.log)")
+    ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the straggler list (0 = no list); 4 "
+                    "measured best with --batch 8 (profiles/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/r2g_straggler_sweep.log)")
     ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
                     "excludes the side stream).  0 = one smr_mp_tick call per tick: five per-round launches + the straggler side launch "
                     "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
@@ -892,10 +892,12 @@ def main():
         if args.fused and "smr::mp_ticks_fused<5, 5>" in k:
             pmc_tick = k["smr::mp_ticks_fused<5, 5>"]["hbm_bytes_per_launch"] / pmc.get("ticks_per_fused_launch", 16)
         elif not args.fused:
-            pmc_tick = sum(k[n]["hbm_bytes_per_launch"] / (H if n == "smr::mp_round_heartbeat" else 1)
-                           for n in ("smr::mp_round_local", "smr::mp_round_deliver", "smr::mp_quorum_tally<5>",
-                                     "smr::mp_round_replies", "smr::mp_round_heartbeat", "smr::mp_straggler_tick",
-                                     "smr::mp_mark_stragglers") if n in k)
+            tpb = float(pmc.get("ticks_per_batch", 8))           # the list's launches: one per batch
+            per = {"smr::mp_round_heartbeat": H, "smr::mp_straggler_batch": tpb, "smr::mp_mark_batch": tpb}
+            names = ("smr::mp_round_local", "smr::mp_round_deliver", "smr::mp_quorum_tally<5>", "smr::mp_round_replies",
+                     "smr::mp_round_heartbeat") + (("smr::mp_straggler_batch", "smr::mp_mark_batch") if args.batch else
+                                                   ("smr::mp_straggler_tick", "smr::mp_mark_stragglers"))
+            pmc_tick = sum(k[n]["hbm_bytes_per_launch"] / per.get(n, 1) for n in names if n in k)
     if args.fused:
         # the dominant kernel of the path is the fused tick kernel itself: every launch of the timed region between
         # its own HIP event pair; algorithmic bytes = the §8(d) figure x the decisions of the launch's ticks

@@ -17,7 +17,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--timeouts", type=float, default=0.01)
 ap.add_argument("--ticks", type=int, default=16)
 ap.add_argument("--extra", action="store_true")
-ap.add_argument("--straggler-ticks", type=int, default=8, help="as bench.py: ticks a group in a leader change spends on the side stream")
+ap.add_argument("--straggler-ticks", type=int, default=4, help="as bench.py: ticks a group in a leader change stays on the straggler list")
+ap.add_argument("--batch", type=int, default=8, help="as bench.py: ticks per smr_mp_run_ticks call (0: one smr_mp_tick call per tick)")
 a = ap.parse_args()
 dev = torch.device("cuda")
 G, R, S, W, H = 65536, 5, 32, 512, 4
@@ -26,11 +27,19 @@ eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_t
 eng.preset_leader(0)
 st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=a.ticks, drop_p=0.1, timeout_frac=a.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2)
 pool = [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(4)]
-for t in range(a.ticks):
+def tick_args(t):
     e = {k: torch.from_numpy(v).to(dev) for k, v in st.tick_events(t).items()}
     fired = bool((st.timeout_tick == t).any())
-    eng.tick(timeout_rep=e["timeout_rep"] if fired else None, timeout_src=e["timeout_src"] if fired else None, req_target=e["req_target"],
-             heartbeat=st.heartbeat(t), **pool[t % 4])
+    return dict(timeout_rep=e["timeout_rep"] if fired else None, timeout_src=e["timeout_src"] if fired else None, req_target=e["req_target"],
+                heartbeat=st.heartbeat(t), **pool[t % 4])
+
+
+if a.batch:
+    for b0 in range(0, a.ticks, a.batch):
+        eng.run_ticks([tick_args(t) for t in range(b0, min(b0 + a.batch, a.ticks))])
+else:
+    for t in range(a.ticks):
+        eng.tick(**tick_args(t))
 torch.cuda.synchronize()
 # the same workload through the fused tick kernel: two launches of 16 ticks each (smr_mp_run_ticks)
 eng2 = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap)

@@ -42,7 +42,7 @@ def main():
                 % (cal["hbm_read_bytes_per_launch"] / 1e6, n * L / 1e6, cal["hbm_write_bytes_per_launch"] / 1e6, n * 2 * sl / 1e6))
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, each with --kernel-trace only): " + sys.argv[3],
                "corrections": "counter unit = KB (1000 B); FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide "
-                              "coalesced read); WRITE_SIZE as reported", "calibration": note, "ticks_per_fused_launch": 16, "kernels": kernels}, sys.stdout, indent=1)
+                              "coalesced read); WRITE_SIZE as reported", "calibration": note, "ticks_per_fused_launch": 16, "ticks_per_batch": 8, "kernels": kernels}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
