@@ -954,6 +954,25 @@ int smr_hb_update_heard_cnt(smr_hb *h, const uint8_t *peer_dev, void *stream);  
 int smr_hb_dump(smr_hb *h, uint64_t *deadline, uint8_t *exploded, uint8_t *is_sending, uint64_t *next_tick, uint64_t *cnt0,
                 uint64_t *cnt1, uint8_t *rep, uint8_t *alive);
 
+/* ---- the WAL backer file as a byte image (server/storage.rs:240-432), host only ------------------------------------------
+ * StorageHubLoggerTask's file operations -- write_entry (:282), append_entry (:326), read_entry (:240), truncate_log (:351),
+ * discard_log (:375) -- on a growable host buffer that stands for the backer file.  Entries are the bincode bytes the
+ * smr_wal_* encoders produce WITHOUT their frame header; the log writes `[u64 BE length][bytes]` itself.  `file_size` is the
+ * logger's own idea of the log's end and is an argument, as in the reference's functions. */
+typedef struct smr_wallog smr_wallog;
+int smr_wallog_create(smr_wallog **out);
+void smr_wallog_destroy(smr_wallog *l);
+int64_t smr_wallog_len(const smr_wallog *l);                                   /* the image's length */
+int64_t smr_wallog_bytes(const smr_wallog *l, uint8_t *out, uint64_t cap);     /* the image itself */
+int smr_wallog_write(smr_wallog *l, uint64_t file_size, const uint8_t *entry, uint64_t entry_len, uint64_t offset, uint8_t *offset_ok,
+                     uint64_t *now_size);
+int smr_wallog_append(smr_wallog *l, uint64_t file_size, const uint8_t *entry, uint64_t entry_len, uint64_t *now_size);
+/* *entry_len = -1: None (then *end_offset = offset) */
+int smr_wallog_read(const smr_wallog *l, uint64_t file_size, uint64_t offset, uint8_t *out, uint64_t cap, int64_t *entry_len,
+                    uint64_t *end_offset);
+int smr_wallog_truncate(smr_wallog *l, uint64_t file_size, uint64_t offset, uint8_t *ok, uint64_t *now_size);
+int smr_wallog_discard(smr_wallog *l, uint64_t file_size, uint64_t offset, uint64_t keep, uint8_t *ok, uint64_t *now_size);
+
 /* ---- LeaseManager (src/server/leaseman.rs:132-935), batched: G groups, one replica id per object -------------------------
  * Time is explicit: one smr_lease_step = the timers that exploded up to now_ms (their GrantTimeout / LeaseTimeout notices,
  * earliest first), then one notice per group, through run()'s lease-number filter (:840-926) and handle_notice (:791-835);

@@ -343,6 +343,15 @@ SYMBOLS = [
     ("smr_hb_update_bcast_cnts", _i, [_vp, _vp, _vp, _vp]),
     ("smr_hb_update_heard_cnt", _i, [_vp, _vp, _vp]),
     ("smr_hb_dump", _i, [_vp] + [_vp] * 8),
+    ("smr_wallog_create", _i, [C.POINTER(_vp)]),
+    ("smr_wallog_destroy", None, [_vp]),
+    ("smr_wallog_len", C.c_int64, [_vp]),
+    ("smr_wallog_bytes", C.c_int64, [_vp, _vp, _u64]),
+    ("smr_wallog_write", _i, [_vp, _u64, C.c_char_p, _u64, _u64, C.POINTER(_u8), C.POINTER(_u64)]),
+    ("smr_wallog_append", _i, [_vp, _u64, C.c_char_p, _u64, C.POINTER(_u64)]),
+    ("smr_wallog_read", _i, [_vp, _u64, _u64, _vp, _u64, C.POINTER(C.c_int64), C.POINTER(_u64)]),
+    ("smr_wallog_truncate", _i, [_vp, _u64, _u64, C.POINTER(_u8), C.POINTER(_u64)]),
+    ("smr_wallog_discard", _i, [_vp, _u64, _u64, _u64, C.POINTER(_u8), C.POINTER(_u64)]),
     ("smr_lease_create", _i, [C.POINTER(LeaseCfg), C.POINTER(_vp)]),
     ("smr_lease_destroy", None, [_vp]),
     ("smr_lease_step", _i, [_vp, _u64] + [_vp] * 8),

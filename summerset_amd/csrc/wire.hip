@@ -714,4 +714,92 @@ int64_t smr_batcher_tick(smr_batcher *b, uint32_t *groups, uint32_t *counts, uin
     return (int64_t)n;
 }
 
+// ---- the WAL backer file as a byte image (server/storage.rs:240-432) ---------------------------------------------------
+// StorageHubLoggerTask's five file operations on a growable host buffer that stands for the backer file: entries are
+// `[u64 BE length][bincode bytes]` frames (what the smr_wal_* encoders above produce); `file_size` is the logger's own idea
+// of the log's end and arrives as an argument, exactly as in the reference's functions; the cursor rests at EOF between calls.
+}  // extern "C"
+struct smr_wallog { std::vector<uint8_t> f; };
+extern "C" {
+
+int smr_wallog_create(smr_wallog **out) {
+    if (!out) return fail(SMR_ERR_ARG, "wallog: null argument");
+    *out = new smr_wallog();
+    return SMR_OK;
+}
+void smr_wallog_destroy(smr_wallog *l) { delete l; }
+
+int64_t smr_wallog_len(const smr_wallog *l) { return l ? (int64_t)l->f.size() : fail(SMR_ERR_ARG, "wallog: null argument"); }
+
+int64_t smr_wallog_bytes(const smr_wallog *l, uint8_t *out, uint64_t cap) {
+    if (!l || (!out && cap)) return fail(SMR_ERR_ARG, "wallog: null argument");
+    if (cap < l->f.size()) return fail(SMR_ERR_ARG, "wallog: output buffer too small");
+    if (!l->f.empty()) memcpy(out, l->f.data(), l->f.size());
+    return (int64_t)l->f.size();
+}
+
+static void wallog_put(smr_wallog *l, uint64_t at, const uint8_t *entry, uint64_t len) {
+    if (l->f.size() < at + 8 + len) l->f.resize(at + 8 + len);
+    for (int i = 0; i < 8; i++) l->f[at + i] = (uint8_t)(len >> (8 * (7 - i)));
+    if (len) memcpy(l->f.data() + at + 8, entry, len);
+}
+
+// write_entry (storage.rs:282-322): LogAction::Write { entry, offset, sync } -> (offset_ok, now_size)
+int smr_wallog_write(smr_wallog *l, uint64_t file_size, const uint8_t *entry, uint64_t entry_len, uint64_t offset, uint8_t *offset_ok,
+                     uint64_t *now_size) {
+    if (!l || (!entry && entry_len) || !offset_ok || !now_size) return fail(SMR_ERR_ARG, "wallog: null argument");
+    if (offset > file_size) { *offset_ok = 0; *now_size = file_size; return SMR_OK; }   // :289-297 no holes in the log file
+    if (offset > l->f.size()) return fail(SMR_ERR_ARG, "wallog: file_size beyond the image");
+    wallog_put(l, offset, entry, entry_len);
+    const uint64_t end = offset + 8 + entry_len;
+    *offset_ok = 1; *now_size = end > file_size ? end : file_size;              // :314-320
+    return SMR_OK;
+}
+
+// append_entry (:326-347): at the cursor, i.e. the image's end; returns file_size + 8 + length
+int smr_wallog_append(smr_wallog *l, uint64_t file_size, const uint8_t *entry, uint64_t entry_len, uint64_t *now_size) {
+    if (!l || (!entry && entry_len) || !now_size) return fail(SMR_ERR_ARG, "wallog: null argument");
+    wallog_put(l, l->f.size(), entry, entry_len);
+    *now_size = file_size + 8 + entry_len;
+    return SMR_OK;
+}
+
+// read_entry (:240-278): *entry_len = -1 for None (then *end_offset = offset), else the entry's bincode bytes in out
+int smr_wallog_read(const smr_wallog *l, uint64_t file_size, uint64_t offset, uint8_t *out, uint64_t cap, int64_t *entry_len,
+                    uint64_t *end_offset) {
+    if (!l || !entry_len || !end_offset || (!out && cap)) return fail(SMR_ERR_ARG, "wallog: null argument");
+    *entry_len = -1; *end_offset = offset;
+    if (offset + 8 > file_size) return SMR_OK;                                   // :245-256
+    if (offset + 8 > l->f.size()) return fail(SMR_ERR_ARG, "wallog: file_size beyond the image");
+    uint64_t len = 0;
+    for (int i = 0; i < 8; i++) len = (len << 8) | l->f[offset + i];
+    if (len > file_size || offset + 8 + len > file_size) return SMR_OK;          // :262-266 invalid length
+    if (offset + 8 + len > l->f.size()) return fail(SMR_ERR_ARG, "wallog: file_size beyond the image");
+    if (cap < len) return fail(SMR_ERR_ARG, "wallog: output buffer too small");
+    if (len) memcpy(out, l->f.data() + offset + 8, len);
+    *entry_len = (int64_t)len; *end_offset = offset + 8 + len;
+    return SMR_OK;
+}
+
+// truncate_log (:351-371): keep the head
+int smr_wallog_truncate(smr_wallog *l, uint64_t file_size, uint64_t offset, uint8_t *ok, uint64_t *now_size) {
+    if (!l || !ok || !now_size) return fail(SMR_ERR_ARG, "wallog: null argument");
+    if (offset > file_size) { *ok = 0; *now_size = file_size; return SMR_OK; }
+    l->f.resize(offset);                                                         // set_len: shrinks or zero-extends
+    *ok = 1; *now_size = offset;
+    return SMR_OK;
+}
+
+// discard_log (:375-417): drop [keep, offset), keeping a fixed head of `keep` bytes and the tail from `offset`
+int smr_wallog_discard(smr_wallog *l, uint64_t file_size, uint64_t offset, uint64_t keep, uint8_t *ok, uint64_t *now_size) {
+    if (!l || !ok || !now_size) return fail(SMR_ERR_ARG, "wallog: null argument");
+    if (offset > file_size || keep >= offset) { *ok = 0; *now_size = file_size; return SMR_OK; }
+    if (file_size > l->f.size()) return fail(SMR_ERR_ARG, "wallog: file_size beyond the image");
+    const uint64_t tail = file_size - offset;
+    if (tail) memmove(l->f.data() + keep, l->f.data() + offset, tail);
+    l->f.resize(keep + tail);
+    *ok = 1; *now_size = keep + tail;
+    return SMR_OK;
+}
+
 }  // extern "C"

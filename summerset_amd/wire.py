@@ -323,3 +323,65 @@ class Batcher:
                 return {groups[k]: (counts[k], buf.raw[off[k]:off[k + 1]]) for k in range(n)}
             _grow_or_raise(n, cap)
             cap *= 8
+
+
+class WalLog:
+    """the WAL backer file as a byte image: StorageHubLoggerTask's file operations (server/storage.rs:240-432) with the
+    reference's signatures -- `file_size` is the caller's idea of the log's end; entries are bincode bytes (what the wal_*
+    encoders return minus their 8-byte frame header, `frame_payload`)"""
+
+    def __init__(self):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.smr_wallog_create(C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.smr_wallog_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return int(self._L.smr_wallog_len(self._h))
+
+    def bytes(self):
+        n = len(self)
+        buf = C.create_string_buffer(max(n, 1))
+        got = self._L.smr_wallog_bytes(self._h, buf, n)
+        if got < 0:
+            check(int(got))
+        return buf.raw[:got]
+
+    def write_entry(self, file_size, entry, offset):
+        ok, now = C.c_uint8(), C.c_uint64()
+        check(self._L.smr_wallog_write(self._h, file_size, bytes(entry), len(entry), offset, C.byref(ok), C.byref(now)))
+        return bool(ok.value), int(now.value)
+
+    def append_entry(self, file_size, entry):
+        now = C.c_uint64()
+        check(self._L.smr_wallog_append(self._h, file_size, bytes(entry), len(entry), C.byref(now)))
+        return int(now.value)
+
+    def read_entry(self, file_size, offset):
+        n, end = C.c_int64(), C.c_uint64()
+        cap = max(len(self), 1)
+        buf = C.create_string_buffer(cap)
+        check(self._L.smr_wallog_read(self._h, file_size, offset, buf, cap, C.byref(n), C.byref(end)))
+        return (None if n.value < 0 else buf.raw[:n.value]), int(end.value)
+
+    def truncate_log(self, file_size, offset):
+        ok, now = C.c_uint8(), C.c_uint64()
+        check(self._L.smr_wallog_truncate(self._h, file_size, offset, C.byref(ok), C.byref(now)))
+        return bool(ok.value), int(now.value)
+
+    def discard_log(self, file_size, offset, keep):
+        ok, now = C.c_uint8(), C.c_uint64()
+        check(self._L.smr_wallog_discard(self._h, file_size, offset, keep, C.byref(ok), C.byref(now)))
+        return bool(ok.value), int(now.value)
+
+
+def frame_payload(frame):
+    """the bincode bytes of a `[u64 BE length][bytes]` frame as the encoders above return it"""
+    n = int.from_bytes(frame[:8], "big")
+    assert len(frame) == 8 + n
+    return frame[8:]
