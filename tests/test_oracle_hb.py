@@ -1,7 +1,9 @@
 """The Heartbeater restatement (oracle/hb_oracle.c) against hand-derived traces of src/server/heartbeat.rs: the
 configuration checks of new_and_setup, hear timers (random timeout inside [min, max], one event per explosion, a re-armed
 timer's queued event is dropped), the send ticker (first tick at once, then the period grid, late ticks skipped), and
-the reply counters with the peer-death / revival rule.  Parity unpinned (the reference has no tests for this module)."""
+the reply counters with the peer-death / revival rule.  The reference has no tests for this module; its hear timers are
+utils::Timer objects, and the reference's own timer tests (src/utils/timer.rs:184-330: timer_timeout, timer_restart,
+set_backwards) are restated on them at the end of this file -- that much of the module is pinned."""
 import numpy as np
 import pytest
 
@@ -97,3 +99,47 @@ def test_reply_counters_death_and_revival(oracle):
     d = h.dump()
     assert (d["cnt0"][1:] == 1).all() and (d["cnt1"] == 0).all() and (d["rep"] == 0).all()
     assert h.update_bcast_cnts(np.zeros(G, np.uint8)).tolist() == [0] and (h.dump()["cnt1"] == 0).all()   # flag clear: no call
+
+
+# ---- the reference's own timer tests (src/utils/timer.rs:184-330) on the Heartbeater's hear timers ----------------------
+# A hear timer IS a utils::Timer (heartbeat.rs:95-110) that kickoff_hear_timer cancels and kicks off with the drawn
+# duration (:174-185); poll() at a time delivers HearTimeout iff the timer has exploded by then.  The tests' durations
+# are reached with min = 100 ms and the draw = duration - 100 (timeout = min + draw mod (max - min + 1)).
+def _timer(oracle):
+    h = oracle.HbOracle(1, 3, 0, 100, 2000, 20, now_ms=0)
+
+    def kickoff(now, dur):
+        draw = np.zeros((3, 1), np.uint32)
+        draw[1, 0] = dur - 100
+        h.kickoff_hear_timer(np.array([1], np.uint8), now, draw)
+
+    def fired(now):
+        return bool(h.poll(now)[0][1, 0])
+    return kickoff, fired
+
+
+def test_reference_timer_timeout(oracle):                       # timer.rs:184-231 (the kickoff parts; extend: lease tests)
+    kickoff, fired = _timer(oracle)
+    kickoff(0, 300)
+    assert not fired(0) and not fired(299)                      # assert!(!timer.exploded())
+    assert fired(300)                                           # finish - start >= 300 ms
+    assert not fired(301)                                       # one timeout per explosion
+    kickoff(300, 300)                                           # twice
+    assert not fired(599) and fired(600)
+
+
+def test_reference_timer_restart(oracle):                       # timer.rs:233-258
+    kickoff, fired = _timer(oracle)
+    kickoff(0, 400)
+    kickoff(100, 400)                                           # 100 ms later: the deadline moves to 500
+    assert not fired(400) and not fired(499)
+    assert fired(500)                                           # >= 500 ms and < 800 ms after the start
+
+
+def test_reference_timer_set_backwards(oracle):                 # timer.rs:308-330
+    kickoff, fired = _timer(oracle)
+    kickoff(0, 600)
+    kickoff(100, 200)                                           # a shorter duration moves the deadline back to 300
+    assert not fired(299)
+    assert fired(300)                                           # >= 300 ms and < 600 ms
+    assert not fired(600)                                       # the long setting is gone

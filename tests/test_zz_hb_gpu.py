@@ -43,7 +43,8 @@ def test_traces_on_the_engine(cuda, oracle):
             except SummersetError as e:
                 raise ValueError(str(e))
     for name in ("test_configuration_checks", "test_hear_timers_by_hand", "test_send_ticker_skips_missed_ticks",
-                 "test_reply_counters_death_and_revival"):
+                 "test_reply_counters_death_and_revival", "test_reference_timer_timeout", "test_reference_timer_restart",
+                 "test_reference_timer_set_backwards"):
         getattr(tr, name)(Fake)
 
 
