@@ -377,7 +377,8 @@ int smr_raft_replica_preset(smr_raft_leader *l, uint8_t role /* 0 Follower 1 Can
                             uint64_t term, uint8_t voted_for /* SMR_NO_REPLICA = None */);
 
 /* One AppendEntries message per group (device arrays [G]; entry_term[k][G], k < max_entries).
- * flags bit0 = a message is present. */
+ * flags bit0 = a message is present.  entry_mask[k][G] (CRaft only, else NULL): avail_shards_map of the k-th entry's
+ * codeword, bit i = shard i (data shards 0 .. majority-1). */
 typedef struct {
     const uint8_t *flags, *leader;
     const uint64_t *term;
@@ -387,6 +388,7 @@ typedef struct {
     const uint64_t *entry_term;
     uint32_t max_entries;
     const uint32_t *leader_commit, *last_snap;
+    const uint8_t *entry_mask;
 } smr_raft_append_entries;
 /* The AppendEntriesReply each group's replica sends (device arrays [G]): flags bit0 = a
  * reply is sent, bit1 = it carries `conflict`. */
@@ -431,6 +433,17 @@ int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev
                                    void *stream);
 int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
                                 uint32_t *n_trunc_host);
+/* The CRaft FOLLOWER (after smr_raft_craft_enable): smr_raft_replica_handle_append_entries then follows the fork's
+ * handle_msg_append_entries (craft/messages.rs:14-254: consistency check on heartbeats too, shards of a re-sent entry
+ * absorbed, execution only with `majority` shards and after reconstruct_data when too few are data shards) and needs
+ * smr_raft_append_entries.entry_mask.  handle_msg_reconstruct (craft/messages.rs:622-663): n[g] asked (slot, term) pairs
+ * [max_slots][G] -> r_has / r_mask [max_slots][G] (the codeword of every slot held under that term, as its bitmap),
+ * r_n[g] of them (0: no ReconstructReply).  dump: the entries' bitmaps [W][G] by slot % W, counters[2] = reconstruct_data
+ * calls, executions postponed for lack of shards.  Not built: the leader's own shard gate with its Reconstruct
+ * broadcasts (craft/messages.rs:315-358) and handle_msg_reconstruct_reply (:665-745). */
+int smr_raft_craft_handle_reconstruct(smr_raft_leader *l, const uint32_t *n_dev, const uint32_t *slot_dev, const uint64_t *term_dev,
+                                      uint32_t max_slots, uint32_t *r_n_dev, uint8_t *r_has_dev, uint8_t *r_mask_dev, void *stream);
+int smr_raft_craft_dump_masks(smr_raft_leader *l, uint8_t *mask_host, uint64_t *counters);
 
 /* ------------------------------------------------------------------------
  * EPaxos command leader / acceptor over G groups (one replica id per group)

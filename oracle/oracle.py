@@ -94,6 +94,9 @@ def _declare(L):
     L.orc_craft_bcast_heartbeats.argtypes = [vp] + [vp] * 5
     L.orc_craft_assignment.argtypes = [vp, vp, vp]
     L.orc_craft_dump.argtypes = [vp] + [vp] * 5
+    L.orc_craft_handle_append_entries.argtypes = [vp] + [vp] * 8 + [u32] + [vp] * 7
+    L.orc_craft_handle_reconstruct.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
+    L.orc_craft_dump_masks.argtypes = [vp, vp, vp]
     L.orc_ep_new.restype = vp; L.orc_ep_new.argtypes = [u32, u8, u8, u32, u32, u8]
     L.orc_ep_free.argtypes = [vp]
     L.orc_ep_propose.argtypes = [vp] + [vp] * 6
@@ -406,6 +409,35 @@ class CRaftOracle(RaftOracle):
                    hb_seen=np.zeros((R, G), np.uint64), hb_repeat=np.zeros((R, G), np.uint8))
         lib().orc_craft_dump(self.h, *[_p(out[k]) for k in ("full_copy_mode", "peer_alive", "hb_replied", "hb_seen", "hb_repeat")])
         return out
+
+    # ---- the CRaft follower (craft/messages.rs:14-254, :622-663) ----
+    def handle_append_entries(self, flags, leader, term, prev_slot, prev_term, n_entries, entry_term, leader_commit, last_snap,
+                              entry_mask=None):
+        """entry_mask [K, G] uint8: avail_shards_map of every sent entry's codeword (None: every shard)"""
+        G = self.G
+        K = entry_term.shape[0]
+        if entry_mask is None:
+            entry_mask = np.full((K, G), (1 << self.R) - 1, np.uint8)
+        assert entry_term.dtype == np.uint64 and entry_term.shape == (K, G) and entry_term.flags.c_contiguous
+        assert entry_mask.dtype == np.uint8 and entry_mask.shape == (K, G) and entry_mask.flags.c_contiguous
+        r = dict(flags=np.zeros(G, np.uint8), term=np.zeros(G, np.uint64), end_slot=np.zeros(G, np.uint32),
+                 conflict_term=np.zeros(G, np.uint64), conflict_slot=np.zeros(G, np.uint32))
+        lib().orc_craft_handle_append_entries(self.h, _p(flags), _p(leader), _p(term), _p(prev_slot), _p(prev_term), _p(n_entries),
+                                              _p(entry_term), _p(entry_mask), K, _p(leader_commit), _p(last_snap), _p(r["flags"]),
+                                              _p(r["term"]), _p(r["end_slot"]), _p(r["conflict_term"]), _p(r["conflict_slot"]))
+        return r
+
+    def handle_reconstruct(self, n, slot, term):
+        """Reconstruct { slots }: n [G], slot / term [K, G] -> the ReconstructReply: n [G], has / mask [K, G]"""
+        G, K = self.G, slot.shape[0]
+        r = dict(n=np.zeros(G, np.uint32), has=np.zeros((K, G), np.uint8), mask=np.zeros((K, G), np.uint8))
+        lib().orc_craft_handle_reconstruct(self.h, _p(n), _p(slot), _p(term), K, _p(r["n"]), _p(r["has"]), _p(r["mask"]))
+        return r
+
+    def dump_masks(self):
+        d = dict(mask=np.zeros((self.W, self.G), np.uint8), counters=np.zeros(2, np.uint64))
+        lib().orc_craft_dump_masks(self.h, _p(d["mask"]), _p(d["counters"]))
+        return d
 
 
 

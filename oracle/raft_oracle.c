@@ -29,6 +29,18 @@
  *   switch_assignment_mode              craft/leadership.rs:80-141
  *   shard assignment of an entry        craft/request.rs:71-100, craft/messages.rs:416-460
  *   Heartbeater reply counters          server/heartbeat.rs:117-119,240-296 (update_bcast_cnts, update_heard_cnt)
+ * and the CRaft FOLLOWER (orc_craft_handle_append_entries, orc_craft_handle_reconstruct):
+ *   handle_msg_append_entries           craft/messages.rs:14-254   (the consistency check also on heartbeats, the leader
+ *                                       recorded also on a failed check, shards of a re-sent entry absorbed, execution
+ *                                       only with `majority` shards and after reconstruct_data when too few are data)
+ *   handle_logged_follower_append       craft/durability.rs:129-165 (identical to raft's)
+ *   handle_msg_reconstruct              craft/messages.rs:622-663
+ *   RSCodeword::absorb_other / reconstruct_data / avail_shards / avail_data_shards   utils/rscoding.rs:296-, as bitmaps
+ * An entry's codeword is its availability bitmap over the population's shards (data shards 0 .. majority-1); payload
+ * bytes are the RS kernels' business.  data_len of a re-sent entry equals the stored one (same slot, same term = same
+ * entry), so craft/messages.rs:133-134's data_len test is always true here.  NOT restated: the leader's own shard gate
+ * and its Reconstruct broadcasts (craft/messages.rs:315-358) and handle_msg_reconstruct_reply (:665-745) -- a leader
+ * that created its log holds every shard, the only leader the engine has.
  * WAL completions are inline (LS-1 rule 0); timers, the WAL file
  * offsets and the `external` reply flag of entries are not modelled.
  * Deliberately literal (forward loops over the log tail exactly as written).
@@ -52,6 +64,8 @@ typedef struct {
     uint8_t votes;            /* votes_granted as a bitmask */
     uint64_t curr_term;
     uint64_t *log_term;       /* term of every entry; index = slot - start_slot */
+    uint8_t *log_mask;        /* CRaft: avail_shards_map of every entry's codeword */
+    uint64_t n_recon_data, n_postponed;   /* CRaft follower: reconstruct_data calls, executions postponed for lack of shards */
     uint32_t n_log, cap_log, start_slot;
     uint32_t ring_W, ring_lo; /* harness guard shared with the engine, whose log is a ring of W entry terms: once the
                                * log has reached length n, slots below n - W are gone for good (also after a truncation) */
@@ -74,14 +88,19 @@ typedef struct {
 
 static uint32_t log_end(const RaftRep *r) { return r->start_slot + r->n_log; }
 
-static void log_push(RaftRep *r, uint64_t term) {
+static void log_push_m(RaftRep *r, uint64_t term, uint8_t mask) {
     if (r->n_log == r->cap_log) {
         r->cap_log = r->cap_log ? r->cap_log * 2 : 16;
         r->log_term = (uint64_t *)realloc(r->log_term, sizeof(uint64_t) * r->cap_log);
+        r->log_mask = (uint8_t *)realloc(r->log_mask, r->cap_log);
     }
+    r->log_mask[r->n_log] = mask;
     r->log_term[r->n_log++] = term;
     if (r->ring_W && log_end(r) > r->ring_W && log_end(r) - r->ring_W > r->ring_lo) r->ring_lo = log_end(r) - r->ring_W;
 }
+
+/* an entry its holder created (or, in plain Raft, any entry): every shard (craft/request.rs:71-76) */
+static void log_push(RaftRep *r, uint64_t term) { log_push_m(r, term, (uint8_t)((1u << r->population) - 1u)); }
 
 void *orc_raft_new(uint32_t G, uint8_t R, uint32_t W, uint8_t leader_id, uint64_t term, uint8_t commit_extra) {
     RaftCl *cl = (RaftCl *)calloc(1, sizeof(RaftCl));
@@ -103,7 +122,7 @@ void *orc_raft_new(uint32_t G, uint8_t R, uint32_t W, uint8_t leader_id, uint64_
 
 void orc_raft_free(void *h) {
     RaftCl *cl = (RaftCl *)h;
-    for (uint32_t g = 0; g < cl->G; g++) free(cl->reps[g].log_term);
+    for (uint32_t g = 0; g < cl->G; g++) { free(cl->reps[g].log_term); free(cl->reps[g].log_mask); }
     free(cl->reps); free(cl);
 }
 
@@ -365,6 +384,128 @@ void orc_raft_handle_append_entries(void *h, const uint8_t *flags, const uint8_t
         handle_msg_append_entries(&cl->reps[g], cl->W, leader[g], term[g], prev_slot[g], prev_term[g], n,
                                   entry_term + g, G, leader_commit[g], last_snap[g], &r_flags[g], &r_term[g],
                                   &r_end[g], &r_cterm[g], &r_cslot[g]);
+    }
+}
+
+/* craft/messages.rs:14-254 + craft/durability.rs:129-165.  emask[s]: avail_shards_map of the s-th entry's codeword.
+ * Reply: flags bit0 = a reply is sent, bit1 = conflict */
+static void craft_handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t leader, uint64_t term, uint32_t prev_slot,
+                                            uint64_t prev_term, uint32_t n, const uint64_t *ent, const uint8_t *emask,
+                                            size_t ent_stride, uint32_t leader_commit, uint32_t last_snap, uint8_t *r_flags,
+                                            uint64_t *r_term, uint32_t *r_end, uint64_t *r_cterm, uint32_t *r_cslot) {
+    *r_flags = 0; *r_term = 0; *r_end = 0; *r_cterm = 0; *r_cslot = 0;
+    if (check_term(r, leader, term) || r->role != ROLE_FOLLOWER) {            /* :33-40 */
+        if (term == r->curr_term && r->role == ROLE_CANDIDATE) {
+            r->curr_term -= 1;
+            check_term(r, leader, term);
+        } else return;
+    }
+    int ok; uint64_t t_prev = term_at(r, prev_slot, W, &ok);
+    if (term < r->curr_term || prev_slot < r->start_slot || prev_slot >= log_end(r) || !ok || t_prev != prev_term) {   /* :43-47, heartbeats too */
+        uint64_t conflict_term = (prev_slot >= r->start_slot && prev_slot < log_end(r) && ok) ? t_prev : 0;
+        uint32_t conflict_slot = prev_slot;
+        while (conflict_term > 0 && conflict_slot > r->start_slot) {          /* :56-64 */
+            int ok2; uint64_t t = term_at(r, conflict_slot - 1, W, &ok2);
+            if (ok2 && t == conflict_term) conflict_slot--; else break;
+        }
+        *r_flags = 3; *r_term = r->curr_term; *r_end = prev_slot + n;         /* :66-73 */
+        *r_cterm = conflict_term; *r_cslot = conflict_slot;
+        if (term >= r->curr_term) r->leader = leader;                         /* :81-84 (+ heard_heartbeat: a timer) */
+        return;
+    }
+    r->leader = leader;                                                       /* :89-90 */
+    const uint8_t data = (uint8_t)((1u << r->quorum_cnt) - 1u);
+    uint32_t first_new = prev_slot + 1;                                       /* :93-147 */
+    for (uint32_t s = 0; s < n; s++) {
+        uint32_t slot = prev_slot + 1 + s;
+        if (slot >= log_end(r)) { first_new = slot; break; }
+        int ok3; uint64_t t = term_at(r, slot, W, &ok3);
+        if (!ok3 || t != ent[s * ent_stride]) {
+            r->n_log = slot - r->start_slot;                                  /* :129 truncate */
+            r->n_trunc++;
+            first_new = slot;
+            break;
+        }
+        uint8_t *m = &r->log_mask[slot - r->start_slot];                      /* :133-146 no conflict: absorb the sent shards */
+        const uint8_t em = emask[s * ent_stride];
+        if (__builtin_popcount(*m & data) < r->quorum_cnt && *m != em) *m |= em;
+    }
+    uint32_t skipped = first_new - prev_slot - 1, num_appended = 0;           /* :149-173 */
+    uint32_t slot_e = prev_slot + n;
+    for (uint32_t s = skipped; s < n; s++) {
+        uint32_t slot = (s - skipped) + first_new;
+        log_push_m(r, ent[s * ent_stride], emask[s * ent_stride]);
+        num_appended++;
+        if (!(slot < r->start_slot || r->role != ROLE_FOLLOWER) && slot == slot_e && r->leader != NO_LEADER) {   /* durability.rs:129-165 */
+            *r_flags = 1; *r_term = r->curr_term; *r_end = slot_e;
+        }
+    }
+    if (num_appended == 0) { *r_flags = 1; *r_term = r->curr_term; *r_end = first_new - 1; }   /* :176-185 */
+    if (leader_commit > r->last_commit) {                                     /* :188-237; entries.len() is now `skipped` */
+        uint32_t new_commit = leader_commit < prev_slot + skipped ? leader_commit : prev_slot + skipped;
+        if (new_commit > log_end(r) - 1) new_commit = log_end(r) - 1;
+        for (uint32_t slot = r->last_commit + 1; slot <= new_commit; slot++) {
+            if (slot < r->ring_lo) break;                                     /* harness guard shared with the engine: left the ring */
+            uint8_t *m = &r->log_mask[slot - r->start_slot];
+            if (__builtin_popcount(*m) < r->quorum_cnt) { r->n_postponed++; break; }      /* :197-208 not enough shards yet */
+            else if (__builtin_popcount(*m & data) < r->quorum_cnt) { *m |= data; r->n_recon_data++; }   /* :209-212 reconstruct_data */
+            r->n_exec++;                                                      /* :213-229 */
+            r->last_commit = slot;                                            /* :233 */
+        }
+    }
+    if (last_snap > r->last_snap) r->last_snap = last_snap;                   /* :240-242 */
+}
+
+void orc_craft_handle_append_entries(void *h, const uint8_t *flags, const uint8_t *leader, const uint64_t *term,
+                                     const uint32_t *prev_slot, const uint64_t *prev_term, const uint32_t *n_entries,
+                                     const uint64_t *entry_term, const uint8_t *entry_mask, uint32_t K, const uint32_t *leader_commit,
+                                     const uint32_t *last_snap, uint8_t *r_flags, uint64_t *r_term, uint32_t *r_end,
+                                     uint64_t *r_cterm, uint32_t *r_cslot) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        r_flags[g] = 0; r_term[g] = 0; r_end[g] = 0; r_cterm[g] = 0; r_cslot[g] = 0;
+        if (!(flags[g] & 1)) continue;
+        uint32_t n = n_entries[g] < K ? n_entries[g] : K;
+        craft_handle_msg_append_entries(&cl->reps[g], cl->W, leader[g], term[g], prev_slot[g], prev_term[g], n,
+                                        entry_term + g, entry_mask + g, G, leader_commit[g], last_snap[g], &r_flags[g], &r_term[g],
+                                        &r_end[g], &r_cterm[g], &r_cslot[g]);
+    }
+}
+
+/* craft/messages.rs:622-663: Reconstruct { slots } from `peer`: n[g] (slot, term) pairs [K][G]; the ReconstructReply holds the
+ * codeword of every slot I have under that term: r_has[K][G] (1 = in the reply), r_mask[K][G]; r_n[g] = how many (0: no reply) */
+void orc_craft_handle_reconstruct(void *h, const uint32_t *n, const uint32_t *slot, const uint64_t *term, uint32_t K, uint32_t *r_n,
+                                  uint8_t *r_has, uint8_t *r_mask) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        r_n[g] = 0;
+        for (uint32_t k = 0; k < K; k++) {
+            const size_t o = (size_t)k * G + g;
+            r_has[o] = 0; r_mask[o] = 0;
+            if (k >= n[g]) continue;
+            int ok; uint64_t t = term_at(r, slot[o], cl->W, &ok);
+            if (slot[o] < r->start_slot || slot[o] >= log_end(r) || !ok || t != term[o]) continue;   /* :631-636 */
+            r_has[o] = 1; r_mask[o] = r->log_mask[slot[o] - r->start_slot]; r_n[g]++;
+        }
+    }
+}
+
+/* CRaft follower state: the entries' shard bitmaps [W][G] by slot % W (slots outside the log or the ring: 0), counters[2] =
+ * reconstruct_data calls, postponed executions */
+void orc_craft_dump_masks(void *h, uint8_t *mask, uint64_t *counters) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G, W = cl->W;
+    counters[0] = counters[1] = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        counters[0] += r->n_recon_data; counters[1] += r->n_postponed;
+        for (uint32_t w = 0; w < W; w++) mask[(size_t)w * G + g] = 0;
+        uint32_t end = log_end(r), lo = end > W ? end - W : r->start_slot;
+        if (lo < r->ring_lo) lo = r->ring_lo;
+        for (uint32_t s = lo; s < end; s++) mask[(size_t)(s % W) * G + g] = r->log_mask[s - r->start_slot];
     }
 }
 

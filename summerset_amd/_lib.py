@@ -103,7 +103,7 @@ _vp, _u8, _u32, _u64, _i = C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.c_in
 class RaftAppendEntries(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("leader", C.c_void_p), ("term", C.c_void_p), ("prev_slot", C.c_void_p),
                 ("prev_term", C.c_void_p), ("n_entries", C.c_void_p), ("entry_term", C.c_void_p),
-                ("max_entries", C.c_uint32), ("leader_commit", C.c_void_p), ("last_snap", C.c_void_p)]
+                ("max_entries", C.c_uint32), ("leader_commit", C.c_void_p), ("last_snap", C.c_void_p), ("entry_mask", C.c_void_p)]
 
 
 class RaftAppendReply(C.Structure):
@@ -245,6 +245,8 @@ SYMBOLS = [
     ("smr_raft_craft_switch_assignment_mode", _i, [_vp, _vp, _vp]),
     ("smr_raft_craft_assignment", _i, [_vp, _vp, _vp, _vp]),
     ("smr_raft_craft_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_craft_handle_reconstruct", _i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
+    ("smr_raft_craft_dump_masks", _i, [_vp, _vp, _vp]),
     ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),
     ("smr_ep_replica_destroy", None, [_vp]),
     ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),

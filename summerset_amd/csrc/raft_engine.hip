@@ -34,7 +34,9 @@ struct RaftView {
     uint32_t *ring_lo;                                  // lowest slot whose term is still in the W-entry ring
     uint32_t *next_slot, *try_next_slot, *match_slot;   // [R][G]
     uint64_t *entry_term;                               // [W][G]
-    unsigned long long *counters;                       // commits, redirects, rejects, entries sent
+    uint8_t *entry_mask;                                // [W][G] CRaft: avail_shards_map of the entry's codeword (NULL: plain Raft)
+    unsigned long long *counters;                       // commits, redirects, rejects, entries sent; CRaft follower: reconstruct_data
+                                                        // calls, executions postponed for lack of shards
 };
 
 // CRaft leader variant (src/protocols/craft/, a fork of raft/): the fall-back flag of craft/mod.rs:283 and the
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                     if (len - snap >= v.W) { c[2]++; continue; }   // ring back-pressure
                     const uint32_t slot = len;                   // request.rs:77
                     v.entry_term[(size_t)(slot & v.Wmask) * v.G + g] = term;
+                    if (v.entry_mask) v.entry_mask[(size_t)(slot & v.Wmask) * v.G + g] = (uint8_t)((1u << v.R) - 1u);   // craft/request.rs:71-76: every shard
                     len++;
                     // durability.rs:28-88: who is sent entries, try_next_slot
 #pragma unroll
@@ -382,11 +385,16 @@ struct RaftLane {
     }
 };
 
-// messages.rs:13-218 + durability.rs:97-132
+// messages.rs:13-218 + durability.rs:97-132.  CRAFT: the fork's follower (craft/messages.rs:14-254): the consistency check
+// also on heartbeats (:43-47), the leader recorded also when it fails (:81-84), the shards of a re-sent entry absorbed
+// (:133-146, RSCodeword::absorb_other as an OR of availability bitmaps), and execution only of entries with `majority`
+// shards, after reconstruct_data when too few of them are data shards (:193-233); entry_mask[s][g] = avail_shards_map of
+// the s-th sent entry
+template <bool CRAFT>
 __global__ __launch_bounds__(256) void raft_append_entries_kernel(
     const RaftView v, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ leader_id,
     const uint64_t *__restrict__ term, const uint32_t *__restrict__ prev_slot, const uint64_t *__restrict__ prev_term,
-    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, uint32_t K,
+    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, const uint8_t *__restrict__ entry_mask, uint32_t K,
     const uint32_t *__restrict__ leader_commit, const uint32_t *__restrict__ last_snap, uint8_t *__restrict__ r_flags,
     uint64_t *__restrict__ r_term, uint32_t *__restrict__ r_end, uint64_t *__restrict__ r_cterm,
     uint32_t *__restrict__ r_cslot) {
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
         if (go) {
             uint64_t t_prev = 0;
             const bool ok = L.term_at(ps, t_prev);
-            if (n != 0 && (tm < L.term || ps < L.start || ps >= L.len || !ok || t_prev != pt)) {   // :46-51
+            if ((CRAFT || n != 0) && (tm < L.term || ps < L.start || ps >= L.len || !ok || t_prev != pt)) {   // :46-51
                 const uint64_t ct = (ps >= L.start && ps < L.len && ok) ? t_prev : 0;
                 uint32_t cs = ps;
                 while (ct > 0 && cs > L.start) {                                // :60-68
@@ -414,7 +422,9 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                     if (L.term_at(cs - 1, t) && t == ct) cs--; else break;
                 }
                 of = 3; ot = L.term; oe = ps + n; oct = ct; ocs = cs;            // :70-77
+                if (CRAFT && tm >= L.term) L.leader = ld;                       // craft/messages.rs:81-84
             } else {
+                const uint32_t quorum = v.R / 2 + 1, data = (1u << quorum) - 1u;
                 L.leader = ld;                                                  // :94
                 uint32_t first_new = ps + 1;                                    // :99-139
                 for (uint32_t s = 0; s < n; s++) {
@@ -427,6 +437,11 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                         first_new = slot;
                         break;
                     }
+                    if (CRAFT) {                                                // craft/messages.rs:133-146 absorb the sent shards
+                        const size_t mi = (size_t)(slot & v.Wmask) * v.G + g;
+                        const uint32_t m = v.entry_mask[mi], em = entry_mask[(size_t)s * v.G + g];
+                        if ((uint32_t)__popc(m & data) < quorum && m != em) v.entry_mask[mi] = (uint8_t)(m | em);
+                    }
                 }
                 // :143-167: everything from first_new on is PUSHED (also when nothing differed)
                 const uint32_t skipped = first_new - ps - 1, slot_e = ps + n;
@@ -434,6 +449,7 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                 for (uint32_t s = skipped; s < n; s++) {
                     const uint32_t slot = (s - skipped) + first_new;
                     v.entry_term[(size_t)(L.len & v.Wmask) * v.G + g] = entry_term[(size_t)s * v.G + g];
+                    if (CRAFT) v.entry_mask[(size_t)(L.len & v.Wmask) * v.G + g] = entry_mask[(size_t)s * v.G + g];
                     L.len++;
                     if (L.len > v.W && L.len - v.W > L.rlo) L.rlo = L.len - v.W;
                     appended++;
@@ -446,8 +462,22 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                 if (lc > L.commit) {                                            // :184-208 (entries.len() == skipped by now)
                     uint32_t nc = lc < ps + skipped ? lc : ps + skipped;
                     if (nc > L.len - 1) nc = L.len - 1;
-                    if (nc > L.commit) v.n_exec[g] += nc - L.commit;
-                    L.commit = nc;
+                    if (!CRAFT) {
+                        if (nc > L.commit) v.n_exec[g] += nc - L.commit;
+                        L.commit = nc;
+                    } else {
+                        uint32_t ex = 0;
+                        for (uint32_t slot = L.commit + 1; slot <= nc; slot++) {   // craft/messages.rs:193-233
+                            if (slot < L.rlo) break;                            // harness guard: the entry left the ring
+                            const size_t mi = (size_t)(slot & v.Wmask) * v.G + g;
+                            const uint32_t m = v.entry_mask[mi];
+                            if ((uint32_t)__popc(m) < quorum) { ctr_add(v.counters, 5, 1); break; }          // not enough shards yet
+                            if ((uint32_t)__popc(m & data) < quorum) { v.entry_mask[mi] = (uint8_t)(m | data); ctr_add(v.counters, 4, 1); }   // reconstruct_data
+                            ex++;
+                            L.commit = slot;
+                        }
+                        if (ex) v.n_exec[g] += ex;
+                    }
                 }
                 const uint32_t ls = last_snap[g];
                 if (ls > L.snap) L.snap = ls;                                   // :211-213
@@ -456,6 +486,29 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
         L.store();
     }
     r_flags[g] = of; r_term[g] = ot; r_end[g] = oe; r_cterm[g] = oct; r_cslot[g] = ocs;
+}
+
+// craft/messages.rs:622-663 handle_msg_reconstruct: the codeword (as its availability bitmap) of every asked slot I hold
+// under the asked term
+__global__ __launch_bounds__(256) void craft_reconstruct_kernel(const RaftView v, const uint32_t *__restrict__ n, const uint32_t *__restrict__ slot,
+                                                                const uint64_t *__restrict__ term, uint32_t K, uint32_t *__restrict__ r_n,
+                                                                uint8_t *__restrict__ r_has, uint8_t *__restrict__ r_mask) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    const uint32_t start = v.start_slot[g], len = v.log_len[g], rlo = v.ring_lo[g], cnt = n[g];
+    uint32_t out = 0;
+    for (uint32_t k = 0; k < K; k++) {
+        const size_t o = (size_t)k * v.G + g;
+        uint8_t has = 0, m = 0;
+        if (k < cnt) {
+            const uint32_t sl = slot[o];
+            if (sl >= start && sl < len && sl >= rlo && v.entry_term[(size_t)(sl & v.Wmask) * v.G + g] == term[o]) {   // :631-636
+                has = 1; m = v.entry_mask[(size_t)(sl & v.Wmask) * v.G + g]; out++;
+            }
+        }
+        r_has[o] = has; r_mask[o] = m;
+    }
+    r_n[g] = out;
 }
 
 // leadership.rs:76-142
@@ -689,13 +742,16 @@ int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t r
     if (fault_tolerance > R - quorum) return fail(SMR_ERR_ARG, "craft: fault_tolerance too large");   // craft/mod.rs:528-533
     const size_t G = l->v.G;
     const size_t n8 = (R * G * 8 + 255) & ~(size_t)255, n1 = (R * G + 255) & ~(size_t)255, ng = (G + 255) & ~(size_t)255;
-    const size_t total = 2 * n8 + n1 + 2 * ng;
+    const size_t nm = ((size_t)l->v.W * G + 255) & ~(size_t)255;
+    const size_t total = 2 * n8 + n1 + 2 * ng + nm;
     SMR_HIP_TRY(hipMalloc((void **)&l->craft_base, total));
     SMR_HIP_TRY(hipMemset(l->craft_base, 0, total));
     CraftView &cv = l->cv;
     uint8_t *b = l->craft_base;
     cv.hb_replied = (uint64_t *)b; b += n8; cv.hb_seen = (uint64_t *)b; b += n8;
-    cv.hb_repeat = b; b += n1; cv.full_copy = b; b += ng; cv.alive = b;
+    cv.hb_repeat = b; b += n1; cv.full_copy = b; b += ng; cv.alive = b; b += ng;
+    l->v.entry_mask = b;                                       // the dummy entry 0 and whatever the log holds so far: every shard
+    SMR_HIP_TRY(hipMemset(l->v.entry_mask, (int)((1u << R) - 1u), (size_t)l->v.W * G));
     cv.ft = fault_tolerance; cv.rep_thr = repeat_threshold; cv.quorum = quorum;
     std::vector<uint64_t> one(R * G, 1);                      // heartbeat.rs:117-119 reply_cnts start at (1, 0, 0)
     for (size_t g = 0; g < G; g++) one[(size_t)l->v.me * G + g] = 0;
@@ -804,11 +860,52 @@ int smr_raft_replica_handle_append_entries(smr_raft_leader *l, const smr_raft_ap
         !m->leader_commit || !m->last_snap || (m->max_entries && !m->entry_term) || !r->flags || !r->term ||
         !r->end_slot || !r->conflict_term || !r->conflict_slot)
         return fail(SMR_ERR_ARG, "raft: null argument");
-    hipLaunchKernelGGL(raft_append_entries_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
-                       m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term,
-                       m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
-                       r->conflict_slot);
+    if (l->craft) {
+        if (m->max_entries && !m->entry_mask) return fail(SMR_ERR_ARG, "craft: AppendEntries without the entries' shard bitmaps");
+        hipLaunchKernelGGL(raft_append_entries_kernel<true>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                           m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term, m->entry_mask,
+                           m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
+                           r->conflict_slot);
+    } else
+        hipLaunchKernelGGL(raft_append_entries_kernel<false>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
+                           m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term, (const uint8_t *)nullptr,
+                           m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
+                           r->conflict_slot);
     SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_handle_reconstruct(smr_raft_leader *l, const uint32_t *n_dev, const uint32_t *slot_dev, const uint64_t *term_dev,
+                                      uint32_t max_slots, uint32_t *r_n_dev, uint8_t *r_has_dev, uint8_t *r_mask_dev, void *stream) {
+    if (!l || !n_dev || !slot_dev || !term_dev || !r_n_dev || !r_has_dev || !r_mask_dev) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this replica");
+    hipLaunchKernelGGL(craft_reconstruct_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_dev, slot_dev,
+                       term_dev, max_slots, r_n_dev, r_has_dev, r_mask_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_dump_masks(smr_raft_leader *l, uint8_t *mask_host, uint64_t *counters) {
+    if (!l || !mask_host || !counters) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this replica");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const RaftView &v = l->v;
+    const size_t G = v.G, W = v.W;
+    std::vector<uint8_t> m(W * G);
+    std::vector<uint32_t> len(G), start(G), rlo(G);
+    SMR_HIP_TRY(hipMemcpy(m.data(), v.entry_mask, W * G, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(len.data(), v.log_len, G * 4, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(start.data(), v.start_slot, G * 4, hipMemcpyDeviceToHost));
+    SMR_HIP_TRY(hipMemcpy(rlo.data(), v.ring_lo, G * 4, hipMemcpyDeviceToHost));
+    unsigned long long c[8];
+    SMR_HIP_TRY(ctr_read(v.counters, 6, c));
+    counters[0] = c[4]; counters[1] = c[5];
+    memset(mask_host, 0, W * G);                               // canonical form: only the slots the log (and the ring) holds
+    for (size_t g = 0; g < G; g++) {
+        uint32_t end = len[g], lo = end > W ? end - (uint32_t)W : start[g];
+        if (lo < rlo[g]) lo = rlo[g];
+        for (uint32_t s2 = lo; s2 < end; s2++) mask_host[(size_t)(s2 & (W - 1)) * G + g] = m[(size_t)(s2 & (W - 1)) * G + g];
+    }
     return SMR_OK;
 }
 

@@ -91,8 +91,9 @@ class RaftLeaderGroup:
         check(self._L.smr_raft_replica_preset(self._h, role, leader, term, voted_for))
 
     def handle_msg_append_entries(self, flags, leader, term, prev_slot, prev_term, n_entries, entry_term,
-                                  leader_commit, last_snap, stream=None):
-        """returns the AppendEntriesReply tensors dict(flags, term, end_slot, conflict_term, conflict_slot)"""
+                                  leader_commit, last_snap, entry_mask=None, stream=None):
+        """returns the AppendEntriesReply tensors dict(flags, term, end_slot, conflict_term, conflict_slot); entry_mask
+        [K, G] uint8 (CRaft replicas only): avail_shards_map of every sent entry's codeword"""
         import torch
         dev, G = flags.device, self.G
         r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev),
@@ -100,7 +101,7 @@ class RaftLeaderGroup:
                  conflict_term=torch.zeros(G, dtype=torch.int64, device=dev),
                  conflict_slot=torch.zeros(G, dtype=torch.int32, device=dev))
         m = RaftAppendEntries(_ptr(flags), _ptr(leader), _ptr(term), _ptr(prev_slot), _ptr(prev_term), _ptr(n_entries),
-                              _ptr(entry_term), int(entry_term.shape[0]), _ptr(leader_commit), _ptr(last_snap))
+                              _ptr(entry_term), int(entry_term.shape[0]), _ptr(leader_commit), _ptr(last_snap), _ptr(entry_mask))
         rr = RaftAppendReply(*[_ptr(r[k]) for k in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])
         check(self._L.smr_raft_replica_handle_append_entries(self._h, C.byref(m), C.byref(rr), stream_ptr(stream)))
         return r
@@ -151,7 +152,9 @@ class CRaftLeaderGroup(RaftLeaderGroup):
     (`switch_assignment_mode`, craft/leadership.rs:80-141) that `bcast_heartbeats` enters when the Heartbeater's reply
     counters (server/heartbeat.rs:240-296) say `fault_tolerance` or more peers are gone (craft/leadership.rs:283-288),
     and the shard assignment of a new entry's RS codeword (craft/request.rs:71-100; the shards themselves:
-    `rscoding.RSCodeword`).  Leader side only: every entry of the log was created by this leader."""
+    `rscoding.RSCodeword`).  Leader side: every entry of the log was created by this leader.  Follower side
+    (`preset(role=0, ...)`): `handle_msg_append_entries` follows the fork's handler (craft/messages.rs:14-254) with the
+    entries' shard bitmaps, `handle_msg_reconstruct` answers a Reconstruct (craft/messages.rs:622-663)."""
 
     def __init__(self, n_groups, population=5, leader_id=0, window=64, term=1, fault_tolerance=1, repeat_threshold=3):
         super().__init__(n_groups, population, leader_id, window, term, commit_extra=0)
@@ -188,3 +191,25 @@ class CRaftLeaderGroup(RaftLeaderGroup):
         check(self._L.smr_raft_craft_dump(self._h, *[out[k].ctypes.data_as(C.c_void_p) for k in
                                                      ("full_copy_mode", "peer_alive", "hb_replied", "hb_seen", "hb_repeat")]))
         return out
+
+
+def _craft_follower_methods():
+    def handle_msg_reconstruct(self, n, slot, term, stream=None):
+        """Reconstruct { slots }: n [G], slot [K, G] int32, term [K, G] int64 -> dict(n [G], has [K, G], mask [K, G])"""
+        import torch
+        dev, G, K = n.device, self.G, int(slot.shape[0])
+        r = dict(n=torch.zeros(G, dtype=torch.int32, device=dev), has=torch.zeros((K, G), dtype=torch.uint8, device=dev),
+                 mask=torch.zeros((K, G), dtype=torch.uint8, device=dev))
+        check(self._L.smr_raft_craft_handle_reconstruct(self._h, _ptr(n), _ptr(slot), _ptr(term), K, _ptr(r["n"]), _ptr(r["has"]),
+                                                        _ptr(r["mask"]), stream_ptr(stream)))
+        return r
+
+    def dump_masks(self):
+        d = dict(mask=np.zeros((self.W, self.G), np.uint8), counters=np.zeros(2, np.uint64))
+        check(self._L.smr_raft_craft_dump_masks(self._h, d["mask"].ctypes.data_as(C.c_void_p), d["counters"].ctypes.data_as(C.c_void_p)))
+        return d
+    CRaftLeaderGroup.handle_msg_reconstruct = handle_msg_reconstruct
+    CRaftLeaderGroup.dump_masks = dump_masks
+
+
+_craft_follower_methods()

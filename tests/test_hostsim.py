@@ -243,6 +243,15 @@ def test_string_kv_state_machine_kernel_on_the_host(sim):
         t.test_full_table_and_heap_are_sticky_not_silent("cpu")
 
 
+def test_craft_follower_kernels_on_the_host(sim, oracle):
+    """the CRaft follower (shard bitmaps absorbed, execution gated on `majority` shards) and the Reconstruct responder"""
+    import test_zz_craft_follower_gpu as t
+    with sim.patched():
+        for trace in t.TRACES:
+            t.test_trace_on_the_engine("cpu", trace)
+        t.test_crafted_rounds_match_the_oracle("cpu", oracle, 300, 32, 1)
+
+
 def test_epaxos_explicit_prepare_kernels_on_the_host(sim, oracle):
     """EPaxos recovery of a dead command leader's row: the hand-derived traces on the kernels, and a crash-and-recovery cluster
     run against the oracle cluster, call by call"""
