@@ -439,10 +439,17 @@ int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uin
  * smr_raft_append_entries.entry_mask.  handle_msg_reconstruct (craft/messages.rs:622-663): n[g] asked (slot, term) pairs
  * [max_slots][G] -> r_has / r_mask [max_slots][G] (the codeword of every slot held under that term, as its bitmap),
  * r_n[g] of them (0: no ReconstructReply).  dump: the entries' bitmaps [W][G] by slot % W, counters[2] = reconstruct_data
- * calls, executions postponed for lack of shards.  Not built: the leader's own shard gate with its Reconstruct
- * broadcasts (craft/messages.rs:315-358) and handle_msg_reconstruct_reply (:665-745). */
+ * calls, executions postponed for lack of shards.
+ * A leader that was a follower once holds entries without every shard: smr_raft_leader_handle_replies then executes only
+ * what it has `majority` shards of and queues the slots it lacks (craft/messages.rs:315-358); smr_raft_craft_poll_reconstructs
+ * hands over (and clears) that queue -- the Reconstruct { slots } to broadcast: n[g] <= max_slots <= 16, slot / term
+ * [max_slots][G].  smr_raft_craft_handle_reconstruct_reply: handle_msg_reconstruct_reply (:665-745) for the ReconstructReply of
+ * peer[g] (SMR_NO_REPLICA: none): n[g] (slot, bitmap) pairs [max_slots][G]. */
 int smr_raft_craft_handle_reconstruct(smr_raft_leader *l, const uint32_t *n_dev, const uint32_t *slot_dev, const uint64_t *term_dev,
                                       uint32_t max_slots, uint32_t *r_n_dev, uint8_t *r_has_dev, uint8_t *r_mask_dev, void *stream);
+int smr_raft_craft_poll_reconstructs(smr_raft_leader *l, uint32_t max_slots, uint32_t *n_dev, uint32_t *slot_dev, uint64_t *term_dev, void *stream);
+int smr_raft_craft_handle_reconstruct_reply(smr_raft_leader *l, const uint8_t *peer_dev, const uint32_t *n_dev, const uint32_t *slot_dev,
+                                            const uint8_t *mask_dev, uint32_t max_slots, void *stream);
 int smr_raft_craft_dump_masks(smr_raft_leader *l, uint8_t *mask_host, uint64_t *counters);
 
 /* ------------------------------------------------------------------------

@@ -97,6 +97,8 @@ def _declare(L):
     L.orc_craft_handle_append_entries.argtypes = [vp] + [vp] * 8 + [u32] + [vp] * 7
     L.orc_craft_handle_reconstruct.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp]
     L.orc_craft_dump_masks.argtypes = [vp, vp, vp]
+    L.orc_craft_take_reconstructs.argtypes = [vp, u32, vp, vp, vp]
+    L.orc_craft_handle_reconstruct_reply.argtypes = [vp, vp, vp, vp, vp, u32]
     L.orc_ep_new.restype = vp; L.orc_ep_new.argtypes = [u32, u8, u8, u32, u32, u8]
     L.orc_ep_free.argtypes = [vp]
     L.orc_ep_propose.argtypes = [vp] + [vp] * 6
@@ -438,6 +440,15 @@ class CRaftOracle(RaftOracle):
         d = dict(mask=np.zeros((self.W, self.G), np.uint8), counters=np.zeros(2, np.uint64))
         lib().orc_craft_dump_masks(self.h, _p(d["mask"]), _p(d["counters"]))
         return d
+
+    def take_reconstructs(self, K=16):
+        """the Reconstruct { slots } the reply handler queued since the last call: dict(n [G], slot / term [K, G])"""
+        r = dict(n=np.zeros(self.G, np.uint32), slot=np.zeros((K, self.G), np.uint32), term=np.zeros((K, self.G), np.uint64))
+        lib().orc_craft_take_reconstructs(self.h, K, _p(r["n"]), _p(r["slot"]), _p(r["term"]))
+        return r
+
+    def handle_reconstruct_reply(self, peer, n, slot, mask):
+        lib().orc_craft_handle_reconstruct_reply(self.h, _p(peer), _p(n), _p(slot), _p(mask), slot.shape[0])
 
 
 

@@ -38,9 +38,10 @@
  *   RSCodeword::absorb_other / reconstruct_data / avail_shards / avail_data_shards   utils/rscoding.rs:296-, as bitmaps
  * An entry's codeword is its availability bitmap over the population's shards (data shards 0 .. majority-1); payload
  * bytes are the RS kernels' business.  data_len of a re-sent entry equals the stored one (same slot, same term = same
- * entry), so craft/messages.rs:133-134's data_len test is always true here.  NOT restated: the leader's own shard gate
- * and its Reconstruct broadcasts (craft/messages.rs:315-358) and handle_msg_reconstruct_reply (:665-745) -- a leader
- * that created its log holds every shard, the only leader the engine has.
+ * entry), so craft/messages.rs:133-134's data_len test is always true here.  The leader's own shard gate with the
+ * Reconstruct slots it asks for (craft/messages.rs:315-358; orc_craft_take_reconstructs drains what a call queued) and
+ * handle_msg_reconstruct_reply (:665-745; its HashMap of slots is walked in the order given -- the outcome does not
+ * depend on it: absorbs commute and the execution loop restarts whenever the slot behind last_commit arrives).
  * WAL completions are inline (LS-1 rule 0); timers, the WAL file
  * offsets and the `external` reply flag of entries are not modelled.
  * Deliberately literal (forward loops over the log tail exactly as written).
@@ -66,6 +67,8 @@ typedef struct {
     uint64_t *log_term;       /* term of every entry; index = slot - start_slot */
     uint8_t *log_mask;        /* CRaft: avail_shards_map of every entry's codeword */
     uint64_t n_recon_data, n_postponed;   /* CRaft follower: reconstruct_data calls, executions postponed for lack of shards */
+    uint32_t last_recon;                  /* CRaft leader: highest slot a Reconstruct was asked for (craft/mod.rs) */
+    uint32_t rq_n, rq_slot[16]; uint64_t rq_term[16];   /* Reconstruct slots queued since the last take (cap 16, more are dropped) */
     uint32_t n_log, cap_log, start_slot;
     uint32_t ring_W, ring_lo; /* harness guard shared with the engine, whose log is a ring of W entry terms: once the
                                * log has reached length n, slots below n - W are gone for good (also after a truncation) */
@@ -246,10 +249,26 @@ static void handle_msg_append_entries_reply(RaftRep *r, uint32_t W, uint8_t peer
                 new_commit = slot;
             }
         }
-        /* craft/messages.rs:315-358: the leader holds every shard of an entry it created itself (request.rs:71-76,
-         * 113-119), so avail_shards() >= majority and every slot up to new_commit is submitted (can_execute stays) */
-        r->n_committed += new_commit - r->last_commit;     /* :278-293 exec submission */
-        r->last_commit = new_commit;                       /* :295 */
+        if (!r->craft) {
+            r->n_committed += new_commit - r->last_commit; /* :278-293 exec submission */
+            r->last_commit = new_commit;                   /* :295 */
+        } else {                                           /* craft/messages.rs:315-358 */
+            const uint8_t data = (uint8_t)((1u << r->quorum_cnt) - 1u);
+            int can_execute = 1;
+            for (uint32_t slot = r->last_commit + 1; slot <= new_commit; slot++) {
+                if (slot < r->ring_lo) break;              /* harness guard shared with the engine */
+                uint8_t *m = &r->log_mask[slot - r->start_slot];
+                if (__builtin_popcount(*m) < r->quorum_cnt) {            /* :318-325 ask the peers for its shards, once */
+                    if (slot > r->last_recon) {
+                        if (r->rq_n < 16) { r->rq_slot[r->rq_n] = slot; r->rq_term[r->rq_n] = r->log_term[slot - r->start_slot]; r->rq_n++; }
+                        r->last_recon = slot;
+                    }
+                    can_execute = 0;
+                    continue;
+                } else if (__builtin_popcount(*m & data) < r->quorum_cnt) { *m |= data; r->n_recon_data++; }   /* :326-328 */
+                if (can_execute) { r->n_committed++; r->last_commit = slot; }                              /* :329-345 */
+            }
+        }
         for (uint32_t slot = r->last_snap + 1; slot <= end_slot; slot++) {   /* :298-309 */
             int match_cnt = 1;
             for (int q = 0; q < r->population; q++)
@@ -489,6 +508,56 @@ void orc_craft_handle_reconstruct(void *h, const uint32_t *n, const uint32_t *sl
             int ok; uint64_t t = term_at(r, slot[o], cl->W, &ok);
             if (slot[o] < r->start_slot || slot[o] >= log_end(r) || !ok || t != term[o]) continue;   /* :631-636 */
             r_has[o] = 1; r_mask[o] = r->log_mask[slot[o] - r->start_slot]; r_n[g]++;
+        }
+    }
+}
+
+/* the Reconstruct { slots } broadcasts the reply handler queued since the last take (craft/messages.rs:347-358): n[g], slot /
+ * term [K][G] */
+void orc_craft_take_reconstructs(void *h, uint32_t K, uint32_t *n, uint32_t *slot, uint64_t *term) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        n[g] = r->rq_n < K ? r->rq_n : K;
+        for (uint32_t k = 0; k < K; k++) {
+            slot[(size_t)k * G + g] = k < n[g] ? r->rq_slot[k] : 0;
+            term[(size_t)k * G + g] = k < n[g] ? r->rq_term[k] : 0;
+        }
+        r->rq_n = 0;
+    }
+}
+
+/* craft/messages.rs:665-745: ReconstructReply { slots_data } from peer[g] (NO_LEADER: none): n[g] (slot, bitmap) pairs [K][G] */
+void orc_craft_handle_reconstruct_reply(void *h, const uint8_t *peer, const uint32_t *n, const uint32_t *slot, const uint8_t *mask,
+                                        uint32_t K) {
+    RaftCl *cl = (RaftCl *)h;
+    const uint32_t G = cl->G;
+    for (uint32_t g = 0; g < G; g++) {
+        RaftRep *r = &cl->reps[g];
+        if (peer[g] == NO_LEADER || peer[g] >= r->population) continue;
+        if (peer[g] != r->id && r->craft) update_heard_cnt(r, peer[g]);       /* :669 heard_heartbeat -> leadership.rs:300-303 */
+        uint32_t ms[MAXR]; int nm = 0;                                        /* :670-683 shadow_last_commit */
+        for (int q = 0; q < r->population; q++) if (q != r->id) ms[nm++] = r->match_slot[q];
+        for (int a = 0; a < nm; a++) for (int b = a + 1; b < nm; b++) if (ms[b] > ms[a]) { uint32_t t = ms[a]; ms[a] = ms[b]; ms[b] = t; }
+        const int idx = r->full_copy_mode ? r->quorum_cnt - 2 : r->quorum_cnt + r->fault_tolerance - 2;
+        const uint32_t shadow = ms[idx];
+        const uint8_t data = (uint8_t)((1u << r->quorum_cnt) - 1u);
+        for (uint32_t k = 0; k < K && k < n[g]; k++) {
+            const uint32_t sl = slot[(size_t)k * G + g];
+            if (sl < r->start_slot || sl >= log_end(r) || sl < r->ring_lo) continue;   /* :685-687 (+ the debug_assert, the ring guard) */
+            r->log_mask[sl - r->start_slot] |= mask[(size_t)k * G + g];                 /* :697 absorb_other */
+            if (sl == r->last_commit + 1) {                                   /* :699-737 */
+                while (r->last_commit < shadow) {
+                    const uint32_t nx = r->last_commit + 1;
+                    if (nx >= log_end(r) || nx < r->ring_lo) break;           /* (harness guards) */
+                    uint8_t *m = &r->log_mask[nx - r->start_slot];
+                    if (__builtin_popcount(*m) < r->quorum_cnt) break;
+                    if (__builtin_popcount(*m & data) < r->quorum_cnt) { *m |= data; r->n_recon_data++; }
+                    r->n_committed++;
+                    r->last_commit += 1;
+                }
+            }
         }
     }
 }

@@ -247,6 +247,8 @@ SYMBOLS = [
     ("smr_raft_craft_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_handle_reconstruct", _i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_dump_masks", _i, [_vp, _vp, _vp]),
+    ("smr_raft_craft_poll_reconstructs", _i, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    ("smr_raft_craft_handle_reconstruct_reply", _i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),
     ("smr_ep_replica_destroy", None, [_vp]),
     ("smr_ep_propose", _i, [_vp, _vp, _vp, C.POINTER(EpMsg), _vp]),

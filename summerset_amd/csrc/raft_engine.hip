@@ -46,7 +46,13 @@ struct CraftView {
     uint8_t *full_copy, *alive;                          // [G]; alive = peer_alive bitmap
     uint8_t *hb_repeat;                                  // [R][G] reply_cnts.2
     uint64_t *hb_replied, *hb_seen;                      // [R][G] reply_cnts.0 / .1
+    // a leader that did not create its whole log (it was a follower once): the shard gate of craft/messages.rs:315-358
+    uint8_t *partial;                                    // [G] the log may hold an entry without every shard (set by the follower kernel)
+    uint32_t *last_recon, *rq_n;                         // [G] highest slot a Reconstruct was asked for; slots queued since the last poll
+    uint32_t *rq_slot;                                   // [CRAFT_RQ][G]
+    uint64_t *rq_term;                                   // [CRAFT_RQ][G]
 };
+constexpr uint32_t CRAFT_RQ = 16;
 
 __device__ __forceinline__ void raft_flush(const RaftView &v, unsigned int c[4]) {
     for (int k = 0; k < 4; k++) {
@@ -259,8 +265,31 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                 if (s2 < rlo) break;                            // beyond the term ring
                 const uint64_t e = s2 == hi ? et[q] : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + g];
                 if (e == lead_term) {
-                    c[0] += s2 - commit;                        // :278-293 exec submissions
-                    commit = s2;
+                    if (!CRAFT || !cv.partial[g]) {
+                        c[0] += s2 - commit;                    // :278-293 exec submissions
+                        commit = s2;
+                    } else {                                    // craft/messages.rs:315-358: only what I hold enough shards of
+                        const uint32_t data = (1u << cv.quorum) - 1u;
+                        bool can_execute = true;
+                        for (uint32_t sl = commit + 1; sl <= s2; sl++) {
+                            if (sl < rlo) break;                // harness guard: the entry left the ring
+                            const size_t mi = (size_t)(sl & v.Wmask) * v.G + g;
+                            const uint32_t m = v.entry_mask[mi];
+                            if ((uint32_t)__popc(m) < cv.quorum) {              // :318-325 ask the peers for its shards, once
+                                if (sl > cv.last_recon[g]) {
+                                    const uint32_t k = cv.rq_n[g];
+                                    if (k < CRAFT_RQ) {
+                                        cv.rq_slot[(size_t)k * v.G + g] = sl; cv.rq_term[(size_t)k * v.G + g] = v.entry_term[mi];
+                                        cv.rq_n[g] = k + 1;
+                                    }
+                                    cv.last_recon[g] = sl;
+                                }
+                                can_execute = false;
+                                continue;
+                            } else if ((uint32_t)__popc(m & data) < cv.quorum) { v.entry_mask[mi] = (uint8_t)(m | data); ctr_add(v.counters, 4, 1); }   // :326-328
+                            if (can_execute) { c[0]++; commit = sl; }           // :329-345
+                        }
+                    }
                     break;
                 }
             }
@@ -394,7 +423,8 @@ template <bool CRAFT>
 __global__ __launch_bounds__(256) void raft_append_entries_kernel(
     const RaftView v, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ leader_id,
     const uint64_t *__restrict__ term, const uint32_t *__restrict__ prev_slot, const uint64_t *__restrict__ prev_term,
-    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, const uint8_t *__restrict__ entry_mask, uint32_t K,
+    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, const uint8_t *__restrict__ entry_mask,
+    uint8_t *__restrict__ partial, uint32_t K,
     const uint32_t *__restrict__ leader_commit, const uint32_t *__restrict__ last_snap, uint8_t *__restrict__ r_flags,
     uint64_t *__restrict__ r_term, uint32_t *__restrict__ r_end, uint64_t *__restrict__ r_cterm,
     uint32_t *__restrict__ r_cslot) {
@@ -449,7 +479,11 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                 for (uint32_t s = skipped; s < n; s++) {
                     const uint32_t slot = (s - skipped) + first_new;
                     v.entry_term[(size_t)(L.len & v.Wmask) * v.G + g] = entry_term[(size_t)s * v.G + g];
-                    if (CRAFT) v.entry_mask[(size_t)(L.len & v.Wmask) * v.G + g] = entry_mask[(size_t)s * v.G + g];
+                    if (CRAFT) {
+                        const uint8_t em = entry_mask[(size_t)s * v.G + g];
+                        v.entry_mask[(size_t)(L.len & v.Wmask) * v.G + g] = em;
+                        if (em != (uint8_t)((1u << v.R) - 1u) && !partial[g]) partial[g] = 1;   // a later leadership has to gate on shards
+                    }
                     L.len++;
                     if (L.len > v.W && L.len - v.W > L.rlo) L.rlo = L.len - v.W;
                     appended++;
@@ -509,6 +543,65 @@ __global__ __launch_bounds__(256) void craft_reconstruct_kernel(const RaftView v
         r_has[o] = has; r_mask[o] = m;
     }
     r_n[g] = out;
+}
+
+// craft/messages.rs:665-745 handle_msg_reconstruct_reply: ReconstructReply { slots_data } from peer[g] (NO_REP: none): absorb the
+// shards, and when the slot behind last_commit arrived go on executing up to the shadow commit index
+__global__ __launch_bounds__(256) void craft_reconstruct_reply_kernel(const RaftView v, const CraftView cv, const uint8_t *__restrict__ peer,
+                                                                      const uint32_t *__restrict__ n, const uint32_t *__restrict__ slot,
+                                                                      const uint8_t *__restrict__ mask, uint32_t K) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    unsigned int c[4] = {0, 0, 0, 0};
+    if (g < v.G && peer[g] != NO_REP && peer[g] < v.R) {
+        const uint32_t pe = peer[g];
+        if (pe != v.me) {                                                       // :669 heard_heartbeat -> heartbeat.rs:284-290
+            cv.hb_replied[(size_t)pe * v.G + g] += 1;
+            const uint32_t al = cv.alive[g];
+            if (!((al >> pe) & 1u)) cv.alive[g] = (uint8_t)(al | (1u << pe));
+        }
+        uint32_t ms[RMAX]; int nm = 0;                                          // :670-683 shadow_last_commit
+        for (uint32_t q = 0; q < v.R; q++) if (q != v.me) ms[nm++] = v.match_slot[(size_t)q * v.G + g];
+        for (int a = 0; a < nm; a++) for (int b = a + 1; b < nm; b++) if (ms[b] > ms[a]) { const uint32_t t = ms[a]; ms[a] = ms[b]; ms[b] = t; }
+        const uint32_t idx = cv.full_copy[g] ? cv.quorum - 2 : cv.quorum + cv.ft - 2;
+        const uint32_t shadow = ms[idx];
+        const uint32_t start = v.start_slot[g], len = v.log_len[g], rlo = v.ring_lo[g], data = (1u << cv.quorum) - 1u;
+        uint32_t commit = v.last_commit[g];
+        const uint32_t o_commit = commit, cnt = n[g] < K ? n[g] : K;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t sl = slot[(size_t)k * v.G + g];
+            if (sl < start || sl >= len || sl < rlo) continue;                  // :685-687
+            const size_t mi = (size_t)(sl & v.Wmask) * v.G + g;
+            v.entry_mask[mi] = (uint8_t)(v.entry_mask[mi] | mask[(size_t)k * v.G + g]);   // :697 absorb_other
+            if (sl == commit + 1) {                                             // :699-737
+                while (commit < shadow) {
+                    const uint32_t nx = commit + 1;
+                    if (nx >= len || nx < rlo) break;
+                    const size_t ni = (size_t)(nx & v.Wmask) * v.G + g;
+                    const uint32_t m = v.entry_mask[ni];
+                    if ((uint32_t)__popc(m) < cv.quorum) break;
+                    if ((uint32_t)__popc(m & data) < cv.quorum) { v.entry_mask[ni] = (uint8_t)(m | data); ctr_add(v.counters, 4, 1); }
+                    c[0]++;
+                    commit = nx;
+                }
+            }
+        }
+        if (commit != o_commit) v.last_commit[g] = commit;
+    }
+    raft_flush(v, c);
+}
+
+// the Reconstruct { slots } the reply kernel queued (craft/messages.rs:347-358), handed over and cleared
+__global__ __launch_bounds__(256) void craft_poll_reconstructs_kernel(const RaftView v, const CraftView cv, uint32_t K, uint32_t *__restrict__ n,
+                                                                      uint32_t *__restrict__ slot, uint64_t *__restrict__ term) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    const uint32_t have = cv.rq_n[g], cnt = have < K ? have : K;
+    for (uint32_t k = 0; k < K; k++) {
+        slot[(size_t)k * v.G + g] = k < cnt ? cv.rq_slot[(size_t)k * v.G + g] : 0u;
+        term[(size_t)k * v.G + g] = k < cnt ? cv.rq_term[(size_t)k * v.G + g] : 0ull;
+    }
+    n[g] = cnt;
+    if (have) cv.rq_n[g] = 0;
 }
 
 // leadership.rs:76-142
@@ -743,7 +836,8 @@ int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t r
     const size_t G = l->v.G;
     const size_t n8 = (R * G * 8 + 255) & ~(size_t)255, n1 = (R * G + 255) & ~(size_t)255, ng = (G + 255) & ~(size_t)255;
     const size_t nm = ((size_t)l->v.W * G + 255) & ~(size_t)255;
-    const size_t total = 2 * n8 + n1 + 2 * ng + nm;
+    const size_t ng4 = (G * 4 + 255) & ~(size_t)255, nq4 = ((size_t)CRAFT_RQ * G * 4 + 255) & ~(size_t)255, nq8 = ((size_t)CRAFT_RQ * G * 8 + 255) & ~(size_t)255;
+    const size_t total = 2 * n8 + n1 + 2 * ng + nm + ng + 2 * ng4 + nq4 + nq8;
     SMR_HIP_TRY(hipMalloc((void **)&l->craft_base, total));
     SMR_HIP_TRY(hipMemset(l->craft_base, 0, total));
     CraftView &cv = l->cv;
@@ -752,6 +846,9 @@ int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t r
     cv.hb_repeat = b; b += n1; cv.full_copy = b; b += ng; cv.alive = b; b += ng;
     l->v.entry_mask = b;                                       // the dummy entry 0 and whatever the log holds so far: every shard
     SMR_HIP_TRY(hipMemset(l->v.entry_mask, (int)((1u << R) - 1u), (size_t)l->v.W * G));
+    b += nm;
+    cv.rq_term = (uint64_t *)b; b += nq8; cv.rq_slot = (uint32_t *)b; b += nq4; cv.last_recon = (uint32_t *)b; b += ng4;
+    cv.rq_n = (uint32_t *)b; b += ng4; cv.partial = b;
     cv.ft = fault_tolerance; cv.rep_thr = repeat_threshold; cv.quorum = quorum;
     std::vector<uint64_t> one(R * G, 1);                      // heartbeat.rs:117-119 reply_cnts start at (1, 0, 0)
     for (size_t g = 0; g < G; g++) one[(size_t)l->v.me * G + g] = 0;
@@ -864,12 +961,12 @@ int smr_raft_replica_handle_append_entries(smr_raft_leader *l, const smr_raft_ap
         if (m->max_entries && !m->entry_mask) return fail(SMR_ERR_ARG, "craft: AppendEntries without the entries' shard bitmaps");
         hipLaunchKernelGGL(raft_append_entries_kernel<true>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
                            m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term, m->entry_mask,
-                           m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
+                           l->cv.partial, m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
                            r->conflict_slot);
     } else
         hipLaunchKernelGGL(raft_append_entries_kernel<false>, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v,
                            m->flags, m->leader, m->term, m->prev_slot, m->prev_term, m->n_entries, m->entry_term, (const uint8_t *)nullptr,
-                           m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
+                           (uint8_t *)nullptr, m->max_entries, m->leader_commit, m->last_snap, r->flags, r->term, r->end_slot, r->conflict_term,
                            r->conflict_slot);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
@@ -881,6 +978,26 @@ int smr_raft_craft_handle_reconstruct(smr_raft_leader *l, const uint32_t *n_dev,
     if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this replica");
     hipLaunchKernelGGL(craft_reconstruct_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, n_dev, slot_dev,
                        term_dev, max_slots, r_n_dev, r_has_dev, r_mask_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_handle_reconstruct_reply(smr_raft_leader *l, const uint8_t *peer_dev, const uint32_t *n_dev, const uint32_t *slot_dev,
+                                            const uint8_t *mask_dev, uint32_t max_slots, void *stream) {
+    if (!l || !peer_dev || !n_dev || !slot_dev || !mask_dev) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this replica");
+    hipLaunchKernelGGL(craft_reconstruct_reply_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv, peer_dev,
+                       n_dev, slot_dev, mask_dev, max_slots);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_craft_poll_reconstructs(smr_raft_leader *l, uint32_t max_slots, uint32_t *n_dev, uint32_t *slot_dev, uint64_t *term_dev, void *stream) {
+    if (!l || !n_dev || !slot_dev || !term_dev) return fail(SMR_ERR_ARG, "craft: null argument");
+    if (!l->craft) return fail(SMR_ERR_ARG, "craft: not enabled on this replica");
+    if (max_slots > CRAFT_RQ) max_slots = CRAFT_RQ;
+    hipLaunchKernelGGL(craft_poll_reconstructs_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv, max_slots,
+                       n_dev, slot_dev, term_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

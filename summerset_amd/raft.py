@@ -208,6 +208,20 @@ def _craft_follower_methods():
         d = dict(mask=np.zeros((self.W, self.G), np.uint8), counters=np.zeros(2, np.uint64))
         check(self._L.smr_raft_craft_dump_masks(self._h, d["mask"].ctypes.data_as(C.c_void_p), d["counters"].ctypes.data_as(C.c_void_p)))
         return d
+    def poll_reconstructs(self, device, max_slots=16, stream=None):
+        """the Reconstruct { slots } the reply handler queued since the last poll: dict(n [G], slot / term [K, G])"""
+        import torch
+        G, K = self.G, int(max_slots)
+        r = dict(n=torch.zeros(G, dtype=torch.int32, device=device), slot=torch.zeros((K, G), dtype=torch.int32, device=device),
+                 term=torch.zeros((K, G), dtype=torch.int64, device=device))
+        check(self._L.smr_raft_craft_poll_reconstructs(self._h, K, _ptr(r["n"]), _ptr(r["slot"]), _ptr(r["term"]), stream_ptr(stream)))
+        return r
+
+    def handle_msg_reconstruct_reply(self, peer, n, slot, mask, stream=None):
+        check(self._L.smr_raft_craft_handle_reconstruct_reply(self._h, _ptr(peer), _ptr(n), _ptr(slot), _ptr(mask), int(slot.shape[0]),
+                                                              stream_ptr(stream)))
+    CRaftLeaderGroup.poll_reconstructs = poll_reconstructs
+    CRaftLeaderGroup.handle_msg_reconstruct_reply = handle_msg_reconstruct_reply
     CRaftLeaderGroup.handle_msg_reconstruct = handle_msg_reconstruct
     CRaftLeaderGroup.dump_masks = dump_masks
 

@@ -126,3 +126,43 @@ def test_reconstruct_answers_what_it_holds_under_the_asked_term(oracle):
     assert (r["n"] == 2).all() and r["has"][:, 0].tolist() == [1, 1, 0, 0] and r["mask"][:, 0].tolist() == [0b00100, 0b01100, 0, 0]
     n[:] = 0
     assert (o.handle_reconstruct(n, slot, term)["n"] == 0).all()       # nothing asked: no ReconstructReply (:649)
+
+
+def test_a_leader_that_was_a_follower_gates_on_shards_and_asks_for_them(oracle):
+    """craft/messages.rs:315-358 and :665-745: replica 2 holds slots 1-3 as replica 0's follower left them (one shard, the data
+    shards, two shards), is elected for term 2, appends slot 4 and gets it replicated: the commit index reaches 4, nothing can
+    execute before slot 1 has majority shards; the peers' ReconstructReplies bring them"""
+    o = _follower(oracle)
+    _ae(o, 0, 0, [1, 1, 1], [0b00100, 0b00111, 0b10100])
+    f = lambda v, dt: np.full(G, v, dt)
+    r = o.become_candidate(f(0, np.uint8))                              # the timer about leader 0 fires
+    assert (r["flags"] == 1).all() and (r["term"] == 2).all()
+    vt = np.zeros((5, G), np.uint64); vf = np.zeros((5, G), np.uint8)
+    vt[[1, 3]] = 2; vf[[1, 3]] = 3                                      # two votes + my own = majority
+    o.handle_vote_replies(vt, vf, None)
+    assert (o.dump()["role"] == 2).all()
+    o.append(f(1, np.uint32))                                           # slot 4, term 2, every shard (I made it)
+    rt = np.zeros((5, G), np.uint64); es = np.zeros((5, G), np.uint32); fl = np.zeros((5, G), np.uint8)
+    rt[[1, 3]] = 2; es[[1, 3]] = 4; fl[[1, 3]] = 1
+    o.handle_replies(rt, es, fl, None, None, None)                      # 3 holders of slot 4 < majority + f = 4
+    assert (o.take_reconstructs()["n"] == 0).all()
+    rt[:] = 0; es[:] = 0; fl[:] = 0
+    rt[4] = 2; es[4] = 4; fl[4] = 1
+    o.handle_replies(rt, es, fl, None, None, None)                      # the fourth: new_commit = 4
+    assert (o.dump()["last_commit"] == 0).all()                         # slot 1 has one shard: nothing executes behind it (:318-325)
+    q = o.take_reconstructs()
+    assert (q["n"] == 2).all() and q["slot"][:2, 0].tolist() == [1, 3] and q["term"][:2, 0].tolist() == [1, 1]
+    assert _masks(o, 5) == [ALL, 0b00100, 0b00111, 0b10100, ALL]
+    o.handle_replies(rt, es, fl, None, None, None)                      # the same reply again: asked only once (last_recon)
+    assert (o.take_reconstructs()["n"] == 0).all()
+    # ReconstructReply of peer 1: its shard (1) of slots 1 and 3
+    n = f(2, np.uint32)
+    slot = np.array([[1] * G, [3] * G], np.uint32); mask = np.array([[0b00010] * G, [0b00010] * G], np.uint8)
+    o.handle_reconstruct_reply(f(1, np.uint8), n, slot, mask)
+    assert _masks(o, 5) == [ALL, 0b00110, 0b00111, 0b10110, ALL] and (o.dump()["last_commit"] == 0).all()   # slot 1: 2 shards
+    # ReconstructReply of peer 3: shard 3 of slot 1 -> 3 shards, 2 of them data: reconstruct_data, then everything up to the
+    # shadow commit index (the 3rd largest match index = 4) executes: slot 3 needs reconstruct_data too
+    o.handle_reconstruct_reply(f(3, np.uint8), f(1, np.uint32), np.array([[1] * G], np.uint32), np.array([[0b01000] * G], np.uint8))
+    assert _masks(o, 5) == [ALL, 0b01111, 0b00111, 0b10111, ALL]
+    assert (o.dump()["last_commit"] == 4).all() and o.total_commits() == 4 * G
+    assert list(o.dump_masks()["counters"]) == [2 * G, 0]

@@ -41,6 +41,27 @@ class _Eng:
         like = dict(flags=np.uint8, term=np.uint64, end_slot=np.uint32, conflict_term=np.uint64, conflict_slot=np.uint32)
         return {k: r[k].cpu().numpy().view(v) for k, v in like.items()}
 
+    def become_candidate(self, src):
+        r = self.e.become_a_candidate(_t(src, self.cuda))
+        like = dict(flags=np.uint8, term=np.uint64, last_slot=np.uint32, last_term=np.uint64)
+        return {k: r[k].cpu().numpy().view(v) for k, v in like.items()}
+
+    def handle_vote_replies(self, term, flags, order):
+        return self.e.handle_msg_request_vote_reply(_t(term, self.cuda), _t(flags, self.cuda), None if order is None else _t(order, self.cuda))
+
+    def handle_replies(self, rt, es, fl, ct, cs, order):
+        f = lambda a: None if a is None else _t(a, self.cuda)
+        self.e.handle_msg_append_entries_reply(_t(rt, self.cuda), _t(es, self.cuda), _t(fl, self.cuda), f(ct), f(cs), f(order))
+
+    def total_commits(self): return self.e.total_commits()
+
+    def take_reconstructs(self, K=16):
+        r = self.e.poll_reconstructs(self.cuda, K)
+        return dict(n=r["n"].cpu().numpy().view(np.uint32), slot=r["slot"].cpu().numpy().view(np.uint32), term=r["term"].cpu().numpy().view(np.uint64))
+
+    def handle_reconstruct_reply(self, peer, n, slot, mask):
+        self.e.handle_msg_reconstruct_reply(_t(peer, self.cuda), _t(n, self.cuda), _t(slot, self.cuda), _t(mask, self.cuda))
+
     def handle_reconstruct(self, n, slot, term):
         r = self.e.handle_msg_reconstruct(_t(n, self.cuda), _t(slot, self.cuda), _t(term, self.cuda))
         return dict(n=r["n"].cpu().numpy().view(np.uint32), has=r["has"].cpu().numpy(), mask=r["mask"].cpu().numpy())
@@ -103,4 +124,51 @@ def test_crafted_rounds_match_the_oracle(cuda, oracle, G, W, seed):
             assert np.array_equal(a[k].astype(np.uint64), b[k].astype(np.uint64)), (step, k)
     c = orc.dump_masks()["counters"]
     assert c[0] > 0 and c[1] > 0                              # reconstruct_data and postponed executions both happened
+    # ---- everybody is elected and leads a log it did not create: the shard gate, Reconstruct queues, ReconstructReplies ----
+    def same(where):
+        a, b = eng.dump(), orc.dump()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (where, k)
+        a, b = eng.dump_masks(), orc.dump_masks()
+        assert np.array_equal(a["mask"], b["mask"]) and list(a["counters"]) == list(b["counters"]), where
+        assert eng.total_commits() == orc.total_commits(), where
+    src = orc.dump()["leader"].astype(np.uint8)
+    src[src == me] = 0
+    ro, re_ = orc.become_candidate(src), eng.become_candidate(src)
+    for k in ro:
+        assert np.array_equal(ro[k], re_[k]), ("candidate", k)
+    t_now = orc.dump()["curr_term"]
+    vt = np.zeros((R, G), np.uint64); vf = np.zeros((R, G), np.uint8)
+    for p in (0, 1, 3):
+        vt[p] = t_now; vf[p] = 3
+    orc.handle_vote_replies(vt, vf, None); eng.handle_vote_replies(vt, vf, None)
+    same("elected")
+    assert (orc.dump()["role"] == 2).mean() > 0.9
+    asked = 0
+    for step in range(12):
+        n_new = rng.integers(0, 3, G).astype(np.uint32)
+        orc.append(n_new); eng.append(n_new)
+        d = orc.dump()
+        rt = np.zeros((R, G), np.uint64); es = np.zeros((R, G), np.uint32); fl = np.zeros((R, G), np.uint8)
+        for p in range(R):
+            if p == me:
+                continue
+            on = rng.random(G) < 0.8
+            rt[p] = d["curr_term"]; fl[p] = on
+            es[p] = (d["log_len"].astype(np.int64) - 1 - rng.integers(0, 3, G)).clip(0)
+        orc.handle_replies(rt, es, fl, None, None, None); eng.handle_replies(rt, es, fl, None, None, None)
+        same(("replies", step))
+        qo, qe = orc.take_reconstructs(8), eng.take_reconstructs(8)
+        for k in qo:
+            assert np.array_equal(qo[k], qe[k]), ("queue", step, k)
+        asked += int(qo["n"].sum())
+        # the peers answer some of what was asked (random shards), one peer per call
+        for p in (0, 3):
+            n = np.where(rng.random(G) < 0.7, qo["n"], 0).astype(np.uint32)
+            mask = rng.integers(0, 32, qo["slot"].shape).astype(np.uint8)
+            peer = np.full(G, p, np.uint8)
+            peer[rng.random(G) < 0.1] = 0xFF
+            orc.handle_reconstruct_reply(peer, n, qo["slot"], mask); eng.handle_reconstruct_reply(peer, n, qo["slot"], mask)
+            same(("reconstruct_reply", step, p))
+    assert asked > 0 and orc.total_commits() > 0
     assert orc.dump_votes()["n_exec"].sum() > 0 and orc.dump_votes()["n_trunc"].sum() > 0
