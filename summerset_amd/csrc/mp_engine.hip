@@ -186,7 +186,15 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
     flush_counters(L, active);
 }
 
-__global__ __launch_bounds__(256) void mp_round_local(const MpParams *__restrict__ Pp, int par,
+// (min wavefronts per SIMD, i.e. the register budget of the bulk round kernels; profiles/r2g1_occupancy.log, r2g2: capping R2 at
+// 96 VGPRs -- its rare paths then spill 548 B per lane -- takes it from 29 to 21.5 us in the steady state; R1, the rest of R3
+// and R4 gain nothing from tighter caps, the tally loses)
+#ifdef MP_R1_MINW
+#define MP_R1_BOUNDS __launch_bounds__(256, MP_R1_MINW)
+#else
+#define MP_R1_BOUNDS __launch_bounds__(256)
+#endif
+__global__ MP_R1_BOUNDS void mp_round_local(const MpParams *__restrict__ Pp, int par,
                                                       const uint8_t *__restrict__ timeout_rep,
                                                       const uint8_t *__restrict__ timeout_src,
                                                       const uint8_t *__restrict__ req_target,
@@ -493,7 +501,10 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
     flush_counters(L, active && loaded);
 }
 
-__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
+#ifndef MP_R2_MINW
+#define MP_R2_MINW 5
+#endif
+__global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
@@ -970,7 +981,12 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
     flush_counters(L, active && loaded);
 }
 
-__global__ __launch_bounds__(256) void mp_round_replies(const MpParams *__restrict__ Pp, int par,
+#ifdef MP_R3_MINW
+#define MP_R3_BOUNDS __launch_bounds__(256, MP_R3_MINW)
+#else
+#define MP_R3_BOUNDS __launch_bounds__(256)
+#endif
+__global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, int par,
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb, int side) {
     const MpParams &P = *Pp;
@@ -1020,7 +1036,12 @@ __device__ __forceinline__ void r4_body(const MpParams &P, int par, const uint32
     flush_counters(L, active);
 }
 
-__global__ __launch_bounds__(256) void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
+#ifdef MP_R4_MINW
+#define MP_R4_BOUNDS __launch_bounds__(256, MP_R4_MINW)
+#else
+#define MP_R4_BOUNDS __launch_bounds__(256)
+#endif
+__global__ MP_R4_BOUNDS void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;

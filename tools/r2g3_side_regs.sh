@@ -1,0 +1,19 @@
+#!/bin/bash
+# r2g3: with R2 capped at 96 VGPRs (5 wavefronts per SIMD), does a smaller batch straggler kernel (register cap, spills) pay now?
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_mp_gpu.py tests/test_baseline_configs_gpu.py tests/test_spread_mp.py -q -m gpu -p no:cacheprovider 2>&1 | tail -2 | tee gpurun_out/r2g3_tests.log
+V=$PWD/summerset_amd/variants
+for lib in "" $V/libsummerset_hip_sbw3.so $V/libsummerset_hip_sbw4.so; do
+  if [ -n "$lib" ]; then export SUMMERSET_HIP_LIB=$lib; else unset SUMMERSET_HIP_LIB; fi
+  for a in "" "--timeouts 0" "--steps 20 --warmup 5" "--steps 20 --warmup 5"; do
+    timeout 200 python bench.py --no-cpu --no-rs --no-extra $a > gpurun_out/r2g3.json 2> gpurun_out/r2g3.err
+    python - "lib=$(basename "$lib") args=[$a]" gpurun_out/r2g3.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+    print(sys.argv[1], "value %.3e" % d["value"], "ms/tick %.4f" % d["ms_per_step"], "frac %.3f" % d["roofline"]["frac"], {n: round(v.get("avg_us") or 0, 1) for n, v in d["kernels"].items()})
+except Exception as e:
+    print(sys.argv[1], "bench failed:", e, open(sys.argv[2].replace(".json", ".err")).read()[-300:])
+PY
+  done
+done 2>&1 | tee gpurun_out/r2g3_side_regs.log
