@@ -114,6 +114,9 @@ __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__re
     }
 }
 
+#ifndef R1_PF
+#define R1_PF 32u     // client batches per group and tick whose tokens R1 prefetches
+#endif
 // R1: HearTimeout -> become_a_leader; client batches -> handle_req_batch
 __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_t *__restrict__ timeout_rep,
                                         const uint8_t *__restrict__ timeout_src, const uint8_t *__restrict__ req_target,
@@ -125,7 +128,15 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
     if (n_req > S) n_req = S;
     active = !has_to && n_req > 0;
     if (active) {
+        // One round of loads for everything the fast path reads: the client batches' tokens (up to R1_PF of them, in
+        // registers), the replica's scalars, the outbox count.  (They used to go out as seven dependent rounds -- scalars,
+        // outbox count, then four batches of eight tokens -- and the leaders' wavefronts are one per SIMD: nothing else
+        // hides a round trip.)
+        uint32_t ptok[R1_PF];
+#pragma unroll
+        for (int q = 0; q < (int)R1_PF; q++) ptok[q] = ((uint32_t)q < n_req) ? req_val[(size_t)q * P.G + g] : 0u;
         L.load();
+        L.ob_load(par);
         uint32_t k0 = 0;
         // Steady-state fast path: a prepared leader whose log has no holes and
         // whose accept_bar sits at the log end appends all n_req batches as a
@@ -144,10 +155,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                 const uint64_t bal = L.bpd;
                 const uint32_t base = L.len, G = P.G, Wm = P.Wmask;
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (r + M_ACKS_SH));
-                for (uint32_t k = 0; k < n_req; k += 8) {
-                    uint32_t tok[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) tok[q] = (k + q < n_req) ? req_val[(size_t)(k + q) * G + g] : 0u;
+                auto put8 = [&](uint32_t k, const uint32_t (&tok)[8]) {
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         if (k + q >= n_req) break;
@@ -158,6 +166,20 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                         if (c0 != 0) { os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; }   // else: follow from ob_reg / ob_rbal
                         ov[o] = tok[q];
                     }
+                };
+#pragma unroll
+                for (int kk = 0; kk < (int)R1_PF; kk += 8) {         // the first R1_PF tokens are in registers already
+                    if ((uint32_t)kk >= n_req) break;
+                    uint32_t tok[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) tok[q] = ptok[kk + q];
+                    put8((uint32_t)kk, tok);
+                }
+                for (uint32_t k = R1_PF; k < n_req; k += 8) {
+                    uint32_t tok[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) tok[q] = (k + q < n_req) ? req_val[(size_t)(k + q) * G + g] : 0u;
+                    put8(k, tok);
                 }
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
                 if (par == 0) L.obn0 = c0 + n_req; else L.obn1 = c0 + n_req;

@@ -114,6 +114,8 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         # with and without the straggler side launch
         for sticks in (0, 4):
             t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=sticks, every=4)
+        # more client batches per tick than R1 prefetches into registers (R1_PF = 32)
+        t._run("cpu", oracle, G=64, R=5, S=40, W=256, n_ticks=12, drop_p=0.05, timeout_frac=0.0, hb_every=4, preset=True)
         # batches of ticks with the straggler list on: the list's groups run the whole batch in one launch
         t._run("cpu", oracle, G=200, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=7, straggler_ticks=3)
         t._run("cpu", oracle, G=70, R=8, S=1, W=32, n_ticks=30, drop_p=0.2, timeout_frac=1.0, hb_every=2, preset=True, fused=16, straggler_ticks=8)

@@ -292,6 +292,12 @@ def test_batched_ticks_with_the_straggler_list_bench_shape(cuda, oracle):
     _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=7, straggler_ticks=4, every=3)
 
 
+def test_more_batches_per_tick_than_r1_prefetches(cuda, oracle):
+    """S = 40 > R1_PF = 32: the tail of a tick's client batches goes through the loop that loads its tokens itself"""
+    _run(cuda, oracle, G=300, R=5, S=40, W=256, n_ticks=16, drop_p=0.05, timeout_frac=0.0, hb_every=4, preset=True)
+    _run(cuda, oracle, G=200, R=5, S=33, W=256, n_ticks=12, drop_p=0.1, timeout_frac=0.3, hb_every=3, preset=True, straggler_ticks=2)
+
+
 def test_batches_and_single_ticks_share_the_list(cuda, oracle):
     """a batch leaves ttl behind that the per-tick mark pass picks up, and the other way round"""
     from summerset_amd import MultiPaxosCluster, stream
