@@ -1129,11 +1129,14 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
 // (STRAG_BATCH_K listed groups per block, on lanes 0 .. K-1 of every replica's wavefront: per tick that packing lost --
 // the cooperative jobs of a wavefront queue behind each other and the tick waits for the longest queue -- but a batch has
 // slack, and what counts here is how many listed groups the 256 blocks get through in the time the bulk needs.)
+// 192 blocks x 6 groups: a quarter of the CUs stay free of the 5-wavefront, 220-VGPR side blocks, which is where the tally's
+// 4-wavefront LDS blocks find their slots when the list is long (26 leader changes per tick: 0.157 -> 0.143 ms per tick against
+// 256 x 4; no difference on the default workload, whose list is shorter than 192 groups -- profiles/r2g6_side_blocks.log)
 #ifndef STRAG_BATCH_K
-#define STRAG_BATCH_K 4
+#define STRAG_BATCH_K 6
 #endif
 #ifndef STRAG_BATCH_BLOCKS
-#define STRAG_BATCH_BLOCKS 256
+#define STRAG_BATCH_BLOCKS 192
 #endif
 #ifndef STRAG_BATCH_MINW
 #define STRAG_BATCH_MINW STRAG_MINW
