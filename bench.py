@@ -46,6 +46,19 @@ def pmc_traffic(kernel):
     return d["kernels"].get(kernel) if d else None
 
 
+TIMEOUT_HORIZON = 72     # ticks of the default run (60 timed + 12 warm-up): --timeouts is the fraction of groups per THIS many ticks
+
+
+def timeout_span(args):
+    return args.timeout_span if args.timeout_span is not None else max(args.steps + args.warmup, TIMEOUT_HORIZON)
+
+
+def timeouts_text(args):
+    span = timeout_span(args)
+    return "%.1f%% of the groups per %d ticks with a leader timeout (%.1f groups per tick)" % (
+        args.timeouts * 100, span, args.timeouts * args.groups / span)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,7 +71,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated tick inputs cycled in HBM")
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
-    ap.add_argument("--timeout-span", type=int, default=None, help="draw the timeout ticks from [0, N) instead of the whole run")
+    ap.add_argument("--timeout-span", type=int, default=None, help="draw the groups' timeout ticks from [0, N).  Default: max(steps + warmup, "
+                    "%d) -- the leader-timeout RATE per tick is the workload's, not the run length's: a run shorter than the default "
+                    "%d ticks sees the same changes per tick as the default run (SURVEY 8(d) spreads its 1 %% over 1024 ticks)" % (TIMEOUT_HORIZON, TIMEOUT_HORIZON))
     ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the straggler list (0 = no list); 4 "
                     "measured best with --batch 8 (profiles/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/r2g_straggler_sweep.log)")
     ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
@@ -685,7 +700,7 @@ def spread_main(args, torch, dist, rank, local, world, dev):
     mine = sorted({b for rk in job.ranks for b in rk.blocks} if virtual else job.blocks)
     n_ticks = args.warmup + args.steps
     skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2,
-               timeout_span=args.timeout_span)
+               timeout_span=timeout_span(args))
     sts = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **skw) for b, (lo, hi) in ((b, shard.group_range(total, nr, b)) for b in mine)}
     pools = {b: [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(args.pool)]
              for b, st in sts.items()}
@@ -719,7 +734,7 @@ def spread_main(args, torch, dist, rank, local, world, dev):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, heartbeat every %d ticks, "
-                                   "%.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout" % (args.groups, S, H, args.drop * 100, args.timeouts * 100),
+                                   "%.0f%% ack loss (<= 2 lost per slot), %s" % (args.groups, S, H, args.drop * 100, timeouts_text(args)),
                        "groups_per_gpu": args.groups, "replicas": R, "slots_per_tick": S, "window": W, "layout": "spread",
                        "spread_ranks": nr, "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
             "exchange": {"collectives_per_tick": "3 with a heartbeat round, else 2 (one all_to_all_single each)",
@@ -804,7 +819,7 @@ def main():
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
     eng.preset_leader(0)
     st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=args.timeouts,
-                                 hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=args.timeout_span,
+                                 hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=timeout_span(args),
                                  group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
     # inputs resident in HBM before the clock starts
     pool = []
@@ -937,8 +952,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, "
-                               "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %.1f%% groups with a leader timeout"
-                               % (G, S, H, args.drop * 100, args.timeouts * 100),
+                               "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %s"
+                               % (G, S, H, args.drop * 100, timeouts_text(args)),
                    "groups_per_gpu": G, "replicas": R, "slots_per_tick": S, "window": W, "layout": "colocated",
                    "launch": ("fused tick kernel, <= %d ticks per launch" % min(args.fused, 16)) if args.fused else
                              ("batches of <= %d ticks per smr_mp_run_ticks call: five per-round launches per tick for the bulk, one "

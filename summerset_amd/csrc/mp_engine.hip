@@ -776,9 +776,20 @@ __device__ __forceinline__ T *rep_shift(T *p0, size_t byte_off) { return (T *)((
 // round is already complete, and tells mp_round_replies which (replica, tile) pairs still need it.
 // Loads are arranged in three dependent rounds: (1) who has an outbox, (2) that replica's
 // scalars + its ack-matrix rows, (3) the ring rows.
+// TALLY_SPEC: the round-2 loads (scalars + ack words) of replica `hint` -- the job's preset leader, wave-uniform --
+// go out WITH round 1; a lane whose replica turns out to be `hint` (all of them in the steady state) starts its ring
+// rows as soon as round 1 lands: two dependent load rounds instead of three.  Other lanes reload as before.
+// TALLY_WAVEFLAGS: a wavefront ANDs the flags of its own rows in a register and hands over ONE byte per lane, so the
+// closed-form test reads 4 LDS bytes per lane instead of one per row.
+#ifndef TALLY_SPEC
+#define TALLY_SPEC 0
+#endif
+#ifndef TALLY_WAVEFLAGS
+#define TALLY_WAVEFLAGS 0
+#endif
 template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
-                                                   int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk) {
+                                                   int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk, uint32_t hint) {
 #ifndef TALLY_C
 #define TALLY_C 4          // 95 VGPRs, five wavefronts per SIMD: measured better than 8 rows per pass (128 VGPRs) with and without
 #endif                     // the side stream's blocks on the same CUs (profiles/r2u_tally_rows_per_pass.log)
@@ -790,13 +801,17 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     const uint32_t R = P.R, G = P.G, Wm = P.Wmask, thresh = P.thresh;
     // ---- round 1: every replica's outbox count and who is owed PrepareReplies --------------------
     const uint32_t ovf = (uint32_t)P.overflow[gg] | (uint32_t)P.slow[gg];
-    uint32_t cnts[MAXR], prc[MAXR], prd[MAXR];
+    // (every load of the round goes out before anything is looked at: the addresses are replica 0's arrays plus a uniform
+    // multiple of rep_stride, clamped to a real replica, so no load sits behind a branch -- the per-replica `d < R ? load : 0`
+    // this replaces compiled to one basic block per replica with a wait on its pr_cnt at the end: R serial round trips)
+    const MpRep &v0 = P.rep[0];
+    uint32_t cnts[NR], prc[NR], prd[NR];
 #pragma unroll
-    for (int d = 0; d < MAXR; d++) {
-        const bool in = (uint32_t)d < R;
-        cnts[d] = in ? P.rep[d].ob_cnt[par][gg] : 0u;
-        prc[d] = in ? P.rep[d].pr_cnt[gg] : 0u;
-        prd[d] = in ? P.rep[d].pr_dest[gg] : 0u;
+    for (int d = 0; d < NR; d++) {
+        const size_t rd = (size_t)((uint32_t)d < R ? d : 0) * P.rep_stride;
+        cnts[d] = rep_shift(v0.ob_cnt[par], rd)[gg];
+        prc[d] = rep_shift(v0.pr_cnt, rd)[gg];
+        prd[d] = rep_shift(v0.pr_dest, rd)[gg];
     }
     uint32_t ctl[C];                                             // the reply order / loss words of my first C rows
 #pragma unroll
@@ -804,27 +819,44 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         const uint32_t j = w + 4u * (uint32_t)k;
         ctl[k] = (ackctl && j < P.cap) ? ackctl[(size_t)j * G + gg] : SMR_CTL_IDENTITY;
     }
+#if TALLY_SPEC
+    const size_t roh = (size_t)(hint < R ? hint : 0u) * P.rep_stride;   // wave-uniform
+    uint64_t abh[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+        abh[q] = ack_bits_base(rep_shift(v0.ack, roh), P.cap, P.G)[tix(MAXR, q, gg)];   // (rows R.. MAXR exist: masked below)
+    const uint32_t h_reg = rep_shift(v0.ob_reg[par], roh)[gg], h_leader = rep_shift(v0.leader, roh)[gg];
+    const uint64_t h_bpd = rep_shift(v0.bal_prepared, roh)[gg], h_rbal = rep_shift(v0.ob_rbal[par], roh)[gg];
+    const uint32_t h_start = rep_shift(v0.start_slot, roh)[gg], h_len = rep_shift(v0.log_len, roh)[gg];
+    const uint32_t h_cbar = rep_shift(v0.commit_bar, roh)[gg], h_ebar = rep_shift(v0.exec_bar, roh)[gg];
+    const uint32_t h_abar = rep_shift(v0.accept_bar, roh)[gg];
+#endif
     const bool active = g < G && !ovf;                          // ovf: frozen, or on the straggler list
     uint32_t prmask = 0;
 #pragma unroll
-    for (int d = 0; d < MAXR; d++) {
-        if (!active || !((P.live >> d) & 1u)) cnts[d] = 0;      // (an image's outbox is its own rank's to tally)
-        if (active && prc[d] != 0) prmask |= 1u << prd[d];
+    for (int d = 0; d < NR; d++) {
+        const bool in = (uint32_t)d < R;
+        if (!in || !active || !((P.live >> d) & 1u)) cnts[d] = 0;   // (an image's outbox is its own rank's to tally)
+        if (in && active && prc[d] != 0) prmask |= 1u << prd[d];
     }
     prmask &= P.live;
     // my replica: the lowest one with a non-empty outbox (a second one, if any, is left to mp_round_replies)
     uint32_t dl = R, cnt = 0;
 #pragma unroll
-    for (int d = MAXR - 1; d >= 0; d--) if (cnts[d] != 0) { dl = (uint32_t)d; cnt = cnts[d]; }
+    for (int d = NR - 1; d >= 0; d--) if (cnts[d] != 0) { dl = (uint32_t)d; cnt = cnts[d]; }
     const bool cand = dl < R && !((prmask >> dl) & 1u) && cnt <= 64;
     const size_t ro = (size_t)(dl < R ? dl : 0) * P.rep_stride;  // per-lane replica: addresses are vector values
-    const MpRep &v0 = P.rep[0];
+#if TALLY_SPEC
+    const bool spec = cand && dl == hint;
+#else
+    constexpr bool spec = false;
+#endif
     SMR_G uint32_t *const sm = rep_shift(v0.s_meta, ro);
     SMR_G const uint64_t *const sb = rep_shift(v0.s_bal, ro);
     uint64_t ab[NR];                                             // my replica's followers, entries < 64 (cand: cnt <= 64)
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        ab[q] = (cand && (uint32_t)q < R) ? ack_bits_base(rep_shift(v0.ack, ro), P.cap, P.G)[tix(MAXR, q, gg)] : 0ull;
+        ab[q] = (cand && !spec && (uint32_t)q < R) ? ack_bits_base(rep_shift(v0.ack, ro), P.cap, P.G)[tix(MAXR, q, gg)] : 0ull;
     SMR_G uint32_t *const p_cbar = rep_shift(v0.commit_bar, ro), *const p_ebar = rep_shift(v0.exec_bar, ro);
     // Rows are dealt to the four wavefronts round robin -- wavefront w takes rows w, w + 4, w + 8, ... -- so WHICH rows a
     // wavefront tallies depends on nothing it has to load first: their ackctl words went out with round 1 above.
@@ -832,7 +864,15 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0;
     uint64_t bpd = 0;
     uint64_t a[C], rbal = 0;
-    if (cand) {
+#if TALLY_SPEC
+    if (spec) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) ab[q] = (uint32_t)q < R ? abh[q] : 0ull;
+        reg = h_reg; bpd = h_bpd; rbal = h_rbal; leader = h_leader; start = h_start; len = h_len;
+        cbar = h_cbar; ebar = h_ebar; abar = h_abar;
+    }
+#endif
+    if (cand && !spec) {
         reg = rep_shift(v0.ob_reg[par], ro)[gg]; bpd = rep_shift(v0.bal_prepared, ro)[gg];
         rbal = rep_shift(v0.ob_rbal[par], ro)[gg];
         leader = rep_shift(v0.leader, ro)[gg];
@@ -840,6 +880,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         cbar = p_cbar[gg]; ebar = p_ebar[gg]; abar = rep_shift(v0.accept_bar, ro)[gg];
     }
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
+    uint32_t wall = 0xFF;                                        // TALLY_WAVEFLAGS: AND of my rows' flags
     // ---- round 3 + tally: C rows per pass (one pass unless the outbox is longer than 4 * C) -------
 #pragma unroll 1
     for (uint32_t k0 = 0; w + 4u * k0 < cnt; k0 += C) {
@@ -880,17 +921,28 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
             if (changed && !committed) sm[tix(P.W, (reg - 1 + j) & Wm, g)] = mk;
             sh_mk[j * 64 + lane] = mk;
-            sh_fl[j * 64 + lane] = (uint8_t)((have ? 1 : 0) | (changed ? 2 : 0) | (committed ? 4 : 0) |
-                                             ((mk & M_NONEMPTY) ? 16 : 0));
+            const uint32_t fl = (have ? 1u : 0u) | (changed ? 2u : 0u) | (committed ? 4u : 0u) | ((mk & M_NONEMPTY) ? 16u : 0u);
+#if TALLY_WAVEFLAGS
+            wall &= fl;
+#else
+            sh_fl[j * 64 + lane] = (uint8_t)fl;
+#endif
         }
     }
+#if TALLY_WAVEFLAGS
+    sh_fl[w * 64 + lane] = (uint8_t)wall;                        // (a wavefront without rows hands over 0xFF)
+#endif
     __syncthreads();
     // ---- the all-commit closed form, or leave the lane to mp_round_replies ------------------------
     bool closed = false;
     const uint32_t first = reg - 1;
     if (fast4) {
+#if TALLY_WAVEFLAGS
+        const uint32_t all = (uint32_t)sh_fl[lane] & sh_fl[64 + lane] & sh_fl[128 + lane] & sh_fl[192 + lane];
+#else
         uint32_t all = 0xFF;
         for (uint32_t j = 0; j < cnt; j++) all &= sh_fl[j * 64 + lane];
+#endif
         // every row: present, changed, committed, non-empty; rows = slots commit_bar.., all below
         // accept_bar, and the run ends behind the last one (accept_bar and log end).  exec_bar rides
         // along from the row that sits AT it (execution.rs:70), if any -- a pinned exec_bar stays.
@@ -903,7 +955,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     // or PrepareReplies waiting; everybody else's round is complete
     uint32_t need = prmask;
 #pragma unroll
-    for (int d = 0; d < MAXR; d++)
+    for (int d = 0; d < NR; d++)
         if (cnts[d] != 0 && !(closed && (uint32_t)d == dl)) need |= 1u << d;
     if (w == 0 && closed) {
         p_cbar[gg] = first + cnt;
@@ -953,10 +1005,10 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #endif
 template <int NR>
 __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
-                                                       const uint32_t *__restrict__ ackctl, int publish_hb) {
+                                                       const uint32_t *__restrict__ ackctl, int publish_hb, uint32_t hint) {
     __shared__ uint8_t sh_fl[64 * 64];
     __shared__ uint32_t sh_mk[64 * 64];
-    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk);
+    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk, hint);
 }
 
 __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32_t *__restrict__ ackctl, int publish_hb,
@@ -1213,7 +1265,7 @@ __device__ __forceinline__ void fused_r2(const MpParams *Pp, int par, uint32_t g
 template <int NR>
 __device__ __forceinline__ void fused_tally(const MpParams *Pp, int par, const uint32_t *ackctl, int publish_hb, uint8_t *sh_fl,
                                          uint32_t *sh_mk) {
-    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk);
+    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk, 0u);
 }
 __device__ __forceinline__ void fused_r3(const MpParams *Pp, int par, const uint32_t *ackctl, int publish_hb, uint32_t g, uint32_t r) {
     r3_body(*Pp, par, ackctl, publish_hb, g, g < Pp->G && !Pp->overflow[g], r);
@@ -1556,6 +1608,7 @@ struct smr_mp_cluster {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
+    uint32_t lead_hint = 0;          // the replica most groups are led by (smr_mp_preset_leader): the tally's speculative loads
     bool profile = false;
     std::vector<ProfEv> evs;
     double prof_ms[5] = {0, 0, 0, 0, 0};
@@ -1782,6 +1835,7 @@ int smr_mp_preset_leader(smr_mp_cluster *c, uint8_t rep) {
             SMR_HIP_TRY(hipMemcpy(v.bal_prepared, b.data(), G * 8, hipMemcpyHostToDevice));
         }
     }
+    c->lead_hint = rep;
     return SMR_OK;
 }
 
@@ -1845,10 +1899,10 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if ((rc = prof_begin(c, 4, st, pt))) return rc;             // the quorum-tally kernel alone
     if (c->cfg.population <= 5)
         hipLaunchKernelGGL(mp_quorum_tally<5>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
-                           c->dp, c->par, ackctl_dev, publish_heartbeat);
+                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint);
     else
         hipLaunchKernelGGL(mp_quorum_tally<MAXR>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
-                           c->dp, c->par, ackctl_dev, publish_heartbeat);
+                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pt, st))) return rc;
     hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, ackctl_dev,
