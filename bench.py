@@ -639,6 +639,59 @@ def quorum_read_leg(torch, dev, ticks=32):
             "conflicts": c[3]}
 
 
+def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
+    """The leader's receive side of one tick on the device (csrc/wire_ingest.hip): 4 connections per group, each
+    with the tick's S AcceptReply frames (`[u64 BE 9][00 03 FB slot16 FB ballot16 00]`, 17 bytes: slots and the ballot in the
+    two-byte varint range) and a Heartbeat in front of every fourth connection's -- parsed into smr_mp_ack / smr_wire_hb records.
+    4 distinct byte buffers in rotation (4 x 145 MB + records: beyond the 256 MiB L3).  Algorithmic bytes: the stream once +
+    the records once."""
+    from summerset_amd import wire
+    from summerset_amd.multipaxos import ACK_DTYPE
+    n_conn, POOL = G * 4, 4
+    hb = np.frombuffer(wire.heartbeat(0x101, 300, 290, 0), np.uint8)
+    one = np.frombuffer(wire.accept_reply(300, 0x101), np.uint8)
+    assert len(one) == 17
+    has_hb = (np.arange(n_conn) % 4 == 0)
+    lens = S * 17 + has_hb * len(hb)
+    off = np.zeros(n_conn + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    bufs = []
+    for k in range(POOL):
+        slots = (300 + 32 * k + np.arange(S)).astype("<u2")
+        body = np.tile(one, (S, 1))
+        body[:, 11:13] = slots.view(np.uint8).reshape(S, 2)          # the slot's two little-endian bytes behind 0xFB
+        body = body.reshape(-1)
+        four = np.concatenate([hb, body, body, body, body])          # connections 4i .. 4i + 3: the first opens with the Heartbeat
+        bufs.append(torch.from_numpy(np.tile(four, n_conn // 4)).to(dev))
+        assert bufs[-1].numel() == int(off[-1])
+    # the sequential decoder agrees on one connection with and one without the heartbeat
+    for c in (0, 1):
+        pos, blob0, n_ok = int(off[c]), bufs[1].cpu().numpy().tobytes(), 0
+        while pos < off[c + 1]:
+            n, m = wire.decode(blob0[pos:int(off[c + 1])])
+            assert n > 0 and m["kind"] in (wire.ACCEPT_REPLY, wire.HEARTBEAT)
+            pos += n; n_ok += 1
+        assert n_ok == S + (1 if has_hb[c] else 0)
+    ing = wire.MpIngest(n_conn, n_conn * S, n_conn, 16, device=dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_grp = torch.from_numpy((np.arange(n_conn) // 4).astype(np.int32)).to(dev)
+    d_peer = torch.from_numpy((1 + np.arange(n_conn) % 4).astype(np.uint8)).to(dev)
+    for k in range(POOL):
+        ing.ingest(bufs[k], d_off, d_grp, d_peer)
+    r = ing.results()
+    assert r["n_acks"] == n_conn * S and r["n_hbs"] == n_conn // 4 and r["n_others"] == 0 and r["n_malformed"] == 0
+    assert (r["consumed"] == lens).all() and (r["acks"]["slot"][:S] == 300 + 32 * 3 + np.arange(S)).all()
+    us = _time_us(torch, lambda i: ing.ingest(bufs[i % POOL], d_off, d_grp, d_peer), iters)
+    stream_bytes = int(off[-1])
+    alg = stream_bytes + r["n_acks"] * ACK_DTYPE.itemsize + r["n_hbs"] * wire.HB_DTYPE.itemsize
+    return {"workload": "leader-side receive path of one tick: %d connections (%d groups x 4 peers), %d AcceptReply frames each + a Heartbeat on every "
+                        "fourth, %d MB of frames -> %d smr_mp_ack records" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
+            "value": r["n_acks"] / (us * 1e-6), "unit": "AcceptReply frames/s", "call_us": us, "stream_GBps": stream_bytes / (us * 1e-6) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + scan + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
+                         "avg_launch_us": us, "traffic": None}}
+
+
 def _cpu_run(a):
     """one process, one thread: the CPU oracle on G groups of the bench workload for about `seconds`"""
     slots, window, drop, timeouts, hb_every, G, seconds = a
@@ -795,7 +848,7 @@ def main():
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
         legs = {"rspaxos": rspaxos_leg, "epaxos_cluster": epaxos_cluster_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
-                "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg}
+                "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg, "wire_ingest": wire_ingest_leg}
         print(json.dumps(legs[args.leg](torch, torch.device("cuda", local))))
         return
     if not torch.cuda.is_available():
@@ -987,6 +1040,7 @@ def main():
             leg("epaxos_cluster", leg_isolated, "epaxos_cluster")
             leg("rspaxos", leg_isolated, "rspaxos")
             leg("repnothing", repnothing_leg)
+            leg("wire_ingest", leg_isolated, "wire_ingest")
             if args.late_legs:
                 leg("epaxos_execution", leg_isolated, "epaxos_execution")
                 leg("rspaxos_replica", leg_isolated, "rspaxos_replica")

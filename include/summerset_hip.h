@@ -852,6 +852,40 @@ typedef struct {
 } smr_wire_ep_msg_t;
 int64_t smr_wire_ep_decode(const uint8_t *buf, uint64_t len, smr_wire_ep_msg_t *out, uint32_t *deps_out, uint32_t max_deps);
 
+/* ---- MultiPaxos peer traffic, parsed on the device (csrc/wire_ingest.hip) ----------------
+ * The receive side of `TcpTransport` (src/server/transport.rs:404-470 -> safetcp.rs:30-70) for a batch of connections:
+ * buf_dev[conn_off[c] .. conn_off[c + 1]) are the bytes connection c -- replica `conn_peer[c]` of group
+ * `conn_group[c]` -- delivered since the last call, frames `[u64 BE length][bincode(PeerMessage)]` back to back, the
+ * last one possibly incomplete.  Every complete frame, in stream order, becomes
+ *   PeerMsg::AcceptReply { slot, ballot, .. }   an smr_mp_ack { group, slot, ballot, peer }: what smr_mp_deliver_acks takes
+ *                                               (a slot above 2^32 - 1 goes to `others`: the engine's slots are u32);
+ *   PeerMsg::Heartbeat / CommitNotice           an smr_wire_hb;
+ *   anything else (Prepare, PrepareReply, Accept, ReadQuery, ReadQueryReply, PeerMessage::Leave, lease traffic)
+ *                                               an smr_wire_other { conn, kind, off, len }: off is the frame's offset
+ *                                               in buf_dev, for the host's smr_wire_decode -- located, not validated.
+ * Records are written in the order the sequential decoder would produce them (connection by connection, frame by
+ * frame); counts_dev[0 .. 3) = their numbers (records past a capacity are counted, not stored), counts_dev[3] = the
+ * connections that hit a malformed frame (smr_wire_decode's rules: a length above 10^12, a variant that does not
+ * parse, a frame that does not end where its length says) -- status_dev[c] = 1 there and the connection stops at
+ * that frame.  consumed_dev[c] = the bytes of c's complete frames: the host keeps the rest for the next call, as
+ * safetcp's read buffer does.  buf_dev must be 16-byte aligned; scratch_dev holds smr_wire_ingest_scratch_bytes(n_conn)
+ * bytes.  Only enqueues work on `stream`. */
+typedef struct {
+    uint32_t group, peer;
+    uint32_t kind;                 /* SMR_WIRE_HEARTBEAT or SMR_WIRE_COMMIT_NOTICE */
+    uint32_t reserved;             /* 0 */
+    uint64_t ballot, commit_bar, exec_bar, snap_bar;   /* CommitNotice: exec_bar = snap_bar = 0 */
+} smr_wire_hb;                     /* 48 bytes */
+typedef struct {
+    uint32_t conn, kind;           /* SMR_WIRE_* of the frame (SMR_WIRE_OTHER: a variant this build does not know) */
+    uint64_t off, len;             /* the whole frame, header included */
+} smr_wire_other;                  /* 24 bytes */
+uint64_t smr_wire_ingest_scratch_bytes(uint32_t n_conn);
+int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                       const uint8_t *conn_peer_dev, uint32_t n_conn, smr_mp_ack *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
+                       uint64_t hb_cap, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev, uint64_t *consumed_dev,
+                       int32_t *status_dev, void *scratch_dev, void *stream);
+
 /* ---- request batching front-end (host only; src/server/external.rs:323-344 get_req_batch, :697-730 the batch
  * ticker): requests queue per group; one tick turns, for every group with queued requests, up to max_batch_size
  * of them (0 = all) into one ReqBatch, FIFO; groups with an empty queue get no batch. */

@@ -881,6 +881,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     }
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
     uint32_t wall = 0xFF;                                        // TALLY_WAVEFLAGS: AND of my rows' flags
+    (void)wall;
     // ---- round 3 + tally: C rows per pass (one pass unless the outbox is longer than 4 * C) -------
 #pragma unroll 1
     for (uint32_t k0 = 0; w + 4u * k0 < cnt; k0 += C) {

@@ -1,0 +1,240 @@
+// Device-side ingest of MultiPaxos peer traffic (the HIP half): the bytes a leader's TCP
+// connections delivered this tick -- `[u64 BE length][bincode(PeerMessage)]` frames, src/utils/safetcp.rs:30-70,
+// 127-132; PeerMsg variants multipaxos/mod.rs:298-384 -- parsed on the device into the records the engine takes:
+// AcceptReply -> smr_mp_ack (what smr_mp_deliver_acks puts into the ack matrix before the quorum tally), Heartbeat /
+// CommitNotice -> smr_wire_hb; every other frame is only located (connection, kind, offset, length) for the host's
+// smr_wire_decode.  The frame rules are smr_wire_decode's (csrc/wire.hip), restated for a lane.
+//
+// One lane per connection, one wavefront per block.  A connection's stream is walked through a 256-byte window that
+// the lane copies from HBM with 16-byte loads (16 in flight) into ITS column of LDS -- dword d of lane l at
+// win[d * 64 + l], so a wavefront's byte reads never share a bank whatever offsets its lanes are at; nothing in LDS
+// is shared between lanes, it is the lane's indexable scratch -- and refilled at the lane's position when the next
+// frame leaves it.  Output order is the sequential decoder's (connection by connection, frame by frame): pass 1
+// counts per lane and per wavefront, a one-block scan turns the wavefronts' counts into bases, pass 2 walks again and
+// writes -- no atomics on the record counters (a same-address atomic per wavefront and pass would cost more than the
+// bytes: smr_common.h on the event counters).
+#include "smr_common.h"
+
+namespace smr {
+
+typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SMR_WI_WIN
+#define SMR_WI_WIN 256                           // 16 KB of LDS per wavefront: 9 blocks per CU (512: 4, 128: 16); >= 16 + 8 + WI_HOT_MAX
+#endif
+constexpr uint32_t WI_WIN = SMR_WI_WIN;          // bytes of a connection's stream in LDS at a time
+constexpr uint32_t WI_DW = WI_WIN / 4;
+constexpr uint32_t WI_HOT_MAX = 64;              // no AcceptReply / Heartbeat / CommitNotice payload is longer (<= 38 bytes)
+
+// smr_wire's Rd over my lane's window (bytes [n, end) of it)
+struct WinRd {
+    const uint32_t *col;                         // &win[lane]
+    uint32_t n, end;
+    bool ok;
+    uint32_t cw = 0, ci = 0xFFFFFFFFu;           // the dword my last byte came from: one LDS read per four bytes
+    __device__ __forceinline__ uint8_t byte() {
+        if (n < end) {
+            const uint32_t i = n >> 2;
+            if (i != ci) { cw = col[i * 64]; ci = i; }
+            const uint8_t b = (uint8_t)(cw >> (8 * (n & 3)));
+            n++;
+            return b;
+        }
+        ok = false;
+        return 0;
+    }
+    __device__ __forceinline__ uint64_t le(int bytes) { uint64_t v = 0; for (int i = 0; i < bytes; i++) v |= (uint64_t)byte() << (8 * i); return v; }
+    __device__ __forceinline__ uint64_t varint() {
+        const uint8_t b = byte();
+        if (b < 251) return b;
+        if (b == 0xFB) return le(2);
+        if (b == 0xFC) return le(4);
+        if (b == 0xFD) return le(8);
+        ok = false;
+        return 0;
+    }
+};
+
+struct IngestArgs {
+    const uint8_t *buf; uint64_t buf_len;
+    const uint64_t *conn_off; const uint32_t *conn_group; const uint8_t *conn_peer; uint32_t n_conn;
+    smr_mp_ack *acks; uint64_t ack_cap;
+    smr_wire_hb *hbs; uint64_t hb_cap;
+    smr_wire_other *others; uint64_t other_cap;
+    uint64_t *wave_cnt;                          // [n_waves][3]: counts (pass 1), then exclusive bases (the scan)
+    uint32_t *lane_cnt;                          // [n_waves * 64][3]: pass 1's counts per connection
+    uint64_t *counts;                            // [4]: acks, heartbeats / commit notices, others, malformed connections
+    uint64_t *consumed; int32_t *status;
+};
+
+// WRITE = false: count my connection's records, report consumed / status; true: write them at my bases
+template <bool WRITE>
+__global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
+    __shared__ uint32_t win[WI_DW * 64];
+    __shared__ uint32_t sh_cnt[3][64];
+    const uint32_t lane = threadIdx.x, c = blockIdx.x * 64 + lane;
+    const bool live = c < A.n_conn;
+    const uint64_t start = live ? A.conn_off[c] : 0, end = live ? A.conn_off[c + 1] : 0;
+    const uint32_t group = live ? A.conn_group[c] : 0, peer = live ? A.conn_peer[c] : 0;
+    uint64_t pos = start;
+    int st = 0;
+    bool done = !live;
+    if (live && (end < start || end > A.buf_len)) { st = 1; done = true; }
+    uint64_t base[3] = {0, 0, 0};
+    if (WRITE) {                                  // where my records go: my wavefront's bases + the lanes before me
+#pragma unroll
+        for (int k = 0; k < 3; k++) sh_cnt[k][lane] = A.lane_cnt[(size_t)c * 3 + k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            uint64_t b = A.wave_cnt[(size_t)blockIdx.x * 3 + k];
+            for (uint32_t l = 0; l < lane; l++) b += sh_cnt[k][l];
+            base[k] = b;
+        }
+    }
+    uint32_t n[3] = {0, 0, 0};
+    uint32_t *const col = &win[lane];
+    while (!done) {
+        // ---- refill my column at my position: what is left of my stream, at most the window ------------
+        const uint64_t wbase = pos & ~15ull;
+        const uint64_t left = end - wbase;
+        const uint32_t nchunk = (uint32_t)(left >= WI_WIN ? WI_WIN / 16 : (left + 15) / 16);
+#pragma unroll 8
+        for (uint32_t k = 0; k < WI_WIN / 16; k++) {
+            if (k >= nchunk) break;
+            const uint64_t off = wbase + 16ull * k;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (off + 16 <= A.buf_len) {
+                const wi_u32x4 q = *(const wi_u32x4 *)(A.buf + off);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+                for (uint32_t i = 0; i < 16 && off + i < A.buf_len; i++) v[i >> 2] |= (uint32_t)A.buf[off + i] << (8 * (i & 3));
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) col[(4 * k + j) * 64] = v[j];
+        }
+        // ---- the frames that lie inside the window -----------------------------------------------------
+        for (;;) {
+            const uint64_t avail = end - pos;
+            if (avail < 8) { done = true; break; }                                  // length not complete yet
+            const uint32_t woff = (uint32_t)(pos - wbase);
+            if (woff + 8 > WI_WIN) break;
+            WinRd r{col, woff, woff + 8, true};
+            uint64_t plen = 0;
+            for (int i = 0; i < 8; i++) plen = (plen << 8) | r.byte();
+            if (plen > 1000000000000ull) { st = 1; done = true; break; }            // safetcp.rs:56-66
+            if (avail - 8 < plen) { done = true; break; }                           // frame not complete yet
+            const uint32_t look = (uint32_t)(plen < WI_HOT_MAX ? plen : WI_HOT_MAX);
+            if (woff + 8 + look > WI_WIN) break;                                    // (after a refill woff < 16: always fits)
+            r.end = woff + 8 + look;
+            const uint64_t outer = r.varint();
+            uint32_t kind = SMR_WIRE_OTHER;
+            bool hot = false;
+            uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+            if (outer == 2) kind = SMR_WIRE_LEAVE;                                  // PeerMessage::Leave
+            else if (outer == 0) {                                                  // PeerMessage::Msg { msg }
+                const uint64_t v = r.varint();
+                kind = (uint32_t)(v <= SMR_WIRE_COMMIT_NOTICE ? v : SMR_WIRE_OTHER);
+                if (v == SMR_WIRE_ACCEPT_REPLY) {
+                    f0 = r.varint(); f1 = r.varint();                               // slot, ballot
+                    const uint8_t ts = r.byte();                                    // Option<SystemTime>
+                    if (ts == 1) { r.varint(); r.varint(); } else if (ts != 0) r.ok = false;
+                    hot = true;
+                } else if (v == SMR_WIRE_HEARTBEAT) {
+                    f0 = r.varint(); f1 = r.varint(); f2 = r.varint(); f3 = r.varint();   // ballot, commit_bar, exec_bar, snap_bar
+                    hot = true;
+                } else if (v == SMR_WIRE_COMMIT_NOTICE) {
+                    f0 = r.varint(); f1 = r.varint();                               // ballot, commit_bar
+                    hot = true;
+                }
+            }
+            // a frame whose leading varints do not parse, or a hot frame that does not end where its length says
+            if (!r.ok || (hot && (uint64_t)(r.n - (woff + 8)) != plen)) { st = 1; done = true; break; }
+            // (an AcceptReply for a slot the engine cannot name -- its slots are u32 -- goes the host's way)
+            const int what = (kind == SMR_WIRE_ACCEPT_REPLY && f0 <= 0xFFFFFFFFull) ? 0 :
+                             (kind == SMR_WIRE_HEARTBEAT || kind == SMR_WIRE_COMMIT_NOTICE) ? 1 : 2;
+            if (WRITE) {
+                const uint64_t at = base[what] + n[what];
+                if (what == 0 && at < A.ack_cap) {
+                    smr_mp_ack a; a.group = group; a.slot = (uint32_t)f0; a.ballot = f1; a.peer = peer; a.reserved = 0;
+                    A.acks[at] = a;
+                } else if (what == 1 && at < A.hb_cap) {
+                    smr_wire_hb h; h.group = group; h.peer = peer; h.kind = kind; h.reserved = 0; h.ballot = f0; h.commit_bar = f1;
+                    h.exec_bar = f2; h.snap_bar = f3;
+                    A.hbs[at] = h;
+                } else if (what == 2 && at < A.other_cap) {
+                    smr_wire_other o; o.conn = c; o.kind = kind; o.off = pos; o.len = 8 + plen;
+                    A.others[at] = o;
+                }
+            }
+            n[what]++;
+            pos += 8 + plen;
+        }
+    }
+    if (!WRITE) {
+        if (live) { A.consumed[c] = pos - start; A.status[c] = st; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A.lane_cnt[(size_t)c * 3 + k] = n[k]; sh_cnt[k][lane] = n[k]; }
+        const unsigned long long bad = __ballot(st != 0);
+        __syncthreads();
+        if (lane < 3) {
+            uint64_t t = 0;
+            for (uint32_t l = 0; l < 64; l++) t += sh_cnt[lane][l];
+            A.wave_cnt[(size_t)blockIdx.x * 3 + lane] = t;
+        }
+        if (lane == 0 && bad) atomicAdd((unsigned long long *)&A.counts[3], (unsigned long long)__popcll(bad));
+    }
+}
+
+// the wavefronts' counts -> exclusive bases, totals into counts[0 .. 3): one block, 256 lanes, a chunk of rows per lane
+__global__ __launch_bounds__(256) void wire_ingest_scan_kernel(uint64_t *__restrict__ wave_cnt, uint32_t n_waves, uint64_t *__restrict__ counts) {
+    __shared__ uint64_t part[3][256];
+    const uint32_t t = threadIdx.x, per = (n_waves + 255) / 256;
+    const uint32_t lo = t * per < n_waves ? t * per : n_waves, hi = lo + per < n_waves ? lo + per : n_waves;
+    uint64_t s[3] = {0, 0, 0};
+    for (uint32_t w = lo; w < hi; w++)
+        for (int k = 0; k < 3; k++) s[k] += wave_cnt[(size_t)w * 3 + k];
+    for (int k = 0; k < 3; k++) part[k][t] = s[k];
+    __syncthreads();
+    uint64_t b[3] = {0, 0, 0};
+    for (uint32_t q = 0; q < t; q++)
+        for (int k = 0; k < 3; k++) b[k] += part[k][q];
+    for (uint32_t w = lo; w < hi; w++)
+        for (int k = 0; k < 3; k++) { const uint64_t x = wave_cnt[(size_t)w * 3 + k]; wave_cnt[(size_t)w * 3 + k] = b[k]; b[k] += x; }
+    if (t == 255) for (int k = 0; k < 3; k++) counts[k] = b[k] ;
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+extern "C" {
+
+uint64_t smr_wire_ingest_scratch_bytes(uint32_t n_conn) {
+    const uint64_t n_waves = ((uint64_t)n_conn + 63) / 64;
+    return n_waves * 3 * 8 + n_waves * 64 * 3 * 4;
+}
+
+int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                       const uint8_t *conn_peer_dev, uint32_t n_conn, smr_mp_ack *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
+                       uint64_t hb_cap, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev, uint64_t *consumed_dev,
+                       int32_t *status_dev, void *scratch_dev, void *stream) {
+    if ((n_conn && (!conn_off_dev || !conn_group_dev || !conn_peer_dev)) || !counts_dev || !consumed_dev || !status_dev || !scratch_dev ||
+        (buf_len && !buf_dev) || (ack_cap && !acks_dev) || (hb_cap && !hbs_dev) || (other_cap && !others_dev))
+        return fail(SMR_ERR_ARG, "wire ingest: null argument");
+    if (((uintptr_t)buf_dev & 15) || ((uintptr_t)scratch_dev & 7))
+        return fail(SMR_ERR_ARG, "wire ingest: the byte buffer must be 16-byte aligned, the scratch 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
+    if (n_conn == 0) return SMR_OK;
+    const uint32_t n_waves = (n_conn + 63) / 64;
+    IngestArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, acks_dev, ack_cap, hbs_dev, hb_cap,
+                 others_dev, other_cap, (uint64_t *)scratch_dev, (uint32_t *)((uint64_t *)scratch_dev + (size_t)n_waves * 3),
+                 counts_dev, consumed_dev, status_dev};
+    hipLaunchKernelGGL(wire_ingest_mp_kernel<false>, dim3(n_waves), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(wire_ingest_scan_kernel, dim3(1), dim3(256), 0, st, A.wave_cnt, n_waves, counts_dev);
+    hipLaunchKernelGGL(wire_ingest_mp_kernel<true>, dim3(n_waves), dim3(64), 0, st, A);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+}  // extern "C"

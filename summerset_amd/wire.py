@@ -385,3 +385,53 @@ def frame_payload(frame):
     n = int.from_bytes(frame[:8], "big")
     assert len(frame) == 8 + n
     return frame[8:]
+
+
+# ---- MultiPaxos peer traffic parsed on the device (smr_wire_ingest_mp, csrc/wire_ingest.hip) ----
+import numpy as _np  # noqa: E402
+
+HB_DTYPE = _np.dtype([("group", "<u4"), ("peer", "<u4"), ("kind", "<u4"), ("reserved", "<u4"), ("ballot", "<u8"),
+                      ("commit_bar", "<u8"), ("exec_bar", "<u8"), ("snap_bar", "<u8")])
+OTHER_DTYPE = _np.dtype([("conn", "<u4"), ("kind", "<u4"), ("off", "<u8"), ("len", "<u8")])
+
+
+class MpIngest:
+    """The receive side of a batch of peer connections on the device: the bytes every connection delivered this tick
+    (device uint8 tensor `buf`, connection c = buf[conn_off[c]:conn_off[c + 1]], sent by replica conn_peer[c] of group
+    conn_group[c]) -> AcceptReply records in `acks` (multipaxos.ACK_DTYPE, the tensor `deliver_acks` takes), Heartbeat /
+    CommitNotice records in `hbs` (HB_DTYPE), every other frame located in `others` (OTHER_DTYPE) for `decode`; all in
+    the sequential decoder's order.  Output tensors are allocated once for the capacities given and reused."""
+
+    def __init__(self, n_conn, ack_cap, hb_cap, other_cap, device):
+        import torch
+        from .multipaxos import ACK_DTYPE
+        L = _lib.load()
+        self._L, self.n_conn, self.device = L, int(n_conn), device
+        self.acks = torch.zeros(max(ack_cap, 1) * ACK_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.hbs = torch.zeros(max(hb_cap, 1) * HB_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.others = torch.zeros(max(other_cap, 1) * OTHER_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.caps = (int(ack_cap), int(hb_cap), int(other_cap))
+        self.counts = torch.zeros(4, dtype=torch.int64, device=device)
+        self.consumed = torch.zeros(max(n_conn, 1), dtype=torch.int64, device=device)
+        self.status = torch.zeros(max(n_conn, 1), dtype=torch.int32, device=device)
+        self.scratch = torch.zeros(max(int(L.smr_wire_ingest_scratch_bytes(self.n_conn)), 8) // 8, dtype=torch.int64, device=device)
+
+    def ingest(self, buf, conn_off, conn_group, conn_peer, stream=None):
+        """buf uint8 (16-byte aligned: a torch allocation is), conn_off int64 [n_conn + 1], conn_group int32 / uint32
+        [n_conn], conn_peer uint8 [n_conn], all on the device; only enqueues work"""
+        assert conn_off.numel() == self.n_conn + 1 and conn_group.numel() == self.n_conn and conn_peer.numel() == self.n_conn
+        assert conn_off.element_size() == 8 and conn_group.element_size() == 4 and conn_peer.element_size() == 1
+        p = lambda t: t.data_ptr()   # noqa: E731
+        check(self._L.smr_wire_ingest_mp(p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_group), p(conn_peer), self.n_conn,
+                                         p(self.acks), self.caps[0], p(self.hbs), self.caps[1], p(self.others), self.caps[2],
+                                         p(self.counts), p(self.consumed), p(self.status), p(self.scratch), _lib.stream_ptr(stream)))
+
+    def results(self):
+        """host copies (synchronises): dict of counts, the record arrays cut to what was stored, consumed, status"""
+        from .multipaxos import ACK_DTYPE
+        n = [int(x) for x in self.counts.cpu().tolist()]
+        cut = lambda t, dt, k, cap: t.cpu().numpy().view(dt)[:min(k, cap)].copy()   # noqa: E731
+        return {"n_acks": n[0], "n_hbs": n[1], "n_others": n[2], "n_malformed": n[3],
+                "acks": cut(self.acks, ACK_DTYPE, n[0], self.caps[0]), "hbs": cut(self.hbs, HB_DTYPE, n[1], self.caps[1]),
+                "others": cut(self.others, OTHER_DTYPE, n[2], self.caps[2]),
+                "consumed": self.consumed.cpu().numpy()[:self.n_conn].copy(), "status": self.status.cpu().numpy()[:self.n_conn].copy()}

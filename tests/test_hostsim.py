@@ -130,6 +130,15 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True, commit_extra=2)
 
 
+def test_wire_ingest_kernels_on_the_host(sim, oracle):
+    """peer traffic parsed on the device (f.1): streams against the sequential decoder, and inside the engine's tick"""
+    import test_zz_wire_ingest_gpu as t
+    with sim.patched():
+        t.test_ingest_matches_the_sequential_decoder("cpu")
+        t.test_empty_and_overfull("cpu")
+        t.test_accept_replies_over_the_wire("cpu", oracle)
+
+
 def test_rs_kernels_on_the_host(sim, oracle):
     import test_rs_gpu as t
     with sim.patched():

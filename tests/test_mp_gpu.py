@@ -113,6 +113,8 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
             eng.round_deliver()
             if per_round == "records":
                 _acks_as_records(eng, cuda, G, R, cap, t)
+            elif callable(per_round):       # a test's own step between R2 and R3 (tests/test_zz_wire_ingest_gpu.py)
+                per_round(eng, cuda, G, R, cap, t)
             eng.round_replies(d["ackctl"], publish_heartbeat=inp["heartbeat"])
             if inp["heartbeat"]:
                 eng.round_heartbeat()
