@@ -85,7 +85,7 @@ def parse():
                     "smr_mp_tick call per tick")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
-    ap.add_argument("--layout", choices=("colocated", "spread"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
+    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
                     "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
     ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
                     "kernels, plans and buffers; the collective is a device copy)")
@@ -801,6 +801,64 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
+    """--layout spread-epaxos: BASELINE config 5 as written -- EPaxos, args.groups groups per GPU x 5 replicas, every replica
+    proposes one instance per group per tick on Zipf(0.99) keys of 64, the replicas of a group on different ranks
+    (summerset_amd/spread_ep.py: five all_to_all_single per tick).  At world 1 the ranks are virtual."""
+    from summerset_amd import shard, spread_ep
+    R, W, K = 5, 32, 64
+    virtual = world == 1
+    nr = args.spread_ranks if virtual else world
+    total = args.groups * (1 if virtual else world)
+    job = spread_ep.in_process(total, R, nr, dev, window=W, n_keys=K) if virtual else spread_ep.SpreadEPaxos(total, R, rank, world, dev, window=W, n_keys=K)
+    homes = [k for rk in job.ranks for k in rk.reps] if virtual else list(job.reps)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    n_ticks = args.warmup + args.steps
+    keys = []
+    for t in range(min(n_ticks, 8)):                                   # keyed by (tick, block, replica): every rank draws its own replicas' keys
+        keys.append({(b, r): torch.from_numpy(np.random.default_rng([0x5EED5EED, t, b, r]).choice(
+            K, shard.group_range(total, nr, b)[1] - shard.group_range(total, nr, b)[0], p=zipf).astype(np.uint8)).to(dev) for b, r in homes})
+    committed = torch.zeros((), dtype=torch.int64, device=dev)
+    slow = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(args.warmup):
+        job.tick(keys[t % len(keys)])
+    torch.cuda.synchronize()
+    sent0 = sum(rk.bytes_sent for rk in job.ranks) if virtual else job.bytes_sent
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_ticks):
+        for o in job.tick(keys[t % len(keys)]).values():
+            committed += o["committed"].sum()
+            slow += (o["decision"] == 2).sum()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    sent = (sum(rk.bytes_sent for rk in job.ranks) if virtual else job.bytes_sent) - sent0
+    n_slow = int(slow.item())
+    elapsed, commits = shard.reduce_metric(elapsed, int(committed.item()), device=dev)
+    line = {"metric": "committed_instances_per_sec", "value": commits / elapsed, "unit": "instances/s", "n_gpus": world,
+            "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "EPaxos closed loop, %d groups/GPU x 5 replicas, every replica proposes 1 instance per group per tick "
+                                   "(Zipf(0.99) keys of 64), optimized quorums" % args.groups,
+                       "groups_per_gpu": args.groups, "replicas": R, "window": W, "layout": "spread", "spread_ranks": nr,
+                       "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
+            "exchange": {"collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1)},
+            "slow_path_instances_this_rank": n_slow, "roofline": None, "cpu_baseline": None,
+            "note": "correctness layout of config 5's inter-replica fan-out (handler calls of the Python driver included); the roofline / "
+                    "cpu_baseline objects belong to the co-located line"}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks exactly as the driver's own
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would and hand
@@ -862,6 +920,8 @@ def main():
     from summerset_amd import MultiPaxosCluster, stream
     if args.layout == "spread":
         return spread_main(args, torch, dist, rank, local, world, dev)
+    if args.layout == "spread-epaxos":
+        return spread_epaxos_main(args, torch, dist, rank, local, world, dev)
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4

@@ -5,8 +5,8 @@
 // CommitNotice -> smr_wire_hb; every other frame is only located (connection, kind, offset, length) for the host's
 // smr_wire_decode.  The frame rules are smr_wire_decode's (csrc/wire.hip), restated for a lane.
 //
-// One lane per connection, one wavefront per block.  A connection's stream is walked through a 256-byte window that
-// the lane copies from HBM with 16-byte loads (16 in flight) into ITS column of LDS -- dword d of lane l at
+// One lane per connection, one wavefront per block.  A connection's stream is walked through a 128-byte window that
+// the lane copies from HBM with 16-byte loads (8 in flight) into ITS column of LDS -- dword d of lane l at
 // win[d * 64 + l], so a wavefront's byte reads never share a bank whatever offsets its lanes are at; nothing in LDS
 // is shared between lanes, it is the lane's indexable scratch -- and refilled at the lane's position when the next
 // frame leaves it.  Output order is the sequential decoder's (connection by connection, frame by frame): pass 1
@@ -19,7 +19,8 @@ namespace smr {
 
 typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SMR_WI_WIN
-#define SMR_WI_WIN 256                           // 16 KB of LDS per wavefront: 9 blocks per CU (512: 4, 128: 16); >= 16 + 8 + WI_HOT_MAX
+#define SMR_WI_WIN 128                           // 8 KB of LDS per wavefront: 16 blocks per CU (256: 9, 512: 4); >= 16 + 8 + WI_HOT_MAX.  Measured
+                                                 // (profiles/r2p_wire_ingest_first.log, same call): 128 -> 451 us, 256 -> 642, 512 -> 709 per ingest
 #endif
 constexpr uint32_t WI_WIN = SMR_WI_WIN;          // bytes of a connection's stream in LDS at a time
 constexpr uint32_t WI_DW = WI_WIN / 4;

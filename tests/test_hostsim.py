@@ -279,3 +279,15 @@ def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
     import test_zz_ep_cluster_gpu as t
     with sim.patched():
         t.test_device_cluster_tick_matches_the_oracle_cluster("cpu", oracle, 300, 6, 0.15)
+
+
+def test_spread_epaxos_exchange_on_the_host(sim):
+    """layout L2 of the EPaxos cluster with every rank in this process (tests/test_spread_ep.py): one all-to-all per
+    exchange, both schedules -- against the co-located closed loop, every tick and the final state"""
+    import test_spread_ep as t
+    with sim.patched():
+        t.run_spread_vs_colocated("cpu", G=130, world=2, n_ticks=6, loss=0.15)
+        t.run_spread_vs_colocated("cpu", G=100, world=3, n_ticks=5, loss=0.15)
+        t.run_spread_vs_colocated("cpu", G=21, world=8, n_ticks=4, loss=0.1)
+        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True)
+        assert job.ranks[0].exchanges_per_tick() == 17

@@ -1,0 +1,117 @@
+"""Spread layout (L2) of the EPaxos cluster -- BASELINE config 5's "fast-quorum kernel with RCCL all-to-all"
+(summerset_amd/spread_ep.py): replica r of block b on rank (b + r) mod world, five exchanges per tick (2 + 3 R in the
+ordered schedule), each one all_to_all_single on device tensors -- against the co-located closed loop of
+summerset_amd/ep_cluster.py on the same keys and losses: every command leader's decisions of every tick and every
+replica's full state.  All ranks of the job in one process here (gpu-marked: on the device; tests/test_hostsim.py
+reruns it on the emulator build); tests/test_spread_ep_gloo.py is the two-process job."""
+import numpy as np
+import pytest
+
+
+def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execute=False, ordered=None, make=None, seed=0):
+    """`make(world)` -> object with tick(keys, drop) and .ranks (default: spread_ep.in_process)"""
+    import torch
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard, spread_ep
+    ref = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    job = spread_ep.in_process(G, R, world, dev, window=W, n_keys=K, execute=execute, ordered=ordered) if make is None else make(world)
+    rng = np.random.default_rng(1000 * world + G + seed)
+    rngs = {b: shard.group_range(G, world, b) for b in range(world)}
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fast = slow = 0
+    for t in range(n_ticks):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q} if loss else None
+        oo = ep_cluster.tick(ref, [dv(keys[r]) for r in range(R)], None if drop is None else {k: dv(v) for k, v in drop.items()},
+                             always_accept_round=True)
+        bk = {(b, r): dv(keys[r, lo:hi]) for b, (lo, hi) in rngs.items() for r in range(R) if hi > lo}
+        bd = None if drop is None else {(b, s, q): dv(v[lo:hi]) for b, (lo, hi) in rngs.items() for (s, q), v in drop.items() if hi > lo}
+        oe = job.tick(bk, bd)
+        assert sorted(oe) == sorted(bk)
+        for (b, s), o in oe.items():
+            lo, hi = rngs[b]
+            for k in o:
+                assert np.array_equal(o[k].cpu().numpy(), oo[s][k][..., lo:hi].cpu().numpy()), (t, b, s, k)
+        fast += sum(int((oo[s]["decision"] == 3).sum()) for s in range(R))
+        slow += sum(int((oo[s]["decision"] == 2).sum()) for s in range(R))
+    full = [ref[r].dump() for r in range(R)]
+    xfull = [ref[r].exec_dump() for r in range(R)] if execute else None
+    seen = set()
+    for rk in job.ranks:
+        for (b, r), rep in rk.reps.items():
+            assert (b, r) not in seen and spread_ep.home(b, r, world) == rk.rank
+            seen.add((b, r))
+            lo, hi = rngs[b]
+            a = rep.dump()
+            for n, x in full[r].items():
+                if n == "counters":
+                    continue
+                gax = {"deps": 2}.get(n, x.ndim - 1)                    # deps is [R, W, G, R]; everything else ends in G
+                assert np.array_equal(a[n], np.take(x, np.arange(lo, hi), axis=gax)), (rk.rank, b, r, n)
+            if execute:
+                xa = rep.exec_dump()
+                for n in ("exec_bars", "kv", "digest"):
+                    assert np.array_equal(xa[n], xfull[r][n][..., lo:hi]), (rk.rank, b, r, "exec", n)
+    assert seen == {(b, r) for b, (lo, hi) in rngs.items() for r in range(R) if hi > lo}
+    for r in range(R):                                                  # the event counters add up over the blocks
+        tot = sum(rep.dump()["counters"] for rk in job.ranks for (b, q), rep in rk.reps.items() if q == r)
+        assert np.array_equal(tot, full[r]["counters"]), r
+    assert fast > 0 and (slow > 0 or not loss)
+    return job
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_spread_epaxos_job_is_the_colocated_one(cuda, world):
+    job = run_spread_vs_colocated(cuda, G=96 * world, world=world, n_ticks=8, loss=0.15)
+    assert all(rk.bytes_sent > 0 and rk.exchanges_per_tick() == 5 for rk in job.ranks)
+
+
+@pytest.mark.gpu
+def test_spread_epaxos_ordered_schedule_with_execution(cuda):
+    job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True)
+    assert all(rk.exchanges_per_tick() == 17 for rk in job.ranks)
+    run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True)
+
+
+def test_plans_agree_across_ranks_without_a_device():
+    """the static plans only: what rank s sends to d is what d expects from s, in every exchange of both schedules, and
+    every (block, replica) has exactly one home -- no library call, no device"""
+    from summerset_amd import shard, spread_ep
+    for world, G, ordered in [(2, 130, False), (3, 100, True), (8, 5, False), (8, 1000, True)]:
+        stubs = []
+        for rank in range(world):
+            s = spread_ep.SpreadEPaxos.__new__(spread_ep.SpreadEPaxos)
+            import torch
+            s.torch, s.R, s.rank, s.world, s.device = torch, 5, rank, world, "cpu"
+            s.range = {b: shard.group_range(G, world, b) for b in range(world)}
+            stubs.append(s)
+        sets = [[s] for s in range(5)] if ordered else [list(range(5))]
+        for kind, ls in [("pre_accept", list(range(5))), ("pa_reply", list(range(5)))] + [(k, l) for l in sets for k in ("accept", "acc_reply", "commit")]:
+            plans = [s._plan(kind, ls) for s in stubs]
+            for a in range(world):
+                for b in range(world):
+                    assert plans[a]["in_split"][b] == plans[b]["out_split"][a]
+                assert plans[a]["in_split"][a] == 0 and sum(plans[a]["in_split"]) == plans[a]["n_send"]
+                assert all(v % 8 == 0 for v in plans[a]["in_split"])
+        homes = [(b, r) for b in range(world) for r in range(5)]
+        assert sorted(homes) == sorted((b, r) for k in range(world) for b in range(world) for r in range(5) if spread_ep.home(b, r, world) == k)
+
+
+def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch):
+    """`bench.py --layout spread-epaxos` end to end with virtual ranks (world 1), the emulator build standing in for the
+    device: the line it prints carries the contract's keys and a positive rate"""
+    import json
+    import sys
+    import torch
+    import hostsim
+    import bench
+    hostsim.build()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--layout", "spread-epaxos", "--groups", "96", "--steps", "3", "--warmup", "1", "--spread-ranks", "3"])
+    args = bench.parse()
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    with hostsim.patched():
+        bench.spread_epaxos_main(args, torch, torch.distributed, 0, 0, 1, "cpu")
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["spread_ranks"] == 3 and line["exchange"]["collectives_per_tick"] == 5
+    assert line["value"] > 0 and line["exchange"]["bytes_sent_per_tick_per_rank"] > 0 and line["steps"] == 3

@@ -1,0 +1,111 @@
+"""Layout L2 of the EPaxos cluster (BASELINE config 5: fast-quorum kernel + all-to-all) as a real two-process job:
+world_size 2 over gloo, the EMULATOR BUILD of the engine on every rank (tests/hostsim: the shipped kernels compiled for
+the host -- not the oracle), one `all_to_all_single` per exchange on the job's own send / receive buffers.  After the
+run every (block, replica) must hold exactly what the single-process co-located cluster holds for those groups, and every
+command leader must have reported the same decisions tick by tick."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, R, W, K, TICKS, LOSS = 150, 5, 32, 6, 7, 0.15
+OUT = ("col", "proposed", "decision", "committed", "seq", "deps")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(t):
+    """tick t's proposals and lost PreAccepts for the WHOLE job (every rank draws the same and keeps its groups)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ep_cluster as ec
+    rng = np.random.default_rng(77 + t)
+    keys = ec.zipf_keys(rng, R, G, K)
+    drop = {(s, q): rng.random(G) < LOSS for s in range(R) for q in range(R) if s != q}
+    return keys, drop
+
+
+def _worker(rank, world, port, out_dir, execute):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    import hostsim
+    from summerset_amd import spread_ep
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tn = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    with hostsim.patched():
+        job = spread_ep.SpreadEPaxos(G, R, rank, world, "cpu", window=W, n_keys=K, execute=execute)
+        out = {}
+        for t in range(TICKS):
+            keys, drop = _inputs(t)
+            bk = {(b, r): tn(keys[r, job.range[b][0]:job.range[b][1]]) for (b, r) in job.reps}
+            bd = {(b, s, q): tn(v[job.range[b][0]:job.range[b][1]]) for (b, s) in job.reps for (s2, q), v in drop.items() if s2 == s}
+            for (b, s), o in job.tick(bk, bd).items():
+                for k in OUT:
+                    out["t%d_b%d_s%d_%s" % (t, b, s, k)] = o[k].numpy().copy()
+        for (b, r), rep in job.reps.items():
+            for n, v in rep.dump().items():
+                out["dump_b%d_r%d_%s" % (b, r, n)] = v
+            if execute:
+                for n, v in rep.exec_dump().items():
+                    out["exec_b%d_r%d_%s" % (b, r, n)] = v
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=np.array(sorted(job.reps)), sent=job.bytes_sent,
+                 exchanges=job.exchanges_per_tick(), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, execute):
+    import torch
+    import torch.multiprocessing as mp
+    import hostsim
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard
+    hostsim.build()                                                   # once, before the workers race to build it
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute), nprocs=2, join=True)
+    ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
+    assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
+    assert all(int(rk["sent"]) > 0 and int(rk["exchanges"]) == (17 if execute else 5) for rk in ranks)
+    tn = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    fast = slow = 0
+    with hostsim.patched():
+        ref = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+        for t in range(TICKS):
+            keys, drop = _inputs(t)
+            oo = ep_cluster.tick(ref, [tn(keys[r]) for r in range(R)], {k: tn(v) for k, v in drop.items()}, always_accept_round=True)
+            for rk in ranks:
+                for b, s in rk["live"].tolist():
+                    lo, hi = shard.group_range(G, 2, b)
+                    for k in OUT:
+                        assert np.array_equal(rk["t%d_b%d_s%d_%s" % (t, b, s, k)], oo[s][k][..., lo:hi].numpy()), (t, b, s, k)
+            fast += sum(int((oo[s]["decision"] == 3).sum()) for s in range(R))
+            slow += sum(int((oo[s]["decision"] == 2).sum()) for s in range(R))
+        for rk in ranks:
+            for b, r in rk["live"].tolist():
+                lo, hi = shard.group_range(G, 2, b)
+                for n, x in ref[r].dump().items():
+                    if n != "counters":
+                        gax = {"deps": 2}.get(n, x.ndim - 1)
+                        assert np.array_equal(rk["dump_b%d_r%d_%s" % (b, r, n)], np.take(x, np.arange(lo, hi), axis=gax)), (b, r, n)
+                if execute:
+                    xd = ref[r].exec_dump()
+                    for n in ("exec_bars", "kv", "digest"):
+                        assert np.array_equal(rk["exec_b%d_r%d_%s" % (b, r, n)], xd[n][..., lo:hi]), (b, r, "exec", n)
+    assert fast > 0 and slow > 0
+
+
+def test_world_size_2_spread_epaxos_job_is_the_colocated_one(tmp_path):
+    _run(tmp_path, execute=False)
+
+
+def test_world_size_2_spread_epaxos_ordered_schedule_with_execution(tmp_path):
+    _run(tmp_path, execute=True)
