@@ -46,6 +46,13 @@ def pmc_traffic(kernel):
     return d["kernels"].get(kernel) if d else None
 
 
+def _leg_traffic(kernel):
+    """HBM bytes per launch of a secondary leg's kernel from the committed PMC passes (tools/pmc_probe.py drives the same
+    leg at the same shape), or None"""
+    t = pmc_traffic(kernel)
+    return t["hbm_bytes_per_launch"] if t else None
+
+
 TIMEOUT_HORIZON = 72     # ticks of the default run (60 timed + 12 warm-up): --timeouts is the fraction of groups per THIS many ticks
 
 
@@ -425,7 +432,8 @@ def raft_leg(torch, dev, S=32, ticks=24):
             "value": commits / (us * 1e-6 * ticks), "unit": "slots/s", "us_per_tick": us,
             "roofline": {"bound": "hbm", "kernel": "raft_replies_kernel", "achieved": alg / (us_k * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us_k * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "alg_bytes_per_launch": alg, "avg_launch_us": us_k, "traffic": None}}
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us_k, "traffic": _leg_traffic("smr::raft_replies_kernel<false, 5>"),
+                         "traffic_source": PMC_NOTE}}
 
 
 def epaxos_leg(torch, dev, ticks=16):
@@ -493,7 +501,8 @@ def epaxos_leg(torch, dev, ticks=16):
             "fast_path_fraction": committed / (G * ticks), "propose_kernel_us": t_prop / ticks * 1e3,
             "roofline": {"bound": "hbm", "kernel": "ep_pre_accept_replies_kernel", "achieved": alg / (us_rep * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us_rep * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "alg_bytes_per_launch": alg, "avg_launch_us": us_rep, "traffic": None}}
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us_rep, "traffic": _leg_traffic("smr::ep_pre_accept_replies_kernel<5>"),
+                         "traffic_source": PMC_NOTE}}
 
 
 

@@ -22,36 +22,48 @@ typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
 #define SMR_WI_WIN 128                           // 8 KB of LDS per wavefront: 16 blocks per CU (256: 9, 512: 4); >= 16 + 8 + WI_HOT_MAX.  Measured
                                                  // (profiles/r2p_wire_ingest_first.log, same call): 128 -> 451 us, 256 -> 642, 512 -> 709 per ingest
 #endif
+#ifndef SMR_WI_COOP
+#define SMR_WI_COOP 1                            // refills loaded by the wavefront together (0: every lane its own window)
+#endif
 constexpr uint32_t WI_WIN = SMR_WI_WIN;          // bytes of a connection's stream in LDS at a time
 constexpr uint32_t WI_DW = WI_WIN / 4;
 constexpr uint32_t WI_HOT_MAX = 64;              // no AcceptReply / Heartbeat / CommitNotice payload is longer (<= 38 bytes)
 
-// smr_wire's Rd over my lane's window (bytes [n, end) of it)
+// smr_wire's Rd over my lane's window (bytes [n, end) of it).  The window is read eight bytes at a time -- three dwords of
+// my column, shifted into place -- and a varint is taken out of that register pair: a byte-at-a-time reader costs a
+// dozen instructions and (every fourth byte) a dependent LDS round trip PER BYTE, and the parse, not the bytes, is what
+// this kernel's time is (a wavefront instruction takes 4 cycles; 33 frames x 17 bytes per lane and pass).
 struct WinRd {
-    const uint32_t *col;                         // &win[lane]
+    const uint32_t *col;                         // &win[lane]; two spare dword rows lie behind the window
     uint32_t n, end;
     bool ok;
-    uint32_t cw = 0, ci = 0xFFFFFFFFu;           // the dword my last byte came from: one LDS read per four bytes
+    __device__ __forceinline__ uint64_t peek64() const {             // bytes n .. n + 7 of the window, little-endian
+        const uint32_t i = n >> 2, sh = 8 * (n & 3);
+        const uint32_t a = col[i * 64], b = col[(i + 1) * 64], c = col[(i + 2) * 64];
+        const uint32_t lo = (uint32_t)((((uint64_t)b << 32) | a) >> sh), hi = (uint32_t)((((uint64_t)c << 32) | b) >> sh);
+        return ((uint64_t)hi << 32) | lo;
+    }
     __device__ __forceinline__ uint8_t byte() {
-        if (n < end) {
-            const uint32_t i = n >> 2;
-            if (i != ci) { cw = col[i * 64]; ci = i; }
-            const uint8_t b = (uint8_t)(cw >> (8 * (n & 3)));
-            n++;
-            return b;
-        }
+        if (n < end) { const uint8_t b = (uint8_t)peek64(); n++; return b; }
         ok = false;
         return 0;
     }
-    __device__ __forceinline__ uint64_t le(int bytes) { uint64_t v = 0; for (int i = 0; i < bytes; i++) v |= (uint64_t)byte() << (8 * i); return v; }
-    __device__ __forceinline__ uint64_t varint() {
-        const uint8_t b = byte();
-        if (b < 251) return b;
-        if (b == 0xFB) return le(2);
-        if (b == 0xFC) return le(4);
-        if (b == 0xFD) return le(8);
+    __device__ __forceinline__ uint64_t be64() {                     // the frame header's length
+        if (n + 8 <= end) { const uint64_t x = peek64(); n += 8; return __builtin_bswap64(x); }
         ok = false;
         return 0;
+    }
+    __device__ __forceinline__ uint64_t varint() {
+        const uint64_t x = peek64();
+        const uint32_t b = (uint32_t)(x & 0xFF);
+        const uint32_t need = b < 251 ? 1 : b == 0xFB ? 3 : b == 0xFC ? 5 : b == 0xFD ? 9 : 0;   // 0xFE (u128), 0xFF: not on this path
+        if (need == 0 || n + need > end) { ok = false; n = end; return 0; }
+        uint64_t v = b;
+        if (need == 3) v = (x >> 8) & 0xFFFF;
+        else if (need == 5) v = (x >> 8) & 0xFFFFFFFFull;
+        else if (need == 9) { n += 1; v = peek64(); n -= 1; }
+        n += need;
+        return v;
     }
 };
 
@@ -70,7 +82,7 @@ struct IngestArgs {
 // WRITE = false: count my connection's records, report consumed / status; true: write them at my bases
 template <bool WRITE>
 __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
-    __shared__ uint32_t win[WI_DW * 64];
+    __shared__ uint32_t win[(WI_DW + 2) * 64];       // + two dword rows: peek64 at the window's last bytes stays inside
     __shared__ uint32_t sh_cnt[3][64];
     const uint32_t lane = threadIdx.x, c = blockIdx.x * 64 + lane;
     const bool live = c < A.n_conn;
@@ -94,11 +106,38 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
     }
     uint32_t n[3] = {0, 0, 0};
     uint32_t *const col = &win[lane];
-    while (!done) {
-        // ---- refill my column at my position: what is left of my stream, at most the window ------------
+    for (;;) {
+        if (!__ballot(!done)) break;              // wave-uniform: a lane that is done stays to help with the refills
+        // ---- refill: every lane's column gets what is left of its stream at its position, at most the window ----
         const uint64_t wbase = pos & ~15ull;
-        const uint64_t left = end - wbase;
+        const uint64_t left = done ? 0 : end - wbase;
         const uint32_t nchunk = (uint32_t)(left >= WI_WIN ? WI_WIN / 16 : (left + 15) / 16);
+#if SMR_WI_COOP
+        // the wavefront loads together: WI_WIN / 16 neighbouring lanes take one connection's window, one 16-byte chunk
+        // each, so an instruction reads whole runs of WI_WIN contiguous bytes (a lane loading its own window alone
+        // touches the same 128-byte line from 8 instructions, 64 different lines per instruction)
+        constexpr uint32_t CPW = WI_WIN / 16, PER = 64 / CPW;                       // lanes per connection; connections per instruction
+        __syncthreads();                                                            // (one wavefront per block) every lane has left the old window
+#pragma unroll
+        for (uint32_t i = 0; i < CPW; i++) {
+            const uint32_t src = i * PER + lane / CPW, k = lane % CPW;
+            const uint64_t wb = __shfl(wbase, (int)src);
+            const uint32_t nc = __shfl(nchunk, (int)src);
+            if (k < nc) {
+                const uint64_t off = wb + 16ull * k;
+                uint32_t v[4] = {0, 0, 0, 0};
+                if (off + 16 <= A.buf_len) {
+                    const wi_u32x4 q = *(const wi_u32x4 *)(A.buf + off);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+                    for (uint32_t b = 0; b < 16 && off + b < A.buf_len; b++) v[b >> 2] |= (uint32_t)A.buf[off + b] << (8 * (b & 3));
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) win[(4 * k + j) * 64 + src] = v[j];
+            }
+        }
+        __syncthreads();
+#else
 #pragma unroll 8
         for (uint32_t k = 0; k < WI_WIN / 16; k++) {
             if (k >= nchunk) break;
@@ -113,15 +152,15 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
 #pragma unroll
             for (uint32_t j = 0; j < 4; j++) col[(4 * k + j) * 64] = v[j];
         }
+#endif
         // ---- the frames that lie inside the window -----------------------------------------------------
-        for (;;) {
+        while (!done) {
             const uint64_t avail = end - pos;
             if (avail < 8) { done = true; break; }                                  // length not complete yet
             const uint32_t woff = (uint32_t)(pos - wbase);
             if (woff + 8 > WI_WIN) break;
             WinRd r{col, woff, woff + 8, true};
-            uint64_t plen = 0;
-            for (int i = 0; i < 8; i++) plen = (plen << 8) | r.byte();
+            const uint64_t plen = r.be64();
             if (plen > 1000000000000ull) { st = 1; done = true; break; }            // safetcp.rs:56-66
             if (avail - 8 < plen) { done = true; break; }                           // frame not complete yet
             const uint32_t look = (uint32_t)(plen < WI_HOT_MAX ? plen : WI_HOT_MAX);

@@ -2,8 +2,8 @@
 (summerset_amd/spread_ep.py): replica r of block b on rank (b + r) mod world, five exchanges per tick (2 + 3 R in the
 ordered schedule), each one all_to_all_single on device tensors -- against the co-located closed loop of
 summerset_amd/ep_cluster.py on the same keys and losses: every command leader's decisions of every tick and every
-replica's full state.  All ranks of the job in one process here (gpu-marked: on the device; tests/test_hostsim.py
-reruns it on the emulator build); tests/test_spread_ep_gloo.py is the two-process job."""
+replica's full state.  All ranks of the job in one process here (on the device: tests/test_zzz_spread_ep_gpu.py; on the emulator
+build: tests/test_hostsim.py); tests/test_spread_ep_gloo.py is the two-process job."""
 import numpy as np
 import pytest
 
@@ -58,20 +58,6 @@ def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execut
         assert np.array_equal(tot, full[r]["counters"]), r
     assert fast > 0 and (slow > 0 or not loss)
     return job
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 8])
-def test_spread_epaxos_job_is_the_colocated_one(cuda, world):
-    job = run_spread_vs_colocated(cuda, G=96 * world, world=world, n_ticks=8, loss=0.15)
-    assert all(rk.bytes_sent > 0 and rk.exchanges_per_tick() == 5 for rk in job.ranks)
-
-
-@pytest.mark.gpu
-def test_spread_epaxos_ordered_schedule_with_execution(cuda):
-    job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True)
-    assert all(rk.exchanges_per_tick() == 17 for rk in job.ranks)
-    run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True)
 
 
 def test_plans_agree_across_ranks_without_a_device():

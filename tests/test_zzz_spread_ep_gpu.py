@@ -1,0 +1,21 @@
+"""Spread layout (L2) of the EPaxos cluster on the device: all ranks of the job in one process on cuda:0, the collective a
+device copy -- summerset_amd/spread_ep.py against the co-located closed loop (tests/test_spread_ep.py holds the
+comparison).  Sorted last: written without a device at hand, a failure here must not keep the rest of the suite from
+running under `pytest -x`."""
+import pytest
+
+from test_spread_ep import run_spread_vs_colocated
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_spread_epaxos_job_is_the_colocated_one(cuda, world):
+    job = run_spread_vs_colocated(cuda, G=96 * world, world=world, n_ticks=8, loss=0.15)
+    assert all(rk.bytes_sent > 0 and rk.exchanges_per_tick() == 5 for rk in job.ranks)
+
+
+def test_spread_epaxos_ordered_schedule_with_execution(cuda):
+    job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True)
+    assert all(rk.exchanges_per_tick() == 17 for rk in job.ranks)
+    run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True)
