@@ -67,6 +67,70 @@ struct WinRd {
     }
 };
 
+// The 16 bytes behind a frame's header in two registers: what every AcceptReply / Heartbeat / CommitNotice of a running
+// cluster fits into (slots, ballots and bars below 2^32 are varints of <= 5 bytes).  Decoding out of registers has no
+// window bounds to watch and no LDS round trip per varint; `n` counts the bytes taken and is compared with the frame's
+// length once, at the end (an overrun anywhere makes the frame malformed either way).
+struct Reg128 {
+    uint64_t lo, hi;
+    uint32_t n;
+    bool ok;
+    __device__ __forceinline__ void take(uint32_t k) {               // drop k <= 9 bytes
+        const uint32_t sft = 8 * k;
+        if (sft >= 64) { lo = hi >> (sft - 64); hi = 0; }
+        else { lo = (lo >> sft) | (hi << (64 - sft)); hi >>= sft; }
+        n += k;
+    }
+    __device__ __forceinline__ uint8_t byte() { const uint8_t b = (uint8_t)lo; take(1); return b; }
+    __device__ __forceinline__ uint64_t varint() {
+        const uint32_t b = (uint32_t)lo & 0xFF;
+        const uint32_t need = b < 251 ? 1 : (0x00953u >> (4 * (b - 251))) & 0xF;    // 0xFB -> 3, 0xFC -> 5, 0xFD -> 9, 0xFE / 0xFF -> 0
+        const uint64_t rest = (lo >> 8) | (hi << 56);
+        const uint64_t v = need == 1 ? b : need == 3 ? (rest & 0xFFFF) : need == 5 ? (rest & 0xFFFFFFFFull) : rest;
+        if (need == 0) { ok = false; n += 64; return 0; }                           // (n past any length: stays malformed)
+        take(need);
+        return v;
+    }
+};
+constexpr uint32_t WI_FAST_MAX = 16;             // payloads up to this long are decoded out of a Reg128
+
+// PeerMessage -> (kind, the hot variants' fields): smr_wire_decode's rules (csrc/wire.hip) for either reader
+template <typename Rd>
+__device__ __forceinline__ void parse_peer_message(Rd &r, uint32_t &kind, bool &hot, uint64_t &f0, uint64_t &f1, uint64_t &f2, uint64_t &f3) {
+    const uint64_t outer = r.varint();
+    if (outer == 2) kind = SMR_WIRE_LEAVE;                                          // PeerMessage::Leave
+    else if (outer == 0) {                                                          // PeerMessage::Msg { msg }
+        const uint64_t v = r.varint();
+        kind = (uint32_t)(v <= SMR_WIRE_COMMIT_NOTICE ? v : SMR_WIRE_OTHER);
+        if (v == SMR_WIRE_ACCEPT_REPLY) {
+            f0 = r.varint(); f1 = r.varint();                                       // slot, ballot
+            const uint8_t ts = r.byte();                                            // Option<SystemTime>
+            if (ts == 1) { r.varint(); r.varint(); } else if (ts != 0) r.ok = false;
+            hot = true;
+        } else if (v == SMR_WIRE_HEARTBEAT) {
+            f0 = r.varint(); f1 = r.varint(); f2 = r.varint(); f3 = r.varint();   // ballot, commit_bar, exec_bar, snap_bar
+            hot = true;
+        } else if (v == SMR_WIRE_COMMIT_NOTICE) {
+            f0 = r.varint(); f1 = r.varint();                                       // ballot, commit_bar
+            hot = true;
+        }
+    }
+}
+
+#ifndef SMR_WI_NT
+#define SMR_WI_NT 0                              // 1: records leave with non-temporal stores (A/B: tools/r2u_wi_loads.sh)
+#endif
+template <typename T> __device__ __forceinline__ void put_record(T *dst, const T &v) {
+    static_assert(sizeof(T) % 8 == 0, "records are whole 8-byte words");
+#if SMR_WI_NT
+    const uint64_t *p = (const uint64_t *)&v;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 8; i++) __builtin_nontemporal_store(p[i], (uint64_t *)dst + i);
+#else
+    *dst = v;
+#endif
+}
+
 struct IngestArgs {
     const uint8_t *buf; uint64_t buf_len;
     const uint64_t *conn_off; const uint32_t *conn_group; const uint8_t *conn_peer; uint32_t n_conn;
@@ -118,22 +182,42 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
         // touches the same 128-byte line from 8 instructions, 64 different lines per instruction)
         constexpr uint32_t CPW = WI_WIN / 16, PER = 64 / CPW;                       // lanes per connection; connections per instruction
         __syncthreads();                                                            // (one wavefront per block) every lane has left the old window
+        // every chunk's load is issued before the first one is waited for (a load inside `if (k < nc)` is waited for inside
+        // it: CPW memory round trips in a row per refill); a chunk that is not wanted, or not whole, reads the buffer's
+        // first 16 bytes instead
+        const uint32_t k = lane % CPW;
+        wi_u32x4 q[CPW];
+        uint32_t want = 0, ragged = 0;                                              // bit i: chunk i of my connection-of-the-round is wanted / is the buffer's ragged end
+        const bool can = A.buf_len >= 16;
 #pragma unroll
         for (uint32_t i = 0; i < CPW; i++) {
-            const uint32_t src = i * PER + lane / CPW, k = lane % CPW;
+            const uint32_t src = i * PER + lane / CPW;
             const uint64_t wb = __shfl(wbase, (int)src);
             const uint32_t nc = __shfl(nchunk, (int)src);
-            if (k < nc) {
-                const uint64_t off = wb + 16ull * k;
-                uint32_t v[4] = {0, 0, 0, 0};
-                if (off + 16 <= A.buf_len) {
-                    const wi_u32x4 q = *(const wi_u32x4 *)(A.buf + off);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-                    for (uint32_t b = 0; b < 16 && off + b < A.buf_len; b++) v[b >> 2] |= (uint32_t)A.buf[off + b] << (8 * (b & 3));
-                }
+            const uint64_t off = wb + 16ull * k;
+            const bool w = k < nc, whole = w && off + 16 <= A.buf_len;
+            want |= (uint32_t)w << i;
+            ragged |= (uint32_t)(w && !whole) << i;
+            q[i] = wi_u32x4{0, 0, 0, 0};
+            if (can) q[i] = *(const wi_u32x4 *)(A.buf + (whole ? off : 0));
+        }
+        if (__ballot(ragged != 0)) {                                                // (one wavefront of the whole grid, once: wave-uniform, the shuffles meet)
 #pragma unroll
-                for (uint32_t j = 0; j < 4; j++) win[(4 * k + j) * 64 + src] = v[j];
+            for (uint32_t i = 0; i < CPW; i++) {
+                const uint64_t off = __shfl(wbase, (int)(i * PER + lane / CPW)) + 16ull * k;
+                if ((ragged >> i) & 1) {
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    for (uint32_t b = 0; b < 16 && off + b < A.buf_len; b++) v[b >> 2] |= (uint32_t)A.buf[off + b] << (8 * (b & 3));
+                    q[i] = wi_u32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < CPW; i++) {
+            if ((want >> i) & 1) {
+                const uint32_t src = i * PER + lane / CPW;
+                win[(4 * k + 0) * 64 + src] = q[i].x; win[(4 * k + 1) * 64 + src] = q[i].y;
+                win[(4 * k + 2) * 64 + src] = q[i].z; win[(4 * k + 3) * 64 + src] = q[i].w;
             }
         }
         __syncthreads();
@@ -165,27 +249,24 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
             if (avail - 8 < plen) { done = true; break; }                           // frame not complete yet
             const uint32_t look = (uint32_t)(plen < WI_HOT_MAX ? plen : WI_HOT_MAX);
             if (woff + 8 + look > WI_WIN) break;                                    // (after a refill woff < 16: always fits)
-            r.end = woff + 8 + look;
-            const uint64_t outer = r.varint();
             uint32_t kind = SMR_WIRE_OTHER;
             bool hot = false;
             uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-            if (outer == 2) kind = SMR_WIRE_LEAVE;                                  // PeerMessage::Leave
-            else if (outer == 0) {                                                  // PeerMessage::Msg { msg }
-                const uint64_t v = r.varint();
-                kind = (uint32_t)(v <= SMR_WIRE_COMMIT_NOTICE ? v : SMR_WIRE_OTHER);
-                if (v == SMR_WIRE_ACCEPT_REPLY) {
-                    f0 = r.varint(); f1 = r.varint();                               // slot, ballot
-                    const uint8_t ts = r.byte();                                    // Option<SystemTime>
-                    if (ts == 1) { r.varint(); r.varint(); } else if (ts != 0) r.ok = false;
-                    hot = true;
-                } else if (v == SMR_WIRE_HEARTBEAT) {
-                    f0 = r.varint(); f1 = r.varint(); f2 = r.varint(); f3 = r.varint();   // ballot, commit_bar, exec_bar, snap_bar
-                    hot = true;
-                } else if (v == SMR_WIRE_COMMIT_NOTICE) {
-                    f0 = r.varint(); f1 = r.varint();                               // ballot, commit_bar
-                    hot = true;
-                }
+            if (plen <= WI_FAST_MAX) {                                              // the whole payload in two registers
+                const uint32_t p = woff + 8, i = p >> 2, sh = 8 * (p & 3);
+                uint32_t d[5];
+#pragma unroll
+                for (uint32_t j = 0; j < 5; j++) d[j] = col[(i + j < WI_DW + 1 ? i + j : WI_DW + 1) * 64];   // (bytes past the frame: any)
+                uint32_t w[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) w[j] = (uint32_t)((((uint64_t)d[j + 1] << 32) | d[j]) >> sh);
+                Reg128 q{((uint64_t)w[1] << 32) | w[0], ((uint64_t)w[3] << 32) | w[2], 0, true};
+                parse_peer_message(q, kind, hot, f0, f1, f2, f3);
+                r.ok = q.ok && q.n <= (uint32_t)plen;
+                r.n = p + q.n;
+            } else {
+                r.end = woff + 8 + look;
+                parse_peer_message(r, kind, hot, f0, f1, f2, f3);
             }
             // a frame whose leading varints do not parse, or a hot frame that does not end where its length says
             if (!r.ok || (hot && (uint64_t)(r.n - (woff + 8)) != plen)) { st = 1; done = true; break; }
@@ -196,14 +277,14 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                 const uint64_t at = base[what] + n[what];
                 if (what == 0 && at < A.ack_cap) {
                     smr_mp_ack a; a.group = group; a.slot = (uint32_t)f0; a.ballot = f1; a.peer = peer; a.reserved = 0;
-                    A.acks[at] = a;
+                    put_record(&A.acks[at], a);
                 } else if (what == 1 && at < A.hb_cap) {
                     smr_wire_hb h; h.group = group; h.peer = peer; h.kind = kind; h.reserved = 0; h.ballot = f0; h.commit_bar = f1;
                     h.exec_bar = f2; h.snap_bar = f3;
-                    A.hbs[at] = h;
+                    put_record(&A.hbs[at], h);
                 } else if (what == 2 && at < A.other_cap) {
                     smr_wire_other o; o.conn = c; o.kind = kind; o.off = pos; o.len = 8 + plen;
-                    A.others[at] = o;
+                    put_record(&A.others[at], o);
                 }
             }
             n[what]++;
@@ -231,15 +312,42 @@ __global__ __launch_bounds__(256) void wire_ingest_scan_kernel(uint64_t *__restr
     const uint32_t t = threadIdx.x, per = (n_waves + 255) / 256;
     const uint32_t lo = t * per < n_waves ? t * per : n_waves, hi = lo + per < n_waves ? lo + per : n_waves;
     uint64_t s[3] = {0, 0, 0};
-    for (uint32_t w = lo; w < hi; w++)
-        for (int k = 0; k < 3; k++) s[k] += wave_cnt[(size_t)w * 3 + k];
+    for (uint32_t w0 = lo; w0 < hi; w0 += 8) {                                      // eight rows' loads in flight together
+        uint64_t x[8][3];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) x[j][k] = wave_cnt[(size_t)(w0 + j < hi ? w0 + j : lo) * 3 + k];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) s[k] += w0 + j < hi ? x[j][k] : 0;
+    }
     for (int k = 0; k < 3; k++) part[k][t] = s[k];
     __syncthreads();
-    uint64_t b[3] = {0, 0, 0};
-    for (uint32_t q = 0; q < t; q++)
-        for (int k = 0; k < 3; k++) b[k] += part[k][q];
-    for (uint32_t w = lo; w < hi; w++)
-        for (int k = 0; k < 3; k++) { const uint64_t x = wave_cnt[(size_t)w * 3 + k]; wave_cnt[(size_t)w * 3 + k] = b[k]; b[k] += x; }
+    for (uint32_t off = 1; off < 256; off <<= 1) {                                  // inclusive scan of the 256 partial sums
+        uint64_t v[3] = {0, 0, 0};
+        if (t >= off) for (int k = 0; k < 3; k++) v[k] = part[k][t - off];
+        __syncthreads();
+        if (t >= off) for (int k = 0; k < 3; k++) part[k][t] += v[k];
+        __syncthreads();
+    }
+    uint64_t b[3];
+    for (int k = 0; k < 3; k++) b[k] = part[k][t] - s[k];                           // exclusive
+    for (uint32_t w0 = lo; w0 < hi; w0 += 8) {
+        uint64_t x[8][3];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) x[j][k] = wave_cnt[(size_t)(w0 + j < hi ? w0 + j : lo) * 3 + k];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            if (w0 + j < hi) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { wave_cnt[(size_t)(w0 + j) * 3 + k] = b[k]; b[k] += x[j][k]; }
+            }
+        }
+    }
     if (t == 255) for (int k = 0; k < 3; k++) counts[k] = b[k] ;
 }
 

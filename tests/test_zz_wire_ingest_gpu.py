@@ -101,7 +101,7 @@ def _random_streams(wire, rng, n_conn):
             f = wire.accept_reply(val(), val()) if rng.random() < 0.5 else wire.heartbeat(val(), val(), val(), val())
             s += f[:int(rng.integers(1, len(f)))]
         elif y < 0.33:                       # malformed frames of the kinds the device parses, then more bytes
-            z = int(rng.integers(0, 5))
+            z = int(rng.integers(0, 7))
             if z == 0:
                 s += struct.pack(">Q", 10**12 + 1) + b"\x00" * 20                       # invalidly large frame
             elif z == 1:
@@ -110,8 +110,11 @@ def _random_streams(wire, rng, n_conn):
                 s += _frame(_varint(0) + _varint(3) + _varint(5) + _varint(0x101) + b"\x00\x00")   # a byte too many
             elif z == 3:
                 s += _frame(_varint(0) + _varint(6) + _varint(5) + _varint(7))          # a Heartbeat two fields short
-            else:
+            elif z == 4:
                 s += _frame(b"")                                                        # an empty payload
+            else:                                                                       # fuzz: a hot kind's tag, then random bytes (the other
+                kind = [wire.ACCEPT_REPLY, wire.HEARTBEAT, wire.COMMIT_NOTICE][int(rng.integers(0, 3))]   # kinds are located, not validated)
+                s += _frame(_varint(0) + _varint(kind) + bytes(rng.integers(0, 256, int(rng.integers(0, 22)), dtype=np.uint8)))
             s += wire.accept_reply(1, 2)
         streams.append(bytes(s))
     return streams
