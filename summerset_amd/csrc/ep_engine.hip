@@ -702,6 +702,10 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 // The PreAcceptReplies to my instance (me, col[g]), applied in peer order exactly as one
 // handle_msg_pre_accept_reply call each (messages.rs:96-270) -- but on a register copy of the
 // instance and of its reply table: every input is loaded up front, the result is stored once.
+#ifndef EP_FLAT_LOADS
+#define EP_FLAT_LOADS 0                          // 1: every input row loaded unconditionally from clamped addresses -- measured SLOWER here
+                                                 // (25.2 vs 21.7 us per launch, profiles/r2w_ep_flat.log), unlike the tally's round 1
+#endif
 template <int NR>
 __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
                                                                     const uint64_t *__restrict__ ballot,
@@ -722,6 +726,58 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
         const size_t i = L.ix(row, c);
         // the incoming replies
         uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
+#if EP_FLAT_LOADS
+        // every row loaded unconditionally from a clamped (always valid) address and zeroed afterwards where it does not
+        // count: `on ? load : 0` compiles to one basic block per peer with a wait at its end -- NR memory round trips in a
+        // row, and the instance's words and its reply table behind them as further dependent rounds (the tally's round 1
+        // had the same shape)
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const uint32_t pp = (uint32_t)p < R ? (uint32_t)p : 0u;
+            const bool on = (uint32_t)p < R && (uint32_t)p != v.me;
+            const size_t o = (size_t)pp * v.G + g;
+            const uint32_t f_ = flags[o];
+            const uint64_t b_ = ballot[o], s_ = seq[o];
+            in_f[p] = on ? f_ : 0u; in_b[p] = on ? b_ : 0ull; in_s[p] = on ? s_ : 0ull;
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                const uint32_t kk = (uint32_t)k < R ? (uint32_t)k : 0u;
+                const uint32_t d_ = deps[((size_t)pp * R + kk) * v.G + g];
+                in_d[p][k] = (on && (uint32_t)k < R) ? d_ : EP_NONE;
+            }
+        }
+        // the instance (its ring cell exists whether or not the column is still held) ...
+        const uint32_t st_ = v.status[i], ak_ = v.pa_acks[i], bk_ = v.bk[i];
+        const uint64_t bal_ = v.bal[i];
+        uint32_t st = h ? st_ : 0u, acks = h ? ak_ : 0u;
+        const uint64_t b = h ? bal_ : 0ull;
+        const uint32_t bk = h ? bk_ : 0u;
+        const bool avoid = h && v.recovery && v.avoid[i];
+        const uint32_t before = st, acks0 = acks;
+        // ... and the replies it already holds: one block, entered only by an instance that holds any
+        uint64_t ps[NR]; uint32_t pd[NR][NR];
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            ps[p] = 0ull;
+#pragma unroll
+            for (int k = 0; k < NR; k++) pd[p][k] = EP_NONE;
+        }
+        if (acks) {
+#pragma unroll
+            for (int p = 0; p < NR; p++) {
+                const uint32_t pp = (uint32_t)p < R ? (uint32_t)p : 0u;
+                const bool on = (acks >> p) & 1u;
+                const uint64_t s_ = v.pa_seq[L.ps_ix(row, c, pp)];
+                ps[p] = on ? s_ : 0ull;
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    const uint32_t kk = (uint32_t)k < R ? (uint32_t)k : 0u;
+                    const uint32_t d_ = v.pa_deps[L.pd_ix(row, c, pp, kk)];
+                    pd[p][k] = (on && (uint32_t)k < R) ? d_ : EP_NONE;
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && (uint32_t)p != v.me;
@@ -744,6 +800,7 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
 #pragma unroll
             for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[L.pd_ix(row, c, p, k)] : EP_NONE;
         }
+#endif
         uint64_t dseq = 0; uint32_t dd[NR];
 #pragma unroll
         for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
