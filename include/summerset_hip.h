@@ -475,7 +475,7 @@ typedef struct {
     uint8_t execute;           /* 1: run attempt_execution (execution.rs:25-149) behind every handler call, see below */
     uint32_t window;           /* W: columns kept per row, power of two */
     uint32_t n_keys;           /* key space per group, 1..255 */
-    uint32_t recovery;         /* 1: explicit prepare (below); leader bookkeeping for every row.  Not together with execute */
+    uint32_t recovery;         /* 1: explicit prepare (below); leader bookkeeping for every row (may be combined with execute) */
 } smr_ep_cfg;
 
 int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out);
@@ -557,6 +557,33 @@ int smr_ep_handle_pre_accept_replies_at(smr_ep_replica *e, const uint8_t *row_de
                                         uint8_t *decision_dev, uint64_t *d_seq_dev, uint32_t *d_deps_dev, void *stream);
 int smr_ep_handle_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *ballot_dev,
                                     const uint8_t *flags_dev, const uint32_t *order_dev, uint8_t *committed_dev, void *stream);
+/* ---- one tick of a co-located EPaxos cluster as ONE call ------------------------------------------------------------
+ * The closed loop a host runs when all R replicas of its groups live on this device (BASELINE config 5 on one GPU; what
+ * summerset_amd/ep_cluster.py drives handler by handler): every replica r proposes keys_dev[r][g] (0xFF: nothing), the
+ * PreAccepts go to all peers (senders ascending at every acceptor), every command leader tallies its PreAcceptReplies
+ * (handle_msg_pre_accept_reply, epaxos/messages.rs:96-270), sends Accepts where it took the slow path (the round always
+ * runs, its flags zero elsewhere), tallies the AcceptReplies (:348-436) and sends CommitNotices -- leaders ascending.  The
+ * same kernels the per-handler entry points launch, back to back on `stream`, the peers' replies written straight into the
+ * leader's stacked reply arrays: no host work between them.  drop_dev (may be NULL): [R * R] pointers, entry s * R + q
+ * (may be NULL) = u8 [G], 1 where the PreAccept from s to q is lost (with its reply).  out[s], device arrays the caller
+ * owns: what leader s proposed (proposed = flags, col, seq0 / deps0 [R][G] = the PreAccept's) and decided (decision 0 /
+ * 2 Accepting / 3 Committed on the fast path, committed = 1 where the instance is committed after the tick, seq, deps
+ * [R][G] of the decision).  Replicas: created with me = index, population = n, equal groups; they stay the caller's. */
+typedef struct smr_ep_cluster smr_ep_cluster;
+typedef struct {
+    uint8_t *proposed;
+    uint32_t *col;
+    uint64_t *seq0;
+    uint32_t *deps0;
+    uint8_t *decision, *committed;
+    uint64_t *seq;
+    uint32_t *deps;
+} smr_ep_cluster_out;
+int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluster **out);
+void smr_ep_cluster_destroy(smr_ep_cluster *c);
+int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev, const smr_ep_cluster_out *out,
+                        void *stream);
+
 /* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with
  * an entry in exp_prepare_voteds (bitmap); those entries [R][W][R][G], deps [R][W][R][R][G]; counters[4] = decisions
  * Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op */

@@ -175,6 +175,10 @@ class WireCodeword(C.Structure):
                 ("data_len", C.c_uint64), ("shard_len", C.c_uint64), ("shard_off", C.c_uint64 * 16)]
 
 
+class EpClusterOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("proposed", "col", "seq0", "deps0", "decision", "committed", "seq", "deps")]
+
+
 class WireEpMsg(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("row", C.c_uint8), ("n_deps", C.c_uint32), ("col", C.c_uint64), ("ballot", C.c_uint64),
                 ("seq", C.c_uint64), ("reqs_off", C.c_uint64), ("reqs_len", C.c_uint64)]
@@ -263,6 +267,9 @@ SYMBOLS = [
     ("smr_ep_handle_exp_prepare", _i, [_vp, C.POINTER(EpExpPrepare), C.POINTER(EpExpPrepareReply), _vp]),
     ("smr_ep_handle_exp_prepare_replies", _i, [_vp, _vp, _vp, _vp, C.POINTER(EpExpPrepareReply)] + [_vp] * 7),
     ("smr_ep_xp_dump", _i, [_vp] + [_vp] * 9),
+    ("smr_ep_cluster_create", _i, [_vp, _u32, _vp]),
+    ("smr_ep_cluster_destroy", None, [_vp]),
+    ("smr_ep_cluster_tick", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),

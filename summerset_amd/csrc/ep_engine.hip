@@ -427,7 +427,7 @@ struct EpExecLane {
             uint64_t d = x.digest[g];
             d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
             x.digest[g] = d;
-            x.order[at(n_order++)] = (uint16_t)ring;
+            if (n_order < 2u * v.R * v.W) x.order[at(n_order++)] = (uint16_t)ring;   // (the list's capacity; beyond it a result would not come: never seen)
             c_exec++;
         }
         v.status[i] = EST_EXECUTING;
@@ -482,8 +482,12 @@ struct EpExecLane {
         x.exec_bars[(size_t)row * v.G + g] = eb;
     }
     // durability.rs:136-160 for the row whose commit bar moved
+    // (APPEND: a handler that runs several of the reference's inner handlers in one call -- heartbeat_timeout -- keeps the
+    // call's earlier submissions in `order`; each inner handler's results still come right behind it)
+    template <bool APPEND = false>
     __device__ __forceinline__ void advanced(uint32_t row, uint32_t cb) {
-        n_order = 0;
+        if (!APPEND) n_order = 0;
+        const uint32_t first = n_order;
         if (attempt(row, cb - 1)) {
             uint32_t re = 0;                                                     // rows to re-attempt, found before any of them runs
             for (uint32_t q = 0; q < v.R; q++) {
@@ -493,7 +497,17 @@ struct EpExecLane {
             for (uint32_t q = 0; q < v.R; q++)
                 if ((re >> q) & 1u) (void)attempt(q, v.commit_bars[(size_t)q * v.G + g] - 1);
         }
-        for (uint32_t i = 0; i < n_order; i++) cmd_result(x.order[at(i)]);
+        for (uint32_t i = first; i < n_order; i++) cmd_result(x.order[at(i)]);
+    }
+    // the attempts of handle_logged_commit_slot for whichever row's commit bar the inner handler just moved (at most one)
+    __device__ __forceinline__ void after_inner_handler() {
+        for (uint32_t row = 0; row < v.R; row++) {
+            const size_t o = (size_t)row * v.G + g;
+            const uint32_t cb = v.commit_bars[o];
+            if (cb == x.prev_cb[o]) continue;
+            x.prev_cb[o] = cb;
+            advanced<true>(row, cb);
+        }
     }
     __device__ __forceinline__ void flush() {
         unsigned int c[5] = {c_exec, c_reexec, c_unheld, c_attempts, c_aborts};
@@ -879,11 +893,17 @@ __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, 
 
 // ---- explicit prepare --------------------------------------------------------------------------------------------------
 // heartbeat.rs:17-125 for HearTimeout { peer = src[g] } (SMR_NO_REPLICA: none in this group)
-__global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView v, const uint8_t *__restrict__ src,
+// EXEC (smr_ep_cfg.execute with recovery): this one call runs SEVERAL inner handlers per group -- a PreAcceptReply per waiting
+// instance, then my own ExpPrepareReplies -- and each may move a commit bar, so the attempts and results the reference runs
+// behind each of them (durability.rs:136-160, LS-1 rule 0) run here, right behind each, in the reference's order; the
+// separate ep_execute_kernel (one moved bar per call) stays what every other handler uses
+template <bool EXEC>
+__global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView v, const EpExec x, const uint8_t *__restrict__ src,
                                                                    const uint8_t *__restrict__ exploded, uint32_t *__restrict__ out_n,
                                                                    uint32_t *__restrict__ out_col, uint64_t *__restrict__ out_bal) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
+    EpExecLane E(v, x, L, L.g);
     if (g < v.G) {
         const uint32_t ts = src[g], R = v.R;
         uint32_t n = 0;
@@ -898,7 +918,10 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
                 for (uint32_t c = v.commit_bars[(size_t)row * v.G + g]; c < end; c++) {
                     if (!L.held(row, c)) continue;
                     const size_t i = L.ix(row, c);
-                    if (v.status[i] == EST_PREACCEPTING && (v.bk[i] & 1)) L.pre_accept_reply(ts, row, c, 0, 0, none, ex);
+                    if (v.status[i] == EST_PREACCEPTING && (v.bk[i] & 1)) {
+                        L.pre_accept_reply(ts, row, c, 0, 0, none, ex);
+                        if (EXEC) E.after_inner_handler();
+                    }
                 }
             }
             // :62-107 ExpPrepare for every in-progress instance of that peer's row (exec bars: 0 without execution)
@@ -921,11 +944,14 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
 #pragma unroll
                 for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? v.deps[L.dx(row, c, q)] : EP_NONE;
                 L.exp_prepare_reply(v.me, row, c, out_bal[(size_t)k * v.G + g], v.bal[i], v.status[i], v.seq[i], d, v.key[i]);
+                if (EXEC) E.after_inner_handler();
             }
         }
         out_n[g] = n;
+        if (EXEC) x.n_sub[g] = E.n_order;
     }
     L.flush();
+    if (EXEC) E.flush();
 }
 
 // messages.rs:511-574: one ExpPrepare { slot = (row, col), new_ballot } from `peer` per group; the ExpPrepareReply back
@@ -1048,6 +1074,23 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
         ecarve(a, x.counters, SMR_CTR_WORDS, dry);
     }
 }
+// ---- the closed loop of a co-located cluster (smr_ep_cluster_*): the little flag arithmetic between the handlers ----------
+// out[g] = in[g] unless drop[g] (a lost message)
+__global__ __launch_bounds__(256) void ep_flags_drop_kernel(uint32_t G, const uint8_t *__restrict__ in, const uint8_t *__restrict__ drop,
+                                                            uint8_t *__restrict__ out) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G) out[g] = drop[g] ? 0 : in[g];
+}
+// out[g] = (a[g] == va) | (b != NULL && b[g] == vb)
+__global__ __launch_bounds__(256) void ep_flags_eq_kernel(uint32_t G, const uint8_t *__restrict__ a, uint8_t va, const uint8_t *__restrict__ b,
+                                                          uint8_t vb, uint8_t *__restrict__ out) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G) out[g] = (uint8_t)((a[g] == va) || (b && b[g] == vb));
+}
+__global__ __launch_bounds__(256) void ep_fill_kernel(uint32_t G, uint8_t *__restrict__ p8, uint8_t v8, uint64_t *__restrict__ p64, uint64_t v64) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g < G) { p8[g] = v8; p64[g] = v64; }
+}
 }  // namespace smr
 
 extern "C" {
@@ -1062,9 +1105,6 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     if (cfg->n_keys == 0 || cfg->n_keys > 255) return fail(SMR_ERR_ARG, "epaxos: n_keys must be in 1..255");
     if (cfg->execute > 1) return fail(SMR_ERR_ARG, "epaxos: execute must be 0 or 1");
     if (cfg->recovery > 1) return fail(SMR_ERR_ARG, "epaxos: recovery must be 0 or 1");
-    if (cfg->recovery && cfg->execute)
-        return fail(SMR_ERR_ARG, "epaxos: explicit prepare and dependency-graph execution are not built to run together (a HearTimeout "
-                                 "can move several commit bars in one call; the execution kernel follows one)");
     if (cfg->execute && (uint64_t)cfg->population * cfg->window > 32768)
         return fail(SMR_ERR_ARG, "epaxos: execution keeps 15-bit ring cell ids: population * window must be <= 32768");
     smr_ep_replica *e = new smr_ep_replica();
@@ -1193,7 +1233,10 @@ int smr_ep_heartbeat_timeout(smr_ep_replica *e, const uint8_t *src_dev, const ui
                              uint64_t *ballot_dev, void *stream) {
     if (!e || !src_dev || !n_dev || !col_dev || !ballot_dev) return fail(SMR_ERR_ARG, "epaxos: null argument");
     if (!e->cfg.recovery) return fail(SMR_ERR_STATE, "epaxos: created without recovery");
-    hipLaunchKernelGGL(ep_heartbeat_timeout_kernel, EP_GRID(e), e->v, src_dev, exploded_dev, n_dev, col_dev, ballot_dev);
+    if (e->cfg.execute)
+        hipLaunchKernelGGL(ep_heartbeat_timeout_kernel<true>, EP_GRID(e), e->v, e->x, src_dev, exploded_dev, n_dev, col_dev, ballot_dev);
+    else
+        hipLaunchKernelGGL(ep_heartbeat_timeout_kernel<false>, EP_GRID(e), e->v, e->x, src_dev, exploded_dev, n_dev, col_dev, ballot_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -1206,7 +1249,7 @@ int smr_ep_handle_exp_prepare(smr_ep_replica *e, const smr_ep_exp_prepare *m, co
     hipLaunchKernelGGL(ep_exp_prepare_kernel, EP_GRID(e), e->v, m->flags, m->peer, m->row, m->col, m->new_ballot, r->flags,
                        r->voted_bal, r->voted_status, r->voted_seq, r->voted_deps, r->voted_key);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ep_execute(e, stream);                 // (moves no commit bar: the call's submission list becomes empty)
 }
 
 int smr_ep_handle_exp_prepare_replies(smr_ep_replica *e, const uint8_t *row_dev, const uint32_t *col_dev, const uint64_t *new_ballot_dev,
@@ -1357,5 +1400,115 @@ int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host,
     if (group_host && row_host && col_host) SMR_HIP_TRY(hipMemset(e->x.n_sub, 0, G * 4));   // a count-only call leaves them
     return SMR_OK;
 }
+
+/* ---- one tick of a co-located EPaxos cluster as ONE call (summerset_amd/ep_cluster.py's closed loop, launch by launch) ---- */
+struct smr_ep_cluster {
+    uint32_t R = 0, G = 0;
+    smr_ep_replica *rep[SMR_MAX_REPLICAS] = {};
+    char *base = nullptr;
+    // per command leader s (all device): the PreAcceptReplies / AcceptReplies of its peers stacked by peer id, its flag arrays
+    uint8_t *r_flags[SMR_MAX_REPLICAS], *a_flags[SMR_MAX_REPLICAS], *slow[SMR_MAX_REPLICAS], *acc[SMR_MAX_REPLICAS], *peer_c[SMR_MAX_REPLICAS];
+    uint8_t *masked;                                         // the PreAccept's flags behind a drop mask
+    uint64_t *r_ballot[SMR_MAX_REPLICAS], *r_seq[SMR_MAX_REPLICAS], *a_ballot[SMR_MAX_REPLICAS], *bal_c[SMR_MAX_REPLICAS];
+    uint32_t *r_deps[SMR_MAX_REPLICAS];
+};
+
+int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluster **out) {
+    if (!reps || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
+    if (n < 3 || n > SMR_MAX_REPLICAS) return fail(SMR_ERR_ARG, "epaxos cluster: 3..8 replicas");
+    for (uint32_t r = 0; r < n; r++) {
+        if (!reps[r]) return fail(SMR_ERR_ARG, "epaxos cluster: null replica");
+        if (reps[r]->cfg.population != n || reps[r]->cfg.me != r || reps[r]->cfg.n_groups != reps[0]->cfg.n_groups)
+            return fail(SMR_ERR_ARG, "epaxos cluster: replica r must be created with me = r, population = n and the same groups");
+    }
+    smr_ep_cluster *c = new smr_ep_cluster();
+    c->R = n; c->G = reps[0]->cfg.n_groups;
+    for (uint32_t r = 0; r < n; r++) c->rep[r] = reps[r];
+    const size_t G = c->G, R = n;
+    // 8-byte arrays first; everything zero: a leader's own row of the stacks is never written and never read as a reply
+    const size_t per64 = (R * G) * 3 + G, per32 = R * R * G, per8 = (R * G) * 2 + G * 3;
+    const size_t bytes = R * (per64 * 8 + per32 * 4 + per8) + G + 4096;
+    if (hipMalloc((void **)&c->base, bytes) != hipSuccess) { delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMalloc failed"); }
+    if (hipMemset(c->base, 0, bytes) != hipSuccess) { (void)hipFree(c->base); delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMemset failed"); }
+    uint64_t *p64 = (uint64_t *)c->base;
+    for (uint32_t s = 0; s < R; s++) { c->r_ballot[s] = p64; p64 += R * G; c->r_seq[s] = p64; p64 += R * G; c->a_ballot[s] = p64; p64 += R * G; c->bal_c[s] = p64; p64 += G; }
+    uint32_t *p32 = (uint32_t *)p64;
+    for (uint32_t s = 0; s < R; s++) { c->r_deps[s] = p32; p32 += R * R * G; }
+    uint8_t *p8 = (uint8_t *)p32;
+    for (uint32_t s = 0; s < R; s++) { c->r_flags[s] = p8; p8 += R * G; c->a_flags[s] = p8; p8 += R * G; c->slow[s] = p8; p8 += G; c->acc[s] = p8; p8 += G; c->peer_c[s] = p8; p8 += G; }
+    c->masked = p8;
+    void *stream = nullptr;
+    for (uint32_t s = 0; s < R; s++)
+        hipLaunchKernelGGL(ep_fill_kernel, dim3((c->G + 255) / 256), dim3(256), 0, (hipStream_t)stream, c->G, c->peer_c[s], (uint8_t)s, c->bal_c[s],
+                           (uint64_t)(s + 1));
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(c->base); delete c;
+        return fail(SMR_ERR_DEVICE, "epaxos cluster: initialisation failed");
+    }
+    *out = c;
+    return SMR_OK;
+}
+
+void smr_ep_cluster_destroy(smr_ep_cluster *c) {
+    if (!c) return;
+    if (c->base) (void)hipFree(c->base);
+    delete c;
+}
+
+int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev, const smr_ep_cluster_out *out,
+                        void *stream) {
+    if (!c || !keys_dev || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
+    const uint32_t R = c->R, G = c->G;
+    for (uint32_t s = 0; s < R; s++)
+        if (!keys_dev[s] || !out[s].proposed || !out[s].col || !out[s].seq0 || !out[s].deps0 || !out[s].decision || !out[s].committed ||
+            !out[s].seq || !out[s].deps)
+            return fail(SMR_ERR_ARG, "epaxos cluster: null key or output array");
+    const dim3 grid((G + 255) / 256), block(256);
+    int rc;
+    // every replica proposes; the PreAccept it broadcasts lies in the caller's arrays
+    for (uint32_t s = 0; s < R; s++) {
+        smr_ep_msg pa{out[s].proposed, nullptr, out[s].col, nullptr, out[s].seq0, out[s].deps0, nullptr, nullptr};
+        if ((rc = smr_ep_propose(c->rep[s], keys_dev[s], nullptr, &pa, stream)) != SMR_OK) return rc;
+    }
+    // acceptors: one sender's PreAccept at a time, senders ascending; the reply goes straight into row q of the sender's stack
+    for (uint32_t q = 0; q < R; q++)
+        for (uint32_t s = 0; s < R; s++) {
+            if (s == q) continue;
+            uint8_t *fl = out[s].proposed;
+            const uint8_t *dm = drop_dev ? drop_dev[(size_t)s * R + q] : nullptr;
+            if (dm) {
+                hipLaunchKernelGGL(ep_flags_drop_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].proposed, dm, c->masked);
+                fl = c->masked;
+            }
+            smr_ep_msg m{fl, c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq0, out[s].deps0, (uint8_t *)keys_dev[s], nullptr};
+            smr_ep_msg r{c->r_flags[s] + (size_t)q * G, nullptr, nullptr, c->r_ballot[s] + (size_t)q * G, c->r_seq[s] + (size_t)q * G,
+                         c->r_deps[s] + (size_t)q * R * G, nullptr, nullptr};
+            if ((rc = smr_ep_handle_pre_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
+        }
+    // command leaders, ascending: decision; the Accept round (flags zero where the fast path was taken); CommitNotices
+    for (uint32_t s = 0; s < R; s++) {
+        if ((rc = smr_ep_handle_pre_accept_replies(c->rep[s], out[s].col, c->r_ballot[s], c->r_seq[s], c->r_deps[s], c->r_flags[s], nullptr,
+                                                   nullptr, out[s].decision, out[s].seq, out[s].deps, stream)) != SMR_OK) return rc;
+        hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)2, (const uint8_t *)nullptr,
+                           (uint8_t)0, c->slow[s]);
+        for (uint32_t q = 0; q < R; q++) {
+            if (q == s) continue;
+            smr_ep_msg m{c->slow[s], c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
+            smr_ep_msg r{c->a_flags[s] + (size_t)q * G, nullptr, nullptr, c->a_ballot[s] + (size_t)q * G, nullptr, nullptr, nullptr, nullptr};
+            if ((rc = smr_ep_handle_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
+        }
+        if ((rc = smr_ep_handle_accept_replies(c->rep[s], out[s].col, c->a_ballot[s], c->a_flags[s], nullptr, c->acc[s], stream)) != SMR_OK) return rc;
+        hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)3, c->acc[s], (uint8_t)1,
+                           out[s].committed);
+        for (uint32_t q = 0; q < R; q++) {
+            if (q == s) continue;
+            smr_ep_msg m{out[s].committed, c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
+            if ((rc = smr_ep_handle_commit_notice(c->rep[q], &m, stream)) != SMR_OK) return rc;
+        }
+    }
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
 
 }  // extern "C"

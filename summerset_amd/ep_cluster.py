@@ -62,3 +62,55 @@ def tick(reps, keys, drop=None, always_accept_round=False):
         out.append(dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec["decision"], committed=committed, seq=dec["seq"],
                         deps=dec["deps"]))
     return out
+
+
+class EPaxosCluster:
+    """The same closed loop as ONE C-ABI call per tick (`smr_ep_cluster_tick`, include/summerset_hip.h): the handler kernels
+    of all R replicas launched back to back by the library, the peers' replies written straight into each command leader's
+    stacked reply arrays -- no Python, no torch glue and no host read between them (the Accept round always runs).  `reps`
+    stay usable on their own (dump, exec_dump, the per-handler calls)."""
+
+    def __init__(self, reps):
+        import ctypes as C
+        from . import _lib
+        self.reps, self.R, self.G = list(reps), len(reps), reps[0].G
+        self._L = _lib.load()
+        arr = (C.c_void_p * self.R)(*[r._h for r in self.reps])
+        h = C.c_void_p()
+        _lib.check(self._L.smr_ep_cluster_create(arr, self.R, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_ep_cluster_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def tick(self, keys, drop=None, stream=None):
+        """keys[r]: uint8 [G] device tensor (0xFF = no proposal); drop[(s, q)] (optional): bool / uint8 [G], the PreAccept
+        from s to q is lost.  Returns per command leader dict(col, proposed, decision, committed, seq, deps) like `tick`."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        R, G, dev = self.R, self.G, keys[0].device
+        outs, held = (_lib.EpClusterOut * R)(), []
+        res = []
+        for s in range(R):
+            o = dict(proposed=torch.empty(G, dtype=torch.uint8, device=dev), col=torch.empty(G, dtype=torch.int32, device=dev),
+                     seq0=torch.empty(G, dtype=torch.int64, device=dev), deps0=torch.empty((R, G), dtype=torch.int32, device=dev),
+                     decision=torch.empty(G, dtype=torch.uint8, device=dev), committed=torch.empty(G, dtype=torch.uint8, device=dev),
+                     seq=torch.empty(G, dtype=torch.int64, device=dev), deps=torch.empty((R, G), dtype=torch.int32, device=dev))
+            for n, _ in _lib.EpClusterOut._fields_:
+                setattr(outs[s], n, o[n].data_ptr())
+            res.append(o)
+        kp = (C.c_void_p * R)(*[k.data_ptr() for k in keys])
+        dp = None
+        if drop:
+            masks = {k: (v if v.dtype == torch.uint8 else v.to(torch.uint8)).contiguous() for k, v in drop.items()}
+            held.append(masks)
+            dp = (C.c_void_p * (R * R))(*[(masks[(s, q)].data_ptr() if (s, q) in masks else None) for s in range(R) for q in range(R)])
+        _lib.check(self._L.smr_ep_cluster_tick(self._h, kp, dp, outs, _lib.stream_ptr(stream)))
+        return [dict(col=o["col"], proposed=o["proposed"], decision=o["decision"], committed=o["committed"], seq=o["seq"], deps=o["deps"])
+                for o in res]

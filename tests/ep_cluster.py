@@ -67,11 +67,13 @@ class NumpyEngine:
 
     def heartbeat_timeout(self, src, exploded=None):
         o = self.e.heartbeat_timeout(self._t(src), self._t(exploded))
+        self._after_call()
         return self._n(o, dict(n=np.uint32, col=np.uint32, ballot=np.uint64))
 
     def handle_exp_prepare(self, flags, peer, row, col, new_ballot):
         o = self.e.handle_msg_exp_prepare(dict(flags=self._t(flags), peer=self._t(peer), row=self._t(row), col=self._t(col),
                                                new_ballot=self._t(new_ballot)))
+        self._after_call()
         r = self._n(o, dict(flags=np.uint8, voted_bal=np.uint64, voted_status=np.uint8, voted_seq=np.uint64, voted_deps=np.uint32,
                             voted_key=np.uint8))
         return dict(flags=r["flags"], voted_bal=r["voted_bal"], status=r["voted_status"], seq=r["voted_seq"], deps=r["voted_deps"],
@@ -82,6 +84,7 @@ class NumpyEngine:
         rep = dict(flags=self._t(flags), voted_bal=self._t(voted_bal), voted_status=self._t(voted_status), voted_seq=self._t(voted_seq),
                    voted_deps=self._t(voted_deps), voted_key=self._t(voted_key))
         o = self.e.handle_msg_exp_prepare_reply(self._t(row), self._t(col), self._t(new_ballot), rep, self._t(order))
+        self._after_call()
         return self._n(o, dict(decision=np.uint8, ballot=np.uint64, seq=np.uint64, deps=np.uint32, key=np.uint8))
 
     def xp_dump(self):

@@ -272,13 +272,18 @@ def test_epaxos_explicit_prepare_kernels_on_the_host(sim, oracle):
             t.test_trace_on_the_engine("cpu", trace)
         t.test_crash_and_recovery_matches_the_oracle_cluster("cpu", oracle, 200, 0, 0.0)
         t.test_crash_and_recovery_matches_the_oracle_cluster("cpu", oracle, 130, 3, 0.2)
-        t.test_recovery_needs_the_flag_and_excludes_execution("cpu")
+        t.test_recovery_needs_the_flag("cpu")
+        import test_zzz_ep_recovery_exec_gpu as tx
+        tx.test_crash_and_recovery_with_execution_matches_the_oracle_cluster("cpu", oracle, 200, 1, 0.0)
+        tx.test_crash_and_recovery_with_execution_matches_the_oracle_cluster("cpu", oracle, 150, 5, 0.15)
 
 
 def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
     import test_zz_ep_cluster_gpu as t
     with sim.patched():
         t.test_device_cluster_tick_matches_the_oracle_cluster("cpu", oracle, 300, 6, 0.15)
+        assert t.run_fused_vs_driver("cpu", 200, 6, 0.15, T=6) > 0              # smr_ep_cluster_tick: the loop as one C call
+        t.run_fused_vs_driver("cpu", 130, 16, 0.0, T=5, execute=False)
 
 
 def test_spread_epaxos_exchange_on_the_host(sim):

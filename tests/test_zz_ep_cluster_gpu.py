@@ -37,3 +37,38 @@ def test_device_cluster_tick_matches_the_oracle_cluster(cuda, oracle, G, K, loss
         for n in xb:
             assert np.array_equal(xa[n], xb[n]), (r, "exec", n)
     assert fast > 0 and (slow > 0 or loss == 0.0)
+
+
+def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5):
+    """`smr_ep_cluster_tick` (one C call per tick) against the handler-by-handler driver on a second set of replicas"""
+    import torch
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster
+    R, W = 5, 32
+    a = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    b = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    fused = ep_cluster.EPaxosCluster(a)
+    rng = np.random.default_rng(seed + G)
+    dv = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    slow = 0
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q and rng.random() < 0.7} if loss else None
+        kd = [dv(keys[r]) for r in range(R)]
+        dd = None if drop is None else {k: dv(v) for k, v in drop.items()}
+        oa = fused.tick(kd, dd)
+        ob = ep_cluster.tick(b, kd, dd, always_accept_round=True)
+        for s in range(R):
+            for k in ob[s]:
+                assert np.array_equal(oa[s][k].cpu().numpy(), ob[s][k].cpu().numpy()), (t, s, k)
+            slow += int((ob[s]["decision"] == 2).sum())
+    for r in range(R):
+        x, y = a[r].dump(), b[r].dump()
+        for n in y:
+            assert np.array_equal(x[n], y[n]), (r, n)
+        if execute:
+            x, y = a[r].exec_dump(), b[r].exec_dump()
+            for n in y:
+                assert np.array_equal(x[n], y[n]), (r, "exec", n)
+    fused.close()
+    return slow

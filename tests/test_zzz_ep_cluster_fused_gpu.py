@@ -1,0 +1,15 @@
+"""`smr_ep_cluster_tick` -- one tick of a co-located EPaxos cluster as ONE C-ABI call -- on the device, against the
+handler-by-handler driver loop of summerset_amd/ep_cluster.py on a second set of replicas: every leader's outputs every
+tick, every replica's instances and execution state.  Sorted last: written when no device was at hand (verified on the
+emulator, tests/test_hostsim.py) -- a failure here must not keep the rest of the suite from running under `pytest -x`."""
+import pytest
+
+from test_zz_ep_cluster_gpu import run_fused_vs_driver
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("G,K,loss", [(700, 6, 0.15), (4096, 64, 0.0)])
+def test_fused_cluster_tick_is_the_driver_loop(cuda, G, K, loss):
+    slow = run_fused_vs_driver(cuda, G, K, loss)
+    assert slow > 0 or loss == 0.0
