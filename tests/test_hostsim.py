@@ -137,6 +137,11 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         t.test_ingest_matches_the_sequential_decoder("cpu")
         t.test_empty_and_overfull("cpu")
         t.test_accept_replies_over_the_wire("cpu", oracle)
+        import test_zzz_wire_ingest_edges_gpu as te                             # the laid-out edges: fast-path boundary, window ends, extremes
+        te.test_payload_lengths_around_the_register_fast_path("cpu")
+        te.test_frames_at_the_window_edges("cpu")
+        te.test_extreme_values_and_odd_encodings("cpu")
+        te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")
 
 
 def test_rs_kernels_on_the_host(sim, oracle):

@@ -1,0 +1,135 @@
+"""Edges of the device-side peer-traffic parser (csrc/wire_ingest.hip) that the random streams of
+tests/test_zz_wire_ingest_gpu.py only meet by chance, each laid out on purpose and compared with the sequential decoder
+`smr_wire_decode` frame by frame: payload lengths either side of the two-register fast path (<= 16 bytes), frames that
+end exactly at, one byte before and one byte behind the end of the lane's 128-byte window and its 16-byte refill
+alignment, every varint width at its extreme values (u64::MAX ballots, slots beyond u32 that go the host's way),
+non-canonical varints, varints that run off the frame, streams that end inside a header / inside a payload, a byte buffer
+whose length is not a multiple of 16, connections of very different lengths in one wavefront.
+Sorted last: written when no device was at hand (verified on the emulator, tests/test_hostsim.py) -- a failure here must
+not keep the rest of the suite from running under `pytest -x`."""
+import struct
+
+import numpy as np
+import pytest
+
+from test_zz_wire_ingest_gpu import _expected, _frame, _ingest, _varint
+
+pytestmark = pytest.mark.gpu
+U64 = (1 << 64) - 1
+
+
+def _fd(v):
+    """a value in the widest encoding whatever its size (the host decoder takes any width: so must the device)"""
+    return b"\xfd" + struct.pack("<Q", v)
+
+
+def _fc(v):
+    return b"\xfc" + struct.pack("<I", v)
+
+
+def _ar(slot, ballot, ts=b"\x00"):
+    return _frame(_varint(0) + _varint(3) + slot + ballot + ts)
+
+
+def _check(wire, cuda, streams, seed=0):
+    from summerset_amd.multipaxos import ACK_DTYPE
+    rng = np.random.default_rng(seed)
+    n = len(streams)
+    groups, peers = rng.integers(0, 1 << 20, n), rng.integers(0, 5, n)
+    acks, hbs, others, consumed, status = _expected(wire, ACK_DTYPE, streams, groups, peers)
+    got = _ingest(wire, cuda, streams, groups, peers)
+    assert (got["n_acks"], got["n_hbs"], got["n_others"], got["n_malformed"]) == (len(acks), len(hbs), len(others), int(status.sum()))
+    assert np.array_equal(got["consumed"], consumed) and np.array_equal(got["status"], status)
+    assert np.array_equal(got["acks"], acks) and np.array_equal(got["hbs"], hbs) and np.array_equal(got["others"], others)
+    return len(acks), len(hbs), len(others), int(status.sum())
+
+
+def test_payload_lengths_around_the_register_fast_path(cuda):
+    """AcceptReplies and Heartbeats whose payload is 3 .. 40 bytes long through every mix of varint widths (the parser decodes
+    payloads of <= 16 bytes out of two registers, longer ones through the window reader); the same frames with one byte too
+    many / one too few declared"""
+    from summerset_amd import wire
+    widths = [lambda v: _varint(v % 251), lambda v: b"\xfb" + struct.pack("<H", v & 0xFFFF), lambda v: _fc(v & 0xFFFFFFFF), _fd]
+    streams, lens = [], set()
+    for a in range(4):
+        for b in range(4):
+            for ts in (b"\x00", b"\x01" + _varint(1790000000) + _varint(999999999), b"\x01" + _fd(5) + _fc(7)):
+                body = _varint(0) + _varint(3) + widths[a](77 + a) + widths[b](0x101 + b) + ts
+                lens.add(len(body))
+                s = _frame(body) + wire.accept_reply(1, 2)
+                streams.append(s)
+                streams.append(struct.pack(">Q", len(body) + 1) + body + wire.accept_reply(1, 2))      # declared one byte longer: malformed
+                streams.append(struct.pack(">Q", len(body) - 1) + body + wire.accept_reply(1, 2))      # one shorter: malformed
+    for a in range(4):
+        for b in range(4):
+            body = _varint(0) + _varint(wire.HEARTBEAT) + widths[a](3) + widths[b](40000) + widths[(a + b) % 4](9) + widths[(a * b) % 4](1)
+            lens.add(len(body))
+            streams.append(_frame(body) + wire.commit_notice(5, 6))
+    assert {15, 16, 17} <= lens and min(lens) <= 6 and max(lens) >= 30
+    na, nh, no, nm = _check(wire, cuda, streams)
+    assert nm == 2 * 48 and na >= 48 and nh >= 16
+
+
+def test_frames_at_the_window_edges(cuda):
+    """a lane walks its stream through a 128-byte window refilled at a 16-byte-aligned position: a filler frame of every
+    length 0 .. 150 in front of hot frames puts their headers and payloads at every offset of the window, across its end and
+    across refills; the stream of each connection starts at an arbitrary offset of the byte buffer"""
+    from summerset_amd import wire
+    streams = []
+    for pad in range(0, 151):
+        filler = _frame(_varint(1) + bytes((pad * 7 + i) & 0xFF for i in range(pad)))                 # lease traffic: located, not parsed
+        s = filler + wire.accept_reply(pad, 0x101) + wire.heartbeat(0x201, pad, 2, 1) + _ar(_fd(pad), _fd(U64)) + wire.commit_notice(9, pad)
+        streams.append(s + wire.accept_reply(65535, 70000) * 9)
+    na, nh, no, nm = _check(wire, cuda, streams, seed=1)
+    assert nm == 0 and na == 151 * 11 and nh == 151 * 2 and no == 151
+
+
+def test_extreme_values_and_odd_encodings(cuda):
+    from summerset_amd import wire
+    ok = [
+        _ar(_fd(U64), _fd(U64)),                                  # a slot the engine cannot name: the host's (others)
+        _ar(_fd((1 << 32)), _varint(1)),                          # first slot beyond u32
+        _ar(_fd((1 << 32) - 1), _fd(U64)),                        # last slot the engine names, the largest ballot
+        _ar(_fc(0), _fd(0)),                                      # zero in wide encodings
+        _frame(_varint(0) + _varint(wire.HEARTBEAT) + _fd(U64) * 4),
+        _frame(_varint(0) + _varint(wire.COMMIT_NOTICE) + _fd(U64) + _fc(0xFFFFFFFF)),
+        _frame(_varint(2)),                                       # PeerMessage::Leave
+        _frame(_fd(0) + _fd(3) + _varint(4) + _varint(5) + b"\x00"),   # the enum tags themselves in the widest encoding
+    ]
+    bad = [
+        _frame(_varint(0) + _varint(3) + b"\xfe" + bytes(16) + _varint(1) + b"\x00"),                 # a u128 varint: not on this path
+        _frame(_varint(0) + _varint(3) + b"\xff" + _varint(1) + b"\x00"),
+        _frame(_varint(0) + _varint(3) + b"\xfd" + bytes(5)),                                         # a varint that runs off the frame
+        _frame(_varint(0) + _varint(3) + _varint(1) + b"\xfb\x01"),
+        _frame(_varint(0) + _varint(wire.HEARTBEAT) + _varint(1) + _varint(2) + _varint(3)),          # a field short
+        _frame(_varint(0) + _varint(wire.COMMIT_NOTICE) + _varint(1) + _varint(2) + _varint(3)),      # a field too many
+        _frame(_varint(0)),                                                                           # Msg without a variant
+        struct.pack(">Q", 10 ** 12 + 1),
+    ]
+    tail = wire.accept_reply(3, 4)
+    streams = [f + tail for f in ok] + [tail + f + tail for f in bad] + [b"".join(ok) + bad[0] + tail]
+    # incomplete ends: every prefix of a frame behind a whole one
+    for f in (wire.accept_reply(70000, 1 << 40), wire.heartbeat(1, 2, 3, 4)):
+        streams += [tail + f[:k] for k in range(0, len(f))]
+    na, nh, no, nm = _check(wire, cuda, streams, seed=2)
+    assert nm == len(bad) + 1 and no >= 3
+
+
+def test_ragged_wavefront_and_unaligned_buffer_end(cuda):
+    """64 connections of one wavefront between 0 bytes and several windows long; the byte buffer ends 1 .. 15 bytes past a
+    multiple of 16 with the last connection's last frame in those bytes"""
+    from summerset_amd import wire
+    rng = np.random.default_rng(3)
+    for extra in (1, 7, 15):
+        streams = []
+        for c in range(64):
+            n = int(rng.integers(0, 60)) if c % 5 else 0
+            streams.append(b"".join(wire.accept_reply(int(rng.integers(0, 1 << 20)), 0x101) if rng.random() < 0.8 else
+                                    wire.heartbeat(0x101, int(rng.integers(0, 300)), 0, 0) for _ in range(n)))
+        total = sum(len(s) for s in streams)
+        pad = (extra - total) % 16
+        streams[-1] += _frame(_varint(1) + bytes(pad + 16 - 9)) if pad + 16 - 9 >= 0 else b""
+        streams[-1] += wire.accept_reply(4242, 0x101)
+        total = sum(len(s) for s in streams)
+        na, nh, no, nm = _check(wire, cuda, streams, seed=4)
+        assert nm == 0 and na > 1000
