@@ -101,7 +101,7 @@ class SpreadEPaxos:
             roff[m[2:]] = off
             off += self._msg_bytes(kind, m[2])
             out_split[m[0]] += self._msg_bytes(kind, m[2])
-        return dict(kind=kind, send=[m[2:] for m in send], soff=soff, roff=roff, in_split=in_split, out_split=out_split, n_send=n_send,
+        return dict(kind=kind, send=[m[2:] for m in send], soff=soff, roff=roff, in_split=in_split, out_split=out_split, n_send=n_send, n_recv=off,
                     sbuf=torch.zeros(max(n_send, 8), dtype=torch.uint8, device=self.device),
                     rbuf=torch.zeros(max(off, 8), dtype=torch.uint8, device=self.device),
                     pad={n: torch.zeros(n, dtype=torch.uint8, device=self.device) for n in range(1, 8)})
@@ -129,8 +129,9 @@ class SpreadEPaxos:
 
     def _collective(self, plan):
         import torch.distributed as dist
-        if self.world > 1:
-            dist.all_to_all_single(plan["rbuf"], plan["sbuf"], output_split_sizes=plan["out_split"], input_split_sizes=plan["in_split"])
+        if self.world > 1:                                     # (the buffers are never empty tensors; the collective sees exactly the planned bytes)
+            dist.all_to_all_single(plan["rbuf"][:plan["n_recv"]], plan["sbuf"][:plan["n_send"]], output_split_sizes=plan["out_split"],
+                                   input_split_sizes=plan["in_split"])
 
     def _get(self, plan, key):
         """the message (block, from, to) as tensors: views of the receive buffer, or the sender's own tensors"""

@@ -158,7 +158,9 @@ class SpreadMultiPaxos:
             if self.peers is not None:                         # all ranks of the job in THIS process (tests, one device)
                 _copy_between(self.peers, phase)
             else:
-                dist.all_to_all_single(p["rbuf"], p["sbuf"], output_split_sizes=p["out_split"], input_split_sizes=p["in_split"])
+                # (the buffers are padded to a minimum size: the collective sees exactly the planned bytes)
+                dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
+                                       input_split_sizes=p["in_split"])
         self._unpack(phase, stream)
 
     # ---- the tick ---------------------------------------------------------------------------------------------------
