@@ -48,6 +48,10 @@ def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5):
     a = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
     b = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
     fused = ep_cluster.EPaxosCluster(a)
+    from summerset_amd import SummersetError
+    for wrong in (a[::-1], a[:2], a[:4] + [b[0]]):               # replica r must sit at index r, all of them, of one population
+        with pytest.raises(SummersetError):
+            ep_cluster.EPaxosCluster(wrong)
     rng = np.random.default_rng(seed + G)
     dv = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     slow = 0
