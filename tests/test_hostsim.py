@@ -303,3 +303,18 @@ def test_spread_epaxos_exchange_on_the_host(sim):
         assert job.ranks[0].exchanges_per_tick() == 17
         assert t.run_spread_vs_colocated("cpu", G=70, world=1, n_ticks=4, loss=0.1).ranks[0].bytes_sent == 0   # one rank: nothing leaves it
         t.run_spread_vs_colocated("cpu", G=60, world=2, n_ticks=4, loss=0.1, R=3, K=4)                         # three replicas
+
+
+def test_cxx_epaxos_host_loop_on_the_host(sim, tmp_path):
+    """examples/ep_host_loop.cpp (the one-call EPaxos cluster tick from C++) compiled for the host against the emulator build
+    of the library: everything proposed commits and executes, the replicas' KV stores agree"""
+    import os
+    import subprocess
+    import test_zzz_example_ep_gpu as t
+    lib = sim.build()
+    exe = str(tmp_path / "ep_host_loop_sim")
+    here = os.path.dirname(os.path.abspath(sim.__file__))
+    subprocess.check_call([sim.CXX, "-std=c++17", "-O1", "-w", "-DEP_HOST_LOOP_ON_THE_EMULATOR", "-DhipStreamCreate(s)=hipStreamCreateWithFlags(s,0)",
+                           "-I", here, "-I", os.path.join(t.ROOT, "include"), os.path.join(t.ROOT, "examples", "ep_host_loop.cpp"),
+                           lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    t.check_output(subprocess.check_output([exe, "96", "6"], timeout=300).decode(), 96, 6)
