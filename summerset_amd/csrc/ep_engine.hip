@@ -1037,6 +1037,7 @@ struct smr_ep_replica {
     EpView v;
     EpExec x;
     Arena arena;
+    bool skip_exec = false;      // smr_ep_cluster_tick around the handlers that cannot move a commit bar (see there)
 };
 
 namespace smr {
@@ -1144,7 +1145,7 @@ void smr_ep_replica_destroy(smr_ep_replica *e) {
 
 // the attempts of handle_logged_commit_slot for whatever the kernel just launched committed
 static int ep_execute(smr_ep_replica *e, void *stream) {
-    if (!e->cfg.execute) return SMR_OK;
+    if (!e->cfg.execute || e->skip_exec) return SMR_OK;
     hipLaunchKernelGGL(ep_execute_kernel, EP_GRID(e), e->v, e->x);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
@@ -1465,9 +1466,20 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
             return fail(SMR_ERR_ARG, "epaxos cluster: null key or output array");
     const dim3 grid((G + 255) / 256), block(256);
     int rc;
+    // With execution on every handler is followed by the execution kernel, which does something only where a commit bar
+    // moved.  A proposal (the leader's own reply alone is below any quorum) and an acceptor's PreAccept / Accept handling
+    // (no commit; its leader-bookkeeping branch exists only under explicit prepare) move none, so the 45 launches behind
+    // them are left out -- unless the replica was created with recovery.  (smr_ep_exec_poll then reports the tick's last
+    // handler, a CommitNotice, as before.)
+    struct NoExec {
+        smr_ep_replica *e;
+        explicit NoExec(smr_ep_replica *e_) : e(e_) { e->skip_exec = !e->cfg.recovery; }
+        ~NoExec() { e->skip_exec = false; }
+    };
     // every replica proposes; the PreAccept it broadcasts lies in the caller's arrays
     for (uint32_t s = 0; s < R; s++) {
         smr_ep_msg pa{out[s].proposed, nullptr, out[s].col, nullptr, out[s].seq0, out[s].deps0, nullptr, nullptr};
+        NoExec ne(c->rep[s]);
         if ((rc = smr_ep_propose(c->rep[s], keys_dev[s], nullptr, &pa, stream)) != SMR_OK) return rc;
     }
     // acceptors: one sender's PreAccept at a time, senders ascending; the reply goes straight into row q of the sender's stack
@@ -1483,6 +1495,7 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
             smr_ep_msg m{fl, c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq0, out[s].deps0, (uint8_t *)keys_dev[s], nullptr};
             smr_ep_msg r{c->r_flags[s] + (size_t)q * G, nullptr, nullptr, c->r_ballot[s] + (size_t)q * G, c->r_seq[s] + (size_t)q * G,
                          c->r_deps[s] + (size_t)q * R * G, nullptr, nullptr};
+            NoExec ne(c->rep[q]);
             if ((rc = smr_ep_handle_pre_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
         }
     // command leaders, ascending: decision; the Accept round (flags zero where the fast path was taken); CommitNotices
@@ -1495,6 +1508,7 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
             if (q == s) continue;
             smr_ep_msg m{c->slow[s], c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
             smr_ep_msg r{c->a_flags[s] + (size_t)q * G, nullptr, nullptr, c->a_ballot[s] + (size_t)q * G, nullptr, nullptr, nullptr, nullptr};
+            NoExec ne(c->rep[q]);
             if ((rc = smr_ep_handle_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
         }
         if ((rc = smr_ep_handle_accept_replies(c->rep[s], out[s].col, c->a_ballot[s], c->a_flags[s], nullptr, c->acc[s], stream)) != SMR_OK) return rc;
