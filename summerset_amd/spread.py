@@ -158,6 +158,62 @@ def read_quorum_step(replicas, rank, world, issuer, q, keys, n, logs, flags, ord
     return (res[:B * G].reshape(B, G).copy(), res[B * G:5 * B * G].view(np.uint32).reshape(B, G).copy(), res[5 * B * G:].copy())
 
 
+def read_quorum_step_device(replicas, rank, world, issuer, q, keys, n, logs, flags, order=None, stable=None, kv=None):
+    """`read_quorum_step` device-resident, for `QuorumReadGroup` objects: every argument a device tensor (keys uint8 [B, G],
+    n uint8 [G], flags uint8 [R, G], order int32 [G], stable uint8 [G], kv int32 [K, G]; logs[r] as
+    `handle_msg_read_query` takes it), every intermediate one too.  The replies of this rank's replicas are byte-viewed
+    into ONE send tensor (val, slot int32 [B, G], state uint8 [B, G], from_leader uint8 [G] per replica, padded to 8
+    bytes), ONE all_gather on device tensors gives every rank all of them, the [R, B, G] arrays the tally kernel takes are
+    views of the gathered buffer restacked by replica id, the issuer's rank tallies, ONE broadcast of (out_val int32, outcome
+    uint8 [B, G], done uint8 [G]) returns the clients' answers -- no `.cpu()`, no numpy.  Returns (outcome, out_val, done)
+    as device tensors on every rank."""
+    import torch
+    import torch.distributed as dist
+    R = len(replicas)
+    mine = [r for r in range(R) if owner_of(r, world) == rank]
+    B, G = keys.shape
+    dev = keys.device
+    per = (9 * B * G + G + 7) & ~7                                 # bytes of one replica's packed reply
+    slots = (R + world - 1) // world                               # replicas per rank, padded
+    pad = torch.zeros(per - 9 * B * G - G, dtype=torch.uint8, device=dev)
+    parts, own = [], None
+    for r in mine:
+        st = stable if (stable is not None and r != issuer) else None
+        out, fl = replicas[r].handle_msg_read_query(keys, n, logs[r], st, kv if st is not None else None)
+        if r == issuer:
+            own = out
+        parts += [out["val"].contiguous().view(torch.uint8).reshape(-1), out["slot"].contiguous().view(torch.uint8).reshape(-1),
+                  out["state"].reshape(-1), fl, pad]
+    if len(mine) < slots:
+        parts.append(torch.zeros((slots - len(mine)) * per, dtype=torch.uint8, device=dev))
+    send = torch.cat(parts)
+    big = torch.empty(world * slots * per, dtype=torch.uint8, device=dev)
+    if world > 1:
+        dist.all_gather(list(big.view(world, slots * per).unbind(0)), send)
+    else:
+        big.copy_(send)
+
+    def field(r, off, nbytes, dt, shape):                          # replica r's field: a view of the gathered buffer
+        o = (owner_of(r, world) * slots + r // world) * per + off
+        return big[o:o + nbytes].view(dt).reshape(shape)
+    rep = dict(val=torch.stack([field(r, 0, 4 * B * G, torch.int32, (B, G)) for r in range(R)]),
+               slot=torch.stack([field(r, 4 * B * G, 4 * B * G, torch.int32, (B, G)) for r in range(R)]),
+               state=torch.stack([field(r, 8 * B * G, B * G, torch.uint8, (B, G)) for r in range(R)]))
+    from_leader = torch.stack([field(r, 9 * B * G, G, torch.uint8, (G,)) for r in range(R)])
+    res = torch.zeros((5 * B * G + G + 7) & ~7, dtype=torch.uint8, device=dev)
+    if owner_of(issuer, world) == rank:
+        replicas[issuer].issue(q, n, own)
+        got = flags & 1
+        fl = (got | ((from_leader << 1) * got)).to(torch.uint8)
+        fl[issuer] = 0
+        outcome, out_val, done = replicas[issuer].handle_msg_read_query_reply(q, rep, fl.contiguous(), order)
+        res = torch.cat([out_val.contiguous().view(torch.uint8).reshape(-1), outcome.reshape(-1), done,
+                         torch.zeros(res.numel() - 5 * B * G - G, dtype=torch.uint8, device=dev)])
+    if world > 1:
+        dist.broadcast(res, src=owner_of(issuer, world))
+    return (res[4 * B * G:5 * B * G].reshape(B, G), res[:4 * B * G].view(torch.int32).reshape(B, G), res[5 * B * G:5 * B * G + G])
+
+
 # ---- MultiPaxos cluster engine: the AcceptReply exchange of L2 (multipaxos.MultiPaxosCluster.collect_acks / deliver_acks) ----
 def split_acks_by_owner(rec, total_groups, world):
     """ACK_DTYPE records with GLOBAL group ids -> one array per rank, by the rank that owns the group's leader-side state
