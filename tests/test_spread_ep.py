@@ -2,7 +2,7 @@
 (summerset_amd/spread_ep.py): replica r of block b on rank (b + r) mod world, five exchanges per tick (2 + 3 R in the
 ordered schedule), each one all_to_all_single on device tensors -- against the co-located closed loop of
 summerset_amd/ep_cluster.py on the same keys and losses: every command leader's decisions of every tick and every
-replica's full state.  All ranks of the job in one process here (on the device: tests/test_zzz_spread_ep_gpu.py; on the emulator
+replica's full state.  All ranks of the job in one process here (on the device: tests/test_zzy_spread_ep_gpu.py; on the emulator
 build: tests/test_hostsim.py); tests/test_spread_ep_gloo.py is the two-process job."""
 import numpy as np
 import pytest

@@ -1,6 +1,6 @@
 """Spread layout (L2) of the EPaxos cluster on the device: all ranks of the job in one process on cuda:0, the collective a
 device copy -- summerset_amd/spread_ep.py against the co-located closed loop (tests/test_spread_ep.py holds the
-comparison).  Sorted last: written without a device at hand, a failure here must not keep the rest of the suite from
+comparison).  Sorted behind the rest (first device run: profiles/r2q), before the files that have not run on a device yet; a failure here must not keep the rest of the suite from
 running under `pytest -x`."""
 import pytest
 
