@@ -136,3 +136,58 @@ def test_batch_matches_single(oracle):
     par = oracle.rs_encode_batch(3, 2, data, L, stride, n).reshape(n, 2, -1)
     for i in range(n):
         assert np.array_equal(par[i], oracle.rs_encode(3, 2, data[i * stride:i * stride + L]))
+
+
+def test_coding_matrix_against_an_independent_restatement(oracle):
+    """The crate's (and Backblaze's / klauspost's) published construction, restated a second time from scratch in plain
+    Python -- GF(2^8) by shift-and-reduce over the polynomial 0x11D (no tables shared with the oracle), the (d + p) x d
+    Vandermonde matrix V[r][c] = r^c, times the inverse of its top d x d square (Gauss-Jordan) -- must give the C oracle's
+    coding matrix for every scheme the reference's protocols can be configured with and the upstream test shapes:
+    systematic on top, the same parity rows below.  (Two restatements of one published algorithm agreeing is not the crate's
+    binary agreeing: DESIGN.md §5 keeps saying so.)"""
+    def mul(a, b):
+        r = 0
+        while b:
+            if b & 1:
+                r ^= a
+            a <<= 1
+            if a & 0x100:
+                a ^= 0x11D
+            b >>= 1
+        return r
+
+    def power(a, n):
+        r = 1
+        for _ in range(n):
+            r = mul(r, a)
+        return r
+
+    def inv(a):
+        return next(x for x in range(1, 256) if mul(a, x) == 1)
+
+    def invert(m):
+        n = len(m)
+        a = [row[:] + [int(i == j) for j in range(n)] for i, row in enumerate(m)]
+        for c in range(n):
+            p = next(r for r in range(c, n) if a[r][c])
+            a[c], a[p] = a[p], a[c]
+            s = inv(a[c][c])
+            a[c] = [mul(x, s) for x in a[c]]
+            for r in range(n):
+                if r != c and a[r][c]:
+                    f = a[r][c]
+                    a[r] = [x ^ mul(f, y) for x, y in zip(a[r], a[c])]
+        return [row[n:] for row in a]
+
+    for d, p in [(3, 2), (2, 1), (4, 2), (5, 5), (6, 4), (10, 4), (12, 8), (17, 3)]:
+        v = [[power(r, c) for c in range(d)] for r in range(d + p)]
+        top = invert(v[:d])
+        want = [[0] * d for _ in range(d + p)]
+        for r in range(d + p):
+            for c in range(d):
+                acc = 0
+                for k in range(d):
+                    acc ^= mul(v[r][k], top[k][c])
+                want[r][c] = acc
+        assert oracle.rs_matrix(d, p).tolist() == want, (d, p)
+        assert want[:d] == [[int(i == j) for j in range(d)] for i in range(d)]
