@@ -8,10 +8,10 @@ mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 2>&1 | tail -60 > gpurun_out/${TAG}_gputests.log
 tail -3 gpurun_out/${TAG}_gputests.log
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench.json; echo
-python - <<'P'
-import json
+TAG=$TAG python - <<'P'
+import json, os
 try:
-    d = json.loads(open("gpurun_out/%s_bench.json" % "${TAG}").read().strip().splitlines()[-1])
+    d = json.loads(open("gpurun_out/%s_bench.json" % os.environ["TAG"]).read().strip().splitlines()[-1])
     print("value", d["value"], "ms/tick", d["ms_per_step"], "tally frac", d["roofline"]["frac"], "legs_failed", d.get("legs_failed"))
     print("epaxos_cluster", {k: d["epaxos_cluster"].get(k) for k in ("value", "ms_per_tick", "one_call_per_tick")})
     print("wire_ingest", d.get("wire_ingest", {}).get("call_us"), d.get("wire_ingest", {}).get("roofline", {}).get("frac"))
