@@ -39,12 +39,11 @@ def test_device_cluster_tick_matches_the_oracle_cluster(cuda, oracle, G, K, loss
     assert fast > 0 and (slow > 0 or loss == 0.0)
 
 
-def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5):
+def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32):
     """`smr_ep_cluster_tick` (one C call per tick) against the handler-by-handler driver on a second set of replicas"""
     import torch
     import ep_cluster as ec
     from summerset_amd import EPaxosReplicaGroup, ep_cluster
-    R, W = 5, 32
     a = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
     b = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
     fused = ep_cluster.EPaxosCluster(a)

@@ -13,3 +13,8 @@ pytestmark = pytest.mark.gpu
 def test_fused_cluster_tick_is_the_driver_loop(cuda, G, K, loss):
     slow = run_fused_vs_driver(cuda, G, K, loss)
     assert slow > 0 or loss == 0.0
+
+
+def test_fused_cluster_tick_other_populations(cuda):
+    assert run_fused_vs_driver(cuda, 900, 4, 0.15, T=6, R=3, W=16) > 0
+    assert run_fused_vs_driver(cuda, 700, 6, 0.15, T=6, R=7, W=16) > 0
