@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--timeouts", type=float, default=0.01)
     ap.add_argument("--timeout-span", type=int, default=None, help="draw the groups' timeout ticks from [0, N).  Default: max(steps + warmup, "
                     "%d) -- the leader-timeout RATE per tick is the workload's, not the run length's: a run shorter than the default "
-                    "%d ticks sees the same changes per tick as the default run (SURVEY 8(d) spreads its 1 %% over 1024 ticks)" % (TIMEOUT_HORIZON, TIMEOUT_HORIZON))
+                    "%d ticks sees the same changes per tick as the default run (SURVEY 8(d) spreads its 1 %%%% over 1024 ticks)" % (TIMEOUT_HORIZON, TIMEOUT_HORIZON))
     ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the straggler list (0 = no list); 4 "
                     "measured best with --batch 8 (profiles/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/r2g_straggler_sweep.log)")
     ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "

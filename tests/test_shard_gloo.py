@@ -136,3 +136,10 @@ def test_bench_self_spawns_the_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "launcher started 1 ranks" in bad.stderr
+
+
+def test_bench_help_prints():
+    """argparse expands % in help strings: a stray one makes `bench.py --help` a traceback"""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--layout" in out.stdout and "spread-epaxos" in out.stdout, out.stderr[-400:]
