@@ -1,7 +1,8 @@
 """Small workload for rocprofv3 passes (--kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE -- each its own run):
 ticks of the bench shape on the DEFAULT workload of bench.py (10 % ack loss, 1 % of the groups changing leader inside the
 run) or the steady one (--timeouts 0), then -- the calibration point, its byte counts are known exactly -- three RS(3,2)
-encodes of 65 536 codewords (268 MB, past the 256 MB L3), and with --extra the Raft / EPaxos reply kernels of their legs.
+encodes of 65 536 codewords (268 MB, past the 256 MB L3), and with --extra the Raft / EPaxos reply kernels of their legs
+and the wire ingest kernels of theirs.
 usage: python tools/pmc_probe.py [--timeouts 0.01] [--ticks 16] [--extra]"""
 import argparse
 import os
@@ -62,5 +63,7 @@ if a.extra:
     import bench
     bench.raft_leg(torch, dev)
     bench.epaxos_leg(torch, dev)
+    torch.cuda.synchronize()
+    bench.wire_ingest_leg(torch, dev)             # the peer-traffic parser's three kernels (round 2: no PMC traffic for them yet)
     torch.cuda.synchronize()
 print("done")
