@@ -67,6 +67,45 @@ struct WinRd {
     }
 };
 
+#ifndef SMR_WI_RING
+#define SMR_WI_RING 0                            // 1 (experiment, DESIGN §4 "next"): the stream as a ring of whole 128-byte lines per lane
+#endif
+// WinRd over a ring of 64 dword rows (two 128-byte lines): row0 = the row of the dword the frame starts in, n / end count
+// bytes from that dword's first byte
+struct RingRd {
+    const uint32_t *col;
+    uint32_t row0, n, end;
+    bool ok;
+    __device__ __forceinline__ uint64_t peek64() const {
+        const uint32_t i = row0 + (n >> 2), sh = 8 * (n & 3);
+        const uint32_t a = col[(i & 63u) * 64], b = col[((i + 1) & 63u) * 64], c = col[((i + 2) & 63u) * 64];
+        const uint32_t lo = (uint32_t)((((uint64_t)b << 32) | a) >> sh), hi = (uint32_t)((((uint64_t)c << 32) | b) >> sh);
+        return ((uint64_t)hi << 32) | lo;
+    }
+    __device__ __forceinline__ uint8_t byte() {
+        if (n < end) { const uint8_t b = (uint8_t)peek64(); n++; return b; }
+        ok = false;
+        return 0;
+    }
+    __device__ __forceinline__ uint64_t be64() {
+        if (n + 8 <= end) { const uint64_t x = peek64(); n += 8; return __builtin_bswap64(x); }
+        ok = false;
+        return 0;
+    }
+    __device__ __forceinline__ uint64_t varint() {
+        const uint64_t x = peek64();
+        const uint32_t b = (uint32_t)(x & 0xFF);
+        const uint32_t need = b < 251 ? 1 : b == 0xFB ? 3 : b == 0xFC ? 5 : b == 0xFD ? 9 : 0;
+        if (need == 0 || n + need > end) { ok = false; n = end; return 0; }
+        uint64_t v = b;
+        if (need == 3) v = (x >> 8) & 0xFFFF;
+        else if (need == 5) v = (x >> 8) & 0xFFFFFFFFull;
+        else if (need == 9) { n += 1; v = peek64(); n -= 1; }
+        n += need;
+        return v;
+    }
+};
+
 // The 16 bytes behind a frame's header in two registers: what every AcceptReply / Heartbeat / CommitNotice of a running
 // cluster fits into (slots, ballots and bars below 2^32 are varints of <= 5 bytes).  Decoding out of registers has no
 // window bounds to watch and no LDS round trip per varint; `n` counts the bytes taken and is compared with the frame's
@@ -146,7 +185,11 @@ struct IngestArgs {
 // WRITE = false: count my connection's records, report consumed / status; true: write them at my bases
 template <bool WRITE>
 __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
+#if SMR_WI_RING
+    __shared__ uint32_t win[64 * 64];                 // two 128-byte lines per lane
+#else
     __shared__ uint32_t win[(WI_DW + 2) * 64];       // + two dword rows: peek64 at the window's last bytes stays inside
+#endif
     __shared__ uint32_t sh_cnt[3][64];
     const uint32_t lane = threadIdx.x, c = blockIdx.x * 64 + lane;
     const bool live = c < A.n_conn;
@@ -170,6 +213,111 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
     }
     uint32_t n[3] = {0, 0, 0};
     uint32_t *const col = &win[lane];
+#if SMR_WI_RING
+    // The stream as whole 128-byte lines: every line of it is fetched ONCE (a refill at the parse position re-fetches the
+    // line it stands in: 2.4x the stream in line traffic), and the next line's loads are in flight while the
+    // frames that end inside the loaded lines are parsed.  A frame's header + look-ahead is <= 72 bytes, so two lines of ring
+    // always hold what the next frame needs once the line after its first byte is in.
+    uint64_t ld = start & ~127ull;                // [the line my position is in .. ld) is in the ring
+    for (;;) {
+        if (!__ballot(!done)) break;
+        const bool want = !done && ld < end;
+        const uint64_t wbase = ld;
+        const uint32_t nchunk = want ? (uint32_t)(end - ld >= 128 ? 8 : (end - ld + 15) / 16) : 0u;
+        const uint32_t k = lane % 8;
+        wi_u32x4 q[8];
+        uint32_t ragged = 0;
+        const bool can = A.buf_len >= 16;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {                                          // the next line of eight connections per instruction
+            const uint32_t src = i * 8 + lane / 8;
+            const uint64_t wb = __shfl(wbase, (int)src);
+            const uint32_t nc = __shfl(nchunk, (int)src);
+            const uint64_t off = wb + 16ull * k;
+            const bool w = k < nc, whole = w && off + 16 <= A.buf_len;
+            ragged |= (uint32_t)(w && !whole) << i;
+            q[i] = wi_u32x4{0, 0, 0, 0};
+            if (can) q[i] = *(const wi_u32x4 *)(A.buf + (whole ? off : 0));
+        }
+        if (__ballot(ragged != 0)) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                const uint64_t off = __shfl(wbase, (int)(i * 8 + lane / 8)) + 16ull * k;
+                if ((ragged >> i) & 1) {
+                    uint32_t v[4] = {0, 0, 0, 0};
+                    for (uint32_t b = 0; b < 16 && off + b < A.buf_len; b++) v[b >> 2] |= (uint32_t)A.buf[off + b] << (8 * (b & 3));
+                    q[i] = wi_u32x4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+        // ---- the frames that end inside the lines already in the ring (the loads above are still in flight) ----
+        while (!done) {
+            const uint64_t avail = end - pos;
+            if (avail < 8) { done = true; break; }
+            if (pos + 8 > ld) break;
+            const uint32_t o = (uint32_t)(pos & 3);
+            RingRd r{col, (uint32_t)(pos >> 2) & 63u, o, o + 8, true};
+            const uint64_t plen = r.be64();
+            if (plen > 1000000000000ull) { st = 1; done = true; break; }
+            if (avail - 8 < plen) { done = true; break; }
+            const uint32_t look = (uint32_t)(plen < WI_HOT_MAX ? plen : WI_HOT_MAX);
+            if (pos + 8 + look > ld) break;
+            uint32_t kind = SMR_WIRE_OTHER;
+            bool hot = false;
+            uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+            if (plen <= WI_FAST_MAX) {
+                const uint64_t lo = r.peek64();
+                r.n += 8;
+                const uint64_t hi = r.peek64();
+                Reg128 p{lo, hi, 0, true};
+                parse_peer_message(p, kind, hot, f0, f1, f2, f3);
+                r.ok = p.ok && p.n <= (uint32_t)plen;
+                r.n = o + 8 + p.n;
+            } else {
+                r.end = o + 8 + look;
+                parse_peer_message(r, kind, hot, f0, f1, f2, f3);
+            }
+            if (!r.ok || (hot && (uint64_t)(r.n - (o + 8)) != plen)) { st = 1; done = true; break; }
+            const int what = (kind == SMR_WIRE_ACCEPT_REPLY && f0 <= 0xFFFFFFFFull) ? 0 :
+                             (kind == SMR_WIRE_HEARTBEAT || kind == SMR_WIRE_COMMIT_NOTICE) ? 1 : 2;
+            if (WRITE) {
+                const uint64_t at = base[what] + n[what];
+                if (what == 0 && at < A.ack_cap) {
+                    smr_mp_ack a; a.group = group; a.slot = (uint32_t)f0; a.ballot = f1; a.peer = peer; a.reserved = 0;
+                    put_record(&A.acks[at], a);
+                } else if (what == 1 && at < A.hb_cap) {
+                    smr_wire_hb h; h.group = group; h.peer = peer; h.kind = kind; h.reserved = 0; h.ballot = f0; h.commit_bar = f1;
+                    h.exec_bar = f2; h.snap_bar = f3;
+                    put_record(&A.hbs[at], h);
+                } else if (what == 2 && at < A.other_cap) {
+                    smr_wire_other oo; oo.conn = c; oo.kind = kind; oo.off = pos; oo.len = 8 + plen;
+                    put_record(&A.others[at], oo);
+                }
+            }
+            n[what]++;
+            pos += 8 + plen;
+        }
+        // ---- the line that was in flight goes into the ring -- unless my position has left everything loaded (a long frame
+        // the device only locates): then the ring restarts at the line my position is in
+        const uint64_t nld = want ? ld + 128 : ld;
+        const bool jump = !done && pos >= nld;
+        const uint32_t nc_w = (want && !jump) ? nchunk : 0u;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint32_t src = i * 8 + lane / 8;
+            const uint64_t wb = __shfl(wbase, (int)src);
+            const uint32_t nc = __shfl(nc_w, (int)src);
+            if (k < nc) {
+                const uint32_t row = (uint32_t)(wb >> 2) + 4 * k;
+                win[((row + 0) & 63u) * 64 + src] = q[i].x; win[((row + 1) & 63u) * 64 + src] = q[i].y;
+                win[((row + 2) & 63u) * 64 + src] = q[i].z; win[((row + 3) & 63u) * 64 + src] = q[i].w;
+            }
+        }
+        __syncthreads();
+        ld = jump ? (pos & ~127ull) : nld;
+    }
+#else
     for (;;) {
         if (!__ballot(!done)) break;              // wave-uniform: a lane that is done stays to help with the refills
         // ---- refill: every lane's column gets what is left of its stream at its position, at most the window ----
@@ -291,6 +439,7 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
             pos += 8 + plen;
         }
     }
+#endif
     if (!WRITE) {
         if (live) { A.consumed[c] = pos - start; A.status[c] = st; }
 #pragma unroll
