@@ -92,7 +92,7 @@ def parse():
                     "smr_mp_tick call per tick")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
-    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
+    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos", "colocated-epaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
                     "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
     ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
                     "kernels, plans and buffers; the collective is a device copy)")
@@ -893,6 +893,58 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+def colocated_epaxos_main(args, torch, dist, rank, local, world, dev):
+    """--layout colocated-epaxos: BASELINE config 5 in layout L1 -- every rank holds ALL five replicas of its block of groups
+    (args.groups per GPU) and runs the closed loop as one C-ABI call per tick (smr_ep_cluster_tick); no data-path collective,
+    weak scaling like the headline line.  Dependency-graph execution on."""
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard
+    G, R, W, K = args.groups, 5, 32, 64
+    lo, _ = shard.group_range(G * world, world, rank)
+    reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    job = ep_cluster.EPaxosCluster(reps)
+    zipf = 1.0 / np.arange(1, K + 1) ** 0.99
+    zipf /= zipf.sum()
+    n_ticks = args.warmup + args.steps
+    keys = [[torch.from_numpy(np.random.default_rng([0x5EED5EED, t, lo, r]).choice(K, G, p=zipf).astype(np.uint8)).to(dev) for r in range(R)]
+            for t in range(min(n_ticks, 8))]                              # keyed by (tick, my block's first group, replica)
+    committed = torch.zeros((), dtype=torch.int64, device=dev)
+    slow = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(args.warmup):
+        job.tick(keys[t % len(keys)])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_ticks):
+        for o in job.tick(keys[t % len(keys)]):
+            committed += o["committed"].sum()
+            slow += (o["decision"] == 2).sum()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_slow = int(slow.item())
+    executed = sum(int(r.exec_dump()["counters"][0]) for r in reps)
+    elapsed, commits = shard.reduce_metric(elapsed, int(committed.item()), device=dev)
+    line = {"metric": "committed_instances_per_sec", "value": commits / elapsed, "unit": "instances/s", "n_gpus": world,
+            "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "EPaxos closed loop, %d groups/GPU x 5 replicas, every replica proposes 1 instance per group per tick "
+                                   "(Zipf(0.99) keys of 64), optimized quorums, dependency-graph execution on" % G,
+                       "groups_per_gpu": G, "replicas": R, "window": W, "layout": "colocated",
+                       "launch": "one smr_ep_cluster_tick call per tick (85 handler launches + 30 execution launches)"},
+            "slow_path_instances_this_rank": n_slow, "commands_executed_this_rank": executed, "roofline": None, "cpu_baseline": None,
+            "note": "config 5 in layout L1; the roofline / cpu_baseline objects belong to the headline line"}
+    if rank == 0:
+        print(json.dumps(line))
+    job.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks exactly as the driver's own
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would and hand
@@ -956,6 +1008,8 @@ def main():
         return spread_main(args, torch, dist, rank, local, world, dev)
     if args.layout == "spread-epaxos":
         return spread_epaxos_main(args, torch, dist, rank, local, world, dev)
+    if args.layout == "colocated-epaxos":
+        return colocated_epaxos_main(args, torch, dist, rank, local, world, dev)
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4

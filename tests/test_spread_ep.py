@@ -101,3 +101,24 @@ def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch):
     line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["config"]["spread_ranks"] == 3 and line["exchange"]["collectives_per_tick"] == 5
     assert line["value"] > 0 and line["exchange"]["bytes_sent_per_tick_per_rank"] > 0 and line["steps"] == 3
+
+
+def test_bench_layout_colocated_epaxos_on_the_emulator(capsys, monkeypatch):
+    """`bench.py --layout colocated-epaxos` (config 5 in layout L1: one smr_ep_cluster_tick call per tick) end to end, the
+    emulator build standing in for the device"""
+    import json
+    import sys
+    import torch
+    import hostsim
+    import bench
+    hostsim.build()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--layout", "colocated-epaxos", "--groups", "96", "--steps", "3", "--warmup", "1"])
+    args = bench.parse()
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    with hostsim.patched():
+        bench.colocated_epaxos_main(args, torch, torch.distributed, 0, 0, 1, "cpu")
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 3 and line["config"]["layout"] == "colocated"
+    # every replica executes every command of all four ticks (a few run twice: an executing slot that add_edge re-inserts,
+    # execution.rs:57-59 -- the reference's behaviour, counted by the engine as re-submissions)
+    assert 5 * 5 * 96 * 4 <= line["commands_executed_this_rank"] <= 5 * 5 * 96 * 4 * 1.02
