@@ -22,6 +22,7 @@ timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-rs --no
 timeout 300 python bench.py --timeouts 0 --no-cpu --no-rs --no-extra > gpurun_out/${TAG}_bench_steady.json 2>> gpurun_out/${TAG}_bench.err
 timeout 300 python bench.py --layout spread --spread-ranks 4 --steps 24 --warmup 6 > gpurun_out/${TAG}_bench_spread4.json 2> gpurun_out/${TAG}_bench_spread.err
 timeout 300 python bench.py --layout spread-epaxos --spread-ranks 4 --steps 8 --warmup 2 > gpurun_out/${TAG}_bench_spread_epaxos4.json 2>> gpurun_out/${TAG}_bench_spread.err
+timeout 300 python bench.py --layout colocated-epaxos --steps 20 --warmup 4 > gpurun_out/${TAG}_bench_colocated_epaxos.json 2>> gpurun_out/${TAG}_bench_spread.err; tail -c 700 gpurun_out/${TAG}_bench_colocated_epaxos.json; echo
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_bench -- python $R/bench.py --no-cpu --no-rs --no-extra > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /dev/null
