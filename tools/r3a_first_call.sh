@@ -5,7 +5,7 @@
 # the two spread layouts with virtual ranks, the kernel trace of the default bench line.  ~6 GPU-minutes.
 TAG=${1:-r3a}
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 2>&1 | tail -60 > gpurun_out/${TAG}_gputests.log
+timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -80 > gpurun_out/${TAG}_gputests.log
 tail -3 gpurun_out/${TAG}_gputests.log
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 600 gpurun_out/${TAG}_bench.json; echo
 TAG=$TAG python - <<'P'
