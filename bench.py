@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-PMC_NOTE = ("profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
+PMC_FILE = os.path.join(ROOT, "profiles", "r3a_pmc_traffic.json")
+PMC_NOTE = ("profiles/r3a_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
             "gfx950 corrections of MI355X_MICROARCH.md applied; bytes per launch at 65536 groups, S=32, default workload)")
 
 
@@ -319,30 +319,52 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
             "value": int(committed.item()) / dt, "unit": "instances committed/s (handler calls of the Python driver included)",
             "ms_per_tick": dt / ticks * 1e3, "slow_path_fraction": int(slow.item()) / max(int(committed.item()), 1),
             "handler_calls_per_tick": R + 2 * R * (R - 1) + 2 * R, "commands_executed": ex}
-    # the same loop as ONE C-ABI call per tick (smr_ep_cluster_tick: the same kernels launched back to back by the library, replies
-    # written straight into the leaders' stacks).  Its own replicas, its own try: first measured by the driver's run of this line
-    # (round 2 had no GPU minutes left for it; emulator-verified against the loop above), so a failure must not cost the number above
-    try:
-        del reps
-        reps2 = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
-        fused = ep_cluster.EPaxosCluster(reps2)
-        for t in range(2):
-            fused.tick(keys[t])
-        torch.cuda.synchronize()
-        c2 = torch.zeros((), dtype=torch.int64, device=dev)
-        t0 = time.perf_counter()
-        for t in range(2, ticks + 2):
-            for o in fused.tick(keys[t]):
-                c2 += o["committed"].sum()
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
-        line["one_call_per_tick"] = {"entry_point": "smr_ep_cluster_tick", "value": int(c2.item()) / dt2, "unit": "instances committed/s",
-                                     "ms_per_tick": dt2 / ticks * 1e3, "same_commits_as_the_driver_loop": int(c2.item()) == int(committed.item()),
-                                     "commands_executed": sum(int(r.exec_dump()["counters"][0]) for r in reps2)}
-        fused.close()
-    except Exception as e:                         # noqa: BLE001
-        line["one_call_per_tick"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        sys.stderr.write("bench.py: epaxos_cluster one_call_per_tick FAILED: %s: %s\n" % (type(e).__name__, e))
+    # the same loop as ONE C-ABI call per tick (smr_ep_cluster_tick): as ONE launch -- a block is the five replicas of 64 groups, the
+    # handlers are steps of that kernel -- and (`per_handler_launches`, round 2's path) as the handler kernels launched back to
+    # back by the library.  Own replicas each; the tick's output arrays are the caller's and are reused.
+    del reps
+    for name, per_handler in (("one_call_per_tick", False), ("one_call_per_tick_per_handler_launches", True)):
+        try:
+            reps2 = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+            fused = ep_cluster.EPaxosCluster(reps2, per_handler_launches=per_handler)
+            outs = fused.new_outputs(dev)
+            for t in range(2):
+                fused.tick(keys[t], out=outs)
+            torch.cuda.synchronize()
+            c2 = torch.zeros((), dtype=torch.int64, device=dev)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * ticks)]
+            t0 = time.perf_counter()
+            for t in range(2, ticks + 2):
+                ev[2 * (t - 2)].record()
+                o = fused.tick(keys[t], out=outs)
+                ev[2 * (t - 2) + 1].record()
+                c2 += torch.stack([x["committed"].sum() for x in o]).sum()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            tick_us = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) * 1e3 for i in range(ticks))
+            n_inst = int(c2.item())
+            leg = {"entry_point": "smr_ep_cluster_tick", "launches_per_tick": 115 if per_handler else 1,
+                   "value": n_inst / dt2, "unit": "instances committed/s", "ms_per_tick": dt2 / ticks * 1e3,
+                   "tick_us_device_median": tick_us[len(tick_us) // 2], "tick_us_device_min": tick_us[0],
+                   "same_commits_as_the_driver_loop": n_inst == int(committed.item()),
+                   "commands_executed": sum(int(r.exec_dump()["counters"][0]) for r in reps2)}
+            if not per_handler:
+                # <= 370 B per instance for the tally (replies read, instance read / written); the tick as a whole
+                # -- proposals, 4 PreAccepts, the tally, 4 CommitNotices, execution per instance -- has no per-unit figure there,
+                # so this is the tally's figure over the WHOLE tick's time: a lower bound on what the kernel moves
+                alg = 370.0 * R * G
+                us = leg["tick_us_device_median"]
+                leg["roofline"] = {"bound": "hbm", "kernel": "ep_cluster_tick_kernel<5> (the whole tick: 1 launch)", "achieved": alg / us / 1e3,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
+                                   "avg_launch_us": us, "traffic": _leg_traffic("smr::ep_cluster_tick_kernel<5>"),
+                                   "note": "alg bytes = SURVEY 8(d)'s <= 370 B per instance x 5 x 65536 instances per tick (the tally's figure; the "
+                                           "tick also runs 5 proposals, 20 PreAccepts, 20 CommitNotices and the execution walks per group)"}
+            line[name] = leg
+            fused.close()
+            del reps2, fused, outs
+        except Exception as e:                         # noqa: BLE001
+            line[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("bench.py: epaxos_cluster %s FAILED: %s: %s\n" % (name, type(e).__name__, e))
     return line
 
 

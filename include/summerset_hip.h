@@ -583,6 +583,12 @@ int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluste
 void smr_ep_cluster_destroy(smr_ep_cluster *c);
 int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev, const smr_ep_cluster_out *out,
                         void *stream);
+/* How smr_ep_cluster_tick runs the tick.  0 (default): ONE launch -- a block is the R replicas (one wavefront each) of 64 groups,
+ * the handlers run as steps of one kernel, messages cross wavefronts behind block barriers, execution runs behind its handler
+ * on the same lane.  1: one launch per handler and (replica, sender) pair, the kernels of the per-handler entry points back to
+ * back (round 2's path: 115 launches per tick at R = 5 with execution on); kept as the decomposition the one-launch tick is
+ * checked against and timed beside.  Both are the handler-by-handler loop bit for bit. */
+int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode);
 
 /* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with
  * an entry in exp_prepare_voteds (bitmap); those entries [R][W][R][G], deps [R][W][R][R][G]; counters[4] = decisions

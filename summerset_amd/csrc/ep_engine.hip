@@ -60,11 +60,12 @@ struct EpView {
     uint32_t *xv_deps;                   // [R][W][R][R][G]
 };
 
-struct EpLane {
+template <int NR>
+struct EpLaneT {
     const EpView &v;
     const uint32_t g;
     unsigned int n_fast = 0, n_slow = 0, n_acc = 0, n_xc = 0, n_xa = 0, n_xp = 0, n_xn = 0;
-    __device__ __forceinline__ EpLane(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
+    __device__ __forceinline__ EpLaneT(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
     // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
     __device__ __forceinline__ size_t pw(uint32_t row, uint32_t col) const { return (size_t)(v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
     __device__ __forceinline__ size_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
@@ -98,14 +99,14 @@ struct EpLane {
         len(row) = col + 1;
         if (row == v.me) v.my_nulls[g] += 1;
     }
-    __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[EMAXR]) const {   // dependency.rs:113-137
+    __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < EMAXR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)key * v.R + i) * v.G + g] : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)key * v.R + i) * v.G + g] : EP_NONE;
     }
-    __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[EMAXR]) const {         // dependency.rs:101-109
+    __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
 #pragma unroll
-        for (int row = 0; row < EMAXR; row++) {
+        for (int row = 0; row < NR; row++) {
             if ((uint32_t)row >= v.R || d[row] == EP_NONE || !held(row, d[row])) continue;
             const uint64_t s = v.seq[ix(row, d[row])];
             if (s > m) m = s;
@@ -147,7 +148,7 @@ struct EpLane {
     }
     // messages.rs:96-270 on an instance I lead; rd = the reply's DepSet
     __device__ __forceinline__ void pre_accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot, uint64_t rseq,
-                                                     const uint32_t (&rd)[EMAXR], uint32_t exploded) {
+                                                     const uint32_t (&rd)[NR], uint32_t exploded) {
         const uint32_t R = v.R;
         if (!held(row, col)) return;                                             // :125-127
         const size_t i = ix(row, col);
@@ -165,58 +166,58 @@ struct EpLane {
         const uint32_t all_cnt = __popc(acks);
         if (all_cnt < v.simple_q) return;
         // the replies held, in registers: seq + DepSet of every acked peer
-        uint64_t ps[EMAXR]; uint32_t pd[EMAXR][EMAXR];
+        uint64_t ps[NR]; uint32_t pd[NR][NR];
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++) {
+        for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && ((acks >> p) & 1u);
             ps[p] = on ? v.pa_seq[ps_ix(row, col, p)] : 0;
 #pragma unroll
-            for (int k = 0; k < EMAXR; k++)
+            for (int k = 0; k < NR; k++)
                 pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[pd_ix(row, col, p, k)] : EP_NONE;
         }
         // dependency.rs:333-367 get_enough_identical: size of the largest class of equal (seq, deps)
         uint32_t max_cnt = 0; int best = -1;
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++) {
+        for (int p = 0; p < NR; p++) {
             if (!((acks >> p) & 1u) || (uint32_t)p >= R) continue;
             uint32_t same = 0;
 #pragma unroll
-            for (int q = 0; q < EMAXR; q++) {
+            for (int q = 0; q < NR; q++) {
                 if (!((acks >> q) & 1u) || (uint32_t)q >= R) continue;
                 bool eq = ps[q] == ps[p];
 #pragma unroll
-                for (int k = 0; k < EMAXR; k++) eq = eq && pd[q][k] == pd[p][k];
+                for (int k = 0; k < NR; k++) eq = eq && pd[q][k] == pd[p][k];
                 same += eq ? 1u : 0u;
             }
             if (same > max_cnt) { max_cnt = same; best = p; }
         }
         uint32_t bad = 0;
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++)
+        for (int p = 0; p < NR; p++)
             if ((uint32_t)p < R && !((acks >> p) & 1u) && (uint32_t)p != v.me && ((exploded >> p) & 1u)) bad++;
-        uint64_t dseq = 0; uint32_t dd[EMAXR];
+        uint64_t dseq = 0; uint32_t dd[NR];
         int next = 0;
         if (!avoid && max_cnt >= v.super_q) {                                    // fast path
             next = EST_COMMITTED;
             dseq = 0;
 #pragma unroll
-            for (int p = 0; p < EMAXR; p++) if (p == best) dseq = ps[p];
+            for (int p = 0; p < NR; p++) if (p == best) dseq = ps[p];
 #pragma unroll
-            for (int k = 0; k < EMAXR; k++) {
+            for (int k = 0; k < NR; k++) {
                 dd[k] = EP_NONE;
 #pragma unroll
-                for (int p = 0; p < EMAXR; p++) if (p == best) dd[k] = pd[p][k];
+                for (int p = 0; p < NR; p++) if (p == best) dd[k] = pd[p][k];
             }
         } else if (avoid || max_cnt + (R - bad - all_cnt) < v.super_q) {         // :221-236 slow path: union / max
             next = EST_ACCEPTING;
 #pragma unroll
-            for (int k = 0; k < EMAXR; k++) dd[k] = EP_NONE;
+            for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
 #pragma unroll
-            for (int p = 0; p < EMAXR; p++) {
+            for (int p = 0; p < NR; p++) {
                 if (!((acks >> p) & 1u) || (uint32_t)p >= R) continue;
                 if (ps[p] > dseq) dseq = ps[p];
 #pragma unroll
-                for (int k = 0; k < EMAXR; k++) {                                // dependency.rs:85-97 union
+                for (int k = 0; k < NR; k++) {                                // dependency.rs:85-97 union
                     if (dd[k] != EP_NONE) { if (pd[p][k] != EP_NONE && pd[p][k] > dd[k]) dd[k] = pd[p][k]; }
                     else dd[k] = pd[p][k];
                 }
@@ -227,7 +228,7 @@ struct EpLane {
         for (uint32_t k = 0; k < R; k++) {
             uint32_t x = EP_NONE;
 #pragma unroll
-            for (int kk = 0; kk < EMAXR; kk++) if ((uint32_t)kk == k) x = dd[kk];
+            for (int kk = 0; kk < NR; kk++) if ((uint32_t)kk == k) x = dd[kk];
             v.deps[dx(row, col, k)] = x;
         }
         if (next == EST_COMMITTED) {                                             // :158-206
@@ -244,7 +245,7 @@ struct EpLane {
     // returns the Status of the message it broadcasts for (row, col) under new_ballot (the instance holds its seq / deps /
     // reqs), 0 = none
     __device__ __forceinline__ int exp_prepare_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t nb, uint64_t vbal,
-                                                     uint32_t vstatus, uint64_t vseq, const uint32_t (&vd)[EMAXR], uint32_t vkey) {
+                                                     uint32_t vstatus, uint64_t vseq, const uint32_t (&vd)[NR], uint32_t vkey) {
         const uint32_t R = v.R;
         if (!held(row, col)) return 0;                                           // :599-601
         const size_t i = ix(row, col);
@@ -263,18 +264,18 @@ struct EpLane {
         v.xp_acks[i] = (uint8_t)acks; v.xp_has[i] = (uint8_t)has;
         if ((uint32_t)__popc(acks) < v.simple_q) return 0;                       // dependency.rs:257-260
         // the voted entries, in registers
-        uint32_t xs[EMAXR], xk[EMAXR]; uint64_t xq[EMAXR]; uint32_t xd[EMAXR][EMAXR];
+        uint32_t xs[NR], xk[NR]; uint64_t xq[NR]; uint32_t xd[NR][NR];
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++) {
+        for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && ((has >> p) & 1u);
             const size_t q = xv_ix(row, col, on ? p : 0);
             xs[p] = on ? v.xv_status[q] : 0xFFu; xq[p] = on ? v.xv_seq[q] : 0; xk[p] = on ? v.xv_key[q] : EP_NO_KEY;
 #pragma unroll
-            for (int k = 0; k < EMAXR; k++) xd[p][k] = (on && (uint32_t)k < R) ? v.xv_deps[(q / v.G * R + k) * v.G + g] : EP_NONE;
+            for (int k = 0; k < NR; k++) xd[p][k] = (on && (uint32_t)k < R) ? v.xv_deps[(q / v.G * R + k) * v.G + g] : EP_NONE;
         }
         int has_commit = -1, has_accept = -1, has_pre = -1;                      // :264-273: the highest peer id of a status
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++) {
+        for (int p = 0; p < NR; p++) {
             if (xs[p] == EST_COMMITTED) has_commit = p;
             else if (xs[p] == EST_ACCEPTING) has_accept = p;
             else if (xs[p] == EST_PREACCEPTING) has_pre = p;
@@ -286,17 +287,17 @@ struct EpLane {
             if (mx == (uint64_t)(row + 1)) {                                     // :286-311 make_default_ballot(slot_row)
                 uint32_t n = 0;
 #pragma unroll
-                for (int p = 0; p < EMAXR; p++) n += ((uint32_t)p != row && xs[p] == EST_PREACCEPTING) ? 1u : 0u;
+                for (int p = 0; p < NR; p++) n += ((uint32_t)p != row && xs[p] == EST_PREACCEPTING) ? 1u : 0u;
                 if (n + 1 >= v.simple_q && n > 0) {
 #pragma unroll
-                    for (int p = 0; p < EMAXR; p++) {                            // a class of >= simple_q equal entries: at most one
+                    for (int p = 0; p < NR; p++) {                            // a class of >= simple_q equal entries: at most one
                         if ((uint32_t)p == row || xs[p] != EST_PREACCEPTING || pick >= 0) continue;
                         uint32_t same = 0;
 #pragma unroll
-                        for (int q = 0; q < EMAXR; q++) {
+                        for (int q = 0; q < NR; q++) {
                             bool eq = (uint32_t)q != row && xs[q] == EST_PREACCEPTING && xq[q] == xq[p] && xk[q] == xk[p];
 #pragma unroll
-                            for (int k = 0; k < EMAXR; k++) eq = eq && xd[q][k] == xd[p][k];
+                            for (int k = 0; k < NR; k++) eq = eq && xd[q][k] == xd[p][k];
                             same += eq ? 1u : 0u;
                         }
                         if (same >= v.simple_q) { next = EST_ACCEPTING; pick = p; }
@@ -305,21 +306,21 @@ struct EpLane {
             }
             if (!next) { next = EST_PREACCEPTING; pick = has_pre; }              // :316-327 (pick < 0: the no-op)
         }
-        uint64_t dseq = 1; uint32_t dkey = EP_NO_KEY; uint32_t dd[EMAXR];
+        uint64_t dseq = 1; uint32_t dkey = EP_NO_KEY; uint32_t dd[NR];
 #pragma unroll
-        for (int k = 0; k < EMAXR; k++) dd[k] = EP_NONE;
+        for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
 #pragma unroll
-        for (int p = 0; p < EMAXR; p++)
+        for (int p = 0; p < NR; p++)
             if (p == pick) {
                 dseq = xq[p]; dkey = xk[p];
 #pragma unroll
-                for (int k = 0; k < EMAXR; k++) dd[k] = xd[p][k];
+                for (int k = 0; k < NR; k++) dd[k] = xd[p][k];
             }
         v.bal[i] = nb; v.status[i] = (uint8_t)next; v.seq[i] = dseq; v.key[i] = (uint8_t)dkey;
         for (uint32_t k = 0; k < R; k++) {
             uint32_t x = EP_NONE;
 #pragma unroll
-            for (int kk = 0; kk < EMAXR; kk++) if ((uint32_t)kk == k) x = dd[kk];
+            for (int kk = 0; kk < NR; kk++) if ((uint32_t)kk == k) x = dd[kk];
             v.deps[dx(row, col, k)] = x;
         }
         refresh_highest_cols(row, col, dkey);
@@ -341,6 +342,7 @@ struct EpLane {
         }
     }
 };
+typedef EpLaneT<EMAXR> EpLane;
 
 // ---- dependency-graph execution ------------------------------------------------------------------
 // One call of a handler kernel moves at most one row's commit bar per group (one message or one
@@ -376,14 +378,15 @@ struct EpExec {
                                          // (unused: components > 1 node), attempts, abandoned attempts
 };
 
-struct EpExecLane {
+template <int NR>
+struct EpExecLaneT {
     const EpView &v;
     const EpExec &x;
-    const EpLane &L;
+    const EpLaneT<NR> &L;
     const uint32_t g, wshift;
     uint32_t n_nodes = 0, n_order = 0, last = XNIL;          // last: ring cell of the slot popped before, XNIL = none / not held
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
-    __device__ __forceinline__ EpExecLane(const EpView &v_, const EpExec &x_, const EpLane &L_, uint32_t g_)
+    __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, const EpLaneT<NR> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
     __device__ __forceinline__ size_t at(uint32_t i) const { return (size_t)i * v.G + g; }
     // the column a ring cell of this row holds (the one of its residue among the last W)
@@ -519,25 +522,124 @@ struct EpExecLane {
         }
     }
 };
+typedef EpExecLaneT<EMAXR> EpExecLane;
+
+// ---- the handlers on one lane (= one group of one replica): what the per-handler kernels below and the one-kernel
+// cluster tick (ep_cluster_tick_kernel) both run ---------------------------------------------------------------------------
+// the attempts of handle_logged_commit_slot behind ONE handler (durability.rs:136-160): at most one row's commit bar moved
+template <int NR>
+__device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpExec &x, EpExecLaneT<NR> &E) {
+    E.n_order = 0;
+    for (uint32_t row = 0; row < v.R; row++) {
+        const size_t o = (size_t)row * v.G + E.g;
+        const uint32_t cb = v.commit_bars[o];
+        if (cb == x.prev_cb[o]) continue;
+        x.prev_cb[o] = cb;
+        E.advanced(row, cb);
+    }
+    x.n_sub[E.g] = E.n_order;                                                // 0 when no commit bar moved
+}
+
+// request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35): key k (EP_NO_KEY: nothing to propose);
+// (of, oc, os, d) = the PreAccept to broadcast
+template <int NR>
+__device__ __forceinline__ void ep_propose_lane(EpLaneT<NR> &L, uint32_t k, uint32_t ex, uint8_t &of, uint32_t &oc, uint64_t &os,
+                                                uint32_t (&d)[NR]) {
+    const EpView &v = L.v;
+    const uint32_t g = L.g;
+    of = 0; oc = 0; os = 0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) d[i] = EP_NONE;
+    if (k == EP_NO_KEY) return;
+    const uint32_t row = v.me;
+    uint32_t col = EP_NONE;                                                  // mod.rs:485-496 (exec_bars stay 0 here)
+    const uint32_t end = L.len(row);
+    if (v.my_nulls[g] != 0)                                                  // only a PreAccept / Accept for my own row pads it
+        for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
+            if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
+    if (col == EP_NONE) { L.push_null(row); col = L.len(row) - 1; }
+    v.my_nulls[g] -= 1;                                                      // the slot stops being null
+    L.identify_deps(k, d);
+    const uint64_t seq = 1 + L.max_seq_num(d);
+    const size_t i = L.ix(row, col);
+    const uint64_t bal = (uint64_t)(v.me + 1);                               // make_default_ballot
+    v.bal[i] = bal; v.seq[i] = seq; v.key[i] = (uint8_t)k;
+    for (uint32_t q = 0; q < v.R; q++) {
+        uint32_t x = EP_NONE;
+#pragma unroll
+        for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = d[qq];
+        v.deps[L.dx(row, col, q)] = x;
+    }
+    L.refresh_highest_cols(row, col, k);
+    L.fresh_leader_bk(i);
+    v.status[i] = EST_PREACCEPTING;
+    of = 1; oc = col; os = seq;
+    L.pre_accept_reply(v.me, row, col, bal, seq, d, ex);
+}
+
+// messages.rs:10-93 (MODE 0: PreAccept) / :273-345 (MODE 1: Accept) / :438-508 (MODE 2: CommitNotice) + the acceptor's
+// WAL completion, for the message (src, row, c, b, s, deps[i * G + g], k) if `on`; (of, ob, os, d) = the reply
+template <int MODE, int NR>
+__device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
+                                                 const uint32_t *__restrict__ deps, uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
+                                                 uint32_t (&d)[NR]) {
+    const EpView &v = L.v;
+    const uint32_t g = L.g;
+    of = 0; ob = 0; os = 0;
+#pragma unroll
+    for (int i = 0; i < NR; i++) d[i] = EP_NONE;
+    if (!on) return;
+    if (!(row < v.R && !(c < L.len(row) && !L.held(row, c)))) return;        // col < start_col analogue
+    while (L.len(row) <= c) L.push_null(row);                                // :33-36
+    const size_t i = L.ix(row, c);
+    if (!(b >= v.bal[i])) return;                                            // :40
+    if (row == v.me && v.status[i] == EST_NULL) v.my_nulls[g] -= 1;
+    uint32_t in[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
+    if (MODE == 0) {
+        uint32_t my[NR];
+        L.identify_deps(k, my);
+#pragma unroll
+        for (int q = 0; q < NR; q++) {                                       // deps.union(&my_deps)
+            if (in[q] != EP_NONE) { if (my[q] != EP_NONE && my[q] > in[q]) in[q] = my[q]; }
+            else in[q] = my[q];
+        }
+        const uint64_t ms = 1 + L.max_seq_num(my);
+        if (ms > s) s = ms;
+    }
+    v.bal[i] = b; v.status[i] = MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING);
+    v.seq[i] = s; v.key[i] = (uint8_t)k;
+    for (uint32_t q = 0; q < v.R; q++) {
+        uint32_t x = EP_NONE;
+#pragma unroll
+        for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = in[qq];
+        v.deps[L.dx(row, c, q)] = x;
+    }
+    L.refresh_highest_cols(row, c, k);
+    if (MODE == 2) {
+        L.logged_commit_slot(row, c);                                        // durability.rs:104-135
+    } else {
+        const uint32_t bk = v.bk[i];
+        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
+        if (bk & 1u) {                                                       // durability.rs:25 / :78: leader_bk first
+            if (MODE == 1) L.accept_reply(v.me, row, c, b); else L.pre_accept_reply(v.me, row, c, b, s, in, 0u);
+        } else {
+            of = 1; ob = b; os = s;
+#pragma unroll
+            for (int q = 0; q < NR; q++) d[q] = in[q];
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void ep_execute_kernel(const EpView v, const EpExec x) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     EpExecLane E(v, x, L, L.g);
-    if (g < v.G) {
-        for (uint32_t row = 0; row < v.R; row++) {
-            const size_t o = (size_t)row * v.G + g;
-            const uint32_t cb = v.commit_bars[o];
-            if (cb == x.prev_cb[o]) continue;
-            x.prev_cb[o] = cb;
-            E.advanced(row, cb);
-        }
-        x.n_sub[g] = E.n_order;                                              // 0 when no commit bar moved
-    }
+    if (g < v.G) ep_exec_after_handler(v, x, E);
     E.flush();
 }
 
-// request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35)
 __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const uint8_t *__restrict__ key,
                                                          const uint8_t *__restrict__ exploded, uint8_t *__restrict__ m_flags,
                                                          uint32_t *__restrict__ m_col, uint64_t *__restrict__ m_seq,
@@ -545,37 +647,9 @@ __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const u
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
     if (g < v.G) {
-        uint8_t of = 0; uint32_t oc = 0; uint64_t os = 0;
+        uint8_t of; uint32_t oc; uint64_t os;
         uint32_t d[EMAXR];
-#pragma unroll
-        for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
-        const uint32_t k = key[g];
-        if (k != EP_NO_KEY) {
-            const uint32_t row = v.me;
-            uint32_t col = EP_NONE;                                              // mod.rs:485-496 (exec_bars stay 0 here)
-            const uint32_t end = L.len(row);
-            if (v.my_nulls[g] != 0)                                              // only a PreAccept / Accept for my own row pads it
-                for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
-                    if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
-            if (col == EP_NONE) { L.push_null(row); col = L.len(row) - 1; }
-            v.my_nulls[g] -= 1;                                                  // the slot stops being null
-            L.identify_deps(k, d);
-            const uint64_t seq = 1 + L.max_seq_num(d);
-            const size_t i = L.ix(row, col);
-            const uint64_t bal = (uint64_t)(v.me + 1);                           // make_default_ballot
-            v.bal[i] = bal; v.seq[i] = seq; v.key[i] = (uint8_t)k;
-            for (uint32_t q = 0; q < v.R; q++) {
-                uint32_t x = EP_NONE;
-#pragma unroll
-                for (int qq = 0; qq < EMAXR; qq++) if ((uint32_t)qq == q) x = d[qq];
-                v.deps[L.dx(row, col, q)] = x;
-            }
-            L.refresh_highest_cols(row, col, k);
-            L.fresh_leader_bk(i);
-            v.status[i] = EST_PREACCEPTING;
-            of = 1; oc = col; os = seq;
-            L.pre_accept_reply(v.me, row, col, bal, seq, d, exploded ? exploded[g] : 0u);
-        }
+        ep_propose_lane(L, key[g], exploded ? exploded[g] : 0u, of, oc, os, d);
         m_flags[g] = of; m_col[g] = oc; m_seq[g] = os;
 #pragma unroll
         for (int i = 0; i < EMAXR; i++) if ((uint32_t)i < v.R) m_deps[(size_t)i * v.G + g] = d[i];
@@ -583,8 +657,6 @@ __global__ __launch_bounds__(256) void ep_propose_kernel(const EpView v, const u
     L.flush();
 }
 
-// messages.rs:10-93 (MODE 0: PreAccept) / :273-345 (MODE 1: Accept) / :438-508 (MODE 2: CommitNotice) + the
-// acceptor's WAL completion
 template <int MODE>
 __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const uint8_t *__restrict__ flags,
                                                           const uint8_t *__restrict__ peer, const uint32_t *__restrict__ col,
@@ -601,52 +673,8 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
 #pragma unroll
         for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
         if (flags[g] & 1) {
-            const uint32_t src = peer[g], row = rows ? rows[g] : src, c = col[g], k = key[g];   // (rows: an instance under explicit prepare)
-            const uint64_t b = ballot[g];
-            if (row < v.R && !(c < L.len(row) && !L.held(row, c))) {             // col < start_col analogue
-                while (L.len(row) <= c) L.push_null(row);                        // :33-36
-                const size_t i = L.ix(row, c);
-                if (b >= v.bal[i]) {                                             // :40
-                    if (row == v.me && v.status[i] == EST_NULL) v.my_nulls[g] -= 1;
-                    uint32_t in[EMAXR];
-#pragma unroll
-                    for (int q = 0; q < EMAXR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
-                    uint64_t s = seq[g];
-                    if (MODE == 0) {
-                        uint32_t my[EMAXR];
-                        L.identify_deps(k, my);
-#pragma unroll
-                        for (int q = 0; q < EMAXR; q++) {                        // deps.union(&my_deps)
-                            if (in[q] != EP_NONE) { if (my[q] != EP_NONE && my[q] > in[q]) in[q] = my[q]; }
-                            else in[q] = my[q];
-                        }
-                        const uint64_t ms = 1 + L.max_seq_num(my);
-                        if (ms > s) s = ms;
-                    }
-                    v.bal[i] = b; v.status[i] = MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING);
-                    v.seq[i] = s; v.key[i] = (uint8_t)k;
-                    for (uint32_t q = 0; q < v.R; q++) {
-                        uint32_t x = EP_NONE;
-#pragma unroll
-                        for (int qq = 0; qq < EMAXR; qq++) if ((uint32_t)qq == q) x = in[qq];
-                        v.deps[L.dx(row, c, q)] = x;
-                    }
-                    L.refresh_highest_cols(row, c, k);
-                    if (MODE == 2) {
-                        L.logged_commit_slot(row, c);                            // durability.rs:104-135
-                    } else {
-                        const uint32_t bk = v.bk[i];
-                        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (src << 2));        // replica_bk.source = peer
-                        if (bk & 1u) {                                           // durability.rs:25 / :78: leader_bk first
-                            if (MODE == 1) L.accept_reply(v.me, row, c, b); else L.pre_accept_reply(v.me, row, c, b, s, in, 0u);
-                        } else {
-                            of = 1; ob = b; os = s;
-#pragma unroll
-                            for (int q = 0; q < EMAXR; q++) d[q] = in[q];
-                        }
-                    }
-                }
-            }
+            const uint32_t src = peer[g];
+            ep_acceptor_lane<MODE>(L, true, src, rows ? rows[g] : src, col[g], ballot[g], seq[g], deps, key[g], of, ob, os, d);   // (rows: an instance under explicit prepare)
         }
         if (MODE != 2) { r_flags[g] = of; r_ballot[g] = ob; }
         if (MODE == 0) {
@@ -713,13 +741,81 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
     return EST_ACCEPTING;
 }
 
-// The PreAcceptReplies to my instance (me, col[g]), applied in peer order exactly as one
+// The PreAcceptReplies to the instance (row, c) I lead, applied in peer order (ctl) exactly as one
 // handle_msg_pre_accept_reply call each (messages.rs:96-270) -- but on a register copy of the
-// instance and of its reply table: every input is loaded up front, the result is stored once.
-#ifndef EP_FLAT_LOADS
-#define EP_FLAT_LOADS 0                          // 1: every input row loaded unconditionally from clamped addresses -- measured SLOWER here
-                                                 // (25.2 vs 21.7 us per launch, profiles/r2w_ep_flat.log), unlike the tally's round 1
-#endif
+// instance and of its reply table: the caller loads every incoming reply up front (in_f / in_b / in_s / in_d, row p = peer
+// p's; my own row unused), the result is stored once.  dec = 0 / EST_ACCEPTING / EST_COMMITTED with (dseq, dd).
+// (Loading every input row unconditionally from clamped addresses was measured SLOWER for this kernel -- 25.2 vs 21.7 us per
+// launch, profiles/r2w_ep_flat.log -- unlike the MultiPaxos tally's round 1; the variant is gone.)
+template <int NR>
+__device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
+                                                   const uint32_t (&in_f)[NR], const uint64_t (&in_b)[NR], const uint64_t (&in_s)[NR],
+                                                   const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR]) {
+    const EpView &v = L.v;
+    const uint32_t R = v.R;
+    const bool h = L.held(row, c);
+    const size_t i = L.ix(row, c);
+    // the instance and the replies it already holds
+    uint32_t st = h ? v.status[i] : 0u, acks = h ? v.pa_acks[i] : 0u;
+    const uint64_t b = h ? v.bal[i] : 0ull;
+    const uint32_t bk = h ? v.bk[i] : 0u;
+    const bool avoid = h && v.recovery && v.avoid[i];
+    const uint32_t before = st, acks0 = acks;
+    uint64_t ps[NR]; uint32_t pd[NR][NR];
+#pragma unroll
+    for (int p = 0; p < NR; p++) {
+        const bool on = (acks >> p) & 1u;
+        ps[p] = on ? v.pa_seq[L.ps_ix(row, c, p)] : 0ull;
+#pragma unroll
+        for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[L.pd_ix(row, c, p, k)] : EP_NONE;
+    }
+    dseq = 0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
+    for (uint32_t oi = 0; oi < R; oi++) {
+        const uint32_t p = (ctl >> (3 * oi)) & 7u;
+        if (p == v.me || p >= R) continue;
+        uint32_t f = 0; uint64_t rb = 0, rs = 0;
+#pragma unroll
+        for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = in_f[q]; rb = in_b[q]; rs = in_s[q]; }
+        if (!(f & 1u) || !h) continue;
+        if (st != EST_PREACCEPTING || (rb > 0 && b != rb) || !(bk & 1u)) continue;   // :129-134
+        if ((acks >> p) & 1u) continue;                                      // :136-138
+        if (rb > 0) {                                                        // :141-144
+#pragma unroll
+            for (int q = 0; q < NR; q++)
+                if ((uint32_t)q == p) {
+                    ps[q] = rs;
+#pragma unroll
+                    for (int k = 0; k < NR; k++) pd[q][k] = in_d[q][k];
+                }
+            acks |= 1u << p;
+        }
+        const int next = ep_eval<NR>(v, acks, ps, pd, ex, avoid, dseq, dd);
+        if (next) st = (uint32_t)next;
+    }
+    // write back: new replies, the ack mask, the decision
+    const uint32_t fresh = acks & ~acks0;
+#pragma unroll
+    for (int p = 0; p < NR; p++)
+        if ((fresh >> p) & 1u) {
+            v.pa_seq[L.ps_ix(row, c, p)] = ps[p];
+#pragma unroll
+            for (int k = 0; k < NR; k++)
+                if ((uint32_t)k < R) v.pa_deps[L.pd_ix(row, c, p, k)] = pd[p][k];
+        }
+    if (fresh) v.pa_acks[i] = (uint8_t)acks;
+    dec = 0;
+    if (h && before == EST_PREACCEPTING && st != EST_PREACCEPTING) {
+        v.seq[i] = dseq;
+#pragma unroll
+        for (int k = 0; k < NR; k++) if ((uint32_t)k < R) v.deps[L.dx(row, c, k)] = dd[k];
+        v.status[i] = (uint8_t)st;
+        if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c); dec = EST_COMMITTED; }   // :158-206
+        else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
+    }
+}
+
 template <int NR>
 __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
                                                                     const uint64_t *__restrict__ ballot,
@@ -731,67 +827,10 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
                                                                     uint8_t *__restrict__ decision, uint64_t *__restrict__ d_seq,
                                                                     uint32_t *__restrict__ d_deps, const uint8_t *__restrict__ rows) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    EpLane L(v, g < v.G ? g : 0);
+    EpLaneT<NR> L(v, g < v.G ? g : 0);
     if (g < v.G) {
-        const uint32_t c = col[g], row = (rows && rows[g] < v.R) ? rows[g] : v.me, R = v.R;
-        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
-        const uint32_t ex = exploded ? exploded[g] : 0u;
-        const bool h = L.held(row, c);
-        const size_t i = L.ix(row, c);
-        // the incoming replies
+        const uint32_t R = v.R;
         uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
-#if EP_FLAT_LOADS
-        // every row loaded unconditionally from a clamped (always valid) address and zeroed afterwards where it does not
-        // count: `on ? load : 0` compiles to one basic block per peer with a wait at its end -- NR memory round trips in a
-        // row, and the instance's words and its reply table behind them as further dependent rounds (the tally's round 1
-        // had the same shape)
-#pragma unroll
-        for (int p = 0; p < NR; p++) {
-            const uint32_t pp = (uint32_t)p < R ? (uint32_t)p : 0u;
-            const bool on = (uint32_t)p < R && (uint32_t)p != v.me;
-            const size_t o = (size_t)pp * v.G + g;
-            const uint32_t f_ = flags[o];
-            const uint64_t b_ = ballot[o], s_ = seq[o];
-            in_f[p] = on ? f_ : 0u; in_b[p] = on ? b_ : 0ull; in_s[p] = on ? s_ : 0ull;
-#pragma unroll
-            for (int k = 0; k < NR; k++) {
-                const uint32_t kk = (uint32_t)k < R ? (uint32_t)k : 0u;
-                const uint32_t d_ = deps[((size_t)pp * R + kk) * v.G + g];
-                in_d[p][k] = (on && (uint32_t)k < R) ? d_ : EP_NONE;
-            }
-        }
-        // the instance (its ring cell exists whether or not the column is still held) ...
-        const uint32_t st_ = v.status[i], ak_ = v.pa_acks[i], bk_ = v.bk[i];
-        const uint64_t bal_ = v.bal[i];
-        uint32_t st = h ? st_ : 0u, acks = h ? ak_ : 0u;
-        const uint64_t b = h ? bal_ : 0ull;
-        const uint32_t bk = h ? bk_ : 0u;
-        const bool avoid = h && v.recovery && v.avoid[i];
-        const uint32_t before = st, acks0 = acks;
-        // ... and the replies it already holds: one block, entered only by an instance that holds any
-        uint64_t ps[NR]; uint32_t pd[NR][NR];
-#pragma unroll
-        for (int p = 0; p < NR; p++) {
-            ps[p] = 0ull;
-#pragma unroll
-            for (int k = 0; k < NR; k++) pd[p][k] = EP_NONE;
-        }
-        if (acks) {
-#pragma unroll
-            for (int p = 0; p < NR; p++) {
-                const uint32_t pp = (uint32_t)p < R ? (uint32_t)p : 0u;
-                const bool on = (acks >> p) & 1u;
-                const uint64_t s_ = v.pa_seq[L.ps_ix(row, c, pp)];
-                ps[p] = on ? s_ : 0ull;
-#pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    const uint32_t kk = (uint32_t)k < R ? (uint32_t)k : 0u;
-                    const uint32_t d_ = v.pa_deps[L.pd_ix(row, c, pp, kk)];
-                    pd[p][k] = (on && (uint32_t)k < R) ? d_ : EP_NONE;
-                }
-            }
-        }
-#else
 #pragma unroll
         for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && (uint32_t)p != v.me;
@@ -800,71 +839,34 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
 #pragma unroll
             for (int k = 0; k < NR; k++) in_d[p][k] = (on && (uint32_t)k < R) ? deps[((size_t)p * R + k) * v.G + g] : EP_NONE;
         }
-        // the instance and the replies it already holds
-        uint32_t st = h ? v.status[i] : 0u, acks = h ? v.pa_acks[i] : 0u;
-        const uint64_t b = h ? v.bal[i] : 0ull;
-        const uint32_t bk = h ? v.bk[i] : 0u;
-        const bool avoid = h && v.recovery && v.avoid[i];
-        const uint32_t before = st, acks0 = acks;
-        uint64_t ps[NR]; uint32_t pd[NR][NR];
-#pragma unroll
-        for (int p = 0; p < NR; p++) {
-            const bool on = (acks >> p) & 1u;
-            ps[p] = on ? v.pa_seq[L.ps_ix(row, c, p)] : 0ull;
-#pragma unroll
-            for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[L.pd_ix(row, c, p, k)] : EP_NONE;
-        }
-#endif
-        uint64_t dseq = 0; uint32_t dd[NR];
-#pragma unroll
-        for (int k = 0; k < NR; k++) dd[k] = EP_NONE;
-        for (uint32_t oi = 0; oi < R; oi++) {
-            const uint32_t p = (ctl >> (3 * oi)) & 7u;
-            if (p == v.me || p >= R) continue;
-            uint32_t f = 0; uint64_t rb = 0, rs = 0;
-#pragma unroll
-            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = in_f[q]; rb = in_b[q]; rs = in_s[q]; }
-            if (!(f & 1u) || !h) continue;
-            if (st != EST_PREACCEPTING || (rb > 0 && b != rb) || !(bk & 1u)) continue;   // :129-134
-            if ((acks >> p) & 1u) continue;                                      // :136-138
-            if (rb > 0) {                                                        // :141-144
-#pragma unroll
-                for (int q = 0; q < NR; q++)
-                    if ((uint32_t)q == p) {
-                        ps[q] = rs;
-#pragma unroll
-                        for (int k = 0; k < NR; k++) pd[q][k] = in_d[q][k];
-                    }
-                acks |= 1u << p;
-            }
-            const int next = ep_eval<NR>(v, acks, ps, pd, ex, avoid, dseq, dd);
-            if (next) st = (uint32_t)next;
-        }
-        // write back: new replies, the ack mask, the decision
-        const uint32_t fresh = acks & ~acks0;
-#pragma unroll
-        for (int p = 0; p < NR; p++)
-            if ((fresh >> p) & 1u) {
-                v.pa_seq[L.ps_ix(row, c, p)] = ps[p];
-#pragma unroll
-                for (int k = 0; k < NR; k++)
-                    if ((uint32_t)k < R) v.pa_deps[L.pd_ix(row, c, p, k)] = pd[p][k];
-            }
-        if (fresh) v.pa_acks[i] = (uint8_t)acks;
-        uint8_t dec = 0;
-        if (h && before == EST_PREACCEPTING && st != EST_PREACCEPTING) {
-            v.seq[i] = dseq;
-#pragma unroll
-            for (int k = 0; k < NR; k++) if ((uint32_t)k < R) v.deps[L.dx(row, c, k)] = dd[k];
-            v.status[i] = (uint8_t)st;
-            if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c); dec = EST_COMMITTED; }   // :158-206
-            else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
-        }
+        uint8_t dec; uint64_t dseq; uint32_t dd[NR];
+        ep_pa_replies_lane<NR>(L, (rows && rows[g] < R) ? rows[g] : v.me, col[g], order ? order[g] : SMR_CTL_IDENTITY,
+                               exploded ? exploded[g] : 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
         decision[g] = dec; d_seq[g] = dec ? dseq : 0ull;
 #pragma unroll
         for (int k = 0; k < NR; k++) if ((uint32_t)k < R) d_deps[(size_t)k * v.G + g] = dec ? dd[k] : EP_NONE;
     }
     L.flush();
+}
+
+// the AcceptReplies to the instance (row, c) I lead: flags / ballot rows by peer (stride G), peers in ctl order, one
+// handle_msg_accept_reply each (messages.rs:348-436); true = the instance went from Accepting to Committed here
+template <int NR>
+__device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR> &L, uint32_t row, uint32_t c, uint32_t ctl,
+                                                       const uint8_t *__restrict__ flags, const uint64_t *__restrict__ ballot,
+                                                       uint64_t fixed_ballot) {
+    const EpView &v = L.v;
+    const uint32_t R = v.R;
+    const bool h = L.held(row, c);
+    const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
+    for (uint32_t oi = 0; oi < R; oi++) {
+        const uint32_t p = (ctl >> (3 * oi)) & 7u;
+        if (p == v.me || p >= R) continue;
+        const size_t o = (size_t)p * v.G + L.g;
+        if (!(flags[o] & 1)) continue;
+        L.accept_reply(p, row, c, ballot ? ballot[o] : fixed_ballot);
+    }
+    return h && before == EST_ACCEPTING && v.status[L.ix(row, c)] >= EST_COMMITTED;
 }
 
 __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
@@ -874,20 +876,9 @@ __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, 
                                                                 uint8_t *__restrict__ committed, const uint8_t *__restrict__ rows) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     EpLane L(v, g < v.G ? g : 0);
-    if (g < v.G) {
-        const uint32_t c = col[g], row = (rows && rows[g] < v.R) ? rows[g] : v.me, R = v.R;
-        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
-        const bool h = L.held(row, c);
-        const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
-        for (uint32_t oi = 0; oi < R; oi++) {
-            const uint32_t p = (ctl >> (3 * oi)) & 7u;
-            if (p == v.me || p >= R) continue;
-            const size_t o = (size_t)p * v.G + g;
-            if (!(flags[o] & 1)) continue;
-            L.accept_reply(p, row, c, ballot[o]);
-        }
-        committed[g] = (h && before == EST_ACCEPTING && v.status[L.ix(row, c)] >= EST_COMMITTED) ? 1 : 0;
-    }
+    if (g < v.G)
+        committed[g] = ep_accept_replies_lane(L, (rows && rows[g] < v.R) ? rows[g] : v.me, col[g], order ? order[g] : SMR_CTL_IDENTITY,
+                                              flags, ballot, 0ull) ? 1 : 0;
     L.flush();
 }
 
@@ -1091,6 +1082,131 @@ __global__ __launch_bounds__(256) void ep_flags_eq_kernel(uint32_t G, const uint
 __global__ __launch_bounds__(256) void ep_fill_kernel(uint32_t G, uint8_t *__restrict__ p8, uint8_t v8, uint64_t *__restrict__ p64, uint64_t v64) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g < G) { p8[g] = v8; p64[g] = v64; }
+}
+
+// ---- one tick of a co-located cluster in ONE launch -----------------------------------------------------------------------
+// A block = R wavefronts over one tile of 64 groups: wavefront q is replica q of those groups (only wavefront q ever touches
+// replica q's state), lane = group.  The tick's handlers run in the order smr_ep_cluster_tick has always fixed -- every
+// replica proposes; every acceptor takes the PreAccepts senders ascending; then command leaders ascending: PreAcceptReplies,
+// the Accept round where the slow path was taken, AcceptReplies, CommitNotices -- as a sequence of steps; the messages cross
+// wavefronts through global arrays (the caller's out[] arrays, the reply stacks) with a block barrier where a step reads what
+// another wavefront's step wrote.  Execution (durability.rs:136-160) runs behind a handler on the same lane instead of as a
+// launch of its own.  115 launches of 1024 wavefronts each became one launch of 5120: the per-group work of different
+// replicas overlaps, and nothing waits for a launch boundary.
+template <int NR>
+struct EpClusterArgs {
+    uint32_t R, G, execute, quiet;               // quiet: handlers that can move no commit bar skip the execution pass (no recovery)
+    EpView v[NR];
+    EpExec x[NR];
+    const uint8_t *keys[NR];
+    const uint8_t *drop[NR * NR];                // [s * NR + q] (may be NULL)
+    smr_ep_cluster_out out[NR];
+    uint8_t *r_flags, *a_flags;                  // [s][q][G]   PreAcceptReply / AcceptReply of q to leader s
+    uint64_t *r_seq;                             // [s][q][G]
+    uint32_t *r_deps;                            // [s][q][R][G]
+};
+
+template <int NR>
+__global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
+    __shared__ uint32_t sh_slow;
+    const uint32_t q = SMR_WAVE_UNIFORM(threadIdx.x >> 6), R = a.R, G = a.G;
+    const uint32_t g0 = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const bool live = g0 < G;
+    const uint32_t g = live ? g0 : 0u;
+    const EpView &v = a.v[q];
+    const EpExec &x = a.x[q];
+    EpLaneT<NR> L(v, g);
+    EpExecLaneT<NR> E(v, x, L, g);
+    const uint32_t n_steps = 1u + R + 4u * R;
+    bool slow_round = true;
+#pragma unroll 1
+    for (uint32_t t = 0; t < n_steps; t++) {
+        bool handled = false, can_commit = false, barrier = true;
+        if (t == 0) {                                                        // every replica proposes
+            if (live) {
+                const smr_ep_cluster_out &o = a.out[q];
+                uint8_t of; uint32_t oc; uint64_t os; uint32_t d[NR];
+                ep_propose_lane<NR>(L, a.keys[q][g], 0u, of, oc, os, d);
+                o.proposed[g] = of; o.col[g] = oc; o.seq0[g] = os;
+#pragma unroll
+                for (int i = 0; i < NR; i++) if ((uint32_t)i < R) o.deps0[(size_t)i * G + g] = d[i];
+                handled = true;
+            }
+        } else if (t <= R) {                                                 // acceptor q: the PreAccept of sender s
+            const uint32_t s = t - 1u;
+            barrier = t == R;
+            if (s != q && live) {
+                const smr_ep_cluster_out &o = a.out[s];
+                const uint8_t *dm = a.drop[s * NR + q];
+                const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
+                uint8_t of; uint64_t ob, os; uint32_t d[NR];
+                ep_acceptor_lane<0, NR>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
+                const size_t ro = ((size_t)s * R + q) * G + g;
+                a.r_flags[ro] = of; a.r_seq[ro] = os;
+#pragma unroll
+                for (int i = 0; i < NR; i++) if ((uint32_t)i < R) a.r_deps[(((size_t)s * R + q) * R + i) * G + g] = d[i];
+                handled = true;
+            }
+        } else {
+            const uint32_t s = (t - 1u - R) >> 2, ph = (t - 1u - R) & 3u;
+            const smr_ep_cluster_out &o = a.out[s];
+            if (ph == 0) {                                                   // leader s: its PreAcceptReplies, peers ascending
+                if (q == s) {
+                    uint8_t dec = 0;
+                    if (live) {
+                        uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
+#pragma unroll
+                        for (int p = 0; p < NR; p++) {
+                            const bool on = (uint32_t)p < R && (uint32_t)p != s;
+                            const size_t ro = ((size_t)s * R + p) * G + g;
+                            in_f[p] = on ? a.r_flags[ro] : 0u; in_s[p] = on ? a.r_seq[ro] : 0ull;
+                            in_b[p] = (in_f[p] & 1u) ? (uint64_t)(s + 1u) : 0ull;   // an acceptor replies with the message's ballot
+#pragma unroll
+                            for (int k = 0; k < NR; k++)
+                                in_d[p][k] = (on && (uint32_t)k < R) ? a.r_deps[(((size_t)s * R + p) * R + k) * G + g] : EP_NONE;
+                        }
+                        uint64_t dseq; uint32_t dd[NR];
+                        ep_pa_replies_lane<NR>(L, s, o.col[g], SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
+                        o.decision[g] = dec; o.seq[g] = dec ? dseq : 0ull;
+#pragma unroll
+                        for (int k = 0; k < NR; k++) if ((uint32_t)k < R) o.deps[(size_t)k * G + g] = dec ? dd[k] : EP_NONE;
+                        handled = true; can_commit = true;
+                    }
+                    const int any_slow = __any(dec == EST_ACCEPTING);
+                    if ((threadIdx.x & 63u) == 0) sh_slow = any_slow ? 1u : 0u;
+                }
+            } else if (ph == 1) {                                            // the Accept round, where leader s took the slow path
+                slow_round = sh_slow != 0;                                   // (block-uniform: read behind the barrier of ph 0)
+                barrier = slow_round;
+                if (slow_round && q != s && live) {
+                    uint8_t of; uint64_t ob, os; uint32_t d[NR];
+                    ep_acceptor_lane<1, NR>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
+                                            a.keys[s][g], of, ob, os, d);
+                    a.a_flags[((size_t)s * R + q) * G + g] = of;
+                    handled = true;
+                }
+            } else if (ph == 2) {                                            // leader s: the AcceptReplies, then what is committed
+                if (q == s && live) {
+                    const bool acc = slow_round && ep_accept_replies_lane<NR>(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G,
+                                                                               nullptr, (uint64_t)(s + 1u));
+                    o.committed[g] = (o.decision[g] == EST_COMMITTED || acc) ? 1 : 0;
+                    handled = true; can_commit = true;
+                }
+            } else {                                                         // the CommitNotices of leader s
+                barrier = false;                                             // (the next step that reads across wavefronts has its own in front)
+                if (q != s && live) {
+                    uint8_t of; uint64_t ob, os; uint32_t d[NR];
+                    ep_acceptor_lane<2, NR>(L, o.committed[g] & 1, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
+                                            os, d);
+                    handled = true; can_commit = true;
+                }
+            }
+        }
+        if (handled && a.execute && (can_commit || !a.quiet)) ep_exec_after_handler<NR>(v, x, E);
+        if (barrier) __syncthreads();
+    }
+    L.flush();
+    if (a.execute) E.flush();
 }
 }  // namespace smr
 
@@ -1402,12 +1518,14 @@ int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host,
     return SMR_OK;
 }
 
-/* ---- one tick of a co-located EPaxos cluster as ONE call (summerset_amd/ep_cluster.py's closed loop, launch by launch) ---- */
+/* ---- one tick of a co-located EPaxos cluster as ONE call: one launch (ep_cluster_tick_kernel), or -- mode 1 -- the handler
+ * kernels back to back, launch by launch, as summerset_amd/ep_cluster.py's closed loop drives them ---- */
 struct smr_ep_cluster {
-    uint32_t R = 0, G = 0;
+    uint32_t R = 0, G = 0, mode = 0;
     smr_ep_replica *rep[SMR_MAX_REPLICAS] = {};
     char *base = nullptr;
-    // per command leader s (all device): the PreAcceptReplies / AcceptReplies of its peers stacked by peer id, its flag arrays
+    // per command leader s (all device): the PreAcceptReplies / AcceptReplies of its peers stacked by peer id ([s][q][G]: the
+    // one-launch tick indexes them from r_flags[0] / r_seq[0] / r_deps[0] / a_flags[0]), its flag arrays (mode 1)
     uint8_t *r_flags[SMR_MAX_REPLICAS], *a_flags[SMR_MAX_REPLICAS], *slow[SMR_MAX_REPLICAS], *acc[SMR_MAX_REPLICAS], *peer_c[SMR_MAX_REPLICAS];
     uint8_t *masked;                                         // the PreAccept's flags behind a drop mask
     uint64_t *r_ballot[SMR_MAX_REPLICAS], *r_seq[SMR_MAX_REPLICAS], *a_ballot[SMR_MAX_REPLICAS], *bal_c[SMR_MAX_REPLICAS];
@@ -1419,24 +1537,36 @@ int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluste
     if (n < 3 || n > SMR_MAX_REPLICAS) return fail(SMR_ERR_ARG, "epaxos cluster: 3..8 replicas");
     for (uint32_t r = 0; r < n; r++) {
         if (!reps[r]) return fail(SMR_ERR_ARG, "epaxos cluster: null replica");
-        if (reps[r]->cfg.population != n || reps[r]->cfg.me != r || reps[r]->cfg.n_groups != reps[0]->cfg.n_groups)
+        const smr_ep_cfg &k = reps[r]->cfg, &k0 = reps[0]->cfg;
+        if (k.population != n || k.me != r || k.n_groups != k0.n_groups)
             return fail(SMR_ERR_ARG, "epaxos cluster: replica r must be created with me = r, population = n and the same groups");
+        // the tick's message layout and its execution-pass rule are the cluster's, not a replica's: a mixed cluster would
+        // quietly leave the handler-by-handler loop
+        if (k.window != k0.window || k.n_keys != k0.n_keys || k.execute != k0.execute || k.recovery != k0.recovery ||
+            k.optimized_quorum != k0.optimized_quorum)
+            return fail(SMR_ERR_ARG, "epaxos cluster: the replicas must agree in window, n_keys, execute, recovery and optimized_quorum");
     }
     smr_ep_cluster *c = new smr_ep_cluster();
     c->R = n; c->G = reps[0]->cfg.n_groups;
     for (uint32_t r = 0; r < n; r++) c->rep[r] = reps[r];
     const size_t G = c->G, R = n;
-    // 8-byte arrays first; everything zero: a leader's own row of the stacks is never written and never read as a reply
-    const size_t per64 = (R * G) * 3 + G, per32 = R * R * G, per8 = (R * G) * 2 + G * 3;
-    const size_t bytes = R * (per64 * 8 + per32 * 4 + per8) + G + 4096;
+    // 8-byte arrays first; everything zero: a leader's own row of the stacks is never written and never read as a reply.
+    // Each kind of stack is ONE array over the leaders ([s][q]...), the per-leader pointers are views of it.
+    const size_t n64 = R * (R * G) * 3 + R * G, n32 = R * (R * R * G), n8 = R * (R * G) * 2 + R * G * 3 + G;
+    const size_t bytes = n64 * 8 + n32 * 4 + n8 + 4096;
     if (hipMalloc((void **)&c->base, bytes) != hipSuccess) { delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMalloc failed"); }
     if (hipMemset(c->base, 0, bytes) != hipSuccess) { (void)hipFree(c->base); delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMemset failed"); }
     uint64_t *p64 = (uint64_t *)c->base;
-    for (uint32_t s = 0; s < R; s++) { c->r_ballot[s] = p64; p64 += R * G; c->r_seq[s] = p64; p64 += R * G; c->a_ballot[s] = p64; p64 += R * G; c->bal_c[s] = p64; p64 += G; }
+    for (uint32_t s = 0; s < R; s++) { c->r_ballot[s] = p64; p64 += R * G; }
+    for (uint32_t s = 0; s < R; s++) { c->r_seq[s] = p64; p64 += R * G; }
+    for (uint32_t s = 0; s < R; s++) { c->a_ballot[s] = p64; p64 += R * G; }
+    for (uint32_t s = 0; s < R; s++) { c->bal_c[s] = p64; p64 += G; }
     uint32_t *p32 = (uint32_t *)p64;
     for (uint32_t s = 0; s < R; s++) { c->r_deps[s] = p32; p32 += R * R * G; }
     uint8_t *p8 = (uint8_t *)p32;
-    for (uint32_t s = 0; s < R; s++) { c->r_flags[s] = p8; p8 += R * G; c->a_flags[s] = p8; p8 += R * G; c->slow[s] = p8; p8 += G; c->acc[s] = p8; p8 += G; c->peer_c[s] = p8; p8 += G; }
+    for (uint32_t s = 0; s < R; s++) { c->r_flags[s] = p8; p8 += R * G; }
+    for (uint32_t s = 0; s < R; s++) { c->a_flags[s] = p8; p8 += R * G; }
+    for (uint32_t s = 0; s < R; s++) { c->slow[s] = p8; p8 += G; c->acc[s] = p8; p8 += G; c->peer_c[s] = p8; p8 += G; }
     c->masked = p8;
     void *stream = nullptr;
     for (uint32_t s = 0; s < R; s++)
@@ -1456,6 +1586,34 @@ void smr_ep_cluster_destroy(smr_ep_cluster *c) {
     delete c;
 }
 
+int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode) {
+    if (!c) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
+    if (mode > 1) return fail(SMR_ERR_ARG, "epaxos cluster: mode must be 0 (one launch per tick) or 1 (one launch per handler)");
+    c->mode = mode;
+    return SMR_OK;
+}
+
+}  // extern "C"
+
+template <int NR>
+static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev,
+                                      const smr_ep_cluster_out *out, void *stream) {
+    const uint32_t R = c->R, G = c->G;
+    EpClusterArgs<NR> a;
+    memset(&a, 0, sizeof(a));
+    a.R = R; a.G = G; a.execute = c->rep[0]->cfg.execute; a.quiet = !c->rep[0]->cfg.recovery;
+    for (uint32_t r = 0; r < R; r++) {
+        a.v[r] = c->rep[r]->v; a.x[r] = c->rep[r]->x; a.keys[r] = keys_dev[r]; a.out[r] = out[r];
+        for (uint32_t q = 0; q < R; q++) a.drop[r * NR + q] = drop_dev ? drop_dev[(size_t)r * R + q] : nullptr;
+    }
+    a.r_flags = c->r_flags[0]; a.a_flags = c->a_flags[0]; a.r_seq = c->r_seq[0]; a.r_deps = c->r_deps[0];
+    hipLaunchKernelGGL(ep_cluster_tick_kernel<NR>, dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+extern "C" {
+
 int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev, const smr_ep_cluster_out *out,
                         void *stream) {
     if (!c || !keys_dev || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
@@ -1464,9 +1622,12 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
         if (!keys_dev[s] || !out[s].proposed || !out[s].col || !out[s].seq0 || !out[s].deps0 || !out[s].decision || !out[s].committed ||
             !out[s].seq || !out[s].deps)
             return fail(SMR_ERR_ARG, "epaxos cluster: null key or output array");
+    if (c->mode == 0)
+        return R <= 5 ? ep_cluster_tick_one_launch<5>(c, keys_dev, drop_dev, out, stream)
+                      : ep_cluster_tick_one_launch<EMAXR>(c, keys_dev, drop_dev, out, stream);
     const dim3 grid((G + 255) / 256), block(256);
     int rc;
-    // With execution on every handler is followed by the execution kernel, which does something only where a commit bar
+    // mode 1, launch by launch.  With execution on every handler is followed by the execution kernel, which does something only where a commit bar
     // moved.  A proposal (the leader's own reply alone is below any quorum) and an acceptor's PreAccept / Accept handling
     // (no commit; its leader-bookkeeping branch exists only under explicit prepare) move none, so the 45 launches behind
     // them are left out -- unless the replica was created with recovery.  (smr_ep_exec_poll then reports the tick's last

@@ -7,6 +7,14 @@
 
 #include "../../include/summerset_hip.h"
 
+// a value every lane of the wavefront holds alike (e.g. the wavefront's index in its block), said to the compiler so that what
+// is indexed by it is loaded through the scalar unit; the host pass (and tests/hostsim) see the plain value
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMR_WAVE_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define SMR_WAVE_UNIFORM(x) ((uint32_t)(x))
+#endif
+
 namespace smr {
 
 void set_error(const std::string &msg);

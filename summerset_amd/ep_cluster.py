@@ -65,12 +65,15 @@ def tick(reps, keys, drop=None, always_accept_round=False):
 
 
 class EPaxosCluster:
-    """The same closed loop as ONE C-ABI call per tick (`smr_ep_cluster_tick`, include/summerset_hip.h): the handler kernels
-    of all R replicas launched back to back by the library, the peers' replies written straight into each command leader's
-    stacked reply arrays -- no Python, no torch glue and no host read between them (the Accept round always runs).  `reps`
-    stay usable on their own (dump, exec_dump, the per-handler calls)."""
+    """The same closed loop as ONE C-ABI call per tick (`smr_ep_cluster_tick`, include/summerset_hip.h) -- and, by default, as
+    ONE LAUNCH: a block of the kernel is the R replicas (a wavefront each) of 64 groups, the handlers are steps of that kernel,
+    the peers' replies cross wavefronts through the cluster's reply stacks behind block barriers, execution runs behind its
+    handler on the same lane.  `per_handler_launches=True` keeps round 2's path: the handler kernels launched back to back
+    by the library (115 launches per tick at R = 5 with execution on) -- the decomposition the one-launch tick is checked
+    against.  No Python, no torch glue and no host read inside a tick either way (the Accept round runs wherever a leader of
+    the tile took the slow path).  `reps` stay usable on their own (dump, exec_dump, the per-handler calls)."""
 
-    def __init__(self, reps):
+    def __init__(self, reps, per_handler_launches=False):
         import ctypes as C
         from . import _lib
         self.reps, self.R, self.G = list(reps), len(reps), reps[0].G
@@ -79,6 +82,9 @@ class EPaxosCluster:
         h = C.c_void_p()
         _lib.check(self._L.smr_ep_cluster_create(arr, self.R, C.byref(h)))
         self._h = h
+        self._held = None                      # the last tick's drop masks: alive until the next tick's have replaced them
+        if per_handler_launches:
+            _lib.check(self._L.smr_ep_cluster_set_mode(self._h, 1))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -88,29 +94,38 @@ class EPaxosCluster:
     def __del__(self):
         self.close()
 
-    def tick(self, keys, drop=None, stream=None):
-        """keys[r]: uint8 [G] device tensor (0xFF = no proposal); drop[(s, q)] (optional): bool / uint8 [G], the PreAccept
-        from s to q is lost.  Returns per command leader dict(col, proposed, decision, committed, seq, deps) like `tick`."""
-        import ctypes as C
+    def new_outputs(self, dev):
+        """one set of the tick's output arrays (per command leader); pass it back as `tick(..., out=)` to reuse it"""
         import torch
-        from . import _lib
-        R, G, dev = self.R, self.G, keys[0].device
-        outs, held = (_lib.EpClusterOut * R)(), []
-        res = []
-        for s in range(R):
-            o = dict(proposed=torch.empty(G, dtype=torch.uint8, device=dev), col=torch.empty(G, dtype=torch.int32, device=dev),
+        R, G = self.R, self.G
+        return [dict(proposed=torch.empty(G, dtype=torch.uint8, device=dev), col=torch.empty(G, dtype=torch.int32, device=dev),
                      seq0=torch.empty(G, dtype=torch.int64, device=dev), deps0=torch.empty((R, G), dtype=torch.int32, device=dev),
                      decision=torch.empty(G, dtype=torch.uint8, device=dev), committed=torch.empty(G, dtype=torch.uint8, device=dev),
                      seq=torch.empty(G, dtype=torch.int64, device=dev), deps=torch.empty((R, G), dtype=torch.int32, device=dev))
+                for _ in range(R)]
+
+    def tick(self, keys, drop=None, stream=None, out=None):
+        """keys[r]: uint8 [G] device tensor (0xFF = no proposal); drop[(s, q)] (optional): bool / uint8 [G], the PreAccept
+        from s to q is lost.  Returns per command leader dict(col, proposed, decision, committed, seq, deps) like `tick`
+        (fresh arrays, or the caller's `out` from `new_outputs`)."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        R, dev = self.R, keys[0].device
+        outs = (_lib.EpClusterOut * R)()
+        res = out if out is not None else self.new_outputs(dev)
+        for s in range(R):
             for n, _ in _lib.EpClusterOut._fields_:
-                setattr(outs[s], n, o[n].data_ptr())
-            res.append(o)
+                setattr(outs[s], n, res[s][n].data_ptr())
         kp = (C.c_void_p * R)(*[k.data_ptr() for k in keys])
-        dp = None
+        dp, masks = None, None
         if drop:
+            # uint8 copies of bool masks are temporaries of THIS call, and the call only enqueues work: they stay referenced
+            # by the object until the next tick (on whatever stream) has replaced them, so the allocator cannot hand their
+            # memory out while a kernel of this tick may still read it
             masks = {k: (v if v.dtype == torch.uint8 else v.to(torch.uint8)).contiguous() for k, v in drop.items()}
-            held.append(masks)
             dp = (C.c_void_p * (R * R))(*[(masks[(s, q)].data_ptr() if (s, q) in masks else None) for s in range(R) for q in range(R)])
         _lib.check(self._L.smr_ep_cluster_tick(self._h, kp, dp, outs, _lib.stream_ptr(stream)))
+        self._held = (masks, list(keys), res)
         return [dict(col=o["col"], proposed=o["proposed"], decision=o["decision"], committed=o["committed"], seq=o["seq"], deps=o["deps"])
                 for o in res]

@@ -287,10 +287,10 @@ def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
     import test_zz_ep_cluster_gpu as t
     with sim.patched():
         t.test_device_cluster_tick_matches_the_oracle_cluster("cpu", oracle, 300, 6, 0.15)
-        assert t.run_fused_vs_driver("cpu", 200, 6, 0.15, T=6) > 0              # smr_ep_cluster_tick: the loop as one C call
-        t.run_fused_vs_driver("cpu", 130, 16, 0.0, T=5, execute=False)
-        assert t.run_fused_vs_driver("cpu", 90, 4, 0.15, T=5, R=3, W=16) > 0    # populations 3 and 7 (the 8-replica kernel instances)
-        assert t.run_fused_vs_driver("cpu", 70, 6, 0.15, T=5, R=7, W=16) > 0
+        assert t.run_fused_vs_driver("cpu", 200, 6, 0.15, T=6, oracle=oracle) > 0    # smr_ep_cluster_tick: one launch / launch by launch / the driver / the oracles
+        t.run_fused_vs_driver("cpu", 130, 16, 0.0, T=5, execute=False, oracle=oracle)
+        assert t.run_fused_vs_driver("cpu", 90, 4, 0.15, T=5, R=3, W=16, oracle=oracle) > 0    # populations 3 and 7 (the 8-replica kernel instances)
+        assert t.run_fused_vs_driver("cpu", 70, 6, 0.15, T=5, R=7, W=16, oracle=oracle) > 0
 
 
 def test_spread_epaxos_exchange_on_the_host(sim):

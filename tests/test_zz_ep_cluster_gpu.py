@@ -39,39 +39,66 @@ def test_device_cluster_tick_matches_the_oracle_cluster(cuda, oracle, G, K, loss
     assert fast > 0 and (slow > 0 or loss == 0.0)
 
 
-def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32):
-    """`smr_ep_cluster_tick` (one C call per tick) against the handler-by-handler driver on a second set of replicas"""
+def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32, oracle=None):
+    """`smr_ep_cluster_tick` -- one C call per tick: as ONE launch (the default) and as the handler kernels back to back -- against
+    the handler-by-handler driver on a third set of replicas and, with `oracle`, against five oracles wired into the same
+    loop (tests/ep_cluster.py): every leader's outputs every tick, every replica's final state"""
     import torch
     import ep_cluster as ec
     from summerset_amd import EPaxosReplicaGroup, ep_cluster
-    a = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
-    b = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    mk = lambda: [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    a, a1, b = mk(), mk(), mk()
     fused = ep_cluster.EPaxosCluster(a)
+    launches = ep_cluster.EPaxosCluster(a1, per_handler_launches=True)
+    orcs = [oracle.EpOracle(G, R, me=r, W=W, n_keys=K, execute=execute) for r in range(R)] if oracle is not None else None
     from summerset_amd import SummersetError
     for wrong in (a[::-1], a[:2], a[:4] + [b[0]]):               # replica r must sit at index r, all of them, of one population
         with pytest.raises(SummersetError):
             ep_cluster.EPaxosCluster(wrong)
+    odd = EPaxosReplicaGroup(G, R, me=R - 1, window=W, n_keys=K, execute=not execute)   # a cluster is homogeneous
+    with pytest.raises(SummersetError):
+        ep_cluster.EPaxosCluster(a[:R - 1] + [odd])
     rng = np.random.default_rng(seed + G)
     dv = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     slow = 0
+    outs = fused.new_outputs(dev)                                # the caller's arrays, reused every tick
     for t in range(T):
         keys = ec.zipf_keys(rng, R, G, K)
         drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q and rng.random() < 0.7} if loss else None
         kd = [dv(keys[r]) for r in range(R)]
         dd = None if drop is None else {k: dv(v) for k, v in drop.items()}
-        oa = fused.tick(kd, dd)
+        oa = fused.tick(kd, dd, out=outs)
+        oa1 = launches.tick(kd, dd)
         ob = ep_cluster.tick(b, kd, dd, always_accept_round=True)
+        oo = ec.tick(orcs, keys, drop) if orcs is not None else None
         for s in range(R):
             for k in ob[s]:
                 assert np.array_equal(oa[s][k].cpu().numpy(), ob[s][k].cpu().numpy()), (t, s, k)
+                assert np.array_equal(oa1[s][k].cpu().numpy(), ob[s][k].cpu().numpy()), (t, s, k, "per-handler launches")
+                if oo is not None:
+                    assert np.array_equal(oa[s][k].cpu().numpy().view(oo[s][k].dtype), oo[s][k]), (t, s, k, "oracle")
             slow += int((ob[s]["decision"] == 2).sum())
     for r in range(R):
-        x, y = a[r].dump(), b[r].dump()
-        for n in y:
-            assert np.array_equal(x[n], y[n]), (r, n)
-        if execute:
-            x, y = a[r].exec_dump(), b[r].exec_dump()
+        y = b[r].dump()
+        for eng in (a, a1):
+            x = eng[r].dump()
             for n in y:
-                assert np.array_equal(x[n], y[n]), (r, "exec", n)
+                assert np.array_equal(x[n], y[n]), (r, n)
+        if orcs is not None:
+            z = orcs[r].dump()
+            x = a[r].dump()
+            for n in z:
+                assert np.array_equal(x[n], z[n]), (r, n, "oracle")
+        if execute:
+            y = b[r].exec_dump()
+            for eng in (a, a1):
+                x = eng[r].exec_dump()
+                for n in y:
+                    assert np.array_equal(x[n], y[n]), (r, "exec", n)
+            if orcs is not None:
+                z, x = orcs[r].exec_dump(), a[r].exec_dump()
+                for n in z:
+                    assert np.array_equal(x[n], z[n]), (r, "exec", n, "oracle")
     fused.close()
+    launches.close()
     return slow

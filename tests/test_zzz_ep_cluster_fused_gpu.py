@@ -6,19 +6,16 @@ import pytest
 
 from test_zz_ep_cluster_gpu import run_fused_vs_driver
 
-# Quarantined until its first device run: written after round 2's GPU minutes were spent (every scenario here passes on the
-# kernel-source emulator, tests/test_hostsim.py).  xfail(strict=False) = it RUNS on the device with the rest of the suite and
-# its outcome is reported (XPASS / xfailed), but a surprise here cannot turn the device suite red or stop `pytest -x` in front
-# of anything else.  Remove the mark once profiles/ holds its first device log (tools/r3a_first_call.sh).
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first device run pending (emulator-verified)")]
+pytestmark = pytest.mark.gpu          # first device run: GPUTEST_r02 (11 XPASS); quarantine removed in round 3
 
 
 @pytest.mark.parametrize("G,K,loss", [(700, 6, 0.15), (4096, 64, 0.0)])
-def test_fused_cluster_tick_is_the_driver_loop(cuda, G, K, loss):
-    slow = run_fused_vs_driver(cuda, G, K, loss)
+def test_fused_cluster_tick_is_the_driver_loop(cuda, oracle, G, K, loss):
+    slow = run_fused_vs_driver(cuda, G, K, loss, oracle=oracle)
     assert slow > 0 or loss == 0.0
 
 
-def test_fused_cluster_tick_other_populations(cuda):
-    assert run_fused_vs_driver(cuda, 900, 4, 0.15, T=6, R=3, W=16) > 0
-    assert run_fused_vs_driver(cuda, 700, 6, 0.15, T=6, R=7, W=16) > 0
+def test_fused_cluster_tick_other_populations(cuda, oracle):
+    assert run_fused_vs_driver(cuda, 900, 4, 0.15, T=6, R=3, W=16, oracle=oracle) > 0
+    assert run_fused_vs_driver(cuda, 700, 6, 0.15, T=6, R=7, W=16, oracle=oracle) > 0
+    run_fused_vs_driver(cuda, 1000, 16, 0.1, T=6, execute=False, oracle=oracle)        # a ragged last tile, execution off

@@ -9,11 +9,7 @@ import ep_cluster as ec
 import test_oracle_ep_recovery as tr
 from test_zz_ep_recovery_gpu import _EngineAsOracle
 
-# Quarantined until its first device run: written after round 2's GPU minutes were spent (every scenario here passes on the
-# kernel-source emulator, tests/test_hostsim.py).  xfail(strict=False) = it RUNS on the device with the rest of the suite and
-# its outcome is reported (XPASS / xfailed), but a surprise here cannot turn the device suite red or stop `pytest -x` in front
-# of anything else.  Remove the mark once profiles/ holds its first device log (tools/r3a_first_call.sh).
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first device run pending (emulator-verified)")]
+pytestmark = pytest.mark.gpu          # first device run: GPUTEST_r02 (11 XPASS); quarantine removed in round 3
 
 
 @pytest.mark.parametrize("G,seed,loss", [(700, 1, 0.0), (1500, 5, 0.15)])

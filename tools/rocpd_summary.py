@@ -1,42 +1,53 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 rocpd SQLite database (`--kernel-trace --stats`) into a
-per-kernel text table: calls, total / average / min / max duration (us), share.
-usage: python tools/rocpd_summary.py <results.db> [> profiles/NAME_kernel_stats.txt]"""
+"""Summarise rocprofv3 rocpd SQLite databases (`--kernel-trace --stats`) into a per-kernel text table: calls, total /
+average / min / max duration (us), share.  A profiled command that starts child processes (bench.py runs every secondary
+leg in its own) leaves ONE database per process: pass a directory (searched recursively) or several files and the table
+covers all of them; `--only SUBSTR` keeps the databases that hold a kernel whose name contains SUBSTR (e.g. the process of
+the headline region: `--only mp_quorum_tally`).
+usage: python tools/rocpd_summary.py <results.db | dir> [...] [--only SUBSTR] [> profiles/NAME_kernel_stats.txt]"""
+import glob
+import os
 import sqlite3
 import sys
 
 
-def main(path):
+def kernel_rows(path):
     db = sqlite3.connect(path)
-    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                      "max(vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size) "
-                      "from kernels group by name order by sum(duration) desc").fetchall()
-    total = sum(r[2] for r in rows) or 1
+    try:
+        return db.execute("select name, duration, vgpr_count, sgpr_count, lds_size, scratch_size from kernels").fetchall()
+    except sqlite3.Error:
+        return []
+    finally:
+        db.close()
+
+
+def main(argv):
+    only, paths = None, []
+    it = iter(argv)
+    for a in it:
+        if a == "--only":
+            only = next(it)
+        elif os.path.isdir(a):
+            paths += sorted(glob.glob(os.path.join(a, "**", "*.db"), recursive=True))
+        else:
+            paths.append(a)
+    acc, used = {}, []
+    for p in paths:
+        rows = kernel_rows(p)
+        if only is not None and not any(only in r[0] for r in rows):
+            continue
+        used.append((p, len(rows)))
+        for n, d, vg, sg, lds, scr in rows:
+            e = acc.setdefault(n, [0, 0, 1 << 62, 0, vg, sg, lds, scr])
+            e[0] += 1; e[1] += d; e[2] = min(e[2], d); e[3] = max(e[3], d)
+    print("# %d database(s): %s" % (len(used), ", ".join("%s (%d dispatches)" % (os.path.basename(p), n) for p, n in used)))
+    total = sum(e[1] for e in acc.values()) or 1
     print("%-72s %7s %12s %10s %10s %10s %6s %5s %5s %6s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us",
                                                                  "max_us", "pct", "vgpr", "sgpr", "lds", "scratch"))
-    for n, c, s, a, mn, mx, vg, sg, lds, scr in rows:
+    for n, (c, s, mn, mx, vg, sg, lds, scr) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         print("%-72s %7d %12.1f %10.2f %10.2f %10.2f %6.2f %5s %5s %6s %7s" %
-              (n[:72], c, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / total, vg, sg, lds, scr))
-    try:
-        pmc = db.execute("select * from counters_collection limit 1").fetchall()
-        if pmc:
-            print("\n# PMC counters (avg per dispatch)")
-            cols = [c[1] for c in db.execute("pragma table_info('counters_collection')")]
-            ni, ci, vi = cols.index("kernel_name") if "kernel_name" in cols else None, None, None
-            for cand in ("counter_name", "name"):
-                if cand in cols:
-                    ci = cols.index(cand)
-            for cand in ("value", "counter_value"):
-                if cand in cols:
-                    vi = cols.index(cand)
-            if None not in (ni, ci, vi):
-                q = "select %s, %s, avg(%s), count(*) from counters_collection group by 1, 2 order by 1, 2" % (
-                    cols[ni], cols[ci], cols[vi])
-                for k, cn, v, n in db.execute(q):
-                    print("%-60s %-24s %18.1f  (n=%d)" % (k[:60], cn, v, n))
-    except sqlite3.Error:
-        pass
+              (n[:72], c, s / 1e3, s / c / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / total, vg, sg, lds, scr))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1:])
