@@ -56,14 +56,25 @@ def _leg_traffic(kernel):
 TIMEOUT_HORIZON = 72     # ticks of the default run (60 timed + 12 warm-up): --timeouts is the fraction of groups per THIS many ticks
 
 
+def n_regions(args):
+    return args.repeats if args.repeats > 0 else (9 if args.steps <= 30 else 3)
+
+
 def timeout_span(args):
-    return args.timeout_span if args.timeout_span is not None else max(args.steps + args.warmup, TIMEOUT_HORIZON)
+    """ticks the groups' timeout ticks are drawn from: the whole run (warm-up + every timed region), at least the horizon"""
+    return args.timeout_span if args.timeout_span is not None else max(args.steps * n_regions(args) + args.warmup, TIMEOUT_HORIZON)
+
+
+def timeout_frac(args):
+    """fraction of the groups that get a leader timeout somewhere in the span: --timeouts is per TIMEOUT_HORIZON ticks, so a longer
+    run (more timed regions) sees the same changes per tick"""
+    return args.timeouts if args.timeout_span is not None else min(1.0, args.timeouts * timeout_span(args) / TIMEOUT_HORIZON)
 
 
 def timeouts_text(args):
     span = timeout_span(args)
-    return "%.1f%% of the groups per %d ticks with a leader timeout (%.1f groups per tick)" % (
-        args.timeouts * 100, span, args.timeouts * args.groups / span)
+    return "%.2f%% of the groups per %d ticks with a leader timeout (%.1f groups per tick)" % (
+        timeout_frac(args) * 100, span, timeout_frac(args) * args.groups / span)
 
 
 def parse():
@@ -96,6 +107,10 @@ def parse():
                     "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
     ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
                     "kernels, plans and buffers; the collective is a device copy)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps ticks each, back to back, every one between its own barrier + "
+                    "synchronize pair; `value` / `ms_per_step` are the MEDIAN region's, the others are listed beside it (a 2 ms region "
+                    "carries +-25 %% box noise, VERDICT r2).  0 = 9 when steps <= 30, else 3.  The leader-timeout rate per tick is kept: "
+                    "the stream's timeout fraction grows with the run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
@@ -296,7 +311,8 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
     message a device tensor between the handlers, dependency-graph execution on."""
     from summerset_amd import EPaxosReplicaGroup, ep_cluster
     G, R, W, K = 65536, 5, 32, 64
-    reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    EXEC = os.environ.get("SMR_EPC_EXECUTE", "1") != "0"            # (experiments only: the tick without dependency-graph execution)
+    reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=EXEC) for r in range(R)]
     rng = np.random.default_rng(0x5EED5EED)
     zipf = 1.0 / np.arange(1, K + 1) ** 0.99
     zipf /= zipf.sum()
@@ -313,7 +329,7 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
             slow += (o["decision"] == 2).sum()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ex = sum(int(r.exec_dump()["counters"][0]) for r in reps)
+    ex = sum(int(r.exec_dump()["counters"][0]) for r in reps) if EXEC else 0
     line = {"workload": "EPaxos closed loop, %d groups x 5 replicas, every replica proposes 1 instance per group per tick (Zipf(0.99) keys "
                         "of 64), execution on; five replica objects on one GPU, messages stay on the device" % G,
             "value": int(committed.item()) / dt, "unit": "instances committed/s (handler calls of the Python driver included)",
@@ -325,7 +341,7 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
     del reps
     for name, per_handler in (("one_call_per_tick", False), ("one_call_per_tick_per_handler_launches", True)):
         try:
-            reps2 = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+            reps2 = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=EXEC) for r in range(R)]
             fused = ep_cluster.EPaxosCluster(reps2, per_handler_launches=per_handler)
             outs = fused.new_outputs(dev)
             for t in range(2):
@@ -347,7 +363,7 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
                    "value": n_inst / dt2, "unit": "instances committed/s", "ms_per_tick": dt2 / ticks * 1e3,
                    "tick_us_device_median": tick_us[len(tick_us) // 2], "tick_us_device_min": tick_us[0],
                    "same_commits_as_the_driver_loop": n_inst == int(committed.item()),
-                   "commands_executed": sum(int(r.exec_dump()["counters"][0]) for r in reps2)}
+                   "commands_executed": sum(int(r.exec_dump()["counters"][0]) for r in reps2) if EXEC else 0}
             if not per_handler:
                 # <= 370 B per instance for the tally (replies read, instance read / written); the tick as a whole
                 # -- proposals, 4 PreAccepts, the tally, 4 CommitNotices, execution per instance -- has no per-unit figure there,
@@ -808,8 +824,8 @@ def spread_main(args, torch, dist, rank, local, world, dev):
     job.preset_leader(0)
     mine = sorted({b for rk in job.ranks for b in rk.blocks} if virtual else job.blocks)
     n_ticks = args.warmup + args.steps
-    skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=args.timeouts, hb_every=H, rand_rows=S + 4, max_drop=2,
-               timeout_span=timeout_span(args))
+    skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=timeout_frac(args), hb_every=H, rand_rows=S + 4, max_drop=2,
+               timeout_span=timeout_span(args))                  # the co-located line's rate of leader changes per tick
     sts = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **skw) for b, (lo, hi) in ((b, shard.group_range(total, nr, b)) for b in mine)}
     pools = {b: [{k: torch.from_numpy(v).to(dev) for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")} for t in range(args.pool)]
              for b, st in sts.items()}
@@ -1035,13 +1051,14 @@ def main():
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4
-    n_timed = args.warmup + args.steps
+    reps = n_regions(args)
+    n_timed = args.warmup + reps * args.steps     # warm-up, then `reps` timed regions of exactly --steps ticks each
     n_ticks = n_timed + args.round_ticks          # the per-round pass goes on where the timed region stopped
     if args.fused:
         args.straggler_ticks = 0                  # the fused tick kernel and the side stream exclude each other
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
     eng.preset_leader(0)
-    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=args.timeouts,
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=timeout_frac(args),
                                  hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=timeout_span(args),
                                  group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
     # inputs resident in HBM before the clock starts
@@ -1093,22 +1110,25 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    c0 = sum(eng.counters(r)["commits"] for r in range(R))
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.warmup, n_timed, timed=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    eng.profile_enable(False)
-    c1 = sum(eng.counters(r)["commits"] for r in range(R))
-    commits = c1 - c0
+    regions = []                                  # (seconds, commits) of every timed region: MAX / SUM over ranks
+    for i in range(reps):
+        a = args.warmup + i * args.steps
+        c0 = sum(eng.counters(r)["commits"] for r in range(R))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(a, a + args.steps, timed=True)        # EXACTLY --steps ticks
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        eng.profile_enable(False)
+        c1 = sum(eng.counters(r)["commits"] for r in range(R))
+        regions.append(shard.reduce_metric(el, c1 - c0, device=dev))
+    elapsed, commits = sorted(regions)[len(regions) // 2]        # the median region (by time)
     rej = sum(eng.counters(r)["rejects"] for r in range(R))
     overflow = int(eng.dump(0)["overflow"].sum()) if G <= 4096 else None
-    elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)   # MAX over ranks, SUM over ranks
     # untimed: the same workload a few ticks further through the per-round kernels, an event pair around each
     if args.fused and args.round_ticks:
         eng.profile_enable(True)
@@ -1173,6 +1193,10 @@ def main():
         "n_gpus": world, "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "timed_regions": {"n": reps, "reported": "median region (by time)", "ms_per_step": [e / args.steps * 1e3 for e, _ in regions],
+                          "value": [c / e for e, c in regions],
+                          "note": "every region is exactly --steps ticks between its own barrier + synchronize pair, the regions run "
+                                  "back to back on one cluster (region i starts where i - 1 stopped); leader-timeout rate per tick constant"},
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, "
                                "heartbeat every %d ticks, %.0f%% ack loss (<= 2 lost per slot), %s"

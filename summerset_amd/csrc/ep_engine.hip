@@ -23,7 +23,10 @@
 // behind their own kernel when smr_ep_cfg.execute is set (see the comment on EpExec).
 //
 // Layout (group fastest): instance fields X[(row * W + (col & (W-1))) * G + g]; DepSets as R
-// consecutive such planes; the per-key highest columns hc[(key * R + row) * G + g].
+// consecutive such planes.  The per-key highest columns are the one array indexed by DATA (the command's key, different in
+// every group): group-major, hc[(g * n_keys + key) * R + row] -- a lane's R entries are 4 R contiguous bytes of its own
+// group's 4 R n_keys, so a wavefront's lookup touches 64-128 lines of 80 KB instead of 5 x (distinct keys) lines, every
+// one in a different 256 KB plane (= a different page: the [key][row][G] layout of rounds 1-2).
 #include <string.h>
 
 #include <vector>
@@ -47,7 +50,7 @@ struct EpView {
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
     uint32_t *len, *commit_bars;         // [R][G]
     uint32_t *my_nulls;                  // [G] null instances currently in my own row (first_null_slot need not scan at 0)
-    uint32_t *hc;                        // [n_keys][R][G]
+    uint32_t *hc;                        // [G][n_keys][R]
     unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits; explicit prepare outcomes:
                                          // Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op
     // explicit prepare (recovery != 0; pa_seq / pa_deps then hold every row: [R][W][R][G] / [R][W][R][R][G])
@@ -60,12 +63,59 @@ struct EpView {
     uint32_t *xv_deps;                   // [R][W][R][R][G]
 };
 
-template <int NR>
+// CACHE: the lane keeps its group's per-row scalars (row lengths, commit bars, my_nulls) in registers from load_scalars() to
+// store_scalars() -- the one-launch cluster tick runs ~15 handlers on a lane, and every one of them starts with these
+// words; a handler kernel of its own (CACHE = false) reads and writes them in place
+template <int NR, bool CACHE = false>
 struct EpLaneT {
     const EpView &v;
     const uint32_t g;
     unsigned int n_fast = 0, n_slow = 0, n_acc = 0, n_xc = 0, n_xa = 0, n_xp = 0, n_xn = 0;
+    uint32_t c_len[CACHE ? NR : 1], c_cb[CACHE ? NR : 1], c_nulls = 0;
     __device__ __forceinline__ EpLaneT(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
+    __device__ __forceinline__ void load_scalars() {
+        if (!CACHE) return;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) {
+            c_len[r] = (uint32_t)r < v.R ? v.len[(size_t)r * v.G + g] : 0u;
+            c_cb[r] = (uint32_t)r < v.R ? v.commit_bars[(size_t)r * v.G + g] : 0u;
+        }
+        c_nulls = v.my_nulls[g];
+    }
+    __device__ __forceinline__ void store_scalars() const {
+        if (!CACHE) return;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++)
+            if ((uint32_t)r < v.R) { v.len[(size_t)r * v.G + g] = c_len[r]; v.commit_bars[(size_t)r * v.G + g] = c_cb[r]; }
+        v.my_nulls[g] = c_nulls;
+    }
+    __device__ __forceinline__ uint32_t get_len(uint32_t row) const {
+        if (!CACHE) return v.len[(size_t)row * v.G + g];
+        uint32_t x = 0;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) x = c_len[r];
+        return x;
+    }
+    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) {
+        if (!CACHE) { v.len[(size_t)row * v.G + g] = x; return; }
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) c_len[r] = (uint32_t)r == row ? x : c_len[r];   // (a select per register: a
+                                                                                              // conditional store would become a store through a chosen POINTER and keep the array in scratch)
+    }
+    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const {
+        if (!CACHE) return v.commit_bars[(size_t)row * v.G + g];
+        uint32_t x = 0;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) x = c_cb[r];
+        return x;
+    }
+    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) {
+        if (!CACHE) { v.commit_bars[(size_t)row * v.G + g] = x; return; }
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) c_cb[r] = (uint32_t)r == row ? x : c_cb[r];
+    }
+    __device__ __forceinline__ uint32_t get_nulls() const { return CACHE ? c_nulls : v.my_nulls[g]; }
+    __device__ __forceinline__ void add_nulls(uint32_t d) { if (CACHE) c_nulls += d; else v.my_nulls[g] += d; }
     // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
     __device__ __forceinline__ size_t pw(uint32_t row, uint32_t col) const { return (size_t)(v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
     __device__ __forceinline__ size_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
@@ -84,24 +134,23 @@ struct EpLaneT {
     __device__ __forceinline__ size_t dx(uint32_t row, uint32_t col, uint32_t i) const {
         return (((size_t)row * v.W + (col & v.Wmask)) * v.R + i) * v.G + g;
     }
-    __device__ __forceinline__ uint32_t &len(uint32_t row) const { return v.len[(size_t)row * v.G + g]; }
     // is the column still in the row's ring of W instances (the harness guard)
     __device__ __forceinline__ bool held(uint32_t row, uint32_t col) const {
-        const uint32_t end = len(row);
+        const uint32_t end = get_len(row);
         return col < end && col + v.W >= end;
     }
     __device__ __forceinline__ void push_null(uint32_t row) {            // mod.rs:467-480
-        const uint32_t col = len(row);
+        const uint32_t col = get_len(row);
         const size_t i = ix(row, col);
         v.bal[i] = 0; v.seq[i] = 0; v.status[i] = EST_NULL; v.key[i] = EP_NO_KEY; v.bk[i] = 0;
         v.pa_acks[i] = 0; v.acc_acks[i] = 0;
         for (uint32_t k = 0; k < v.R; k++) v.deps[dx(row, col, k)] = EP_NONE;
-        len(row) = col + 1;
-        if (row == v.me) v.my_nulls[g] += 1;
+        set_len(row, col + 1);
+        if (row == v.me) add_nulls(1u);
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)key * v.R + i) * v.G + g] : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)g * v.n_keys + key) * v.R + i] : EP_NONE;
     }
     __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
@@ -115,21 +164,21 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
         if (key == EP_NO_KEY) return;
-        const size_t o = ((size_t)key * v.R + row) * v.G + g;
+        const size_t o = ((size_t)g * v.n_keys + key) * v.R + row;
         const uint32_t hc = v.hc[o];
         if (hc == EP_NONE || col > hc) v.hc[o] = col;
     }
     __device__ __forceinline__ void logged_commit_slot(uint32_t row, uint32_t col) {             // durability.rs:104-135
-        uint32_t cb = v.commit_bars[(size_t)row * v.G + g];
+        uint32_t cb = get_cb(row);
         if (col != cb) return;
-        while (cb < len(row) && held(row, cb)) {
+        while (cb < get_len(row) && held(row, cb)) {
             const size_t i = ix(row, cb);
             const uint32_t st = v.status[i];
             if (st < EST_COMMITTED) break;
             if (v.key[i] == EP_NO_KEY) v.status[i] = EST_EXECUTED;
             cb++;
         }
-        v.commit_bars[(size_t)row * v.G + g] = cb;
+        set_cb(row, cb);
     }
     // messages.rs:348-436 on an instance I lead
     __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot) {
@@ -342,7 +391,7 @@ struct EpLaneT {
         }
     }
 };
-typedef EpLaneT<EMAXR> EpLane;
+typedef EpLaneT<EMAXR, false> EpLane;
 
 // ---- dependency-graph execution ------------------------------------------------------------------
 // One call of a handler kernel moves at most one row's commit bar per group (one message or one
@@ -378,20 +427,65 @@ struct EpExec {
                                          // (unused: components > 1 node), attempts, abandoned attempts
 };
 
-template <int NR>
+template <int NR, bool CACHE = false>
 struct EpExecLaneT {
     const EpView &v;
     const EpExec &x;
-    const EpLaneT<NR> &L;
+    EpLaneT<NR, CACHE> &L;
+    uint32_t c_eb[CACHE ? NR : 1], c_pcb[CACHE ? NR : 1];                    // exec_bars / prev_cb in registers (see EpLaneT)
+    __device__ __forceinline__ void load_scalars() {
+        if (!CACHE) return;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) {
+            c_eb[r] = (uint32_t)r < v.R ? x.exec_bars[(size_t)r * v.G + g] : 0u;
+            c_pcb[r] = (uint32_t)r < v.R ? x.prev_cb[(size_t)r * v.G + g] : 0u;
+        }
+    }
+    __device__ __forceinline__ void store_scalars() const {
+        if (!CACHE) return;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++)
+            if ((uint32_t)r < v.R) { x.exec_bars[(size_t)r * v.G + g] = c_eb[r]; x.prev_cb[(size_t)r * v.G + g] = c_pcb[r]; }
+    }
+    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const {
+        if (!CACHE) return x.exec_bars[(size_t)row * v.G + g];
+        uint32_t y = 0;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) y = c_eb[r];
+        return y;
+    }
+    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) {
+        if (!CACHE) { x.exec_bars[(size_t)row * v.G + g] = y; return; }
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) c_eb[r] = (uint32_t)r == row ? y : c_eb[r];
+    }
+    // has the row's commit bar moved since the last look (then the copy follows it)
+    __device__ __forceinline__ bool cb_moved(uint32_t row, uint32_t cb) {
+        if (!CACHE) {
+            const size_t o = (size_t)row * v.G + g;
+            if (cb == x.prev_cb[o]) return false;
+            x.prev_cb[o] = cb;
+            return true;
+        }
+        bool moved = false;
+#pragma unroll
+        for (int r = 0; r < (CACHE ? NR : 1); r++) {
+            const bool hit = (uint32_t)r == row && c_pcb[r] != cb;
+            moved = moved || hit;
+            c_pcb[r] = hit ? cb : c_pcb[r];
+        }
+        return moved;
+    }
     const uint32_t g, wshift;
     uint32_t n_nodes = 0, n_order = 0, last = XNIL;          // last: ring cell of the slot popped before, XNIL = none / not held
+    uint32_t last_node = 0;                                  // node_of[last] (node id + 1; 0: not a node), kept beside it
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
-    __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, const EpLaneT<NR> &L_, uint32_t g_)
+    __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
     __device__ __forceinline__ size_t at(uint32_t i) const { return (size_t)i * v.G + g; }
     // the column a ring cell of this row holds (the one of its residue among the last W)
     __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
-        const uint32_t end = L.len(row), lo = end > v.W ? end - v.W : 0u;
+        const uint32_t end = L.get_len(row), lo = end > v.W ? end - v.W : 0u;
         uint32_t c = (lo & ~v.Wmask) | w;
         if (c < lo) c += v.W;
         return c;
@@ -403,25 +497,27 @@ struct EpExecLaneT {
         x.node_of[at(ring)] = (uint16_t)(id + 1);
         return id;
     }
-    // one pop of the walk (execution.rs:37-82); true = the attempt is abandoned
-    __device__ __forceinline__ bool pop(uint32_t row, uint32_t col) {
-        if (col >= v.commit_bars[(size_t)row * v.G + g]) return true;            // :41-45
-        if (!L.held(row, col)) { c_unheld++; last = XNIL; return false; }        // harness: left the ring = executed
-        const uint32_t ring = (row << wshift) | (col & v.Wmask);
-        if (v.status[L.ix(row, col)] >= EST_EXECUTING || x.node_of[at(ring)] != 0) { last = ring; return false; }   // :46-54
+    // One pop of the walk (execution.rs:37-82) behind its commit-bar and ring checks, on a cell whose Status `st` and node_of
+    // word `no` the caller has at hand.  A node made here changes node_of[ring] and -- add_edge's missing endpoint --
+    // possibly node_of[last]: (p1, v1) / (p2, v2) = (ring cell, its new node_of word) for the caller to patch the copies it
+    // holds, XNONE = no such change.  node_of[last] itself is tracked in last_node, so an edge costs no load.
+    static constexpr uint32_t XNONE = 0xFFFFFFFFu, XUNUSED = 0xFFFFFFFEu;
+    __device__ __forceinline__ void visit(uint32_t ring, uint32_t st, uint32_t no, uint32_t &p1, uint32_t &v1, uint32_t &p2, uint32_t &v2) {
+        p1 = p2 = XNONE; v1 = v2 = 0;
+        if (st >= EST_EXECUTING || no != 0) { last = ring; last_node = no; return; }   // :46-54
         const uint32_t id = new_node(ring, XNEW);                                // :56-59
+        p1 = ring; v1 = id + 1;
         if (last != XNIL) {
-            uint32_t a = x.node_of[at(last)];
-            if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; }               // add_edge inserts the missing endpoint
+            uint32_t a = last_node;
+            if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; p2 = last; v2 = a; }   // add_edge inserts the missing endpoint
             a -= 1;
             x.sib[at(id)] = x.head[at(a)]; x.head[at(a)] = (uint16_t)id; x.parent[at(id)] = (uint16_t)a;
         }
-        last = ring;
-        return false;
+        last = ring; last_node = id + 1;
     }
-    // execution.rs:105-142 for one node, sync_exec = false
-    __device__ __forceinline__ void submit(uint32_t id) {
-        const uint32_t ring = x.nslot[at(id)] & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
+    // execution.rs:105-142 for one node's instance, sync_exec = false
+    __device__ __forceinline__ void submit_ring(uint32_t ring) {
+        const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
         const size_t i = L.ix(row, col);
         const uint32_t key = v.key[i];
         if (key != EP_NO_KEY) {
@@ -435,24 +531,62 @@ struct EpExecLaneT {
         }
         v.status[i] = EST_EXECUTING;
     }
+    // attempt_execution (execution.rs:25-149) from the tail (trow, tcol).  The walk is latency, not bytes: a lane's loads are
+    // round trips to HBM one behind the other, so a node's R dependencies and its row predecessor are looked at with all
+    // their words loaded up front (deps; then Status + node_of of the R + 1 cells), not cell by cell -- the pops still happen
+    // one by one, in the reference's order, on those copies (patched where an earlier pop of the batch made a node).
     __device__ __forceinline__ bool attempt(uint32_t trow, uint32_t tcol) {
         c_attempts++;
-        n_nodes = 0; last = XNIL;
-        bool abandoned = pop(trow, tcol);
+        n_nodes = 0; last = XNIL; last_node = 0;
+        bool abandoned = false;
+        uint32_t p1, v1, p2, v2, ring0 = XNIL;
+        if (tcol >= L.get_cb(trow)) abandoned = true;                            // :41-45
+        else if (!L.held(trow, tcol)) { c_unheld++; last = XNIL; }               // harness: left the ring = executed
+        else {
+            ring0 = (trow << wshift) | (tcol & v.Wmask);
+            const uint32_t st = v.status[L.ix(trow, tcol)], no = x.node_of[at(ring0)];
+            visit(ring0, st, no, p1, v1, p2, v2);
+        }
         for (uint32_t i = 0; !abandoned && i < n_nodes; i++) {
-            const uint32_t s = x.nslot[at(i)];
+            const uint32_t s = (i == 0) ? (ring0 | XNEW) : x.nslot[at(i)];      // (node 0 is the tail, new by construction)
             if (!(s & XNEW)) continue;
             const uint32_t ring = s & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
-            for (uint32_t k = 0; k < v.R && !abandoned; k++) {                   // :62-73 its dependencies, row order
-                const uint32_t d = v.deps[L.dx(row, col, k)];
-                if (d != EP_NONE) abandoned = pop(k, d);
+            uint32_t cc[NR + 1], cr[NR + 1], cst[NR + 1], cno[NR + 1];           // per cell: column, ring cell (XUNUSED: no pop), Status, node_of
+#pragma unroll
+            for (int k = 0; k < NR; k++) cc[k] = (uint32_t)k < v.R ? v.deps[L.dx(row, col, k)] : EP_NONE;   // :62-73 its dependencies, row order
+            cc[NR] = col > 0 ? col - 1 : EP_NONE;                                // :74-77 the row predecessor
+#pragma unroll
+            for (int e = 0; e <= NR; e++) {
+                const uint32_t erow = e < NR ? (uint32_t)e : row;
+                const bool on = cc[e] != EP_NONE;
+                const uint32_t r_ = on ? erow : 0u, c_ = on ? cc[e] : 0u, rg = (r_ << wshift) | (c_ & v.Wmask);
+                cr[e] = on ? rg : XUNUSED;
+                cst[e] = v.status[L.ix(r_, c_)];
+                cno[e] = x.node_of[at(rg)];
             }
-            if (!abandoned && col > 0) abandoned = pop(row, col - 1);            // :74-77 the row predecessor
+#pragma unroll
+            for (int e = 0; e <= NR; e++) {
+                if (abandoned || cr[e] == XUNUSED) continue;
+                const uint32_t erow = e < NR ? (uint32_t)e : row;
+                if (cc[e] >= L.get_cb(erow)) { abandoned = true; continue; }     // :41-45
+                if (!L.held(erow, cc[e])) { c_unheld++; last = XNIL; continue; }
+                visit(cr[e], cst[e], cno[e], p1, v1, p2, v2);
+#pragma unroll
+                for (int f = e + 1; f <= NR; f++) {
+                    if (cr[f] == p1) cno[f] = v1;
+                    if (cr[f] == p2) cno[f] = v2;
+                }
+            }
         }
         if (abandoned) {
             c_aborts++;
             for (uint32_t i = 0; i < n_nodes; i++) x.node_of[at(x.nslot[at(i)] & 0x7FFFu)] = 0;
             return false;
+        }
+        if (n_nodes == 1) {                                                      // the tail alone (no edge was made): no links to walk
+            x.node_of[at(ring0)] = 0;
+            submit_ring(ring0);
+            return true;
         }
         // post-order over the forest; entering a node clears its node_of cell (= visited, and the cleanup)
         for (uint32_t root = 0; root < n_nodes; root++) {
@@ -464,10 +598,10 @@ struct EpExecLaneT {
                 const uint32_t c = x.head[at(u)];
                 if (c != XNIL) {
                     x.head[at(u)] = x.sib[at(c)];
-                    const uint32_t cr = x.nslot[at(c)] & 0x7FFFu;
-                    if (x.node_of[at(cr)] != 0) { x.node_of[at(cr)] = 0; u = c; }
+                    const uint32_t cr_ = x.nslot[at(c)] & 0x7FFFu;
+                    if (x.node_of[at(cr_)] != 0) { x.node_of[at(cr_)] = 0; u = c; }
                 } else {
-                    submit(u);
+                    submit_ring(x.nslot[at(u)] & 0x7FFFu);
                     if (u == root) break;
                     u = x.parent[at(u)];
                 }
@@ -479,10 +613,10 @@ struct EpExecLaneT {
     __device__ __forceinline__ void cmd_result(uint32_t ring) {
         const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
         v.status[L.ix(row, col)] = EST_EXECUTED;
-        uint32_t eb = x.exec_bars[(size_t)row * v.G + g];
+        uint32_t eb = get_eb(row);
         if (col != eb) return;
-        while (eb < L.len(row) && L.held(row, eb) && v.status[L.ix(row, eb)] >= EST_EXECUTED) eb++;
-        x.exec_bars[(size_t)row * v.G + g] = eb;
+        while (eb < L.get_len(row) && L.held(row, eb) && v.status[L.ix(row, eb)] >= EST_EXECUTED) eb++;
+        set_eb(row, eb);
     }
     // durability.rs:136-160 for the row whose commit bar moved
     // (APPEND: a handler that runs several of the reference's inner handlers in one call -- heartbeat_timeout -- keeps the
@@ -493,22 +627,23 @@ struct EpExecLaneT {
         const uint32_t first = n_order;
         if (attempt(row, cb - 1)) {
             uint32_t re = 0;                                                     // rows to re-attempt, found before any of them runs
-            for (uint32_t q = 0; q < v.R; q++) {
-                const uint32_t c = v.commit_bars[(size_t)q * v.G + g];
-                if (c > x.exec_bars[(size_t)q * v.G + g] && L.held(q, c - 1) && v.status[L.ix(q, c - 1)] == EST_COMMITTED) re |= 1u << q;
+#pragma unroll
+            for (int q = 0; q < NR; q++) {                                       // (the R tails' Status words: one round of loads)
+                const uint32_t qq = (uint32_t)q < v.R ? (uint32_t)q : 0u, c = L.get_cb(qq);
+                const bool ok = (uint32_t)q < v.R && c > get_eb(qq) && L.held(qq, c - 1);
+                const uint32_t st = v.status[L.ix(qq, ok ? c - 1 : 0u)];
+                if (ok && st == EST_COMMITTED) re |= 1u << q;
             }
             for (uint32_t q = 0; q < v.R; q++)
-                if ((re >> q) & 1u) (void)attempt(q, v.commit_bars[(size_t)q * v.G + g] - 1);
+                if ((re >> q) & 1u) (void)attempt(q, L.get_cb(q) - 1);
         }
         for (uint32_t i = first; i < n_order; i++) cmd_result(x.order[at(i)]);
     }
     // the attempts of handle_logged_commit_slot for whichever row's commit bar the inner handler just moved (at most one)
     __device__ __forceinline__ void after_inner_handler() {
         for (uint32_t row = 0; row < v.R; row++) {
-            const size_t o = (size_t)row * v.G + g;
-            const uint32_t cb = v.commit_bars[o];
-            if (cb == x.prev_cb[o]) continue;
-            x.prev_cb[o] = cb;
+            const uint32_t cb = L.get_cb(row);
+            if (!cb_moved(row, cb)) continue;
             advanced<true>(row, cb);
         }
     }
@@ -522,19 +657,17 @@ struct EpExecLaneT {
         }
     }
 };
-typedef EpExecLaneT<EMAXR> EpExecLane;
+typedef EpExecLaneT<EMAXR, false> EpExecLane;
 
 // ---- the handlers on one lane (= one group of one replica): what the per-handler kernels below and the one-kernel
 // cluster tick (ep_cluster_tick_kernel) both run ---------------------------------------------------------------------------
 // the attempts of handle_logged_commit_slot behind ONE handler (durability.rs:136-160): at most one row's commit bar moved
-template <int NR>
-__device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpExec &x, EpExecLaneT<NR> &E) {
+template <int NR, bool C>
+__device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpExec &x, EpExecLaneT<NR, C> &E) {
     E.n_order = 0;
     for (uint32_t row = 0; row < v.R; row++) {
-        const size_t o = (size_t)row * v.G + E.g;
-        const uint32_t cb = v.commit_bars[o];
-        if (cb == x.prev_cb[o]) continue;
-        x.prev_cb[o] = cb;
+        const uint32_t cb = E.L.get_cb(row);
+        if (!E.cb_moved(row, cb)) continue;
         E.advanced(row, cb);
     }
     x.n_sub[E.g] = E.n_order;                                                // 0 when no commit bar moved
@@ -542,23 +675,22 @@ __device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpE
 
 // request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35): key k (EP_NO_KEY: nothing to propose);
 // (of, oc, os, d) = the PreAccept to broadcast
-template <int NR>
-__device__ __forceinline__ void ep_propose_lane(EpLaneT<NR> &L, uint32_t k, uint32_t ex, uint8_t &of, uint32_t &oc, uint64_t &os,
+template <int NR, bool C>
+__device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, uint32_t ex, uint8_t &of, uint32_t &oc, uint64_t &os,
                                                 uint32_t (&d)[NR]) {
     const EpView &v = L.v;
-    const uint32_t g = L.g;
     of = 0; oc = 0; os = 0;
 #pragma unroll
     for (int i = 0; i < NR; i++) d[i] = EP_NONE;
     if (k == EP_NO_KEY) return;
     const uint32_t row = v.me;
     uint32_t col = EP_NONE;                                                  // mod.rs:485-496 (exec_bars stay 0 here)
-    const uint32_t end = L.len(row);
-    if (v.my_nulls[g] != 0)                                                  // only a PreAccept / Accept for my own row pads it
+    const uint32_t end = L.get_len(row);
+    if (L.get_nulls() != 0)                                                  // only a PreAccept / Accept for my own row pads it
         for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
             if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
-    if (col == EP_NONE) { L.push_null(row); col = L.len(row) - 1; }
-    v.my_nulls[g] -= 1;                                                      // the slot stops being null
+    if (col == EP_NONE) { L.push_null(row); col = L.get_len(row) - 1; }
+    L.add_nulls(0xFFFFFFFFu);                                                      // the slot stops being null
     L.identify_deps(k, d);
     const uint64_t seq = 1 + L.max_seq_num(d);
     const size_t i = L.ix(row, col);
@@ -574,13 +706,26 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR> &L, uint32_t k, uint
     L.fresh_leader_bk(i);
     v.status[i] = EST_PREACCEPTING;
     of = 1; oc = col; os = seq;
-    L.pre_accept_reply(v.me, row, col, bal, seq, d, ex);
+    // my own PreAcceptReply (durability.rs:25-35 -> messages.rs:96-270) on bookkeeping that is fresh: it is recorded and is the
+    // only one held, and one reply is below any quorum (simple_q >= 2 at populations >= 3) -- handle_msg_pre_accept_reply
+    // returns at dependency.rs:205 without looking at `ex`
+    v.pa_seq[L.ps_ix(row, col, v.me)] = seq;
+    for (uint32_t q = 0; q < v.R; q++) {
+        uint32_t x = EP_NONE;
+#pragma unroll
+        for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = d[qq];
+        v.pa_deps[L.pd_ix(row, col, v.me, q)] = x;
+    }
+    v.pa_acks[i] = (uint8_t)(1u << v.me);
+    (void)ex;
 }
 
 // messages.rs:10-93 (MODE 0: PreAccept) / :273-345 (MODE 1: Accept) / :438-508 (MODE 2: CommitNotice) + the acceptor's
 // WAL completion, for the message (src, row, c, b, s, deps[i * G + g], k) if `on`; (of, ob, os, d) = the reply
-template <int MODE, int NR>
-__device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
+// LBK = false: the caller knows the instance cannot carry leader bookkeeping at this replica (another replica's row in a
+// cluster without explicit prepare), and the branch that answers the leader's own message is left out
+template <int MODE, int NR, bool LBK, bool C>
+__device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
                                                  const uint32_t *__restrict__ deps, uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
                                                  uint32_t (&d)[NR]) {
     const EpView &v = L.v;
@@ -589,11 +734,11 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR> &L, bool on, uint32
 #pragma unroll
     for (int i = 0; i < NR; i++) d[i] = EP_NONE;
     if (!on) return;
-    if (!(row < v.R && !(c < L.len(row) && !L.held(row, c)))) return;        // col < start_col analogue
-    while (L.len(row) <= c) L.push_null(row);                                // :33-36
+    if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
+    while (L.get_len(row) <= c) L.push_null(row);                            // :33-36
     const size_t i = L.ix(row, c);
     if (!(b >= v.bal[i])) return;                                            // :40
-    if (row == v.me && v.status[i] == EST_NULL) v.my_nulls[g] -= 1;
+    if (row == v.me && v.status[i] == EST_NULL) L.add_nulls(0xFFFFFFFFu);
     uint32_t in[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
@@ -622,7 +767,7 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR> &L, bool on, uint32
     } else {
         const uint32_t bk = v.bk[i];
         v.bk[i] = (uint8_t)((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
-        if (bk & 1u) {                                                       // durability.rs:25 / :78: leader_bk first
+        if (LBK && (bk & 1u)) {                                              // durability.rs:25 / :78: leader_bk first
             if (MODE == 1) L.accept_reply(v.me, row, c, b); else L.pre_accept_reply(v.me, row, c, b, s, in, 0u);
         } else {
             of = 1; ob = b; os = s;
@@ -632,10 +777,11 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR> &L, bool on, uint32
     }
 }
 
+template <int NR>
 __global__ __launch_bounds__(256) void ep_execute_kernel(const EpView v, const EpExec x) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    EpLane L(v, g < v.G ? g : 0);
-    EpExecLane E(v, x, L, L.g);
+    EpLaneT<NR, false> L(v, g < v.G ? g : 0);
+    EpExecLaneT<NR, false> E(v, x, L, L.g);
     if (g < v.G) ep_exec_after_handler(v, x, E);
     E.flush();
 }
@@ -674,7 +820,7 @@ __global__ __launch_bounds__(256) void ep_acceptor_kernel(const EpView v, const 
         for (int i = 0; i < EMAXR; i++) d[i] = EP_NONE;
         if (flags[g] & 1) {
             const uint32_t src = peer[g];
-            ep_acceptor_lane<MODE>(L, true, src, rows ? rows[g] : src, col[g], ballot[g], seq[g], deps, key[g], of, ob, os, d);   // (rows: an instance under explicit prepare)
+            ep_acceptor_lane<MODE, EMAXR, true>(L, true, src, rows ? rows[g] : src, col[g], ballot[g], seq[g], deps, key[g], of, ob, os, d);   // (rows: an instance under explicit prepare)
         }
         if (MODE != 2) { r_flags[g] = of; r_ballot[g] = ob; }
         if (MODE == 0) {
@@ -747,8 +893,8 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 // p's; my own row unused), the result is stored once.  dec = 0 / EST_ACCEPTING / EST_COMMITTED with (dseq, dd).
 // (Loading every input row unconditionally from clamped addresses was measured SLOWER for this kernel -- 25.2 vs 21.7 us per
 // launch, profiles/r2w_ep_flat.log -- unlike the MultiPaxos tally's round 1; the variant is gone.)
-template <int NR>
-__device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
+template <int NR, bool C>
+__device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
                                                    const uint32_t (&in_f)[NR], const uint64_t (&in_b)[NR], const uint64_t (&in_s)[NR],
                                                    const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR]) {
     const EpView &v = L.v;
@@ -840,7 +986,7 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
             for (int k = 0; k < NR; k++) in_d[p][k] = (on && (uint32_t)k < R) ? deps[((size_t)p * R + k) * v.G + g] : EP_NONE;
         }
         uint8_t dec; uint64_t dseq; uint32_t dd[NR];
-        ep_pa_replies_lane<NR>(L, (rows && rows[g] < R) ? rows[g] : v.me, col[g], order ? order[g] : SMR_CTL_IDENTITY,
+        ep_pa_replies_lane(L, (rows && rows[g] < R) ? rows[g] : v.me, col[g], order ? order[g] : SMR_CTL_IDENTITY,
                                exploded ? exploded[g] : 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
         decision[g] = dec; d_seq[g] = dec ? dseq : 0ull;
 #pragma unroll
@@ -851,8 +997,8 @@ __global__ __launch_bounds__(256) void ep_pre_accept_replies_kernel(const EpView
 
 // the AcceptReplies to the instance (row, c) I lead: flags / ballot rows by peer (stride G), peers in ctl order, one
 // handle_msg_accept_reply each (messages.rs:348-436); true = the instance went from Accepting to Committed here
-template <int NR>
-__device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR> &L, uint32_t row, uint32_t c, uint32_t ctl,
+template <int NR, bool C>
+__device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl,
                                                        const uint8_t *__restrict__ flags, const uint64_t *__restrict__ ballot,
                                                        uint64_t fixed_ballot) {
     const EpView &v = L.v;
@@ -905,8 +1051,8 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             for (int k = 0; k < EMAXR; k++) none[k] = EP_NONE;
             // :35-60 every PreAccepting instance I lead, from its row's commit bar: "reply" with ballot 0
             for (uint32_t row = 0; row < R; row++) {
-                const uint32_t end = L.len(row);
-                for (uint32_t c = v.commit_bars[(size_t)row * v.G + g]; c < end; c++) {
+                const uint32_t end = L.get_len(row);
+                for (uint32_t c = L.get_cb(row); c < end; c++) {
                     if (!L.held(row, c)) continue;
                     const size_t i = L.ix(row, c);
                     if (v.status[i] == EST_PREACCEPTING && (v.bk[i] & 1)) {
@@ -916,7 +1062,7 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
                 }
             }
             // :62-107 ExpPrepare for every in-progress instance of that peer's row (exec bars: 0 without execution)
-            const uint32_t row = ts, end = L.len(row);
+            const uint32_t row = ts, end = L.get_len(row);
             for (uint32_t c = end > v.W ? end - v.W : 0u; c < end; c++) {
                 const size_t i = L.ix(row, c);
                 const uint32_t st = v.status[i], bk = v.bk[i];
@@ -961,8 +1107,8 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_kernel(const EpView v, con
     for (int q = 0; q < EMAXR; q++) d[q] = EP_NONE;
     if (flags[g] & 1) {
         const uint32_t row = rows[g], c = col[g];
-        if (row < v.R && !(c < L.len(row) && !L.held(row, c))) {
-            while (L.len(row) <= c) L.push_null(row);                            // :530-533
+        if (row < v.R && !(c < L.get_len(row) && !L.held(row, c))) {
+            while (L.get_len(row) <= c) L.push_null(row);                        // :530-533
             const size_t i = L.ix(row, c);
             if (nbal[g] > v.bal[i]) {                                            // :537
                 v.bk[i] = (uint8_t)((v.bk[i] & 1u) | 2u | ((uint32_t)peer[g] << 2));   // replica_bk.source = peer
@@ -1106,8 +1252,11 @@ struct EpClusterArgs {
     uint32_t *r_deps;                            // [s][q][R][G]
 };
 
-template <int NR>
-__global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
+#ifndef EPC_WAVES_PER_EU
+#define EPC_WAVES_PER_EU 3                   // R <= 5: 168 VGPRs = 12 wavefronts per CU = two 5-wavefront blocks (at 2 per SIMD only ONE block fits)
+#endif
+template <int NR, bool RECOVERY>
+__global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
     __shared__ uint32_t sh_slow;
     const uint32_t q = SMR_WAVE_UNIFORM(threadIdx.x >> 6), R = a.R, G = a.G;
     const uint32_t g0 = blockIdx.x * 64u + (threadIdx.x & 63u);
@@ -1115,8 +1264,9 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
     const uint32_t g = live ? g0 : 0u;
     const EpView &v = a.v[q];
     const EpExec &x = a.x[q];
-    EpLaneT<NR> L(v, g);
-    EpExecLaneT<NR> E(v, x, L, g);
+    EpLaneT<NR, true> L(v, g);
+    EpExecLaneT<NR, true> E(v, x, L, g);
+    if (live) { L.load_scalars(); if (a.execute) E.load_scalars(); }
     const uint32_t n_steps = 1u + R + 4u * R;
     bool slow_round = true;
 #pragma unroll 1
@@ -1126,7 +1276,7 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
             if (live) {
                 const smr_ep_cluster_out &o = a.out[q];
                 uint8_t of; uint32_t oc; uint64_t os; uint32_t d[NR];
-                ep_propose_lane<NR>(L, a.keys[q][g], 0u, of, oc, os, d);
+                ep_propose_lane(L, a.keys[q][g], 0u, of, oc, os, d);
                 o.proposed[g] = of; o.col[g] = oc; o.seq0[g] = os;
 #pragma unroll
                 for (int i = 0; i < NR; i++) if ((uint32_t)i < R) o.deps0[(size_t)i * G + g] = d[i];
@@ -1140,7 +1290,7 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
                 const uint8_t *dm = a.drop[s * NR + q];
                 const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
                 uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                ep_acceptor_lane<0, NR>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
+                ep_acceptor_lane<0, NR, RECOVERY>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
                 const size_t ro = ((size_t)s * R + q) * G + g;
                 a.r_flags[ro] = of; a.r_seq[ro] = os;
 #pragma unroll
@@ -1166,7 +1316,7 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
                                 in_d[p][k] = (on && (uint32_t)k < R) ? a.r_deps[(((size_t)s * R + p) * R + k) * G + g] : EP_NONE;
                         }
                         uint64_t dseq; uint32_t dd[NR];
-                        ep_pa_replies_lane<NR>(L, s, o.col[g], SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
+                        ep_pa_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
                         o.decision[g] = dec; o.seq[g] = dec ? dseq : 0ull;
 #pragma unroll
                         for (int k = 0; k < NR; k++) if ((uint32_t)k < R) o.deps[(size_t)k * G + g] = dec ? dd[k] : EP_NONE;
@@ -1180,14 +1330,14 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
                 barrier = slow_round;
                 if (slow_round && q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                    ep_acceptor_lane<1, NR>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
+                    ep_acceptor_lane<1, NR, RECOVERY>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
                                             a.keys[s][g], of, ob, os, d);
                     a.a_flags[((size_t)s * R + q) * G + g] = of;
                     handled = true;
                 }
             } else if (ph == 2) {                                            // leader s: the AcceptReplies, then what is committed
                 if (q == s && live) {
-                    const bool acc = slow_round && ep_accept_replies_lane<NR>(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G,
+                    const bool acc = slow_round && ep_accept_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G,
                                                                                nullptr, (uint64_t)(s + 1u));
                     o.committed[g] = (o.decision[g] == EST_COMMITTED || acc) ? 1 : 0;
                     handled = true; can_commit = true;
@@ -1196,15 +1346,16 @@ __global__ __launch_bounds__(NR * 64) void ep_cluster_tick_kernel(const EpCluste
                 barrier = false;                                             // (the next step that reads across wavefronts has its own in front)
                 if (q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                    ep_acceptor_lane<2, NR>(L, o.committed[g] & 1, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
+                    ep_acceptor_lane<2, NR, RECOVERY>(L, o.committed[g] & 1, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
                                             os, d);
                     handled = true; can_commit = true;
                 }
             }
         }
-        if (handled && a.execute && (can_commit || !a.quiet)) ep_exec_after_handler<NR>(v, x, E);
+        if (handled && a.execute && (can_commit || RECOVERY)) ep_exec_after_handler(v, x, E);
         if (barrier) __syncthreads();
     }
+    if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
     L.flush();
     if (a.execute) E.flush();
 }
@@ -1262,7 +1413,8 @@ void smr_ep_replica_destroy(smr_ep_replica *e) {
 // the attempts of handle_logged_commit_slot for whatever the kernel just launched committed
 static int ep_execute(smr_ep_replica *e, void *stream) {
     if (!e->cfg.execute || e->skip_exec) return SMR_OK;
-    hipLaunchKernelGGL(ep_execute_kernel, EP_GRID(e), e->v, e->x);
+    if (e->v.R <= 5) hipLaunchKernelGGL(ep_execute_kernel<5>, EP_GRID(e), e->v, e->x);
+    else hipLaunchKernelGGL(ep_execute_kernel<EMAXR>, EP_GRID(e), e->v, e->x);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -1440,7 +1592,13 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
     const size_t G = v.G, W = v.W, R = v.R, K = v.n_keys;
 #define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     D2H(hb->len, v.len, R * G * 4); D2H(hb->commit_bars, v.commit_bars, R * G * 4);
-    D2H(hb->highest_cols, v.hc, K * R * G * 4);
+    {                                                                            // device [G][K][R] -> the dump's [K][R][G]
+        std::vector<uint32_t> hc(K * R * G);
+        D2H(hc.data(), v.hc, K * R * G * 4);
+        for (size_t g = 0; g < G; g++)
+            for (size_t k = 0; k < K; k++)
+                for (size_t r = 0; r < R; r++) hb->highest_cols[(k * R + r) * G + g] = hc[(g * K + k) * R + r];
+    }
     std::vector<uint64_t> bal(R * W * G), seq(R * W * G);
     std::vector<uint8_t> st(R * W * G), key(R * W * G), bk(R * W * G), pa(R * W * G), ac(R * W * G);
     std::vector<uint32_t> deps(R * W * R * G);
@@ -1607,7 +1765,10 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
         for (uint32_t q = 0; q < R; q++) a.drop[r * NR + q] = drop_dev ? drop_dev[(size_t)r * R + q] : nullptr;
     }
     a.r_flags = c->r_flags[0]; a.a_flags = c->a_flags[0]; a.r_seq = c->r_seq[0]; a.r_deps = c->r_deps[0];
-    hipLaunchKernelGGL(ep_cluster_tick_kernel<NR>, dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
+    if (a.quiet)
+        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, true>), dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
