@@ -384,45 +384,119 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
     return line
 
 
-def rspaxos_leg(torch, dev, ticks=40, warmup=8):
-    """BASELINE config 4: RSPaxos, 16 384 groups x 5 replicas, one Put of a 4 KiB value per batch: per tick the leader
-    RS(3,2)-encodes the tick's 16 384 request batches (rspaxos/request.rs:71-77) and the batch runs through the
-    MultiPaxos engine with the RSPaxos commit rule majority + fault_tolerance, f = 1 (rspaxos/messages.rs:438-439).
-    The followers' shard-availability gate of RSPaxos is not modelled."""
-    from summerset_amd import MultiPaxosCluster, RSCodewordBatch, stream
-    G, R, S, W, L = 16384, 5, 1, 64, 4113                                     # bincode ReqBatch of one 4 KiB Put
-    cap = W + 4
-    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, commit_extra=1)
-    eng.preset_leader(0)
-    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=warmup + ticks, drop_p=0.1, timeout_frac=0.0, hb_every=4,
-                                 rand_rows=S + 4, max_drop=1)                 # 4 of 5 must answer: at most 1 lost
-    pool = []
-    for t in range(4):
-        x = st.tick(t)
-        pool.append({k: torch.from_numpy(x[k]).to(dev) for k in ("req_cnt", "req_val", "ackctl", "req_target")})
-    data = torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev)
-    cw = RSCodewordBatch.from_data(data, 3, 2)
+def rspaxos_leg(torch, dev, ticks=48, warmup=8):
+    """BASELINE config 4 on the RSPaxos ENGINE (csrc/rsp_engine.hip; rounds 1-2 timed a MultiPaxos-engine stand-in here):
+    16 384 groups x 5 replica objects, f = 1, leader 0, one Put of a 4 KiB value per group per tick.  Per tick, all on the
+    device (summerset_amd/rsp_cluster.SteadyLoop): from_data + RS(3,2) encode of the tick's 16 384 request batches in ONE
+    pass (smr_rs_from_data_encode, L = 4113 = bincode(ReqBatch) of one 4 KiB Put) out of one of NB rotating source / codeword
+    buffer pairs (NB x 180 MB: beyond the 256 MiB L3) which ALSO fills every replica's shard store (the fan-out of
+    rspaxos/request.rs:127-142: the co-located stand-in for the Accepts' payload); the leader's handle_req_batch; the four followers' handle_msg_accept
+    with the ONE shard they hold; the leader's AcceptReply tally at majority + f with the shard-availability gate of the
+    commit-bar run behind it (rspaxos/durability.rs:140-160: a replica holding fewer than d shards of a slot cannot execute
+    it -- a follower holds one of five -- so that gate is on the timed path at every replica); every 4th tick the
+    Heartbeats.  <= 1 AcceptReply of 4 lost per slot (the threshold is 4 of 5 and nothing is retransmitted).
+    The tick is captured into ONE HIP graph of NB ticks and replayed (HIP graphs instead of per-launch host calls: a tick is
+    ~14 launches of a few microseconds each); the eager loop is timed beside it."""
+    from summerset_amd import RSCodewordBatch, RSPaxosReplicaGroup, rsp_cluster
+    G, R, W, L, NB, H = 16384, 5, 64, 4113, 4, 4
+    reps = [RSPaxosReplicaGroup(G, R, me=r, window=W, fault_tolerance=1) for r in range(R)]
+    for r in reps:
+        r.preset_leader(0)
+    loop = rsp_cluster.SteadyLoop(reps, leader=0)
+    rng = np.random.default_rng(0x5EED5EED)
+    srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
+    cws = [RSCodewordBatch(G, L, 3, 2, device=dev, zero=False) for _ in range(NB)]
+    masks = []
+    for k in range(NB):
+        who = rng.integers(1, R, G)
+        hit = rng.random(G) < 0.3                                        # ~30 % of the slots lose ONE of their four replies
+        masks.append({("accept_reply", q, 0): torch.from_numpy(hit & (who == q)).to(dev) for q in range(1, R)})
+    ar = torch.arange(G, dtype=torch.int64, device=dev)
+    base = torch.ones((), dtype=torch.int64, device=dev)
 
-    def step(t):
-        cw.compute_parity()                                                   # the tick's batches -> 5 shards each
-        p = pool[t % 4]
-        eng.tick(req_target=p["req_target"], req_cnt=p["req_cnt"], req_val=p["req_val"], ackctl=p["ackctl"],
-                 heartbeat=st.heartbeat(t))
+    def one_tick(k, hb):
+        loop.encode(srcs[k], out=cws[k])                                 # from_data + encode + the five shard stores: one pass
+        val = ((base + ar) & 0x3FFFFFFF).to(torch.int32)                 # the tick's batch tokens, made on the device
+        base.add_(G)
+        return loop.tick(val, lost=masks[k], heartbeat=hb)
+
+    def commits():
+        return int(reps[0].dump()["counters"][0])
 
     for t in range(warmup):
-        step(t)
+        one_tick(t % NB, t % H == H - 1)
     torch.cuda.synchronize()
-    c0 = eng.counters(0)["commits"]
+    line = {"workload": "RSPaxos engine (f = 1), %d groups x 5 replica objects on one GPU, one 4 KiB Put per group per tick: from_data + RS(3,2) "
+                        "encode in one pass (L = %d, %d rotating buffer pairs = %.0f MB), leader's handle_req_batch, shard fan-out to the "
+                        "followers' stores, 4 x handle_msg_accept (one shard each), AcceptReply tally at majority + 1 with the "
+                        "shard-availability gate, Heartbeats every %d ticks; <= 1 of 4 replies lost per slot"
+                        % (G, L, NB, NB * (G * L + G * cws[0].cw_stride) / 1e6, H),
+            "engine": "csrc/rsp_engine.hip (rsp_* kernels) + rs_from_data_xtime<2, 4>"}
+    # eager: one host call per handler
+    c0 = commits()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for t in range(warmup, warmup + ticks):
-        step(t)
+    e0.record()
+    for t in range(ticks):
+        one_tick(t % NB, t % H == H - 1)
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    commits = eng.counters(0)["commits"] - c0
-    return {"workload": "RSPaxos (f = 1), %d groups x 5 replicas, one 4 KiB Put per group per tick: RS(3,2) encode of the "
-                        "tick's batches (L = %d) + the commit path with threshold majority + 1" % (G, L),
-            "value": commits / dt, "unit": "slots/s", "ms_per_tick": dt / ticks * 1e3,
-            "rs_payload_GiBps": G * L * ticks / 2**30 / dt, "committed_per_tick": commits / ticks}
+    n_c = commits() - c0
+    line["eager"] = {"value": n_c / dt, "unit": "slots/s", "ms_per_tick": dt / ticks * 1e3, "device_ms_per_tick": e0.elapsed_time(e1) / ticks,
+                     "committed_per_tick": n_c / ticks, "rs_payload_GiBps": G * L * ticks / 2**30 / dt}
+    # the same NB ticks as one HIP graph
+    try:
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for k in range(NB):                                          # (a pass on the capture stream first: allocator warm-up)
+                one_tick(k, k == NB - 1)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for k in range(NB):
+                one_tick(k, k == NB - 1)
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        c0 = commits()
+        reps_ = max(ticks // NB, 4)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(reps_):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_c = commits() - c0
+        nt = reps_ * NB
+        ms = e0.elapsed_time(e1) / nt
+        alg = G * (L + 10 * cws[0].shard_len) + G * (52 + 33)   # the encode pass (L read, the codeword + the five stores written) + the tally's 8(d) bytes
+        line["graph"] = {"value": n_c / dt, "unit": "slots/s", "ms_per_tick": dt / nt * 1e3, "device_ms_per_tick": ms, "ticks_per_graph": NB,
+                         "committed_per_tick": n_c / nt, "rs_payload_GiBps": G * L * nt / 2**30 / dt}
+        line["roofline"] = {"bound": "hbm", "kernel": "the whole tick (one HIP graph of %d ticks): rs_from_data_xtime<2, 4> + the fan-out copy + rsp_* handlers" % NB,
+                            "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "alg_bytes_per_launch": alg, "avg_launch_us": ms * 1e3, "traffic": None,
+                            "note": "alg bytes per tick = 16384 x (L read + 5 shard_len written for the leader's codeword + 5 shard_len for the shard "
+                                    "stores) for from_data + encode + fan-out, 85 B per slot for the tally (SURVEY 8(d))"}
+        line["value"], line["unit"], line["ms_per_tick"] = line["graph"]["value"], "slots/s", line["graph"]["ms_per_tick"]
+        line["rs_payload_GiBps"] = line["graph"]["rs_payload_GiBps"]
+    except Exception as e:                         # noqa: BLE001
+        line["graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        line["value"], line["unit"], line["ms_per_tick"] = line["eager"]["value"], "slots/s", line["eager"]["ms_per_tick"]
+        line["rs_payload_GiBps"] = line["eager"]["rs_payload_GiBps"]
+    # the encode pass alone, in rotation: from_data + compute_parity as two steps against the one-pass kernel
+    us_two = _time_us(torch, lambda i: RSCodewordBatch.from_data(srcs[i % NB], 3, 2).compute_parity(), 16)
+    us_one = _time_us(torch, lambda i: RSCodewordBatch.from_data_and_encode(srcs[i % NB], 3, 2, out=cws[i % NB]), 32)
+    sl = cws[0].shard_len
+    line["from_data_and_encode"] = {"one_pass_us": us_one, "one_pass_payload_TiBps": G * L / 2**40 / (us_one * 1e-6),
+                                    "one_pass_frac": G * (L + 5 * sl) / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "two_step_us": us_two, "two_step_payload_TiBps": G * L / 2**40 / (us_two * 1e-6),
+                                    "note": "one pass moves L + 5 shard_len bytes per codeword (read once, d + p shards written); "
+                                            "two steps = copy into a zeroed codeword buffer, then smr_rs_encode"}
+    return line
 
 
 def leg_isolated(name, timeout=180):

@@ -83,6 +83,24 @@ int smr_rs_encode(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride
                   int d, int p, uint8_t *parity_dev, uint64_t par_stride,
                   uint64_t par_shard_stride, void *stream);
 
+/* RSCodeword::from_data + compute_parity in ONE pass (rscoding.rs:165-243, :447-486): codeword i's serialized bytes are
+ * src_dev[i*src_stride .. + data_len) (rows may be packed: src_stride == data_len); its d data shards -- consecutive
+ * shard_len-byte slices of those bytes, the last one zero-padded (rscoding.rs:188-200) -- and its p parity shards are
+ * written to cw_dev[i*cw_stride + k*shard_len .. + shard_len), k in [0, d+p).  The bytes are read once: against
+ * "copy into the codeword buffer, then smr_rs_encode" this moves (1 + (d+p)/d) L instead of (3 + p/d) L per codeword.
+ * p == 0 only lays out the data shards.  src and cw buffers must not overlap.  Errors as smr_rs_encode. */
+int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                            uint8_t *cw_dev, uint64_t cw_stride, void *stream);
+
+/* ... and with the shard fan-out of an RSPaxos / CRaft leader in the same pass (rspaxos/request.rs:127-142: shard k goes to
+ * replica k): besides the codeword at cw_dev, shard k of codeword i is ALSO written to
+ * fan_dev[k*fan_shard_stride + i*fan_cw_stride .. + shard_len) for every k whose bit is set in fan_mask -- one contiguous
+ * store per shard holder (fan_cw_stride >= shard_len, fan_shard_stride >= the bytes of one store), filled without reading
+ * the codewords again.  fan_mask == 0: exactly smr_rs_from_data_encode. */
+int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                   uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
+                                   uint64_t fan_cw_stride, uint32_t fan_mask, void *stream);
+
 /* Same, with the GF(2^8) multiplies done through LDS-resident product tables
  * instead of bit-sliced xtime arithmetic (kept selectable for A/B runs). */
 int smr_rs_encode_lut(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw,

@@ -38,6 +38,12 @@ struct RsArgs {
     uint64_t in_cw_stride, out_cw_stride;
     uint64_t in_off[RS_MAX_IN];    // byte offset of input shard c inside a codeword
     uint64_t out_off[RS_MAX_OUT];  // byte offset of output shard r inside a codeword
+    uint8_t *copy_base;            // from_data fused in (rs_from_data_xtime): the input columns are also WRITTEN, shard c of codeword
+    uint64_t copy_cw_stride;       // i to copy_base + i * copy_cw_stride + in_off[c], zero padding included; NULL otherwise
+    uint8_t *fan_base;             // shard fan-out fused in as well: shard k (k < n_in: data, else parity k - n_in) of codeword i ALSO
+    uint64_t fan_shard_stride;     // to fan_base + k * fan_shard_stride + i * fan_cw_stride, for the k in fan_mask -- every holder's
+    uint64_t fan_cw_stride;        // shard store filled by the pass that makes the shards (rspaxos/request.rs:127-142); NULL otherwise
+    uint32_t fan_mask;
     uint64_t in_valid;             // bytes of a codeword's input that exist (beyond: zero)
     uint64_t in_bytes;             // bytes readable from in_base (end of the last codeword's input)
     uint64_t shard_len;
@@ -99,11 +105,11 @@ __device__ __forceinline__ u32x4 load_cols(const RsArgs &a, const uint8_t *cw, i
     return (u32x4){w0, w1, w2, w3};
 }
 
-// the shard's last block stores its n < 16 bytes as whole dwords plus at most three single bytes
-__device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, uint64_t c0, u32x4 v) {
-    uint8_t *p = cw + a.out_off[r] + c0;
-    if (c0 + 16 <= a.shard_len) { store16(p, v); return; }
-    const uint32_t n = (uint32_t)(a.shard_len - c0);
+// 16 byte columns of a shard from its column c0 on, to p; the shard's last block stores its n < 16 bytes as whole dwords
+// plus at most three single bytes
+__device__ __forceinline__ void store_block(uint8_t *p, uint64_t c0, uint64_t shard_len, u32x4 v) {
+    if (c0 + 16 <= shard_len) { store16(p, v); return; }
+    const uint32_t n = (uint32_t)(shard_len - c0);
     const uint32_t w0 = v.x, w1 = v.y, w2 = v.z, w3 = v.w;
 #define SMR_ST_PART(k, w)                                                                  \
     if (n >= 4 * (k) + 4) __builtin_memcpy(p + 4 * (k), &w, 4);                          \
@@ -115,13 +121,27 @@ __device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, 
     SMR_ST_PART(0, w0) SMR_ST_PART(1, w1) SMR_ST_PART(2, w2) SMR_ST_PART(3, w3)
 #undef SMR_ST_PART
 }
+__device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, uint64_t c0, u32x4 v) {
+    store_block(cw + a.out_off[r] + c0, c0, a.shard_len, v);
+}
 
 // acc[r] = XOR_c coef[r][c] * in_c for 16 byte columns, all input loads issued up front
-template <int NOUT, int NIN>
-__device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t *cw, uint64_t c0, u32x4 (&acc)[NOUT]) {
+// (COPY: the columns just loaded -- zero beyond the valid bytes -- are also stored as the codeword's data shards at copy_cw:
+// RSCodeword::from_data's pad + split, rscoding.rs:188-200, at no extra read)
+template <int NOUT, int NIN, bool COPY = false>
+__device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t *cw, uint64_t c0, u32x4 (&acc)[NOUT],
+                                                 uint8_t *copy_cw = nullptr, uint8_t *fan_cw = nullptr) {
     u32x4 x[NIN];
 #pragma unroll
     for (int c = 0; c < NIN; c++) x[c] = (c < a.n_in) ? load_cols(a, cw, c, c0) : (u32x4){0u, 0u, 0u, 0u};
+    if (COPY) {
+#pragma unroll
+        for (int c = 0; c < NIN; c++)
+            if (c < a.n_in) {
+                store_block(copy_cw + a.in_off[c] + c0, c0, a.shard_len, x[c]);
+                if (fan_cw && ((a.fan_mask >> c) & 1u)) store_block(fan_cw + (uint64_t)c * a.fan_shard_stride + c0, c0, a.shard_len, x[c]);
+            }
+    }
 #pragma unroll
     for (int r = 0; r < NOUT; r++) {
         u32x4 s = {0u, 0u, 0u, 0u};
@@ -159,6 +179,24 @@ __global__ __launch_bounds__(256) void rs_matmul_xtime(const RsArgs a) {
 #pragma unroll
     for (int r = 0; r < NOUT; r++)
         if (r < a.n_out) store_cols(a, ocw, r, c0, acc[r]);
+}
+
+// from_data + compute_parity in one pass over the serialized bytes (rscoding.rs:165-243 + :447-486): read L, write d + p shards
+template <int NOUT, int NIN>
+__global__ __launch_bounds__(256) void rs_from_data_xtime(const RsArgs a) {
+    uint64_t cw_i, c0;
+    if (!rs_locate(a, cw_i, c0)) return;
+    u32x4 acc[NOUT];
+    uint8_t *fan_cw = a.fan_base ? a.fan_base + cw_i * a.fan_cw_stride : nullptr;
+    rs_product_xtime<NOUT, NIN, true>(a, a.in_base + cw_i * a.in_cw_stride, c0, acc, a.copy_base + cw_i * a.copy_cw_stride, fan_cw);
+    uint8_t *ocw = a.out_base + cw_i * a.out_cw_stride;
+#pragma unroll
+    for (int r = 0; r < NOUT; r++)
+        if (r < a.n_out) {
+            store_cols(a, ocw, r, c0, acc[r]);
+            if (fan_cw && ((a.fan_mask >> (a.n_in + r)) & 1u))
+                store_block(fan_cw + (uint64_t)(a.n_in + r) * a.fan_shard_stride + c0, c0, a.shard_len, acc[r]);
+        }
 }
 
 // LDS product-table variant: tab[(r * n_in + c) * 256 + v] = coef[r][c] * v
@@ -361,6 +399,8 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
         if (a.n_out <= 2) hipLaunchKernelGGL(rs_matmul_lut<2>, grid, block, ntab, st, a, lut);
         else if (a.n_out <= 4) hipLaunchKernelGGL(rs_matmul_lut<4>, grid, block, ntab, st, a, lut);
         else hipLaunchKernelGGL(rs_matmul_lut<8>, grid, block, ntab, st, a, lut);
+    } else if (a.copy_base) {
+        RS_DISPATCH(rs_from_data_xtime, a, grid, block, 0, st, a);
     } else {
         RS_DISPATCH(rs_matmul_xtime, a, grid, block, 0, st, a);
     }
@@ -370,10 +410,12 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
 
 template <bool LUT>
 static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,
-                          int p, uint8_t *parity, uint64_t par_stride, uint64_t par_shard_stride, void *stream) {
+                          int p, uint8_t *parity, uint64_t par_stride, uint64_t par_shard_stride, void *stream,
+                          uint8_t *copy_base = nullptr, uint64_t copy_cw_stride = 0, uint8_t *fan_base = nullptr,
+                          uint64_t fan_shard_stride = 0, uint64_t fan_cw_stride = 0, uint32_t fan_mask = 0) {
     if (d <= 0) return fail(SMR_ERR_ARG, "num_data_shards is zero");          // rscoding.rs:172-174
     if (data_len == 0) return fail(SMR_ERR_ARG, "codeword is null");          // rscoding.rs:451-453
-    if (p == 0) return SMR_OK;                                                 // rscoding.rs:454-456
+    if (p == 0 && !copy_base) return SMR_OK;                                   // rscoding.rs:454-456
     if (d > RS_MAX_IN || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: scheme exceeds d<=16, p<=8");
     if (!data || !parity) return fail(SMR_ERR_ARG, "rs: null buffer");
     uint8_t m[(RS_MAX_IN + RS_MAX_OUT) * RS_MAX_IN];
@@ -381,6 +423,8 @@ static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_st
     RsArgs a = {};
     a.in_base = data; a.out_base = parity;
     a.in_cw_stride = cw_stride; a.out_cw_stride = par_stride;
+    a.copy_base = copy_base; a.copy_cw_stride = copy_cw_stride;
+    a.fan_base = fan_mask ? fan_base : nullptr; a.fan_shard_stride = fan_shard_stride; a.fan_cw_stride = fan_cw_stride; a.fan_mask = fan_mask;
     a.shard_len = smr_rs_shard_len(data_len, d);
     a.in_valid = data_len;
     a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + data_len : 0;   // rows may be packed tightly (cw_stride == data_len)
@@ -414,6 +458,29 @@ int smr_rs_encode(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride
                   uint8_t *parity_dev, uint64_t par_stride, uint64_t par_shard_stride, void *stream) {
     return rs_encode_impl<false>(data_dev, data_len, cw_stride, n_cw, d, p, parity_dev, par_stride,
                                  par_shard_stride, stream);
+}
+
+int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                   uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
+                                   uint64_t fan_cw_stride, uint32_t fan_mask, void *stream) {
+    if (!cw_dev) return fail(SMR_ERR_ARG, "rs: null buffer");
+    const uint64_t sl = smr_rs_shard_len(data_len, d);
+    if (d > 0 && cw_stride < (uint64_t)(d + p) * sl) return fail(SMR_ERR_ARG, "rs: cw_stride < (d + p) * shard_len");
+    if (src_dev && src_dev < cw_dev + n_cw * cw_stride && cw_dev < src_dev + n_cw * src_stride)
+        return fail(SMR_ERR_ARG, "rs: source and codeword buffers overlap");
+    if (fan_mask) {
+        if (!fan_dev) return fail(SMR_ERR_ARG, "rs: fan-out mask without a buffer");
+        if (d > 0 && (fan_mask >> (d + p))) return fail(SMR_ERR_ARG, "rs: fan-out mask names a shard beyond d + p");
+        if (fan_cw_stride < sl || (n_cw && fan_shard_stride < (n_cw - 1) * fan_cw_stride + sl))
+            return fail(SMR_ERR_ARG, "rs: fan-out strides: a store holds n_cw shards of shard_len bytes, fan_cw_stride apart");
+    }
+    return rs_encode_impl<false>(src_dev, data_len, src_stride, n_cw, d, p, cw_dev + (uint64_t)(d > 0 ? d : 0) * sl, cw_stride, sl, stream,
+                                 cw_dev, cw_stride, fan_dev, fan_shard_stride, fan_cw_stride, fan_mask);
+}
+
+int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                            uint8_t *cw_dev, uint64_t cw_stride, void *stream) {
+    return smr_rs_from_data_encode_fanout(src_dev, data_len, src_stride, n_cw, d, p, cw_dev, cw_stride, nullptr, 0, 0, 0, stream);
 }
 
 int smr_rs_encode_lut(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,

@@ -34,7 +34,7 @@ def rs_shard_len(data_len, d):
 class RSCodewordBatch:
     """n RSCodewords sharing (d, p, data_len); see module docstring."""
 
-    def __init__(self, n, data_len, num_data_shards, num_parity_shards, device="cuda"):
+    def __init__(self, n, data_len, num_data_shards, num_parity_shards, device="cuda", zero=True):
         import torch
         if num_data_shards == 0:
             raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards is zero")
@@ -45,7 +45,8 @@ class RSCodewordBatch:
         self.shard_len = rs_shard_len(self.data_len, self.d) if self.data_len else 0
         total = (self.d + self.p) * self.shard_len
         self.cw_stride = (total + 15) // 16 * 16
-        self.buf = torch.zeros((self.n, max(self.cw_stride, 16)), dtype=torch.uint8, device=device)
+        alloc = torch.zeros if zero else torch.empty
+        self.buf = alloc((self.n, max(self.cw_stride, 16)), dtype=torch.uint8, device=device)
         self.avail = 0  # bitmap of available shard indexes (avail_shards_map)
 
     # -- constructors ------------------------------------------------------
@@ -55,6 +56,38 @@ class RSCodewordBatch:
         cw = cls(data.shape[0], data.shape[1], num_data_shards, num_parity_shards, device=data.device)
         cw.buf[:, :cw.data_len].copy_(data)
         cw.avail = (1 << cw.d) - 1
+        return cw
+
+    @classmethod
+    def from_data_and_encode(cls, data, num_data_shards, num_parity_shards, stream=None, out=None, fan_out=None, fan_mask=None):
+        """`from_data` followed by `compute_parity` (what an RSPaxos / CRaft leader does with every batch,
+        rspaxos/request.rs:88-101) as ONE pass over `data` (`smr_rs_from_data_encode`): the serialized bytes are read once
+        and the d data shards (zero padding included) and p parity shards are written -- no separate copy into the codeword
+        buffer.  `data`: uint8 [n, data_len], rows contiguous.  `out`: a batch of the same geometry to refill (its buffer is
+        reused); else a new one.  `fan_out`: uint8 [d + p, n, shard_len] (contiguous) -- store k receives shard k of every
+        codeword in the same pass, for the k in `fan_mask` (default: all): the leader's shard fan-out, rspaxos/request.rs:127-142."""
+        if data.dim() != 2 or data.stride(1) != 1:
+            raise SummersetError(_lib.SMR_ERR_ARG, "data must be [n, data_len] with contiguous rows")
+        n, L = int(data.shape[0]), int(data.shape[1])
+        if out is None:
+            cw = cls(n, L, num_data_shards, num_parity_shards, device=data.device, zero=False)
+        else:
+            cw = out
+            if (cw.n, cw.data_len, cw.d, cw.p) != (n, L, int(num_data_shards), int(num_parity_shards)):
+                raise SummersetError(_lib.SMR_ERR_ARG, "`out` has another geometry")
+        if L == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        if fan_out is None:
+            check(_lib.load().smr_rs_from_data_encode(data.data_ptr(), L, int(data.stride(0)), n, cw.d, cw.p, cw.buf.data_ptr(),
+                                                      cw.cw_stride, stream_ptr(stream)))
+        else:
+            if tuple(fan_out.shape) != (cw.d + cw.p, n, cw.shard_len) or not fan_out.is_contiguous():
+                raise SummersetError(_lib.SMR_ERR_ARG, "fan_out must be a contiguous uint8 [d + p, n, shard_len]")
+            mask = (1 << (cw.d + cw.p)) - 1 if fan_mask is None else int(fan_mask)
+            check(_lib.load().smr_rs_from_data_encode_fanout(data.data_ptr(), L, int(data.stride(0)), n, cw.d, cw.p, cw.buf.data_ptr(),
+                                                             cw.cw_stride, fan_out.data_ptr(), n * cw.shard_len, cw.shard_len, mask,
+                                                             stream_ptr(stream)))
+        cw.avail = (1 << (cw.d + cw.p)) - 1
         return cw
 
     @classmethod

@@ -170,3 +170,83 @@ def tick(reps, val, target, timeouts=None, drop=None, heartbeat=False):
             hb = reps[s].bcast_heartbeat(fl)
             _deliver_heartbeat(reps, s, fl, hb["ballot"], hb["commit_bar"], hb["exec_bar"], hb["snap_bar"], drop)
     return log
+
+
+class SteadyLoop:
+    """The steady state of a co-located RSPaxos cluster (one prepared leader, no timeouts) with every message a DEVICE tensor
+    between the handlers -- the closed loop `tick` above drives through numpy, here without a host round trip, so that a tick
+    can be timed and captured into a HIP graph: per tick the leader's `handle_req_batch` on the tick's batches, the followers'
+    `handle_msg_accept` with the mask of the ONE shard they were sent, the leader's `handle_msg_accept_reply` tally with the
+    shard-availability gate behind it (durability.rs:140-160), and -- on a heartbeat tick -- the leader's Heartbeat, the
+    followers' handling of it and their Heartbeats back.  Same handler calls, same order as `tick` for such a tick
+    (tests/test_zz_rsp_steady_gpu.py holds it against `tick` on five oracles).  The shard fan-out (follower q gets shard q of
+    every new codeword, rspaxos/request.rs:127-142) is `encode`: from_data + RS encode + the R shard stores in ONE pass over the
+    serialized batches (smr_rs_from_data_encode_fanout) -- the co-located stand-in for the Accepts' payload.
+    Every output and scratch tensor is made once and written again every tick."""
+
+    def __init__(self, reps, leader=0):
+        self.reps, self.R, self.G, self.s = list(reps), len(reps), reps[0].G, int(leader)
+        self.stores = None                       # [R, G, shard_len]: store q = what replica q holds of the tick's codewords (shard q)
+        self._b = None
+
+    def _bufs(self, dev):
+        import torch
+        if self._b is None:
+            R, G, W = self.R, self.G, self.reps[0].W
+            z = lambda dt, *sh: torch.zeros(sh or (G,), dtype=dt, device=dev)
+            hb = lambda: dict(ballot=z(torch.int64), commit_bar=z(torch.int32), exec_bar=z(torch.int32), snap_bar=z(torch.int32))
+            self._b = dict(acc=dict(a_n=z(torch.int32), a_slot=z(torch.int32, W, G), a_val=z(torch.int32, W, G), a_ballot=z(torch.int64)),
+                           peer=[torch.full((G,), q, dtype=torch.uint8, device=dev) for q in range(R)],
+                           mask=[torch.full((G,), 1 << q, dtype=torch.uint8, device=dev) for q in range(R)],
+                           ballot=z(torch.int64, R, G), r_slot=z(torch.int32, R, G), committed=dict(committed=z(torch.uint8)),
+                           ones=torch.ones(G, dtype=torch.uint8, device=dev), hb=hb(),
+                           rp=[dict(reply=z(torch.uint8), **hb()) for _ in range(R)], back=dict(reply=z(torch.uint8), **hb()))
+        return self._b
+
+    def encode(self, data, out=None, stream=None):
+        """from_data + compute_parity of the tick's batches (`data`: uint8 [G, L]) and every replica's shard store, one pass"""
+        import torch
+        from .rscoding import RSCodewordBatch, rs_shard_len
+        sl = rs_shard_len(int(data.shape[1]), self.R // 2 + 1)
+        if self.stores is None or self.stores.shape[2] != sl:
+            self.stores = torch.empty((self.R, self.G, sl), dtype=torch.uint8, device=data.device)
+        d = self.R // 2 + 1                       # rspaxos/mod.rs:599-609: RS(majority, R - majority)
+        return RSCodewordBatch.from_data_and_encode(data, d, self.R - d, stream=stream, out=out, fan_out=self.stores)
+
+    def tick(self, val, lost=None, heartbeat=False):
+        """val: int32 [G] batch tokens (NULL = none); lost: optional dict (kind, from, to) -> bool [G] like `tick`'s drop.
+        Returns the leader's `committed` flags [G] (valid until the next tick)."""
+        import torch
+        R, s, dev = self.R, self.s, val.device
+        reps, b = self.reps, self._bufs(dev)
+        gone = lambda kind, a, c: None if lost is None else lost.get((kind, a, c))
+        acc = reps[s].req_batch(val, out=b["acc"])
+        live = (acc["a_n"] > 0).to(torch.uint8)
+        slot, tok = acc["a_slot"][0], acc["a_val"][0]
+        for q in range(R):
+            if q == s:
+                continue
+            fl = live if gone("accept", s, q) is None else (live & ~gone("accept", s, q).to(torch.uint8))
+            reps[q].accept(flags=fl, peer=b["peer"][s], slot=slot, ballot=acc["a_ballot"], val=tok, mask=b["mask"][q],
+                           out=dict(r_ballot=b["ballot"][q], r_slot=b["r_slot"][q]))
+        flags = (b["ballot"] != 0).to(torch.uint8)                  # (row s stays zero: nobody writes it)
+        if lost is not None:
+            for q in range(R):
+                if q != s and gone("accept_reply", q, s) is not None:
+                    flags[q] &= ~gone("accept_reply", q, s).to(torch.uint8)
+        res = reps[s].accept_replies(slot=slot, ballot=b["ballot"], flags=flags, out=b["committed"])
+        committed = res["committed"] & live
+        if heartbeat:
+            hb = reps[s].bcast_heartbeat(b["ones"], out=b["hb"])
+            for q in range(R):
+                if q == s:
+                    continue
+                fl = b["ones"] if gone("hb", s, q) is None else (b["ones"] & ~gone("hb", s, q).to(torch.uint8))
+                rp = reps[q].heartbeat(flags=fl, peer=b["peer"][s], ballot=hb["ballot"], commit_bar=hb["commit_bar"], exec_bar=hb["exec_bar"],
+                                       snap_bar=hb["snap_bar"], out=b["rp"][q])
+                back = rp["reply"]
+                if gone("hb", q, s) is not None:
+                    back = back & ~gone("hb", q, s).to(torch.uint8)
+                reps[s].heartbeat(flags=back, peer=b["peer"][q], ballot=rp["ballot"], commit_bar=rp["commit_bar"], exec_bar=rp["exec_bar"],
+                                  snap_bar=rp["snap_bar"], out=b["back"])
+        return committed

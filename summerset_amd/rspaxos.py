@@ -48,37 +48,40 @@ class RSPaxosReplicaGroup:
         import torch
         return torch.full(shape or (self.G,), fill, dtype=dtype, device=dev)
 
-    def _accepts(self, dev):
+    def _accepts(self, dev, out=None):
         import torch
-        d = dict(a_n=self._z(dev, torch.int32), a_slot=self._z(dev, torch.int32, self.W, self.G),
-                 a_val=self._z(dev, torch.int32, self.W, self.G), a_ballot=self._z(dev, torch.int64))
+        d = out if out is not None else dict(a_n=self._z(dev, torch.int32), a_slot=self._z(dev, torch.int32, self.W, self.G),
+                                             a_val=self._z(dev, torch.int32, self.W, self.G), a_ballot=self._z(dev, torch.int64))
         return d, RspAccepts(_ptr(d["a_n"]), _ptr(d["a_slot"]), _ptr(d["a_val"]), _ptr(d["a_ballot"]))
 
-    def _hb(self, dev, prefix, with_flags):
+    def _hb(self, dev, prefix, with_flags, out=None):
         import torch
-        d = {prefix + "ballot": self._z(dev, torch.int64), prefix + "commit": self._z(dev, torch.int32),
-             prefix + "exec": self._z(dev, torch.int32), prefix + "snap": self._z(dev, torch.int32)}
-        if with_flags:
+        d = out if out is not None else {prefix + "ballot": self._z(dev, torch.int64), prefix + "commit": self._z(dev, torch.int32),
+                                         prefix + "exec": self._z(dev, torch.int32), prefix + "snap": self._z(dev, torch.int32)}
+        if with_flags and out is None:
             d[prefix + "flags"] = self._z(dev, torch.uint8)
         return d, RspHeartbeat(_ptr(d.get(prefix + "flags")), _ptr(d[prefix + "ballot"]), _ptr(d[prefix + "commit"]),
                                _ptr(d[prefix + "exec"]), _ptr(d[prefix + "snap"]))
 
     # ---- handlers -------------------------------------------------------------------------------
-    def req_batch(self, val, stream=None):
-        d, s = self._accepts(val.device)
+    # `out` (where a handler takes it): the dict an earlier call of the same handler returned -- its tensors are written again
+    # instead of fresh ones being made and filled (every kernel writes every element of its per-group outputs; of a [W, G]
+    # list the first a_n[g] entries): what a loop that runs the same handlers every tick, or inside a HIP graph, passes
+    def req_batch(self, val, stream=None, out=None):
+        d, s = self._accepts(val.device, out)
         check(self._L.smr_rsp_req_batch(self._h, _ptr(val), C.byref(s), stream_ptr(stream)))
         return d
 
-    def accept(self, flags, peer, slot, ballot, val, mask, stream=None):
+    def accept(self, flags, peer, slot, ballot, val, mask, stream=None, out=None):
         import torch
-        d = dict(r_ballot=self._z(flags.device, torch.int64), r_slot=self._z(flags.device, torch.int32))
+        d = out if out is not None else dict(r_ballot=self._z(flags.device, torch.int64), r_slot=self._z(flags.device, torch.int32))
         check(self._L.smr_rsp_handle_accept(self._h, _ptr(flags), _ptr(peer), _ptr(slot), _ptr(ballot), _ptr(val), _ptr(mask),
                                             _ptr(d["r_ballot"]), _ptr(d["r_slot"]), stream_ptr(stream)))
         return d
 
-    def accept_replies(self, slot, ballot, flags, order=None, stream=None):
+    def accept_replies(self, slot, ballot, flags, order=None, stream=None, out=None):
         import torch
-        d = dict(committed=self._z(flags.device, torch.uint8))
+        d = out if out is not None else dict(committed=self._z(flags.device, torch.uint8))
         check(self._L.smr_rsp_handle_accept_replies(self._h, _ptr(slot), _ptr(ballot), _ptr(flags), _ptr(order),
                                                     _ptr(d["committed"]), stream_ptr(stream)))
         return d
@@ -125,18 +128,27 @@ class RSPaxosReplicaGroup:
         s = RspShards(_ptr(rr_n), _ptr(rr_slot), _ptr(rr_bal), _ptr(rr_val), _ptr(rr_mask))
         check(self._L.smr_rsp_handle_reconstruct_reply(self._h, _ptr(flags), C.byref(s), stream_ptr(stream)))
 
-    def heartbeat(self, flags, peer, ballot, commit_bar, exec_bar, snap_bar, stream=None):
+    def heartbeat(self, flags, peer, ballot, commit_bar, exec_bar, snap_bar, stream=None, out=None):
         import torch
         dev = flags.device
-        o, out = self._hb(dev, "", False)
-        reply = self._z(dev, torch.uint8)
+        if out is not None:
+            o = dict(ballot=out["ballot"], commit=out["commit_bar"], exec=out["exec_bar"], snap=out["snap_bar"])
+            reply = out["reply"]
+            hb = RspHeartbeat(None, _ptr(o["ballot"]), _ptr(o["commit"]), _ptr(o["exec"]), _ptr(o["snap"]))
+        else:
+            o, hb = self._hb(dev, "", False)
+            reply = self._z(dev, torch.uint8)
         inp = RspHeartbeat(_ptr(flags), _ptr(ballot), _ptr(commit_bar), _ptr(exec_bar), _ptr(snap_bar))
-        check(self._L.smr_rsp_handle_heartbeat(self._h, _ptr(peer), C.byref(inp), _ptr(reply), C.byref(out), stream_ptr(stream)))
+        check(self._L.smr_rsp_handle_heartbeat(self._h, _ptr(peer), C.byref(inp), _ptr(reply), C.byref(hb), stream_ptr(stream)))
         return dict(reply=reply, ballot=o["ballot"], commit_bar=o["commit"], exec_bar=o["exec"], snap_bar=o["snap"])
 
-    def bcast_heartbeat(self, flags, stream=None):
-        o, out = self._hb(flags.device, "", False)
-        check(self._L.smr_rsp_bcast_heartbeat(self._h, _ptr(flags), C.byref(out), stream_ptr(stream)))
+    def bcast_heartbeat(self, flags, stream=None, out=None):
+        if out is not None:
+            o = dict(ballot=out["ballot"], commit=out["commit_bar"], exec=out["exec_bar"], snap=out["snap_bar"])
+            hb = RspHeartbeat(None, _ptr(o["ballot"]), _ptr(o["commit"]), _ptr(o["exec"]), _ptr(o["snap"]))
+        else:
+            o, hb = self._hb(flags.device, "", False)
+        check(self._L.smr_rsp_bcast_heartbeat(self._h, _ptr(flags), C.byref(hb), stream_ptr(stream)))
         return dict(ballot=o["ballot"], commit_bar=o["commit"], exec_bar=o["exec"], snap_bar=o["snap"])
 
     def dump(self):

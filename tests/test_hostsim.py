@@ -158,6 +158,9 @@ def test_rs_kernels_on_the_host(sim, oracle):
         t.test_verify_detects_corruption("cpu")
         t.test_padding_bytes_are_never_read("cpu", oracle)
         t.test_subset_copy_and_absorb_other_rspaxos_flow("cpu", oracle)
+        for scheme, L in (((3, 2), 1), ((3, 2), 2), ((3, 2), 47), ((3, 2), 4099), ((6, 4), 777), ((1, 1), 33), ((12, 8), 1000), ((3, 0), 100)):
+            t.test_from_data_and_encode_one_pass("cpu", oracle, scheme, L)
+        t.test_from_data_and_encode_fans_the_shards_out("cpu", oracle)
 
 
 def test_rspaxos_kernels_on_the_host(sim, oracle):
@@ -170,6 +173,15 @@ def test_rspaxos_kernels_on_the_host(sim, oracle):
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 8, 0, 0)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 150, 16, 2, 1)
         t.test_random_handler_calls_match_oracle("cpu", oracle, 500, 32, 4, 2)
+
+
+def test_rspaxos_device_steady_loop_on_the_host(sim, oracle):
+    """summerset_amd/rsp_cluster.SteadyLoop (what the config-4 bench leg times) == the numpy-staged closed loop on oracles"""
+    import test_zz_rsp_steady_gpu as t
+    with sim.patched():
+        assert t.run_steady("cpu", oracle, 200, 16, 1, 0.1) > 0
+        assert t.run_steady("cpu", oracle, 130, 8, 0, 0.2, T=10) > 0
+        assert t.run_steady("cpu", oracle, 90, 16, 1, 0.05, T=5, with_cw=True) > 0
 
 
 def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):

@@ -212,3 +212,67 @@ def test_subset_copy_and_absorb_other_rspaxos_flow(cuda, oracle):
     again = cw.subset_copy(0b00111)
     again.absorb_other(cw.subset_copy(0b11100))               # overlapping shard 2: kept, not overwritten
     assert again.avail_shards() == 5 and again.verify_parity().all()
+
+
+@pytest.mark.parametrize("scheme,L", [((3, 2), 1), ((3, 2), 2), ((3, 2), 47), ((3, 2), 4099), ((3, 2), 4113), ((6, 4), 777), ((1, 1), 33),
+                                      ((4, 1), 4096), ((12, 8), 1000), ((3, 0), 100)])
+def test_from_data_and_encode_one_pass(cuda, oracle, scheme, L):
+    """`smr_rs_from_data_encode` -- from_data's pad + split fused into the encode's loads -- against the oracle (parity), the
+    source bytes (data shards, zero padding) and the two-step path (from_data, compute_parity) byte for byte; source rows
+    packed (stride = L) and strided; an existing batch refilled"""
+    import torch
+    from summerset_amd import RSCodewordBatch, SummersetError
+    d, p = scheme
+    rng = np.random.default_rng(L * 7 + d)
+    n = 41
+    data = rng.integers(0, 256, (n, L), dtype=np.uint8)
+    src = torch.from_numpy(data).to(cuda)
+    cw = RSCodewordBatch.from_data_and_encode(src, d, p)
+    sl = cw.shard_len
+    got = cw.buf[:, :(d + p) * sl].cpu().numpy()
+    padded = np.zeros((n, d * sl), np.uint8)
+    padded[:, :L] = data
+    assert np.array_equal(got[:, :d * sl], padded)                           # rscoding.rs:188-200
+    for i in range(n):
+        if p:
+            assert np.array_equal(got[i, d * sl:].reshape(p, sl), oracle.rs_encode(d, p, data[i])), (scheme, L, i)
+    two = RSCodewordBatch.from_data(src, d, p)
+    two.compute_parity()
+    assert np.array_equal(two.buf[:, :(d + p) * sl].cpu().numpy(), got)
+    assert cw.avail_shards() == d + p and np.array_equal(cw.get_data().cpu().numpy(), data)
+    if p:
+        assert cw.verify_parity().all()
+    wide = torch.zeros((n, L + 13), dtype=torch.uint8, device=cuda)          # rows with a stride of their own
+    wide[:, :L] = src
+    cw2 = RSCodewordBatch.from_data_and_encode(wide[:, :L], d, p, out=cw)
+    assert cw2 is cw and np.array_equal(cw.buf[:, :(d + p) * sl].cpu().numpy(), got)
+    with pytest.raises(SummersetError):
+        RSCodewordBatch.from_data_and_encode(src, d, p, out=RSCodewordBatch(n, L + 1, d, p, device=cuda))
+    with pytest.raises(SummersetError):
+        RSCodewordBatch.from_data_and_encode(src[:, :0], d, p)               # "codeword is null"
+
+
+def test_from_data_and_encode_fans_the_shards_out(cuda, oracle):
+    """`smr_rs_from_data_encode_fanout`: the same pass also fills one store per shard holder; masks; argument errors"""
+    import torch
+    from summerset_amd import RSCodewordBatch, SummersetError
+    rng = np.random.default_rng(99)
+    for (d, p), L, n in (((3, 2), 4113, 53), ((3, 2), 2, 5), ((6, 4), 1000, 17)):
+        data = rng.integers(0, 256, (n, L), dtype=np.uint8)
+        src = torch.from_numpy(data).to(cuda)
+        ref = RSCodewordBatch.from_data(src, d, p)
+        ref.compute_parity()
+        sl = ref.shard_len
+        for mask in (None, 0b10110 & ((1 << (d + p)) - 1), 1 << (d + p - 1)):
+            fan = torch.full((d + p, n, sl), 0xAB, dtype=torch.uint8, device=cuda)
+            cw = RSCodewordBatch.from_data_and_encode(src, d, p, fan_out=fan, fan_mask=mask)
+            assert torch.equal(cw.buf[:, :(d + p) * sl], ref.buf[:, :(d + p) * sl])
+            for k in range(d + p):
+                if mask is None or (mask >> k) & 1:
+                    assert torch.equal(fan[k], ref.shard(k)), (d, p, L, mask, k)
+                else:
+                    assert bool((fan[k] == 0xAB).all()), (d, p, L, mask, k)          # a store outside the mask is not touched
+        with pytest.raises(SummersetError):
+            RSCodewordBatch.from_data_and_encode(src, d, p, fan_out=torch.zeros((d + p, n, sl + 1), dtype=torch.uint8, device=cuda))
+        with pytest.raises(SummersetError):
+            RSCodewordBatch.from_data_and_encode(src, d, p, fan_out=torch.zeros((d + p, n, sl), dtype=torch.uint8, device=cuda), fan_mask=1 << (d + p))
