@@ -356,6 +356,22 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
                                    const uint32_t *end_slot_dev, const uint64_t *conflict_term_dev,
                                    const uint32_t *conflict_slot_dev, const uint8_t *flags_dev,
                                    const uint32_t *order_dev, void *stream);
+/* A BATCH of ticks in one call and -- per <= 16 ticks -- ONE launch: tick t = smr_raft_leader_append(n_new) followed by
+ * smr_raft_leader_handle_replies(the tick's replies), exactly as the two calls would do it, the group's state kept in
+ * registers from tick to tick (groups never talk to each other, so a lane runs its group's ticks back to back) and the next
+ * tick's inputs requested while this tick's are worked on.  n_new == NULL: no appends in that tick; flags == NULL: no
+ * replies in that tick.  Every array of every tick of the batch must stay untouched until the call's stream work is done.
+ * Plain Raft leaders (SMR_ERR_STATE after smr_raft_craft_enable). */
+typedef struct {
+    const uint32_t *n_new;          /* [G] */
+    const uint64_t *reply_term;     /* [R][G] */
+    const uint32_t *end_slot;       /* [R][G] */
+    const uint64_t *conflict_term;  /* [R][G] or NULL */
+    const uint32_t *conflict_slot;  /* [R][G] or NULL */
+    const uint8_t *flags;           /* [R][G] */
+    const uint32_t *order;          /* [G] or NULL = identity */
+} smr_raft_tick;
+int smr_raft_leader_run_ticks(smr_raft_leader *l, const smr_raft_tick *ticks, uint32_t n_ticks, void *stream);
 typedef struct {
     uint8_t *role; uint64_t *curr_term; uint32_t *log_len, *last_commit, *last_snap;
     uint32_t *next_slot, *try_next_slot, *match_slot;   /* [R][G] */

@@ -175,6 +175,10 @@ class WireCodeword(C.Structure):
                 ("data_len", C.c_uint64), ("shard_len", C.c_uint64), ("shard_off", C.c_uint64 * 16)]
 
 
+class RaftTick(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("n_new", "reply_term", "end_slot", "conflict_term", "conflict_slot", "flags", "order")]
+
+
 class EpClusterOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("proposed", "col", "seq0", "deps0", "decision", "committed", "seq", "deps")]
 
@@ -236,6 +240,7 @@ SYMBOLS = [
     ("smr_raft_leader_destroy", None, [_vp]),
     ("smr_raft_leader_append", _i, [_vp, _vp, _vp]),
     ("smr_raft_leader_handle_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_leader_run_ticks", _i, [_vp, _vp, _u32, _vp]),
     ("smr_raft_leader_dump", _i, [_vp, C.POINTER(RaftDumpBufs)]),
     ("smr_raft_leader_total_commits", _i, [_vp, C.POINTER(_u64)]),
     ("smr_raft_replica_preset", _i, [_vp, _u8, _u8, _u64, _u8]),

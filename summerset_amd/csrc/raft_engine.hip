@@ -62,6 +62,30 @@ __device__ __forceinline__ void raft_flush(const RaftView &v, unsigned int c[4])
     }
 }
 
+// handle_req_batch x n + handle_logged_leader_append per entry (request.rs:10-91, durability.rs:12-94) for one group's leader,
+// on registers: `len` and the peers' try_next_slot go in and out, the entries' terms (and CRaft masks) are stored, fs[p] = the
+// first slot sent to peer p by these appends (0xFFFFFFFF: none).  c[2] rejects (ring back-pressure), c[3] entries sent.
+template <int NR>
+__device__ __forceinline__ void raft_append_body(const RaftView &v, uint32_t g, uint32_t n, uint32_t &len, uint32_t start, uint32_t snap,
+                                                 uint64_t term, uint32_t (&tn)[NR], uint32_t (&fs)[NR], unsigned int (&c)[4]) {
+    for (uint32_t k = 0; k < n; k++) {
+        if (len - snap >= v.W) { c[2]++; continue; }   // ring back-pressure
+        const uint32_t slot = len;                   // request.rs:77
+        v.entry_term[(size_t)(slot & v.Wmask) * v.G + g] = term;
+        if (v.entry_mask) v.entry_mask[(size_t)(slot & v.Wmask) * v.G + g] = (uint8_t)((1u << v.R) - 1u);   // craft/request.rs:71-76: every shard
+        len++;
+        // durability.rs:28-88: who is sent entries, try_next_slot
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            if ((uint32_t)p >= v.R || (uint32_t)p == v.me || tn[p] < 1) continue;
+            uint32_t prev = tn[p] - 1;
+            if (prev < start) break;                 // logged_err
+            if (prev >= len) continue;
+            if (slot >= tn[p]) { if (fs[p] == 0xFFFFFFFFu) fs[p] = tn[p]; c[3] += slot + 1 - tn[p]; tn[p] = slot + 1; }
+        }
+    }
+}
+
 template <int NR>
 __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, const uint32_t *__restrict__ n_new,
                                                           uint32_t *__restrict__ ae_first) {
@@ -81,22 +105,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
                 uint32_t tn[NR];
 #pragma unroll
                 for (int p = 0; p < NR; p++) tn[p] = (uint32_t)p < v.R ? v.try_next_slot[(size_t)p * v.G + g] : 0;
-                for (uint32_t k = 0; k < n; k++) {
-                    if (len - snap >= v.W) { c[2]++; continue; }   // ring back-pressure
-                    const uint32_t slot = len;                   // request.rs:77
-                    v.entry_term[(size_t)(slot & v.Wmask) * v.G + g] = term;
-                    if (v.entry_mask) v.entry_mask[(size_t)(slot & v.Wmask) * v.G + g] = (uint8_t)((1u << v.R) - 1u);   // craft/request.rs:71-76: every shard
-                    len++;
-                    // durability.rs:28-88: who is sent entries, try_next_slot
-#pragma unroll
-                    for (int p = 0; p < NR; p++) {
-                        if ((uint32_t)p >= v.R || (uint32_t)p == v.me || tn[p] < 1) continue;
-                        uint32_t prev = tn[p] - 1;
-                        if (prev < start) break;                 // logged_err
-                        if (prev >= len) continue;
-                        if (slot >= tn[p]) { if (fs[p] == 0xFFFFFFFFu) fs[p] = tn[p]; c[3] += slot + 1 - tn[p]; tn[p] = slot + 1; }
-                    }
-                }
+                raft_append_body<NR>(v, g, n, len, start, snap, term, tn, fs, c);
                 v.log_len[g] = len;
                 if (len > v.W && len - v.W > v.ring_lo[g]) v.ring_lo[g] = len - v.W;
 #pragma unroll
@@ -121,6 +130,201 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
 // NR >= population: every per-peer array and every loop over peers is NR wide (5 for the common populations -- the
 // R x R match-index comparison is 25 selects instead of 64; one lane per group is one wavefront per SIMD, so the kernel's
 // time is its straight-line ALU between the two load rounds)
+// The leader's per-group state the reply handler works on, in registers (raft_replies_kernel loads and stores it around one
+// round of replies; raft_ticks_kernel keeps it across the ticks of a batch)
+template <int NR>
+struct RaftLeaderRegs {
+    uint32_t role, leader, len, start, rlo, commit, snap;
+    uint64_t term;
+    uint32_t nx[NR], tn[NR], mt[NR];
+    bool dirty[NR];
+    uint32_t o_role, o_leader, o_commit, o_snap;
+    uint64_t o_term;
+    __device__ __forceinline__ void load(const RaftView &v, uint32_t g) {
+        role = v.role[g]; leader = v.leader[g]; term = v.curr_term[g];
+        len = v.log_len[g]; start = v.start_slot[g]; rlo = v.ring_lo[g];
+        commit = v.last_commit[g]; snap = v.last_snap[g];
+        o_role = role; o_leader = leader; o_commit = commit; o_snap = snap; o_term = term;
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+            const size_t o = (size_t)p * v.G + g;
+            nx[p] = on ? v.next_slot[o] : 0; tn[p] = on ? v.try_next_slot[o] : 0; mt[p] = on ? v.match_slot[o] : 0;
+            dirty[p] = false;
+        }
+    }
+    __device__ __forceinline__ void store(const RaftView &v, uint32_t g) const {
+        if (role != o_role) v.role[g] = (uint8_t)role;
+        if (leader != o_leader) v.leader[g] = (uint8_t)leader;
+        if (term != o_term) v.curr_term[g] = term;
+        if (commit != o_commit) v.last_commit[g] = commit;
+        if (snap != o_snap) v.last_snap[g] = snap;
+#pragma unroll
+        for (int p = 0; p < NR; p++)
+            if (dirty[p]) {
+                const size_t o = (size_t)p * v.G + g;
+                v.next_slot[o] = nx[p]; v.try_next_slot[o] = tn[p]; v.match_slot[o] = mt[p];
+            }
+    }
+};
+
+// One AppendEntriesReply per peer (rf / rtm / res by peer id; conflict words read where a reply carries one), applied in `ctl`
+// order: handle_msg_append_entries_reply (raft/messages.rs:222-388) with check_term.
+// One lane per group and 65 536 groups are one wavefront per SIMD: the handler is a chain of dependent memory round trips,
+// so the chain is kept at TWO rounds of loads.  Round 1 (the caller's): the group's scalars, every peer's state and every
+// peer's reply (addressed by peer id, not by the delivery order, so nothing waits for the order word).  Pass A then replays
+// the replies in delivery order in registers -- everything of the handler except the commit scan, whose upper end `hi`
+// depends only on the match indices -- and round 2 loads the entry terms at those (<= R - 1) slots together.  Pass B
+// finishes the commit scans in the same order; it goes back to memory only when the entry at `hi` is of an older term (never
+// in a steady term).
+template <bool CRAFT, int NR>
+__device__ __forceinline__ void raft_replies_body(const RaftView &v, const CraftView &cv, uint32_t g, RaftLeaderRegs<NR> &S, uint32_t ctl,
+                                                  const uint32_t (&rf)[NR], const uint64_t (&rtm)[NR], const uint32_t (&res)[NR],
+                                                  const uint64_t *__restrict__ conflict_term, const uint32_t *__restrict__ conflict_slot,
+                                                  uint32_t commit_need, uint32_t &heard, unsigned int (&c)[4]) {
+    uint32_t &role = S.role, &leader = S.leader, &commit = S.commit, &snap = S.snap;
+    uint64_t &term = S.term;
+    const uint32_t len = S.len, start = S.start, rlo = S.rlo;
+    uint32_t (&nx)[NR] = S.nx, (&tn)[NR] = S.tn, (&mt)[NR] = S.mt;
+    bool (&dirty)[NR] = S.dirty;
+    uint32_t hi_at[NR];                                   // by delivery position: upper end of that reply's commit scan
+#pragma unroll
+    for (int q = 0; q < NR; q++) hi_at[q] = 0xFFFFFFFFu;
+    const uint64_t lead_term = term;                        // commit scans only happen while I lead: in this term
+    // ---- pass A -------------------------------------------------------------------------------------------
+    for (uint32_t oi = 0; oi < v.R; oi++) {
+        const uint32_t p = (ctl >> (3 * oi)) & 7u;
+        if (p == v.me || p >= v.R) continue;
+        const size_t o = (size_t)p * v.G + g;
+        // registers indexed by a runtime peer id: unrolled select
+        uint32_t f = 0, es = 0, nxp = 0, tnp = 0;
+        uint64_t rt = 0;
+#pragma unroll
+        for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
+        if (!(f & 1)) continue;
+        // leadership.rs:16-72 check_term
+        bool stepped = false;
+        if (rt > term) {
+            term = rt; leader = p;
+            v.voted_for[g] = NO_REP; v.votes[g] = 0;        // :21-22
+            if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
+        }
+        if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
+        if (CRAFT) heard |= 1u << p;
+        uint32_t mtp;
+        if (!(f & 2)) {
+            if (!CRAFT && nxp > es + 1) continue;           // :245-247
+            nxp = es + 1;
+            if (tnp < es + 1) tnp = es + 1;
+            mtp = es;
+#pragma unroll
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
+            // commit index, closed form of :256-275
+            const uint32_t need = CRAFT ? commit_need : v.thresh - 1;   // peers needed besides me
+            uint32_t m = 0xFFFFFFFFu;
+            if (need > 0) {
+                m = 0;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    if ((uint32_t)q >= v.R || (uint32_t)q == v.me) continue;
+                    uint32_t ge = 0;
+#pragma unroll
+                    for (int q2 = 0; q2 < NR; q2++)
+                        if ((uint32_t)q2 < v.R && (uint32_t)q2 != v.me && mt[q2] >= mt[q]) ge++;
+                    if (ge >= need && mt[q] > m) m = mt[q];
+                }
+            }
+            const uint32_t hi = m < len - 1 ? m : len - 1;
+#pragma unroll
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
+            // snapshot-safe index, closed form of :298-309
+            uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < NR; q++)
+                if ((uint32_t)q < v.R && (uint32_t)q != v.me && mt[q] < mn) mn = mt[q];
+            uint32_t cand = mn < es ? mn : es;
+            if (cand > snap) snap = cand;
+        } else {
+            if (nxp == 1) {                                 // :313-316
+                tnp = 1;
+            } else {
+                nxp -= 1;                                   // :318
+                const uint64_t ct = conflict_term ? conflict_term[o] : 0;
+                const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
+                for (bool more = true; more;) {              // :320-330, eight candidates per round of loads: the
+                    uint64_t e8[8]; bool ok8[8];            // loop's tests depend on next_slot alone
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t cnd = nxp - (uint32_t)k;
+                        ok8[k] = (uint32_t)k < nxp && cnd > start && cnd < len && cnd >= rlo && cnd >= cs && cnd > 1;
+                        e8[k] = ok8[k] ? v.entry_term[(size_t)(cnd & v.Wmask) * v.G + g] : 0ull;
+                    }
+                    more = false;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        if (!ok8[k] || e8[k] != ct) break;
+                        nxp -= 1;
+                        if (k == 7) more = true;
+                    }
+                }
+                tnp = nxp;                                  // :331
+                uint32_t prev = nxp - 1;
+                if (prev >= start && prev < len) {          // :335-340
+                    if (es + 1 > nxp) c[3] += es + 1 - nxp;
+                    tnp = es + 1;                           // :384
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
+        }
+    }
+    // ---- round 2: the entry terms at the scans' upper ends, together -------------------------------------------
+    uint64_t et[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const uint32_t h = hi_at[q];
+        et[q] = (h != 0xFFFFFFFFu && h > commit && h >= rlo) ? v.entry_term[(size_t)(h & v.Wmask) * v.G + g] : 0ull;
+    }
+    // ---- pass B: the scans of :256-275 / :278-293 in delivery order ----------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const uint32_t hi = hi_at[q];
+        if (hi == 0xFFFFFFFFu) continue;
+        for (uint32_t s2 = hi; s2 > commit; s2--) {
+            if (s2 < rlo) break;                            // beyond the term ring
+            const uint64_t e = s2 == hi ? et[q] : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + g];
+            if (e == lead_term) {
+                if (!CRAFT || !cv.partial[g]) {
+                    c[0] += s2 - commit;                    // :278-293 exec submissions
+                    commit = s2;
+                } else {                                    // craft/messages.rs:315-358: only what I hold enough shards of
+                    const uint32_t data = (1u << cv.quorum) - 1u;
+                    bool can_execute = true;
+                    for (uint32_t sl = commit + 1; sl <= s2; sl++) {
+                        if (sl < rlo) break;                // harness guard: the entry left the ring
+                        const size_t mi = (size_t)(sl & v.Wmask) * v.G + g;
+                        const uint32_t m = v.entry_mask[mi];
+                        if ((uint32_t)__popc(m) < cv.quorum) {              // :318-325 ask the peers for its shards, once
+                            if (sl > cv.last_recon[g]) {
+                                const uint32_t k = cv.rq_n[g];
+                                if (k < CRAFT_RQ) {
+                                    cv.rq_slot[(size_t)k * v.G + g] = sl; cv.rq_term[(size_t)k * v.G + g] = v.entry_term[mi];
+                                    cv.rq_n[g] = k + 1;
+                                }
+                                cv.last_recon[g] = sl;
+                            }
+                            can_execute = false;
+                            continue;
+                        } else if ((uint32_t)__popc(m & data) < cv.quorum) { v.entry_mask[mi] = (uint8_t)(m | data); ctr_add(v.counters, 4, 1); }   // :326-328
+                        if (can_execute) { c[0]++; commit = sl; }           // :329-345
+                    }
+                }
+                break;
+            }
+        }
+    }
+}
+
 template <bool CRAFT, int NR>
 __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, const uint64_t *__restrict__ reply_term,
                                                            const uint32_t *__restrict__ end_slot,
@@ -131,186 +335,105 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
     if (g < v.G) {
-        // One lane per group and 65 536 groups are one wavefront per SIMD: the kernel is a chain of dependent memory
-        // round trips, so the chain is kept at TWO rounds of loads.  Round 1: the group's scalars, every peer's state
-        // and every peer's reply (addressed by peer id, not by the delivery order, so nothing waits for the order
-        // word).  Pass A then replays the replies in delivery order in registers -- everything of the handler except
-        // the commit scan, whose upper end `hi` depends only on the match indices -- and round 2 loads the entry terms
-        // at those (<= R - 1) slots together.  Pass B finishes the commit scans in the same order; it goes back to
-        // memory only when the entry at `hi` is of an older term (never in a steady term).
         uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
         if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
-        uint32_t role = v.role[g], leader = v.leader[g];
-        uint64_t term = v.curr_term[g];
-        const uint32_t len = v.log_len[g], start = v.start_slot[g], rlo = v.ring_lo[g];
-        uint32_t commit = v.last_commit[g], snap = v.last_snap[g];
-        const uint32_t o_role = role, o_leader = leader, o_commit = commit, o_snap = snap;
-        const uint64_t o_term = term;
-        uint32_t nx[NR], tn[NR], mt[NR], rf[NR], res[NR];
+        RaftLeaderRegs<NR> S;
+        S.load(v, g);
+        uint32_t rf[NR], res[NR];
         uint64_t rtm[NR];
-        bool dirty[NR];
 #pragma unroll
         for (int p = 0; p < NR; p++) {
-            bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
-            size_t o = (size_t)p * v.G + g;
-            nx[p] = on ? v.next_slot[o] : 0; tn[p] = on ? v.try_next_slot[o] : 0; mt[p] = on ? v.match_slot[o] : 0;
-            rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
-            dirty[p] = false;
-        }
-        const uint32_t ctl = order ? order[g] : SMR_CTL_IDENTITY;
-        uint32_t hi_at[NR];                                   // by delivery position: upper end of that reply's commit scan
-#pragma unroll
-        for (int q = 0; q < NR; q++) hi_at[q] = 0xFFFFFFFFu;
-        const uint64_t lead_term = term;                        // commit scans only happen while I lead: in this term
-        // ---- pass A -------------------------------------------------------------------------------------------
-        for (uint32_t oi = 0; oi < v.R; oi++) {
-            const uint32_t p = (ctl >> (3 * oi)) & 7u;
-            if (p == v.me || p >= v.R) continue;
+            const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
             const size_t o = (size_t)p * v.G + g;
-            // registers indexed by a runtime peer id: unrolled select
-            uint32_t f = 0, es = 0, nxp = 0, tnp = 0;
-            uint64_t rt = 0;
-#pragma unroll
-            for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = rf[q]; rt = rtm[q]; es = res[q]; nxp = nx[q]; tnp = tn[q]; }
-            if (!(f & 1)) continue;
-            // leadership.rs:16-72 check_term
-            bool stepped = false;
-            if (rt > term) {
-                term = rt; leader = p;
-                v.voted_for[g] = NO_REP; v.votes[g] = 0;        // :21-22
-                if (role != ROLE_FOLLOWER) { role = ROLE_FOLLOWER; stepped = true; }
-            }
-            if (stepped || role != ROLE_LEADER) continue;      // messages.rs:239-241
-            if (CRAFT) heard |= 1u << p;
-            uint32_t mtp;
-            if (!(f & 2)) {
-                if (!CRAFT && nxp > es + 1) continue;           // :245-247
-                nxp = es + 1;
-                if (tnp < es + 1) tnp = es + 1;
-                mtp = es;
-#pragma unroll
-                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; mt[q] = mtp; dirty[q] = true; }
-                // commit index, closed form of :256-275
-                const uint32_t need = CRAFT ? commit_need : v.thresh - 1;   // peers needed besides me
-                uint32_t m = 0xFFFFFFFFu;
-                if (need > 0) {
-                    m = 0;
-#pragma unroll
-                    for (int q = 0; q < NR; q++) {
-                        if ((uint32_t)q >= v.R || (uint32_t)q == v.me) continue;
-                        uint32_t ge = 0;
-#pragma unroll
-                        for (int q2 = 0; q2 < NR; q2++)
-                            if ((uint32_t)q2 < v.R && (uint32_t)q2 != v.me && mt[q2] >= mt[q]) ge++;
-                        if (ge >= need && mt[q] > m) m = mt[q];
-                    }
-                }
-                const uint32_t hi = m < len - 1 ? m : len - 1;
-#pragma unroll
-                for (int q = 0; q < NR; q++) if ((uint32_t)q == oi) hi_at[q] = hi;
-                // snapshot-safe index, closed form of :298-309
-                uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < NR; q++)
-                    if ((uint32_t)q < v.R && (uint32_t)q != v.me && mt[q] < mn) mn = mt[q];
-                uint32_t cand = mn < es ? mn : es;
-                if (cand > snap) snap = cand;
-            } else {
-                if (nxp == 1) {                                 // :313-316
-                    tnp = 1;
-                } else {
-                    nxp -= 1;                                   // :318
-                    const uint64_t ct = conflict_term ? conflict_term[o] : 0;
-                    const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
-                    for (bool more = true; more;) {              // :320-330, eight candidates per round of loads: the
-                        uint64_t e8[8]; bool ok8[8];            // loop's tests depend on next_slot alone
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const uint32_t cnd = nxp - (uint32_t)k;
-                            ok8[k] = (uint32_t)k < nxp && cnd > start && cnd < len && cnd >= rlo && cnd >= cs && cnd > 1;
-                            e8[k] = ok8[k] ? v.entry_term[(size_t)(cnd & v.Wmask) * v.G + g] : 0ull;
-                        }
-                        more = false;
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            if (!ok8[k] || e8[k] != ct) break;
-                            nxp -= 1;
-                            if (k == 7) more = true;
-                        }
-                    }
-                    tnp = nxp;                                  // :331
-                    uint32_t prev = nxp - 1;
-                    if (prev >= start && prev < len) {          // :335-340
-                        if (es + 1 > nxp) c[3] += es + 1 - nxp;
-                        tnp = es + 1;                           // :384
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { nx[q] = nxp; tn[q] = tnp; dirty[q] = true; }
-            }
+            rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
         }
-        // ---- round 2: the entry terms at the scans' upper ends, together -------------------------------------------
-        uint64_t et[NR];
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const uint32_t h = hi_at[q];
-            et[q] = (h != 0xFFFFFFFFu && h > commit && h >= rlo) ? v.entry_term[(size_t)(h & v.Wmask) * v.G + g] : 0ull;
-        }
-        // ---- pass B: the scans of :256-275 / :278-293 in delivery order ----------------------------------------------
-#pragma unroll
-        for (int q = 0; q < NR; q++) {
-            const uint32_t hi = hi_at[q];
-            if (hi == 0xFFFFFFFFu) continue;
-            for (uint32_t s2 = hi; s2 > commit; s2--) {
-                if (s2 < rlo) break;                            // beyond the term ring
-                const uint64_t e = s2 == hi ? et[q] : v.entry_term[(size_t)(s2 & v.Wmask) * v.G + g];
-                if (e == lead_term) {
-                    if (!CRAFT || !cv.partial[g]) {
-                        c[0] += s2 - commit;                    // :278-293 exec submissions
-                        commit = s2;
-                    } else {                                    // craft/messages.rs:315-358: only what I hold enough shards of
-                        const uint32_t data = (1u << cv.quorum) - 1u;
-                        bool can_execute = true;
-                        for (uint32_t sl = commit + 1; sl <= s2; sl++) {
-                            if (sl < rlo) break;                // harness guard: the entry left the ring
-                            const size_t mi = (size_t)(sl & v.Wmask) * v.G + g;
-                            const uint32_t m = v.entry_mask[mi];
-                            if ((uint32_t)__popc(m) < cv.quorum) {              // :318-325 ask the peers for its shards, once
-                                if (sl > cv.last_recon[g]) {
-                                    const uint32_t k = cv.rq_n[g];
-                                    if (k < CRAFT_RQ) {
-                                        cv.rq_slot[(size_t)k * v.G + g] = sl; cv.rq_term[(size_t)k * v.G + g] = v.entry_term[mi];
-                                        cv.rq_n[g] = k + 1;
-                                    }
-                                    cv.last_recon[g] = sl;
-                                }
-                                can_execute = false;
-                                continue;
-                            } else if ((uint32_t)__popc(m & data) < cv.quorum) { v.entry_mask[mi] = (uint8_t)(m | data); ctr_add(v.counters, 4, 1); }   // :326-328
-                            if (can_execute) { c[0]++; commit = sl; }           // :329-345
-                        }
-                    }
-                    break;
-                }
-            }
-        }
-        if (role != o_role) v.role[g] = (uint8_t)role;
-        if (leader != o_leader) v.leader[g] = (uint8_t)leader;
-        if (term != o_term) v.curr_term[g] = term;
-        if (commit != o_commit) v.last_commit[g] = commit;
-        if (snap != o_snap) v.last_snap[g] = snap;
-#pragma unroll
-        for (int p = 0; p < NR; p++)
-            if (dirty[p]) {
-                size_t o = (size_t)p * v.G + g;
-                v.next_slot[o] = nx[p]; v.try_next_slot[o] = tn[p]; v.match_slot[o] = mt[p];
-            }
+        raft_replies_body<CRAFT, NR>(v, cv, g, S, order ? order[g] : SMR_CTL_IDENTITY, rf, rtm, res, conflict_term, conflict_slot, commit_need, heard, c);
+        S.store(v, g);
         if (CRAFT && heard) {                                   // heartbeat.rs:284-290 update_heard_cnt
             for (uint32_t p = 0; p < v.R; p++)
                 if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
             const uint32_t al = cv.alive[g];
             if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
         }
+    }
+    raft_flush(v, c);
+}
+
+// A batch of <= RAFT_MAX_BATCH ticks in ONE launch: per tick the appends of that tick, then the peers' AppendEntriesReplies of
+// that tick -- what smr_raft_leader_append + smr_raft_leader_handle_replies do call by call, with the group's state kept in
+// registers across the ticks (groups never talk to each other, so a lane can run its group's ticks back to back) and the
+// next tick's inputs requested before this tick's are worked on.  Plain Raft leaders.
+constexpr int RAFT_MAX_BATCH = 16;
+struct RaftTickBatch {
+    uint32_t n;
+    const uint32_t *n_new[RAFT_MAX_BATCH];
+    const uint64_t *reply_term[RAFT_MAX_BATCH];
+    const uint32_t *end_slot[RAFT_MAX_BATCH];
+    const uint64_t *conflict_term[RAFT_MAX_BATCH];
+    const uint32_t *conflict_slot[RAFT_MAX_BATCH];
+    const uint8_t *flags[RAFT_MAX_BATCH];
+    const uint32_t *order[RAFT_MAX_BATCH];
+};
+
+template <int NR>
+__global__ __launch_bounds__(256) void raft_ticks_kernel(const RaftView v, const RaftTickBatch b) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    unsigned int c[4] = {0, 0, 0, 0};
+    if (g < v.G) {
+        const CraftView cv{};
+        RaftLeaderRegs<NR> S;
+        S.load(v, g);
+        const uint32_t len0 = S.len, rlo0 = S.rlo;
+        uint32_t heard = 0;
+        // the first tick's inputs (a tick without appends / without replies passes NULL)
+        uint32_t n = b.n_new[0] ? b.n_new[0][g] : 0u, ctl = b.order[0] ? b.order[0][g] : SMR_CTL_IDENTITY;
+        uint32_t rf[NR], res[NR];
+        uint64_t rtm[NR];
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+            const size_t o = (size_t)p * v.G + g;
+            const bool on0 = on && b.flags[0];
+            rf[p] = on0 ? b.flags[0][o] : 0u; rtm[p] = on0 ? b.reply_term[0][o] : 0ull; res[p] = on0 ? b.end_slot[0][o] : 0u;
+        }
+        for (uint32_t t = 0; t < b.n; t++) {
+            // the next tick's inputs, on their way while this tick runs (the last tick re-reads its own)
+            const uint32_t tn_ = t + 1 < b.n ? t + 1 : t;
+            const uint32_t n2 = b.n_new[tn_] ? b.n_new[tn_][g] : 0u, ctl2 = b.order[tn_] ? b.order[tn_][g] : SMR_CTL_IDENTITY;
+            uint32_t rf2[NR], res2[NR];
+            uint64_t rtm2[NR];
+#pragma unroll
+            for (int p = 0; p < NR; p++) {
+                const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+                const size_t o = (size_t)p * v.G + g;
+                const bool on2 = on && b.flags[tn_];
+                rf2[p] = on2 ? b.flags[tn_][o] : 0u; rtm2[p] = on2 ? b.reply_term[tn_][o] : 0ull; res2[p] = on2 ? b.end_slot[tn_][o] : 0u;
+            }
+            // smr_raft_leader_append
+            if (n) {
+                if (S.role != ROLE_LEADER) c[1] += n;          // request.rs:19-42 redirect
+                else {
+                    uint32_t fs[NR];
+#pragma unroll
+                    for (int p = 0; p < NR; p++) fs[p] = 0xFFFFFFFFu;
+                    const uint32_t before = S.len;
+                    raft_append_body<NR>(v, g, n, S.len, S.start, S.snap, S.term, S.tn, fs, c);
+                    if (S.len != before) {
+#pragma unroll
+                        for (int p = 0; p < NR; p++) if ((uint32_t)p < v.R && (uint32_t)p != v.me) S.dirty[p] = true;   // (try_next_slot moved)
+                    }
+                    if (S.len > v.W && S.len - v.W > S.rlo) S.rlo = S.len - v.W;
+                }
+            }
+            // smr_raft_leader_handle_replies
+            raft_replies_body<false, NR>(v, cv, g, S, ctl, rf, rtm, res, b.conflict_term[t], b.conflict_slot[t], v.thresh - 1, heard, c);
+            n = n2; ctl = ctl2;
+#pragma unroll
+            for (int p = 0; p < NR; p++) { rf[p] = rf2[p]; rtm[p] = rtm2[p]; res[p] = res2[p]; }
+        }
+        S.store(v, g);
+        if (S.len != len0) v.log_len[g] = S.len;
+        if (S.rlo != rlo0) v.ring_lo[g] = S.rlo;
     }
     raft_flush(v, c);
 }
@@ -825,6 +948,28 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
     else { if (l->craft) RAFT_REPLIES(true, RMAX); else RAFT_REPLIES(false, RMAX); }
 #undef RAFT_REPLIES
     SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_leader_run_ticks(smr_raft_leader *l, const smr_raft_tick *ticks, uint32_t n_ticks, void *stream) {
+    if (!l || (n_ticks && !ticks)) return fail(SMR_ERR_ARG, "raft: null argument");
+    if (l->craft) return fail(SMR_ERR_STATE, "raft: batches of ticks are for plain Raft leaders (a CRaft leader's tick has its own heartbeat step)");
+    for (uint32_t t = 0; t < n_ticks; t++)
+        if (ticks[t].flags && (!ticks[t].reply_term || !ticks[t].end_slot)) return fail(SMR_ERR_ARG, "raft: a tick with replies needs reply_term and end_slot");
+    const dim3 grid((l->v.G + 255) / 256), block(256);
+    for (uint32_t t0 = 0; t0 < n_ticks; t0 += RAFT_MAX_BATCH) {
+        RaftTickBatch b;
+        memset(&b, 0, sizeof(b));
+        b.n = n_ticks - t0 < (uint32_t)RAFT_MAX_BATCH ? n_ticks - t0 : (uint32_t)RAFT_MAX_BATCH;
+        for (uint32_t k = 0; k < b.n; k++) {
+            const smr_raft_tick &x = ticks[t0 + k];
+            b.n_new[k] = x.n_new; b.reply_term[k] = x.reply_term; b.end_slot[k] = x.end_slot; b.conflict_term[k] = x.conflict_term;
+            b.conflict_slot[k] = x.conflict_slot; b.flags[k] = x.flags; b.order[k] = x.order;
+        }
+        if (l->v.R <= 5) hipLaunchKernelGGL(raft_ticks_kernel<5>, grid, block, 0, (hipStream_t)stream, l->v, b);
+        else hipLaunchKernelGGL(raft_ticks_kernel<RMAX>, grid, block, 0, (hipStream_t)stream, l->v, b);
+        SMR_HIP_TRY(hipGetLastError());
+    }
     return SMR_OK;
 }
 

@@ -70,6 +70,19 @@ class RaftLeaderGroup:
                                                      _ptr(conflict_slot), _ptr(flags), _ptr(order),
                                                      stream_ptr(stream)))
 
+    def run_ticks(self, ticks, stream=None):
+        """a batch of ticks as ONE call (`smr_raft_leader_run_ticks`: one launch per <= 16 ticks): ticks[t] = dict(n_new=[G] or
+        None, reply_term / end_slot / flags = [R, G] (or flags None: no replies), conflict_term / conflict_slot / order
+        optional) -- tick t = handle_req_batch(n_new) then handle_msg_append_entries_reply(...), as the two calls would do it.
+        The tensors must stay untouched until the stream's work is done (they are kept referenced until the next call)."""
+        from ._lib import RaftTick
+        arr = (RaftTick * len(ticks))()
+        for t, x in enumerate(ticks):
+            for n, _ in RaftTick._fields_:
+                setattr(arr[t], n, _ptr(x.get(n)))
+        check(self._L.smr_raft_leader_run_ticks(self._h, arr, len(ticks), stream_ptr(stream)))
+        self._held_ticks = list(ticks)
+
     def dump(self):
         G, W, R = self.G, self.W, self.R
         out, bufs = {}, RaftDumpBufs()

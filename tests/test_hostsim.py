@@ -46,6 +46,11 @@ def test_raft_kernels_on_the_host(sim, oracle):
     import test_raft_gpu as t
     with sim.patched():
         t.test_raft_steady("cpu", oracle)
+        t._run_batched("cpu", oracle, G=300, R=5, W=64, T=25, batches=(1, 5, 16, 3))      # smr_raft_leader_run_ticks
+        t._run_batched("cpu", oracle, G=200, R=3, W=32, T=24, batches=(7, 17), higher_p=0.004)
+        t._run_batched("cpu", oracle, G=130, R=7, W=16, T=20, batches=(20,), n_new_max=9)
+        t._run_batched("cpu", oracle, G=130, R=5, W=64, T=8, batches=(8,), quiet={("append", 2), ("replies", 4), ("append", 7), ("replies", 7)})
+        t.test_craft_leader_refuses_batches("cpu")
         t.test_raft_three_replicas_and_stepdown("cpu", oracle)
         t.test_craft_threshold("cpu", oracle)
         t.test_follower_and_elections_match_oracle("cpu", oracle, 300, 64)

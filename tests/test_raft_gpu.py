@@ -53,6 +53,62 @@ def _run(cuda, oracle, G, R, W, T, commit_extra=0, higher_p=0.0, n_new_max=3, se
     return eng, orc
 
 
+def _run_batched(cuda, oracle, G, R, W, T, batches, higher_p=0.0, n_new_max=3, seed=78, quiet=()):
+    """`smr_raft_leader_run_ticks` (one launch per <= 16 ticks, the state in registers from tick to tick) against the oracle's
+    tick-by-tick run of the same inputs: state at every batch boundary.  `quiet`: ticks that pass NULL for their appends /
+    replies (and give the oracle none)"""
+    import torch
+    from summerset_amd import RaftLeaderGroup, SummersetError
+    eng = RaftLeaderGroup(G, R, 0, W, term=1)
+    orc = oracle.RaftOracle(G, R, W, 0, 1, 0)
+    dev = lambda a: torch.from_numpy(a).to(cuda)
+    ticks, snaps = [], []
+    for t in range(T):
+        n_new = (stream._key(seed, 9, t, np.arange(G, dtype=np.uint64)) % np.uint64(n_new_max + 1)).astype(np.uint32)
+        x = {}
+        if ("append", t) not in quiet:
+            orc.append(n_new)
+            x["n_new"] = dev(n_new)
+        d = orc.dump()
+        term, es, fl, ct, cs, order = _replies(seed, t, G, R, d["log_len"], d["curr_term"], higher_p=higher_p)
+        if ("replies", t) not in quiet:
+            orc.handle_replies(term, es, fl, ct, cs, order)
+            x.update(reply_term=dev(term), end_slot=dev(es), flags=dev(fl), conflict_term=dev(ct), conflict_slot=dev(cs), order=dev(order))
+        ticks.append(x)
+        snaps.append((orc.dump(), orc.total_commits()))
+    t0 = 0
+    for k in batches:
+        eng.run_ticks(ticks[t0:t0 + k])
+        t0 += k
+        a, (b, commits) = eng.dump(), snaps[t0 - 1]
+        for n in b:
+            assert np.array_equal(a[n], b[n]), "after tick %d field %s" % (t0 - 1, n)
+        assert eng.total_commits() == commits
+    assert t0 == T and orc.total_commits() > 0
+    with pytest.raises(SummersetError):
+        eng.run_ticks([dict(flags=ticks[0]["flags"])])                   # replies without their terms / end slots
+    return eng, orc
+
+
+def test_raft_batched_ticks_match_the_oracle(cuda, oracle):
+    _run_batched(cuda, oracle, G=1000, R=5, W=64, T=47, batches=(1, 5, 16, 20, 2, 3))
+    eng, orc = _run_batched(cuda, oracle, G=500, R=3, W=32, T=40, batches=(7, 33), higher_p=0.002)
+    assert (orc.dump()["role"] == 0).any()                             # leaders that step down in the middle of a batch
+    _run_batched(cuda, oracle, G=300, R=7, W=16, T=30, batches=(30,), n_new_max=9)                  # ring back-pressure, the 8-wide instance
+    _run_batched(cuda, oracle, G=300, R=5, W=64, T=12, batches=(12,), quiet={("append", 3), ("replies", 5), ("append", 11), ("replies", 11)})
+
+
+def test_raft_batched_ticks_config2_size(cuda, oracle):
+    _run_batched(cuda, oracle, G=65536, R=5, W=64, T=16, batches=(16,))
+
+
+def test_craft_leader_refuses_batches(cuda):
+    from summerset_amd import CRaftLeaderGroup, SummersetError
+    eng = CRaftLeaderGroup(64, 5, 0, 64, term=1)
+    with pytest.raises(SummersetError):
+        eng.run_ticks([{}])
+
+
 def test_raft_steady(cuda, oracle):
     _run(cuda, oracle, G=1000, R=5, W=64, T=60)
 
