@@ -111,6 +111,8 @@ def parse():
                     "synchronize pair; `value` / `ms_per_step` are the MEDIAN region's, the others are listed beside it (a 2 ms region "
                     "carries +-25 %% box noise, VERDICT r2).  0 = 9 when steps <= 30, else 3.  The leader-timeout rate per tick is kept: "
                     "the stream's timeout fraction grows with the run")
+    ap.add_argument("--no-l2", action="store_true", help="skip the `l2` object (the same workload a few ticks in the spread layout, one "
+                    "all_to_all_single per exchange: RCCL at --gpus > 1, four virtual ranks on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
@@ -903,9 +905,10 @@ def cpu_leg(args, seconds):
                       "path cannot be built here (no cargo, no vendored crates)" % (args.slots, cores, sn, s1, n1)}
 
 
-def spread_main(args, torch, dist, rank, local, world, dev):
-    """--layout spread: the headline workload with the replicas of every group on different ranks.  Weak scaling like the
-    co-located line: args.groups groups per GPU.  At world 1 the job's ranks are virtual (spread_mp.in_process)."""
+def spread_run(args, torch, dist, rank, world, dev, steps, warmup, call_by_call=False):
+    """the headline workload with the replicas of every group on different ranks (layout L2): `steps` timed ticks behind `warmup`.
+    Weak scaling like the co-located line: args.groups groups per GPU.  At world 1 the job's ranks are virtual
+    (spread_mp.in_process).  Collective on every rank; returns the line's dict."""
     from summerset_amd import shard, spread_mp, stream
     R, S, W, H = 5, args.slots, args.window, args.hb_every
     cap = W + 4
@@ -916,7 +919,7 @@ def spread_main(args, torch, dist, rank, local, world, dev):
     job = spread_mp.in_process(total, R, W, nr, dev, S, **kw) if virtual else spread_mp.SpreadMultiPaxos(total, R, W, rank, world, dev, S, **kw)
     job.preset_leader(0)
     mine = sorted({b for rk in job.ranks for b in rk.blocks} if virtual else job.blocks)
-    n_ticks = args.warmup + args.steps
+    n_ticks = warmup + steps
     skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=timeout_frac(args), hb_every=H, rand_rows=S + 4, max_drop=2,
                timeout_span=timeout_span(args))                  # the co-located line's rate of leader changes per tick
     sts = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **skw) for b, (lo, hi) in ((b, shard.group_range(total, nr, b)) for b in mine)}
@@ -925,10 +928,12 @@ def spread_main(args, torch, dist, rank, local, world, dev):
     evs = {b: [{k: torch.from_numpy(v).to(dev) for k, v in st.tick_events(t).items()} for t in range(n_ticks)] for b, st in sts.items()}
     hb = next(iter(sts.values())).heartbeat
 
+    tick_fn = job.tick_call_by_call if call_by_call else job.tick
+
     def step(t):
-        job.tick({b: dict(pools[b][t % args.pool], **evs[b][t]) for b in mine}, heartbeat=hb(t))
+        tick_fn({b: dict(pools[b][t % args.pool], **evs[b][t]) for b in mine}, heartbeat=hb(t))
     commits_of = (lambda: sum(rk.commits() for rk in job.ranks)) if virtual else job.commits
-    for t in range(args.warmup):
+    for t in range(warmup):
         step(t)
     torch.cuda.synchronize()
     c0 = commits_of()
@@ -937,7 +942,7 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for t in range(args.warmup, n_ticks):
+    for t in range(warmup, n_ticks):
         step(t)
     torch.cuda.synchronize()
     if world > 1:
@@ -947,18 +952,33 @@ def spread_main(args, torch, dist, rank, local, world, dev):
     sent = (sum(rk.bytes_sent for rk in job.ranks) if virtual else job.bytes_sent) - sent0
     dropped = sum(rk.dropped_overflow_entries() for rk in job.ranks) if virtual else job.dropped_overflow_entries()
     elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)
+    plans = (job.ranks[0] if virtual else job)._plans
     line = {"metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s", "n_gpus": world,
-            "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "ranks": shard.count_ranks(dev), "backend": dist.get_backend() if world > 1 else None, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "MultiPaxos lock-step, %d groups/GPU x 5 replicas, S=%d new slots/group/tick, heartbeat every %d ticks, "
                                    "%.0f%% ack loss (<= 2 lost per slot), %s" % (args.groups, S, H, args.drop * 100, timeouts_text(args)),
                        "groups_per_gpu": args.groups, "replicas": R, "slots_per_tick": S, "window": W, "layout": "spread",
                        "spread_ranks": nr, "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
             "exchange": {"collectives_per_tick": "3 with a heartbeat round, else 2 (one all_to_all_single each)",
-                         "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1), "overflow_entries_dropped": dropped},
+                         "host_calls_per_tick": "one smr_mp_spread_segment call per segment (3, 4 with a heartbeat round) + the collectives"
+                                                if not call_by_call else "one per round per block + one per pack / unpack (rounds 1-2)",
+                         "bytes_per_exchange_per_rank": {ph: int(sum(p["in_split"])) for ph, p in plans.items()},
+                         "bytes_sent_per_tick_per_rank": sent / steps / (nr if virtual else 1), "overflow_entries_dropped": dropped},
             "roofline": None, "cpu_baseline": None,
             "note": "correctness layout of the north star's inter-replica fan-out; the roofline / cpu_baseline objects belong to the co-located line"}
+    for rk in (job.ranks if virtual else [job]):
+        rk.close()
+    return line
+
+
+def spread_main(args, torch, dist, rank, local, world, dev):
+    """--layout spread: see spread_run"""
+    line = spread_run(args, torch, dist, rank, world, dev, args.steps, args.warmup)
+    if os.environ.get("SMR_SPREAD_AB"):                            # (experiments: the call-by-call tick of rounds 1-2 beside it)
+        old = spread_run(args, torch, dist, rank, world, dev, args.steps, args.warmup, call_by_call=True)
+        line["call_by_call"] = {"ms_per_step": old["ms_per_step"], "value": old["value"]}
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -1305,8 +1325,27 @@ def main():
         "generic_path_batches": [eng.debug_generic_units(r) for r in range(R)],
         "decisions_per_sec": G * S * args.steps / elapsed,
     }
+    # Layout L2 in the line the driver runs: the same workload a few ticks in the spread layout -- the replicas of every group on
+    # different ranks, every protocol message through one all_to_all_single per exchange (RCCL over xGMI at N > 1; at N = 1 the
+    # job's four ranks are virtual: same kernels, plans and buffers, the collective a device copy).  Collective: every rank runs it.
+    l2 = None
+    if not args.no_l2:
+        try:
+            del eng
+            torch.cuda.empty_cache()
+            x = spread_run(args, torch, dist, rank, world, dev, steps=max(4, min(args.steps, 12)), warmup=4)
+            l2 = {"layout": "spread (SURVEY 8e L2): replica r of block b on rank (b + r) mod N", "ranks": x["config"]["spread_ranks"],
+                  "ranks_are": x["config"]["ranks_are"], "value": x["value"], "unit": "slots/s", "ms_per_tick": x["ms_per_step"],
+                  "steps": x["steps"], "warmup": x["warmup"], "exchange": x["exchange"], "backend": x["backend"]}
+        except Exception as e:                     # noqa: BLE001 -- never at the headline's cost; named in legs_failed
+            l2 = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("bench.py: the l2 pass FAILED: %s: %s\n" % (type(e).__name__, e))
     if rank == 0:
         failed = []
+        if l2 is not None:
+            line["l2"] = l2
+            if "error" in l2:
+                failed.append("l2")
 
         def leg(name, fn, *a):                     # a secondary leg must never cost the headline line -- but it must not
             try:                                   # fail silently either: `legs_failed` names it at the top level, stderr says why

@@ -247,6 +247,24 @@ void smr_mp_image_plan_destroy(smr_mp_image_plan *p);
 int smr_mp_image_plan_run(smr_mp_image_plan *p, int unpack, void *stream);
 /* closes the tick (flips the outbox parity); smr_mp_tick calls it itself */
 int smr_mp_end_tick(smr_mp_cluster *c);
+/* A rank's part of an L2 job as ONE object, the tick's orchestration in the library: `clusters` = the rank's block clusters (in the
+ * order the inputs will come in), pack[k] / unpack[k] = the plans of exchange k (0 outbox, 1 replies, 2 heartbeat; they stay the
+ * caller's, as do the clusters).  A tick is then one call per SEGMENT with the caller's collective -- one all_to_all_single over
+ * the plans' send / receive buffers (torch.distributed = RCCL) -- between the segments:
+ *   0: R1 on every block, pack(outbox)            | exchange 0 |
+ *   1: unpack(outbox), R2 on every block, pack(replies)         | exchange 1 |
+ *   2: unpack(replies), R3 on every block; heartbeat tick: pack(heartbeat) | exchange 2 | else: the tick ends
+ *   3: (heartbeat ticks) unpack(heartbeat), R4 on every block, the tick ends
+ * in[b] = block b's inputs (segments 0 and 2 read them; do_heartbeat is ignored: `heartbeat` is the tick's).  What
+ * summerset_amd/spread_mp.py used to do call by call (~25 host calls per segment at 4 ranks). */
+typedef struct smr_mp_spread smr_mp_spread;
+int smr_mp_spread_create(smr_mp_cluster *const *clusters, uint32_t n_blocks, smr_mp_image_plan *const *pack, smr_mp_image_plan *const *unpack,
+                         smr_mp_spread **out);
+void smr_mp_spread_destroy(smr_mp_spread *s);
+int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *in, int heartbeat, void *stream);
+/* The blocks' rounds inside a segment run concurrently on streams of the object's own, forked behind the segment's unpack and
+ * joined in front of its pack on `stream` (default on); 0 = one after the other on `stream`. */
+int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on);
 
 /* Device pointer + geometry of replica `rep`'s ack matrix: one 8-byte word per (outbox entry,
  * group); byte r of the word = 1 iff replica r sent an AcceptReply to that entry.  An AcceptReply

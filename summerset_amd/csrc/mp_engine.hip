@@ -8,6 +8,7 @@
 // multi-GPU layout, the exchange sits between them).
 #include <string.h>
 
+#include <functional>
 #include <vector>
 
 #include "mp_device.h"
@@ -2361,6 +2362,113 @@ int smr_mp_profile_read(smr_mp_cluster *c, int which, double *total_ms, uint64_t
     if (total_ms) *total_ms = c->prof_ms[which];
     if (launches) *launches = c->prof_n[which];
     return SMR_OK;
+}
+
+/* ---- a rank's part of an L2 (spread) job as ONE object: the tick's orchestration in the library --------------------------------
+ * What summerset_amd/spread_mp.py did call by call -- a round on every block cluster of the rank, the exchange's pack in front
+ * of the collective, its unpack behind it -- as one C call per SEGMENT of the tick; the collectives between the segments stay the
+ * caller's (torch.distributed over RCCL: all_to_all_single on the plans' buffers).  Stand-in for server/transport.rs:208-275. */
+struct smr_mp_spread {
+    std::vector<smr_mp_cluster *> cl;
+    smr_mp_image_plan *pack[3] = {nullptr, nullptr, nullptr}, *unpack[3] = {nullptr, nullptr, nullptr};   // outbox, replies, heartbeat
+    // A round on block b has nothing to do with the round on block b': the blocks' launches go to side streams (block 0 stays on
+    // the caller's), forked behind the unpack and joined in front of the pack.  A block's round kernel is latency-bound at a
+    // quarter or an eighth of the groups (~20-40 us whatever its size): back to back they were the tick.
+    std::vector<hipStream_t> side;               // [n_blocks - 1]
+    std::vector<hipEvent_t> done;                // [n_blocks - 1]
+    hipEvent_t fork = nullptr;
+    bool concurrent = true;
+};
+
+// a round on every block: block 0 on the caller's stream, the others on their side streams between a fork and a join
+static int spread_each_block(smr_mp_spread *s, hipStream_t st, const std::function<int(size_t, void *)> &round) {
+    const size_t n = s->cl.size();
+    int rc;
+    if (!s->concurrent || n < 2) {
+        for (size_t b = 0; b < n; b++)
+            if ((rc = round(b, (void *)st)) != SMR_OK) return rc;
+        return SMR_OK;
+    }
+    SMR_HIP_TRY(hipEventRecord(s->fork, st));
+    for (size_t b = 1; b < n; b++) {
+        SMR_HIP_TRY(hipStreamWaitEvent(s->side[b - 1], s->fork, 0));
+        if ((rc = round(b, (void *)s->side[b - 1])) != SMR_OK) return rc;
+        SMR_HIP_TRY(hipEventRecord(s->done[b - 1], s->side[b - 1]));
+    }
+    if ((rc = round(0, (void *)st)) != SMR_OK) return rc;
+    for (size_t b = 1; b < n; b++) SMR_HIP_TRY(hipStreamWaitEvent(st, s->done[b - 1], 0));
+    return SMR_OK;
+}
+
+int smr_mp_spread_create(smr_mp_cluster *const *clusters, uint32_t n_blocks, smr_mp_image_plan *const *pack, smr_mp_image_plan *const *unpack,
+                         smr_mp_spread **out) {
+    if (!out || (n_blocks && !clusters) || !pack || !unpack) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    for (uint32_t b = 0; b < n_blocks; b++)
+        if (!clusters[b]) return fail(SMR_ERR_ARG, "mp spread: null cluster");
+    for (int k = 0; k < 3; k++)
+        if (!pack[k] || !unpack[k]) return fail(SMR_ERR_ARG, "mp spread: the three exchanges (outbox, replies, heartbeat) need a pack and an unpack plan each");
+    smr_mp_spread *s = new smr_mp_spread();
+    s->cl.assign(clusters, clusters + n_blocks);
+    for (int k = 0; k < 3; k++) { s->pack[k] = pack[k]; s->unpack[k] = unpack[k]; }
+    bool ok = hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) == hipSuccess;
+    for (uint32_t b = 1; ok && b < n_blocks; b++) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+        if (st) s->side.push_back(st);
+        if (ev) s->done.push_back(ev);
+    }
+    if (!ok) { smr_mp_spread_destroy(s); return fail(SMR_ERR_DEVICE, "mp spread: stream / event creation failed"); }
+    *out = s;
+    return SMR_OK;
+}
+
+void smr_mp_spread_destroy(smr_mp_spread *s) {
+    if (!s) return;
+    for (hipStream_t st : s->side) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : s->done) (void)hipEventDestroy(ev);
+    if (s->fork) (void)hipEventDestroy(s->fork);
+    delete s;
+}
+
+int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on) {
+    if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    s->concurrent = on != 0;
+    return SMR_OK;
+}
+
+int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *in, int heartbeat, void *stream) {
+    if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    if (segment < 0 || segment > 3) return fail(SMR_ERR_ARG, "mp spread: segment must be 0..3");
+    if ((segment == 0 || segment == 2) && !s->cl.empty() && !in) return fail(SMR_ERR_ARG, "mp spread: segments 0 and 2 take the blocks' inputs");
+    if (segment == 3 && !heartbeat) return fail(SMR_ERR_ARG, "mp spread: segment 3 exists on heartbeat ticks only");
+    int rc;
+    const size_t n = s->cl.size();
+    hipStream_t st = (hipStream_t)stream;
+    switch (segment) {
+    case 0:                                                  // R1 everywhere, then the outboxes into the send buffer
+        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) {
+                 return smr_mp_round_local(s->cl[b], in[b].timeout_rep_dev, in[b].timeout_src_dev, in[b].req_target_dev, in[b].req_cnt_dev,
+                                           in[b].req_val_dev, in[b].S, sb); })) != SMR_OK) return rc;
+        return smr_mp_image_plan_run(s->pack[0], 0, stream);
+    case 1:                                                  // the peers' outboxes arrive; R2; replies into the send buffer
+        if ((rc = smr_mp_image_plan_run(s->unpack[0], 1, stream)) != SMR_OK) return rc;
+        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_deliver(s->cl[b], sb); })) != SMR_OK) return rc;
+        return smr_mp_image_plan_run(s->pack[1], 0, stream);
+    case 2:                                                  // the replies arrive; R3; a heartbeat tick publishes and packs, else the tick ends
+        if ((rc = smr_mp_image_plan_run(s->unpack[1], 1, stream)) != SMR_OK) return rc;
+        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_replies(s->cl[b], in[b].ackctl_dev, heartbeat, sb); })) != SMR_OK)
+            return rc;
+        if (heartbeat) return smr_mp_image_plan_run(s->pack[2], 0, stream);
+        for (size_t b = 0; b < n; b++)
+            if ((rc = smr_mp_end_tick(s->cl[b])) != SMR_OK) return rc;
+        return SMR_OK;
+    default:                                                 // the heartbeats arrive; R4; the tick ends
+        if ((rc = smr_mp_image_plan_run(s->unpack[2], 1, stream)) != SMR_OK) return rc;
+        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_heartbeat(s->cl[b], sb); })) != SMR_OK) return rc;
+        for (size_t b = 0; b < n; b++)
+            if ((rc = smr_mp_end_tick(s->cl[b])) != SMR_OK) return rc;
+        return SMR_OK;
+    }
 }
 
 }  // extern "C"

@@ -60,6 +60,17 @@ class SpreadMultiPaxos:
         self.peers = None                                      # set by in_process(): every rank's object, for a job inside one process
         # the three exchanges: every rank derives the same global message lists, in the same order
         self._plans = {ph: self._plan(ph) for ph in ("outbox", "replies", "heartbeat")}
+        # the tick's orchestration lives in the library: one C call per segment of the tick (smr_mp_spread_segment), the
+        # collectives between them stay here
+        import ctypes as C
+        self._order = sorted(self.blocks)                      # the order the blocks' inputs are handed over in
+        cls = (C.c_void_p * max(len(self._order), 1))(*[self.blocks[b][0]._h for b in self._order])
+        names = ("outbox", "replies", "heartbeat")
+        pk = (C.c_void_p * 3)(*[self._plans[n]["pack"] for n in names])
+        up = (C.c_void_p * 3)(*[self._plans[n]["unpack"] for n in names])
+        h = C.c_void_p()
+        check(self._L.smr_mp_spread_create(cls, len(self._order), pk, up, C.byref(h)))
+        self._spread = h
 
     # ---- static plan --------------------------------------------------------------------------------------------
     def _ranks_of(self, b):
@@ -132,6 +143,9 @@ class SpreadMultiPaxos:
         return h
 
     def close(self):
+        if getattr(self, "_spread", None):
+            self._L.smr_mp_spread_destroy(self._spread)
+            self._spread = None
         for p in getattr(self, "_plans", {}).values():
             for k in ("pack", "unpack"):
                 if p.get(k):
@@ -145,15 +159,15 @@ class SpreadMultiPaxos:
     def _pack(self, phase, stream=None):
         p = self._plans[phase]
         check(self._L.smr_mp_image_plan_run(p["pack"], 0, stream_ptr(stream)))
-        self.bytes_sent += sum(p["in_split"])
 
     def _unpack(self, phase, stream=None):
         check(self._L.smr_mp_image_plan_run(self._plans[phase]["unpack"], 1, stream_ptr(stream)))
 
-    def _exchange(self, phase, stream=None):
+    def _collective(self, phase):
+        """the exchange itself: ONE all_to_all_single over the plan's send / receive buffers (RCCL over xGMI)"""
         import torch.distributed as dist
         p = self._plans[phase]
-        self._pack(phase, stream)
+        self.bytes_sent += sum(p["in_split"])
         if self.world > 1:
             if self.peers is not None:                         # all ranks of the job in THIS process (tests, one device)
                 _copy_between(self.peers, phase)
@@ -161,12 +175,44 @@ class SpreadMultiPaxos:
                 # (the buffers are padded to a minimum size: the collective sees exactly the planned bytes)
                 dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
                                        input_split_sizes=p["in_split"])
+
+    def _exchange(self, phase, stream=None):
+        self._pack(phase, stream)
+        self._collective(phase)
         self._unpack(phase, stream)
+
+    def _inputs(self, inputs):
+        from ._lib import MpTickIn
+        arr = (MpTickIn * max(len(self._order), 1))()
+        for a, b in zip(arr, self._order):
+            x = inputs[b]
+            rv = x.get("req_val")
+            ptr = lambda t: None if t is None else t.data_ptr()
+            a.timeout_rep_dev, a.timeout_src_dev, a.req_target_dev = ptr(x.get("timeout_rep")), ptr(x.get("timeout_src")), ptr(x.get("req_target"))
+            a.req_cnt_dev, a.req_val_dev, a.S = ptr(x.get("req_cnt")), ptr(rv), (0 if rv is None else int(rv.shape[0]))
+            a.ackctl_dev = ptr(x.get("ackctl"))
+        return arr
+
+    def segment(self, k, arr, heartbeat, stream=None):
+        check(self._L.smr_mp_spread_segment(self._spread, k, arr, int(bool(heartbeat)), stream_ptr(stream)))
 
     # ---- the tick ---------------------------------------------------------------------------------------------------
     def tick(self, inputs, heartbeat=False, stream=None):
         """inputs[b] = dict(timeout_rep, timeout_src, req_target, req_cnt, req_val, ackctl) of block b's groups (device
-        tensors; every rank that holds block b passes the same arrays -- the streams are keyed by global group id)"""
+        tensors; every rank that holds block b passes the same arrays -- the streams are keyed by global group id).
+        Three or four library calls (the segments between the collectives) and two or three collectives."""
+        arr = self._inputs(inputs)
+        self.segment(0, arr, heartbeat, stream)
+        self._collective("outbox")
+        self.segment(1, arr, heartbeat, stream)
+        self._collective("replies")
+        self.segment(2, arr, heartbeat, stream)
+        if heartbeat:
+            self._collective("heartbeat")
+            self.segment(3, arr, heartbeat, stream)
+
+    def tick_call_by_call(self, inputs, heartbeat=False, stream=None):
+        """the same tick with every round and every pack / unpack its own host call (rounds 1-2; kept for the comparison)"""
         for b, (cl, _, _, _) in self.blocks.items():
             x = inputs[b]
             cl.round_local(x.get("timeout_rep"), x.get("timeout_src"), x.get("req_target"), x.get("req_cnt"), x.get("req_val"), stream=stream)
@@ -229,12 +275,57 @@ class in_process:
         self.ranks[0]._arrived = {}
         for r in self.ranks:
             r.peers = self.ranks
+        # on a device every virtual rank gets a stream of its own: ranks are processes on GPUs of their own in the real job, so
+        # nothing orders rank 1's kernels behind rank 0's -- only the collectives do
+        self._streams = None
+        if getattr(device, "type", str(device)) == "cuda":
+            import torch
+            self._streams = [torch.cuda.Stream(device=device) for _ in self.ranks]
 
     def preset_leader(self, rep=0):
         for r in self.ranks:
             r.preset_leader(rep)
 
     def tick(self, inputs, heartbeat=False):
+        """every rank through a segment before any rank starts the next one -- the order the collectives impose on separate
+        processes; the collective between two segments is a copy between the ranks' buffers"""
+        rs = self.ranks
+        arrs = [r._inputs(inputs) for r in rs]
+        sts = self._streams
+        if sts is not None:
+            import torch
+            main = torch.cuda.current_stream()
+            for st in sts:
+                st.wait_stream(main)                           # the tick's inputs were made on the caller's stream
+
+        def segment(k):
+            for i, (r, a) in enumerate(zip(rs, arrs)):
+                r.segment(k, a, heartbeat, stream=None if sts is None else sts[i].cuda_stream)
+
+        def collective(phase):
+            for r in rs:
+                r.bytes_sent += sum(r._plans[phase]["in_split"])
+            if sts is not None:                                # the collective: every rank has packed; the copies; every rank goes on
+                for st in sts:
+                    main.wait_stream(st)
+            for r in rs:
+                _copy_between(rs, phase)
+            if sts is not None:
+                for st in sts:
+                    st.wait_stream(main)
+        segment(0)
+        collective("outbox")
+        segment(1)
+        collective("replies")
+        segment(2)
+        if heartbeat:
+            collective("heartbeat")
+            segment(3)
+        if sts is not None:
+            for st in sts:
+                main.wait_stream(st)
+
+    def tick_call_by_call(self, inputs, heartbeat=False):
         rs = self.ranks
 
         def each(fn):
