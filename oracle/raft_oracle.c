@@ -358,6 +358,8 @@ static void handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t leader, ui
     for (uint32_t s = 0; s < n; s++) {
         uint32_t slot = prev_slot + 1 + s;
         if (slot >= log_end(r)) { first_new = slot; break; }
+        if (slot >= r->start_slot && slot < r->ring_lo) continue;           /* harness guard shared with the engine: an entry that left the
+                                                                               W-entry term ring is taken as matching, never as a conflict */
         int ok3; uint64_t t = term_at(r, slot, W, &ok3);
         if (!ok3 || t != ent[s * ent_stride]) {
             r->n_log = slot - r->start_slot;                                  /* :136 truncate */
@@ -438,6 +440,8 @@ static void craft_handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t lead
     for (uint32_t s = 0; s < n; s++) {
         uint32_t slot = prev_slot + 1 + s;
         if (slot >= log_end(r)) { first_new = slot; break; }
+        if (slot >= r->start_slot && slot < r->ring_lo) continue;           /* harness guard shared with the engine: an entry that left the
+                                                                               W-entry term ring is taken as matching, never as a conflict */
         int ok3; uint64_t t = term_at(r, slot, W, &ok3);
         if (!ok3 || t != ent[s * ent_stride]) {
             r->n_log = slot - r->start_slot;                                  /* :129 truncate */

@@ -584,6 +584,10 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                     const uint32_t slot = ps + 1 + s;
                     if (slot >= L.len) { first_new = slot; break; }
                     uint64_t t;
+                    // (harness: an entry that has left the W-entry term ring is >= W entries behind the log's end -- its term is
+                    // no longer held, which is NOT a term conflict: it is taken as matching, never as a reason to truncate a
+                    // suffix that may be committed; the oracle shares the rule)
+                    if (slot >= L.start && slot < L.rlo) continue;
                     if (!L.term_at(slot, t) || t != entry_term[(size_t)s * v.G + g]) {
                         L.len = slot;                                           // :136 truncate
                         v.n_trunc[g] += 1;

@@ -140,6 +140,7 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
     import test_zz_wire_ingest_gpu as t
     with sim.patched():
         t.test_ingest_matches_the_sequential_decoder("cpu")
+        t.test_ingest_against_what_the_test_wrote("cpu")                       # no product codec in the loop
         t.test_empty_and_overfull("cpu")
         t.test_accept_replies_over_the_wire("cpu", oracle)
         import test_zzz_wire_ingest_edges_gpu as te                             # the laid-out edges: fast-path boundary, window ends, extremes

@@ -208,3 +208,51 @@ def test_accept_replies_over_the_wire(cuda, oracle):
     travel as frames and the cluster still matches the oracle after every tick"""
     import test_mp_gpu as t
     t._run(cuda, oracle, G=130, R=5, S=2, W=64, n_ticks=24, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, per_round=_acks_over_the_wire)
+
+
+def test_ingest_against_what_the_test_wrote(cuda):
+    """No product decoder and no product encoder in the loop: frames laid out here from the reference's own type definitions --
+    `[u64 BE len]` (safetcp.rs:46,127-132) + bincode-standard `PeerMessage::Msg { msg: PeerMsg::X { .. } }` with the variant
+    indexes of multipaxos/mod.rs:298-384 (Prepare 0 .. AcceptReply 3 .. Heartbeat 6, CommitNotice 7) and SURVEY Appendix C's
+    varint rule -- and the records the ingest kernel makes of them compared with the values the test put in, field by field,
+    in stream order.  (The rest of this file holds the parser against `smr_wire_decode`; this test holds it -- and through the
+    first one that decoder -- against the layout itself.)"""
+    from summerset_amd import wire
+    from summerset_amd.multipaxos import ACK_DTYPE
+    rng = np.random.default_rng(5)
+    edge = [0, 1, 250, 251, 252, 65535, 65536, (1 << 32) - 1]
+    wide = [1 << 32, (1 << 40) + 3, (1 << 63) + 5, (1 << 64) - 1]
+    n_conn = 130
+    groups, peers = rng.integers(0, 1 << 20, n_conn), rng.integers(0, 5, n_conn)
+    streams, want_acks, want_hbs = [], [], []
+    for c in range(n_conn):
+        s = bytearray()
+        for _ in range(int(rng.integers(1, 30))):
+            pick = lambda lst: lst[int(rng.integers(0, len(lst)))]       # noqa: E731 -- (by index: numpy would turn 2^64 - 1 into a float)
+            v = lambda big=False: pick(edge + (wide if big else [])) if rng.random() < 0.4 else int(rng.integers(0, 70000))   # noqa: E731
+            x = rng.random()
+            if x < 0.6:                                                  # AcceptReply { slot, ballot, reply_ts: None | Some(SystemTime) }
+                slot, ballot = v(), v(True)
+                ts = b"\x00" if rng.random() < 0.7 else b"\x01" + _varint(1790000000 + int(rng.integers(0, 1000))) + _varint(int(rng.integers(0, 10**9)))
+                s += _frame(_varint(0) + _varint(3) + _varint(slot) + _varint(ballot) + ts)
+                want_acks.append((groups[c], slot, ballot, peers[c], 0))
+            elif x < 0.8:                                                # Heartbeat { ballot, commit_bar, exec_bar, snap_bar }
+                f = [v(True), v(), v(), v()]
+                s += _frame(_varint(0) + _varint(6) + b"".join(_varint(q) for q in f))
+                want_hbs.append((groups[c], peers[c], 6, 0, f[0], f[1], f[2], f[3]))
+            else:                                                        # CommitNotice { ballot, commit_bar }
+                f = [v(True), v()]
+                s += _frame(_varint(0) + _varint(7) + _varint(f[0]) + _varint(f[1]))
+                want_hbs.append((groups[c], peers[c], 7, 0, f[0], f[1], 0, 0))
+        streams.append(bytes(s))
+    got = _ingest(wire, cuda, streams, groups, peers)
+    assert got["n_malformed"] == 0 and got["n_others"] == 0
+    assert np.array_equal(got["consumed"], [len(s) for s in streams])
+    acks, hbs = np.array(want_acks, ACK_DTYPE), np.array(want_hbs, wire.HB_DTYPE)
+    assert got["n_acks"] == len(acks) and np.array_equal(got["acks"], acks)
+    assert got["n_hbs"] == len(hbs)
+    for name in ("group", "peer", "kind", "ballot", "commit_bar"):
+        assert np.array_equal(got["hbs"][name], hbs[name]), name
+    hb6 = hbs["kind"] == 6                                               # a CommitNotice carries no exec / snap bar
+    assert np.array_equal(got["hbs"]["exec_bar"][hb6], hbs["exec_bar"][hb6]) and np.array_equal(got["hbs"]["snap_bar"][hb6], hbs["snap_bar"][hb6])
+    assert len(acks) > 800 and len(hbs) > 300
