@@ -103,7 +103,7 @@ def parse():
                     "smr_mp_tick call per tick")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
-    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos", "colocated-epaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
+    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos", "colocated-epaxos", "spread-rspaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
                     "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
     ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
                     "kernels, plans and buffers; the collective is a device copy)")
@@ -986,6 +986,64 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
+    """--layout spread-rspaxos: BASELINE config 4 in layout L2 -- RSPaxos, 16 384 groups per GPU x 5 replicas, one 4 KiB Put per
+    group per tick, the replicas of a group on different ranks (summerset_amd/spread_rsp.py): per tick one all_to_all_single
+    with the Accepts AND the followers' shards of the tick's codewords, one with the AcceptReplies, two more on heartbeat
+    ticks.  At world 1 the ranks are virtual (--spread-ranks).  Weak scaling: --groups is ignored, 16 384 groups per GPU."""
+    from summerset_amd import shard, spread_rsp
+    G, R, W, L, NB, H = 16384, 5, 64, 4113, 3, 4
+    virtual = world == 1
+    nr = args.spread_ranks if virtual else world
+    total = G * nr
+    job = spread_rsp.in_process(total, R, W, nr, dev, L) if virtual else spread_rsp.SpreadRSPaxos(total, R, W, rank, world, dev, L)
+    ranks = job.ranks if virtual else [job]
+    blocks = sorted({b for rk in ranks for b in rk.lead})
+    srcs = {b: [torch.randint(0, 256, (shard.group_range(total, nr, b)[1] - shard.group_range(total, nr, b)[0], L), dtype=torch.uint8, device=dev)
+                for _ in range(NB)] for b in blocks}
+    ar = {b: torch.arange(srcs[b][0].shape[0], dtype=torch.int64, device=dev) for b in blocks}
+    n_ticks = args.warmup + args.steps
+
+    def step(t):
+        job.tick({b: srcs[b][t % NB] for b in blocks}, {b: ((1 + t * total + ar[b]) & 0x3FFFFFFF).to(torch.int32) for b in blocks},
+                 heartbeat=t % H == H - 1)
+    commits_of = lambda: sum(rk.commits() for rk in ranks)       # noqa: E731
+    for t in range(args.warmup):
+        step(t)
+    torch.cuda.synchronize()
+    c0, sent0 = commits_of(), sum(rk.bytes_sent for rk in ranks)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, n_ticks):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    commits = commits_of() - c0
+    sent = sum(rk.bytes_sent for rk in ranks) - sent0
+    elapsed, commits = shard.reduce_metric(elapsed, commits, device=dev)
+    p = ranks[0]._plans
+    line = {"metric": "committed_slots_per_sec", "value": commits / elapsed, "unit": "slots/s", "n_gpus": world, "ranks": shard.count_ranks(dev),
+            "backend": dist.get_backend() if world > 1 else None, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (GF(2^8)) + u64 ballots", "data": "synthetic",
+            "config": {"workload": "RSPaxos (f = 1), %d groups/GPU x 5 replicas, one 4 KiB Put per group per tick (L = %d), RS(3,2), heartbeats every %d ticks"
+                                   % (G, L, H), "groups_per_gpu": G, "replicas": R, "layout": "spread-rspaxos", "spread_ranks": nr,
+                       "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
+            "exchange": {"collectives_per_tick": "2 (Accepts + shards out, AcceptReplies back); 4 on a heartbeat tick",
+                         "bytes_per_exchange_per_rank": {k: int(sum(x["in_split"])) for k, x in p.items()},
+                         "bytes_sent_per_tick_per_rank": sent / args.steps / len(ranks),
+                         "rs_payload_GiBps": len(blocks) * G * L * args.steps / 2**30 / elapsed * (1 if virtual else world)},
+            "roofline": None, "cpu_baseline": None}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
     """--layout spread-epaxos: BASELINE config 5 as written -- EPaxos, args.groups groups per GPU x 5 replicas, every replica
     proposes one instance per group per tick on Zipf(0.99) keys of 64, the replicas of a group on different ranks
@@ -1161,6 +1219,8 @@ def main():
         return spread_epaxos_main(args, torch, dist, rank, local, world, dev)
     if args.layout == "colocated-epaxos":
         return colocated_epaxos_main(args, torch, dist, rank, local, world, dev)
+    if args.layout == "spread-rspaxos":
+        return spread_rspaxos_main(args, torch, dist, rank, local, world, dev)
 
     G, R, S, W, H = args.groups, 5, args.slots, args.window, args.hb_every
     cap = W + 4

@@ -100,6 +100,11 @@ int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t 
 int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
                                    uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
                                    uint64_t fan_cw_stride, uint32_t fan_mask, void *stream);
+/* The general form: shard k of codeword i also to shard_dst[k] + i*dst_cw_stride for every k with shard_dst[k] != NULL
+ * (shard_dst: HOST array of d + p DEVICE pointers) -- e.g. straight into the per-destination slices of a collective's send
+ * buffer, which are not equally spaced (summerset_amd/spread_rsp.py). */
+int smr_rs_from_data_encode_scatter(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                    uint8_t *cw_dev, uint64_t cw_stride, uint8_t *const *shard_dst, uint64_t dst_cw_stride, void *stream);
 
 /* Same, with the GF(2^8) multiplies done through LDS-resident product tables
  * instead of bit-sliced xtime arithmetic (kept selectable for A/B runs). */

@@ -40,10 +40,9 @@ struct RsArgs {
     uint64_t out_off[RS_MAX_OUT];  // byte offset of output shard r inside a codeword
     uint8_t *copy_base;            // from_data fused in (rs_from_data_xtime): the input columns are also WRITTEN, shard c of codeword
     uint64_t copy_cw_stride;       // i to copy_base + i * copy_cw_stride + in_off[c], zero padding included; NULL otherwise
-    uint8_t *fan_base;             // shard fan-out fused in as well: shard k (k < n_in: data, else parity k - n_in) of codeword i ALSO
-    uint64_t fan_shard_stride;     // to fan_base + k * fan_shard_stride + i * fan_cw_stride, for the k in fan_mask -- every holder's
-    uint64_t fan_cw_stride;        // shard store filled by the pass that makes the shards (rspaxos/request.rs:127-142); NULL otherwise
-    uint32_t fan_mask;
+    uint8_t *fan_dst[RS_MAX_IN + RS_MAX_OUT];   // shard fan-out fused in as well: shard k (k < n_in: data, else parity k - n_in) of codeword
+    uint64_t fan_cw_stride;        // i ALSO to fan_dst[k] + i * fan_cw_stride where fan_dst[k] != NULL -- every holder's shard store (or its
+    uint32_t fan_any;              // slice of a send buffer) filled by the pass that makes the shards (rspaxos/request.rs:127-142)
     uint64_t in_valid;             // bytes of a codeword's input that exist (beyond: zero)
     uint64_t in_bytes;             // bytes readable from in_base (end of the last codeword's input)
     uint64_t shard_len;
@@ -130,7 +129,7 @@ __device__ __forceinline__ void store_cols(const RsArgs &a, uint8_t *cw, int r, 
 // RSCodeword::from_data's pad + split, rscoding.rs:188-200, at no extra read)
 template <int NOUT, int NIN, bool COPY = false>
 __device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t *cw, uint64_t c0, u32x4 (&acc)[NOUT],
-                                                 uint8_t *copy_cw = nullptr, uint8_t *fan_cw = nullptr) {
+                                                 uint8_t *copy_cw = nullptr, bool fan = false, uint64_t fan_off = 0) {
     u32x4 x[NIN];
 #pragma unroll
     for (int c = 0; c < NIN; c++) x[c] = (c < a.n_in) ? load_cols(a, cw, c, c0) : (u32x4){0u, 0u, 0u, 0u};
@@ -139,7 +138,7 @@ __device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t 
         for (int c = 0; c < NIN; c++)
             if (c < a.n_in) {
                 store_block(copy_cw + a.in_off[c] + c0, c0, a.shard_len, x[c]);
-                if (fan_cw && ((a.fan_mask >> c) & 1u)) store_block(fan_cw + (uint64_t)c * a.fan_shard_stride + c0, c0, a.shard_len, x[c]);
+                if (fan && a.fan_dst[c]) store_block(a.fan_dst[c] + fan_off + c0, c0, a.shard_len, x[c]);
             }
     }
 #pragma unroll
@@ -187,15 +186,15 @@ __global__ __launch_bounds__(256) void rs_from_data_xtime(const RsArgs a) {
     uint64_t cw_i, c0;
     if (!rs_locate(a, cw_i, c0)) return;
     u32x4 acc[NOUT];
-    uint8_t *fan_cw = a.fan_base ? a.fan_base + cw_i * a.fan_cw_stride : nullptr;
-    rs_product_xtime<NOUT, NIN, true>(a, a.in_base + cw_i * a.in_cw_stride, c0, acc, a.copy_base + cw_i * a.copy_cw_stride, fan_cw);
+    const bool fan = a.fan_any != 0;
+    const uint64_t fan_off = cw_i * a.fan_cw_stride;
+    rs_product_xtime<NOUT, NIN, true>(a, a.in_base + cw_i * a.in_cw_stride, c0, acc, a.copy_base + cw_i * a.copy_cw_stride, fan, fan_off);
     uint8_t *ocw = a.out_base + cw_i * a.out_cw_stride;
 #pragma unroll
     for (int r = 0; r < NOUT; r++)
         if (r < a.n_out) {
             store_cols(a, ocw, r, c0, acc[r]);
-            if (fan_cw && ((a.fan_mask >> (a.n_in + r)) & 1u))
-                store_block(fan_cw + (uint64_t)(a.n_in + r) * a.fan_shard_stride + c0, c0, a.shard_len, acc[r]);
+            if (fan && a.fan_dst[a.n_in + r]) store_block(a.fan_dst[a.n_in + r] + fan_off + c0, c0, a.shard_len, acc[r]);
         }
 }
 
@@ -411,8 +410,8 @@ static int rs_launch(RsArgs &a, hipStream_t st) {
 template <bool LUT>
 static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,
                           int p, uint8_t *parity, uint64_t par_stride, uint64_t par_shard_stride, void *stream,
-                          uint8_t *copy_base = nullptr, uint64_t copy_cw_stride = 0, uint8_t *fan_base = nullptr,
-                          uint64_t fan_shard_stride = 0, uint64_t fan_cw_stride = 0, uint32_t fan_mask = 0) {
+                          uint8_t *copy_base = nullptr, uint64_t copy_cw_stride = 0, uint8_t *const *fan_dst = nullptr,
+                          uint64_t fan_cw_stride = 0) {
     if (d <= 0) return fail(SMR_ERR_ARG, "num_data_shards is zero");          // rscoding.rs:172-174
     if (data_len == 0) return fail(SMR_ERR_ARG, "codeword is null");          // rscoding.rs:451-453
     if (p == 0 && !copy_base) return SMR_OK;                                   // rscoding.rs:454-456
@@ -424,7 +423,8 @@ static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_st
     a.in_base = data; a.out_base = parity;
     a.in_cw_stride = cw_stride; a.out_cw_stride = par_stride;
     a.copy_base = copy_base; a.copy_cw_stride = copy_cw_stride;
-    a.fan_base = fan_mask ? fan_base : nullptr; a.fan_shard_stride = fan_shard_stride; a.fan_cw_stride = fan_cw_stride; a.fan_mask = fan_mask;
+    a.fan_cw_stride = fan_cw_stride;
+    for (int k = 0; fan_dst && k < d + p; k++) { a.fan_dst[k] = fan_dst[k]; if (fan_dst[k]) a.fan_any = 1; }
     a.shard_len = smr_rs_shard_len(data_len, d);
     a.in_valid = data_len;
     a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + data_len : 0;   // rows may be packed tightly (cw_stride == data_len)
@@ -460,22 +460,32 @@ int smr_rs_encode(const uint8_t *data_dev, uint64_t data_len, uint64_t cw_stride
                                  par_shard_stride, stream);
 }
 
-int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
-                                   uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
-                                   uint64_t fan_cw_stride, uint32_t fan_mask, void *stream) {
+int smr_rs_from_data_encode_scatter(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                    uint8_t *cw_dev, uint64_t cw_stride, uint8_t *const *shard_dst, uint64_t dst_cw_stride, void *stream) {
     if (!cw_dev) return fail(SMR_ERR_ARG, "rs: null buffer");
     const uint64_t sl = smr_rs_shard_len(data_len, d);
     if (d > 0 && cw_stride < (uint64_t)(d + p) * sl) return fail(SMR_ERR_ARG, "rs: cw_stride < (d + p) * shard_len");
     if (src_dev && src_dev < cw_dev + n_cw * cw_stride && cw_dev < src_dev + n_cw * src_stride)
         return fail(SMR_ERR_ARG, "rs: source and codeword buffers overlap");
+    if (shard_dst && dst_cw_stride < sl) return fail(SMR_ERR_ARG, "rs: fan-out stride below shard_len");
+    return rs_encode_impl<false>(src_dev, data_len, src_stride, n_cw, d, p, cw_dev + (uint64_t)(d > 0 ? d : 0) * sl, cw_stride, sl, stream,
+                                 cw_dev, cw_stride, shard_dst, dst_cw_stride);
+}
+
+int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                   uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
+                                   uint64_t fan_cw_stride, uint32_t fan_mask, void *stream) {
+    uint8_t *dst[RS_MAX_IN + RS_MAX_OUT] = {};
     if (fan_mask) {
+        const uint64_t sl = smr_rs_shard_len(data_len, d);
         if (!fan_dev) return fail(SMR_ERR_ARG, "rs: fan-out mask without a buffer");
-        if (d > 0 && (fan_mask >> (d + p))) return fail(SMR_ERR_ARG, "rs: fan-out mask names a shard beyond d + p");
+        if (d <= 0 || d > RS_MAX_IN || p < 0 || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, d <= 0 ? "num_data_shards is zero" : "rs: scheme exceeds d<=16, p<=8");
+        if (fan_mask >> (d + p)) return fail(SMR_ERR_ARG, "rs: fan-out mask names a shard beyond d + p");
         if (fan_cw_stride < sl || (n_cw && fan_shard_stride < (n_cw - 1) * fan_cw_stride + sl))
             return fail(SMR_ERR_ARG, "rs: fan-out strides: a store holds n_cw shards of shard_len bytes, fan_cw_stride apart");
+        for (int k = 0; k < d + p; k++) dst[k] = ((fan_mask >> k) & 1u) ? fan_dev + (uint64_t)k * fan_shard_stride : nullptr;
     }
-    return rs_encode_impl<false>(src_dev, data_len, src_stride, n_cw, d, p, cw_dev + (uint64_t)(d > 0 ? d : 0) * sl, cw_stride, sl, stream,
-                                 cw_dev, cw_stride, fan_dev, fan_shard_stride, fan_cw_stride, fan_mask);
+    return smr_rs_from_data_encode_scatter(src_dev, data_len, src_stride, n_cw, d, p, cw_dev, cw_stride, fan_mask ? dst : nullptr, fan_cw_stride, stream);
 }
 
 int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,

@@ -59,7 +59,7 @@ class RSCodewordBatch:
         return cw
 
     @classmethod
-    def from_data_and_encode(cls, data, num_data_shards, num_parity_shards, stream=None, out=None, fan_out=None, fan_mask=None):
+    def from_data_and_encode(cls, data, num_data_shards, num_parity_shards, stream=None, out=None, fan_out=None, fan_mask=None, shard_dst=None):
         """`from_data` followed by `compute_parity` (what an RSPaxos / CRaft leader does with every batch,
         rspaxos/request.rs:88-101) as ONE pass over `data` (`smr_rs_from_data_encode`): the serialized bytes are read once
         and the d data shards (zero padding included) and p parity shards are written -- no separate copy into the codeword
@@ -77,7 +77,17 @@ class RSCodewordBatch:
                 raise SummersetError(_lib.SMR_ERR_ARG, "`out` has another geometry")
         if L == 0:
             raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
-        if fan_out is None:
+        if shard_dst is not None:                  # per-shard destinations: uint8 [n, shard_len] tensors (rows contiguous, one row stride) or None
+            if len(shard_dst) != cw.d + cw.p:
+                raise SummersetError(_lib.SMR_ERR_ARG, "shard_dst needs d + p entries")
+            live = [t for t in shard_dst if t is not None]
+            strides = {int(t.stride(0)) for t in live}
+            if any(tuple(t.shape) != (n, cw.shard_len) or t.stride(1) != 1 for t in live) or len(strides) > 1:
+                raise SummersetError(_lib.SMR_ERR_ARG, "shard_dst entries must be uint8 [n, shard_len] with contiguous rows and one row stride")
+            ptrs = (C.c_void_p * (cw.d + cw.p))(*[None if t is None else t.data_ptr() for t in shard_dst])
+            check(_lib.load().smr_rs_from_data_encode_scatter(data.data_ptr(), L, int(data.stride(0)), n, cw.d, cw.p, cw.buf.data_ptr(),
+                                                              cw.cw_stride, ptrs, strides.pop() if strides else cw.shard_len, stream_ptr(stream)))
+        elif fan_out is None:
             check(_lib.load().smr_rs_from_data_encode(data.data_ptr(), L, int(data.stride(0)), n, cw.d, cw.p, cw.buf.data_ptr(),
                                                       cw.cw_stride, stream_ptr(stream)))
         else:

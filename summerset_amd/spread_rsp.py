@@ -1,0 +1,344 @@
+"""Layout L2 (BASELINE config 4's "1 -> 8 GPU shard over xGMI") for the RSPaxos replica engine,
+device-resident: the steady state of `rsp_cluster.SteadyLoop` with the replicas of every group on DIFFERENT ranks.
+
+The job's groups are block-partitioned over the ranks (shard.group_range); replica r of block b lives on rank
+(b + r) mod world (as in spread_mp / spread_ep), so block b is led from rank b and each of its Accepts -- header AND
+the follower's shard of the batch's codeword, the one exchange of the path with real bytes (rspaxos/request.rs:127-142:
+one shard per peer; messages.rs:468-595) -- crosses to another rank, and each AcceptReply crosses back.  The stand-in for
+`server/transport.rs:208-275` (`send_msg`).
+
+Per tick, per rank:
+  A  for the block it leads: from_data + RS encode of the tick's batches with every follower's shard written STRAIGHT into
+     that follower's slice of the send buffer (smr_rs_from_data_encode_scatter: nothing is read again to fill send buffers),
+     `handle_req_batch`, the Accept header (flags, slot, ballot, token) copied in front of every shard
+  X1 ONE all_to_all_single (device tensors, static split sizes)
+  B  for every (block, follower) it holds: `handle_msg_accept` on views of the receive buffer with the mask of the one shard
+     it was sent; the reply ballots are written by the kernel straight into the backward send buffer
+  X2 ONE all_to_all_single
+  C  the leader's `handle_msg_accept_reply` tally (majority + f, the shard-availability gate behind it)
+  on a heartbeat tick two more exchanges: the leader's Heartbeat out, the followers' Heartbeats back.
+Results are bit for bit the co-located loop's (tests/test_spread_rsp_gloo.py: world_size 2 over gloo with the emulator
+build of the engine, against `rsp_cluster.SteadyLoop` in one process; tests/test_spread_rsp.py: every rank in one process)."""
+import numpy as np
+
+from . import shard
+from .rscoding import RSCodewordBatch, rs_shard_len
+from .rspaxos import RSPaxosReplicaGroup
+
+NULL = 0xFFFFFFFF
+_A16 = lambda n: (n + 15) // 16 * 16   # noqa: E731
+
+
+def home(block, replica, world):
+    return (block + replica) % world
+
+
+class SpreadRSPaxos:
+    """one rank's part of the job.  `exchange(kind, send, recv, in_split, out_split)` (optional) replaces the collective --
+    tests with every rank in one process."""
+
+    LEADER = 0
+
+    def __init__(self, total_groups, population, window, rank, world, device, data_len, fault_tolerance=1, exchange=None):
+        import torch
+        self.torch = torch
+        self.R, self.W, self.rank, self.world, self.device, self.L = int(population), int(window), int(rank), int(world), device, int(data_len)
+        self.d = self.R // 2 + 1
+        self.sl = rs_shard_len(self.L, self.d)
+        self.exchange = exchange
+        self.bytes_sent = 0
+        self.n_groups = {b: shard.group_range(total_groups, world, b) for b in range(world)}
+        self.reps = {}                                          # (block, replica) -> RSPaxosReplicaGroup, the ones that live here
+        for b in range(world):
+            lo, hi = self.n_groups[b]
+            for r in range(self.R):
+                if home(b, r, world) == rank and hi > lo:
+                    e = RSPaxosReplicaGroup(hi - lo, self.R, me=r, window=self.W, fault_tolerance=fault_tolerance)
+                    e.preset_leader(self.LEADER)
+                    self.reps[(b, r)] = e
+        self.lead = [b for b in range(world) if (b, self.LEADER) in self.reps]      # (at most one: block `rank`)
+        self._plans = {k: self._plan(k) for k in ("accept", "accept_reply", "hb", "hb_back")}
+        self._bufs = {}
+        self.cw = {}
+
+    # ---- static plans: who sends what to whom, the same list on every rank --------------------------------------------
+    def _msg_bytes(self, kind, b):
+        lo, hi = self.n_groups[b]
+        G = hi - lo
+        if kind == "accept":                                    # ballot u64 | slot u32 | token u32 | flags u8 | pad | the shard
+            return _A16(G * 17) + _A16(G * self.sl)
+        if kind == "accept_reply":
+            return _A16(G * 8)                                  # r_ballot (0 = no reply)
+        if kind == "hb":
+            return _A16(G * 20)                                 # ballot u64 | commit u32 | exec u32 | snap u32
+        return _A16(G * 21)                                     # hb_back: the same + reply u8
+
+    def _plan(self, kind):
+        torch = self.torch
+        msgs = []                                               # (src, dst, block, follower)
+        for b in range(self.world):
+            lo, hi = self.n_groups[b]
+            if hi <= lo:
+                continue
+            hl = home(b, self.LEADER, self.world)
+            for q in range(self.R):
+                if q == self.LEADER:
+                    continue
+                hq = home(b, q, self.world)
+                msgs.append((hl, hq, b, q) if kind in ("accept", "hb") else (hq, hl, b, q))
+        send = sorted([m for m in msgs if m[0] == self.rank], key=lambda m: m[1])       # stable: canonical order per destination
+        recv = sorted([m for m in msgs if m[1] == self.rank], key=lambda m: m[0])
+        in_split, out_split = [0] * self.world, [0] * self.world
+        soff, roff, o = {}, {}, 0
+        for m in send:
+            soff[(m[2], m[3])] = o
+            n = self._msg_bytes(kind, m[2])
+            o += n
+            in_split[m[1]] += n
+        n_send, o = o, 0
+        for m in recv:
+            roff[(m[2], m[3])] = o
+            n = self._msg_bytes(kind, m[2])
+            o += n
+            out_split[m[0]] += n
+        return dict(soff=soff, roff=roff, in_split=in_split, out_split=out_split,
+                    sbuf=torch.zeros(max(n_send, 16), dtype=torch.uint8, device=self.device),
+                    rbuf=torch.zeros(max(o, 16), dtype=torch.uint8, device=self.device))
+
+    def _collective(self, kind):
+        import torch.distributed as dist
+        p = self._plans[kind]
+        self.bytes_sent += sum(p["in_split"])
+        if self.exchange is not None:
+            self.exchange(kind, self)
+        elif self.world > 1:
+            dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
+                                   input_split_sizes=p["in_split"])
+        else:
+            p["rbuf"][:sum(p["out_split"])].copy_(p["sbuf"][:sum(p["in_split"])])
+
+    # ---- typed views of a message inside a buffer -------------------------------------------------------------------------
+    def _fields(self, buf, off, G, spec):
+        torch = self.torch
+        out, o = {}, off
+        for name, dt, width in spec:
+            n = G * width
+            out[name] = buf[o:o + n].view(dt)
+            o += n
+        return out, o
+
+    def _accept_msg(self, buf, off, G):
+        torch = self.torch
+        f, o = self._fields(buf, off, G, (("ballot", torch.int64, 8), ("slot", torch.int32, 4), ("val", torch.int32, 4), ("flags", torch.uint8, 1)))
+        base = off + _A16(G * 17)
+        f["shard"] = buf[base:base + G * self.sl].view(G, self.sl)
+        f["header"] = buf[off:off + G * 17]
+        return f
+
+    def _hb_msg(self, buf, off, G, back):
+        torch = self.torch
+        spec = (("ballot", torch.int64, 8), ("commit_bar", torch.int32, 4), ("exec_bar", torch.int32, 4), ("snap_bar", torch.int32, 4))
+        if back:
+            spec = spec + (("reply", torch.uint8, 1),)
+        return self._fields(buf, off, G, spec)[0]
+
+    def _b(self, key, make):
+        if key not in self._bufs:
+            self._bufs[key] = make()
+        return self._bufs[key]
+
+    # ---- the tick's phases ----------------------------------------------------------------------------------------------------
+    def phase_a(self, data, val, lost=None):
+        """leaders: data[b] uint8 [G_b, L] = the tick's serialized batches, val[b] int32 [G_b] their tokens (NULL = none)"""
+        torch = self.torch
+        R, s, p = self.R, self.LEADER, self._plans["accept"]
+        for b in self.lead:
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            eng = self.reps[(b, s)]
+            msgs = {q: self._accept_msg(p["sbuf"], p["soff"][(b, q)], G) for q in range(R) if q != s}
+            if b not in self.cw:
+                self.cw[b] = RSCodewordBatch(G, self.L, self.d, R - self.d, device=self.device, zero=False)
+            RSCodewordBatch.from_data_and_encode(data[b], self.d, R - self.d, out=self.cw[b],
+                                                 shard_dst=[None if q == s else msgs[q]["shard"] for q in range(R)])
+            acc = eng.req_batch(val[b], out=self._b(("acc", b), lambda: dict(
+                a_n=torch.zeros(G, dtype=torch.int32, device=self.device), a_slot=torch.zeros((self.W, G), dtype=torch.int32, device=self.device),
+                a_val=torch.zeros((self.W, G), dtype=torch.int32, device=self.device), a_ballot=torch.zeros(G, dtype=torch.int64, device=self.device))))
+            live = (acc["a_n"] > 0).to(torch.uint8)
+            self._bufs[("live", b)] = live
+            first = None
+            for q in range(R):
+                if q == s:
+                    continue
+                m = msgs[q]
+                if first is None:                               # the header once, then byte copies of it
+                    m["ballot"].copy_(acc["a_ballot"]); m["slot"].copy_(acc["a_slot"][0]); m["val"].copy_(acc["a_val"][0]); m["flags"].copy_(live)
+                    first = m
+                else:
+                    m["header"].copy_(first["header"])
+                g = None if lost is None else lost.get(b, {}).get(("accept", s, q))
+                if g is not None:
+                    m["flags"].copy_(live & ~g.to(torch.uint8))
+
+    def phase_b(self, lost=None):
+        """followers: handle_msg_accept on what arrived; the reply ballots land in the backward send buffer"""
+        torch = self.torch
+        s, pa, pr = self.LEADER, self._plans["accept"], self._plans["accept_reply"]
+        for (b, q), eng in self.reps.items():
+            if q == s:
+                continue
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            m = self._accept_msg(pa["rbuf"], pa["roff"][(b, q)], G)
+            o = pr["soff"][(b, q)]
+            r_ballot = pr["sbuf"][o:o + G * 8].view(torch.int64)
+            eng.accept(flags=m["flags"], peer=self._b(("peer", b, s), lambda: torch.full((G,), s, dtype=torch.uint8, device=self.device)), slot=m["slot"],
+                       ballot=m["ballot"], val=m["val"], mask=self._b(("mask", b, q), lambda: torch.full((G,), 1 << q, dtype=torch.uint8, device=self.device)),
+                       out=dict(r_ballot=r_ballot, r_slot=self._b(("r_slot", b, q), lambda: torch.zeros(G, dtype=torch.int32, device=self.device))))
+            g = None if lost is None else lost.get(b, {}).get(("accept_reply", q, s))
+            if g is not None:
+                r_ballot.masked_fill_(g, 0)                     # a lost reply
+
+    def phase_c(self):
+        """leaders: the AcceptReply tally; returns {block: committed flags [G_b]}"""
+        torch = self.torch
+        R, s, pr = self.R, self.LEADER, self._plans["accept_reply"]
+        out = {}
+        for b in self.lead:
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            ballot = self._b(("ballot", b), lambda: torch.zeros((R, G), dtype=torch.int64, device=self.device))
+            for q in range(R):
+                if q != s:
+                    o = pr["roff"][(b, q)]
+                    ballot[q].copy_(pr["rbuf"][o:o + G * 8].view(torch.int64))
+            flags = (ballot != 0).to(torch.uint8)
+            acc = self._bufs[("acc", b)]
+            res = self.reps[(b, s)].accept_replies(slot=acc["a_slot"][0], ballot=ballot, flags=flags,
+                                                   out=self._b(("committed", b), lambda: dict(committed=torch.zeros(G, dtype=torch.uint8, device=self.device))))
+            out[b] = res["committed"] & self._bufs[("live", b)]
+        return out
+
+    def phase_hb_out(self, lost=None):
+        torch = self.torch
+        R, s, p = self.R, self.LEADER, self._plans["hb"]
+        for b in self.lead:
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            ones = self._b(("ones", b), lambda: torch.ones(G, dtype=torch.uint8, device=self.device))
+            first = None
+            for q in range(R):
+                if q == s:
+                    continue
+                m = self._hb_msg(p["sbuf"], p["soff"][(b, q)], G, False)
+                if first is None:
+                    self.reps[(b, s)].bcast_heartbeat(ones, out=m)
+                    first = p["soff"][(b, q)]
+                else:
+                    o = p["soff"][(b, q)]
+                    p["sbuf"][o:o + G * 20].copy_(p["sbuf"][first:first + G * 20])
+
+    def phase_hb_in(self, lost=None):
+        torch = self.torch
+        s, p, pb = self.LEADER, self._plans["hb"], self._plans["hb_back"]
+        for (b, q), eng in self.reps.items():
+            if q == s:
+                continue
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            m = self._hb_msg(p["rbuf"], p["roff"][(b, q)], G, False)
+            back = self._hb_msg(pb["sbuf"], pb["soff"][(b, q)], G, True)
+            fl = self._b(("ones", b), lambda: torch.ones(G, dtype=torch.uint8, device=self.device))
+            g = None if lost is None else lost.get(b, {}).get(("hb", s, q))
+            if g is not None:
+                fl = fl & ~g.to(torch.uint8)
+            eng.heartbeat(flags=fl, peer=self._b(("peer", b, s), lambda: torch.full((G,), s, dtype=torch.uint8, device=self.device)), ballot=m["ballot"],
+                          commit_bar=m["commit_bar"], exec_bar=m["exec_bar"], snap_bar=m["snap_bar"], out=back)
+            g = None if lost is None else lost.get(b, {}).get(("hb", q, s))
+            if g is not None:
+                back["reply"].masked_fill_(g, 0)
+
+    def phase_hb_back(self):
+        torch = self.torch
+        R, s, pb = self.R, self.LEADER, self._plans["hb_back"]
+        for b in self.lead:
+            lo, hi = self.n_groups[b]
+            G = hi - lo
+            for q in range(R):
+                if q == s:
+                    continue
+                m = self._hb_msg(pb["rbuf"], pb["roff"][(b, q)], G, True)
+                self.reps[(b, s)].heartbeat(flags=m["reply"], peer=self._b(("peer", b, q), lambda: torch.full((G,), q, dtype=torch.uint8, device=self.device)),
+                                            ballot=m["ballot"], commit_bar=m["commit_bar"], exec_bar=m["exec_bar"], snap_bar=m["snap_bar"],
+                                            out=self._b(("hb_scratch", b), lambda: dict(reply=torch.zeros(G, dtype=torch.uint8, device=self.device),
+                                                                                       ballot=torch.zeros(G, dtype=torch.int64, device=self.device),
+                                                                                       commit_bar=torch.zeros(G, dtype=torch.int32, device=self.device),
+                                                                                       exec_bar=torch.zeros(G, dtype=torch.int32, device=self.device),
+                                                                                       snap_bar=torch.zeros(G, dtype=torch.int32, device=self.device))))
+
+    def tick(self, data, val, lost=None, heartbeat=False):
+        """data / val: per led block (see phase_a); lost[b][(kind, from, to)] = bool [G_b] (optional).  Returns {block: committed}"""
+        self.phase_a(data, val, lost)
+        self._collective("accept")
+        self.phase_b(lost)
+        self._collective("accept_reply")
+        committed = self.phase_c()
+        if heartbeat:
+            self.phase_hb_out(lost)
+            self._collective("hb")
+            self.phase_hb_in(lost)
+            self._collective("hb_back")
+            self.phase_hb_back()
+        return committed
+
+    def commits(self):
+        return sum(int(self.reps[(b, self.LEADER)].dump()["counters"][0]) for b in self.lead)
+
+
+def _copy_between(ranks, kind):
+    """the all-to-all of a job whose ranks all live in this process"""
+    for s_, ps in enumerate(ranks):
+        p = ps._plans[kind]
+        so = 0
+        for d, n in enumerate(p["in_split"]):
+            q = ranks[d]._plans[kind]
+            ro = sum(q["out_split"][:s_])
+            assert q["out_split"][s_] == n
+            q["rbuf"][ro:ro + n].copy_(p["sbuf"][so:so + n])
+            so += n
+
+
+class in_process:
+    """every rank of the job inside one process (one device, or the emulator): same objects, plans and buffers, the collective a
+    copy; every rank finishes a phase before any rank starts the next"""
+
+    def __init__(self, total_groups, population, window, world, device, data_len, fault_tolerance=1):
+        self.ranks = [SpreadRSPaxos(total_groups, population, window, r, world, device, data_len, fault_tolerance, exchange=lambda k, me: None)
+                      for r in range(world)]
+
+    def tick(self, data, val, lost=None, heartbeat=False):
+        rs = self.ranks
+
+        def coll(kind):
+            for r in rs:
+                r.bytes_sent += sum(r._plans[kind]["in_split"])
+            _copy_between(rs, kind)
+        for r in rs:
+            r.phase_a(data, val, lost)
+        coll("accept")
+        for r in rs:
+            r.phase_b(lost)
+        coll("accept_reply")
+        committed = {}
+        for r in rs:
+            committed.update(r.phase_c())
+        if heartbeat:
+            for r in rs:
+                r.phase_hb_out(lost)
+            coll("hb")
+            for r in rs:
+                r.phase_hb_in(lost)
+            coll("hb_back")
+            for r in rs:
+                r.phase_hb_back()
+        return committed

@@ -190,6 +190,15 @@ def test_rspaxos_device_steady_loop_on_the_host(sim, oracle):
         assert t.run_steady("cpu", oracle, 90, 16, 1, 0.05, T=5, with_cw=True) > 0
 
 
+def test_spread_rspaxos_exchange_on_the_host(sim):
+    """layout L2 of the RSPaxos engine with every rank in this process (tests/test_spread_rsp.py): against the co-located steady loop"""
+    import test_spread_rsp as t
+    with sim.patched():
+        t.run_spread_vs_colocated("cpu", 2, 130, T=7)
+        t.run_spread_vs_colocated("cpu", 3, 100, T=6)
+        t.run_spread_vs_colocated("cpu", 8, 170, T=5, loss=0.0)
+
+
 def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
     import test_zz_rsp_bytes_gpu as t
     with sim.patched():

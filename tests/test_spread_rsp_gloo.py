@@ -1,0 +1,109 @@
+"""Layout L2 of the RSPaxos engine as a real two-process job: world_size 2 over gloo, the EMULATOR BUILD of the engine on every
+rank (tests/hostsim: the shipped kernels compiled for the host -- not the oracle), ONE `all_to_all_single` per exchange on the
+job's own send / receive buffers: the leader's Accepts WITH the followers' shards of the tick's codewords out, the
+AcceptReplies back, Heartbeats both ways on heartbeat ticks (summerset_amd/spread_rsp.py).  Every replica on every rank must
+end in the state the single-process co-located steady loop (`rsp_cluster.SteadyLoop`) leaves it in, with the same commits
+every tick and the same shard bytes at every follower."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G, R, W, L, FT, TICKS, HB, LOSS = 200, 5, 16, 131, 1, 10, 3, 0.1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(t, b, lo, hi):
+    """the tick's batches, tokens and losses of block b: a function of (t, b) alone, so every process makes the same"""
+    rng = np.random.default_rng(1000 * t + b)
+    n = hi - lo
+    val = (1 + t * G + lo + np.arange(n)).astype(np.uint32)
+    val[rng.random(n) < 0.1] = 0xFFFFFFFF
+    data = rng.integers(0, 256, (n, L), dtype=np.uint8)
+    lost = {}
+    for q in range(1, R):
+        for kind, a, c in (("accept", 0, q), ("accept_reply", q, 0), ("hb", 0, q), ("hb", q, 0)):
+            lost[(kind, a, c)] = rng.random(n) < LOSS
+    return data, val, lost
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    import hostsim
+    from summerset_amd import spread_rsp
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    with hostsim.patched():
+        job = spread_rsp.SpreadRSPaxos(G, R, W, rank, world, "cpu", L, fault_tolerance=FT)
+        for t in range(TICKS):
+            data, val, lost = {}, {}, {}
+            for b in range(world):
+                lo, hi = job.n_groups[b]
+                d, v, ls = _inputs(t, b, lo, hi)
+                data[b], val[b] = torch.from_numpy(d), torch.from_numpy(v.view(np.int32))
+                lost[b] = {k: torch.from_numpy(x) for k, x in ls.items()}
+            committed = job.tick(data, val, lost=lost, heartbeat=(t % HB) == HB - 1)
+            for b, c in committed.items():
+                out["t%d_b%d_committed" % (t, b)] = c.numpy().copy()
+            p = job._plans["accept"]
+            for (b, q) in job.reps:
+                if q != 0:
+                    lo, hi = job.n_groups[b]
+                    out["t%d_b%d_q%d_shard" % (t, b, q)] = job._accept_msg(p["rbuf"], p["roff"][(b, q)], hi - lo)["shard"].numpy().copy()
+        for (b, r), e in job.reps.items():
+            for k, v in e.dump().items():
+                out["b%d_r%d_%s" % (b, r, k)] = v
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=np.array(sorted(job.reps)), sent=job.bytes_sent, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_spread_rspaxos_job_is_the_colocated_loop(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    import hostsim
+    from summerset_amd import RSPaxosReplicaGroup, rsp_cluster, shard, spread_rsp
+    hostsim.build()                                                   # once, before the workers race to build it
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
+    assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
+    assert all(int(rk["sent"]) > 0 for rk in ranks)
+    n_commit = 0
+    with hostsim.patched():
+        for b in range(2):
+            lo, hi = shard.group_range(G, 2, b)
+            reps = [RSPaxosReplicaGroup(hi - lo, R, me=r, window=W, fault_tolerance=FT) for r in range(R)]
+            for e in reps:
+                e.preset_leader(0)
+            loop = rsp_cluster.SteadyLoop(reps, leader=0)
+            for t in range(TICKS):
+                d, v, ls = _inputs(t, b, lo, hi)
+                cw = loop.encode(torch.from_numpy(d))
+                want = loop.tick(torch.from_numpy(v.view(np.int32)), lost={k: torch.from_numpy(x) for k, x in ls.items()},
+                                 heartbeat=(t % HB) == HB - 1).numpy()
+                lead = ranks[spread_rsp.home(b, 0, 2)]
+                assert np.array_equal(lead["t%d_b%d_committed" % (t, b)], want), (t, b)
+                n_commit += int(want.sum())
+                for q in range(1, R):
+                    rk = ranks[spread_rsp.home(b, q, 2)]
+                    assert np.array_equal(rk["t%d_b%d_q%d_shard" % (t, b, q)], cw.shard(q).numpy()), (t, b, q)
+            for r in range(R):
+                rk = ranks[spread_rsp.home(b, r, 2)]
+                for k, y in reps[r].dump().items():
+                    assert np.array_equal(rk["b%d_r%d_%s" % (b, r, k)], y), (b, r, k)
+    assert n_commit > 0
