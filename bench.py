@@ -501,10 +501,10 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     return line
 
 
-def leg_isolated(name, timeout=180):
+def leg_isolated(name, timeout=180, extra=()):
     """a secondary leg in a child process: a device fault there cannot take the headline line with it"""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name], capture_output=True, timeout=timeout)
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name] + list(extra), capture_output=True, timeout=timeout)
     if out.returncode != 0:
         raise RuntimeError("child exited %d: %s" % (out.returncode, out.stderr.decode(errors="replace")[-300:]))
     return json.loads(out.stdout.decode().strip().splitlines()[-1])
@@ -1198,6 +1198,10 @@ def main():
         return launch_check(rank, local, world)
     import torch
     import torch.distributed as dist
+    if args.leg == "l2":                           # child of the headline run at N = 1: the spread layout on virtual ranks
+        torch.cuda.set_device(local)
+        print(json.dumps(spread_run(args, torch, dist, 0, 1, torch.device("cuda", local), steps=args.steps, warmup=4)))
+        return
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
         legs = {"rspaxos": rspaxos_leg, "epaxos_cluster": epaxos_cluster_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
@@ -1393,7 +1397,11 @@ def main():
         try:
             del eng
             torch.cuda.empty_cache()
-            x = spread_run(args, torch, dist, rank, world, dev, steps=max(4, min(args.steps, 12)), warmup=4)
+            if world == 1:                         # virtual ranks: a child process (its quarter-size launches stay out of this process' kernel trace)
+                x = leg_isolated("l2", extra=["--groups", str(args.groups), "--slots", str(args.slots), "--window", str(args.window), "--steps",
+                                              str(max(4, min(args.steps, 12))), "--spread-ranks", str(args.spread_ranks)])
+            else:
+                x = spread_run(args, torch, dist, rank, world, dev, steps=max(4, min(args.steps, 12)), warmup=4)
             l2 = {"layout": "spread (SURVEY 8e L2): replica r of block b on rank (b + r) mod N", "ranks": x["config"]["spread_ranks"],
                   "ranks_are": x["config"]["ranks_are"], "value": x["value"], "unit": "slots/s", "ms_per_tick": x["ms_per_step"],
                   "steps": x["steps"], "warmup": x["warmup"], "exchange": x["exchange"], "backend": x["backend"]}

@@ -40,12 +40,21 @@ constexpr uint32_t EP_NONE = 0xFFFFFFFFu;
 constexpr uint8_t EP_NO_KEY = 0xFF;
 enum { EST_NULL = 0, EST_PREACCEPTING = 1, EST_ACCEPTING = 2, EST_COMMITTED = 3, EST_EXECUTING = 4, EST_EXECUTED = 5 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// An instance is ONE RECORD of 16-byte words, each word a plane [R][W][G] (group fastest, so a wavefront's access to a word is
+// one contiguous 1 KB request):
+//   p0 = { bal lo, bal hi, seq lo, seq hi }
+//   p1 = { deps[0..3] }
+//   p2 = { deps[4], m0, m1, deps[5] }     m0 = status | key << 8 | bk << 16 | pa_acks << 24   (bk: has_lbk | has_rbk << 1 | source << 2)
+//                                          m1 = acc_acks | avoid_fast_path << 8 | exp_prepare_acks << 16 | exp_prepare has-entry bits << 24
+//   p3 = { deps[6], deps[7], -, - }        (populations 7 and 8 only)
+// Rounds 1-2 kept every field in a plane of its own: a handler that takes an instance was 13 loads or 13 stores of 1-8 bytes.
+// The one-launch tick's time turned out to be its NUMBER of memory instructions (profiles/r3o: ~0.65 us per load or store,
+// whatever its width), so the fields a handler touches together now travel together: an instance is 3 loads or 3 stores.
 struct EpView {
     uint32_t G, W, Wmask, R, me, n_keys, simple_q, super_q;
-    uint64_t *bal, *seq;                 // [R][W][G]
-    uint8_t *status, *key, *bk;          // bk: has_lbk | has_rbk << 1 | source << 2
-    uint8_t *pa_acks, *acc_acks;
-    uint32_t *deps;                      // [R][W][R][G]
+    u32x4 *p0, *p1, *p2, *p3;            // [R][W][G] each; p3 NULL at populations <= 6
     uint64_t *pa_seq;                    // my row only: [W][R][G]
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
     uint32_t *len, *commit_bars;         // [R][G]
@@ -55,12 +64,39 @@ struct EpView {
                                          // Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op
     // explicit prepare (recovery != 0; pa_seq / pa_deps then hold every row: [R][W][R][G] / [R][W][R][R][G])
     uint32_t recovery;
-    uint8_t *avoid;                      // [R][W][G] avoid_fast_path
-    uint8_t *xp_acks, *xp_has;           // [R][W][G] exp_prepare_acks, the peers with an entry in exp_prepare_voteds
-    uint64_t *xp_max;                    // [R][W][G] exp_prepare_max_bal
+    uint64_t *xp_max;                    // [R][W][G] exp_prepare_max_bal (avoid_fast_path, exp_prepare_acks and the has-entry bits: m1)
     uint8_t *xv_status, *xv_key;         // [R][W][R][G] exp_prepare_voteds
     uint64_t *xv_seq;
     uint32_t *xv_deps;                   // [R][W][R][R][G]
+};
+
+// an instance in registers
+template <int NR>
+struct EpInst {
+    uint64_t bal, seq;
+    uint32_t d[NR];
+    uint32_t m0, m1;
+    __device__ __forceinline__ uint32_t status() const { return m0 & 0xFFu; }
+    __device__ __forceinline__ uint32_t key() const { return (m0 >> 8) & 0xFFu; }
+    __device__ __forceinline__ uint32_t bk() const { return (m0 >> 16) & 0xFFu; }
+    __device__ __forceinline__ uint32_t pa_acks() const { return m0 >> 24; }
+    __device__ __forceinline__ uint32_t acc_acks() const { return m1 & 0xFFu; }
+    __device__ __forceinline__ uint32_t avoid() const { return (m1 >> 8) & 0xFFu; }
+    __device__ __forceinline__ uint32_t xp_acks() const { return (m1 >> 16) & 0xFFu; }
+    __device__ __forceinline__ uint32_t xp_has() const { return m1 >> 24; }
+    __device__ __forceinline__ void set_status(uint32_t x) { m0 = (m0 & ~0xFFu) | (x & 0xFFu); }
+    __device__ __forceinline__ void set_key(uint32_t x) { m0 = (m0 & ~0xFF00u) | ((x & 0xFFu) << 8); }
+    __device__ __forceinline__ void set_bk(uint32_t x) { m0 = (m0 & ~0xFF0000u) | ((x & 0xFFu) << 16); }
+    __device__ __forceinline__ void set_pa_acks(uint32_t x) { m0 = (m0 & 0x00FFFFFFu) | (x << 24); }
+    __device__ __forceinline__ void set_acc_acks(uint32_t x) { m1 = (m1 & ~0xFFu) | (x & 0xFFu); }
+    __device__ __forceinline__ void set_avoid(uint32_t x) { m1 = (m1 & ~0xFF00u) | ((x & 0xFFu) << 8); }
+    __device__ __forceinline__ void set_xp_acks(uint32_t x) { m1 = (m1 & ~0xFF0000u) | ((x & 0xFFu) << 16); }
+    __device__ __forceinline__ void set_xp_has(uint32_t x) { m1 = (m1 & 0x00FFFFFFu) | (x << 24); }
+    __device__ __forceinline__ void make_null() {                            // mod.rs:467-480
+        bal = 0; seq = 0; m0 = (uint32_t)EP_NO_KEY << 8; m1 = 0;
+#pragma unroll
+        for (int k = 0; k < NR; k++) d[k] = EP_NONE;
+    }
 };
 
 // CACHE: the lane keeps its group's per-row scalars (row lengths, commit bars, my_nulls) in registers from load_scalars() to
@@ -125,26 +161,63 @@ struct EpLaneT {
     __device__ __forceinline__ size_t xv_ix(uint32_t row, uint32_t col, uint32_t peer) const {
         return (((size_t)row * v.W + (col & v.Wmask)) * v.R + peer) * v.G + g;
     }
-    __device__ __forceinline__ void fresh_leader_bk(size_t i) const {        // request.rs:48-57, heartbeat.rs:88-97
-        v.bk[i] = (uint8_t)(v.bk[i] | 1u);
-        v.pa_acks[i] = 0; v.acc_acks[i] = 0;
-        if (v.recovery) { v.xp_acks[i] = 0; v.xp_has[i] = 0; v.xp_max[i] = 0; }
-    }
+    // ---- the instance record (see EpView) ----
     __device__ __forceinline__ size_t ix(uint32_t row, uint32_t col) const { return ((size_t)row * v.W + (col & v.Wmask)) * v.G + g; }
-    __device__ __forceinline__ size_t dx(uint32_t row, uint32_t col, uint32_t i) const {
-        return (((size_t)row * v.W + (col & v.Wmask)) * v.R + i) * v.G + g;
+    __device__ __forceinline__ static void unpack_p2(u32x4 w, EpInst<NR> &I) {
+        if (NR > 4) I.d[4 < NR ? 4 : 0] = w.x;
+        I.m0 = w.y; I.m1 = w.z;
+        if (NR > 5) I.d[5 < NR ? 5 : 0] = w.w;
+    }
+    __device__ __forceinline__ static u32x4 pack_p2(const EpInst<NR> &I) {
+        return (u32x4){NR > 4 ? I.d[4 < NR ? 4 : 0] : EP_NONE, I.m0, I.m1, NR > 5 ? I.d[5 < NR ? 5 : 0] : EP_NONE};
+    }
+    __device__ __forceinline__ EpInst<NR> load_inst(size_t i) const {        // every word of the record in one round of loads
+        EpInst<NR> I;
+        const u32x4 a = v.p0[i], b = v.p1[i], c = v.p2[i];
+        I.bal = (uint64_t)a.x | ((uint64_t)a.y << 32); I.seq = (uint64_t)a.z | ((uint64_t)a.w << 32);
+#pragma unroll
+        for (int k = 0; k < NR; k++) I.d[k] = EP_NONE;
+        I.d[0] = b.x;
+        if (NR > 1) I.d[1 < NR ? 1 : 0] = b.y;
+        if (NR > 2) I.d[2 < NR ? 2 : 0] = b.z;
+        if (NR > 3) I.d[3 < NR ? 3 : 0] = b.w;
+        unpack_p2(c, I);
+        if (NR > 6 && v.R > 6) { const u32x4 e = v.p3[i]; I.d[6 < NR ? 6 : 0] = e.x; I.d[7 < NR ? 7 : 0] = e.y; }
+        return I;
+    }
+    __device__ __forceinline__ void store_p0(size_t i, const EpInst<NR> &I) const {
+        v.p0[i] = (u32x4){(uint32_t)I.bal, (uint32_t)(I.bal >> 32), (uint32_t)I.seq, (uint32_t)(I.seq >> 32)};
+    }
+    __device__ __forceinline__ void store_deps(size_t i, const EpInst<NR> &I) const {   // p1, p2 (with the meta words) and p3
+        v.p1[i] = (u32x4){I.d[0], NR > 1 ? I.d[1 < NR ? 1 : 0] : EP_NONE, NR > 2 ? I.d[2 < NR ? 2 : 0] : EP_NONE, NR > 3 ? I.d[3 < NR ? 3 : 0] : EP_NONE};
+        v.p2[i] = pack_p2(I);
+        if (NR > 6 && v.R > 6) v.p3[i] = (u32x4){I.d[6 < NR ? 6 : 0], I.d[7 < NR ? 7 : 0], 0u, 0u};
+    }
+    __device__ __forceinline__ void store_inst(size_t i, const EpInst<NR> &I) const { store_p0(i, I); store_deps(i, I); }
+    // the words that hold Status / key / bookkeeping / ack masks (and deps[4], deps[5]): a read-modify-write of ONE word of the record
+    __device__ __forceinline__ void load_meta(size_t i, EpInst<NR> &I) const { unpack_p2(v.p2[i], I); }
+    __device__ __forceinline__ void store_meta(size_t i, const EpInst<NR> &I) const { v.p2[i] = pack_p2(I); }
+    __device__ __forceinline__ uint32_t status_at(size_t i) const { return v.p2[i].y & 0xFFu; }
+    __device__ __forceinline__ uint64_t seq_at(size_t i) const { const u32x4 a = v.p0[i]; return (uint64_t)a.z | ((uint64_t)a.w << 32); }
+    __device__ __forceinline__ uint64_t bal_at(size_t i) const { const u32x4 a = v.p0[i]; return (uint64_t)a.x | ((uint64_t)a.y << 32); }
+    __device__ __forceinline__ void fresh_leader_bk(size_t i, EpInst<NR> &I) const {   // request.rs:48-57, heartbeat.rs:88-97
+        I.set_bk(I.bk() | 1u);
+        I.set_pa_acks(0); I.set_acc_acks(0);
+        if (v.recovery) { I.set_xp_acks(0); I.set_xp_has(0); v.xp_max[i] = 0; }
     }
     // is the column still in the row's ring of W instances (the harness guard)
     __device__ __forceinline__ bool held(uint32_t row, uint32_t col) const {
         const uint32_t end = get_len(row);
         return col < end && col + v.W >= end;
     }
-    __device__ __forceinline__ void push_null(uint32_t row) {            // mod.rs:467-480
+    // `write` = false: the caller is about to store the whole record of that very cell itself
+    __device__ __forceinline__ void push_null(uint32_t row, bool write = true) {            // mod.rs:467-480
         const uint32_t col = get_len(row);
-        const size_t i = ix(row, col);
-        v.bal[i] = 0; v.seq[i] = 0; v.status[i] = EST_NULL; v.key[i] = EP_NO_KEY; v.bk[i] = 0;
-        v.pa_acks[i] = 0; v.acc_acks[i] = 0;
-        for (uint32_t k = 0; k < v.R; k++) v.deps[dx(row, col, k)] = EP_NONE;
+        if (write) {
+            EpInst<NR> I;
+            I.make_null();
+            store_inst(ix(row, col), I);
+        }
         set_len(row, col + 1);
         if (row == v.me) add_nulls(1u);
     }
@@ -157,7 +230,7 @@ struct EpLaneT {
 #pragma unroll
         for (int row = 0; row < NR; row++) {
             if ((uint32_t)row >= v.R || d[row] == EP_NONE || !held(row, d[row])) continue;
-            const uint64_t s = v.seq[ix(row, d[row])];
+            const uint64_t s = seq_at(ix(row, d[row]));
             if (s > m) m = s;
         }
         return m;
@@ -168,14 +241,18 @@ struct EpLaneT {
         const uint32_t hc = v.hc[o];
         if (hc == EP_NONE || col > hc) v.hc[o] = col;
     }
-    __device__ __forceinline__ void logged_commit_slot(uint32_t row, uint32_t col) {             // durability.rs:104-135
+    // `known` (optional): the meta words of the cell (row, col) as the caller just stored them -- the walk starts at that very
+    // cell, and re-reading what was written an instant ago is a round trip to memory on the handler's critical path
+    __device__ __forceinline__ void logged_commit_slot(uint32_t row, uint32_t col, const EpInst<NR> *known = nullptr) {   // durability.rs:104-135
         uint32_t cb = get_cb(row);
         if (col != cb) return;
         while (cb < get_len(row) && held(row, cb)) {
             const size_t i = ix(row, cb);
-            const uint32_t st = v.status[i];
-            if (st < EST_COMMITTED) break;
-            if (v.key[i] == EP_NO_KEY) v.status[i] = EST_EXECUTED;
+            EpInst<NR> I;
+            if (known && cb == col) { I.m0 = known->m0; I.m1 = known->m1; I.d[NR > 4 ? 4 : 0] = known->d[NR > 4 ? 4 : 0]; if (NR > 5) I.d[NR > 5 ? 5 : 0] = known->d[NR > 5 ? 5 : 0]; }
+            else load_meta(i, I);
+            if (I.status() < EST_COMMITTED) break;
+            if (I.key() == EP_NO_KEY) { I.set_status(EST_EXECUTED); store_meta(i, I); }
             cb++;
         }
         set_cb(row, cb);
@@ -184,13 +261,17 @@ struct EpLaneT {
     __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot) {
         if (!held(row, col)) return;
         const size_t i = ix(row, col);
-        if (v.status[i] != EST_ACCEPTING || v.bal[i] != ballot || !(v.bk[i] & 1)) return;   // :371-376
-        uint32_t acks = v.acc_acks[i];
+        EpInst<NR> I;
+        load_meta(i, I);
+        if (I.status() != EST_ACCEPTING || !(I.bk() & 1) || bal_at(i) != ballot) return;   // :371-376
+        uint32_t acks = I.acc_acks();
         if ((acks >> peer) & 1u) return;
         acks |= 1u << peer;
-        v.acc_acks[i] = (uint8_t)acks;
-        if ((uint32_t)__popc(acks) >= v.simple_q) {                              // :386
-            v.status[i] = EST_COMMITTED;
+        I.set_acc_acks(acks);
+        const bool commit = (uint32_t)__popc(acks) >= v.simple_q;                // :386
+        if (commit) I.set_status(EST_COMMITTED);
+        store_meta(i, I);
+        if (commit) {
             n_acc++;
             logged_commit_slot(row, col);
         }
@@ -201,16 +282,18 @@ struct EpLaneT {
         const uint32_t R = v.R;
         if (!held(row, col)) return;                                             // :125-127
         const size_t i = ix(row, col);
-        if (v.status[i] != EST_PREACCEPTING || (ballot > 0 && v.bal[i] != ballot) || !(v.bk[i] & 1)) return;   // :129-134
-        uint32_t acks = v.pa_acks[i];
+        EpInst<NR> I = load_inst(i);
+        if (I.status() != EST_PREACCEPTING || (ballot > 0 && I.bal != ballot) || !(I.bk() & 1)) return;   // :129-134
+        uint32_t acks = I.pa_acks();
         if ((acks >> peer) & 1u) return;                                         // :136-138
         if (ballot > 0) {                                                        // :141-144
             v.pa_seq[ps_ix(row, col, peer)] = rseq;
             for (uint32_t k = 0; k < R; k++) v.pa_deps[pd_ix(row, col, peer, k)] = rd[k];
             acks |= 1u << peer;
-            v.pa_acks[i] = (uint8_t)acks;
+            I.set_pa_acks(acks);
+            store_meta(i, I);
         }
-        const bool avoid = v.recovery && v.avoid[i];                             // dependency.rs:196
+        const bool avoid = v.recovery && I.avoid();                              // dependency.rs:196
         // dependency.rs:175-240 fast_quorum_eligibility
         const uint32_t all_cnt = __popc(acks);
         if (all_cnt < v.simple_q) return;
@@ -273,21 +356,17 @@ struct EpLaneT {
             }
         }
         if (next == 0) return;
-        v.seq[i] = dseq;
-        for (uint32_t k = 0; k < R; k++) {
-            uint32_t x = EP_NONE;
+        I.seq = dseq;
 #pragma unroll
-            for (int kk = 0; kk < NR; kk++) if ((uint32_t)kk == k) x = dd[kk];
-            v.deps[dx(row, col, k)] = x;
-        }
+        for (int k = 0; k < NR; k++) I.d[k] = (uint32_t)k < R ? dd[k] : EP_NONE;
+        I.set_status(next == EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING);
+        store_inst(i, I);
         if (next == EST_COMMITTED) {                                             // :158-206
-            v.status[i] = EST_COMMITTED;
             n_fast++;
             logged_commit_slot(row, col);
         } else {                                                                 // :209-262
-            v.status[i] = EST_ACCEPTING;
             n_slow++;
-            accept_reply(v.me, row, col, v.bal[i]);                              // durability.rs:78-83
+            accept_reply(v.me, row, col, I.bal);                                 // durability.rs:78-83
         }
     }
     // messages.rs:577-821 with exp_prepare_next_step (dependency.rs:249-327) and the WAL completions of what it logs;
@@ -298,8 +377,9 @@ struct EpLaneT {
         const uint32_t R = v.R;
         if (!held(row, col)) return 0;                                           // :599-601
         const size_t i = ix(row, col);
-        if (nb <= v.bal[i] || !(v.bk[i] & 1)) return 0;                          // :603-605
-        uint32_t acks = v.xp_acks[i], has = v.xp_has[i];
+        EpInst<NR> I = load_inst(i);
+        if (nb <= I.bal || !(I.bk() & 1)) return 0;                              // :603-605
+        uint32_t acks = I.xp_acks(), has = I.xp_has();
         if ((acks >> peer) & 1u) return 0;                                       // :607-609
         uint64_t mx = v.xp_max[i];
         if (vbal > mx) { has = 0; mx = vbal; v.xp_max[i] = mx; }                 // :612-615
@@ -310,7 +390,8 @@ struct EpLaneT {
             for (uint32_t k = 0; k < R; k++) v.xv_deps[(q / v.G * R + k) * v.G + g] = vd[k];
         }
         acks |= 1u << peer;
-        v.xp_acks[i] = (uint8_t)acks; v.xp_has[i] = (uint8_t)has;
+        I.set_xp_acks(acks); I.set_xp_has(has);
+        store_meta(i, I);
         if ((uint32_t)__popc(acks) < v.simple_q) return 0;                       // dependency.rs:257-260
         // the voted entries, in registers
         uint32_t xs[NR], xk[NR]; uint64_t xq[NR]; uint32_t xd[NR][NR];
@@ -365,18 +446,15 @@ struct EpLaneT {
 #pragma unroll
                 for (int k = 0; k < NR; k++) dd[k] = xd[p][k];
             }
-        v.bal[i] = nb; v.status[i] = (uint8_t)next; v.seq[i] = dseq; v.key[i] = (uint8_t)dkey;
-        for (uint32_t k = 0; k < R; k++) {
-            uint32_t x = EP_NONE;
+        I.bal = nb; I.set_status((uint32_t)next); I.seq = dseq; I.set_key(dkey);
 #pragma unroll
-            for (int kk = 0; kk < NR; kk++) if ((uint32_t)kk == k) x = dd[kk];
-            v.deps[dx(row, col, k)] = x;
-        }
+        for (int k = 0; k < NR; k++) I.d[k] = (uint32_t)k < R ? dd[k] : EP_NONE;
+        if (next == EST_PREACCEPTING) I.set_avoid(1);                            // :747-815
+        store_inst(i, I);
         refresh_highest_cols(row, col, dkey);
         if (next == EST_COMMITTED) { n_xc++; logged_commit_slot(row, col); }     // :637-690
         else if (next == EST_ACCEPTING) { n_xa++; accept_reply(v.me, row, col, nb); }   // :692-745
-        else {                                                                   // :747-815
-            v.avoid[i] = 1;
+        else {
             if (dkey == EP_NO_KEY) n_xn++; else n_xp++;
             pre_accept_reply(v.me, row, col, nb, dseq, dd, 0u);
         }
@@ -519,7 +597,9 @@ struct EpExecLaneT {
     __device__ __forceinline__ void submit_ring(uint32_t ring) {
         const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
         const size_t i = L.ix(row, col);
-        const uint32_t key = v.key[i];
+        EpInst<NR> I;
+        L.load_meta(i, I);
+        const uint32_t key = I.key();
         if (key != EP_NO_KEY) {
             const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = x.kv[(size_t)key * v.G + g];
             x.kv[(size_t)key * v.G + g] = tok;
@@ -529,7 +609,8 @@ struct EpExecLaneT {
             if (n_order < 2u * v.R * v.W) x.order[at(n_order++)] = (uint16_t)ring;   // (the list's capacity; beyond it a result would not come: never seen)
             c_exec++;
         }
-        v.status[i] = EST_EXECUTING;
+        I.set_status(EST_EXECUTING);
+        L.store_meta(i, I);
     }
     // attempt_execution (execution.rs:25-149) from the tail (trow, tcol).  The walk is latency, not bytes: a lane's loads are
     // round trips to HBM one behind the other, so a node's R dependencies and its row predecessor are looked at with all
@@ -544,7 +625,7 @@ struct EpExecLaneT {
         else if (!L.held(trow, tcol)) { c_unheld++; last = XNIL; }               // harness: left the ring = executed
         else {
             ring0 = (trow << wshift) | (tcol & v.Wmask);
-            const uint32_t st = v.status[L.ix(trow, tcol)], no = x.node_of[at(ring0)];
+            const uint32_t st = L.status_at(L.ix(trow, tcol)), no = x.node_of[at(ring0)];
             visit(ring0, st, no, p1, v1, p2, v2);
         }
         for (uint32_t i = 0; !abandoned && i < n_nodes; i++) {
@@ -552,8 +633,11 @@ struct EpExecLaneT {
             if (!(s & XNEW)) continue;
             const uint32_t ring = s & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
             uint32_t cc[NR + 1], cr[NR + 1], cst[NR + 1], cno[NR + 1];           // per cell: column, ring cell (XUNUSED: no pop), Status, node_of
+            {
+                const EpInst<NR> I = L.load_inst(L.ix(row, col));                // :62-73 its dependencies, row order
 #pragma unroll
-            for (int k = 0; k < NR; k++) cc[k] = (uint32_t)k < v.R ? v.deps[L.dx(row, col, k)] : EP_NONE;   // :62-73 its dependencies, row order
+                for (int k = 0; k < NR; k++) cc[k] = (uint32_t)k < v.R ? I.d[k] : EP_NONE;
+            }
             cc[NR] = col > 0 ? col - 1 : EP_NONE;                                // :74-77 the row predecessor
 #pragma unroll
             for (int e = 0; e <= NR; e++) {
@@ -561,7 +645,7 @@ struct EpExecLaneT {
                 const bool on = cc[e] != EP_NONE;
                 const uint32_t r_ = on ? erow : 0u, c_ = on ? cc[e] : 0u, rg = (r_ << wshift) | (c_ & v.Wmask);
                 cr[e] = on ? rg : XUNUSED;
-                cst[e] = v.status[L.ix(r_, c_)];
+                cst[e] = L.status_at(L.ix(r_, c_));
                 cno[e] = x.node_of[at(rg)];
             }
 #pragma unroll
@@ -612,10 +696,17 @@ struct EpExecLaneT {
     // execution.rs:152-211, one command per instance
     __device__ __forceinline__ void cmd_result(uint32_t ring) {
         const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
-        v.status[L.ix(row, col)] = EST_EXECUTED;
+        {
+            const size_t i = L.ix(row, col);
+            EpInst<NR> I;
+            L.load_meta(i, I);
+            I.set_status(EST_EXECUTED);
+            L.store_meta(i, I);
+        }
         uint32_t eb = get_eb(row);
         if (col != eb) return;
-        while (eb < L.get_len(row) && L.held(row, eb) && v.status[L.ix(row, eb)] >= EST_EXECUTED) eb++;
+        eb++;                                                                    // (col itself: Executed just now)
+        while (eb < L.get_len(row) && L.held(row, eb) && L.status_at(L.ix(row, eb)) >= EST_EXECUTED) eb++;
         set_eb(row, eb);
     }
     // durability.rs:136-160 for the row whose commit bar moved
@@ -631,7 +722,7 @@ struct EpExecLaneT {
             for (int q = 0; q < NR; q++) {                                       // (the R tails' Status words: one round of loads)
                 const uint32_t qq = (uint32_t)q < v.R ? (uint32_t)q : 0u, c = L.get_cb(qq);
                 const bool ok = (uint32_t)q < v.R && c > get_eb(qq) && L.held(qq, c - 1);
-                const uint32_t st = v.status[L.ix(qq, ok ? c - 1 : 0u)];
+                const uint32_t st = L.status_at(L.ix(qq, ok ? c - 1 : 0u));
                 if (ok && st == EST_COMMITTED) re |= 1u << q;
             }
             for (uint32_t q = 0; q < v.R; q++)
@@ -686,25 +777,44 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
     const uint32_t row = v.me;
     uint32_t col = EP_NONE;                                                  // mod.rs:485-496 (exec_bars stay 0 here)
     const uint32_t end = L.get_len(row);
+    EpInst<NR> I;
+    I.make_null();
     if (L.get_nulls() != 0)                                                  // only a PreAccept / Accept for my own row pads it
-        for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++)
-            if (v.status[L.ix(row, c)] == EST_NULL) { col = c; break; }
-    if (col == EP_NONE) { L.push_null(row); col = L.get_len(row) - 1; }
+        for (uint32_t c = end > v.W ? end - v.W : 0; c < end; c++) {
+            EpInst<NR> J;
+            L.load_meta(L.ix(row, c), J);
+            if (J.status() == EST_NULL) { col = c; I.m0 = J.m0; I.m1 = J.m1; break; }   // (a padded slot may carry replica bookkeeping: explicit prepare)
+        }
+    if (col == EP_NONE) { L.push_null(row, false); col = L.get_len(row) - 1; }   // (the null record itself is never stored: the whole cell is, below)
     L.add_nulls(0xFFFFFFFFu);                                                      // the slot stops being null
-    L.identify_deps(k, d);
-    const uint64_t seq = 1 + L.max_seq_num(d);
+    L.identify_deps(k, d);                                                   // (one round: the key's R highest columns)
+    uint64_t seq = 0;
+    {                                                                        // max_seq_num: the R sequence numbers in one round
+        bool ok[NR]; uint64_t sq[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            ok[q] = (uint32_t)q < v.R && d[q] != EP_NONE && L.held((uint32_t)q < v.R ? q : 0, d[q]);
+            sq[q] = L.seq_at(L.ix((uint32_t)q < v.R ? q : 0, ok[q] ? d[q] : 0u));
+        }
+#pragma unroll
+        for (int q = 0; q < NR; q++) if (ok[q] && sq[q] > seq) seq = sq[q];
+        seq += 1;
+    }
     const size_t i = L.ix(row, col);
     const uint64_t bal = (uint64_t)(v.me + 1);                               // make_default_ballot
-    v.bal[i] = bal; v.seq[i] = seq; v.key[i] = (uint8_t)k;
-    for (uint32_t q = 0; q < v.R; q++) {
-        uint32_t x = EP_NONE;
+    I.bal = bal; I.seq = seq; I.set_key(k);
 #pragma unroll
-        for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = d[qq];
-        v.deps[L.dx(row, col, q)] = x;
+    for (int q = 0; q < NR; q++) I.d[q] = (uint32_t)q < v.R ? d[q] : EP_NONE;
+    {                                                                        // refresh_highest_cols: hc[key][row] is d[row], loaded above
+        uint32_t hc_row = EP_NONE;
+#pragma unroll
+        for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
+        if (hc_row == EP_NONE || col > hc_row) v.hc[((size_t)L.g * v.n_keys + k) * v.R + row] = col;
     }
-    L.refresh_highest_cols(row, col, k);
-    L.fresh_leader_bk(i);
-    v.status[i] = EST_PREACCEPTING;
+    L.fresh_leader_bk(i, I);
+    I.set_status(EST_PREACCEPTING);
+    I.set_pa_acks(1u << v.me);                                               // (my own PreAcceptReply, below)
+    L.store_inst(i, I);
     of = 1; oc = col; os = seq;
     // my own PreAcceptReply (durability.rs:25-35 -> messages.rs:96-270) on bookkeeping that is fresh: it is recorded and is the
     // only one held, and one reply is below any quorum (simple_q >= 2 at populations >= 3) -- handle_msg_pre_accept_reply
@@ -716,7 +826,6 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = d[qq];
         v.pa_deps[L.pd_ix(row, col, v.me, q)] = x;
     }
-    v.pa_acks[i] = (uint8_t)(1u << v.me);
     (void)ex;
 }
 
@@ -733,40 +842,77 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uin
     of = 0; ob = 0; os = 0;
 #pragma unroll
     for (int i = 0; i < NR; i++) d[i] = EP_NONE;
-    if (!on) return;
-    if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
-    while (L.get_len(row) <= c) L.push_null(row);                            // :33-36
-    const size_t i = L.ix(row, c);
-    if (!(b >= v.bal[i])) return;                                            // :40
-    if (row == v.me && v.status[i] == EST_NULL) L.add_nulls(0xFFFFFFFFu);
+    // The handler is a chain of memory round trips and little else, so its loads are issued in as few ROUNDS as the data
+    // dependences allow, unconditionally and from clamped (always valid) addresses -- what a round loads for a message that
+    // turns out not to be taken is dropped:
+    //   round 1 (with the caller's loads of the message's scalars): the message's DepSet
+    //   round 2: the cell's ballot and meta words, the key's highest columns
+    //   round 3 (PreAccept): the sequence numbers of the key's highest instances
+    const uint32_t rw = row < v.R ? row : 0u;
     uint32_t in[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
+    const size_t i = L.ix(rw, c);
+    const bool need_meta = LBK || MODE == 2 || rw == v.me;                   // (LBK = false: Status / bookkeeping are read only where they can matter;
+    const u32x4 w0 = v.p0[i];                                                //  a CommitNotice leaves the bookkeeping as it is)
+    u32x4 w2 = (u32x4){EP_NONE, (uint32_t)EP_NO_KEY << 8, 0u, EP_NONE};
+    if (need_meta) w2 = v.p2[i];
+    const uint32_t kk = k != EP_NO_KEY ? k : 0u;
+    uint32_t my[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++)
+        my[q] = ((MODE == 0 || (uint32_t)q == rw) && (uint32_t)q < v.R) ? v.hc[((size_t)g * v.n_keys + kk) * v.R + q] : EP_NONE;
+    if (!on) return;
+    if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
+    // :33-36 pad the row up to the column; the cell of the column itself is written below if the message is taken (a fresh
+    // cell's ballot is 0: it always is), so its null record is not stored first
+    bool fresh = false;
+    while (L.get_len(row) <= c) { fresh = L.get_len(row) == c; L.push_null(row, !fresh); }
+    EpInst<NR> I;
+    I.make_null();
+    if (!fresh) {
+        I.bal = (uint64_t)w0.x | ((uint64_t)w0.y << 32);
+        if (need_meta) L.unpack_p2(w2, I);
+    }
+    if (!(b >= I.bal)) return;                                               // :40
+    if (row == v.me && I.status() == EST_NULL) L.add_nulls(0xFFFFFFFFu);
+    uint32_t hc_row = EP_NONE;                                               // hc[key][row] as loaded: refresh_highest_cols needs no second look
+#pragma unroll
+    for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = my[q];
     if (MODE == 0) {
-        uint32_t my[NR];
-        L.identify_deps(k, my);
+        if (k == EP_NO_KEY) {
+#pragma unroll
+            for (int q = 0; q < NR; q++) my[q] = EP_NONE;                    // dependency.rs:113-137: no key, no dependencies
+        }
+        // max_seq_num (dependency.rs:101-109): the R sequence numbers in one round
+        uint64_t ms = 0;
+        bool ok[NR]; uint64_t sq[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            ok[q] = (uint32_t)q < v.R && my[q] != EP_NONE && L.held((uint32_t)q < v.R ? q : 0, my[q]);
+            sq[q] = L.seq_at(L.ix((uint32_t)q < v.R ? q : 0, ok[q] ? my[q] : 0u));
+        }
+#pragma unroll
+        for (int q = 0; q < NR; q++) if (ok[q] && sq[q] > ms) ms = sq[q];
+        ms += 1;
 #pragma unroll
         for (int q = 0; q < NR; q++) {                                       // deps.union(&my_deps)
             if (in[q] != EP_NONE) { if (my[q] != EP_NONE && my[q] > in[q]) in[q] = my[q]; }
             else in[q] = my[q];
         }
-        const uint64_t ms = 1 + L.max_seq_num(my);
         if (ms > s) s = ms;
     }
-    v.bal[i] = b; v.status[i] = MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING);
-    v.seq[i] = s; v.key[i] = (uint8_t)k;
-    for (uint32_t q = 0; q < v.R; q++) {
-        uint32_t x = EP_NONE;
+    I.bal = b; I.set_status(MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING));
+    I.seq = s; I.set_key(k);
 #pragma unroll
-        for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = in[qq];
-        v.deps[L.dx(row, c, q)] = x;
-    }
-    L.refresh_highest_cols(row, c, k);
+    for (int q = 0; q < NR; q++) I.d[q] = (uint32_t)q < v.R ? in[q] : EP_NONE;
+    const uint32_t bk = I.bk();
+    if (MODE != 2) I.set_bk((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
+    L.store_inst(i, I);
+    if (k != EP_NO_KEY && (hc_row == EP_NONE || c > hc_row)) v.hc[((size_t)g * v.n_keys + k) * v.R + row] = c;   // refresh_highest_cols, dependency.rs:141-167
     if (MODE == 2) {
-        L.logged_commit_slot(row, c);                                        // durability.rs:104-135
+        L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
     } else {
-        const uint32_t bk = v.bk[i];
-        v.bk[i] = (uint8_t)((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
         if (LBK && (bk & 1u)) {                                              // durability.rs:25 / :78: leader_bk first
             if (MODE == 1) L.accept_reply(v.me, row, c, b); else L.pre_accept_reply(v.me, row, c, b, s, in, 0u);
         } else {
@@ -901,11 +1047,16 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
     const uint32_t R = v.R;
     const bool h = L.held(row, c);
     const size_t i = L.ix(row, c);
-    // the instance and the replies it already holds
-    uint32_t st = h ? v.status[i] : 0u, acks = h ? v.pa_acks[i] : 0u;
-    const uint64_t b = h ? v.bal[i] : 0ull;
-    const uint32_t bk = h ? v.bk[i] : 0u;
-    const bool avoid = h && v.recovery && v.avoid[i];
+    // the instance (its ballot and meta words; the ring cell exists whether or not the column is still held) and the replies
+    // it already holds
+    EpInst<NR> I;
+    I.make_null();
+    I.bal = L.bal_at(i);
+    L.load_meta(i, I);
+    uint32_t st = h ? I.status() : 0u, acks = h ? I.pa_acks() : 0u;
+    const uint64_t b = h ? I.bal : 0ull;
+    const uint32_t bk = h ? I.bk() : 0u;
+    const bool avoid = h && v.recovery && I.avoid();
     const uint32_t before = st, acks0 = acks;
     uint64_t ps[NR]; uint32_t pd[NR][NR];
 #pragma unroll
@@ -950,15 +1101,18 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
             for (int k = 0; k < NR; k++)
                 if ((uint32_t)k < R) v.pa_deps[L.pd_ix(row, c, p, k)] = pd[p][k];
         }
-    if (fresh) v.pa_acks[i] = (uint8_t)acks;
+    if (fresh) I.set_pa_acks(acks);
     dec = 0;
     if (h && before == EST_PREACCEPTING && st != EST_PREACCEPTING) {
-        v.seq[i] = dseq;
+        I.seq = dseq;
 #pragma unroll
-        for (int k = 0; k < NR; k++) if ((uint32_t)k < R) v.deps[L.dx(row, c, k)] = dd[k];
-        v.status[i] = (uint8_t)st;
-        if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c); dec = EST_COMMITTED; }   // :158-206
-        else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = v.status[i] >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
+        for (int k = 0; k < NR; k++) I.d[k] = (uint32_t)k < R ? dd[k] : EP_NONE;
+        I.set_status(st);
+        L.store_inst(i, I);                                                  // (ballot unchanged, seq / deps / Status / ack mask new)
+        if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c, &I); dec = EST_COMMITTED; }   // :158-206
+        else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = L.status_at(i) >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
+    } else if (fresh) {
+        L.store_meta(i, I);                                                  // only the ack mask moved (deps[4], deps[5] as loaded)
     }
 }
 
@@ -1004,7 +1158,7 @@ __device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR, C> &L, uint32
     const EpView &v = L.v;
     const uint32_t R = v.R;
     const bool h = L.held(row, c);
-    const uint32_t before = h ? v.status[L.ix(row, c)] : 0u;
+    const uint32_t before = h ? L.status_at(L.ix(row, c)) : 0u;
     for (uint32_t oi = 0; oi < R; oi++) {
         const uint32_t p = (ctl >> (3 * oi)) & 7u;
         if (p == v.me || p >= R) continue;
@@ -1012,7 +1166,7 @@ __device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR, C> &L, uint32
         if (!(flags[o] & 1)) continue;
         L.accept_reply(p, row, c, ballot ? ballot[o] : fixed_ballot);
     }
-    return h && before == EST_ACCEPTING && v.status[L.ix(row, c)] >= EST_COMMITTED;
+    return h && before == EST_ACCEPTING && L.status_at(L.ix(row, c)) >= EST_COMMITTED;
 }
 
 __global__ __launch_bounds__(256) void ep_accept_replies_kernel(const EpView v, const uint32_t *__restrict__ col,
@@ -1055,7 +1209,9 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
                 for (uint32_t c = L.get_cb(row); c < end; c++) {
                     if (!L.held(row, c)) continue;
                     const size_t i = L.ix(row, c);
-                    if (v.status[i] == EST_PREACCEPTING && (v.bk[i] & 1)) {
+                    EpInst<EMAXR> J;
+                    L.load_meta(i, J);
+                    if (J.status() == EST_PREACCEPTING && (J.bk() & 1)) {
                         L.pre_accept_reply(ts, row, c, 0, 0, none, ex);
                         if (EXEC) E.after_inner_handler();
                     }
@@ -1065,11 +1221,14 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             const uint32_t row = ts, end = L.get_len(row);
             for (uint32_t c = end > v.W ? end - v.W : 0u; c < end; c++) {
                 const size_t i = L.ix(row, c);
-                const uint32_t st = v.status[i], bk = v.bk[i];
+                EpInst<EMAXR> J;
+                L.load_meta(i, J);
+                const uint32_t st = J.status(), bk = J.bk();
                 if (st >= EST_EXECUTING || ((bk & 2u) && ((bk >> 2) & 7u) != ts)) continue;   // :73-80
                 if (st == EST_COMMITTED) continue;                               // :82-84
-                const uint64_t nb = (((v.bal[i] >> 8) + 1) << 8) | (uint64_t)(v.me + 1);   // make_greater_ballot, mod.rs:500-508
-                L.fresh_leader_bk(i);
+                const uint64_t nb = (((L.bal_at(i) >> 8) + 1) << 8) | (uint64_t)(v.me + 1);   // make_greater_ballot, mod.rs:500-508
+                L.fresh_leader_bk(i, J);
+                L.store_meta(i, J);
                 out_col[(size_t)n * v.G + g] = c; out_bal[(size_t)n * v.G + g] = nb;
                 n++;
             }
@@ -1077,10 +1236,11 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             for (uint32_t k = 0; k < n; k++) {
                 const uint32_t c = out_col[(size_t)k * v.G + g];
                 const size_t i = L.ix(row, c);
+                const EpInst<EMAXR> J = L.load_inst(i);
                 uint32_t d[EMAXR];
 #pragma unroll
-                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? v.deps[L.dx(row, c, q)] : EP_NONE;
-                L.exp_prepare_reply(v.me, row, c, out_bal[(size_t)k * v.G + g], v.bal[i], v.status[i], v.seq[i], d, v.key[i]);
+                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? J.d[q] : EP_NONE;
+                L.exp_prepare_reply(v.me, row, c, out_bal[(size_t)k * v.G + g], J.bal, J.status(), J.seq, d, J.key());
                 if (EXEC) E.after_inner_handler();
             }
         }
@@ -1110,11 +1270,13 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_kernel(const EpView v, con
         if (row < v.R && !(c < L.get_len(row) && !L.held(row, c))) {
             while (L.get_len(row) <= c) L.push_null(row);                        // :530-533
             const size_t i = L.ix(row, c);
-            if (nbal[g] > v.bal[i]) {                                            // :537
-                v.bk[i] = (uint8_t)((v.bk[i] & 1u) | 2u | ((uint32_t)peer[g] << 2));   // replica_bk.source = peer
-                of = 1; ob = v.bal[i]; ost = v.status[i]; os = v.seq[i]; ok = v.key[i];
+            EpInst<EMAXR> J = L.load_inst(i);
+            if (nbal[g] > J.bal) {                                               // :537
+                J.set_bk((J.bk() & 1u) | 2u | ((uint32_t)peer[g] << 2));         // replica_bk.source = peer
+                L.store_meta(i, J);
+                of = 1; ob = J.bal; ost = (uint8_t)J.status(); os = J.seq; ok = (uint8_t)J.key();
 #pragma unroll
-                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < v.R ? v.deps[L.dx(row, c, q)] : EP_NONE;
+                for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < v.R ? J.d[q] : EP_NONE;
             }
         }
     }
@@ -1152,10 +1314,10 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_replies_kernel(const EpVie
             for (int q = 0; q < EMAXR; q++) d[q] = (uint32_t)q < R ? vdeps[((size_t)p * R + q) * v.G + g] : EP_NONE;
             const int next = L.exp_prepare_reply(p, row, c, nbal[o], vbal[o], vstatus[o], vseq[o], d, vkey[o]);
             if (next) {
-                const size_t i = L.ix(row, c);
-                dec = (uint8_t)next; db = nbal[o]; ds = v.seq[i]; dk = v.key[i];
+                const EpInst<EMAXR> J = L.load_inst(L.ix(row, c));
+                dec = (uint8_t)next; db = nbal[o]; ds = J.seq; dk = (uint8_t)J.key();
 #pragma unroll
-                for (int q = 0; q < EMAXR; q++) dd[q] = (uint32_t)q < R ? v.deps[L.dx(row, c, q)] : EP_NONE;
+                for (int q = 0; q < EMAXR; q++) dd[q] = (uint32_t)q < R ? J.d[q] : EP_NONE;
             }
         }
         decision[g] = dec; d_bal[g] = db; d_seq[g] = ds; d_key[g] = dk;
@@ -1187,14 +1349,11 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     a.used = 0;
     EpView &v = e->v;
     const size_t G = e->cfg.n_groups, W = e->cfg.window, R = e->cfg.population, K = e->cfg.n_keys;
-    ecarve(a, v.bal, R * W * G, dry); ecarve(a, v.seq, R * W * G, dry);
-    ecarve(a, v.status, R * W * G, dry); ecarve(a, v.key, R * W * G, dry); ecarve(a, v.bk, R * W * G, dry);
-    ecarve(a, v.pa_acks, R * W * G, dry); ecarve(a, v.acc_acks, R * W * G, dry);
-    ecarve(a, v.deps, R * W * R * G, dry);
+    ecarve(a, v.p0, R * W * G, dry); ecarve(a, v.p1, R * W * G, dry); ecarve(a, v.p2, R * W * G, dry);
+    if (R > 6) ecarve(a, v.p3, R * W * G, dry);
     const size_t PR = e->cfg.recovery ? R : 1;                                   // reply tables: every row / my row only
     ecarve(a, v.pa_seq, PR * W * R * G, dry); ecarve(a, v.pa_deps, PR * W * R * R * G, dry);
     if (e->cfg.recovery) {
-        ecarve(a, v.avoid, R * W * G, dry); ecarve(a, v.xp_acks, R * W * G, dry); ecarve(a, v.xp_has, R * W * G, dry);
         ecarve(a, v.xp_max, R * W * G, dry);
         ecarve(a, v.xv_status, R * W * R * G, dry); ecarve(a, v.xv_key, R * W * R * G, dry); ecarve(a, v.xv_seq, R * W * R * G, dry);
         ecarve(a, v.xv_deps, R * W * R * R * G, dry);
@@ -1213,6 +1372,13 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     }
 }
 // ---- the closed loop of a co-located cluster (smr_ep_cluster_*): the little flag arithmetic between the handlers ----------
+__global__ __launch_bounds__(256) void ep_init_records_kernel(u32x4 *__restrict__ p1, u32x4 *__restrict__ p2, u32x4 *__restrict__ p3, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    p1[i] = (u32x4){EP_NONE, EP_NONE, EP_NONE, EP_NONE};
+    p2[i] = (u32x4){EP_NONE, (uint32_t)EP_NO_KEY << 8, 0u, EP_NONE};
+    if (p3) p3[i] = (u32x4){EP_NONE, EP_NONE, 0u, 0u};
+}
 // out[g] = in[g] unless drop[g] (a lost message)
 __global__ __launch_bounds__(256) void ep_flags_drop_kernel(uint32_t G, const uint8_t *__restrict__ in, const uint8_t *__restrict__ drop,
                                                             uint8_t *__restrict__ out) {
@@ -1239,21 +1405,44 @@ __global__ __launch_bounds__(256) void ep_fill_kernel(uint32_t G, uint8_t *__res
 // another wavefront's step wrote.  Execution (durability.rs:136-160) runs behind a handler on the same lane instead of as a
 // launch of its own.  115 launches of 1024 wavefronts each became one launch of 5120: the per-group work of different
 // replicas overlaps, and nothing waits for a launch boundary.
+template <typename T> __device__ __forceinline__ void ep_shift_ptr(T *&p, int64_t d) { p = (T *)((char *)p + d); }
+__device__ __forceinline__ void ep_shift(EpView &v, int64_t d) {
+    ep_shift_ptr(v.p0, d); ep_shift_ptr(v.p1, d); ep_shift_ptr(v.p2, d); ep_shift_ptr(v.p3, d);
+    ep_shift_ptr(v.pa_seq, d); ep_shift_ptr(v.pa_deps, d); ep_shift_ptr(v.len, d); ep_shift_ptr(v.commit_bars, d);
+    ep_shift_ptr(v.my_nulls, d); ep_shift_ptr(v.hc, d); ep_shift_ptr(v.counters, d); ep_shift_ptr(v.xp_max, d);
+    ep_shift_ptr(v.xv_status, d); ep_shift_ptr(v.xv_key, d); ep_shift_ptr(v.xv_seq, d); ep_shift_ptr(v.xv_deps, d);
+}
+__device__ __forceinline__ void ep_shift(EpExec &x, int64_t d) {
+    ep_shift_ptr(x.exec_bars, d); ep_shift_ptr(x.prev_cb, d); ep_shift_ptr(x.kv, d); ep_shift_ptr(x.digest, d);
+    ep_shift_ptr(x.node_of, d); ep_shift_ptr(x.nslot, d); ep_shift_ptr(x.head, d); ep_shift_ptr(x.sib, d); ep_shift_ptr(x.parent, d);
+    ep_shift_ptr(x.order, d); ep_shift_ptr(x.n_sub, d); ep_shift_ptr(x.counters, d);
+}
+
 template <int NR>
 struct EpClusterArgs {
     uint32_t R, G, execute, quiet;               // quiet: handlers that can move no commit bar skip the execution pass (no recovery)
-    EpView v[NR];
-    EpExec x[NR];
+    // The replicas of a cluster are created alike, so their arenas have ONE layout: replica q's arrays are replica 0's, `delta[q]`
+    // bytes further on.  A wavefront builds its view from v0 / x0 with a handful of scalar adds and keeps it in SGPRs; indexing an
+    // array of R views by the wavefront's number made every pointer a scalar LOAD from the kernel arguments wherever the
+    // register budget had dropped it (535 per wavefront per tick, each a dependent round trip to the scalar cache).
+    EpView v0;
+    EpExec x0;
+    int64_t delta[NR];
     const uint8_t *keys[NR];
     const uint8_t *drop[NR * NR];                // [s * NR + q] (may be NULL)
     smr_ep_cluster_out out[NR];
     uint8_t *r_flags, *a_flags;                  // [s][q][G]   PreAcceptReply / AcceptReply of q to leader s
     uint64_t *r_seq;                             // [s][q][G]
     uint32_t *r_deps;                            // [s][q][R][G]
+#ifdef EPC_STAMPS
+    unsigned long long *stamps;                  // [8 blocks][NR wavefronts][64 steps]: experiments only (tools/dbg_epc_stamps.py)
+#endif
 };
 
 #ifndef EPC_WAVES_PER_EU
-#define EPC_WAVES_PER_EU 3                   // R <= 5: 168 VGPRs = 12 wavefronts per CU = two 5-wavefront blocks (at 2 per SIMD only ONE block fits)
+#define EPC_WAVES_PER_EU 2                   // one 5-wavefront block per CU and no spills.  Measured with per-step stamps (profiles/r3r): at 168
+                                             // VGPRs (3 per SIMD) the hardware still ran ONE block per CU; at 128 / 96 two / three blocks share a CU but
+                                             // each runs 1.7-4x longer (spills + contention) -- the tick is a chain of dependent steps, not a throughput job
 #endif
 template <int NR, bool RECOVERY>
 __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
@@ -1262,8 +1451,11 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
     const uint32_t g0 = blockIdx.x * 64u + (threadIdx.x & 63u);
     const bool live = g0 < G;
     const uint32_t g = live ? g0 : 0u;
-    const EpView &v = a.v[q];
-    const EpExec &x = a.x[q];
+    EpView v = a.v0;
+    EpExec x = a.x0;
+    ep_shift(v, a.delta[q]);
+    ep_shift(x, a.delta[q]);
+    v.me = q;
     EpLaneT<NR, true> L(v, g);
     EpExecLaneT<NR, true> E(v, x, L, g);
     if (live) { L.load_scalars(); if (a.execute) E.load_scalars(); }
@@ -1272,6 +1464,10 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
 #pragma unroll 1
     for (uint32_t t = 0; t < n_steps; t++) {
         bool handled = false, can_commit = false, barrier = true;
+#ifdef EPC_STAMPS
+        if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
+            a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + t] = wall_clock64();
+#endif
         if (t == 0) {                                                        // every replica proposes
             if (live) {
                 const smr_ep_cluster_out &o = a.out[q];
@@ -1356,6 +1552,10 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
         if (barrier) __syncthreads();
     }
     if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
+#ifdef EPC_STAMPS
+    if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
+        a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + n_steps] = wall_clock64();
+#endif
     L.flush();
     if (a.execute) E.flush();
 }
@@ -1392,8 +1592,12 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     v.super_q = cfg->optimized_quorum ? R / 2 + (R / 2 + 1) / 2 : (R / 2) * 2;   // mod.rs:694-698
     err = hipMemset(e->arena.base, 0, e->arena.size);
     if (err == hipSuccess) err = hipMemset(v.hc, 0xFF, (size_t)cfg->n_keys * R * v.G * 4);
-    if (err == hipSuccess) err = hipMemset(v.deps, 0xFF, (size_t)R * v.W * R * v.G * 4);
-    if (err == hipSuccess) err = hipMemset(v.key, 0xFF, (size_t)R * v.W * v.G);
+    if (err == hipSuccess) {                                                     // every ring cell a null instance (deps None, key None)
+        const size_t n = (size_t)R * v.W * v.G;
+        hipLaunchKernelGGL(ep_init_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)nullptr, v.p1, v.p2, v.p3, n);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+    }
     if (err != hipSuccess) {
         (void)hipFree(e->arena.base); delete e;
         return fail(SMR_ERR_DEVICE, std::string("epaxos: init: ") + hipGetErrorString(err));
@@ -1549,8 +1753,15 @@ int smr_ep_xp_dump(smr_ep_replica *e, uint8_t *acks, uint64_t *max_bal, uint8_t 
     std::vector<uint64_t> mx(N), xq(N * R);
     std::vector<uint32_t> xd(N * R * R);
 #define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
-    D2H(len.data(), v.len, R * G * 4); D2H(a.data(), v.xp_acks, N); D2H(h.data(), v.xp_has, N); D2H(av.data(), v.avoid, N);
-    D2H(bk.data(), v.bk, N); D2H(mx.data(), v.xp_max, N * 8);
+    D2H(len.data(), v.len, R * G * 4); D2H(mx.data(), v.xp_max, N * 8);
+    {                                                                            // the meta words of the instance records (EpView)
+        std::vector<uint32_t> p2(N * 4);
+        D2H(p2.data(), v.p2, N * 16);
+        for (size_t o = 0; o < N; o++) {
+            const uint32_t m0 = p2[o * 4 + 1], m1 = p2[o * 4 + 2];
+            bk[o] = (uint8_t)(m0 >> 16); av[o] = (uint8_t)(m1 >> 8); a[o] = (uint8_t)(m1 >> 16); h[o] = (uint8_t)(m1 >> 24);
+        }
+    }
     D2H(xs.data(), v.xv_status, N * R); D2H(xk.data(), v.xv_key, N * R); D2H(xq.data(), v.xv_seq, N * R * 8);
     D2H(xd.data(), v.xv_deps, N * R * R * 4);
 #undef D2H
@@ -1602,10 +1813,24 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
     std::vector<uint64_t> bal(R * W * G), seq(R * W * G);
     std::vector<uint8_t> st(R * W * G), key(R * W * G), bk(R * W * G), pa(R * W * G), ac(R * W * G);
     std::vector<uint32_t> deps(R * W * R * G);
-    D2H(bal.data(), v.bal, R * W * G * 8); D2H(seq.data(), v.seq, R * W * G * 8);
-    D2H(st.data(), v.status, R * W * G); D2H(key.data(), v.key, R * W * G); D2H(bk.data(), v.bk, R * W * G);
-    D2H(pa.data(), v.pa_acks, R * W * G); D2H(ac.data(), v.acc_acks, R * W * G);
-    D2H(deps.data(), v.deps, R * W * R * G * 4);
+    {                                                                            // the instance records (EpView), unpacked to the planes of the dump
+        const size_t N = R * W * G;
+        std::vector<uint32_t> p0(N * 4), p1(N * 4), p2(N * 4), p3(R > 6 ? N * 4 : 0);
+        D2H(p0.data(), v.p0, N * 16); D2H(p1.data(), v.p1, N * 16); D2H(p2.data(), v.p2, N * 16);
+        if (R > 6) D2H(p3.data(), v.p3, N * 16);
+        for (size_t rw = 0; rw < R * W; rw++)
+            for (size_t g = 0; g < G; g++) {
+                const size_t o = rw * G + g;
+                bal[o] = (uint64_t)p0[o * 4] | ((uint64_t)p0[o * 4 + 1] << 32);
+                seq[o] = (uint64_t)p0[o * 4 + 2] | ((uint64_t)p0[o * 4 + 3] << 32);
+                const uint32_t m0 = p2[o * 4 + 1], m1 = p2[o * 4 + 2];
+                st[o] = (uint8_t)m0; key[o] = (uint8_t)(m0 >> 8); bk[o] = (uint8_t)(m0 >> 16); pa[o] = (uint8_t)(m0 >> 24); ac[o] = (uint8_t)m1;
+                for (size_t i = 0; i < R; i++) {
+                    const uint32_t d = i < 4 ? p1[o * 4 + i] : i == 4 ? p2[o * 4] : i == 5 ? p2[o * 4 + 3] : p3[o * 4 + (i - 6)];
+                    deps[(rw * R + i) * G + g] = d;
+                }
+            }
+    }
     unsigned long long c[4];
     SMR_HIP_TRY(ctr_read(v.counters, 4, c));   // (explicit-prepare outcomes: smr_ep_xp_dump)
 #undef D2H
@@ -1676,6 +1901,16 @@ int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host,
     return SMR_OK;
 }
 
+#ifdef EPC_STAMPS
+static unsigned long long *g_epc_stamps = nullptr;
+static size_t g_epc_stamps_n = 0;
+int smr_dbg_epc_stamps(unsigned long long *host, size_t cap) {      // experiments only: the last tick's per-step wall-clock stamps (100 MHz)
+    if (!g_epc_stamps || cap < g_epc_stamps_n) return SMR_ERR_ARG;
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    SMR_HIP_TRY(hipMemcpy(host, g_epc_stamps, g_epc_stamps_n * 8, hipMemcpyDeviceToHost));
+    return (int)g_epc_stamps_n;
+}
+#endif
 /* ---- one tick of a co-located EPaxos cluster as ONE call: one launch (ep_cluster_tick_kernel), or -- mode 1 -- the handler
  * kernels back to back, launch by launch, as summerset_amd/ep_cluster.py's closed loop drives them ---- */
 struct smr_ep_cluster {
@@ -1760,11 +1995,24 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
     EpClusterArgs<NR> a;
     memset(&a, 0, sizeof(a));
     a.R = R; a.G = G; a.execute = c->rep[0]->cfg.execute; a.quiet = !c->rep[0]->cfg.recovery;
+    a.v0 = c->rep[0]->v; a.x0 = c->rep[0]->x;
     for (uint32_t r = 0; r < R; r++) {
-        a.v[r] = c->rep[r]->v; a.x[r] = c->rep[r]->x; a.keys[r] = keys_dev[r]; a.out[r] = out[r];
+        a.delta[r] = (int64_t)(c->rep[r]->arena.base - c->rep[0]->arena.base);
+        // (one layout: smr_ep_cluster_create took only replicas that agree in everything the layout depends on)
+        if ((char *)c->rep[r]->v.p0 - c->rep[r]->arena.base != (char *)c->rep[0]->v.p0 - c->rep[0]->arena.base ||
+            (char *)c->rep[r]->v.counters - c->rep[r]->arena.base != (char *)c->rep[0]->v.counters - c->rep[0]->arena.base)
+            return fail(SMR_ERR_STATE, "epaxos cluster: the replicas' arenas differ in layout");
+        a.keys[r] = keys_dev[r]; a.out[r] = out[r];
         for (uint32_t q = 0; q < R; q++) a.drop[r * NR + q] = drop_dev ? drop_dev[(size_t)r * R + q] : nullptr;
     }
     a.r_flags = c->r_flags[0]; a.a_flags = c->a_flags[0]; a.r_seq = c->r_seq[0]; a.r_deps = c->r_deps[0];
+#ifdef EPC_STAMPS
+    static unsigned long long *g_stamps = nullptr;
+    if (!g_stamps) { SMR_HIP_TRY(hipMalloc((void **)&g_stamps, 8 * NR * 64 * 8)); }
+    SMR_HIP_TRY(hipMemsetAsync(g_stamps, 0, 8 * NR * 64 * 8, (hipStream_t)stream));
+    a.stamps = g_stamps;
+    g_epc_stamps = g_stamps; g_epc_stamps_n = 8 * NR * 64;
+#endif
     if (a.quiet)
         hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
     else

@@ -66,4 +66,8 @@ if a.extra:
     torch.cuda.synchronize()
     bench.wire_ingest_leg(torch, dev)             # the peer-traffic parser's three kernels (round 2: no PMC traffic for them yet)
     torch.cuda.synchronize()
+    bench.epaxos_cluster_leg(torch, dev, ticks=4)  # round 3: the one-launch cluster tick (ep_cluster_tick_kernel)
+    torch.cuda.synchronize()
+    bench.rspaxos_leg(torch, dev, ticks=8, warmup=4)   # round 3: the one-pass from_data + encode + fan-out (rs_from_data_xtime) and the rsp_* handlers
+    torch.cuda.synchronize()
 print("done")
