@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r3a_pmc_traffic.json")
-PMC_NOTE = ("profiles/r3a_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
+PMC_FILE = os.path.join(ROOT, "profiles", "r3m_pmc_traffic.json")
+PMC_NOTE = ("profiles/r3m_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
             "gfx950 corrections of MI355X_MICROARCH.md applied; bytes per launch at 65536 groups, S=32, default workload)")
 
 
@@ -374,7 +374,7 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
                 us = leg["tick_us_device_median"]
                 leg["roofline"] = {"bound": "hbm", "kernel": "ep_cluster_tick_kernel<5> (the whole tick: 1 launch)", "achieved": alg / us / 1e3,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
-                                   "avg_launch_us": us, "traffic": _leg_traffic("smr::ep_cluster_tick_kernel<5>"),
+                                   "avg_launch_us": us, "traffic": _leg_traffic("smr::ep_cluster_tick_kernel<5, false>"), "traffic_source": PMC_NOTE,
                                    "note": "alg bytes = SURVEY 8(d)'s <= 370 B per instance x 5 x 65536 instances per tick (the tally's figure; the "
                                            "tick also runs 5 proposals, 20 PreAccepts, 20 CommitNotices and the execution walks per group)"}
             line[name] = leg
@@ -404,7 +404,7 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     reps = [RSPaxosReplicaGroup(G, R, me=r, window=W, fault_tolerance=1) for r in range(R)]
     for r in reps:
         r.preset_leader(0)
-    loop = rsp_cluster.SteadyLoop(reps, leader=0)
+    loop = rsp_cluster.SteadyLoop(reps, leader=0, one_launch=os.environ.get("SMR_RSP_CALL_BY_CALL") is None)
     rng = np.random.default_rng(0x5EED5EED)
     srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
     cws = [RSCodewordBatch(G, L, 3, 2, device=dev, zero=False) for _ in range(NB)]
@@ -433,7 +433,9 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
                         "followers' stores, 4 x handle_msg_accept (one shard each), AcceptReply tally at majority + 1 with the "
                         "shard-availability gate, Heartbeats every %d ticks; <= 1 of 4 replies lost per slot"
                         % (G, L, NB, NB * (G * L + G * cws[0].cw_stride) / 1e6, H),
-            "engine": "csrc/rsp_engine.hip (rsp_* kernels) + rs_from_data_xtime<2, 4>"}
+            "engine": "csrc/rsp_engine.hip (rsp_cluster_tick_kernel: the tick's handlers in one launch, messages through LDS%s) + rs_from_data_xtime<2, 4>"
+                      % ("" if loop._cl is not None else " -- here: SMR_RSP_CALL_BY_CALL, one launch per handler"),
+            "launches_per_tick": 2 if loop._cl is not None else "~15"}
     # eager: one host call per handler
     c0 = commits()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -478,9 +480,10 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
         alg = G * (L + 10 * cws[0].shard_len) + G * (52 + 33)   # the encode pass (L read, the codeword + the five stores written) + the tally's 8(d) bytes
         line["graph"] = {"value": n_c / dt, "unit": "slots/s", "ms_per_tick": dt / nt * 1e3, "device_ms_per_tick": ms, "ticks_per_graph": NB,
                          "committed_per_tick": n_c / nt, "rs_payload_GiBps": G * L * nt / 2**30 / dt}
-        line["roofline"] = {"bound": "hbm", "kernel": "the whole tick (one HIP graph of %d ticks): rs_from_data_xtime<2, 4> + the fan-out copy + rsp_* handlers" % NB,
+        t_enc, t_tick = _leg_traffic("smr::rs_from_data_xtime<2, 4>"), _leg_traffic("smr::rsp_cluster_tick_kernel")
+        line["roofline"] = {"bound": "hbm", "kernel": "the whole tick (one HIP graph of %d ticks): rs_from_data_xtime<2, 4> (encode + fan-out) + rsp_cluster_tick_kernel" % NB,
                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "alg_bytes_per_launch": alg, "avg_launch_us": ms * 1e3, "traffic": None,
+                            "alg_bytes_per_launch": alg, "avg_launch_us": ms * 1e3, "traffic": (t_enc + t_tick) if (t_enc and t_tick) else None, "traffic_source": PMC_NOTE,
                             "note": "alg bytes per tick = 16384 x (L read + 5 shard_len written for the leader's codeword + 5 shard_len for the shard "
                                     "stores) for from_data + encode + fan-out, 85 B per slot for the tally (SURVEY 8(d))"}
         line["value"], line["unit"], line["ms_per_tick"] = line["graph"]["value"], "slots/s", line["graph"]["ms_per_tick"]

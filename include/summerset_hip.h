@@ -745,6 +745,20 @@ int smr_rsp_handle_reconstruct(smr_rsp_replica *e, const uint8_t *flags_dev, con
                                const smr_rsp_shards *out, void *stream);
 int smr_rsp_handle_reconstruct_reply(smr_rsp_replica *e, const uint8_t *flags_dev, const smr_rsp_shards *in, void *stream);
 /* in->flags: a Heartbeat from peer_dev[g] arrives; reply_dev[g] = 1: mine goes back (fields in `out`) */
+/* The steady state of a co-located RSPaxos cluster (one prepared leader, no timeouts) as ONE launch per tick: a block is the R
+ * replicas (a wavefront each) of 64 groups; the leader's handle_req_batch on val_dev[g] (0xFFFFFFFF: none), the followers'
+ * handle_msg_accept with the mask of the one shard each holds, the leader's handle_msg_accept_reply tally peers ascending and --
+ * heartbeat != 0 -- the leader's Heartbeat, the followers' heard_heartbeat + Heartbeats back, the leader hearing them; messages
+ * cross wavefronts through LDS.  What summerset_amd/rsp_cluster.SteadyLoop does call by call (same handler bodies, same order).
+ * lost_dev (may be NULL): [4 * R] device pointers, entry k * R + q (may be NULL) = u8 [G], 1 where the message is lost:
+ * k = 0 Accept leader -> q, 1 AcceptReply q -> leader, 2 Heartbeat leader -> q, 3 Heartbeat q -> leader.
+ * committed_dev[g] = 1 where the tick's slot committed at the leader.  Replicas: me = index, one population / groups / window /
+ * fault_tolerance; they stay the caller's.  (The shard bytes are smr_rs_from_data_encode_fanout's.) */
+typedef struct smr_rsp_cluster smr_rsp_cluster;
+int smr_rsp_cluster_create(smr_rsp_replica *const *reps, uint32_t n, smr_rsp_cluster **out);
+void smr_rsp_cluster_destroy(smr_rsp_cluster *c);
+int smr_rsp_cluster_steady_tick(smr_rsp_cluster *c, uint8_t leader, const uint32_t *val_dev, const uint8_t *const *lost_dev, int heartbeat,
+                                uint8_t *committed_dev, void *stream);
 int smr_rsp_handle_heartbeat(smr_rsp_replica *e, const uint8_t *peer_dev, const smr_rsp_heartbeat *in, uint8_t *reply_dev,
                              const smr_rsp_heartbeat *out, void *stream);
 int smr_rsp_bcast_heartbeat(smr_rsp_replica *e, const uint8_t *flags_dev, const smr_rsp_heartbeat *out, void *stream);

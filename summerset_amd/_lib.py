@@ -288,6 +288,9 @@ SYMBOLS = [
     ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("smr_rsp_replica_create", _i, [C.POINTER(RspCfg), C.POINTER(_vp)]),
     ("smr_rsp_replica_destroy", None, [_vp]),
+    ("smr_rsp_cluster_create", _i, [_vp, _u32, _vp]),
+    ("smr_rsp_cluster_destroy", None, [_vp]),
+    ("smr_rsp_cluster_steady_tick", _i, [_vp, _u8, _vp, _vp, _i, _vp, _vp]),
     ("smr_rsp_preset_leader", _i, [_vp, _u8]),
     ("smr_rsp_req_batch", _i, [_vp, _vp, C.POINTER(RspAccepts), _vp]),
     ("smr_rsp_handle_accept", _i, [_vp] + [_vp] * 9),

@@ -254,30 +254,51 @@ struct RspLane {
     }                \
     L.flush();
 
-// request.rs:10-151 + my AcceptData completion
+// request.rs:10-151 + my AcceptData completion on one lane: the batch token x (RSP_NULL: none); n = 1 with (slot, ab) = the Accept to send
+__device__ __forceinline__ void rsp_req_batch_lane(RspLane &L, uint32_t x, uint32_t &n, uint32_t &slot, uint64_t &ab) {
+    const RspView &v = L.v;
+    n = 0; ab = 0; slot = 0;
+    if (x == RSP_NULL) return;
+    if (!L.is_leader() || L.bpd == 0) { L.c_redirect++; return; }       // :19-42
+    slot = RSP_NULL;                                                     // mod.rs:434-442
+    for (uint32_t s = L.ebar > L.ring_lo() ? L.ebar : L.ring_lo(); s < L.len; s++)
+        if (v.s_st[L.ix(s)] == RST_NULL) { slot = s; break; }
+    if (slot == RSP_NULL) { L.push_null(); slot = L.len - 1; }
+    const size_t i = L.ix(slot);
+    v.s_val[i] = x; v.s_mask[i] = (uint8_t)L.all_mask();                 // from_data + compute_parity
+    v.s_fl[i] = (uint8_t)(v.s_fl[i] | RFL_EXT);
+    L.set_lbk(i, 0, 0);
+    v.s_bal[i] = L.bpd; v.s_st[i] = RST_ACCEPTING;
+    v.s_vbal[i] = L.bpd; v.s_vval[i] = x; v.s_vmask[i] = (uint8_t)(1u << v.me);
+    n = 1; ab = L.bpd;
+    L.accept_reply(v.me, slot, L.bpd);                                   // durability.rs:100-104
+}
+
+// messages.rs:343-403 + the AcceptData completion (durability.rs:85-122) on one lane; (rb, rs) = the AcceptReply (rb = 0: none)
+__device__ __forceinline__ void rsp_accept_lane(RspLane &L, bool on, uint32_t peer, uint32_t s, uint64_t b, uint32_t val, uint32_t mask, uint64_t &rb,
+                                                uint32_t &rs) {
+    const RspView &v = L.v;
+    rb = 0; rs = 0;
+    if (!(on && !(s < L.len && !L.held(s)) && b >= L.bms)) return;
+    L.check_leader(peer, b);
+    L.pad_to(s);
+    const size_t i = L.ix(s);
+    v.s_bal[i] = b; v.s_st[i] = RST_ACCEPTING;
+    v.s_val[i] = val; v.s_mask[i] = (uint8_t)mask;
+    v.s_fl[i] = (uint8_t)(v.s_fl[i] | RFL_RBK); v.s_rsrc[i] = (uint8_t)peer; v.s_rtrig[i] = 0; v.s_rendp[i] = 0;
+    v.s_vbal[i] = b; v.s_vval[i] = val; v.s_vmask[i] = (uint8_t)mask;
+    if (L.is_leader()) L.accept_reply(v.me, s, b);
+    else { rb = b; rs = s; }
+}
+
 __global__ __launch_bounds__(256) void rsp_req_batch_kernel(const RspView v, const uint32_t *__restrict__ val, uint32_t *__restrict__ a_n,
                                                             uint32_t *__restrict__ a_slot, uint32_t *__restrict__ a_val,
                                                             uint64_t *__restrict__ a_ballot) {
     RSP_LANE_BEGIN
-    uint32_t n = 0; uint64_t ab = 0;
+    uint32_t n, slot; uint64_t ab;
     const uint32_t x = val[g];
-    if (x != RSP_NULL) {
-        if (!L.is_leader() || L.bpd == 0) L.c_redirect++;                // :19-42
-        else {
-            uint32_t slot = RSP_NULL;                                    // mod.rs:434-442
-            for (uint32_t s = L.ebar > L.ring_lo() ? L.ebar : L.ring_lo(); s < L.len; s++)
-                if (v.s_st[L.ix(s)] == RST_NULL) { slot = s; break; }
-            if (slot == RSP_NULL) { L.push_null(); slot = L.len - 1; }
-            const size_t i = L.ix(slot);
-            v.s_val[i] = x; v.s_mask[i] = (uint8_t)L.all_mask();         // from_data + compute_parity
-            v.s_fl[i] = (uint8_t)(v.s_fl[i] | RFL_EXT);
-            L.set_lbk(i, 0, 0);
-            v.s_bal[i] = L.bpd; v.s_st[i] = RST_ACCEPTING;
-            v.s_vbal[i] = L.bpd; v.s_vval[i] = x; v.s_vmask[i] = (uint8_t)(1u << v.me);
-            a_slot[g] = slot; a_val[g] = x; n = 1; ab = L.bpd;
-            L.accept_reply(v.me, slot, L.bpd);                           // durability.rs:100-104
-        }
-    }
+    rsp_req_batch_lane(L, x, n, slot, ab);
+    if (n) { a_slot[g] = slot; a_val[g] = x; }
     a_n[g] = n; a_ballot[g] = ab;
     RSP_LANE_END
 }
@@ -288,20 +309,8 @@ __global__ __launch_bounds__(256) void rsp_accept_kernel(const RspView v, const 
                                                          const uint32_t *__restrict__ val, const uint8_t *__restrict__ mask,
                                                          uint64_t *__restrict__ r_ballot, uint32_t *__restrict__ r_slot) {
     RSP_LANE_BEGIN
-    uint64_t rb = 0; uint32_t rs = 0;
-    const uint32_t s = slot[g];
-    const uint64_t b = ballot[g];
-    if ((flags[g] & 1) && !(s < L.len && !L.held(s)) && b >= L.bms) {
-        L.check_leader(peer[g], b);
-        L.pad_to(s);
-        const size_t i = L.ix(s);
-        v.s_bal[i] = b; v.s_st[i] = RST_ACCEPTING;
-        v.s_val[i] = val[g]; v.s_mask[i] = mask[g];
-        v.s_fl[i] = (uint8_t)(v.s_fl[i] | RFL_RBK); v.s_rsrc[i] = peer[g]; v.s_rtrig[i] = 0; v.s_rendp[i] = 0;
-        v.s_vbal[i] = b; v.s_vval[i] = val[g]; v.s_vmask[i] = mask[g];
-        if (L.is_leader()) L.accept_reply(v.me, s, b);
-        else { rb = b; rs = s; }
-    }
+    uint64_t rb; uint32_t rs;
+    rsp_accept_lane(L, flags[g] & 1, peer[g], slot[g], ballot[g], val[g], mask[g], rb, rs);
     r_ballot[g] = rb; r_slot[g] = rs;
     RSP_LANE_END
 }
@@ -517,6 +526,114 @@ __global__ __launch_bounds__(256) void rsp_heartbeat_kernel(const RspView v, con
     RSP_LANE_END
 }
 
+
+// ---- the steady state of a co-located cluster as ONE launch per tick (smr_rsp_cluster_steady_tick) ------------------------
+// A block = R wavefronts over 64 groups, wavefront q = replica q (as ep_cluster_tick_kernel): the leader's handle_req_batch |
+// the followers' handle_msg_accept with the ONE shard each was sent | the leader's handle_msg_accept_reply tally, peers
+// ascending | on a heartbeat tick: the leader's Heartbeat, the followers' heard_heartbeat + their Heartbeats back, the leader
+// hearing those, peers ascending.  Messages cross wavefronts through LDS behind block barriers.  Same handler bodies, same
+// order as summerset_amd/rsp_cluster.SteadyLoop call by call.
+struct RspClusterArgs {
+    uint32_t R, G, leader, heartbeat;
+    RspView v0;                                  // replica 0's view; replica q's arrays are delta[q] bytes further on (one layout)
+    int64_t delta[SMR_MAX_REPLICAS];
+    const uint32_t *val;                         // [G] the tick's batch tokens (RSP_NULL: none)
+    const uint8_t *lost[4][SMR_MAX_REPLICAS];    // [kind][q] (NULL: nothing lost): 0 Accept leader -> q, 1 AcceptReply q -> leader, 2 / 3 Heartbeat out / back
+    uint8_t *committed;                          // [G] out
+};
+
+template <typename T> __device__ __forceinline__ void rsp_shift_ptr(T *&p, int64_t d) { p = (T *)((char *)p + d); }
+__device__ __forceinline__ void rsp_shift(RspView &v, int64_t d) {
+    rsp_shift_ptr(v.leader, d); rsp_shift_ptr(v.bps, d); rsp_shift_ptr(v.bpd, d); rsp_shift_ptr(v.bms, d);
+    rsp_shift_ptr(v.len, d); rsp_shift_ptr(v.cbar, d); rsp_shift_ptr(v.ebar, d); rsp_shift_ptr(v.snap, d); rsp_shift_ptr(v.peb, d);
+    rsp_shift_ptr(v.digest, d); rsp_shift_ptr(v.s_bal, d); rsp_shift_ptr(v.s_vbal, d); rsp_shift_ptr(v.s_pmax, d);
+    rsp_shift_ptr(v.s_st, d); rsp_shift_ptr(v.s_mask, d); rsp_shift_ptr(v.s_vmask, d); rsp_shift_ptr(v.s_fl, d); rsp_shift_ptr(v.s_packs, d);
+    rsp_shift_ptr(v.s_aacks, d); rsp_shift_ptr(v.s_rsrc, d); rsp_shift_ptr(v.s_val, d); rsp_shift_ptr(v.s_vval, d); rsp_shift_ptr(v.s_ltrig, d);
+    rsp_shift_ptr(v.s_lendp, d); rsp_shift_ptr(v.s_rtrig, d); rsp_shift_ptr(v.s_rendp, d); rsp_shift_ptr(v.xq, d); rsp_shift_ptr(v.xn, d);
+    rsp_shift_ptr(v.counters, d);
+}
+
+__global__ __launch_bounds__(SMR_MAX_REPLICAS * 64) void rsp_cluster_tick_kernel(const RspClusterArgs a) {
+    __shared__ uint32_t m_n[64], m_slot[64], m_val[64];
+    __shared__ uint64_t m_bal[64];
+    __shared__ uint64_t r_bal[SMR_MAX_REPLICAS][64];
+    __shared__ uint64_t h_bal[64];
+    __shared__ uint32_t h_commit[64], h_exec[64], h_snap[64];
+    __shared__ uint64_t b_bal[SMR_MAX_REPLICAS][64];
+    __shared__ uint32_t b_commit[SMR_MAX_REPLICAS][64], b_exec[SMR_MAX_REPLICAS][64], b_snap[SMR_MAX_REPLICAS][64];
+    __shared__ uint8_t b_reply[SMR_MAX_REPLICAS][64];
+    const uint32_t q = SMR_WAVE_UNIFORM(threadIdx.x >> 6), lane = threadIdx.x & 63u, s = a.leader;
+    const uint32_t g0 = blockIdx.x * 64u + lane;
+    const bool live = g0 < a.G;
+    const uint32_t g = live ? g0 : 0u;
+    RspView v = a.v0;
+    rsp_shift(v, a.delta[q]);
+    v.me = q;
+    RspLane L(v, g);                                                     // (a dead lane reads group 0's scalars and writes nothing)
+    // 1. the leader: handle_req_batch
+    if (q == s) {
+        uint32_t n = 0, slot = 0; uint64_t ab = 0;
+        const uint32_t x = live ? a.val[g] : RSP_NULL;
+        if (live) rsp_req_batch_lane(L, x, n, slot, ab);
+        m_n[lane] = n; m_slot[lane] = slot; m_val[lane] = x; m_bal[lane] = ab;
+    }
+    __syncthreads();
+    // 2. the followers: handle_msg_accept with the mask of the one shard they hold
+    if (q != s) {
+        uint64_t rb = 0; uint32_t rs = 0;
+        if (live) {
+            const uint8_t *la = a.lost[0][q], *lr = a.lost[1][q];
+            const bool on = m_n[lane] > 0 && !(la && la[g]);
+            rsp_accept_lane(L, on, s, m_slot[lane], m_bal[lane], m_val[lane], 1u << q, rb, rs);
+            if (lr && lr[g]) rb = 0;                                     // the AcceptReply is lost
+        }
+        r_bal[q][lane] = rb;
+    }
+    __syncthreads();
+    // 3. the leader: the AcceptReplies, peers ascending
+    if (q == s && live) {
+        const uint32_t slot = m_slot[lane];
+        const bool was_live = m_n[lane] > 0;
+        const uint32_t before = L.held(slot) ? v.s_st[L.ix(slot)] : 0u;
+        for (uint32_t p = 0; p < a.R; p++) {
+            if (p == s) continue;
+            const uint64_t rb = r_bal[p][lane];
+            if (rb != 0) L.accept_reply(p, slot, rb);
+        }
+        a.committed[g] = (was_live && before == RST_ACCEPTING && L.held(slot) && v.s_st[L.ix(slot)] >= RST_COMMITTED) ? 1 : 0;
+    }
+    if (a.heartbeat) {
+        // 4. the leader's periodic Heartbeat (it hears itself)
+        if (q == s) {
+            h_bal[lane] = L.bms; h_commit[lane] = L.cbar; h_exec[lane] = L.ebar; h_snap[lane] = L.snap;
+            if (live) (void)L.heard_heartbeat(v.me, L.bms, L.cbar, L.ebar, L.snap);
+        }
+        __syncthreads();
+        // 5. the followers hear it; their Heartbeat back is sent right after check_leader, before the commit learning
+        if (q != s) {
+            uint8_t rp = 0; uint64_t ob = 0; uint32_t oc = 0, oe = 0, os = 0;
+            const uint8_t *lo = a.lost[2][q], *lb = a.lost[3][q];
+            if (live && !(lo && lo[g])) {
+                const uint64_t b = h_bal[lane];
+                const uint64_t bms_after = b > L.bms ? b : L.bms;
+                const uint32_t cb = L.cbar, eb = L.ebar, sb = L.snap;
+                if (L.heard_heartbeat(s, b, h_commit[lane], h_exec[lane], h_snap[lane])) { rp = 1; ob = bms_after; oc = cb; oe = eb; os = sb; }
+                if (lb && lb[g]) rp = 0;
+            }
+            b_reply[q][lane] = rp; b_bal[q][lane] = ob; b_commit[q][lane] = oc; b_exec[q][lane] = oe; b_snap[q][lane] = os;
+        }
+        __syncthreads();
+        // 6. the leader hears the followers' Heartbeats, peers ascending
+        if (q == s && live)
+            for (uint32_t p = 0; p < a.R; p++) {
+                if (p == s || !b_reply[p][lane]) continue;
+                (void)L.heard_heartbeat(p, b_bal[p][lane], b_commit[p][lane], b_exec[p][lane], b_snap[p][lane]);
+            }
+    }
+    if (live) L.store();
+    L.flush();
+}
+
 }  // namespace smr
 
 using namespace smr;
@@ -695,6 +812,48 @@ int smr_rsp_bcast_heartbeat(smr_rsp_replica *e, const uint8_t *flags_dev, const 
     hipLaunchKernelGGL(rsp_heartbeat_kernel<1>, RSP_GRID(e), e->v, flags_dev, (const uint8_t *)nullptr, (const uint64_t *)nullptr,
                        (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint8_t *)nullptr, out->ballot,
                        out->commit_bar, out->exec_bar, out->snap_bar);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+struct smr_rsp_cluster {
+    uint32_t R = 0, G = 0;
+    smr_rsp_replica *rep[SMR_MAX_REPLICAS] = {};
+};
+
+int smr_rsp_cluster_create(smr_rsp_replica *const *reps, uint32_t n, smr_rsp_cluster **out) {
+    if (!reps || !out) return fail(SMR_ERR_ARG, "rspaxos cluster: null argument");
+    if (n < 3 || n > SMR_MAX_REPLICAS) return fail(SMR_ERR_ARG, "rspaxos cluster: 3..8 replicas");
+    for (uint32_t r = 0; r < n; r++) {
+        if (!reps[r]) return fail(SMR_ERR_ARG, "rspaxos cluster: null replica");
+        const smr_rsp_cfg &k = reps[r]->cfg, &k0 = reps[0]->cfg;
+        if (k.population != n || k.me != r || k.n_groups != k0.n_groups || k.window != k0.window || k.fault_tolerance != k0.fault_tolerance)
+            return fail(SMR_ERR_ARG, "rspaxos cluster: replica r must be created with me = r, population = n and the same groups, window and fault_tolerance");
+        if ((char *)reps[r]->v.counters - reps[r]->arena.base != (char *)reps[0]->v.counters - reps[0]->arena.base)
+            return fail(SMR_ERR_STATE, "rspaxos cluster: the replicas' arenas differ in layout");
+    }
+    smr_rsp_cluster *c = new smr_rsp_cluster();
+    c->R = n; c->G = reps[0]->cfg.n_groups;
+    for (uint32_t r = 0; r < n; r++) c->rep[r] = reps[r];
+    *out = c;
+    return SMR_OK;
+}
+
+void smr_rsp_cluster_destroy(smr_rsp_cluster *c) { delete c; }
+
+int smr_rsp_cluster_steady_tick(smr_rsp_cluster *c, uint8_t leader, const uint32_t *val_dev, const uint8_t *const *lost_dev, int heartbeat,
+                                uint8_t *committed_dev, void *stream) {
+    if (!c || !val_dev || !committed_dev) return fail(SMR_ERR_ARG, "rspaxos cluster: null argument");
+    if (leader >= c->R) return fail(SMR_ERR_ARG, "rspaxos cluster: leader out of range");
+    RspClusterArgs a;
+    memset(&a, 0, sizeof(a));
+    a.R = c->R; a.G = c->G; a.leader = leader; a.heartbeat = heartbeat ? 1u : 0u;
+    a.v0 = c->rep[0]->v;
+    for (uint32_t r = 0; r < c->R; r++) a.delta[r] = (int64_t)(c->rep[r]->arena.base - c->rep[0]->arena.base);
+    a.val = val_dev; a.committed = committed_dev;
+    for (int k = 0; k < 4; k++)
+        for (uint32_t r = 0; r < c->R; r++) a.lost[k][r] = lost_dev ? lost_dev[(size_t)k * c->R + r] : nullptr;
+    hipLaunchKernelGGL(rsp_cluster_tick_kernel, dim3((c->G + 63) / 64), dim3(c->R * 64), 0, (hipStream_t)stream, a);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

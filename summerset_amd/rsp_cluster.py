@@ -184,10 +184,55 @@ class SteadyLoop:
     serialized batches (smr_rs_from_data_encode_fanout) -- the co-located stand-in for the Accepts' payload.
     Every output and scratch tensor is made once and written again every tick."""
 
-    def __init__(self, reps, leader=0):
+    def __init__(self, reps, leader=0, one_launch=False):
+        """one_launch: the tick's handlers as ONE kernel launch (`smr_rsp_cluster_steady_tick`: a block = the R replicas of 64 groups,
+        messages through LDS) instead of one call per handler; `reps` must then be RSPaxosReplicaGroup objects"""
         self.reps, self.R, self.G, self.s = list(reps), len(reps), reps[0].G, int(leader)
         self.stores = None                       # [R, G, shard_len]: store q = what replica q holds of the tick's codewords (shard q)
         self._b = None
+        self._cl = None
+        if one_launch:
+            import ctypes as C
+            from . import _lib
+            self._L = _lib.load()
+            arr = (C.c_void_p * self.R)(*[r._h for r in self.reps])
+            h = C.c_void_p()
+            _lib.check(self._L.smr_rsp_cluster_create(arr, self.R, C.byref(h)))
+            self._cl = h
+            self._held = None
+
+    def close(self):
+        if getattr(self, "_cl", None):
+            self._L.smr_rsp_cluster_destroy(self._cl)
+            self._cl = None
+
+    def __del__(self):
+        self.close()
+
+    _KINDS = (("accept", True), ("accept_reply", False), ("hb", True), ("hb", False))   # (kind, leader -> q?) in lost_dev's order
+
+    def _tick_one_launch(self, val, lost, heartbeat, stream=None):
+        import ctypes as C
+        import torch
+        from . import _lib
+        R, s, dev = self.R, self.s, val.device
+        if self._b is None:
+            self._b = dict(committed=torch.zeros(self.G, dtype=torch.uint8, device=dev))
+        lp, keep = None, []
+        if lost:
+            ptrs = []
+            for kind, out in self._KINDS:
+                for q in range(R):
+                    m = None if q == s else lost.get((kind, s, q) if out else (kind, q, s))
+                    if m is not None:
+                        m = (m if m.dtype == torch.uint8 else m.to(torch.uint8)).contiguous()
+                        keep.append(m)
+                    ptrs.append(None if m is None else m.data_ptr())
+            lp = (C.c_void_p * (4 * R))(*ptrs)
+        _lib.check(self._L.smr_rsp_cluster_steady_tick(self._cl, s, val.data_ptr(), lp, int(bool(heartbeat)), self._b["committed"].data_ptr(),
+                                                       _lib.stream_ptr(stream)))
+        self._held = (keep, val)                  # alive until the next tick has replaced them (the call only enqueues work)
+        return self._b["committed"]
 
     def _bufs(self, dev):
         import torch
@@ -217,6 +262,8 @@ class SteadyLoop:
         """val: int32 [G] batch tokens (NULL = none); lost: optional dict (kind, from, to) -> bool [G] like `tick`'s drop.
         Returns the leader's `committed` flags [G] (valid until the next tick)."""
         import torch
+        if self._cl is not None:
+            return self._tick_one_launch(val, lost, heartbeat)
         R, s, dev = self.R, self.s, val.device
         reps, b = self.reps, self._bufs(dev)
         gone = lambda kind, a, c: None if lost is None else lost.get((kind, a, c))

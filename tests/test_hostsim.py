@@ -188,6 +188,10 @@ def test_rspaxos_device_steady_loop_on_the_host(sim, oracle):
         assert t.run_steady("cpu", oracle, 200, 16, 1, 0.1) > 0
         assert t.run_steady("cpu", oracle, 130, 8, 0, 0.2, T=10) > 0
         assert t.run_steady("cpu", oracle, 90, 16, 1, 0.05, T=5, with_cw=True) > 0
+        assert t.run_steady("cpu", oracle, 200, 16, 1, 0.1, one_launch=True) > 0       # smr_rsp_cluster_steady_tick
+        assert t.run_steady("cpu", oracle, 130, 8, 0, 0.2, T=10, one_launch=True) > 0
+        assert t.run_steady("cpu", oracle, 65, 16, 1, 0.3, T=9, one_launch=True) > 0
+        t.test_one_launch_cluster_argument_errors("cpu")
 
 
 def test_spread_rspaxos_exchange_on_the_host(sim):

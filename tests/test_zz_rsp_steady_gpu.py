@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def run_steady(dev, oracle, G, W, ft, loss, T=14, hb_every=3, with_cw=False):
+def run_steady(dev, oracle, G, W, ft, loss, T=14, hb_every=3, with_cw=False, one_launch=False):
     import torch
     from summerset_amd import RSCodewordBatch, RSPaxosReplicaGroup, rsp_cluster as rc
     R, s = 5, 0
@@ -16,7 +16,7 @@ def run_steady(dev, oracle, G, W, ft, loss, T=14, hb_every=3, with_cw=False):
     orcs = [oracle.RspOracle(G, R, me=r, W=W, fault_tolerance=ft) for r in range(R)]
     for x in engs + orcs:
         x.preset_leader(s)
-    loop = rc.SteadyLoop(engs, leader=s)
+    loop = rc.SteadyLoop(engs, leader=s, one_launch=one_launch)
     rng = np.random.default_rng(G * 7 + ft)
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     total = 0
@@ -60,6 +60,21 @@ def run_steady(dev, oracle, G, W, ft, loss, T=14, hb_every=3, with_cw=False):
 @pytest.mark.parametrize("G,W,ft,loss", [(700, 16, 1, 0.1), (1500, 32, 0, 0.2), (300, 8, 1, 0.0)])
 def test_device_steady_loop_is_the_closed_loop(cuda, oracle, G, W, ft, loss):
     assert run_steady(cuda, oracle, G, W, ft, loss) > 0
+
+
+@pytest.mark.parametrize("G,W,ft,loss", [(700, 16, 1, 0.1), (1500, 32, 0, 0.2), (300, 8, 1, 0.0), (64, 8, 1, 0.3), (65, 16, 0, 0.05)])
+def test_one_launch_steady_tick_is_the_closed_loop(cuda, oracle, G, W, ft, loss):
+    """`smr_rsp_cluster_steady_tick` (one launch per tick, messages through LDS) against five oracles in the numpy-staged loop"""
+    assert run_steady(cuda, oracle, G, W, ft, loss, one_launch=True) > 0
+
+
+def test_one_launch_cluster_argument_errors(cuda):
+    from summerset_amd import RSPaxosReplicaGroup, SummersetError, rsp_cluster as rc
+    a = [RSPaxosReplicaGroup(64, 5, me=r, window=8, fault_tolerance=1) for r in range(5)]
+    odd = RSPaxosReplicaGroup(64, 5, me=4, window=16, fault_tolerance=1)
+    for wrong in (a[::-1], a[:2], a[:4] + [odd]):
+        with pytest.raises(SummersetError):
+            rc.SteadyLoop(wrong, one_launch=True)
 
 
 def test_device_steady_loop_fans_the_shards_out(cuda, oracle):
