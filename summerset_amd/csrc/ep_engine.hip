@@ -730,6 +730,93 @@ struct EpExecLaneT {
         }
         for (uint32_t i = first; i < n_order; i++) cmd_result(x.order[at(i)]);
     }
+    // `advanced` for the common case behind a handler that has the committed instance in registers: the row's commit bar went
+    // from the instance's column to the next (tail = that instance, H = its record as stored, a real command), and every cell
+    // the walk pops from it -- its dependencies, its row predecessor -- turns out executed or gone: a single-node graph.
+    // Then nothing of the walk needs memory but the popped cells' Status words, and those, the R rows' tails for the
+    // re-attempt scan, the cell behind mine for the exec-bar scan and the KV / digest words all go out in ONE round of loads
+    // (node_of is zero everywhere between attempts, so a first pop never needs it).  Returns false -- having touched nothing
+    // -- when the case is another one; `advanced` then does it in general.
+    __device__ __forceinline__ bool advanced_hinted(uint32_t row, uint32_t cb, const EpInst<NR> &H, uint32_t hcol) {
+        const uint32_t key = H.key();
+        if (hcol + 1 != cb || H.status() != EST_COMMITTED || key == EP_NO_KEY || !L.held(row, hcol)) return false;
+        const uint32_t R = v.R;
+        uint32_t cc[NR + 1], cst[NR + 1];
+#pragma unroll
+        for (int k = 0; k < NR; k++) cc[k] = (uint32_t)k < R ? H.d[k] : EP_NONE;
+        cc[NR] = hcol > 0 ? hcol - 1 : EP_NONE;
+#pragma unroll
+        for (int e = 0; e <= NR; e++) {
+            const uint32_t erow = e < NR ? (uint32_t)e : row;
+            const bool on = cc[e] != EP_NONE;
+            cst[e] = L.status_at(L.ix(on ? erow : 0u, on ? cc[e] : 0u));
+        }
+        uint32_t tst[NR]; bool tok[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+            const uint32_t qq = (uint32_t)q < R ? (uint32_t)q : 0u, c = L.get_cb(qq);
+            tok[q] = (uint32_t)q < R && c > get_eb(qq) && L.held(qq, c - 1);
+            tst[q] = L.status_at(L.ix(qq, tok[q] ? c - 1 : 0u));
+        }
+        const uint32_t nst = L.status_at(L.ix(row, hcol + 1));
+        const uint64_t old = x.kv[(size_t)key * v.G + g];
+        uint64_t dg = x.digest[g];
+        // the pops, in the reference's order, on those words
+        bool abandoned = false;
+        uint32_t unheld = 0;
+#pragma unroll
+        for (int e = 0; e <= NR; e++) {
+            if (abandoned || cc[e] == EP_NONE) continue;
+            const uint32_t erow = e < NR ? (uint32_t)e : row;
+            if (cc[e] >= L.get_cb(erow)) { abandoned = true; continue; }         // :41-45
+            if (!L.held(erow, cc[e])) { unheld++; continue; }
+            if (cst[e] < EST_EXECUTING) return false;                            // a second node: the general walk
+        }
+        c_attempts++; c_unheld += unheld;
+        if (abandoned) { c_aborts++; return true; }                              // (nothing was stored, nothing to clean up)
+        // the graph is the tail alone: submit it (execution.rs:105-142)
+        const size_t i = L.ix(row, hcol);
+        const uint32_t ring = (row << wshift) | (hcol & v.Wmask);
+        EpInst<NR> I = H;
+        const uint32_t first = n_order;
+        {
+            const uint64_t tok_ = ((uint64_t)(row + 1) << 32) | hcol;
+            x.kv[(size_t)key * v.G + g] = tok_;
+            dg = (dg ^ tok_) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
+            x.digest[g] = dg;
+            if (n_order < 2u * v.R * v.W) x.order[at(n_order++)] = (uint16_t)ring;
+            c_exec++;
+        }
+        uint32_t re = 0;                                                         // rows to re-attempt (my own tail is Executing now)
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+            if (tok[q] && (uint32_t)q != row && tst[q] == EST_COMMITTED) re |= 1u << q;
+        if (re) {                                                                // rare: the general walk for those, results in order
+            I.set_status(EST_EXECUTING);
+            L.store_meta(i, I);
+            for (uint32_t q = 0; q < R; q++)
+                if ((re >> q) & 1u) (void)attempt(q, L.get_cb(q) - 1);
+            for (uint32_t k = first; k < n_order; k++) cmd_result(x.order[at(k)]);
+            return true;
+        }
+        if (n_order > first) {                                                   // my command's result (execution.rs:152-211)
+            I.set_status(EST_EXECUTED);
+            L.store_meta(i, I);
+            uint32_t eb = get_eb(row);
+            if (hcol == eb) {
+                eb++;
+                if (eb < L.get_len(row) && L.held(row, eb) && nst >= EST_EXECUTED) {
+                    eb++;
+                    while (eb < L.get_len(row) && L.held(row, eb) && L.status_at(L.ix(row, eb)) >= EST_EXECUTED) eb++;
+                }
+                set_eb(row, eb);
+            }
+        } else {                                                                 // (the order list was full: no result comes)
+            I.set_status(EST_EXECUTING);
+            L.store_meta(i, I);
+        }
+        return true;
+    }
     // the attempts of handle_logged_commit_slot for whichever row's commit bar the inner handler just moved (at most one)
     __device__ __forceinline__ void after_inner_handler() {
         for (uint32_t row = 0; row < v.R; row++) {
@@ -753,12 +840,15 @@ typedef EpExecLaneT<EMAXR, false> EpExecLane;
 // ---- the handlers on one lane (= one group of one replica): what the per-handler kernels below and the one-kernel
 // cluster tick (ep_cluster_tick_kernel) both run ---------------------------------------------------------------------------
 // the attempts of handle_logged_commit_slot behind ONE handler (durability.rs:136-160): at most one row's commit bar moved
+// (hint: the instance (hrow, hcol) the handler committed, as it stored it -- see advanced_hinted)
 template <int NR, bool C>
-__device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpExec &x, EpExecLaneT<NR, C> &E) {
+__device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpExec &x, EpExecLaneT<NR, C> &E, const EpInst<NR> *hint = nullptr,
+                                                      uint32_t hrow = 0, uint32_t hcol = 0) {
     E.n_order = 0;
     for (uint32_t row = 0; row < v.R; row++) {
         const uint32_t cb = E.L.get_cb(row);
         if (!E.cb_moved(row, cb)) continue;
+        if (hint && row == hrow && E.advanced_hinted(row, cb, *hint, hcol)) continue;
         E.advanced(row, cb);
     }
     x.n_sub[E.g] = E.n_order;                                                // 0 when no commit bar moved
@@ -836,10 +926,11 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
 template <int MODE, int NR, bool LBK, bool C>
 __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
                                                  const uint32_t *__restrict__ deps, uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
-                                                 uint32_t (&d)[NR]) {
+                                                 uint32_t (&d)[NR], EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
     const EpView &v = L.v;
     const uint32_t g = L.g;
     of = 0; ob = 0; os = 0;
+    if (stored) *stored = false;
 #pragma unroll
     for (int i = 0; i < NR; i++) d[i] = EP_NONE;
     // The handler is a chain of memory round trips and little else, so its loads are issued in as few ROUNDS as the data
@@ -909,6 +1000,7 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uin
     const uint32_t bk = I.bk();
     if (MODE != 2) I.set_bk((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
     L.store_inst(i, I);
+    if (rec) { *rec = I; *stored = true; }
     if (k != EP_NO_KEY && (hc_row == EP_NONE || c > hc_row)) v.hc[((size_t)g * v.n_keys + k) * v.R + row] = c;   // refresh_highest_cols, dependency.rs:141-167
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
@@ -1042,8 +1134,10 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 template <int NR, bool C>
 __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
                                                    const uint32_t (&in_f)[NR], const uint64_t (&in_b)[NR], const uint64_t (&in_s)[NR],
-                                                   const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR]) {
+                                                   const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
+                                                   EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
     const EpView &v = L.v;
+    if (stored) *stored = false;
     const uint32_t R = v.R;
     const bool h = L.held(row, c);
     const size_t i = L.ix(row, c);
@@ -1109,6 +1203,7 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
         for (int k = 0; k < NR; k++) I.d[k] = (uint32_t)k < R ? dd[k] : EP_NONE;
         I.set_status(st);
         L.store_inst(i, I);                                                  // (ballot unchanged, seq / deps / Status / ack mask new)
+        if (rec && st == EST_COMMITTED) { *rec = I; *stored = true; }
         if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c, &I); dec = EST_COMMITTED; }   // :158-206
         else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = L.status_at(i) >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
     } else if (fresh) {
@@ -1464,6 +1559,9 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
 #pragma unroll 1
     for (uint32_t t = 0; t < n_steps; t++) {
         bool handled = false, can_commit = false, barrier = true;
+        EpInst<NR> H;                                                        // the instance this step's handler committed, if it did
+        bool have_h = false;
+        uint32_t h_row = 0, h_col = 0;
 #ifdef EPC_STAMPS
         if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
             a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + t] = wall_clock64();
@@ -1512,7 +1610,8 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
                                 in_d[p][k] = (on && (uint32_t)k < R) ? a.r_deps[(((size_t)s * R + p) * R + k) * G + g] : EP_NONE;
                         }
                         uint64_t dseq; uint32_t dd[NR];
-                        ep_pa_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd);
+                        h_row = s; h_col = o.col[g];
+                        ep_pa_replies_lane(L, s, h_col, SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd, &H, &have_h);
                         o.decision[g] = dec; o.seq[g] = dec ? dseq : 0ull;
 #pragma unroll
                         for (int k = 0; k < NR; k++) if ((uint32_t)k < R) o.deps[(size_t)k * G + g] = dec ? dd[k] : EP_NONE;
@@ -1542,13 +1641,14 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
                 barrier = false;                                             // (the next step that reads across wavefronts has its own in front)
                 if (q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                    ep_acceptor_lane<2, NR, RECOVERY>(L, o.committed[g] & 1, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
-                                            os, d);
+                    h_row = s; h_col = o.col[g];
+                    ep_acceptor_lane<2, NR, RECOVERY>(L, o.committed[g] & 1, s, s, h_col, (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
+                                            os, d, &H, &have_h);
                     handled = true; can_commit = true;
                 }
             }
         }
-        if (handled && a.execute && (can_commit || RECOVERY)) ep_exec_after_handler(v, x, E);
+        if (handled && a.execute && (can_commit || RECOVERY)) ep_exec_after_handler(v, x, E, have_h ? &H : nullptr, h_row, h_col);
         if (barrier) __syncthreads();
     }
     if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
