@@ -145,6 +145,7 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         t.test_accept_replies_over_the_wire("cpu", oracle)
         import test_zzz_wire_ingest_edges_gpu as te                             # the laid-out edges: fast-path boundary, window ends, extremes
         te.test_payload_lengths_around_the_register_fast_path("cpu")
+        te.test_every_frame_of_the_straight_line_path("cpu")
         te.test_frames_at_the_window_edges("cpu")
         te.test_extreme_values_and_odd_encodings("cpu")
         te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")
@@ -351,21 +352,3 @@ def test_cxx_epaxos_host_loop_on_the_host(sim, tmp_path):
                            "-I", here, "-I", os.path.join(t.ROOT, "include"), os.path.join(t.ROOT, "examples", "ep_host_loop.cpp"),
                            lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     t.check_output(subprocess.check_output([exe, "96", "6"], timeout=300).decode(), 96, 6)
-
-
-@pytest.mark.skipif(not __import__("os").environ.get("SMR_TEST_EXPERIMENTS"), reason="experimental kernel variants (compile-time macros that are "
-                    "off in the shipped build): set SMR_TEST_EXPERIMENTS=1 -- each builds its own emulator library (~2 min)")
-def test_experimental_wire_ingest_ring_variant_on_the_host(oracle):
-    """-DSMR_WI_RING=1 (csrc/wire_ingest.hip: the stream as a ring of whole 128-byte lines per lane, the next line in flight
-    while the loaded ones are parsed): every parity test of the shipped parser, on the emulator.  No device number yet."""
-    import hostsim
-    import test_zz_wire_ingest_gpu as t
-    import test_zzz_wire_ingest_edges_gpu as te
-    with hostsim.patched(defines=("SMR_WI_RING=1",)):
-        t.test_ingest_matches_the_sequential_decoder("cpu")
-        t.test_empty_and_overfull("cpu")
-        t.test_accept_replies_over_the_wire("cpu", oracle)
-        te.test_payload_lengths_around_the_register_fast_path("cpu")
-        te.test_frames_at_the_window_edges("cpu")
-        te.test_extreme_values_and_odd_encodings("cpu")
-        te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")

@@ -1,6 +1,7 @@
 """Edges of the device-side peer-traffic parser (csrc/wire_ingest.hip) that the random streams of
 tests/test_zz_wire_ingest_gpu.py only meet by chance, each laid out on purpose and compared with the sequential decoder
-`smr_wire_decode` frame by frame: payload lengths either side of the two-register fast path (<= 16 bytes), frames that
+`smr_wire_decode` frame by frame: payload lengths either side of the straight-line path (2 .. 24 bytes, varints below
+2^32; round 2's two-register path ended at 16), frames that
 end exactly at, one byte before and one byte behind the end of the lane's 128-byte window and its 16-byte refill
 alignment, every varint width at its extreme values (u64::MAX ballots, slots beyond u32 that go the host's way),
 non-canonical varints, varints that run off the frame, streams that end inside a header / inside a payload, a byte buffer
@@ -70,6 +71,54 @@ def test_payload_lengths_around_the_register_fast_path(cuda):
     assert nm == 2 * 48 and na >= 48 and nh >= 16
 
 
+def test_every_frame_of_the_straight_line_path(cuda):
+    """the parser's branch-free path takes payloads of 2 .. 24 bytes whose varints are 1, 3 or 5 bytes long: Heartbeats through
+    all 81 mixes of those widths (6 .. 22 bytes), AcceptReplies and CommitNotices through all 9, each also with one byte too
+    many / too few declared (malformed), with a 64-bit field in every position (the general reader's), and the short frames
+    the device only locates (Prepare, a short PrepareReply, Leave, an unknown variant, lease traffic) between them; a
+    timestamped AcceptReply short enough for the path (it must leave it)"""
+    from summerset_amd import wire
+    W = [lambda v: _varint(v % 251), lambda v: b"\xfb" + struct.pack("<H", 251 + v % 60000), lambda v: _fc(70000 + v)]
+    tail = wire.accept_reply(1, 2)
+    streams, n_bad, lens = [], 0, set()
+    k = 0
+    for a in range(3):
+        for b in range(3):
+            bodies = [_varint(0) + _varint(3) + W[a](k) + W[b](k + 1) + b"\x00",
+                      _varint(0) + _varint(wire.COMMIT_NOTICE) + W[a](k + 2) + W[b](k + 3),
+                      _varint(0) + _varint(3) + W[a](k) + W[b](k + 1) + b"\x01" + _varint(5) + _varint(7),          # Some(SystemTime), tiny
+                      _varint(0) + _varint(3) + W[a](k) + W[b](k + 1) + b"\x02"]                                     # no such Option tag
+            for c in range(3):
+                for d in range(3):
+                    bodies.append(_varint(0) + _varint(wire.HEARTBEAT) + W[a](k) + W[b](k + 1) + W[c](k + 2) + W[d](k + 3))
+                    k += 5
+            for i, body in enumerate(bodies):
+                lens.add(len(body))
+                streams.append(tail + _frame(body) + tail)
+                n_bad += i == 3
+                for delta in (1, -1):
+                    streams.append(tail + struct.pack(">Q", len(body) + delta) + body + tail)
+                    n_bad += 1
+    # a 64-bit varint in every field of a frame that is otherwise the path's
+    for pos in range(4):
+        f = [_varint(9), _fc(70000), _varint(3), _varint(4)]
+        f[pos] = _fd(1 << 40)
+        streams.append(_frame(_varint(0) + _varint(wire.HEARTBEAT) + b"".join(f)) + tail)
+    for pos in range(2):
+        f = [_varint(9), _varint(3)]
+        f[pos] = _fd((1 << 32) - 1)
+        streams.append(_frame(_varint(0) + _varint(3) + b"".join(f) + b"\x00") + tail)
+    # short frames that are only located, hot frames right behind them
+    located = [wire.prepare(7, 0x101), wire.prepare(70000, 1 << 33), wire.prepare_reply(3, 3, 4, 0x101), _frame(_varint(2)),
+               _frame(_varint(1) + bytes(range(20))), _frame(_varint(250) + b"\xff" * 22), _frame(_varint(0) + _varint(200) + b"\xfe" * 10)]
+    for f in located:
+        assert wire.decode(f)[0] == len(f)
+        streams.append(tail + f + wire.heartbeat(0x101, 70000, 69999, 300) + f + tail)
+    assert {6, 22} <= lens and max(len(frame) - 8 for frame in located) >= 20
+    na, nh, no, nm = _check(wire, cuda, streams, seed=5)
+    assert nm == n_bad and nh >= 81 * 9 // 9 and no >= 2 * len(located)
+
+
 def test_frames_at_the_window_edges(cuda):
     """a lane walks its stream through a 128-byte window refilled at a 16-byte-aligned position: a filler frame of every
     length 0 .. 150 in front of hot frames puts their headers and payloads at every offset of the window, across its end and
@@ -79,9 +128,10 @@ def test_frames_at_the_window_edges(cuda):
     for pad in range(0, 151):
         filler = _frame(_varint(1) + bytes((pad * 7 + i) & 0xFF for i in range(pad)))                 # lease traffic: located, not parsed
         s = filler + wire.accept_reply(pad, 0x101) + wire.heartbeat(0x201, pad, 2, 1) + _ar(_fd(pad), _fd(U64)) + wire.commit_notice(9, pad)
+        s += wire.heartbeat(70000 + pad, 80000, 90000, 100000)                                        # 22 bytes: the longest straight-line frame
         streams.append(s + wire.accept_reply(65535, 70000) * 9)
     na, nh, no, nm = _check(wire, cuda, streams, seed=1)
-    assert nm == 0 and na == 151 * 11 and nh == 151 * 2 and no == 151
+    assert nm == 0 and na == 151 * 11 and nh == 151 * 3 and no == 151
 
 
 def test_extreme_values_and_odd_encodings(cuda):
