@@ -857,7 +857,7 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
     return {"workload": "leader-side receive path of one tick: %d connections (%d groups x 4 peers), %d AcceptReply frames each + a Heartbeat on every "
                         "fourth, %d MB of frames -> %d smr_mp_ack records" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
             "value": r["n_acks"] / (us * 1e-6), "unit": "AcceptReply frames/s", "call_us": us, "stream_GBps": stream_bytes / (us * 1e-6) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + scan + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
                          "avg_launch_us": us, "traffic": None}}
 

@@ -15,9 +15,9 @@
 // bytes whose varints are below 2^32 -- take a straight-line path without a branch, every varint out of the two dwords
 // it lies in; everything else (long frames, 64-bit values, timestamps, odd encodings, malformed input) takes the general
 // reader, which the wavefront enters only when one of its lanes needs it.  Output order is the sequential decoder's
-// (connection by connection, frame by frame): pass 1 counts per lane and per wavefront, a one-block scan turns the
-// wavefronts' counts into bases, pass 2 walks again and writes -- no atomics on the record counters (a same-address atomic
-// per wavefront and pass would cost more than the bytes: smr_common.h on the event counters).  Pass 2 keeps a window's
+// (connection by connection, frame by frame): pass 1 counts per lane, per wavefront and per group of 64 wavefronts, pass 2
+// sums what lies before its wavefront (two loads per lane), walks again and writes -- no same-address atomics on the
+// record counters (three per wavefront on its group's row; smr_common.h on the event counters).  Pass 2 keeps a window's
 // AcceptReplies as (slot, ballot) in the window itself -- 12 bytes over the >= 13 bytes of the frame they came from, so
 // record j of a window lies wholly below the first unread byte -- and stores them as smr_mp_ack records when the window
 // is done: a lane's records of a window leave back to back and merge in L2 (one 24-byte store per frame as it was parsed
@@ -27,6 +27,9 @@
 namespace smr {
 
 typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef SMR_WI_DIAG
+#define SMR_WI_DIAG 0                            // 1, 2: diagnostic builds (tools/r3z_wi_diag.sh), wrong results on purpose
+#endif
 #ifndef SMR_WI_WIN
 #define SMR_WI_WIN 128                           // 9 KB of LDS per wavefront: 16 blocks per CU; >= 16 + 8 + WI_HOT_MAX
 #endif
@@ -102,9 +105,58 @@ __device__ __forceinline__ uint64_t wi_bytes_at(const uint32_t *col, uint32_t a)
 // length check then fails) and value
 __device__ __forceinline__ void fast_varint(uint64_t x, uint32_t &need, uint32_t &v) {
     const uint32_t b = (uint32_t)x & 0xFF, rest = (uint32_t)(x >> 8);
-    need = b < 251 ? 1u : b == 0xFB ? 3u : b == 0xFC ? 5u : 99u;
-    v = b < 251 ? b : b == 0xFB ? (rest & 0xFFFFu) : rest;
+    const uint32_t t = (b > 250 ? b : 250u) - 250;                   // 0: one byte; 1, 2: 0xFB, 0xFC; 3 .. 5: not this path's
+    need = (0x636363050301ull >> (8 * t)) & 0xFF;                  // 1, 3, 5, 99, 99, 99 (a table in a constant)
+    v = t == 0 ? b : t == 1 ? (rest & 0xFFFFu) : rest;
 }
+
+// One frame as the straight-line path sees it: a payload of 2 .. 24 bytes, all of it in the window, varints below 2^32.
+struct WiFrame {
+    uint32_t plen, kind, adv;                    // payload length (garbage unless the header was looked at), SMR_WIRE_*, 8 + length
+    uint64_t f0, f1, f2, f3;                     // the hot variants' fields
+    bool fast;                                   // this path takes the frame
+    bool slow;                                   // the general reader has to look at it
+    bool fin, nxt;                               // not complete in the stream: my connection is done / needs the next window
+    bool take, ack, hbt, loc;                    // the frame is taken: as an smr_mp_ack / an smr_wire_hb / located by this path (the general reader stores its own)
+    // the frame at window offset wo (0 if !act), r8 = my stream's bytes from there on, less 8 (>= 0)
+    __device__ __forceinline__ void look(const uint32_t *col, uint32_t wo, bool act, int64_t r8) {
+        // the header and the payload's first eight bytes: five dwords of my column, shifted into place
+        const uint32_t hi0 = wo >> 2, hsh = 8 * (wo & 3);
+        const uint32_t d0 = col[hi0 * 64], d1 = col[(hi0 + 1) * 64], d2 = col[(hi0 + 2) * 64], d3 = col[(hi0 + 3) * 64], d4 = col[(hi0 + 4) * 64];
+        const uint32_t Hx = (uint32_t)((((uint64_t)d1 << 32) | d0) >> hsh), Hy = (uint32_t)((((uint64_t)d2 << 32) | d1) >> hsh);
+        const uint32_t Hz = (uint32_t)((((uint64_t)d3 << 32) | d2) >> hsh), Hw = (uint32_t)((((uint64_t)d4 << 32) | d3) >> hsh);
+        const bool big = Hx != 0;                                                   // a length of 2^32 or more: the general reader's
+        plen = __builtin_bswap32(Hy);
+        const uint32_t room = WI_WIN - 8 - wo;
+        const bool whole = act && !big && (int64_t)plen <= r8;
+        fin = act && !big && !whole;                                                // frame not complete yet
+        nxt = whole && (plen < WI_HOT_MAX ? plen : WI_HOT_MAX) > room;              // (after a refill the offset is < 16: always fits)
+        act = act && !fin && !nxt;
+        const uint64_t lo = ((uint64_t)Hw << 32) | Hz;
+        const uint32_t b0 = Hz & 0xFF, b1 = (Hz >> 8) & 0xFF;
+        const bool msg = b0 == 0;
+        const bool isar = msg && b1 == SMR_WIRE_ACCEPT_REPLY, ishb = msg && b1 == SMR_WIRE_HEARTBEAT, iscn = msg && b1 == SMR_WIRE_COMMIT_NOTICE;
+        const bool hot = isar || ishb || iscn;
+        uint32_t k0, k1, k2, k3, v0, v1, v2, v3;                                    // (a varint past the frame reads bytes nobody looks at)
+        fast_varint(lo >> 16, k0, v0);
+        const uint32_t p1 = wo + 10 + k0;
+        fast_varint(wi_bytes_at(col, p1), k1, v1);
+        const uint32_t p2 = p1 + k1;
+        const uint64_t x2 = wi_bytes_at(col, p2);
+        fast_varint(x2, k2, v2);
+        const uint32_t p3 = p2 + k2;
+        fast_varint(wi_bytes_at(col, p3), k3, v3);
+        const uint32_t p4 = p3 + k3;
+        const uint32_t used = (isar ? p2 + 1 : ishb ? p4 : p2) - (wo + 8);
+        fast = act && !big && plen >= 2 && plen <= WI_FAST_MAX && b0 < 251 && (!msg || b1 < 251) &&
+               (!hot || (used == plen && (!isar || (uint8_t)x2 == 0)));
+        slow = act && !fast;
+        take = fast; ack = fast && isar; hbt = fast && hot && !isar; loc = fast && !hot;
+        kind = b0 == 2 ? (uint32_t)SMR_WIRE_LEAVE : msg && b1 <= SMR_WIRE_COMMIT_NOTICE ? b1 : (uint32_t)SMR_WIRE_OTHER;
+        f0 = v0; f1 = v1; f2 = ishb ? v2 : 0u; f3 = ishb ? v3 : 0u;
+        adv = 8 + plen;
+    }
+};
 
 struct IngestArgs {
     const uint8_t *buf; uint64_t buf_len;
@@ -112,7 +164,8 @@ struct IngestArgs {
     smr_mp_ack *acks; uint64_t ack_cap;
     smr_wire_hb *hbs; uint64_t hb_cap;
     smr_wire_other *others; uint64_t other_cap;
-    uint64_t *wave_cnt;                          // [n_waves][3]: counts (pass 1), then exclusive bases (the scan)
+    uint64_t *super;                             // [ceil(n_waves / 64)][3]: the counts of 64 wavefronts together (pass 1, atomics)
+    uint64_t *wave_cnt;                          // [n_waves][3]: a wavefront's counts (pass 1)
     uint32_t *lane_cnt;                          // [n_waves * 64][3]: pass 1's counts per connection
     uint64_t *counts;                            // [4]: acks, heartbeats / commit notices, others, malformed connections
     uint64_t *consumed; int32_t *status;
@@ -130,6 +183,13 @@ __device__ __forceinline__ uint32_t wave_exclusive_sum(uint32_t x, uint32_t lane
     return s - x;
 }
 
+// the sum of a 64-bit x over the wavefront
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) x += __shfl_xor(x, m);
+    return x;
+}
+
 // WRITE = false: count my connection's records, report consumed / status; true: write them at my bases
 template <bool WRITE>
 __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
@@ -138,26 +198,46 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
     const bool live = c < A.n_conn;
     const uint64_t start = live ? A.conn_off[c] : 0, end = live ? A.conn_off[c + 1] : 0;
     const uint32_t group = live ? A.conn_group[c] : 0, peer = live ? A.conn_peer[c] : 0;
-    uint64_t pos = start;
     int st = 0;
     bool done = !live;
     if (live && (end < start || end > A.buf_len)) { st = 1; done = true; }
     uint64_t base0 = 0, base1 = 0, base2 = 0;
-    if (WRITE) {                                  // where my records go: my wavefront's bases + the lanes before me
+    if (WRITE) {
+        // where my records go: the wavefronts before mine -- whole groups of 64 of them out of `super`, the rest of my group
+        // out of their own counts, a row per lane -- and the lanes before me
+        const uint32_t w = blockIdx.x, g0 = w & ~63u;
+        uint64_t s0 = 0, s1 = 0, s2 = 0;
+        for (uint32_t i = lane; i < w / 64; i += 64) { s0 += A.super[i * 3 + 0]; s1 += A.super[i * 3 + 1]; s2 += A.super[i * 3 + 2]; }
+        if (g0 + lane < w) { s0 += A.wave_cnt[(size_t)(g0 + lane) * 3 + 0]; s1 += A.wave_cnt[(size_t)(g0 + lane) * 3 + 1]; s2 += A.wave_cnt[(size_t)(g0 + lane) * 3 + 2]; }
         uint32_t t;
-        base0 = A.wave_cnt[(size_t)blockIdx.x * 3 + 0] + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 0] : 0u, lane, t);
-        base1 = A.wave_cnt[(size_t)blockIdx.x * 3 + 1] + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 1] : 0u, lane, t);
-        base2 = A.wave_cnt[(size_t)blockIdx.x * 3 + 2] + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 2] : 0u, lane, t);
+        base0 = wave_sum64(s0) + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 0] : 0u, lane, t);
+        base1 = wave_sum64(s1) + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 1] : 0u, lane, t);
+        base2 = wave_sum64(s2) + wave_exclusive_sum(live ? A.lane_cnt[(size_t)c * 3 + 2] : 0u, lane, t);
+        if (w == 0) {                             // the call's totals: every group's sum (pass 1 is complete)
+            uint64_t t0 = 0, t1 = 0, t2 = 0;
+            for (uint32_t i = lane; i < (gridDim.x + 63) / 64; i += 64) { t0 += A.super[i * 3 + 0]; t1 += A.super[i * 3 + 1]; t2 += A.super[i * 3 + 2]; }
+            t0 = wave_sum64(t0); t1 = wave_sum64(t1); t2 = wave_sum64(t2);
+            if (lane == 0) { A.counts[0] = t0; A.counts[1] = t1; A.counts[2] = t2; }
+        }
     }
-    uint32_t n0 = 0, n1 = 0, n2 = 0;              // my records so far: acks, heartbeats / commit notices, others
+    uint32_t n0 = 0, n1 = 0, nall = 0;            // my records so far: acks, heartbeats / commit notices, all (the others: the difference)
     uint32_t *const col = &win[lane];
+    // my position: byte woff of the window whose first byte is the stream's byte wlo; r8 = the bytes of my stream from it on, less 8
+    uint64_t wlo = start & ~15ull;
+    uint32_t woff = (uint32_t)(start - wlo);
+    int64_t r8 = done ? -1 : (int64_t)(end - start) - 8;
     for (;;) {
         if (!__ballot(!done)) break;              // wave-uniform: a lane that is done stays to help with the refills
         // ---- refill: every lane's column gets what is left of its stream at its position, at most the window.  The wavefront
         // loads together: WI_WIN / 16 neighbouring lanes take one connection's window, one 16-byte chunk each, so an
         // instruction reads whole runs of WI_WIN contiguous bytes; every chunk's load is issued before the first one is
         // waited for; a chunk that is not wanted, or not whole, reads the buffer's first 16 bytes instead
-        const uint64_t wbase = pos & ~15ull;
+        {
+            const uint64_t pos = wlo + woff;
+            wlo = pos & ~15ull;
+            woff = (uint32_t)(pos - wlo);
+        }
+        const uint64_t wbase = wlo;
         const uint64_t left = done ? 0 : end - wbase;
         const uint32_t nchunk = (uint32_t)(left >= WI_WIN ? WI_WIN / 16 : (left + 15) / 16);
         constexpr uint32_t CPW = WI_WIN / 16, PER = 64 / CPW;                       // lanes per connection; connections per instruction
@@ -198,167 +278,137 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
             }
         }
         __syncthreads();
-        // ---- the frames that lie inside the window -----------------------------------------------------
+        // ---- the frames that lie inside the window, two per turn: the second frame's position needs only the first one's
+        // length, so the two frames' chains of dependent LDS reads (header, then one per varint) run side by side
         bool wait = false;                                                          // my next frame needs the next window
-        uint32_t held = 0;                                                          // pass 2: AcceptReplies of this window kept in my column
+        uint32_t *hp = col;                                                         // pass 2: where the next AcceptReply of this window is kept in my column
         for (;;) {
             bool act = !done && !wait;
-            const uint64_t avail = end - pos, wo64 = pos - wbase;
-            if (act && avail < 8) { done = true; act = false; }                     // length not complete yet
-            if (act && wo64 + 8 > WI_WIN) { wait = true; act = false; }
+            if (act && r8 < 0) { done = true; act = false; }                        // length not complete yet
+            if (act && woff + 8 > WI_WIN) { wait = true; act = false; }
             if (!__ballot(act)) break;
-            const uint32_t woff = act ? (uint32_t)wo64 : 0u;
-            // the header and the payload's first eight bytes: five dwords of my column, shifted into place
-            const uint32_t hi0 = woff >> 2, hsh = 8 * (woff & 3);
-            const uint32_t d0 = col[hi0 * 64], d1 = col[(hi0 + 1) * 64], d2 = col[(hi0 + 2) * 64], d3 = col[(hi0 + 3) * 64], d4 = col[(hi0 + 4) * 64];
-            const uint32_t Hx = (uint32_t)((((uint64_t)d1 << 32) | d0) >> hsh), Hy = (uint32_t)((((uint64_t)d2 << 32) | d1) >> hsh);
-            const uint32_t Hz = (uint32_t)((((uint64_t)d3 << 32) | d2) >> hsh), Hw = (uint32_t)((((uint64_t)d4 << 32) | d3) >> hsh);
-            const bool big = Hx != 0;                                               // a length of 2^32 or more: the general reader's
-            const uint32_t plen = __builtin_bswap32(Hy), room = WI_WIN - 8 - woff;
-            const bool whole = act && !big && (uint64_t)plen <= avail - 8;
-            if (act && !big && !whole) { done = true; act = false; }                // frame not complete yet
-            if (whole && (plen < WI_HOT_MAX ? plen : WI_HOT_MAX) > room) { wait = true; act = false; }   // (after a refill woff < 16: always fits)
-            // ---- the straight-line path: a payload of 2 .. 24 bytes, all of it in the window, varints below 2^32
-            const uint64_t lo = ((uint64_t)Hw << 32) | Hz;
-            const uint32_t b0 = Hz & 0xFF, b1 = (Hz >> 8) & 0xFF;
-            const bool msg = b0 == 0;
-            const bool isar = msg && b1 == SMR_WIRE_ACCEPT_REPLY, ishb = msg && b1 == SMR_WIRE_HEARTBEAT, iscn = msg && b1 == SMR_WIRE_COMMIT_NOTICE;
-            const bool hot = isar || ishb || iscn;
-            uint32_t k0, k1, k2, k3, v0, v1, v2, v3;                                // (a varint past the frame reads bytes nobody looks at)
-            fast_varint(lo >> 16, k0, v0);
-            const uint32_t p1 = woff + 10 + k0;
-            fast_varint(wi_bytes_at(col, p1), k1, v1);
-            const uint32_t p2 = p1 + k1;
-            const uint64_t x2 = wi_bytes_at(col, p2);
-            fast_varint(x2, k2, v2);
-            const uint32_t p3 = p2 + k2;
-            fast_varint(wi_bytes_at(col, p3), k3, v3);
-            const uint32_t p4 = p3 + k3;
-            const uint32_t used = (isar ? p2 + 1 : ishb ? p4 : p2) - (woff + 8);
-            const bool fast = act && !big && plen >= 2 && plen <= WI_FAST_MAX && b0 < 251 && (!msg || b1 < 251) &&
-                              (!hot || (used == plen && (!isar || (uint8_t)x2 == 0)));
-            const bool slow = act && !fast;
-            uint32_t what = isar ? 0u : hot ? 1u : 2u;
-            uint32_t kind = b0 == 2 ? (uint32_t)SMR_WIRE_LEAVE : msg && b1 <= SMR_WIRE_COMMIT_NOTICE ? b1 : (uint32_t)SMR_WIRE_OTHER;
-            uint64_t f0 = v0, f1 = v1, f2 = ishb ? v2 : 0u, f3 = ishb ? v3 : 0u, flen = plen;
-            bool take = fast;
+            WiFrame F[2];
+            F[0].look(col, act ? woff : 0u, act, r8);
+            const uint32_t wo1 = woff + 8 + F[0].plen;
+            const int64_t r81 = r8 - (int64_t)(8 + F[0].plen);
+            const bool act1 = F[0].fast && r81 >= 0 && wo1 + 8 <= WI_WIN;          // (else the next turn looks at it)
+            F[1].look(col, act1 ? wo1 : 0u, act1, r81);
+            done |= F[0].fin || F[1].fin;
+            wait |= F[0].nxt || F[1].nxt;
+            const uint64_t wlo0 = wlo;                                              // (the general reader may step wlo over a very long frame)
+            const bool slow = F[0].slow || F[1].slow;                               // (at most one of them: a second frame is only looked at behind a fast one)
             if (__ballot(slow)) {                                                   // rare: the general reader (smr_wire_decode's rules in full)
                 if (slow) {
-                    ColRd r{col, woff, woff + 8, true};
+                    const bool second = !F[0].slow;
+                    const uint32_t wo = second ? wo1 : woff;
+                    const int64_t rr = second ? r81 : r8;
+                    WiFrame G = second ? F[1] : F[0];
+                    ColRd r{col, wo, wo + 8, true};
                     const uint64_t gl = __builtin_bswap64(r.peek64());
                     r.n += 8;
                     if (gl > 1000000000000ull) { st = 1; done = true; }             // safetcp.rs:56-66
-                    else if (avail - 8 < gl) done = true;                           // frame not complete yet
-                    else if ((uint32_t)(gl < WI_HOT_MAX ? gl : WI_HOT_MAX) > room) wait = true;   // (only a length of 2^32 or more gets here unchecked)
+                    else if ((uint64_t)rr < gl) done = true;                        // frame not complete yet
+                    else if ((uint32_t)(gl < WI_HOT_MAX ? gl : WI_HOT_MAX) > WI_WIN - 8 - wo) wait = true;   // (only a length of 2^32 or more gets here unchecked)
                     else {
                         const uint32_t look = (uint32_t)(gl < WI_HOT_MAX ? gl : WI_HOT_MAX);
-                        r.end = woff + 8 + look;
+                        r.end = wo + 8 + look;
                         uint32_t gk = SMR_WIRE_OTHER;
                         bool gh = false;
                         uint64_t g0 = 0, g1 = 0, g2 = 0, g3 = 0;
                         parse_peer_message(r, gk, gh, g0, g1, g2, g3);
                         // a frame whose leading varints do not parse, or a hot frame that does not end where its length says
-                        if (!r.ok || (gh && (uint64_t)(r.n - (woff + 8)) != gl)) { st = 1; done = true; }
+                        if (!r.ok || (gh && (uint64_t)(r.n - (wo + 8)) != gl)) { st = 1; done = true; }
                         else {
                             // (an AcceptReply for a slot the engine cannot name -- its slots are u32 -- goes the host's way)
-                            what = (gk == SMR_WIRE_ACCEPT_REPLY && g0 <= 0xFFFFFFFFull) ? 0u : (gk == SMR_WIRE_HEARTBEAT || gk == SMR_WIRE_COMMIT_NOTICE) ? 1u : 2u;
-                            kind = gk; f0 = g0; f1 = g1; f2 = g2; f3 = g3; flen = gl;
-                            take = true;
+                            G.ack = gk == SMR_WIRE_ACCEPT_REPLY && g0 <= 0xFFFFFFFFull;
+                            G.hbt = gk == SMR_WIRE_HEARTBEAT || gk == SMR_WIRE_COMMIT_NOTICE;
+                            G.kind = gk; G.f0 = g0; G.f1 = g1; G.f2 = g2; G.f3 = g3;
+                            G.take = true; G.loc = false;
+                            if (WRITE && !G.ack && !G.hbt) {                        // (located: here, where its 64-bit length is at hand)
+                                const uint64_t at = base2 + (nall - n0 - n1) + (second ? (uint32_t)F[0].loc : 0u);
+                                if (at < A.other_cap) {
+                                    smr_wire_other o; o.conn = c; o.kind = gk; o.off = wlo + wo; o.len = 8 + gl;
+                                    A.others[at] = o;
+                                }
+                            }
+                            if (gl > 0x7FFFFFF0u) {                                 // a frame longer than my 32-bit window offset can step over
+                                wlo += 8 + gl; r8 -= (int64_t)(8 + gl); G.adv = 0; wait = true;   // (its end, 16-aligned down at the refill)
+                            } else G.adv = 8 + (uint32_t)gl;
+                        }
+                    }
+                    if (second) F[1] = G; else F[0] = G;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const WiFrame &X = F[u];
+                if (WRITE) {
+                    if (X.ack) {                                                    // kept in the window: three dwords over a frame of >= 13 bytes
+                        hp[0] = (uint32_t)X.f0; hp[64] = (uint32_t)X.f1; hp[128] = (uint32_t)(X.f1 >> 32);
+                        hp += 192;
+                    } else if (X.hbt) {
+                        const uint64_t at = base1 + n1;
+                        if (at < A.hb_cap) {
+                            smr_wire_hb h; h.group = group; h.peer = peer; h.kind = X.kind; h.reserved = 0; h.ballot = X.f0; h.commit_bar = X.f1;
+                            h.exec_bar = X.f2; h.snap_bar = X.f3;
+                            A.hbs[at] = h;
+                        }
+                    } else if (X.loc) {                                             // a short frame the device only locates
+                        const uint64_t at = base2 + (nall - n0 - n1);
+                        if (at < A.other_cap) {
+                            smr_wire_other o; o.conn = c; o.kind = X.kind; o.off = wlo0 + woff; o.len = X.adv;
+                            A.others[at] = o;
                         }
                     }
                 }
+                n0 += X.ack; n1 += X.hbt; nall += X.take;
+                woff += X.take ? X.adv : 0u;
+                r8 -= X.take ? (int64_t)X.adv : 0;
             }
-            if (WRITE) {
-                if (take && what == 0) {                                            // kept in the window: three dwords over a frame of >= 13 bytes
-                    col[(3 * held + 0) * 64] = (uint32_t)f0; col[(3 * held + 1) * 64] = (uint32_t)f1; col[(3 * held + 2) * 64] = (uint32_t)(f1 >> 32);
-                    held++;
-                } else if (take && what == 1) {
-                    const uint64_t at = base1 + n1;
-                    if (at < A.hb_cap) {
-                        smr_wire_hb h; h.group = group; h.peer = peer; h.kind = kind; h.reserved = 0; h.ballot = f0; h.commit_bar = f1;
-                        h.exec_bar = f2; h.snap_bar = f3;
-                        A.hbs[at] = h;
-                    }
-                } else if (take) {
-                    const uint64_t at = base2 + n2;
-                    if (at < A.other_cap) {
-                        smr_wire_other o; o.conn = c; o.kind = kind; o.off = pos; o.len = 8 + flen;
-                        A.others[at] = o;
-                    }
-                }
-            }
-            n0 += take && what == 0; n1 += take && what == 1; n2 += take && what == 2;
-            pos += take ? 8 + flen : 0;
         }
         if (WRITE) {                                                                // this window's AcceptReplies leave, a lane's back to back
+            const uint32_t held = (uint32_t)(hp - col) / 192;
             const uint64_t first = base0 + (n0 - held);
-            for (uint32_t j = 0; __ballot(j < held); j++) {
-                if (j < held && first + j < A.ack_cap) {
-                    smr_mp_ack a; a.group = group; a.slot = col[(3 * j + 0) * 64];
-                    a.ballot = ((uint64_t)col[(3 * j + 2) * 64] << 32) | col[(3 * j + 1) * 64]; a.peer = peer; a.reserved = 0;
-                    A.acks[first + j] = a;
+            const uint32_t fits = first >= A.ack_cap ? 0u : A.ack_cap - first < held ? (uint32_t)(A.ack_cap - first) : held;
+#if SMR_WI_DIAG == 1                                                                // (diagnostic build only: WRONG addresses, 64 lanes' records side by side)
+            smr_mp_ack *dst = A.acks + ((first - (n0 - held)) / 2048 * 2048 + (n0 - held) * 64 + lane) % (A.ack_cap - 704);
+#else
+            smr_mp_ack *dst = A.acks + first;
+#endif
+            const uint32_t *rp = col;
+#if SMR_WI_DIAG == 1
+            for (uint32_t j = 0; __ballot(j < fits); j++, dst += 64, rp += 192) {
+#else
+            for (uint32_t j = 0; __ballot(j < fits); j++, dst++, rp += 192) {
+#endif
+                if (j < fits) {
+                    smr_mp_ack a; a.group = group; a.slot = rp[0]; a.ballot = ((uint64_t)rp[128] << 32) | rp[64]; a.peer = peer; a.reserved = 0;
+#if SMR_WI_DIAG == 2                                                                // (diagnostic build only: no record leaves)
+                    if (a.slot == 0xFFFFFFF1u && a.ballot == 77) *dst = a;
+#else
+                    *dst = a;
+#endif
                 }
             }
         }
     }
     if (!WRITE) {
         if (live) {
-            A.consumed[c] = pos - start; A.status[c] = st;
-            A.lane_cnt[(size_t)c * 3 + 0] = n0; A.lane_cnt[(size_t)c * 3 + 1] = n1; A.lane_cnt[(size_t)c * 3 + 2] = n2;
+            A.consumed[c] = wlo + woff - start; A.status[c] = st;
+            A.lane_cnt[(size_t)c * 3 + 0] = n0; A.lane_cnt[(size_t)c * 3 + 1] = n1; A.lane_cnt[(size_t)c * 3 + 2] = nall - n0 - n1;
         }
         uint32_t t0, t1, t2;
-        (void)wave_exclusive_sum(n0, lane, t0); (void)wave_exclusive_sum(n1, lane, t1); (void)wave_exclusive_sum(n2, lane, t2);
+        (void)wave_exclusive_sum(n0, lane, t0); (void)wave_exclusive_sum(n1, lane, t1); (void)wave_exclusive_sum(nall - n0 - n1, lane, t2);
         const unsigned long long bad = __ballot(st != 0);
         if (lane == 0) {
             A.wave_cnt[(size_t)blockIdx.x * 3 + 0] = t0; A.wave_cnt[(size_t)blockIdx.x * 3 + 1] = t1; A.wave_cnt[(size_t)blockIdx.x * 3 + 2] = t2;
+            // my group's sums: three atomics per wavefront on one of n_waves / 64 rows (64 wavefronts per address, not all of them)
+            atomicAdd((unsigned long long *)&A.super[(blockIdx.x / 64) * 3 + 0], (unsigned long long)t0);
+            atomicAdd((unsigned long long *)&A.super[(blockIdx.x / 64) * 3 + 1], (unsigned long long)t1);
+            atomicAdd((unsigned long long *)&A.super[(blockIdx.x / 64) * 3 + 2], (unsigned long long)t2);
             if (bad) atomicAdd((unsigned long long *)&A.counts[3], (unsigned long long)__popcll(bad));
         }
     }
-}
-
-// the wavefronts' counts -> exclusive bases, totals into counts[0 .. 3): one block, 256 lanes, a chunk of rows per lane
-__global__ __launch_bounds__(256) void wire_ingest_scan_kernel(uint64_t *__restrict__ wave_cnt, uint32_t n_waves, uint64_t *__restrict__ counts) {
-    __shared__ uint64_t part[3][256];
-    const uint32_t t = threadIdx.x, per = (n_waves + 255) / 256;
-    const uint32_t lo = t * per < n_waves ? t * per : n_waves, hi = lo + per < n_waves ? lo + per : n_waves;
-    uint64_t s[3] = {0, 0, 0};
-    for (uint32_t w0 = lo; w0 < hi; w0 += 8) {                                      // eight rows' loads in flight together
-        uint64_t x[8][3];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) x[j][k] = wave_cnt[(size_t)(w0 + j < hi ? w0 + j : lo) * 3 + k];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) s[k] += w0 + j < hi ? x[j][k] : 0;
-    }
-    for (int k = 0; k < 3; k++) part[k][t] = s[k];
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {                                  // inclusive scan of the 256 partial sums
-        uint64_t v[3] = {0, 0, 0};
-        if (t >= off) for (int k = 0; k < 3; k++) v[k] = part[k][t - off];
-        __syncthreads();
-        if (t >= off) for (int k = 0; k < 3; k++) part[k][t] += v[k];
-        __syncthreads();
-    }
-    uint64_t b[3];
-    for (int k = 0; k < 3; k++) b[k] = part[k][t] - s[k];                           // exclusive
-    for (uint32_t w0 = lo; w0 < hi; w0 += 8) {
-        uint64_t x[8][3];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++)
-#pragma unroll
-            for (int k = 0; k < 3; k++) x[j][k] = wave_cnt[(size_t)(w0 + j < hi ? w0 + j : lo) * 3 + k];
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            if (w0 + j < hi) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) { wave_cnt[(size_t)(w0 + j) * 3 + k] = b[k]; b[k] += x[j][k]; }
-            }
-        }
-    }
-    if (t == 255) for (int k = 0; k < 3; k++) counts[k] = b[k] ;
 }
 
 }  // namespace smr
@@ -368,8 +418,8 @@ using namespace smr;
 extern "C" {
 
 uint64_t smr_wire_ingest_scratch_bytes(uint32_t n_conn) {
-    const uint64_t n_waves = ((uint64_t)n_conn + 63) / 64;
-    return n_waves * 3 * 8 + n_waves * 64 * 3 * 4;
+    const uint64_t n_waves = ((uint64_t)n_conn + 63) / 64, n_super = (n_waves + 63) / 64;
+    return n_super * 3 * 8 + n_waves * 3 * 8 + n_waves * 64 * 3 * 4;
 }
 
 int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
@@ -384,12 +434,12 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
     hipStream_t st = (hipStream_t)stream;
     SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
     if (n_conn == 0) return SMR_OK;
-    const uint32_t n_waves = (n_conn + 63) / 64;
+    const uint32_t n_waves = (n_conn + 63) / 64, n_super = (n_waves + 63) / 64;
+    uint64_t *super = (uint64_t *)scratch_dev, *wave_cnt = super + (size_t)n_super * 3;
+    SMR_HIP_TRY(hipMemsetAsync(super, 0, (size_t)n_super * 3 * 8, st));
     IngestArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, acks_dev, ack_cap, hbs_dev, hb_cap,
-                 others_dev, other_cap, (uint64_t *)scratch_dev, (uint32_t *)((uint64_t *)scratch_dev + (size_t)n_waves * 3),
-                 counts_dev, consumed_dev, status_dev};
+                 others_dev, other_cap, super, wave_cnt, (uint32_t *)(wave_cnt + (size_t)n_waves * 3), counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_mp_kernel<false>, dim3(n_waves), dim3(64), 0, st, A);
-    hipLaunchKernelGGL(wire_ingest_scan_kernel, dim3(1), dim3(256), 0, st, A.wave_cnt, n_waves, counts_dev);
     hipLaunchKernelGGL(wire_ingest_mp_kernel<true>, dim3(n_waves), dim3(64), 0, st, A);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
