@@ -862,6 +862,37 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
                          "avg_launch_us": us, "traffic": None}}
 
 
+def reply_ingest_leg(torch, dev, G=65536, R=5, iters=12, junk_every=16):
+    """The Raft leader's receive side of one tick on the device (csrc/wire_ingest_replies.hip): one connection per (group, follower),
+    each with one AppendEntriesReply frame (a conflict on every eighth, a RequestVoteReply in front of every sixteenth) -> the
+    [R][G] arrays `smr_raft_leader_handle_replies` takes.  A launch-bound call: ~17 bytes per connection."""
+    from summerset_amd import wire
+    n_conn = G * (R - 1)
+    ok = np.frombuffer(wire.raft_append_entries_reply(3, 70000), np.uint8)
+    conf = np.frombuffer(wire.raft_append_entries_reply(3, 70000, (2, 69000)), np.uint8)
+    vote = np.frombuffer(wire.raft_request_vote_reply(3, False), np.uint8)
+    parts = [np.concatenate(([vote] if junk_every and c % junk_every == 0 else []) + [conf if c % 8 == 0 else ok]) for c in range(16)]
+    lens = np.tile(np.array([len(x) for x in parts], np.int64), n_conn // 16)
+    off = np.zeros(n_conn + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    buf = torch.from_numpy(np.tile(np.concatenate(parts), n_conn // 16)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_grp = torch.from_numpy((np.arange(n_conn) // (R - 1)).astype(np.int32)).to(dev)
+    d_peer = torch.from_numpy((1 + np.arange(n_conn) % (R - 1)).astype(np.uint8)).to(dev)
+    ing = wire.ReplyIngest(n_conn, G, R, n_conn, dev)
+    o = ing.raft(buf, d_off, d_grp, d_peer)
+    r = ing.results()
+    assert r["n_replies"] == n_conn and r["n_others"] == (n_conn // junk_every if junk_every else 0) and r["n_malformed"] == 0 and (r["consumed"] == lens).all()
+    assert int(o["flags"][1:].sum().item()) == n_conn + 2 * (n_conn // 8) and int(o["end_slot"][1, 5].item()) == 70000
+    us = _time_us(torch, lambda i: ing.raft(buf, d_off, d_grp, d_peer), iters)
+    alg = int(off[-1]) + n_conn * (8 + 4 + 1) + (n_conn // 8) * 12
+    return {"workload": "Raft leader-side receive path of one tick: %d connections (%d groups x %d followers), one AppendEntriesReply each -> the "
+                        "[R][G] reply arrays" % (n_conn, G, R - 1), "value": n_conn / (us * 1e-6), "unit": "AppendEntriesReply frames/s", "call_us": us,
+            "roofline": {"bound": "hbm", "kernel": "wire_ingest_replies_kernel<0> (+ two memsets: one smr_wire_ingest_raft_replies call)",
+                         "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us, "traffic": None}}
+
+
 def _cpu_run(a):
     """one process, one thread: the CPU oracle on G groups of the bench workload for about `seconds`"""
     slots, window, drop, timeouts, hb_every, G, seconds = a
@@ -1208,7 +1239,7 @@ def main():
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
         legs = {"rspaxos": rspaxos_leg, "epaxos_cluster": epaxos_cluster_leg, "epaxos_execution": epaxos_exec_leg, "rspaxos_replica": rspaxos_replica_leg,
-                "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg, "wire_ingest": wire_ingest_leg}
+                "craft_leader": craft_leader_leg, "quorum_read": quorum_read_leg, "wire_ingest": wire_ingest_leg, "reply_ingest": reply_ingest_leg}
         print(json.dumps(legs[args.leg](torch, torch.device("cuda", local))))
         return
     if not torch.cuda.is_available():
@@ -1438,6 +1469,7 @@ def main():
             leg("rspaxos", leg_isolated, "rspaxos")
             leg("repnothing", repnothing_leg)
             leg("wire_ingest", leg_isolated, "wire_ingest")
+            leg("reply_ingest", leg_isolated, "reply_ingest")
             if args.late_legs:
                 leg("epaxos_execution", leg_isolated, "epaxos_execution")
                 leg("rspaxos_replica", leg_isolated, "rspaxos_replica")

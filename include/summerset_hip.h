@@ -990,6 +990,38 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
                        uint64_t hb_cap, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev, uint64_t *consumed_dev,
                        int32_t *status_dev, void *scratch_dev, void *stream);
 
+/* ---- Raft / EPaxos reply traffic parsed on the device (round 3; csrc/wire_ingest_replies.hip).  The Raft leader and the
+ * EPaxos command leader take ONE reply per (peer, group) and call, as arrays [R][G]: these calls fill those arrays from the
+ * bytes the leader's connections delivered -- connection c = the stream from peer conn_peer[c] (< population) of group
+ * conn_group[c] (< n_groups), frames `[u64 BE length][bincode(PeerMessage)]` back to back in
+ * buf_dev[conn_off[c] .. conn_off[c + 1]), the last one possibly incomplete.  Per connection, in stream order: the FIRST
+ *   Raft    PeerMsg::AppendEntriesReply { term, end_slot, conflict }   (raft/mod.rs:203-234; what the follower's
+ *           handle_msg_append_entries sends, raft/messages.rs:128-240)
+ *   EPaxos  PeerMsg::PreAcceptReply { slot, ballot, seq, deps } for MY instance slot == (me, col_dev[group]) with
+ *           `population` dependencies (epaxos/mod.rs:306-377; messages.rs:81-88)
+ * is written at [peer][group] of the arrays smr_raft_leader_handle_replies / smr_raft_tick resp.
+ * smr_ep_handle_pre_accept_replies take (flags bit0 = present, Raft bit1 = `conflict` is Some; deps [R][R][G] = (peer, dep
+ * row, group)); the walk STOPS in front of a second one (consumed_dev[c] = where the next call's stream starts;
+ * counts_dev[3] counts such connections).  Every other complete frame -- and a reply the arrays cannot hold: a slot
+ * beyond u32, a PreAcceptReply for another instance -- is located for the host in others_dev (in no particular order;
+ * counts_dev[1] = their number, those past other_cap are counted, not stored).  A frame that breaks the host decoder's
+ * rules (smr_wire_raft_decode / smr_wire_ep_decode: a length above 10^12, an unknown Raft variant, a reply that does not
+ * end where its length says) makes its connection malformed: status_dev[c] = 1, consumed_dev[c] = 0, nothing of it
+ * counts (a reply it delivered before stays in the arrays); counts_dev[2] = such connections.  counts_dev[0] = the
+ * replies taken.  flags_dev is zeroed by the call; the other arrays are only written where flags says so.  Two connections
+ * with the same (group, peer): the caller's error (one of them wins).  buf_dev must be 16-byte aligned.  Only enqueues work
+ * on `stream`. */
+int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                                 const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population,
+                                 uint64_t *reply_term_dev, uint32_t *end_slot_dev, uint64_t *conflict_term_dev, uint32_t *conflict_slot_dev,
+                                 uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
+                                 uint64_t *consumed_dev, int32_t *status_dev, void *stream);
+int smr_wire_ingest_ep_pre_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                                          const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint8_t me,
+                                          const uint32_t *col_dev, uint64_t *ballot_dev, uint64_t *seq_dev, uint32_t *deps_dev,
+                                          uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
+                                          uint64_t *consumed_dev, int32_t *status_dev, void *stream);
+
 /* ---- request batching front-end (host only; src/server/external.rs:323-344 get_req_batch, :697-730 the batch
  * ticker): requests queue per group; one tick turns, for every group with queued requests, up to max_batch_size
  * of them (0 = all) into one ReqBatch, FIFO; groups with an empty queue get no batch. */

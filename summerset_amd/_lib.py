@@ -339,6 +339,9 @@ SYMBOLS = [
     ("smr_wire_ep_decode", C.c_int64, [_vp, _u64, C.POINTER(WireEpMsg), _vp, _u32]),
     ("smr_wire_ingest_scratch_bytes", _u64, [_u32]),
     ("smr_wire_ingest_mp", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_wire_ingest_raft_replies", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("smr_wire_ingest_ep_pre_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u8, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp,
+                                                   _vp]),
     ("smr_batcher_create", _i, [_u32, _u32, C.POINTER(_vp)]),
     ("smr_batcher_destroy", None, [_vp]),
     ("smr_batcher_submit", _i, [_vp, _u32, _u64, _u64, _u8, C.c_char_p, _u32, C.c_char_p, _u32]),

@@ -435,3 +435,56 @@ class MpIngest:
                 "acks": cut(self.acks, ACK_DTYPE, n[0], self.caps[0]), "hbs": cut(self.hbs, HB_DTYPE, n[1], self.caps[1]),
                 "others": cut(self.others, OTHER_DTYPE, n[2], self.caps[2]),
                 "consumed": self.consumed.cpu().numpy()[:self.n_conn].copy(), "status": self.status.cpu().numpy()[:self.n_conn].copy()}
+
+
+# ---- Raft / EPaxos reply traffic parsed on the device (csrc/wire_ingest_replies.hip) ----
+class ReplyIngest:
+    """One reply per (peer, group) and call out of the bytes the leader's connections delivered, straight into the arrays
+    the engines take: `raft(...)` -> dict(reply_term, end_slot, conflict_term, conflict_slot, flags) [R, G] for
+    `RaftLeaderGroup.handle_msg_append_entries_reply` / `run_ticks`; `ep_pre_accept(...)` -> dict(ballot, seq, deps
+    [R, R, G], flags) for `EPaxosReplicaGroup.handle_pre_accept_replies`.  Tensors are allocated once and reused; other
+    frames are located in `others` (OTHER_DTYPE, unordered)."""
+
+    def __init__(self, n_conn, n_groups, population, other_cap, device):
+        import torch
+        self._L, self.n_conn, self.G, self.R, self.device = _lib.load(), int(n_conn), int(n_groups), int(population), device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)   # noqa: E731
+        R, G = self.R, self.G
+        self.u64a, self.u64b = z((R, G), torch.int64), z((R, G), torch.int64)
+        self.u32a, self.deps = z((R, G), torch.int32), z((R, R, G), torch.int32)
+        self.u32b = z((R, G), torch.int32)
+        self.flags = z((R, G), torch.uint8)
+        self.others = z(max(other_cap, 1) * OTHER_DTYPE.itemsize, torch.uint8)
+        self.other_cap = int(other_cap)
+        self.counts = z(4, torch.int64)
+        self.consumed = z(max(self.n_conn, 1), torch.int64)
+        self.status = z(max(self.n_conn, 1), torch.int32)
+
+    def _conn(self, buf, conn_off, conn_group, conn_peer):
+        assert conn_off.numel() == self.n_conn + 1 and conn_group.numel() == self.n_conn and conn_peer.numel() == self.n_conn
+        assert conn_off.element_size() == 8 and conn_group.element_size() == 4 and conn_peer.element_size() == 1
+        p = lambda t: t.data_ptr()   # noqa: E731
+        return (p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_group), p(conn_peer), self.n_conn, self.G, self.R)
+
+    def raft(self, buf, conn_off, conn_group, conn_peer, stream=None):
+        p = lambda t: t.data_ptr()   # noqa: E731
+        check(self._L.smr_wire_ingest_raft_replies(*self._conn(buf, conn_off, conn_group, conn_peer), p(self.u64a), p(self.u32a), p(self.u64b),
+                                                   p(self.u32b), p(self.flags), p(self.others), self.other_cap, p(self.counts),
+                                                   p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
+        return dict(reply_term=self.u64a, end_slot=self.u32a, conflict_term=self.u64b, conflict_slot=self.u32b, flags=self.flags)
+
+    def ep_pre_accept(self, buf, conn_off, conn_group, conn_peer, me, col, stream=None):
+        """col: int32 / uint32 [G] on the device -- the column of MY instance every group's replies are for"""
+        p = lambda t: t.data_ptr()   # noqa: E731
+        assert col.numel() == self.G and col.element_size() == 4
+        check(self._L.smr_wire_ingest_ep_pre_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer), int(me), p(col), p(self.u64a),
+                                                            p(self.u64b), p(self.deps), p(self.flags), p(self.others), self.other_cap,
+                                                            p(self.counts), p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
+        return dict(ballot=self.u64a, seq=self.u64b, deps=self.deps, flags=self.flags)
+
+    def results(self):
+        """host copies (synchronises): counts, located frames, consumed, status"""
+        n = [int(x) for x in self.counts.cpu().tolist()]
+        return {"n_replies": n[0], "n_others": n[1], "n_malformed": n[2], "n_deferred": n[3],
+                "others": self.others.cpu().numpy().view(OTHER_DTYPE)[:min(n[1], self.other_cap)].copy(),
+                "consumed": self.consumed.cpu().numpy()[:self.n_conn].copy(), "status": self.status.cpu().numpy()[:self.n_conn].copy()}

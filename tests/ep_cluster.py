@@ -106,9 +106,11 @@ class NumpyEngine:
         return g[k], r[k], c[k]
 
 
-def tick(reps, keys, drop=None):
+def tick(reps, keys, drop=None, via=None):
     """reps[r]: backend of replica r; keys[r][G]: proposal of replica r (0xFF none);
     drop[(s, q)] (optional): bool [G] -- the PreAccept from s to q is lost (with its reply).
+    via (optional): via(s, col, ballot, seq, deps, flags) -> (ballot, seq, deps, flags) -- the PreAcceptReplies on their way
+    to command leader s (tests/test_zz_reply_ingest_gpu.py sends them as frames through the device parser).
     Returns per-leader decisions."""
     R = len(reps)
     G = keys.shape[1]
@@ -135,6 +137,8 @@ def tick(reps, keys, drop=None):
                 continue
             r_ = rep[(q, s)]
             flags[q] = r_["flags"]; ballot[q] = r_["ballot"]; seq[q] = r_["seq"]; deps[q] = r_["deps"]
+        if via is not None:
+            ballot, seq, deps, flags = via(s, pa[s]["col"], ballot, seq, deps, flags)
         dec = reps[s].handle_pre_accept_replies(pa[s]["col"], ballot, seq, deps, flags)
         # slow path: Accept round for the instances that went Accepting
         slow = (dec["decision"] == 2).astype(np.uint8)

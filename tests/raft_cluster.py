@@ -66,9 +66,11 @@ class NumpyRaft:
         return self.e.dump_votes()
 
 
-def tick(reps, timeouts, n_new, K):
+def tick(reps, timeouts, n_new, K, via=None):
     """timeouts[r][G]: HearTimeout source at replica r (0xFF none); n_new[r][G]: client batches handed to
-    replica r (those that do not lead redirect them).  Returns nothing; state lives in the replicas."""
+    replica r (those that do not lead redirect them).  Returns nothing; state lives in the replicas.
+    via (optional): via(s, rt, es, fl, ct, cs) -> the same five [R][G] arrays -- the AppendEntriesReplies on their way to
+    leader s (tests/test_zz_reply_ingest_gpu.py sends them as frames through the device parser)."""
     R = len(reps)
     G = timeouts.shape[1]
     u8 = lambda v: np.full(G, v, np.uint8)
@@ -104,4 +106,6 @@ def tick(reps, timeouts, n_new, K):
                 continue
             r_ = rep[(q, s)]
             rt[q] = r_["term"]; es[q] = r_["end_slot"]; fl[q] = r_["flags"]; ct[q] = r_["conflict_term"]; cs[q] = r_["conflict_slot"]
+        if via is not None:
+            rt, es, fl, ct, cs = via(s, rt, es, fl, ct, cs)
         reps[s].handle_replies(rt, es, fl, ct, cs)

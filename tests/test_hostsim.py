@@ -151,6 +151,17 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")
 
 
+def test_reply_ingest_kernels_on_the_host(sim, oracle):
+    """Raft AppendEntriesReply / EPaxos PreAcceptReply frames parsed into the engines' [R][G] arrays (f.1, round 3): frame by
+    frame against what the test wrote, and inside the closed-loop clusters against the oracles"""
+    import test_zz_reply_ingest_gpu as t
+    with sim.patched():
+        t.test_raft_replies_frame_by_frame("cpu")
+        t.test_ep_pre_accept_replies_frame_by_frame("cpu")
+        t.test_raft_cluster_replies_over_the_wire("cpu", oracle)
+        t.test_ep_cluster_pre_accept_replies_over_the_wire("cpu", oracle)
+
+
 def test_rs_kernels_on_the_host(sim, oracle):
     import test_rs_gpu as t
     with sim.patched():
