@@ -340,11 +340,24 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
     # the same loop as ONE C-ABI call per tick (smr_ep_cluster_tick): as ONE launch -- a block is the five replicas of 64 groups, the
     # handlers are steps of that kernel -- and (`per_handler_launches`, round 2's path) as the handler kernels launched back to
     # back by the library.  Own replicas each; the tick's output arrays are the caller's and are reused.
+    # ... and (`phase_major`) with the command leaders' steps PHASE BY PHASE instead of leader by leader: another legal delivery
+    # order of the same messages, in which all five replicas of a group work in every step of the kernel.  Its reference is the
+    # Python loop run in that order on a fresh set of replicas (same decisions and commits as the default order; the
+    # executors' attempt order differs, so their counters may).
     del reps
-    for name, per_handler in (("one_call_per_tick", False), ("one_call_per_tick_per_handler_launches", True)):
+    reps_pm = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=EXEC) for r in range(R)]
+    committed_pm = torch.zeros((), dtype=torch.int64, device=dev)
+    for t in range(ticks + 2):
+        for o in ep_cluster.tick(reps_pm, keys[t], phase_major=True):
+            if t >= 2:
+                committed_pm += o["committed"].sum()
+    ex_pm = sum(int(r.exec_dump()["counters"][0]) for r in reps_pm) if EXEC else 0
+    del reps_pm
+    for name, per_handler, pm in (("one_call_per_tick", False, False), ("one_call_per_tick_per_handler_launches", True, False),
+                                  ("one_call_per_tick_phase_by_phase", False, True)):
         try:
             reps2 = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=EXEC) for r in range(R)]
-            fused = ep_cluster.EPaxosCluster(reps2, per_handler_launches=per_handler)
+            fused = ep_cluster.EPaxosCluster(reps2, per_handler_launches=per_handler, phase_major=pm)
             outs = fused.new_outputs(dev)
             for t in range(2):
                 fused.tick(keys[t], out=outs)
@@ -364,8 +377,11 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
             leg = {"entry_point": "smr_ep_cluster_tick", "launches_per_tick": 115 if per_handler else 1,
                    "value": n_inst / dt2, "unit": "instances committed/s", "ms_per_tick": dt2 / ticks * 1e3,
                    "tick_us_device_median": tick_us[len(tick_us) // 2], "tick_us_device_min": tick_us[0],
-                   "same_commits_as_the_driver_loop": n_inst == int(committed.item()),
+                   "same_commits_as_the_driver_loop": n_inst == int((committed_pm if pm else committed).item()),
                    "commands_executed": sum(int(r.exec_dump()["counters"][0]) for r in reps2) if EXEC else 0}
+            if pm:
+                leg["order"] = "the leaders' steps phase by phase (smr_ep_cluster_set_mode bit 1); reference = ep_cluster.tick(.., phase_major=True)"
+                leg["same_commands_executed_as_the_driver_loop"] = leg["commands_executed"] == ex_pm
             if not per_handler:
                 # <= 370 B per instance for the tally (replies read, instance read / written); the tick as a whole
                 # -- proposals, 4 PreAccepts, the tally, 4 CommitNotices, execution per instance -- has no per-unit figure there,

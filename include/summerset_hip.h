@@ -644,7 +644,14 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
  * the handlers run as steps of one kernel, messages cross wavefronts behind block barriers, execution runs behind its handler
  * on the same lane.  1: one launch per handler and (replica, sender) pair, the kernels of the per-handler entry points back to
  * back (round 2's path: 115 launches per tick at R = 5 with execution on); kept as the decomposition the one-launch tick is
- * checked against and timed beside.  Both are the handler-by-handler loop bit for bit. */
+ * checked against and timed beside.  Both are the handler-by-handler loop bit for bit.
+ * Bit 1 of `mode` (2: one launch, 3: launch by launch) orders the command leaders' part of the tick PHASE BY PHASE -- every
+ * leader's PreAcceptReplies, then every Accept round, every AcceptReply tally, every CommitNotice (an acceptor still takes the
+ * senders in ascending order) -- instead of leader by leader: another legal delivery order of the same messages
+ * (epaxos/messages.rs handles them one at a time in whatever order the transport delivers), in which all R replicas of a group
+ * work in every step of the one-launch kernel.  Same commits and decisions; with execution on, the executors' attempt order (and
+ * with it the counters of abandoned attempts) differs from modes 0 / 1.  The loops `ep_cluster.tick(.., phase_major=True)` and
+ * tests/ep_cluster.py run that order for the engines and for the oracle. */
 int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode);
 
 /* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with

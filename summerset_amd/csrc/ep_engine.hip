@@ -1516,6 +1516,7 @@ __device__ __forceinline__ void ep_shift(EpExec &x, int64_t d) {
 template <int NR>
 struct EpClusterArgs {
     uint32_t R, G, execute, quiet;               // quiet: handlers that can move no commit bar skip the execution pass (no recovery)
+    uint32_t phase_major;                        // the leaders' steps in the order (phase, leader) instead of (leader, phase): see the kernel
     // The replicas of a cluster are created alike, so their arenas have ONE layout: replica q's arrays are replica 0's, `delta[q]`
     // bytes further on.  A wavefront builds its view from v0 / x0 with a handful of scalar adds and keeps it in SGPRs; indexing an
     // array of R views by the wavefront's number made every pointer a scalar LOAD from the kernel arguments wherever the
@@ -1535,15 +1536,25 @@ struct EpClusterArgs {
 };
 
 #ifndef EPC_WAVES_PER_EU
-#define EPC_WAVES_PER_EU 2                   // one 5-wavefront block per CU and no spills.  Measured with per-step stamps (profiles/r3r): at 168
-                                             // VGPRs (3 per SIMD) the hardware still ran ONE block per CU; at 128 / 96 two / three blocks share a CU but
-                                             // each runs 1.7-4x longer (spills + contention) -- the tick is a chain of dependent steps, not a throughput job
+#define EPC_WAVES_PER_EU 3                   // 168 VGPRs (147 spilled, 320 B of scratch per lane) with EPC_SETS 2: see there.  Round 3's first setting was 2
+                                             // (250 VGPRs, no spills, one 5-wavefront block per CU).  Measured with per-step stamps (profiles/r3r): at 168
+                                             // VGPRs the hardware still ran ONE 5-wavefront block per CU; at 128 / 96 two / three blocks share a CU but each
+                                             // runs 1.7-4x longer (spills + contention)
 #endif
+#ifndef EPC_SETS
+#define EPC_SETS 2                           // sets of 64 groups per block (R <= 5): a block = EPC_SETS x R wavefronts.  Five wavefronts on a CU's four
+                                             // SIMDs leave one SIMD with two of them; ten spread 3 / 3 / 2 / 2.  profiles/r4i, r4k: the default order
+                                             // 1078 -> 1058 us per tick, phase by phase 766 -> 711 us (the kernel is bound by instruction issue per SIMD:
+                                             // two blocks' worth of wavefronts on a CU took exactly as long as one after the other)
+#endif
+template <int NR> constexpr int epc_sets() { return NR <= 5 ? EPC_SETS : 1; }   // (16 wavefronts of the 8-replica instance would have to fit 128 VGPRs)
 template <int NR, bool RECOVERY>
-__global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
-    __shared__ uint32_t sh_slow;
-    const uint32_t q = SMR_WAVE_UNIFORM(threadIdx.x >> 6), R = a.R, G = a.G;
-    const uint32_t g0 = blockIdx.x * 64u + (threadIdx.x & 63u);
+__global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
+    constexpr int SETS = epc_sets<NR>();
+    __shared__ uint32_t sh_slow[SETS * NR];                                  // [set][leader]: some group of the set took leader s's slow path
+    const uint32_t R = a.R, G = a.G;
+    const uint32_t wv = SMR_WAVE_UNIFORM(threadIdx.x >> 6), set = wv / R, q = wv - set * R;
+    const uint32_t g0 = (blockIdx.x * SETS + set) * 64u + (threadIdx.x & 63u);
     const bool live = g0 < G;
     const uint32_t g = live ? g0 : 0u;
     EpView v = a.v0;
@@ -1563,7 +1574,7 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
         bool have_h = false;
         uint32_t h_row = 0, h_col = 0;
 #ifdef EPC_STAMPS
-        if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
+        if ((threadIdx.x & 63u) == 0 && set == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
             a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + t] = wall_clock64();
 #endif
         if (t == 0) {                                                        // every replica proposes
@@ -1592,7 +1603,16 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
                 handled = true;
             }
         } else {
-            const uint32_t s = (t - 1u - R) >> 2, ph = (t - 1u - R) & 3u;
+            // The command leaders' part of the tick is R x 4 steps: (leader s, phase): its PreAcceptReplies, the Accept round where
+            // it went slow, its AcceptReplies, its CommitNotices.  Default order: leader by leader, as the handler-by-handler loops
+            // (ep_cluster.tick, tests/ep_cluster.py) run them -- one wavefront of five works in a leader's own phases.
+            // phase_major: phase by phase -- every leader's replies (all five wavefronts at once, each on its own instance), then
+            // every Accept, every AcceptReply tally, every CommitNotice (an acceptor takes the senders in ascending order, as
+            // before); barriers only between the phases.  A different, equally legal delivery order (the loops run it with
+            // phase_major=True; the oracle cluster likewise), not bit-identical to the default one where execution is on: which
+            // instances are committed at a replica when it tries to execute another one differs.
+            const uint32_t u = t - 1u - R;
+            const uint32_t s = a.phase_major ? u % R : u >> 2, ph = a.phase_major ? u / R : u & 3u;
             const smr_ep_cluster_out &o = a.out[s];
             if (ph == 0) {                                                   // leader s: its PreAcceptReplies, peers ascending
                 if (q == s) {
@@ -1618,11 +1638,14 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
                         handled = true; can_commit = true;
                     }
                     const int any_slow = __any(dec == EST_ACCEPTING);
-                    if ((threadIdx.x & 63u) == 0) sh_slow = any_slow ? 1u : 0u;
+                    if ((threadIdx.x & 63u) == 0) sh_slow[set * NR + s] = any_slow ? 1u : 0u;
                 }
+                if (a.phase_major) barrier = s == R - 1u;
             } else if (ph == 1) {                                            // the Accept round, where leader s took the slow path
-                slow_round = sh_slow != 0;                                   // (block-uniform: read behind the barrier of ph 0)
+                slow_round = sh_slow[set * NR + s] != 0;                     // (uniform over my set's wavefronts: read behind the barrier of ph 0)
                 barrier = slow_round;
+                for (uint32_t k = 0; k < (uint32_t)SETS; k++) barrier = barrier || sh_slow[k * NR + s] != 0;   // (the block's sets meet at the same barriers)
+                if (a.phase_major) barrier = s == R - 1u;
                 if (slow_round && q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
                     ep_acceptor_lane<1, NR, RECOVERY>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
@@ -1631,6 +1654,7 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
                     handled = true;
                 }
             } else if (ph == 2) {                                            // leader s: the AcceptReplies, then what is committed
+                if (a.phase_major) { slow_round = sh_slow[set * NR + s] != 0; barrier = s == R - 1u; }
                 if (q == s && live) {
                     const bool acc = slow_round && ep_accept_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G,
                                                                                nullptr, (uint64_t)(s + 1u));
@@ -1653,7 +1677,7 @@ __global__ __launch_bounds__(NR * 64, (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_
     }
     if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
 #ifdef EPC_STAMPS
-    if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
+    if ((threadIdx.x & 63u) == 0 && set == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u)
         a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + n_steps] = wall_clock64();
 #endif
     L.flush();
@@ -2081,7 +2105,7 @@ void smr_ep_cluster_destroy(smr_ep_cluster *c) {
 
 int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode) {
     if (!c) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
-    if (mode > 1) return fail(SMR_ERR_ARG, "epaxos cluster: mode must be 0 (one launch per tick) or 1 (one launch per handler)");
+    if (mode > 3) return fail(SMR_ERR_ARG, "epaxos cluster: mode must be 0 .. 3 (bit 0: one launch per handler, bit 1: the leaders' steps phase by phase)");
     c->mode = mode;
     return SMR_OK;
 }
@@ -2095,6 +2119,7 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
     EpClusterArgs<NR> a;
     memset(&a, 0, sizeof(a));
     a.R = R; a.G = G; a.execute = c->rep[0]->cfg.execute; a.quiet = !c->rep[0]->cfg.recovery;
+    a.phase_major = (c->mode >> 1) & 1u;
     a.v0 = c->rep[0]->v; a.x0 = c->rep[0]->x;
     for (uint32_t r = 0; r < R; r++) {
         a.delta[r] = (int64_t)(c->rep[r]->arena.base - c->rep[0]->arena.base);
@@ -2114,9 +2139,11 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
     g_epc_stamps = g_stamps; g_epc_stamps_n = 8 * NR * 64;
 #endif
     if (a.quiet)
-        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
+                           (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, true>), dim3((G + 63) / 64), dim3(R * 64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, true>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
+                           (hipStream_t)stream, a);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -2131,7 +2158,7 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
         if (!keys_dev[s] || !out[s].proposed || !out[s].col || !out[s].seq0 || !out[s].deps0 || !out[s].decision || !out[s].committed ||
             !out[s].seq || !out[s].deps)
             return fail(SMR_ERR_ARG, "epaxos cluster: null key or output array");
-    if (c->mode == 0)
+    if ((c->mode & 1u) == 0)
         return R <= 5 ? ep_cluster_tick_one_launch<5>(c, keys_dev, drop_dev, out, stream)
                       : ep_cluster_tick_one_launch<EMAXR>(c, keys_dev, drop_dev, out, stream);
     const dim3 grid((G + 255) / 256), block(256);
@@ -2168,28 +2195,37 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
             NoExec ne(c->rep[q]);
             if ((rc = smr_ep_handle_pre_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
         }
-    // command leaders, ascending: decision; the Accept round (flags zero where the fast path was taken); CommitNotices
-    for (uint32_t s = 0; s < R; s++) {
-        if ((rc = smr_ep_handle_pre_accept_replies(c->rep[s], out[s].col, c->r_ballot[s], c->r_seq[s], c->r_deps[s], c->r_flags[s], nullptr,
-                                                   nullptr, out[s].decision, out[s].seq, out[s].deps, stream)) != SMR_OK) return rc;
-        hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)2, (const uint8_t *)nullptr,
-                           (uint8_t)0, c->slow[s]);
-        for (uint32_t q = 0; q < R; q++) {
-            if (q == s) continue;
-            smr_ep_msg m{c->slow[s], c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
-            smr_ep_msg r{c->a_flags[s] + (size_t)q * G, nullptr, nullptr, c->a_ballot[s] + (size_t)q * G, nullptr, nullptr, nullptr, nullptr};
-            NoExec ne(c->rep[q]);
-            if ((rc = smr_ep_handle_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
+    // command leaders, ascending: decision; the Accept round (flags zero where the fast path was taken); CommitNotices -- leader by
+    // leader, or (mode bit 1) phase by phase: every leader's decision, then every Accept round, ...
+    const bool pm = (c->mode >> 1) & 1u;
+    for (uint32_t ph = 0; ph < (pm ? 4u : 1u); ph++)
+        for (uint32_t s = 0; s < R; s++) {
+            if (!pm || ph == 0) {
+                if ((rc = smr_ep_handle_pre_accept_replies(c->rep[s], out[s].col, c->r_ballot[s], c->r_seq[s], c->r_deps[s], c->r_flags[s], nullptr,
+                                                           nullptr, out[s].decision, out[s].seq, out[s].deps, stream)) != SMR_OK) return rc;
+                hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)2, (const uint8_t *)nullptr,
+                                   (uint8_t)0, c->slow[s]);
+            }
+            if (!pm || ph == 1)
+                for (uint32_t q = 0; q < R; q++) {
+                    if (q == s) continue;
+                    smr_ep_msg m{c->slow[s], c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
+                    smr_ep_msg r{c->a_flags[s] + (size_t)q * G, nullptr, nullptr, c->a_ballot[s] + (size_t)q * G, nullptr, nullptr, nullptr, nullptr};
+                    NoExec ne(c->rep[q]);
+                    if ((rc = smr_ep_handle_accept(c->rep[q], &m, &r, stream)) != SMR_OK) return rc;
+                }
+            if (!pm || ph == 2) {
+                if ((rc = smr_ep_handle_accept_replies(c->rep[s], out[s].col, c->a_ballot[s], c->a_flags[s], nullptr, c->acc[s], stream)) != SMR_OK) return rc;
+                hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)3, c->acc[s], (uint8_t)1,
+                                   out[s].committed);
+            }
+            if (!pm || ph == 3)
+                for (uint32_t q = 0; q < R; q++) {
+                    if (q == s) continue;
+                    smr_ep_msg m{out[s].committed, c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
+                    if ((rc = smr_ep_handle_commit_notice(c->rep[q], &m, stream)) != SMR_OK) return rc;
+                }
         }
-        if ((rc = smr_ep_handle_accept_replies(c->rep[s], out[s].col, c->a_ballot[s], c->a_flags[s], nullptr, c->acc[s], stream)) != SMR_OK) return rc;
-        hipLaunchKernelGGL(ep_flags_eq_kernel, grid, block, 0, (hipStream_t)stream, G, out[s].decision, (uint8_t)3, c->acc[s], (uint8_t)1,
-                           out[s].committed);
-        for (uint32_t q = 0; q < R; q++) {
-            if (q == s) continue;
-            smr_ep_msg m{out[s].committed, c->peer_c[s], out[s].col, c->bal_c[s], out[s].seq, out[s].deps, (uint8_t *)keys_dev[s], nullptr};
-            if ((rc = smr_ep_handle_commit_notice(c->rep[q], &m, stream)) != SMR_OK) return rc;
-        }
-    }
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

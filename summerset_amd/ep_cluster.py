@@ -11,9 +11,11 @@ NO_KEY = 0xFF
 NONE = -1                                       # Option::None in a DepSet (0xFFFFFFFF as int32)
 
 
-def tick(reps, keys, drop=None, always_accept_round=False):
+def tick(reps, keys, drop=None, always_accept_round=False, phase_major=False):
     """reps[r]: EPaxosReplicaGroup of replica r; keys[r]: uint8 [G] device tensor, replica r's proposal per group
     (0xFF = none); drop[(s, q)] (optional): bool [G], the PreAccept from s to q is lost (with its reply).
+    phase_major: the command leaders' part phase by phase (every leader's PreAcceptReplies, then every Accept round, every
+    AcceptReply tally, every CommitNotice) instead of leader by leader -- the order `smr_ep_cluster_set_mode(c, 2)` runs.
     Returns per command leader dict(col, proposed, decision, committed, seq, deps) of device tensors."""
     import torch
     R = len(reps)
@@ -32,36 +34,52 @@ def tick(reps, keys, drop=None, always_accept_round=False):
                 fl = torch.where(drop[(s, q)], torch.zeros_like(fl), fl)
             rep[(q, s)] = reps[q].handle_msg_pre_accept(dict(flags=fl, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=pa[s]["seq"],
                                                              deps=pa[s]["deps"], key=keys[s]))
-    out = []
     zero_f, zero_b = torch.zeros(G, dtype=torch.uint8, device=dev), torch.zeros(G, dtype=torch.int64, device=dev)
     none_d = torch.full((R, G), NONE, dtype=torch.int32, device=dev)
-    for s in range(R):
+    dec, slow, aflags, aballot, committed = [None] * R, [None] * R, [None] * R, [None] * R, [None] * R
+
+    def replies(s):
         flags = torch.stack([zero_f if q == s else rep[(q, s)]["flags"] for q in range(R)])
         ballot = torch.stack([zero_b if q == s else rep[(q, s)]["ballot"] for q in range(R)])
         seq = torch.stack([zero_b if q == s else rep[(q, s)]["seq"] for q in range(R)])
         deps = torch.stack([none_d if q == s else rep[(q, s)]["deps"] for q in range(R)])
-        dec = reps[s].handle_msg_pre_accept_reply(pa[s]["col"], ballot, seq, deps, flags)
-        slow = (dec["decision"] == 2).to(torch.uint8)
-        aflags = torch.zeros((R, G), dtype=torch.uint8, device=dev)
-        aballot = torch.zeros((R, G), dtype=torch.int64, device=dev)
-        if always_accept_round or bool(slow.any()):              # (.any() is the one device -> host read of the tick)
+        dec[s] = reps[s].handle_msg_pre_accept_reply(pa[s]["col"], ballot, seq, deps, flags)
+        slow[s] = (dec[s]["decision"] == 2).to(torch.uint8)
+
+    def accepts(s):
+        aflags[s] = torch.zeros((R, G), dtype=torch.uint8, device=dev)
+        aballot[s] = torch.zeros((R, G), dtype=torch.int64, device=dev)
+        if always_accept_round or bool(slow[s].any()):           # (.any() is the one device -> host read of the tick)
             for q in range(R):
                 if q == s:
                     continue
-                ar = reps[q].handle_msg_accept(dict(flags=slow, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec["seq"],
-                                                    deps=dec["deps"], key=keys[s]))
-                aflags[q] = ar["flags"]
-                aballot[q] = ar["ballot"]
-        acc = reps[s].handle_msg_accept_reply(pa[s]["col"], aballot, aflags)
-        committed = ((dec["decision"] == 3) | (acc["committed"] == 1)).to(torch.uint8)
+                ar = reps[q].handle_msg_accept(dict(flags=slow[s], peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec[s]["seq"],
+                                                    deps=dec[s]["deps"], key=keys[s]))
+                aflags[s][q] = ar["flags"]
+                aballot[s][q] = ar["ballot"]
+
+    def accept_replies(s):
+        acc = reps[s].handle_msg_accept_reply(pa[s]["col"], aballot[s], aflags[s])
+        committed[s] = ((dec[s]["decision"] == 3) | (acc["committed"] == 1)).to(torch.uint8)
+
+    def commits(s):
         for q in range(R):
             if q == s:
                 continue
-            reps[q].handle_msg_commit_notice(dict(flags=committed, peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec["seq"],
-                                                  deps=dec["deps"], key=keys[s]))
-        out.append(dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec["decision"], committed=committed, seq=dec["seq"],
-                        deps=dec["deps"]))
-    return out
+            reps[q].handle_msg_commit_notice(dict(flags=committed[s], peer=u8(s), col=pa[s]["col"], ballot=i64(s + 1), seq=dec[s]["seq"],
+                                                  deps=dec[s]["deps"], key=keys[s]))
+
+    phases = (replies, accepts, accept_replies, commits)
+    if phase_major:
+        for ph in phases:
+            for s in range(R):
+                ph(s)
+    else:
+        for s in range(R):
+            for ph in phases:
+                ph(s)
+    return [dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec[s]["decision"], committed=committed[s], seq=dec[s]["seq"],
+                 deps=dec[s]["deps"]) for s in range(R)]
 
 
 class EPaxosCluster:
@@ -73,7 +91,7 @@ class EPaxosCluster:
     against.  No Python, no torch glue and no host read inside a tick either way (the Accept round runs wherever a leader of
     the tile took the slow path).  `reps` stay usable on their own (dump, exec_dump, the per-handler calls)."""
 
-    def __init__(self, reps, per_handler_launches=False):
+    def __init__(self, reps, per_handler_launches=False, phase_major=False):
         import ctypes as C
         from . import _lib
         self.reps, self.R, self.G = list(reps), len(reps), reps[0].G
@@ -83,8 +101,8 @@ class EPaxosCluster:
         _lib.check(self._L.smr_ep_cluster_create(arr, self.R, C.byref(h)))
         self._h = h
         self._held = None                      # the last tick's drop masks: alive until the next tick's have replaced them
-        if per_handler_launches:
-            _lib.check(self._L.smr_ep_cluster_set_mode(self._h, 1))
+        if per_handler_launches or phase_major:                  # (phase_major: `tick(.., phase_major=True)`'s order, see there)
+            _lib.check(self._L.smr_ep_cluster_set_mode(self._h, (1 if per_handler_launches else 0) | (2 if phase_major else 0)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -106,11 +106,13 @@ class NumpyEngine:
         return g[k], r[k], c[k]
 
 
-def tick(reps, keys, drop=None, via=None):
+def tick(reps, keys, drop=None, via=None, phase_major=False):
     """reps[r]: backend of replica r; keys[r][G]: proposal of replica r (0xFF none);
     drop[(s, q)] (optional): bool [G] -- the PreAccept from s to q is lost (with its reply).
     via (optional): via(s, col, ballot, seq, deps, flags) -> (ballot, seq, deps, flags) -- the PreAcceptReplies on their way
     to command leader s (tests/test_zz_reply_ingest_gpu.py sends them as frames through the device parser).
+    phase_major: the leaders' part of the tick phase by phase instead of leader by leader (every leader's replies, then every
+    Accept round, every AcceptReply tally, every CommitNotice): the order smr_ep_cluster_set_mode(c, 2) runs.
     Returns per-leader decisions."""
     R = len(reps)
     G = keys.shape[1]
@@ -128,8 +130,9 @@ def tick(reps, keys, drop=None, via=None):
             rep[(q, s)] = reps[q].handle_pre_accept(flags=fl, peer=u8(s), col=pa[s]["col"],
                                                     ballot=np.full(G, s + 1, np.uint64), seq=pa[s]["seq"],
                                                     deps=np.ascontiguousarray(pa[s]["deps"]), key=np.ascontiguousarray(keys[s]))
-    out = []
-    for s in range(R):
+    dec, slowf, aflags, aballot, committed = [None] * R, [None] * R, [None] * R, [None] * R, [None] * R
+
+    def replies(s):
         ballot = np.zeros((R, G), np.uint64); seq = np.zeros((R, G), np.uint64)
         deps = np.full((R, R, G), N, np.uint32); flags = np.zeros((R, G), np.uint8)
         for q in range(R):
@@ -139,30 +142,43 @@ def tick(reps, keys, drop=None, via=None):
             flags[q] = r_["flags"]; ballot[q] = r_["ballot"]; seq[q] = r_["seq"]; deps[q] = r_["deps"]
         if via is not None:
             ballot, seq, deps, flags = via(s, pa[s]["col"], ballot, seq, deps, flags)
-        dec = reps[s].handle_pre_accept_replies(pa[s]["col"], ballot, seq, deps, flags)
-        # slow path: Accept round for the instances that went Accepting
-        slow = (dec["decision"] == 2).astype(np.uint8)
-        aflags = np.zeros((R, G), np.uint8); aballot = np.zeros((R, G), np.uint64)
-        if slow.any():
+        dec[s] = reps[s].handle_pre_accept_replies(pa[s]["col"], ballot, seq, deps, flags)
+        slowf[s] = (dec[s]["decision"] == 2).astype(np.uint8)
+
+    def accepts(s):                                          # slow path: Accept round for the instances that went Accepting
+        aflags[s] = np.zeros((R, G), np.uint8); aballot[s] = np.zeros((R, G), np.uint64)
+        if slowf[s].any():
             for q in range(R):
                 if q == s:
                     continue
-                ar = reps[q].handle_accept(flags=slow, peer=u8(s), col=pa[s]["col"], ballot=np.full(G, s + 1, np.uint64),
-                                           seq=dec["seq"], deps=np.ascontiguousarray(dec["deps"]),
+                ar = reps[q].handle_accept(flags=slowf[s], peer=u8(s), col=pa[s]["col"], ballot=np.full(G, s + 1, np.uint64),
+                                           seq=dec[s]["seq"], deps=np.ascontiguousarray(dec[s]["deps"]),
                                            key=np.ascontiguousarray(keys[s]))
-                aflags[q] = ar["flags"]; aballot[q] = ar["ballot"]
-        acc = reps[s].handle_accept_replies(pa[s]["col"], aballot, aflags)
-        committed = ((dec["decision"] == 3) | (acc["committed"] == 1)).astype(np.uint8)
-        # the committed (seq, deps): the fast-path class resp. the Accept's
+                aflags[s][q] = ar["flags"]; aballot[s][q] = ar["ballot"]
+
+    def accept_replies(s):
+        acc = reps[s].handle_accept_replies(pa[s]["col"], aballot[s], aflags[s])
+        committed[s] = ((dec[s]["decision"] == 3) | (acc["committed"] == 1)).astype(np.uint8)
+
+    def commits(s):                                          # the committed (seq, deps): the fast-path class resp. the Accept's
         for q in range(R):
             if q == s:
                 continue
-            reps[q].handle_commit_notice(flags=committed, peer=u8(s), col=pa[s]["col"], ballot=np.full(G, s + 1, np.uint64),
-                                         seq=dec["seq"], deps=np.ascontiguousarray(dec["deps"]),
+            reps[q].handle_commit_notice(flags=committed[s], peer=u8(s), col=pa[s]["col"], ballot=np.full(G, s + 1, np.uint64),
+                                         seq=dec[s]["seq"], deps=np.ascontiguousarray(dec[s]["deps"]),
                                          key=np.ascontiguousarray(keys[s]))
-        out.append(dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec["decision"], committed=committed,
-                        seq=dec["seq"], deps=dec["deps"]))
-    return out
+
+    phases = (replies, accepts, accept_replies, commits)
+    if phase_major:                                          # (smr_ep_cluster_set_mode bit 1: another legal delivery order)
+        for ph in phases:
+            for s in range(R):
+                ph(s)
+    else:
+        for s in range(R):
+            for ph in phases:
+                ph(s)
+    return [dict(col=pa[s]["col"], proposed=pa[s]["flags"], decision=dec[s]["decision"], committed=committed[s],
+                 seq=dec[s]["seq"], deps=dec[s]["deps"]) for s in range(R)]
 
 
 def zipf_keys(rng, R, G, n_keys, p_propose=0.9):

@@ -334,6 +334,9 @@ def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
         t.run_fused_vs_driver("cpu", 130, 16, 0.0, T=5, execute=False, oracle=oracle)
         assert t.run_fused_vs_driver("cpu", 90, 4, 0.15, T=5, R=3, W=16, oracle=oracle) > 0    # populations 3 and 7 (the 8-replica kernel instances)
         assert t.run_fused_vs_driver("cpu", 70, 6, 0.15, T=5, R=7, W=16, oracle=oracle) > 0
+        assert t.run_fused_vs_driver("cpu", 200, 6, 0.15, T=6, oracle=oracle, phase_major=True) > 0   # the leaders' steps phase by phase (set_mode bit 1)
+        assert t.run_fused_vs_driver("cpu", 70, 6, 0.15, T=5, R=7, W=16, oracle=oracle, phase_major=True) > 0
+        t.run_fused_vs_driver("cpu", 130, 16, 0.1, T=5, execute=False, oracle=oracle, phase_major=True)
 
 
 def test_spread_epaxos_exchange_on_the_host(sim):

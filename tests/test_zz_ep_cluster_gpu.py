@@ -39,17 +39,18 @@ def test_device_cluster_tick_matches_the_oracle_cluster(cuda, oracle, G, K, loss
     assert fast > 0 and (slow > 0 or loss == 0.0)
 
 
-def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32, oracle=None):
+def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32, oracle=None, phase_major=False):
     """`smr_ep_cluster_tick` -- one C call per tick: as ONE launch (the default) and as the handler kernels back to back -- against
     the handler-by-handler driver on a third set of replicas and, with `oracle`, against five oracles wired into the same
-    loop (tests/ep_cluster.py): every leader's outputs every tick, every replica's final state"""
+    loop (tests/ep_cluster.py): every leader's outputs every tick, every replica's final state.  phase_major: all four in the
+    phase-by-phase order of the leaders' steps (smr_ep_cluster_set_mode bit 1)."""
     import torch
     import ep_cluster as ec
     from summerset_amd import EPaxosReplicaGroup, ep_cluster
     mk = lambda: [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
     a, a1, b = mk(), mk(), mk()
-    fused = ep_cluster.EPaxosCluster(a)
-    launches = ep_cluster.EPaxosCluster(a1, per_handler_launches=True)
+    fused = ep_cluster.EPaxosCluster(a, phase_major=phase_major)
+    launches = ep_cluster.EPaxosCluster(a1, per_handler_launches=True, phase_major=phase_major)
     orcs = [oracle.EpOracle(G, R, me=r, W=W, n_keys=K, execute=execute) for r in range(R)] if oracle is not None else None
     from summerset_amd import SummersetError
     for wrong in (a[::-1], a[:2], a[:4] + [b[0]]):               # replica r must sit at index r, all of them, of one population
@@ -69,8 +70,8 @@ def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32, o
         dd = None if drop is None else {k: dv(v) for k, v in drop.items()}
         oa = fused.tick(kd, dd, out=outs)
         oa1 = launches.tick(kd, dd)
-        ob = ep_cluster.tick(b, kd, dd, always_accept_round=True)
-        oo = ec.tick(orcs, keys, drop) if orcs is not None else None
+        ob = ep_cluster.tick(b, kd, dd, always_accept_round=True, phase_major=phase_major)
+        oo = ec.tick(orcs, keys, drop, phase_major=phase_major) if orcs is not None else None
         for s in range(R):
             for k in ob[s]:
                 assert np.array_equal(oa[s][k].cpu().numpy(), ob[s][k].cpu().numpy()), (t, s, k)
