@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r3m_pmc_traffic.json")
-PMC_NOTE = ("profiles/r3m_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
+PMC_FILE = os.path.join(ROOT, "profiles", "r4m_pmc_traffic.json")
+PMC_NOTE = ("profiles/r4m_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
             "gfx950 corrections of MI355X_MICROARCH.md applied; bytes per launch at 65536 groups, S=32, default workload)")
 
 
@@ -875,7 +875,13 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
             "value": r["n_acks"] / (us * 1e-6), "unit": "AcceptReply frames/s", "call_us": us, "stream_GBps": stream_bytes / (us * 1e-6) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
-                         "avg_launch_us": us, "traffic": None}}
+                         "avg_launch_us": us, "traffic": _sum_traffic("smr::wire_ingest_mp_kernel<false>", "smr::wire_ingest_mp_kernel<true>"),
+                         "traffic_source": PMC_NOTE}}
+
+
+def _sum_traffic(*kernels):
+    t = [_leg_traffic(k) for k in kernels]
+    return sum(t) if all(t) else None
 
 
 def reply_ingest_leg(torch, dev, G=65536, R=5, iters=12, junk_every=16):
@@ -906,7 +912,8 @@ def reply_ingest_leg(torch, dev, G=65536, R=5, iters=12, junk_every=16):
                         "[R][G] reply arrays" % (n_conn, G, R - 1), "value": n_conn / (us * 1e-6), "unit": "AppendEntriesReply frames/s", "call_us": us,
             "roofline": {"bound": "hbm", "kernel": "wire_ingest_replies_kernel<0> (+ two memsets: one smr_wire_ingest_raft_replies call)",
                          "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "alg_bytes_per_launch": alg, "avg_launch_us": us, "traffic": None}}
+                         "alg_bytes_per_launch": alg, "avg_launch_us": us, "traffic": _leg_traffic("smr::wire_ingest_replies_kernel<0>"),
+                         "traffic_source": PMC_NOTE}}
 
 
 def _cpu_run(a):

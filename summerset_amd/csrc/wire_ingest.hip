@@ -28,7 +28,7 @@ namespace smr {
 
 typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SMR_WI_DIAG
-#define SMR_WI_DIAG 0                            // 1, 2: diagnostic builds (tools/r3z_wi_diag.sh), wrong results on purpose
+#define SMR_WI_DIAG 0                            // 1, 2: diagnostic builds (tools/runs/r3z_wi_diag.sh), wrong results on purpose
 #endif
 #ifndef SMR_WI_WIN
 #define SMR_WI_WIN 128                           // 9 KB of LDS per wavefront: 16 blocks per CU; >= 16 + 8 + WI_HOT_MAX

@@ -64,7 +64,9 @@ if a.extra:
     bench.raft_leg(torch, dev)
     bench.epaxos_leg(torch, dev)
     torch.cuda.synchronize()
-    bench.wire_ingest_leg(torch, dev)             # the peer-traffic parser's three kernels (round 2: no PMC traffic for them yet)
+    bench.wire_ingest_leg(torch, dev)             # the peer-traffic parser's two passes
+    torch.cuda.synchronize()
+    bench.reply_ingest_leg(torch, dev)            # round 3: Raft replies parsed into the [R][G] arrays
     torch.cuda.synchronize()
     bench.epaxos_cluster_leg(torch, dev, ticks=4)  # round 3: the one-launch cluster tick (ep_cluster_tick_kernel)
     torch.cuda.synchronize()

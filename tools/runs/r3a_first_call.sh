@@ -3,7 +3,7 @@
 #   whole -m gpu suite (no -x, no xfail marks left) | default bench line | driver flags | steady
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command (bench.py --gpus 1 --steps 20 --warmup 5)
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra
-#   kernel trace of the EPaxos cluster leg; the wire-ingest ring-of-lines A/B (tools/r3b_wi_ring.sh)
+#   kernel trace of the EPaxos cluster leg; the wire-ingest ring-of-lines A/B (tools/runs/r3b_wi_ring.sh)
 TAG=${1:-r3a}
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -60 > gpurun_out/${TAG}_gputests.log
@@ -24,4 +24,4 @@ python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_wr
 rm -rf gpurun_out/${TAG}_prof_bench gpurun_out/${TAG}_prof_epc gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write
 grep -v "at::native" gpurun_out/${TAG}_kernel_stats_default_bench.txt | head -12 | cut -c1-150
 grep -v "at::native" gpurun_out/${TAG}_kernel_stats_epaxos_cluster.txt | head -8 | cut -c1-150
-[ -f summerset_amd/variants/libsummerset_hip_wi_ring.so ] && bash tools/r3b_wi_ring.sh > /dev/null 2>&1; tail -12 gpurun_out/r3b_wi_ring.log | cut -c1-300
+[ -f summerset_amd/variants/libsummerset_hip_wi_ring.so ] && bash tools/runs/r3b_wi_ring.sh > /dev/null 2>&1; tail -12 gpurun_out/r3b_wi_ring.log | cut -c1-300

@@ -17,5 +17,5 @@ for lib in "" $V/libsummerset_hip_epc_w4.so; do
   echo "lib=$(basename "$lib") execute=0"; SMR_EPC_EXECUTE=0 run
 done
 unset SUMMERSET_HIP_LIB
-bash tools/r3o_epc_loads.sh > /dev/null 2>&1; cat gpurun_out/r3o_epc_loads.txt | cut -c1-330
+bash tools/runs/r3o_epc_loads.sh > /dev/null 2>&1; cat gpurun_out/r3o_epc_loads.txt | cut -c1-330
 } 2>&1 | tee gpurun_out/${TAG}_epc_records.log
