@@ -1110,7 +1110,9 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
     virtual = world == 1
     nr = args.spread_ranks if virtual else world
     total = args.groups * (1 if virtual else world)
-    job = spread_ep.in_process(total, R, nr, dev, window=W, n_keys=K) if virtual else spread_ep.SpreadEPaxos(total, R, rank, world, dev, window=W, n_keys=K)
+    # dependency-graph execution ON with the 5-exchange schedule: the co-located loop's phase-by-phase order (tests/test_zzy_spread_ep_gpu.py)
+    kw = dict(window=W, n_keys=K, execute=True, ordered=False)
+    job = spread_ep.in_process(total, R, nr, dev, **kw) if virtual else spread_ep.SpreadEPaxos(total, R, rank, world, dev, **kw)
     homes = [k for rk in job.ranks for k in rk.reps] if virtual else list(job.reps)
     zipf = 1.0 / np.arange(1, K + 1) ** 0.99
     zipf /= zipf.sum()
@@ -1145,7 +1147,7 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "EPaxos closed loop, %d groups/GPU x 5 replicas, every replica proposes 1 instance per group per tick "
-                                   "(Zipf(0.99) keys of 64), optimized quorums" % args.groups,
+                                   "(Zipf(0.99) keys of 64), optimized quorums, dependency-graph execution on" % args.groups,
                        "groups_per_gpu": args.groups, "replicas": R, "window": W, "layout": "spread", "spread_ranks": nr,
                        "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
             "exchange": {"collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1)},
@@ -1167,7 +1169,7 @@ def colocated_epaxos_main(args, torch, dist, rank, local, world, dev):
     G, R, W, K = args.groups, 5, 32, 64
     lo, _ = shard.group_range(G * world, world, rank)
     reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
-    job = ep_cluster.EPaxosCluster(reps)
+    job = ep_cluster.EPaxosCluster(reps, phase_major=True)            # (the leaders' steps phase by phase: DESIGN §4, smr_ep_cluster_set_mode bit 1)
     zipf = 1.0 / np.arange(1, K + 1) ** 0.99
     zipf /= zipf.sum()
     n_ticks = args.warmup + args.steps

@@ -17,9 +17,13 @@ Two schedules:
   * `ordered=False` (default): all command leaders tally together -- 5 exchanges per tick.  An acceptor then handles the
     tick's Accepts before the tick's CommitNotices instead of leader by leader; instances of different rows do not read
     each other on these paths, so the protocol state is bit for bit `ep_cluster.tick`'s (tests/test_spread_ep*.py).
-    Dependency-graph execution does look across rows when it runs, so with `execute=True` use
-  * `ordered=True`: the Accept / AcceptReply / CommitNotice exchanges once per command leader, leaders ascending --
-    2 + 3 R exchanges per tick, the exact handler order of `ep_cluster.tick`, execution state included.
+    Dependency-graph execution does look across rows when it runs: with `execute=True` this schedule is bit for bit
+    `ep_cluster.tick(.., phase_major=True)` -- the co-located loop with the command leaders' steps phase by phase, the order
+    `smr_ep_cluster_set_mode(c, 2)` runs and the oracle cluster is checked in (round 3; tests/test_zzy_spread_ep_gpu.py) --
+    not the default leader-by-leader loop.  For that one:
+  * `ordered=True` (the default where `execute=True`): the Accept / AcceptReply / CommitNotice exchanges once per command
+    leader, leaders ascending -- 2 + 3 R exchanges per tick, the exact handler order of `ep_cluster.tick`, execution state
+    included.
 """
 from . import shard
 from .epaxos import EPaxosReplicaGroup

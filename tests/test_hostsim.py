@@ -349,6 +349,9 @@ def test_spread_epaxos_exchange_on_the_host(sim):
         t.run_spread_vs_colocated("cpu", G=21, world=8, n_ticks=4, loss=0.1)
         job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True)
         assert job.ranks[0].exchanges_per_tick() == 17
+        # execution on with the 5-exchange schedule: the phase-by-phase order of the colocated loop (smr_ep_cluster_set_mode bit 1)
+        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True)
+        assert job.ranks[0].exchanges_per_tick() == 5
         assert t.run_spread_vs_colocated("cpu", G=70, world=1, n_ticks=4, loss=0.1).ranks[0].bytes_sent == 0   # one rank: nothing leaves it
         t.run_spread_vs_colocated("cpu", G=60, world=2, n_ticks=4, loss=0.1, R=3, K=4)                         # three replicas
 

@@ -8,8 +8,9 @@ import numpy as np
 import pytest
 
 
-def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execute=False, ordered=None, make=None, seed=0):
-    """`make(world)` -> object with tick(keys, drop) and .ranks (default: spread_ep.in_process)"""
+def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execute=False, ordered=None, make=None, seed=0, ref_phase_major=False):
+    """`make(world)` -> object with tick(keys, drop) and .ranks (default: spread_ep.in_process).  ref_phase_major: the colocated
+    reference loop runs the leaders' steps phase by phase -- the order of the 5-exchange schedule (`ordered=False`)"""
     import torch
     import ep_cluster as ec
     from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard, spread_ep
@@ -23,7 +24,7 @@ def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execut
         keys = ec.zipf_keys(rng, R, G, K)
         drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q} if loss else None
         oo = ep_cluster.tick(ref, [dv(keys[r]) for r in range(R)], None if drop is None else {k: dv(v) for k, v in drop.items()},
-                             always_accept_round=True)
+                             always_accept_round=True, phase_major=ref_phase_major)
         bk = {(b, r): dv(keys[r, lo:hi]) for b, (lo, hi) in rngs.items() for r in range(R) if hi > lo}
         bd = None if drop is None else {(b, s, q): dv(v[lo:hi]) for b, (lo, hi) in rngs.items() for (s, q), v in drop.items() if hi > lo}
         oe = job.tick(bk, bd)

@@ -19,3 +19,12 @@ def test_spread_epaxos_ordered_schedule_with_execution(cuda):
     job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True)
     assert all(rk.exchanges_per_tick() == 17 for rk in job.ranks)
     run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True)
+
+
+def test_spread_epaxos_five_exchanges_with_execution(cuda):
+    """execution on with the 5-exchange schedule (`ordered=False`): that IS the co-located loop with the command leaders' steps
+    phase by phase (`ep_cluster.tick(.., phase_major=True)`, smr_ep_cluster_set_mode bit 1) -- decisions, protocol state and
+    the executors' state bit for bit"""
+    job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True)
+    assert job.ranks[0].exchanges_per_tick() == 5
+    run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True, ordered=False, ref_phase_major=True)
