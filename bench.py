@@ -118,6 +118,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
     ap.add_argument("--late-legs", action="store_true", help="also run the legs of kernels that have not had a device run yet "
                     "(EPaxos execution, the RSPaxos replica engine), each in a child process")
+    ap.add_argument("--role-rotation", type=int, default=0, help="1: rows of the bulk round launches by role (smr_mp_set_role_rotation): row 0 runs "
+                    "every group's leader, whoever that is")
     ap.add_argument("--leg", default=None, help="internal: run one secondary leg in this process and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--launch-check", action="store_true", help="only prove the launch: start the ranks --gpus asks for, count them "
@@ -1293,6 +1295,8 @@ def main():
     if args.fused:
         args.straggler_ticks = 0                  # the fused tick kernel and the side stream exclude each other
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
+    if args.role_rotation and args.straggler_ticks:
+        eng.set_role_rotation(True)
     eng.preset_leader(0)
     st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=timeout_frac(args),
                                  hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=timeout_span(args),

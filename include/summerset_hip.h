@@ -228,6 +228,12 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
  * image header (uint32 [2]) and the entries are lost: size ovf_cap for the leader changes a tick can hold. */
 enum { SMR_IMG_OUTBOX = 0, SMR_IMG_ACKS = 1, SMR_IMG_PREPARE_REPLIES = 2, SMR_IMG_HEARTBEAT = 3 };
 int smr_mp_set_live(smr_mp_cluster *c, uint32_t live_mask);
+/* Role rotation (round 3; needs straggler_ticks > 0 and every replica on this device).  The bulk round launches are a grid of
+ * (64-group tiles) x (R rows); row y normally runs replica y of every group, so once leaders have moved a wavefront holds
+ * leaders and followers side by side and runs both roles' code.  With rotation on, row y runs replica (y + leader[g]) mod R of
+ * group g -- leader[g] as the tick's mark pass read it --: row 0 is every group's leader, rows 1 .. R - 1 its followers.
+ * Every (group, replica) pair is still handled exactly once per round; results are bit for bit the same. */
+int smr_mp_set_role_rotation(smr_mp_cluster *c, int on);
 int64_t smr_mp_image_bytes(smr_mp_cluster *c, int kind, uint32_t rows, uint32_t ovf_cap);
 int smr_mp_image_pack(smr_mp_cluster *c, int kind, uint8_t rep, uint8_t other, uint8_t *img_dev, uint64_t img_bytes,
                       uint32_t rows, uint32_t ovf_cap, void *stream);

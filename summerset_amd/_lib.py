@@ -213,6 +213,7 @@ SYMBOLS = [
     ("smr_mp_tick", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _i, _vp]),
     ("smr_mp_run_ticks", _i, [_vp, C.POINTER(MpTickIn), _u32, _vp]),
     ("smr_mp_set_live", _i, [_vp, _u32]),
+    ("smr_mp_set_role_rotation", _i, [_vp, _i]),
     ("smr_mp_image_bytes", C.c_int64, [_vp, _i, _u32, _u32]),
     ("smr_mp_image_pack", _i, [_vp, _i, _u8, _u8, _vp, _u64, _u32, _u32, _vp]),
     ("smr_mp_image_unpack", _i, [_vp, _i, _u8, _u8, _vp, _u64, _u32, _u32, _vp]),

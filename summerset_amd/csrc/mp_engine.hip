@@ -83,6 +83,24 @@ __device__ __forceinline__ bool pick_group(const MpParams &P, int side, uint32_t
     return !P.overflow[g];
 }
 
+// Which replica of its group a lane of a bulk launch stands for: block row y, rotated by the group's leader where role
+// rotation is on (MpParams::role_rot).  Every (group, replica) pair is still taken exactly once per launch.
+__device__ __forceinline__ uint32_t pick_replica(const MpParams &P, int side, uint32_t g) {
+    uint32_t d = blockIdx.y;
+    if (P.rot_on && side == 0) {
+        d += P.role_rot[g < P.G ? g : 0];
+        if (d >= P.R) d -= P.R;
+    }
+    return d;
+}
+// (the mark pass: the leader replica 0 knows of, which is the leader wherever no change is in flight)
+__device__ __forceinline__ void mark_role(const MpParams &P, uint32_t g) {
+    if (!P.rot_on) return;
+    const uint32_t l = P.rep[0].leader[g];
+    const uint8_t r = (uint8_t)(l < P.R ? l : 0u);
+    if (P.role_rot[g] != r) P.role_rot[g] = r;
+}
+
 // start of a tick: a HearTimeout puts its group on the straggler list for `ttl` ticks
 __global__ __launch_bounds__(256) void mp_mark_stragglers(const MpParams *__restrict__ Pp, int lpar,
                                                           const uint8_t *__restrict__ timeout_rep, uint32_t ttl) {
@@ -90,6 +108,7 @@ __global__ __launch_bounds__(256) void mp_mark_stragglers(const MpParams *__rest
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g == 0) P.slow_n[lpar ^ 1] = 0;                          // next tick's counter
     if (g >= P.G) return;
+    mark_role(P, g);
     uint32_t t = P.slow_ttl[g];
     if (timeout_rep && timeout_rep[g] != NO_REP) t = ttl;
     uint8_t s = 0;
@@ -227,7 +246,7 @@ __global__ MP_R1_BOUNDS void mp_round_local(const MpParams *__restrict__ Pp, int
     if (!((P.live >> blockIdx.y) & 1u)) return;                 // spread layout: that replica lives on another rank
     uint32_t g;
     const bool active = pick_group(P, side, g);
-    r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, active, blockIdx.y);
+    r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, active, pick_replica(P, side, g));
 }
 
 // ---- R2 ---------------------------------------------------------------------
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver(const MpPara
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
-    r2_body(P, par, g, active, blockIdx.y);
+    r2_body(P, par, g, active, pick_replica(P, side, g));
 }
 
 // ---- R3 ---------------------------------------------------------------------
@@ -1071,11 +1090,14 @@ __global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, i
         const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;   // 64-group tiles of this block
         uint32_t any = 0;
         for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+        if (P.rot_on)                                            // (my row's replicas differ from group to group: any replica's flag)
+            for (uint32_t y = 0; y < P.R; y++)
+                for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)y * ntile + t0 + k] : 0u;
         if (!any) return;
     }
     uint32_t g;
     const bool active = pick_group(P, side, g);
-    r3_body(P, par, ackctl, publish_hb, g, active, blockIdx.y);
+    r3_body(P, par, ackctl, publish_hb, g, active, pick_replica(P, side, g));
 }
 
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
@@ -1122,7 +1144,7 @@ __global__ MP_R4_BOUNDS void mp_round_heartbeat(const MpParams *__restrict__ Pp,
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
-    r4_body(P, par, g, active, blockIdx.y);
+    r4_body(P, par, g, active, pick_replica(P, side, g));
 }
 
 // One launch for the whole tick of the straggler list: a block per listed group (round robin), one
@@ -1230,6 +1252,7 @@ __global__ __launch_bounds__(256) void mp_mark_batch(const MpParams *__restrict_
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     if (g == 0) P.slow_n[lpar ^ 1] = 0;
     if (g >= P.G) return;
+    mark_role(P, g);
     uint32_t t = P.slow_ttl[g];
     bool any = false;
     for (uint32_t k = 0; k < B.n; k++) {
@@ -1641,7 +1664,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     carve(a, P.overflow, G, dry);
     carve(a, P.dbg, 64, dry);
     carve(a, P.r3_need, R * ((G + 63) / 64), dry);
-    carve(a, P.slow, G, dry); carve(a, P.slow_ttl, G, dry);
+    carve(a, P.slow, G, dry); carve(a, P.slow_ttl, G, dry); carve(a, P.role_rot, G, dry);
     carve(a, P.slow_list, (size_t)SLOW_CAP, dry); carve(a, P.slow_n, 2, dry);
     for (size_t r = 0; r < R; r++) {
         MpRep &v = P.rep[r];
@@ -2030,11 +2053,24 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
     return SMR_OK;
 }
 
+int smr_mp_set_role_rotation(smr_mp_cluster *c, int on) {
+    if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
+    const uint32_t all = (1u << c->cfg.population) - 1u;
+    if (on && c->hp.live != all) return fail(SMR_ERR_STATE, "mp: role rotation needs every replica on this device");
+    if (on && !c->ttl) return fail(SMR_ERR_STATE, "mp: role rotation rides on the straggler mark pass (straggler_ticks > 0)");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    c->hp.rot_on = on ? 1u : 0u;
+    SMR_HIP_TRY(hipMemset(c->hp.role_rot, 0, c->cfg.n_groups));
+    SMR_HIP_TRY(hipMemcpy(c->dp, &c->hp, sizeof(MpParams), hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
 int smr_mp_set_live(smr_mp_cluster *c, uint32_t live_mask) {
     if (!c) return fail(SMR_ERR_ARG, "mp: null cluster");
     const uint32_t all = (1u << c->cfg.population) - 1u;
     if ((live_mask & ~all) != 0) return fail(SMR_ERR_ARG, "mp: live mask names a replica beyond the population");
     if (c->ttl && live_mask != all) return fail(SMR_ERR_STATE, "mp: the spread layout and the straggler side stream exclude each other");
+    if (c->hp.rot_on && live_mask != all) return fail(SMR_ERR_STATE, "mp: the spread layout and role rotation exclude each other");
     SMR_HIP_TRY(hipDeviceSynchronize());
     c->hp.live = live_mask;
     SMR_HIP_TRY(hipMemcpy(c->dp, &c->hp, sizeof(MpParams), hipMemcpyHostToDevice));

@@ -222,6 +222,11 @@ struct MpParams {
     SMR_G uint32_t *slow_list;      // [slow_cap]
     SMR_G uint32_t *slow_n;         // [2] list length, by tick parity
     uint32_t slow_cap;
+    // role rotation (smr_mp_set_role_rotation): block row y of a bulk round launch takes, of group g, replica
+    // (y + role_rot[g]) mod R instead of replica y; role_rot[g] = the group's leader as the tick's mark pass found it, so row 0
+    // runs every group's LEADER and rows 1 .. R - 1 its followers -- a wavefront then runs one role's code, whoever leads
+    SMR_G uint8_t *role_rot;        // [G]
+    uint32_t rot_on;
     uint32_t live;                  // bit r: replica r runs on this device (spread layout: the others are images, see mp_img_*)
     size_t rep_stride;              // bytes from an array of replica d to the same array of replica d + 1
     MpRep rep[MAXR];

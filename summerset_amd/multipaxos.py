@@ -52,6 +52,11 @@ class MultiPaxosCluster:
     def preset_leader(self, rep=0):
         check(self._L.smr_mp_preset_leader(self._h, rep))
 
+    def set_role_rotation(self, on=True):
+        """row y of the bulk round launches runs replica (y + leader[g]) mod R of group g instead of replica y: wavefronts of
+        one role, whoever leads (smr_mp_set_role_rotation; needs straggler_ticks > 0).  Same results bit for bit."""
+        check(self._L.smr_mp_set_role_rotation(self._h, 1 if on else 0))
+
     def tick(self, timeout_rep=None, timeout_src=None, req_target=None, req_cnt=None, req_val=None, ackctl=None,
              heartbeat=False, stream=None):
         """One lock-step tick; arguments are device tensors (uint8 / uint32), see smr_mp_tick."""

@@ -119,6 +119,11 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         # with and without the straggler side launch
         for sticks in (0, 4):
             t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=sticks, every=4)
+        # role rotation (smr_mp_set_role_rotation): rows of the bulk launches by role, same results
+        t._run("cpu", oracle, G=130, R=5, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, straggler_ticks=2, rotate=True)
+        t._run("cpu", oracle, G=96, R=3, S=2, W=32, n_ticks=30, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5, straggler_ticks=4, rotate=True)
+        t._run("cpu", oracle, G=70, R=7, S=2, W=64, n_ticks=24, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6, straggler_ticks=8, rotate=True)
+        t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=4, every=4, fused=8, rotate=True)
         # more client batches per tick than R1 prefetches into registers (R1_PF = 32)
         t._run("cpu", oracle, G=64, R=5, S=40, W=256, n_ticks=12, drop_p=0.05, timeout_frac=0.0, hb_every=4, preset=True)
         # batches of ticks with the straggler list on: the list's groups run the whole batch in one launch

@@ -74,11 +74,13 @@ def _acks_as_records(eng, cuda, G, R, cap, t):
 
 
 def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, preset, commit_extra=0, seed=None,
-         every=1, timeout_rep=1, straggler_ticks=0, per_round=False, fused=0):
+         every=1, timeout_rep=1, straggler_ticks=0, per_round=False, fused=0, rotate=False):
     from summerset_amd import MultiPaxosCluster, stream
     cap = W + 4
     eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * (S * 4 * max(fused, 1) + W) + 64,
                             straggler_ticks=straggler_ticks)
+    if rotate:                              # rows of the bulk launches by role (smr_mp_set_role_rotation): same results
+        eng.set_role_rotation(True)
     orc = oracle.MpOracle(G, R, W, cap=cap, commit_extra=commit_extra)
     if preset:
         eng.preset_leader(0)
@@ -209,7 +211,7 @@ def test_config2_4096_groups(cuda, oracle):
          preset=True, every=8)
 
 
-def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, every=6, log=None, fused=0):
+def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, every=6, log=None, fused=0, rotate=False):
     """bench.py's shape (S=32, W=512, pooled tick inputs, <= 2 acks lost per slot) with leader
     changes: logs of 100+ slots go through the long-outbox / cooperative paths the small shapes
     above never reach."""
@@ -217,6 +219,8 @@ def _run_bench_shape(cuda, oracle, G, frac, span, n_ticks, straggler_ticks=0, ev
     R, S, W, H = 5, 32, 512, 4
     cap = W + 4
     eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=straggler_ticks)
+    if rotate:
+        eng.set_role_rotation(True)
     orc = oracle.MpOracle(G, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
     eng.preset_leader(0)
     orc.preset_leader(0)
@@ -323,3 +327,17 @@ def test_batches_and_single_ticks_share_the_list(cuda, oracle):
         _compare(eng, orc, R, t)
     for r in range(R):
         assert eng.counters(r)["commits"] == orc.total_commits(r)
+
+
+def test_role_rotation_is_bit_exact(cuda, oracle):
+    """smr_mp_set_role_rotation: row y of the bulk round launches runs replica (y + leader[g]) mod R of group g -- leaders in row
+    0, followers behind -- instead of replica y.  Leader changes all over the run (so the rotation differs from group to group
+    and from tick to tick), loss, heartbeats; one call per tick and batches; 3 / 5 / 7 replicas; the bench's own shape"""
+    _run(cuda, oracle, G=300, R=5, S=2, W=64, n_ticks=40, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, straggler_ticks=2, rotate=True)
+    _run(cuda, oracle, G=257, R=3, S=2, W=32, n_ticks=40, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5, straggler_ticks=4, rotate=True)
+    _run(cuda, oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6, straggler_ticks=8, rotate=True)
+    _run(cuda, oracle, G=128, R=5, S=1, W=64, n_ticks=30, drop_p=0.05, timeout_frac=0.3, hb_every=4, preset=False, straggler_ticks=2, rotate=True)
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=8, straggler_ticks=4, every=3, rotate=True)
+    from summerset_amd import MultiPaxosCluster, SummersetError
+    with pytest.raises(SummersetError):                                           # it rides on the straggler mark pass
+        MultiPaxosCluster(64, 5, 64, outbox_cap=68).set_role_rotation(True)
