@@ -141,8 +141,9 @@ def _rs_cpu_run(a):
 def rse_sweep(torch, dev):
     """benches/rse_bench.rs:19-26: RS(3,2) over String values of 4 KiB ... 4 MiB.  Per size: batches of codewords sized to
     ~256 MB per launch, 3 batches in rotation.  `encode` = compute_parity alone on bytes already laid out as a codeword;
-    `from_data_and_encode` adds the from_data-equivalent work of the reference's loop body (rse_bench.rs:161-169): copying
-    the serialized bytes into the codeword buffer (a device copy stands in for bincode + allocation)."""
+    `from_data_and_encode` adds the from_data-equivalent work of the reference's loop body (rse_bench.rs:161-169): the
+    serialized bytes into the codeword's data shards (pad + split) -- in one pass with the parity product
+    (`smr_rs_from_data_encode`), and, for comparison, as round 2 did it: a device copy into the codeword buffer, then encode."""
     from summerset_amd import RSCodewordBatch
     out = []
     for size in (4096, 16 * 1024, 64 * 1024, 256 * 1024, 1024 * 1024, 4096 * 1024):
@@ -159,10 +160,19 @@ def rse_sweep(torch, dev):
             c.buf[:, :L].copy_(srcs[i % 3])                   # from_data: the serialized bytes into the shard buffer
             c.compute_parity()
         us_both = _time_us(torch, both, 9)
+        # round 3: from_data + compute_parity as ONE pass over the serialized bytes (smr_rs_from_data_encode) -- checked here
+        # against the two steps on the first batch, then timed
+        ref = cws[0].buf.clone()
+        RSCodewordBatch.from_data_and_encode(srcs[0], 3, 2, out=cws[0])
+        assert torch.equal(cws[0].buf, ref), "one-pass from_data + encode differs from from_data, compute_parity"
+        del ref
+        us_one = _time_us(torch, lambda i: RSCodewordBatch.from_data_and_encode(srcs[i % 3], 3, 2, out=cws[i % 3]), 9)
         sl = cws[0].shard_len
         out.append({"value_bytes": size, "codewords_per_launch": n, "encode_GiBps": n * L / 2**30 / (us_enc * 1e-6),
                     "encode_frac": n * 5 * sl / (us_enc * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "from_data_and_encode_GiBps": n * L / 2**30 / (us_both * 1e-6)})
+                    "from_data_and_encode_GiBps": n * L / 2**30 / (us_one * 1e-6),
+                    "from_data_and_encode_frac": n * (L + 5 * sl) / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "from_data_then_encode_two_steps_GiBps": n * L / 2**30 / (us_both * 1e-6)})
         del srcs, cws
     return out
 

@@ -1035,6 +1035,32 @@ int smr_wire_ingest_ep_pre_accept_replies(const uint8_t *buf_dev, uint64_t buf_l
                                           uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
                                           uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 
+int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                                       const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
+                                       uint64_t *ballot_dev, uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap,
+                                       uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream);
+/* (RSPaxos PeerMsg::AcceptReply { slot, ballot }, rspaxos/mod.rs:262-305 -> the [R][G] arrays smr_rsp_handle_accept_replies takes; same rules) */
+
+/* ---- reply frames written on the device (round 3; csrc/wire_emit.hip): the send half.  A follower's handler leaves its
+ * replies as device arrays; these calls write, for every reply, the frame TcpTransport would send -- `[u64 BE length]
+ * [bincode(PeerMessage::Msg { msg })]`, the bytes of smr_wire_accept_reply / smr_wire_raft_append_entries_reply /
+ * smr_wire_ep_msg -- into slot i of `frames_dev` (fixed stride, 8-byte aligned) and its length into len_dev[i] (0: no reply):
+ *   smr_wire_emit_mp_accept_replies      record i of smr_mp_collect_acks -> PeerMsg::AcceptReply { slot, ballot, reply_ts: None }
+ *   smr_wire_emit_raft_replies           group g of smr_raft_replica_handle_append_entries' reply arrays (flags bit0 = sent, bit1 =
+ *                                        conflict) -> PeerMsg::AppendEntriesReply { term, end_slot, conflict }
+ *   smr_wire_emit_ep_pre_accept_replies  group g of smr_ep_handle_pre_accept's reply (flags bit0 = sent; deps [R][G]) for the instance
+ *                                        (row, col[g]) -> PeerMsg::PreAcceptReply { slot, ballot, seq, deps }
+ * The socket layer (or an exchange's pack pass) sends len[i] bytes from frames + i * stride.  Only enqueue work on `stream`. */
+#define SMR_WIRE_EMIT_MP_STRIDE 32
+#define SMR_WIRE_EMIT_RAFT_STRIDE 48
+#define SMR_WIRE_EMIT_EP_STRIDE 96
+int smr_wire_emit_mp_accept_replies(const smr_mp_ack *acks_dev, uint64_t n, uint8_t *frames_dev, uint8_t *len_dev, void *stream);
+int smr_wire_emit_raft_replies(const uint8_t *flags_dev, const uint64_t *term_dev, const uint32_t *end_slot_dev, const uint64_t *conflict_term_dev,
+                               const uint32_t *conflict_slot_dev, uint32_t n_groups, uint8_t *frames_dev, uint8_t *len_dev, void *stream);
+int smr_wire_emit_ep_pre_accept_replies(const uint8_t *flags_dev, uint8_t row, const uint32_t *col_dev, const uint64_t *ballot_dev,
+                                        const uint64_t *seq_dev, const uint32_t *deps_dev, uint32_t n_groups, uint8_t population,
+                                        uint8_t *frames_dev, uint8_t *len_dev, void *stream);
+
 /* ---- request batching front-end (host only; src/server/external.rs:323-344 get_req_batch, :697-730 the batch
  * ticker): requests queue per group; one tick turns, for every group with queued requests, up to max_batch_size
  * of them (0 = all) into one ReqBatch, FIFO; groups with an empty queue get no batch. */

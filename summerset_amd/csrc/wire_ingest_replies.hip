@@ -4,6 +4,7 @@
 // smr_raft_tick, smr_ep_handle_pre_accept_replies -- so here the parser writes those arrays directly:
 //   Raft    PeerMsg::AppendEntriesReply { term, end_slot, conflict: Option<(Term, usize)> }   raft/mod.rs:203-234 (variant 1)
 //   EPaxos  PeerMsg::PreAcceptReply { slot: SlotIdx(row, col), ballot, seq, deps }             epaxos/mod.rs:306-377 (variant 1)
+//   RSPaxos PeerMsg::AcceptReply { slot, ballot }                                               rspaxos/mod.rs:262-305 (variant 3)
 // each inside `[u64 BE length][bincode(PeerMessage::Msg { msg })]` (safetcp.rs:30-70, 127-132), with the rules of the
 // host's smr_wire_raft_decode / smr_wire_ep_decode (csrc/wire.hip) restated for a lane.
 //
@@ -82,7 +83,7 @@ struct ReplyArgs {
     uint64_t *consumed; int32_t *status;
 };
 
-constexpr int WR_RAFT = 0, WR_EPAXOS = 1;
+constexpr int WR_RAFT = 0, WR_EPAXOS = 1, WR_RSPAXOS = 2;
 constexpr uint32_t WR_EMAXR = 8;
 
 template <int PROTO>
@@ -149,6 +150,21 @@ __global__ __launch_bounds__(WR_BLOCK) void wire_ingest_replies_kernel(ReplyArgs
                         const size_t i = (size_t)peer * A.G + g;
                         A.a[i] = term; A.b[i] = (uint32_t)end_slot; A.c[i] = ct; A.d[i] = (uint32_t)cs;
                         A.flags[i] = (uint8_t)(1u | (has ? 2u : 0u));
+                        have = true;
+                    }
+                }
+            } else if (PROTO == WR_RSPAXOS) {
+                if (!r.ok) { st = 1; break; }
+                kind = (uint32_t)(v <= SMR_WIRE_RSP_HEARTBEAT ? v : SMR_WIRE_OTHER);
+                if (v == SMR_WIRE_ACCEPT_REPLY) {                                   // AcceptReply { slot, ballot }: smr_rsp_handle_accept_replies' arrays
+                    const uint64_t slot = r.varint(), ballot = r.varint();
+                    if (!r.ok || r.n != r.end) { st = 1; break; }
+                    mine = slot <= 0xFFFFFFFFull;
+                    if (mine) {
+                        if (have) { deferred = true; break; }
+                        const size_t i = (size_t)peer * A.G + g;
+                        A.a[i] = ballot; A.b[i] = (uint32_t)slot;
+                        A.flags[i] = 1;
                         have = true;
                     }
                 }
@@ -249,6 +265,24 @@ int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const
     ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, reply_term_dev, end_slot_dev,
                 conflict_term_dev, conflict_slot_dev, flags_dev, 0, nullptr, others_dev, other_cap, counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_replies_kernel<WR_RAFT>, dim3((n_conn + WR_BLOCK - 1) / WR_BLOCK), dim3(WR_BLOCK), 0, st, A);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                                       const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
+                                       uint64_t *ballot_dev, uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap,
+                                       uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream) {
+    const int rc = reply_args_ok(buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, ballot_dev, slot_dev,
+                                 ballot_dev, slot_dev, flags_dev, others_dev, other_cap, counts_dev, consumed_dev, status_dev);
+    if (rc != SMR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
+    SMR_HIP_TRY(hipMemsetAsync(flags_dev, 0, (size_t)population * n_groups, st));
+    if (n_conn == 0) return SMR_OK;
+    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, ballot_dev, slot_dev,
+                nullptr, nullptr, flags_dev, 0, nullptr, others_dev, other_cap, counts_dev, consumed_dev, status_dev};
+    hipLaunchKernelGGL(wire_ingest_replies_kernel<WR_RSPAXOS>, dim3((n_conn + WR_BLOCK - 1) / WR_BLOCK), dim3(WR_BLOCK), 0, st, A);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -482,9 +482,53 @@ class ReplyIngest:
                                                             p(self.counts), p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
         return dict(ballot=self.u64a, seq=self.u64b, deps=self.deps, flags=self.flags)
 
+    def rsp_accept(self, buf, conn_off, conn_group, conn_peer, stream=None):
+        """RSPaxos AcceptReplies -> dict(slot, ballot, flags) [R, G] for `RSPaxosReplicaGroup.accept_replies`"""
+        p = lambda t: t.data_ptr()   # noqa: E731
+        check(self._L.smr_wire_ingest_rsp_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer), p(self.u32a), p(self.u64a), p(self.flags),
+                                                         p(self.others), self.other_cap, p(self.counts), p(self.consumed), p(self.status),
+                                                         _lib.stream_ptr(stream)))
+        return dict(slot=self.u32a, ballot=self.u64a, flags=self.flags)
+
     def results(self):
         """host copies (synchronises): counts, located frames, consumed, status"""
         n = [int(x) for x in self.counts.cpu().tolist()]
         return {"n_replies": n[0], "n_others": n[1], "n_malformed": n[2], "n_deferred": n[3],
                 "others": self.others.cpu().numpy().view(OTHER_DTYPE)[:min(n[1], self.other_cap)].copy(),
                 "consumed": self.consumed.cpu().numpy()[:self.n_conn].copy(), "status": self.status.cpu().numpy()[:self.n_conn].copy()}
+
+
+# ---- reply frames written on the device (csrc/wire_emit.hip) ----
+EMIT_MP_STRIDE, EMIT_RAFT_STRIDE, EMIT_EP_STRIDE = 32, 48, 96
+
+
+def _emit_out(n, stride, device):
+    import torch
+    return (torch.zeros((max(n, 1), stride), dtype=torch.uint8, device=device), torch.zeros(max(n, 1), dtype=torch.uint8, device=device))
+
+
+def emit_mp_accept_replies(acks, n, stream=None):
+    """acks: device uint8 tensor of `n` smr_mp_ack records (what `MultiPaxosCluster.collect_acks` fills) -> (frames uint8 [n, 32],
+    len uint8 [n]): record i as the AcceptReply frame the follower would send"""
+    frames, ln = _emit_out(n, EMIT_MP_STRIDE, acks.device)
+    check(_lib.load().smr_wire_emit_mp_accept_replies(acks.data_ptr(), int(n), frames.data_ptr(), ln.data_ptr(), _lib.stream_ptr(stream)))
+    return frames, ln
+
+
+def emit_raft_replies(flags, term, end_slot, conflict_term, conflict_slot, stream=None):
+    """the [G] reply tensors of `RaftLeaderGroup.handle_msg_append_entries` -> (frames uint8 [G, 48], len uint8 [G])"""
+    G = int(flags.numel())
+    frames, ln = _emit_out(G, EMIT_RAFT_STRIDE, flags.device)
+    check(_lib.load().smr_wire_emit_raft_replies(flags.data_ptr(), term.data_ptr(), end_slot.data_ptr(), conflict_term.data_ptr(),
+                                                 conflict_slot.data_ptr(), G, frames.data_ptr(), ln.data_ptr(), _lib.stream_ptr(stream)))
+    return frames, ln
+
+
+def emit_ep_pre_accept_replies(flags, row, col, ballot, seq, deps, stream=None):
+    """the [G] reply tensors of `EPaxosReplicaGroup.handle_msg_pre_accept` (deps [R, G]) for the instances (row, col[g]) ->
+    (frames uint8 [G, 96], len uint8 [G])"""
+    G, R = int(flags.numel()), int(deps.shape[0])
+    frames, ln = _emit_out(G, EMIT_EP_STRIDE, flags.device)
+    check(_lib.load().smr_wire_emit_ep_pre_accept_replies(flags.data_ptr(), int(row), col.data_ptr(), ballot.data_ptr(), seq.data_ptr(),
+                                                          deps.data_ptr(), G, R, frames.data_ptr(), ln.data_ptr(), _lib.stream_ptr(stream)))
+    return frames, ln

@@ -167,6 +167,20 @@ def test_reply_ingest_kernels_on_the_host(sim, oracle):
         t.test_ep_cluster_pre_accept_replies_over_the_wire("cpu", oracle)
 
 
+def test_wire_emit_kernels_on_the_host(sim, oracle):
+    """reply frames written by kernels (f.1, the send half): byte for byte what the test lays out, back through the ingest
+    kernels, and as the senders of the Raft / EPaxos closed loops"""
+    import test_zz_wire_emit_gpu as t
+    with sim.patched():
+        t.test_mp_accept_reply_frames("cpu")
+        t.test_raft_reply_frames("cpu")
+        for R in (3, 5, 7):
+            t.test_ep_pre_accept_reply_frames("cpu", R)
+        t.test_rsp_accept_replies_ingest("cpu")
+        t.test_raft_cluster_with_emitted_replies("cpu", oracle)
+        t.test_ep_cluster_with_emitted_replies("cpu", oracle)
+
+
 def test_rs_kernels_on_the_host(sim, oracle):
     import test_rs_gpu as t
     with sim.patched():
