@@ -1478,6 +1478,10 @@ def main():
             l2 = {"layout": "spread (SURVEY 8e L2): replica r of block b on rank (b + r) mod N", "ranks": x["config"]["spread_ranks"],
                   "ranks_are": x["config"]["ranks_are"], "value": x["value"], "unit": "slots/s", "ms_per_tick": x["ms_per_step"],
                   "steps": x["steps"], "warmup": x["warmup"], "exchange": x["exchange"], "backend": x["backend"]}
+            if world == 1:                         # all the virtual ranks' kernels ran one after the other on this ONE GPU
+                l2["ms_per_tick_per_virtual_rank"] = x["ms_per_step"] / max(x["config"]["spread_ranks"], 1)
+                l2["note"] = ("virtual ranks share one GPU and one stream order: ms_per_tick is the SUM of the ranks' work (each holds "
+                              "groups / ranks groups' five replicas in pieces); a rank's share = ms_per_tick / ranks, before the wire")
         except Exception as e:                     # noqa: BLE001 -- never at the headline's cost; named in legs_failed
             l2 = {"error": "%s: %s" % (type(e).__name__, e)}
             sys.stderr.write("bench.py: the l2 pass FAILED: %s: %s\n" % (type(e).__name__, e))
