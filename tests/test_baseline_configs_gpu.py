@@ -249,3 +249,47 @@ def run_epaxos_slices(cuda, oracle, G, W, K, T, width, n_slices, execute=True, l
 
 def test_config4_epaxos_65536_groups_all_replicas_propose(cuda, oracle):
     run_epaxos_slices(cuda, oracle, G=65536, W=16, K=64, T=8, width=512, n_slices=6)
+
+
+def run_epaxos_cluster_slices(cuda, oracle, G, W, K, T, width, n_slices, phase_major, loss=0.1):
+    """BASELINE config 5 through `smr_ep_cluster_tick` -- the whole tick ONE launch -- at full size, against five oracles per
+    slice wired into tests/ep_cluster.py's loop in the same order: every leader's outputs every tick, every replica's protocol
+    and execution state at the end"""
+    import torch
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup, ep_cluster
+    R = 5
+    sl = _slices(G, width, n_slices, seed=G + K + 1)
+    reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    job = ep_cluster.EPaxosCluster(reps, phase_major=phase_major)
+    orcs = [[oracle.EpOracle(n, R, me=r, W=W, n_keys=K, execute=True) for r in range(R)] for _, n in sl]
+    rng = np.random.default_rng(G + W + 1)
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)   # noqa: E731
+    fast = slow = 0
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): rng.random(G) < loss for s in range(R) for q in range(R) if s != q}
+        oe = job.tick([dv(keys[r]) for r in range(R)], {k: dv(v) for k, v in drop.items()})
+        oe = [{k: v.cpu().numpy() for k, v in o.items()} for o in oe]
+        for (g0, n), oc in zip(sl, orcs):
+            oo = ec.tick(oc, np.ascontiguousarray(keys[:, g0:g0 + n]), {k: v[g0:g0 + n] for k, v in drop.items()}, phase_major=phase_major)
+            for s in range(R):
+                for k in oo[s]:
+                    assert np.array_equal(oe[s][k][..., g0:g0 + n].view(oo[s][k].dtype), oo[s][k]), (t, g0, s, k)
+                fast += int((oo[s]["decision"] == 3).sum())
+                slow += int((oo[s]["decision"] == 2).sum())
+    full = [(e.dump(), e.exec_dump()) for e in reps]
+    for (g0, n), oc in zip(sl, orcs):
+        for r in range(R):
+            for a, b in ((_cut(full[r][0], G, g0, n), _cut(oc[r].dump(), n, 0, n)), (_cut(full[r][1], G, g0, n), _cut(oc[r].exec_dump(), n, 0, n))):
+                assert set(a) == set(b)
+                for name in b:
+                    assert np.array_equal(a[name], b[name]), (g0, r, name)
+    job.close()
+    assert fast > 0 and slow > 0
+
+
+@pytest.mark.parametrize("phase_major", [False, True])
+def test_config5_epaxos_65536_groups_one_launch(cuda, oracle, phase_major):
+    """the one-launch cluster tick at BASELINE config 5's size, in the loops' order and with the leaders' steps phase by phase"""
+    run_epaxos_cluster_slices(cuda, oracle, G=65536, W=16, K=64, T=8, width=512, n_slices=4, phase_major=phase_major)

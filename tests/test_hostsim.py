@@ -257,6 +257,8 @@ def test_baseline_config_slice_tests_on_the_host(sim, oracle):
         assert changed > 0 and total > 0
         t.run_rspaxos_slices("cpu", oracle, G=256, W=16, T=12, ft=1, loss=0.05, width=64, n_slices=3)
         t.run_epaxos_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=3)
+        for pm in (False, True):                                # the one-launch cluster tick against oracle slices, both orders
+            t.run_epaxos_cluster_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=2, phase_major=pm)
 
 
 def test_fused_tick_kernel_on_the_host(sim, oracle):
