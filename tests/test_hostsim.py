@@ -163,6 +163,7 @@ def test_reply_ingest_kernels_on_the_host(sim, oracle):
     with sim.patched():
         t.test_raft_replies_frame_by_frame("cpu")
         t.test_ep_pre_accept_replies_frame_by_frame("cpu")
+        t.test_reply_ingest_argument_edges("cpu")
         t.test_raft_cluster_replies_over_the_wire("cpu", oracle)
         t.test_ep_cluster_pre_accept_replies_over_the_wire("cpu", oracle)
 

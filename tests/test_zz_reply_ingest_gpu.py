@@ -309,3 +309,42 @@ def test_ep_cluster_pre_accept_replies_over_the_wire(cuda, oracle):
         for n in b:
             assert np.array_equal(a[n], b[n]), (r, n)
     assert fast > 0 and slow > 0
+
+
+def test_reply_ingest_argument_edges(cuda):
+    """no connections at all; a connection whose group / peer the arrays have no place for (malformed, nothing taken); located
+    frames beyond `other_cap` are counted, not stored; a byte buffer that is not 16-byte aligned is refused; more connections in
+    a block's span than its stage holds (the lanes behind read from the buffer)"""
+    import torch
+    from summerset_amd import SummersetError, wire
+    G, R = 40, 5
+    ing = wire.ReplyIngest(0, G, R, 4, cuda)
+    z = torch.zeros(0, dtype=torch.uint8, device=cuda)
+    o = ing.raft(z, torch.zeros(1, dtype=torch.int64, device=cuda), torch.zeros(0, dtype=torch.int32, device=cuda), z)
+    assert int(o["flags"].sum().item()) == 0 and ing.results()["n_replies"] == 0
+    # out-of-range descriptors, an other_cap of 2 against 5 located frames
+    junk = _frame(_varint(1) + b"abc")
+    streams = [_raft_reply(3, 4), _raft_reply(5, 6), _raft_reply(7, 8), junk * 5 + _raft_reply(9, 10)]
+    buf, off, grp, peer, _ = _layout(torch, cuda, streams, [1, G, 2, 3], [1, 1, R, 2])
+    ing = wire.ReplyIngest(4, G, R, 2, cuda)
+    o = {k: v.cpu().numpy() for k, v in ing.raft(buf, off, grp, peer).items()}
+    res = ing.results()
+    assert list(res["status"]) == [0, 1, 1, 0] and list(res["consumed"]) == [len(streams[0]), 0, 0, len(streams[3])]
+    assert res["n_replies"] == 2 and res["n_malformed"] == 2 and res["n_others"] == 5 and len(res["others"]) == 2
+    assert o["flags"].sum() == 2 and o["flags"][1, 1] == 1 and o["flags"][2, 3] == 1 and int(o["end_slot"][2, 3]) == 10
+    # alignment
+    big = torch.zeros(64, dtype=torch.uint8, device=cuda)
+    with pytest.raises(SummersetError):
+        ing.raft(big[1:33], off, grp, peer)
+    # a block of 1024 connections whose streams span more than the 32 KB a block stages: 60-byte filler in front of every reply
+    n = 1100
+    fill = _frame(_varint(1) + bytes(51))
+    streams = [fill + _raft_reply(100 + c, c) for c in range(n)]
+    buf, off, grp, peer, _ = _layout(torch, cuda, streams, np.arange(n) % G, np.ones(n, np.int64))
+    ing = wire.ReplyIngest(n, G, R, n, cuda)
+    o = {k: v.cpu().numpy() for k, v in ing.raft(buf, off, grp, peer).items()}
+    res = ing.results()
+    assert res["n_replies"] == n and res["n_others"] == n and res["n_malformed"] == 0 and list(res["consumed"]) == [len(x) for x in streams]
+    assert sum(len(x) for x in streams[:1024]) > 32 * 1024
+    last = {g: max(c for c in range(n) if c % G == g) for g in range(G)}          # (several connections per (group, peer): the caller's error -- one wins)
+    assert all(int(o["end_slot"][1, g]) % G == g for g in range(G)) and set(int(o["reply_term"][1, g]) - 100 for g in range(G)) <= set(range(n)) and last
