@@ -919,9 +919,25 @@ def reply_ingest_leg(torch, dev, G=65536, R=5, iters=12, junk_every=16):
     assert r["n_replies"] == n_conn and r["n_others"] == (n_conn // junk_every if junk_every else 0) and r["n_malformed"] == 0 and (r["consumed"] == lens).all()
     assert int(o["flags"][1:].sum().item()) == n_conn + 2 * (n_conn // 8) and int(o["end_slot"][1, 5].item()) == 70000
     us = _time_us(torch, lambda i: ing.raft(buf, d_off, d_grp, d_peer), iters)
+    # the follower side + the leader side without leaving the device: reply arrays -> frames (smr_wire_emit_raft_replies, one slot per
+    # reply) -> the leader's arrays (the slots as connections: conn_off = slot starts, conn_len = the emitted lengths)
+    fl = torch.where(torch.arange(n_conn, device=dev) % 8 == 0, 3, 1).to(torch.uint8)
+    term = torch.full((n_conn,), 3, dtype=torch.int64, device=dev)
+    es = torch.full((n_conn,), 70000, dtype=torch.int32, device=dev)
+    ct, cs = torch.full((n_conn,), 2, dtype=torch.int64, device=dev), torch.full((n_conn,), 69000, dtype=torch.int32, device=dev)
+    slot_off = torch.arange(n_conn, dtype=torch.int64, device=dev) * wire.EMIT_RAFT_STRIDE
+
+    def loop(i):
+        frames, ln = wire.emit_raft_replies(fl, term, es, ct, cs)
+        ing.raft(frames.view(-1), slot_off, d_grp, d_peer, conn_len=ln)
+    loop(0)
+    r2 = ing.results()
+    assert r2["n_replies"] == n_conn and r2["n_malformed"] == 0 and int(o["flags"][1:].sum().item()) == n_conn + 2 * (n_conn // 8)
+    us_loop = _time_us(torch, loop, iters)
     alg = int(off[-1]) + n_conn * (8 + 4 + 1) + (n_conn // 8) * 12
     return {"workload": "Raft leader-side receive path of one tick: %d connections (%d groups x %d followers), one AppendEntriesReply each -> the "
                         "[R][G] reply arrays" % (n_conn, G, R - 1), "value": n_conn / (us * 1e-6), "unit": "AppendEntriesReply frames/s", "call_us": us,
+            "emit_then_ingest_us": us_loop,
             "roofline": {"bound": "hbm", "kernel": "wire_ingest_replies_kernel<0> (+ two memsets: one smr_wire_ingest_raft_replies call)",
                          "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": alg, "avg_launch_us": us, "traffic": _leg_traffic("smr::wire_ingest_replies_kernel<0>"),

@@ -1022,21 +1022,24 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
  * end where its length says) makes its connection malformed: status_dev[c] = 1, consumed_dev[c] = 0, nothing of it
  * counts (a reply it delivered before stays in the arrays); counts_dev[2] = such connections.  counts_dev[0] = the
  * replies taken.  flags_dev is zeroed by the call; the other arrays are only written where flags says so.  Two connections
- * with the same (group, peer): the caller's error (one of them wins).  buf_dev must be 16-byte aligned.  Only enqueues work
- * on `stream`. */
+ * with the same (group, peer): the caller's error (one of them wins).  buf_dev must be 16-byte aligned.  conn_len_dev (may be
+ * NULL): the length of every connection's bytes where they do not lie back to back -- connection c is then
+ * buf_dev[conn_off[c] .. conn_off[c] + conn_len[c]) and conn_off needs n_conn entries, ascending; this is the layout the emit
+ * calls below leave (slot i at i * stride, len_dev[i] bytes), so replies can go from a follower's arrays through frames into
+ * the leader's arrays without leaving the device.  Only enqueues work on `stream`. */
 int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                 const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population,
+                                 const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population,
                                  uint64_t *reply_term_dev, uint32_t *end_slot_dev, uint64_t *conflict_term_dev, uint32_t *conflict_slot_dev,
                                  uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
                                  uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 int smr_wire_ingest_ep_pre_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                          const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint8_t me,
+                                          const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint8_t me,
                                           const uint32_t *col_dev, uint64_t *ballot_dev, uint64_t *seq_dev, uint32_t *deps_dev,
                                           uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
                                           uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 
 int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                       const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
+                                       const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
                                        uint64_t *ballot_dev, uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap,
                                        uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 /* (RSPaxos PeerMsg::AcceptReply { slot, ballot }, rspaxos/mod.rs:262-305 -> the [R][G] arrays smr_rsp_handle_accept_replies takes; same rules) */

@@ -340,12 +340,12 @@ SYMBOLS = [
     ("smr_wire_ep_decode", C.c_int64, [_vp, _u64, C.POINTER(WireEpMsg), _vp, _u32]),
     ("smr_wire_ingest_scratch_bytes", _u64, [_u32]),
     ("smr_wire_ingest_mp", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
-    ("smr_wire_ingest_raft_replies", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
-    ("smr_wire_ingest_rsp_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u8, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("smr_wire_ingest_raft_replies", _i, [_vp, _u64, _vp, _vp, _vp, _vp, _u32, _u32, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    ("smr_wire_ingest_rsp_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp, _vp, _u32, _u32, _u8, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("smr_wire_emit_mp_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp]),
     ("smr_wire_emit_raft_replies", _i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     ("smr_wire_emit_ep_pre_accept_replies", _i, [_vp, _u8, _vp, _vp, _vp, _vp, _u32, _u8, _vp, _vp, _vp]),
-    ("smr_wire_ingest_ep_pre_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp, _u32, _u32, _u8, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp,
+    ("smr_wire_ingest_ep_pre_accept_replies", _i, [_vp, _u64, _vp, _vp, _vp, _vp, _u32, _u32, _u8, _u8, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp,
                                                    _vp]),
     ("smr_batcher_create", _i, [_u32, _u32, C.POINTER(_vp)]),
     ("smr_batcher_destroy", None, [_vp]),

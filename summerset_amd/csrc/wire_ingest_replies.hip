@@ -74,6 +74,7 @@ struct GlRd {
 struct ReplyArgs {
     const uint8_t *buf; uint64_t buf_len;
     const uint64_t *conn_off; const uint32_t *conn_group; const uint8_t *conn_peer; uint32_t n_conn;
+    const uint8_t *conn_len;                     // NULL: connection c ends where c + 1 starts; else its bytes are conn_off[c] .. + conn_len[c]
     uint32_t G, R;
     // Raft: reply_term, end_slot, conflict_term, conflict_slot, flags.  EPaxos: ballot (in a), seq (in c), deps, flags; me, col
     uint64_t *a; uint32_t *b; uint64_t *c; uint32_t *d; uint8_t *flags;
@@ -95,10 +96,10 @@ __global__ __launch_bounds__(WR_BLOCK) void wire_ingest_replies_kernel(ReplyArgs
     if (threadIdx.x < 4) blk[threadIdx.x] = 0;
     const uint32_t c = blockIdx.x * WR_BLOCK + threadIdx.x;
     const bool live = c < A.n_conn;
-    const uint64_t start = live ? A.conn_off[c] : 0, end = live ? A.conn_off[c + 1] : 0;
+    const uint64_t start = live ? A.conn_off[c] : 0, end = !live ? 0 : A.conn_len ? start + A.conn_len[c] : A.conn_off[c + 1];
     // my block's span of the buffer -> LDS: from its first connection's start (16-byte aligned down) as far as the stage goes
     const uint32_t c0 = blockIdx.x * WR_BLOCK, c1 = c0 + WR_BLOCK < A.n_conn ? c0 + WR_BLOCK : A.n_conn;
-    const uint64_t s0 = A.conn_off[c0] & ~15ull, s1 = A.conn_off[c1];
+    const uint64_t s0 = A.conn_off[c0] & ~15ull, s1 = A.conn_len ? A.conn_off[c1 - 1] + A.conn_len[c1 - 1] : A.conn_off[c1];
     uint64_t slo = 0, shi = 0;
     if (s0 < s1 && s1 <= A.buf_len) {
         slo = s0; shi = s1 - s0 <= WR_STAGE ? s1 : s0 + WR_STAGE;
@@ -250,7 +251,7 @@ using namespace smr;
 extern "C" {
 
 int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                 const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population,
+                                 const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population,
                                  uint64_t *reply_term_dev, uint32_t *end_slot_dev, uint64_t *conflict_term_dev, uint32_t *conflict_slot_dev,
                                  uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
                                  uint64_t *consumed_dev, int32_t *status_dev, void *stream) {
@@ -262,7 +263,7 @@ int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const
     SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
     SMR_HIP_TRY(hipMemsetAsync(flags_dev, 0, (size_t)population * n_groups, st));
     if (n_conn == 0) return SMR_OK;
-    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, reply_term_dev, end_slot_dev,
+    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, conn_len_dev, n_groups, population, reply_term_dev, end_slot_dev,
                 conflict_term_dev, conflict_slot_dev, flags_dev, 0, nullptr, others_dev, other_cap, counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_replies_kernel<WR_RAFT>, dim3((n_conn + WR_BLOCK - 1) / WR_BLOCK), dim3(WR_BLOCK), 0, st, A);
     SMR_HIP_TRY(hipGetLastError());
@@ -270,7 +271,7 @@ int smr_wire_ingest_raft_replies(const uint8_t *buf_dev, uint64_t buf_len, const
 }
 
 int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                       const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
+                                       const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint32_t *slot_dev,
                                        uint64_t *ballot_dev, uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap,
                                        uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream) {
     const int rc = reply_args_ok(buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, ballot_dev, slot_dev,
@@ -280,7 +281,7 @@ int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len,
     SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
     SMR_HIP_TRY(hipMemsetAsync(flags_dev, 0, (size_t)population * n_groups, st));
     if (n_conn == 0) return SMR_OK;
-    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, ballot_dev, slot_dev,
+    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, conn_len_dev, n_groups, population, ballot_dev, slot_dev,
                 nullptr, nullptr, flags_dev, 0, nullptr, others_dev, other_cap, counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_replies_kernel<WR_RSPAXOS>, dim3((n_conn + WR_BLOCK - 1) / WR_BLOCK), dim3(WR_BLOCK), 0, st, A);
     SMR_HIP_TRY(hipGetLastError());
@@ -288,7 +289,7 @@ int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len,
 }
 
 int smr_wire_ingest_ep_pre_accept_replies(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                                          const uint8_t *conn_peer_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint8_t me,
+                                          const uint8_t *conn_peer_dev, const uint8_t *conn_len_dev, uint32_t n_conn, uint32_t n_groups, uint8_t population, uint8_t me,
                                           const uint32_t *col_dev, uint64_t *ballot_dev, uint64_t *seq_dev, uint32_t *deps_dev,
                                           uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap, uint64_t *counts_dev,
                                           uint64_t *consumed_dev, int32_t *status_dev, void *stream) {
@@ -300,7 +301,7 @@ int smr_wire_ingest_ep_pre_accept_replies(const uint8_t *buf_dev, uint64_t buf_l
     SMR_HIP_TRY(hipMemsetAsync(counts_dev, 0, 4 * 8, st));
     SMR_HIP_TRY(hipMemsetAsync(flags_dev, 0, (size_t)population * n_groups, st));
     if (n_conn == 0) return SMR_OK;
-    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, n_groups, population, ballot_dev, nullptr,
+    ReplyArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, conn_len_dev, n_groups, population, ballot_dev, nullptr,
                 seq_dev, deps_dev, flags_dev, me, col_dev, others_dev, other_cap, counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_replies_kernel<WR_EPAXOS>, dim3((n_conn + WR_BLOCK - 1) / WR_BLOCK), dim3(WR_BLOCK), 0, st, A);
     SMR_HIP_TRY(hipGetLastError());

@@ -460,32 +460,36 @@ class ReplyIngest:
         self.consumed = z(max(self.n_conn, 1), torch.int64)
         self.status = z(max(self.n_conn, 1), torch.int32)
 
-    def _conn(self, buf, conn_off, conn_group, conn_peer):
-        assert conn_off.numel() == self.n_conn + 1 and conn_group.numel() == self.n_conn and conn_peer.numel() == self.n_conn
+    def _conn(self, buf, conn_off, conn_group, conn_peer, conn_len=None):
+        """conn_len (uint8 [n_conn], optional): connection c = buf[conn_off[c] : conn_off[c] + conn_len[c]] (the emit calls'
+        layout: frames.view(-1), conn_off = arange * stride, conn_len = len) instead of back-to-back streams"""
+        assert conn_off.numel() >= self.n_conn + (conn_len is None) and conn_group.numel() == self.n_conn and conn_peer.numel() == self.n_conn
         assert conn_off.element_size() == 8 and conn_group.element_size() == 4 and conn_peer.element_size() == 1
+        assert conn_len is None or (conn_len.numel() == self.n_conn and conn_len.element_size() == 1)
         p = lambda t: t.data_ptr()   # noqa: E731
-        return (p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_group), p(conn_peer), self.n_conn, self.G, self.R)
+        return (p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_group), p(conn_peer), None if conn_len is None else p(conn_len),
+                self.n_conn, self.G, self.R)
 
-    def raft(self, buf, conn_off, conn_group, conn_peer, stream=None):
+    def raft(self, buf, conn_off, conn_group, conn_peer, stream=None, conn_len=None):
         p = lambda t: t.data_ptr()   # noqa: E731
-        check(self._L.smr_wire_ingest_raft_replies(*self._conn(buf, conn_off, conn_group, conn_peer), p(self.u64a), p(self.u32a), p(self.u64b),
+        check(self._L.smr_wire_ingest_raft_replies(*self._conn(buf, conn_off, conn_group, conn_peer, conn_len), p(self.u64a), p(self.u32a), p(self.u64b),
                                                    p(self.u32b), p(self.flags), p(self.others), self.other_cap, p(self.counts),
                                                    p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
         return dict(reply_term=self.u64a, end_slot=self.u32a, conflict_term=self.u64b, conflict_slot=self.u32b, flags=self.flags)
 
-    def ep_pre_accept(self, buf, conn_off, conn_group, conn_peer, me, col, stream=None):
+    def ep_pre_accept(self, buf, conn_off, conn_group, conn_peer, me, col, stream=None, conn_len=None):
         """col: int32 / uint32 [G] on the device -- the column of MY instance every group's replies are for"""
         p = lambda t: t.data_ptr()   # noqa: E731
         assert col.numel() == self.G and col.element_size() == 4
-        check(self._L.smr_wire_ingest_ep_pre_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer), int(me), p(col), p(self.u64a),
+        check(self._L.smr_wire_ingest_ep_pre_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer, conn_len), int(me), p(col), p(self.u64a),
                                                             p(self.u64b), p(self.deps), p(self.flags), p(self.others), self.other_cap,
                                                             p(self.counts), p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
         return dict(ballot=self.u64a, seq=self.u64b, deps=self.deps, flags=self.flags)
 
-    def rsp_accept(self, buf, conn_off, conn_group, conn_peer, stream=None):
+    def rsp_accept(self, buf, conn_off, conn_group, conn_peer, stream=None, conn_len=None):
         """RSPaxos AcceptReplies -> dict(slot, ballot, flags) [R, G] for `RSPaxosReplicaGroup.accept_replies`"""
         p = lambda t: t.data_ptr()   # noqa: E731
-        check(self._L.smr_wire_ingest_rsp_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer), p(self.u32a), p(self.u64a), p(self.flags),
+        check(self._L.smr_wire_ingest_rsp_accept_replies(*self._conn(buf, conn_off, conn_group, conn_peer, conn_len), p(self.u32a), p(self.u64a), p(self.flags),
                                                          p(self.others), self.other_cap, p(self.counts), p(self.consumed), p(self.status),
                                                          _lib.stream_ptr(stream)))
         return dict(slot=self.u32a, ballot=self.u64a, flags=self.flags)

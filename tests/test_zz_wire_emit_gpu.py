@@ -59,7 +59,8 @@ def test_raft_reply_frames(cuda):
     ct = np.array([_pick(rng, True) for _ in range(G)], np.uint64)
     cs = np.array([_pick(rng) for _ in range(G)], np.uint32)
     dv = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else (a.view(np.int32) if a.dtype == np.uint32 else a)).to(cuda)   # noqa: E731
-    fr = _frames(*wire.emit_raft_replies(dv(flags), dv(term), dv(es), dv(ct), dv(cs)))
+    frames_dev, len_dev = wire.emit_raft_replies(dv(flags), dv(term), dv(es), dv(ct), dv(cs))
+    fr = _frames(frames_dev, len_dev)
     for g in range(G):
         if not flags[g] & 1:
             assert fr[g] == b""
@@ -77,6 +78,14 @@ def test_raft_reply_frames(cuda):
     assert np.array_equal(o["reply_term"][2].view(np.uint64)[m], term[m]) and np.array_equal(o["end_slot"][2].view(np.uint32)[m], es[m])
     mc = (flags & 2) != 0
     assert np.array_equal(o["conflict_term"][2].view(np.uint64)[mc], ct[mc]) and np.array_equal(o["conflict_slot"][2].view(np.uint32)[mc], cs[mc])
+    # ... and without leaving the device: the emit call's slots ARE the connections (conn_off = slot starts, conn_len = len)
+    ing2 = wire.ReplyIngest(G, G, R, 16, cuda)
+    slot_off = torch.arange(G, dtype=torch.int64, device=frames_dev.device) * wire.EMIT_RAFT_STRIDE
+    o2 = {k: v.cpu().numpy() for k, v in ing2.raft(frames_dev.view(-1), slot_off, grp, peer, conn_len=len_dev).items()}
+    assert ing2.results()["n_replies"] == int(m.sum()) and np.array_equal(ing2.results()["consumed"], len_dev.cpu().numpy())
+    for k in o:
+        assert np.array_equal(np.where(o["flags"] != 0, o[k], 0) if k != "flags" and "conflict" not in k else np.where((o["flags"] & (2 if "conflict" in k else 1)) != 0, o[k], 0),
+                              np.where(o2["flags"] != 0, o2[k], 0) if k != "flags" and "conflict" not in k else np.where((o2["flags"] & (2 if "conflict" in k else 1)) != 0, o2[k], 0)), k
 
 
 @pytest.mark.parametrize("R", [3, 5, 7])
@@ -91,7 +100,8 @@ def test_ep_pre_accept_reply_frames(cuda, R):
     seq = np.array([_pick(rng, True) for _ in range(G)], np.uint64)
     deps = np.array([[NONE32 if rng.random() < 0.3 else min(_pick(rng), NONE32 - 1) for _ in range(G)] for _ in range(R)], np.uint32)
     dv = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else (np.int32 if a.dtype == np.uint32 else a.dtype))).to(cuda)   # noqa: E731
-    fr = _frames(*wire.emit_ep_pre_accept_replies(dv(flags), row, dv(col), dv(ballot), dv(seq), dv(deps)))
+    frames_dev, len_dev = wire.emit_ep_pre_accept_replies(dv(flags), row, dv(col), dv(ballot), dv(seq), dv(deps))
+    fr = _frames(frames_dev, len_dev)
     for g in range(G):
         if not flags[g]:
             assert fr[g] == b""
@@ -108,6 +118,12 @@ def test_ep_pre_accept_reply_frames(cuda, R):
     assert np.array_equal(o["flags"][q], flags)
     assert np.array_equal(o["ballot"][q].view(np.uint64)[m], ballot[m]) and np.array_equal(o["seq"][q].view(np.uint64)[m], seq[m])
     assert np.array_equal(o["deps"][q].view(np.uint32)[:, m], deps[:, m])
+    # the emit call's slots as the connections: no host in the loop
+    ing2 = wire.ReplyIngest(G, G, R, 16, cuda)
+    slot_off = torch.arange(G, dtype=torch.int64, device=frames_dev.device) * wire.EMIT_EP_STRIDE
+    o2 = {k: v.cpu().numpy() for k, v in ing2.ep_pre_accept(frames_dev.view(-1), slot_off, grp, peer, row, dv(col), conn_len=len_dev).items()}
+    assert ing2.results()["n_replies"] == int(m.sum()) and np.array_equal(o2["flags"], o["flags"])
+    assert np.array_equal(o2["ballot"][q][m], o["ballot"][q][m]) and np.array_equal(o2["seq"][q][m], o["seq"][q][m]) and np.array_equal(o2["deps"][q][:, m], o["deps"][q][:, m])
 
 
 def test_rsp_accept_replies_ingest(cuda):
