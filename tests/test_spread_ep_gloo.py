@@ -32,7 +32,7 @@ def _inputs(t):
     return keys, drop
 
 
-def _worker(rank, world, port, out_dir, execute):
+def _worker(rank, world, port, out_dir, execute, ordered):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir, execute):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tn = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     with hostsim.patched():
-        job = spread_ep.SpreadEPaxos(G, R, rank, world, "cpu", window=W, n_keys=K, execute=execute)
+        job = spread_ep.SpreadEPaxos(G, R, rank, world, "cpu", window=W, n_keys=K, execute=execute, ordered=ordered)
         out = {}
         for t in range(TICKS):
             keys, drop = _inputs(t)
@@ -64,24 +64,27 @@ def _worker(rank, world, port, out_dir, execute):
     dist.destroy_process_group()
 
 
-def _run(tmp_path, execute):
+def _run(tmp_path, execute, ordered=None):
+    """ordered=False with execution: the 5-exchange schedule = the co-located loop with the leaders' steps phase by phase"""
     import torch
     import torch.multiprocessing as mp
     import hostsim
     from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard
     hostsim.build()                                                   # once, before the workers race to build it
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute, ordered), nprocs=2, join=True)
+    five = not execute or ordered is False
     ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
     pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
     assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
-    assert all(int(rk["sent"]) > 0 and int(rk["exchanges"]) == (17 if execute else 5) for rk in ranks)
+    assert all(int(rk["sent"]) > 0 and int(rk["exchanges"]) == (5 if five else 17) for rk in ranks)
     tn = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     fast = slow = 0
     with hostsim.patched():
         ref = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
         for t in range(TICKS):
             keys, drop = _inputs(t)
-            oo = ep_cluster.tick(ref, [tn(keys[r]) for r in range(R)], {k: tn(v) for k, v in drop.items()}, always_accept_round=True)
+            oo = ep_cluster.tick(ref, [tn(keys[r]) for r in range(R)], {k: tn(v) for k, v in drop.items()}, always_accept_round=True,
+                                 phase_major=execute and ordered is False)
             for rk in ranks:
                 for b, s in rk["live"].tolist():
                     lo, hi = shard.group_range(G, 2, b)
@@ -109,3 +112,7 @@ def test_world_size_2_spread_epaxos_job_is_the_colocated_one(tmp_path):
 
 def test_world_size_2_spread_epaxos_ordered_schedule_with_execution(tmp_path):
     _run(tmp_path, execute=True)
+
+
+def test_world_size_2_spread_epaxos_five_exchanges_with_execution(tmp_path):
+    _run(tmp_path, execute=True, ordered=False)
