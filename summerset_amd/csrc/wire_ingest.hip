@@ -27,9 +27,6 @@
 namespace smr {
 
 typedef uint32_t wi_u32x4 __attribute__((ext_vector_type(4)));
-#ifndef SMR_WI_DIAG
-#define SMR_WI_DIAG 0                            // 1, 2: diagnostic builds (tools/runs/r3z_wi_diag.sh), wrong results on purpose
-#endif
 #ifndef SMR_WI_WIN
 #define SMR_WI_WIN 128                           // 9 KB of LDS per wavefront: 16 blocks per CU; >= 16 + 8 + WI_HOT_MAX
 #endif
@@ -370,24 +367,17 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
             const uint32_t held = (uint32_t)(hp - col) / 192;
             const uint64_t first = base0 + (n0 - held);
             const uint32_t fits = first >= A.ack_cap ? 0u : A.ack_cap - first < held ? (uint32_t)(A.ack_cap - first) : held;
-#if SMR_WI_DIAG == 1                                                                // (diagnostic build only: WRONG addresses, 64 lanes' records side by side)
-            smr_mp_ack *dst = A.acks + ((first - (n0 - held)) / 2048 * 2048 + (n0 - held) * 64 + lane) % (A.ack_cap - 704);
-#else
-            smr_mp_ack *dst = A.acks + first;
-#endif
+            // two records per turn: 48 contiguous bytes = three 16-byte stores (a record alone is a 16- and an 8-byte one): 1.5 store
+            // instructions per record instead of 2 -- each costs the memory pipeline 64 different lines (r3z)
+            uint8_t *dst = (uint8_t *)(A.acks + first);
             const uint32_t *rp = col;
-#if SMR_WI_DIAG == 1
-            for (uint32_t j = 0; __ballot(j < fits); j++, dst += 64, rp += 192) {
-#else
-            for (uint32_t j = 0; __ballot(j < fits); j++, dst++, rp += 192) {
-#endif
-                if (j < fits) {
-                    smr_mp_ack a; a.group = group; a.slot = rp[0]; a.ballot = ((uint64_t)rp[128] << 32) | rp[64]; a.peer = peer; a.reserved = 0;
-#if SMR_WI_DIAG == 2                                                                // (diagnostic build only: no record leaves)
-                    if (a.slot == 0xFFFFFFF1u && a.ballot == 77) *dst = a;
-#else
-                    *dst = a;
-#endif
+            for (uint32_t j = 0; __ballot(j < fits); j += 2, dst += 48, rp += 384) {
+                if (j + 1 < fits) {
+                    const wi_u32x4 w0{group, rp[0], rp[64], rp[128]}, w1{peer, 0u, group, rp[192]}, w2{rp[256], rp[320], peer, 0u};
+                    __builtin_memcpy(dst, &w0, 16); __builtin_memcpy(dst + 16, &w1, 16); __builtin_memcpy(dst + 32, &w2, 16);
+                } else if (j < fits) {
+                    smr_mp_ack a1; a1.group = group; a1.slot = rp[0]; a1.ballot = ((uint64_t)rp[128] << 32) | rp[64]; a1.peer = peer; a1.reserved = 0;
+                    *(smr_mp_ack *)dst = a1;
                 }
             }
         }

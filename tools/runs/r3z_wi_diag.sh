@@ -1,5 +1,5 @@
 #!/bin/bash
-# r3z: what pass 2's stores cost: the shipped build, a build whose 64 lanes write side by side (wrong addresses), a build that stores nothing
+# r3z: what pass 2's stores cost: the shipped build, a build whose 64 lanes write side by side (wrong addresses), a build that stores nothing  (the -DSMR_WI_DIAG builds it names were removed from wire_ingest.hip after this run)
 mkdir -p gpurun_out
 R=$PWD; export PYTHONPATH=$R
 cat > gpurun_out/r3z_wi_time.py <<'P'
