@@ -189,6 +189,7 @@ class SteadyLoop:
         messages through LDS) instead of one call per handler; `reps` must then be RSPaxosReplicaGroup objects"""
         self.reps, self.R, self.G, self.s = list(reps), len(reps), reps[0].G, int(leader)
         self.stores = None                       # [R, G, shard_len]: store q = what replica q holds of the tick's codewords (shard q)
+        self._stores = {}                        # (the buffers behind it, by `encode`'s slot)
         self._b = None
         self._cl = None
         if one_launch:
@@ -248,13 +249,16 @@ class SteadyLoop:
                            rp=[dict(reply=z(torch.uint8), **hb()) for _ in range(R)], back=dict(reply=z(torch.uint8), **hb()))
         return self._b
 
-    def encode(self, data, out=None, stream=None):
-        """from_data + compute_parity of the tick's batches (`data`: uint8 [G, L]) and every replica's shard store, one pass"""
+    def encode(self, data, out=None, stream=None, slot=0):
+        """from_data + compute_parity of the tick's batches (`data`: uint8 [G, L]) and every replica's shard store, one pass.
+        `slot`: which of the replicas' shard-store buffers receives the fan-out -- a host that encodes batch k + 1 while tick k
+        is still being processed (another stream) alternates two, as a leader with a batch in flight does."""
         import torch
         from .rscoding import RSCodewordBatch, rs_shard_len
         sl = rs_shard_len(int(data.shape[1]), self.R // 2 + 1)
-        if self.stores is None or self.stores.shape[2] != sl:
-            self.stores = torch.empty((self.R, self.G, sl), dtype=torch.uint8, device=data.device)
+        if self._stores.get(slot) is None or self._stores[slot].shape[2] != sl:
+            self._stores[slot] = torch.empty((self.R, self.G, sl), dtype=torch.uint8, device=data.device)
+        self.stores = self._stores[slot]
         d = self.R // 2 + 1                       # rspaxos/mod.rs:599-609: RS(majority, R - majority)
         return RSCodewordBatch.from_data_and_encode(data, d, self.R - d, stream=stream, out=out, fan_out=self.stores)
 
