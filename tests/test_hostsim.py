@@ -391,3 +391,17 @@ def test_cxx_epaxos_host_loop_on_the_host(sim, tmp_path):
                            "-I", here, "-I", os.path.join(t.ROOT, "include"), os.path.join(t.ROOT, "examples", "ep_host_loop.cpp"),
                            lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     t.check_output(subprocess.check_output([exe, "96", "6"], timeout=300).decode(), 96, 6)
+
+
+def test_cxx_raft_wire_loop_on_the_host(sim, tmp_path):
+    """examples/raft_wire_loop.cpp (Raft replication with the replies as wire frames written and parsed by kernels) compiled for
+    the host against the emulator build of the library: every appended entry commits"""
+    import os
+    import subprocess
+    import test_zzz_example_raft_wire_gpu as t
+    lib = sim.build()
+    exe = str(tmp_path / "raft_wire_loop_sim")
+    here = os.path.dirname(os.path.abspath(sim.__file__))
+    subprocess.check_call([sim.CXX, "-std=c++17", "-O1", "-w", "-DRAFT_WIRE_LOOP_ON_THE_EMULATOR", "-I", here, "-I", os.path.join(t.ROOT, "include"),
+                           os.path.join(t.ROOT, "examples", "raft_wire_loop.cpp"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    t.check_output(subprocess.check_output([exe, "96", "6"], timeout=300).decode(), 96, 6)
