@@ -1506,7 +1506,27 @@ def main():
                 x = leg_isolated("l2", extra=["--groups", str(args.groups), "--slots", str(args.slots), "--window", str(args.window), "--steps",
                                               str(max(4, min(args.steps, 12))), "--spread-ranks", str(args.spread_ranks)])
             else:
-                x = spread_run(args, torch, dist, rank, world, dev, steps=max(4, min(args.steps, 12)), warmup=4)
+                # Real ranks: the first time this pass meets RCCL is the driver's scaling run.  It runs on a watchdog thread: if it
+                # has not come back in SMR_BENCH_L2_TIMEOUT seconds (a collective that never completes), the headline line --
+                # measured above, nothing of it depends on this pass -- is printed with l2 = {"error": "timeout"} and the
+                # process leaves through os._exit instead of the closing barrier.
+                import threading
+                box = {}
+
+                def work():
+                    try:
+                        torch.cuda.set_device(dev)
+                        box["x"] = spread_run(args, torch, dist, rank, world, dev, steps=max(4, min(args.steps, 12)), warmup=4)
+                    except BaseException as e:     # noqa: BLE001
+                        box["e"] = e
+                th = threading.Thread(target=work, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("SMR_BENCH_L2_TIMEOUT", "150")))
+                if th.is_alive():
+                    raise TimeoutError("the spread pass did not finish in time on rank %d" % rank)
+                if "e" in box:
+                    raise box["e"]
+                x = box["x"]
             l2 = {"layout": "spread (SURVEY 8e L2): replica r of block b on rank (b + r) mod N", "ranks": x["config"]["spread_ranks"],
                   "ranks_are": x["config"]["ranks_are"], "value": x["value"], "unit": "slots/s", "ms_per_tick": x["ms_per_step"],
                   "steps": x["steps"], "warmup": x["warmup"], "exchange": x["exchange"], "backend": x["backend"]}
@@ -1560,7 +1580,15 @@ def main():
                             failed.append(name + ".cpu_baseline")
         line["legs_failed"] = failed               # [] = every leg that was asked for ran (a missing cpu_baseline / roofline is an error here)
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        if l2 is not None and "error" in l2:       # a rank whose L2 pass failed or hung cannot trust a collective any more: the closing barrier
+            import threading                       # gets a few seconds on a thread, then every such rank leaves (the line is out)
+            th = threading.Thread(target=lambda: dist.barrier(), daemon=True)
+            th.start()
+            th.join(timeout=20.0)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 
