@@ -430,29 +430,23 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     Heartbeats.  <= 1 AcceptReply of 4 lost per slot (the threshold is 4 of 5 and nothing is retransmitted).
     The tick is captured into ONE HIP graph of NB ticks and replayed (HIP graphs instead of per-launch host calls: a tick is
     ~14 launches of a few microseconds each); the eager loop is timed beside it."""
-    from summerset_amd import RSCodewordBatch, RSPaxosReplicaGroup, rsp_cluster
-    G, R, W, L, NB, H = 16384, 5, 64, 4113, 4, 4
-    reps = [RSPaxosReplicaGroup(G, R, me=r, window=W, fault_tolerance=1) for r in range(R)]
-    for r in reps:
-        r.preset_leader(0)
-    loop = rsp_cluster.SteadyLoop(reps, leader=0, one_launch=os.environ.get("SMR_RSP_CALL_BY_CALL") is None)
+    from summerset_amd import RSCodewordBatch, workloads
+    c4 = workloads.CONFIG4
+    G, R, W, L, NB, H = c4["G"], c4["R"], c4["W"], c4["L"], c4["n_buffers"], c4["H"]
+    # cluster, loss masks, tokens and the tick itself from summerset_amd/workloads.py -- what
+    # tests/test_baseline_configs_gpu.py::test_config3_rspaxos_one_launch_tick_16384_groups holds against the oracle
+    reps, loop = workloads.config4_cluster(G, W, c4["ft"], one_launch=os.environ.get("SMR_RSP_CALL_BY_CALL") is None)
     rng = np.random.default_rng(0x5EED5EED)
     srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
     cws = [RSCodewordBatch(G, L, 3, 2, device=dev, zero=False) for _ in range(NB)]
-    masks = []
-    for k in range(NB):
-        who = rng.integers(1, R, G)
-        hit = rng.random(G) < 0.3                                        # ~30 % of the slots lose ONE of their four replies
-        masks.append({("accept_reply", q, 0): torch.from_numpy((hit & (who == q)).astype(np.uint8)).to(dev) for q in range(1, R)})   # (uint8: taken as they are)
-    ar = torch.arange(G, dtype=torch.int64, device=dev)
-    vals = [((1 + ar + j * G) & 0x3FFFFFFF).to(torch.int32) for j in range(8 * NB)]   # the ticks' batch tokens: inputs, resident before the timed region
+    masks = [{k_: torch.from_numpy(v).to(dev) for k_, v in workloads.config4_loss(rng, G).items()} for k in range(NB)]   # ~30 % of the slots lose ONE of their four replies
+    vals = [torch.from_numpy(workloads.config4_tokens(G, j)).to(dev) for j in range(8 * NB)]   # the ticks' batch tokens: inputs, resident before the timed region
     n_tick = [0]                                                         # (round 3 made them with four torch kernels INSIDE every tick: ~25 us of a 0.125 ms tick, profiles/r4w)
 
     def one_tick(k, hb):
-        loop.encode(srcs[k], out=cws[k])                                 # from_data + encode + the five shard stores: one pass
         val = vals[(n_tick[0] // NB * NB + k) % len(vals)]
         n_tick[0] += 1
-        return loop.tick(val, lost=masks[k], heartbeat=hb)
+        return workloads.config4_tick(loop, k, srcs[k], cws[k], val, masks[k], hb)   # encode + fan-out (one pass), then the tick (one launch)
 
     def commits():
         return int(reps[0].dump()["counters"][0])
@@ -1336,13 +1330,12 @@ def main():
     n_ticks = n_timed + args.round_ticks          # the per-round pass goes on where the timed region stopped
     if args.fused:
         args.straggler_ticks = 0                  # the fused tick kernel and the side stream exclude each other
-    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=args.straggler_ticks)
-    if args.role_rotation and args.straggler_ticks:
-        eng.set_role_rotation(True)
-    eng.preset_leader(0)
-    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_timed, drop_p=args.drop, timeout_frac=timeout_frac(args),
-                                 hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=timeout_span(args),
-                                 group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
+    # cluster, stream and launch mode come from summerset_amd/workloads.py: the SAME helpers the BASELINE-size parity tests
+    # call (tests/test_baseline_configs_gpu.py::test_headline_*_bench_launch), so the timed shape is the checked shape
+    from summerset_amd import workloads
+    eng = workloads.headline_cluster(G, W=W, R=R, straggler_ticks=args.straggler_ticks, role_rotation=bool(args.role_rotation))
+    st = workloads.headline_stream(G, n_timed, timeout_frac(args), timeout_span(args), S=S, W=W, R=R, H=H, drop_p=args.drop,
+                                   group_base=shard.group_range(G * world, world, rank)[0])   # my block of the job's groups
     # inputs resident in HBM before the clock starts
     pool = []
     for t in range(args.pool):
@@ -1365,18 +1358,15 @@ def main():
 
     def run(t0_, t1_, timed=False):
         if args.batch and not args.fused:
-            chunks = [list(range(b0, min(b0 + min(args.batch, 16), t1_))) for b0 in range(t0_, t1_, min(args.batch, 16))]
-            for i, ch in enumerate(chunks):
-                # event pairs around the round kernels of ONE batch of the timed region (the last: the shortest when the
-                # steps do not divide): they cost launch-gap time on every tick they cover
-                eng.profile_enable(timed and i == len(chunks) - 1)
-                eng.run_ticks([tick_args(t) for t in ch])
+            # event pairs around the round kernels of ONE batch of the timed region (the last: the shortest when the
+            # steps do not divide): they cost launch-gap time on every tick they cover
+            workloads.drive_headline(eng, tick_args, t0_, t1_, batch=args.batch,
+                                     before_call=lambda i, n, ch: eng.profile_enable(timed and i == n - 1))
             return
         if not args.fused:
-            for t in range(t0_, t1_):
-                if timed:
-                    eng.profile_enable((t - t0_) % 3 == 0)   # event pairs on every third tick (all tick phases come by):
-                eng.tick(**tick_args(t))          # the events themselves cost launch-gap time
+            # event pairs on every third tick (all tick phases come by): the events themselves cost launch-gap time
+            workloads.drive_headline(eng, tick_args, t0_, t1_, batch=0,
+                                     before_call=(lambda i, n, ch: eng.profile_enable(i % 3 == 0)) if timed else None)
             return
         for b0 in range(t0_, t1_, args.fused):
             batch = [tick_args(t) for t in range(b0, min(b0 + args.fused, t1_))]

@@ -340,6 +340,11 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]);
  * instead of the steady-state fast path (a performance, not a correctness, figure) */
 int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out);
 
+/* the straggler list (smr_mp_cfg.straggler_ticks): out[0] = its capacity in groups (0: list off), out[1] = the number of
+ * groups the LAST mark pass (of smr_mp_tick / of a smr_mp_run_ticks batch) wanted on it.  out[1] > out[0]: the list was
+ * full and the groups beyond it stayed with the bulk kernels (same results, slower tick).  Synchronises the device. */
+int smr_mp_straggler_stats(smr_mp_cluster *c, uint64_t out[2]);
+
 /* debug: 64 wall-clock stamps (100 MHz) of the cooperative jobs' phases; all zero unless the library was
  * built with -DSMR_JOB_STAMPS (tools/dbg_stamps.py) */
 int smr_mp_debug_stamps(smr_mp_cluster *c, uint64_t *out64);

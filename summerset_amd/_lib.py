@@ -239,6 +239,7 @@ SYMBOLS = [
     ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),
     ("smr_mp_debug_generic_units", _i, [_vp, _u8, C.POINTER(_u64)]),
     ("smr_mp_debug_stamps", _i, [_vp, _vp]),
+    ("smr_mp_straggler_stats", _i, [_vp, C.POINTER(_u64 * 2)]),
     ("smr_mp_poll_commits", _i, [_vp, _u8, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("smr_mp_profile_enable", _i, [_vp, _i]),
     ("smr_mp_profile_read", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(_u64)]),

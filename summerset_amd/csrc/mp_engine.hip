@@ -2336,6 +2336,17 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]) {
     return SMR_OK;
 }
 
+int smr_mp_straggler_stats(smr_mp_cluster *c, uint64_t out[2]) {
+    if (!c || !out) return fail(SMR_ERR_ARG, "mp: bad argument");
+    out[0] = c->ttl ? (uint64_t)SLOW_CAP : 0u; out[1] = 0;
+    if (!c->ttl) return SMR_OK;
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    uint32_t n[2];
+    SMR_HIP_TRY(hipMemcpy(n, c->hp.slow_n, 8, hipMemcpyDeviceToHost));
+    out[1] = n[c->lpar ^ 1];                                   // the parity the last mark pass counted into
+    return SMR_OK;
+}
+
 int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
     if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());

@@ -154,6 +154,13 @@ class MultiPaxosCluster:
         check(self._L.smr_mp_debug_generic_units(self._h, rep, C.byref(n)))
         return int(n.value)
 
+    def straggler_stats(self):
+        """(capacity of the straggler list, groups the last mark pass wanted on it): more wanted than capacity = the list
+        overflowed and the rest stayed with the bulk kernels (`smr_mp_straggler_stats`)"""
+        arr = (C.c_uint64 * 2)()
+        check(self._L.smr_mp_straggler_stats(self._h, C.byref(arr)))
+        return int(arr[0]), int(arr[1])
+
     def poll_commits(self, rep, cap=None):
         cap = self.commit_list_cap if cap is None else cap
         g = np.zeros(cap, np.uint32)

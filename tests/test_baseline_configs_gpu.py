@@ -42,73 +42,110 @@ def test_config1_multipaxos_4096_groups_bit_exact(cuda, oracle):
 # the headline metric's configuration: "65 536 groups, 5 replicas" at bench.py's shape (S = 32, W = 512, heartbeat
 # every 4th tick, 10 % ack loss capped at 2 per slot, 1 % of the groups change leader)
 # ---------------------------------------------------------------------------------------------------------------
-def run_multipaxos_slices(cuda, oracle, G, S, W, n_ticks, frac, span, width, n_slices, every=4, straggler_ticks=0):
+def run_multipaxos_slices(cuda, oracle, G, S, W, n_ticks, frac, span, width, n_slices, every=4, straggler_ticks=0, batch=0):
+    """cluster, stream and launch mode from summerset_amd/workloads.py -- the helpers bench.py's headline run calls.
+    batch = 0: one smr_mp_tick per tick; batch > 0: smr_mp_run_ticks over chunks of `batch` ticks, which with
+    straggler_ticks > 0 is the TIMED shape (bulk kernels tick by tick + mp_mark_batch + mp_straggler_batch on the side
+    stream); the state is then compared at chunk ends (`every` counts chunks).  Returns (groups whose leader changed in
+    the slices, commits, the longest straggler list any mark pass wanted, the list's capacity)."""
     from oracle.oracle import MP_SCALARS, MP_SLOTS
-    from summerset_amd import MultiPaxosCluster, stream
-    R, H = 5, 4
-    cap = W + 4
-    kw = dict(cap=cap, n_ticks=n_ticks, drop_p=0.1, timeout_frac=frac, hb_every=H, rand_rows=S + 4, max_drop=2, timeout_span=span)
-    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=straggler_ticks)
-    eng.preset_leader(0)
-    st = stream.MultiPaxosStream(G, R, S, **kw)
+    from summerset_amd import workloads
+    R = 5
+    eng = workloads.headline_cluster(G, W=W, R=R, straggler_ticks=straggler_ticks)
+    st = workloads.headline_stream(G, n_ticks, frac, span, S=S, W=W, R=R)
     sl = _slices(G, width, n_slices, seed=G + S)
     orcs, sts, pools = [], [], []
     for g0, n in sl:
-        o = oracle.MpOracle(n, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
+        o = oracle.MpOracle(n, R, W, win_reserve=W // 8, cap=W + 4, record_commits=False)
         o.preset_leader(0)
         orcs.append(o)
-        sts.append(stream.MultiPaxosStream(n, R, S, group_base=g0, **kw))
+        sts.append(workloads.headline_stream(n, n_ticks, frac, span, S=S, W=W, R=R, group_base=g0))
         pools.append([sts[-1].tick(t) for t in range(4)])
     pool = [_to_dev({k: v for k, v in st.tick(t).items() if k in ("req_cnt", "req_val", "ackctl")}, cuda) for t in range(4)]
     # the slice streams ARE the global stream (keyed by global group id): checked on the inputs themselves
     for (g0, n), p in zip(sl, pools):
         full = st.tick(1)
         assert np.array_equal(full["ackctl"][:, g0:g0 + n], p[1]["ackctl"]) and np.array_equal(full["req_val"][:, g0:g0 + n], p[1]["req_val"])
+    events = [_to_dev(st.tick_events(t), cuda) for t in range(n_ticks)]
+    fired = [bool((st.tick_events(t)["timeout_rep"] != 0xFF).any()) for t in range(n_ticks)]
+
+    def tick_args(t):                                    # bench.py's tick_args: no timeout arrays on a tick without a timer
+        e = events[t]
+        return dict(timeout_rep=e["timeout_rep"] if fired[t] else None, timeout_src=e["timeout_src"] if fired[t] else None,
+                    req_target=e["req_target"], heartbeat=st.heartbeat(t), **pool[t % 4])
+
+    def compare(t):
+        for (g0, n), o in zip(sl, orcs):
+            for r in range(R):
+                a, b = eng.dump(r, g0, n), o.dump(r)
+                assert np.array_equal(a["overflow"], b["overflow"]), (t, g0, r)
+                live = b["overflow"] == 0
+                for name in MP_SCALARS:
+                    assert np.array_equal(a[name][live], b[name][live]), "tick %d slice %d rep %d %s: groups %s" % (
+                        t, g0, r, name, g0 + np.nonzero((a[name] != b[name]) & live)[0][:5])
+                assert np.array_equal(a["peer_exec_bar"][:, live], b["peer_exec_bar"][:, live]), (t, g0, r)
+                for name, _ in MP_SLOTS:
+                    assert np.array_equal(a[name][:, live], b[name][:, live]), (t, g0, r, name)
+
+    chunks = workloads.batches(0, n_ticks, batch) if batch else [[t] for t in range(n_ticks)]
+    want_max, cap = 0, 0
+    for i, ch in enumerate(chunks):
+        workloads.drive_headline(eng, tick_args, ch[0], ch[-1] + 1, batch=batch)
+        if straggler_ticks:
+            cap, want = eng.straggler_stats()
+            want_max = max(want_max, want)
+        for t in ch:
+            for o, s_, p in zip(orcs, sts, pools):
+                inp = dict(p[t % 4])
+                inp.update(s_.tick_events(t))
+                inp["heartbeat"] = s_.heartbeat(t)
+                o.tick(**inp)
+        if i % every == every - 1 or i == len(chunks) - 1:
+            compare(ch[-1])
     changed = 0
-    for t in range(n_ticks):
-        ev = st.tick_events(t)
-        fired = bool((ev["timeout_rep"] != 0xFF).any())
-        eng.tick(timeout_rep=_to_dev(ev, cuda)["timeout_rep"] if fired else None, timeout_src=_to_dev(ev, cuda)["timeout_src"] if fired else None,
-                 req_target=_to_dev(ev, cuda)["req_target"], heartbeat=st.heartbeat(t), **pool[t % 4])
-        for o, s_, p in zip(orcs, sts, pools):
-            inp = dict(p[t % 4])
-            inp.update(s_.tick_events(t))
-            inp["heartbeat"] = s_.heartbeat(t)
-            o.tick(**inp)
-        if t % every == every - 1 or t == n_ticks - 1:
-            for (g0, n), o in zip(sl, orcs):
-                for r in range(R):
-                    a, b = eng.dump(r, g0, n), o.dump(r)
-                    assert np.array_equal(a["overflow"], b["overflow"]), (t, g0, r)
-                    live = b["overflow"] == 0
-                    for name in MP_SCALARS:
-                        assert np.array_equal(a[name][live], b[name][live]), "tick %d slice %d rep %d %s: groups %s" % (
-                            t, g0, r, name, g0 + np.nonzero((a[name] != b[name]) & live)[0][:5])
-                    assert np.array_equal(a["peer_exec_bar"][:, live], b["peer_exec_bar"][:, live]), (t, g0, r)
-                    for name, _ in MP_SLOTS:
-                        assert np.array_equal(a[name][:, live], b[name][:, live]), (t, g0, r, name)
     for (g0, n), o in zip(sl, orcs):
         changed += int((o.dump(1)["leader"] != 0).sum())
         assert int(o.dump(0)["commit_bar"].min()) > 0
-    # whole-population sanity next to the slices: total commits = sum of the leaders' commit bars' progress is not
-    # available per slice from the engine's counters, so check the counters against the bars of a full scalar dump
     total = sum(eng.counters(r)["commits"] for r in range(R))
     assert total > 0
-    return changed, total
+    return changed, total, want_max, cap
 
 
 def test_headline_multipaxos_65536_groups_s32(cuda, oracle):
     """8 slices x 512 groups of the 65 536: full state of all five replicas (every slot of the 512-slot rings) against
     the oracle every 4th tick, 24 ticks with the leader changes of 1 % of the groups inside them"""
-    changed, total = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=24, frac=0.01, span=12, width=512, n_slices=8)
+    changed, total, _, _ = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=24, frac=0.01, span=12, width=512, n_slices=8)
     assert total > 65536 * 32 * 16                       # >= 16 of the 24 ticks' slots committed (loss is quorum-preserving)
 
 
 def test_headline_multipaxos_65536_groups_s32_many_leader_changes(cuda, oracle):
     """the same population with a quarter of the groups changing leader inside 10 ticks: the cooperative rare path at
     full occupancy (long re-Accept outboxes, Prepare batches) next to the bulk path"""
-    changed, _ = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=20, frac=0.25, span=10, width=256, n_slices=6)
+    changed, _, _, _ = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=20, frac=0.25, span=10, width=256, n_slices=6)
     assert changed > 100
+
+
+# --- the launch shape bench.py TIMES (VERDICT r3 weak #1): smr_mp_run_ticks in batches of 8, straggler list on (ttl 4) ----
+def test_headline_multipaxos_65536_groups_s32_bench_launch(cuda, oracle):
+    """bench.py's default headline run as it is launched -- workloads.headline_cluster(straggler_ticks=4) driven by
+    workloads.drive_headline(batch=8): per batch one mp_mark_batch, one mp_straggler_batch on the side stream and the bulk
+    round kernels tick by tick -- with 1 % of the 65 536 groups changing leader inside 24 ticks (~27 per tick, the driver
+    command's rate).  Full state of all five replicas of 8 x 512 groups against the oracle after every batch; the
+    straggler list (1024 groups) must never have been full."""
+    changed, total, want, cap = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=24, frac=0.01, span=24, width=512,
+                                                      n_slices=8, every=1, straggler_ticks=4, batch=8)
+    assert total > 65536 * 32 * 16
+    assert cap == 1024 and 0 < want <= cap, "straggler list: %d groups wanted, capacity %d" % (want, cap)
+
+
+def test_headline_multipaxos_65536_groups_s32_bench_launch_many_leader_changes(cuda, oracle):
+    """the same launch shape with a quarter of the groups changing leader inside 16 ticks (~1000 per tick): every batch's
+    mark pass wants far more groups than the list holds, so the 192 x 6 side blocks run full and the overflow groups'
+    leader changes go through the bulk kernels' cooperative jobs -- both must be the oracle's, bit for bit"""
+    changed, total, want, cap = run_multipaxos_slices(cuda, oracle, G=65536, S=32, W=512, n_ticks=24, frac=0.25, span=16, width=256,
+                                                      n_slices=6, every=1, straggler_ticks=4, batch=8)
+    assert changed > 100
+    assert want > cap == 1024, "this workload is meant to overflow the list (%d wanted)" % want
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -180,6 +217,65 @@ def run_rspaxos_slices(cuda, oracle, G, W, T, ft, loss, width, n_slices):
                 assert np.array_equal(eg[m] - g0, og) and np.array_equal(es[m], os_) and np.array_equal(ev[m], ov), (t, g0, r, "executed")
         counters += np.asarray(orcs[0].dump()["counters"][:3], np.int64)
     assert counters[0] > 0 and counters[1] > 0
+
+
+def run_rspaxos_one_launch(cuda, oracle, G, W, L, T, ft):
+    """bench.py's config-4 leg as it is launched (summerset_amd/workloads.py: config4_cluster / config4_loss / config4_tokens
+    / config4_tick): per tick ONE pass `rs_from_data_xtime` (from_data + RS(3,2) encode + the five shard stores) and ONE
+    launch `smr_rsp_cluster_steady_tick` -- against five ORACLES of the WHOLE population in the numpy-staged closed loop
+    (rsp_cluster.tick) and the oracle's RS encoder on every codeword of every tick.  Compared: the leader's committed flags
+    every tick, the codeword bytes and every replica's shard store byte for byte every tick, every replica's full state
+    at the end."""
+    import torch
+    from summerset_amd import RSCodewordBatch, rsp_cluster as rc, workloads
+    c4 = workloads.CONFIG4
+    R, NB, H = c4["R"], c4["n_buffers"], c4["H"]
+    reps, loop = workloads.config4_cluster(G, W, ft, one_launch=True)
+    orcs = [oracle.RspOracle(G, R, me=r, W=W, fault_tolerance=ft) for r in range(R)]
+    for o in orcs:
+        o.preset_leader(0)
+    rng = np.random.default_rng(0x5EED5EED)
+    data = [rng.integers(0, 256, (G, L), dtype=np.uint8) for _ in range(NB)]
+    srcs = [torch.from_numpy(d).to(cuda) for d in data]
+    cws = [RSCodewordBatch(G, L, 3, 2, device=cuda, zero=False) for _ in range(NB)]
+    sl_ = cws[0].shard_len
+    want_par = [oracle.rs_encode_batch(3, 2, d, L, L, G).reshape(G, 2, sl_) for d in data]   # the oracle's encoder, every codeword
+    padded = []
+    for d in data:                                       # from_data geometry (rscoding.rs:165-220): zero-padded to 3 shard_len, split
+        x = np.zeros((G, 3 * sl_), np.uint8)
+        x[:, :L] = d
+        padded.append(x.reshape(G, 3, sl_))
+    masks = [workloads.config4_loss(rng, G) for _ in range(NB)]
+    dmasks = [{k: torch.from_numpy(v).to(cuda) for k, v in m.items()} for m in masks]
+    total = 0
+    for t in range(T):
+        k, hb = t % NB, t % H == H - 1
+        val = workloads.config4_tokens(G, t)
+        got = workloads.config4_tick(loop, k, srcs[k], cws[k], torch.from_numpy(val).to(cuda), dmasks[k], hb).cpu().numpy()
+        log = rc.tick(orcs, val.view(np.uint32), np.zeros(G, np.uint8), drop={k_: v.astype(bool) for k_, v in masks[k].items()}, heartbeat=hb)
+        want = [e for e in log if e["kind"] == "commit"]
+        assert len(want) == 1 and np.array_equal(got, want[0]["committed"]), t
+        total += int(got.sum())
+        cwb = cws[k].buf.cpu().numpy()
+        stores = loop.stores.cpu().numpy()               # [R, G, shard_len]: what replica q holds of this tick's codewords
+        for q in range(R):
+            exp = padded[k][:, q] if q < 3 else want_par[k][:, q - 3]
+            assert np.array_equal(cwb[:, q * sl_:(q + 1) * sl_], exp), (t, q, "codeword")
+            assert np.array_equal(stores[q], exp), (t, q, "shard store")
+    for r in range(R):
+        a, b = reps[r].dump(), orcs[r].dump()
+        assert len(b) > 8
+        for n in b:
+            assert np.array_equal(a[n], b[n]), (r, n)
+    return total
+
+
+def test_config3_rspaxos_one_launch_tick_16384_groups(cuda, oracle):
+    """the launches bench.py TIMES for config 4 -- `smr_rsp_cluster_steady_tick` + `rs_from_data_xtime`
+    with the fan-out -- at 16 384 groups x L = 4113, every group and every byte against the oracles, 12 ticks (three
+    rotations of the four buffer pairs, three heartbeat ticks), ~30 % of the slots losing one of their four replies"""
+    total = run_rspaxos_one_launch(cuda, oracle, G=16384, W=64, L=4113, T=12, ft=1)
+    assert total > 16384 * 10
 
 
 def test_config3_rspaxos_16384_groups_rs32_4k_values(cuda, oracle):

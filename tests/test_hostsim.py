@@ -154,6 +154,7 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         te.test_frames_at_the_window_edges("cpu")
         te.test_extreme_values_and_odd_encodings("cpu")
         te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")
+        te.test_frames_laid_out_by_hand_give_records_laid_out_by_hand("cpu")     # expected records written out by the test
 
 
 def test_reply_ingest_kernels_on_the_host(sim, oracle):
@@ -254,9 +255,14 @@ def test_baseline_config_slice_tests_on_the_host(sim, oracle):
     whose flag is clear"""
     import test_baseline_configs_gpu as t
     with sim.patched():
-        changed, total = t.run_multipaxos_slices("cpu", oracle, G=320, S=4, W=64, n_ticks=14, frac=0.3, span=6, width=64, n_slices=3, every=3)
+        changed, total, _, _ = t.run_multipaxos_slices("cpu", oracle, G=320, S=4, W=64, n_ticks=14, frac=0.3, span=6, width=64, n_slices=3, every=3)
         assert changed > 0 and total > 0
+        # the launch shape bench.py times: batches of 8 through smr_mp_run_ticks with the straggler list on
+        changed, total, want, cap = t.run_multipaxos_slices("cpu", oracle, G=320, S=4, W=64, n_ticks=20, frac=0.3, span=10, width=64,
+                                                            n_slices=3, every=1, straggler_ticks=4, batch=8)
+        assert changed > 0 and total > 0 and 0 < want <= cap
         t.run_rspaxos_slices("cpu", oracle, G=256, W=16, T=12, ft=1, loss=0.05, width=64, n_slices=3)
+        assert t.run_rspaxos_one_launch("cpu", oracle, G=200, W=16, L=133, T=9, ft=1) > 0   # config 4's timed launches
         t.run_epaxos_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=3)
         for pm in (False, True):                                # the one-launch cluster tick against oracle slices, both orders
             t.run_epaxos_cluster_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=2, phase_major=pm)
@@ -361,18 +367,18 @@ def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
         t.run_fused_vs_driver("cpu", 130, 16, 0.1, T=5, execute=False, oracle=oracle, phase_major=True)
 
 
-def test_spread_epaxos_exchange_on_the_host(sim):
+def test_spread_epaxos_exchange_on_the_host(sim, oracle):
     """layout L2 of the EPaxos cluster with every rank in this process (tests/test_spread_ep.py): one all-to-all per
     exchange, both schedules -- against the co-located closed loop, every tick and the final state"""
     import test_spread_ep as t
     with sim.patched():
-        t.run_spread_vs_colocated("cpu", G=130, world=2, n_ticks=6, loss=0.15)
+        t.run_spread_vs_colocated("cpu", G=130, world=2, n_ticks=6, loss=0.15, oracle=oracle)     # (oracle: also held against five EpOracles)
         t.run_spread_vs_colocated("cpu", G=100, world=3, n_ticks=5, loss=0.15)
         t.run_spread_vs_colocated("cpu", G=21, world=8, n_ticks=4, loss=0.1)
-        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True)
+        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True, oracle=oracle)
         assert job.ranks[0].exchanges_per_tick() == 17
         # execution on with the 5-exchange schedule: the phase-by-phase order of the colocated loop (smr_ep_cluster_set_mode bit 1)
-        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True)
+        job = t.run_spread_vs_colocated("cpu", G=120, world=4, n_ticks=6, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True, oracle=oracle)
         assert job.ranks[0].exchanges_per_tick() == 5
         assert t.run_spread_vs_colocated("cpu", G=70, world=1, n_ticks=4, loss=0.1).ranks[0].bytes_sent == 0   # one rank: nothing leaves it
         t.run_spread_vs_colocated("cpu", G=60, world=2, n_ticks=4, loss=0.1, R=3, K=4)                         # three replicas

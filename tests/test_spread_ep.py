@@ -8,13 +8,17 @@ import numpy as np
 import pytest
 
 
-def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execute=False, ordered=None, make=None, seed=0, ref_phase_major=False):
+def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execute=False, ordered=None, make=None, seed=0, ref_phase_major=False,
+                            oracle=None):
     """`make(world)` -> object with tick(keys, drop) and .ranks (default: spread_ep.in_process).  ref_phase_major: the colocated
-    reference loop runs the leaders' steps phase by phase -- the order of the 5-exchange schedule (`ordered=False`)"""
+    reference loop runs the leaders' steps phase by phase -- the order of the 5-exchange schedule (`ordered=False`).
+    oracle: the oracle module -- five EpOracle objects then run the same ticks in tests/ep_cluster.tick and every block's
+    decisions and every (block, replica)'s final state are held against THEM, not only against the co-located engine."""
     import torch
     import ep_cluster as ec
     from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard, spread_ep
     ref = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=execute) for r in range(R)]
+    orcs = [oracle.EpOracle(G, R, me=r, W=W, n_keys=K, execute=execute) for r in range(R)] if oracle is not None else None
     job = spread_ep.in_process(G, R, world, dev, window=W, n_keys=K, execute=execute, ordered=ordered) if make is None else make(world)
     rng = np.random.default_rng(1000 * world + G + seed)
     rngs = {b: shard.group_range(G, world, b) for b in range(world)}
@@ -29,14 +33,19 @@ def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execut
         bd = None if drop is None else {(b, s, q): dv(v[lo:hi]) for b, (lo, hi) in rngs.items() for (s, q), v in drop.items() if hi > lo}
         oe = job.tick(bk, bd)
         assert sorted(oe) == sorted(bk)
+        oc = ec.tick(orcs, keys, drop, phase_major=ref_phase_major) if orcs is not None else None
         for (b, s), o in oe.items():
             lo, hi = rngs[b]
             for k in o:
                 assert np.array_equal(o[k].cpu().numpy(), oo[s][k][..., lo:hi].cpu().numpy()), (t, b, s, k)
+                if oc is not None:                                      # the spread job against the ORACLE cluster directly
+                    assert np.array_equal(o[k].cpu().numpy().view(oc[s][k].dtype), oc[s][k][..., lo:hi]), (t, b, s, k, "oracle")
         fast += sum(int((oo[s]["decision"] == 3).sum()) for s in range(R))
         slow += sum(int((oo[s]["decision"] == 2).sum()) for s in range(R))
     full = [ref[r].dump() for r in range(R)]
     xfull = [ref[r].exec_dump() for r in range(R)] if execute else None
+    ofull = [o.dump() for o in orcs] if orcs is not None else None
+    oxfull = [o.exec_dump() for o in orcs] if (orcs is not None and execute) else None
     seen = set()
     for rk in job.ranks:
         for (b, r), rep in rk.reps.items():
@@ -44,6 +53,16 @@ def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execut
             seen.add((b, r))
             lo, hi = rngs[b]
             a = rep.dump()
+            if ofull is not None:                                       # ... and its final state against the oracle's
+                for n, x in ofull[r].items():
+                    if n == "counters":
+                        continue
+                    gax = {"deps": 2}.get(n, x.ndim - 1)
+                    assert np.array_equal(a[n], np.take(x, np.arange(lo, hi), axis=gax)), (rk.rank, b, r, n, "oracle")
+                if execute:
+                    xa = rep.exec_dump()
+                    for n in ("exec_bars", "kv", "digest"):
+                        assert np.array_equal(xa[n], oxfull[r][n][..., lo:hi]), (rk.rank, b, r, "exec", n, "oracle")
             for n, x in full[r].items():
                 if n == "counters":
                     continue

@@ -183,3 +183,50 @@ def test_ragged_wavefront_and_unaligned_buffer_end(cuda):
         total = sum(len(s) for s in streams)
         na, nh, no, nm = _check(wire, cuda, streams, seed=4)
         assert nm == 0 and na > 1000
+
+
+def test_frames_laid_out_by_hand_give_records_laid_out_by_hand(cuda):
+    """no decoder of the product on the expected side.  Frames written byte by byte from the reference's
+    definitions -- `[u64 BE length][bincode]` (utils/safetcp.rs:46,127-132), `PeerMessage::Msg` = variant 0
+    (server/transport.rs:37-55), MultiPaxos `PeerMsg` variants in declaration order Prepare 0 ... AcceptReply 3 ... Heartbeat
+    6, CommitNotice 7 (multipaxos/mod.rs:298-384), varints 1 / 3 / 5 / 9 bytes, AcceptReply's trailing Option<SystemTime> --
+    and the records the parser must produce written out as plain tuples next to them."""
+    from summerset_amd import wire
+    from summerset_amd.multipaxos import ACK_DTYPE
+    be = lambda n: struct.pack(">Q", n)                          # noqa: E731
+    conns = [
+        # connection 0 (group 7, peer 1): three AcceptReplies -- 1-byte varints, a u16 slot, a u32 slot with a u64 ballot
+        (7, 1,
+         be(5) + bytes([0, 3, 9, 17, 0])
+         + be(7) + bytes([0, 3, 0xFB, 0x39, 0x30, 250, 0])                                   # slot 12345 = 0x3039 LE
+         + be(17) + bytes([0, 3, 0xFC, 0x15, 0xCD, 0x5B, 0x07, 0xFD, 0x02, 0x01, 0, 0, 0, 0, 0, 0x80, 0]),   # 123456789, 0x8000000000000102
+         [(7, 9, 17, 1, 0), (7, 12345, 250, 1, 0), (7, 123456789, 0x8000000000000102, 1, 0)], [], []),
+        # connection 1 (group 70000, peer 4): Heartbeat {ballot 0x101 (u16), commit_bar 300 (u16), exec_bar 5, snap_bar 0}, an
+        # AcceptReply {slot 2, ballot 3, Some(SystemTime {secs 1790000000 (u32), nanos 7})} = 11 bytes, CommitNotice {ballot 258
+        # (u16), commit_bar 1}
+        (70000, 4,
+         be(10) + bytes([0, 6, 0xFB, 0x01, 0x01, 0xFB, 0x2C, 0x01, 5, 0])
+         + be(11) + bytes([0, 3, 2, 3, 1, 0xFC]) + struct.pack("<I", 1790000000) + bytes([7])
+         + be(6) + bytes([0, 7, 0xFB, 0x02, 0x01, 1]),
+         [(70000, 2, 3, 4, 0)], [(70000, 4, 6, 0, 0x101, 300, 5, 0), (70000, 4, 7, 0, 258, 1, 0, 0)], []),
+        # connection 2 (group 3, peer 0): Leave (PeerMessage variant 2), a Prepare {trigger 4, ballot 9}, then an AcceptReply: the first
+        # two are only located
+        (3, 0, be(1) + bytes([2]) + be(4) + bytes([0, 0, 4, 9]) + be(5) + bytes([0, 3, 1, 2, 0]),
+         [(3, 1, 2, 0, 0)], [], [(0xFF, 1), (0, 4)]),            # (kind the host decoder names it by, frame payload length)
+        # connection 3 (group 11, peer 2): an AcceptReply, then a frame whose Option tag is 2 -- malformed from there on
+        (11, 2, be(5) + bytes([0, 3, 8, 8, 0]) + be(5) + bytes([0, 3, 8, 8, 2]) + be(5) + bytes([0, 3, 9, 9, 0]),
+         [(11, 8, 8, 2, 0)], [], []),
+    ]
+    streams = [c[2] for c in conns]
+    got = _ingest(wire, cuda, streams, [c[0] for c in conns], [c[1] for c in conns])
+    acks = np.array([a for c in conns for a in c[3]], ACK_DTYPE)
+    hbs = np.array([h for c in conns for h in c[4]], wire.HB_DTYPE)
+    assert got["n_acks"] == len(acks) and np.array_equal(got["acks"], acks)
+    assert got["n_hbs"] == len(hbs) and np.array_equal(got["hbs"], hbs)
+    # located frames: (connection, offset of the frame in the whole buffer, bytes incl. the 8-byte length)
+    base2 = len(streams[0]) + len(streams[1])
+    assert got["n_others"] == 2
+    assert [(int(o["conn"]), int(o["off"]), int(o["len"])) for o in got["others"]] == [(2, base2, 9), (2, base2 + 9, 12)]
+    # every byte of connections 0 - 2 consumed; connection 3 stops in front of the bad frame (13 bytes in) with status 1
+    assert list(got["consumed"]) == [len(streams[0]), len(streams[1]), len(streams[2]), 13]
+    assert list(got["status"]) == [0, 0, 0, 1] and got["n_malformed"] == 1
