@@ -277,6 +277,40 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
  * joined in front of its pack on `stream` (default on); 0 = one after the other on `stream`. */
 int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on);
 
+/* ---- the exchange itself: RCCL behind the C-ABI -----------------------------------------------------------------------------
+ * Replaces `TransportHub::send_msg` / `bcast_msg` (/root/reference/src/server/transport.rs:208-275) for a host that binds
+ * this library: instead of one bincode frame per peer through a TCP messenger task, a rank hands over ONE packed device
+ * buffer with a byte count per peer rank and receives ONE buffer back (an all-to-all with split sizes), issued as grouped
+ * ncclSend / ncclRecv pairs over xGMI on the caller's HIP stream.  The call only enqueues; the buffers stay the caller's.
+ *   smr_comm_unique_id   one process makes the 128-byte id (the manager's role: clusman.rs hands out ids and peer lists) and
+ *                        ships it over the host's control channel;
+ *   smr_comm_init_rank   every rank, with its device current (hipSetDevice), blocks until all `world` ranks have called;
+ *   smr_comm_exchange    segment k of `send_dev` (send_bytes[k] bytes, segments back to back in rank order) goes to rank k,
+ *                        recv_bytes[k] bytes from rank k land in segment k of `recv_dev`; a rank's own segment is a device
+ *                        copy (SMR_COMM_SELF_VIA_RCCL: through an ncclSend / ncclRecv pair to itself, for tests);
+ *   smr_comm_all_reduce_u64  sum / max of n u64 words in place (agreeing on a tick count, a job's max elapsed time);
+ *   smr_comm_info        out = {rank, world, exchanges so far, bytes sent to other ranks, bytes received from them}. */
+typedef struct smr_comm smr_comm;
+#define SMR_COMM_ID_BYTES 128
+#define SMR_COMM_SELF_VIA_RCCL 1u
+#define SMR_COMM_SUM 0
+#define SMR_COMM_MAX 1
+int smr_comm_unique_id(uint8_t *out, uint64_t cap);
+int smr_comm_init_rank(const uint8_t *id, uint64_t id_bytes, uint32_t rank, uint32_t world, smr_comm **out);
+void smr_comm_destroy(smr_comm *c);
+int smr_comm_exchange(smr_comm *c, const void *send_dev, const uint64_t *send_bytes, void *recv_dev, const uint64_t *recv_bytes,
+                      uint32_t flags, void *stream);
+int smr_comm_all_reduce_u64(smr_comm *c, uint64_t *inout_dev, uint64_t n, int op, void *stream);
+int smr_comm_info(smr_comm *c, uint64_t out[5]);
+/* The L2 tick with its exchanges INSIDE the library: bind the communicator and the three exchanges' buffers -- send_dev[k] /
+ * recv_dev[k] = the buffers exchange k's pack / unpack plans were made over, send_bytes[k * world + r] / recv_bytes[k * world + r]
+ * = the bytes exchange k moves to / from rank r (k: 0 outbox, 1 replies, 2 heartbeat) -- then ONE call per tick:
+ * smr_mp_spread_tick = segment 0, exchange 0, segment 1, exchange 1, segment 2 [, exchange 2, segment 3], all enqueued on
+ * `stream`.  comm = NULL unbinds (the segments' caller runs the collectives again). */
+int smr_mp_spread_bind_comm(smr_mp_spread *s, smr_comm *comm, const void *const send_dev[3], const uint64_t *send_bytes,
+                            void *const recv_dev[3], const uint64_t *recv_bytes, uint32_t world);
+int smr_mp_spread_tick(smr_mp_spread *s, const smr_mp_tick_in *in, int heartbeat, void *stream);
+
 /* Device pointer + geometry of replica `rep`'s ack matrix: one 8-byte word per (outbox entry,
  * group); byte r of the word = 1 iff replica r sent an AcceptReply to that entry.  An AcceptReply
  * always carries the ballot of the Accept it answers (multipaxos/durability.rs:108-131), so the cell

@@ -239,6 +239,14 @@ SYMBOLS = [
     ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),
     ("smr_mp_debug_generic_units", _i, [_vp, _u8, C.POINTER(_u64)]),
     ("smr_mp_debug_stamps", _i, [_vp, _vp]),
+    ("smr_comm_unique_id", _i, [_vp, _u64]),
+    ("smr_comm_init_rank", _i, [_vp, _u64, _u32, _u32, C.POINTER(_vp)]),
+    ("smr_comm_destroy", None, [_vp]),
+    ("smr_comm_exchange", _i, [_vp, _vp, C.POINTER(_u64), _vp, C.POINTER(_u64), _u32, _vp]),
+    ("smr_comm_all_reduce_u64", _i, [_vp, _vp, _u64, _i, _vp]),
+    ("smr_comm_info", _i, [_vp, C.POINTER(_u64 * 5)]),
+    ("smr_mp_spread_bind_comm", _i, [_vp, _vp, C.POINTER(_vp * 3), C.POINTER(_u64), C.POINTER(_vp * 3), C.POINTER(_u64), _u32]),
+    ("smr_mp_spread_tick", _i, [_vp, _vp, _i, _vp]),
     ("smr_mp_straggler_stats", _i, [_vp, C.POINTER(_u64 * 2)]),
     ("smr_mp_poll_commits", _i, [_vp, _u8, _vp, _vp, _u64, C.POINTER(_u64)]),
     ("smr_mp_profile_enable", _i, [_vp, _i]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsummerset_hip.so")
-SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
 HEADERS = ["smr_common.h", "mp_types.h", "mp_device.h", os.path.join("..", "..", "include", "summerset_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -37,7 +37,9 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # librccl: the L2 exchange behind the C-ABI (csrc/comm.hip).  Its soname (librccl.so.1) is the one PyTorch's own copy
+        # carries, so a process that imported torch first runs both on ONE RCCL.
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -2425,6 +2425,12 @@ struct smr_mp_spread {
     std::vector<hipEvent_t> done;                // [n_blocks - 1]
     hipEvent_t fork = nullptr;
     bool concurrent = true;
+    int next_segment = 0, tick_heartbeat = 0;    // the segment the open tick expects next, and the `heartbeat` its segment 0 came with
+    // the exchange in the library (smr_mp_spread_bind_comm): the three exchanges' buffers and per-peer byte counts
+    smr_comm *comm = nullptr;
+    const void *sbuf[3] = {nullptr, nullptr, nullptr};
+    void *rbuf[3] = {nullptr, nullptr, nullptr};
+    std::vector<uint64_t> in_split[3], out_split[3];
 };
 
 // a round on every block: block 0 on the caller's stream, the others on their side streams between a fork and a join
@@ -2437,13 +2443,23 @@ static int spread_each_block(smr_mp_spread *s, hipStream_t st, const std::functi
         return SMR_OK;
     }
     SMR_HIP_TRY(hipEventRecord(s->fork, st));
-    for (size_t b = 1; b < n; b++) {
-        SMR_HIP_TRY(hipStreamWaitEvent(s->side[b - 1], s->fork, 0));
-        if ((rc = round(b, (void *)s->side[b - 1])) != SMR_OK) return rc;
-        SMR_HIP_TRY(hipEventRecord(s->done[b - 1], s->side[b - 1]));
+    // a round that fails leaves no side stream unjoined: whatever was forked is recorded and waited for before the error goes back
+    size_t forked = 0;
+    rc = SMR_OK;
+    hipError_t he = hipSuccess;
+    for (size_t b = 1; b < n && rc == SMR_OK && he == hipSuccess; b++) {
+        if ((he = hipStreamWaitEvent(s->side[b - 1], s->fork, 0)) != hipSuccess) break;
+        forked = b;
+        rc = round(b, (void *)s->side[b - 1]);
     }
-    if ((rc = round(0, (void *)st)) != SMR_OK) return rc;
-    for (size_t b = 1; b < n; b++) SMR_HIP_TRY(hipStreamWaitEvent(st, s->done[b - 1], 0));
+    if (rc == SMR_OK && he == hipSuccess) rc = round(0, (void *)st);
+    for (size_t b = 1; b <= forked; b++) {
+        const hipError_t e1 = hipEventRecord(s->done[b - 1], s->side[b - 1]);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, s->done[b - 1], 0) : e1;
+        if (he == hipSuccess) he = e2;
+    }
+    if (rc != SMR_OK) return rc;
+    SMR_HIP_TRY(he);
     return SMR_OK;
 }
 
@@ -2488,6 +2504,15 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
     if (segment < 0 || segment > 3) return fail(SMR_ERR_ARG, "mp spread: segment must be 0..3");
     if ((segment == 0 || segment == 2) && !s->cl.empty() && !in) return fail(SMR_ERR_ARG, "mp spread: segments 0 and 2 take the blocks' inputs");
     if (segment == 3 && !heartbeat) return fail(SMR_ERR_ARG, "mp spread: segment 3 exists on heartbeat ticks only");
+    // the segments of a tick come in order and with the `heartbeat` the tick opened with: segment 2 without it ends the tick, a
+    // later segment 3 with it would end it again and flip the outbox parity twice
+    if (segment != s->next_segment)
+        return fail(SMR_ERR_STATE, "mp spread: segment " + std::to_string(segment) + " out of order (the open tick expects segment " +
+                                       std::to_string(s->next_segment) + ")");
+    if (segment == 0) s->tick_heartbeat = heartbeat ? 1 : 0;
+    else if ((heartbeat ? 1 : 0) != s->tick_heartbeat)
+        return fail(SMR_ERR_STATE, "mp spread: `heartbeat` differs from the one the tick's segment 0 was called with");
+    s->next_segment = (segment == 3 || (segment == 2 && !heartbeat)) ? 0 : segment + 1;
     int rc;
     const size_t n = s->cl.size();
     hipStream_t st = (hipStream_t)stream;
@@ -2516,6 +2541,39 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
             if ((rc = smr_mp_end_tick(s->cl[b])) != SMR_OK) return rc;
         return SMR_OK;
     }
+}
+
+int smr_mp_spread_bind_comm(smr_mp_spread *s, smr_comm *comm, const void *const send_dev[3], const uint64_t *send_bytes,
+                            void *const recv_dev[3], const uint64_t *recv_bytes, uint32_t world) {
+    if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    if (s->next_segment != 0) return fail(SMR_ERR_STATE, "mp spread: bind_comm inside an open tick");
+    if (!comm) { s->comm = nullptr; return SMR_OK; }           // unbind: the collectives are the caller's again
+    if (!send_dev || !send_bytes || !recv_dev || !recv_bytes) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    uint64_t info[5];
+    int rc = smr_comm_info(comm, info);
+    if (rc != SMR_OK) return rc;
+    if (info[1] != world) return fail(SMR_ERR_ARG, "mp spread: the byte counts are per rank of the communicator's world");
+    for (int k = 0; k < 3; k++) {
+        s->sbuf[k] = send_dev[k]; s->rbuf[k] = recv_dev[k];
+        s->in_split[k].assign(send_bytes + (size_t)k * world, send_bytes + (size_t)(k + 1) * world);
+        s->out_split[k].assign(recv_bytes + (size_t)k * world, recv_bytes + (size_t)(k + 1) * world);
+    }
+    s->comm = comm;
+    return SMR_OK;
+}
+
+int smr_mp_spread_tick(smr_mp_spread *s, const smr_mp_tick_in *in, int heartbeat, void *stream) {
+    if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    if (!s->comm) return fail(SMR_ERR_STATE, "mp spread: no communicator bound (smr_mp_spread_bind_comm)");
+    const int n_seg = heartbeat ? 4 : 3;
+    for (int k = 0; k < n_seg; k++) {
+        int rc = smr_mp_spread_segment(s, k, in, heartbeat, stream);
+        if (rc != SMR_OK) return rc;
+        if (k + 1 < n_seg)                                       // exchange k sits between segments k and k + 1, on the same stream
+            if ((rc = smr_comm_exchange(s->comm, s->sbuf[k], s->in_split[k].data(), s->rbuf[k], s->out_split[k].data(), 0, stream)) != SMR_OK)
+                return rc;
+    }
+    return SMR_OK;
 }
 
 }  // extern "C"

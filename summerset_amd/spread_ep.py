@@ -134,8 +134,11 @@ class SpreadEPaxos:
     def _collective(self, plan):
         import torch.distributed as dist
         if self.world > 1:                                     # (the buffers are never empty tensors; the collective sees exactly the planned bytes)
-            dist.all_to_all_single(plan["rbuf"][:plan["n_recv"]], plan["sbuf"][:plan["n_send"]], output_split_sizes=plan["out_split"],
-                                   input_split_sizes=plan["in_split"])
+            if getattr(self, "comm", None) is not None:        # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
+                self.comm.exchange(plan["sbuf"], plan["in_split"], plan["rbuf"], plan["out_split"])
+            else:
+                dist.all_to_all_single(plan["rbuf"][:plan["n_recv"]], plan["sbuf"][:plan["n_send"]], output_split_sizes=plan["out_split"],
+                                       input_split_sizes=plan["in_split"])
 
     def _get(self, plan, key):
         """the message (block, from, to) as tensors: views of the receive buffer, or the sender's own tensors"""

@@ -58,6 +58,7 @@ class SpreadMultiPaxos:
         self.n_groups = {b: shard.group_range(total_groups, world, b) for b in range(world)}
         self.bytes_sent = 0
         self.peers = None                                      # set by in_process(): every rank's object, for a job inside one process
+        self.comm = None                                       # set by bind_comm(): the exchanges run inside the library (RCCL)
         # the three exchanges: every rank derives the same global message lists, in the same order
         self._plans = {ph: self._plan(ph) for ph in ("outbox", "replies", "heartbeat")}
         # the tick's orchestration lives in the library: one C call per segment of the tick (smr_mp_spread_segment), the
@@ -176,6 +177,23 @@ class SpreadMultiPaxos:
                 dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
                                        input_split_sizes=p["in_split"])
 
+    def bind_comm(self, comm):
+        """the collectives into the library: `comm` (summerset_amd.comm.Comm, one per rank of the job) and the three exchanges'
+        buffers / split sizes are handed to the spread object once (`smr_mp_spread_bind_comm`); `tick` is then ONE C call
+        (`smr_mp_spread_tick`: segments and RCCL exchanges enqueued back to back on the stream).  None unbinds."""
+        import ctypes as C
+        if comm is None:
+            check(self._L.smr_mp_spread_bind_comm(self._spread, None, None, None, None, None, self.world))
+            self.comm = None
+            return
+        names = ("outbox", "replies", "heartbeat")
+        sd = (C.c_void_p * 3)(*[self._plans[n]["sbuf"].data_ptr() for n in names])
+        rd = (C.c_void_p * 3)(*[self._plans[n]["rbuf"].data_ptr() for n in names])
+        sb = (C.c_uint64 * (3 * self.world))(*[int(x) for n in names for x in self._plans[n]["in_split"]])
+        rb = (C.c_uint64 * (3 * self.world))(*[int(x) for n in names for x in self._plans[n]["out_split"]])
+        check(self._L.smr_mp_spread_bind_comm(self._spread, comm._h, C.byref(sd), sb, C.byref(rd), rb, self.world))
+        self.comm = comm
+
     def _exchange(self, phase, stream=None):
         self._pack(phase, stream)
         self._collective(phase)
@@ -202,6 +220,10 @@ class SpreadMultiPaxos:
         tensors; every rank that holds block b passes the same arrays -- the streams are keyed by global group id).
         Three or four library calls (the segments between the collectives) and two or three collectives."""
         arr = self._inputs(inputs)
+        if getattr(self, "comm", None) is not None:            # the exchanges are the library's: the whole tick is one call
+            check(self._L.smr_mp_spread_tick(self._spread, arr, int(bool(heartbeat)), stream_ptr(stream)))
+            self.bytes_sent += sum(sum(self._plans[p]["in_split"]) for p in (("outbox", "replies", "heartbeat") if heartbeat else ("outbox", "replies")))
+            return
         self.segment(0, arr, heartbeat, stream)
         self._collective("outbox")
         self.segment(1, arr, heartbeat, stream)

@@ -111,6 +111,8 @@ class SpreadRSPaxos:
         self.bytes_sent += sum(p["in_split"])
         if self.exchange is not None:
             self.exchange(kind, self)
+        elif self.world > 1 and getattr(self, "comm", None) is not None:   # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
+            self.comm.exchange(p["sbuf"], p["in_split"], p["rbuf"], p["out_split"])
         elif self.world > 1:
             dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
                                    input_split_sizes=p["in_split"])
@@ -176,9 +178,10 @@ class SpreadRSPaxos:
                     first = m
                 else:
                     m["header"].copy_(first["header"])
+                # every follower's flags are written from `live`, never inherited through the header copy: the first
+                # follower's header carries THAT follower's losses, and a partial `lost` dict used to leak them
                 g = None if lost is None else lost.get(b, {}).get(("accept", s, q))
-                if g is not None:
-                    m["flags"].copy_(live & ~g.to(torch.uint8))
+                m["flags"].copy_(live if g is None else (live & ~g.to(torch.uint8)))
 
     def phase_b(self, lost=None):
         """followers: handle_msg_accept on what arrived; the reply ballots land in the backward send buffer"""

@@ -48,7 +48,8 @@ def _build(extra):
     os.makedirs(_OUT, exist_ok=True)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     rt = os.path.join(_HERE, "hipsim_rt.cpp")
-    deps = srcs + [rt, os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
+    comm = os.path.join(_HERE, "comm_sim.cpp")                  # smr_comm_* for a world of one rank (the shipped one is RCCL: csrc/comm.hip)
+    deps = srcs + [rt, comm, os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
     deps += [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
@@ -60,6 +61,9 @@ def _build(extra):
         objs.append(o)
     o = os.path.join(_OUT, "hipsim_rt.o")
     subprocess.run(base + ["-c", rt, "-o", o], check=True)
+    oc = os.path.join(_OUT, "comm_sim.o")
+    subprocess.run(base + ["-c", comm, "-o", oc], check=True)
+    objs.append(oc)
     subprocess.run([CXX, "-shared", "-o", LIB + ".tmp"] + objs + [o], check=True)
     _rank_sites(LIB + ".tmp", LIB + ".sites")
     os.replace(LIB + ".tmp", LIB)

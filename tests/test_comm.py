@@ -1,0 +1,154 @@
+"""The L2 exchange behind the C-ABI (`smr_comm_*`, `smr_mp_spread_bind_comm`, `smr_mp_spread_tick`; csrc/comm.hip) --
+stand-in for `TransportHub::send_msg` / `bcast_msg` (server/transport.rs:208-275).
+
+CPU half (emulator build, a world of one rank: tests/hostsim/comm_sim.cpp): the tick with its exchanges inside the library
+gives the co-located engine's state; the segment-order guard; argument checks.  Device half (real RCCL, one
+rank): `smr_comm_exchange` against `torch.distributed.all_to_all_single` on the same buffers, the self segment through an
+ncclSend / ncclRecv pair, the all-reduce, and the same spread tick -- in a CHILD process under a timeout, so that a
+collective that never completes fails this file instead of hanging the suite."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _OneRankJob:
+    """a spread job of ONE rank whose exchanges run inside the library (bind_comm): `tick` is smr_mp_spread_tick"""
+
+    def __init__(self, G, R, W, dev, S, **kw):
+        from summerset_amd import comm, spread_mp
+        self.rank0 = spread_mp.SpreadMultiPaxos(G, R, W, 0, 1, dev, S, **kw)
+        self.comm = comm.Comm(comm.Comm.unique_id(), 0, 1)
+        self.rank0.bind_comm(self.comm)
+        self.ranks = [self.rank0]
+
+    def preset_leader(self, rep=0):
+        self.rank0.preset_leader(rep)
+
+    def tick(self, inputs, heartbeat=False):
+        self.rank0.tick(inputs, heartbeat)
+
+
+def run_library_tick(dev, G=192, n_ticks=20):
+    from test_spread_mp import run_spread_vs_colocated
+    job = run_spread_vs_colocated(dev, G=G, R=5, S=2, W=64, world=1, n_ticks=n_ticks, drop_p=0.1, timeout_frac=1.0,
+                                  make=lambda world: _OneRankJob(G, 5, 64, dev, 2, ovf_cap=8192, outbox_cap=68))
+    info = job.comm.info()
+    # two exchanges per tick, three on a heartbeat tick (hb_every = 3): the library ran them, nobody else
+    assert info["world"] == 1 and info["exchanges"] == 2 * n_ticks + n_ticks // 3 and info["bytes_sent"] == 0
+    return job
+
+
+def test_library_tick_on_the_emulator(oracle):
+    import hostsim
+    hostsim.build()
+    with hostsim.patched():
+        run_library_tick("cpu")
+
+
+def test_segment_order_and_bind_errors_on_the_emulator(oracle):
+    """smr_mp_spread_segment used to take any segment in any order -- segment 2 without `heartbeat` ended the tick and
+    a later segment 3 ended it again.  Now SMR_ERR_STATE."""
+    import torch
+    import hostsim
+    from summerset_amd import SummersetError, comm, spread_mp, stream
+    hostsim.build()
+    with hostsim.patched():
+        G, R, S, W = 64, 5, 2, 64
+        sp = spread_mp.SpreadMultiPaxos(G, R, W, 0, 1, "cpu", S, outbox_cap=W + 4)
+        sp.preset_leader(0)
+        st = stream.MultiPaxosStream(G, R, S, cap=W + 4, n_ticks=4, drop_p=0.0, timeout_frac=0.0, hb_every=2)
+        x = {0: {k: torch.from_numpy(v) for k, v in st.tick(0).items() if isinstance(v, np.ndarray)}}
+        arr = sp._inputs(x)
+        with pytest.raises(SummersetError):
+            sp.segment(1, arr, False)                            # a tick opens with segment 0
+        sp.segment(0, arr, False)
+        with pytest.raises(SummersetError):
+            sp.segment(0, arr, False)                            # ... once
+        with pytest.raises(SummersetError):
+            sp.segment(1, arr, True)                             # `heartbeat` is the tick's, not the segment's
+        sp.segment(1, arr, False)
+        sp.segment(2, arr, False)                                # no heartbeat: the tick ends here
+        with pytest.raises(SummersetError):
+            sp.segment(3, arr, True)                             # ... and cannot be ended again
+        from summerset_amd._lib import check
+        with pytest.raises(SummersetError):
+            check(sp._L.smr_mp_spread_tick(sp._spread, arr, 0, None))          # no communicator bound
+        c = comm.Comm(comm.Comm.unique_id(), 0, 1)
+        sp.segment(0, arr, False)
+        with pytest.raises(SummersetError):
+            sp.bind_comm(c)                                      # not inside an open tick
+        sp.segment(1, arr, False)
+        sp.segment(2, arr, False)
+        sp.bind_comm(c)
+        sp.tick(x)                                               # one C call now
+        assert c.info()["exchanges"] == 2
+        with pytest.raises(SummersetError):
+            comm.Comm(comm.Comm.unique_id(), 1, 1)               # rank must be below world
+        with pytest.raises(ValueError):
+            c.exchange(None, [0, 0], None, [0])                  # split sizes are per rank
+        a, b = torch.arange(32, dtype=torch.uint8), torch.zeros(32, dtype=torch.uint8)
+        with pytest.raises(SummersetError):
+            c.exchange(a, [16], b, [8])                          # my segment for myself is what I expect from myself
+        c.exchange(a, [32], b, [32])
+        assert torch.equal(a, b)
+
+
+_CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+from summerset_amd import comm
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+c = comm.Comm.from_torch_distributed(dev)
+assert c.info()["world"] == 1
+g = torch.Generator(device=dev); g.manual_seed(7)
+for n in (8, 4096, 1 << 20, (1 << 24) + 24):
+    a = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g)
+    want = torch.zeros_like(a)
+    dist.all_to_all_single(want, a, output_split_sizes=[n], input_split_sizes=[n])       # the torch path (RCCL through c10d)
+    for via in (False, True):                                    # the self segment: a device copy / an ncclSend + ncclRecv pair
+        got = torch.zeros_like(a)
+        c.exchange(a, [n], got, [n], self_via_rccl=via)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got, a), (n, via)
+st = torch.cuda.Stream()
+with torch.cuda.stream(st):                                      # on a stream of the caller's
+    a = torch.arange(4096, dtype=torch.int64, device=dev).view(torch.uint8)
+    got = torch.zeros_like(a)
+    c.exchange(a, [a.numel()], got, [a.numel()], stream=st.cuda_stream, self_via_rccl=True)
+st.synchronize()
+assert torch.equal(got, a)
+t = torch.tensor([5, 1 << 40, 0], dtype=torch.int64, device=dev)
+c.all_reduce(t, comm.SUM); c.all_reduce(t, comm.MAX)
+torch.cuda.synchronize()
+assert t.tolist() == [5, 1 << 40, 0]
+info = c.info()
+assert info["exchanges"] == 9 and info["bytes_sent"] == 0
+# the spread tick with its exchanges inside the library, against the co-located engine
+import test_comm
+from oracle import oracle as O
+O.build()
+job = test_comm.run_library_tick(dev, G=256, n_ticks=24)
+c.close()
+dist.destroy_process_group()
+print("COMM-OK rccl exchanges", info["exchanges"], "library ticks", 24)
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_rccl_exchange_one_rank_against_the_torch_path(cuda):
+    """real RCCL, one rank, in a child process under a timeout"""
+    p = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "COMM-OK" in p.stdout, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
