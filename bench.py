@@ -26,9 +26,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r4m_pmc_traffic.json")
-PMC_NOTE = ("profiles/r4m_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, "
-            "gfx950 corrections of MI355X_MICROARCH.md applied; bytes per launch at 65536 groups, S=32, default workload)")
+PMC_FILES = ("r5m_pmc_traffic.json", "r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
+                os.path.join(ROOT, "profiles", PMC_FILES[0]))
+PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
+            "MI355X_MICROARCH.md applied; bytes per launch of the SAME grid size as the timed launch: 65536 groups, S=32, default workload)"
+            % os.path.basename(PMC_FILE))
 
 
 def pmc_file():
@@ -41,15 +44,22 @@ def pmc_file():
         return None
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, pick=None):
+    """the kernel's entry of the committed PMC record.  The record is keyed by (kernel, grid size) (tools/pmc_traffic.py: the
+    probe runs some kernels at two sizes): pick = "smallest" / "largest" names the grid size this caller timed; None = the
+    kernel's most-launched size (the only one for every kernel the probe runs at one size: `grids` == 1)."""
     d = pmc_file()
-    return d["kernels"].get(kernel) if d else None
+    e = d["kernels"].get(kernel) if d else None
+    if e and pick and e.get("by_grid"):
+        g = (min if pick == "smallest" else max)(int(x) for x in e["by_grid"])
+        e = dict(e["by_grid"][str(g)], grid=g, grids=len(e["by_grid"]))
+    return e
 
 
-def _leg_traffic(kernel):
+def _leg_traffic(kernel, pick=None):
     """HBM bytes per launch of a secondary leg's kernel from the committed PMC passes (tools/pmc_probe.py drives the same
     leg at the same shape), or None"""
-    t = pmc_traffic(kernel)
+    t = pmc_traffic(kernel, pick)
     return t["hbm_bytes_per_launch"] if t else None
 
 
@@ -209,15 +219,17 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
     us_big = _time_us(torch, lambda i: big.compute_parity(), 12)
     us_hot = _time_us(torch, lambda i: batches[0].compute_parity(), 48)
     del big
-    t_rs = pmc_traffic("smr::rs_matmul_xtime<2, 4>")
+    t_rs = pmc_traffic("smr::rs_matmul_xtime<2, 4>", pick="smallest")     # the probe's 16384-codeword launches (it also runs 65536 for the calibration)
+    same_size = bool(t_rs and t_rs.get("grids", 1) > 1)                   # (a record from before round 4 holds one average: scaled as before)
     res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String) per launch, "
                        "%d distinct batches in rotation (%.0f MB in + out: beyond the 256 MiB L3)" % (NB, NB * n * 5 * cw.shard_len / 1e6),
            "value": out["xtime"]["payload_GiBps"], "unit": "GiB/s payload",
            "roofline": {"bound": "hbm", "achieved": out["xtime"]["achieved_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": out["xtime"]["frac"], "kernel": "rs_matmul_xtime<2, 4>",
                         "alg_bytes_per_launch": n * 5 * cw.shard_len, "avg_launch_us": out["xtime"]["ms_per_launch"] * 1e3,
-                        "traffic": (t_rs["hbm_bytes_per_launch"] / 65536 * n) if t_rs else None,
-                        "traffic_note": "PMC bytes of a 65536-codeword launch scaled to this launch's %d codewords" % n},
+                        "traffic": (t_rs["hbm_bytes_per_launch"] if same_size else t_rs["hbm_bytes_per_launch"] / 65536 * n) if t_rs else None,
+                        "traffic_note": ("PMC bytes of the probe's %d-codeword launches (same grid size as this leg's)" % n) if same_size else
+                                        ("PMC bytes of a 65536-codeword launch scaled to this launch's %d codewords" % n)},
            "lut_variant_GiBps": out["lut"]["payload_GiBps"],
            "one_launch_65536_codewords": {"avg_launch_us": us_big, "frac": 65536 * 5 * cw.shard_len / (us_big * 1e-6) / 1e9 / HBM_PEAK_GBS},
            "single_hot_batch_L3_assisted": {"avg_launch_us": us_hot, "frac": n * 5 * cw.shard_len / (us_hot * 1e-6) / 1e9 / HBM_PEAK_GBS},
@@ -507,8 +519,10 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
         line["graph"] = {"value": n_c / dt, "unit": "slots/s", "ms_per_tick": dt / nt * 1e3, "device_ms_per_tick": ms, "ticks_per_graph": NB,
                          "committed_per_tick": n_c / nt, "rs_payload_GiBps": G * L * nt / 2**30 / dt}
         t_enc, t_tick = _leg_traffic("smr::rs_from_data_xtime<2, 4>"), _leg_traffic("smr::rsp_cluster_tick_kernel")
+        alg_8d = G * 5 * cws[0].shard_len + G * (52 + 33)        # 5 * ceil(L / 3) per codeword (3 shards in, 2 out) + the tally's bytes
         line["roofline"] = {"bound": "hbm", "kernel": "the whole tick (one HIP graph of %d ticks): rs_from_data_xtime<2, 4> (encode + fan-out) + rsp_cluster_tick_kernel" % NB,
                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "frac_on_survey_8d_bytes": alg_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "survey_8d_bytes_per_launch": alg_8d,
                             "alg_bytes_per_launch": alg, "avg_launch_us": ms * 1e3, "traffic": (t_enc + t_tick) if (t_enc and t_tick) else None, "traffic_source": PMC_NOTE,
                             "note": "alg bytes per tick = 16384 x (L read + 5 shard_len written for the leader's codeword + 5 shard_len for the shard "
                                     "stores) for from_data + encode + fan-out, 85 B per slot for the tally (SURVEY 8(d))"}

@@ -125,6 +125,9 @@ struct Lane {
     }
 
     __device__ __forceinline__ size_t ix(uint32_t slot) const { return tix(P.W, slot & P.Wmask, g); }
+    // a slot's ballot: inside the run [brun, len) it is bal_max_seen and not stored (the follower's steady appends since
+    // round 2, the leader's since round 4)
+    __device__ __forceinline__ uint64_t slot_bal(uint32_t slot, size_t i) const { return slot >= brun ? bms : v.s_bal()[i]; }
     __device__ __forceinline__ bool is_leader() const { return leader == me; }
 
     // mod.rs:553-561
@@ -336,7 +339,7 @@ struct Lane {
         size_t i = ix(slot);
         uint32_t m = v.s_meta()[i];
         if (!is_leader() || m_st(m) != SMR_ST_ACCEPTING) return;   // :394-399
-        if (ballot < v.s_bal()[i]) return;
+        if (ballot < slot_bal(slot, i)) return;
         if (!(m & M_LBK)) return;                               // debug_assert :402
         uint32_t bit = 1u << (peer + M_ACKS_SH);
         if (m & bit) return;                                    // :404-406
@@ -389,7 +392,7 @@ struct Lane {
     // durability.rs:85-145 handle_logged_accept_data, leader branch
     __device__ __forceinline__ void self_accept_logged(uint32_t slot) {
         size_t i = ix(slot);
-        accept_reply(me, slot, v.s_bal()[i]);                     // :99-103
+        accept_reply(me, slot, slot_bal(slot, i));                // :99-103
         accept_bar_scan(slot);
     }
 

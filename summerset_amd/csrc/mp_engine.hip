@@ -163,15 +163,22 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
         // tight store-only loop.  Exactly what req_batch() does per batch in that
         // state (first_null_slot -> push, fresh LeaderBookkeeping + self ack,
         // Accept bcast, accept_bar + 1), with the array pointers hoisted.
-        if (L.is_leader() && L.bpd != 0 && P.thresh > 1 && L.nlb >= L.len && L.abar == L.len &&
+        // (bpd == bal_max_seen for every prepared leader -- a higher ballot seen deposes it (check_leader) -- and is tested so
+        // that the ballot run below rests on nothing unstated)
+        if (L.is_leader() && L.bpd != 0 && L.bpd == L.bms && P.thresh > 1 && L.nlb >= L.len && L.abar == L.len &&
             (L.len - L.start) + n_req - 1 + P.win_reserve < P.W) {
             L.ob_load(par);
             const uint32_t c0 = par == 0 ? L.obn0 : L.obn1;
             if (c0 + n_req <= P.cap) {
                 const RepView &v = L.v;
-                SMR_G uint64_t *const sb = v.s_bal(); SMR_G uint32_t *const sv = v.s_val(); SMR_G uint32_t *const sm = v.s_meta();
+                SMR_G uint32_t *const sv = v.s_val(); SMR_G uint32_t *const sm = v.s_meta();
                 SMR_G uint32_t *const os = v.ob_slot(par); SMR_G uint64_t *const obl = v.ob_bal(par);
                 SMR_G uint32_t *const ov = v.ob_val(par);
+                // Leader-side ballot run (round 4): the appended slots' ballot IS bal_prepared == bal_max_seen, so it is not
+                // stored -- [bal_lo, log_len) is the run the follower's append path already keeps (mp_device.h: brun), its
+                // readers (the tally, r3_accept_replies, accept_reply) take bal_max_seen for a slot inside it, and whoever
+                // writes another ballot or moves bal_max_seen writes the run's ballots out first (BAL_TOUCH).  8 of the 16 B
+                // this loop stored per slot, and 8 of the 12 B the tally loaded per row.
                 const uint64_t bal = L.bpd;
                 const uint32_t base = L.len, G = P.G, Wm = P.Wmask;
                 const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (r + M_ACKS_SH));
@@ -182,7 +189,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                         const uint32_t slot = base + k + q;
                         const size_t i = tix(P.W, slot & Wm, g);
                         const size_t o = tix(P.cap, c0 + k + q, g);
-                        sb[i] = bal; sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
+                        sv[i] = tok[q]; sm[i] = m0 | (tok[q] ? M_NONEMPTY : 0u);
                         if (c0 != 0) { os[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); obl[o] = bal; }   // else: follow from ob_reg / ob_rbal
                         ov[o] = tok[q];
                     }
@@ -201,6 +208,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
                     for (int q = 0; q < 8; q++) tok[q] = (k + q < n_req) ? req_val[(size_t)(k + q) * G + g] : 0u;
                     put8(k, tok);
                 }
+                if (L.brun == 0xFFFFFFFFu || L.brun > base) L.brun = base;   // the run starts here, or goes on
                 L.len = base + n_req; L.abar = L.len; L.nlb = L.len;
                 if (par == 0) L.obn0 = c0 + n_req; else L.obn1 = c0 + n_req;
                 v.ob_reg(par)[g] = c0 == 0 ? base + 1 : 0u;
@@ -650,7 +658,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             const bool have = in && (e >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
             const size_t i = tix(P.W, slot & Wm, g);
             const uint32_t m0 = have ? sm[i] : 0u;
-            const uint64_t b = have ? sb[i] : 0ull;
+            const uint64_t b = !have ? 0ull : (slot >= L.brun ? L.bms : sb[i]);   // (a leader's ballot run: unstored)
             uint32_t mk = m0;
             bool changed = false, committed = false;
             if (have && lead && (mk & M_LBK)) mk = tally_row<NR>(m0, b, ctl, a, d, eb, bpd, thresh, R, changed, committed);
@@ -723,7 +731,7 @@ __device__ __forceinline__ void r3_accept_replies(Lane &L, const uint32_t *__res
             have[k] = (e[k] >> OB_KIND_SH) == OB_ACCEPT && slot >= L.start && slot < L.len;
             const size_t i = tix(P.W, slot & Wm, g);
             m[k] = have[k] ? sm[i] : 0u;
-            b[k] = have[k] ? sb[i] : 0ull;
+            b[k] = !have[k] ? 0ull : (slot >= L.brun ? L.bms : sb[i]);
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {
@@ -850,6 +858,8 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     const uint32_t h_start = rep_shift(v0.start_slot, roh)[gg], h_len = rep_shift(v0.log_len, roh)[gg];
     const uint32_t h_cbar = rep_shift(v0.commit_bar, roh)[gg], h_ebar = rep_shift(v0.exec_bar, roh)[gg];
     const uint32_t h_abar = rep_shift(v0.accept_bar, roh)[gg];
+    const uint32_t h_brun = rep_shift(v0.bal_lo, roh)[gg];
+    const uint64_t h_bms = rep_shift(v0.bal_max_seen, roh)[gg];
 #endif
     const bool active = g < G && !ovf;                          // ovf: frozen, or on the straggler list
     uint32_t prmask = 0;
@@ -881,15 +891,15 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     // Rows are dealt to the four wavefronts round robin -- wavefront w takes rows w, w + 4, w + 8, ... -- so WHICH rows a
     // wavefront tallies depends on nothing it has to load first: their ackctl words went out with round 1 above.
     // ---- round 2: my replica's scalars -------------------------------------------------------------
-    uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0;
-    uint64_t bpd = 0;
+    uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0, brun = 0xFFFFFFFFu;
+    uint64_t bpd = 0, bms = 0;
     uint64_t a[C], rbal = 0;
 #if TALLY_SPEC
     if (spec) {
 #pragma unroll
         for (int q = 0; q < NR; q++) ab[q] = (uint32_t)q < R ? abh[q] : 0ull;
         reg = h_reg; bpd = h_bpd; rbal = h_rbal; leader = h_leader; start = h_start; len = h_len;
-        cbar = h_cbar; ebar = h_ebar; abar = h_abar;
+        cbar = h_cbar; ebar = h_ebar; abar = h_abar; brun = h_brun; bms = h_bms;
     }
 #endif
     if (cand && !spec) {
@@ -898,6 +908,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         leader = rep_shift(v0.leader, ro)[gg];
         start = rep_shift(v0.start_slot, ro)[gg]; len = rep_shift(v0.log_len, ro)[gg];
         cbar = p_cbar[gg]; ebar = p_ebar[gg]; abar = rep_shift(v0.accept_bar, ro)[gg];
+        brun = rep_shift(v0.bal_lo, ro)[gg]; bms = rep_shift(v0.bal_max_seen, ro)[gg];   // the leader's ballot run (R1)
     }
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
     uint32_t wall = 0xFF;                                        // TALLY_WAVEFLAGS: AND of my rows' flags
@@ -920,7 +931,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             const bool have = fast4 && j < cnt && slot >= start && slot < len;
             const size_t i = tix(P.W, slot & Wm, g);
             m[k] = have ? sm[i] : 0xFFFFFFFFu;
-            b[k] = have ? sb[i] : 0ull;
+            b[k] = !have ? 0ull : (slot >= brun ? bms : sb[i]);      // inside the run the ballot is bal_max_seen, unstored
             a[k] = (cand && j < cnt) ? ack_word_from_bits<NR>(ab, j) : 0ull;
         }
 #pragma unroll
