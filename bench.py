@@ -250,6 +250,54 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
     return res
 
 
+def _on_all_cores(fn, seconds=3.0, **kw):
+    """a one-thread CPU baseline `fn(seconds=..., **kw)` -> its object, and next to it the same thing as one single-threaded
+    process per host core side by side ((a) one thread, (b) nproc): groups are independent, so that is how a
+    multi-core host runs them; rates summed, `cores` = the processes really used"""
+    import multiprocessing as mp
+    one = fn(seconds=seconds, **kw)
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
+    out = dict(one, single_core_value=one["value"], cores=1)
+    if cores > 1:
+        with mp.get_context("fork").Pool(cores) as pool:
+            res = pool.starmap(_call_kw, [(fn, dict(kw, seconds=seconds))] * cores)
+        out["value"], out["cores"] = sum(r["value"] for r in res), cores
+        out["sample"] = "%d single-threaded processes side by side (rates summed), each: %s; one process alone: %.4g %s" % (
+            cores, one["sample"], one["value"], one["unit"])
+    return out
+
+
+def _call_kw(fn, kw):
+    return fn(**kw)
+
+
+def rspaxos_cpu_baseline(G=1024, L=4113, seconds=3.0):
+    """config 4 on the CPU oracles (one core): per tick the RS(3,2) encode of G request batches of L bytes (oracle/rs_oracle.c)
+    and the steady tick of five RspOracle replicas in the numpy-staged closed loop (summerset_amd/rsp_cluster.tick)"""
+    from oracle import oracle as O
+    from summerset_amd import rsp_cluster, workloads
+    R = 5
+    orcs = [O.RspOracle(G, R, me=r, W=64, fault_tolerance=1) for r in range(R)]
+    for o in orcs:
+        o.preset_leader(0)
+    rng = np.random.default_rng(0x5EED5EED)
+    data = rng.integers(0, 256, (G, L), dtype=np.uint8)
+    lost = {k: v.astype(bool) for k, v in workloads.config4_loss(rng, G).items()}
+    leader = np.zeros(G, np.uint8)
+    spent, t, committed = 0.0, 0, 0
+    while spent < seconds:
+        val = workloads.config4_tokens(G, t).view(np.uint32)
+        t0 = time.perf_counter()
+        O.rs_encode_batch(3, 2, data, L, L, G)
+        log = rsp_cluster.tick(orcs, val, leader, drop=lost, heartbeat=(t % 4 == 3))
+        spent += time.perf_counter() - t0
+        committed += sum(int(e["committed"].sum()) for e in log if e["kind"] == "commit")
+        t += 1
+    return {"value": committed / spent, "unit": "slots/s", "cores": 1, "kind": "port",
+            "sample": "oracle/rs_oracle.c + oracle/rsp_oracle.c, %d ticks of %d groups x 5 replicas (RS(3,2) of L = %d per group per tick), "
+                      "one thread, %.1f s" % (t, G, L, spent)}
+
+
 def raft_cpu_baseline(S=32, G=4096, seconds=3.0):
     """oracle/raft_oracle.c on the Raft leg's stream (one core): appends + four replies per group per tick"""
     from oracle import oracle as O
@@ -1575,10 +1623,10 @@ def main():
                 leg("craft_leader", leg_isolated, "craft_leader")
                 leg("quorum_read", leg_isolated, "quorum_read")
             if not args.no_cpu:                    # their CPU baselines sit inside the legs' objects
-                for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline)):
+                for name, fn in (("raft_quorum", raft_cpu_baseline), ("epaxos_fast_quorum", epaxos_cpu_baseline), ("rspaxos", rspaxos_cpu_baseline)):
                     if isinstance(line.get(name), dict) and "error" not in line[name]:
                         try:
-                            line[name]["cpu_baseline"] = fn()
+                            line[name]["cpu_baseline"] = _on_all_cores(fn, seconds=2.0)   # one thread AND one process per core
                         except Exception as e:     # noqa: BLE001
                             line[name]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
                             failed.append(name + ".cpu_baseline")

@@ -1136,9 +1136,11 @@ typedef struct { uint8_t *state; uint32_t *slot, *val; } smr_qread_replies;   /*
  * uint8 [window][G], token uint32 [window][G].  mp_layout 1: the arrays of a replica of the MultiPaxos cluster engine as
  * they lie in HBM (smr_mp_replica_log_view): wave-tiled rings, status = the low 3 bits of the 32-bit meta words.
  * run_lo / run_hi [G] (both NULL, or both set): slots in [run_lo[g], run_hi[g]) are Executed whatever the stored status
- * says -- the engine keeps the statuses its followers learn by heartbeat implicit in (run start, commit_bar). */
+ * says -- the engine keeps the statuses its followers learn by heartbeat implicit in (run start, commit_bar).
+ * run_leader [G] (NULL: none) with run_rep: where run_leader[g] != run_rep the replica is a follower whose run stores no
+ * status word at all (round 4) -- a slot of [run_lo[g], log_end[g]) at or above run_hi[g] is then Accepting. */
 typedef struct { const uint32_t *start_slot, *log_end; const void *status; const uint32_t *token; uint32_t window, mp_layout;
-                 const uint32_t *run_lo, *run_hi; } smr_qread_log;
+                 const uint32_t *run_lo, *run_hi; const uint8_t *run_leader; uint32_t run_rep; } smr_qread_log;
 /* the log of replica `rep` of a MultiPaxos cluster as smr_qread_handle_read_query reads it, in place (device pointers
  * into the cluster's arena; valid while the cluster lives; read them between ticks) */
 int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out);

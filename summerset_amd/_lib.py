@@ -81,7 +81,8 @@ class QreadReplies(C.Structure):
 
 class QreadLog(C.Structure):
     _fields_ = [("start_slot", C.c_void_p), ("log_end", C.c_void_p), ("status", C.c_void_p), ("token", C.c_void_p),
-                ("window", C.c_uint32), ("mp_layout", C.c_uint32), ("run_lo", C.c_void_p), ("run_hi", C.c_void_p)]
+                ("window", C.c_uint32), ("mp_layout", C.c_uint32), ("run_lo", C.c_void_p), ("run_hi", C.c_void_p),
+                ("run_leader", C.c_void_p), ("run_rep", C.c_uint32)]
 
 
 class RaftCfg(C.Structure):

@@ -64,9 +64,15 @@ struct Lane {
     // passes them all; a run slot below commit_bar is Executed by definition (stored: Accepting), and whoever ends the
     // run writes those statuses out first.  Nothing reads a slot below commit_bar before that: the bar scans start at
     // commit_bar / accept_bar, every generic handler ends the run on entry.
-#define BAL_MAT_BAL(_s) v.s_bal()[ix(_s)] = bms
-#define BAL_MAT_ST(_s) do { if ((_s) < cbar) { const size_t _i = ix(_s); v.s_meta()[_i] = m_set_st(v.s_meta()[_i], SMR_ST_EXECUTED); } } while (0)
-#define BAL_TOUCH() do { if (brun != 0xFFFFFFFFu) { for (uint32_t _s = (brun > start ? brun : start) + cl; _s < len; _s += cn) { BAL_MAT_BAL(_s); BAL_MAT_ST(_s); } brun = 0xFFFFFFFFu; } } while (0)
+    // Round 4, one step further for the FOLLOWER's run: its steady-state append stores neither ballot NOR meta word (8 + 4 of
+    // the 16 B it wrote per slot in round 1; only the batch token remains) -- a slot it appended under leader `leader` is
+    // `follower_run_meta(token, leader, slot < commit_bar)`: fresh ReplicaBookkeeping from that leader, voted = (ballot,
+    // reqs), Accepting, or Executed once the bars passed it.  Whoever ends the run (end_run(): everything that writes a
+    // ballot, moves bal_max_seen or changes `leader` -- always BEFORE it does) writes ballots and metas out first.  The only
+    // handler that meets run slots without ending the run is the heartbeat's commit learning (hb_advance), which knows.
+    // The LEADER's run (mp_round_local's fast path) keeps its metas stored -- they carry the accept_acks -- and only leaves
+    // out the ballots.  Which kind a run is follows from leader == me: a role change ends the run first.
+#define BAL_TOUCH() end_run()
 #define BAL_EXTEND(from) do { if (brun == 0xFFFFFFFFu || brun > (from)) brun = (from); } while (0)
 #define HB_BAL(slot, i) ((slot) >= brun ? ballot : v.s_bal()[i])
     uint32_t obn0, obn1;           // outbox counts of parity 0 / 1 (scalars: a runtime-indexed
@@ -89,6 +95,39 @@ struct Lane {
     }
 
     __device__ __forceinline__ void bal_touch() { BAL_TOUCH(); }   // for callers outside the struct (experiments, see above)
+    static __device__ __forceinline__ uint32_t follower_run_meta(uint32_t tok, uint32_t ldr, bool executed) {
+        return (executed ? SMR_ST_EXECUTED : SMR_ST_ACCEPTING) | M_RBK | (ldr << M_SRC_SH) | (VM_SAME << M_VMODE_SH) |
+               (tok ? M_NONEMPTY : 0u);
+    }
+    // is `slot` inside a follower's run: its meta word is not stored (see above)
+    __device__ __forceinline__ bool meta_unstored(uint32_t slot) const { return slot >= brun && leader != me; }
+    // end the run [brun, len): write out what its slots left unstored.  Uniform mode: every lane its share.
+    __device__ __forceinline__ void end_run() {
+        if (brun == 0xFFFFFFFFu) return;
+        const uint32_t lo = brun > start ? brun : start;
+        if (leader != me) {                                      // a follower's run: ballots and metas (4 token loads per round)
+            for (uint32_t s0 = lo + cl; s0 < len; s0 += 4 * cn) {
+                uint32_t tk[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) tk[u] = (s0 + u * cn < len) ? v.s_val()[ix(s0 + u * cn)] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t s_ = s0 + u * cn;
+                    if (s_ >= len) break;
+                    const size_t i_ = ix(s_);
+                    v.s_bal()[i_] = bms;
+                    v.s_meta()[i_] = follower_run_meta(tk[u], leader, s_ < cbar);
+                }
+            }
+        } else {                                                 // the leader's: ballots; metas are stored (a slot below commit_bar is Executed)
+            for (uint32_t s_ = lo + cl; s_ < len; s_ += cn) {
+                const size_t i_ = ix(s_);
+                v.s_bal()[i_] = bms;
+                if (s_ < cbar) v.s_meta()[i_] = m_set_st(v.s_meta()[i_], SMR_ST_EXECUTED);
+            }
+        }
+        brun = 0xFFFFFFFFu;
+    }
     __device__ __forceinline__ void set_uniform() { wr = __lane_id() == 0; cl = (uint32_t)__lane_id(); cn = 64; }
     __device__ __forceinline__ bool coop() const { return cn != 1; }
 
@@ -690,6 +729,7 @@ struct Lane {
     // the in-progress instances; 8 slots per batch of loads.
     __device__ __forceinline__ void become_a_leader(uint32_t src) {
         if (leader != NO_REP && leader != src) return;          // :77-81
+        BAL_TOUCH();                                            // (a follower's run is written out under the leader it was built under)
         leader = me;                                            // :98
         // :104 bcast_heartbeats() now, still carrying the old bal_max_seen (:240-247)
         ob_push(par, OB_HEARTBEAT, cbar, bms, ebar, snap);
@@ -866,7 +906,8 @@ struct Lane {
                 if (simple && lz && sfx >= brun && sfx < hb_commit) {
                     const uint32_t tgt = hb_commit < abar ? hb_commit : abar;
                     if (tgt > sfx) {
-                        if (sfx == e0 && (v.s_meta()[ix(sfx)] & M_NONEMPTY)) chase = true;
+                        // (M_NONEMPTY mirrors s_val != 0; a follower's run stores no meta word)
+                        if (sfx == e0 && (meta_unstored(sfx) ? v.s_val()[ix(sfx)] != 0u : (v.s_meta()[ix(sfx)] & M_NONEMPTY) != 0u)) chase = true;
                         sfx = tgt;
                     }
                 }
@@ -882,7 +923,9 @@ struct Lane {
                     for (int k = 0; k < 8; k++) {
                         bool in = s + k < hb_commit;
                         size_t i = ix(s + k);
-                        mm[k] = in ? v.s_meta()[i] : 0u;
+                        // (a slot of a follower's run: its meta is what the append would have stored -- Accepting here, the bars
+                        // have not passed it)
+                        mm[k] = !in ? 0u : (meta_unstored(s + k) ? follower_run_meta(v.s_val()[i], leader, false) : v.s_meta()[i]);
                         bb[k] = in ? HB_BAL(s + k, i) : 0ull;
                     }
 #pragma unroll
@@ -902,7 +945,9 @@ struct Lane {
             }
             if (sfx > c0) {
                 // the run started in the fused prefix goes on from commit_bar, whatever marked it
-                if (cbar < len) commit_complete<8>(cbar, v.s_meta()[ix(cbar)], 0xFFFFFFFFu, chase);
+                // a slot of a follower's run at commit_bar is Accepting: the run of commits ends in front of it, exec_bar rides
+                // up to it (what commit_complete does with such a slot, without reading the meta word that is not there)
+                if (cbar < len && !meta_unstored(cbar)) commit_complete<8>(cbar, v.s_meta()[ix(cbar)], 0xFFFFFFFFu, chase);
                 else if (chase) ebar = cbar;
             } else if (first != 0xFFFFFFFFu) {
                 // CommitSlot completions: only the first can sit at commit_bar

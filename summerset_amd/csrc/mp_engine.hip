@@ -490,8 +490,8 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         for (int k = 0; k < 8; k++) {
                             if (j0 + k >= cnt) break;
                             const size_t i = tix(W, (len + j0 + k) & Wm, g);
-                            (void)sb;
-                            sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+                            (void)sb; (void)sm; (void)m0;            // neither ballot nor meta: the run (mp_device.h: end_run)
+                            sv[i] = val[k];
                             ACK_STORE(ack, j0 + k, 1);
                         }
                     }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
                         }
                         const size_t i = tix(W, len & Wm, g);
                         (void)sb;
-                        sv[i] = val[k]; sm[i] = m0 | (val[k] ? M_NONEMPTY : 0u);
+                        sv[i] = val[k];
                         ACK_STORE(ack, j0 + k, 1);
                         len++;
                         fast_done++;
@@ -2247,6 +2247,7 @@ int smr_mp_replica_log_view(smr_mp_cluster *c, uint8_t rep, smr_qread_log *out) 
     out->start_slot = v.start_slot; out->log_end = v.log_len;       // log_len is kept as start_slot + insts.len()
     out->status = v.s_meta; out->token = v.s_val; out->window = c->cfg.window; out->mp_layout = 1;
     out->run_lo = v.bal_lo; out->run_hi = v.commit_bar;             // inside the run a slot below commit_bar is Executed, unwritten
+    out->run_leader = v.leader; out->run_rep = rep;                 // ... and one at or above it Accepting, unwritten, in a follower's run
     return SMR_OK;
 }
 
@@ -2315,7 +2316,10 @@ int smr_mp_dump_range(smr_mp_cluster *c, uint8_t rep, uint32_t g0, uint32_t n, c
             const size_t t = tix((uint32_t)W, s & (uint32_t)(W - 1), (uint32_t)g);   // index inside the copied tiles
             uint32_t m = meta[t];
             if (s >= bal_lo[g]) bal[t] = hb->bal_max_seen[g];                    // inside the run the ballot is not stored
-            if (s >= bal_lo[g] && s < hb->commit_bar[g]) m = (m & ~M_STATUS) | SMR_ST_EXECUTED;   // nor the statuses the bars imply
+            if (s >= bal_lo[g] && hb->leader[g] != rep)                          // a follower's run: nor the meta word (mp_device.h)
+                m = (s < hb->commit_bar[g] ? SMR_ST_EXECUTED : SMR_ST_ACCEPTING) | M_RBK | ((uint32_t)hb->leader[g] << M_SRC_SH) |
+                    (VM_SAME << M_VMODE_SH) | (val[t] ? M_NONEMPTY : 0u);
+            else if (s >= bal_lo[g] && s < hb->commit_bar[g]) m = (m & ~M_STATUS) | SMR_ST_EXECUTED;   // nor the statuses the bars imply
             hb->s_bal[o] = bal[t]; hb->s_status[o] = (uint8_t)(m & M_STATUS); hb->s_reqs[o] = val[t];
             uint32_t vm = (m >> M_VMODE_SH) & 3u;
             hb->s_vbal[o] = vm == VM_SAME ? bal[t] : (vm == VM_SIDE ? vbal[t] : 0);

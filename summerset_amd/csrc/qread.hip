@@ -14,7 +14,7 @@
 namespace smr {
 
 constexpr uint32_t QR_NONE = 0xFFFFFFFFu;
-enum { QR_COMMITTED = 3, QR_EXECUTED = 4 };
+enum { QR_ACCEPTING = 2, QR_COMMITTED = 3, QR_EXECUTED = 4 };
 enum { RP_NONE = 0, RP_SLOT = 1, RP_VALUE = 2 };
 enum { OUT_PENDING = 0, OUT_NOT_FOUND = 1, OUT_RETRY = 2, OUT_VALUE = 3 };
 
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void qr_read_query_kernel(const QrView v, cons
                                                             const uint32_t *__restrict__ log_end, const void *__restrict__ status,
                                                             const uint32_t *__restrict__ token, uint32_t Wmask, uint32_t mp_layout,
                                                             const uint32_t *__restrict__ run_lo, const uint32_t *__restrict__ run_hi,
+                                                            const uint8_t *__restrict__ run_leader, uint32_t run_rep,
                                                             uint8_t *__restrict__ o_state, uint32_t *__restrict__ o_slot,
                                                             uint32_t *__restrict__ o_val, uint8_t *__restrict__ from_leader) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
@@ -74,7 +75,10 @@ __global__ __launch_bounds__(256) void qr_read_query_kernel(const QrView v, cons
                         // mp_layout: the MultiPaxos engine's own rings -- wave-tiled (mp_types.h tix) meta words, Status in the low 3 bits
                         const size_t w = mp_layout ? ((size_t)(g >> 6) * (Wmask + 1) + (h & Wmask)) * 64 + (g & 63) : (size_t)(h & Wmask) * v.G + g;
                         uint32_t sv = mp_layout ? (((const uint32_t *)status)[w] & 7u) : ((const uint8_t *)status)[w];
-                        if (run_lo && h >= run_lo[g] && h < run_hi[g]) sv = QR_EXECUTED;   // status implied by the bars
+                        if (run_lo && h >= run_lo[g]) {
+                            if (h < run_hi[g]) sv = QR_EXECUTED;                        // status implied by the bars
+                            else if (run_leader && run_leader[g] != run_rep) sv = QR_ACCEPTING;   // a follower's run stores no status word
+                        }
                         if (sv >= QR_COMMITTED) { st = RP_VALUE; vl = token[w]; }
                     }
                 }
@@ -256,7 +260,7 @@ int smr_qread_handle_read_query(smr_qread *h, const uint8_t *keys_dev, const uin
     if (!log->window || (log->window & (log->window - 1))) return fail(SMR_ERR_ARG, "qread: log window must be a power of two");
     if (!log->run_lo != !log->run_hi) return fail(SMR_ERR_ARG, "qread: run_lo and run_hi go together");
     hipLaunchKernelGGL(qr_read_query_kernel, QR_GRID(h), h->v, keys_dev, n_dev, stable_leader_dev, kv_dev, log->start_slot,
-                       log->log_end, log->status, log->token, log->window - 1, log->mp_layout, log->run_lo, log->run_hi, out->state, out->slot, out->val, from_leader_dev);
+                       log->log_end, log->status, log->token, log->window - 1, log->mp_layout, log->run_lo, log->run_hi, log->run_leader, log->run_rep, out->state, out->slot, out->val, from_leader_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
