@@ -498,7 +498,7 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     reps, loop = workloads.config4_cluster(G, W, c4["ft"], one_launch=os.environ.get("SMR_RSP_CALL_BY_CALL") is None)
     rng = np.random.default_rng(0x5EED5EED)
     srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
-    cws = [RSCodewordBatch(G, L, 3, 2, device=dev, zero=False) for _ in range(NB)]
+    sl = -(-L // 3)                                                      # shard_len = ceil(L / d)
     masks = [{k_: torch.from_numpy(v).to(dev) for k_, v in workloads.config4_loss(rng, G).items()} for k in range(NB)]   # ~30 % of the slots lose ONE of their four replies
     vals = [torch.from_numpy(workloads.config4_tokens(G, j)).to(dev) for j in range(8 * NB)]   # the ticks' batch tokens: inputs, resident before the timed region
     n_tick = [0]                                                         # (round 3 made them with four torch kernels INSIDE every tick: ~25 us of a 0.125 ms tick, profiles/r4w)
@@ -506,7 +506,7 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     def one_tick(k, hb):
         val = vals[(n_tick[0] // NB * NB + k) % len(vals)]
         n_tick[0] += 1
-        return workloads.config4_tick(loop, k, srcs[k], cws[k], val, masks[k], hb)   # encode + fan-out (one pass), then the tick (one launch)
+        return workloads.config4_tick(loop, k, srcs[k], val, masks[k], hb)[0]   # encode straight into the holders' stores (each shard written once), then the tick (one launch)
 
     def commits():
         return int(reps[0].dump()["counters"][0])
@@ -518,8 +518,8 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
                         "encode in one pass (L = %d, %d rotating buffer pairs = %.0f MB), leader's handle_req_batch, shard fan-out to the "
                         "followers' stores, 4 x handle_msg_accept (one shard each), AcceptReply tally at majority + 1 with the "
                         "shard-availability gate, Heartbeats every %d ticks; <= 1 of 4 replies lost per slot"
-                        % (G, L, NB, NB * (G * L + G * cws[0].cw_stride) / 1e6, H),
-            "engine": "csrc/rsp_engine.hip (rsp_cluster_tick_kernel: the tick's handlers in one launch, messages through LDS%s) + rs_from_data_xtime<2, 4>"
+                        % (G, L, NB, NB * (G * L + G * 5 * sl) / 1e6, H),
+            "engine": "csrc/rsp_engine.hip (rsp_cluster_tick_kernel: the tick's handlers in one launch, messages through LDS%s) + rs_from_data_xtime<2, 4> writing every shard once into its holder's store"
                       % ("" if loop._cl is not None else " -- here: SMR_RSP_CALL_BY_CALL, one launch per handler"),
             "launches_per_tick": 2 if loop._cl is not None else "~15"}
     # eager: one host call per handler
@@ -563,17 +563,18 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
         n_c = commits() - c0
         nt = reps_ * NB
         ms = e0.elapsed_time(e1) / nt
-        alg = G * (L + 10 * cws[0].shard_len) + G * (52 + 33)   # the encode pass (L read, the codeword + the five stores written) + the tally's 8(d) bytes
+        alg = G * (L + 5 * sl) + G * (52 + 33)   # the encode pass (L read, the five shards written ONCE, into their holders' stores) + the tally's 8(d) bytes
         line["graph"] = {"value": n_c / dt, "unit": "slots/s", "ms_per_tick": dt / nt * 1e3, "device_ms_per_tick": ms, "ticks_per_graph": NB,
                          "committed_per_tick": n_c / nt, "rs_payload_GiBps": G * L * nt / 2**30 / dt}
         t_enc, t_tick = _leg_traffic("smr::rs_from_data_xtime<2, 4>"), _leg_traffic("smr::rsp_cluster_tick_kernel")
-        alg_8d = G * 5 * cws[0].shard_len + G * (52 + 33)        # 5 * ceil(L / 3) per codeword (3 shards in, 2 out) + the tally's bytes
+        alg_8d = G * 5 * sl + G * (52 + 33)        # 5 * ceil(L / 3) per codeword (3 shards in, 2 out) + the tally's bytes
         line["roofline"] = {"bound": "hbm", "kernel": "the whole tick (one HIP graph of %d ticks): rs_from_data_xtime<2, 4> (encode + fan-out) + rsp_cluster_tick_kernel" % NB,
                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "frac_on_survey_8d_bytes": alg_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "survey_8d_bytes_per_launch": alg_8d,
                             "alg_bytes_per_launch": alg, "avg_launch_us": ms * 1e3, "traffic": (t_enc + t_tick) if (t_enc and t_tick) else None, "traffic_source": PMC_NOTE,
-                            "note": "alg bytes per tick = 16384 x (L read + 5 shard_len written for the leader's codeword + 5 shard_len for the shard "
-                                    "stores) for from_data + encode + fan-out, 85 B per slot for the tally (SURVEY 8(d))"}
+                            "note": "alg bytes per tick = 16384 x (L read + 5 shard_len written: every shard once, straight into its holder's "
+                                    "store -- the leader's codeword is a view of the stores) for from_data + encode + fan-out, 85 B per slot for the "
+                                    "tally (SURVEY 8(d)); round 3 wrote the codeword AND the stores (L + 10 shard_len)"}
         best = "graph" if line["graph"]["value"] >= line["eager"]["value"] else "eager"   # (two launches per tick: a graph of four ticks saves little)
         line["value"], line["unit"], line["ms_per_tick"], line["value_is"] = line[best]["value"], "slots/s", line[best]["ms_per_tick"], best
         line["rs_payload_GiBps"] = line[best]["rs_payload_GiBps"]
@@ -583,10 +584,12 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
         line["rs_payload_GiBps"] = line["eager"]["rs_payload_GiBps"]
     # the encode pass alone, in rotation: from_data + compute_parity as two steps against the one-pass kernel
     us_two = _time_us(torch, lambda i: RSCodewordBatch.from_data(srcs[i % NB], 3, 2).compute_parity(), 16)
+    cws = [RSCodewordBatch(G, L, 3, 2, device=dev, zero=False) for _ in range(NB)]
     us_one = _time_us(torch, lambda i: RSCodewordBatch.from_data_and_encode(srcs[i % NB], 3, 2, out=cws[i % NB]), 32)
-    sl = cws[0].shard_len
+    us_st = _time_us(torch, lambda i: loop.encode_stores(srcs[i % NB], slot=i % NB), 32)
     line["from_data_and_encode"] = {"one_pass_us": us_one, "one_pass_payload_TiBps": G * L / 2**40 / (us_one * 1e-6),
                                     "one_pass_frac": G * (L + 5 * sl) / (us_one * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "into_stores_us": us_st, "into_stores_frac": G * (L + 5 * sl) / (us_st * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                     "two_step_us": us_two, "two_step_payload_TiBps": G * L / 2**40 / (us_two * 1e-6),
                                     "note": "one pass moves L + 5 shard_len bytes per codeword (read once, d + p shards written); "
                                             "two steps = copy into a zeroed codeword buffer, then smr_rs_encode"}

@@ -100,6 +100,14 @@ int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t 
 int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
                                    uint8_t *cw_dev, uint64_t cw_stride, uint8_t *fan_dev, uint64_t fan_shard_stride,
                                    uint64_t fan_cw_stride, uint32_t fan_mask, void *stream);
+/* from_data + compute_parity with every shard written ONCE, shard-major: shard k (k < d: data, zero padding included; else
+ * parity k - d) of codeword i goes to stores_dev + k * shard_stride + i * cw_stride -- store k is what replica k holds of the
+ * batch (rspaxos/request.rs:127-142: the Accept for peer k carries subset_copy({k})), and the leader's own codeword IS the
+ * d + p stores (rscoding.rs:255-346: a codeword is a set of shards, not a buffer).  No contiguous codeword is written:
+ * L bytes read, (d + p) * shard_len written per codeword -- smr_rs_from_data_encode_fanout wrote every shard twice.
+ * smr_rs_reconstruct / smr_rs_verify take the same layout (shard_stride, cw_stride). */
+int smr_rs_from_data_encode_stores(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                   uint8_t *stores_dev, uint64_t shard_stride, uint64_t cw_stride, void *stream);
 /* The general form: shard k of codeword i also to shard_dst[k] + i*dst_cw_stride for every k with shard_dst[k] != NULL
  * (shard_dst: HOST array of d + p DEVICE pointers) -- e.g. straight into the per-destination slices of a collective's send
  * buffer, which are not equally spaced (summerset_amd/spread_rsp.py). */

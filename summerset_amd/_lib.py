@@ -205,6 +205,7 @@ SYMBOLS = [
     ("smr_rs_encode_lut", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _u64, _vp]),
     ("smr_rs_from_data_encode", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _vp]),
     ("smr_rs_from_data_encode_fanout", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _vp, _u64, _u64, _u32, _vp]),
+    ("smr_rs_from_data_encode_stores", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _u64, _vp]),
     ("smr_rs_from_data_encode_scatter", _i, [_vp, _u64, _u64, _u64, _i, _i, _vp, _u64, _vp, _u64, _vp]),
     ("smr_rs_reconstruct", _i, [_vp, _u64, _u64, _u64, _u64, _i, _i, _u32, _i, _vp]),
     ("smr_rs_verify", _i, [_vp, _u64, _u64, _u64, _u64, _i, _i, _vp, _vp]),

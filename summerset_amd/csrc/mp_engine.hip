@@ -819,8 +819,13 @@ template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
                                                    int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk, uint32_t hint) {
 #ifndef TALLY_C
-#define TALLY_C 4          // 95 VGPRs, five wavefronts per SIMD: measured better than 8 rows per pass (128 VGPRs) with and without
-#endif                     // the side stream's blocks on the same CUs (profiles/r2u_tally_rows_per_pass.log)
+#define TALLY_C 4          // rows per wavefront and pass.  Since round 4 a row in flight is its meta word alone -- the ballots of the leader's
+#endif                     // run are not stored (one bit per row says "bal_prepared >= the slot's ballot", loaded only for rows outside
+                           // the run) and the answers are taken from the followers' bit words as they are needed: 82 VGPRs (was 96).
+                           // Same-call A/Bs (profiles/r5e_tally_rows_ab.log, r5f_tally_w6_rsp_stores.log): 8 rows per pass (one pass
+                           // for S = 32, 102 VGPRs) the same in the steady state and worse beside the side stream's blocks (27.9 vs
+                           // 26.4 us); capped at 80 VGPRs for a sixth wavefront per SIMD (-DTALLY_MINW=6, 12 B of scratch): no
+                           // difference.  (Round 2: profiles/r2u_tally_rows_per_pass.log.)
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (w >= 4) { __syncthreads(); return; }                    // (the fused tick kernel's block has a wavefront per replica)
@@ -874,6 +879,9 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     uint32_t dl = R, cnt = 0;
 #pragma unroll
     for (int d = NR - 1; d >= 0; d--) if (cnts[d] != 0) { dl = (uint32_t)d; cnt = cnts[d]; }
+    uint32_t nzmask = 0;                                         // bit d: replica d has a non-empty outbox (all that is needed of cnts[] below)
+#pragma unroll
+    for (int d = 0; d < NR; d++) nzmask |= cnts[d] != 0 ? 1u << d : 0u;
     const bool cand = dl < R && !((prmask >> dl) & 1u) && cnt <= 64;
     const size_t ro = (size_t)(dl < R ? dl : 0) * P.rep_stride;  // per-lane replica: addresses are vector values
 #if TALLY_SPEC
@@ -893,7 +901,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     // ---- round 2: my replica's scalars -------------------------------------------------------------
     uint32_t reg = 0, leader = NO_REP, start = 0, len = 0, cbar = 0, ebar = 0, abar = 0, brun = 0xFFFFFFFFu;
     uint64_t bpd = 0, bms = 0;
-    uint64_t a[C], rbal = 0;
+    uint64_t rbal = 0;
 #if TALLY_SPEC
     if (spec) {
 #pragma unroll
@@ -911,6 +919,9 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         brun = rep_shift(v0.bal_lo, ro)[gg]; bms = rep_shift(v0.bal_max_seen, ro)[gg];   // the leader's ballot run (R1)
     }
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
+    // (what the loop needs of the 64-bit scalars, as bits: they are dead from here on -- the kernel is 2 VGPRs from a sixth wavefront)
+    const bool run_bal_ok = bpd >= bms;                          // a slot of the run: bal_prepared >= its ballot (= bal_max_seen)
+    const bool answers_ok = rbal != 0 && rbal == bpd;            // an answer carries the Accept's ballot (ob_rbal): messages.rs:388
     uint32_t wall = 0xFF;                                        // TALLY_WAVEFLAGS: AND of my rows' flags
     (void)wall;
     // ---- round 3 + tally: C rows per pass (one pass unless the outbox is longer than 4 * C) -------
@@ -923,7 +934,11 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
                 ctl[k] = (cand && j < cnt && ackctl) ? ackctl[(size_t)j * G + g] : SMR_CTL_IDENTITY;
             }
         }
-        uint32_t m[C]; uint64_t b[C];
+        uint32_t m[C];
+        // bit k: bal_prepared >= the ballot of row k's slot (messages.rs:396).  Inside the leader's run the ballot is
+        // bal_max_seen, unstored: one comparison for all rows; a row below the run (none in the steady state: the run starts
+        // with the first steady append) loads its ballot -- one by one, so that no row holds two more registers in flight
+        uint32_t bok = run_bal_ok ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int k = 0; k < C; k++) {
             const uint32_t j = w + 4u * (k0 + k);
@@ -931,8 +946,16 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             const bool have = fast4 && j < cnt && slot >= start && slot < len;
             const size_t i = tix(P.W, slot & Wm, g);
             m[k] = have ? sm[i] : 0xFFFFFFFFu;
-            b[k] = !have ? 0ull : (slot >= brun ? bms : sb[i]);      // inside the run the ballot is bal_max_seen, unstored
-            a[k] = (cand && j < cnt) ? ack_word_from_bits<NR>(ab, j) : 0ull;
+        }
+        if (fast4 && reg - 1 + w + 4u * k0 < brun) {                 // (rows are consecutive slots: the pass's first row tells)
+#pragma unroll 1
+            for (int k = 0; k < C; k++) {
+                const uint32_t j = w + 4u * (k0 + k);
+                const uint32_t slot = reg - 1 + j;
+                if (!(j < cnt && slot >= start && slot < len) || slot >= brun) continue;
+                const bool ok = bpd >= sb[tix(P.W, slot & Wm, g)];
+                bok = ok ? (bok | (1u << k)) : (bok & ~(1u << k));
+            }
         }
 #pragma unroll
         for (int k = 0; k < C; k++) {
@@ -943,12 +966,13 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             bool changed = false, committed = false;
             if (have && (mk & M_LBK)) {
                 uint32_t valid = 0;                              // an answer carries the Accept's ballot: ob_rbal
-                if (rbal != 0 && rbal == bpd) {
+                if (answers_ok) {
 #pragma unroll
-                    for (int q = 0; q < NR; q++) valid |= ((uint32_t)(a[k] >> (8 * q)) & 1u) << q;
+                    for (int q = 0; q < NR; q++) valid |= (uint32_t)((ab[q] >> j) & 1ull) << q;   // (cand: j < cnt <= 64)
                     valid &= ~(1u << dl);
                 }
-                mk = tally_valid<NR>(mk, b[k], ctl[k], valid, bpd, thresh, R, changed, committed);
+                // (tally_valid's ballot test is `bpd >= b`: b = 0 passes, b = ~0 fails)
+                mk = tally_valid<NR>(mk, ((bok >> k) & 1u) ? 0ull : ~0ull, ctl[k], valid, bpd, thresh, R, changed, committed);
             }
             // a row short of the quorum keeps its new acks; re-tallying it later changes nothing
             if (changed && !committed) sm[tix(P.W, (reg - 1 + j) & Wm, g)] = mk;
@@ -985,10 +1009,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     }
     // which replicas of my group still need mp_round_replies: a non-empty outbox I did not close,
     // or PrepareReplies waiting; everybody else's round is complete
-    uint32_t need = prmask;
-#pragma unroll
-    for (int d = 0; d < NR; d++)
-        if (cnts[d] != 0 && !(closed && (uint32_t)d == dl)) need |= 1u << d;
+    const uint32_t need = prmask | (closed ? nzmask & ~(1u << dl) : nzmask);
     if (w == 0 && closed) {
         p_cbar[gg] = first + cnt;
         if (ebar >= first && ebar < first + cnt) p_ebar[gg] = first + cnt;

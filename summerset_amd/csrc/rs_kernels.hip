@@ -39,7 +39,8 @@ struct RsArgs {
     uint64_t in_off[RS_MAX_IN];    // byte offset of input shard c inside a codeword
     uint64_t out_off[RS_MAX_OUT];  // byte offset of output shard r inside a codeword
     uint8_t *copy_base;            // from_data fused in (rs_from_data_xtime): the input columns are also WRITTEN, shard c of codeword
-    uint64_t copy_cw_stride;       // i to copy_base + i * copy_cw_stride + in_off[c], zero padding included; NULL otherwise
+    uint64_t copy_cw_stride;       // i to copy_base + i * copy_cw_stride + copy_off[c], zero padding included; NULL otherwise
+    uint64_t copy_off[RS_MAX_IN];  // (= in_off[c] for a codeword buffer; c * shard_stride for shard-major stores, smr_rs_from_data_encode_stores)
     uint8_t *fan_dst[RS_MAX_IN + RS_MAX_OUT];   // shard fan-out fused in as well: shard k (k < n_in: data, else parity k - n_in) of codeword
     uint64_t fan_cw_stride;        // i ALSO to fan_dst[k] + i * fan_cw_stride where fan_dst[k] != NULL -- every holder's shard store (or its
     uint32_t fan_any;              // slice of a send buffer) filled by the pass that makes the shards (rspaxos/request.rs:127-142)
@@ -137,7 +138,7 @@ __device__ __forceinline__ void rs_product_xtime(const RsArgs &a, const uint8_t 
 #pragma unroll
         for (int c = 0; c < NIN; c++)
             if (c < a.n_in) {
-                store_block(copy_cw + a.in_off[c] + c0, c0, a.shard_len, x[c]);
+                store_block(copy_cw + a.copy_off[c] + c0, c0, a.shard_len, x[c]);
                 if (fan && a.fan_dst[c]) store_block(a.fan_dst[c] + fan_off + c0, c0, a.shard_len, x[c]);
             }
     }
@@ -411,7 +412,7 @@ template <bool LUT>
 static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_stride, uint64_t n_cw, int d,
                           int p, uint8_t *parity, uint64_t par_stride, uint64_t par_shard_stride, void *stream,
                           uint8_t *copy_base = nullptr, uint64_t copy_cw_stride = 0, uint8_t *const *fan_dst = nullptr,
-                          uint64_t fan_cw_stride = 0) {
+                          uint64_t fan_cw_stride = 0, uint64_t copy_shard_stride = 0) {
     if (d <= 0) return fail(SMR_ERR_ARG, "num_data_shards is zero");          // rscoding.rs:172-174
     if (data_len == 0) return fail(SMR_ERR_ARG, "codeword is null");          // rscoding.rs:451-453
     if (p == 0 && !copy_base) return SMR_OK;                                   // rscoding.rs:454-456
@@ -430,7 +431,7 @@ static int rs_encode_impl(const uint8_t *data, uint64_t data_len, uint64_t cw_st
     a.in_bytes = n_cw ? (n_cw - 1) * cw_stride + data_len : 0;   // rows may be packed tightly (cw_stride == data_len)
     a.n_cw = n_cw; a.n_in = d; a.n_out = p;
     if (par_shard_stride < a.shard_len) return fail(SMR_ERR_ARG, "rs: par_shard_stride < shard_len");
-    for (int c = 0; c < d; c++) a.in_off[c] = (uint64_t)c * a.shard_len;
+    for (int c = 0; c < d; c++) { a.in_off[c] = (uint64_t)c * a.shard_len; a.copy_off[c] = (uint64_t)c * (copy_shard_stride ? copy_shard_stride : a.shard_len); }
     for (int r = 0; r < p; r++) {
         a.out_off[r] = (uint64_t)r * par_shard_stride;
         for (int c = 0; c < d; c++) a.coef[r][c] = m[(d + r) * d + c];
@@ -486,6 +487,23 @@ int smr_rs_from_data_encode_fanout(const uint8_t *src_dev, uint64_t data_len, ui
         for (int k = 0; k < d + p; k++) dst[k] = ((fan_mask >> k) & 1u) ? fan_dev + (uint64_t)k * fan_shard_stride : nullptr;
     }
     return smr_rs_from_data_encode_scatter(src_dev, data_len, src_stride, n_cw, d, p, cw_dev, cw_stride, fan_mask ? dst : nullptr, fan_cw_stride, stream);
+}
+
+int smr_rs_from_data_encode_stores(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,
+                                   uint8_t *stores_dev, uint64_t shard_stride, uint64_t cw_stride, void *stream) {
+    if (!stores_dev) return fail(SMR_ERR_ARG, "rs: null buffer");
+    if (d <= 0) return fail(SMR_ERR_ARG, "num_data_shards is zero");
+    if (d > RS_MAX_IN || p < 0 || p > RS_MAX_OUT) return fail(SMR_ERR_ARG, "rs: scheme exceeds d<=16, p<=8");
+    const uint64_t sl = smr_rs_shard_len(data_len, d);
+    if (cw_stride < sl || (n_cw && shard_stride < (n_cw - 1) * cw_stride + sl))
+        return fail(SMR_ERR_ARG, "rs: store strides: a store holds n_cw shards of shard_len bytes, cw_stride apart");
+    const uint64_t span = (uint64_t)(d + p - 1) * shard_stride + (n_cw ? (n_cw - 1) * cw_stride + sl : 0);
+    if (src_dev && src_dev < stores_dev + span && stores_dev < src_dev + n_cw * src_stride)
+        return fail(SMR_ERR_ARG, "rs: source and shard stores overlap");
+    // shard k of codeword i at stores + k * shard_stride + i * cw_stride: the data shards through the from_data copy, the parity
+    // shards through the product's own stores -- every shard written ONCE, straight into its holder's store
+    return rs_encode_impl<false>(src_dev, data_len, src_stride, n_cw, d, p, stores_dev + (uint64_t)d * shard_stride, cw_stride, shard_stride, stream,
+                                 stores_dev, cw_stride, nullptr, 0, shard_stride);
 }
 
 int smr_rs_from_data_encode(const uint8_t *src_dev, uint64_t data_len, uint64_t src_stride, uint64_t n_cw, int d, int p,

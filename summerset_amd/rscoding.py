@@ -101,6 +101,44 @@ class RSCodewordBatch:
         return cw
 
     @classmethod
+    def from_data_and_encode_stores(cls, data, num_data_shards, num_parity_shards, stores=None, stream=None):
+        """`from_data` + `compute_parity` with every shard written ONCE, shard-major (`smr_rs_from_data_encode_stores`): shard k of
+        codeword i lands in `stores[k, i, :]` (uint8 [d + p, n, shard_len], contiguous; made if None) -- store k is what
+        replica k holds of the batch (the payload of its Accept, rspaxos/request.rs:127-142) and the leader's codeword IS
+        the d + p stores: the returned batch keeps no buffer of its own (`buf` is None, `shard(k)` = `stores[k]`);
+        reconstruct / verify / erase / subset_copy / absorb_other work on it as they are."""
+        import torch
+        if data.dim() != 2 or data.stride(1) != 1:
+            raise SummersetError(_lib.SMR_ERR_ARG, "data must be [n, data_len] with contiguous rows")
+        n, L = int(data.shape[0]), int(data.shape[1])
+        if num_data_shards == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "num_data_shards is zero")
+        if L == 0:
+            raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
+        cw = cls.__new__(cls)
+        cw.n, cw.d, cw.p, cw.data_len = n, int(num_data_shards), int(num_parity_shards), L
+        cw.shard_len = rs_shard_len(L, cw.d)
+        cw.cw_stride, cw.buf = cw.shard_len, None
+        if stores is None:
+            stores = torch.empty((cw.d + cw.p, n, cw.shard_len), dtype=torch.uint8, device=data.device)
+        if tuple(stores.shape) != (cw.d + cw.p, n, cw.shard_len) or not stores.is_contiguous() or stores.dtype != torch.uint8:
+            raise SummersetError(_lib.SMR_ERR_ARG, "stores must be a contiguous uint8 [d + p, n, shard_len]")
+        cw.stores = stores
+        check(_lib.load().smr_rs_from_data_encode_stores(data.data_ptr(), L, int(data.stride(0)), n, cw.d, cw.p, stores.data_ptr(),
+                                                         n * cw.shard_len, cw.shard_len, stream_ptr(stream)))
+        cw.avail = (1 << (cw.d + cw.p)) - 1
+        return cw
+
+    def _layout(self):
+        """(base pointer, byte stride between the shards of a codeword, byte stride between codewords)"""
+        if self.buf is None:
+            return self.stores.data_ptr(), self.n * self.shard_len, self.shard_len
+        return self.buf.data_ptr(), self.shard_len, self.cw_stride
+
+    def _device(self):
+        return self.stores.device if self.buf is None else self.buf.device
+
+    @classmethod
     def from_null(cls, n, num_data_shards, num_parity_shards, device="cuda"):
         return cls(n, 0, num_data_shards, num_parity_shards, device=device)
 
@@ -113,7 +151,7 @@ class RSCodewordBatch:
             raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
         if subset >> (self.d + self.p):
             raise SummersetError(_lib.SMR_ERR_ARG, "shard index %d out-of-bound" % (subset.bit_length() - 1))
-        out = RSCodewordBatch(self.n, self.data_len, self.d, self.p, device=self.buf.device)
+        out = RSCodewordBatch(self.n, self.data_len, self.d, self.p, device=self._device())
         for k in range(self.d + self.p):
             if (subset >> k) & 1 and (self.avail >> k) & 1:
                 out.shard(k).copy_(self.shard(k))
@@ -133,7 +171,7 @@ class RSCodewordBatch:
         if self.n != other.n:
             raise SummersetError(_lib.SMR_ERR_ARG, "batch size mismatch: expected %d, other %d" % (self.n, other.n))
         if self.data_len == 0:                      # null so far: same data_len / shard_len as the input
-            fresh = RSCodewordBatch(self.n, other.data_len, self.d, self.p, device=other.buf.device)
+            fresh = RSCodewordBatch(self.n, other.data_len, self.d, self.p, device=other._device())
             self.data_len, self.shard_len, self.cw_stride, self.buf = fresh.data_len, fresh.shard_len, fresh.cw_stride, fresh.buf
         for k in range(self.d + self.p):
             if (other.avail >> k) & 1 and not (self.avail >> k) & 1:
@@ -165,6 +203,8 @@ class RSCodewordBatch:
 
     def shard(self, k):
         """view [n, shard_len] of shard k"""
+        if self.buf is None:
+            return self.stores[k]
         return self.buf[:, k * self.shard_len:(k + 1) * self.shard_len]
 
     def erase(self, idxs):
@@ -185,6 +225,8 @@ class RSCodewordBatch:
         if self.avail_data_shards() < self.d:
             raise SummersetError(_lib.SMR_ERR_ARG, "not all data shards present: %d / %d"
                                  % (self.avail_data_shards(), self.d))
+        if self.buf is None:
+            raise SummersetError(_lib.SMR_ERR_STATE, "a shard-major batch is encoded when it is made (from_data_and_encode_stores)")
         L = _lib.load()
         fn = L.smr_rs_encode_lut if lut else L.smr_rs_encode
         base = self.buf.data_ptr()
@@ -202,8 +244,8 @@ class RSCodewordBatch:
                                  % (self.avail_data_shards(), self.d))
         if not rs:
             raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon coder is None")
-        check(_lib.load().smr_rs_reconstruct(self.buf.data_ptr(), self.shard_len, self.shard_len,
-                                             self.cw_stride, self.n, self.d, self.p, self.avail,
+        base, shard_stride, cw_stride = self._layout()
+        check(_lib.load().smr_rs_reconstruct(base, self.shard_len, shard_stride, cw_stride, self.n, self.d, self.p, self.avail,
                                              int(data_only), stream_ptr(stream)))
         self.avail |= (1 << self.d) - 1
         if not data_only:
@@ -222,15 +264,16 @@ class RSCodewordBatch:
             raise SummersetError(_lib.SMR_ERR_ARG, "codeword is null")
         if self.p == 0:
             if self.avail_data_shards() == self.d:
-                return torch.ones(self.n, dtype=torch.bool, device=self.buf.device)
+                return torch.ones(self.n, dtype=torch.bool, device=self._device())
             raise SummersetError(_lib.SMR_ERR_ARG, "not all shards present")
         if not rs:
             raise SummersetError(_lib.SMR_ERR_ARG, "ReedSolomon is None")
         if self.avail_shards() < self.d + self.p:
             raise SummersetError(_lib.SMR_ERR_ARG, "not all shards present: %d / %d"
                                  % (self.avail_shards(), self.d + self.p))
-        ok = torch.empty(self.n, dtype=torch.uint8, device=self.buf.device)
-        check(_lib.load().smr_rs_verify(self.buf.data_ptr(), self.shard_len, self.shard_len, self.cw_stride,
+        ok = torch.empty(self.n, dtype=torch.uint8, device=self._device())
+        base, shard_stride, cw_stride = self._layout()
+        check(_lib.load().smr_rs_verify(base, self.shard_len, shard_stride, cw_stride,
                                         self.n, self.d, self.p, ok.data_ptr(), stream_ptr(stream)))
         return ok.bool()
 
@@ -241,4 +284,7 @@ class RSCodewordBatch:
         if self.avail_data_shards() < self.d:
             raise SummersetError(_lib.SMR_ERR_ARG, "not all data shards present: %d / %d"
                                  % (self.avail_data_shards(), self.d))
+        if self.buf is None:                       # shard-major: the data shards side by side (a copy)
+            import torch
+            return torch.cat([self.stores[k] for k in range(self.d)], dim=1)[:, :self.data_len]
         return self.buf[:, :self.data_len]

@@ -262,6 +262,20 @@ class SteadyLoop:
         d = self.R // 2 + 1                       # rspaxos/mod.rs:599-609: RS(majority, R - majority)
         return RSCodewordBatch.from_data_and_encode(data, d, self.R - d, stream=stream, out=out, fan_out=self.stores)
 
+    def encode_stores(self, data, stream=None, slot=0):
+        """`encode` with every shard written ONCE (round 4): from_data + RS encode straight into the R replicas' shard
+        stores (`smr_rs_from_data_encode_stores`) -- store q = shard q of the tick's codewords = what replica q holds; the leader's
+        codeword is those stores (the returned batch is a view of them: `RSCodewordBatch.from_data_and_encode_stores`).  `encode`
+        wrote a contiguous codeword AND the stores: 10 shard_len per batch instead of 5."""
+        import torch
+        from .rscoding import RSCodewordBatch, rs_shard_len
+        d = self.R // 2 + 1                       # rspaxos/mod.rs:599-609: RS(majority, R - majority)
+        sl = rs_shard_len(int(data.shape[1]), d)
+        if self._stores.get(slot) is None or self._stores[slot].shape[2] != sl:
+            self._stores[slot] = torch.empty((self.R, self.G, sl), dtype=torch.uint8, device=data.device)
+        self.stores = self._stores[slot]
+        return RSCodewordBatch.from_data_and_encode_stores(data, d, self.R - d, stores=self.stores, stream=stream)
+
     def tick(self, val, lost=None, heartbeat=False):
         """val: int32 [G] batch tokens (NULL = none); lost: optional dict (kind, from, to) -> bool [G] like `tick`'s drop.
         Returns the leader's `committed` flags [G] (valid until the next tick)."""

@@ -88,8 +88,9 @@ def config4_tokens(G, j):
     return ((1 + np.arange(G, dtype=np.int64) + j * G) & 0x3FFFFFFF).astype(np.int32)
 
 
-def config4_tick(loop, k, src, cw, val, lost, heartbeat):
-    """one tick of the leg: the encode pass out of buffer pair k (fills `cw` and every replica's shard store), then the
-    tick's handlers in one launch"""
-    loop.encode(src, out=cw)
-    return loop.tick(val, lost=lost, heartbeat=heartbeat)
+def config4_tick(loop, k, src, val, lost, heartbeat):
+    """one tick of the leg: the encode pass out of source buffer k -- from_data + RS(3,2) with every shard written once,
+    straight into its holder's store (slot k of the rotating stores) -- then the tick's handlers in one launch.
+    Returns (the leader's committed flags, the tick's codewords as a view of the stores)."""
+    cw = loop.encode_stores(src, slot=k)
+    return loop.tick(val, lost=lost, heartbeat=heartbeat), cw

@@ -221,7 +221,7 @@ def run_rspaxos_slices(cuda, oracle, G, W, T, ft, loss, width, n_slices):
 
 def run_rspaxos_one_launch(cuda, oracle, G, W, L, T, ft):
     """bench.py's config-4 leg as it is launched (summerset_amd/workloads.py: config4_cluster / config4_loss / config4_tokens
-    / config4_tick): per tick ONE pass `rs_from_data_xtime` (from_data + RS(3,2) encode + the five shard stores) and ONE
+    / config4_tick): per tick ONE pass `rs_from_data_xtime` (from_data + RS(3,2) encode, every shard written once into its holder's store) and ONE
     launch `smr_rsp_cluster_steady_tick` -- against five ORACLES of the WHOLE population in the numpy-staged closed loop
     (rsp_cluster.tick) and the oracle's RS encoder on every codeword of every tick.  Compared: the leader's committed flags
     every tick, the codeword bytes and every replica's shard store byte for byte every tick, every replica's full state
@@ -237,8 +237,7 @@ def run_rspaxos_one_launch(cuda, oracle, G, W, L, T, ft):
     rng = np.random.default_rng(0x5EED5EED)
     data = [rng.integers(0, 256, (G, L), dtype=np.uint8) for _ in range(NB)]
     srcs = [torch.from_numpy(d).to(cuda) for d in data]
-    cws = [RSCodewordBatch(G, L, 3, 2, device=cuda, zero=False) for _ in range(NB)]
-    sl_ = cws[0].shard_len
+    sl_ = -(-L // 3)
     want_par = [oracle.rs_encode_batch(3, 2, d, L, L, G).reshape(G, 2, sl_) for d in data]   # the oracle's encoder, every codeword
     padded = []
     for d in data:                                       # from_data geometry (rscoding.rs:165-220): zero-padded to 3 shard_len, split
@@ -251,17 +250,20 @@ def run_rspaxos_one_launch(cuda, oracle, G, W, L, T, ft):
     for t in range(T):
         k, hb = t % NB, t % H == H - 1
         val = workloads.config4_tokens(G, t)
-        got = workloads.config4_tick(loop, k, srcs[k], cws[k], torch.from_numpy(val).to(cuda), dmasks[k], hb).cpu().numpy()
+        got, cw = workloads.config4_tick(loop, k, srcs[k], torch.from_numpy(val).to(cuda), dmasks[k], hb)
+        got = got.cpu().numpy()
         log = rc.tick(orcs, val.view(np.uint32), np.zeros(G, np.uint8), drop={k_: v.astype(bool) for k_, v in masks[k].items()}, heartbeat=hb)
         want = [e for e in log if e["kind"] == "commit"]
         assert len(want) == 1 and np.array_equal(got, want[0]["committed"]), t
         total += int(got.sum())
-        cwb = cws[k].buf.cpu().numpy()
         stores = loop.stores.cpu().numpy()               # [R, G, shard_len]: what replica q holds of this tick's codewords
+        assert cw.buf is None and cw.stores.data_ptr() == loop.stores.data_ptr() and cw.shard_len == sl_   # the leader's codeword IS the stores
         for q in range(R):
             exp = padded[k][:, q] if q < 3 else want_par[k][:, q - 3]
-            assert np.array_equal(cwb[:, q * sl_:(q + 1) * sl_], exp), (t, q, "codeword")
             assert np.array_equal(stores[q], exp), (t, q, "shard store")
+        if t < NB:                                       # the shard-major batch as a codeword: parity verifies, the data is the batch
+            assert bool(cw.verify_parity().all())
+            assert np.array_equal(cw.get_data().cpu().numpy(), data[k])
     for r in range(R):
         a, b = reps[r].dump(), orcs[r].dump()
         assert len(b) > 8

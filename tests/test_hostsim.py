@@ -197,6 +197,7 @@ def test_rs_kernels_on_the_host(sim, oracle):
         t.test_verify_detects_corruption("cpu")
         t.test_padding_bytes_are_never_read("cpu", oracle)
         t.test_subset_copy_and_absorb_other_rspaxos_flow("cpu", oracle)
+        t.test_from_data_and_encode_into_shard_stores("cpu", oracle)            # every shard written once, shard-major (round 4)
         for scheme, L in (((3, 2), 1), ((3, 2), 2), ((3, 2), 47), ((3, 2), 4099), ((6, 4), 777), ((1, 1), 33), ((12, 8), 1000), ((3, 0), 100)):
             t.test_from_data_and_encode_one_pass("cpu", oracle, scheme, L)
         t.test_from_data_and_encode_fans_the_shards_out("cpu", oracle)

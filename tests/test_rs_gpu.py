@@ -276,3 +276,54 @@ def test_from_data_and_encode_fans_the_shards_out(cuda, oracle):
             RSCodewordBatch.from_data_and_encode(src, d, p, fan_out=torch.zeros((d + p, n, sl + 1), dtype=torch.uint8, device=cuda))
         with pytest.raises(SummersetError):
             RSCodewordBatch.from_data_and_encode(src, d, p, fan_out=torch.zeros((d + p, n, sl), dtype=torch.uint8, device=cuda), fan_mask=1 << (d + p))
+
+
+def test_from_data_and_encode_into_shard_stores(cuda, oracle):
+    """`smr_rs_from_data_encode_stores` (round 4): every shard written ONCE, shard-major -- store k = shard k of every codeword, the
+    codeword a view of the stores.  Against the oracle's parity and the source bytes (zero padding included) byte for byte;
+    the shard-major batch through verify / erase / reconstruct (every pattern of RS(3,2)) / get_data / subset_copy; bytes
+    outside the stores untouched; argument errors."""
+    import itertools
+    import torch
+    from summerset_amd import RSCodewordBatch, SummersetError
+    rng = np.random.default_rng(1234)
+    for (d, p), L, n in (((3, 2), 4113, 67), ((3, 2), 2, 5), ((3, 2), 48, 64), ((6, 4), 1000, 17), ((5, 0), 77, 9)):
+        data = rng.integers(0, 256, (n, L), dtype=np.uint8)
+        src = torch.from_numpy(data).to(cuda)
+        sl = -(-L // d)
+        guard = torch.full(((d + p) * n * sl + 64,), 0xCD, dtype=torch.uint8, device=cuda)
+        stores = guard[32:32 + (d + p) * n * sl].view(d + p, n, sl)
+        cw = RSCodewordBatch.from_data_and_encode_stores(src, d, p, stores=stores)
+        assert cw.buf is None and cw.shard_len == sl and cw.avail_shards() == d + p
+        assert bool((guard[:32] == 0xCD).all()) and bool((guard[32 + (d + p) * n * sl:] == 0xCD).all())
+        got = stores.cpu().numpy()
+        padded = np.zeros((n, d * sl), np.uint8)
+        padded[:, :L] = data
+        for k in range(d):
+            assert np.array_equal(got[k], padded[:, k * sl:(k + 1) * sl]), (d, p, L, k)          # rscoding.rs:188-200
+        if p:
+            want = oracle.rs_encode_batch(d, p, data, L, L, n).reshape(n, p, sl)
+            for r in range(p):
+                assert np.array_equal(got[d + r], want[:, r]), (d, p, L, r)
+            assert bool(cw.verify_parity().all())
+        assert np.array_equal(cw.get_data().cpu().numpy(), data)
+        sub = cw.subset_copy(0b101)
+        assert sub.avail == 0b101 and torch.equal(sub.shard(2), stores[2])
+        if (d, p) == (3, 2):
+            keep = stores.clone()
+            for pat in itertools.combinations(range(5), 2):
+                cw.erase(pat)
+                cw.reconstruct_all()
+                assert torch.equal(stores, keep), pat
+            cw.erase((0, 1))
+            cw.reconstruct_data()
+            assert np.array_equal(cw.get_data().cpu().numpy(), data)
+        if p:
+            with pytest.raises(SummersetError):
+                cw.compute_parity()                                                      # encoded when it was made
+        with pytest.raises(SummersetError):
+            RSCodewordBatch.from_data_and_encode_stores(src, d, p, stores=torch.zeros((d + p, n, sl + 1), dtype=torch.uint8, device=cuda))
+        with pytest.raises(SummersetError):
+            RSCodewordBatch.from_data_and_encode_stores(src, 0, p)
+    made = RSCodewordBatch.from_data_and_encode_stores(torch.from_numpy(data).to(cuda), 5, 0)   # stores made by the call
+    assert made.stores.shape == (5, n, -(-L // 5))

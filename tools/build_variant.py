@@ -16,12 +16,16 @@ def main():
     out_dir = os.path.join(B.HERE, "variants", tag)
     os.makedirs(out_dir, exist_ok=True)
     objs = []
+    only = os.environ.get("VARIANT_ONLY", "").split()      # e.g. VARIANT_ONLY=mp_engine.hip: the other objects are the shipped build's
     for s in B.SOURCES:
+        if only and s not in only:
+            objs.append(os.path.join(B.CSRC, s.replace(".hip", ".o")))
+            continue
         o = os.path.join(out_dir, s.replace(".hip", ".o"))
         subprocess.check_call([B.HIPCC] + B.FLAGS + flags + ["-c", os.path.join(B.CSRC, s), "-o", o])
         objs.append(o)
     lib = os.path.join(B.HERE, "variants", "libsummerset_hip_%s.so" % tag)
-    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
     print(lib)
 
 
