@@ -923,10 +923,11 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
 // WAL completion, for the message (src, row, c, b, s, deps[i * G + g], k) if `on`; (of, ob, os, d) = the reply
 // LBK = false: the caller knows the instance cannot carry leader bookkeeping at this replica (another replica's row in a
 // cluster without explicit prepare), and the branch that answers the leader's own message is left out
+// (ep_acceptor_lane_in: the message's DepSet already in registers -- the one-launch tick takes it out of LDS)
 template <int MODE, int NR, bool LBK, bool C>
-__device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
-                                                 const uint32_t *__restrict__ deps, uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
-                                                 uint32_t (&d)[NR], EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
+__device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
+                                                    uint32_t (&in)[NR], uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
+                                                    uint32_t (&d)[NR], EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
     const EpView &v = L.v;
     const uint32_t g = L.g;
     of = 0; ob = 0; os = 0;
@@ -940,9 +941,6 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uin
     //   round 2: the cell's ballot and meta words, the key's highest columns
     //   round 3 (PreAccept): the sequence numbers of the key's highest instances
     const uint32_t rw = row < v.R ? row : 0u;
-    uint32_t in[NR];
-#pragma unroll
-    for (int q = 0; q < NR; q++) in[q] = (uint32_t)q < v.R ? deps[(size_t)q * v.G + g] : EP_NONE;
     const size_t i = L.ix(rw, c);
     const bool need_meta = LBK || MODE == 2 || rw == v.me;                   // (LBK = false: Status / bookkeeping are read only where they can matter;
     const u32x4 w0 = v.p0[i];                                                //  a CommitNotice leaves the bookkeeping as it is)
@@ -1013,6 +1011,16 @@ __device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uin
             for (int q = 0; q < NR; q++) d[q] = in[q];
         }
     }
+}
+
+template <int MODE, int NR, bool LBK, bool C>
+__device__ __forceinline__ void ep_acceptor_lane(EpLaneT<NR, C> &L, bool on, uint32_t src, uint32_t row, uint32_t c, uint64_t b, uint64_t s,
+                                                 const uint32_t *__restrict__ deps, uint32_t k, uint8_t &of, uint64_t &ob, uint64_t &os,
+                                                 uint32_t (&d)[NR], EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
+    uint32_t in[NR];                                                         // round 1: the message's DepSet [R][G]
+#pragma unroll
+    for (int q = 0; q < NR; q++) in[q] = (uint32_t)q < L.v.R ? deps[(size_t)q * L.v.G + L.g] : EP_NONE;
+    ep_acceptor_lane_in<MODE, NR, LBK, C>(L, on, src, row, c, b, s, in, k, of, ob, os, d, rec, stored);
 }
 
 template <int NR>
@@ -1131,11 +1139,29 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 // p's; my own row unused), the result is stored once.  dec = 0 / EST_ACCEPTING / EST_COMMITTED with (dseq, dd).
 // (Loading every input row unconditionally from clamped addresses was measured SLOWER for this kernel -- 25.2 vs 21.7 us per
 // launch, profiles/r2w_ep_flat.log -- unlike the MultiPaxos tally's round 1; the variant is gone.)
-template <int NR, bool C>
-__device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
-                                                   const uint32_t (&in_f)[NR], const uint64_t (&in_b)[NR], const uint64_t (&in_s)[NR],
-                                                   const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
-                                                   EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
+// where the incoming replies lie: `RD::get(p, f, rb, rs, rd)` hands over peer p's (flag, ballot, seq, deps) -- out of register
+// arrays the caller loaded (EpRepliesInRegs: the handler kernel), or out of the block's LDS (the one-launch tick)
+template <int NR>
+struct EpRepliesInRegs {
+    const uint32_t (&in_f)[NR]; const uint64_t (&in_b)[NR]; const uint64_t (&in_s)[NR]; const uint32_t (&in_d)[NR][NR];
+    __device__ __forceinline__ void get(uint32_t p, uint32_t &f, uint64_t &rb, uint64_t &rs, uint32_t (&rd)[NR]) const {
+        f = 0; rb = 0; rs = 0;
+#pragma unroll
+        for (int k = 0; k < NR; k++) rd[k] = EP_NONE;
+#pragma unroll
+        for (int q = 0; q < NR; q++)
+            if ((uint32_t)q == p) {
+                f = in_f[q]; rb = in_b[q]; rs = in_s[q];
+#pragma unroll
+                for (int k = 0; k < NR; k++) rd[k] = in_d[q][k];
+            }
+    }
+};
+
+template <int NR, bool C, typename RD>
+__device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex, const RD &rdr,
+                                                      uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
+                                                      EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
     const EpView &v = L.v;
     if (stored) *stored = false;
     const uint32_t R = v.R;
@@ -1166,9 +1192,8 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
     for (uint32_t oi = 0; oi < R; oi++) {
         const uint32_t p = (ctl >> (3 * oi)) & 7u;
         if (p == v.me || p >= R) continue;
-        uint32_t f = 0; uint64_t rb = 0, rs = 0;
-#pragma unroll
-        for (int q = 0; q < NR; q++) if ((uint32_t)q == p) { f = in_f[q]; rb = in_b[q]; rs = in_s[q]; }
+        uint32_t f; uint64_t rb, rs; uint32_t rd[NR];
+        rdr.get(p, f, rb, rs, rd);
         if (!(f & 1u) || !h) continue;
         if (st != EST_PREACCEPTING || (rb > 0 && b != rb) || !(bk & 1u)) continue;   // :129-134
         if ((acks >> p) & 1u) continue;                                      // :136-138
@@ -1178,7 +1203,7 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
                 if ((uint32_t)q == p) {
                     ps[q] = rs;
 #pragma unroll
-                    for (int k = 0; k < NR; k++) pd[q][k] = in_d[q][k];
+                    for (int k = 0; k < NR; k++) pd[q][k] = rd[k];
                 }
             acks |= 1u << p;
         }
@@ -1209,6 +1234,15 @@ __device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t r
     } else if (fresh) {
         L.store_meta(i, I);                                                  // only the ack mask moved (deps[4], deps[5] as loaded)
     }
+}
+
+template <int NR, bool C>
+__device__ __forceinline__ void ep_pa_replies_lane(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex,
+                                                   const uint32_t (&in_f)[NR], const uint64_t (&in_b)[NR], const uint64_t (&in_s)[NR],
+                                                   const uint32_t (&in_d)[NR][NR], uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
+                                                   EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
+    const EpRepliesInRegs<NR> rdr{in_f, in_b, in_s, in_d};
+    ep_pa_replies_lane_rd<NR, C>(L, row, c, ctl, ex, rdr, dec, dseq, dd, rec, stored);
 }
 
 template <int NR>
@@ -1260,6 +1294,21 @@ __device__ __forceinline__ bool ep_accept_replies_lane(EpLaneT<NR, C> &L, uint32
         const size_t o = (size_t)p * v.G + L.g;
         if (!(flags[o] & 1)) continue;
         L.accept_reply(p, row, c, ballot ? ballot[o] : fixed_ballot);
+    }
+    return h && before == EST_ACCEPTING && L.status_at(L.ix(row, c)) >= EST_COMMITTED;
+}
+
+// the same with the replies as a bit mask (bit p: peer p answered, with the Accept's ballot `fixed_ballot`): the one-launch tick
+template <int NR, bool C>
+__device__ __forceinline__ bool ep_accept_replies_mask(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t fmask, uint64_t fixed_ballot) {
+    const EpView &v = L.v;
+    const uint32_t R = v.R;
+    const bool h = L.held(row, c);
+    const uint32_t before = h ? L.status_at(L.ix(row, c)) : 0u;
+    for (uint32_t oi = 0; oi < R; oi++) {
+        const uint32_t p = (ctl >> (3 * oi)) & 7u;
+        if (p == v.me || p >= R || !((fmask >> p) & 1u)) continue;
+        L.accept_reply(p, row, c, fixed_ballot);
     }
     return h && before == EST_ACCEPTING && L.status_at(L.ix(row, c)) >= EST_COMMITTED;
 }
@@ -1548,13 +1597,47 @@ struct EpClusterArgs {
                                              // two blocks' worth of wavefronts on a CU took exactly as long as one after the other)
 #endif
 template <int NR> constexpr int epc_sets() { return NR <= 5 ? EPC_SETS : 1; }   // (16 wavefronts of the 8-replica instance would have to fit 128 VGPRs)
+// Round 4: the messages between the replica-wavefronts of a block go through LDS (NR <= 5; as rsp_cluster_tick_kernel has
+// done since round 3) instead of the global reply stacks r_flags / r_seq / r_deps / a_flags and re-reads of the leaders' out[]
+// arrays (the launch moved 16x its algorithmic bytes).  Lane = group in every wavefront of a set, so a
+// message word is [word][lane] and its reader is the same lane of another wavefront, behind the block barrier that already
+// separated the steps:
+//   sh_pa  [set][leader s][10][64]: what leader s broadcasts -- word 0 flags (bit 0 proposed, bits 8-15 the decision, bit 16
+//          committed), 1 col, 2 key, 3-4 seq, 5-9 deps: the PreAccept's (seq0, deps0) until s's own PreAcceptReply step
+//          overwrites them with the decision's (every acceptor has taken the PreAccept by then: barrier behind step R)
+//   sh_rep [set][leader s][acceptor q != s][8][64]: q's PreAcceptReply -- flag, seq lo, seq hi, deps[5]
+//   sh_af  [set][leader s][acceptor q][64] bytes: q's AcceptReply flag
+// The out[] arrays are still WRITTEN (they are the call's outputs); nothing of the tick reads them back.  The leader's step takes
+// a reply out of LDS when its turn comes instead of holding all four in registers (50 VGPRs of the old step).
+template <int NR> constexpr bool epc_lds() { return NR <= 5; }
+constexpr int EPC_PA_WORDS = 10, EPC_REP_WORDS = 8;
+template <int NR>
+struct EpRepliesInLds {
+    const uint32_t *rep;                                                     // sh_rep + the set's and the leader's offset
+    uint32_t s, lane;
+    __device__ __forceinline__ void get(uint32_t p, uint32_t &f, uint64_t &rb, uint64_t &rs, uint32_t (&rd)[NR]) const {
+        const uint32_t qi = p - (p > s ? 1u : 0u);                           // (p != s: the caller skips the leader itself)
+        const uint32_t *w = rep + (size_t)qi * EPC_REP_WORDS * 64 + lane;
+        f = w[0];
+        rs = (uint64_t)w[64] | ((uint64_t)w[128] << 32);
+        rb = (f & 1u) ? (uint64_t)(s + 1u) : 0ull;                           // an acceptor replies with the message's ballot
+#pragma unroll
+        for (int k = 0; k < NR; k++) rd[k] = k < 5 ? w[(3 + k) * 64] : EP_NONE;
+    }
+};
+
 template <int NR, bool RECOVERY>
 __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_EU : 2)) void ep_cluster_tick_kernel(const EpClusterArgs<NR> a) {
     constexpr int SETS = epc_sets<NR>();
+    constexpr bool LDS = epc_lds<NR>();
     __shared__ uint32_t sh_slow[SETS * NR];                                  // [set][leader]: some group of the set took leader s's slow path
+    __shared__ uint32_t sh_pa[LDS ? SETS * NR * EPC_PA_WORDS * 64 : 1];
+    __shared__ uint32_t sh_rep[LDS ? SETS * NR * (NR - 1) * EPC_REP_WORDS * 64 : 1];
+    __shared__ uint8_t sh_af[LDS ? SETS * NR * NR * 64 : 1];
     const uint32_t R = a.R, G = a.G;
     const uint32_t wv = SMR_WAVE_UNIFORM(threadIdx.x >> 6), set = wv / R, q = wv - set * R;
-    const uint32_t g0 = (blockIdx.x * SETS + set) * 64u + (threadIdx.x & 63u);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g0 = (blockIdx.x * SETS + set) * 64u + lane;
     const bool live = g0 < G;
     const uint32_t g = live ? g0 : 0u;
     EpView v = a.v0;
@@ -1565,6 +1648,11 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
     EpLaneT<NR, true> L(v, g);
     EpExecLaneT<NR, true> E(v, x, L, g);
     if (live) { L.load_scalars(); if (a.execute) E.load_scalars(); }
+    // word w of leader s's broadcast / of acceptor qq's reply to leader s, this lane's
+    auto PA = [&](uint32_t s, int w) -> uint32_t & { return sh_pa[((size_t)(set * NR + s) * EPC_PA_WORDS + w) * 64 + lane]; };
+    auto RP = [&](uint32_t s, uint32_t qq, int w) -> uint32_t & {
+        return sh_rep[(((size_t)(set * NR + s) * (NR - 1) + (qq - (qq > s ? 1u : 0u))) * EPC_REP_WORDS + w) * 64 + lane];
+    };
     const uint32_t n_steps = 1u + R + 4u * R;
     bool slow_round = true;
 #pragma unroll 1
@@ -1581,10 +1669,16 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
             if (live) {
                 const smr_ep_cluster_out &o = a.out[q];
                 uint8_t of; uint32_t oc; uint64_t os; uint32_t d[NR];
-                ep_propose_lane(L, a.keys[q][g], 0u, of, oc, os, d);
+                const uint32_t key = a.keys[q][g];
+                ep_propose_lane(L, key, 0u, of, oc, os, d);
                 o.proposed[g] = of; o.col[g] = oc; o.seq0[g] = os;
 #pragma unroll
                 for (int i = 0; i < NR; i++) if ((uint32_t)i < R) o.deps0[(size_t)i * G + g] = d[i];
+                if (LDS) {
+                    PA(q, 0) = of; PA(q, 1) = oc; PA(q, 2) = key; PA(q, 3) = (uint32_t)os; PA(q, 4) = (uint32_t)(os >> 32);
+#pragma unroll
+                    for (int i = 0; i < NR; i++) if (i < 5) PA(q, 5 + i) = d[i];
+                }
                 handled = true;
             }
         } else if (t <= R) {                                                 // acceptor q: the PreAccept of sender s
@@ -1593,13 +1687,25 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
             if (s != q && live) {
                 const smr_ep_cluster_out &o = a.out[s];
                 const uint8_t *dm = a.drop[s * NR + q];
-                const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
                 uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                ep_acceptor_lane<0, NR, RECOVERY>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
-                const size_t ro = ((size_t)s * R + q) * G + g;
-                a.r_flags[ro] = of; a.r_seq[ro] = os;
+                if (LDS) {
+                    const bool on = (PA(s, 0) & 1u) && !(dm && dm[g]);
+                    uint32_t in[NR];
 #pragma unroll
-                for (int i = 0; i < NR; i++) if ((uint32_t)i < R) a.r_deps[(((size_t)s * R + q) * R + i) * G + g] = d[i];
+                    for (int i = 0; i < NR; i++) in[i] = (i < 5 && (uint32_t)i < R) ? PA(s, 5 + i) : EP_NONE;
+                    ep_acceptor_lane_in<0, NR, RECOVERY>(L, on, s, s, PA(s, 1), (uint64_t)(s + 1u), (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in,
+                                                         PA(s, 2), of, ob, os, d);
+                    RP(s, q, 0) = of; RP(s, q, 1) = (uint32_t)os; RP(s, q, 2) = (uint32_t)(os >> 32);
+#pragma unroll
+                    for (int i = 0; i < NR; i++) if (i < 5) RP(s, q, 3 + i) = d[i];
+                } else {
+                    const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
+                    ep_acceptor_lane<0, NR, RECOVERY>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
+                    const size_t ro = ((size_t)s * R + q) * G + g;
+                    a.r_flags[ro] = of; a.r_seq[ro] = os;
+#pragma unroll
+                    for (int i = 0; i < NR; i++) if ((uint32_t)i < R) a.r_deps[(((size_t)s * R + q) * R + i) * G + g] = d[i];
+                }
                 handled = true;
             }
         } else {
@@ -1618,20 +1724,32 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                 if (q == s) {
                     uint8_t dec = 0;
                     if (live) {
-                        uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
-#pragma unroll
-                        for (int p = 0; p < NR; p++) {
-                            const bool on = (uint32_t)p < R && (uint32_t)p != s;
-                            const size_t ro = ((size_t)s * R + p) * G + g;
-                            in_f[p] = on ? a.r_flags[ro] : 0u; in_s[p] = on ? a.r_seq[ro] : 0ull;
-                            in_b[p] = (in_f[p] & 1u) ? (uint64_t)(s + 1u) : 0ull;   // an acceptor replies with the message's ballot
-#pragma unroll
-                            for (int k = 0; k < NR; k++)
-                                in_d[p][k] = (on && (uint32_t)k < R) ? a.r_deps[(((size_t)s * R + p) * R + k) * G + g] : EP_NONE;
-                        }
                         uint64_t dseq; uint32_t dd[NR];
-                        h_row = s; h_col = o.col[g];
-                        ep_pa_replies_lane(L, s, h_col, SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd, &H, &have_h);
+                        h_row = s;
+                        if (LDS) {
+                            h_col = PA(s, 1);
+                            const EpRepliesInLds<NR> rdr{sh_rep + (size_t)(set * NR + s) * (NR - 1) * EPC_REP_WORDS * 64, s, lane};
+                            ep_pa_replies_lane_rd<NR, true>(L, s, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h);
+                            // the broadcast's (seq, deps) become the decision's: what the Accept / CommitNotice of s carries
+                            PA(s, 0) = (PA(s, 0) & 1u) | ((uint32_t)dec << 8);
+                            PA(s, 3) = dec ? (uint32_t)dseq : 0u; PA(s, 4) = dec ? (uint32_t)(dseq >> 32) : 0u;
+#pragma unroll
+                            for (int k = 0; k < NR; k++) if (k < 5) PA(s, 5 + k) = dec ? dd[k] : EP_NONE;
+                        } else {
+                            uint32_t in_f[NR]; uint64_t in_b[NR], in_s[NR]; uint32_t in_d[NR][NR];
+#pragma unroll
+                            for (int p = 0; p < NR; p++) {
+                                const bool on = (uint32_t)p < R && (uint32_t)p != s;
+                                const size_t ro = ((size_t)s * R + p) * G + g;
+                                in_f[p] = on ? a.r_flags[ro] : 0u; in_s[p] = on ? a.r_seq[ro] : 0ull;
+                                in_b[p] = (in_f[p] & 1u) ? (uint64_t)(s + 1u) : 0ull;   // an acceptor replies with the message's ballot
+#pragma unroll
+                                for (int k = 0; k < NR; k++)
+                                    in_d[p][k] = (on && (uint32_t)k < R) ? a.r_deps[(((size_t)s * R + p) * R + k) * G + g] : EP_NONE;
+                            }
+                            h_col = o.col[g];
+                            ep_pa_replies_lane(L, s, h_col, SMR_CTL_IDENTITY, 0u, in_f, in_b, in_s, in_d, dec, dseq, dd, &H, &have_h);
+                        }
                         o.decision[g] = dec; o.seq[g] = dec ? dseq : 0ull;
 #pragma unroll
                         for (int k = 0; k < NR; k++) if ((uint32_t)k < R) o.deps[(size_t)k * G + g] = dec ? dd[k] : EP_NONE;
@@ -1648,26 +1766,59 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                 if (a.phase_major) barrier = s == R - 1u;
                 if (slow_round && q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                    ep_acceptor_lane<1, NR, RECOVERY>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
-                                            a.keys[s][g], of, ob, os, d);
-                    a.a_flags[((size_t)s * R + q) * G + g] = of;
+                    if (LDS) {
+                        uint32_t in[NR];
+#pragma unroll
+                        for (int i = 0; i < NR; i++) in[i] = (i < 5 && (uint32_t)i < R) ? PA(s, 5 + i) : EP_NONE;
+                        ep_acceptor_lane_in<1, NR, RECOVERY>(L, ((PA(s, 0) >> 8) & 0xFFu) == EST_ACCEPTING, s, s, PA(s, 1), (uint64_t)(s + 1u),
+                                                             (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in, PA(s, 2), of, ob, os, d);
+                        sh_af[((size_t)(set * NR + s) * NR + q) * 64 + lane] = of;
+                    } else {
+                        ep_acceptor_lane<1, NR, RECOVERY>(L, o.decision[g] == EST_ACCEPTING, s, s, o.col[g], (uint64_t)(s + 1u), o.seq[g], o.deps,
+                                                a.keys[s][g], of, ob, os, d);
+                        a.a_flags[((size_t)s * R + q) * G + g] = of;
+                    }
                     handled = true;
                 }
             } else if (ph == 2) {                                            // leader s: the AcceptReplies, then what is committed
                 if (a.phase_major) { slow_round = sh_slow[set * NR + s] != 0; barrier = s == R - 1u; }
                 if (q == s && live) {
-                    const bool acc = slow_round && ep_accept_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G,
-                                                                               nullptr, (uint64_t)(s + 1u));
-                    o.committed[g] = (o.decision[g] == EST_COMMITTED || acc) ? 1 : 0;
+                    bool acc = false, fastc;
+                    if (LDS) {
+                        if (slow_round) {
+                            uint32_t fm = 0;
+#pragma unroll
+                            for (int p = 0; p < NR; p++)
+                                if ((uint32_t)p < R && (uint32_t)p != s) fm |= (uint32_t)(sh_af[((size_t)(set * NR + s) * NR + p) * 64 + lane] & 1u) << p;
+                            // (a flag of an earlier tick's slow round cannot be met: a set's slow round rewrites every acceptor's flag of leader s)
+                            acc = ep_accept_replies_mask(L, s, PA(s, 1), SMR_CTL_IDENTITY, fm, (uint64_t)(s + 1u));
+                        }
+                        fastc = ((PA(s, 0) >> 8) & 0xFFu) == EST_COMMITTED;
+                        if (fastc || acc) PA(s, 0) |= 1u << 16;
+                    } else {
+                        acc = slow_round && ep_accept_replies_lane(L, s, o.col[g], SMR_CTL_IDENTITY, a.a_flags + (size_t)s * R * G, nullptr, (uint64_t)(s + 1u));
+                        fastc = o.decision[g] == EST_COMMITTED;
+                    }
+                    o.committed[g] = (fastc || acc) ? 1 : 0;
                     handled = true; can_commit = true;
                 }
             } else {                                                         // the CommitNotices of leader s
                 barrier = false;                                             // (the next step that reads across wavefronts has its own in front)
                 if (q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
-                    h_row = s; h_col = o.col[g];
-                    ep_acceptor_lane<2, NR, RECOVERY>(L, o.committed[g] & 1, s, s, h_col, (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
-                                            os, d, &H, &have_h);
+                    h_row = s;
+                    if (LDS) {
+                        h_col = PA(s, 1);
+                        uint32_t in[NR];
+#pragma unroll
+                        for (int i = 0; i < NR; i++) in[i] = (i < 5 && (uint32_t)i < R) ? PA(s, 5 + i) : EP_NONE;
+                        ep_acceptor_lane_in<2, NR, RECOVERY>(L, (PA(s, 0) >> 16) & 1u, s, s, h_col, (uint64_t)(s + 1u),
+                                                             (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in, PA(s, 2), of, ob, os, d, &H, &have_h);
+                    } else {
+                        h_col = o.col[g];
+                        ep_acceptor_lane<2, NR, RECOVERY>(L, o.committed[g] & 1, s, s, h_col, (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob,
+                                                os, d, &H, &have_h);
+                    }
                     handled = true; can_commit = true;
                 }
             }
