@@ -102,54 +102,41 @@ struct EpInst {
 // CACHE: the lane keeps its group's per-row scalars (row lengths, commit bars, my_nulls) in registers from load_scalars() to
 // store_scalars() -- the one-launch cluster tick runs ~15 handlers on a lane, and every one of them starts with these
 // words; a handler kernel of its own (CACHE = false) reads and writes them in place
+// CACHE: the lane keeps its group's per-row scalars (row lengths, commit bars; the executor's exec bars and commit-bar copies)
+// from load_scalars() to store_scalars() in a block of LDS the kernel hands it (bind_cache: [4][NR][64] words per wavefront,
+// word = [array][row][lane]) -- the one-launch cluster tick runs ~15 handlers on a lane, and every one of them starts with these
+// words; a handler kernel of its own (CACHE = false) reads and writes them in place.  (Round 3 kept them in 21 registers, every
+// access a chain of NR compare-and-selects because `row` is a run-time value: since round 4 an access is one ds_read / ds_write,
+// and the registers went to the handlers.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMR_L __attribute__((address_space(3)))
+#else
+#define SMR_L
+#endif
 template <int NR, bool CACHE = false>
 struct EpLaneT {
     const EpView &v;
     const uint32_t g;
     unsigned int n_fast = 0, n_slow = 0, n_acc = 0, n_xc = 0, n_xa = 0, n_xp = 0, n_xn = 0;
-    uint32_t c_len[CACHE ? NR : 1], c_cb[CACHE ? NR : 1], c_nulls = 0;
+    SMR_L uint32_t *lc = nullptr;                                            // CACHE: this lane's column of the wavefront's cache block
+    uint32_t c_nulls = 0;
     __device__ __forceinline__ EpLaneT(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
+    __device__ __forceinline__ void bind_cache(uint32_t *block_of_my_wavefront, uint32_t lane) { lc = (SMR_L uint32_t *)(block_of_my_wavefront + lane); }
+    __device__ __forceinline__ SMR_L uint32_t &cw(int arr, uint32_t row) const { return lc[((uint32_t)arr * NR + row) * 64u]; }
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) {
-            c_len[r] = (uint32_t)r < v.R ? v.len[(size_t)r * v.G + g] : 0u;
-            c_cb[r] = (uint32_t)r < v.R ? v.commit_bars[(size_t)r * v.G + g] : 0u;
-        }
+        for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = v.len[(size_t)r * v.G + g]; cw(1, r) = v.commit_bars[(size_t)r * v.G + g]; }
         c_nulls = v.my_nulls[g];
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++)
-            if ((uint32_t)r < v.R) { v.len[(size_t)r * v.G + g] = c_len[r]; v.commit_bars[(size_t)r * v.G + g] = c_cb[r]; }
+        for (uint32_t r = 0; r < v.R; r++) { v.len[(size_t)r * v.G + g] = cw(0, r); v.commit_bars[(size_t)r * v.G + g] = cw(1, r); }
         v.my_nulls[g] = c_nulls;
     }
-    __device__ __forceinline__ uint32_t get_len(uint32_t row) const {
-        if (!CACHE) return v.len[(size_t)row * v.G + g];
-        uint32_t x = 0;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) x = c_len[r];
-        return x;
-    }
-    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) {
-        if (!CACHE) { v.len[(size_t)row * v.G + g] = x; return; }
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) c_len[r] = (uint32_t)r == row ? x : c_len[r];   // (a select per register: a
-                                                                                              // conditional store would become a store through a chosen POINTER and keep the array in scratch)
-    }
-    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const {
-        if (!CACHE) return v.commit_bars[(size_t)row * v.G + g];
-        uint32_t x = 0;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) x = c_cb[r];
-        return x;
-    }
-    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) {
-        if (!CACHE) { v.commit_bars[(size_t)row * v.G + g] = x; return; }
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) c_cb[r] = (uint32_t)r == row ? x : c_cb[r];
-    }
+    __device__ __forceinline__ uint32_t get_len(uint32_t row) const { return CACHE ? cw(0, row) : v.len[(size_t)row * v.G + g]; }
+    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) { if (CACHE) cw(0, row) = x; else v.len[(size_t)row * v.G + g] = x; }
+    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const { return CACHE ? cw(1, row) : v.commit_bars[(size_t)row * v.G + g]; }
+    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) { if (CACHE) cw(1, row) = x; else v.commit_bars[(size_t)row * v.G + g] = x; }
     __device__ __forceinline__ uint32_t get_nulls() const { return CACHE ? c_nulls : v.my_nulls[g]; }
     __device__ __forceinline__ void add_nulls(uint32_t d) { if (CACHE) c_nulls += d; else v.my_nulls[g] += d; }
     // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
@@ -510,33 +497,17 @@ struct EpExecLaneT {
     const EpView &v;
     const EpExec &x;
     EpLaneT<NR, CACHE> &L;
-    uint32_t c_eb[CACHE ? NR : 1], c_pcb[CACHE ? NR : 1];                    // exec_bars / prev_cb in registers (see EpLaneT)
+    // CACHE: exec_bars / prev_cb in arrays 2 and 3 of the lane's LDS cache block (see EpLaneT)
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) {
-            c_eb[r] = (uint32_t)r < v.R ? x.exec_bars[(size_t)r * v.G + g] : 0u;
-            c_pcb[r] = (uint32_t)r < v.R ? x.prev_cb[(size_t)r * v.G + g] : 0u;
-        }
+        for (uint32_t r = 0; r < v.R; r++) { L.cw(2, r) = x.exec_bars[(size_t)r * v.G + g]; L.cw(3, r) = x.prev_cb[(size_t)r * v.G + g]; }
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++)
-            if ((uint32_t)r < v.R) { x.exec_bars[(size_t)r * v.G + g] = c_eb[r]; x.prev_cb[(size_t)r * v.G + g] = c_pcb[r]; }
+        for (uint32_t r = 0; r < v.R; r++) { x.exec_bars[(size_t)r * v.G + g] = L.cw(2, r); x.prev_cb[(size_t)r * v.G + g] = L.cw(3, r); }
     }
-    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const {
-        if (!CACHE) return x.exec_bars[(size_t)row * v.G + g];
-        uint32_t y = 0;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) if ((uint32_t)r == row) y = c_eb[r];
-        return y;
-    }
-    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) {
-        if (!CACHE) { x.exec_bars[(size_t)row * v.G + g] = y; return; }
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) c_eb[r] = (uint32_t)r == row ? y : c_eb[r];
-    }
+    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : x.exec_bars[(size_t)row * v.G + g]; }
+    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else x.exec_bars[(size_t)row * v.G + g] = y; }
     // has the row's commit bar moved since the last look (then the copy follows it)
     __device__ __forceinline__ bool cb_moved(uint32_t row, uint32_t cb) {
         if (!CACHE) {
@@ -545,14 +516,9 @@ struct EpExecLaneT {
             x.prev_cb[o] = cb;
             return true;
         }
-        bool moved = false;
-#pragma unroll
-        for (int r = 0; r < (CACHE ? NR : 1); r++) {
-            const bool hit = (uint32_t)r == row && c_pcb[r] != cb;
-            moved = moved || hit;
-            c_pcb[r] = hit ? cb : c_pcb[r];
-        }
-        return moved;
+        if (L.cw(3, row) == cb) return false;
+        L.cw(3, row) = cb;
+        return true;
     }
     const uint32_t g, wshift;
     uint32_t n_nodes = 0, n_order = 0, last = XNIL;          // last: ring cell of the slot popped before, XNIL = none / not held
@@ -1605,12 +1571,13 @@ template <int NR> constexpr int epc_sets() { return NR <= 5 ? EPC_SETS : 1; }   
 //   sh_pa  [set][leader s][10][64]: what leader s broadcasts -- word 0 flags (bit 0 proposed, bits 8-15 the decision, bit 16
 //          committed), 1 col, 2 key, 3-4 seq, 5-9 deps: the PreAccept's (seq0, deps0) until s's own PreAcceptReply step
 //          overwrites them with the decision's (every acceptor has taken the PreAccept by then: barrier behind step R)
-//   sh_rep [set][leader s][acceptor q != s][8][64]: q's PreAcceptReply -- flag, seq lo, seq hi, deps[5]
+//   sh_rep [set][leader s][acceptor q != s][7][64]: q's PreAcceptReply -- seq lo, seq hi | flag << 31, deps[5]
+//   sh_sc  [wavefront][4][NR][64]: the lanes' per-row scalars (EpLaneT::bind_cache)
 //   sh_af  [set][leader s][acceptor q][64] bytes: q's AcceptReply flag
 // The out[] arrays are still WRITTEN (they are the call's outputs); nothing of the tick reads them back.  The leader's step takes
 // a reply out of LDS when its turn comes instead of holding all four in registers (50 VGPRs of the old step).
 template <int NR> constexpr bool epc_lds() { return NR <= 5; }
-constexpr int EPC_PA_WORDS = 10, EPC_REP_WORDS = 8;
+constexpr int EPC_PA_WORDS = 10, EPC_REP_WORDS = 7;       // a reply: seq lo, seq hi | flag << 31 (a sequence number stays below 2^63), deps[5]
 template <int NR>
 struct EpRepliesInLds {
     const uint32_t *rep;                                                     // sh_rep + the set's and the leader's offset
@@ -1618,11 +1585,12 @@ struct EpRepliesInLds {
     __device__ __forceinline__ void get(uint32_t p, uint32_t &f, uint64_t &rb, uint64_t &rs, uint32_t (&rd)[NR]) const {
         const uint32_t qi = p - (p > s ? 1u : 0u);                           // (p != s: the caller skips the leader itself)
         const uint32_t *w = rep + (size_t)qi * EPC_REP_WORDS * 64 + lane;
-        f = w[0];
-        rs = (uint64_t)w[64] | ((uint64_t)w[128] << 32);
+        const uint32_t hi = w[64];
+        f = hi >> 31;
+        rs = (uint64_t)w[0] | ((uint64_t)(hi & 0x7FFFFFFFu) << 32);
         rb = (f & 1u) ? (uint64_t)(s + 1u) : 0ull;                           // an acceptor replies with the message's ballot
 #pragma unroll
-        for (int k = 0; k < NR; k++) rd[k] = k < 5 ? w[(3 + k) * 64] : EP_NONE;
+        for (int k = 0; k < NR; k++) rd[k] = k < 5 ? w[(2 + k) * 64] : EP_NONE;
     }
 };
 
@@ -1634,6 +1602,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
     __shared__ uint32_t sh_pa[LDS ? SETS * NR * EPC_PA_WORDS * 64 : 1];
     __shared__ uint32_t sh_rep[LDS ? SETS * NR * (NR - 1) * EPC_REP_WORDS * 64 : 1];
     __shared__ uint8_t sh_af[LDS ? SETS * NR * NR * 64 : 1];
+    __shared__ uint32_t sh_sc[SETS * NR * 4 * NR * 64];                      // the lanes' scalar caches: [wavefront][array][row][lane] (EpLaneT::bind_cache)
     const uint32_t R = a.R, G = a.G;
     const uint32_t wv = SMR_WAVE_UNIFORM(threadIdx.x >> 6), set = wv / R, q = wv - set * R;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1646,6 +1615,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
     ep_shift(x, a.delta[q]);
     v.me = q;
     EpLaneT<NR, true> L(v, g);
+    L.bind_cache(sh_sc + (size_t)wv * 4 * NR * 64, lane);
     EpExecLaneT<NR, true> E(v, x, L, g);
     if (live) { L.load_scalars(); if (a.execute) E.load_scalars(); }
     // word w of leader s's broadcast / of acceptor qq's reply to leader s, this lane's
@@ -1695,9 +1665,9 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                     for (int i = 0; i < NR; i++) in[i] = (i < 5 && (uint32_t)i < R) ? PA(s, 5 + i) : EP_NONE;
                     ep_acceptor_lane_in<0, NR, RECOVERY>(L, on, s, s, PA(s, 1), (uint64_t)(s + 1u), (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in,
                                                          PA(s, 2), of, ob, os, d);
-                    RP(s, q, 0) = of; RP(s, q, 1) = (uint32_t)os; RP(s, q, 2) = (uint32_t)(os >> 32);
+                    RP(s, q, 0) = (uint32_t)os; RP(s, q, 1) = ((uint32_t)(os >> 32) & 0x7FFFFFFFu) | ((uint32_t)(of & 1u) << 31);
 #pragma unroll
-                    for (int i = 0; i < NR; i++) if (i < 5) RP(s, q, 3 + i) = d[i];
+                    for (int i = 0; i < NR; i++) if (i < 5) RP(s, q, 2 + i) = d[i];
                 } else {
                     const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
                     ep_acceptor_lane<0, NR, RECOVERY>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
