@@ -1067,6 +1067,18 @@ def spread_run(args, torch, dist, rank, world, dev, steps, warmup, call_by_call=
     kw = dict(win_reserve=W // 8, outbox_cap=cap)
     job = spread_mp.in_process(total, R, W, nr, dev, S, **kw) if virtual else spread_mp.SpreadMultiPaxos(total, R, W, rank, world, dev, S, **kw)
     job.preset_leader(0)
+    via = "a device copy between the virtual ranks' buffers" if virtual else "torch.distributed.all_to_all_single"
+    comm = None
+    if not virtual and dist.get_backend() == "nccl" and os.environ.get("SMR_L2_TORCH") is None:
+        # the exchange inside the library (round 4): smr_comm_exchange = grouped ncclSend / ncclRecv pairs on the plans' buffers, the whole
+        # tick one C call (smr_mp_spread_tick).  SMR_L2_TORCH=1 keeps the collectives in torch.distributed.
+        try:
+            from summerset_amd import comm as _comm
+            comm = _comm.Comm.from_torch_distributed(dev)
+            job.bind_comm(comm)
+            via = "smr_comm_exchange (libsummerset_hip.so: RCCL send / recv pairs), the tick one smr_mp_spread_tick call"
+        except Exception as e:                                   # noqa: BLE001
+            via += " (smr_comm_init_rank failed: %s)" % e
     mine = sorted({b for rk in job.ranks for b in rk.blocks} if virtual else job.blocks)
     n_ticks = warmup + steps
     skw = dict(cap=cap, n_ticks=n_ticks, drop_p=args.drop, timeout_frac=timeout_frac(args), hb_every=H, rand_rows=S + 4, max_drop=2,
@@ -1110,7 +1122,7 @@ def spread_run(args, torch, dist, rank, world, dev, steps, warmup, call_by_call=
                                    "%.0f%% ack loss (<= 2 lost per slot), %s" % (args.groups, S, H, args.drop * 100, timeouts_text(args)),
                        "groups_per_gpu": args.groups, "replicas": R, "slots_per_tick": S, "window": W, "layout": "spread",
                        "spread_ranks": nr, "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
-            "exchange": {"collectives_per_tick": "3 with a heartbeat round, else 2 (one all_to_all_single each)",
+            "exchange": {"via": via, "collectives_per_tick": "3 with a heartbeat round, else 2 (one all_to_all_single each)",
                          "host_calls_per_tick": "one smr_mp_spread_segment call per segment (3, 4 with a heartbeat round) + the collectives"
                                                 if not call_by_call else "one per round per block + one per pack / unpack (rounds 1-2)",
                          "bytes_per_exchange_per_rank": {ph: int(sum(p["in_split"])) for ph, p in plans.items()},
@@ -1119,6 +1131,8 @@ def spread_run(args, torch, dist, rank, world, dev, steps, warmup, call_by_call=
             "note": "correctness layout of the north star's inter-replica fan-out; the roofline / cpu_baseline objects belong to the co-located line"}
     for rk in (job.ranks if virtual else [job]):
         rk.close()
+    if comm is not None:
+        comm.close()
     return line
 
 
@@ -1362,7 +1376,17 @@ def main():
     import torch.distributed as dist
     if args.leg == "l2":                           # child of the headline run at N = 1: the spread layout on virtual ranks
         torch.cuda.set_device(local)
-        print(json.dumps(spread_run(args, torch, dist, 0, 1, torch.device("cuda", local), steps=args.steps, warmup=4)))
+        line = spread_run(args, torch, dist, 0, 1, torch.device("cuda", local), steps=args.steps, warmup=4)
+        # the same layout without leader changes: in L2 every round is a launch the whole job waits for, so ONE group's leader
+        # change (a chain of ~100 us of wave-cooperative handlers, on the side stream in L1) is the round's length for everybody;
+        # the steady figure is what the layout itself costs
+        import copy
+        a2 = copy.copy(args)
+        a2.timeouts = 0.0
+        st = spread_run(a2, torch, dist, 0, 1, torch.device("cuda", local), steps=args.steps, warmup=4)
+        line["steady_state"] = {"ms_per_tick": st["ms_per_step"], "value": st["value"], "unit": st["unit"],
+                                "note": "--timeouts 0: no leader change in flight (layout L1's steady tick is ~0.056 ms for the same groups)"}
+        print(json.dumps(line))
         return
     if args.leg:                                   # child of leg_isolated(): one secondary leg, own process
         torch.cuda.set_device(local)
@@ -1585,6 +1609,8 @@ def main():
             l2 = {"layout": "spread (SURVEY 8e L2): replica r of block b on rank (b + r) mod N", "ranks": x["config"]["spread_ranks"],
                   "ranks_are": x["config"]["ranks_are"], "value": x["value"], "unit": "slots/s", "ms_per_tick": x["ms_per_step"],
                   "steps": x["steps"], "warmup": x["warmup"], "exchange": x["exchange"], "backend": x["backend"]}
+            if "steady_state" in x:
+                l2["steady_state"] = dict(x["steady_state"], ms_per_tick_per_virtual_rank=x["steady_state"]["ms_per_tick"] / max(x["config"]["spread_ranks"], 1))
             if world == 1:                         # all the virtual ranks' kernels ran one after the other on this ONE GPU
                 l2["ms_per_tick_per_virtual_rank"] = x["ms_per_step"] / max(x["config"]["spread_ranks"], 1)
                 l2["note"] = ("virtual ranks share one GPU and one stream order: ms_per_tick is the SUM of the ranks' work (each holds "
