@@ -1,6 +1,7 @@
 """Per-step wall-clock stamps of the one-launch EPaxos cluster tick (a -DEPC_STAMPS build: tools/build_file_variant.sh epc_stamps
 ep_engine.hip -DEPC_STAMPS): where a block's time goes, step by step and wavefront by wavefront.  100 MHz counter (10 ns).
-usage: SUMMERSET_HIP_LIB=summerset_amd/variants/libsummerset_hip_epc_stamps.so python tools/dbg_epc_stamps.py [execute]"""
+usage: SUMMERSET_HIP_LIB=summerset_amd/variants/libsummerset_hip_epc_stamps.so python tools/dbg_epc_stamps.py [execute 0|1] [pm]
+(pm: the leaders' steps phase by phase, the order bench.py's best figure runs)"""
 import ctypes as C
 import os
 import sys
@@ -12,10 +13,11 @@ import torch
 from summerset_amd import EPaxosReplicaGroup, _lib, ep_cluster
 
 EXEC = len(sys.argv) > 1 and sys.argv[1] == "1"
+PM = len(sys.argv) > 2 and sys.argv[2] == "pm"
 dev = torch.device("cuda")
 G, R, W, K = 65536, 5, 32, 64
 reps = [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=EXEC) for r in range(R)]
-cl = ep_cluster.EPaxosCluster(reps)
+cl = ep_cluster.EPaxosCluster(reps, phase_major=PM)
 rng = np.random.default_rng(0x5EED5EED)
 zipf = 1.0 / np.arange(1, K + 1) ** 0.99
 zipf /= zipf.sum()
@@ -29,7 +31,8 @@ L.smr_dbg_epc_stamps.restype = C.c_int
 buf = np.zeros(8 * 5 * 64, np.uint64)
 n = L.smr_dbg_epc_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 s = buf.reshape(8, 5, 64)
-names = ["P"] + ["A%d" % i for i in range(R)] + [x for l in range(R) for x in ("R%d" % l, "Ac%d" % l, "AR%d" % l, "C%d" % l)] + ["end"]
+names = ["P"] + ["A%d" % i for i in range(R)] + ([x % l for x in ("R%d", "Ac%d", "AR%d", "C%d") for l in range(R)] if PM else
+                                               [x for l in range(R) for x in ("R%d" % l, "Ac%d" % l, "AR%d" % l, "C%d" % l)]) + ["end"]
 print("execute =", EXEC, " (us since the block's first stamp; one row per wavefront q; block = stamped block k)")
 base = int(s[0][:, 0].min())
 print("block starts / ends (us): " + "  ".join("b%d: %.0f-%.0f" % (k * 128 + 5, (int(s[k][:, 0].min()) - base) / 100.0, (int(s[k][:, :len(names)].max()) - base) / 100.0) for k in range(8)))
