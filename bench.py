@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("r5m_pmc_traffic.json", "r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -103,13 +103,13 @@ def parse():
                     "%d) -- the leader-timeout RATE per tick is the workload's, not the run length's: a run shorter than the default "
                     "%d ticks sees the same changes per tick as the default run (SURVEY 8(d) spreads its 1 %%%% over 1024 ticks)" % (TIMEOUT_HORIZON, TIMEOUT_HORIZON))
     ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the straggler list (0 = no list); 4 "
-                    "measured best with --batch 8 (profiles/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/r2g_straggler_sweep.log)")
+                    "measured best with --batch 8 (profiles/round2/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/round2/r2g_straggler_sweep.log)")
     ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
                     "excludes the side stream).  0 = one smr_mp_tick call per tick: five per-round launches + the straggler side launch "
                     "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
     ap.add_argument("--batch", type=int, default=8, help="> 0: ticks per smr_mp_run_ticks call WITH the straggler list on: the bulk kernels still "
                     "run tick by tick, the list's groups go through the whole batch in one side-stream launch and the streams meet "
-                    "once per batch (<= 16 ticks) instead of once per tick; 8 measured best (profiles/r2z_batch.log).  0 = one "
+                    "once per batch (<= 16 ticks) instead of once per tick; 8 measured best (profiles/round2/r2z_batch.log).  0 = one "
                     "smr_mp_tick call per tick")
     ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
                     "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
@@ -501,7 +501,7 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     sl = -(-L // 3)                                                      # shard_len = ceil(L / d)
     masks = [{k_: torch.from_numpy(v).to(dev) for k_, v in workloads.config4_loss(rng, G).items()} for k in range(NB)]   # ~30 % of the slots lose ONE of their four replies
     vals = [torch.from_numpy(workloads.config4_tokens(G, j)).to(dev) for j in range(8 * NB)]   # the ticks' batch tokens: inputs, resident before the timed region
-    n_tick = [0]                                                         # (round 3 made them with four torch kernels INSIDE every tick: ~25 us of a 0.125 ms tick, profiles/r4w)
+    n_tick = [0]                                                         # (round 3 made them with four torch kernels INSIDE every tick: ~25 us of a 0.125 ms tick, profiles/round3/r4w)
 
     def one_tick(k, hb):
         val = vals[(n_tick[0] // NB * NB + k) % len(vals)]

@@ -50,7 +50,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //                                          m1 = acc_acks | avoid_fast_path << 8 | exp_prepare_acks << 16 | exp_prepare has-entry bits << 24
 //   p3 = { deps[6], deps[7], -, - }        (populations 7 and 8 only)
 // Rounds 1-2 kept every field in a plane of its own: a handler that takes an instance was 13 loads or 13 stores of 1-8 bytes.
-// The one-launch tick's time turned out to be its NUMBER of memory instructions (profiles/r3o: ~0.65 us per load or store,
+// The one-launch tick's time turned out to be its NUMBER of memory instructions (profiles/round3/r3o: ~0.65 us per load or store,
 // whatever its width), so the fields a handler touches together now travel together: an instance is 3 loads or 3 stores.
 struct EpView {
     uint32_t G, W, Wmask, R, me, n_keys, simple_q, super_q;
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ int ep_eval(const EpView &v, uint32_t acks, const uin
 // instance and of its reply table: the caller loads every incoming reply up front (in_f / in_b / in_s / in_d, row p = peer
 // p's; my own row unused), the result is stored once.  dec = 0 / EST_ACCEPTING / EST_COMMITTED with (dseq, dd).
 // (Loading every input row unconditionally from clamped addresses was measured SLOWER for this kernel -- 25.2 vs 21.7 us per
-// launch, profiles/r2w_ep_flat.log -- unlike the MultiPaxos tally's round 1; the variant is gone.)
+// launch, profiles/round2/r2w_ep_flat.log -- unlike the MultiPaxos tally's round 1; the variant is gone.)
 // where the incoming replies lie: `RD::get(p, f, rb, rs, rd)` hands over peer p's (flag, ballot, seq, deps) -- out of register
 // arrays the caller loaded (EpRepliesInRegs: the handler kernel), or out of the block's LDS (the one-launch tick)
 template <int NR>
@@ -1552,13 +1552,13 @@ struct EpClusterArgs {
 
 #ifndef EPC_WAVES_PER_EU
 #define EPC_WAVES_PER_EU 3                   // 168 VGPRs (147 spilled, 320 B of scratch per lane) with EPC_SETS 2: see there.  Round 3's first setting was 2
-                                             // (250 VGPRs, no spills, one 5-wavefront block per CU).  Measured with per-step stamps (profiles/r3r): at 168
+                                             // (250 VGPRs, no spills, one 5-wavefront block per CU).  Measured with per-step stamps (profiles/round3/r3r): at 168
                                              // VGPRs the hardware still ran ONE 5-wavefront block per CU; at 128 / 96 two / three blocks share a CU but each
                                              // runs 1.7-4x longer (spills + contention)
 #endif
 #ifndef EPC_SETS
 #define EPC_SETS 2                           // sets of 64 groups per block (R <= 5): a block = EPC_SETS x R wavefronts.  Five wavefronts on a CU's four
-                                             // SIMDs leave one SIMD with two of them; ten spread 3 / 3 / 2 / 2.  profiles/r4i, r4k: the default order
+                                             // SIMDs leave one SIMD with two of them; ten spread 3 / 3 / 2 / 2.  profiles/round3/r4i, r4k: the default order
                                              // 1078 -> 1058 us per tick, phase by phase 766 -> 711 us (the kernel is bound by instruction issue per SIMD:
                                              // two blocks' worth of wavefronts on a CU took exactly as long as one after the other)
 #endif

@@ -236,7 +236,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
     flush_counters(L, active);
 }
 
-// (min wavefronts per SIMD, i.e. the register budget of the bulk round kernels; profiles/r2g1_occupancy.log, r2g2: capping R2 at
+// (min wavefronts per SIMD, i.e. the register budget of the bulk round kernels; profiles/round2/r2g1_occupancy.log, r2g2: capping R2 at
 // 96 VGPRs -- its rare paths then spill 548 B per lane -- takes it from 29 to 21.5 us in the steady state; R1, the rest of R3
 // and R4 gain nothing from tighter caps, the tally loses)
 #ifdef MP_R1_MINW
@@ -825,7 +825,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
                            // Same-call A/Bs (profiles/r5e_tally_rows_ab.log, r5f_tally_w6_rsp_stores.log): 8 rows per pass (one pass
                            // for S = 32, 102 VGPRs) the same in the steady state and worse beside the side stream's blocks (27.9 vs
                            // 26.4 us); capped at 80 VGPRs for a sixth wavefront per SIMD (-DTALLY_MINW=6, 12 B of scratch): no
-                           // difference.  (Round 2: profiles/r2u_tally_rows_per_pass.log.)
+                           // difference.  (Round 2: profiles/round2/r2u_tally_rows_per_pass.log.)
     constexpr int C = NR <= 5 ? TALLY_C : 4;                    // rows per wavefront per pass
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (w >= 4) { __syncthreads(); return; }                    // (the fused tick kernel's block has a wavefront per replica)
@@ -1184,9 +1184,9 @@ __global__ MP_R4_BOUNDS void mp_round_heartbeat(const MpParams *__restrict__ Pp,
 // between -- what the bulk launches get from stream order.  Removes three launch boundaries from the
 // stragglers' critical path (a leader change's handlers are serial latency, not bandwidth).
 // (Round 2 tried packing the list tighter, twice.  A listed group's replicas on neighbouring lanes of ONE wavefront:
-// 0.208 ms per tick against 0.157 (profiles/r2w_strag_lanes.log) -- the replicas' handlers are divergent serial chains; on
+// 0.208 ms per tick against 0.157 (profiles/round2/r2w_strag_lanes.log) -- the replicas' handlers are divergent serial chains; on
 // one wavefront they run one after the other, on five they overlap.  STRAG_K listed groups per block, on lanes 0..K-1 of
-// every replica's wavefront: 0.19 ms at K = 2, 0.24 at K = 4 (profiles/r2x_strag_k.log) -- cooperative jobs of the same
+// every replica's wavefront: 0.19 ms at K = 2, 0.24 at K = 4 (profiles/round2/r2x_strag_k.log) -- cooperative jobs of the same
 // wavefront queue behind each other.  What both runs showed: bench.py's list is a few dozen groups per tick, nowhere
 // near the 256 blocks; this launch lasts as long as ONE group's leader change takes through its four rounds (~128 us
 // of dependent memory round trips), and neither residency nor packing touches that.)
@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
 // slack, and what counts here is how many listed groups the 256 blocks get through in the time the bulk needs.)
 // 192 blocks x 6 groups: a quarter of the CUs stay free of the 5-wavefront, 220-VGPR side blocks, which is where the tally's
 // 4-wavefront LDS blocks find their slots when the list is long (26 leader changes per tick: 0.157 -> 0.143 ms per tick against
-// 256 x 4; no difference on the default workload, whose list is shorter than 192 groups -- profiles/r2g6_side_blocks.log)
+// 256 x 4; no difference on the default workload, whose list is shorter than 192 groups -- profiles/round2/r2g6_side_blocks.log)
 #ifndef STRAG_BATCH_K
 #define STRAG_BATCH_K 6
 #endif

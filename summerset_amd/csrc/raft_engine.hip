@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, cons
 // CRAFT: craft/messages.rs:256-404 -- every reply a leader takes also counts as a heard heartbeat (:275 ->
 // heartbeat.rs:280-296), a success reply is not tested for staleness (:279 is a debug_assert; a release build goes
 // on), and the commit rule is `majority + fault_tolerance` matches, `majority` in full-copy mode (:307-313)
-// (Measured and dropped, profiles/r2s_raft_lanes_ab.log: eight lanes per group with width-8 shuffles -- 8192 wavefronts --
+// (Measured and dropped, profiles/round2/r2s_raft_lanes_ab.log: eight lanes per group with width-8 shuffles -- 8192 wavefronts --
 // ran 29.5 us against this kernel's 17.3: each load then touches eight 32-byte pieces of eight rows instead of one
 // contiguous run.  What HAD made one lane per group slow were the shared counter words, see ctr_add.)
 // NR >= population: every per-peer array and every loop over peers is NR wide (5 for the common populations -- the

@@ -34,7 +34,7 @@ inline int fail(int code, const std::string &msg) {
 
 // Event counters (commits, redirects, ...) are kept as SMR_CTR_SHARDS partial sums, one 64-byte line each: a kernel's
 // wavefronts add to different lines, the host sums them when it reads.  One shared word per counter looked harmless and
-// WAS the kernels' run time: ~15 ns per same-address atomic, 1024 wavefronts -> 15-30 us (profiles/r2q: the Raft reply
+// WAS the kernels' run time: ~15 ns per same-address atomic, 1024 wavefronts -> 15-30 us (profiles/round2/r2q: the Raft reply
 // kernel went from 33 to 126 us when eight lanes per group made it 8192 wavefronts -- its atomics, not its loads).
 constexpr uint32_t SMR_CTR_SHARDS = 256, SMR_CTR_STRIDE = 8;     // u64 words per shard
 constexpr size_t SMR_CTR_WORDS = (size_t)SMR_CTR_SHARDS * SMR_CTR_STRIDE;

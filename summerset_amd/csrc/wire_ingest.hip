@@ -10,7 +10,7 @@
 // wavefront's reads never share a bank whatever offsets its lanes are at, and every read is an aligned dword (gfx950's
 // LDS does take unaligned 8- and 16-byte reads, but r3v's counters showed SQ_LDS_UNALIGNED_STALL at 87 % of the LDS
 // unit's busy cycles with a row-per-lane layout read that way); nothing in LDS is shared between lanes, a column is its
-// lane's indexable scratch -- and refilled at the lane's position when the next frame leaves it.  Round 3 (profiles/r3m:
+// lane's indexable scratch -- and refilled at the lane's position when the next frame leaves it.  Round 3 (profiles/round3/r3m:
 // ~600 wavefront instructions per frame through 188 branches): the frames a running cluster sends -- payloads of 2 .. 24
 // bytes whose varints are below 2^32 -- take a straight-line path without a branch, every varint out of the two dwords
 // it lies in; everything else (long frames, 64-bit values, timestamps, odd encodings, malformed input) takes the general

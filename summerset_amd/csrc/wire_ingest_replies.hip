@@ -17,7 +17,7 @@
 // connections of a block lie side by side in the buffer: the block copies its span of the buffer into LDS with aligned
 // 16-byte loads (up to 24 KB; a block whose connections carry more reads the rest from HBM) and every lane parses out of
 // LDS -- the first version read its frames straight out of HBM eight unaligned bytes at a time, eight dependent loads per
-// frame: 105 us for 262 144 connections (profiles/r4c, r4e), four Raft ticks' worth.  What those 105 us were, though, was
+// frame: 105 us for 262 144 connections (profiles/round3/r4c, r4e), four Raft ticks' worth.  What those 105 us were, though, was
 // neither the loads nor the parse (r4g): 8192 atomics on ONE address -- the wavefronts' reply counts and the located frames'
 // indices; a same-address atomic takes ~10 ns whatever it carries -- so a block of 1024 lanes now counts in LDS, keeps the
 // frames it locates in LDS, and goes to the call's counters once: 256 atomics per counter.

@@ -1,7 +1,7 @@
 """Spread layout (L2) of the EPaxos cluster on the device: all ranks of the job in one process on cuda:0, the collective a
 device copy -- summerset_amd/spread_ep.py against the co-located closed loop (tests/test_spread_ep.py holds the
 comparison) AND, since round 4, against five EpOracle objects running the same ticks: every block's
-decisions of every tick and every (block, replica)'s final state directly against the oracle.  Sorted behind the rest (first device run: profiles/r2q), before the files that have not run on a device yet; a failure here must not keep the rest of the suite from
+decisions of every tick and every (block, replica)'s final state directly against the oracle.  Sorted behind the rest (first device run: profiles/round2/r2q), before the files that have not run on a device yet; a failure here must not keep the rest of the suite from
 running under `pytest -x`."""
 import pytest
 

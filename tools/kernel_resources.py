@@ -3,7 +3,7 @@
 (`-Rpass-analysis=kernel-resource-usage`, device pass only): VGPRs, AGPRs, SGPRs, scratch (spill) bytes per lane,
 LDS bytes per block, and the occupancy (waves per SIMD) the register / LDS budget allows.  No GPU needed.
 
-    python tools/kernel_resources.py > profiles/r1h_kernel_resources.txt
+    python tools/kernel_resources.py > profiles/round1/r1h_kernel_resources.txt
 
 It is what can be said about a kernel that has not run on the device yet: whether it spills, and how many
 wavefronts can be in flight to hide its HBM latency.  Not a measurement."""
