@@ -621,7 +621,7 @@ def _time_us(torch, fn, iters, sleep_cycles=6_000_000):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-def raft_leg(torch, dev, S=32, ticks=48):
+def raft_leg(torch, dev, S=32, ticks=48, conflict_p=0.005):
     """BASELINE config 3: Raft, 65 536 groups x 5 replicas, leader-side AppendEntriesReply match-index quorum
     (raft/messages.rs:222-388): per tick S appends, then one reply per follower with end_slot = leader_last -
     lag (lag 0..3 seeded), 5 % dropped, 0.5 % stale-term, 0.5 % conflict replies.  Headline of the leg: batches of 16 ticks
@@ -640,7 +640,7 @@ def raft_leg(torch, dev, S=32, ticks=48):
         flags = (u >= 0.05).astype(np.uint8)
         term = np.full((R, G), 2, np.uint64)
         term[(u >= 0.05) & (u < 0.055)] = 1                                   # stale term: ignored
-        conflict = (u >= 0.055) & (u < 0.06)
+        conflict = (u >= 0.055) & (u < 0.055 + conflict_p)
         flags[conflict] |= 2
         end_slot = np.maximum(last - lag, 0).astype(np.uint32)
         pool.append(tuple(torch.from_numpy(x.view(np.int64) if x.dtype == np.uint64 else
