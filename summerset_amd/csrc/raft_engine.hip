@@ -73,7 +73,10 @@ __device__ __forceinline__ void raft_append_body(const RaftView &v, uint32_t g, 
     // send [try_next, len] with the first append and one more entry with each further one: first slot sent = try_next,
     // entries sent = (len + 1 - try_next) + (n - 1), try_next = len + n.  What is left of the n iterations is their n
     // stores, independent of each other.  (One lane per group is one wavefront per SIMD: the loop's ~45 dependent
-    // instructions per append were a third of the batched tick, profiles/r5k, r5l.)
+    // instructions per append were MORE THAN HALF of the batched tick, 26.1 -> 11.3 us, profiles/r5k, r5l.  Asking for a
+    // conflict reply's words and candidate terms a round of loads ahead, with the next tick's inputs, gained nothing --
+    // 11.2 us, and 9.4 instead of 9.2 without conflicts, profiles/r5n: what a conflict costs is its divergent code, not
+    // its round trips.)
     bool simple = n > 0 && len + n - 1 - snap < v.W;
 #pragma unroll
     for (int p = 0; p < NR; p++)
