@@ -561,6 +561,10 @@ int smr_raft_craft_poll_reconstructs(smr_raft_leader *l, uint32_t max_slots, uin
 int smr_raft_craft_handle_reconstruct_reply(smr_raft_leader *l, const uint8_t *peer_dev, const uint32_t *n_dev, const uint32_t *slot_dev,
                                             const uint8_t *mask_dev, uint32_t max_slots, void *stream);
 int smr_raft_craft_dump_masks(smr_raft_leader *l, uint8_t *mask_host, uint64_t *counters);
+/* How many entries of AppendEntries messages this replica's follower path skipped because they had left its W-entry term ring
+ * (it takes such an entry as matching; raft/messages.rs:128-140 compares terms in an unbounded Vec).  A harness rule for
+ * bounded memory, shared with the oracle: size `window` so that this stays 0 -- the parity tests assert it. */
+int smr_raft_ring_guard_hits(smr_raft_leader *l, uint64_t *out);
 
 /* ------------------------------------------------------------------------
  * EPaxos command leader / acceptor over G groups (one replica id per group)
@@ -1067,8 +1071,10 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
  * counts_dev[1] = their number, those past other_cap are counted, not stored).  A frame that breaks the host decoder's
  * rules (smr_wire_raft_decode / smr_wire_ep_decode: a length above 10^12, an unknown Raft variant, a reply that does not
  * end where its length says) makes its connection malformed: status_dev[c] = 1, consumed_dev[c] = 0, nothing of it
- * counts (a reply it delivered before stays in the arrays); counts_dev[2] = such connections.  counts_dev[0] = the
- * replies taken.  flags_dev is zeroed by the call; the other arrays are only written where flags says so.  Two connections
+ * counts (a reply it delivered before stays in the arrays, with its flag set, and so do the frames of that connection
+ * already located in others_dev: a host that re-decodes the connection from byte 0 because consumed_dev[c] = 0 must first
+ * drop the others_dev entries whose conn has status 1, or it handles those frames twice); counts_dev[2] = such
+ * connections.  counts_dev[0] = the replies taken.  flags_dev is zeroed by the call; the other arrays are only written where flags says so.  Two connections
  * with the same (group, peer): the caller's error (one of them wins).  buf_dev must be 16-byte aligned.  conn_len_dev (may be
  * NULL): the length of every connection's bytes where they do not lie back to back -- connection c is then
  * buf_dev[conn_off[c] .. conn_off[c] + conn_len[c]) and conn_off needs n_conn entries, ascending; this is the layout the emit

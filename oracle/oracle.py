@@ -76,6 +76,8 @@ def _declare(L):
     L.orc_raft_dump.argtypes = [vp] + [vp] * 11
     L.orc_raft_total_commits.restype = u64; L.orc_raft_total_commits.argtypes = [vp]
     L.orc_raft_counters.argtypes = [vp, vp]
+    L.orc_raft_ring_guard_hits.argtypes = [vp]
+    L.orc_raft_ring_guard_hits.restype = C.c_uint64
     L.orc_raft_preset.argtypes = [vp, u8, u8, u64, u8]
     L.orc_raft_handle_append_entries.argtypes = [vp] + [vp] * 7 + [u32] + [vp] * 7
     L.orc_raft_become_candidate.argtypes = [vp] + [vp] * 5
@@ -329,6 +331,11 @@ class RaftOracle:
         c = np.zeros(4, np.uint64)
         lib().orc_raft_counters(self.h, _p(c))
         return c
+
+    def ring_guard_hits(self):
+        """entries a follower's AppendEntries handling skipped because they had left the term ring (a harness rule shared
+        with the engine, not the reference's): a parity run should keep this at 0"""
+        return int(lib().orc_raft_ring_guard_hits(self.h))
 
     # ---- follower side and elections ----
     def preset(self, role, leader, term, voted_for=0xFF):

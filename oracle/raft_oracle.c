@@ -76,6 +76,8 @@ typedef struct {
     uint32_t next_slot[MAXR], try_next_slot[MAXR], match_slot[MAXR];
     uint64_t n_committed, n_redirect, n_reject, n_sent;
     uint64_t n_exec, n_trunc; /* follower: entries submitted for execution, log truncations */
+    uint64_t n_ring_guard;    /* follower: entries of an AppendEntries skipped by the ring guard (NOT the reference's rule: see
+                                 orc_raft_ring_guard_hits) */
     uint32_t ae_first[MAXR];  /* first slot sent to each peer during the current append call (NONE32 = nothing) */
     /* CRaft leader variant */
     uint8_t craft, fault_tolerance, full_copy_mode, repeat_threshold;
@@ -358,7 +360,7 @@ static void handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t leader, ui
     for (uint32_t s = 0; s < n; s++) {
         uint32_t slot = prev_slot + 1 + s;
         if (slot >= log_end(r)) { first_new = slot; break; }
-        if (slot >= r->start_slot && slot < r->ring_lo) continue;           /* harness guard shared with the engine: an entry that left the
+        if (slot >= r->start_slot && slot < r->ring_lo) { r->n_ring_guard++; continue; }   /* harness guard shared with the engine: an entry that left the
                                                                                W-entry term ring is taken as matching, never as a conflict */
         int ok3; uint64_t t = term_at(r, slot, W, &ok3);
         if (!ok3 || t != ent[s * ent_stride]) {
@@ -440,7 +442,7 @@ static void craft_handle_msg_append_entries(RaftRep *r, uint32_t W, uint8_t lead
     for (uint32_t s = 0; s < n; s++) {
         uint32_t slot = prev_slot + 1 + s;
         if (slot >= log_end(r)) { first_new = slot; break; }
-        if (slot >= r->start_slot && slot < r->ring_lo) continue;           /* harness guard shared with the engine: an entry that left the
+        if (slot >= r->start_slot && slot < r->ring_lo) { r->n_ring_guard++; continue; }   /* harness guard shared with the engine: an entry that left the
                                                                                W-entry term ring is taken as matching, never as a conflict */
         int ok3; uint64_t t = term_at(r, slot, W, &ok3);
         if (!ok3 || t != ent[s * ent_stride]) {
@@ -693,6 +695,16 @@ uint64_t orc_raft_total_commits(void *h) {
     RaftCl *cl = (RaftCl *)h;
     uint64_t t = 0;
     for (uint32_t g = 0; g < cl->G; g++) t += cl->reps[g].n_committed;
+    return t;
+}
+
+/* How often the follower's prev-term check met an entry that had left the W-entry term ring and took it as matching -- where
+ * raft/messages.rs:128-140 compares terms.  Engine and oracle share the deviation (a ring cannot hold what the reference's
+ * Vec holds), so a parity run in which this is not 0 proves nothing about those entries: the tests assert it. */
+uint64_t orc_raft_ring_guard_hits(void *h) {
+    RaftCl *cl = (RaftCl *)h;
+    uint64_t t = 0;
+    for (uint32_t g = 0; g < cl->G; g++) t += cl->reps[g].n_ring_guard;
     return t;
 }
 

@@ -275,6 +275,7 @@ SYMBOLS = [
     ("smr_raft_craft_dump", _i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_handle_reconstruct", _i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_dump_masks", _i, [_vp, _vp, _vp]),
+    ("smr_raft_ring_guard_hits", _i, [_vp, C.POINTER(_u64)]),
     ("smr_raft_craft_poll_reconstructs", _i, [_vp, _u32, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_handle_reconstruct_reply", _i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     ("smr_ep_replica_create", _i, [C.POINTER(EpCfg), C.POINTER(_vp)]),

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
                     // (harness: an entry that has left the W-entry term ring is >= W entries behind the log's end -- its term is
                     // no longer held, which is NOT a term conflict: it is taken as matching, never as a reason to truncate a
                     // suffix that may be committed; the oracle shares the rule)
-                    if (slot >= L.start && slot < L.rlo) continue;
+                    if (slot >= L.start && slot < L.rlo) { ctr_add(v.counters, 6, 1); continue; }   // (counted: smr_raft_ring_guard_hits)
                     if (!L.term_at(slot, t) || t != entry_term[(size_t)s * v.G + g]) {
                         L.len = slot;                                           // :136 truncate
                         v.n_trunc[g] += 1;
@@ -1183,6 +1183,15 @@ int smr_raft_craft_poll_reconstructs(smr_raft_leader *l, uint32_t max_slots, uin
     hipLaunchKernelGGL(craft_poll_reconstructs_kernel, dim3((l->v.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, l->v, l->cv, max_slots,
                        n_dev, slot_dev, term_dev);
     SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_ring_guard_hits(smr_raft_leader *l, uint64_t *out) {
+    if (!l || !out) return fail(SMR_ERR_ARG, "raft: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[8];
+    SMR_HIP_TRY(ctr_read(l->v.counters, 8, c));
+    *out = c[6];
     return SMR_OK;
 }
 

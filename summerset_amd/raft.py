@@ -150,6 +150,13 @@ class RaftLeaderGroup:
                                                            stream_ptr(stream)))
         return r
 
+    def ring_guard_hits(self):
+        """entries of AppendEntries messages the follower path skipped because they had left the W-entry term ring
+        (`smr_raft_ring_guard_hits`: a harness rule, not the reference's; size `window` so that it stays 0)"""
+        n = C.c_uint64()
+        check(self._L.smr_raft_ring_guard_hits(self._h, C.byref(n)))
+        return int(n.value)
+
     def dump_votes(self):
         G = self.G
         r = dict(voted_for=np.zeros(G, np.uint8), votes=np.zeros(G, np.uint8), n_exec=np.zeros(G, np.uint32),

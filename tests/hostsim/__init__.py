@@ -46,6 +46,18 @@ def build(defines=()):
 
 def _build(extra):
     os.makedirs(_OUT, exist_ok=True)
+    # one builder at a time: pytest-xdist workers all reach here when a source is newer than the library, and a worker that
+    # linked while another was still compiling an object has handed out a half-written file before (FileNotFoundError, round 4)
+    import fcntl
+    with open(os.path.join(_OUT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(extra)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(extra):
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     rt = os.path.join(_HERE, "hipsim_rt.cpp")
     comm = os.path.join(_HERE, "comm_sim.cpp")                  # smr_comm_* for a world of one rank (the shipped one is RCCL: csrc/comm.hip)

@@ -197,6 +197,13 @@ def test_follower_and_elections_match_oracle(cuda, oracle, G, W):
     assert (roles == 0).any() and (roles == 1).any() and (roles == 2).any()      # every role was reached
     v = orc.dump_votes()
     assert v["n_trunc"].sum() > 0 and v["n_exec"].sum() > 0
+    # engine and oracle share ONE deviation from raft/messages.rs:128-140 -- an entry that has left the W-entry term
+    # ring is taken as matching -- so the comparison above says nothing about such entries.  Both sides count them: the
+    # counts agree, and at W = 64 (the window is as long as this scenario's logs get) no decision of this run rests on the rule
+    hits = eng.ring_guard_hits()
+    assert hits == orc.ring_guard_hits(), (hits, orc.ring_guard_hits())
+    if W >= 64:
+        assert hits == 0, "the follower parity run reached the ring guard %d times" % hits
 
 
 def test_closed_loop_cluster_matches_oracle(cuda, oracle):
