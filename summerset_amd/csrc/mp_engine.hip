@@ -1113,6 +1113,10 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
 #else
 #define MP_R3_BOUNDS __launch_bounds__(256)
 #endif
+// (Round 4 measured the bulk launch as ONE row of blocks that walk the replica rows themselves -- G / 256 blocks instead of R times
+// as many to read the tiles' flag bytes and leave: no difference, 31.8 against 32.0 us for the tally + this launch
+// (profiles/r5o_r3rest_one_row_negative.log).  The ~5 us this launch costs a steady tick are a launch's fixed cost, not its
+// 5120 wavefronts coming and going.)
 __global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, int par,
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb, int side) {
