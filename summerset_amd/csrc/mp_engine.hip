@@ -1136,6 +1136,38 @@ __global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, i
     r3_body(P, par, ackctl, publish_hb, g, active, pick_replica(P, side, g));
 }
 
+// Inside a batch of ticks (smr_mp_run_ticks with the list on) the rest of tick t's R3 rides in the launch of tick t + 1's R1
+// (round 4): mp_round_replies has nothing to do in the steady state and still cost the tick a launch (~5 us: a launch's
+// fixed cost, profiles/r5o), and what it does do -- lanes the tally's closed form left -- needs nothing of tick t + 1 and
+// nothing of it is needed before R2 of tick t + 1: it reads its own replica's state, the ack matrix and the PrepareReplies
+// R2 of tick t wrote, and appends to its own outbox of the NEXT parity, which is the outbox R1 of tick t + 1 appends to
+// right behind it in the same lane.  Not on a heartbeat tick (R4 reads the records R3 publishes) and not for a batch's last
+// tick.  Same results: the handlers of a (group, replica) still run in the same order.
+__global__ __launch_bounds__(256) void mp_rest_then_local(const MpParams *__restrict__ Pp, int par_prev,
+                                                          const uint32_t *__restrict__ ackctl_prev, int par,
+                                                          const uint8_t *__restrict__ timeout_rep, const uint8_t *__restrict__ timeout_src,
+                                                          const uint8_t *__restrict__ req_target, const uint32_t *__restrict__ req_cnt,
+                                                          const uint32_t *__restrict__ req_val, uint32_t S) {
+    const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    const uint32_t d = pick_replica(P, 0, g);
+    {
+        const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+        if (P.rot_on)
+            for (uint32_t y = 0; y < P.R; y++)
+                for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)y * ntile + t0 + k] : 0u;
+        if (any) {                                                // (block-uniform)
+            r3_body(P, par_prev, ackctl_prev, 0, g, active, d);
+            __syncthreads();                                      // (a cooperative job's stores -- a group frozen by lane 0 -- before R1 looks)
+        }
+    }
+    r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, active && !P.overflow[g < P.G ? g : 0], d);
+}
+
 // R4: all-to-all heartbeats (mod.rs:695, leadership.rs:217-265), then the ring
 // trim (snapshot.rs:121-186, in-memory part) to min(my exec_bar, peers' exec_bar
 // as carried by this round's heartbeats).
@@ -1669,6 +1701,11 @@ struct smr_mp_cluster {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
+    uint32_t quiet_ticks = 0;        // smr_mp_run_ticks: ticks in a row without a HearTimeout array (the side launch has nothing listed)
+    bool defer_rest = false;         // smr_mp_run_ticks: the next smr_mp_round_replies launches the tally only ...
+    bool rest_pending = false;       // ... and the rest of that R3 rides in the next R1 launch (mp_rest_then_local)
+    int rest_par = 0;
+    const uint32_t *rest_ackctl = nullptr;
     uint32_t lead_hint = 0;          // the replica most groups are led by (smr_mp_preset_leader): the tally's speculative loads
     bool profile = false;
     std::vector<ProfEv> evs;
@@ -1908,7 +1945,14 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     if (req_target_dev && (!req_cnt_dev || !req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
     hipStream_t st = (hipStream_t)stream;
     int rc = ensure_marked(c, timeout_rep_dev, st); if (rc) return rc;
-    if (!timeout_rep_dev && !req_target_dev) return SMR_OK;
+    if (!timeout_rep_dev && !req_target_dev) {
+        if (c->rest_pending) {                                   // no R1 launch to ride in: the previous tick's R3 rest on its own
+            c->rest_pending = false;
+            hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->rest_par, c->rest_ackctl, 0, 0);
+            SMR_HIP_TRY(hipGetLastError());
+        }
+        return SMR_OK;
+    }
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
     if (c->side_on && !c->side_fused) {
@@ -1918,8 +1962,13 @@ int smr_mp_round_local(smr_mp_cluster *c, const uint8_t *timeout_rep_dev, const 
     }
     int pi;
     if ((rc = prof_begin(c, 0, st, pi))) return rc;
-    hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, timeout_rep_dev,
-                       timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 0);
+    if (c->rest_pending) {                                       // the previous tick's R3 rest, then this tick's R1: one launch
+        c->rest_pending = false;
+        hipLaunchKernelGGL(mp_rest_then_local, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->rest_par, c->rest_ackctl, c->par,
+                           timeout_rep_dev, timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S);
+    } else
+        hipLaunchKernelGGL(mp_round_local, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, timeout_rep_dev,
+                           timeout_src_dev, req_target_dev, req_cnt_dev, req_val_dev, S, 0);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
@@ -1966,9 +2015,13 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
                            c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pt, st))) return rc;
-    hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, ackctl_dev,
-                       publish_heartbeat, 0);
-    SMR_HIP_TRY(hipGetLastError());
+    if (c->defer_rest && !publish_heartbeat) {                   // (smr_mp_run_ticks: the rest rides in the next tick's R1 launch)
+        c->rest_pending = true; c->rest_par = c->par; c->rest_ackctl = ackctl_dev;
+    } else {
+        hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, ackctl_dev,
+                           publish_heartbeat, 0);
+        SMR_HIP_TRY(hipGetLastError());
+    }
     if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
 }
@@ -2060,6 +2113,10 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             c->par ^= (int)(b.n & 1u);
             continue;
         }
+        bool any_to = false;
+        for (uint32_t k = 0; k < b.n; k++) any_to = any_to || ticks[i0 + k].timeout_rep_dev != nullptr;
+        c->quiet_ticks = any_to ? 0u : c->quiet_ticks + b.n;
+        const bool quiet = c->quiet_ticks >= 2u * MP_FUSED_MAXT + c->ttl;   // every ttl has run out batches ago: the list is empty
         // Straggler list on: the list of the whole batch, its groups' ticks back to back in ONE launch on the side stream,
         // the bulk kernels tick by tick on the caller's stream; the streams meet at the end of the batch.
         hipLaunchKernelGGL(mp_mark_batch, dim3((c->cfg.n_groups + 255) / 256), dim3(256), 0, st, c->dp, c->lpar, b, c->ttl);
@@ -2074,9 +2131,19 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             const smr_mp_tick_in &x = ticks[i0 + k];
             rc = smr_mp_round_local(c, x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.S, stream);
             if (!rc) rc = smr_mp_round_deliver(c, stream);
+            // (not on a heartbeat tick: smr_mp_round_replies looks.  And only while nothing is on the straggler list: the fused
+            // launch needs 171 VGPRs where R1 alone needs 158 -- two wavefronts per SIMD instead of three -- and beside the side
+            // stream's blocks that costs R1 more than the launch saves: driver's command 0.0972 -> 0.0987 ms per tick, steady
+            // 0.0568 -> 0.0542, profiles/r5p_rest_in_next_r1_ab.log)
+            c->defer_rest = k + 1 < b.n && quiet;
             if (!rc) rc = smr_mp_round_replies(c, x.ackctl_dev, x.do_heartbeat ? 1 : 0, stream);
+            c->defer_rest = false;
             if (!rc && x.do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
             c->par ^= 1;
+        }
+        if (c->rest_pending) {                                   // (a round failed behind a deferral: nothing may stay pending)
+            c->rest_pending = false;
+            hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->rest_par, c->rest_ackctl, 0, 0);
         }
         c->marked = c->side_on = c->forked = c->side_fused = false;
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);

@@ -131,6 +131,7 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=70, R=8, S=1, W=32, n_ticks=30, drop_p=0.2, timeout_frac=1.0, hb_every=2, preset=True, fused=16, straggler_ticks=8)
         t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=4, every=4, fused=4)
         t.test_batches_and_single_ticks_share_the_list("cpu", oracle)
+        t.run_rest_rides_in_next_r1("cpu", oracle, G=130, S=3, W=64, n_ticks=64, drop_p=0.3)   # mp_rest_then_local (round 4)
         # populations the device tests do not run (the 8-replica template instances of the tally and the reply kernels)
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
         t._run("cpu", oracle, G=100, R=4, S=3, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=3, preset=True)

@@ -341,3 +341,40 @@ def test_role_rotation_is_bit_exact(cuda, oracle):
     from summerset_amd import MultiPaxosCluster, SummersetError
     with pytest.raises(SummersetError):                                           # it rides on the straggler mark pass
         MultiPaxosCluster(64, 5, 64, outbox_cap=68).set_role_rotation(True)
+
+
+def run_rest_rides_in_next_r1(cuda, oracle, G, S, W, n_ticks, drop_p):
+    """`smr_mp_run_ticks` with the list on and NO timer for more than 2 x 16 + ttl ticks: the rest of a tick's R3 then rides in
+    the next tick's R1 launch (`mp_rest_then_local`, round 4).  Uncapped i.i.d. reply loss, so that the tally's closed form
+    fails for many lanes and that rest has real work -- rows short of their quorum, commit-bar runs that stop inside the
+    batch of rows -- in every tick; leader changes in the first ticks leave groups led by other replicas.  Full state against
+    the oracle at every batch end."""
+    from summerset_amd import MultiPaxosCluster, stream
+    R, H, cap = 5, 4, W + 4
+    eng = MultiPaxosCluster(G, R, W, win_reserve=W // 8, outbox_cap=cap, straggler_ticks=4)
+    orc = oracle.MpOracle(G, R, W, win_reserve=W // 8, cap=cap, record_commits=False)
+    eng.preset_leader(0); orc.preset_leader(0)
+    st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=drop_p, timeout_frac=0.3, hb_every=H, timeout_span=5)
+    batch, deferred_possible = [], 0
+    for t in range(n_ticks):
+        inp = st.tick(t)
+        orc.tick(**inp)
+        fired = bool((inp["timeout_rep"] != 0xFF).any())
+        assert fired == (t < 5) or not fired
+        if not fired:                                              # a host knows when no timer fired: no array at all
+            inp["timeout_rep"] = inp["timeout_src"] = None
+        batch.append(_to_dev(inp, cuda))
+        if len(batch) == 8 or t == n_ticks - 1:
+            eng.run_ticks(batch)
+            batch = []
+            _compare(eng, orc, R, t)
+            deferred_possible += t >= 5 + 2 * 16 + 4
+    assert deferred_possible >= 3                                  # batches that ran the fused launch
+    for r in range(R):
+        assert eng.counters(r)["commits"] == orc.total_commits(r)
+    assert (orc.dump(1)["leader"] != 0).any()
+
+
+def test_batched_ticks_rest_rides_in_next_r1(cuda, oracle):
+    run_rest_rides_in_next_r1(cuda, oracle, G=600, S=3, W=64, n_ticks=72, drop_p=0.3)
+    run_rest_rides_in_next_r1(cuda, oracle, G=256, S=8, W=128, n_ticks=64, drop_p=0.15)
