@@ -42,6 +42,15 @@ enum { EST_NULL = 0, EST_PREACCEPTING = 1, EST_ACCEPTING = 2, EST_COMMITTED = 3,
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// Element `idx` of a device array through a 32-bit BYTE offset (round 4): the engine's arrays are indexed by (row, column,
+// group) products that fit 32 bits -- smr_ep_replica_create refuses a geometry whose largest array passes 4 GB -- and an
+// address that is "uniform base + 32-bit lane offset" is one global_load with an SGPR base, where the size_t index products
+// of rounds 1-3 were 64-bit multiply-adds and add-with-carry chains in front of every access.  The one-launch tick is bound by
+// VALU issue (a wave64 VALU instruction occupies its SIMD for four cycles, ~2.5 wavefronts share a SIMD): address arithmetic
+// was a fifth of its instructions.
+template <typename T>
+__device__ __forceinline__ T &EA(T *base, uint32_t idx) { return *(T *)((char *)base + (uint32_t)(idx * (uint32_t)sizeof(T))); }
+
 // An instance is ONE RECORD of 16-byte words, each word a plane [R][W][G] (group fastest, so a wavefront's access to a word is
 // one contiguous 1 KB request):
 //   p0 = { bal lo, bal hi, seq lo, seq hi }
@@ -125,31 +134,31 @@ struct EpLaneT {
     __device__ __forceinline__ SMR_L uint32_t &cw(int arr, uint32_t row) const { return lc[((uint32_t)arr * NR + row) * 64u]; }
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = v.len[(size_t)r * v.G + g]; cw(1, r) = v.commit_bars[(size_t)r * v.G + g]; }
-        c_nulls = v.my_nulls[g];
+        for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = EA(v.len, r * v.G + g); cw(1, r) = EA(v.commit_bars, r * v.G + g); }
+        c_nulls = EA(v.my_nulls, g);
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { v.len[(size_t)r * v.G + g] = cw(0, r); v.commit_bars[(size_t)r * v.G + g] = cw(1, r); }
-        v.my_nulls[g] = c_nulls;
+        for (uint32_t r = 0; r < v.R; r++) { EA(v.len, r * v.G + g) = cw(0, r); EA(v.commit_bars, r * v.G + g) = cw(1, r); }
+        EA(v.my_nulls, g) = c_nulls;
     }
-    __device__ __forceinline__ uint32_t get_len(uint32_t row) const { return CACHE ? cw(0, row) : v.len[(size_t)row * v.G + g]; }
-    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) { if (CACHE) cw(0, row) = x; else v.len[(size_t)row * v.G + g] = x; }
-    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const { return CACHE ? cw(1, row) : v.commit_bars[(size_t)row * v.G + g]; }
-    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) { if (CACHE) cw(1, row) = x; else v.commit_bars[(size_t)row * v.G + g] = x; }
-    __device__ __forceinline__ uint32_t get_nulls() const { return CACHE ? c_nulls : v.my_nulls[g]; }
-    __device__ __forceinline__ void add_nulls(uint32_t d) { if (CACHE) c_nulls += d; else v.my_nulls[g] += d; }
+    __device__ __forceinline__ uint32_t get_len(uint32_t row) const { return CACHE ? cw(0, row) : EA(v.len, row * v.G + g); }
+    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) { if (CACHE) cw(0, row) = x; else EA(v.len, row * v.G + g) = x; }
+    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const { return CACHE ? cw(1, row) : EA(v.commit_bars, row * v.G + g); }
+    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) { if (CACHE) cw(1, row) = x; else EA(v.commit_bars, row * v.G + g) = x; }
+    __device__ __forceinline__ uint32_t get_nulls() const { return CACHE ? c_nulls : EA(v.my_nulls, g); }
+    __device__ __forceinline__ void add_nulls(uint32_t d) { if (CACHE) c_nulls += d; else EA(v.my_nulls, g) += d; }
     // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
-    __device__ __forceinline__ size_t pw(uint32_t row, uint32_t col) const { return (size_t)(v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
-    __device__ __forceinline__ size_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
-    __device__ __forceinline__ size_t pd_ix(uint32_t row, uint32_t col, uint32_t peer, uint32_t k) const {
+    __device__ __forceinline__ uint32_t pw(uint32_t row, uint32_t col) const { return (v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
+    __device__ __forceinline__ uint32_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
+    __device__ __forceinline__ uint32_t pd_ix(uint32_t row, uint32_t col, uint32_t peer, uint32_t k) const {
         return ((pw(row, col) * v.R + peer) * v.R + k) * v.G + g;
     }
-    __device__ __forceinline__ size_t xv_ix(uint32_t row, uint32_t col, uint32_t peer) const {
-        return (((size_t)row * v.W + (col & v.Wmask)) * v.R + peer) * v.G + g;
+    __device__ __forceinline__ uint32_t xv_ix(uint32_t row, uint32_t col, uint32_t peer) const {
+        return ((row * v.W + (col & v.Wmask)) * v.R + peer) * v.G + g;
     }
     // ---- the instance record (see EpView) ----
-    __device__ __forceinline__ size_t ix(uint32_t row, uint32_t col) const { return ((size_t)row * v.W + (col & v.Wmask)) * v.G + g; }
+    __device__ __forceinline__ uint32_t ix(uint32_t row, uint32_t col) const { return (row * v.W + (col & v.Wmask)) * v.G + g; }
     __device__ __forceinline__ static void unpack_p2(u32x4 w, EpInst<NR> &I) {
         if (NR > 4) I.d[4 < NR ? 4 : 0] = w.x;
         I.m0 = w.y; I.m1 = w.z;
@@ -158,9 +167,9 @@ struct EpLaneT {
     __device__ __forceinline__ static u32x4 pack_p2(const EpInst<NR> &I) {
         return (u32x4){NR > 4 ? I.d[4 < NR ? 4 : 0] : EP_NONE, I.m0, I.m1, NR > 5 ? I.d[5 < NR ? 5 : 0] : EP_NONE};
     }
-    __device__ __forceinline__ EpInst<NR> load_inst(size_t i) const {        // every word of the record in one round of loads
+    __device__ __forceinline__ EpInst<NR> load_inst(uint32_t i) const {        // every word of the record in one round of loads
         EpInst<NR> I;
-        const u32x4 a = v.p0[i], b = v.p1[i], c = v.p2[i];
+        const u32x4 a = EA(v.p0, i), b = EA(v.p1, i), c = EA(v.p2, i);
         I.bal = (uint64_t)a.x | ((uint64_t)a.y << 32); I.seq = (uint64_t)a.z | ((uint64_t)a.w << 32);
 #pragma unroll
         for (int k = 0; k < NR; k++) I.d[k] = EP_NONE;
@@ -169,28 +178,28 @@ struct EpLaneT {
         if (NR > 2) I.d[2 < NR ? 2 : 0] = b.z;
         if (NR > 3) I.d[3 < NR ? 3 : 0] = b.w;
         unpack_p2(c, I);
-        if (NR > 6 && v.R > 6) { const u32x4 e = v.p3[i]; I.d[6 < NR ? 6 : 0] = e.x; I.d[7 < NR ? 7 : 0] = e.y; }
+        if (NR > 6 && v.R > 6) { const u32x4 e = EA(v.p3, i); I.d[6 < NR ? 6 : 0] = e.x; I.d[7 < NR ? 7 : 0] = e.y; }
         return I;
     }
-    __device__ __forceinline__ void store_p0(size_t i, const EpInst<NR> &I) const {
-        v.p0[i] = (u32x4){(uint32_t)I.bal, (uint32_t)(I.bal >> 32), (uint32_t)I.seq, (uint32_t)(I.seq >> 32)};
+    __device__ __forceinline__ void store_p0(uint32_t i, const EpInst<NR> &I) const {
+        EA(v.p0, i) = (u32x4){(uint32_t)I.bal, (uint32_t)(I.bal >> 32), (uint32_t)I.seq, (uint32_t)(I.seq >> 32)};
     }
-    __device__ __forceinline__ void store_deps(size_t i, const EpInst<NR> &I) const {   // p1, p2 (with the meta words) and p3
-        v.p1[i] = (u32x4){I.d[0], NR > 1 ? I.d[1 < NR ? 1 : 0] : EP_NONE, NR > 2 ? I.d[2 < NR ? 2 : 0] : EP_NONE, NR > 3 ? I.d[3 < NR ? 3 : 0] : EP_NONE};
-        v.p2[i] = pack_p2(I);
-        if (NR > 6 && v.R > 6) v.p3[i] = (u32x4){I.d[6 < NR ? 6 : 0], I.d[7 < NR ? 7 : 0], 0u, 0u};
+    __device__ __forceinline__ void store_deps(uint32_t i, const EpInst<NR> &I) const {   // p1, p2 (with the meta words) and p3
+        EA(v.p1, i) = (u32x4){I.d[0], NR > 1 ? I.d[1 < NR ? 1 : 0] : EP_NONE, NR > 2 ? I.d[2 < NR ? 2 : 0] : EP_NONE, NR > 3 ? I.d[3 < NR ? 3 : 0] : EP_NONE};
+        EA(v.p2, i) = pack_p2(I);
+        if (NR > 6 && v.R > 6) EA(v.p3, i) = (u32x4){I.d[6 < NR ? 6 : 0], I.d[7 < NR ? 7 : 0], 0u, 0u};
     }
-    __device__ __forceinline__ void store_inst(size_t i, const EpInst<NR> &I) const { store_p0(i, I); store_deps(i, I); }
+    __device__ __forceinline__ void store_inst(uint32_t i, const EpInst<NR> &I) const { store_p0(i, I); store_deps(i, I); }
     // the words that hold Status / key / bookkeeping / ack masks (and deps[4], deps[5]): a read-modify-write of ONE word of the record
-    __device__ __forceinline__ void load_meta(size_t i, EpInst<NR> &I) const { unpack_p2(v.p2[i], I); }
-    __device__ __forceinline__ void store_meta(size_t i, const EpInst<NR> &I) const { v.p2[i] = pack_p2(I); }
-    __device__ __forceinline__ uint32_t status_at(size_t i) const { return v.p2[i].y & 0xFFu; }
-    __device__ __forceinline__ uint64_t seq_at(size_t i) const { const u32x4 a = v.p0[i]; return (uint64_t)a.z | ((uint64_t)a.w << 32); }
-    __device__ __forceinline__ uint64_t bal_at(size_t i) const { const u32x4 a = v.p0[i]; return (uint64_t)a.x | ((uint64_t)a.y << 32); }
-    __device__ __forceinline__ void fresh_leader_bk(size_t i, EpInst<NR> &I) const {   // request.rs:48-57, heartbeat.rs:88-97
+    __device__ __forceinline__ void load_meta(uint32_t i, EpInst<NR> &I) const { unpack_p2(EA(v.p2, i), I); }
+    __device__ __forceinline__ void store_meta(uint32_t i, const EpInst<NR> &I) const { EA(v.p2, i) = pack_p2(I); }
+    __device__ __forceinline__ uint32_t status_at(uint32_t i) const { return EA(v.p2, i).y & 0xFFu; }
+    __device__ __forceinline__ uint64_t seq_at(uint32_t i) const { const u32x4 a = EA(v.p0, i); return (uint64_t)a.z | ((uint64_t)a.w << 32); }
+    __device__ __forceinline__ uint64_t bal_at(uint32_t i) const { const u32x4 a = EA(v.p0, i); return (uint64_t)a.x | ((uint64_t)a.y << 32); }
+    __device__ __forceinline__ void fresh_leader_bk(uint32_t i, EpInst<NR> &I) const {   // request.rs:48-57, heartbeat.rs:88-97
         I.set_bk(I.bk() | 1u);
         I.set_pa_acks(0); I.set_acc_acks(0);
-        if (v.recovery) { I.set_xp_acks(0); I.set_xp_has(0); v.xp_max[i] = 0; }
+        if (v.recovery) { I.set_xp_acks(0); I.set_xp_has(0); EA(v.xp_max, i) = 0; }
     }
     // is the column still in the row's ring of W instances (the harness guard)
     __device__ __forceinline__ bool held(uint32_t row, uint32_t col) const {
@@ -210,7 +219,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? v.hc[((size_t)g * v.n_keys + key) * v.R + i] : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.R + i) : EP_NONE;
     }
     __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
@@ -224,9 +233,9 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
         if (key == EP_NO_KEY) return;
-        const size_t o = ((size_t)g * v.n_keys + key) * v.R + row;
-        const uint32_t hc = v.hc[o];
-        if (hc == EP_NONE || col > hc) v.hc[o] = col;
+        const uint32_t o = (g * v.n_keys + key) * v.R + row;
+        const uint32_t hc = EA(v.hc, o);
+        if (hc == EP_NONE || col > hc) EA(v.hc, o) = col;
     }
     // `known` (optional): the meta words of the cell (row, col) as the caller just stored them -- the walk starts at that very
     // cell, and re-reading what was written an instant ago is a round trip to memory on the handler's critical path
@@ -234,7 +243,7 @@ struct EpLaneT {
         uint32_t cb = get_cb(row);
         if (col != cb) return;
         while (cb < get_len(row) && held(row, cb)) {
-            const size_t i = ix(row, cb);
+            const uint32_t i = ix(row, cb);
             EpInst<NR> I;
             if (known && cb == col) { I.m0 = known->m0; I.m1 = known->m1; I.d[NR > 4 ? 4 : 0] = known->d[NR > 4 ? 4 : 0]; if (NR > 5) I.d[NR > 5 ? 5 : 0] = known->d[NR > 5 ? 5 : 0]; }
             else load_meta(i, I);
@@ -247,7 +256,7 @@ struct EpLaneT {
     // messages.rs:348-436 on an instance I lead
     __device__ __forceinline__ void accept_reply(uint32_t peer, uint32_t row, uint32_t col, uint64_t ballot) {
         if (!held(row, col)) return;
-        const size_t i = ix(row, col);
+        const uint32_t i = ix(row, col);
         EpInst<NR> I;
         load_meta(i, I);
         if (I.status() != EST_ACCEPTING || !(I.bk() & 1) || bal_at(i) != ballot) return;   // :371-376
@@ -268,14 +277,14 @@ struct EpLaneT {
                                                      const uint32_t (&rd)[NR], uint32_t exploded) {
         const uint32_t R = v.R;
         if (!held(row, col)) return;                                             // :125-127
-        const size_t i = ix(row, col);
+        const uint32_t i = ix(row, col);
         EpInst<NR> I = load_inst(i);
         if (I.status() != EST_PREACCEPTING || (ballot > 0 && I.bal != ballot) || !(I.bk() & 1)) return;   // :129-134
         uint32_t acks = I.pa_acks();
         if ((acks >> peer) & 1u) return;                                         // :136-138
         if (ballot > 0) {                                                        // :141-144
-            v.pa_seq[ps_ix(row, col, peer)] = rseq;
-            for (uint32_t k = 0; k < R; k++) v.pa_deps[pd_ix(row, col, peer, k)] = rd[k];
+            EA(v.pa_seq, ps_ix(row, col, peer)) = rseq;
+            for (uint32_t k = 0; k < R; k++) EA(v.pa_deps, pd_ix(row, col, peer, k)) = rd[k];
             acks |= 1u << peer;
             I.set_pa_acks(acks);
             store_meta(i, I);
@@ -289,10 +298,10 @@ struct EpLaneT {
 #pragma unroll
         for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && ((acks >> p) & 1u);
-            ps[p] = on ? v.pa_seq[ps_ix(row, col, p)] : 0;
+            ps[p] = on ? EA(v.pa_seq, ps_ix(row, col, p)) : 0;
 #pragma unroll
             for (int k = 0; k < NR; k++)
-                pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[pd_ix(row, col, p, k)] : EP_NONE;
+                pd[p][k] = (on && (uint32_t)k < R) ? EA(v.pa_deps, pd_ix(row, col, p, k)) : EP_NONE;
         }
         // dependency.rs:333-367 get_enough_identical: size of the largest class of equal (seq, deps)
         uint32_t max_cnt = 0; int best = -1;
@@ -363,18 +372,18 @@ struct EpLaneT {
                                                      uint32_t vstatus, uint64_t vseq, const uint32_t (&vd)[NR], uint32_t vkey) {
         const uint32_t R = v.R;
         if (!held(row, col)) return 0;                                           // :599-601
-        const size_t i = ix(row, col);
+        const uint32_t i = ix(row, col);
         EpInst<NR> I = load_inst(i);
         if (nb <= I.bal || !(I.bk() & 1)) return 0;                              // :603-605
         uint32_t acks = I.xp_acks(), has = I.xp_has();
         if ((acks >> peer) & 1u) return 0;                                       // :607-609
-        uint64_t mx = v.xp_max[i];
-        if (vbal > mx) { has = 0; mx = vbal; v.xp_max[i] = mx; }                 // :612-615
+        uint64_t mx = EA(v.xp_max, i);
+        if (vbal > mx) { has = 0; mx = vbal; EA(v.xp_max, i) = mx; }                 // :612-615
         if (vbal >= mx) {                                                        // :616-621
             has |= 1u << peer;
-            const size_t q = xv_ix(row, col, peer);
-            v.xv_status[q] = (uint8_t)vstatus; v.xv_seq[q] = vseq; v.xv_key[q] = (uint8_t)vkey;
-            for (uint32_t k = 0; k < R; k++) v.xv_deps[(q / v.G * R + k) * v.G + g] = vd[k];
+            const uint32_t q = xv_ix(row, col, peer);
+            EA(v.xv_status, q) = (uint8_t)vstatus; EA(v.xv_seq, q) = vseq; EA(v.xv_key, q) = (uint8_t)vkey;
+            for (uint32_t k = 0; k < R; k++) EA(v.xv_deps, (q / v.G * R + k) * v.G + g) = vd[k];
         }
         acks |= 1u << peer;
         I.set_xp_acks(acks); I.set_xp_has(has);
@@ -385,10 +394,10 @@ struct EpLaneT {
 #pragma unroll
         for (int p = 0; p < NR; p++) {
             const bool on = (uint32_t)p < R && ((has >> p) & 1u);
-            const size_t q = xv_ix(row, col, on ? p : 0);
-            xs[p] = on ? v.xv_status[q] : 0xFFu; xq[p] = on ? v.xv_seq[q] : 0; xk[p] = on ? v.xv_key[q] : EP_NO_KEY;
+            const uint32_t q = xv_ix(row, col, on ? p : 0);
+            xs[p] = on ? EA(v.xv_status, q) : 0xFFu; xq[p] = on ? EA(v.xv_seq, q) : 0; xk[p] = on ? EA(v.xv_key, q) : EP_NO_KEY;
 #pragma unroll
-            for (int k = 0; k < NR; k++) xd[p][k] = (on && (uint32_t)k < R) ? v.xv_deps[(q / v.G * R + k) * v.G + g] : EP_NONE;
+            for (int k = 0; k < NR; k++) xd[p][k] = (on && (uint32_t)k < R) ? EA(v.xv_deps, (q / v.G * R + k) * v.G + g) : EP_NONE;
         }
         int has_commit = -1, has_accept = -1, has_pre = -1;                      // :264-273: the highest peer id of a status
 #pragma unroll
@@ -500,20 +509,20 @@ struct EpExecLaneT {
     // CACHE: exec_bars / prev_cb in arrays 2 and 3 of the lane's LDS cache block (see EpLaneT)
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { L.cw(2, r) = x.exec_bars[(size_t)r * v.G + g]; L.cw(3, r) = x.prev_cb[(size_t)r * v.G + g]; }
+        for (uint32_t r = 0; r < v.R; r++) { L.cw(2, r) = EA(x.exec_bars, r * v.G + g); L.cw(3, r) = EA(x.prev_cb, r * v.G + g); }
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { x.exec_bars[(size_t)r * v.G + g] = L.cw(2, r); x.prev_cb[(size_t)r * v.G + g] = L.cw(3, r); }
+        for (uint32_t r = 0; r < v.R; r++) { EA(x.exec_bars, r * v.G + g) = L.cw(2, r); EA(x.prev_cb, r * v.G + g) = L.cw(3, r); }
     }
-    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : x.exec_bars[(size_t)row * v.G + g]; }
-    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else x.exec_bars[(size_t)row * v.G + g] = y; }
+    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : EA(x.exec_bars, row * v.G + g); }
+    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else EA(x.exec_bars, row * v.G + g) = y; }
     // has the row's commit bar moved since the last look (then the copy follows it)
     __device__ __forceinline__ bool cb_moved(uint32_t row, uint32_t cb) {
         if (!CACHE) {
-            const size_t o = (size_t)row * v.G + g;
-            if (cb == x.prev_cb[o]) return false;
-            x.prev_cb[o] = cb;
+            const uint32_t o = row * v.G + g;
+            if (cb == EA(x.prev_cb, o)) return false;
+            EA(x.prev_cb, o) = cb;
             return true;
         }
         if (L.cw(3, row) == cb) return false;
@@ -526,7 +535,7 @@ struct EpExecLaneT {
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
-    __device__ __forceinline__ size_t at(uint32_t i) const { return (size_t)i * v.G + g; }
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i * v.G + g; }
     // the column a ring cell of this row holds (the one of its residue among the last W)
     __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
         const uint32_t end = L.get_len(row), lo = end > v.W ? end - v.W : 0u;
@@ -536,9 +545,9 @@ struct EpExecLaneT {
     }
     __device__ __forceinline__ uint32_t new_node(uint32_t ring, uint16_t flag) {
         const uint32_t id = n_nodes++;
-        x.nslot[at(id)] = (uint16_t)(ring | flag);
-        x.head[at(id)] = XNIL; x.sib[at(id)] = XNIL; x.parent[at(id)] = XNIL;
-        x.node_of[at(ring)] = (uint16_t)(id + 1);
+        EA(x.nslot, at(id)) = (uint16_t)(ring | flag);
+        EA(x.head, at(id)) = XNIL; EA(x.sib, at(id)) = XNIL; EA(x.parent, at(id)) = XNIL;
+        EA(x.node_of, at(ring)) = (uint16_t)(id + 1);
         return id;
     }
     // One pop of the walk (execution.rs:37-82) behind its commit-bar and ring checks, on a cell whose Status `st` and node_of
@@ -555,24 +564,24 @@ struct EpExecLaneT {
             uint32_t a = last_node;
             if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; p2 = last; v2 = a; }   // add_edge inserts the missing endpoint
             a -= 1;
-            x.sib[at(id)] = x.head[at(a)]; x.head[at(a)] = (uint16_t)id; x.parent[at(id)] = (uint16_t)a;
+            EA(x.sib, at(id)) = EA(x.head, at(a)); EA(x.head, at(a)) = (uint16_t)id; EA(x.parent, at(id)) = (uint16_t)a;
         }
         last = ring; last_node = id + 1;
     }
     // execution.rs:105-142 for one node's instance, sync_exec = false
     __device__ __forceinline__ void submit_ring(uint32_t ring) {
         const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
-        const size_t i = L.ix(row, col);
+        const uint32_t i = L.ix(row, col);
         EpInst<NR> I;
         L.load_meta(i, I);
         const uint32_t key = I.key();
         if (key != EP_NO_KEY) {
-            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = x.kv[(size_t)key * v.G + g];
-            x.kv[(size_t)key * v.G + g] = tok;
-            uint64_t d = x.digest[g];
+            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = EA(x.kv, key * v.G + g);
+            EA(x.kv, key * v.G + g) = tok;
+            uint64_t d = EA(x.digest, g);
             d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
-            x.digest[g] = d;
-            if (n_order < 2u * v.R * v.W) x.order[at(n_order++)] = (uint16_t)ring;   // (the list's capacity; beyond it a result would not come: never seen)
+            EA(x.digest, g) = d;
+            if (n_order < 2u * v.R * v.W) EA(x.order, at(n_order++)) = (uint16_t)ring;   // (the list's capacity; beyond it a result would not come: never seen)
             c_exec++;
         }
         I.set_status(EST_EXECUTING);
@@ -591,11 +600,11 @@ struct EpExecLaneT {
         else if (!L.held(trow, tcol)) { c_unheld++; last = XNIL; }               // harness: left the ring = executed
         else {
             ring0 = (trow << wshift) | (tcol & v.Wmask);
-            const uint32_t st = L.status_at(L.ix(trow, tcol)), no = x.node_of[at(ring0)];
+            const uint32_t st = L.status_at(L.ix(trow, tcol)), no = EA(x.node_of, at(ring0));
             visit(ring0, st, no, p1, v1, p2, v2);
         }
         for (uint32_t i = 0; !abandoned && i < n_nodes; i++) {
-            const uint32_t s = (i == 0) ? (ring0 | XNEW) : x.nslot[at(i)];      // (node 0 is the tail, new by construction)
+            const uint32_t s = (i == 0) ? (ring0 | XNEW) : EA(x.nslot, at(i));      // (node 0 is the tail, new by construction)
             if (!(s & XNEW)) continue;
             const uint32_t ring = s & 0x7FFFu, row = ring >> wshift, col = col_of(row, ring & v.Wmask);
             uint32_t cc[NR + 1], cr[NR + 1], cst[NR + 1], cno[NR + 1];           // per cell: column, ring cell (XUNUSED: no pop), Status, node_of
@@ -612,7 +621,7 @@ struct EpExecLaneT {
                 const uint32_t r_ = on ? erow : 0u, c_ = on ? cc[e] : 0u, rg = (r_ << wshift) | (c_ & v.Wmask);
                 cr[e] = on ? rg : XUNUSED;
                 cst[e] = L.status_at(L.ix(r_, c_));
-                cno[e] = x.node_of[at(rg)];
+                cno[e] = EA(x.node_of, at(rg));
             }
 #pragma unroll
             for (int e = 0; e <= NR; e++) {
@@ -630,30 +639,30 @@ struct EpExecLaneT {
         }
         if (abandoned) {
             c_aborts++;
-            for (uint32_t i = 0; i < n_nodes; i++) x.node_of[at(x.nslot[at(i)] & 0x7FFFu)] = 0;
+            for (uint32_t i = 0; i < n_nodes; i++) EA(x.node_of, at(EA(x.nslot, at(i)) & 0x7FFFu)) = 0;
             return false;
         }
         if (n_nodes == 1) {                                                      // the tail alone (no edge was made): no links to walk
-            x.node_of[at(ring0)] = 0;
+            EA(x.node_of, at(ring0)) = 0;
             submit_ring(ring0);
             return true;
         }
         // post-order over the forest; entering a node clears its node_of cell (= visited, and the cleanup)
         for (uint32_t root = 0; root < n_nodes; root++) {
-            const uint32_t rr = x.nslot[at(root)] & 0x7FFFu;
-            if (x.node_of[at(rr)] == 0) continue;
-            x.node_of[at(rr)] = 0;
+            const uint32_t rr = EA(x.nslot, at(root)) & 0x7FFFu;
+            if (EA(x.node_of, at(rr)) == 0) continue;
+            EA(x.node_of, at(rr)) = 0;
             uint32_t u = root;
             for (;;) {
-                const uint32_t c = x.head[at(u)];
+                const uint32_t c = EA(x.head, at(u));
                 if (c != XNIL) {
-                    x.head[at(u)] = x.sib[at(c)];
-                    const uint32_t cr_ = x.nslot[at(c)] & 0x7FFFu;
-                    if (x.node_of[at(cr_)] != 0) { x.node_of[at(cr_)] = 0; u = c; }
+                    EA(x.head, at(u)) = EA(x.sib, at(c));
+                    const uint32_t cr_ = EA(x.nslot, at(c)) & 0x7FFFu;
+                    if (EA(x.node_of, at(cr_)) != 0) { EA(x.node_of, at(cr_)) = 0; u = c; }
                 } else {
-                    submit_ring(x.nslot[at(u)] & 0x7FFFu);
+                    submit_ring(EA(x.nslot, at(u)) & 0x7FFFu);
                     if (u == root) break;
-                    u = x.parent[at(u)];
+                    u = EA(x.parent, at(u));
                 }
             }
         }
@@ -663,7 +672,7 @@ struct EpExecLaneT {
     __device__ __forceinline__ void cmd_result(uint32_t ring) {
         const uint32_t row = ring >> wshift, col = col_of(row, ring & v.Wmask);
         {
-            const size_t i = L.ix(row, col);
+            const uint32_t i = L.ix(row, col);
             EpInst<NR> I;
             L.load_meta(i, I);
             I.set_status(EST_EXECUTED);
@@ -694,7 +703,7 @@ struct EpExecLaneT {
             for (uint32_t q = 0; q < v.R; q++)
                 if ((re >> q) & 1u) (void)attempt(q, L.get_cb(q) - 1);
         }
-        for (uint32_t i = first; i < n_order; i++) cmd_result(x.order[at(i)]);
+        for (uint32_t i = first; i < n_order; i++) cmd_result(EA(x.order, at(i)));
     }
     // `advanced` for the common case behind a handler that has the committed instance in registers: the row's commit bar went
     // from the instance's column to the next (tail = that instance, H = its record as stored, a real command), and every cell
@@ -725,8 +734,8 @@ struct EpExecLaneT {
             tst[q] = L.status_at(L.ix(qq, tok[q] ? c - 1 : 0u));
         }
         const uint32_t nst = L.status_at(L.ix(row, hcol + 1));
-        const uint64_t old = x.kv[(size_t)key * v.G + g];
-        uint64_t dg = x.digest[g];
+        const uint64_t old = EA(x.kv, key * v.G + g);
+        uint64_t dg = EA(x.digest, g);
         // the pops, in the reference's order, on those words
         bool abandoned = false;
         uint32_t unheld = 0;
@@ -741,16 +750,16 @@ struct EpExecLaneT {
         c_attempts++; c_unheld += unheld;
         if (abandoned) { c_aborts++; return true; }                              // (nothing was stored, nothing to clean up)
         // the graph is the tail alone: submit it (execution.rs:105-142)
-        const size_t i = L.ix(row, hcol);
+        const uint32_t i = L.ix(row, hcol);
         const uint32_t ring = (row << wshift) | (hcol & v.Wmask);
         EpInst<NR> I = H;
         const uint32_t first = n_order;
         {
             const uint64_t tok_ = ((uint64_t)(row + 1) << 32) | hcol;
-            x.kv[(size_t)key * v.G + g] = tok_;
+            EA(x.kv, key * v.G + g) = tok_;
             dg = (dg ^ tok_) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
-            x.digest[g] = dg;
-            if (n_order < 2u * v.R * v.W) x.order[at(n_order++)] = (uint16_t)ring;
+            EA(x.digest, g) = dg;
+            if (n_order < 2u * v.R * v.W) EA(x.order, at(n_order++)) = (uint16_t)ring;
             c_exec++;
         }
         uint32_t re = 0;                                                         // rows to re-attempt (my own tail is Executing now)
@@ -762,7 +771,7 @@ struct EpExecLaneT {
             L.store_meta(i, I);
             for (uint32_t q = 0; q < R; q++)
                 if ((re >> q) & 1u) (void)attempt(q, L.get_cb(q) - 1);
-            for (uint32_t k = first; k < n_order; k++) cmd_result(x.order[at(k)]);
+            for (uint32_t k = first; k < n_order; k++) cmd_result(EA(x.order, at(k)));
             return true;
         }
         if (n_order > first) {                                                   // my command's result (execution.rs:152-211)
@@ -817,7 +826,7 @@ __device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpE
         if (hint && row == hrow && E.advanced_hinted(row, cb, *hint, hcol)) continue;
         E.advanced(row, cb);
     }
-    x.n_sub[E.g] = E.n_order;                                                // 0 when no commit bar moved
+    EA(x.n_sub, E.g) = E.n_order;                                                // 0 when no commit bar moved
 }
 
 // request.rs:10-108 + my own PreAcceptSlot completion (durability.rs:25-35): key k (EP_NO_KEY: nothing to propose);
@@ -856,7 +865,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         for (int q = 0; q < NR; q++) if (ok[q] && sq[q] > seq) seq = sq[q];
         seq += 1;
     }
-    const size_t i = L.ix(row, col);
+    const uint32_t i = L.ix(row, col);
     const uint64_t bal = (uint64_t)(v.me + 1);                               // make_default_ballot
     I.bal = bal; I.seq = seq; I.set_key(k);
 #pragma unroll
@@ -865,7 +874,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         uint32_t hc_row = EP_NONE;
 #pragma unroll
         for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
-        if (hc_row == EP_NONE || col > hc_row) v.hc[((size_t)L.g * v.n_keys + k) * v.R + row] = col;
+        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.R + row) = col;
     }
     L.fresh_leader_bk(i, I);
     I.set_status(EST_PREACCEPTING);
@@ -875,12 +884,12 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
     // my own PreAcceptReply (durability.rs:25-35 -> messages.rs:96-270) on bookkeeping that is fresh: it is recorded and is the
     // only one held, and one reply is below any quorum (simple_q >= 2 at populations >= 3) -- handle_msg_pre_accept_reply
     // returns at dependency.rs:205 without looking at `ex`
-    v.pa_seq[L.ps_ix(row, col, v.me)] = seq;
+    EA(v.pa_seq, L.ps_ix(row, col, v.me)) = seq;
     for (uint32_t q = 0; q < v.R; q++) {
         uint32_t x = EP_NONE;
 #pragma unroll
         for (int qq = 0; qq < NR; qq++) if ((uint32_t)qq == q) x = d[qq];
-        v.pa_deps[L.pd_ix(row, col, v.me, q)] = x;
+        EA(v.pa_deps, L.pd_ix(row, col, v.me, q)) = x;
     }
     (void)ex;
 }
@@ -907,16 +916,16 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     //   round 2: the cell's ballot and meta words, the key's highest columns
     //   round 3 (PreAccept): the sequence numbers of the key's highest instances
     const uint32_t rw = row < v.R ? row : 0u;
-    const size_t i = L.ix(rw, c);
+    const uint32_t i = L.ix(rw, c);
     const bool need_meta = LBK || MODE == 2 || rw == v.me;                   // (LBK = false: Status / bookkeeping are read only where they can matter;
-    const u32x4 w0 = v.p0[i];                                                //  a CommitNotice leaves the bookkeeping as it is)
+    const u32x4 w0 = EA(v.p0, i);                                            //  a CommitNotice leaves the bookkeeping as it is)
     u32x4 w2 = (u32x4){EP_NONE, (uint32_t)EP_NO_KEY << 8, 0u, EP_NONE};
-    if (need_meta) w2 = v.p2[i];
+    if (need_meta) w2 = EA(v.p2, i);
     const uint32_t kk = k != EP_NO_KEY ? k : 0u;
     uint32_t my[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        my[q] = ((MODE == 0 || (uint32_t)q == rw) && (uint32_t)q < v.R) ? v.hc[((size_t)g * v.n_keys + kk) * v.R + q] : EP_NONE;
+        my[q] = ((MODE == 0 || (uint32_t)q == rw) && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.R + q) : EP_NONE;
     if (!on) return;
     if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
     // :33-36 pad the row up to the column; the cell of the column itself is written below if the message is taken (a fresh
@@ -965,7 +974,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     if (MODE != 2) I.set_bk((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
     L.store_inst(i, I);
     if (rec) { *rec = I; *stored = true; }
-    if (k != EP_NO_KEY && (hc_row == EP_NONE || c > hc_row)) v.hc[((size_t)g * v.n_keys + k) * v.R + row] = c;   // refresh_highest_cols, dependency.rs:141-167
+    if (k != EP_NO_KEY && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.R + row) = c;   // refresh_highest_cols, dependency.rs:141-167
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
     } else {
@@ -1132,7 +1141,7 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
     if (stored) *stored = false;
     const uint32_t R = v.R;
     const bool h = L.held(row, c);
-    const size_t i = L.ix(row, c);
+    const uint32_t i = L.ix(row, c);
     // the instance (its ballot and meta words; the ring cell exists whether or not the column is still held) and the replies
     // it already holds
     EpInst<NR> I;
@@ -1148,9 +1157,9 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
 #pragma unroll
     for (int p = 0; p < NR; p++) {
         const bool on = (acks >> p) & 1u;
-        ps[p] = on ? v.pa_seq[L.ps_ix(row, c, p)] : 0ull;
+        ps[p] = on ? EA(v.pa_seq, L.ps_ix(row, c, p)) : 0ull;
 #pragma unroll
-        for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? v.pa_deps[L.pd_ix(row, c, p, k)] : EP_NONE;
+        for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? EA(v.pa_deps, L.pd_ix(row, c, p, k)) : EP_NONE;
     }
     dseq = 0;
 #pragma unroll
@@ -1181,10 +1190,10 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
 #pragma unroll
     for (int p = 0; p < NR; p++)
         if ((fresh >> p) & 1u) {
-            v.pa_seq[L.ps_ix(row, c, p)] = ps[p];
+            EA(v.pa_seq, L.ps_ix(row, c, p)) = ps[p];
 #pragma unroll
             for (int k = 0; k < NR; k++)
-                if ((uint32_t)k < R) v.pa_deps[L.pd_ix(row, c, p, k)] = pd[p][k];
+                if ((uint32_t)k < R) EA(v.pa_deps, L.pd_ix(row, c, p, k)) = pd[p][k];
         }
     if (fresh) I.set_pa_acks(acks);
     dec = 0;
@@ -1318,7 +1327,7 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
                 const uint32_t end = L.get_len(row);
                 for (uint32_t c = L.get_cb(row); c < end; c++) {
                     if (!L.held(row, c)) continue;
-                    const size_t i = L.ix(row, c);
+                    const uint32_t i = L.ix(row, c);
                     EpInst<EMAXR> J;
                     L.load_meta(i, J);
                     if (J.status() == EST_PREACCEPTING && (J.bk() & 1)) {
@@ -1330,7 +1339,7 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             // :62-107 ExpPrepare for every in-progress instance of that peer's row (exec bars: 0 without execution)
             const uint32_t row = ts, end = L.get_len(row);
             for (uint32_t c = end > v.W ? end - v.W : 0u; c < end; c++) {
-                const size_t i = L.ix(row, c);
+                const uint32_t i = L.ix(row, c);
                 EpInst<EMAXR> J;
                 L.load_meta(i, J);
                 const uint32_t st = J.status(), bk = J.bk();
@@ -1345,7 +1354,7 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             // :110-123 my own ExpPrepareReplies
             for (uint32_t k = 0; k < n; k++) {
                 const uint32_t c = out_col[(size_t)k * v.G + g];
-                const size_t i = L.ix(row, c);
+                const uint32_t i = L.ix(row, c);
                 const EpInst<EMAXR> J = L.load_inst(i);
                 uint32_t d[EMAXR];
 #pragma unroll
@@ -1355,7 +1364,7 @@ __global__ __launch_bounds__(256) void ep_heartbeat_timeout_kernel(const EpView 
             }
         }
         out_n[g] = n;
-        if (EXEC) x.n_sub[g] = E.n_order;
+        if (EXEC) EA(x.n_sub, g) = E.n_order;
     }
     L.flush();
     if (EXEC) E.flush();
@@ -1379,7 +1388,7 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_kernel(const EpView v, con
         const uint32_t row = rows[g], c = col[g];
         if (row < v.R && !(c < L.get_len(row) && !L.held(row, c))) {
             while (L.get_len(row) <= c) L.push_null(row);                        // :530-533
-            const size_t i = L.ix(row, c);
+            const uint32_t i = L.ix(row, c);
             EpInst<EMAXR> J = L.load_inst(i);
             if (nbal[g] > J.bal) {                                               // :537
                 J.set_bk((J.bk() & 1u) | 2u | ((uint32_t)peer[g] << 2));         // replica_bk.source = peer
@@ -1820,6 +1829,14 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     if (cfg->recovery > 1) return fail(SMR_ERR_ARG, "epaxos: recovery must be 0 or 1");
     if (cfg->execute && (uint64_t)cfg->population * cfg->window > 32768)
         return fail(SMR_ERR_ARG, "epaxos: execution keeps 15-bit ring cell ids: population * window must be <= 32768");
+    {   // every array is addressed through 32-bit byte offsets (EA): the largest must stay under 4 GB
+        const uint64_t G = cfg->n_groups, W = cfg->window, R = cfg->population, K = cfg->n_keys, PR = cfg->recovery ? R : 1;
+        uint64_t most = R * W * G * 16;                                          // a record plane
+        most = std::max(most, PR * W * R * R * G * 4);                           // pa_deps / xv_deps
+        most = std::max(most, K * R * G * 8);                                    // hc, kv
+        if (most >= (1ull << 32))
+            return fail(SMR_ERR_ARG, "epaxos: n_groups * window too large: an array would pass 4 GB (32-bit offsets); shard the groups over more replicas objects");
+    }
     smr_ep_replica *e = new smr_ep_replica();
     e->cfg = *cfg;
     memset(&e->v, 0, sizeof(e->v));
