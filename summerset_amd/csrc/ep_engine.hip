@@ -68,6 +68,8 @@ struct EpView {
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
     uint32_t *len, *commit_bars;         // [R][G]
     uint32_t *my_nulls;                  // [G] null instances currently in my own row (first_null_slot need not scan at 0)
+    uint8_t *rewritten;                  // [G] sticky: a message once rewrote a cell below its row's commit bar (a duplicate, a late or an explicit-prepare
+                                         //     message): from then on "below the exec bar" no longer means Executed for this group (EpExecLaneT::attempt)
     uint32_t *hc;                        // [G][n_keys][R]
     unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits; explicit prepare outcomes:
                                          // Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op
@@ -122,13 +124,27 @@ struct EpInst {
 #else
 #define SMR_L
 #endif
+#ifdef EPC_STAMPS
+#define EPC_SUB(L, k) do { __builtin_amdgcn_s_waitcnt(0); if ((L).sub) (L).sub[k] = wall_clock64(); } while (0)   /* experiments only */
+#else
+#define EPC_SUB(L, k) do { } while (0)
+#endif
+
 template <int NR, bool CACHE = false>
 struct EpLaneT {
+#ifdef EPC_STAMPS
+    unsigned long long *sub = nullptr;   // experiments only: where this lane writes the sub-stamps of one handler (tools/dbg_epc_stamps.py)
+#endif
     const EpView &v;
     const uint32_t g;
     unsigned int n_fast = 0, n_slow = 0, n_acc = 0, n_xc = 0, n_xa = 0, n_xp = 0, n_xn = 0;
     SMR_L uint32_t *lc = nullptr;                                            // CACHE: this lane's column of the wavefront's cache block
     uint32_t c_nulls = 0;
+    bool rewritten = false;                                                  // CACHE: v.rewritten[g]
+    // a handler is about to rewrite the existing cell (row, col), possibly to a lower Status
+    __device__ __forceinline__ void note_rewrite(uint32_t col, uint32_t cb_of_row) {
+        if (col < cb_of_row) { rewritten = true; EA(v.rewritten, g) = 1; }
+    }
     __device__ __forceinline__ EpLaneT(const EpView &v_, uint32_t g_) : v(v_), g(g_) {}
     __device__ __forceinline__ void bind_cache(uint32_t *block_of_my_wavefront, uint32_t lane) { lc = (SMR_L uint32_t *)(block_of_my_wavefront + lane); }
     __device__ __forceinline__ SMR_L uint32_t &cw(int arr, uint32_t row) const { return lc[((uint32_t)arr * NR + row) * 64u]; }
@@ -136,6 +152,7 @@ struct EpLaneT {
         if (!CACHE) return;
         for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = EA(v.len, r * v.G + g); cw(1, r) = EA(v.commit_bars, r * v.G + g); }
         c_nulls = EA(v.my_nulls, g);
+        rewritten = EA(v.rewritten, g) != 0;
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
@@ -442,6 +459,7 @@ struct EpLaneT {
 #pragma unroll
                 for (int k = 0; k < NR; k++) dd[k] = xd[p][k];
             }
+        note_rewrite(col, get_cb(row));
         I.bal = nb; I.set_status((uint32_t)next); I.seq = dseq; I.set_key(dkey);
 #pragma unroll
         for (int k = 0; k < NR; k++) I.d[k] = (uint32_t)k < R ? dd[k] : EP_NONE;
@@ -517,6 +535,24 @@ struct EpExecLaneT {
     }
     __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : EA(x.exec_bars, row * v.G + g); }
     __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else EA(x.exec_bars, row * v.G + g) = y; }
+    // every row's exec bar in one round of loads (CACHE: they are in LDS and nothing is loaded here), and one of them
+    // (known_executed_below: 0 for every row of a group in which a cell below a commit bar was once rewritten --
+    // EpView::rewritten: there a cell below the exec bar may have been taken back to an earlier Status, and the walk must look)
+    __device__ __forceinline__ void load_ebs(uint32_t (&ebs)[NR]) {
+        if (!CACHE) L.rewritten = EA(v.rewritten, g) != 0;
+#pragma unroll
+        for (int q = 0; q < NR; q++) ebs[q] = (!CACHE && (uint32_t)q < v.R) ? EA(x.exec_bars, (uint32_t)q * v.G + g) : 0u;
+    }
+    __device__ __forceinline__ uint32_t known_executed_below(const uint32_t (&ebs)[NR], uint32_t row) const {
+        return L.rewritten ? 0u : eb_of(ebs, row);
+    }
+    __device__ __forceinline__ uint32_t eb_of(const uint32_t (&ebs)[NR], uint32_t row) const {
+        if (CACHE) return L.cw(2, row);
+        uint32_t y = 0;
+#pragma unroll
+        for (int q = 0; q < NR; q++) if ((uint32_t)q == row) y = ebs[q];
+        return y;
+    }
     // has the row's commit bar moved since the last look (then the copy follows it)
     __device__ __forceinline__ bool cb_moved(uint32_t row, uint32_t cb) {
         if (!CACHE) {
@@ -532,6 +568,7 @@ struct EpExecLaneT {
     const uint32_t g, wshift;
     uint32_t n_nodes = 0, n_order = 0, last = XNIL;          // last: ring cell of the slot popped before, XNIL = none / not held
     uint32_t last_node = 0;                                  // node_of[last] (node id + 1; 0: not a node), kept beside it
+    bool reins = false;                                      // this attempt made a node of an executed cell (add_edge's missing endpoint)
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
@@ -562,7 +599,7 @@ struct EpExecLaneT {
         p1 = ring; v1 = id + 1;
         if (last != XNIL) {
             uint32_t a = last_node;
-            if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; p2 = last; v2 = a; }   // add_edge inserts the missing endpoint
+            if (a == 0) { a = new_node(last, 0) + 1; c_reexec++; reins = true; p2 = last; v2 = a; }   // add_edge inserts the missing endpoint
             a -= 1;
             EA(x.sib, at(id)) = EA(x.head, at(a)); EA(x.head, at(a)) = (uint16_t)id; EA(x.parent, at(id)) = (uint16_t)a;
         }
@@ -593,9 +630,11 @@ struct EpExecLaneT {
     // one by one, in the reference's order, on those copies (patched where an earlier pop of the batch made a node).
     __device__ __forceinline__ bool attempt(uint32_t trow, uint32_t tcol) {
         c_attempts++;
-        n_nodes = 0; last = XNIL; last_node = 0;
+        n_nodes = 0; last = XNIL; last_node = 0; reins = false;
         bool abandoned = false;
         uint32_t p1, v1, p2, v2, ring0 = XNIL;
+        uint32_t ebs[NR];
+        load_ebs(ebs);                                                           // (no exec bar moves inside an attempt)
         if (tcol >= L.get_cb(trow)) abandoned = true;                            // :41-45
         else if (!L.held(trow, tcol)) { c_unheld++; last = XNIL; }               // harness: left the ring = executed
         else {
@@ -620,8 +659,17 @@ struct EpExecLaneT {
                 const bool on = cc[e] != EP_NONE;
                 const uint32_t r_ = on ? erow : 0u, c_ = on ? cc[e] : 0u, rg = (r_ << wshift) | (c_ & v.Wmask);
                 cr[e] = on ? rg : XUNUSED;
-                cst[e] = L.status_at(L.ix(r_, c_));
-                cno[e] = EA(x.node_of, at(rg));
+                // a cell below its row's exec bar is Executed, and no node unless this attempt made it one (node_of is zero
+                // outside an attempt; inside, an executed cell becomes a node only as add_edge's missing endpoint -- `reins`;
+                // one made in this very batch is patched in below): nothing to load -- and that is most dependencies and every
+                // row predecessor of a cluster that keeps up.  (These are gathers: a lane's cell is a cache line of its own.)
+                // (no branch around a load -- the join would wait for it: a lane that needs nothing loads cell (0, 0), which every
+                // such lane of the device shares, and drops the word)
+                const bool need = on && c_ >= known_executed_below(ebs, r_), need_no = need || (on && reins);
+                cst[e] = L.status_at(L.ix(need ? r_ : 0u, need ? c_ : 0u));
+                cno[e] = EA(x.node_of, at(need_no ? rg : 0u));
+                if (!need) cst[e] = EST_EXECUTED;
+                if (!need_no) cno[e] = 0u;
             }
 #pragma unroll
             for (int e = 0; e <= NR; e++) {
@@ -716,6 +764,8 @@ struct EpExecLaneT {
         const uint32_t key = H.key();
         if (hcol + 1 != cb || H.status() != EST_COMMITTED || key == EP_NO_KEY || !L.held(row, hcol)) return false;
         const uint32_t R = v.R;
+        uint32_t ebs[NR];
+        load_ebs(ebs);
         uint32_t cc[NR + 1], cst[NR + 1];
 #pragma unroll
         for (int k = 0; k < NR; k++) cc[k] = (uint32_t)k < R ? H.d[k] : EP_NONE;
@@ -723,19 +773,23 @@ struct EpExecLaneT {
 #pragma unroll
         for (int e = 0; e <= NR; e++) {
             const uint32_t erow = e < NR ? (uint32_t)e : row;
-            const bool on = cc[e] != EP_NONE;
-            cst[e] = L.status_at(L.ix(on ? erow : 0u, on ? cc[e] : 0u));
+            const bool need = cc[e] != EP_NONE && cc[e] >= known_executed_below(ebs, erow);         // below the exec bar: Executed (see attempt)
+            cst[e] = L.status_at(L.ix(need ? erow : 0u, need ? cc[e] : 0u));     // (no branch around a load: see attempt)
+            if (!need) cst[e] = EST_EXECUTED;
         }
         uint32_t tst[NR]; bool tok[NR];
 #pragma unroll
         for (int q = 0; q < NR; q++) {
             const uint32_t qq = (uint32_t)q < R ? (uint32_t)q : 0u, c = L.get_cb(qq);
-            tok[q] = (uint32_t)q < R && c > get_eb(qq) && L.held(qq, c - 1);
+            tok[q] = (uint32_t)q < R && c > eb_of(ebs, qq) && L.held(qq, c - 1);
             tst[q] = L.status_at(L.ix(qq, tok[q] ? c - 1 : 0u));
         }
-        const uint32_t nst = L.status_at(L.ix(row, hcol + 1));
+        // (the cell behind mine matters to the exec-bar scan only: when the bar is at my column and that cell exists)
+        const bool need_n = hcol == eb_of(ebs, row) && hcol + 1 < L.get_len(row) && L.held(row, hcol + 1);
+        const uint32_t nst = L.status_at(L.ix(row, need_n ? hcol + 1 : 0u));
         const uint64_t old = EA(x.kv, key * v.G + g);
         uint64_t dg = EA(x.digest, g);
+        EPC_SUB(L, 10);
         // the pops, in the reference's order, on those words
         bool abandoned = false;
         uint32_t unheld = 0;
@@ -823,8 +877,10 @@ __device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpE
     for (uint32_t row = 0; row < v.R; row++) {
         const uint32_t cb = E.L.get_cb(row);
         if (!E.cb_moved(row, cb)) continue;
-        if (hint && row == hrow && E.advanced_hinted(row, cb, *hint, hcol)) continue;
+        if (hint && row == hrow && E.advanced_hinted(row, cb, *hint, hcol)) { EPC_SUB(E.L, 11); continue; }
+        EPC_SUB(E.L, 12);
         E.advanced(row, cb);
+        EPC_SUB(E.L, 13);
     }
     EA(x.n_sub, E.g) = E.n_order;                                                // 0 when no commit bar moved
 }
@@ -917,7 +973,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     //   round 3 (PreAccept): the sequence numbers of the key's highest instances
     const uint32_t rw = row < v.R ? row : 0u;
     const uint32_t i = L.ix(rw, c);
-    const bool need_meta = LBK || MODE == 2 || rw == v.me;                   // (LBK = false: Status / bookkeeping are read only where they can matter;
+    const bool need_meta = LBK || MODE != 0 || rw == v.me;                   // (LBK = false: Status / bookkeeping are read only where they can matter;
     const u32x4 w0 = EA(v.p0, i);                                            //  a CommitNotice leaves the bookkeeping as it is)
     u32x4 w2 = (u32x4){EP_NONE, (uint32_t)EP_NO_KEY << 8, 0u, EP_NONE};
     if (need_meta) w2 = EA(v.p2, i);
@@ -925,13 +981,15 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     uint32_t my[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        my[q] = ((MODE == 0 || (uint32_t)q == rw) && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.R + q) : EP_NONE;
+        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.R + q) : EP_NONE;
+    EPC_SUB(L, 1);
     if (!on) return;
     if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
     // :33-36 pad the row up to the column; the cell of the column itself is written below if the message is taken (a fresh
     // cell's ballot is 0: it always is), so its null record is not stored first
     bool fresh = false;
     while (L.get_len(row) <= c) { fresh = L.get_len(row) == c; L.push_null(row, !fresh); }
+    EPC_SUB(L, 2);
     EpInst<NR> I;
     I.make_null();
     if (!fresh) {
@@ -943,6 +1001,12 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     uint32_t hc_row = EP_NONE;                                               // hc[key][row] as loaded: refresh_highest_cols needs no second look
 #pragma unroll
     for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = my[q];
+    // An Accept / CommitNotice for a cell that already holds an instance of this key (its PreAccept came by here): the key's
+    // highest column in this row was raised to at least c when that instance was stored and never falls, so
+    // refresh_highest_cols has nothing to do -- and hc[g][key] is a cache line of this lane's own, not fetched.  Otherwise
+    // (the PreAccept was lost) the word is loaded now, one round trip later than the rest.
+    const bool hc_known = MODE != 0 && !fresh && I.status() != EST_NULL && I.key() == k;
+    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.R + row);
     if (MODE == 0) {
         if (k == EP_NO_KEY) {
 #pragma unroll
@@ -959,6 +1023,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
 #pragma unroll
         for (int q = 0; q < NR; q++) if (ok[q] && sq[q] > ms) ms = sq[q];
         ms += 1;
+        EPC_SUB(L, 3);
 #pragma unroll
         for (int q = 0; q < NR; q++) {                                       // deps.union(&my_deps)
             if (in[q] != EP_NONE) { if (my[q] != EP_NONE && my[q] > in[q]) in[q] = my[q]; }
@@ -966,15 +1031,18 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
         }
         if (ms > s) s = ms;
     }
+    L.note_rewrite(c, L.get_cb(row));
     I.bal = b; I.set_status(MODE == 2 ? EST_COMMITTED : (MODE == 1 ? EST_ACCEPTING : EST_PREACCEPTING));
     I.seq = s; I.set_key(k);
 #pragma unroll
     for (int q = 0; q < NR; q++) I.d[q] = (uint32_t)q < v.R ? in[q] : EP_NONE;
     const uint32_t bk = I.bk();
     if (MODE != 2) I.set_bk((bk & 1u) | 2u | (src << 2));                    // replica_bk.source = peer
+    EPC_SUB(L, 4);
     L.store_inst(i, I);
     if (rec) { *rec = I; *stored = true; }
-    if (k != EP_NO_KEY && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.R + row) = c;   // refresh_highest_cols, dependency.rs:141-167
+    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.R + row) = c;   // refresh_highest_cols, dependency.rs:141-167
+    EPC_SUB(L, 5);
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
     } else {
@@ -1477,7 +1545,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
         ecarve(a, v.xv_status, R * W * R * G, dry); ecarve(a, v.xv_key, R * W * R * G, dry); ecarve(a, v.xv_seq, R * W * R * G, dry);
         ecarve(a, v.xv_deps, R * W * R * R * G, dry);
     }
-    ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry);
+    ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry); ecarve(a, v.rewritten, G, dry);
     ecarve(a, v.hc, K * R * G, dry);
     ecarve(a, v.counters, SMR_CTR_WORDS, dry);
     if (e->cfg.execute) {
@@ -1528,7 +1596,7 @@ template <typename T> __device__ __forceinline__ void ep_shift_ptr(T *&p, int64_
 __device__ __forceinline__ void ep_shift(EpView &v, int64_t d) {
     ep_shift_ptr(v.p0, d); ep_shift_ptr(v.p1, d); ep_shift_ptr(v.p2, d); ep_shift_ptr(v.p3, d);
     ep_shift_ptr(v.pa_seq, d); ep_shift_ptr(v.pa_deps, d); ep_shift_ptr(v.len, d); ep_shift_ptr(v.commit_bars, d);
-    ep_shift_ptr(v.my_nulls, d); ep_shift_ptr(v.hc, d); ep_shift_ptr(v.counters, d); ep_shift_ptr(v.xp_max, d);
+    ep_shift_ptr(v.my_nulls, d); ep_shift_ptr(v.rewritten, d); ep_shift_ptr(v.hc, d); ep_shift_ptr(v.counters, d); ep_shift_ptr(v.xp_max, d);
     ep_shift_ptr(v.xv_status, d); ep_shift_ptr(v.xv_key, d); ep_shift_ptr(v.xv_seq, d); ep_shift_ptr(v.xv_deps, d);
 }
 __device__ __forceinline__ void ep_shift(EpExec &x, int64_t d) {
@@ -1663,6 +1731,11 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
         } else if (t <= R) {                                                 // acceptor q: the PreAccept of sender s
             const uint32_t s = t - 1u;
             barrier = t == R;
+#ifdef EPC_STAMPS
+            L.sub = ((threadIdx.x & 63u) == 0 && set == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u && t == (q == 2 ? 4u : 3u))
+                        ? &a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + 32] : nullptr;
+            EPC_SUB(L, 0);
+#endif
             if (s != q && live) {
                 const smr_ep_cluster_out &o = a.out[s];
                 const uint8_t *dm = a.drop[s * NR + q];
@@ -1677,6 +1750,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                     RP(s, q, 0) = (uint32_t)os; RP(s, q, 1) = ((uint32_t)(os >> 32) & 0x7FFFFFFFu) | ((uint32_t)(of & 1u) << 31);
 #pragma unroll
                     for (int i = 0; i < NR; i++) if (i < 5) RP(s, q, 2 + i) = d[i];
+                    EPC_SUB(L, 6);
                 } else {
                     const bool on = (o.proposed[g] & 1) && !(dm && dm[g]);
                     ep_acceptor_lane<0, NR, RECOVERY>(L, on, s, s, o.col[g], (uint64_t)(s + 1u), o.seq0[g], o.deps0, a.keys[s][g], of, ob, os, d);
@@ -1783,6 +1857,11 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                 }
             } else {                                                         // the CommitNotices of leader s
                 barrier = false;                                             // (the next step that reads across wavefronts has its own in front)
+#ifdef EPC_STAMPS
+                L.sub = ((threadIdx.x & 63u) == 0 && set == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u && s == (q == 2 ? 3u : 2u))
+                            ? &a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + 32] : nullptr;
+                EPC_SUB(L, 8);
+#endif
                 if (q != s && live) {
                     uint8_t of; uint64_t ob, os; uint32_t d[NR];
                     h_row = s;
@@ -1802,7 +1881,12 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
                 }
             }
         }
+        EPC_SUB(L, 9);
         if (handled && a.execute && (can_commit || RECOVERY)) ep_exec_after_handler(v, x, E, have_h ? &H : nullptr, h_row, h_col);
+        EPC_SUB(L, 15);
+#ifdef EPC_STAMPS
+        L.sub = nullptr;
+#endif
         if (barrier) __syncthreads();
     }
     if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }

@@ -7,5 +7,5 @@ o=$(basename $f .hip).o
 mkdir -p summerset_amd/variants/$tag
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c summerset_amd/csrc/$f -o summerset_amd/variants/$tag/$o
 objs=$(ls summerset_amd/csrc/*.o | grep -v "/$o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o summerset_amd/variants/libsummerset_hip_$tag.so $objs summerset_amd/variants/$tag/$o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o summerset_amd/variants/libsummerset_hip_$tag.so $objs summerset_amd/variants/$tag/$o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo summerset_amd/variants/libsummerset_hip_$tag.so

@@ -44,3 +44,17 @@ for k in (0, 3, 7):
         print("  q%d " % q + " ".join("%s=%.0f" % (nm, v) for nm, v in zip(names, row)))
     d = [(int(s[k][:, t + 1].max()) - int(s[k][:, t].max())) / 100.0 for t in range(len(names) - 1)]
     print("  step durations (max over wavefronts): " + " ".join("%s:%.1f" % (nm, v) for nm, v in zip(names, d)))
+# sub-stamps of ONE PreAccept handler (third acceptor step; fourth for wavefront 2), slots 32..38 of each wavefront's row:
+# 0 step entry, 1 first round of loads landed, 2 row padded, 3 sequence numbers landed + max, 4 record built, 5 stores issued
+# (and landed: the stamp waits), 6 reply in LDS
+for k in (0, 3):
+    for q in range(R):
+        sub = [int(x) for x in s[k][q][32:48]]
+        if not sub[0]: continue
+        print("  block %d q%d PreAccept handler sub-stamps (us since entry): " % (k * 128 + 5, q) +
+              " ".join("%d:%s" % (j, ("%.2f" % ((sub[j] - sub[0]) / 100.0)) if sub[j] else "-") for j in range(7)))
+        # one CommitNotice step: 8 entry, 9 handler done (stores landed), 10 the hinted attempt's loads landed, 11 hinted attempt done,
+        # 12 / 13 the general walk entered / done (either a miss of the hint or another row's bar), 15 step done
+        if sub[8]:
+            print("  block %d q%d CommitNotice step sub-stamps (us since entry): " % (k * 128 + 5, q) +
+                  " ".join("%d:%s" % (j, ("%.2f" % ((sub[j] - sub[8]) / 100.0)) if sub[j] else "-") for j in range(8, 16)))
