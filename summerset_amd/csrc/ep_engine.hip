@@ -63,6 +63,7 @@ __device__ __forceinline__ T &EA(T *base, uint32_t idx) { return *(T *)((char *)
 // whatever its width), so the fields a handler touches together now travel together: an instance is 3 loads or 3 stores.
 struct EpView {
     uint32_t G, W, Wmask, R, me, n_keys, simple_q, super_q;
+    uint32_t hc_ew;                      // words of an hc entry: 8 at R <= 6 (32 bytes, four keys to a cache line), else 16
     u32x4 *p0, *p1, *p2, *p3;            // [R][W][G] each; p3 NULL at populations <= 6
     uint64_t *pa_seq;                    // my row only: [W][R][G]
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
@@ -70,7 +71,10 @@ struct EpView {
     uint32_t *my_nulls;                  // [G] null instances currently in my own row (first_null_slot need not scan at 0)
     uint8_t *rewritten;                  // [G] sticky: a message once rewrote a cell below its row's commit bar (a duplicate, a late or an explicit-prepare
                                          //     message): from then on "below the exec bar" no longer means Executed for this group (EpExecLaneT::attempt)
-    uint32_t *hc;                        // [G][n_keys][R]
+    uint32_t *hc;                        // [G][n_keys][hc_ew]: per (group, key) the key's highest column in each row (words 0 .. R) and, round 4, the
+                                         //     executor's KV word of the key (the last two words): both are lines of the lane's own -- a gather and a
+                                         //     scatter each -- and an instance's PreAccept touches the first a phase or two before its execution touches
+                                         //     the second; in one line, the second is a cache hit more often than not
     unsigned long long *counters;        // fast commits, slow-path entries, slow-path commits; explicit prepare outcomes:
                                          // Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op
     // explicit prepare (recovery != 0; pa_seq / pa_deps then hold every row: [R][W][R][G] / [R][W][R][R][G])
@@ -236,7 +240,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.R + i) : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.hc_ew + i) : EP_NONE;
     }
     __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
@@ -250,7 +254,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
         if (key == EP_NO_KEY) return;
-        const uint32_t o = (g * v.n_keys + key) * v.R + row;
+        const uint32_t o = (g * v.n_keys + key) * v.hc_ew + row;
         const uint32_t hc = EA(v.hc, o);
         if (hc == EP_NONE || col > hc) EA(v.hc, o) = col;
     }
@@ -510,7 +514,7 @@ constexpr uint64_t EP_DG_MUL = 0x100000001B3ull;
 
 struct EpExec {
     uint32_t *exec_bars, *prev_cb;       // [R][G]
-    uint64_t *kv;                        // [n_keys][G] token of the last Put, 0 = none
+                                         // (the KV words -- token of the last Put, 0 = none -- live in the hc entries: EpView::hc)
     uint64_t *digest;                    // [G] chain over (token, old token) in submission order
     uint16_t *node_of, *nslot, *head, *sib, *parent;   // [R*W][G]
     uint16_t *order;                     // [2*R*W][G] this call's submissions (ring cells), ...
@@ -573,6 +577,8 @@ struct EpExecLaneT {
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
     __device__ __forceinline__ uint32_t at(uint32_t i) const { return i * v.G + g; }
+    // the KV word of a key: the last two words of the key's hc entry (EpView::hc)
+    __device__ __forceinline__ uint64_t &kv_at(uint32_t key) const { return *(uint64_t *)&EA(v.hc, (g * v.n_keys + key) * v.hc_ew + v.hc_ew - 2u); }
     // the column a ring cell of this row holds (the one of its residue among the last W)
     __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
         const uint32_t end = L.get_len(row), lo = end > v.W ? end - v.W : 0u;
@@ -613,8 +619,8 @@ struct EpExecLaneT {
         L.load_meta(i, I);
         const uint32_t key = I.key();
         if (key != EP_NO_KEY) {
-            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = EA(x.kv, key * v.G + g);
-            EA(x.kv, key * v.G + g) = tok;
+            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = kv_at(key);
+            kv_at(key) = tok;
             uint64_t d = EA(x.digest, g);
             d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
             EA(x.digest, g) = d;
@@ -787,7 +793,7 @@ struct EpExecLaneT {
         // (the cell behind mine matters to the exec-bar scan only: when the bar is at my column and that cell exists)
         const bool need_n = hcol == eb_of(ebs, row) && hcol + 1 < L.get_len(row) && L.held(row, hcol + 1);
         const uint32_t nst = L.status_at(L.ix(row, need_n ? hcol + 1 : 0u));
-        const uint64_t old = EA(x.kv, key * v.G + g);
+        const uint64_t old = kv_at(key);
         uint64_t dg = EA(x.digest, g);
         EPC_SUB(L, 10);
         // the pops, in the reference's order, on those words
@@ -810,7 +816,7 @@ struct EpExecLaneT {
         const uint32_t first = n_order;
         {
             const uint64_t tok_ = ((uint64_t)(row + 1) << 32) | hcol;
-            EA(x.kv, key * v.G + g) = tok_;
+            kv_at(key) = tok_;
             dg = (dg ^ tok_) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
             EA(x.digest, g) = dg;
             if (n_order < 2u * v.R * v.W) EA(x.order, at(n_order++)) = (uint16_t)ring;
@@ -930,7 +936,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         uint32_t hc_row = EP_NONE;
 #pragma unroll
         for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
-        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.R + row) = col;
+        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.hc_ew + row) = col;
     }
     L.fresh_leader_bk(i, I);
     I.set_status(EST_PREACCEPTING);
@@ -981,7 +987,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     uint32_t my[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.R + q) : EP_NONE;
+        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.hc_ew + q) : EP_NONE;
     EPC_SUB(L, 1);
     if (!on) return;
     if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
@@ -1006,7 +1012,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     // refresh_highest_cols has nothing to do -- and hc[g][key] is a cache line of this lane's own, not fetched.  Otherwise
     // (the PreAccept was lost) the word is loaded now, one round trip later than the rest.
     const bool hc_known = MODE != 0 && !fresh && I.status() != EST_NULL && I.key() == k;
-    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.R + row);
+    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.hc_ew + row);
     if (MODE == 0) {
         if (k == EP_NO_KEY) {
 #pragma unroll
@@ -1041,7 +1047,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     EPC_SUB(L, 4);
     L.store_inst(i, I);
     if (rec) { *rec = I; *stored = true; }
-    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.R + row) = c;   // refresh_highest_cols, dependency.rs:141-167
+    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.hc_ew + row) = c;   // refresh_highest_cols, dependency.rs:141-167
     EPC_SUB(L, 5);
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
@@ -1546,12 +1552,12 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
         ecarve(a, v.xv_deps, R * W * R * R * G, dry);
     }
     ecarve(a, v.len, R * G, dry); ecarve(a, v.commit_bars, R * G, dry); ecarve(a, v.my_nulls, G, dry); ecarve(a, v.rewritten, G, dry);
-    ecarve(a, v.hc, K * R * G, dry);
+    ecarve(a, v.hc, K * (size_t)(R <= 6 ? 8 : 16) * G, dry);
     ecarve(a, v.counters, SMR_CTR_WORDS, dry);
     if (e->cfg.execute) {
         EpExec &x = e->x;
         ecarve(a, x.exec_bars, R * G, dry); ecarve(a, x.prev_cb, R * G, dry);
-        ecarve(a, x.kv, K * G, dry); ecarve(a, x.digest, G, dry);
+        ecarve(a, x.digest, G, dry);
         ecarve(a, x.node_of, R * W * G, dry); ecarve(a, x.nslot, R * W * G, dry); ecarve(a, x.head, R * W * G, dry);
         ecarve(a, x.sib, R * W * G, dry); ecarve(a, x.parent, R * W * G, dry);
         ecarve(a, x.order, 2 * R * W * G, dry); ecarve(a, x.n_sub, G, dry);
@@ -1600,7 +1606,7 @@ __device__ __forceinline__ void ep_shift(EpView &v, int64_t d) {
     ep_shift_ptr(v.xv_status, d); ep_shift_ptr(v.xv_key, d); ep_shift_ptr(v.xv_seq, d); ep_shift_ptr(v.xv_deps, d);
 }
 __device__ __forceinline__ void ep_shift(EpExec &x, int64_t d) {
-    ep_shift_ptr(x.exec_bars, d); ep_shift_ptr(x.prev_cb, d); ep_shift_ptr(x.kv, d); ep_shift_ptr(x.digest, d);
+    ep_shift_ptr(x.exec_bars, d); ep_shift_ptr(x.prev_cb, d); ep_shift_ptr(x.digest, d);
     ep_shift_ptr(x.node_of, d); ep_shift_ptr(x.nslot, d); ep_shift_ptr(x.head, d); ep_shift_ptr(x.sib, d); ep_shift_ptr(x.parent, d);
     ep_shift_ptr(x.order, d); ep_shift_ptr(x.n_sub, d); ep_shift_ptr(x.counters, d);
 }
@@ -1917,7 +1923,7 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
         const uint64_t G = cfg->n_groups, W = cfg->window, R = cfg->population, K = cfg->n_keys, PR = cfg->recovery ? R : 1;
         uint64_t most = R * W * G * 16;                                          // a record plane
         most = std::max(most, PR * W * R * R * G * 4);                           // pa_deps / xv_deps
-        most = std::max(most, K * R * G * 8);                                    // hc, kv
+        most = std::max(most, K * (R <= 6 ? 8 : 16) * G * 4);                   // hc (with the KV words)
         if (most >= (1ull << 32))
             return fail(SMR_ERR_ARG, "epaxos: n_groups * window too large: an array would pass 4 GB (32-bit offsets); shard the groups over more replicas objects");
     }
@@ -1934,10 +1940,13 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     const uint32_t R = cfg->population;
     v.G = cfg->n_groups; v.W = cfg->window; v.Wmask = cfg->window - 1; v.R = R; v.me = cfg->me; v.n_keys = cfg->n_keys;
     v.recovery = cfg->recovery;
+    v.hc_ew = R <= 6 ? 8u : 16u;
     v.simple_q = R / 2 + 1;                                                      // mod.rs:693
     v.super_q = cfg->optimized_quorum ? R / 2 + (R / 2 + 1) / 2 : (R / 2) * 2;   // mod.rs:694-698
     err = hipMemset(e->arena.base, 0, e->arena.size);
-    if (err == hipSuccess) err = hipMemset(v.hc, 0xFF, (size_t)cfg->n_keys * R * v.G * 4);
+    if (err == hipSuccess) err = hipMemset(v.hc, 0xFF, (size_t)cfg->n_keys * v.hc_ew * v.G * 4);
+    if (err == hipSuccess)                                                       // ... and every entry's KV word 0
+        err = hipMemset2D((char *)v.hc + (v.hc_ew - 2) * 4, (size_t)v.hc_ew * 4, 0, 8, (size_t)cfg->n_keys * v.G);
     if (err == hipSuccess) {                                                     // every ring cell a null instance (deps None, key None)
         const size_t n = (size_t)R * v.W * v.G;
         hipLaunchKernelGGL(ep_init_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)nullptr, v.p1, v.p2, v.p3, n);
@@ -2150,11 +2159,12 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
 #define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     D2H(hb->len, v.len, R * G * 4); D2H(hb->commit_bars, v.commit_bars, R * G * 4);
     {                                                                            // device [G][K][R] -> the dump's [K][R][G]
-        std::vector<uint32_t> hc(K * R * G);
-        D2H(hc.data(), v.hc, K * R * G * 4);
+        const size_t EW = v.hc_ew;
+        std::vector<uint32_t> hc(K * EW * G);
+        D2H(hc.data(), v.hc, K * EW * G * 4);
         for (size_t g = 0; g < G; g++)
             for (size_t k = 0; k < K; k++)
-                for (size_t r = 0; r < R; r++) hb->highest_cols[(k * R + r) * G + g] = hc[(g * K + k) * R + r];
+                for (size_t r = 0; r < R; r++) hb->highest_cols[(k * R + r) * G + g] = hc[(g * K + k) * EW + r];
     }
     std::vector<uint64_t> bal(R * W * G), seq(R * W * G);
     std::vector<uint8_t> st(R * W * G), key(R * W * G), bk(R * W * G), pa(R * W * G), ac(R * W * G);
@@ -2209,7 +2219,14 @@ int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint6
     const EpView &v = e->v;
     const size_t G = v.G, R = v.R, K = v.n_keys;
     SMR_HIP_TRY(hipMemcpy(exec_bars, e->x.exec_bars, R * G * 4, hipMemcpyDeviceToHost));
-    SMR_HIP_TRY(hipMemcpy(kv, e->x.kv, K * G * 8, hipMemcpyDeviceToHost));
+    {                                                                            // device: in the hc entries [G][K][hc_ew] -> the dump's [K][G]
+        const size_t EW = v.hc_ew;
+        std::vector<uint32_t> hc(K * EW * G);
+        SMR_HIP_TRY(hipMemcpy(hc.data(), v.hc, K * EW * G * 4, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < G; g++)
+            for (size_t k = 0; k < K; k++)
+                kv[k * G + g] = (uint64_t)hc[(g * K + k) * EW + EW - 2] | ((uint64_t)hc[(g * K + k) * EW + EW - 1] << 32);
+    }
     SMR_HIP_TRY(hipMemcpy(digest, e->x.digest, G * 8, hipMemcpyDeviceToHost));
     unsigned long long c[8];
     SMR_HIP_TRY(ctr_read(e->x.counters, 8, c));

@@ -69,6 +69,7 @@ template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipM
 inline hipError_t hipFree(void *p) { hipsim::dev_free(p); return hipSuccess; }
 inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemset2D(void *p, size_t pitch, int v, size_t w, size_t h) { for (size_t r = 0; r < h; r++) memset((char *)p + r * pitch, v, w); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
