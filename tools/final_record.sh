@@ -1,16 +1,16 @@
 #!/bin/bash
-# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m):
+# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m):
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra
-TAG=${1:-r5m}
+TAG=${1:-r6m}
 mkdir -p gpurun_out
 R=$PWD
 # 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic.json for every `traffic` field of its line
 ( cd /tmp && export TMPDIR=/tmp
   timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1
   timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1 )
-python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write "tools/pmc_probe.py --extra at HEAD: 16 ticks of the bench shape on the default workload (65536 groups x 5, S=32, H=4, 10% loss, 1% leader changes) as bench.py runs them (summerset_amd/workloads.py: two smr_mp_run_ticks batches of 8, straggler list on, ttl 4), 32 more through the fused tick kernel + 3 RS(3,2) encodes of 65536 x 4099 B + the Raft (incl. batches of 16 ticks) / EPaxos / wire-ingest legs + the reply-ingest leg + the one-launch EPaxos cluster tick (both orders, messages through LDS) + the RSPaxos-engine leg (shards written once)" > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
+python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write "tools/pmc_probe.py --extra at HEAD: 16 ticks of the bench shape on the default workload (65536 groups x 5, S=32, H=4, 10% loss, 1% leader changes) as bench.py runs them (summerset_amd/workloads.py: two smr_mp_run_ticks batches of 8, straggler list on, ttl 4), 32 more through the fused tick kernel + 3 RS(3,2) encodes of 65536 x 4099 B + the Raft (incl. batches of 16 ticks) / EPaxos / wire-ingest legs + the reply-ingest leg + the one-launch EPaxos cluster tick (both orders, messages through LDS, KV words in the hc entries) + the RSPaxos-engine leg (shards written once)" > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 # 2. the suite, the bench lines
 timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -40 > gpurun_out/${TAG}_gputests.log
