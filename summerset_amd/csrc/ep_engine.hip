@@ -1259,11 +1259,15 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
         const int next = ep_eval<NR>(v, acks, ps, pd, ex, avoid, dseq, dd);
         if (next) st = (uint32_t)next;
     }
-    // write back: new replies, the ack mask, the decision
+    // write back: new replies, the ack mask, the decision.  (A reply is kept for the calls to come: once the instance has left
+    // PreAccepting in THIS call nobody reads the table again -- a reader looks at acked peers of a PreAccepting instance only,
+    // and fresh bookkeeping starts from an empty ack mask -- so the replies of a decided instance are not stored: 28 bytes per
+    // peer, the common case of the one-launch tick, where all of an instance's replies arrive in one call.)
     const uint32_t fresh = acks & ~acks0;
+    const bool decided = h && before == EST_PREACCEPTING && st != EST_PREACCEPTING;
 #pragma unroll
     for (int p = 0; p < NR; p++)
-        if ((fresh >> p) & 1u) {
+        if (((fresh >> p) & 1u) && !decided) {
             EA(v.pa_seq, L.ps_ix(row, c, p)) = ps[p];
 #pragma unroll
             for (int k = 0; k < NR; k++)
@@ -1893,6 +1897,8 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
 #ifdef EPC_STAMPS
         L.sub = nullptr;
 #endif
+        // (a barrier per set of R wavefronts, counted in LDS, so that the block's two sets drift apart and one's loads overlap the
+        // other's compute: measured 2 % slower than the block barrier, profiles/r6g)
         if (barrier) __syncthreads();
     }
     if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
