@@ -935,6 +935,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             }
         }
         uint32_t m[C];
+        // the followers' answer bits of this pass's rows (j = w + 4 (k0 + k): bit 4 k of the word shifted down to the pass's first
+        // row), 32 bits wide: one 64-bit shift per follower and pass instead of one per follower and ROW (quarter rate on this chip)
+        uint32_t a32[NR];
+#pragma unroll
+        for (int q = 0; q < NR; q++) a32[q] = (uint32_t)(ab[q] >> (w + 4u * k0));
+        static_assert(4 * (C - 1) < 32, "a pass's rows must fit the 32-bit window");
         // bit k: bal_prepared >= the ballot of row k's slot (messages.rs:396).  Inside the leader's run the ballot is
         // bal_max_seen, unstored: one comparison for all rows; a row below the run (none in the steady state: the run starts
         // with the first steady append) loads its ballot -- one by one, so that no row holds two more registers in flight
@@ -968,7 +974,7 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
                 uint32_t valid = 0;                              // an answer carries the Accept's ballot: ob_rbal
                 if (answers_ok) {
 #pragma unroll
-                    for (int q = 0; q < NR; q++) valid |= (uint32_t)((ab[q] >> j) & 1ull) << q;   // (cand: j < cnt <= 64)
+                    for (int q = 0; q < NR; q++) valid |= ((a32[q] >> (4 * k)) & 1u) << q;        // (cand: j < cnt <= 64)
                     valid &= ~(1u << dl);
                 }
                 // (tally_valid's ballot test is `bpd >= b`: b = 0 passes, b = ~0 fails)
