@@ -1663,15 +1663,40 @@ def main():
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
-        if l2 is not None and "error" in l2:       # a rank whose L2 pass failed or hung cannot trust a collective any more: the closing barrier
-            import threading                       # gets a few seconds on a thread, then every such rank leaves (the line is out)
+        # Every rank learns whether ANY rank's L2 pass failed or hung before it picks the way out: through the job's
+        # key-value store, not through the backend that may just have hung.  A rank whose own pass was fine used to walk into
+        # the plain barrier and wait there for a peer that had already left.
+        bad = _l2_outcome_of_all_ranks(dist, world, l2 is not None and "error" in l2)
+        if bad:
+            import threading                       # the closing barrier gets a few seconds on a thread, then every rank leaves (the line is out)
             th = threading.Thread(target=lambda: dist.barrier(), daemon=True)
             th.start()
             th.join(timeout=20.0)
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(0)                            # 0: the headline line is valid and printed; the failure is in `legs_failed` and on stderr
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _l2_outcome_of_all_ranks(dist, world, mine_failed, wait_s=None):
+    """True if any rank's L2 pass failed (or the question itself could not be settled).  Each rank adds itself to `l2_done` and its
+    failure to `l2_failed` in the process group's store, then waits until all `world` ranks are in: the longest a rank can be behind is
+    the watchdog's own timeout."""
+    import time
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        store = c10d._get_default_store()
+        store.add("smr_bench_l2_failed", 1 if mine_failed else 0)
+        store.add("smr_bench_l2_done", 1)
+        limit = time.time() + (float(os.environ.get("SMR_BENCH_L2_TIMEOUT", "150")) + 30.0 if wait_s is None else wait_s)
+        while store.add("smr_bench_l2_done", 0) < world:
+            if time.time() > limit:
+                return True
+            time.sleep(0.05)
+        return store.add("smr_bench_l2_failed", 0) > 0
+    except Exception as e:                         # noqa: BLE001 -- no store, or its host is gone: do not trust a collective
+        sys.stderr.write("bench.py: could not settle the ranks' L2 outcome (%s: %s)\n" % (type(e).__name__, e))
+        return True if mine_failed else False
 
 
 if __name__ == "__main__":

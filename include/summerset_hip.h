@@ -846,6 +846,52 @@ int smr_rsp_dump(smr_rsp_replica *e, const smr_rsp_dump_bufs *host_bufs);
 int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_host, uint32_t *val_host, uint64_t cap, uint64_t *n_out);
 
 /* ------------------------------------------------------------------------
+ * RSPaxos payload store: the shard BYTES behind a replica's instances, resident in HBM, keyed by (slot, shard) --
+ * `inst.reqs_cw` and the voted copy `inst.voted.1` (rspaxos/mod.rs:168-233) as two planes (0 = reqs, 1 = voted), each a
+ * ring of W rows x n shards x G groups.  The replica engine above decides which shards exist where (token + mask per
+ * instance); the store makes the bytes follow:
+ *   smr_rsp_pstore_put       the leader's RSCodeword::from_data + compute_parity (rspaxos/request.rs:71-101,
+ *                            rscoding.rs:165-243,447-486) of a tick's batches into the rows smr_rsp_req_batch chose: a_n /
+ *                            a_slot / a_val = that call's smr_rsp_accepts (its first list entry), data_dev = uint8
+ *                            [G][data_stride] serialized batches, len_dev (may be NULL) = per-group lengths <= data_len
+ *   smr_rsp_pstore_follow    after ANY handler call of replica e: for every ring cell of both planes, the shards the
+ *                            engine's mask has and the row lacks are taken from the sources (store, plane) that hold the
+ *                            SAME token -- the sender's subset_copy + the receiver's `inst.reqs_cw = reqs_cw` /
+ *                            absorb_other (rscoding.rs:255-346; messages.rs:180-194,373-380,547-560) -- entries of src may
+ *                            be NULL (a list indexed by replica id has an empty seat at my own); sel_dev (may be NULL) = u8
+ *                            [G]: in group g only source sel_dev[g] may give shards (the `peer` array of the handler call:
+ *                            the message's sender); my own other plane is always a source; what is still missing is
+ *                            rebuilt from any d shards present
+ *                            (reconstruct_data on commit and at the prepare quorum, compute_parity for the re-Accepts:
+ *                            durability.rs:140-160, messages.rs:227-259); a row whose token changed drops its shards.
+ *                            Payload identity is the token: shard bytes are a function of (token, shard index).  Token 0
+ *                            = ReqBatch::new() (messages.rs:246-252), serialized as the one byte 0x00, is synthesised.
+ *   smr_rsp_pstore_get_data  RSCodeword::get_data (rscoding.rs:583-609) for a list of instances: item i = (group_dev[i], or
+ *                            i when NULL; slot_dev[i], SMR_RSP_NULL = skip) -> out_dev[i][0 .. len), len_out_dev[i],
+ *                            ok_dev[i] = 1 iff the row holds every data shard (and token expect_dev[i], when given)
+ * Host-side reads: _dump (tok / avail / dlen [W][G] of a plane; NULL = skip), _read_row (the n x G x group_stride bytes of
+ * a slot's row), _layout (device pointer + strides of a plane: shard k of group g of row r at bytes_dev + r * row_stride +
+ * k * shard_stride + g * group_stride -- a row is a shard-major batch smr_rs_reconstruct / smr_rs_verify accept),
+ * _counters: shards copied, shards rebuilt, shards the engine has that no source could give (0 in a correct run),
+ * rows whose token changed while they held shards.  n_shards = the population (<= 8), n_data_shards = the majority.
+ * ---------------------------------------------------------------------- */
+typedef struct smr_rsp_pstore smr_rsp_pstore;
+int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
+                          smr_rsp_pstore **out);
+void smr_rsp_pstore_destroy(smr_rsp_pstore *s);
+int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
+                       const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, void *stream);
+int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
+                          const uint8_t *sel_dev, void *stream);
+int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
+                            uint8_t *out_dev, uint64_t out_stride, uint32_t *len_out_dev, uint8_t *ok_dev, void *stream);
+int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_t *avail_host, uint32_t *dlen_host);
+int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host);
+int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,
+                          uint64_t *group_stride);
+int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host);
+
+/* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing
  * ---------------------------------------------------------------------- */
 typedef struct smr_repnothing smr_repnothing;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "smr_common.h"
+#include "rsp_peek.h"
 
 namespace smr {
 
@@ -664,6 +665,10 @@ static void rsp_layout(smr_rsp_replica *e, bool dry) {
     qcarve(a, v.s_rtrig, W * G, dry); qcarve(a, v.s_rendp, W * G, dry);
     qcarve(a, v.xq, W * G, dry); qcarve(a, v.xn, G, dry);
     qcarve(a, v.counters, SMR_CTR_WORDS, dry);
+}
+RspPeek rsp_peek(const smr_rsp_replica *e) {
+    const RspView &v = e->v;
+    return RspPeek{v.G, v.W, v.R, v.me, v.majority, v.s_val, v.s_vval, v.s_mask, v.s_vmask};
 }
 }  // namespace smr
 

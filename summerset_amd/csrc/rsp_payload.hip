@@ -1,0 +1,512 @@
+// RSPaxos payload store: the shard BYTES behind an RSPaxos replica's instances, resident in HBM, keyed by (slot, shard).
+//
+// The replica engine (rsp_engine.hip) keeps a codeword as (batch token, mask of shards present); this object keeps what
+// the reference keeps in `inst.reqs_cw` and `inst.voted.1` (rspaxos/mod.rs:168-233): the shards themselves.  Two planes
+// per replica -- REQS and VOTED -- each a ring of W rows x n shards x G groups x cap_sl bytes, plus per (row, group) the
+// token whose bytes the row holds, the shards present and the data length.  The engine decides which shards exist where;
+// the store makes the bytes FOLLOW that decision:
+//   smr_rsp_pstore_put     the leader's RSCodeword::from_data + compute_parity of a tick's batches (request.rs:71-101,
+//                          rscoding.rs:165-243,447-486) into the rows the engine's handle_req_batch put them
+//   smr_rsp_pstore_follow  after any handler call: for every ring cell, take the shards the engine's mask has and the row
+//                          has not from the given sources where they hold the same token (subset_copy at the sender +
+//                          `inst.reqs_cw = reqs_cw` / absorb_other at the receiver: rscoding.rs:255-346, messages.rs:180-194,
+//                          373-380, 547-560), then rebuild what is still missing from any d present shards
+//                          (reconstruct_data on commit / at the prepare quorum, compute_parity for the re-Accepts:
+//                          durability.rs:140-160, messages.rs:227-259; ReedSolomon::reconstruct's first-d-present rule)
+//   smr_rsp_pstore_get_data  the serialized batch of an instance for execution (rscoding.rs:583-609)
+// Payload identity is the token: the bytes of a shard are a function of (token, shard index), so a row whose token
+// changed drops its shards, and a source is usable for a row exactly when it holds the row's token.  Token 0 is the
+// empty batch `ReqBatch::new()` (messages.rs:246-252): its serialization is the single byte 0x00 and is synthesised.
+//
+// HBM-bound byte work, rare path except `put` and one shard copy per follower and tick: a plan kernel (one lane per ring
+// cell) compares the engine's masks with the rows' and compacts the cells with work onto a list; a byte kernel walks the
+// list, one wavefront per cell, a lane per 16-byte column: copies are 16-byte loads / stores, rebuilds a per-lane
+// coefficient x 16-byte GF(2^8) multiply-accumulate (bit-sliced xtime on 4 packed bytes per VGPR, poly 0x11D) against
+// a 256-pattern table of (all shards from the first d present) matrices.
+#include <string.h>
+
+#include <vector>
+
+#include "smr_common.h"
+#include "rsp_peek.h"
+
+namespace smr {
+
+constexpr uint32_t PS_NULL = 0xFFFFFFFFu;
+constexpr uint32_t PS_NONE = 0xFF, PS_OWN = 0xFE, PS_EMPTY = 0xFD;     // a shard's source: none / my other plane / the empty batch
+constexpr uint32_t PS_MAX_SRC = 16, PS_MAX_N = 8;
+constexpr uint64_t PS_NO_SRC = ~0ull;
+
+struct PsPlane {
+    uint8_t *bytes;        // [(row * n + k) * G + g] * cap_sl
+    uint32_t *tok;         // [W][G] the token whose bytes the row holds (PS_NULL: nothing)
+    uint8_t *avail;        // [W][G] shards present
+    uint32_t *dlen;        // [W][G] data length of the codeword
+};
+struct PsView {
+    uint32_t G, W, Wmask, n, d, cap_sl;
+    PsPlane pl[2];
+    const uint8_t *mat;    // [256][8][8]: shard r = XOR_c mat[pat][r][c] * (c-th present shard of pat)
+    uint32_t *it_n;        // the list of cells with work: count, then per item the cell, per plane the shards' sources
+    uint32_t *it_cell;     // (8 bits each), the shards to rebuild | the pattern to rebuild from, and the shard length
+    uint64_t *it_src[2];
+    uint32_t *it_rc;
+    uint32_t *it_sl[2];
+    unsigned long long *counters;   // 0 shards copied, 1 shards rebuilt, 2 shards the engine has and nobody could give, 3 rows re-keyed
+};
+struct PsSrcs {
+    uint32_t n;
+    PsPlane p[PS_MAX_SRC];
+};
+
+typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t ps_off(const PsView &v, uint32_t row, uint32_t k, uint32_t g) {
+    return (((size_t)row * v.n + k) * v.G + g) * v.cap_sl;
+}
+__device__ __forceinline__ uint32_t ps_shard_len(uint32_t L, uint32_t d) { return (L + d - 1) / d; }   // rscoding.rs:177-181
+__device__ __forceinline__ ps_u32x4 ps_load16(const uint8_t *p) {
+    ps_u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void ps_store16(uint8_t *p, ps_u32x4 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ uint32_t ps_xtime4(uint32_t x) {               // 4 packed GF(2^8) bytes times 2
+    const uint32_t hi = x & 0x80808080u;
+    return ((x << 1) & 0xFEFEFEFEu) ^ ((hi - (hi >> 7)) & 0x1D1D1D1Du);
+}
+// acc ^= c * x over 16 bytes, c a per-lane coefficient
+__device__ __forceinline__ void ps_axpy16(ps_u32x4 &acc, ps_u32x4 x, uint32_t c) {
+    while (c) {
+        if (c & 1u) acc ^= x;
+        x.x = ps_xtime4(x.x); x.y = ps_xtime4(x.y); x.z = ps_xtime4(x.z); x.w = ps_xtime4(x.w);
+        c >>= 1;
+    }
+}
+// the shards in `need` of cell (row, g), columns [c0, c0 + 16), from the first d shards of `pat` (all in `base`'s plane)
+__device__ __forceinline__ void ps_rebuild(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
+                                           uint32_t pat) {
+    const uint8_t *m = v.mat + (size_t)pat * 64;
+    ps_u32x4 acc[PS_MAX_N];
+#pragma unroll
+    for (int r = 0; r < (int)PS_MAX_N; r++) acc[r] = (ps_u32x4){0u, 0u, 0u, 0u};
+    uint32_t p = pat;
+    for (uint32_t c = 0; c < v.d; c++) {
+        const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
+        p &= p - 1u;
+        const ps_u32x4 x = ps_load16(base + ps_off(v, row, k, g) + c0);
+#pragma unroll
+        for (int r = 0; r < (int)PS_MAX_N; r++)
+            if ((need >> r) & 1u) ps_axpy16(acc[r], x, m[r * 8 + c]);
+    }
+#pragma unroll
+    for (int r = 0; r < (int)PS_MAX_N; r++)
+        if ((need >> r) & 1u) ps_store16(base + ps_off(v, row, (uint32_t)r, g) + c0, acc[r]);
+}
+// 16 bytes of a serialized batch from offset `off`; bytes at or beyond `lim` read as zero (from_data's padding,
+// rscoding.rs:188-189, and the next shard's bytes)
+__device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t off, uint32_t lim) {
+    if (off + 16u <= lim) return ps_load16(p + off);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t b = (off + (uint32_t)i < lim) ? p[off + i] : 0u;
+        w[i >> 2] |= b << (8 * (i & 3));
+    }
+    return (ps_u32x4){w[0], w[1], w[2], w[3]};
+}
+
+// request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches
+__global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
+                                                     const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
+                                                     const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    if (g >= v.G || a_n[g] == 0) return;
+    const uint32_t row = a_slot[g] & v.Wmask;
+    uint32_t L = len ? len[g] : data_len;
+    if (L > data_len) L = data_len;
+    const uint32_t sl = ps_shard_len(L, v.d), c0 = blk * 16u;
+    if (blk == 0) {
+        const size_t i = (size_t)row * v.G + g;
+        v.pl[0].tok[i] = a_val[g];
+        v.pl[0].avail[i] = (uint8_t)((1u << v.n) - 1u);
+        v.pl[0].dlen[i] = L;
+    }
+    if (c0 >= sl) return;
+    const uint8_t *src = data + (size_t)g * data_stride;
+    for (uint32_t c = 0; c < v.d; c++) {
+        const uint32_t end = (c + 1u) * sl;
+        ps_store16(v.pl[0].bytes + ps_off(v, row, c, g) + c0, ps_load_data16(src, c * sl + c0, end < L ? end : L));
+    }
+    const uint32_t dm = (1u << v.d) - 1u;
+    ps_rebuild(v, v.pl[0].bytes, row, g, c0, ((1u << v.n) - 1u) & ~dm, dm);                  // compute_parity
+}
+
+// one lane per ring cell: what the engine says the cell holds against what the rows hold
+// (sel: per group the ONE source a shard may come from -- the sender of the message the handler consumed -- or NULL: any)
+__global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const bool on = t < v.W * v.G;
+    const uint32_t i = on ? t : 0u;
+    uint64_t src[2] = {PS_NO_SRC, PS_NO_SRC};
+    uint32_t rc = 0, sl[2] = {0u, 0u};
+    uint32_t n_copy = 0, n_rebuilt = 0, n_unsat = 0, n_rekey = 0;
+    uint32_t reqs_tok = PS_NULL, reqs_have = 0, reqs_len = 0;              // plane 0's new state: plane 1's "own other plane"
+    const uint32_t all = (1u << v.n) - 1u;
+    if (on) {
+        const uint32_t only = sel ? sel[i % v.G] : PS_NONE;
+        for (int pl = 0; pl < 2; pl++) {
+            uint32_t want_tok = pl == 0 ? e.s_val[i] : e.s_vval[i];
+            uint32_t want = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
+            if (want_tok == PS_NULL) want = 0;
+            if (want == 0) want_tok = PS_NULL;
+            uint32_t have = v.pl[pl].avail[i], L = v.pl[pl].dlen[i];
+            if (v.pl[pl].tok[i] != want_tok) {
+                if (have) n_rekey++;
+                have = 0; L = 0;
+            }
+            have &= want;                                                    // `inst.reqs_cw = reqs_cw`: shards the engine dropped
+            uint32_t need = want & ~have;
+            uint64_t sb = PS_NO_SRC;
+            if (need && want_tok == 0) {                                     // from_data(ReqBatch::new()): one zero byte
+                for (uint32_t m = need; m; m &= m - 1u) {
+                    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                    sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)PS_EMPTY << (8 * k));
+                }
+                have |= need; need = 0; L = 1;
+            }
+            for (uint32_t j = 0; j <= S.n && need; j++) {
+                uint32_t s_tok, s_av, s_len, code;
+                if (j < S.n) {
+                    if (!S.p[j].tok || (sel && only != j)) continue;
+                    s_tok = S.p[j].tok[i]; s_av = S.p[j].avail[i]; s_len = S.p[j].dlen[i]; code = j;
+                }
+                else if (pl == 0) { s_tok = v.pl[1].tok[i]; s_av = v.pl[1].avail[i]; s_len = v.pl[1].dlen[i]; code = PS_OWN; }
+                else { s_tok = reqs_tok; s_av = reqs_have; s_len = reqs_len; code = PS_OWN; }
+                const uint32_t take = (s_tok == want_tok) ? (need & s_av) : 0u;
+                if (!take) continue;
+                for (uint32_t m = take; m; m &= m - 1u) {
+                    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                    sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)code << (8 * k));
+                }
+                n_copy += (uint32_t)__popc(take);
+                L = s_len; need &= ~take; have |= take;
+            }
+            if (need && (uint32_t)__popc(have) >= v.d) {                     // reconstruct_data / compute_parity
+                rc |= (need | (have << 8)) << (16 * pl);
+                n_rebuilt += (uint32_t)__popc(need);
+                have |= need; need = 0;
+            }
+            n_unsat += (uint32_t)__popc(need);
+            v.pl[pl].tok[i] = want_tok; v.pl[pl].avail[i] = (uint8_t)have; v.pl[pl].dlen[i] = L;
+            src[pl] = sb; sl[pl] = ps_shard_len(L, v.d);
+            if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
+        }
+    }
+    const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0);
+    const unsigned long long b = __ballot(work);
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (lane == 0 && b) base = atomicAdd(v.it_n, (uint32_t)__popcll(b));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (work) {
+        const uint32_t o = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        v.it_cell[o] = i; v.it_src[0][o] = src[0]; v.it_src[1][o] = src[1]; v.it_rc[o] = rc; v.it_sl[0][o] = sl[0]; v.it_sl[1][o] = sl[1];
+    }
+    uint32_t c[4] = {n_copy, n_rebuilt, n_unsat, n_rekey};
+    for (int k = 0; k < 4; k++) {
+        uint32_t x = c[k];
+        for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+        if (lane == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
+    }
+}
+
+// one wavefront per listed cell, a lane per 16-byte column; plane 0 first (plane 1 may copy from it)
+__global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) {
+    const uint32_t n_items = *v.it_n;
+    const uint32_t lane = threadIdx.x & 63u, nw = gridDim.x * 4u;
+    for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < n_items; it += nw) {
+        const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G, rcw = v.it_rc[it];
+        for (int pl = 0; pl < 2; pl++) {
+            const uint64_t sb = v.it_src[pl][it];
+            const uint32_t rc = (rcw >> (16 * pl)) & 0xFFFFu, sl = v.it_sl[pl][it];
+            if (sb == PS_NO_SRC && !rc) continue;
+            uint8_t *mine = v.pl[pl].bytes;
+            for (uint32_t c0 = lane * 16u; c0 < sl; c0 += 64u * 16u) {
+                for (uint32_t k = 0; k < v.n; k++) {
+                    const uint32_t s = (uint32_t)(sb >> (8 * k)) & 0xFFu;
+                    if (s == PS_NONE) continue;
+                    ps_u32x4 x = {0u, 0u, 0u, 0u};
+                    if (s != PS_EMPTY) x = ps_load16((s == PS_OWN ? v.pl[1 - pl].bytes : S.p[s].bytes) + ps_off(v, row, k, g) + c0);
+                    ps_store16(mine + ps_off(v, row, k, g) + c0, x);
+                }
+                if (rc) ps_rebuild(v, mine, row, g, c0, rc & 0xFFu, rc >> 8);
+            }
+        }
+    }
+}
+
+// rscoding.rs:583-609 for a list of instances: item i = (group[i] or i, slot[i]) -> out[i][0 .. dlen)
+__global__ __launch_bounds__(256) void ps_get_kernel(const PsView v, uint32_t n_items, const uint32_t *__restrict__ group,
+                                                     const uint32_t *__restrict__ slot, const uint32_t *__restrict__ expect, uint8_t *__restrict__ out,
+                                                     uint64_t out_stride, uint32_t *__restrict__ len_out, uint8_t *__restrict__ ok, uint32_t nblk) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t it = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    if (it >= n_items) return;
+    const uint32_t g = group ? group[it] : it, s = slot[it];
+    bool good = s != PS_NULL && g < v.G;
+    uint32_t row = 0, L = 0;
+    if (good) {
+        row = s & v.Wmask;
+        const size_t i = (size_t)row * v.G + g;
+        const uint32_t dm = (1u << v.d) - 1u, tok = v.pl[0].tok[i];
+        L = v.pl[0].dlen[i];
+        good = tok != PS_NULL && (v.pl[0].avail[i] & dm) == dm && (!expect || expect[it] == tok) && L <= out_stride;
+    }
+    if (blk == 0) { ok[it] = good ? 1 : 0; len_out[it] = good ? L : 0u; }
+    if (!good) return;
+    const uint32_t sl = ps_shard_len(L, v.d), c0 = blk * 16u;
+    if (c0 >= sl) return;
+    uint8_t *dst = out + (size_t)it * out_stride;
+    for (uint32_t c = 0; c < v.d; c++) {
+        const uint32_t o = c * sl + c0;                                   // offset in the serialized bytes
+        if (o >= L) break;
+        uint32_t nb = sl - c0 < 16u ? sl - c0 : 16u;
+        if (L - o < nb) nb = L - o;
+        const uint8_t *p = v.pl[0].bytes + ps_off(v, row, c, g) + c0;
+        if (nb == 16u) ps_store16(dst + o, ps_load16(p));
+        else for (uint32_t b = 0; b < nb; b++) dst[o + b] = p[b];
+    }
+}
+
+// ---- host: GF(2^8) matrices for the rebuild table ------------------------------------------------------------------
+struct PsGf {
+    uint8_t exp[512], log[256];
+    PsGf() {
+        int x = 1;
+        for (int i = 0; i < 255; i++) {
+            exp[i] = (uint8_t)x; log[x] = (uint8_t)i;
+            x <<= 1; if (x & 0x100) x ^= 0x11D;
+        }
+        for (int i = 255; i < 512; i++) exp[i] = exp[i - 255];
+        log[0] = 0;
+    }
+    uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+    uint8_t inv(uint8_t a) const { return exp[255 - log[a]]; }
+};
+// Gauss-Jordan inverse of a d x d matrix (row major, stride 8); false if singular
+static bool ps_invert(const PsGf &gf, uint8_t (*m)[PS_MAX_N], int d) {
+    uint8_t aug[PS_MAX_N][2 * PS_MAX_N] = {};
+    for (int r = 0; r < d; r++) {
+        for (int c = 0; c < d; c++) aug[r][c] = m[r][c];
+        aug[r][d + r] = 1;
+    }
+    for (int c = 0; c < d; c++) {
+        int piv = -1;
+        for (int r = c; r < d; r++) if (aug[r][c]) { piv = r; break; }
+        if (piv < 0) return false;
+        if (piv != c) for (int k = 0; k < 2 * d; k++) { const uint8_t t = aug[c][k]; aug[c][k] = aug[piv][k]; aug[piv][k] = t; }
+        const uint8_t iv = gf.inv(aug[c][c]);
+        for (int k = 0; k < 2 * d; k++) aug[c][k] = gf.mul(aug[c][k], iv);
+        for (int r = 0; r < d; r++) {
+            if (r == c || !aug[r][c]) continue;
+            const uint8_t f = aug[r][c];
+            for (int k = 0; k < 2 * d; k++) aug[r][k] ^= gf.mul(f, aug[c][k]);
+        }
+    }
+    for (int r = 0; r < d; r++) for (int c = 0; c < d; c++) m[r][c] = aug[r][d + c];
+    return true;
+}
+// table[pat][r][c]: every shard r from the first d present shards of pat (ReedSolomon::reconstruct: the sub-matrix of the
+// first d present rows of the coding matrix, inverted; then the coding matrix times it)
+static bool ps_build_table(int n, int d, std::vector<uint8_t> &tab) {
+    std::vector<uint8_t> M((size_t)n * d);
+    if (smr_rs_matrix(d, n - d, M.data()) != SMR_OK) return false;
+    const PsGf gf;
+    tab.assign(256 * 64, 0);
+    for (int pat = 0; pat < (1 << n); pat++) {
+        if (__builtin_popcount((unsigned)pat) < d) continue;
+        uint8_t sub[PS_MAX_N][PS_MAX_N] = {};
+        int idx = 0;
+        for (int k = 0; k < n && idx < d; k++)
+            if ((pat >> k) & 1) { for (int c = 0; c < d; c++) sub[idx][c] = M[(size_t)k * d + c]; idx++; }
+        if (!ps_invert(gf, sub, d)) return false;
+        for (int r = 0; r < n; r++)
+            for (int c = 0; c < d; c++) {
+                uint8_t acc = 0;
+                for (int k = 0; k < d; k++) acc ^= gf.mul(M[(size_t)r * d + k], sub[k][c]);
+                tab[(size_t)pat * 64 + r * 8 + c] = acc;
+            }
+    }
+    return true;
+}
+
+}  // namespace smr
+
+using namespace smr;
+
+struct smr_rsp_pstore {
+    PsView v;
+    uint64_t plane_bytes;
+    uint32_t max_data_len;
+    void *meta;            // one allocation: tok / avail / dlen of both planes, the table, the list, the counters
+};
+
+extern "C" {
+
+int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
+                          smr_rsp_pstore **out) {
+    if (!out) return fail(SMR_ERR_ARG, "pstore: null argument");
+    if (n_groups == 0) return fail(SMR_ERR_ARG, "pstore: n_groups is zero");
+    if (n_shards < 2 || n_shards > PS_MAX_N || n_data_shards == 0 || n_data_shards >= n_shards)
+        return fail(SMR_ERR_ARG, "pstore: need 1 <= data shards < shards <= 8");
+    if (!window || (window & (window - 1))) return fail(SMR_ERR_ARG, "pstore: window must be a power of two");
+    if (max_data_len == 0) return fail(SMR_ERR_ARG, "pstore: max_data_len is zero");
+    if ((uint64_t)window * n_groups > 0xFFFFFFFFull) return fail(SMR_ERR_ARG, "pstore: window x groups exceeds 2^32 cells");
+    std::vector<uint8_t> tab;
+    if (!ps_build_table((int)n_shards, (int)n_data_shards, tab)) return fail(SMR_ERR_ARG, "pstore: bad scheme");
+    smr_rsp_pstore *s = new smr_rsp_pstore();
+    memset(&s->v, 0, sizeof(s->v));
+    PsView &v = s->v;
+    v.G = n_groups; v.W = window; v.Wmask = window - 1; v.n = n_shards; v.d = n_data_shards;
+    const uint32_t sl = (max_data_len + n_data_shards - 1) / n_data_shards;
+    v.cap_sl = (sl + 15u) / 16u * 16u;
+    s->max_data_len = max_data_len;
+    s->plane_bytes = (uint64_t)window * n_shards * n_groups * v.cap_sl;
+    const size_t cells = (size_t)window * n_groups;
+    Arena a;
+    size_t o_tok[2], o_av[2], o_len[2], o_src[2], o_sl[2];
+    for (int p = 0; p < 2; p++) { o_tok[p] = a.reserve(cells * 4); o_av[p] = a.reserve(cells); o_len[p] = a.reserve(cells * 4); }
+    const size_t o_mat = a.reserve(tab.size()), o_n = a.reserve(256), o_cell = a.reserve(cells * 4);
+    for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
+    const size_t o_rc = a.reserve(cells * 4), o_ctr = a.reserve(SMR_CTR_WORDS * 8);
+    a.size = a.used + 256;
+    hipError_t err = hipMalloc((void **)&a.base, a.size);
+    for (int p = 0; p < 2 && err == hipSuccess; p++) err = hipMalloc((void **)&v.pl[p].bytes, s->plane_bytes);
+    if (err == hipSuccess) err = hipMemset(a.base, 0, a.size);
+    for (int p = 0; p < 2 && err == hipSuccess; p++) {
+        v.pl[p].tok = a.at<uint32_t>(o_tok[p]); v.pl[p].avail = a.at<uint8_t>(o_av[p]); v.pl[p].dlen = a.at<uint32_t>(o_len[p]);
+        v.it_src[p] = a.at<uint64_t>(o_src[p]); v.it_sl[p] = a.at<uint32_t>(o_sl[p]);
+        err = hipMemset(v.pl[p].tok, 0xFF, cells * 4);
+        if (err == hipSuccess) err = hipMemset(v.pl[p].bytes, 0, s->plane_bytes);
+    }
+    if (err == hipSuccess) err = hipMemcpy(a.base + o_mat, tab.data(), tab.size(), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        for (int p = 0; p < 2; p++) if (v.pl[p].bytes) (void)hipFree(v.pl[p].bytes);
+        if (a.base) (void)hipFree(a.base);
+        delete s;
+        return fail(SMR_ERR_DEVICE, std::string("pstore: allocation: ") + hipGetErrorString(err));
+    }
+    v.mat = a.at<uint8_t>(o_mat); v.it_n = a.at<uint32_t>(o_n); v.it_cell = a.at<uint32_t>(o_cell); v.it_rc = a.at<uint32_t>(o_rc);
+    v.counters = a.at<unsigned long long>(o_ctr);
+    s->meta = a.base;
+    *out = s;
+    return SMR_OK;
+}
+
+void smr_rsp_pstore_destroy(smr_rsp_pstore *s) {
+    if (!s) return;
+    for (int p = 0; p < 2; p++) if (s->v.pl[p].bytes) (void)hipFree(s->v.pl[p].bytes);
+    if (s->meta) (void)hipFree(s->meta);
+    delete s;
+}
+
+int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
+                       const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, void *stream) {
+    if (!s || !a_n_dev || !a_slot_dev || !a_val_dev || !data_dev) return fail(SMR_ERR_ARG, "pstore put: null argument");
+    if (data_len == 0 || data_len > s->max_data_len) return fail(SMR_ERR_ARG, "pstore put: data_len must be in 1..max_data_len");
+    if (data_stride < data_len) return fail(SMR_ERR_ARG, "pstore put: data_stride is shorter than data_len");
+    const PsView &v = s->v;
+    const uint32_t nblk = ((data_len + v.d - 1) / v.d + 15u) / 16u;
+    const uint64_t threads = (uint64_t)v.G * nblk;
+    hipLaunchKernelGGL(ps_put_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev,
+                       a_val_dev, data_dev, data_stride, len_dev, data_len, nblk);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
+                          const uint8_t *sel_dev, void *stream) {
+    if (!s || !e || (n_src && (!src || !src_plane))) return fail(SMR_ERR_ARG, "pstore follow: null argument");
+    if (n_src > PS_MAX_SRC) return fail(SMR_ERR_ARG, "pstore follow: at most 16 sources");
+    const PsView &v = s->v;
+    const RspPeek pk = rsp_peek(e);
+    if (pk.G != v.G || pk.W != v.W || pk.R != v.n || pk.majority != v.d)
+        return fail(SMR_ERR_ARG, "pstore follow: the replica's groups / window / population / majority differ from the store's");
+    PsSrcs S;
+    memset(&S, 0, sizeof(S));
+    S.n = n_src;
+    for (uint32_t j = 0; j < n_src; j++) {
+        const smr_rsp_pstore *o = src[j];
+        if (!o) continue;                                                    // an empty seat (e.g. my own id in a list indexed by replica)
+        if (src_plane[j] > 1) return fail(SMR_ERR_ARG, "pstore follow: bad source plane");
+        if (o == s) return fail(SMR_ERR_ARG, "pstore follow: a store's own planes are sources already");
+        if (o->v.G != v.G || o->v.W != v.W || o->v.n != v.n || o->v.d != v.d || o->v.cap_sl != v.cap_sl)
+            return fail(SMR_ERR_ARG, "pstore follow: a source has another geometry");
+        S.p[j] = o->v.pl[src_plane[j]];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    SMR_HIP_TRY(hipMemsetAsync(v.it_n, 0, 4, st));
+    const uint32_t cells = v.W * v.G;
+    hipLaunchKernelGGL(ps_plan_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev);
+    SMR_HIP_TRY(hipGetLastError());
+    uint32_t blocks = (cells + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ps_bytes_kernel, dim3(blocks), dim3(256), 0, st, v, S);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
+                            uint8_t *out_dev, uint64_t out_stride, uint32_t *len_out_dev, uint8_t *ok_dev, void *stream) {
+    if (!s || !slot_dev || !out_dev || !len_out_dev || !ok_dev) return fail(SMR_ERR_ARG, "pstore get_data: null argument");
+    if (n_items == 0) return SMR_OK;
+    if (!group_dev && n_items > s->v.G) return fail(SMR_ERR_ARG, "pstore get_data: more items than groups without a group list");
+    const PsView &v = s->v;
+    const uint32_t nblk = v.cap_sl / 16u;
+    const uint64_t threads = (uint64_t)n_items * nblk;
+    hipLaunchKernelGGL(ps_get_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n_items, group_dev, slot_dev,
+                       expect_dev, out_dev, out_stride, len_out_dev, ok_dev, nblk);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_t *avail_host, uint32_t *dlen_host) {
+    if (!s || plane < 0 || plane > 1) return fail(SMR_ERR_ARG, "pstore dump: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const size_t cells = (size_t)s->v.W * s->v.G;
+    if (tok_host) SMR_HIP_TRY(hipMemcpy(tok_host, s->v.pl[plane].tok, cells * 4, hipMemcpyDeviceToHost));
+    if (avail_host) SMR_HIP_TRY(hipMemcpy(avail_host, s->v.pl[plane].avail, cells, hipMemcpyDeviceToHost));
+    if (dlen_host) SMR_HIP_TRY(hipMemcpy(dlen_host, s->v.pl[plane].dlen, cells * 4, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host) {
+    if (!s || plane < 0 || plane > 1 || !bytes_host) return fail(SMR_ERR_ARG, "pstore read_row: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    const size_t row_bytes = (size_t)s->v.n * s->v.G * s->v.cap_sl;
+    SMR_HIP_TRY(hipMemcpy(bytes_host, s->v.pl[plane].bytes + (size_t)(slot & s->v.Wmask) * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,
+                          uint64_t *group_stride) {
+    if (!s || plane < 0 || plane > 1) return fail(SMR_ERR_ARG, "pstore layout: bad argument");
+    if (bytes_dev) *bytes_dev = s->v.pl[plane].bytes;
+    if (row_stride) *row_stride = (uint64_t)s->v.n * s->v.G * s->v.cap_sl;
+    if (shard_stride) *shard_stride = (uint64_t)s->v.G * s->v.cap_sl;
+    if (group_stride) *group_stride = s->v.cap_sl;
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host) {
+    if (!s || !out4_host) return fail(SMR_ERR_ARG, "pstore counters: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[4];
+    SMR_HIP_TRY(ctr_read(s->v.counters, 4, c));
+    for (int k = 0; k < 4; k++) out4_host[k] = c[k];
+    return SMR_OK;
+}
+
+}  // extern "C"

@@ -244,6 +244,18 @@ def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):
         t.test_tokens_are_real_shard_bytes("cpu", oracle)
 
 
+def test_rspaxos_payload_store_on_the_host(sim, oracle):
+    """the shard bytes behind the replicas' masks (csrc/rsp_payload.hip) through leader changes, against the oracle's codewords"""
+    import test_zz_rsp_payload_gpu as t
+    with sim.patched():
+        tot, n_exec, n_cmp = t.run_closed_loop("cpu", oracle, 40, 16, 1, 0.1, 77, T=15)
+        assert tot["rebuilt"] > 0 and n_exec > 0
+        t.run_closed_loop("cpu", oracle, 24, 8, 0, 0.0, 20, T=12)
+        t.test_steady_tick_is_one_put_and_one_shard_per_follower("cpu", oracle)
+        t.test_rows_are_shard_major_batches_the_rs_kernels_accept("cpu", oracle)
+        t.test_argument_errors("cpu")
+
+
 def test_accept_reply_records_on_the_host(sim, oracle):
     """the AcceptReply record <-> ack matrix kernels (smr_mp_collect_acks / smr_mp_deliver_acks) under the emulator"""
     import test_mp_gpu as t
