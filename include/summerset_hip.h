@@ -874,6 +874,9 @@ int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_h
  * k * shard_stride + g * group_stride -- a row is a shard-major batch smr_rs_reconstruct / smr_rs_verify accept),
  * _counters: shards copied, shards rebuilt, shards the engine has that no source could give (0 in a correct run),
  * rows whose token changed while they held shards.  n_shards = the population (<= 8), n_data_shards = the majority.
+ * The calls on one store only enqueue work and must be issued on ONE stream at a time (their scratch list is the store's);
+ * a source's rows must not be written by another stream meanwhile.  A message is consumed in the tick that produced it: the
+ * sender's row must still hold the token the message named when the receiver's follow runs (or go through _extract / _ingest).
  * ---------------------------------------------------------------------- */
 typedef struct smr_rsp_pstore smr_rsp_pstore;
 int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
@@ -885,6 +888,18 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
                           const uint8_t *sel_dev, void *stream);
 int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
                             uint8_t *out_dev, uint64_t out_stride, uint32_t *len_out_dev, uint8_t *ok_dev, void *stream);
+/* The payload of a message between replicas on DIFFERENT devices / hosts.  A message buffer is laid out like one row: shard k of
+ * group g at k * shard_stride + g * group_stride (smr_rsp_pstore_layout), n_shards x G x group_stride bytes.
+ *   _extract  sender: RSCodeword::subset_copy (rscoding.rs:255-293) -- per group g with flags_dev[g] != 0 (NULL: all) the shards
+ *             mask_dev[g] of row slot_dev[g] of `plane` that the row holds go to out_dev; tok_out / mask_out / dlen_out [G] = the
+ *             codeword's header (token SMR_RSP_NULL, mask 0: nothing)
+ *   _ingest   receiver: row slot_dev[g] of `plane` of a STAGING store (same geometry as the replica's store) := that header and
+ *             those bytes, replacing what it held; smr_rsp_pstore_follow then names (staging, plane) as the source behind the
+ *             handler call that consumes the message.  Only enqueue work on `stream`. */
+int smr_rsp_pstore_extract(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint8_t *mask_dev,
+                           uint8_t *out_dev, uint32_t *tok_out_dev, uint8_t *mask_out_dev, uint32_t *dlen_out_dev, void *stream);
+int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint32_t *tok_dev,
+                          const uint8_t *mask_dev, const uint32_t *dlen_dev, const uint8_t *in_dev, void *stream);
 int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_t *avail_host, uint32_t *dlen_host);
 int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host);
 int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,

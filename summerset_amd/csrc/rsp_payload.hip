@@ -47,7 +47,8 @@ struct PsView {
     uint32_t G, W, Wmask, n, d, cap_sl;
     PsPlane pl[2];
     const uint8_t *mat;    // [256][8][8]: shard r = XOR_c mat[pat][r][c] * (c-th present shard of pat)
-    uint32_t *it_n;        // the list of cells with work: count, then per item the cell, per plane the shards' sources
+    uint32_t *it_n;        // the list of cells with work: count (it_n[flip]; the plan kernel zeroes it_n[flip ^ 1] for the next
+    uint32_t flip;         // call, so no memset launch sits in front of it), then per item the cell, per plane the shards' sources
     uint32_t *it_cell;     // (8 bits each), the shards to rebuild | the pattern to rebuild from, and the shard length
     uint64_t *it_src[2];
     uint32_t *it_rc;
@@ -75,34 +76,65 @@ __device__ __forceinline__ uint32_t ps_xtime4(uint32_t x) {               // 4 p
     const uint32_t hi = x & 0x80808080u;
     return ((x << 1) & 0xFEFEFEFEu) ^ ((hi - (hi >> 7)) & 0x1D1D1D1Du);
 }
-// acc ^= c * x over 16 bytes, c a per-lane coefficient
-__device__ __forceinline__ void ps_axpy16(ps_u32x4 &acc, ps_u32x4 x, uint32_t c) {
-    while (c) {
-        if (c & 1u) acc ^= x;
-        x.x = ps_xtime4(x.x); x.y = ps_xtime4(x.y); x.z = ps_xtime4(x.z); x.w = ps_xtime4(x.w);
-        c >>= 1;
-    }
-}
-// the shards in `need` of cell (row, g), columns [c0, c0 + 16), from the first d shards of `pat` (all in `base`'s plane)
+// the shards in `need` of cell (row, g), columns [c0, c0 + 16), from the first d shards of `pat` (all in `base`'s plane).
+// Per output row a Horner scheme over the coefficient BIT PLANES, as rs_kernels.hip evaluates its products:
+//     out_r = XOR_b 2^b * (XOR_{c : bit b of m[r][c]} in_c) = (..(P_hb * 2 ^ P_hb-1) * 2 ^ ..) * 2 ^ P_0
+// -- (highest coefficient bit) doublings per row instead of 8 per coefficient (RS(3,2) parity: 0 and 3).  The coefficients are
+// per-lane values (a lane's own erasure pattern); in ps_put_kernel they are wave-uniform and the plane tests scalar.
 __device__ __forceinline__ void ps_rebuild(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
                                            uint32_t pat) {
     const uint8_t *m = v.mat + (size_t)pat * 64;
-    ps_u32x4 acc[PS_MAX_N];
-#pragma unroll
-    for (int r = 0; r < (int)PS_MAX_N; r++) acc[r] = (ps_u32x4){0u, 0u, 0u, 0u};
+    ps_u32x4 in[PS_MAX_N];
     uint32_t p = pat;
-    for (uint32_t c = 0; c < v.d; c++) {
-        const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
-        p &= p - 1u;
-        const ps_u32x4 x = ps_load16(base + ps_off(v, row, k, g) + c0);
 #pragma unroll
-        for (int r = 0; r < (int)PS_MAX_N; r++)
-            if ((need >> r) & 1u) ps_axpy16(acc[r], x, m[r * 8 + c]);
+    for (int c = 0; c < (int)PS_MAX_N; c++) {
+        in[c] = (ps_u32x4){0u, 0u, 0u, 0u};
+        if (c < (int)v.d) {
+            const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
+            p &= p - 1u;
+            in[c] = ps_load16(base + ps_off(v, row, k, g) + c0);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < (int)PS_MAX_N; r++)
-        if ((need >> r) & 1u) ps_store16(base + ps_off(v, row, (uint32_t)r, g) + c0, acc[r]);
+    for (int r = 0; r < (int)PS_MAX_N; r++) {
+        if (!((need >> r) & 1u)) continue;
+        uint32_t co[PS_MAX_N], any = 0;
+#pragma unroll
+        for (int c = 0; c < (int)PS_MAX_N; c++) { co[c] = c < (int)v.d ? m[r * 8 + c] : 0u; any |= co[c]; }
+        ps_u32x4 acc = {0u, 0u, 0u, 0u};
+        for (int b = any ? 31 - __clz((int)any) : -1; b >= 0; b--) {
+            acc.x = ps_xtime4(acc.x); acc.y = ps_xtime4(acc.y); acc.z = ps_xtime4(acc.z); acc.w = ps_xtime4(acc.w);
+#pragma unroll
+            for (int c = 0; c < (int)PS_MAX_N; c++)
+                if ((co[c] >> b) & 1u) acc ^= in[c];
+        }
+        ps_store16(base + ps_off(v, row, (uint32_t)r, g) + c0, acc);
+    }
 }
+// the same product with nothing held across rows: per output row a walk over the d inputs (re-read, they are this lane's own
+// cache lines by now), one bit-serial multiply-accumulate per coefficient.  For the byte kernel, whose common path is plain copies:
+// the Horner form's 8 x 16-byte input registers would set every wavefront's register budget (196 VGPRs, two wavefronts per SIMD)
+// for a path that runs at leader changes only.
+__device__ __forceinline__ void ps_rebuild_small(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
+                                                 uint32_t pat) {
+    const uint8_t *m = v.mat + (size_t)pat * 64;
+    for (uint32_t nd = need; nd; nd &= nd - 1u) {
+        const uint32_t r = (uint32_t)__ffs((int)nd) - 1u;
+        ps_u32x4 acc = {0u, 0u, 0u, 0u};
+        uint32_t p = pat;
+        for (uint32_t c = 0; c < v.d; c++) {
+            const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
+            p &= p - 1u;
+            ps_u32x4 x = ps_load16(base + ps_off(v, row, k, g) + c0);
+            for (uint32_t co = m[r * 8 + c]; co; co >>= 1) {
+                if (co & 1u) acc ^= x;
+                x.x = ps_xtime4(x.x); x.y = ps_xtime4(x.y); x.z = ps_xtime4(x.z); x.w = ps_xtime4(x.w);
+            }
+        }
+        ps_store16(base + ps_off(v, row, r, g) + c0, acc);
+    }
+}
+
 // 16 bytes of a serialized batch from offset `off`; bytes at or beyond `lim` read as zero (from_data's padding,
 // rscoding.rs:188-189, and the next shard's bytes)
 __device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t off, uint32_t lim) {
@@ -176,7 +208,10 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
                 }
                 have |= need; need = 0; L = 1;
             }
-            for (uint32_t j = 0; j <= S.n && need; j++) {
+            // sources in order: the voted plane asks my own reqs plane FIRST (its new state is in registers: no load, and the byte
+            // kernel forwards the shard it has just stored there); the reqs plane asks the named sources, then my own voted plane
+            for (uint32_t jj = 0; jj <= S.n && need; jj++) {
+                const uint32_t j = pl == 1 ? (jj == 0 ? S.n : jj - 1u) : jj;
                 uint32_t s_tok, s_av, s_len, code;
                 if (j < S.n) {
                     if (!S.p[j].tok || (sel && only != j)) continue;
@@ -208,7 +243,8 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     const unsigned long long b = __ballot(work);
     const uint32_t lane = __lane_id();
     uint32_t base = 0;
-    if (lane == 0 && b) base = atomicAdd(v.it_n, (uint32_t)__popcll(b));
+    if (t == 0) v.it_n[v.flip ^ 1u] = 0;                                   // the next call's counter (this stream runs it after my byte kernel)
+    if (lane == 0 && b) base = atomicAdd(&v.it_n[v.flip], (uint32_t)__popcll(b));
     base = (uint32_t)__shfl((int)base, 0);
     if (work) {
         const uint32_t o = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
@@ -222,27 +258,49 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     }
 }
 
-// one wavefront per listed cell, a lane per 16-byte column; plane 0 first (plane 1 may copy from it)
+// one wavefront per listed cell, a lane per 16-byte column; plane 0 first (plane 1 may copy from it).  Where plane 0 is only
+// copied into, a shard goes through both planes in one step: what plane 1 takes from plane 0 ("own other plane": a follower's
+// vote is the shard it has just been sent) is the register that was stored there, not a read back.
 __global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) {
-    const uint32_t n_items = *v.it_n;
+    const uint32_t n_items = v.it_n[v.flip];
     const uint32_t lane = threadIdx.x & 63u, nw = gridDim.x * 4u;
     for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < n_items; it += nw) {
         const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G, rcw = v.it_rc[it];
-        for (int pl = 0; pl < 2; pl++) {
-            const uint64_t sb = v.it_src[pl][it];
-            const uint32_t rc = (rcw >> (16 * pl)) & 0xFFFFu, sl = v.it_sl[pl][it];
-            if (sb == PS_NO_SRC && !rc) continue;
-            uint8_t *mine = v.pl[pl].bytes;
-            for (uint32_t c0 = lane * 16u; c0 < sl; c0 += 64u * 16u) {
-                for (uint32_t k = 0; k < v.n; k++) {
-                    const uint32_t s = (uint32_t)(sb >> (8 * k)) & 0xFFu;
-                    if (s == PS_NONE) continue;
-                    ps_u32x4 x = {0u, 0u, 0u, 0u};
-                    if (s != PS_EMPTY) x = ps_load16((s == PS_OWN ? v.pl[1 - pl].bytes : S.p[s].bytes) + ps_off(v, row, k, g) + c0);
-                    ps_store16(mine + ps_off(v, row, k, g) + c0, x);
+        const uint64_t sb0 = v.it_src[0][it], sb1 = v.it_src[1][it];
+        const uint32_t rc0 = rcw & 0xFFFFu, rc1 = rcw >> 16, sl0 = v.it_sl[0][it], sl1 = v.it_sl[1][it];
+        const bool w0 = sb0 != PS_NO_SRC || rc0, w1 = sb1 != PS_NO_SRC || rc1;
+        const uint32_t e0 = w0 ? sl0 : 0u, e1 = w1 ? sl1 : 0u;
+        for (uint32_t c0 = lane * 16u; c0 < (e0 > e1 ? e0 : e1); c0 += 64u * 16u) {
+            const bool in0 = c0 < e0, in1 = c0 < e1;
+            for (uint32_t k = 0; k < v.n; k++) {
+                const size_t o = ps_off(v, row, k, g) + c0;
+                const uint32_t s0 = in0 ? (uint32_t)(sb0 >> (8 * k)) & 0xFFu : PS_NONE;
+                ps_u32x4 x = {0u, 0u, 0u, 0u};
+                if (s0 != PS_NONE) {
+                    if (s0 != PS_EMPTY) x = ps_load16((s0 == PS_OWN ? v.pl[1].bytes : S.p[s0].bytes) + o);
+                    ps_store16(v.pl[0].bytes + o, x);
                 }
-                if (rc) ps_rebuild(v, mine, row, g, c0, rc & 0xFFu, rc >> 8);
+                if (rc0) continue;                                          // plane 1 waits for plane 0's rebuild (below)
+                const uint32_t s1 = in1 ? (uint32_t)(sb1 >> (8 * k)) & 0xFFu : PS_NONE;
+                if (s1 == PS_NONE) continue;
+                if (!(s1 == PS_OWN && s0 != PS_NONE)) {                     // (else: x is what plane 0 holds there now)
+                    x = (ps_u32x4){0u, 0u, 0u, 0u};
+                    if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
+                }
+                ps_store16(v.pl[1].bytes + o, x);
             }
+            if (rc0) {
+                if (in0) ps_rebuild_small(v, v.pl[0].bytes, row, g, c0, rc0 & 0xFFu, rc0 >> 8);
+                for (uint32_t k = 0; k < v.n && in1; k++) {
+                    const uint32_t s1 = (uint32_t)(sb1 >> (8 * k)) & 0xFFu;
+                    if (s1 == PS_NONE) continue;
+                    const size_t o = ps_off(v, row, k, g) + c0;
+                    ps_u32x4 x = {0u, 0u, 0u, 0u};
+                    if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
+                    ps_store16(v.pl[1].bytes + o, x);
+                }
+            }
+            if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8);
         }
     }
 }
@@ -278,6 +336,46 @@ __global__ __launch_bounds__(256) void ps_get_kernel(const PsView v, uint32_t n_
         if (nb == 16u) ps_store16(dst + o, ps_load16(p));
         else for (uint32_t b = 0; b < nb; b++) dst[o + b] = p[b];
     }
+}
+
+// The payload of a message, sender side: RSCodeword::subset_copy (rscoding.rs:255-293) of row slot[g] into a message buffer laid
+// out like one row ([n][G][cap_sl]); what the row does not hold stays out of mask_out.  One lane per (group, 16-byte column).
+__global__ __launch_bounds__(256) void ps_extract_kernel(const PsView v, int plane, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ slot,
+                                                         const uint8_t *__restrict__ mask, uint8_t *__restrict__ out, uint32_t *__restrict__ tok_out,
+                                                         uint8_t *__restrict__ mask_out, uint32_t *__restrict__ dlen_out, uint32_t nblk) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    if (g >= v.G) return;
+    const bool on = (!flags || flags[g]) && slot[g] != PS_NULL;
+    const uint32_t row = on ? (slot[g] & v.Wmask) : 0u;
+    const size_t i = (size_t)row * v.G + g;
+    const uint32_t tok = on ? v.pl[plane].tok[i] : PS_NULL;
+    const uint32_t m = (on && tok != PS_NULL) ? ((uint32_t)mask[g] & v.pl[plane].avail[i]) : 0u;
+    const uint32_t L = m ? v.pl[plane].dlen[i] : 0u;
+    if (blk == 0) { tok_out[g] = m ? tok : PS_NULL; mask_out[g] = (uint8_t)m; dlen_out[g] = L; }
+    const uint32_t c0 = blk * 16u;
+    if (!m || c0 >= ps_shard_len(L, v.d)) return;
+    for (uint32_t k = 0; k < v.n; k++)
+        if ((m >> k) & 1u) ps_store16(out + ((size_t)k * v.G + g) * v.cap_sl + c0, ps_load16(v.pl[plane].bytes + ps_off(v, row, k, g) + c0));
+}
+
+// ... and receiver side: the codeword a message carried becomes row slot[g] of a (staging) store -- token, shards present, length
+// and bytes REPLACE what the row held -- for smr_rsp_pstore_follow to name as the source behind the handler that consumes the message
+__global__ __launch_bounds__(256) void ps_ingest_kernel(const PsView v, int plane, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ slot,
+                                                        const uint32_t *__restrict__ tok, const uint8_t *__restrict__ mask,
+                                                        const uint32_t *__restrict__ dlen, const uint8_t *__restrict__ in, uint32_t nblk) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    if (g >= v.G || (flags && !flags[g]) || slot[g] == PS_NULL) return;
+    const uint32_t row = slot[g] & v.Wmask;
+    const size_t i = (size_t)row * v.G + g;
+    uint32_t m = (uint32_t)mask[g] & ((1u << v.n) - 1u), L = dlen[g];
+    if (tok[g] == PS_NULL || L > v.cap_sl * v.d) m = 0;
+    if (blk == 0) { v.pl[plane].tok[i] = m ? tok[g] : PS_NULL; v.pl[plane].avail[i] = (uint8_t)m; v.pl[plane].dlen[i] = m ? L : 0u; }
+    const uint32_t c0 = blk * 16u;
+    if (!m || c0 >= ps_shard_len(L, v.d)) return;
+    for (uint32_t k = 0; k < v.n; k++)
+        if ((m >> k) & 1u) ps_store16(v.pl[plane].bytes + ps_off(v, row, k, g) + c0, ps_load16(in + ((size_t)k * v.G + g) * v.cap_sl + c0));
 }
 
 // ---- host: GF(2^8) matrices for the rebuild table ------------------------------------------------------------------
@@ -447,7 +545,7 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
         S.p[j] = o->v.pl[src_plane[j]];
     }
     hipStream_t st = (hipStream_t)stream;
-    SMR_HIP_TRY(hipMemsetAsync(v.it_n, 0, 4, st));
+    s->v.flip ^= 1u;                               // (calls on one store are issued on one stream at a time: the header says so)
     const uint32_t cells = v.W * v.G;
     hipLaunchKernelGGL(ps_plan_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev);
     SMR_HIP_TRY(hipGetLastError());
@@ -468,6 +566,31 @@ int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t 
     const uint64_t threads = (uint64_t)n_items * nblk;
     hipLaunchKernelGGL(ps_get_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n_items, group_dev, slot_dev,
                        expect_dev, out_dev, out_stride, len_out_dev, ok_dev, nblk);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_extract(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint8_t *mask_dev,
+                           uint8_t *out_dev, uint32_t *tok_out_dev, uint8_t *mask_out_dev, uint32_t *dlen_out_dev, void *stream) {
+    if (!s || plane < 0 || plane > 1 || !slot_dev || !mask_dev || !out_dev || !tok_out_dev || !mask_out_dev || !dlen_out_dev)
+        return fail(SMR_ERR_ARG, "pstore extract: bad argument");
+    const PsView &v = s->v;
+    const uint32_t nblk = v.cap_sl / 16u;
+    const uint64_t threads = (uint64_t)v.G * nblk;
+    hipLaunchKernelGGL(ps_extract_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, plane, flags_dev, slot_dev,
+                       mask_dev, out_dev, tok_out_dev, mask_out_dev, dlen_out_dev, nblk);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint32_t *tok_dev,
+                          const uint8_t *mask_dev, const uint32_t *dlen_dev, const uint8_t *in_dev, void *stream) {
+    if (!s || plane < 0 || plane > 1 || !slot_dev || !tok_dev || !mask_dev || !dlen_dev || !in_dev) return fail(SMR_ERR_ARG, "pstore ingest: bad argument");
+    const PsView &v = s->v;
+    const uint32_t nblk = v.cap_sl / 16u;
+    const uint64_t threads = (uint64_t)v.G * nblk;
+    hipLaunchKernelGGL(ps_ingest_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, plane, flags_dev, slot_dev,
+                       tok_dev, mask_dev, dlen_dev, in_dev, nblk);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -80,6 +80,25 @@ class RSPaxosPayloadStore:
                                               ln.data_ptr(), ok.data_ptr(), stream_ptr(stream)))
         return out, ln, ok.bool()
 
+    # ---- a message's payload between replicas that do not share a device ----------------------------------------------
+    def extract(self, slot, mask, plane=REQS, flags=None, out=None, stream=None):
+        """sender: `subset_copy` of the rows `slot` [G] (shards `mask` [G]) into a message: dict(buf uint8 [R, G, group_stride],
+        tok, mask, dlen [G]) -- `out`: an earlier message to refill"""
+        import torch
+        dev = slot.device
+        m = out if out is not None else dict(buf=torch.zeros((self.R, self.G, self.group_stride), dtype=torch.uint8, device=dev),
+                                             tok=torch.zeros(self.G, dtype=torch.int32, device=dev),
+                                             mask=torch.zeros(self.G, dtype=torch.uint8, device=dev),
+                                             dlen=torch.zeros(self.G, dtype=torch.int32, device=dev))
+        check(self._L.smr_rsp_pstore_extract(self._h, int(plane), _ptr(flags), _ptr(slot), _ptr(mask), m["buf"].data_ptr(), m["tok"].data_ptr(),
+                                             m["mask"].data_ptr(), m["dlen"].data_ptr(), stream_ptr(stream)))
+        return m
+
+    def ingest(self, msg, slot, plane=REQS, flags=None, stream=None):
+        """receiver: the message becomes row `slot` of this (staging) store, replacing what the row held"""
+        check(self._L.smr_rsp_pstore_ingest(self._h, int(plane), _ptr(flags), _ptr(slot), msg["tok"].data_ptr(), msg["mask"].data_ptr(),
+                                            msg["dlen"].data_ptr(), msg["buf"].data_ptr(), stream_ptr(stream)))
+
     # ---- host-side reads ------------------------------------------------------------------------------------------
     def dump(self, plane=REQS):
         tok, av, ln = np.zeros((self.W, self.G), np.uint32), np.zeros((self.W, self.G), np.uint8), np.zeros((self.W, self.G), np.uint32)
@@ -110,23 +129,26 @@ class RSPaxosReplicaWithPayload:
     they come from -- the peers' stores (`set_peers`, indexed by replica id) stand for the message's payload:
         accept(peer=s, ...)            shard {me} of the sender's REQS plane        (Accept, request.rs:127-142)
         prepare_replies(peer=q, ...)   the voted shards of q's VOTED plane          (PrepareReply, messages.rs:55-83)
-        reconstruct_reply(...)         any peer's REQS plane (the call names no sender; ReconstructReply, messages.rs:467-515)
+        reconstruct_reply(...)         the REQS plane of whoever answered the Reconstruct (ReconstructReply, messages.rs:467-515)
     every other handler moves no bytes between replicas: what its commit-bar run or prepare quorum asks for is rebuilt from
     the shards the row holds.  What a co-located cluster (every replica's store in this GPU's HBM) runs per handler; the
     lock-step schedule consumes every message in the tick that produced it, so a sender's row still holds the token the
     message named when `follow` runs."""
     HANDLERS = ("accept", "accept_replies", "become_leader", "prepare", "prepare_replies", "reconstruct", "reconstruct_reply", "heartbeat",
                 "bcast_heartbeat")
-    CARRIES = {"accept": REQS, "prepare_replies": VOTED, "reconstruct_reply": REQS}
 
-    def __init__(self, replica, store, payload=None):
-        self.replica, self.store, self.payload = replica, store, payload     # payload(val) -> (data uint8 [G, L], lens int32 [G] or None)
+    def __init__(self, replica, store, payload=None, staging=None):
+        """`staging`: a second store of the same geometry -- the replica then takes NOTHING from its peers' stores: a message's payload
+        is extracted at the sender (`subset_copy`), ingested into `staging`, and `follow` names the staging store as its only source
+        (what replicas on different devices do, with the wire between `extract` and `ingest`)"""
+        self.replica, self.store, self.payload, self.staging = replica, store, payload, staging   # payload(val) -> (data uint8 [G, L], lens int32 [G] or None)
         self.G, self.R, self.W, self.me = replica.G, replica.R, replica.W, replica.me
-        self.peers = []
+        self.cluster, self.shared, self._msg = [], {}, None
 
     def set_peers(self, cluster):
         """`cluster`: the R objects of this kind, by replica id"""
-        self.peers = [None if o is self else o.store for o in cluster]
+        self.cluster = list(cluster)
+        self.shared = cluster[0].shared                                   # (who answered the last Reconstruct: see reconstruct_reply)
 
     def req_batch(self, val, data=None, lens=None, stream=None, out=None):
         acc = self.replica.req_batch(val, stream=stream, out=out)
@@ -137,19 +159,74 @@ class RSPaxosReplicaWithPayload:
         self.store.follow(self.replica, stream=stream)
         return acc
 
+    def reconstruct(self, *a, **kw):
+        out = self.replica.reconstruct(*a, **kw)
+        self.shared["responder"] = self.me                               # the reply names no sender: the host knows who it asked
+        self.store.follow(self.replica, stream=kw.get("stream"))
+        return out
+
+    def _carry(self, sender, plane, rows, stream):
+        """ship the named rows' shards from `sender`'s plane into my staging store: rows = [(flags, slot, mask)] device tensors"""
+        for flags, slot, mask in rows:
+            self._msg = sender.store.extract(slot, mask, plane, flags, out=self._msg, stream=stream)
+            self.staging.ingest(self._msg, slot, REQS, flags, stream=stream)
+
+    def _follow_peers(self, plane, sel, stream):
+        """co-located: the peers' stores are the payload -- in group g only the store of replica sel[g] (None: any)"""
+        srcs = [None if o is self else (o.store, plane) for o in self.cluster]
+        self.store.follow(self.replica, srcs, sel=sel, stream=stream)
+
+    @staticmethod
+    def _uniform(peer):
+        p = int(peer[0].item())
+        assert bool((peer == p).all().item()), "one message = one sender: the `peer` array of a call with a staging store must be uniform"
+        return p
+
+    def accept(self, flags, peer, slot, ballot, val, mask, stream=None, out=None):
+        sender = self._uniform(peer) if self.staging is not None else None
+        if sender is not None:                                           # the Accept's shard, as the sender holds it NOW (before my handler runs)
+            self._carry(self.cluster[sender], REQS, [(flags, slot, mask)], stream)
+        res = self.replica.accept(flags, peer, slot, ballot, val, mask, stream=stream, out=out)
+        if sender is not None:
+            self.store.follow(self.replica, [(self.staging, REQS)], stream=stream)
+        else:
+            self._follow_peers(REQS, peer, stream)
+        return res
+
+    def prepare_replies(self, peer, pr_n, pr_trig, pr_endp, pr_ballot, pr_vbal, pr_vval, pr_vmask, stream=None):
+        if self.staging is not None:                                     # row k of the reply = the voted shards of slot trig + k
+            sender, n = self._uniform(peer), int(pr_n.max().item()) if pr_n.numel() else 0
+            rows = [(((pr_n > k) & (pr_vbal[k] != 0)).to(pr_vmask.dtype), pr_trig + k, pr_vmask[k].contiguous()) for k in range(min(n, self.W))]
+            self._carry(self.cluster[sender], VOTED, rows, stream)
+        res = self.replica.prepare_replies(peer, pr_n, pr_trig, pr_endp, pr_ballot, pr_vbal, pr_vval, pr_vmask, stream=stream)
+        if self.staging is not None:
+            self.store.follow(self.replica, [(self.staging, REQS)], stream=stream)
+        else:
+            self._follow_peers(VOTED, peer, stream)
+        return res
+
+    def reconstruct_reply(self, flags, rr_n, rr_slot, rr_bal, rr_val, rr_mask, stream=None, responder=None):
+        who = self.shared.get("responder") if responder is None else responder
+        if self.staging is not None:
+            n = int(rr_n.max().item()) if rr_n.numel() else 0
+            rows = [(((rr_n > k) & (flags != 0)).to(rr_mask.dtype), rr_slot[k].contiguous(), rr_mask[k].contiguous()) for k in range(min(n, self.W))]
+            self._carry(self.cluster[who], REQS, rows, stream)
+        self.replica.reconstruct_reply(flags, rr_n, rr_slot, rr_bal, rr_val, rr_mask, stream=stream)
+        if self.staging is not None:
+            self.store.follow(self.replica, [(self.staging, REQS)], stream=stream)
+        else:
+            import torch
+            sel = None if who is None else torch.full((self.G,), int(who), dtype=torch.uint8, device=flags.device)
+            self._follow_peers(REQS, sel, stream)
+
     def __getattr__(self, name):
         fn = getattr(self.replica, name)
         if name not in self.HANDLERS:
             return fn
 
-        def call(*a, **kw):
+        def call(*a, **kw):                                              # handlers that move no bytes between replicas
             out = fn(*a, **kw)
-            plane = self.CARRIES.get(name)
-            if plane is None:
-                self.store.follow(self.replica, stream=kw.get("stream"))
-            else:
-                peer = kw.get("peer", a[1] if name == "accept" and len(a) > 1 else (a[0] if name == "prepare_replies" and a else None))
-                self.store.follow(self.replica, [None if p is None else (p, plane) for p in self.peers], sel=peer, stream=kw.get("stream"))
+            self.store.follow(self.replica, stream=kw.get("stream"))
             return out
         return call
 

@@ -253,6 +253,9 @@ def test_rspaxos_payload_store_on_the_host(sim, oracle):
         t.run_closed_loop("cpu", oracle, 24, 8, 0, 0.0, 20, T=12)
         t.test_steady_tick_is_one_put_and_one_shard_per_follower("cpu", oracle)
         t.test_rows_are_shard_major_batches_the_rs_kernels_accept("cpu", oracle)
+        t.test_extract_and_ingest_round_trip("cpu", oracle)
+        tot, n_exec, n_cmp = t.run_closed_loop("cpu", oracle, 40, 16, 1, 0.1, 77, T=15, staging=True)    # bytes travel as messages only
+        assert tot["rebuilt"] > 0 and n_exec > 0
         t.test_argument_errors("cpu")
 
 
@@ -411,6 +414,20 @@ def test_cxx_epaxos_host_loop_on_the_host(sim, tmp_path):
                            "-I", here, "-I", os.path.join(t.ROOT, "include"), os.path.join(t.ROOT, "examples", "ep_host_loop.cpp"),
                            lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     t.check_output(subprocess.check_output([exe, "96", "6"], timeout=300).decode(), 96, 6)
+
+
+def test_cxx_rspaxos_payload_loop_on_the_host(sim, tmp_path):
+    """examples/rsp_payload_loop.cpp (RSPaxos replicas + payload stores from C++: leader change, reconstruction, every executed batch
+    read back) compiled for the host against the emulator build of the library"""
+    import os
+    import subprocess
+    import test_zzz_example_rsp_payload_gpu as t
+    lib = sim.build()
+    exe = str(tmp_path / "rsp_payload_loop_sim")
+    here = os.path.dirname(os.path.abspath(sim.__file__))
+    subprocess.check_call([sim.CXX, "-std=c++17", "-O1", "-w", "-DRSP_PAYLOAD_LOOP_ON_THE_EMULATOR", "-I", here, "-I", os.path.join(t.ROOT, "include"),
+                           os.path.join(t.ROOT, "examples", "rsp_payload_loop.cpp"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    t.check_output(subprocess.check_output([exe, "70", "100"], timeout=300).decode(), 70)
 
 
 def test_cxx_raft_wire_loop_on_the_host(sim, tmp_path):

@@ -52,7 +52,7 @@ class Expect:
         return self.memo[tok]
 
 
-def make_cluster(dev, G, R, W, ft, L):
+def make_cluster(dev, G, R, W, ft, L, staging=False):
     import torch
     import rsp_cluster as rc
     from summerset_amd import RSPaxosPayloadStore, RSPaxosReplicaGroup, RSPaxosReplicaWithPayload
@@ -66,7 +66,8 @@ def make_cluster(dev, G, R, W, ft, L):
         data[junk] = 0x5A
         return torch.from_numpy(data).to(dev), torch.from_numpy(lens.view(np.int32)).to(dev)
     reps = [RSPaxosReplicaWithPayload(RSPaxosReplicaGroup(G, R, me=r, window=W, fault_tolerance=ft),
-                                      RSPaxosPayloadStore(G, R, W, max_data_len=L), payload) for r in range(R)]
+                                      RSPaxosPayloadStore(G, R, W, max_data_len=L), payload,
+                                      staging=RSPaxosPayloadStore(G, R, W, max_data_len=L) if staging else None) for r in range(R)]
     for r in reps:
         r.set_peers(reps)
     return reps, [rc.NumpyEngine(r, dev) for r in reps]
@@ -114,11 +115,11 @@ def check_executed(rep, dev, exp, where):
     return len(g)
 
 
-def run_closed_loop(dev, oracle, G, W, ft, loss, L, T=21):
+def run_closed_loop(dev, oracle, G, W, ft, loss, L, T=21, staging=False):
     import rsp_scenarios as sc
     from summerset_amd import rsp_payload as rp
     R = 5
-    reps, engs = make_cluster(dev, G, R, W, ft, L)
+    reps, engs = make_cluster(dev, G, R, W, ft, L, staging)
     exp = Expect(oracle, R, R // 2 + 1, L)
     n_exec = [0]
     # executions are read back right after the handler that ran them (the list is the last call's)
@@ -141,6 +142,60 @@ def run_closed_loop(dev, oracle, G, W, ft, loss, L, T=21):
 def test_bytes_follow_the_engine_through_leader_changes(cuda, oracle, G, W, ft, loss, L):
     tot, n_exec, n_cmp = run_closed_loop(cuda, oracle, G, W, ft, loss, L)
     assert tot["rekeyed"] >= 0
+
+
+@pytest.mark.parametrize("G,W,ft,loss,L", [(96, 16, 1, 0.1, 333), (130, 8, 0, 0.05, 50)])
+def test_bytes_travel_as_messages_between_replicas_that_share_nothing(cuda, oracle, G, W, ft, loss, L):
+    """the same closed loop with a staging store per replica: no replica reads a peer's store -- every Accept, PrepareReply row
+    and ReconstructReply row is `extract`ed at its sender (subset_copy, rscoding.rs:255-293), `ingest`ed at the receiver and
+    named as `follow`'s only source; same checks, byte for byte"""
+    tot, n_exec, n_cmp = run_closed_loop(cuda, oracle, G, W, ft, loss, L, staging=True)
+    assert tot["copied"] > 0 and tot["rebuilt"] > 0
+
+
+def test_extract_and_ingest_round_trip(cuda, oracle):
+    """extract: only shards the row holds, only where flagged, the header beside the bytes; ingest: replaces the row"""
+    import torch
+    from summerset_amd import RSPaxosPayloadStore, RSPaxosReplicaGroup
+    from summerset_amd.rsp_payload import REQS, VOTED
+    G, R, W, L = 70, 5, 8, 200
+    rep, st, other = RSPaxosReplicaGroup(G, R, me=0, window=W), RSPaxosPayloadStore(G, R, W, max_data_len=L), RSPaxosPayloadStore(G, R, W, max_data_len=L)
+    rep.preset_leader(0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    tok = np.arange(1, G + 1, dtype=np.uint32)
+    lens = batch_len(tok, L)
+    acc = rep.req_batch(t(tok.view(np.int32)))
+    st.put(acc, t(batch_bytes(tok, L)), t(lens.view(np.int32)))
+    exp = Expect(oracle, R, 3, L)
+    slot = np.zeros(G, np.uint32); slot[5] = 0xFFFFFFFF                     # a NULL slot: nothing
+    want = (np.arange(G) % 32).astype(np.uint8)                              # every subset of the five shards
+    flags = np.ones(G, np.uint8); flags[7] = 0
+    msg = st.extract(t(slot.view(np.int32)), t(want), REQS, t(flags))
+    m, tk, dl, buf = (msg[k].cpu().numpy() for k in ("mask", "tok", "dlen", "buf"))
+    tk, dl = tk.view(np.uint32), dl.view(np.uint32)
+    for g in range(G):
+        live = flags[g] and slot[g] == 0 and want[g]
+        assert m[g] == (want[g] if live else 0) and tk[g] == (tok[g] if live else 0xFFFFFFFF), (g, m[g], tk[g])
+        assert dl[g] == (lens[g] if live else 0)
+        cw = exp.shards(tok[g])[0]
+        for k in range(R):
+            if live and (want[g] >> k) & 1:
+                assert np.array_equal(buf[k, g, :cw.shape[1]], cw[k]), (g, k)
+    assert st.extract(t(slot.view(np.int32)), t(want), VOTED)["mask"].cpu().numpy().sum() == 0   # nothing voted yet in this store
+    # the receiver: rows of slot 9 (ring row 1) take the messages; an earlier occupant is replaced
+    slot9 = t(np.full(G, 9, np.int32))
+    other.ingest(msg, slot9, REQS)
+    d = other.dump(REQS)
+    assert np.array_equal(d["avail"][1], m) and np.array_equal(d["tok"][1][m != 0], tok[m != 0]) and (d["tok"][1][m == 0] == 0xFFFFFFFF).all()
+    row = other.read_row(9)
+    for g in range(G):
+        cw = exp.shards(tok[g])[0]
+        for k in range(R):
+            if (m[g] >> k) & 1:
+                assert np.array_equal(row[k, g, :cw.shape[1]], cw[k])
+    msg["mask"].fill_(0)
+    other.ingest(msg, slot9, REQS)                                           # an empty message empties the row
+    assert not other.dump(REQS)["avail"].any()
 
 
 def test_steady_tick_is_one_put_and_one_shard_per_follower(cuda, oracle):
