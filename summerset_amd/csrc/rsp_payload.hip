@@ -81,31 +81,23 @@ __device__ __forceinline__ uint32_t ps_xtime4(uint32_t x) {               // 4 p
 //     out_r = XOR_b 2^b * (XOR_{c : bit b of m[r][c]} in_c) = (..(P_hb * 2 ^ P_hb-1) * 2 ^ ..) * 2 ^ P_0
 // -- (highest coefficient bit) doublings per row instead of 8 per coefficient (RS(3,2) parity: 0 and 3).  The coefficients are
 // per-lane values (a lane's own erasure pattern); in ps_put_kernel they are wave-uniform and the plane tests scalar.
-__device__ __forceinline__ void ps_rebuild(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
-                                           uint32_t pat) {
+// (in[c] = the 16 columns of the c-th present shard of `pat`, already in registers: put has just loaded them from the batch --
+// reading them back from the row it stored them to put a store -> load round trip in front of the parity: 60 -> 46 us, profiles/r7d)
+template <int D>
+__device__ __forceinline__ void ps_rebuild_from(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
+                                                uint32_t pat, const ps_u32x4 (&in)[D]) {
     const uint8_t *m = v.mat + (size_t)pat * 64;
-    ps_u32x4 in[PS_MAX_N];
-    uint32_t p = pat;
-#pragma unroll
-    for (int c = 0; c < (int)PS_MAX_N; c++) {
-        in[c] = (ps_u32x4){0u, 0u, 0u, 0u};
-        if (c < (int)v.d) {
-            const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
-            p &= p - 1u;
-            in[c] = ps_load16(base + ps_off(v, row, k, g) + c0);
-        }
-    }
 #pragma unroll
     for (int r = 0; r < (int)PS_MAX_N; r++) {
         if (!((need >> r) & 1u)) continue;
-        uint32_t co[PS_MAX_N], any = 0;
+        uint32_t co[D], any = 0;
 #pragma unroll
-        for (int c = 0; c < (int)PS_MAX_N; c++) { co[c] = c < (int)v.d ? m[r * 8 + c] : 0u; any |= co[c]; }
+        for (int c = 0; c < D; c++) { co[c] = m[r * 8 + c]; any |= co[c]; }
         ps_u32x4 acc = {0u, 0u, 0u, 0u};
         for (int b = any ? 31 - __clz((int)any) : -1; b >= 0; b--) {
             acc.x = ps_xtime4(acc.x); acc.y = ps_xtime4(acc.y); acc.z = ps_xtime4(acc.z); acc.w = ps_xtime4(acc.w);
 #pragma unroll
-            for (int c = 0; c < (int)PS_MAX_N; c++)
+            for (int c = 0; c < D; c++)
                 if ((co[c] >> b) & 1u) acc ^= in[c];
         }
         ps_store16(base + ps_off(v, row, (uint32_t)r, g) + c0, acc);
@@ -136,19 +128,35 @@ __device__ __forceinline__ void ps_rebuild_small(const PsView &v, uint8_t *base,
 }
 
 // 16 bytes of a serialized batch from offset `off`; bytes at or beyond `lim` read as zero (from_data's padding,
-// rscoding.rs:188-189, and the next shard's bytes)
-__device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t off, uint32_t lim) {
+// rscoding.rs:188-189, and the next shard's bytes).  The window that straddles `lim` is still ONE 16-byte load with the excess
+// masked off while it stays inside the buffer (`room` readable bytes from p): with shard_len = ceil(L / d) nearly every wavefront
+// holds such a lane, and a byte-wise path there is run, divergently, by the whole wavefront (put: 78 -> 60 us, profiles/r7c).  Only the last
+// bytes of the whole buffer take the byte loop.
+__device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t off, uint32_t lim, uint64_t room) {
     if (off + 16u <= lim) return ps_load16(p + off);
+    const uint32_t nv = off >= lim ? 0u : lim - off;                        // < 16 bytes of the window exist
+    ps_u32x4 x = {0u, 0u, 0u, 0u};
+    if (nv == 0) return x;
+    if ((uint64_t)off + 16u <= room) {
+        x = ps_load16(p + off);
+        const uint32_t m0 = nv >= 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u;
+        const uint32_t m1 = nv >= 8 ? 0xFFFFFFFFu : (nv > 4 ? (1u << (8 * (nv - 4))) - 1u : 0u);
+        const uint32_t m2 = nv >= 12 ? 0xFFFFFFFFu : (nv > 8 ? (1u << (8 * (nv - 8))) - 1u : 0u);
+        const uint32_t m3 = nv > 12 ? (1u << (8 * (nv - 12))) - 1u : 0u;
+        x.x &= m0; x.y &= m1; x.z &= m2; x.w &= m3;
+        return x;
+    }
     uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const uint32_t b = (off + (uint32_t)i < lim) ? p[off + i] : 0u;
+        const uint32_t b = ((uint32_t)i < nv) ? p[off + i] : 0u;
         w[i >> 2] |= b << (8 * (i & 3));
     }
     return (ps_u32x4){w[0], w[1], w[2], w[3]};
 }
 
-// request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches
+// request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches; D = the number of data shards
+template <int D>
 __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
                                                      const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
                                                      const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk) {
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
     const uint32_t row = a_slot[g] & v.Wmask;
     uint32_t L = len ? len[g] : data_len;
     if (L > data_len) L = data_len;
-    const uint32_t sl = ps_shard_len(L, v.d), c0 = blk * 16u;
+    const uint32_t sl = ps_shard_len(L, (uint32_t)D), c0 = blk * 16u;
     if (blk == 0) {
         const size_t i = (size_t)row * v.G + g;
         v.pl[0].tok[i] = a_val[g];
@@ -167,12 +175,17 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
     }
     if (c0 >= sl) return;
     const uint8_t *src = data + (size_t)g * data_stride;
-    for (uint32_t c = 0; c < v.d; c++) {
-        const uint32_t end = (c + 1u) * sl;
-        ps_store16(v.pl[0].bytes + ps_off(v, row, c, g) + c0, ps_load_data16(src, c * sl + c0, end < L ? end : L));
+    const uint64_t room = (uint64_t)(v.G - 1u - g) * data_stride + data_len;   // readable bytes from this batch's start
+    ps_u32x4 in[D];
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        const uint32_t end = ((uint32_t)c + 1u) * sl;
+        in[c] = ps_load_data16(src, (uint32_t)c * sl + c0, end < L ? end : L, room);
     }
-    const uint32_t dm = (1u << v.d) - 1u;
-    ps_rebuild(v, v.pl[0].bytes, row, g, c0, ((1u << v.n) - 1u) & ~dm, dm);                  // compute_parity
+#pragma unroll
+    for (int c = 0; c < D; c++) ps_store16(v.pl[0].bytes + ps_off(v, row, (uint32_t)c, g) + c0, in[c]);
+    const uint32_t dm = (1u << D) - 1u;
+    ps_rebuild_from<D>(v, v.pl[0].bytes, row, g, c0, ((1u << v.n) - 1u) & ~dm, dm, in);     // compute_parity
 }
 
 // one lane per ring cell: what the engine says the cell holds against what the rows hold
@@ -241,11 +254,20 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     }
     const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0);
     const unsigned long long b = __ballot(work);
-    const uint32_t lane = __lane_id();
-    uint32_t base = 0;
+    const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
+    // one append per BLOCK: the cells with work are neighbours (a tick's row), and ~15 ns per same-address atomic times one per
+    // wavefront was a fifth of this kernel (9.6 -> 7.7 us, profiles/r7d)
+    __shared__ uint32_t w_cnt[4], b_base;
+    if (lane == 0) w_cnt[wv] = (uint32_t)__popcll(b);
     if (t == 0) v.it_n[v.flip ^ 1u] = 0;                                   // the next call's counter (this stream runs it after my byte kernel)
-    if (lane == 0 && b) base = atomicAdd(&v.it_n[v.flip], (uint32_t)__popcll(b));
-    base = (uint32_t)__shfl((int)base, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
+        b_base = tot ? atomicAdd(&v.it_n[v.flip], tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = b_base;
+    for (uint32_t k = 0; k < wv; k++) base += w_cnt[k];
     if (work) {
         const uint32_t o = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         v.it_cell[o] = i; v.it_src[0][o] = src[0]; v.it_src[1][o] = src[1]; v.it_rc[o] = rc; v.it_sl[0][o] = sl[0]; v.it_sl[1][o] = sl[1];
@@ -258,50 +280,51 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     }
 }
 
-// one wavefront per listed cell, a lane per 16-byte column; plane 0 first (plane 1 may copy from it).  Where plane 0 is only
-// copied into, a shard goes through both planes in one step: what plane 1 takes from plane 0 ("own other plane": a follower's
-// vote is the shard it has just been sent) is the register that was stored there, not a read back.
+// a lane per (listed cell, 16-byte column), columns fastest, in a grid-stride loop over cells x columns: the lanes of a wavefront
+// run over cell boundaries (a wavefront per cell left a third of the lanes idle, 86 columns on 64 lanes: 22.6 -> 17.3 us, r7e).  Plane 0 first (plane 1
+// may copy from it).  Where plane 0 is only copied into, a shard goes through both planes in one step: what plane 1 takes from
+// plane 0 ("own other plane": a follower's vote is the shard it has just been sent) is the register that was stored there, not
+// a read back.
 __global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) {
-    const uint32_t n_items = v.it_n[v.flip];
-    const uint32_t lane = threadIdx.x & 63u, nw = gridDim.x * 4u;
-    for (uint32_t it = blockIdx.x * 4u + (threadIdx.x >> 6); it < n_items; it += nw) {
-        const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G, rcw = v.it_rc[it];
+    const uint32_t n_items = v.it_n[v.flip], ncol = v.cap_sl / 16u;
+    const uint64_t total = (uint64_t)n_items * ncol, step = (uint64_t)gridDim.x * 256u;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += step) {
+        const uint32_t it = (uint32_t)(t / ncol), c0 = (uint32_t)(t % ncol) * 16u;
+        const uint32_t rcw = v.it_rc[it], sl0 = v.it_sl[0][it], sl1 = v.it_sl[1][it];
         const uint64_t sb0 = v.it_src[0][it], sb1 = v.it_src[1][it];
-        const uint32_t rc0 = rcw & 0xFFFFu, rc1 = rcw >> 16, sl0 = v.it_sl[0][it], sl1 = v.it_sl[1][it];
-        const bool w0 = sb0 != PS_NO_SRC || rc0, w1 = sb1 != PS_NO_SRC || rc1;
-        const uint32_t e0 = w0 ? sl0 : 0u, e1 = w1 ? sl1 : 0u;
-        for (uint32_t c0 = lane * 16u; c0 < (e0 > e1 ? e0 : e1); c0 += 64u * 16u) {
-            const bool in0 = c0 < e0, in1 = c0 < e1;
-            for (uint32_t k = 0; k < v.n; k++) {
-                const size_t o = ps_off(v, row, k, g) + c0;
-                const uint32_t s0 = in0 ? (uint32_t)(sb0 >> (8 * k)) & 0xFFu : PS_NONE;
-                ps_u32x4 x = {0u, 0u, 0u, 0u};
-                if (s0 != PS_NONE) {
-                    if (s0 != PS_EMPTY) x = ps_load16((s0 == PS_OWN ? v.pl[1].bytes : S.p[s0].bytes) + o);
-                    ps_store16(v.pl[0].bytes + o, x);
-                }
-                if (rc0) continue;                                          // plane 1 waits for plane 0's rebuild (below)
-                const uint32_t s1 = in1 ? (uint32_t)(sb1 >> (8 * k)) & 0xFFu : PS_NONE;
+        const uint32_t rc0 = rcw & 0xFFFFu, rc1 = rcw >> 16;
+        const bool in0 = (sb0 != PS_NO_SRC || rc0) && c0 < sl0, in1 = (sb1 != PS_NO_SRC || rc1) && c0 < sl1;
+        if (!in0 && !in1) continue;
+        const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G;
+        for (uint32_t k = 0; k < v.n; k++) {
+            const size_t o = ps_off(v, row, k, g) + c0;
+            const uint32_t s0 = in0 ? (uint32_t)(sb0 >> (8 * k)) & 0xFFu : PS_NONE;
+            ps_u32x4 x = {0u, 0u, 0u, 0u};
+            if (s0 != PS_NONE) {
+                if (s0 != PS_EMPTY) x = ps_load16((s0 == PS_OWN ? v.pl[1].bytes : S.p[s0].bytes) + o);
+                ps_store16(v.pl[0].bytes + o, x);
+            }
+            if (rc0) continue;                                              // plane 1 waits for plane 0's rebuild (below)
+            const uint32_t s1 = in1 ? (uint32_t)(sb1 >> (8 * k)) & 0xFFu : PS_NONE;
+            if (s1 == PS_NONE) continue;
+            if (!(s1 == PS_OWN && s0 != PS_NONE)) {                         // (else: x is what plane 0 holds there now)
+                x = (ps_u32x4){0u, 0u, 0u, 0u};
+                if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
+            }
+            ps_store16(v.pl[1].bytes + o, x);
+        }
+        if (rc0) {
+            if (in0) ps_rebuild_small(v, v.pl[0].bytes, row, g, c0, rc0 & 0xFFu, rc0 >> 8);
+            for (uint32_t k = 0; k < v.n && in1; k++) {
+                const uint32_t s1 = (uint32_t)(sb1 >> (8 * k)) & 0xFFu;
                 if (s1 == PS_NONE) continue;
-                if (!(s1 == PS_OWN && s0 != PS_NONE)) {                     // (else: x is what plane 0 holds there now)
-                    x = (ps_u32x4){0u, 0u, 0u, 0u};
-                    if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
-                }
+                const size_t o = ps_off(v, row, k, g) + c0;
+                ps_u32x4 x = {0u, 0u, 0u, 0u};
+                if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
                 ps_store16(v.pl[1].bytes + o, x);
             }
-            if (rc0) {
-                if (in0) ps_rebuild_small(v, v.pl[0].bytes, row, g, c0, rc0 & 0xFFu, rc0 >> 8);
-                for (uint32_t k = 0; k < v.n && in1; k++) {
-                    const uint32_t s1 = (uint32_t)(sb1 >> (8 * k)) & 0xFFu;
-                    if (s1 == PS_NONE) continue;
-                    const size_t o = ps_off(v, row, k, g) + c0;
-                    ps_u32x4 x = {0u, 0u, 0u, 0u};
-                    if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
-                    ps_store16(v.pl[1].bytes + o, x);
-                }
-            }
-            if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8);
         }
+        if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8);
     }
 }
 
@@ -518,8 +541,13 @@ int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_
     const PsView &v = s->v;
     const uint32_t nblk = ((data_len + v.d - 1) / v.d + 15u) / 16u;
     const uint64_t threads = (uint64_t)v.G * nblk;
-    hipLaunchKernelGGL(ps_put_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev,
-                       a_val_dev, data_dev, data_stride, len_dev, data_len, nblk);
+#define PS_PUT(D)                                                                                                                         \
+    case D:                                                                                                                               \
+        hipLaunchKernelGGL(ps_put_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, \
+                           a_val_dev, data_dev, data_stride, len_dev, data_len, nblk);                                                    \
+        break;
+    switch (v.d) { PS_PUT(1) PS_PUT(2) PS_PUT(3) PS_PUT(4) PS_PUT(5) PS_PUT(6) PS_PUT(7) default: return fail(SMR_ERR_ARG, "pstore put: bad scheme"); }
+#undef PS_PUT
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -549,9 +577,9 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
     const uint32_t cells = v.W * v.G;
     hipLaunchKernelGGL(ps_plan_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev);
     SMR_HIP_TRY(hipGetLastError());
-    uint32_t blocks = (cells + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ps_bytes_kernel, dim3(blocks), dim3(256), 0, st, v, S);
+    uint64_t blocks = ((uint64_t)cells * (v.cap_sl / 16u) + 255) / 256;            // (an upper bound: the list's length is the device's)
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ps_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v, S);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
