@@ -615,31 +615,25 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
     path that also serves leader changes, where the `rspaxos` leg writes the tick's shards into flat per-tick stores.  The
     leg ends with the checks a host can make without the oracle: nothing unsatisfied, every row's token and mask = the engine's,
     the last row's parity verified by the RS kernels."""
-    from summerset_amd import RSPaxosPayloadStore, _lib, workloads
+    from summerset_amd import _lib, workloads
     from summerset_amd.rsp_payload import REQS
     c4 = workloads.CONFIG4
-    G, R, L, NB, H, W = c4["G"], c4["R"], c4["L"], c4["n_buffers"], c4["H"], 16
-    reps, loop = workloads.config4_cluster(G, W, c4["ft"], one_launch=True)
-    stores = [RSPaxosPayloadStore(G, R, W, max_data_len=L) for _ in range(R)]
+    G, R, L, NB, H, W = c4["G"], c4["R"], c4["L"], c4["n_buffers"], c4["H"], workloads.PAYLOAD_W
+    # cluster, stores and the tick itself from summerset_amd/workloads.py -- what
+    # tests/test_baseline_configs_gpu.py::test_config3_payload_store_16384_groups holds against the oracles
+    reps, loop, stores = workloads.config4_payload_cluster(G, W, c4["ft"], L)
     rng = np.random.default_rng(0x5EED5EED)
     srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
     masks = [{k_: torch.from_numpy(v).to(dev) for k_, v in workloads.config4_loss(rng, G).items()} for k in range(NB)]
     vals = [torch.from_numpy(workloads.config4_tokens(G, j)).to(dev) for j in range(warmup + 2 * ticks + 8)]
     ones = torch.ones(G, dtype=torch.int32, device=dev)
     slots = [torch.full((G,), j, dtype=torch.int32, device=dev) for j in range(len(vals))]   # every group appends every tick: slot = tick
-    from_leader = [None] + [[(stores[0], REQS)] for _ in range(1, R)]
     n = [0]
 
     def one_tick(_i=0, engine=True, bytes_=True):
         j = n[0]
         n[0] += 1
-        if engine:
-            loop.tick(vals[j], lost=masks[j % NB], heartbeat=j % H == H - 1)
-        if bytes_:
-            stores[0].put(dict(a_n=ones, a_slot=slots[j], a_val=vals[j]), srcs[j % NB])
-            stores[0].follow(reps[0])
-            for q in range(1, R):
-                stores[q].follow(reps[q], from_leader[q])
+        workloads.config4_payload_tick(reps, loop, stores, slots[j], srcs[j % NB], vals[j], masks[j % NB], j % H == H - 1, ones, engine, bytes_)
     for _ in range(warmup):
         one_tick()
     # ~17 host calls per tick at 10-20 us each: a 12 ms device-side sleep in front lets the host queue the whole region first

@@ -94,3 +94,33 @@ def config4_tick(loop, k, src, val, lost, heartbeat):
     Returns (the leader's committed flags, the tick's codewords as a view of the stores)."""
     cw = loop.encode_stores(src, slot=k)
     return loop.tick(val, lost=lost, heartbeat=heartbeat), cw
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4 with the shard bytes in the product's payload store (bench.py's `rspaxos_payload` leg; held against the oracles
+# at 16 384 groups x L = 4113 by tests/test_baseline_configs_gpu.py::test_config3_payload_store_16384_groups)
+# ---------------------------------------------------------------------------------------------------------------------
+PAYLOAD_W = 16                                    # the stores' ring (two planes x W x 5 shards x G x 1376 B per replica: 3.6 GB at 16 384 groups)
+
+
+def config4_payload_cluster(G=CONFIG4["G"], W=PAYLOAD_W, ft=CONFIG4["ft"], L=CONFIG4["L"], leader=0):
+    """config 4's engines + one-launch steady loop, and one payload store per replica"""
+    from .rsp_payload import RSPaxosPayloadStore
+    reps, loop = config4_cluster(G, W, ft, leader=leader, one_launch=True)
+    return reps, loop, [RSPaxosPayloadStore(G, CONFIG4["R"], W, max_data_len=L) for _ in range(CONFIG4["R"])]
+
+
+def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, ones, engine=True, bytes_=True):
+    """one tick: the engines' handlers in one launch, then the tick's bytes -- the leader's put of the serialized batches `src`
+    (uint8 [G, L]) into the rows of `slot` (int32 [G]: in the steady state every group appends every tick, slot = tick) and one
+    follow per replica, the followers' out of the leader's REQS plane.  Returns the leader's committed flags (None without engine)."""
+    from .rsp_payload import REQS
+    s = loop.s
+    committed = loop.tick(val, lost=lost, heartbeat=heartbeat) if engine else None
+    if bytes_:
+        stores[s].put(dict(a_n=ones, a_slot=slot, a_val=val), src)
+        stores[s].follow(reps[s])
+        for q in range(len(reps)):
+            if q != s:
+                stores[q].follow(reps[q], [(stores[s], REQS)])
+    return committed

@@ -280,6 +280,74 @@ def test_config3_rspaxos_one_launch_tick_16384_groups(cuda, oracle):
     assert total > 16384 * 10
 
 
+def run_rspaxos_payload(cuda, oracle, G, W, L, T, ft):
+    """bench.py's `rspaxos_payload` leg as it is launched (summerset_amd/workloads.py: config4_payload_cluster / config4_payload_tick):
+    per tick the engines' one-launch tick, the leader's `smr_rsp_pstore_put` and one `smr_rsp_pstore_follow` per replica --
+    against five ORACLES of the whole population (committed flags every tick, every replica's state at the end) and the
+    oracle's RS encoder on every codeword of every tick: the leader's row (all five shards), every follower's shard in both
+    planes, tokens / masks / lengths of the tick's cells, and the batch read back through `get_data`, byte for byte.  T > W:
+    the ring wraps and every row is re-keyed."""
+    import torch
+    from summerset_amd import rsp_cluster as rc, workloads
+    from summerset_amd.rsp_payload import REQS, VOTED
+    c4 = workloads.CONFIG4
+    R, NB, H = c4["R"], c4["n_buffers"], c4["H"]
+    reps, loop, stores = workloads.config4_payload_cluster(G, W, ft, L)
+    orcs = [oracle.RspOracle(G, R, me=r, W=W, fault_tolerance=ft) for r in range(R)]
+    for o in orcs:
+        o.preset_leader(0)
+    rng = np.random.default_rng(0x5EED5EED)
+    data = [rng.integers(0, 256, (G, L), dtype=np.uint8) for _ in range(NB)]
+    srcs = [torch.from_numpy(d).to(cuda) for d in data]
+    sl_ = -(-L // 3)
+    want = []
+    for d in data:                                       # the oracle's codeword of every batch: from_data geometry + compute_parity
+        x = np.zeros((G, 3 * sl_), np.uint8)
+        x[:, :L] = d
+        want.append(np.concatenate([x.reshape(G, 3, sl_), oracle.rs_encode_batch(3, 2, d, L, L, G).reshape(G, 2, sl_)], axis=1))   # [G, 5, sl]
+    masks = [workloads.config4_loss(rng, G) for _ in range(NB)]
+    dmasks = [{k: torch.from_numpy(v).to(cuda) for k, v in m.items()} for m in masks]
+    ones = torch.ones(G, dtype=torch.int32, device=cuda)
+    shard = [torch.full((G,), 1 << q, dtype=torch.uint8, device=cuda) for q in range(R)]
+    every = torch.full((G,), (1 << R) - 1, dtype=torch.uint8, device=cuda)
+    total = 0
+    for t in range(T):
+        k, hb = t % NB, t % H == H - 1
+        val = workloads.config4_tokens(G, t)
+        slot = torch.full((G,), t, dtype=torch.int32, device=cuda)
+        got = workloads.config4_payload_tick(reps, loop, stores, slot, srcs[k], torch.from_numpy(val).to(cuda), dmasks[k], hb, ones).cpu().numpy()
+        log = rc.tick(orcs, val.view(np.uint32), np.zeros(G, np.uint8), drop={k_: v.astype(bool) for k_, v in masks[k].items()}, heartbeat=hb)
+        cm = [e for e in log if e["kind"] == "commit"]
+        assert len(cm) == 1 and np.array_equal(got, cm[0]["committed"]), t
+        total += int(got.sum())
+        # the tick's cells through `extract` (the header a message would carry + the bytes)
+        for q in range(R):
+            for plane in (REQS, VOTED):
+                m = stores[q].extract(slot, every, plane)
+                held = (1 << R) - 1 if (q == 0 and plane == REQS) else 1 << q        # the leader's codeword; a vote / a follower: its own shard
+                assert (m["mask"].cpu().numpy() == held).all() and (m["dlen"].cpu().numpy() == L).all(), (t, q, plane)
+                assert np.array_equal(m["tok"].cpu().numpy(), val), (t, q, plane)
+                for s_ in range(R):
+                    if (held >> s_) & 1:
+                        assert np.array_equal(m["buf"][s_, :, :sl_].cpu().numpy(), want[k][:, s_]), (t, q, plane, s_)
+        out, ln, ok = stores[0].get_data(slot, expect=torch.from_numpy(val).to(cuda))
+        assert bool(ok.all()) and (ln.cpu().numpy() == L).all() and np.array_equal(out[:, :L].cpu().numpy(), data[k]), t
+    for r in range(R):
+        a, b = reps[r].dump(), orcs[r].dump()
+        for n in b:
+            assert np.array_equal(a[n], b[n]), (r, n)
+        c = stores[r].counters()
+        assert c["unsatisfied"] == 0 and c["rebuilt"] == 0 and c["copied"] == (1 if r == 0 else 2) * G * T, (r, c)
+        assert c["rekeyed"] == (1 if r == 0 else 2) * G * max(T - W, 0), (r, c)       # once the ring wrapped: both planes of a follower's row; the leader's put re-keys its REQS row itself
+    return total
+
+
+def test_config3_payload_store_16384_groups(cuda, oracle):
+    """the launches bench.py's `rspaxos_payload` leg TIMES, at its size (16 384 groups x L = 4113, window 16), 20 ticks"""
+    total = run_rspaxos_payload(cuda, oracle, G=16384, W=16, L=4113, T=20, ft=1)
+    assert total > 16384 * 17
+
+
 def test_config3_rspaxos_16384_groups_rs32_4k_values(cuda, oracle):
     import torch
     from summerset_amd import RSCodewordBatch
