@@ -872,7 +872,8 @@ int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_h
  * Host-side reads: _dump (tok / avail / dlen [W][G] of a plane; NULL = skip), _read_row (the n x G x group_stride bytes of
  * a slot's row), _layout (device pointer + strides of a plane: shard k of group g of row r at bytes_dev + r * row_stride +
  * k * shard_stride + g * group_stride -- a row is a shard-major batch smr_rs_reconstruct / smr_rs_verify accept),
- * _counters: shards copied, shards rebuilt, shards the engine has that no source could give (0 in a correct run),
+ * _counters: shards copied, shards rebuilt, shards the engine has that no source could give (0 in a correct run; counted by every
+ * follow call while they stay missing -- after an absorb of a DIFFERENT token, which rscoding.rs:296-346 refuses, they always do),
  * rows whose token changed while they held shards.  n_shards = the population (<= 8), n_data_shards = the majority.
  * The calls on one store only enqueue work and must be issued on ONE stream at a time (their scratch list is the store's);
  * a source's rows must not be written by another stream meanwhile.  A message is consumed in the tick that produced it: the

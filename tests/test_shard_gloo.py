@@ -100,6 +100,47 @@ def test_world_size_2_gloo(tmp_path):
     assert np.array_equal(leader, np.concatenate([r0["leader"], r1["leader"]]))
 
 
+def _l2_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = bench._l2_outcome_of_all_ranks(dist, world, False)              # nobody failed
+    with open(os.path.join(out_dir, "l2_rank%d.txt" % rank), "w") as f:
+        f.write("%d" % int(a))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_settle_the_l2_outcome_through_the_store(tmp_path):
+    """bench.py at N > 1: a rank whose own L2 pass was fine must learn that a peer's failed before it walks into the
+    closing barrier -- through the process group's store.  Two gloo ranks: nobody failed -> False on both."""
+    import torch.multiprocessing as mp
+    mp.spawn(_l2_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for k in range(2):
+        assert open(str(tmp_path / ("l2_rank%d.txt" % k))).read().split()[0] == "0"
+
+
+def _l2_fail_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bad = bench._l2_outcome_of_all_ranks(dist, world, rank == 1, wait_s=20.0)   # rank 1's pass "failed"
+    with open(os.path.join(out_dir, "l2f_rank%d.txt" % rank), "w") as f:
+        f.write("%d" % int(bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_failed_l2_pass_is_seen_by_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_l2_fail_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(str(tmp_path / ("l2f_rank%d.txt" % k))).read() for k in range(2)] == ["1", "1"]
+
+
 def test_bench_launch_plan():
     """`python bench.py --gpus N` is how the driver asks for N ranks at round end (through torchrun) and how a user does
     without one: the flag and the launcher's environment must agree, and without a launcher the script spawns the ranks"""

@@ -198,6 +198,99 @@ def test_extract_and_ingest_round_trip(cuda, oracle):
     assert not other.dump(REQS)["avail"].any()
 
 
+def run_random_calls(dev, oracle, G, W, me, ft, steps=120, L=61):
+    """seeded random -- NOT protocol-legal -- handler calls (tests/rsp_random.py: stale and higher ballots, holes, slots outside the
+    ring, replies to instances in every status, reconstruction rows for unknown slots, masks of any shape): whatever a call
+    carries is ingested into a staging store with the ORACLE's bytes for its (token, shards), the engine handles the call, the
+    store follows.  The engine may then claim shards nobody can give (an absorb of a different token, rscoding.rs:296-346
+    would have erred): those are counted, never invented -- what the store holds is always a subset of the engine's mask
+    under the engine's token, and every held shard is the oracle's byte for byte; where no such absorb happened the store
+    holds exactly the engine's mask."""
+    import torch
+    import rsp_cluster as rc
+    import rsp_random as rr
+    from summerset_amd import RSPaxosPayloadStore, RSPaxosReplicaGroup
+    from summerset_amd.rsp_payload import REQS, VOTED
+    R = 5
+    rep = RSPaxosReplicaGroup(G, R, me=me, window=W, fault_tolerance=ft)
+    eng = rc.NumpyEngine(rep, dev)
+    orc = oracle.RspOracle(G, R, me=me, W=W, fault_tolerance=ft)
+    eng.preset_leader(0); orc.preset_leader(0)
+    store, staging = RSPaxosPayloadStore(G, R, W, max_data_len=L), RSPaxosPayloadStore(G, R, W, max_data_len=L)
+    exp = Expect(oracle, R, 3, L)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    gs = store.group_stride
+
+    def stage(flags, slot, tok, mask):
+        """the message rows (slot, token, shards) [G] with the oracle's bytes -> the staging store"""
+        buf = np.zeros((R, G, gs), np.uint8)
+        dlen = np.zeros(G, np.uint32)
+        live = (flags != 0) & (tok != NULL) & (mask != 0)
+        for g in np.nonzero(live)[0]:
+            cw, data = exp.shards(tok[g])
+            dlen[g] = data.size
+            for k in range(R):
+                if (mask[g] >> k) & 1:
+                    buf[k, g, :cw.shape[1]] = cw[k]
+        msg = dict(buf=t(buf), tok=t(tok.astype(np.uint32).view(np.int32)), mask=t(np.where(live, mask, 0).astype(np.uint8)), dlen=t(dlen.view(np.int32)))
+        staging.ingest(msg, t(slot.astype(np.uint32).view(np.int32)), REQS, t(flags.astype(np.uint8)))
+
+    rng = np.random.default_rng(G + W + me)
+    n_cmp, n_exact = 0, 0
+    for step in range(steps):
+        for name, kw in rr.calls(rng, orc.dump(), G, R, me, W):
+            if name == "req_batch":
+                a = eng.req_batch(**kw)
+                tok = kw["val"]
+                data = batch_bytes(tok, L)
+                store.put({k: t(v.view(np.int32)) for k, v in a.items() if k in ("a_n", "a_slot", "a_val")}, t(data), t(batch_len(tok, L).view(np.int32)))
+                store.follow(rep)
+            else:
+                if name == "accept":
+                    stage(kw["flags"], kw["slot"], kw["val"], kw["mask"])
+                elif name == "prepare_replies":
+                    for k in range(int(kw["pr_n"].max()) if G else 0):
+                        stage((kw["pr_n"] > k) & (kw["pr_vbal"][k] > 0), kw["pr_trig"].astype(np.int64) + k, kw["pr_vval"][k], kw["pr_vmask"][k])
+                elif name == "reconstruct_reply":
+                    for k in range(int(kw["rr_n"].max()) if G else 0):
+                        stage((kw["rr_n"] > k) & (kw["flags"] != 0), kw["rr_slot"][k], kw["rr_val"][k], kw["rr_mask"][k])
+                getattr(eng, name)(**kw)
+                store.follow(rep, [(staging, REQS)])
+            getattr(orc, name)(**kw)                                    # (the oracle only shapes the next calls)
+        if step % 10 != 9:
+            continue
+        d = rep.dump()
+        mixed = d["counters"][2]
+        for plane, (kt, km) in enumerate((("s_val", "s_mask"), ("s_vval", "s_vmask"))):
+            want_tok, want = d[kt].copy(), d[km].copy() & 0x1F
+            want[want_tok == NULL] = 0
+            s = store.dump(plane)
+            assert not (s["avail"] & ~want).any(), (step, plane, "a shard the engine does not have")
+            held = s["avail"] != 0
+            assert np.array_equal(s["tok"][held], want_tok[held]), (step, plane)
+            if mixed == 0 and store.counters()["unsatisfied"] == 0:
+                assert np.array_equal(s["avail"], want), (step, plane)
+                n_exact += 1
+            for w in range(W):
+                if not held[w].any():
+                    continue
+                row = store.read_row(w, plane)
+                for g in np.nonzero(held[w])[0]:
+                    cw, data = exp.shards(s["tok"][w, g])
+                    assert s["dlen"][w, g] == data.size
+                    for k in range(R):
+                        if (s["avail"][w, g] >> k) & 1:
+                            assert np.array_equal(row[k, g, :cw.shape[1]], cw[k]), (step, plane, w, g, k)
+                            n_cmp += 1
+    return n_cmp, store.counters()
+
+
+@pytest.mark.parametrize("G,W,me,ft", [(150, 8, 0, 0), (150, 16, 2, 1)])
+def test_random_handler_calls_never_invent_a_shard(cuda, oracle, G, W, me, ft):
+    n_cmp, c = run_random_calls(cuda, oracle, G, W, me, ft)
+    assert n_cmp > 1000 and c["copied"] > 0 and c["rebuilt"] > 0, (n_cmp, c)
+
+
 def test_steady_tick_is_one_put_and_one_shard_per_follower(cuda, oracle):
     """no loss, no leader change: per slot the leader encodes (n shards), every follower copies its one shard into both
     planes, nothing is rebuilt except the leader's parity -- the counters say so exactly"""
