@@ -887,6 +887,11 @@ int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_
                        const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, void *stream);
 int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
                           const uint8_t *sel_dev, void *stream);
+/* smr_rsp_pstore_follow for n <= 8 replicas that consumed ONE sender's message (an Accept reaches every follower): stores[k]
+ * follows replicas[k], each with the single source (src, src_plane) (src may be NULL: none) -- two launches for all of them
+ * instead of two each.  src must not be one of the stores (nothing a store writes in this call is read by another). */
+int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
+                               int src_plane, void *stream);
 int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
                             uint8_t *out_dev, uint64_t out_stride, uint32_t *len_out_dev, uint8_t *ok_dev, void *stream);
 /* The payload of a message between replicas on DIFFERENT devices / hosts.  A message buffer is laid out like one row: shard k of

@@ -321,6 +321,7 @@ SYMBOLS = [
     ("smr_rsp_pstore_destroy", None, [_vp]),
     ("smr_rsp_pstore_put", _i, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _u32, _vp]),
     ("smr_rsp_pstore_follow", _i, [_vp, _vp, _u32, C.POINTER(_vp), _vp, _vp, _vp]),
+    ("smr_rsp_pstore_follow_many", _i, [_u32, C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp]),
     ("smr_rsp_pstore_get_data", _i, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     ("smr_rsp_pstore_extract", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_rsp_pstore_ingest", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
 
 // one lane per ring cell: what the engine says the cell holds against what the rows hold
 // (sel: per group the ONE source a shard may come from -- the sender of the message the handler consumed -- or NULL: any)
-__global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
+__device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, const RspPeek &e, const PsSrcs &S, const uint8_t *__restrict__ sel) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const bool on = t < v.W * v.G;
     const uint32_t i = on ? t : 0u;
@@ -259,11 +259,11 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     // wavefront was a fifth of this kernel (9.6 -> 7.7 us, profiles/r7d)
     __shared__ uint32_t w_cnt[4], b_base;
     if (lane == 0) w_cnt[wv] = (uint32_t)__popcll(b);
-    if (t == 0) v.it_n[v.flip ^ 1u] = 0;                                   // the next call's counter (this stream runs it after my byte kernel)
+    if (t == 0) v.it_n[flip ^ 1u] = 0;                                     // the next call's counter (this stream runs it after my byte kernel)
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = w_cnt[0] + w_cnt[1] + w_cnt[2] + w_cnt[3];
-        b_base = tot ? atomicAdd(&v.it_n[v.flip], tot) : 0u;
+        b_base = tot ? atomicAdd(&v.it_n[flip], tot) : 0u;
     }
     __syncthreads();
     uint32_t base = b_base;
@@ -280,13 +280,29 @@ __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspP
     }
 }
 
+__global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
+    ps_plan_body(v, v.flip, e, S, sel);
+}
+// several replicas that consume ONE sender's message (an Accept goes to every follower): blockIdx.y = which of them.  Their views
+// are read from the device copies the stores keep (a by-value table of whole views, indexed by the block, went to scratch:
+// 2320 B per lane); which of a store's two list counters is live comes as a bit of `flips`.  The source is none of them (the
+// host checks), so nothing one of them writes is read by another.
+struct PsMany {
+    const PsView *v[PS_MAX_N];
+    RspPeek e[PS_MAX_N];
+    uint32_t flips;
+};
+__global__ __launch_bounds__(256) void ps_plan_many_kernel(const PsMany M, const PsSrcs S, const uint8_t *__restrict__ sel) {
+    ps_plan_body(*M.v[blockIdx.y], (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, sel);
+}
+
 // a lane per (listed cell, 16-byte column), columns fastest, in a grid-stride loop over cells x columns: the lanes of a wavefront
 // run over cell boundaries (a wavefront per cell left a third of the lanes idle, 86 columns on 64 lanes: 22.6 -> 17.3 us, r7e).  Plane 0 first (plane 1
 // may copy from it).  Where plane 0 is only copied into, a shard goes through both planes in one step: what plane 1 takes from
 // plane 0 ("own other plane": a follower's vote is the shard it has just been sent) is the register that was stored there, not
 // a read back.
-__global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) {
-    const uint32_t n_items = v.it_n[v.flip], ncol = v.cap_sl / 16u;
+__device__ __forceinline__ void ps_bytes_body(const PsView &v, uint32_t flip, const PsSrcs &S) {
+    const uint32_t n_items = v.it_n[flip], ncol = v.cap_sl / 16u;
     const uint64_t total = (uint64_t)n_items * ncol, step = (uint64_t)gridDim.x * 256u;
     for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += step) {
         const uint32_t it = (uint32_t)(t / ncol), c0 = (uint32_t)(t % ncol) * 16u;
@@ -326,6 +342,11 @@ __global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsS
         }
         if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8);
     }
+}
+
+__global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) { ps_bytes_body(v, v.flip, S); }
+__global__ __launch_bounds__(256) void ps_bytes_many_kernel(const PsMany M, const PsSrcs S) {
+    ps_bytes_body(*M.v[blockIdx.y], (M.flips >> blockIdx.y) & 1u, S);
 }
 
 // rscoding.rs:583-609 for a list of instances: item i = (group[i] or i, slot[i]) -> out[i][0 .. dlen)
@@ -471,7 +492,8 @@ struct smr_rsp_pstore {
     PsView v;
     uint64_t plane_bytes;
     uint32_t max_data_len;
-    void *meta;            // one allocation: tok / avail / dlen of both planes, the table, the list, the counters
+    void *meta;            // one allocation: tok / avail / dlen of both planes, the table, the list, the counters, a copy of v
+    PsView *d_view;        // the device copy of v (flip excepted) smr_rsp_pstore_follow_many's kernels read
 };
 
 extern "C" {
@@ -501,7 +523,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     for (int p = 0; p < 2; p++) { o_tok[p] = a.reserve(cells * 4); o_av[p] = a.reserve(cells); o_len[p] = a.reserve(cells * 4); }
     const size_t o_mat = a.reserve(tab.size()), o_n = a.reserve(256), o_cell = a.reserve(cells * 4);
     for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
-    const size_t o_rc = a.reserve(cells * 4), o_ctr = a.reserve(SMR_CTR_WORDS * 8);
+    const size_t o_rc = a.reserve(cells * 4), o_ctr = a.reserve(SMR_CTR_WORDS * 8), o_view = a.reserve(sizeof(PsView));
     a.size = a.used + 256;
     hipError_t err = hipMalloc((void **)&a.base, a.size);
     for (int p = 0; p < 2 && err == hipSuccess; p++) err = hipMalloc((void **)&v.pl[p].bytes, s->plane_bytes);
@@ -522,6 +544,12 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     v.mat = a.at<uint8_t>(o_mat); v.it_n = a.at<uint32_t>(o_n); v.it_cell = a.at<uint32_t>(o_cell); v.it_rc = a.at<uint32_t>(o_rc);
     v.counters = a.at<unsigned long long>(o_ctr);
     s->meta = a.base;
+    s->d_view = a.at<PsView>(o_view);
+    err = hipMemcpy(s->d_view, &s->v, sizeof(PsView), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        smr_rsp_pstore_destroy(s);
+        return fail(SMR_ERR_DEVICE, std::string("pstore: view copy: ") + hipGetErrorString(err));
+    }
     *out = s;
     return SMR_OK;
 }
@@ -580,6 +608,49 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
     uint64_t blocks = ((uint64_t)cells * (v.cap_sl / 16u) + 255) / 256;            // (an upper bound: the list's length is the device's)
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(ps_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v, S);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
+                               int src_plane, void *stream) {
+    if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "pstore follow_many: 1 .. 8 stores");
+    if (src && (src_plane < 0 || src_plane > 1)) return fail(SMR_ERR_ARG, "pstore follow_many: bad source plane");
+    PsMany M;
+    memset(&M, 0, sizeof(M));
+    PsSrcs S;
+    memset(&S, 0, sizeof(S));
+    const PsView &v0 = stores[0] ? stores[0]->v : PsView();
+    for (uint32_t k = 0; k < n; k++) {
+        smr_rsp_pstore *s = stores[k];
+        if (!s || !replicas[k]) return fail(SMR_ERR_ARG, "pstore follow_many: null store / replica");
+        if (s == src) return fail(SMR_ERR_ARG, "pstore follow_many: the source must not be one of the stores that follow");
+        for (uint32_t j = 0; j < k; j++) if (stores[j] == s) return fail(SMR_ERR_ARG, "pstore follow_many: a store is listed twice");
+        const RspPeek pk = rsp_peek(replicas[k]);
+        if (s->v.G != v0.G || s->v.W != v0.W || s->v.n != v0.n || s->v.d != v0.d || s->v.cap_sl != v0.cap_sl)
+            return fail(SMR_ERR_ARG, "pstore follow_many: the stores differ in geometry");
+        if (pk.G != v0.G || pk.W != v0.W || pk.R != v0.n || pk.majority != v0.d)
+            return fail(SMR_ERR_ARG, "pstore follow_many: a replica's groups / window / population / majority differ from the stores'");
+        M.e[k] = pk;
+    }
+    if (src) {
+        if (src->v.G != v0.G || src->v.W != v0.W || src->v.n != v0.n || src->v.d != v0.d || src->v.cap_sl != v0.cap_sl)
+            return fail(SMR_ERR_ARG, "pstore follow_many: the source has another geometry");
+        S.n = 1;
+        S.p[0] = src->v.pl[src_plane];
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        stores[k]->v.flip ^= 1u;
+        M.v[k] = stores[k]->d_view;
+        M.flips |= stores[k]->v.flip << k;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t cells = v0.W * v0.G;
+    hipLaunchKernelGGL(ps_plan_many_kernel, dim3((cells + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr);
+    SMR_HIP_TRY(hipGetLastError());
+    uint64_t blocks = ((uint64_t)cells * (v0.cap_sl / 16u) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ps_bytes_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, st, M, S);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -69,6 +69,16 @@ class RSPaxosPayloadStore:
         planes = (C.c_uint8 * max(n, 1))(*[0 if s is None else int(s[1]) for s in sources])
         check(self._L.smr_rsp_pstore_follow(self._h, replica._h, n, arr, C.cast(planes, C.c_void_p), _ptr(sel), stream_ptr(stream)))
 
+    @staticmethod
+    def follow_many(stores, replicas, source=None, stream=None):
+        """`follow` for several replicas that consumed ONE sender's message: stores[k] follows replicas[k], each with the single
+        source `source` = (store, plane), which is none of them -- two launches for all of them"""
+        n = len(stores)
+        sa = (C.c_void_p * n)(*[s._h for s in stores])
+        ra = (C.c_void_p * n)(*[r._h for r in replicas])
+        check(stores[0]._L.smr_rsp_pstore_follow_many(n, sa, ra, None if source is None else source[0]._h, 0 if source is None else int(source[1]),
+                                                      stream_ptr(stream)))
+
     def get_data(self, slot, group=None, expect=None, stream=None):
         """serialized batches of the instances (group[i] or i, slot[i]) -> (uint8 [n, max_data_len], int32 [n] lengths, bool [n] ok)"""
         import torch

@@ -120,7 +120,6 @@ def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, on
     if bytes_:
         stores[s].put(dict(a_n=ones, a_slot=slot, a_val=val), src)
         stores[s].follow(reps[s])
-        for q in range(len(reps)):
-            if q != s:
-                stores[q].follow(reps[q], [(stores[s], REQS)])
+        others = [q for q in range(len(reps)) if q != s]                  # the followers consumed ONE Accept broadcast: one call for all of them
+        stores[s].follow_many([stores[q] for q in others], [reps[q] for q in others], (stores[s], REQS))
     return committed

@@ -356,6 +356,14 @@ def test_argument_errors(cuda):
         st.follow(rep, [(other, 0)])                             # a source of another geometry
     with pytest.raises(SummersetError):
         st.follow(rep, [(st, 1)])                                # my own planes are sources already
+    twin = RSPaxosPayloadStore(8, 5, 8, 100)
+    with pytest.raises(SummersetError):
+        RSPaxosPayloadStore.follow_many([st, twin], [rep, rep], (st, 0))     # the source is one of the followers
+    with pytest.raises(SummersetError):
+        RSPaxosPayloadStore.follow_many([st, st], [rep, rep])                # a store twice
+    with pytest.raises(SummersetError):
+        RSPaxosPayloadStore.follow_many([st, other], [rep, rep16])           # two geometries
+    RSPaxosPayloadStore.follow_many([st], [rep], (twin, 1))
     rep.preset_leader(0)
     acc = rep.req_batch(torch.ones(8, dtype=torch.int32, device=cuda))
     with pytest.raises(SummersetError):
