@@ -172,11 +172,18 @@ int main(int argc, char **argv) {
     // the committed instances: reconstruction reads bring shards 2 and 3 in; with its own shard 1 the new leader has three
     smr_rsp_shards rr = {dalloc<uint32_t>(G), dalloc<uint32_t>((size_t)W * G), dalloc<uint64_t>((size_t)W * G), dalloc<uint32_t>((size_t)W * G, 0xFF),
                          dalloc<uint8_t>((size_t)W * G)};
+    hipEvent_t ev0, ev1;
+    HIPCHECK(hipEventCreate(&ev0)); HIPCHECK(hipEventCreate(&ev1));
+    float follow_ms[2] = {0, 0};                                           // the new leader's follow behind each ReconstructReply
     for (uint32_t q : {2u, 3u}) {
         CHECK(smr_rsp_handle_reconstruct(rep[q], ones, rc_n, rc_slot, &rr, nullptr));
         CHECK(smr_rsp_pstore_follow(store[q], rep[q], 0, nullptr, nullptr, nullptr, nullptr));
         CHECK(smr_rsp_handle_reconstruct_reply(rep[1], ones, &rr, nullptr));
+        HIPCHECK(hipEventRecord(ev0, nullptr));
         CHECK(smr_rsp_pstore_follow(store[1], rep[1], R, src1, plane_reqs, is_peer[q], nullptr));        // the reply's payload: q's shards
+        HIPCHECK(hipEventRecord(ev1, nullptr));
+        HIPCHECK(hipEventSynchronize(ev1));
+        HIPCHECK(hipEventElapsedTime(&follow_ms[q - 2], ev0, ev1));
         const long n = check_executed(rep[1], store[1]);                  // reconstruct_data (shard 0 rebuilt from {1, 2, 3}), then execution
         if (n < 0) return 2;
         by_new += n;
@@ -188,6 +195,9 @@ int main(int argc, char **argv) {
     }
     printf("%u groups x 5 replicas, batches of up to %u bytes: %ld batches read back byte for byte at the old leader, %ld at the new leader "
            "after reconstruction, %llu open instances became empty batches\n", G, L, by_old, by_new, empties);
+    printf("new leader's follow behind the ReconstructReplies: %.3f ms (absorb one shard of %u instances per group), %.3f ms (absorb one + rebuild "
+           "one data shard of each from three: <= %.1f MB of shards rebuilt)\n", follow_ms[0], T - 2, follow_ms[1],
+           (double)(T - 2) * G * ((L + 2) / 3) / 1e6);
     printf("payload stores: %llu shards copied, %llu rebuilt, %llu unsatisfied\n", (unsigned long long)tot[0], (unsigned long long)tot[1],
            (unsigned long long)tot[2]);
     for (uint32_t r = 0; r < R; r++) { smr_rsp_pstore_destroy(store[r]); smr_rsp_replica_destroy(rep[r]); }
