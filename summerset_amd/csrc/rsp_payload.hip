@@ -496,6 +496,7 @@ struct smr_rsp_pstore {
     uint32_t max_data_len;
     void *meta;            // one allocation: tok / avail / dlen of both planes, the table, the list, the counters, a copy of v
     PsView *d_view;        // the device copy of v (flip excepted) smr_rsp_pstore_follow_many's kernels read
+    void *plane_alloc[2];  // the planes' allocations (v.pl[p].bytes lies at their start)
 };
 
 extern "C" {
@@ -520,15 +521,27 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     s->max_data_len = max_data_len;
     s->plane_bytes = (uint64_t)window * n_shards * n_groups * v.cap_sl;
     const size_t cells = (size_t)window * n_groups;
-    Arena a;
-    size_t o_tok[2], o_av[2], o_len[2], o_src[2], o_sl[2];
-    for (int p = 0; p < 2; p++) { o_tok[p] = a.reserve(cells * 4); o_av[p] = a.reserve(cells); o_len[p] = a.reserve(cells * 4); }
-    const size_t o_mat = a.reserve(tab.size()), o_n = a.reserve(256), o_cell = a.reserve(cells * 4);
-    for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
-    const size_t o_rc = a.reserve(cells * 4), o_ctr = a.reserve(SMR_CTR_WORDS * 8), o_view = a.reserve(sizeof(PsView));
+    Arena a, pa[2];
+    size_t o_tok[2], o_av[2], o_len[2], o_src[2], o_sl[2], o_mat = 0, o_n = 0, o_cell = 0, o_rc = 0, o_ctr = 0, o_view = 0, o_bytes[2] = {0, 0};
+    // twice: sizes first, then -- the arenas allocated -- once more so that the kernel-source emulator of the CPU suite can mark the
+    // unowned gap behind every array (SMR_ARENA_GUARD, smr_common.h); the offsets are the same both times
+    auto layout = [&]() {
+        a.used = 0;
+        for (int p = 0; p < 2; p++) { o_tok[p] = a.reserve(cells * 4); o_av[p] = a.reserve(cells); o_len[p] = a.reserve(cells * 4); }
+        o_mat = a.reserve(tab.size()); o_n = a.reserve(256); o_cell = a.reserve(cells * 4);
+        for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
+        o_rc = a.reserve(cells * 4); o_ctr = a.reserve(SMR_CTR_WORDS * 8); o_view = a.reserve(sizeof(PsView));
+        for (int p = 0; p < 2; p++) { pa[p].used = 0; o_bytes[p] = pa[p].reserve(s->plane_bytes); }
+    };
+    layout();
     a.size = a.used + 256;
     hipError_t err = hipMalloc((void **)&a.base, a.size);
-    for (int p = 0; p < 2 && err == hipSuccess; p++) err = hipMalloc((void **)&v.pl[p].bytes, s->plane_bytes);
+    for (int p = 0; p < 2 && err == hipSuccess; p++) {
+        pa[p].size = pa[p].used + 256;
+        err = hipMalloc((void **)&pa[p].base, pa[p].size);
+    }
+    if (err == hipSuccess) layout();
+    for (int p = 0; p < 2 && err == hipSuccess; p++) v.pl[p].bytes = pa[p].at<uint8_t>(o_bytes[p]);
     if (err == hipSuccess) err = hipMemset(a.base, 0, a.size);
     for (int p = 0; p < 2 && err == hipSuccess; p++) {
         v.pl[p].tok = a.at<uint32_t>(o_tok[p]); v.pl[p].avail = a.at<uint8_t>(o_av[p]); v.pl[p].dlen = a.at<uint32_t>(o_len[p]);
@@ -538,7 +551,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     }
     if (err == hipSuccess) err = hipMemcpy(a.base + o_mat, tab.data(), tab.size(), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
-        for (int p = 0; p < 2; p++) if (v.pl[p].bytes) (void)hipFree(v.pl[p].bytes);
+        for (int p = 0; p < 2; p++) if (pa[p].base) (void)hipFree(pa[p].base);
         if (a.base) (void)hipFree(a.base);
         delete s;
         return fail(SMR_ERR_DEVICE, std::string("pstore: allocation: ") + hipGetErrorString(err));
@@ -546,6 +559,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     v.mat = a.at<uint8_t>(o_mat); v.it_n = a.at<uint32_t>(o_n); v.it_cell = a.at<uint32_t>(o_cell); v.it_rc = a.at<uint32_t>(o_rc);
     v.counters = a.at<unsigned long long>(o_ctr);
     s->meta = a.base;
+    s->plane_alloc[0] = pa[0].base; s->plane_alloc[1] = pa[1].base;
     s->d_view = a.at<PsView>(o_view);
     err = hipMemcpy(s->d_view, &s->v, sizeof(PsView), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -558,7 +572,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
 
 void smr_rsp_pstore_destroy(smr_rsp_pstore *s) {
     if (!s) return;
-    for (int p = 0; p < 2; p++) if (s->v.pl[p].bytes) (void)hipFree(s->v.pl[p].bytes);
+    for (int p = 0; p < 2; p++) if (s->plane_alloc[p]) (void)hipFree(s->plane_alloc[p]);
     if (s->meta) (void)hipFree(s->meta);
     delete s;
 }
