@@ -39,7 +39,12 @@ class SpreadRSPaxos:
 
     LEADER = 0
 
-    def __init__(self, total_groups, population, window, rank, world, device, data_len, fault_tolerance=1, exchange=None):
+    def __init__(self, total_groups, population, window, rank, world, device, data_len, fault_tolerance=1, exchange=None, payload=False):
+        """payload: every replica that lives here gets an `RSPaxosPayloadStore` (and every follower a staging store): the leader's
+        batches go into its store (`put`), an Accept's shard is `extract`ed from that store into the message, what arrives is
+        `ingest`ed into the receiver's staging store and `follow` runs behind every handler -- the bytes of layout L2 in the
+        product's store instead of in this module's per-tick buffers (off: the fused encode writes the shards straight into the
+        send buffers and nothing keeps them)"""
         import torch
         self.torch = torch
         self.R, self.W, self.rank, self.world, self.device, self.L = int(population), int(window), int(rank), int(world), device, int(data_len)
@@ -57,6 +62,13 @@ class SpreadRSPaxos:
                     e.preset_leader(self.LEADER)
                     self.reps[(b, r)] = e
         self.lead = [b for b in range(world) if (b, self.LEADER) in self.reps]      # (at most one: block `rank`)
+        self.stores, self.staging, self._pmsg = {}, {}, {}
+        if payload:
+            from .rsp_payload import RSPaxosPayloadStore
+            for (b, r), e in self.reps.items():
+                self.stores[(b, r)] = RSPaxosPayloadStore(e.G, self.R, self.W, max_data_len=self.L)
+                if r != self.LEADER:
+                    self.staging[(b, r)] = RSPaxosPayloadStore(e.G, self.R, self.W, max_data_len=self.L)
         self._plans = {k: self._plan(k) for k in ("accept", "accept_reply", "hb", "hb_back")}
         self._bufs = {}
         self.cw = {}
@@ -159,15 +171,26 @@ class SpreadRSPaxos:
             G = hi - lo
             eng = self.reps[(b, s)]
             msgs = {q: self._accept_msg(p["sbuf"], p["soff"][(b, q)], G) for q in range(R) if q != s}
-            if b not in self.cw:
-                self.cw[b] = RSCodewordBatch(G, self.L, self.d, R - self.d, device=self.device, zero=False)
-            RSCodewordBatch.from_data_and_encode(data[b], self.d, R - self.d, out=self.cw[b],
-                                                 shard_dst=[None if q == s else msgs[q]["shard"] for q in range(R)])
+            if not self.stores:
+                if b not in self.cw:
+                    self.cw[b] = RSCodewordBatch(G, self.L, self.d, R - self.d, device=self.device, zero=False)
+                RSCodewordBatch.from_data_and_encode(data[b], self.d, R - self.d, out=self.cw[b],
+                                                     shard_dst=[None if q == s else msgs[q]["shard"] for q in range(R)])
             acc = eng.req_batch(val[b], out=self._b(("acc", b), lambda: dict(
                 a_n=torch.zeros(G, dtype=torch.int32, device=self.device), a_slot=torch.zeros((self.W, G), dtype=torch.int32, device=self.device),
                 a_val=torch.zeros((self.W, G), dtype=torch.int32, device=self.device), a_ballot=torch.zeros(G, dtype=torch.int64, device=self.device))))
             live = (acc["a_n"] > 0).to(torch.uint8)
             self._bufs[("live", b)] = live
+            if self.stores:                                     # the codeword lives in the leader's store; every Accept's shard is taken out of it
+                from .rsp_payload import REQS
+                st = self.stores[(b, s)]
+                st.put(acc, data[b])
+                st.follow(eng)
+                for q in range(R):
+                    if q != s:
+                        self._pmsg[b] = st.extract(acc["a_slot"][0], self._b(("mask", b, q), lambda: torch.full((G,), 1 << q, dtype=torch.uint8, device=self.device)),
+                                                   REQS, live, out=self._pmsg.get(b))
+                        msgs[q]["shard"].copy_(self._pmsg[b]["buf"][q, :, :self.sl])
             first = None
             for q in range(R):
                 if q == s:
@@ -195,9 +218,18 @@ class SpreadRSPaxos:
             m = self._accept_msg(pa["rbuf"], pa["roff"][(b, q)], G)
             o = pr["soff"][(b, q)]
             r_ballot = pr["sbuf"][o:o + G * 8].view(torch.int64)
+            mask_q = self._b(("mask", b, q), lambda: torch.full((G,), 1 << q, dtype=torch.uint8, device=self.device))
+            if self.stores:                                     # what arrived -> the staging store (the message's header + its one shard)
+                from .rsp_payload import REQS
+                pm = self._b(("pmsg_in", b, q), lambda: dict(buf=torch.zeros((self.R, G, self.stores[(b, q)].group_stride), dtype=torch.uint8, device=self.device),
+                                                             dlen=torch.full((G,), self.L, dtype=torch.int32, device=self.device)))
+                pm["buf"][q, :, :self.sl].copy_(m["shard"])
+                self.staging[(b, q)].ingest(dict(buf=pm["buf"], tok=m["val"], mask=mask_q, dlen=pm["dlen"]), m["slot"], REQS, m["flags"])
             eng.accept(flags=m["flags"], peer=self._b(("peer", b, s), lambda: torch.full((G,), s, dtype=torch.uint8, device=self.device)), slot=m["slot"],
-                       ballot=m["ballot"], val=m["val"], mask=self._b(("mask", b, q), lambda: torch.full((G,), 1 << q, dtype=torch.uint8, device=self.device)),
+                       ballot=m["ballot"], val=m["val"], mask=mask_q,
                        out=dict(r_ballot=r_ballot, r_slot=self._b(("r_slot", b, q), lambda: torch.zeros(G, dtype=torch.int32, device=self.device))))
+            if self.stores:
+                self.stores[(b, q)].follow(eng, [(self.staging[(b, q)], REQS)])
             g = None if lost is None else lost.get(b, {}).get(("accept_reply", q, s))
             if g is not None:
                 r_ballot.masked_fill_(g, 0)                     # a lost reply
@@ -220,6 +252,8 @@ class SpreadRSPaxos:
             res = self.reps[(b, s)].accept_replies(slot=acc["a_slot"][0], ballot=ballot, flags=flags,
                                                    out=self._b(("committed", b), lambda: dict(committed=torch.zeros(G, dtype=torch.uint8, device=self.device))))
             out[b] = res["committed"] & self._bufs[("live", b)]
+            if self.stores:
+                self.stores[(b, s)].follow(self.reps[(b, s)])
         return out
 
     def phase_hb_out(self, lost=None):
@@ -257,6 +291,8 @@ class SpreadRSPaxos:
                 fl = fl & ~g.to(torch.uint8)
             eng.heartbeat(flags=fl, peer=self._b(("peer", b, s), lambda: torch.full((G,), s, dtype=torch.uint8, device=self.device)), ballot=m["ballot"],
                           commit_bar=m["commit_bar"], exec_bar=m["exec_bar"], snap_bar=m["snap_bar"], out=back)
+            if self.stores:
+                self.stores[(b, q)].follow(eng)
             g = None if lost is None else lost.get(b, {}).get(("hb", q, s))
             if g is not None:
                 back["reply"].masked_fill_(g, 0)
@@ -278,6 +314,8 @@ class SpreadRSPaxos:
                                                                                        commit_bar=torch.zeros(G, dtype=torch.int32, device=self.device),
                                                                                        exec_bar=torch.zeros(G, dtype=torch.int32, device=self.device),
                                                                                        snap_bar=torch.zeros(G, dtype=torch.int32, device=self.device))))
+            if self.stores:
+                self.stores[(b, s)].follow(self.reps[(b, s)])
 
     def tick(self, data, val, lost=None, heartbeat=False):
         """data / val: per led block (see phase_a); lost[b][(kind, from, to)] = bool [G_b] (optional).  Returns {block: committed}"""
@@ -315,9 +353,9 @@ class in_process:
     """every rank of the job inside one process (one device, or the emulator): same objects, plans and buffers, the collective a
     copy; every rank finishes a phase before any rank starts the next"""
 
-    def __init__(self, total_groups, population, window, world, device, data_len, fault_tolerance=1):
-        self.ranks = [SpreadRSPaxos(total_groups, population, window, r, world, device, data_len, fault_tolerance, exchange=lambda k, me: None)
-                      for r in range(world)]
+    def __init__(self, total_groups, population, window, world, device, data_len, fault_tolerance=1, payload=False):
+        self.ranks = [SpreadRSPaxos(total_groups, population, window, r, world, device, data_len, fault_tolerance, exchange=lambda k, me: None,
+                                    payload=payload) for r in range(world)]
 
     def tick(self, data, val, lost=None, heartbeat=False):
         rs = self.ranks

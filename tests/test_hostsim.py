@@ -229,13 +229,15 @@ def test_rspaxos_device_steady_loop_on_the_host(sim, oracle):
         t.test_one_launch_cluster_argument_errors("cpu")
 
 
-def test_spread_rspaxos_exchange_on_the_host(sim):
+def test_spread_rspaxos_exchange_on_the_host(sim, oracle):
     """layout L2 of the RSPaxos engine with every rank in this process (tests/test_spread_rsp.py): against the co-located steady loop"""
     import test_spread_rsp as t
     with sim.patched():
         t.run_spread_vs_colocated("cpu", 2, 130, T=7)
         t.run_spread_vs_colocated("cpu", 3, 100, T=6)
         t.run_spread_vs_colocated("cpu", 8, 170, T=5, loss=0.0)
+        t.run_spread_vs_colocated("cpu", 2, 90, T=7, payload=True, oracle=oracle)     # ... with the bytes in payload stores
+        t.run_spread_vs_colocated("cpu", 3, 80, T=5, loss=0.0, payload=True, oracle=oracle)
 
 
 def test_rspaxos_masks_and_rs_bytes_end_to_end(sim, oracle):

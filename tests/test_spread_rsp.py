@@ -7,11 +7,14 @@ import numpy as np
 import pytest
 
 
-def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9, hb_every=3, seed=3):
+def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9, hb_every=3, seed=3, payload=False, oracle=None):
+    """payload: the job keeps its bytes in payload stores (put / extract -> message -> ingest / follow); on top of everything else
+    every store cell must then hold what its engine says it holds and every held shard must be the ORACLE's codeword of the batch"""
     import torch
     from summerset_amd import RSPaxosReplicaGroup, rsp_cluster, shard, spread_rsp
     R = 5
-    job = spread_rsp.in_process(total, R, W, world, dev, L, fault_tolerance=ft)
+    job = spread_rsp.in_process(total, R, W, world, dev, L, fault_tolerance=ft, payload=payload)
+    batches = {}                                                 # token -> the serialized batch (host copy)
     ref = {}
     for b in range(world):
         lo, hi = shard.group_range(total, world, b)
@@ -29,7 +32,10 @@ def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9,
             G = hi - lo
             v = (1 + t * total + lo + np.arange(G)).astype(np.uint32)
             v[rng.random(G) < 0.1] = rsp_cluster.NULL
-            data[b], val[b] = dv(rng.integers(0, 256, (G, L), dtype=np.uint8)), dv(v.view(np.int32))
+            raw = rng.integers(0, 256, (G, L), dtype=np.uint8)
+            data[b], val[b] = dv(raw), dv(v.view(np.int32))
+            if payload:
+                batches.update({int(v[g]): raw[g] for g in range(G) if v[g] != rsp_cluster.NULL})
             lost[b] = {}
             if loss:
                 for q in range(1, R):
@@ -46,8 +52,15 @@ def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9,
                 rk = job.ranks[spread_rsp.home(b, q, world)]
                 p = rk._plans["accept"]
                 m = rk._accept_msg(p["rbuf"], p["roff"][(b, q)], hi - lo)
-                assert torch.equal(m["shard"], cw.shard(q)), (t, b, q)
-            assert torch.equal(job.ranks[b % world].cw[b].buf[:, :5 * cw.shard_len], cw.buf[:, :5 * cw.shard_len])
+                if payload:                                  # (a group without a batch this tick has no row to take a shard from)
+                    has = val[b] != -1
+                    assert torch.equal(m["shard"][has], cw.shard(q)[has]), (t, b, q)
+                else:
+                    assert torch.equal(m["shard"], cw.shard(q)), (t, b, q)
+            if not payload:
+                assert torch.equal(job.ranks[b % world].cw[b].buf[:, :5 * cw.shard_len], cw.buf[:, :5 * cw.shard_len])
+        if payload:
+            _check_stores(job, world, R, L, batches, oracle, t)
     for b, (loop, lo, hi) in ref.items():
         for r in range(R):
             x = job.ranks[spread_rsp.home(b, r, world)].reps[(b, r)].dump()
@@ -60,6 +73,39 @@ def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9,
     return n_commit
 
 
+def _check_stores(job, world, R, L, batches, oracle, where):
+    from summerset_amd import spread_rsp
+    sl = oracle.rs_shard_len(L, 3)
+    memo = {}
+    n = 0
+    for rk in job.ranks:
+        for (b, r), st in rk.stores.items():
+            d = rk.reps[(b, r)].dump()
+            c = st.counters()
+            assert c["unsatisfied"] == 0, (where, b, r, c)
+            for plane, (kt, km) in enumerate((("s_val", "s_mask"), ("s_vval", "s_vmask"))):
+                want_tok, want = d[kt].copy(), d[km].copy()
+                want[want_tok == 0xFFFFFFFF] = 0
+                sd = st.dump(plane)
+                assert np.array_equal(sd["avail"], want) and np.array_equal(sd["tok"][want != 0], want_tok[want != 0]), (where, b, r, plane)
+                for w in range(st.W):
+                    if not want[w].any():
+                        continue
+                    row = st.read_row(w, plane)
+                    for g in np.nonzero(want[w])[0]:
+                        tok = int(want_tok[w, g])
+                        if tok not in memo:
+                            x = np.zeros(3 * sl, np.uint8)
+                            x[:L] = batches[tok]
+                            memo[tok] = np.concatenate([x.reshape(3, sl), oracle.rs_encode(3, 2, batches[tok])])
+                        for k in range(R):
+                            if (want[w, g] >> k) & 1:
+                                assert np.array_equal(row[k, g, :sl], memo[tok][k]), (where, b, r, plane, w, g, k)
+                                n += 1
+    assert n > 0
+    return n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,total", [(2, 600), (3, 500), (8, 2048)])
 def test_spread_rspaxos_is_the_colocated_loop(cuda, world, total):
@@ -69,3 +115,10 @@ def test_spread_rspaxos_is_the_colocated_loop(cuda, world, total):
 @pytest.mark.gpu
 def test_spread_rspaxos_no_loss_4k_values(cuda):
     run_spread_vs_colocated(cuda, 4, 1024, W=32, L=4113, loss=0.0, T=6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,total", [(2, 300), (4, 512)])
+def test_spread_rspaxos_with_the_bytes_in_payload_stores(cuda, oracle, world, total):
+    """layout L2 with `payload=True`: put at the leader, extract -> message -> ingest -> follow at every follower"""
+    run_spread_vs_colocated(cuda, world, total, T=7, payload=True, oracle=oracle)
