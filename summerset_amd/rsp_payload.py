@@ -189,7 +189,8 @@ class RSPaxosReplicaWithPayload:
     @staticmethod
     def _uniform(peer):
         p = int(peer[0].item())
-        assert bool((peer == p).all().item()), "one message = one sender: the `peer` array of a call with a staging store must be uniform"
+        if not bool((peer == p).all().item()):
+            raise _lib.SummersetError(_lib.SMR_ERR_ARG, "one message = one sender: the `peer` array of a call with a staging store must be uniform")
         return p
 
     def accept(self, flags, peer, slot, ballot, val, mask, stream=None, out=None):
