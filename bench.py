@@ -597,7 +597,9 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
 
 
 def _payload_leg_traffic():
-    """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or None"""
+    """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or None.  (r7g was
+    taken with one follow per replica -- five plan and five byte launches per tick; follow_many issues the followers' four as one
+    launch each over the same cells and bytes, so the per-tick sum is the same.)"""
     try:
         with open(os.path.join(ROOT, "profiles", "r7g_pmc_traffic_payload_leg.json")) as f:
             k = json.load(f)["kernels"]
@@ -662,7 +664,7 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": moved,
                          "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic(),
                          "traffic_source": "profiles/r7g_pmc_traffic_payload_leg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; "
-                                           "per tick = one ps_put_kernel<3> + five ps_plan_kernel + five ps_bytes_kernel launches)",
+                                           "per tick = one ps_put_kernel<3> + five ps_plan_kernel + five ps_bytes_kernel launches; taken before follow_many merged the followers' four)",
                          "note": "per tick (tick with the stores minus the engines' tick alone); bytes the path has to move: L read + 5 shard_len "
                                  "written by put, one shard read + written for the leader's voted copy, (1 + 1) shards read + written by "
                                  "each of 4 followers (reqs, then voted)"},

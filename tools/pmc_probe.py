@@ -67,4 +67,6 @@ if a.extra:
     torch.cuda.synchronize()
     bench.rspaxos_leg(torch, dev, ticks=8, warmup=4)   # round 3: the one-pass from_data + encode + fan-out (rs_from_data_xtime) and the rsp_* handlers
     torch.cuda.synchronize()
+    bench.rspaxos_payload_leg(torch, dev, ticks=8, warmup=4)   # round 4: the payload store (ps_put_kernel<3>, ps_plan* / ps_bytes* kernels)
+    torch.cuda.synchronize()
 print("done")
