@@ -657,10 +657,10 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
     us_engine = _time_us(torch, lambda i: one_tick(bytes_=False), 12)   # the engines' tick alone (after the checks: the stores stay behind from here)
     us_bytes = max(us - us_engine, 1e-3)
     return {"workload": "config 4's engines + one-launch tick, and the tick's shard bytes through the payload store: put (from_data + RS(3,2) "
-                        "encode into the ring, %d groups x L = %d) + one follow per replica (window %d, two planes)" % (G, L, W),
+                        "encode into the ring, %d groups x L = %d) + the leader's follow + one follow_many for the four followers (window %d, two planes)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
             "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6),
-            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel + 5 x (ps_plan_kernel + ps_bytes_kernel)", "achieved": moved / (us_bytes * 1e-6) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3> + the leader's ps_plan_kernel / ps_bytes_kernel + the four followers' ps_plan_many_kernel / ps_bytes_many_kernel", "achieved": moved / (us_bytes * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": moved,
                          "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic(),
                          "traffic_source": "profiles/r7g_pmc_traffic_payload_leg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; "
