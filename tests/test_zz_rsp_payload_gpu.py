@@ -291,6 +291,53 @@ def test_random_handler_calls_never_invent_a_shard(cuda, oracle, G, W, me, ft):
     assert n_cmp > 1000 and c["copied"] > 0 and c["rebuilt"] > 0, (n_cmp, c)
 
 
+def test_one_call_with_two_senders_takes_each_group_s_shard_from_its_own_sender(cuda, oracle):
+    """`sel_dev`: even groups are led by replica 0, odd groups by replica 1 (each preset so in its own engine), both encode a tick's
+    batches; follower 2 handles BOTH leaders' Accepts in ONE handle_msg_accept call (`peer` = 0, 1, 0, 1, ...) and its follow must
+    take shard 2 of every group from the store of that group's sender (the other leader's store holds ANOTHER batch in the same
+    row: another token, never taken); with the senders swapped in `sel_dev` nobody can give anything and the store says so"""
+    import torch
+    from summerset_amd import RSPaxosPayloadStore, RSPaxosReplicaGroup
+    from summerset_amd.rsp_payload import REQS, VOTED
+    G, R, W, L = 64, 5, 8, 90
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    reps = [RSPaxosReplicaGroup(G, R, me=r, window=W) for r in range(3)]
+    stores = [RSPaxosPayloadStore(G, R, W, max_data_len=L) for _ in range(3)]
+    exp = Expect(oracle, R, 3, L)
+    even = np.arange(G) % 2 == 0
+    acc = []
+    for ld in (0, 1):
+        reps[ld].preset_leader(ld)
+        tok = (1000 * (ld + 1) + np.arange(G)).astype(np.uint32)
+        a = reps[ld].req_batch(t(tok.view(np.int32)))
+        stores[ld].put(a, t(batch_bytes(tok, L)), t(batch_len(tok, L).view(np.int32)))
+        stores[ld].follow(reps[ld])
+        acc.append((a, tok))
+    # follower 2 follows leader 0 in the even groups and leader 1 in the odd ones: one Accept call carrying both
+    peer = np.where(even, 0, 1).astype(np.uint8)
+    pick = lambda k: torch.where(t(even), acc[0][0][k] if acc[0][0][k].dim() == 1 else acc[0][0][k][0], acc[1][0][k] if acc[1][0][k].dim() == 1 else acc[1][0][k][0])
+    reps[2].preset_leader(0)
+    res = reps[2].accept(flags=t(np.ones(G, np.uint8)), peer=t(peer), slot=pick("a_slot"), ballot=pick("a_ballot"), val=pick("a_val"),
+                         mask=t(np.full(G, 1 << 2, np.uint8)))
+    took = res["r_ballot"].cpu().numpy() != 0                    # (leader 1's ballot is the higher one: every odd group accepts; the even ones accept leader 0's)
+    assert took.all()
+    stores[2].follow(reps[2], [(stores[0], REQS), (stores[1], REQS), None], sel=t(peer))
+    assert stores[2].counters() == dict(copied=2 * G, rebuilt=0, unsatisfied=0, rekeyed=0)
+    want_tok = np.where(even, acc[0][1], acc[1][1])
+    for plane in (REQS, VOTED):
+        d = stores[2].dump(plane)
+        assert (d["avail"][0] == 1 << 2).all() and np.array_equal(d["tok"][0], want_tok)
+        row = stores[2].read_row(0, plane)
+        for g in range(G):
+            cw = exp.shards(want_tok[g])[0]
+            assert np.array_equal(row[2, g, :cw.shape[1]], cw[2]), (plane, g)
+    # a sender named for a group must be the one that gives: with the senders swapped nobody can give anything
+    fresh = RSPaxosPayloadStore(G, R, W, max_data_len=L)
+    fresh.follow(reps[2], [(stores[0], REQS), (stores[1], REQS), None], sel=t(1 - peer))
+    c = fresh.counters()
+    assert c["copied"] == 0 and c["unsatisfied"] == 2 * G and not fresh.dump(REQS)["avail"].any()
+
+
 def test_steady_tick_is_one_put_and_one_shard_per_follower(cuda, oracle):
     """no loss, no leader change: per slot the leader encodes (n shards), every follower copies its one shard into both
     planes, nothing is rebuilt except the leader's parity -- the counters say so exactly"""
