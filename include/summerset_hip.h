@@ -906,6 +906,13 @@ int smr_rsp_pstore_extract(const smr_rsp_pstore *s, int plane, const uint8_t *fl
                            uint8_t *out_dev, uint32_t *tok_out_dev, uint8_t *mask_out_dev, uint32_t *dlen_out_dev, void *stream);
 int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint32_t *tok_dev,
                           const uint8_t *mask_dev, const uint32_t *dlen_dev, const uint8_t *in_dev, void *stream);
+/* The Accepts of a call as the frames TcpTransport writes (safetcp.rs:127-132; PeerMsg::Accept { slot, ballot, reqs_cw },
+ * rspaxos/mod.rs:262-270; RSCodeword's Encode, utils/rscoding.rs:43-77), payload included, straight out of the store: frame g =
+ * frames_dev[g * stride .. + len_dev[g]) carries the shards mask_dev[g] of row slot_dev[g] of `plane` that the row holds -- byte
+ * for byte smr_wire_rsp_accept(smr_wire_rscodeword(..)).  len_dev[g] = 0: nothing to send (flags_dev[g] = 0, a NULL slot, no
+ * shard of the mask present); 0xFFFFFFFF: the frame does not fit `stride` (header <= 64 bytes + 11 per shard + the shards). */
+int smr_rsp_pstore_emit_accepts(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint64_t *ballot_dev,
+                                const uint8_t *mask_dev, uint8_t *frames_dev, uint64_t stride, uint32_t *len_dev, void *stream);
 int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_t *avail_host, uint32_t *dlen_host);
 int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host);
 int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,

@@ -325,6 +325,7 @@ SYMBOLS = [
     ("smr_rsp_pstore_get_data", _i, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     ("smr_rsp_pstore_extract", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_rsp_pstore_ingest", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_rsp_pstore_emit_accepts", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     ("smr_rsp_pstore_dump", _i, [_vp, _i, _vp, _vp, _vp]),
     ("smr_rsp_pstore_read_row", _i, [_vp, _i, _u32, _vp]),
     ("smr_rsp_pstore_layout", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),

@@ -424,6 +424,66 @@ __global__ __launch_bounds__(256) void ps_ingest_kernel(const PsView v, int plan
         if ((m >> k) & 1u) ps_store16(v.pl[plane].bytes + ps_off(v, row, k, g) + c0, ps_load16(in + ((size_t)k * v.G + g) * v.cap_sl + c0));
 }
 
+// The Accept a leader sends, as the frame TcpTransport writes (safetcp.rs:127-132: u64 BE length, then bincode "standard" of
+// PeerMessage::Msg { msg: PeerMsg::Accept { slot, ballot, reqs_cw } }, rspaxos/mod.rs:262-270 -- variants 0 and 2 -- with
+// RSCodeword's own Encode, utils/rscoding.rs:43-77: d u8, p u8, data_len, shard_len, Vec<Option<Vec<u8>>> shards, data_copy None)
+// straight out of the store: per group g the shards mask[g] of row slot[g] that the row holds (`subset_copy`, request.rs:127-142)
+// into frames + g * stride, byte for byte what smr_wire_rsp_accept(smr_wire_rscodeword(..)) writes on the host.  One lane per
+// (group, 16-byte column): every lane walks the d + p Option headers for the offsets, the column-0 lane writes the header bytes.
+__device__ __forceinline__ uint32_t ps_vl(uint64_t v) { return v < 251 ? 1u : v < (1ull << 16) ? 3u : v < (1ull << 32) ? 5u : 9u; }
+__device__ __forceinline__ uint32_t ps_put_varint(uint8_t *p, uint64_t v) {
+    if (v < 251) { p[0] = (uint8_t)v; return 1; }
+    const uint32_t nb = v < (1ull << 16) ? 2u : v < (1ull << 32) ? 4u : 8u;
+    p[0] = (uint8_t)(nb == 2 ? 0xFB : nb == 4 ? 0xFC : 0xFD);
+    for (uint32_t i = 0; i < nb; i++) p[1 + i] = (uint8_t)(v >> (8 * i));
+    return 1 + nb;
+}
+__global__ __launch_bounds__(256) void ps_emit_accepts_kernel(const PsView v, int plane, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ slot,
+                                                              const uint64_t *__restrict__ ballot, const uint8_t *__restrict__ mask,
+                                                              uint8_t *__restrict__ frames, uint64_t stride, uint32_t *__restrict__ len, uint32_t nblk) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    if (g >= v.G) return;
+    const bool on = (!flags || flags[g]) && slot[g] != PS_NULL;
+    const uint32_t row = on ? (slot[g] & v.Wmask) : 0u;
+    const size_t i = (size_t)row * v.G + g;
+    const uint32_t m = (on && v.pl[plane].tok[i] != PS_NULL) ? ((uint32_t)mask[g] & v.pl[plane].avail[i]) : 0u;
+    if (!m) { if (blk == 0) len[g] = 0; return; }
+    const uint32_t L = v.pl[plane].dlen[i], sl = ps_shard_len(L, v.d), c0 = blk * 16u;
+    const uint64_t sv = slot[g], bv = ballot[g];
+    const uint32_t h0 = 8u + 1u + 1u + ps_vl(sv) + ps_vl(bv) + 2u + ps_vl(L) + ps_vl(sl) + 1u;     // up to the first Option tag
+    const uint32_t per = 1u + ps_vl(sl) + sl;
+    const uint32_t total = h0 + (uint32_t)__popc(m) * per + (v.n - (uint32_t)__popc(m)) + 1u;
+    if (total > stride) { if (blk == 0) len[g] = 0xFFFFFFFFu; return; }                           // the caller's slot is too short
+    uint8_t *f = frames + (size_t)g * stride;
+    if (blk == 0) {
+        len[g] = total;
+        const uint64_t plen = total - 8u;
+        for (int b = 0; b < 8; b++) f[b] = (uint8_t)(plen >> (8 * (7 - b)));
+        uint32_t o = 8;
+        f[o++] = 0; f[o++] = 2;                                                                    // PeerMessage::Msg, PeerMsg::Accept
+        o += ps_put_varint(f + o, sv); o += ps_put_varint(f + o, bv);
+        f[o++] = (uint8_t)v.d; f[o++] = (uint8_t)(v.n - v.d);
+        o += ps_put_varint(f + o, L); o += ps_put_varint(f + o, sl);
+        f[o++] = (uint8_t)v.n;
+        for (uint32_t k = 0; k < v.n; k++) {
+            if ((m >> k) & 1u) { f[o++] = 1; o += ps_put_varint(f + o, sl); o += sl; }
+            else f[o++] = 0;
+        }
+        f[o] = 0;                                                                                  // data_copy: None
+    }
+    if (c0 >= sl) return;
+    uint32_t o = h0;
+    for (uint32_t k = 0; k < v.n; k++) {
+        if (!((m >> k) & 1u)) { o += 1; continue; }
+        uint8_t *dst = f + o + 1u + ps_vl(sl) + c0;
+        const uint8_t *src = v.pl[plane].bytes + ps_off(v, row, k, g) + c0;
+        if (c0 + 16u <= sl) ps_store16(dst, ps_load16(src));
+        else for (uint32_t b = 0; b < sl - c0; b++) dst[b] = src[b];
+        o += per;
+    }
+}
+
 // ---- host: GF(2^8) matrices for the rebuild table ------------------------------------------------------------------
 struct PsGf {
     uint8_t exp[512], log[256];
@@ -706,6 +766,20 @@ int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev
     const uint64_t threads = (uint64_t)v.G * nblk;
     hipLaunchKernelGGL(ps_ingest_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, plane, flags_dev, slot_dev,
                        tok_dev, mask_dev, dlen_dev, in_dev, nblk);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_emit_accepts(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint64_t *ballot_dev,
+                                const uint8_t *mask_dev, uint8_t *frames_dev, uint64_t stride, uint32_t *len_dev, void *stream) {
+    if (!s || plane < 0 || plane > 1 || !slot_dev || !ballot_dev || !mask_dev || !frames_dev || !len_dev)
+        return fail(SMR_ERR_ARG, "pstore emit_accepts: bad argument");
+    if (stride < 64) return fail(SMR_ERR_ARG, "pstore emit_accepts: stride is shorter than a frame's header");
+    const PsView &v = s->v;
+    const uint32_t nblk = v.cap_sl / 16u;
+    const uint64_t threads = (uint64_t)v.G * nblk;
+    hipLaunchKernelGGL(ps_emit_accepts_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, plane, flags_dev,
+                       slot_dev, ballot_dev, mask_dev, frames_dev, stride, len_dev, nblk);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -109,6 +109,16 @@ class RSPaxosPayloadStore:
         check(self._L.smr_rsp_pstore_ingest(self._h, int(plane), _ptr(flags), _ptr(slot), msg["tok"].data_ptr(), msg["mask"].data_ptr(),
                                             msg["dlen"].data_ptr(), msg["buf"].data_ptr(), stream_ptr(stream)))
 
+    def emit_accepts(self, slot, ballot, mask, stride, plane=REQS, flags=None, stream=None):
+        """the Accepts (slot, ballot, shards `mask` of the row) as wire frames with their payload: (uint8 [G, stride], int32 [G] lengths;
+        0 = nothing to send, -1 = does not fit `stride`)"""
+        import torch
+        frames = torch.zeros((self.G, int(stride)), dtype=torch.uint8, device=slot.device)
+        ln = torch.zeros(self.G, dtype=torch.int32, device=slot.device)
+        check(self._L.smr_rsp_pstore_emit_accepts(self._h, int(plane), _ptr(flags), _ptr(slot), _ptr(ballot), _ptr(mask), frames.data_ptr(), int(stride),
+                                                  ln.data_ptr(), stream_ptr(stream)))
+        return frames, ln
+
     # ---- host-side reads ------------------------------------------------------------------------------------------
     def dump(self, plane=REQS):
         tok, av, ln = np.zeros((self.W, self.G), np.uint32), np.zeros((self.W, self.G), np.uint8), np.zeros((self.W, self.G), np.uint32)
