@@ -342,7 +342,9 @@ def test_accept_frames_with_their_payload_are_the_host_encoder_s(cuda, oracle):
     """`smr_rsp_pstore_emit_accepts`: the Accept frames a leader sends, shard bytes included, written by a kernel straight out of
     the store -- byte for byte what the host encoder (`smr_wire_rsp_accept` around `smr_wire_rscodeword`, the reference's frame:
     safetcp.rs:127-132, rspaxos/mod.rs:262-270, rscoding.rs:43-77) writes from the ORACLE's codeword: ragged batch lengths (1-,
-    3-byte varints), ballots up to 2^40 (9-byte varints), every subset of shards, groups with nothing to send, a slot too short"""
+    3-byte varints), ballots up to 2^40 (9-byte varints), every subset of shards, groups with nothing to send, a slot too short.
+    (Written when the round's GPU budget was spent: tests/test_hostsim.py runs it on the kernel-source emulator; its first device
+    run is the driver's at round end.)"""
     import torch
     from summerset_amd import RSPaxosPayloadStore, RSPaxosReplicaGroup, wire
     from summerset_amd.rsp_payload import REQS, VOTED
