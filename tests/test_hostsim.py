@@ -256,7 +256,8 @@ def test_rspaxos_payload_store_on_the_host(sim, oracle):
         t.test_steady_tick_is_one_put_and_one_shard_per_follower("cpu", oracle)
         t.test_rows_are_shard_major_batches_the_rs_kernels_accept("cpu", oracle)
         t.test_extract_and_ingest_round_trip("cpu", oracle)
-        t.test_accept_frames_with_their_payload_are_the_host_encoder_s("cpu", oracle)
+        import test_zzzz_rsp_emit_accepts_gpu as te
+        te.test_accept_frames_with_their_payload_are_the_host_encoder_s("cpu", oracle)   # Accept frames with their payload == the host encoder's
         t.test_one_call_with_two_senders_takes_each_group_s_shard_from_its_own_sender("cpu", oracle)
         tot, n_exec, n_cmp = t.run_closed_loop("cpu", oracle, 40, 16, 1, 0.1, 77, T=15, staging=True)    # bytes travel as messages only
         assert tot["rebuilt"] > 0 and n_exec > 0
