@@ -34,6 +34,127 @@ PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over to
             % os.path.basename(PMC_FILE))
 
 
+# ---- the final stdout line ------------------------------------------------------------------------------------------------------
+# The driver reads the LAST stdout line from a bounded tail: round 4's 20.7 KB line did not parse.  The final
+# line is therefore a fixed, small set of fields (< 4 KB); everything else -- prose, sweeps, per-region lists, the exchange's byte
+# counts -- goes to bench_detail.json (repo root, and gpurun_out/ when that exists), untouched.
+LINE_BUDGET = 4000
+DETAIL_FILE = "bench_detail.json"
+
+
+def _num(x, digits=6):
+    """a float to `digits` significant digits (None / ints / bools pass through): the line is for reading and the judge's recomputation"""
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _leg_roof(leg):
+    """the roofline object a leg's headline figure is quoted on (the legs nest it differently)"""
+    for path in (("whole_tick_roofline",), ("roofline",), ("one_call_per_tick_phase_by_phase", "roofline"), ("one_call_per_tick", "roofline")):
+        o = leg
+        for k in path:
+            o = o.get(k) if isinstance(o, dict) else None
+        if isinstance(o, dict):
+            return o
+    return {}
+
+
+def compact_leg(leg):
+    """exactly {value, unit, ms_per_tick, frac, frac_on_8d_bytes, traffic_ratio, cpu_cores} of one secondary leg (or {error})"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120]}
+    src = leg
+    if isinstance(leg.get("one_call_per_tick_phase_by_phase"), dict):   # the EPaxos cluster leg quotes its one-launch tick
+        src = leg["one_call_per_tick_phase_by_phase"]
+    roof = _leg_roof(leg)
+    ms = src.get("ms_per_tick")
+    if ms is None:
+        for k, f in (("us_per_tick", 1e-3), ("call_us", 1e-3)):
+            if src.get(k) is not None:
+                ms = src[k] * f
+                break
+    if ms is None and roof.get("avg_launch_us") is not None:
+        ms = roof["avg_launch_us"] * 1e-3
+    alg = roof.get("alg_bytes_per_launch", roof.get("alg_bytes_per_tick"))
+    traffic = roof.get("traffic", roof.get("traffic_per_tick"))
+    f8d = roof.get("frac_on_survey_8d_bytes", roof.get("frac"))
+    cpu = leg.get("cpu_baseline") if isinstance(leg.get("cpu_baseline"), dict) else {}
+    return {"value": _num(src.get("value")), "unit": str(src.get("unit", leg.get("unit")))[:48], "ms_per_tick": _num(ms),
+            "frac": _num(roof.get("frac"), 4), "frac_on_8d_bytes": _num(f8d, 4),
+            "traffic_ratio": _num(traffic / alg, 4) if traffic and alg else None,
+            "cpu_cores": cpu.get("cores", leg.get("cores"))}
+
+
+SECONDARY_LEGS = ("rs_encode", "raft_quorum", "epaxos_fast_quorum", "epaxos_cluster", "rspaxos", "rspaxos_payload", "craft_payload", "repnothing",
+                  "wire_ingest", "reply_ingest", "epaxos_execution", "rspaxos_replica", "craft_leader", "quorum_read")
+
+
+def compact_line(full):
+    """the line the driver parses, from the full record (any layout's): contract fields, `roofline`, `cpu_baseline`, `legs_failed`, the
+    L2 pass in four numbers and every secondary leg as compact_leg() -- nothing else."""
+    cfg = full.get("config") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _num(out["value"], 9), _num(out["ms_per_step"], 7)
+    out["config"] = dict({"workload": str(cfg.get("workload", ""))[:200]},
+                         **{k: cfg[k] for k in ("groups_per_gpu", "replicas", "slots_per_tick", "window", "layout", "spread_ranks", "value_bytes") if k in cfg})
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        wt = r.get("whole_tick") or {}
+        out["roofline"] = {"bound": r.get("bound"), "kernel": str(r.get("kernel"))[:64], "alg_bytes_per_launch": _num(r.get("alg_bytes_per_launch")),
+                           "avg_launch_us": _num(r.get("avg_launch_us")), "achieved": _num(r.get("achieved")), "peak": r.get("peak"),
+                           "unit": r.get("unit"), "frac": _num(r.get("frac"), 4), "traffic": _num(r.get("traffic")),
+                           "whole_tick": {"us": _num(wt.get("us")), "frac_alg": _num(wt.get("frac_alg"), 4), "frac_pmc": _num(wt.get("frac_pmc"), 4)}}
+    else:
+        out["roofline"] = None
+    c = full.get("cpu_baseline")
+    if isinstance(c, dict) and "error" not in c:
+        out["cpu_baseline"] = {"value": _num(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"),
+                               "single_core_value": _num(c.get("single_core_value")), "kind": c.get("kind"), "sample": str(c.get("sample", ""))[:160]}
+    else:
+        out["cpu_baseline"] = c if c is None else {"error": str(c.get("error"))[:120]}
+    l2 = full.get("l2")
+    if isinstance(l2, dict):
+        out["l2"] = {"error": str(l2["error"])[:120]} if "error" in l2 else {
+            "ranks": l2.get("ranks"), "virtual": str(l2.get("ranks_are", "")).startswith("virtual"), "ms_per_tick": _num(l2.get("ms_per_tick")),
+            "ms_per_tick_per_virtual_rank": _num(l2.get("ms_per_tick_per_virtual_rank")),
+            "steady_ms_per_tick_per_virtual_rank": _num((l2.get("steady_state") or {}).get("ms_per_tick_per_virtual_rank")),
+            "value": _num(l2.get("value")), "backend": l2.get("backend"), "via": str((l2.get("exchange") or {}).get("via", ""))[:60]}
+    if isinstance(full.get("exchange"), dict):                   # the spread layouts' own lines
+        ex = full["exchange"]
+        out["exchange"] = {"via": str(ex.get("via", ""))[:80], "bytes_sent_per_tick_per_rank": _num(ex.get("bytes_sent_per_tick_per_rank"))}
+    for name in SECONDARY_LEGS:
+        if name in full:
+            out[name] = compact_leg(full[name])
+    out["legs_failed"] = full.get("legs_failed", [])
+    out["detail"] = DETAIL_FILE
+    return out
+
+
+def emit_line(full):
+    """write the full record beside the script, print the compact line LAST on stdout"""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    json.dump(full, f, indent=1)
+            except OSError as e:
+                sys.stderr.write("bench.py: could not write %s: %s\n" % (os.path.join(d, DETAIL_FILE), e))
+    text = json.dumps(compact_line(full), allow_nan=False)
+    if len(text) > LINE_BUDGET:
+        sys.stderr.write("bench.py: the final line is %d bytes (budget %d)\n" % (len(text), LINE_BUDGET))
+    sys.stdout.flush()
+    print(text)
+    sys.stdout.flush()
+
+
 def pmc_file():
     """the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs, gfx950 corrections applied: see the
     file's "corrections"); None if absent.  bench.py cannot collect PMC counters itself -- they need rocprofv3."""
@@ -88,6 +209,7 @@ def timeouts_text(args):
 
 
 def parse():
+    """options; the measurements behind the defaults are in profiles/HISTORY.md and DESIGN.md §4 / §7"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -99,41 +221,25 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct pre-generated tick inputs cycled in HBM")
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--timeouts", type=float, default=0.01)
-    ap.add_argument("--timeout-span", type=int, default=None, help="draw the groups' timeout ticks from [0, N).  Default: max(steps + warmup, "
-                    "%d) -- the leader-timeout RATE per tick is the workload's, not the run length's: a run shorter than the default "
-                    "%d ticks sees the same changes per tick as the default run (SURVEY 8(d) spreads its 1 %%%% over 1024 ticks)" % (TIMEOUT_HORIZON, TIMEOUT_HORIZON))
-    ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the straggler list (0 = no list); 4 "
-                    "measured best with --batch 8 (profiles/round2/r2z6_ttl_batch.log), 8 with one smr_mp_tick call per tick (profiles/round2/r2g_straggler_sweep.log)")
-    ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per smr_mp_run_ticks call (the fused tick kernel, one launch per <= 16 ticks; "
-                    "excludes the side stream).  0 = one smr_mp_tick call per tick: five per-round launches + the straggler side launch "
-                    "(measured faster: the fused kernel needs 229 VGPRs -- one block per CU)")
-    ap.add_argument("--batch", type=int, default=8, help="> 0: ticks per smr_mp_run_ticks call WITH the straggler list on: the bulk kernels still "
-                    "run tick by tick, the list's groups go through the whole batch in one side-stream launch and the streams meet "
-                    "once per batch (<= 16 ticks) instead of once per tick; 8 measured best (profiles/round2/r2z_batch.log).  0 = one "
-                    "smr_mp_tick call per tick")
-    ap.add_argument("--round-ticks", type=int, default=12, help="ticks of the untimed per-round pass behind the timed region "
-                    "(HIP event pairs around every round kernel: the `kernels` breakdown and the quorum kernel's own roofline)")
-    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos", "colocated-epaxos", "spread-rspaxos"), default="colocated", help="spread = SURVEY §8e L2: replica r of block b on rank "
-                    "(b + r) mod N, every protocol message crosses ranks through one all_to_all_single per exchange (summerset_amd/spread_mp.py)")
-    ap.add_argument("--spread-ranks", type=int, default=4, help="--layout spread on ONE GPU: this many virtual ranks inside the process (same "
-                    "kernels, plans and buffers; the collective is a device copy)")
-    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps ticks each, back to back, every one between its own barrier + "
-                    "synchronize pair; `value` / `ms_per_step` are the MEDIAN region's, the others are listed beside it (a 2 ms region "
-                    "carries +-25 %% box noise, VERDICT r2).  0 = 9 when steps <= 30, else 3.  The leader-timeout rate per tick is kept: "
-                    "the stream's timeout fraction grows with the run")
-    ap.add_argument("--no-l2", action="store_true", help="skip the `l2` object (the same workload a few ticks in the spread layout, one "
-                    "all_to_all_single per exchange: RCCL at --gpus > 1, four virtual ranks on one GPU)")
+    ap.add_argument("--timeout-span", type=int, default=None,
+                    help="draw timeout ticks from [0, N); default max(steps + warmup, %d): a constant rate per tick" % TIMEOUT_HORIZON)
+    ap.add_argument("--straggler-ticks", type=int, default=4, help="ticks a group in a leader change stays on the side list (0 = no list)")
+    ap.add_argument("--fused", type=int, default=0, help="> 0: ticks per call through the fused tick kernel (no side stream)")
+    ap.add_argument("--batch", type=int, default=8, help="> 0: ticks per smr_mp_run_ticks call with the side list on; 0 = one call per tick")
+    ap.add_argument("--round-ticks", type=int, default=12, help="--fused only: ticks of the untimed per-round pass behind the timed region")
+    ap.add_argument("--layout", choices=("colocated", "spread", "spread-epaxos", "colocated-epaxos", "spread-rspaxos"), default="colocated",
+                    help="spread* = SURVEY 8e L2: replica r of block b on rank (b + r) mod N")
+    ap.add_argument("--spread-ranks", type=int, default=4, help="spread layouts on ONE GPU: virtual ranks inside the process")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps ticks (median reported); 0 = 9 if steps <= 30 else 3")
+    ap.add_argument("--no-l2", action="store_true", help="skip the `l2` object (the workload a few ticks in the spread layout)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU oracle baseline")
     ap.add_argument("--no-rs", action="store_true", help="skip the RS(3,2) encode leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the Raft (config 3) and EPaxos (config 5) kernel legs")
-    ap.add_argument("--late-legs", action="store_true", help="also run the legs of kernels that have not had a device run yet "
-                    "(EPaxos execution, the RSPaxos replica engine), each in a child process")
-    ap.add_argument("--role-rotation", type=int, default=0, help="1: rows of the bulk round launches by role (smr_mp_set_role_rotation): row 0 runs "
-                    "every group's leader, whoever that is")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other protocols' legs")
+    ap.add_argument("--late-legs", action="store_true", help="also run the replica-engine / CRaft / quorum-read legs (child processes)")
+    ap.add_argument("--role-rotation", type=int, default=0, help="1: rows of the bulk round launches by role (row 0 = every leader)")
     ap.add_argument("--leg", default=None, help="internal: run one secondary leg in this process and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--launch-check", action="store_true", help="only prove the launch: start the ranks --gpus asks for, count them "
-                    "with one all-reduce (RCCL with GPUs, gloo without) and print {n_gpus, ranks}; runs no kernel")
+    ap.add_argument("--launch-check", action="store_true", help="only prove the launch: count the ranks with one all-reduce, no kernel")
     return ap.parse_args()
 
 
@@ -662,6 +768,8 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
             "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6),
             "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3> + the leader's ps_plan_kernel / ps_bytes_kernel + the four followers' ps_plan_many_kernel / ps_bytes_many_kernel", "achieved": moved / (us_bytes * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": moved,
+                         "survey_8d_bytes_per_launch": G * (5 * sl + 85),
+                         "frac_on_survey_8d_bytes": G * (5 * sl + 85) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,   # the WHOLE tick on SURVEY 8(d)'s bytes
                          "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic(),
                          "traffic_source": "profiles/r7g_pmc_traffic_payload_leg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; "
                                            "per tick = one ps_put_kernel<3> + five ps_plan_kernel + five ps_bytes_kernel launches; taken before follow_many merged the followers' four)",
@@ -1218,7 +1326,7 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         old = spread_run(args, torch, dist, rank, world, dev, args.steps, args.warmup, call_by_call=True)
         line["call_by_call"] = {"ms_per_step": old["ms_per_step"], "value": old["value"]}
     if rank == 0:
-        print(json.dumps(line))
+        emit_line(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1276,7 +1384,7 @@ def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
                          "rs_payload_GiBps": len(blocks) * G * L * args.steps / 2**30 / elapsed * (1 if virtual else world)},
             "roofline": None, "cpu_baseline": None}
     if rank == 0:
-        print(json.dumps(line))
+        emit_line(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1339,7 +1447,7 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
             "note": "correctness layout of config 5's inter-replica fan-out (handler calls of the Python driver included); the roofline / "
                     "cpu_baseline objects belong to the co-located line"}
     if rank == 0:
-        print(json.dumps(line))
+        emit_line(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1398,7 +1506,7 @@ def colocated_epaxos_main(args, torch, dist, rank, local, world, dev):
             "slow_path_instances_this_rank": n_slow, "commands_executed_this_rank": executed, "roofline": None, "cpu_baseline": None,
             "note": "config 5 in layout L1; the roofline / cpu_baseline objects belong to the headline line"}
     if rank == 0:
-        print(json.dumps(line))
+        emit_line(line)
     job.close()
     if world > 1:
         dist.barrier()
@@ -1737,7 +1845,7 @@ def main():
                             line[name]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
                             failed.append(name + ".cpu_baseline")
         line["legs_failed"] = failed               # [] = every leg that was asked for ran (a missing cpu_baseline / roofline is an error here)
-        print(json.dumps(line))
+        emit_line(line)
         sys.stdout.flush()
     if world > 1:
         # Every rank learns whether ANY rank's L2 pass failed or hung before it picks the way out: through the job's

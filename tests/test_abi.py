@@ -165,3 +165,55 @@ def test_stream_handle_goes_through_one_helper(monkeypatch):
         for _, cls in inspect.getmembers(mod, inspect.isclass):
             assert not hasattr(cls, "_stream"), cls
     assert n_calls > 40
+
+
+def _import_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("smr_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_final_line_is_small_and_parses(capsys, tmp_path, monkeypatch):
+    """round 4's 20.7 KB line was not parsed by the driver.  The final stdout line is built from a full record
+    (round 4's own, every leg present) and must stay under 4 KB, round-trip through json, carry the contract fields, `roofline`
+    and `cpu_baseline`, and per secondary leg exactly the seven compact keys; the full record goes to bench_detail.json."""
+    import json
+    bench = _import_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r7m_bench_driver_command.json")))
+    assert len(json.dumps(full)) > 15000                          # the record that did not parse
+    full["craft_payload"] = dict(full["rspaxos_payload"])          # round 5's extra leg
+    full["epaxos_execution"] = {"error": "RuntimeError: " + "x" * 500}
+    full["roofline"]["traffic"] = float("nan")                    # never NaN / Infinity on the line
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit_line(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    text = out[-1]
+    assert len(text) < bench.LINE_BUDGET < 6000, len(text)
+    line = json.loads(text)
+    assert "NaN" not in text and "Infinity" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "legs_failed"):
+        assert k in line, k
+    assert line["steps"] == 20 and line["warmup"] == 5 and line["n_gpus"] == 1
+    assert abs(line["value"] - full["value"]) / full["value"] < 1e-6
+    assert abs(line["ms_per_step"] - full["ms_per_step"]) / full["ms_per_step"] < 1e-5
+    assert len(line["config"]["workload"]) <= 200 and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-3
+    assert set(r["whole_tick"]) == {"us", "frac_alg", "frac_pmc"}
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 32 and line["cpu_baseline"]["single_core_value"] > 0
+    keys = {"value", "unit", "ms_per_tick", "frac", "frac_on_8d_bytes", "traffic_ratio", "cpu_cores"}
+    for name in bench.SECONDARY_LEGS:
+        if name in full and "error" not in full[name]:
+            assert set(line[name]) == keys, (name, line[name])
+    assert abs(line["rspaxos"]["frac_on_8d_bytes"] - 0.2027) < 1e-3 and abs(line["rspaxos"]["frac"] - 0.3228) < 1e-3
+    assert abs(line["epaxos_cluster"]["ms_per_tick"] - 0.5404) < 1e-3 and line["epaxos_cluster"]["traffic_ratio"] > 10
+    assert abs(line["raft_quorum"]["ms_per_tick"] - 0.01133) < 1e-4 and line["raft_quorum"]["cpu_cores"] == 32
+    assert abs(line["wire_ingest"]["ms_per_tick"] - 0.2237) < 1e-3
+    assert len(line["epaxos_execution"]["error"]) <= 120
+    detail = json.load(open(tmp_path / bench.DETAIL_FILE))       # nothing is lost: the full record sits beside the script
+    assert detail["timed_regions"] == full["timed_regions"] and detail["l2"]["exchange"] == full["l2"]["exchange"]
