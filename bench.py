@@ -1332,6 +1332,22 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+def _bind_library_exchange(job, dist, dev, virtual):
+    """at N > 1 over RCCL the spread layouts' exchanges run inside the library (smr_comm_exchange: grouped ncclSend / ncclRecv on the
+    plans' buffers); SMR_L2_TORCH=1 keeps torch.distributed.all_to_all_single.  Returns (comm or None, how the bytes travel)."""
+    if virtual:
+        return None, "a device copy between the virtual ranks' buffers"
+    if dist.get_backend() != "nccl" or os.environ.get("SMR_L2_TORCH") is not None:
+        return None, "torch.distributed.all_to_all_single"
+    try:
+        from summerset_amd import comm as _comm
+        c = _comm.Comm.from_torch_distributed(dev)
+        job.bind_comm(c)
+        return c, "smr_comm_exchange (libsummerset_hip.so: RCCL send / recv pairs)"
+    except Exception as e:                                       # noqa: BLE001
+        return None, "torch.distributed.all_to_all_single (smr_comm_init_rank failed: %s)" % e
+
+
 def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
     """--layout spread-rspaxos: BASELINE config 4 in layout L2 -- RSPaxos, 16 384 groups per GPU x 5 replicas, one 4 KiB Put per
     group per tick, the replicas of a group on different ranks (summerset_amd/spread_rsp.py): per tick one all_to_all_single
@@ -1343,6 +1359,7 @@ def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
     nr = args.spread_ranks if virtual else world
     total = G * nr
     job = spread_rsp.in_process(total, R, W, nr, dev, L) if virtual else spread_rsp.SpreadRSPaxos(total, R, W, rank, world, dev, L)
+    comm, via = _bind_library_exchange(job, dist, dev, virtual)
     ranks = job.ranks if virtual else [job]
     blocks = sorted({b for rk in ranks for b in rk.lead})
     srcs = {b: [torch.randint(0, 256, (shard.group_range(total, nr, b)[1] - shard.group_range(total, nr, b)[0], L), dtype=torch.uint8, device=dev)
@@ -1378,13 +1395,16 @@ def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
             "config": {"workload": "RSPaxos (f = 1), %d groups/GPU x 5 replicas, one 4 KiB Put per group per tick (L = %d), RS(3,2), heartbeats every %d ticks"
                                    % (G, L, H), "groups_per_gpu": G, "replicas": R, "layout": "spread-rspaxos", "spread_ranks": nr,
                        "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
-            "exchange": {"collectives_per_tick": "2 (Accepts + shards out, AcceptReplies back); 4 on a heartbeat tick",
+            "exchange": {"via": via, "collectives_per_tick": "2 (Accepts + shards out, AcceptReplies back); 4 on a heartbeat tick",
                          "bytes_per_exchange_per_rank": {k: int(sum(x["in_split"])) for k, x in p.items()},
                          "bytes_sent_per_tick_per_rank": sent / args.steps / len(ranks),
                          "rs_payload_GiBps": len(blocks) * G * L * args.steps / 2**30 / elapsed * (1 if virtual else world)},
             "roofline": None, "cpu_baseline": None}
     if rank == 0:
         emit_line(line)
+    if comm is not None:
+        job.bind_comm(None)
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1402,6 +1422,7 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
     # dependency-graph execution ON with the 5-exchange schedule: the co-located loop's phase-by-phase order (tests/test_zzy_spread_ep_gpu.py)
     kw = dict(window=W, n_keys=K, execute=True, ordered=False)
     job = spread_ep.in_process(total, R, nr, dev, **kw) if virtual else spread_ep.SpreadEPaxos(total, R, rank, world, dev, **kw)
+    comm, via = _bind_library_exchange(job, dist, dev, virtual)
     homes = [k for rk in job.ranks for k in rk.reps] if virtual else list(job.reps)
     zipf = 1.0 / np.arange(1, K + 1) ** 0.99
     zipf /= zipf.sum()
@@ -1442,12 +1463,15 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
                                    "(Zipf(0.99) keys of 64), optimized quorums, dependency-graph execution on" % args.groups,
                        "groups_per_gpu": args.groups, "replicas": R, "window": W, "layout": "spread", "spread_ranks": nr,
                        "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
-            "exchange": {"collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1)},
+            "exchange": {"via": via, "collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1)},
             "slow_path_instances_this_rank": n_slow, "roofline": None, "cpu_baseline": None,
             "note": "correctness layout of config 5's inter-replica fan-out (handler calls of the Python driver included); the roofline / "
                     "cpu_baseline objects belong to the co-located line"}
     if rank == 0:
         emit_line(line)
+    if comm is not None:
+        job.bind_comm(None)
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

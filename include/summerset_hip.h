@@ -281,6 +281,10 @@ int smr_mp_spread_create(smr_mp_cluster *const *clusters, uint32_t n_blocks, smr
                          smr_mp_spread **out);
 void smr_mp_spread_destroy(smr_mp_spread *s);
 int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *in, int heartbeat, void *stream);
+/* A segment (or the collective between two) failed: close the open tick so that the object takes segment 0, bind_comm and
+ * smr_mp_spread_tick again.  Runs and undoes nothing: the blocks hold a partly run tick, the host restores them (smr_mp_load_state
+ * or new clusters) before it ticks again.  smr_mp_spread_tick does this itself when one of its steps fails. */
+int smr_mp_spread_abort_tick(smr_mp_spread *s);
 /* The blocks' rounds inside a segment run concurrently on streams of the object's own, forked behind the segment's unpack and
  * joined in front of its pack on `stream` (default on); 0 = one after the other on `stream`. */
 int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on);

@@ -231,6 +231,7 @@ SYMBOLS = [
     ("smr_mp_spread_destroy", None, [_vp]),
     ("smr_mp_spread_segment", _i, [_vp, _i, _vp, _i, _vp]),
     ("smr_mp_spread_set_concurrent", _i, [_vp, _i]),
+    ("smr_mp_spread_abort_tick", _i, [_vp]),
     ("smr_mp_ack_matrix", _i, [_vp, _u8, C.POINTER(_vp), C.POINTER(_u64)]),
     ("smr_mp_deliver_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),
     ("smr_mp_collect_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),

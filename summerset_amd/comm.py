@@ -65,7 +65,13 @@ class Comm:
                                         rbuf.data_ptr() if rbuf is not None else None, b, 1 if self_via_rccl else 0, stream_ptr(stream)))
 
     def all_reduce(self, t, op=SUM, stream=None):
-        """in place over the ranks; t: int64 / uint64 device tensor"""
+        """in place over the ranks; t: device tensor of 64-bit words reduced as UNSIGNED (ncclUint64): uint64, or int64 holding
+        non-negative values only -- MAX over negative int64 values is refused here rather than answered wrongly"""
+        import torch
+        if t.dtype not in (torch.int64, torch.uint64):
+            raise TypeError("all_reduce takes 64-bit integer tensors")
+        if t.dtype == torch.int64 and t.numel() and bool((t < 0).any()):
+            raise ValueError("all_reduce reduces unsigned words: negative int64 values are not supported")
         check(self._L.smr_comm_all_reduce_u64(self._h, t.data_ptr(), t.numel(), int(op), stream_ptr(stream)))
         return t
 

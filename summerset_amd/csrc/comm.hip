@@ -27,6 +27,16 @@ struct smr_comm {
 
 namespace smr {
 
+// the communicator belongs to the device that was current at smr_comm_init_rank: a call made with another one current would
+// enqueue on a stream of the wrong device and go wrong silently
+static int on_my_device(const smr_comm *c) {
+    int d = -1;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return fail(SMR_ERR_DEVICE, std::string("comm: hipGetDevice: ") + hipGetErrorString(e));
+    if (d != c->device) return fail(SMR_ERR_STATE, "comm: the current device is not the one the communicator was made on");
+    return SMR_OK;
+}
+
 #define SMR_NCCL_TRY(expr)                                                                                   \
     do {                                                                                                     \
         ncclResult_t _r = (expr);                                                                            \
@@ -77,6 +87,7 @@ int smr_comm_exchange(smr_comm *c, const void *send_dev, const uint64_t *send_by
                       uint32_t flags, void *stream) {
     if (!c || !send_bytes || !recv_bytes) return fail(SMR_ERR_ARG, "comm: null argument");
     if (flags & ~(uint32_t)SMR_COMM_SELF_VIA_RCCL) return fail(SMR_ERR_ARG, "comm: unknown flag");
+    if (int rc = on_my_device(c)) return rc;
     const uint32_t n = c->world, me = c->rank;
     uint64_t tot_s = 0, tot_r = 0;
     for (uint32_t k = 0; k < n; k++) { tot_s += send_bytes[k]; tot_r += recv_bytes[k]; }
@@ -123,6 +134,7 @@ int smr_comm_all_reduce_u64(smr_comm *c, uint64_t *inout_dev, uint64_t n, int op
     if (!c || (n && !inout_dev)) return fail(SMR_ERR_ARG, "comm: null argument");
     if (op != SMR_COMM_SUM && op != SMR_COMM_MAX) return fail(SMR_ERR_ARG, "comm: op is SMR_COMM_SUM or SMR_COMM_MAX");
     if (!n) return SMR_OK;
+    if (int rc = on_my_device(c)) return rc;
     SMR_NCCL_TRY(ncclAllReduce(inout_dev, inout_dev, n, ncclUint64, op == SMR_COMM_SUM ? ncclSum : ncclMax, c->nccl, (hipStream_t)stream));
     return SMR_OK;
 }

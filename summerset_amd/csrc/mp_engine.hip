@@ -2656,6 +2656,17 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
     }
 }
 
+// A segment or an exchange that fails leaves the tick OPEN (the next segment is still expected) and the blocks in the state of a
+// partly run tick.  The host's way out (the object used to answer SMR_ERR_STATE for ever): abort the tick -- the
+// object takes segment 0, bind_comm and destroy again -- and bring the clusters back to a state it trusts (smr_mp_load_state /
+// new clusters) before the next tick.  Nothing is run or undone here.
+int smr_mp_spread_abort_tick(smr_mp_spread *s) {
+    if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
+    s->next_segment = 0;
+    s->tick_heartbeat = 0;
+    return SMR_OK;
+}
+
 int smr_mp_spread_bind_comm(smr_mp_spread *s, smr_comm *comm, const void *const send_dev[3], const uint64_t *send_bytes,
                             void *const recv_dev[3], const uint64_t *recv_bytes, uint32_t world) {
     if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
@@ -2679,12 +2690,15 @@ int smr_mp_spread_tick(smr_mp_spread *s, const smr_mp_tick_in *in, int heartbeat
     if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
     if (!s->comm) return fail(SMR_ERR_STATE, "mp spread: no communicator bound (smr_mp_spread_bind_comm)");
     const int n_seg = heartbeat ? 4 : 3;
+    if (s->next_segment != 0) return fail(SMR_ERR_STATE, "mp spread: a tick is open (its segments were called one by one, or it failed: smr_mp_spread_abort_tick)");
     for (int k = 0; k < n_seg; k++) {
         int rc = smr_mp_spread_segment(s, k, in, heartbeat, stream);
-        if (rc != SMR_OK) return rc;
-        if (k + 1 < n_seg)                                       // exchange k sits between segments k and k + 1, on the same stream
-            if ((rc = smr_comm_exchange(s->comm, s->sbuf[k], s->in_split[k].data(), s->rbuf[k], s->out_split[k].data(), 0, stream)) != SMR_OK)
-                return rc;
+        if (rc == SMR_OK && k + 1 < n_seg)                       // exchange k sits between segments k and k + 1, on the same stream
+            rc = smr_comm_exchange(s->comm, s->sbuf[k], s->in_split[k].data(), s->rbuf[k], s->out_split[k].data(), 0, stream);
+        if (rc != SMR_OK) {                                      // this call opened the tick, so it closes it: the object stays usable,
+            (void)smr_mp_spread_abort_tick(s);                   // the blocks' state is the host's to restore (see abort_tick)
+            return rc;
+        }
     }
     return SMR_OK;
 }

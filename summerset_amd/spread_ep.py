@@ -60,6 +60,7 @@ class SpreadEPaxos:
                                                           optimized_quorum=optimized_quorum, execute=execute)
         self.bytes_sent = 0
         self.peers = None                                      # set by in_process(): every rank's object
+        self.comm = None                                       # set by bind_comm(): the exchanges run inside the library (RCCL)
         self._plans = {}
         leaders = [[s] for s in range(self.R)] if self.ordered else [list(range(self.R))]
         self._leader_sets = leaders
@@ -134,11 +135,19 @@ class SpreadEPaxos:
     def _collective(self, plan):
         import torch.distributed as dist
         if self.world > 1:                                     # (the buffers are never empty tensors; the collective sees exactly the planned bytes)
-            if getattr(self, "comm", None) is not None:        # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
+            if self.comm is not None:                          # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
                 self.comm.exchange(plan["sbuf"], plan["in_split"], plan["rbuf"], plan["out_split"])
             else:
                 dist.all_to_all_single(plan["rbuf"][:plan["n_recv"]], plan["sbuf"][:plan["n_send"]], output_split_sizes=plan["out_split"],
                                        input_split_sizes=plan["in_split"])
+
+    def bind_comm(self, comm):
+        """every exchange of the tick through the library: `comm` (summerset_amd.comm.Comm, this rank's end of the job's
+        communicator) -> `smr_comm_exchange` on the plans' own send / receive buffers with their static split sizes, on the
+        stream the handlers' kernels run on.  None: back to torch.distributed.all_to_all_single (gloo jobs)."""
+        if comm is not None and (comm.world != self.world or comm.rank != self.rank):
+            raise ValueError("the communicator is rank %d of %d, the job's rank is %d of %d" % (comm.rank, comm.world, self.rank, self.world))
+        self.comm = comm
 
     def _get(self, plan, key):
         """the message (block, from, to) as tensors: views of the receive buffer, or the sender's own tensors"""

@@ -194,6 +194,11 @@ class SpreadMultiPaxos:
         check(self._L.smr_mp_spread_bind_comm(self._spread, comm._h, C.byref(sd), sb, C.byref(rd), rb, self.world))
         self.comm = comm
 
+    def abort_tick(self):
+        """after a segment or a collective failed: the object takes a new tick (and bind_comm) again; the blocks hold a partly
+        run tick and are the caller's to restore"""
+        check(self._L.smr_mp_spread_abort_tick(self._spread))
+
     def _exchange(self, phase, stream=None):
         self._pack(phase, stream)
         self._collective(phase)
@@ -220,7 +225,7 @@ class SpreadMultiPaxos:
         tensors; every rank that holds block b passes the same arrays -- the streams are keyed by global group id).
         Three or four library calls (the segments between the collectives) and two or three collectives."""
         arr = self._inputs(inputs)
-        if getattr(self, "comm", None) is not None:            # the exchanges are the library's: the whole tick is one call
+        if self.comm is not None:                              # the exchanges are the library's: the whole tick is one call
             check(self._L.smr_mp_spread_tick(self._spread, arr, int(bool(heartbeat)), stream_ptr(stream)))
             self.bytes_sent += sum(sum(self._plans[p]["in_split"]) for p in (("outbox", "replies", "heartbeat") if heartbeat else ("outbox", "replies")))
             return

@@ -51,6 +51,7 @@ class SpreadRSPaxos:
         self.d = self.R // 2 + 1
         self.sl = rs_shard_len(self.L, self.d)
         self.exchange = exchange
+        self.comm = None                                        # set by bind_comm(): the exchanges run inside the library (RCCL)
         self.bytes_sent = 0
         self.n_groups = {b: shard.group_range(total_groups, world, b) for b in range(world)}
         self.reps = {}                                          # (block, replica) -> RSPaxosReplicaGroup, the ones that live here
@@ -123,13 +124,21 @@ class SpreadRSPaxos:
         self.bytes_sent += sum(p["in_split"])
         if self.exchange is not None:
             self.exchange(kind, self)
-        elif self.world > 1 and getattr(self, "comm", None) is not None:   # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
+        elif self.world > 1 and self.comm is not None:          # the library's exchange (smr_comm_exchange: RCCL send / recv pairs)
             self.comm.exchange(p["sbuf"], p["in_split"], p["rbuf"], p["out_split"])
         elif self.world > 1:
             dist.all_to_all_single(p["rbuf"][:sum(p["out_split"])], p["sbuf"][:sum(p["in_split"])], output_split_sizes=p["out_split"],
                                    input_split_sizes=p["in_split"])
         else:
             p["rbuf"][:sum(p["out_split"])].copy_(p["sbuf"][:sum(p["in_split"])])
+
+    def bind_comm(self, comm):
+        """every exchange of the tick (Accepts + shards out, AcceptReplies back, the two heartbeat legs) through the library:
+        `comm` (summerset_amd.comm.Comm) -> `smr_comm_exchange` on the plans' own buffers with their static split sizes.
+        None: back to torch.distributed.all_to_all_single (gloo jobs)."""
+        if comm is not None and (comm.world != self.world or comm.rank != self.rank):
+            raise ValueError("the communicator is rank %d of %d, the job's rank is %d of %d" % (comm.rank, comm.world, self.rank, self.world))
+        self.comm = comm
 
     # ---- typed views of a message inside a buffer -------------------------------------------------------------------------
     def _fields(self, buf, off, G, spec):

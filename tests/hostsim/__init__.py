@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "summerset_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build")
-SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "rsp_engine.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
 LIB = os.path.join(_OUT, "libsummerset_sim.so")
 # clang: the RS kernels use ext_vector_type, which g++ does not have (this is the host compiler hipcc itself drives)
 CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
@@ -60,23 +60,32 @@ def _build(extra):
 def _build_locked(extra):
     srcs = [os.path.join(_CSRC, s) for s in SOURCES]
     rt = os.path.join(_HERE, "hipsim_rt.cpp")
-    comm = os.path.join(_HERE, "comm_sim.cpp")                  # smr_comm_* for a world of one rank (the shipped one is RCCL: csrc/comm.hip)
-    deps = srcs + [rt, comm, os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
+    # the shipped csrc/comm.hip is compiled like every other source; what stands in is RCCL itself (rccl/rccl.h + rccl_sim.cpp:
+    # sends and receives between the PROCESSES of one host through POSIX shared memory), so smr_comm_exchange's N > 1 path runs here
+    comm = os.path.join(_HERE, "rccl_sim.cpp")
+    deps = srcs + [rt, comm, os.path.join(_HERE, "rccl", "rccl.h"), os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
     deps += [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     base, kern = _BASE, _KERN
     objs = []
+    hdrs = [d for d in deps if d.endswith(".h")] + [os.path.abspath(__file__)]
+
+    def stale(obj, src):                                         # per object: a change to one source does not rebuild the other sixteen
+        return not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d) for d in [src] + hdrs)
     for s in srcs:
         o = os.path.join(_OUT, os.path.basename(LIB) + "." + os.path.basename(s) + ".o")
-        subprocess.run(base + kern + list(extra) + ["-c", "-x", "c++", s, "-o", o], check=True)
+        if stale(o, s):
+            subprocess.run(base + kern + list(extra) + ["-c", "-x", "c++", s, "-o", o], check=True)
         objs.append(o)
     o = os.path.join(_OUT, "hipsim_rt.o")
-    subprocess.run(base + ["-c", rt, "-o", o], check=True)
-    oc = os.path.join(_OUT, "comm_sim.o")
-    subprocess.run(base + ["-c", comm, "-o", oc], check=True)
+    if stale(o, rt):
+        subprocess.run(base + ["-c", rt, "-o", o], check=True)
+    oc = os.path.join(_OUT, "rccl_sim.o")
+    if stale(oc, comm):
+        subprocess.run(base + ["-c", comm, "-o", oc], check=True)
     objs.append(oc)
-    subprocess.run([CXX, "-shared", "-o", LIB + ".tmp"] + objs + [o], check=True)
+    subprocess.run([CXX, "-shared", "-o", LIB + ".tmp"] + objs + [o, "-lrt"], check=True)
     _rank_sites(LIB + ".tmp", LIB + ".sites")
     os.replace(LIB + ".tmp", LIB)
     return LIB

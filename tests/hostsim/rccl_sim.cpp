@@ -124,8 +124,12 @@ ncclResult_t run_ops(std::vector<Op> &ops) {
     }
     for (const Op &o : ops)
         if (o.send && r == ncclSuccess) { uint64_t k = 0; r = post_send(o.comm, o, &k); sends.push_back({&o, k}); }
-    for (const Op &o : ops)
-        if (!o.send && r == ncclSuccess) r = complete_recv(o.comm, o);
+    for (const Op &o : ops) {                                   // a size mismatch fails THIS rank's call; the other receives are still taken so
+        if (o.send || (r != ncclSuccess && r != ncclInvalidUsage)) continue;   // that the peers' groups complete (the message is consumed)
+        const ncclResult_t e = complete_recv(o.comm, o);
+        if (r == ncclSuccess) r = e;
+    }
+    if (r == ncclInvalidUsage) { for (auto &s : sends) (void)wait_taken(s.first->comm, s.first->peer, s.second); ops.clear(); return r; }
     for (auto &s : sends)
         if (r == ncclSuccess) r = wait_taken(s.first->comm, s.first->peer, s.second);
     ops.clear();

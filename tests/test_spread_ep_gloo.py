@@ -32,7 +32,7 @@ def _inputs(t):
     return keys, drop
 
 
-def _worker(rank, world, port, out_dir, execute, ordered):
+def _worker(rank, world, port, out_dir, execute, ordered, via="torch"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -45,6 +45,11 @@ def _worker(rank, world, port, out_dir, execute, ordered):
     with hostsim.patched():
         job = spread_ep.SpreadEPaxos(G, R, rank, world, "cpu", window=W, n_keys=K, execute=execute, ordered=ordered)
         out = {}
+        comm = None
+        if via == "library":                                      # every exchange through smr_comm_exchange (csrc/comm.hip on tests/hostsim/rccl_sim.cpp)
+            from summerset_amd import comm as smr_comm
+            comm = smr_comm.Comm.from_torch_distributed("cpu")
+            job.bind_comm(comm)
         for t in range(TICKS):
             keys, drop = _inputs(t)
             bk = {(b, r): tn(keys[r, job.range[b][0]:job.range[b][1]]) for (b, r) in job.reps}
@@ -58,22 +63,30 @@ def _worker(rank, world, port, out_dir, execute, ordered):
             if execute:
                 for n, v in rep.exec_dump().items():
                     out["exec_b%d_r%d_%s" % (b, r, n)] = v
+        info = comm.info() if comm is not None else dict(exchanges=0, bytes_sent=0, bytes_received=0)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=np.array(sorted(job.reps)), sent=job.bytes_sent,
-                 exchanges=job.exchanges_per_tick(), **out)
+                 exchanges=job.exchanges_per_tick(), lib_exchanges=info["exchanges"], lib_sent=info["bytes_sent"], lib_received=info["bytes_received"], **out)
+        if comm is not None:
+            comm.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(tmp_path, execute, ordered=None):
+def _run(tmp_path, execute, ordered=None, via="torch"):
     """ordered=False with execution: the 5-exchange schedule = the co-located loop with the leaders' steps phase by phase"""
     import torch
     import torch.multiprocessing as mp
     import hostsim
     from summerset_amd import EPaxosReplicaGroup, ep_cluster, shard
     hostsim.build()                                                   # once, before the workers race to build it
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute, ordered), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute, ordered, via), nprocs=2, join=True)
     five = not execute or ordered is False
     ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    if via == "library":                                              # the library moved every byte the job counts, both ways
+        assert all(int(rk["lib_exchanges"]) == TICKS * (5 if five else 17) and int(rk["lib_sent"]) == int(rk["sent"]) for rk in ranks)
+        assert int(ranks[0]["lib_sent"]) == int(ranks[1]["lib_received"]) and int(ranks[1]["lib_sent"]) == int(ranks[0]["lib_received"])
+    else:
+        assert all(int(rk["lib_exchanges"]) == 0 for rk in ranks)
     pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
     assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
     assert all(int(rk["sent"]) > 0 and int(rk["exchanges"]) == (5 if five else 17) for rk in ranks)
@@ -116,3 +129,9 @@ def test_world_size_2_spread_epaxos_ordered_schedule_with_execution(tmp_path):
 
 def test_world_size_2_spread_epaxos_five_exchanges_with_execution(tmp_path):
     _run(tmp_path, execute=True, ordered=False)
+
+
+def test_world_size_2_spread_epaxos_through_the_library_exchange(tmp_path):
+    """BASELINE config 5's layout with every exchange inside the library: `bind_comm` -> smr_comm_exchange, the SHIPPED
+    csrc/comm.hip with two ranks (its receive-first ring posting order, per-peer sizes), RCCL stood in by shared memory"""
+    _run(tmp_path, execute=True, ordered=False, via="library")

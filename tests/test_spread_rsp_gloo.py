@@ -36,7 +36,7 @@ def _inputs(t, b, lo, hi):
     return data, val, lost
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, via="torch"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
@@ -48,6 +48,11 @@ def _worker(rank, world, port, out_dir):
     out = {}
     with hostsim.patched():
         job = spread_rsp.SpreadRSPaxos(G, R, W, rank, world, "cpu", L, fault_tolerance=FT)
+        comm = None
+        if via == "library":                                      # every exchange through smr_comm_exchange (csrc/comm.hip on tests/hostsim/rccl_sim.cpp)
+            from summerset_amd import comm as smr_comm
+            comm = smr_comm.Comm.from_torch_distributed("cpu")
+            job.bind_comm(comm)
         for t in range(TICKS):
             data, val, lost = {}, {}, {}
             for b in range(world):
@@ -66,20 +71,35 @@ def _worker(rank, world, port, out_dir):
         for (b, r), e in job.reps.items():
             for k, v in e.dump().items():
                 out["b%d_r%d_%s" % (b, r, k)] = v
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=np.array(sorted(job.reps)), sent=job.bytes_sent, **out)
+        info = comm.info() if comm is not None else dict(exchanges=0, bytes_sent=0, bytes_received=0)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=np.array(sorted(job.reps)), sent=job.bytes_sent, lib_exchanges=info["exchanges"],
+                 lib_sent=info["bytes_sent"], lib_received=info["bytes_received"],
+                 self_bytes=sum(job._plans[k]["in_split"][rank] * (TICKS if k in ("accept", "accept_reply") else TICKS // HB) for k in job._plans), **out)
+        if comm is not None:
+            comm.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_spread_rspaxos_job_is_the_colocated_loop(tmp_path):
+def test_world_size_2_spread_rspaxos_through_the_library_exchange(tmp_path):
+    """BASELINE config 4's layout with every exchange inside the library: `bind_comm` -> smr_comm_exchange, the SHIPPED
+    csrc/comm.hip with two ranks (a rank's own segment a device copy, the peer's an ncclRecv / ncclSend pair)"""
+    test_world_size_2_spread_rspaxos_job_is_the_colocated_loop(tmp_path, via="library")
+
+
+def test_world_size_2_spread_rspaxos_job_is_the_colocated_loop(tmp_path, via="torch"):
     import torch
     import torch.multiprocessing as mp
     import hostsim
     from summerset_amd import RSPaxosReplicaGroup, rsp_cluster, shard, spread_rsp
     hostsim.build()                                                   # once, before the workers race to build it
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), via), nprocs=2, join=True)
     ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
+    if via == "library":                                              # 2 exchanges per tick + 2 per heartbeat tick; a rank's own segment is not "sent"
+        assert all(int(rk["lib_exchanges"]) == 2 * TICKS + 2 * (TICKS // HB) for rk in ranks)
+        assert all(int(rk["lib_sent"]) == int(rk["sent"]) - int(rk["self_bytes"]) > 0 for rk in ranks)
+        assert int(ranks[0]["lib_sent"]) == int(ranks[1]["lib_received"]) and int(ranks[1]["lib_sent"]) == int(ranks[0]["lib_received"])
     pairs = sorted(tuple(x) for rk in ranks for x in rk["live"].tolist())
     assert pairs == sorted((b, r) for b in range(2) for r in range(R))          # every (block, replica) lives on exactly one rank
     assert all(int(rk["sent"]) > 0 for rk in ranks)
