@@ -923,6 +923,32 @@ int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, 
                           uint64_t *group_stride);
 int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host);
 
+/* CRaft: the same store keyed by LOG INDEX -- the shard bytes of `LogEntry::reqs_cw` (/root/reference/src/protocols/craft/mod.rs:129-150)
+ * behind a CRaft replica (smr_raft_leader with smr_raft_craft_enable: leader or follower).  The engine keeps an entry's codeword as
+ * the avail_shards_map of ring cell [slot % window]; the store makes the bytes follow it:
+ *   smr_craft_pstore_create  one plane (a log entry has one codeword; the voted plane of the RSPaxos store is not allocated and
+ *                            plane 1 is refused by every call); n_data_shards = the majority, n_shards = the population
+ *   smr_craft_pstore_put     the leader's RSCodeword::from_data + compute_parity of the batch it appended at slot_dev[g]
+ *                            (SMR_RSP_NULL: none) -- craft/request.rs:71-76: the leader holds every shard.  Call it behind
+ *                            smr_raft_leader_append / _append_emit with one entry per group
+ *   smr_craft_pstore_follow  after ANY handler call of replica e: every held log entry's shards the engine's bitmap has and the row
+ *                            lacks are taken from the sources' rows that hold the SAME (slot, term) -- an AppendEntries' entries
+ *                            (craft/durability.rs:41-80: one's own shard, or the data shards in full-copy mode,
+ *                            leadership.rs:80-141; absorbed at craft/messages.rs:133-146), a ReconstructReply's slots_data
+ *                            (messages.rs:665-745); sel_dev (may be NULL) = the message's sender per group, an index into src --
+ *                            and what the bitmap gained by reconstruct_data on commit (messages.rs:193-233, 699-737) is rebuilt
+ *                            from any majority of shards present.  An entry the log no longer holds (truncated, overwritten by
+ *                            another term's, trimmed) drops its shards.
+ * An entry's identity is (slot, term) (what the consistency check compares); everything else -- smr_rsp_pstore_get_data for the
+ * executed entries, _extract / _ingest for replicas on different devices, _dump, _read_row, _layout, _counters, _destroy -- is the
+ * RSPaxos store's, on plane 0. */
+int smr_craft_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
+                            smr_rsp_pstore **out);
+int smr_craft_pstore_put(smr_rsp_pstore *s, const smr_raft_leader *e, const uint32_t *slot_dev, const uint8_t *data_dev, uint64_t data_stride,
+                         const uint32_t *len_dev, uint32_t data_len, void *stream);
+int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *sel_dev,
+                            void *stream);
+
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing
  * ---------------------------------------------------------------------- */

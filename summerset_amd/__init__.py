@@ -14,7 +14,7 @@ from .quorumread import KvStateMachine, QuorumReadGroup, StringKvStateMachine  #
 from .raft import CRaftLeaderGroup, RaftLeaderGroup  # noqa: F401
 from .epaxos import EPaxosReplicaGroup  # noqa: F401
 from .rspaxos import RSPaxosReplicaGroup  # noqa: F401
-from .rsp_payload import RSPaxosPayloadStore, RSPaxosReplicaWithPayload  # noqa: F401
+from .rsp_payload import CRaftPayloadStore, RSPaxosPayloadStore, RSPaxosReplicaWithPayload  # noqa: F401
 from .repnothing import RepNothingReplica  # noqa: F401
 from .heartbeater import Heartbeater  # noqa: F401
 from .leaseman import LeaseManager  # noqa: F401

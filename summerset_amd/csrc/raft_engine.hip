@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "smr_common.h"
+#include "raft_peek.h"
 
 namespace smr {
 
@@ -914,6 +915,11 @@ static void raft_layout(smr_raft_leader *l, bool dry) {
     rcarve(a, v.next_slot, R * G, dry); rcarve(a, v.try_next_slot, R * G, dry); rcarve(a, v.match_slot, R * G, dry);
     rcarve(a, v.entry_term, W * G, dry);
     rcarve(a, v.counters, SMR_CTR_WORDS, dry);
+}
+RaftPeek raft_peek(const smr_raft_leader *l) {
+    const RaftView &v = l->v;
+    return RaftPeek{v.G, v.W, v.R, l->craft ? l->cv.quorum : v.R / 2 + 1, v.entry_term, l->craft ? v.entry_mask : nullptr,
+                    v.log_len, v.start_slot, v.ring_lo};
 }
 }  // namespace smr
 

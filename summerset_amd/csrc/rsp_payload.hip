@@ -29,6 +29,7 @@
 
 #include "smr_common.h"
 #include "rsp_peek.h"
+#include "raft_peek.h"
 
 namespace smr {
 
@@ -484,6 +485,42 @@ __global__ __launch_bounds__(256) void ps_emit_accepts_kernel(const PsView v, in
     }
 }
 
+// ---- CRaft: the same store keyed by LOG INDEX (craft/mod.rs:129-150 `LogEntry { term, reqs_cw, .. }`) -----------------------
+// A Raft entry's identity is (slot, term) (the Log Matching property; the consistency check of craft/messages.rs:95-131 compares
+// exactly that), so the token of ring cell [slot % W] is a function of the two: 20 bits of the slot, 10 of the term, bit 30 set
+// (never 0 = the synthesised empty batch, never PS_NULL).  Two entries that meet in one cell differ by a multiple of W in their
+// slots: their tokens could only agree 2^20 / W wraps of the ring apart, and every wrap re-keys the cell.
+__device__ __forceinline__ uint32_t craft_token(uint32_t slot, uint64_t term) {
+    return 0x40000000u | (((uint32_t)term & 0x3FFu) << 20) | (slot & 0xFFFFFu);
+}
+// the slot ring cell `row` of group g holds now (PS_NULL: none -- the dummy entry 0 carries no codeword)
+__device__ __forceinline__ uint32_t craft_cell_slot(const RaftPeek &e, uint32_t row, uint32_t g) {
+    const uint32_t len = e.log_len[g], st = e.start_slot[g], rl = e.ring_lo[g];
+    if (len == 0) return PS_NULL;
+    uint32_t s = ((len - 1u) & ~(e.W - 1u)) | row;                          // the highest slot <= len - 1 + (W - 1) in this cell ...
+    if (s > len - 1u) { if (s < e.W) return PS_NULL; s -= e.W; }             // ... brought below the log's end
+    const uint32_t lo = st > rl ? st : rl;
+    return (s >= lo && s != 0u) ? s : PS_NULL;
+}
+// one lane per ring cell: the token the engine's log says the cell holds (the masks are the engine's own array)
+__global__ __launch_bounds__(256) void craft_tokens_kernel(const RaftPeek e, uint32_t *__restrict__ tok) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= e.W * e.G) return;
+    const uint32_t row = i / e.G, g = i % e.G;
+    const uint32_t s = craft_cell_slot(e, row, g);
+    tok[i] = s == PS_NULL ? PS_NULL : craft_token(s, e.entry_term[i]);
+}
+// the put of the entry the leader appended at slot[g] (PS_NULL: none): a_n / a_val as ps_put_kernel takes them
+__global__ __launch_bounds__(256) void craft_put_args_kernel(const RaftPeek e, const uint32_t *__restrict__ slot, uint32_t *__restrict__ a_n,
+                                                             uint32_t *__restrict__ a_val) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= e.G) return;
+    const uint32_t s = slot[g];
+    const bool on = s != PS_NULL && s != 0u && craft_cell_slot(e, s & (e.W - 1u), g) == s;   // the log holds that slot
+    a_n[g] = on ? 1u : 0u;
+    a_val[g] = on ? craft_token(s, e.entry_term[(size_t)(s & (e.W - 1u)) * e.G + g]) : PS_NULL;
+}
+
 // ---- host: GF(2^8) matrices for the rebuild table ------------------------------------------------------------------
 struct PsGf {
     uint8_t exp[512], log[256];
@@ -557,12 +594,17 @@ struct smr_rsp_pstore {
     void *meta;            // one allocation: tok / avail / dlen of both planes, the table, the list, the counters, a copy of v
     PsView *d_view;        // the device copy of v (flip excepted) smr_rsp_pstore_follow_many's kernels read
     void *plane_alloc[2];  // the planes' allocations (v.pl[p].bytes lies at their start)
+    int planes;            // 2; 1 for a CRaft store (a log entry has one codeword: no VOTED bytes are allocated)
+    // CRaft (smr_craft_pstore_*): the tokens the log implies per ring cell, an all-NULL token array standing for the absent voted
+    // plane, and the put's per-group arguments -- one allocation, made by smr_craft_pstore_create
+    uint32_t *craft_tok, *craft_null, *craft_an, *craft_aval;
+    void *craft_alloc;
 };
 
 extern "C" {
 
-int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
-                          smr_rsp_pstore **out) {
+static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len, int planes,
+                     smr_rsp_pstore **out) {
     if (!out) return fail(SMR_ERR_ARG, "pstore: null argument");
     if (n_groups == 0) return fail(SMR_ERR_ARG, "pstore: n_groups is zero");
     if (n_shards < 2 || n_shards > PS_MAX_N || n_data_shards == 0 || n_data_shards >= n_shards)
@@ -579,6 +621,9 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     const uint32_t sl = (max_data_len + n_data_shards - 1) / n_data_shards;
     v.cap_sl = (sl + 15u) / 16u * 16u;
     s->max_data_len = max_data_len;
+    s->planes = planes;
+    s->craft_tok = s->craft_null = s->craft_an = s->craft_aval = nullptr;
+    s->craft_alloc = nullptr;
     s->plane_bytes = (uint64_t)window * n_shards * n_groups * v.cap_sl;
     const size_t cells = (size_t)window * n_groups;
     Arena a, pa[2];
@@ -591,7 +636,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
         o_mat = a.reserve(tab.size()); o_n = a.reserve(256); o_cell = a.reserve(cells * 4);
         for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
         o_rc = a.reserve(cells * 4); o_ctr = a.reserve(SMR_CTR_WORDS * 8); o_view = a.reserve(sizeof(PsView));
-        for (int p = 0; p < 2; p++) { pa[p].used = 0; o_bytes[p] = pa[p].reserve(s->plane_bytes); }
+        for (int p = 0; p < 2; p++) { pa[p].used = 0; o_bytes[p] = pa[p].reserve(p < planes ? s->plane_bytes : 256); }
     };
     layout();
     a.size = a.used + 256;
@@ -607,7 +652,7 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
         v.pl[p].tok = a.at<uint32_t>(o_tok[p]); v.pl[p].avail = a.at<uint8_t>(o_av[p]); v.pl[p].dlen = a.at<uint32_t>(o_len[p]);
         v.it_src[p] = a.at<uint64_t>(o_src[p]); v.it_sl[p] = a.at<uint32_t>(o_sl[p]);
         err = hipMemset(v.pl[p].tok, 0xFF, cells * 4);
-        if (err == hipSuccess) err = hipMemset(v.pl[p].bytes, 0, s->plane_bytes);
+        if (err == hipSuccess) err = hipMemset(v.pl[p].bytes, 0, p < planes ? s->plane_bytes : 256);
     }
     if (err == hipSuccess) err = hipMemcpy(a.base + o_mat, tab.data(), tab.size(), hipMemcpyHostToDevice);
     if (err != hipSuccess) {
@@ -630,8 +675,35 @@ int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_
     return SMR_OK;
 }
 
+int smr_rsp_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
+                          smr_rsp_pstore **out) {
+    return ps_create(n_groups, n_shards, n_data_shards, window, max_data_len, 2, out);
+}
+
+int smr_craft_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shards, uint32_t window, uint32_t max_data_len,
+                            smr_rsp_pstore **out) {
+    int rc = ps_create(n_groups, n_shards, n_data_shards, window, max_data_len, 1, out);
+    if (rc != SMR_OK) return rc;
+    smr_rsp_pstore *s = *out;
+    const size_t cells = (size_t)window * n_groups;
+    const size_t bytes = (cells * 2 + (size_t)n_groups * 2) * 4;
+    hipError_t err = hipMalloc(&s->craft_alloc, bytes);
+    if (err == hipSuccess) err = hipMemset(s->craft_alloc, 0xFF, bytes);
+    if (err != hipSuccess) {
+        smr_rsp_pstore_destroy(s);
+        *out = nullptr;
+        return fail(SMR_ERR_DEVICE, std::string("craft pstore: allocation: ") + hipGetErrorString(err));
+    }
+    s->craft_tok = (uint32_t *)s->craft_alloc;
+    s->craft_null = s->craft_tok + cells;
+    s->craft_an = s->craft_null + cells;
+    s->craft_aval = s->craft_an + n_groups;
+    return SMR_OK;
+}
+
 void smr_rsp_pstore_destroy(smr_rsp_pstore *s) {
     if (!s) return;
+    if (s->craft_alloc) (void)hipFree(s->craft_alloc);
     for (int p = 0; p < 2; p++) if (s->plane_alloc[p]) (void)hipFree(s->plane_alloc[p]);
     if (s->meta) (void)hipFree(s->meta);
     delete s;
@@ -656,12 +728,12 @@ int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_
     return SMR_OK;
 }
 
-int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
-                          const uint8_t *sel_dev, void *stream) {
-    if (!s || !e || (n_src && (!src || !src_plane))) return fail(SMR_ERR_ARG, "pstore follow: null argument");
+// the store follows the (token, mask) arrays `pk` names: smr_rsp_pstore_follow's an RSPaxos replica's, smr_craft_pstore_follow's the
+// ones a CRaft replica's log implies
+static int ps_follow(smr_rsp_pstore *s, const RspPeek &pk, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
+                     const uint8_t *sel_dev, void *stream) {
     if (n_src > PS_MAX_SRC) return fail(SMR_ERR_ARG, "pstore follow: at most 16 sources");
     const PsView &v = s->v;
-    const RspPeek pk = rsp_peek(e);
     if (pk.G != v.G || pk.W != v.W || pk.R != v.n || pk.majority != v.d)
         return fail(SMR_ERR_ARG, "pstore follow: the replica's groups / window / population / majority differ from the store's");
     PsSrcs S;
@@ -670,7 +742,7 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
     for (uint32_t j = 0; j < n_src; j++) {
         const smr_rsp_pstore *o = src[j];
         if (!o) continue;                                                    // an empty seat (e.g. my own id in a list indexed by replica)
-        if (src_plane[j] > 1) return fail(SMR_ERR_ARG, "pstore follow: bad source plane");
+        if ((int)src_plane[j] >= o->planes) return fail(SMR_ERR_ARG, "pstore follow: bad source plane");
         if (o == s) return fail(SMR_ERR_ARG, "pstore follow: a store's own planes are sources already");
         if (o->v.G != v.G || o->v.W != v.W || o->v.n != v.n || o->v.d != v.d || o->v.cap_sl != v.cap_sl)
             return fail(SMR_ERR_ARG, "pstore follow: a source has another geometry");
@@ -688,10 +760,52 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
     return SMR_OK;
 }
 
+int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *src_plane,
+                          const uint8_t *sel_dev, void *stream) {
+    if (!s || !e || (n_src && (!src || !src_plane))) return fail(SMR_ERR_ARG, "pstore follow: null argument");
+    if (s->planes != 2) return fail(SMR_ERR_STATE, "pstore follow: a CRaft store follows a Raft replica (smr_craft_pstore_follow)");
+    return ps_follow(s, rsp_peek(e), n_src, src, src_plane, sel_dev, stream);
+}
+
+// ---- CRaft: put at append, follow behind AppendEntries / ReconstructReply / commit (craft/request.rs:71-76, messages.rs:133-146,
+// 193-233, 697-737; leadership.rs:80-141 decides the masks) ------------------------------------------------------------------
+static int craft_peek_of(smr_rsp_pstore *s, const smr_raft_leader *e, RaftPeek &rp) {
+    if (!s->craft_alloc) return fail(SMR_ERR_STATE, "craft pstore: not a CRaft store (smr_craft_pstore_create)");
+    rp = raft_peek(e);
+    if (!rp.entry_mask) return fail(SMR_ERR_STATE, "craft pstore: CRaft is not enabled on this replica (smr_raft_craft_enable)");
+    if (rp.G != s->v.G || rp.W != s->v.W || rp.R != s->v.n || rp.quorum != s->v.d)
+        return fail(SMR_ERR_ARG, "craft pstore: the replica's groups / window / population / majority differ from the store's");
+    return SMR_OK;
+}
+
+int smr_craft_pstore_put(smr_rsp_pstore *s, const smr_raft_leader *e, const uint32_t *slot_dev, const uint8_t *data_dev, uint64_t data_stride,
+                         const uint32_t *len_dev, uint32_t data_len, void *stream) {
+    if (!s || !e || !slot_dev || !data_dev) return fail(SMR_ERR_ARG, "craft pstore put: null argument");
+    RaftPeek rp;
+    if (int rc = craft_peek_of(s, e, rp)) return rc;
+    hipLaunchKernelGGL(craft_put_args_kernel, dim3((rp.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, slot_dev, s->craft_an, s->craft_aval);
+    SMR_HIP_TRY(hipGetLastError());
+    return smr_rsp_pstore_put(s, s->craft_an, slot_dev, s->craft_aval, data_dev, data_stride, len_dev, data_len, stream);
+}
+
+int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *sel_dev,
+                            void *stream) {
+    if (!s || !e || (n_src && !src)) return fail(SMR_ERR_ARG, "craft pstore follow: null argument");
+    RaftPeek rp;
+    if (int rc = craft_peek_of(s, e, rp)) return rc;
+    const uint32_t cells = rp.W * rp.G;
+    hipLaunchKernelGGL(craft_tokens_kernel, dim3((cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, s->craft_tok);
+    SMR_HIP_TRY(hipGetLastError());
+    // the log's codewords are the REQS plane; the voted plane's tokens are all NULL (nothing is wanted there, nothing is allocated)
+    const RspPeek pk{rp.G, rp.W, rp.R, 0u, rp.quorum, s->craft_tok, s->craft_null, rp.entry_mask, rp.entry_mask};
+    uint8_t planes[PS_MAX_SRC] = {0};
+    return ps_follow(s, pk, n_src, src, planes, sel_dev, stream);
+}
+
 int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
                                int src_plane, void *stream) {
     if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "pstore follow_many: 1 .. 8 stores");
-    if (src && (src_plane < 0 || src_plane > 1)) return fail(SMR_ERR_ARG, "pstore follow_many: bad source plane");
+    if (src && (src_plane < 0 || src_plane >= src->planes)) return fail(SMR_ERR_ARG, "pstore follow_many: bad source plane");
     PsMany M;
     memset(&M, 0, sizeof(M));
     PsSrcs S;
@@ -701,6 +815,7 @@ int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const 
         smr_rsp_pstore *s = stores[k];
         if (!s || !replicas[k]) return fail(SMR_ERR_ARG, "pstore follow_many: null store / replica");
         if (s == src) return fail(SMR_ERR_ARG, "pstore follow_many: the source must not be one of the stores that follow");
+        if (s->planes != 2) return fail(SMR_ERR_STATE, "pstore follow_many: a CRaft store follows a Raft replica (smr_craft_pstore_follow)");
         for (uint32_t j = 0; j < k; j++) if (stores[j] == s) return fail(SMR_ERR_ARG, "pstore follow_many: a store is listed twice");
         const RspPeek pk = rsp_peek(replicas[k]);
         if (s->v.G != v0.G || s->v.W != v0.W || s->v.n != v0.n || s->v.d != v0.d || s->v.cap_sl != v0.cap_sl)
@@ -747,7 +862,7 @@ int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t 
 
 int smr_rsp_pstore_extract(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint8_t *mask_dev,
                            uint8_t *out_dev, uint32_t *tok_out_dev, uint8_t *mask_out_dev, uint32_t *dlen_out_dev, void *stream) {
-    if (!s || plane < 0 || plane > 1 || !slot_dev || !mask_dev || !out_dev || !tok_out_dev || !mask_out_dev || !dlen_out_dev)
+    if (!s || plane < 0 || plane >= s->planes || !slot_dev || !mask_dev || !out_dev || !tok_out_dev || !mask_out_dev || !dlen_out_dev)
         return fail(SMR_ERR_ARG, "pstore extract: bad argument");
     const PsView &v = s->v;
     const uint32_t nblk = v.cap_sl / 16u;
@@ -760,7 +875,7 @@ int smr_rsp_pstore_extract(const smr_rsp_pstore *s, int plane, const uint8_t *fl
 
 int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint32_t *tok_dev,
                           const uint8_t *mask_dev, const uint32_t *dlen_dev, const uint8_t *in_dev, void *stream) {
-    if (!s || plane < 0 || plane > 1 || !slot_dev || !tok_dev || !mask_dev || !dlen_dev || !in_dev) return fail(SMR_ERR_ARG, "pstore ingest: bad argument");
+    if (!s || plane < 0 || plane >= s->planes || !slot_dev || !tok_dev || !mask_dev || !dlen_dev || !in_dev) return fail(SMR_ERR_ARG, "pstore ingest: bad argument");
     const PsView &v = s->v;
     const uint32_t nblk = v.cap_sl / 16u;
     const uint64_t threads = (uint64_t)v.G * nblk;
@@ -772,7 +887,7 @@ int smr_rsp_pstore_ingest(smr_rsp_pstore *s, int plane, const uint8_t *flags_dev
 
 int smr_rsp_pstore_emit_accepts(const smr_rsp_pstore *s, int plane, const uint8_t *flags_dev, const uint32_t *slot_dev, const uint64_t *ballot_dev,
                                 const uint8_t *mask_dev, uint8_t *frames_dev, uint64_t stride, uint32_t *len_dev, void *stream) {
-    if (!s || plane < 0 || plane > 1 || !slot_dev || !ballot_dev || !mask_dev || !frames_dev || !len_dev)
+    if (!s || plane < 0 || plane >= s->planes || !slot_dev || !ballot_dev || !mask_dev || !frames_dev || !len_dev)
         return fail(SMR_ERR_ARG, "pstore emit_accepts: bad argument");
     if (stride < 64) return fail(SMR_ERR_ARG, "pstore emit_accepts: stride is shorter than a frame's header");
     const PsView &v = s->v;
@@ -785,7 +900,7 @@ int smr_rsp_pstore_emit_accepts(const smr_rsp_pstore *s, int plane, const uint8_
 }
 
 int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_t *avail_host, uint32_t *dlen_host) {
-    if (!s || plane < 0 || plane > 1) return fail(SMR_ERR_ARG, "pstore dump: bad argument");
+    if (!s || plane < 0 || plane >= s->planes) return fail(SMR_ERR_ARG, "pstore dump: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());
     const size_t cells = (size_t)s->v.W * s->v.G;
     if (tok_host) SMR_HIP_TRY(hipMemcpy(tok_host, s->v.pl[plane].tok, cells * 4, hipMemcpyDeviceToHost));
@@ -795,7 +910,7 @@ int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_
 }
 
 int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host) {
-    if (!s || plane < 0 || plane > 1 || !bytes_host) return fail(SMR_ERR_ARG, "pstore read_row: bad argument");
+    if (!s || plane < 0 || plane >= s->planes || !bytes_host) return fail(SMR_ERR_ARG, "pstore read_row: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());
     const size_t row_bytes = (size_t)s->v.n * s->v.G * s->v.cap_sl;
     SMR_HIP_TRY(hipMemcpy(bytes_host, s->v.pl[plane].bytes + (size_t)(slot & s->v.Wmask) * row_bytes, row_bytes, hipMemcpyDeviceToHost));
@@ -804,7 +919,7 @@ int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t
 
 int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,
                           uint64_t *group_stride) {
-    if (!s || plane < 0 || plane > 1) return fail(SMR_ERR_ARG, "pstore layout: bad argument");
+    if (!s || plane < 0 || plane >= s->planes) return fail(SMR_ERR_ARG, "pstore layout: bad argument");
     if (bytes_dev) *bytes_dev = s->v.pl[plane].bytes;
     if (row_stride) *row_stride = (uint64_t)s->v.n * s->v.G * s->v.cap_sl;
     if (shard_stride) *shard_stride = (uint64_t)s->v.G * s->v.cap_sl;

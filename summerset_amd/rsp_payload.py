@@ -32,13 +32,15 @@ def _ptr(t):
 
 
 class RSPaxosPayloadStore:
+    _CREATE = "smr_rsp_pstore_create"
+
     def __init__(self, n_groups, population=5, window=32, max_data_len=4096, num_data_shards=None):
         self.G, self.R, self.W = int(n_groups), int(population), int(window)
         self.d = int(num_data_shards) if num_data_shards is not None else self.R // 2 + 1     # majority (mod.rs:606-611)
         self.max_data_len = int(max_data_len)
         self._L = _lib.load()
         h = C.c_void_p()
-        check(self._L.smr_rsp_pstore_create(self.G, self.R, self.d, self.W, self.max_data_len, C.byref(h)))
+        check(getattr(self._L, self._CREATE)(self.G, self.R, self.d, self.W, self.max_data_len, C.byref(h)))
         self._h = h
         rs, ss, gs = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(self._L.smr_rsp_pstore_layout(self._h, 0, None, C.byref(rs), C.byref(ss), C.byref(gs)))
@@ -141,6 +143,42 @@ class RSPaxosPayloadStore:
         c = np.zeros(4, np.uint64)
         check(self._L.smr_rsp_pstore_counters(self._h, c.ctypes.data_as(C.c_void_p)))
         return dict(copied=int(c[0]), rebuilt=int(c[1]), unsatisfied=int(c[2]), rekeyed=int(c[3]))
+
+
+class CRaftPayloadStore(RSPaxosPayloadStore):
+    """The shard bytes behind a CRaft replica's log (`smr_craft_pstore_*`): what the reference keeps in `LogEntry::reqs_cw`
+    (src/protocols/craft/mod.rs:129-150), one plane keyed by log index.  `CRaftLeaderGroup` (leader or follower) keeps an
+    entry's codeword as its avail_shards_map; the store makes the bytes follow:
+
+        first = leader.handle_req_batch_emit(n_new)           # one entry per group: at slot log_len - 1
+        store.put(leader, slot, data)                         # from_data + compute_parity, every shard (craft/request.rs:71-76)
+        follower.handle_msg_append_entries(..., entry_mask=send[q])   # one's own shard, or the data shards in full-copy mode
+        fstore.follow(follower, sources=[store])              # absorb what the message carried (craft/messages.rs:133-146); on
+                                                              # commit, reconstruct_data's shards are rebuilt (messages.rs:193-233)
+    `get_data`, `extract` / `ingest`, `dump`, `read_row` are the RSPaxos store's, on plane 0 (REQS)."""
+    _CREATE = "smr_craft_pstore_create"
+
+    def put(self, replica, slot, data, lens=None, stream=None):
+        """`replica`: the CRaftLeaderGroup that appended; `slot`: int32 [G] the entry's log index per group (-1: none);
+        `data`: uint8 [G, L] serialized batches (rows contiguous), `lens`: int32 [G] or None"""
+        if data.dim() != 2 or data.stride(1) != 1 or int(data.shape[0]) != self.G:
+            raise _lib.SummersetError(_lib.SMR_ERR_ARG, "data must be uint8 [G, L] with contiguous rows")
+        check(self._L.smr_craft_pstore_put(self._h, replica._h, slot.data_ptr(), data.data_ptr(), int(data.stride(0)), _ptr(lens),
+                                           int(data.shape[1]), stream_ptr(stream)))
+
+    def follow(self, replica, sources=(), sel=None, stream=None):
+        """`sources`: the stores a shard may come from (None: an empty seat); `sel`: uint8 [G] or None -- in group g only
+        sources[sel[g]] may give shards (the sender of the message the handler consumed)"""
+        n = len(sources)
+        arr = (C.c_void_p * max(n, 1))(*[None if s is None else s._h for s in sources])
+        check(self._L.smr_craft_pstore_follow(self._h, replica._h, n, arr, _ptr(sel), stream_ptr(stream)))
+
+    @staticmethod
+    def follow_many(*a, **kw):
+        raise _lib.SummersetError(_lib.SMR_ERR_STATE, "a CRaft store follows one Raft replica per call")
+
+    def emit_accepts(self, *a, **kw):
+        raise _lib.SummersetError(_lib.SMR_ERR_STATE, "Accept frames are RSPaxos'")
 
 
 class RSPaxosReplicaWithPayload:

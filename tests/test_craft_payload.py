@@ -1,0 +1,62 @@
+"""CRaft shard bytes (`smr_craft_pstore_*`, csrc/rsp_payload.hip) on the kernel-source emulator: the closed loop of
+tests/craft_payload_loop.py -- put at append, follow behind AppendEntries (own shard / full-copy / a majority without the data
+shards -> reconstruct_data on commit), a new leader's Reconstruct round -- every shard byte against the oracle's encoder; the
+ring wrapping; argument and state errors.  The device run of the same loop: tests/test_zz_craft_payload_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+
+
+@pytest.mark.parametrize("staging", [False, True], ids=["colocated", "messages"])
+def test_craft_payload_loop_on_the_emulator(oracle, staging):
+    import hostsim
+    import craft_payload_loop as cl
+    hostsim.build()
+    with hostsim.patched():
+        cl.run("cpu", oracle, G=70, W=32, L=67, staging=staging)
+
+
+def test_craft_payload_ring_wraps_on_the_emulator(oracle):
+    """W = 8: the log outgrows the ring, cells are re-keyed by later entries, the followers' stores follow"""
+    import hostsim
+    import craft_payload_loop as cl
+    hostsim.build()
+    with hostsim.patched():
+        lp = cl.Loop("cpu", oracle, G=40, W=8, L=40, seed=3)
+        for t in range(14):
+            lp.tick(p_new=1.0)
+        assert int(lp.reps[0].dump()["log_len"].max()) > 8
+        assert sum(int(s.counters()["rekeyed"]) for s in lp.stores) > 0
+        for r in range(lp.R):
+            lp.check(r, ("end", r))
+
+
+def test_craft_store_errors_on_the_emulator(oracle):
+    import torch
+    import hostsim
+    from summerset_amd import CRaftLeaderGroup, CRaftPayloadStore, RaftLeaderGroup, RSPaxosPayloadStore, RSPaxosReplicaGroup, SummersetError
+    from summerset_amd.rsp_payload import VOTED
+    hostsim.build()
+    with hostsim.patched():
+        G, R, W, L = 8, 5, 8, 32
+        st, eng = CRaftPayloadStore(G, R, W, max_data_len=L), CRaftLeaderGroup(G, R, leader_id=0, window=W, term=1)
+        slot = torch.zeros(G, dtype=torch.int32)
+        data = torch.zeros((G, L), dtype=torch.uint8)
+        with pytest.raises(SummersetError):
+            st.put(RaftLeaderGroup(G, R, leader_id=0, window=W, term=1), slot, data)      # a plain Raft replica has no codewords
+        with pytest.raises(SummersetError):
+            st.follow(CRaftLeaderGroup(G, R, leader_id=0, window=2 * W, term=1))          # another window
+        with pytest.raises(SummersetError):
+            st.dump(VOTED)                                                               # a log entry has one codeword
+        with pytest.raises(SummersetError):
+            RSPaxosPayloadStore(G, R, W, max_data_len=L).follow(eng)                      # ... and an RSPaxos store follows an RSPaxos replica
+        rsp = RSPaxosReplicaGroup(G, R, me=0, window=W)
+        with pytest.raises(SummersetError):
+            RSPaxosPayloadStore.follow(st, rsp)                                           # smr_rsp_pstore_follow on a CRaft store
+        st.put(eng, slot.fill_(-1), data)                                                 # nothing appended: nothing stored
+        st.follow(eng)
+        assert int(st.dump()["avail"].sum()) == 0 and st.counters()["unsatisfied"] == 0

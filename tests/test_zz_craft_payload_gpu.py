@@ -1,0 +1,32 @@
+"""CRaft shard bytes on the device (`smr_craft_pstore_*`): the closed loop of tests/craft_payload_loop.py through the C-ABI --
+balanced / full-copy assignment, reconstruct_data on commit, a new leader's Reconstruct round -- every shard byte of every
+replica's store against the oracle's encoder after every handler call; a larger shape with 4 KiB batches; the ring wrapping."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("staging", [False, True], ids=["colocated", "messages"])
+def test_craft_payload_loop(cuda, oracle, staging):
+    import craft_payload_loop as cl
+    cl.run(cuda, oracle, G=96, W=32, L=131, staging=staging)
+
+
+def test_craft_payload_loop_4k_batches(cuda, oracle):
+    import craft_payload_loop as cl
+    cl.run(cuda, oracle, G=300, W=32, L=4113, seed=11, staging=True)
+
+
+def test_craft_payload_ring_wraps(cuda, oracle):
+    import craft_payload_loop as cl
+    lp = cl.Loop(cuda, oracle, G=128, W=8, L=200, seed=3)
+    for t in range(20):
+        lp.tick(p_new=1.0)
+    assert int(lp.reps[0].dump()["log_len"].max()) > 8
+    assert sum(int(s.counters()["rekeyed"]) for s in lp.stores) > 0
+    for r in range(lp.R):
+        lp.check(r, ("end", r))
