@@ -129,7 +129,9 @@ def compact_line(full):
             "value": _num(l2.get("value")), "backend": l2.get("backend"), "via": str((l2.get("exchange") or {}).get("via", ""))[:60]}
     if isinstance(full.get("exchange"), dict):                   # the spread layouts' own lines
         ex = full["exchange"]
-        out["exchange"] = {"via": str(ex.get("via", ""))[:80], "bytes_sent_per_tick_per_rank": _num(ex.get("bytes_sent_per_tick_per_rank"))}
+        cpt = ex.get("collectives_per_tick")
+        out["exchange"] = {"via": str(ex.get("via", ""))[:80], "collectives_per_tick": cpt if isinstance(cpt, int) else str(cpt)[:80],
+                           "bytes_sent_per_tick_per_rank": _num(ex.get("bytes_sent_per_tick_per_rank"))}
     for name in SECONDARY_LEGS:
         if name in full:
             out[name] = compact_leg(full[name])
@@ -140,7 +142,8 @@ def compact_line(full):
 
 def emit_line(full):
     """write the full record beside the script, print the compact line LAST on stdout"""
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    where = os.environ.get("SMR_BENCH_DETAIL_DIR")                # (tests: keep the repo root clean)
+    for d in ((where,) if where else (ROOT, os.path.join(ROOT, "gpurun_out"))):
         if os.path.isdir(d):
             try:
                 with open(os.path.join(d, DETAIL_FILE), "w") as f:

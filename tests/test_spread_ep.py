@@ -104,7 +104,7 @@ def test_plans_agree_across_ranks_without_a_device():
         assert sorted(homes) == sorted((b, r) for k in range(world) for b in range(world) for r in range(5) if spread_ep.home(b, r, world) == k)
 
 
-def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch):
+def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch, tmp_path):
     """`bench.py --layout spread-epaxos` end to end with virtual ranks (world 1), the emulator build standing in for the
     device: the line it prints carries the contract's keys and a positive rate"""
     import json
@@ -114,6 +114,7 @@ def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch):
     import bench
     hostsim.build()
     monkeypatch.setattr(sys, "argv", ["bench.py", "--layout", "spread-epaxos", "--groups", "96", "--steps", "3", "--warmup", "1", "--spread-ranks", "3"])
+    monkeypatch.setenv("SMR_BENCH_DETAIL_DIR", str(tmp_path))
     args = bench.parse()
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     with hostsim.patched():
@@ -123,7 +124,7 @@ def test_bench_layout_spread_epaxos_on_the_emulator(capsys, monkeypatch):
     assert line["value"] > 0 and line["exchange"]["bytes_sent_per_tick_per_rank"] > 0 and line["steps"] == 3
 
 
-def test_bench_layout_colocated_epaxos_on_the_emulator(capsys, monkeypatch):
+def test_bench_layout_colocated_epaxos_on_the_emulator(capsys, monkeypatch, tmp_path):
     """`bench.py --layout colocated-epaxos` (config 5 in layout L1: one smr_ep_cluster_tick call per tick) end to end, the
     emulator build standing in for the device"""
     import json
@@ -133,6 +134,7 @@ def test_bench_layout_colocated_epaxos_on_the_emulator(capsys, monkeypatch):
     import bench
     hostsim.build()
     monkeypatch.setattr(sys, "argv", ["bench.py", "--layout", "colocated-epaxos", "--groups", "96", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setenv("SMR_BENCH_DETAIL_DIR", str(tmp_path))    # the full record goes beside the (small) final line
     args = bench.parse()
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     with hostsim.patched():
@@ -141,4 +143,6 @@ def test_bench_layout_colocated_epaxos_on_the_emulator(capsys, monkeypatch):
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["steps"] == 3 and line["config"]["layout"] == "colocated"
     # every replica executes every command of all four ticks (a few run twice: an executing slot that add_edge re-inserts,
     # execution.rs:57-59 -- the reference's behaviour, counted by the engine as re-submissions)
-    assert 5 * 5 * 96 * 4 <= line["commands_executed_this_rank"] <= 5 * 5 * 96 * 4 * 1.02
+    detail = json.load(open(tmp_path / bench.DETAIL_FILE))
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-6) and len(json.dumps(line)) < bench.LINE_BUDGET
+    assert 5 * 5 * 96 * 4 <= detail["commands_executed_this_rank"] <= 5 * 5 * 96 * 4 * 1.02
