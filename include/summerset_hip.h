@@ -686,7 +686,11 @@ int smr_ep_handle_accept_replies_at(smr_ep_replica *e, const uint8_t *row_dev, c
  * (may be NULL) = u8 [G], 1 where the PreAccept from s to q is lost (with its reply).  out[s], device arrays the caller
  * owns: what leader s proposed (proposed = flags, col, seq0 / deps0 [R][G] = the PreAccept's) and decided (decision 0 /
  * 2 Accepting / 3 Committed on the fast path, committed = 1 where the instance is committed after the tick, seq, deps
- * [R][G] of the decision).  Replicas: created with me = index, population = n, equal groups; they stay the caller's. */
+ * [R][G] of the decision).  Replicas: created with me = index, population = n, equal groups; they stay the caller's.
+ * While the cluster lives (populations <= 5) its replicas keep their per-key tables -- a key's highest columns, the executor's
+ * KV word -- in ONE table of the cluster's, a 128-byte line per (group, key) with a slot per replica: every call on such a
+ * replica, its own handlers and dumps included, works there; smr_ep_cluster_destroy hands the entries back to the replicas'
+ * own tables, a replica destroyed first leaves its seat empty (smr_ep_cluster_tick then answers SMR_ERR_STATE). */
 typedef struct smr_ep_cluster smr_ep_cluster;
 typedef struct {
     uint8_t *proposed;

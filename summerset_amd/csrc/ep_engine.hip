@@ -27,6 +27,7 @@
 // every group): group-major, hc[(g * n_keys + key) * R + row] -- a lane's R entries are 4 R contiguous bytes of its own
 // group's 4 R n_keys, so a wavefront's lookup touches 64-128 lines of 80 KB instead of 5 x (distinct keys) lines, every
 // one in a different 256 KB plane (= a different page: the [key][row][G] layout of rounds 1-2).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -64,6 +65,9 @@ __device__ __forceinline__ T &EA(T *base, uint32_t idx) { return *(T *)((char *)
 struct EpView {
     uint32_t G, W, Wmask, R, me, n_keys, simple_q, super_q;
     uint32_t hc_ew;                      // words of an hc entry: 8 at R <= 6 (32 bytes, four keys to a cache line), else 16
+    uint32_t hc_es, hc_kv;               // words between the entries of two keys (= hc_ew; round 5: 32 where a cluster shares one table --
+                                         //     smr_ep_cluster_create: the R replicas' entries of a (group, key) in ONE 128-byte line);
+                                         //     the word of an entry that holds the executor's KV word
     u32x4 *p0, *p1, *p2, *p3;            // [R][W][G] each; p3 NULL at populations <= 6
     uint64_t *pa_seq;                    // my row only: [W][R][G]
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
@@ -240,7 +244,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.hc_ew + i) : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.hc_es + i) : EP_NONE;
     }
     __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
@@ -254,7 +258,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
         if (key == EP_NO_KEY) return;
-        const uint32_t o = (g * v.n_keys + key) * v.hc_ew + row;
+        const uint32_t o = (g * v.n_keys + key) * v.hc_es + row;
         const uint32_t hc = EA(v.hc, o);
         if (hc == EP_NONE || col > hc) EA(v.hc, o) = col;
     }
@@ -508,6 +512,10 @@ typedef EpLaneT<EMAXR, false> EpLane;
 // the nodes joined.  Per group: nodes in insertion order (nslot, bit 15 = new), the forest as
 // head / sib / parent links over node ids, node_of[ring cell] = node id + 1, and the submissions of
 // the whole call in `order`; all uint16 [index][G].
+// the executor's KV word in 32 bits: a token is (row + 1) << 32 | col with row + 1 <= 8 and -- a column grows by one per tick --
+// col < 2^28 for 8 years of ticks at 1 kHz
+__host__ __device__ __forceinline__ uint32_t ep_kv_pack(uint64_t tok) { return tok ? (uint32_t)((tok >> 32) << 28) | ((uint32_t)tok & 0x0FFFFFFFu) : 0u; }
+__host__ __device__ __forceinline__ uint64_t ep_kv_unpack(uint32_t w) { return w ? ((uint64_t)(w >> 28) << 32) | (w & 0x0FFFFFFFu) : 0ull; }
 constexpr uint16_t XNIL = 0xFFFF;
 constexpr uint16_t XNEW = 0x8000;
 constexpr uint64_t EP_DG_MUL = 0x100000001B3ull;
@@ -577,8 +585,9 @@ struct EpExecLaneT {
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
     __device__ __forceinline__ uint32_t at(uint32_t i) const { return i * v.G + g; }
-    // the KV word of a key: the last two words of the key's hc entry (EpView::hc)
-    __device__ __forceinline__ uint64_t &kv_at(uint32_t key) const { return *(uint64_t *)&EA(v.hc, (g * v.n_keys + key) * v.hc_ew + v.hc_ew - 2u); }
+    // the KV word of a key: word hc_kv of the key's hc entry (EpView::hc) -- the token of the key's last Put, (row + 1) << 32 | col,
+    // packed into 32 bits (ep_kv_pack: 4 bits of row + 1, 28 of the column; 0 = none) so that five replicas' entries fit one line
+    __device__ __forceinline__ uint32_t &kv_at(uint32_t key) const { return EA(v.hc, (g * v.n_keys + key) * v.hc_es + v.hc_kv); }
     // the column a ring cell of this row holds (the one of its residue among the last W)
     __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
         const uint32_t end = L.get_len(row), lo = end > v.W ? end - v.W : 0u;
@@ -619,8 +628,8 @@ struct EpExecLaneT {
         L.load_meta(i, I);
         const uint32_t key = I.key();
         if (key != EP_NO_KEY) {
-            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = kv_at(key);
-            kv_at(key) = tok;
+            const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = ep_kv_unpack(kv_at(key));
+            kv_at(key) = ep_kv_pack(tok);
             uint64_t d = EA(x.digest, g);
             d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
             EA(x.digest, g) = d;
@@ -793,7 +802,7 @@ struct EpExecLaneT {
         // (the cell behind mine matters to the exec-bar scan only: when the bar is at my column and that cell exists)
         const bool need_n = hcol == eb_of(ebs, row) && hcol + 1 < L.get_len(row) && L.held(row, hcol + 1);
         const uint32_t nst = L.status_at(L.ix(row, need_n ? hcol + 1 : 0u));
-        const uint64_t old = kv_at(key);
+        const uint64_t old = ep_kv_unpack(kv_at(key));
         uint64_t dg = EA(x.digest, g);
         EPC_SUB(L, 10);
         // the pops, in the reference's order, on those words
@@ -816,7 +825,7 @@ struct EpExecLaneT {
         const uint32_t first = n_order;
         {
             const uint64_t tok_ = ((uint64_t)(row + 1) << 32) | hcol;
-            kv_at(key) = tok_;
+            kv_at(key) = ep_kv_pack(tok_);
             dg = (dg ^ tok_) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
             EA(x.digest, g) = dg;
             if (n_order < 2u * v.R * v.W) EA(x.order, at(n_order++)) = (uint16_t)ring;
@@ -936,7 +945,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         uint32_t hc_row = EP_NONE;
 #pragma unroll
         for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
-        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.hc_ew + row) = col;
+        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.hc_es + row) = col;
     }
     L.fresh_leader_bk(i, I);
     I.set_status(EST_PREACCEPTING);
@@ -987,7 +996,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     uint32_t my[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.hc_ew + q) : EP_NONE;
+        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.hc_es + q) : EP_NONE;
     EPC_SUB(L, 1);
     if (!on) return;
     if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
@@ -1012,7 +1021,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     // refresh_highest_cols has nothing to do -- and hc[g][key] is a cache line of this lane's own, not fetched.  Otherwise
     // (the PreAccept was lost) the word is loaded now, one round trip later than the rest.
     const bool hc_known = MODE != 0 && !fresh && I.status() != EST_NULL && I.key() == k;
-    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.hc_ew + row);
+    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.hc_es + row);
     if (MODE == 0) {
         if (k == EP_NO_KEY) {
 #pragma unroll
@@ -1047,7 +1056,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     EPC_SUB(L, 4);
     L.store_inst(i, I);
     if (rec) { *rec = I; *stored = true; }
-    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.hc_ew + row) = c;   // refresh_highest_cols, dependency.rs:141-167
+    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.hc_es + row) = c;   // refresh_highest_cols, dependency.rs:141-167
     EPC_SUB(L, 5);
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
@@ -1534,6 +1543,7 @@ struct smr_ep_replica {
     EpExec x;
     Arena arena;
     bool skip_exec = false;      // smr_ep_cluster_tick around the handlers that cannot move a commit bar (see there)
+    smr_ep_replica **seat = nullptr;   // my seat in the cluster whose per-key table I use (smr_ep_cluster_create): cleared when I go first
 };
 
 namespace smr {
@@ -1569,6 +1579,21 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     }
 }
 // ---- the closed loop of a co-located cluster (smr_ep_cluster_*): the little flag arithmetic between the handlers ----------
+// A cluster's replicas share ONE per-key table (round 5): entry (g, key) is a 128-byte line, replica q's R + 1 words (the key's
+// highest column in each row, the executor's KV word) at word q * (R + 1) of it.  The five replica-wavefronts of a tick's block
+// look a key up in the same steps: one line in, one line out per (group, key) where five private tables moved five
+// (profiles/r5v: the entries' lines were most of the tick's 10x traffic).  to_shared: private entries -> slots; else back.
+__global__ __launch_bounds__(256) void ep_hc_migrate_kernel(uint32_t *__restrict__ priv, uint32_t priv_es, uint32_t priv_kv, uint32_t *__restrict__ slot0,
+                                                            uint32_t shared_es, uint32_t R, uint32_t n_entries, int to_shared) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries) return;
+    uint32_t *a = priv + (size_t)e * priv_es, *b = slot0 + (size_t)e * shared_es;
+    for (uint32_t w = 0; w <= R; w++) {
+        const uint32_t pw = w < R ? w : priv_kv;                            // (the slot keeps its KV word right behind the R columns)
+        if (to_shared) b[w] = a[pw]; else a[pw] = b[w];
+    }
+}
+
 __global__ __launch_bounds__(256) void ep_init_records_kernel(u32x4 *__restrict__ p1, u32x4 *__restrict__ p2, u32x4 *__restrict__ p3, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1626,6 +1651,7 @@ struct EpClusterArgs {
     EpView v0;
     EpExec x0;
     int64_t delta[NR];
+    uint32_t hc_slot_bytes;                      // > 0: the cluster's shared per-key table -- replica q's slot of an entry lies q * this behind replica 0's
     const uint8_t *keys[NR];
     const uint8_t *drop[NR * NR];                // [s * NR + q] (may be NULL)
     smr_ep_cluster_out out[NR];
@@ -1700,6 +1726,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
     EpExec x = a.x0;
     ep_shift(v, a.delta[q]);
     ep_shift(x, a.delta[q]);
+    if (a.hc_slot_bytes) v.hc = (uint32_t *)((char *)a.v0.hc + q * a.hc_slot_bytes);   // (one table for the cluster, not one per arena)
     v.me = q;
     EpLaneT<NR, true> L(v, g);
     L.bind_cache(sh_sc + (size_t)wv * 4 * NR * 64, lane);
@@ -1947,12 +1974,13 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
     v.G = cfg->n_groups; v.W = cfg->window; v.Wmask = cfg->window - 1; v.R = R; v.me = cfg->me; v.n_keys = cfg->n_keys;
     v.recovery = cfg->recovery;
     v.hc_ew = R <= 6 ? 8u : 16u;
+    v.hc_es = v.hc_ew; v.hc_kv = v.hc_ew - 2u;
     v.simple_q = R / 2 + 1;                                                      // mod.rs:693
     v.super_q = cfg->optimized_quorum ? R / 2 + (R / 2 + 1) / 2 : (R / 2) * 2;   // mod.rs:694-698
     err = hipMemset(e->arena.base, 0, e->arena.size);
     if (err == hipSuccess) err = hipMemset(v.hc, 0xFF, (size_t)cfg->n_keys * v.hc_ew * v.G * 4);
     if (err == hipSuccess)                                                       // ... and every entry's KV word 0
-        err = hipMemset2D((char *)v.hc + (v.hc_ew - 2) * 4, (size_t)v.hc_ew * 4, 0, 8, (size_t)cfg->n_keys * v.G);
+        err = hipMemset2D((char *)v.hc + v.hc_kv * 4, (size_t)v.hc_es * 4, 0, 8, (size_t)cfg->n_keys * v.G);
     if (err == hipSuccess) {                                                     // every ring cell a null instance (deps None, key None)
         const size_t n = (size_t)R * v.W * v.G;
         hipLaunchKernelGGL(ep_init_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)nullptr, v.p1, v.p2, v.p3, n);
@@ -1969,6 +1997,7 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
 
 void smr_ep_replica_destroy(smr_ep_replica *e) {
     if (!e) return;
+    if (e->seat) *e->seat = nullptr;                             // (the cluster then has nothing of mine to hand back)
     if (e->arena.base) (void)hipFree(e->arena.base);
     delete e;
 }
@@ -2165,9 +2194,9 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *hb) {
 #define D2H(dst, src, n) SMR_HIP_TRY(hipMemcpy((dst), (src), (n), hipMemcpyDeviceToHost))
     D2H(hb->len, v.len, R * G * 4); D2H(hb->commit_bars, v.commit_bars, R * G * 4);
     {                                                                            // device [G][K][R] -> the dump's [K][R][G]
-        const size_t EW = v.hc_ew;
-        std::vector<uint32_t> hc(K * EW * G);
-        D2H(hc.data(), v.hc, K * EW * G * 4);
+        const size_t EW = v.hc_es;                                               // (a cluster's shared table: this replica's slot of every entry, the
+        std::vector<uint32_t> hc(K * EW * G);                                    // view's base pointing at it)
+        D2H(hc.data(), v.hc, (K * EW * G - (EW - v.hc_ew)) * 4);
         for (size_t g = 0; g < G; g++)
             for (size_t k = 0; k < K; k++)
                 for (size_t r = 0; r < R; r++) hb->highest_cols[(k * R + r) * G + g] = hc[(g * K + k) * EW + r];
@@ -2225,13 +2254,12 @@ int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint6
     const EpView &v = e->v;
     const size_t G = v.G, R = v.R, K = v.n_keys;
     SMR_HIP_TRY(hipMemcpy(exec_bars, e->x.exec_bars, R * G * 4, hipMemcpyDeviceToHost));
-    {                                                                            // device: in the hc entries [G][K][hc_ew] -> the dump's [K][G]
-        const size_t EW = v.hc_ew;
+    {                                                                            // device: in the hc entries [G][K][hc_es] -> the dump's [K][G]
+        const size_t EW = v.hc_es;
         std::vector<uint32_t> hc(K * EW * G);
-        SMR_HIP_TRY(hipMemcpy(hc.data(), v.hc, K * EW * G * 4, hipMemcpyDeviceToHost));
+        SMR_HIP_TRY(hipMemcpy(hc.data(), v.hc, (K * EW * G - (EW - v.hc_ew)) * 4, hipMemcpyDeviceToHost));
         for (size_t g = 0; g < G; g++)
-            for (size_t k = 0; k < K; k++)
-                kv[k * G + g] = (uint64_t)hc[(g * K + k) * EW + EW - 2] | ((uint64_t)hc[(g * K + k) * EW + EW - 1] << 32);
+            for (size_t k = 0; k < K; k++) kv[k * G + g] = ep_kv_unpack(hc[(g * K + k) * EW + v.hc_kv]);
     }
     SMR_HIP_TRY(hipMemcpy(digest, e->x.digest, G * 8, hipMemcpyDeviceToHost));
     unsigned long long c[8];
@@ -2292,7 +2320,13 @@ struct smr_ep_cluster {
     uint8_t *masked;                                         // the PreAccept's flags behind a drop mask
     uint64_t *r_ballot[SMR_MAX_REPLICAS], *r_seq[SMR_MAX_REPLICAS], *a_ballot[SMR_MAX_REPLICAS], *bal_c[SMR_MAX_REPLICAS];
     uint32_t *r_deps[SMR_MAX_REPLICAS];
+    // the shared per-key table (see ep_hc_migrate_kernel; NULL: the replicas keep their private tables -- populations > 5, or a
+    // table that would pass the 32-bit offsets) and what the replicas' views held before
+    uint32_t *hc_shared = nullptr;
+    uint32_t *hc_priv[SMR_MAX_REPLICAS] = {};
+    uint32_t hc_priv_ew = 0, hc_priv_kv = 0;
 };
+constexpr uint32_t EP_HC_SHARED_ES = 32;                 // words between two keys' entries of the shared table: one 128-byte line
 
 int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluster **out) {
     if (!reps || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
@@ -2338,12 +2372,57 @@ int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluste
         (void)hipFree(c->base); delete c;
         return fail(SMR_ERR_DEVICE, "epaxos cluster: initialisation failed");
     }
+    // one per-key table for the whole cluster, where R slots of R + 1 words fit a line and the table the 32-bit offsets; a replica
+    // that already sits in another cluster's table (its entry stride says so) keeps what it has
+    const uint64_t K = reps[0]->cfg.n_keys, tbytes = (uint64_t)G * K * EP_HC_SHARED_ES * 4;
+    bool share = R * (R + 1) <= EP_HC_SHARED_ES && tbytes < (1ull << 32) && getenv("SMR_EP_PRIVATE_HC") == nullptr;
+    for (uint32_t r = 0; r < R; r++) share = share && reps[r]->v.hc_es == reps[r]->v.hc_ew;
+    if (share && hipMalloc((void **)&c->hc_shared, tbytes) == hipSuccess) {
+        bool ok = hipMemset(c->hc_shared, 0xFF, tbytes) == hipSuccess;
+        c->hc_priv_ew = reps[0]->v.hc_ew; c->hc_priv_kv = reps[0]->v.hc_kv;
+        const uint32_t n_entries = (uint32_t)(G * K);
+        for (uint32_t r = 0; r < R && ok; r++) {
+            EpView &v = reps[r]->v;
+            c->hc_priv[r] = v.hc;
+            uint32_t *slot0 = c->hc_shared + (size_t)r * (R + 1);
+            hipLaunchKernelGGL(ep_hc_migrate_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, (hipStream_t)stream, v.hc, v.hc_es, v.hc_kv, slot0,
+                               EP_HC_SHARED_ES, (uint32_t)R, n_entries, 1);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipDeviceSynchronize() == hipSuccess;
+        if (!ok) {
+            (void)hipFree(c->hc_shared); (void)hipFree(c->base); delete c;
+            return fail(SMR_ERR_DEVICE, "epaxos cluster: the shared per-key table could not be filled");
+        }
+        for (uint32_t r = 0; r < R; r++) {                       // from here on every kernel of replica r -- its own handlers too -- works in its slot
+            EpView &v = reps[r]->v;
+            reps[r]->seat = &c->rep[r];
+            v.hc = c->hc_shared + (size_t)r * (R + 1);
+            v.hc_es = EP_HC_SHARED_ES; v.hc_ew = (uint32_t)R + 1u; v.hc_kv = (uint32_t)R;
+        }
+    } else {
+        c->hc_shared = nullptr;
+    }
     *out = c;
     return SMR_OK;
 }
 
 void smr_ep_cluster_destroy(smr_ep_cluster *c) {
     if (!c) return;
+    if (c->hc_shared) {                                          // the replicas outlive the cluster: their entries go back into their own tables
+        (void)hipDeviceSynchronize();
+        const uint32_t n_entries = c->G * c->rep[0]->cfg.n_keys;
+        for (uint32_t r = 0; r < c->R; r++) {
+            if (!c->rep[r]) continue;                            // that replica is gone already
+            c->rep[r]->seat = nullptr;
+            EpView &v = c->rep[r]->v;
+            hipLaunchKernelGGL(ep_hc_migrate_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, (hipStream_t)nullptr, c->hc_priv[r], c->hc_priv_ew,
+                               c->hc_priv_kv, v.hc, EP_HC_SHARED_ES, c->R, n_entries, 0);
+            v.hc = c->hc_priv[r]; v.hc_es = v.hc_ew = c->hc_priv_ew; v.hc_kv = c->hc_priv_kv;
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipFree(c->hc_shared);
+    }
     if (c->base) (void)hipFree(c->base);
     delete c;
 }
@@ -2366,7 +2445,12 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
     a.R = R; a.G = G; a.execute = c->rep[0]->cfg.execute; a.quiet = !c->rep[0]->cfg.recovery;
     a.phase_major = (c->mode >> 1) & 1u;
     a.v0 = c->rep[0]->v; a.x0 = c->rep[0]->x;
+    // (read off the views, not off c->hc_shared: the table may be another cluster's of the same replicas)
+    a.hc_slot_bytes = c->rep[0]->v.hc_es != c->rep[0]->v.hc_ew ? (R + 1u) * 4u : 0u;
     for (uint32_t r = 0; r < R; r++) {
+        if (a.hc_slot_bytes ? c->rep[r]->v.hc != c->rep[0]->v.hc + (size_t)r * (R + 1u) || c->rep[r]->v.hc_es != c->rep[0]->v.hc_es
+                            : c->rep[r]->v.hc_es != c->rep[r]->v.hc_ew)
+            return fail(SMR_ERR_STATE, "epaxos cluster: the replicas' per-key tables are not one cluster's");
         a.delta[r] = (int64_t)(c->rep[r]->arena.base - c->rep[0]->arena.base);
         // (one layout: smr_ep_cluster_create took only replicas that agree in everything the layout depends on)
         if ((char *)c->rep[r]->v.p0 - c->rep[r]->arena.base != (char *)c->rep[0]->v.p0 - c->rep[0]->arena.base ||
@@ -2399,6 +2483,8 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
                         void *stream) {
     if (!c || !keys_dev || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
     const uint32_t R = c->R, G = c->G;
+    for (uint32_t s = 0; s < R; s++)
+        if (!c->rep[s]) return fail(SMR_ERR_STATE, "epaxos cluster: a replica of this cluster was destroyed");
     for (uint32_t s = 0; s < R; s++)
         if (!keys_dev[s] || !out[s].proposed || !out[s].col || !out[s].seq0 || !out[s].deps0 || !out[s].decision || !out[s].committed ||
             !out[s].seq || !out[s].deps)

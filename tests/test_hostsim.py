@@ -390,6 +390,7 @@ def test_device_resident_epaxos_cluster_tick_on_the_host(sim, oracle):
         assert t.run_fused_vs_driver("cpu", 200, 6, 0.15, T=6, oracle=oracle, phase_major=True) > 0   # the leaders' steps phase by phase (set_mode bit 1)
         assert t.run_fused_vs_driver("cpu", 70, 6, 0.15, T=5, R=7, W=16, oracle=oracle, phase_major=True) > 0
         t.run_fused_vs_driver("cpu", 130, 16, 0.1, T=5, execute=False, oracle=oracle, phase_major=True)
+        t.run_shared_table_vs_private("cpu", G=150, K=6)             # round 5: one per-key table per cluster vs private tables
 
 
 def test_spread_epaxos_exchange_on_the_host(sim, oracle):

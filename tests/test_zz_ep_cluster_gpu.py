@@ -103,3 +103,66 @@ def run_fused_vs_driver(dev, G, K, loss, T=7, execute=True, seed=5, R=5, W=32, o
     fused.close()
     launches.close()
     return slow
+
+
+def run_shared_table_vs_private(dev, G=300, K=6, T=6, R=5, W=32, seed=9):
+    """Round 5: a cluster's replicas share ONE per-key table (a 128-byte line per (group, key): csrc/ep_engine.hip
+    ep_hc_migrate_kernel).  The same ticks on private tables (SMR_EP_PRIVATE_HC) must leave every replica in the same state;
+    a replica outlives its cluster with its entries back in its own table, and goes first without harm."""
+    import os
+    import torch
+    import ep_cluster as ec
+    from summerset_amd import EPaxosReplicaGroup, SummersetError, ep_cluster
+    mk = lambda: [EPaxosReplicaGroup(G, R, me=r, window=W, n_keys=K, execute=True) for r in range(R)]
+    a, b = mk(), mk()
+    shared = ep_cluster.EPaxosCluster(a, phase_major=True)
+    os.environ["SMR_EP_PRIVATE_HC"] = "1"
+    try:
+        private = ep_cluster.EPaxosCluster(b, phase_major=True)
+    finally:
+        del os.environ["SMR_EP_PRIVATE_HC"]
+    rng = np.random.default_rng(seed)
+    tn = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+    def same(where):
+        for r in range(R):
+            x, y = a[r].dump(), b[r].dump()
+            for n in y:
+                assert np.array_equal(x[n], y[n]), (where, r, n)
+            x, y = a[r].exec_dump(), b[r].exec_dump()
+            for n in y:
+                assert np.array_equal(x[n], y[n]), (where, r, "exec", n)
+    for t in range(T):
+        keys = ec.zipf_keys(rng, R, G, K)
+        drop = {(s, q): tn(rng.random(G) < 0.1) for s in range(R) for q in range(R) if s != q}
+        oa, ob = shared.tick([tn(keys[r]) for r in range(R)], drop), private.tick([tn(keys[r]) for r in range(R)], drop)
+        for s in range(R):
+            for k in ob[s]:
+                assert torch.equal(oa[s][k], ob[s][k]), (t, s, k)
+    same("ticks")
+    assert int(a[0].exec_dump()["kv"].max()) >> 32 >= 1 and int(a[0].dump()["highest_cols"].max()) > 0
+    # the handlers of a replica that sits in a cluster work in the shared table too: one more tick through the per-handler loop
+    keys = ec.zipf_keys(rng, R, G, K)
+    ep_cluster.tick(a, [tn(keys[r]) for r in range(R)], None, phase_major=True)
+    ep_cluster.tick(b, [tn(keys[r]) for r in range(R)], None, phase_major=True)
+    same("per-handler tick inside the cluster")
+    shared.close()                                               # the entries go home
+    same("after the cluster")
+    keys = ec.zipf_keys(rng, R, G, K)
+    ep_cluster.tick(a, [tn(keys[r]) for r in range(R)], None, phase_major=True)
+    ep_cluster.tick(b, [tn(keys[r]) for r in range(R)], None, phase_major=True)
+    same("per-handler tick after the cluster")
+    again = ep_cluster.EPaxosCluster(a, phase_major=True)        # ... and into a new cluster's table
+    keys = ec.zipf_keys(rng, R, G, K)
+    again.tick([tn(keys[r]) for r in range(R)])
+    private.tick([tn(keys[r]) for r in range(R)])
+    same("second cluster")
+    a[R - 1].close()                                             # a replica that goes before its cluster
+    with pytest.raises(SummersetError):
+        again.tick([tn(keys[r]) for r in range(R)])
+    again.close()
+    private.close()
+
+
+def test_cluster_shares_one_per_key_table(cuda):
+    run_shared_table_vs_private(cuda, G=1500, K=64)
