@@ -1148,7 +1148,12 @@ __global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, i
 // nothing of it is needed before R2 of tick t + 1: it reads its own replica's state, the ack matrix and the PrepareReplies
 // R2 of tick t wrote, and appends to its own outbox of the NEXT parity, which is the outbox R1 of tick t + 1 appends to
 // right behind it in the same lane.  Not on a heartbeat tick (R4 reads the records R3 publishes) and not for a batch's last
-// tick.  Same results: the handlers of a (group, replica) still run in the same order.
+// tick.  Same results: the handlers of a (group, replica) still run in the same order.  The one value that crosses replicas between
+// the two halves is the group's `overflow` flag (a frozen group skips R1): the engine only defers in a quiet stretch (no HearTimeout
+// for 2 x 16 + ttl ticks: smr_mp_run_ticks), and without Prepare traffic the rest of R3 has no path that freezes a group -- the
+// window and outbox checks that set the flag sit in R1 / R2 and in the PrepareReply handlers (mp_device.h) -- so no replica's R1
+// can run ahead of a flag another replica's deferred R3 would have set (ADVICE r4;
+// tests/test_mp_gpu.py::test_window_overflow_while_the_r3_rest_rides_in_the_next_r1).
 __global__ __launch_bounds__(256) void mp_rest_then_local(const MpParams *__restrict__ Pp, int par_prev,
                                                           const uint32_t *__restrict__ ackctl_prev, int par,
                                                           const uint8_t *__restrict__ timeout_rep, const uint8_t *__restrict__ timeout_src,

@@ -207,8 +207,9 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
             uint32_t want = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
             if (want_tok == PS_NULL) want = 0;
             if (want == 0) want_tok = PS_NULL;
-            uint32_t have = v.pl[pl].avail[i], L = v.pl[pl].dlen[i];
-            if (v.pl[pl].tok[i] != want_tok) {
+            const uint32_t had_tok = v.pl[pl].tok[i], had = v.pl[pl].avail[i], had_len = v.pl[pl].dlen[i];
+            uint32_t have = had, L = had_len;
+            if (had_tok != want_tok) {
                 if (have) n_rekey++;
                 have = 0; L = 0;
             }
@@ -248,7 +249,11 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
                 have |= need; need = 0;
             }
             n_unsat += (uint32_t)__popc(need);
-            v.pl[pl].tok[i] = want_tok; v.pl[pl].avail[i] = (uint8_t)have; v.pl[pl].dlen[i] = L;
+            // (only what changed: the steady tick touches one row of W, and 9 bytes x every cell x every call was ~19 MB of writes per
+            // follow_many at config 4's size -- ADVICE r4)
+            if (had_tok != want_tok) v.pl[pl].tok[i] = want_tok;
+            if (had != have) v.pl[pl].avail[i] = (uint8_t)have;
+            if (had_len != L) v.pl[pl].dlen[i] = L;
             src[pl] = sb; sl[pl] = ps_shard_len(L, v.d);
             if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
         }

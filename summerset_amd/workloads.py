@@ -123,3 +123,17 @@ def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, on
         others = [q for q in range(len(reps)) if q != s]                  # the followers consumed ONE Accept broadcast: one call for all of them
         stores[s].follow_many([stores[q] for q in others], [reps[q] for q in others], (stores[s], REQS))
     return committed
+
+
+# ---- serialized request batches behind a token (the payload stores' device tests and their emulator runs) --------------------
+def payload_batch_len(tok, L):
+    """length of the batch a token stands for: a function of the token alone, in 1 .. L"""
+    return (1 + (tok.astype(np.uint64) * np.uint64(7919)) % np.uint64(L)).astype(np.uint32)
+
+
+def payload_batch_bytes(tok, L):
+    """the serialized request batch behind a token: a function of the token alone; [n, L] (bytes past the length are junk the
+    store must never read into a shard)"""
+    t = tok.astype(np.uint64)[:, None]
+    i = np.arange(L, dtype=np.uint64)[None, :]
+    return (((t * np.uint64(2654435761) + i * np.uint64(40503)) >> np.uint64(7)) & np.uint64(0xFF)).astype(np.uint8)

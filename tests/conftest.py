@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "stage(n): run order across modules -- lower stages first, unmarked tests are stage 0 (stable within a stage)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """the order of the device suite is said HERE, not by file names: modules may carry `pytest.mark.stage(n)`"""
+    def stage(item):
+        m = item.get_closest_marker("stage")
+        return int(m.args[0]) if m and m.args else 0
+    items.sort(key=stage)                                           # (list.sort is stable: collection order inside a stage)
 
 
 @pytest.fixture(scope="session")

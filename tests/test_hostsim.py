@@ -114,6 +114,10 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=100, R=5, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True,
                commit_extra=1)
         eng, _ = t._run("cpu", oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True)
+        # a window that overflows while the rest of R3 rides in the next R1 launch (quiet stretch, batches of 8)
+        e2, _ = t._run("cpu", oracle, G=70, R=5, S=4, W=16, n_ticks=72, drop_p=0.05, timeout_frac=0.0, hb_every=12, preset=True, fused=8,
+                       straggler_ticks=4, every=8, no_array_when_quiet=True)
+        assert e2.counters(0)["rejects"] > 0
         assert eng.counters(0)["rejects"] > 0
         # bench.py's shape (S = 32, W = 512, no commit list: the tally's closed form; long outboxes after a leader change),
         # with and without the straggler side launch

@@ -74,7 +74,7 @@ def _acks_as_records(eng, cuda, G, R, cap, t):
 
 
 def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, preset, commit_extra=0, seed=None,
-         every=1, timeout_rep=1, straggler_ticks=0, per_round=False, fused=0, rotate=False):
+         every=1, timeout_rep=1, straggler_ticks=0, per_round=False, fused=0, rotate=False, no_array_when_quiet=False):
     from summerset_amd import MultiPaxosCluster, stream
     cap = W + 4
     eng = MultiPaxosCluster(G, R, W, outbox_cap=cap, commit_extra=commit_extra, commit_list_cap=G * (S * 4 * max(fused, 1) + W) + 64,
@@ -101,6 +101,8 @@ def _run(cuda, oracle, G, R, S, W, n_ticks, drop_p, timeout_frac, hb_every, pres
         inp = st.tick(t)
         orc.tick(**inp)
         if fused:                           # batches of `fused` ticks through the fused tick kernel (one launch each)
+            if no_array_when_quiet and not (inp["timeout_rep"] != 0xFF).any():   # a host knows when no timer fired: no array at all,
+                inp = dict(inp, timeout_rep=None, timeout_src=None)              # which is what lets the engine call a stretch quiet
             pending.append(_to_dev(inp, cuda))
             for r in range(R):
                 g_, s_ = orc.take_commits(r)
@@ -203,6 +205,19 @@ def test_window_backpressure_and_overflow_flags(cuda, oracle):
     eng, orc = _run(cuda, oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8,
                     preset=True)
     assert eng.counters(0)["rejects"] > 0
+
+
+def test_window_overflow_while_the_r3_rest_rides_in_the_next_r1(cuda, oracle):
+    """in a quiet stretch (no HearTimeout for 2 x 16 + ttl ticks) smr_mp_run_ticks defers the rest of a tick's R3 into the
+    next tick's R1 launch (mp_rest_then_local), where the group's `overflow` flag is re-read behind the block's own R3 only.  A
+    tiny window with heartbeats far apart makes groups refuse batches and freeze in exactly such stretches; flags and every
+    unfrozen group's state must stay the oracle's, batch after batch.  (What makes the fused launch safe: without Prepare traffic
+    the rest of R3 has no path that freezes a group -- the window and outbox checks sit in R1 / R2 and in the PrepareReply
+    handlers -- so no replica's R1 can miss a flag another replica's deferred R3 would have set.)"""
+    for W, S, hb in ((16, 3, 8), (16, 5, 16), (32, 4, 12)):
+        eng, _ = _run(cuda, oracle, G=96, R=5, S=S, W=W, n_ticks=96, drop_p=0.05, timeout_frac=0.0, hb_every=hb, preset=True, fused=8,
+                      straggler_ticks=4, every=8, no_array_when_quiet=True)
+        assert eng.counters(0)["rejects"] > 0
 
 
 def test_config2_4096_groups(cuda, oracle):

@@ -18,16 +18,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 NULL = 0xFFFFFFFF
 
 
-def batch_len(tok, L):
-    return (1 + (tok.astype(np.uint64) * np.uint64(7919)) % np.uint64(L)).astype(np.uint32)
-
-
-def batch_bytes(tok, L):
-    """the serialized request batch behind a token: a function of the token alone; [n, L] (bytes past the length are junk
-    the store must never read into a shard)"""
-    t = tok.astype(np.uint64)[:, None]
-    i = np.arange(L, dtype=np.uint64)[None, :]
-    return (((t * np.uint64(2654435761) + i * np.uint64(40503)) >> np.uint64(7)) & np.uint64(0xFF)).astype(np.uint8)
+from summerset_amd.workloads import payload_batch_bytes as batch_bytes, payload_batch_len as batch_len  # noqa: E402
 
 
 class Expect:

@@ -5,9 +5,9 @@ emulator), so its first device run is the driver's at round end, behind everythi
 import numpy as np
 import pytest
 
-from test_zz_rsp_payload_gpu import batch_bytes, batch_len
+from summerset_amd.workloads import payload_batch_bytes as batch_bytes, payload_batch_len as batch_len
 
-pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300), pytest.mark.stage(9)]
 
 
 def test_accept_frames_with_their_payload_are_the_host_encoder_s(cuda, oracle):
