@@ -952,6 +952,10 @@ int smr_craft_pstore_put(smr_rsp_pstore *s, const smr_raft_leader *e, const uint
                          const uint32_t *len_dev, uint32_t data_len, void *stream);
 int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *sel_dev,
                             void *stream);
+/* smr_craft_pstore_follow for n <= 8 followers that consumed ONE leader's AppendEntries: stores[k] follows replicas[k], each with
+ * the single source src (may be NULL; none of the stores) -- three launches for all of them instead of three each */
+int smr_craft_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_raft_leader *const *replicas, const smr_rsp_pstore *src,
+                                 void *stream);
 
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing

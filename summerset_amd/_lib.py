@@ -334,6 +334,7 @@ SYMBOLS = [
     ("smr_craft_pstore_create", _i, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("smr_craft_pstore_put", _i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _vp]),
     ("smr_craft_pstore_follow", _i, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    ("smr_craft_pstore_follow_many", _i, [_u32, _vp, _vp, _vp, _vp]),
     ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
     ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),

@@ -515,6 +515,19 @@ __global__ __launch_bounds__(256) void craft_tokens_kernel(const RaftPeek e, uin
     const uint32_t s = craft_cell_slot(e, row, g);
     tok[i] = s == PS_NULL ? PS_NULL : craft_token(s, e.entry_term[i]);
 }
+// ... for several replicas in one launch (blockIdx.y = which): smr_craft_pstore_follow_many
+struct CraftMany {
+    RaftPeek e[PS_MAX_N];
+    uint32_t *tok[PS_MAX_N];
+};
+__global__ __launch_bounds__(256) void craft_tokens_many_kernel(const CraftMany M) {
+    const RaftPeek e = M.e[blockIdx.y];
+    uint32_t *const tok = M.tok[blockIdx.y];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= e.W * e.G) return;
+    const uint32_t s = craft_cell_slot(e, i / e.G, i % e.G);
+    tok[i] = s == PS_NULL ? PS_NULL : craft_token(s, e.entry_term[i]);
+}
 // the put of the entry the leader appended at slot[g] (PS_NULL: none): a_n / a_val as ps_put_kernel takes them
 __global__ __launch_bounds__(256) void craft_put_args_kernel(const RaftPeek e, const uint32_t *__restrict__ slot, uint32_t *__restrict__ a_n,
                                                              uint32_t *__restrict__ a_val) {
@@ -807,27 +820,23 @@ int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_
     return ps_follow(s, pk, n_src, src, planes, sel_dev, stream);
 }
 
-int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
-                               int src_plane, void *stream) {
-    if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "pstore follow_many: 1 .. 8 stores");
+// stores[k] follows the (token, mask) arrays pk[k] names, each with the single source (src, src_plane): two launches for all of them
+static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPeek *pk, const smr_rsp_pstore *src, int src_plane, void *stream) {
     if (src && (src_plane < 0 || src_plane >= src->planes)) return fail(SMR_ERR_ARG, "pstore follow_many: bad source plane");
     PsMany M;
     memset(&M, 0, sizeof(M));
     PsSrcs S;
     memset(&S, 0, sizeof(S));
-    const PsView &v0 = stores[0] ? stores[0]->v : PsView();
+    const PsView &v0 = stores[0]->v;
     for (uint32_t k = 0; k < n; k++) {
         smr_rsp_pstore *s = stores[k];
-        if (!s || !replicas[k]) return fail(SMR_ERR_ARG, "pstore follow_many: null store / replica");
         if (s == src) return fail(SMR_ERR_ARG, "pstore follow_many: the source must not be one of the stores that follow");
-        if (s->planes != 2) return fail(SMR_ERR_STATE, "pstore follow_many: a CRaft store follows a Raft replica (smr_craft_pstore_follow)");
         for (uint32_t j = 0; j < k; j++) if (stores[j] == s) return fail(SMR_ERR_ARG, "pstore follow_many: a store is listed twice");
-        const RspPeek pk = rsp_peek(replicas[k]);
         if (s->v.G != v0.G || s->v.W != v0.W || s->v.n != v0.n || s->v.d != v0.d || s->v.cap_sl != v0.cap_sl)
             return fail(SMR_ERR_ARG, "pstore follow_many: the stores differ in geometry");
-        if (pk.G != v0.G || pk.W != v0.W || pk.R != v0.n || pk.majority != v0.d)
+        if (pk[k].G != v0.G || pk[k].W != v0.W || pk[k].R != v0.n || pk[k].majority != v0.d)
             return fail(SMR_ERR_ARG, "pstore follow_many: a replica's groups / window / population / majority differ from the stores'");
-        M.e[k] = pk;
+        M.e[k] = pk[k];
     }
     if (src) {
         if (src->v.G != v0.G || src->v.W != v0.W || src->v.n != v0.n || src->v.d != v0.d || src->v.cap_sl != v0.cap_sl)
@@ -849,6 +858,41 @@ int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const 
     hipLaunchKernelGGL(ps_bytes_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, st, M, S);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
+}
+
+int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
+                               int src_plane, void *stream) {
+    if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "pstore follow_many: 1 .. 8 stores");
+    RspPeek pk[PS_MAX_N];
+    for (uint32_t k = 0; k < n; k++) {
+        if (!stores[k] || !replicas[k]) return fail(SMR_ERR_ARG, "pstore follow_many: null store / replica");
+        if (stores[k]->planes != 2) return fail(SMR_ERR_STATE, "pstore follow_many: a CRaft store follows a Raft replica (smr_craft_pstore_follow_many)");
+        pk[k] = rsp_peek(replicas[k]);
+    }
+    return ps_follow_many(n, stores, pk, src, src_plane, stream);
+}
+
+// smr_craft_pstore_follow for n <= 8 followers that consumed ONE leader's AppendEntries: a token launch, a plan launch and a byte
+// launch for all of them
+int smr_craft_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_raft_leader *const *replicas, const smr_rsp_pstore *src,
+                                 void *stream) {
+    if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "craft pstore follow_many: 1 .. 8 stores");
+    RspPeek pk[PS_MAX_N];
+    CraftMany C;
+    memset(&C, 0, sizeof(C));
+    for (uint32_t k = 0; k < n; k++) {
+        if (!stores[k] || !replicas[k]) return fail(SMR_ERR_ARG, "craft pstore follow_many: null store / replica");
+        RaftPeek rp;
+        if (int rc = craft_peek_of(stores[k], replicas[k], rp)) return rc;
+        C.e[k] = rp; C.tok[k] = stores[k]->craft_tok;
+        pk[k] = RspPeek{rp.G, rp.W, rp.R, 0u, rp.quorum, stores[k]->craft_tok, stores[k]->craft_null, rp.entry_mask, rp.entry_mask};
+    }
+    const uint32_t cells = C.e[0].W * C.e[0].G;
+    for (uint32_t k = 1; k < n; k++)
+        if (C.e[k].W * C.e[k].G != cells) return fail(SMR_ERR_ARG, "craft pstore follow_many: the replicas differ in groups / window");
+    hipLaunchKernelGGL(craft_tokens_many_kernel, dim3((cells + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, C);
+    SMR_HIP_TRY(hipGetLastError());
+    return ps_follow_many(n, stores, pk, src, 0, stream);
 }
 
 int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,

@@ -174,8 +174,13 @@ class CRaftPayloadStore(RSPaxosPayloadStore):
         check(self._L.smr_craft_pstore_follow(self._h, replica._h, n, arr, _ptr(sel), stream_ptr(stream)))
 
     @staticmethod
-    def follow_many(*a, **kw):
-        raise _lib.SummersetError(_lib.SMR_ERR_STATE, "a CRaft store follows one Raft replica per call")
+    def follow_many(stores, replicas, source=None, stream=None):
+        """`follow` for several followers that consumed ONE leader's AppendEntries: stores[k] follows replicas[k], each with the
+        single source `source` (a store, none of them) -- three launches for all of them"""
+        n = len(stores)
+        sa = (C.c_void_p * n)(*[s._h for s in stores])
+        ra = (C.c_void_p * n)(*[r._h for r in replicas])
+        check(stores[0]._L.smr_craft_pstore_follow_many(n, sa, ra, None if source is None else source._h, stream_ptr(stream)))
 
     def emit_accepts(self, *a, **kw):
         raise _lib.SummersetError(_lib.SMR_ERR_STATE, "Accept frames are RSPaxos'")

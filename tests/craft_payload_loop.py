@@ -14,7 +14,7 @@ def craft_token(slot, term):
 
 
 class Loop:
-    def __init__(self, dev, oracle, G=96, R=5, W=32, L=131, ft=1, seed=7, staging=False):
+    def __init__(self, dev, oracle, G=96, R=5, W=32, L=131, ft=1, seed=7, staging=False, many=False):
         """staging: a message's payload is what the message CARRIES -- `extract`ed at the sender (subset_copy of the sent shards),
         `ingest`ed into the receiver's staging store, which `follow` names as its only source (replicas on different devices);
         off: the sender's store itself stands for the payload (co-located replicas)"""
@@ -27,6 +27,7 @@ class Loop:
         self.stores = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)]
         self.staging = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)] if staging else None
         self._msg = None
+        self.many = many and not staging                                  # the followers of one AppendEntries broadcast: ONE follow_many call
         self.leader = 0
         for r in range(1, R):
             self.reps[r].preset(0, 0, 1)                                  # followers of replica 0 in term 1
@@ -140,12 +141,19 @@ class Loop:
                 self.carry(ld, q, [(self.t((on & (ne > k)).astype(np.uint8)), self.t((p1 + k).astype(np.uint32)), em[k].contiguous())
                                    for k in range(int(ne[on].max()) if on.any() else 0)])
             r = self.reps[q].handle_msg_append_entries(**m, entry_mask=em)
-            src, sel = self.sources(q, ld)
-            self.stores[q].follow(self.reps[q], sources=src, sel=sel)
-            self.check(q, ("append_entries", q))
+            if not self.many:
+                src, sel = self.sources(q, ld)
+                self.stores[q].follow(self.reps[q], sources=src, sel=sel)
+                self.check(q, ("append_entries", q))
             rt[q] = r["term"].cpu().numpy().view(np.uint64); es[q] = r["end_slot"].cpu().numpy().view(np.uint32)
             fl[q] = r["flags"].cpu().numpy(); ct[q] = r["conflict_term"].cpu().numpy().view(np.uint64)
             cs[q] = r["conflict_slot"].cpu().numpy().view(np.uint32)
+        if self.many:
+            qs = [q for q in range(R) if q != ld and q not in skip]
+            if qs:
+                type(st).follow_many([self.stores[q] for q in qs], [self.reps[q] for q in qs], source=st)
+            for q in qs:
+                self.check(q, ("append_entries, follow_many", q))
         eng.handle_msg_append_entries_reply(self.t(rt), self.t(es), self.t(fl), self.t(ct), self.t(cs), None)
         st.follow(eng)
         self.check(ld, ("replies", ld))
@@ -210,8 +218,8 @@ class Loop:
         return len(gs)
 
 
-def run(dev, oracle, G=96, W=32, L=131, seed=7, staging=False):
-    lp = Loop(dev, oracle, G=G, W=W, L=L, seed=seed, staging=staging)
+def run(dev, oracle, G=96, W=32, L=131, seed=7, staging=False, many=False):
+    lp = Loop(dev, oracle, G=G, W=W, L=L, seed=seed, staging=staging, many=many)
     R = lp.R
     # groups 1 mod 4: every AppendEntries carries shards {0, 3, 4} -- a majority with one data shard among them, so a follower's
     # commit runs reconstruct_data and the store rebuilds shards 1 and 2; the others: the leader's own assignment

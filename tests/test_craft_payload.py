@@ -11,13 +11,13 @@ import pytest
 sys.path.insert(0, os.path.dirname(__file__))
 
 
-@pytest.mark.parametrize("staging", [False, True], ids=["colocated", "messages"])
-def test_craft_payload_loop_on_the_emulator(oracle, staging):
+@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True)], ids=["colocated", "messages", "follow_many"])
+def test_craft_payload_loop_on_the_emulator(oracle, staging, many):
     import hostsim
     import craft_payload_loop as cl
     hostsim.build()
     with hostsim.patched():
-        cl.run("cpu", oracle, G=70, W=32, L=67, staging=staging)
+        cl.run("cpu", oracle, G=70, W=32, L=67, staging=staging, many=many)
 
 
 def test_craft_payload_ring_wraps_on_the_emulator(oracle):
@@ -60,3 +60,24 @@ def test_craft_store_errors_on_the_emulator(oracle):
         st.put(eng, slot.fill_(-1), data)                                                 # nothing appended: nothing stored
         st.follow(eng)
         assert int(st.dump()["avail"].sum()) == 0 and st.counters()["unsatisfied"] == 0
+
+
+def test_bench_leg_craft_payload_on_the_emulator(oracle):
+    """bench.py's `craft_payload` leg -- its loop and its own end-of-leg checks -- at a small shape, the emulator as the device"""
+    import importlib.util
+    import torch
+    import hostsim
+    spec = importlib.util.spec_from_file_location("smr_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    hostsim.build()
+
+    def run_untimed(torch_, fn, iters, sleep_cycles=0):
+        for i in range(iters):
+            fn(i)
+        return 100.0
+    with hostsim.patched():
+        out = bench.craft_payload_leg(torch, "cpu", ticks=5, warmup=2, G=130, L=67, time_us=run_untimed)
+    assert out["verified"] and out["counters"]["unsatisfied"] == 0 and out["counters"]["copied"] > 0
+    line = bench.compact_leg(out)
+    assert set(line) == {"value", "unit", "ms_per_tick", "frac", "frac_on_8d_bytes", "traffic_ratio", "cpu_cores"}

@@ -10,10 +10,10 @@ sys.path.insert(0, os.path.dirname(__file__))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("staging", [False, True], ids=["colocated", "messages"])
-def test_craft_payload_loop(cuda, oracle, staging):
+@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True)], ids=["colocated", "messages", "follow_many"])
+def test_craft_payload_loop(cuda, oracle, staging, many):
     import craft_payload_loop as cl
-    cl.run(cuda, oracle, G=96, W=32, L=131, staging=staging)
+    cl.run(cuda, oracle, G=96, W=32, L=131, staging=staging, many=many)
 
 
 def test_craft_payload_loop_4k_batches(cuda, oracle):
