@@ -6,6 +6,7 @@
 // lanes pick their group's leader, whichever replica that is.)  Rounds are separate launches because
 // each consumes what the previous one wrote for OTHER replicas (and, in the
 // multi-GPU layout, the exchange sits between them).
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -442,12 +443,29 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 }
 
 // R2: every replica consumes the other replicas' outboxes (sender-major, FIFO)
+// MODE 0: all of it (the side stream's kernels, the fused tick, quiet stretches).  Round 5, for the bulk launch beside a busy side
+// stream: MODE 1 = the steady-state fast path ALONE -- a lane whose outboxes it cannot finish leaves (sender, entry) in r2_res and
+// raises its tile's r2_need flag -- and MODE 2 = the cooperative jobs of exactly those lanes, a launch of its own right behind
+// (mp_round_deliver_rest: exits on the flags).  The generic handlers inlined into one kernel with the fast path set its register
+// budget (96 VGPRs with 852 B of scratch per lane) for work a handful of groups per tick have; alone, the fast path
+// is 79 VGPRs and no scratch: six wavefronts per SIMD instead of five, and three instead of two on a SIMD that hosts a 232-VGPR
+// wavefront of the side stream -- the launch fits the chip in one pass with ~110 CUs half taken.  MEASURED (profiles/r8i, same
+// call A/B on the driver's command): the fast launch takes 24.2 us where the one launch took 26.8 (15.3 against 14.2 at best), and
+// the rest launch costs its 4.9 us every tick: 0.0906-0.0921 ms per tick against 0.0905-0.0907.  Occupancy is NOT what the side
+// stream costs R2 -- an EMPTY launch (mp_round_replies with nothing flagged) is 30 % slower beside it too (4.9-5.5 us against
+// 3.7-4.0, profiles/r8c) -- so the split stays off (SMR_MP_SPLIT_R2 in the environment turns it on; the tests run both).
+template <int MODE>
 __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32_t g, bool active, const uint32_t r) {
     Lane L(P, r, g < P.G ? g : 0, par);
     bool job = false;
     uint32_t job_sender = 0, job_j = 0;
     bool loaded = false;
-    if (active) {
+    if (MODE == 2) {
+        if (active) {
+            const uint32_t w = P.r2_res[(size_t)r * P.G + g];
+            if (w) { job = true; job_sender = (w >> 4) & 0xFu; job_j = w >> 8; P.r2_res[(size_t)r * P.G + g] = 0; }
+        }
+    } else if (active) {
         if (L.v.pr_cnt()[g]) L.v.pr_cnt()[g] = 0;
         uint32_t cnts[MAXR];
         uint32_t n_senders = 0, the_sender = 0, the_cnt = 0, first = MAXR;
@@ -534,7 +552,13 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
         if (n_senders > 1) { job = true; job_sender = first; job_j = 0; }
         else if (n_senders == 1 && fast_done < the_cnt) { job = true; job_sender = the_sender; job_j = fast_done; }
         if (loaded) L.store();
+        if (MODE == 1 && job) {                                  // ... of the launch behind this one
+            P.r2_res[(size_t)r * P.G + g] = 1u | (job_sender << 4) | (job_j << 8);
+            P.r2_need[(size_t)blockIdx.y * ((P.G + 63) / 64) + (g >> 6)] = 1;   // (lanes of a wavefront share a tile: same byte, same value)
+            job = false;
+        }
     }
+    if (MODE != 1)
     SMR_FOR_EACH_JOB(job, src) {
         const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src), rj = __shfl(r, src);
         Lane J(P, rj, gj, par);
@@ -554,12 +578,35 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
 #ifndef MP_R2_MINW
 #define MP_R2_MINW 5
 #endif
-__global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver(const MpParams *__restrict__ Pp, int par, int side) {
+// everything of R2 in one launch: the side stream's blocks, the spread layout, stretches without a leader change
+__global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver_all(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
-    r2_body(P, par, g, active, pick_replica(P, side, g));
+    r2_body<0>(P, par, g, active, pick_replica(P, side, g));
+}
+// the bulk launch beside a busy side stream: the fast path alone ...
+__global__ __launch_bounds__(256) void mp_round_deliver(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r2_body<1>(P, par, g, active, pick_replica(P, 0, g));
+}
+// ... and what it left, for the tiles whose flag is up (same grid, same lane -> (group, replica) mapping)
+__global__ __launch_bounds__(256) void mp_round_deliver_rest(const MpParams *__restrict__ Pp, int par) {
+    const MpParams &P = *Pp;
+    if (!((P.live >> blockIdx.y) & 1u)) return;
+    const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;
+    uint32_t any = 0;
+    for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r2_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+    if (!any) return;                                            // (block-uniform)
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r2_body<2>(P, par, g, active, pick_replica(P, 0, g));
+    __syncthreads();
+    if (threadIdx.x < tpb && t0 + threadIdx.x < ntile) P.r2_need[(size_t)blockIdx.y * ntile + t0 + threadIdx.x] = 0;
 }
 
 // ---- R3 ---------------------------------------------------------------------
@@ -1264,7 +1311,7 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
         if (timeout_rep || req_target)
             r1_body(P, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, mine && !P.overflow[g], r);
         __syncthreads();
-        r2_body(P, par, g, mine && !P.overflow[g], r);                         // (a round may freeze the group)
+        r2_body<0>(P, par, g, mine && !P.overflow[g], r);                      // (a round may freeze the group)
         __syncthreads();
         r3_body(P, par, ackctl, do_heartbeat, g, mine && !P.overflow[g], r);
         __syncthreads();
@@ -1312,7 +1359,7 @@ __global__ __launch_bounds__(512, STRAG_BATCH_MINW) void mp_straggler_batch(cons
             if (in.timeout_rep || in.req_target)
                 r1_body(P, par, in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, mine && !P.overflow[g], r);
             __syncthreads();
-            r2_body(P, par, g, mine && !P.overflow[g], r);
+            r2_body<0>(P, par, g, mine && !P.overflow[g], r);
             __syncthreads();
             r3_body(P, par, in.ackctl, in.heartbeat, g, mine && !P.overflow[g], r);
             __syncthreads();
@@ -1364,7 +1411,7 @@ __device__ __forceinline__ void fused_r1(const MpParams *Pp, int par, const uint
     r1_body(*Pp, par, timeout_rep, timeout_src, req_target, req_cnt, req_val, S, g, g < Pp->G && !Pp->overflow[g], r);
 }
 __device__ __forceinline__ void fused_r2(const MpParams *Pp, int par, uint32_t g, uint32_t r) {
-    r2_body(*Pp, par, g, g < Pp->G && !Pp->overflow[g], r);     // (a round may freeze the group)
+    r2_body<0>(*Pp, par, g, g < Pp->G && !Pp->overflow[g], r);  // (a round may freeze the group)
 }
 template <int NR>
 __device__ __forceinline__ void fused_tally(const MpParams *Pp, int par, const uint32_t *ackctl, int publish_hb, uint8_t *sh_fl,
@@ -1713,6 +1760,9 @@ struct smr_mp_cluster {
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     uint32_t quiet_ticks = 0;        // smr_mp_run_ticks: ticks in a row without a HearTimeout array (the side launch has nothing listed)
+    bool no_split_r2 = true;         // the split is OFF unless SMR_MP_SPLIT_R2 is in the environment at smr_mp_create: measured, it does not
+                                     // pay (profiles/r8i: fast path alone 24.2 us + rest 4.9 us against 26.8 us for the one launch)
+    bool split_r2 = false;           // smr_mp_run_ticks, the side stream busy: R2's bulk launch = fast path + rest (r2_body)
     bool defer_rest = false;         // smr_mp_run_ticks: the next smr_mp_round_replies launches the tally only ...
     bool rest_pending = false;       // ... and the rest of that R3 rides in the next R1 launch (mp_rest_then_local)
     int rest_par = 0;
@@ -1748,6 +1798,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     carve(a, P.overflow, G, dry);
     carve(a, P.dbg, 64, dry);
     carve(a, P.r3_need, R * ((G + 63) / 64), dry);
+    carve(a, P.r2_need, R * ((G + 63) / 64), dry); carve(a, P.r2_res, R * G, dry);
     carve(a, P.slow, G, dry); carve(a, P.slow_ttl, G, dry); carve(a, P.role_rot, G, dry);
     carve(a, P.slow_list, (size_t)SLOW_CAP, dry); carve(a, P.slow_n, 2, dry);
     for (size_t r = 0; r < R; r++) {
@@ -1906,6 +1957,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
         return fail(SMR_ERR_DEVICE, std::string("mp: init: ") + hipGetErrorString(e));
     }
     c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
+    c->no_split_r2 = getenv("SMR_MP_SPLIT_R2") == nullptr;
     if (c->ttl) {
         e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -1992,12 +2044,18 @@ int smr_mp_round_deliver(smr_mp_cluster *c, void *stream) {
     bool own;
     if ((rc = fork_side(c, st, own))) return rc;
     if (c->side_on && !c->side_fused) {
-        hipLaunchKernelGGL(mp_round_deliver, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
+        hipLaunchKernelGGL(mp_round_deliver_all, side_grid(c), dim3(256), 0, c->side, c->dp, c->par, 1 + c->lpar);
         SMR_HIP_TRY(hipGetLastError());
     }
     int pi;
     if ((rc = prof_begin(c, 1, st, pi))) return rc;
-    hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, 0);
+    if (c->split_r2) {                                           // (smr_mp_run_ticks beside a busy side stream: see r2_body)
+        hipLaunchKernelGGL(mp_round_deliver, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par);
+        SMR_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(mp_round_deliver_rest, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par);
+    } else {
+        hipLaunchKernelGGL(mp_round_deliver_all, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->par, 0);
+    }
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pi, st))) return rc;
     return join_side(c, st, own);
@@ -2137,6 +2195,7 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
         hipLaunchKernelGGL(mp_straggler_batch, dim3(STRAG_BATCH_BLOCKS), dim3(R <= 5 ? 320 : 512), 0, c->side, c->dp, c->lpar, b);
         SMR_HIP_TRY(hipGetLastError());
         c->marked = c->side_on = c->forked = c->side_fused = true;   // the round calls below: bulk only, no fork of their own
+        c->split_r2 = !quiet && !c->no_split_r2;
         int rc = SMR_OK;
         for (uint32_t k = 0; k < b.n && !rc; k++) {
             const smr_mp_tick_in &x = ticks[i0 + k];
@@ -2157,6 +2216,7 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             hipLaunchKernelGGL(mp_round_replies, mp_grid(c), dim3(MP_BLOCK), 0, st, c->dp, c->rest_par, c->rest_ackctl, 0, 0);
         }
         c->marked = c->side_on = c->forked = c->side_fused = false;
+        c->split_r2 = false;
         hipError_t e1 = hipEventRecord(c->ev_join, c->side);
         hipError_t e2 = hipStreamWaitEvent(st, c->ev_join, 0);
         c->lpar ^= 1;

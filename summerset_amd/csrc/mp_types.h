@@ -215,6 +215,8 @@ struct MpParams {
     SMR_G uint8_t *overflow;        // [G] sticky, shared by all replicas of a group
     SMR_G unsigned long long *dbg;  // [64] debug clock stamps
     SMR_G uint8_t *r3_need;         // [R][ceil(G/64)]: this 64-group tile has work left for mp_round_replies
+    SMR_G uint8_t *r2_need;         // [R][ceil(G/64)]: a lane of this row's tile left messages to mp_round_deliver_rest (round 5) ...
+    SMR_G uint32_t *r2_res;         // [R][G] ... and where it stopped: 1 | sender << 4 | entry << 8 (0: nothing left)
     // straggler list of the tick (mp_mark_stragglers): groups in a leader change are taken out of the
     // bulk launches and run one per wavefront on a side stream
     SMR_G uint8_t *slow;            // [G] 1 = on the list this tick

@@ -3,6 +3,8 @@ fiber, cross-lane operations meeting per wavefront / block -- against the CPU or
 C-ABI and Python mirror.  This reruns scenarios of tests/test_*_gpu.py (at smaller shapes) where no GPU
 is at hand: it checks the kernels' logic, not their behaviour on the device (the gpu-marked tests do
 that)."""
+import os
+
 import pytest
 
 
@@ -114,6 +116,13 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run("cpu", oracle, G=100, R=5, S=2, W=64, n_ticks=30, drop_p=0.15, timeout_frac=0.0, hb_every=4, preset=True,
                commit_extra=1)
         eng, _ = t._run("cpu", oracle, G=64, R=5, S=3, W=16, n_ticks=40, drop_p=0.0, timeout_frac=0.0, hb_every=8, preset=True)
+        # round 5: R2's bulk launch as fast path + rest (SMR_MP_SPLIT_R2; off by default), a short ttl so that the rest launch has work
+        os.environ["SMR_MP_SPLIT_R2"] = "1"
+        try:
+            t._run("cpu", oracle, G=130, R=5, S=2, W=64, n_ticks=32, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=8, straggler_ticks=1)
+            t._run("cpu", oracle, G=96, R=3, S=2, W=32, n_ticks=30, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5, straggler_ticks=1)
+        finally:
+            del os.environ["SMR_MP_SPLIT_R2"]
         # a window that overflows while the rest of R3 rides in the next R1 launch (quiet stretch, batches of 8)
         e2, _ = t._run("cpu", oracle, G=70, R=5, S=4, W=16, n_ticks=72, drop_p=0.05, timeout_frac=0.0, hb_every=12, preset=True, fused=8,
                        straggler_ticks=4, every=8, no_array_when_quiet=True)

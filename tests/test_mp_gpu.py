@@ -300,6 +300,17 @@ def test_batched_ticks_with_the_straggler_list(cuda, oracle, fused, sticks):
          straggler_ticks=sticks)
 
 
+def test_batched_ticks_with_r2_split_into_fast_path_and_rest(cuda, oracle, monkeypatch):
+    """SMR_MP_SPLIT_R2 (round 5; off by default: it did not pay, profiles/r8i): beside the side stream R2's bulk launch is the fast
+    path alone (mp_round_deliver: 79 VGPRs, no scratch) + mp_round_deliver_rest for the lanes it could not finish.  Leader changes
+    all over the run with a short ttl, so that groups come back to the bulk kernels mid-change and the rest launch has work."""
+    monkeypatch.setenv("SMR_MP_SPLIT_R2", "1")
+    _run(cuda, oracle, G=512, R=5, S=2, W=64, n_ticks=48, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=8, straggler_ticks=1)
+    _run(cuda, oracle, G=300, R=5, S=3, W=64, n_ticks=40, drop_p=0.05, timeout_frac=0.5, hb_every=4, preset=True, fused=5, straggler_ticks=2)
+    _run(cuda, oracle, G=257, R=3, S=2, W=32, n_ticks=40, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=16, straggler_ticks=1)
+    _run_bench_shape(cuda, oracle, G=1024, frac=0.25, span=10, n_ticks=30, fused=8, straggler_ticks=1)
+
+
 def test_batched_ticks_with_the_straggler_list_other_shapes(cuda, oracle):
     _run(cuda, oracle, G=257, R=3, S=2, W=32, n_ticks=40, drop_p=0.2, timeout_frac=0.5, hb_every=2, preset=True, fused=5, straggler_ticks=4)
     _run(cuda, oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True, fused=6, straggler_ticks=8)
