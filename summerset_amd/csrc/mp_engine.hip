@@ -135,6 +135,40 @@ __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__re
     }
 }
 
+// handle_req_batch x n_req of a prepared leader in its steady state as ONE step of a wavefront in uniform mode: lane k appends
+// batch k -- r1_body's store-only fast path turned by ninety degrees (same preconditions, same words stored).  For the side
+// stream's batch kernel (round 5), where a listed group's lane has the wavefront to itself and every round of loads a lane
+// makes is a round trip nobody hides.  false: not that state (or more batches than lanes): the caller takes the generic loop.
+__device__ __forceinline__ bool r1_coop_append(Lane &J, int par, const uint32_t *__restrict__ req_val, uint32_t n_req) {
+    const MpParams &P = J.P;
+    const uint32_t g = J.g, r = J.me;
+    if (!(J.is_leader() && J.bpd != 0 && J.bpd == J.bms && P.thresh > 1 && J.nlb >= J.len && J.abar == J.len && n_req <= 64u &&
+          (J.len - J.start) + n_req - 1 + P.win_reserve < P.W))
+        return false;
+    J.ob_load(par);
+    const uint32_t c0 = par == 0 ? J.obn0 : J.obn1;
+    if (c0 + n_req > P.cap) return false;
+    const RepView &v = J.v;
+    const uint64_t bal = J.bpd;
+    const uint32_t base = J.len, k = J.cl;
+    const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (r + M_ACKS_SH));
+    if (k < n_req) {
+        const uint32_t tok = req_val[(size_t)k * P.G + g], slot = base + k;
+        const size_t i = tix(P.W, slot & P.Wmask, g), o = tix(P.cap, c0 + k, g);
+        v.s_val()[i] = tok; v.s_meta()[i] = m0 | (tok ? M_NONEMPTY : 0u);
+        if (c0 != 0) { v.ob_slot(par)[o] = (OB_ACCEPT << OB_KIND_SH) | (slot & OB_SLOT_MASK); v.ob_bal(par)[o] = bal; }
+        v.ob_val(par)[o] = tok;
+    }
+    if (J.brun == 0xFFFFFFFFu || J.brun > base) J.brun = base;
+    J.len = base + n_req; J.abar = J.len; J.nlb = J.len;
+    if (par == 0) J.obn0 = c0 + n_req; else J.obn1 = c0 + n_req;
+    if (J.wr) {
+        v.ob_reg(par)[g] = c0 == 0 ? base + 1 : 0u;
+        if (c0 == 0) v.ob_rbal(par)[g] = bal;
+    }
+    return true;
+}
+
 #ifndef R1_PF
 #define R1_PF 32u     // client batches per group and tick whose tokens R1 prefetches
 #endif
@@ -142,12 +176,15 @@ __device__ __forceinline__ void r1_generic_batches(Lane &L, const uint32_t *__re
 __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_t *__restrict__ timeout_rep,
                                         const uint8_t *__restrict__ timeout_src, const uint8_t *__restrict__ req_target,
                                         const uint32_t *__restrict__ req_cnt, const uint32_t *__restrict__ req_val,
-                                        uint32_t S, const uint32_t g, bool active, const uint32_t r) {
+                                        uint32_t S, const uint32_t g, bool active, const uint32_t r, const bool force_coop = false) {
     Lane L(P, r, g < P.G ? g : 0, par);
     const bool has_to = active && timeout_rep && timeout_rep[g] == r;
     uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
     if (n_req > S) n_req = S;
     active = !has_to && n_req > 0;
+    // force_coop (the side stream's batch kernel): the appends too are a job of the whole wavefront, one lane per batch
+    const bool app_job = force_coop && active;
+    if (app_job) active = false;
     if (active) {
         // One round of loads for everything the fast path reads: the client batches' tokens (up to R1_PF of them, in
         // registers), the replica's scalars, the outbox count.  (They used to go out as seven dependent rounds -- scalars,
@@ -232,6 +269,15 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
         r1_generic_batches(J, req_val, 0, nj);
         J.store();
         JSTAMP(11);
+        flush_job(J);
+    }
+    SMR_FOR_EACH_JOB(app_job, src) {
+        const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src), rj = __shfl(r, src);
+        Lane J(P, rj, gj, par);
+        J.set_uniform();
+        J.load();
+        if (!r1_coop_append(J, par, req_val, nj)) r1_generic_batches(J, req_val, 0, nj);
+        J.store();
         flush_job(J);
     }
     flush_counters(L, active);
@@ -455,7 +501,7 @@ __device__ __forceinline__ void r2_generic(Lane &L, uint32_t first_sender, uint3
 // stream costs R2 -- an EMPTY launch (mp_round_replies with nothing flagged) is 30 % slower beside it too (4.9-5.5 us against
 // 3.7-4.0, profiles/r8c) -- so the split stays off (SMR_MP_SPLIT_R2 in the environment turns it on; the tests run both).
 template <int MODE>
-__device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32_t g, bool active, const uint32_t r) {
+__device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32_t g, bool active, const uint32_t r, const bool force_coop = false) {
     Lane L(P, r, g < P.G ? g : 0, par);
     bool job = false;
     uint32_t job_sender = 0, job_j = 0;
@@ -482,7 +528,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
         // fused (fresh ReplicaBookkeeping, voted = (ballot, reqs)), the WAL completion
         // answers with the ballot, accept_bar + 1.  The first message that does not
         // fit hands the rest of the outbox to the generic handlers.
-        if (n_senders == 1) {
+        if (n_senders == 1 && !force_coop) {                     // (force_coop: every outbox is a job of the whole wavefront)
             L.load(); loaded = true;
             const uint32_t s = the_sender;                       // differs from lane to lane: addressed like my own arrays
             if (L.leader == s && L.abar == L.len) {
@@ -549,7 +595,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
             }
         }
         // whatever is left goes to the wave as a cooperative job
-        if (n_senders > 1) { job = true; job_sender = first; job_j = 0; }
+        if (n_senders > 1 || (force_coop && n_senders == 1)) { job = true; job_sender = first; job_j = 0; }
         else if (n_senders == 1 && fast_done < the_cnt) { job = true; job_sender = the_sender; job_j = fast_done; }
         if (loaded) L.store();
         if (MODE == 1 && job) {                                  // ... of the launch behind this one
@@ -1118,7 +1164,7 @@ __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParam
 }
 
 __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32_t *__restrict__ ackctl, int publish_hb,
-                                        const uint32_t g, bool active, const uint32_t d) {
+                                        const uint32_t g, bool active, const uint32_t d, const bool force_coop = false) {
     Lane L(P, d, g < P.G ? g : 0, par);
     bool loaded = false, job = false;
     if (active) {
@@ -1131,7 +1177,7 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
         // (a lane mp_quorum_tally closed shows up here with an empty outbox)
         // a leader change in flight (PrepareReplies for me, or the long outbox of the
         // re-Accept round) is a cooperative job for the whole wave
-        job = has_pr || cnt > 64;
+        job = has_pr || cnt > 64 || (force_coop && (cnt != 0 || publish_hb));
         if (!job) {
             if (cnt) {
                 L.load(); loaded = true;
@@ -1337,6 +1383,15 @@ __global__ __launch_bounds__(512, STRAG_MINW) void mp_straggler_tick(const MpPar
 #ifndef STRAG_BATCH_K
 #define STRAG_BATCH_K 6
 #endif
+// Round 5: a listed group's lane has its wavefront to itself (one listed group per block while the list is shorter than the grid),
+// and in a quiet tick of its listing it ran the bulk kernels' per-lane fast paths -- three or four dependent rounds of loads per
+// round, nothing to hide them: ~58 us per tick, 8 ticks per launch, which made the side launch as long as the bulk's whole batch
+// (575 of 640 us, profiles/r8c_headline_timeline.txt) and the bulk kernels run beside it all the time.  With STRAG_COOP every
+// round of a listed (group, replica) is a wave-cooperative job -- one lane per client batch (r1_coop_append), per message
+// (r2_generic's append run), per ack-matrix row (r3_accept_replies' uniform mode) -- the paths a leader change takes anyway.
+#ifndef STRAG_COOP
+#define STRAG_COOP true
+#endif
 #ifndef STRAG_BATCH_BLOCKS
 #define STRAG_BATCH_BLOCKS 192
 #endif
@@ -1348,20 +1403,26 @@ __global__ __launch_bounds__(512, STRAG_BATCH_MINW) void mp_straggler_batch(cons
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t n = P.slow_n[lpar];
     if (n > P.slow_cap) n = P.slow_cap;
+#ifdef STRAG_PACK                                                 // (experiments: STRAG_PACK listed groups side by side in a block from the first one on)
+    for (uint32_t idx0 = blockIdx.x * STRAG_PACK; idx0 < n; idx0 += gridDim.x * STRAG_PACK) {
+        const uint32_t idx = idx0 + lane;
+        const bool mine = w < P.R && lane < STRAG_PACK && idx < n;
+#else
     for (uint32_t idx0 = blockIdx.x; idx0 < n; idx0 += gridDim.x * STRAG_BATCH_K) {  // uniform per block
         const uint32_t idx = idx0 + lane * gridDim.x;
         const bool mine = w < P.R && lane < STRAG_BATCH_K && idx < n;
+#endif
         const uint32_t g = mine ? P.slow_list[idx] : P.G;
         const uint32_t r = w < P.R ? w : 0;
         for (uint32_t t = 0; t < B.n; t++) {
             const MpTickIn &in = B.t[t];
             const int par = B.par0 ^ (int)(t & 1u);
             if (in.timeout_rep || in.req_target)
-                r1_body(P, par, in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, mine && !P.overflow[g], r);
+                r1_body(P, par, in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, mine && !P.overflow[g], r, STRAG_COOP);
             __syncthreads();
-            r2_body<0>(P, par, g, mine && !P.overflow[g], r);
+            r2_body<0>(P, par, g, mine && !P.overflow[g], r, STRAG_COOP);
             __syncthreads();
-            r3_body(P, par, in.ackctl, in.heartbeat, g, mine && !P.overflow[g], r);
+            r3_body(P, par, in.ackctl, in.heartbeat, g, mine && !P.overflow[g], r, STRAG_COOP);
             __syncthreads();
             if (in.heartbeat) {
                 r4_body(P, par, g, mine && !P.overflow[g], r);
