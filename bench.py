@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -705,17 +705,27 @@ def rspaxos_leg(torch, dev, ticks=48, warmup=8):
     return line
 
 
-def _payload_leg_traffic():
-    """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or None.  (r7g was
-    taken with one follow per replica -- five plan and five byte launches per tick; follow_many issues the followers' four as one
-    launch each over the same cells and bytes, so the per-tick sum is the same.)"""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r7g_pmc_traffic_payload_leg.json")) as f:
-            k = json.load(f)["kernels"]
-        return (k["smr::ps_put_kernel<3>"]["hbm_bytes_per_launch"] + 5 * k["smr::ps_plan_kernel"]["hbm_bytes_per_launch"]
-                + 5 * k["smr::ps_bytes_kernel"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+def _payload_leg_traffic(name="rspaxos_payload"):
+    """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or (None, None): the
+    sum over every ps_* / craft_* kernel of (bytes per launch x launches per tick), launches per tick = the kernel's launches in
+    the profiled run / the run's ticks (recorded in the file by tools/final_record.sh)."""
+    for f in ("r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
+        if not f:
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", f)) as fh:
+                d = json.load(fh)
+            k = d["kernels"]
+            if f.startswith("r7g"):                                  # (round 4's file: one follow per replica, five plan + five byte launches)
+                return (k["smr::ps_put_kernel<3>"]["hbm_bytes_per_launch"] + 5 * k["smr::ps_plan_kernel"]["hbm_bytes_per_launch"]
+                        + 5 * k["smr::ps_bytes_kernel"]["hbm_bytes_per_launch"]), "profiles/" + f
+            put = next(v for n, v in k.items() if "ps_put_kernel" in n)
+            ticks = put["launches"]                                  # one put per tick
+            tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if "::ps_" in n or "::craft_" in n)
+            return tot / ticks, "profiles/" + f
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
+    return None, None
 
 
 def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
@@ -773,9 +783,9 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": moved,
                          "survey_8d_bytes_per_launch": G * (5 * sl + 85),
                          "frac_on_survey_8d_bytes": G * (5 * sl + 85) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,   # the WHOLE tick on SURVEY 8(d)'s bytes
-                         "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic(),
-                         "traffic_source": "profiles/r7g_pmc_traffic_payload_leg.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; "
-                                           "per tick = one ps_put_kernel<3> + five ps_plan_kernel + five ps_bytes_kernel launches; taken before follow_many merged the followers' four)",
+                         "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic("rspaxos_payload")[0],
+                         "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; per tick = every ps_* launch of a tick)"
+                                           % _payload_leg_traffic("rspaxos_payload")[1],
                          "note": "per tick (tick with the stores minus the engines' tick alone); bytes the path has to move: L read + 5 shard_len "
                                  "written by put, one shard read + written for the leader's voted copy, (1 + 1) shards read + written by "
                                  "each of 4 followers (reqs, then voted)"},
@@ -842,7 +852,8 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
             "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 11, "bytes": 6},
             "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3> + craft_tokens / ps_plan / ps_bytes (the leader's, and the followers' _many)",
                          "achieved": moved / (us_bytes * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "alg_bytes_per_launch": moved, "avg_launch_us": us_bytes, "traffic": None,
+                         "alg_bytes_per_launch": moved, "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic("craft_payload")[0] if G == 16384 else None,
+                         "traffic_source": _payload_leg_traffic("craft_payload")[1],
                          "survey_8d_bytes_per_launch": G * (5 * sl + 85), "frac_on_survey_8d_bytes": G * (5 * sl + 85) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "note": "per tick (tick with the stores minus the engines' tick alone); bytes the path has to move: L read + 5 shard_len written "
                                  "by put, one shard read + written by each of 4 followers"},
@@ -1791,7 +1802,7 @@ def main():
         elif not args.fused:
             tpb = float(pmc.get("ticks_per_batch", 8))           # the list's launches: one per batch
             per = {"smr::mp_round_heartbeat": H, "smr::mp_straggler_batch": tpb, "smr::mp_mark_batch": tpb}
-            names = ("smr::mp_round_local", "smr::mp_round_deliver", "smr::mp_quorum_tally<5>", "smr::mp_round_replies",
+            names = ("smr::mp_round_local", "smr::mp_round_deliver_all", "smr::mp_round_deliver", "smr::mp_round_deliver_rest", "smr::mp_quorum_tally<5>", "smr::mp_round_replies",
                      "smr::mp_round_heartbeat") + (("smr::mp_straggler_batch", "smr::mp_mark_batch") if args.batch else
                                                    ("smr::mp_straggler_tick", "smr::mp_mark_stragglers"))
             pmc_tick = sum(k[n]["hbm_bytes_per_launch"] / per.get(n, 1) for n in names if n in k)

@@ -1,36 +1,45 @@
 #!/bin/bash
-# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m):
+# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m):
+#   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra and over the two payload legs
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
-#   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra
-TAG=${1:-r6m}
+TAG=${1:-r8m}
 mkdir -p gpurun_out
 R=$PWD
-# 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic.json for every `traffic` field of its line
+# 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic*.json for every `traffic` field of its line
 ( cd /tmp && export TMPDIR=/tmp
   timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1
-  timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1 )
-python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write "tools/pmc_probe.py --extra at HEAD: 16 ticks of the bench shape on the default workload (65536 groups x 5, S=32, H=4, 10% loss, 1% leader changes) as bench.py runs them (summerset_amd/workloads.py: two smr_mp_run_ticks batches of 8, straggler list on, ttl 4), 32 more through the fused tick kernel + 3 RS(3,2) encodes of 65536 x 4099 B + the Raft (incl. batches of 16 ticks) / EPaxos / wire-ingest legs + the reply-ingest leg + the one-launch EPaxos cluster tick (both orders, messages through LDS, KV words in the hc entries) + the RSPaxos-engine leg (shards written once)" > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
+  timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1
+  for leg in rspaxos_payload craft_payload; do
+    timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_$leg -- python $R/bench.py --leg $leg > /dev/null 2>&1
+    timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_$leg -- python $R/bench.py --leg $leg > /dev/null 2>&1
+  done )
+python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write "tools/pmc_probe.py --extra at HEAD: 16 ticks of the bench shape on the default workload (65536 groups x 5, S=32, H=4, 10% loss, 1% leader changes) as bench.py runs them (summerset_amd/workloads.py: two smr_mp_run_ticks batches of 8, straggler list on, ttl 4, the side kernel's rounds cooperative), 32 more through the fused tick kernel + 3 RS(3,2) encodes of 65536 x 4099 B + the Raft (incl. batches of 16 ticks) / EPaxos / wire-ingest legs + the reply-ingest leg + the one-launch EPaxos cluster tick (both orders, one per-key table per cluster) + the RSPaxos-engine leg (shards written once)" > gpurun_out/${TAG}_pmc_traffic.json 2> gpurun_out/${TAG}_pmc_traffic.err
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+for leg in rspaxos_payload craft_payload; do
+  python tools/pmc_traffic.py gpurun_out/${TAG}_pmc_fetch_$leg gpurun_out/${TAG}_pmc_write_$leg "bench.py --leg $leg at HEAD under rocprofv3 --pmc (16384 groups x L = 4113): every launch of the leg's run" > gpurun_out/${TAG}_pmc_traffic_${leg}_leg.json 2>> gpurun_out/${TAG}_pmc_traffic.err
+  cp gpurun_out/${TAG}_pmc_traffic_${leg}_leg.json profiles/${TAG}_pmc_traffic_${leg}_leg.json
+done
 # 2. the suite, the bench lines
 timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -40 > gpurun_out/${TAG}_gputests.log
 tail -3 gpurun_out/${TAG}_gputests.log
-timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.json; echo
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_command.json 2>> gpurun_out/${TAG}_bench.err
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cp bench_detail.json gpurun_out/${TAG}_bench_detail.json; tail -c 300 gpurun_out/${TAG}_bench.json; echo
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_command.json 2>> gpurun_out/${TAG}_bench.err; cp bench_detail.json gpurun_out/${TAG}_bench_driver_command_detail.json
 timeout 300 python bench.py --timeouts 0 --no-cpu --no-rs --no-extra --no-l2 > gpurun_out/${TAG}_bench_steady.json 2>> gpurun_out/${TAG}_bench.err
 # 3. per-kernel times of the driver's exact command
 ( cd /tmp && export TMPDIR=/tmp
   timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /dev/null )
 python tools/rocpd_summary.py gpurun_out/${TAG}_prof_bench --only mp_straggler_batch > gpurun_out/${TAG}_kernel_stats_default_bench.txt 2>&1
 python tools/rocpd_summary.py gpurun_out/${TAG}_prof_bench > gpurun_out/${TAG}_kernel_stats_default_bench_all_processes.txt 2>&1
-rm -rf gpurun_out/${TAG}_prof_bench gpurun_out/${TAG}_pmc_fetch gpurun_out/${TAG}_pmc_write
+rm -rf gpurun_out/${TAG}_prof_bench gpurun_out/${TAG}_pmc_fetch* gpurun_out/${TAG}_pmc_write*
 grep -v "at::native" gpurun_out/${TAG}_kernel_stats_default_bench.txt | head -12 | cut -c1-150
 python - <<P
 import json
 for f in ("bench", "bench_driver_command", "bench_steady", "bench_under_rocprof"):
     try:
-        d = json.loads(open("gpurun_out/${TAG}_%s.json" % f).read().strip().splitlines()[-1])
-        print(f, "value %.4g" % d["value"], "ms/step %.4f" % d["ms_per_step"], "tally us %.1f frac %.3f" % (d["roofline"]["avg_launch_us"], d["roofline"]["frac"]),
+        t = open("gpurun_out/${TAG}_%s.json" % f).read().strip().splitlines()[-1]
+        d = json.loads(t)
+        print(f, "line %d bytes" % len(t), "value %.4g" % d["value"], "ms/step %.4f" % d["ms_per_step"], "tally us %.1f frac %.3f" % (d["roofline"]["avg_launch_us"], d["roofline"]["frac"]),
               "whole_tick frac_pmc", d["roofline"]["whole_tick"].get("frac_pmc"), "legs_failed", d.get("legs_failed"))
     except Exception as e:
         print(f, "unreadable:", e)
