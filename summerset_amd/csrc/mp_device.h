@@ -12,6 +12,13 @@
 
 #include "mp_types.h"
 
+// phase stamps inside a handler (experiments only: a -DSMR_JOB_STAMPS build, tools/dbg_stamps.py)
+#ifdef SMR_JOB_STAMPS
+#define LSTAMP(k) do { if (__lane_id() == 0) P.dbg[(k)] = wall_clock64(); } while (0)
+#else
+#define LSTAMP(k) do { } while (0)
+#endif
+
 namespace smr {
 
 __device__ __forceinline__ uint32_t m_st(uint32_t m) { return m & M_STATUS; }
@@ -785,10 +792,14 @@ struct Lane {
     __device__ __forceinline__ void msg_prepare(uint32_t peer, uint32_t trig, uint64_t ballot) {
         if (trig < start) return;                               // :18-20
         if (ballot < bms) return;                               // :29
+        LSTAMP(40);
         BAL_TOUCH();                                            // (reads slot ballots below)
+        LSTAMP(41);
         check_leader(peer, ballot);
+        LSTAMP(42);
         if (!pad_to(trig)) return;                              // :37-39
         const uint32_t last = last_status(start, len, SMR_ST_NULL, false, start);   // :43-52 (unwrap_or(0))
+        LSTAMP(43);
         const uint32_t endp = last > trig ? last : trig;
         const uint32_t n = endp - trig + 1;
         const bool follower = !is_leader();
@@ -811,6 +822,7 @@ struct Lane {
                 v.pr_vbal()[o] = vb; v.pr_vval()[o] = vv;
             }
         }
+        LSTAMP(44);
         if (follower) {
             if (wr) v.pr_dest()[g] = (uint8_t)peer; if (wr) v.pr_trig()[g] = trig; if (wr) v.pr_endp()[g] = endp;
             if (wr) v.pr_bal()[g] = ballot; if (wr) v.pr_abar()[g] = abar;

@@ -59,8 +59,13 @@ __device__ __forceinline__ void flush_job(const Lane &J) {
 // build (tools/dbg_stamps.py), nothing in the shipped kernels
 #ifdef SMR_JOB_STAMPS
 #define JSTAMP(k) do { if (__lane_id() == 0) P.dbg[(k)] = wall_clock64(); } while (0)
+/* the longest job of a kind so far (dbg[48 + kind]) and how many there were (dbg[52 + kind]) */
+#define JBEGIN() const unsigned long long _jt0 = wall_clock64()
+#define JEND(kind) do { if (__lane_id() == 0) { atomicMax(&P.dbg[48 + (kind)], wall_clock64() - _jt0); atomicAdd(&P.dbg[52 + (kind)], 1ull); atomicAdd(&P.dbg[56 + (kind)], wall_clock64() - _jt0); } } while (0)
 #else
 #define JSTAMP(k) do { } while (0)
+#define JBEGIN() do { } while (0)
+#define JEND(kind) do { } while (0)
 #endif
 #define SMR_FOR_EACH_JOB(pending, src)                                            \
     for (unsigned long long _jm = __ballot(pending); _jm; _jm &= _jm - 1)        \
@@ -261,6 +266,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
         const uint32_t gj = __shfl(g, src), nj = __shfl(n_req, src), rj = __shfl(r, src);   // (lanes may stand for different replicas)
         Lane J(P, rj, gj, par);
         J.set_uniform();
+        JBEGIN();
         JSTAMP(8);
         J.load();
         JSTAMP(9);
@@ -269,6 +275,7 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
         r1_generic_batches(J, req_val, 0, nj);
         J.store();
         JSTAMP(11);
+        JEND(0);
         flush_job(J);
     }
     SMR_FOR_EACH_JOB(app_job, src) {
@@ -609,6 +616,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
         const uint32_t gj = __shfl(g, src), sj = __shfl(job_sender, src), jj = __shfl(job_j, src), rj = __shfl(r, src);
         Lane J(P, rj, gj, par);
         J.set_uniform();
+        JBEGIN();
         JSTAMP(16);
         J.load();
         JSTAMP(17);
@@ -616,6 +624,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
         JSTAMP(18);
         J.store();
         JSTAMP(19);
+        JEND(1);
         flush_job(J);
     }
     flush_counters(L, active && loaded);
@@ -1191,6 +1200,7 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
         const uint32_t gj = __shfl(g, src), dj = __shfl(d, src);
         Lane J(P, dj, gj, par);
         J.set_uniform();
+        JBEGIN();
         JSTAMP(24);
         J.load();
         JSTAMP(25);
@@ -1202,6 +1212,7 @@ __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32
         if (publish_hb) r3_publish_hb(J);
         J.store();
         JSTAMP(28);
+        JEND(2);
         flush_job(J);
     }
     flush_counters(L, active && loaded);
