@@ -800,35 +800,20 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
     `handle_msg_append_entries`; ONE `follow_many` for the four followers; the replies' match-index quorum at the leader.  The leg
     ends with the checks a host can make without the oracle: every follower holds exactly its own shard of every entry, the last
     row's parity verifies, nothing unsatisfied."""
-    from summerset_amd import CRaftLeaderGroup, CRaftPayloadStore, _lib
-    R, W, NB = 5, 32, 3
+    from summerset_amd import _lib, workloads
+    R, W, NB = workloads.CRAFT_PAYLOAD["R"], workloads.CRAFT_PAYLOAD["W"], 3
     time_us = time_us or _time_us                             # (tests/test_craft_payload.py runs the leg's loop on the emulator)
-    reps = [CRaftLeaderGroup(G, R, leader_id=r, window=W, term=1, fault_tolerance=1) for r in range(R)]
-    for r in range(1, R):
-        reps[r].preset(0, 0, 1)
-    stores = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)]
+    # cluster, stores and the tick itself from summerset_amd/workloads.py -- what
+    # tests/test_baseline_configs_gpu.py::test_craft_payload_store_16384_groups holds against the oracles
+    reps, stores, bufs = workloads.craft_payload_cluster(G, W, L, device=dev)
     srcs = [torch.randint(0, 256, (G, L), dtype=torch.uint8, device=dev) for _ in range(NB)]
-    ones = torch.ones(G, dtype=torch.int32, device=dev)
-    _, send = reps[0].assignment(dev)
-    em = [send[q].to(torch.uint8).reshape(1, G).contiguous() for q in range(R)]
     slots = [torch.full((G,), 1 + j, dtype=torch.int32, device=dev) for j in range(warmup + 2 * ticks + 8)]
-    rt, es, fl = (torch.zeros((R, G), dtype=dt, device=dev) for dt in (torch.int64, torch.int32, torch.uint8))
     n = [0]
 
     def one_tick(_i=0, bytes_=True):
         j = n[0]
         n[0] += 1
-        first = reps[0].handle_req_batch_emit(ones)
-        if bytes_:
-            stores[0].put(reps[0], slots[j], srcs[j % NB])
-            stores[0].follow(reps[0])
-        for q in range(1, R):
-            m = reps[0].gather_entries(first[q], 1)
-            r = reps[q].handle_msg_append_entries(**m, entry_mask=em[q])
-            rt[q].copy_(r["term"]); es[q].copy_(r["end_slot"]); fl[q].copy_(r["flags"])
-        if bytes_:
-            CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])
-        reps[0].handle_msg_append_entries_reply(rt, es, fl)
+        workloads.craft_payload_tick(reps, stores, bufs, slots[j], srcs[j % NB], bytes_=bytes_)
     for _ in range(warmup):
         one_tick()
     us = time_us(torch, one_tick, ticks, sleep_cycles=24_000_000)

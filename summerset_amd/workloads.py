@@ -125,6 +125,55 @@ def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, on
     return committed
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# CRaft with its shard bytes in the payload store, config 4's shape on the Raft fork (bench.py's `craft_payload` leg; held
+# against the CRaft oracles and the oracle's encoder at 16 384 groups x L = 4113 by
+# tests/test_baseline_configs_gpu.py::test_craft_payload_store_16384_groups)
+# ---------------------------------------------------------------------------------------------------------------------
+CRAFT_PAYLOAD = dict(G=16384, R=5, W=32, L=4113, ft=1)
+
+
+def craft_payload_cluster(G=CRAFT_PAYLOAD["G"], W=CRAFT_PAYLOAD["W"], L=CRAFT_PAYLOAD["L"], ft=CRAFT_PAYLOAD["ft"], device=None):
+    """replica 0 leads term 1, replicas 1 .. 4 follow; one CRaft payload store per replica; the tick's reusable device buffers"""
+    import torch
+    from .raft import CRaftLeaderGroup
+    from .rsp_payload import CRaftPayloadStore
+    R = CRAFT_PAYLOAD["R"]
+    reps = [CRaftLeaderGroup(G, R, leader_id=r, window=W, term=1, fault_tolerance=ft) for r in range(R)]
+    for r in range(1, R):
+        reps[r].preset(0, 0, 1)
+    stores = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)]
+    _, send = reps[0].assignment(device)                                  # balanced assignment: every follower is sent its own shard
+    bufs = dict(ones=torch.ones(G, dtype=torch.int32, device=device),
+                em=[send[q].to(torch.uint8).reshape(1, G).contiguous() for q in range(R)],
+                rt=torch.zeros((R, G), dtype=torch.int64, device=device), es=torch.zeros((R, G), dtype=torch.int32, device=device),
+                fl=torch.zeros((R, G), dtype=torch.uint8, device=device))
+    return reps, stores, bufs
+
+
+def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True):
+    """one tick: the leader appends one batch per group (slot [G] int32 = where: in the steady state log_len before the call = 1 +
+    the tick's number) and `put`s the serialized batches `src` (uint8 [G, L]); its follow; per follower the AppendEntries out of the
+    leader's log + `handle_msg_append_entries`; ONE follow_many for the four followers; the replies' match-index quorum at the
+    leader.  Returns the AppendEntries messages (for a checker)."""
+    from .rsp_payload import CRaftPayloadStore
+    R = len(reps)
+    first = reps[0].handle_req_batch_emit(bufs["ones"])
+    if bytes_:
+        stores[0].put(reps[0], slot, src, lens)
+        stores[0].follow(reps[0])
+    msgs = {}
+    for q in range(1, R):
+        m = reps[0].gather_entries(first[q], 1)
+        r = reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q])
+        bufs["rt"][q].copy_(r["term"]); bufs["es"][q].copy_(r["end_slot"]); bufs["fl"][q].copy_(r["flags"])
+        msgs[q] = m
+    if bytes_:
+        CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])
+    reps[0].handle_msg_append_entries_reply(bufs["rt"], bufs["es"], bufs["fl"])
+    return msgs
+
+
 # ---- serialized request batches behind a token (the payload stores' device tests and their emulator runs) --------------------
 def payload_batch_len(tok, L):
     """length of the batch a token stands for: a function of the token alone, in 1 .. L"""

@@ -348,6 +348,98 @@ def test_config3_payload_store_16384_groups(cuda, oracle):
     assert total > 16384 * 17
 
 
+def run_craft_payload(cuda, oracle, G, W, L, T, width=256, n_slices=4):
+    """the launches bench.py's `craft_payload` leg TIMES (summerset_amd/workloads.py: craft_payload_cluster / craft_payload_tick), T ticks
+    with ragged batch lengths.  Engines: every follower's replies and every replica's final log, bitmaps and counters against CRaft
+    oracles on 64-aligned slices fed the same AppendEntries.  Bytes: after the run EVERY cell of EVERY replica's store against its
+    engine's avail_shards_map, and the rows of the last ticks -- all five shards at the leader, one's own at every follower, all
+    groups -- against the oracle's encoder; the last entries read back (`get_data`) as the batches that were appended."""
+    import torch
+    from summerset_amd import workloads
+    R, d = 5, 3
+    reps, stores, bufs = workloads.craft_payload_cluster(G, W, L, device=cuda)
+    sl = _slices(G, width, n_slices, seed=G + L)
+    orcs = [[oracle.CRaftOracle(n, R, W, leader_id=r, term=1, fault_tolerance=1) for r in range(R)] for _, n in sl]
+    for oc in orcs:
+        for r in range(1, R):
+            oc[r].preset(0, 0, 1)
+    rng = np.random.default_rng(G * 3 + L)
+    u = lambda t, dt: t.cpu().numpy().view(dt)
+    keep = {}                                                              # tick -> (data, lens) of the last ticks
+    for j in range(T):
+        data = rng.integers(0, 256, (G, L), dtype=np.uint8)
+        lens = rng.integers(1, L + 1, G).astype(np.uint32)
+        lens[rng.random(G) < 0.3] = L
+        keep = {k: v for k, v in keep.items() if k >= j - 2}
+        keep[j] = (data, lens)
+        slot = torch.full((G,), 1 + j, dtype=torch.int32, device=cuda)
+        msgs = workloads.craft_payload_tick(reps, stores, bufs, slot, torch.from_numpy(data).to(cuda), torch.from_numpy(lens.view(np.int32)).to(cuda))
+        for (g0, n), oc in zip(sl, orcs):
+            oc[0].append(np.ones(n, np.uint32))
+            rt, es, fl = np.zeros((R, n), np.uint64), np.zeros((R, n), np.uint32), np.zeros((R, n), np.uint8)
+            for q in range(1, R):
+                m = msgs[q]
+                cut = lambda a, dt: np.ascontiguousarray(u(a, dt)[..., g0:g0 + n])
+                r = oc[q].handle_append_entries(cut(m["flags"], np.uint8), cut(m["leader"], np.uint8), cut(m["term"], np.uint64), cut(m["prev_slot"], np.uint32),
+                                                cut(m["prev_term"], np.uint64), cut(m["n_entries"], np.uint32), cut(m["entry_term"], np.uint64),
+                                                cut(m["leader_commit"], np.uint32), cut(m["last_snap"], np.uint32), entry_mask=cut(bufs["em"][q], np.uint8))
+                assert np.array_equal(r["term"], u(bufs["rt"][q], np.uint64)[g0:g0 + n]) and np.array_equal(r["end_slot"], u(bufs["es"][q], np.uint32)[g0:g0 + n]) \
+                    and np.array_equal(r["flags"], u(bufs["fl"][q], np.uint8)[g0:g0 + n]), (j, g0, q)
+                rt[q], es[q], fl[q] = r["term"], r["end_slot"], r["flags"]
+            oc[0].handle_replies(rt, es, fl, None, None, None)
+    dumps = [(e.dump(), e.dump_masks()) for e in reps]
+    for (g0, n), oc in zip(sl, orcs):
+        for r in range(R):
+            a, b = dumps[r][0], oc[r].dump()
+            for k in b:
+                assert np.array_equal(a[k][..., g0:g0 + n], b[k]), (g0, r, k)
+            am, bm = dumps[r][1], oc[r].dump_masks()
+            assert np.array_equal(am["mask"][:, g0:g0 + n], bm["mask"]), (g0, r, "masks")
+        assert oc[0].total_commits() > 0
+    # ---- the bytes: every cell of every store = its engine's bitmap ...
+    shard_len = lambda ln: -(-ln // d)
+    for r in range(R):
+        dmp, masks, sd = dumps[r][0], dumps[r][1]["mask"], stores[r].dump()
+        ln = dmp["log_len"].astype(np.int64)
+        assert (ln == T + 1).all() and (dmp["start_slot"] <= 1).all() if T + 1 <= W else True
+        for s in range(max(1, T + 1 - W), T + 1):
+            w = s % W
+            assert np.array_equal(sd["avail"][w], masks[w]), (r, s, "avail")
+            assert (masks[w] == (31 if r == 0 else 1 << r)).all(), (r, s, "balanced assignment: the leader every shard, a follower its own")
+        assert stores[r].counters()["unsatisfied"] == 0
+    # ... and the last ticks' rows byte for byte the oracle's codewords, all groups
+    total = 0
+    for j, (data, lens) in sorted(keep.items()):
+        s = 1 + j
+        rows = [stores[r].read_row(s) for r in range(R)]                  # [R][R shards][G][group_stride]
+        for ln_ in np.unique(lens):
+            gs = np.nonzero(lens == ln_)[0]
+            if len(gs) > 64:
+                gs = gs[:: max(1, len(gs) // 64)]                        # (the full-length batches: a sample of them; ragged lengths are all distinct groups)
+            sl_ = shard_len(int(ln_))
+            pad = np.zeros((len(gs), d * sl_), np.uint8)
+            pad[:, :ln_] = data[gs, :ln_]
+            cw = np.concatenate([pad.reshape(len(gs), d, sl_), np.stack([np.asarray(oracle.rs_encode(d, R - d, data[g, :ln_]), np.uint8).reshape(R - d, sl_) for g in gs])], axis=1)
+            for k in range(R):
+                assert np.array_equal(rows[0][k][gs, :sl_], cw[:, k]), (j, "leader", k, int(ln_))
+            for q in range(1, R):
+                assert np.array_equal(rows[q][q][gs, :sl_], cw[:, q]), (j, "follower", q, int(ln_))
+            total += len(gs)
+        out, got_len, ok = stores[0].get_data(torch.full((G,), s, dtype=torch.int32, device=cuda))
+        out, got_len, ok = out.cpu().numpy(), got_len.cpu().numpy(), ok.cpu().numpy()
+        assert ok.all() and np.array_equal(got_len.view(np.uint32), lens)
+        full = lens == L
+        assert np.array_equal(out[full], data[full])
+        g_ = int(np.nonzero(~full)[0][0])
+        assert np.array_equal(out[g_, :lens[g_]], data[g_, :lens[g_]])
+    return total
+
+
+def test_craft_payload_store_16384_groups(cuda, oracle):
+    """the launches bench.py's `craft_payload` leg TIMES, at its size (16 384 groups x L = 4113, window 32), 10 ticks"""
+    assert run_craft_payload(cuda, oracle, G=16384, W=32, L=4113, T=10) > 2000
+
+
 def test_config3_rspaxos_16384_groups_rs32_4k_values(cuda, oracle):
     import torch
     from summerset_amd import RSCodewordBatch

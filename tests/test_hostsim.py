@@ -301,6 +301,7 @@ def test_baseline_config_slice_tests_on_the_host(sim, oracle):
         t.run_rspaxos_slices("cpu", oracle, G=256, W=16, T=12, ft=1, loss=0.05, width=64, n_slices=3)
         assert t.run_rspaxos_one_launch("cpu", oracle, G=200, W=16, L=133, T=9, ft=1) > 0   # config 4's timed launches
         assert t.run_rspaxos_payload("cpu", oracle, G=130, W=8, L=133, T=11, ft=1) > 0      # ... with the bytes in the payload store
+        assert t.run_craft_payload("cpu", oracle, G=200, W=16, L=67, T=9, width=64, n_slices=3) > 0   # the `craft_payload` leg's launches
         t.run_epaxos_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=3)
         for pm in (False, True):                                # the one-launch cluster tick against oracle slices, both orders
             t.run_epaxos_cluster_slices("cpu", oracle, G=256, W=16, K=8, T=5, width=64, n_slices=2, phase_major=pm)
