@@ -42,21 +42,23 @@ class RaftLeaderGroup:
         """append n_new[g] entries of the current term to every group's log"""
         check(self._L.smr_raft_leader_append(self._h, _ptr(n_new), stream_ptr(stream)))
 
-    def handle_req_batch_emit(self, n_new, stream=None):
-        """handle_req_batch + [R, G] first slot of the entries sent to each peer (-1 = nothing)"""
+    def handle_req_batch_emit(self, n_new, stream=None, out=None):
+        """handle_req_batch + [R, G] first slot of the entries sent to each peer (-1 = nothing); `out`: an earlier result to refill"""
         import torch
-        first = torch.zeros((self.R, self.G), dtype=torch.int32, device=n_new.device)
+        first = out if out is not None else torch.zeros((self.R, self.G), dtype=torch.int32, device=n_new.device)
         check(self._L.smr_raft_leader_append_emit(self._h, _ptr(n_new), _ptr(first), stream_ptr(stream)))
         return first
 
-    def gather_entries(self, first, max_entries, stream=None):
-        """the AppendEntries for one peer out of my log: first[g] = first slot to send (row of handle_req_batch_emit)"""
+    def gather_entries(self, first, max_entries, stream=None, out=None):
+        """the AppendEntries for one peer out of my log: first[g] = first slot to send (row of handle_req_batch_emit); `out`: an
+        earlier message of the same `max_entries` to refill (the kernel writes every field of every group)"""
         import torch
         dev, G, K = first.device, self.G, int(max_entries)
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        m = dict(flags=z(G, torch.uint8), leader=z(G, torch.uint8), term=z(G, torch.int64), prev_slot=z(G, torch.int32),
-                 prev_term=z(G, torch.int64), n_entries=z(G, torch.int32), entry_term=z((K, G), torch.int64),
-                 leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
+        m = out if out is not None else dict(
+            flags=z(G, torch.uint8), leader=z(G, torch.uint8), term=z(G, torch.int64), prev_slot=z(G, torch.int32),
+            prev_term=z(G, torch.int64), n_entries=z(G, torch.int32), entry_term=z((K, G), torch.int64),
+            leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
         msg = RaftAppendEntries(_ptr(m["flags"]), _ptr(m["leader"]), _ptr(m["term"]), _ptr(m["prev_slot"]),
                                 _ptr(m["prev_term"]), _ptr(m["n_entries"]), _ptr(m["entry_term"]), K,
                                 _ptr(m["leader_commit"]), _ptr(m["last_snap"]))
@@ -104,15 +106,17 @@ class RaftLeaderGroup:
         check(self._L.smr_raft_replica_preset(self._h, role, leader, term, voted_for))
 
     def handle_msg_append_entries(self, flags, leader, term, prev_slot, prev_term, n_entries, entry_term,
-                                  leader_commit, last_snap, entry_mask=None, stream=None):
+                                  leader_commit, last_snap, entry_mask=None, stream=None, out=None):
         """returns the AppendEntriesReply tensors dict(flags, term, end_slot, conflict_term, conflict_slot); entry_mask
-        [K, G] uint8 (CRaft replicas only): avail_shards_map of every sent entry's codeword"""
+        [K, G] uint8 (CRaft replicas only): avail_shards_map of every sent entry's codeword; `out`: the reply tensors to fill (e.g.
+        rows of the leader's [R, G] reply arrays: the kernel writes every group's reply)"""
         import torch
         dev, G = flags.device, self.G
-        r = dict(flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev),
-                 end_slot=torch.zeros(G, dtype=torch.int32, device=dev),
-                 conflict_term=torch.zeros(G, dtype=torch.int64, device=dev),
-                 conflict_slot=torch.zeros(G, dtype=torch.int32, device=dev))
+        r = out if out is not None else dict(
+            flags=torch.zeros(G, dtype=torch.uint8, device=dev), term=torch.zeros(G, dtype=torch.int64, device=dev),
+            end_slot=torch.zeros(G, dtype=torch.int32, device=dev),
+            conflict_term=torch.zeros(G, dtype=torch.int64, device=dev),
+            conflict_slot=torch.zeros(G, dtype=torch.int32, device=dev))
         m = RaftAppendEntries(_ptr(flags), _ptr(leader), _ptr(term), _ptr(prev_slot), _ptr(prev_term), _ptr(n_entries),
                               _ptr(entry_term), int(entry_term.shape[0]), _ptr(leader_commit), _ptr(last_snap), _ptr(entry_mask))
         rr = RaftAppendReply(*[_ptr(r[k]) for k in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])

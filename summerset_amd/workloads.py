@@ -144,11 +144,12 @@ def craft_payload_cluster(G=CRAFT_PAYLOAD["G"], W=CRAFT_PAYLOAD["W"], L=CRAFT_PA
         reps[r].preset(0, 0, 1)
     stores = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)]
     _, send = reps[0].assignment(device)                                  # balanced assignment: every follower is sent its own shard
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
     bufs = dict(ones=torch.ones(G, dtype=torch.int32, device=device),
                 em=[send[q].to(torch.uint8).reshape(1, G).contiguous() for q in range(R)],
-                rt=torch.zeros((R, G), dtype=torch.int64, device=device), es=torch.zeros((R, G), dtype=torch.int32, device=device),
-                fl=torch.zeros((R, G), dtype=torch.uint8, device=device))
-    return reps, stores, bufs
+                rt=z((R, G), torch.int64), es=z((R, G), torch.int32), fl=z((R, G), torch.uint8), ct=z((R, G), torch.int64), cs=z((R, G), torch.int32),
+                first=z((R, G), torch.int32), msg=[None] * R)            # every message and reply lives in buffers of the loop's own:
+    return reps, stores, bufs                                            # a tick is its handlers' launches and nothing else
 
 
 def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True):
@@ -158,15 +159,16 @@ def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True):
     leader.  Returns the AppendEntries messages (for a checker)."""
     from .rsp_payload import CRaftPayloadStore
     R = len(reps)
-    first = reps[0].handle_req_batch_emit(bufs["ones"])
+    first = reps[0].handle_req_batch_emit(bufs["ones"], out=bufs["first"])
     if bytes_:
         stores[0].put(reps[0], slot, src, lens)
         stores[0].follow(reps[0])
     msgs = {}
     for q in range(1, R):
-        m = reps[0].gather_entries(first[q], 1)
-        r = reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q])
-        bufs["rt"][q].copy_(r["term"]); bufs["es"][q].copy_(r["end_slot"]); bufs["fl"][q].copy_(r["flags"])
+        m = bufs["msg"][q] = reps[0].gather_entries(first[q], 1, out=bufs["msg"][q])
+        reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q],          # the reply straight into the leader's [R, G] arrays
+                                          out=dict(flags=bufs["fl"][q], term=bufs["rt"][q], end_slot=bufs["es"][q], conflict_term=bufs["ct"][q],
+                                                   conflict_slot=bufs["cs"][q]))
         msgs[q] = m
     if bytes_:
         CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])
