@@ -285,8 +285,10 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
  * smr_mp_spread_tick again.  Runs and undoes nothing: the blocks hold a partly run tick, the host restores them (smr_mp_load_state
  * or new clusters) before it ticks again.  smr_mp_spread_tick does this itself when one of its steps fails. */
 int smr_mp_spread_abort_tick(smr_mp_spread *s);
-/* The blocks' rounds inside a segment run concurrently on streams of the object's own, forked behind the segment's unpack and
- * joined in front of its pack on `stream` (default on); 0 = one after the other on `stream`. */
+/* How the blocks' rounds inside a segment are launched: 2 (default since round 5) = ONE launch for all blocks of the rank
+ * (blockIdx.z = the block; ~12 host calls per segment less than 1); 1 = side by side on streams of the object's own, forked
+ * behind the segment's unpack and joined in front of its pack on `stream` (round 4); 0 = one after the other on `stream`.
+ * Same results either way. */
 int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on);
 
 /* ---- the exchange itself: RCCL behind the C-ABI -----------------------------------------------------------------------------

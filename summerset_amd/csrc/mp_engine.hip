@@ -1814,6 +1814,61 @@ __global__ __launch_bounds__(256) void mp_collect_acks_kernel(const MpParams *__
         }
     }
 }
+// ---- the rounds of SEVERAL clusters in one launch (round 5, layout L2): a rank holds a cluster per block of groups it takes part
+// in, and a round on block b has nothing to do with the round on block b'.  Round 4 ran them side by side on streams of the spread
+// object's own -- a fork event, a launch per block, a join event per block: ~12 host calls per segment where the launches are
+// ~10 us of device time each, so a rank's tick was its host's.  blockIdx.z = the cluster; a cluster with fewer groups leaves its
+// surplus blocks at once.  Only for clusters without a straggler list (the spread layout's).
+struct MpMulti {
+    const MpParams *p[MAXR];
+    int par[MAXR];
+    uint32_t hint[MAXR];
+    MpTickIn in[MAXR];
+};
+__global__ __launch_bounds__(256) void mp_round_local_multi(const MpMulti M) {
+    const MpParams &P = *M.p[blockIdx.z];
+    if (blockIdx.x * blockDim.x >= P.G || !((P.live >> blockIdx.y) & 1u)) return;
+    const MpTickIn &in = M.in[blockIdx.z];
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r1_body(P, M.par[blockIdx.z], in.timeout_rep, in.timeout_src, in.req_target, in.req_cnt, in.req_val, in.S, g, active, pick_replica(P, 0, g));
+}
+__global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver_multi(const MpMulti M) {
+    const MpParams &P = *M.p[blockIdx.z];
+    if (blockIdx.x * blockDim.x >= P.G || !((P.live >> blockIdx.y) & 1u)) return;
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r2_body<0>(P, M.par[blockIdx.z], g, active, pick_replica(P, 0, g));
+}
+template <int NR>
+__global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally_multi(const MpMulti M, int publish_hb) {
+    __shared__ uint8_t sh_fl[64 * 64];
+    __shared__ uint32_t sh_mk[64 * 64];
+    const MpParams &P = *M.p[blockIdx.z];
+    if (blockIdx.x * 64u >= P.G) return;                          // (block-uniform: nobody is left at a barrier)
+    quorum_tally_block<NR>(P, M.par[blockIdx.z], M.in[blockIdx.z].ackctl, publish_hb, sh_fl, sh_mk, M.hint[blockIdx.z]);
+}
+__global__ __launch_bounds__(256) void mp_round_replies_multi(const MpMulti M, int publish_hb) {
+    const MpParams &P = *M.p[blockIdx.z];
+    if (blockIdx.x * blockDim.x >= P.G || !((P.live >> blockIdx.y) & 1u)) return;
+    {
+        const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;
+        uint32_t any = 0;
+        for (uint32_t k = 0; k < tpb; k++) any |= (t0 + k < ntile) ? P.r3_need[(size_t)blockIdx.y * ntile + t0 + k] : 0u;
+        if (!any) return;
+    }
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r3_body(P, M.par[blockIdx.z], M.in[blockIdx.z].ackctl, publish_hb, g, active, pick_replica(P, 0, g));
+}
+__global__ __launch_bounds__(256) void mp_round_heartbeat_multi(const MpMulti M) {
+    const MpParams &P = *M.p[blockIdx.z];
+    if (blockIdx.x * blockDim.x >= P.G || !((P.live >> blockIdx.y) & 1u)) return;
+    uint32_t g;
+    const bool active = pick_group(P, 0, g);
+    r4_body(P, M.par[blockIdx.z], g, active, pick_replica(P, 0, g));
+}
+
 }  // namespace smr
 
 using namespace smr;
@@ -2675,6 +2730,7 @@ struct smr_mp_spread {
     std::vector<hipEvent_t> done;                // [n_blocks - 1]
     hipEvent_t fork = nullptr;
     bool concurrent = true;
+    bool multi = true;                           // round 5: the blocks' rounds as ONE launch (blockIdx.z = block) instead of side by side on streams
     int next_segment = 0, tick_heartbeat = 0;    // the segment the open tick expects next, and the `heartbeat` its segment 0 came with
     // the exchange in the library (smr_mp_spread_bind_comm): the three exchanges' buffers and per-peer byte counts
     smr_comm *comm = nullptr;
@@ -2746,6 +2802,46 @@ void smr_mp_spread_destroy(smr_mp_spread *s) {
 int smr_mp_spread_set_concurrent(smr_mp_spread *s, int on) {
     if (!s) return fail(SMR_ERR_ARG, "mp spread: null argument");
     s->concurrent = on != 0;
+    s->multi = on >= 2 || on < 0;                                 // 2 (the default since round 5): the blocks' rounds in ONE launch; 1: side by side
+    return SMR_OK;                                                // on streams of the object's own (round 4); 0: one after the other
+}
+
+// the blocks' round `which` (0 R1, 1 R2, 2 R3, 3 R4) as one launch (two for R3: the tally, then what it left); false: this
+// object's clusters cannot go together (a straggler list, a profile pass, more blocks than a launch takes): the per-block path
+static bool spread_multi_ok(const smr_mp_spread *s) {
+    if (!s->multi || s->cl.size() < 2 || s->cl.size() > (size_t)MAXR) return false;
+    for (const smr_mp_cluster *c : s->cl)
+        if (c->ttl || c->profile || c->rest_pending || c->cfg.population != s->cl[0]->cfg.population) return false;
+    return true;
+}
+static int spread_multi_round(smr_mp_spread *s, int which, const smr_mp_tick_in *in, int heartbeat, hipStream_t st) {
+    MpMulti M;
+    memset(&M, 0, sizeof(M));
+    uint32_t gmax = 0;
+    const size_t n = s->cl.size();
+    for (size_t b = 0; b < n; b++) {
+        const smr_mp_cluster *c = s->cl[b];
+        M.p[b] = c->dp; M.par[b] = c->par; M.hint[b] = c->lead_hint;
+        if (in) {
+            const smr_mp_tick_in &x = in[b];
+            M.in[b] = MpTickIn{x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.ackctl_dev, x.S, heartbeat};
+        }
+        if (c->cfg.n_groups > gmax) gmax = c->cfg.n_groups;
+    }
+    const uint32_t R = s->cl[0]->cfg.population;
+    const dim3 grid((gmax + MP_BLOCK - 1) / MP_BLOCK, R, (unsigned)n);
+    switch (which) {
+    case 0: hipLaunchKernelGGL(mp_round_local_multi, grid, dim3(MP_BLOCK), 0, st, M); break;
+    case 1: hipLaunchKernelGGL(mp_round_deliver_multi, grid, dim3(MP_BLOCK), 0, st, M); break;
+    case 2:
+        if (R <= 5) hipLaunchKernelGGL(mp_quorum_tally_multi<5>, dim3((gmax + 63) / 64, 1, (unsigned)n), dim3(256), 0, st, M, heartbeat);
+        else hipLaunchKernelGGL(mp_quorum_tally_multi<MAXR>, dim3((gmax + 63) / 64, 1, (unsigned)n), dim3(256), 0, st, M, heartbeat);
+        SMR_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(mp_round_replies_multi, grid, dim3(MP_BLOCK), 0, st, M, heartbeat);
+        break;
+    default: hipLaunchKernelGGL(mp_round_heartbeat_multi, grid, dim3(MP_BLOCK), 0, st, M); break;
+    }
+    SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
 
@@ -2768,17 +2864,20 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
     hipStream_t st = (hipStream_t)stream;
     switch (segment) {
     case 0:                                                  // R1 everywhere, then the outboxes into the send buffer
-        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) {
+        if (spread_multi_ok(s)) { if ((rc = spread_multi_round(s, 0, in, heartbeat, st)) != SMR_OK) return rc; }
+        else if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) {
                  return smr_mp_round_local(s->cl[b], in[b].timeout_rep_dev, in[b].timeout_src_dev, in[b].req_target_dev, in[b].req_cnt_dev,
                                            in[b].req_val_dev, in[b].S, sb); })) != SMR_OK) return rc;
         return smr_mp_image_plan_run(s->pack[0], 0, stream);
     case 1:                                                  // the peers' outboxes arrive; R2; replies into the send buffer
         if ((rc = smr_mp_image_plan_run(s->unpack[0], 1, stream)) != SMR_OK) return rc;
-        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_deliver(s->cl[b], sb); })) != SMR_OK) return rc;
+        if (spread_multi_ok(s)) { if ((rc = spread_multi_round(s, 1, nullptr, heartbeat, st)) != SMR_OK) return rc; }
+        else if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_deliver(s->cl[b], sb); })) != SMR_OK) return rc;
         return smr_mp_image_plan_run(s->pack[1], 0, stream);
     case 2:                                                  // the replies arrive; R3; a heartbeat tick publishes and packs, else the tick ends
         if ((rc = smr_mp_image_plan_run(s->unpack[1], 1, stream)) != SMR_OK) return rc;
-        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_replies(s->cl[b], in[b].ackctl_dev, heartbeat, sb); })) != SMR_OK)
+        if (spread_multi_ok(s)) { if ((rc = spread_multi_round(s, 2, in, heartbeat, st)) != SMR_OK) return rc; }
+        else if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_replies(s->cl[b], in[b].ackctl_dev, heartbeat, sb); })) != SMR_OK)
             return rc;
         if (heartbeat) return smr_mp_image_plan_run(s->pack[2], 0, stream);
         for (size_t b = 0; b < n; b++)
@@ -2786,7 +2885,8 @@ int smr_mp_spread_segment(smr_mp_spread *s, int segment, const smr_mp_tick_in *i
         return SMR_OK;
     default:                                                 // the heartbeats arrive; R4; the tick ends
         if ((rc = smr_mp_image_plan_run(s->unpack[2], 1, stream)) != SMR_OK) return rc;
-        if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_heartbeat(s->cl[b], sb); })) != SMR_OK) return rc;
+        if (spread_multi_ok(s)) { if ((rc = spread_multi_round(s, 3, nullptr, heartbeat, st)) != SMR_OK) return rc; }
+        else if ((rc = spread_each_block(s, st, [&](size_t b, void *sb) { return smr_mp_round_heartbeat(s->cl[b], sb); })) != SMR_OK) return rc;
         for (size_t b = 0; b < n; b++)
             if ((rc = smr_mp_end_tick(s->cl[b])) != SMR_OK) return rc;
         return SMR_OK;

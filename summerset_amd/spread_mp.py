@@ -276,20 +276,32 @@ class SpreadMultiPaxos:
 
 def _copy_between(peers, phase):
     """the all-to-all of a job whose ranks all live in this process: rank s's segment for d -> d's segment from s.  Runs
-    once per exchange, when the LAST rank arrives (the ranks are stepped one after the other, see in_process)."""
+    once per exchange, when the LAST rank arrives (the ranks are stepped one after the other, see in_process).  The segment
+    pairs of an exchange never change: their views are made once, and an exchange is ONE multi-tensor copy (round 5: twelve
+    `copy_` calls at ~10 us of host time each were a tenth of a virtual-rank tick)."""
     peers[0]._arrived[phase] = peers[0]._arrived.get(phase, 0) + 1
     if peers[0]._arrived[phase] < len(peers):
         return
     peers[0]._arrived[phase] = 0
-    for s_, ps in enumerate(peers):
-        p = ps._plans[phase]
-        so = 0
-        for d, n in enumerate(p["in_split"]):
-            q = peers[d]._plans[phase]
-            ro = sum(q["out_split"][:s_])
-            assert q["out_split"][s_] == n
-            q["rbuf"][ro:ro + n].copy_(p["sbuf"][so:so + n])
-            so += n
+    pairs = peers[0]._pairs.get(phase) if hasattr(peers[0], "_pairs") else None
+    if pairs is None:
+        dsts, srcs = [], []
+        for s_, ps in enumerate(peers):
+            p = ps._plans[phase]
+            so = 0
+            for d, n in enumerate(p["in_split"]):
+                q = peers[d]._plans[phase]
+                ro = sum(q["out_split"][:s_])
+                assert q["out_split"][s_] == n
+                if n:
+                    dsts.append(q["rbuf"][ro:ro + n]); srcs.append(p["sbuf"][so:so + n])
+                so += n
+        pairs = (dsts, srcs)
+        if not hasattr(peers[0], "_pairs"):
+            peers[0]._pairs = {}
+        peers[0]._pairs[phase] = pairs
+    if pairs[0]:
+        peers[0].torch._foreach_copy_(pairs[0], pairs[1])
 
 
 class in_process:

@@ -329,6 +329,8 @@ def test_spread_layout_images_on_the_host(sim):
         t.run_spread_vs_colocated("cpu", G=256, R=5, S=2, W=64, world=2, n_ticks=24, drop_p=0.1, timeout_frac=1.0)
         t.run_spread_vs_colocated("cpu", G=192, R=5, S=2, W=64, world=3, n_ticks=18, drop_p=0.1, timeout_frac=1.0)
         t.run_spread_vs_colocated("cpu", G=128, R=3, S=2, W=32, world=2, n_ticks=16, drop_p=0.2, timeout_frac=0.5, hb_every=2)
+        # (the runs above: the blocks' rounds in ONE launch, round 5's default; round 4's per-block launches stay selectable)
+        t.run_spread_vs_colocated("cpu", G=192, R=5, S=2, W=64, world=3, n_ticks=12, drop_p=0.1, timeout_frac=1.0, rounds=1)
 
 
 def test_heartbeater_kernels_on_the_host(sim, oracle):

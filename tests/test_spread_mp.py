@@ -11,8 +11,10 @@ def _to_dev(t, dev):
     return {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
 
 
-def run_spread_vs_colocated(dev, G, R, S, W, world, n_ticks, drop_p, timeout_frac, hb_every=3, ovf_cap=8192, make=None, compare_every=1):
-    """`make(world)` -> object with preset_leader / tick(inputs, heartbeat) and .ranks (default: spread_mp.in_process)"""
+def run_spread_vs_colocated(dev, G, R, S, W, world, n_ticks, drop_p, timeout_frac, hb_every=3, ovf_cap=8192, make=None, compare_every=1, rounds=None):
+    """`make(world)` -> object with preset_leader / tick(inputs, heartbeat) and .ranks (default: spread_mp.in_process).
+    rounds: smr_mp_spread_set_concurrent's argument -- 2 the blocks' rounds in one launch (the default), 1 side by side on streams
+    (round 4), 0 one after the other"""
     from oracle.oracle import MP_SCALARS, MP_SLOTS
     from summerset_amd import MultiPaxosCluster, shard, spread_mp, stream
     cap = W + 4
@@ -20,6 +22,10 @@ def run_spread_vs_colocated(dev, G, R, S, W, world, n_ticks, drop_p, timeout_fra
     ref.preset_leader(0)
     job = spread_mp.in_process(G, R, W, world, dev, S, ovf_cap=ovf_cap, outbox_cap=cap) if make is None else make(world)
     job.preset_leader(0)
+    if rounds is not None:
+        from summerset_amd._lib import check
+        for rk in job.ranks:
+            check(rk._L.smr_mp_spread_set_concurrent(rk._spread, int(rounds)))
     kw = dict(cap=cap, n_ticks=n_ticks, drop_p=drop_p, timeout_frac=timeout_frac, hb_every=hb_every)
     st = stream.MultiPaxosStream(G, R, S, **kw)
     bst = {b: stream.MultiPaxosStream(hi - lo, R, S, group_base=lo, **kw) for b, (lo, hi) in
@@ -51,6 +57,13 @@ def test_spread_job_is_the_colocated_one(cuda, world):
     # ack byte cells), step-up heartbeats -- all through the images' overflow lists
     job = run_spread_vs_colocated(cuda, G=64 * world * 2, R=5, S=2, W=64, world=world, n_ticks=30, drop_p=0.1, timeout_frac=1.0)
     assert all(rk.bytes_sent > 0 for rk in job.ranks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rounds", [1, 0])
+def test_spread_job_with_the_blocks_rounds_launched_one_by_one(cuda, rounds):
+    """round 5 launches the rounds of a rank's blocks as ONE kernel (blockIdx.z = block); round 4's ways stay selectable"""
+    run_spread_vs_colocated(cuda, G=64 * 3 * 2, R=5, S=2, W=64, world=3, n_ticks=24, drop_p=0.1, timeout_frac=1.0, rounds=rounds)
 
 
 @pytest.mark.gpu
