@@ -3,7 +3,7 @@
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra and over the two payload legs
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
-TAG=${1:-r8m}
+TAG=${1:-r8z}
 mkdir -p gpurun_out
 R=$PWD
 # 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic*.json for every `traffic` field of its line
