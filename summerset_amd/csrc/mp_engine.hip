@@ -1887,6 +1887,8 @@ struct smr_mp_cluster {
     bool forked = false, marked = false, side_on = false, side_fused = false;
     uint32_t side_live = 0;          // ticks the side stream stays on without a new HearTimeout array
     uint32_t quiet_ticks = 0;        // smr_mp_run_ticks: ticks in a row without a HearTimeout array (the side launch has nothing listed)
+    bool always_defer = false;       // SMR_MP_ALWAYS_DEFER_REST in the environment at smr_mp_create (A/B runs): the R3 rest rides in the next R1 launch
+                                     // beside a busy side stream too
     bool no_split_r2 = true;         // the split is OFF unless SMR_MP_SPLIT_R2 is in the environment at smr_mp_create: measured, it does not
                                      // pay (profiles/r8i: fast path alone 24.2 us + rest 4.9 us against 26.8 us for the one launch)
     bool split_r2 = false;           // smr_mp_run_ticks, the side stream busy: R2's bulk launch = fast path + rest (r2_body)
@@ -2085,6 +2087,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     }
     c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
     c->no_split_r2 = getenv("SMR_MP_SPLIT_R2") == nullptr;
+    c->always_defer = getenv("SMR_MP_ALWAYS_DEFER_REST") != nullptr;
     if (c->ttl) {
         e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -2332,7 +2335,7 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             // launch needs 171 VGPRs where R1 alone needs 158 -- two wavefronts per SIMD instead of three -- and beside the side
             // stream's blocks that costs R1 more than the launch saves: driver's command 0.0972 -> 0.0987 ms per tick, steady
             // 0.0568 -> 0.0542, profiles/r5p_rest_in_next_r1_ab.log)
-            c->defer_rest = k + 1 < b.n && quiet;
+            c->defer_rest = k + 1 < b.n && (quiet || c->always_defer);
             if (!rc) rc = smr_mp_round_replies(c, x.ackctl_dev, x.do_heartbeat ? 1 : 0, stream);
             c->defer_rest = false;
             if (!rc && x.do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
