@@ -885,6 +885,14 @@ int smr_rsp_exec_poll(smr_rsp_replica *e, uint32_t *group_host, uint32_t *slot_h
  * _counters: shards copied, shards rebuilt, shards the engine has that no source could give (0 in a correct run; counted by every
  * follow call while they stay missing -- after an absorb of a DIFFERENT token, which rscoding.rs:296-346 refuses, they always do),
  * rows whose token changed while they held shards.  n_shards = the population (<= 8), n_data_shards = the majority.
+ * A vote is the codeword the instance holds at that moment (`inst.voted = (ballot, reqs_cw.clone())`, messages.rs:373-380;
+ * request.rs:103-118), so a VOTED shard that equals the REQS row's shard -- same token, present there -- is NOT stored a second
+ * time: it is an ALIAS of the REQS row's bytes (counted as copied all the same) until the two part ways (reqs_cw takes another
+ * value in the Prepare phase, messages.rs:180-194), when follow first moves it into the VOTED row.  Every call above reads
+ * through the aliases (_extract, _emit_accepts, _read_row and a follow that names plane 1 of this store as a source); a host
+ * that reads plane 1 through _layout needs _voted_alias: u8 [W][G], bit k = shard k of that cell is read at the SAME offset of
+ * plane 0.  _put and an _ingest into plane 0 replace a REQS row: votes that lived in it go with it (the handler in front of
+ * either has re-initialised the instance's vote; the next follow re-derives the cell).
  * The calls on one store only enqueue work and must be issued on ONE stream at a time (their scratch list is the store's);
  * a source's rows must not be written by another stream meanwhile.  A message is consumed in the tick that produced it: the
  * sender's row must still hold the token the message named when the receiver's follow runs (or go through _extract / _ingest).
@@ -927,6 +935,7 @@ int smr_rsp_pstore_dump(smr_rsp_pstore *s, int plane, uint32_t *tok_host, uint8_
 int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t *bytes_host);
 int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,
                           uint64_t *group_stride);
+int smr_rsp_pstore_voted_alias(const smr_rsp_pstore *s, const uint8_t **alias_dev, uint8_t *alias_host);   /* either may be NULL */
 int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host);
 
 /* CRaft: the same store keyed by LOG INDEX -- the shard bytes of `LogEntry::reqs_cw` (/root/reference/src/protocols/craft/mod.rs:129-150)

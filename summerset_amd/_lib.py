@@ -330,6 +330,7 @@ SYMBOLS = [
     ("smr_rsp_pstore_dump", _i, [_vp, _i, _vp, _vp, _vp]),
     ("smr_rsp_pstore_read_row", _i, [_vp, _i, _u32, _vp]),
     ("smr_rsp_pstore_layout", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    ("smr_rsp_pstore_voted_alias", _i, [_vp, C.POINTER(_vp), _vp]),
     ("smr_rsp_pstore_counters", _i, [_vp, _vp]),
     ("smr_craft_pstore_create", _i, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("smr_craft_pstore_put", _i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _vp]),

@@ -43,7 +43,13 @@ struct PsPlane {
     uint32_t *tok;         // [W][G] the token whose bytes the row holds (PS_NULL: nothing)
     uint8_t *avail;        // [W][G] shards present
     uint32_t *dlen;        // [W][G] data length of the codeword
+    uint8_t *alias;        // the VOTED plane of a two-plane store: [W][G] shards of the cell that LIVE IN THE REQS PLANE's row (below);
+    uint8_t *base0;        // that plane's bytes.  NULL / unused for every other plane
 };
+// where shard k of cell i (= row * G + g) of plane p is read from
+__device__ __forceinline__ const uint8_t *ps_rd(const PsPlane &p, size_t i, uint32_t k) {
+    return (p.alias && ((p.alias[i] >> k) & 1u)) ? p.base0 : p.bytes;
+}
 struct PsView {
     uint32_t G, W, Wmask, n, d, cap_sl;
     PsPlane pl[2];
@@ -53,18 +59,30 @@ struct PsView {
     uint32_t *it_cell;     // (8 bits each), the shards to rebuild | the pattern to rebuild from, and the shard length
     uint64_t *it_src[2];
     uint32_t *it_rc;
+    uint8_t *it_mat;       // VOTED shards to move out of the REQS row (their alias ends) before anything else touches the cell
     uint32_t *it_sl[2];
     unsigned long long *counters;   // 0 shards copied, 1 shards rebuilt, 2 shards the engine has and nobody could give, 3 rows re-keyed
 };
+constexpr uint32_t PS_VIA0 = 0x40;  // a source code's flag: the shard is an alias in that source -- read it from the source STORE's reqs plane
 struct PsSrcs {
     uint32_t n;
-    PsPlane p[PS_MAX_SRC];
+    PsPlane p[PS_MAX_SRC];              // (the plan kernel's: tokens, masks, lengths, alias bits)
+    const uint8_t *rd[2 * PS_MAX_SRC];  // the byte kernel's: [2 j] = source j's plane, [2 j + 1] = its store's reqs plane (one indexed load per
+                                        // shard: a choice between two fields of p[j] by a per-lane j put the whole table into scratch, 800 B)
+    __host__ void set(uint32_t j, const PsPlane &pl) { p[j] = pl; rd[2 * j] = pl.bytes; rd[2 * j + 1] = pl.alias ? pl.base0 : pl.bytes; }
 };
+__device__ __forceinline__ const uint8_t *ps_src(const PsSrcs &S, uint32_t code) { return S.rd[((code & 15u) << 1) | ((code >> 6) & 1u)]; }
 
 typedef uint32_t ps_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ size_t ps_off(const PsView &v, uint32_t row, uint32_t k, uint32_t g) {
     return (((size_t)row * v.n + k) * v.G + g) * v.cap_sl;
+}
+// t = q * d + r for a lane index t: 32-bit whenever t fits (it nearly always does -- the emulated 64-bit division is ~150
+// instructions, and it sat at the top of every lane of the byte kernels)
+__device__ __forceinline__ void ps_divmod(uint64_t t, uint32_t d, uint32_t &q, uint32_t &r) {
+    if (t >> 32) { q = (uint32_t)(t / d); r = (uint32_t)(t % d); }
+    else { const uint32_t t32 = (uint32_t)t; q = t32 / d; r = t32 - q * d; }
 }
 __device__ __forceinline__ uint32_t ps_shard_len(uint32_t L, uint32_t d) { return (L + d - 1) / d; }   // rscoding.rs:177-181
 __device__ __forceinline__ ps_u32x4 ps_load16(const uint8_t *p) {
@@ -108,8 +126,9 @@ __device__ __forceinline__ void ps_rebuild_from(const PsView &v, uint8_t *base, 
 // cache lines by now), one bit-serial multiply-accumulate per coefficient.  For the byte kernel, whose common path is plain copies:
 // the Horner form's 8 x 16-byte input registers would set every wavefront's register budget (196 VGPRs, two wavefronts per SIMD)
 // for a path that runs at leader changes only.
+// (`in0`: the present shards whose bytes are read from `base0` instead -- a VOTED row's aliased shards)
 __device__ __forceinline__ void ps_rebuild_small(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
-                                                 uint32_t pat) {
+                                                 uint32_t pat, uint32_t in0 = 0u, const uint8_t *base0 = nullptr) {
     const uint8_t *m = v.mat + (size_t)pat * 64;
     for (uint32_t nd = need; nd; nd &= nd - 1u) {
         const uint32_t r = (uint32_t)__ffs((int)nd) - 1u;
@@ -118,7 +137,7 @@ __device__ __forceinline__ void ps_rebuild_small(const PsView &v, uint8_t *base,
         for (uint32_t c = 0; c < v.d; c++) {
             const uint32_t k = (uint32_t)__ffs((int)p) - 1u;
             p &= p - 1u;
-            ps_u32x4 x = ps_load16(base + ps_off(v, row, k, g) + c0);
+            ps_u32x4 x = ps_load16((((in0 >> k) & 1u) ? base0 : base) + ps_off(v, row, k, g) + c0);
             for (uint32_t co = m[r * 8 + c]; co; co >>= 1) {
                 if (co & 1u) acc ^= x;
                 x.x = ps_xtime4(x.x); x.y = ps_xtime4(x.y); x.z = ps_xtime4(x.z); x.w = ps_xtime4(x.w);
@@ -156,13 +175,27 @@ __device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t of
     return (ps_u32x4){w[0], w[1], w[2], w[3]};
 }
 
+// A REQS row about to be REPLACED (put, ingest): the VOTED shards that lived in it go with it.  (The handler behind either call has
+// re-initialised the instance's vote already -- handle_req_batch votes for its own batch, request.rs:103-118, and the ring cell of a
+// slot one window back is no instance of the engine's any more -- so the next follow re-derives the VOTED cell from the engine.)
+__device__ __forceinline__ void ps_drop_aliased(const PsView &v, size_t i) {
+    if (!v.pl[1].alias) return;
+    const uint32_t a = v.pl[1].alias[i];
+    if (!a) return;
+    const uint32_t left = (uint32_t)v.pl[1].avail[i] & ~a;
+    v.pl[1].avail[i] = (uint8_t)left;
+    if (!left) { v.pl[1].tok[i] = PS_NULL; v.pl[1].dlen[i] = 0; }
+    v.pl[1].alias[i] = 0;
+}
+
 // request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches; D = the number of data shards
 template <int D>
 __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
                                                      const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
                                                      const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    uint32_t g, blk;
+    ps_divmod(t, nblk, g, blk);
     if (g >= v.G || a_n[g] == 0) return;
     const uint32_t row = a_slot[g] & v.Wmask;
     uint32_t L = len ? len[g] : data_len;
@@ -170,6 +203,7 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
     const uint32_t sl = ps_shard_len(L, (uint32_t)D), c0 = blk * 16u;
     if (blk == 0) {
         const size_t i = (size_t)row * v.G + g;
+        ps_drop_aliased(v, i);
         v.pl[0].tok[i] = a_val[g];
         v.pl[0].avail[i] = (uint8_t)((1u << v.n) - 1u);
         v.pl[0].dlen[i] = L;
@@ -199,9 +233,18 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
     uint32_t rc = 0, sl[2] = {0u, 0u};
     uint32_t n_copy = 0, n_rebuilt = 0, n_unsat = 0, n_rekey = 0;
     uint32_t reqs_tok = PS_NULL, reqs_have = 0, reqs_len = 0;              // plane 0's new state: plane 1's "own other plane"
+    uint32_t mat = 0;                                                      // VOTED shards whose alias ends with this call
     const uint32_t all = (1u << v.n) - 1u;
     if (on) {
         const uint32_t only = sel ? sel[i % v.G] : PS_NONE;
+        // A VOTED shard that equals the REQS row's -- same token, the shard present there -- is not stored twice: its bit in `alias`
+        // says "read it from the REQS row".  That is every vote of a steady tick (`inst.voted = (ballot, reqs_cw.clone())`,
+        // messages.rs:373-380; the leader's subset of its own codeword, request.rs:103-118), which made the second copy 38 % of the
+        // bytes this store moved per tick.  The two part ways in the Prepare phase (reqs_cw takes the highest vote reported,
+        // messages.rs:180-194, while my own vote stays): the shard is then moved into the VOTED row first (`mat`).
+        const bool can_alias = v.pl[1].alias != nullptr;
+        const uint32_t alias_old = can_alias ? v.pl[1].alias[i] : 0u;
+        uint32_t alias_new = 0;
         for (int pl = 0; pl < 2; pl++) {
             uint32_t want_tok = pl == 0 ? e.s_val[i] : e.s_vval[i];
             uint32_t want = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
@@ -214,6 +257,12 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
                 have = 0; L = 0;
             }
             have &= want;                                                    // `inst.reqs_cw = reqs_cw`: shards the engine dropped
+            if (pl == 1) {
+                // aliases that go on: the REQS row still holds that token and that shard (it was not rewritten: a shard the row had
+                // and keeps is never in its `need`); the others the vote still has move out of the REQS row now
+                alias_new = reqs_tok == want_tok ? (alias_old & have & reqs_have) : 0u;
+                mat = alias_old & have & ~alias_new;
+            }
             uint32_t need = want & ~have;
             uint64_t sb = PS_NO_SRC;
             if (need && want_tok == 0) {                                     // from_data(ReqBatch::new()): one zero byte
@@ -223,23 +272,27 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
                 }
                 have |= need; need = 0; L = 1;
             }
-            // sources in order: the voted plane asks my own reqs plane FIRST (its new state is in registers: no load, and the byte
-            // kernel forwards the shard it has just stored there); the reqs plane asks the named sources, then my own voted plane
+            // sources in order: the voted plane asks my own reqs plane FIRST (its new state is in registers: no load, and nothing is
+            // copied -- the shard becomes an alias); the reqs plane asks the named sources, then my own voted plane
             for (uint32_t jj = 0; jj <= S.n && need; jj++) {
                 const uint32_t j = pl == 1 ? (jj == 0 ? S.n : jj - 1u) : jj;
-                uint32_t s_tok, s_av, s_len, code;
+                uint32_t s_tok, s_av, s_len, code, s_al = 0;                 // s_al: the source's shards that are aliases there
                 if (j < S.n) {
                     if (!S.p[j].tok || (sel && only != j)) continue;
                     s_tok = S.p[j].tok[i]; s_av = S.p[j].avail[i]; s_len = S.p[j].dlen[i]; code = j;
+                    s_al = S.p[j].alias ? S.p[j].alias[i] : 0u;
                 }
-                else if (pl == 0) { s_tok = v.pl[1].tok[i]; s_av = v.pl[1].avail[i]; s_len = v.pl[1].dlen[i]; code = PS_OWN; }
+                // (my voted row's aliased shards ARE the reqs row's: nothing to take there)
+                else if (pl == 0) { s_tok = v.pl[1].tok[i]; s_av = (uint32_t)v.pl[1].avail[i] & ~alias_old; s_len = v.pl[1].dlen[i]; code = PS_OWN; }
                 else { s_tok = reqs_tok; s_av = reqs_have; s_len = reqs_len; code = PS_OWN; }
                 const uint32_t take = (s_tok == want_tok) ? (need & s_av) : 0u;
                 if (!take) continue;
-                for (uint32_t m = take; m; m &= m - 1u) {
-                    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
-                    sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)code << (8 * k));
-                }
+                if (pl == 1 && code == PS_OWN && can_alias) alias_new |= take;
+                else
+                    for (uint32_t m = take; m; m &= m - 1u) {
+                        const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                        sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)(code | (((s_al >> k) & 1u) ? PS_VIA0 : 0u)) << (8 * k));
+                    }
                 n_copy += (uint32_t)__popc(take);
                 L = s_len; need &= ~take; have |= take;
             }
@@ -257,8 +310,9 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
             src[pl] = sb; sl[pl] = ps_shard_len(L, v.d);
             if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
         }
+        if (alias_new != alias_old) v.pl[1].alias[i] = (uint8_t)alias_new;
     }
-    const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0);
+    const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0 || mat != 0);
     const unsigned long long b = __ballot(work);
     const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
     // one append per BLOCK: the cells with work are neighbours (a tick's row), and ~15 ns per same-address atomic times one per
@@ -277,6 +331,7 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
     if (work) {
         const uint32_t o = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         v.it_cell[o] = i; v.it_src[0][o] = src[0]; v.it_src[1][o] = src[1]; v.it_rc[o] = rc; v.it_sl[0][o] = sl[0]; v.it_sl[1][o] = sl[1];
+        v.it_mat[o] = (uint8_t)mat;
     }
     uint32_t c[4] = {n_copy, n_rebuilt, n_unsat, n_rekey};
     for (int k = 0; k < 4; k++) {
@@ -306,48 +361,62 @@ __global__ __launch_bounds__(256) void ps_plan_many_kernel(const PsMany M, const
 // a lane per (listed cell, 16-byte column), columns fastest, in a grid-stride loop over cells x columns: the lanes of a wavefront
 // run over cell boundaries (a wavefront per cell left a third of the lanes idle, 86 columns on 64 lanes: 22.6 -> 17.3 us, r7e).  Plane 0 first (plane 1
 // may copy from it).  Where plane 0 is only copied into, a shard goes through both planes in one step: what plane 1 takes from
-// plane 0 ("own other plane": a follower's vote is the shard it has just been sent) is the register that was stored there, not
-// a read back.
+// plane 0 ("own other plane") without the alias array -- a CRaft store has one plane, so this is for completeness -- is the register
+// that was stored there, not a read back; with it (every RSPaxos store) such a shard is no copy at all, see ps_plan_body.
+// One (listed cell, 16-byte column):
+__device__ __forceinline__ void ps_bytes_one(const PsView &v, const PsSrcs &S, uint32_t it, uint32_t c0) {
+    const uint32_t rcw = v.it_rc[it], sl0 = v.it_sl[0][it], sl1 = v.it_sl[1][it];
+    const uint64_t sb0 = v.it_src[0][it], sb1 = v.it_src[1][it];
+    const uint32_t rc0 = rcw & 0xFFFFu, rc1 = rcw >> 16;
+    const uint32_t mat = c0 < sl1 ? (uint32_t)v.it_mat[it] : 0u;
+    const bool in0 = (sb0 != PS_NO_SRC || rc0) && c0 < sl0, in1 = (sb1 != PS_NO_SRC || rc1) && c0 < sl1;
+    if (!in0 && !in1 && !mat) return;
+    const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G;
+    for (uint32_t k = 0; k < v.n; k++) {
+        const size_t o = ps_off(v, row, k, g) + c0;
+        // a vote that stops being an alias of the reqs row's shard: into its own row before this call's bytes land in the reqs row
+        if ((mat >> k) & 1u) ps_store16(v.pl[1].bytes + o, ps_load16(v.pl[0].bytes + o));
+        const uint32_t s0 = in0 ? (uint32_t)(sb0 >> (8 * k)) & 0xFFu : PS_NONE;
+        ps_u32x4 x = {0u, 0u, 0u, 0u};
+        if (s0 != PS_NONE) {
+            if (s0 != PS_EMPTY) x = ps_load16((s0 == PS_OWN ? v.pl[1].bytes : ps_src(S, s0)) + o);
+            ps_store16(v.pl[0].bytes + o, x);
+        }
+        if (rc0) continue;                                              // plane 1 waits for plane 0's rebuild (below)
+        const uint32_t s1 = in1 ? (uint32_t)(sb1 >> (8 * k)) & 0xFFu : PS_NONE;
+        if (s1 == PS_NONE) continue;
+        if (!(s1 == PS_OWN && s0 != PS_NONE)) {                         // (else: x is what plane 0 holds there now)
+            x = (ps_u32x4){0u, 0u, 0u, 0u};
+            if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : ps_src(S, s1)) + o);
+        }
+        ps_store16(v.pl[1].bytes + o, x);
+    }
+    if (rc0) {
+        if (in0) ps_rebuild_small(v, v.pl[0].bytes, row, g, c0, rc0 & 0xFFu, rc0 >> 8);
+        for (uint32_t k = 0; k < v.n && in1; k++) {
+            const uint32_t s1 = (uint32_t)(sb1 >> (8 * k)) & 0xFFu;
+            if (s1 == PS_NONE) continue;
+            const size_t o = ps_off(v, row, k, g) + c0;
+            ps_u32x4 x = {0u, 0u, 0u, 0u};
+            if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : ps_src(S, s1)) + o);
+            ps_store16(v.pl[1].bytes + o, x);
+        }
+    }
+    // (a vote rebuilt from d present shards: the ones that are aliases are read from the reqs row -- the plan kernel has stored
+    // the cell's alias bits as they are after this call)
+    if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8, v.pl[1].alias ? v.pl[1].alias[cell] : 0u, v.pl[0].bytes);
+}
+
+// (Measured and dropped, profiles/r9c: four columns per lane and trip with their loads issued ahead of the first store -- 48.1 us
+// against 49.0 for the four followers' launch; 32-bit index arithmetic instead of the emulated 64-bit division -- kept, no
+// difference; 1024 .. 8192 blocks per store -- flat.  180 MB in 48 us is what a copy of this shape gets here.)
 __device__ __forceinline__ void ps_bytes_body(const PsView &v, uint32_t flip, const PsSrcs &S) {
     const uint32_t n_items = v.it_n[flip], ncol = v.cap_sl / 16u;
     const uint64_t total = (uint64_t)n_items * ncol, step = (uint64_t)gridDim.x * 256u;
     for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += step) {
-        const uint32_t it = (uint32_t)(t / ncol), c0 = (uint32_t)(t % ncol) * 16u;
-        const uint32_t rcw = v.it_rc[it], sl0 = v.it_sl[0][it], sl1 = v.it_sl[1][it];
-        const uint64_t sb0 = v.it_src[0][it], sb1 = v.it_src[1][it];
-        const uint32_t rc0 = rcw & 0xFFFFu, rc1 = rcw >> 16;
-        const bool in0 = (sb0 != PS_NO_SRC || rc0) && c0 < sl0, in1 = (sb1 != PS_NO_SRC || rc1) && c0 < sl1;
-        if (!in0 && !in1) continue;
-        const uint32_t cell = v.it_cell[it], row = cell / v.G, g = cell % v.G;
-        for (uint32_t k = 0; k < v.n; k++) {
-            const size_t o = ps_off(v, row, k, g) + c0;
-            const uint32_t s0 = in0 ? (uint32_t)(sb0 >> (8 * k)) & 0xFFu : PS_NONE;
-            ps_u32x4 x = {0u, 0u, 0u, 0u};
-            if (s0 != PS_NONE) {
-                if (s0 != PS_EMPTY) x = ps_load16((s0 == PS_OWN ? v.pl[1].bytes : S.p[s0].bytes) + o);
-                ps_store16(v.pl[0].bytes + o, x);
-            }
-            if (rc0) continue;                                              // plane 1 waits for plane 0's rebuild (below)
-            const uint32_t s1 = in1 ? (uint32_t)(sb1 >> (8 * k)) & 0xFFu : PS_NONE;
-            if (s1 == PS_NONE) continue;
-            if (!(s1 == PS_OWN && s0 != PS_NONE)) {                         // (else: x is what plane 0 holds there now)
-                x = (ps_u32x4){0u, 0u, 0u, 0u};
-                if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
-            }
-            ps_store16(v.pl[1].bytes + o, x);
-        }
-        if (rc0) {
-            if (in0) ps_rebuild_small(v, v.pl[0].bytes, row, g, c0, rc0 & 0xFFu, rc0 >> 8);
-            for (uint32_t k = 0; k < v.n && in1; k++) {
-                const uint32_t s1 = (uint32_t)(sb1 >> (8 * k)) & 0xFFu;
-                if (s1 == PS_NONE) continue;
-                const size_t o = ps_off(v, row, k, g) + c0;
-                ps_u32x4 x = {0u, 0u, 0u, 0u};
-                if (s1 != PS_EMPTY) x = ps_load16((s1 == PS_OWN ? v.pl[0].bytes : S.p[s1].bytes) + o);
-                ps_store16(v.pl[1].bytes + o, x);
-            }
-        }
-        if (rc1 && in1) ps_rebuild_small(v, v.pl[1].bytes, row, g, c0, rc1 & 0xFFu, rc1 >> 8);
+        uint32_t it, c0;
+        ps_divmod(t, ncol, it, c0);
+        ps_bytes_one(v, S, it, c0 * 16u);
     }
 }
 
@@ -362,7 +431,8 @@ __global__ __launch_bounds__(256) void ps_get_kernel(const PsView v, uint32_t n_
                                                      const uint32_t *__restrict__ slot, const uint32_t *__restrict__ expect, uint8_t *__restrict__ out,
                                                      uint64_t out_stride, uint32_t *__restrict__ len_out, uint8_t *__restrict__ ok, uint32_t nblk) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t it = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    uint32_t it, blk;
+    ps_divmod(t, nblk, it, blk);
     if (it >= n_items) return;
     const uint32_t g = group ? group[it] : it, s = slot[it];
     bool good = s != PS_NULL && g < v.G;
@@ -396,7 +466,8 @@ __global__ __launch_bounds__(256) void ps_extract_kernel(const PsView v, int pla
                                                          const uint8_t *__restrict__ mask, uint8_t *__restrict__ out, uint32_t *__restrict__ tok_out,
                                                          uint8_t *__restrict__ mask_out, uint32_t *__restrict__ dlen_out, uint32_t nblk) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    uint32_t g, blk;
+    ps_divmod(t, nblk, g, blk);
     if (g >= v.G) return;
     const bool on = (!flags || flags[g]) && slot[g] != PS_NULL;
     const uint32_t row = on ? (slot[g] & v.Wmask) : 0u;
@@ -408,7 +479,7 @@ __global__ __launch_bounds__(256) void ps_extract_kernel(const PsView v, int pla
     const uint32_t c0 = blk * 16u;
     if (!m || c0 >= ps_shard_len(L, v.d)) return;
     for (uint32_t k = 0; k < v.n; k++)
-        if ((m >> k) & 1u) ps_store16(out + ((size_t)k * v.G + g) * v.cap_sl + c0, ps_load16(v.pl[plane].bytes + ps_off(v, row, k, g) + c0));
+        if ((m >> k) & 1u) ps_store16(out + ((size_t)k * v.G + g) * v.cap_sl + c0, ps_load16(ps_rd(v.pl[plane], i, k) + ps_off(v, row, k, g) + c0));
 }
 
 // ... and receiver side: the codeword a message carried becomes row slot[g] of a (staging) store -- token, shards present, length
@@ -417,13 +488,18 @@ __global__ __launch_bounds__(256) void ps_ingest_kernel(const PsView v, int plan
                                                         const uint32_t *__restrict__ tok, const uint8_t *__restrict__ mask,
                                                         const uint32_t *__restrict__ dlen, const uint8_t *__restrict__ in, uint32_t nblk) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    uint32_t g, blk;
+    ps_divmod(t, nblk, g, blk);
     if (g >= v.G || (flags && !flags[g]) || slot[g] == PS_NULL) return;
     const uint32_t row = slot[g] & v.Wmask;
     const size_t i = (size_t)row * v.G + g;
     uint32_t m = (uint32_t)mask[g] & ((1u << v.n) - 1u), L = dlen[g];
     if (tok[g] == PS_NULL || L > v.cap_sl * v.d) m = 0;
-    if (blk == 0) { v.pl[plane].tok[i] = m ? tok[g] : PS_NULL; v.pl[plane].avail[i] = (uint8_t)m; v.pl[plane].dlen[i] = m ? L : 0u; }
+    if (blk == 0) {
+        if (plane == 0) ps_drop_aliased(v, i);
+        else if (v.pl[1].alias && v.pl[1].alias[i]) v.pl[1].alias[i] = 0;           // (the row's own bytes from here on)
+        v.pl[plane].tok[i] = m ? tok[g] : PS_NULL; v.pl[plane].avail[i] = (uint8_t)m; v.pl[plane].dlen[i] = m ? L : 0u;
+    }
     const uint32_t c0 = blk * 16u;
     if (!m || c0 >= ps_shard_len(L, v.d)) return;
     for (uint32_t k = 0; k < v.n; k++)
@@ -448,7 +524,8 @@ __global__ __launch_bounds__(256) void ps_emit_accepts_kernel(const PsView v, in
                                                               const uint64_t *__restrict__ ballot, const uint8_t *__restrict__ mask,
                                                               uint8_t *__restrict__ frames, uint64_t stride, uint32_t *__restrict__ len, uint32_t nblk) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t g = (uint32_t)(t / nblk), blk = (uint32_t)(t % nblk);
+    uint32_t g, blk;
+    ps_divmod(t, nblk, g, blk);
     if (g >= v.G) return;
     const bool on = (!flags || flags[g]) && slot[g] != PS_NULL;
     const uint32_t row = on ? (slot[g] & v.Wmask) : 0u;
@@ -483,7 +560,7 @@ __global__ __launch_bounds__(256) void ps_emit_accepts_kernel(const PsView v, in
     for (uint32_t k = 0; k < v.n; k++) {
         if (!((m >> k) & 1u)) { o += 1; continue; }
         uint8_t *dst = f + o + 1u + ps_vl(sl) + c0;
-        const uint8_t *src = v.pl[plane].bytes + ps_off(v, row, k, g) + c0;
+        const uint8_t *src = ps_rd(v.pl[plane], i, k) + ps_off(v, row, k, g) + c0;
         if (c0 + 16u <= sl) ps_store16(dst, ps_load16(src));
         else for (uint32_t b = 0; b < sl - c0; b++) dst[b] = src[b];
         o += per;
@@ -646,6 +723,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
     const size_t cells = (size_t)window * n_groups;
     Arena a, pa[2];
     size_t o_tok[2], o_av[2], o_len[2], o_src[2], o_sl[2], o_mat = 0, o_n = 0, o_cell = 0, o_rc = 0, o_ctr = 0, o_view = 0, o_bytes[2] = {0, 0};
+    size_t o_alias = 0, o_itmat = 0;
     // twice: sizes first, then -- the arenas allocated -- once more so that the kernel-source emulator of the CPU suite can mark the
     // unowned gap behind every array (SMR_ARENA_GUARD, smr_common.h); the offsets are the same both times
     auto layout = [&]() {
@@ -654,6 +732,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
         o_mat = a.reserve(tab.size()); o_n = a.reserve(256); o_cell = a.reserve(cells * 4);
         for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
         o_rc = a.reserve(cells * 4); o_ctr = a.reserve(SMR_CTR_WORDS * 8); o_view = a.reserve(sizeof(PsView));
+        o_alias = a.reserve(cells); o_itmat = a.reserve(cells);
         for (int p = 0; p < 2; p++) { pa[p].used = 0; o_bytes[p] = pa[p].reserve(p < planes ? s->plane_bytes : 256); }
     };
     layout();
@@ -681,6 +760,8 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
     }
     v.mat = a.at<uint8_t>(o_mat); v.it_n = a.at<uint32_t>(o_n); v.it_cell = a.at<uint32_t>(o_cell); v.it_rc = a.at<uint32_t>(o_rc);
     v.counters = a.at<unsigned long long>(o_ctr);
+    v.it_mat = a.at<uint8_t>(o_itmat);
+    if (planes == 2) { v.pl[1].alias = a.at<uint8_t>(o_alias); v.pl[1].base0 = v.pl[0].bytes; }   // (zeroed with the arena: no aliases yet)
     s->meta = a.base;
     s->plane_alloc[0] = pa[0].base; s->plane_alloc[1] = pa[1].base;
     s->d_view = a.at<PsView>(o_view);
@@ -764,7 +845,7 @@ static int ps_follow(smr_rsp_pstore *s, const RspPeek &pk, uint32_t n_src, smr_r
         if (o == s) return fail(SMR_ERR_ARG, "pstore follow: a store's own planes are sources already");
         if (o->v.G != v.G || o->v.W != v.W || o->v.n != v.n || o->v.d != v.d || o->v.cap_sl != v.cap_sl)
             return fail(SMR_ERR_ARG, "pstore follow: a source has another geometry");
-        S.p[j] = o->v.pl[src_plane[j]];
+        S.set(j, o->v.pl[src_plane[j]]);
     }
     hipStream_t st = (hipStream_t)stream;
     s->v.flip ^= 1u;                               // (calls on one store are issued on one stream at a time: the header says so)
@@ -842,7 +923,7 @@ static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPe
         if (src->v.G != v0.G || src->v.W != v0.W || src->v.n != v0.n || src->v.d != v0.d || src->v.cap_sl != v0.cap_sl)
             return fail(SMR_ERR_ARG, "pstore follow_many: the source has another geometry");
         S.n = 1;
-        S.p[0] = src->v.pl[src_plane];
+        S.set(0, src->v.pl[src_plane]);
     }
     for (uint32_t k = 0; k < n; k++) {
         stores[k]->v.flip ^= 1u;
@@ -962,17 +1043,45 @@ int smr_rsp_pstore_read_row(smr_rsp_pstore *s, int plane, uint32_t slot, uint8_t
     if (!s || plane < 0 || plane >= s->planes || !bytes_host) return fail(SMR_ERR_ARG, "pstore read_row: bad argument");
     SMR_HIP_TRY(hipDeviceSynchronize());
     const size_t row_bytes = (size_t)s->v.n * s->v.G * s->v.cap_sl;
-    SMR_HIP_TRY(hipMemcpy(bytes_host, s->v.pl[plane].bytes + (size_t)(slot & s->v.Wmask) * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+    const uint32_t row = slot & s->v.Wmask;
+    SMR_HIP_TRY(hipMemcpy(bytes_host, s->v.pl[plane].bytes + (size_t)row * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+    if (s->v.pl[plane].alias) {                                               // the row's shards that live in the REQS row
+        std::vector<uint8_t> al(s->v.G);
+        SMR_HIP_TRY(hipMemcpy(al.data(), s->v.pl[plane].alias + (size_t)row * s->v.G, s->v.G, hipMemcpyDeviceToHost));
+        bool any = false;
+        for (uint32_t g = 0; g < s->v.G && !any; g++) any = al[g] != 0;
+        if (any) {
+            std::vector<uint8_t> r0(row_bytes);
+            SMR_HIP_TRY(hipMemcpy(r0.data(), s->v.pl[plane].base0 + (size_t)row * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < s->v.G; g++)
+                for (uint32_t k = 0; k < s->v.n; k++)
+                    if ((al[g] >> k) & 1u) {
+                        const size_t o = ((size_t)k * s->v.G + g) * s->v.cap_sl;
+                        memcpy(bytes_host + o, r0.data() + o, s->v.cap_sl);
+                    }
+        }
+    }
     return SMR_OK;
 }
 
 int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, uint64_t *row_stride, uint64_t *shard_stride,
                           uint64_t *group_stride) {
     if (!s || plane < 0 || plane >= s->planes) return fail(SMR_ERR_ARG, "pstore layout: bad argument");
-    if (bytes_dev) *bytes_dev = s->v.pl[plane].bytes;
+    if (bytes_dev) *bytes_dev = s->v.pl[plane].bytes;     // (plane 1: see smr_rsp_pstore_voted_alias)
     if (row_stride) *row_stride = (uint64_t)s->v.n * s->v.G * s->v.cap_sl;
     if (shard_stride) *shard_stride = (uint64_t)s->v.G * s->v.cap_sl;
     if (group_stride) *group_stride = s->v.cap_sl;
+    return SMR_OK;
+}
+
+int smr_rsp_pstore_voted_alias(const smr_rsp_pstore *s, const uint8_t **alias_dev, uint8_t *alias_host) {
+    if (!s) return fail(SMR_ERR_ARG, "pstore voted_alias: null argument");
+    if (s->planes != 2) return fail(SMR_ERR_STATE, "pstore voted_alias: the store has no VOTED plane");
+    if (alias_dev) *alias_dev = s->v.pl[1].alias;
+    if (alias_host) {
+        SMR_HIP_TRY(hipDeviceSynchronize());
+        SMR_HIP_TRY(hipMemcpy(alias_host, s->v.pl[1].alias, (size_t)s->v.W * s->v.G, hipMemcpyDeviceToHost));
+    }
     return SMR_OK;
 }
 

@@ -139,6 +139,18 @@ class RSPaxosPayloadStore:
         check(self._L.smr_rsp_pstore_layout(self._h, int(plane), C.byref(p), None, None, None))
         return int(p.value)
 
+    def voted_alias_ptr(self):
+        """device pointer of the u8 [W][G] array: bit k = the VOTED shard k of that cell is read from the REQS plane"""
+        p = C.c_void_p()
+        check(self._L.smr_rsp_pstore_voted_alias(self._h, C.byref(p), None))
+        return int(p.value)
+
+    def voted_alias(self):
+        """uint8 [W, G] on the host: which VOTED shards are aliases of the REQS row's"""
+        a = np.zeros((self.W, self.G), np.uint8)
+        check(self._L.smr_rsp_pstore_voted_alias(self._h, None, a.ctypes.data_as(C.c_void_p)))
+        return a
+
     def counters(self):
         c = np.zeros(4, np.uint64)
         check(self._L.smr_rsp_pstore_counters(self._h, c.ctypes.data_as(C.c_void_p)))

@@ -338,7 +338,11 @@ def run_rspaxos_payload(cuda, oracle, G, W, L, T, ft):
             assert np.array_equal(a[n], b[n]), (r, n)
         c = stores[r].counters()
         assert c["unsatisfied"] == 0 and c["rebuilt"] == 0 and c["copied"] == (1 if r == 0 else 2) * G * T, (r, c)
-        assert c["rekeyed"] == (1 if r == 0 else 2) * G * max(T - W, 0), (r, c)       # once the ring wrapped: both planes of a follower's row; the leader's put re-keys its REQS row itself
+        # once the ring wrapped: both planes of a follower's row; the leader's put re-keys its REQS row itself, and the vote that was an
+        # alias of that row's shard goes with it
+        assert c["rekeyed"] == (0 if r == 0 else 2) * G * max(T - W, 0), (r, c)
+        from summerset_amd.rsp_payload import VOTED
+        assert np.array_equal(stores[r].voted_alias(), stores[r].dump(VOTED)["avail"]), r      # no vote was stored a second time
     return total
 
 

@@ -275,7 +275,7 @@ def test_rspaxos_payload_store_on_the_host(sim, oracle):
         tot, n_exec, n_cmp = t.run_closed_loop("cpu", oracle, 40, 16, 1, 0.1, 77, T=15, staging=True)    # bytes travel as messages only
         assert tot["rebuilt"] > 0 and n_exec > 0
         n_cmp, c = t.run_random_calls("cpu", oracle, 60, 8, 0, 0, steps=60)                               # adversarial calls: never a shard invented
-        assert n_cmp > 500 and c["copied"] > 0
+        assert n_cmp > 500 and c["copied"] > 0 and c["aliases"] > 0 and c["moved_out"] > 0, c    # (votes as aliases; some left the reqs row)
         t.test_argument_errors("cpu")
 
 

@@ -227,7 +227,21 @@ def run_random_calls(dev, oracle, G, W, me, ft, steps=120, L=61):
         staging.ingest(msg, t(slot.astype(np.uint32).view(np.int32)), REQS, t(flags.astype(np.uint8)))
 
     rng = np.random.default_rng(G + W + me)
-    n_cmp, n_exact = 0, 0
+    n_cmp, n_exact, n_moved, n_alias = 0, 0, 0, 0
+    al0, v0 = store.voted_alias(), store.dump(VOTED)
+
+    def votes_that_left_the_reqs_row():
+        """a VOTED shard that was an alias of the REQS row's before the call, is the row's own bytes now and still the same vote"""
+        nonlocal al0, v0
+        al1, v1 = store.voted_alias(), store.dump(VOTED)
+        assert not (al1 & ~v1["avail"]).any(), "an alias bit without the shard"
+        r1 = store.dump(REQS)
+        on = al1 != 0
+        assert np.array_equal(r1["tok"][on], v1["tok"][on]) and not (al1 & ~r1["avail"]).any(), "an alias into a row that holds something else"
+        moved = al0 & ~al1 & v1["avail"] & np.where(v1["tok"] == v0["tok"], 0xFF, 0).astype(np.uint8)
+        al0, v0 = al1, v1
+        return int(np.unpackbits(moved).sum()), int(np.unpackbits(al1).sum())
+
     for step in range(steps):
         for name, kw in rr.calls(rng, orc.dump(), G, R, me, W):
             if name == "req_batch":
@@ -247,6 +261,8 @@ def run_random_calls(dev, oracle, G, W, me, ft, steps=120, L=61):
                         stage((kw["rr_n"] > k) & (kw["flags"] != 0), kw["rr_slot"][k], kw["rr_val"][k], kw["rr_mask"][k])
                 getattr(eng, name)(**kw)
                 store.follow(rep, [(staging, REQS)])
+            m, a = votes_that_left_the_reqs_row()
+            n_moved += m; n_alias = max(n_alias, a)
             getattr(orc, name)(**kw)                                    # (the oracle only shapes the next calls)
         if step % 10 != 9:
             continue
@@ -273,13 +289,15 @@ def run_random_calls(dev, oracle, G, W, me, ft, steps=120, L=61):
                         if (s["avail"][w, g] >> k) & 1:
                             assert np.array_equal(row[k, g, :cw.shape[1]], cw[k]), (step, plane, w, g, k)
                             n_cmp += 1
-    return n_cmp, store.counters()
+    return n_cmp, dict(store.counters(), moved_out=n_moved, aliases=n_alias)
 
 
 @pytest.mark.parametrize("G,W,me,ft", [(150, 8, 0, 0), (150, 16, 2, 1)])
 def test_random_handler_calls_never_invent_a_shard(cuda, oracle, G, W, me, ft):
     n_cmp, c = run_random_calls(cuda, oracle, G, W, me, ft)
     assert n_cmp > 1000 and c["copied"] > 0 and c["rebuilt"] > 0, (n_cmp, c)
+    # votes were aliases of the reqs row's shards, and some had to leave it (reqs_cw took another value, the vote stayed)
+    assert c["aliases"] > 0 and c["moved_out"] > 0, c
 
 
 def test_one_call_with_two_senders_takes_each_group_s_shard_from_its_own_sender(cuda, oracle):
@@ -343,6 +361,11 @@ def test_steady_tick_is_one_put_and_one_shard_per_follower(cuda, oracle):
     assert c[0] == dict(copied=slots, rebuilt=0, unsatisfied=0, rekeyed=0)          # the leader's voted shard, from its own reqs plane
     for q in range(1, R):
         assert c[q] == dict(copied=2 * slots, rebuilt=0, unsatisfied=0, rekeyed=0)  # shard q into reqs, then into voted
+    # ... and none of those votes was stored a second time: every VOTED shard is an alias of the REQS row's
+    from summerset_amd.rsp_payload import VOTED
+    for r in reps:
+        v = r.store.dump(VOTED)
+        assert v["avail"].any() and np.array_equal(r.store.voted_alias(), v["avail"])
 
 
 def test_rows_are_shard_major_batches_the_rs_kernels_accept(cuda, oracle):
