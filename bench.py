@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -709,7 +709,7 @@ def _payload_leg_traffic(name="rspaxos_payload"):
     """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or (None, None): the
     sum over every ps_* / craft_* kernel of (bytes per launch x launches per tick), launches per tick = the kernel's launches in
     the profiled run / the run's ticks (recorded in the file by tools/final_record.sh)."""
-    for f in ("r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
+    for f in ("r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
         if not f:
             continue
         try:

@@ -547,6 +547,15 @@ int smr_raft_leader_append_emit(smr_raft_leader *l, const uint32_t *n_new_dev, u
  * appended batch; a follower that handles them in order ends in the same state). */
 int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev, const smr_raft_append_entries *msg,
                                    void *stream);
+/* A leader's AppendEntries for n <= 8 followers that live on its device, and the followers' handlers, in ONE launch: per k,
+ * smr_raft_leader_gather_entries(leader, first_dev[k], &msgs[k]) followed by
+ * smr_raft_replica_handle_append_entries(followers[k], &msgs[k], &replies[k]) -- the state, the messages (written: a checker or a
+ * wire emitter may read them) and the replies are those of the 2 n calls (the fan-out of raft/durability.rs:57-80 and
+ * handle_msg_append_entries, raft/messages.rs:13-218 / craft/messages.rs:14-254, of a co-located cluster).  first_dev, msgs,
+ * replies: host arrays of n; the messages share max_entries; leader and followers share groups / window / population and are all
+ * Raft or all CRaft replicas (CRaft: msgs[k].entry_mask = what follower k is sent). */
+int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
+                               const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, void *stream);
 int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
                                 uint32_t *n_trunc_host);
 /* The CRaft FOLLOWER (after smr_raft_craft_enable): smr_raft_replica_handle_append_entries then follows the fork's

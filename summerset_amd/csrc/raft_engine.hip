@@ -578,17 +578,13 @@ struct RaftLane {
 // (:133-146, RSCodeword::absorb_other as an OR of availability bitmaps), and execution only of entries with `majority`
 // shards, after reconstruct_data when too few of them are data shards (:193-233); entry_mask[s][g] = avail_shards_map of
 // the s-th sent entry
+// (the pointers carry no __restrict__ here: raft_replicate_kernel hands this body the message its own lane has just written)
 template <bool CRAFT>
-__global__ __launch_bounds__(256) void raft_append_entries_kernel(
-    const RaftView v, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ leader_id,
-    const uint64_t *__restrict__ term, const uint32_t *__restrict__ prev_slot, const uint64_t *__restrict__ prev_term,
-    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, const uint8_t *__restrict__ entry_mask,
-    uint8_t *__restrict__ partial, uint32_t K,
-    const uint32_t *__restrict__ leader_commit, const uint32_t *__restrict__ last_snap, uint8_t *__restrict__ r_flags,
-    uint64_t *__restrict__ r_term, uint32_t *__restrict__ r_end, uint64_t *__restrict__ r_cterm,
-    uint32_t *__restrict__ r_cslot) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= v.G) return;
+__device__ __forceinline__ void raft_append_entries_body(
+    const RaftView &v, uint32_t g, const uint8_t *flags, const uint8_t *leader_id, const uint64_t *term, const uint32_t *prev_slot,
+    const uint64_t *prev_term, const uint32_t *n_entries, const uint64_t *entry_term, const uint8_t *entry_mask, uint8_t *partial, uint32_t K,
+    const uint32_t *leader_commit, const uint32_t *last_snap, uint8_t *r_flags, uint64_t *r_term, uint32_t *r_end, uint64_t *r_cterm,
+    uint32_t *r_cslot) {
     uint8_t of = 0; uint64_t ot = 0, oct = 0; uint32_t oe = 0, ocs = 0;
     if (flags[g] & 1) {
         RaftLane L(v, g);
@@ -683,6 +679,20 @@ __global__ __launch_bounds__(256) void raft_append_entries_kernel(
         L.store();
     }
     r_flags[g] = of; r_term[g] = ot; r_end[g] = oe; r_cterm[g] = oct; r_cslot[g] = ocs;
+}
+template <bool CRAFT>
+__global__ __launch_bounds__(256) void raft_append_entries_kernel(
+    const RaftView v, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ leader_id,
+    const uint64_t *__restrict__ term, const uint32_t *__restrict__ prev_slot, const uint64_t *__restrict__ prev_term,
+    const uint32_t *__restrict__ n_entries, const uint64_t *__restrict__ entry_term, const uint8_t *__restrict__ entry_mask,
+    uint8_t *__restrict__ partial, uint32_t K,
+    const uint32_t *__restrict__ leader_commit, const uint32_t *__restrict__ last_snap, uint8_t *__restrict__ r_flags,
+    uint64_t *__restrict__ r_term, uint32_t *__restrict__ r_end, uint64_t *__restrict__ r_cterm,
+    uint32_t *__restrict__ r_cslot) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    raft_append_entries_body<CRAFT>(v, g, flags, leader_id, term, prev_slot, prev_term, n_entries, entry_term, entry_mask, partial, K, leader_commit,
+                                    last_snap, r_flags, r_term, r_end, r_cterm, r_cslot);
 }
 
 // craft/messages.rs:622-663 handle_msg_reconstruct: the codeword (as its availability bitmap) of every asked slot I hold
@@ -860,14 +870,9 @@ __global__ __launch_bounds__(256) void raft_vote_replies_kernel(const RaftView v
 // The AppendEntries a leader's appends produced for one peer, as ONE message per group (the reference
 // sends one per appended batch, durability.rs:57-80; a follower handling them in order ends in the same
 // state): entries [first, min(first + K, log end)), prev = first - 1.
-__global__ __launch_bounds__(256) void raft_gather_kernel(const RaftView v, const uint32_t *__restrict__ first, uint32_t K,
-                                                          uint8_t *__restrict__ flags, uint8_t *__restrict__ leader,
-                                                          uint64_t *__restrict__ term, uint32_t *__restrict__ prev_slot,
-                                                          uint64_t *__restrict__ prev_term, uint32_t *__restrict__ n_entries,
-                                                          uint64_t *__restrict__ entry_term, uint32_t *__restrict__ leader_commit,
-                                                          uint32_t *__restrict__ last_snap) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= v.G) return;
+__device__ __forceinline__ void raft_gather_body(const RaftView &v, uint32_t g, const uint32_t *first, uint32_t K, uint8_t *flags, uint8_t *leader,
+                                                 uint64_t *term, uint32_t *prev_slot, uint64_t *prev_term, uint32_t *n_entries, uint64_t *entry_term,
+                                                 uint32_t *leader_commit, uint32_t *last_snap) {
     RaftLane L(v, g);
     const uint32_t f = first[g];
     uint8_t fl = 0; uint32_t ps = 0, n = 0; uint64_t pt = 0;
@@ -884,6 +889,59 @@ __global__ __launch_bounds__(256) void raft_gather_kernel(const RaftView v, cons
     flags[g] = fl; leader[g] = (uint8_t)v.me; term[g] = L.term; prev_slot[g] = ps; prev_term[g] = pt; n_entries[g] = n;
     leader_commit[g] = L.commit; last_snap[g] = L.snap;
 }
+__global__ __launch_bounds__(256) void raft_gather_kernel(const RaftView v, const uint32_t *__restrict__ first, uint32_t K,
+                                                          uint8_t *__restrict__ flags, uint8_t *__restrict__ leader,
+                                                          uint64_t *__restrict__ term, uint32_t *__restrict__ prev_slot,
+                                                          uint64_t *__restrict__ prev_term, uint32_t *__restrict__ n_entries,
+                                                          uint64_t *__restrict__ entry_term, uint32_t *__restrict__ leader_commit,
+                                                          uint32_t *__restrict__ last_snap) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= v.G) return;
+    raft_gather_body(v, g, first, K, flags, leader, term, prev_slot, prev_term, n_entries, entry_term, leader_commit, last_snap);
+}
+
+// The leader's AppendEntries for n co-located followers and the followers' handlers in ONE launch (blockIdx.y = which follower):
+// the gather of follower k's message out of the leader's log, then -- same lane, the message it has just written -- follower k's
+// handle_msg_append_entries.  What smr_raft_leader_gather_entries + smr_raft_replica_handle_append_entries do in 2 n launches; the
+// leader's state is only read, follower k's only touched by its own blocks.  The followers' views are read from the device copies
+// their objects keep (a by-value table indexed by the block goes to scratch, csrc/rsp_payload.hip PsMany); the per-follower
+// pointers are picked out of the argument with compile-time indices.
+struct RaftRepl {
+    const RaftView *fv[RMAX];
+    uint8_t *partial[RMAX];
+    const uint32_t *first[RMAX];
+    uint8_t *m_flags[RMAX], *m_leader[RMAX];
+    uint64_t *m_term[RMAX], *m_prev_term[RMAX], *m_eterm[RMAX];
+    uint32_t *m_prev_slot[RMAX], *m_n[RMAX], *m_lc[RMAX], *m_ls[RMAX];
+    const uint8_t *m_emask[RMAX];
+    uint8_t *r_flags[RMAX];
+    uint64_t *r_term[RMAX], *r_cterm[RMAX];
+    uint32_t *r_end[RMAX], *r_cslot[RMAX];
+    uint32_t K;
+};
+template <bool CRAFT>
+__global__ __launch_bounds__(256) void raft_replicate_kernel(const RaftView lv, const RaftRepl A) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const RaftView *fvp = nullptr;
+    uint8_t *partial = nullptr, *m_flags = nullptr, *m_leader = nullptr, *r_flags = nullptr;
+    const uint32_t *first = nullptr;
+    uint64_t *m_term = nullptr, *m_prev_term = nullptr, *m_eterm = nullptr, *r_term = nullptr, *r_cterm = nullptr;
+    uint32_t *m_prev_slot = nullptr, *m_n = nullptr, *m_lc = nullptr, *m_ls = nullptr, *r_end = nullptr, *r_cslot = nullptr;
+    const uint8_t *m_emask = nullptr;
+#pragma unroll
+    for (int k = 0; k < (int)RMAX; k++)
+        if (blockIdx.y == (unsigned)k) {
+            fvp = A.fv[k]; partial = A.partial[k]; first = A.first[k]; m_flags = A.m_flags[k]; m_leader = A.m_leader[k]; m_term = A.m_term[k];
+            m_prev_term = A.m_prev_term[k]; m_eterm = A.m_eterm[k]; m_prev_slot = A.m_prev_slot[k]; m_n = A.m_n[k]; m_lc = A.m_lc[k];
+            m_ls = A.m_ls[k]; m_emask = A.m_emask[k]; r_flags = A.r_flags[k]; r_term = A.r_term[k]; r_cterm = A.r_cterm[k]; r_end = A.r_end[k];
+            r_cslot = A.r_cslot[k];
+        }
+    const RaftView fv = *fvp;                         // a copy in registers
+    if (g >= lv.G) return;
+    raft_gather_body(lv, g, first, A.K, m_flags, m_leader, m_term, m_prev_slot, m_prev_term, m_n, m_eterm, m_lc, m_ls);
+    raft_append_entries_body<CRAFT>(fv, g, m_flags, m_leader, m_term, m_prev_slot, m_prev_term, m_n, m_eterm, m_emask, partial, A.K, m_lc, m_ls, r_flags,
+                                    r_term, r_end, r_cterm, r_cslot);
+}
 
 }  // namespace smr
 
@@ -896,6 +954,8 @@ struct smr_raft_leader {
     bool craft = false;
     CraftView cv;
     uint8_t *craft_base = nullptr;
+    RaftView *d_view = nullptr;      // a device copy of v for smr_raft_cluster_replicate (made on first use; craft_enable changes v)
+    bool d_view_ok = false;
 };
 
 namespace smr {
@@ -969,6 +1029,7 @@ void smr_raft_leader_destroy(smr_raft_leader *l) {
     if (!l) return;
     if (l->arena.base) (void)hipFree(l->arena.base);
     if (l->craft_base) (void)hipFree(l->craft_base);
+    if (l->d_view) (void)hipFree(l->d_view);
     delete l;
 }
 
@@ -1046,6 +1107,7 @@ int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t r
     SMR_HIP_TRY(hipMemset(cv.alive, (int)((1u << R) - 1u), G));   // heartbeat.rs:131
     l->v.thresh = quorum + fault_tolerance;
     l->craft = true;
+    l->d_view_ok = false;
     return SMR_OK;
 }
 
@@ -1287,6 +1349,45 @@ int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev
                        m->max_entries, (uint8_t *)m->flags, (uint8_t *)m->leader, (uint64_t *)m->term, (uint32_t *)m->prev_slot,
                        (uint64_t *)m->prev_term, (uint32_t *)m->n_entries, (uint64_t *)m->entry_term,
                        (uint32_t *)m->leader_commit, (uint32_t *)m->last_snap);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
+                               const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, void *stream) {
+    if (!leader || !followers || !first_dev || !msgs || !replies) return fail(SMR_ERR_ARG, "raft replicate: null argument");
+    if (n == 0 || n > RMAX) return fail(SMR_ERR_ARG, "raft replicate: 1 .. 8 followers");
+    RaftRepl A;
+    memset(&A, 0, sizeof(A));
+    A.K = msgs[0].max_entries;
+    for (uint32_t k = 0; k < n; k++) {
+        smr_raft_leader *f = followers[k];
+        const smr_raft_append_entries &m = msgs[k];
+        const smr_raft_append_reply &r = replies[k];
+        if (!f || f == leader) return fail(SMR_ERR_ARG, "raft replicate: a follower is null or the leader itself");
+        for (uint32_t j = 0; j < k; j++) if (followers[j] == f) return fail(SMR_ERR_ARG, "raft replicate: a follower is listed twice");
+        if (f->v.G != leader->v.G || f->v.W != leader->v.W || f->v.R != leader->v.R || f->craft != leader->craft)
+            return fail(SMR_ERR_ARG, "raft replicate: a follower differs from the leader in groups / window / population / variant");
+        if (!first_dev[k] || !m.flags || !m.leader || !m.term || !m.prev_slot || !m.prev_term || !m.n_entries || !m.leader_commit || !m.last_snap ||
+            (m.max_entries && !m.entry_term) || !r.flags || !r.term || !r.end_slot || !r.conflict_term || !r.conflict_slot)
+            return fail(SMR_ERR_ARG, "raft replicate: null argument");
+        if (m.max_entries != A.K) return fail(SMR_ERR_ARG, "raft replicate: the messages differ in max_entries");
+        if (f->craft && m.max_entries && !m.entry_mask) return fail(SMR_ERR_ARG, "craft: AppendEntries without the entries' shard bitmaps");
+        if (!f->d_view) SMR_HIP_TRY(hipMalloc((void **)&f->d_view, sizeof(RaftView)));
+        if (!f->d_view_ok) {
+            SMR_HIP_TRY(hipMemcpy(f->d_view, &f->v, sizeof(RaftView), hipMemcpyHostToDevice));
+            f->d_view_ok = true;
+        }
+        A.fv[k] = f->d_view; A.partial[k] = f->craft ? f->cv.partial : nullptr; A.first[k] = first_dev[k];
+        A.m_flags[k] = (uint8_t *)m.flags; A.m_leader[k] = (uint8_t *)m.leader; A.m_term[k] = (uint64_t *)m.term;
+        A.m_prev_slot[k] = (uint32_t *)m.prev_slot; A.m_prev_term[k] = (uint64_t *)m.prev_term; A.m_n[k] = (uint32_t *)m.n_entries;
+        A.m_eterm[k] = (uint64_t *)m.entry_term; A.m_lc[k] = (uint32_t *)m.leader_commit; A.m_ls[k] = (uint32_t *)m.last_snap;
+        A.m_emask[k] = f->craft ? m.entry_mask : nullptr;
+        A.r_flags[k] = r.flags; A.r_term[k] = r.term; A.r_end[k] = r.end_slot; A.r_cterm[k] = r.conflict_term; A.r_cslot[k] = r.conflict_slot;
+    }
+    const dim3 grid((leader->v.G + 255) / 256, n), block(256);
+    if (leader->craft) hipLaunchKernelGGL(raft_replicate_kernel<true>, grid, block, 0, (hipStream_t)stream, leader->v, A);
+    else hipLaunchKernelGGL(raft_replicate_kernel<false>, grid, block, 0, (hipStream_t)stream, leader->v, A);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

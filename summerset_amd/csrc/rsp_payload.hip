@@ -3,8 +3,9 @@
 // The replica engine (rsp_engine.hip) keeps a codeword as (batch token, mask of shards present); this object keeps what
 // the reference keeps in `inst.reqs_cw` and `inst.voted.1` (rspaxos/mod.rs:168-233): the shards themselves.  Two planes
 // per replica -- REQS and VOTED -- each a ring of W rows x n shards x G groups x cap_sl bytes, plus per (row, group) the
-// token whose bytes the row holds, the shards present and the data length.  The engine decides which shards exist where;
-// the store makes the bytes FOLLOW that decision:
+// token whose bytes the row holds, the shards present and the data length; a VOTED shard that equals the REQS row's (the
+// vote is a clone of reqs_cw, messages.rs:373-380) is an ALIAS of it -- a bit per shard, no second copy (ps_plan_body).
+// The engine decides which shards exist where; the store makes the bytes FOLLOW that decision:
 //   smr_rsp_pstore_put     the leader's RSCodeword::from_data + compute_parity of a tick's batches (request.rs:71-101,
 //                          rscoding.rs:165-243,447-486) into the rows the engine's handle_req_batch put them
 //   smr_rsp_pstore_follow  after any handler call: for every ring cell, take the shards the engine's mask has and the row
@@ -175,6 +176,28 @@ __device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t of
     return (ps_u32x4){w[0], w[1], w[2], w[3]};
 }
 
+// (CRaft: the token of a log entry; its comment stands in front of the CRaft calls below)
+__device__ __forceinline__ uint32_t craft_token(uint32_t slot, uint64_t term) {
+    return 0x40000000u | (((uint32_t)term & 0x3FFu) << 20) | (slot & 0xFFFFFu);
+}
+// the slot ring cell `row` of group g holds now (PS_NULL: none -- the dummy entry 0 carries no codeword)
+__device__ __forceinline__ uint32_t craft_cell_slot(uint32_t len, uint32_t st, uint32_t rl, uint32_t W, uint32_t row) {
+    if (len == 0) return PS_NULL;
+    uint32_t s = ((len - 1u) & ~(W - 1u)) | row;                            // the highest slot <= len - 1 + (W - 1) in this cell ...
+    if (s > len - 1u) { if (s < W) return PS_NULL; s -= W; }                 // ... brought below the log's end
+    const uint32_t lo = st > rl ? st : rl;
+    return (s >= lo && s != 0u) ? s : PS_NULL;
+}
+__device__ __forceinline__ uint32_t craft_cell_slot(const RaftPeek &e, uint32_t row, uint32_t g) {
+    return craft_cell_slot(e.log_len[g], e.start_slot[g], e.ring_lo[g], e.W, row);
+}
+// ... and its token, for the plan kernel (e: a CRaft replica's log behind an RspPeek)
+__device__ __forceinline__ uint32_t craft_want_tok(const RspPeek &e, uint32_t i) {
+    const uint32_t row = i / e.G, g = i - row * e.G;
+    const uint32_t s = craft_cell_slot(e.c_len[g], e.c_start[g], e.c_rlo[g], e.W, row);
+    return s == PS_NULL ? PS_NULL : craft_token(s, e.c_term[i]);
+}
+
 // A REQS row about to be REPLACED (put, ingest): the VOTED shards that lived in it go with it.  (The handler behind either call has
 // re-initialised the instance's vote already -- handle_req_batch votes for its own batch, request.rs:103-118, and the ring cell of a
 // slot one window back is no instance of the engine's any more -- so the next follow re-derives the VOTED cell from the engine.)
@@ -189,14 +212,25 @@ __device__ __forceinline__ void ps_drop_aliased(const PsView &v, size_t i) {
 }
 
 // request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches; D = the number of data shards
-template <int D>
+// (CRAFT: the entry a CRaft leader appended at a_slot[g] -- PS_NULL: none -- where its log holds that slot; the token is the
+// entry's, a_n / a_val are not read)
+template <int D, bool CRAFT>
 __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
                                                      const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
-                                                     const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk) {
+                                                     const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk, const RaftPeek cr) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t g, blk;
     ps_divmod(t, nblk, g, blk);
-    if (g >= v.G || a_n[g] == 0) return;
+    if (g >= v.G) return;
+    uint32_t tok;
+    if (CRAFT) {
+        const uint32_t sl_ = a_slot[g];
+        if (sl_ == PS_NULL || sl_ == 0u || craft_cell_slot(cr, sl_ & v.Wmask, g) != sl_) return;   // (the log does not hold that slot)
+        tok = craft_token(sl_, cr.entry_term[(size_t)(sl_ & v.Wmask) * v.G + g]);
+    } else {
+        if (a_n[g] == 0) return;
+        tok = a_val[g];
+    }
     const uint32_t row = a_slot[g] & v.Wmask;
     uint32_t L = len ? len[g] : data_len;
     if (L > data_len) L = data_len;
@@ -204,7 +238,7 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
     if (blk == 0) {
         const size_t i = (size_t)row * v.G + g;
         ps_drop_aliased(v, i);
-        v.pl[0].tok[i] = a_val[g];
+        v.pl[0].tok[i] = tok;
         v.pl[0].avail[i] = (uint8_t)((1u << v.n) - 1u);
         v.pl[0].dlen[i] = L;
     }
@@ -246,7 +280,7 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
         const uint32_t alias_old = can_alias ? v.pl[1].alias[i] : 0u;
         uint32_t alias_new = 0;
         for (int pl = 0; pl < 2; pl++) {
-            uint32_t want_tok = pl == 0 ? e.s_val[i] : e.s_vval[i];
+            uint32_t want_tok = e.c_len ? (pl == 0 ? craft_want_tok(e, i) : PS_NULL) : (pl == 0 ? e.s_val[i] : e.s_vval[i]);
             uint32_t want = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
             if (want_tok == PS_NULL) want = 0;
             if (want == 0) want_tok = PS_NULL;
@@ -572,49 +606,8 @@ __global__ __launch_bounds__(256) void ps_emit_accepts_kernel(const PsView v, in
 // exactly that), so the token of ring cell [slot % W] is a function of the two: 20 bits of the slot, 10 of the term, bit 30 set
 // (never 0 = the synthesised empty batch, never PS_NULL).  Two entries that meet in one cell differ by a multiple of W in their
 // slots: their tokens could only agree 2^20 / W wraps of the ring apart, and every wrap re-keys the cell.
-__device__ __forceinline__ uint32_t craft_token(uint32_t slot, uint64_t term) {
-    return 0x40000000u | (((uint32_t)term & 0x3FFu) << 20) | (slot & 0xFFFFFu);
-}
-// the slot ring cell `row` of group g holds now (PS_NULL: none -- the dummy entry 0 carries no codeword)
-__device__ __forceinline__ uint32_t craft_cell_slot(const RaftPeek &e, uint32_t row, uint32_t g) {
-    const uint32_t len = e.log_len[g], st = e.start_slot[g], rl = e.ring_lo[g];
-    if (len == 0) return PS_NULL;
-    uint32_t s = ((len - 1u) & ~(e.W - 1u)) | row;                          // the highest slot <= len - 1 + (W - 1) in this cell ...
-    if (s > len - 1u) { if (s < e.W) return PS_NULL; s -= e.W; }             // ... brought below the log's end
-    const uint32_t lo = st > rl ? st : rl;
-    return (s >= lo && s != 0u) ? s : PS_NULL;
-}
-// one lane per ring cell: the token the engine's log says the cell holds (the masks are the engine's own array)
-__global__ __launch_bounds__(256) void craft_tokens_kernel(const RaftPeek e, uint32_t *__restrict__ tok) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= e.W * e.G) return;
-    const uint32_t row = i / e.G, g = i % e.G;
-    const uint32_t s = craft_cell_slot(e, row, g);
-    tok[i] = s == PS_NULL ? PS_NULL : craft_token(s, e.entry_term[i]);
-}
-// ... for several replicas in one launch (blockIdx.y = which): smr_craft_pstore_follow_many
-struct CraftMany {
-    RaftPeek e[PS_MAX_N];
-    uint32_t *tok[PS_MAX_N];
-};
-__global__ __launch_bounds__(256) void craft_tokens_many_kernel(const CraftMany M) {
-    const RaftPeek e = M.e[blockIdx.y];
-    uint32_t *const tok = M.tok[blockIdx.y];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= e.W * e.G) return;
-    const uint32_t s = craft_cell_slot(e, i / e.G, i % e.G);
-    tok[i] = s == PS_NULL ? PS_NULL : craft_token(s, e.entry_term[i]);
-}
-// the put of the entry the leader appended at slot[g] (PS_NULL: none): a_n / a_val as ps_put_kernel takes them
-__global__ __launch_bounds__(256) void craft_put_args_kernel(const RaftPeek e, const uint32_t *__restrict__ slot, uint32_t *__restrict__ a_n,
-                                                             uint32_t *__restrict__ a_val) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= e.G) return;
-    const uint32_t s = slot[g];
-    const bool on = s != PS_NULL && s != 0u && craft_cell_slot(e, s & (e.W - 1u), g) == s;   // the log holds that slot
-    a_n[g] = on ? 1u : 0u;
-    a_val[g] = on ? craft_token(s, e.entry_term[(size_t)(s & (e.W - 1u)) * e.G + g]) : PS_NULL;
-}
+// (Round 5b: the tokens are computed where they are compared -- craft_want_tok in the plan kernel, the put kernel's own lanes --
+// instead of by a launch of their own into an array per store: three launches and 13 MB per tick less at config 4's size.)
 
 // ---- host: GF(2^8) matrices for the rebuild table ------------------------------------------------------------------
 struct PsGf {
@@ -690,10 +683,7 @@ struct smr_rsp_pstore {
     PsView *d_view;        // the device copy of v (flip excepted) smr_rsp_pstore_follow_many's kernels read
     void *plane_alloc[2];  // the planes' allocations (v.pl[p].bytes lies at their start)
     int planes;            // 2; 1 for a CRaft store (a log entry has one codeword: no VOTED bytes are allocated)
-    // CRaft (smr_craft_pstore_*): the tokens the log implies per ring cell, an all-NULL token array standing for the absent voted
-    // plane, and the put's per-group arguments -- one allocation, made by smr_craft_pstore_create
-    uint32_t *craft_tok, *craft_null, *craft_an, *craft_aval;
-    void *craft_alloc;
+    bool craft_store;      // made by smr_craft_pstore_create
 };
 
 extern "C" {
@@ -717,8 +707,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
     v.cap_sl = (sl + 15u) / 16u * 16u;
     s->max_data_len = max_data_len;
     s->planes = planes;
-    s->craft_tok = s->craft_null = s->craft_an = s->craft_aval = nullptr;
-    s->craft_alloc = nullptr;
+    s->craft_store = false;
     s->plane_bytes = (uint64_t)window * n_shards * n_groups * v.cap_sl;
     const size_t cells = (size_t)window * n_groups;
     Arena a, pa[2];
@@ -783,48 +772,45 @@ int smr_craft_pstore_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_dat
                             smr_rsp_pstore **out) {
     int rc = ps_create(n_groups, n_shards, n_data_shards, window, max_data_len, 1, out);
     if (rc != SMR_OK) return rc;
-    smr_rsp_pstore *s = *out;
-    const size_t cells = (size_t)window * n_groups;
-    const size_t bytes = (cells * 2 + (size_t)n_groups * 2) * 4;
-    hipError_t err = hipMalloc(&s->craft_alloc, bytes);
-    if (err == hipSuccess) err = hipMemset(s->craft_alloc, 0xFF, bytes);
-    if (err != hipSuccess) {
-        smr_rsp_pstore_destroy(s);
-        *out = nullptr;
-        return fail(SMR_ERR_DEVICE, std::string("craft pstore: allocation: ") + hipGetErrorString(err));
-    }
-    s->craft_tok = (uint32_t *)s->craft_alloc;
-    s->craft_null = s->craft_tok + cells;
-    s->craft_an = s->craft_null + cells;
-    s->craft_aval = s->craft_an + n_groups;
+    (*out)->craft_store = true;
     return SMR_OK;
 }
 
 void smr_rsp_pstore_destroy(smr_rsp_pstore *s) {
     if (!s) return;
-    if (s->craft_alloc) (void)hipFree(s->craft_alloc);
     for (int p = 0; p < 2; p++) if (s->plane_alloc[p]) (void)hipFree(s->plane_alloc[p]);
     if (s->meta) (void)hipFree(s->meta);
     delete s;
 }
 
-int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
-                       const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, void *stream) {
-    if (!s || !a_n_dev || !a_slot_dev || !a_val_dev || !data_dev) return fail(SMR_ERR_ARG, "pstore put: null argument");
+static int ps_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev, const uint8_t *data_dev,
+                  uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, const RaftPeek *craft, void *stream) {
     if (data_len == 0 || data_len > s->max_data_len) return fail(SMR_ERR_ARG, "pstore put: data_len must be in 1..max_data_len");
     if (data_stride < data_len) return fail(SMR_ERR_ARG, "pstore put: data_stride is shorter than data_len");
     const PsView &v = s->v;
     const uint32_t nblk = ((data_len + v.d - 1) / v.d + 15u) / 16u;
     const uint64_t threads = (uint64_t)v.G * nblk;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    RaftPeek cr;
+    memset(&cr, 0, sizeof(cr));
+    if (craft) cr = *craft;
 #define PS_PUT(D)                                                                                                                         \
     case D:                                                                                                                               \
-        hipLaunchKernelGGL(ps_put_kernel<D>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, \
-                           a_val_dev, data_dev, data_stride, len_dev, data_len, nblk);                                                    \
+        if (craft) hipLaunchKernelGGL((ps_put_kernel<D, true>), grid, block, 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, a_val_dev, data_dev,  \
+                                      data_stride, len_dev, data_len, nblk, cr);                                                          \
+        else hipLaunchKernelGGL((ps_put_kernel<D, false>), grid, block, 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, a_val_dev, data_dev,       \
+                                data_stride, len_dev, data_len, nblk, cr);                                                                \
         break;
     switch (v.d) { PS_PUT(1) PS_PUT(2) PS_PUT(3) PS_PUT(4) PS_PUT(5) PS_PUT(6) PS_PUT(7) default: return fail(SMR_ERR_ARG, "pstore put: bad scheme"); }
 #undef PS_PUT
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
+}
+
+int smr_rsp_pstore_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
+                       const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, void *stream) {
+    if (!s || !a_n_dev || !a_slot_dev || !a_val_dev || !data_dev) return fail(SMR_ERR_ARG, "pstore put: null argument");
+    return ps_put(s, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, nullptr, stream);
 }
 
 // the store follows the (token, mask) arrays `pk` names: smr_rsp_pstore_follow's an RSPaxos replica's, smr_craft_pstore_follow's the
@@ -868,8 +854,16 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
 
 // ---- CRaft: put at append, follow behind AppendEntries / ReconstructReply / commit (craft/request.rs:71-76, messages.rs:133-146,
 // 193-233, 697-737; leadership.rs:80-141 decides the masks) ------------------------------------------------------------------
+static RspPeek craft_as_peek(const RaftPeek &rp) {
+    RspPeek pk;
+    memset(&pk, 0, sizeof(pk));
+    pk.G = rp.G; pk.W = rp.W; pk.R = rp.R; pk.me = 0; pk.majority = rp.quorum;
+    pk.s_mask = rp.entry_mask; pk.s_vmask = rp.entry_mask;
+    pk.c_len = rp.log_len; pk.c_start = rp.start_slot; pk.c_rlo = rp.ring_lo; pk.c_term = rp.entry_term;
+    return pk;
+}
 static int craft_peek_of(smr_rsp_pstore *s, const smr_raft_leader *e, RaftPeek &rp) {
-    if (!s->craft_alloc) return fail(SMR_ERR_STATE, "craft pstore: not a CRaft store (smr_craft_pstore_create)");
+    if (!s->craft_store) return fail(SMR_ERR_STATE, "craft pstore: not a CRaft store (smr_craft_pstore_create)");
     rp = raft_peek(e);
     if (!rp.entry_mask) return fail(SMR_ERR_STATE, "craft pstore: CRaft is not enabled on this replica (smr_raft_craft_enable)");
     if (rp.G != s->v.G || rp.W != s->v.W || rp.R != s->v.n || rp.quorum != s->v.d)
@@ -882,9 +876,7 @@ int smr_craft_pstore_put(smr_rsp_pstore *s, const smr_raft_leader *e, const uint
     if (!s || !e || !slot_dev || !data_dev) return fail(SMR_ERR_ARG, "craft pstore put: null argument");
     RaftPeek rp;
     if (int rc = craft_peek_of(s, e, rp)) return rc;
-    hipLaunchKernelGGL(craft_put_args_kernel, dim3((rp.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, slot_dev, s->craft_an, s->craft_aval);
-    SMR_HIP_TRY(hipGetLastError());
-    return smr_rsp_pstore_put(s, s->craft_an, slot_dev, s->craft_aval, data_dev, data_stride, len_dev, data_len, stream);
+    return ps_put(s, nullptr, slot_dev, nullptr, data_dev, data_stride, len_dev, data_len, &rp, stream);
 }
 
 int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_t n_src, smr_rsp_pstore *const *src, const uint8_t *sel_dev,
@@ -892,11 +884,8 @@ int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_
     if (!s || !e || (n_src && !src)) return fail(SMR_ERR_ARG, "craft pstore follow: null argument");
     RaftPeek rp;
     if (int rc = craft_peek_of(s, e, rp)) return rc;
-    const uint32_t cells = rp.W * rp.G;
-    hipLaunchKernelGGL(craft_tokens_kernel, dim3((cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, s->craft_tok);
-    SMR_HIP_TRY(hipGetLastError());
-    // the log's codewords are the REQS plane; the voted plane's tokens are all NULL (nothing is wanted there, nothing is allocated)
-    const RspPeek pk{rp.G, rp.W, rp.R, 0u, rp.quorum, s->craft_tok, s->craft_null, rp.entry_mask, rp.entry_mask};
+    // the log's codewords are the REQS plane (their tokens: craft_want_tok in the plan kernel); nothing is wanted in the voted plane
+    const RspPeek pk = craft_as_peek(rp);
     uint8_t planes[PS_MAX_SRC] = {0};
     return ps_follow(s, pk, n_src, src, planes, sel_dev, stream);
 }
@@ -953,26 +942,17 @@ int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const 
     return ps_follow_many(n, stores, pk, src, src_plane, stream);
 }
 
-// smr_craft_pstore_follow for n <= 8 followers that consumed ONE leader's AppendEntries: a token launch, a plan launch and a byte
-// launch for all of them
+// smr_craft_pstore_follow for n <= 8 followers that consumed ONE leader's AppendEntries: a plan launch and a byte launch for all of them
 int smr_craft_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_raft_leader *const *replicas, const smr_rsp_pstore *src,
                                  void *stream) {
     if (!n || n > PS_MAX_N || !stores || !replicas) return fail(SMR_ERR_ARG, "craft pstore follow_many: 1 .. 8 stores");
     RspPeek pk[PS_MAX_N];
-    CraftMany C;
-    memset(&C, 0, sizeof(C));
     for (uint32_t k = 0; k < n; k++) {
         if (!stores[k] || !replicas[k]) return fail(SMR_ERR_ARG, "craft pstore follow_many: null store / replica");
         RaftPeek rp;
         if (int rc = craft_peek_of(stores[k], replicas[k], rp)) return rc;
-        C.e[k] = rp; C.tok[k] = stores[k]->craft_tok;
-        pk[k] = RspPeek{rp.G, rp.W, rp.R, 0u, rp.quorum, stores[k]->craft_tok, stores[k]->craft_null, rp.entry_mask, rp.entry_mask};
+        pk[k] = craft_as_peek(rp);
     }
-    const uint32_t cells = C.e[0].W * C.e[0].G;
-    for (uint32_t k = 1; k < n; k++)
-        if (C.e[k].W * C.e[k].G != cells) return fail(SMR_ERR_ARG, "craft pstore follow_many: the replicas differ in groups / window");
-    hipLaunchKernelGGL(craft_tokens_many_kernel, dim3((cells + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, C);
-    SMR_HIP_TRY(hipGetLastError());
     return ps_follow_many(n, stores, pk, src, 0, stream);
 }
 

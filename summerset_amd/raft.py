@@ -65,6 +65,33 @@ class RaftLeaderGroup:
         check(self._L.smr_raft_leader_gather_entries(self._h, _ptr(first), C.byref(msg), stream_ptr(stream)))
         return m
 
+    def replicate_many(self, followers, first, msgs, replies, entry_masks=None, stream=None):
+        """`gather_entries(first[k], K, out=msgs[k])` + `followers[k].handle_msg_append_entries(**msgs[k], entry_mask=entry_masks[k],
+        out=replies[k])` for every k in ONE launch (`smr_raft_cluster_replicate`): followers = replica objects on my device, first[k] =
+        int32 [G] (a row of `handle_req_batch_emit`), msgs[k] = a message dict as `gather_entries` returns it (refilled), replies[k] =
+        the reply tensors to fill (e.g. rows of my [R, G] reply arrays), entry_masks[k] = uint8 [K, G] (CRaft).  Returns msgs."""
+        n = len(followers)
+        hs = (C.c_void_p * n)(*[f._h for f in followers])
+        fs = (C.c_void_p * n)(*[_ptr(first[k]) for k in range(n)])
+        ms, rs = (RaftAppendEntries * n)(), (RaftAppendReply * n)()
+        for k in range(n):
+            m, r = msgs[k], replies[k]
+            ms[k] = RaftAppendEntries(_ptr(m["flags"]), _ptr(m["leader"]), _ptr(m["term"]), _ptr(m["prev_slot"]), _ptr(m["prev_term"]),
+                                      _ptr(m["n_entries"]), _ptr(m["entry_term"]), int(m["entry_term"].shape[0]), _ptr(m["leader_commit"]),
+                                      _ptr(m["last_snap"]), _ptr(entry_masks[k]) if entry_masks is not None else None)
+            rs[k] = RaftAppendReply(*[_ptr(r[x]) for x in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])
+        check(self._L.smr_raft_cluster_replicate(self._h, n, hs, fs, ms, rs, stream_ptr(stream)))
+        return msgs
+
+    def new_message(self, max_entries, device):
+        """the tensors of one AppendEntries message (what `gather_entries` allocates when it is given no `out`)"""
+        import torch
+        G, K = self.G, int(max_entries)
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+        return dict(flags=z(G, torch.uint8), leader=z(G, torch.uint8), term=z(G, torch.int64), prev_slot=z(G, torch.int32),
+                    prev_term=z(G, torch.int64), n_entries=z(G, torch.int32), entry_term=z((K, G), torch.int64),
+                    leader_commit=z(G, torch.int32), last_snap=z(G, torch.int32))
+
     def handle_msg_append_entries_reply(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None,
                                         order=None, stream=None):
         """one AppendEntriesReply per (peer, group); device tensors shaped [R, G]"""

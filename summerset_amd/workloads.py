@@ -152,11 +152,12 @@ def craft_payload_cluster(G=CRAFT_PAYLOAD["G"], W=CRAFT_PAYLOAD["W"], L=CRAFT_PA
     return reps, stores, bufs                                            # a tick is its handlers' launches and nothing else
 
 
-def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True):
+def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, one_launch=True):
     """one tick: the leader appends one batch per group (slot [G] int32 = where: in the steady state log_len before the call = 1 +
     the tick's number) and `put`s the serialized batches `src` (uint8 [G, L]); its follow; per follower the AppendEntries out of the
-    leader's log + `handle_msg_append_entries`; ONE follow_many for the four followers; the replies' match-index quorum at the
-    leader.  Returns the AppendEntries messages (for a checker)."""
+    leader's log + `handle_msg_append_entries` -- all four in ONE launch (`smr_raft_cluster_replicate`; one_launch=False: the eight
+    calls it stands for); ONE follow_many for the four followers; the replies' match-index quorum at the leader.  Returns the
+    AppendEntries messages (for a checker)."""
     from .rsp_payload import CRaftPayloadStore
     R = len(reps)
     first = reps[0].handle_req_batch_emit(bufs["ones"], out=bufs["first"])
@@ -164,11 +165,19 @@ def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True):
         stores[0].put(reps[0], slot, src, lens)
         stores[0].follow(reps[0])
     msgs = {}
-    for q in range(1, R):
+    reply = lambda q: dict(flags=bufs["fl"][q], term=bufs["rt"][q], end_slot=bufs["es"][q], conflict_term=bufs["ct"][q],
+                           conflict_slot=bufs["cs"][q])                           # the reply straight into the leader's [R, G] arrays
+    if one_launch:
+        qs = list(range(1, R))
+        for q in qs:
+            if bufs["msg"][q] is None:
+                bufs["msg"][q] = reps[0].new_message(1, first.device)
+        reps[0].replicate_many([reps[q] for q in qs], [first[q] for q in qs], [bufs["msg"][q] for q in qs], [reply(q) for q in qs],
+                               entry_masks=[bufs["em"][q] for q in qs])
+        msgs = {q: bufs["msg"][q] for q in qs}
+    for q in range(1, R) if not one_launch else ():
         m = bufs["msg"][q] = reps[0].gather_entries(first[q], 1, out=bufs["msg"][q])
-        reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q],          # the reply straight into the leader's [R, G] arrays
-                                          out=dict(flags=bufs["fl"][q], term=bufs["rt"][q], end_slot=bufs["es"][q], conflict_term=bufs["ct"][q],
-                                                   conflict_slot=bufs["cs"][q]))
+        reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q], out=reply(q))
         msgs[q] = m
     if bytes_:
         CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])

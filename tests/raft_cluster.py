@@ -55,6 +55,19 @@ class NumpyRaft:
         return self._n(o, dict(flags=np.uint8, term=np.uint64, end_slot=np.uint32, conflict_term=np.uint64,
                                conflict_slot=np.uint32))
 
+    def replicate_many(self, followers, firsts, K):
+        """my AppendEntries for `followers` (NumpyRaft objects) and their handlers in one launch; returns [(message, reply)] as numpy"""
+        torch, dev, G = self.torch, self.cuda, self.G
+        msgs = [self.e.new_message(K, dev) for _ in followers]
+        z = lambda dt: torch.zeros(G, dtype=dt, device=dev)
+        reps = [dict(flags=z(torch.uint8), term=z(torch.int64), end_slot=z(torch.int32), conflict_term=z(torch.int64), conflict_slot=z(torch.int32))
+                for _ in followers]
+        self.e.replicate_many([f.e for f in followers], [self._t(np.ascontiguousarray(f)) for f in firsts], msgs, reps)
+        ml = dict(flags=np.uint8, leader=np.uint8, term=np.uint64, prev_slot=np.uint32, prev_term=np.uint64, n_entries=np.uint32,
+                  entry_term=np.uint64, leader_commit=np.uint32, last_snap=np.uint32)
+        rl = dict(flags=np.uint8, term=np.uint64, end_slot=np.uint32, conflict_term=np.uint64, conflict_slot=np.uint32)
+        return [(self._n(m, ml), self._n(r, rl)) for m, r in zip(msgs, reps)]
+
     def handle_replies(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None, order=None):
         self.e.handle_msg_append_entries_reply(self._t(reply_term), self._t(end_slot), self._t(flags), self._t(conflict_term),
                                                self._t(conflict_slot), self._t(order))
@@ -66,9 +79,12 @@ class NumpyRaft:
         return self.e.dump_votes()
 
 
-def tick(reps, timeouts, n_new, K, via=None):
+def tick(reps, timeouts, n_new, K, via=None, sender_major=False, one_launch=False, seen=None):
     """timeouts[r][G]: HearTimeout source at replica r (0xFF none); n_new[r][G]: client batches handed to
     replica r (those that do not lead redirect them).  Returns nothing; state lives in the replicas.
+    sender_major: the replication step goes sender by sender (every follower handles sender 0's message, then sender 1's ..)
+    instead of receiver by receiver -- the order in which `one_launch` (NumpyRaft.replicate_many: a sender's messages and their
+    handlers in one launch) can stand for the calls; seen (a list): the (sender, receiver, message, reply) tuples of the step.
     via (optional): via(s, rt, es, fl, ct, cs) -> the same five [R][G] arrays -- the AppendEntriesReplies on their way to
     leader s (tests/test_zz_reply_ingest_gpu.py sends them as frames through the device parser)."""
     R = len(reps)
@@ -92,7 +108,21 @@ def tick(reps, timeouts, n_new, K, via=None):
     # replication
     first = [reps[r].append_emit(np.ascontiguousarray(n_new[r])) for r in range(R)]
     rep = {}
-    for q in range(R):
+    if sender_major:
+        for s in range(R):
+            qs = [q for q in range(R) if q != s]
+            if one_launch:
+                out = reps[s].replicate_many([reps[q] for q in qs], [first[s][q] for q in qs], K)
+            else:
+                out = []
+                for q in qs:
+                    m = reps[s].gather_entries(first[s][q], K)
+                    out.append((m, reps[q].handle_append_entries(**m)))
+            for q, (m, r) in zip(qs, out):
+                rep[(q, s)] = r
+                if seen is not None:
+                    seen.append((s, q, m, r))
+    for q in range(R) if not sender_major else ():
         for s in range(R):
             if s == q:
                 continue

@@ -81,3 +81,37 @@ def test_bench_leg_craft_payload_on_the_emulator(oracle):
     assert out["verified"] and out["counters"]["unsatisfied"] == 0 and out["counters"]["copied"] > 0
     line = bench.compact_leg(out)
     assert set(line) == {"value", "unit", "ms_per_tick", "frac", "frac_on_8d_bytes", "traffic_ratio", "cpu_cores"}
+
+
+def run_one_launch_replication_is_the_eight_calls(dev, G=150, W=8, L=40, T=11):
+    """two CRaft clusters on the same inputs: one replicates with gather_entries + handle_msg_append_entries per follower, the other
+    with the one-launch `replicate_many` -- engines, messages, replies and stores stay identical tick by tick (W = 8: the ring wraps)"""
+    import torch
+    from summerset_amd import workloads
+    a, b = workloads.craft_payload_cluster(G, W, L, 1, dev), workloads.craft_payload_cluster(G, W, L, 1, dev)
+    rng = np.random.default_rng(5)
+    for t in range(T):
+        slot = torch.full((G,), t + 1, dtype=torch.int32, device=dev)
+        src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
+        ma = workloads.craft_payload_tick(*a, slot, src, one_launch=False)
+        mb = workloads.craft_payload_tick(*b, slot, src, one_launch=True)
+        for q in ma:
+            for k in ma[q]:
+                assert torch.equal(ma[q][k], mb[q][k]), (t, q, k)
+        for k in ("rt", "es", "fl", "ct", "cs"):
+            assert torch.equal(a[2][k], b[2][k]), (t, k)
+        for r in range(len(a[0])):
+            da, db = a[0][r].dump(), b[0][r].dump()
+            for k in da:
+                assert np.array_equal(da[k], db[k]), (t, r, k)
+            sa, sb = a[1][r].dump(), b[1][r].dump()
+            for k in sa:
+                assert np.array_equal(sa[k], sb[k]), (t, r, k)
+    assert int(a[0][0].dump()["last_commit"].min()) >= T - 2
+
+
+def test_one_launch_replication_on_the_emulator():
+    import hostsim
+    hostsim.build()
+    with hostsim.patched():
+        run_one_launch_replication_is_the_eight_calls("cpu", G=70)

@@ -57,6 +57,7 @@ def test_raft_kernels_on_the_host(sim, oracle):
         t.test_craft_threshold("cpu", oracle)
         t.test_follower_and_elections_match_oracle("cpu", oracle, 300, 64)
         t.test_closed_loop_cluster_matches_oracle("cpu", oracle)
+        assert t.run_one_launch_replication("cpu", oracle, G=200, W=64, K=8, T=12) > 300     # smr_raft_cluster_replicate == the 2 n calls == the oracle
 
 
 def test_craft_leader_kernels_on_the_host(sim, oracle):

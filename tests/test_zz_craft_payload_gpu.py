@@ -30,3 +30,9 @@ def test_craft_payload_ring_wraps(cuda, oracle):
     assert sum(int(s.counters()["rekeyed"]) for s in lp.stores) > 0
     for r in range(lp.R):
         lp.check(r, ("end", r))
+
+
+def test_one_launch_replication_is_the_eight_calls(cuda):
+    """`smr_raft_cluster_replicate` (the leader's four AppendEntries and their handlers in one launch) against the eight calls"""
+    import test_craft_payload as t
+    t.run_one_launch_replication_is_the_eight_calls(cuda, G=1000, W=8, L=200, T=14)

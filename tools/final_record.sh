@@ -1,9 +1,9 @@
 #!/bin/bash
-# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m):
+# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m, r8z, r9z):
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra and over the two payload legs
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
-TAG=${1:-r8z}
+TAG=${1:-r9z}
 mkdir -p gpurun_out
 R=$PWD
 # 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic*.json for every `traffic` field of its line
