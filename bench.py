@@ -834,10 +834,11 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
     us_engine = time_us(torch, lambda i: one_tick(bytes_=False), 12)   # the engines' tick alone (after the checks)
     us_bytes = max(us - us_engine, 1e-3)
     return {"workload": "CRaft, %d groups x 5 replicas, one %d-byte batch per group per tick, balanced assignment; bytes through smr_craft_pstore_* "
-                        "(put + the leader's follow + one follow_many for the four followers, window %d)" % (G, L, W),
+                        "(put + the leader's follow + one follow_many for the four followers, window %d); the four AppendEntries and their handlers "
+                        "are one launch (smr_raft_cluster_replicate)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
-            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 11, "bytes": 6},
-            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3> + craft_tokens / ps_plan / ps_bytes (the leader's, and the followers' _many)",
+            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 3, "bytes": 5},
+            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3, true> + ps_plan / ps_bytes (the leader's, and the followers' _many)",
                          "achieved": moved / (us_bytes * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": moved, "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic("craft_payload")[0] if G == 16384 else None,
                          "traffic_source": _payload_leg_traffic("craft_payload")[1],

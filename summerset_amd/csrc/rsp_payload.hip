@@ -277,14 +277,23 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
         // bytes this store moved per tick.  The two part ways in the Prepare phase (reqs_cw takes the highest vote reported,
         // messages.rs:180-194, while my own vote stays): the shard is then moved into the VOTED row first (`mat`).
         const bool can_alias = v.pl[1].alias != nullptr;
-        const uint32_t alias_old = can_alias ? v.pl[1].alias[i] : 0u;
-        uint32_t alias_new = 0;
+        // what the engine says against what the rows hold, both planes; a cell where they agree -- every cell but the tick's row, in
+        // a steady tick -- is done here: its lengths, its alias bits and the sources' cells are not even read (38 -> 20 bytes per cell)
+        uint32_t w_tok[2], w_mask[2], h_tok[2], h_mask[2];
+        bool same = true;
         for (int pl = 0; pl < 2; pl++) {
-            uint32_t want_tok = e.c_len ? (pl == 0 ? craft_want_tok(e, i) : PS_NULL) : (pl == 0 ? e.s_val[i] : e.s_vval[i]);
-            uint32_t want = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
-            if (want_tok == PS_NULL) want = 0;
-            if (want == 0) want_tok = PS_NULL;
-            const uint32_t had_tok = v.pl[pl].tok[i], had = v.pl[pl].avail[i], had_len = v.pl[pl].dlen[i];
+            w_tok[pl] = e.c_len ? (pl == 0 ? craft_want_tok(e, i) : PS_NULL) : (pl == 0 ? e.s_val[i] : e.s_vval[i]);
+            w_mask[pl] = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
+            if (w_tok[pl] == PS_NULL) w_mask[pl] = 0;
+            if (w_mask[pl] == 0) w_tok[pl] = PS_NULL;
+            h_tok[pl] = v.pl[pl].tok[i]; h_mask[pl] = v.pl[pl].avail[i];
+            same = same && h_mask[pl] == w_mask[pl] && h_tok[pl] == w_tok[pl];
+        }
+        const uint32_t alias_old = (can_alias && !same) ? v.pl[1].alias[i] : 0u;
+        uint32_t alias_new = 0;
+        for (int pl = 0; pl < 2 && !same; pl++) {
+            uint32_t want_tok = w_tok[pl], want = w_mask[pl];
+            const uint32_t had_tok = h_tok[pl], had = h_mask[pl], had_len = v.pl[pl].dlen[i];
             uint32_t have = had, L = had_len;
             if (had_tok != want_tok) {
                 if (have) n_rekey++;
@@ -344,7 +353,7 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
             src[pl] = sb; sl[pl] = ps_shard_len(L, v.d);
             if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
         }
-        if (alias_new != alias_old) v.pl[1].alias[i] = (uint8_t)alias_new;
+        if (!same && alias_new != alias_old) v.pl[1].alias[i] = (uint8_t)alias_new;
     }
     const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0 || mat != 0);
     const unsigned long long b = __ballot(work);
