@@ -167,6 +167,7 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         te.test_payload_lengths_around_the_register_fast_path("cpu")
         te.test_every_frame_of_the_straight_line_path("cpu")
         te.test_frames_at_the_window_edges("cpu")
+        te.test_frames_around_the_ring_of_two_lines("cpu")
         te.test_extreme_values_and_odd_encodings("cpu")
         te.test_ragged_wavefront_and_unaligned_buffer_end("cpu")
         te.test_frames_laid_out_by_hand_give_records_laid_out_by_hand("cpu")     # expected records written out by the test

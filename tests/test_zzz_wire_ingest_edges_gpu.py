@@ -134,6 +134,28 @@ def test_frames_at_the_window_edges(cuda):
     assert nm == 0 and na == 151 * 11 and nh == 151 * 3 and no == 151
 
 
+def test_frames_around_the_ring_of_two_lines(cuda):
+    """written for round 5's ring experiment (a lane's stream through a ring of two aligned 128-byte lines, the next line in
+    flight while the ring is parsed: tools/experiments/wire_ingest_ring_r5.patch, measured slower, profiles/r9g) and kept for
+    whatever walks the stream: a located filler of every length 0 .. 420 (shorter than a line, a line, two, more: the position
+    jumps over bytes that need not be loaded) in front of hot frames, and behind them enough AcceptReplies for several more
+    refills, so that every window / ring offset sees a header, a payload's end and a record kept in place of read bytes; two
+    long fillers back to back; streams that end inside a frame"""
+    from summerset_amd import wire
+    streams = []
+    for pad in range(0, 421):
+        filler = _frame(_varint(1) + bytes((pad * 11 + i) & 0xFF for i in range(pad)))
+        s = filler + wire.accept_reply(pad, 0x101) + wire.heartbeat(0x201, pad, 2, 1) + _ar(_fd(pad), _fd(U64))
+        if pad % 3 == 0:
+            s += _frame(_varint(1) + bytes(200 + pad % 97)) + _frame(_varint(1) + bytes(127 + pad % 5))
+        s += wire.accept_reply(65535 + pad, 70000) * (20 + pad % 23)
+        if pad % 7 == 0:
+            s += wire.heartbeat(1, 2, 3, 4)[:pad % 13]                                              # ends inside a frame
+        streams.append(s)
+    na, nh, no, nm = _check(wire, cuda, streams, seed=6)
+    assert nm == 0 and nh == 421 and no == 421 + 2 * 141 and na == sum(2 + 20 + pad % 23 for pad in range(421))
+
+
 def test_extreme_values_and_odd_encodings(cuda):
     from summerset_amd import wire
     ok = [
