@@ -15,6 +15,14 @@
 #include "mp_device.h"
 #include "smr_common.h"
 
+// experiment (profiles/r9h): the bulk round kernels' wavefronts at a raised issue priority, so that on a SIMD they share with the
+// side launch's wavefronts they go first.  Off unless built with -DSMR_BULK_PRIO=1..3
+#ifdef SMR_BULK_PRIO
+#define SMR_RAISE_PRIO() __builtin_amdgcn_s_setprio(SMR_BULK_PRIO)
+#else
+#define SMR_RAISE_PRIO() ((void)0)
+#endif
+
 namespace smr {
 
 // wave-reduce the counters, one atomic per wave and replica
@@ -305,6 +313,7 @@ __global__ MP_R1_BOUNDS void mp_round_local(const MpParams *__restrict__ Pp, int
                                                       const uint32_t *__restrict__ req_cnt,
                                                       const uint32_t *__restrict__ req_val, uint32_t S, int side) {
     const MpParams &P = *Pp;
+    if (!side) SMR_RAISE_PRIO();
     if (!((P.live >> blockIdx.y) & 1u)) return;                 // spread layout: that replica lives on another rank
     uint32_t g;
     const bool active = pick_group(P, side, g);
@@ -636,6 +645,7 @@ __device__ __forceinline__ void r2_body(const MpParams &P, int par, const uint32
 // everything of R2 in one launch: the side stream's blocks, the spread layout, stretches without a leader change
 __global__ __launch_bounds__(256, MP_R2_MINW) void mp_round_deliver_all(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
+    if (!side) SMR_RAISE_PRIO();
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
@@ -1169,6 +1179,7 @@ __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParam
                                                        const uint32_t *__restrict__ ackctl, int publish_hb, uint32_t hint) {
     __shared__ uint8_t sh_fl[64 * 64];
     __shared__ uint32_t sh_mk[64 * 64];
+    SMR_RAISE_PRIO();
     quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk, hint);
 }
 
@@ -1231,6 +1242,7 @@ __global__ MP_R3_BOUNDS void mp_round_replies(const MpParams *__restrict__ Pp, i
                                                         const uint32_t *__restrict__ ackctl,
                                                         int publish_hb, int side) {
     const MpParams &P = *Pp;
+    if (!side) SMR_RAISE_PRIO();
     if (!((P.live >> blockIdx.y) & 1u)) return;
     if (side == 0) {   // mp_quorum_tally left a flag per (replica, 64-group tile): nothing flagged, nothing to do
         const uint32_t ntile = (P.G + 63) / 64, tpb = blockDim.x >> 6, t0 = blockIdx.x * tpb;   // 64-group tiles of this block
@@ -1264,6 +1276,7 @@ __global__ __launch_bounds__(256) void mp_rest_then_local(const MpParams *__rest
                                                           const uint8_t *__restrict__ req_target, const uint32_t *__restrict__ req_cnt,
                                                           const uint32_t *__restrict__ req_val, uint32_t S) {
     const MpParams &P = *Pp;
+    SMR_RAISE_PRIO();
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, 0, g);
@@ -1324,6 +1337,7 @@ __device__ __forceinline__ void r4_body(const MpParams &P, int par, const uint32
 #endif
 __global__ MP_R4_BOUNDS void mp_round_heartbeat(const MpParams *__restrict__ Pp, int par, int side) {
     const MpParams &P = *Pp;
+    if (!side) SMR_RAISE_PRIO();
     if (!((P.live >> blockIdx.y) & 1u)) return;
     uint32_t g;
     const bool active = pick_group(P, side, g);
