@@ -49,6 +49,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // of rounds 1-3 were 64-bit multiply-adds and add-with-carry chains in front of every access.  The one-launch tick is bound by
 // VALU issue (a wave64 VALU instruction occupies its SIMD for four cycles, ~2.5 wavefronts share a SIMD): address arithmetic
 // was a fifth of its instructions.
+// index arithmetic: a product of two values below 2^24 is ONE full-rate instruction (v_mul_u32_u24 / v_mad_u32_u24) where the
+// 32-bit v_mul_lo_u32 is quarter rate -- and the tick kernel has ~400 of them.  smr_ep_replica_create guarantees the operands'
+// range (G < 2^24 follows from the 4 GB rule; the reply tables' cell index W * R * R * (recovery ? R : 1) < 2^24 is checked).
+#ifdef EP_MUL24
+__device__ __forceinline__ uint32_t M24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+__device__ __forceinline__ uint32_t SHL_OF(uint32_t x, uint32_t pow2) { return x << (uint32_t)__builtin_ctz(pow2); }
+#else
+__device__ __forceinline__ uint32_t M24(uint32_t a, uint32_t b) { return a * b; }
+__device__ __forceinline__ uint32_t SHL_OF(uint32_t x, uint32_t pow2) { return x * pow2; }
+#endif
 template <typename T>
 __device__ __forceinline__ T &EA(T *base, uint32_t idx) { return *(T *)((char *)base + (uint32_t)(idx * (uint32_t)sizeof(T))); }
 
@@ -158,32 +168,32 @@ struct EpLaneT {
     __device__ __forceinline__ SMR_L uint32_t &cw(int arr, uint32_t row) const { return lc[((uint32_t)arr * NR + row) * 64u]; }
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = EA(v.len, r * v.G + g); cw(1, r) = EA(v.commit_bars, r * v.G + g); }
+        for (uint32_t r = 0; r < v.R; r++) { cw(0, r) = EA(v.len, M24(r, v.G) + g); cw(1, r) = EA(v.commit_bars, M24(r, v.G) + g); }
         c_nulls = EA(v.my_nulls, g);
         rewritten = EA(v.rewritten, g) != 0;
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { EA(v.len, r * v.G + g) = cw(0, r); EA(v.commit_bars, r * v.G + g) = cw(1, r); }
+        for (uint32_t r = 0; r < v.R; r++) { EA(v.len, M24(r, v.G) + g) = cw(0, r); EA(v.commit_bars, M24(r, v.G) + g) = cw(1, r); }
         EA(v.my_nulls, g) = c_nulls;
     }
-    __device__ __forceinline__ uint32_t get_len(uint32_t row) const { return CACHE ? cw(0, row) : EA(v.len, row * v.G + g); }
-    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) { if (CACHE) cw(0, row) = x; else EA(v.len, row * v.G + g) = x; }
-    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const { return CACHE ? cw(1, row) : EA(v.commit_bars, row * v.G + g); }
-    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) { if (CACHE) cw(1, row) = x; else EA(v.commit_bars, row * v.G + g) = x; }
+    __device__ __forceinline__ uint32_t get_len(uint32_t row) const { return CACHE ? cw(0, row) : EA(v.len, M24(row, v.G) + g); }
+    __device__ __forceinline__ void set_len(uint32_t row, uint32_t x) { if (CACHE) cw(0, row) = x; else EA(v.len, M24(row, v.G) + g) = x; }
+    __device__ __forceinline__ uint32_t get_cb(uint32_t row) const { return CACHE ? cw(1, row) : EA(v.commit_bars, M24(row, v.G) + g); }
+    __device__ __forceinline__ void set_cb(uint32_t row, uint32_t x) { if (CACHE) cw(1, row) = x; else EA(v.commit_bars, M24(row, v.G) + g) = x; }
     __device__ __forceinline__ uint32_t get_nulls() const { return CACHE ? c_nulls : EA(v.my_nulls, g); }
     __device__ __forceinline__ void add_nulls(uint32_t d) { if (CACHE) c_nulls += d; else EA(v.my_nulls, g) += d; }
     // the plane of the reply tables a (row, col) instance uses: one per row with recovery, else my row's only
-    __device__ __forceinline__ uint32_t pw(uint32_t row, uint32_t col) const { return (v.recovery ? row : 0u) * v.W + (col & v.Wmask); }
-    __device__ __forceinline__ uint32_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return (pw(row, col) * v.R + peer) * v.G + g; }
+    __device__ __forceinline__ uint32_t pw(uint32_t row, uint32_t col) const { return M24(v.recovery ? row : 0u, v.W) + (col & v.Wmask); }
+    __device__ __forceinline__ uint32_t ps_ix(uint32_t row, uint32_t col, uint32_t peer) const { return M24(M24(pw(row, col), v.R) + peer, v.G) + g; }
     __device__ __forceinline__ uint32_t pd_ix(uint32_t row, uint32_t col, uint32_t peer, uint32_t k) const {
-        return ((pw(row, col) * v.R + peer) * v.R + k) * v.G + g;
+        return M24(M24(M24(pw(row, col), v.R) + peer, v.R) + k, v.G) + g;
     }
     __device__ __forceinline__ uint32_t xv_ix(uint32_t row, uint32_t col, uint32_t peer) const {
-        return ((row * v.W + (col & v.Wmask)) * v.R + peer) * v.G + g;
+        return M24(M24(M24(row, v.W) + (col & v.Wmask), v.R) + peer, v.G) + g;
     }
     // ---- the instance record (see EpView) ----
-    __device__ __forceinline__ uint32_t ix(uint32_t row, uint32_t col) const { return (row * v.W + (col & v.Wmask)) * v.G + g; }
+    __device__ __forceinline__ uint32_t ix(uint32_t row, uint32_t col) const { return M24(M24(row, v.W) + (col & v.Wmask), v.G) + g; }
     __device__ __forceinline__ static void unpack_p2(u32x4 w, EpInst<NR> &I) {
         if (NR > 4) I.d[4 < NR ? 4 : 0] = w.x;
         I.m0 = w.y; I.m1 = w.z;
@@ -244,7 +254,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void identify_deps(uint32_t key, uint32_t (&d)[NR]) const {   // dependency.rs:113-137
 #pragma unroll
-        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, (g * v.n_keys + key) * v.hc_es + i) : EP_NONE;
+        for (int i = 0; i < NR; i++) d[i] = (key != EP_NO_KEY && (uint32_t)i < v.R) ? EA(v.hc, SHL_OF(M24(g, v.n_keys) + key, v.hc_es) + i) : EP_NONE;
     }
     __device__ __forceinline__ uint64_t max_seq_num(const uint32_t (&d)[NR]) const {         // dependency.rs:101-109
         uint64_t m = 0;
@@ -258,7 +268,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void refresh_highest_cols(uint32_t row, uint32_t col, uint32_t key) {   // dependency.rs:141-167
         if (key == EP_NO_KEY) return;
-        const uint32_t o = (g * v.n_keys + key) * v.hc_es + row;
+        const uint32_t o = SHL_OF(M24(g, v.n_keys) + key, v.hc_es) + row;
         const uint32_t hc = EA(v.hc, o);
         if (hc == EP_NONE || col > hc) EA(v.hc, o) = col;
     }
@@ -539,21 +549,21 @@ struct EpExecLaneT {
     // CACHE: exec_bars / prev_cb in arrays 2 and 3 of the lane's LDS cache block (see EpLaneT)
     __device__ __forceinline__ void load_scalars() {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { L.cw(2, r) = EA(x.exec_bars, r * v.G + g); L.cw(3, r) = EA(x.prev_cb, r * v.G + g); }
+        for (uint32_t r = 0; r < v.R; r++) { L.cw(2, r) = EA(x.exec_bars, M24(r, v.G) + g); L.cw(3, r) = EA(x.prev_cb, M24(r, v.G) + g); }
     }
     __device__ __forceinline__ void store_scalars() const {
         if (!CACHE) return;
-        for (uint32_t r = 0; r < v.R; r++) { EA(x.exec_bars, r * v.G + g) = L.cw(2, r); EA(x.prev_cb, r * v.G + g) = L.cw(3, r); }
+        for (uint32_t r = 0; r < v.R; r++) { EA(x.exec_bars, M24(r, v.G) + g) = L.cw(2, r); EA(x.prev_cb, M24(r, v.G) + g) = L.cw(3, r); }
     }
-    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : EA(x.exec_bars, row * v.G + g); }
-    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else EA(x.exec_bars, row * v.G + g) = y; }
+    __device__ __forceinline__ uint32_t get_eb(uint32_t row) const { return CACHE ? L.cw(2, row) : EA(x.exec_bars, M24(row, v.G) + g); }
+    __device__ __forceinline__ void set_eb(uint32_t row, uint32_t y) { if (CACHE) L.cw(2, row) = y; else EA(x.exec_bars, M24(row, v.G) + g) = y; }
     // every row's exec bar in one round of loads (CACHE: they are in LDS and nothing is loaded here), and one of them
     // (known_executed_below: 0 for every row of a group in which a cell below a commit bar was once rewritten --
     // EpView::rewritten: there a cell below the exec bar may have been taken back to an earlier Status, and the walk must look)
     __device__ __forceinline__ void load_ebs(uint32_t (&ebs)[NR]) {
         if (!CACHE) L.rewritten = EA(v.rewritten, g) != 0;
 #pragma unroll
-        for (int q = 0; q < NR; q++) ebs[q] = (!CACHE && (uint32_t)q < v.R) ? EA(x.exec_bars, (uint32_t)q * v.G + g) : 0u;
+        for (int q = 0; q < NR; q++) ebs[q] = (!CACHE && (uint32_t)q < v.R) ? EA(x.exec_bars, (uint32_t)M24(q, v.G) + g) : 0u;
     }
     __device__ __forceinline__ uint32_t known_executed_below(const uint32_t (&ebs)[NR], uint32_t row) const {
         return L.rewritten ? 0u : eb_of(ebs, row);
@@ -568,7 +578,7 @@ struct EpExecLaneT {
     // has the row's commit bar moved since the last look (then the copy follows it)
     __device__ __forceinline__ bool cb_moved(uint32_t row, uint32_t cb) {
         if (!CACHE) {
-            const uint32_t o = row * v.G + g;
+            const uint32_t o = M24(row, v.G) + g;
             if (cb == EA(x.prev_cb, o)) return false;
             EA(x.prev_cb, o) = cb;
             return true;
@@ -584,10 +594,10 @@ struct EpExecLaneT {
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
-    __device__ __forceinline__ uint32_t at(uint32_t i) const { return i * v.G + g; }
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return M24(i, v.G) + g; }
     // the KV word of a key: word hc_kv of the key's hc entry (EpView::hc) -- the token of the key's last Put, (row + 1) << 32 | col,
     // packed into 32 bits (ep_kv_pack: 4 bits of row + 1, 28 of the column; 0 = none) so that five replicas' entries fit one line
-    __device__ __forceinline__ uint32_t &kv_at(uint32_t key) const { return EA(v.hc, (g * v.n_keys + key) * v.hc_es + v.hc_kv); }
+    __device__ __forceinline__ uint32_t &kv_at(uint32_t key) const { return EA(v.hc, SHL_OF(M24(g, v.n_keys) + key, v.hc_es) + v.hc_kv); }
     // the column a ring cell of this row holds (the one of its residue among the last W)
     __device__ __forceinline__ uint32_t col_of(uint32_t row, uint32_t w) const {
         const uint32_t end = L.get_len(row), lo = end > v.W ? end - v.W : 0u;
@@ -945,7 +955,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         uint32_t hc_row = EP_NONE;
 #pragma unroll
         for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
-        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, (L.g * v.n_keys + k) * v.hc_es + row) = col;
+        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, SHL_OF(M24(L.g, v.n_keys) + k, v.hc_es) + row) = col;
     }
     L.fresh_leader_bk(i, I);
     I.set_status(EST_PREACCEPTING);
@@ -996,7 +1006,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     uint32_t my[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++)
-        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, (g * v.n_keys + kk) * v.hc_es + q) : EP_NONE;
+        my[q] = (MODE == 0 && (uint32_t)q < v.R) ? EA(v.hc, SHL_OF(M24(g, v.n_keys) + kk, v.hc_es) + q) : EP_NONE;
     EPC_SUB(L, 1);
     if (!on) return;
     if (!(row < v.R && !(c < L.get_len(row) && !L.held(row, c)))) return;    // col < start_col analogue
@@ -1021,7 +1031,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     // refresh_highest_cols has nothing to do -- and hc[g][key] is a cache line of this lane's own, not fetched.  Otherwise
     // (the PreAccept was lost) the word is loaded now, one round trip later than the rest.
     const bool hc_known = MODE != 0 && !fresh && I.status() != EST_NULL && I.key() == k;
-    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, (g * v.n_keys + k) * v.hc_es + row);
+    if (MODE != 0 && !hc_known && k != EP_NO_KEY) hc_row = EA(v.hc, SHL_OF(M24(g, v.n_keys) + k, v.hc_es) + row);
     if (MODE == 0) {
         if (k == EP_NO_KEY) {
 #pragma unroll
@@ -1056,7 +1066,7 @@ __device__ __forceinline__ void ep_acceptor_lane_in(EpLaneT<NR, C> &L, bool on, 
     EPC_SUB(L, 4);
     L.store_inst(i, I);
     if (rec) { *rec = I; *stored = true; }
-    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, (g * v.n_keys + k) * v.hc_es + row) = c;   // refresh_highest_cols, dependency.rs:141-167
+    if (k != EP_NO_KEY && !hc_known && (hc_row == EP_NONE || c > hc_row)) EA(v.hc, SHL_OF(M24(g, v.n_keys) + k, v.hc_es) + row) = c;   // refresh_highest_cols, dependency.rs:141-167
     EPC_SUB(L, 5);
     if (MODE == 2) {
         L.logged_commit_slot(row, c, &I);                                    // durability.rs:104-135
@@ -1488,7 +1498,7 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_kernel(const EpView v, con
     }
     r_flags[g] = of; r_vbal[g] = ob; r_status[g] = ost; r_seq[g] = os; r_key[g] = ok;
 #pragma unroll
-    for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < v.R) r_deps[(size_t)q * v.G + g] = d[q];
+    for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < v.R) r_deps[(size_t)M24(q, v.G) + g] = d[q];
 }
 
 // The ExpPrepareReplies to the instance (rows[g], col[g]) I am preparing, one handle_msg_exp_prepare_reply each, peers in
@@ -1528,7 +1538,7 @@ __global__ __launch_bounds__(256) void ep_exp_prepare_replies_kernel(const EpVie
         }
         decision[g] = dec; d_bal[g] = db; d_seq[g] = ds; d_key[g] = dk;
 #pragma unroll
-        for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < R) d_deps[(size_t)q * v.G + g] = dd[q];
+        for (int q = 0; q < EMAXR; q++) if ((uint32_t)q < R) d_deps[(size_t)M24(q, v.G) + g] = dd[q];
     }
     L.flush();
 }
@@ -1959,6 +1969,8 @@ int smr_ep_replica_create(const smr_ep_cfg *cfg, smr_ep_replica **out) {
         most = std::max(most, K * (R <= 6 ? 8 : 16) * G * 4);                   // hc (with the KV words)
         if (most >= (1ull << 32))
             return fail(SMR_ERR_ARG, "epaxos: n_groups * window too large: an array would pass 4 GB (32-bit offsets); shard the groups over more replicas objects");
+        if (W * R * R * PR >= (1ull << 24) || G >= (1ull << 24))                 // (M24: the index arithmetic's 24-bit multiplies)
+            return fail(SMR_ERR_ARG, "epaxos: window * population^2 (* population with recovery) and n_groups must stay below 2^24 (24-bit index arithmetic)");
     }
     smr_ep_replica *e = new smr_ep_replica();
     e->cfg = *cfg;

@@ -92,6 +92,7 @@ inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
 inline int __ffs(int x) { return __builtin_ffs(x); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }   // (the low 24 bits of each: v_mul_u32_u24)
 inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 inline unsigned __lane_id(void) { return threadIdx.x & 63u; }
 inline void __threadfence(void) {}
