@@ -1848,6 +1848,7 @@ def main():
         "kernels": prof, "kernels_pass": "untimed per-round pass" if args.fused else "timed region",
         "rejected_batches": rej, "overflow_groups": overflow,
         "generic_path_batches": [eng.debug_generic_units(r) for r in range(R)],
+        "straggler_list": dict(zip(("capacity", "wanted_by_last_mark_pass"), eng.straggler_stats())) if args.straggler_ticks else None,
         "decisions_per_sec": G * S * args.steps / elapsed,
     }
     # Layout L2 in the line the driver runs: the same workload a few ticks in the spread layout -- the replicas of every group on

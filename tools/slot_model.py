@@ -7,8 +7,9 @@ counts come from tools/kernel_resources.py's table; the measured times beside it
 
 Model: 256 CUs x 4 SIMDs x 512 VGPRs, allocation granule 8, at most 8 wavefronts per SIMD.  A side block is 5 wavefronts
 placed 2 / 1 / 1 / 1 on its CU's SIMDs, one block per listed group, at most one per CU while the list is shorter than the
-CUs.  The driver's command lists ~110 groups per batch of 8 ticks: 9.1 groups per tick meet a leader timeout and stay listed
-for 4 more ticks, so a batch holds the timeouts of 12 ticks (192 = the launch's grid: every block with a group).  A bulk launch of the headline shape (65 536 groups x 5 replicas) is 5120 wavefronts (the tally: 4096)."""
+CUs.  The driver's command lists 70-110 groups per batch of 8 ticks: 9.1 groups per tick meet a leader timeout and stay
+listed for 4 more ticks (`straggler_list` in bench_detail.json: 67 wanted by the run's last mark pass); 192 = the launch's
+grid, every block with a group.  A bulk launch of the headline shape (65 536 groups x 5 replicas) is 5120 wavefronts (the tally: 4096)."""
 import re
 import sys
 
@@ -25,7 +26,7 @@ def per_cu(v, side_v=0, side=(0, 0, 0, 0)):
 
 def main():
     table = open(sys.argv[1]).read()
-    n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 110
+    n_side = int(sys.argv[2]) if len(sys.argv) > 2 else 90
     vg = {}
     for line in table.splitlines():
         m = re.match(r"\S+\s+(?:void )?(\S+(?:<[^>]*>)?)\s+(\d+)\s+\d+\s+\d+\s+(\d+)\s+(\d+)\s+\d+\s*$", line)
