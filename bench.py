@@ -1198,13 +1198,30 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
     us = _time_us(torch, lambda i: ing.ingest(bufs[i % POOL], d_off, d_grp, d_peer), iters)
     stream_bytes = int(off[-1])
     alg = stream_bytes + r["n_acks"] * ACK_DTYPE.itemsize + r["n_hbs"] * wire.HB_DTYPE.itemsize
+    dense = {"what": "smr_wire_ingest_mp: dense lists in the sequential decoder's order across connections (a counting parse in front of the writing one)",
+             "value": r["n_acks"] / (us * 1e-6), "call_us": us,
+             "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
+                          "avg_launch_us": us, "traffic": _sum_traffic("smr::wire_ingest_mp_kernel<false>", "smr::wire_ingest_mp_kernel<true>")}}
+    del ing
+    # round 5: the same parse in ONE pass, a segment per connection (smr_wire_ingest_mp_conn) -- what smr_mp_deliver_acks_conn takes
+    ingc = wire.MpIngestConn(n_conn, stream_bytes, 1, 1, device=dev)
+    for k in range(POOL):
+        ingc.ingest(bufs[k], d_off, d_grp, d_peer)
+    cnt = ingc.cnt.cpu().numpy()
+    assert int(cnt[:, 0].sum()) == n_conn * S and int(cnt[:, 1].sum()) == n_conn // 4 and int(cnt[:, 2].sum()) == 0
+    assert (ingc.status.cpu().numpy() == 0).all() and (ingc.consumed.cpu().numpy() == lens).all()
+    seg0 = ingc.acks.cpu().numpy().view(ACK_DTYPE)[int(off[5]) // 13:int(off[5]) // 13 + S]         # connection 5's segment
+    assert (seg0["slot"] == 300 + 32 * 3 + np.arange(S)).all() and (seg0["group"] == 1).all() and (seg0["peer"] == 2).all()
+    us1 = _time_us(torch, lambda i: ingc.ingest(bufs[i % POOL], d_off, d_grp, d_peer), iters)
     return {"workload": "leader-side receive path of one tick: %d connections (%d groups x 4 peers), %d AcceptReply frames each + a Heartbeat on every "
-                        "fourth, %d MB of frames -> %d smr_mp_ack records" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
-            "value": r["n_acks"] / (us * 1e-6), "unit": "AcceptReply frames/s", "call_us": us, "stream_GBps": stream_bytes / (us * 1e-6) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
-                         "avg_launch_us": us, "traffic": _sum_traffic("smr::wire_ingest_mp_kernel<false>", "smr::wire_ingest_mp_kernel<true>"),
-                         "traffic_source": PMC_NOTE}}
+                        "fourth, %d MB of frames -> %d smr_mp_ack records; one pass, a segment per connection" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
+            "value": r["n_acks"] / (us1 * 1e-6), "unit": "AcceptReply frames/s", "call_us": us1, "stream_GBps": stream_bytes / (us1 * 1e-6) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<true, true> (one smr_wire_ingest_mp_conn call)", "achieved": alg / (us1 * 1e-6) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
+                         "avg_launch_us": us1, "traffic": _leg_traffic("smr::wire_ingest_mp_kernel<true, true>"),
+                         "traffic_source": PMC_NOTE},
+            "dense_lists": dense}
 
 
 def _sum_traffic(*kernels):

@@ -110,6 +110,7 @@ __device__ __forceinline__ void fast_varint(uint64_t x, uint32_t &need, uint32_t
 // One frame as the straight-line path sees it: a payload of 2 .. 24 bytes, all of it in the window, varints below 2^32.
 struct WiFrame {
     uint32_t plen, kind, adv;                    // payload length (garbage unless the header was looked at), SMR_WIRE_*, 8 + length
+    uint64_t glen;                               // the whole frame's length where the general reader took it (SEG: its located record)
     uint64_t f0, f1, f2, f3;                     // the hot variants' fields
     bool fast;                                   // this path takes the frame
     bool slow;                                   // the general reader has to look at it
@@ -166,6 +167,11 @@ struct IngestArgs {
     uint32_t *lane_cnt;                          // [n_waves * 64][3]: pass 1's counts per connection
     uint64_t *counts;                            // [4]: acks, heartbeats / commit notices, others, malformed connections
     uint64_t *consumed; int32_t *status;
+    // one pass, a segment per connection (smr_wire_ingest_mp_conn): connection c's acks from record conn_off[c] / 13 on (an
+    // AcceptReply frame has >= 13 bytes: the segments cannot meet), its first hb_per_conn / other_per_conn heartbeats / located
+    // frames at [c][..]; seg_cnt [n_conn][3] = how many of each
+    uint32_t hb_per_conn, other_per_conn;
+    uint32_t *seg_cnt;
 };
 
 // the sum of x over the lanes before mine (the block is one wavefront)
@@ -187,8 +193,11 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t x) {
     return x;
 }
 
-// WRITE = false: count my connection's records, report consumed / status; true: write them at my bases
-template <bool WRITE>
+// WRITE = false: count my connection's records, report consumed / status; true: write them at my bases.
+// SEG (with WRITE): the only pass -- my bases are my connection's own segments (IngestArgs), nothing is counted first and no
+// record's place depends on another connection; a heartbeat / located frame my segment has no room for stops the walk in
+// front of it (status 2: not malformed -- consumed says where the next call goes on)
+template <bool WRITE, bool SEG = false>
 __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
     __shared__ uint32_t win[WI_ROWS * 64];
     const uint32_t lane = threadIdx.x, c = blockIdx.x * 64 + lane;
@@ -199,7 +208,9 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
     bool done = !live;
     if (live && (end < start || end > A.buf_len)) { st = 1; done = true; }
     uint64_t base0 = 0, base1 = 0, base2 = 0;
-    if (WRITE) {
+    if (SEG) {
+        base0 = start / 13u; base1 = (uint64_t)c * A.hb_per_conn; base2 = (uint64_t)c * A.other_per_conn;
+    } else if (WRITE) {
         // where my records go: the wavefronts before mine -- whole groups of 64 of them out of `super`, the rest of my group
         // out of their own counts, a row per lane -- and the lanes before me
         const uint32_t w = blockIdx.x, g0 = w & ~63u;
@@ -321,7 +332,8 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                             G.hbt = gk == SMR_WIRE_HEARTBEAT || gk == SMR_WIRE_COMMIT_NOTICE;
                             G.kind = gk; G.f0 = g0; G.f1 = g1; G.f2 = g2; G.f3 = g3;
                             G.take = true; G.loc = false;
-                            if (WRITE && !G.ack && !G.hbt) {                        // (located: here, where its 64-bit length is at hand)
+                            G.glen = 8 + gl;
+                            if (WRITE && !SEG && !G.ack && !G.hbt) {                // (located: here, where its 64-bit length is at hand)
                                 const uint64_t at = base2 + (nall - n0 - n1) + (second ? (uint32_t)F[0].loc : 0u);
                                 if (at < A.other_cap) {
                                     smr_wire_other o; o.conn = c; o.kind = gk; o.off = wlo + wo; o.len = 8 + gl;
@@ -336,9 +348,15 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                     if (second) F[1] = G; else F[0] = G;
                 }
             }
+            bool stop = false;                                                      // SEG: a record my segment has no room for: nothing from it on is taken
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const WiFrame &X = F[u];
+                const bool other = X.take && !X.ack && !X.hbt;                      // located by either path
+                if (SEG) {
+                    if (!stop && ((X.hbt && n1 >= A.hb_per_conn) || (other && nall - n0 - n1 >= A.other_per_conn))) { stop = true; st = 2; done = true; }
+                    if (stop) continue;
+                }
                 if (WRITE) {
                     if (X.ack) {                                                    // kept in the window: three dwords over a frame of >= 13 bytes
                         hp[0] = (uint32_t)X.f0; hp[64] = (uint32_t)X.f1; hp[128] = (uint32_t)(X.f1 >> 32);
@@ -350,10 +368,10 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                             h.exec_bar = X.f2; h.snap_bar = X.f3;
                             A.hbs[at] = h;
                         }
-                    } else if (X.loc) {                                             // a short frame the device only locates
+                    } else if (SEG ? other : X.loc) {                               // a frame the device only locates (SEG: the general reader's too)
                         const uint64_t at = base2 + (nall - n0 - n1);
                         if (at < A.other_cap) {
-                            smr_wire_other o; o.conn = c; o.kind = X.kind; o.off = wlo0 + woff; o.len = X.adv;
+                            smr_wire_other o; o.conn = c; o.kind = X.kind; o.off = wlo0 + woff; o.len = X.loc ? X.adv : X.glen;
                             A.others[at] = o;
                         }
                     }
@@ -362,6 +380,7 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                 woff += X.take ? X.adv : 0u;
                 r8 -= X.take ? (int64_t)X.adv : 0;
             }
+            if (SEG && stop && wlo != wlo0) { r8 += (int64_t)(wlo - wlo0); wlo = wlo0; }   // (a very long frame stepped over, then not taken)
         }
         if (WRITE) {                                                                // this window's AcceptReplies leave, a lane's back to back
             const uint32_t held = (uint32_t)(hp - col) / 192;
@@ -380,6 +399,12 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
                     *(smr_mp_ack *)dst = a1;
                 }
             }
+        }
+    }
+    if (SEG) {
+        if (live) {
+            A.consumed[c] = wlo + woff - start; A.status[c] = st;
+            A.seg_cnt[(size_t)c * 3 + 0] = n0; A.seg_cnt[(size_t)c * 3 + 1] = n1; A.seg_cnt[(size_t)c * 3 + 2] = nall - n0 - n1;
         }
     }
     if (!WRITE) {
@@ -431,6 +456,29 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
                  others_dev, other_cap, super, wave_cnt, (uint32_t *)(wave_cnt + (size_t)n_waves * 3), counts_dev, consumed_dev, status_dev};
     hipLaunchKernelGGL(wire_ingest_mp_kernel<false>, dim3(n_waves), dim3(64), 0, st, A);
     hipLaunchKernelGGL(wire_ingest_mp_kernel<true>, dim3(n_waves), dim3(64), 0, st, A);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+// One pass, a segment per connection (round 5).  The two-pass call above exists for ONE property: its lists are dense and in the
+// sequential decoder's order across connections -- which costs a whole counting parse (76 of the call's 214 us at 262 144
+// connections).  Nothing downstream needs it: the reference handles a connection's messages in order and connections in whatever
+// order its event loop meets them (transport.rs:404-470), and smr_mp_deliver_acks_conn takes the segments as they are.
+int smr_wire_ingest_mp_conn(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
+                            const uint8_t *conn_peer_dev, uint32_t n_conn, smr_mp_ack *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
+                            uint32_t hb_per_conn, smr_wire_other *others_dev, uint32_t other_per_conn, uint32_t *cnt_dev, uint64_t *consumed_dev,
+                            int32_t *status_dev, void *stream) {
+    if ((n_conn && (!conn_off_dev || !conn_group_dev || !conn_peer_dev || !cnt_dev)) || !consumed_dev || !status_dev || (buf_len && !buf_dev) ||
+        (ack_cap && !acks_dev) || (hb_per_conn && !hbs_dev) || (other_per_conn && !others_dev))
+        return fail(SMR_ERR_ARG, "wire ingest: null argument");
+    if ((uintptr_t)buf_dev & 15) return fail(SMR_ERR_ARG, "wire ingest: the byte buffer must be 16-byte aligned");
+    if (ack_cap < buf_len / 13 + 1)
+        return fail(SMR_ERR_ARG, "wire ingest: the ack array must hold buf_len / 13 + 1 records (a segment per connection, an AcceptReply frame has >= 13 bytes)");
+    if (n_conn == 0) return SMR_OK;
+    const uint32_t n_waves = (n_conn + 63) / 64;
+    IngestArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, acks_dev, ack_cap, hbs_dev, (uint64_t)n_conn * hb_per_conn,
+                 others_dev, (uint64_t)n_conn * other_per_conn, nullptr, nullptr, nullptr, nullptr, consumed_dev, status_dev, hb_per_conn, other_per_conn, cnt_dev};
+    hipLaunchKernelGGL((wire_ingest_mp_kernel<true, true>), dim3(n_waves), dim3(64), 0, (hipStream_t)stream, A);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

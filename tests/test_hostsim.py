@@ -173,6 +173,16 @@ def test_wire_ingest_kernels_on_the_host(sim, oracle):
         te.test_frames_laid_out_by_hand_give_records_laid_out_by_hand("cpu")     # expected records written out by the test
 
 
+def test_wire_ingest_one_pass_segments_on_the_host(sim, oracle):
+    """the same traffic parsed in ONE pass into a segment per connection (smr_wire_ingest_mp_conn), and smr_mp_deliver_acks_conn"""
+    import test_zz_wire_ingest_conn_gpu as t
+    with sim.patched():
+        t.test_segments_are_the_sequential_decoders_lists("cpu")
+        t.test_a_full_segment_stops_the_connection_in_front_of_the_frame("cpu")
+        t.test_edges("cpu")
+        t.test_accept_replies_over_the_wire_in_segments("cpu", oracle)
+
+
 def test_reply_ingest_kernels_on_the_host(sim, oracle):
     """Raft AppendEntriesReply / EPaxos PreAcceptReply frames parsed into the engines' [R][G] arrays (f.1, round 3): frame by
     frame against what the test wrote, and inside the closed-loop clusters against the oracles"""
