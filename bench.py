@@ -1202,7 +1202,8 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
              "value": r["n_acks"] / (us * 1e-6), "call_us": us,
              "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<false> + <true> (one smr_wire_ingest_mp call)", "achieved": alg / (us * 1e-6) / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
-                          "avg_launch_us": us, "traffic": _sum_traffic("smr::wire_ingest_mp_kernel<false>", "smr::wire_ingest_mp_kernel<true>")}}
+                          "avg_launch_us": us, "traffic": _sum_traffic("smr::wire_ingest_mp_kernel<false, false>", "smr::wire_ingest_mp_kernel<true, false>") or
+                                                         _sum_traffic("smr::wire_ingest_mp_kernel<false>", "smr::wire_ingest_mp_kernel<true>")}}   # (the names before the template's second parameter)
     del ing
     # round 5: the same parse in ONE pass, a segment per connection (smr_wire_ingest_mp_conn) -- what smr_mp_deliver_acks_conn takes
     ingc = wire.MpIngestConn(n_conn, stream_bytes, 1, 1, device=dev)
