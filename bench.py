@@ -1212,11 +1212,12 @@ def wire_ingest_leg(torch, dev, G=65536, S=32, iters=12):
     cnt = ingc.cnt.cpu().numpy()
     assert int(cnt[:, 0].sum()) == n_conn * S and int(cnt[:, 1].sum()) == n_conn // 4 and int(cnt[:, 2].sum()) == 0
     assert (ingc.status.cpu().numpy() == 0).all() and (ingc.consumed.cpu().numpy() == lens).all()
-    seg0 = ingc.acks.cpu().numpy().view(ACK_DTYPE)[int(off[5]) // 13:int(off[5]) // 13 + S]         # connection 5's segment
-    assert (seg0["slot"] == 300 + 32 * 3 + np.arange(S)).all() and (seg0["group"] == 1).all() and (seg0["peer"] == 2).all()
+    seg0 = ingc.acks.cpu().numpy().view(wire.ACK12_DTYPE)[int(off[5]) // 13:int(off[5]) // 13 + S]  # connection 5's segment: (slot, ballot) records
+    assert (seg0["slot"] == 300 + 32 * 3 + np.arange(S)).all() and (seg0["ballot_lo"] == 0x101).all() and (seg0["ballot_hi"] == 0).all()
     us1 = _time_us(torch, lambda i: ingc.ingest(bufs[i % POOL], d_off, d_grp, d_peer), iters)
     return {"workload": "leader-side receive path of one tick: %d connections (%d groups x 4 peers), %d AcceptReply frames each + a Heartbeat on every "
-                        "fourth, %d MB of frames -> %d smr_mp_ack records; one pass, a segment per connection" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
+                        "fourth, %d MB of frames -> %d AcceptReply records; one pass, a segment per connection, 12-byte (slot, ballot) records (the group "
+                        "and the peer are the connection's): the roofline's bytes stay the stream + 24 B per record, what the dense list carries" % (n_conn, G, S, stream_bytes // 1000000, r["n_acks"]),
             "value": r["n_acks"] / (us1 * 1e-6), "unit": "AcceptReply frames/s", "call_us": us1, "stream_GBps": stream_bytes / (us1 * 1e-6) / 1e9,
             "roofline": {"bound": "hbm", "kernel": "wire_ingest_mp_kernel<true, true> (one smr_wire_ingest_mp_conn call)", "achieved": alg / (us1 * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,

@@ -355,10 +355,12 @@ typedef struct {
 } smr_mp_ack;               /* 24 bytes */
 int smr_mp_deliver_acks(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_dev, uint64_t n, uint64_t *dropped_dev,
                         void *stream);
-/* smr_mp_deliver_acks for records in one segment per connection, as smr_wire_ingest_mp_conn leaves them: connection c's
- * cnt_dev[3 * c] records from record conn_off_dev[c] / 13 on (records at or past ack_cap are not there). */
-int smr_mp_deliver_acks_conn(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_dev, uint64_t ack_cap, const uint64_t *conn_off_dev,
-                             const uint32_t *cnt_dev, uint32_t n_conn, uint64_t *dropped_dev, void *stream);
+/* smr_mp_deliver_acks for records in one segment per connection, as smr_wire_ingest_mp_conn leaves them: connection c -- replica
+ * conn_peer_dev[c] of group conn_group_dev[c] -- has cnt_dev[3 * c] 12-byte records { slot, ballot lo, ballot hi }
+ * (smr_wire_ack12, declared with that call) from record conn_off_dev[c] / 13 on (records at or past ack_cap are not there). */
+int smr_mp_deliver_acks_conn(smr_mp_cluster *c, uint8_t rep, const void *acks12_dev, uint64_t ack_cap, const uint64_t *conn_off_dev,
+                             const uint32_t *conn_group_dev, const uint8_t *conn_peer_dev, const uint32_t *cnt_dev, uint32_t n_conn,
+                             uint64_t *dropped_dev, void *stream);
 int smr_mp_collect_acks(smr_mp_cluster *c, uint8_t rep, smr_mp_ack *out_dev, uint64_t cap, uint64_t *n_dev, void *stream);
 int smr_mp_clear_acks(smr_mp_cluster *c, uint8_t rep, void *stream);
 
@@ -1193,15 +1195,19 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
  * the sequential decoder's order ACROSS connections, which costs a counting parse of the whole buffer in front of the writing one.
  * The reference promises less: a connection's messages in order, connections in whatever order the event loop meets them
  * (transport.rs:404-470).  Here every connection has segments of its own and nothing is counted first:
- *   acks_dev    connection c's smr_mp_ack records from record conn_off[c] / 13 on (an AcceptReply frame has >= 13 bytes, so the
- *               segments cannot meet; ack_cap >= buf_len / 13 + 1 is required) -- smr_mp_deliver_acks_conn takes them as they are;
+ *   acks_dev    connection c's AcceptReplies as smr_wire_ack12 { slot, ballot } -- the group and the peer are the connection's --
+ *               from record conn_off[c] / 13 on (an AcceptReply frame has >= 13 bytes, so the segments cannot meet; ack_cap >=
+ *               buf_len / 13 + 1 records is required); smr_mp_deliver_acks_conn takes them as they are;
  *   hbs_dev     [n_conn][hb_per_conn], others_dev [n_conn][other_per_conn]: c's first Heartbeats / CommitNotices and located frames;
  *               one more than that stops the connection IN FRONT of the frame (status_dev[c] = 2, not malformed: consumed_dev[c]
  *               says where the next call goes on -- what an incomplete frame does too);
  *   cnt_dev     u32 [n_conn][3]: how many of each connection c has (sum them where a total is wanted).
  * Frame rules, consumed_dev / status_dev (1 = malformed) and the records themselves are smr_wire_ingest_mp's; no scratch. */
+typedef struct {
+    uint32_t slot, ballot_lo, ballot_hi;     /* PeerMsg::AcceptReply { slot, ballot } of the connection the segment belongs to */
+} smr_wire_ack12;                            /* 12 bytes */
 int smr_wire_ingest_mp_conn(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                            const uint8_t *conn_peer_dev, uint32_t n_conn, smr_mp_ack *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
+                            const uint8_t *conn_peer_dev, uint32_t n_conn, smr_wire_ack12 *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
                             uint32_t hb_per_conn, smr_wire_other *others_dev, uint32_t other_per_conn, uint32_t *cnt_dev, uint64_t *consumed_dev,
                             int32_t *status_dev, void *stream);
 

@@ -234,7 +234,7 @@ SYMBOLS = [
     ("smr_mp_spread_abort_tick", _i, [_vp]),
     ("smr_mp_ack_matrix", _i, [_vp, _u8, C.POINTER(_vp), C.POINTER(_u64)]),
     ("smr_mp_deliver_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),
-    ("smr_mp_deliver_acks_conn", _i, [_vp, _u8, _vp, _u64, _vp, _vp, _u32, _vp, _vp]),
+    ("smr_mp_deliver_acks_conn", _i, [_vp, _u8, _vp, _u64, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     ("smr_mp_collect_acks", _i, [_vp, _u8, _vp, _u64, _vp, _vp]),
     ("smr_mp_clear_acks", _i, [_vp, _u8, _vp]),
     ("smr_mp_read_group_state", _i, [_vp, _u32, _u8, C.POINTER(MpGroupState)]),

@@ -1793,30 +1793,33 @@ __global__ __launch_bounds__(256) void mp_deliver_acks_kernel(const MpParams *__
     if (__lane_id() == 0 && drop && dropped) atomicAdd(dropped, (unsigned long long)drop);
 }
 
-// the same for records in one segment per connection (smr_wire_ingest_mp_conn: connection c's cnt[c][0] records from record
-// conn_off[c] / 13 on): a wavefront per connection, a lane per record of it
+// the same for records in one segment per connection (smr_wire_ingest_mp_conn: connection c's cnt[c][0] 12-byte records
+// { slot, ballot } from record conn_off[c] / 13 on; the group and the peer are the connection's): a wavefront per connection, a
+// lane per record of it
 __global__ __launch_bounds__(256) void mp_deliver_acks_conn_kernel(const MpParams *__restrict__ Pp, int par, uint32_t rep,
-                                                                   const smr_mp_ack *__restrict__ recs, uint64_t cap, const uint64_t *__restrict__ conn_off,
+                                                                   const uint32_t *__restrict__ recs, uint64_t cap, const uint64_t *__restrict__ conn_off,
+                                                                   const uint32_t *__restrict__ conn_group, const uint8_t *__restrict__ conn_peer,
                                                                    const uint32_t *__restrict__ cnt, uint32_t n_conn,
                                                                    unsigned long long *__restrict__ dropped) {
     const MpParams &P = *Pp;
     const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     uint32_t drop = 0;
     if (c < n_conn) {
-        const uint32_t n = cnt[(size_t)c * 3];
+        const uint32_t n = cnt[(size_t)c * 3], group = conn_group[c], peer = conn_peer[c];
         const uint64_t base = conn_off[c] / 13u;
         const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
+        const bool mine = group < P.G && peer < P.R && peer != rep;
         for (uint32_t j = lane; j < n; j += 64u) {
             if (base + j >= cap) break;
-            const smr_mp_ack a = recs[base + j];
+            const uint32_t *r = recs + (base + j) * 3u;
             uint32_t d = 1;
-            if (a.group < P.G && a.peer < P.R && a.peer != rep) {
-                const uint32_t e = find_accept_entry(P, v, par, a.group, a.slot, a.ballot);
+            if (mine) {
+                const uint32_t e = find_accept_entry(P, v, par, group, r[0], (uint64_t)r[1] | ((uint64_t)r[2] << 32));
                 if (e != NO_ENTRY) {
                     d = 0;
-                    if (e < 64u) atomicOr((unsigned long long *)&ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, a.peer, a.group)], 1ull << e);
+                    if (e < 64u) atomicOr((unsigned long long *)&ack_bits_base(v.ack(), P.cap, P.G)[tix(MAXR, peer, group)], 1ull << e);
                     else
-                    v.ack()[ack_ix(P.cap, e, a.peer, a.group)] = 1;
+                    v.ack()[ack_ix(P.cap, e, peer, group)] = 1;
                 }
             }
             drop += d;
@@ -2564,12 +2567,14 @@ int smr_mp_deliver_acks(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_d
     return SMR_OK;
 }
 
-int smr_mp_deliver_acks_conn(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_dev, uint64_t ack_cap, const uint64_t *conn_off_dev,
-                             const uint32_t *cnt_dev, uint32_t n_conn, uint64_t *dropped_dev, void *stream) {
-    if (!c || rep >= c->cfg.population || (n_conn && (!acks_dev || !conn_off_dev || !cnt_dev))) return fail(SMR_ERR_ARG, "mp: bad argument");
+int smr_mp_deliver_acks_conn(smr_mp_cluster *c, uint8_t rep, const void *acks12_dev, uint64_t ack_cap, const uint64_t *conn_off_dev,
+                             const uint32_t *conn_group_dev, const uint8_t *conn_peer_dev, const uint32_t *cnt_dev, uint32_t n_conn,
+                             uint64_t *dropped_dev, void *stream) {
+    if (!c || rep >= c->cfg.population || (n_conn && (!acks12_dev || !conn_off_dev || !conn_group_dev || !conn_peer_dev || !cnt_dev)))
+        return fail(SMR_ERR_ARG, "mp: bad argument");
     if (!n_conn) return SMR_OK;
     hipLaunchKernelGGL(mp_deliver_acks_conn_kernel, dim3((n_conn + 3) / 4), dim3(256), 0, (hipStream_t)stream, c->dp, c->par, (uint32_t)rep,
-                       acks_dev, ack_cap, conn_off_dev, cnt_dev, n_conn, (unsigned long long *)dropped_dev);
+                       (const uint32_t *)acks12_dev, ack_cap, conn_off_dev, conn_group_dev, conn_peer_dev, cnt_dev, n_conn, (unsigned long long *)dropped_dev);
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -167,9 +167,9 @@ struct IngestArgs {
     uint32_t *lane_cnt;                          // [n_waves * 64][3]: pass 1's counts per connection
     uint64_t *counts;                            // [4]: acks, heartbeats / commit notices, others, malformed connections
     uint64_t *consumed; int32_t *status;
-    // one pass, a segment per connection (smr_wire_ingest_mp_conn): connection c's acks from record conn_off[c] / 13 on (an
-    // AcceptReply frame has >= 13 bytes: the segments cannot meet), its first hb_per_conn / other_per_conn heartbeats / located
-    // frames at [c][..]; seg_cnt [n_conn][3] = how many of each
+    // one pass, a segment per connection (smr_wire_ingest_mp_conn): connection c's acks -- 12-byte smr_wire_ack12 records behind
+    // `acks` -- from record conn_off[c] / 13 on (an AcceptReply frame has >= 13 bytes: the segments cannot meet), its first
+    // hb_per_conn / other_per_conn heartbeats / located frames at [c][..]; seg_cnt [n_conn][3] = how many of each
     uint32_t hb_per_conn, other_per_conn;
     uint32_t *seg_cnt;
 };
@@ -382,7 +382,28 @@ __global__ __launch_bounds__(64) void wire_ingest_mp_kernel(IngestArgs A) {
             }
             if (SEG && stop && wlo != wlo0) { r8 += (int64_t)(wlo - wlo0); wlo = wlo0; }   // (a very long frame stepped over, then not taken)
         }
-        if (WRITE) {                                                                // this window's AcceptReplies leave, a lane's back to back
+        if (SEG) {
+            // a segment's records are (slot, ballot) alone -- 12 bytes, smr_wire_ack12: the group and the peer are the connection's --
+            // so a lane's records of a window are the staged dwords as they stand, four records = three 16-byte stores.  What the
+            // records cost is the stores' line requests, not their bytes alone (a probe of the dense call's second pass without its
+            // stores ran 76 instead of 151 us): half the bytes, half the requests
+            const uint32_t held = (uint32_t)(hp - col) / 192;
+            const uint64_t first = base0 + (n0 - held);
+            const uint32_t fits = first >= A.ack_cap ? 0u : A.ack_cap - first < held ? (uint32_t)(A.ack_cap - first) : held;
+            uint32_t *dst = (uint32_t *)A.acks + first * 3u;
+            const uint32_t nd = 3u * fits;                                          // staged dwords to store: rows 0 .. nd - 1 of my column
+            const uint32_t *rp = col;
+            for (uint32_t d = 0; __ballot(d < nd); d += 4, dst += 4, rp += 256) {
+                if (d + 4 <= nd) {
+                    const wi_u32x4 w{rp[0], rp[64], rp[128], rp[192]};
+                    __builtin_memcpy(dst, &w, 16);
+                } else if (d < nd) {
+                    dst[0] = rp[0];
+                    if (d + 1 < nd) dst[1] = rp[64];
+                    if (d + 2 < nd) dst[2] = rp[128];
+                }
+            }
+        } else if (WRITE) {                                                         // this window's AcceptReplies leave, a lane's back to back
             const uint32_t held = (uint32_t)(hp - col) / 192;
             const uint64_t first = base0 + (n0 - held);
             const uint32_t fits = first >= A.ack_cap ? 0u : A.ack_cap - first < held ? (uint32_t)(A.ack_cap - first) : held;
@@ -465,7 +486,7 @@ int smr_wire_ingest_mp(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t 
 // connections).  Nothing downstream needs it: the reference handles a connection's messages in order and connections in whatever
 // order its event loop meets them (transport.rs:404-470), and smr_mp_deliver_acks_conn takes the segments as they are.
 int smr_wire_ingest_mp_conn(const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev, const uint32_t *conn_group_dev,
-                            const uint8_t *conn_peer_dev, uint32_t n_conn, smr_mp_ack *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
+                            const uint8_t *conn_peer_dev, uint32_t n_conn, smr_wire_ack12 *acks_dev, uint64_t ack_cap, smr_wire_hb *hbs_dev,
                             uint32_t hb_per_conn, smr_wire_other *others_dev, uint32_t other_per_conn, uint32_t *cnt_dev, uint64_t *consumed_dev,
                             int32_t *status_dev, void *stream) {
     if ((n_conn && (!conn_off_dev || !conn_group_dev || !conn_peer_dev || !cnt_dev)) || !consumed_dev || !status_dev || (buf_len && !buf_dev) ||
@@ -476,7 +497,7 @@ int smr_wire_ingest_mp_conn(const uint8_t *buf_dev, uint64_t buf_len, const uint
         return fail(SMR_ERR_ARG, "wire ingest: the ack array must hold buf_len / 13 + 1 records (a segment per connection, an AcceptReply frame has >= 13 bytes)");
     if (n_conn == 0) return SMR_OK;
     const uint32_t n_waves = (n_conn + 63) / 64;
-    IngestArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, acks_dev, ack_cap, hbs_dev, (uint64_t)n_conn * hb_per_conn,
+    IngestArgs A{buf_dev, buf_len, conn_off_dev, conn_group_dev, conn_peer_dev, n_conn, (smr_mp_ack *)acks_dev, ack_cap, hbs_dev, (uint64_t)n_conn * hb_per_conn,
                  others_dev, (uint64_t)n_conn * other_per_conn, nullptr, nullptr, nullptr, nullptr, consumed_dev, status_dev, hb_per_conn, other_per_conn, cnt_dev};
     hipLaunchKernelGGL((wire_ingest_mp_kernel<true, true>), dim3(n_waves), dim3(64), 0, (hipStream_t)stream, A);
     SMR_HIP_TRY(hipGetLastError());

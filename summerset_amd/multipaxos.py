@@ -114,9 +114,10 @@ class MultiPaxosCluster:
         and R3); records answering no Accept of this tick are ignored and counted in the device int64 `dropped`"""
         check(self._L.smr_mp_deliver_acks(self._h, rep, _ptr(recs), int(n), _ptr(dropped), stream_ptr(stream)))
 
-    def deliver_acks_conn(self, rep, ing, conn_off, dropped=None, stream=None):
-        """`deliver_acks` for the per-connection segments of a `wire.MpIngestConn` (smr_mp_deliver_acks_conn)"""
-        check(self._L.smr_mp_deliver_acks_conn(self._h, rep, _ptr(ing.acks), ing.ack_cap, _ptr(conn_off), _ptr(ing.cnt), ing.n_conn,
+    def deliver_acks_conn(self, rep, ing, dropped=None, stream=None):
+        """`deliver_acks` for the per-connection segments of a `wire.MpIngestConn`'s last call (smr_mp_deliver_acks_conn)"""
+        off, grp, peer = ing.conn
+        check(self._L.smr_mp_deliver_acks_conn(self._h, rep, _ptr(ing.acks), ing.ack_cap, _ptr(off), _ptr(grp), _ptr(peer), _ptr(ing.cnt), ing.n_conn,
                                                _ptr(dropped), stream_ptr(stream)))
 
     def clear_acks(self, rep, stream=None):

@@ -439,25 +439,29 @@ class MpIngest:
 
 
 
+ACK12_DTYPE = _np.dtype([("slot", "<u4"), ("ballot_lo", "<u4"), ("ballot_hi", "<u4")])        # smr_wire_ack12
+
+
 class MpIngestConn:
-    """`MpIngest` in ONE pass (smr_wire_ingest_mp_conn): every connection has segments of its own -- connection c's AcceptReply
-    records in `acks` from record conn_off[c] // 13 on (what `MultiPaxosCluster.deliver_acks_conn` takes as it is), its first
-    `hb_per_conn` Heartbeats / CommitNotices in `hbs[c]`, its first `other_per_conn` located frames in `others[c]`, and
-    `cnt[c] = (acks, hbs, others)`.  One record more than a segment holds stops the connection in front of that frame
-    (status 2; `consumed[c]` says where the next call goes on).  `max_buf_len` sizes the ack array (max_buf_len // 13 + 1)."""
+    """`MpIngest` in ONE pass (smr_wire_ingest_mp_conn): every connection has segments of its own -- connection c's AcceptReplies
+    as 12-byte (slot, ballot) records (ACK12_DTYPE: the group and the peer are the connection's) in `acks` from record
+    conn_off[c] // 13 on (what `MultiPaxosCluster.deliver_acks_conn` takes as it is), its first `hb_per_conn` Heartbeats /
+    CommitNotices in `hbs[c]`, its first `other_per_conn` located frames in `others[c]`, and `cnt[c] = (acks, hbs, others)`.
+    One record more than a segment holds stops the connection in front of that frame (status 2; `consumed[c]` says where the
+    next call goes on).  `max_buf_len` sizes the ack array (max_buf_len // 13 + 1 records)."""
 
     def __init__(self, n_conn, max_buf_len, hb_per_conn, other_per_conn, device):
         import torch
-        from .multipaxos import ACK_DTYPE
         self._L, self.n_conn, self.device = _lib.load(), int(n_conn), device
         self.ack_cap = int(max_buf_len) // 13 + 1
         self.hb_per_conn, self.other_per_conn = int(hb_per_conn), int(other_per_conn)
-        self.acks = torch.zeros(self.ack_cap * ACK_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.acks = torch.zeros(self.ack_cap * ACK12_DTYPE.itemsize, dtype=torch.uint8, device=device)
         self.hbs = torch.zeros(max(self.n_conn * self.hb_per_conn, 1) * HB_DTYPE.itemsize, dtype=torch.uint8, device=device)
         self.others = torch.zeros(max(self.n_conn * self.other_per_conn, 1) * OTHER_DTYPE.itemsize, dtype=torch.uint8, device=device)
         self.cnt = torch.zeros((max(self.n_conn, 1), 3), dtype=torch.int32, device=device)
         self.consumed = torch.zeros(max(n_conn, 1), dtype=torch.int64, device=device)
         self.status = torch.zeros(max(n_conn, 1), dtype=torch.int32, device=device)
+        self.conn = None                                         # (conn_off, conn_group, conn_peer) of the last call
 
     def ingest(self, buf, conn_off, conn_group, conn_peer, stream=None):
         assert conn_off.numel() == self.n_conn + 1 and conn_group.numel() == self.n_conn and conn_peer.numel() == self.n_conn
@@ -466,19 +470,28 @@ class MpIngestConn:
         check(self._L.smr_wire_ingest_mp_conn(p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_group), p(conn_peer), self.n_conn,
                                               p(self.acks), self.ack_cap, p(self.hbs), self.hb_per_conn, p(self.others), self.other_per_conn,
                                               p(self.cnt), p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
+        self.conn = (conn_off, conn_group, conn_peer)
 
-    def results(self, conn_off):
-        """host copies (synchronises): the segments gathered connection by connection -- the lists `MpIngest.results` gives
-        where no connection was stopped -- plus cnt, consumed, status"""
+    def results(self):
+        """host copies (synchronises) of the last call: the segments gathered connection by connection and widened to
+        multipaxos.ACK_DTYPE -- the lists `MpIngest.results` gives where no connection was stopped -- plus cnt, consumed, status"""
         from .multipaxos import ACK_DTYPE
-        off = _np.asarray(conn_off.cpu().numpy() if hasattr(conn_off, "cpu") else conn_off, dtype=_np.int64)
-        cnt = self.cnt.cpu().numpy()[:self.n_conn].astype(_np.int64)
-        acks, hbs, others = (self.acks.cpu().numpy().view(ACK_DTYPE), self.hbs.cpu().numpy().view(HB_DTYPE), self.others.cpu().numpy().view(OTHER_DTYPE))
-        take = lambda arr, first, n: arr[_np.concatenate([_np.arange(f, f + k) for f, k in zip(first, n)] or [_np.zeros(0, _np.int64)]).astype(_np.int64)]   # noqa: E731
-        c = _np.arange(self.n_conn, dtype=_np.int64)
-        return {"cnt": cnt, "acks": take(acks, off[:-1] // 13, cnt[:, 0]), "hbs": take(hbs, c * self.hb_per_conn, cnt[:, 1]),
-                "others": take(others, c * self.other_per_conn, cnt[:, 2]),
-                "consumed": self.consumed.cpu().numpy()[:self.n_conn].copy(), "status": self.status.cpu().numpy()[:self.n_conn].copy()}
+        n = self.n_conn
+        off = self.conn[0].cpu().numpy().astype(_np.int64) if n else _np.zeros(1, _np.int64)
+        grp = self.conn[1].cpu().numpy().view(_np.uint32) if n else _np.zeros(0, _np.uint32)
+        peer = self.conn[2].cpu().numpy() if n else _np.zeros(0, _np.uint8)
+        cnt = self.cnt.cpu().numpy()[:n].astype(_np.int64)
+        a12, hbs, others = (self.acks.cpu().numpy().view(ACK12_DTYPE), self.hbs.cpu().numpy().view(HB_DTYPE), self.others.cpu().numpy().view(OTHER_DTYPE))
+        idx = lambda first, k: _np.concatenate([_np.arange(f, f + m) for f, m in zip(first, k)] or [_np.zeros(0, _np.int64)]).astype(_np.int64)   # noqa: E731
+        c = _np.arange(n, dtype=_np.int64)
+        seg = a12[idx(off[:-1] // 13, cnt[:, 0])]
+        acks = _np.zeros(len(seg), ACK_DTYPE)
+        acks["slot"] = seg["slot"]
+        acks["ballot"] = seg["ballot_lo"].astype(_np.uint64) | (seg["ballot_hi"].astype(_np.uint64) << _np.uint64(32))
+        acks["group"] = _np.repeat(grp, cnt[:, 0]); acks["peer"] = _np.repeat(peer, cnt[:, 0])
+        return {"cnt": cnt, "acks": acks, "hbs": hbs[idx(c * self.hb_per_conn, cnt[:, 1])], "others": others[idx(c * self.other_per_conn, cnt[:, 2])],
+                "consumed": self.consumed.cpu().numpy()[:n].copy(), "status": self.status.cpu().numpy()[:n].copy()}
+
 
 # ---- Raft / EPaxos reply traffic parsed on the device (csrc/wire_ingest_replies.hip) ----
 class ReplyIngest:

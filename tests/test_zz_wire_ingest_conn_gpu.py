@@ -1,4 +1,5 @@
-"""`smr_wire_ingest_mp_conn` (round 5): MultiPaxos peer traffic parsed in ONE pass into a segment per connection, and
+"""`smr_wire_ingest_mp_conn` (round 5): MultiPaxos peer traffic parsed in ONE pass into a segment per connection (AcceptReplies as
+12-byte (slot, ballot) records: the group and the peer are the connection's; `MpIngestConn.results` widens them), and
 `smr_mp_deliver_acks_conn`, which takes the segments as they are.  The frames and their rules are `smr_wire_ingest_mp`'s
 (tests/test_zz_wire_ingest_gpu.py): here the segments, gathered connection by connection, must BE the two-pass call's dense
 lists -- the sequential decoder's -- wherever no connection was stopped, and a connection that has one Heartbeat or located
@@ -59,7 +60,7 @@ def _ingest_conn(wire, cuda, streams, groups, peers, hb_per, other_per, slack=0)
     ing = wire.MpIngestConn(n, len(blob) + slack, hb_per, other_per, device=cuda)
     d_off = torch.from_numpy(off).to(cuda)
     ing.ingest(buf, d_off, torch.from_numpy(np.asarray(groups, np.uint32).view(np.int32)).to(cuda), torch.from_numpy(np.asarray(peers, np.uint8)).to(cuda))
-    return ing, d_off, ing.results(off)
+    return ing, d_off, ing.results()
 
 
 def _same(got, want):
@@ -146,7 +147,7 @@ def test_edges(cuda):
     buf = torch.from_numpy(np.frombuffer(f, np.uint8).copy()).to(cuda)
     off = torch.tensor([0, len(f), len(f) + 40], dtype=torch.int64, device=cuda)
     ing.ingest(buf, off, torch.tensor([5, 6], dtype=torch.int32, device=cuda), torch.tensor([1, 2], dtype=torch.uint8, device=cuda))
-    got = ing.results(off)
+    got = ing.results()
     assert list(got["cnt"][:, 0]) == [1, 0] and list(got["status"]) == [0, 1] and list(got["consumed"]) == [13, 0]
     small = wire.MpIngestConn(1, 13, 1, 1, device=cuda)
     small.ack_cap = 1                                                          # (buf_len // 13 + 1 = 2 are asked for)
@@ -186,7 +187,7 @@ def _acks_over_the_wire_conn(eng, cuda, G, R, cap, t):
         eng.clear_acks(r)
         dropped = torch.zeros(1, dtype=torch.int64, device=cuda)
         if conns:
-            eng.deliver_acks_conn(r, ing, d_off, dropped)
+            eng.deliver_acks_conn(r, ing, dropped)
         eng.collect_acks(r, out, n)
         assert int(dropped.item()) == 0 and int(n.item()) == n0, (t, r)
         back = out.cpu().numpy().view(ACK_DTYPE)[:n0]
