@@ -6,6 +6,11 @@
 TAG=${1:-r9z}
 mkdir -p gpurun_out
 R=$PWD
+# 0. is this box's GPU sane?  (round 5's third take met one that faulted in every process; every step below then ran into its own
+# timeout and the call used up the round's device minutes.)  One small launch of the hot path against the oracle, or nothing.
+if ! timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; then
+  echo "final_record: smoke() failed or hung on this box -- not taking a record"; tail -5 gpurun_out/${TAG}_smoke.log; exit 3
+fi
 # 1. the PMC passes first: bench.py reads profiles/${TAG}_pmc_traffic*.json for every `traffic` field of its line
 ( cd /tmp && export TMPDIR=/tmp
   timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- python $R/tools/pmc_probe.py --extra > /dev/null 2>&1
@@ -21,7 +26,7 @@ for leg in rspaxos_payload craft_payload; do
   cp gpurun_out/${TAG}_pmc_traffic_${leg}_leg.json profiles/${TAG}_pmc_traffic_${leg}_leg.json
 done
 # 2. the suite, the bench lines
-timeout 1500 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -40 > gpurun_out/${TAG}_gputests.log
+timeout 900 python -m pytest tests -m gpu -q -rxX -p no:cacheprovider --durations=8 2>&1 | tail -40 > gpurun_out/${TAG}_gputests.log
 tail -3 gpurun_out/${TAG}_gputests.log
 timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; cp bench_detail.json gpurun_out/${TAG}_bench_detail.json; tail -c 300 gpurun_out/${TAG}_bench.json; echo
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_command.json 2>> gpurun_out/${TAG}_bench.err; cp bench_detail.json gpurun_out/${TAG}_bench_driver_command_detail.json
