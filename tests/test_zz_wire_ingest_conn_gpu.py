@@ -58,9 +58,22 @@ def _ingest_conn(wire, cuda, streams, groups, peers, hb_per, other_per, slack=0)
     blob = b"".join(streams)
     buf = torch.from_numpy(np.frombuffer(blob, np.uint8).copy()).to(cuda) if blob else torch.zeros(0, dtype=torch.uint8, device=cuda)
     ing = wire.MpIngestConn(n, len(blob) + slack, hb_per, other_per, device=cuda)
+    # every output array sits in front of 256 bytes of 0xAB that must still be there afterwards: a segment that ran over its
+    # array's end would write into them (the capacities handed to the call are the arrays' own)
+    guards = []
+    for name in ("acks", "hbs", "others", "cnt"):
+        t = getattr(ing, name)
+        nb = t.numel() * t.element_size()
+        big = torch.full((nb + 256,), 0xAB, dtype=torch.uint8, device=cuda)
+        big[:nb].zero_()
+        setattr(ing, name, big[:nb].view(t.dtype).view(t.shape))
+        guards.append((name, big, nb))
     d_off = torch.from_numpy(off).to(cuda)
     ing.ingest(buf, d_off, torch.from_numpy(np.asarray(groups, np.uint32).view(np.int32)).to(cuda), torch.from_numpy(np.asarray(peers, np.uint8)).to(cuda))
-    return ing, d_off, ing.results()
+    res = ing.results()
+    for name, big, nb in guards:
+        assert bool((big[nb:] == 0xAB).all()), "the call wrote past the end of `%s`" % name
+    return ing, d_off, res
 
 
 def _same(got, want):
