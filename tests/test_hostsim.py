@@ -181,6 +181,7 @@ def test_wire_ingest_one_pass_segments_on_the_host(sim, oracle):
         t.test_a_full_segment_stops_the_connection_in_front_of_the_frame("cpu")
         import test_zzzz_wire_conn_edges_gpu as t2                             # (no device run yet: sorted last there)
         t2.test_the_dense_calls_edge_streams_through_the_one_pass_call("cpu")
+        t2.test_frames_laid_out_by_hand_give_segments_laid_out_by_hand("cpu")     # raw output arrays written out by the test
         t.test_edges("cpu")
         t.test_accept_replies_over_the_wire_in_segments("cpu", oracle)
 
