@@ -22,6 +22,16 @@
 // record j of a window lies wholly below the first unread byte -- and stores them as smr_mp_ack records when the window
 // is done: a lane's records of a window leave back to back and merge in L2 (one 24-byte store per frame as it was parsed
 // left every 128-byte line of the record array in L2 five times: 417 MB of HBM writes for 201 MB of records, r3m PMC).
+//
+// Round 5, smr_wire_ingest_mp_conn: the same walk as the ONLY pass.  What the counting pass buys is lists that are dense and in
+// the decoder's order ACROSS connections, which the reference does not promise (a connection's messages in order, connections as
+// the event loop meets them: server/transport.rs:404-470).  With a segment per connection nothing has to be counted: connection
+// c's AcceptReplies start at record conn_off[c] / 13 (no frame that makes a record has fewer than 13 bytes, so the floors keep
+// the segments apart), its Heartbeats and located frames have hb_per_conn / other_per_conn places at [c][..], and one more than
+// that stops the walk IN FRONT of the frame (status 2: the host hands the rest to the next call, as it does with an incomplete
+// frame).  A segment's records are the staged (slot, ballot) dwords as they stand -- 12 bytes, smr_wire_ack12: the group and the
+// peer are the connection's -- because what records cost here is their stores' line requests: a probe of pass 2 without its
+// stores ran 76 instead of 151 us.  235 -> 145 us per call at 262 144 connections (profiles/r9n, r9q).
 #include "smr_common.h"
 
 namespace smr {
