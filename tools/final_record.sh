@@ -52,3 +52,6 @@ d = json.load(open("gpurun_out/${TAG}_pmc_traffic.json"))
 for k, v in d["kernels"].items():
     print("  pmc", k[:60], v["launches"], round(v["hbm_bytes_per_launch"] / 1e6, 2), "MB")
 P
+# (the files of the record are gpurun_out/${TAG}_*: gpurun merges that directory back, NOT profiles/ of the box -- copy them into profiles/ after the call,
+#  the ${TAG}_pmc_traffic*.json among them: round 5 left those behind once and had to rebuild them from this script's printout)
+echo "final_record: done -- now, in the repository: cp gpurun_out/${TAG}_* profiles/"
