@@ -566,6 +566,8 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
             if pm:
                 leg["order"] = "the leaders' steps phase by phase (smr_ep_cluster_set_mode bit 1); reference = ep_cluster.tick(.., phase_major=True)"
                 leg["same_commands_executed_as_the_driver_loop"] = leg["commands_executed"] == ex_pm
+                st = fused.batch_stats()                      # round 6: a lane's 4 PreAccepts / 4 CommitNotices as one batched step each
+                leg["batch_stats"] = dict(st, lanes_per_phase=(ticks + 2) * R * G)
             if not per_handler:
                 # <= 370 B per instance for the tally (replies read, instance read / written); the tick as a whole
                 # -- proposals, 4 PreAccepts, the tally, 4 CommitNotices, execution per instance -- has no per-unit figure there,

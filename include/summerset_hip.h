@@ -735,6 +735,14 @@ int smr_ep_cluster_tick(smr_ep_cluster *c, const uint8_t *const *keys_dev, const
  * with it the counters of abandoned attempts) differs from modes 0 / 1.  The loops `ep_cluster.tick(.., phase_major=True)` and
  * tests/ep_cluster.py run that order for the engines and for the oracle. */
 int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode);
+/* Round 6: with mode 2 (one launch, phase by phase) on a cluster of <= 5 replicas without explicit prepare, a lane's four
+ * PreAccepts (epaxos/messages.rs:10-93) and its four CommitNotices with their executions (messages.rs:438-508,
+ * durability.rs:104-160, execution.rs:25-211) each run as ONE batched step -- one round of loads for the whole phase -- where
+ * every message of the phase is the common case (a PreAccept for a fresh cell at its row's end; a CommitNotice for a cell that
+ * holds the PreAccepted instance whose dependencies are all executed); any other lane runs the phase's handlers one by one.
+ * Same results bit for bit.  out[0] / out[1] = (replica, group, tick) lanes that ran their PreAccept / CommitNotice phase one
+ * by one since the replicas were created (each wraps at 2^32). */
+int smr_ep_cluster_batch_stats(smr_ep_cluster *c, uint64_t out[2]);
 
 /* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with
  * an entry in exp_prepare_voteds (bitmap); those entries [R][W][R][G], deps [R][W][R][R][G]; counters[4] = decisions

@@ -299,6 +299,7 @@ SYMBOLS = [
     ("smr_ep_cluster_destroy", None, [_vp]),
     ("smr_ep_cluster_tick", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_cluster_set_mode", _i, [_vp, _u32]),
+    ("smr_ep_cluster_batch_stats", _i, [_vp, _vp]),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),

@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "smr_common.h"
@@ -79,6 +81,10 @@ struct EpView {
                                          //     smr_ep_cluster_create: the R replicas' entries of a (group, key) in ONE 128-byte line);
                                          //     the word of an entry that holds the executor's KV word
     u32x4 *p0, *p1, *p2, *p3;            // [R][W][G] each; p3 NULL at populations <= 6
+    uint32_t *sq32;                      // [R][W][G] round 6: min(seq, 2^32 - 1) of every cell, kept beside p0 by every store of it -- max_seq_num
+                                         //     (dependency.rs:101-109) looks at R sequence numbers per PreAccept and nothing else of those cells:
+                                         //     4 bytes per lane instead of a 16-byte word (25 such loads per lane and tick, 0.3 of 2.8 KB); a cell
+                                         //     that reads 2^32 - 1 sends its reader to p0
     uint64_t *pa_seq;                    // my row only: [W][R][G]
     uint32_t *pa_deps;                   // my row only: [W][R][R][G]
     uint32_t *len, *commit_bars;         // [R][G]
@@ -218,6 +224,7 @@ struct EpLaneT {
     }
     __device__ __forceinline__ void store_p0(uint32_t i, const EpInst<NR> &I) const {
         EA(v.p0, i) = (u32x4){(uint32_t)I.bal, (uint32_t)(I.bal >> 32), (uint32_t)I.seq, (uint32_t)(I.seq >> 32)};
+        EA(v.sq32, i) = I.seq < 0xFFFFFFFFull ? (uint32_t)I.seq : 0xFFFFFFFFu;
     }
     __device__ __forceinline__ void store_deps(uint32_t i, const EpInst<NR> &I) const {   // p1, p2 (with the meta words) and p3
         EA(v.p1, i) = (u32x4){I.d[0], NR > 1 ? I.d[1 < NR ? 1 : 0] : EP_NONE, NR > 2 ? I.d[2 < NR ? 2 : 0] : EP_NONE, NR > 3 ? I.d[3 < NR ? 3 : 0] : EP_NONE};
@@ -229,7 +236,12 @@ struct EpLaneT {
     __device__ __forceinline__ void load_meta(uint32_t i, EpInst<NR> &I) const { unpack_p2(EA(v.p2, i), I); }
     __device__ __forceinline__ void store_meta(uint32_t i, const EpInst<NR> &I) const { EA(v.p2, i) = pack_p2(I); }
     __device__ __forceinline__ uint32_t status_at(uint32_t i) const { return EA(v.p2, i).y & 0xFFu; }
-    __device__ __forceinline__ uint64_t seq_at(uint32_t i) const { const u32x4 a = EA(v.p0, i); return (uint64_t)a.z | ((uint64_t)a.w << 32); }
+    __device__ __forceinline__ uint64_t seq_at(uint32_t i) const {
+        const uint32_t s = EA(v.sq32, i);
+        if (s != 0xFFFFFFFFu) return s;
+        const u32x4 a = EA(v.p0, i);
+        return (uint64_t)a.z | ((uint64_t)a.w << 32);
+    }
     __device__ __forceinline__ uint64_t bal_at(uint32_t i) const { const u32x4 a = EA(v.p0, i); return (uint64_t)a.x | ((uint64_t)a.y << 32); }
     __device__ __forceinline__ void fresh_leader_bk(uint32_t i, EpInst<NR> &I) const {   // request.rs:48-57, heartbeat.rs:88-97
         I.set_bk(I.bk() | 1u);
@@ -594,7 +606,12 @@ struct EpExecLaneT {
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
-    __device__ __forceinline__ uint32_t at(uint32_t i) const { return M24(i, v.G) + g; }
+    // (the walk's arrays are [index][G] planes of the arena -- or, where the caller hands the lane private ones (walk_in: a few lanes of a
+    // kernel that has LDS to spare, ep_cluster_commit_one_by_one_kernel), [index][stride] with the lane's column `off`: every access of
+    // the walk is a dependent round trip, ~30 of them per attempt with a second node)
+    uint32_t at_stride = 0, at_off = 0;
+    __device__ __forceinline__ void walk_in(uint32_t stride, uint32_t off) { at_stride = stride; at_off = off; }
+    __device__ __forceinline__ uint32_t at(uint32_t i) const { return at_stride ? i * at_stride + at_off : M24(i, v.G) + g; }
     // the KV word of a key: word hc_kv of the key's hc entry (EpView::hc) -- the token of the key's last Put, (row + 1) << 32 | col,
     // packed into 32 bits (ep_kv_pack: 4 bits of row + 1, 28 of the column; 0 = none) so that five replicas' entries fit one line
     __device__ __forceinline__ uint32_t &kv_at(uint32_t key) const { return EA(v.hc, SHL_OF(M24(g, v.n_keys) + key, v.hc_es) + v.hc_kv); }
@@ -1568,6 +1585,7 @@ static void ep_layout(smr_ep_replica *e, bool dry) {
     const size_t G = e->cfg.n_groups, W = e->cfg.window, R = e->cfg.population, K = e->cfg.n_keys;
     ecarve(a, v.p0, R * W * G, dry); ecarve(a, v.p1, R * W * G, dry); ecarve(a, v.p2, R * W * G, dry);
     if (R > 6) ecarve(a, v.p3, R * W * G, dry);
+    ecarve(a, v.sq32, R * W * G, dry);
     const size_t PR = e->cfg.recovery ? R : 1;                                   // reply tables: every row / my row only
     ecarve(a, v.pa_seq, PR * W * R * G, dry); ecarve(a, v.pa_deps, PR * W * R * R * G, dry);
     if (e->cfg.recovery) {
@@ -1639,7 +1657,7 @@ __global__ __launch_bounds__(256) void ep_fill_kernel(uint32_t G, uint8_t *__res
 // replicas overlaps, and nothing waits for a launch boundary.
 template <typename T> __device__ __forceinline__ void ep_shift_ptr(T *&p, int64_t d) { p = (T *)((char *)p + d); }
 __device__ __forceinline__ void ep_shift(EpView &v, int64_t d) {
-    ep_shift_ptr(v.p0, d); ep_shift_ptr(v.p1, d); ep_shift_ptr(v.p2, d); ep_shift_ptr(v.p3, d);
+    ep_shift_ptr(v.p0, d); ep_shift_ptr(v.p1, d); ep_shift_ptr(v.p2, d); ep_shift_ptr(v.p3, d); ep_shift_ptr(v.sq32, d);
     ep_shift_ptr(v.pa_seq, d); ep_shift_ptr(v.pa_deps, d); ep_shift_ptr(v.len, d); ep_shift_ptr(v.commit_bars, d);
     ep_shift_ptr(v.my_nulls, d); ep_shift_ptr(v.rewritten, d); ep_shift_ptr(v.hc, d); ep_shift_ptr(v.counters, d); ep_shift_ptr(v.xp_max, d);
     ep_shift_ptr(v.xv_status, d); ep_shift_ptr(v.xv_key, d); ep_shift_ptr(v.xv_seq, d); ep_shift_ptr(v.xv_deps, d);
@@ -1668,6 +1686,10 @@ struct EpClusterArgs {
     uint8_t *r_flags, *a_flags;                  // [s][q][G]   PreAcceptReply / AcceptReply of q to leader s
     uint64_t *r_seq;                             // [s][q][G]
     uint32_t *r_deps;                            // [s][q][R][G]
+    // ep_cluster_tick_pm_kernel: the lanes whose CommitNotice phase goes one by one, for ep_cluster_commit_one_by_one_kernel --
+    // defer_cnt[(parity * NR + q) * 32] lanes of replica q, their groups in defer_list[q * G ..]
+    uint32_t *defer_cnt, *defer_list;
+    uint32_t parity;
 #ifdef EPC_STAMPS
     unsigned long long *stamps;                  // [8 blocks][NR wavefronts][64 steps]: experiments only (tools/dbg_epc_stamps.py)
 #endif
@@ -1945,6 +1967,517 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), (NR <= 5 ? EPC_WAVES_PER_
 #endif
     L.flush();
     if (a.execute) E.flush();
+}
+
+#ifdef EPC_PM_WHY
+extern "C" { unsigned long long g_epc_pm_why[16]; }          /* emulator experiments only: why a lane left the batched CommitNotice phase */
+#define EPC_WHY(k, cond) do { if (usual && !(cond)) atomicAdd(&g_epc_pm_why[k], 1ull); usual = usual && (cond); } while (0)
+#else
+#define EPC_WHY(k, cond) do { usual = usual && (cond); } while (0)
+#endif
+// ---- the phase-by-phase tick with a lane's handlers of one phase BATCHED (round 6) -----------------------------------------
+// ep_cluster_tick_kernel in its phase-major order runs 26 steps, and a lane's 4 PreAccepts and 4 CommitNotices are 8 of them,
+// each a chain of 2-4 dependent rounds of loads (profiles/r5j, s0: ~10 us a PreAccept step, 11-17 us a CommitNotice + execution
+// step, of a block's ~150-200 us).  Between two barriers a lane's handlers touch that replica's state alone, so they may run
+// as ONE step as long as the result is what the sequence leaves.  This kernel does that for the two long phases:
+//   * the 4 PreAccepts of a lane: the 4 keys' per-key entries in one round, the <= 20 sequence numbers in a second, then the
+//     four handlers back to back on registers -- what handler s would have read from memory behind handler s' < s (the
+//     key's highest column in row s', the sequence number of the instance s' just stored) is patched from s' 's registers;
+//   * the 4 CommitNotices of a lane with their executions: the cells' words, the keys' KV words and the digest in one round,
+//     then commit + attempt_execution + the command's result of each, back to back on registers (a dependency that an earlier
+//     member of the batch just executed is below that row's exec bar by then).
+// Both take the common case only -- PreAccept: a fresh cell at the row's end; CommitNotice: the cell holds the PreAccepted
+// instance, and execution finds every dependency executed or gone (a single-node graph, advanced_hinted's case) with no tail
+// of another row waiting.  A lane outside it runs the phase's handlers one by one, as ep_cluster_tick_kernel does -- the code
+// is the same (ep_acceptor_lane_in, ep_exec_after_handler), nothing of the fast path has been stored by then.
+// R <= 5, no explicit prepare (a cluster with recovery keeps the step-by-step kernel).
+#ifdef EPC_STAMPS
+#define EPC_PM_STAMP(t) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && set == 0 && (blockIdx.x & 127u) == 5u && (blockIdx.x >> 7) < 8u) a.stamps[(((blockIdx.x >> 7) * NR) + q) * 64 + (t)] = wall_clock64(); } while (0)
+#else
+#define EPC_PM_STAMP(t) do { } while (0)
+#endif
+template <int NR>
+__global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep_cluster_tick_pm_kernel(const EpClusterArgs<NR> a) {
+    static_assert(NR <= 5, "messages in LDS: populations <= 5");
+    constexpr int SETS = epc_sets<NR>();
+    __shared__ uint32_t sh_slow[SETS * NR];
+    __shared__ uint32_t sh_pa[SETS * NR * EPC_PA_WORDS * 64];
+    __shared__ uint32_t sh_rep[SETS * NR * (NR - 1) * EPC_REP_WORDS * 64];
+    __shared__ uint8_t sh_af[SETS * NR * NR * 64];
+    __shared__ uint32_t sh_sc[SETS * NR * 4 * NR * 64];
+    const uint32_t R = a.R, G = a.G;
+    const uint32_t wv = SMR_WAVE_UNIFORM(threadIdx.x >> 6), set = wv / R, q = wv - set * R;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t g0 = (blockIdx.x * SETS + set) * 64u + lane;
+    const bool live = g0 < G;
+    const uint32_t g = live ? g0 : 0u;
+    EpView v = a.v0;
+    EpExec x = a.x0;
+    ep_shift(v, a.delta[q]);
+    ep_shift(x, a.delta[q]);
+    if (a.hc_slot_bytes) v.hc = (uint32_t *)((char *)a.v0.hc + q * a.hc_slot_bytes);
+    v.me = q;
+    EpLaneT<NR, true> L(v, g);
+    L.bind_cache(sh_sc + (size_t)wv * 4 * NR * 64, lane);
+    EpExecLaneT<NR, true> E(v, x, L, g);
+    if (live) { L.load_scalars(); if (a.execute) E.load_scalars(); }
+    auto PA = [&](uint32_t s, int w) -> uint32_t & { return sh_pa[((size_t)(set * NR + s) * EPC_PA_WORDS + w) * 64 + lane]; };
+    auto RP = [&](uint32_t s, uint32_t qq, int w) -> uint32_t & {
+        return sh_rep[(((size_t)(set * NR + s) * (NR - 1) + (qq - (qq > s ? 1u : 0u))) * EPC_REP_WORDS + w) * 64 + lane];
+    };
+    const uint32_t hc_g = M24(g, v.n_keys);                                  // (entry of key k: word SHL_OF(hc_g + k, v.hc_es))
+    unsigned long long n_one_by_one = 0;                                     // lanes that left a batched phase: PreAccepts (low word), CommitNotices (high)
+    // ---- every replica proposes ----
+    EPC_PM_STAMP(0);
+    if (live) {
+        const smr_ep_cluster_out &o = a.out[q];
+        uint8_t of; uint32_t oc; uint64_t os; uint32_t d[NR];
+        const uint32_t key = a.keys[q][g];
+        ep_propose_lane(L, key, 0u, of, oc, os, d);
+        o.proposed[g] = of; o.col[g] = oc; o.seq0[g] = os;
+#pragma unroll
+        for (int i = 0; i < NR; i++) if ((uint32_t)i < R) o.deps0[(size_t)i * G + g] = d[i];
+        PA(q, 0) = of; PA(q, 1) = oc; PA(q, 2) = key; PA(q, 3) = (uint32_t)os; PA(q, 4) = (uint32_t)(os >> 32);
+#pragma unroll
+        for (int i = 0; i < NR; i++) PA(q, 5 + i) = d[i];
+    }
+    EPC_PM_STAMP(1);
+    __syncthreads();
+    // ---- acceptor q: the PreAccepts of every sender s != q, ascending ----
+    EPC_PM_STAMP(2);
+    if (live) {
+        uint32_t onm = 0, col[NR], key[NR];
+        bool fast = true;
+#pragma unroll
+        for (int s = 0; s < NR; s++) {
+            col[s] = 0; key[s] = 0;
+            if ((uint32_t)s >= R || (uint32_t)s == q) continue;
+            const uint8_t *dm = a.drop[s * NR + q];
+            col[s] = PA(s, 1); key[s] = PA(s, 2);
+            if ((PA(s, 0) & 1u) && !(dm && dm[g])) {
+                onm |= 1u << s;
+                fast = fast && L.get_len(s) == col[s] && key[s] != EP_NO_KEY;   // a fresh cell at the row's end: nothing to pad, nothing to read of it
+            } else {
+                key[s] = 0;
+            }
+        }
+        if (fast) {
+            // round 1: the keys' highest columns
+            uint32_t my[NR][NR];
+#pragma unroll
+            for (int s = 0; s < NR; s++)
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+                    my[s][r] = ((uint32_t)s < R && (uint32_t)s != q && (uint32_t)r < R) ? EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + r) : EP_NONE;
+            // what handler s reads behind handler s' < s of the same key: hc[key][s'] as s' left it (dependency.rs:141-167)
+#pragma unroll
+            for (int s = 1; s < NR; s++)
+#pragma unroll
+                for (int sp = 0; sp < s; sp++)
+                    if (((onm >> s) & 1u) && ((onm >> sp) & 1u) && key[sp] == key[s] && (my[s][sp] == EP_NONE || col[sp] > my[s][sp])) my[s][sp] = col[sp];
+            // round 2: the sequence numbers of those instances (any cell of the ring is a valid address; used only where held)
+            uint64_t sq[NR][NR];
+#pragma unroll
+            for (int s = 0; s < NR; s++)
+#pragma unroll
+                for (int r = 0; r < NR; r++)
+                    sq[s][r] = ((uint32_t)s < R && (uint32_t)s != q && (uint32_t)r < R) ? L.seq_at(L.ix(r, my[s][r])) : 0ull;
+            uint64_t nseq[NR];
+#pragma unroll
+            for (int s = 0; s < NR; s++) {
+                nseq[s] = 0;
+                if ((uint32_t)s >= R || (uint32_t)s == q) continue;
+                if (!((onm >> s) & 1u)) {                                    // not sent / lost: the empty reply
+                    RP(s, q, 0) = 0u; RP(s, q, 1) = 0u;
+#pragma unroll
+                    for (int i = 0; i < NR; i++) RP(s, q, 2 + i) = EP_NONE;
+                    continue;
+                }
+                const uint32_t c = col[s], k = key[s];
+                L.set_len(s, c + 1u);                                        // messages.rs:33-36: the row grows by this very cell
+                uint64_t ms = 0;                                             // dependency.rs:101-109
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    const uint32_t d = my[s][r];
+                    const bool ok = (uint32_t)r < R && d != EP_NONE && L.held((uint32_t)r < R ? r : 0, d);
+                    uint64_t val = sq[s][r];
+                    if (r < s && ((onm >> r) & 1u) && d == col[r]) val = nseq[r];   // the instance handler r stored an instant ago
+                    if (ok && val > ms) ms = val;
+                }
+                ms += 1;
+                uint64_t sn = (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32);
+                if (ms > sn) sn = ms;
+                nseq[s] = sn;
+                EpInst<NR> I;
+                I.make_null();
+#pragma unroll
+                for (int r = 0; r < NR; r++) {                               // deps.union(&my_deps), dependency.rs:85-97
+                    uint32_t in = (uint32_t)r < R ? PA(s, 5 + r) : EP_NONE;
+                    const uint32_t m = (uint32_t)r < R ? my[s][r] : EP_NONE;
+                    if (in != EP_NONE) { if (m != EP_NONE && m > in) in = m; }
+                    else in = m;
+                    I.d[r] = in;
+                }
+                I.bal = (uint64_t)(s + 1u); I.seq = sn;
+                I.set_status(EST_PREACCEPTING); I.set_key(k); I.set_bk(2u | ((uint32_t)s << 2));
+                L.store_inst(L.ix(s, c), I);
+                if (my[s][s] == EP_NONE || c > my[s][s]) EA(v.hc, SHL_OF(hc_g + k, v.hc_es) + s) = c;
+                RP(s, q, 0) = (uint32_t)sn; RP(s, q, 1) = ((uint32_t)(sn >> 32) & 0x7FFFFFFFu) | (1u << 31);
+#pragma unroll
+                for (int i = 0; i < NR; i++) RP(s, q, 2 + i) = I.d[i];
+            }
+        } else {
+            for (uint32_t s = 0; s < R; s++) {
+                if (s == q) continue;
+                const uint8_t *dm = a.drop[s * NR + q];
+                uint8_t of; uint64_t ob, os; uint32_t d[NR];
+                const bool on = (PA(s, 0) & 1u) && !(dm && dm[g]);
+                uint32_t in[NR];
+#pragma unroll
+                for (int i = 0; i < NR; i++) in[i] = (uint32_t)i < R ? PA(s, 5 + i) : EP_NONE;
+                ep_acceptor_lane_in<0, NR, false>(L, on, s, s, PA(s, 1), (uint64_t)(s + 1u), (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in,
+                                                  PA(s, 2), of, ob, os, d);
+                RP(s, q, 0) = (uint32_t)os; RP(s, q, 1) = ((uint32_t)(os >> 32) & 0x7FFFFFFFu) | ((uint32_t)(of & 1u) << 31);
+#pragma unroll
+                for (int i = 0; i < NR; i++) RP(s, q, 2 + i) = d[i];
+            }
+            n_one_by_one += 1ull;                                            // (smr_ep_cluster_batch_stats)
+        }
+    }
+    EPC_PM_STAMP(3);
+    __syncthreads();
+    // ---- command leader q: its PreAcceptReplies, peers ascending (messages.rs:96-270), and the execution behind a fast commit ----
+    EPC_PM_STAMP(4);
+    {
+        uint8_t dec = 0;
+        if (live) {
+            const smr_ep_cluster_out &o = a.out[q];
+            uint64_t dseq; uint32_t dd[NR];
+            EpInst<NR> H;
+            bool have_h = false;
+            const uint32_t h_col = PA(q, 1);
+            const EpRepliesInLds<NR> rdr{sh_rep + (size_t)(set * NR + q) * (NR - 1) * EPC_REP_WORDS * 64, q, lane};
+            ep_pa_replies_lane_rd<NR, true>(L, q, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h);
+            PA(q, 0) = (PA(q, 0) & 1u) | ((uint32_t)dec << 8);
+            PA(q, 3) = dec ? (uint32_t)dseq : 0u; PA(q, 4) = dec ? (uint32_t)(dseq >> 32) : 0u;
+#pragma unroll
+            for (int k = 0; k < NR; k++) PA(q, 5 + k) = dec ? dd[k] : EP_NONE;
+            o.decision[g] = dec; o.seq[g] = dec ? dseq : 0ull;
+#pragma unroll
+            for (int k = 0; k < NR; k++) if ((uint32_t)k < R) o.deps[(size_t)k * G + g] = dec ? dd[k] : EP_NONE;
+            if (a.execute) ep_exec_after_handler(v, x, E, have_h ? &H : nullptr, q, h_col);
+        }
+        const int any_slow = __any(dec == EST_ACCEPTING);
+        if (lane == 0) sh_slow[set * NR + q] = any_slow ? 1u : 0u;
+    }
+    EPC_PM_STAMP(5);
+    __syncthreads();
+    EPC_PM_STAMP(6);
+    // ---- the Accept round of every leader that took the slow path in some group of my set (messages.rs:273-345) ----
+    {
+        bool any = false;
+        for (uint32_t k = 0; k < (uint32_t)SETS * R; k++) any = any || sh_slow[k] != 0;
+        if (any) {                                                           // (block-uniform: the barrier below is met by all or none)
+            for (uint32_t s = 0; s < R; s++) {
+                if (sh_slow[set * NR + s] == 0 || s == q || !live) continue;
+                uint8_t of; uint64_t ob, os; uint32_t d[NR], in[NR];
+#pragma unroll
+                for (int i = 0; i < NR; i++) in[i] = (uint32_t)i < R ? PA(s, 5 + i) : EP_NONE;
+                ep_acceptor_lane_in<1, NR, false>(L, ((PA(s, 0) >> 8) & 0xFFu) == EST_ACCEPTING, s, s, PA(s, 1), (uint64_t)(s + 1u),
+                                                  (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in, PA(s, 2), of, ob, os, d);
+                sh_af[((size_t)(set * NR + s) * NR + q) * 64 + lane] = of;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- command leader q: the AcceptReplies (messages.rs:348-436), then what is committed ----
+    EPC_PM_STAMP(7);
+    if (live) {
+        const smr_ep_cluster_out &o = a.out[q];
+        bool acc = false;
+        if (sh_slow[set * NR + q] != 0) {
+            uint32_t fm = 0;
+#pragma unroll
+            for (int p = 0; p < NR; p++)
+                if ((uint32_t)p < R && (uint32_t)p != q) fm |= (uint32_t)(sh_af[((size_t)(set * NR + q) * NR + p) * 64 + lane] & 1u) << p;
+            acc = ep_accept_replies_mask(L, q, PA(q, 1), SMR_CTL_IDENTITY, fm, (uint64_t)(q + 1u));
+        }
+        const bool fastc = ((PA(q, 0) >> 8) & 0xFFu) == EST_COMMITTED;
+        if (fastc || acc) PA(q, 0) |= 1u << 16;
+        o.committed[g] = (fastc || acc) ? 1 : 0;
+        if (a.execute) ep_exec_after_handler(v, x, E);
+    }
+    EPC_PM_STAMP(8);
+    __syncthreads();
+    EPC_PM_STAMP(9);
+    // ---- acceptor q: the CommitNotices of every leader s != q, ascending (messages.rs:438-508), each with its execution ----
+    bool defer = false;
+    if (live) {
+        const uint32_t W = v.W;
+        // every instance of this tick by its row r: (r, col[r]) with key[r] and -- in LDS, the leader's broadcast -- the decision's
+        // seq / deps; onm: the CommitNotices I take; my own row's instance matters where its execution is still waiting (below)
+        uint32_t onm = 0, col[NR], key[NR];
+        bool usual = true;
+        EPC_WHY(0, !L.rewritten);
+        uint32_t s_last = 0;                                                 // the phase's last handler: what smr_ep_exec_poll reports
+#pragma unroll
+        for (int s = 0; s < NR; s++) {
+            col[s] = 0; key[s] = 0;
+            if ((uint32_t)s >= R) continue;
+            const bool committed = (PA(s, 0) >> 16) & 1u;
+            if (committed) { col[s] = PA(s, 1); key[s] = PA(s, 2); }
+            if ((uint32_t)s == q) continue;
+            s_last = s;
+            if (committed) { onm |= 1u << s; EPC_WHY(1, key[s] != EP_NO_KEY); }
+        }
+        if (key[0] == EP_NO_KEY) key[0] = 0;                                 // (a clamped key for the loads; such a lane has left the fast path)
+#pragma unroll
+        for (int s = 1; s < NR; s++) if (key[s] == EP_NO_KEY) key[s] = 0;
+        // the one round of loads: the cells' ballot / sequence and meta words, the keys' KV words, the digest
+        u32x4 w0[NR], w2[NR]; uint32_t kvcur[NR];
+#pragma unroll
+        for (int s = 0; s < NR; s++) {
+            const bool m = (uint32_t)s < R;
+            const uint32_t i = L.ix(m ? s : 0u, col[s]);
+            w0[s] = (m && (uint32_t)s != q) ? EA(v.p0, i) : (u32x4){0u, 0u, 0u, 0u};
+            w2[s] = m ? EA(v.p2, i) : (u32x4){0u, 0u, 0u, 0u};
+            kvcur[s] = (m && a.execute) ? EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + v.hc_kv) : 0u;
+        }
+        uint64_t dg = a.execute ? EA(x.digest, g) : 0ull;
+        // the scalars the members move, on copies: commit bars, exec bars (row lengths stay)
+        uint32_t cbL[NR], ebL[NR];
+        // pend: rows whose tail is THIS tick's instance, Committed and waiting for its execution (attempt_execution abandoned:
+        // a dependency was not committed here yet) -- what the re-attempts behind a successful attempt go through
+        // (durability.rs:148-158).  Going in, that can only be my own row (my instance committed a phase ago).
+        uint32_t pend = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            cbL[r] = (uint32_t)r < R ? L.get_cb(r) : 0u;
+            ebL[r] = ((uint32_t)r < R && a.execute) ? E.get_eb(r) : 0u;
+            if ((uint32_t)r < R && a.execute) {
+                EPC_WHY(2, L.cw(3, r) == cbL[r]);                            // (no commit bar moved unseen: cb_moved would say so)
+                if (cbL[r] != ebL[r]) {
+                    const bool mine = (uint32_t)r == q && ((PA(r, 0) >> 16) & 1u) && cbL[r] == ebL[r] + 1u && ebL[r] == col[r] &&
+                                      L.get_len(r) == cbL[r] && (w2[r].y & 0xFFu) == EST_COMMITTED && ((w2[r].y >> 8) & 0xFFu) == key[r] &&
+                                      PA(r, 2) != EP_NO_KEY;
+                    EPC_WHY(8, mine);
+                    pend |= 1u << r;
+                }
+            }
+        }
+        uint32_t stf[NR];                                                    // per row: the final Status of this tick's instance where this phase sets it (0: untouched)
+        uint32_t n_exec = 0, n_att = 0, n_unh = 0, n_abort = 0, last_sub = 0;
+        uint32_t ordv[NR], ordm = 0;                                         // the submission list as the phase leaves it: position k written (bit k) with ordv[k]
+        uint32_t exm = 0;                                                    // rows whose instance was executed in this phase
+#pragma unroll
+        for (int r = 0; r < NR; r++) { stf[r] = 0; ordv[r] = 0; }
+        // attempt_execution (execution.rs:25-149) from the tail (r, col[r]) as far as this path goes: every dependency and the row
+        // predecessor not committed here (abandoned), gone from the ring, or Executed / Executing -- below its row's exec bar as
+        // moved so far; anything else (a second node of the graph) leaves the fast path.  true = the instance may run.
+        auto attempt = [&](auto RC) -> bool {
+            constexpr int r = decltype(RC)::value;
+            bool abandoned = false;
+            uint32_t unheld = 0;
+#pragma unroll
+            for (int e = 0; e <= NR; e++) {
+                const uint32_t d = e < NR ? ((uint32_t)e < R ? PA(r, 5 + (e < NR ? e : 0)) : EP_NONE) : (col[r] > 0 ? col[r] - 1u : EP_NONE);
+                constexpr int er_c = 0;
+                (void)er_c;
+                const int er = e < NR ? e : r;
+                if (d == EP_NONE || abandoned) continue;
+                if (d >= cbL[er]) { abandoned = true; continue; }            // execution.rs:41-45
+                if (!L.held(er, d)) { unheld++; continue; }                  // (left the ring = executed)
+#ifdef EPC_PM_WHY
+                if (usual && !(d < ebL[er])) printf("why9 g=%u q=%u r=%d e=%d d=%u col=[%u %u %u %u %u] key=[%u %u %u %u %u] onm=%x pend=%x exm=%x cb=[%u %u %u %u %u] eb=[%u %u %u %u %u] deps_r=[%d %d %d %d %d] deps_er=[%d %d %d %d %d]\n", g, q, r, e, d, col[0], col[1], col[2], col[3], col[4], key[0], key[1], key[2], key[3], key[4], onm, pend, exm, cbL[0], cbL[1], cbL[2], cbL[3], cbL[4], ebL[0], ebL[1], ebL[2], ebL[3], ebL[4], (int)PA(r,5), (int)PA(r,6), (int)PA(r,7), (int)PA(r,8), (int)PA(r,9), (int)PA(er < NR ? er : 0,5), (int)PA(er < NR ? er : 0,6), (int)PA(er < NR ? er : 0,7), (int)PA(er < NR ? er : 0,8), (int)PA(er < NR ? er : 0,9));
+#endif
+                EPC_WHY(9 + (e == NR ? 1 : 0), d < ebL[er]);                 // below the exec bar: Executed (or Executing: an earlier member of this very handler)
+            }
+            n_att++; n_unh += unheld;
+            if (abandoned) n_abort++;
+            return !abandoned;
+        };
+        // execution.rs:105-142 + the command's result (:152-211) for the single-node graph (r, col[r]); n_ord: position in the handler's list
+        auto run = [&](auto RC, uint32_t &n_ord) {
+            constexpr int r = decltype(RC)::value;
+            const uint64_t tok = ((uint64_t)(r + 1u) << 32) | col[r];
+            const uint64_t old = ep_kv_unpack(kvcur[r]);
+            dg = (dg ^ tok) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
+            const uint32_t tw = ep_kv_pack(tok);
+#pragma unroll
+            for (int r2 = 0; r2 < NR; r2++) if (key[r2] == key[r]) kvcur[r2] = tw;   // (the key's KV word as every later reader of it sees it)
+            const uint32_t ring = ((uint32_t)r << E.wshift) | (col[r] & v.Wmask);
+#pragma unroll
+            for (int k = 0; k < NR; k++) if (n_ord == (uint32_t)k) { ordv[k] = ring; ordm |= 1u << k; }
+            EPC_WHY(11, n_ord < (uint32_t)NR);
+            n_ord++;
+            exm |= 1u << r; n_exec++;
+            stf[r] = EST_EXECUTED;
+            if (col[r] == ebL[r]) ebL[r] = col[r] + 1u;
+            pend &= ~(1u << r);
+        };
+        auto member = [&](auto SC) {
+            constexpr int s = decltype(SC)::value;
+            if (!((onm >> s) & 1u)) return;
+            const uint32_t c = col[s], k = key[s], len = L.get_len(s);
+            const uint64_t bal = (uint64_t)w0[s].x | ((uint64_t)w0[s].y << 32);
+            const uint32_t m0 = w2[s].y;
+            EPC_WHY(3, c < len && c + W >= len);                             // the cell is in the ring
+            EPC_WHY(4, (uint64_t)(s + 1u) >= bal);                           // messages.rs:455
+            EPC_WHY(5, (m0 & 0xFFu) != EST_NULL && ((m0 >> 8) & 0xFFu) == k);   // it holds this instance (its PreAccept came by): the key's entry stands
+            EPC_WHY(6, c >= cbL[s]);                                         // not a rewrite below the commit bar
+            stf[s] = EST_COMMITTED;
+            if (c != cbL[s]) return;                                         // (a gap below it: the bar stays)
+            EPC_WHY(7, len == c + 1u);                                       // durability.rs:104-135: the bar moves over this cell -- and no further
+            cbL[s] = c + 1u;
+            if (!a.execute) return;
+            EPC_WHY(12, c == ebL[s]);                                        // durability.rs:136-160 -> execution.rs:25-149 from the tail (s, c)
+            uint32_t n_ord = 0;
+            if (attempt(SC)) {
+                run(SC, n_ord);
+                // the re-attempts on every OTHER row whose tail is still Committed, rows ascending, found before any of them runs
+                const uint32_t re = pend & ~(1u << s);
+                auto again = [&](auto RC) {
+                    constexpr int r = decltype(RC)::value;
+                    if (r != s && ((re >> r) & 1u) && attempt(RC)) run(RC, n_ord);
+                };
+                again(std::integral_constant<int, 0>{}); again(std::integral_constant<int, 1>{}); again(std::integral_constant<int, 2>{});
+                again(std::integral_constant<int, 3>{}); again(std::integral_constant<int, 4>{});
+            } else {
+                pend |= 1u << s;
+            }
+            if ((uint32_t)s == s_last) last_sub = n_ord;
+        };
+        member(std::integral_constant<int, 0>{}); member(std::integral_constant<int, 1>{}); member(std::integral_constant<int, 2>{});
+        member(std::integral_constant<int, 3>{}); member(std::integral_constant<int, 4>{});
+        if (usual) {
+#pragma unroll
+            for (int s = 0; s < NR; s++) {
+                if ((uint32_t)s >= R || !stf[s]) continue;
+                const uint32_t c = col[s], i = L.ix(s, c);
+                if ((uint32_t)s != q) {
+                    const uint32_t sl = PA(s, 3), sh = PA(s, 4);
+                    if (w0[s].x != (uint32_t)(s + 1u) || w0[s].y != 0u || w0[s].z != sl || w0[s].w != sh) {
+                        EA(v.p0, i) = (u32x4){(uint32_t)(s + 1u), 0u, sl, sh};
+                        EA(v.sq32, i) = (sh == 0u && sl != 0xFFFFFFFFu) ? sl : 0xFFFFFFFFu;
+                    }
+                    // deps[0..3] as my PreAcceptReply of this tick carried them are what the cell holds while it is still PreAccepting:
+                    // the word is written only where the decision differs
+                    const bool same_p1 = (w2[s].y & 0xFFu) == EST_PREACCEPTING && (RP(s, q, 1) >> 31) && RP(s, q, 2) == PA(s, 5) && RP(s, q, 3) == PA(s, 6) &&
+                                         RP(s, q, 4) == PA(s, 7) && RP(s, q, 5) == PA(s, 8);
+                    if (!same_p1)
+                        EA(v.p1, i) = (u32x4){PA(s, 5), NR > 1 ? PA(s, 6) : EP_NONE, NR > 2 ? PA(s, 7) : EP_NONE, NR > 3 ? PA(s, 8) : EP_NONE};
+                    EA(v.p2, i) = (u32x4){NR > 4 ? PA(s, 9) : EP_NONE, (w2[s].y & 0xFFFF0000u) | (key[s] << 8) | stf[s], w2[s].z, EP_NONE};
+                } else {
+                    EA(v.p2, i) = (u32x4){w2[s].x, (w2[s].y & ~0xFFu) | stf[s], w2[s].z, w2[s].w};   // (my own instance ran behind a member: its Status alone)
+                }
+                if ((exm >> s) & 1u) EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + v.hc_kv) = kvcur[s];
+            }
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                if ((uint32_t)r >= R) continue;
+                L.set_cb(r, cbL[r]);
+                if (a.execute) { E.set_eb(r, ebL[r]); L.cw(3, r) = cbL[r]; }
+            }
+            if (a.execute) {
+                if (exm) EA(x.digest, g) = dg;
+#pragma unroll
+                for (int k = 0; k < NR; k++) if ((ordm >> k) & 1u) EA(x.order, E.at(k)) = (uint16_t)ordv[k];
+                EA(x.n_sub, g) = last_sub;
+                E.c_exec += n_exec; E.c_attempts += n_att; E.c_unheld += n_unh; E.c_aborts += n_abort;
+            }
+        } else {
+            defer = true;                                                    // nothing of this phase has been stored for the lane
+            n_one_by_one += 1ull << 32;
+        }
+    }
+    {   // the lanes that go one by one: onto replica q's list (one atomic per wavefront)
+        const unsigned long long dm = __ballot(defer);
+        if (dm) {
+            const uint32_t first = (uint32_t)__ffsll(dm) - 1u;
+            uint32_t base = 0;
+            if (lane == first) base = atomicAdd(&a.defer_cnt[(a.parity * NR + q) * 32u], (uint32_t)__popcll(dm));
+            base = __shfl(base, (int)first);
+            if (defer) a.defer_list[(size_t)q * G + base + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = g;
+        }
+    }
+    EPC_PM_STAMP(10);
+    if (live) { L.store_scalars(); if (a.execute) E.store_scalars(); }
+    EPC_PM_STAMP(11);
+    L.flush();
+    if (a.execute) E.flush();
+    for (int off = 32; off > 0; off >>= 1) n_one_by_one += __shfl_xor(n_one_by_one, off);
+    if (lane == 0 && n_one_by_one) ctr_add(v.counters, 7, n_one_by_one);
+}
+
+// The CommitNotice phase of the lanes ep_cluster_tick_pm_kernel put on its lists (a Commit for a cell that does not hold the
+// PreAccepted instance, an execution whose graph has a second node, ...: under 1 % of the lanes of a running cluster, but one per
+// wavefront there would hold its whole block for four handlers' round trips): handler by handler, the messages out of the
+// tick's output arrays, a wavefront of listed lanes per block (blockIdx.y = the replica).  Also empties the OTHER parity's
+// counts for the next tick.
+#ifndef EPC_CL_LANES
+#define EPC_CL_LANES 4u
+#endif
+template <int NR>
+__global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const EpClusterArgs<NR> a) {
+    __shared__ uint32_t sh_sc[4 * NR * 64];
+    constexpr uint32_t WALK_CELLS = 512;                                     // population * window up to here: the walk's arrays in LDS
+    __shared__ uint16_t sh_walk[7 * WALK_CELLS * EPC_CL_LANES];               // node_of, nslot, head, sib, parent [cell][lane]; order [2 cells][lane]
+    const uint32_t q = blockIdx.y, R = a.R, G = a.G, lane = threadIdx.x;
+    const uint32_t n = SMR_WAVE_UNIFORM(a.defer_cnt[(a.parity * NR + q) * 32u]);
+    const uint32_t RW = R * a.v0.W;
+    const bool lds_walk = a.execute && RW <= WALK_CELLS;
+    if (lds_walk) for (uint32_t i = lane; i < RW * EPC_CL_LANES; i += 64u) sh_walk[i] = 0;   // node_of: zero between attempts (the walk leaves it so)
+    __syncthreads();
+    if (blockIdx.x == 0 && lane == 0) a.defer_cnt[((a.parity ^ 1u) * NR + q) * 32u] = 0;
+    EpView v = a.v0;
+    EpExec x = a.x0;
+    ep_shift(v, a.delta[q]);
+    ep_shift(x, a.delta[q]);
+    if (a.hc_slot_bytes) v.hc = (uint32_t *)((char *)a.v0.hc + q * a.hc_slot_bytes);
+    v.me = q;
+    // EPC_CL_LANES listed lanes per wavefront, not 64: the walks of attempt_execution are chains of ~30 dependent round trips that
+    // different lanes enter behind different members of the batch, and a wavefront pays every one of them in turn (64 lanes
+    // per wavefront: 250 us for ~2 750 listed lanes, profiles/s6: the fourth member's step alone 100 us)
+    for (uint32_t base = blockIdx.x * EPC_CL_LANES; base < n; base += gridDim.x * EPC_CL_LANES) {
+        const bool active = lane < EPC_CL_LANES && base + lane < n;
+        const uint32_t g = active ? a.defer_list[(size_t)q * G + base + lane] : 0u;
+        EpLaneT<NR, true> L(v, g);                                          // (the lane's per-row scalars in LDS, as in the tick kernel: every handler starts with them)
+        L.bind_cache(sh_sc, lane);
+        EpExec xl = x;
+        if (lds_walk) {
+            xl.node_of = sh_walk; xl.nslot = sh_walk + RW * EPC_CL_LANES; xl.head = sh_walk + 2 * RW * EPC_CL_LANES;
+            xl.sib = sh_walk + 3 * RW * EPC_CL_LANES; xl.parent = sh_walk + 4 * RW * EPC_CL_LANES; xl.order = sh_walk + 5 * RW * EPC_CL_LANES;
+        }
+        EpExecLaneT<NR, true> E(v, xl, L, g);
+        if (lds_walk) E.walk_in(EPC_CL_LANES, lane < EPC_CL_LANES ? lane : 0u);
+        uint32_t n_listed = 0;                                               // (the longest submission list a handler of this lane left)
+        if (active) { L.load_scalars(); if (a.execute) E.load_scalars(); }
+#ifdef EPC_STAMPS
+#define EPC_CL_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && blockIdx.x == 0 && base == 0) a.stamps[q * 64 + 40 + (k)] = wall_clock64(); } while (0)
+#else
+#define EPC_CL_STAMP(k) do { } while (0)
+#endif
+        EPC_CL_STAMP(0);
+        if (active)
+            for (uint32_t s = 0; s < R; s++) {
+                if (s == q) continue;
+                const smr_ep_cluster_out &o = a.out[s];
+                uint8_t of; uint64_t ob, os; uint32_t d[NR];
+                EpInst<NR> H;
+                bool have_h = false;
+                const uint32_t h_col = o.col[g];
+                ep_acceptor_lane<2, NR, false>(L, o.committed[g] & 1, s, s, h_col, (uint64_t)(s + 1u), o.seq[g], o.deps, a.keys[s][g], of, ob, os, d, &H, &have_h);
+                EPC_CL_STAMP(1 + 2 * s);
+                if (a.execute) { ep_exec_after_handler(v, xl, E, have_h ? &H : nullptr, s, h_col); n_listed = E.n_order > n_listed ? E.n_order : n_listed; }
+                EPC_CL_STAMP(2 + 2 * s);
+            }
+        if (active && lds_walk)                                              // the lists as the handlers left them, where smr_ep_exec_poll reads them
+            for (uint32_t k = 0; k < n_listed; k++) EA(x.order, M24(k, G) + g) = xl.order[k * EPC_CL_LANES + lane];
+        if (active) { L.store_scalars(); if (a.execute) E.store_scalars(); }
+        EPC_CL_STAMP(11);
+        L.flush();
+        if (a.execute) E.flush();
+    }
 }
 }  // namespace smr
 
@@ -2337,6 +2870,9 @@ struct smr_ep_cluster {
     uint32_t *hc_shared = nullptr;
     uint32_t *hc_priv[SMR_MAX_REPLICAS] = {};
     uint32_t hc_priv_ew = 0, hc_priv_kv = 0;
+    uint32_t *defer_cnt = nullptr, *defer_list = nullptr;    // ep_cluster_tick_pm_kernel's lists (EpClusterArgs)
+    uint32_t parity = 0;
+    bool unbatched = false;                                  // SMR_EP_PM_UNBATCHED (A/B runs): the phase-by-phase order on the step-by-step kernel
 };
 constexpr uint32_t EP_HC_SHARED_ES = 32;                 // words between two keys' entries of the shared table: one 128-byte line
 
@@ -2356,11 +2892,12 @@ int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluste
     }
     smr_ep_cluster *c = new smr_ep_cluster();
     c->R = n; c->G = reps[0]->cfg.n_groups;
+    c->unbatched = getenv("SMR_EP_PM_UNBATCHED") != nullptr;
     for (uint32_t r = 0; r < n; r++) c->rep[r] = reps[r];
     const size_t G = c->G, R = n;
     // 8-byte arrays first; everything zero: a leader's own row of the stacks is never written and never read as a reply.
     // Each kind of stack is ONE array over the leaders ([s][q]...), the per-leader pointers are views of it.
-    const size_t n64 = R * (R * G) * 3 + R * G, n32 = R * (R * R * G), n8 = R * (R * G) * 2 + R * G * 3 + G;
+    const size_t n64 = R * (R * G) * 3 + R * G, n32 = R * (R * R * G) + R * G + 2 * SMR_MAX_REPLICAS * 32, n8 = R * (R * G) * 2 + R * G * 3 + G;
     const size_t bytes = n64 * 8 + n32 * 4 + n8 + 4096;
     if (hipMalloc((void **)&c->base, bytes) != hipSuccess) { delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMalloc failed"); }
     if (hipMemset(c->base, 0, bytes) != hipSuccess) { (void)hipFree(c->base); delete c; return fail(SMR_ERR_DEVICE, "epaxos cluster: hipMemset failed"); }
@@ -2371,6 +2908,8 @@ int smr_ep_cluster_create(smr_ep_replica *const *reps, uint32_t n, smr_ep_cluste
     for (uint32_t s = 0; s < R; s++) { c->bal_c[s] = p64; p64 += G; }
     uint32_t *p32 = (uint32_t *)p64;
     for (uint32_t s = 0; s < R; s++) { c->r_deps[s] = p32; p32 += R * R * G; }
+    c->defer_list = p32; p32 += R * G;
+    c->defer_cnt = p32; p32 += 2 * SMR_MAX_REPLICAS * 32;
     uint8_t *p8 = (uint8_t *)p32;
     for (uint32_t s = 0; s < R; s++) { c->r_flags[s] = p8; p8 += R * G; }
     for (uint32_t s = 0; s < R; s++) { c->a_flags[s] = p8; p8 += R * G; }
@@ -2439,6 +2978,19 @@ void smr_ep_cluster_destroy(smr_ep_cluster *c) {
     delete c;
 }
 
+int smr_ep_cluster_batch_stats(smr_ep_cluster *c, uint64_t out[2]) {
+    if (!c || !out) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
+    out[0] = out[1] = 0;
+    for (uint32_t r = 0; r < c->R; r++) {
+        if (!c->rep[r]) return fail(SMR_ERR_STATE, "epaxos cluster: a replica of this cluster was destroyed");
+        unsigned long long k[8];
+        SMR_HIP_TRY(hipDeviceSynchronize());
+        SMR_HIP_TRY(ctr_read(c->rep[r]->v.counters, 8, k));
+        out[0] += k[7] & 0xFFFFFFFFull; out[1] += k[7] >> 32;
+    }
+    return SMR_OK;
+}
+
 int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode) {
     if (!c) return fail(SMR_ERR_ARG, "epaxos cluster: null argument");
     if (mode > 3) return fail(SMR_ERR_ARG, "epaxos cluster: mode must be 0 .. 3 (bit 0: one launch per handler, bit 1: the leaders' steps phase by phase)");
@@ -2479,7 +3031,16 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
     a.stamps = g_stamps;
     g_epc_stamps = g_stamps; g_epc_stamps_n = 8 * NR * 64;
 #endif
-    if (a.quiet)
+    if (a.quiet && a.phase_major && NR <= 5 && !c->unbatched) {
+        // (NR > 5 never gets here; the instantiation is kept out of the 8-replica build by the constant)
+        if constexpr (NR <= 5) {
+            a.defer_cnt = c->defer_cnt; a.defer_list = c->defer_list; a.parity = c->parity;
+            c->parity ^= 1u;
+            hipLaunchKernelGGL((ep_cluster_tick_pm_kernel<NR>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
+                               (hipStream_t)stream, a);
+            hipLaunchKernelGGL((ep_cluster_commit_one_by_one_kernel<NR>), dim3(std::min<uint32_t>((G + EPC_CL_LANES - 1u) / EPC_CL_LANES, 1024u), R), dim3(64), 0, (hipStream_t)stream, a);
+        }
+    } else if (a.quiet)
         hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
                            (hipStream_t)stream, a);
     else

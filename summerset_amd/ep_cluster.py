@@ -112,6 +112,15 @@ class EPaxosCluster:
     def __del__(self):
         self.close()
 
+    def batch_stats(self):
+        """(replica, group, tick) lanes whose PreAccept / CommitNotice phase left the batched step of the phase-by-phase
+        one-launch tick and ran handler by handler (`smr_ep_cluster_batch_stats`)"""
+        import ctypes as C
+        from . import _lib
+        out = (C.c_uint64 * 2)()
+        _lib.check(self._L.smr_ep_cluster_batch_stats(self._h, out))
+        return dict(pre_accept_lanes_one_by_one=int(out[0]), commit_lanes_one_by_one=int(out[1]))
+
     def new_outputs(self, dev):
         """one set of the tick's output arrays (per command leader); pass it back as `tick(..., out=)` to reuse it"""
         import torch
