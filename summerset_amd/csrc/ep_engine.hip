@@ -2027,6 +2027,29 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
     };
     const uint32_t hc_g = M24(g, v.n_keys);                                  // (entry of key k: word SHL_OF(hc_g + k, v.hc_es))
     unsigned long long n_one_by_one = 0;                                     // lanes that left a batched phase: PreAccepts (low word), CommitNotices (high)
+    // The PreAccepted instance of sender s (bit s of defm) is NOT in memory yet: the record an acceptor stores for a PreAccept is its
+    // reply (sequence number, dependencies: sh_rep) under the message's column and key (sh_pa), and in a running cluster the
+    // CommitNotice of the same tick overwrites it -- 52 bytes written, 32 read back and up to 52 written again per (acceptor,
+    // instance), and the key's entry written back a second time.  So the batched PreAccept step keeps the record (and the key's
+    // highest column of row s, bit s of hcm) to itself, the batched CommitNotice step writes the cell ONCE, and whoever else
+    // needs the cell in memory first -- an Accept for it, a lane that leaves a batched step, a CommitNotice that does not come
+    // -- calls materialize(s): exactly the stores the PreAccept handler makes (messages.rs:60-93).  Nothing between the two
+    // steps reads such a cell unasked: the leader's own handlers touch its own row, and execution looks at a dependency's cell
+    // only below that row's commit bar (execution.rs:41-45), where a PreAccepting instance is not.
+    uint32_t defm = 0, hcm = 0;
+    auto materialize = [&](uint32_t s) {
+        EpInst<NR> I;
+        I.make_null();
+        const uint32_t c = PA(s, 1), k = PA(s, 2);
+        I.bal = (uint64_t)(s + 1u);
+        I.seq = (uint64_t)RP(s, q, 0) | ((uint64_t)(RP(s, q, 1) & 0x7FFFFFFFu) << 32);
+#pragma unroll
+        for (int r = 0; r < NR; r++) I.d[r] = RP(s, q, 2 + r);
+        I.set_status(EST_PREACCEPTING); I.set_key(k); I.set_bk(2u | (s << 2));
+        L.store_inst(L.ix(s, c), I);
+        if ((hcm >> s) & 1u) EA(v.hc, SHL_OF(hc_g + k, v.hc_es) + s) = c;
+        defm &= ~(1u << s); hcm &= ~(1u << s);
+    };
     // ---- every replica proposes ----
     EPC_PM_STAMP(0);
     if (live) {
@@ -2120,8 +2143,8 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 }
                 I.bal = (uint64_t)(s + 1u); I.seq = sn;
                 I.set_status(EST_PREACCEPTING); I.set_key(k); I.set_bk(2u | ((uint32_t)s << 2));
-                L.store_inst(L.ix(s, c), I);
-                if (my[s][s] == EP_NONE || c > my[s][s]) EA(v.hc, SHL_OF(hc_g + k, v.hc_es) + s) = c;
+                defm |= 1u << s;                                             // (the record and the key's entry: see materialize)
+                if (my[s][s] == EP_NONE || c > my[s][s]) hcm |= 1u << s;
                 RP(s, q, 0) = (uint32_t)sn; RP(s, q, 1) = ((uint32_t)(sn >> 32) & 0x7FFFFFFFu) | (1u << 31);
 #pragma unroll
                 for (int i = 0; i < NR; i++) RP(s, q, 2 + i) = I.d[i];
@@ -2183,6 +2206,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 uint8_t of; uint64_t ob, os; uint32_t d[NR], in[NR];
 #pragma unroll
                 for (int i = 0; i < NR; i++) in[i] = (uint32_t)i < R ? PA(s, 5 + i) : EP_NONE;
+                if (((PA(s, 0) >> 8) & 0xFFu) == EST_ACCEPTING && ((defm >> s) & 1u)) materialize(s);   // (the handler reads the cell)
                 ep_acceptor_lane_in<1, NR, false>(L, ((PA(s, 0) >> 8) & 0xFFu) == EST_ACCEPTING, s, s, PA(s, 1), (uint64_t)(s + 1u),
                                                   (uint64_t)PA(s, 3) | ((uint64_t)PA(s, 4) << 32), in, PA(s, 2), of, ob, os, d);
                 sh_af[((size_t)(set * NR + s) * NR + q) * 64 + lane] = of;
@@ -2239,8 +2263,14 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
         for (int s = 0; s < NR; s++) {
             const bool m = (uint32_t)s < R;
             const uint32_t i = L.ix(m ? s : 0u, col[s]);
-            w0[s] = (m && (uint32_t)s != q) ? EA(v.p0, i) : (u32x4){0u, 0u, 0u, 0u};
-            w2[s] = m ? EA(v.p2, i) : (u32x4){0u, 0u, 0u, 0u};
+            w0[s] = (u32x4){0u, 0u, 0u, 0u}; w2[s] = (u32x4){0u, 0u, 0u, 0u};
+            if ((defm >> s) & 1u) {                                          // what materialize(s) would have stored: known, not loaded
+                w0[s] = (u32x4){(uint32_t)(s + 1u), 0u, RP(s, q, 0), RP(s, q, 1) & 0x7FFFFFFFu};
+                w2[s] = (u32x4){RP(s, q, 6), (uint32_t)EST_PREACCEPTING | (PA(s, 2) << 8) | ((2u | ((uint32_t)s << 2)) << 16), 0u, EP_NONE};
+            } else if (m) {
+                if ((uint32_t)s != q) w0[s] = EA(v.p0, i);
+                w2[s] = EA(v.p2, i);
+            }
             kvcur[s] = (m && a.execute) ? EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + v.hc_kv) : 0u;
         }
         uint64_t dg = a.execute ? EA(x.digest, g) : 0ull;
@@ -2356,13 +2386,16 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 const uint32_t c = col[s], i = L.ix(s, c);
                 if ((uint32_t)s != q) {
                     const uint32_t sl = PA(s, 3), sh = PA(s, 4);
-                    if (w0[s].x != (uint32_t)(s + 1u) || w0[s].y != 0u || w0[s].z != sl || w0[s].w != sh) {
+                    const bool fresh = (defm >> s) & 1u;                     // nothing of the cell is in memory: every word goes out, once
+                    if (fresh && ((hcm >> s) & 1u)) EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + s) = c;
+                    defm &= ~(1u << s); hcm &= ~(1u << s);
+                    if (fresh || w0[s].x != (uint32_t)(s + 1u) || w0[s].y != 0u || w0[s].z != sl || w0[s].w != sh) {
                         EA(v.p0, i) = (u32x4){(uint32_t)(s + 1u), 0u, sl, sh};
                         EA(v.sq32, i) = (sh == 0u && sl != 0xFFFFFFFFu) ? sl : 0xFFFFFFFFu;
                     }
                     // deps[0..3] as my PreAcceptReply of this tick carried them are what the cell holds while it is still PreAccepting:
                     // the word is written only where the decision differs
-                    const bool same_p1 = (w2[s].y & 0xFFu) == EST_PREACCEPTING && (RP(s, q, 1) >> 31) && RP(s, q, 2) == PA(s, 5) && RP(s, q, 3) == PA(s, 6) &&
+                    const bool same_p1 = !fresh && (w2[s].y & 0xFFu) == EST_PREACCEPTING && (RP(s, q, 1) >> 31) && RP(s, q, 2) == PA(s, 5) && RP(s, q, 3) == PA(s, 6) &&
                                          RP(s, q, 4) == PA(s, 7) && RP(s, q, 5) == PA(s, 8);
                     if (!same_p1)
                         EA(v.p1, i) = (u32x4){PA(s, 5), NR > 1 ? PA(s, 6) : EP_NONE, NR > 2 ? PA(s, 7) : EP_NONE, NR > 3 ? PA(s, 8) : EP_NONE};
@@ -2385,7 +2418,10 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 EA(x.n_sub, g) = last_sub;
                 E.c_exec += n_exec; E.c_attempts += n_att; E.c_unheld += n_unh; E.c_aborts += n_abort;
             }
+            for (uint32_t s = 0; s < R; s++)                                 // a PreAccepted instance whose CommitNotice did not come: as the handler leaves it
+                if ((defm >> s) & 1u) materialize(s);
         } else {
+            for (uint32_t s = 0; s < R; s++) if ((defm >> s) & 1u) materialize(s);
             defer = true;                                                    // nothing of this phase has been stored for the lane
             n_one_by_one += 1ull << 32;
         }

@@ -26,6 +26,26 @@ def test_exports_every_declared_symbol(engine_lib):
     assert engine_lib.smr_abi_version() == 1
 
 
+def test_integration_md_declares_every_symbol(engine_lib):
+    """INTEGRATION.md named 145 of the 237 exported symbols.  Its §6 is generated from the header
+    (tools/gen_rust_extern.py): the block must be current, and every `smr_*` symbol the built library exports must have its
+    `pub fn` there -- and the other way round."""
+    import subprocess
+    import sys
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_extern.py"), "--check"])
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("<!-- BEGIN GENERATED: tools/gen_rust_extern.py -->"):doc.index("<!-- END GENERATED: tools/gen_rust_extern.py -->")]
+    bound = set(re.findall(r"pub fn (smr_[a-z0-9_]+)\(", block))
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "summerset_amd", "libsummerset_hip.so")], check=True,
+                        capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("smr_") and ln.split()[-2] in "TtWw"}
+    assert exported - bound == set(), "exported but not declared in INTEGRATION.md: %s" % sorted(exported - bound)
+    assert bound - exported == set(), "declared in INTEGRATION.md but not exported: %s" % sorted(bound - exported)
+    assert bound == set(_declared())
+    # the structs are #[repr(C)] field for field: spot checks against the ctypes mirror the tests run on
+    assert "pub struct SmrMpCfg {" in block and "pub n_groups: u32," in block and "pub struct SmrEpClusterOut {" in block
+
+
 def test_host_only_entry_points(engine_lib):
     from summerset_amd import rs_matrix, rs_shard_len
     assert rs_matrix(3, 2).tolist() == [[1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [15, 8, 6]]
