@@ -574,9 +574,17 @@ def epaxos_cluster_leg(torch, dev, ticks=10):
                 # so this is the tally's figure over the WHOLE tick's time: a lower bound on what the kernel moves
                 alg = 370.0 * R * G
                 us = leg["tick_us_device_median"]
-                leg["roofline"] = {"bound": "hbm", "kernel": "ep_cluster_tick_kernel<5> (the whole tick: 1 launch)", "achieved": alg / us / 1e3,
+                # (phase by phase, round 6: the batched tick kernel + the launch that takes the lanes it lists one by one -- both
+                #  inside the timed call, both in `traffic`)
+                kern = ("ep_cluster_tick_pm_kernel<5> + ep_cluster_commit_one_by_one_kernel<5> (the whole tick: 2 launches)" if pm else
+                        "ep_cluster_tick_kernel<5> (the whole tick: 1 launch)")
+                traffic = (_sum_traffic("smr::ep_cluster_tick_pm_kernel<5>", "smr::ep_cluster_commit_one_by_one_kernel<5>") if pm else
+                           _leg_traffic("smr::ep_cluster_tick_kernel<5, false>"))
+                if pm:
+                    leg["launches_per_tick"] = 2
+                leg["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": alg / us / 1e3,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / us / 1e3 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
-                                   "avg_launch_us": us, "traffic": _leg_traffic("smr::ep_cluster_tick_kernel<5, false>"), "traffic_source": PMC_NOTE,
+                                   "avg_launch_us": us, "traffic": traffic, "traffic_source": PMC_NOTE,
                                    "note": "alg bytes = SURVEY 8(d)'s <= 370 B per instance x 5 x 65536 instances per tick (the tally's figure; the "
                                            "tick also runs 5 proposals, 20 PreAccepts, 20 CommitNotices and the execution walks per group)"}
             line[name] = leg

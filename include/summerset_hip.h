@@ -357,7 +357,9 @@ int smr_mp_deliver_acks(smr_mp_cluster *c, uint8_t rep, const smr_mp_ack *acks_d
                         void *stream);
 /* smr_mp_deliver_acks for records in one segment per connection, as smr_wire_ingest_mp_conn leaves them: connection c -- replica
  * conn_peer_dev[c] of group conn_group_dev[c] -- has cnt_dev[3 * c] 12-byte records { slot, ballot lo, ballot hi }
- * (smr_wire_ack12, declared with that call) from record conn_off_dev[c] / 13 on (records at or past ack_cap are not there). */
+ * (smr_wire_ack12, declared with that call) from record conn_off_dev[c] / 13 on (records at or past ack_cap are not there).
+ * conn_off_dev [n_conn + 1] and cnt_dev are the arrays of the SAME ingest call: a count that reaches past the connection's own
+ * segment (conn_off[c + 1] / 13) or past ack_cap is cut there and the rest counted in *dropped_dev. */
 int smr_mp_deliver_acks_conn(smr_mp_cluster *c, uint8_t rep, const void *acks12_dev, uint64_t ack_cap, const uint64_t *conn_off_dev,
                              const uint32_t *conn_group_dev, const uint8_t *conn_peer_dev, const uint32_t *cnt_dev, uint32_t n_conn,
                              uint64_t *dropped_dev, void *stream);
@@ -775,7 +777,10 @@ int smr_ep_dump(smr_ep_replica *e, const smr_ep_dump_bufs *host_bufs);
  * d = (d ^ token) * 0x100000001B3, d = (d ^ old) * 0x100000001B3 over the submissions of a group.
  * Host buffers: exec_bars [R][G], kv [n_keys][G], digest [G], counters[6] = commands submitted, of them
  * re-submissions of an already executing instance, pops of an instance that left the ring (counted
- * as executed), 0, attempts, abandoned attempts. */
+ * as executed), 0, attempts, abandoned attempts.
+ * The device keeps a key's KV word in 32 bits (4 of row + 1, 28 of the column): once an instance has been executed at a column
+ * >= 2^28 this call and smr_ep_exec_poll answer SMR_ERR_STATE (the buffers are still filled) -- tokens that are not the
+ * reference's are never handed out silently. */
 int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint64_t *digest, uint64_t *counters);
 /* the commands the LAST handler call submitted to the state machine (state_machine.submit_cmd, execution.rs:113-131),
  * group-major, in submission order within a group: instance (row, col) of group -- the host applies them in this

@@ -534,8 +534,12 @@ typedef EpLaneT<EMAXR, false> EpLane;
 // the nodes joined.  Per group: nodes in insertion order (nslot, bit 15 = new), the forest as
 // head / sib / parent links over node ids, node_of[ring cell] = node id + 1, and the submissions of
 // the whole call in `order`; all uint16 [index][G].
-// the executor's KV word in 32 bits: a token is (row + 1) << 32 | col with row + 1 <= 8 and -- a column grows by one per tick --
-// col < 2^28 for 8 years of ticks at 1 kHz
+// the executor's KV word in 32 bits: a token is (row + 1) << 32 | col with row + 1 <= 8, and the word keeps 28 bits of the column.  A
+// column grows by at most one per tick: 2^28 ticks are 3.1 days at 1 kHz and 6.5 hours at the 0.09 ms ticks of the bench (ADVICE
+// r5: round 5's comment said years).  An instance executed at a column >= 2^28 would leave a word that unpacks to another
+// token: the executor COUNTS such submissions (EpExecLaneT::c_kvovf, counter slot 3) and smr_ep_exec_dump / smr_ep_exec_poll
+// answer SMR_ERR_STATE from then on instead of handing out tokens that are not the reference's.
+constexpr uint32_t EP_KV_COL_LIMIT = 1u << 28;
 __host__ __device__ __forceinline__ uint32_t ep_kv_pack(uint64_t tok) { return tok ? (uint32_t)((tok >> 32) << 28) | ((uint32_t)tok & 0x0FFFFFFFu) : 0u; }
 __host__ __device__ __forceinline__ uint64_t ep_kv_unpack(uint32_t w) { return w ? ((uint64_t)(w >> 28) << 32) | (w & 0x0FFFFFFFu) : 0ull; }
 constexpr uint16_t XNIL = 0xFFFF;
@@ -604,6 +608,7 @@ struct EpExecLaneT {
     uint32_t last_node = 0;                                  // node_of[last] (node id + 1; 0: not a node), kept beside it
     bool reins = false;                                      // this attempt made a node of an executed cell (add_edge's missing endpoint)
     unsigned int c_exec = 0, c_reexec = 0, c_unheld = 0, c_attempts = 0, c_aborts = 0;
+    unsigned int c_kvovf = 0;                                // submissions whose column does not fit the 32-bit KV word (ep_kv_pack)
     __device__ __forceinline__ EpExecLaneT(const EpView &v_, const EpExec &x_, EpLaneT<NR, CACHE> &L_, uint32_t g_)
         : v(v_), x(x_), L(L_), g(g_), wshift(31u - (uint32_t)__clz((int)v_.W)) {}
     // (the walk's arrays are [index][G] planes of the arena -- or, where the caller hands the lane private ones (walk_in: a few lanes of a
@@ -656,6 +661,7 @@ struct EpExecLaneT {
         const uint32_t key = I.key();
         if (key != EP_NO_KEY) {
             const uint64_t tok = ((uint64_t)(row + 1) << 32) | col, old = ep_kv_unpack(kv_at(key));
+            if (col >= EP_KV_COL_LIMIT) c_kvovf++;
             kv_at(key) = ep_kv_pack(tok);
             uint64_t d = EA(x.digest, g);
             d = (d ^ tok) * EP_DG_MUL; d = (d ^ old) * EP_DG_MUL;
@@ -852,6 +858,7 @@ struct EpExecLaneT {
         const uint32_t first = n_order;
         {
             const uint64_t tok_ = ((uint64_t)(row + 1) << 32) | hcol;
+            if (hcol >= EP_KV_COL_LIMIT) c_kvovf++;
             kv_at(key) = ep_kv_pack(tok_);
             dg = (dg ^ tok_) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
             EA(x.digest, g) = dg;
@@ -897,9 +904,9 @@ struct EpExecLaneT {
         }
     }
     __device__ __forceinline__ void flush() {
-        unsigned int c[5] = {c_exec, c_reexec, c_unheld, c_attempts, c_aborts};
-        const int slot[5] = {0, 1, 2, 4, 5};
-        for (int k = 0; k < 5; k++) {
+        unsigned int c[6] = {c_exec, c_reexec, c_unheld, c_attempts, c_aborts, c_kvovf};
+        const int slot[6] = {0, 1, 2, 4, 5, 3};
+        for (int k = 0; k < 6; k++) {
             unsigned int y = c[k];
             for (int off = 32; off > 0; off >>= 1) y += __shfl_xor(y, off);
             if (__lane_id() == 0 && y) ctr_add(x.counters, (int)slot[k], (unsigned long long)y);
@@ -931,7 +938,9 @@ __device__ __forceinline__ void ep_exec_after_handler(const EpView &v, const EpE
 // (of, oc, os, d) = the PreAccept to broadcast
 template <int NR, bool C>
 __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, uint32_t ex, uint8_t &of, uint32_t &oc, uint64_t &os,
-                                                uint32_t (&d)[NR]) {
+                                                uint32_t (&d)[NR], bool *hc_later = nullptr, bool *rec_later = nullptr) {
+    // hc_later: the key's entry is the caller's to update.  rec_later: where the instance takes a fresh cell at the row's end, neither its
+    // record nor my own PreAcceptReply is stored -- *rec_later = true, and both are the caller's (ep_cluster_tick_pm_kernel: materialize_own)
     const EpView &v = L.v;
     of = 0; oc = 0; os = 0;
 #pragma unroll
@@ -948,6 +957,7 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
             L.load_meta(L.ix(row, c), J);
             if (J.status() == EST_NULL) { col = c; I.m0 = J.m0; I.m1 = J.m1; break; }   // (a padded slot may carry replica bookkeeping: explicit prepare)
         }
+    const bool at_end = col == EP_NONE;
     if (col == EP_NONE) { L.push_null(row, false); col = L.get_len(row) - 1; }   // (the null record itself is never stored: the whole cell is, below)
     L.add_nulls(0xFFFFFFFFu);                                                      // the slot stops being null
     L.identify_deps(k, d);                                                   // (one round: the key's R highest columns)
@@ -972,13 +982,16 @@ __device__ __forceinline__ void ep_propose_lane(EpLaneT<NR, C> &L, uint32_t k, u
         uint32_t hc_row = EP_NONE;
 #pragma unroll
         for (int q = 0; q < NR; q++) if ((uint32_t)q == row) hc_row = d[q];
-        if (hc_row == EP_NONE || col > hc_row) EA(v.hc, SHL_OF(M24(L.g, v.n_keys) + k, v.hc_es) + row) = col;
+        const bool up = hc_row == EP_NONE || col > hc_row;
+        if (hc_later) *hc_later = up;
+        else if (up) EA(v.hc, SHL_OF(M24(L.g, v.n_keys) + k, v.hc_es) + row) = col;
     }
     L.fresh_leader_bk(i, I);
     I.set_status(EST_PREACCEPTING);
     I.set_pa_acks(1u << v.me);                                               // (my own PreAcceptReply, below)
-    L.store_inst(i, I);
     of = 1; oc = col; os = seq;
+    if (rec_later && at_end && !v.recovery) { *rec_later = true; return; }
+    L.store_inst(i, I);
     // my own PreAcceptReply (durability.rs:25-35 -> messages.rs:96-270) on bookkeeping that is fresh: it is recorded and is the
     // only one held, and one reply is below any quorum (simple_q >= 2 at populations >= 3) -- handle_msg_pre_accept_reply
     // returns at dependency.rs:205 without looking at `ex`
@@ -1243,10 +1256,13 @@ struct EpRepliesInRegs {
     }
 };
 
+// own (ep_cluster_tick_pm_kernel): the instance as my proposal of this tick made it -- nothing of it or of my own reply is in memory
+// yet (ep_propose_lane's rec_later): the record comes from *own, my reply is (own->seq, own->d), and whatever this call leaves
+// behind goes out in full
 template <int NR, bool C, typename RD>
 __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex, const RD &rdr,
                                                       uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
-                                                      EpInst<NR> *rec = nullptr, bool *stored = nullptr) {
+                                                      EpInst<NR> *rec = nullptr, bool *stored = nullptr, const EpInst<NR> *own = nullptr) {
     const EpView &v = L.v;
     if (stored) *stored = false;
     const uint32_t R = v.R;
@@ -1256,8 +1272,8 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
     // it already holds
     EpInst<NR> I;
     I.make_null();
-    I.bal = L.bal_at(i);
-    L.load_meta(i, I);
+    if (own) I = *own;
+    else { I.bal = L.bal_at(i); L.load_meta(i, I); }
     uint32_t st = h ? I.status() : 0u, acks = h ? I.pa_acks() : 0u;
     const uint64_t b = h ? I.bal : 0ull;
     const uint32_t bk = h ? I.bk() : 0u;
@@ -1266,10 +1282,10 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
     uint64_t ps[NR]; uint32_t pd[NR][NR];
 #pragma unroll
     for (int p = 0; p < NR; p++) {
-        const bool on = (acks >> p) & 1u;
-        ps[p] = on ? EA(v.pa_seq, L.ps_ix(row, c, p)) : 0ull;
+        const bool on = (acks >> p) & 1u, mine = own && (uint32_t)p == v.me;
+        ps[p] = mine ? own->seq : (on ? EA(v.pa_seq, L.ps_ix(row, c, p)) : 0ull);
 #pragma unroll
-        for (int k = 0; k < NR; k++) pd[p][k] = (on && (uint32_t)k < R) ? EA(v.pa_deps, L.pd_ix(row, c, p, k)) : EP_NONE;
+        for (int k = 0; k < NR; k++) pd[p][k] = mine ? own->d[k] : ((on && (uint32_t)k < R) ? EA(v.pa_deps, L.pd_ix(row, c, p, k)) : EP_NONE);
     }
     dseq = 0;
 #pragma unroll
@@ -1299,7 +1315,7 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
     // PreAccepting in THIS call nobody reads the table again -- a reader looks at acked peers of a PreAccepting instance only,
     // and fresh bookkeeping starts from an empty ack mask -- so the replies of a decided instance are not stored: 28 bytes per
     // peer, the common case of the one-launch tick, where all of an instance's replies arrive in one call.)
-    const uint32_t fresh = acks & ~acks0;
+    const uint32_t fresh = own ? acks : (acks & ~acks0);                     // (own: my reply is not in the table either)
     const bool decided = h && before == EST_PREACCEPTING && st != EST_PREACCEPTING;
 #pragma unroll
     for (int p = 0; p < NR; p++)
@@ -1320,6 +1336,8 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
         if (rec && st == EST_COMMITTED) { *rec = I; *stored = true; }
         if (st == EST_COMMITTED) { L.n_fast++; L.logged_commit_slot(row, c, &I); dec = EST_COMMITTED; }   // :158-206
         else { L.n_slow++; L.accept_reply(v.me, row, c, b); dec = L.status_at(i) >= EST_COMMITTED ? EST_COMMITTED : EST_ACCEPTING; }   // :209-262
+    } else if (own) {
+        L.store_inst(i, I);                                                  // undecided: the proposal's record, with the acks so far, for the first time
     } else if (fresh) {
         L.store_meta(i, I);                                                  // only the ack mask moved (deps[4], deps[5] as loaded)
     }
@@ -2038,9 +2056,14 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
     // only below that row's commit bar (execution.rs:41-45), where a PreAccepting instance is not.
     uint32_t defm = 0, hcm = 0;
     auto materialize = [&](uint32_t s) {
+        const uint32_t c = PA(s, 1), k = PA(s, 2);
+        if (s == q) {                                                        // my own proposal: its record went out with the proposal, the key's entry waits
+            if ((hcm >> s) & 1u) EA(v.hc, SHL_OF(hc_g + k, v.hc_es) + s) = c;
+            hcm &= ~(1u << s);
+            return;
+        }
         EpInst<NR> I;
         I.make_null();
-        const uint32_t c = PA(s, 1), k = PA(s, 2);
         I.bal = (uint64_t)(s + 1u);
         I.seq = (uint64_t)RP(s, q, 0) | ((uint64_t)(RP(s, q, 1) & 0x7FFFFFFFu) << 32);
 #pragma unroll
@@ -2050,13 +2073,38 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
         if ((hcm >> s) & 1u) EA(v.hc, SHL_OF(hc_g + k, v.hc_es) + s) = c;
         defm &= ~(1u << s); hcm &= ~(1u << s);
     };
+    // ... and my own proposal of this tick likewise (own_def): its record and my own PreAcceptReply go out when my PreAcceptReplies
+    // step has the decision -- once, instead of a proposal's record now, 32 bytes of it read back and the decision's written then --
+    // or, undecided, as the proposal left them.  Between the two only my own PreAccept handlers look at that cell (its sequence
+    // number, for an instance of the same key): the batched step takes it out of sh_pa, a lane that leaves it materializes first.
+    bool own_def = false;
+    auto own_inst = [&]() -> EpInst<NR> {                                    // (before the PreAcceptReplies step overwrites sh_pa's seq / deps)
+        EpInst<NR> I;
+        I.make_null();
+        I.bal = (uint64_t)(q + 1u); I.seq = (uint64_t)PA(q, 3) | ((uint64_t)PA(q, 4) << 32);
+#pragma unroll
+        for (int r = 0; r < NR; r++) I.d[r] = PA(q, 5 + r);
+        I.set_status(EST_PREACCEPTING); I.set_key(PA(q, 2)); I.set_bk(1u); I.set_pa_acks(1u << q);
+        return I;
+    };
+    auto materialize_own = [&]() {                                           // what ep_propose_lane stores (request.rs:48-108, durability.rs:25-35)
+        if (!own_def) return;
+        const EpInst<NR> I = own_inst();
+        const uint32_t c = PA(q, 1);
+        L.store_inst(L.ix(q, c), I);
+        EA(v.pa_seq, L.ps_ix(q, c, q)) = I.seq;
+        for (uint32_t r = 0; r < R; r++) EA(v.pa_deps, L.pd_ix(q, c, q, r)) = PA(q, 5 + r);
+        own_def = false;
+    };
     // ---- every replica proposes ----
     EPC_PM_STAMP(0);
     if (live) {
         const smr_ep_cluster_out &o = a.out[q];
         uint8_t of; uint32_t oc; uint64_t os; uint32_t d[NR];
         const uint32_t key = a.keys[q][g];
-        ep_propose_lane(L, key, 0u, of, oc, os, d);
+        bool up = false;
+        ep_propose_lane(L, key, 0u, of, oc, os, d, &up, &own_def);
+        if (up && of) hcm |= 1u << q;                                        // (my key's highest column in my row: written with the tick's other words of that line)
         o.proposed[g] = of; o.col[g] = oc; o.seq0[g] = os;
 #pragma unroll
         for (int i = 0; i < NR; i++) if ((uint32_t)i < R) o.deps0[(size_t)i * G + g] = d[i];
@@ -2092,6 +2140,15 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
 #pragma unroll
                 for (int r = 0; r < NR; r++)
                     my[s][r] = ((uint32_t)s < R && (uint32_t)s != q && (uint32_t)r < R) ? EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + r) : EP_NONE;
+            // ... behind my own proposal, whose update of its key's entry is still with me (hcm bit q)
+            if ((hcm >> q) & 1u) {
+                const uint32_t cq = PA(q, 1), kq = PA(q, 2);
+#pragma unroll
+                for (int s = 0; s < NR; s++)
+#pragma unroll
+                    for (int r = 0; r < NR; r++)
+                        if ((uint32_t)r == q && ((onm >> s) & 1u) && key[s] == kq && (my[s][r] == EP_NONE || cq > my[s][r])) my[s][r] = cq;
+            }
             // what handler s reads behind handler s' < s of the same key: hc[key][s'] as s' left it (dependency.rs:141-167)
 #pragma unroll
             for (int s = 1; s < NR; s++)
@@ -2125,6 +2182,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                     const bool ok = (uint32_t)r < R && d != EP_NONE && L.held((uint32_t)r < R ? r : 0, d);
                     uint64_t val = sq[s][r];
                     if (r < s && ((onm >> r) & 1u) && d == col[r]) val = nseq[r];   // the instance handler r stored an instant ago
+                    if ((uint32_t)r == q && own_def && d == PA(q, 1)) val = (uint64_t)PA(q, 3) | ((uint64_t)PA(q, 4) << 32);   // my own proposal of this tick
                     if (ok && val > ms) ms = val;
                 }
                 ms += 1;
@@ -2150,6 +2208,8 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 for (int i = 0; i < NR; i++) RP(s, q, 2 + i) = I.d[i];
             }
         } else {
+            materialize(q);                                                  // (the handlers read the keys' entries in memory, and my proposal's sequence number)
+            materialize_own();
             for (uint32_t s = 0; s < R; s++) {
                 if (s == q) continue;
                 const uint8_t *dm = a.drop[s * NR + q];
@@ -2180,7 +2240,9 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
             bool have_h = false;
             const uint32_t h_col = PA(q, 1);
             const EpRepliesInLds<NR> rdr{sh_rep + (size_t)(set * NR + q) * (NR - 1) * EPC_REP_WORDS * 64, q, lane};
-            ep_pa_replies_lane_rd<NR, true>(L, q, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h);
+            const EpInst<NR> mine = own_inst();
+            ep_pa_replies_lane_rd<NR, true>(L, q, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h, own_def ? &mine : nullptr);
+            own_def = false;                                                 // (decided or not, the cell is in memory now)
             PA(q, 0) = (PA(q, 0) & 1u) | ((uint32_t)dec << 8);
             PA(q, 3) = dec ? (uint32_t)dseq : 0u; PA(q, 4) = dec ? (uint32_t)(dseq >> 32) : 0u;
 #pragma unroll
@@ -2331,6 +2393,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
             constexpr int r = decltype(RC)::value;
             const uint64_t tok = ((uint64_t)(r + 1u) << 32) | col[r];
             const uint64_t old = ep_kv_unpack(kvcur[r]);
+            EPC_WHY(13, col[r] < EP_KV_COL_LIMIT);                           // (counted where the handlers run one by one)
             dg = (dg ^ tok) * EP_DG_MUL; dg = (dg ^ old) * EP_DG_MUL;
             const uint32_t tw = ep_kv_pack(tok);
 #pragma unroll
@@ -2419,9 +2482,9 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
                 E.c_exec += n_exec; E.c_attempts += n_att; E.c_unheld += n_unh; E.c_aborts += n_abort;
             }
             for (uint32_t s = 0; s < R; s++)                                 // a PreAccepted instance whose CommitNotice did not come: as the handler leaves it
-                if ((defm >> s) & 1u) materialize(s);
+                if (((defm | hcm) >> s) & 1u) materialize(s);                //     (and my own key's entry)
         } else {
-            for (uint32_t s = 0; s < R; s++) if ((defm >> s) & 1u) materialize(s);
+            for (uint32_t s = 0; s < R; s++) if (((defm | hcm) >> s) & 1u) materialize(s);
             defer = true;                                                    // nothing of this phase has been stored for the lane
             n_one_by_one += 1ull << 32;
         }
@@ -2846,6 +2909,9 @@ int smr_ep_exec_dump(smr_ep_replica *e, uint32_t *exec_bars, uint64_t *kv, uint6
     unsigned long long c[8];
     SMR_HIP_TRY(ctr_read(e->x.counters, 8, c));
     for (int k = 0; k < 6; k++) counters[k] = c[k];
+    counters[3] = 0;                                                             // (the dump's slot 3 stays the reference's unused counter)
+    if (c[3]) return fail(SMR_ERR_STATE, "epaxos: " + std::to_string(c[3]) + " instances were executed at a column >= 2^28: the 32-bit KV words of the per-key "
+                                         "table cannot hold their tokens (start a fresh replica object; ep_kv_pack)");
     return SMR_OK;
 }
 
@@ -2876,6 +2942,11 @@ int smr_ep_exec_poll(smr_ep_replica *e, uint32_t *group_host, uint8_t *row_host,
         }
     *n_out = n;
     if (group_host && row_host && col_host) SMR_HIP_TRY(hipMemset(e->x.n_sub, 0, G * 4));   // a count-only call leaves them
+    {
+        unsigned long long c[8];
+        SMR_HIP_TRY(ctr_read(e->x.counters, 8, c));
+        if (c[3]) return fail(SMR_ERR_STATE, "epaxos: an instance was executed at a column >= 2^28: its token does not fit the 32-bit KV word (ep_kv_pack)");
+    }
     return SMR_OK;
 }
 

@@ -1805,12 +1805,18 @@ __global__ __launch_bounds__(256) void mp_deliver_acks_conn_kernel(const MpParam
     const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     uint32_t drop = 0;
     if (c < n_conn) {
-        const uint32_t n = cnt[(size_t)c * 3], group = conn_group[c], peer = conn_peer[c];
+        const uint32_t n_said = cnt[(size_t)c * 3], group = conn_group[c], peer = conn_peer[c];
         const uint64_t base = conn_off[c] / 13u;
+        // a connection's segment ends where the next one's begins (conn_off has n_conn + 1 entries) and at `cap`: a count that
+        // says more -- arrays of two different ingest calls -- must not make a neighbour's records this connection's;
+        // what is cut off is counted as dropped
+        const uint64_t room_seg = conn_off[c + 1] / 13u - base, room_cap = cap > base ? cap - base : 0ull;
+        const uint64_t room = room_seg < room_cap ? room_seg : room_cap;
+        const uint32_t n = (uint64_t)n_said < room ? n_said : (uint32_t)room;
+        if (lane == 0) drop += n_said - n;
         const RepView v{P.rep[0], (size_t)rep * P.rep_stride};
         const bool mine = group < P.G && peer < P.R && peer != rep;
         for (uint32_t j = lane; j < n; j += 64u) {
-            if (base + j >= cap) break;
             const uint32_t *r = recs + (base + j) * 3u;
             uint32_t d = 1;
             if (mine) {
@@ -2889,6 +2895,9 @@ static int spread_multi_round(smr_mp_spread *s, int which, const smr_mp_tick_in 
         M.p[b] = c->dp; M.par[b] = c->par; M.hint[b] = c->lead_hint;
         if (in) {
             const smr_mp_tick_in &x = in[b];
+            // (the checks smr_mp_round_local makes per cluster: here the arrays go to the device as they are -- ADVICE r5)
+            if (which == 0 && x.timeout_rep_dev && !x.timeout_src_dev) return fail(SMR_ERR_ARG, "mp: timeout_rep without timeout_src");
+            if (which == 0 && x.req_target_dev && (!x.req_cnt_dev || !x.req_val_dev)) return fail(SMR_ERR_ARG, "mp: incomplete request arrays");
             M.in[b] = MpTickIn{x.timeout_rep_dev, x.timeout_src_dev, x.req_target_dev, x.req_cnt_dev, x.req_val_dev, x.ackctl_dev, x.S, heartbeat};
         }
         if (c->cfg.n_groups > gmax) gmax = c->cfg.n_groups;

@@ -954,6 +954,7 @@ struct smr_raft_leader {
     bool craft = false;
     CraftView cv;
     uint8_t *craft_base = nullptr;
+    int device = -1;                 // the device current when the object was created: where its arena is
     RaftView *d_view = nullptr;      // a device copy of v for smr_raft_cluster_replicate (made on first use; craft_enable changes v)
     bool d_view_ok = false;
 };
@@ -1017,10 +1018,17 @@ int smr_raft_leader_create(const smr_raft_cfg *cfg, smr_raft_leader **out) {
     if (e == hipSuccess) e = hipMemcpy(v.log_len, one.data(), G * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v.next_slot, one.data(), G * v.R * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(v.try_next_slot, one.data(), G * v.R * 4, hipMemcpyHostToDevice);
+    // the device copy of the view smr_raft_cluster_replicate's followers are read through: made HERE (and again by craft_enable),
+    // so that the stream-ordered call allocates and copies nothing (a blocking hipMalloc + hipMemcpy inside it)
+    if (e == hipSuccess) e = hipGetDevice(&l->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->d_view, sizeof(RaftView));
+    if (e == hipSuccess) e = hipMemcpy(l->d_view, &l->v, sizeof(RaftView), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
+        if (l->d_view) (void)hipFree(l->d_view);
         (void)hipFree(l->arena.base); delete l;
         return fail(SMR_ERR_DEVICE, std::string("raft: init: ") + hipGetErrorString(e));
     }
+    l->d_view_ok = true;
     *out = l;
     return SMR_OK;
 }
@@ -1107,7 +1115,8 @@ int smr_raft_craft_enable(smr_raft_leader *l, uint8_t fault_tolerance, uint8_t r
     SMR_HIP_TRY(hipMemset(cv.alive, (int)((1u << R) - 1u), G));   // heartbeat.rs:131
     l->v.thresh = quorum + fault_tolerance;
     l->craft = true;
-    l->d_view_ok = false;
+    SMR_HIP_TRY(hipMemcpy(l->d_view, &l->v, sizeof(RaftView), hipMemcpyHostToDevice));   // (the threshold moved: the view's device copy follows)
+    l->d_view_ok = true;
     return SMR_OK;
 }
 
@@ -1373,11 +1382,14 @@ int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_lea
             return fail(SMR_ERR_ARG, "raft replicate: null argument");
         if (m.max_entries != A.K) return fail(SMR_ERR_ARG, "raft replicate: the messages differ in max_entries");
         if (f->craft && m.max_entries && !m.entry_mask) return fail(SMR_ERR_ARG, "craft: AppendEntries without the entries' shard bitmaps");
-        if (!f->d_view) SMR_HIP_TRY(hipMalloc((void **)&f->d_view, sizeof(RaftView)));
-        if (!f->d_view_ok) {
-            SMR_HIP_TRY(hipMemcpy(f->d_view, &f->v, sizeof(RaftView), hipMemcpyHostToDevice));
-            f->d_view_ok = true;
-        }
+        if (!f->d_view || !f->d_view_ok) return fail(SMR_ERR_STATE, "raft replicate: a follower has no device copy of its view");
+        // blocks of different blockIdx.y write follower k's message and reply arrays: two followers must not share them
+        for (uint32_t j = 0; j < k; j++)
+            if (msgs[j].flags == m.flags || msgs[j].n_entries == m.n_entries || msgs[j].term == m.term || replies[j].flags == r.flags ||
+                replies[j].end_slot == r.end_slot || replies[j].term == r.term)
+                return fail(SMR_ERR_ARG, "raft replicate: two followers share a message or reply buffer");
+        if (f->device != leader->device)                         // ... and the follower's state must be on the device the launch runs on
+            return fail(SMR_ERR_ARG, "raft replicate: a follower lives on another device than the leader");
         A.fv[k] = f->d_view; A.partial[k] = f->craft ? f->cv.partial : nullptr; A.first[k] = first_dev[k];
         A.m_flags[k] = (uint8_t *)m.flags; A.m_leader[k] = (uint8_t *)m.leader; A.m_term[k] = (uint64_t *)m.term;
         A.m_prev_slot[k] = (uint32_t *)m.prev_slot; A.m_prev_term[k] = (uint64_t *)m.prev_term; A.m_n[k] = (uint32_t *)m.n_entries;

@@ -177,8 +177,12 @@ __device__ __forceinline__ ps_u32x4 ps_load_data16(const uint8_t *p, uint32_t of
 }
 
 // (CRaft: the token of a log entry; its comment stands in front of the CRaft calls below)
+// 16 bits of the term and 14 of the slot folded over itself (round 6, ADVICE r5: 10 bits of the term let two conflicting entries
+// of one slot whose terms differ by a multiple of 1024 -- a partitioned candidate bumps its term every election timeout --
+// share a token, and the plan kernel then kept the stale shards).  A ring cell only ever holds slots that differ by multiples of
+// the window, so the fold tells generations of a cell apart for 2^14 windows; terms for 65 536 elections.
 __device__ __forceinline__ uint32_t craft_token(uint32_t slot, uint64_t term) {
-    return 0x40000000u | (((uint32_t)term & 0x3FFu) << 20) | (slot & 0xFFFFFu);
+    return 0x40000000u | (((uint32_t)term & 0xFFFFu) << 14) | ((slot ^ (slot >> 14)) & 0x3FFFu);
 }
 // the slot ring cell `row` of group g holds now (PS_NULL: none -- the dummy entry 0 carries no codeword)
 __device__ __forceinline__ uint32_t craft_cell_slot(uint32_t len, uint32_t st, uint32_t rl, uint32_t W, uint32_t row) {

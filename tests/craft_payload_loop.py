@@ -10,7 +10,7 @@ NULL = 0xFFFFFFFF
 
 
 def craft_token(slot, term):
-    return 0x40000000 | ((int(term) & 0x3FF) << 20) | (int(slot) & 0xFFFFF)
+    return 0x40000000 | ((int(term) & 0xFFFF) << 14) | ((int(slot) ^ (int(slot) >> 14)) & 0x3FFF)
 
 
 class Loop:
