@@ -110,7 +110,7 @@ def compact_line(full):
         wt = r.get("whole_tick") or {}
         out["roofline"] = {"bound": r.get("bound"), "kernel": str(r.get("kernel"))[:64], "alg_bytes_per_launch": _num(r.get("alg_bytes_per_launch")),
                            "avg_launch_us": _num(r.get("avg_launch_us")), "achieved": _num(r.get("achieved")), "peak": r.get("peak"),
-                           "unit": r.get("unit"), "frac": _num(r.get("frac"), 4), "traffic": _num(r.get("traffic")),
+                           "unit": r.get("unit"), "frac": _num(r.get("frac"), 4), "frac_pmc": _num(r.get("frac_pmc"), 4), "traffic": _num(r.get("traffic")),
                            "whole_tick": {"us": _num(wt.get("us")), "frac_alg": _num(wt.get("frac_alg"), 4), "frac_pmc": _num(wt.get("frac_pmc"), 4)}}
     else:
         out["roofline"] = None
@@ -1275,18 +1275,52 @@ def reply_ingest_leg(torch, dev, G=65536, R=5, iters=12, junk_every=16):
     def loop(i):
         frames, ln = wire.emit_raft_replies(fl, term, es, ct, cs)
         ing.raft(frames.view(-1), slot_off, d_grp, d_peer, conn_len=ln)
+    # round 6: the parse as the prologue of the leader's reply handler (smr_raft_leader_handle_wire_replies: ONE launch, no [R][G]
+    # arrays, no memsets) beside the two calls it stands for, on two leaders in the same state: frames -> last_commit
+    from summerset_amd import RaftLeaderGroup
+    lead_a, lead_b = RaftLeaderGroup(G, R, leader_id=0, window=64, term=3), RaftLeaderGroup(G, R, leader_id=0, window=64, term=3)
+    ing_b = wire.ReplyIngest(n_conn, G, R, n_conn, dev)
+    n32 = torch.full((G,), 32, dtype=torch.int32, device=dev)
+    ok2 = np.frombuffer(wire.raft_append_entries_reply(3, 30), np.uint8)
+    conf2 = np.frombuffer(wire.raft_append_entries_reply(3, 30, (2, 9)), np.uint8)
+    parts2 = [np.concatenate(([vote] if junk_every and c % junk_every == 0 else []) + [conf2 if c % 8 == 0 else ok2]) for c in range(16)]
+    off2 = np.zeros(n_conn + 1, np.int64)
+    off2[1:] = np.cumsum(np.tile(np.array([len(x) for x in parts2], np.int64), n_conn // 16))
+    buf2, d_off2 = torch.from_numpy(np.tile(np.concatenate(parts2), n_conn // 16)).to(dev), torch.from_numpy(off2).to(dev)
+    for ld in (lead_a, lead_b):
+        ld.handle_req_batch(n32)
+
+    def two_calls(i):
+        o2 = ing.raft(buf2, d_off2, d_grp, d_peer)
+        lead_a.handle_msg_append_entries_reply(o2["reply_term"], o2["end_slot"], o2["flags"], o2["conflict_term"], o2["conflict_slot"])
+    two_calls(0)
+    ing_b.raft_into(lead_b, buf2, d_off2)
+    ra, rb = ing.results(), ing_b.results()
+    da, db = lead_a.dump(), lead_b.dump()
+    assert all(ra[k] == rb[k] for k in ("n_replies", "n_others", "n_malformed", "n_deferred")) and all(np.array_equal(da[k], db[k]) for k in da)
+    assert int(db["last_commit"].min()) == 30
+    us_two = _time_us(torch, two_calls, iters)
+    us_fused = _time_us(torch, lambda i: ing_b.raft_into(lead_b, buf2, d_off2), iters)
     loop(0)
     r2 = ing.results()
     assert r2["n_replies"] == n_conn and r2["n_malformed"] == 0 and int(o["flags"][1:].sum().item()) == n_conn + 2 * (n_conn // 8)
     us_loop = _time_us(torch, loop, iters)
     alg = int(off[-1]) + n_conn * (8 + 4 + 1) + (n_conn // 8) * 12
     return {"workload": "Raft leader-side receive path of one tick: %d connections (%d groups x %d followers), one AppendEntriesReply each -> the "
-                        "[R][G] reply arrays" % (n_conn, G, R - 1), "value": n_conn / (us * 1e-6), "unit": "AppendEntriesReply frames/s", "call_us": us,
-            "emit_then_ingest_us": us_loop,
-            "roofline": {"bound": "hbm", "kernel": "wire_ingest_replies_kernel<0> (+ two memsets: one smr_wire_ingest_raft_replies call)",
-                         "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "alg_bytes_per_launch": alg, "avg_launch_us": us, "traffic": _leg_traffic("smr::wire_ingest_replies_kernel<0>"),
-                         "traffic_source": PMC_NOTE}}
+                        "leader's last_commit in one launch" % (n_conn, G, R - 1), "value": n_conn / (us_fused * 1e-6), "unit": "AppendEntriesReply frames/s",
+            "call_us": us_fused, "emit_then_ingest_us": us_loop,
+            "frames_to_last_commit": {"one_launch_us": us_fused, "two_calls_us": us_two, "entry_point": "smr_raft_leader_handle_wire_replies",
+                                      "same_state_and_counts_as_the_two_calls": True},
+            # the leg's figure since round 6: the ONE-launch call -- the frames' bytes + the leader's per-group state (280 B per
+            # group and tick of replies) over its time; `ingest_alone` keeps the parse-into-arrays call of rounds 3-5
+            "roofline": {"bound": "hbm", "kernel": "raft_wire_replies_kernel<false, 5> (parse + reply handler: one smr_raft_leader_handle_wire_replies call)",
+                         "achieved": (int(off2[-1]) + 280 * G) / (us_fused * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (int(off2[-1]) + 280 * G) / (us_fused * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": int(off2[-1]) + 280 * G, "avg_launch_us": us_fused,
+                         "traffic": _leg_traffic("smr::raft_wire_replies_kernel<false, 5>"), "traffic_source": PMC_NOTE},
+            "ingest_alone": {"kernel": "wire_ingest_replies_kernel<0> (+ two memsets: one smr_wire_ingest_raft_replies call)", "call_us": us,
+                             "alg_bytes_per_launch": alg, "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": _leg_traffic("smr::wire_ingest_replies_kernel<0>")}}
 
 
 def _cpu_run(a):
@@ -1842,6 +1876,9 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (t_qt["hbm_bytes_per_launch"] * (G / 65536.0)) if t_qt else None, "traffic_source": PMC_NOTE,
                 "kernel": "mp_quorum_tally", "alg_bytes_per_launch": alg_tick, "avg_launch_us": qt_us}
+        # ... and on the bytes the kernel really moves (since round 4 the ballot runs are not stored, and `frac` is a
+        # figure on 8(d) bytes the kernel does not touch: it is latency-bound, and this is the number that says so)
+        roof["frac_pmc"] = (roof["traffic"] / (qt_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if roof["traffic"] and qt_us else None
     # the whole tick against the roofline, both ways: on the §8(d) algorithmic bytes of its decisions and on the HBM
     # bytes the tick really moves (PMC); and the quorum kernel alone, from the per-round pass
     roof["whole_tick"] = {"us": tick_us, "frac_alg": alg_tick / (tick_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -1266,6 +1266,18 @@ int smr_wire_ingest_rsp_accept_replies(const uint8_t *buf_dev, uint64_t buf_len,
                                        uint64_t *ballot_dev, uint8_t *flags_dev, smr_wire_other *others_dev, uint64_t other_cap,
                                        uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 /* (RSPaxos PeerMsg::AcceptReply { slot, ballot }, rspaxos/mod.rs:262-305 -> the [R][G] arrays smr_rsp_handle_accept_replies takes; same rules) */
+/* Round 6: the Raft leader's receive side of a tick in ONE launch -- smr_wire_ingest_raft_replies as the prologue of
+ * smr_raft_leader_handle_replies (safetcp.rs:46,127-132 framing, raft/mod.rs:203-234 AppendEntriesReply, raft/messages.rs:222-309
+ * the handler): no [R][G] reply arrays in between, nothing to clear in front (the two calls: two memsets, two launches, 13 bytes
+ * per connection written and read back).  The connections come DENSE: n_conn == n_groups * (population - 1), connection
+ * g * (population - 1) + k is group g's k-th follower, peer ids ascending with the leader's own left out; their bytes as in
+ * smr_wire_ingest_raft_replies (conn_off_dev [n_conn + 1], or starts + conn_len_dev).  Frames taken, frames located
+ * (others_dev, counts), consumed_dev / status_dev: exactly that call's; what the leader then does with the replies (order_dev:
+ * delivery order per group, NULL = peer order): exactly smr_raft_leader_handle_replies'.  counts_dev[4] is WRITTEN by the
+ * call's last block (no need to clear it). */
+int smr_raft_leader_handle_wire_replies(smr_raft_leader *l, const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev,
+                                        const uint8_t *conn_len_dev, uint32_t n_conn, const uint32_t *order_dev, smr_wire_other *others_dev,
+                                        uint64_t other_cap, uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream);
 
 /* ---- reply frames written on the device (round 3; csrc/wire_emit.hip): the send half.  A follower's handler leaves its
  * replies as device arrays; these calls write, for every reply, the frame TcpTransport would send -- `[u64 BE length]

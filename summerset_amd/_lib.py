@@ -259,6 +259,7 @@ SYMBOLS = [
     ("smr_raft_leader_destroy", None, [_vp]),
     ("smr_raft_leader_append", _i, [_vp, _vp, _vp]),
     ("smr_raft_leader_handle_replies", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("smr_raft_leader_handle_wire_replies", _i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     ("smr_raft_leader_run_ticks", _i, [_vp, _vp, _u32, _vp]),
     ("smr_raft_leader_dump", _i, [_vp, C.POINTER(RaftDumpBufs)]),
     ("smr_raft_leader_total_commits", _i, [_vp, C.POINTER(_u64)]),

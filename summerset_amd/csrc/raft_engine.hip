@@ -18,6 +18,7 @@
 
 #include "smr_common.h"
 #include "raft_peek.h"
+#include "wire_rd.h"
 
 namespace smr {
 
@@ -217,7 +218,8 @@ template <bool CRAFT, int NR>
 __device__ __forceinline__ void raft_replies_body(const RaftView &v, const CraftView &cv, uint32_t g, RaftLeaderRegs<NR> &S, uint32_t ctl,
                                                   const uint32_t (&rf)[NR], const uint64_t (&rtm)[NR], const uint32_t (&res)[NR],
                                                   const uint64_t *__restrict__ conflict_term, const uint32_t *__restrict__ conflict_slot,
-                                                  uint32_t commit_need, uint32_t &heard, unsigned int (&c)[4]) {
+                                                  uint32_t commit_need, uint32_t &heard, unsigned int (&c)[4],
+                                                  uint32_t conf_stride = 0, uint32_t conf_g = 0) {   // conf_stride != 0: the conflict arrays are [peer][conf_stride], mine at conf_g
     uint32_t &role = S.role, &leader = S.leader, &commit = S.commit, &snap = S.snap;
     uint64_t &term = S.term;
     const uint32_t len = S.len, start = S.start, rlo = S.rlo;
@@ -285,8 +287,11 @@ __device__ __forceinline__ void raft_replies_body(const RaftView &v, const Craft
                 tnp = 1;
             } else {
                 nxp -= 1;                                   // :318
-                const uint64_t ct = conflict_term ? conflict_term[o] : 0;
-                const uint32_t cs = conflict_slot ? conflict_slot[o] : 0;
+                // (where the reply's conflict words lie: [peer][G] arrays, or -- raft_wire_replies_kernel, conf_stride = all ones -- a group's
+                //  followers side by side from word conf_g on, the leader's own id left out)
+                const size_t oc = conf_stride == 0xFFFFFFFFu ? (size_t)conf_g + (p < v.me ? p : p - 1u) : conf_stride ? (size_t)p * conf_stride + conf_g : o;
+                const uint64_t ct = conflict_term ? conflict_term[oc] : 0;
+                const uint32_t cs = conflict_slot ? conflict_slot[oc] : 0;
                 for (bool more = true; more;) {              // :320-330, eight candidates per round of loads: the
                     uint64_t e8[8]; bool ok8[8];            // loop's tests depend on next_slot alone
 #pragma unroll
@@ -393,6 +398,204 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
         }
     }
     raft_flush(v, c);
+}
+
+// ---- the leader's receive side of a tick in ONE launch (round 6) ---------------------------------------------------
+// smr_wire_ingest_raft_replies parses the followers' connections into [R][G] arrays (two memsets in front: the flag plane, the
+// counters) and smr_raft_leader_handle_replies reads them back: three stream operations and 13 bytes per connection out and in
+// again for 25-byte frames.  Here the parse is the prologue of the handler.  The connections come DENSE: connection
+// c = g * (R - 1) + k is group g's k-th follower (peer ids ascending, the leader's own left out) -- the order a server keeps
+// its peers' sockets in -- so a block's 256 / (R - 1) groups have all their connections in the block: every lane parses its
+// connection out of the block's LDS copy of the buffer span (wire_rd.h, as wire_ingest_replies_kernel does: same frames taken,
+// same frames located, same `consumed` / `status`), leaves the reply in LDS [peer slot][group], and behind one barrier the
+// block's first lanes run raft_replies_body on their group (messages.rs:222-309) out of those words.  No intermediate array,
+// nothing to zero: a reply that did not come is a flag of zero in LDS.  The call's four counters are summed per block into
+// a scratch of the leader's and handed out by the last block (which leaves the scratch zero for the next call).
+struct RaftWire {
+    const uint8_t *buf; uint64_t buf_len;
+    const uint64_t *conn_off; const uint8_t *conn_len; uint32_t n_conn;
+    const uint32_t *order;
+    smr_wire_other *others; uint64_t other_cap;
+    uint64_t *counts, *consumed; int32_t *status;
+    unsigned long long *acc;                     // the leader's: [0..3] the counters of the call in flight, [4] blocks done
+};
+
+// every counter word of the call lives in L2 and is only ever touched by atomics, so "my adds before my ticket" needs my adds
+// ACKNOWLEDGED, not a fence: __threadfence() is an agent-scope release -- an L2 write-back on gfx950 -- once per block,
+// and the call's time grew with its number of blocks (47 / 33 / 28 us at 1024 / 512 / 256 blocks, profiles/s14)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RW_DRAIN() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define RW_DRAIN() __threadfence()
+#endif
+#ifndef RW_BLOCK_N
+#define RW_BLOCK_N 1024          // (256 / 512 / 1024 lanes per block: 47.2 / 33.4 / 28.5 us for 262 144 connections, profiles/s14 -- every block
+#endif                           //  that located a frame asks ONE word for its place, a returning same-address atomic per block)
+constexpr uint32_t RW_BLOCK = RW_BLOCK_N, RW_STAGE = RW_BLOCK * 40, RW_LOC = RW_BLOCK / 2;
+// the call's counters without a word every block adds to (a same-address atomic is ~10 ns, a returning one several times that, and
+// there are up to 1024 blocks): 16 shards of the three plain counters, arrival tickets in two levels of <= 32 arrivals each --
+// only the located frames' places come from ONE word (acc[1]), asked for by blocks that located something
+constexpr uint32_t RW_SHARDS = 16, RW_ACC_WORDS = 8 + RW_SHARDS * 4 + 64;   // acc[1]: located; [4]: top ticket; [8 ..): shards; then 64 level-1 tickets
+template <bool CRAFT, int NR>
+__global__ __launch_bounds__(RW_BLOCK) void raft_wire_replies_kernel(const RaftView v, const CraftView cv, const RaftWire A) {
+    __shared__ uint32_t stage[RW_STAGE / 4 + 4];
+    __shared__ smr_wire_other loc[RW_LOC];
+    __shared__ uint32_t blk[4];
+    __shared__ unsigned long long loc_base;
+    __shared__ uint64_t sh_term[RW_BLOCK], sh_ct[RW_BLOCK];
+    __shared__ uint32_t sh_end[RW_BLOCK], sh_cs[RW_BLOCK];
+    __shared__ uint8_t sh_fl[RW_BLOCK];
+    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
+    const uint32_t F = v.R - 1u, GPB = RW_BLOCK / F;                          // followers per group, groups per block
+    const uint32_t g0 = blockIdx.x * GPB, c0 = g0 * F;
+    const uint32_t n_here = (A.n_conn - c0) < GPB * F ? (A.n_conn - c0) : GPB * F;
+    const bool live = threadIdx.x < n_here;
+    const uint32_t c = c0 + threadIdx.x;
+    const uint64_t start = live ? A.conn_off[c] : 0, end = !live ? 0 : A.conn_len ? start + A.conn_len[c] : A.conn_off[c + 1];
+    const uint32_t c1 = c0 + n_here;
+    const uint64_t s0 = A.conn_off[c0] & ~15ull, s1 = A.conn_len ? A.conn_off[c1 - 1] + A.conn_len[c1 - 1] : A.conn_off[c1];
+    uint64_t slo = 0, shi = 0;
+    if (s0 < s1 && s1 <= A.buf_len) {
+        slo = s0; shi = s1 - s0 <= RW_STAGE ? s1 : s0 + RW_STAGE;
+        const uint32_t n16 = (uint32_t)((shi - slo + 15) / 16);
+        for (uint32_t i = threadIdx.x; i <= n16; i += RW_BLOCK) {
+            const uint64_t off = slo + 16ull * i;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (off + 16 <= A.buf_len) {
+                const wr_u32x4 x = *(const wr_u32x4 *)(A.buf + off);
+                w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+            } else {
+                for (uint32_t b = 0; b < 16 && off + b < A.buf_len; b++) w[b >> 2] |= (uint32_t)A.buf[off + b] << (8 * (b & 3));
+            }
+            if (4 * i + 3 < RW_STAGE / 4 + 4) { stage[4 * i] = w[0]; stage[4 * i + 1] = w[1]; stage[4 * i + 2] = w[2]; stage[4 * i + 3] = w[3]; }
+        }
+    }
+    sh_fl[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t pos = start;
+    int st = 0;
+    bool have = false, deferred = false;
+    if (live && (end < start || end > A.buf_len)) st = 1;
+    while (live && st == 0) {
+        const uint64_t avail = end - pos;
+        if (avail < 8) break;
+        GlRd r{A.buf, pos, pos + 8, A.buf_len, true, stage, slo, shi};
+        const uint64_t plen = __builtin_bswap64(r.peek64());
+        if (plen > 1000000000000ull) { st = 1; break; }                             // safetcp.rs:56-66
+        if (avail - 8 < plen) break;
+        r.n = pos + 8; r.end = pos + 8 + plen;
+        uint32_t kind = SMR_WIRE_OTHER;
+        bool mine = false;
+        const uint64_t outer = r.varint();
+        if (outer == 2) kind = SMR_WIRE_LEAVE;
+        else if (outer == 0) {
+            const uint64_t var = r.varint();
+            if (!r.ok || var > 3) { st = 1; break; }
+            kind = (uint32_t)var;
+            if (var == 1) {                                                         // AppendEntriesReply
+                uint64_t term, end_slot, ct, cs;
+                uint8_t has;
+                if (!wr_raft_append_reply(r, term, end_slot, has, ct, cs)) { st = 1; break; }
+                mine = end_slot <= 0xFFFFFFFFull && cs <= 0xFFFFFFFFull;
+                if (mine) {
+                    if (have) { deferred = true; break; }
+                    sh_term[threadIdx.x] = term; sh_end[threadIdx.x] = (uint32_t)end_slot; sh_ct[threadIdx.x] = ct; sh_cs[threadIdx.x] = (uint32_t)cs;
+                    sh_fl[threadIdx.x] = (uint8_t)(1u | (has ? 2u : 0u));
+                    have = true;
+                }
+            }
+        }
+        if (!r.ok) { st = 1; break; }
+        if (!mine) {
+            smr_wire_other o; o.conn = c; o.kind = kind; o.off = pos; o.len = 8 + plen;
+            const uint32_t at = atomicAdd(&blk[1], 1u);
+            if (at < RW_LOC) loc[at] = o;
+            else {
+                const unsigned long long far = atomicAdd(&A.acc[1], 1ull);        // (past the block's own list: rare)
+                if (far < A.other_cap) A.others[far] = o;
+            }
+        }
+        pos += 8 + plen;
+    }
+    if (live) {
+        A.consumed[c] = st ? 0 : pos - start;
+        A.status[c] = st;
+    }
+    const unsigned long long m0 = __ballot(have && st == 0), m2 = __ballot(st != 0), m3 = __ballot(deferred);
+    if (threadIdx.x % 64 == 0) {
+        if (m0) atomicAdd(&blk[0], (uint32_t)__popcll(m0));
+        if (m2) atomicAdd(&blk[2], (uint32_t)__popcll(m2));
+        if (m3) atomicAdd(&blk[3], (uint32_t)__popcll(m3));
+    }
+    __syncthreads();
+    // (the located frames' place in the call's list: asked for NOW, used behind the handler -- the word is one for all blocks, and the
+    //  round trip of a contended returning atomic is as long as the handler)
+    const uint32_t n_kept = blk[1] < RW_LOC ? blk[1] : RW_LOC;
+    unsigned long long my_base = 0;
+    if (threadIdx.x == 0 && n_kept) my_base = atomicAdd(&A.acc[1], (unsigned long long)n_kept);
+    // ---- the handler: one lane per group of the block, its followers' replies out of LDS ----
+    unsigned int cn[4] = {0, 0, 0, 0};
+    const uint32_t g = g0 + threadIdx.x;
+    if (threadIdx.x < GPB && g < v.G) {
+        uint32_t heard = 0, commit_need = v.thresh - 1;
+        if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
+        RaftLeaderRegs<NR> S;
+        S.load(v, g);
+        uint32_t rf[NR], res[NR];
+        uint64_t rtm[NR];
+#pragma unroll
+        for (int p = 0; p < NR; p++) {
+            const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+            const uint32_t slot = threadIdx.x * F + ((uint32_t)p < v.me ? (uint32_t)p : (uint32_t)p - 1u);   // peer p's connection of my group
+            const bool there = on && slot < n_here;
+            rf[p] = there ? sh_fl[there ? slot : 0] : 0u; rtm[p] = there ? sh_term[there ? slot : 0] : 0ull; res[p] = there ? sh_end[there ? slot : 0] : 0u;
+        }
+        const uint32_t base = threadIdx.x * F;                                      // (my group's followers' words start here)
+        raft_replies_body<CRAFT, NR>(v, cv, g, S, A.order ? A.order[g] : SMR_CTL_IDENTITY, rf, rtm, res, sh_ct, sh_cs, commit_need, heard, cn, 0xFFFFFFFFu, base);
+        S.store(v, g);
+        if (CRAFT && heard) {
+            for (uint32_t p = 0; p < v.R; p++)
+                if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
+            const uint32_t al = cv.alive[g];
+            if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
+        }
+    }
+    raft_flush(v, cn);
+    // ---- the call's counters: this block's share, the located frames' place, and -- the last block -- the totals ----
+    unsigned long long *const shard = A.acc + 8 + (blockIdx.x % RW_SHARDS) * 4u;
+    if (threadIdx.x == 0) {
+        if (blk[0]) atomicAdd(&shard[0], (unsigned long long)blk[0]);
+        if (blk[2]) atomicAdd(&shard[2], (unsigned long long)blk[2]);
+        if (blk[3]) atomicAdd(&shard[3], (unsigned long long)blk[3]);
+        loc_base = my_base;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n_kept; j += RW_BLOCK)
+        if (loc_base + j < A.other_cap) A.others[loc_base + j] = loc[j];
+    if (threadIdx.x == 0) {
+        RW_DRAIN();
+        // arrivals: my level-1 ticket (blocks 32 k .. 32 k + 31), its last arrival goes on to the top ticket; the last of all hands the totals out
+        const uint32_t n1 = (gridDim.x + 31u) / 32u, t1 = blockIdx.x / 32u;
+        const uint32_t mine = t1 + 1u < n1 ? 32u : gridDim.x - 32u * (n1 - 1u);
+        unsigned long long *const tick1 = A.acc + 8 + RW_SHARDS * 4 + (t1 % 64u);
+        bool last = false;
+        if (n1 > 64u) last = atomicAdd(&A.acc[4], 1ull) == (unsigned long long)gridDim.x - 1ull;   // (more level-1 groups than tickets: one level)
+        else if (atomicAdd(tick1, 1ull) == (unsigned long long)mine - 1ull) {
+            atomicExch(tick1, 0ull);
+            RW_DRAIN();
+            last = atomicAdd(&A.acc[4], 1ull) == (unsigned long long)n1 - 1ull;
+        }
+        if (last) {                                                                 // every other block's adds are behind their fences
+            unsigned long long tot[4] = {0ull, 0ull, 0ull, 0ull};
+            for (uint32_t sh = 0; sh < RW_SHARDS; sh++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (q != 1) tot[q] += atomicExch(&A.acc[8 + sh * 4 + q], 0ull);
+            tot[1] = atomicExch(&A.acc[1], 0ull);
+#pragma unroll
+            for (int q = 0; q < 4; q++) A.counts[q] = tot[q];
+            atomicExch(&A.acc[4], 0ull);
+        }
+    }
 }
 
 // A batch of <= RAFT_MAX_BATCH ticks in ONE launch: per tick the appends of that tick, then the peers' AppendEntriesReplies of
@@ -955,6 +1158,7 @@ struct smr_raft_leader {
     CraftView cv;
     uint8_t *craft_base = nullptr;
     int device = -1;                 // the device current when the object was created: where its arena is
+    unsigned long long *wire_acc = nullptr;   // smr_raft_leader_handle_wire_replies: the counters of the call in flight + blocks done (zero between calls)
     RaftView *d_view = nullptr;      // a device copy of v for smr_raft_cluster_replicate (made on first use; craft_enable changes v)
     bool d_view_ok = false;
 };
@@ -1021,10 +1225,13 @@ int smr_raft_leader_create(const smr_raft_cfg *cfg, smr_raft_leader **out) {
     // the device copy of the view smr_raft_cluster_replicate's followers are read through: made HERE (and again by craft_enable),
     // so that the stream-ordered call allocates and copies nothing (a blocking hipMalloc + hipMemcpy inside it)
     if (e == hipSuccess) e = hipGetDevice(&l->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&l->wire_acc, RW_ACC_WORDS * 8);
+    if (e == hipSuccess) e = hipMemset(l->wire_acc, 0, RW_ACC_WORDS * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&l->d_view, sizeof(RaftView));
     if (e == hipSuccess) e = hipMemcpy(l->d_view, &l->v, sizeof(RaftView), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (l->d_view) (void)hipFree(l->d_view);
+        if (l->wire_acc) (void)hipFree(l->wire_acc);
         (void)hipFree(l->arena.base); delete l;
         return fail(SMR_ERR_DEVICE, std::string("raft: init: ") + hipGetErrorString(e));
     }
@@ -1038,6 +1245,7 @@ void smr_raft_leader_destroy(smr_raft_leader *l) {
     if (l->arena.base) (void)hipFree(l->arena.base);
     if (l->craft_base) (void)hipFree(l->craft_base);
     if (l->d_view) (void)hipFree(l->d_view);
+    if (l->wire_acc) (void)hipFree(l->wire_acc);
     delete l;
 }
 
@@ -1061,6 +1269,29 @@ int smr_raft_leader_handle_replies(smr_raft_leader *l, const uint64_t *reply_ter
     if (l->v.R <= 5) { if (l->craft) RAFT_REPLIES(true, 5); else RAFT_REPLIES(false, 5); }
     else { if (l->craft) RAFT_REPLIES(true, RMAX); else RAFT_REPLIES(false, RMAX); }
 #undef RAFT_REPLIES
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_leader_handle_wire_replies(smr_raft_leader *l, const uint8_t *buf_dev, uint64_t buf_len, const uint64_t *conn_off_dev,
+                                        const uint8_t *conn_len_dev, uint32_t n_conn, const uint32_t *order_dev, smr_wire_other *others_dev,
+                                        uint64_t other_cap, uint64_t *counts_dev, uint64_t *consumed_dev, int32_t *status_dev, void *stream) {
+    if (!l || !conn_off_dev || !counts_dev || !consumed_dev || !status_dev || (buf_len && !buf_dev) || (other_cap && !others_dev))
+        return fail(SMR_ERR_ARG, "raft wire replies: null argument");
+    if ((uintptr_t)buf_dev & 15) return fail(SMR_ERR_ARG, "raft wire replies: the byte buffer must be 16-byte aligned");
+    const uint32_t F = l->v.R - 1u;
+    if (n_conn != l->v.G * F)
+        return fail(SMR_ERR_ARG, "raft wire replies: the connections come dense -- n_groups * (population - 1) of them, connection g * (population - 1) + k "
+                                 "= group g's k-th follower in ascending id");
+    const uint32_t GPB = RW_BLOCK / F;
+    const RaftWire A{buf_dev, buf_len, conn_off_dev, conn_len_dev, n_conn, order_dev, others_dev, other_cap, counts_dev, consumed_dev, status_dev, l->wire_acc};
+    const dim3 grid((l->v.G + GPB - 1) / GPB), block(RW_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const CraftView cv = l->craft ? l->cv : CraftView{};
+#define RAFT_WIRE(C, N) hipLaunchKernelGGL((raft_wire_replies_kernel<C, N>), grid, block, 0, st, l->v, cv, A)
+    if (l->v.R <= 5) { if (l->craft) RAFT_WIRE(true, 5); else RAFT_WIRE(false, 5); }
+    else { if (l->craft) RAFT_WIRE(true, RMAX); else RAFT_WIRE(false, RMAX); }
+#undef RAFT_WIRE
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

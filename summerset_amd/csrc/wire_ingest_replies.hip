@@ -22,54 +22,9 @@
 // indices; a same-address atomic takes ~10 ns whatever it carries -- so a block of 1024 lanes now counts in LDS, keeps the
 // frames it locates in LDS, and goes to the call's counters once: 256 atomics per counter.
 #include "smr_common.h"
+#include "wire_rd.h"
 
 namespace smr {
-
-typedef uint64_t wr_u64_u __attribute__((aligned(1)));
-typedef uint32_t wr_u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr uint32_t WR_STAGE = 32 * 1024;         // bytes of the buffer a block keeps in LDS (+ 16 of slack)
-constexpr uint32_t WR_BLOCK = 1024;              // lanes = connections per block
-constexpr uint32_t WR_LOC = 512;                 // located frames a block keeps in LDS before it asks for their place
-
-// smr_wire's Rd over the buffer's bytes [n, end) (a frame's payload); `lim` = the buffer's length; the buffer's bytes
-// [slo, shi) are in LDS (dword-aligned slo; two more dwords behind shi are there to be read)
-struct GlRd {
-    const uint8_t *p;
-    uint64_t n, end, lim;
-    bool ok;
-    const uint32_t *lds; uint64_t slo, shi;
-    __device__ __forceinline__ uint64_t peek64() const {             // bytes n .. n + 7, little-endian (those past the buffer: zero)
-        if (n >= slo && n < shi) {                                   // three aligned dwords, shifted into place
-            const uint32_t k = (uint32_t)(n - slo), i = k >> 2, sh = 8 * (k & 3);
-            const uint32_t a = lds[i], b = lds[i + 1], c = lds[i + 2];
-            const uint32_t lo = (uint32_t)((((uint64_t)b << 32) | a) >> sh), hi = (uint32_t)((((uint64_t)c << 32) | b) >> sh);
-            return ((uint64_t)hi << 32) | lo;
-        }
-        if (n + 8 <= lim) return *(const wr_u64_u *)(p + n);
-        uint64_t x = 0;
-        for (uint32_t b = 0; b < 8 && n + b < lim; b++) x |= (uint64_t)p[n + b] << (8 * b);
-        return x;
-    }
-    __device__ __forceinline__ uint8_t byte() {
-        if (n < end) { const uint8_t b = (uint8_t)peek64(); n++; return b; }
-        ok = false;
-        return 0;
-    }
-    __device__ __forceinline__ uint64_t varint() {
-        if (n >= end) { ok = false; return 0; }
-        const uint64_t x = peek64();
-        const uint32_t b = (uint32_t)(x & 0xFF);
-        const uint32_t need = b < 251 ? 1 : b == 0xFB ? 3 : b == 0xFC ? 5 : b == 0xFD ? 9 : 0;   // 0xFE (u128), 0xFF: not on this path
-        if (need == 0 || n + need > end) { ok = false; n = end; return 0; }
-        uint64_t v = b;
-        if (need == 3) v = (x >> 8) & 0xFFFF;
-        else if (need == 5) v = (x >> 8) & 0xFFFFFFFFull;
-        else if (need == 9) { n += 1; v = peek64(); n -= 1; }
-        n += need;
-        return v;
-    }
-};
 
 struct ReplyArgs {
     const uint8_t *buf; uint64_t buf_len;
@@ -140,11 +95,9 @@ __global__ __launch_bounds__(WR_BLOCK) void wire_ingest_replies_kernel(ReplyArgs
                 if (!r.ok || v > 3) { st = 1; break; }                              // smr_wire_raft_decode: unknown Raft message
                 kind = (uint32_t)v;
                 if (v == 1) {                                                       // AppendEntriesReply
-                    const uint64_t term = r.varint(), end_slot = r.varint();
-                    const uint8_t has = r.byte();
-                    uint64_t ct = 0, cs = 0;
-                    if (has == 1) { ct = r.varint(); cs = r.varint(); } else if (has != 0) r.ok = false;
-                    if (!r.ok || r.n != r.end) { st = 1; break; }
+                    uint64_t term, end_slot, ct, cs;
+                    uint8_t has;
+                    if (!wr_raft_append_reply(r, term, end_slot, has, ct, cs)) { st = 1; break; }
                     mine = end_slot <= 0xFFFFFFFFull && cs <= 0xFFFFFFFFull;        // (the engine's slots are u32: a wider one goes the host's way)
                     if (mine) {
                         if (have) { deferred = true; break; }                       // the next call's

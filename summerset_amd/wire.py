@@ -533,6 +533,19 @@ class ReplyIngest:
                                                    p(self.consumed), p(self.status), _lib.stream_ptr(stream)))
         return dict(reply_term=self.u64a, end_slot=self.u32a, conflict_term=self.u64b, conflict_slot=self.u32b, flags=self.flags)
 
+    def raft_into(self, leader, buf, conn_off, order=None, stream=None, conn_len=None):
+        """`raft(...)` + `leader.handle_msg_append_entries_reply(...)` as ONE launch (`smr_raft_leader_handle_wire_replies`): the
+        parse is the prologue of the leader's reply handler, no [R, G] arrays in between.  The connections come dense --
+        n_groups * (population - 1) of them, connection g * (population - 1) + k = group g's k-th follower in ascending id, the
+        leader's own left out.  `results()` as after `raft(...)`."""
+        p = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        assert self.n_conn == self.G * (self.R - 1) and conn_off.numel() >= self.n_conn + (conn_len is None) and conn_off.element_size() == 8
+        assert conn_len is None or (conn_len.numel() == self.n_conn and conn_len.element_size() == 1)
+        assert order is None or (order.numel() == self.G and order.element_size() == 4)
+        check(self._L.smr_raft_leader_handle_wire_replies(leader._h, p(buf) if buf.numel() else None, buf.numel(), p(conn_off), p(conn_len), self.n_conn,
+                                                          p(order), p(self.others), self.other_cap, p(self.counts), p(self.consumed),
+                                                          p(self.status), _lib.stream_ptr(stream)))
+
     def ep_pre_accept(self, buf, conn_off, conn_group, conn_peer, me, col, stream=None, conn_len=None):
         """col: int32 / uint32 [G] on the device -- the column of MY instance every group's replies are for"""
         p = lambda t: t.data_ptr()   # noqa: E731

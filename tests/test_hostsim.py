@@ -198,6 +198,17 @@ def test_reply_ingest_kernels_on_the_host(sim, oracle):
         t.test_ep_cluster_pre_accept_replies_over_the_wire("cpu", oracle)
 
 
+def test_fused_raft_wire_replies_on_the_host(sim, oracle):
+    """smr_raft_leader_handle_wire_replies (the parse as the prologue of the leader's reply handler, one launch) against the two
+    calls and the oracle"""
+    import test_zz_reply_ingest_gpu as t
+    with sim.patched():
+        assert t.run_fused_raft_wire_replies("cpu", oracle, G=300, T=5) > 0
+        assert t.run_fused_raft_wire_replies("cpu", oracle, G=1100, R=3, me=0, seed=5, T=3) > 0
+        assert t.run_fused_raft_wire_replies("cpu", oracle, G=400, R=7, W=32, me=6, seed=6, T=3) > 0
+        t.test_fused_raft_wire_replies_refuse_sparse_connections("cpu")
+
+
 def test_wire_emit_kernels_on_the_host(sim, oracle):
     """reply frames written by kernels (f.1, the send half): byte for byte what the test lays out, back through the ingest
     kernels, and as the senders of the Raft / EPaxos closed loops"""

@@ -348,3 +348,96 @@ def test_reply_ingest_argument_edges(cuda):
     assert sum(len(x) for x in streams[:1024]) > 32 * 1024
     last = {g: max(c for c in range(n) if c % G == g) for g in range(G)}          # (several connections per (group, peer): the caller's error -- one wins)
     assert all(int(o["end_slot"][1, g]) % G == g for g in range(G)) and set(int(o["reply_term"][1, g]) - 100 for g in range(G)) <= set(range(n)) and last
+
+
+def run_fused_raft_wire_replies(cuda, oracle, G=300, R=5, W=64, T=6, seed=21, me=2):
+    """`smr_raft_leader_handle_wire_replies` (round 6: the parse as the prologue of the leader's reply handler, ONE launch, dense
+    connections) against the two calls it stands for -- `smr_wire_ingest_raft_replies` + `smr_raft_leader_handle_replies` -- on a
+    second leader in the same state, and both against the oracle fed the decoded replies directly: T ticks of appends and replies
+    with conflicts, higher terms, junk frames around the replies, second replies (deferred), incomplete tails and malformed
+    connections.  Counts, located frames, `consumed`, `status` and the leaders' state every tick."""
+    import torch
+    from summerset_amd import RaftLeaderGroup, wire
+    rng = np.random.default_rng(seed)
+    F = R - 1
+    a, b = RaftLeaderGroup(G, R, leader_id=me, window=W, term=2), RaftLeaderGroup(G, R, leader_id=me, window=W, term=2)
+    orc = oracle.RaftOracle(G, R, W, leader_id=me, term=2) if oracle is not None else None
+    ing_a, ing_b = wire.ReplyIngest(G * F, G, R, 4 * G * F, cuda), wire.ReplyIngest(G * F, G, R, 4 * G * F, cuda)
+    peers_of = [p for p in range(R) if p != me]
+    grp = torch.from_numpy(np.repeat(np.arange(G), F).astype(np.int32)).to(cuda)
+    peer = torch.from_numpy(np.tile(np.array(peers_of, np.uint8), G)).to(cuda)
+    junk = [_frame(_varint(0) + _varint(3) + _varint(7) + b"\x01"), _frame(_varint(2)), _frame(_varint(1) + bytes(range(20)))]
+    n_exec = 0
+    for t in range(T):
+        n_new = rng.integers(0, 4, G).astype(np.int32)
+        for x in (a, b):
+            x.handle_req_batch(torch.from_numpy(n_new).to(cuda))
+        if orc is not None:
+            orc.append(n_new.astype(np.uint32))
+        len_now = a.dump()["log_len"].astype(np.int64)
+        rt, es, fl = np.zeros((R, G), np.uint64), np.zeros((R, G), np.uint32), np.zeros((R, G), np.uint8)
+        ct, cs = np.zeros((R, G), np.uint64), np.zeros((R, G), np.uint32)
+        streams = []
+        for g in range(G):
+            for p in peers_of:
+                s = bytearray()
+                if rng.random() < 0.15:
+                    s += junk[int(rng.integers(0, len(junk)))]
+                x = rng.random()
+                if x < 0.85:
+                    term = 2 if rng.random() < 0.995 else 3                                        # (a higher term now and then: the leader steps down)
+                    end = int(rng.integers(0, max(int(len_now[g]), 1)))
+                    conflict = (int(rng.integers(1, 3)), int(rng.integers(0, max(end, 1)))) if rng.random() < 0.1 else None
+                    s += _raft_reply(term, end, conflict)
+                    rt[p, g], es[p, g], fl[p, g] = term, end, 1 | (2 if conflict else 0)
+                    if conflict:
+                        ct[p, g], cs[p, g] = conflict
+                    y = rng.random()
+                    if y < 0.05:
+                        s += _raft_reply(2, 1)                                                       # a second reply: the next call's
+                    elif y < 0.1:
+                        s += _raft_reply(1 << 40, 7)[:int(rng.integers(1, 11))]                      # an incomplete tail
+                    elif y < 0.13:
+                        s += _frame(_varint(0) + _varint(9))                                         # malformed behind a delivered reply
+                elif x < 0.9:
+                    s += _raft_reply(2, (1 << 32) + 5)                                               # a slot beyond u32: located, not taken
+                streams.append(bytes(s))
+        buf, off, _, _, _ = _layout(torch, cuda, streams, [0] * len(streams), [0] * len(streams))
+        o = ing_a.raft(buf, off, grp, peer)
+        a.handle_msg_append_entries_reply(o["reply_term"], o["end_slot"], o["flags"], o["conflict_term"], o["conflict_slot"])
+        ing_b.raft_into(b, buf, off)
+        ra, rb = ing_a.results(), ing_b.results()
+        for k in ("n_replies", "n_others", "n_malformed", "n_deferred"):
+            assert ra[k] == rb[k], (t, k, ra[k], rb[k])
+        assert np.array_equal(ra["consumed"], rb["consumed"]) and np.array_equal(ra["status"], rb["status"])
+        key = lambda z: np.sort(z, order=["conn", "off"])
+        assert np.array_equal(key(ra["others"]), key(rb["others"])), t
+        da, db = a.dump(), b.dump()
+        for n in da:
+            assert np.array_equal(da[n], db[n]), (t, n)
+        if orc is not None:
+            taken = o["flags"].cpu().numpy()
+            assert np.array_equal(taken != 0, fl != 0)
+            orc.handle_replies(rt, es, np.ascontiguousarray(taken), ct, cs)
+            do = orc.dump()
+            for n in do:
+                assert np.array_equal(db[n], do[n]), (t, n, "oracle")
+        n_exec = int(db["last_commit"].sum())
+    assert n_exec > 0
+    return n_exec
+
+
+def test_fused_raft_wire_replies_equal_the_two_calls(cuda, oracle):
+    run_fused_raft_wire_replies(cuda, oracle)
+    run_fused_raft_wire_replies(cuda, oracle, G=1100, R=3, me=0, seed=5, T=4)      # 128 groups per block, the leader's id in front
+    run_fused_raft_wire_replies(cuda, oracle, G=700, R=7, W=32, me=6, seed=6, T=4)  # 42 groups per block (252 of 256 lanes), the 8-wide instance
+
+
+def test_fused_raft_wire_replies_refuse_sparse_connections(cuda):
+    import torch
+    from summerset_amd import RaftLeaderGroup, SummersetError, wire
+    ld = RaftLeaderGroup(64, 5, leader_id=0, window=32, term=1)
+    ing = wire.ReplyIngest(64 * 4, 64, 5, 16, cuda)
+    ing.n_conn = 100                                                                   # not n_groups * (population - 1)
+    with pytest.raises((SummersetError, AssertionError)):
+        ing.raft_into(ld, torch.zeros(16, dtype=torch.uint8, device=cuda), torch.zeros(101, dtype=torch.int64, device=cuda))
