@@ -142,6 +142,9 @@ def compact_line(full):
 
 def emit_line(full):
     """write the full record beside the script, print the compact line LAST on stdout"""
+    if globals().get("L2_EXCHANGE_FAILED"):                       # a library exchange that could not be bound at N > 1: a failed leg of ANY layout's line
+        full["legs_failed"] = sorted(set(list(full.get("legs_failed") or []) + ["l2_exchange"]))
+        full["l2_exchange_error"] = "; ".join(L2_EXCHANGE_FAILED)[:300]
     where = os.environ.get("SMR_BENCH_DETAIL_DIR")                # (tests: keep the repo root clean)
     for d in ((where,) if where else (ROOT, os.path.join(ROOT, "gpurun_out"))):
         if os.path.isdir(d):
@@ -1464,6 +1467,9 @@ def spread_main(args, torch, dist, rank, local, world, dev):
         dist.destroy_process_group()
 
 
+L2_EXCHANGE_FAILED = []                                       # what _bind_library_exchange could not bind (-> the line's legs_failed)
+
+
 def _bind_library_exchange(job, dist, dev, virtual):
     """at N > 1 over RCCL the spread layouts' exchanges run inside the library (smr_comm_exchange: grouped ncclSend / ncclRecv on the
     plans' buffers); SMR_L2_TORCH=1 keeps torch.distributed.all_to_all_single.  Returns (comm or None, how the bytes travel)."""
@@ -1477,7 +1483,10 @@ def _bind_library_exchange(job, dist, dev, virtual):
         job.bind_comm(c)
         return c, "smr_comm_exchange (libsummerset_hip.so: RCCL send / recv pairs)"
     except Exception as e:                                       # noqa: BLE001
-        return None, "torch.distributed.all_to_all_single (smr_comm_init_rank failed: %s)" % e
+        # (at N > 1 a library exchange that cannot be had is a FAILED leg of the line, not a `via` string;
+        #  the run still completes over torch.distributed so that the job's other ranks are not left in a collective)
+        L2_EXCHANGE_FAILED.append("smr_comm_init_rank: %s" % e)
+        return None, "torch.distributed.all_to_all_single (smr_comm_init_rank FAILED: %s)" % e
 
 
 def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
@@ -1555,6 +1564,13 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
     kw = dict(window=W, n_keys=K, execute=True, ordered=False)
     job = spread_ep.in_process(total, R, nr, dev, **kw) if virtual else spread_ep.SpreadEPaxos(total, R, rank, world, dev, **kw)
     comm, via = _bind_library_exchange(job, dist, dev, virtual)
+    # round 6: the tick itself inside the library (smr_ep_spread_*: schedule, message plan, packing -- and, with the communicator
+    # bound, the exchanges: ONE C call per tick; virtual ranks / torch collectives: one call per segment); SMR_L2_PYTHON_TICK=1
+    # keeps the Python-driven tick of rounds 3-5
+    lib_tick = os.environ.get("SMR_L2_PYTHON_TICK") is None
+    if lib_tick:
+        for rk in (job.ranks if virtual else [job]):
+            rk.use_library_tick()
     homes = [k for rk in job.ranks for k in rk.reps] if virtual else list(job.reps)
     zipf = 1.0 / np.arange(1, K + 1) ** 0.99
     zipf /= zipf.sum()
@@ -1595,12 +1611,18 @@ def spread_epaxos_main(args, torch, dist, rank, local, world, dev):
                                    "(Zipf(0.99) keys of 64), optimized quorums, dependency-graph execution on" % args.groups,
                        "groups_per_gpu": args.groups, "replicas": R, "window": W, "layout": "spread", "spread_ranks": nr,
                        "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
-            "exchange": {"via": via, "collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1)},
+            "exchange": {"via": via, "collectives_per_tick": 5, "bytes_sent_per_tick_per_rank": sent / args.steps / (nr if virtual else 1),
+                         "tick": ("smr_ep_spread_tick: one C call per tick, exchanges inside" if (lib_tick and comm is not None) else
+                                  "smr_ep_spread_segment: one C call per segment (6 per tick), the host moves the exchange's buffers" if lib_tick else
+                                  "summerset_amd/spread_ep.py: one ctypes call per handler (SMR_L2_PYTHON_TICK)")},
+            "legs_failed": (["l2_exchange"] if L2_EXCHANGE_FAILED else []),
             "slow_path_instances_this_rank": n_slow, "roofline": None, "cpu_baseline": None,
             "note": "correctness layout of config 5's inter-replica fan-out (handler calls of the Python driver included); the roofline / "
                     "cpu_baseline objects belong to the co-located line"}
     if rank == 0:
         emit_line(line)
+    for rk in (job.ranks if virtual else [job]):
+        rk.close_library_tick()
     if comm is not None:
         job.bind_comm(None)
         comm.close()

@@ -746,6 +746,38 @@ int smr_ep_cluster_set_mode(smr_ep_cluster *c, uint32_t mode);
  * by one since the replicas were created (each wraps at 2^32). */
 int smr_ep_cluster_batch_stats(smr_ep_cluster *c, uint64_t out[2]);
 
+/* ---- layout L2 of the EPaxos cluster as ONE call per tick (round 6; BASELINE config 5 as written: the groups block-partitioned
+ * over `world` ranks, replica r of block b on rank (b + r) mod world) ----------------------------------------------------
+ * What summerset_amd/spread_ep.py drove from Python in rounds 3-5 -- the handlers of smr_ep_cluster_tick's launch-by-launch
+ * mode cut at the five points where a message crosses replicas, the messages packed into one send buffer per exchange, one
+ * all-to-all with static split sizes per exchange (TransportHub::send_msg / bcast_msg, server/transport.rs:208-275) -- with the
+ * schedule, the message plan, the packing and the exchanges inside the library.
+ *   smr_ep_spread_create   reps[i] = replica rep_id[i] of block rep_block[i], every one that lives on `rank` (created with
+ *                          me = rep_id[i], n_groups = block_groups[rep_block[i]]); block_groups[world]; ordered = 0: 5 exchanges per
+ *                          tick, all command leaders tally together (the co-located loop's phase-by-phase order, mode 2 of
+ *                          smr_ep_cluster_set_mode); 1: 2 + 3 R exchanges, leader by leader (modes 0 / 1, execution state included).
+ *   smr_ep_spread_segment  the compute between exchange seg - 1 and exchange seg (seg = n_exchanges: behind the last), for a host
+ *                          that moves the buffers itself (smr_ep_spread_buffers: exchange k's send / receive buffer and the bytes
+ *                          to / from every rank -- a gloo job, a test); segments come in order, smr_ep_spread_abort_tick reopens.
+ *   smr_ep_spread_tick     all of it: segments and smr_comm_exchange calls back to back on `stream` (smr_ep_spread_bind_comm
+ *                          first; a job of one rank needs none).
+ * keys_dev[i] / out[i]: replica i's proposals (u8 [G], 0xFF: none) and its results as a command leader, as in smr_ep_cluster_tick;
+ * drop_dev (may be NULL): [n_reps * R] pointers, entry i * R + q (may be NULL) = u8 [G], 1 where replica i's PreAccept to q is
+ * lost (with its reply).  smr_ep_spread_info: out = {exchanges per tick, bytes put into send buffers so far}. */
+typedef struct smr_ep_spread smr_ep_spread;
+int smr_ep_spread_create(smr_ep_replica *const *reps, const uint32_t *rep_block, const uint8_t *rep_id, uint32_t n_reps,
+                         const uint32_t *block_groups, uint32_t world, uint32_t rank, uint8_t population, int ordered, smr_ep_spread **out);
+void smr_ep_spread_destroy(smr_ep_spread *s);
+int smr_ep_spread_n_exchanges(const smr_ep_spread *s);
+int smr_ep_spread_buffers(smr_ep_spread *s, uint32_t exchange, void **send_dev, uint64_t *send_bytes, void **recv_dev, uint64_t *recv_bytes);
+int smr_ep_spread_bind_comm(smr_ep_spread *s, smr_comm *comm);
+int smr_ep_spread_segment(smr_ep_spread *s, uint32_t seg, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev,
+                          const smr_ep_cluster_out *out, void *stream);
+int smr_ep_spread_abort_tick(smr_ep_spread *s);
+int smr_ep_spread_tick(smr_ep_spread *s, const uint8_t *const *keys_dev, const uint8_t *const *drop_dev, const smr_ep_cluster_out *out,
+                       void *stream);
+int smr_ep_spread_info(const smr_ep_spread *s, uint64_t out[2]);
+
 /* host buffers [R][W][G] by col % W like smr_ep_dump: exp_prepare_acks, exp_prepare_max_bal, avoid_fast_path, the peers with
  * an entry in exp_prepare_voteds (bitmap); those entries [R][W][R][G], deps [R][W][R][R][G]; counters[4] = decisions
  * Committed, Accepting, PreAccepting with a command, PreAccepting as a no-op */

@@ -141,6 +141,96 @@ class SpreadEPaxos:
                 dist.all_to_all_single(plan["rbuf"][:plan["n_recv"]], plan["sbuf"][:plan["n_send"]], output_split_sizes=plan["out_split"],
                                        input_split_sizes=plan["in_split"])
 
+    # ---- the tick inside the library (round 6: smr_ep_spread_*, csrc/ep_spread.hip) ---------------------------------------------
+    def use_library_tick(self):
+        """from now on `tick` is the library's: the schedule, the message plan, the packing and -- with `bind_comm` -- the exchanges
+        run inside `smr_ep_spread_tick` (one C call per tick); without a communicator (a gloo job, `in_process`) the segments are
+        `smr_ep_spread_segment` calls and this class only moves the exchange's buffers.  Same messages, same order, same state."""
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.load()
+        order = sorted(self.reps)
+        self._lib_order = order
+        n = len(order)
+        arr = (C.c_void_p * max(n, 1))(*[self.reps[k]._h for k in order])
+        blocks = (C.c_uint32 * max(n, 1))(*[k[0] for k in order])
+        ids = (C.c_uint8 * max(n, 1))(*[k[1] for k in order])
+        groups = (C.c_uint32 * self.world)(*[self.range[b][1] - self.range[b][0] for b in range(self.world)])
+        h = C.c_void_p()
+        _lib.check(self._L.smr_ep_spread_create(arr, blocks, ids, n, groups, self.world, self.rank, self.R, 1 if self.ordered else 0, C.byref(h)))
+        self._lib_h = h
+        assert self._L.smr_ep_spread_n_exchanges(h) == self.exchanges_per_tick()
+        if self.comm is not None:
+            _lib.check(self._L.smr_ep_spread_bind_comm(h, self.comm._h))
+        # the exchanges' buffers as tensors (for a host that moves them itself)
+        self._lib_bufs = []
+        for k in range(self.exchanges_per_tick()):
+            sp, rp = C.c_void_p(), C.c_void_p()
+            sb, rb = (C.c_uint64 * self.world)(), (C.c_uint64 * self.world)()
+            _lib.check(self._L.smr_ep_spread_buffers(h, k, C.byref(sp), sb, C.byref(rp), rb))
+            self._lib_bufs.append(dict(send=sp.value, recv=rp.value, in_split=[int(x) for x in sb], out_split=[int(x) for x in rb]))
+        self._lib_outs = None
+        return self
+
+    def _lib_args(self, keys, drop):
+        import ctypes as C
+        from . import _lib
+        torch, order, R = self.torch, self._lib_order, self.R
+        n = len(order)
+        if self._lib_outs is None:
+            self._lib_outs = {}
+            for (b, s) in order:
+                G = self.range[b][1] - self.range[b][0]
+                e = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)   # noqa: E731
+                self._lib_outs[(b, s)] = dict(proposed=e(G, torch.uint8), col=e(G, torch.int32), seq0=e(G, torch.int64), deps0=e((R, G), torch.int32),
+                                              decision=e(G, torch.uint8), committed=e(G, torch.uint8), seq=e(G, torch.int64), deps=e((R, G), torch.int32))
+        outs = (_lib.EpClusterOut * max(n, 1))()
+        for i, k in enumerate(order):
+            for f, _ in _lib.EpClusterOut._fields_:
+                setattr(outs[i], f, self._lib_outs[k][f].data_ptr())
+        kp = (C.c_void_p * max(n, 1))(*[keys[k].data_ptr() for k in order])
+        dp, masks = None, None
+        if drop:
+            masks = {k: (v if v.dtype == torch.uint8 else v.to(torch.uint8)).contiguous() for k, v in drop.items()}
+            dp = (C.c_void_p * max(n * R, 1))(*[(masks[(b, s, q)].data_ptr() if (b, s, q) in masks else None) for (b, s) in order for q in range(R)])
+        self._lib_held = (masks, dict(keys))               # alive until the next tick's have replaced them
+        return kp, dp, outs
+
+    def _lib_results(self):
+        self.out = {k: dict(col=o["col"], proposed=o["proposed"], decision=o["decision"], committed=o["committed"], seq=o["seq"], deps=o["deps"])
+                    for k, o in self._lib_outs.items()}
+        import ctypes as C
+        from . import _lib
+        info = (C.c_uint64 * 2)()
+        _lib.check(self._L.smr_ep_spread_info(self._lib_h, info))
+        self.bytes_sent = int(info[1])
+        return self.out
+
+    def _lib_steps(self, keys, drop=None):
+        """the library's segments, yielding before every exchange what `_collective` / `in_process` need to move its buffers"""
+        from . import _lib
+        kp, dp, outs = self._lib_args(keys, drop)
+        nx = self.exchanges_per_tick()
+        for seg in range(nx + 1):
+            _lib.check(self._L.smr_ep_spread_segment(self._lib_h, seg, kp, dp, outs, _lib.stream_ptr(None)))
+            if seg < nx:
+                yield self._lib_plan(seg)
+        self._lib_results()
+
+    def _lib_plan(self, k):
+        """exchange k's buffers as the dict `_collective` takes (tensors over the library's memory)"""
+        b = self._lib_bufs[k]
+        if "sbuf" not in b:
+            n_send, n_recv = sum(b["in_split"]), sum(b["out_split"])
+            b.update(kind=k, n_send=n_send, n_recv=n_recv, sbuf=_tensor_over(self.torch, b["send"], max(n_send, 8), self.device),
+                     rbuf=_tensor_over(self.torch, b["recv"], max(n_recv, 8), self.device))
+        return b
+
+    def close_library_tick(self):
+        if getattr(self, "_lib_h", None):
+            self._L.smr_ep_spread_destroy(self._lib_h)
+            self._lib_h = None
+
     def bind_comm(self, comm):
         """every exchange of the tick through the library: `comm` (summerset_amd.comm.Comm, this rank's end of the job's
         communicator) -> `smr_comm_exchange` on the plans' own send / receive buffers with their static split sizes, on the
@@ -148,6 +238,9 @@ class SpreadEPaxos:
         if comm is not None and (comm.world != self.world or comm.rank != self.rank):
             raise ValueError("the communicator is rank %d of %d, the job's rank is %d of %d" % (comm.rank, comm.world, self.rank, self.world))
         self.comm = comm
+        if getattr(self, "_lib_h", None):
+            from . import _lib
+            _lib.check(self._L.smr_ep_spread_bind_comm(self._lib_h, comm._h if comm is not None else None))
 
     def _get(self, plan, key):
         """the message (block, from, to) as tensors: views of the receive buffer, or the sender's own tensors"""
@@ -263,6 +356,15 @@ class SpreadEPaxos:
         """keys[(b, r)]: uint8 [groups of block b] device tensor for every replica that lives here (0xFF = no proposal);
         drop[(b, s, q)] (optional): bool per group, the PreAccept from s to q is lost (with its reply).  Returns
         {(b, s): dict(col, proposed, decision, committed, seq, deps)} for the command leaders of this rank."""
+        if getattr(self, "_lib_h", None):
+            if self.comm is not None or self.world == 1:               # ONE call: segments and exchanges inside the library
+                from . import _lib
+                kp, dp, outs = self._lib_args(keys, drop)
+                _lib.check(self._L.smr_ep_spread_tick(self._lib_h, kp, dp, outs, _lib.stream_ptr(None)))
+                return self._lib_results()
+            for plan in self._lib_steps(keys, drop):                   # (a gloo job: the library's segments, torch moves the buffers)
+                self._collective(plan)
+            return self.out
         for plan in self._steps(keys, drop):
             self._collective(plan)
         return self.out
@@ -276,6 +378,19 @@ class SpreadEPaxos:
         return sum(o["committed"].sum() for o in out.values())
 
 
+def _tensor_over(torch, ptr, nbytes, device):
+    """a uint8 tensor over `nbytes` of device (or, on the emulator, host) memory the library owns"""
+    import ctypes as C
+    import numpy as np
+    if str(device).startswith("cuda"):
+        class _Mem:                                          # __cuda_array_interface__: torch.as_tensor wraps device memory without a copy
+            pass
+        m = _Mem()
+        m.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr="|u1", data=(int(ptr), False), version=2)
+        return torch.as_tensor(m, device=device)
+    return torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * int(nbytes)).from_address(int(ptr))))
+
+
 class in_process:
     """All `world` ranks of a spread EPaxos job inside one process (one device, or the emulator): the same objects,
     plans and buffers as the multi-process job; only the collective is a copy.  Every rank runs a stage before any rank
@@ -286,7 +401,7 @@ class in_process:
 
     def tick(self, keys, drop=None):
         """keys / drop for every (block, replica) of the job; every rank picks its own"""
-        gens = [r._steps(keys, drop) for r in self.ranks]
+        gens = [(r._lib_steps(keys, drop) if getattr(r, "_lib_h", None) else r._steps(keys, drop)) for r in self.ranks]
         while True:
             plans = []
             for g in gens:

@@ -452,6 +452,14 @@ def test_spread_epaxos_exchange_on_the_host(sim, oracle):
         t.run_spread_vs_colocated("cpu", G=60, world=2, n_ticks=4, loss=0.1, R=3, K=4)                         # three replicas
 
 
+def test_spread_epaxos_library_tick_on_the_host(sim, oracle):
+    """round 6: layout L2 of the EPaxos cluster with the tick inside the library (smr_ep_spread_*, csrc/ep_spread.hip) -- both
+    schedules, populations 3 and 5, 1 / 2 / 3 / 4 / 8 ranks -- against the co-located loop and the oracle cluster"""
+    import test_spread_ep as t
+    with sim.patched():
+        t.run_library_tick_cases("cpu", oracle)
+
+
 def test_cxx_epaxos_host_loop_on_the_host(sim, tmp_path):
     """examples/ep_host_loop.cpp (the one-call EPaxos cluster tick from C++) compiled for the host against the emulator build
     of the library: everything proposed commits and executes, the replicas' KV stores agree"""

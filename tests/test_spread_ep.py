@@ -80,6 +80,58 @@ def run_spread_vs_colocated(dev, G, world, n_ticks, loss, K=8, R=5, W=32, execut
     return job
 
 
+def library_tick_job(G, R=5, W=32, K=8, execute=False, ordered=None, dev="cpu"):
+    """`make` for run_spread_vs_colocated: the in-process job with every rank's tick inside the library (round 6:
+    `smr_ep_spread_segment`, csrc/ep_spread.hip -- schedule, message plan and packing are the library's; here the test moves the
+    exchanges' buffers between the virtual ranks)"""
+    from summerset_amd import spread_ep
+
+    def make(world):
+        job = spread_ep.in_process(G, R, world, dev, window=W, n_keys=K, execute=execute, ordered=ordered)
+        for rk in job.ranks:
+            rk.use_library_tick()
+        return job
+    return make
+
+
+def run_library_tick_cases(dev, oracle, scale=1):
+    """the cases of the Python-driven layout (tests/test_hostsim.py, tests/test_zzy_spread_ep_gpu.py) through the library's tick"""
+    g = lambda n: n * scale   # noqa: E731
+    run_spread_vs_colocated(dev, G=g(130), world=2, n_ticks=5, loss=0.15, make=library_tick_job(g(130), dev=dev), oracle=oracle)
+    run_spread_vs_colocated(dev, G=g(100), world=3, n_ticks=4, loss=0.15, make=library_tick_job(g(100), dev=dev))
+    run_spread_vs_colocated(dev, G=21, world=8, n_ticks=3, loss=0.1, make=library_tick_job(21, dev=dev))             # blocks of 2-3 groups
+    job = run_spread_vs_colocated(dev, G=g(120), world=4, n_ticks=5, loss=0.15, K=6, execute=True,
+                                  make=library_tick_job(g(120), K=6, execute=True, dev=dev), oracle=oracle)
+    assert job.ranks[0].exchanges_per_tick() == 17
+    job = run_spread_vs_colocated(dev, G=g(120), world=4, n_ticks=5, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True,
+                                  make=library_tick_job(g(120), K=6, execute=True, ordered=False, dev=dev), oracle=oracle)
+    assert job.ranks[0].exchanges_per_tick() == 5 and all(rk.bytes_sent > 0 for rk in job.ranks)
+    job = run_spread_vs_colocated(dev, G=g(70), world=1, n_ticks=4, loss=0.1, make=library_tick_job(g(70), dev=dev))  # ONE C call per tick: smr_ep_spread_tick
+    assert job.ranks[0].bytes_sent == 0
+    run_spread_vs_colocated(dev, G=g(60), world=2, n_ticks=4, loss=0.1, R=3, K=4, make=library_tick_job(g(60), R=3, K=4, dev=dev))
+    for rk in job.ranks:
+        rk.close_library_tick()
+
+
+def test_library_tick_refuses_bad_arguments():
+    """argument errors of smr_ep_spread_create / _segment need no device"""
+    import ctypes as C
+    import hostsim
+    from summerset_amd import SummersetError, _lib
+    hostsim.build()
+    with hostsim.patched() as L:
+        h = C.c_void_p()
+        groups = (C.c_uint32 * 2)(8, 8)
+        for args, frag in (((None, None, None, 0, groups, 2, 2, 5, 0, C.byref(h)), "rank / world"),
+                           ((None, None, None, 0, groups, 2, 0, 2, 0, C.byref(h)), "population"),
+                           ((None, None, None, 0, groups, 2, 0, 5, 0, C.byref(h)), "was not handed over")):
+            with pytest.raises(SummersetError) as e:
+                _lib.check(L.smr_ep_spread_create(*args))
+            assert frag in e.value.msg, e.value.msg
+        with pytest.raises(SummersetError):
+            _lib.check(L.smr_ep_spread_segment(None, 0, None, None, None, None))
+
+
 def test_plans_agree_across_ranks_without_a_device():
     """the static plans only: what rank s sends to d is what d expects from s, in every exchange of both schedules, and
     every (block, replica) has exactly one home -- no library call, no device"""

