@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("t1z_pmc_traffic.json", "r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -332,7 +332,11 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
     us_hot = _time_us(torch, lambda i: batches[0].compute_parity(), 48)
     del big
     t_rs = pmc_traffic("smr::rs_matmul_xtime<2, 4>", pick="smallest")     # the probe's 16384-codeword launches (it also runs 65536 for the calibration)
-    same_size = bool(t_rs and t_rs.get("grids", 1) > 1)                   # (a record from before round 4 holds one average: scaled as before)
+    # a record WITHOUT `by_grid` (rebuilt by hand from a log) says nothing about which launch size its figure is --
+    # rescaling it "from a 65536-codeword launch" put 0.26 where 1.04 was true.  No `by_grid`, no traffic figure.
+    if t_rs is not None and not (pmc_file() or {}).get("kernels", {}).get("smr::rs_matmul_xtime<2, 4>", {}).get("by_grid"):
+        t_rs = None
+    same_size = bool(t_rs and t_rs.get("grids", 1) > 1)
     res = {"workload": "RS(3,2) GF(2^8) encode, 16384 codewords x L=4099 B (4 KiB value as bincode String) per launch, "
                        "%d distinct batches in rotation (%.0f MB in + out: beyond the 256 MiB L3)" % (NB, NB * n * 5 * cw.shard_len / 1e6),
            "value": out["xtime"]["payload_GiBps"], "unit": "GiB/s payload",
@@ -340,8 +344,9 @@ def rs_leg(torch, dev, run_cpu, cpu_seconds):
                         "unit": "GB/s", "frac": out["xtime"]["frac"], "kernel": "rs_matmul_xtime<2, 4>",
                         "alg_bytes_per_launch": n * 5 * cw.shard_len, "avg_launch_us": out["xtime"]["ms_per_launch"] * 1e3,
                         "traffic": (t_rs["hbm_bytes_per_launch"] if same_size else t_rs["hbm_bytes_per_launch"] / 65536 * n) if t_rs else None,
-                        "traffic_note": ("PMC bytes of the probe's %d-codeword launches (same grid size as this leg's)" % n) if same_size else
-                                        ("PMC bytes of a 65536-codeword launch scaled to this launch's %d codewords" % n)},
+                        "traffic_note": "no PMC figure keyed by grid size in the committed record" if not t_rs else
+                                        ("PMC bytes of the probe's %d-codeword launches (same grid size as this leg's)" % n) if same_size else
+                                        ("PMC bytes of the record's only launch size (65536 codewords) scaled to this launch's %d codewords" % n)},
            "lut_variant_GiBps": out["lut"]["payload_GiBps"],
            "one_launch_65536_codewords": {"avg_launch_us": us_big, "frac": 65536 * 5 * cw.shard_len / (us_big * 1e-6) / 1e9 / HBM_PEAK_GBS},
            "single_hot_batch_L3_assisted": {"avg_launch_us": us_hot, "frac": n * 5 * cw.shard_len / (us_hot * 1e-6) / 1e9 / HBM_PEAK_GBS},

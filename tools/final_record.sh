@@ -1,9 +1,12 @@
 #!/bin/bash
-# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m, r8z, r9z):
+# The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m, r8z, r9z;
+# round 6: t1z).  EVERYTHING the record consists of is written under gpurun_out/ (the one directory gpurun merges back) -- VERDICT r5 weak #8: round 5's
+# PMC JSONs were copied to the box's profiles/ only and had to be rebuilt by hand -- and the JSONs are ALSO packed into ${TAG}_record_files.b64 so that a
+# truncated merge can be undone (tools/final_record_unpack.py).  Take it while >= 20 GPU-minutes remain; launch nothing after it.
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra and over the two payload legs
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
-TAG=${1:-r9z}
+TAG=${1:-t1z}
 mkdir -p gpurun_out
 R=$PWD
 # 0. is this box's GPU sane?  (round 5's third take met one that faulted in every process; every step below then ran into its own
@@ -52,6 +55,14 @@ d = json.load(open("gpurun_out/${TAG}_pmc_traffic.json"))
 for k, v in d["kernels"].items():
     print("  pmc", k[:60], v["launches"], round(v["hbm_bytes_per_launch"] / 1e6, 2), "MB")
 P
-# (the files of the record are gpurun_out/${TAG}_*: gpurun merges that directory back, NOT profiles/ of the box -- copy them into profiles/ after the call,
-#  the ${TAG}_pmc_traffic*.json among them: round 5 left those behind once and had to rebuild them from this script's printout)
-echo "final_record: done -- now, in the repository: cp gpurun_out/${TAG}_* profiles/"
+# every JSON of the record once more, gzip + base64, in ONE text file: whatever of gpurun_out/ makes it home, this does
+python - <<P
+import base64, glob, gzip, json, os
+out = {}
+for f in sorted(glob.glob("gpurun_out/${TAG}_*.json") + glob.glob("gpurun_out/${TAG}_kernel_*.txt")):
+    out[os.path.basename(f)] = base64.b64encode(gzip.compress(open(f, "rb").read())).decode()
+json.dump(out, open("gpurun_out/${TAG}_record_files.b64", "w"))
+print("final_record: %d files packed into gpurun_out/${TAG}_record_files.b64 (%d bytes)" % (len(out), os.path.getsize("gpurun_out/${TAG}_record_files.b64")))
+P
+# (the files of the record are gpurun_out/${TAG}_*: gpurun merges that directory back, NOT profiles/ of the box -- copy them into profiles/ after the call)
+echo "final_record: done -- now, in the repository: cp gpurun_out/${TAG}_* profiles/  (or: python tools/final_record_unpack.py gpurun_out/${TAG}_record_files.b64 profiles/)"
