@@ -1507,6 +1507,12 @@ def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
     job = spread_rsp.in_process(total, R, W, nr, dev, L) if virtual else spread_rsp.SpreadRSPaxos(total, R, W, rank, world, dev, L)
     comm, via = _bind_library_exchange(job, dist, dev, virtual)
     ranks = job.ranks if virtual else [job]
+    # round 6: the tick's phases inside the library (smr_rsp_spread_*: fused encode + scatter, handlers, headers, loss masks -- and, with
+    # the communicator bound, the exchanges: ONE C call per tick); SMR_L2_PYTHON_TICK=1 keeps the Python-driven tick of rounds 3-5
+    lib_tick = os.environ.get("SMR_L2_PYTHON_TICK") is None
+    if lib_tick:
+        for rk in ranks:
+            rk.use_library_tick()
     blocks = sorted({b for rk in ranks for b in rk.lead})
     srcs = {b: [torch.randint(0, 256, (shard.group_range(total, nr, b)[1] - shard.group_range(total, nr, b)[0], L), dtype=torch.uint8, device=dev)
                 for _ in range(NB)] for b in blocks}
@@ -1542,12 +1548,17 @@ def spread_rspaxos_main(args, torch, dist, rank, local, world, dev):
                                    % (G, L, H), "groups_per_gpu": G, "replicas": R, "layout": "spread-rspaxos", "spread_ranks": nr,
                        "ranks_are": "virtual (one process, one GPU: the collective is a device copy)" if virtual else "processes, one per GPU"},
             "exchange": {"via": via, "collectives_per_tick": "2 (Accepts + shards out, AcceptReplies back); 4 on a heartbeat tick",
+                         "tick": ("smr_rsp_spread_tick: one C call per tick, exchanges inside" if (lib_tick and comm is not None) else
+                                  "smr_rsp_spread_segment: one C call per segment (3; 6 on a heartbeat tick), the host moves the exchange's buffers" if lib_tick
+                                  else "summerset_amd/spread_rsp.py: one ctypes call per handler + torch ops (SMR_L2_PYTHON_TICK)"),
                          "bytes_per_exchange_per_rank": {k: int(sum(x["in_split"])) for k, x in p.items()},
                          "bytes_sent_per_tick_per_rank": sent / args.steps / len(ranks),
                          "rs_payload_GiBps": len(blocks) * G * L * args.steps / 2**30 / elapsed * (1 if virtual else world)},
             "roofline": None, "cpu_baseline": None}
     if rank == 0:
         emit_line(line)
+    for rk in ranks:
+        rk.close_library_tick()
     if comm is not None:
         job.bind_comm(None)
         comm.close()

@@ -896,6 +896,36 @@ int smr_rsp_cluster_steady_tick(smr_rsp_cluster *c, uint8_t leader, const uint32
 int smr_rsp_handle_heartbeat(smr_rsp_replica *e, const uint8_t *peer_dev, const smr_rsp_heartbeat *in, uint8_t *reply_dev,
                              const smr_rsp_heartbeat *out, void *stream);
 int smr_rsp_bcast_heartbeat(smr_rsp_replica *e, const uint8_t *flags_dev, const smr_rsp_heartbeat *out, void *stream);
+/* ---- layout L2 of the RSPaxos replica engine as ONE call per tick (round 6; BASELINE config 4 as written: "1 -> 8 GPU shard over
+ * xGMI"; the groups block-partitioned over `world` ranks, replica r of block b on rank (b + r) mod world: block b is led -- replica 0,
+ * prepared -- from rank b) ------------------------------------------------------------------------------------------------------
+ * What summerset_amd/spread_rsp.py drove from Python in rounds 3-5: the leader's from_data + RS encode with every follower's shard
+ * written straight into that follower's slice of the send buffer, handle_req_batch and the Accept headers (segment 0); the
+ * followers' handle_msg_accept, reply ballots straight into the backward buffer (1); the leader's tally (2); on a heartbeat tick the
+ * Heartbeat out (3), heard_heartbeat + the Heartbeats back (4), the leader hearing them (5).  Exchanges (one all-to-all with static
+ * split sizes each; TransportHub::send_msg, server/transport.rs:208-275) behind segments 0, 1, 3 and 4: exchange 0 Accept (header +
+ * shard), 1 AcceptReply, 2 Heartbeat, 3 Heartbeat back.
+ *   smr_rsp_spread_create    reps[i] = replica rep_id[i] of block rep_block[i], every one that lives on `rank`, preset to leader 0
+ *                            (smr_rsp_preset_leader), window and fault_tolerance as the job's; data_len = bytes of a serialized batch
+ *   smr_rsp_spread_segment   one segment, for a host that moves the buffers itself (smr_rsp_spread_buffers)
+ *   smr_rsp_spread_tick      all of it: segments and smr_comm_exchange calls back to back on `stream` (smr_rsp_spread_bind_comm first)
+ * data_dev / val_dev: the led block's batches (u8 [G][data_len]) and tokens (u32 [G], SMR_RSP_NULL: none), NULL on a rank that
+ * leads no block; lost_dev (may be NULL): [world * 4 * R] pointers, entry (b * 4 + k) * R + q (may be NULL) = u8 [G_b], 1 where
+ * block b's message is lost -- k = 0 Accept leader -> q, 1 AcceptReply q -> leader, 2 Heartbeat leader -> q, 3 Heartbeat q ->
+ * leader (as smr_rsp_cluster_steady_tick's); committed_dev: u8 [G] of the led block, 1 where the tick's slot committed. */
+typedef struct smr_rsp_spread smr_rsp_spread;
+int smr_rsp_spread_create(smr_rsp_replica *const *reps, const uint32_t *rep_block, const uint8_t *rep_id, uint32_t n_reps,
+                          const uint32_t *block_groups, uint32_t world, uint32_t rank, uint8_t population, uint32_t window, uint64_t data_len,
+                          smr_rsp_spread **out);
+void smr_rsp_spread_destroy(smr_rsp_spread *s);
+int smr_rsp_spread_buffers(smr_rsp_spread *s, uint32_t exchange, void **send_dev, uint64_t *send_bytes, void **recv_dev, uint64_t *recv_bytes);
+int smr_rsp_spread_bind_comm(smr_rsp_spread *s, smr_comm *comm);
+int smr_rsp_spread_segment(smr_rsp_spread *s, uint32_t seg, const uint8_t *data_dev, const uint32_t *val_dev, const uint8_t *const *lost_dev,
+                           int heartbeat, uint8_t *committed_dev, void *stream);
+int smr_rsp_spread_abort_tick(smr_rsp_spread *s);
+int smr_rsp_spread_tick(smr_rsp_spread *s, const uint8_t *data_dev, const uint32_t *val_dev, const uint8_t *const *lost_dev, int heartbeat,
+                        uint8_t *committed_dev, void *stream);
+int smr_rsp_spread_info(const smr_rsp_spread *s, uint64_t out[2]);
 /* host buffers: scalars [G], peer_exec_bar [R][G], per slot [W][G] by slot % W (cells outside the ring read as
  * null instances); s_flags: bit0 leader_bk, bit1 replica_bk, bit2 external; counters[4] = commits, commands
  * executed, absorbs of a different token (none in a correct run), redirected batches */

@@ -310,6 +310,14 @@ SYMBOLS = [
     ("smr_ep_spread_abort_tick", _i, [_vp]),
     ("smr_ep_spread_tick", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_spread_info", _i, [_vp, _vp]),
+    ("smr_rsp_spread_create", _i, [_vp, _vp, _vp, _u32, _vp, _u32, _u32, _u8, _u32, _u64, _vp]),
+    ("smr_rsp_spread_destroy", None, [_vp]),
+    ("smr_rsp_spread_buffers", _i, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    ("smr_rsp_spread_bind_comm", _i, [_vp, _vp]),
+    ("smr_rsp_spread_segment", _i, [_vp, _u32, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("smr_rsp_spread_abort_tick", _i, [_vp]),
+    ("smr_rsp_spread_tick", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    ("smr_rsp_spread_info", _i, [_vp, _vp]),
     ("smr_ep_dump", _i, [_vp, C.POINTER(EpDumpBufs)]),
     ("smr_ep_exec_dump", _i, [_vp, _vp, _vp, _vp, _vp]),
     ("smr_ep_exec_poll", _i, [_vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsummerset_hip.so")
-SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "ep_spread.hip", "rsp_engine.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "ep_spread.hip", "rsp_engine.hip", "rsp_spread.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
 HEADERS = ["smr_common.h", "mp_types.h", "mp_device.h", "rsp_peek.h", "raft_peek.h", "wire_rd.h", os.path.join("..", "..", "include", "summerset_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -132,6 +132,74 @@ class SpreadRSPaxos:
         else:
             p["rbuf"][:sum(p["out_split"])].copy_(p["sbuf"][:sum(p["in_split"])])
 
+    # ---- the tick inside the library (round 6: smr_rsp_spread_*, csrc/rsp_spread.hip) --------------------------------------------
+    def use_library_tick(self):
+        """from now on the tick's phases are the library's segments (`smr_rsp_spread_segment`: encode + scatter, handlers, header
+        copies, loss masks -- no torch op in a tick) and, with `bind_comm`, `tick` is ONE C call (`smr_rsp_spread_tick`, exchanges
+        inside).  The plans' send / receive buffers become views of the library's (same layout: what the tests read out of them
+        stays where it was).  Not with payload stores (those stay this module's)."""
+        import ctypes as C
+        from . import _lib
+        from .spread_ep import _tensor_over
+        if self.stores:
+            raise ValueError("the library tick carries the shards in the exchange's buffers: payload=False")
+        self._L = _lib.load()
+        order = sorted(self.reps)
+        n = len(order)
+        arr = (C.c_void_p * max(n, 1))(*[self.reps[k]._h for k in order])
+        blocks = (C.c_uint32 * max(n, 1))(*[k[0] for k in order])
+        ids = (C.c_uint8 * max(n, 1))(*[k[1] for k in order])
+        groups = (C.c_uint32 * self.world)(*[self.n_groups[b][1] - self.n_groups[b][0] for b in range(self.world)])
+        h = C.c_void_p()
+        _lib.check(self._L.smr_rsp_spread_create(arr, blocks, ids, n, groups, self.world, self.rank, self.R, self.W, self.L, C.byref(h)))
+        self._lib_h = h
+        for k, kind in enumerate(("accept", "accept_reply", "hb", "hb_back")):
+            sp, rp = C.c_void_p(), C.c_void_p()
+            sb, rb = (C.c_uint64 * self.world)(), (C.c_uint64 * self.world)()
+            _lib.check(self._L.smr_rsp_spread_buffers(h, k, C.byref(sp), sb, C.byref(rp), rb))
+            p = self._plans[kind]
+            assert [int(x) for x in sb] == p["in_split"] and [int(x) for x in rb] == p["out_split"], kind
+            p["sbuf"] = _tensor_over(self.torch, sp.value, max(sum(p["in_split"]), 16), self.device)
+            p["rbuf"] = _tensor_over(self.torch, rp.value, max(sum(p["out_split"]), 16), self.device)
+        if self.comm is not None:
+            _lib.check(self._L.smr_rsp_spread_bind_comm(h, self.comm._h))
+        self._lib_committed = {b: self.torch.zeros(self.n_groups[b][1] - self.n_groups[b][0], dtype=self.torch.uint8, device=self.device) for b in self.lead}
+        return self
+
+    def close_library_tick(self):
+        if getattr(self, "_lib_h", None):
+            self._L.smr_rsp_spread_destroy(self._lib_h)
+            self._lib_h = None
+
+    def _lib_args(self, data, val, lost, heartbeat):
+        """(data ptr, val ptr, lost table, heartbeat, committed ptr) of this tick; kept until the next tick has replaced them"""
+        import ctypes as C
+        torch, R = self.torch, self.R
+        b = self.lead[0] if self.lead else None
+        d = data[b].contiguous() if b is not None else None
+        v = val[b].contiguous() if b is not None else None
+        tab, masks = None, None
+        if lost:
+            kinds = (("accept", lambda q: (0, q)), ("accept_reply", lambda q: (q, 0)), ("hb", lambda q: (0, q)), ("hb", lambda q: (q, 0)))
+            masks, ptrs = [], []
+            for bb in range(self.world):
+                for kind, ft in kinds:
+                    for q in range(R):
+                        g = lost.get(bb, {}).get((kind,) + ft(q)) if q else None
+                        if g is not None:
+                            g = (g if g.dtype == torch.uint8 else g.to(torch.uint8)).contiguous()
+                            masks.append(g)
+                        ptrs.append(None if g is None else g.data_ptr())
+            tab = (C.c_void_p * len(ptrs))(*ptrs)
+        self._lib_held = (d, v, masks, tab)
+        self._lib_call = (None if d is None else d.data_ptr(), None if v is None else v.data_ptr(), tab, 1 if heartbeat else 0,
+                          None if b is None else self._lib_committed[b].data_ptr())
+
+    def _lib_segment(self, seg):
+        from . import _lib
+        d, v, tab, hb, c = self._lib_call
+        _lib.check(self._L.smr_rsp_spread_segment(self._lib_h, seg, d, v, tab, hb, c, _lib.stream_ptr(None)))
+
     def bind_comm(self, comm):
         """every exchange of the tick (Accepts + shards out, AcceptReplies back, the two heartbeat legs) through the library:
         `comm` (summerset_amd.comm.Comm) -> `smr_comm_exchange` on the plans' own buffers with their static split sizes.
@@ -139,6 +207,9 @@ class SpreadRSPaxos:
         if comm is not None and (comm.world != self.world or comm.rank != self.rank):
             raise ValueError("the communicator is rank %d of %d, the job's rank is %d of %d" % (comm.rank, comm.world, self.rank, self.world))
         self.comm = comm
+        if getattr(self, "_lib_h", None):
+            from . import _lib
+            _lib.check(self._L.smr_rsp_spread_bind_comm(self._lib_h, comm._h if comm is not None else None))
 
     # ---- typed views of a message inside a buffer -------------------------------------------------------------------------
     def _fields(self, buf, off, G, spec):
@@ -171,8 +242,11 @@ class SpreadRSPaxos:
         return self._bufs[key]
 
     # ---- the tick's phases ----------------------------------------------------------------------------------------------------
-    def phase_a(self, data, val, lost=None):
+    def phase_a(self, data, val, lost=None, heartbeat=False):
         """leaders: data[b] uint8 [G_b, L] = the tick's serialized batches, val[b] int32 [G_b] their tokens (NULL = none)"""
+        if getattr(self, "_lib_h", None):
+            self._lib_args(data, val, lost, heartbeat)
+            return self._lib_segment(0)
         torch = self.torch
         R, s, p = self.R, self.LEADER, self._plans["accept"]
         for b in self.lead:
@@ -217,6 +291,8 @@ class SpreadRSPaxos:
 
     def phase_b(self, lost=None):
         """followers: handle_msg_accept on what arrived; the reply ballots land in the backward send buffer"""
+        if getattr(self, "_lib_h", None):
+            return self._lib_segment(1)
         torch = self.torch
         s, pa, pr = self.LEADER, self._plans["accept"], self._plans["accept_reply"]
         for (b, q), eng in self.reps.items():
@@ -245,6 +321,9 @@ class SpreadRSPaxos:
 
     def phase_c(self):
         """leaders: the AcceptReply tally; returns {block: committed flags [G_b]}"""
+        if getattr(self, "_lib_h", None):
+            self._lib_segment(2)
+            return {b: self._lib_committed[b] for b in self.lead}
         torch = self.torch
         R, s, pr = self.R, self.LEADER, self._plans["accept_reply"]
         out = {}
@@ -266,6 +345,8 @@ class SpreadRSPaxos:
         return out
 
     def phase_hb_out(self, lost=None):
+        if getattr(self, "_lib_h", None):
+            return self._lib_segment(3)
         torch = self.torch
         R, s, p = self.R, self.LEADER, self._plans["hb"]
         for b in self.lead:
@@ -285,6 +366,8 @@ class SpreadRSPaxos:
                     p["sbuf"][o:o + G * 20].copy_(p["sbuf"][first:first + G * 20])
 
     def phase_hb_in(self, lost=None):
+        if getattr(self, "_lib_h", None):
+            return self._lib_segment(4)
         torch = self.torch
         s, p, pb = self.LEADER, self._plans["hb"], self._plans["hb_back"]
         for (b, q), eng in self.reps.items():
@@ -307,6 +390,8 @@ class SpreadRSPaxos:
                 back["reply"].masked_fill_(g, 0)
 
     def phase_hb_back(self):
+        if getattr(self, "_lib_h", None):
+            return self._lib_segment(5)
         torch = self.torch
         R, s, pb = self.R, self.LEADER, self._plans["hb_back"]
         for b in self.lead:
@@ -328,7 +413,14 @@ class SpreadRSPaxos:
 
     def tick(self, data, val, lost=None, heartbeat=False):
         """data / val: per led block (see phase_a); lost[b][(kind, from, to)] = bool [G_b] (optional).  Returns {block: committed}"""
-        self.phase_a(data, val, lost)
+        if getattr(self, "_lib_h", None) and self.exchange is None and (self.comm is not None or self.world == 1):
+            from . import _lib                                   # ONE call: segments and exchanges inside the library
+            self._lib_args(data, val, lost, heartbeat)
+            d, v, tab, hb, c = self._lib_call
+            _lib.check(self._L.smr_rsp_spread_tick(self._lib_h, d, v, tab, hb, c, _lib.stream_ptr(None)))
+            self.bytes_sent += sum(sum(self._plans[k]["in_split"]) for k in (("accept", "accept_reply", "hb", "hb_back") if heartbeat else ("accept", "accept_reply")))
+            return {b: self._lib_committed[b] for b in self.lead}
+        self.phase_a(data, val, lost, heartbeat)
         self._collective("accept")
         self.phase_b(lost)
         self._collective("accept_reply")
@@ -374,7 +466,7 @@ class in_process:
                 r.bytes_sent += sum(r._plans[kind]["in_split"])
             _copy_between(rs, kind)
         for r in rs:
-            r.phase_a(data, val, lost)
+            r.phase_a(data, val, lost, heartbeat)
         coll("accept")
         for r in rs:
             r.phase_b(lost)

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "summerset_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build")
-SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "ep_spread.hip", "rsp_engine.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
+SOURCES = ["core.hip", "rs_kernels.hip", "mp_engine.hip", "raft_engine.hip", "ep_engine.hip", "ep_spread.hip", "rsp_engine.hip", "rsp_spread.hip", "rsp_payload.hip", "rep_nothing.hip", "wire.hip", "wire_ingest.hip", "wire_ingest_replies.hip", "wire_emit.hip", "qread.hip", "kv_exec.hip", "heartbeater.hip", "skv_exec.hip", "leaseman.hip", "comm.hip"]
 LIB = os.path.join(_OUT, "libsummerset_sim.so")
 # clang: the RS kernels use ext_vector_type, which g++ does not have (this is the host compiler hipcc itself drives)
 CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")

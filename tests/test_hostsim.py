@@ -452,6 +452,18 @@ def test_spread_epaxos_exchange_on_the_host(sim, oracle):
         t.run_spread_vs_colocated("cpu", G=60, world=2, n_ticks=4, loss=0.1, R=3, K=4)                         # three replicas
 
 
+def test_spread_rspaxos_library_tick_on_the_host(sim):
+    """round 6: layout L2 of the RSPaxos engine with the tick's segments inside the library (smr_rsp_spread_*, csrc/rsp_spread.hip)
+    against the co-located steady loop: commits, every replica's state, the shard bytes every follower received"""
+    import test_spread_rsp as t
+    with sim.patched():
+        assert t.run_spread_vs_colocated("cpu", 2, 130, library_tick=True) > 0
+        assert t.run_spread_vs_colocated("cpu", 3, 100, library_tick=True) > 0
+        assert t.run_spread_vs_colocated("cpu", 8, 70, T=5, library_tick=True) > 0
+        assert t.run_spread_vs_colocated("cpu", 4, 96, W=32, L=4113, loss=0.0, T=4, library_tick=True) > 0
+        assert t.run_spread_vs_colocated("cpu", 1, 60, T=5, library_tick=True) > 0       # one rank: ONE C call per tick, its own exchange a device copy
+
+
 def test_spread_epaxos_library_tick_on_the_host(sim, oracle):
     """round 6: layout L2 of the EPaxos cluster with the tick inside the library (smr_ep_spread_*, csrc/ep_spread.hip) -- both
     schedules, populations 3 and 5, 1 / 2 / 3 / 4 / 8 ranks -- against the co-located loop and the oracle cluster"""

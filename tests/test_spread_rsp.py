@@ -7,13 +7,16 @@ import numpy as np
 import pytest
 
 
-def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9, hb_every=3, seed=3, payload=False, oracle=None):
+def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9, hb_every=3, seed=3, payload=False, oracle=None, library_tick=False):
     """payload: the job keeps its bytes in payload stores (put / extract -> message -> ingest / follow); on top of everything else
     every store cell must then hold what its engine says it holds and every held shard must be the ORACLE's codeword of the batch"""
     import torch
     from summerset_amd import RSPaxosReplicaGroup, rsp_cluster, shard, spread_rsp
     R = 5
     job = spread_rsp.in_process(total, R, W, world, dev, L, fault_tolerance=ft, payload=payload)
+    if library_tick:                                             # round 6: every rank's phases are the library's segments (csrc/rsp_spread.hip)
+        for rk in job.ranks:
+            rk.use_library_tick()
     batches = {}                                                 # token -> the serialized batch (host copy)
     ref = {}
     for b in range(world):
@@ -57,7 +60,7 @@ def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9,
                     assert torch.equal(m["shard"][has], cw.shard(q)[has]), (t, b, q)
                 else:
                     assert torch.equal(m["shard"], cw.shard(q)), (t, b, q)
-            if not payload:
+            if not payload and not library_tick:                 # (the library keeps the leader's codeword buffer to itself)
                 assert torch.equal(job.ranks[b % world].cw[b].buf[:, :5 * cw.shard_len], cw.buf[:, :5 * cw.shard_len])
         if payload:
             _check_stores(job, world, R, L, batches, oracle, t)
@@ -70,6 +73,8 @@ def run_spread_vs_colocated(dev, world, total, W=16, L=100, ft=1, loss=0.1, T=9,
     assert n_commit > 0
     sent = sum(rk.bytes_sent for rk in job.ranks)
     assert sent > 0
+    for rk in job.ranks:
+        rk.close_library_tick()
     return n_commit
 
 
@@ -110,6 +115,15 @@ def _check_stores(job, world, R, L, batches, oracle, where):
 @pytest.mark.parametrize("world,total", [(2, 600), (3, 500), (8, 2048)])
 def test_spread_rspaxos_is_the_colocated_loop(cuda, world, total):
     run_spread_vs_colocated(cuda, world, total)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,total", [(2, 600), (3, 500), (8, 2048)])
+def test_spread_rspaxos_tick_inside_the_library(cuda, world, total):
+    """round 6: the same layout with the tick's segments inside the library (smr_rsp_spread_segment, csrc/rsp_spread.hip)"""
+    run_spread_vs_colocated(cuda, world, total, library_tick=True)
+    if world == 2:
+        run_spread_vs_colocated(cuda, 4, 1024, W=32, L=4113, loss=0.0, T=6, library_tick=True)
 
 
 @pytest.mark.gpu
