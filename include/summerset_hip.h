@@ -396,6 +396,13 @@ int smr_mp_counters(smr_mp_cluster *c, uint8_t rep, uint64_t out[3]);
  * instead of the steady-state fast path (a performance, not a correctness, figure) */
 int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out);
 
+/* debug: client batches of replica `rep` that the quorum-tally launch of the PREVIOUS tick appended (smr_mp_run_ticks, round 6:
+ * a leader's steady-state handle_req_batch calls of tick t + 1 -- multipaxos/request.rs:13-127 -- ride in the launch that
+ * completes its tick t, where its scalars are in registers already) instead of that tick's own smr_mp_round_local launch
+ * (a performance, not a correctness, figure; only with SMR_MP_FOLD_R1 in the environment at smr_mp_create: off by default,
+ * measured a wash -- DESIGN.md 10) */
+int smr_mp_debug_folded_batches(smr_mp_cluster *c, uint8_t rep, uint64_t *out);
+
 /* the straggler list (smr_mp_cfg.straggler_ticks): out[0] = its capacity in groups (0: list off), out[1] = the number of
  * groups the LAST mark pass (of smr_mp_tick / of a smr_mp_run_ticks batch) wanted on it.  out[1] > out[0]: the list was
  * full and the groups beyond it stayed with the bulk kernels (same results, slower tick).  Synchronises the device. */

@@ -242,6 +242,7 @@ SYMBOLS = [
     ("smr_mp_dump_range", _i, [_vp, C.c_uint8, _u32, _u32, C.POINTER(MpDumpBufs)]),
     ("smr_mp_counters", _i, [_vp, _u8, C.POINTER(_u64 * 3)]),
     ("smr_mp_debug_generic_units", _i, [_vp, _u8, C.POINTER(_u64)]),
+    ("smr_mp_debug_folded_batches", _i, [_vp, _u8, C.POINTER(_u64)]),
     ("smr_mp_debug_stamps", _i, [_vp, _vp]),
     ("smr_comm_unique_id", _i, [_vp, _u64]),
     ("smr_comm_init_rank", _i, [_vp, _u64, _u32, _u32, C.POINTER(_vp)]),

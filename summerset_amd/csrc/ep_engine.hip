@@ -2134,12 +2134,31 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
         }
         if (fast) {
             // round 1: the keys' highest columns
+            // (an entry's R columns are consecutive words at an 8-byte aligned address -- a slot of R + 1 words at word q (R + 1) of the
+            //  shared table's line, or a private entry of 8 / 16 words: two 8-byte loads and a word per key, not five words; every one
+            //  of these is a gather over 64 lines)
             uint32_t my[NR][NR];
 #pragma unroll
-            for (int s = 0; s < NR; s++)
-#pragma unroll
-                for (int r = 0; r < NR; r++)
-                    my[s][r] = ((uint32_t)s < R && (uint32_t)s != q && (uint32_t)r < R) ? EA(v.hc, SHL_OF(hc_g + key[s], v.hc_es) + r) : EP_NONE;
+            for (int s = 0; s < NR; s++) {
+                const bool on = (uint32_t)s < R && (uint32_t)s != q;
+                const uint32_t e0 = SHL_OF(hc_g + key[s], v.hc_es);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const bool wide = on && (v.hc_es & 1u) == 0 && ((uintptr_t)v.hc & 7u) == 0;
+                u32x2 a = (u32x2){EP_NONE, EP_NONE}, b = (u32x2){EP_NONE, EP_NONE};
+                uint32_t c4 = EP_NONE;
+                if (wide) {
+                    a = *(const u32x2 *)((const char *)v.hc + (uint32_t)(e0 * 4u));
+                    b = *(const u32x2 *)((const char *)v.hc + (uint32_t)(e0 * 4u + 8u));
+                    c4 = EA(v.hc, e0 + 4u);
+                } else if (on) {
+                    a.x = EA(v.hc, e0); a.y = EA(v.hc, e0 + 1u); b.x = EA(v.hc, e0 + 2u); b.y = EA(v.hc, e0 + 3u); c4 = EA(v.hc, e0 + 4u);
+                }
+                my[s][0] = (on && 0u < R) ? a.x : EP_NONE;
+                if (NR > 1) my[s][1 < NR ? 1 : 0] = (on && 1u < R) ? a.y : EP_NONE;
+                if (NR > 2) my[s][2 < NR ? 2 : 0] = (on && 2u < R) ? b.x : EP_NONE;
+                if (NR > 3) my[s][3 < NR ? 3 : 0] = (on && 3u < R) ? b.y : EP_NONE;
+                if (NR > 4) my[s][4 < NR ? 4 : 0] = (on && 4u < R) ? c4 : EP_NONE;
+            }
             // ... behind my own proposal, whose update of its key's entry is still with me (hcm bit q)
             if ((hcm >> q) & 1u) {
                 const uint32_t cq = PA(q, 1), kq = PA(q, 2);

@@ -194,6 +194,9 @@ __device__ __forceinline__ void r1_body(const MpParams &P, int par, const uint8_
     const bool has_to = active && timeout_rep && timeout_rep[g] == r;
     uint32_t n_req = (active && req_target && req_target[g] == r) ? req_cnt[g] : 0;
     if (n_req > S) n_req = S;
+    // (round 6) the previous tick's mp_quorum_tally may have run these batches already (MpNextLocal): nothing left of them here
+    const uint32_t r1_dn = P.r1_done[g < P.G ? g : 0];
+    if (n_req != 0 && r1_dn != 0) { n_req = 0; P.r1_done[g] = 0; }
     active = !has_to && n_req > 0;
     // force_coop (the side stream's batch kernel): the appends too are a job of the whole wavefront, one lane per batch
     const bool app_job = force_coop && active;
@@ -929,7 +932,8 @@ __device__ __forceinline__ T *rep_shift(T *p0, size_t byte_off) { return (T *)((
 #endif
 template <int NR>
 __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, const uint32_t *__restrict__ ackctl,
-                                                   int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk, uint32_t hint) {
+                                                   int publish_hb, uint8_t *sh_fl, uint32_t *sh_mk, uint32_t hint,
+                                                   const MpNextLocal nx = MpNextLocal{nullptr, nullptr, nullptr, nullptr, 0u}) {
 #ifndef TALLY_C
 #define TALLY_C 4          // rows per wavefront and pass.  Since round 4 a row in flight is its meta word alone -- the ballots of the leader's
 #endif                     // run are not stored (one bit per row says "bal_prepared >= the slot's ballot", loaded only for rows outside
@@ -963,6 +967,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
     for (int k = 0; k < C; k++) {
         const uint32_t j = w + 4u * (uint32_t)k;
         ctl[k] = (ackctl && j < P.cap) ? ackctl[(size_t)j * G + gg] : SMR_CTL_IDENTITY;
+    }
+    // (round 6) the NEXT tick's client batches of this group: whom they are addressed to, how many, and that replica's HearTimeout
+    uint32_t nx_tgt = NO_REP, nx_cnt = 0, nx_to = NO_REP;
+    if (nx.req_target) {
+        nx_tgt = nx.req_target[gg]; nx_cnt = nx.req_cnt[gg];
+        if (nx.timeout_rep) nx_to = nx.timeout_rep[gg];
     }
 #if TALLY_SPEC
     const size_t roh = (size_t)(hint < R ? hint : 0u) * P.rep_stride;   // wave-uniform
@@ -1031,6 +1041,17 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         brun = rep_shift(v0.bal_lo, ro)[gg]; bms = rep_shift(v0.bal_max_seen, ro)[gg];   // the leader's ballot run (R1)
     }
     const bool fast4 = cand && reg != 0 && bpd != 0 && leader == dl;
+    // (round 6) mp_round_local's steady-state fast path of the NEXT tick, decided on what this tick's closed form leaves behind:
+    // fold_n = the batches my replica will append below, 0 = that tick's R1 launch does it (r1_body's preconditions, one by one;
+    // the closed form adds accept_bar == log end and an empty outbox of this parity, and moves nothing r1_body looks at)
+    uint32_t fold_n = 0;
+    if (nx.req_target && fast4 && nx_tgt == dl && nx_to != dl && !publish_hb) {
+        const uint32_t nlb = rep_shift(v0.null_lb, ro)[gg], c0n = rep_shift(v0.ob_cnt[par ^ 1], ro)[gg];
+        const uint32_t n_req = nx_cnt < nx.S ? nx_cnt : nx.S;
+        if (n_req != 0 && bpd == bms && thresh > 1 && nlb >= len && abar == len && c0n == 0 && n_req <= P.cap &&
+            (len - start) + n_req - 1 + P.win_reserve < P.W)
+            fold_n = n_req;
+    }
     // (what the loop needs of the 64-bit scalars, as bits: they are dead from here on -- the kernel is 2 VGPRs from a sixth wavefront)
     const bool run_bal_ok = bpd >= bms;                          // a slot of the run: bal_prepared >= its ballot (= bal_max_seen)
     const bool answers_ok = rbal != 0 && rbal == bpd;            // an answer carries the Accept's ballot (ob_rbal): messages.rs:388
@@ -1106,6 +1127,14 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #if TALLY_WAVEFLAGS
     sh_fl[w * 64 + lane] = (uint8_t)wall;                        // (a wavefront without rows hands over 0xFF)
 #endif
+    // (round 6) my share of the next tick's batch tokens -- batches w, w + 4, ... -- in flight across the barrier
+    constexpr int NXQ = 8;
+    uint32_t nxtok[NXQ];
+#pragma unroll
+    for (int q = 0; q < NXQ; q++) {
+        const uint32_t k = w + 4u * (uint32_t)q;
+        nxtok[q] = k < fold_n ? nx.req_val[(size_t)k * G + gg] : 0u;
+    }
     __syncthreads();
     // ---- the all-commit closed form, or leave the lane to mp_round_replies ------------------------
     bool closed = false;
@@ -1132,6 +1161,41 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
         p_cbar[gg] = first + cnt;
         if (ebar >= first && ebar < first + cnt) p_ebar[gg] = first + cnt;
         rep_shift(v0.ob_cnt[par], ro)[gg] = 0;                 // outbox consumed: nothing left for mp_round_replies
+    }
+    // (round 6) the group's tick is complete (nobody of it goes to mp_round_replies): my replica's handle_req_batch calls of the
+    // NEXT tick, exactly r1_body's store-only fast path -- slots len .. len + n - 1 Accepting with my self-ack, the regular outbox
+    // of the next parity (ob_reg / ob_rbal name slot and ballot, only the tokens are stored), the run of unstored ballots
+    // extended, accept_bar and log end + n -- with the four wavefronts taking every fourth batch.  r1_done tells that tick's R1.
+    const bool folded = closed && need == 0 && fold_n != 0;
+    if (folded) {
+        const int np = par ^ 1;
+        SMR_G uint32_t *const sv = rep_shift(v0.s_val, ro);
+        SMR_G uint32_t *const ov = rep_shift(v0.ob_val[np], ro);
+        const uint32_t m0 = SMR_ST_ACCEPTING | M_EXT | M_LBK | (VM_SAME << M_VMODE_SH) | (1u << (dl + M_ACKS_SH));
+#pragma unroll
+        for (int q = 0; q < NXQ; q++) {
+            const uint32_t k = w + 4u * (uint32_t)q;
+            if (k >= fold_n) break;
+            const size_t i = tix(P.W, (len + k) & Wm, g);
+            sv[i] = nxtok[q]; sm[i] = m0 | (nxtok[q] ? M_NONEMPTY : 0u);
+            ov[tix(P.cap, k, g)] = nxtok[q];
+        }
+        for (uint32_t k = w + 4u * NXQ; k < fold_n; k += 4) {    // (more than 32 batches per tick)
+            const uint32_t tok = nx.req_val[(size_t)k * G + gg];
+            const size_t i = tix(P.W, (len + k) & Wm, g);
+            sv[i] = tok; sm[i] = m0 | (tok ? M_NONEMPTY : 0u);
+            ov[tix(P.cap, k, g)] = tok;
+        }
+        if (w == 0) {
+            if (brun == 0xFFFFFFFFu || brun > len) rep_shift(v0.bal_lo, ro)[gg] = len;
+            rep_shift(v0.log_len, ro)[gg] = len + fold_n;
+            rep_shift(v0.accept_bar, ro)[gg] = len + fold_n;
+            rep_shift(v0.null_lb, ro)[gg] = len + fold_n;
+            rep_shift(v0.ob_cnt[np], ro)[gg] = fold_n;
+            rep_shift(v0.ob_reg[np], ro)[gg] = len + 1;
+            rep_shift(v0.ob_rbal[np], ro)[gg] = rep_shift(v0.ob_rbal[par], ro)[gg];   // = bal_prepared (answers_ok: every row committed)
+            P.r1_done[gg] = 1;
+        }
     }
     if (publish_hb && active) {                                 // leadership.rs:240-247 record, complete rounds only
         for (uint32_t d = w; d < R; d += 4) {                   // replicas dealt over the four wavefronts
@@ -1163,6 +1227,14 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
             }
         }
     }
+    if (__any(folded)) {                                         // counter 4: client batches appended here instead of in R1 (a performance figure)
+        for (uint32_t d = 0; d < R; d++) {
+            if (!__any(folded && dl == d)) continue;
+            unsigned int x = (folded && dl == d) ? fold_n : 0u;
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+            if (lane == 0 && x) ctr_add((unsigned long long *)P.rep[d].counters, 4, (unsigned long long)x);
+        }
+    }
     uint32_t nd = need;
     for (int off = 32; off > 0; off >>= 1) nd |= __shfl_xor(nd, off);
     if (lane == 0) {
@@ -1176,11 +1248,12 @@ __device__ __forceinline__ void quorum_tally_block(const MpParams &P, int par, c
 #endif
 template <int NR>
 __global__ __launch_bounds__(256, TALLY_MINW) void mp_quorum_tally(const MpParams *__restrict__ Pp, int par,
-                                                       const uint32_t *__restrict__ ackctl, int publish_hb, uint32_t hint) {
+                                                       const uint32_t *__restrict__ ackctl, int publish_hb, uint32_t hint,
+                                                       const MpNextLocal nx) {
     __shared__ uint8_t sh_fl[64 * 64];
     __shared__ uint32_t sh_mk[64 * 64];
     SMR_RAISE_PRIO();
-    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk, hint);
+    quorum_tally_block<NR>(*Pp, par, ackctl, publish_hb, sh_fl, sh_mk, hint, nx);
 }
 
 __device__ __forceinline__ void r3_body(const MpParams &P, int par, const uint32_t *__restrict__ ackctl, int publish_hb,
@@ -1948,6 +2021,9 @@ struct smr_mp_cluster {
     bool no_split_r2 = true;         // the split is OFF unless SMR_MP_SPLIT_R2 is in the environment at smr_mp_create: measured, it does not
                                      // pay (profiles/r8i: fast path alone 24.2 us + rest 4.9 us against 26.8 us for the one launch)
     bool split_r2 = false;           // smr_mp_run_ticks, the side stream busy: R2's bulk launch = fast path + rest (r2_body)
+    MpNextLocal next_local = MpNextLocal{nullptr, nullptr, nullptr, nullptr, 0u};   // smr_mp_run_ticks: the NEXT tick's client batches, for the tally launch of this one (round 6)
+    bool fold_r1 = false;            // SMR_MP_FOLD_R1 in the environment at smr_mp_create: the tally launch of tick t also runs the leaders' steady-state
+                                     // appends of tick t + 1 (built, tested both ways, off by default: a wash -- profiles/s18, s19)
     bool defer_rest = false;         // smr_mp_run_ticks: the next smr_mp_round_replies launches the tally only ...
     bool rest_pending = false;       // ... and the rest of that R3 rides in the next R1 launch (mp_rest_then_local)
     int rest_par = 0;
@@ -1985,6 +2061,7 @@ static void layout(smr_mp_cluster *c, bool dry) {
     carve(a, P.r3_need, R * ((G + 63) / 64), dry);
     carve(a, P.r2_need, R * ((G + 63) / 64), dry); carve(a, P.r2_res, R * G, dry);
     carve(a, P.slow, G, dry); carve(a, P.slow_ttl, G, dry); carve(a, P.role_rot, G, dry);
+    carve(a, P.r1_done, G, dry);
     carve(a, P.slow_list, (size_t)SLOW_CAP, dry); carve(a, P.slow_n, 2, dry);
     for (size_t r = 0; r < R; r++) {
         MpRep &v = P.rep[r];
@@ -2144,6 +2221,7 @@ int smr_mp_cluster_create(const smr_mp_cfg *cfg, smr_mp_cluster **out) {
     c->ttl = cfg->straggler_ticks == SMR_STRAGGLER_OFF ? 0u : cfg->straggler_ticks;
     c->no_split_r2 = getenv("SMR_MP_SPLIT_R2") == nullptr;
     c->always_defer = getenv("SMR_MP_ALWAYS_DEFER_REST") != nullptr;
+    c->fold_r1 = getenv("SMR_MP_FOLD_R1") != nullptr;
     if (c->ttl) {
         e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -2264,10 +2342,10 @@ int smr_mp_round_replies(smr_mp_cluster *c, const uint32_t *ackctl_dev, int publ
     if ((rc = prof_begin(c, 4, st, pt))) return rc;             // the quorum-tally kernel alone
     if (c->cfg.population <= 5)
         hipLaunchKernelGGL(mp_quorum_tally<5>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
-                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint);
+                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint, c->next_local);
     else
         hipLaunchKernelGGL(mp_quorum_tally<MAXR>, dim3((c->cfg.n_groups + 63) / 64), dim3(256), 0, st,
-                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint);
+                           c->dp, c->par, ackctl_dev, publish_heartbeat, c->lead_hint, c->next_local);
     SMR_HIP_TRY(hipGetLastError());
     if ((rc = prof_end(c, pt, st))) return rc;
     if (c->defer_rest && !publish_heartbeat) {                   // (smr_mp_run_ticks: the rest rides in the next tick's R1 launch)
@@ -2392,7 +2470,17 @@ int smr_mp_run_ticks(smr_mp_cluster *c, const smr_mp_tick_in *ticks, uint32_t n,
             // stream's blocks that costs R1 more than the launch saves: driver's command 0.0972 -> 0.0987 ms per tick, steady
             // 0.0568 -> 0.0542, profiles/r5p_rest_in_next_r1_ab.log)
             c->defer_rest = k + 1 < b.n && (quiet || c->always_defer);
+            // (round 6, SMR_MP_FOLD_R1) ... and the leaders' steady-state appends of tick k + 1 ride in the tally launch of tick k: a group
+            // the tally's closed form completes has nothing between the two but the heartbeat round, so not on a heartbeat tick.
+            // MEASURED (profiles/s18, s19): the appends cost what they cost wherever they run -- tally 17.9 -> 22.3 us, the R1 launch
+            // 12.4 -> 7.0 (steady), 24.2 -> 30.0 / 16.3 -> 10.4 beside the side launch: 0.0570 -> 0.0565 and 0.0892 -> 0.0895 ms per tick.
+            // R1 is bound by the 39 MB it moves, not by its launch or its one wavefront per SIMD.
+            if (k + 1 < b.n && !x.do_heartbeat && c->fold_r1 && ticks[i0 + k + 1].req_target_dev) {
+                const smr_mp_tick_in &y = ticks[i0 + k + 1];
+                c->next_local = MpNextLocal{y.timeout_rep_dev, y.req_target_dev, y.req_cnt_dev, y.req_val_dev, y.S};
+            }
             if (!rc) rc = smr_mp_round_replies(c, x.ackctl_dev, x.do_heartbeat ? 1 : 0, stream);
+            c->next_local = MpNextLocal{nullptr, nullptr, nullptr, nullptr, 0u};
             c->defer_rest = false;
             if (!rc && x.do_heartbeat) rc = smr_mp_round_heartbeat(c, stream);
             c->par ^= 1;
@@ -2729,6 +2817,15 @@ int smr_mp_debug_generic_units(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
     unsigned long long h[4];
     SMR_HIP_TRY(ctr_read((const unsigned long long *)c->hp.rep[rep].counters, 4, h));
     *out = h[3];
+    return SMR_OK;
+}
+
+int smr_mp_debug_folded_batches(smr_mp_cluster *c, uint8_t rep, uint64_t *out) {
+    if (!c || !out || rep >= c->cfg.population) return fail(SMR_ERR_ARG, "mp: bad argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[5];
+    SMR_HIP_TRY(ctr_read((const unsigned long long *)c->hp.rep[rep].counters, 5, h));
+    *out = h[4];
     return SMR_OK;
 }
 

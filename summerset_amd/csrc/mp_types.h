@@ -228,6 +228,9 @@ struct MpParams {
     // (y + role_rot[g]) mod R instead of replica y; role_rot[g] = the group's leader as the tick's mark pass found it, so row 0
     // runs every group's LEADER and rows 1 .. R - 1 its followers -- a wavefront then runs one role's code, whoever leads
     SMR_G uint8_t *role_rot;        // [G]
+    // round 6: mp_quorum_tally of tick t may already have run the leader's steady-state handle_req_batch calls of tick t + 1
+    // (MpNextLocal, smr_mp_run_ticks); r1_body of tick t + 1 then finds 1 here, skips that replica's batches and clears it
+    SMR_G uint8_t *r1_done;         // [G]
     uint32_t rot_on;
     uint32_t live;                  // bit r: replica r runs on this device (spread layout: the others are images, see mp_img_*)
     size_t rep_stride;              // bytes from an array of replica d to the same array of replica d + 1
@@ -242,6 +245,13 @@ struct MpTickIn {
     const uint32_t *req_cnt, *req_val, *ackctl;
     uint32_t S;
     int32_t heartbeat;
+};
+// The client batches of the NEXT tick, handed to mp_quorum_tally (round 6): a group whose tick the tally's closed form completes
+// gets its leader's steady-state appends of that tick in the same lanes (req_target == nullptr: none).
+struct MpNextLocal {
+    const uint8_t *timeout_rep, *req_target;
+    const uint32_t *req_cnt, *req_val;
+    uint32_t S;
 };
 constexpr uint32_t MP_FUSED_MAXT = 16;
 struct MpTickBatch {

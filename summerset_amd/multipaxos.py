@@ -160,6 +160,12 @@ class MultiPaxosCluster:
         check(self._L.smr_mp_debug_generic_units(self._h, rep, C.byref(n)))
         return int(n.value)
 
+    def debug_folded_batches(self, rep):
+        """client batches of `rep` that the previous tick's quorum-tally launch appended (`smr_mp_run_ticks`, round 6)"""
+        n = C.c_uint64()
+        check(self._L.smr_mp_debug_folded_batches(self._h, rep, C.byref(n)))
+        return int(n.value)
+
     def straggler_stats(self):
         """(capacity of the straggler list, groups the last mark pass wanted on it): more wanted than capacity = the list
         overflowed and the rest stayed with the bulk kernels (`smr_mp_straggler_stats`)"""

@@ -146,6 +146,14 @@ def test_multipaxos_kernels_on_the_host(sim, oracle):
         t._run_bench_shape("cpu", oracle, G=130, frac=0.25, span=8, n_ticks=20, straggler_ticks=4, every=4, fused=4)
         t.test_batches_and_single_ticks_share_the_list("cpu", oracle)
         t.run_rest_rides_in_next_r1("cpu", oracle, G=130, S=3, W=64, n_ticks=64, drop_p=0.3)   # mp_rest_then_local (round 4)
+        # round 6: the next tick's steady-state appends in the tally launch (MpNextLocal)
+        assert t.run_next_appends_ride_in_the_tally("cpu", oracle, G=130, S=32, W=512, n_ticks=18, frac=0.25) > 0
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=70, S=40, W=512, n_ticks=10, frac=0.1)
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=96, S=6, W=32, n_ticks=40, frac=0.1, H=12, win_reserve=2, expect_rejects=True)
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=70, S=3, W=64, n_ticks=24, frac=0.4, R=3, max_drop=1, batch=5, H=3)
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=70, S=3, W=64, n_ticks=24, frac=0.3, rotate=True, batch=16)
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=70, S=2, W=64, n_ticks=20, frac=0.2, R=7, max_drop=3)
+        t.run_next_appends_ride_in_the_tally("cpu", oracle, G=130, S=3, W=64, n_ticks=32, frac=0.2, drop_p=0.3, max_drop=None)
         # populations the device tests do not run (the 8-replica template instances of the tally and the reply kernels)
         t._run("cpu", oracle, G=100, R=7, S=2, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=4, preset=True)
         t._run("cpu", oracle, G=100, R=4, S=3, W=64, n_ticks=30, drop_p=0.1, timeout_frac=1.0, hb_every=3, preset=True)

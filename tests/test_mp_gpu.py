@@ -1,6 +1,8 @@
 """MultiPaxos lock-step parity: HIP engine (through the C-ABI) vs the CPU oracle
 on identical seeded streams, compared after EVERY tick on the full canonical
 state of all replicas (bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -399,6 +401,64 @@ def run_rest_rides_in_next_r1(cuda, oracle, G, S, W, n_ticks, drop_p):
     for r in range(R):
         assert eng.counters(r)["commits"] == orc.total_commits(r)
     assert (orc.dump(1)["leader"] != 0).any()
+
+
+def run_next_appends_ride_in_the_tally(cuda, oracle, G, S, W, n_ticks, frac, batch=8, H=4, R=5, win_reserve=None, straggler_ticks=4,
+                                       rotate=False, max_drop=2, drop_p=0.1, expect_rejects=False):
+    """`smr_mp_run_ticks` with the list on (round 6): the quorum-tally launch of tick t also runs the leader's steady-state
+    `handle_req_batch` calls of tick t + 1 for every group whose tick t its closed form completes (`MpNextLocal`,
+    `quorum_tally_block`), and that tick's R1 launch skips them (`r1_done`).  Quorum-preserving loss and no commit list, as in
+    bench.py, so that the closed form is the common case; leader changes (other replicas lead afterwards, batches addressed to
+    a deposed leader are redirected), heartbeat ticks (no fold across the heartbeat round), batch ends (the next batch's
+    inputs are not known) and, with a small window, back-pressure (the fold's window test fails and R1 refuses the batch).
+    Full state against the oracle at every batch end; the counter says that the path ran.  The engine only does it with
+    SMR_MP_FOLD_R1 in the environment (measured a wash, off by default): both ways here."""
+    from summerset_amd import MultiPaxosCluster, stream
+    cap = W + 4
+    wr = W // 8 if win_reserve is None else win_reserve
+    folded = {}
+    for no_fold in (False, True):
+        if not no_fold:
+            os.environ["SMR_MP_FOLD_R1"] = "1"
+        try:
+            eng = MultiPaxosCluster(G, R, W, win_reserve=wr, outbox_cap=cap, straggler_ticks=straggler_ticks)
+        finally:
+            os.environ.pop("SMR_MP_FOLD_R1", None)
+        if rotate:
+            eng.set_role_rotation(True)
+        orc = oracle.MpOracle(G, R, W, win_reserve=wr, cap=cap, record_commits=False)
+        eng.preset_leader(0); orc.preset_leader(0)
+        st = stream.MultiPaxosStream(G, R, S, cap=cap, n_ticks=n_ticks, drop_p=drop_p, timeout_frac=frac, hb_every=H,
+                                     rand_rows=S + 4, max_drop=max_drop, timeout_span=max(n_ticks // 2, 1))
+        pending = []
+        for t in range(n_ticks):
+            inp = st.tick(t)
+            orc.tick(**inp)
+            if not (inp["timeout_rep"] != 0xFF).any():
+                inp = dict(inp, timeout_rep=None, timeout_src=None)
+            pending.append(_to_dev(inp, cuda))
+            if len(pending) == batch or t == n_ticks - 1:
+                eng.run_ticks(pending)
+                pending = []
+                _compare(eng, orc, R, t)
+        for r in range(R):
+            assert eng.counters(r)["commits"] == orc.total_commits(r)
+        folded[no_fold] = sum(eng.debug_folded_batches(r) for r in range(R))
+        if expect_rejects:
+            assert sum(eng.counters(r)["rejects"] for r in range(R)) > 0
+    assert folded[False] > 0 and folded[True] == 0, folded
+    return folded[False]
+
+
+def test_next_ticks_appends_ride_in_the_tally(cuda, oracle):
+    n = run_next_appends_ride_in_the_tally(cuda, oracle, G=1024, S=32, W=512, n_ticks=40, frac=0.25)
+    assert n > 1024 * 32 * 10                                       # most groups, 6 of 8 ticks
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=300, S=40, W=512, n_ticks=24, frac=0.1)        # more batches than the tally prefetches
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=200, S=6, W=32, n_ticks=48, frac=0.1, H=12, win_reserve=2, expect_rejects=True)
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=257, S=4, W=64, n_ticks=40, frac=0.5, R=3, max_drop=1, batch=5, H=3)
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=130, S=3, W=64, n_ticks=36, frac=0.3, rotate=True, batch=16)
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=130, S=2, W=64, n_ticks=36, frac=0.2, R=7, max_drop=3)
+    run_next_appends_ride_in_the_tally(cuda, oracle, G=600, S=3, W=64, n_ticks=48, frac=0.2, drop_p=0.3, max_drop=None)   # uncapped loss: rows short of the quorum
 
 
 def test_batched_ticks_rest_rides_in_next_r1(cuda, oracle):
