@@ -76,6 +76,17 @@ def test_bincode_encode_decode(B):             # :390-403: a round trip in the r
     assert B.from_ones(5, [0, 3]).bincode() == bytes([5, 1, 9])
 
 
+def test_bincode_length_bits(B):               # :404-419: 24 bits, a round trip in the reference; here the bytes and the bits back
+    ones = [1, 5, 7, 12, 17, 23]
+    m = B(24, False)
+    for i in ones:
+        m.set(i, True)
+    word = sum(1 << i for i in ones)           # one 32-bit block: 0x008210A2
+    enc = m.bincode()                          # usize len 24 | one block | varint(u32 >= 2^16: 0xFC + 4 bytes LE)
+    assert enc == bytes([24, 1, 0xFC]) + word.to_bytes(4, "little")
+    assert m.size() == 24 and [m.get(i) for i in range(24)] == [i in ones for i in range(24)]
+
+
 def test_mask_convention_and_quorum_freeze(B):
     """bit i of the mask = id i; the accept-ack bitmap of handle_msg_accept_reply (multipaxos/messages.rs:404-412)
     freezes at exactly quorum_cnt bits in arrival order -- the same statement in Bitmap terms as the engine's tally"""
