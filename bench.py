@@ -727,7 +727,7 @@ def _payload_leg_traffic(name="rspaxos_payload"):
     """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or (None, None): the
     sum over every ps_* / craft_* kernel of (bytes per launch x launches per tick), launches per tick = the kernel's launches in
     the profiled run / the run's ticks (recorded in the file by tools/final_record.sh)."""
-    for f in ("r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
+    for f in ("t1z_pmc_traffic_%s_leg.json" % name, "r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
         if not f:
             continue
         try:
