@@ -261,111 +261,155 @@ __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint3
     ps_rebuild_from<D>(v, v.pl[0].bytes, row, g, c0, ((1u << v.n) - 1u) & ~dm, dm, in);     // compute_parity
 }
 
-// one lane per ring cell: what the engine says the cell holds against what the rows hold
+// what the engine says a ring cell holds against what the rows hold.  A lane takes RPL cells -- rows RPL q .. RPL q + RPL - 1 of one
+// group, lanes side by side in the group: every load of a wavefront is still one run of bytes -- and looks at all of them in ONE
+// round of loads (round 6: with a lane per cell the launch was four times the wavefronts, each waiting out its own round trip for
+// 20 bytes; a steady tick changes one row of W).  A cell where the two agree is done there; the others go through ps_plan_cell.
 // (sel: per group the ONE source a shard may come from -- the sender of the message the handler consumed -- or NULL: any)
+struct PsCellOut {
+    uint64_t src[2];
+    uint32_t rc, sl[2], mat;
+    bool work;
+};
+__device__ __forceinline__ PsCellOut ps_plan_cell(const PsView &v, const PsSrcs &S, const uint8_t *__restrict__ sel, uint32_t i, uint32_t g,
+                                                  const uint32_t (&w_tok)[2], const uint32_t (&w_mask)[2], const uint32_t (&h_tok)[2],
+                                                  const uint32_t (&h_mask)[2], uint32_t &n_copy, uint32_t &n_rebuilt, uint32_t &n_unsat,
+                                                  uint32_t &n_rekey) {
+    PsCellOut o;
+    o.src[0] = o.src[1] = PS_NO_SRC; o.rc = 0; o.sl[0] = o.sl[1] = 0; o.mat = 0;
+    uint32_t reqs_tok = PS_NULL, reqs_have = 0, reqs_len = 0;              // plane 0's new state: plane 1's "own other plane"
+    const uint32_t only = sel ? sel[g] : PS_NONE;
+    // A VOTED shard that equals the REQS row's -- same token, the shard present there -- is not stored twice: its bit in `alias`
+    // says "read it from the REQS row".  That is every vote of a steady tick (`inst.voted = (ballot, reqs_cw.clone())`,
+    // messages.rs:373-380; the leader's subset of its own codeword, request.rs:103-118), which made the second copy 38 % of the
+    // bytes this store moved per tick.  The two part ways in the Prepare phase (reqs_cw takes the highest vote reported,
+    // messages.rs:180-194, while my own vote stays): the shard is then moved into the VOTED row first (`mat`).
+    const bool can_alias = v.pl[1].alias != nullptr;
+    const uint32_t alias_old = can_alias ? v.pl[1].alias[i] : 0u;
+    uint32_t alias_new = 0;
+    for (int pl = 0; pl < 2; pl++) {
+        uint32_t want_tok = w_tok[pl], want = w_mask[pl];
+        const uint32_t had_tok = h_tok[pl], had = h_mask[pl], had_len = v.pl[pl].dlen[i];
+        uint32_t have = had, L = had_len;
+        if (had_tok != want_tok) {
+            if (have) n_rekey++;
+            have = 0; L = 0;
+        }
+        have &= want;                                                    // `inst.reqs_cw = reqs_cw`: shards the engine dropped
+        if (pl == 1) {
+            // aliases that go on: the REQS row still holds that token and that shard (it was not rewritten: a shard the row had
+            // and keeps is never in its `need`); the others the vote still has move out of the REQS row now
+            alias_new = reqs_tok == want_tok ? (alias_old & have & reqs_have) : 0u;
+            o.mat = alias_old & have & ~alias_new;
+        }
+        uint32_t need = want & ~have;
+        uint64_t sb = PS_NO_SRC;
+        if (need && want_tok == 0) {                                     // from_data(ReqBatch::new()): one zero byte
+            for (uint32_t m = need; m; m &= m - 1u) {
+                const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)PS_EMPTY << (8 * k));
+            }
+            have |= need; need = 0; L = 1;
+        }
+        // sources in order: the voted plane asks my own reqs plane FIRST (its new state is in registers: no load, and nothing is
+        // copied -- the shard becomes an alias); the reqs plane asks the named sources, then my own voted plane
+        for (uint32_t jj = 0; jj <= S.n && need; jj++) {
+            const uint32_t j = pl == 1 ? (jj == 0 ? S.n : jj - 1u) : jj;
+            uint32_t s_tok, s_av, s_len, code, s_al = 0;                 // s_al: the source's shards that are aliases there
+            if (j < S.n) {
+                if (!S.p[j].tok || (sel && only != j)) continue;
+                s_tok = S.p[j].tok[i]; s_av = S.p[j].avail[i]; s_len = S.p[j].dlen[i]; code = j;
+                s_al = S.p[j].alias ? S.p[j].alias[i] : 0u;
+            }
+            // (my voted row's aliased shards ARE the reqs row's: nothing to take there)
+            else if (pl == 0) { s_tok = v.pl[1].tok[i]; s_av = (uint32_t)v.pl[1].avail[i] & ~alias_old; s_len = v.pl[1].dlen[i]; code = PS_OWN; }
+            else { s_tok = reqs_tok; s_av = reqs_have; s_len = reqs_len; code = PS_OWN; }
+            const uint32_t take = (s_tok == want_tok) ? (need & s_av) : 0u;
+            if (!take) continue;
+            if (pl == 1 && code == PS_OWN && can_alias) alias_new |= take;
+            else
+                for (uint32_t m = take; m; m &= m - 1u) {
+                    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                    sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)(code | (((s_al >> k) & 1u) ? PS_VIA0 : 0u)) << (8 * k));
+                }
+            n_copy += (uint32_t)__popc(take);
+            L = s_len; need &= ~take; have |= take;
+        }
+        if (need && (uint32_t)__popc(have) >= v.d) {                     // reconstruct_data / compute_parity
+            o.rc |= (need | (have << 8)) << (16 * pl);
+            n_rebuilt += (uint32_t)__popc(need);
+            have |= need; need = 0;
+        }
+        n_unsat += (uint32_t)__popc(need);
+        // (only what changed: the steady tick touches one row of W, and 9 bytes x every cell x every call was ~19 MB of writes per
+        // follow_many at config 4's size -- ADVICE r4)
+        if (had_tok != want_tok) v.pl[pl].tok[i] = want_tok;
+        if (had != have) v.pl[pl].avail[i] = (uint8_t)have;
+        if (had_len != L) v.pl[pl].dlen[i] = L;
+        o.src[pl] = sb; o.sl[pl] = ps_shard_len(L, v.d);
+        if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
+    }
+    if (alias_new != alias_old) v.pl[1].alias[i] = (uint8_t)alias_new;
+    o.work = o.src[0] != PS_NO_SRC || o.src[1] != PS_NO_SRC || o.rc != 0 || o.mat != 0;
+    return o;
+}
+
+template <int RPL>
 __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, const RspPeek &e, const PsSrcs &S, const uint8_t *__restrict__ sel) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    const bool on = t < v.W * v.G;
-    const uint32_t i = on ? t : 0u;
-    uint64_t src[2] = {PS_NO_SRC, PS_NO_SRC};
-    uint32_t rc = 0, sl[2] = {0u, 0u};
+    const uint32_t nq = v.W / RPL;                                         // (RPL divides W: both powers of two, RPL <= W)
+    const bool on = t < nq * v.G;
+    const uint32_t q = on ? t / v.G : 0u, g = on ? t - q * v.G : 0u;
     uint32_t n_copy = 0, n_rebuilt = 0, n_unsat = 0, n_rekey = 0;
-    uint32_t reqs_tok = PS_NULL, reqs_have = 0, reqs_len = 0;              // plane 0's new state: plane 1's "own other plane"
-    uint32_t mat = 0;                                                      // VOTED shards whose alias ends with this call
     const uint32_t all = (1u << v.n) - 1u;
-    if (on) {
-        const uint32_t only = sel ? sel[i % v.G] : PS_NONE;
-        // A VOTED shard that equals the REQS row's -- same token, the shard present there -- is not stored twice: its bit in `alias`
-        // says "read it from the REQS row".  That is every vote of a steady tick (`inst.voted = (ballot, reqs_cw.clone())`,
-        // messages.rs:373-380; the leader's subset of its own codeword, request.rs:103-118), which made the second copy 38 % of the
-        // bytes this store moved per tick.  The two part ways in the Prepare phase (reqs_cw takes the highest vote reported,
-        // messages.rs:180-194, while my own vote stays): the shard is then moved into the VOTED row first (`mat`).
-        const bool can_alias = v.pl[1].alias != nullptr;
-        // what the engine says against what the rows hold, both planes; a cell where they agree -- every cell but the tick's row, in
-        // a steady tick -- is done here: its lengths, its alias bits and the sources' cells are not even read (38 -> 20 bytes per cell)
-        uint32_t w_tok[2], w_mask[2], h_tok[2], h_mask[2];
-        bool same = true;
-        for (int pl = 0; pl < 2; pl++) {
-            w_tok[pl] = e.c_len ? (pl == 0 ? craft_want_tok(e, i) : PS_NULL) : (pl == 0 ? e.s_val[i] : e.s_vval[i]);
-            w_mask[pl] = (pl == 0 ? e.s_mask[i] : e.s_vmask[i]) & all;
-            if (w_tok[pl] == PS_NULL) w_mask[pl] = 0;
-            if (w_mask[pl] == 0) w_tok[pl] = PS_NULL;
-            h_tok[pl] = v.pl[pl].tok[i]; h_mask[pl] = v.pl[pl].avail[i];
-            same = same && h_mask[pl] == w_mask[pl] && h_tok[pl] == w_tok[pl];
-        }
-        const uint32_t alias_old = (can_alias && !same) ? v.pl[1].alias[i] : 0u;
-        uint32_t alias_new = 0;
-        for (int pl = 0; pl < 2 && !same; pl++) {
-            uint32_t want_tok = w_tok[pl], want = w_mask[pl];
-            const uint32_t had_tok = h_tok[pl], had = h_mask[pl], had_len = v.pl[pl].dlen[i];
-            uint32_t have = had, L = had_len;
-            if (had_tok != want_tok) {
-                if (have) n_rekey++;
-                have = 0; L = 0;
-            }
-            have &= want;                                                    // `inst.reqs_cw = reqs_cw`: shards the engine dropped
-            if (pl == 1) {
-                // aliases that go on: the REQS row still holds that token and that shard (it was not rewritten: a shard the row had
-                // and keeps is never in its `need`); the others the vote still has move out of the REQS row now
-                alias_new = reqs_tok == want_tok ? (alias_old & have & reqs_have) : 0u;
-                mat = alias_old & have & ~alias_new;
-            }
-            uint32_t need = want & ~have;
-            uint64_t sb = PS_NO_SRC;
-            if (need && want_tok == 0) {                                     // from_data(ReqBatch::new()): one zero byte
-                for (uint32_t m = need; m; m &= m - 1u) {
-                    const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
-                    sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)PS_EMPTY << (8 * k));
-                }
-                have |= need; need = 0; L = 1;
-            }
-            // sources in order: the voted plane asks my own reqs plane FIRST (its new state is in registers: no load, and nothing is
-            // copied -- the shard becomes an alias); the reqs plane asks the named sources, then my own voted plane
-            for (uint32_t jj = 0; jj <= S.n && need; jj++) {
-                const uint32_t j = pl == 1 ? (jj == 0 ? S.n : jj - 1u) : jj;
-                uint32_t s_tok, s_av, s_len, code, s_al = 0;                 // s_al: the source's shards that are aliases there
-                if (j < S.n) {
-                    if (!S.p[j].tok || (sel && only != j)) continue;
-                    s_tok = S.p[j].tok[i]; s_av = S.p[j].avail[i]; s_len = S.p[j].dlen[i]; code = j;
-                    s_al = S.p[j].alias ? S.p[j].alias[i] : 0u;
-                }
-                // (my voted row's aliased shards ARE the reqs row's: nothing to take there)
-                else if (pl == 0) { s_tok = v.pl[1].tok[i]; s_av = (uint32_t)v.pl[1].avail[i] & ~alias_old; s_len = v.pl[1].dlen[i]; code = PS_OWN; }
-                else { s_tok = reqs_tok; s_av = reqs_have; s_len = reqs_len; code = PS_OWN; }
-                const uint32_t take = (s_tok == want_tok) ? (need & s_av) : 0u;
-                if (!take) continue;
-                if (pl == 1 && code == PS_OWN && can_alias) alias_new |= take;
-                else
-                    for (uint32_t m = take; m; m &= m - 1u) {
-                        const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
-                        sb = (sb & ~(0xFFull << (8 * k))) | ((uint64_t)(code | (((s_al >> k) & 1u) ? PS_VIA0 : 0u)) << (8 * k));
-                    }
-                n_copy += (uint32_t)__popc(take);
-                L = s_len; need &= ~take; have |= take;
-            }
-            if (need && (uint32_t)__popc(have) >= v.d) {                     // reconstruct_data / compute_parity
-                rc |= (need | (have << 8)) << (16 * pl);
-                n_rebuilt += (uint32_t)__popc(need);
-                have |= need; need = 0;
-            }
-            n_unsat += (uint32_t)__popc(need);
-            // (only what changed: the steady tick touches one row of W, and 9 bytes x every cell x every call was ~19 MB of writes per
-            // follow_many at config 4's size -- ADVICE r4)
-            if (had_tok != want_tok) v.pl[pl].tok[i] = want_tok;
-            if (had != have) v.pl[pl].avail[i] = (uint8_t)have;
-            if (had_len != L) v.pl[pl].dlen[i] = L;
-            src[pl] = sb; sl[pl] = ps_shard_len(L, v.d);
-            if (pl == 0) { reqs_tok = want_tok; reqs_have = have; reqs_len = L; }
-        }
-        if (!same && alias_new != alias_old) v.pl[1].alias[i] = (uint8_t)alias_new;
+    // ---- one round of loads: what the engine says against what the rows hold, both planes, RPL cells; a cell where they agree --
+    // every cell but the tick's row, in a steady tick -- is done here: its lengths, its alias bits and the sources' cells are not read
+    uint32_t w_tok[RPL][2], w_mask[RPL][2], h_tok[RPL][2], h_mask[RPL][2];
+    uint32_t c_len = 0, c_st = 0, c_rl = 0;
+    if (e.c_len) { c_len = e.c_len[g]; c_st = e.c_start[g]; c_rl = e.c_rlo[g]; }
+#pragma unroll
+    for (int k = 0; k < RPL; k++) {
+        const uint32_t row = q * RPL + (uint32_t)k, i = row * v.G + g;
+        if (e.c_len) {                                                    // a CRaft log: the token the (slot, term) of the cell implies
+            const uint32_t sl_ = craft_cell_slot(c_len, c_st, c_rl, e.W, row);
+            const uint64_t tm = e.c_term[i];
+            w_tok[k][0] = sl_ == PS_NULL ? PS_NULL : craft_token(sl_, tm);
+            w_tok[k][1] = PS_NULL;
+        } else { w_tok[k][0] = e.s_val[i]; w_tok[k][1] = e.s_vval[i]; }
+        w_mask[k][0] = e.s_mask[i]; w_mask[k][1] = e.s_vmask[i];
+        h_tok[k][0] = v.pl[0].tok[i]; h_tok[k][1] = v.pl[1].tok[i];
+        h_mask[k][0] = v.pl[0].avail[i]; h_mask[k][1] = v.pl[1].avail[i];
     }
-    const bool work = on && (src[0] != PS_NO_SRC || src[1] != PS_NO_SRC || rc != 0 || mat != 0);
-    const unsigned long long b = __ballot(work);
+    PsCellOut out[RPL];
+    uint32_t n_work = 0;
+#pragma unroll
+    for (int k = 0; k < RPL; k++) {
+        out[k].work = false;
+        bool same = true;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            w_mask[k][pl] &= all;
+            if (w_tok[k][pl] == PS_NULL) w_mask[k][pl] = 0;
+            if (w_mask[k][pl] == 0) w_tok[k][pl] = PS_NULL;
+            same = same && h_mask[k][pl] == w_mask[k][pl] && h_tok[k][pl] == w_tok[k][pl];
+        }
+        if (on && !same) {
+            const uint32_t i = (q * RPL + (uint32_t)k) * v.G + g;
+            out[k] = ps_plan_cell(v, S, sel, i, g, w_tok[k], w_mask[k], h_tok[k], h_mask[k], n_copy, n_rebuilt, n_unsat, n_rekey);
+            n_work += out[k].work ? 1u : 0u;
+        }
+    }
+    // ---- the cells with work onto the list: one append per BLOCK (the cells with work are neighbours -- a tick's row -- and ~15 ns
+    // per same-address atomic times one per wavefront was a fifth of this kernel: 9.6 -> 7.7 us, profiles/r7d)
     const uint32_t lane = __lane_id(), wv = threadIdx.x >> 6;
-    // one append per BLOCK: the cells with work are neighbours (a tick's row), and ~15 ns per same-address atomic times one per
-    // wavefront was a fifth of this kernel (9.6 -> 7.7 us, profiles/r7d)
     __shared__ uint32_t w_cnt[4], b_base;
-    if (lane == 0) w_cnt[wv] = (uint32_t)__popcll(b);
+    uint32_t incl = n_work;                                                // inclusive scan of n_work over the wavefront
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl((int)incl, (int)(lane >= d ? lane - d : lane));
+        if (lane >= d) incl += x;
+    }
+    if (lane == 63) w_cnt[wv] = incl;
     if (t == 0) v.it_n[flip ^ 1u] = 0;                                     // the next call's counter (this stream runs it after my byte kernel)
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -373,23 +417,33 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
         b_base = tot ? atomicAdd(&v.it_n[flip], tot) : 0u;
     }
     __syncthreads();
-    uint32_t base = b_base;
-    for (uint32_t k = 0; k < wv; k++) base += w_cnt[k];
-    if (work) {
-        const uint32_t o = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        v.it_cell[o] = i; v.it_src[0][o] = src[0]; v.it_src[1][o] = src[1]; v.it_rc[o] = rc; v.it_sl[0][o] = sl[0]; v.it_sl[1][o] = sl[1];
-        v.it_mat[o] = (uint8_t)mat;
+    if (n_work) {
+        uint32_t o = b_base + incl - n_work;
+        for (uint32_t k = 0; k < wv; k++) o += w_cnt[k];
+#pragma unroll
+        for (int k = 0; k < RPL; k++) {
+            if (!out[k].work) continue;
+            v.it_cell[o] = (q * RPL + (uint32_t)k) * v.G + g;
+            v.it_src[0][o] = out[k].src[0]; v.it_src[1][o] = out[k].src[1]; v.it_rc[o] = out[k].rc;
+            v.it_sl[0][o] = out[k].sl[0]; v.it_sl[1][o] = out[k].sl[1]; v.it_mat[o] = (uint8_t)out[k].mat;
+            o++;
+        }
     }
     uint32_t c[4] = {n_copy, n_rebuilt, n_unsat, n_rekey};
-    for (int k = 0; k < 4; k++) {
-        uint32_t x = c[k];
-        for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
-        if (lane == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
-    }
+    if (__any((c[0] | c[1] | c[2] | c[3]) != 0))
+        for (int k = 0; k < 4; k++) {
+            uint32_t x = c[k];
+            for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
+            if (lane == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
+        }
 }
 
+// rows per lane of a plan launch for a window of W rows (a power of two)
+static inline uint32_t ps_rpl(uint32_t W) { return W >= 4 ? 4u : W; }
+
+template <int RPL>
 __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
-    ps_plan_body(v, v.flip, e, S, sel);
+    ps_plan_body<RPL>(v, v.flip, e, S, sel);
 }
 // several replicas that consume ONE sender's message (an Accept goes to every follower): blockIdx.y = which of them.  Their views
 // are read from the device copies the stores keep (a by-value table of whole views, indexed by the block, went to scratch:
@@ -400,9 +454,10 @@ struct PsMany {
     RspPeek e[PS_MAX_N];
     uint32_t flips;
 };
+template <int RPL>
 __global__ __launch_bounds__(256) void ps_plan_many_kernel(const PsMany M, const PsSrcs S, const uint8_t *__restrict__ sel) {
     const PsView v = *M.v[blockIdx.y];             // a copy in registers: through the pointer every field is reloaded behind every store
-    ps_plan_body(v, (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, sel);
+    ps_plan_body<RPL>(v, (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, sel);
 }
 
 // a lane per (listed cell, 16-byte column), columns fastest, in a grid-stride loop over cells x columns: the lanes of a wavefront
@@ -849,7 +904,12 @@ static int ps_follow(smr_rsp_pstore *s, const RspPeek &pk, uint32_t n_src, smr_r
     hipStream_t st = (hipStream_t)stream;
     s->v.flip ^= 1u;                               // (calls on one store are issued on one stream at a time: the header says so)
     const uint32_t cells = v.W * v.G;
-    hipLaunchKernelGGL(ps_plan_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev);
+    const uint32_t lanes = cells / ps_rpl(v.W);
+    switch (ps_rpl(v.W)) {
+    case 4: hipLaunchKernelGGL(ps_plan_kernel<4>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
+    case 2: hipLaunchKernelGGL(ps_plan_kernel<2>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
+    default: hipLaunchKernelGGL(ps_plan_kernel<1>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
+    }
     SMR_HIP_TRY(hipGetLastError());
     uint64_t blocks = ((uint64_t)cells * (v.cap_sl / 16u) + 255) / 256;            // (an upper bound: the list's length is the device's)
     if (blocks > 4096) blocks = 4096;
@@ -934,7 +994,12 @@ static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPe
     }
     hipStream_t st = (hipStream_t)stream;
     const uint32_t cells = v0.W * v0.G;
-    hipLaunchKernelGGL(ps_plan_many_kernel, dim3((cells + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr);
+    const uint32_t lanes = cells / ps_rpl(v0.W);
+    switch (ps_rpl(v0.W)) {
+    case 4: hipLaunchKernelGGL(ps_plan_many_kernel<4>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
+    case 2: hipLaunchKernelGGL(ps_plan_many_kernel<2>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
+    default: hipLaunchKernelGGL(ps_plan_many_kernel<1>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
+    }
     SMR_HIP_TRY(hipGetLastError());
     uint64_t blocks = ((uint64_t)cells * (v0.cap_sl / 16u) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
