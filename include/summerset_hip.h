@@ -1007,6 +1007,18 @@ int smr_rsp_pstore_follow(smr_rsp_pstore *s, const smr_rsp_replica *e, uint32_t 
  * instead of two each.  src must not be one of the stores (nothing a store writes in this call is read by another). */
 int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
                                int src_plane, void *stream);
+/* A co-located leader's tick of the byte path as ONE call and four launches (round 6): smr_rsp_pstore_put(s, ..) +
+ * smr_rsp_pstore_follow(s, e, no sources) + smr_rsp_pstore_follow_many(n, stores, replicas, s, SMR_RSP_PLANE_REQS) -- the leader's
+ * from_data + compute_parity (rspaxos/request.rs:71-101), its vote (request.rs:103-118) and what its n <= 8 co-located followers'
+ * Accept handlers took of it (messages.rs:373-380) -- with the same cells, bytes and counters as the three calls (five launches):
+ * the leader's byte launch rides in the followers' plan launch, and the put launch writes the shards the followers' engines took of
+ * the new codewords into THEIR rows as well (`subset_copy` at the sender + `inst.reqs_cw = reqs_cw` at the receiver, request.rs:127-142,
+ * messages.rs:373-380, without reading the leader's row back; the followers' plan counts them as copied and lists nothing).  n = 0:
+ * the first two calls alone.  Call it AFTER the engines' handlers of the tick, as the three calls are. */
+int smr_rsp_pstore_put_follow_all(smr_rsp_pstore *s, const smr_rsp_replica *e, const uint32_t *a_n_dev, const uint32_t *a_slot_dev,
+                                  const uint32_t *a_val_dev, const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev,
+                                  uint32_t data_len, uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas,
+                                  void *stream);
 int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
                             uint8_t *out_dev, uint64_t out_stride, uint32_t *len_out_dev, uint8_t *ok_dev, void *stream);
 /* The payload of a message between replicas on DIFFERENT devices / hosts.  A message buffer is laid out like one row: shard k of
@@ -1034,6 +1046,9 @@ int smr_rsp_pstore_layout(const smr_rsp_pstore *s, int plane, void **bytes_dev, 
                           uint64_t *group_stride);
 int smr_rsp_pstore_voted_alias(const smr_rsp_pstore *s, const uint8_t **alias_dev, uint8_t *alias_host);   /* either may be NULL */
 int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host);
+/* of `copied`: the shards a sender's put launch wrote straight into this store (smr_*_pstore_put_follow_all, below: a follower's
+ * steady-tick copy out of the leader's row is done by the launch that has the leader's bytes in registers); 0 with SMR_PS_DELIVER=0 */
+int smr_rsp_pstore_debug_delivered(smr_rsp_pstore *s, uint64_t *out_host);
 
 /* CRaft: the same store keyed by LOG INDEX -- the shard bytes of `LogEntry::reqs_cw` (/root/reference/src/protocols/craft/mod.rs:129-150)
  * behind a CRaft replica (smr_raft_leader with smr_raft_craft_enable: leader or follower).  The engine keeps an entry's codeword as
@@ -1064,6 +1079,12 @@ int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_
  * the single source src (may be NULL; none of the stores) -- three launches for all of them instead of three each */
 int smr_craft_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_raft_leader *const *replicas, const smr_rsp_pstore *src,
                                  void *stream);
+/* smr_craft_pstore_put(s, e, ..) + smr_craft_pstore_follow(s, e, no sources) + smr_craft_pstore_follow_many(n, stores, replicas, s)
+ * in four launches, as smr_rsp_pstore_put_follow_all: call it after the leader's append AND the followers' AppendEntries handlers
+ * (craft/request.rs:71-100, craft/messages.rs:133-146) -- the entries' terms and masks are the engines' */
+int smr_craft_pstore_put_follow_all(smr_rsp_pstore *s, const smr_raft_leader *e, const uint32_t *slot_dev, const uint8_t *data_dev,
+                                    uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, uint32_t n,
+                                    smr_rsp_pstore *const *stores, const smr_raft_leader *const *replicas, void *stream);
 
 /* ------------------------------------------------------------------------
  * RepNothing (BASELINE config 1) + the KV state machine: host-only plumbing

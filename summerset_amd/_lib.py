@@ -345,6 +345,7 @@ SYMBOLS = [
     ("smr_rsp_pstore_put", _i, [_vp, _vp, _vp, _vp, _vp, _u64, _vp, _u32, _vp]),
     ("smr_rsp_pstore_follow", _i, [_vp, _vp, _u32, C.POINTER(_vp), _vp, _vp, _vp]),
     ("smr_rsp_pstore_follow_many", _i, [_u32, C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp]),
+    ("smr_rsp_pstore_put_follow_all", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _u32, _u32, C.POINTER(_vp), C.POINTER(_vp), _vp]),
     ("smr_rsp_pstore_get_data", _i, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp]),
     ("smr_rsp_pstore_extract", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_rsp_pstore_ingest", _i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -354,10 +355,12 @@ SYMBOLS = [
     ("smr_rsp_pstore_layout", _i, [_vp, _i, C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     ("smr_rsp_pstore_voted_alias", _i, [_vp, C.POINTER(_vp), _vp]),
     ("smr_rsp_pstore_counters", _i, [_vp, _vp]),
+    ("smr_rsp_pstore_debug_delivered", _i, [_vp, _vp]),
     ("smr_craft_pstore_create", _i, [_u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     ("smr_craft_pstore_put", _i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _vp]),
     ("smr_craft_pstore_follow", _i, [_vp, _vp, _u32, _vp, _vp, _vp]),
     ("smr_craft_pstore_follow_many", _i, [_u32, _vp, _vp, _vp, _vp]),
+    ("smr_craft_pstore_put_follow_all", _i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _u32, _vp, _vp, _vp]),
     ("smr_wire_reqbatch", C.c_int64, [C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     ("smr_wire_prepare", C.c_int64, [_u64, _u64, _vp, _u64]),
     ("smr_wire_prepare_reply", C.c_int64, [_u64, _u64, _u64, _u64, _i, _u64, _vp, _u64, _u64, _vp, _u64]),

@@ -24,6 +24,7 @@
 // list, one wavefront per cell, a lane per 16-byte column: copies are 16-byte loads / stores, rebuilds a per-lane
 // coefficient x 16-byte GF(2^8) multiply-accumulate (bit-sliced xtime on 4 packed bytes per VGPR, poly 0x11D) against
 // a 256-pattern table of (all shards from the first d present) matrices.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -62,7 +63,10 @@ struct PsView {
     uint32_t *it_rc;
     uint8_t *it_mat;       // VOTED shards to move out of the REQS row (their alias ends) before anything else touches the cell
     uint32_t *it_sl[2];
-    unsigned long long *counters;   // 0 shards copied, 1 shards rebuilt, 2 shards the engine has and nobody could give, 3 rows re-keyed
+    unsigned long long *counters;   // 0 shards copied, 1 shards rebuilt, 2 shards the engine has and nobody could give, 3 rows re-keyed,
+                                    // 4 of the copied: written by the sender's put launch (dlv)
+    uint8_t *dlv;          // [W][G] REQS shards whose bytes the sender's put launch has written into this store's row already (ps_put_deliver_kernel):
+                           // the plan of the same call counts them as copied and lists no copy for them; zero between calls
 };
 constexpr uint32_t PS_VIA0 = 0x40;  // a source code's flag: the shard is an alias in that source -- read it from the source STORE's reqs plane
 struct PsSrcs {
@@ -103,9 +107,8 @@ __device__ __forceinline__ uint32_t ps_xtime4(uint32_t x) {               // 4 p
 // per-lane values (a lane's own erasure pattern); in ps_put_kernel they are wave-uniform and the plane tests scalar.
 // (in[c] = the 16 columns of the c-th present shard of `pat`, already in registers: put has just loaded them from the batch --
 // reading them back from the row it stored them to put a store -> load round trip in front of the parity: 60 -> 46 us, profiles/r7d)
-template <int D>
-__device__ __forceinline__ void ps_rebuild_from(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
-                                                uint32_t pat, const ps_u32x4 (&in)[D]) {
+template <int D, typename F>
+__device__ __forceinline__ void ps_rebuild_emit(const PsView &v, uint32_t need, uint32_t pat, const ps_u32x4 (&in)[D], F emit) {
     const uint8_t *m = v.mat + (size_t)pat * 64;
 #pragma unroll
     for (int r = 0; r < (int)PS_MAX_N; r++) {
@@ -120,8 +123,13 @@ __device__ __forceinline__ void ps_rebuild_from(const PsView &v, uint8_t *base, 
             for (int c = 0; c < D; c++)
                 if ((co[c] >> b) & 1u) acc ^= in[c];
         }
-        ps_store16(base + ps_off(v, row, (uint32_t)r, g) + c0, acc);
+        emit((uint32_t)r, acc);
     }
+}
+template <int D>
+__device__ __forceinline__ void ps_rebuild_from(const PsView &v, uint8_t *base, uint32_t row, uint32_t g, uint32_t c0, uint32_t need,
+                                                uint32_t pat, const ps_u32x4 (&in)[D]) {
+    ps_rebuild_emit<D>(v, need, pat, in, [&](uint32_t r, ps_u32x4 acc) { ps_store16(base + ps_off(v, row, r, g) + c0, acc); });
 }
 // the same product with nothing held across rows: per output row a walk over the d inputs (re-read, they are this lane's own
 // cache lines by now), one bit-serial multiply-accumulate per coefficient.  For the byte kernel, whose common path is plain copies:
@@ -218,47 +226,181 @@ __device__ __forceinline__ void ps_drop_aliased(const PsView &v, size_t i) {
 // request.rs:71-101: one lane per (group, 16-byte column) of the tick's batches; D = the number of data shards
 // (CRAFT: the entry a CRaft leader appended at a_slot[g] -- PS_NULL: none -- where its log holds that slot; the token is the
 // entry's, a_n / a_val are not read)
+// what group g puts this tick, if anything: the token, the ring row, the batch's length
+template <bool CRAFT>
+__device__ __forceinline__ bool ps_put_what(const PsView &v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
+                                            const uint32_t *__restrict__ a_val, const uint32_t *__restrict__ len, uint32_t data_len, const RaftPeek &cr,
+                                            uint32_t g, uint32_t &tok, uint32_t &row, uint32_t &L) {
+    const uint32_t sl_ = a_slot[g];
+    if (CRAFT) {
+        if (sl_ == PS_NULL || sl_ == 0u || craft_cell_slot(cr, sl_ & v.Wmask, g) != sl_) return false;   // (the log does not hold that slot)
+        tok = craft_token(sl_, cr.entry_term[(size_t)(sl_ & v.Wmask) * v.G + g]);
+    } else {
+        if (a_n[g] == 0) return false;
+        tok = a_val[g];
+    }
+    row = sl_ & v.Wmask;
+    L = len ? len[g] : data_len;
+    if (L > data_len) L = data_len;
+    return true;
+}
+
+// ---- round 6: the put launch writes the FOLLOWERS' shards too (smr_*_pstore_put_follow_all) --------------------------------------
+// In a steady tick a follower's follow copies ONE thing: the shards of the leader's new codeword its engine has just accepted, out of
+// the leader's REQS row into its own -- bytes the put launch holds in registers a few microseconds earlier (90 MB read back and 90 MB
+// written by ps_bytes_many_kernel at config 4's size, 48 us).  ps_put_deliver_kernel decides per (group, follower) which shards that
+// copy WILL be -- ps_deliver_mask: exactly the `take` ps_plan_cell computes for plane 0 from source 0, the leader's row as the
+// leader's own follow leaves it -- stores them beside the leader's, and leaves the mask in the follower's `dlv` array; the follower's plan
+// (same call, next launch) does everything it always does -- headers, aliases, counters, the list -- except listing those copies.
+// Everything else a follow can mean (rebuilds, other sources, votes that part from the reqs row) stays with the plan / byte kernels.
+struct PsHdrs {                        // a follower store's REQS / VOTED headers
+    const uint32_t *tok0, *tok1;
+    const uint8_t *av0, *av1, *alias;  // (alias: NULL for a one-plane store)
+    uint8_t *dlv, *b0;                 // its delivered-shards array, its REQS plane's bytes
+};
+struct PsDeliver {
+    uint32_t n, all;                   // followers; (1 << shards) - 1
+    PsHdrs h[PS_MAX_N];
+    RspPeek e[PS_MAX_N];               // the followers' engines
+    RspPeek lead;                      // the leader's: what its own follow leaves of the row just put
+};
+// what the engine behind `e` wants in cell (row, g), both planes, in the plan's normal form (a plane that wants nothing wants the
+// null token)
+__device__ __forceinline__ void ps_cell_want(const RspPeek &e, uint32_t G, uint32_t all, uint32_t row, uint32_t g, uint32_t c_len, uint32_t c_st,
+                                             uint32_t c_rl, uint32_t (&w_tok)[2], uint32_t (&w_mask)[2]) {
+    const uint32_t i = row * G + g;
+    if (e.c_len) {                                                        // a CRaft log: the token the (slot, term) of the cell implies
+        const uint32_t sl_ = craft_cell_slot(c_len, c_st, c_rl, e.W, row);
+        const uint64_t tm = e.c_term[i];
+        w_tok[0] = sl_ == PS_NULL ? PS_NULL : craft_token(sl_, tm);
+        w_tok[1] = PS_NULL;
+    } else { w_tok[0] = e.s_val[i]; w_tok[1] = e.s_vval[i]; }
+    w_mask[0] = e.s_mask[i]; w_mask[1] = e.s_vmask[i];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        w_mask[pl] &= all;
+        if (w_tok[pl] == PS_NULL) w_mask[pl] = 0;
+        if (w_mask[pl] == 0) w_tok[pl] = PS_NULL;
+    }
+}
+__device__ __forceinline__ uint32_t ps_deliver_mask(const PsHdrs &h, const RspPeek &fe, const RspPeek &le, uint32_t G, uint32_t all, uint32_t row,
+                                                    uint32_t g, uint32_t tok) {
+    if (tok == 0u || tok == PS_NULL) return 0u;                           // (the empty batch is synthesised, not copied)
+    const uint32_t i = row * G + g;
+    uint32_t lw_tok[2], lw_mask[2], w_tok[2], w_mask[2];
+    uint32_t lc_len = 0, lc_st = 0, lc_rl = 0, c_len = 0, c_st = 0, c_rl = 0;
+    if (le.c_len) { lc_len = le.c_len[g]; lc_st = le.c_start[g]; lc_rl = le.c_rlo[g]; }
+    if (fe.c_len) { c_len = fe.c_len[g]; c_st = fe.c_start[g]; c_rl = fe.c_rlo[g]; }
+    ps_cell_want(le, G, all, row, g, lc_len, lc_st, lc_rl, lw_tok, lw_mask);
+    ps_cell_want(fe, G, all, row, g, c_len, c_st, c_rl, w_tok, w_mask);
+    const uint32_t h_tok0 = h.tok0[i], h_tok1 = h.tok1[i], h_av0 = h.av0[i], h_av1 = h.av1[i];
+    const uint32_t al = h.alias ? h.alias[i] : 0u;
+    // the leader's own follow (between the put and the followers' plan): the row keeps the shards its engine wants of THIS token
+    if (lw_tok[0] != tok || w_tok[0] != tok) return 0u;
+    const uint32_t have0 = h_tok0 == tok ? (h_av0 & w_mask[0]) : 0u;
+    const uint32_t take = w_mask[0] & ~have0 & lw_mask[0];
+    // a vote that lives in this REQS row and outlives the row's token moves out FIRST (ps_plan_cell's `mat`): the byte kernel's business
+    const uint32_t have1 = h_tok1 == w_tok[1] ? (h_av1 & w_mask[1]) : 0u;
+    if ((al & have1) && h_tok0 != tok) return 0u;
+    return take;
+}
+
+// (two halves around the deliver kernel's barrier: the batch's bytes are on their way while the masks are decided)
+template <int D>
+struct PsPutLane {
+    uint32_t g, blk, tok, row, L, sl, c0;
+    bool put, bytes;                   // the group puts this tick; this lane has a column of its shards
+    ps_u32x4 in[D];
+};
+template <int D, bool CRAFT>
+__device__ __forceinline__ void ps_put_load(PsPutLane<D> &p, const PsView &v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
+                                            const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
+                                            const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk, const RaftPeek &cr) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    ps_divmod(t, nblk, p.g, p.blk);
+    p.put = p.bytes = false;
+    p.tok = PS_NULL; p.row = p.L = p.sl = 0; p.c0 = p.blk * 16u;
+    if (p.g >= v.G) return;
+    p.put = ps_put_what<CRAFT>(v, a_n, a_slot, a_val, len, data_len, cr, p.g, p.tok, p.row, p.L);
+    if (!p.put) return;
+    p.sl = ps_shard_len(p.L, (uint32_t)D);
+    p.bytes = p.c0 < p.sl;
+    if (!p.bytes) return;
+    const uint8_t *src = data + (size_t)p.g * data_stride;
+    const uint64_t room = (uint64_t)(v.G - 1u - p.g) * data_stride + data_len;   // readable bytes from this batch's start
+#pragma unroll
+    for (int c = 0; c < D; c++) {
+        const uint32_t end = ((uint32_t)c + 1u) * p.sl;
+        p.in[c] = ps_load_data16(src, (uint32_t)c * p.sl + p.c0, end < p.L ? end : p.L, room);
+    }
+}
+template <int D, bool DELIVER>
+__device__ __forceinline__ void ps_put_store(const PsPutLane<D> &p, const PsView &v, const PsDeliver *dv, const uint8_t *sh_dm, uint32_t g_first) {
+    if (!p.put) return;
+    const uint32_t g = p.g, row = p.row, c0 = p.c0;
+    if (p.blk == 0) {
+        const size_t i = (size_t)row * v.G + g;
+        ps_drop_aliased(v, i);
+        v.pl[0].tok[i] = p.tok;
+        v.pl[0].avail[i] = (uint8_t)((1u << v.n) - 1u);
+        v.pl[0].dlen[i] = p.L;
+    }
+    if (!p.bytes) return;
+    uint32_t dm[PS_MAX_N];                                                 // per follower: the shards to write there as well
+    if (DELIVER) {
+#pragma unroll
+        for (int k = 0; k < (int)PS_MAX_N; k++) dm[k] = (uint32_t)k < dv->n ? sh_dm[(g - g_first) * PS_MAX_N + (uint32_t)k] : 0u;
+    }
+    auto emit = [&](uint32_t r, ps_u32x4 x) {
+        const size_t o = ps_off(v, row, r, g) + c0;
+        ps_store16(v.pl[0].bytes + o, x);
+        if (DELIVER) {
+#pragma unroll
+            for (int k = 0; k < (int)PS_MAX_N; k++)
+                if ((dm[k] >> r) & 1u) ps_store16(dv->h[k].b0 + o, x);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < D; c++) emit((uint32_t)c, p.in[c]);
+    const uint32_t dmask = (1u << D) - 1u;
+    ps_rebuild_emit<D>(v, ((1u << v.n) - 1u) & ~dmask, dmask, p.in, emit);  // compute_parity
+}
 template <int D, bool CRAFT>
 __global__ __launch_bounds__(256) void ps_put_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
                                                      const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data, uint64_t data_stride,
                                                      const uint32_t *__restrict__ len, uint32_t data_len, uint32_t nblk, const RaftPeek cr) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t g, blk;
-    ps_divmod(t, nblk, g, blk);
-    if (g >= v.G) return;
-    uint32_t tok;
-    if (CRAFT) {
-        const uint32_t sl_ = a_slot[g];
-        if (sl_ == PS_NULL || sl_ == 0u || craft_cell_slot(cr, sl_ & v.Wmask, g) != sl_) return;   // (the log does not hold that slot)
-        tok = craft_token(sl_, cr.entry_term[(size_t)(sl_ & v.Wmask) * v.G + g]);
-    } else {
-        if (a_n[g] == 0) return;
-        tok = a_val[g];
-    }
-    const uint32_t row = a_slot[g] & v.Wmask;
-    uint32_t L = len ? len[g] : data_len;
-    if (L > data_len) L = data_len;
-    const uint32_t sl = ps_shard_len(L, (uint32_t)D), c0 = blk * 16u;
-    if (blk == 0) {
-        const size_t i = (size_t)row * v.G + g;
-        ps_drop_aliased(v, i);
-        v.pl[0].tok[i] = tok;
-        v.pl[0].avail[i] = (uint8_t)((1u << v.n) - 1u);
-        v.pl[0].dlen[i] = L;
-    }
-    if (c0 >= sl) return;
-    const uint8_t *src = data + (size_t)g * data_stride;
-    const uint64_t room = (uint64_t)(v.G - 1u - g) * data_stride + data_len;   // readable bytes from this batch's start
-    ps_u32x4 in[D];
+    PsPutLane<D> p;
+    ps_put_load<D, CRAFT>(p, v, a_n, a_slot, a_val, data, data_stride, len, data_len, nblk, cr);
+    ps_put_store<D, false>(p, v, nullptr, nullptr, 0u);
+}
+// thread j of a block decides for the j-th group the block's lanes belong to (a block's 256 lanes cover 256 / nblk + 1 groups at
+// most -- four at config 4's size) and for every follower; the masks go through LDS to the group's lanes
+template <int D, bool CRAFT>
+__global__ __launch_bounds__(256) void ps_put_deliver_kernel(const PsView v, const uint32_t *__restrict__ a_n, const uint32_t *__restrict__ a_slot,
+                                                             const uint32_t *__restrict__ a_val, const uint8_t *__restrict__ data,
+                                                             uint64_t data_stride, const uint32_t *__restrict__ len, uint32_t data_len,
+                                                             uint32_t nblk, const RaftPeek cr, const PsDeliver dv) {
+    __shared__ uint8_t sh_dm[256 * PS_MAX_N];
+    PsPutLane<D> p;
+    ps_put_load<D, CRAFT>(p, v, a_n, a_slot, a_val, data, data_stride, len, data_len, nblk, cr);
+    const uint64_t t0 = (uint64_t)blockIdx.x * 256;
+    uint32_t g_first, g_last, rem;
+    ps_divmod(t0, nblk, g_first, rem);
+    ps_divmod(t0 + 255u, nblk, g_last, rem);
+    const uint32_t gg = g_first + threadIdx.x;
+    if (gg <= g_last && gg < v.G) {
+        uint32_t tok = PS_NULL, row = 0, L = 0;
+        const bool put = ps_put_what<CRAFT>(v, a_n, a_slot, a_val, len, data_len, cr, gg, tok, row, L);
 #pragma unroll
-    for (int c = 0; c < D; c++) {
-        const uint32_t end = ((uint32_t)c + 1u) * sl;
-        in[c] = ps_load_data16(src, (uint32_t)c * sl + c0, end < L ? end : L, room);
+        for (int k = 0; k < (int)PS_MAX_N; k++) {
+            if ((uint32_t)k >= dv.n) break;
+            const uint32_t m = put ? ps_deliver_mask(dv.h[k], dv.e[k], dv.lead, v.G, dv.all, row, gg, tok) : 0u;
+            sh_dm[threadIdx.x * PS_MAX_N + (uint32_t)k] = (uint8_t)m;
+            if (m) dv.h[k].dlv[row * v.G + gg] = (uint8_t)m;                // (a group that straddles two blocks: both write the same value)
+        }
     }
-#pragma unroll
-    for (int c = 0; c < D; c++) ps_store16(v.pl[0].bytes + ps_off(v, row, (uint32_t)c, g) + c0, in[c]);
-    const uint32_t dm = (1u << D) - 1u;
-    ps_rebuild_from<D>(v, v.pl[0].bytes, row, g, c0, ((1u << v.n) - 1u) & ~dm, dm, in);     // compute_parity
+    __syncthreads();
+    ps_put_store<D, true>(p, v, &dv, sh_dm, g_first);
 }
 
 // what the engine says a ring cell holds against what the rows hold.  A lane takes RPL cells -- rows RPL q .. RPL q + RPL - 1 of one
@@ -274,7 +416,7 @@ struct PsCellOut {
 __device__ __forceinline__ PsCellOut ps_plan_cell(const PsView &v, const PsSrcs &S, const uint8_t *__restrict__ sel, uint32_t i, uint32_t g,
                                                   const uint32_t (&w_tok)[2], const uint32_t (&w_mask)[2], const uint32_t (&h_tok)[2],
                                                   const uint32_t (&h_mask)[2], uint32_t &n_copy, uint32_t &n_rebuilt, uint32_t &n_unsat,
-                                                  uint32_t &n_rekey) {
+                                                  uint32_t &n_rekey, uint32_t &n_dlv) {
     PsCellOut o;
     o.src[0] = o.src[1] = PS_NO_SRC; o.rc = 0; o.sl[0] = o.sl[1] = 0; o.mat = 0;
     uint32_t reqs_tok = PS_NULL, reqs_have = 0, reqs_len = 0;              // plane 0's new state: plane 1's "own other plane"
@@ -335,6 +477,14 @@ __device__ __forceinline__ PsCellOut ps_plan_cell(const PsView &v, const PsSrcs 
             n_copy += (uint32_t)__popc(take);
             L = s_len; need &= ~take; have |= take;
         }
+        if (pl == 0 && v.dlv) {                                          // shards the sender's put launch has written here already (ps_put_deliver_kernel)
+            const uint32_t dl = v.dlv[i];
+            if (dl) {
+                v.dlv[i] = 0;
+                n_dlv += (uint32_t)__popc(dl);
+                for (uint32_t m = dl; m; m &= m - 1u) sb |= 0xFFull << (8 * ((uint32_t)__ffs((int)m) - 1u));
+            }
+        }
         if (need && (uint32_t)__popc(have) >= v.d) {                     // reconstruct_data / compute_parity
             o.rc |= (need | (have << 8)) << (16 * pl);
             n_rebuilt += (uint32_t)__popc(need);
@@ -354,48 +504,43 @@ __device__ __forceinline__ PsCellOut ps_plan_cell(const PsView &v, const PsSrcs 
     return o;
 }
 
+// cell (row, g): what the engine wants in the two planes and what the rows hold; `same`: the cell is done
+__device__ __forceinline__ bool ps_cell_state(const PsView &v, const RspPeek &e, uint32_t row, uint32_t g, uint32_t c_len, uint32_t c_st, uint32_t c_rl,
+                                              uint32_t (&w_tok)[2], uint32_t (&w_mask)[2], uint32_t (&h_tok)[2], uint32_t (&h_mask)[2]) {
+    const uint32_t i = row * v.G + g;
+    ps_cell_want(e, v.G, (1u << v.n) - 1u, row, g, c_len, c_st, c_rl, w_tok, w_mask);
+    h_tok[0] = v.pl[0].tok[i]; h_tok[1] = v.pl[1].tok[i];
+    h_mask[0] = v.pl[0].avail[i]; h_mask[1] = v.pl[1].avail[i];
+    return h_mask[0] == w_mask[0] && h_tok[0] == w_tok[0] && h_mask[1] == w_mask[1] && h_tok[1] == w_tok[1];
+}
+
 template <int RPL>
-__device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, const RspPeek &e, const PsSrcs &S, const uint8_t *__restrict__ sel) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, const RspPeek &e, const PsSrcs &S, const uint8_t *__restrict__ sel,
+                                             uint32_t bx) {
+    const uint32_t t = bx * 256 + threadIdx.x;
     const uint32_t nq = v.W / RPL;                                         // (RPL divides W: both powers of two, RPL <= W)
     const bool on = t < nq * v.G;
     const uint32_t q = on ? t / v.G : 0u, g = on ? t - q * v.G : 0u;
-    uint32_t n_copy = 0, n_rebuilt = 0, n_unsat = 0, n_rekey = 0;
-    const uint32_t all = (1u << v.n) - 1u;
+    uint32_t n_copy = 0, n_rebuilt = 0, n_unsat = 0, n_rekey = 0, n_dlv = 0;
     // ---- one round of loads: what the engine says against what the rows hold, both planes, RPL cells; a cell where they agree --
     // every cell but the tick's row, in a steady tick -- is done here: its lengths, its alias bits and the sources' cells are not read
     uint32_t w_tok[RPL][2], w_mask[RPL][2], h_tok[RPL][2], h_mask[RPL][2];
+    bool same[RPL];
     uint32_t c_len = 0, c_st = 0, c_rl = 0;
     if (e.c_len) { c_len = e.c_len[g]; c_st = e.c_start[g]; c_rl = e.c_rlo[g]; }
 #pragma unroll
     for (int k = 0; k < RPL; k++) {
-        const uint32_t row = q * RPL + (uint32_t)k, i = row * v.G + g;
-        if (e.c_len) {                                                    // a CRaft log: the token the (slot, term) of the cell implies
-            const uint32_t sl_ = craft_cell_slot(c_len, c_st, c_rl, e.W, row);
-            const uint64_t tm = e.c_term[i];
-            w_tok[k][0] = sl_ == PS_NULL ? PS_NULL : craft_token(sl_, tm);
-            w_tok[k][1] = PS_NULL;
-        } else { w_tok[k][0] = e.s_val[i]; w_tok[k][1] = e.s_vval[i]; }
-        w_mask[k][0] = e.s_mask[i]; w_mask[k][1] = e.s_vmask[i];
-        h_tok[k][0] = v.pl[0].tok[i]; h_tok[k][1] = v.pl[1].tok[i];
-        h_mask[k][0] = v.pl[0].avail[i]; h_mask[k][1] = v.pl[1].avail[i];
+        const uint32_t row = q * RPL + (uint32_t)k;
+        same[k] = ps_cell_state(v, e, row, g, c_len, c_st, c_rl, w_tok[k], w_mask[k], h_tok[k], h_mask[k]);
     }
     PsCellOut out[RPL];
     uint32_t n_work = 0;
 #pragma unroll
     for (int k = 0; k < RPL; k++) {
         out[k].work = false;
-        bool same = true;
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-            w_mask[k][pl] &= all;
-            if (w_tok[k][pl] == PS_NULL) w_mask[k][pl] = 0;
-            if (w_mask[k][pl] == 0) w_tok[k][pl] = PS_NULL;
-            same = same && h_mask[k][pl] == w_mask[k][pl] && h_tok[k][pl] == w_tok[k][pl];
-        }
-        if (on && !same) {
+        if (on && !same[k]) {
             const uint32_t i = (q * RPL + (uint32_t)k) * v.G + g;
-            out[k] = ps_plan_cell(v, S, sel, i, g, w_tok[k], w_mask[k], h_tok[k], h_mask[k], n_copy, n_rebuilt, n_unsat, n_rekey);
+            out[k] = ps_plan_cell(v, S, sel, i, g, w_tok[k], w_mask[k], h_tok[k], h_mask[k], n_copy, n_rebuilt, n_unsat, n_rekey, n_dlv);
             n_work += out[k].work ? 1u : 0u;
         }
     }
@@ -429,9 +574,9 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
             o++;
         }
     }
-    uint32_t c[4] = {n_copy, n_rebuilt, n_unsat, n_rekey};
+    uint32_t c[5] = {n_copy, n_rebuilt, n_unsat, n_rekey, n_dlv};        // (4: of the copied shards, those a put launch had written already)
     if (__any((c[0] | c[1] | c[2] | c[3]) != 0))
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             uint32_t x = c[k];
             for (int off = 32; off > 0; off >>= 1) x += (uint32_t)__shfl_xor((int)x, off);
             if (lane == 0 && x) ctr_add(v.counters, k, (unsigned long long)x);
@@ -443,7 +588,7 @@ static inline uint32_t ps_rpl(uint32_t W) { return W >= 4 ? 4u : W; }
 
 template <int RPL>
 __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
-    ps_plan_body<RPL>(v, v.flip, e, S, sel);
+    ps_plan_body<RPL>(v, v.flip, e, S, sel, blockIdx.x);
 }
 // several replicas that consume ONE sender's message (an Accept goes to every follower): blockIdx.y = which of them.  Their views
 // are read from the device copies the stores keep (a by-value table of whole views, indexed by the block, went to scratch:
@@ -457,7 +602,7 @@ struct PsMany {
 template <int RPL>
 __global__ __launch_bounds__(256) void ps_plan_many_kernel(const PsMany M, const PsSrcs S, const uint8_t *__restrict__ sel) {
     const PsView v = *M.v[blockIdx.y];             // a copy in registers: through the pointer every field is reloaded behind every store
-    ps_plan_body<RPL>(v, (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, sel);
+    ps_plan_body<RPL>(v, (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, sel, blockIdx.x);
 }
 
 // a lane per (listed cell, 16-byte column), columns fastest, in a grid-stride loop over cells x columns: the lanes of a wavefront
@@ -512,20 +657,39 @@ __device__ __forceinline__ void ps_bytes_one(const PsView &v, const PsSrcs &S, u
 // (Measured and dropped, profiles/r9c: four columns per lane and trip with their loads issued ahead of the first store -- 48.1 us
 // against 49.0 for the four followers' launch; 32-bit index arithmetic instead of the emulated 64-bit division -- kept, no
 // difference; 1024 .. 8192 blocks per store -- flat.  180 MB in 48 us is what a copy of this shape gets here.)
-__device__ __forceinline__ void ps_bytes_body(const PsView &v, uint32_t flip, const PsSrcs &S) {
+__device__ __forceinline__ void ps_bytes_body(const PsView &v, uint32_t flip, const PsSrcs &S, uint32_t bx, uint32_t nbx) {
     const uint32_t n_items = v.it_n[flip], ncol = v.cap_sl / 16u;
-    const uint64_t total = (uint64_t)n_items * ncol, step = (uint64_t)gridDim.x * 256u;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x; t < total; t += step) {
+    const uint64_t total = (uint64_t)n_items * ncol, step = (uint64_t)nbx * 256u;
+    for (uint64_t t = (uint64_t)bx * 256u + threadIdx.x; t < total; t += step) {
         uint32_t it, c0;
         ps_divmod(t, ncol, it, c0);
         ps_bytes_one(v, S, it, c0 * 16u);
     }
 }
 
-__global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) { ps_bytes_body(v, v.flip, S); }
+__global__ __launch_bounds__(256) void ps_bytes_kernel(const PsView v, const PsSrcs S) { ps_bytes_body(v, v.flip, S, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void ps_bytes_many_kernel(const PsMany M, const PsSrcs S) {
     const PsView v = *M.v[blockIdx.y];             // (as above: 103 -> 63 us for four followers, profiles/r7j -> r7k)
-    ps_bytes_body(v, (M.flips >> blockIdx.y) & 1u, S);
+    ps_bytes_body(v, (M.flips >> blockIdx.y) & 1u, S, blockIdx.x, gridDim.x);
+}
+
+// ---- a co-located leader's tick of the byte path as one call (round 6: smr_rsp_pstore_put_follow_all / smr_craft_pstore_put_follow_all)
+// = put, the leader's own follow, one follow_many for its followers -- five launches as separate calls, four here: the leader's
+// BYTE launch rides in the followers' PLAN launch (the first reads the leader's list and writes the leader's bytes, the second reads
+// the leader's HEADERS, as its source's, and the followers': nothing one of them writes is read by the other).
+// MEASURED and dropped (profiles/s21, s22): the leader's plan inside the put launch -- extra blocks for the cells the put does not
+// write, a header's lane planning its own cell behind its own stores: bit-exact, three launches, and SLOWER: the plan's registers
+// are the launch's (74 VGPRs against the put's 37: six wavefronts per SIMD instead of eight) and a wavefront with a header lane
+// waits out that lane's three dependent rounds -- 52.9 / 55.1 us (plan blocks last / first in the grid) against 41.9 + 6.7.
+constexpr uint32_t PS_LEADER_BYTE_BLOCKS = 64;     // of launch (2): the leader's list is empty in a steady tick (its vote is an alias)
+template <int RPL>
+__global__ __launch_bounds__(256) void ps_bytes_plan_many_kernel(const PsMany M, const PsSrcs S, const PsView lv) {
+    if (blockIdx.x < PS_LEADER_BYTE_BLOCKS) {
+        if (blockIdx.y == 0) ps_bytes_body(lv, lv.flip, S, blockIdx.x, PS_LEADER_BYTE_BLOCKS);   // (its items name no source: S is not looked at)
+        return;
+    }
+    const PsView v = *M.v[blockIdx.y];
+    ps_plan_body<RPL>(v, (M.flips >> blockIdx.y) & 1u, M.e[blockIdx.y], S, nullptr, blockIdx.x - PS_LEADER_BYTE_BLOCKS);
 }
 
 // rscoding.rs:583-609 for a list of instances: item i = (group[i] or i, slot[i]) -> out[i][0 .. dlen)
@@ -780,7 +944,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
     const size_t cells = (size_t)window * n_groups;
     Arena a, pa[2];
     size_t o_tok[2], o_av[2], o_len[2], o_src[2], o_sl[2], o_mat = 0, o_n = 0, o_cell = 0, o_rc = 0, o_ctr = 0, o_view = 0, o_bytes[2] = {0, 0};
-    size_t o_alias = 0, o_itmat = 0;
+    size_t o_alias = 0, o_itmat = 0, o_dlv = 0;
     // twice: sizes first, then -- the arenas allocated -- once more so that the kernel-source emulator of the CPU suite can mark the
     // unowned gap behind every array (SMR_ARENA_GUARD, smr_common.h); the offsets are the same both times
     auto layout = [&]() {
@@ -789,7 +953,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
         o_mat = a.reserve(tab.size()); o_n = a.reserve(256); o_cell = a.reserve(cells * 4);
         for (int p = 0; p < 2; p++) { o_src[p] = a.reserve(cells * 8); o_sl[p] = a.reserve(cells * 4); }
         o_rc = a.reserve(cells * 4); o_ctr = a.reserve(SMR_CTR_WORDS * 8); o_view = a.reserve(sizeof(PsView));
-        o_alias = a.reserve(cells); o_itmat = a.reserve(cells);
+        o_alias = a.reserve(cells); o_itmat = a.reserve(cells); o_dlv = a.reserve(cells);
         for (int p = 0; p < 2; p++) { pa[p].used = 0; o_bytes[p] = pa[p].reserve(p < planes ? s->plane_bytes : 256); }
     };
     layout();
@@ -818,6 +982,7 @@ static int ps_create(uint32_t n_groups, uint32_t n_shards, uint32_t n_data_shard
     v.mat = a.at<uint8_t>(o_mat); v.it_n = a.at<uint32_t>(o_n); v.it_cell = a.at<uint32_t>(o_cell); v.it_rc = a.at<uint32_t>(o_rc);
     v.counters = a.at<unsigned long long>(o_ctr);
     v.it_mat = a.at<uint8_t>(o_itmat);
+    v.dlv = a.at<uint8_t>(o_dlv);                                             // (zeroed with the arena: nothing delivered)
     if (planes == 2) { v.pl[1].alias = a.at<uint8_t>(o_alias); v.pl[1].base0 = v.pl[0].bytes; }   // (zeroed with the arena: no aliases yet)
     s->meta = a.base;
     s->plane_alloc[0] = pa[0].base; s->plane_alloc[1] = pa[1].base;
@@ -852,7 +1017,7 @@ void smr_rsp_pstore_destroy(smr_rsp_pstore *s) {
 }
 
 static int ps_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev, const uint8_t *data_dev,
-                  uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, const RaftPeek *craft, void *stream) {
+                  uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, const RaftPeek *craft, void *stream, const PsDeliver *dv = nullptr) {
     if (data_len == 0 || data_len > s->max_data_len) return fail(SMR_ERR_ARG, "pstore put: data_len must be in 1..max_data_len");
     if (data_stride < data_len) return fail(SMR_ERR_ARG, "pstore put: data_stride is shorter than data_len");
     const PsView &v = s->v;
@@ -862,15 +1027,17 @@ static int ps_put(smr_rsp_pstore *s, const uint32_t *a_n_dev, const uint32_t *a_
     RaftPeek cr;
     memset(&cr, 0, sizeof(cr));
     if (craft) cr = *craft;
+#define PS_PUT_ARGS grid, block, 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, nblk, cr
 #define PS_PUT(D)                                                                                                                         \
     case D:                                                                                                                               \
-        if (craft) hipLaunchKernelGGL((ps_put_kernel<D, true>), grid, block, 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, a_val_dev, data_dev,  \
-                                      data_stride, len_dev, data_len, nblk, cr);                                                          \
-        else hipLaunchKernelGGL((ps_put_kernel<D, false>), grid, block, 0, (hipStream_t)stream, v, a_n_dev, a_slot_dev, a_val_dev, data_dev,       \
-                                data_stride, len_dev, data_len, nblk, cr);                                                                \
+        if (dv && craft) hipLaunchKernelGGL((ps_put_deliver_kernel<D, true>), PS_PUT_ARGS, *dv);                                          \
+        else if (dv) hipLaunchKernelGGL((ps_put_deliver_kernel<D, false>), PS_PUT_ARGS, *dv);                                             \
+        else if (craft) hipLaunchKernelGGL((ps_put_kernel<D, true>), PS_PUT_ARGS);                                                        \
+        else hipLaunchKernelGGL((ps_put_kernel<D, false>), PS_PUT_ARGS);                                                                  \
         break;
     switch (v.d) { PS_PUT(1) PS_PUT(2) PS_PUT(3) PS_PUT(4) PS_PUT(5) PS_PUT(6) PS_PUT(7) default: return fail(SMR_ERR_ARG, "pstore put: bad scheme"); }
 #undef PS_PUT
+#undef PS_PUT_ARGS
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }
@@ -964,11 +1131,9 @@ int smr_craft_pstore_follow(smr_rsp_pstore *s, const smr_raft_leader *e, uint32_
 }
 
 // stores[k] follows the (token, mask) arrays pk[k] names, each with the single source (src, src_plane): two launches for all of them
-static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPeek *pk, const smr_rsp_pstore *src, int src_plane, void *stream) {
+static int ps_many_setup(uint32_t n, smr_rsp_pstore *const *stores, const RspPeek *pk, const smr_rsp_pstore *src, int src_plane, PsMany &M, PsSrcs &S) {
     if (src && (src_plane < 0 || src_plane >= src->planes)) return fail(SMR_ERR_ARG, "pstore follow_many: bad source plane");
-    PsMany M;
     memset(&M, 0, sizeof(M));
-    PsSrcs S;
     memset(&S, 0, sizeof(S));
     const PsView &v0 = stores[0]->v;
     for (uint32_t k = 0; k < n; k++) {
@@ -987,11 +1152,30 @@ static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPe
         S.n = 1;
         S.set(0, src->v.pl[src_plane]);
     }
+    return SMR_OK;
+}
+// (every check passed: from here on the stores' list counters flip)
+static void ps_many_flip(uint32_t n, smr_rsp_pstore *const *stores, PsMany &M) {
     for (uint32_t k = 0; k < n; k++) {
         stores[k]->v.flip ^= 1u;
         M.v[k] = stores[k]->d_view;
         M.flips |= stores[k]->v.flip << k;
     }
+}
+static int ps_many_bytes(uint32_t n, const PsView &v0, const PsMany &M, const PsSrcs &S, hipStream_t st) {
+    const uint32_t cells = v0.W * v0.G;
+    uint64_t blocks = ((uint64_t)cells * (v0.cap_sl / 16u) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ps_bytes_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, st, M, S);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPeek *pk, const smr_rsp_pstore *src, int src_plane, void *stream) {
+    PsMany M;
+    PsSrcs S;
+    if (int rc = ps_many_setup(n, stores, pk, src, src_plane, M, S)) return rc;
+    ps_many_flip(n, stores, M);
+    const PsView &v0 = stores[0]->v;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t cells = v0.W * v0.G;
     const uint32_t lanes = cells / ps_rpl(v0.W);
@@ -1001,11 +1185,66 @@ static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPe
     default: hipLaunchKernelGGL(ps_plan_many_kernel<1>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
     }
     SMR_HIP_TRY(hipGetLastError());
-    uint64_t blocks = ((uint64_t)cells * (v0.cap_sl / 16u) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ps_bytes_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, st, M, S);
+    return ps_many_bytes(n, v0, M, S, st);
+}
+
+// (SMR_PS_DELIVER=0: the followers' shards through the byte kernel as before round 6 -- for A/B runs and the tests that compare the two)
+static bool ps_deliver_on() {
+    const char *e = getenv("SMR_PS_DELIVER");
+    return !(e && e[0] == '0');
+}
+// put + the leader's follow + its followers' follow_many: four launches (ps_put_kernel, ps_plan_kernel, ps_bytes_plan_many_kernel,
+// ps_bytes_many_kernel); a window of fewer than four rows takes the separate calls' five
+static int ps_put_follow_all(smr_rsp_pstore *s, const RspPeek &pk, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
+                             const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, const RaftPeek *craft,
+                             uint32_t n, smr_rsp_pstore *const *stores, const RspPeek *fpk, void *stream) {
+    if (data_len == 0 || data_len > s->max_data_len) return fail(SMR_ERR_ARG, "pstore put: data_len must be in 1..max_data_len");
+    if (data_stride < data_len) return fail(SMR_ERR_ARG, "pstore put: data_stride is shorter than data_len");
+    const PsView &v = s->v;
+    if (pk.G != v.G || pk.W != v.W || pk.R != v.n || pk.majority != v.d)
+        return fail(SMR_ERR_ARG, "pstore follow: the replica's groups / window / population / majority differ from the store's");
+    PsMany M;
+    PsSrcs S;
+    if (n) if (int rc = ps_many_setup(n, stores, fpk, s, 0, M, S)) return rc;
+    if (n && (stores[0]->v.G != v.G || stores[0]->v.W != v.W || stores[0]->v.n != v.n || stores[0]->v.d != v.d || stores[0]->v.cap_sl != v.cap_sl))
+        return fail(SMR_ERR_ARG, "pstore follow_many: the source has another geometry");
+    if (v.W < 4) {
+        if (int rc = ps_put(s, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, craft, stream)) return rc;
+        if (int rc = ps_follow(s, pk, 0, nullptr, nullptr, nullptr, stream)) return rc;
+        return n ? ps_follow_many(n, stores, fpk, s, 0, stream) : SMR_OK;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    PsDeliver dv;                                                          // the followers' shards of this tick's codewords: written by the put launch
+    memset(&dv, 0, sizeof(dv));
+    dv.n = n; dv.all = (1u << v.n) - 1u; dv.lead = pk;
+    for (uint32_t k = 0; k < n; k++) {
+        const PsView &f = stores[k]->v;
+        dv.h[k] = PsHdrs{f.pl[0].tok, f.pl[1].tok, f.pl[0].avail, f.pl[1].avail, f.pl[1].alias, f.dlv, f.pl[0].bytes};
+        dv.e[k] = fpk[k];
+    }
+    if (int rc = ps_put(s, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, craft, stream, (n && ps_deliver_on()) ? &dv : nullptr))
+        return rc;
+    const uint32_t cells = v.W * v.G, n_plan = (cells / 4u + 255) / 256;
+    s->v.flip ^= 1u;
+    {
+        PsSrcs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(ps_plan_kernel<4>, dim3(n_plan), dim3(256), 0, st, v, pk, none, (const uint8_t *)nullptr);
+        SMR_HIP_TRY(hipGetLastError());
+    }
+    if (!n) {                                                              // no followers here: the leader's bytes in a launch of their own
+        uint64_t blocks = ((uint64_t)cells * (v.cap_sl / 16u) + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        PsSrcs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(ps_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v, none);
+        SMR_HIP_TRY(hipGetLastError());
+        return SMR_OK;
+    }
+    ps_many_flip(n, stores, M);
+    hipLaunchKernelGGL(ps_bytes_plan_many_kernel<4>, dim3(PS_LEADER_BYTE_BLOCKS + n_plan, n), dim3(256), 0, st, M, S, s->v);
     SMR_HIP_TRY(hipGetLastError());
-    return SMR_OK;
+    return ps_many_bytes(n, v, M, S, st);
 }
 
 int smr_rsp_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, const smr_rsp_pstore *src,
@@ -1032,6 +1271,38 @@ int smr_craft_pstore_follow_many(uint32_t n, smr_rsp_pstore *const *stores, cons
         pk[k] = craft_as_peek(rp);
     }
     return ps_follow_many(n, stores, pk, src, 0, stream);
+}
+
+int smr_rsp_pstore_put_follow_all(smr_rsp_pstore *s, const smr_rsp_replica *e, const uint32_t *a_n_dev, const uint32_t *a_slot_dev, const uint32_t *a_val_dev,
+                                  const uint8_t *data_dev, uint64_t data_stride, const uint32_t *len_dev, uint32_t data_len, uint32_t n,
+                                  smr_rsp_pstore *const *stores, const smr_rsp_replica *const *replicas, void *stream) {
+    if (!s || !e || !a_n_dev || !a_slot_dev || !a_val_dev || !data_dev || n > PS_MAX_N || (n && (!stores || !replicas)))
+        return fail(SMR_ERR_ARG, "pstore put_follow_all: null argument / more than 8 followers");
+    if (s->planes != 2) return fail(SMR_ERR_STATE, "pstore put_follow_all: a CRaft store follows a Raft replica (smr_craft_pstore_put_follow_all)");
+    RspPeek pk[PS_MAX_N];
+    for (uint32_t k = 0; k < n; k++) {
+        if (!stores[k] || !replicas[k]) return fail(SMR_ERR_ARG, "pstore put_follow_all: null store / replica");
+        if (stores[k]->planes != 2) return fail(SMR_ERR_STATE, "pstore put_follow_all: a CRaft store follows a Raft replica");
+        pk[k] = rsp_peek(replicas[k]);
+    }
+    return ps_put_follow_all(s, rsp_peek(e), a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, nullptr, n, stores, pk, stream);
+}
+
+int smr_craft_pstore_put_follow_all(smr_rsp_pstore *s, const smr_raft_leader *e, const uint32_t *slot_dev, const uint8_t *data_dev, uint64_t data_stride,
+                                    const uint32_t *len_dev, uint32_t data_len, uint32_t n, smr_rsp_pstore *const *stores,
+                                    const smr_raft_leader *const *replicas, void *stream) {
+    if (!s || !e || !slot_dev || !data_dev || n > PS_MAX_N || (n && (!stores || !replicas)))
+        return fail(SMR_ERR_ARG, "craft pstore put_follow_all: null argument / more than 8 followers");
+    RaftPeek rp;
+    if (int rc = craft_peek_of(s, e, rp)) return rc;
+    RspPeek pk[PS_MAX_N];
+    for (uint32_t k = 0; k < n; k++) {
+        if (!stores[k] || !replicas[k]) return fail(SMR_ERR_ARG, "craft pstore put_follow_all: null store / replica");
+        RaftPeek fr;
+        if (int rc = craft_peek_of(stores[k], replicas[k], fr)) return rc;
+        pk[k] = craft_as_peek(fr);
+    }
+    return ps_put_follow_all(s, craft_as_peek(rp), nullptr, slot_dev, nullptr, data_dev, data_stride, len_dev, data_len, &rp, n, stores, pk, stream);
 }
 
 int smr_rsp_pstore_get_data(smr_rsp_pstore *s, uint32_t n_items, const uint32_t *group_dev, const uint32_t *slot_dev, const uint32_t *expect_dev,
@@ -1149,6 +1420,16 @@ int smr_rsp_pstore_counters(smr_rsp_pstore *s, uint64_t *out4_host) {
     unsigned long long c[4];
     SMR_HIP_TRY(ctr_read(s->v.counters, 4, c));
     for (int k = 0; k < 4; k++) out4_host[k] = c[k];
+    return SMR_OK;
+}
+
+// of `copied`: the shards a sender's put launch wrote into this store (smr_*_pstore_put_follow_all), no copy listed for them
+int smr_rsp_pstore_debug_delivered(smr_rsp_pstore *s, uint64_t *out_host) {
+    if (!s || !out_host) return fail(SMR_ERR_ARG, "pstore delivered: null argument");
+    SMR_HIP_TRY(hipDeviceSynchronize());
+    unsigned long long c[5];
+    SMR_HIP_TRY(ctr_read(s->v.counters, 5, c));
+    *out_host = c[4];
     return SMR_OK;
 }
 

@@ -81,6 +81,18 @@ class RSPaxosPayloadStore:
         check(stores[0]._L.smr_rsp_pstore_follow_many(n, sa, ra, None if source is None else source[0]._h, 0 if source is None else int(source[1]),
                                                       stream_ptr(stream)))
 
+    def put_follow_all(self, replica, accepts, data, followers=(), follower_replicas=(), lens=None, stream=None):
+        """a co-located leader's tick of the byte path in ONE call and four launches (`smr_rsp_pstore_put_follow_all`):
+        `put(accepts, data, lens)` + `follow(replica)` + `follow_many(followers, follower_replicas, source=(self, REQS))`"""
+        if data.dim() != 2 or data.stride(1) != 1 or int(data.shape[0]) != self.G:
+            raise _lib.SummersetError(_lib.SMR_ERR_ARG, "data must be uint8 [G, L] with contiguous rows")
+        n = len(followers)
+        sa = (C.c_void_p * max(n, 1))(*[s._h for s in followers])
+        ra = (C.c_void_p * max(n, 1))(*[r._h for r in follower_replicas])
+        check(self._L.smr_rsp_pstore_put_follow_all(self._h, replica._h, _ptr(accepts["a_n"]), _ptr(accepts["a_slot"]), _ptr(accepts["a_val"]),
+                                                    data.data_ptr(), int(data.stride(0)), _ptr(lens), int(data.shape[1]), n, sa, ra,
+                                                    stream_ptr(stream)))
+
     def get_data(self, slot, group=None, expect=None, stream=None):
         """serialized batches of the instances (group[i] or i, slot[i]) -> (uint8 [n, max_data_len], int32 [n] lengths, bool [n] ok)"""
         import torch
@@ -156,6 +168,12 @@ class RSPaxosPayloadStore:
         check(self._L.smr_rsp_pstore_counters(self._h, c.ctypes.data_as(C.c_void_p)))
         return dict(copied=int(c[0]), rebuilt=int(c[1]), unsatisfied=int(c[2]), rekeyed=int(c[3]))
 
+    def delivered(self):
+        """of `counters()["copied"]`: shards a sender's `put_follow_all` wrote here from its put launch (no copy out of its row)"""
+        c = np.zeros(1, np.uint64)
+        check(self._L.smr_rsp_pstore_debug_delivered(self._h, c.ctypes.data_as(C.c_void_p)))
+        return int(c[0])
+
 
 class CRaftPayloadStore(RSPaxosPayloadStore):
     """The shard bytes behind a CRaft replica's log (`smr_craft_pstore_*`): what the reference keeps in `LogEntry::reqs_cw`
@@ -193,6 +211,17 @@ class CRaftPayloadStore(RSPaxosPayloadStore):
         sa = (C.c_void_p * n)(*[s._h for s in stores])
         ra = (C.c_void_p * n)(*[r._h for r in replicas])
         check(stores[0]._L.smr_craft_pstore_follow_many(n, sa, ra, None if source is None else source._h, stream_ptr(stream)))
+
+    def put_follow_all(self, replica, slot, data, followers=(), follower_replicas=(), lens=None, stream=None):
+        """`put(replica, slot, data, lens)` + `follow(replica)` + `follow_many(followers, follower_replicas, source=self)` in ONE call
+        and four launches (`smr_craft_pstore_put_follow_all`); behind the leader's append AND the followers' handlers"""
+        if data.dim() != 2 or data.stride(1) != 1 or int(data.shape[0]) != self.G:
+            raise _lib.SummersetError(_lib.SMR_ERR_ARG, "data must be uint8 [G, L] with contiguous rows")
+        n = len(followers)
+        sa = (C.c_void_p * max(n, 1))(*[s._h for s in followers])
+        ra = (C.c_void_p * max(n, 1))(*[r._h for r in follower_replicas])
+        check(self._L.smr_craft_pstore_put_follow_all(self._h, replica._h, slot.data_ptr(), data.data_ptr(), int(data.stride(0)), _ptr(lens),
+                                                      int(data.shape[1]), n, sa, ra, stream_ptr(stream)))
 
     def emit_accepts(self, *a, **kw):
         raise _lib.SummersetError(_lib.SMR_ERR_STATE, "Accept frames are RSPaxos'")

@@ -110,7 +110,7 @@ def config4_payload_cluster(G=CONFIG4["G"], W=PAYLOAD_W, ft=CONFIG4["ft"], L=CON
     return reps, loop, [RSPaxosPayloadStore(G, CONFIG4["R"], W, max_data_len=L) for _ in range(CONFIG4["R"])]
 
 
-def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, ones, engine=True, bytes_=True):
+def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, ones, engine=True, bytes_=True, one_call=True):
     """one tick: the engines' handlers in one launch, then the tick's bytes -- the leader's put of the serialized batches `src`
     (uint8 [G, L]) into the rows of `slot` (int32 [G]: in the steady state every group appends every tick, slot = tick) and one
     follow per replica, the followers' out of the leader's REQS plane.  Returns the leader's committed flags (None without engine)."""
@@ -118,10 +118,13 @@ def config4_payload_tick(reps, loop, stores, slot, src, val, lost, heartbeat, on
     s = loop.s
     committed = loop.tick(val, lost=lost, heartbeat=heartbeat) if engine else None
     if bytes_:
-        stores[s].put(dict(a_n=ones, a_slot=slot, a_val=val), src)
-        stores[s].follow(reps[s])
         others = [q for q in range(len(reps)) if q != s]                  # the followers consumed ONE Accept broadcast: one call for all of them
-        stores[s].follow_many([stores[q] for q in others], [reps[q] for q in others], (stores[s], REQS))
+        if one_call:                                                      # round 6: the three calls below as one, four launches instead of five
+            stores[s].put_follow_all(reps[s], dict(a_n=ones, a_slot=slot, a_val=val), src, [stores[q] for q in others], [reps[q] for q in others])
+        else:
+            stores[s].put(dict(a_n=ones, a_slot=slot, a_val=val), src)
+            stores[s].follow(reps[s])
+            stores[s].follow_many([stores[q] for q in others], [reps[q] for q in others], (stores[s], REQS))
     return committed
 
 
@@ -152,7 +155,7 @@ def craft_payload_cluster(G=CRAFT_PAYLOAD["G"], W=CRAFT_PAYLOAD["W"], L=CRAFT_PA
     return reps, stores, bufs                                            # a tick is its handlers' launches and nothing else
 
 
-def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, one_launch=True):
+def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, one_launch=True, one_call=True):
     """one tick: the leader appends one batch per group (slot [G] int32 = where: in the steady state log_len before the call = 1 +
     the tick's number) and `put`s the serialized batches `src` (uint8 [G, L]); its follow; per follower the AppendEntries out of the
     leader's log + `handle_msg_append_entries` -- all four in ONE launch (`smr_raft_cluster_replicate`; one_launch=False: the eight
@@ -161,7 +164,7 @@ def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, on
     from .rsp_payload import CRaftPayloadStore
     R = len(reps)
     first = reps[0].handle_req_batch_emit(bufs["ones"], out=bufs["first"])
-    if bytes_:
+    if bytes_ and not one_call:
         stores[0].put(reps[0], slot, src, lens)
         stores[0].follow(reps[0])
     msgs = {}
@@ -179,7 +182,9 @@ def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, on
         m = bufs["msg"][q] = reps[0].gather_entries(first[q], 1, out=bufs["msg"][q])
         reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q], out=reply(q))
         msgs[q] = m
-    if bytes_:
+    if bytes_ and one_call:            # round 6: put + the leader's follow + the followers' follow_many as ONE call, four launches --
+        stores[0].put_follow_all(reps[0], slot, src, stores[1:], reps[1:], lens=lens)   # behind the followers' handlers (their masks)
+    elif bytes_:
         CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])
     reps[0].handle_msg_append_entries_reply(bufs["rt"], bufs["es"], bufs["fl"])
     return msgs

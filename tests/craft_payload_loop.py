@@ -28,6 +28,7 @@ class Loop:
         self.staging = [CRaftPayloadStore(G, R, W, max_data_len=L) for _ in range(R)] if staging else None
         self._msg = None
         self.many = many and not staging                                  # the followers of one AppendEntries broadcast: ONE follow_many call
+        self.one_call = self.many and many == "one_call"                  # put + the leader's follow + that follow_many: put_follow_all
         self.leader = 0
         for r in range(1, R):
             self.reps[r].preset(0, 0, 1)                                  # followers of replica 0 in term 1
@@ -116,9 +117,10 @@ class Loop:
             term = int(d1["entry_term"][s % self.W, g])
             b = data[g, :lens[g]].copy()
             self.book[(int(g), s, term)] = (b, self.codeword(b))
-        st.put(eng, self.t(slot), self.t(data), self.t(lens))
-        st.follow(eng)
-        self.check(ld, ("put", ld))
+        if not self.one_call:                                             # (one_call: behind the followers' handlers, with their follow)
+            st.put(eng, self.t(slot), self.t(data), self.t(lens))
+            st.follow(eng)
+            self.check(ld, ("put", ld))
         _, send = eng.assignment(self.dev)
         send = send.cpu().numpy().astype(np.uint8)
         if exotic is not None:
@@ -150,7 +152,10 @@ class Loop:
             cs[q] = r["conflict_slot"].cpu().numpy().view(np.uint32)
         if self.many:
             qs = [q for q in range(R) if q != ld and q not in skip]
-            if qs:
+            if self.one_call:                                             # the put launch writes the followers' shards of the new entries
+                st.put_follow_all(eng, self.t(slot), self.t(data), [self.stores[q] for q in qs], [self.reps[q] for q in qs], lens=self.t(lens))
+                self.check(ld, ("put_follow_all", ld))
+            elif qs:
                 type(st).follow_many([self.stores[q] for q in qs], [self.reps[q] for q in qs], source=st)
             for q in qs:
                 self.check(q, ("append_entries, follow_many", q))

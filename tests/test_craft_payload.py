@@ -11,13 +11,17 @@ import pytest
 sys.path.insert(0, os.path.dirname(__file__))
 
 
-@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True)], ids=["colocated", "messages", "follow_many"])
+@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True), (False, "one_call")],
+                         ids=["colocated", "messages", "follow_many", "put_follow_all"])
 def test_craft_payload_loop_on_the_emulator(oracle, staging, many):
     import hostsim
     import craft_payload_loop as cl
     hostsim.build()
     with hostsim.patched():
-        cl.run("cpu", oracle, G=70, W=32, L=67, staging=staging, many=many)
+        lp = cl.run("cpu", oracle, G=70, W=32, L=67, staging=staging, many=many)
+        if many == "one_call":                                           # the put launch wrote followers' shards -- and not all of them
+            dl, cp = [s.delivered() for s in lp.stores], [s.counters()["copied"] for s in lp.stores]
+            assert sum(dl) > 0 and all(d <= c for d, c in zip(dl, cp)) and sum(dl) < sum(cp), (dl, cp)
 
 
 def test_craft_payload_ring_wraps_on_the_emulator(oracle):
@@ -115,3 +119,79 @@ def test_one_launch_replication_on_the_emulator():
     hostsim.build()
     with hostsim.patched():
         run_one_launch_replication_is_the_eight_calls("cpu", G=70)
+
+
+# ---- round 6: put + the leader's follow + the followers' follow_many as ONE call, four launches (smr_*_pstore_put_follow_all) ----
+def _stores_equal(sa, sb, planes, W, tag):
+    for pl in range(planes):
+        da, db = sa.dump(pl), sb.dump(pl)
+        for k in da:
+            assert np.array_equal(da[k], db[k]), (tag, pl, k)
+        for row in range(W):                                          # every byte of every shard the headers name
+            ra, rb = sa.read_row(row, pl), sb.read_row(row, pl)
+            sl = -(-da["dlen"][row].astype(np.int64) // (sa.R // 2 + 1))
+            for k in range(sa.R):
+                m = ((da["avail"][row] >> k) & 1).astype(bool)
+                if planes == 2 and pl == 1:
+                    m &= ~((sa.voted_alias()[row] >> k) & 1).astype(bool)   # (an aliased vote's bytes live in the REQS row)
+                cols = np.arange(ra.shape[2])[None, :] < sl[:, None]
+                assert np.array_equal(ra[k][m[:, None] & cols], rb[k][m[:, None] & cols]), (tag, pl, row, k)
+    if planes == 2:
+        assert np.array_equal(sa.voted_alias(), sb.voted_alias()), tag
+    assert sa.counters() == sb.counters(), (tag, sa.counters(), sb.counters())
+
+
+def run_craft_one_call_is_the_three_calls(dev, G=150, W=8, L=40, T=11):
+    """two CRaft clusters on the same inputs, the byte path of one as put / follow / follow_many, of the other as
+    `put_follow_all`: engines, stores (headers, every named shard byte) and counters identical tick by tick; W = 8: the ring wraps"""
+    import torch
+    from summerset_amd import workloads
+    a, b = workloads.craft_payload_cluster(G, W, L, 1, dev), workloads.craft_payload_cluster(G, W, L, 1, dev)
+    rng = np.random.default_rng(7)
+    for t in range(T):
+        slot = torch.full((G,), t + 1, dtype=torch.int32, device=dev)
+        if t == 4:
+            slot[::3] = -1                                             # groups that do not put this tick (their entry has no bytes yet)
+        src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
+        lens = torch.from_numpy(rng.integers(1, L + 1, G).astype(np.int32)).to(dev)
+        workloads.craft_payload_tick(*a, slot, src, lens=lens, one_call=False)
+        workloads.craft_payload_tick(*b, slot, src, lens=lens, one_call=True)
+        for r in range(len(a[0])):
+            da, db = a[0][r].dump(), b[0][r].dump()
+            for k in da:
+                assert np.array_equal(da[k], db[k]), (t, r, k)
+            _stores_equal(a[1][r], b[1][r], 1, W, (t, r))
+    assert a[1][1].counters()["copied"] > 0
+    assert a[1][1].delivered() == 0 and 0 < b[1][1].delivered() <= b[1][1].counters()["copied"]   # (the put launch wrote them)
+
+
+def run_rspaxos_one_call_is_the_three_calls(dev, G=130, W=8, L=67, T=12):
+    """config 4's cluster + payload stores twice, one tick as the three calls, the other as `put_follow_all`, reply loss on"""
+    import torch
+    from summerset_amd import workloads
+    a, b = workloads.config4_payload_cluster(G, W, 1, L), workloads.config4_payload_cluster(G, W, 1, L)
+    rng = np.random.default_rng(11)
+    ones = torch.ones(G, dtype=torch.int32, device=dev)
+    for t in range(T):
+        slot = torch.full((G,), t, dtype=torch.int32, device=dev)
+        src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
+        val = torch.from_numpy(workloads.config4_tokens(G, t)).to(dev)
+        lost = {k: torch.from_numpy(v).to(dev) for k, v in workloads.config4_loss(rng, G, p=0.2).items()}
+        ca = workloads.config4_payload_tick(*a, slot, src, val, lost, t % 4 == 3, ones, one_call=False)
+        cb = workloads.config4_payload_tick(*b, slot, src, val, lost, t % 4 == 3, ones, one_call=True)
+        assert torch.equal(ca, cb), t
+        for r in range(len(a[0])):
+            da, db = a[0][r].dump(), b[0][r].dump()
+            for k in da:
+                assert np.array_equal(da[k], db[k]), (t, r, k)
+            _stores_equal(a[2][r], b[2][r], 2, W, (t, r))
+    assert a[2][1].counters()["copied"] > 0
+    assert a[2][1].delivered() == 0 and 0 < b[2][1].delivered() <= b[2][1].counters()["copied"]
+
+
+def test_one_call_byte_path_on_the_emulator():
+    import hostsim
+    hostsim.build()
+    with hostsim.patched():
+        run_craft_one_call_is_the_three_calls("cpu", G=70)
+        run_rspaxos_one_call_is_the_three_calls("cpu", G=70)

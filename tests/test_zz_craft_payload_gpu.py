@@ -10,10 +10,13 @@ sys.path.insert(0, os.path.dirname(__file__))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True)], ids=["colocated", "messages", "follow_many"])
+@pytest.mark.parametrize("staging,many", [(False, False), (True, False), (False, True), (False, "one_call")],
+                         ids=["colocated", "messages", "follow_many", "put_follow_all"])
 def test_craft_payload_loop(cuda, oracle, staging, many):
     import craft_payload_loop as cl
-    cl.run(cuda, oracle, G=96, W=32, L=131, staging=staging, many=many)
+    lp = cl.run(cuda, oracle, G=96, W=32, L=131, staging=staging, many=many)
+    if many == "one_call":
+        assert 0 < sum(s.delivered() for s in lp.stores) < sum(s.counters()["copied"] for s in lp.stores)
 
 
 def test_craft_payload_loop_4k_batches(cuda, oracle):
@@ -36,3 +39,11 @@ def test_one_launch_replication_is_the_eight_calls(cuda):
     """`smr_raft_cluster_replicate` (the leader's four AppendEntries and their handlers in one launch) against the eight calls"""
     import test_craft_payload as t
     t.run_one_launch_replication_is_the_eight_calls(cuda, G=1000, W=8, L=200, T=14)
+
+
+def test_one_call_byte_path_is_the_three_calls(cuda):
+    """`smr_craft_pstore_put_follow_all` / `smr_rsp_pstore_put_follow_all` (round 6: put + the leader's follow + the followers'
+    follow_many in four launches) against the three calls, stores compared byte for byte every tick"""
+    import test_craft_payload as t
+    t.run_craft_one_call_is_the_three_calls(cuda, G=1000, W=8, L=200, T=14)
+    t.run_rspaxos_one_call_is_the_three_calls(cuda, G=1000, W=8, L=333, T=14)

@@ -1,6 +1,6 @@
 # round 6: the payload stores' plan kernels, four ring rows per lane -- device tests, the two payload legs, their kernel stats
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_zz_rsp_payload_gpu.py tests/test_zz_craft_payload_gpu.py tests/test_zzz_example_rsp_payload_gpu.py tests/test_zzzz_rsp_emit_accepts_gpu.py tests/test_zz_rsp_bytes_gpu.py tests/test_baseline_configs_gpu.py -q -m gpu -k "payload or craft or rsp or config3 or config4" -p no:cacheprovider 2>&1 | tail -4 > gpurun_out/s20_payload_tests.log; cat gpurun_out/s20_payload_tests.log
+timeout 900 python -m pytest tests/test_zz_rsp_payload_gpu.py tests/test_zz_craft_payload_gpu.py tests/test_zz_craft_gpu.py tests/test_zzz_example_rsp_payload_gpu.py tests/test_zzzz_rsp_emit_accepts_gpu.py tests/test_zz_rsp_bytes_gpu.py tests/test_baseline_configs_gpu.py -q -m gpu -k "payload or craft or rsp or config3 or config4" -p no:cacheprovider 2>&1 | tail -4 > gpurun_out/s20_payload_tests.log; cat gpurun_out/s20_payload_tests.log
 for leg in rspaxos_payload craft_payload; do
   for i in 1 2; do
     timeout 300 python bench.py --leg $leg > gpurun_out/s20_leg_${leg}_$i.json 2> gpurun_out/s20_leg_${leg}_$i.err
