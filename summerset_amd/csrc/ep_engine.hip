@@ -1257,12 +1257,16 @@ struct EpRepliesInRegs {
 };
 
 // own (ep_cluster_tick_pm_kernel): the instance as my proposal of this tick made it -- nothing of it or of my own reply is in memory
-// yet (ep_propose_lane's rec_later): the record comes from *own, my reply is (own->seq, own->d), and whatever this call leaves
+// yet (ep_propose_lane's rec_later): the record comes from *own_p, my reply is (own_p->seq, own_p->d), and whatever this call leaves
 // behind goes out in full
 template <int NR, bool C, typename RD>
 __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_t row, uint32_t c, uint32_t ctl, uint32_t ex, const RD &rdr,
                                                       uint8_t &dec, uint64_t &dseq, uint32_t (&dd)[NR],
-                                                      EpInst<NR> *rec = nullptr, bool *stored = nullptr, const EpInst<NR> *own = nullptr) {
+                                                      EpInst<NR> *rec = nullptr, bool *stored = nullptr, const EpInst<NR> *own_p = nullptr,
+                                                      bool own_on = true) {
+    // (own_p names the caller's object whether or not this lane has an unmaterialized proposal -- own_on says that: a pointer
+    // that is &object in some lanes and null in others kept the object in scratch, 44 B per lane)
+    const bool own = own_p && own_on;
     const EpView &v = L.v;
     if (stored) *stored = false;
     const uint32_t R = v.R;
@@ -1272,7 +1276,7 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
     // it already holds
     EpInst<NR> I;
     I.make_null();
-    if (own) I = *own;
+    if (own) I = *own_p;
     else { I.bal = L.bal_at(i); L.load_meta(i, I); }
     uint32_t st = h ? I.status() : 0u, acks = h ? I.pa_acks() : 0u;
     const uint64_t b = h ? I.bal : 0ull;
@@ -1283,9 +1287,9 @@ __device__ __forceinline__ void ep_pa_replies_lane_rd(EpLaneT<NR, C> &L, uint32_
 #pragma unroll
     for (int p = 0; p < NR; p++) {
         const bool on = (acks >> p) & 1u, mine = own && (uint32_t)p == v.me;
-        ps[p] = mine ? own->seq : (on ? EA(v.pa_seq, L.ps_ix(row, c, p)) : 0ull);
+        ps[p] = mine ? own_p->seq : (on ? EA(v.pa_seq, L.ps_ix(row, c, p)) : 0ull);
 #pragma unroll
-        for (int k = 0; k < NR; k++) pd[p][k] = mine ? own->d[k] : ((on && (uint32_t)k < R) ? EA(v.pa_deps, L.pd_ix(row, c, p, k)) : EP_NONE);
+        for (int k = 0; k < NR; k++) pd[p][k] = mine ? own_p->d[k] : ((on && (uint32_t)k < R) ? EA(v.pa_deps, L.pd_ix(row, c, p, k)) : EP_NONE);
     }
     dseq = 0;
 #pragma unroll
@@ -2260,7 +2264,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
             const uint32_t h_col = PA(q, 1);
             const EpRepliesInLds<NR> rdr{sh_rep + (size_t)(set * NR + q) * (NR - 1) * EPC_REP_WORDS * 64, q, lane};
             const EpInst<NR> mine = own_inst();
-            ep_pa_replies_lane_rd<NR, true>(L, q, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h, own_def ? &mine : nullptr);
+            ep_pa_replies_lane_rd<NR, true>(L, q, h_col, SMR_CTL_IDENTITY, 0u, rdr, dec, dseq, dd, &H, &have_h, &mine, own_def);
             own_def = false;                                                 // (decided or not, the cell is in memory now)
             PA(q, 0) = (PA(q, 0) & 1u) | ((uint32_t)dec << 8);
             PA(q, 3) = dec ? (uint32_t)dseq : 0u; PA(q, 4) = dec ? (uint32_t)(dseq >> 32) : 0u;
@@ -2378,10 +2382,11 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
         }
         uint32_t stf[NR];                                                    // per row: the final Status of this tick's instance where this phase sets it (0: untouched)
         uint32_t n_exec = 0, n_att = 0, n_unh = 0, n_abort = 0, last_sub = 0;
-        uint32_t ordv[NR], ordm = 0;                                         // the submission list as the phase leaves it: position k written (bit k) with ordv[k]
+        uint64_t ord_lo = 0, ord_hi = 0; uint32_t ordm = 0;                  // the submission list as the phase leaves it: position k written (bit k), 16 bits each
+                                                                             // (an array here became a runtime-indexed one in scratch: `if (n == k) a[k] = x` for every k is a[n] = x to the compiler)
         uint32_t exm = 0;                                                    // rows whose instance was executed in this phase
 #pragma unroll
-        for (int r = 0; r < NR; r++) { stf[r] = 0; ordv[r] = 0; }
+        for (int r = 0; r < NR; r++) stf[r] = 0;
         // attempt_execution (execution.rs:25-149) from the tail (r, col[r]) as far as this path goes: every dependency and the row
         // predecessor not committed here (abandoned), gone from the ring, or Executed / Executing -- below its row's exec bar as
         // moved so far; anything else (a second node of the graph) leaves the fast path.  true = the instance may run.
@@ -2418,8 +2423,11 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
 #pragma unroll
             for (int r2 = 0; r2 < NR; r2++) if (key[r2] == key[r]) kvcur[r2] = tw;   // (the key's KV word as every later reader of it sees it)
             const uint32_t ring = ((uint32_t)r << E.wshift) | (col[r] & v.Wmask);
-#pragma unroll
-            for (int k = 0; k < NR; k++) if (n_ord == (uint32_t)k) { ordv[k] = ring; ordm |= 1u << k; }
+            if (n_ord < (uint32_t)NR) {
+                const uint64_t sh = (uint64_t)(ring & 0xFFFFu) << (16u * (n_ord & 3u));
+                if (n_ord < 4u) ord_lo |= sh; else ord_hi |= sh;
+                ordm |= 1u << n_ord;
+            }
             EPC_WHY(11, n_ord < (uint32_t)NR);
             n_ord++;
             exm |= 1u << r; n_exec++;
@@ -2496,7 +2504,7 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
             if (a.execute) {
                 if (exm) EA(x.digest, g) = dg;
 #pragma unroll
-                for (int k = 0; k < NR; k++) if ((ordm >> k) & 1u) EA(x.order, E.at(k)) = (uint16_t)ordv[k];
+                for (int k = 0; k < NR; k++) if ((ordm >> k) & 1u) EA(x.order, E.at(k)) = (uint16_t)((k < 4 ? ord_lo : ord_hi) >> (16 * (k & 3)));
                 EA(x.n_sub, g) = last_sub;
                 E.c_exec += n_exec; E.c_attempts += n_att; E.c_unheld += n_unh; E.c_aborts += n_abort;
             }
