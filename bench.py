@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("t1z_pmc_traffic.json", "r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("t2z_pmc_traffic.json", "t1z_pmc_traffic.json", "r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -727,7 +727,7 @@ def _payload_leg_traffic(name="rspaxos_payload"):
     """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or (None, None): the
     sum over every ps_* / craft_* kernel of (bytes per launch x launches per tick), launches per tick = the kernel's launches in
     the profiled run / the run's ticks (recorded in the file by tools/final_record.sh)."""
-    for f in ("t1z_pmc_traffic_%s_leg.json" % name, "r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
+    for f in ("t2z_pmc_traffic_%s_leg.json" % name, "t1z_pmc_traffic_%s_leg.json" % name, "r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
         if not f:
             continue
         try:
@@ -737,7 +737,7 @@ def _payload_leg_traffic(name="rspaxos_payload"):
             if f.startswith("r7g"):                                  # (round 4's file: one follow per replica, five plan + five byte launches)
                 return (k["smr::ps_put_kernel<3>"]["hbm_bytes_per_launch"] + 5 * k["smr::ps_plan_kernel"]["hbm_bytes_per_launch"]
                         + 5 * k["smr::ps_bytes_kernel"]["hbm_bytes_per_launch"]), "profiles/" + f
-            put = next(v for n, v in k.items() if "ps_put_kernel" in n)
+            put = next(v for n, v in k.items() if "::ps_put_" in n)       # (ps_put_kernel / round 6: ps_put_deliver_kernel)
             ticks = put["launches"]                                  # one put per tick
             tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in k.items() if "::ps_" in n or "::craft_" in n)
             return tot / ticks, "profiles/" + f
@@ -778,7 +778,9 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
     # ~17 host calls per tick at 10-20 us each: a 12 ms device-side sleep in front lets the host queue the whole region first
     us = _time_us(torch, one_tick, ticks, sleep_cycles=24_000_000)
     sl = -(-L // 3)
-    moved = G * (L + 5 * sl + 4 * 2 * sl)          # put: L read, 5 shards written; 4 followers x one shard (r + w) -- every vote is an alias
+    # put: L read, 5 shards written; 4 followers x one shard WRITTEN -- round 6: by the put launch, out of its registers (until then
+    # read back out of the leader's row: + 4 shard_len); every vote is an alias
+    moved = G * (L + 5 * sl + 4 * sl)
     c = [st.counters() for st in stores]
     ok = all(x["unsatisfied"] == 0 for x in c)
     for q in range(R):                             # every ring cell of both planes holds what the engine says it holds
@@ -799,7 +801,8 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
                         "encode into the ring, %d groups x L = %d) + the leader's follow + one follow_many for the four followers (window %d, two planes)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
             "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6),
-            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3> + the leader's ps_plan_kernel / ps_bytes_kernel + the four followers' ps_plan_many_kernel / ps_bytes_many_kernel", "achieved": moved / (us_bytes * 1e-6) / 1e9,
+            "launches_per_tick": {"engine": 1, "bytes": 4}, "shards_delivered_by_the_put_launch": sum(st.delivered() for st in stores),
+            "roofline": {"bound": "hbm", "kernel": "ps_put_deliver_kernel<3> (the leader's five shards and each follower's one) + ps_plan_kernel + ps_bytes_plan_many_kernel + ps_bytes_many_kernel (metadata: nothing is left to copy in a steady tick)", "achieved": moved / (us_bytes * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": moved,
                          "survey_8d_bytes_per_launch": G * (5 * sl + 85),
                          "frac_on_survey_8d_bytes": G * (5 * sl + 85) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,   # the WHOLE tick on SURVEY 8(d)'s bytes
@@ -807,8 +810,9 @@ def rspaxos_payload_leg(torch, dev, ticks=32, warmup=6):
                          "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over this leg; per tick = every ps_* launch of a tick)"
                                            % _payload_leg_traffic("rspaxos_payload")[1],
                          "note": "per tick (tick with the stores minus the engines' tick alone); bytes the path has to move: L read + 5 shard_len "
-                                 "written by put, one shard read + written by each of 4 followers (a vote is an alias of the reqs row's shard, "
-                                 "not a second copy: rounds 4-5a moved 584 MB here)"},
+                                 "written by put for the leader and one shard per follower written by the same launch (round 6; rounds 5b-6a read "
+                                 "it back out of the leader's row: 359 MB; a vote is an alias of the reqs row's shard, not a second copy: rounds "
+                                 "4-5a moved 584 MB here)"},
             "counters": {k: sum(x[k] for x in c) for k in c[0]}, "verified": ok}
 
 
@@ -838,7 +842,7 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
         one_tick()
     us = time_us(torch, one_tick, ticks, sleep_cycles=24_000_000)
     sl = -(-L // 3)
-    moved = G * (L + 5 * sl + 4 * 2 * sl)                     # put: L read, 5 shards written; every follower: its shard read + written
+    moved = G * (L + 5 * sl + 4 * sl)                         # put: L read, 5 shards written; every follower's shard written by the same launch (round 6)
     c = [st.counters() for st in stores]
     ok = all(x["unsatisfied"] == 0 for x in c) and reps[0].total_commits() >= G * (n[0] - 2)
     last = n[0] % W                                           # the slot of the last tick is n[0]: its ring cell
@@ -855,14 +859,15 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
                         "(put + the leader's follow + one follow_many for the four followers, window %d); the four AppendEntries and their handlers "
                         "are one launch (smr_raft_cluster_replicate)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
-            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 3, "bytes": 5},
-            "roofline": {"bound": "hbm", "kernel": "ps_put_kernel<3, true> + ps_plan / ps_bytes (the leader's, and the followers' _many)",
+            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 3, "bytes": 4},
+            "shards_delivered_by_the_put_launch": sum(st.delivered() for st in stores),
+            "roofline": {"bound": "hbm", "kernel": "ps_put_deliver_kernel<3, true> + ps_plan_kernel + ps_bytes_plan_many_kernel + ps_bytes_many_kernel",
                          "achieved": moved / (us_bytes * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": moved, "avg_launch_us": us_bytes, "traffic": _payload_leg_traffic("craft_payload")[0] if G == 16384 else None,
                          "traffic_source": _payload_leg_traffic("craft_payload")[1],
                          "survey_8d_bytes_per_launch": G * (5 * sl + 85), "frac_on_survey_8d_bytes": G * (5 * sl + 85) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "note": "per tick (tick with the stores minus the engines' tick alone); bytes the path has to move: L read + 5 shard_len written "
-                                 "by put, one shard read + written by each of 4 followers"},
+                                 "by put for the leader, one shard per follower written by the same launch (round 6)"},
             "counters": {k: sum(x[k] for x in c) for k in c[0]}, "verified": ok}
 
 
