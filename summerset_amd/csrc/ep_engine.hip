@@ -2538,23 +2538,26 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
 // The CommitNotice phase of the lanes ep_cluster_tick_pm_kernel put on its lists (a Commit for a cell that does not hold the
 // PreAccepted instance, an execution whose graph has a second node, ...: under 1 % of the lanes of a running cluster, but one per
 // wavefront there would hold its whole block for four handlers' round trips): handler by handler, the messages out of the
-// tick's output arrays, a wavefront of listed lanes per block (blockIdx.y = the replica).  Also empties the OTHER parity's
+// tick's output arrays, a wavefront of listed lanes per block (blockIdx.x = the replica, so that the blocks with work -- the first
+// n / EPC_CL_LANES of every replica -- are the first the dispatcher places: with the replica as blockIdx.y the last replica's chains started
+// behind four replicas' rows of empty blocks).  Also empties the OTHER parity's
 // counts for the next tick.
 #ifndef EPC_CL_LANES
-#define EPC_CL_LANES 4u
+#define EPC_CL_LANES 2u                       // (1: the same; 4: +12 us per tick, 8: +6, profiles/s28)
 #endif
 template <int NR>
 __global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const EpClusterArgs<NR> a) {
     __shared__ uint32_t sh_sc[4 * NR * 64];
     constexpr uint32_t WALK_CELLS = 512;                                     // population * window up to here: the walk's arrays in LDS
     __shared__ uint16_t sh_walk[7 * WALK_CELLS * EPC_CL_LANES];               // node_of, nslot, head, sib, parent [cell][lane]; order [2 cells][lane]
-    const uint32_t q = blockIdx.y, R = a.R, G = a.G, lane = threadIdx.x;
+    const uint32_t q = blockIdx.x, bx = blockIdx.y, nbx = gridDim.y, R = a.R, G = a.G, lane = threadIdx.x;
     const uint32_t n = SMR_WAVE_UNIFORM(a.defer_cnt[(a.parity * NR + q) * 32u]);
+    if (bx != 0u && bx * EPC_CL_LANES >= n) return;                           // (block 0 also empties the other parity's count, below)
     const uint32_t RW = R * a.v0.W;
     const bool lds_walk = a.execute && RW <= WALK_CELLS;
     if (lds_walk) for (uint32_t i = lane; i < RW * EPC_CL_LANES; i += 64u) sh_walk[i] = 0;   // node_of: zero between attempts (the walk leaves it so)
     __syncthreads();
-    if (blockIdx.x == 0 && lane == 0) a.defer_cnt[((a.parity ^ 1u) * NR + q) * 32u] = 0;
+    if (bx == 0 && lane == 0) a.defer_cnt[((a.parity ^ 1u) * NR + q) * 32u] = 0;
     EpView v = a.v0;
     EpExec x = a.x0;
     ep_shift(v, a.delta[q]);
@@ -2564,7 +2567,7 @@ __global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const 
     // EPC_CL_LANES listed lanes per wavefront, not 64: the walks of attempt_execution are chains of ~30 dependent round trips that
     // different lanes enter behind different members of the batch, and a wavefront pays every one of them in turn (64 lanes
     // per wavefront: 250 us for ~2 750 listed lanes, profiles/s6: the fourth member's step alone 100 us)
-    for (uint32_t base = blockIdx.x * EPC_CL_LANES; base < n; base += gridDim.x * EPC_CL_LANES) {
+    for (uint32_t base = bx * EPC_CL_LANES; base < n; base += nbx * EPC_CL_LANES) {
         const bool active = lane < EPC_CL_LANES && base + lane < n;
         const uint32_t g = active ? a.defer_list[(size_t)q * G + base + lane] : 0u;
         EpLaneT<NR, true> L(v, g);                                          // (the lane's per-row scalars in LDS, as in the tick kernel: every handler starts with them)
@@ -2579,7 +2582,7 @@ __global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const 
         uint32_t n_listed = 0;                                               // (the longest submission list a handler of this lane left)
         if (active) { L.load_scalars(); if (a.execute) E.load_scalars(); }
 #ifdef EPC_STAMPS
-#define EPC_CL_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && blockIdx.x == 0 && base == 0) a.stamps[q * 64 + 40 + (k)] = wall_clock64(); } while (0)
+#define EPC_CL_STAMP(k) do { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && bx == 0 && base == 0) a.stamps[q * 64 + 40 + (k)] = wall_clock64(); } while (0)
 #else
 #define EPC_CL_STAMP(k) do { } while (0)
 #endif
@@ -3172,7 +3175,7 @@ static int ep_cluster_tick_one_launch(smr_ep_cluster *c, const uint8_t *const *k
             c->parity ^= 1u;
             hipLaunchKernelGGL((ep_cluster_tick_pm_kernel<NR>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
                                (hipStream_t)stream, a);
-            hipLaunchKernelGGL((ep_cluster_commit_one_by_one_kernel<NR>), dim3(std::min<uint32_t>((G + EPC_CL_LANES - 1u) / EPC_CL_LANES, 1024u), R), dim3(64), 0, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((ep_cluster_commit_one_by_one_kernel<NR>), dim3(R, std::min<uint32_t>((G + EPC_CL_LANES - 1u) / EPC_CL_LANES, 1024u)), dim3(64), 0, (hipStream_t)stream, a);
         }
     } else if (a.quiet)
         hipLaunchKernelGGL((ep_cluster_tick_kernel<NR, false>), dim3((G + 64 * epc_sets<NR>() - 1) / (64 * epc_sets<NR>())), dim3(R * 64 * epc_sets<NR>()), 0,
