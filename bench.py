@@ -859,7 +859,7 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
                         "(put + the leader's follow + one follow_many for the four followers, window %d); the four AppendEntries and their handlers "
                         "are one launch (smr_raft_cluster_replicate)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
-            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 3, "bytes": 4},
+            "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 1 if os.environ.get("SMR_RAFT_CLUSTER_TICK", "1") != "0" else 3, "bytes": 4},
             "shards_delivered_by_the_put_launch": sum(st.delivered() for st in stores),
             "roofline": {"bound": "hbm", "kernel": "ps_put_deliver_kernel<3, true> + ps_plan_kernel + ps_bytes_plan_many_kernel + ps_bytes_many_kernel",
                          "achieved": moved / (us_bytes * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": moved / (us_bytes * 1e-6) / 1e9 / HBM_PEAK_GBS,

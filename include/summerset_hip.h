@@ -571,6 +571,18 @@ int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev
  * Raft or all CRaft replicas (CRaft: msgs[k].entry_mask = what follower k is sent). */
 int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
                                const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, void *stream);
+/* A co-located cluster's steady tick in ONE launch (round 6): smr_raft_leader_append_emit(leader, n_new_dev, first_sent_dev), then
+ * smr_raft_cluster_replicate(leader, n, followers, first_dev, msgs, replies), then smr_raft_leader_handle_replies(leader, reply_term_dev,
+ * end_slot_dev, conflict_term_dev, conflict_slot_dev, flags_dev, order_dev) -- handle_req_batch + the fan-out of raft/durability.rs:28-88,
+ * the followers' handle_msg_append_entries (raft/messages.rs:13-218, craft/messages.rs:14-254) and the leader's
+ * handle_msg_append_entries_reply (raft/messages.rs:222-335, craft/messages.rs:256-404) -- with the state, messages, replies and counters
+ * of the three calls.  A block owns 64 groups: the leader's wavefront, one wavefront per follower, a block barrier between the steps.
+ * For the replies to be this tick's, first_dev[k] points at row (follower k's id) of first_sent_dev and replies[k] at that row of
+ * the [R][G] reply arrays (any other arrangement is taken as given: the three calls would read the same memory). */
+int smr_raft_cluster_tick(smr_raft_leader *leader, const uint32_t *n_new_dev, uint32_t *first_sent_dev, uint32_t n, smr_raft_leader *const *followers,
+                          const uint32_t *const *first_dev, const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies,
+                          const uint64_t *reply_term_dev, const uint32_t *end_slot_dev, const uint64_t *conflict_term_dev,
+                          const uint32_t *conflict_slot_dev, const uint8_t *flags_dev, const uint32_t *order_dev, void *stream);
 int smr_raft_replica_dump_votes(smr_raft_leader *l, uint8_t *voted_for_host, uint8_t *votes_host, uint32_t *n_exec_host,
                                 uint32_t *n_trunc_host);
 /* The CRaft FOLLOWER (after smr_raft_craft_enable): smr_raft_replica_handle_append_entries then follows the fork's

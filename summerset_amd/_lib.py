@@ -273,6 +273,7 @@ SYMBOLS = [
     ("smr_raft_leader_append_emit", _i, [_vp, _vp, _vp, _vp]),
     ("smr_raft_leader_gather_entries", _i, [_vp, _vp, C.POINTER(RaftAppendEntries), _vp]),
     ("smr_raft_cluster_replicate", _i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(RaftAppendEntries), C.POINTER(RaftAppendReply), _vp]),
+    ("smr_raft_cluster_tick", _i, [_vp, _vp, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(RaftAppendEntries), C.POINTER(RaftAppendReply), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_enable", _i, [_vp, _u8, _u8]),
     ("smr_raft_craft_bcast_heartbeats", _i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("smr_raft_craft_switch_assignment_mode", _i, [_vp, _vp, _vp]),

@@ -123,38 +123,42 @@ __device__ __forceinline__ void raft_append_body(const RaftView &v, uint32_t g, 
     }
 }
 
+// smr_raft_leader_append(_emit) for one group's lane (raft_append_kernel; the first step of raft_cluster_tick_kernel)
+template <int NR>
+__device__ __forceinline__ void raft_append_lane(const RaftView &v, uint32_t g, const uint32_t *__restrict__ n_new, uint32_t *__restrict__ ae_first,
+                                                 unsigned int (&c)[4]) {
+    uint32_t fs[NR];                                     // first slot sent to each peer by this call's appends
+#pragma unroll
+    for (int p = 0; p < NR; p++) fs[p] = 0xFFFFFFFFu;
+    const uint32_t n = n_new[g];
+    if (n) {
+        if (v.role[g] != ROLE_LEADER) c[1] += n;           // request.rs:19-42 redirect
+        else {
+            uint32_t len = v.log_len[g];
+            const uint32_t start = v.start_slot[g], snap = v.last_snap[g];
+            const uint64_t term = v.curr_term[g];
+            uint32_t tn[NR];
+#pragma unroll
+            for (int p = 0; p < NR; p++) tn[p] = (uint32_t)p < v.R ? v.try_next_slot[(size_t)p * v.G + g] : 0;
+            raft_append_body<NR>(v, g, n, len, start, snap, term, tn, fs, c);
+            v.log_len[g] = len;
+            if (len > v.W && len - v.W > v.ring_lo[g]) v.ring_lo[g] = len - v.W;
+#pragma unroll
+            for (int p = 0; p < NR; p++)
+                if ((uint32_t)p < v.R && (uint32_t)p != v.me) v.try_next_slot[(size_t)p * v.G + g] = tn[p];
+        }
+    }
+    if (ae_first) {
+#pragma unroll
+        for (int p = 0; p < NR; p++) if ((uint32_t)p < v.R) ae_first[(size_t)p * v.G + g] = fs[p];
+    }
+}
 template <int NR>
 __global__ __launch_bounds__(256) void raft_append_kernel(const RaftView v, const uint32_t *__restrict__ n_new,
                                                           uint32_t *__restrict__ ae_first) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
-    if (g < v.G) {
-        uint32_t fs[NR];                                     // first slot sent to each peer by this call's appends
-#pragma unroll
-        for (int p = 0; p < NR; p++) fs[p] = 0xFFFFFFFFu;
-        const uint32_t n = n_new[g];
-        if (n) {
-            if (v.role[g] != ROLE_LEADER) c[1] = n;            // request.rs:19-42 redirect
-            else {
-                uint32_t len = v.log_len[g];
-                const uint32_t start = v.start_slot[g], snap = v.last_snap[g];
-                const uint64_t term = v.curr_term[g];
-                uint32_t tn[NR];
-#pragma unroll
-                for (int p = 0; p < NR; p++) tn[p] = (uint32_t)p < v.R ? v.try_next_slot[(size_t)p * v.G + g] : 0;
-                raft_append_body<NR>(v, g, n, len, start, snap, term, tn, fs, c);
-                v.log_len[g] = len;
-                if (len > v.W && len - v.W > v.ring_lo[g]) v.ring_lo[g] = len - v.W;
-#pragma unroll
-                for (int p = 0; p < NR; p++)
-                    if ((uint32_t)p < v.R && (uint32_t)p != v.me) v.try_next_slot[(size_t)p * v.G + g] = tn[p];
-            }
-        }
-        if (ae_first) {
-#pragma unroll
-            for (int p = 0; p < NR; p++) if ((uint32_t)p < v.R) ae_first[(size_t)p * v.G + g] = fs[p];
-        }
-    }
+    if (g < v.G) raft_append_lane<NR>(v, g, n_new, ae_first, c);
     raft_flush(v, c);
 }
 
@@ -366,6 +370,33 @@ __device__ __forceinline__ void raft_replies_body(const RaftView &v, const Craft
     }
 }
 
+// smr_raft_leader_handle_replies for one group's lane (raft_replies_kernel; the last step of raft_cluster_tick_kernel)
+template <bool CRAFT, int NR>
+__device__ __forceinline__ void raft_replies_lane(const RaftView &v, const CraftView &cv, uint32_t g, const uint64_t *__restrict__ reply_term,
+                                                  const uint32_t *__restrict__ end_slot, const uint64_t *__restrict__ conflict_term,
+                                                  const uint32_t *__restrict__ conflict_slot, const uint8_t *__restrict__ flags,
+                                                  const uint32_t *__restrict__ order, unsigned int (&c)[4]) {
+    uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
+    if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
+    RaftLeaderRegs<NR> S;
+    S.load(v, g);
+    uint32_t rf[NR], res[NR];
+    uint64_t rtm[NR];
+#pragma unroll
+    for (int p = 0; p < NR; p++) {
+        const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
+        const size_t o = (size_t)p * v.G + g;
+        rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
+    }
+    raft_replies_body<CRAFT, NR>(v, cv, g, S, order ? order[g] : SMR_CTL_IDENTITY, rf, rtm, res, conflict_term, conflict_slot, commit_need, heard, c);
+    S.store(v, g);
+    if (CRAFT && heard) {                                   // heartbeat.rs:284-290 update_heard_cnt
+        for (uint32_t p = 0; p < v.R; p++)
+            if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
+        const uint32_t al = cv.alive[g];
+        if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
+    }
+}
 template <bool CRAFT, int NR>
 __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, const uint64_t *__restrict__ reply_term,
                                                            const uint32_t *__restrict__ end_slot,
@@ -375,28 +406,7 @@ __global__ __launch_bounds__(256) void raft_replies_kernel(const RaftView v, con
                                                            const uint32_t *__restrict__ order, const CraftView cv) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     unsigned int c[4] = {0, 0, 0, 0};
-    if (g < v.G) {
-        uint32_t heard = 0, commit_need = v.thresh - 1;     // peers needed besides me
-        if (CRAFT && cv.full_copy[g]) commit_need = cv.quorum - 1;
-        RaftLeaderRegs<NR> S;
-        S.load(v, g);
-        uint32_t rf[NR], res[NR];
-        uint64_t rtm[NR];
-#pragma unroll
-        for (int p = 0; p < NR; p++) {
-            const bool on = (uint32_t)p < v.R && (uint32_t)p != v.me;
-            const size_t o = (size_t)p * v.G + g;
-            rf[p] = on ? flags[o] : 0u; rtm[p] = on ? reply_term[o] : 0ull; res[p] = on ? end_slot[o] : 0u;
-        }
-        raft_replies_body<CRAFT, NR>(v, cv, g, S, order ? order[g] : SMR_CTL_IDENTITY, rf, rtm, res, conflict_term, conflict_slot, commit_need, heard, c);
-        S.store(v, g);
-        if (CRAFT && heard) {                                   // heartbeat.rs:284-290 update_heard_cnt
-            for (uint32_t p = 0; p < v.R; p++)
-                if ((heard >> p) & 1u) cv.hb_replied[(size_t)p * v.G + g] += 1;
-            const uint32_t al = cv.alive[g];
-            if ((al | heard) != al) cv.alive[g] = (uint8_t)(al | heard);
-        }
-    }
+    if (g < v.G) raft_replies_lane<CRAFT, NR>(v, cv, g, reply_term, end_slot, conflict_term, conflict_slot, flags, order, c);
     raft_flush(v, c);
 }
 
@@ -1146,6 +1156,52 @@ __global__ __launch_bounds__(256) void raft_replicate_kernel(const RaftView lv, 
                                     r_term, r_end, r_cterm, r_cslot);
 }
 
+// A co-located cluster's whole steady tick in ONE launch (round 6, VERDICT r5 #5: "CRaft's engine tick as one launch, like RSPaxos's"):
+// smr_raft_leader_append_emit + smr_raft_cluster_replicate + smr_raft_leader_handle_replies.  Groups never talk to each other, so the
+// three steps only have to be ordered within a group: a block owns 64 groups, wavefront 0 is the leader, wavefront 1 + k follower k,
+// and a block barrier stands where the three launches have a kernel boundary (HIP's barrier carries a workgroup-scope release /
+// acquire and the wavefronts of a block share their CU's L1: what the leader's wavefront stored is what the followers' load, and
+// back -- as mp_ticks_fused relies on).  Same state, messages, replies and counters as the three calls.
+struct RaftTickRest {
+    const uint32_t *n_new; uint32_t *ae_first;
+    const uint64_t *reply_term, *conflict_term; const uint32_t *end_slot, *conflict_slot, *order; const uint8_t *flags;
+    uint32_t n;
+};
+template <bool CRAFT, int NR>
+__global__ __launch_bounds__(64 * (RMAX + 1)) void raft_cluster_tick_kernel(const RaftView lv, const CraftView cv, const RaftRepl A, const RaftTickRest T) {
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, g = blockIdx.x * 64u + lane;
+    unsigned int c[4] = {0, 0, 0, 0};
+    if (w == 0 && g < lv.G) raft_append_lane<NR>(lv, g, T.n_new, T.ae_first, c);
+    __syncthreads();
+    if (w >= 1u && w <= T.n) {
+        const RaftView *fvp = nullptr;
+        uint8_t *partial = nullptr, *m_flags = nullptr, *m_leader = nullptr, *r_flags = nullptr;
+        const uint32_t *first = nullptr;
+        uint64_t *m_term = nullptr, *m_prev_term = nullptr, *m_eterm = nullptr, *r_term = nullptr, *r_cterm = nullptr;
+        uint32_t *m_prev_slot = nullptr, *m_n = nullptr, *m_lc = nullptr, *m_ls = nullptr, *r_end = nullptr, *r_cslot = nullptr;
+        const uint8_t *m_emask = nullptr;
+#pragma unroll
+        for (int k = 0; k < (int)RMAX; k++)
+            if (w == (unsigned)k + 1u) {
+                fvp = A.fv[k]; partial = A.partial[k]; first = A.first[k]; m_flags = A.m_flags[k]; m_leader = A.m_leader[k]; m_term = A.m_term[k];
+                m_prev_term = A.m_prev_term[k]; m_eterm = A.m_eterm[k]; m_prev_slot = A.m_prev_slot[k]; m_n = A.m_n[k]; m_lc = A.m_lc[k];
+                m_ls = A.m_ls[k]; m_emask = A.m_emask[k]; r_flags = A.r_flags[k]; r_term = A.r_term[k]; r_cterm = A.r_cterm[k]; r_end = A.r_end[k];
+                r_cslot = A.r_cslot[k];
+            }
+        const RaftView fv = *fvp;                         // a copy in registers
+        if (g < lv.G) {
+            raft_gather_body(lv, g, first, A.K, m_flags, m_leader, m_term, m_prev_slot, m_prev_term, m_n, m_eterm, m_lc, m_ls);
+            raft_append_entries_body<CRAFT>(fv, g, m_flags, m_leader, m_term, m_prev_slot, m_prev_term, m_n, m_eterm, m_emask, partial, A.K, m_lc, m_ls,
+                                            r_flags, r_term, r_end, r_cterm, r_cslot);
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        if (g < lv.G) raft_replies_lane<CRAFT, NR>(lv, cv, g, T.reply_term, T.end_slot, T.conflict_term, T.conflict_slot, T.flags, T.order, c);
+        raft_flush(lv, c);
+    }
+}
+
 }  // namespace smr
 
 using namespace smr;
@@ -1593,11 +1649,10 @@ int smr_raft_leader_gather_entries(smr_raft_leader *l, const uint32_t *first_dev
     return SMR_OK;
 }
 
-int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
-                               const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, void *stream) {
+static int raft_repl_setup(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
+                           const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, RaftRepl &A) {
     if (!leader || !followers || !first_dev || !msgs || !replies) return fail(SMR_ERR_ARG, "raft replicate: null argument");
     if (n == 0 || n > RMAX) return fail(SMR_ERR_ARG, "raft replicate: 1 .. 8 followers");
-    RaftRepl A;
     memset(&A, 0, sizeof(A));
     A.K = msgs[0].max_entries;
     for (uint32_t k = 0; k < n; k++) {
@@ -1628,9 +1683,35 @@ int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_lea
         A.m_emask[k] = f->craft ? m.entry_mask : nullptr;
         A.r_flags[k] = r.flags; A.r_term[k] = r.term; A.r_end[k] = r.end_slot; A.r_cterm[k] = r.conflict_term; A.r_cslot[k] = r.conflict_slot;
     }
+    return SMR_OK;
+}
+
+int smr_raft_cluster_replicate(smr_raft_leader *leader, uint32_t n, smr_raft_leader *const *followers, const uint32_t *const *first_dev,
+                               const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies, void *stream) {
+    RaftRepl A;
+    if (int rc = raft_repl_setup(leader, n, followers, first_dev, msgs, replies, A)) return rc;
     const dim3 grid((leader->v.G + 255) / 256, n), block(256);
     if (leader->craft) hipLaunchKernelGGL(raft_replicate_kernel<true>, grid, block, 0, (hipStream_t)stream, leader->v, A);
     else hipLaunchKernelGGL(raft_replicate_kernel<false>, grid, block, 0, (hipStream_t)stream, leader->v, A);
+    SMR_HIP_TRY(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_raft_cluster_tick(smr_raft_leader *leader, const uint32_t *n_new_dev, uint32_t *first_sent_dev, uint32_t n, smr_raft_leader *const *followers,
+                          const uint32_t *const *first_dev, const smr_raft_append_entries *msgs, const smr_raft_append_reply *replies,
+                          const uint64_t *reply_term_dev, const uint32_t *end_slot_dev, const uint64_t *conflict_term_dev,
+                          const uint32_t *conflict_slot_dev, const uint8_t *flags_dev, const uint32_t *order_dev, void *stream) {
+    if (!leader || !n_new_dev || !first_sent_dev || !reply_term_dev || !end_slot_dev || !flags_dev) return fail(SMR_ERR_ARG, "raft cluster tick: null argument");
+    RaftRepl A;
+    if (int rc = raft_repl_setup(leader, n, followers, first_dev, msgs, replies, A)) return rc;
+    const RaftTickRest T{n_new_dev, first_sent_dev, reply_term_dev, conflict_term_dev, end_slot_dev, conflict_slot_dev, order_dev, flags_dev, n};
+    const CraftView cv = leader->craft ? leader->cv : CraftView{};
+    const dim3 grid((leader->v.G + 63) / 64), block(64 * (n + 1));
+    hipStream_t st = (hipStream_t)stream;
+#define RAFT_TICK(C, N) hipLaunchKernelGGL((raft_cluster_tick_kernel<C, N>), grid, block, 0, st, leader->v, cv, A, T)
+    if (leader->v.R <= 5) { if (leader->craft) RAFT_TICK(true, 5); else RAFT_TICK(false, 5); }
+    else { if (leader->craft) RAFT_TICK(true, RMAX); else RAFT_TICK(false, RMAX); }
+#undef RAFT_TICK
     SMR_HIP_TRY(hipGetLastError());
     return SMR_OK;
 }

@@ -83,6 +83,26 @@ class RaftLeaderGroup:
         check(self._L.smr_raft_cluster_replicate(self._h, n, hs, fs, ms, rs, stream_ptr(stream)))
         return msgs
 
+    def cluster_tick(self, n_new, first, followers, msgs, replies, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None,
+                     order=None, entry_masks=None, stream=None):
+        """a co-located cluster's steady tick in ONE launch (`smr_raft_cluster_tick`): `handle_req_batch_emit(n_new, out=first)` +
+        `replicate_many(followers, [first[id of follower k]], msgs, replies, entry_masks)` + `handle_msg_append_entries_reply(
+        reply_term, end_slot, flags, conflict_term, conflict_slot, order)`; replies[k] = follower k's rows of the [R, G] reply
+        arrays.  Returns msgs."""
+        n = len(followers)
+        hs = (C.c_void_p * n)(*[f._h for f in followers])
+        fs = (C.c_void_p * n)(*[_ptr(first[f.me]) for f in followers])
+        ms, rs = (RaftAppendEntries * n)(), (RaftAppendReply * n)()
+        for k in range(n):
+            m, r = msgs[k], replies[k]
+            ms[k] = RaftAppendEntries(_ptr(m["flags"]), _ptr(m["leader"]), _ptr(m["term"]), _ptr(m["prev_slot"]), _ptr(m["prev_term"]),
+                                      _ptr(m["n_entries"]), _ptr(m["entry_term"]), int(m["entry_term"].shape[0]), _ptr(m["leader_commit"]),
+                                      _ptr(m["last_snap"]), _ptr(entry_masks[k]) if entry_masks is not None else None)
+            rs[k] = RaftAppendReply(*[_ptr(r[x]) for x in ("flags", "term", "end_slot", "conflict_term", "conflict_slot")])
+        check(self._L.smr_raft_cluster_tick(self._h, _ptr(n_new), _ptr(first), n, hs, fs, ms, rs, _ptr(reply_term), _ptr(end_slot),
+                                            _ptr(conflict_term), _ptr(conflict_slot), _ptr(flags), _ptr(order), stream_ptr(stream)))
+        return msgs
+
     def new_message(self, max_entries, device):
         """the tensors of one AppendEntries message (what `gather_entries` allocates when it is given no `out`)"""
         import torch

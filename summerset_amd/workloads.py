@@ -6,6 +6,8 @@ launch mode from here: `headline_cluster` / `headline_stream` / `drive_headline`
 (reference: multipaxos/request.rs:156-224, messages.rs:295-443), `config4_*` for the RSPaxos one-launch tick with the
 fused encode + fan-out (rspaxos/request.rs:71-142).
 """
+import os
+
 import numpy as np
 
 # what the headline line is quoted on (BASELINE.json: 65 536 groups x 5 replicas; bench.py's defaults)
@@ -155,14 +157,31 @@ def craft_payload_cluster(G=CRAFT_PAYLOAD["G"], W=CRAFT_PAYLOAD["W"], L=CRAFT_PA
     return reps, stores, bufs                                            # a tick is its handlers' launches and nothing else
 
 
-def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, one_launch=True, one_call=True):
+def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, one_launch=True, one_call=True, one_tick_launch=None,
+                       replies_first=False):
     """one tick: the leader appends one batch per group (slot [G] int32 = where: in the steady state log_len before the call = 1 +
     the tick's number) and `put`s the serialized batches `src` (uint8 [G, L]); its follow; per follower the AppendEntries out of the
     leader's log + `handle_msg_append_entries` -- all four in ONE launch (`smr_raft_cluster_replicate`; one_launch=False: the eight
     calls it stands for); ONE follow_many for the four followers; the replies' match-index quorum at the leader.  Returns the
-    AppendEntries messages (for a checker)."""
+    AppendEntries messages (for a checker).
+    one_tick_launch (round 6, with one_launch and one_call): the engines' three launches -- append, replicate, replies -- as ONE
+    (`smr_raft_cluster_tick`), the tick's bytes behind it; replies_first: the separate calls in that order (its reference)."""
     from .rsp_payload import CRaftPayloadStore
     R = len(reps)
+    if one_tick_launch is None:                                          # (SMR_RAFT_CLUSTER_TICK=0: the three launches, for A/B runs)
+        one_tick_launch = os.environ.get("SMR_RAFT_CLUSTER_TICK", "1") != "0"
+    if one_tick_launch and one_launch and one_call:
+        qs = list(range(1, R))
+        for q in qs:
+            if bufs["msg"][q] is None:
+                bufs["msg"][q] = reps[0].new_message(1, bufs["first"].device)
+        rep_rows = [dict(flags=bufs["fl"][q], term=bufs["rt"][q], end_slot=bufs["es"][q], conflict_term=bufs["ct"][q], conflict_slot=bufs["cs"][q])
+                    for q in qs]
+        reps[0].cluster_tick(bufs["ones"], bufs["first"], [reps[q] for q in qs], [bufs["msg"][q] for q in qs], rep_rows, bufs["rt"], bufs["es"],
+                             bufs["fl"], entry_masks=[bufs["em"][q] for q in qs])
+        if bytes_:
+            stores[0].put_follow_all(reps[0], slot, src, stores[1:], reps[1:], lens=lens)
+        return {q: bufs["msg"][q] for q in qs}
     first = reps[0].handle_req_batch_emit(bufs["ones"], out=bufs["first"])
     if bytes_ and not one_call:
         stores[0].put(reps[0], slot, src, lens)
@@ -182,11 +201,14 @@ def craft_payload_tick(reps, stores, bufs, slot, src, lens=None, bytes_=True, on
         m = bufs["msg"][q] = reps[0].gather_entries(first[q], 1, out=bufs["msg"][q])
         reps[q].handle_msg_append_entries(**m, entry_mask=bufs["em"][q], out=reply(q))
         msgs[q] = m
+    if replies_first:
+        reps[0].handle_msg_append_entries_reply(bufs["rt"], bufs["es"], bufs["fl"])
     if bytes_ and one_call:            # round 6: put + the leader's follow + the followers' follow_many as ONE call, four launches --
         stores[0].put_follow_all(reps[0], slot, src, stores[1:], reps[1:], lens=lens)   # behind the followers' handlers (their masks)
     elif bytes_:
         CRaftPayloadStore.follow_many(stores[1:], reps[1:], source=stores[0])
-    reps[0].handle_msg_append_entries_reply(bufs["rt"], bufs["es"], bufs["fl"])
+    if not replies_first:
+        reps[0].handle_msg_append_entries_reply(bufs["rt"], bufs["es"], bufs["fl"])
     return msgs
 
 

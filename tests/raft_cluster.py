@@ -68,6 +68,22 @@ class NumpyRaft:
         rl = dict(flags=np.uint8, term=np.uint64, end_slot=np.uint32, conflict_term=np.uint64, conflict_slot=np.uint32)
         return [(self._n(m, ml), self._n(r, rl)) for m, r in zip(msgs, reps)]
 
+    def cluster_tick(self, n_new, followers, K):
+        """my append + my AppendEntries for `followers` + their handlers + my reply handler in ONE launch (`smr_raft_cluster_tick`);
+        returns (first [R][G], [(message, reply)]) as numpy"""
+        torch, dev, G, R = self.torch, self.cuda, self.G, self.R
+        msgs = [self.e.new_message(K, dev) for _ in followers]
+        z = lambda dt: torch.zeros((R, G), dtype=dt, device=dev)
+        arr = dict(flags=z(torch.uint8), term=z(torch.int64), end_slot=z(torch.int32), conflict_term=z(torch.int64), conflict_slot=z(torch.int32))
+        first = torch.zeros((R, G), dtype=torch.int32, device=dev)
+        reps = [{k: v[f.e.me] for k, v in arr.items()} for f in followers]
+        self.e.cluster_tick(self._t(np.ascontiguousarray(n_new)), first, [f.e for f in followers], msgs, reps, arr["term"], arr["end_slot"], arr["flags"],
+                            arr["conflict_term"], arr["conflict_slot"])
+        ml = dict(flags=np.uint8, leader=np.uint8, term=np.uint64, prev_slot=np.uint32, prev_term=np.uint64, n_entries=np.uint32,
+                  entry_term=np.uint64, leader_commit=np.uint32, last_snap=np.uint32)
+        rl = dict(flags=np.uint8, term=np.uint64, end_slot=np.uint32, conflict_term=np.uint64, conflict_slot=np.uint32)
+        return first.cpu().numpy().view(np.uint32), [(self._n(m, ml), self._n(r, rl)) for m, r in zip(msgs, reps)]
+
     def handle_replies(self, reply_term, end_slot, flags, conflict_term=None, conflict_slot=None, order=None):
         self.e.handle_msg_append_entries_reply(self._t(reply_term), self._t(end_slot), self._t(flags), self._t(conflict_term),
                                                self._t(conflict_slot), self._t(order))
@@ -79,12 +95,14 @@ class NumpyRaft:
         return self.e.dump_votes()
 
 
-def tick(reps, timeouts, n_new, K, via=None, sender_major=False, one_launch=False, seen=None):
+def tick(reps, timeouts, n_new, K, via=None, sender_major=False, one_launch=False, seen=None, sender_ticks=False):
     """timeouts[r][G]: HearTimeout source at replica r (0xFF none); n_new[r][G]: client batches handed to
     replica r (those that do not lead redirect them).  Returns nothing; state lives in the replicas.
     sender_major: the replication step goes sender by sender (every follower handles sender 0's message, then sender 1's ..)
     instead of receiver by receiver -- the order in which `one_launch` (NumpyRaft.replicate_many: a sender's messages and their
     handlers in one launch) can stand for the calls; seen (a list): the (sender, receiver, message, reply) tuples of the step.
+    sender_ticks: a sender's append, replication and replies before the next sender's append -- the order in which `one_launch="tick"`
+    (NumpyRaft.cluster_tick: all three in one launch) can stand for the calls.
     via (optional): via(s, rt, es, fl, ct, cs) -> the same five [R][G] arrays -- the AppendEntriesReplies on their way to
     leader s (tests/test_zz_reply_ingest_gpu.py sends them as frames through the device parser)."""
     R = len(reps)
@@ -106,6 +124,26 @@ def tick(reps, timeouts, n_new, K, via=None, sender_major=False, one_launch=Fals
                 term[q] = vote[(q, c)]["term"]; flags[q] = vote[(q, c)]["flags"] & 1
         reps[c].handle_vote_replies(term, flags)
     # replication
+    if sender_ticks:                    # sender by sender, each its WHOLE tick: append, AppendEntries + handlers, replies
+        for s in range(R):
+            qs = [q for q in range(R) if q != s]
+            if one_launch == "tick":
+                _, out = reps[s].cluster_tick(n_new[s], [reps[q] for q in qs], K)
+            else:
+                f = reps[s].append_emit(np.ascontiguousarray(n_new[s]))
+                out = []
+                for q in qs:
+                    m = reps[s].gather_entries(f[q], K)
+                    out.append((m, reps[q].handle_append_entries(**m)))
+                rt = np.zeros((R, G), np.uint64); es = np.zeros((R, G), np.uint32); fl = np.zeros((R, G), np.uint8)
+                ct = np.zeros((R, G), np.uint64); cs = np.zeros((R, G), np.uint32)
+                for q, (m, r_) in zip(qs, out):
+                    rt[q] = r_["term"]; es[q] = r_["end_slot"]; fl[q] = r_["flags"]; ct[q] = r_["conflict_term"]; cs[q] = r_["conflict_slot"]
+                reps[s].handle_replies(rt, es, fl, ct, cs)
+            if seen is not None:
+                for q, (m, r_) in zip(qs, out):
+                    seen.append((s, q, m, r_))
+        return
     first = [reps[r].append_emit(np.ascontiguousarray(n_new[r])) for r in range(R)]
     rep = {}
     if sender_major:

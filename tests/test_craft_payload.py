@@ -98,7 +98,7 @@ def run_one_launch_replication_is_the_eight_calls(dev, G=150, W=8, L=40, T=11):
         slot = torch.full((G,), t + 1, dtype=torch.int32, device=dev)
         src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
         ma = workloads.craft_payload_tick(*a, slot, src, one_launch=False)
-        mb = workloads.craft_payload_tick(*b, slot, src, one_launch=True)
+        mb = workloads.craft_payload_tick(*b, slot, src, one_launch=True, one_tick_launch=False)
         for q in ma:
             for k in ma[q]:
                 assert torch.equal(ma[q][k], mb[q][k]), (t, q, k)
@@ -155,7 +155,7 @@ def run_craft_one_call_is_the_three_calls(dev, G=150, W=8, L=40, T=11):
         src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
         lens = torch.from_numpy(rng.integers(1, L + 1, G).astype(np.int32)).to(dev)
         workloads.craft_payload_tick(*a, slot, src, lens=lens, one_call=False)
-        workloads.craft_payload_tick(*b, slot, src, lens=lens, one_call=True)
+        workloads.craft_payload_tick(*b, slot, src, lens=lens, one_call=True, one_tick_launch=False)
         for r in range(len(a[0])):
             da, db = a[0][r].dump(), b[0][r].dump()
             for k in da:
@@ -187,6 +187,41 @@ def run_rspaxos_one_call_is_the_three_calls(dev, G=130, W=8, L=67, T=12):
             _stores_equal(a[2][r], b[2][r], 2, W, (t, r))
     assert a[2][1].counters()["copied"] > 0
     assert a[2][1].delivered() == 0 and 0 < b[2][1].delivered() <= b[2][1].counters()["copied"]
+
+
+def run_one_launch_tick_is_the_three_launches(dev, G=150, W=8, L=40, T=11):
+    """two CRaft clusters on the same inputs: the engines' tick of one as append / replicate / replies (three launches, the replies in
+    front of the tick's bytes), of the other as `smr_raft_cluster_tick` (one launch) -- engines, messages, the leader's reply arrays,
+    stores and counters identical tick by tick; W = 8: the ring wraps.  Then the same without the stores on a plain Raft cluster."""
+    import torch
+    from summerset_amd import workloads
+    a, b = workloads.craft_payload_cluster(G, W, L, 1, dev), workloads.craft_payload_cluster(G, W, L, 1, dev)
+    rng = np.random.default_rng(17)
+    for t in range(T):
+        slot = torch.full((G,), t + 1, dtype=torch.int32, device=dev)
+        src = torch.from_numpy(rng.integers(0, 256, (G, L), dtype=np.uint8)).to(dev)
+        lens = torch.from_numpy(rng.integers(1, L + 1, G).astype(np.int32)).to(dev)
+        ma = workloads.craft_payload_tick(*a, slot, src, lens=lens, one_tick_launch=False, replies_first=True)
+        mb = workloads.craft_payload_tick(*b, slot, src, lens=lens, one_tick_launch=True)
+        for q in ma:
+            for k in ma[q]:
+                assert torch.equal(ma[q][k], mb[q][k]), (t, q, k)
+        for k in ("first", "rt", "es", "fl", "ct", "cs"):
+            assert torch.equal(a[2][k], b[2][k]), (t, k)
+        for r in range(len(a[0])):
+            da, db = a[0][r].dump(), b[0][r].dump()
+            for k in da:
+                assert np.array_equal(da[k], db[k]), (t, r, k)
+            assert a[0][r].total_commits() == b[0][r].total_commits(), (t, r)
+            _stores_equal(a[1][r], b[1][r], 1, W, (t, r))
+    assert int(a[0][0].dump()["last_commit"].min()) >= T - 2
+
+
+def test_one_launch_tick_on_the_emulator():
+    import hostsim
+    hostsim.build()
+    with hostsim.patched():
+        run_one_launch_tick_is_the_three_launches("cpu", G=70)
 
 
 def test_one_call_byte_path_on_the_emulator():

@@ -60,6 +60,12 @@ def test_raft_kernels_on_the_host(sim, oracle):
         assert t.run_one_launch_replication("cpu", oracle, G=200, W=64, K=8, T=12) > 300     # smr_raft_cluster_replicate == the 2 n calls == the oracle
 
 
+def test_raft_one_launch_tick_on_the_host(sim, oracle):
+    import test_raft_gpu as t
+    with sim.patched():
+        assert t.run_one_launch_tick("cpu", oracle, G=200, W=64, K=8, T=12) > 300            # smr_raft_cluster_tick == the 2 + 2 n calls == the oracle
+
+
 def test_craft_leader_kernels_on_the_host(sim, oracle):
     """the CRaft leader variant (a15): reply kernel with the fork's rules, heartbeat tick with the reply counters and the
     full-copy fall-back, mode switches, shard assignment + the RS kernels"""

@@ -299,5 +299,61 @@ def run_one_launch_replication(dev, oracle, G=600, W=64, K=8, T=16):
     return n_msg
 
 
+def run_one_launch_tick(dev, oracle, G=600, W=64, K=8, T=16):
+    """`smr_raft_cluster_tick` -- a sender's append, its AppendEntries for its four peers, their handlers and its reply handler in ONE
+    launch -- in the closed loop of tests/raft_cluster.py (elections, a second election in a third of the groups, conflicts and
+    truncations behind it), every sender's whole tick before the next sender's: a cluster that runs the 2 + 2 n calls, one that runs
+    the one launch and five oracles stay identical -- every message, every reply, every replica's state, tick by tick"""
+    import raft_cluster as rc
+    from summerset_amd import RaftLeaderGroup
+    R = 5
+    mk = lambda: [rc.NumpyRaft(RaftLeaderGroup(G, R, leader_id=r, window=W, term=1), dev) for r in range(R)]
+    calls, fused = mk(), mk()
+    orcs = [oracle.RaftOracle(G, R, W, leader_id=r, term=1) for r in range(R)]
+    for x in calls + fused + orcs:
+        x.preset(rc.FOLLOWER, 0xFF, 0)
+    rng = np.random.default_rng(19)
+    none = np.full((R, G), 0xFF, np.uint8)
+    n_msg = 0
+
+    def step(to, n_new, where):
+        nonlocal n_msg
+        seen = ([], [], [])
+        for reps, one, sn in ((calls, False, seen[0]), (fused, "tick", seen[1]), (orcs, False, seen[2])):
+            rc.tick(reps, to, n_new, K, sender_ticks=True, one_launch=one, seen=sn)
+        for (s, q, m0, r0), (_, _, m1, r1), (_, _, m2, r2) in zip(*seen):
+            on = m2["flags"] != 0
+            n_msg += int(on.sum())
+            for k in m2:
+                assert np.array_equal(m0[k], m1[k]), (where, "message", s, q, k)
+                sel = (slice(None), on) if k == "entry_term" else on
+                assert np.array_equal(np.asarray(m1[k])[sel].astype(np.uint64), np.asarray(m2[k])[sel].astype(np.uint64)), (where, "message vs oracle", s, q, k)
+            for k in r2:
+                assert np.array_equal(r0[k], r1[k]) and np.array_equal(r1[k].astype(np.uint64), r2[k].astype(np.uint64)), (where, "reply", s, q, k)
+        for r in range(R):
+            a, b, c = calls[r].dump(), fused[r].dump(), orcs[r].dump()
+            for n in c:
+                assert np.array_equal(a[n], b[n]) and np.array_equal(b[n], c[n]), (where, r, n)
+
+    to = none.copy()
+    to[np.arange(G) % R, np.arange(G)] = 0xFE
+    step(to, np.zeros((R, G), np.uint32), "election")
+    for t in range(T):
+        n_new = rng.integers(0, 4, (R, G)).astype(np.uint32)
+        to = none.copy()
+        if t == 7:
+            gs = np.arange(0, G, 3)
+            to[(gs + 2) % R, gs] = (gs % R).astype(np.uint8)
+        step(to, n_new, t)
+    d = [o.dump() for o in orcs]
+    assert min(int(np.stack([x["last_commit"] for x in d]).max(axis=0).min()), 99) > 5
+    assert (np.stack([x["curr_term"] for x in d]).max(axis=0) == 2).any() and n_msg > 1000
+    return n_msg
+
+
+def test_one_launch_tick_is_the_calls_and_the_oracle_s(cuda, oracle):
+    run_one_launch_tick(cuda, oracle)
+
+
 def test_one_launch_replication_is_the_2n_calls_and_the_oracle_s(cuda, oracle):
     run_one_launch_replication(cuda, oracle)

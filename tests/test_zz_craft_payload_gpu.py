@@ -47,3 +47,9 @@ def test_one_call_byte_path_is_the_three_calls(cuda):
     import test_craft_payload as t
     t.run_craft_one_call_is_the_three_calls(cuda, G=1000, W=8, L=200, T=14)
     t.run_rspaxos_one_call_is_the_three_calls(cuda, G=1000, W=8, L=333, T=14)
+
+
+def test_one_launch_tick_is_the_three_launches(cuda):
+    """`smr_raft_cluster_tick` (round 6: append + replicate + replies of a co-located CRaft cluster in one launch) against the three"""
+    import test_craft_payload as t
+    t.run_one_launch_tick_is_the_three_launches(cuda, G=1000, W=8, L=200, T=14)
