@@ -584,7 +584,10 @@ __device__ __forceinline__ void ps_plan_body(const PsView &v, uint32_t flip, con
 }
 
 // rows per lane of a plan launch for a window of W rows (a power of two)
-static inline uint32_t ps_rpl(uint32_t W) { return W >= 4 ? 4u : W; }
+#ifndef PS_RPL_MAX
+#define PS_RPL_MAX 4       // (8: measured, profiles/s33)
+#endif
+static inline uint32_t ps_rpl(uint32_t W) { return W >= PS_RPL_MAX ? (uint32_t)PS_RPL_MAX : W >= 4 ? 4u : W; }
 
 template <int RPL>
 __global__ __launch_bounds__(256) void ps_plan_kernel(const PsView v, const RspPeek e, const PsSrcs S, const uint8_t *__restrict__ sel) {
@@ -1073,7 +1076,10 @@ static int ps_follow(smr_rsp_pstore *s, const RspPeek &pk, uint32_t n_src, smr_r
     const uint32_t cells = v.W * v.G;
     const uint32_t lanes = cells / ps_rpl(v.W);
     switch (ps_rpl(v.W)) {
+    case PS_RPL_MAX: hipLaunchKernelGGL(ps_plan_kernel<PS_RPL_MAX>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
+#if PS_RPL_MAX != 4
     case 4: hipLaunchKernelGGL(ps_plan_kernel<4>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
+#endif
     case 2: hipLaunchKernelGGL(ps_plan_kernel<2>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
     default: hipLaunchKernelGGL(ps_plan_kernel<1>, dim3((lanes + 255) / 256), dim3(256), 0, st, v, pk, S, sel_dev); break;
     }
@@ -1180,7 +1186,10 @@ static int ps_follow_many(uint32_t n, smr_rsp_pstore *const *stores, const RspPe
     const uint32_t cells = v0.W * v0.G;
     const uint32_t lanes = cells / ps_rpl(v0.W);
     switch (ps_rpl(v0.W)) {
+    case PS_RPL_MAX: hipLaunchKernelGGL(ps_plan_many_kernel<PS_RPL_MAX>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
+#if PS_RPL_MAX != 4
     case 4: hipLaunchKernelGGL(ps_plan_many_kernel<4>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
+#endif
     case 2: hipLaunchKernelGGL(ps_plan_many_kernel<2>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
     default: hipLaunchKernelGGL(ps_plan_many_kernel<1>, dim3((lanes + 255) / 256, n), dim3(256), 0, st, M, S, (const uint8_t *)nullptr); break;
     }
@@ -1208,7 +1217,7 @@ static int ps_put_follow_all(smr_rsp_pstore *s, const RspPeek &pk, const uint32_
     if (n) if (int rc = ps_many_setup(n, stores, fpk, s, 0, M, S)) return rc;
     if (n && (stores[0]->v.G != v.G || stores[0]->v.W != v.W || stores[0]->v.n != v.n || stores[0]->v.d != v.d || stores[0]->v.cap_sl != v.cap_sl))
         return fail(SMR_ERR_ARG, "pstore follow_many: the source has another geometry");
-    if (v.W < 4) {
+    if (v.W < PS_RPL_MAX) {
         if (int rc = ps_put(s, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, craft, stream)) return rc;
         if (int rc = ps_follow(s, pk, 0, nullptr, nullptr, nullptr, stream)) return rc;
         return n ? ps_follow_many(n, stores, fpk, s, 0, stream) : SMR_OK;
@@ -1224,12 +1233,12 @@ static int ps_put_follow_all(smr_rsp_pstore *s, const RspPeek &pk, const uint32_
     }
     if (int rc = ps_put(s, a_n_dev, a_slot_dev, a_val_dev, data_dev, data_stride, len_dev, data_len, craft, stream, (n && ps_deliver_on()) ? &dv : nullptr))
         return rc;
-    const uint32_t cells = v.W * v.G, n_plan = (cells / 4u + 255) / 256;
+    const uint32_t cells = v.W * v.G, n_plan = (cells / (uint32_t)PS_RPL_MAX + 255) / 256;
     s->v.flip ^= 1u;
     {
         PsSrcs none;
         memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(ps_plan_kernel<4>, dim3(n_plan), dim3(256), 0, st, v, pk, none, (const uint8_t *)nullptr);
+        hipLaunchKernelGGL(ps_plan_kernel<PS_RPL_MAX>, dim3(n_plan), dim3(256), 0, st, v, pk, none, (const uint8_t *)nullptr);
         SMR_HIP_TRY(hipGetLastError());
     }
     if (!n) {                                                              // no followers here: the leader's bytes in a launch of their own
@@ -1242,7 +1251,7 @@ static int ps_put_follow_all(smr_rsp_pstore *s, const RspPeek &pk, const uint32_
         return SMR_OK;
     }
     ps_many_flip(n, stores, M);
-    hipLaunchKernelGGL(ps_bytes_plan_many_kernel<4>, dim3(PS_LEADER_BYTE_BLOCKS + n_plan, n), dim3(256), 0, st, M, S, s->v);
+    hipLaunchKernelGGL(ps_bytes_plan_many_kernel<PS_RPL_MAX>, dim3(PS_LEADER_BYTE_BLOCKS + n_plan, n), dim3(256), 0, st, M, S, s->v);
     SMR_HIP_TRY(hipGetLastError());
     return ps_many_bytes(n, v, M, S, st);
 }
