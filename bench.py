@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-PMC_FILES = ("t2z_pmc_traffic.json", "t1z_pmc_traffic.json", "r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
+PMC_FILES = ("t3z_pmc_traffic.json", "t2z_pmc_traffic.json", "t1z_pmc_traffic.json", "r9z_pmc_traffic.json", "r8z_pmc_traffic.json", "r8m_pmc_traffic.json", "r6m_pmc_traffic.json", "r5m_pmc_traffic.json", "round3/r4m_pmc_traffic.json")      # the newest committed record first (tools/final_record.sh TAG)
 PMC_FILE = next((os.path.join(ROOT, "profiles", f) for f in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", f))),
                 os.path.join(ROOT, "profiles", PMC_FILES[0]))
 PMC_NOTE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_probe.py, separate runs, gfx950 corrections of "
@@ -727,7 +727,7 @@ def _payload_leg_traffic(name="rspaxos_payload"):
     """HBM bytes per tick of the payload store's kernels from the committed PMC passes over this very leg, or (None, None): the
     sum over every ps_* / craft_* kernel of (bytes per launch x launches per tick), launches per tick = the kernel's launches in
     the profiled run / the run's ticks (recorded in the file by tools/final_record.sh)."""
-    for f in ("t2z_pmc_traffic_%s_leg.json" % name, "t1z_pmc_traffic_%s_leg.json" % name, "r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
+    for f in ("t3z_pmc_traffic_%s_leg.json" % name, "t2z_pmc_traffic_%s_leg.json" % name, "t1z_pmc_traffic_%s_leg.json" % name, "r9z_pmc_traffic_%s_leg.json" % name, "r8z_pmc_traffic_%s_leg.json" % name, "r8m_pmc_traffic_%s_leg.json" % name, "r7g_pmc_traffic_payload_leg.json" if name == "rspaxos_payload" else None):
         if not f:
             continue
         try:
@@ -856,8 +856,8 @@ def craft_payload_leg(torch, dev, ticks=24, warmup=6, G=16384, L=4113, time_us=N
     us_engine = time_us(torch, lambda i: one_tick(bytes_=False), 12)   # the engines' tick alone (after the checks)
     us_bytes = max(us - us_engine, 1e-3)
     return {"workload": "CRaft, %d groups x 5 replicas, one %d-byte batch per group per tick, balanced assignment; bytes through smr_craft_pstore_* "
-                        "(put + the leader's follow + one follow_many for the four followers, window %d); the four AppendEntries and their handlers "
-                        "are one launch (smr_raft_cluster_replicate)" % (G, L, W),
+                        "(put + the leader's follow + one follow_many for the four followers, window %d); the engines' tick -- the leader's append, its "
+                        "four AppendEntries and their handlers, the replies -- is one launch (smr_raft_cluster_tick)" % (G, L, W),
             "value": G / (us * 1e-6), "unit": "slots/s", "ms_per_tick": us * 1e-3, "engine_only_ms_per_tick": us_engine * 1e-3,
             "bytes_path_ms_per_tick": us_bytes * 1e-3, "rs_payload_GiBps": G * L / 2**30 / (us * 1e-6), "launches_per_tick": {"engine": 1 if os.environ.get("SMR_RAFT_CLUSTER_TICK", "1") != "0" else 3, "bytes": 4},
             "shards_delivered_by_the_put_launch": sum(st.delivered() for st in stores),

@@ -1,12 +1,12 @@
 #!/bin/bash
 # The record of the shipped build (run again whenever a kernel changes; TAG names the build; round 3: r3m .. r4m; round 4: r5m, r6m; round 5: r8m, r8z, r9z;
-# round 6: t1z, t2z).  EVERYTHING the record consists of is written under gpurun_out/ (the one directory gpurun merges back) -- VERDICT r5 weak #8: round 5's
+# round 6: t1z, t2z, t3z).  EVERYTHING the record consists of is written under gpurun_out/ (the one directory gpurun merges back) -- VERDICT r5 weak #8: round 5's
 # PMC JSONs were copied to the box's profiles/ only and had to be rebuilt by hand -- and the JSONs are ALSO packed into ${TAG}_record_files.b64 so that a
 # truncated merge can be undone (tools/final_record_unpack.py).  Take it while >= 20 GPU-minutes remain; launch nothing after it.
 #   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) over tools/pmc_probe.py --extra and over the two payload legs
 #   whole -m gpu suite | the default bench line | the driver's exact command | steady state
 #   rocprofv3 --kernel-trace --stats over the EXACT driver command, summarised over the headline process
-TAG=${1:-t2z}
+TAG=${1:-t3z}
 mkdir -p gpurun_out
 R=$PWD
 # 0. is this box's GPU sane?  (round 5's third take met one that faulted in every process; every step below then ran into its own
