@@ -64,6 +64,7 @@ def test_raft_one_launch_tick_on_the_host(sim, oracle):
     import test_raft_gpu as t
     with sim.patched():
         assert t.run_one_launch_tick("cpu", oracle, G=200, W=64, K=8, T=12) > 300            # smr_raft_cluster_tick == the 2 + 2 n calls == the oracle
+        assert t.run_one_launch_tick("cpu", oracle, G=70, W=64, K=8, T=8, R=7) > 100            # ... and with seven replicas (the R > 5 instantiation)
 
 
 def test_craft_leader_kernels_on_the_host(sim, oracle):

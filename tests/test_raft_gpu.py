@@ -299,14 +299,13 @@ def run_one_launch_replication(dev, oracle, G=600, W=64, K=8, T=16):
     return n_msg
 
 
-def run_one_launch_tick(dev, oracle, G=600, W=64, K=8, T=16):
+def run_one_launch_tick(dev, oracle, G=600, W=64, K=8, T=16, R=5):
     """`smr_raft_cluster_tick` -- a sender's append, its AppendEntries for its four peers, their handlers and its reply handler in ONE
     launch -- in the closed loop of tests/raft_cluster.py (elections, a second election in a third of the groups, conflicts and
     truncations behind it), every sender's whole tick before the next sender's: a cluster that runs the 2 + 2 n calls, one that runs
     the one launch and five oracles stay identical -- every message, every reply, every replica's state, tick by tick"""
     import raft_cluster as rc
     from summerset_amd import RaftLeaderGroup
-    R = 5
     mk = lambda: [rc.NumpyRaft(RaftLeaderGroup(G, R, leader_id=r, window=W, term=1), dev) for r in range(R)]
     calls, fused = mk(), mk()
     orcs = [oracle.RaftOracle(G, R, W, leader_id=r, term=1) for r in range(R)]
@@ -346,13 +345,18 @@ def run_one_launch_tick(dev, oracle, G=600, W=64, K=8, T=16):
             to[(gs + 2) % R, gs] = (gs % R).astype(np.uint8)
         step(to, n_new, t)
     d = [o.dump() for o in orcs]
-    assert min(int(np.stack([x["last_commit"] for x in d]).max(axis=0).min()), 99) > 5
-    assert (np.stack([x["curr_term"] for x in d]).max(axis=0) == 2).any() and n_msg > 1000
+    assert min(int(np.stack([x["last_commit"] for x in d]).max(axis=0).min()), 99) > (5 if T >= 12 else 1)
+    assert (np.stack([x["curr_term"] for x in d]).max(axis=0) == 2).any() and n_msg > (1000 if G >= 200 else 100)
     return n_msg
 
 
 def test_one_launch_tick_is_the_calls_and_the_oracle_s(cuda, oracle):
     run_one_launch_tick(cuda, oracle)
+
+
+def test_one_launch_tick_of_seven_replicas(cuda, oracle):
+    """the same with seven replicas: the kernel's other instantiation (R > 5), seven wavefronts per block"""
+    run_one_launch_tick(cuda, oracle, G=200, T=10, R=7)
 
 
 def test_one_launch_replication_is_the_2n_calls_and_the_oracle_s(cuda, oracle):
