@@ -2545,11 +2545,16 @@ __global__ __launch_bounds__(NR * 64 * epc_sets<NR>(), EPC_WAVES_PER_EU) void ep
 #ifndef EPC_CL_LANES
 #define EPC_CL_LANES 2u                       // (1: the same; 4: +12 us per tick, 8: +6, profiles/s28)
 #endif
+#ifdef EPC_CL_NOLDS                                 // (experiments, profiles/s35: the launch without LDS -- per-row scalars and the walk's arrays in place -- so that
+constexpr bool EPC_CL_LDS = false;                  //  its blocks fit on a CU beside a block of the batched kernel)
+#else
+constexpr bool EPC_CL_LDS = true;
+#endif
 template <int NR>
 __global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const EpClusterArgs<NR> a) {
-    __shared__ uint32_t sh_sc[4 * NR * 64];
-    constexpr uint32_t WALK_CELLS = 512;                                     // population * window up to here: the walk's arrays in LDS
-    __shared__ uint16_t sh_walk[7 * WALK_CELLS * EPC_CL_LANES];               // node_of, nslot, head, sib, parent [cell][lane]; order [2 cells][lane]
+    __shared__ uint32_t sh_sc[EPC_CL_LDS ? 4 * NR * 64 : 1];
+    constexpr uint32_t WALK_CELLS = EPC_CL_LDS ? 512 : 0;                    // population * window up to here: the walk's arrays in LDS
+    __shared__ uint16_t sh_walk[EPC_CL_LDS ? 7 * WALK_CELLS * EPC_CL_LANES : 1];   // node_of, nslot, head, sib, parent [cell][lane]; order [2 cells][lane]
     const uint32_t q = blockIdx.x, bx = blockIdx.y, nbx = gridDim.y, R = a.R, G = a.G, lane = threadIdx.x;
     const uint32_t n = SMR_WAVE_UNIFORM(a.defer_cnt[(a.parity * NR + q) * 32u]);
     if (bx != 0u && bx * EPC_CL_LANES >= n) return;                           // (block 0 also empties the other parity's count, below)
@@ -2570,14 +2575,14 @@ __global__ __launch_bounds__(64) void ep_cluster_commit_one_by_one_kernel(const 
     for (uint32_t base = bx * EPC_CL_LANES; base < n; base += nbx * EPC_CL_LANES) {
         const bool active = lane < EPC_CL_LANES && base + lane < n;
         const uint32_t g = active ? a.defer_list[(size_t)q * G + base + lane] : 0u;
-        EpLaneT<NR, true> L(v, g);                                          // (the lane's per-row scalars in LDS, as in the tick kernel: every handler starts with them)
-        L.bind_cache(sh_sc, lane);
+        EpLaneT<NR, EPC_CL_LDS> L(v, g);                                    // (the lane's per-row scalars in LDS, as in the tick kernel: every handler starts with them)
+        if (EPC_CL_LDS) L.bind_cache(sh_sc, lane);
         EpExec xl = x;
         if (lds_walk) {
             xl.node_of = sh_walk; xl.nslot = sh_walk + RW * EPC_CL_LANES; xl.head = sh_walk + 2 * RW * EPC_CL_LANES;
             xl.sib = sh_walk + 3 * RW * EPC_CL_LANES; xl.parent = sh_walk + 4 * RW * EPC_CL_LANES; xl.order = sh_walk + 5 * RW * EPC_CL_LANES;
         }
-        EpExecLaneT<NR, true> E(v, xl, L, g);
+        EpExecLaneT<NR, EPC_CL_LDS> E(v, xl, L, g);
         if (lds_walk) E.walk_in(EPC_CL_LANES, lane < EPC_CL_LANES ? lane : 0u);
         uint32_t n_listed = 0;                                               // (the longest submission list a handler of this lane left)
         if (active) { L.load_scalars(); if (a.execute) E.load_scalars(); }
