@@ -27,7 +27,10 @@ CXX = os.environ.get("HOSTSIM_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 # hooks; no sanitizer runtime is linked); no block placement; SMR_ARENA_GUARD: unowned gaps between an arena's arrays
 _BASE = [CXX, "-O1", "-gline-tables-only", "-fno-optimize-sibling-calls", "-fno-omit-frame-pointer", "-std=c++17", "-fPIC",
          "-w", "-I", _HERE]
-_KERN = ["-DSMR_ARENA_GUARD=4096", "-mllvm", "-disable-block-placement", "-fsanitize=thread", "-mllvm",
+# STRAG_BATCH_BLOCKS: the side launch's grid -- 192 blocks of 512 lanes on the device, where a listed group has a block to itself; here a
+# launch costs its lanes whether they have work or not, and 12 blocks x 6 lanes walk a test's list of 100-200 groups in several passes
+# (the multi-pass loop the device's grid hardly ever enters)
+_KERN = ["-DSMR_ARENA_GUARD=4096", "-DSTRAG_BATCH_BLOCKS=12", "-mllvm", "-disable-block-placement", "-fsanitize=thread", "-mllvm",
          "-tsan-instrument-func-entry-exit=0", "-mllvm", "-tsan-instrument-atomics=0", "-mllvm", "-tsan-instrument-memintrinsics=0"]
 
 
@@ -65,6 +68,7 @@ def _build_locked(extra):
     comm = os.path.join(_HERE, "rccl_sim.cpp")
     deps = srcs + [rt, comm, os.path.join(_HERE, "rccl", "rccl.h"), os.path.join(_HERE, "hip", "hip_runtime.h"), os.path.join(_ROOT, "include", "summerset_hip.h")]
     deps += [os.path.join(_CSRC, h) for h in os.listdir(_CSRC) if h.endswith(".h")]
+    deps.append(os.path.abspath(__file__))                       # (the flags above are part of the build)
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
     base, kern = _BASE, _KERN
